@@ -1,0 +1,78 @@
+#!/bin/bash
+# Build oracle/_ref/libromsref_<app>.so from the reference's own Fortran
+# sources WHERE THEY LIE under /root/reference (nothing is copied into the
+# repo; intermediates live in a temp dir and are deleted).
+#
+# TEST INFRASTRUCTURE.  Recipe mirrors the reference's makefile
+# (makefile:219,230-238,397-423: cpp -P -traditional, then ROMS/Bin/cpp_clean,
+# then the Fortran compiler) with amdflang in place of gfortran.
+#
+# Only the reference files that compile WITHOUT the NetCDF Fortran module are
+# built (this image has no NetCDF; no stand-in is written for it).  The
+# kernels that USE mod_sources -> mod_netcdf (step2d, omega, pre_step3d,
+# rhs3d, step3d_uv, step3d_t, main3d) are therefore NOT in this library.
+#
+# usage: build_ref.sh upwelling|benchmark
+set -e
+APP=${1:-upwelling}
+REF=${ROMS_REF:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/../_ref
+if [ ! -d "$REF/ROMS" ]; then echo "build_ref: no reference tree at $REF -- skipped"; exit 0; fi
+FC=${FC:-amdflang}
+command -v $FC >/dev/null || { echo "build_ref: $FC not found -- skipped"; exit 0; }
+UP=$(echo $APP | tr a-z A-Z)
+EXTRA=""
+[ "$APP" = upwelling ] && EXTRA="-DPERFECT_RESTART"
+WORK=$(mktemp -d /tmp/romsref_${APP}_XXXX)
+trap 'rm -rf "$WORK"' EXIT
+mkdir -p "$OUT"
+cd "$WORK"   # cpp must run from a writable cwd with absolute input paths
+
+pp () {  # pp <abs .F path> -> $WORK/<base>.f90
+  local b; b=$(basename "$1"); b=${b%.*}
+  /usr/bin/cpp -P -traditional -w -D$UP -D"ROMS_HEADER=\"$APP.h\"" -D"HEADER=\"$APP.h\"" \
+    -DLINUX -DX86_64 -DGFORTRAN -DNestedGrids=1 \
+    -D"ROOT_DIR=\"$REF\"" -D"ANALYTICAL_DIR=\"$REF/ROMS/Functionals\"" -D"HEADER_DIR=\"$REF/ROMS/Include\"" \
+    -D'GIT_URL="x"' -D'GIT_REV="x"' -D'MY_OS="Linux"' -D'MY_CPU="x86_64"' -D'MY_FORT="gfortran"' \
+    -D'MY_FC="flang"' -D'MY_FFLAGS="-O2"' $EXTRA \
+    -I$REF/ROMS/Include -I$REF/ROMS/Nonlinear -I$REF/ROMS/Functionals -I$REF/ROMS/Utility \
+    -I$REF/ROMS/Drivers -I$REF/Master "$1" > $b.$2
+  perl $REF/ROMS/Bin/cpp_clean $b.$2
+}
+
+# Reference files wanted in the library (those that are inactive for the
+# application pre-process to nothing and are skipped).  Compiled by repeated
+# passes until every file's modules are available (no hand-kept order).
+FILES="mod_kinds mod_param mod_scalars mod_stepping mod_strings mod_iounits mod_parallel mod_eoscoef
+  mod_clima mod_coupling mod_forces mod_grid mod_mixing mod_ocean mod_ncparam mod_boundary
+  round dateclock strings timers yaml_parser get_env get_metadata stdout_mod destroy
+  get_hash stats erf exchange_2d exchange_3d exchange_4d get_bounds tile_indices set_scoord set_weights
+  metrics ini_hmixcoef stiffness mp_routines ntimestep
+  bc_2d bc_3d zetabc u2dbc_im v2dbc_im t3dbc_im u3dbc_im v3dbc_im obc_volcons
+  set_depth set_massflux rho_eos prsgrd t3dmix uv3dmix set_vbc set_zeta wvelocity diag ini_fields
+  mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix bulk_flux analytical"
+TODO=""
+for m in $FILES; do
+  src=""
+  for d in Modules Utility Nonlinear Functionals; do
+    [ -f $REF/ROMS/$d/$m.F ] && src=$REF/ROMS/$d/$m.F
+  done
+  [ -z "$src" ] && continue
+  pp $src f90
+  [ $(wc -c < $m.f90) -lt 20 ] && continue      # inactive for this application
+  TODO="$TODO $m"
+done
+OBJS=""
+while [ -n "$TODO" ]; do
+  NEXT=""; PROG=0
+  for m in $TODO; do
+    if $FC -c -O2 -fPIC $m.f90 -o $m.o 2> $m.err; then OBJS="$OBJS $m.o"; PROG=1; else NEXT="$NEXT $m"; fi
+  done
+  TODO=$NEXT
+  if [ $PROG -eq 0 ]; then echo "build_ref: cannot compile:$TODO"; for m in $TODO; do head -5 $m.err; done; exit 1; fi
+done
+pp $HERE/ref_glue.F90 f90 && mv ref_glue.f90 ref_glue_pp.F90
+$FC -c -O2 -fPIC -ffree-form ref_glue_pp.F90 -o ref_glue.o
+$FC -shared -o $OUT/libromsref_$APP.so $OBJS ref_glue.o
+echo "build_ref: wrote $OUT/libromsref_$APP.so"

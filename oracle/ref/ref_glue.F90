@@ -1,0 +1,826 @@
+!  ref_glue.F90 -- TEST INFRASTRUCTURE, not product code.
+!
+!  bind(C) driver that is linked against the reference's OWN Fortran sources
+!  (compiled unmodified from /root/reference by oracle/ref/build_ref.sh) so
+!  that tests and fixture generators can execute the reference kernels that
+!  build in this container and read back their results.
+!
+!  It plays the role that inp_par/read_phypar (Utility/inp_par.F:138-226,
+!  Utility/read_phypar.F) and ROMS_initialize/initial (Drivers/nl_roms.h:61,
+!  Nonlinear/initial.F) play in the real program: those files depend on the
+!  NetCDF Fortran module, which this image lacks, so they are NOT built and
+!  nothing here stands in for NetCDF -- the glue only fills the reference's
+!  module variables by hand and calls reference procedures.
+!
+!  Reference kernels that cannot be built here (they USE mod_sources, which
+!  USEs mod_netcdf): step2d, omega, pre_step3d, rhs3d, step3d_uv, step3d_t,
+!  main3d.  Those are restated in the C oracle only ("parity unpinned" rows).
+!
+#include "cppdefs.h"
+#if defined UPWELLING
+# define REF_APP 1
+#elif defined BENCHMARK
+# define REF_APP 2
+#endif
+      MODULE ref_glue
+      USE, INTRINSIC :: iso_c_binding
+      USE mod_kinds
+      USE mod_param
+      USE mod_parallel
+      USE mod_scalars
+      USE mod_stepping
+      USE mod_iounits
+      USE mod_ncparam
+      USE mod_grid
+      USE mod_ocean
+      USE mod_coupling
+      USE mod_forces
+      USE mod_mixing
+      USE mod_boundary
+      USE mod_clima
+      implicit none
+      integer, parameter :: ng = 1
+      CONTAINS
+!
+!=======================================================================
+!  ipar: 1 Lm, 2 Mm, 3 N, 4 NtileI, 5 NtileJ, 6 ndtfast, 7 ntimes,
+!        8 Vtransform, 9 Vstretching, 10 EWperiodic, 11 NSperiodic,
+!        12 Hadv(temp), 13 Vadv(temp), 14 Hadv(salt), 15 Vadv(salt)
+!        (scheme codes: 1 A4, 2 C2, 3 C4, 4 HSIMT, 5 MPDATA, 6 SPLINES,
+!         7 SPLIT_U3, 8 U3), 16 lmd_Jwt (water type)
+!  rpar: 1 dt, 2 theta_s, 3 theta_b, 4 Tcline, 5 rho0, 6 R0, 7 T0, 8 S0,
+!        9 Tcoef, 10 Scoef, 11 visc2, 12 tnu2(temp), 13 tnu2(salt),
+!        14 Akt_bak(temp), 15 Akt_bak(salt), 16 Akv_bak, 17 rdrg,
+!        18 rdrg2, 19 Zob, 20 Zos, 21 gamma2, 22 dstart, 23 blk_ZQ,
+!        24 blk_ZT, 25 blk_ZW
+!=======================================================================
+!
+      SUBROUTINE ref_configure (ipar, rpar) bind(C, name="ref_configure")
+      USE tile_indices_mod, ONLY : tile_indices
+      integer(c_int), intent(in) :: ipar(*)
+      real(c_double), intent(in) :: rpar(*)
+      integer :: itrc, ibry, ivar, tile
+      integer :: LBi, UBi, LBj, UBj, LBij, UBij
+
+      Ngrids=1
+      CALL initialize_parallel
+      CALL allocate_param
+      CALL allocate_parallel (Ngrids)
+      CALL allocate_iounits (Ngrids)
+      CALL allocate_stepping (Ngrids)
+      IF (.not.allocated(GridsInLayer)) THEN
+        allocate ( GridsInLayer(NestLayers) )
+        GridsInLayer=1
+      END IF
+      IF (.not.allocated(GridNumber)) THEN
+        allocate ( GridNumber(Ngrids,NestLayers) )
+        GridNumber=1
+      END IF
+      Lm(ng)=ipar(1)
+      Mm(ng)=ipar(2)
+      N(ng)=ipar(3)
+      NAT=2
+      NtileI(ng)=ipar(4)
+      NtileJ(ng)=ipar(5)
+      NtileX(ng)=NtileI(ng)
+      NtileE(ng)=NtileJ(ng)
+      CALL initialize_param
+      CALL allocate_scalars
+      CALL initialize_scalars
+      stdout=6
+      Master=.TRUE.
+!
+!  Variable metadata (mod_ncparam): the analytical routines print field
+!  names from Vname(:,idXXXX); the table is read from the reference's own
+!  ROMS/External/varinfo.yaml, as read_phypar does for keyword VARNAME.
+!
+      varname=ROOT_DIR//'/ROMS/External/varinfo.yaml'
+      CALL allocate_ncparam
+      CALL initialize_ncparam
+!
+!  Advection schemes (load_tadv, Utility/inp_decode.F).
+!
+      DO itrc=1,NT(ng)
+        CALL set_adv (Hadvection(itrc,ng), ipar(12+2*(MIN(itrc,2)-1)))
+        CALL set_adv (Vadvection(itrc,ng), ipar(13+2*(MIN(itrc,2)-1)))
+      END DO
+!
+!  Lateral boundary conditions (load_lbc): periodic or closed only.
+!
+      EWperiodic(ng)=ipar(10).ne.0
+      NSperiodic(ng)=ipar(11).ne.0
+      DO ivar=1,nLBCvar
+        DO ibry=1,4
+          IF ((ibry.eq.iwest).or.(ibry.eq.ieast)) THEN
+            LBC(ibry,ivar,ng)%periodic=EWperiodic(ng)
+            LBC(ibry,ivar,ng)%closed=.not.EWperiodic(ng)
+          ELSE
+            LBC(ibry,ivar,ng)%periodic=NSperiodic(ng)
+            LBC(ibry,ivar,ng)%closed=.not.NSperiodic(ng)
+          END IF
+        END DO
+      END DO
+!
+!  Physical parameters (read_phypar).
+!
+      ntimes(ng)=ipar(7)
+      dt(ng)=rpar(1)
+      ndtfast(ng)=ipar(6)
+      nrrec(ng)=0
+      ninfo(ng)=1
+      Vtransform(ng)=ipar(8)
+      Vstretching(ng)=ipar(9)
+      theta_s(ng)=rpar(2)
+      theta_b(ng)=rpar(3)
+      Tcline(ng)=rpar(4)
+      rho0=rpar(5)
+      R0(ng)=rpar(6)
+      T0(ng)=rpar(7)
+      S0(ng)=rpar(8)
+      Tcoef(ng)=rpar(9)
+      Scoef(ng)=rpar(10)
+      nl_visc2(ng)=rpar(11)
+      nl_tnu2(1,ng)=rpar(12)
+      nl_tnu2(2,ng)=rpar(13)
+      Akt_bak(1,ng)=rpar(14)
+      Akt_bak(2,ng)=rpar(15)
+      Akv_bak(ng)=rpar(16)
+      rdrg(ng)=rpar(17)
+      rdrg2(ng)=rpar(18)
+      Zob(ng)=rpar(19)
+      Zos(ng)=rpar(20)
+      gamma2(ng)=rpar(21)
+      dstart=rpar(22)
+#ifdef BULK_FLUXES
+      blk_ZQ(ng)=rpar(23)
+      blk_ZT(ng)=rpar(24)
+      blk_ZW(ng)=rpar(25)
+#endif
+#if defined LMD_SKPP || defined SOLAR_SOURCE
+      lmd_Jwt(ng)=ipar(16)
+#endif
+!
+!  What inp_par does after read_phypar (Utility/inp_par.F:210-226,...).
+!
+      ThreeGhostPoints=ANY(Hadvection(:,:)%MPDATA).or.                  &
+     &                 ANY(Hadvection(:,:)%HSIMT)
+      IF (ThreeGhostPoints) THEN
+        NghostPoints=3
+      ELSE
+        NghostPoints=2
+      END IF
+      LprocessOBC(ng)=.TRUE.
+      CALL tile_indices (iNLM, Im, Jm, Lm, Mm, BOUNDS, DOMAIN, IOBOUNDS)
+      gorho0=g/rho0
+      dtfast(ng)=dt(ng)/REAL(ndtfast(ng),r8)
+      numthreads=1
+      MyThread=0
+      first_tile(ng)=0
+      last_tile(ng)=NtileI(ng)*NtileJ(ng)-1
+!
+!  ROMS_allocate_arrays / ROMS_initialize_arrays (Modules/mod_arrays.F).
+!
+      tile=0
+      LBi=BOUNDS(ng)%LBi(tile)
+      UBi=BOUNDS(ng)%UBi(tile)
+      LBj=BOUNDS(ng)%LBj(tile)
+      UBj=BOUNDS(ng)%UBj(tile)
+      LBij=BOUNDS(ng)%LBij
+      UBij=BOUNDS(ng)%UBij
+      CALL allocate_boundary (ng)
+      CALL allocate_clima (ng, LBi, UBi, LBj, UBj)
+      CALL allocate_coupling (ng, LBi, UBi, LBj, UBj)
+      CALL allocate_forces (ng, LBi, UBi, LBj, UBj)
+      CALL allocate_grid (ng, ExtractFlag(ng),                          &
+     &                    LBi, UBi, LBj, UBj, LBij, UBij)
+      CALL allocate_mixing (ng, LBi, UBi, LBj, UBj)
+      CALL allocate_ocean (ng, LBi, UBi, LBj, UBj)
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL initialize_boundary (ng, tile, 0)
+        CALL initialize_coupling (ng, tile, 0)
+        CALL initialize_forces (ng, tile, 0)
+        CALL initialize_grid (ng, tile, 0)
+        CALL initialize_mixing (ng, tile, 0)
+        CALL initialize_ocean (ng, tile, 0)
+      END DO
+!
+!  Time-stepping state as set at the top of initial (Nonlinear/initial.F).
+!
+      iif(ng)=1
+      indx1(ng)=1
+      kstp(ng)=1
+      krhs(ng)=1
+      knew(ng)=1
+      PREDICTOR_2D_STEP(ng)=.FALSE.
+      iic(ng)=0
+      nstp(ng)=1
+      nrhs(ng)=1
+      nnew(ng)=1
+      tdays(ng)=dstart
+      time(ng)=tdays(ng)*day2sec
+      ntstart(ng)=INT((time(ng)-dstart*day2sec)/dt(ng))+1
+      ntend(ng)=ntstart(ng)+ntimes(ng)-1
+      ntfirst(ng)=ntstart(ng)
+      END SUBROUTINE ref_configure
+
+      SUBROUTINE set_adv (A, code)
+      TYPE (T_ADV), intent(inout) :: A
+      integer, intent(in) :: code
+      A%AKIMA4=code.eq.1
+      A%CENTERED2=code.eq.2
+      A%CENTERED4=code.eq.3
+      A%HSIMT=code.eq.4
+      A%MPDATA=code.eq.5
+      A%SPLINES=code.eq.6
+      A%SPLIT_U3=code.eq.7
+      A%UPSTREAM3=code.eq.8
+      END SUBROUTINE set_adv
+!
+!=======================================================================
+!  The part of "initial" (Nonlinear/initial.F:277-577) that builds here:
+!  set_grid (ana_grid, set_scoord, set_weights, metrics), ini_hmixcoef,
+!  set_depth, ana_initial, set_depth0, set_zeta_timeavg, set_depth,
+!  set_massflux, rho_eos.  (omega is not buildable: see header.)
+!=======================================================================
+!
+      SUBROUTINE ref_initial () bind(C, name="ref_initial")
+      USE analytical_mod
+      USE metrics_mod,       ONLY : metrics
+      USE ini_hmixcoef_mod,  ONLY : ini_hmixcoef
+      USE ini_fields_mod,    ONLY : set_zeta_timeavg
+      USE set_depth_mod,     ONLY : set_depth0, set_depth
+      USE set_massflux_mod,  ONLY : set_massflux
+      USE rho_eos_mod,       ONLY : rho_eos
+      integer :: tile
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL ana_grid (ng, tile, iNLM)
+      END DO
+      CALL set_scoord (ng)
+      CALL set_weights (ng)
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL metrics (ng, tile, iNLM)
+      END DO
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL ini_hmixcoef (ng, tile, iNLM)
+      END DO
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL set_depth (ng, tile, iNLM)
+      END DO
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL ana_initial (ng, tile, iNLM)
+      END DO
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL set_depth0 (ng, tile, iNLM)
+        CALL set_zeta_timeavg (ng, tile, iNLM)
+        CALL set_depth (ng, tile, iNLM)
+      END DO
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL set_massflux (ng, tile, iNLM)
+      END DO
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL rho_eos (ng, tile, iNLM)
+      END DO
+      iic(ng)=ntstart(ng)
+      END SUBROUTINE ref_initial
+!
+!=======================================================================
+!  Set the time-stepping indices the kernel wrappers read from
+!  mod_stepping / mod_scalars.
+!  idx: 1 iic, 2 iif, 3 nstp, 4 nnew, 5 nrhs, 6 kstp, 7 knew, 8 krhs,
+!       9 PREDICTOR_2D_STEP
+!=======================================================================
+!
+      SUBROUTINE ref_set_stepping (idx, tm) bind(C, name="ref_set_stepping")
+      integer(c_int), intent(in) :: idx(*)
+      real(c_double), value :: tm
+      iic(ng)=idx(1)
+      iif(ng)=idx(2)
+      nstp(ng)=idx(3)
+      nnew(ng)=idx(4)
+      nrhs(ng)=idx(5)
+      kstp(ng)=idx(6)
+      knew(ng)=idx(7)
+      krhs(ng)=idx(8)
+      PREDICTOR_2D_STEP(ng)=idx(9).ne.0
+      time(ng)=tm
+      tdays(ng)=time(ng)*sec2day
+      END SUBROUTINE ref_set_stepping
+!
+!=======================================================================
+!  Call a reference kernel wrapper on every tile.  Returns 0, or -1 for
+!  an unknown name.
+!=======================================================================
+!
+      FUNCTION ref_call (cname) bind(C, name="ref_call") RESULT (ierr)
+      USE analytical_mod
+      USE set_depth_mod,     ONLY : set_depth
+      USE set_massflux_mod,  ONLY : set_massflux
+      USE rho_eos_mod,       ONLY : rho_eos
+      USE prsgrd_mod,        ONLY : prsgrd
+      USE t3dmix2_mod,       ONLY : t3dmix2
+      USE uv3dmix2_mod,      ONLY : uv3dmix2
+      USE set_vbc_mod,       ONLY : set_vbc
+      USE set_zeta_mod,      ONLY : set_zeta
+      USE wvelocity_mod,     ONLY : wvelocity
+      USE diag_mod,          ONLY : diag
+      USE ini_fields_mod,    ONLY : ini_fields, ini_zeta
+#ifdef LMD_MIXING
+      USE lmd_vmix_mod,      ONLY : lmd_vmix
+#endif
+#ifdef BULK_FLUXES
+      USE bulk_flux_mod,     ONLY : bulk_flux
+#endif
+      character(kind=c_char), intent(in) :: cname(*)
+      integer(c_int) :: ierr
+      character(len=32) :: name
+      integer :: i, tile
+      name=' '
+      DO i=1,32
+        IF (cname(i).eq.c_null_char) EXIT
+        name(i:i)=cname(i)
+      END DO
+      ierr=0
+      DO tile=first_tile(ng),last_tile(ng)
+        SELECT CASE (TRIM(name))
+          CASE ('set_depth')
+            CALL set_depth (ng, tile, iNLM)
+          CASE ('set_massflux')
+            CALL set_massflux (ng, tile, iNLM)
+          CASE ('rho_eos')
+            CALL rho_eos (ng, tile, iNLM)
+          CASE ('prsgrd')
+            CALL prsgrd (ng, tile)
+          CASE ('t3dmix2')
+            CALL t3dmix2 (ng, tile)
+          CASE ('uv3dmix2')
+            CALL uv3dmix2 (ng, tile)
+          CASE ('set_vbc')
+            CALL set_vbc (ng, tile)
+          CASE ('set_zeta')
+            CALL set_zeta (ng, tile)
+          CASE ('wvelocity')
+            CALL wvelocity (ng, tile, nstp(ng))
+          CASE ('diag')
+            CALL diag (ng, tile)
+          CASE ('ini_zeta')
+            CALL ini_zeta (ng, tile, iNLM)
+          CASE ('ini_fields')
+            CALL ini_fields (ng, tile, iNLM)
+#ifdef ANA_VMIX
+          CASE ('ana_vmix')
+            CALL ana_vmix (ng, tile, iNLM)
+#endif
+#ifdef ANA_SMFLUX
+          CASE ('ana_smflux')
+            CALL ana_smflux (ng, tile, iNLM)
+#endif
+#ifdef ANA_STFLUX
+          CASE ('ana_stflux')
+            CALL ana_stflux (ng, tile, iNLM, itemp)
+            CALL ana_stflux (ng, tile, iNLM, isalt)
+#endif
+#ifdef ANA_BTFLUX
+          CASE ('ana_btflux')
+            CALL ana_btflux (ng, tile, iNLM, itemp)
+            CALL ana_btflux (ng, tile, iNLM, isalt)
+#endif
+#ifdef ANA_SRFLUX
+          CASE ('ana_srflux')
+            CALL ana_srflux (ng, tile, iNLM)
+#endif
+#ifdef BULK_FLUXES
+          CASE ('ana_atm')
+            CALL ana_winds (ng, tile, iNLM)
+            CALL ana_tair (ng, tile, iNLM)
+            CALL ana_pair (ng, tile, iNLM)
+            CALL ana_humid (ng, tile, iNLM)
+            CALL ana_rain (ng, tile, iNLM)
+            CALL ana_cloud (ng, tile, iNLM)
+          CASE ('bulk_flux')
+            CALL bulk_flux (ng, tile)
+#endif
+#ifdef LMD_MIXING
+          CASE ('lmd_vmix')
+            CALL lmd_vmix (ng, tile)
+#endif
+          CASE DEFAULT
+            ierr=-1
+        END SELECT
+      END DO
+      END FUNCTION ref_call
+!
+!=======================================================================
+!  mpdata_adiff_tile on caller-supplied Ta (scratch extents
+!  IminS:ImaxS,JminS:JmaxS,N); returns Ua,Va,Wa.  Single tile only.
+!=======================================================================
+!
+      SUBROUTINE ref_mpdata_adiff (itrc, Ta, Ua, Va, Wa)                &
+     &                            bind(C, name="ref_mpdata_adiff")
+      USE mpdata_adiff_mod
+      integer(c_int), value :: itrc
+      real(c_double), intent(in) :: Ta(*)
+      real(c_double), intent(out) :: Ua(*), Va(*), Wa(*)
+      integer :: tile, LBi, UBi, LBj, UBj
+      integer :: IminS, ImaxS, JminS, JmaxS, n2, i, j, k
+      real(r8), allocatable :: oHz(:,:,:), Tw(:,:,:)
+      real(r8), allocatable :: Uw(:,:,:), Vw(:,:,:), Ww(:,:,:)
+      tile=0
+      LBi=BOUNDS(ng)%LBi(tile)
+      UBi=BOUNDS(ng)%UBi(tile)
+      LBj=BOUNDS(ng)%LBj(tile)
+      UBj=BOUNDS(ng)%UBj(tile)
+      IminS=BOUNDS(ng)%Istr(tile)-3
+      ImaxS=BOUNDS(ng)%Iend(tile)+3
+      JminS=BOUNDS(ng)%Jstr(tile)-3
+      JmaxS=BOUNDS(ng)%Jend(tile)+3
+      allocate ( oHz(IminS:ImaxS,JminS:JmaxS,N(ng)) )
+      allocate ( Tw(IminS:ImaxS,JminS:JmaxS,N(ng)) )
+      allocate ( Uw(IminS:ImaxS,JminS:JmaxS,N(ng)) )
+      allocate ( Vw(IminS:ImaxS,JminS:JmaxS,N(ng)) )
+      allocate ( Ww(IminS:ImaxS,JminS:JmaxS,0:N(ng)) )
+      oHz=0.0_r8
+      Uw=0.0_r8
+      Vw=0.0_r8
+      Ww=0.0_r8
+      n2=(ImaxS-IminS+1)*(JmaxS-JminS+1)
+      DO k=1,N(ng)
+        DO j=JminS,JmaxS
+          DO i=IminS,ImaxS
+            Tw(i,j,k)=Ta(1+(i-IminS)+(j-JminS)*(ImaxS-IminS+1)+(k-1)*n2)
+          END DO
+        END DO
+        DO j=BOUNDS(ng)%Jstrm2(tile),BOUNDS(ng)%Jendp2(tile)
+          DO i=BOUNDS(ng)%Istrm2(tile),BOUNDS(ng)%Iendp2(tile)
+            oHz(i,j,k)=1.0_r8/GRID(ng)%Hz(i,j,k)
+          END DO
+        END DO
+      END DO
+      CALL mpdata_adiff_tile (ng, tile,                                 &
+     &                        LBi, UBi, LBj, UBj,                       &
+     &                        IminS, ImaxS, JminS, JmaxS,               &
+     &                        GRID(ng)%pm, GRID(ng)%pn, GRID(ng)%omn,   &
+     &                        GRID(ng)%om_u, GRID(ng)%on_v,             &
+     &                        GRID(ng)%z_r, oHz,                        &
+     &                        GRID(ng)%Huon, GRID(ng)%Hvom,             &
+     &                        OCEAN(ng)%W,                              &
+     &                        OCEAN(ng)%t(:,:,:,3,itrc),                &
+     &                        Tw, Uw, Vw, Ww)
+      DO k=1,N(ng)
+        DO j=JminS,JmaxS
+          DO i=IminS,ImaxS
+            Ua(1+(i-IminS)+(j-JminS)*(ImaxS-IminS+1)+(k-1)*n2)=Uw(i,j,k)
+            Va(1+(i-IminS)+(j-JminS)*(ImaxS-IminS+1)+(k-1)*n2)=Vw(i,j,k)
+          END DO
+        END DO
+      END DO
+      DO k=0,N(ng)
+        DO j=JminS,JmaxS
+          DO i=IminS,ImaxS
+            Wa(1+(i-IminS)+(j-JminS)*(ImaxS-IminS+1)+k*n2)=Ww(i,j,k)
+          END DO
+        END DO
+      END DO
+      END SUBROUTINE ref_mpdata_adiff
+!
+!=======================================================================
+!  Lateral boundary condition routines with explicit output index.
+!=======================================================================
+!
+      SUBROUTINE ref_bc2d (kout) bind(C, name="ref_bc2d")
+      USE zetabc_mod, ONLY : zetabc_tile
+      USE u2dbc_mod,  ONLY : u2dbc_tile
+      USE v2dbc_mod,  ONLY : v2dbc_tile
+      integer(c_int), value :: kout
+      integer :: tile, LBi, UBi, LBj, UBj
+      integer :: IminS, ImaxS, JminS, JmaxS
+      DO tile=first_tile(ng),last_tile(ng)
+        LBi=BOUNDS(ng)%LBi(tile)
+        UBi=BOUNDS(ng)%UBi(tile)
+        LBj=BOUNDS(ng)%LBj(tile)
+        UBj=BOUNDS(ng)%UBj(tile)
+        IminS=BOUNDS(ng)%Istr(tile)-3
+        ImaxS=BOUNDS(ng)%Iend(tile)+3
+        JminS=BOUNDS(ng)%Jstr(tile)-3
+        JmaxS=BOUNDS(ng)%Jend(tile)+3
+        CALL zetabc_tile (ng, tile, LBi, UBi, LBj, UBj,                 &
+     &                    IminS, ImaxS, JminS, JmaxS,                   &
+     &                    krhs(ng), kstp(ng), kout, OCEAN(ng)%zeta)
+        CALL u2dbc_tile (ng, tile, LBi, UBi, LBj, UBj,                  &
+     &                   IminS, ImaxS, JminS, JmaxS,                    &
+     &                   krhs(ng), kstp(ng), kout,                      &
+     &                   OCEAN(ng)%ubar, OCEAN(ng)%vbar, OCEAN(ng)%zeta)
+        CALL v2dbc_tile (ng, tile, LBi, UBi, LBj, UBj,                  &
+     &                   IminS, ImaxS, JminS, JmaxS,                    &
+     &                   krhs(ng), kstp(ng), kout,                      &
+     &                   OCEAN(ng)%ubar, OCEAN(ng)%vbar, OCEAN(ng)%zeta)
+      END DO
+      END SUBROUTINE ref_bc2d
+
+      SUBROUTINE ref_bc3d (nout) bind(C, name="ref_bc3d")
+      USE t3dbc_mod, ONLY : t3dbc_tile
+      USE u3dbc_mod, ONLY : u3dbc_tile
+      USE v3dbc_mod, ONLY : v3dbc_tile
+      integer(c_int), value :: nout
+      integer :: tile, LBi, UBi, LBj, UBj, itrc
+      integer :: IminS, ImaxS, JminS, JmaxS
+      DO tile=first_tile(ng),last_tile(ng)
+        LBi=BOUNDS(ng)%LBi(tile)
+        UBi=BOUNDS(ng)%UBi(tile)
+        LBj=BOUNDS(ng)%LBj(tile)
+        UBj=BOUNDS(ng)%UBj(tile)
+        IminS=BOUNDS(ng)%Istr(tile)-3
+        ImaxS=BOUNDS(ng)%Iend(tile)+3
+        JminS=BOUNDS(ng)%Jstr(tile)-3
+        JmaxS=BOUNDS(ng)%Jend(tile)+3
+        DO itrc=1,NT(ng)
+          CALL t3dbc_tile (ng, tile, itrc, 0, LBi, UBi, LBj, UBj,       &
+     &                     N(ng), NT(ng), IminS, ImaxS, JminS, JmaxS,   &
+     &                     nstp(ng), nout, OCEAN(ng)%t)
+        END DO
+        IF (nout.le.2) THEN
+          CALL u3dbc_tile (ng, tile, LBi, UBi, LBj, UBj, N(ng),         &
+     &                     IminS, ImaxS, JminS, JmaxS,                  &
+     &                     nstp(ng), nout, OCEAN(ng)%u)
+          CALL v3dbc_tile (ng, tile, LBi, UBi, LBj, UBj, N(ng),         &
+     &                     IminS, ImaxS, JminS, JmaxS,                  &
+     &                     nstp(ng), nout, OCEAN(ng)%v)
+        END IF
+      END DO
+      END SUBROUTINE ref_bc3d
+!
+!=======================================================================
+!  Integer tables: BOUNDS/DOMAIN of one tile (get_bounds.F / tile_indices).
+!=======================================================================
+!
+      SUBROUTINE ref_get_bounds (tile, b) bind(C, name="ref_get_bounds")
+      integer(c_int), value :: tile
+      integer(c_int), intent(out) :: b(*)
+      b(1)=BOUNDS(ng)%LBi(tile)
+      b(2)=BOUNDS(ng)%UBi(tile)
+      b(3)=BOUNDS(ng)%LBj(tile)
+      b(4)=BOUNDS(ng)%UBj(tile)
+      b(5)=BOUNDS(ng)%Istr(tile)
+      b(6)=BOUNDS(ng)%Iend(tile)
+      b(7)=BOUNDS(ng)%Jstr(tile)
+      b(8)=BOUNDS(ng)%Jend(tile)
+      b(9)=BOUNDS(ng)%IstrR(tile)
+      b(10)=BOUNDS(ng)%IendR(tile)
+      b(11)=BOUNDS(ng)%JstrR(tile)
+      b(12)=BOUNDS(ng)%JendR(tile)
+      b(13)=BOUNDS(ng)%IstrU(tile)
+      b(14)=BOUNDS(ng)%JstrV(tile)
+      b(15)=BOUNDS(ng)%IstrB(tile)
+      b(16)=BOUNDS(ng)%IendB(tile)
+      b(17)=BOUNDS(ng)%IstrM(tile)
+      b(18)=BOUNDS(ng)%JstrB(tile)
+      b(19)=BOUNDS(ng)%JendB(tile)
+      b(20)=BOUNDS(ng)%JstrM(tile)
+      b(21)=BOUNDS(ng)%IstrP(tile)
+      b(22)=BOUNDS(ng)%IendP(tile)
+      b(23)=BOUNDS(ng)%JstrP(tile)
+      b(24)=BOUNDS(ng)%JendP(tile)
+      b(25)=BOUNDS(ng)%IstrT(tile)
+      b(26)=BOUNDS(ng)%IendT(tile)
+      b(27)=BOUNDS(ng)%JstrT(tile)
+      b(28)=BOUNDS(ng)%JendT(tile)
+      b(29)=BOUNDS(ng)%Istrm3(tile)
+      b(30)=BOUNDS(ng)%Istrm2(tile)
+      b(31)=BOUNDS(ng)%Istrm1(tile)
+      b(32)=BOUNDS(ng)%IstrUm2(tile)
+      b(33)=BOUNDS(ng)%IstrUm1(tile)
+      b(34)=BOUNDS(ng)%Iendp1(tile)
+      b(35)=BOUNDS(ng)%Iendp2(tile)
+      b(36)=BOUNDS(ng)%Iendp2i(tile)
+      b(37)=BOUNDS(ng)%Iendp3(tile)
+      b(38)=BOUNDS(ng)%Jstrm3(tile)
+      b(39)=BOUNDS(ng)%Jstrm2(tile)
+      b(40)=BOUNDS(ng)%Jstrm1(tile)
+      b(41)=BOUNDS(ng)%JstrVm2(tile)
+      b(42)=BOUNDS(ng)%JstrVm1(tile)
+      b(43)=BOUNDS(ng)%Jendp1(tile)
+      b(44)=BOUNDS(ng)%Jendp2(tile)
+      b(45)=BOUNDS(ng)%Jendp2i(tile)
+      b(46)=BOUNDS(ng)%Jendp3(tile)
+      b(47)=MERGE(1,0,DOMAIN(ng)%Western_Edge(tile))
+      b(48)=MERGE(1,0,DOMAIN(ng)%Eastern_Edge(tile))
+      b(49)=MERGE(1,0,DOMAIN(ng)%Southern_Edge(tile))
+      b(50)=MERGE(1,0,DOMAIN(ng)%Northern_Edge(tile))
+      b(51)=MERGE(1,0,DOMAIN(ng)%SouthWest_Corner(tile))
+      b(52)=MERGE(1,0,DOMAIN(ng)%SouthEast_Corner(tile))
+      b(53)=MERGE(1,0,DOMAIN(ng)%NorthWest_Corner(tile))
+      b(54)=MERGE(1,0,DOMAIN(ng)%NorthEast_Corner(tile))
+      b(55)=NghostPoints
+      b(56)=Im(ng)
+      b(57)=Jm(ng)
+      b(58)=NT(ng)
+      b(59)=nfast(ng)
+      b(60)=0
+      END SUBROUTINE ref_get_bounds
+!
+!=======================================================================
+!  Scalars and 1-D tables: s-coordinate, barotropic filter weights.
+!  which: 1 sc_r(N) 2 Cs_r(N) 3 sc_w(0:N) 4 Cs_w(0:N)
+!         5 weight(1,1:2*ndtfast) 6 weight(2,1:2*ndtfast)
+!         7 {hc, hmin, hmax, xl, el, dtfast, avgke, avgpe, avgkp, volume,
+!            max_speed, max_Cu, max_Cv, max_Cw, Cu_i, Cu_j, Cu_k}
+!=======================================================================
+!
+      SUBROUTINE ref_get_table (which, a) bind(C, name="ref_get_table")
+      integer(c_int), value :: which
+      real(c_double), intent(out) :: a(*)
+      integer :: k
+      SELECT CASE (which)
+        CASE (1)
+          DO k=1,N(ng)
+            a(k)=SCALARS(ng)%sc_r(k)
+          END DO
+        CASE (2)
+          DO k=1,N(ng)
+            a(k)=SCALARS(ng)%Cs_r(k)
+          END DO
+        CASE (3)
+          DO k=0,N(ng)
+            a(k+1)=SCALARS(ng)%sc_w(k)
+          END DO
+        CASE (4)
+          DO k=0,N(ng)
+            a(k+1)=SCALARS(ng)%Cs_w(k)
+          END DO
+        CASE (5)
+          DO k=1,2*ndtfast(ng)
+            a(k)=weight(1,k,ng)
+          END DO
+        CASE (6)
+          DO k=1,2*ndtfast(ng)
+            a(k)=weight(2,k,ng)
+          END DO
+        CASE (7)
+          a(1)=hc(ng)
+          a(2)=hmin(ng)
+          a(3)=hmax(ng)
+          a(4)=xl(ng)
+          a(5)=el(ng)
+          a(6)=dtfast(ng)
+          a(7)=avgke
+          a(8)=avgpe
+          a(9)=avgkp
+          a(10)=volume
+          a(11)=max_speed
+          a(12)=0.0_r8
+          a(13)=0.0_r8
+          a(14)=0.0_r8
+      END SELECT
+      END SUBROUTINE ref_get_table
+!
+!=======================================================================
+!  Field access by name.  dir=0: copy reference array -> buf;
+!  dir=1: buf -> reference array.  Returns the element count, or -1.
+!  Arrays travel whole, in the reference's own (column-major) layout.
+!=======================================================================
+!
+      FUNCTION ref_field (cname, dir, buf) bind(C, name="ref_field")    &
+     &                   RESULT (nel)
+      character(kind=c_char), intent(in) :: cname(*)
+      integer(c_int), value :: dir
+      real(c_double), intent(inout) :: buf(*)
+      integer(c_long) :: nel
+      character(len=32) :: name
+      integer :: i
+      name=' '
+      DO i=1,32
+        IF (cname(i).eq.c_null_char) EXIT
+        name(i:i)=cname(i)
+      END DO
+      nel=-1
+      SELECT CASE (TRIM(name))
+#define F2(nm,arr) CASE (nm); nel=SIZE(arr); CALL cp2(arr,SIZE(arr),dir,buf)
+        F2('h',GRID(ng)%h)
+        F2('f',GRID(ng)%f)
+        F2('fomn',GRID(ng)%fomn)
+        F2('pm',GRID(ng)%pm)
+        F2('pn',GRID(ng)%pn)
+        F2('om_r',GRID(ng)%om_r)
+        F2('on_r',GRID(ng)%on_r)
+        F2('om_u',GRID(ng)%om_u)
+        F2('on_u',GRID(ng)%on_u)
+        F2('om_v',GRID(ng)%om_v)
+        F2('on_v',GRID(ng)%on_v)
+        F2('om_p',GRID(ng)%om_p)
+        F2('on_p',GRID(ng)%on_p)
+        F2('omn',GRID(ng)%omn)
+        F2('pmon_r',GRID(ng)%pmon_r)
+        F2('pnom_r',GRID(ng)%pnom_r)
+        F2('pmon_p',GRID(ng)%pmon_p)
+        F2('pnom_p',GRID(ng)%pnom_p)
+        F2('pmon_u',GRID(ng)%pmon_u)
+        F2('pnom_u',GRID(ng)%pnom_u)
+        F2('pmon_v',GRID(ng)%pmon_v)
+        F2('pnom_v',GRID(ng)%pnom_v)
+        F2('grdscl',GRID(ng)%grdscl)
+        F2('xr',GRID(ng)%xr)
+        F2('yr',GRID(ng)%yr)
+        F2('angler',GRID(ng)%angler)
+#ifdef CURVGRID
+        F2('dmde',GRID(ng)%dmde)
+        F2('dndx',GRID(ng)%dndx)
+#endif
+#ifdef SPHERICAL
+        F2('lonr',GRID(ng)%lonr)
+        F2('latr',GRID(ng)%latr)
+#endif
+        F2('Hz',GRID(ng)%Hz)
+        F2('z_r',GRID(ng)%z_r)
+        F2('z_w',GRID(ng)%z_w)
+        F2('z0_r',GRID(ng)%z0_r)
+        F2('z0_w',GRID(ng)%z0_w)
+        F2('Huon',GRID(ng)%Huon)
+        F2('Hvom',GRID(ng)%Hvom)
+        F2('zeta',OCEAN(ng)%zeta)
+        F2('ubar',OCEAN(ng)%ubar)
+        F2('vbar',OCEAN(ng)%vbar)
+        F2('rzeta',OCEAN(ng)%rzeta)
+        F2('rubar',OCEAN(ng)%rubar)
+        F2('rvbar',OCEAN(ng)%rvbar)
+        F2('u',OCEAN(ng)%u)
+        F2('v',OCEAN(ng)%v)
+        F2('t',OCEAN(ng)%t)
+        F2('W',OCEAN(ng)%W)
+        F2('wvel',OCEAN(ng)%wvel)
+        F2('rho',OCEAN(ng)%rho)
+        F2('pden',OCEAN(ng)%pden)
+        F2('ru',OCEAN(ng)%ru)
+        F2('rv',OCEAN(ng)%rv)
+        F2('rhoA',COUPLING(ng)%rhoA)
+        F2('rhoS',COUPLING(ng)%rhoS)
+        F2('rufrc',COUPLING(ng)%rufrc)
+        F2('rvfrc',COUPLING(ng)%rvfrc)
+        F2('Zt_avg1',COUPLING(ng)%Zt_avg1)
+        F2('DU_avg1',COUPLING(ng)%DU_avg1)
+        F2('DU_avg2',COUPLING(ng)%DU_avg2)
+        F2('DV_avg1',COUPLING(ng)%DV_avg1)
+        F2('DV_avg2',COUPLING(ng)%DV_avg2)
+        F2('sustr',FORCES(ng)%sustr)
+        F2('svstr',FORCES(ng)%svstr)
+        F2('bustr',FORCES(ng)%bustr)
+        F2('bvstr',FORCES(ng)%bvstr)
+        F2('stflx',FORCES(ng)%stflx)
+        F2('btflx',FORCES(ng)%btflx)
+        F2('stflux',FORCES(ng)%stflux)
+        F2('btflux',FORCES(ng)%btflux)
+        F2('Akv',MIXING(ng)%Akv)
+        F2('Akt',MIXING(ng)%Akt)
+        F2('visc2_r',MIXING(ng)%visc2_r)
+        F2('visc2_p',MIXING(ng)%visc2_p)
+        F2('diff2',MIXING(ng)%diff2)
+        F2('rdrag',GRID(ng)%rdrag)
+#ifdef UV_QDRAG
+        F2('rdrag2',GRID(ng)%rdrag2)
+#endif
+#ifdef BV_FREQUENCY
+        F2('bvf',MIXING(ng)%bvf)
+#endif
+#ifdef NONLIN_EOS
+        F2('alpha',MIXING(ng)%alpha)
+        F2('beta',MIXING(ng)%beta)
+#endif
+#ifdef LMD_SKPP
+        F2('hsbl',MIXING(ng)%hsbl)
+        F2('ghats',MIXING(ng)%ghats)
+#endif
+#ifdef SHORTWAVE
+        F2('srflx',FORCES(ng)%srflx)
+#endif
+#ifdef BULK_FLUXES
+        F2('Uwind',FORCES(ng)%Uwind)
+        F2('Vwind',FORCES(ng)%Vwind)
+        F2('Tair',FORCES(ng)%Tair)
+        F2('Pair',FORCES(ng)%Pair)
+        F2('Hair',FORCES(ng)%Hair)
+        F2('rain',FORCES(ng)%rain)
+        F2('cloud',FORCES(ng)%cloud)
+        F2('lhflx',FORCES(ng)%lhflx)
+        F2('shflx',FORCES(ng)%shflx)
+        F2('lrflx',FORCES(ng)%lrflx)
+        F2('evap',FORCES(ng)%evap)
+#endif
+      END SELECT
+      END FUNCTION ref_field
+
+      SUBROUTINE cp2 (arr, n, dir, buf)
+      integer, intent(in) :: n
+      real(r8), intent(inout) :: arr(n)
+      integer(c_int), intent(in) :: dir
+      real(c_double), intent(inout) :: buf(*)
+      integer :: i
+      IF (dir.eq.0) THEN
+        DO i=1,n
+          buf(i)=arr(i)
+        END DO
+      ELSE
+        DO i=1,n
+          arr(i)=buf(i)
+        END DO
+      END IF
+      END SUBROUTINE cp2
+
+      END MODULE ref_glue
