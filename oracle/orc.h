@@ -1,0 +1,203 @@
+/*
+ * orc.h -- CPU ORACLE for the ROMS nonlinear 3-D time step.  TEST INFRASTRUCTURE.
+ *
+ * Plain-C restatement of the reference algorithm (myroms/roms, ROMS/Nonlinear),
+ * written loop-for-loop after the reference's serial (non-DISTRIBUTE) code so
+ * that results can be compared bit-for-bit with the reference build in
+ * oracle/_ref (gcc -O2 -ffp-contract=off, no -march => no FMA, like the
+ * amdflang x86-64 baseline build of the reference).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * this library; the product (roms_amd/, libroms_hip.so) never links or calls it.
+ *
+ * PARITY STATUS per function is stated in each source file header:
+ *   "pinned"   = checked against the reference routine itself (oracle/_ref,
+ *                tests/test_oracle_vs_ref.py) and committed golden vectors;
+ *   "unpinned" = the reference routine needs the NetCDF Fortran module and
+ *                cannot be built in this image (step2d, omega, pre_step3d,
+ *                rhs3d_tile, step3d_uv, step3d_t); checked only through
+ *                properties (tiling invariance, conservation, constancy).
+ *
+ * Array layout = the reference's (mod_grid.F / mod_ocean.F): column-major,
+ * i fastest, lower bounds LBi,LBj; rho-type levels 1..N, w-type levels 0..N.
+ */
+#ifndef ORC_H
+#define ORC_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* tracer advection scheme codes (Hadvection/Vadvection, mod_param.F:324-335) */
+enum { ORC_A4 = 1, ORC_C2 = 2, ORC_C4 = 3, ORC_HSIMT = 4, ORC_MPDATA = 5,
+       ORC_SPLINES = 6, ORC_SPLIT_U3 = 7, ORC_U3 = 8 };
+
+/* cpp-option bits (ROMS/Include/cppdefs.h names) */
+enum {
+  ORC_UV_ADV = 1 << 0, ORC_UV_COR = 1 << 1, ORC_UV_VIS2 = 1 << 2, ORC_TS_DIF2 = 1 << 3,
+  ORC_MIX_GEO_TS = 1 << 4,   /* else MIX_S_TS */
+  ORC_CURVGRID = 1 << 5, ORC_NONLIN_EOS = 1 << 6, ORC_UV_QDRAG = 1 << 7, /* else UV_LDRAG */
+  ORC_LMD_MIXING = 1 << 8, ORC_BULK_FLUXES = 1 << 9, ORC_SOLAR_SOURCE = 1 << 10,
+  ORC_ANA_VMIX = 1 << 11, ORC_SALINITY = 1 << 12, ORC_SPHERICAL = 1 << 13,
+  ORC_APP_UPWELLING = 1 << 20, ORC_APP_BENCHMARK = 1 << 21
+};
+
+/* loop bounds of one tile: BOUNDS(ng)%xxx(tile), get_bounds.F:1044-1884 */
+typedef struct {
+  int Istr, Iend, Jstr, Jend;
+  int IstrR, IendR, JstrR, JendR;
+  int IstrU, JstrV;
+  int IstrB, IendB, IstrM, JstrB, JendB, JstrM;
+  int IstrP, IendP, JstrP, JendP;
+  int IstrT, IendT, JstrT, JendT;
+  int Istrm3, Istrm2, Istrm1, IstrUm2, IstrUm1;
+  int Iendp1, Iendp2, Iendp2i, Iendp3;
+  int Jstrm3, Jstrm2, Jstrm1, JstrVm2, JstrVm1;
+  int Jendp1, Jendp2, Jendp2i, Jendp3;
+  int west, east, south, north;          /* DOMAIN(ng)%Western_Edge(tile) ... */
+  int sw, se, nw, ne;                    /* DOMAIN(ng)%SouthWest_Corner(tile) ... */
+} orc_bounds;
+
+#define ORC_MAXT 4
+#define ORC_MAXW 512
+
+typedef struct {
+  /* sizes */
+  int Lm, Mm, N, NT, NAT, Nghost;
+  int LBi, UBi, LBj, UBj;               /* allocation bounds (global arrays) */
+  int NtileI, NtileJ;
+  int EWperiodic, NSperiodic;
+  int options;                          /* ORC_* bits */
+  int hadv[ORC_MAXT], vadv[ORC_MAXT];
+  /* time stepping */
+  int ntfirst, ntstart, ndtfast, nfast;
+  double dt, dtfast;
+  double weight[2][ORC_MAXW + 1];       /* weight(1:2,1:2*ndtfast), 1-based */
+  /* physics */
+  double rho0, g, lambda, gamma2, Cp;
+  double R0, T0, S0, Tcoef, Scoef;
+  double hc; int Vtransform;
+  double rdrg, rdrg2, Zob;
+  double Akt_bak[ORC_MAXT], Akv_bak;
+  double dstart;
+  double blk_ZQ, blk_ZT, blk_ZW;
+  int lmd_Jwt;
+  double cc1, cc2, cc3;                 /* HSIMT constants mod_scalars.F */
+} orc_cfg;
+
+/* time-level state of main3d / mod_stepping */
+typedef struct {
+  int iic, iif;
+  int nstp, nnew, nrhs;
+  int kstp, knew, krhs, indx1;
+  int predictor;                        /* PREDICTOR_2D_STEP */
+  double time, tdays;
+} orc_step;
+
+typedef struct orc_s {
+  orc_cfg c;
+  orc_step s;
+  orc_bounds *b;                        /* NtileI*NtileJ tiles */
+  int ntiles;
+  size_t ni, nj, nij;
+  /* s-coordinate */
+  double *sc_r, *Cs_r, *sc_w, *Cs_w;    /* sc_r[k-1], sc_w[k] */
+  /* mod_grid 2-D */
+  double *h, *f, *fomn, *pm, *pn, *om_r, *on_r, *om_u, *on_u, *om_v, *on_v, *om_p, *on_p,
+      *omn, *pmon_r, *pnom_r, *pmon_p, *pnom_p, *pmon_u, *pnom_u, *pmon_v, *pnom_v,
+      *dmde, *dndx, *angler, *xr, *yr, *lonr, *latr, *rdrag, *rdrag2;
+  /* mod_grid 3-D */
+  double *Hz, *z_r, *z_w, *Huon, *Hvom;
+  /* mod_ocean */
+  double *zeta, *ubar, *vbar, *rzeta, *rubar, *rvbar;
+  double *u, *v, *t, *W, *wvel, *rho, *pden, *ru, *rv;
+  /* mod_coupling */
+  double *rhoA, *rhoS, *rufrc, *rvfrc, *Zt_avg1, *DU_avg1, *DU_avg2, *DV_avg1, *DV_avg2;
+  /* mod_forces */
+  double *sustr, *svstr, *bustr, *bvstr, *stflx, *btflx, *stflux, *btflux, *srflx;
+  double *Uwind, *Vwind, *Tair, *Pair, *Hair, *rain, *cloud, *lhflx, *shflx, *lrflx, *evap;
+  /* mod_mixing */
+  double *Akv, *Akt, *visc2_r, *visc2_p, *diff2, *bvf, *alpha, *beta, *hsbl, *ghats;
+  int *ksbl;
+  /* diag results: avgke, avgpe, avgkp, volume, max_speed, Cu_max ... */
+  double diag[16];
+} orc_t;
+
+/* ---- index helpers (valid inside functions that define LBi,LBj,ni,nij,N) ---- */
+#define X2(i, j) ((size_t)((i) - LBi) + (size_t)((j) - LBj) * ni)
+#define X3(i, j, k) (X2(i, j) + (size_t)((k) - 1) * nij)                 /* rho levels 1..N */
+#define XW(i, j, k) (X2(i, j) + (size_t)(k) * nij)                       /* w levels 0..N   */
+#define X4(i, j, k, n) (X3(i, j, k) + (size_t)((n) - 1) * nij * N)       /* u,v(i,j,k,n)    */
+#define XW4(i, j, k, n) (XW(i, j, k) + (size_t)((n) - 1) * nij * (N + 1))/* ru,rv,Akt(i,j,k,n) */
+#define XT(i, j, k, n, it) (X3(i, j, k) + ((size_t)((n) - 1) + 3 * (size_t)((it) - 1)) * nij * N)
+#define X2T(i, j, n) (X2(i, j) + (size_t)((n) - 1) * nij)                /* zeta(i,j,n) ... */
+
+#define ORC_LOCALS(o)                                                        \
+  const int LBi = (o)->c.LBi, LBj = (o)->c.LBj, N = (o)->c.N;                \
+  const size_t ni = (o)->ni, nij = (o)->nij;                                 \
+  (void)LBi; (void)LBj; (void)N; (void)ni; (void)nij
+
+/* ---- API ---- */
+orc_t *orc_create(const orc_cfg *cfg);
+void orc_destroy(orc_t *o);
+double *orc_field(orc_t *o, const char *name, long *nel);   /* pointer into the state */
+orc_step *orc_stepping(orc_t *o);
+orc_cfg *orc_config(orc_t *o);
+void orc_get_bounds(orc_t *o, int tile, int *out);           /* same order as ref_get_bounds */
+
+/* tiling: get_bounds.F */
+void orc_tile_bounds(const orc_cfg *c, int tile, orc_bounds *b);
+
+/* periodic copies: exchange_2d.F / exchange_3d.F ('r','u','v','p' grids) */
+void orc_exchange2d(const orc_t *o, const orc_bounds *b, char grid, double *A);
+void orc_exchange3d(const orc_t *o, const orc_bounds *b, char grid, double *A, int nk);
+/* gradient / closed fills: bc_2d.F, bc_3d.F */
+void orc_bc_r2d(const orc_t *o, const orc_bounds *b, double *A);
+void orc_bc_u2d(const orc_t *o, const orc_bounds *b, double *A);
+void orc_bc_v2d(const orc_t *o, const orc_bounds *b, double *A);
+void orc_bc_w3d(const orc_t *o, const orc_bounds *b, double *A, int nk);
+/* state BCs: zetabc.F u2dbc_im.F v2dbc_im.F t3dbc_im.F u3dbc_im.F v3dbc_im.F */
+void orc_zetabc(const orc_t *o, const orc_bounds *b, int kout);
+void orc_u2dbc(const orc_t *o, const orc_bounds *b, int kout);
+void orc_v2dbc(const orc_t *o, const orc_bounds *b, int kout);
+void orc_t3dbc(const orc_t *o, const orc_bounds *b, int nout, int itrc);
+void orc_u3dbc(const orc_t *o, const orc_bounds *b, int nout);
+void orc_v3dbc(const orc_t *o, const orc_bounds *b, int nout);
+
+/* kernels (tile = 0..ntiles-1) */
+void orc_set_depth(orc_t *o, int tile);
+void orc_set_massflux(orc_t *o, int tile);
+void orc_rho_eos(orc_t *o, int tile);
+void orc_set_vbc(orc_t *o, int tile);
+void orc_ana_vmix(orc_t *o, int tile);
+void orc_set_data(orc_t *o, int tile);       /* analytic forcing of this step */
+void orc_omega(orc_t *o, int tile);
+void orc_wvelocity(orc_t *o, int tile, int ninp);
+void orc_set_zeta(orc_t *o, int tile);
+void orc_ini_zeta(orc_t *o, int tile);
+void orc_ini_fields(orc_t *o, int tile);
+void orc_pre_step3d(orc_t *o, int tile);
+void orc_prsgrd(orc_t *o, int tile);
+void orc_t3dmix2(orc_t *o, int tile);
+void orc_uv3dmix2(orc_t *o, int tile);
+void orc_rhs3d_tile(orc_t *o, int tile);
+void orc_rhs3d(orc_t *o, int tile);          /* pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2 */
+void orc_step2d(orc_t *o, int tile);
+void orc_step3d_uv(orc_t *o, int tile);
+void orc_step3d_t(orc_t *o, int tile);
+void orc_diag(orc_t *o);
+void orc_lmd_vmix(orc_t *o, int tile);
+void orc_bulk_flux(orc_t *o, int tile);
+void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta, double *Ua, double *Va,
+                      double *Wa, const double *oHz);
+
+/* one baroclinic step, main3d.F:216-1148 */
+int orc_main3d_step(orc_t *o);
+/* start-of-run: initial.F tail (iic=ntstart) */
+void orc_start(orc_t *o);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

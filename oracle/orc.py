@@ -1,0 +1,137 @@
+"""ctypes binding of the CPU oracle (liborc.so).  TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module; the product package roms_amd never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAXT, MAXW = 4, 512
+
+# scheme codes / option bits: keep in sync with orc.h
+A4, C2, C4, HSIMT, MPDATA, SPLINES, SPLIT_U3, U3 = range(1, 9)
+SCHEMES = dict(A4=A4, C2=C2, C4=C4, HSIMT=HSIMT, MPDATA=MPDATA, SPLINES=SPLINES, SU3=SPLIT_U3, U3=U3)
+UV_ADV, UV_COR, UV_VIS2, TS_DIF2, MIX_GEO_TS, CURVGRID, NONLIN_EOS, UV_QDRAG, LMD_MIXING, \
+    BULK_FLUXES, SOLAR_SOURCE, ANA_VMIX, SALINITY, SPHERICAL = [1 << k for k in range(14)]
+APP_UPWELLING, APP_BENCHMARK = 1 << 20, 1 << 21
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("Lm", C.c_int), ("Mm", C.c_int), ("N", C.c_int), ("NT", C.c_int), ("NAT", C.c_int),
+        ("Nghost", C.c_int), ("LBi", C.c_int), ("UBi", C.c_int), ("LBj", C.c_int), ("UBj", C.c_int),
+        ("NtileI", C.c_int), ("NtileJ", C.c_int), ("EWperiodic", C.c_int), ("NSperiodic", C.c_int),
+        ("options", C.c_int), ("hadv", C.c_int * MAXT), ("vadv", C.c_int * MAXT),
+        ("ntfirst", C.c_int), ("ntstart", C.c_int), ("ndtfast", C.c_int), ("nfast", C.c_int),
+        ("dt", C.c_double), ("dtfast", C.c_double), ("weight", (C.c_double * (MAXW + 1)) * 2),
+        ("rho0", C.c_double), ("g", C.c_double), ("lambda_", C.c_double), ("gamma2", C.c_double),
+        ("Cp", C.c_double), ("R0", C.c_double), ("T0", C.c_double), ("S0", C.c_double),
+        ("Tcoef", C.c_double), ("Scoef", C.c_double), ("hc", C.c_double), ("Vtransform", C.c_int),
+        ("rdrg", C.c_double), ("rdrg2", C.c_double), ("Zob", C.c_double),
+        ("Akt_bak", C.c_double * MAXT), ("Akv_bak", C.c_double), ("dstart", C.c_double),
+        ("blk_ZQ", C.c_double), ("blk_ZT", C.c_double), ("blk_ZW", C.c_double),
+        ("lmd_Jwt", C.c_int), ("cc1", C.c_double), ("cc2", C.c_double), ("cc3", C.c_double),
+    ]
+
+
+class Step(C.Structure):
+    _fields_ = [("iic", C.c_int), ("iif", C.c_int), ("nstp", C.c_int), ("nnew", C.c_int),
+                ("nrhs", C.c_int), ("kstp", C.c_int), ("knew", C.c_int), ("krhs", C.c_int),
+                ("indx1", C.c_int), ("predictor", C.c_int), ("time", C.c_double), ("tdays", C.c_double)]
+
+
+def build(force=False):
+    so = os.path.join(HERE, "liborc.so")
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", HERE, "-j4"])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(Cfg)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_field.restype = C.POINTER(C.c_double)
+        L.orc_field.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]
+        L.orc_stepping.restype = C.POINTER(Step)
+        L.orc_stepping.argtypes = [C.c_void_p]
+        L.orc_config.restype = C.POINTER(Cfg)
+        L.orc_config.argtypes = [C.c_void_p]
+        L.orc_get_bounds.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_main3d_step.argtypes = [C.c_void_p]
+        L.orc_start.argtypes = [C.c_void_p]
+        L.orc_diag.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+TILE_KERNELS = ["set_depth", "set_massflux", "rho_eos", "set_vbc", "ana_vmix", "set_data", "omega",
+                "set_zeta", "ini_zeta", "ini_fields", "pre_step3d", "prsgrd", "t3dmix2", "uv3dmix2",
+                "rhs3d_tile", "rhs3d", "step2d", "step3d_uv", "step3d_t", "lmd_vmix", "bulk_flux"]
+
+
+class Oracle:
+    """One oracle state (global arrays, reference layout)."""
+
+    def __init__(self, cfg: Cfg):
+        self.L = lib()
+        self.h = self.L.orc_create(C.byref(cfg))
+        self.cfg = self.L.orc_config(self.h).contents
+        self.step = self.L.orc_stepping(self.h).contents
+        self.ni = self.cfg.UBi - self.cfg.LBi + 1
+        self.nj = self.cfg.UBj - self.cfg.LBj + 1
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def field(self, name):
+        """Flat numpy view (no copy) of a state array."""
+        n = C.c_long()
+        p = self.L.orc_field(self.h, name.encode(), C.byref(n))
+        if n.value < 0:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def arr(self, name):
+        """View shaped (..., nj, ni) (C order == Fortran (i,j,...) order reversed)."""
+        a = self.field(name)
+        if a.size % (self.ni * self.nj) == 0 and a.size >= self.ni * self.nj:
+            return a.reshape(-1, self.nj, self.ni)
+        return a
+
+    def bounds(self, tile=0):
+        b = (C.c_int * 64)()
+        self.L.orc_get_bounds(self.h, tile, b)
+        return list(b)[:54]
+
+    def call(self, kernel, tile=None, *args):
+        f = getattr(self.L, "orc_" + kernel)
+        tiles = range(self.cfg.NtileI * self.cfg.NtileJ) if tile is None else [tile]
+        for t in tiles:
+            f(C.c_void_p(self.h), C.c_int(t), *[C.c_int(a) for a in args])
+
+    def start(self):
+        self.L.orc_start(self.h)
+
+    def main3d_step(self, n=1):
+        for _ in range(n):
+            self.L.orc_main3d_step(self.h)
+
+    def diag(self):
+        """Run orc_diag; returns [avgke, avgpe, avgkp, volume, maxspeed, Cu, Cv, Cw, Ci, Cj, Ck, C]."""
+        self.L.orc_diag(C.c_void_p(self.h))
+        out = (C.c_double * 16)()
+        self.L.orc_get_diag(C.c_void_p(self.h), out)
+        return list(out)[:12]

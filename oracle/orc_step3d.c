@@ -1,0 +1,582 @@
+/*
+ * orc_step3d.c -- corrector steps for 3-D momentum and tracers.
+ * TEST INFRASTRUCTURE (see orc.h).
+ *
+ *   orc_step3d_uv  step3d_uv_tile  ROMS/Nonlinear/step3d_uv.F:134-1844  UNPINNED
+ *   orc_step3d_t   step3d_t_tile   ROMS/Nonlinear/step3d_t.F:120-1974   UNPINNED
+ * (both files USE mod_sources -> mod_netcdf: not buildable in this image).
+ * mpdata_adiff_tile, which step3d_t calls, IS pinned (orc_mpdata.c).
+ */
+#include "orc.h"
+#include <math.h>
+#include <stdlib.h>
+
+#define MAX(a, b) ((a) > (b) ? (a) : (b))
+#define MIN(a, b) ((a) < (b) ? (a) : (b))
+#define CX(A, i, k) A[(size_t)((i) - LBi) + (size_t)(k) * ni]
+
+void orc_hadv_flux(const orc_t *o, const orc_bounds *b, int scheme, const double *T, const double *Huon,
+                   const double *Hvom, double *FX, double *FE, double *curv, double *grad);
+void orc_vadv_flux(const orc_t *o, const orc_bounds *b, int scheme, int corrector, int j, const double *T,
+                   double *FC, double *CF);
+
+/* --------------------------------------------------------------- step3d_uv */
+void orc_step3d_uv(orc_t *o, int tile) {
+  ORC_LOCALS(o);
+  const orc_bounds *b = &o->b[tile];
+  const orc_cfg *c = &o->c;
+  const int nrhs = o->s.nrhs, nnew = o->s.nnew, iic = o->s.iic;
+  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
+  const int IstrU = b->IstrU, JstrV = b->JstrV;
+  const double dt = c->dt;
+  double *u = o->u, *v = o->v, *Hz = o->Hz, *Akv = o->Akv, *ru = o->ru, *rv = o->rv;
+  double *pm = o->pm, *pn = o->pn, *on_u = o->on_u, *om_v = o->om_v;
+  double *Huon = o->Huon, *Hvom = o->Hvom;
+  double cff, cff1;
+  const size_t cs = ni * (size_t)(N + 1);
+  double *AK = (double *)calloc(7 * cs, sizeof(double));
+  double *BC = AK + cs, *CF = AK + 2 * cs, *DC = AK + 3 * cs, *FC = AK + 4 * cs, *Hzk = AK + 5 * cs,
+         *oHz = AK + 6 * cs;
+
+  for (int j = Jstr; j <= Jend; j++) {
+    for (int dir = 0; dir < 2; dir++) {
+      /* dir 0: u on IstrU:Iend; dir 1: v on Istr:Iend if j>=JstrV (identical algebra) */
+      if (dir == 1 && j < JstrV) break;
+      const int i0 = dir == 0 ? IstrU : Istr;
+      const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1;
+      double *q = dir == 0 ? u : v;
+      double *rq = dir == 0 ? ru : rv;
+      for (int i = i0; i <= Iend; i++) {
+        CX(AK, i, 0) = 0.5 * (Akv[XW(i - di, j - dj, 0)] + Akv[XW(i, j, 0)]);
+        for (int k = 1; k <= N; k++) {
+          CX(AK, i, k) = 0.5 * (Akv[XW(i - di, j - dj, k)] + Akv[XW(i, j, k)]);
+          CX(Hzk, i, k) = 0.5 * (Hz[X3(i - di, j - dj, k)] + Hz[X3(i, j, k)]);
+          CX(oHz, i, k) = 1.0 / CX(Hzk, i, k);
+        }
+      }
+      /* time step RHS terms :345-358 */
+      if (iic == c->ntfirst) cff = 0.25 * dt;
+      else if (iic == c->ntfirst + 1) cff = 0.25 * dt * 3.0 / 2.0;
+      else cff = 0.25 * dt * 23.0 / 12.0;
+      for (int i = i0; i <= Iend; i++)
+        CX(DC, i, 0) = cff * (pm[X2(i, j)] + pm[X2(i - di, j - dj)]) * (pn[X2(i, j)] + pn[X2(i - di, j - dj)]);
+      for (int k = 1; k <= N; k++)
+        for (int i = i0; i <= Iend; i++) {
+          q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] + CX(DC, i, 0) * rq[XW4(i, j, k, nrhs)];
+          q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] * CX(oHz, i, k);
+        }
+      /* implicit vertical viscosity, parabolic splines (SPLINES_VVISC) :361-450 */
+      cff1 = 1.0 / 6.0;
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = i0; i <= Iend; i++) {
+          CX(FC, i, k) = cff1 * CX(Hzk, i, k) - dt * CX(AK, i, k - 1) * CX(oHz, i, k);
+          CX(CF, i, k) = cff1 * CX(Hzk, i, k + 1) - dt * CX(AK, i, k + 1) * CX(oHz, i, k + 1);
+        }
+      for (int i = i0; i <= Iend; i++) { CX(CF, i, 0) = 0.0; CX(DC, i, 0) = 0.0; }
+      cff1 = 1.0 / 3.0;
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = i0; i <= Iend; i++) {
+          CX(BC, i, k) = cff1 * (CX(Hzk, i, k) + CX(Hzk, i, k + 1)) +
+                         dt * CX(AK, i, k) * (CX(oHz, i, k) + CX(oHz, i, k + 1));
+          cff = 1.0 / (CX(BC, i, k) - CX(FC, i, k) * CX(CF, i, k - 1));
+          CX(CF, i, k) = cff * CX(CF, i, k);
+          CX(DC, i, k) = cff * (q[X4(i, j, k + 1, nnew)] - q[X4(i, j, k, nnew)] - CX(FC, i, k) * CX(DC, i, k - 1));
+        }
+      for (int i = i0; i <= Iend; i++) CX(DC, i, N) = 0.0;
+      for (int k = N - 1; k >= 1; k--)
+        for (int i = i0; i <= Iend; i++) CX(DC, i, k) = CX(DC, i, k) - CX(CF, i, k) * CX(DC, i, k + 1);
+      for (int k = 1; k <= N; k++)
+        for (int i = i0; i <= Iend; i++) {
+          CX(DC, i, k) = CX(DC, i, k) * CX(AK, i, k);
+          cff = dt * CX(oHz, i, k) * (CX(DC, i, k) - CX(DC, i, k - 1));
+          q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] + cff;
+        }
+      /* replace vertical mean with the barotropic one :594-730 / :1061-1200 */
+      for (int i = i0; i <= Iend; i++) {
+        CX(CF, i, 0) = CX(Hzk, i, 1);
+        CX(DC, i, 0) = q[X4(i, j, 1, nnew)] * CX(Hzk, i, 1);
+      }
+      for (int k = 2; k <= N; k++)
+        for (int i = i0; i <= Iend; i++) {
+          CX(CF, i, 0) = CX(CF, i, 0) + CX(Hzk, i, k);
+          CX(DC, i, 0) = CX(DC, i, 0) + q[X4(i, j, k, nnew)] * CX(Hzk, i, k);
+        }
+      const double *omn1 = dir == 0 ? on_u : om_v;
+      const double *Davg = dir == 0 ? o->DU_avg1 : o->DV_avg1;
+      for (int i = i0; i <= Iend; i++) {
+        cff1 = 1.0 / (CX(CF, i, 0) * omn1[X2(i, j)]);
+        CX(DC, i, 0) = (CX(DC, i, 0) * omn1[X2(i, j)] - Davg[X2(i, j)]) * cff1;
+      }
+      for (int k = 1; k <= N; k++)
+        for (int i = i0; i <= Iend; i++) q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] - CX(DC, i, 0);
+    }
+  }
+
+  orc_u3dbc(o, b, nnew);                                                /* :1266 */
+  orc_v3dbc(o, b, nnew);                                                /* :1271 */
+
+  /* couple 2-D and 3-D momentum at the boundaries; corrected mass fluxes :1310-1750 */
+  for (int j = b->JstrT; j <= b->JendT; j++) {
+    for (int i = b->IstrP; i <= b->IendT; i++) { CX(DC, i, 0) = 0.0; CX(CF, i, 0) = 0.0; CX(FC, i, 0) = 0.0; }
+    for (int k = 1; k <= N; k++)
+      for (int i = b->IstrP; i <= b->IendT; i++) {
+        cff = 0.5 * on_u[X2(i, j)];
+        CX(DC, i, k) = cff * (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]);
+        CX(DC, i, 0) = CX(DC, i, 0) + CX(DC, i, k);
+        CX(CF, i, 0) = CX(CF, i, 0) + CX(DC, i, k) * u[X4(i, j, k, nnew)];
+      }
+    for (int i = b->IstrP; i <= b->IendT; i++) {
+      CX(DC, i, 0) = 1.0 / CX(DC, i, 0);
+      CX(CF, i, 0) = CX(DC, i, 0) * (CX(CF, i, 0) - o->DU_avg1[X2(i, j)]);
+      o->ubar[X2T(i, j, 1)] = CX(DC, i, 0) * o->DU_avg1[X2(i, j)];
+      o->ubar[X2T(i, j, 2)] = o->ubar[X2T(i, j, 1)];
+    }
+    if (!c->EWperiodic) {
+      if (b->west) for (int k = 1; k <= N; k++) u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] - CX(CF, Istr, 0);
+      if (b->east)
+        for (int k = 1; k <= N; k++) u[X4(Iend + 1, j, k, nnew)] = u[X4(Iend + 1, j, k, nnew)] - CX(CF, Iend + 1, 0);
+    }
+    if (!c->NSperiodic) {
+      if (j == 0)
+        for (int k = 1; k <= N; k++)
+          for (int i = IstrU; i <= Iend; i++) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] - CX(CF, i, 0);
+      if (j == c->Mm + 1)
+        for (int k = 1; k <= N; k++)
+          for (int i = IstrU; i <= Iend; i++) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] - CX(CF, i, 0);
+    }
+    for (int k = N; k >= 1; k--)
+      for (int i = b->IstrP; i <= b->IendT; i++) {
+        Huon[X3(i, j, k)] = 0.5 * (Huon[X3(i, j, k)] + u[X4(i, j, k, nnew)] * CX(DC, i, k));
+        CX(FC, i, 0) = CX(FC, i, 0) + Huon[X3(i, j, k)];
+      }
+    for (int i = b->IstrP; i <= b->IendT; i++) CX(FC, i, 0) = CX(DC, i, 0) * (CX(FC, i, 0) - o->DU_avg2[X2(i, j)]);
+    for (int k = 1; k <= N; k++)
+      for (int i = b->IstrP; i <= b->IendT; i++) Huon[X3(i, j, k)] = Huon[X3(i, j, k)] - CX(DC, i, k) * CX(FC, i, 0);
+
+    if (j >= Jstr) {
+      for (int i = b->IstrT; i <= b->IendT; i++) { CX(DC, i, 0) = 0.0; CX(CF, i, 0) = 0.0; CX(FC, i, 0) = 0.0; }
+      for (int k = 1; k <= N; k++)
+        for (int i = b->IstrT; i <= b->IendT; i++) {
+          cff = 0.5 * om_v[X2(i, j)];
+          CX(DC, i, k) = cff * (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]);
+          CX(DC, i, 0) = CX(DC, i, 0) + CX(DC, i, k);
+          CX(CF, i, 0) = CX(CF, i, 0) + CX(DC, i, k) * v[X4(i, j, k, nnew)];
+        }
+      for (int i = b->IstrT; i <= b->IendT; i++) {
+        CX(DC, i, 0) = 1.0 / CX(DC, i, 0);
+        CX(CF, i, 0) = CX(DC, i, 0) * (CX(CF, i, 0) - o->DV_avg1[X2(i, j)]);
+        o->vbar[X2T(i, j, 1)] = CX(DC, i, 0) * o->DV_avg1[X2(i, j)];
+        o->vbar[X2T(i, j, 2)] = o->vbar[X2T(i, j, 1)];
+      }
+      if (!c->EWperiodic) {
+        if (b->west)
+          for (int k = 1; k <= N; k++) v[X4(Istr - 1, j, k, nnew)] = v[X4(Istr - 1, j, k, nnew)] - CX(CF, Istr - 1, 0);
+        if (b->east)
+          for (int k = 1; k <= N; k++) v[X4(Iend + 1, j, k, nnew)] = v[X4(Iend + 1, j, k, nnew)] - CX(CF, Iend + 1, 0);
+      }
+      if (!c->NSperiodic) {
+        if (j == 1)
+          for (int k = 1; k <= N; k++)
+            for (int i = Istr; i <= Iend; i++) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] - CX(CF, i, 0);
+        if (j == c->Mm + 1)
+          for (int k = 1; k <= N; k++)
+            for (int i = Istr; i <= Iend; i++) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] - CX(CF, i, 0);
+      }
+      for (int k = N; k >= 1; k--)
+        for (int i = b->IstrT; i <= b->IendT; i++) {
+          Hvom[X3(i, j, k)] = 0.5 * (Hvom[X3(i, j, k)] + v[X4(i, j, k, nnew)] * CX(DC, i, k));
+          CX(FC, i, 0) = CX(FC, i, 0) + Hvom[X3(i, j, k)];
+        }
+      for (int i = b->IstrT; i <= b->IendT; i++)
+        CX(FC, i, 0) = CX(DC, i, 0) * (CX(FC, i, 0) - o->DV_avg2[X2(i, j)]);
+      for (int k = 1; k <= N; k++)
+        for (int i = b->IstrT; i <= b->IendT; i++)
+          Hvom[X3(i, j, k)] = Hvom[X3(i, j, k)] - CX(DC, i, k) * CX(FC, i, 0);
+    }
+  }
+  orc_exchange3d(o, b, 'u', u + (size_t)(nnew - 1) * nij * N, N);      /* :1763-1830 */
+  orc_exchange3d(o, b, 'v', v + (size_t)(nnew - 1) * nij * N, N);
+  orc_exchange3d(o, b, 'u', Huon, N);
+  orc_exchange3d(o, b, 'v', Hvom, N);
+  for (int k = 0; k < 2; k++) {
+    orc_exchange2d(o, b, 'u', o->ubar + (size_t)k * nij);
+    orc_exchange2d(o, b, 'v', o->vbar + (size_t)k * nij);
+  }
+  free(AK);
+}
+
+/* ---------------------------------------------------------------- step3d_t */
+
+/* HSIMT limiter kernel (Wu and Zhu 2010): value added to the upstream tracer.
+   step3d_t.F:520-560 -- grad = gradX(i), gradu = upstream-side neighbour gradient,
+   Ka, Kau likewise, oKa = 1/Ka. */
+static double hsimt_lim(const orc_cfg *c, double grad, double gradu, double Ka, double Kau, double oKa) {
+  const double eps1 = 1.0E-12;
+  double r, rka;
+  if (fabs(grad) <= eps1) { r = 0.0; rka = 0.0; }
+  else { r = gradu / grad; rka = Kau * oKa; }
+  double a1 = c->cc1 * Ka + c->cc2 - c->cc3 * oKa;
+  double b1 = -c->cc1 * Ka + c->cc2 + c->cc3 * oKa;
+  double beta = a1 + b1 * r;
+  /* MAX(0, MIN(2, 2*r*rka, beta)) */
+  double m = 2.0;
+  double x = 2.0 * r * rka;
+  if (x < m) m = x;
+  if (beta < m) m = beta;
+  if (m < 0.0) m = 0.0;
+  return 0.5 * m * grad * Ka;
+}
+
+void orc_step3d_t(orc_t *o, int tile) {
+  ORC_LOCALS(o);
+  const orc_bounds *b = &o->b[tile];
+  const orc_cfg *c = &o->c;
+  const int nnew = o->s.nnew;
+  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
+  const int IstrU = b->IstrU, JstrV = b->JstrV;
+  const double dt = c->dt, eps1 = 1.0E-12;
+  double *t = o->t, *Hz = o->Hz, *Huon = o->Huon, *Hvom = o->Hvom, *W = o->W, *z_r = o->z_r;
+  double *pm = o->pm, *pn = o->pn, *Akt = o->Akt;
+  double cff, cff1, cff2, cff3;
+  int Lhsimt = 0, Lmpdata = 0, anyH = 0, anyV = 0, anyHm = 0, anyVm = 0;
+  for (int it = 0; it < c->NT; it++) {
+    anyH |= c->hadv[it] == ORC_HSIMT;
+    anyV |= c->vadv[it] == ORC_HSIMT;
+    anyHm |= c->hadv[it] == ORC_MPDATA;
+    anyVm |= c->vadv[it] == ORC_MPDATA;
+  }
+  Lhsimt = anyH && anyV;
+  Lmpdata = anyHm && anyVm;
+  const size_t cs = ni * (size_t)(N + 1);
+  double *CF = (double *)calloc(4 * cs, sizeof(double));
+  double *BC = CF + cs, *DC = CF + 2 * cs, *FC = CF + 3 * cs;
+  double *FE = (double *)calloc(4 * nij, sizeof(double));
+  double *FX = FE + nij, *curv = FE + 2 * nij, *grad = FE + 3 * nij;
+  double *oHz = (double *)calloc(nij * (size_t)N, sizeof(double));
+  const size_t nmax = (o->ni > o->nj ? o->ni : o->nj) + (size_t)N + 8;
+  double *g1 = (double *)calloc(3 * nmax, sizeof(double)), *Ka = g1 + nmax, *oKa = g1 + 2 * nmax;
+  double *Ta = NULL, *Ua = NULL, *Va = NULL, *Wa = NULL;
+  if (Lmpdata) {
+    Ta = (double *)calloc(nij * (size_t)N * (size_t)c->NT, sizeof(double));
+    Ua = (double *)calloc(nij * (size_t)N, sizeof(double));
+    Va = (double *)calloc(nij * (size_t)N, sizeof(double));
+    Wa = (double *)calloc(nij * (size_t)(N + 1), sizeof(double));
+  }
+#define TA(i, j, k, it) Ta[X3(i, j, k) + (size_t)((it) - 1) * nij * N]
+
+  /* inverse thickness :383-405 */
+  if (Lmpdata || Lhsimt) {
+    for (int k = 1; k <= N; k++)
+      for (int j = b->Jstrm2; j <= b->Jendp2; j++)
+        for (int i = b->Istrm2; i <= b->Iendp2; i++) oHz[X3(i, j, k)] = 1.0 / Hz[X3(i, j, k)];
+  } else {
+    for (int k = 1; k <= N; k++)
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = Istr; i <= Iend; i++) oHz[X3(i, j, k)] = 1.0 / Hz[X3(i, j, k)];
+  }
+
+  /* horizontal advection :412-915 */
+  for (int itrc = 1; itrc <= c->NT; itrc++) {
+    const int hs = c->hadv[itrc - 1];
+    if (hs == ORC_MPDATA || hs == ORC_HSIMT)
+      orc_exchange3d(o, b, 'r', t + XT(LBi, LBj, 1, nnew, itrc), N);  /* :420 */
+    for (int k = 1; k <= N; k++) {
+      const double *T3 = t + XT(LBi, LBj, k, 3, itrc);
+      const double *Hu = Huon + X3(LBi, LBj, k), *Hv = Hvom + X3(LBi, LBj, k);
+      if (hs == ORC_MPDATA) {
+        /* first-order upstream on the extended range :451-470 */
+        for (int j = b->JstrVm2; j <= b->Jendp2i; j++)
+          for (int i = b->IstrUm2; i <= b->Iendp3; i++) {
+            cff1 = MAX(Hu[X2(i, j)], 0.0);
+            cff2 = MIN(Hu[X2(i, j)], 0.0);
+            FX[X2(i, j)] = cff1 * T3[X2(i - 1, j)] + cff2 * T3[X2(i, j)];
+          }
+        for (int j = b->JstrVm2; j <= b->Jendp3; j++)
+          for (int i = b->IstrUm2; i <= b->Iendp2i; i++) {
+            cff1 = MAX(Hv[X2(i, j)], 0.0);
+            cff2 = MIN(Hv[X2(i, j)], 0.0);
+            FE[X2(i, j)] = cff1 * T3[X2(i, j - 1)] + cff2 * T3[X2(i, j)];
+          }
+      } else if (hs == ORC_HSIMT) {
+        /* third-order HSIMT-TVD :472-632 */
+        const double *oH = oHz + X3(LBi, LBj, k);
+#define GX(i) g1[(i) - LBi + 4]
+#define KX(i) Ka[(i) - LBi + 4]
+#define OKX(i) oKa[(i) - LBi + 4]
+        for (int j = Jstr; j <= Jend; j++) {
+          for (int i = IstrU - 1; i <= b->Iendp2; i++) {
+            cff = 0.125 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (pn[X2(i - 1, j)] + pn[X2(i, j)]) * dt;
+            cff1 = cff * (oH[X2(i - 1, j)] + oH[X2(i, j)]);
+            GX(i) = T3[X2(i, j)] - T3[X2(i - 1, j)];
+            KX(i) = 1.0 - fabs(Hu[X2(i, j)] * cff1);
+          }
+          if (!c->EWperiodic) {
+            if (b->west && Hu[X2(Istr, j)] >= 0.0) { GX(Istr - 1) = 0.0; KX(Istr - 1) = 0.0; }
+            if (b->east && Hu[X2(Iend + 1, j)] < 0.0) { GX(Iend + 2) = 0.0; KX(Iend + 2) = 0.0; }
+          }
+          for (int i = Istr; i <= Iend + 1; i++) {
+            double sw_xi;
+            if (KX(i) <= eps1) OKX(i) = 0.0;
+            else OKX(i) = 1.0 / MAX(KX(i), eps1);
+            if (Hu[X2(i, j)] >= 0.0)
+              sw_xi = T3[X2(i - 1, j)] + hsimt_lim(c, GX(i), GX(i - 1), KX(i), KX(i - 1), OKX(i));
+            else
+              sw_xi = T3[X2(i, j)] - hsimt_lim(c, GX(i), GX(i + 1), KX(i), KX(i + 1), OKX(i));
+            FX[X2(i, j)] = sw_xi * Hu[X2(i, j)];
+          }
+        }
+#undef GX
+#undef KX
+#undef OKX
+#define GE(j) g1[(j) - LBj + 4]
+#define KE(j) Ka[(j) - LBj + 4]
+#define OKE(j) oKa[(j) - LBj + 4]
+        for (int i = Istr; i <= Iend; i++) {
+          for (int j = JstrV - 1; j <= b->Jendp2; j++) {
+            cff = 0.125 * (pn[X2(i, j)] + pn[X2(i, j - 1)]) * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * dt;
+            cff1 = cff * (oH[X2(i, j)] + oH[X2(i, j - 1)]);
+            GE(j) = T3[X2(i, j)] - T3[X2(i, j - 1)];
+            KE(j) = 1.0 - fabs(Hv[X2(i, j)] * cff1);
+          }
+          if (!c->NSperiodic) {
+            if (b->south && Hv[X2(i, Jstr)] >= 0.0) { GE(Jstr - 1) = 0.0; KE(Jstr - 1) = 0.0; }
+            if (b->north && Hv[X2(i, Jend + 1)] < 0.0) { GE(Jend + 2) = 0.0; KE(Jend + 2) = 0.0; }
+          }
+          for (int j = Jstr; j <= Jend + 1; j++) {
+            double sw_eta;
+            if (KE(j) <= eps1) OKE(j) = 0.0;
+            else OKE(j) = 1.0 / MAX(KE(j), eps1);
+            if (Hv[X2(i, j)] >= 0.0)
+              sw_eta = T3[X2(i, j - 1)] + hsimt_lim(c, GE(j), GE(j - 1), KE(j), KE(j - 1), OKE(j));
+            else
+              sw_eta = T3[X2(i, j)] - hsimt_lim(c, GE(j), GE(j + 1), KE(j), KE(j + 1), OKE(j));
+            FE[X2(i, j)] = sw_eta * Hv[X2(i, j)];
+          }
+        }
+#undef GE
+#undef KE
+#undef OKE
+      } else {
+        orc_hadv_flux(o, b, hs, T3, Hu, Hv, FX, FE, curv, grad);
+      }
+      /* time-step horizontal advection :873-915 */
+      if (hs == ORC_MPDATA) {
+        for (int j = b->JstrVm2; j <= b->Jendp2i; j++)
+          for (int i = b->IstrUm2; i <= b->Iendp2i; i++) {
+            cff = dt * pm[X2(i, j)] * pn[X2(i, j)];
+            cff1 = cff * (FX[X2(i + 1, j)] - FX[X2(i, j)]);
+            cff2 = cff * (FE[X2(i, j + 1)] - FE[X2(i, j)]);
+            cff3 = cff1 + cff2;
+            TA(i, j, k, itrc) = t[XT(i, j, k, nnew, itrc)] - cff3;
+          }
+      } else {
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff = dt * pm[X2(i, j)] * pn[X2(i, j)];
+            cff1 = cff * (FX[X2(i + 1, j)] - FX[X2(i, j)]);
+            cff2 = cff * (FE[X2(i, j + 1)] - FE[X2(i, j)]);
+            cff3 = cff1 + cff2;
+            t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] - cff3;
+          }
+      }
+    }
+  }
+
+  /* vertical advection :920-1340 */
+  for (int itrc = 1; itrc <= c->NT; itrc++) {
+    const int vs = c->vadv[itrc - 1];
+    const int JminT = vs == ORC_MPDATA ? b->JstrVm2 : Jstr;
+    const int JmaxT = vs == ORC_MPDATA ? b->Jendp2i : Jend;
+    const double *T3 = t + XT(LBi, LBj, 1, 3, itrc);
+    for (int j = JminT; j <= JmaxT; j++) {
+      if (vs == ORC_MPDATA) {
+        for (int i = b->IstrUm2; i <= b->Iendp2i; i++) {
+          for (int k = 1; k <= N - 1; k++) {
+            cff1 = MAX(W[XW(i, j, k)], 0.0);
+            cff2 = MIN(W[XW(i, j, k)], 0.0);
+            CX(FC, i, k) = cff1 * T3[X3(i, j, k)] + cff2 * T3[X3(i, j, k + 1)];
+          }
+          CX(FC, i, 0) = 0.0;
+          CX(FC, i, N) = 0.0;
+        }
+      } else if (vs == ORC_HSIMT) {
+        /* :1069-1150 */
+        double *gZ = g1, *KaZ = Ka, *oKaZ = oKa;
+        for (int i = Istr; i <= Iend; i++) {
+          KaZ[0] = 0.0; oKaZ[0] = 0.0; gZ[0] = 0.0;
+          for (int k = 1; k <= N - 1; k++) {
+            cff = pm[X2(i, j)] * pn[X2(i, j)] * dt;
+            KaZ[k] = 1.0 - fabs(cff * W[XW(i, j, k)] / (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]));
+            oKaZ[k] = 1.0 / KaZ[k];
+            gZ[k] = T3[X3(i, j, k + 1)] - T3[X3(i, j, k)];
+          }
+          KaZ[N] = 0.0; oKaZ[N] = 0.0; gZ[N] = 0.0;
+          for (int k = 1; k <= N - 1; k++) {
+            cff1 = W[XW(i, j, k)];
+            if (k == 1 && cff1 >= 0.0) CX(FC, i, k) = cff1 * T3[X3(i, j, k)];
+            else if (k == N - 1 && cff1 < 0.0) CX(FC, i, k) = cff1 * T3[X3(i, j, k + 1)];
+            else {
+              double sw;
+              if (cff1 >= 0.0) sw = T3[X3(i, j, k)] + hsimt_lim(c, gZ[k], gZ[k - 1], KaZ[k], KaZ[k - 1], oKaZ[k]);
+              else sw = T3[X3(i, j, k + 1)] - hsimt_lim(c, gZ[k], gZ[k + 1], KaZ[k], KaZ[k + 1], oKaZ[k]);
+              CX(FC, i, k) = cff1 * sw;
+            }
+          }
+          CX(FC, i, 0) = 0.0;
+          CX(FC, i, N) = 0.0;
+        }
+      } else {
+        orc_vadv_flux(o, b, vs, 1, j, T3, FC, CF);
+      }
+      /* time-step vertical advection :1246-1340 */
+      if (vs == ORC_MPDATA) {
+        for (int i = b->IstrUm2; i <= b->Iendp2i; i++) CX(CF, i, 0) = dt * pm[X2(i, j)] * pn[X2(i, j)];
+        for (int k = 1; k <= N; k++)
+          for (int i = b->IstrUm2; i <= b->Iendp2i; i++) {
+            cff1 = CX(CF, i, 0) * (CX(FC, i, k) - CX(FC, i, k - 1));
+            TA(i, j, k, itrc) = (TA(i, j, k, itrc) - cff1) * oHz[X3(i, j, k)];
+          }
+      } else {
+        for (int i = Istr; i <= Iend; i++) CX(CF, i, 0) = dt * pm[X2(i, j)] * pn[X2(i, j)];
+        for (int k = 1; k <= N; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff1 = CX(CF, i, 0) * (CX(FC, i, k) - CX(FC, i, k - 1));
+            t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] - cff1;
+            t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] * oHz[X3(i, j, k)];
+          }
+      }
+    }
+  }
+
+  /* MPDATA anti-diffusive correction :1375-1500 */
+  for (int itrc = 1; itrc <= c->NT; itrc++) {
+    if (!(c->hadv[itrc - 1] == ORC_MPDATA && c->vadv[itrc - 1] == ORC_MPDATA)) continue;
+    double *Tai = Ta + (size_t)(itrc - 1) * nij * N;
+    orc_mpdata_adiff(o, tile, itrc, Tai, Ua, Va, Wa, oHz);
+    for (int k = 1; k <= N; k++) {
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = Istr; i <= Iend + 1; i++) {
+          cff1 = MAX(Ua[X3(i, j, k)], 0.0);
+          cff2 = MIN(Ua[X3(i, j, k)], 0.0);
+          FX[X2(i, j)] = (cff1 * TA(i - 1, j, k, itrc) + cff2 * TA(i, j, k, itrc)) * 0.5 *
+                         (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]) * o->on_u[X2(i, j)];
+        }
+      for (int j = Jstr; j <= Jend + 1; j++)
+        for (int i = Istr; i <= Iend; i++) {
+          cff1 = MAX(Va[X3(i, j, k)], 0.0);
+          cff2 = MIN(Va[X3(i, j, k)], 0.0);
+          FE[X2(i, j)] = (cff1 * TA(i, j - 1, k, itrc) + cff2 * TA(i, j, k, itrc)) * 0.5 *
+                         (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]) * o->om_v[X2(i, j)];
+        }
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = Istr; i <= Iend; i++) {
+          cff = dt * pm[X2(i, j)] * pn[X2(i, j)];
+          cff1 = cff * (FX[X2(i + 1, j)] - FX[X2(i, j)]);
+          cff2 = cff * (FE[X2(i, j + 1)] - FE[X2(i, j)]);
+          cff3 = cff1 + cff2;
+          t[XT(i, j, k, nnew, itrc)] = TA(i, j, k, itrc) * Hz[X3(i, j, k)] - cff3;
+        }
+    }
+    for (int j = Jstr; j <= Jend; j++) {
+      for (int k = 1; k <= N - 1; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          cff1 = MAX(Wa[XW(i, j, k)], 0.0);
+          cff2 = MIN(Wa[XW(i, j, k)], 0.0);
+          CX(FC, i, k) = cff1 * TA(i, j, k, itrc) + cff2 * TA(i, j, k + 1, itrc);
+        }
+      for (int i = Istr; i <= Iend; i++) { CX(FC, i, 0) = 0.0; CX(FC, i, N) = 0.0; }
+      for (int i = Istr; i <= Iend; i++) CX(CF, i, 0) = dt * pm[X2(i, j)] * pn[X2(i, j)];
+      for (int k = 1; k <= N; k++)
+        for (int i = Istr; i <= Iend; i++) {
+          cff1 = CX(CF, i, 0) * (CX(FC, i, k) - CX(FC, i, k - 1));
+          t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] - cff1;
+        }
+    }
+  }
+
+  /* implicit vertical diffusion :1664-1790 */
+  for (int j = Jstr; j <= Jend; j++)
+    for (int itrc = 1; itrc <= c->NT; itrc++) {
+      const int ltrc = MIN(c->NAT, itrc);
+      if (!(c->hadv[itrc - 1] == ORC_MPDATA && c->vadv[itrc - 1] == ORC_MPDATA)) {
+        /* parabolic splines (SPLINES_VDIFF) */
+        cff1 = 1.0 / 6.0;
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            CX(FC, i, k) = cff1 * Hz[X3(i, j, k)] - dt * Akt[XW4(i, j, k - 1, ltrc)] * oHz[X3(i, j, k)];
+            CX(CF, i, k) = cff1 * Hz[X3(i, j, k + 1)] - dt * Akt[XW4(i, j, k + 1, ltrc)] * oHz[X3(i, j, k + 1)];
+          }
+        for (int i = Istr; i <= Iend; i++) { CX(CF, i, 0) = 0.0; CX(DC, i, 0) = 0.0; }
+        cff1 = 1.0 / 3.0;
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            CX(BC, i, k) = cff1 * (Hz[X3(i, j, k)] + Hz[X3(i, j, k + 1)]) +
+                           dt * Akt[XW4(i, j, k, ltrc)] * (oHz[X3(i, j, k)] + oHz[X3(i, j, k + 1)]);
+            cff = 1.0 / (CX(BC, i, k) - CX(FC, i, k) * CX(CF, i, k - 1));
+            CX(CF, i, k) = cff * CX(CF, i, k);
+            CX(DC, i, k) = cff * (t[XT(i, j, k + 1, nnew, itrc)] - t[XT(i, j, k, nnew, itrc)] -
+                                  CX(FC, i, k) * CX(DC, i, k - 1));
+          }
+        for (int i = Istr; i <= Iend; i++) CX(DC, i, N) = 0.0;
+        for (int k = N - 1; k >= 1; k--)
+          for (int i = Istr; i <= Iend; i++) CX(DC, i, k) = CX(DC, i, k) - CX(CF, i, k) * CX(DC, i, k + 1);
+        for (int k = 1; k <= N; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            CX(DC, i, k) = CX(DC, i, k) * Akt[XW4(i, j, k, ltrc)];
+            cff1 = dt * oHz[X3(i, j, k)] * (CX(DC, i, k) - CX(DC, i, k - 1));
+            t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] + cff1;
+          }
+      } else {
+        /* plain tridiagonal (MPDATA tracers) :1724-1790 */
+        cff = -dt * c->lambda;
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff1 = 1.0 / (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]);
+            CX(FC, i, k) = cff * cff1 * Akt[XW4(i, j, k, ltrc)];
+          }
+        for (int i = Istr; i <= Iend; i++) { CX(FC, i, 0) = 0.0; CX(FC, i, N) = 0.0; }
+        for (int k = 1; k <= N; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            CX(BC, i, k) = Hz[X3(i, j, k)] - CX(FC, i, k) - CX(FC, i, k - 1);
+            CX(DC, i, k) = t[XT(i, j, k, nnew, itrc)];
+          }
+        for (int i = Istr; i <= Iend; i++) {
+          cff = 1.0 / CX(BC, i, 1);
+          CX(CF, i, 1) = cff * CX(FC, i, 1);
+          CX(DC, i, 1) = cff * CX(DC, i, 1);
+        }
+        for (int k = 2; k <= N - 1; k++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff = 1.0 / (CX(BC, i, k) - CX(FC, i, k - 1) * CX(CF, i, k - 1));
+            CX(CF, i, k) = cff * CX(FC, i, k);
+            CX(DC, i, k) = cff * (CX(DC, i, k) - CX(FC, i, k - 1) * CX(DC, i, k - 1));
+          }
+        for (int i = Istr; i <= Iend; i++) {
+          CX(DC, i, N) = (CX(DC, i, N) - CX(FC, i, N - 1) * CX(DC, i, N - 1)) /
+                         (CX(BC, i, N) - CX(FC, i, N - 1) * CX(CF, i, N - 1));
+          t[XT(i, j, N, nnew, itrc)] = CX(DC, i, N);
+        }
+        for (int k = N - 1; k >= 1; k--)
+          for (int i = Istr; i <= Iend; i++) {
+            CX(DC, i, k) = CX(DC, i, k) - CX(CF, i, k) * CX(DC, i, k + 1);
+            t[XT(i, j, k, nnew, itrc)] = CX(DC, i, k);
+          }
+        cff = -dt * c->lambda; /* restore (cff reused above) */
+      }
+    }
+
+  /* lateral BCs and exchange :1858-1920 */
+  for (int itrc = 1; itrc <= c->NT; itrc++) {
+    orc_t3dbc(o, b, nnew, itrc);
+    orc_exchange3d(o, b, 'r', t + XT(LBi, LBj, 1, nnew, itrc), N);
+  }
+  free(CF);
+  free(FE);
+  free(oHz);
+  free(g1);
+  free(Ta);
+  free(Ua);
+  free(Va);
+  free(Wa);
+#undef TA
+}
