@@ -1,0 +1,157 @@
+/*
+ * roms_hip.h -- C ABI of libroms_hip.so: the MI355X (gfx950) implementation of the
+ * ROMS nonlinear 3-D time step (main3d -> step2d / rhs3d / step3d_uv / step3d_t ...).
+ *
+ * This is the drop-in boundary.  The reference has no FFI: the replaceable seam is
+ * the set of module procedures that main3d USEs (ROMS/Nonlinear/main3d.F:108-157),
+ * each of the form  kernel(ng, tile)  that reads loop bounds from BOUNDS(ng), time
+ * indices from mod_stepping and the state from the mod_grid/mod_ocean/mod_coupling/
+ * mod_forces/mod_mixing arrays.  Every entry point below names the reference
+ * procedure it replaces.  A Fortran caller binds them with ISO_C_BINDING
+ * (roms_amd/host/roms_hip_mod.f90; INTEGRATION.md shows the stub to add to the
+ * reference's main3d.F).
+ *
+ * Conventions
+ *   - plain C types only; all arrays are double precision (real(r8));
+ *   - arrays cross the boundary in the reference's own layout: column-major,
+ *     i fastest, bounds LBi:UBi x LBj:UBj, rho-levels 1:N, w-levels 0:N,
+ *     time levels as in mod_ocean.F:386-454 (t(i,j,k,3,NT), u(i,j,k,2), zeta(i,j,3),
+ *     ru(i,j,0:N,2) ...).  Sizes are implied by the dimensions given at create;
+ *   - every function returns 0 on success; a non-zero value maps onto the
+ *     reference's exit_flag (mod_scalars.F:548-560): 1 blow-up, 2 device/comm
+ *     error, 5 bad configuration, 8 algorithm/usage error;
+ *   - a context is bound to one HIP device and one stream; not re-entrant.
+ */
+#ifndef ROMS_HIP_H
+#define ROMS_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ROMS_HIP_ABI_VERSION 1
+#define ROMS_MAXT 4              /* max tracers handled (NT) */
+#define ROMS_MAXW 512            /* max 2*ndtfast */
+
+/* tracer advection schemes: Hadvection/Vadvection(itrc,ng)%..., mod_param.F:324-335 */
+enum { ROMS_A4 = 1, ROMS_C2 = 2, ROMS_C4 = 3, ROMS_HSIMT = 4, ROMS_MPDATA = 5,
+       ROMS_SPLINES = 6, ROMS_SPLIT_U3 = 7, ROMS_U3 = 8 };
+
+/* cpp options of the application header (ROMS/Include/cppdefs.h names) */
+enum {
+  ROMS_UV_ADV = 1 << 0, ROMS_UV_COR = 1 << 1, ROMS_UV_VIS2 = 1 << 2, ROMS_TS_DIF2 = 1 << 3,
+  ROMS_MIX_GEO_TS = 1 << 4, ROMS_CURVGRID = 1 << 5, ROMS_NONLIN_EOS = 1 << 6,
+  ROMS_UV_QDRAG = 1 << 7, ROMS_LMD_MIXING = 1 << 8, ROMS_BULK_FLUXES = 1 << 9,
+  ROMS_SOLAR_SOURCE = 1 << 10, ROMS_ANA_VMIX = 1 << 11, ROMS_SALINITY = 1 << 12,
+  ROMS_SPHERICAL = 1 << 13,
+  ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21
+};
+
+/* Everything the kernels read from mod_param / mod_scalars / BOUNDS(ng) / DOMAIN(ng)
+   for ONE tile (= one GPU).  Filled by the host (inp_par + get_bounds restatement). */
+typedef struct roms_hip_config {
+  int abi_version;               /* ROMS_HIP_ABI_VERSION */
+  int device;                    /* HIP device ordinal */
+  /* mod_param.F */
+  int Lm, Mm, N, NT, NAT, Nghost;
+  int LBi, UBi, LBj, UBj;        /* BOUNDS(ng)%LBi(tile) ... allocation bounds of this tile */
+  int NtileI, NtileJ, tile;      /* tile = MyRank */
+  int EWperiodic, NSperiodic;
+  int options;                   /* ROMS_* option bits */
+  int hadv[ROMS_MAXT], vadv[ROMS_MAXT];
+  /* BOUNDS(ng)%xxx(tile): Istr Iend Jstr Jend; the derived ranges (IstrU, Istrm1 ...)
+     are recomputed on the device by the rules of get_bounds.F:1044-1884 */
+  int Istr, Iend, Jstr, Jend;
+  /* DOMAIN(ng)%Western_Edge(tile) ... */
+  int west_edge, east_edge, south_edge, north_edge;
+  /* mod_scalars.F */
+  int ntfirst, ntstart, ndtfast, nfast;
+  int ninfo;                     /* diag every ninfo steps (NINFO); 0 = only on request */
+  double dt, dtfast;
+  double weight[2][ROMS_MAXW + 1];   /* weight(1:2,1:2*ndtfast,ng), index 0 unused */
+  double rho0, g, lambda, gamma2, Cp;
+  double R0, T0, S0, Tcoef, Scoef;
+  double hc; int Vtransform;
+  double rdrg, rdrg2, Zob;
+  double Akt_bak[ROMS_MAXT], Akv_bak;
+  double dstart;
+  double blk_ZQ, blk_ZT, blk_ZW;
+  int lmd_Jwt;
+  double sc_r[256], Cs_r[256], sc_w[257], Cs_w[257];   /* SCALARS(ng)%sc_r(1:N) -> [k-1]; sc_w(0:N) -> [k] */
+} roms_hip_config;
+
+/* time indices of mod_stepping.F / mod_scalars.F that the kernel wrappers read */
+typedef struct roms_hip_stepping {
+  int iic, iif;
+  int nstp, nnew, nrhs;
+  int kstp, knew, krhs, indx1;
+  int predictor;                 /* PREDICTOR_2D_STEP(ng) */
+  double time;                   /* time(ng), seconds */
+} roms_hip_stepping;
+
+typedef struct roms_hip_ctx roms_hip_ctx;
+
+/* life cycle (ROMS_allocate_arrays / ROMS_deallocate_arrays, mod_arrays.F) */
+int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **ctx);
+int roms_hip_destroy(roms_hip_ctx *ctx);
+const char *roms_hip_last_error(void);
+int roms_hip_abi_version(void);
+
+/* state transfer, whole arrays in the reference layout.  name = the reference's
+   component name ("zeta","u","t","Hz","pm","Akv","DU_avg1",...).  n = element count
+   (checked).  roms_hip_field_size returns the count, or -1 for an unknown name. */
+long roms_hip_field_size(roms_hip_ctx *ctx, const char *name);
+int roms_hip_upload(roms_hip_ctx *ctx, const char *name, const double *host, long n);
+int roms_hip_download(roms_hip_ctx *ctx, const char *name, double *host, long n);
+int roms_hip_sync(roms_hip_ctx *ctx);
+
+/* time indices for the per-kernel entry points below */
+int roms_hip_set_stepping(roms_hip_ctx *ctx, const roms_hip_stepping *s);
+int roms_hip_get_stepping(roms_hip_ctx *ctx, roms_hip_stepping *s);
+
+/* ---- one entry per reference procedure  kernel(ng,tile)  (asynchronous on the
+        context's stream; state stays on the device) ---- */
+int roms_hip_set_depth(roms_hip_ctx *ctx);     /* set_depth      set_depth.F:28      */
+int roms_hip_set_massflux(roms_hip_ctx *ctx);  /* set_massflux   set_massflux.F:26   */
+int roms_hip_rho_eos(roms_hip_ctx *ctx);       /* rho_eos        rho_eos.F:53        */
+int roms_hip_set_vbc(roms_hip_ctx *ctx);       /* set_vbc        set_vbc.F:46        */
+int roms_hip_ana_vmix(roms_hip_ctx *ctx);      /* ana_vmix       ana_vmix.h          */
+int roms_hip_set_data(roms_hip_ctx *ctx);      /* set_data       set_data.F:19 (analytic forcing) */
+int roms_hip_omega(roms_hip_ctx *ctx);         /* omega          omega.F:35          */
+int roms_hip_wvelocity(roms_hip_ctx *ctx, int ninp); /* wvelocity wvelocity.F:27     */
+int roms_hip_set_zeta(roms_hip_ctx *ctx);      /* set_zeta       set_zeta.F:23       */
+int roms_hip_ini_zeta(roms_hip_ctx *ctx);      /* ini_zeta       ini_fields.F:700    */
+int roms_hip_ini_fields(roms_hip_ctx *ctx);    /* ini_fields     ini_fields.F:47     */
+int roms_hip_pre_step3d(roms_hip_ctx *ctx);    /* pre_step3d     pre_step3d.F:48     */
+int roms_hip_prsgrd(roms_hip_ctx *ctx);        /* prsgrd         prsgrd32.h:33       */
+int roms_hip_t3dmix2(roms_hip_ctx *ctx);       /* t3dmix2        t3dmix2_s.h / t3dmix2_geo.h */
+int roms_hip_uv3dmix2(roms_hip_ctx *ctx);      /* uv3dmix2       uv3dmix2_s.h:40     */
+int roms_hip_rhs3d_tile(roms_hip_ctx *ctx);    /* rhs3d_tile     rhs3d.F:196         */
+int roms_hip_rhs3d(roms_hip_ctx *ctx);         /* rhs3d          rhs3d.F:25 (the five above in order) */
+int roms_hip_step2d(roms_hip_ctx *ctx);        /* step2d         step2d_LF_AM3.h:18  */
+int roms_hip_step3d_uv(roms_hip_ctx *ctx);     /* step3d_uv      step3d_uv.F:40      */
+int roms_hip_step3d_t(roms_hip_ctx *ctx);      /* step3d_t       step3d_t.F:40       */
+int roms_hip_lmd_vmix(roms_hip_ctx *ctx);      /* lmd_vmix       lmd_vmix.F:45       */
+int roms_hip_bulk_flux(roms_hip_ctx *ctx);     /* bulk_flux      bulk_flux.F:100     */
+/* diag diag.F:30 -- synchronises; out[0..11] = avgke avgpe avgkp volume maxspeed
+   max_Cu max_Cv max_Cw max_Ci max_Cj max_Ck max_C */
+int roms_hip_diag(roms_hip_ctx *ctx, double *out);
+
+/* initial.F:549-577 tail (set_massflux, omega, rho_eos at iic = ntstart) */
+int roms_hip_start(roms_hip_ctx *ctx);
+/* nsteps passes of main3d's STEP_LOOP (main3d.F:216-1148) with the state resident on
+   the device; the stepping indices advance exactly as in the reference. */
+int roms_hip_main3d(roms_hip_ctx *ctx, int nsteps);
+
+/* per-region device timing (the reference's wclock regions, mod_strings.F:39-135):
+   seconds accumulated since create / the last reset, measured with HIP events when
+   enabled with roms_hip_profile(ctx,1).  region ids as in the reference (9 = 2D kernel,
+   21 = rhs3d, 22 = pre_step3d, 23 = prsgrd, 34 = step3d_uv, 35 = step3d_t ...). */
+int roms_hip_profile(roms_hip_ctx *ctx, int enable);
+int roms_hip_region_seconds(roms_hip_ctx *ctx, int region, double *seconds, long *calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,136 @@
+// g_diag3d.cpp -- launch sequences of the diagnostic 3-D kernels (k_diag3d.h): the bodies of the
+// reference wrappers set_depth, set_massflux, rho_eos, set_vbc, ana_vmix, set_data, omega,
+// wvelocity, set_zeta, ini_zeta, ini_fields, each followed by the same boundary fills / periodic
+// exchanges the reference issues at the tail of the _tile routine.
+#include "roms_host.h"
+#include "k_diag3d.h"
+
+static inline KArgs mk(roms_hip_ctx *c, int p0 = 0, int p1 = 0, int p2 = 0) {
+  KArgs a;
+  a.G = c->G;
+  a.F = c->F;
+  a.p0 = p0; a.p1 = p1; a.p2 = p2;
+  return a;
+}
+
+int run_eos_nonlinear(roms_hip_ctx *c);   // g_eos.cpp
+int run_set_data_benchmark(roms_hip_ctx *c);
+
+int run_set_depth(roms_hip_ctx *c) {
+  const TB &B = c->G.T;
+  const int N = c->G.N;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_set_depth, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, N, c->stream, a);
+  launch_halo(c, c->F.h, 1, BC_NONE, 'r');
+  launch_halo(c, c->F.z_w, N + 1, BC_NONE, 'r');
+  launch_halo(c, c->F.z_r, N, BC_NONE, 'r');
+  launch_halo(c, c->F.Hz, N, BC_NONE, 'r');
+  return 0;
+}
+
+int run_set_massflux(roms_hip_ctx *c) {
+  const TB &B = c->G.T;
+  const int N = c->G.N;
+  KArgs a = mk(c);
+  const int i0 = KMIN(B.IstrP, B.IstrT), j0 = KMIN(B.JstrT, B.JstrP);
+  LAUNCH_THREAD(k_set_massflux, B.IendT - i0 + 1, B.JendT - j0 + 1, N, c->stream, a);
+  launch_halo(c, c->F.Huon, N, BC_NONE, 'u');
+  launch_halo(c, c->F.Hvom, N, BC_NONE, 'v');
+  return 0;
+}
+
+int run_rho_eos(roms_hip_ctx *c) {
+  if (c->G.options & ROMS_NONLIN_EOS) return run_eos_nonlinear(c);
+  const TB &B = c->G.T;
+  const int N = c->G.N;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_rho_eos_lin, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
+  launch_halo(c, c->F.rho, N, BC_NONE, 'r');
+  launch_halo(c, c->F.pden, N, BC_NONE, 'r');
+  launch_halo(c, c->F.rhoA, 1, BC_NONE, 'r');
+  launch_halo(c, c->F.rhoS, 1, BC_NONE, 'r');
+  return 0;
+}
+
+int run_set_vbc(roms_hip_ctx *c) {
+  const TB &B = c->G.T;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_set_vbc, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, 1, c->stream, a);
+  launch_halo(c, c->F.bustr, 1, BC_U, 'u');   // bc_u2d_tile
+  launch_halo(c, c->F.bvstr, 1, BC_V, 'v');   // bc_v2d_tile
+  return 0;
+}
+
+int run_ana_vmix(roms_hip_ctx *c) {
+  const TB &B = c->G.T;
+  const int N = c->G.N;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_ana_vmix, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, N - 1, c->stream, a);
+  launch_halo(c, c->F.Akv, N + 1, BC_NONE, 'r');
+  launch_halo(c, c->F.Akt, (N + 1) * c->G.NAT, BC_NONE, 'r');
+  return 0;
+}
+
+int run_set_data(roms_hip_ctx *c) {
+  if (c->G.options & ROMS_APP_BENCHMARK) return run_set_data_benchmark(c);
+  const TB &B = c->G.T;
+  KArgs a = mk(c);
+  const int i0 = KMIN(B.IstrP, B.IstrT), j0 = KMIN(B.JstrP, B.JstrT);
+  LAUNCH_THREAD(k_set_data_upw, B.IendT - i0 + 1, B.JendT - j0 + 1, 1, c->stream, a);
+  launch_halo(c, c->F.stflux, 2, BC_NONE, 'r');
+  launch_halo(c, c->F.sustr, 1, BC_NONE, 'u');
+  launch_halo(c, c->F.svstr, 1, BC_NONE, 'v');
+  return 0;
+}
+
+int run_omega(roms_hip_ctx *c) {
+  const TB &B = c->G.T;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_omega, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  launch_halo(c, c->F.W, c->G.N + 1, BC_R, 'r');   // bc_w3d_tile
+  return 0;
+}
+
+int run_wvelocity(roms_hip_ctx *c, int ninp) {
+  const TB &B = c->G.T;
+  const int N = c->G.N;
+  launch_halo(c, c->F.DU_avg1, 1, BC_NONE, 'u');
+  launch_halo(c, c->F.DV_avg1, 1, BC_NONE, 'v');
+  KArgs a = mk(c, ninp);
+  LAUNCH_THREAD(k_wvel_vert, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N, c->stream, a);
+  LAUNCH_THREAD(k_wvel, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N + 1, c->stream, a);
+  launch_halo(c, c->F.wvel, N + 1, BC_R, 'r');     // bc_w3d_tile
+  return 0;
+}
+
+int run_set_zeta(roms_hip_ctx *c) {
+  const TB &B = c->G.T;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_set_zeta, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, 1, c->stream, a);
+  launch_halo(c, c->F.zeta, 2, BC_NONE, 'r');
+  return 0;
+}
+
+int run_ini_zeta(roms_hip_ctx *c) {
+  const TB &B = c->G.T;
+  const int kstp = c->G.kstp;
+  launch_halo(c, lev2d(c, c->F.zeta, kstp), 1, BC_R, 'r');   // zetabc_tile + exchange
+  KArgs a = mk(c, kstp);
+  LAUNCH_THREAD(k_copy_zt, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
+  launch_halo(c, c->F.Zt_avg1, 1, BC_NONE, 'r');
+  return 0;
+}
+
+int run_ini_fields(roms_hip_ctx *c) {
+  const TB &B = c->G.T;
+  const int N = c->G.N, nstp = c->G.nstp, kstp = c->G.kstp;
+  launch_halo(c, uv_lev(c, c->F.u, nstp), N, BC_U, 'u');     // u3dbc_tile + exchange_u3d
+  launch_halo(c, uv_lev(c, c->F.v, nstp), N, BC_V, 'v');
+  KArgs a = mk(c);
+  const int i0 = KMIN(B.IstrM, B.IstrB);
+  LAUNCH_THREAD(k_ini_bar, B.IendB - i0 + 1, B.JendB - B.JstrB + 1, 1, c->stream, a);
+  launch_halo(c, lev2d(c, c->F.ubar, kstp), 1, BC_U, 'u');   // u2dbc_tile + exchange
+  launch_halo(c, lev2d(c, c->F.vbar, kstp), 1, BC_V, 'v');
+  for (int it = 1; it <= c->G.NT; it++) launch_halo(c, t_lev(c, nstp, it), N, BC_R, 'r');   // t3dbc + exchange
+  return 0;
+}

@@ -1,0 +1,31 @@
+// g_step2d.cpp -- step2d(ng,tile): one k_step2d launch + one halo launch.
+#include "roms_host.h"
+#include "k_step2d.h"
+
+int run_step2d(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const roms_hip_config &cf = c->cfg;
+  Step2dArgs a;
+  a.G = G;
+  a.F = c->F;
+  const int iif = G.iif;
+  a.w1_m1 = (iif >= 2) ? cf.weight[0][iif - 1] : 0.0;
+  a.w2_0 = cf.weight[1][iif];
+  a.w2_p1 = (iif + 1 <= ROMS_MAXW) ? cf.weight[1][iif + 1] : 0.0;
+  const size_t lds = (size_t)STEP2D_NLDS * (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
+  LAUNCH_COOP(k_step2d, G.nbx, G.nby, 1, 256, lds, c->stream, a);
+  if (iif == G.nfast + 1 && G.predictor) {
+    // final fast-time averages :821-883
+    HaloSpec sp[3] = {{c->F.Zt_avg1, 1, BC_NONE, 'r'}, {c->F.DU_avg1, 1, BC_NONE, 'u'}, {c->F.DV_avg1, 1, BC_NONE, 'v'}};
+    launch_halo_multi(c, sp, 3);
+  }
+  if (iif > G.nfast) return 0;
+  HaloSpec sp[4];
+  int n = 0;
+  sp[n++] = {lev2d(c, c->F.zeta, G.knew), 1, BC_R, 'r'};                        // zetabc :1057 + exchange :1068
+  if (G.predictor) sp[n++] = {lev2d(c, c->F.rzeta, G.krhs), 1, BC_NONE, 'r'};   // :1030
+  sp[n++] = {lev2d(c, c->F.ubar, G.knew), 1, BC_U, 'u'};                        // u2dbc :2871 + exchange :3043
+  sp[n++] = {lev2d(c, c->F.vbar, G.knew), 1, BC_V, 'v'};                        // v2dbc :2876
+  launch_halo_multi(c, sp, n);
+  return 0;
+}

@@ -1,0 +1,340 @@
+// k_diag3d.h -- depths, mass fluxes, equation of state, surface/bottom BCs, omega,
+// true vertical velocity, zeta reset, start-up fields.
+//
+//   k_set_depth     set_depth_tile     ROMS/Nonlinear/set_depth.F:76-278
+//   k_set_massflux  set_massflux_tile  ROMS/Nonlinear/set_massflux.F:73-188
+//   k_rho_eos_lin   rho_eos_tile       ROMS/Nonlinear/rho_eos.F:688-880 (linear EOS)
+//   k_set_vbc       set_vbc_tile       ROMS/Nonlinear/set_vbc.F:110
+//   k_ana_vmix      ana_vmix_tile      ROMS/Functionals/ana_vmix.h (UPWELLING)
+//   k_set_data_upw  set_data_tile      ROMS/Nonlinear/set_data.F -> ana_smflux.h:306-318, ...
+//   k_omega         omega_tile         ROMS/Nonlinear/omega.F:96-377
+//   k_wvel_vert / k_wvel  wvelocity_tile  ROMS/Nonlinear/wvelocity.F:64-289
+//   k_set_zeta      set_zeta_tile      ROMS/Nonlinear/set_zeta.F:59-118
+//   k_copy_zt       set_zeta_timeavg_tile ROMS/Nonlinear/ini_fields.F:1017
+//   k_ini_bar       ini_fields_tile    ROMS/Nonlinear/ini_fields.F:136 (vertical means)
+//
+// All are HBM-bound: one thread per point (3-D point-wise) or per sigma-column (vertical
+// recurrences), lanes along xi so every level of a column is one coalesced wave access.
+#pragma once
+#include "roms_ctx.h"
+
+struct KArgs {
+  DGrid G;
+  Fields F;
+  int p0, p1, p2;
+};
+
+#define XT(i, j, k, n, it) (X3(i, j, k) + ((size_t)((n) - 1) + 3 * (size_t)((it) - 1)) * (size_t)G.nij * (size_t)G.N)
+#define X4(i, j, k, n) (X3(i, j, k) + (size_t)((n) - 1) * (size_t)G.nij * (size_t)G.N)
+#define XW4(i, j, k, n) (XW(i, j, k) + (size_t)((n) - 1) * (size_t)G.nij * (size_t)(G.N + 1))
+#define X2T(i, j, n) (X2(i, j) + (size_t)((n) - 1) * (size_t)G.nij)
+
+// ------------------------------------------------------------------------------ set_depth
+// index space: (IstrT:IendT, JstrT:JendT, 1:N)
+THREAD_KERNEL(k_set_depth, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, k = gz + 1;
+  const double hc = G.hc;
+  const double hwater = F.h[X2(i, j)];
+  const double zt = F.Zt_avg1[X2(i, j)];
+  double zw_k, zw_km1, zr_k;
+  if (G.Vtransform == 1) {
+    const double hinv = 1.0 / hwater;
+    {
+      const double cff_w = hc * (F.sc_w[k] - F.Cs_w[k]);
+      const double z_w0 = cff_w + F.Cs_w[k] * hwater;
+      zw_k = z_w0 + zt * (1.0 + z_w0 * hinv);
+    }
+    if (k == 1) zw_km1 = -hwater;
+    else {
+      const double cff_w = hc * (F.sc_w[k - 1] - F.Cs_w[k - 1]);
+      const double z_w0 = cff_w + F.Cs_w[k - 1] * hwater;
+      zw_km1 = z_w0 + zt * (1.0 + z_w0 * hinv);
+    }
+    const double cff_r = hc * (F.sc_r[k - 1] - F.Cs_r[k - 1]);
+    const double z_r0 = cff_r + F.Cs_r[k - 1] * hwater;
+    zr_k = z_r0 + zt * (1.0 + z_r0 * hinv);
+  } else {
+    const double hinv = 1.0 / (hc + hwater);
+    {
+      const double cff_w = hc * F.sc_w[k];
+      const double cff2_w = (cff_w + F.Cs_w[k] * hwater) * hinv;
+      zw_k = zt + (zt + hwater) * cff2_w;
+    }
+    if (k == 1) zw_km1 = -hwater;
+    else {
+      const double cff_w = hc * F.sc_w[k - 1];
+      const double cff2_w = (cff_w + F.Cs_w[k - 1] * hwater) * hinv;
+      zw_km1 = zt + (zt + hwater) * cff2_w;
+    }
+    const double cff_r = hc * F.sc_r[k - 1];
+    const double cff2_r = (cff_r + F.Cs_r[k - 1] * hwater) * hinv;
+    zr_k = zt + (zt + hwater) * cff2_r;
+  }
+  if (k == 1) F.z_w[XW(i, j, 0)] = zw_km1;
+  F.z_w[XW(i, j, k)] = zw_k;
+  F.z_r[X3(i, j, k)] = zr_k;
+  F.Hz[X3(i, j, k)] = zw_k - zw_km1;
+}
+THREAD_GLOBAL(k_set_depth, KArgs)
+
+// --------------------------------------------------------------------------- set_massflux
+// index space: (IstrP:IendT union IstrT:IendT, JstrT:JendT union JstrP:JendT, 1:N) -> start at
+// min(IstrP,IstrT), min(JstrT,JstrP)
+THREAD_KERNEL(k_set_massflux, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = KMIN(B.IstrP, B.IstrT) + gx, j = KMIN(B.JstrT, B.JstrP) + gy, k = gz + 1;
+  const int nrhs = G.nrhs;
+  if (i >= B.IstrP && i <= B.IendT && j >= B.JstrT && j <= B.JendT)
+    F.Huon[X3(i, j, k)] =
+        0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i - 1, j, k)]) * F.u[X4(i, j, k, nrhs)] * F.on_u[X2(i, j)];
+  if (i >= B.IstrT && i <= B.IendT && j >= B.JstrP && j <= B.JendT)
+    F.Hvom[X3(i, j, k)] =
+        0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i, j - 1, k)]) * F.v[X4(i, j, k, nrhs)] * F.om_v[X2(i, j)];
+}
+THREAD_GLOBAL(k_set_massflux, KArgs)
+
+// ------------------------------------------------------------------------ rho_eos (linear)
+// one thread per column (IstrT:IendT, JstrT:JendT)
+THREAD_KERNEL(k_rho_eos_lin, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, N = G.N, nrhs = G.nrhs;
+  const bool salt = (G.options & ROMS_SALINITY) != 0;
+  double rhoA = 0.0, rhoS = 0.0;
+  for (int k = N; k >= 1; k--) {
+    double r = G.R0 - G.R0 * G.Tcoef * (F.t[XT(i, j, k, nrhs, 1)] - G.T0);
+    if (salt) r = r + G.R0 * G.Scoef * (F.t[XT(i, j, k, nrhs, 2)] - G.S0);
+    r = r - 1000.0;
+    F.rho[X3(i, j, k)] = r;
+    F.pden[X3(i, j, k)] = r;
+    const double Hzk = F.Hz[X3(i, j, k)];
+    const double cff1 = r * Hzk;
+    if (k == N) {
+      rhoS = 0.5 * cff1 * Hzk;
+      rhoA = cff1;
+    } else {
+      rhoS = rhoS + Hzk * (rhoA + 0.5 * cff1);
+      rhoA = rhoA + cff1;
+    }
+  }
+  const double cff2 = 1.0 / G.rho0;
+  const double cff1 = 1.0 / (F.z_w[XW(i, j, N)] - F.z_w[XW(i, j, 0)]);
+  F.rhoA[X2(i, j)] = cff2 * cff1 * rhoA;
+  F.rhoS[X2(i, j)] = 2.0 * cff1 * cff1 * cff2 * rhoS;
+}
+THREAD_GLOBAL(k_rho_eos_lin, KArgs)
+
+// -------------------------------------------------------------------------------- set_vbc
+// index space (IstrR:IendR, JstrR:JendR)
+THREAD_KERNEL(k_set_vbc, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = B.IstrR + gx, j = B.JstrR + gy, N = G.N, nrhs = G.nrhs;
+  F.stflx[X2T(i, j, 1)] = F.stflux[X2T(i, j, 1)];
+  F.btflx[X2T(i, j, 1)] = F.btflux[X2T(i, j, 1)];
+  const double EmP = F.stflux[X2T(i, j, 2)];
+  F.stflx[X2T(i, j, 2)] = EmP * F.t[XT(i, j, N, nrhs, 2)];
+  F.btflx[X2T(i, j, 2)] = F.btflx[X2T(i, j, 2)] * F.t[XT(i, j, 1, nrhs, 2)];
+  const bool qdrag = (G.options & ROMS_UV_QDRAG) != 0;
+  if (i >= B.IstrU && i <= B.Iend && j >= B.Jstr && j <= B.Jend) {
+    if (qdrag) {
+      const double cff1 = 0.25 * (F.v[X4(i, j, 1, nrhs)] + F.v[X4(i, j + 1, 1, nrhs)] + F.v[X4(i - 1, j, 1, nrhs)] +
+                                  F.v[X4(i - 1, j + 1, 1, nrhs)]);
+      const double uu = F.u[X4(i, j, 1, nrhs)];
+      const double cff2 = sqrt(uu * uu + cff1 * cff1);
+      F.bustr[X2(i, j)] = 0.5 * (F.rdrag2[X2(i - 1, j)] + F.rdrag2[X2(i, j)]) * uu * cff2;
+    } else {
+      F.bustr[X2(i, j)] = 0.5 * (F.rdrag[X2(i - 1, j)] + F.rdrag[X2(i, j)]) * F.u[X4(i, j, 1, nrhs)];
+    }
+  }
+  if (i >= B.Istr && i <= B.Iend && j >= B.JstrV && j <= B.Jend) {
+    if (qdrag) {
+      const double cff1 = 0.25 * (F.u[X4(i, j, 1, nrhs)] + F.u[X4(i + 1, j, 1, nrhs)] + F.u[X4(i, j - 1, 1, nrhs)] +
+                                  F.u[X4(i + 1, j - 1, 1, nrhs)]);
+      const double vv = F.v[X4(i, j, 1, nrhs)];
+      const double cff2 = sqrt(cff1 * cff1 + vv * vv);
+      F.bvstr[X2(i, j)] = 0.5 * (F.rdrag2[X2(i, j - 1)] + F.rdrag2[X2(i, j)]) * vv * cff2;
+    } else {
+      F.bvstr[X2(i, j)] = 0.5 * (F.rdrag[X2(i, j - 1)] + F.rdrag[X2(i, j)]) * F.v[X4(i, j, 1, nrhs)];
+    }
+  }
+}
+THREAD_GLOBAL(k_set_vbc, KArgs)
+
+// ------------------------------------------------------------------------------- ana_vmix
+// index space (IstrT:IendT, JstrT:JendT, 1:N-1)
+THREAD_KERNEL(k_ana_vmix, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, k = gz + 1;
+  F.Akv[XW(i, j, k)] = 2.0E-03 + 8.0E-03 * exp(F.z_w[XW(i, j, k)] / 150.0);
+  F.Akt[XW4(i, j, k, 1)] = G.Akt_bak[0];
+  F.Akt[XW4(i, j, k, 2)] = G.Akt_bak[1];
+}
+THREAD_GLOBAL(k_ana_vmix, KArgs)
+
+// ------------------------------------------------------------- set_data (UPWELLING forcing)
+// index space (min(IstrP,IstrT):IendT, min(JstrP,JstrT):JendT)
+THREAD_KERNEL(k_set_data_upw, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = KMIN(B.IstrP, B.IstrT) + gx, j = KMIN(B.JstrP, B.JstrT) + gy;
+  const double pi = 3.14159265358979323846;
+  if (i >= B.IstrT && i <= B.IendT && j >= B.JstrT && j <= B.JendT) {
+    F.stflux[X2T(i, j, 1)] = 0.0;
+    F.stflux[X2T(i, j, 2)] = 0.0;
+    F.btflux[X2T(i, j, 1)] = 0.0;
+    F.btflux[X2T(i, j, 2)] = 0.0;
+  }
+  double windamp;
+  if ((G.tdays - G.dstart) <= 2.0) windamp = -0.1 * sin(pi * (G.tdays - G.dstart) / 4.0) / G.rho0;
+  else windamp = -0.1 / G.rho0;
+  const bool urange = i >= B.IstrP && i <= B.IendT && j >= B.JstrT && j <= B.JendT;
+  const bool vrange = i >= B.IstrT && i <= B.IendT && j >= B.JstrP && j <= B.JendT;
+  if (G.nsp) {
+    if (urange) F.sustr[X2(i, j)] = 0.0;
+    if (vrange) F.svstr[X2(i, j)] = windamp;
+  } else if (G.ewp) {
+    if (urange) F.sustr[X2(i, j)] = windamp;
+    if (vrange) F.svstr[X2(i, j)] = 0.0;
+  }
+}
+THREAD_GLOBAL(k_set_data_upw, KArgs)
+
+// ---------------------------------------------------------------------------------- omega
+// one thread per column (Istr:Iend, Jstr:Jend)
+THREAD_KERNEL(k_omega, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  double Wk = 0.0;
+  F.W[XW(i, j, 0)] = 0.0;
+  for (int k = 1; k <= N; k++) {
+    Wk = Wk - (F.Huon[X3(i + 1, j, k)] - F.Huon[X3(i, j, k)] + F.Hvom[X3(i, j + 1, k)] - F.Hvom[X3(i, j, k)]);
+    F.W[XW(i, j, k)] = Wk;
+  }
+  const double zw0 = F.z_w[XW(i, j, 0)];
+  const double wrk = Wk / (F.z_w[XW(i, j, N)] - zw0);
+  for (int k = N - 1; k >= 1; k--) F.W[XW(i, j, k)] = F.W[XW(i, j, k)] - wrk * (F.z_w[XW(i, j, k)] - zw0);
+  F.W[XW(i, j, N)] = 0.0;
+}
+THREAD_GLOBAL(k_omega, KArgs)
+
+// ------------------------------------------------------------------------------ wvelocity
+// vert(i,j,k) into F.wrk3[0]; index space (Istr:Iend, Jstr:Jend, 1:N); p0 = Ninp
+THREAD_KERNEL(k_wvel_vert, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz + 1, Ninp = a.p0;
+  const double wi = F.u[X4(i, j, k, Ninp)] * (F.z_r[X3(i, j, k)] - F.z_r[X3(i - 1, j, k)]) *
+                    (F.pm[X2(i - 1, j)] + F.pm[X2(i, j)]);
+  const double wip = F.u[X4(i + 1, j, k, Ninp)] * (F.z_r[X3(i + 1, j, k)] - F.z_r[X3(i, j, k)]) *
+                     (F.pm[X2(i, j)] + F.pm[X2(i + 1, j)]);
+  double vert = 0.25 * (wi + wip);
+  const double wj = F.v[X4(i, j, k, Ninp)] * (F.z_r[X3(i, j, k)] - F.z_r[X3(i, j - 1, k)]) *
+                    (F.pn[X2(i, j - 1)] + F.pn[X2(i, j)]);
+  const double wjp = F.v[X4(i, j + 1, k, Ninp)] * (F.z_r[X3(i, j + 1, k)] - F.z_r[X3(i, j, k)]) *
+                     (F.pn[X2(i, j)] + F.pn[X2(i, j + 1)]);
+  vert = vert + 0.25 * (wj + wjp);
+  F.wrk3[0][X3(i, j, k)] = vert;
+}
+THREAD_GLOBAL(k_wvel_vert, KArgs)
+
+// wvel(i,j,k), k = 0..N; index space (Istr:Iend, Jstr:Jend, 0:N)
+THREAD_KERNEL(k_wvel, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz, N = G.N;
+  const double *vert = F.wrk3[0];
+  const double cff1 = 3.0 / 8.0, cff2 = 3.0 / 4.0, cff3 = 1.0 / 8.0, cff4 = 9.0 / 16.0, cff5 = 1.0 / 16.0;
+  const double zw0 = F.z_w[XW(i, j, 0)];
+  const double wrk = (F.DU_avg1[X2(i, j)] - F.DU_avg1[X2(i + 1, j)] + F.DV_avg1[X2(i, j)] - F.DV_avg1[X2(i, j + 1)]) /
+                     (F.z_w[XW(i, j, N)] - zw0);
+  const double pmn = F.pm[X2(i, j)] * F.pn[X2(i, j)];
+  double w;
+  if (k == 0) {
+    const double slope = (F.z_r[X3(i, j, 1)] - zw0) / (F.z_r[X3(i, j, 2)] - F.z_r[X3(i, j, 1)]);
+    w = cff1 * (vert[X3(i, j, 1)] - slope * (vert[X3(i, j, 2)] - vert[X3(i, j, 1)])) + cff2 * vert[X3(i, j, 1)] -
+        cff3 * vert[X3(i, j, 2)];
+  } else if (k == 1) {
+    w = pmn * (F.W[XW(i, j, 1)] + wrk * (F.z_w[XW(i, j, 1)] - zw0)) + cff1 * vert[X3(i, j, 1)] +
+        cff2 * vert[X3(i, j, 2)] - cff3 * vert[X3(i, j, 3)];
+  } else if (k == N) {
+    const double slope = (F.z_w[XW(i, j, N)] - F.z_r[X3(i, j, N)]) / (F.z_r[X3(i, j, N)] - F.z_r[X3(i, j, N - 1)]);
+    w = pmn * wrk * (F.z_w[XW(i, j, N)] - zw0) +
+        cff1 * (vert[X3(i, j, N)] + slope * (vert[X3(i, j, N)] - vert[X3(i, j, N - 1)])) + cff2 * vert[X3(i, j, N)] -
+        cff3 * vert[X3(i, j, N - 1)];
+  } else if (k == N - 1) {
+    w = pmn * (F.W[XW(i, j, N - 1)] + wrk * (F.z_w[XW(i, j, N - 1)] - zw0)) + cff1 * vert[X3(i, j, N)] +
+        cff2 * vert[X3(i, j, N - 1)] - cff3 * vert[X3(i, j, N - 2)];
+  } else {
+    w = pmn * (F.W[XW(i, j, k)] + wrk * (F.z_w[XW(i, j, k)] - zw0)) +
+        cff4 * (vert[X3(i, j, k)] + vert[X3(i, j, k + 1)]) - cff5 * (vert[X3(i, j, k - 1)] + vert[X3(i, j, k + 2)]);
+  }
+  F.wvel[XW(i, j, k)] = w;
+}
+THREAD_GLOBAL(k_wvel, KArgs)
+
+// ------------------------------------------------------------------------------- set_zeta
+// index space (IstrR:IendR, JstrR:JendR)
+THREAD_KERNEL(k_set_zeta, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.IstrR + gx, j = G.T.JstrR + gy;
+  const double z = F.Zt_avg1[X2(i, j)];
+  F.zeta[X2T(i, j, 1)] = z;
+  F.zeta[X2T(i, j, 2)] = z;
+}
+THREAD_GLOBAL(k_set_zeta, KArgs)
+
+// Zt_avg1 = zeta(kstp) on (IstrT:IendT, JstrT:JendT); p0 = kstp
+THREAD_KERNEL(k_copy_zt, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.IstrT + gx, j = G.T.JstrT + gy;
+  F.Zt_avg1[X2(i, j)] = F.zeta[X2T(i, j, a.p0)];
+}
+THREAD_GLOBAL(k_copy_zt, KArgs)
+
+// ini_fields: ubar,vbar(kstp) = vertical mean of u,v(nstp); index space
+// (min(IstrM,IstrB):IendB, JstrB:JendB)
+THREAD_KERNEL(k_ini_bar, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = KMIN(B.IstrM, B.IstrB) + gx, j = B.JstrB + gy, N = G.N, nstp = G.nstp, kstp = G.kstp;
+  if (i >= B.IstrM && i <= B.IendB) {
+    double DC0 = 0.0, CF0 = 0.0;
+    for (int k = 1; k <= N; k++) {
+      const double DCk = 0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i - 1, j, k)]);
+      DC0 = DC0 + DCk;
+      CF0 = CF0 + DCk * F.u[X4(i, j, k, nstp)];
+    }
+    const double cff1 = 1.0 / DC0;
+    F.ubar[X2T(i, j, kstp)] = CF0 * cff1;
+  }
+  if (j >= B.JstrM && i >= B.IstrB && i <= B.IendB) {
+    double DC0 = 0.0, CF0 = 0.0;
+    for (int k = 1; k <= N; k++) {
+      const double DCk = 0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i, j - 1, k)]);
+      DC0 = DC0 + DCk;
+      CF0 = CF0 + DCk * F.v[X4(i, j, k, nstp)];
+    }
+    const double cff1 = 1.0 / DC0;
+    F.vbar[X2T(i, j, kstp)] = CF0 * cff1;
+  }
+}
+THREAD_GLOBAL(k_ini_bar, KArgs)

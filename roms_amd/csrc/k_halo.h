@@ -1,0 +1,137 @@
+// k_halo.h -- lateral boundary fills and periodic ghost copies on the GPU tile.
+//
+// Replaces, for closed/periodic edges (the LBC kinds of the BASELINE configs):
+//   exchange_{p,r,u,v}2d_tile  ROMS/Nonlinear/exchange_2d.F:63-807
+//   exchange_{r,u,v,w}3d_tile  ROMS/Nonlinear/exchange_3d.F:280-1126
+//   bc_{r,u,v}2d_tile          ROMS/Nonlinear/bc_2d.F:41-516     bc_w3d_tile bc_3d.F:588
+//   zetabc_tile zetabc.F:60 (closed :577-590), u2dbc_tile u2dbc_im.F:51, v2dbc_tile v2dbc_im.F:52,
+//   t3dbc_tile t3dbc_im.F:50, u3dbc_tile u3dbc_im.F:50, v3dbc_tile v3dbc_im.F:50
+//
+// One thread block per horizontal plane; three barrier-separated phases
+// (edge fills -> corner averages -> periodic copies), as the reference orders them.
+#pragma once
+#include "roms_ctx.h"
+
+
+struct HaloItem {
+  double *A;           // first plane
+  int nk;              // number of consecutive planes
+  int bc;              // BC_*
+  int gtype;           // 'r','u','v','p' (exchange transverse ranges), 0 = no exchange
+};
+#define HALO_MAXITEMS 8
+struct HaloArgs {
+  DGrid G;
+  int nitems;
+  HaloItem it[HALO_MAXITEMS];
+};
+
+COOP_KERNEL(halo_kernel, HaloArgs) {
+  (void)bx; (void)by; (void)lds;
+  const DGrid &G = a.G;
+  const TB &B = G.T;
+  int item = 0, plane = bz;
+  while (item < a.nitems - 1 && plane >= a.it[item].nk) { plane -= a.it[item].nk; item++; }
+  double *A = a.it[item].A + (size_t)plane * (size_t)G.nij;
+  const int bc = a.it[item].bc;
+  const int gtype = a.it[item].gtype;
+  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
+  const int Lm = G.Lm, Mm = G.Mm;
+  const double gamma2 = G.gamma2;
+  // ---- phase 1: edges of closed boundaries
+  if (bc == BC_R) {
+    if (!G.ewp) {
+      if (B.west) KLOOP1(j, Jstr, Jend) A[X2(Istr - 1, j)] = A[X2(Istr, j)];
+      if (B.east) KLOOP1(j, Jstr, Jend) A[X2(Iend + 1, j)] = A[X2(Iend, j)];
+    }
+    if (!G.nsp) {
+      if (B.south) KLOOP1(i, Istr, Iend) A[X2(i, Jstr - 1)] = A[X2(i, Jstr)];
+      if (B.north) KLOOP1(i, Istr, Iend) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
+    }
+  } else if (bc == BC_U) {
+    if (!G.ewp) {
+      if (B.west) KLOOP1(j, Jstr, Jend) A[X2(Istr, j)] = 0.0;
+      if (B.east) KLOOP1(j, Jstr, Jend) A[X2(Iend + 1, j)] = 0.0;
+    }
+    KSYNC();
+    if (!G.nsp) {
+      const int Imin = G.ewp ? B.IstrU : B.Istr, Imax = G.ewp ? B.Iend : B.IendR;
+      if (B.south) KLOOP1(i, Imin, Imax) A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)];
+      if (B.north) KLOOP1(i, Imin, Imax) A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)];
+    }
+  } else if (bc == BC_V) {
+    if (!G.ewp) {
+      const int Jmin = G.nsp ? B.JstrV : B.Jstr, Jmax = G.nsp ? B.Jend : B.JendR;
+      if (B.west) KLOOP1(j, Jmin, Jmax) A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)];
+      if (B.east) KLOOP1(j, Jmin, Jmax) A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)];
+    }
+    KSYNC();
+    if (!G.nsp) {
+      if (B.south) KLOOP1(i, Istr, Iend) A[X2(i, Jstr)] = 0.0;
+      if (B.north) KLOOP1(i, Istr, Iend) A[X2(i, Jend + 1)] = 0.0;
+    }
+  }
+  KSYNC();
+  // ---- phase 2: corners (only when neither direction is periodic)
+  if (bc != BC_NONE && !(G.ewp || G.nsp) && KTID == 0) {
+    if (bc == BC_R) {
+      if (B.sw) A[X2(Istr - 1, Jstr - 1)] = 0.5 * (A[X2(Istr, Jstr - 1)] + A[X2(Istr - 1, Jstr)]);
+      if (B.se) A[X2(Iend + 1, Jstr - 1)] = 0.5 * (A[X2(Iend, Jstr - 1)] + A[X2(Iend + 1, Jstr)]);
+      if (B.nw) A[X2(Istr - 1, Jend + 1)] = 0.5 * (A[X2(Istr - 1, Jend)] + A[X2(Istr, Jend + 1)]);
+      if (B.ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend + 1, Jend)] + A[X2(Iend, Jend + 1)]);
+    } else if (bc == BC_U) {
+      if (B.sw) A[X2(Istr, Jstr - 1)] = 0.5 * (A[X2(Istr + 1, Jstr - 1)] + A[X2(Istr, Jstr)]);
+      if (B.se) A[X2(Iend + 1, Jstr - 1)] = 0.5 * (A[X2(Iend, Jstr - 1)] + A[X2(Iend + 1, Jstr)]);
+      if (B.nw) A[X2(Istr, Jend + 1)] = 0.5 * (A[X2(Istr, Jend)] + A[X2(Istr + 1, Jend + 1)]);
+      if (B.ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend + 1, Jend)] + A[X2(Iend, Jend + 1)]);
+    } else {
+      if (B.sw) A[X2(Istr - 1, Jstr)] = 0.5 * (A[X2(Istr, Jstr)] + A[X2(Istr - 1, Jstr + 1)]);
+      if (B.se) A[X2(Iend + 1, Jstr)] = 0.5 * (A[X2(Iend, Jstr)] + A[X2(Iend + 1, Jstr + 1)]);
+      if (B.nw) A[X2(Istr - 1, Jend + 1)] = 0.5 * (A[X2(Istr - 1, Jend)] + A[X2(Istr, Jend + 1)]);
+      if (B.ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend + 1, Jend)] + A[X2(Iend, Jend + 1)]);
+    }
+  }
+  KSYNC();
+  // ---- phase 3: periodic ghost copies (single tile in the periodic direction)
+  if (gtype != 0 && (G.ewp || G.nsp)) {
+    const int gt = gtype;
+    int Jmin, Jmax, Imin, Imax;
+    if (G.nsp) { Jmin = B.Jstr; Jmax = B.Jend; }
+    else { Jmin = (gt == 'r' || gt == 'u') ? B.JstrR : B.Jstr; Jmax = B.JendR; }
+    if (G.ewp) { Imin = B.Istr; Imax = B.Iend; }
+    else { Imin = (gt == 'r' || gt == 'v') ? B.IstrR : B.Istr; Imax = B.IendR; }
+    const int ng3 = G.Nghost == 3;
+    if (G.ewp && B.west && B.east) {
+      KLOOP1(j, Jmin, Jmax) {
+        A[X2(Lm + 1, j)] = A[X2(1, j)];
+        A[X2(Lm + 2, j)] = A[X2(2, j)];
+        if (ng3) A[X2(Lm + 3, j)] = A[X2(3, j)];
+        A[X2(-2, j)] = A[X2(Lm - 2, j)];
+        A[X2(-1, j)] = A[X2(Lm - 1, j)];
+        A[X2(0, j)] = A[X2(Lm, j)];
+      }
+    }
+    if (G.nsp && B.south && B.north) {
+      KLOOP1(i, Imin, Imax) {
+        A[X2(i, Mm + 1)] = A[X2(i, 1)];
+        A[X2(i, Mm + 2)] = A[X2(i, 2)];
+        if (ng3) A[X2(i, Mm + 3)] = A[X2(i, 3)];
+        A[X2(i, -2)] = A[X2(i, Mm - 2)];
+        A[X2(i, -1)] = A[X2(i, Mm - 1)];
+        A[X2(i, 0)] = A[X2(i, Mm)];
+      }
+    }
+    if (G.ewp && G.nsp && B.sw && B.ne && KTID == 0) {
+      const int ne = ng3 ? 3 : 2;
+      for (int dj = 1; dj <= ne; dj++)
+        for (int di = 1; di <= ne; di++) A[X2(Lm + di, Mm + dj)] = A[X2(di, dj)];
+      for (int dj = 1; dj <= ne; dj++)
+        for (int di = -2; di <= 0; di++) A[X2(di, Mm + dj)] = A[X2(Lm + di, dj)];
+      for (int dj = -2; dj <= 0; dj++)
+        for (int di = 1; di <= ne; di++) A[X2(Lm + di, dj)] = A[X2(di, Mm + dj)];
+      for (int dj = -2; dj <= 0; dj++)
+        for (int di = -2; di <= 0; di++) A[X2(di, dj)] = A[X2(Lm + di, Mm + dj)];
+    }
+  }
+}
+COOP_GLOBAL(halo_kernel, HaloArgs)

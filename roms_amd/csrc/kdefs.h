@@ -1,0 +1,96 @@
+// kdefs.h -- kernel definition / launch macros for the HIP kernels of libroms_hip.so.
+//
+// Two kernel shapes are used throughout:
+//
+//  COOP   a thread block works cooperatively on one horizontal sub-tile of the GPU's
+//         (xi,eta) tile -- exactly a ROMS "tile" with its private scratch arrays
+//         (IminS:ImaxS,JminS:JmaxS) held in LDS.  Loop nests of the algorithm become
+//         block-strided loops (KLOOP2) separated by __syncthreads() (KSYNC).
+//  THREAD one thread per (i,j[,k]) point with no inter-thread communication:
+//         point-wise updates and sigma-column recurrences (tridiagonal solves,
+//         vertical integrals) with the column held in registers / private memory.
+//
+// The same kernel bodies can also be compiled by a host C++ compiler with
+// -DROMS_CPU_EMU (tests/emu/): blocks and threads are then executed serially.  That
+// build exists ONLY so that kernel logic can be unit-tested on machines without a GPU
+// (tests/, not-gpu marker); it is never built by __graft_entry__.build(), never loaded
+// by the roms_amd package and is not a fallback of the product library.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cmath>
+
+#ifdef ROMS_CPU_EMU
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#define KDEV inline
+#define KTID 0
+#define KNT 1
+#define KSYNC() ((void)0)
+typedef void *kstream_t;
+struct kdim3 { int x, y, z; };
+
+#define COOP_KERNEL(name, ArgT) static inline void name##_body(const ArgT &a, int bx, int by, int bz, double *lds)
+#define COOP_GLOBAL(name, ArgT)
+#define LAUNCH_COOP(name, gx, gy, gz, nthreads, lds_doubles, stream, args)               \
+  do {                                                                                   \
+    std::vector<double> lds_((size_t)(lds_doubles) + 8);                                 \
+    for (int bz_ = 0; bz_ < (gz); bz_++)                                                 \
+      for (int by_ = 0; by_ < (gy); by_++)                                               \
+        for (int bx_ = 0; bx_ < (gx); bx_++) name##_body(args, bx_, by_, bz_, lds_.data()); \
+  } while (0)
+
+#define THREAD_KERNEL(name, ArgT) static inline void name##_body(const ArgT &a, int gx, int gy, int gz)
+#define THREAD_GLOBAL(name, ArgT)
+#define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
+  do {                                                                                   \
+    for (int gz_ = 0; gz_ < (nz); gz_++)                                                 \
+      for (int gy_ = 0; gy_ < (ny); gy_++)                                               \
+        for (int gx_ = 0; gx_ < (nx); gx_++) name##_body(args, gx_, gy_, gz_);           \
+  } while (0)
+
+#else  // ------------------------------------------------------------------ HIP / gfx950
+#include <hip/hip_runtime.h>
+#define KDEV __device__ __forceinline__
+#define KTID ((int)threadIdx.x)
+#define KNT ((int)blockDim.x)
+#define KSYNC() __syncthreads()
+typedef hipStream_t kstream_t;
+
+#define COOP_KERNEL(name, ArgT) static __device__ void name##_body(const ArgT &a, int bx, int by, int bz, double *lds)
+// the __global__ entry: dynamic LDS, block index -> sub-tile (with the XCD-aware remap done
+// by the body through DGrid, see roms_ctx.h:block_rect)
+#define COOP_GLOBAL(name, ArgT)                                                          \
+  __global__ void name(const ArgT a) {                                                   \
+    extern __shared__ double lds_dyn_[];                                                 \
+    name##_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds_dyn_);         \
+  }
+#define LAUNCH_COOP(name, gx, gy, gz, nthreads, lds_doubles, stream, args)               \
+  hipLaunchKernelGGL(name, dim3((unsigned)(gx), (unsigned)(gy), (unsigned)(gz)), dim3((unsigned)(nthreads)), \
+                     (size_t)(lds_doubles) * sizeof(double), stream, args)
+
+#define THREAD_KERNEL(name, ArgT) static __device__ void name##_body(const ArgT &a, int gx, int gy, int gz)
+#define THREAD_GLOBAL(name, ArgT)                                                        \
+  __global__ void name(const ArgT a, int nx, int ny, int nz) {                           \
+    int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);                               \
+    int gy = (int)(blockIdx.y * blockDim.y + threadIdx.y);                               \
+    int gz = (int)blockIdx.z;                                                            \
+    if (gx < nx && gy < ny && gz < nz) name##_body(a, gx, gy, gz);                       \
+  }
+// 64 lanes along xi (coalesced), 4 rows of eta per block
+#define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
+  hipLaunchKernelGGL(name, dim3((unsigned)(((nx) + 63) / 64), (unsigned)(((ny) + 3) / 4), (unsigned)(nz)), \
+                     dim3(64, 4, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz))
+#endif
+
+// block-strided loop nest over the rectangle [ilo,ihi] x [jlo,jhi] (inclusive), i fastest
+#define KLOOP2(i, j, ilo, ihi, jlo, jhi)                                                 \
+  for (int w_ = (ihi) - (ilo) + 1, n_ = (w_ > 0 && (jhi) >= (jlo)) ? w_ * ((jhi) - (jlo) + 1) : 0, \
+           q_ = KTID, i = 0, j = 0;                                                      \
+       q_ < n_ && ((j = (jlo) + q_ / w_), (i = (ilo) + q_ - (j - (jlo)) * w_), true); q_ += KNT)
+// block-strided 1-D loop
+#define KLOOP1(i, ilo, ihi) for (int i = (ilo) + KTID; i <= (ihi); i += KNT)
+
+#define KMAX(a, b) ((a) > (b) ? (a) : (b))
+#define KMIN(a, b) ((a) < (b) ? (a) : (b))

@@ -1,0 +1,152 @@
+// roms_ctx.h -- device-side descriptors and the host context of libroms_hip.so.
+#pragma once
+#include "kdefs.h"
+#include "../../include/roms_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// Loop bounds of a (sub-)tile: BOUNDS(ng)%xxx(tile) of the reference, recomputed by the rules of
+// var_bounds (ROMS/Utility/get_bounds.F:1044-1884).  The same rules are applied to the whole
+// GPU tile and to the sub-tile owned by one thread block.
+// ---------------------------------------------------------------------------------------------
+struct TB {
+  int Istr, Iend, Jstr, Jend;
+  int IstrR, IendR, JstrR, JendR;
+  int IstrU, JstrV;
+  int IstrB, IendB, IstrM, JstrB, JendB, JstrM;
+  int IstrP, IendP, JstrP, JendP;
+  int IstrT, IendT, JstrT, JendT;
+  int Istrm3, Istrm2, Istrm1, IstrUm2, IstrUm1;
+  int Iendp1, Iendp2, Iendp2i, Iendp3;
+  int Jstrm3, Jstrm2, Jstrm1, JstrVm2, JstrVm1;
+  int Jendp1, Jendp2, Jendp2i, Jendp3;
+  int west, east, south, north;   // DOMAIN%Western_Edge ... (of the global domain)
+  int sw, se, nw, ne;
+};
+
+// Grid/time/physics descriptor passed BY VALUE to every kernel.
+struct DGrid {
+  // allocation
+  int LBi, LBj, ni, nj;
+  long nij;
+  int N, NT, NAT, Lm, Mm, Nghost;
+  int ewp, nsp, options;
+  int hadv[ROMS_MAXT], vadv[ROMS_MAXT];
+  TB T;                       // bounds of this GPU's tile
+  int nbx, nby;               // thread-block decomposition of the tile for COOP kernels
+  int bw, bh;                 // max sub-tile extent (LDS scratch is (bw+6) x (bh+6))
+  // stepping (mod_stepping)
+  int iic, iif, nstp, nnew, nrhs, kstp, knew, krhs, predictor;
+  int ntfirst, nfast;
+  double time, tdays;
+  // scalars
+  double dt, dtfast, rho0, g, lambda, gamma2, Cp, R0, T0, S0, Tcoef, Scoef, hc, dstart;
+  double Akt_bak[ROMS_MAXT], Akv_bak;
+  int Vtransform;
+};
+
+#ifdef ROMS_CPU_EMU
+#define KHD inline
+#else
+#define KHD __host__ __device__ __forceinline__
+#endif
+
+// var_bounds for the rectangle [i0,i1]x[j0,j1]; w/e/s/n: the rectangle touches that edge of the
+// global domain.
+KHD TB make_bounds(int Lm, int Mm, int ewp, int nsp, int i0, int i1, int j0, int j1, int w, int e, int s,
+                   int n) {
+  TB b;
+  b.west = w; b.east = e; b.south = s; b.north = n;
+  b.sw = w && s; b.se = e && s; b.nw = w && n; b.ne = e && n;
+  const int pw = w && !ewp, pe = e && !ewp, ps = s && !nsp, pn = n && !nsp;
+  b.Istr = i0; b.IstrP = i0;
+  b.IstrR = pw ? i0 - 1 : i0;
+  b.IstrT = b.IstrR;
+  b.IstrU = pw ? i0 + 1 : i0;
+  b.IstrB = pw ? b.IstrT + 1 : i0;
+  b.IstrM = pw ? b.IstrP + 1 : b.IstrU;
+  b.Istrm3 = pw ? KMAX(0, i0 - 3) : i0 - 3;
+  b.Istrm2 = pw ? KMAX(0, i0 - 2) : i0 - 2;
+  b.Istrm1 = pw ? KMAX(1, i0 - 1) : i0 - 1;
+  b.IstrUm2 = pw ? KMAX(1, b.IstrU - 2) : b.IstrU - 2;
+  b.IstrUm1 = pw ? KMAX(2, b.IstrU - 1) : b.IstrU - 1;
+  b.Iend = i1;
+  b.IendR = pe ? i1 + 1 : i1;
+  b.IendP = b.IendR; b.IendT = b.IendR;
+  b.IendB = pe ? b.IendT - 1 : i1;
+  b.Iendp1 = pe ? KMIN(i1 + 1, Lm) : i1 + 1;
+  b.Iendp2i = pe ? KMIN(i1 + 2, Lm) : i1 + 2;
+  b.Iendp2 = pe ? KMIN(i1 + 2, Lm + 1) : i1 + 2;
+  b.Iendp3 = pe ? KMIN(i1 + 3, Lm + 1) : i1 + 3;
+  b.Jstr = j0; b.JstrP = j0;
+  b.JstrR = ps ? j0 - 1 : j0;
+  b.JstrT = b.JstrR;
+  b.JstrV = ps ? j0 + 1 : j0;
+  b.JstrB = ps ? b.JstrT + 1 : j0;
+  b.JstrM = ps ? b.JstrP + 1 : b.JstrV;
+  b.Jstrm3 = ps ? KMAX(0, j0 - 3) : j0 - 3;
+  b.Jstrm2 = ps ? KMAX(0, j0 - 2) : j0 - 2;
+  b.Jstrm1 = ps ? KMAX(1, j0 - 1) : j0 - 1;
+  b.JstrVm2 = ps ? KMAX(1, b.JstrV - 2) : b.JstrV - 2;
+  b.JstrVm1 = ps ? KMAX(2, b.JstrV - 1) : b.JstrV - 1;
+  b.Jend = j1;
+  b.JendR = pn ? j1 + 1 : j1;
+  b.JendP = b.JendR; b.JendT = b.JendR;
+  b.JendB = pn ? b.JendT - 1 : j1;
+  b.Jendp1 = pn ? KMIN(j1 + 1, Mm) : j1 + 1;
+  b.Jendp2i = pn ? KMIN(j1 + 2, Mm) : j1 + 2;
+  b.Jendp2 = pn ? KMIN(j1 + 2, Mm + 1) : j1 + 2;
+  b.Jendp3 = pn ? KMIN(j1 + 3, Mm + 1) : j1 + 3;
+  return b;
+}
+
+// Sub-tile of thread block (bx,by): the GPU tile is split into nbx x nby nearly equal
+// rectangles with the reference's own partition rule (tile_bounds_2d, get_bounds.F:972-1042).
+// Consecutive blockIdx.x values land on different XCDs (block b -> XCD b%8); the i-fastest
+// linear order keeps eta-neighbouring sub-tiles of one XCD's L2 8 blocks apart, which is
+// irrelevant for correctness.
+KHD TB block_bounds(const DGrid &G, int bx, int by) {
+  const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
+  const int cI = (LmT + G.nbx - 1) / G.nbx, cJ = (MmT + G.nby - 1) / G.nby;
+  const int mI = (G.nbx * cI - LmT) / 2, mJ = (G.nby * cJ - MmT) / 2;
+  int i0 = 1 + bx * cI - mI, i1 = i0 + cI - 1;
+  int j0 = 1 + by * cJ - mJ, j1 = j0 + cJ - 1;
+  i0 = KMAX(i0, 1); i1 = KMIN(i1, LmT);
+  j0 = KMAX(j0, 1); j1 = KMIN(j1, MmT);
+  i0 += G.T.Istr - 1; i1 += G.T.Istr - 1;
+  j0 += G.T.Jstr - 1; j1 += G.T.Jstr - 1;
+  return make_bounds(G.Lm, G.Mm, G.ewp, G.nsp, i0, i1, j0, j1, G.T.west && bx == 0, G.T.east && bx == G.nbx - 1,
+                     G.T.south && by == 0, G.T.north && by == G.nby - 1);
+}
+
+// ------------------------------------------------------------------ indexing (reference layout)
+#define X2(i, j) ((size_t)((i) - G.LBi) + (size_t)((j) - G.LBj) * (size_t)G.ni)
+#define X3(i, j, k) (X2(i, j) + (size_t)((k) - 1) * (size_t)G.nij)   /* rho levels 1..N */
+#define XW(i, j, k) (X2(i, j) + (size_t)(k) * (size_t)G.nij)         /* w levels 0..N   */
+// LDS scratch of a sub-tile b: (IminS:ImaxS,JminS:JmaxS) = (Istr-3:Iend+3, Jstr-3:Jend+3)
+#define SW_(b) ((b).Iend - (b).Istr + 7)
+#define S2(i, j) ((size_t)((i) - (B.Istr - 3)) + (size_t)((j) - (B.Jstr - 3)) * (size_t)SW_(B))
+
+// All device arrays (reference component names).  Pointers only; passed to kernels through the
+// small per-kernel argument structs.
+struct Fields {
+  // mod_grid
+  double *h, *f, *fomn, *pm, *pn, *om_r, *on_r, *om_u, *on_u, *om_v, *on_v, *om_p, *on_p, *omn, *pmon_r, *pnom_r,
+      *pmon_p, *pnom_p, *pmon_u, *pnom_u, *pmon_v, *pnom_v, *dmde, *dndx, *angler, *xr, *yr, *lonr, *latr, *rdrag,
+      *rdrag2;
+  double *Hz, *z_r, *z_w, *Huon, *Hvom;
+  // mod_ocean
+  double *zeta, *ubar, *vbar, *rzeta, *rubar, *rvbar, *u, *v, *t, *W, *wvel, *rho, *pden, *ru, *rv;
+  // mod_coupling
+  double *rhoA, *rhoS, *rufrc, *rvfrc, *Zt_avg1, *DU_avg1, *DU_avg2, *DV_avg1, *DV_avg2;
+  // mod_forces
+  double *sustr, *svstr, *bustr, *bvstr, *stflx, *btflx, *stflux, *btflux, *srflx;
+  double *Uwind, *Vwind, *Tair, *Pair, *Hair, *rain, *cloud, *lhflx, *shflx, *lrflx, *evap;
+  // mod_mixing
+  double *Akv, *Akt, *visc2_r, *visc2_p, *diff2, *bvf, *alpha, *beta, *hsbl, *ghats;
+  // s-coordinate tables (device copies)
+  double *sc_r, *Cs_r, *sc_w, *Cs_w;
+  // work space: private 3-D arrays of the reference kernels (P of prsgrd, vert of wvelocity,
+  // oHz/Ta/Ua/Va/Wa of step3d_t, swdk of pre_step3d ...)
+  double *wrk3[6];
+  double *wrk2[4];
+};

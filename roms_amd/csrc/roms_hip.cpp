@@ -1,0 +1,431 @@
+// roms_hip.cpp -- context, memory, C ABI and the main3d step sequence of libroms_hip.so.
+//
+// Sequencing follows main3d (ROMS/Nonlinear/main3d.F:216-1148) and the LF-AM3 barotropic index
+// state machine (:810-918); see roms_hip_main3d below.
+#include "roms_host.h"
+#include "k_halo.h"
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+extern "C" const char *roms_hip_last_error(void) { return g_last_error.c_str(); }
+extern "C" int roms_hip_abi_version(void) { return ROMS_HIP_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------ device memory
+#ifdef ROMS_CPU_EMU
+static int dmalloc(void **p, size_t bytes) { *p = calloc(bytes ? bytes : 8, 1); return *p ? 0 : 2; }
+static void dfree(void *p) { free(p); }
+static int h2d(void *d, const void *h, size_t bytes, kstream_t) { memcpy(d, h, bytes); return 0; }
+static int d2h(void *h, const void *d, size_t bytes, kstream_t) { memcpy(h, d, bytes); return 0; }
+static int dsync(kstream_t) { return 0; }
+int ctx_check(roms_hip_ctx *, const char *) { return 0; }
+#else
+static int hipfail(hipError_t e, const char *what) {
+  if (e == hipSuccess) return 0;
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return 2;
+}
+static int dmalloc(void **p, size_t bytes) {
+  int r = hipfail(hipMalloc(p, bytes ? bytes : 8), "hipMalloc");
+  if (r) return r;
+  return hipfail(hipMemset(*p, 0, bytes ? bytes : 8), "hipMemset");
+}
+static void dfree(void *p) { (void)hipFree(p); }
+static int h2d(void *d, const void *h, size_t bytes, kstream_t s) {
+  int r = hipfail(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s), "hipMemcpy H2D");
+  if (r) return r;
+  return hipfail(hipStreamSynchronize(s), "hipStreamSynchronize");
+}
+static int d2h(void *h, const void *d, size_t bytes, kstream_t s) {
+  int r = hipfail(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s), "hipMemcpy D2H");
+  if (r) return r;
+  return hipfail(hipStreamSynchronize(s), "hipStreamSynchronize");
+}
+static int dsync(kstream_t s) { return hipfail(hipStreamSynchronize(s), "hipStreamSynchronize"); }
+int ctx_check(roms_hip_ctx *, const char *what) { return hipfail(hipGetLastError(), what); }
+#endif
+
+// ------------------------------------------------------------------------------- field table
+#define FD(nm, kind) { #nm, offsetof(Fields, nm), kind }
+static const FieldDesc g_fields[] = {
+    FD(h, FK_2D), FD(f, FK_2D), FD(fomn, FK_2D), FD(pm, FK_2D), FD(pn, FK_2D), FD(om_r, FK_2D), FD(on_r, FK_2D),
+    FD(om_u, FK_2D), FD(on_u, FK_2D), FD(om_v, FK_2D), FD(on_v, FK_2D), FD(om_p, FK_2D), FD(on_p, FK_2D),
+    FD(omn, FK_2D), FD(pmon_r, FK_2D), FD(pnom_r, FK_2D), FD(pmon_p, FK_2D), FD(pnom_p, FK_2D), FD(pmon_u, FK_2D),
+    FD(pnom_u, FK_2D), FD(pmon_v, FK_2D), FD(pnom_v, FK_2D), FD(dmde, FK_2D), FD(dndx, FK_2D), FD(angler, FK_2D),
+    FD(xr, FK_2D), FD(yr, FK_2D), FD(lonr, FK_2D), FD(latr, FK_2D), FD(rdrag, FK_2D), FD(rdrag2, FK_2D),
+    FD(Hz, FK_R), FD(z_r, FK_R), FD(z_w, FK_W), FD(Huon, FK_R), FD(Hvom, FK_R),
+    FD(zeta, FK_2Dx3), FD(ubar, FK_2Dx3), FD(vbar, FK_2Dx3), FD(rzeta, FK_2Dx2), FD(rubar, FK_2Dx2),
+    FD(rvbar, FK_2Dx2), FD(u, FK_Rx2), FD(v, FK_Rx2), FD(t, FK_T), FD(W, FK_W), FD(wvel, FK_W), FD(rho, FK_R),
+    FD(pden, FK_R), FD(ru, FK_Wx2), FD(rv, FK_Wx2),
+    FD(rhoA, FK_2D), FD(rhoS, FK_2D), FD(rufrc, FK_2D), FD(rvfrc, FK_2D), FD(Zt_avg1, FK_2D), FD(DU_avg1, FK_2D),
+    FD(DU_avg2, FK_2D), FD(DV_avg1, FK_2D), FD(DV_avg2, FK_2D),
+    FD(sustr, FK_2D), FD(svstr, FK_2D), FD(bustr, FK_2D), FD(bvstr, FK_2D), FD(stflx, FK_2DxNT),
+    FD(btflx, FK_2DxNT), FD(stflux, FK_2DxNT), FD(btflux, FK_2DxNT), FD(srflx, FK_2D),
+    FD(Uwind, FK_2D), FD(Vwind, FK_2D), FD(Tair, FK_2D), FD(Pair, FK_2D), FD(Hair, FK_2D), FD(rain, FK_2D),
+    FD(cloud, FK_2D), FD(lhflx, FK_2D), FD(shflx, FK_2D), FD(lrflx, FK_2D), FD(evap, FK_2D),
+    FD(Akv, FK_W), FD(Akt, FK_WxNAT), FD(visc2_r, FK_2D), FD(visc2_p, FK_2D), FD(diff2, FK_2DxNT), FD(bvf, FK_W),
+    FD(alpha, FK_2D), FD(beta, FK_2D), FD(hsbl, FK_2D), FD(ghats, FK_WxNAT),
+    FD(sc_r, FK_TABR), FD(Cs_r, FK_TABR), FD(sc_w, FK_TABW), FD(Cs_w, FK_TABW),
+};
+static const int g_nfields = (int)(sizeof(g_fields) / sizeof(g_fields[0]));
+
+long field_elems(const roms_hip_ctx *c, int kind) {
+  const long p = c->G.nij, N = c->G.N, NT = c->G.NT, NAT = c->G.NAT;
+  switch (kind) {
+    case FK_2D: return p;
+    case FK_R: return p * N;
+    case FK_W: return p * (N + 1);
+    case FK_2Dx3: return p * 3;
+    case FK_2Dx2: return p * 2;
+    case FK_Rx2: return p * N * 2;
+    case FK_T: return p * N * 3 * NT;
+    case FK_Wx2: return p * (N + 1) * 2;
+    case FK_2DxNT: return p * NT;
+    case FK_WxNAT: return p * (N + 1) * NAT;
+    case FK_TABR: return N;
+    case FK_TABW: return N + 1;
+  }
+  return -1;
+}
+
+const FieldDesc *find_field(const char *name) {
+  for (int k = 0; k < g_nfields; k++)
+    if (!strcmp(name, g_fields[k].name)) return &g_fields[k];
+  return nullptr;
+}
+
+// -------------------------------------------------------------------------------- life cycle
+static void choose_blocks(DGrid &G) {
+  // Sub-tile size of the COOP kernels.  LDS scratch per array is (bw+6)*(bh+6) doubles.  Small
+  // grids get smaller sub-tiles so that a launch still spreads over many of the 256 CUs.
+  const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
+  int bw = 32, bh = 8;
+  if ((long)LmT * MmT >= 512L * 256L) { bw = 32; bh = 16; }
+  G.nbx = (LmT + bw - 1) / bw;
+  G.nby = (MmT + bh - 1) / bh;
+  if (G.nbx < 1) G.nbx = 1;
+  if (G.nby < 1) G.nby = 1;
+  G.bw = (LmT + G.nbx - 1) / G.nbx;
+  G.bh = (MmT + G.nby - 1) / G.nby;
+}
+
+extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
+  if (!cfg || !out) { set_error("null argument"); return 8; }
+  if (cfg->abi_version != ROMS_HIP_ABI_VERSION) { set_error("ABI version mismatch"); return 5; }
+  if (cfg->N < 4 || cfg->N > 255 || cfg->NT < 1 || cfg->NT > ROMS_MAXT || 2 * cfg->ndtfast > ROMS_MAXW) {
+    set_error("unsupported dimensions (need 4 <= N <= 255, NT <= 4, 2*ndtfast <= 512)");
+    return 5;
+  }
+  if (cfg->NtileI * cfg->NtileJ != 1) {
+    set_error("this build handles one tile per process domain (NtileI*NtileJ == 1)");
+    return 5;
+  }
+#ifndef ROMS_CPU_EMU
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    set_error("no HIP device: libroms_hip.so needs an AMD GPU (there is no CPU fallback)");
+    return 2;
+  }
+  if (hipfail(hipSetDevice(cfg->device), "hipSetDevice")) return 2;
+#endif
+  roms_hip_ctx *c = new roms_hip_ctx();
+  c->cfg = *cfg;
+  DGrid &G = c->G;
+  memset(&G, 0, sizeof(G));
+  G.LBi = cfg->LBi; G.LBj = cfg->LBj;
+  G.ni = cfg->UBi - cfg->LBi + 1; G.nj = cfg->UBj - cfg->LBj + 1;
+  G.nij = (long)G.ni * G.nj;
+  G.N = cfg->N; G.NT = cfg->NT; G.NAT = cfg->NAT; G.Lm = cfg->Lm; G.Mm = cfg->Mm; G.Nghost = cfg->Nghost;
+  G.ewp = cfg->EWperiodic; G.nsp = cfg->NSperiodic; G.options = cfg->options;
+  for (int i = 0; i < ROMS_MAXT; i++) { G.hadv[i] = cfg->hadv[i]; G.vadv[i] = cfg->vadv[i]; G.Akt_bak[i] = cfg->Akt_bak[i]; }
+  G.T = make_bounds(cfg->Lm, cfg->Mm, cfg->EWperiodic, cfg->NSperiodic, cfg->Istr, cfg->Iend, cfg->Jstr, cfg->Jend,
+                    cfg->west_edge, cfg->east_edge, cfg->south_edge, cfg->north_edge);
+  choose_blocks(G);
+  G.ntfirst = cfg->ntfirst; G.nfast = cfg->nfast;
+  G.dt = cfg->dt; G.dtfast = cfg->dtfast; G.rho0 = cfg->rho0; G.g = cfg->g; G.lambda = cfg->lambda;
+  G.gamma2 = cfg->gamma2; G.Cp = cfg->Cp; G.R0 = cfg->R0; G.T0 = cfg->T0; G.S0 = cfg->S0; G.Tcoef = cfg->Tcoef;
+  G.Scoef = cfg->Scoef; G.hc = cfg->hc; G.dstart = cfg->dstart; G.Akv_bak = cfg->Akv_bak;
+  G.Vtransform = cfg->Vtransform;
+  c->profile = false;
+  memset(c->regions, 0, sizeof(c->regions));
+#ifdef ROMS_CPU_EMU
+  c->stream = nullptr;
+#else
+  if (hipfail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return 2; }
+  (void)hipEventCreate(&c->ev0);
+  (void)hipEventCreate(&c->ev1);
+#endif
+  // state arrays
+  memset(&c->F, 0, sizeof(c->F));
+  for (int k = 0; k < g_nfields; k++) {
+    void *p = nullptr;
+    if (dmalloc(&p, (size_t)field_elems(c, g_fields[k].kind) * sizeof(double))) { roms_hip_destroy(c); return 2; }
+    c->allocs.push_back(p);
+    *(double **)((char *)&c->F + g_fields[k].offset) = (double *)p;
+  }
+  for (int k = 0; k < 6; k++) {
+    void *p = nullptr;
+    size_t n = (size_t)G.nij * (size_t)(G.N + 1) * (k == 0 ? (size_t)G.NT : 1);
+    if (dmalloc(&p, n * sizeof(double))) { roms_hip_destroy(c); return 2; }
+    c->allocs.push_back(p);
+    c->F.wrk3[k] = (double *)p;
+  }
+  for (int k = 0; k < 4; k++) {
+    void *p = nullptr;
+    if (dmalloc(&p, (size_t)G.nij * sizeof(double))) { roms_hip_destroy(c); return 2; }
+    c->allocs.push_back(p);
+    c->F.wrk2[k] = (double *)p;
+  }
+  // s-coordinate tables
+  if (h2d(c->F.sc_r, cfg->sc_r, sizeof(double) * (size_t)G.N, c->stream) ||
+      h2d(c->F.Cs_r, cfg->Cs_r, sizeof(double) * (size_t)G.N, c->stream) ||
+      h2d(c->F.sc_w, cfg->sc_w, sizeof(double) * (size_t)(G.N + 1), c->stream) ||
+      h2d(c->F.Cs_w, cfg->Cs_w, sizeof(double) * (size_t)(G.N + 1), c->stream)) { roms_hip_destroy(c); return 2; }
+  // diag scratch
+  c->nblk_diag = 256;
+  {
+    void *p = nullptr;
+    if (dmalloc(&p, sizeof(double) * 16 * (size_t)(G.nj + 8))) { roms_hip_destroy(c); return 2; }
+    c->allocs.push_back(p);
+    c->d_diag = (double *)p;
+    c->h_diag = (double *)calloc(16 * (size_t)(G.nj + 8), sizeof(double));
+  }
+  memset(&c->s, 0, sizeof(c->s));
+  c->s.iif = 1; c->s.indx1 = 1; c->s.kstp = 1; c->s.krhs = 1; c->s.knew = 1;
+  c->s.nstp = 1; c->s.nrhs = 1; c->s.nnew = 1;
+  c->s.time = cfg->dstart * 86400.0;
+  ctx_sync_stepping(c);
+  *out = c;
+  return 0;
+}
+
+extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
+  if (!c) return 0;
+  (void)dsync(c->stream);
+  for (void *p : c->allocs) dfree(p);
+  free(c->h_diag);
+#ifndef ROMS_CPU_EMU
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+#endif
+  delete c;
+  return 0;
+}
+
+void ctx_sync_stepping(roms_hip_ctx *c) {
+  DGrid &G = c->G;
+  const roms_hip_stepping &s = c->s;
+  G.iic = s.iic; G.iif = s.iif; G.nstp = s.nstp; G.nnew = s.nnew; G.nrhs = s.nrhs;
+  G.kstp = s.kstp; G.knew = s.knew; G.krhs = s.krhs; G.predictor = s.predictor;
+  G.time = s.time;
+  G.tdays = s.time * (1.0 / 86400.0);
+}
+
+extern "C" int roms_hip_set_stepping(roms_hip_ctx *c, const roms_hip_stepping *s) {
+  if (!c || !s) return 8;
+  c->s = *s;
+  ctx_sync_stepping(c);
+  return 0;
+}
+extern "C" int roms_hip_get_stepping(roms_hip_ctx *c, roms_hip_stepping *s) {
+  if (!c || !s) return 8;
+  *s = c->s;
+  return 0;
+}
+
+extern "C" long roms_hip_field_size(roms_hip_ctx *c, const char *name) {
+  const FieldDesc *f = find_field(name);
+  return f ? field_elems(c, f->kind) : -1;
+}
+extern "C" int roms_hip_upload(roms_hip_ctx *c, const char *name, const double *host, long n) {
+  const FieldDesc *f = find_field(name);
+  if (!f) { set_error(std::string("unknown field ") + name); return 8; }
+  if (n != field_elems(c, f->kind)) { set_error(std::string("size mismatch for field ") + name); return 8; }
+  return h2d(*(double **)((char *)&c->F + f->offset), host, (size_t)n * sizeof(double), c->stream);
+}
+extern "C" int roms_hip_download(roms_hip_ctx *c, const char *name, double *host, long n) {
+  const FieldDesc *f = find_field(name);
+  if (!f) { set_error(std::string("unknown field ") + name); return 8; }
+  if (n != field_elems(c, f->kind)) { set_error(std::string("size mismatch for field ") + name); return 8; }
+  return d2h(host, *(double **)((char *)&c->F + f->offset), (size_t)n * sizeof(double), c->stream);
+}
+extern "C" int roms_hip_sync(roms_hip_ctx *c) { return dsync(c->stream); }
+
+// ------------------------------------------------------------------------------ region timing
+RegionTimer::RegionTimer(roms_hip_ctx *c_, int id_) : c(c_), id(id_) {
+#ifndef ROMS_CPU_EMU
+  if (c->profile) (void)hipEventRecord(c->ev0, c->stream);
+#endif
+}
+RegionTimer::~RegionTimer() {
+#ifndef ROMS_CPU_EMU
+  if (c->profile) {
+    (void)hipEventRecord(c->ev1, c->stream);
+    (void)hipEventSynchronize(c->ev1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->regions[id].seconds += 1.0e-3 * (double)ms;
+  }
+#endif
+  c->regions[id].calls += 1;
+}
+extern "C" int roms_hip_profile(roms_hip_ctx *c, int enable) {
+  c->profile = enable != 0;
+  memset(c->regions, 0, sizeof(c->regions));
+  return 0;
+}
+extern "C" int roms_hip_region_seconds(roms_hip_ctx *c, int region, double *seconds, long *calls) {
+  if (region < 0 || region >= 96) return 8;
+  if (seconds) *seconds = c->regions[region].seconds;
+  if (calls) *calls = c->regions[region].calls;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------- halo
+void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype) {
+  HaloSpec sp = {A, nk, bc, gtype};
+  launch_halo_multi(c, &sp, 1);
+}
+void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n) {
+  HaloArgs a;
+  a.G = c->G;
+  a.nitems = n;
+  int planes = 0;
+  for (int k = 0; k < n; k++) {
+    a.it[k].A = sp[k].A; a.it[k].nk = sp[k].nk; a.it[k].bc = sp[k].bc; a.it[k].gtype = (int)sp[k].gtype;
+    planes += sp[k].nk;
+  }
+  LAUNCH_COOP(halo_kernel, 1, 1, planes, 256, 0, c->stream, a);
+}
+
+// ---------------------------------------------------------------------- per-kernel C entries
+#define ENTRY(name, region)                                             \
+  extern "C" int roms_hip_##name(roms_hip_ctx *c) {                     \
+    if (!c) return 8;                                                   \
+    RegionTimer rt(c, region);                                          \
+    int r = run_##name(c);                                              \
+    return r ? r : ctx_check(c, #name);                                 \
+  }
+ENTRY(set_depth, 12)
+ENTRY(set_massflux, 12)
+ENTRY(rho_eos, 14)
+ENTRY(set_vbc, 6)
+ENTRY(ana_vmix, 18)
+ENTRY(set_data, 4)
+ENTRY(omega, 13)
+ENTRY(set_zeta, 12)
+ENTRY(ini_zeta, 2)
+ENTRY(ini_fields, 2)
+ENTRY(pre_step3d, 22)
+ENTRY(prsgrd, 23)
+ENTRY(t3dmix2, 24)
+ENTRY(uv3dmix2, 30)
+ENTRY(rhs3d_tile, 21)
+ENTRY(step2d, 9)
+ENTRY(step3d_uv, 34)
+ENTRY(step3d_t, 35)
+ENTRY(lmd_vmix, 18)
+ENTRY(bulk_flux, 17)
+
+extern "C" int roms_hip_wvelocity(roms_hip_ctx *c, int ninp) {
+  RegionTimer rt(c, 12);
+  int r = run_wvelocity(c, ninp);
+  return r ? r : ctx_check(c, "wvelocity");
+}
+extern "C" int roms_hip_rhs3d(roms_hip_ctx *c) {
+  int r;
+  if ((r = roms_hip_pre_step3d(c))) return r;
+  if ((r = roms_hip_prsgrd(c))) return r;
+  if ((r = roms_hip_t3dmix2(c))) return r;
+  if ((r = roms_hip_rhs3d_tile(c))) return r;
+  return roms_hip_uv3dmix2(c);
+}
+extern "C" int roms_hip_diag(roms_hip_ctx *c, double *out) {
+  RegionTimer rt(c, 7);
+  return run_diag(c, out);
+}
+
+// initial.F tail
+extern "C" int roms_hip_start(roms_hip_ctx *c) {
+  roms_hip_stepping &s = c->s;
+  s.iif = 1; s.indx1 = 1; s.kstp = 1; s.krhs = 1; s.knew = 1; s.predictor = 0;
+  s.nstp = 1; s.nrhs = 1; s.nnew = 1;
+  s.time = c->cfg.dstart * 86400.0;
+  ctx_sync_stepping(c);
+  int r;
+  if ((r = roms_hip_set_massflux(c))) return r;
+  if ((r = roms_hip_omega(c))) return r;
+  if ((r = roms_hip_rho_eos(c))) return r;
+  s.iic = c->cfg.ntstart;
+  ctx_sync_stepping(c);
+  return 0;
+}
+
+// one pass of STEP_LOOP, main3d.F:216-1148
+static int main3d_one(roms_hip_ctx *c) {
+  roms_hip_stepping &s = c->s;
+  const roms_hip_config &cf = c->cfg;
+  int r;
+#define DO(call) do { if ((r = (call))) return r; } while (0)
+  s.nstp = 1 + (s.iic - cf.ntstart) % 2;                    // :220-231
+  s.nnew = 3 - s.nstp;
+  s.nrhs = s.nstp;
+  ctx_sync_stepping(c);
+  DO(roms_hip_set_data(c));                                 // :258
+  if (s.iic == cf.ntstart) {                                // post_initial :335
+    DO(roms_hip_ini_zeta(c));
+    DO(roms_hip_set_depth(c));
+    DO(roms_hip_ini_fields(c));
+  }
+  DO(roms_hip_set_massflux(c));                             // :348
+  DO(roms_hip_rho_eos(c));                                  // :350
+  // diag (:355) is a host-visible reduction: run on request through roms_hip_diag
+  if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));   // :439
+  DO(roms_hip_set_vbc(c));                                  // :445
+  if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));       // :525
+  else if (cf.options & ROMS_LMD_MIXING) DO(roms_hip_lmd_vmix(c)); // :527
+  DO(roms_hip_omega(c));                                    // :534
+  DO(roms_hip_wvelocity(c, s.nstp));                        // :535
+  DO(roms_hip_set_zeta(c));                                 // :556
+  DO(roms_hip_rhs3d(c));                                    // :632
+  for (int my_iif = 1; my_iif <= cf.nfast + 1; my_iif++) {  // :810-918
+    const int next_indx1 = 3 - s.indx1;
+    if (!s.predictor && my_iif <= cf.nfast + 1) {
+      s.predictor = 1;
+      s.iif = my_iif;
+      s.kstp = (s.iif == 1) ? s.indx1 : 3 - s.indx1;
+      s.knew = 3;
+      s.krhs = s.indx1;
+    }
+    ctx_sync_stepping(c);
+    DO(roms_hip_step2d(c));
+    if (s.predictor) {
+      s.predictor = 0;
+      s.knew = next_indx1;
+      s.kstp = 3 - s.knew;
+      s.krhs = 3;
+      if (s.iif < cf.nfast + 1) s.indx1 = next_indx1;
+    }
+    ctx_sync_stepping(c);
+    if (s.iif < cf.nfast + 1) DO(roms_hip_step2d(c));
+  }
+  DO(roms_hip_set_depth(c));                                // :963
+  DO(roms_hip_step3d_uv(c));                                // :990
+  DO(roms_hip_omega(c));                                    // :1017
+  DO(roms_hip_step3d_t(c));                                 // :1045
+  s.iic = s.iic + 1;                                        // :1145-1148
+  s.time = s.time + cf.dt;
+  ctx_sync_stepping(c);
+#undef DO
+  return 0;
+}
+
+extern "C" int roms_hip_main3d(roms_hip_ctx *c, int nsteps) {
+  if (!c) return 8;
+  for (int n = 0; n < nsteps; n++) {
+    int r = main3d_one(c);
+    if (r) return r;
+  }
+  return 0;
+}

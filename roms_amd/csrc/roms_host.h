@@ -1,0 +1,89 @@
+// roms_host.h -- host-side context of libroms_hip.so (shared by the translation units).
+#pragma once
+#include "roms_ctx.h"
+#include <string>
+#include <vector>
+
+#ifdef ROMS_CPU_EMU
+typedef void *kevent_t;
+#else
+typedef hipEvent_t kevent_t;
+#endif
+
+struct FieldDesc {
+  const char *name;
+  size_t offset;   // offsetof(Fields, name)
+  int kind;        // plane count rule, see field_planes()
+};
+
+enum { FK_2D = 0, FK_R, FK_W, FK_2Dx3, FK_2Dx2, FK_Rx2, FK_T, FK_Wx2, FK_2DxNT, FK_WxNAT, FK_TABR, FK_TABW };
+
+struct Region { double seconds; long calls; };
+
+struct roms_hip_ctx {
+  roms_hip_config cfg;
+  DGrid G;
+  Fields F;
+  kstream_t stream;
+  std::vector<void *> allocs;
+  roms_hip_stepping s;
+  bool profile;
+  Region regions[96];
+  kevent_t ev0, ev1;
+  double *d_diag;      // device scratch for diag reductions
+  double *h_diag;      // pinned host mirror
+  int nblk_diag;
+};
+
+// helpers (roms_hip.cpp)
+void ctx_sync_stepping(roms_hip_ctx *c);           // copy c->s into c->G
+int ctx_check(roms_hip_ctx *c, const char *what);  // hipGetLastError -> exit_flag style code
+void set_error(const std::string &msg);
+long field_elems(const roms_hip_ctx *c, int kind);
+const FieldDesc *find_field(const char *name);
+
+// halo / BC launcher (k_halo.h): nk planes starting at A
+enum { BC_NONE = 0, BC_R = 1, BC_U = 2, BC_V = 3 };
+struct HaloSpec { double *A; int nk; int bc; char gtype; };
+void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype);
+void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n);   // n <= 8 fields in one launch
+
+// region timing
+struct RegionTimer {
+  roms_hip_ctx *c; int id;
+  RegionTimer(roms_hip_ctx *c_, int id_);
+  ~RegionTimer();
+};
+
+// kernel groups (one translation unit each)
+int run_set_depth(roms_hip_ctx *c);
+int run_set_massflux(roms_hip_ctx *c);
+int run_rho_eos(roms_hip_ctx *c);
+int run_set_vbc(roms_hip_ctx *c);
+int run_ana_vmix(roms_hip_ctx *c);
+int run_set_data(roms_hip_ctx *c);
+int run_omega(roms_hip_ctx *c);
+int run_wvelocity(roms_hip_ctx *c, int ninp);
+int run_set_zeta(roms_hip_ctx *c);
+int run_ini_zeta(roms_hip_ctx *c);
+int run_ini_fields(roms_hip_ctx *c);
+int run_pre_step3d(roms_hip_ctx *c);
+int run_prsgrd(roms_hip_ctx *c);
+int run_t3dmix2(roms_hip_ctx *c);
+int run_uv3dmix2(roms_hip_ctx *c);
+int run_rhs3d_tile(roms_hip_ctx *c);
+int run_step2d(roms_hip_ctx *c);
+int run_step3d_uv(roms_hip_ctx *c);
+int run_step3d_t(roms_hip_ctx *c);
+int run_lmd_vmix(roms_hip_ctx *c);
+int run_bulk_flux(roms_hip_ctx *c);
+int run_diag(roms_hip_ctx *c, double *out);
+
+// pointer helpers for time levels
+static inline double *t_lev(roms_hip_ctx *c, int n, int itrc) {
+  return c->F.t + ((size_t)(n - 1) + 3 * (size_t)(itrc - 1)) * (size_t)c->G.nij * (size_t)c->G.N;
+}
+static inline double *uv_lev(roms_hip_ctx *c, double *q, int n) {
+  return q + (size_t)(n - 1) * (size_t)c->G.nij * (size_t)c->G.N;
+}
+static inline double *lev2d(roms_hip_ctx *c, double *q, int n) { return q + (size_t)(n - 1) * (size_t)c->G.nij; }

@@ -1,0 +1,166 @@
+"""ctypes binding of libroms_hip.so (C ABI: include/roms_hip.h)."""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libroms_hip.so")
+MAXT, MAXW = 4, 512
+
+A4, C2, C4, HSIMT, MPDATA, SPLINES, SPLIT_U3, U3 = range(1, 9)
+SCHEMES = dict(A4=A4, C2=C2, C4=C4, HSIMT=HSIMT, MPDATA=MPDATA, SPLINES=SPLINES, SU3=SPLIT_U3, U3=U3)
+OPTIONS = {name: 1 << k for k, name in enumerate(
+    ["UV_ADV", "UV_COR", "UV_VIS2", "TS_DIF2", "MIX_GEO_TS", "CURVGRID", "NONLIN_EOS", "UV_QDRAG",
+     "LMD_MIXING", "BULK_FLUXES", "SOLAR_SOURCE", "ANA_VMIX", "SALINITY", "SPHERICAL"])}
+OPTIONS.update(APP_UPWELLING=1 << 20, APP_BENCHMARK=1 << 21)
+
+
+class Config(C.Structure):
+    """roms_hip_config"""
+    _fields_ = [
+        ("abi_version", C.c_int), ("device", C.c_int),
+        ("Lm", C.c_int), ("Mm", C.c_int), ("N", C.c_int), ("NT", C.c_int), ("NAT", C.c_int),
+        ("Nghost", C.c_int), ("LBi", C.c_int), ("UBi", C.c_int), ("LBj", C.c_int), ("UBj", C.c_int),
+        ("NtileI", C.c_int), ("NtileJ", C.c_int), ("tile", C.c_int),
+        ("EWperiodic", C.c_int), ("NSperiodic", C.c_int), ("options", C.c_int),
+        ("hadv", C.c_int * MAXT), ("vadv", C.c_int * MAXT),
+        ("Istr", C.c_int), ("Iend", C.c_int), ("Jstr", C.c_int), ("Jend", C.c_int),
+        ("west_edge", C.c_int), ("east_edge", C.c_int), ("south_edge", C.c_int), ("north_edge", C.c_int),
+        ("ntfirst", C.c_int), ("ntstart", C.c_int), ("ndtfast", C.c_int), ("nfast", C.c_int),
+        ("ninfo", C.c_int),
+        ("dt", C.c_double), ("dtfast", C.c_double), ("weight", (C.c_double * (MAXW + 1)) * 2),
+        ("rho0", C.c_double), ("g", C.c_double), ("lambda_", C.c_double), ("gamma2", C.c_double),
+        ("Cp", C.c_double), ("R0", C.c_double), ("T0", C.c_double), ("S0", C.c_double),
+        ("Tcoef", C.c_double), ("Scoef", C.c_double), ("hc", C.c_double), ("Vtransform", C.c_int),
+        ("rdrg", C.c_double), ("rdrg2", C.c_double), ("Zob", C.c_double),
+        ("Akt_bak", C.c_double * MAXT), ("Akv_bak", C.c_double), ("dstart", C.c_double),
+        ("blk_ZQ", C.c_double), ("blk_ZT", C.c_double), ("blk_ZW", C.c_double), ("lmd_Jwt", C.c_int),
+        ("sc_r", C.c_double * 256), ("Cs_r", C.c_double * 256), ("sc_w", C.c_double * 257),
+        ("Cs_w", C.c_double * 257),
+    ]
+
+
+class Stepping(C.Structure):
+    """roms_hip_stepping"""
+    _fields_ = [("iic", C.c_int), ("iif", C.c_int), ("nstp", C.c_int), ("nnew", C.c_int),
+                ("nrhs", C.c_int), ("kstp", C.c_int), ("knew", C.c_int), ("krhs", C.c_int),
+                ("indx1", C.c_int), ("predictor", C.c_int), ("time", C.c_double)]
+
+
+KERNELS = ["set_depth", "set_massflux", "rho_eos", "set_vbc", "ana_vmix", "set_data", "omega", "set_zeta",
+           "ini_zeta", "ini_fields", "pre_step3d", "prsgrd", "t3dmix2", "uv3dmix2", "rhs3d_tile", "rhs3d",
+           "step2d", "step3d_uv", "step3d_t", "lmd_vmix", "bulk_flux"]
+
+EXPORTS = ["roms_hip_create", "roms_hip_destroy", "roms_hip_last_error", "roms_hip_abi_version",
+           "roms_hip_field_size", "roms_hip_upload", "roms_hip_download", "roms_hip_sync",
+           "roms_hip_set_stepping", "roms_hip_get_stepping", "roms_hip_wvelocity", "roms_hip_diag",
+           "roms_hip_start", "roms_hip_main3d", "roms_hip_profile", "roms_hip_region_seconds"] + \
+          ["roms_hip_" + k for k in KERNELS]
+
+
+class RomsHipError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Load the native library.  No fallback: raises if it is missing."""
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise RomsHipError(f"{path} not found: build it with roms_amd/build.py "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(path)
+    L.roms_hip_last_error.restype = C.c_char_p
+    L.roms_hip_field_size.restype = C.c_long
+    L.roms_hip_field_size.argtypes = [C.c_void_p, C.c_char_p]
+    L.roms_hip_upload.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long]
+    L.roms_hip_download.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long]
+    L.roms_hip_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.roms_hip_destroy.argtypes = [C.c_void_p]
+    L.roms_hip_sync.argtypes = [C.c_void_p]
+    L.roms_hip_set_stepping.argtypes = [C.c_void_p, C.POINTER(Stepping)]
+    L.roms_hip_get_stepping.argtypes = [C.c_void_p, C.POINTER(Stepping)]
+    L.roms_hip_wvelocity.argtypes = [C.c_void_p, C.c_int]
+    L.roms_hip_diag.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.roms_hip_start.argtypes = [C.c_void_p]
+    L.roms_hip_main3d.argtypes = [C.c_void_p, C.c_int]
+    L.roms_hip_profile.argtypes = [C.c_void_p, C.c_int]
+    L.roms_hip_region_seconds.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    for k in KERNELS:
+        getattr(L, "roms_hip_" + k).argtypes = [C.c_void_p]
+    return L
+
+
+class Context:
+    """One device context = one tile on one GPU (mirrors the reference's kernel(ng,tile) wrappers)."""
+
+    def __init__(self, cfg: Config, lib_path=None):
+        self.L = load(lib_path)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        self._ck(self.L.roms_hip_create(C.byref(cfg), C.byref(self.h)))
+        self.ni = cfg.UBi - cfg.LBi + 1
+        self.nj = cfg.UBj - cfg.LBj + 1
+
+    def _ck(self, r):
+        if r != 0:
+            msg = self.L.roms_hip_last_error()
+            raise RomsHipError(f"exit_flag={r}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if self.h:
+            self.L.roms_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def size(self, name):
+        n = self.L.roms_hip_field_size(self.h, name.encode())
+        if n < 0:
+            raise KeyError(name)
+        return n
+
+    def upload(self, name, a):
+        a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+        self._ck(self.L.roms_hip_upload(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+
+    def download(self, name):
+        a = np.empty(self.size(name), dtype=np.float64)
+        self._ck(self.L.roms_hip_download(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
+    def set_stepping(self, **kw):
+        s = self.get_stepping()
+        for k, v in kw.items():
+            setattr(s, k, v)
+        self._ck(self.L.roms_hip_set_stepping(self.h, C.byref(s)))
+
+    def get_stepping(self):
+        s = Stepping()
+        self._ck(self.L.roms_hip_get_stepping(self.h, C.byref(s)))
+        return s
+
+    def call(self, kernel, *args):
+        if kernel == "wvelocity":
+            self._ck(self.L.roms_hip_wvelocity(self.h, int(args[0])))
+        else:
+            self._ck(getattr(self.L, "roms_hip_" + kernel)(self.h))
+
+    def sync(self):
+        self._ck(self.L.roms_hip_sync(self.h))
+
+    def start(self):
+        self._ck(self.L.roms_hip_start(self.h))
+
+    def main3d(self, nsteps=1):
+        self._ck(self.L.roms_hip_main3d(self.h, int(nsteps)))
+
+    def diag(self):
+        out = (C.c_double * 16)()
+        self._ck(self.L.roms_hip_diag(self.h, out))
+        return list(out)[:12]
+
+    def profile(self, enable=True):
+        self._ck(self.L.roms_hip_profile(self.h, int(enable)))
+
+    def region(self, rid):
+        s, n = C.c_double(), C.c_long()
+        self._ck(self.L.roms_hip_region_seconds(self.h, rid, C.byref(s), C.byref(n)))
+        return s.value, n.value

@@ -83,3 +83,49 @@ def oracle_cfg(cs, hc, nfast, weight):
     c.blk_ZQ, c.blk_ZT, c.blk_ZW, c.lmd_Jwt = cs["blk_ZQ"], cs["blk_ZT"], cs["blk_ZW"], cs["lmd_Jwt"]
     c.cc1, c.cc2, c.cc3 = 0.25, 0.5, 1.0 / 12.0
     return c
+
+
+def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
+    """roms_hip_config for a single tile covering the domain (include/roms_hip.h)."""
+    from roms_amd import hiplib
+    c = hiplib.Config()
+    c.abi_version, c.device = 1, device
+    c.Lm, c.Mm, c.N, c.NT, c.NAT = cs["Lm"], cs["Mm"], cs["N"], 2, 2
+    hs = [SCHEME[x] for x in cs["hadv"]]
+    vs = [SCHEME[x] for x in cs["vadv"]]
+    c.Nghost = 3 if (hiplib.MPDATA in hs or hiplib.HSIMT in hs) else 2
+    Im = cs["Lm"] + ((cs["Lm"] + 2) // 2 - (cs["Lm"] + 1) // 2)
+    Jm = cs["Mm"] + ((cs["Mm"] + 2) // 2 - (cs["Mm"] + 1) // 2)
+    c.LBi, c.UBi = (-c.Nghost, Im + c.Nghost) if cs["EWperiodic"] else (0, Im + 1)
+    c.LBj, c.UBj = (-c.Nghost, Jm + c.Nghost) if cs["NSperiodic"] else (0, Jm + 1)
+    c.NtileI = c.NtileJ = 1
+    c.tile = 0
+    c.EWperiodic, c.NSperiodic = cs["EWperiodic"], cs["NSperiodic"]
+    opt = 0
+    for name in cs["options"]:
+        opt |= hiplib.OPTIONS[name]
+    c.options = opt
+    for i in range(2):
+        c.hadv[i], c.vadv[i] = hs[i], vs[i]
+    c.Istr, c.Iend, c.Jstr, c.Jend = 1, cs["Lm"], 1, cs["Mm"]
+    c.west_edge = c.east_edge = c.south_edge = c.north_edge = 1
+    c.ntfirst = c.ntstart = 1
+    c.ndtfast, c.nfast, c.ninfo = cs["ndtfast"], nfast, 0
+    c.dt = cs["dt"]
+    c.dtfast = cs["dt"] / float(cs["ndtfast"])
+    w = np.asarray(weight, dtype=np.float64).reshape(2, -1)
+    for k in range(w.shape[1]):
+        c.weight[0][k + 1] = w[0, k]
+        c.weight[1][k + 1] = w[1, k]
+    c.rho0, c.g, c.lambda_, c.gamma2, c.Cp = cs["rho0"], 9.81, 1.0, cs["gamma2"], 3985.0
+    c.R0, c.T0, c.S0, c.Tcoef, c.Scoef = cs["R0"], cs["T0"], cs["S0"], cs["Tcoef"], cs["Scoef"]
+    c.hc, c.Vtransform = hc, cs["Vtransform"]
+    c.rdrg, c.rdrg2, c.Zob = cs["rdrg"], cs["rdrg2"], cs["Zob"]
+    c.Akt_bak[0], c.Akt_bak[1], c.Akv_bak = cs["Akt_bak"][0], cs["Akt_bak"][1], cs["Akv_bak"]
+    c.dstart = cs["dstart"]
+    c.blk_ZQ, c.blk_ZT, c.blk_ZW, c.lmd_Jwt = cs["blk_ZQ"], cs["blk_ZT"], cs["blk_ZW"], cs["lmd_Jwt"]
+    for k in range(cs["N"]):
+        c.sc_r[k], c.Cs_r[k] = sc_r[k], Cs_r[k]
+    for k in range(cs["N"] + 1):
+        c.sc_w[k], c.Cs_w[k] = sc_w[k], Cs_w[k]
+    return c

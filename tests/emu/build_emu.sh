@@ -1,0 +1,24 @@
+#!/bin/bash
+# tests/emu/build_emu.sh -- DEVELOPMENT/TEST ONLY.
+# Compiles the HIP kernel sources of roms_amd/csrc with a host C++ compiler and
+# -DROMS_CPU_EMU (thread blocks and threads executed serially) into
+# tests/emu/libroms_hip_emu.so, so that kernel LOGIC can be unit-tested against the
+# oracle on machines without a GPU.  Not built by __graft_entry__.build(), never
+# loaded by the roms_amd package: the product has no CPU fallback.
+set -e
+HERE=$(cd "$(dirname "$0")" && pwd)
+SRC=$HERE/../../roms_amd/csrc
+OUT=$HERE/libroms_hip_emu.so
+DEFS="${ROMS_DEFS:-}"
+mkdir -p $HERE/obj
+objs=""
+for f in $SRC/*.cpp; do
+  o=$HERE/obj/$(basename ${f%.cpp}).o
+  if [ ! -f $o ] || [ $f -nt $o ] || [ -n "$(find $SRC -name '*.h' -newer $o)" ] || [ $HERE/../../include/roms_hip.h -nt $o ]; then
+    g++ -O2 -g -fPIC -std=c++17 -ffp-contract=off -DROMS_CPU_EMU $DEFS -Wall -Wno-unused-variable -Wno-unused-but-set-variable -c $f -o $o &
+  fi
+  objs="$objs $o"
+done
+wait
+g++ -shared -o $OUT $objs
+echo "built $OUT"
