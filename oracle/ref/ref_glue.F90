@@ -801,7 +801,9 @@
         F2('lhflx',FORCES(ng)%lhflx)
         F2('shflx',FORCES(ng)%shflx)
         F2('lrflx',FORCES(ng)%lrflx)
+#ifdef EMINUSP
         F2('evap',FORCES(ng)%evap)
+#endif
 #endif
       END SELECT
       END FUNCTION ref_field

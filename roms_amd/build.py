@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: no FMA contraction, so results are bit-comparable with the reference's
 # plain IEEE arithmetic (memory-bound kernels: no measurable cost).
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
-            "-Wno-unused-value", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+            "-Wno-unused-value", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-function"]
 
 
 def _newer(src_list, target):

@@ -1,0 +1,35 @@
+// g_diag.cpp -- diag(ng,tile): three ordered reduction kernels + 12 doubles to the host.
+#include "roms_host.h"
+#include "k_diag.h"
+#include <cstring>
+#include <cmath>
+
+int run_diag_async(roms_hip_ctx *c, double *d_out) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  DiagArgs a;
+  a.G = G;
+  a.F = c->F;
+  a.col = c->F.wrk3[0];                 // free at this point of the step (vert of wvelocity)
+  a.row = c->F.wrk3[0] + 8 * (size_t)G.nij;
+  a.out = d_out;
+  LAUNCH_THREAD(k_diag_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  LAUNCH_THREAD(k_diag_row, B.Iend - B.Istr + 1, 1, 1, c->stream, a);
+  LAUNCH_THREAD(k_diag_fin, 1, 1, 1, c->stream, a);
+  return 0;
+}
+
+int fetch_diag(roms_hip_ctx *c, const double *d_out, double *out);   // roms_hip.cpp
+
+int run_diag(roms_hip_ctx *c, double *out) {
+  int r = run_diag_async(c, c->d_diag);
+  if (r) return r;
+  r = fetch_diag(c, c->d_diag, out);
+  if (r) return r;
+  // blow-up test of diag.F:510-540
+  if (!(std::isfinite(out[0]) && std::isfinite(out[1])) || out[4] > 20.0) {
+    set_error("blow-up: KE/PE not finite or MaxSpeed > 20 m/s");
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,66 @@
+// g_rhs3d.cpp -- launch sequences of pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2.
+#include "roms_host.h"
+#include "k_rhs3d.h"
+
+static inline KArgs mk(roms_hip_ctx *c, int p0 = 0, int p1 = 0, int p2 = 0) {
+  KArgs a;
+  a.G = c->G;
+  a.F = c->F;
+  a.p0 = p0; a.p1 = p1; a.p2 = p2;
+  return a;
+}
+static inline size_t lds_sz(const DGrid &G) { return (size_t)(G.bw + 6) * (size_t)(G.bh + 6); }
+
+int run_swdk(roms_hip_ctx *c);            // g_lmd.cpp: solar penetration fractions into wrk3[5]
+int run_t3dmix2_geo(roms_hip_ctx *c);     // g_geo.cpp
+
+int run_pre_step3d(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  if (G.options & ROMS_SOLAR_SOURCE) { int r = run_swdk(c); if (r) return r; }
+  KArgs a = mk(c);
+  LAUNCH_COOP(k_pre_t3h, G.nbx, G.nby, G.N * G.NT, 256, 3 * lds_sz(G), c->stream, a);
+  LAUNCH_THREAD(k_pre_t3v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);
+  LAUNCH_THREAD(k_pre_new, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N, c->stream, a);
+  HaloSpec sp[ROMS_MAXT];
+  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, 3, it), G.N, BC_R, 'r'};   // t3dbc + exchange :1157-1171
+  launch_halo_multi(c, sp, G.NT);
+  return 0;
+}
+
+int run_prsgrd(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_prs_P, B.Iend - (B.IstrU - 1) + 1, B.Jend - (B.JstrV - 1) + 1, 1, c->stream, a);
+  LAUNCH_THREAD(k_prs_grad, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N, c->stream, a);
+  return 0;
+}
+
+int run_t3dmix2(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  if (!(G.options & ROMS_TS_DIF2)) return 0;
+  if (G.options & ROMS_MIX_GEO_TS) return run_t3dmix2_geo(c);
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_t3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N * G.NT, c->stream, a);
+  return 0;
+}
+
+int run_uv3dmix2(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  if (!(G.options & ROMS_UV_VIS2)) return 0;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  return 0;
+}
+
+int run_rhs3d_tile(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  KArgs a = mk(c);
+  LAUNCH_COOP(k_rhs3d_h, G.nbx, G.nby, G.N, 256, RHS3D_NLDS * lds_sz(G), c->stream, a);
+  LAUNCH_THREAD(k_rhs3d_v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  return 0;
+}

@@ -1,0 +1,51 @@
+// g_step3d.cpp -- launch sequences of step3d_uv and step3d_t.
+#include "roms_host.h"
+#include "k_step3d.h"
+
+static inline KArgs mk(roms_hip_ctx *c, int p0 = 0) {
+  KArgs a;
+  a.G = c->G;
+  a.F = c->F;
+  a.p0 = p0; a.p1 = 0; a.p2 = 0;
+  return a;
+}
+static inline size_t lds_sz(const DGrid &G) { return (size_t)(G.bw + 6) * (size_t)(G.bh + 6); }
+
+int run_step3d_t_mpdata(roms_hip_ctx *c);   // g_mpdata.cpp
+
+int run_step3d_uv(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  const int N = G.N, nnew = G.nnew;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_s3uv_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+  {
+    HaloSpec sp[2] = {{uv_lev(c, c->F.u, nnew), N, BC_U, 0}, {uv_lev(c, c->F.v, nnew), N, BC_V, 0}};   // u3dbc/v3dbc :1266,1271
+    launch_halo_multi(c, sp, 2);
+  }
+  LAUNCH_THREAD(k_s3uv_couple, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, c->stream, a);
+  {
+    HaloSpec sp[6] = {{uv_lev(c, c->F.u, nnew), N, BC_NONE, 'u'}, {uv_lev(c, c->F.v, nnew), N, BC_NONE, 'v'},
+                      {c->F.Huon, N, BC_NONE, 'u'},               {c->F.Hvom, N, BC_NONE, 'v'},
+                      {c->F.ubar, 2, BC_NONE, 'u'},               {c->F.vbar, 2, BC_NONE, 'v'}};   // :1763-1830
+    launch_halo_multi(c, sp, 6);
+  }
+  return 0;
+}
+
+int run_step3d_t(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  const int N = G.N, nnew = G.nnew;
+  bool any_mp = false;
+  for (int it = 0; it < G.NT; it++) any_mp |= (G.hadv[it] == ROMS_MPDATA || G.vadv[it] == ROMS_MPDATA);
+  if (any_mp) return run_step3d_t_mpdata(c);
+  KArgs a = mk(c);
+  // exchange of t(nnew) for HSIMT tracers (:420) only refreshes ghost points that are not read here
+  LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
+  LAUNCH_THREAD(k_s3t_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);
+  HaloSpec sp[ROMS_MAXT];
+  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, BC_R, 'r'};   // t3dbc :1858 + exchange :1920
+  launch_halo_multi(c, sp, G.NT);
+  return 0;
+}

@@ -1,0 +1,691 @@
+// k_rhs3d.h -- baroclinic right-hand sides: pre_step3d, prsgrd32, t3dmix2_s, uv3dmix2_s, rhs3d_tile.
+//
+//   k_pre_t3h      pre_step3d_tile T_LOOP1/K_LOOP   ROMS/Nonlinear/pre_step3d.F:357-625
+//   k_pre_t3v      pre_step3d_tile J_LOOP1          ROMS/Nonlinear/pre_step3d.F:634-852
+//   k_pre_new      pre_step3d_tile                  ROMS/Nonlinear/pre_step3d.F:855-1145
+//   k_prs_P, k_prs_grad  prsgrd32_tile              ROMS/Nonlinear/prsgrd32.h:246-430
+//   k_t3dmix2_s    t3dmix2_s_tile                   ROMS/Nonlinear/t3dmix2_s.h:89
+//   k_uv3dmix2_s   uv3dmix2_s_tile                  ROMS/Nonlinear/uv3dmix2_s.h:114
+//   k_rhs3d_h      rhs3d_tile K_LOOP                ROMS/Nonlinear/rhs3d.F:500-1000
+//   k_rhs3d_v      rhs3d_tile J_LOOP                ROMS/Nonlinear/rhs3d.F:1132-1918
+//
+// Horizontal flux stages: one block = one (sub-tile, level) with the reference's 2-D work arrays
+// in LDS.  Vertical stages: one thread per sigma-column, the k-recurrences streamed through
+// registers (every vertical flux of the supported schemes is a local function of <= 4 levels).
+#pragma once
+#include "roms_ctx.h"
+#include "k_diag3d.h"   // KArgs, index macros
+
+// -------------------------------------------------------------------------------------------
+// horizontal advective tracer flux stage, shared by pre_step3d (T = t(nstp)) and step3d_t
+// (T = t(3)).  On exit FX on (Istr:Iend+1, Jstr:Jend), FE on (Istr:Iend, Jstr:Jend+1).
+// wk is a third LDS array (curv / grad).  pre_step3d.F:357-534 == step3d_t.F:633-768.
+// -------------------------------------------------------------------------------------------
+KDEV void hadv_flux_lds(const DGrid &G, const TB &B, int scheme, const double *T, const double *Hu,
+                        const double *Hv, double *FX, double *FE, double *wk) {
+  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
+  const double eps = 1.0E-16;
+  if (scheme == ROMS_C2) {
+    KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend + 1) {
+      if (j <= Jend) FX[S2(i, j)] = Hu[X2(i, j)] * 0.5 * (T[X2(i - 1, j)] + T[X2(i, j)]);
+      if (i <= Iend) FE[S2(i, j)] = Hv[X2(i, j)] * 0.5 * (T[X2(i, j - 1)] + T[X2(i, j)]);
+    }
+    KSYNC();
+    return;
+  }
+  if (scheme == ROMS_MPDATA || scheme == ROMS_HSIMT) {
+    KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend + 1) {
+      if (j <= Jend) {
+        const double cff1 = KMAX(Hu[X2(i, j)], 0.0), cff2 = KMIN(Hu[X2(i, j)], 0.0);
+        FX[S2(i, j)] = cff1 * T[X2(i - 1, j)] + cff2 * T[X2(i, j)];
+      }
+      if (i <= Iend) {
+        const double cff1 = KMAX(Hv[X2(i, j)], 0.0), cff2 = KMIN(Hv[X2(i, j)], 0.0);
+        FE[S2(i, j)] = cff1 * T[X2(i, j - 1)] + cff2 * T[X2(i, j)];
+      }
+    }
+    KSYNC();
+    return;
+  }
+  const double cff1 = 1.0 / 6.0, cff2 = 1.0 / 3.0;
+  // ---- xi direction
+  KLOOP2(i, j, B.Istrm1, B.Iendp2, Jstr, Jend) FX[S2(i, j)] = T[X2(i, j)] - T[X2(i - 1, j)];
+  KSYNC();
+  if (!G.ewp) {
+    if (B.west) KLOOP1(j, Jstr, Jend) FX[S2(Istr - 1, j)] = FX[S2(Istr, j)];
+    if (B.east) KLOOP1(j, Jstr, Jend) FX[S2(Iend + 2, j)] = FX[S2(Iend + 1, j)];
+  }
+  KSYNC();
+  KLOOP2(i, j, Istr - 1, Iend + 1, Jstr, Jend) {
+    if (scheme == ROMS_U3) wk[S2(i, j)] = FX[S2(i + 1, j)] - FX[S2(i, j)];
+    else if (scheme == ROMS_A4) {
+      const double cff = 2.0 * FX[S2(i + 1, j)] * FX[S2(i, j)];
+      wk[S2(i, j)] = (cff > eps) ? cff / (FX[S2(i + 1, j)] + FX[S2(i, j)]) : 0.0;
+    } else wk[S2(i, j)] = 0.5 * (FX[S2(i + 1, j)] + FX[S2(i, j)]);
+  }
+  KSYNC();
+  KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend) {
+    if (scheme == ROMS_U3)
+      FX[S2(i, j)] = Hu[X2(i, j)] * 0.5 * (T[X2(i - 1, j)] + T[X2(i, j)]) -
+                     cff1 * (wk[S2(i - 1, j)] * KMAX(Hu[X2(i, j)], 0.0) + wk[S2(i, j)] * KMIN(Hu[X2(i, j)], 0.0));
+    else
+      FX[S2(i, j)] = Hu[X2(i, j)] * 0.5 * (T[X2(i - 1, j)] + T[X2(i, j)] - cff2 * (wk[S2(i, j)] - wk[S2(i - 1, j)]));
+  }
+  KSYNC();
+  // ---- eta direction
+  KLOOP2(i, j, Istr, Iend, B.Jstrm1, B.Jendp2) FE[S2(i, j)] = T[X2(i, j)] - T[X2(i, j - 1)];
+  KSYNC();
+  if (!G.nsp) {
+    if (B.south) KLOOP1(i, Istr, Iend) FE[S2(i, Jstr - 1)] = FE[S2(i, Jstr)];
+    if (B.north) KLOOP1(i, Istr, Iend) FE[S2(i, Jend + 2)] = FE[S2(i, Jend + 1)];
+  }
+  KSYNC();
+  KLOOP2(i, j, Istr, Iend, Jstr - 1, Jend + 1) {
+    if (scheme == ROMS_U3) wk[S2(i, j)] = FE[S2(i, j + 1)] - FE[S2(i, j)];
+    else if (scheme == ROMS_A4) {
+      const double cff = 2.0 * FE[S2(i, j + 1)] * FE[S2(i, j)];
+      wk[S2(i, j)] = (cff > eps) ? cff / (FE[S2(i, j + 1)] + FE[S2(i, j)]) : 0.0;
+    } else wk[S2(i, j)] = 0.5 * (FE[S2(i, j + 1)] + FE[S2(i, j)]);
+  }
+  KSYNC();
+  KLOOP2(i, j, Istr, Iend, Jstr, Jend + 1) {
+    if (scheme == ROMS_U3)
+      FE[S2(i, j)] = Hv[X2(i, j)] * 0.5 * (T[X2(i, j - 1)] + T[X2(i, j)]) -
+                     cff1 * (wk[S2(i, j - 1)] * KMAX(Hv[X2(i, j)], 0.0) + wk[S2(i, j)] * KMIN(Hv[X2(i, j)], 0.0));
+    else
+      FE[S2(i, j)] = Hv[X2(i, j)] * 0.5 * (T[X2(i, j - 1)] + T[X2(i, j)] - cff2 * (wk[S2(i, j)] - wk[S2(i, j - 1)]));
+  }
+  KSYNC();
+}
+
+// pre_step3d: t(3) = Hz*(cff1*t(nstp)+cff2*t(nnew)) - cff*pm*pn*div(FX,FE); grid.z = (k-1)+N*(itrc-1)
+COOP_KERNEL(k_pre_t3h, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB B = block_bounds(G, bx, by);
+  const int k = bz % G.N + 1, itrc = bz / G.N + 1;
+  const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
+  double *FX = lds, *FE = lds + sz, *wk = lds + 2 * sz;
+  const int hs = G.hadv[itrc - 1];
+  const double *T = F.t + XT(G.LBi, G.LBj, k, G.nstp, itrc);
+  hadv_flux_lds(G, B, hs, T, F.Huon + X3(G.LBi, G.LBj, k), F.Hvom + X3(G.LBi, G.LBj, k), FX, FE, wk);
+  const double Gamma = (hs == ROMS_MPDATA || hs == ROMS_HSIMT) ? 0.5 : 1.0 / 6.0;
+  double cff, cff1, cff2;
+  if (G.iic == G.ntfirst) { cff = 0.5 * G.dt; cff1 = 1.0; cff2 = 0.0; }
+  else { cff = (1.0 - Gamma) * G.dt; cff1 = 0.5 + Gamma; cff2 = 0.5 - Gamma; }
+  KLOOP2(i, j, B.Istr, B.Iend, B.Jstr, B.Jend)
+    F.t[XT(i, j, k, 3, itrc)] =
+        F.Hz[X3(i, j, k)] * (cff1 * F.t[XT(i, j, k, G.nstp, itrc)] + cff2 * F.t[XT(i, j, k, G.nnew, itrc)]) -
+        cff * F.pm[X2(i, j)] * F.pn[X2(i, j)] *
+            (FX[S2(i + 1, j)] - FX[S2(i, j)] + FE[S2(i, j + 1)] - FE[S2(i, j)]);
+}
+COOP_GLOBAL(k_pre_t3h, KArgs)
+
+// -------------------------------------------------------------------------------------------
+// vertical advective flux FC(k) = W(k)*T_w(k) as a LOCAL function of the column (k = 0..N).
+// Tc(kk) reads level kk of the advected tracer; Wc(kk) reads omega at w-level kk.
+// Schemes: C4/SPLIT_U3, C2, A4, first-order upstream (MPDATA/HSIMT predictor).
+// pre_step3d.F:634-809 / step3d_t.F:936-1186 (SPLINES is handled by k_vspline).
+// -------------------------------------------------------------------------------------------
+#define VFLUX_LOCAL(FCk, scheme, k, N, Tc, Wc)                                                      \
+  do {                                                                                             \
+    if ((k) <= 0 || (k) >= (N)) { FCk = 0.0; }                                                     \
+    else if ((scheme) == ROMS_C2) { FCk = Wc(k) * 0.5 * (Tc(k) + Tc((k) + 1)); }                   \
+    else if ((scheme) == ROMS_MPDATA || (scheme) == ROMS_HSIMT) {                                  \
+      const double c1_ = KMAX(Wc(k), 0.0), c2_ = KMIN(Wc(k), 0.0);                                 \
+      FCk = c1_ * Tc(k) + c2_ * Tc((k) + 1);                                                       \
+    } else if ((scheme) == ROMS_A4) {                                                              \
+      /* FC(kk)=T(kk+1)-T(kk), FC(0)=FC(1), FC(N)=FC(N-1); CF(kk)=harm(FC(kk),FC(kk-1)) */         \
+      const double eps_ = 1.0E-16;                                                                 \
+      const double d0_ = ((k) - 1 >= 1) ? Tc(k) - Tc((k) - 1) : Tc(2) - Tc(1);                     \
+      const double d1_ = Tc((k) + 1) - Tc(k);                                                      \
+      const double d2_ = ((k) + 1 <= (N) - 1) ? Tc((k) + 2) - Tc((k) + 1) : Tc(N) - Tc((N) - 1);   \
+      const double p0_ = 2.0 * d1_ * d0_, p1_ = 2.0 * d2_ * d1_;                                   \
+      const double CFk_ = (p0_ > eps_) ? p0_ / (d1_ + d0_) : 0.0;                                  \
+      const double CFk1_ = (p1_ > eps_) ? p1_ / (d2_ + d1_) : 0.0;                                 \
+      FCk = Wc(k) * 0.5 * (Tc(k) + Tc((k) + 1) - (1.0 / 3.0) * (CFk1_ - CFk_));                    \
+    } else { /* CENTERED4, SPLIT_U3 */                                                             \
+      const double c1_ = 0.5, c2_ = 7.0 / 12.0, c3_ = 1.0 / 12.0;                                  \
+      if ((k) == 1) FCk = Wc(1) * (c1_ * Tc(1) + c2_ * Tc(2) - c3_ * Tc(3));                       \
+      else if ((k) == (N) - 1) FCk = Wc((N) - 1) * (c1_ * Tc(N) + c2_ * Tc((N) - 1) - c3_ * Tc((N) - 2)); \
+      else FCk = Wc(k) * (c2_ * (Tc(k) + Tc((k) + 1)) - c3_ * (Tc((k) - 1) + Tc((k) + 2)));       \
+    }                                                                                              \
+  } while (0)
+
+// Parabolic-spline vertical flux (SPLINES): tridiagonal recurrence; FC kept in the 3-D work
+// array wrk3[3] (w-levels), CF in wrk3[4].  corrector = 0: pre_step3d end conditions
+// (1.5, 0.5, 3, 2); 1: step3d_t (2, 1, 2, 1).
+KDEV void vspline_flux(const DGrid &G, const Fields &F, int i, int j, const double *T /*level 1*/, int corrector) {
+  const int N = G.N;
+  double *FC = F.wrk3[3], *CF = F.wrk3[4];
+  const double a0 = corrector ? 2.0 : 1.5, c1 = corrector ? 1.0 : 0.5;
+  const double aN = corrector ? 2.0 : 3.0, dN = corrector ? 1.0 : 2.0;
+  FC[XW(i, j, 0)] = a0 * T[X3(i, j, 1)];
+  CF[XW(i, j, 1)] = c1;
+  for (int k = 1; k <= N - 1; k++) {
+    const double cff = 1.0 / (2.0 * F.Hz[X3(i, j, k)] + F.Hz[X3(i, j, k + 1)] * (2.0 - CF[XW(i, j, k)]));
+    CF[XW(i, j, k + 1)] = cff * F.Hz[X3(i, j, k)];
+    FC[XW(i, j, k)] = cff * (3.0 * (F.Hz[X3(i, j, k)] * T[X3(i, j, k + 1)] + F.Hz[X3(i, j, k + 1)] * T[X3(i, j, k)]) -
+                             F.Hz[X3(i, j, k + 1)] * FC[XW(i, j, k - 1)]);
+  }
+  FC[XW(i, j, N)] = (aN * T[X3(i, j, N)] - FC[XW(i, j, N - 1)]) / (dN - CF[XW(i, j, N)]);
+  for (int k = N - 1; k >= 0; k--) {
+    FC[XW(i, j, k)] = FC[XW(i, j, k)] - CF[XW(i, j, k + 1)] * FC[XW(i, j, k + 1)];
+    FC[XW(i, j, k + 1)] = F.W[XW(i, j, k + 1)] * FC[XW(i, j, k + 1)];
+  }
+  FC[XW(i, j, N)] = 0.0;
+  FC[XW(i, j, 0)] = 0.0;
+}
+
+// pre_step3d vertical part: one thread per column and tracer; index space (Istr:Iend,Jstr:Jend,NT)
+THREAD_KERNEL(k_pre_t3v, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = G.N;
+  const int vs = G.vadv[itrc - 1];
+  const double *T = F.t + XT(G.LBi, G.LBj, 1, G.nstp, itrc);
+  double *t3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
+  const double Gamma = (vs == ROMS_MPDATA || vs == ROMS_HSIMT) ? 0.5 : 1.0 / 6.0;
+  const double cff = (G.iic == G.ntfirst) ? 0.5 * G.dt : (1.0 - Gamma) * G.dt;
+  const double pmn = F.pm[X2(i, j)] * F.pn[X2(i, j)];
+  if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, T, 0);
+#define Tc(kk) T[X3(i, j, kk)]
+#define Wc(kk) F.W[XW(i, j, kk)]
+  double FCm = 0.0;   // FC(k-1)
+  for (int k = 1; k <= N; k++) {
+    double FCk;
+    if (vs == ROMS_SPLINES) FCk = F.wrk3[3][XW(i, j, k)];
+    else VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
+    const double DC = 1.0 / (F.Hz[X3(i, j, k)] -
+                             cff * pmn * (F.Huon[X3(i + 1, j, k)] - F.Huon[X3(i, j, k)] + F.Hvom[X3(i, j + 1, k)] -
+                                          F.Hvom[X3(i, j, k)] + (F.W[XW(i, j, k)] - F.W[XW(i, j, k - 1)])));
+    const double cff1 = cff * pmn;
+    t3[X3(i, j, k)] = DC * (t3[X3(i, j, k)] - cff1 * (FCk - FCm));
+    FCm = FCk;
+  }
+#undef Tc
+#undef Wc
+}
+THREAD_GLOBAL(k_pre_t3v, KArgs)
+
+// pre_step3d: start of t(nnew), u(nnew), v(nnew) -- point-wise in 3-D (all vertical fluxes local);
+// index space (min(Istr,IstrU):Iend, Jstr:Jend, 1:N); F.wrk3[5] = swdk when SOLAR_SOURCE
+THREAD_KERNEL(k_pre_new, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, N = G.N;
+  const int nstp = G.nstp, nnew = G.nnew, nrhs = G.nrhs, indx = 3 - G.nrhs;
+  const double dt = G.dt;
+  const double cff3 = dt * (1.0 - G.lambda);
+  // ---- tracers :855-935
+  for (int itrc = 1; itrc <= G.NT; itrc++) {
+    const int ltrc = KMIN(G.NAT, itrc);
+    double FCk, FCm;
+#define TFLUX(FCo, kk)                                                                                         \
+  do {                                                                                                         \
+    if ((kk) == 0) FCo = dt * F.btflx[X2T(i, j, itrc)];                                                        \
+    else if ((kk) == N) FCo = dt * F.stflx[X2T(i, j, itrc)];                                                   \
+    else {                                                                                                     \
+      const double c_ = 1.0 / (F.z_r[X3(i, j, (kk) + 1)] - F.z_r[X3(i, j, kk)]);                               \
+      FCo = cff3 * c_ * F.Akt[XW4(i, j, kk, ltrc)] * (F.t[XT(i, j, (kk) + 1, nstp, itrc)] - F.t[XT(i, j, kk, nstp, itrc)]); \
+      if ((G.options & ROMS_LMD_MIXING) && itrc <= G.NAT)                                                      \
+        FCo = FCo - dt * F.Akt[XW4(i, j, kk, itrc)] * F.ghats[XW4(i, j, kk, itrc)];                            \
+      if ((G.options & ROMS_SOLAR_SOURCE) && itrc == 1) FCo = FCo + dt * F.srflx[X2(i, j)] * F.wrk3[5][XW(i, j, kk)]; \
+    }                                                                                                          \
+  } while (0)
+    TFLUX(FCk, k);
+    TFLUX(FCm, k - 1);
+#undef TFLUX
+    const double cff1 = F.Hz[X3(i, j, k)] * F.t[XT(i, j, k, nstp, itrc)];
+    const double cff2 = FCk - FCm;
+    F.t[XT(i, j, k, nnew, itrc)] = cff1 + cff2;
+  }
+  // ---- u :943-1040
+  if (i >= B.IstrU) {
+    double FCk, FCm;
+#define UFLUX(FCo, kk)                                                                                         \
+  do {                                                                                                         \
+    if ((kk) == 0) FCo = dt * F.bustr[X2(i, j)];                                                               \
+    else if ((kk) == N) FCo = dt * F.sustr[X2(i, j)];                                                          \
+    else {                                                                                                     \
+      const double c_ = 1.0 / (F.z_r[X3(i, j, (kk) + 1)] + F.z_r[X3(i - 1, j, (kk) + 1)] - F.z_r[X3(i, j, kk)] - \
+                               F.z_r[X3(i - 1, j, kk)]);                                                       \
+      FCo = cff3 * c_ * (F.u[X4(i, j, (kk) + 1, nstp)] - F.u[X4(i, j, kk, nstp)]) *                            \
+            (F.Akv[XW(i, j, kk)] + F.Akv[XW(i - 1, j, kk)]);                                                   \
+    }                                                                                                          \
+  } while (0)
+    UFLUX(FCk, k);
+    UFLUX(FCm, k - 1);
+#undef UFLUX
+    const double cff = dt * 0.25;
+    const double DC0 = cff * (F.pm[X2(i, j)] + F.pm[X2(i - 1, j)]) * (F.pn[X2(i, j)] + F.pn[X2(i - 1, j)]);
+    const double hu = F.u[X4(i, j, k, nstp)] * 0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i - 1, j, k)]);
+    const double dF = FCk - FCm;
+    double un;
+    if (G.iic == G.ntfirst) un = hu + dF;
+    else if (G.iic == G.ntfirst + 1) {
+      const double c3 = 0.5 * DC0;
+      un = hu - c3 * F.ru[XW4(i, j, k, indx)] + dF;
+    } else {
+      const double c1 = 5.0 / 12.0, c2 = 16.0 / 12.0;
+      un = hu + DC0 * (c1 * F.ru[XW4(i, j, k, nrhs)] - c2 * F.ru[XW4(i, j, k, indx)]) + dF;
+    }
+    F.u[X4(i, j, k, nnew)] = un;
+  }
+  // ---- v :1045-1145
+  if (j >= B.JstrV) {
+    double FCk, FCm;
+#define VFLUXM(FCo, kk)                                                                                        \
+  do {                                                                                                         \
+    if ((kk) == 0) FCo = dt * F.bvstr[X2(i, j)];                                                               \
+    else if ((kk) == N) FCo = dt * F.svstr[X2(i, j)];                                                          \
+    else {                                                                                                     \
+      const double c_ = 1.0 / (F.z_r[X3(i, j, (kk) + 1)] + F.z_r[X3(i, j - 1, (kk) + 1)] - F.z_r[X3(i, j, kk)] - \
+                               F.z_r[X3(i, j - 1, kk)]);                                                       \
+      FCo = cff3 * c_ * (F.v[X4(i, j, (kk) + 1, nstp)] - F.v[X4(i, j, kk, nstp)]) *                            \
+            (F.Akv[XW(i, j, kk)] + F.Akv[XW(i, j - 1, kk)]);                                                   \
+    }                                                                                                          \
+  } while (0)
+    VFLUXM(FCk, k);
+    VFLUXM(FCm, k - 1);
+#undef VFLUXM
+    const double cff = dt * 0.25;
+    const double DC0 = cff * (F.pm[X2(i, j)] + F.pm[X2(i, j - 1)]) * (F.pn[X2(i, j)] + F.pn[X2(i, j - 1)]);
+    const double hv = F.v[X4(i, j, k, nstp)] * 0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i, j - 1, k)]);
+    const double dF = FCk - FCm;
+    double vn;
+    if (G.iic == G.ntfirst) vn = hv + dF;
+    else if (G.iic == G.ntfirst + 1) {
+      const double c3 = 0.5 * DC0;
+      vn = hv - c3 * F.rv[XW4(i, j, k, indx)] + dF;
+    } else {
+      const double c1 = 5.0 / 12.0, c2 = 16.0 / 12.0;
+      vn = hv + DC0 * (c1 * F.rv[XW4(i, j, k, nrhs)] - c2 * F.rv[XW4(i, j, k, indx)]) + dF;
+    }
+    F.v[X4(i, j, k, nnew)] = vn;
+  }
+}
+THREAD_GLOBAL(k_pre_new, KArgs)
+
+// -------------------------------------------------------------------------------- prsgrd32
+// P(i,j,k) into F.wrk3[1]; one thread per column of (IstrU-1:Iend, JstrV-1:Jend)
+THREAD_KERNEL(k_prs_P, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.IstrU - 1 + gx, j = G.T.JstrV - 1 + gy, N = G.N;
+  const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0, eps = 1.0E-10;
+  const double g = G.g, GRho = g / G.rho0, HalfGRho = 0.5 * GRho;
+  const double *rho = F.rho, *z_r = F.z_r, *z_w = F.z_w;
+  double *P = F.wrk3[1];
+  // raw differences dR(kk)=rho(kk+1)-rho(kk), kk=1..N-1; dR(N)=dR(N-1); dR(0)=dR(1)
+#define RAWR(kk) ((kk) >= N ? rho[X3(i, j, N)] - rho[X3(i, j, N - 1)] : ((kk) <= 0 ? rho[X3(i, j, 2)] - rho[X3(i, j, 1)] : rho[X3(i, j, (kk) + 1)] - rho[X3(i, j, kk)]))
+#define RAWZ(kk) ((kk) >= N ? z_r[X3(i, j, N)] - z_r[X3(i, j, N - 1)] : ((kk) <= 0 ? z_r[X3(i, j, 2)] - z_r[X3(i, j, 1)] : z_r[X3(i, j, (kk) + 1)] - z_r[X3(i, j, kk)]))
+  // harmonic means, level kk in 1..N: dR(kk) <- harm(raw(kk), raw(kk-1))
+#define HARMR(out, kk) do { const double r1_ = RAWR(kk), r0_ = RAWR((kk) - 1); const double c_ = 2.0 * r1_ * r0_; out = (c_ > eps) ? c_ / (r1_ + r0_) : 0.0; } while (0)
+#define HARMZ(out, kk) do { const double z1_ = RAWZ(kk), z0_ = RAWZ((kk) - 1); out = 2.0 * z1_ * z0_ / (z1_ + z0_); } while (0)
+  const double cff1 = 1.0 / (z_r[X3(i, j, N)] - z_r[X3(i, j, N - 1)]);
+  const double cff2 = 0.5 * (rho[X3(i, j, N)] - rho[X3(i, j, N - 1)]) * (z_w[XW(i, j, N)] - z_r[X3(i, j, N)]) * cff1;
+  double Pk = g * z_w[XW(i, j, N)] + GRho * (rho[X3(i, j, N)] + cff2) * (z_w[XW(i, j, N)] - z_r[X3(i, j, N)]);
+  P[X3(i, j, N)] = Pk;
+  double dR1, dZ1;   // level k+1
+  HARMR(dR1, N);
+  HARMZ(dZ1, N);
+  for (int k = N - 1; k >= 1; k--) {
+    double dR0, dZ0;
+    HARMR(dR0, k);
+    HARMZ(dZ0, k);
+    Pk = Pk + HalfGRho * ((rho[X3(i, j, k + 1)] + rho[X3(i, j, k)]) * (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]) -
+                          OneFifth * ((dR1 - dR0) * (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)] - OneTwelfth * (dZ1 + dZ0)) -
+                                      (dZ1 - dZ0) * (rho[X3(i, j, k + 1)] - rho[X3(i, j, k)] - OneTwelfth * (dR1 + dR0))));
+    P[X3(i, j, k)] = Pk;
+    dR1 = dR0;
+    dZ1 = dZ0;
+  }
+#undef RAWR
+#undef RAWZ
+#undef HARMR
+#undef HARMZ
+}
+THREAD_GLOBAL(k_prs_P, KArgs)
+
+// ru,rv(nrhs) from P: point-wise 3-D; index space (min(IstrU,Istr):Iend, min(Jstr,JstrV):Jend, 1:N)
+THREAD_KERNEL(k_prs_grad, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, nrhs = G.nrhs;
+  const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0, eps = 1.0E-10;
+  const double HalfGRho = 0.5 * (G.g / G.rho0);
+  const double *rho = F.rho, *z_r = F.z_r, *Hz = F.Hz, *P = F.wrk3[1];
+  if (i >= B.IstrU) {
+    // aux(ii)=z_r(ii)-z_r(ii-1), FC(ii)=rho(ii)-rho(ii-1); dZx(ii)=harm(aux(ii),aux(ii+1)) ...
+    const double am = z_r[X3(i - 1, j, k)] - z_r[X3(i - 2, j, k)], a0 = z_r[X3(i, j, k)] - z_r[X3(i - 1, j, k)],
+                 ap = z_r[X3(i + 1, j, k)] - z_r[X3(i, j, k)];
+    const double fm = rho[X3(i - 1, j, k)] - rho[X3(i - 2, j, k)], f0 = rho[X3(i, j, k)] - rho[X3(i - 1, j, k)],
+                 fp = rho[X3(i + 1, j, k)] - rho[X3(i, j, k)];
+    double dZx0, dZxm, dRx0, dRxm, cff, cff1, cff2;
+    cff = 2.0 * a0 * ap;
+    if (cff > eps) { cff1 = 1.0 / (a0 + ap); dZx0 = cff * cff1; } else dZx0 = 0.0;
+    cff1 = 2.0 * f0 * fp;
+    if (cff1 > eps) { cff2 = 1.0 / (f0 + fp); dRx0 = cff1 * cff2; } else dRx0 = 0.0;
+    cff = 2.0 * am * a0;
+    if (cff > eps) { cff1 = 1.0 / (am + a0); dZxm = cff * cff1; } else dZxm = 0.0;
+    cff1 = 2.0 * fm * f0;
+    if (cff1 > eps) { cff2 = 1.0 / (fm + f0); dRxm = cff1 * cff2; } else dRxm = 0.0;
+    F.ru[XW4(i, j, k, nrhs)] =
+        F.on_u[X2(i, j)] * 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]) *
+        (P[X3(i - 1, j, k)] - P[X3(i, j, k)] -
+         HalfGRho * ((rho[X3(i, j, k)] + rho[X3(i - 1, j, k)]) * (z_r[X3(i, j, k)] - z_r[X3(i - 1, j, k)]) -
+                     OneFifth * ((dRx0 - dRxm) * (z_r[X3(i, j, k)] - z_r[X3(i - 1, j, k)] - OneTwelfth * (dZx0 + dZxm)) -
+                                 (dZx0 - dZxm) * (rho[X3(i, j, k)] - rho[X3(i - 1, j, k)] - OneTwelfth * (dRx0 + dRxm)))));
+  }
+  if (j >= B.JstrV) {
+    const double am = z_r[X3(i, j - 1, k)] - z_r[X3(i, j - 2, k)], a0 = z_r[X3(i, j, k)] - z_r[X3(i, j - 1, k)],
+                 ap = z_r[X3(i, j + 1, k)] - z_r[X3(i, j, k)];
+    const double fm = rho[X3(i, j - 1, k)] - rho[X3(i, j - 2, k)], f0 = rho[X3(i, j, k)] - rho[X3(i, j - 1, k)],
+                 fp = rho[X3(i, j + 1, k)] - rho[X3(i, j, k)];
+    double dZx0, dZxm, dRx0, dRxm, cff, cff1, cff2;
+    cff = 2.0 * a0 * ap;
+    if (cff > eps) { cff1 = 1.0 / (a0 + ap); dZx0 = cff * cff1; } else dZx0 = 0.0;
+    cff1 = 2.0 * f0 * fp;
+    if (cff1 > eps) { cff2 = 1.0 / (f0 + fp); dRx0 = cff1 * cff2; } else dRx0 = 0.0;
+    cff = 2.0 * am * a0;
+    if (cff > eps) { cff1 = 1.0 / (am + a0); dZxm = cff * cff1; } else dZxm = 0.0;
+    cff1 = 2.0 * fm * f0;
+    if (cff1 > eps) { cff2 = 1.0 / (fm + f0); dRxm = cff1 * cff2; } else dRxm = 0.0;
+    F.rv[XW4(i, j, k, nrhs)] =
+        F.om_v[X2(i, j)] * 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]) *
+        (P[X3(i, j - 1, k)] - P[X3(i, j, k)] -
+         HalfGRho * ((rho[X3(i, j, k)] + rho[X3(i, j - 1, k)]) * (z_r[X3(i, j, k)] - z_r[X3(i, j - 1, k)]) -
+                     OneFifth * ((dRx0 - dRxm) * (z_r[X3(i, j, k)] - z_r[X3(i, j - 1, k)] - OneTwelfth * (dZx0 + dZxm)) -
+                                 (dZx0 - dZxm) * (rho[X3(i, j, k)] - rho[X3(i, j - 1, k)] - OneTwelfth * (dRx0 + dRxm)))));
+  }
+}
+THREAD_GLOBAL(k_prs_grad, KArgs)
+
+// ------------------------------------------------------------------------------- t3dmix2_s
+// point-wise 3-D; index space (Istr:Iend, Jstr:Jend, N*NT)
+THREAD_KERNEL(k_t3dmix2_s, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz % G.N + 1, itrc = gz / G.N + 1;
+  const int nrhs = G.nrhs, nnew = G.nnew;
+  const double *Hz = F.Hz, *diff2 = F.diff2;
+#define FXm(ii) (0.25 * (diff2[X2T(ii, j, itrc)] + diff2[X2T((ii) - 1, j, itrc)]) * F.pmon_u[X2(ii, j)] * \
+                 (Hz[X3(ii, j, k)] + Hz[X3((ii) - 1, j, k)]) * (F.t[XT(ii, j, k, nrhs, itrc)] - F.t[XT((ii) - 1, j, k, nrhs, itrc)]))
+#define FEm(jj) (0.25 * (diff2[X2T(i, jj, itrc)] + diff2[X2T(i, (jj) - 1, itrc)]) * F.pnom_v[X2(i, jj)] * \
+                 (Hz[X3(i, jj, k)] + Hz[X3(i, (jj) - 1, k)]) * (F.t[XT(i, jj, k, nrhs, itrc)] - F.t[XT(i, (jj) - 1, k, nrhs, itrc)]))
+  const double cff = G.dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
+  const double cff1 = cff * (FXm(i + 1) - FXm(i));
+  const double cff2 = cff * (FEm(j + 1) - FEm(j));
+  const double cff3 = cff1 + cff2;
+  F.t[XT(i, j, k, nnew, itrc)] = F.t[XT(i, j, k, nnew, itrc)] + cff3;
+#undef FXm
+#undef FEm
+}
+THREAD_GLOBAL(k_t3dmix2_s, KArgs)
+
+// ------------------------------------------------------------------------------ uv3dmix2_s
+// One thread per column (the rufrc/rvfrc sums run over k in order); index space
+// (min(IstrU,Istr):Iend, min(Jstr,JstrV):Jend).  Stress-tensor components at rho (R) and psi (P)
+// points are evaluated in-line.
+THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs, nnew = G.nnew;
+  const double *pm = F.pm, *pn = F.pn, *Hz = F.Hz;
+  const double *u = F.u + (size_t)(nrhs - 1) * G.nij * N, *v = F.v + (size_t)(nrhs - 1) * G.nij * N;
+  const bool do_u = i >= B.IstrU, do_v = j >= B.JstrV;
+  double ruf = do_u ? F.rufrc[X2(i, j)] : 0.0, rvf = do_v ? F.rvfrc[X2(i, j)] : 0.0;
+  for (int k = 1; k <= N; k++) {
+    // cff at rho point (ii,jj) and at psi point (ii,jj)
+#define CFFR(ii, jj)                                                                                                   \
+  (Hz[X3(ii, jj, k)] * 0.5 *                                                                                           \
+   (F.pmon_r[X2(ii, jj)] * ((pn[X2(ii, jj)] + pn[X2((ii) + 1, jj)]) * u[X3((ii) + 1, jj, k)] -                          \
+                            (pn[X2((ii) - 1, jj)] + pn[X2(ii, jj)]) * u[X3(ii, jj, k)]) -                               \
+    F.pnom_r[X2(ii, jj)] * ((pm[X2(ii, jj)] + pm[X2(ii, (jj) + 1)]) * v[X3(ii, (jj) + 1, k)] -                          \
+                            (pm[X2(ii, (jj) - 1)] + pm[X2(ii, jj)]) * v[X3(ii, jj, k)])))
+#define CFFP(ii, jj)                                                                                                   \
+  (0.125 * (Hz[X3((ii) - 1, jj, k)] + Hz[X3(ii, jj, k)] + Hz[X3((ii) - 1, (jj) - 1, k)] + Hz[X3(ii, (jj) - 1, k)]) *    \
+   (F.pmon_p[X2(ii, jj)] * ((pn[X2(ii, (jj) - 1)] + pn[X2(ii, jj)]) * v[X3(ii, jj, k)] -                                \
+                            (pn[X2((ii) - 1, (jj) - 1)] + pn[X2((ii) - 1, jj)]) * v[X3((ii) - 1, jj, k)]) +             \
+    F.pnom_p[X2(ii, jj)] * ((pm[X2((ii) - 1, jj)] + pm[X2(ii, jj)]) * u[X3(ii, jj, k)] -                                \
+                            (pm[X2((ii) - 1, (jj) - 1)] + pm[X2(ii, (jj) - 1)]) * u[X3(ii, (jj) - 1, k)])))
+#define UFXr(ii, jj) (F.on_r[X2(ii, jj)] * F.on_r[X2(ii, jj)] * F.visc2_r[X2(ii, jj)] * CFFR(ii, jj))
+#define VFEr(ii, jj) (F.om_r[X2(ii, jj)] * F.om_r[X2(ii, jj)] * F.visc2_r[X2(ii, jj)] * CFFR(ii, jj))
+#define UFEp(ii, jj) (F.om_p[X2(ii, jj)] * F.om_p[X2(ii, jj)] * F.visc2_p[X2(ii, jj)] * CFFP(ii, jj))
+#define VFXp(ii, jj) (F.on_p[X2(ii, jj)] * F.on_p[X2(ii, jj)] * F.visc2_p[X2(ii, jj)] * CFFP(ii, jj))
+    if (do_u) {
+      const double cff = G.dt * 0.25 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (pn[X2(i - 1, j)] + pn[X2(i, j)]);
+      const double cff1 = 0.5 * (pn[X2(i - 1, j)] + pn[X2(i, j)]) * (UFXr(i, j) - UFXr(i - 1, j));
+      const double cff2 = 0.5 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (UFEp(i, j + 1) - UFEp(i, j));
+      const double cff3 = cff * (cff1 + cff2);
+      ruf = ruf + cff1 + cff2;
+      F.u[X4(i, j, k, nnew)] = F.u[X4(i, j, k, nnew)] + cff3;
+    }
+    if (do_v) {
+      const double cff = G.dt * 0.25 * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]);
+      const double cff1 = 0.5 * (pn[X2(i, j - 1)] + pn[X2(i, j)]) * (VFXp(i + 1, j) - VFXp(i, j));
+      const double cff2 = 0.5 * (pm[X2(i, j - 1)] + pm[X2(i, j)]) * (VFEr(i, j) - VFEr(i, j - 1));
+      const double cff3 = cff * (cff1 - cff2);
+      rvf = rvf + cff1 - cff2;
+      F.v[X4(i, j, k, nnew)] = F.v[X4(i, j, k, nnew)] + cff3;
+    }
+#undef CFFR
+#undef CFFP
+#undef UFXr
+#undef VFEr
+#undef UFEp
+#undef VFXp
+  }
+  if (do_u) F.rufrc[X2(i, j)] = ruf;
+  if (do_v) F.rvfrc[X2(i, j)] = rvf;
+}
+THREAD_GLOBAL(k_uv3dmix2_s, KArgs)
+
+// -------------------------------------------------------------------------------- rhs3d_tile
+// K_LOOP: Coriolis, curvilinear terms, third-order upstream horizontal advection of momentum.
+// One block = (sub-tile, k); 8 LDS arrays (the reference's 14 after aliasing).
+#define RHS3D_NLDS 8
+COOP_KERNEL(k_rhs3d_h, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB B = block_bounds(G, bx, by);
+  const int k = bz + 1, nrhs = G.nrhs, N = G.N;
+  const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
+  double *UFx = lds, *UFe = lds + sz, *VFx = lds + 2 * sz, *VFe = lds + 3 * sz;
+  double *w0 = lds + 4 * sz, *w1 = lds + 5 * sz, *w2 = lds + 6 * sz, *w3 = lds + 7 * sz;
+  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend, IstrU = B.IstrU, JstrV = B.JstrV;
+  const double Gadv = -0.25;
+  const double *u = F.u + (size_t)(nrhs - 1) * G.nij * N + (size_t)(k - 1) * G.nij;   // plane
+  const double *v = F.v + (size_t)(nrhs - 1) * G.nij * N + (size_t)(k - 1) * G.nij;
+  const double *Hu = F.Huon + (size_t)(k - 1) * G.nij, *Hv = F.Hvom + (size_t)(k - 1) * G.nij;
+  const double *Hzk = F.Hz + (size_t)(k - 1) * G.nij;
+  double *ru = F.ru + (size_t)(nrhs - 1) * G.nij * (N + 1) + (size_t)k * G.nij;
+  double *rv = F.rv + (size_t)(nrhs - 1) * G.nij * (N + 1) + (size_t)k * G.nij;
+  // the r.h.s. increments are accumulated in registers per owned point in the reference's order
+  if (G.options & ROMS_UV_COR) {
+    KLOOP2(i, j, IstrU - 1, Iend, JstrV - 1, Jend) {
+      const double cff = 0.5 * Hzk[X2(i, j)] * F.fomn[X2(i, j)];
+      UFx[S2(i, j)] = cff * (v[X2(i, j)] + v[X2(i, j + 1)]);
+      VFe[S2(i, j)] = cff * (u[X2(i, j)] + u[X2(i + 1, j)]);
+    }
+    KSYNC();
+    KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
+      if (i >= IstrU) { const double cff1 = 0.5 * (UFx[S2(i, j)] + UFx[S2(i - 1, j)]); ru[X2(i, j)] = ru[X2(i, j)] + cff1; }
+      if (j >= JstrV) { const double cff1 = 0.5 * (VFe[S2(i, j)] + VFe[S2(i, j - 1)]); rv[X2(i, j)] = rv[X2(i, j)] - cff1; }
+    }
+    KSYNC();
+  }
+  if ((G.options & ROMS_CURVGRID) && (G.options & ROMS_UV_ADV)) {
+    KLOOP2(i, j, IstrU - 1, Iend, JstrV - 1, Jend) {
+      const double cff1 = 0.5 * (v[X2(i, j)] + v[X2(i, j + 1)]);
+      const double cff2 = 0.5 * (u[X2(i, j)] + u[X2(i + 1, j)]);
+      const double cff3 = cff1 * F.dndx[X2(i, j)];
+      const double cff4 = cff2 * F.dmde[X2(i, j)];
+      const double cff = Hzk[X2(i, j)] * (cff3 - cff4);
+      UFx[S2(i, j)] = cff * cff1;
+      VFe[S2(i, j)] = cff * cff2;
+    }
+    KSYNC();
+    KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
+      if (i >= IstrU) { const double cff1 = 0.5 * (UFx[S2(i, j)] + UFx[S2(i - 1, j)]); ru[X2(i, j)] = ru[X2(i, j)] + cff1; }
+      if (j >= JstrV) { const double cff1 = 0.5 * (VFe[S2(i, j)] + VFe[S2(i, j - 1)]); rv[X2(i, j)] = rv[X2(i, j)] - cff1; }
+    }
+    KSYNC();
+  }
+  if (!(G.options & ROMS_UV_ADV)) return;
+  // ---- UFx: uxx=w0, Huxx=w1
+  KLOOP2(i, j, B.IstrUm1, B.Iendp1, Jstr, Jend) {
+    w0[S2(i, j)] = u[X2(i - 1, j)] - 2.0 * u[X2(i, j)] + u[X2(i + 1, j)];
+    w1[S2(i, j)] = Hu[X2(i - 1, j)] - 2.0 * Hu[X2(i, j)] + Hu[X2(i + 1, j)];
+  }
+  // ---- UFe prerequisites: uee=w2 on (IstrU:Iend, Jstrm1:Jendp1); Hvxx=w3 on (IstrU-1:Iend, Jstr:Jend+1)
+  KLOOP2(i, j, IstrU, Iend, B.Jstrm1, B.Jendp1) w2[S2(i, j)] = u[X2(i, j - 1)] - 2.0 * u[X2(i, j)] + u[X2(i, j + 1)];
+  KLOOP2(i, j, IstrU - 1, Iend, Jstr, Jend + 1) w3[S2(i, j)] = Hv[X2(i - 1, j)] - 2.0 * Hv[X2(i, j)] + Hv[X2(i + 1, j)];
+  KSYNC();
+  if (!G.ewp) {
+    if (B.west) KLOOP1(j, Jstr, Jend) { w0[S2(Istr, j)] = w0[S2(Istr + 1, j)]; w1[S2(Istr, j)] = w1[S2(Istr + 1, j)]; }
+    if (B.east) KLOOP1(j, Jstr, Jend) { w0[S2(Iend + 1, j)] = w0[S2(Iend, j)]; w1[S2(Iend + 1, j)] = w1[S2(Iend, j)]; }
+  }
+  if (!G.nsp) {
+    if (B.south) KLOOP1(i, IstrU, Iend) w2[S2(i, Jstr - 1)] = w2[S2(i, Jstr)];
+    if (B.north) KLOOP1(i, IstrU, Iend) w2[S2(i, Jend + 1)] = w2[S2(i, Jend)];
+  }
+  KSYNC();
+  KLOOP2(i, j, IstrU - 1, Iend, Jstr, Jend) {
+    const double cff1 = u[X2(i, j)] + u[X2(i + 1, j)];
+    const double cff = (cff1 > 0.0) ? w0[S2(i, j)] : w0[S2(i + 1, j)];
+    UFx[S2(i, j)] = 0.25 * (cff1 + Gadv * cff) * (Hu[X2(i, j)] + Hu[X2(i + 1, j)] + Gadv * 0.5 * (w1[S2(i, j)] + w1[S2(i + 1, j)]));
+  }
+  KLOOP2(i, j, IstrU, Iend, Jstr, Jend + 1) {
+    const double cff1 = u[X2(i, j)] + u[X2(i, j - 1)];
+    const double cff2 = Hv[X2(i, j)] + Hv[X2(i - 1, j)];
+    const double cff = (cff2 > 0.0) ? w2[S2(i, j - 1)] : w2[S2(i, j)];
+    UFe[S2(i, j)] = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * (w3[S2(i, j)] + w3[S2(i - 1, j)]));
+  }
+  KSYNC();
+  // ---- VFx: vxx=w0 on (Istrm1:Iendp1, JstrV:Jend), Huee=w1 on (Istr:Iend+1, JstrV-1:Jend);
+  //      VFe: vee=w2, Hvee=w3 on (Istr:Iend, JstrVm1:Jendp1)
+  KLOOP2(i, j, B.Istrm1, B.Iendp1, JstrV, Jend) w0[S2(i, j)] = v[X2(i - 1, j)] - 2.0 * v[X2(i, j)] + v[X2(i + 1, j)];
+  KLOOP2(i, j, Istr, Iend + 1, JstrV - 1, Jend) w1[S2(i, j)] = Hu[X2(i, j - 1)] - 2.0 * Hu[X2(i, j)] + Hu[X2(i, j + 1)];
+  KLOOP2(i, j, Istr, Iend, B.JstrVm1, B.Jendp1) {
+    w2[S2(i, j)] = v[X2(i, j - 1)] - 2.0 * v[X2(i, j)] + v[X2(i, j + 1)];
+    w3[S2(i, j)] = Hv[X2(i, j - 1)] - 2.0 * Hv[X2(i, j)] + Hv[X2(i, j + 1)];
+  }
+  KSYNC();
+  if (!G.ewp) {
+    if (B.west) KLOOP1(j, JstrV, Jend) w0[S2(Istr - 1, j)] = w0[S2(Istr, j)];
+    if (B.east) KLOOP1(j, JstrV, Jend) w0[S2(Iend + 1, j)] = w0[S2(Iend, j)];
+  }
+  if (!G.nsp) {
+    if (B.south) KLOOP1(i, Istr, Iend) { w2[S2(i, Jstr)] = w2[S2(i, Jstr + 1)]; w3[S2(i, Jstr)] = w3[S2(i, Jstr + 1)]; }
+    if (B.north) KLOOP1(i, Istr, Iend) { w2[S2(i, Jend + 1)] = w2[S2(i, Jend)]; w3[S2(i, Jend + 1)] = w3[S2(i, Jend)]; }
+  }
+  KSYNC();
+  KLOOP2(i, j, Istr, Iend + 1, JstrV, Jend) {
+    const double cff1 = v[X2(i, j)] + v[X2(i - 1, j)];
+    const double cff2 = Hu[X2(i, j)] + Hu[X2(i, j - 1)];
+    const double cff = (cff2 > 0.0) ? w0[S2(i - 1, j)] : w0[S2(i, j)];
+    VFx[S2(i, j)] = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * (w1[S2(i, j)] + w1[S2(i, j - 1)]));
+  }
+  KLOOP2(i, j, Istr, Iend, JstrV - 1, Jend) {
+    const double cff1 = v[X2(i, j)] + v[X2(i, j + 1)];
+    const double cff = (cff1 > 0.0) ? w2[S2(i, j)] : w2[S2(i, j + 1)];
+    VFe[S2(i, j)] = 0.25 * (cff1 + Gadv * cff) * (Hv[X2(i, j)] + Hv[X2(i, j + 1)] + Gadv * 0.5 * (w3[S2(i, j)] + w3[S2(i, j + 1)]));
+  }
+  KSYNC();
+  KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
+    if (i >= IstrU) {
+      const double cff1 = UFx[S2(i, j)] - UFx[S2(i - 1, j)];
+      const double cff2 = UFe[S2(i, j + 1)] - UFe[S2(i, j)];
+      const double cff = cff1 + cff2;
+      ru[X2(i, j)] = ru[X2(i, j)] - cff;
+    }
+    if (j >= JstrV) {
+      const double cff1 = VFx[S2(i + 1, j)] - VFx[S2(i, j)];
+      const double cff2 = VFe[S2(i, j)] - VFe[S2(i, j - 1)];
+      const double cff = cff1 + cff2;
+      rv[X2(i, j)] = rv[X2(i, j)] - cff;
+    }
+  }
+}
+COOP_GLOBAL(k_rhs3d_h, KArgs)
+
+// J_LOOP: 4th-order (9/16,1/16) vertical advection, vertical sums rufrc/rvfrc + surface/bottom
+// stress.  One thread per column of (Istr:Iend, Jstr:Jend).
+THREAD_KERNEL(k_rhs3d_v, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs;
+  const double *u = F.u + (size_t)(nrhs - 1) * G.nij * N, *v = F.v + (size_t)(nrhs - 1) * G.nij * N, *W = F.W;
+  double *ru = F.ru + (size_t)(nrhs - 1) * G.nij * (N + 1), *rv = F.rv + (size_t)(nrhs - 1) * G.nij * (N + 1);
+  const bool adv = (G.options & ROMS_UV_ADV) != 0;
+  const double cff1 = 9.0 / 16.0, cff2 = 1.0 / 16.0;
+  if (i >= B.IstrU) {
+    // FC(k) for k=0..N (local)
+#define WU(kk) (cff1 * (W[XW(i, j, kk)] + W[XW(i - 1, j, kk)]) - cff2 * (W[XW(i + 1, j, kk)] + W[XW(i - 2, j, kk)]))
+#define FCU(out, kk)                                                                                                   \
+  do {                                                                                                                 \
+    if ((kk) <= 0 || (kk) >= N) out = 0.0;                                                                             \
+    else if ((kk) == N - 1) out = (cff1 * (u[X3(i, j, N - 1)] + u[X3(i, j, N)]) - cff2 * (u[X3(i, j, N - 2)] + u[X3(i, j, N)])) * WU(N - 1); \
+    else if ((kk) == 1) out = (cff1 * (u[X3(i, j, 1)] + u[X3(i, j, 2)]) - cff2 * (u[X3(i, j, 1)] + u[X3(i, j, 3)])) * WU(1); \
+    else out = (cff1 * (u[X3(i, j, kk)] + u[X3(i, j, (kk) + 1)]) - cff2 * (u[X3(i, j, (kk) - 1)] + u[X3(i, j, (kk) + 2)])) * WU(kk); \
+  } while (0)
+    double FCm = 0.0, sum = 0.0;
+    for (int k = 1; k <= N; k++) {
+      double r = ru[XW(i, j, k)];
+      if (adv) {
+        double FCk;
+        FCU(FCk, k);
+        const double cff = FCk - FCm;
+        r = r - cff;
+        ru[XW(i, j, k)] = r;
+        FCm = FCk;
+      }
+      sum = (k == 1) ? r : sum + r;
+    }
+#undef FCU
+#undef WU
+    const double cff = F.om_u[X2(i, j)] * F.on_u[X2(i, j)];
+    const double c1 = F.sustr[X2(i, j)] * cff;
+    const double c2 = -F.bustr[X2(i, j)] * cff;
+    F.rufrc[X2(i, j)] = sum + c1 + c2;
+  }
+  if (j >= B.JstrV) {
+#define WV(kk) (cff1 * (W[XW(i, j, kk)] + W[XW(i, j - 1, kk)]) - cff2 * (W[XW(i, j + 1, kk)] + W[XW(i, j - 2, kk)]))
+#define FCV(out, kk)                                                                                                   \
+  do {                                                                                                                 \
+    if ((kk) <= 0 || (kk) >= N) out = 0.0;                                                                             \
+    else if ((kk) == N - 1) out = (cff1 * (v[X3(i, j, N - 1)] + v[X3(i, j, N)]) - cff2 * (v[X3(i, j, N - 2)] + v[X3(i, j, N)])) * WV(N - 1); \
+    else if ((kk) == 1) out = (cff1 * (v[X3(i, j, 1)] + v[X3(i, j, 2)]) - cff2 * (v[X3(i, j, 1)] + v[X3(i, j, 3)])) * WV(1); \
+    else out = (cff1 * (v[X3(i, j, kk)] + v[X3(i, j, (kk) + 1)]) - cff2 * (v[X3(i, j, (kk) - 1)] + v[X3(i, j, (kk) + 2)])) * WV(kk); \
+  } while (0)
+    double FCm = 0.0, sum = 0.0;
+    for (int k = 1; k <= N; k++) {
+      double r = rv[XW(i, j, k)];
+      if (adv) {
+        double FCk;
+        FCV(FCk, k);
+        const double cff = FCk - FCm;
+        r = r - cff;
+        rv[XW(i, j, k)] = r;
+        FCm = FCk;
+      }
+      sum = (k == 1) ? r : sum + r;
+    }
+#undef FCV
+#undef WV
+    const double cff = F.om_v[X2(i, j)] * F.on_v[X2(i, j)];
+    const double c1 = F.svstr[X2(i, j)] * cff;
+    const double c2 = -F.bvstr[X2(i, j)] * cff;
+    F.rvfrc[X2(i, j)] = sum + c1 + c2;
+  }
+}
+THREAD_GLOBAL(k_rhs3d_v, KArgs)

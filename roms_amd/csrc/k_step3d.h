@@ -1,0 +1,311 @@
+// k_step3d.h -- corrector steps: step3d_uv and step3d_t.
+//
+//   k_s3uv_col     step3d_uv_tile (first J loop)    ROMS/Nonlinear/step3d_uv.F:345-1200
+//   k_s3uv_couple  step3d_uv_tile (second J loop)   ROMS/Nonlinear/step3d_uv.F:1310-1750
+//   k_s3t_h        step3d_t_tile T_LOOP1/K_LOOP     ROMS/Nonlinear/step3d_t.F:432-915
+//   k_s3t_col      step3d_t_tile T_LOOP2 + J_LOOP2  ROMS/Nonlinear/step3d_t.F:936-1340, :1664-1790
+//
+// Column kernels: one thread per sigma-column, lanes along xi (every k-level access of a wave is
+// one coalesced 512-byte row segment).  The tridiagonal (parabolic-spline) solves keep the two
+// elimination coefficients of the column in private memory.
+#pragma once
+#include "roms_ctx.h"
+#include "k_diag3d.h"
+#include "k_rhs3d.h"   // hadv_flux_lds, VFLUX_LOCAL, vspline_flux
+
+#define ROMS_NPRIV 128   // max N+1 held per thread in the tridiagonal solves
+
+// --------------------------------------------------------------------------------- step3d_uv
+// grid.z = 0: u on (IstrU:Iend, Jstr:Jend); 1: v on (Istr:Iend, JstrV:Jend)
+THREAD_KERNEL(k_s3uv_col, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int dir = gz;
+  const int i = (dir == 0 ? B.IstrU : B.Istr) + gx, j = (dir == 0 ? B.Jstr : B.JstrV) + gy;
+  if (i > B.Iend || j > B.Jend) return;
+  const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1;
+  const int N = G.N, nrhs = G.nrhs, nnew = G.nnew;
+  const double dt = G.dt;
+  double *q = (dir == 0 ? F.u : F.v) + (size_t)(nnew - 1) * G.nij * N;
+  const double *rq = (dir == 0 ? F.ru : F.rv) + (size_t)(nrhs - 1) * G.nij * (N + 1);
+  const double *Akv = F.Akv, *Hz = F.Hz;
+  double CF[ROMS_NPRIV], DC[ROMS_NPRIV];
+#define AKc(kk) (0.5 * (Akv[XW(i - di, j - dj, kk)] + Akv[XW(i, j, kk)]))
+#define HZc(kk) (0.5 * (Hz[X3(i - di, j - dj, kk)] + Hz[X3(i, j, kk)]))
+  double cff;
+  if (G.iic == G.ntfirst) cff = 0.25 * dt;
+  else if (G.iic == G.ntfirst + 1) cff = 0.25 * dt * 3.0 / 2.0;
+  else cff = 0.25 * dt * 23.0 / 12.0;
+  const double DC0 = cff * (F.pm[X2(i, j)] + F.pm[X2(i - di, j - dj)]) * (F.pn[X2(i, j)] + F.pn[X2(i - di, j - dj)]);
+  // time step r.h.s. :345-358  (q = (q + DC0*rq) / Hzk)
+  for (int k = 1; k <= N; k++) {
+    double qq = q[X3(i, j, k)] + DC0 * rq[XW(i, j, k)];
+    qq = qq * (1.0 / HZc(k));
+    q[X3(i, j, k)] = qq;
+  }
+  // implicit vertical viscosity, parabolic splines :361-450
+  {
+    const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
+    CF[0] = 0.0;
+    DC[0] = 0.0;
+    double Hk = HZc(1), oHk = 1.0 / Hk, qk = q[X3(i, j, 1)];
+    for (int k = 1; k <= N - 1; k++) {
+      const double Hk1 = HZc(k + 1), oHk1 = 1.0 / Hk1, qk1 = q[X3(i, j, k + 1)];
+      const double FCk = c6 * Hk - dt * AKc(k - 1) * oHk;
+      const double CFk = c6 * Hk1 - dt * AKc(k + 1) * oHk1;
+      const double BCk = c3 * (Hk + Hk1) + dt * AKc(k) * (oHk + oHk1);
+      const double cf = 1.0 / (BCk - FCk * CF[k - 1]);
+      CF[k] = cf * CFk;
+      DC[k] = cf * (qk1 - qk - FCk * DC[k - 1]);
+      Hk = Hk1; oHk = oHk1; qk = qk1;
+    }
+    DC[N] = 0.0;
+    for (int k = N - 1; k >= 1; k--) DC[k] = DC[k] - CF[k] * DC[k + 1];
+  }
+  // add the viscous flux divergence, then replace the vertical mean :594-730 / :1061-1200
+  double CF0 = 0.0, DCs = 0.0, DCm = 0.0;   // DCm = DC(k-1)*AK(k-1)
+  for (int k = 1; k <= N; k++) {
+    const double Hk = HZc(k), oHk = 1.0 / Hk;
+    const double DCk = DC[k] * AKc(k);
+    const double c = dt * oHk * (DCk - DCm);
+    const double qq = q[X3(i, j, k)] + c;
+    q[X3(i, j, k)] = qq;
+    DCm = DCk;
+    if (k == 1) { CF0 = Hk; DCs = qq * Hk; }
+    else { CF0 = CF0 + Hk; DCs = DCs + qq * Hk; }
+  }
+  const double omn1 = (dir == 0 ? F.on_u : F.om_v)[X2(i, j)];
+  const double Davg = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
+  const double cff1 = 1.0 / (CF0 * omn1);
+  const double corr = (DCs * omn1 - Davg) * cff1;
+  for (int k = 1; k <= N; k++) q[X3(i, j, k)] = q[X3(i, j, k)] - corr;
+#undef AKc
+#undef HZc
+}
+THREAD_GLOBAL(k_s3uv_col, KArgs)
+
+// coupling of 2-D and 3-D momentum, corrected mass fluxes, ubar/vbar(1:2).
+// grid.z = 0: u part on (IstrP:IendT, JstrT:JendT); 1: v part on (IstrT:IendT, Jstr:JendT)
+THREAD_KERNEL(k_s3uv_couple, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int dir = gz;
+  const int i = (dir == 0 ? B.IstrP : B.IstrT) + gx, j = (dir == 0 ? B.JstrT : B.Jstr) + gy;
+  if (i > B.IendT || j > B.JendT) return;
+  const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1;
+  const int N = G.N, nnew = G.nnew;
+  double *q = (dir == 0 ? F.u : F.v) + (size_t)(nnew - 1) * G.nij * N;
+  double *Hq = dir == 0 ? F.Huon : F.Hvom;
+  const double *Hz = F.Hz;
+  const double cffm = 0.5 * (dir == 0 ? F.on_u : F.om_v)[X2(i, j)];
+  const double Davg1 = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
+  const double Davg2 = (dir == 0 ? F.DU_avg2 : F.DV_avg2)[X2(i, j)];
+  double DC0 = 0.0, CF0 = 0.0, FC0 = 0.0;
+  for (int k = 1; k <= N; k++) {
+    const double DCk = cffm * (Hz[X3(i, j, k)] + Hz[X3(i - di, j - dj, k)]);
+    DC0 = DC0 + DCk;
+    CF0 = CF0 + DCk * q[X3(i, j, k)];
+  }
+  DC0 = 1.0 / DC0;
+  CF0 = DC0 * (CF0 - Davg1);
+  double *bar = dir == 0 ? F.ubar : F.vbar;
+  const double b1 = DC0 * Davg1;
+  bar[X2T(i, j, 1)] = b1;
+  bar[X2T(i, j, 2)] = b1;
+  // boundary columns: remove the mismatch of the vertical mean :1400-1490
+  bool fix = false;
+  if (dir == 0) {
+    if (!G.ewp && ((B.west && i == B.Istr) || (B.east && i == B.Iend + 1))) fix = true;
+    if (!G.nsp && (j == 0 || j == G.Mm + 1) && i >= B.IstrU && i <= B.Iend) fix = true;
+  } else {
+    if (!G.ewp && ((B.west && i == B.Istr - 1) || (B.east && i == B.Iend + 1))) fix = true;
+    if (!G.nsp && (j == 1 || j == G.Mm + 1) && i >= B.Istr && i <= B.Iend) fix = true;
+  }
+  if (fix)
+    for (int k = 1; k <= N; k++) q[X3(i, j, k)] = q[X3(i, j, k)] - CF0;
+  for (int k = N; k >= 1; k--) {
+    const double DCk = cffm * (Hz[X3(i, j, k)] + Hz[X3(i - di, j - dj, k)]);
+    const double Hn = 0.5 * (Hq[X3(i, j, k)] + q[X3(i, j, k)] * DCk);
+    Hq[X3(i, j, k)] = Hn;
+    FC0 = FC0 + Hn;
+  }
+  FC0 = DC0 * (FC0 - Davg2);
+  for (int k = 1; k <= N; k++) {
+    const double DCk = cffm * (Hz[X3(i, j, k)] + Hz[X3(i - di, j - dj, k)]);
+    Hq[X3(i, j, k)] = Hq[X3(i, j, k)] - DCk * FC0;
+  }
+}
+THREAD_GLOBAL(k_s3uv_couple, KArgs)
+
+// ---------------------------------------------------------------------------------- step3d_t
+// HSIMT limiter (Wu and Zhu 2010), step3d_t.F:520-560
+KDEV double hsimt_lim(double grad, double gradu, double Ka, double Kau, double oKa) {
+  const double eps1 = 1.0E-12, cc1 = 0.25, cc2 = 0.5, cc3 = 1.0 / 12.0;
+  double r, rka;
+  if (fabs(grad) <= eps1) { r = 0.0; rka = 0.0; }
+  else { r = gradu / grad; rka = Kau * oKa; }
+  const double a1 = cc1 * Ka + cc2 - cc3 * oKa;
+  const double b1 = -cc1 * Ka + cc2 + cc3 * oKa;
+  const double beta = a1 + b1 * r;
+  double m = 2.0;
+  const double x = 2.0 * r * rka;
+  if (x < m) m = x;
+  if (beta < m) m = beta;
+  if (m < 0.0) m = 0.0;
+  return 0.5 * m * grad * Ka;
+}
+
+// horizontal advection of t(3) -> t(nnew); grid.z = (k-1)+N*(itrc-1); 4 LDS arrays
+#define S3T_NLDS 4
+COOP_KERNEL(k_s3t_h, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB B = block_bounds(G, bx, by);
+  const int k = bz % G.N + 1, itrc = bz / G.N + 1;
+  const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
+  double *FX = lds, *FE = lds + sz, *wk = lds + 2 * sz, *wk2 = lds + 3 * sz;
+  const int hs = G.hadv[itrc - 1];
+  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
+  const double *T3 = F.t + XT(G.LBi, G.LBj, k, 3, itrc);
+  const double *Hu = F.Huon + X3(G.LBi, G.LBj, k), *Hv = F.Hvom + X3(G.LBi, G.LBj, k);
+  const double *Hzk = F.Hz + X3(G.LBi, G.LBj, k);
+  const double dt = G.dt, eps1 = 1.0E-12;
+  if (hs == ROMS_HSIMT) {
+    // xi direction: gradX = wk, KaX = wk2 on (IstrU-1:Iendp2, Jstr:Jend)  :472-550
+    KLOOP2(i, j, B.IstrU - 1, B.Iendp2, Jstr, Jend) {
+      const double cff = 0.125 * (F.pm[X2(i - 1, j)] + F.pm[X2(i, j)]) * (F.pn[X2(i - 1, j)] + F.pn[X2(i, j)]) * dt;
+      const double cff1 = cff * (1.0 / Hzk[X2(i - 1, j)] + 1.0 / Hzk[X2(i, j)]);
+      wk[S2(i, j)] = T3[X2(i, j)] - T3[X2(i - 1, j)];
+      wk2[S2(i, j)] = 1.0 - fabs(Hu[X2(i, j)] * cff1);
+    }
+    KSYNC();
+    if (!G.ewp) {
+      if (B.west) KLOOP1(j, Jstr, Jend) if (Hu[X2(Istr, j)] >= 0.0) { wk[S2(Istr - 1, j)] = 0.0; wk2[S2(Istr - 1, j)] = 0.0; }
+      if (B.east) KLOOP1(j, Jstr, Jend) if (Hu[X2(Iend + 1, j)] < 0.0) { wk[S2(Iend + 2, j)] = 0.0; wk2[S2(Iend + 2, j)] = 0.0; }
+    }
+    KSYNC();
+    KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend) {
+      const double Ka = wk2[S2(i, j)];
+      const double oKa = (Ka <= eps1) ? 0.0 : 1.0 / KMAX(Ka, eps1);
+      double sw;
+      if (Hu[X2(i, j)] >= 0.0) sw = T3[X2(i - 1, j)] + hsimt_lim(wk[S2(i, j)], wk[S2(i - 1, j)], Ka, wk2[S2(i - 1, j)], oKa);
+      else sw = T3[X2(i, j)] - hsimt_lim(wk[S2(i, j)], wk[S2(i + 1, j)], Ka, wk2[S2(i + 1, j)], oKa);
+      FX[S2(i, j)] = sw * Hu[X2(i, j)];
+    }
+    KSYNC();
+    // eta direction  :552-632
+    KLOOP2(i, j, Istr, Iend, B.JstrV - 1, B.Jendp2) {
+      const double cff = 0.125 * (F.pn[X2(i, j)] + F.pn[X2(i, j - 1)]) * (F.pm[X2(i, j)] + F.pm[X2(i, j - 1)]) * dt;
+      const double cff1 = cff * (1.0 / Hzk[X2(i, j)] + 1.0 / Hzk[X2(i, j - 1)]);
+      wk[S2(i, j)] = T3[X2(i, j)] - T3[X2(i, j - 1)];
+      wk2[S2(i, j)] = 1.0 - fabs(Hv[X2(i, j)] * cff1);
+    }
+    KSYNC();
+    if (!G.nsp) {
+      if (B.south) KLOOP1(i, Istr, Iend) if (Hv[X2(i, Jstr)] >= 0.0) { wk[S2(i, Jstr - 1)] = 0.0; wk2[S2(i, Jstr - 1)] = 0.0; }
+      if (B.north) KLOOP1(i, Istr, Iend) if (Hv[X2(i, Jend + 1)] < 0.0) { wk[S2(i, Jend + 2)] = 0.0; wk2[S2(i, Jend + 2)] = 0.0; }
+    }
+    KSYNC();
+    KLOOP2(i, j, Istr, Iend, Jstr, Jend + 1) {
+      const double Ka = wk2[S2(i, j)];
+      const double oKa = (Ka <= eps1) ? 0.0 : 1.0 / KMAX(Ka, eps1);
+      double sw;
+      if (Hv[X2(i, j)] >= 0.0) sw = T3[X2(i, j - 1)] + hsimt_lim(wk[S2(i, j)], wk[S2(i, j - 1)], Ka, wk2[S2(i, j - 1)], oKa);
+      else sw = T3[X2(i, j)] - hsimt_lim(wk[S2(i, j)], wk[S2(i, j + 1)], Ka, wk2[S2(i, j + 1)], oKa);
+      FE[S2(i, j)] = sw * Hv[X2(i, j)];
+    }
+    KSYNC();
+  } else {
+    hadv_flux_lds(G, B, hs, T3, Hu, Hv, FX, FE, wk);
+  }
+  // time-step horizontal advection :873-915
+  double *tn = F.t + XT(G.LBi, G.LBj, k, G.nnew, itrc);
+  KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
+    const double cff = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
+    const double cff1 = cff * (FX[S2(i + 1, j)] - FX[S2(i, j)]);
+    const double cff2 = cff * (FE[S2(i, j + 1)] - FE[S2(i, j)]);
+    const double cff3 = cff1 + cff2;
+    tn[X2(i, j)] = tn[X2(i, j)] - cff3;
+  }
+}
+COOP_GLOBAL(k_s3t_h, KArgs)
+
+// vertical advection + implicit vertical diffusion; one thread per column and tracer;
+// index space (Istr:Iend, Jstr:Jend, NT).  (MPDATA tracers are handled in k_mpdata.h.)
+THREAD_KERNEL(k_s3t_col, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = G.N;
+  const int vs = G.vadv[itrc - 1], ltrc = KMIN(G.NAT, itrc);
+  const double dt = G.dt, eps1 = 1.0E-12;
+  const double *T3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
+  double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);
+  const double *Hz = F.Hz, *W = F.W, *z_r = F.z_r;
+  const double *Akt = F.Akt + (size_t)(ltrc - 1) * G.nij * (N + 1);
+  const double pmn_dt = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];   // CF(i,0)
+  double CF[ROMS_NPRIV], DC[ROMS_NPRIV];
+  if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, T3, 1);
+#define Tc(kk) T3[X3(i, j, kk)]
+#define Wc(kk) W[XW(i, j, kk)]
+  // HSIMT vertical: KaZ, gradZ local functions of the column :1069-1150
+#define KAZ(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : 1.0 - fabs(F.pm[X2(i, j)] * F.pn[X2(i, j)] * dt * W[XW(i, j, kk)] / (z_r[X3(i, j, (kk) + 1)] - z_r[X3(i, j, kk)])))
+#define GZ(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : T3[X3(i, j, (kk) + 1)] - T3[X3(i, j, kk)])
+  double FCm = 0.0;
+  for (int k = 1; k <= N; k++) {
+    double FCk;
+    if (vs == ROMS_SPLINES) FCk = F.wrk3[3][XW(i, j, k)];
+    else if (vs == ROMS_HSIMT) {
+      if (k >= N) FCk = 0.0;
+      else {
+        const double w = W[XW(i, j, k)];
+        if (k == 1 && w >= 0.0) FCk = w * Tc(k);
+        else if (k == N - 1 && w < 0.0) FCk = w * Tc(k + 1);
+        else {
+          const double Ka = KAZ(k), oKa = 1.0 / Ka;
+          double sw;
+          if (w >= 0.0) sw = Tc(k) + hsimt_lim(GZ(k), GZ(k - 1), Ka, KAZ(k - 1), oKa);
+          else sw = Tc(k + 1) - hsimt_lim(GZ(k), GZ(k + 1), Ka, KAZ(k + 1), oKa);
+          FCk = w * sw;
+        }
+      }
+    } else VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
+    const double cff1 = pmn_dt * (FCk - FCm);
+    double tt = tn[X3(i, j, k)] - cff1;
+    tt = tt * (1.0 / Hz[X3(i, j, k)]);
+    tn[X3(i, j, k)] = tt;
+    FCm = FCk;
+  }
+#undef Tc
+#undef Wc
+#undef KAZ
+#undef GZ
+  // implicit vertical diffusion, parabolic splines (SPLINES_VDIFF) :1664-1722
+  {
+    const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
+    CF[0] = 0.0;
+    DC[0] = 0.0;
+    double Hk = Hz[X3(i, j, 1)], oHk = 1.0 / Hk, tk = tn[X3(i, j, 1)];
+    for (int k = 1; k <= N - 1; k++) {
+      const double Hk1 = Hz[X3(i, j, k + 1)], oHk1 = 1.0 / Hk1, tk1 = tn[X3(i, j, k + 1)];
+      const double FCk = c6 * Hk - dt * Akt[XW(i, j, k - 1)] * oHk;
+      const double CFk = c6 * Hk1 - dt * Akt[XW(i, j, k + 1)] * oHk1;
+      const double BCk = c3 * (Hk + Hk1) + dt * Akt[XW(i, j, k)] * (oHk + oHk1);
+      const double cf = 1.0 / (BCk - FCk * CF[k - 1]);
+      CF[k] = cf * CFk;
+      DC[k] = cf * (tk1 - tk - FCk * DC[k - 1]);
+      Hk = Hk1; oHk = oHk1; tk = tk1;
+    }
+    DC[N] = 0.0;
+    for (int k = N - 1; k >= 1; k--) DC[k] = DC[k] - CF[k] * DC[k + 1];
+    double DCm = 0.0;
+    for (int k = 1; k <= N; k++) {
+      const double DCk = DC[k] * Akt[XW(i, j, k)];
+      const double cff1 = dt * (1.0 / Hz[X3(i, j, k)]) * (DCk - DCm);
+      tn[X3(i, j, k)] = tn[X3(i, j, k)] + cff1;
+      DCm = DCk;
+    }
+  }
+}
+THREAD_GLOBAL(k_s3t_col, KArgs)

@@ -62,7 +62,7 @@ typedef hipStream_t kstream_t;
 // the __global__ entry: dynamic LDS, block index -> sub-tile (with the XCD-aware remap done
 // by the body through DGrid, see roms_ctx.h:block_rect)
 #define COOP_GLOBAL(name, ArgT)                                                          \
-  __global__ void name(const ArgT a) {                                                   \
+  static __global__ void name(const ArgT a) {                                                   \
     extern __shared__ double lds_dyn_[];                                                 \
     name##_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds_dyn_);         \
   }
@@ -72,7 +72,7 @@ typedef hipStream_t kstream_t;
 
 #define THREAD_KERNEL(name, ArgT) static __device__ void name##_body(const ArgT &a, int gx, int gy, int gz)
 #define THREAD_GLOBAL(name, ArgT)                                                        \
-  __global__ void name(const ArgT a, int nx, int ny, int nz) {                           \
+  static __global__ void name(const ArgT a, int nx, int ny, int nz) {                           \
     int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);                               \
     int gy = (int)(blockIdx.y * blockDim.y + threadIdx.y);                               \
     int gz = (int)blockIdx.z;                                                            \

@@ -102,7 +102,6 @@ static void choose_blocks(DGrid &G) {
   // grids get smaller sub-tiles so that a launch still spreads over many of the 256 CUs.
   const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
   int bw = 32, bh = 8;
-  if ((long)LmT * MmT >= 512L * 256L) { bw = 32; bh = 16; }
   G.nbx = (LmT + bw - 1) / bw;
   G.nby = (MmT + bh - 1) / bh;
   if (G.nbx < 1) G.nbx = 1;
@@ -114,8 +113,8 @@ static void choose_blocks(DGrid &G) {
 extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   if (!cfg || !out) { set_error("null argument"); return 8; }
   if (cfg->abi_version != ROMS_HIP_ABI_VERSION) { set_error("ABI version mismatch"); return 5; }
-  if (cfg->N < 4 || cfg->N > 255 || cfg->NT < 1 || cfg->NT > ROMS_MAXT || 2 * cfg->ndtfast > ROMS_MAXW) {
-    set_error("unsupported dimensions (need 4 <= N <= 255, NT <= 4, 2*ndtfast <= 512)");
+  if (cfg->N < 4 || cfg->N > 127 || cfg->NT < 1 || cfg->NT > ROMS_MAXT || 2 * cfg->ndtfast > ROMS_MAXW) {
+    set_error("unsupported dimensions (need 4 <= N <= 127, NT <= 4, 2*ndtfast <= 512)");
     return 5;
   }
   if (cfg->NtileI * cfg->NtileJ != 1) {
@@ -251,6 +250,8 @@ extern "C" int roms_hip_download(roms_hip_ctx *c, const char *name, double *host
   return d2h(host, *(double **)((char *)&c->F + f->offset), (size_t)n * sizeof(double), c->stream);
 }
 extern "C" int roms_hip_sync(roms_hip_ctx *c) { return dsync(c->stream); }
+int fetch_diag(roms_hip_ctx *c, const double *d_out, double *out) { return d2h(out, d_out, 16 * sizeof(double), c->stream); }
+int run_diag_async(roms_hip_ctx *c, double *d_out);   // g_diag.cpp
 
 // ------------------------------------------------------------------------------ region timing
 RegionTimer::RegionTimer(roms_hip_ctx *c_, int id_) : c(c_), id(id_) {
@@ -380,7 +381,9 @@ static int main3d_one(roms_hip_ctx *c) {
   }
   DO(roms_hip_set_massflux(c));                             // :348
   DO(roms_hip_rho_eos(c));                                  // :350
-  // diag (:355) is a host-visible reduction: run on request through roms_hip_diag
+  // diag (:355): device-side reduction every ninfo steps; the blow-up test is made on the host
+  // when roms_hip_main3d returns (no per-step host synchronisation)
+  if (cf.ninfo > 0 && (s.iic - 1) % cf.ninfo == 0) DO(run_diag_async(c, c->d_diag));
   if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));   // :439
   DO(roms_hip_set_vbc(c));                                  // :445
   if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));       // :525
@@ -426,6 +429,15 @@ extern "C" int roms_hip_main3d(roms_hip_ctx *c, int nsteps) {
   for (int n = 0; n < nsteps; n++) {
     int r = main3d_one(c);
     if (r) return r;
+  }
+  if (c->cfg.ninfo > 0 && nsteps > 0) {
+    double out[16];
+    int r = fetch_diag(c, c->d_diag, out);
+    if (r) return r;
+    if (!(out[0] == out[0] && out[1] == out[1]) || out[4] > 20.0) {   // diag.F:510-540
+      set_error("blow-up: KE/PE not finite or MaxSpeed > 20 m/s");
+      return 1;
+    }
   }
   return 0;
 }

@@ -1,0 +1,68 @@
+"""Helpers shared by the tests: load golden fixtures, build oracle / HIP states from them."""
+import os
+
+import numpy as np
+
+from tests import cases
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EMU_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libroms_hip_emu.so")
+
+INIT_FIELDS = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", "on_v", "om_p", "on_p", "omn",
+               "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v", "angler", "xr", "yr",
+               "rdrag", "visc2_r", "visc2_p", "diff2", "Hz", "z_r", "z_w", "Huon", "Hvom", "zeta", "ubar", "vbar",
+               "u", "v", "t", "rho", "pden", "rhoA", "rhoS", "Zt_avg1", "Akv", "Akt"]
+STATE_FIELDS = INIT_FIELDS + ["rzeta", "rubar", "rvbar", "W", "wvel", "ru", "rv", "rufrc", "rvfrc", "DU_avg1",
+                              "DU_avg2", "DV_avg1", "DV_avg2", "sustr", "svstr", "bustr", "bvstr", "stflx", "btflx",
+                              "stflux", "btflux"]
+PROGNOSTIC = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "wvel", "Hz", "z_r", "z_w", "Huon", "Hvom", "rho", "ru", "rv",
+              "Zt_avg1", "DU_avg1", "DV_avg1", "DU_avg2", "DV_avg2", "rufrc", "rvfrc", "rzeta", "rubar", "rvbar"]
+
+
+def load_init(tag):
+    return dict(np.load(os.path.join(GOLDEN, f"{tag}_init.npz")))
+
+
+def case_for(tag, **kw):
+    if tag == "upwelling":
+        return cases.upwelling(**kw)
+    if tag == "upwelling_small":
+        return cases.upwelling(Lm=14, Mm=18, N=8, **kw)
+    raise KeyError(tag)
+
+
+def make_oracle(cs, g):
+    from oracle import orc
+    O = orc.Oracle(cases.oracle_cfg(cs, float(g["scalars"][0]), int(g["bounds"][58]), g["weight"]))
+    for n in INIT_FIELDS:
+        if n in g:
+            O.field(n)[:] = g[n]
+    for n in ["sc_r", "Cs_r", "sc_w", "Cs_w"]:
+        O.field(n)[:] = g[n]
+    return O
+
+
+def make_hip(cs, g, lib_path=None, device=0, ninfo=0):
+    from roms_amd import hiplib
+    cfg = cases.hip_cfg(cs, float(g["scalars"][0]), int(g["bounds"][58]), g["weight"], g["sc_r"], g["Cs_r"],
+                        g["sc_w"], g["Cs_w"], device=device)
+    cfg.ninfo = ninfo
+    H = hiplib.Context(cfg, lib_path)
+    for n in INIT_FIELDS:
+        if n in g:
+            H.upload(n, g[n])
+    return H
+
+
+def push_state(O, H, fields=STATE_FIELDS):
+    for n in fields:
+        H.upload(n, O.field(n))
+    s = O.step
+    H.set_stepping(iic=s.iic, iif=s.iif, nstp=s.nstp, nnew=s.nnew, nrhs=s.nrhs, kstp=s.kstp, knew=s.knew,
+                   krhs=s.krhs, indx1=s.indx1, predictor=s.predictor, time=s.time)
+
+
+def relrms(a, b):
+    d = np.sqrt(np.mean((a - b) ** 2))
+    s = np.sqrt(np.mean(b ** 2))
+    return d / s if s > 0 else d
