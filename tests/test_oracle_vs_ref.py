@@ -1,0 +1,60 @@
+"""Oracle against the reference's OWN Fortran (oracle/_ref, built from /root/reference by
+oracle/ref/build_ref.sh).  Only runs where that build exists (the build container); skipped
+elsewhere.  One configuration per process, so each case runs in a subprocess."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from oracle import ref
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+pytestmark = pytest.mark.ref
+
+SCRIPT = r'''
+import sys, os, numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import orc, ref
+from tests import cases, util
+cs = cases.upwelling(Lm=14, Mm=18, N=8, hadv=%(hadv)r, vadv=%(vadv)r)
+ip, rp = cases.ref_params(cs)
+R = ref.Ref("upwelling", ip, rp); R.initial()
+b = R.bounds(0)
+w = np.stack([R.table(5, 60), R.table(6, 60)])
+O = orc.Oracle(cases.oracle_cfg(cs, R.table(7, 8)[0], b[58], w))
+assert b[:54] == O.bounds(0)
+for n in util.INIT_FIELDS: O.field(n)[:] = R.get(n)
+for k, n in enumerate(["sc_r", "Cs_r", "sc_w", "Cs_w"]): O.field(n)[:] = R.table(k + 1, O.field(n).size)
+st = O.step
+st.iic = 4; st.iif = 1; st.nstp = 2; st.nnew = 1; st.nrhs = 2; st.kstp = 1; st.knew = 1; st.krhs = 1
+st.predictor = 0; st.time = 900.0; st.tdays = 900.0 / 86400.0
+R.set_stepping(st.iic, st.iif, st.nstp, st.nnew, st.nrhs, st.kstp, st.knew, st.krhs, st.predictor, st.time)
+rng = np.random.default_rng(7)
+for n, amp in [("u", 0.05), ("v", 0.05), ("zeta", 0.1), ("t", 0.01), ("ubar", 0.02), ("vbar", 0.02)]:
+    a = O.field(n); a[:] += amp * rng.standard_normal(a.size)
+O.field("Zt_avg1")[:] = O.field("zeta")[:O.ni * O.nj]
+for n in ["u", "v", "zeta", "t", "Zt_avg1", "ubar", "vbar"]: R.put(n, O.field(n))
+seq = [("set_depth", ["Hz", "z_r", "z_w"]), ("set_massflux", ["Huon", "Hvom"]),
+       ("rho_eos", ["rho", "pden", "rhoA", "rhoS"]), ("set_vbc", ["bustr", "bvstr", "stflx", "btflx"]),
+       ("ana_vmix", ["Akv", "Akt"]), ("ana_smflux", ["sustr", "svstr"]), ("prsgrd", ["ru", "rv"]),
+       ("t3dmix2", ["t"]), ("uv3dmix2", ["u", "v", "rufrc", "rvfrc"]), ("set_zeta", ["zeta"]),
+       ("wvelocity", ["wvel"]), ("ini_zeta", ["zeta", "Zt_avg1"]), ("ini_fields", ["u", "v", "ubar", "vbar", "t"])]
+for k, fl in seq:
+    R.call(k)
+    if k == "wvelocity": O.call(k, None, st.nstp)
+    elif k == "ana_smflux": O.call("set_data")
+    else: O.call(k)
+    for n in fl:
+        assert np.array_equal(R.get(n), O.field(n)), (k, n)
+print("PINNED-OK")
+'''
+
+
+@pytest.mark.parametrize("hadv,vadv", [(("U3", "HSIMT"), ("C4", "HSIMT")), (("U3", "U3"), ("C4", "C4"))])
+def test_pinned_kernels_bitwise(hadv, vadv):
+    if not ref.available("upwelling"):
+        pytest.skip("reference build oracle/_ref not available here")
+    code = SCRIPT % dict(root=ROOT, hadv=hadv, vadv=vadv)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "PINNED-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
