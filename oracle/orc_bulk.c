@@ -1,0 +1,298 @@
+/*
+ * orc_bulk.c -- COARE-3.0 bulk air-sea fluxes and the analytic atmospheric forcing of BENCHMARK.
+ * TEST INFRASTRUCTURE (see orc.h).
+ *
+ *   orc_bulk_flux           bulk_flux_tile  ROMS/Nonlinear/bulk_flux.F:208-1595 (LONGWAVE; no
+ *                                           COOL_SKIN, EMINUSP, WIND_MINUS_CURRENT, ICE)
+ *   bulk_psiu / bulk_psit                   ROMS/Nonlinear/bulk_flux.F:1598-1710
+ *   orc_set_data_benchmark  set_data_tile   ROMS/Nonlinear/set_data.F -> ana_cloud.h, ana_tair.h,
+ *                                           ana_humid.h, ana_srflux.h:200-330, ana_winds.h,
+ *                                           ana_rain.h, ana_btflux.h, ana_stflux.h, ana_pair.h
+ *   orc_caldate             caldate/datevec/datenum/ROUND  ROMS/Utility/dateclock.F, round.F
+ *                                           (time_ref = 0: proleptic Gregorian from 0001-01-01)
+ * PARITY: pinned (bulk_flux.F, analytical.F, dateclock.F build in oracle/_ref).
+ */
+#include "orc.h"
+#include <math.h>
+#include <stdlib.h>
+#define MAX(a, b) ((a) > (b) ? (a) : (b))
+#define MIN(a, b) ((a) < (b) ? (a) : (b))
+
+static const double pi = 3.14159265358979323846;
+static const double deg2rad = 3.14159265358979323846 / 180.0;
+static const double StefBo = 5.67E-8, emmiss = 0.97, blk_Cpa = 1004.67, blk_Cpw = 4000.0, blk_Rgas = 287.1,
+                    blk_Zabl = 600.0, blk_beta = 1.2, vonKar = 0.41, rhow = 1000.0, Csolar = 1353.0;
+
+/* ---- tolerant round (round.F) ---- */
+static double ufloor(double X) { return X - fmod(X, 1.0) - fmod(2.0 + copysign(1.0, X), 3.0); }
+static double tfloor(double X, double CT) {
+  double Q = 1.0;
+  if (X < 0.0) Q = 1.0 - CT;
+  const double RMAX = Q / (2.0 - CT);
+  const double EPS5 = CT / Q;
+  double Y = ufloor(X + MAX(CT, MIN(RMAX, EPS5 * fabs(1.0 + ufloor(X)))));
+  if (X <= 0.0 || (Y - X) < RMAX) return Y;
+  return Y - 1.0;
+}
+static double tround(double X, double CT) { return tfloor(X + 0.5, CT); }
+
+/* caldate(tdays, yd_dp=yday, h_dp=hour) for time_ref = 0 */
+void orc_caldate(double tdays, double *yday, double *hour) {
+  const double RefDateNumber = 367.0;       /* datenum(0001,01,01): dateclock.F datenum */
+  const double DateNumber = RefDateNumber + tdays;
+  const double DayFraction = fabs(DateNumber - trunc(DateNumber));
+  /* datevec, default branch */
+  double MyDateNumber = DateNumber;
+  const double offset = 61.0;
+  if (MyDateNumber < offset) MyDateNumber = MyDateNumber - offset + 1.0;
+  else MyDateNumber = MyDateNumber - offset;
+  int MyYear = (int)((10000.0 * trunc(MyDateNumber) + 14780.0) / 3652425.0);
+  int MyDay = (int)MyDateNumber - ((int)(365.0 * (double)MyYear) + (int)(0.25 * (double)MyYear) -
+                                   (int)(0.01 * (double)MyYear) + (int)(0.0025 * (double)MyYear));
+  if (MyDay < 0) {
+    MyYear = MyYear - 1;
+    MyDay = (int)MyDateNumber - ((int)(365.0 * (double)MyYear) + (int)(0.25 * (double)MyYear) -
+                                 (int)(0.01 * (double)MyYear) + (int)(0.0025 * (double)MyYear));
+  }
+  const int MyMonth = (int)((100.0 * (double)MyDay + 52.0) / 3060.0);
+  const int month = (MyMonth + 2) % 12 + 1;
+  const int year = MyYear + (int)(((double)MyMonth + 2.0) / 12.0);
+  const int day = MyDay - (int)(0.1 * ((double)MyMonth * 306.0 + 5.0)) + 1;
+  double seconds = DayFraction * 86400.0;
+  const double CT = 3.0 * 2.220446049250313e-16;
+  seconds = tround(seconds, CT);
+  *hour = seconds / 3600.0;
+  /* yearday */
+  int fac = (((year % 4 == 0) && (year % 100 != 0)) || (year % 400 == 0)) ? 1 : 2;
+  const int yd = (int)((275.0f * (float)month) / 9.0f) - fac * ((month + 9) / 12) + day - 30;
+  *yday = (double)yd + DayFraction;
+}
+
+static double bulk_psiu(double ZoL) {
+  const double r3 = 1.0 / 3.0;
+  if (ZoL < 0.0) {
+    const double x = pow(1.0 - 15.0 * ZoL, 0.25);
+    const double psik = 2.0 * log(0.5 * (1.0 + x)) + log(0.5 * (1.0 + x * x)) - 2.0 * atan(x) + 0.5 * pi;
+    double cff = sqrt(3.0);
+    const double y = pow(1.0 - 10.15 * ZoL, r3);
+    const double psic = 1.5 * log(r3 * (1.0 + y + y * y)) - cff * atan((1.0 + 2.0 * y) / cff) + pi / cff;
+    cff = ZoL * ZoL;
+    const double Fw = cff / (1.0 + cff);
+    return (1.0 - Fw) * psik + Fw * psic;
+  }
+  const double cff = MIN(50.0, 0.35 * ZoL);
+  return -((1.0 + ZoL) + 0.6667 * (ZoL - 14.28) / exp(cff) + 8.525);
+}
+
+static double bulk_psit(double ZoL) {
+  const double r3 = 1.0 / 3.0;
+  if (ZoL < 0.0) {
+    const double x = pow(1.0 - 15.0 * ZoL, 0.5);
+    const double psik = 2.0 * log(0.5 * (1.0 + x));
+    double cff = sqrt(3.0);
+    const double y = pow(1.0 - 34.15 * ZoL, r3);
+    const double psic = 1.5 * log(r3 * (1.0 + y + y * y)) - cff * atan((1.0 + 2.0 * y) / cff) + pi / cff;
+    cff = ZoL * ZoL;
+    const double Fw = cff / (1.0 + cff);
+    return (1.0 - Fw) * psik + Fw * psic;
+  }
+  const double cff = MIN(50.0, 0.35 * ZoL);
+  return -(pow(1.0 + 2.0 * ZoL, 1.5) + 0.6667 * (ZoL - 14.28) / exp(cff) + 8.525);
+}
+
+void orc_bulk_flux(orc_t *o, int tile) {
+  ORC_LOCALS(o);
+  const orc_bounds *b = &o->b[tile];
+  const orc_cfg *c = &o->c;
+  const int nrhs = o->s.nrhs;
+  const int Istr = b->Istr, Jstr = b->Jstr, IendR = b->IendR, JendR = b->JendR;
+  const double eps = 1.0E-20, r3 = 1.0 / 3.0, g = c->g;
+  const double ZW = c->blk_ZW, ZT = c->blk_ZT, ZQ = c->blk_ZQ;
+  double *S = (double *)calloc(5 * nij, sizeof(double));
+  double *LHeat = S, *LRad = S + nij, *SHeat = S + 2 * nij, *Taux = S + 3 * nij, *Tauy = S + 4 * nij;
+  double Hscale = c->rho0 * c->Cp;
+  for (int j = Jstr - 1; j <= JendR; j++)
+    for (int i = Istr - 1; i <= IendR; i++) {
+      const double Uair = o->Uwind[X2(i, j)], Vair = o->Vwind[X2(i, j)];
+      const double Wmag = sqrt(Uair * Uair + Vair * Vair);
+      const double PairM = o->Pair[X2(i, j)];
+      const double TairC = o->Tair[X2(i, j)];
+      const double TairK = TairC + 273.16;
+      const double TseaC = o->t[XT(i, j, N, nrhs, 1)];
+      const double TseaK = TseaC + 273.16;
+      const double RH = o->Hair[X2(i, j)];
+      double delTc = 0.0, delQc = 0.0;
+      double cff, cff1, cff2;
+      /* net longwave radiation (LONGWAVE, Berliand formula) */
+      cff = (0.7859 + 0.03477 * TairC) / (1.0 + 0.00412 * TairC);
+      const double e_sat = pow(10.0, cff);
+      const double vap_p = e_sat * RH;
+      cff2 = TairK * TairK * TairK;
+      cff1 = cff2 * TairK;
+      LRad[X2(i, j)] = -emmiss * StefBo *
+                       (cff1 * (0.39 - 0.05 * sqrt(vap_p)) * (1.0 - 0.6823 * o->cloud[X2(i, j)] * o->cloud[X2(i, j)]) +
+                        cff2 * 4.0 * (TseaK - TairK));
+      /* specific humidities */
+      cff = (1.0007 + 3.46E-6 * PairM) * 6.1121 * exp(17.502 * TairC / (240.97 + TairC));
+      const double Qair = 0.62197 * (cff / (PairM - 0.378 * cff + eps));
+      double Q;
+      if (RH < 2.0) {
+        cff = cff * RH;
+        Q = 0.62197 * (cff / (PairM - 0.378 * cff + eps));
+      } else Q = RH / 1000.0;
+      cff = (1.0007 + 3.46E-6 * PairM) * 6.1121 * exp(17.502 * TseaC / (240.97 + TseaC));
+      cff = cff * 0.98;
+      const double Qsea = 0.62197 * (cff / (PairM - 0.378 * cff));
+      const double rhoAir = PairM * 100.0 / (blk_Rgas * TairK * (1.0 + 0.61 * Q));
+      const double VisAir = 1.326E-5 * (1.0 + TairC * (6.542E-3 + TairC * (8.301E-6 - 4.84E-9 * TairC)));
+      const double Hlv = (2.501 - 0.00237 * TseaC) * 1.0E+6;
+      double Wgus = 0.5;
+      double delW = sqrt(Wmag * Wmag + Wgus * Wgus);
+      const double delQ = Qsea - Q;
+      const double delT = TseaC - TairC;
+      /* neutral first guess */
+      double ZoW = 0.0001;
+      const double u10 = delW * log(10.0 / ZoW) / log(ZW / ZoW);
+      double Wstar = 0.035 * u10;
+      const double Zo10 = 0.011 * Wstar * Wstar / g + 0.11 * VisAir / Wstar;
+      double tmp = vonKar / log(10.0 / Zo10);
+      const double Cd10 = tmp * tmp;
+      const double Ch10 = 0.00115;
+      const double Ct10 = Ch10 / sqrt(Cd10);
+      const double ZoT10 = 10.0 / exp(vonKar / Ct10);
+      tmp = vonKar / log(ZW / Zo10);
+      const double Cd = tmp * tmp;
+      const double Ct = vonKar / log(ZT / ZoT10);
+      const double CC = vonKar * Ct / Cd;
+      delTc = 0.0;
+      const double Ribcu = -ZW / (blk_Zabl * 0.004 * (blk_beta * blk_beta * blk_beta));
+      const double Ri = -g * ZW * ((delT - delTc) + 0.61 * TairK * delQ) / (TairK * delW * delW + eps);
+      double Zetu;
+      if (Ri < 0.0) Zetu = CC * Ri / (1.0 + Ri / Ribcu);
+      else Zetu = CC * Ri / (1.0 + 3.0 * Ri / CC);
+      const double L10 = ZW / Zetu;
+      Wstar = delW * vonKar / (log(ZW / Zo10) - bulk_psiu(ZW / L10));
+      double Tstar = -(delT - delTc) * vonKar / (log(ZT / ZoT10) - bulk_psit(ZT / L10));
+      double Qstar = -(delQ - delQc) * vonKar / (log(ZQ / ZoT10) - bulk_psit(ZQ / L10));
+      const double charn = MIN(0.028, -0.005 + 0.0017 * delW);
+      for (int Iter = 1; Iter <= 3; Iter++) {
+        ZoW = charn * Wstar * Wstar / g + 0.11 * VisAir / (Wstar + eps);
+        const double Rr = ZoW * Wstar / VisAir;
+        const double ZoQ = MIN(1.6e-4, 5.8e-5 / pow(Rr, 0.72));
+        const double ZoT = ZoQ;
+        const double ZoL = vonKar * g * ZW * (Tstar * (1.0 + 0.61 * Q) + 0.61 * TairK * Qstar) /
+                           (TairK * Wstar * Wstar * (1.0 + 0.61 * Q) + eps);
+        const double L = ZW / (ZoL + eps);
+        const double Wpsi = bulk_psiu(ZoL);
+        const double Tpsi = bulk_psit(ZT / L);
+        const double Qpsi = bulk_psit(ZQ / L);
+        Wstar = MAX(eps, delW * vonKar / (log(ZW / ZoW) - Wpsi));
+        Tstar = -(delT - delTc) * vonKar / (log(ZT / ZoT) - Tpsi);
+        Qstar = -(delQ - delQc) * vonKar / (log(ZQ / ZoQ) - Qpsi);
+        const double Bf = -g / TairK * Wstar * (Tstar + 0.61 * TairK * Qstar);
+        if (Bf > 0.0) Wgus = blk_beta * pow(Bf * blk_Zabl, r3);
+        else Wgus = 0.2;
+        delW = sqrt(Wmag * Wmag + Wgus * Wgus);
+      }
+      /* heat and momentum fluxes */
+      const double Hs = -blk_Cpa * rhoAir * Wstar * Tstar;
+      const double diffw = 2.11E-5 * pow(TairK / 273.16, 1.94);
+      const double diffh = 0.02411 * (1.0 + TairC * (3.309E-3 - 1.44E-6 * TairC)) / (rhoAir * blk_Cpa + eps);
+      cff = Qair * Hlv / (blk_Rgas * TairK * TairK);
+      const double wet_bulb = 1.0 / (1.0 + 0.622 * (cff * Hlv * diffw) / (blk_Cpa * diffh));
+      const double Hsr = fabs(o->rain[X2(i, j)]) * wet_bulb * blk_Cpw * ((TseaC - TairC) + (Qsea - Q) * Hlv / blk_Cpa);
+      SHeat[X2(i, j)] = (Hs + Hsr);
+      const double Hl = -Hlv * rhoAir * Wstar * Qstar;
+      const double upvel = -1.61 * Wstar * Qstar - (1.0 + 1.61 * Q) * Wstar * Tstar / TairK;
+      const double Hlw = rhoAir * Hlv * upvel * Q;
+      LHeat[X2(i, j)] = (Hl + Hlw);
+      const double Taur = 0.85 * fabs(o->rain[X2(i, j)]) * Wmag;
+      cff = rhoAir * (Wstar * Wstar + Taur / rhoAir) / (Wmag + eps);
+      Taux[X2(i, j)] = cff * Uair;
+      Tauy[X2(i, j)] = cff * Vair;
+    }
+  Hscale = 1.0 / (c->rho0 * c->Cp);
+  for (int j = b->JstrR; j <= JendR; j++)
+    for (int i = b->IstrR; i <= IendR; i++) {
+      o->lrflx[X2(i, j)] = LRad[X2(i, j)] * Hscale;
+      o->lhflx[X2(i, j)] = -LHeat[X2(i, j)] * Hscale;
+      o->shflx[X2(i, j)] = -SHeat[X2(i, j)] * Hscale;
+      o->stflux[X2T(i, j, 1)] = (o->srflx[X2(i, j)] + o->lrflx[X2(i, j)] + o->lhflx[X2(i, j)] + o->shflx[X2(i, j)]);
+    }
+  const double cff = 0.5 / c->rho0;
+  for (int j = b->JstrR; j <= JendR; j++)
+    for (int i = Istr; i <= IendR; i++) o->sustr[X2(i, j)] = cff * (Taux[X2(i - 1, j)] + Taux[X2(i, j)]);
+  for (int j = Jstr; j <= JendR; j++)
+    for (int i = b->IstrR; i <= IendR; i++) o->svstr[X2(i, j)] = cff * (Tauy[X2(i, j - 1)] + Tauy[X2(i, j)]);
+  free(S);
+  (void)rhow;
+  orc_exchange2d(o, b, 'r', o->lrflx);
+  orc_exchange2d(o, b, 'r', o->lhflx);
+  orc_exchange2d(o, b, 'r', o->shflx);
+  orc_exchange2d(o, b, 'r', o->stflux);
+  orc_exchange2d(o, b, 'u', o->sustr);
+  orc_exchange2d(o, b, 'v', o->svstr);
+}
+
+/* set_data for BENCHMARK: analytic cloud, Tair, Hair, srflux, winds, rain, btflux, stflux(salt), Pair */
+void orc_set_data_benchmark(orc_t *o, int tile) {
+  ORC_LOCALS(o);
+  const orc_bounds *b = &o->b[tile];
+  const orc_cfg *c = &o->c;
+  const int i0 = b->IstrT, i1 = b->IendT, j0 = b->JstrT, j1 = b->JendT;
+  for (int j = j0; j <= j1; j++)
+    for (int i = i0; i <= i1; i++) {
+      o->cloud[X2(i, j)] = 0.6;
+      o->Tair[X2(i, j)] = 4.0;
+      o->Hair[X2(i, j)] = 0.8;
+    }
+  orc_exchange2d(o, b, 'r', o->cloud);
+  orc_exchange2d(o, b, 'r', o->Tair);
+  orc_exchange2d(o, b, 'r', o->Hair);
+  /* ana_srflux */
+  double yday, hour;
+  orc_caldate(o->s.tdays, &yday, &hour);
+  double Dangle = 23.44 * cos((172.0 - yday) * 2.0 * pi / 365.2425);
+  Dangle = Dangle * deg2rad;
+  const double Hangle = (12.0 - hour) * pi / 12.0;
+  const double Rsolar = Csolar / (c->rho0 * c->Cp);
+  const double alb_w = 0.06;
+  for (int j = j0; j <= j1; j++)
+    for (int i = i0; i <= i1; i++) {
+      const double LatRad = o->latr[X2(i, j)] * deg2rad;
+      const double cff1 = sin(LatRad) * sin(Dangle);
+      const double cff2 = cos(LatRad) * cos(Dangle);
+      double sr = 0.0;
+      const double zenith = cff1 + cff2 * cos(Hangle - o->lonr[X2(i, j)] * deg2rad);
+      if (zenith > 0.0) {
+        const double cff = (0.7859 + 0.03477 * o->Tair[X2(i, j)]) / (1.0 + 0.00412 * o->Tair[X2(i, j)]);
+        const double e_sat = pow(10.0, cff);
+        const double vap_p = e_sat * o->Hair[X2(i, j)];
+        const double cl = o->cloud[X2(i, j)];
+        sr = Rsolar * zenith * zenith * (1.0 - 0.6 * (cl * cl * cl)) /
+             ((zenith + 2.7) * vap_p * 1.0E-3 + 1.085 * zenith + 0.1);
+      }
+      o->srflx[X2(i, j)] = (1.0 - alb_w) * sr;
+    }
+  orc_exchange2d(o, b, 'r', o->srflx);
+  /* ana_winds */
+  for (int j = j0; j <= j1; j++)
+    for (int i = i0; i <= i1; i++) {
+      const double cff = 0.2 * (60.0 + o->latr[X2(i, j)]);
+      o->Uwind[X2(i, j)] = 15.0 * exp(-cff * cff);
+      o->Vwind[X2(i, j)] = 0.0;
+    }
+  orc_exchange2d(o, b, 'r', o->Uwind);
+  orc_exchange2d(o, b, 'r', o->Vwind);
+  for (int j = j0; j <= j1; j++)
+    for (int i = i0; i <= i1; i++) {
+      o->rain[X2(i, j)] = 0.0;
+      o->btflux[X2T(i, j, 1)] = 0.0;
+      o->stflux[X2T(i, j, 2)] = 0.0;
+      o->btflux[X2T(i, j, 2)] = 0.0;
+      o->Pair[X2(i, j)] = 1025.0;
+    }
+  orc_exchange2d(o, b, 'r', o->rain);
+  orc_exchange2d(o, b, 'r', o->stflux + nij);
+  orc_exchange2d(o, b, 'r', o->Pair);
+}

@@ -57,6 +57,7 @@
 !
       SUBROUTINE ref_configure (ipar, rpar) bind(C, name="ref_configure")
       USE tile_indices_mod, ONLY : tile_indices
+      USE dateclock_mod,    ONLY : ref_clock
       integer(c_int), intent(in) :: ipar(*)
       real(c_double), intent(in) :: rpar(*)
       integer :: itrc, ibry, ivar, tile
@@ -151,6 +152,8 @@
       Zos(ng)=rpar(20)
       gamma2(ng)=rpar(21)
       dstart=rpar(22)
+      time_ref=0.0_dp
+      CALL ref_clock (time_ref)
 #ifdef BULK_FLUXES
       blk_ZQ(ng)=rpar(23)
       blk_ZT(ng)=rpar(24)
