@@ -1,0 +1,143 @@
+// g_bench.cpp -- launch sequences of the BENCHMARK-only physics: nonlinear EOS, geopotential
+// tracer mixing, KPP vertical mixing, COARE bulk fluxes, analytic atmospheric forcing.
+#include "roms_host.h"
+#include "k_bench.h"
+#include "k_lmd.h"
+#include <cmath>
+
+static inline size_t lds_sz(const DGrid &G) { return (size_t)(G.bw + 6) * (size_t)(G.bh + 6); }
+
+static inline KArgs mk(roms_hip_ctx *c) {
+  KArgs a;
+  a.G = c->G;
+  a.F = c->F;
+  a.p0 = a.p1 = a.p2 = 0;
+  return a;
+}
+
+// Jerlov water type tables, mod_scalars.F:1110-1118
+static const double k_mu1[9] = {0.35, 0.6, 1.0, 1.5, 1.4, 0.42, 0.37, 0.33, 0.00468592};
+static const double k_mu2[9] = {23.0, 20.0, 17.0, 14.0, 7.9, 5.13, 3.54, 2.34, 1.51};
+static const double k_r1[9] = {0.58, 0.62, 0.67, 0.77, 0.78, 0.57, 0.57, 0.57, 0.55};
+
+int run_eos_nonlinear(roms_hip_ctx *c) {
+  const TB &B = c->G.T;
+  const int N = c->G.N;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_eos_nl, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
+  HaloSpec sp[7] = {{c->F.rho, N, BC_NONE, 'r'},  {c->F.pden, N, BC_NONE, 'r'}, {c->F.alpha, 1, BC_NONE, 'r'},
+                    {c->F.beta, 1, BC_NONE, 'r'}, {c->F.rhoA, 1, BC_NONE, 'r'}, {c->F.rhoS, 1, BC_NONE, 'r'},
+                    {c->F.bvf, N + 1, BC_NONE, 'r'}};
+  launch_halo_multi(c, sp, 7);
+  return 0;
+}
+
+int run_t3dmix2_geo(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  KArgs a = mk(c);
+  LAUNCH_COOP(k_t3dmix2_geo, G.nbx, G.nby, G.N * G.NT, 256, GEO_NLDS * lds_sz(G), c->stream, a);
+  return 0;
+}
+
+int run_swdk(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  const int J = c->cfg.lmd_Jwt;
+  if (J < 1 || J > 9) { set_error("lmd_Jwt out of range"); return 5; }
+  SwArgs a;
+  a.G = G; a.F = c->F;
+  a.fac1 = -1.0 / k_mu1[J - 1]; a.fac2 = -1.0 / k_mu2[J - 1]; a.fac3 = k_r1[J - 1];
+  LAUNCH_THREAD(k_swdk, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
+  return 0;
+}
+
+int run_lmd_vmix(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  const int N = G.N, J = c->cfg.lmd_Jwt;
+  if (J < 1 || J > 9) { set_error("lmd_Jwt out of range"); return 5; }
+  LmdArgs a;
+  a.G = G; a.F = c->F;
+  a.fac1 = -1.0 / k_mu1[J - 1]; a.fac2 = -1.0 / k_mu2[J - 1]; a.fac3 = k_r1[J - 1];
+  const double lmd_Cstar = 10.0, lmd_Cv = 1.25, lmd_Ric = 0.3, lmd_betaT = -0.2, lmd_cs = 98.96, lmd_epsilon = 0.1,
+               vonKar = 0.41;
+  a.lmd_Cg = lmd_Cstar * vonKar * pow(lmd_cs * vonKar * lmd_epsilon, 1.0 / 3.0);          // mod_scalars.F:2862
+  a.Vtc = lmd_Cv * sqrt(-lmd_betaT) / (sqrt(lmd_cs * lmd_epsilon) * lmd_Ric * vonKar * vonKar);
+  const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
+  LAUNCH_THREAD(k_lmd_interior, nx, ny, 1, c->stream, a);
+  LAUNCH_THREAD(k_lmd_skpp, nx, ny, 1, c->stream, a);
+  LAUNCH_THREAD(k_lmd_finish, nx, ny, N - 1, c->stream, a);
+  HaloSpec sp[3] = {{c->F.hsbl, 1, BC_R, 'r'},                       // bc_r2d_tile lmd_skpp.F:608
+                    {c->F.Akv, N + 1, BC_R, 'r'},                    // bc_w3d_tile lmd_vmix.F:740-760
+                    {c->F.Akt, (N + 1) * G.NAT, BC_R, 'r'}};
+  launch_halo_multi(c, sp, 3);
+  return 0;
+}
+
+int run_bulk_flux(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  BulkArgs a;
+  a.G = G; a.F = c->F;
+  a.ZW = c->cfg.blk_ZW; a.ZT = c->cfg.blk_ZT; a.ZQ = c->cfg.blk_ZQ;
+  LAUNCH_THREAD(k_bulk_pt, B.IendR - (B.Istr - 1) + 1, B.JendR - (B.Jstr - 1) + 1, 1, c->stream, a);
+  LAUNCH_THREAD(k_bulk_str, B.IendR - KMIN(B.Istr, B.IstrR) + 1, B.JendR - KMIN(B.Jstr, B.JstrR) + 1, 1, c->stream, a);
+  HaloSpec sp[6] = {{c->F.lrflx, 1, BC_NONE, 'r'},  {c->F.lhflx, 1, BC_NONE, 'r'}, {c->F.shflx, 1, BC_NONE, 'r'},
+                    {c->F.stflux, 1, BC_NONE, 'r'}, {c->F.sustr, 1, BC_NONE, 'u'}, {c->F.svstr, 1, BC_NONE, 'v'}};
+  launch_halo_multi(c, sp, 6);
+  return 0;
+}
+
+// ---- calendar of the reference for time_ref = 0 (caldate/datevec/datenum, dateclock.F; tolerant
+//      ROUND, round.F): day of the year (fractional) and hour of the day of model time tdays.
+static double k_ufloor(double X) { return X - fmod(X, 1.0) - fmod(2.0 + copysign(1.0, X), 3.0); }
+static double k_tfloor(double X, double CT) {
+  double Q = 1.0;
+  if (X < 0.0) Q = 1.0 - CT;
+  const double RMAX = Q / (2.0 - CT), EPS5 = CT / Q;
+  const double Y = k_ufloor(X + fmax(CT, fmin(RMAX, EPS5 * fabs(1.0 + k_ufloor(X)))));
+  if (X <= 0.0 || (Y - X) < RMAX) return Y;
+  return Y - 1.0;
+}
+void roms_caldate(double tdays, double *yday, double *hour) {
+  const double DateNumber = 367.0 + tdays;            // datenum(0001-01-01) = 367
+  const double DayFraction = fabs(DateNumber - trunc(DateNumber));
+  double D = DateNumber;
+  D = (D < 61.0) ? D - 61.0 + 1.0 : D - 61.0;
+  int yr = (int)((10000.0 * trunc(D) + 14780.0) / 3652425.0);
+  int dy = (int)D - ((int)(365.0 * yr) + (int)(0.25 * yr) - (int)(0.01 * yr) + (int)(0.0025 * yr));
+  if (dy < 0) {
+    yr -= 1;
+    dy = (int)D - ((int)(365.0 * yr) + (int)(0.25 * yr) - (int)(0.01 * yr) + (int)(0.0025 * yr));
+  }
+  const int mo = (int)((100.0 * dy + 52.0) / 3060.0);
+  const int month = (mo + 2) % 12 + 1;
+  const int year = yr + (int)((mo + 2.0) / 12.0);
+  const int day = dy - (int)(0.1 * (mo * 306.0 + 5.0)) + 1;
+  double seconds = DayFraction * 86400.0;
+  seconds = k_tfloor(seconds + 0.5, 3.0 * 2.220446049250313e-16);
+  *hour = seconds / 3600.0;
+  const int fac = (((year % 4 == 0) && (year % 100 != 0)) || (year % 400 == 0)) ? 1 : 2;
+  const int yd = (int)((275.0f * (float)month) / 9.0f) - fac * ((month + 9) / 12) + day - 30;
+  *yday = (double)yd + DayFraction;
+}
+
+int run_set_data_benchmark(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  const double pi = 3.14159265358979323846, deg2rad = pi / 180.0;
+  SetDataBmArgs a;
+  a.G = G; a.F = c->F;
+  double yday, hour;
+  roms_caldate(G.tdays, &yday, &hour);
+  double Dangle = 23.44 * cos((172.0 - yday) * 2.0 * pi / 365.2425);   // ana_srflux.h:215-220
+  a.Dangle = Dangle * deg2rad;
+  a.Hangle = (12.0 - hour) * pi / 12.0;
+  LAUNCH_THREAD(k_set_data_bm, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
+  HaloSpec s1[8] = {{c->F.cloud, 1, BC_NONE, 'r'}, {c->F.Tair, 1, BC_NONE, 'r'},  {c->F.Hair, 1, BC_NONE, 'r'},
+                    {c->F.srflx, 1, BC_NONE, 'r'}, {c->F.Uwind, 1, BC_NONE, 'r'}, {c->F.Vwind, 1, BC_NONE, 'r'},
+                    {c->F.rain, 1, BC_NONE, 'r'},  {c->F.Pair, 1, BC_NONE, 'r'}};
+  launch_halo_multi(c, s1, 8);
+  launch_halo(c, c->F.stflux + G.nij, 1, BC_NONE, 'r');
+  return 0;
+}

@@ -1,23 +1,11 @@
 // g_stubs.cpp -- entry points whose kernels are not written yet return exit_flag 8 (loudly).
 #include "roms_host.h"
 #define STUB(name) int name(roms_hip_ctx *) { set_error(#name ": not implemented in this build"); return 8; }
-#ifndef HAVE_GEO
-STUB(run_t3dmix2_geo)
-#endif
 #if 0
 STUB(run_step2d)
 #endif
 #ifndef HAVE_MPDATA
 STUB(run_step3d_t_mpdata)
-#endif
-#ifndef HAVE_LMD
-STUB(run_lmd_vmix) STUB(run_swdk)
-#endif
-#ifndef HAVE_BULK
-STUB(run_bulk_flux) STUB(run_set_data_benchmark)
-#endif
-#ifndef HAVE_EOS
-STUB(run_eos_nonlinear)
 #endif
 #if 0
 int run_diag(roms_hip_ctx *, double *) { set_error("run_diag: not implemented in this build"); return 8; }

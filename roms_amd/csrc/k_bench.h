@@ -1,0 +1,455 @@
+// k_bench.h -- physics that only BENCHMARK-type applications switch on:
+//
+//   k_eos_nl        rho_eos_tile (NONLIN_EOS)   ROMS/Nonlinear/rho_eos.F:247-560, mod_eoscoef.F
+//   k_t3dmix2_geo   t3dmix2_geo_tile            ROMS/Nonlinear/t3dmix2_geo.h:90-420
+//   k_bulk_pt, k_bulk_str  bulk_flux_tile       ROMS/Nonlinear/bulk_flux.F:208-1595 (COARE 3.0)
+//   k_set_data_bm   set_data_tile (analytic)    ana_cloud/tair/humid/srflux/winds/rain/pair .h
+//   k_swdk          lmd_swfrac_tile             ROMS/Nonlinear/lmd_swfrac.F:6-140 (pre_step3d use)
+//
+// All point-wise / column-wise and HBM-bound except bulk_flux (2-D, transcendental-bound, tiny).
+#pragma once
+#include "roms_ctx.h"
+#include "k_diag3d.h"
+
+// ------------------------------------------------------------------------------- nonlinear EOS
+// one thread per column of (IstrT:IendT, JstrT:JendT); den1, bulk0/1/2 of level k+1 are carried
+// in registers for the Brunt-Vaisala frequency, rhoA/rhoS are accumulated top-down.
+struct EosLevel { double den, den1, bulk, bulk0, bulk1, bulk2, DbulkDS, DbulkDT, Dden1DS, Dden1DT; };
+
+KDEV EosLevel eos_level(double Tt_in, double Ts_in, double Tp) {
+  const double A00 = +1.909256e+04, A01 = +2.098925e+02, A02 = -3.041638e+00, A03 = -1.852732e-03, A04 = -1.361629e-05,
+               B00 = +1.044077e+02, B01 = -6.500517e+00, B02 = +1.553190e-01, B03 = +2.326469e-04, D00 = -5.587545e+00,
+               D01 = +7.390729e-01, D02 = -1.909078e-02, E00 = +4.721788e-01, E01 = +1.028859e-02, E02 = -2.512549e-04,
+               E03 = -5.939910e-07, F00 = -1.571896e-02, F01 = -2.598241e-04, F02 = +7.267926e-06, G00 = +2.042967e-03,
+               G01 = +1.045941e-05, G02 = -5.782165e-10, G03 = +1.296821e-07, H00 = -2.595994e-07, H01 = -1.248266e-09,
+               H02 = -3.508914e-09, Q00 = +9.99842594e+02, Q01 = +6.793952e-02, Q02 = -9.095290e-03, Q03 = +1.001685e-04,
+               Q04 = -1.120083e-06, Q05 = +6.536332e-09, U00 = +8.24493e-01, U01 = -4.08990e-03, U02 = +7.64380e-05,
+               U03 = -8.24670e-07, U04 = +5.38750e-09, V00 = -5.72466e-03, V01 = +1.02270e-04, V02 = -1.65460e-06,
+               W00 = +4.8314e-04;
+  EosLevel L;
+  const double Tt = KMAX(-2.0, Tt_in), Ts = KMAX(0.0, Ts_in);
+  const double sqrtTs = sqrt(Ts);
+  const double Tpr10 = 0.1 * Tp;
+  double C[10], dCdT[10];
+  C[0] = Q00 + Tt * (Q01 + Tt * (Q02 + Tt * (Q03 + Tt * (Q04 + Tt * Q05))));
+  C[1] = U00 + Tt * (U01 + Tt * (U02 + Tt * (U03 + Tt * U04)));
+  C[2] = V00 + Tt * (V01 + Tt * V02);
+  dCdT[0] = Q01 + Tt * (2.0 * Q02 + Tt * (3.0 * Q03 + Tt * (4.0 * Q04 + Tt * 5.0 * Q05)));
+  dCdT[1] = U01 + Tt * (2.0 * U02 + Tt * (3.0 * U03 + Tt * 4.0 * U04));
+  dCdT[2] = V01 + Tt * 2.0 * V02;
+  L.den1 = C[0] + Ts * (C[1] + sqrtTs * C[2] + Ts * W00);
+  L.Dden1DS = C[1] + 1.5 * C[2] * sqrtTs + 2.0 * W00 * Ts;
+  L.Dden1DT = dCdT[0] + Ts * (dCdT[1] + sqrtTs * dCdT[2]);
+  C[3] = A00 + Tt * (A01 + Tt * (A02 + Tt * (A03 + Tt * A04)));
+  C[4] = B00 + Tt * (B01 + Tt * (B02 + Tt * B03));
+  C[5] = D00 + Tt * (D01 + Tt * D02);
+  C[6] = E00 + Tt * (E01 + Tt * (E02 + Tt * E03));
+  C[7] = F00 + Tt * (F01 + Tt * F02);
+  C[8] = G01 + Tt * (G02 + Tt * G03);
+  C[9] = H00 + Tt * (H01 + Tt * H02);
+  dCdT[3] = A01 + Tt * (2.0 * A02 + Tt * (3.0 * A03 + Tt * 4.0 * A04));
+  dCdT[4] = B01 + Tt * (2.0 * B02 + Tt * 3.0 * B03);
+  dCdT[5] = D01 + Tt * 2.0 * D02;
+  dCdT[6] = E01 + Tt * (2.0 * E02 + Tt * 3.0 * E03);
+  dCdT[7] = F01 + Tt * 2.0 * F02;
+  dCdT[8] = G02 + Tt * 2.0 * G03;
+  dCdT[9] = H01 + Tt * 2.0 * H02;
+  L.bulk0 = C[3] + Ts * (C[4] + sqrtTs * C[5]);
+  L.bulk1 = C[6] + Ts * (C[7] + sqrtTs * G00);
+  L.bulk2 = C[8] + Ts * C[9];
+  L.bulk = L.bulk0 - Tp * (L.bulk1 - Tp * L.bulk2);
+  L.DbulkDS = C[4] + sqrtTs * 1.5 * C[5] - Tp * (C[7] + sqrtTs * 1.5 * G00 - Tp * C[9]);
+  L.DbulkDT = dCdT[3] + Ts * (dCdT[4] + sqrtTs * dCdT[5]) - Tp * (dCdT[6] + Ts * dCdT[7] - Tp * (dCdT[8] + Ts * dCdT[9]));
+  const double cff = 1.0 / (L.bulk + Tpr10);
+  double den = L.den1 * L.bulk * cff;
+  L.den = den - 1000.0;
+  return L;
+}
+
+THREAD_KERNEL(k_eos_nl, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, N = G.N, nrhs = G.nrhs;
+  const double g = G.g;
+  double rhoA = 0.0, rhoS = 0.0;
+  EosLevel up = {};   // level k+1
+  for (int k = N; k >= 1; k--) {
+    const EosLevel L = eos_level(F.t[XT(i, j, k, nrhs, 1)], F.t[XT(i, j, k, nrhs, 2)], F.z_r[X3(i, j, k)]);
+    F.rho[X3(i, j, k)] = L.den;
+    F.pden[X3(i, j, k)] = (L.den1 - 1000.0);
+    const double Hzk = F.Hz[X3(i, j, k)];
+    const double cff1 = L.den * Hzk;
+    if (k == N) {
+      rhoS = 0.5 * cff1 * Hzk;
+      rhoA = cff1;
+      // thermal expansion / saline contraction at the surface :470-500
+      const double Tpr10 = 0.1 * F.z_r[X3(i, j, k)];
+      const double cff = L.bulk + Tpr10;
+      const double c1 = Tpr10 * L.den1;
+      const double c2 = L.bulk * cff;
+      const double wrk = (L.den + 1000.0) * cff * cff;
+      const double Tcof = -(L.DbulkDT * c1 + L.Dden1DT * c2);
+      const double Scof = (L.DbulkDS * c1 + L.Dden1DS * c2);
+      const double o = 1.0 / wrk;
+      F.alpha[X2(i, j)] = o * Tcof;
+      F.beta[X2(i, j)] = o * Scof;
+    } else {
+      rhoS = rhoS + Hzk * (rhoA + 0.5 * cff1);
+      rhoA = rhoA + cff1;
+      // Brunt-Vaisala frequency at W-level k (between k and k+1)
+      const double zw = F.z_w[XW(i, j, k)];
+      const double bulk_up = up.bulk0 - zw * (up.bulk1 - up.bulk2 * zw);
+      const double bulk_dn = L.bulk0 - zw * (L.bulk1 - L.bulk2 * zw);
+      const double c1 = 1.0 / (bulk_up + 0.1 * zw);
+      const double c2 = 1.0 / (bulk_dn + 0.1 * zw);
+      const double den_up = c1 * (up.den1 * bulk_up);
+      const double den_dn = c2 * (L.den1 * bulk_dn);
+      F.bvf[XW(i, j, k)] = -g * (den_up - den_dn) / (0.5 * (den_up + den_dn) * (F.z_r[X3(i, j, k + 1)] - F.z_r[X3(i, j, k)]));
+    }
+    up = L;
+  }
+  F.bvf[XW(i, j, 0)] = 0.0;
+  F.bvf[XW(i, j, N)] = 0.0;
+  const double cff2 = 1.0 / G.rho0;
+  const double cff1 = 1.0 / (F.z_w[XW(i, j, N)] - F.z_w[XW(i, j, 0)]);
+  F.rhoA[X2(i, j)] = cff2 * cff1 * rhoA;
+  F.rhoS[X2(i, j)] = 2.0 * cff1 * cff1 * cff2 * rhoS;
+}
+THREAD_GLOBAL(k_eos_nl, KArgs)
+
+// --------------------------------------------------------------------------------- t3dmix2_geo
+// One block = (sub-tile, rho-level k, tracer).  The reference's two-level rolling buffers become
+// LDS planes for the two rho levels (k, k+1) and the two W levels (k-1, k) that level k needs; the
+// vertical flux FS is evaluated at both W levels by the block itself (no inter-block dependency).
+#define GEO_NLDS 12
+COOP_KERNEL(k_t3dmix2_geo, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB B = block_bounds(G, bx, by);
+  const int k = bz % G.N + 1, itrc = bz / G.N + 1, N = G.N;
+  const int nrhs = G.nrhs, nnew = G.nnew;
+  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
+  const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
+  // rho-level planes: index 0 -> level k, 1 -> level k+1 ; W-level planes: 0 -> W level k-1, 1 -> W level k
+  double *dTdx[2] = {lds, lds + sz}, *dZdx[2] = {lds + 2 * sz, lds + 3 * sz}, *dTde[2] = {lds + 4 * sz, lds + 5 * sz},
+         *dZde[2] = {lds + 6 * sz, lds + 7 * sz}, *dTdz[2] = {lds + 8 * sz, lds + 9 * sz};
+  double *FX = lds + 10 * sz, *FE = lds + 11 * sz;
+  const double *t = F.t + XT(G.LBi, G.LBj, 1, nrhs, itrc);   // level 1 of t(nrhs)
+  const double *z_r = F.z_r, *pm = F.pm, *pn = F.pn, *Hz = F.Hz;
+  const double *diff2 = F.diff2 + (size_t)(itrc - 1) * G.nij;
+  for (int l = 0; l < 2; l++) {
+    const int kk = k + l;        // rho level
+    if (kk <= N) {
+      KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend + 1) {
+        if (j <= Jend) {
+          const double cff = 0.5 * (pm[X2(i, j)] + pm[X2(i - 1, j)]);
+          dZdx[l][S2(i, j)] = cff * (z_r[X3(i, j, kk)] - z_r[X3(i - 1, j, kk)]);
+          dTdx[l][S2(i, j)] = cff * (t[X3(i, j, kk)] - t[X3(i - 1, j, kk)]);
+        }
+        if (i <= Iend) {
+          const double cff = 0.5 * (pn[X2(i, j)] + pn[X2(i, j - 1)]);
+          dZde[l][S2(i, j)] = cff * (z_r[X3(i, j, kk)] - z_r[X3(i, j - 1, kk)]);
+          dTde[l][S2(i, j)] = cff * (t[X3(i, j, kk)] - t[X3(i, j - 1, kk)]);
+        }
+      }
+    }
+    const int kw = k - 1 + l;    // W level
+    KLOOP2(i, j, Istr - 1, Iend + 1, Jstr - 1, Jend + 1) {
+      if (kw == 0 || kw == N) dTdz[l][S2(i, j)] = 0.0;
+      else {
+        const double cff = 1.0 / (z_r[X3(i, j, kw + 1)] - z_r[X3(i, j, kw)]);
+        dTdz[l][S2(i, j)] = cff * (t[X3(i, j, kw + 1)] - t[X3(i, j, kw)]);
+      }
+    }
+  }
+  KSYNC();
+  // horizontal fluxes at rho level k: k1 <-> plane 0 (level k, W level k-1), k2 <-> plane 1
+  KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend + 1) {
+    if (j <= Jend) {
+      const double cff = 0.25 * (diff2[X2(i, j)] + diff2[X2(i - 1, j)]) * F.on_u[X2(i, j)];
+      FX[S2(i, j)] = cff * (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]) *
+                     (dTdx[0][S2(i, j)] -
+                      0.5 * (KMIN(dZdx[0][S2(i, j)], 0.0) * (dTdz[0][S2(i - 1, j)] + dTdz[1][S2(i, j)]) +
+                             KMAX(dZdx[0][S2(i, j)], 0.0) * (dTdz[1][S2(i - 1, j)] + dTdz[0][S2(i, j)])));
+    }
+    if (i <= Iend) {
+      const double cff = 0.25 * (diff2[X2(i, j)] + diff2[X2(i, j - 1)]) * F.om_v[X2(i, j)];
+      FE[S2(i, j)] = cff * (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]) *
+                     (dTde[0][S2(i, j)] -
+                      0.5 * (KMIN(dZde[0][S2(i, j)], 0.0) * (dTdz[0][S2(i, j - 1)] + dTdz[1][S2(i, j)]) +
+                             KMAX(dZde[0][S2(i, j)], 0.0) * (dTdz[1][S2(i, j - 1)] + dTdz[0][S2(i, j)])));
+    }
+  }
+  KSYNC();
+  double *tn = F.t + XT(G.LBi, G.LBj, k, nnew, itrc);
+  KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
+    // vertical flux FS at W level k (FS2) and k-1 (FS1).  FS at W level kw couples rho levels kw
+    // (reference "k1") and kw+1 ("k2"): FS(kw) = f(dZdx(.,kw), dZdx(.,kw+1), dTdz(kw), dTdx ...)
+    double FS2 = 0.0, FS1 = 0.0;
+    const double cff = 0.5 * diff2[X2(i, j)];
+    if (k < N) {
+      const double tz = dTdz[1][S2(i, j)];
+      double c1 = KMIN(dZdx[0][S2(i, j)], 0.0), c2 = KMIN(dZdx[1][S2(i + 1, j)], 0.0);
+      double c3 = KMAX(dZdx[1][S2(i, j)], 0.0), c4 = KMAX(dZdx[0][S2(i + 1, j)], 0.0);
+      FS2 = cff * (c1 * (c1 * tz - dTdx[0][S2(i, j)]) + c2 * (c2 * tz - dTdx[1][S2(i + 1, j)]) +
+                   c3 * (c3 * tz - dTdx[1][S2(i, j)]) + c4 * (c4 * tz - dTdx[0][S2(i + 1, j)]));
+      c1 = KMIN(dZde[0][S2(i, j)], 0.0); c2 = KMIN(dZde[1][S2(i, j + 1)], 0.0);
+      c3 = KMAX(dZde[1][S2(i, j)], 0.0); c4 = KMAX(dZde[0][S2(i, j + 1)], 0.0);
+      FS2 = FS2 + cff * (c1 * (c1 * tz - dTde[0][S2(i, j)]) + c2 * (c2 * tz - dTde[1][S2(i, j + 1)]) +
+                         c3 * (c3 * tz - dTde[1][S2(i, j)]) + c4 * (c4 * tz - dTde[0][S2(i, j + 1)]));
+    }
+    if (k > 1) {
+      // W level k-1 couples rho levels k-1 ("k1") and k ("k2"); level k-1 differences in-line
+      const int km = k - 1;
+      const double cxi = 0.5 * (pm[X2(i, j)] + pm[X2(i - 1, j)]), cxp = 0.5 * (pm[X2(i + 1, j)] + pm[X2(i, j)]);
+      const double cei = 0.5 * (pn[X2(i, j)] + pn[X2(i, j - 1)]), cep = 0.5 * (pn[X2(i, j + 1)] + pn[X2(i, j)]);
+      const double dZx_i = cxi * (z_r[X3(i, j, km)] - z_r[X3(i - 1, j, km)]);
+      const double dZx_p = cxp * (z_r[X3(i + 1, j, km)] - z_r[X3(i, j, km)]);
+      const double dTx_i = cxi * (t[X3(i, j, km)] - t[X3(i - 1, j, km)]);
+      const double dTx_p = cxp * (t[X3(i + 1, j, km)] - t[X3(i, j, km)]);
+      const double dZe_j = cei * (z_r[X3(i, j, km)] - z_r[X3(i, j - 1, km)]);
+      const double dZe_p = cep * (z_r[X3(i, j + 1, km)] - z_r[X3(i, j, km)]);
+      const double dTe_j = cei * (t[X3(i, j, km)] - t[X3(i, j - 1, km)]);
+      const double dTe_p = cep * (t[X3(i, j + 1, km)] - t[X3(i, j, km)]);
+      const double tz = dTdz[0][S2(i, j)];
+      double c1 = KMIN(dZx_i, 0.0), c2 = KMIN(dZdx[0][S2(i + 1, j)], 0.0);
+      double c3 = KMAX(dZdx[0][S2(i, j)], 0.0), c4 = KMAX(dZx_p, 0.0);
+      FS1 = cff * (c1 * (c1 * tz - dTx_i) + c2 * (c2 * tz - dTdx[0][S2(i + 1, j)]) +
+                   c3 * (c3 * tz - dTdx[0][S2(i, j)]) + c4 * (c4 * tz - dTx_p));
+      c1 = KMIN(dZe_j, 0.0); c2 = KMIN(dZde[0][S2(i, j + 1)], 0.0);
+      c3 = KMAX(dZde[0][S2(i, j)], 0.0); c4 = KMAX(dZe_p, 0.0);
+      FS1 = FS1 + cff * (c1 * (c1 * tz - dTe_j) + c2 * (c2 * tz - dTde[0][S2(i, j + 1)]) +
+                         c3 * (c3 * tz - dTde[0][S2(i, j)]) + c4 * (c4 * tz - dTe_p));
+    }
+    const double c = G.dt * pm[X2(i, j)] * pn[X2(i, j)];
+    const double cff1 = c * (FX[S2(i + 1, j)] - FX[S2(i, j)]);
+    const double cff2 = c * (FE[S2(i, j + 1)] - FE[S2(i, j)]);
+    const double cff3 = G.dt * (FS2 - FS1);
+    const double cff4 = cff1 + cff2 + cff3;
+    tn[X2(i, j)] = tn[X2(i, j)] + cff4;
+  }
+}
+COOP_GLOBAL(k_t3dmix2_geo, KArgs)
+
+// ------------------------------------------------------------------------------------ bulk_flux
+KDEV double blk_psiu(double ZoL) {
+  const double pi = 3.14159265358979323846, r3 = 1.0 / 3.0;
+  if (ZoL < 0.0) {
+    const double x = pow(1.0 - 15.0 * ZoL, 0.25);
+    const double psik = 2.0 * log(0.5 * (1.0 + x)) + log(0.5 * (1.0 + x * x)) - 2.0 * atan(x) + 0.5 * pi;
+    double cff = sqrt(3.0);
+    const double y = pow(1.0 - 10.15 * ZoL, r3);
+    const double psic = 1.5 * log(r3 * (1.0 + y + y * y)) - cff * atan((1.0 + 2.0 * y) / cff) + pi / cff;
+    cff = ZoL * ZoL;
+    const double Fw = cff / (1.0 + cff);
+    return (1.0 - Fw) * psik + Fw * psic;
+  }
+  const double cff = KMIN(50.0, 0.35 * ZoL);
+  return -((1.0 + ZoL) + 0.6667 * (ZoL - 14.28) / exp(cff) + 8.525);
+}
+KDEV double blk_psit(double ZoL) {
+  const double pi = 3.14159265358979323846, r3 = 1.0 / 3.0;
+  if (ZoL < 0.0) {
+    const double x = pow(1.0 - 15.0 * ZoL, 0.5);
+    const double psik = 2.0 * log(0.5 * (1.0 + x));
+    double cff = sqrt(3.0);
+    const double y = pow(1.0 - 34.15 * ZoL, r3);
+    const double psic = 1.5 * log(r3 * (1.0 + y + y * y)) - cff * atan((1.0 + 2.0 * y) / cff) + pi / cff;
+    cff = ZoL * ZoL;
+    const double Fw = cff / (1.0 + cff);
+    return (1.0 - Fw) * psik + Fw * psic;
+  }
+  const double cff = KMIN(50.0, 0.35 * ZoL);
+  return -(pow(1.0 + 2.0 * ZoL, 1.5) + 0.6667 * (ZoL - 14.28) / exp(cff) + 8.525);
+}
+
+struct BulkArgs {
+  DGrid G;
+  Fields F;
+  double ZW, ZT, ZQ;
+};
+
+// point-wise over (Istr-1:IendR, Jstr-1:JendR): Taux -> wrk2[0], Tauy -> wrk2[1]; heat fluxes stored
+// on (IstrR:IendR, JstrR:JendR)
+THREAD_KERNEL(k_bulk_pt, BulkArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = B.Istr - 1 + gx, j = B.Jstr - 1 + gy, N = G.N, nrhs = G.nrhs;
+  const double StefBo = 5.67E-8, emmiss = 0.97, blk_Cpa = 1004.67, blk_Cpw = 4000.0, blk_Rgas = 287.1, blk_Zabl = 600.0,
+               blk_beta = 1.2, vonKar = 0.41;
+  const double eps = 1.0E-20, r3 = 1.0 / 3.0, g = G.g;
+  const double ZW = a.ZW, ZT = a.ZT, ZQ = a.ZQ;
+  const double Uair = F.Uwind[X2(i, j)], Vair = F.Vwind[X2(i, j)];
+  const double Wmag = sqrt(Uair * Uair + Vair * Vair);
+  const double PairM = F.Pair[X2(i, j)];
+  const double TairC = F.Tair[X2(i, j)];
+  const double TairK = TairC + 273.16;
+  const double TseaC = F.t[XT(i, j, N, nrhs, 1)];
+  const double TseaK = TseaC + 273.16;
+  const double RH = F.Hair[X2(i, j)];
+  double delTc = 0.0, delQc = 0.0;
+  double cff, cff1, cff2;
+  cff = (0.7859 + 0.03477 * TairC) / (1.0 + 0.00412 * TairC);
+  const double e_sat = pow(10.0, cff);
+  const double vap_p = e_sat * RH;
+  cff2 = TairK * TairK * TairK;
+  cff1 = cff2 * TairK;
+  const double cl = F.cloud[X2(i, j)];
+  const double LRad = -emmiss * StefBo * (cff1 * (0.39 - 0.05 * sqrt(vap_p)) * (1.0 - 0.6823 * cl * cl) + cff2 * 4.0 * (TseaK - TairK));
+  cff = (1.0007 + 3.46E-6 * PairM) * 6.1121 * exp(17.502 * TairC / (240.97 + TairC));
+  const double Qair = 0.62197 * (cff / (PairM - 0.378 * cff + eps));
+  double Q;
+  if (RH < 2.0) { cff = cff * RH; Q = 0.62197 * (cff / (PairM - 0.378 * cff + eps)); }
+  else Q = RH / 1000.0;
+  cff = (1.0007 + 3.46E-6 * PairM) * 6.1121 * exp(17.502 * TseaC / (240.97 + TseaC));
+  cff = cff * 0.98;
+  const double Qsea = 0.62197 * (cff / (PairM - 0.378 * cff));
+  const double rhoAir = PairM * 100.0 / (blk_Rgas * TairK * (1.0 + 0.61 * Q));
+  const double VisAir = 1.326E-5 * (1.0 + TairC * (6.542E-3 + TairC * (8.301E-6 - 4.84E-9 * TairC)));
+  const double Hlv = (2.501 - 0.00237 * TseaC) * 1.0E+6;
+  double Wgus = 0.5;
+  double delW = sqrt(Wmag * Wmag + Wgus * Wgus);
+  const double delQ = Qsea - Q;
+  const double delT = TseaC - TairC;
+  double ZoW = 0.0001;
+  const double u10 = delW * log(10.0 / ZoW) / log(ZW / ZoW);
+  double Wstar = 0.035 * u10;
+  const double Zo10 = 0.011 * Wstar * Wstar / g + 0.11 * VisAir / Wstar;
+  double tmp = vonKar / log(10.0 / Zo10);
+  const double Cd10 = tmp * tmp;
+  const double Ch10 = 0.00115;
+  const double Ct10 = Ch10 / sqrt(Cd10);
+  const double ZoT10 = 10.0 / exp(vonKar / Ct10);
+  tmp = vonKar / log(ZW / Zo10);
+  const double Cd = tmp * tmp;
+  const double Ct = vonKar / log(ZT / ZoT10);
+  const double CC = vonKar * Ct / Cd;
+  delTc = 0.0;
+  const double Ribcu = -ZW / (blk_Zabl * 0.004 * (blk_beta * blk_beta * blk_beta));
+  const double Ri = -g * ZW * ((delT - delTc) + 0.61 * TairK * delQ) / (TairK * delW * delW + eps);
+  double Zetu;
+  if (Ri < 0.0) Zetu = CC * Ri / (1.0 + Ri / Ribcu);
+  else Zetu = CC * Ri / (1.0 + 3.0 * Ri / CC);
+  const double L10 = ZW / Zetu;
+  Wstar = delW * vonKar / (log(ZW / Zo10) - blk_psiu(ZW / L10));
+  double Tstar = -(delT - delTc) * vonKar / (log(ZT / ZoT10) - blk_psit(ZT / L10));
+  double Qstar = -(delQ - delQc) * vonKar / (log(ZQ / ZoT10) - blk_psit(ZQ / L10));
+  const double charn = KMIN(0.028, -0.005 + 0.0017 * delW);
+  for (int Iter = 1; Iter <= 3; Iter++) {
+    ZoW = charn * Wstar * Wstar / g + 0.11 * VisAir / (Wstar + eps);
+    const double Rr = ZoW * Wstar / VisAir;
+    const double ZoQ = KMIN(1.6e-4, 5.8e-5 / pow(Rr, 0.72));
+    const double ZoT = ZoQ;
+    const double ZoL = vonKar * g * ZW * (Tstar * (1.0 + 0.61 * Q) + 0.61 * TairK * Qstar) /
+                       (TairK * Wstar * Wstar * (1.0 + 0.61 * Q) + eps);
+    const double L = ZW / (ZoL + eps);
+    const double Wpsi = blk_psiu(ZoL);
+    const double Tpsi = blk_psit(ZT / L);
+    const double Qpsi = blk_psit(ZQ / L);
+    Wstar = KMAX(eps, delW * vonKar / (log(ZW / ZoW) - Wpsi));
+    Tstar = -(delT - delTc) * vonKar / (log(ZT / ZoT) - Tpsi);
+    Qstar = -(delQ - delQc) * vonKar / (log(ZQ / ZoQ) - Qpsi);
+    const double Bf = -g / TairK * Wstar * (Tstar + 0.61 * TairK * Qstar);
+    if (Bf > 0.0) Wgus = blk_beta * pow(Bf * blk_Zabl, r3);
+    else Wgus = 0.2;
+    delW = sqrt(Wmag * Wmag + Wgus * Wgus);
+  }
+  const double Hs = -blk_Cpa * rhoAir * Wstar * Tstar;
+  const double diffw = 2.11E-5 * pow(TairK / 273.16, 1.94);
+  const double diffh = 0.02411 * (1.0 + TairC * (3.309E-3 - 1.44E-6 * TairC)) / (rhoAir * blk_Cpa + eps);
+  cff = Qair * Hlv / (blk_Rgas * TairK * TairK);
+  const double wet_bulb = 1.0 / (1.0 + 0.622 * (cff * Hlv * diffw) / (blk_Cpa * diffh));
+  const double rn = fabs(F.rain[X2(i, j)]);
+  const double Hsr = rn * wet_bulb * blk_Cpw * ((TseaC - TairC) + (Qsea - Q) * Hlv / blk_Cpa);
+  const double SHeat = (Hs + Hsr);
+  const double Hl = -Hlv * rhoAir * Wstar * Qstar;
+  const double upvel = -1.61 * Wstar * Qstar - (1.0 + 1.61 * Q) * Wstar * Tstar / TairK;
+  const double Hlw = rhoAir * Hlv * upvel * Q;
+  const double LHeat = (Hl + Hlw);
+  const double Taur = 0.85 * rn * Wmag;
+  cff = rhoAir * (Wstar * Wstar + Taur / rhoAir) / (Wmag + eps);
+  F.wrk2[0][X2(i, j)] = cff * Uair;
+  F.wrk2[1][X2(i, j)] = cff * Vair;
+  if (i >= B.IstrR && j >= B.JstrR) {
+    const double Hscale = 1.0 / (G.rho0 * G.Cp);
+    const double lr = LRad * Hscale, lh = -LHeat * Hscale, sh = -SHeat * Hscale;
+    F.lrflx[X2(i, j)] = lr;
+    F.lhflx[X2(i, j)] = lh;
+    F.shflx[X2(i, j)] = sh;
+    F.stflux[X2T(i, j, 1)] = (F.srflx[X2(i, j)] + lr + lh + sh);
+  }
+}
+THREAD_GLOBAL(k_bulk_pt, BulkArgs)
+
+// surface stresses at u,v points; index space (min(Istr,IstrR):IendR, min(Jstr,JstrR):JendR)
+THREAD_KERNEL(k_bulk_str, BulkArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = KMIN(B.Istr, B.IstrR) + gx, j = KMIN(B.Jstr, B.JstrR) + gy;
+  const double cff = 0.5 / G.rho0;
+  if (i >= B.Istr && j >= B.JstrR) F.sustr[X2(i, j)] = cff * (F.wrk2[0][X2(i - 1, j)] + F.wrk2[0][X2(i, j)]);
+  if (i >= B.IstrR && j >= B.Jstr) F.svstr[X2(i, j)] = cff * (F.wrk2[1][X2(i, j - 1)] + F.wrk2[1][X2(i, j)]);
+}
+THREAD_GLOBAL(k_bulk_str, BulkArgs)
+
+// -------------------------------------------------------------------------- set_data (BENCHMARK)
+struct SetDataBmArgs {
+  DGrid G;
+  Fields F;
+  double Dangle, Hangle;   // solar declination and hour angle of this step (host: caldate)
+};
+// index space (IstrT:IendT, JstrT:JendT)
+THREAD_KERNEL(k_set_data_bm, SetDataBmArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.IstrT + gx, j = G.T.JstrT + gy;
+  const double deg2rad = 3.14159265358979323846 / 180.0, Csolar = 1353.0, alb_w = 0.06;
+  const double cl = 0.6, Ta = 4.0, Ha = 0.8;
+  F.cloud[X2(i, j)] = cl;
+  F.Tair[X2(i, j)] = Ta;
+  F.Hair[X2(i, j)] = Ha;
+  const double Rsolar = Csolar / (G.rho0 * G.Cp);
+  const double LatRad = F.latr[X2(i, j)] * deg2rad;
+  const double cff1 = sin(LatRad) * sin(a.Dangle);
+  const double cff2 = cos(LatRad) * cos(a.Dangle);
+  double sr = 0.0;
+  const double zenith = cff1 + cff2 * cos(a.Hangle - F.lonr[X2(i, j)] * deg2rad);
+  if (zenith > 0.0) {
+    const double cff = (0.7859 + 0.03477 * Ta) / (1.0 + 0.00412 * Ta);
+    const double e_sat = pow(10.0, cff);
+    const double vap_p = e_sat * Ha;
+    sr = Rsolar * zenith * zenith * (1.0 - 0.6 * (cl * cl * cl)) / ((zenith + 2.7) * vap_p * 1.0E-3 + 1.085 * zenith + 0.1);
+  }
+  F.srflx[X2(i, j)] = (1.0 - alb_w) * sr;
+  const double cff = 0.2 * (60.0 + F.latr[X2(i, j)]);
+  F.Uwind[X2(i, j)] = 15.0 * exp(-cff * cff);
+  F.Vwind[X2(i, j)] = 0.0;
+  F.rain[X2(i, j)] = 0.0;
+  F.btflux[X2T(i, j, 1)] = 0.0;
+  F.stflux[X2T(i, j, 2)] = 0.0;
+  F.btflux[X2T(i, j, 2)] = 0.0;
+  F.Pair[X2(i, j)] = 1025.0;
+}
+THREAD_GLOBAL(k_set_data_bm, SetDataBmArgs)
+
+// ---------------------------------------------------------------- solar penetration (pre_step3d)
+struct SwArgs {
+  DGrid G;
+  Fields F;
+  double fac1, fac2, fac3;   // Zscale/lmd_mu1(Jwt), Zscale/lmd_mu2(Jwt), lmd_r1(Jwt) with Zscale = -1
+};
+// swdk(i,j,k) into wrk3[5] for k = 1..N-1; index space (Istr:Iend, Jstr:Jend, N-1)
+THREAD_KERNEL(k_swdk, SwArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz + 1, N = G.N;
+  const double Z = F.z_w[XW(i, j, N)] - F.z_w[XW(i, j, k)];
+  F.wrk3[5][XW(i, j, k)] = exp(Z * a.fac1) * a.fac3 + exp(Z * a.fac2) * (1.0 - a.fac3);
+}
+THREAD_GLOBAL(k_swdk, SwArgs)

@@ -1,0 +1,269 @@
+// k_lmd.h -- K-profile vertical mixing (Large, McWilliams and Doney 1994).
+//
+//   k_lmd_interior  lmd_vmix_tile    ROMS/Nonlinear/lmd_vmix.F:99-460  (LMD_RIMIX, RI_SPLINES)
+//   k_lmd_skpp      lmd_skpp_tile    ROMS/Nonlinear/lmd_skpp.F:98-930  (LMD_SKPP, LMD_NONLOCAL)
+//                   lmd_swfrac_tile  ROMS/Nonlinear/lmd_swfrac.F:6-140
+//   k_lmd_finish    lmd_finish_tile  ROMS/Nonlinear/lmd_vmix.F:465-560 (LMD_CONVEC; the edge fills
+//                                    :560-760 are done by the halo kernel)
+//
+// Pure column physics: one thread per sigma-column; the per-column work arrays of the reference
+// (FC, dR, dU, dV, Bflux: 0:N) live in 3-D work arrays so that every level access of a wave is
+// coalesced.
+#pragma once
+#include "roms_ctx.h"
+#include "k_diag3d.h"
+
+struct LmdArgs {
+  DGrid G;
+  Fields F;
+  double fac1, fac2, fac3;   // lmd_swfrac coefficients for Zscale = -1 and this Jerlov water type
+  double lmd_Cg, Vtc;
+};
+
+#define LMD_CONSTS                                                                                             \
+  const double lmd_Ri0 = 0.7, lmd_bvfcon = -2.0E-5, lmd_nu0c = 0.01, lmd_nu0m = 10.0E-4, lmd_nu0s = 10.0E-4;  \
+  const double lmd_Ric = 0.3, lmd_am = 1.257, lmd_as = -28.86, lmd_cekman = 0.7, lmd_cmonob = 1.0,            \
+               lmd_cm = 8.36, lmd_cs = 98.96, lmd_epsilon = 0.1, lmd_zetam = -0.2, lmd_zetas = -1.0,          \
+               vonKar = 0.41;                                                                                  \
+  (void)lmd_Ri0; (void)lmd_bvfcon; (void)lmd_nu0c; (void)lmd_nu0m; (void)lmd_nu0s; (void)lmd_Ric;             \
+  (void)lmd_am; (void)lmd_as; (void)lmd_cekman; (void)lmd_cmonob; (void)lmd_cm; (void)lmd_cs;                  \
+  (void)lmd_epsilon; (void)lmd_zetam; (void)lmd_zetas; (void)vonKar
+
+// vertical parabolic-spline derivatives of R, U, V at W-points for column (i,j)
+KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const double *R, double *FC, double *dR,
+                          double *dU, double *dV) {
+  const int N = G.N;
+  const double *Hz = F.Hz;
+  const double *u = F.u + (size_t)(G.nstp - 1) * G.nij * N, *v = F.v + (size_t)(G.nstp - 1) * G.nij * N;
+  FC[XW(i, j, 0)] = 0.0; dR[XW(i, j, 0)] = 0.0; dU[XW(i, j, 0)] = 0.0; dV[XW(i, j, 0)] = 0.0;
+  double FCm = 0.0, dRm = 0.0, dUm = 0.0, dVm = 0.0;
+  for (int k = 1; k <= N - 1; k++) {
+    const double cff = 1.0 / (2.0 * Hz[X3(i, j, k + 1)] + Hz[X3(i, j, k)] * (2.0 - FCm));
+    FCm = cff * Hz[X3(i, j, k + 1)];
+    dRm = cff * (6.0 * (R[X3(i, j, k + 1)] - R[X3(i, j, k)]) - Hz[X3(i, j, k)] * dRm);
+    dUm = cff * (3.0 * (u[X3(i, j, k + 1)] - u[X3(i, j, k)] + u[X3(i + 1, j, k + 1)] - u[X3(i + 1, j, k)]) -
+                 Hz[X3(i, j, k)] * dUm);
+    dVm = cff * (3.0 * (v[X3(i, j, k + 1)] - v[X3(i, j, k)] + v[X3(i, j + 1, k + 1)] - v[X3(i, j + 1, k)]) -
+                 Hz[X3(i, j, k)] * dVm);
+    FC[XW(i, j, k)] = FCm; dR[XW(i, j, k)] = dRm; dU[XW(i, j, k)] = dUm; dV[XW(i, j, k)] = dVm;
+  }
+  dR[XW(i, j, N)] = 0.0; dU[XW(i, j, N)] = 0.0; dV[XW(i, j, N)] = 0.0;
+  double r1 = 0.0, u1 = 0.0, v1 = 0.0;
+  for (int k = N - 1; k >= 1; k--) {
+    const double fc = FC[XW(i, j, k)];
+    r1 = dR[XW(i, j, k)] - fc * r1;
+    u1 = dU[XW(i, j, k)] - fc * u1;
+    v1 = dV[XW(i, j, k)] - fc * v1;
+    dR[XW(i, j, k)] = r1; dU[XW(i, j, k)] = u1; dV[XW(i, j, k)] = v1;
+  }
+}
+
+// interior mixing: index space (Istr:Iend, Jstr:Jend)
+THREAD_KERNEL(k_lmd_interior, LmdArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  LMD_CONSTS;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  const double eps = 1.0E-14;
+  double *FC = F.wrk3[1], *dR = F.wrk3[2], *dU = F.wrk3[3], *dV = F.wrk3[4];
+  lmd_col_splines(G, F, i, j, F.rho, FC, dR, dU, dV);
+  for (int k = 1; k <= N - 1; k++) {
+    const double du = dU[XW(i, j, k)], dv = dV[XW(i, j, k)];
+    double shear2 = du * du + dv * dv;
+    const double bv = F.bvf[XW(i, j, k)];
+    const double Rig = bv / (shear2 + eps);
+    double cff = KMIN(1.0, KMAX(0.0, Rig) / lmd_Ri0);
+    double nu_sx = 1.0 - cff * cff;
+    nu_sx = nu_sx * nu_sx * nu_sx;
+    shear2 = bv / (Rig + eps);
+    cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
+    nu_sx = cff * nu_sx;
+    cff = 1.0 / sqrt(KMAX(bv, 1.0E-7));
+    const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
+    F.Akv[XW(i, j, k)] = lmd_iwm + lmd_nu0m * nu_sx;
+    const double akt = lmd_iws + lmd_nu0s * nu_sx;
+    F.Akt[XW4(i, j, k, 1)] = akt;
+    F.Akt[XW4(i, j, k, 2)] = akt;
+  }
+}
+THREAD_GLOBAL(k_lmd_interior, LmdArgs)
+
+KDEV void lmd_wscale(double Ustar, double zetahat, double Ustar3, double &wm, double &ws) {
+  const double small = 1.0E-20, r3 = 1.0 / 3.0;
+  const double vonKar = 0.41, lmd_zetam = -0.2, lmd_zetas = -1.0, lmd_am = 1.257, lmd_as = -28.86, lmd_cm = 8.36,
+               lmd_cs = 98.96;
+  const double zetapar = zetahat / (Ustar3 + small);
+  if (zetahat >= 0.0) {
+    wm = vonKar * Ustar / (1.0 + 5.0 * zetapar);
+    ws = wm;
+  } else {
+    if (zetapar > lmd_zetam) wm = vonKar * Ustar * pow(1.0 - 16.0 * zetapar, 0.25);
+    else wm = vonKar * pow(lmd_am * Ustar3 - lmd_cm * zetahat, r3);
+    if (zetapar > lmd_zetas) ws = vonKar * Ustar * pow(1.0 - 16.0 * zetapar, 0.5);
+    else ws = vonKar * pow(lmd_as * Ustar3 - lmd_cs * zetahat, r3);
+  }
+}
+
+#define SWFRAC(Z) (exp((Z) * a.fac1) * a.fac3 + exp((Z) * a.fac2) * (1.0 - a.fac3))
+
+// surface boundary layer: index space (Istr:Iend, Jstr:Jend).  hsbl is written on the interior;
+// its boundary fill / exchange (bc_r2d_tile, lmd_skpp.F:608) follows in the halo kernel.
+THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  LMD_CONSTS;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  const double eps = 1.0E-10, g = G.g, gorho0 = G.g / G.rho0;
+  const double *z_w = F.z_w, *Hz = F.Hz, *pden = F.pden, *bvf = F.bvf;
+  const double *u = F.u + (size_t)(G.nstp - 1) * G.nij * N, *v = F.v + (size_t)(G.nstp - 1) * G.nij * N;
+  double *FC = F.wrk3[1], *dR = F.wrk3[2], *dU = F.wrk3[3], *dV = F.wrk3[4], *Bflux = F.wrk3[0];
+  const double zwN = z_w[XW(i, j, N)];
+  double hsbl = F.hsbl[X2(i, j)];
+  double sl_dpth = lmd_epsilon * (zwN - hsbl);
+  double Ustar;
+  {
+    const double sa = 0.5 * (F.sustr[X2(i, j)] + F.sustr[X2(i + 1, j)]), sc = 0.5 * (F.svstr[X2(i, j)] + F.svstr[X2(i, j + 1)]);
+    Ustar = sqrt(sqrt(sa * sa + sc * sc));
+  }
+  const double st1 = F.stflx[X2T(i, j, 1)], st2 = F.stflx[X2T(i, j, 2)], sr = F.srflx[X2(i, j)];
+  const double Bo = g * (F.alpha[X2(i, j)] * (st1 - sr) - F.beta[X2(i, j)] * st2);
+  const double Bosol = g * F.alpha[X2(i, j)] * sr;
+  for (int k = 0; k <= N; k++) {
+    const double swdk = SWFRAC(zwN - z_w[XW(i, j, k)]);
+    const double bf = (Bo + Bosol * (1.0 - swdk));
+    Bflux[XW(i, j, k)] = bf;
+    const double cff = 1.0 - (0.5 + copysign(0.5, bf));
+    F.ghats[XW4(i, j, k, 1)] = -cff * (st1 - sr + sr * (1.0 - swdk));
+    F.ghats[XW4(i, j, k, 2)] = cff * st2;
+  }
+  lmd_col_splines(G, F, i, j, pden, FC, dR, dU, dV);
+  const double c13 = 1.0 / 3.0, c16 = 1.0 / 6.0;
+  const double Rref = pden[X3(i, j, N)] + Hz[X3(i, j, N)] * (c13 * dR[XW(i, j, N)] + c16 * dR[XW(i, j, N - 1)]);
+  const double Uref = 0.5 * (u[X3(i, j, N)] + u[X3(i + 1, j, N)]) + Hz[X3(i, j, N)] * (c13 * dU[XW(i, j, N)] + c16 * dU[XW(i, j, N - 1)]);
+  const double Vref = 0.5 * (v[X3(i, j, N)] + v[X3(i, j + 1, N)]) + Hz[X3(i, j, N)] * (c13 * dV[XW(i, j, N)] + c16 * dV[XW(i, j, N - 1)]);
+  const double Ustar3 = Ustar * Ustar * Ustar;
+  double wm = 0.0, ws = 0.0;
+  // bulk Richardson number criterion; FC(k) overwrites the spline work array (as the reference)
+  FC[XW(i, j, N)] = 0.0;
+  for (int k = N; k >= 1; k--) {
+    const double depth = zwN - z_w[XW(i, j, k - 1)];
+    const double bf = Bflux[XW(i, j, k - 1)];
+    const double sigma = (bf < 0.0) ? KMIN(sl_dpth, depth) : depth;
+    const double zetahat = vonKar * sigma * bf;
+    lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+    const double Rk = pden[X3(i, j, k)] - Hz[X3(i, j, k)] * (c13 * dR[XW(i, j, k - 1)] + c16 * dR[XW(i, j, k)]);
+    const double Uk = 0.5 * (u[X3(i, j, k)] + u[X3(i + 1, j, k)]) - Hz[X3(i, j, k)] * (c13 * dU[XW(i, j, k - 1)] + c16 * dU[XW(i, j, k)]);
+    const double Vk = 0.5 * (v[X3(i, j, k)] + v[X3(i, j + 1, k)]) - Hz[X3(i, j, k)] * (c13 * dV[XW(i, j, k - 1)] + c16 * dV[XW(i, j, k)]);
+    const double Ritop = -gorho0 * (Rref - Rk) * depth;
+    const double du_ = Uref - Uk, dv_ = Vref - Vk;
+    const double Ribot = du_ * du_ + dv_ * dv_ + a.Vtc * depth * ws * sqrt(fabs(bvf[XW(i, j, k - 1)]));
+    FC[XW(i, j, k - 1)] = Ritop - lmd_Ric * Ribot;
+  }
+  int ksbl = 1;
+  hsbl = z_w[XW(i, j, 1)];
+  for (int k = N; k >= 2; k--) {
+    const double fkm = FC[XW(i, j, k - 1)];
+    if (ksbl == 1 && fkm > 0.0) {
+      const double fk = FC[XW(i, j, k)];
+      hsbl = (z_w[XW(i, j, k)] * fkm - z_w[XW(i, j, k - 1)] * fk) / (fkm - fk);
+      ksbl = k;
+    }
+  }
+  double Bfsfc = (Bo + Bosol * (1.0 - SWFRAC(zwN - hsbl)));
+  if (Ustar > 0.0 && Bfsfc > 0.0) {
+    const double hekman = lmd_cekman * Ustar / KMAX(fabs(F.f[X2(i, j)]), eps);
+    const double hmonob = lmd_cmonob * Ustar * Ustar * Ustar / KMAX(vonKar * Bfsfc, eps);
+    double m = KMIN(hekman, hmonob);
+    m = KMIN(m, zwN - hsbl);
+    hsbl = (zwN - m);
+  }
+  hsbl = KMIN(hsbl, zwN);
+  hsbl = KMAX(hsbl, z_w[XW(i, j, 0)]);
+  F.hsbl[X2(i, j)] = hsbl;
+  ksbl = 1;
+  for (int k = N; k >= 2; k--)
+    if (ksbl == 1 && z_w[XW(i, j, k - 1)] < hsbl) ksbl = k;
+  Bfsfc = (Bo + Bosol * (1.0 - SWFRAC(zwN - hsbl)));
+  sl_dpth = lmd_epsilon * (zwN - hsbl);
+  {
+    const double cff = (Bfsfc > 0.0) ? 1.0 : lmd_epsilon;
+    const double sigma = cff * (zwN - hsbl);
+    const double zetahat = vonKar * sigma * Bfsfc;
+    lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+  }
+  const double f1 = 5.0 * KMAX(0.0, Bfsfc) * vonKar / (Ustar * Ustar * Ustar * Ustar + eps);
+  const double zbl = zwN - hsbl;
+  double Gm1, Gt1, Gs1, dGm1dS, dGt1dS, dGs1dS;
+  if (hsbl > z_w[XW(i, j, 1)]) {
+    const int k = ksbl;
+    const double cff = 1.0 / (z_w[XW(i, j, k)] - z_w[XW(i, j, k - 1)]);
+    const double cff_dn = cff * (hsbl - z_w[XW(i, j, k - 1)]);
+    const double cff_up = cff * (z_w[XW(i, j, k)] - hsbl);
+    double K_bl = cff_dn * F.Akv[XW(i, j, k)] + cff_up * F.Akv[XW(i, j, k - 1)];
+    double dK_bl = cff * (F.Akv[XW(i, j, k)] - F.Akv[XW(i, j, k - 1)]);
+    Gm1 = K_bl / (zbl * wm + eps);
+    dGm1dS = KMIN(0.0, -dK_bl / (wm + eps) - K_bl * f1);
+    K_bl = cff_dn * F.Akt[XW4(i, j, k, 1)] + cff_up * F.Akt[XW4(i, j, k - 1, 1)];
+    dK_bl = cff * (F.Akt[XW4(i, j, k, 1)] - F.Akt[XW4(i, j, k - 1, 1)]);
+    Gt1 = K_bl / (zbl * ws + eps);
+    dGt1dS = KMIN(0.0, -dK_bl / (ws + eps) - K_bl * f1);
+    K_bl = cff_dn * F.Akt[XW4(i, j, k, 2)] + cff_up * F.Akt[XW4(i, j, k - 1, 2)];
+    dK_bl = cff * (F.Akt[XW4(i, j, k, 2)] - F.Akt[XW4(i, j, k - 1, 2)]);
+    Gs1 = K_bl / (zbl * ws + eps);
+    dGs1dS = KMIN(0.0, -dK_bl / (ws + eps) - K_bl * f1);
+  } else {
+    ksbl = 0;
+    const double ba = 0.5 * (F.bustr[X2(i, j)] + F.bustr[X2(i + 1, j)]), bc = 0.5 * (F.bvstr[X2(i, j)] + F.bvstr[X2(i, j + 1)]);
+    const double Ustarb = sqrt(sqrt(ba * ba + bc * bc));
+    const double dK_bl = vonKar * Ustarb;
+    const double K_bl = dK_bl * (hsbl - z_w[XW(i, j, 0)]);
+    Gm1 = K_bl / (zbl * wm + eps);
+    dGm1dS = KMIN(0.0, -dK_bl / (wm + eps) - K_bl * f1);
+    Gt1 = K_bl / (zbl * ws + eps);
+    dGt1dS = KMIN(0.0, -dK_bl / (ws + eps) - K_bl * f1);
+    Gs1 = Gt1;
+    dGs1dS = dGt1dS;
+  }
+  for (int k = 1; k <= N - 1; k++) {
+    if (k > ksbl) {
+      const double depth = zwN - z_w[XW(i, j, k)];
+      const double bf = Bflux[XW(i, j, k)];
+      double sigma = (bf < 0.0) ? KMIN(sl_dpth, depth) : depth;
+      const double zetahat = vonKar * sigma * bf;
+      lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+      sigma = depth / (zbl + eps);
+      const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
+      const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
+      const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;
+      const double Gs = a1 + a2 * Gs1 + a3 * dGs1dS;
+      F.Akv[XW(i, j, k)] = depth * wm * (1.0 + sigma * Gm);
+      F.Akt[XW4(i, j, k, 1)] = depth * ws * (1.0 + sigma * Gt);
+      F.Akt[XW4(i, j, k, 2)] = depth * ws * (1.0 + sigma * Gs);
+      const double cff = a.lmd_Cg * (1.0 - (0.5 + copysign(0.5, bf))) / (zbl * ws + eps);
+      F.ghats[XW4(i, j, k, 1)] = cff * F.ghats[XW4(i, j, k, 1)];
+      F.ghats[XW4(i, j, k, 2)] = cff * F.ghats[XW4(i, j, k, 2)];
+    } else {
+      F.ghats[XW4(i, j, k, 1)] = 0.0;
+      F.ghats[XW4(i, j, k, 2)] = 0.0;
+    }
+  }
+}
+THREAD_GLOBAL(k_lmd_skpp, LmdArgs)
+
+// convective adjustment: point-wise; index space (Istr:Iend, Jstr:Jend, N-1)
+THREAD_KERNEL(k_lmd_finish, LmdArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  LMD_CONSTS;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz + 1;
+  double cff = KMAX(F.bvf[XW(i, j, k)], lmd_bvfcon);
+  cff = KMIN(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
+  double nu_sxc = 1.0 - cff * cff;
+  nu_sxc = nu_sxc * nu_sxc * nu_sxc;
+  F.Akv[XW(i, j, k)] = F.Akv[XW(i, j, k)] + lmd_nu0c * nu_sxc;
+  F.Akt[XW4(i, j, k, 1)] = F.Akt[XW4(i, j, k, 1)] + lmd_nu0c * nu_sxc;
+  F.Akt[XW4(i, j, k, 2)] = F.Akt[XW4(i, j, k, 2)] + lmd_nu0c * nu_sxc;
+}
+THREAD_GLOBAL(k_lmd_finish, LmdArgs)

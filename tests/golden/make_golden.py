@@ -28,7 +28,7 @@ GRID2D = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", 
           "rdrag", "visc2_r", "visc2_p", "diff2"]
 STATE = ["Hz", "z_r", "z_w", "Huon", "Hvom", "zeta", "ubar", "vbar", "u", "v", "t", "rho", "pden", "rhoA", "rhoS",
          "Zt_avg1", "Akv", "Akt"]
-EXTRA = {"benchmark": ["dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta"]}
+EXTRA = {"benchmark": ["dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta", "hsbl"]}
 ALLSTATE = STATE + ["rzeta", "rubar", "rvbar", "W", "wvel", "ru", "rv", "rufrc", "rvfrc", "DU_avg1", "DU_avg2",
                     "DV_avg1", "DV_avg2", "sustr", "svstr", "bustr", "bvstr", "stflx", "btflx", "stflux", "btflux"]
 
@@ -94,7 +94,7 @@ if __name__ == "__main__":
         make_bounds()
     else:
         py = sys.executable
-        for case in ["upwelling", "upwelling_small:Lm=14,Mm=18,N=8"]:
+        for case in ["upwelling", "upwelling_small:Lm=14,Mm=18,N=8", "benchmark_small:Lm=24,Mm=16,N=10"]:
             subprocess.check_call([py, __file__, "--case", case])
         for spec in ["upwelling,41,80,1,1,HSIMT", "upwelling,41,80,2,2,HSIMT", "upwelling,41,80,2,4,U3",
                      "upwelling,41,80,3,3,U3", "benchmark,512,64,1,1,U3", "benchmark,512,64,2,2,U3",

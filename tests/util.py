@@ -11,12 +11,15 @@ EMU_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libro
 INIT_FIELDS = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", "on_v", "om_p", "on_p", "omn",
                "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v", "angler", "xr", "yr",
                "rdrag", "visc2_r", "visc2_p", "diff2", "Hz", "z_r", "z_w", "Huon", "Hvom", "zeta", "ubar", "vbar",
-               "u", "v", "t", "rho", "pden", "rhoA", "rhoS", "Zt_avg1", "Akv", "Akt"]
+               "u", "v", "t", "rho", "pden", "rhoA", "rhoS", "Zt_avg1", "Akv", "Akt",
+               "dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta", "hsbl"]
 STATE_FIELDS = INIT_FIELDS + ["rzeta", "rubar", "rvbar", "W", "wvel", "ru", "rv", "rufrc", "rvfrc", "DU_avg1",
                               "DU_avg2", "DV_avg1", "DV_avg2", "sustr", "svstr", "bustr", "bvstr", "stflx", "btflx",
-                              "stflux", "btflux"]
+                              "stflux", "btflux", "srflx", "ghats", "Uwind", "Vwind", "Tair", "Pair", "Hair", "rain",
+                              "cloud", "lhflx", "shflx", "lrflx"]
 PROGNOSTIC = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "wvel", "Hz", "z_r", "z_w", "Huon", "Hvom", "rho", "ru", "rv",
-              "Zt_avg1", "DU_avg1", "DV_avg1", "DU_avg2", "DV_avg2", "rufrc", "rvfrc", "rzeta", "rubar", "rvbar"]
+              "Zt_avg1", "DU_avg1", "DV_avg1", "DU_avg2", "DV_avg2", "rufrc", "rvfrc", "rzeta", "rubar", "rvbar",
+              "Akv", "Akt", "hsbl", "ghats", "stflx", "sustr", "svstr", "bustr", "bvstr", "srflx", "bvf"]
 
 
 def load_init(tag, nghost=None):
@@ -49,6 +52,8 @@ def case_for(tag, **kw):
         return cases.upwelling(**kw)
     if tag == "upwelling_small":
         return cases.upwelling(Lm=14, Mm=18, N=8, **kw)
+    if tag == "benchmark_small":
+        return cases.benchmark(Lm=24, Mm=16, N=10, **kw)
     raise KeyError(tag)
 
 
