@@ -101,6 +101,15 @@ class Context:
         self.ni = cfg.UBi - cfg.LBi + 1
         self.nj = cfg.UBj - cfg.LBj + 1
 
+    @classmethod
+    def from_handle(cls, handle, lib_path=None):
+        """View of a context created elsewhere (the Fortran host driver); close() is the owner's job."""
+        self = cls.__new__(cls)
+        self.L = load(lib_path)
+        self.cfg = None
+        self.h = C.c_void_p(handle)
+        return self
+
     def _ck(self, r):
         if r != 0:
             msg = self.L.roms_hip_last_error()

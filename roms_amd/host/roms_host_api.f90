@@ -1,0 +1,168 @@
+!  roms_host_api.f90 -- C-callable surface of the Fortran host driver (libroms_host.so), used by
+!  romsM below, by roms_amd/hostlib.py and by bench.py.
+!
+      MODULE roms_host_api
+      USE, INTRINSIC :: iso_c_binding
+      USE roms_hip
+      USE roms_host
+      implicit none
+      CONTAINS
+
+      FUNCTION c2f (s) RESULT (f_)
+      character(kind=c_char), intent(in) :: s(*)
+      character(len=:), allocatable :: f_
+      integer :: n
+      n=0
+      DO WHILE (s(n+1).ne.c_null_char)
+        n=n+1
+      END DO
+      allocate (character(len=n) :: f_)
+      f_=TRANSFER(s(1:n), f_)
+      END FUNCTION c2f
+!
+!  Read roms.in and build the host state only (no device needed).
+!
+      FUNCTION roms_host_setup (infile) bind(C, name='roms_host_setup') RESULT (ierr)
+      character(kind=c_char), intent(in) :: infile(*)
+      integer(c_int) :: ierr
+      integer :: e
+      CALL read_roms_in (c2f(infile), e)
+      IF (e.eq.0) CALL host_setup (e)
+      exit_flag=e
+      ierr=e
+      END FUNCTION roms_host_setup
+!
+!  Create the device context, upload the state, finish "initial" on the device.
+!
+      FUNCTION roms_host_device_init (device) bind(C, name='roms_host_device_init') RESULT (ierr)
+      integer(c_int), value :: device
+      integer(c_int) :: ierr
+      integer :: e
+      IF (.not.allocated(h)) THEN
+        ierr=8
+        RETURN
+      END IF
+      CALL device_init (INT(device), e)
+      exit_flag=e
+      ierr=e
+      END FUNCTION roms_host_device_init
+!
+!  Advance nsteps baroclinic steps: mode 0 = fused roms_hip_main3d, 1 = kernel-by-kernel main3d.
+!
+      FUNCTION roms_host_run (nsteps, mode) bind(C, name='roms_host_run') RESULT (ierr)
+      integer(c_int), value :: nsteps, mode
+      integer(c_int) :: ierr
+      integer :: e
+      IF (.not.c_associated(ctx)) THEN
+        ierr=8
+        RETURN
+      END IF
+      IF (mode.eq.0) THEN
+        e=roms_hip_main3d(ctx, nsteps)
+      ELSE
+        CALL main3d_kernels (INT(nsteps), e)
+      END IF
+      exit_flag=e
+      ierr=e
+      END FUNCTION roms_host_run
+
+      FUNCTION roms_host_ctx () bind(C, name='roms_host_ctx') RESULT (p)
+      TYPE (c_ptr) :: p
+      p=ctx
+      END FUNCTION roms_host_ctx
+
+      FUNCTION roms_host_finalize () bind(C, name='roms_host_finalize') RESULT (ierr)
+      integer(c_int) :: ierr
+      ierr=0
+      IF (c_associated(ctx)) ierr=roms_hip_destroy(ctx)
+      ctx=c_null_ptr
+      IF (allocated(h)) CALL host_free ()
+      END FUNCTION roms_host_finalize
+!
+!  dims(1:24): Lm Mm N NT Nghost LBi UBi LBj UBj nfast ndtfast ntimes options EW NS hadv(1:4) vadv(1:4) ninfo
+!  reals(1:8): dt dtfast hc hmin hmax xl el dstart
+!
+      SUBROUTINE roms_host_dims (dims, reals) bind(C, name='roms_host_dims')
+      integer(c_int), intent(out) :: dims(24)
+      real(c_double), intent(out) :: reals(8)
+      dims(1:13)=(/ Lm, Mm, N, NT, Nghost, LBi, UBi, LBj, UBj, nfast, ndtfast, ntimes, options /)
+      dims(14)=MERGE(1,0,EWperiodic)
+      dims(15)=MERGE(1,0,NSperiodic)
+      dims(16:19)=hadv
+      dims(20:23)=vadv
+      dims(24)=ninfo
+      reals=(/ dt, dtfast, hc, hmin, hmax, xl, el, dstart /)
+      END SUBROUTINE roms_host_dims
+!
+!  Copy a host array out by its reference name; returns the number of values (0 = unknown name).
+!
+      FUNCTION roms_host_get (name, buf, nmax) bind(C, name='roms_host_get') RESULT (n)
+      character(kind=c_char), intent(in) :: name(*)
+      integer(c_long), value :: nmax
+      real(c_double), intent(out) :: buf(*)
+      integer(c_long) :: n
+      n=0
+      IF (.not.allocated(h)) RETURN
+      SELECT CASE (c2f(name))
+        CASE ('h');       CALL put (RESHAPE(h,(/SIZE(h)/)))
+        CASE ('f');       CALL put (RESHAPE(f,(/SIZE(f)/)))
+        CASE ('fomn');    CALL put (RESHAPE(fomn,(/SIZE(fomn)/)))
+        CASE ('pm');      CALL put (RESHAPE(pm,(/SIZE(pm)/)))
+        CASE ('pn');      CALL put (RESHAPE(pn,(/SIZE(pn)/)))
+        CASE ('om_r');    CALL put (RESHAPE(om_r,(/SIZE(om_r)/)))
+        CASE ('on_r');    CALL put (RESHAPE(on_r,(/SIZE(on_r)/)))
+        CASE ('om_u');    CALL put (RESHAPE(om_u,(/SIZE(om_u)/)))
+        CASE ('on_u');    CALL put (RESHAPE(on_u,(/SIZE(on_u)/)))
+        CASE ('om_v');    CALL put (RESHAPE(om_v,(/SIZE(om_v)/)))
+        CASE ('on_v');    CALL put (RESHAPE(on_v,(/SIZE(on_v)/)))
+        CASE ('om_p');    CALL put (RESHAPE(om_p,(/SIZE(om_p)/)))
+        CASE ('on_p');    CALL put (RESHAPE(on_p,(/SIZE(on_p)/)))
+        CASE ('omn');     CALL put (RESHAPE(omn,(/SIZE(omn)/)))
+        CASE ('pmon_r');  CALL put (RESHAPE(pmon_r,(/SIZE(pmon_r)/)))
+        CASE ('pnom_r');  CALL put (RESHAPE(pnom_r,(/SIZE(pnom_r)/)))
+        CASE ('pmon_p');  CALL put (RESHAPE(pmon_p,(/SIZE(pmon_p)/)))
+        CASE ('pnom_p');  CALL put (RESHAPE(pnom_p,(/SIZE(pnom_p)/)))
+        CASE ('pmon_u');  CALL put (RESHAPE(pmon_u,(/SIZE(pmon_u)/)))
+        CASE ('pnom_u');  CALL put (RESHAPE(pnom_u,(/SIZE(pnom_u)/)))
+        CASE ('pmon_v');  CALL put (RESHAPE(pmon_v,(/SIZE(pmon_v)/)))
+        CASE ('pnom_v');  CALL put (RESHAPE(pnom_v,(/SIZE(pnom_v)/)))
+        CASE ('dmde');    CALL put (RESHAPE(dmde,(/SIZE(dmde)/)))
+        CASE ('dndx');    CALL put (RESHAPE(dndx,(/SIZE(dndx)/)))
+        CASE ('angler');  CALL put (RESHAPE(angler,(/SIZE(angler)/)))
+        CASE ('xr');      CALL put (RESHAPE(xr,(/SIZE(xr)/)))
+        CASE ('yr');      CALL put (RESHAPE(yr,(/SIZE(yr)/)))
+        CASE ('lonr');    CALL put (RESHAPE(lonr,(/SIZE(lonr)/)))
+        CASE ('latr');    CALL put (RESHAPE(latr,(/SIZE(latr)/)))
+        CASE ('rdrag');   CALL put (RESHAPE(rdrag,(/SIZE(rdrag)/)))
+        CASE ('rdrag2');  CALL put (RESHAPE(rdrag2,(/SIZE(rdrag2)/)))
+        CASE ('visc2_r'); CALL put (RESHAPE(visc2_r,(/SIZE(visc2_r)/)))
+        CASE ('visc2_p'); CALL put (RESHAPE(visc2_p,(/SIZE(visc2_p)/)))
+        CASE ('diff2');   CALL put (RESHAPE(diff2,(/SIZE(diff2)/)))
+        CASE ('Zt_avg1'); CALL put (RESHAPE(Zt_avg1,(/SIZE(Zt_avg1)/)))
+        CASE ('Hz');      CALL put (RESHAPE(Hz,(/SIZE(Hz)/)))
+        CASE ('z_r');     CALL put (RESHAPE(z_r,(/SIZE(z_r)/)))
+        CASE ('z_w');     CALL put (RESHAPE(z_w,(/SIZE(z_w)/)))
+        CASE ('zeta');    CALL put (RESHAPE(zeta,(/SIZE(zeta)/)))
+        CASE ('ubar');    CALL put (RESHAPE(ubar,(/SIZE(ubar)/)))
+        CASE ('vbar');    CALL put (RESHAPE(vbar,(/SIZE(vbar)/)))
+        CASE ('u');       CALL put (RESHAPE(u,(/SIZE(u)/)))
+        CASE ('v');       CALL put (RESHAPE(v,(/SIZE(v)/)))
+        CASE ('t');       CALL put (RESHAPE(t,(/SIZE(t)/)))
+        CASE ('Akv');     CALL put (RESHAPE(Akv,(/SIZE(Akv)/)))
+        CASE ('Akt');     CALL put (RESHAPE(Akt,(/SIZE(Akt)/)))
+        CASE ('sc_r');    CALL put (sc_r)
+        CASE ('Cs_r');    CALL put (Cs_r)
+        CASE ('sc_w');    CALL put (sc_w)
+        CASE ('Cs_w');    CALL put (Cs_w)
+        CASE ('weight1'); CALL put (weight(1,:))
+        CASE ('weight2'); CALL put (weight(2,:))
+      END SELECT
+      CONTAINS
+        SUBROUTINE put (A)
+        real(r8), intent(in) :: A(:)
+        n=SIZE(A)
+        IF (n.le.nmax) buf(1:n)=A
+        END SUBROUTINE put
+      END FUNCTION roms_host_get
+
+      END MODULE roms_host_api

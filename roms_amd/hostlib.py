@@ -1,0 +1,125 @@
+"""ctypes binding of libroms_host.so, the Fortran host driver (roms_amd/host/*.f90).
+
+The driver's input is a standard roms.in (the reference's own run-time interface, subset of keywords
+read by ROMS/Utility/read_phypar.F); `write_roms_in` produces one from a parameter dict so that tests
+and bench.py can run any grid size.
+"""
+import ctypes as C
+import os
+import tempfile
+
+import numpy as np
+
+from . import build as _build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libroms_host.so")
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError(f"{LIB} is not built (python -m roms_amd.build)")
+        lib = C.CDLL(LIB, mode=C.RTLD_GLOBAL)
+        lib.roms_host_setup.argtypes = [C.c_char_p]
+        lib.roms_host_device_init.argtypes = [C.c_int]
+        lib.roms_host_run.argtypes = [C.c_int, C.c_int]
+        lib.roms_host_ctx.restype = C.c_void_p
+        lib.roms_host_dims.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        lib.roms_host_dims.restype = None
+        lib.roms_host_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_long]
+        lib.roms_host_get.restype = C.c_long
+        _lib = lib
+    return _lib
+
+
+def write_roms_in(path, p):
+    """p: dict with the reference's keyword names (see tests/cases.py)."""
+    tr = lambda xs: " ".join(str(x) for x in xs)
+    d = lambda x: repr(float(x)).replace("e", "d") if "e" in repr(float(x)) else repr(float(x)) + "d0"
+    per = lambda f: "Per" if f else "Clo"
+    lines = [
+        f"    MyAppCPP = {p['app'].upper()}",
+        f"          Lm == {p['Lm']}", f"          Mm == {p['Mm']}", f"           N == {p['N']}",
+        "      NtileI == 1", "      NtileJ == 1",
+        f"  Hadvection == {p['hadv'][0]} \\", f"                {p['hadv'][1]}",
+        f"  Vadvection == {p['vadv'][0]} \\", f"                {p['vadv'][1]}",
+        f" LBC(isFsur) == {per(p['EWperiodic'])} {per(p['NSperiodic'])} {per(p['EWperiodic'])} {per(p['NSperiodic'])}",
+        f"      NTIMES == {p.get('ntimes', 10)}", f"          DT == {d(p['dt'])}",
+        f"     NDTFAST == {p['ndtfast']}", f"       NINFO == {p.get('ninfo', 1)}",
+        f"        TNU2 == {tr(d(x) for x in p['tnu2'])}", f"       VISC2 == {d(p['visc2'])}",
+        f"     AKT_BAK == {tr(d(x) for x in p['Akt_bak'])}", f"     AKV_BAK == {d(p['Akv_bak'])}",
+        f"        RDRG == {d(p['rdrg'])}", f"       RDRG2 == {d(p['rdrg2'])}",
+        f"         Zob == {d(p['Zob'])}", f"         Zos == {d(p['Zos'])}",
+        f"      BLK_ZQ == {d(p.get('blk_ZQ', 10.0))}", f"      BLK_ZT == {d(p.get('blk_ZT', 10.0))}",
+        f"      BLK_ZW == {d(p.get('blk_ZW', 10.0))}", f"       WTYPE == {p.get('lmd_Jwt', 1)}",
+        f"  Vtransform == {p['Vtransform']}", f" Vstretching == {p['Vstretching']}",
+        f"     THETA_S == {d(p['theta_s'])}", f"     THETA_B == {d(p['theta_b'])}",
+        f"      TCLINE == {d(p['Tcline'])}", f"        RHO0 == {d(p['rho0'])}",
+        f"      DSTART == {d(p.get('dstart', 0.0))}", "    TIME_REF == 0.0d0",
+        f"          R0 == {d(p['R0'])}", f"          T0 == {d(p['T0'])}", f"          S0 == {d(p['S0'])}",
+        f"       TCOEF == {d(p['Tcoef'])}", f"       SCOEF == {d(p['Scoef'])}",
+        f"      GAMMA2 == {d(p['gamma2'])}",
+    ]
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+class Host:
+    """One ROMS run owned by the Fortran host (module state: one instance per process)."""
+
+    def __init__(self, infile=None, params=None):
+        self.lib = load()
+        tmp = None
+        if infile is None:
+            fd, tmp = tempfile.mkstemp(suffix=".in", prefix="roms_")
+            os.close(fd)
+            write_roms_in(tmp, params)
+            infile = tmp
+        try:
+            r = self.lib.roms_host_setup(infile.encode())
+        finally:
+            if tmp:
+                os.unlink(tmp)
+        if r != 0:
+            raise RuntimeError(f"roms_host_setup failed, exit_flag={r}")
+        di = (C.c_int * 24)()
+        dr = (C.c_double * 8)()
+        self.lib.roms_host_dims(di, dr)
+        names = ["Lm", "Mm", "N", "NT", "Nghost", "LBi", "UBi", "LBj", "UBj", "nfast", "ndtfast", "ntimes", "options",
+                 "EWper", "NSper"]
+        self.dims = dict(zip(names, list(di)[:15]))
+        self.dims["hadv"], self.dims["vadv"], self.dims["ninfo"] = list(di)[15:19], list(di)[19:23], di[23]
+        self.reals = dict(zip(["dt", "dtfast", "hc", "hmin", "hmax", "xl", "el", "dstart"], list(dr)))
+
+    def get(self, name):
+        n = self.lib.roms_host_get(name.encode(), None, 0)
+        if n <= 0:
+            raise KeyError(name)
+        a = np.empty(n)
+        self.lib.roms_host_get(name.encode(), a.ctypes.data_as(C.POINTER(C.c_double)), n)
+        return a
+
+    def device_init(self, device=0):
+        r = self.lib.roms_host_device_init(device)
+        if r != 0:
+            from . import hiplib
+            msg = hiplib.load().roms_hip_last_error()
+            raise hiplib.RomsHipError(f"exit_flag={r}: {msg.decode() if msg else ''}")
+        return self.context()
+
+    def context(self):
+        """The device context as a roms_amd.hiplib.Context view (not owning)."""
+        from . import hiplib
+        return hiplib.Context.from_handle(self.lib.roms_host_ctx())
+
+    def run(self, nsteps, kernels=False):
+        r = self.lib.roms_host_run(nsteps, 1 if kernels else 0)
+        if r != 0:
+            raise RuntimeError(f"roms_host_run: exit_flag={r}")
+
+    def finalize(self):
+        self.lib.roms_host_finalize()
