@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- grid-cell-updates/sec of the nonlinear 3-D time step (main3d) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload benchmark1|benchmark2|benchmark3|ns512|upwelling]
+
+A "step" is one pass of main3d's STEP_LOOP (ROMS/Nonlinear/main3d.F:216-1148) with the full physics
+of the application (BENCHMARK: nonlinear EOS, KPP, COARE bulk fluxes, geopotential tracer mixing,
+nfast+1 LF-AM3 barotropic predictor/corrector pairs ...) and the state resident in HBM.  The default
+workload is BASELINE.json configs[1]: BENCHMARK1 512x64x30.  For N > 1 the driver starts one rank per
+GPU (torch.distributed, nccl = RCCL); each rank owns one tile of NtileI x NtileJ = N tiles (weak
+scaling: the per-GPU tile stays 512x64x30 and the global grid grows along xi).
+
+One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel: algorithmic bytes / average launch duration measured with HIP events
+                on the library's stream inside the timed region
+  cpu_baseline  the C oracle (oracle/, a scalar port of the reference's algorithm) timed on one host
+                core on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+WORKLOADS = {
+    # name: (app, Lm, Mm, N)   -- ROMS/External/roms_benchmark{1,2,3}.in, roms_upwelling.in
+    "benchmark1": ("benchmark", 512, 64, 30),
+    "benchmark2": ("benchmark", 1024, 128, 30),
+    "benchmark3": ("benchmark", 2048, 256, 30),
+    "ns512": ("benchmark", 512, 512, 50),       # north_star roofline size (512x512x50)
+    "upwelling": ("upwelling", 41, 80, 16),
+}
+
+# Algorithmic HBM bytes per launch of each hot kernel, as (3-D arrays read+written per cell,
+# 2-D arrays per column) -- each distinct input array read once, each output written once, f64.
+# Derivation per kernel: DESIGN.md "Kernels and rooflines".  P = horizontal points, N = levels.
+ALGO_ARRAYS = {
+    #                3-D  2-D
+    "k_step2d":     (0, 58),
+    "k_rhs3d_h":    (9, 10),
+    "k_rhs3d_v":    (7, 6),
+    "k_pre_t3h":    (6, 6),
+    "k_pre_t3v":    (6, 2),
+    "k_pre_new":    (5, 2),
+    "k_s3t_h":      (6, 6),
+    "k_s3t_col":    (5, 2),
+    "k_s3uv_col":   (9, 10),
+    "k_s3uv_couple": (6, 12),
+    "k_t3dmix2_geo": (7, 8),
+    "k_t3dmix2_s":  (4, 8),
+    "k_uv3dmix2_s": (7, 12),
+    "k_prs_P":      (4, 0),
+    "k_prs_grad":   (6, 4),
+    "k_eos_nl":     (9, 3),
+    "k_lmd_interior": (9, 2),
+    "k_lmd_skpp":   (12, 12),
+    "k_lmd_finish": (8, 4),
+    "k_omega":      (3, 2),
+    "k_set_depth":  (3, 3),
+    "k_set_massflux": (5, 4),
+}
+# kernels launched once per tracer (block z / launch carries itrc): bytes above are per tracer
+PER_TRACER = {"k_pre_t3h", "k_pre_t3v", "k_pre_new", "k_s3t_h", "k_s3t_col", "k_t3dmix2_geo", "k_t3dmix2_s"}
+
+
+def algo_bytes(kernel, Lm, Mm, N, launches_per_step_hint=None):
+    if kernel not in ALGO_ARRAYS:
+        return None
+    a3, a2 = ALGO_ARRAYS[kernel]
+    P = Lm * Mm
+    return 8.0 * P * (a3 * N + a2)
+
+
+def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
+    from tests import cases
+    app, lm, mm, n = WORKLOADS[workload]
+    Lm, Mm, N = Lm or lm, Mm or mm, N or n
+    cs = cases.benchmark(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes) if app == "benchmark" else \
+        cases.upwelling(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
+    return cs
+
+
+def cpu_baseline(cs, H, budget_s=20.0):
+    """Time the oracle (scalar C port, one core) on the same workload, a few steps."""
+    import numpy as np
+    from oracle import orc
+    from tests import cases, util
+    orc.build()
+    w = np.stack([H.get("weight1"), H.get("weight2")])
+    O = orc.Oracle(cases.oracle_cfg(cs, H.reals["hc"], H.dims["nfast"], w))
+    from tests.test_host import HOST_FIELDS
+    for n in HOST_FIELDS:
+        try:
+            O.field(n)[:] = H.get(n)
+        except KeyError:
+            pass
+    O.start()
+    cells = cs["Lm"] * cs["Mm"] * cs["N"]
+    t0 = time.perf_counter()
+    O.main3d_step(1)                       # first step (start-up branches), also sizes the sample
+    t1 = time.perf_counter()
+    nsteps = max(2, min(40, int(budget_s / max(t1 - t0, 1e-3))))
+    t0 = time.perf_counter()
+    O.main3d_step(nsteps)
+    t1 = time.perf_counter()
+    O.close()
+    return {"value": cells * nsteps / (t1 - t0), "unit": "grid-cell-updates/sec", "cores": 1, "kind": "port",
+            "sample": f"{cs['app'].upper()} {cs['Lm']}x{cs['Mm']}x{cs['N']}, steps 2..{nsteps + 1} of the same run, "
+                      f"oracle/liborc.so (gcc -O2, scalar, 1 thread), {t1 - t0:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="benchmark1", choices=sorted(WORKLOADS))
+    ap.add_argument("--Lm", type=int)
+    ap.add_argument("--Mm", type=int)
+    ap.add_argument("--N", type=int)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--breakdown-file", default=None, help="write the per-kernel table (JSON) here")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N with N > 1 must be started by torch.distributed.run "
+                             "(one rank per GPU); see the module docstring")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from roms_amd import hiplib, hostlib, tiling
+
+    cs = params_for(args.workload, args.Lm, args.Mm, args.N, ntimes=args.steps + args.warmup)
+    cs["ninfo"] = 1                          # NINFO of roms_benchmark1.in: diagnostics every step
+    run = tiling.TiledRun(cs, rank=rank, world=world, device=local_rank, dist=dist)
+    cells_per_rank = cs["Lm"] * cs["Mm"] * cs["N"]
+
+    def barrier_sync():
+        run.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run.step(args.warmup)
+    barrier_sync()
+
+    # dominant kernel: per-kernel breakdown over a few extra steps (synchronous events), then the
+    # timed region with asynchronous event pairs on that kernel only
+    dominant, table = None, {}
+    if not args.no_breakdown:
+        hiplib.kprof(1)
+        run.step(2)
+        run.sync()
+        table = hiplib.kprof_table()
+        hiplib.kprof(0)
+        ranked = sorted(((k, v) for k, v in table.items() if k in ALGO_ARRAYS), key=lambda kv: -kv[1][0])
+        if ranked:
+            dominant = ranked[0][0]
+        if args.breakdown_file and rank == 0:
+            with open(args.breakdown_file, "w") as f:
+                json.dump({k: {"seconds": v[0], "launches": v[1]} for k, v in table.items()}, f, indent=1)
+    if dominant:
+        hiplib.kprof(2, dominant)
+    barrier_sync()
+
+    t0 = time.perf_counter()
+    run.step(args.steps)
+    barrier_sync()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    roofline = None
+    if dominant:
+        sec, launches = hiplib.kprof_table().get(dominant, (0.0, 0))
+        hiplib.kprof(0)
+        if launches > 0:
+            avg = sec / launches
+            nb = algo_bytes(dominant, cs["Lm"], cs["Mm"], cs["N"])
+            achieved = nb / avg / 1e9
+            roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_us": avg * 1e6, "launches": launches,
+                        "algorithmic_bytes_per_launch": nb}
+
+    run.check()                              # blow-up test of the last diagnostics (exit_flag)
+    out = None
+    if rank == 0:
+        value = cells_per_rank * world * args.steps / elapsed
+        out = {
+            "metric": "grid-cell-updates/sec", "value": value, "unit": "grid-cell-updates/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{cs['app'].upper()} {run.global_Lm}x{run.global_Mm}x{cs['N']} "
+                                   f"(tile {cs['Lm']}x{cs['Mm']}x{cs['N']} per GPU), dt={cs['dt']:g}s ndtfast={cs['ndtfast']}, "
+                                   "analytic grid/initial/forcing, full application physics",
+                       "tiles": f"{run.NtileI}x{run.NtileJ}", "nfast": run.nfast},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cs, run.host)
+        else:
+            out["cpu_baseline"] = None
+    run.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

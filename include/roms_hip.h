@@ -134,8 +134,10 @@ int roms_hip_step3d_uv(roms_hip_ctx *ctx);     /* step3d_uv      step3d_uv.F:40 
 int roms_hip_step3d_t(roms_hip_ctx *ctx);      /* step3d_t       step3d_t.F:40       */
 int roms_hip_lmd_vmix(roms_hip_ctx *ctx);      /* lmd_vmix       lmd_vmix.F:45       */
 int roms_hip_bulk_flux(roms_hip_ctx *ctx);     /* bulk_flux      bulk_flux.F:100     */
-/* diag diag.F:30 -- synchronises; out[0..11] = avgke avgpe avgkp volume maxspeed
-   max_Cu max_Cv max_Cw max_Ci max_Cj max_Ck max_C */
+/* diag diag.F:30 -- synchronises; out must hold 16 doubles: out[0..11] = avgke avgpe avgkp volume
+   maxspeed max_Cu max_Cv max_Cw max_Ci max_Cj max_Ck max_C of this context's tile, out[12..13] =
+   the un-normalised kinetic / potential energy sums (a multi-tile caller adds out[3], out[12],
+   out[13] over the tiles and takes the maximum of out[4], out[11], as mp_reduce does in diag.F:331) */
 int roms_hip_diag(roms_hip_ctx *ctx, double *out);
 
 /* initial.F:549-577 tail (set_massflux, omega, rho_eos at iic = ntstart) */
@@ -150,6 +152,38 @@ int roms_hip_main3d(roms_hip_ctx *ctx, int nsteps);
    21 = rhs3d, 22 = pre_step3d, 23 = prsgrd, 34 = step3d_uv, 35 = step3d_t ...). */
 int roms_hip_profile(roms_hip_ctx *ctx, int enable);
 int roms_hip_region_seconds(roms_hip_ctx *ctx, int region, double *seconds, long *calls);
+/* ---- one tile per GPU: halo exchange between contexts of different processes -------------
+   A context created with NtileI*NtileJ > 1 owns tile `tile` (= itile + jtile*NtileI, the
+   reference's tile/rank numbering, get_bounds.F:972) with arrays allocated LBi:UBi x LBj:UBj
+   around [Istr,Iend]x[Jstr,Jend]: three ghost columns/rows on the low side, Nghost on the high
+   side (the layout of the reference's periodic arrays), or the boundary points of the domain
+   edge.  Wherever the reference calls mp_exchange2d/3d/4d (mp_exchange.F:28,1025,1755) the
+   library packs the strips on the device and moves them with one of two transports, which must
+   be installed before roms_hip_start:
+     roms_hip_comm_rccl      built-in RCCL send/recv on the context's stream (rank = tile);
+                             the 128-byte unique id comes from roms_hip_rccl_unique_id on rank 0
+                             and is distributed by the caller (MPI_Bcast, torch.distributed ...)
+     roms_hip_set_exchange   a caller-supplied function: it receives DEVICE pointers (host
+                             pointers in the CPU-emulated test build) after the stream has been
+                             synchronised, must complete all sends and receives before it
+                             returns, and returns 0 on success.  Message m is matched by
+                             (peer, tag): tags 0/1 = eastward/westward, 2/3 = northward/southward. */
+typedef int (*roms_hip_exchange_fn)(void *user, int nsend, const int *send_peer, double *const *send_buf,
+                                    const long *send_count, const int *send_tag, int nrecv,
+                                    const int *recv_peer, double *const *recv_buf, const long *recv_count,
+                                    const int *recv_tag);
+int roms_hip_set_exchange(roms_hip_ctx *ctx, roms_hip_exchange_fn fn, void *user);
+int roms_hip_rccl_unique_id(void *id128);
+int roms_hip_comm_rccl(roms_hip_ctx *ctx, const void *id128, int nranks, int rank);
+/* number of halo exchanges performed so far (0 for a single-tile context) */
+long roms_hip_exchange_count(roms_hip_ctx *ctx);
+
+/* per-kernel device timing with HIP events on the library's stream (process-wide table):
+   mode 0 off; 1 = every launch, synchronous (breakdown pass); 2 = only launches of `kernel`,
+   asynchronous event pairs resolved when the table is read (usable inside a timed region).
+   roms_hip_kprof resets the table; roms_hip_kprof_get enumerates it (returns 8 past the end). */
+int roms_hip_kprof(int mode, const char *kernel);
+int roms_hip_kprof_get(int index, char *name, int name_len, double *seconds, long *calls);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,14 @@ class Ref:
             raise KeyError(name)
         return self._buf[:n].copy()
 
+    def has(self, name):
+        """Fields behind cpp options the application does not define (CURVGRID, BULK_FLUXES ...) are absent."""
+        try:
+            self.get(name)
+            return True
+        except KeyError:
+            return False
+
     def put(self, name, a):
         a = np.ascontiguousarray(a, dtype=np.float64).ravel()
         n = self.L.ref_field(name.encode(), C.c_int(1), a.ctypes.data_as(C.c_void_p))

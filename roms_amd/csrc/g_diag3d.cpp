@@ -21,10 +21,13 @@ int run_set_depth(roms_hip_ctx *c) {
   const int N = c->G.N;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_set_depth, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, N, c->stream, a);
-  launch_halo(c, c->F.h, 1, BC_NONE, 'r');
-  launch_halo(c, c->F.z_w, N + 1, BC_NONE, 'r');
-  launch_halo(c, c->F.z_r, N, BC_NONE, 'r');
-  launch_halo(c, c->F.Hz, N, BC_NONE, 'r');
+  const HaloSpec hs1[] = {
+      {c->F.h, 1, BC_NONE, 'r'},
+      {c->F.z_w, N + 1, BC_NONE, 'r'},
+      {c->F.z_r, N, BC_NONE, 'r'},
+      {c->F.Hz, N, BC_NONE, 'r'},
+  };
+  launch_halo_multi(c, hs1, 4);
   return 0;
 }
 
@@ -34,8 +37,11 @@ int run_set_massflux(roms_hip_ctx *c) {
   KArgs a = mk(c);
   const int i0 = KMIN(B.IstrP, B.IstrT), j0 = KMIN(B.JstrT, B.JstrP);
   LAUNCH_THREAD(k_set_massflux, B.IendT - i0 + 1, B.JendT - j0 + 1, N, c->stream, a);
-  launch_halo(c, c->F.Huon, N, BC_NONE, 'u');
-  launch_halo(c, c->F.Hvom, N, BC_NONE, 'v');
+  const HaloSpec hs2[] = {
+      {c->F.Huon, N, BC_NONE, 'u'},
+      {c->F.Hvom, N, BC_NONE, 'v'},
+  };
+  launch_halo_multi(c, hs2, 2);
   return 0;
 }
 
@@ -45,10 +51,13 @@ int run_rho_eos(roms_hip_ctx *c) {
   const int N = c->G.N;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_rho_eos_lin, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
-  launch_halo(c, c->F.rho, N, BC_NONE, 'r');
-  launch_halo(c, c->F.pden, N, BC_NONE, 'r');
-  launch_halo(c, c->F.rhoA, 1, BC_NONE, 'r');
-  launch_halo(c, c->F.rhoS, 1, BC_NONE, 'r');
+  const HaloSpec hs3[] = {
+      {c->F.rho, N, BC_NONE, 'r'},
+      {c->F.pden, N, BC_NONE, 'r'},
+      {c->F.rhoA, 1, BC_NONE, 'r'},
+      {c->F.rhoS, 1, BC_NONE, 'r'},
+  };
+  launch_halo_multi(c, hs3, 4);
   return 0;
 }
 
@@ -56,8 +65,11 @@ int run_set_vbc(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_set_vbc, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, 1, c->stream, a);
-  launch_halo(c, c->F.bustr, 1, BC_U, 'u');   // bc_u2d_tile
-  launch_halo(c, c->F.bvstr, 1, BC_V, 'v');   // bc_v2d_tile
+  const HaloSpec hs4[] = {
+      {c->F.bustr, 1, BC_U, 'u'},   // bc_u2d_tile
+      {c->F.bvstr, 1, BC_V, 'v'},   // bc_v2d_tile
+  };
+  launch_halo_multi(c, hs4, 2);
   return 0;
 }
 
@@ -66,8 +78,11 @@ int run_ana_vmix(roms_hip_ctx *c) {
   const int N = c->G.N;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_ana_vmix, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, N - 1, c->stream, a);
-  launch_halo(c, c->F.Akv, N + 1, BC_NONE, 'r');
-  launch_halo(c, c->F.Akt, (N + 1) * c->G.NAT, BC_NONE, 'r');
+  const HaloSpec hs5[] = {
+      {c->F.Akv, N + 1, BC_NONE, 'r'},
+      {c->F.Akt, (N + 1) * c->G.NAT, BC_NONE, 'r'},
+  };
+  launch_halo_multi(c, hs5, 2);
   return 0;
 }
 
@@ -77,9 +92,12 @@ int run_set_data(roms_hip_ctx *c) {
   KArgs a = mk(c);
   const int i0 = KMIN(B.IstrP, B.IstrT), j0 = KMIN(B.JstrP, B.JstrT);
   LAUNCH_THREAD(k_set_data_upw, B.IendT - i0 + 1, B.JendT - j0 + 1, 1, c->stream, a);
-  launch_halo(c, c->F.stflux, 2, BC_NONE, 'r');
-  launch_halo(c, c->F.sustr, 1, BC_NONE, 'u');
-  launch_halo(c, c->F.svstr, 1, BC_NONE, 'v');
+  const HaloSpec hs6[] = {
+      {c->F.stflux, 2, BC_NONE, 'r'},
+      {c->F.sustr, 1, BC_NONE, 'u'},
+      {c->F.svstr, 1, BC_NONE, 'v'},
+  };
+  launch_halo_multi(c, hs6, 3);
   return 0;
 }
 
@@ -94,8 +112,11 @@ int run_omega(roms_hip_ctx *c) {
 int run_wvelocity(roms_hip_ctx *c, int ninp) {
   const TB &B = c->G.T;
   const int N = c->G.N;
-  launch_halo(c, c->F.DU_avg1, 1, BC_NONE, 'u');
-  launch_halo(c, c->F.DV_avg1, 1, BC_NONE, 'v');
+  const HaloSpec hs7[] = {
+      {c->F.DU_avg1, 1, BC_NONE, 'u'},
+      {c->F.DV_avg1, 1, BC_NONE, 'v'},
+  };
+  launch_halo_multi(c, hs7, 2);
   KArgs a = mk(c, ninp);
   LAUNCH_THREAD(k_wvel_vert, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N, c->stream, a);
   LAUNCH_THREAD(k_wvel, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N + 1, c->stream, a);
@@ -124,13 +145,23 @@ int run_ini_zeta(roms_hip_ctx *c) {
 int run_ini_fields(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   const int N = c->G.N, nstp = c->G.nstp, kstp = c->G.kstp;
-  launch_halo(c, uv_lev(c, c->F.u, nstp), N, BC_U, 'u');     // u3dbc_tile + exchange_u3d
-  launch_halo(c, uv_lev(c, c->F.v, nstp), N, BC_V, 'v');
+  const HaloSpec hs8[] = {
+      {uv_lev(c, c->F.u, nstp), N, BC_U, 'u'},     // u3dbc_tile + exchange_u3d
+      {uv_lev(c, c->F.v, nstp), N, BC_V, 'v'},
+  };
+  launch_halo_multi(c, hs8, 2);
   KArgs a = mk(c);
   const int i0 = KMIN(B.IstrM, B.IstrB);
   LAUNCH_THREAD(k_ini_bar, B.IendB - i0 + 1, B.JendB - B.JstrB + 1, 1, c->stream, a);
-  launch_halo(c, lev2d(c, c->F.ubar, kstp), 1, BC_U, 'u');   // u2dbc_tile + exchange
-  launch_halo(c, lev2d(c, c->F.vbar, kstp), 1, BC_V, 'v');
-  for (int it = 1; it <= c->G.NT; it++) launch_halo(c, t_lev(c, nstp, it), N, BC_R, 'r');   // t3dbc + exchange
+  const HaloSpec hs9[] = {
+      {lev2d(c, c->F.ubar, kstp), 1, BC_U, 'u'},   // u2dbc_tile + exchange
+      {lev2d(c, c->F.vbar, kstp), 1, BC_V, 'v'},
+  };
+  launch_halo_multi(c, hs9, 2);
+  {
+    HaloSpec ht[ROMS_MAXT];
+    for (int it = 1; it <= c->G.NT; it++) ht[it - 1] = HaloSpec{t_lev(c, nstp, it), N, BC_R, 'r'};   // t3dbc + exchange
+    launch_halo_multi(c, ht, c->G.NT);
+  }
   return 0;
 }

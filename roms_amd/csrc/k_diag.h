@@ -120,5 +120,6 @@ THREAD_KERNEL(k_diag_fin, DiagArgs) {
   out[0] = avgke; out[1] = avgpe; out[2] = avgke + avgpe; out[3] = vol; out[4] = spd;
   out[5] = bCu; out[6] = bCv; out[7] = bCw; out[8] = (double)bi; out[9] = (double)bj; out[10] = (double)bk;
   out[11] = bC;
+  out[12] = kes; out[13] = pes;   // un-normalised sums: combined over tiles by the caller
 }
 THREAD_GLOBAL(k_diag_fin, DiagArgs)

@@ -135,3 +135,57 @@ COOP_KERNEL(halo_kernel, HaloArgs) {
   }
 }
 COOP_GLOBAL(halo_kernel, HaloArgs)
+
+// ------------------------------------------------------------------------------------------
+// Inter-tile halo strips (multi-GPU): the data movement of mp_exchange2d/3d/4d
+// (ROMS/Utility/mp_exchange.F:28-2300) with the strip geometry of the periodic copies above --
+// a tile's three west ghost columns {Istr-3..Istr-1} come from its west neighbour's last three
+// interior columns {Iend-2..Iend}; its Nghost east ghost columns {Iend+1..Iend+Nghost} from the
+// east neighbour's first Nghost interior columns; the same along eta.  Phase 0 moves full-height
+// xi strips, phase 1 full-width eta strips (which then carry the corners), as in the reference.
+//
+// Message layout: [plane][line][c], c = position across the strip.
+// ------------------------------------------------------------------------------------------
+struct StripArgs {
+  DGrid G;
+  int nitems;
+  HaloItem it[HALO_MAXITEMS];
+  int phase;           // 0: xi (west/east neighbours), 1: eta (south/north)
+  int unpack;          // 0: pack own interior columns into send buffers, 1: unpack into ghosts
+  double *lo;          // pack: strip sent to the west/south neighbour ; unpack: received from it
+  double *hi;          // pack: strip sent to the east/north neighbour ; unpack: received from it
+};
+
+COOP_KERNEL(strip_kernel, StripArgs) {
+  (void)bx; (void)by; (void)lds;
+  const DGrid &G = a.G;
+  const TB &B = G.T;
+  int item = 0, plane = bz;
+  while (item < a.nitems - 1 && plane >= a.it[item].nk) { plane -= a.it[item].nk; item++; }
+  double *A = a.it[item].A + (size_t)plane * (size_t)G.nij;
+  const int ng = G.Nghost;
+  if (a.phase == 0) {
+    const int nl = G.nj;                       // lines = all local rows
+    double *lo = a.lo ? a.lo + (size_t)bz * (size_t)nl * (a.unpack ? 3 : ng) : nullptr;
+    double *hi = a.hi ? a.hi + (size_t)bz * (size_t)nl * (a.unpack ? ng : 3) : nullptr;
+    if (!a.unpack) {
+      if (lo) KLOOP2(c, l, 0, ng - 1, 0, nl - 1) lo[l * ng + c] = A[X2(B.Istr + c, G.LBj + l)];
+      if (hi) KLOOP2(c, l, 0, 2, 0, nl - 1) hi[l * 3 + c] = A[X2(B.Iend - 2 + c, G.LBj + l)];
+    } else {
+      if (lo) KLOOP2(c, l, 0, 2, 0, nl - 1) A[X2(B.Istr - 3 + c, G.LBj + l)] = lo[l * 3 + c];
+      if (hi) KLOOP2(c, l, 0, ng - 1, 0, nl - 1) A[X2(B.Iend + 1 + c, G.LBj + l)] = hi[l * ng + c];
+    }
+  } else {
+    const int nl = G.ni;                       // lines = all local columns
+    double *lo = a.lo ? a.lo + (size_t)bz * (size_t)nl * (a.unpack ? 3 : ng) : nullptr;
+    double *hi = a.hi ? a.hi + (size_t)bz * (size_t)nl * (a.unpack ? ng : 3) : nullptr;
+    if (!a.unpack) {
+      if (lo) KLOOP2(l, c, 0, nl - 1, 0, ng - 1) lo[c * nl + l] = A[X2(G.LBi + l, B.Jstr + c)];
+      if (hi) KLOOP2(l, c, 0, nl - 1, 0, 2) hi[c * nl + l] = A[X2(G.LBi + l, B.Jend - 2 + c)];
+    } else {
+      if (lo) KLOOP2(l, c, 0, nl - 1, 0, 2) A[X2(G.LBi + l, B.Jstr - 3 + c)] = lo[c * nl + l];
+      if (hi) KLOOP2(l, c, 0, nl - 1, 0, ng - 1) A[X2(G.LBi + l, B.Jend + 1 + c)] = hi[c * nl + l];
+    }
+  }
+}
+COOP_GLOBAL(strip_kernel, StripArgs)

@@ -66,9 +66,21 @@ typedef hipStream_t kstream_t;
     extern __shared__ double lds_dyn_[];                                                 \
     name##_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds_dyn_);         \
   }
+// per-kernel HIP-event timing (roms_hip_kprof, roms_hip.cpp): mode 0 off, 1 every launch
+// (synchronous), 2 launches of one selected kernel (asynchronous event pairs)
+extern int g_kprof_mode;
+int kprof_begin(const char *name, hipStream_t stream);
+void kprof_end(int slot, hipStream_t stream);
+#define KPROF_WRAP(name, stream, launch)                                                 \
+  do {                                                                                   \
+    int kp_ = g_kprof_mode ? kprof_begin(#name, stream) : -1;                            \
+    launch;                                                                              \
+    if (kp_ >= 0) kprof_end(kp_, stream);                                                \
+  } while (0)
 #define LAUNCH_COOP(name, gx, gy, gz, nthreads, lds_doubles, stream, args)               \
+  KPROF_WRAP(name, stream,                                                               \
   hipLaunchKernelGGL(name, dim3((unsigned)(gx), (unsigned)(gy), (unsigned)(gz)), dim3((unsigned)(nthreads)), \
-                     (size_t)(lds_doubles) * sizeof(double), stream, args)
+                     (size_t)(lds_doubles) * sizeof(double), stream, args))
 
 #define THREAD_KERNEL(name, ArgT) static __device__ void name##_body(const ArgT &a, int gx, int gy, int gz)
 #define THREAD_GLOBAL(name, ArgT)                                                        \
@@ -80,8 +92,9 @@ typedef hipStream_t kstream_t;
   }
 // 64 lanes along xi (coalesced), 4 rows of eta per block
 #define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
+  KPROF_WRAP(name, stream,                                                               \
   hipLaunchKernelGGL(name, dim3((unsigned)(((nx) + 63) / 64), (unsigned)(((ny) + 3) / 4), (unsigned)(nz)), \
-                     dim3(64, 4, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz))
+                     dim3(64, 4, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
 #endif
 
 // block-strided loop nest over the rectangle [ilo,ihi] x [jlo,jhi] (inclusive), i fastest

@@ -20,7 +20,7 @@ static void dfree(void *p) { free(p); }
 static int h2d(void *d, const void *h, size_t bytes, kstream_t) { memcpy(d, h, bytes); return 0; }
 static int d2h(void *h, const void *d, size_t bytes, kstream_t) { memcpy(h, d, bytes); return 0; }
 static int dsync(kstream_t) { return 0; }
-int ctx_check(roms_hip_ctx *, const char *) { return 0; }
+int ctx_check(roms_hip_ctx *c, const char *) { return c->comm_failed ? 2 : 0; }
 #else
 static int hipfail(hipError_t e, const char *what) {
   if (e == hipSuccess) return 0;
@@ -44,7 +44,10 @@ static int d2h(void *h, const void *d, size_t bytes, kstream_t s) {
   return hipfail(hipStreamSynchronize(s), "hipStreamSynchronize");
 }
 static int dsync(kstream_t s) { return hipfail(hipStreamSynchronize(s), "hipStreamSynchronize"); }
-int ctx_check(roms_hip_ctx *, const char *what) { return hipfail(hipGetLastError(), what); }
+int ctx_check(roms_hip_ctx *c, const char *what) {
+  if (c->comm_failed) return 2;
+  return hipfail(hipGetLastError(), what);
+}
 #endif
 
 // ------------------------------------------------------------------------------- field table
@@ -110,6 +113,7 @@ static void choose_blocks(DGrid &G) {
   G.bh = (MmT + G.nby - 1) / G.nby;
 }
 
+static void comm_destroy(roms_hip_ctx *c);
 extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   if (!cfg || !out) { set_error("null argument"); return 8; }
   if (cfg->abi_version != ROMS_HIP_ABI_VERSION) { set_error("ABI version mismatch"); return 5; }
@@ -117,9 +121,16 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     set_error("unsupported dimensions (need 4 <= N <= 127, NT <= 4, 2*ndtfast <= 512)");
     return 5;
   }
-  if (cfg->NtileI * cfg->NtileJ != 1) {
-    set_error("this build handles one tile per process domain (NtileI*NtileJ == 1)");
+  if (cfg->NtileI < 1 || cfg->NtileJ < 1 || cfg->tile < 0 || cfg->tile >= cfg->NtileI * cfg->NtileJ) {
+    set_error("bad tile partition (NtileI, NtileJ, tile)");
     return 5;
+  }
+  {  // array bounds must hold the ghost zone the kernels and the strip exchange assume
+    const int pw = cfg->west_edge && !cfg->EWperiodic, pe = cfg->east_edge && !cfg->EWperiodic;
+    const int ps = cfg->south_edge && !cfg->NSperiodic, pn = cfg->north_edge && !cfg->NSperiodic;
+    const bool ok = cfg->LBi <= (pw ? cfg->Istr - 1 : cfg->Istr - 3) && cfg->UBi >= (pe ? cfg->Iend + 1 : cfg->Iend + cfg->Nghost) &&
+                    cfg->LBj <= (ps ? cfg->Jstr - 1 : cfg->Jstr - 3) && cfg->UBj >= (pn ? cfg->Jend + 1 : cfg->Jend + cfg->Nghost);
+    if (!ok) { set_error("array bounds LBi:UBi,LBj:UBj too small for the tile's ghost zone"); return 5; }
   }
 #ifndef ROMS_CPU_EMU
   int ndev = 0;
@@ -149,6 +160,16 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   G.Vtransform = cfg->Vtransform;
   c->profile = false;
   memset(c->regions, 0, sizeof(c->regions));
+  memset(&c->comm, 0, sizeof(c->comm));
+  c->comm_failed = false;
+  {  // neighbours in the reference's tile numbering; a periodic direction wraps around
+    const int NI = cfg->NtileI, NJ = cfg->NtileJ, it = cfg->tile % NI, jt = cfg->tile / NI;
+    int *nb = c->comm.nbr;
+    nb[0] = it > 0 ? cfg->tile - 1 : (cfg->EWperiodic && NI > 1 ? cfg->tile + NI - 1 : -1);
+    nb[1] = it < NI - 1 ? cfg->tile + 1 : (cfg->EWperiodic && NI > 1 ? cfg->tile - (NI - 1) : -1);
+    nb[2] = jt > 0 ? cfg->tile - NI : (cfg->NSperiodic && NJ > 1 ? cfg->tile + NI * (NJ - 1) : -1);
+    nb[3] = jt < NJ - 1 ? cfg->tile + NI : (cfg->NSperiodic && NJ > 1 ? cfg->tile - NI * (NJ - 1) : -1);
+  }
 #ifdef ROMS_CPU_EMU
   c->stream = nullptr;
 #else
@@ -204,6 +225,8 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   if (!c) return 0;
   (void)dsync(c->stream);
   for (void *p : c->allocs) dfree(p);
+  for (int k = 0; k < 4; k++) { if (c->comm.sbuf[k]) dfree(c->comm.sbuf[k]); if (c->comm.rbuf[k]) dfree(c->comm.rbuf[k]); }
+  comm_destroy(c);
   free(c->h_diag);
 #ifndef ROMS_CPU_EMU
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -283,11 +306,231 @@ extern "C" int roms_hip_region_seconds(roms_hip_ctx *c, int region, double *seco
   return 0;
 }
 
+// -------------------------------------------------------------------- per-kernel timing
+// Process-wide table keyed by the kernel's name (the LAUNCH_* macros pass it).  Mode 1 brackets
+// every launch with an event pair and waits for it (a breakdown pass; slows the step down).
+// Mode 2 brackets only launches of the selected kernel with event pairs taken from a pool and
+// resolves them when the pool is full or when the table is read: no host synchronisation inside
+// the timed region.
+#ifndef ROMS_CPU_EMU
+int g_kprof_mode = 0;
+namespace {
+struct KSlot { char name[48]; double seconds; long calls; };
+const int KMAXSLOT = 128, KPOOL = 8192;
+KSlot g_kslot[KMAXSLOT];
+int g_nkslot = 0;
+char g_kselect[48] = "";
+hipEvent_t g_kev[2 * KPOOL];
+int g_kev_slot[KPOOL];
+int g_kev_made = 0, g_kev_used = 0;
+int kslot_of(const char *name) {
+  for (int i = 0; i < g_nkslot; i++)
+    if (!strcmp(g_kslot[i].name, name)) return i;
+  if (g_nkslot >= KMAXSLOT) return -1;
+  KSlot &k = g_kslot[g_nkslot];
+  strncpy(k.name, name, sizeof(k.name) - 1); k.name[sizeof(k.name) - 1] = 0;
+  k.seconds = 0.0; k.calls = 0;
+  return g_nkslot++;
+}
+void kprof_resolve() {
+  for (int i = 0; i < g_kev_used; i++) {
+    (void)hipEventSynchronize(g_kev[2 * i + 1]);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, g_kev[2 * i], g_kev[2 * i + 1]);
+    g_kslot[g_kev_slot[i]].seconds += 1.0e-3 * (double)ms;
+    g_kslot[g_kev_slot[i]].calls += 1;
+  }
+  g_kev_used = 0;
+}
+}  // namespace
+int kprof_begin(const char *name, hipStream_t stream) {
+  if (g_kprof_mode == 2 && strcmp(name, g_kselect)) return -1;
+  int slot = kslot_of(name);
+  if (slot < 0) return -1;
+  if (g_kev_used >= KPOOL) kprof_resolve();
+  if (g_kev_used >= g_kev_made) {
+    (void)hipEventCreate(&g_kev[2 * g_kev_made]);
+    (void)hipEventCreate(&g_kev[2 * g_kev_made + 1]);
+    g_kev_made++;
+  }
+  int e = g_kev_used++;
+  g_kev_slot[e] = slot;
+  (void)hipEventRecord(g_kev[2 * e], stream);
+  return e;
+}
+void kprof_end(int e, hipStream_t stream) {
+  (void)hipEventRecord(g_kev[2 * e + 1], stream);
+  if (g_kprof_mode == 1) kprof_resolve();
+}
+extern "C" int roms_hip_kprof(int mode, const char *kernel) {
+  kprof_resolve();
+  g_kprof_mode = mode;
+  g_nkslot = 0;
+  g_kselect[0] = 0;
+  if (kernel) { strncpy(g_kselect, kernel, sizeof(g_kselect) - 1); g_kselect[sizeof(g_kselect) - 1] = 0; }
+  return 0;
+}
+extern "C" int roms_hip_kprof_get(int index, char *name, int name_len, double *seconds, long *calls) {
+  kprof_resolve();
+  if (index < 0 || index >= g_nkslot) return 8;
+  if (name && name_len > 0) { strncpy(name, g_kslot[index].name, (size_t)name_len - 1); name[name_len - 1] = 0; }
+  if (seconds) *seconds = g_kslot[index].seconds;
+  if (calls) *calls = g_kslot[index].calls;
+  return 0;
+}
+#else
+extern "C" int roms_hip_kprof(int, const char *) { return 0; }
+extern "C" int roms_hip_kprof_get(int, char *, int, double *, long *) { return 8; }
+#endif
+
 // ------------------------------------------------------------------------------------- halo
 void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype) {
   HaloSpec sp = {A, nk, bc, gtype};
   launch_halo_multi(c, &sp, 1);
 }
+// ---- transports ---------------------------------------------------------------------------
+#ifndef ROMS_CPU_EMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct RcclApi {
+  void *lib;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*GroupStart)();
+  ncclResult_t (*GroupEnd)();
+  const char *(*GetErrorString)(ncclResult_t);
+} g_rccl = {};
+// RCCL is opened on first use so that single-GPU runs do not depend on it; a copy that the
+// process already loaded (PyTorch ships one) is reused.
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }
+  if (!h) for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+  if (!h) { set_error(std::string("cannot load RCCL: ") + dlerror()); return 2; }
+#define RSYM(f) *(void **)(&g_rccl.f) = dlsym(h, "nccl" #f); if (!g_rccl.f) { set_error("RCCL symbol nccl" #f " missing"); return 2; }
+  RSYM(GetUniqueId) RSYM(CommInitRank) RSYM(CommDestroy) RSYM(Send) RSYM(Recv) RSYM(GroupStart) RSYM(GroupEnd)
+  RSYM(GetErrorString)
+#undef RSYM
+  g_rccl.lib = h;
+  return 0;
+}
+int rcclfail(ncclResult_t r, const char *what) {
+  if (r == ncclSuccess) return 0;
+  set_error(std::string(what) + ": " + g_rccl.GetErrorString(r));
+  return 2;
+}
+}  // namespace
+extern "C" int roms_hip_rccl_unique_id(void *id128) {
+  if (!id128) return 8;
+  if (rccl_load()) return 2;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  return rcclfail(g_rccl.GetUniqueId((ncclUniqueId *)id128), "ncclGetUniqueId");
+}
+extern "C" int roms_hip_comm_rccl(roms_hip_ctx *c, const void *id128, int nranks, int rank) {
+  if (!c || !id128) return 8;
+  if (nranks != c->cfg.NtileI * c->cfg.NtileJ || rank != c->cfg.tile) {
+    set_error("roms_hip_comm_rccl: need nranks == NtileI*NtileJ and rank == tile");
+    return 5;
+  }
+  if (rccl_load()) return 2;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t comm = nullptr;
+  if (rcclfail(g_rccl.CommInitRank(&comm, nranks, id, rank), "ncclCommInitRank")) return 2;
+  c->comm.nccl = (void *)comm;
+  return 0;
+}
+static void comm_destroy(roms_hip_ctx *c) {
+  if (c->comm.nccl && g_rccl.lib) (void)g_rccl.CommDestroy((ncclComm_t)c->comm.nccl);
+  c->comm.nccl = nullptr;
+}
+#else
+extern "C" int roms_hip_rccl_unique_id(void *) { set_error("RCCL is not part of the CPU-emulated test build"); return 2; }
+extern "C" int roms_hip_comm_rccl(roms_hip_ctx *, const void *, int, int) {
+  set_error("RCCL is not part of the CPU-emulated test build");
+  return 2;
+}
+static void comm_destroy(roms_hip_ctx *) {}
+#endif
+extern "C" int roms_hip_set_exchange(roms_hip_ctx *c, roms_hip_exchange_fn fn, void *user) {
+  if (!c) return 8;
+  c->comm.fn = fn;
+  c->comm.user = user;
+  return 0;
+}
+extern "C" long roms_hip_exchange_count(roms_hip_ctx *c) { return c ? c->comm.nexchanges : 0; }
+
+// One phase (0: xi, 1: eta) of the strip exchange for the fields of a halo launch.
+static int exchange_phase(roms_hip_ctx *c, const HaloArgs &h, int planes, int phase) {
+  TileComm &m = c->comm;
+  const int lo = m.nbr[2 * phase], hi = m.nbr[2 * phase + 1];
+  if (lo < 0 && hi < 0) return 0;
+  if (!m.fn && !m.nccl) {
+    set_error("multi-tile context without a transport: call roms_hip_comm_rccl or roms_hip_set_exchange first");
+    return 8;
+  }
+  const DGrid &G = c->G;
+  const size_t lines = phase == 0 ? (size_t)G.nj : (size_t)G.ni;
+  const size_t need = (size_t)planes * lines * 3;
+  if (need > m.cap) {
+    (void)dsync(c->stream);
+    for (int k = 0; k < 4; k++) {
+      if (m.sbuf[k]) dfree(m.sbuf[k]);
+      if (m.rbuf[k]) dfree(m.rbuf[k]);
+      void *p = nullptr, *q = nullptr;
+      if (dmalloc(&p, need * sizeof(double)) || dmalloc(&q, need * sizeof(double))) return 2;
+      m.sbuf[k] = (double *)p; m.rbuf[k] = (double *)q;
+    }
+    m.cap = need;
+  }
+  const long n_lo_out = (long)((size_t)planes * lines * (size_t)G.Nghost);   // my first Nghost lines -> low neighbour
+  const long n_hi_out = (long)((size_t)planes * lines * 3);                  // my last 3 lines      -> high neighbour
+  StripArgs a;
+  a.G = G; a.nitems = h.nitems;
+  for (int k = 0; k < h.nitems; k++) a.it[k] = h.it[k];
+  a.phase = phase; a.unpack = 0;
+  a.lo = lo >= 0 ? m.sbuf[2 * phase] : nullptr;
+  a.hi = hi >= 0 ? m.sbuf[2 * phase + 1] : nullptr;
+  LAUNCH_COOP(strip_kernel, 1, 1, planes, 256, 0, c->stream, a);
+  // sends: [to hi: "upward" strip, to lo: "downward" strip]; receives: [from lo: its upward strip,
+  // from hi: its downward strip].  With this order two messages between the same pair of ranks
+  // (two tiles across a periodic direction) match by issue order as well as by tag.
+  int sp[2], st[2], rp[2], rt[2], ns = 0, nr = 0;
+  double *sb[2], *rb[2];
+  long sc[2], rc[2];
+  if (hi >= 0) { sp[ns] = hi; sb[ns] = m.sbuf[2 * phase + 1]; sc[ns] = n_hi_out; st[ns] = 2 * phase; ns++; }
+  if (lo >= 0) { sp[ns] = lo; sb[ns] = m.sbuf[2 * phase]; sc[ns] = n_lo_out; st[ns] = 2 * phase + 1; ns++; }
+  if (lo >= 0) { rp[nr] = lo; rb[nr] = m.rbuf[2 * phase]; rc[nr] = n_hi_out; rt[nr] = 2 * phase; nr++; }
+  if (hi >= 0) { rp[nr] = hi; rb[nr] = m.rbuf[2 * phase + 1]; rc[nr] = n_lo_out; rt[nr] = 2 * phase + 1; nr++; }
+  if (m.fn) {
+    int r = dsync(c->stream);
+    if (r) return r;
+    if (m.fn(m.user, ns, sp, sb, sc, st, nr, rp, rb, rc, rt)) { set_error("halo exchange transport failed"); return 2; }
+  } else {
+#ifndef ROMS_CPU_EMU
+    ncclComm_t comm = (ncclComm_t)m.nccl;
+    if (rcclfail(g_rccl.GroupStart(), "ncclGroupStart")) return 2;
+    for (int k = 0; k < ns; k++)
+      if (rcclfail(g_rccl.Send(sb[k], (size_t)sc[k], ncclDouble, sp[k], comm, c->stream), "ncclSend")) return 2;
+    for (int k = 0; k < nr; k++)
+      if (rcclfail(g_rccl.Recv(rb[k], (size_t)rc[k], ncclDouble, rp[k], comm, c->stream), "ncclRecv")) return 2;
+    if (rcclfail(g_rccl.GroupEnd(), "ncclGroupEnd")) return 2;
+#endif
+  }
+  a.unpack = 1;
+  a.lo = lo >= 0 ? m.rbuf[2 * phase] : nullptr;
+  a.hi = hi >= 0 ? m.rbuf[2 * phase + 1] : nullptr;
+  LAUNCH_COOP(strip_kernel, 1, 1, planes, 256, 0, c->stream, a);
+  m.nexchanges++;
+  return 0;
+}
+
 void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n) {
   HaloArgs a;
   a.G = c->G;
@@ -298,6 +541,8 @@ void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n) {
     planes += sp[k].nk;
   }
   LAUNCH_COOP(halo_kernel, 1, 1, planes, 256, 0, c->stream, a);
+  // neighbouring tiles on other GPUs: xi strips, then eta strips (corners travel with the latter)
+  if (exchange_phase(c, a, planes, 0) || exchange_phase(c, a, planes, 1)) c->comm_failed = true;
 }
 
 // ---------------------------------------------------------------------- per-kernel C entries

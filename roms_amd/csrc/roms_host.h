@@ -20,8 +20,21 @@ enum { FK_2D = 0, FK_R, FK_W, FK_2Dx3, FK_2Dx2, FK_Rx2, FK_T, FK_Wx2, FK_2DxNT, 
 
 struct Region { double seconds; long calls; };
 
+// inter-tile communication state (multi-GPU runs: one tile per process/GPU)
+struct TileComm {
+  int nbr[4];                   // ranks of the west, east, south, north neighbours (-1: none)
+  double *sbuf[4], *rbuf[4];    // device staging buffers per neighbour
+  size_t cap;                   // doubles per staging buffer
+  roms_hip_exchange_fn fn;      // user transport (MPI, gloo ...) or null
+  void *user;
+  void *nccl;                   // ncclComm_t of the built-in RCCL transport or null
+  long nexchanges;
+};
+
 struct roms_hip_ctx {
   roms_hip_config cfg;
+  TileComm comm;
+  bool comm_failed;             // a halo exchange failed (reported by the next ctx_check)
   DGrid G;
   Fields F;
   kstream_t stream;

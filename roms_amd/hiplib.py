@@ -54,8 +54,16 @@ KERNELS = ["set_depth", "set_massflux", "rho_eos", "set_vbc", "ana_vmix", "set_d
 EXPORTS = ["roms_hip_create", "roms_hip_destroy", "roms_hip_last_error", "roms_hip_abi_version",
            "roms_hip_field_size", "roms_hip_upload", "roms_hip_download", "roms_hip_sync",
            "roms_hip_set_stepping", "roms_hip_get_stepping", "roms_hip_wvelocity", "roms_hip_diag",
-           "roms_hip_start", "roms_hip_main3d", "roms_hip_profile", "roms_hip_region_seconds"] + \
+           "roms_hip_start", "roms_hip_main3d", "roms_hip_profile", "roms_hip_region_seconds",
+           "roms_hip_kprof", "roms_hip_kprof_get", "roms_hip_set_exchange", "roms_hip_rccl_unique_id",
+           "roms_hip_comm_rccl", "roms_hip_exchange_count"] + \
           ["roms_hip_" + k for k in KERNELS]
+
+
+# roms_hip_exchange_fn (include/roms_hip.h)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p),
+                          C.POINTER(C.c_long), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_long), C.POINTER(C.c_int))
 
 
 class RomsHipError(RuntimeError):
@@ -85,9 +93,33 @@ def load(path=None):
     L.roms_hip_main3d.argtypes = [C.c_void_p, C.c_int]
     L.roms_hip_profile.argtypes = [C.c_void_p, C.c_int]
     L.roms_hip_region_seconds.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    L.roms_hip_set_exchange.argtypes = [C.c_void_p, EXCHANGE_FN, C.c_void_p]
+    L.roms_hip_rccl_unique_id.argtypes = [C.c_void_p]
+    L.roms_hip_comm_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.roms_hip_exchange_count.argtypes = [C.c_void_p]
+    L.roms_hip_exchange_count.restype = C.c_long
+    L.roms_hip_kprof.argtypes = [C.c_int, C.c_char_p]
+    L.roms_hip_kprof_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     for k in KERNELS:
         getattr(L, "roms_hip_" + k).argtypes = [C.c_void_p]
     return L
+
+
+def kprof(mode, kernel=None, lib_path=None):
+    """Per-kernel HIP-event timing: 0 off, 1 all launches (synchronous), 2 only `kernel` (asynchronous)."""
+    load(lib_path).roms_hip_kprof(mode, kernel.encode() if kernel else None)
+
+
+def kprof_table(lib_path=None):
+    """{kernel name: (seconds, launches)} accumulated since the last kprof() call."""
+    L = load(lib_path)
+    out, i = {}, 0
+    name = C.create_string_buffer(64)
+    sec, calls = C.c_double(), C.c_long()
+    while L.roms_hip_kprof_get(i, name, 64, C.byref(sec), C.byref(calls)) == 0:
+        out[name.value.decode()] = (sec.value, calls.value)
+        i += 1
+    return out
 
 
 class Context:
@@ -161,10 +193,10 @@ class Context:
     def main3d(self, nsteps=1):
         self._ck(self.L.roms_hip_main3d(self.h, int(nsteps)))
 
-    def diag(self):
+    def diag(self, raw=False):
         out = (C.c_double * 16)()
         self._ck(self.L.roms_hip_diag(self.h, out))
-        return list(out)[:12]
+        return list(out) if raw else list(out)[:12]
 
     def profile(self, enable=True):
         self._ck(self.L.roms_hip_profile(self.h, int(enable)))

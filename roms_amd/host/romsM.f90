@@ -8,7 +8,7 @@
       implicit none
       character(len=512) :: infile, arg2
       integer :: ierr, istep, nchunk, mode
-      real(c_double) :: d(12)
+      real(c_double) :: d(16)
       integer(8) :: c0, c1, crate
       IF (COMMAND_ARGUMENT_COUNT().lt.1) THEN
         print '(a)', ' usage: romsM roms.in [kernels]'
@@ -31,7 +31,12 @@
         STOP 5
       END IF
       print '(1x,a,a,3(1x,i0),a,i0,a,f8.2)', TRIM(MyAppCPP), ':', Lm, Mm, N, '  nfast = ', nfast, '  dt = ', dt
-      CALL device_init (0, ierr)
+      IF (NtileI*NtileJ.ne.1) THEN
+        print '(a)', ' romsM: one process drives one GPU tile; multi-GPU runs are launched through roms_amd.tiling'
+        STOP 5
+      END IF
+      CALL device_init (0, 0, ierr)
+      IF (ierr.eq.0) CALL device_start (ierr)
       IF (ierr.ne.0) THEN
         print '(a,i0)', ' romsM: device initialisation failed, exit_flag = ', ierr
         STOP 2

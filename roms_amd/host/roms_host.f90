@@ -36,6 +36,7 @@
       integer :: Nghost, Im, Jm, LBi, UBi, LBj, UBj, nfast
       integer :: Istr, Iend, Jstr, Jend, IstrR, IendR, JstrR, JendR, IstrT, IendT, JstrT, JendT
       integer :: IstrP, JstrP
+      integer :: my_tile = 0, tIstr, tIend, tJstr, tJend, tLBi, tUBi, tLBj, tUBj    ! this process' tile
       real(dp) :: dtfast, hc, hmin, hmax, xl, el
       real(dp), allocatable :: weight(:,:), sc_r(:), Cs_r(:), sc_w(:), Cs_w(:)
 
@@ -865,21 +866,54 @@
 !  Device context: fill roms_hip_config, upload the state, run the tail of "initial".
 !=======================================================================
 !
-      SUBROUTINE device_init (device, ierr)
-      integer, intent(in) :: device
+      SUBROUTINE device_init (device, tile, ierr)
+      integer, intent(in) :: device, tile
       integer, intent(out) :: ierr
       TYPE (roms_hip_config) :: cfg
-      integer :: i
+      integer :: i, itile, jtile, chunk, margin
+      logical :: tw, te, ts, tn
+      ierr=0
+      IF (tile.lt.0.or.tile.ge.NtileI*NtileJ) THEN
+        ierr=5
+        RETURN
+      END IF
+!
+!  Tile partition, tile_bounds_2d (get_bounds.F:972-1042); rank = tile = itile + jtile*NtileI.
+!
+      my_tile=tile
+      itile=MOD(tile,NtileI)
+      jtile=tile/NtileI
+      chunk=(Lm+NtileI-1)/NtileI
+      margin=(NtileI*chunk-Lm)/2
+      tIstr=MAX(1+itile*chunk-margin,1)
+      tIend=MIN(1+itile*chunk-margin+chunk-1,Lm)
+      chunk=(Mm+NtileJ-1)/NtileJ
+      margin=(NtileJ*chunk-Mm)/2
+      tJstr=MAX(1+jtile*chunk-margin,1)
+      tJend=MIN(1+jtile*chunk-margin+chunk-1,Mm)
+      tw=itile.eq.0
+      te=itile.eq.NtileI-1
+      ts=jtile.eq.0
+      tn=jtile.eq.NtileJ-1
+!
+!  Tile arrays: the domain's own bounds at a domain edge, otherwise three ghost lines on the low
+!  side and Nghost on the high side (the periodic layout of mod_param.F:1640-1665 around the tile).
+!
+      tLBi=MERGE(LBi, tIstr-1-Nghost, tw)
+      tUBi=MERGE(UBi, tIend+Nghost, te)
+      tLBj=MERGE(LBj, tJstr-1-Nghost, ts)
+      tUBj=MERGE(UBj, tJend+Nghost, tn)
       cfg%abi_version=1
       cfg%device=device
       cfg%Lm=Lm; cfg%Mm=Mm; cfg%N=N; cfg%NT=NT; cfg%NAT=NAT; cfg%Nghost=Nghost
-      cfg%LBi=LBi; cfg%UBi=UBi; cfg%LBj=LBj; cfg%UBj=UBj
-      cfg%NtileI=1; cfg%NtileJ=1; cfg%tile=0
+      cfg%LBi=tLBi; cfg%UBi=tUBi; cfg%LBj=tLBj; cfg%UBj=tUBj
+      cfg%NtileI=NtileI; cfg%NtileJ=NtileJ; cfg%tile=tile
       cfg%EWperiodic=MERGE(1,0,EWperiodic); cfg%NSperiodic=MERGE(1,0,NSperiodic)
       cfg%options=options
       cfg%hadv=hadv; cfg%vadv=vadv
-      cfg%Istr=Istr; cfg%Iend=Iend; cfg%Jstr=Jstr; cfg%Jend=Jend
-      cfg%west_edge=1; cfg%east_edge=1; cfg%south_edge=1; cfg%north_edge=1
+      cfg%Istr=tIstr; cfg%Iend=tIend; cfg%Jstr=tJstr; cfg%Jend=tJend
+      cfg%west_edge=MERGE(1,0,tw); cfg%east_edge=MERGE(1,0,te)
+      cfg%south_edge=MERGE(1,0,ts); cfg%north_edge=MERGE(1,0,tn)
       cfg%ntfirst=1; cfg%ntstart=1; cfg%ndtfast=ndtfast; cfg%nfast=nfast; cfg%ninfo=ninfo
       cfg%dt=dt; cfg%dtfast=dtfast
       cfg%weight=0.0_dp
@@ -898,37 +932,56 @@
       cfg%sc_r(1:N)=sc_r; cfg%Cs_r(1:N)=Cs_r; cfg%sc_w(0:N)=sc_w; cfg%Cs_w(0:N)=Cs_w
       ierr=roms_hip_create(cfg, ctx)
       IF (ierr.ne.0) RETURN
-      CALL up ('h', h, ierr); CALL up ('f', f, ierr); CALL up ('fomn', fomn, ierr)
-      CALL up ('pm', pm, ierr); CALL up ('pn', pn, ierr); CALL up ('om_r', om_r, ierr)
-      CALL up ('on_r', on_r, ierr); CALL up ('om_u', om_u, ierr); CALL up ('on_u', on_u, ierr)
-      CALL up ('om_v', om_v, ierr); CALL up ('on_v', on_v, ierr); CALL up ('om_p', om_p, ierr)
-      CALL up ('on_p', on_p, ierr); CALL up ('omn', omn, ierr); CALL up ('pmon_r', pmon_r, ierr)
-      CALL up ('pnom_r', pnom_r, ierr); CALL up ('pmon_p', pmon_p, ierr); CALL up ('pnom_p', pnom_p, ierr)
-      CALL up ('pmon_u', pmon_u, ierr); CALL up ('pnom_u', pnom_u, ierr); CALL up ('pmon_v', pmon_v, ierr)
-      CALL up ('pnom_v', pnom_v, ierr); CALL up ('dmde', dmde, ierr); CALL up ('dndx', dndx, ierr)
-      CALL up ('angler', angler, ierr); CALL up ('xr', xr, ierr); CALL up ('yr', yr, ierr)
-      CALL up ('lonr', lonr, ierr); CALL up ('latr', latr, ierr); CALL up ('rdrag', rdrag, ierr)
-      CALL up ('rdrag2', rdrag2, ierr); CALL up ('visc2_r', visc2_r, ierr); CALL up ('visc2_p', visc2_p, ierr)
-      CALL up ('diff2', diff2, ierr); CALL up ('Zt_avg1', Zt_avg1, ierr)
-      CALL up ('Hz', Hz, ierr); CALL up ('z_r', z_r, ierr); CALL up ('z_w', z_w, ierr)
-      CALL up ('zeta', zeta, ierr); CALL up ('ubar', ubar, ierr); CALL up ('vbar', vbar, ierr)
-      CALL up ('u', u, ierr); CALL up ('v', v, ierr); CALL up ('t', t, ierr)
-      CALL up ('Akv', Akv, ierr); CALL up ('Akt', Akt, ierr)
-      IF (ierr.ne.0) RETURN
-      ierr=roms_hip_start(ctx)                  ! set_massflux, omega, rho_eos (initial.F:562-577)
+      CALL up ('h', h, 1, ierr); CALL up ('f', f, 1, ierr); CALL up ('fomn', fomn, 1, ierr)
+      CALL up ('pm', pm, 1, ierr); CALL up ('pn', pn, 1, ierr); CALL up ('om_r', om_r, 1, ierr)
+      CALL up ('on_r', on_r, 1, ierr); CALL up ('om_u', om_u, 1, ierr); CALL up ('on_u', on_u, 1, ierr)
+      CALL up ('om_v', om_v, 1, ierr); CALL up ('on_v', on_v, 1, ierr); CALL up ('om_p', om_p, 1, ierr)
+      CALL up ('on_p', on_p, 1, ierr); CALL up ('omn', omn, 1, ierr); CALL up ('pmon_r', pmon_r, 1, ierr)
+      CALL up ('pnom_r', pnom_r, 1, ierr); CALL up ('pmon_p', pmon_p, 1, ierr)
+      CALL up ('pnom_p', pnom_p, 1, ierr); CALL up ('pmon_u', pmon_u, 1, ierr)
+      CALL up ('pnom_u', pnom_u, 1, ierr); CALL up ('pmon_v', pmon_v, 1, ierr)
+      CALL up ('pnom_v', pnom_v, 1, ierr); CALL up ('dmde', dmde, 1, ierr); CALL up ('dndx', dndx, 1, ierr)
+      CALL up ('angler', angler, 1, ierr); CALL up ('xr', xr, 1, ierr); CALL up ('yr', yr, 1, ierr)
+      CALL up ('lonr', lonr, 1, ierr); CALL up ('latr', latr, 1, ierr); CALL up ('rdrag', rdrag, 1, ierr)
+      CALL up ('rdrag2', rdrag2, 1, ierr); CALL up ('visc2_r', visc2_r, 1, ierr)
+      CALL up ('visc2_p', visc2_p, 1, ierr); CALL up ('diff2', diff2, NT, ierr)
+      CALL up ('Zt_avg1', Zt_avg1, 1, ierr)
+      CALL up ('Hz', Hz, N, ierr); CALL up ('z_r', z_r, N, ierr); CALL up ('z_w', z_w, N+1, ierr)
+      CALL up ('zeta', zeta, 3, ierr); CALL up ('ubar', ubar, 3, ierr); CALL up ('vbar', vbar, 3, ierr)
+      CALL up ('u', u, 2*N, ierr); CALL up ('v', v, 2*N, ierr); CALL up ('t', t, 3*N*NT, ierr)
+      CALL up ('Akv', Akv, N+1, ierr); CALL up ('Akt', Akt, (N+1)*NAT, ierr)
       END SUBROUTINE device_init
-
-      SUBROUTINE up (name, A, ierr)
+!
+!  Upload the tile's window (tLBi:tUBi,tLBj:tUBj) of a host array with np horizontal planes.
+!
+      SUBROUTINE up (name, A, np, ierr)
       character(len=*), intent(in) :: name
-      real(r8), intent(in) :: A(*)
+      integer, intent(in) :: np
+      real(r8), intent(in) :: A(LBi:UBi,LBj:UBj,np)
       integer, intent(inout) :: ierr
+      real(r8), allocatable :: win(:,:,:)
       integer(c_long) :: n
       integer :: r
       IF (ierr.ne.0) RETURN
+      allocate ( win(tLBi:tUBi,tLBj:tUBj,np) )
+      win=A(tLBi:tUBi,tLBj:tUBj,:)
       n=roms_hip_field_size(ctx, TRIM(name)//c_null_char)
-      r=roms_hip_upload(ctx, TRIM(name)//c_null_char, A, n)
-      IF (r.ne.0) ierr=r
+      IF (n.ne.SIZE(win,KIND=c_long)) THEN
+        ierr=8
+      ELSE
+        r=roms_hip_upload(ctx, TRIM(name)//c_null_char, win, n)
+        IF (r.ne.0) ierr=r
+      END IF
+      deallocate ( win )
       END SUBROUTINE up
+!
+!  Tail of "initial" on the device: set_massflux, omega, rho_eos (initial.F:562-577).  In a multi-tile
+!  run the halo transport (roms_hip_comm_rccl / roms_hip_set_exchange) must be installed first.
+!
+      SUBROUTINE device_start (ierr)
+      integer, intent(out) :: ierr
+      ierr=roms_hip_start(ctx)
+      END SUBROUTINE device_start
 !
 !=======================================================================
 !  main3d, Nonlinear/main3d.F:216-1148, kernel by kernel through the C ABI (the seam a maintainer

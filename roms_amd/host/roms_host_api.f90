@@ -34,18 +34,39 @@
 !
 !  Create the device context, upload the state, finish "initial" on the device.
 !
-      FUNCTION roms_host_device_init (device) bind(C, name='roms_host_device_init') RESULT (ierr)
-      integer(c_int), value :: device
+      FUNCTION roms_host_device_init (device, tile) bind(C, name='roms_host_device_init') RESULT (ierr)
+      integer(c_int), value :: device, tile
       integer(c_int) :: ierr
       integer :: e
       IF (.not.allocated(h)) THEN
         ierr=8
         RETURN
       END IF
-      CALL device_init (INT(device), e)
+      CALL device_init (INT(device), INT(tile), e)
       exit_flag=e
       ierr=e
       END FUNCTION roms_host_device_init
+!
+!  Finish "initial" on the device (after the halo transport of a multi-tile run is installed).
+!
+      FUNCTION roms_host_start () bind(C, name='roms_host_start') RESULT (ierr)
+      integer(c_int) :: ierr
+      integer :: e
+      IF (.not.c_associated(ctx)) THEN
+        ierr=8
+        RETURN
+      END IF
+      CALL device_start (e)
+      exit_flag=e
+      ierr=e
+      END FUNCTION roms_host_start
+!
+!  b(1:12) = tile, Istr, Iend, Jstr, Jend, LBi, UBi, LBj, UBj of the tile arrays, NtileI, NtileJ, 0
+!
+      SUBROUTINE roms_host_tile (b) bind(C, name='roms_host_tile')
+      integer(c_int), intent(out) :: b(12)
+      b=(/ my_tile, tIstr, tIend, tJstr, tJend, tLBi, tUBi, tLBj, tUBj, NtileI, NtileJ, 0 /)
+      END SUBROUTINE roms_host_tile
 !
 !  Advance nsteps baroclinic steps: mode 0 = fused roms_hip_main3d, 1 = kernel-by-kernel main3d.
 !

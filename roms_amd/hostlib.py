@@ -15,25 +15,27 @@ from . import build as _build
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libroms_host.so")
 
-_lib = None
+_libs = {}
 
 
-def load():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB):
-            raise RuntimeError(f"{LIB} is not built (python -m roms_amd.build)")
-        lib = C.CDLL(LIB, mode=C.RTLD_GLOBAL)
+def load(path=None):
+    path = os.path.abspath(path or LIB)
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is not built (python -m roms_amd.build)")
+        lib = C.CDLL(path)
         lib.roms_host_setup.argtypes = [C.c_char_p]
-        lib.roms_host_device_init.argtypes = [C.c_int]
+        lib.roms_host_device_init.argtypes = [C.c_int, C.c_int]
+        lib.roms_host_tile.argtypes = [C.POINTER(C.c_int)]
+        lib.roms_host_tile.restype = None
         lib.roms_host_run.argtypes = [C.c_int, C.c_int]
         lib.roms_host_ctx.restype = C.c_void_p
         lib.roms_host_dims.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double)]
         lib.roms_host_dims.restype = None
         lib.roms_host_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_long]
         lib.roms_host_get.restype = C.c_long
-        _lib = lib
-    return _lib
+        _libs[path] = lib
+    return _libs[path]
 
 
 def write_roms_in(path, p):
@@ -44,7 +46,7 @@ def write_roms_in(path, p):
     lines = [
         f"    MyAppCPP = {p['app'].upper()}",
         f"          Lm == {p['Lm']}", f"          Mm == {p['Mm']}", f"           N == {p['N']}",
-        "      NtileI == 1", "      NtileJ == 1",
+        f"      NtileI == {p.get('NtileI', 1)}", f"      NtileJ == {p.get('NtileJ', 1)}",
         f"  Hadvection == {p['hadv'][0]} \\", f"                {p['hadv'][1]}",
         f"  Vadvection == {p['vadv'][0]} \\", f"                {p['vadv'][1]}",
         f" LBC(isFsur) == {per(p['EWperiodic'])} {per(p['NSperiodic'])} {per(p['EWperiodic'])} {per(p['NSperiodic'])}",
@@ -71,8 +73,9 @@ def write_roms_in(path, p):
 class Host:
     """One ROMS run owned by the Fortran host (module state: one instance per process)."""
 
-    def __init__(self, infile=None, params=None):
-        self.lib = load()
+    def __init__(self, infile=None, params=None, lib_path=None, hip_lib_path=None):
+        self.lib = load(lib_path)
+        self.hip_lib_path = hip_lib_path
         tmp = None
         if infile is None:
             fd, tmp = tempfile.mkstemp(suffix=".in", prefix="roms_")
@@ -103,23 +106,39 @@ class Host:
         self.lib.roms_host_get(name.encode(), a.ctypes.data_as(C.POINTER(C.c_double)), n)
         return a
 
-    def device_init(self, device=0):
-        r = self.lib.roms_host_device_init(device)
+    def _fail(self, what, r):
+        from . import hiplib
+        msg = hiplib.load(self.hip_lib_path).roms_hip_last_error()
+        raise hiplib.RomsHipError(f"{what}: exit_flag={r}: {msg.decode() if msg else ''}")
+
+    def device_init(self, device=0, tile=0, start=True):
+        """Create the device context of `tile` and upload its window of the state; with start=False
+        the caller installs a halo transport on context() and then calls start()."""
+        r = self.lib.roms_host_device_init(device, tile)
         if r != 0:
-            from . import hiplib
-            msg = hiplib.load().roms_hip_last_error()
-            raise hiplib.RomsHipError(f"exit_flag={r}: {msg.decode() if msg else ''}")
+            self._fail("roms_host_device_init", r)
+        b = (C.c_int * 12)()
+        self.lib.roms_host_tile(b)
+        self.tile = dict(zip(["tile", "Istr", "Iend", "Jstr", "Jend", "LBi", "UBi", "LBj", "UBj", "NtileI", "NtileJ"],
+                             list(b)))
+        if start:
+            self.start()
         return self.context()
+
+    def start(self):
+        r = self.lib.roms_host_start()
+        if r != 0:
+            self._fail("roms_host_start", r)
 
     def context(self):
         """The device context as a roms_amd.hiplib.Context view (not owning)."""
         from . import hiplib
-        return hiplib.Context.from_handle(self.lib.roms_host_ctx())
+        return hiplib.Context.from_handle(self.lib.roms_host_ctx(), self.hip_lib_path)
 
     def run(self, nsteps, kernels=False):
         r = self.lib.roms_host_run(nsteps, 1 if kernels else 0)
         if r != 0:
-            raise RuntimeError(f"roms_host_run: exit_flag={r}")
+            self._fail("roms_host_run", r)
 
     def finalize(self):
         self.lib.roms_host_finalize()

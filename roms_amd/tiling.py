@@ -1,0 +1,148 @@
+"""One ROMS tile per GPU/process: partition, halo transport, gathering.
+
+The reference runs one MPI rank per tile (rank = tile = itile + jtile*NtileI, get_bounds.F:972) and
+moves ghost strips with mp_exchange2d/3d/4d.  Here every rank builds the (cheap, host-side) global
+set-up with the Fortran host, uploads only its tile's window to its GPU and installs a halo
+transport on the device context:
+
+  "rccl"  the library's built-in RCCL send/recv on its own HIP stream (multi-GPU runs); the RCCL
+          unique id is created on rank 0 and broadcast through torch.distributed
+  "dist"  a callback that moves the strips with torch.distributed isend/irecv on host tensors --
+          used with the gloo backend and the CPU-emulated kernels by tests/test_tiles.py
+
+Weak scaling: `weak=True` replicates the case's Lm x Mm tile NtileI x NtileJ times, i.e. the global
+grid is (Lm*NtileI) x (Mm*NtileJ); `weak=False` splits the case's own grid.
+"""
+import ctypes as C
+import traceback
+
+import numpy as np
+
+from . import hiplib, hostlib
+
+
+def partition(world):
+    """NtileI x NtileJ for `world` ranks: as square as possible, the longer side along xi
+    (1 -> 1x1, 2 -> 2x1, 4 -> 2x2, 8 -> 4x2)."""
+    nj = int(np.floor(np.sqrt(world)))
+    while world % nj:
+        nj -= 1
+    return world // nj, nj
+
+
+class TiledRun:
+    def __init__(self, cs, rank=0, world=1, device=0, dist=None, transport=None, weak=True,
+                 host_lib=None, hip_lib=None, tiles=None):
+        self.rank, self.world, self.dist = rank, world, dist
+        self.NtileI, self.NtileJ = tiles or partition(world)
+        assert self.NtileI * self.NtileJ == world
+        g = dict(cs)
+        if weak:
+            g["Lm"], g["Mm"] = cs["Lm"] * self.NtileI, cs["Mm"] * self.NtileJ
+        g["NtileI"], g["NtileJ"] = self.NtileI, self.NtileJ
+        self.global_Lm, self.global_Mm = g["Lm"], g["Mm"]
+        self.case = g
+        self.host = hostlib.Host(params=g, lib_path=host_lib, hip_lib_path=hip_lib)
+        self.nfast = self.host.dims["nfast"]
+        self.ctx = self.host.device_init(device, tile=rank, start=False)
+        self._cb = None
+        if world > 1:
+            transport = transport or "rccl"
+            if transport == "rccl":
+                self._install_rccl()
+            elif transport == "dist":
+                self._install_dist()
+            else:
+                raise ValueError(transport)
+        self.host.start()
+
+    # ------------------------------------------------------------------ transports
+    def _install_rccl(self):
+        import torch
+        L = self.ctx.L
+        uid = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            self.ctx._ck(L.roms_hip_rccl_unique_id(uid))
+        t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda" if torch.cuda.is_available() else "cpu")
+        self.dist.broadcast(t, 0)
+        raw = bytes(t.cpu().tolist())
+        self.ctx._ck(L.roms_hip_comm_rccl(self.ctx.h, raw, self.world, self.rank))
+
+    def _install_dist(self):
+        import torch
+        dist = self.dist
+
+        def view(ptr, n):
+            return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,)))
+
+        def cb(user, ns, sp, sb, sc, st, nr, rp, rb, rc, rt):
+            try:
+                reqs = [dist.irecv(view(rb[k], rc[k]), src=rp[k], tag=rt[k]) for k in range(nr)]
+                reqs += [dist.isend(view(sb[k], sc[k]), dst=sp[k], tag=st[k]) for k in range(ns)]
+                for r in reqs:
+                    r.wait()
+                return 0
+            except Exception:       # a Python exception must not unwind through the C frames
+                traceback.print_exc()
+                return 1
+
+        self._cb = hiplib.EXCHANGE_FN(cb)          # keep the trampoline alive
+        self.ctx._ck(self.ctx.L.roms_hip_set_exchange(self.ctx.h, self._cb, None))
+
+    # ------------------------------------------------------------------ running
+    def step(self, n=1, kernels=False):
+        self.host.run(n, kernels=kernels)
+
+    def sync(self):
+        self.ctx.sync()
+
+    def diag(self):
+        """Global diagnostics of diag.F (energies, volume, maximum speed / Courant number)."""
+        d = np.array(self.ctx.diag(raw=True))
+        if self.world > 1:
+            import torch
+            dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+            sums = torch.tensor([d[3], d[12], d[13]], dtype=torch.float64, device=dev)
+            maxs = torch.tensor([d[4], d[11]], dtype=torch.float64, device=dev)
+            self.dist.all_reduce(sums)
+            self.dist.all_reduce(maxs, op=self.dist.ReduceOp.MAX)
+            vol, kes, pes = [float(x) for x in sums.cpu()]
+            spd, C_ = [float(x) for x in maxs.cpu()]
+        else:
+            vol, kes, pes, spd, C_ = d[3], d[12], d[13], d[4], d[11]
+        return {"avgke": kes / vol, "avgpe": pes / vol, "avgkp": (kes + pes) / vol, "volume": vol,
+                "maxspeed": spd, "max_C": C_}
+
+    def check(self):
+        d = self.diag()
+        if not (np.isfinite(d["avgke"]) and np.isfinite(d["avgpe"])) or d["maxspeed"] > 20.0:
+            raise hiplib.RomsHipError(f"blow-up (exit_flag=1): {d}")
+        return d
+
+    def gather(self, name):
+        """The global field `name` (interior + domain boundary points of every tile) on every rank,
+        shaped (planes, nj_global, ni_global) with the reference's index origin (LBj, LBi)."""
+        t = self.host.tile
+        a = self.ctx.download(name)
+        ni, nj = t["UBi"] - t["LBi"] + 1, t["UBj"] - t["LBj"] + 1
+        a = a.reshape(-1, nj, ni)
+        d = self.host.dims
+        G = np.zeros((a.shape[0], d["UBj"] - d["LBj"] + 1, d["UBi"] - d["LBi"] + 1))
+        it, jt = t["tile"] % self.NtileI, t["tile"] // self.NtileI
+        # own range: interior, extended to the array edge on domain edges (boundary + periodic ghosts)
+        i0 = t["LBi"] if it == 0 else t["Istr"]
+        i1 = t["UBi"] if it == self.NtileI - 1 else t["Iend"]
+        j0 = t["LBj"] if jt == 0 else t["Jstr"]
+        j1 = t["UBj"] if jt == self.NtileJ - 1 else t["Jend"]
+        G[:, j0 - d["LBj"]:j1 - d["LBj"] + 1, i0 - d["LBi"]:i1 - d["LBi"] + 1] = \
+            a[:, j0 - t["LBj"]:j1 - t["LBj"] + 1, i0 - t["LBi"]:i1 - t["LBi"] + 1]
+        if self.world > 1:
+            import torch
+            dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+            T = torch.from_numpy(G).to(dev)
+            self.dist.all_reduce(T)
+            G = T.cpu().numpy()
+        return G
+
+    def close(self):
+        self.host.finalize()

@@ -20,5 +20,18 @@ for f in $SRC/*.cpp; do
   objs="$objs $o"
 done
 wait
-g++ -shared -o $OUT $objs
+g++ -shared -Wl,-Bsymbolic -o $OUT $objs
 echo "built $OUT"
+
+# Fortran host driver linked against the emulated library (multi-tile CPU tests)
+FOBJ=$HERE/obj_f
+mkdir -p $FOBJ
+HOSTSRC=$HERE/../../roms_amd/host
+for f in roms_hip_mod roms_host roms_host_api; do
+  if [ ! -f $FOBJ/$f.o ] || [ $HOSTSRC/$f.f90 -nt $FOBJ/$f.o ]; then
+    /opt/rocm/bin/amdflang -O2 -fPIC -ffp-contract=off -module-dir $FOBJ -c $HOSTSRC/$f.f90 -o $FOBJ/$f.o
+  fi
+done
+/opt/rocm/bin/amdflang -shared -o $HERE/libroms_host_emu.so $FOBJ/roms_hip_mod.o $FOBJ/roms_host.o $FOBJ/roms_host_api.o \
+  -L$HERE -lroms_hip_emu -Wl,-rpath,'$ORIGIN'
+echo "built $HERE/libroms_host_emu.so"

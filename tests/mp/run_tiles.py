@@ -1,0 +1,40 @@
+"""Worker of tests/test_tiles.py: one rank of a multi-tile run with the CPU-emulated kernels and the
+torch.distributed (gloo) halo transport.  Started by torch.distributed.run; rank 0 writes the gathered
+fields to the npz file given on the command line."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out, spec = sys.argv[1], json.loads(sys.argv[2])
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from roms_amd import tiling
+    from tests import util
+    cs = util.case_for(spec["tag"], **spec.get("kw", {}))
+    cs["ninfo"] = 0
+    emu = os.path.join(ROOT, "tests", "emu")
+    run = tiling.TiledRun(cs, rank=rank, world=world, dist=dist, transport="dist", weak=False,
+                          tiles=tuple(spec["tiles"]), host_lib=os.path.join(emu, "libroms_host_emu.so"),
+                          hip_lib=os.path.join(emu, "libroms_hip_emu.so"))
+    run.step(spec["steps"], kernels=spec.get("kernels", False))
+    res = {n: run.gather(n) for n in spec["fields"]}
+    d = run.diag()
+    nx = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
+    if rank == 0:
+        np.savez(out, nexchanges=nx, diag=np.array([d["avgke"], d["avgpe"], d["volume"], d["maxspeed"]]), **res)
+    run.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

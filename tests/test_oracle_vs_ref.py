@@ -24,7 +24,8 @@ b = R.bounds(0)
 w = np.stack([R.table(5, 60), R.table(6, 60)])
 O = orc.Oracle(cases.oracle_cfg(cs, R.table(7, 8)[0], b[58], w))
 assert b[:54] == O.bounds(0)
-for n in util.INIT_FIELDS: O.field(n)[:] = R.get(n)
+for n in util.INIT_FIELDS:
+    if R.has(n): O.field(n)[:] = R.get(n)
 for k, n in enumerate(["sc_r", "Cs_r", "sc_w", "Cs_w"]): O.field(n)[:] = R.table(k + 1, O.field(n).size)
 st = O.step
 st.iic = 4; st.iif = 1; st.nstp = 2; st.nnew = 1; st.nrhs = 2; st.kstp = 1; st.knew = 1; st.krhs = 1
