@@ -32,7 +32,8 @@ WORKLOADS = {
     "benchmark1": ("benchmark", 512, 64, 30),
     "benchmark2": ("benchmark", 1024, 128, 30),
     "benchmark3": ("benchmark", 2048, 256, 30),
-    "ns512": ("benchmark", 512, 512, 50),       # north_star roofline size (512x512x50)
+    "ns512": ("upwelling", 512, 512, 50),       # north_star roofline size (512x512x50); UPWELLING keeps
+                                                # 1 km cells at any size (BENCHMARK's shelf steepens with Mm)
     "upwelling": ("upwelling", 41, 80, 16),
 }
 
@@ -181,7 +182,9 @@ def main():
             with open(args.breakdown_file, "w") as f:
                 json.dump({k: {"seconds": v[0], "launches": v[1]} for k, v in table.items()}, f, indent=1)
     if dominant:
-        hiplib.kprof(2, dominant)
+        # sample every 8th launch: two event records per launch would otherwise slow the step down
+        launches_per_step = table[dominant][1] // 2
+        hiplib.kprof(2, dominant, stride=8 if launches_per_step >= 16 else 1)
     barrier_sync()
 
     t0 = time.perf_counter()

@@ -183,6 +183,9 @@ long roms_hip_exchange_count(roms_hip_ctx *ctx);
    asynchronous event pairs resolved when the table is read (usable inside a timed region).
    roms_hip_kprof resets the table; roms_hip_kprof_get enumerates it (returns 8 past the end). */
 int roms_hip_kprof(int mode, const char *kernel);
+/* mode 2 only: time every `every`-th launch of the selected kernel (keeps the event overhead out
+   of a timed region) */
+int roms_hip_kprof_stride(int every);
 int roms_hip_kprof_get(int index, char *name, int name_len, double *seconds, long *calls);
 
 #ifdef __cplusplus

@@ -12,8 +12,9 @@ int run_step2d(roms_hip_ctx *c) {
   a.w1_m1 = (iif >= 2) ? cf.weight[0][iif - 1] : 0.0;
   a.w2_0 = cf.weight[1][iif];
   a.w2_p1 = (iif + 1 <= ROMS_MAXW) ? cf.weight[1][iif + 1] : 0.0;
-  const size_t lds = (size_t)STEP2D_NLDS * (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
-  LAUNCH_COOP(k_step2d, G.nbx, G.nby, 1, 256, lds, c->stream, a);
+  const size_t lds = (size_t)STEP2D_NLDS * (size_t)(G.bw2 + 6) * (size_t)(G.bh2 + 6);
+  LAUNCH_COOP(k_step2d, G.nbx2, G.nby2, 1, 256, lds, c->stream, a);
+  if (G.fuse_halo) return 0;   // the kernel filled the boundary and periodic ghost points itself
   if (iif == G.nfast + 1 && G.predictor) {
     // final fast-time averages :821-883
     HaloSpec sp[3] = {{c->F.Zt_avg1, 1, BC_NONE, 'r'}, {c->F.DU_avg1, 1, BC_NONE, 'u'}, {c->F.DV_avg1, 1, BC_NONE, 'v'}};

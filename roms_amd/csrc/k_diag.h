@@ -3,9 +3,11 @@
 //
 // The reference sums column values first along eta (j) for every xi (i), then along xi, to limit
 // round-off (:289-325).  The same order is kept so that the result is reproducible bit-for-bit:
-//   k_diag_col  one thread per column (k = N..1 as in the reference)
-//   k_diag_row  one thread per i: ordered sum over j, ordered max
-//   k_diag_fin  one thread: ordered sum over i
+//   k_diag_col  one thread per column (k = N..1 as in the reference); writes the products
+//               omn*ke, omn*pe, omn*dz the row sums need
+//   k_diag_row  one block per 64 values of i: chunks of rows are staged in LDS by all threads,
+//               then one thread per i adds them in j order; the maxima (order-free) use all threads
+//   k_diag_fin  one block: row sums staged in LDS, one thread adds them in i order
 #pragma once
 #include "roms_ctx.h"
 #include "k_diag3d.h"
@@ -43,8 +45,10 @@ THREAD_KERNEL(k_diag_col, DiagArgs) {
     if (s > spd) spd = s;
   }
   double *col = a.col;
-  col[X2(i, j)] = ke;
-  col[X2(i, j) + G.nij] = pe;
+  const double omn = F.omn[X2(i, j)];
+  col[X2(i, j)] = omn * ke;
+  col[X2(i, j) + G.nij] = omn * pe;
+  col[X2(i, j) + 8 * G.nij] = omn * (F.z_w[XW(i, j, N)] - F.z_w[XW(i, j, 0)]);
   col[X2(i, j) + 2 * G.nij] = maxC;
   col[X2(i, j) + 3 * G.nij] = mCu;
   col[X2(i, j) + 4 * G.nij] = mCv;
@@ -62,64 +66,179 @@ KDEV bool diag_better(double C, int j, int k, int i, double C0, int j0, int k0, 
   return i < i0;
 }
 
-// one thread per i of Istr:Iend (index space nx = Iend-Istr+1)
-THREAD_KERNEL(k_diag_row, DiagArgs) {
-  (void)gy; (void)gz;
+// ---- row stage: block bx owns i = Istr + 64*bx .. +63 -------------------------------------
+#define DIAG_IW 64
+#define DIAG_JC 16
+struct DiagBest { double C; int j, k; };
+COOP_KERNEL(k_diag_row, DiagArgs) {
+  (void)by; (void)bz;
   const DGrid &G = a.G;
-  const Fields &F = a.F;
-  const int i = G.T.Istr + gx, N = G.N;
+  const TB &T = G.T;
   const double *col = a.col;
-  double vol = 0.0, pes = 0.0, kes = 0.0, spd = 0.0;
-  double bC = 0.0, bCu = 0.0, bCv = 0.0, bCw = 0.0;
-  int bj = 0, bk = 0;
-  for (int j = G.T.Jstr; j <= G.T.Jend; j++) {
-    const double omn = F.omn[X2(i, j)];
-    vol = vol + omn * (F.z_w[XW(i, j, N)] - F.z_w[XW(i, j, 0)]);
-    pes = pes + omn * col[X2(i, j) + G.nij];
-    kes = kes + omn * col[X2(i, j)];
-    const double C = col[X2(i, j) + 2 * G.nij];
-    const int k = (int)col[X2(i, j) + 6 * G.nij];
-    if (C > 0.0 && (bC == 0.0 || diag_better(C, j, k, i, bC, bj, bk, i))) {
-      bC = C; bCu = col[X2(i, j) + 3 * G.nij]; bCv = col[X2(i, j) + 4 * G.nij]; bCw = col[X2(i, j) + 5 * G.nij];
-      bj = j; bk = k;
+  const int i0 = T.Istr + DIAG_IW * bx;
+  const int nw = KMIN(DIAG_IW, T.Iend - i0 + 1);
+  double *sK = lds, *sP = lds + DIAG_IW * DIAG_JC, *sV = lds + 2 * DIAG_IW * DIAG_JC;
+  double vol = 0.0, pes = 0.0, kes = 0.0;
+  for (int j0 = T.Jstr; j0 <= T.Jend; j0 += DIAG_JC) {
+    const int nj = KMIN(DIAG_JC, T.Jend - j0 + 1);
+    KSYNC();
+    KLOOP2(di, dj, 0, nw - 1, 0, nj - 1) {
+      const size_t q = X2(i0 + di, j0 + dj);
+      sK[dj * DIAG_IW + di] = col[q];
+      sP[dj * DIAG_IW + di] = col[q + G.nij];
+      sV[dj * DIAG_IW + di] = col[q + 8 * G.nij];
     }
-    const double s = col[X2(i, j) + 7 * G.nij];
-    if (s > spd) spd = s;
+    KSYNC();
+    // ordered accumulation: thread di adds rows j0..j0+nj-1 of column i0+di
+#ifdef ROMS_CPU_EMU
+    // serial emulation: the accumulators of all 64 columns live in LDS
+    double *acc = lds + 3 * DIAG_IW * DIAG_JC;
+    if (j0 == T.Jstr) for (int di = 0; di < 3 * DIAG_IW; di++) acc[di] = 0.0;
+    for (int di = 0; di < nw; di++)
+      for (int dj = 0; dj < nj; dj++) {
+        acc[di] = acc[di] + sV[dj * DIAG_IW + di];
+        acc[DIAG_IW + di] = acc[DIAG_IW + di] + sP[dj * DIAG_IW + di];
+        acc[2 * DIAG_IW + di] = acc[2 * DIAG_IW + di] + sK[dj * DIAG_IW + di];
+      }
+#else
+    if (KTID < nw)
+      for (int dj = 0; dj < nj; dj++) {
+        vol = vol + sV[dj * DIAG_IW + KTID];
+        pes = pes + sP[dj * DIAG_IW + KTID];
+        kes = kes + sK[dj * DIAG_IW + KTID];
+      }
+#endif
   }
   double *row = a.row;
-  const int ni = G.ni, ii = i - G.LBi;
-  row[ii] = vol; row[ii + ni] = pes; row[ii + 2 * ni] = kes; row[ii + 3 * ni] = spd;
-  row[ii + 4 * ni] = bC; row[ii + 5 * ni] = bCu; row[ii + 6 * ni] = bCv; row[ii + 7 * ni] = bCw;
-  row[ii + 8 * ni] = (double)bj; row[ii + 9 * ni] = (double)bk;
+  const int ni = G.ni;
+#ifdef ROMS_CPU_EMU
+  {
+    const double *acc = lds + 3 * DIAG_IW * DIAG_JC;
+    for (int di = 0; di < nw; di++) {
+      const int ii = i0 + di - G.LBi;
+      row[ii] = acc[di]; row[ii + ni] = acc[DIAG_IW + di]; row[ii + 2 * ni] = acc[2 * DIAG_IW + di];
+    }
+  }
+#else
+  if (KTID < nw) {
+    const int ii = i0 + KTID - G.LBi;
+    row[ii] = vol; row[ii + ni] = pes; row[ii + 2 * ni] = kes;
+  }
+#endif
+  // maxima: every thread scans a strided subset of rows of one column, then the partial results of
+  // a column are merged (the ordering relation diag_better is total, so the merge order is free)
+  KSYNC();
+  const int nsub = KMAX(1, KNT / DIAG_IW);
+  double *mC = lds;                               // [nsub][64] C, spd ; ints packed as doubles
+  double *mS = lds + 4 * DIAG_IW, *mJ = lds + 8 * DIAG_IW, *mK = lds + 12 * DIAG_IW;
+  for (int t = KTID; t < nsub * DIAG_IW; t += KNT) {
+    const int di = t % DIAG_IW, sub = t / DIAG_IW;
+    double bC = 0.0, spd = 0.0;
+    int bj = 0, bk = 0;
+    if (di < nw) {
+      const int i = i0 + di;
+      for (int j = T.Jstr + sub; j <= T.Jend; j += nsub) {
+        const double C = col[X2(i, j) + 2 * G.nij];
+        const int k = (int)col[X2(i, j) + 6 * G.nij];
+        if (C > 0.0 && (bC == 0.0 || diag_better(C, j, k, i, bC, bj, bk, i))) { bC = C; bj = j; bk = k; }
+        const double s = col[X2(i, j) + 7 * G.nij];
+        if (s > spd) spd = s;
+      }
+    }
+    mC[sub * DIAG_IW + di] = bC; mS[sub * DIAG_IW + di] = spd;
+    mJ[sub * DIAG_IW + di] = (double)bj; mK[sub * DIAG_IW + di] = (double)bk;
+  }
+  KSYNC();
+  for (int di = KTID; di < nw; di += KNT) {
+    const int i = i0 + di;
+    double bC = 0.0, spd = 0.0;
+    int bj = 0, bk = 0;
+    for (int sub = 0; sub < nsub; sub++) {
+      const double C = mC[sub * DIAG_IW + di];
+      const int j = (int)mJ[sub * DIAG_IW + di], k = (int)mK[sub * DIAG_IW + di];
+      if (C > 0.0 && (bC == 0.0 || diag_better(C, j, k, i, bC, bj, bk, i))) { bC = C; bj = j; bk = k; }
+      if (mS[sub * DIAG_IW + di] > spd) spd = mS[sub * DIAG_IW + di];
+    }
+    const int ii = i - G.LBi;
+    row[ii + 3 * ni] = spd;
+    row[ii + 4 * ni] = bC;
+    if (bC > 0.0) {
+      row[ii + 5 * ni] = col[X2(i, bj) + 3 * G.nij]; row[ii + 6 * ni] = col[X2(i, bj) + 4 * G.nij];
+      row[ii + 7 * ni] = col[X2(i, bj) + 5 * G.nij];
+    } else {
+      row[ii + 5 * ni] = 0.0; row[ii + 6 * ni] = 0.0; row[ii + 7 * ni] = 0.0;
+    }
+    row[ii + 8 * ni] = (double)bj; row[ii + 9 * ni] = (double)bk;
+  }
 }
-THREAD_GLOBAL(k_diag_row, DiagArgs)
+COOP_GLOBAL(k_diag_row, DiagArgs)
+#define DIAG_ROW_LDS (3 * DIAG_IW * DIAG_JC + 16 * DIAG_IW)
 
-THREAD_KERNEL(k_diag_fin, DiagArgs) {
-  (void)gx; (void)gy; (void)gz;
+// ---- final stage: one block ----------------------------------------------------------------
+#define DIAG_FC 1024
+COOP_KERNEL(k_diag_fin, DiagArgs) {
+  (void)bx; (void)by; (void)bz;
   const DGrid &G = a.G;
   const double *row = a.row;
   const int ni = G.ni;
   double vol = 0.0, pes = 0.0, kes = 0.0, spd = -1.0E+20;
   double bC = 0.0, bCu = 0.0, bCv = 0.0, bCw = 0.0;
   int bi = 0, bj = 0, bk = 0;
-  for (int i = G.T.Istr; i <= G.T.Iend; i++) {
-    const int ii = i - G.LBi;
-    vol = vol + row[ii];
-    pes = pes + row[ii + ni];
-    kes = kes + row[ii + 2 * ni];
-    if (row[ii + 3 * ni] > spd) spd = row[ii + 3 * ni];
-    const double C = row[ii + 4 * ni];
-    const int j = (int)row[ii + 8 * ni], k = (int)row[ii + 9 * ni];
-    if (C > 0.0 && (bC == 0.0 || diag_better(C, j, k, i, bC, bj, bk, bi))) {
-      bC = C; bCu = row[ii + 5 * ni]; bCv = row[ii + 6 * ni]; bCw = row[ii + 7 * ni];
-      bi = i; bj = j; bk = k;
+  double *sV = lds, *sP = lds + DIAG_FC, *sK = lds + 2 * DIAG_FC;
+  for (int c0 = G.T.Istr; c0 <= G.T.Iend; c0 += DIAG_FC) {
+    const int nc = KMIN(DIAG_FC, G.T.Iend - c0 + 1);
+    KSYNC();
+    KLOOP1(d, 0, nc - 1) {
+      const int ii = c0 + d - G.LBi;
+      sV[d] = row[ii]; sP[d] = row[ii + ni]; sK[d] = row[ii + 2 * ni];
     }
+    KSYNC();
+    if (KTID == 0)
+      for (int d = 0; d < nc; d++) {
+        vol = vol + sV[d];
+        pes = pes + sP[d];
+        kes = kes + sK[d];
+      }
   }
-  double *out = a.out;
-  const double avgke = kes / vol, avgpe = pes / vol;
-  out[0] = avgke; out[1] = avgpe; out[2] = avgke + avgpe; out[3] = vol; out[4] = spd;
-  out[5] = bCu; out[6] = bCv; out[7] = bCw; out[8] = (double)bi; out[9] = (double)bj; out[10] = (double)bk;
-  out[11] = bC;
-  out[12] = kes; out[13] = pes;   // un-normalised sums: combined over tiles by the caller
+  // maxima (order-free): every thread scans a strided subset, thread 0 merges the partial results
+  KSYNC();
+  double *mC = lds, *mS = lds + 256, *mI = lds + 512;
+  {
+    double pC = 0.0, pS = -1.0E+20;
+    int pi = 0, pj = 0, pk = 0;
+    KLOOP1(i, G.T.Istr, G.T.Iend) {
+      const int ii = i - G.LBi;
+      if (row[ii + 3 * ni] > pS) pS = row[ii + 3 * ni];
+      const double C = row[ii + 4 * ni];
+      const int j = (int)row[ii + 8 * ni], k = (int)row[ii + 9 * ni];
+      if (C > 0.0 && (pC == 0.0 || diag_better(C, j, k, i, pC, pj, pk, pi))) { pC = C; pi = i; pj = j; pk = k; }
+    }
+    if (KTID < 256) { mC[KTID] = pC; mS[KTID] = pS; mI[KTID] = (double)pi; }
+  }
+  KSYNC();
+  if (KTID == 0) {
+    const int np = KMIN(KNT, 256);
+    for (int t = 0; t < np; t++) {
+      if (mS[t] > spd) spd = mS[t];
+      const double C = mC[t];
+      const int i = (int)mI[t];
+      if (C > 0.0) {
+        const int ii = i - G.LBi;
+        const int j = (int)row[ii + 8 * ni], k = (int)row[ii + 9 * ni];
+        if (bC == 0.0 || diag_better(C, j, k, i, bC, bj, bk, bi)) { bC = C; bi = i; bj = j; bk = k; }
+      }
+    }
+    if (bC > 0.0) {
+      const int ii = bi - G.LBi;
+      bCu = row[ii + 5 * ni]; bCv = row[ii + 6 * ni]; bCw = row[ii + 7 * ni];
+    }
+    double *out = a.out;
+    const double avgke = kes / vol, avgpe = pes / vol;
+    out[0] = avgke; out[1] = avgpe; out[2] = avgke + avgpe; out[3] = vol; out[4] = spd;
+    out[5] = bCu; out[6] = bCv; out[7] = bCw; out[8] = (double)bi; out[9] = (double)bj; out[10] = (double)bk;
+    out[11] = bC;
+    out[12] = kes; out[13] = pes;   // un-normalised sums: combined over tiles by the caller
+  }
 }
-THREAD_GLOBAL(k_diag_fin, DiagArgs)
+COOP_GLOBAL(k_diag_fin, DiagArgs)
+#define DIAG_FIN_LDS (3 * DIAG_FC)

@@ -30,11 +30,23 @@ COOP_KERNEL(halo_kernel, HaloArgs) {
   (void)bx; (void)by; (void)lds;
   const DGrid &G = a.G;
   const TB &B = G.T;
-  int item = 0, plane = bz;
-  while (item < a.nitems - 1 && plane >= a.it[item].nk) { plane -= a.it[item].nk; item++; }
-  double *A = a.it[item].A + (size_t)plane * (size_t)G.nij;
-  const int bc = a.it[item].bc;
-  const int gtype = a.it[item].gtype;
+  // select this block's item without indexing the kernel-argument array dynamically (a dynamic
+  // index makes the compiler copy the whole argument struct to scratch memory)
+  double *A = nullptr;
+  int bc = BC_NONE, gtype = 0;
+  {
+    int first = 0;
+#pragma unroll
+    for (int k = 0; k < HALO_MAXITEMS; k++) {
+      const int nk = k < a.nitems ? a.it[k].nk : 0;
+      if (bz >= first && bz < first + nk) {
+        A = a.it[k].A + (size_t)(bz - first) * (size_t)G.nij;
+        bc = a.it[k].bc;
+        gtype = a.it[k].gtype;
+      }
+      first += nk;
+    }
+  }
   const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
   const int Lm = G.Lm, Mm = G.Mm;
   const double gamma2 = G.gamma2;
@@ -160,9 +172,16 @@ COOP_KERNEL(strip_kernel, StripArgs) {
   (void)bx; (void)by; (void)lds;
   const DGrid &G = a.G;
   const TB &B = G.T;
-  int item = 0, plane = bz;
-  while (item < a.nitems - 1 && plane >= a.it[item].nk) { plane -= a.it[item].nk; item++; }
-  double *A = a.it[item].A + (size_t)plane * (size_t)G.nij;
+  double *A = nullptr;
+  {
+    int first = 0;
+#pragma unroll
+    for (int k = 0; k < HALO_MAXITEMS; k++) {
+      const int nk = k < a.nitems ? a.it[k].nk : 0;
+      if (bz >= first && bz < first + nk) A = a.it[k].A + (size_t)(bz - first) * (size_t)G.nij;
+      first += nk;
+    }
+  }
   const int ng = G.Nghost;
   if (a.phase == 0) {
     const int nl = G.nj;                       // lines = all local rows

@@ -428,21 +428,19 @@ THREAD_KERNEL(k_t3dmix2_s, KArgs) {
 THREAD_GLOBAL(k_t3dmix2_s, KArgs)
 
 // ------------------------------------------------------------------------------ uv3dmix2_s
-// One thread per column (the rufrc/rvfrc sums run over k in order); index space
-// (min(IstrU,Istr):Iend, min(Jstr,JstrV):Jend).  Stress-tensor components at rho (R) and psi (P)
-// points are evaluated in-line.
+// k_uv3dmix2_s: one thread per (i,j,k) of (Istr:Iend, Jstr:Jend, 1:N); the stress-tensor components
+// at rho (R) and psi (P) points are evaluated in-line.  The two terms each momentum point adds to
+// rufrc/rvfrc are kept in work arrays and summed over k, in order, by k_uv3dmix2_sum (the reference
+// accumulates rufrc inside its k loop, uv3dmix2_s.h:226-262).
 THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
-  (void)gz;
   const DGrid &G = a.G;
   const Fields &F = a.F;
   const TB &B = G.T;
-  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs, nnew = G.nnew;
+  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, N = G.N, nrhs = G.nrhs, nnew = G.nnew;
   const double *pm = F.pm, *pn = F.pn, *Hz = F.Hz;
   const double *u = F.u + (size_t)(nrhs - 1) * G.nij * N, *v = F.v + (size_t)(nrhs - 1) * G.nij * N;
   const bool do_u = i >= B.IstrU, do_v = j >= B.JstrV;
-  double ruf = do_u ? F.rufrc[X2(i, j)] : 0.0, rvf = do_v ? F.rvfrc[X2(i, j)] : 0.0;
-  for (int k = 1; k <= N; k++) {
-    // cff at rho point (ii,jj) and at psi point (ii,jj)
+  // cff at rho point (ii,jj) and at psi point (ii,jj)
 #define CFFR(ii, jj)                                                                                                   \
   (Hz[X3(ii, jj, k)] * 0.5 *                                                                                           \
    (F.pmon_r[X2(ii, jj)] * ((pn[X2(ii, jj)] + pn[X2((ii) + 1, jj)]) * u[X3((ii) + 1, jj, k)] -                          \
@@ -455,37 +453,59 @@ THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
                             (pn[X2((ii) - 1, (jj) - 1)] + pn[X2((ii) - 1, jj)]) * v[X3((ii) - 1, jj, k)]) +             \
     F.pnom_p[X2(ii, jj)] * ((pm[X2((ii) - 1, jj)] + pm[X2(ii, jj)]) * u[X3(ii, jj, k)] -                                \
                             (pm[X2((ii) - 1, (jj) - 1)] + pm[X2(ii, (jj) - 1)]) * u[X3(ii, (jj) - 1, k)])))
-#define UFXr(ii, jj) (F.on_r[X2(ii, jj)] * F.on_r[X2(ii, jj)] * F.visc2_r[X2(ii, jj)] * CFFR(ii, jj))
-#define VFEr(ii, jj) (F.om_r[X2(ii, jj)] * F.om_r[X2(ii, jj)] * F.visc2_r[X2(ii, jj)] * CFFR(ii, jj))
-#define UFEp(ii, jj) (F.om_p[X2(ii, jj)] * F.om_p[X2(ii, jj)] * F.visc2_p[X2(ii, jj)] * CFFP(ii, jj))
-#define VFXp(ii, jj) (F.on_p[X2(ii, jj)] * F.on_p[X2(ii, jj)] * F.visc2_p[X2(ii, jj)] * CFFP(ii, jj))
-    if (do_u) {
-      const double cff = G.dt * 0.25 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (pn[X2(i - 1, j)] + pn[X2(i, j)]);
-      const double cff1 = 0.5 * (pn[X2(i - 1, j)] + pn[X2(i, j)]) * (UFXr(i, j) - UFXr(i - 1, j));
-      const double cff2 = 0.5 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (UFEp(i, j + 1) - UFEp(i, j));
-      const double cff3 = cff * (cff1 + cff2);
-      ruf = ruf + cff1 + cff2;
-      F.u[X4(i, j, k, nnew)] = F.u[X4(i, j, k, nnew)] + cff3;
-    }
-    if (do_v) {
-      const double cff = G.dt * 0.25 * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]);
-      const double cff1 = 0.5 * (pn[X2(i, j - 1)] + pn[X2(i, j)]) * (VFXp(i + 1, j) - VFXp(i, j));
-      const double cff2 = 0.5 * (pm[X2(i, j - 1)] + pm[X2(i, j)]) * (VFEr(i, j) - VFEr(i, j - 1));
-      const double cff3 = cff * (cff1 - cff2);
-      rvf = rvf + cff1 - cff2;
-      F.v[X4(i, j, k, nnew)] = F.v[X4(i, j, k, nnew)] + cff3;
-    }
+  const double cR = CFFR(i, j), cP = CFFP(i, j);
+  if (do_u) {
+    const double cRw = CFFR(i - 1, j), cPn = CFFP(i, j + 1);
+    const double UFx1 = F.on_r[X2(i, j)] * F.on_r[X2(i, j)] * F.visc2_r[X2(i, j)] * cR;
+    const double UFx0 = F.on_r[X2(i - 1, j)] * F.on_r[X2(i - 1, j)] * F.visc2_r[X2(i - 1, j)] * cRw;
+    const double UFe1 = F.om_p[X2(i, j + 1)] * F.om_p[X2(i, j + 1)] * F.visc2_p[X2(i, j + 1)] * cPn;
+    const double UFe0 = F.om_p[X2(i, j)] * F.om_p[X2(i, j)] * F.visc2_p[X2(i, j)] * cP;
+    const double cff = G.dt * 0.25 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (pn[X2(i - 1, j)] + pn[X2(i, j)]);
+    const double cff1 = 0.5 * (pn[X2(i - 1, j)] + pn[X2(i, j)]) * (UFx1 - UFx0);
+    const double cff2 = 0.5 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (UFe1 - UFe0);
+    const double cff3 = cff * (cff1 + cff2);
+    F.wrk3[1][X3(i, j, k)] = cff1;
+    F.wrk3[2][X3(i, j, k)] = cff2;
+    F.u[X4(i, j, k, nnew)] = F.u[X4(i, j, k, nnew)] + cff3;
+  }
+  if (do_v) {
+    const double cRs = CFFR(i, j - 1), cPe = CFFP(i + 1, j);
+    const double VFx1 = F.on_p[X2(i + 1, j)] * F.on_p[X2(i + 1, j)] * F.visc2_p[X2(i + 1, j)] * cPe;
+    const double VFx0 = F.on_p[X2(i, j)] * F.on_p[X2(i, j)] * F.visc2_p[X2(i, j)] * cP;
+    const double VFe1 = F.om_r[X2(i, j)] * F.om_r[X2(i, j)] * F.visc2_r[X2(i, j)] * cR;
+    const double VFe0 = F.om_r[X2(i, j - 1)] * F.om_r[X2(i, j - 1)] * F.visc2_r[X2(i, j - 1)] * cRs;
+    const double cff = G.dt * 0.25 * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]);
+    const double cff1 = 0.5 * (pn[X2(i, j - 1)] + pn[X2(i, j)]) * (VFx1 - VFx0);
+    const double cff2 = 0.5 * (pm[X2(i, j - 1)] + pm[X2(i, j)]) * (VFe1 - VFe0);
+    const double cff3 = cff * (cff1 - cff2);
+    F.wrk3[3][X3(i, j, k)] = cff1;
+    F.wrk3[4][X3(i, j, k)] = cff2;
+    F.v[X4(i, j, k, nnew)] = F.v[X4(i, j, k, nnew)] + cff3;
+  }
 #undef CFFR
 #undef CFFP
-#undef UFXr
-#undef VFEr
-#undef UFEp
-#undef VFXp
-  }
-  if (do_u) F.rufrc[X2(i, j)] = ruf;
-  if (do_v) F.rvfrc[X2(i, j)] = rvf;
 }
 THREAD_GLOBAL(k_uv3dmix2_s, KArgs)
+
+// rufrc/rvfrc: ordered sum over k of the terms stored by k_uv3dmix2_s; one thread per column
+THREAD_KERNEL(k_uv3dmix2_sum, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.F;
+  const TB &B = G.T;
+  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N;
+  if (i >= B.IstrU) {
+    double ruf = F.rufrc[X2(i, j)];
+    for (int k = 1; k <= N; k++) ruf = ruf + F.wrk3[1][X3(i, j, k)] + F.wrk3[2][X3(i, j, k)];
+    F.rufrc[X2(i, j)] = ruf;
+  }
+  if (j >= B.JstrV) {
+    double rvf = F.rvfrc[X2(i, j)];
+    for (int k = 1; k <= N; k++) rvf = rvf + F.wrk3[3][X3(i, j, k)] - F.wrk3[4][X3(i, j, k)];
+    F.rvfrc[X2(i, j)] = rvf;
+  }
+}
+THREAD_GLOBAL(k_uv3dmix2_sum, KArgs)
 
 // -------------------------------------------------------------------------------- rhs3d_tile
 // K_LOOP: Coriolis, curvilinear terms, third-order upstream horizontal advection of momentum.

@@ -12,6 +12,7 @@
 // halo_multi (k_halo.h).
 #pragma once
 #include "roms_ctx.h"
+#include "k_haloblock.h"
 
 struct Step2dArgs {
   DGrid G;
@@ -26,8 +27,8 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   (void)bz;
   const DGrid &G = a.G;
   const Fields &F = a.F;
-  const TB B = block_bounds(G, bx, by);
-  const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
+  const TB B = block_bounds2(G, bx, by);
+  const size_t sz = (size_t)(G.bw2 + 6) * (size_t)(G.bh2 + 6);
   double *Drhs = lds, *DUon = lds + sz, *DVom = lds + 2 * sz, *Dnew = lds + 3 * sz, *rhs_ubar = lds + 4 * sz,
          *rhs_vbar = lds + 5 * sz;
   double *zwrk = lds + 6 * sz, *gzeta = lds + 7 * sz, *gzeta2 = lds + 8 * sz, *gzetaSA = lds + 9 * sz;
@@ -101,7 +102,17 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
       if (i >= IstrR && j >= Jstr) F.DV_avg2[X2(i, j)] = F.DV_avg2[X2(i, j)] + cff2 * DVom[S2(i, j)];
     }
   }
-  if (iif > G.nfast) return;   // auxiliary last predictor call :883 (uniform over the grid)
+  if (iif > G.nfast) {         // auxiliary last predictor call :883 (uniform over the grid)
+    if (G.fuse_halo && PRED) { // final fast-time averages: exchange :821-883
+      HaloBlockItems H;
+      H.n = 3;
+      H.A[0] = F.Zt_avg1; H.bc[0] = BC_NONE; H.gt[0] = 'r';
+      H.A[1] = F.DU_avg1; H.bc[1] = BC_NONE; H.gt[1] = 'u';
+      H.A[2] = F.DV_avg1; H.bc[2] = BC_NONE; H.gt[2] = 'v';
+      halo_block(G, B, H);
+    }
+    return;
+  }
 
   // free-surface step :886-1000
   {
@@ -389,6 +400,17 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
         if (PRED) rvb_k[X2(i, j)] = r;
       }
     }
+  }
+  // zetabc :1057 + exchange :1068, rzeta exchange :1030, u2dbc/v2dbc :2871-2876 + exchange :3043
+  if (G.fuse_halo) {
+    HaloBlockItems H;
+    int n = 0;
+    H.A[n] = zn; H.bc[n] = BC_R; H.gt[n] = 'r'; n++;
+    if (PRED) { H.A[n] = F.rzeta + (size_t)(krhs - 1) * G.nij; H.bc[n] = BC_NONE; H.gt[n] = 'r'; n++; }
+    H.A[n] = un; H.bc[n] = BC_U; H.gt[n] = 'u'; n++;
+    H.A[n] = vn; H.bc[n] = BC_V; H.gt[n] = 'v'; n++;
+    H.n = n;
+    halo_block(G, B, H);
   }
 }
 COOP_GLOBAL(k_step2d, Step2dArgs)

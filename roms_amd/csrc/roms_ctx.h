@@ -32,8 +32,11 @@ struct DGrid {
   int ewp, nsp, options;
   int hadv[ROMS_MAXT], vadv[ROMS_MAXT];
   TB T;                       // bounds of this GPU's tile
-  int nbx, nby;               // thread-block decomposition of the tile for COOP kernels
+  int nbx, nby;               // thread-block decomposition of the tile for the 3-D COOP kernels
   int bw, bh;                 // max sub-tile extent (LDS scratch is (bw+6) x (bh+6))
+  int fuse_halo;              // 1: single tile, COOP kernels fill boundary/periodic ghost points themselves
+  int nbx2, nby2, bw2, bh2;   // the same for the 2-D (barotropic) kernel: smaller sub-tiles, the
+                              // 2-D grid alone cannot fill 256 CUs otherwise
   // stepping (mod_stepping)
   int iic, iif, nstp, nnew, nrhs, kstp, knew, krhs, predictor;
   int ntfirst, nfast;
@@ -104,19 +107,24 @@ KHD TB make_bounds(int Lm, int Mm, int ewp, int nsp, int i0, int i1, int j0, int
 // Consecutive blockIdx.x values land on different XCDs (block b -> XCD b%8); the i-fastest
 // linear order keeps eta-neighbouring sub-tiles of one XCD's L2 8 blocks apart, which is
 // irrelevant for correctness.
-KHD TB block_bounds(const DGrid &G, int bx, int by) {
+KHD TB block_bounds_n(const DGrid &G, int nbx, int nby, int bx, int by) {
   const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
-  const int cI = (LmT + G.nbx - 1) / G.nbx, cJ = (MmT + G.nby - 1) / G.nby;
-  const int mI = (G.nbx * cI - LmT) / 2, mJ = (G.nby * cJ - MmT) / 2;
+  const int cI = (LmT + nbx - 1) / nbx, cJ = (MmT + nby - 1) / nby;
+  const int mI = (nbx * cI - LmT) / 2, mJ = (nby * cJ - MmT) / 2;
   int i0 = 1 + bx * cI - mI, i1 = i0 + cI - 1;
   int j0 = 1 + by * cJ - mJ, j1 = j0 + cJ - 1;
   i0 = KMAX(i0, 1); i1 = KMIN(i1, LmT);
   j0 = KMAX(j0, 1); j1 = KMIN(j1, MmT);
   i0 += G.T.Istr - 1; i1 += G.T.Istr - 1;
   j0 += G.T.Jstr - 1; j1 += G.T.Jstr - 1;
-  return make_bounds(G.Lm, G.Mm, G.ewp, G.nsp, i0, i1, j0, j1, G.T.west && bx == 0, G.T.east && bx == G.nbx - 1,
-                     G.T.south && by == 0, G.T.north && by == G.nby - 1);
+  return make_bounds(G.Lm, G.Mm, G.ewp, G.nsp, i0, i1, j0, j1, G.T.west && bx == 0, G.T.east && bx == nbx - 1,
+                     G.T.south && by == 0, G.T.north && by == nby - 1);
 }
+KHD TB block_bounds(const DGrid &G, int bx, int by) { return block_bounds_n(G, G.nbx, G.nby, bx, by); }
+KHD TB block_bounds2(const DGrid &G, int bx, int by) { return block_bounds_n(G, G.nbx2, G.nby2, bx, by); }
+
+// boundary-fill kinds of the halo code (k_halo.h, k_haloblock.h)
+enum { BC_NONE = 0, BC_R = 1, BC_U = 2, BC_V = 3 };
 
 // ------------------------------------------------------------------ indexing (reference layout)
 #define X2(i, j) ((size_t)((i) - G.LBi) + (size_t)((j) - G.LBj) * (size_t)G.ni)

@@ -5,6 +5,7 @@
 #include "roms_host.h"
 #include "k_halo.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -100,17 +101,41 @@ const FieldDesc *find_field(const char *name) {
 }
 
 // -------------------------------------------------------------------------------- life cycle
+static void split_tile(int LmT, int MmT, int bw, int bh, int &nbx, int &nby, int &w, int &h) {
+  nbx = (LmT + bw - 1) / bw;
+  nby = (MmT + bh - 1) / bh;
+  if (nbx < 1) nbx = 1;
+  if (nby < 1) nby = 1;
+  w = (LmT + nbx - 1) / nbx;
+  h = (MmT + nby - 1) / nby;
+}
+static bool env_tile(const char *name, int &bw, int &bh) {
+  const char *e = getenv(name);
+  int a = 0, b = 0;
+  if (e && sscanf(e, "%dx%d", &a, &b) == 2 && a >= 4 && b >= 2 && (a + 6) * (b + 6) <= 672) { bw = a; bh = b; return true; }
+  return false;
+}
 static void choose_blocks(DGrid &G) {
-  // Sub-tile size of the COOP kernels.  LDS scratch per array is (bw+6)*(bh+6) doubles.  Small
-  // grids get smaller sub-tiles so that a launch still spreads over many of the 256 CUs.
+  // Sub-tile size of the COOP kernels; LDS scratch per array is (bw+6)*(bh+6) doubles (at most 12
+  // arrays, 64 KB).  The 3-D kernels launch sub-tiles x N blocks and keep 32x8 sub-tiles (lanes
+  // along xi).  The 2-D barotropic kernel is a chain of ~25 barrier-separated phases whose cost is
+  // latency, not bandwidth: on small grids it gets small sub-tiles so that every CU holds several
+  // blocks whose phases overlap.  ROMS_HIP_TILE3D / ROMS_HIP_TILE2D ("WxH") override for tuning.
   const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
   int bw = 32, bh = 8;
-  G.nbx = (LmT + bw - 1) / bw;
-  G.nby = (MmT + bh - 1) / bh;
-  if (G.nbx < 1) G.nbx = 1;
-  if (G.nby < 1) G.nby = 1;
-  G.bw = (LmT + G.nbx - 1) / G.nbx;
-  G.bh = (MmT + G.nby - 1) / G.nby;
+  env_tile("ROMS_HIP_TILE3D", bw, bh);
+  split_tile(LmT, MmT, bw, bh, G.nbx, G.nby, G.bw, G.bh);
+  int bw2 = 32, bh2 = 8;
+  if ((long)LmT * MmT <= 256L * 1024L) { bw2 = 16; bh2 = 8; }
+  if ((long)LmT * MmT <= 64L * 1024L) { bw2 = 16; bh2 = 4; }
+  env_tile("ROMS_HIP_TILE2D", bw2, bh2);
+  split_tile(LmT, MmT, bw2, bh2, G.nbx2, G.nby2, G.bw2, G.bh2);
+}
+// narrowest first/last sub-tile of a tile_bounds_2d partition of n points into nb pieces
+static int edge_subtile(int n, int nb) {
+  const int c = (n + nb - 1) / nb, m = (nb * c - n) / 2;
+  const int first = KMIN(c - m, n), last = n - KMAX(1 + (nb - 1) * c - m, 1) + 1;
+  return KMIN(first, last);
 }
 
 static void comm_destroy(roms_hip_ctx *c);
@@ -153,6 +178,13 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   G.T = make_bounds(cfg->Lm, cfg->Mm, cfg->EWperiodic, cfg->NSperiodic, cfg->Istr, cfg->Iend, cfg->Jstr, cfg->Jend,
                     cfg->west_edge, cfg->east_edge, cfg->south_edge, cfg->north_edge);
   choose_blocks(G);
+  {  // producer-side halo fills need the whole domain on this GPU and edge sub-tiles that own the
+     // three source lines of a periodic copy
+    const int LmT = cfg->Iend - cfg->Istr + 1, MmT = cfg->Jend - cfg->Jstr + 1;
+    const char *e = getenv("ROMS_HIP_FUSE_HALO");
+    G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && edge_subtile(LmT, G.nbx2) >= 3 && edge_subtile(MmT, G.nby2) >= 3 &&
+                  !(e && e[0] == '0');
+  }
   G.ntfirst = cfg->ntfirst; G.nfast = cfg->nfast;
   G.dt = cfg->dt; G.dtfast = cfg->dtfast; G.rho0 = cfg->rho0; G.g = cfg->g; G.lambda = cfg->lambda;
   G.gamma2 = cfg->gamma2; G.Cp = cfg->Cp; G.R0 = cfg->R0; G.T0 = cfg->T0; G.S0 = cfg->S0; G.Tcoef = cfg->Tcoef;
@@ -343,8 +375,13 @@ void kprof_resolve() {
   g_kev_used = 0;
 }
 }  // namespace
+static int g_kstride = 1, g_kcount = 0;
+extern "C" int roms_hip_kprof_stride(int every) { g_kstride = every > 0 ? every : 1; g_kcount = 0; return 0; }
 int kprof_begin(const char *name, hipStream_t stream) {
-  if (g_kprof_mode == 2 && strcmp(name, g_kselect)) return -1;
+  if (g_kprof_mode == 2) {
+    if (strcmp(name, g_kselect)) return -1;
+    if (g_kcount++ % g_kstride) return -1;     // sample every g_kstride-th launch of the selected kernel
+  }
   int slot = kslot_of(name);
   if (slot < 0) return -1;
   if (g_kev_used >= KPOOL) kprof_resolve();
@@ -380,6 +417,7 @@ extern "C" int roms_hip_kprof_get(int index, char *name, int name_len, double *s
 }
 #else
 extern "C" int roms_hip_kprof(int, const char *) { return 0; }
+extern "C" int roms_hip_kprof_stride(int) { return 0; }
 extern "C" int roms_hip_kprof_get(int, char *, int, double *, long *) { return 8; }
 #endif
 

@@ -56,7 +56,6 @@ long field_elems(const roms_hip_ctx *c, int kind);
 const FieldDesc *find_field(const char *name);
 
 // halo / BC launcher (k_halo.h): nk planes starting at A
-enum { BC_NONE = 0, BC_R = 1, BC_U = 2, BC_V = 3 };
 struct HaloSpec { double *A; int nk; int bc; char gtype; };
 void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype);
 void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n);   // n <= 8 fields in one launch

@@ -153,3 +153,36 @@ def test_benchmark_physics_kernels_and_steps():
     for name in ["u", "v", "wvel", "W", "t", "zeta", "Akv", "Akt", "hsbl"]:
         assert worst[name] <= TOL, (name, worst[name])
     H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernels", [False, True])
+def test_fortran_host_drives_gpu_like_the_oracle(kernels):
+    """roms.in -> Fortran host set-up -> device -> main3d (fused, and kernel by kernel through the
+    per-kernel C entries) against the oracle started from the same host arrays."""
+    from roms_amd import tiling
+    from oracle import orc
+    from tests import cases
+    from tests.test_host import HOST_FIELDS
+    cs = util.case_for("benchmark_small")
+    cs["ninfo"] = 1
+    run = tiling.TiledRun(cs, weak=False)
+    H = run.host
+    w = np.stack([H.get("weight1"), H.get("weight2")])
+    O = orc.Oracle(cases.oracle_cfg(cs, H.reals["hc"], H.dims["nfast"], w))
+    for n in HOST_FIELDS:
+        try:
+            O.field(n)[:] = H.get(n)
+        except KeyError:
+            pass
+    O.start()
+    nsteps = 12
+    run.step(nsteps, kernels=kernels)
+    O.main3d_step(nsteps)
+    for n in ["zeta", "u", "v", "t", "Hz", "W", "Akv", "rho"]:
+        e = util.relrms(run.ctx.download(n), O.field(n))
+        assert e <= 1e-10, (n, e)
+    d = run.check()
+    do = O.diag()
+    assert d["volume"] == pytest.approx(do[3], rel=1e-13)
+    run.close()
