@@ -12,8 +12,21 @@ int run_step2d(roms_hip_ctx *c) {
   a.w1_m1 = (iif >= 2) ? cf.weight[0][iif - 1] : 0.0;
   a.w2_0 = cf.weight[1][iif];
   a.w2_p1 = (iif + 1 <= ROMS_MAXW) ? cf.weight[1][iif + 1] : 0.0;
-  const size_t lds = (size_t)STEP2D_NLDS * (size_t)(G.bw2 + 6) * (size_t)(G.bh2 + 6);
-  LAUNCH_COOP(k_step2d, G.nbx2, G.nby2, 1, 256, lds, c->stream, a);
+  const size_t tile = (size_t)(G.bw2 + 6) * (size_t)(G.bh2 + 6);
+  const size_t lds = (size_t)STEP2D_NLDS * tile;
+  // every thread owns at most STEP2D_PTS points of the sub-tile rectangle
+  const int nthreads = tile <= 256 * STEP2D_PTS ? 256 : 512;   // launch bound of k_step2d: 512
+#ifndef ROMS_CPU_EMU
+  static bool big_lds = false;
+  if (lds * sizeof(double) > 64 * 1024 && !big_lds) {   // more than the default dynamic LDS limit
+    if (hipFuncSetAttribute((const void *)k_step2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      set_error("k_step2d: cannot raise the dynamic LDS limit");
+      return 2;
+    }
+    big_lds = true;
+  }
+#endif
+  LAUNCH_COOP(k_step2d, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
   if (G.fuse_halo) return 0;   // the kernel filled the boundary and periodic ghost points itself
   if (iif == G.nfast + 1 && G.predictor) {
     // final fast-time averages :821-883

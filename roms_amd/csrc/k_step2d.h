@@ -4,12 +4,18 @@
 // UV_ADV 4th-order centred :1246-1395, UV_COR, CURVGRID, UV_VIS2).
 //
 // Mapping: one thread block = one ROMS sub-tile; the reference's private work arrays
-// (IminS:ImaxS,JminS:JmaxS) live in LDS (12 arrays after aliasing), every loop nest of the
-// reference is a block-strided loop and dependent nests are separated by a barrier.  All
-// stencil reach (2 cells of DUon/DVom, 3 of Drhs) is satisfied from the 3-cell LDS halo, so the
-// kernel reads each 2-D field once per sub-tile and writes zeta/ubar/vbar(knew), the r.h.s.
-// history and the fast-time averages once.  Boundary fills and periodic copies follow in
-// halo_multi (k_halo.h).
+// (IminS:ImaxS,JminS:JmaxS) live in LDS, every loop nest of the reference is a masked sweep over
+// the sub-tile's (Istr-3:Iend+3, Jstr-3:Jend+3) rectangle and dependent nests are separated by a
+// barrier.
+//
+// The kernel is a chain of ~25 short dependent phases, so its cost is latency, not bandwidth.  All
+// global reads are therefore issued in ONE prologue: fields that are needed at neighbouring points
+// (zeta+h, ubar, vbar, h, pm, pn, rhoA, Dstp) go to LDS tiles with the 3-cell halo, everything
+// that is only needed at a thread's own points (metrics, r.h.s. history, running averages) stays
+// in that thread's registers -- every sweep uses the same point -> thread mapping.  The phases then
+// touch LDS and registers only; the epilogue stores zeta/ubar/vbar(knew), the r.h.s. history and
+// the fast-time averages, and (single-tile runs) fills boundary and periodic ghost points
+// (k_haloblock.h).
 #pragma once
 #include "roms_ctx.h"
 #include "k_haloblock.h"
@@ -21,7 +27,26 @@ struct Step2dArgs {
   double w2_0, w2_p1;  // weight(2,iif), weight(2,iif+1)
 };
 
-#define STEP2D_NLDS 12
+#define STEP2D_NLDS 21
+#define STEP2D_PTS 2      // tile points per thread: the launch uses >= tile/2 threads
+
+// Sweep over the sub-tile rectangle with a fixed point -> thread mapping.
+#ifdef ROMS_CPU_EMU
+// serial emulation: one "thread" visits all points; own-point values are read where they are used
+#define TLOOP(i, j)                                                                                                    \
+  for (int m = 0, i = 0, j = 0; m < NTILE && ((j = JT0 + m / TW), (i = IT0 + m - (m / TW) * TW), true); m++)
+#define PWDECL(name)
+#define PWLOAD(name, expr) ((void)0)
+#define PW(name, expr) (expr)
+#else
+#define TLOOP(i, j)                                                                                                    \
+  _Pragma("unroll") for (int m = 0; m < STEP2D_PTS; m++) if (tq[m])                                                    \
+    for (int i = ti[m], j = tj[m], once_ = 1; once_; once_ = 0)
+#define PWDECL(name) double name[STEP2D_PTS]
+#define PWLOAD(name, expr) name[m] = (expr)
+#define PW(name, expr) name[m]
+#endif
+#define INR(i, j, i0, i1, j0, j1) ((i) >= (i0) && (i) <= (i1) && (j) >= (j0) && (j) <= (j1))
 
 COOP_KERNEL(k_step2d, Step2dArgs) {
   (void)bz;
@@ -35,6 +60,11 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   double *grad = lds + 6 * sz, *Dgrad = lds + 7 * sz, *UFx = lds + 8 * sz, *UFe = lds + 9 * sz, *VFx = lds + 10 * sz,
          *VFe = lds + 11 * sz;
   double *Drhs_p = grad;
+  double *sUk = lds + 12 * sz, *sVk = lds + 13 * sz, *sH = lds + 14 * sz, *sPm = lds + 15 * sz, *sPn = lds + 16 * sz,
+         *sRhoA = lds + 17 * sz, *sDstp = lds + 18 * sz;
+  // new values kept for the boundary/periodic fills of the epilogue (halo_block_lds)
+  double *sZn = lds + 19 * sz, *sRz = lds + 20 * sz, *sUn = UFx, *sVn = UFe;
+  double *sZt = Dnew, *sDU1 = rhs_ubar, *sDV1 = rhs_vbar;
   const int krhs = G.krhs, kstp = G.kstp, knew = G.knew, nstp = G.nstp, nnew = G.nnew, iif = G.iif, iic = G.iic;
   const bool PRED = G.predictor != 0;
   const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend, IstrU = B.IstrU, JstrV = B.JstrV;
@@ -46,21 +76,104 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   const double *vk = F.vbar + (size_t)(krhs - 1) * G.nij, *vs = F.vbar + (size_t)(kstp - 1) * G.nij;
   double *zn = F.zeta + (size_t)(knew - 1) * G.nij, *un = F.ubar + (size_t)(knew - 1) * G.nij,
          *vn = F.vbar + (size_t)(knew - 1) * G.nij;
-  const double *h = F.h, *pm = F.pm, *pn = F.pn, *on_u = F.on_u, *om_v = F.om_v, *rhoA = F.rhoA, *rhoS = F.rhoS;
+  const double *rz_s = F.rzeta + (size_t)(kstp - 1) * G.nij, *rz_p = F.rzeta + (size_t)(ptsk - 1) * G.nij;
+  double *rz_k = F.rzeta + (size_t)(krhs - 1) * G.nij;
+  const double *rub_s = F.rubar + (size_t)(kstp - 1) * G.nij, *rub_p = F.rubar + (size_t)(ptsk - 1) * G.nij;
+  const double *rvb_s = F.rvbar + (size_t)(kstp - 1) * G.nij, *rvb_p = F.rvbar + (size_t)(ptsk - 1) * G.nij;
+  double *rub_k = F.rubar + (size_t)(krhs - 1) * G.nij, *rvb_k = F.rvbar + (size_t)(krhs - 1) * G.nij;
+  double *ru0_stp = F.ru + (size_t)(nstp - 1) * G.nij * (size_t)(G.N + 1);   // ru(:,:,0,nstp)
+  double *ru0_new = F.ru + (size_t)(nnew - 1) * G.nij * (size_t)(G.N + 1);
+  double *rv0_stp = F.rv + (size_t)(nstp - 1) * G.nij * (size_t)(G.N + 1);
+  double *rv0_new = F.rv + (size_t)(nnew - 1) * G.nij * (size_t)(G.N + 1);
+  const bool last = iif > G.nfast;                 // auxiliary last predictor call :883
+  const int first = (iif == 1 && PRED);
+  const int corr = (!PRED && iif != 1);
+  const int startup = (iic == G.ntfirst) ? 0 : ((iic == G.ntfirst + 1) ? 1 : 2);
 
-  // total depth and mass fluxes :600-700
-  KLOOP2(i, j, B.IstrUm2 - 1, B.Iendp2, B.JstrVm2 - 1, B.Jendp2) Drhs[S2(i, j)] = zk[X2(i, j)] + h[X2(i, j)];
-  KSYNC();
-  KLOOP2(i, j, B.IstrUm2 - 1, B.Iendp2, B.JstrVm2 - 1, B.Jendp2) {
-    if (i >= B.IstrUm2) {
-      const double cff = 0.5 * on_u[X2(i, j)];
-      const double cff1 = cff * (Drhs[S2(i, j)] + Drhs[S2(i - 1, j)]);
-      DUon[S2(i, j)] = uk[X2(i, j)] * cff1;
+  // sub-tile rectangle and the point -> thread mapping
+  const int IT0 = Istr - 3, JT0 = Jstr - 3, TW = Iend - Istr + 7, TH = Jend - Jstr + 7, NTILE = TW * TH;
+  const int UBi = G.LBi + G.ni - 1, UBj = G.LBj + G.nj - 1;
+#ifndef ROMS_CPU_EMU
+  int ti[STEP2D_PTS], tj[STEP2D_PTS];
+  bool tq[STEP2D_PTS];
+#pragma unroll
+  for (int m = 0; m < STEP2D_PTS; m++) {
+    const int q = KTID + m * KNT;
+    tq[m] = q < NTILE;
+    tj[m] = JT0 + q / TW;
+    ti[m] = IT0 + q - (q / TW) * TW;
+  }
+#endif
+  PWDECL(r_zk); PWDECL(r_zs); PWDECL(r_on_u); PWDECL(r_om_v); PWDECL(r_rhoS); PWDECL(r_fomn); PWDECL(r_dndx);
+  PWDECL(r_dmde); PWDECL(r_visc2_r); PWDECL(r_pmon_r); PWDECL(r_pnom_r); PWDECL(r_on_r); PWDECL(r_om_r);
+  PWDECL(r_visc2_p); PWDECL(r_pmon_p); PWDECL(r_pnom_p); PWDECL(r_om_p); PWDECL(r_on_p);
+  PWDECL(r_Zt); PWDECL(r_DU1); PWDECL(r_DU2); PWDECL(r_DV1); PWDECL(r_DV2);
+  PWDECL(r_rz_s); PWDECL(r_rz_p);
+  PWDECL(r_rub_s); PWDECL(r_rub_p); PWDECL(r_rvb_s); PWDECL(r_rvb_p); PWDECL(r_rufrc); PWDECL(r_rvfrc);
+  PWDECL(r_ru0n); PWDECL(r_ru0s); PWDECL(r_rv0n); PWDECL(r_rv0s); PWDECL(r_us); PWDECL(r_vs);
+
+  // ---- prologue: every global read of the kernel -------------------------------------------
+  const double SENT = hb_sentinel();
+  TLOOP(i, j) {
+    const size_t s = S2(i, j);
+    sZn[s] = SENT; sRz[s] = SENT;
+    if (last) { sZt[s] = SENT; sDU1[s] = SENT; sDV1[s] = SENT; }
+    if (INR(i, j, G.LBi, UBi, G.LBj, UBj)) {
+      // each array is read only as far from the sub-tile as some phase below needs it
+      const bool ring2 = INR(i, j, Istr - 2, Iend + 2, Jstr - 2, Jend + 2);
+      const bool ring1 = INR(i, j, Istr - 1, Iend + 1, Jstr - 1, Jend + 1);
+      const bool own = INR(i, j, Istr, Iend, Jstr, Jend);
+      const size_t x = X2(i, j);
+      const double zkv = zk[x], hv = F.h[x];
+      Drhs[s] = zkv + hv;                                    // total depth :600
+      sUk[s] = uk[x]; sVk[s] = vk[x]; sH[s] = hv;
+      PWLOAD(r_zk, zkv);
+      PWLOAD(r_on_u, F.on_u[x]); PWLOAD(r_om_v, F.om_v[x]);
+      if (ring2) { sPm[s] = F.pm[x]; sPn[s] = F.pn[x]; }
+      if (ring1) {
+        const double zsv = zs[x];
+        sDstp[s] = zsv + hv;
+        PWLOAD(r_zs, zsv);
+        sRhoA[s] = F.rhoA[x];
+        PWLOAD(r_Zt, F.Zt_avg1[x]); PWLOAD(r_DU1, F.DU_avg1[x]); PWLOAD(r_DU2, F.DU_avg2[x]);
+        PWLOAD(r_DV1, F.DV_avg1[x]); PWLOAD(r_DV2, F.DV_avg2[x]);
+        if (!last) {
+          PWLOAD(r_rhoS, F.rhoS[x]); PWLOAD(r_fomn, F.fomn[x]); PWLOAD(r_dndx, F.dndx[x]); PWLOAD(r_dmde, F.dmde[x]);
+          PWLOAD(r_visc2_r, F.visc2_r[x]); PWLOAD(r_pmon_r, F.pmon_r[x]); PWLOAD(r_pnom_r, F.pnom_r[x]);
+          PWLOAD(r_on_r, F.on_r[x]); PWLOAD(r_om_r, F.om_r[x]);
+          PWLOAD(r_visc2_p, F.visc2_p[x]); PWLOAD(r_pmon_p, F.pmon_p[x]); PWLOAD(r_pnom_p, F.pnom_p[x]);
+          PWLOAD(r_om_p, F.om_p[x]); PWLOAD(r_on_p, F.on_p[x]);
+          if (corr) { PWLOAD(r_rz_s, rz_s[x]); PWLOAD(r_rz_p, rz_p[x]); }
+        }
+      }
+      if (own && !last) {
+        PWLOAD(r_us, us[x]); PWLOAD(r_vs, vs[x]);
+        PWLOAD(r_rufrc, F.rufrc[x]); PWLOAD(r_rvfrc, F.rvfrc[x]);
+        if (corr) {
+          PWLOAD(r_rub_s, rub_s[x]); PWLOAD(r_rub_p, rub_p[x]); PWLOAD(r_rvb_s, rvb_s[x]); PWLOAD(r_rvb_p, rvb_p[x]);
+        }
+        if (first && startup >= 1) { PWLOAD(r_ru0n, ru0_new[x]); PWLOAD(r_rv0n, rv0_new[x]); }
+        if (first && startup >= 2) { PWLOAD(r_ru0s, ru0_stp[x]); PWLOAD(r_rv0s, rv0_stp[x]); }
+      }
+    } else {
+      Drhs[s] = 0.0; sDstp[s] = 0.0; sUk[s] = 0.0; sVk[s] = 0.0; sH[s] = 0.0; sPm[s] = 0.0; sPn[s] = 0.0; sRhoA[s] = 0.0;
     }
-    if (j >= B.JstrVm2) {
-      const double cff = 0.5 * om_v[X2(i, j)];
-      const double cff1 = cff * (Drhs[S2(i, j)] + Drhs[S2(i, j - 1)]);
-      DVom[S2(i, j)] = vk[X2(i, j)] * cff1;
+  }
+  KSYNC();
+
+  // mass fluxes :600-700
+  TLOOP(i, j) {
+    if (INR(i, j, B.IstrUm2 - 1, B.Iendp2, B.JstrVm2 - 1, B.Jendp2)) {
+      if (i >= B.IstrUm2) {
+        const double cff = 0.5 * PW(r_on_u, F.on_u[X2(i, j)]);
+        const double cff1 = cff * (Drhs[S2(i, j)] + Drhs[S2(i - 1, j)]);
+        DUon[S2(i, j)] = sUk[S2(i, j)] * cff1;
+      }
+      if (j >= B.JstrVm2) {
+        const double cff = 0.5 * PW(r_om_v, F.om_v[X2(i, j)]);
+        const double cff1 = cff * (Drhs[S2(i, j)] + Drhs[S2(i, j - 1)]);
+        DVom[S2(i, j)] = sVk[S2(i, j)] * cff1;
+      }
     }
   }
   KSYNC();
@@ -69,47 +182,58 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   if (PRED) {
     if (iif == 1) {
       const double cff2 = (-1.0 / 12.0) * a.w2_p1;
-      KLOOP2(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR) {
-        if (i >= IstrR && j >= JstrR) F.Zt_avg1[X2(i, j)] = 0.0;
-        if (i >= Istr && j >= JstrR) {
-          F.DU_avg1[X2(i, j)] = 0.0;
-          F.DU_avg2[X2(i, j)] = cff2 * DUon[S2(i, j)];
-        }
-        if (i >= IstrR && j >= Jstr) {
-          F.DV_avg1[X2(i, j)] = 0.0;
-          F.DV_avg2[X2(i, j)] = cff2 * DVom[S2(i, j)];
+      TLOOP(i, j) {
+        if (INR(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR)) {
+          if (i >= IstrR && j >= JstrR) F.Zt_avg1[X2(i, j)] = 0.0;
+          if (i >= Istr && j >= JstrR) {
+            F.DU_avg1[X2(i, j)] = 0.0;
+            F.DU_avg2[X2(i, j)] = cff2 * DUon[S2(i, j)];
+          }
+          if (i >= IstrR && j >= Jstr) {
+            F.DV_avg1[X2(i, j)] = 0.0;
+            F.DV_avg2[X2(i, j)] = cff2 * DVom[S2(i, j)];
+          }
         }
       }
     } else {
       const double cff1 = a.w1_m1;
       const double cff2 = (8.0 / 12.0) * a.w2_0 - (1.0 / 12.0) * a.w2_p1;
-      KLOOP2(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR) {
-        if (i >= IstrR && j >= JstrR) F.Zt_avg1[X2(i, j)] = F.Zt_avg1[X2(i, j)] + cff1 * zk[X2(i, j)];
-        if (i >= Istr && j >= JstrR) {
-          F.DU_avg1[X2(i, j)] = F.DU_avg1[X2(i, j)] + cff1 * DUon[S2(i, j)];
-          F.DU_avg2[X2(i, j)] = F.DU_avg2[X2(i, j)] + cff2 * DUon[S2(i, j)];
-        }
-        if (i >= IstrR && j >= Jstr) {
-          F.DV_avg1[X2(i, j)] = F.DV_avg1[X2(i, j)] + cff1 * DVom[S2(i, j)];
-          F.DV_avg2[X2(i, j)] = F.DV_avg2[X2(i, j)] + cff2 * DVom[S2(i, j)];
+      TLOOP(i, j) {
+        if (INR(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR)) {
+          if (i >= IstrR && j >= JstrR) {
+            const double v = PW(r_Zt, F.Zt_avg1[X2(i, j)]) + cff1 * PW(r_zk, zk[X2(i, j)]);
+            F.Zt_avg1[X2(i, j)] = v;
+            if (last) sZt[S2(i, j)] = v;
+          }
+          if (i >= Istr && j >= JstrR) {
+            const double v = PW(r_DU1, F.DU_avg1[X2(i, j)]) + cff1 * DUon[S2(i, j)];
+            F.DU_avg1[X2(i, j)] = v;
+            if (last) sDU1[S2(i, j)] = v;
+            F.DU_avg2[X2(i, j)] = PW(r_DU2, F.DU_avg2[X2(i, j)]) + cff2 * DUon[S2(i, j)];
+          }
+          if (i >= IstrR && j >= Jstr) {
+            const double v = PW(r_DV1, F.DV_avg1[X2(i, j)]) + cff1 * DVom[S2(i, j)];
+            F.DV_avg1[X2(i, j)] = v;
+            if (last) sDV1[S2(i, j)] = v;
+            F.DV_avg2[X2(i, j)] = PW(r_DV2, F.DV_avg2[X2(i, j)]) + cff2 * DVom[S2(i, j)];
+          }
         }
       }
     }
   } else {
     const double cff2 = (iif == 1) ? a.w2_0 : (5.0 / 12.0) * a.w2_0;
-    KLOOP2(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR) {
-      if (i >= Istr && j >= JstrR) F.DU_avg2[X2(i, j)] = F.DU_avg2[X2(i, j)] + cff2 * DUon[S2(i, j)];
-      if (i >= IstrR && j >= Jstr) F.DV_avg2[X2(i, j)] = F.DV_avg2[X2(i, j)] + cff2 * DVom[S2(i, j)];
+    TLOOP(i, j) {
+      if (INR(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR)) {
+        if (i >= Istr && j >= JstrR) F.DU_avg2[X2(i, j)] = PW(r_DU2, F.DU_avg2[X2(i, j)]) + cff2 * DUon[S2(i, j)];
+        if (i >= IstrR && j >= Jstr) F.DV_avg2[X2(i, j)] = PW(r_DV2, F.DV_avg2[X2(i, j)]) + cff2 * DVom[S2(i, j)];
+      }
     }
   }
-  if (iif > G.nfast) {         // auxiliary last predictor call :883 (uniform over the grid)
+  if (last) {                  // auxiliary last predictor call :883 (uniform over the grid)
     if (G.fuse_halo && PRED) { // final fast-time averages: exchange :821-883
-      HaloBlockItems H;
-      H.n = 3;
-      H.A[0] = F.Zt_avg1; H.bc[0] = BC_NONE; H.gt[0] = 'r';
-      H.A[1] = F.DU_avg1; H.bc[1] = BC_NONE; H.gt[1] = 'u';
-      H.A[2] = F.DV_avg1; H.bc[2] = BC_NONE; H.gt[2] = 'v';
-      halo_block(G, B, H);
+      const HbItem I0 = {F.Zt_avg1, sZt, BC_NONE, 'r'}, I1 = {F.DU_avg1, sDU1, BC_NONE, 'u'},
+                   I2 = {F.DV_avg1, sDV1, BC_NONE, 'v'};
+      halo_block(G, B, 3, I0, I1, I2, I2);
     }
     return;
   }
@@ -122,31 +246,35 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     if (iif == 1) { mode = 0; cff1 = dtfast; cff4 = 0.0; cff5 = 0.0; }
     else if (PRED) { mode = 1; cff1 = 2.0 * dtfast; cff4 = 4.0 / 25.0; cff5 = 1.0 - 2.0 * cff4; }
     else { mode = 2; cff1 = dtfast * 5.0 / 12.0; cff2 = dtfast * 8.0 / 12.0; cff3 = dtfast * 1.0 / 12.0; cff4 = 2.0 / 5.0; cff5 = 1.0 - cff4; }
-    const double *rz_s = F.rzeta + (size_t)(kstp - 1) * G.nij, *rz_p = F.rzeta + (size_t)(ptsk - 1) * G.nij;
-    double *rz_k = F.rzeta + (size_t)(krhs - 1) * G.nij;
-    KLOOP2(i, j, IstrU - 1, Iend, JstrV - 1, Jend) {
-      const double rhs_zeta = (DUon[S2(i, j)] - DUon[S2(i + 1, j)]) + (DVom[S2(i, j)] - DVom[S2(i, j + 1)]);
-      double zeta_new, zw;
-      if (mode == 0) {
-        zeta_new = zs[X2(i, j)] + pm[X2(i, j)] * pn[X2(i, j)] * cff1 * rhs_zeta;
-        zw = 0.5 * (zs[X2(i, j)] + zeta_new);
-      } else if (mode == 1) {
-        zeta_new = zs[X2(i, j)] + pm[X2(i, j)] * pn[X2(i, j)] * cff1 * rhs_zeta;
-        zw = cff5 * zk[X2(i, j)] + cff4 * (zs[X2(i, j)] + zeta_new);
-      } else {
-        const double cff = cff1 * rhs_zeta;
-        zeta_new = zs[X2(i, j)] + pm[X2(i, j)] * pn[X2(i, j)] * (cff + cff2 * rz_s[X2(i, j)] - cff3 * rz_p[X2(i, j)]);
-        zw = cff5 * zeta_new + cff4 * zk[X2(i, j)];
-      }
-      Dnew[S2(i, j)] = zeta_new + h[X2(i, j)];
-      zwrk[S2(i, j)] = zw;
-      const double gz = (fac + rhoS[X2(i, j)]) * zw;
-      gzeta[S2(i, j)] = gz;
-      gzeta2[S2(i, j)] = gz * zw;
-      gzetaSA[S2(i, j)] = zw * (rhoS[X2(i, j)] - rhoA[X2(i, j)]);
-      if (i >= Istr && j >= Jstr) {
-        zn[X2(i, j)] = zeta_new;
-        if (PRED) rz_k[X2(i, j)] = rhs_zeta;
+    TLOOP(i, j) {
+      if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
+        const size_t s = S2(i, j);
+        const double rhs_zeta = (DUon[s] - DUon[S2(i + 1, j)]) + (DVom[s] - DVom[S2(i, j + 1)]);
+        const double zsv = PW(r_zs, zs[X2(i, j)]), zkv = PW(r_zk, zk[X2(i, j)]);
+        double zeta_new, zw;
+        if (mode == 0) {
+          zeta_new = zsv + sPm[s] * sPn[s] * cff1 * rhs_zeta;
+          zw = 0.5 * (zsv + zeta_new);
+        } else if (mode == 1) {
+          zeta_new = zsv + sPm[s] * sPn[s] * cff1 * rhs_zeta;
+          zw = cff5 * zkv + cff4 * (zsv + zeta_new);
+        } else {
+          const double cff = cff1 * rhs_zeta;
+          zeta_new = zsv + sPm[s] * sPn[s] * (cff + cff2 * PW(r_rz_s, rz_s[X2(i, j)]) - cff3 * PW(r_rz_p, rz_p[X2(i, j)]));
+          zw = cff5 * zeta_new + cff4 * zkv;
+        }
+        const double rhoSv = PW(r_rhoS, F.rhoS[X2(i, j)]);
+        Dnew[s] = zeta_new + sH[s];
+        zwrk[s] = zw;
+        const double gz = (fac + rhoSv) * zw;
+        gzeta[s] = gz;
+        gzeta2[s] = gz * zw;
+        gzetaSA[s] = zw * (rhoSv - sRhoA[s]);
+        if (i >= Istr && j >= Jstr) {
+          zn[X2(i, j)] = zeta_new;
+          sZn[s] = zeta_new;
+          if (PRED) { rz_k[X2(i, j)] = rhs_zeta; sRz[s] = rhs_zeta; }
+        }
       }
     }
   }
@@ -155,23 +283,25 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   // pressure gradient (VAR_RHO_2D) :1080-1200
   {
     const double cff1 = 0.5 * g, cff2 = 1.0 / 3.0;
-    KLOOP2(i, j, KMIN(IstrU, Istr), Iend, Jstr, Jend) {
-      if (i >= IstrU)
-        rhs_ubar[S2(i, j)] =
-            cff1 * on_u[X2(i, j)] *
-            ((h[X2(i - 1, j)] + h[X2(i, j)]) * (gzeta[S2(i - 1, j)] - gzeta[S2(i, j)]) +
-             (h[X2(i - 1, j)] - h[X2(i, j)]) *
-                 (gzetaSA[S2(i - 1, j)] + gzetaSA[S2(i, j)] +
-                  cff2 * (rhoA[X2(i - 1, j)] - rhoA[X2(i, j)]) * (zwrk[S2(i - 1, j)] - zwrk[S2(i, j)])) +
-             (gzeta2[S2(i - 1, j)] - gzeta2[S2(i, j)]));
-      if (j >= JstrV)
-        rhs_vbar[S2(i, j)] =
-            cff1 * om_v[X2(i, j)] *
-            ((h[X2(i, j - 1)] + h[X2(i, j)]) * (gzeta[S2(i, j - 1)] - gzeta[S2(i, j)]) +
-             (h[X2(i, j - 1)] - h[X2(i, j)]) *
-                 (gzetaSA[S2(i, j - 1)] + gzetaSA[S2(i, j)] +
-                  cff2 * (rhoA[X2(i, j - 1)] - rhoA[X2(i, j)]) * (zwrk[S2(i, j - 1)] - zwrk[S2(i, j)])) +
-             (gzeta2[S2(i, j - 1)] - gzeta2[S2(i, j)]));
+    TLOOP(i, j) {
+      if (INR(i, j, KMIN(IstrU, Istr), Iend, Jstr, Jend)) {
+        if (i >= IstrU)
+          rhs_ubar[S2(i, j)] =
+              cff1 * PW(r_on_u, F.on_u[X2(i, j)]) *
+              ((sH[S2(i - 1, j)] + sH[S2(i, j)]) * (gzeta[S2(i - 1, j)] - gzeta[S2(i, j)]) +
+               (sH[S2(i - 1, j)] - sH[S2(i, j)]) *
+                   (gzetaSA[S2(i - 1, j)] + gzetaSA[S2(i, j)] +
+                    cff2 * (sRhoA[S2(i - 1, j)] - sRhoA[S2(i, j)]) * (zwrk[S2(i - 1, j)] - zwrk[S2(i, j)])) +
+               (gzeta2[S2(i - 1, j)] - gzeta2[S2(i, j)]));
+        if (j >= JstrV)
+          rhs_vbar[S2(i, j)] =
+              cff1 * PW(r_om_v, F.om_v[X2(i, j)]) *
+              ((sH[S2(i, j - 1)] + sH[S2(i, j)]) * (gzeta[S2(i, j - 1)] - gzeta[S2(i, j)]) +
+               (sH[S2(i, j - 1)] - sH[S2(i, j)]) *
+                   (gzetaSA[S2(i, j - 1)] + gzetaSA[S2(i, j)] +
+                    cff2 * (sRhoA[S2(i, j - 1)] - sRhoA[S2(i, j)]) * (zwrk[S2(i, j - 1)] - zwrk[S2(i, j)])) +
+               (gzeta2[S2(i, j - 1)] - gzeta2[S2(i, j)]));
+      }
     }
   }
   KSYNC();   // group-1 scratch is dead from here on (aliased by grad,Dgrad,UFx,UFe)
@@ -179,98 +309,122 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   if (G.options & ROMS_UV_ADV) {
     const double cff = 1.0 / 6.0;
     // ---- UFx :1249-1290
-    KLOOP2(i, j, B.IstrUm1, B.Iendp1, Jstr, Jend) {
-      grad[S2(i, j)] = uk[X2(i - 1, j)] - 2.0 * uk[X2(i, j)] + uk[X2(i + 1, j)];
-      Dgrad[S2(i, j)] = DUon[S2(i - 1, j)] - 2.0 * DUon[S2(i, j)] + DUon[S2(i + 1, j)];
+    TLOOP(i, j) {
+      if (INR(i, j, B.IstrUm1, B.Iendp1, Jstr, Jend)) {
+        grad[S2(i, j)] = sUk[S2(i - 1, j)] - 2.0 * sUk[S2(i, j)] + sUk[S2(i + 1, j)];
+        Dgrad[S2(i, j)] = DUon[S2(i - 1, j)] - 2.0 * DUon[S2(i, j)] + DUon[S2(i + 1, j)];
+      }
     }
     KSYNC();
     if (!G.ewp) {
       if (B.west) KLOOP1(j, Jstr, Jend) { grad[S2(Istr, j)] = grad[S2(Istr + 1, j)]; Dgrad[S2(Istr, j)] = Dgrad[S2(Istr + 1, j)]; }
       if (B.east) KLOOP1(j, Jstr, Jend) { grad[S2(Iend + 1, j)] = grad[S2(Iend, j)]; Dgrad[S2(Iend + 1, j)] = Dgrad[S2(Iend, j)]; }
+      KSYNC();
+    }
+    TLOOP(i, j) {
+      if (INR(i, j, IstrU - 1, Iend, Jstr, Jend))
+        UFx[S2(i, j)] = 0.25 * (sUk[S2(i, j)] + sUk[S2(i + 1, j)] - cff * (grad[S2(i, j)] + grad[S2(i + 1, j)])) *
+                        (DUon[S2(i, j)] + DUon[S2(i + 1, j)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i + 1, j)]));
     }
     KSYNC();
-    KLOOP2(i, j, IstrU - 1, Iend, Jstr, Jend)
-      UFx[S2(i, j)] = 0.25 * (uk[X2(i, j)] + uk[X2(i + 1, j)] - cff * (grad[S2(i, j)] + grad[S2(i + 1, j)])) *
-                      (DUon[S2(i, j)] + DUon[S2(i + 1, j)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i + 1, j)]));
-    KSYNC();
     // ---- UFe :1292-1330
-    KLOOP2(i, j, IstrU, Iend, B.Jstrm1, B.Jendp1)
-      grad[S2(i, j)] = uk[X2(i, j - 1)] - 2.0 * uk[X2(i, j)] + uk[X2(i, j + 1)];
-    KLOOP2(i, j, IstrU - 1, Iend, Jstr, Jend + 1)
-      Dgrad[S2(i, j)] = DVom[S2(i - 1, j)] - 2.0 * DVom[S2(i, j)] + DVom[S2(i + 1, j)];
+    TLOOP(i, j) {
+      if (INR(i, j, IstrU, Iend, B.Jstrm1, B.Jendp1))
+        grad[S2(i, j)] = sUk[S2(i, j - 1)] - 2.0 * sUk[S2(i, j)] + sUk[S2(i, j + 1)];
+      if (INR(i, j, IstrU - 1, Iend, Jstr, Jend + 1))
+        Dgrad[S2(i, j)] = DVom[S2(i - 1, j)] - 2.0 * DVom[S2(i, j)] + DVom[S2(i + 1, j)];
+    }
     KSYNC();
     if (!G.nsp) {
       if (B.south) KLOOP1(i, IstrU, Iend) grad[S2(i, Jstr - 1)] = grad[S2(i, Jstr)];
       if (B.north) KLOOP1(i, IstrU, Iend) grad[S2(i, Jend + 1)] = grad[S2(i, Jend)];
+      KSYNC();
+    }
+    TLOOP(i, j) {
+      if (INR(i, j, IstrU, Iend, Jstr, Jend + 1))
+        UFe[S2(i, j)] = 0.25 * (sUk[S2(i, j)] + sUk[S2(i, j - 1)] - cff * (grad[S2(i, j)] + grad[S2(i, j - 1)])) *
+                        (DVom[S2(i, j)] + DVom[S2(i - 1, j)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i - 1, j)]));
     }
     KSYNC();
-    KLOOP2(i, j, IstrU, Iend, Jstr, Jend + 1)
-      UFe[S2(i, j)] = 0.25 * (uk[X2(i, j)] + uk[X2(i, j - 1)] - cff * (grad[S2(i, j)] + grad[S2(i, j - 1)])) *
-                      (DVom[S2(i, j)] + DVom[S2(i - 1, j)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i - 1, j)]));
-    KSYNC();
     // u-momentum advection r.h.s. (UFx,UFe complete)
-    KLOOP2(i, j, IstrU, Iend, Jstr, Jend) {
-      const double cff1 = UFx[S2(i, j)] - UFx[S2(i - 1, j)];
-      const double cff2 = UFe[S2(i, j + 1)] - UFe[S2(i, j)];
-      const double fac = cff1 + cff2;
-      rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] - fac;
+    TLOOP(i, j) {
+      if (INR(i, j, IstrU, Iend, Jstr, Jend)) {
+        const double cff1 = UFx[S2(i, j)] - UFx[S2(i - 1, j)];
+        const double cff2 = UFe[S2(i, j + 1)] - UFe[S2(i, j)];
+        const double fac = cff1 + cff2;
+        rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] - fac;
+      }
     }
     KSYNC();
     // ---- VFx :1332-1370
-    KLOOP2(i, j, B.Istrm1, B.Iendp1, JstrV, Jend)
-      grad[S2(i, j)] = vk[X2(i - 1, j)] - 2.0 * vk[X2(i, j)] + vk[X2(i + 1, j)];
-    KLOOP2(i, j, Istr, Iend + 1, JstrV - 1, Jend)
-      Dgrad[S2(i, j)] = DUon[S2(i, j - 1)] - 2.0 * DUon[S2(i, j)] + DUon[S2(i, j + 1)];
+    TLOOP(i, j) {
+      if (INR(i, j, B.Istrm1, B.Iendp1, JstrV, Jend))
+        grad[S2(i, j)] = sVk[S2(i - 1, j)] - 2.0 * sVk[S2(i, j)] + sVk[S2(i + 1, j)];
+      if (INR(i, j, Istr, Iend + 1, JstrV - 1, Jend))
+        Dgrad[S2(i, j)] = DUon[S2(i, j - 1)] - 2.0 * DUon[S2(i, j)] + DUon[S2(i, j + 1)];
+    }
     KSYNC();
     if (!G.ewp) {
       if (B.west) KLOOP1(j, JstrV, Jend) grad[S2(Istr - 1, j)] = grad[S2(Istr, j)];
       if (B.east) KLOOP1(j, JstrV, Jend) grad[S2(Iend + 1, j)] = grad[S2(Iend, j)];
+      KSYNC();
+    }
+    TLOOP(i, j) {
+      if (INR(i, j, Istr, Iend + 1, JstrV, Jend))
+        VFx[S2(i, j)] = 0.25 * (sVk[S2(i, j)] + sVk[S2(i - 1, j)] - cff * (grad[S2(i, j)] + grad[S2(i - 1, j)])) *
+                        (DUon[S2(i, j)] + DUon[S2(i, j - 1)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i, j - 1)]));
     }
     KSYNC();
-    KLOOP2(i, j, Istr, Iend + 1, JstrV, Jend)
-      VFx[S2(i, j)] = 0.25 * (vk[X2(i, j)] + vk[X2(i - 1, j)] - cff * (grad[S2(i, j)] + grad[S2(i - 1, j)])) *
-                      (DUon[S2(i, j)] + DUon[S2(i, j - 1)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i, j - 1)]));
-    KSYNC();
     // ---- VFe :1372-1410
-    KLOOP2(i, j, Istr, Iend, B.JstrVm1, B.Jendp1) {
-      grad[S2(i, j)] = vk[X2(i, j - 1)] - 2.0 * vk[X2(i, j)] + vk[X2(i, j + 1)];
-      Dgrad[S2(i, j)] = DVom[S2(i, j - 1)] - 2.0 * DVom[S2(i, j)] + DVom[S2(i, j + 1)];
+    TLOOP(i, j) {
+      if (INR(i, j, Istr, Iend, B.JstrVm1, B.Jendp1)) {
+        grad[S2(i, j)] = sVk[S2(i, j - 1)] - 2.0 * sVk[S2(i, j)] + sVk[S2(i, j + 1)];
+        Dgrad[S2(i, j)] = DVom[S2(i, j - 1)] - 2.0 * DVom[S2(i, j)] + DVom[S2(i, j + 1)];
+      }
     }
     KSYNC();
     if (!G.nsp) {
       if (B.south) KLOOP1(i, Istr, Iend) { grad[S2(i, Jstr)] = grad[S2(i, Jstr + 1)]; Dgrad[S2(i, Jstr)] = Dgrad[S2(i, Jstr + 1)]; }
       if (B.north) KLOOP1(i, Istr, Iend) { grad[S2(i, Jend + 1)] = grad[S2(i, Jend)]; Dgrad[S2(i, Jend + 1)] = Dgrad[S2(i, Jend)]; }
+      KSYNC();
+    }
+    TLOOP(i, j) {
+      if (INR(i, j, Istr, Iend, JstrV - 1, Jend))
+        VFe[S2(i, j)] = 0.25 * (sVk[S2(i, j)] + sVk[S2(i, j + 1)] - cff * (grad[S2(i, j)] + grad[S2(i, j + 1)])) *
+                        (DVom[S2(i, j)] + DVom[S2(i, j + 1)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i, j + 1)]));
     }
     KSYNC();
-    KLOOP2(i, j, Istr, Iend, JstrV - 1, Jend)
-      VFe[S2(i, j)] = 0.25 * (vk[X2(i, j)] + vk[X2(i, j + 1)] - cff * (grad[S2(i, j)] + grad[S2(i, j + 1)])) *
-                      (DVom[S2(i, j)] + DVom[S2(i, j + 1)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i, j + 1)]));
-    KSYNC();
-    KLOOP2(i, j, Istr, Iend, JstrV, Jend) {
-      const double cff1 = VFx[S2(i + 1, j)] - VFx[S2(i, j)];
-      const double cff2 = VFe[S2(i, j)] - VFe[S2(i, j - 1)];
-      const double fac = cff1 + cff2;
-      rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] - fac;
+    TLOOP(i, j) {
+      if (INR(i, j, Istr, Iend, JstrV, Jend)) {
+        const double cff1 = VFx[S2(i + 1, j)] - VFx[S2(i, j)];
+        const double cff2 = VFe[S2(i, j)] - VFe[S2(i, j - 1)];
+        const double fac = cff1 + cff2;
+        rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] - fac;
+      }
     }
     KSYNC();
   }
 
   if (G.options & ROMS_UV_COR) {
     // Coriolis :1429-1490
-    KLOOP2(i, j, IstrU - 1, Iend, JstrV - 1, Jend) {
-      const double cff = 0.5 * Drhs[S2(i, j)] * F.fomn[X2(i, j)];
-      UFx[S2(i, j)] = cff * (vk[X2(i, j)] + vk[X2(i, j + 1)]);
-      VFe[S2(i, j)] = cff * (uk[X2(i, j)] + uk[X2(i + 1, j)]);
+    TLOOP(i, j) {
+      if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
+        const double cff = 0.5 * Drhs[S2(i, j)] * PW(r_fomn, F.fomn[X2(i, j)]);
+        UFx[S2(i, j)] = cff * (sVk[S2(i, j)] + sVk[S2(i, j + 1)]);
+        VFe[S2(i, j)] = cff * (sUk[S2(i, j)] + sUk[S2(i + 1, j)]);
+      }
     }
     KSYNC();
-    KLOOP2(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend) {
-      if (i >= IstrU && j >= Jstr) {
-        const double fac1 = 0.5 * (UFx[S2(i, j)] + UFx[S2(i - 1, j)]);
-        rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] + fac1;
-      }
-      if (i >= Istr && j >= JstrV) {
-        const double fac1 = 0.5 * (VFe[S2(i, j)] + VFe[S2(i, j - 1)]);
-        rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] - fac1;
+    TLOOP(i, j) {
+      if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
+        if (i >= IstrU && j >= Jstr) {
+          const double fac1 = 0.5 * (UFx[S2(i, j)] + UFx[S2(i - 1, j)]);
+          rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] + fac1;
+        }
+        if (i >= Istr && j >= JstrV) {
+          const double fac1 = 0.5 * (VFe[S2(i, j)] + VFe[S2(i, j - 1)]);
+          rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] - fac1;
+        }
       }
     }
     KSYNC();
@@ -278,24 +432,28 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
 
   if ((G.options & ROMS_CURVGRID) && (G.options & ROMS_UV_ADV)) {
     // curvilinear metric terms :1494-1560
-    KLOOP2(i, j, IstrU - 1, Iend, JstrV - 1, Jend) {
-      const double cff1 = 0.5 * (vk[X2(i, j)] + vk[X2(i, j + 1)]);
-      const double cff2 = 0.5 * (uk[X2(i, j)] + uk[X2(i + 1, j)]);
-      const double cff3 = cff1 * F.dndx[X2(i, j)];
-      const double cff4 = cff2 * F.dmde[X2(i, j)];
-      const double cff = Drhs[S2(i, j)] * (cff3 - cff4);
-      UFx[S2(i, j)] = cff * cff1;
-      VFe[S2(i, j)] = cff * cff2;
+    TLOOP(i, j) {
+      if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
+        const double cff1 = 0.5 * (sVk[S2(i, j)] + sVk[S2(i, j + 1)]);
+        const double cff2 = 0.5 * (sUk[S2(i, j)] + sUk[S2(i + 1, j)]);
+        const double cff3 = cff1 * PW(r_dndx, F.dndx[X2(i, j)]);
+        const double cff4 = cff2 * PW(r_dmde, F.dmde[X2(i, j)]);
+        const double cff = Drhs[S2(i, j)] * (cff3 - cff4);
+        UFx[S2(i, j)] = cff * cff1;
+        VFe[S2(i, j)] = cff * cff2;
+      }
     }
     KSYNC();
-    KLOOP2(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend) {
-      if (i >= IstrU && j >= Jstr) {
-        const double fac1 = 0.5 * (UFx[S2(i, j)] + UFx[S2(i - 1, j)]);
-        rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] + fac1;
-      }
-      if (i >= Istr && j >= JstrV) {
-        const double fac1 = 0.5 * (VFe[S2(i, j)] + VFe[S2(i, j - 1)]);
-        rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] - fac1;
+    TLOOP(i, j) {
+      if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
+        if (i >= IstrU && j >= Jstr) {
+          const double fac1 = 0.5 * (UFx[S2(i, j)] + UFx[S2(i - 1, j)]);
+          rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] + fac1;
+        }
+        if (i >= Istr && j >= JstrV) {
+          const double fac1 = 0.5 * (VFe[S2(i, j)] + VFe[S2(i, j - 1)]);
+          rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] - fac1;
+        }
       }
     }
     KSYNC();
@@ -303,114 +461,123 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
 
   if (G.options & ROMS_UV_VIS2) {
     // harmonic viscosity :1567-1660
-    KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend + 1)
-      Drhs_p[S2(i, j)] = 0.25 * (Drhs[S2(i, j)] + Drhs[S2(i - 1, j)] + Drhs[S2(i, j - 1)] + Drhs[S2(i - 1, j - 1)]);
-    KLOOP2(i, j, IstrU - 1, Iend, JstrV - 1, Jend) {
-      const double cff = F.visc2_r[X2(i, j)] * Drhs[S2(i, j)] * 0.5 *
-                         (F.pmon_r[X2(i, j)] * ((pn[X2(i, j)] + pn[X2(i + 1, j)]) * uk[X2(i + 1, j)] -
-                                                (pn[X2(i - 1, j)] + pn[X2(i, j)]) * uk[X2(i, j)]) -
-                          F.pnom_r[X2(i, j)] * ((pm[X2(i, j)] + pm[X2(i, j + 1)]) * vk[X2(i, j + 1)] -
-                                                (pm[X2(i, j - 1)] + pm[X2(i, j)]) * vk[X2(i, j)]));
-      UFx[S2(i, j)] = F.on_r[X2(i, j)] * F.on_r[X2(i, j)] * cff;
-      VFe[S2(i, j)] = F.om_r[X2(i, j)] * F.om_r[X2(i, j)] * cff;
-    }
-    KSYNC();
-    KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend + 1) {
-      const double cff = F.visc2_p[X2(i, j)] * Drhs_p[S2(i, j)] * 0.5 *
-                         (F.pmon_p[X2(i, j)] * ((pn[X2(i, j - 1)] + pn[X2(i, j)]) * vk[X2(i, j)] -
-                                                (pn[X2(i - 1, j - 1)] + pn[X2(i - 1, j)]) * vk[X2(i - 1, j)]) +
-                          F.pnom_p[X2(i, j)] * ((pm[X2(i - 1, j)] + pm[X2(i, j)]) * uk[X2(i, j)] -
-                                                (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]) * uk[X2(i, j - 1)]));
-      UFe[S2(i, j)] = F.om_p[X2(i, j)] * F.om_p[X2(i, j)] * cff;
-      VFx[S2(i, j)] = F.on_p[X2(i, j)] * F.on_p[X2(i, j)] * cff;
-    }
-    KSYNC();
-    KLOOP2(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend) {
-      if (i >= IstrU && j >= Jstr) {
-        const double cff1 = 0.5 * (pn[X2(i - 1, j)] + pn[X2(i, j)]) * (UFx[S2(i, j)] - UFx[S2(i - 1, j)]);
-        const double cff2 = 0.5 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (UFe[S2(i, j + 1)] - UFe[S2(i, j)]);
-        const double fac = cff1 + cff2;
-        rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] + fac;
+    TLOOP(i, j) {
+      if (INR(i, j, Istr, Iend + 1, Jstr, Jend + 1))
+        Drhs_p[S2(i, j)] = 0.25 * (Drhs[S2(i, j)] + Drhs[S2(i - 1, j)] + Drhs[S2(i, j - 1)] + Drhs[S2(i - 1, j - 1)]);
+      if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
+        const double cff = PW(r_visc2_r, F.visc2_r[X2(i, j)]) * Drhs[S2(i, j)] * 0.5 *
+                           (PW(r_pmon_r, F.pmon_r[X2(i, j)]) * ((sPn[S2(i, j)] + sPn[S2(i + 1, j)]) * sUk[S2(i + 1, j)] -
+                                                               (sPn[S2(i - 1, j)] + sPn[S2(i, j)]) * sUk[S2(i, j)]) -
+                            PW(r_pnom_r, F.pnom_r[X2(i, j)]) * ((sPm[S2(i, j)] + sPm[S2(i, j + 1)]) * sVk[S2(i, j + 1)] -
+                                                               (sPm[S2(i, j - 1)] + sPm[S2(i, j)]) * sVk[S2(i, j)]));
+        UFx[S2(i, j)] = PW(r_on_r, F.on_r[X2(i, j)]) * PW(r_on_r, F.on_r[X2(i, j)]) * cff;
+        VFe[S2(i, j)] = PW(r_om_r, F.om_r[X2(i, j)]) * PW(r_om_r, F.om_r[X2(i, j)]) * cff;
       }
-      if (i >= Istr && j >= JstrV) {
-        const double cff1 = 0.5 * (pn[X2(i, j - 1)] + pn[X2(i, j)]) * (VFx[S2(i + 1, j)] - VFx[S2(i, j)]);
-        const double cff2 = 0.5 * (pm[X2(i, j - 1)] + pm[X2(i, j)]) * (VFe[S2(i, j)] - VFe[S2(i, j - 1)]);
-        const double fac = cff1 - cff2;
-        rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] + fac;
+    }
+    KSYNC();
+    TLOOP(i, j) {
+      if (INR(i, j, Istr, Iend + 1, Jstr, Jend + 1)) {
+        const double cff = PW(r_visc2_p, F.visc2_p[X2(i, j)]) * Drhs_p[S2(i, j)] * 0.5 *
+                           (PW(r_pmon_p, F.pmon_p[X2(i, j)]) * ((sPn[S2(i, j - 1)] + sPn[S2(i, j)]) * sVk[S2(i, j)] -
+                                                               (sPn[S2(i - 1, j - 1)] + sPn[S2(i - 1, j)]) * sVk[S2(i - 1, j)]) +
+                            PW(r_pnom_p, F.pnom_p[X2(i, j)]) * ((sPm[S2(i - 1, j)] + sPm[S2(i, j)]) * sUk[S2(i, j)] -
+                                                               (sPm[S2(i - 1, j - 1)] + sPm[S2(i, j - 1)]) * sUk[S2(i, j - 1)]));
+        UFe[S2(i, j)] = PW(r_om_p, F.om_p[X2(i, j)]) * PW(r_om_p, F.om_p[X2(i, j)]) * cff;
+        VFx[S2(i, j)] = PW(r_on_p, F.on_p[X2(i, j)]) * PW(r_on_p, F.on_p[X2(i, j)]) * cff;
+      }
+    }
+    KSYNC();
+    TLOOP(i, j) {
+      if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
+        if (i >= IstrU && j >= Jstr) {
+          const double cff1 = 0.5 * (sPn[S2(i - 1, j)] + sPn[S2(i, j)]) * (UFx[S2(i, j)] - UFx[S2(i - 1, j)]);
+          const double cff2 = 0.5 * (sPm[S2(i - 1, j)] + sPm[S2(i, j)]) * (UFe[S2(i, j + 1)] - UFe[S2(i, j)]);
+          const double fac = cff1 + cff2;
+          rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] + fac;
+        }
+        if (i >= Istr && j >= JstrV) {
+          const double cff1 = 0.5 * (sPn[S2(i, j - 1)] + sPn[S2(i, j)]) * (VFx[S2(i + 1, j)] - VFx[S2(i, j)]);
+          const double cff2 = 0.5 * (sPm[S2(i, j - 1)] + sPm[S2(i, j)]) * (VFe[S2(i, j)] - VFe[S2(i, j - 1)]);
+          const double fac = cff1 - cff2;
+          rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] + fac;
+        }
       }
     }
     KSYNC();
   }
 
   // coupling with the 3-D forcing :2225-2460, then the momentum step :2488-2670 -- point-wise
+  if (G.fuse_halo) {           // tiles of the new ubar/vbar for the epilogue fills (alias UFx, UFe: dead now)
+    TLOOP(i, j) { sUn[S2(i, j)] = SENT; sVn[S2(i, j)] = SENT; }
+    KSYNC();
+  }
   {
-    const int first = (iif == 1 && PRED);
-    const int startup = (iic == G.ntfirst) ? 0 : ((iic == G.ntfirst + 1) ? 1 : 2);
-    const double *rub_s = F.rubar + (size_t)(kstp - 1) * G.nij, *rub_p = F.rubar + (size_t)(ptsk - 1) * G.nij;
-    const double *rvb_s = F.rvbar + (size_t)(kstp - 1) * G.nij, *rvb_p = F.rvbar + (size_t)(ptsk - 1) * G.nij;
-    double *rub_k = F.rubar + (size_t)(krhs - 1) * G.nij, *rvb_k = F.rvbar + (size_t)(krhs - 1) * G.nij;
-    double *ru0_stp = F.ru + (size_t)(nstp - 1) * G.nij * (size_t)(G.N + 1);   // ru(:,:,0,nstp)
-    double *ru0_new = F.ru + (size_t)(nnew - 1) * G.nij * (size_t)(G.N + 1);
-    double *rv0_stp = F.rv + (size_t)(nstp - 1) * G.nij * (size_t)(G.N + 1);
-    double *rv0_new = F.rv + (size_t)(nnew - 1) * G.nij * (size_t)(G.N + 1);
-    const int corr = (!PRED && iif != 1);
     const double c1 = (iif == 1) ? 0.5 * dtfast : dtfast;
     const double k1 = 0.5 * dtfast * 5.0 / 12.0, k2 = 0.5 * dtfast * 8.0 / 12.0, k3 = 0.5 * dtfast * 1.0 / 12.0;
-    KLOOP2(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend) {
-      if (i >= IstrU && j >= Jstr) {
-        double r = rhs_ubar[S2(i, j)];
-        if (first) {
-          const double fr = F.rufrc[X2(i, j)] - r;
-          F.rufrc[X2(i, j)] = fr;
-          if (startup == 0) r = r + fr;
-          else if (startup == 1) r = r + 1.5 * fr - 0.5 * ru0_new[X2(i, j)];
-          else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * ru0_new[X2(i, j)] + (5.0 / 12.0) * ru0_stp[X2(i, j)];
-          ru0_stp[X2(i, j)] = fr;
-        } else {
-          r = r + F.rufrc[X2(i, j)];
+    TLOOP(i, j) {
+      if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
+        if (i >= IstrU && j >= Jstr) {
+          double r = rhs_ubar[S2(i, j)];
+          if (first) {
+            const double fr = PW(r_rufrc, F.rufrc[X2(i, j)]) - r;
+            F.rufrc[X2(i, j)] = fr;
+            if (startup == 0) r = r + fr;
+            else if (startup == 1) r = r + 1.5 * fr - 0.5 * PW(r_ru0n, ru0_new[X2(i, j)]);
+            else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * PW(r_ru0n, ru0_new[X2(i, j)]) +
+                     (5.0 / 12.0) * PW(r_ru0s, ru0_stp[X2(i, j)]);
+            ru0_stp[X2(i, j)] = fr;
+          } else {
+            r = r + PW(r_rufrc, F.rufrc[X2(i, j)]);
+          }
+          const double cff = (sPm[S2(i, j)] + sPm[S2(i - 1, j)]) * (sPn[S2(i, j)] + sPn[S2(i - 1, j)]);
+          const double fac = 1.0 / (Dnew[S2(i, j)] + Dnew[S2(i - 1, j)]);
+          const double Dstp_i = sDstp[S2(i, j)], Dstp_im = sDstp[S2(i - 1, j)];
+          double ub;
+          if (!corr) ub = (PW(r_us, us[X2(i, j)]) * (Dstp_i + Dstp_im) + cff * c1 * r) * fac;
+          else ub = (PW(r_us, us[X2(i, j)]) * (Dstp_i + Dstp_im) +
+                     cff * (k1 * r + k2 * PW(r_rub_s, rub_s[X2(i, j)]) - k3 * PW(r_rub_p, rub_p[X2(i, j)]))) * fac;
+          un[X2(i, j)] = ub;
+          sUn[S2(i, j)] = ub;
+          if (PRED) rub_k[X2(i, j)] = r;
         }
-        const double cff = (pm[X2(i, j)] + pm[X2(i - 1, j)]) * (pn[X2(i, j)] + pn[X2(i - 1, j)]);
-        const double fac = 1.0 / (Dnew[S2(i, j)] + Dnew[S2(i - 1, j)]);
-        const double Dstp_i = zs[X2(i, j)] + h[X2(i, j)], Dstp_im = zs[X2(i - 1, j)] + h[X2(i - 1, j)];
-        double ub;
-        if (!corr) ub = (us[X2(i, j)] * (Dstp_i + Dstp_im) + cff * c1 * r) * fac;
-        else ub = (us[X2(i, j)] * (Dstp_i + Dstp_im) + cff * (k1 * r + k2 * rub_s[X2(i, j)] - k3 * rub_p[X2(i, j)])) * fac;
-        un[X2(i, j)] = ub;
-        if (PRED) rub_k[X2(i, j)] = r;
-      }
-      if (i >= Istr && j >= JstrV) {
-        double r = rhs_vbar[S2(i, j)];
-        if (first) {
-          const double fr = F.rvfrc[X2(i, j)] - r;
-          F.rvfrc[X2(i, j)] = fr;
-          if (startup == 0) r = r + fr;
-          else if (startup == 1) r = r + 1.5 * fr - 0.5 * rv0_new[X2(i, j)];
-          else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * rv0_new[X2(i, j)] + (5.0 / 12.0) * rv0_stp[X2(i, j)];
-          rv0_stp[X2(i, j)] = fr;
-        } else {
-          r = r + F.rvfrc[X2(i, j)];
+        if (i >= Istr && j >= JstrV) {
+          double r = rhs_vbar[S2(i, j)];
+          if (first) {
+            const double fr = PW(r_rvfrc, F.rvfrc[X2(i, j)]) - r;
+            F.rvfrc[X2(i, j)] = fr;
+            if (startup == 0) r = r + fr;
+            else if (startup == 1) r = r + 1.5 * fr - 0.5 * PW(r_rv0n, rv0_new[X2(i, j)]);
+            else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * PW(r_rv0n, rv0_new[X2(i, j)]) +
+                     (5.0 / 12.0) * PW(r_rv0s, rv0_stp[X2(i, j)]);
+            rv0_stp[X2(i, j)] = fr;
+          } else {
+            r = r + PW(r_rvfrc, F.rvfrc[X2(i, j)]);
+          }
+          const double cff = (sPm[S2(i, j)] + sPm[S2(i, j - 1)]) * (sPn[S2(i, j)] + sPn[S2(i, j - 1)]);
+          const double fac = 1.0 / (Dnew[S2(i, j)] + Dnew[S2(i, j - 1)]);
+          const double Dstp_j = sDstp[S2(i, j)], Dstp_jm = sDstp[S2(i, j - 1)];
+          double vb;
+          if (!corr) vb = (PW(r_vs, vs[X2(i, j)]) * (Dstp_j + Dstp_jm) + cff * c1 * r) * fac;
+          else vb = (PW(r_vs, vs[X2(i, j)]) * (Dstp_j + Dstp_jm) +
+                     cff * (k1 * r + k2 * PW(r_rvb_s, rvb_s[X2(i, j)]) - k3 * PW(r_rvb_p, rvb_p[X2(i, j)]))) * fac;
+          vn[X2(i, j)] = vb;
+          sVn[S2(i, j)] = vb;
+          if (PRED) rvb_k[X2(i, j)] = r;
         }
-        const double cff = (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]);
-        const double fac = 1.0 / (Dnew[S2(i, j)] + Dnew[S2(i, j - 1)]);
-        const double Dstp_j = zs[X2(i, j)] + h[X2(i, j)], Dstp_jm = zs[X2(i, j - 1)] + h[X2(i, j - 1)];
-        double vb;
-        if (!corr) vb = (vs[X2(i, j)] * (Dstp_j + Dstp_jm) + cff * c1 * r) * fac;
-        else vb = (vs[X2(i, j)] * (Dstp_j + Dstp_jm) + cff * (k1 * r + k2 * rvb_s[X2(i, j)] - k3 * rvb_p[X2(i, j)])) * fac;
-        vn[X2(i, j)] = vb;
-        if (PRED) rvb_k[X2(i, j)] = r;
       }
     }
   }
   // zetabc :1057 + exchange :1068, rzeta exchange :1030, u2dbc/v2dbc :2871-2876 + exchange :3043
   if (G.fuse_halo) {
-    HaloBlockItems H;
-    int n = 0;
-    H.A[n] = zn; H.bc[n] = BC_R; H.gt[n] = 'r'; n++;
-    if (PRED) { H.A[n] = F.rzeta + (size_t)(krhs - 1) * G.nij; H.bc[n] = BC_NONE; H.gt[n] = 'r'; n++; }
-    H.A[n] = un; H.bc[n] = BC_U; H.gt[n] = 'u'; n++;
-    H.A[n] = vn; H.bc[n] = BC_V; H.gt[n] = 'v'; n++;
-    H.n = n;
-    halo_block(G, B, H);
+    const HbItem Iz = {zn, sZn, BC_R, 'r'}, Ir = {rz_k, sRz, BC_NONE, 'r'}, Iu = {un, sUn, BC_U, 'u'},
+                 Iv = {vn, sVn, BC_V, 'v'};
+    if (PRED) halo_block(G, B, 4, Iz, Ir, Iu, Iv);
+    else halo_block(G, B, 3, Iz, Iu, Iv, Iv);
   }
 }
-COOP_GLOBAL(k_step2d, Step2dArgs)
+COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)
+#undef TLOOP
+#undef PWDECL
+#undef PWLOAD
+#undef PW
+#undef INR

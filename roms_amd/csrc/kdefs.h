@@ -33,6 +33,7 @@ struct kdim3 { int x, y, z; };
 
 #define COOP_KERNEL(name, ArgT) static inline void name##_body(const ArgT &a, int bx, int by, int bz, double *lds)
 #define COOP_GLOBAL(name, ArgT)
+#define COOP_GLOBAL_LB(name, ArgT, maxthreads)
 #define LAUNCH_COOP(name, gx, gy, gz, nthreads, lds_doubles, stream, args)               \
   do {                                                                                   \
     std::vector<double> lds_((size_t)(lds_doubles) + 8);                                 \
@@ -58,14 +59,17 @@ struct kdim3 { int x, y, z; };
 #define KSYNC() __syncthreads()
 typedef hipStream_t kstream_t;
 
-#define COOP_KERNEL(name, ArgT) static __device__ void name##_body(const ArgT &a, int bx, int by, int bz, double *lds)
+#define COOP_KERNEL(name, ArgT) static __device__ __forceinline__ void name##_body(const ArgT &a, int bx, int by, int bz, double *lds)
 // the __global__ entry: dynamic LDS, block index -> sub-tile (with the XCD-aware remap done
 // by the body through DGrid, see roms_ctx.h:block_rect)
-#define COOP_GLOBAL(name, ArgT)                                                          \
-  static __global__ void name(const ArgT a) {                                                   \
+// All COOP launches use 256 threads unless the kernel is declared with COOP_GLOBAL_LB; telling the
+// compiler (instead of its default assumption of 1024) doubles the VGPR budget per thread.
+#define COOP_GLOBAL_LB(name, ArgT, maxthreads)                                           \
+  static __global__ void __launch_bounds__(maxthreads) name(const ArgT a) {              \
     extern __shared__ double lds_dyn_[];                                                 \
     name##_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds_dyn_);         \
   }
+#define COOP_GLOBAL(name, ArgT) COOP_GLOBAL_LB(name, ArgT, 256)
 // per-kernel HIP-event timing (roms_hip_kprof, roms_hip.cpp): mode 0 off, 1 every launch
 // (synchronous), 2 launches of one selected kernel (asynchronous event pairs)
 extern int g_kprof_mode;
@@ -82,9 +86,9 @@ void kprof_end(int slot, hipStream_t stream);
   hipLaunchKernelGGL(name, dim3((unsigned)(gx), (unsigned)(gy), (unsigned)(gz)), dim3((unsigned)(nthreads)), \
                      (size_t)(lds_doubles) * sizeof(double), stream, args))
 
-#define THREAD_KERNEL(name, ArgT) static __device__ void name##_body(const ArgT &a, int gx, int gy, int gz)
+#define THREAD_KERNEL(name, ArgT) static __device__ __forceinline__ void name##_body(const ArgT &a, int gx, int gy, int gz)
 #define THREAD_GLOBAL(name, ArgT)                                                        \
-  static __global__ void name(const ArgT a, int nx, int ny, int nz) {                           \
+  static __global__ void __launch_bounds__(256) name(const ArgT a, int nx, int ny, int nz) {    \
     int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x);                               \
     int gy = (int)(blockIdx.y * blockDim.y + threadIdx.y);                               \
     int gz = (int)blockIdx.z;                                                            \

@@ -34,6 +34,7 @@ struct DGrid {
   TB T;                       // bounds of this GPU's tile
   int nbx, nby;               // thread-block decomposition of the tile for the 3-D COOP kernels
   int bw, bh;                 // max sub-tile extent (LDS scratch is (bw+6) x (bh+6))
+  int dbg_stop;
   int fuse_halo;              // 1: single tile, COOP kernels fill boundary/periodic ghost points themselves
   int nbx2, nby2, bw2, bh2;   // the same for the 2-D (barotropic) kernel: smaller sub-tiles, the
                               // 2-D grid alone cannot fill 256 CUs otherwise

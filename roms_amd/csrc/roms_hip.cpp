@@ -109,10 +109,10 @@ static void split_tile(int LmT, int MmT, int bw, int bh, int &nbx, int &nby, int
   w = (LmT + nbx - 1) / nbx;
   h = (MmT + nby - 1) / nby;
 }
-static bool env_tile(const char *name, int &bw, int &bh) {
+static bool env_tile(const char *name, int &bw, int &bh, long maxpts) {
   const char *e = getenv(name);
   int a = 0, b = 0;
-  if (e && sscanf(e, "%dx%d", &a, &b) == 2 && a >= 4 && b >= 2 && (a + 6) * (b + 6) <= 672) { bw = a; bh = b; return true; }
+  if (e && sscanf(e, "%dx%d", &a, &b) == 2 && a >= 4 && b >= 2 && (a + 6) * (b + 6) <= (int)maxpts) { bw = a; bh = b; return true; }
   return false;
 }
 static void choose_blocks(DGrid &G) {
@@ -123,12 +123,11 @@ static void choose_blocks(DGrid &G) {
   // blocks whose phases overlap.  ROMS_HIP_TILE3D / ROMS_HIP_TILE2D ("WxH") override for tuning.
   const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
   int bw = 32, bh = 8;
-  env_tile("ROMS_HIP_TILE3D", bw, bh);
+  env_tile("ROMS_HIP_TILE3D", bw, bh, 672);              // 12 LDS arrays, 64 KB
   split_tile(LmT, MmT, bw, bh, G.nbx, G.nby, G.bw, G.bh);
-  int bw2 = 32, bh2 = 8;
-  if ((long)LmT * MmT <= 256L * 1024L) { bw2 = 16; bh2 = 8; }
-  if ((long)LmT * MmT <= 64L * 1024L) { bw2 = 16; bh2 = 4; }
-  env_tile("ROMS_HIP_TILE2D", bw2, bh2);
+  int bw2 = 32, bh2 = 6;
+  if ((long)LmT * MmT <= 64L * 1024L) { bw2 = 32; bh2 = 4; }
+  env_tile("ROMS_HIP_TILE2D", bw2, bh2, 970);             // 21 LDS arrays <= 160 KB; 2 points x 512 threads
   split_tile(LmT, MmT, bw2, bh2, G.nbx2, G.nby2, G.bw2, G.bh2);
 }
 // narrowest first/last sub-tile of a tile_bounds_2d partition of n points into nb pieces
@@ -178,6 +177,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   G.T = make_bounds(cfg->Lm, cfg->Mm, cfg->EWperiodic, cfg->NSperiodic, cfg->Istr, cfg->Iend, cfg->Jstr, cfg->Jend,
                     cfg->west_edge, cfg->east_edge, cfg->south_edge, cfg->north_edge);
   choose_blocks(G);
+  G.dbg_stop = getenv("ROMS_HIP_DBG_STOP") ? atoi(getenv("ROMS_HIP_DBG_STOP")) : 0;
   {  // producer-side halo fills need the whole domain on this GPU and edge sub-tiles that own the
      // three source lines of a periodic copy
     const int LmT = cfg->Iend - cfg->Istr + 1, MmT = cfg->Jend - cfg->Jstr + 1;
