@@ -1,5 +1,6 @@
 // g_step2d.cpp -- step2d(ng,tile): one k_step2d launch + one halo launch.
 #include "roms_host.h"
+#include <cstdlib>
 #include "k_step2d.h"
 
 int run_step2d(roms_hip_ctx *c) {
@@ -15,7 +16,11 @@ int run_step2d(roms_hip_ctx *c) {
   const size_t tile = (size_t)(G.bw2 + 6) * (size_t)(G.bh2 + 6);
   const size_t lds = (size_t)STEP2D_NLDS * tile;
   // every thread owns at most STEP2D_PTS points of the sub-tile rectangle
-  const int nthreads = tile <= 256 * STEP2D_PTS ? 256 : 512;   // launch bound of k_step2d: 512
+  // one thread per point of the sub-tile rectangle where that fits the launch bound (512): two
+  // waves per SIMD hide the LDS latency of the short dependent phases better than 2 points/thread
+  int nthreads = tile <= 512 ? (int)((tile + 63) / 64) * 64 : 512;
+  if (nthreads < 256) nthreads = 256;
+  if (getenv("ROMS_HIP_S2D_THREADS")) nthreads = atoi(getenv("ROMS_HIP_S2D_THREADS"));
 #ifndef ROMS_CPU_EMU
   static bool big_lds = false;
   if (lds * sizeof(double) > 64 * 1024 && !big_lds) {   // more than the default dynamic LDS limit

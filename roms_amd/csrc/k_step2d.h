@@ -14,8 +14,8 @@
 // that is only needed at a thread's own points (metrics, r.h.s. history, running averages) stays
 // in that thread's registers -- every sweep uses the same point -> thread mapping.  The phases then
 // touch LDS and registers only; the epilogue stores zeta/ubar/vbar(knew), the r.h.s. history and
-// the fast-time averages, and (single-tile runs) fills boundary and periodic ghost points
-// (k_haloblock.h).
+// the fast-time averages; in single-tile runs with a periodic direction every thread also stores
+// the boundary and periodic images of its values (k_haloblock.h), so no halo launch follows.
 #pragma once
 #include "roms_ctx.h"
 #include "k_haloblock.h"
@@ -27,21 +27,22 @@ struct Step2dArgs {
   double w2_0, w2_p1;  // weight(2,iif), weight(2,iif+1)
 };
 
-#define STEP2D_NLDS 21
+#define STEP2D_NLDS 19
 #define STEP2D_PTS 2      // tile points per thread: the launch uses >= tile/2 threads
 
 // Sweep over the sub-tile rectangle with a fixed point -> thread mapping.
 #ifdef ROMS_CPU_EMU
 // serial emulation: one "thread" visits all points; own-point values are read where they are used
 #define TLOOP(i, j)                                                                                                    \
-  for (int m = 0, i = 0, j = 0; m < NTILE && ((j = JT0 + m / TW), (i = IT0 + m - (m / TW) * TW), true); m++)
+  for (int m = 0, i = 0, j = 0, s0 = 0; m < NTILE && ((j = JT0 + m / TW), (i = IT0 + m - (m / TW) * TW), (s0 = m), true); m++) \
+    for (long x0 = (long)X2(i, j), once_ = 1; once_; once_ = 0)
 #define PWDECL(name)
 #define PWLOAD(name, expr) ((void)0)
 #define PW(name, expr) (expr)
 #else
 #define TLOOP(i, j)                                                                                                    \
   _Pragma("unroll") for (int m = 0; m < STEP2D_PTS; m++) if (tq[m])                                                    \
-    for (int i = ti[m], j = tj[m], once_ = 1; once_; once_ = 0)
+    for (int i = ti[m], j = tj[m], s0 = KTID + m * KNT, x0 = tx[m], once_ = 1; once_; once_ = 0)
 #define PWDECL(name) double name[STEP2D_PTS]
 #define PWLOAD(name, expr) name[m] = (expr)
 #define PW(name, expr) name[m]
@@ -62,9 +63,6 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   double *Drhs_p = grad;
   double *sUk = lds + 12 * sz, *sVk = lds + 13 * sz, *sH = lds + 14 * sz, *sPm = lds + 15 * sz, *sPn = lds + 16 * sz,
          *sRhoA = lds + 17 * sz, *sDstp = lds + 18 * sz;
-  // new values kept for the boundary/periodic fills of the epilogue (halo_block_lds)
-  double *sZn = lds + 19 * sz, *sRz = lds + 20 * sz, *sUn = UFx, *sVn = UFe;
-  double *sZt = Dnew, *sDU1 = rhs_ubar, *sDV1 = rhs_vbar;
   const int krhs = G.krhs, kstp = G.kstp, knew = G.knew, nstp = G.nstp, nnew = G.nnew, iif = G.iif, iic = G.iic;
   const bool PRED = G.predictor != 0;
   const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend, IstrU = B.IstrU, JstrV = B.JstrV;
@@ -86,6 +84,7 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   double *rv0_stp = F.rv + (size_t)(nstp - 1) * G.nij * (size_t)(G.N + 1);
   double *rv0_new = F.rv + (size_t)(nnew - 1) * G.nij * (size_t)(G.N + 1);
   const bool last = iif > G.nfast;                 // auxiliary last predictor call :883
+  const bool fuse = G.fuse_halo != 0, fuse_last = fuse && last && PRED;
   const int first = (iif == 1 && PRED);
   const int corr = (!PRED && iif != 1);
   const int startup = (iic == G.ntfirst) ? 0 : ((iic == G.ntfirst + 1) ? 1 : 2);
@@ -94,7 +93,7 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   const int IT0 = Istr - 3, JT0 = Jstr - 3, TW = Iend - Istr + 7, TH = Jend - Jstr + 7, NTILE = TW * TH;
   const int UBi = G.LBi + G.ni - 1, UBj = G.LBj + G.nj - 1;
 #ifndef ROMS_CPU_EMU
-  int ti[STEP2D_PTS], tj[STEP2D_PTS];
+  int ti[STEP2D_PTS], tj[STEP2D_PTS], tx[STEP2D_PTS];   // point, and its offset in the global 2-D arrays
   bool tq[STEP2D_PTS];
 #pragma unroll
   for (int m = 0; m < STEP2D_PTS; m++) {
@@ -102,6 +101,7 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     tq[m] = q < NTILE;
     tj[m] = JT0 + q / TW;
     ti[m] = IT0 + q - (q / TW) * TW;
+    tx[m] = (ti[m] - G.LBi) + (tj[m] - G.LBj) * G.ni;   // may lie outside the array for masked points
   }
 #endif
   PWDECL(r_zk); PWDECL(r_zs); PWDECL(r_on_u); PWDECL(r_om_v); PWDECL(r_rhoS); PWDECL(r_fomn); PWDECL(r_dndx);
@@ -113,50 +113,45 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   PWDECL(r_ru0n); PWDECL(r_ru0s); PWDECL(r_rv0n); PWDECL(r_rv0s); PWDECL(r_us); PWDECL(r_vs);
 
   // ---- prologue: every global read of the kernel -------------------------------------------
-  const double SENT = hb_sentinel();
   TLOOP(i, j) {
-    const size_t s = S2(i, j);
-    sZn[s] = SENT; sRz[s] = SENT;
-    if (last) { sZt[s] = SENT; sDU1[s] = SENT; sDV1[s] = SENT; }
     if (INR(i, j, G.LBi, UBi, G.LBj, UBj)) {
       // each array is read only as far from the sub-tile as some phase below needs it
       const bool ring2 = INR(i, j, Istr - 2, Iend + 2, Jstr - 2, Jend + 2);
       const bool ring1 = INR(i, j, Istr - 1, Iend + 1, Jstr - 1, Jend + 1);
       const bool own = INR(i, j, Istr, Iend, Jstr, Jend);
-      const size_t x = X2(i, j);
-      const double zkv = zk[x], hv = F.h[x];
-      Drhs[s] = zkv + hv;                                    // total depth :600
-      sUk[s] = uk[x]; sVk[s] = vk[x]; sH[s] = hv;
+      const double zkv = zk[x0], hv = F.h[x0];
+      Drhs[s0] = zkv + hv;                                    // total depth :600
+      sUk[s0] = uk[x0]; sVk[s0] = vk[x0]; sH[s0] = hv;
       PWLOAD(r_zk, zkv);
-      PWLOAD(r_on_u, F.on_u[x]); PWLOAD(r_om_v, F.om_v[x]);
-      if (ring2) { sPm[s] = F.pm[x]; sPn[s] = F.pn[x]; }
+      PWLOAD(r_on_u, F.on_u[x0]); PWLOAD(r_om_v, F.om_v[x0]);
+      if (ring2) { sPm[s0] = F.pm[x0]; sPn[s0] = F.pn[x0]; }
       if (ring1) {
-        const double zsv = zs[x];
-        sDstp[s] = zsv + hv;
+        const double zsv = zs[x0];
+        sDstp[s0] = zsv + hv;
         PWLOAD(r_zs, zsv);
-        sRhoA[s] = F.rhoA[x];
-        PWLOAD(r_Zt, F.Zt_avg1[x]); PWLOAD(r_DU1, F.DU_avg1[x]); PWLOAD(r_DU2, F.DU_avg2[x]);
-        PWLOAD(r_DV1, F.DV_avg1[x]); PWLOAD(r_DV2, F.DV_avg2[x]);
+        sRhoA[s0] = F.rhoA[x0];
+        PWLOAD(r_Zt, F.Zt_avg1[x0]); PWLOAD(r_DU1, F.DU_avg1[x0]); PWLOAD(r_DU2, F.DU_avg2[x0]);
+        PWLOAD(r_DV1, F.DV_avg1[x0]); PWLOAD(r_DV2, F.DV_avg2[x0]);
         if (!last) {
-          PWLOAD(r_rhoS, F.rhoS[x]); PWLOAD(r_fomn, F.fomn[x]); PWLOAD(r_dndx, F.dndx[x]); PWLOAD(r_dmde, F.dmde[x]);
-          PWLOAD(r_visc2_r, F.visc2_r[x]); PWLOAD(r_pmon_r, F.pmon_r[x]); PWLOAD(r_pnom_r, F.pnom_r[x]);
-          PWLOAD(r_on_r, F.on_r[x]); PWLOAD(r_om_r, F.om_r[x]);
-          PWLOAD(r_visc2_p, F.visc2_p[x]); PWLOAD(r_pmon_p, F.pmon_p[x]); PWLOAD(r_pnom_p, F.pnom_p[x]);
-          PWLOAD(r_om_p, F.om_p[x]); PWLOAD(r_on_p, F.on_p[x]);
-          if (corr) { PWLOAD(r_rz_s, rz_s[x]); PWLOAD(r_rz_p, rz_p[x]); }
+          PWLOAD(r_rhoS, F.rhoS[x0]); PWLOAD(r_fomn, F.fomn[x0]); PWLOAD(r_dndx, F.dndx[x0]); PWLOAD(r_dmde, F.dmde[x0]);
+          PWLOAD(r_visc2_r, F.visc2_r[x0]); PWLOAD(r_pmon_r, F.pmon_r[x0]); PWLOAD(r_pnom_r, F.pnom_r[x0]);
+          PWLOAD(r_on_r, F.on_r[x0]); PWLOAD(r_om_r, F.om_r[x0]);
+          PWLOAD(r_visc2_p, F.visc2_p[x0]); PWLOAD(r_pmon_p, F.pmon_p[x0]); PWLOAD(r_pnom_p, F.pnom_p[x0]);
+          PWLOAD(r_om_p, F.om_p[x0]); PWLOAD(r_on_p, F.on_p[x0]);
+          if (corr) { PWLOAD(r_rz_s, rz_s[x0]); PWLOAD(r_rz_p, rz_p[x0]); }
         }
       }
       if (own && !last) {
-        PWLOAD(r_us, us[x]); PWLOAD(r_vs, vs[x]);
-        PWLOAD(r_rufrc, F.rufrc[x]); PWLOAD(r_rvfrc, F.rvfrc[x]);
+        PWLOAD(r_us, us[x0]); PWLOAD(r_vs, vs[x0]);
+        PWLOAD(r_rufrc, F.rufrc[x0]); PWLOAD(r_rvfrc, F.rvfrc[x0]);
         if (corr) {
-          PWLOAD(r_rub_s, rub_s[x]); PWLOAD(r_rub_p, rub_p[x]); PWLOAD(r_rvb_s, rvb_s[x]); PWLOAD(r_rvb_p, rvb_p[x]);
+          PWLOAD(r_rub_s, rub_s[x0]); PWLOAD(r_rub_p, rub_p[x0]); PWLOAD(r_rvb_s, rvb_s[x0]); PWLOAD(r_rvb_p, rvb_p[x0]);
         }
-        if (first && startup >= 1) { PWLOAD(r_ru0n, ru0_new[x]); PWLOAD(r_rv0n, rv0_new[x]); }
-        if (first && startup >= 2) { PWLOAD(r_ru0s, ru0_stp[x]); PWLOAD(r_rv0s, rv0_stp[x]); }
+        if (first && startup >= 1) { PWLOAD(r_ru0n, ru0_new[x0]); PWLOAD(r_rv0n, rv0_new[x0]); }
+        if (first && startup >= 2) { PWLOAD(r_ru0s, ru0_stp[x0]); PWLOAD(r_rv0s, rv0_stp[x0]); }
       }
     } else {
-      Drhs[s] = 0.0; sDstp[s] = 0.0; sUk[s] = 0.0; sVk[s] = 0.0; sH[s] = 0.0; sPm[s] = 0.0; sPn[s] = 0.0; sRhoA[s] = 0.0;
+      Drhs[s0] = 0.0; sDstp[s0] = 0.0; sUk[s0] = 0.0; sVk[s0] = 0.0; sH[s0] = 0.0; sPm[s0] = 0.0; sPn[s0] = 0.0; sRhoA[s0] = 0.0;
     }
   }
   KSYNC();
@@ -165,14 +160,14 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   TLOOP(i, j) {
     if (INR(i, j, B.IstrUm2 - 1, B.Iendp2, B.JstrVm2 - 1, B.Jendp2)) {
       if (i >= B.IstrUm2) {
-        const double cff = 0.5 * PW(r_on_u, F.on_u[X2(i, j)]);
-        const double cff1 = cff * (Drhs[S2(i, j)] + Drhs[S2(i - 1, j)]);
-        DUon[S2(i, j)] = sUk[S2(i, j)] * cff1;
+        const double cff = 0.5 * PW(r_on_u, F.on_u[x0]);
+        const double cff1 = cff * (Drhs[s0] + Drhs[(s0 - 1)]);
+        DUon[s0] = sUk[s0] * cff1;
       }
       if (j >= B.JstrVm2) {
-        const double cff = 0.5 * PW(r_om_v, F.om_v[X2(i, j)]);
-        const double cff1 = cff * (Drhs[S2(i, j)] + Drhs[S2(i, j - 1)]);
-        DVom[S2(i, j)] = sVk[S2(i, j)] * cff1;
+        const double cff = 0.5 * PW(r_om_v, F.om_v[x0]);
+        const double cff1 = cff * (Drhs[s0] + Drhs[(s0 - TW)]);
+        DVom[s0] = sVk[s0] * cff1;
       }
     }
   }
@@ -184,14 +179,14 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
       const double cff2 = (-1.0 / 12.0) * a.w2_p1;
       TLOOP(i, j) {
         if (INR(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR)) {
-          if (i >= IstrR && j >= JstrR) F.Zt_avg1[X2(i, j)] = 0.0;
+          if (i >= IstrR && j >= JstrR) F.Zt_avg1[x0] = 0.0;
           if (i >= Istr && j >= JstrR) {
-            F.DU_avg1[X2(i, j)] = 0.0;
-            F.DU_avg2[X2(i, j)] = cff2 * DUon[S2(i, j)];
+            F.DU_avg1[x0] = 0.0;
+            F.DU_avg2[x0] = cff2 * DUon[s0];
           }
           if (i >= IstrR && j >= Jstr) {
-            F.DV_avg1[X2(i, j)] = 0.0;
-            F.DV_avg2[X2(i, j)] = cff2 * DVom[S2(i, j)];
+            F.DV_avg1[x0] = 0.0;
+            F.DV_avg2[x0] = cff2 * DVom[s0];
           }
         }
       }
@@ -201,21 +196,21 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
       TLOOP(i, j) {
         if (INR(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR)) {
           if (i >= IstrR && j >= JstrR) {
-            const double v = PW(r_Zt, F.Zt_avg1[X2(i, j)]) + cff1 * PW(r_zk, zk[X2(i, j)]);
-            F.Zt_avg1[X2(i, j)] = v;
-            if (last) sZt[S2(i, j)] = v;
+            const double v = PW(r_Zt, F.Zt_avg1[x0]) + cff1 * PW(r_zk, zk[x0]);
+            if (fuse_last) hb_emit(G, B, F.Zt_avg1, BC_NONE, i, j, v);   // final averages: exchange :821-883
+            else F.Zt_avg1[x0] = v;
           }
           if (i >= Istr && j >= JstrR) {
-            const double v = PW(r_DU1, F.DU_avg1[X2(i, j)]) + cff1 * DUon[S2(i, j)];
-            F.DU_avg1[X2(i, j)] = v;
-            if (last) sDU1[S2(i, j)] = v;
-            F.DU_avg2[X2(i, j)] = PW(r_DU2, F.DU_avg2[X2(i, j)]) + cff2 * DUon[S2(i, j)];
+            const double v = PW(r_DU1, F.DU_avg1[x0]) + cff1 * DUon[s0];
+            if (fuse_last) hb_emit(G, B, F.DU_avg1, BC_NONE, i, j, v);
+            else F.DU_avg1[x0] = v;
+            F.DU_avg2[x0] = PW(r_DU2, F.DU_avg2[x0]) + cff2 * DUon[s0];
           }
           if (i >= IstrR && j >= Jstr) {
-            const double v = PW(r_DV1, F.DV_avg1[X2(i, j)]) + cff1 * DVom[S2(i, j)];
-            F.DV_avg1[X2(i, j)] = v;
-            if (last) sDV1[S2(i, j)] = v;
-            F.DV_avg2[X2(i, j)] = PW(r_DV2, F.DV_avg2[X2(i, j)]) + cff2 * DVom[S2(i, j)];
+            const double v = PW(r_DV1, F.DV_avg1[x0]) + cff1 * DVom[s0];
+            if (fuse_last) hb_emit(G, B, F.DV_avg1, BC_NONE, i, j, v);
+            else F.DV_avg1[x0] = v;
+            F.DV_avg2[x0] = PW(r_DV2, F.DV_avg2[x0]) + cff2 * DVom[s0];
           }
         }
       }
@@ -224,19 +219,12 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     const double cff2 = (iif == 1) ? a.w2_0 : (5.0 / 12.0) * a.w2_0;
     TLOOP(i, j) {
       if (INR(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR)) {
-        if (i >= Istr && j >= JstrR) F.DU_avg2[X2(i, j)] = PW(r_DU2, F.DU_avg2[X2(i, j)]) + cff2 * DUon[S2(i, j)];
-        if (i >= IstrR && j >= Jstr) F.DV_avg2[X2(i, j)] = PW(r_DV2, F.DV_avg2[X2(i, j)]) + cff2 * DVom[S2(i, j)];
+        if (i >= Istr && j >= JstrR) F.DU_avg2[x0] = PW(r_DU2, F.DU_avg2[x0]) + cff2 * DUon[s0];
+        if (i >= IstrR && j >= Jstr) F.DV_avg2[x0] = PW(r_DV2, F.DV_avg2[x0]) + cff2 * DVom[s0];
       }
     }
   }
-  if (last) {                  // auxiliary last predictor call :883 (uniform over the grid)
-    if (G.fuse_halo && PRED) { // final fast-time averages: exchange :821-883
-      const HbItem I0 = {F.Zt_avg1, sZt, BC_NONE, 'r'}, I1 = {F.DU_avg1, sDU1, BC_NONE, 'u'},
-                   I2 = {F.DV_avg1, sDV1, BC_NONE, 'v'};
-      halo_block(G, B, 3, I0, I1, I2, I2);
-    }
-    return;
-  }
+  if (last) return;            // auxiliary last predictor call :883 (uniform over the grid)
 
   // free-surface step :886-1000
   {
@@ -248,32 +236,36 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     else { mode = 2; cff1 = dtfast * 5.0 / 12.0; cff2 = dtfast * 8.0 / 12.0; cff3 = dtfast * 1.0 / 12.0; cff4 = 2.0 / 5.0; cff5 = 1.0 - cff4; }
     TLOOP(i, j) {
       if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
-        const size_t s = S2(i, j);
-        const double rhs_zeta = (DUon[s] - DUon[S2(i + 1, j)]) + (DVom[s] - DVom[S2(i, j + 1)]);
-        const double zsv = PW(r_zs, zs[X2(i, j)]), zkv = PW(r_zk, zk[X2(i, j)]);
+            const double rhs_zeta = (DUon[s0] - DUon[(s0 + 1)]) + (DVom[s0] - DVom[(s0 + TW)]);
+        const double zsv = PW(r_zs, zs[x0]), zkv = PW(r_zk, zk[x0]);
         double zeta_new, zw;
         if (mode == 0) {
-          zeta_new = zsv + sPm[s] * sPn[s] * cff1 * rhs_zeta;
+          zeta_new = zsv + sPm[s0] * sPn[s0] * cff1 * rhs_zeta;
           zw = 0.5 * (zsv + zeta_new);
         } else if (mode == 1) {
-          zeta_new = zsv + sPm[s] * sPn[s] * cff1 * rhs_zeta;
+          zeta_new = zsv + sPm[s0] * sPn[s0] * cff1 * rhs_zeta;
           zw = cff5 * zkv + cff4 * (zsv + zeta_new);
         } else {
           const double cff = cff1 * rhs_zeta;
-          zeta_new = zsv + sPm[s] * sPn[s] * (cff + cff2 * PW(r_rz_s, rz_s[X2(i, j)]) - cff3 * PW(r_rz_p, rz_p[X2(i, j)]));
+          zeta_new = zsv + sPm[s0] * sPn[s0] * (cff + cff2 * PW(r_rz_s, rz_s[x0]) - cff3 * PW(r_rz_p, rz_p[x0]));
           zw = cff5 * zeta_new + cff4 * zkv;
         }
-        const double rhoSv = PW(r_rhoS, F.rhoS[X2(i, j)]);
-        Dnew[s] = zeta_new + sH[s];
-        zwrk[s] = zw;
+        const double rhoSv = PW(r_rhoS, F.rhoS[x0]);
+        Dnew[s0] = zeta_new + sH[s0];
+        zwrk[s0] = zw;
         const double gz = (fac + rhoSv) * zw;
-        gzeta[s] = gz;
-        gzeta2[s] = gz * zw;
-        gzetaSA[s] = zw * (rhoSv - sRhoA[s]);
+        gzeta[s0] = gz;
+        gzeta2[s0] = gz * zw;
+        gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (i >= Istr && j >= Jstr) {
-          zn[X2(i, j)] = zeta_new;
-          sZn[s] = zeta_new;
-          if (PRED) { rz_k[X2(i, j)] = rhs_zeta; sRz[s] = rhs_zeta; }
+          // zetabc :1057 + exchange :1068, rzeta exchange :1030
+          if (fuse) {
+            hb_emit(G, B, zn, BC_R, i, j, zeta_new);
+            if (PRED) hb_emit(G, B, rz_k, BC_NONE, i, j, rhs_zeta);
+          } else {
+            zn[x0] = zeta_new;
+            if (PRED) rz_k[x0] = rhs_zeta;
+          }
         }
       }
     }
@@ -286,21 +278,21 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     TLOOP(i, j) {
       if (INR(i, j, KMIN(IstrU, Istr), Iend, Jstr, Jend)) {
         if (i >= IstrU)
-          rhs_ubar[S2(i, j)] =
-              cff1 * PW(r_on_u, F.on_u[X2(i, j)]) *
-              ((sH[S2(i - 1, j)] + sH[S2(i, j)]) * (gzeta[S2(i - 1, j)] - gzeta[S2(i, j)]) +
-               (sH[S2(i - 1, j)] - sH[S2(i, j)]) *
-                   (gzetaSA[S2(i - 1, j)] + gzetaSA[S2(i, j)] +
-                    cff2 * (sRhoA[S2(i - 1, j)] - sRhoA[S2(i, j)]) * (zwrk[S2(i - 1, j)] - zwrk[S2(i, j)])) +
-               (gzeta2[S2(i - 1, j)] - gzeta2[S2(i, j)]));
+          rhs_ubar[s0] =
+              cff1 * PW(r_on_u, F.on_u[x0]) *
+              ((sH[(s0 - 1)] + sH[s0]) * (gzeta[(s0 - 1)] - gzeta[s0]) +
+               (sH[(s0 - 1)] - sH[s0]) *
+                   (gzetaSA[(s0 - 1)] + gzetaSA[s0] +
+                    cff2 * (sRhoA[(s0 - 1)] - sRhoA[s0]) * (zwrk[(s0 - 1)] - zwrk[s0])) +
+               (gzeta2[(s0 - 1)] - gzeta2[s0]));
         if (j >= JstrV)
-          rhs_vbar[S2(i, j)] =
-              cff1 * PW(r_om_v, F.om_v[X2(i, j)]) *
-              ((sH[S2(i, j - 1)] + sH[S2(i, j)]) * (gzeta[S2(i, j - 1)] - gzeta[S2(i, j)]) +
-               (sH[S2(i, j - 1)] - sH[S2(i, j)]) *
-                   (gzetaSA[S2(i, j - 1)] + gzetaSA[S2(i, j)] +
-                    cff2 * (sRhoA[S2(i, j - 1)] - sRhoA[S2(i, j)]) * (zwrk[S2(i, j - 1)] - zwrk[S2(i, j)])) +
-               (gzeta2[S2(i, j - 1)] - gzeta2[S2(i, j)]));
+          rhs_vbar[s0] =
+              cff1 * PW(r_om_v, F.om_v[x0]) *
+              ((sH[(s0 - TW)] + sH[s0]) * (gzeta[(s0 - TW)] - gzeta[s0]) +
+               (sH[(s0 - TW)] - sH[s0]) *
+                   (gzetaSA[(s0 - TW)] + gzetaSA[s0] +
+                    cff2 * (sRhoA[(s0 - TW)] - sRhoA[s0]) * (zwrk[(s0 - TW)] - zwrk[s0])) +
+               (gzeta2[(s0 - TW)] - gzeta2[s0]));
       }
     }
   }
@@ -311,8 +303,8 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     // ---- UFx :1249-1290
     TLOOP(i, j) {
       if (INR(i, j, B.IstrUm1, B.Iendp1, Jstr, Jend)) {
-        grad[S2(i, j)] = sUk[S2(i - 1, j)] - 2.0 * sUk[S2(i, j)] + sUk[S2(i + 1, j)];
-        Dgrad[S2(i, j)] = DUon[S2(i - 1, j)] - 2.0 * DUon[S2(i, j)] + DUon[S2(i + 1, j)];
+        grad[s0] = sUk[(s0 - 1)] - 2.0 * sUk[s0] + sUk[(s0 + 1)];
+        Dgrad[s0] = DUon[(s0 - 1)] - 2.0 * DUon[s0] + DUon[(s0 + 1)];
       }
     }
     KSYNC();
@@ -323,16 +315,16 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     }
     TLOOP(i, j) {
       if (INR(i, j, IstrU - 1, Iend, Jstr, Jend))
-        UFx[S2(i, j)] = 0.25 * (sUk[S2(i, j)] + sUk[S2(i + 1, j)] - cff * (grad[S2(i, j)] + grad[S2(i + 1, j)])) *
-                        (DUon[S2(i, j)] + DUon[S2(i + 1, j)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i + 1, j)]));
+        UFx[s0] = 0.25 * (sUk[s0] + sUk[(s0 + 1)] - cff * (grad[s0] + grad[(s0 + 1)])) *
+                        (DUon[s0] + DUon[(s0 + 1)] - cff * (Dgrad[s0] + Dgrad[(s0 + 1)]));
     }
     KSYNC();
     // ---- UFe :1292-1330
     TLOOP(i, j) {
       if (INR(i, j, IstrU, Iend, B.Jstrm1, B.Jendp1))
-        grad[S2(i, j)] = sUk[S2(i, j - 1)] - 2.0 * sUk[S2(i, j)] + sUk[S2(i, j + 1)];
+        grad[s0] = sUk[(s0 - TW)] - 2.0 * sUk[s0] + sUk[(s0 + TW)];
       if (INR(i, j, IstrU - 1, Iend, Jstr, Jend + 1))
-        Dgrad[S2(i, j)] = DVom[S2(i - 1, j)] - 2.0 * DVom[S2(i, j)] + DVom[S2(i + 1, j)];
+        Dgrad[s0] = DVom[(s0 - 1)] - 2.0 * DVom[s0] + DVom[(s0 + 1)];
     }
     KSYNC();
     if (!G.nsp) {
@@ -342,26 +334,26 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     }
     TLOOP(i, j) {
       if (INR(i, j, IstrU, Iend, Jstr, Jend + 1))
-        UFe[S2(i, j)] = 0.25 * (sUk[S2(i, j)] + sUk[S2(i, j - 1)] - cff * (grad[S2(i, j)] + grad[S2(i, j - 1)])) *
-                        (DVom[S2(i, j)] + DVom[S2(i - 1, j)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i - 1, j)]));
+        UFe[s0] = 0.25 * (sUk[s0] + sUk[(s0 - TW)] - cff * (grad[s0] + grad[(s0 - TW)])) *
+                        (DVom[s0] + DVom[(s0 - 1)] - cff * (Dgrad[s0] + Dgrad[(s0 - 1)]));
     }
     KSYNC();
     // u-momentum advection r.h.s. (UFx,UFe complete)
     TLOOP(i, j) {
       if (INR(i, j, IstrU, Iend, Jstr, Jend)) {
-        const double cff1 = UFx[S2(i, j)] - UFx[S2(i - 1, j)];
-        const double cff2 = UFe[S2(i, j + 1)] - UFe[S2(i, j)];
+        const double cff1 = UFx[s0] - UFx[(s0 - 1)];
+        const double cff2 = UFe[(s0 + TW)] - UFe[s0];
         const double fac = cff1 + cff2;
-        rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] - fac;
+        rhs_ubar[s0] = rhs_ubar[s0] - fac;
       }
     }
     KSYNC();
     // ---- VFx :1332-1370
     TLOOP(i, j) {
       if (INR(i, j, B.Istrm1, B.Iendp1, JstrV, Jend))
-        grad[S2(i, j)] = sVk[S2(i - 1, j)] - 2.0 * sVk[S2(i, j)] + sVk[S2(i + 1, j)];
+        grad[s0] = sVk[(s0 - 1)] - 2.0 * sVk[s0] + sVk[(s0 + 1)];
       if (INR(i, j, Istr, Iend + 1, JstrV - 1, Jend))
-        Dgrad[S2(i, j)] = DUon[S2(i, j - 1)] - 2.0 * DUon[S2(i, j)] + DUon[S2(i, j + 1)];
+        Dgrad[s0] = DUon[(s0 - TW)] - 2.0 * DUon[s0] + DUon[(s0 + TW)];
     }
     KSYNC();
     if (!G.ewp) {
@@ -371,15 +363,15 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     }
     TLOOP(i, j) {
       if (INR(i, j, Istr, Iend + 1, JstrV, Jend))
-        VFx[S2(i, j)] = 0.25 * (sVk[S2(i, j)] + sVk[S2(i - 1, j)] - cff * (grad[S2(i, j)] + grad[S2(i - 1, j)])) *
-                        (DUon[S2(i, j)] + DUon[S2(i, j - 1)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i, j - 1)]));
+        VFx[s0] = 0.25 * (sVk[s0] + sVk[(s0 - 1)] - cff * (grad[s0] + grad[(s0 - 1)])) *
+                        (DUon[s0] + DUon[(s0 - TW)] - cff * (Dgrad[s0] + Dgrad[(s0 - TW)]));
     }
     KSYNC();
     // ---- VFe :1372-1410
     TLOOP(i, j) {
       if (INR(i, j, Istr, Iend, B.JstrVm1, B.Jendp1)) {
-        grad[S2(i, j)] = sVk[S2(i, j - 1)] - 2.0 * sVk[S2(i, j)] + sVk[S2(i, j + 1)];
-        Dgrad[S2(i, j)] = DVom[S2(i, j - 1)] - 2.0 * DVom[S2(i, j)] + DVom[S2(i, j + 1)];
+        grad[s0] = sVk[(s0 - TW)] - 2.0 * sVk[s0] + sVk[(s0 + TW)];
+        Dgrad[s0] = DVom[(s0 - TW)] - 2.0 * DVom[s0] + DVom[(s0 + TW)];
       }
     }
     KSYNC();
@@ -390,16 +382,16 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     }
     TLOOP(i, j) {
       if (INR(i, j, Istr, Iend, JstrV - 1, Jend))
-        VFe[S2(i, j)] = 0.25 * (sVk[S2(i, j)] + sVk[S2(i, j + 1)] - cff * (grad[S2(i, j)] + grad[S2(i, j + 1)])) *
-                        (DVom[S2(i, j)] + DVom[S2(i, j + 1)] - cff * (Dgrad[S2(i, j)] + Dgrad[S2(i, j + 1)]));
+        VFe[s0] = 0.25 * (sVk[s0] + sVk[(s0 + TW)] - cff * (grad[s0] + grad[(s0 + TW)])) *
+                        (DVom[s0] + DVom[(s0 + TW)] - cff * (Dgrad[s0] + Dgrad[(s0 + TW)]));
     }
     KSYNC();
     TLOOP(i, j) {
       if (INR(i, j, Istr, Iend, JstrV, Jend)) {
-        const double cff1 = VFx[S2(i + 1, j)] - VFx[S2(i, j)];
-        const double cff2 = VFe[S2(i, j)] - VFe[S2(i, j - 1)];
+        const double cff1 = VFx[(s0 + 1)] - VFx[s0];
+        const double cff2 = VFe[s0] - VFe[(s0 - TW)];
         const double fac = cff1 + cff2;
-        rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] - fac;
+        rhs_vbar[s0] = rhs_vbar[s0] - fac;
       }
     }
     KSYNC();
@@ -409,21 +401,21 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     // Coriolis :1429-1490
     TLOOP(i, j) {
       if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
-        const double cff = 0.5 * Drhs[S2(i, j)] * PW(r_fomn, F.fomn[X2(i, j)]);
-        UFx[S2(i, j)] = cff * (sVk[S2(i, j)] + sVk[S2(i, j + 1)]);
-        VFe[S2(i, j)] = cff * (sUk[S2(i, j)] + sUk[S2(i + 1, j)]);
+        const double cff = 0.5 * Drhs[s0] * PW(r_fomn, F.fomn[x0]);
+        UFx[s0] = cff * (sVk[s0] + sVk[(s0 + TW)]);
+        VFe[s0] = cff * (sUk[s0] + sUk[(s0 + 1)]);
       }
     }
     KSYNC();
     TLOOP(i, j) {
       if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
         if (i >= IstrU && j >= Jstr) {
-          const double fac1 = 0.5 * (UFx[S2(i, j)] + UFx[S2(i - 1, j)]);
-          rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] + fac1;
+          const double fac1 = 0.5 * (UFx[s0] + UFx[(s0 - 1)]);
+          rhs_ubar[s0] = rhs_ubar[s0] + fac1;
         }
         if (i >= Istr && j >= JstrV) {
-          const double fac1 = 0.5 * (VFe[S2(i, j)] + VFe[S2(i, j - 1)]);
-          rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] - fac1;
+          const double fac1 = 0.5 * (VFe[s0] + VFe[(s0 - TW)]);
+          rhs_vbar[s0] = rhs_vbar[s0] - fac1;
         }
       }
     }
@@ -434,25 +426,25 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     // curvilinear metric terms :1494-1560
     TLOOP(i, j) {
       if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
-        const double cff1 = 0.5 * (sVk[S2(i, j)] + sVk[S2(i, j + 1)]);
-        const double cff2 = 0.5 * (sUk[S2(i, j)] + sUk[S2(i + 1, j)]);
-        const double cff3 = cff1 * PW(r_dndx, F.dndx[X2(i, j)]);
-        const double cff4 = cff2 * PW(r_dmde, F.dmde[X2(i, j)]);
-        const double cff = Drhs[S2(i, j)] * (cff3 - cff4);
-        UFx[S2(i, j)] = cff * cff1;
-        VFe[S2(i, j)] = cff * cff2;
+        const double cff1 = 0.5 * (sVk[s0] + sVk[(s0 + TW)]);
+        const double cff2 = 0.5 * (sUk[s0] + sUk[(s0 + 1)]);
+        const double cff3 = cff1 * PW(r_dndx, F.dndx[x0]);
+        const double cff4 = cff2 * PW(r_dmde, F.dmde[x0]);
+        const double cff = Drhs[s0] * (cff3 - cff4);
+        UFx[s0] = cff * cff1;
+        VFe[s0] = cff * cff2;
       }
     }
     KSYNC();
     TLOOP(i, j) {
       if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
         if (i >= IstrU && j >= Jstr) {
-          const double fac1 = 0.5 * (UFx[S2(i, j)] + UFx[S2(i - 1, j)]);
-          rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] + fac1;
+          const double fac1 = 0.5 * (UFx[s0] + UFx[(s0 - 1)]);
+          rhs_ubar[s0] = rhs_ubar[s0] + fac1;
         }
         if (i >= Istr && j >= JstrV) {
-          const double fac1 = 0.5 * (VFe[S2(i, j)] + VFe[S2(i, j - 1)]);
-          rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] - fac1;
+          const double fac1 = 0.5 * (VFe[s0] + VFe[(s0 - TW)]);
+          rhs_vbar[s0] = rhs_vbar[s0] - fac1;
         }
       }
     }
@@ -463,43 +455,43 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     // harmonic viscosity :1567-1660
     TLOOP(i, j) {
       if (INR(i, j, Istr, Iend + 1, Jstr, Jend + 1))
-        Drhs_p[S2(i, j)] = 0.25 * (Drhs[S2(i, j)] + Drhs[S2(i - 1, j)] + Drhs[S2(i, j - 1)] + Drhs[S2(i - 1, j - 1)]);
+        Drhs_p[s0] = 0.25 * (Drhs[s0] + Drhs[(s0 - 1)] + Drhs[(s0 - TW)] + Drhs[(s0 - 1 - TW)]);
       if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
-        const double cff = PW(r_visc2_r, F.visc2_r[X2(i, j)]) * Drhs[S2(i, j)] * 0.5 *
-                           (PW(r_pmon_r, F.pmon_r[X2(i, j)]) * ((sPn[S2(i, j)] + sPn[S2(i + 1, j)]) * sUk[S2(i + 1, j)] -
-                                                               (sPn[S2(i - 1, j)] + sPn[S2(i, j)]) * sUk[S2(i, j)]) -
-                            PW(r_pnom_r, F.pnom_r[X2(i, j)]) * ((sPm[S2(i, j)] + sPm[S2(i, j + 1)]) * sVk[S2(i, j + 1)] -
-                                                               (sPm[S2(i, j - 1)] + sPm[S2(i, j)]) * sVk[S2(i, j)]));
-        UFx[S2(i, j)] = PW(r_on_r, F.on_r[X2(i, j)]) * PW(r_on_r, F.on_r[X2(i, j)]) * cff;
-        VFe[S2(i, j)] = PW(r_om_r, F.om_r[X2(i, j)]) * PW(r_om_r, F.om_r[X2(i, j)]) * cff;
+        const double cff = PW(r_visc2_r, F.visc2_r[x0]) * Drhs[s0] * 0.5 *
+                           (PW(r_pmon_r, F.pmon_r[x0]) * ((sPn[s0] + sPn[(s0 + 1)]) * sUk[(s0 + 1)] -
+                                                               (sPn[(s0 - 1)] + sPn[s0]) * sUk[s0]) -
+                            PW(r_pnom_r, F.pnom_r[x0]) * ((sPm[s0] + sPm[(s0 + TW)]) * sVk[(s0 + TW)] -
+                                                               (sPm[(s0 - TW)] + sPm[s0]) * sVk[s0]));
+        UFx[s0] = PW(r_on_r, F.on_r[x0]) * PW(r_on_r, F.on_r[x0]) * cff;
+        VFe[s0] = PW(r_om_r, F.om_r[x0]) * PW(r_om_r, F.om_r[x0]) * cff;
       }
     }
     KSYNC();
     TLOOP(i, j) {
       if (INR(i, j, Istr, Iend + 1, Jstr, Jend + 1)) {
-        const double cff = PW(r_visc2_p, F.visc2_p[X2(i, j)]) * Drhs_p[S2(i, j)] * 0.5 *
-                           (PW(r_pmon_p, F.pmon_p[X2(i, j)]) * ((sPn[S2(i, j - 1)] + sPn[S2(i, j)]) * sVk[S2(i, j)] -
-                                                               (sPn[S2(i - 1, j - 1)] + sPn[S2(i - 1, j)]) * sVk[S2(i - 1, j)]) +
-                            PW(r_pnom_p, F.pnom_p[X2(i, j)]) * ((sPm[S2(i - 1, j)] + sPm[S2(i, j)]) * sUk[S2(i, j)] -
-                                                               (sPm[S2(i - 1, j - 1)] + sPm[S2(i, j - 1)]) * sUk[S2(i, j - 1)]));
-        UFe[S2(i, j)] = PW(r_om_p, F.om_p[X2(i, j)]) * PW(r_om_p, F.om_p[X2(i, j)]) * cff;
-        VFx[S2(i, j)] = PW(r_on_p, F.on_p[X2(i, j)]) * PW(r_on_p, F.on_p[X2(i, j)]) * cff;
+        const double cff = PW(r_visc2_p, F.visc2_p[x0]) * Drhs_p[s0] * 0.5 *
+                           (PW(r_pmon_p, F.pmon_p[x0]) * ((sPn[(s0 - TW)] + sPn[s0]) * sVk[s0] -
+                                                               (sPn[(s0 - 1 - TW)] + sPn[(s0 - 1)]) * sVk[(s0 - 1)]) +
+                            PW(r_pnom_p, F.pnom_p[x0]) * ((sPm[(s0 - 1)] + sPm[s0]) * sUk[s0] -
+                                                               (sPm[(s0 - 1 - TW)] + sPm[(s0 - TW)]) * sUk[(s0 - TW)]));
+        UFe[s0] = PW(r_om_p, F.om_p[x0]) * PW(r_om_p, F.om_p[x0]) * cff;
+        VFx[s0] = PW(r_on_p, F.on_p[x0]) * PW(r_on_p, F.on_p[x0]) * cff;
       }
     }
     KSYNC();
     TLOOP(i, j) {
       if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
         if (i >= IstrU && j >= Jstr) {
-          const double cff1 = 0.5 * (sPn[S2(i - 1, j)] + sPn[S2(i, j)]) * (UFx[S2(i, j)] - UFx[S2(i - 1, j)]);
-          const double cff2 = 0.5 * (sPm[S2(i - 1, j)] + sPm[S2(i, j)]) * (UFe[S2(i, j + 1)] - UFe[S2(i, j)]);
+          const double cff1 = 0.5 * (sPn[(s0 - 1)] + sPn[s0]) * (UFx[s0] - UFx[(s0 - 1)]);
+          const double cff2 = 0.5 * (sPm[(s0 - 1)] + sPm[s0]) * (UFe[(s0 + TW)] - UFe[s0]);
           const double fac = cff1 + cff2;
-          rhs_ubar[S2(i, j)] = rhs_ubar[S2(i, j)] + fac;
+          rhs_ubar[s0] = rhs_ubar[s0] + fac;
         }
         if (i >= Istr && j >= JstrV) {
-          const double cff1 = 0.5 * (sPn[S2(i, j - 1)] + sPn[S2(i, j)]) * (VFx[S2(i + 1, j)] - VFx[S2(i, j)]);
-          const double cff2 = 0.5 * (sPm[S2(i, j - 1)] + sPm[S2(i, j)]) * (VFe[S2(i, j)] - VFe[S2(i, j - 1)]);
+          const double cff1 = 0.5 * (sPn[(s0 - TW)] + sPn[s0]) * (VFx[(s0 + 1)] - VFx[s0]);
+          const double cff2 = 0.5 * (sPm[(s0 - TW)] + sPm[s0]) * (VFe[s0] - VFe[(s0 - TW)]);
           const double fac = cff1 - cff2;
-          rhs_vbar[S2(i, j)] = rhs_vbar[S2(i, j)] + fac;
+          rhs_vbar[s0] = rhs_vbar[s0] + fac;
         }
       }
     }
@@ -507,72 +499,61 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   }
 
   // coupling with the 3-D forcing :2225-2460, then the momentum step :2488-2670 -- point-wise
-  if (G.fuse_halo) {           // tiles of the new ubar/vbar for the epilogue fills (alias UFx, UFe: dead now)
-    TLOOP(i, j) { sUn[S2(i, j)] = SENT; sVn[S2(i, j)] = SENT; }
-    KSYNC();
-  }
   {
     const double c1 = (iif == 1) ? 0.5 * dtfast : dtfast;
     const double k1 = 0.5 * dtfast * 5.0 / 12.0, k2 = 0.5 * dtfast * 8.0 / 12.0, k3 = 0.5 * dtfast * 1.0 / 12.0;
     TLOOP(i, j) {
       if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
         if (i >= IstrU && j >= Jstr) {
-          double r = rhs_ubar[S2(i, j)];
+          double r = rhs_ubar[s0];
           if (first) {
-            const double fr = PW(r_rufrc, F.rufrc[X2(i, j)]) - r;
-            F.rufrc[X2(i, j)] = fr;
+            const double fr = PW(r_rufrc, F.rufrc[x0]) - r;
+            F.rufrc[x0] = fr;
             if (startup == 0) r = r + fr;
-            else if (startup == 1) r = r + 1.5 * fr - 0.5 * PW(r_ru0n, ru0_new[X2(i, j)]);
-            else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * PW(r_ru0n, ru0_new[X2(i, j)]) +
-                     (5.0 / 12.0) * PW(r_ru0s, ru0_stp[X2(i, j)]);
-            ru0_stp[X2(i, j)] = fr;
+            else if (startup == 1) r = r + 1.5 * fr - 0.5 * PW(r_ru0n, ru0_new[x0]);
+            else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * PW(r_ru0n, ru0_new[x0]) +
+                     (5.0 / 12.0) * PW(r_ru0s, ru0_stp[x0]);
+            ru0_stp[x0] = fr;
           } else {
-            r = r + PW(r_rufrc, F.rufrc[X2(i, j)]);
+            r = r + PW(r_rufrc, F.rufrc[x0]);
           }
-          const double cff = (sPm[S2(i, j)] + sPm[S2(i - 1, j)]) * (sPn[S2(i, j)] + sPn[S2(i - 1, j)]);
-          const double fac = 1.0 / (Dnew[S2(i, j)] + Dnew[S2(i - 1, j)]);
-          const double Dstp_i = sDstp[S2(i, j)], Dstp_im = sDstp[S2(i - 1, j)];
+          const double cff = (sPm[s0] + sPm[(s0 - 1)]) * (sPn[s0] + sPn[(s0 - 1)]);
+          const double fac = 1.0 / (Dnew[s0] + Dnew[(s0 - 1)]);
+          const double Dstp_i = sDstp[s0], Dstp_im = sDstp[(s0 - 1)];
           double ub;
-          if (!corr) ub = (PW(r_us, us[X2(i, j)]) * (Dstp_i + Dstp_im) + cff * c1 * r) * fac;
-          else ub = (PW(r_us, us[X2(i, j)]) * (Dstp_i + Dstp_im) +
-                     cff * (k1 * r + k2 * PW(r_rub_s, rub_s[X2(i, j)]) - k3 * PW(r_rub_p, rub_p[X2(i, j)]))) * fac;
-          un[X2(i, j)] = ub;
-          sUn[S2(i, j)] = ub;
-          if (PRED) rub_k[X2(i, j)] = r;
+          if (!corr) ub = (PW(r_us, us[x0]) * (Dstp_i + Dstp_im) + cff * c1 * r) * fac;
+          else ub = (PW(r_us, us[x0]) * (Dstp_i + Dstp_im) +
+                     cff * (k1 * r + k2 * PW(r_rub_s, rub_s[x0]) - k3 * PW(r_rub_p, rub_p[x0]))) * fac;
+          if (fuse) hb_emit(G, B, un, BC_U, i, j, ub);   // u2dbc :2871 + exchange :3043
+          else un[x0] = ub;
+          if (PRED) rub_k[x0] = r;
         }
         if (i >= Istr && j >= JstrV) {
-          double r = rhs_vbar[S2(i, j)];
+          double r = rhs_vbar[s0];
           if (first) {
-            const double fr = PW(r_rvfrc, F.rvfrc[X2(i, j)]) - r;
-            F.rvfrc[X2(i, j)] = fr;
+            const double fr = PW(r_rvfrc, F.rvfrc[x0]) - r;
+            F.rvfrc[x0] = fr;
             if (startup == 0) r = r + fr;
-            else if (startup == 1) r = r + 1.5 * fr - 0.5 * PW(r_rv0n, rv0_new[X2(i, j)]);
-            else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * PW(r_rv0n, rv0_new[X2(i, j)]) +
-                     (5.0 / 12.0) * PW(r_rv0s, rv0_stp[X2(i, j)]);
-            rv0_stp[X2(i, j)] = fr;
+            else if (startup == 1) r = r + 1.5 * fr - 0.5 * PW(r_rv0n, rv0_new[x0]);
+            else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * PW(r_rv0n, rv0_new[x0]) +
+                     (5.0 / 12.0) * PW(r_rv0s, rv0_stp[x0]);
+            rv0_stp[x0] = fr;
           } else {
-            r = r + PW(r_rvfrc, F.rvfrc[X2(i, j)]);
+            r = r + PW(r_rvfrc, F.rvfrc[x0]);
           }
-          const double cff = (sPm[S2(i, j)] + sPm[S2(i, j - 1)]) * (sPn[S2(i, j)] + sPn[S2(i, j - 1)]);
-          const double fac = 1.0 / (Dnew[S2(i, j)] + Dnew[S2(i, j - 1)]);
-          const double Dstp_j = sDstp[S2(i, j)], Dstp_jm = sDstp[S2(i, j - 1)];
+          const double cff = (sPm[s0] + sPm[(s0 - TW)]) * (sPn[s0] + sPn[(s0 - TW)]);
+          const double fac = 1.0 / (Dnew[s0] + Dnew[(s0 - TW)]);
+          const double Dstp_j = sDstp[s0], Dstp_jm = sDstp[(s0 - TW)];
           double vb;
-          if (!corr) vb = (PW(r_vs, vs[X2(i, j)]) * (Dstp_j + Dstp_jm) + cff * c1 * r) * fac;
-          else vb = (PW(r_vs, vs[X2(i, j)]) * (Dstp_j + Dstp_jm) +
-                     cff * (k1 * r + k2 * PW(r_rvb_s, rvb_s[X2(i, j)]) - k3 * PW(r_rvb_p, rvb_p[X2(i, j)]))) * fac;
-          vn[X2(i, j)] = vb;
-          sVn[S2(i, j)] = vb;
-          if (PRED) rvb_k[X2(i, j)] = r;
+          if (!corr) vb = (PW(r_vs, vs[x0]) * (Dstp_j + Dstp_jm) + cff * c1 * r) * fac;
+          else vb = (PW(r_vs, vs[x0]) * (Dstp_j + Dstp_jm) +
+                     cff * (k1 * r + k2 * PW(r_rvb_s, rvb_s[x0]) - k3 * PW(r_rvb_p, rvb_p[x0]))) * fac;
+          if (fuse) hb_emit(G, B, vn, BC_V, i, j, vb);   // v2dbc :2876 + exchange :3043
+          else vn[x0] = vb;
+          if (PRED) rvb_k[x0] = r;
         }
       }
     }
-  }
-  // zetabc :1057 + exchange :1068, rzeta exchange :1030, u2dbc/v2dbc :2871-2876 + exchange :3043
-  if (G.fuse_halo) {
-    const HbItem Iz = {zn, sZn, BC_R, 'r'}, Ir = {rz_k, sRz, BC_NONE, 'r'}, Iu = {un, sUn, BC_U, 'u'},
-                 Iv = {vn, sVn, BC_V, 'v'};
-    if (PRED) halo_block(G, B, 4, Iz, Ir, Iu, Iv);
-    else halo_block(G, B, 3, Iz, Iu, Iv, Iv);
   }
 }
 COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)

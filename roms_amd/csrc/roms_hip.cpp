@@ -127,7 +127,7 @@ static void choose_blocks(DGrid &G) {
   split_tile(LmT, MmT, bw, bh, G.nbx, G.nby, G.bw, G.bh);
   int bw2 = 32, bh2 = 6;
   if ((long)LmT * MmT <= 64L * 1024L) { bw2 = 32; bh2 = 4; }
-  env_tile("ROMS_HIP_TILE2D", bw2, bh2, 970);             // 21 LDS arrays <= 160 KB; 2 points x 512 threads
+  env_tile("ROMS_HIP_TILE2D", bw2, bh2, 1024);            // 19 LDS arrays < 160 KB; 2 points x 512 threads
   split_tile(LmT, MmT, bw2, bh2, G.nbx2, G.nby2, G.bw2, G.bh2);
 }
 // narrowest first/last sub-tile of a tile_bounds_2d partition of n points into nb pieces
@@ -182,7 +182,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
      // three source lines of a periodic copy
     const int LmT = cfg->Iend - cfg->Istr + 1, MmT = cfg->Jend - cfg->Jstr + 1;
     const char *e = getenv("ROMS_HIP_FUSE_HALO");
-    G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && edge_subtile(LmT, G.nbx2) >= 3 && edge_subtile(MmT, G.nby2) >= 3 &&
+    G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && (cfg->EWperiodic || cfg->NSperiodic) && LmT >= 6 && MmT >= 6 &&
                   !(e && e[0] == '0');
   }
   G.ntfirst = cfg->ntfirst; G.nfast = cfg->nfast;
