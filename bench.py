@@ -37,36 +37,40 @@ WORKLOADS = {
     "upwelling": ("upwelling", 41, 80, 16),
 }
 
-# Algorithmic HBM bytes per launch of each hot kernel, as (3-D arrays read+written per cell,
-# 2-D arrays per column) -- each distinct input array read once, each output written once, f64.
-# Derivation per kernel: DESIGN.md "Kernels and rooflines".  P = horizontal points, N = levels.
+# Algorithmic HBM traffic per launch of each kernel, in "words per cell": the number of distinct full
+# 3-D f64 arrays the launch must read or write once (read-modify-write = 2; NT=2 tracers; perfect reuse
+# inside the kernel, none across kernels -- SURVEY.md 8(d)'s unit), plus the 2-D arrays per column.
+# The per-kernel derivation is the table "Kernels and rooflines" in DESIGN.md.
 ALGO_ARRAYS = {
-    #                3-D  2-D
-    "k_step2d":     (0, 58),
-    "k_rhs3d_h":    (9, 10),
-    "k_rhs3d_v":    (7, 6),
-    "k_pre_t3h":    (6, 6),
-    "k_pre_t3v":    (6, 2),
-    "k_pre_new":    (5, 2),
-    "k_s3t_h":      (6, 6),
-    "k_s3t_col":    (5, 2),
-    "k_s3uv_col":   (9, 10),
-    "k_s3uv_couple": (6, 12),
-    "k_t3dmix2_geo": (7, 8),
-    "k_t3dmix2_s":  (4, 8),
-    "k_uv3dmix2_s": (7, 12),
-    "k_prs_P":      (4, 0),
-    "k_prs_grad":   (6, 4),
-    "k_eos_nl":     (9, 3),
-    "k_lmd_interior": (9, 2),
-    "k_lmd_skpp":   (12, 12),
-    "k_lmd_finish": (8, 4),
-    "k_omega":      (3, 2),
-    "k_set_depth":  (3, 3),
-    "k_set_massflux": (5, 4),
+    #                  3-D  2-D
+    "k_step2d":       (0, 44),
+    "k_pre_t3h":      (7, 2),
+    "k_pre_t3v":      (10, 2),
+    "k_pre_new":      (19, 9),
+    "k_prs_P":        (3, 0),
+    "k_prs_grad":     (6, 2),
+    "k_t3dmix2_s":    (7, 5),
+    "k_t3dmix2_geo":  (8, 5),
+    "k_uv3dmix2_s":   (11, 12),
+    "k_uv3dmix2_sum": (4, 4),
+    "k_rhs3d_h":      (9, 3),
+    "k_rhs3d_v":      (7, 10),
+    "k_s3uv_col":     (8, 6),
+    "k_s3uv_couple":  (9, 8),
+    "k_s3t_h":        (8, 2),
+    "k_s3t_col":      (11, 2),
+    "k_omega":        (4, 0),
+    "k_eos_nl":       (8, 4),
+    "k_rho_eos_lin":  (5, 2),
+    "k_lmd_interior": (9, 0),
+    "k_lmd_skpp":     (17, 10),
+    "k_lmd_finish":   (7, 0),
+    "k_set_depth":    (3, 2),
+    "k_set_massflux": (5, 2),
+    "k_diag_col":     (7, 3),
+    "k_wvel_vert":    (4, 2),
+    "k_wvel":         (5, 4),
 }
-# kernels launched once per tracer (block z / launch carries itrc): bytes above are per tracer
-PER_TRACER = {"k_pre_t3h", "k_pre_t3v", "k_pre_new", "k_s3t_h", "k_s3t_col", "k_t3dmix2_geo", "k_t3dmix2_s"}
 
 
 def algo_bytes(kernel, Lm, Mm, N, launches_per_step_hint=None):
@@ -75,6 +79,24 @@ def algo_bytes(kernel, Lm, Mm, N, launches_per_step_hint=None):
     a3, a2 = ALGO_ARRAYS[kernel]
     P = Lm * Mm
     return 8.0 * P * (a3 * N + a2)
+
+
+def pmc_traffic(workload, kernel, world):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json,
+    written by tools/summarize_profiles.py: FETCH_SIZE + WRITE_SIZE, corrected with the calibration
+    factors measured on k_copy_probe as the MI355X guide prescribes).  None if no profile of this
+    workload is committed."""
+    import glob
+    if world != 1:
+        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == workload and kernel in d.get("kernels", {}):
+            return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    return None
 
 
 def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
@@ -127,6 +149,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--breakdown-file", default=None, help="write the per-kernel table (JSON) here")
+    ap.add_argument("--copy-probe", action="store_true",
+                    help="also time the library's streaming-copy kernel on this workload's 3-D arrays")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -210,6 +234,10 @@ def main():
                         "avg_launch_us": avg * 1e6, "launches": launches,
                         "algorithmic_bytes_per_launch": nb}
 
+    copy_gbs = run.ctx.copy_probe() if args.copy_probe else None
+    if roofline is not None:
+        roofline["measured_copy_GBs"] = copy_gbs
+        roofline["traffic"] = pmc_traffic(args.workload, dominant, world)
     run.check()                              # blow-up test of the last diagnostics (exit_flag)
     out = None
     if rank == 0:

@@ -178,6 +178,11 @@ int roms_hip_comm_rccl(roms_hip_ctx *ctx, const void *id128, int nranks, int ran
 /* number of halo exchanges performed so far (0 for a single-tile context) */
 long roms_hip_exchange_count(roms_hip_ctx *ctx);
 
+/* measurement aid: `reps` launches of a plain streaming copy (kernel k_copy_probe) between two 3-D
+   work arrays; *bytes_per_launch = bytes read + written by one launch.  Timed by the caller with
+   roms_hip_kprof: the measured HBM ceiling quoted next to the roofline fractions. */
+int roms_hip_copy_probe(roms_hip_ctx *ctx, int reps, long *bytes_per_launch);
+
 /* per-kernel device timing with HIP events on the library's stream (process-wide table):
    mode 0 off; 1 = every launch, synchronous (breakdown pass); 2 = only launches of `kernel`,
    asynchronous event pairs resolved when the table is read (usable inside a timed region).

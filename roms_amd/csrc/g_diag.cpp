@@ -9,7 +9,7 @@ int run_diag_async(roms_hip_ctx *c, double *d_out) {
   const TB &B = G.T;
   DiagArgs a;
   a.G = G;
-  a.F = c->F;
+  a.Fp = c->d_F;
   a.col = c->F.wrk3[0];                 // free at this point of the step (vert of wvelocity)
   a.row = c->F.wrk3[0] + 9 * (size_t)G.nij;
   a.out = d_out;

@@ -8,7 +8,7 @@
 static inline KArgs mk(roms_hip_ctx *c, int p0 = 0, int p1 = 0, int p2 = 0) {
   KArgs a;
   a.G = c->G;
-  a.F = c->F;
+  a.Fp = c->d_F;
   a.p0 = p0; a.p1 = p1; a.p2 = p2;
   return a;
 }
@@ -163,5 +163,15 @@ int run_ini_fields(roms_hip_ctx *c) {
     for (int it = 1; it <= c->G.NT; it++) ht[it - 1] = HaloSpec{t_lev(c, nstp, it), N, BC_R, 'r'};   // t3dbc + exchange
     launch_halo_multi(c, ht, c->G.NT);
   }
+  return 0;
+}
+
+// copy `planes` horizontal planes wrk3[1] -> wrk3[2] `reps` times; the caller times it (kprof / events)
+int run_copy_probe(roms_hip_ctx *c, int reps) {
+  CopyArgs a;
+  a.src = c->F.wrk3[1];
+  a.dst = c->F.wrk3[2];
+  a.n = (long)c->G.nij * (long)(c->G.N + 1);
+  for (int r = 0; r < reps; r++) LAUNCH_THREAD(k_copy_probe, 64 * 4096, 1, 1, c->stream, a);
   return 0;
 }

@@ -8,7 +8,7 @@ int run_step2d(roms_hip_ctx *c) {
   const roms_hip_config &cf = c->cfg;
   Step2dArgs a;
   a.G = G;
-  a.F = c->F;
+  a.Fp = c->d_F;
   const int iif = G.iif;
   a.w1_m1 = (iif >= 2) ? cf.weight[0][iif - 1] : 0.0;
   a.w2_0 = cf.weight[1][iif];

@@ -5,7 +5,7 @@
 static inline KArgs mk(roms_hip_ctx *c, int p0 = 0) {
   KArgs a;
   a.G = c->G;
-  a.F = c->F;
+  a.Fp = c->d_F;
   a.p0 = p0; a.p1 = 0; a.p2 = 0;
   return a;
 }

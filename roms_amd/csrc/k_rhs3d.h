@@ -101,7 +101,7 @@ KDEV void hadv_flux_lds(const DGrid &G, const TB &B, int scheme, const double *T
 // pre_step3d: t(3) = Hz*(cff1*t(nstp)+cff2*t(nnew)) - cff*pm*pn*div(FX,FE); grid.z = (k-1)+N*(itrc-1)
 COOP_KERNEL(k_pre_t3h, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB B = block_bounds(G, bx, by);
   const int k = bz % G.N + 1, itrc = bz / G.N + 1;
   const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
@@ -180,7 +180,7 @@ KDEV void vspline_flux(const DGrid &G, const Fields &F, int i, int j, const doub
 // pre_step3d vertical part: one thread per column and tracer; index space (Istr:Iend,Jstr:Jend,NT)
 THREAD_KERNEL(k_pre_t3v, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = G.N;
   const int vs = G.vadv[itrc - 1];
   const double *T = F.t + XT(G.LBi, G.LBj, 1, G.nstp, itrc);
@@ -212,7 +212,7 @@ THREAD_GLOBAL(k_pre_t3v, KArgs)
 // index space (min(Istr,IstrU):Iend, Jstr:Jend, 1:N); F.wrk3[5] = swdk when SOLAR_SOURCE
 THREAD_KERNEL(k_pre_new, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, N = G.N;
   const int nstp = G.nstp, nnew = G.nnew, nrhs = G.nrhs, indx = 3 - G.nrhs;
@@ -313,7 +313,7 @@ THREAD_GLOBAL(k_pre_new, KArgs)
 THREAD_KERNEL(k_prs_P, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const int i = G.T.IstrU - 1 + gx, j = G.T.JstrV - 1 + gy, N = G.N;
   const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0, eps = 1.0E-10;
   const double g = G.g, GRho = g / G.rho0, HalfGRho = 0.5 * GRho;
@@ -353,7 +353,7 @@ THREAD_GLOBAL(k_prs_P, KArgs)
 // ru,rv(nrhs) from P: point-wise 3-D; index space (min(IstrU,Istr):Iend, min(Jstr,JstrV):Jend, 1:N)
 THREAD_KERNEL(k_prs_grad, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, nrhs = G.nrhs;
   const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0, eps = 1.0E-10;
@@ -409,7 +409,7 @@ THREAD_GLOBAL(k_prs_grad, KArgs)
 // point-wise 3-D; index space (Istr:Iend, Jstr:Jend, N*NT)
 THREAD_KERNEL(k_t3dmix2_s, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz % G.N + 1, itrc = gz / G.N + 1;
   const int nrhs = G.nrhs, nnew = G.nnew;
   const double *Hz = F.Hz, *diff2 = F.diff2;
@@ -434,7 +434,7 @@ THREAD_GLOBAL(k_t3dmix2_s, KArgs)
 // accumulates rufrc inside its k loop, uv3dmix2_s.h:226-262).
 THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, N = G.N, nrhs = G.nrhs, nnew = G.nnew;
   const double *pm = F.pm, *pn = F.pn, *Hz = F.Hz;
@@ -491,7 +491,7 @@ THREAD_GLOBAL(k_uv3dmix2_s, KArgs)
 THREAD_KERNEL(k_uv3dmix2_sum, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N;
   if (i >= B.IstrU) {
@@ -513,7 +513,7 @@ THREAD_GLOBAL(k_uv3dmix2_sum, KArgs)
 #define RHS3D_NLDS 8
 COOP_KERNEL(k_rhs3d_h, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB B = block_bounds(G, bx, by);
   const int k = bz + 1, nrhs = G.nrhs, N = G.N;
   const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
@@ -641,7 +641,7 @@ COOP_GLOBAL(k_rhs3d_h, KArgs)
 THREAD_KERNEL(k_rhs3d_v, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs;
   const double *u = F.u + (size_t)(nrhs - 1) * G.nij * N, *v = F.v + (size_t)(nrhs - 1) * G.nij * N, *W = F.W;

@@ -22,7 +22,7 @@
 
 struct Step2dArgs {
   DGrid G;
-  Fields F;
+  const Fields *Fp;   // device-resident table of array pointers (roms_hip_ctx::d_F)
   double w1_m1;        // weight(1,iif-1)
   double w2_0, w2_p1;  // weight(2,iif), weight(2,iif+1)
 };
@@ -52,7 +52,7 @@ struct Step2dArgs {
 COOP_KERNEL(k_step2d, Step2dArgs) {
   (void)bz;
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB B = block_bounds2(G, bx, by);
   const size_t sz = (size_t)(G.bw2 + 6) * (size_t)(G.bh2 + 6);
   double *Drhs = lds, *DUon = lds + sz, *DVom = lds + 2 * sz, *Dnew = lds + 3 * sz, *rhs_ubar = lds + 4 * sz,

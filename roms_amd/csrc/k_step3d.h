@@ -19,7 +19,7 @@
 // grid.z = 0: u on (IstrU:Iend, Jstr:Jend); 1: v on (Istr:Iend, JstrV:Jend)
 THREAD_KERNEL(k_s3uv_col, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB &B = G.T;
   const int dir = gz;
   const int i = (dir == 0 ? B.IstrU : B.Istr) + gx, j = (dir == 0 ? B.Jstr : B.JstrV) + gy;
@@ -89,7 +89,7 @@ THREAD_GLOBAL(k_s3uv_col, KArgs)
 // grid.z = 0: u part on (IstrP:IendT, JstrT:JendT); 1: v part on (IstrT:IendT, Jstr:JendT)
 THREAD_KERNEL(k_s3uv_couple, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB &B = G.T;
   const int dir = gz;
   const int i = (dir == 0 ? B.IstrP : B.IstrT) + gx, j = (dir == 0 ? B.JstrT : B.Jstr) + gy;
@@ -161,7 +161,7 @@ KDEV double hsimt_lim(double grad, double gradu, double Ka, double Kau, double o
 #define S3T_NLDS 4
 COOP_KERNEL(k_s3t_h, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const TB B = block_bounds(G, bx, by);
   const int k = bz % G.N + 1, itrc = bz / G.N + 1;
   const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
@@ -236,7 +236,7 @@ COOP_GLOBAL(k_s3t_h, KArgs)
 // index space (Istr:Iend, Jstr:Jend, NT).  (MPDATA tracers are handled in k_mpdata.h.)
 THREAD_KERNEL(k_s3t_col, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = a.F;
+  const Fields &F = *a.Fp;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = G.N;
   const int vs = G.vadv[itrc - 1], ltrc = KMIN(G.NAT, itrc);
   const double dt = G.dt, eps1 = 1.0E-12;

@@ -230,6 +230,17 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     c->allocs.push_back(p);
     c->F.wrk2[k] = (double *)p;
   }
+  {  // pointer table for the kernels
+#ifdef ROMS_CPU_EMU
+    c->d_F = &c->F;
+#else
+    void *p = nullptr;
+    if (dmalloc(&p, sizeof(Fields))) { roms_hip_destroy(c); return 2; }
+    c->allocs.push_back(p);
+    c->d_F = (Fields *)p;
+    if (h2d(c->d_F, &c->F, sizeof(Fields), c->stream)) { roms_hip_destroy(c); return 2; }
+#endif
+  }
   // s-coordinate tables
   if (h2d(c->F.sc_r, cfg->sc_r, sizeof(double) * (size_t)G.N, c->stream) ||
       h2d(c->F.Cs_r, cfg->Cs_r, sizeof(double) * (size_t)G.N, c->stream) ||
@@ -244,6 +255,11 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     c->d_diag = (double *)p;
     c->h_diag = (double *)calloc(16 * (size_t)(G.nj + 8), sizeof(double));
   }
+#ifndef ROMS_CPU_EMU
+  // the zero fills above ran on the null stream; the context's stream is non-blocking and would
+  // not wait for them
+  if (hipfail(hipDeviceSynchronize(), "hipDeviceSynchronize")) { roms_hip_destroy(c); return 2; }
+#endif
   memset(&c->s, 0, sizeof(c->s));
   c->s.iif = 1; c->s.indx1 = 1; c->s.kstp = 1; c->s.krhs = 1; c->s.knew = 1;
   c->s.nstp = 1; c->s.nrhs = 1; c->s.nnew = 1;
@@ -525,6 +541,9 @@ static int exchange_phase(roms_hip_ctx *c, const HaloArgs &h, int planes, int ph
       if (dmalloc(&p, need * sizeof(double)) || dmalloc(&q, need * sizeof(double))) return 2;
       m.sbuf[k] = (double *)p; m.rbuf[k] = (double *)q;
     }
+#ifndef ROMS_CPU_EMU
+    (void)hipDeviceSynchronize();   // zero fills of the new buffers (null stream) before use on c->stream
+#endif
     m.cap = need;
   }
   const long n_lo_out = (long)((size_t)planes * lines * (size_t)G.Nghost);   // my first Nghost lines -> low neighbour
@@ -624,6 +643,12 @@ extern "C" int roms_hip_rhs3d(roms_hip_ctx *c) {
   if ((r = roms_hip_t3dmix2(c))) return r;
   if ((r = roms_hip_rhs3d_tile(c))) return r;
   return roms_hip_uv3dmix2(c);
+}
+extern "C" int roms_hip_copy_probe(roms_hip_ctx *c, int reps, long *bytes_per_launch) {
+  if (!c) return 8;
+  if (bytes_per_launch) *bytes_per_launch = 2L * 8L * (long)c->G.nij * (long)(c->G.N + 1);   // read + write
+  int r = run_copy_probe(c, reps);
+  return r ? r : ctx_check(c, "copy_probe");
 }
 extern "C" int roms_hip_diag(roms_hip_ctx *c, double *out) {
   RegionTimer rt(c, 7);

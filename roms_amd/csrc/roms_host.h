@@ -36,7 +36,9 @@ struct roms_hip_ctx {
   TileComm comm;
   bool comm_failed;             // a halo exchange failed (reported by the next ctx_check)
   DGrid G;
-  Fields F;
+  Fields F;                     // host copy of the pointer table
+  Fields *d_F;                  // the same table in device memory: kernels take it by pointer, which
+                                // keeps the by-value kernel arguments small
   kstream_t stream;
   std::vector<void *> allocs;
   roms_hip_stepping s;
@@ -90,6 +92,7 @@ int run_step3d_t(roms_hip_ctx *c);
 int run_lmd_vmix(roms_hip_ctx *c);
 int run_bulk_flux(roms_hip_ctx *c);
 int run_diag(roms_hip_ctx *c, double *out);
+int run_copy_probe(roms_hip_ctx *c, int reps);
 
 // pointer helpers for time levels
 static inline double *t_lev(roms_hip_ctx *c, int n, int itrc) {

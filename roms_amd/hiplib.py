@@ -56,7 +56,7 @@ EXPORTS = ["roms_hip_create", "roms_hip_destroy", "roms_hip_last_error", "roms_h
            "roms_hip_set_stepping", "roms_hip_get_stepping", "roms_hip_wvelocity", "roms_hip_diag",
            "roms_hip_start", "roms_hip_main3d", "roms_hip_profile", "roms_hip_region_seconds",
            "roms_hip_kprof", "roms_hip_kprof_get", "roms_hip_kprof_stride", "roms_hip_set_exchange", "roms_hip_rccl_unique_id",
-           "roms_hip_comm_rccl", "roms_hip_exchange_count"] + \
+           "roms_hip_comm_rccl", "roms_hip_exchange_count", "roms_hip_copy_probe"] + \
           ["roms_hip_" + k for k in KERNELS]
 
 
@@ -98,6 +98,7 @@ def load(path=None):
     L.roms_hip_comm_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.roms_hip_exchange_count.argtypes = [C.c_void_p]
     L.roms_hip_exchange_count.restype = C.c_long
+    L.roms_hip_copy_probe.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_long)]
     L.roms_hip_kprof.argtypes = [C.c_int, C.c_char_p]
     L.roms_hip_kprof_get.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     for k in KERNELS:
@@ -200,6 +201,18 @@ class Context:
         out = (C.c_double * 16)()
         self._ck(self.L.roms_hip_diag(self.h, out))
         return list(out) if raw else list(out)[:12]
+
+    def copy_probe(self, reps=20):
+        """Measured streaming-copy bandwidth in GB/s (read + write bytes / time) of k_copy_probe."""
+        nb = C.c_long()
+        self._ck(self.L.roms_hip_copy_probe(self.h, 3, C.byref(nb)))      # warm-up
+        self.sync()
+        kprof(1)
+        self._ck(self.L.roms_hip_copy_probe(self.h, reps, C.byref(nb)))
+        self.sync()
+        sec, n = kprof_table().get("k_copy_probe", (0.0, 0))
+        kprof(0)
+        return nb.value * n / sec / 1e9 if sec > 0 else None
 
     def profile(self, enable=True):
         self._ck(self.L.roms_hip_profile(self.h, int(enable)))
