@@ -95,7 +95,7 @@ def pmc_traffic(workload, kernel, world):
         except (OSError, ValueError):
             continue
         if d.get("workload") == workload and kernel in d.get("kernels", {}):
-            return d["kernels"][kernel]["hbm_bytes_per_launch"]
+            return d["kernels"][kernel].get("hbm_bytes_per_launch")
     return None
 
 

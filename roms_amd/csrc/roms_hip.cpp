@@ -31,7 +31,11 @@ static int hipfail(hipError_t e, const char *what) {
 static int dmalloc(void **p, size_t bytes) {
   int r = hipfail(hipMalloc(p, bytes ? bytes : 8), "hipMalloc");
   if (r) return r;
-  return hipfail(hipMemset(*p, 0, bytes ? bytes : 8), "hipMemset");
+  // The fill runs asynchronously on the null stream, which the contexts' non-blocking streams do
+  // not wait for: finish it here, or it may land after a later upload into the same buffer.
+  r = hipfail(hipMemset(*p, 0, bytes ? bytes : 8), "hipMemset");
+  if (r) return r;
+  return hipfail(hipDeviceSynchronize(), "hipDeviceSynchronize");
 }
 static void dfree(void *p) { (void)hipFree(p); }
 static int h2d(void *d, const void *h, size_t bytes, kstream_t s) {
@@ -125,7 +129,7 @@ static void choose_blocks(DGrid &G) {
   int bw = 32, bh = 8;
   env_tile("ROMS_HIP_TILE3D", bw, bh, 672);              // 12 LDS arrays, 64 KB
   split_tile(LmT, MmT, bw, bh, G.nbx, G.nby, G.bw, G.bh);
-  int bw2 = 32, bh2 = 6;
+  int bw2 = 64, bh2 = 8;   // measured best of 32x6..64x8 on 1024x128, 2048x256 and 512x512 grids
   if ((long)LmT * MmT <= 64L * 1024L) { bw2 = 32; bh2 = 4; }
   env_tile("ROMS_HIP_TILE2D", bw2, bh2, 1024);            // 19 LDS arrays < 160 KB; 2 points x 512 threads
   split_tile(LmT, MmT, bw2, bh2, G.nbx2, G.nby2, G.bw2, G.bh2);
@@ -398,6 +402,8 @@ int kprof_begin(const char *name, hipStream_t stream) {
     if (strcmp(name, g_kselect)) return -1;
     if (g_kcount++ % g_kstride) return -1;     // sample every g_kstride-th launch of the selected kernel
   }
+  static const bool trace = getenv("ROMS_HIP_TRACE") != nullptr;   // debugging aid: name every launch
+  if (trace) { fprintf(stderr, "launch %s\n", name); fflush(stderr); }
   int slot = kslot_of(name);
   if (slot < 0) return -1;
   if (g_kev_used >= KPOOL) kprof_resolve();
