@@ -83,9 +83,9 @@ def algo_bytes(kernel, Lm, Mm, N, launches_per_step_hint=None):
 
 def pmc_traffic(workload, kernel, world):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json,
-    written by tools/summarize_profiles.py: FETCH_SIZE + WRITE_SIZE, corrected with the calibration
-    factors measured on k_copy_probe as the MI355X guide prescribes).  None if no profile of this
-    workload is committed."""
+    FETCH_SIZE + WRITE_SIZE passes corrected with the calibration factors measured on k_copy_probe, as
+    the MI355X guide prescribes).  None if no such profile of this workload is committed (round 1:
+    none)."""
     import glob
     if world != 1:
         return None
