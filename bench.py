@@ -167,7 +167,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):   # started by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,

@@ -101,12 +101,18 @@ COOP_KERNEL(k_diag_row, DiagArgs) {
         acc[2 * DIAG_IW + di] = acc[2 * DIAG_IW + di] + sK[dj * DIAG_IW + di];
       }
 #else
-    if (KTID < nw)
-      for (int dj = 0; dj < nj; dj++) {
-        vol = vol + sV[dj * DIAG_IW + KTID];
-        pes = pes + sP[dj * DIAG_IW + KTID];
-        kes = kes + sK[dj * DIAG_IW + KTID];
+    if (KTID < nw) {
+      // all LDS reads of the chunk are issued before the (ordered, dependent) additions
+      double rv[DIAG_JC], rp[DIAG_JC], rk[DIAG_JC];
+#pragma unroll
+      for (int dj = 0; dj < DIAG_JC; dj++) {
+        const int d = dj < nj ? dj : 0;
+        rv[dj] = sV[d * DIAG_IW + KTID]; rp[dj] = sP[d * DIAG_IW + KTID]; rk[dj] = sK[d * DIAG_IW + KTID];
       }
+#pragma unroll
+      for (int dj = 0; dj < DIAG_JC; dj++)
+        if (dj < nj) { vol = vol + rv[dj]; pes = pes + rp[dj]; kes = kes + rk[dj]; }
+    }
 #endif
   }
   double *row = a.row;
@@ -193,12 +199,28 @@ COOP_KERNEL(k_diag_fin, DiagArgs) {
       sV[d] = row[ii]; sP[d] = row[ii + ni]; sK[d] = row[ii + 2 * ni];
     }
     KSYNC();
-    if (KTID == 0)
+    if (KTID == 0) {
+#ifdef ROMS_CPU_EMU
       for (int d = 0; d < nc; d++) {
         vol = vol + sV[d];
         pes = pes + sP[d];
         kes = kes + sK[d];
       }
+#else
+      // 16 values at a time: the LDS reads are issued together, the additions stay in order
+      for (int d0 = 0; d0 < nc; d0 += 16) {
+        double rv[16], rp[16], rk[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int d = d0 + q < nc ? d0 + q : d0;
+          rv[q] = sV[d]; rp[q] = sP[d]; rk[q] = sK[d];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+          if (d0 + q < nc) { vol = vol + rv[q]; pes = pes + rp[q]; kes = kes + rk[q]; }
+      }
+#endif
+    }
   }
   // maxima (order-free): every thread scans a strided subset, thread 0 merges the partial results
   KSYNC();

@@ -5,6 +5,8 @@ reference after 100 steps.  The kernels are built with -ffp-contract=off, so for
 (no transcendental functions on the device except exp() in ana_vmix) the fields are expected to
 agree to round-off of a few ulp; the asserted tolerance is the north-star 1e-10.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -185,4 +187,79 @@ def test_fortran_host_drives_gpu_like_the_oracle(kernels):
     d = run.check()
     do = O.diag()
     assert d["volume"] == pytest.approx(do[3], rel=1e-13)
+    run.close()
+
+
+@pytest.mark.gpu
+def test_rccl_transport_loads_and_initialises():
+    """The built-in RCCL transport: library found, symbols resolved, a communicator created on the
+    context's device (one rank = one tile here; the strip exchange itself needs two GPUs and is
+    covered on CPU by tests/test_tiles.py with the callback transport)."""
+    import ctypes as C
+    from roms_amd import tiling
+    cs = util.case_for("upwelling_small")
+    run = tiling.TiledRun(cs, weak=False)
+    L, h = run.ctx.L, run.ctx.h
+    uid = (C.c_ubyte * 128)()
+    assert L.roms_hip_rccl_unique_id(uid) == 0, L.roms_hip_last_error()
+    assert any(uid)
+    assert L.roms_hip_comm_rccl(h, bytes(uid), 1, 0) == 0, L.roms_hip_last_error()
+    assert L.roms_hip_comm_rccl(h, bytes(uid), 2, 0) == 5          # nranks must equal NtileI*NtileJ
+    run.step(2)
+    assert L.roms_hip_exchange_count(h) == 0                        # single tile: nothing travels
+    run.check()
+    run.close()
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_single_rank(tmp_path):
+    """bench.py through the launcher the driver uses for N > 1 (here N = 1): rendezvous, nccl process
+    group, barrier and max-reduction glue."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29655", os.path.join(root, "bench.py"),
+           "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["metric"] == "grid-cell-updates/sec" and d["n_gpus"] == 1 and d["value"] > 1e7
+    assert d["roofline"]["kernel"] and 0 < d["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,nsteps,tol", [("benchmark1", 4, 1e-12), ("upwelling", 12, 1e-11)])
+def test_baseline_size_matches_oracle(workload, nsteps, tol):
+    """BASELINE.json's own grids (BENCHMARK1 512x64x30 with its full physics; UPWELLING 41x80x16), set
+    up by the Fortran host from roms.in values: every prognostic field against the oracle, plus the
+    size-independent property the domain offers -- the volume integral is conserved to round-off."""
+    import bench
+    from roms_amd import tiling
+    from oracle import orc
+    from tests import cases
+    from tests.test_host import HOST_FIELDS
+    cs = bench.params_for(workload)
+    cs["ninfo"] = 1
+    run = tiling.TiledRun(cs)
+    H = run.host
+    w = np.stack([H.get("weight1"), H.get("weight2")])
+    O = orc.Oracle(cases.oracle_cfg(cs, H.reals["hc"], H.dims["nfast"], w))
+    for n in HOST_FIELDS:
+        try:
+            O.field(n)[:] = H.get(n)
+        except KeyError:
+            pass
+    O.start()
+    v0 = run.check()["volume"]
+    run.step(nsteps)
+    O.main3d_step(nsteps)
+    for n in ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "rho", "Akv", "Akt", "Huon", "DU_avg1"]:
+        e = util.relrms(run.ctx.download(n), O.field(n))
+        assert e <= tol, (workload, n, e)
+    d = run.check()
+    assert abs(d["volume"] - v0) <= 1e-12 * v0
+    assert d["volume"] == pytest.approx(O.diag()[3], rel=1e-14)
     run.close()
