@@ -15,11 +15,12 @@ int run_step2d(roms_hip_ctx *c) {
   a.w2_p1 = (iif + 1 <= ROMS_MAXW) ? cf.weight[1][iif + 1] : 0.0;
   const size_t tile = (size_t)(G.bw2 + 6) * (size_t)(G.bh2 + 6);
   const size_t lds = (size_t)STEP2D_NLDS * tile;
-  // every thread owns at most STEP2D_PTS points of the sub-tile rectangle
-  // one thread per point of the sub-tile rectangle where that fits the launch bound (512): two
-  // waves per SIMD hide the LDS latency of the short dependent phases better than 2 points/thread
-  int nthreads = tile <= 512 ? (int)((tile + 63) / 64) * 64 : 512;
+  // every thread owns at most STEP2D_PTS rectangle points (stages 1-3) and STEP2D_PTS of the
+  // 2*bw*bh momentum-point work items (stage 4); one of each where the launch bound (512) allows
+  const size_t need = tile > 2 * (size_t)G.bw2 * (size_t)G.bh2 ? tile : 2 * (size_t)G.bw2 * (size_t)G.bh2;
+  int nthreads = need <= 512 ? (int)((need + 63) / 64) * 64 : 512;
   if (nthreads < 256) nthreads = 256;
+  if (need > (size_t)STEP2D_PTS * 512) { set_error("k_step2d: sub-tile too large for the launch bound"); return 5; }
   if (getenv("ROMS_HIP_S2D_THREADS")) nthreads = atoi(getenv("ROMS_HIP_S2D_THREADS"));
 #ifndef ROMS_CPU_EMU
   static bool big_lds = false;

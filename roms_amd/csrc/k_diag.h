@@ -224,7 +224,7 @@ COOP_KERNEL(k_diag_fin, DiagArgs) {
   }
   // maxima (order-free): every thread scans a strided subset, thread 0 merges the partial results
   KSYNC();
-  double *mC = lds, *mS = lds + 256, *mI = lds + 512;
+  double *mC = lds, *mS = lds + 256, *mI = lds + 512, *mJ = lds + 768, *mK = lds + 1024;
   {
     double pC = 0.0, pS = -1.0E+20;
     int pi = 0, pj = 0, pk = 0;
@@ -235,7 +235,7 @@ COOP_KERNEL(k_diag_fin, DiagArgs) {
       const int j = (int)row[ii + 8 * ni], k = (int)row[ii + 9 * ni];
       if (C > 0.0 && (pC == 0.0 || diag_better(C, j, k, i, pC, pj, pk, pi))) { pC = C; pi = i; pj = j; pk = k; }
     }
-    if (KTID < 256) { mC[KTID] = pC; mS[KTID] = pS; mI[KTID] = (double)pi; }
+    if (KTID < 256) { mC[KTID] = pC; mS[KTID] = pS; mI[KTID] = (double)pi; mJ[KTID] = (double)pj; mK[KTID] = (double)pk; }
   }
   KSYNC();
   if (KTID == 0) {
@@ -245,8 +245,7 @@ COOP_KERNEL(k_diag_fin, DiagArgs) {
       const double C = mC[t];
       const int i = (int)mI[t];
       if (C > 0.0) {
-        const int ii = i - G.LBi;
-        const int j = (int)row[ii + 8 * ni], k = (int)row[ii + 9 * ni];
+        const int j = (int)mJ[t], k = (int)mK[t];
         if (bC == 0.0 || diag_better(C, j, k, i, bC, bj, bk, bi)) { bC = C; bi = i; bj = j; bk = k; }
       }
     }

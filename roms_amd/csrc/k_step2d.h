@@ -3,19 +3,27 @@
 // Replaces step2d_tile, ROMS/Nonlinear/step2d_LF_AM3.h:163-3056 (options SOLVE3D, VAR_RHO_2D,
 // UV_ADV 4th-order centred :1246-1395, UV_COR, CURVGRID, UV_VIS2).
 //
-// Mapping: one thread block = one ROMS sub-tile; the reference's private work arrays
-// (IminS:ImaxS,JminS:JmaxS) live in LDS, every loop nest of the reference is a masked sweep over
-// the sub-tile's (Istr-3:Iend+3, Jstr-3:Jend+3) rectangle and dependent nests are separated by a
-// barrier.
+// One thread block = one ROMS sub-tile.  The kernel is a chain of dependent stencil stages on a
+// small 2-D grid, so its cost is latency (global-load round trips and barriers), not bandwidth.
+// It is therefore organised as FOUR stages with three barriers:
 //
-// The kernel is a chain of ~25 short dependent phases, so its cost is latency, not bandwidth.  All
-// global reads are therefore issued in ONE prologue: fields that are needed at neighbouring points
-// (zeta+h, ubar, vbar, h, pm, pn, rhoA, Dstp) go to LDS tiles with the 3-cell halo, everything
-// that is only needed at a thread's own points (metrics, r.h.s. history, running averages) stays
-// in that thread's registers -- every sweep uses the same point -> thread mapping.  The phases then
-// touch LDS and registers only; the epilogue stores zeta/ubar/vbar(knew), the r.h.s. history and
-// the fast-time averages; in single-tile runs with a periodic direction every thread also stores
-// the boundary and periodic images of its values (k_haloblock.h), so no halo launch follows.
+//   1  prologue   every global read of the kernel is issued here.  Fields needed at neighbouring
+//                 points (zeta+h, ubar, vbar, h, pm, pn, rhoA, zeta(kstp)+h) go to LDS tiles over
+//                 the sub-tile rectangle (Istr-3:Iend+3, Jstr-3:Jend+3); values needed only at
+//                 a thread's own points stay in registers (fixed point -> thread mapping).
+//   2  fluxes     DUon, DVom on the rectangle (LDS) + fast-time averaging at the own points
+//   3  zeta       new free surface and the pressure-gradient work arrays on the rectangle (LDS)
+//   4  momentum   each momentum point (u-point or v-point of an interior cell = one work item)
+//                 evaluates its complete right-hand side -- pressure gradient, 4th-order
+//                 advection, Coriolis, curvilinear terms, harmonic viscosity -- directly from the
+//                 LDS tiles, recomputing the handful of neighbouring flux values it needs instead
+//                 of exchanging them through LDS and barriers as the reference's loop nests
+//                 (private arrays UFx, UFe, VFx, VFe, grad, Dgrad) would; then the coupling with
+//                 the 3-D forcing and the time step.  Every flux value is computed with exactly
+//                 the reference's expression, so results are bit-identical to the loop-nest form.
+//
+// In single-tile runs with a periodic direction every thread also stores the boundary and periodic
+// images of its values (k_haloblock.h), so no halo launch follows.
 #pragma once
 #include "roms_ctx.h"
 #include "k_haloblock.h"
@@ -27,8 +35,8 @@ struct Step2dArgs {
   double w2_0, w2_p1;  // weight(2,iif), weight(2,iif+1)
 };
 
-#define STEP2D_NLDS 19
-#define STEP2D_PTS 2      // tile points per thread: the launch uses >= tile/2 threads
+#define STEP2D_NLDS 15
+#define STEP2D_PTS 2      // rectangle points (stages 1-3) and work items (stage 4) per thread
 
 // Sweep over the sub-tile rectangle with a fixed point -> thread mapping.
 #ifdef ROMS_CPU_EMU
@@ -36,6 +44,7 @@ struct Step2dArgs {
 #define TLOOP(i, j)                                                                                                    \
   for (int m = 0, i = 0, j = 0, s0 = 0; m < NTILE && ((j = JT0 + m / TW), (i = IT0 + m - (m / TW) * TW), (s0 = m), true); m++) \
     for (long x0 = (long)X2(i, j), once_ = 1; once_; once_ = 0)
+#define WLOOP(w) for (int w = 0, m = 0; w < NWORK; w++, m++)
 #define PWDECL(name)
 #define PWLOAD(name, expr) ((void)0)
 #define PW(name, expr) (expr)
@@ -43,6 +52,9 @@ struct Step2dArgs {
 #define TLOOP(i, j)                                                                                                    \
   _Pragma("unroll") for (int m = 0; m < STEP2D_PTS; m++) if (tq[m])                                                    \
     for (int i = ti[m], j = tj[m], s0 = KTID + m * KNT, x0 = tx[m], once_ = 1; once_; once_ = 0)
+#define WLOOP(w)                                                                                                       \
+  _Pragma("unroll") for (int m = 0; m < STEP2D_PTS; m++)                                                               \
+    for (int w = KTID + m * KNT, once_ = 1; once_ && w < NWORK; once_ = 0)
 #define PWDECL(name) double name[STEP2D_PTS]
 #define PWLOAD(name, expr) name[m] = (expr)
 #define PW(name, expr) name[m]
@@ -55,14 +67,10 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   const Fields &F = *a.Fp;
   const TB B = block_bounds2(G, bx, by);
   const size_t sz = (size_t)(G.bw2 + 6) * (size_t)(G.bh2 + 6);
-  double *Drhs = lds, *DUon = lds + sz, *DVom = lds + 2 * sz, *Dnew = lds + 3 * sz, *rhs_ubar = lds + 4 * sz,
-         *rhs_vbar = lds + 5 * sz;
-  double *zwrk = lds + 6 * sz, *gzeta = lds + 7 * sz, *gzeta2 = lds + 8 * sz, *gzetaSA = lds + 9 * sz;
-  double *grad = lds + 6 * sz, *Dgrad = lds + 7 * sz, *UFx = lds + 8 * sz, *UFe = lds + 9 * sz, *VFx = lds + 10 * sz,
-         *VFe = lds + 11 * sz;
-  double *Drhs_p = grad;
-  double *sUk = lds + 12 * sz, *sVk = lds + 13 * sz, *sH = lds + 14 * sz, *sPm = lds + 15 * sz, *sPn = lds + 16 * sz,
-         *sRhoA = lds + 17 * sz, *sDstp = lds + 18 * sz;
+  double *Drhs = lds, *DUon = lds + sz, *DVom = lds + 2 * sz, *Dnew = lds + 3 * sz;
+  double *zwrk = lds + 4 * sz, *gzeta = lds + 5 * sz, *gzeta2 = lds + 6 * sz, *gzetaSA = lds + 7 * sz;
+  double *sUk = lds + 8 * sz, *sVk = lds + 9 * sz, *sH = lds + 10 * sz, *sPm = lds + 11 * sz, *sPn = lds + 12 * sz,
+         *sRhoA = lds + 13 * sz, *sDstp = lds + 14 * sz;
   const int krhs = G.krhs, kstp = G.kstp, knew = G.knew, nstp = G.nstp, nnew = G.nnew, iif = G.iif, iic = G.iic;
   const bool PRED = G.predictor != 0;
   const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend, IstrU = B.IstrU, JstrV = B.JstrV;
@@ -88,9 +96,13 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   const int first = (iif == 1 && PRED);
   const int corr = (!PRED && iif != 1);
   const int startup = (iic == G.ntfirst) ? 0 : ((iic == G.ntfirst + 1) ? 1 : 2);
+  const bool wfix = !G.ewp && B.west, efix = !G.ewp && B.east, sfix = !G.nsp && B.south, nfix = !G.nsp && B.north;
+  const int ni = G.ni;
 
-  // sub-tile rectangle and the point -> thread mapping
+  // sub-tile rectangle (stages 1-3) and work items (stage 4): item w < NOWN is the u-point of interior
+  // cell w, item NOWN + w its v-point
   const int IT0 = Istr - 3, JT0 = Jstr - 3, TW = Iend - Istr + 7, TH = Jend - Jstr + 7, NTILE = TW * TH;
+  const int OW = Iend - Istr + 1, NOWN = OW * (Jend - Jstr + 1), NWORK = 2 * NOWN;
   const int UBi = G.LBi + G.ni - 1, UBj = G.LBj + G.nj - 1;
 #ifndef ROMS_CPU_EMU
   int ti[STEP2D_PTS], tj[STEP2D_PTS], tx[STEP2D_PTS];   // point, and its offset in the global 2-D arrays
@@ -104,21 +116,25 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     tx[m] = (ti[m] - G.LBi) + (tj[m] - G.LBj) * G.ni;   // may lie outside the array for masked points
   }
 #endif
-  PWDECL(r_zk); PWDECL(r_zs); PWDECL(r_on_u); PWDECL(r_om_v); PWDECL(r_rhoS); PWDECL(r_fomn); PWDECL(r_dndx);
-  PWDECL(r_dmde); PWDECL(r_visc2_r); PWDECL(r_pmon_r); PWDECL(r_pnom_r); PWDECL(r_on_r); PWDECL(r_om_r);
-  PWDECL(r_visc2_p); PWDECL(r_pmon_p); PWDECL(r_pnom_p); PWDECL(r_om_p); PWDECL(r_on_p);
+  // stage 2-3 own-point values
+  PWDECL(r_zk); PWDECL(r_zs); PWDECL(r_on_u); PWDECL(r_om_v); PWDECL(r_rhoS);
   PWDECL(r_Zt); PWDECL(r_DU1); PWDECL(r_DU2); PWDECL(r_DV1); PWDECL(r_DV2);
   PWDECL(r_rz_s); PWDECL(r_rz_p);
-  PWDECL(r_rub_s); PWDECL(r_rub_p); PWDECL(r_rvb_s); PWDECL(r_rvb_p); PWDECL(r_rufrc); PWDECL(r_rvfrc);
-  PWDECL(r_ru0n); PWDECL(r_ru0s); PWDECL(r_rv0n); PWDECL(r_rv0s); PWDECL(r_us); PWDECL(r_vs);
+  // stage 4 values of a work item: metrics at its two rho points (P0 = own cell, P1 = the cell on the
+  // other side of the momentum point) and its two psi points (Q0 = (i,j), Q1 = next along the face)
+  PWDECL(w_onom); PWDECL(w_fomn0); PWDECL(w_fomn1); PWDECL(w_dndx0); PWDECL(w_dndx1); PWDECL(w_dmde0); PWDECL(w_dmde1);
+  PWDECL(w_v2r0); PWDECL(w_v2r1); PWDECL(w_pmr0); PWDECL(w_pmr1); PWDECL(w_pnr0); PWDECL(w_pnr1);
+  PWDECL(w_onr0); PWDECL(w_onr1); PWDECL(w_omr0); PWDECL(w_omr1);
+  PWDECL(w_v2p0); PWDECL(w_v2p1); PWDECL(w_pmp0); PWDECL(w_pmp1); PWDECL(w_pnp0); PWDECL(w_pnp1);
+  PWDECL(w_omp0); PWDECL(w_omp1); PWDECL(w_onp0); PWDECL(w_onp1);
+  PWDECL(w_s); PWDECL(w_frc); PWDECL(w_rs); PWDECL(w_rp); PWDECL(w_r0n); PWDECL(w_r0s);
 
-  // ---- prologue: every global read of the kernel -------------------------------------------
+  // ---- stage 1: every global read of the kernel ----------------------------------------------
   TLOOP(i, j) {
     if (INR(i, j, G.LBi, UBi, G.LBj, UBj)) {
-      // each array is read only as far from the sub-tile as some phase below needs it
+      // each array is read only as far from the sub-tile as some stage below needs it
       const bool ring2 = INR(i, j, Istr - 2, Iend + 2, Jstr - 2, Jend + 2);
       const bool ring1 = INR(i, j, Istr - 1, Iend + 1, Jstr - 1, Jend + 1);
-      const bool own = INR(i, j, Istr, Iend, Jstr, Jend);
       const double zkv = zk[x0], hv = F.h[x0];
       Drhs[s0] = zkv + hv;                                    // total depth :600
       sUk[s0] = uk[x0]; sVk[s0] = vk[x0]; sH[s0] = hv;
@@ -133,100 +149,108 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
         PWLOAD(r_Zt, F.Zt_avg1[x0]); PWLOAD(r_DU1, F.DU_avg1[x0]); PWLOAD(r_DU2, F.DU_avg2[x0]);
         PWLOAD(r_DV1, F.DV_avg1[x0]); PWLOAD(r_DV2, F.DV_avg2[x0]);
         if (!last) {
-          PWLOAD(r_rhoS, F.rhoS[x0]); PWLOAD(r_fomn, F.fomn[x0]); PWLOAD(r_dndx, F.dndx[x0]); PWLOAD(r_dmde, F.dmde[x0]);
-          PWLOAD(r_visc2_r, F.visc2_r[x0]); PWLOAD(r_pmon_r, F.pmon_r[x0]); PWLOAD(r_pnom_r, F.pnom_r[x0]);
-          PWLOAD(r_on_r, F.on_r[x0]); PWLOAD(r_om_r, F.om_r[x0]);
-          PWLOAD(r_visc2_p, F.visc2_p[x0]); PWLOAD(r_pmon_p, F.pmon_p[x0]); PWLOAD(r_pnom_p, F.pnom_p[x0]);
-          PWLOAD(r_om_p, F.om_p[x0]); PWLOAD(r_on_p, F.on_p[x0]);
+          PWLOAD(r_rhoS, F.rhoS[x0]);
           if (corr) { PWLOAD(r_rz_s, rz_s[x0]); PWLOAD(r_rz_p, rz_p[x0]); }
         }
-      }
-      if (own && !last) {
-        PWLOAD(r_us, us[x0]); PWLOAD(r_vs, vs[x0]);
-        PWLOAD(r_rufrc, F.rufrc[x0]); PWLOAD(r_rvfrc, F.rvfrc[x0]);
-        if (corr) {
-          PWLOAD(r_rub_s, rub_s[x0]); PWLOAD(r_rub_p, rub_p[x0]); PWLOAD(r_rvb_s, rvb_s[x0]); PWLOAD(r_rvb_p, rvb_p[x0]);
-        }
-        if (first && startup >= 1) { PWLOAD(r_ru0n, ru0_new[x0]); PWLOAD(r_rv0n, rv0_new[x0]); }
-        if (first && startup >= 2) { PWLOAD(r_ru0s, ru0_stp[x0]); PWLOAD(r_rv0s, rv0_stp[x0]); }
       }
     } else {
       Drhs[s0] = 0.0; sDstp[s0] = 0.0; sUk[s0] = 0.0; sVk[s0] = 0.0; sH[s0] = 0.0; sPm[s0] = 0.0; sPn[s0] = 0.0; sRhoA[s0] = 0.0;
     }
   }
-  KSYNC();
-
-  // mass fluxes :600-700
-  TLOOP(i, j) {
-    if (INR(i, j, B.IstrUm2 - 1, B.Iendp2, B.JstrVm2 - 1, B.Jendp2)) {
-      if (i >= B.IstrUm2) {
-        const double cff = 0.5 * PW(r_on_u, F.on_u[x0]);
-        const double cff1 = cff * (Drhs[s0] + Drhs[(s0 - 1)]);
-        DUon[s0] = sUk[s0] * cff1;
-      }
-      if (j >= B.JstrVm2) {
-        const double cff = 0.5 * PW(r_om_v, F.om_v[x0]);
-        const double cff1 = cff * (Drhs[s0] + Drhs[(s0 - TW)]);
-        DVom[s0] = sVk[s0] * cff1;
+  if (!last) {
+    WLOOP(w) {
+      const int isv = w >= NOWN, c = isv ? w - NOWN : w;
+      const int j = Jstr + c / OW, i = Istr + c - (c / OW) * OW;
+      if (isv ? (j >= JstrV) : (i >= IstrU)) {
+        const long x = (long)X2(i, j);
+        const long x1 = isv ? x - ni : x - 1;        // P1: (i,j-1) for a v-point, (i-1,j) for a u-point
+        const long q1 = isv ? x + 1 : x + ni;        // Q1: (i+1,j) for a v-point, (i,j+1) for a u-point
+        PWLOAD(w_onom, isv ? F.om_v[x] : F.on_u[x]);
+        PWLOAD(w_fomn0, F.fomn[x]); PWLOAD(w_fomn1, F.fomn[x1]);
+        PWLOAD(w_dndx0, F.dndx[x]); PWLOAD(w_dndx1, F.dndx[x1]);
+        PWLOAD(w_dmde0, F.dmde[x]); PWLOAD(w_dmde1, F.dmde[x1]);
+        PWLOAD(w_v2r0, F.visc2_r[x]); PWLOAD(w_v2r1, F.visc2_r[x1]);
+        PWLOAD(w_pmr0, F.pmon_r[x]); PWLOAD(w_pmr1, F.pmon_r[x1]);
+        PWLOAD(w_pnr0, F.pnom_r[x]); PWLOAD(w_pnr1, F.pnom_r[x1]);
+        PWLOAD(w_onr0, F.on_r[x]); PWLOAD(w_onr1, F.on_r[x1]);
+        PWLOAD(w_omr0, F.om_r[x]); PWLOAD(w_omr1, F.om_r[x1]);
+        PWLOAD(w_v2p0, F.visc2_p[x]); PWLOAD(w_v2p1, F.visc2_p[q1]);
+        PWLOAD(w_pmp0, F.pmon_p[x]); PWLOAD(w_pmp1, F.pmon_p[q1]);
+        PWLOAD(w_pnp0, F.pnom_p[x]); PWLOAD(w_pnp1, F.pnom_p[q1]);
+        PWLOAD(w_omp0, F.om_p[x]); PWLOAD(w_omp1, F.om_p[q1]);
+        PWLOAD(w_onp0, F.on_p[x]); PWLOAD(w_onp1, F.on_p[q1]);
+        PWLOAD(w_s, isv ? vs[x] : us[x]);
+        PWLOAD(w_frc, isv ? F.rvfrc[x] : F.rufrc[x]);
+        if (corr) { PWLOAD(w_rs, isv ? rvb_s[x] : rub_s[x]); PWLOAD(w_rp, isv ? rvb_p[x] : rub_p[x]); }
+        if (first && startup >= 1) PWLOAD(w_r0n, isv ? rv0_new[x] : ru0_new[x]);
+        if (first && startup >= 2) PWLOAD(w_r0s, isv ? rv0_stp[x] : ru0_stp[x]);
       }
     }
   }
   KSYNC();
 
-  // fast-time averaging :739-880
-  if (PRED) {
-    if (iif == 1) {
-      const double cff2 = (-1.0 / 12.0) * a.w2_p1;
-      TLOOP(i, j) {
-        if (INR(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR)) {
-          if (i >= IstrR && j >= JstrR) F.Zt_avg1[x0] = 0.0;
-          if (i >= Istr && j >= JstrR) {
-            F.DU_avg1[x0] = 0.0;
-            F.DU_avg2[x0] = cff2 * DUon[s0];
-          }
-          if (i >= IstrR && j >= Jstr) {
-            F.DV_avg1[x0] = 0.0;
-            F.DV_avg2[x0] = cff2 * DVom[s0];
-          }
+  // ---- stage 2: mass fluxes :600-700 and fast-time averaging :739-880 -------------------------
+  {
+    double cA1 = 0.0, cA2;   // weights of DU_avg1 / DU_avg2 for this call
+    int amode;               // 0: first predictor (reset), 1: predictor, 2: corrector
+    if (PRED) {
+      if (iif == 1) { amode = 0; cA2 = (-1.0 / 12.0) * a.w2_p1; }
+      else { amode = 1; cA1 = a.w1_m1; cA2 = (8.0 / 12.0) * a.w2_0 - (1.0 / 12.0) * a.w2_p1; }
+    } else {
+      amode = 2;
+      cA2 = (iif == 1) ? a.w2_0 : (5.0 / 12.0) * a.w2_0;
+    }
+    TLOOP(i, j) {
+      double du = 0.0, dv = 0.0;
+      if (INR(i, j, B.IstrUm2 - 1, B.Iendp2, B.JstrVm2 - 1, B.Jendp2)) {
+        if (i >= B.IstrUm2) {
+          const double cff = 0.5 * PW(r_on_u, F.on_u[x0]);
+          const double cff1 = cff * (Drhs[s0] + Drhs[(s0 - 1)]);
+          du = sUk[s0] * cff1;
+          DUon[s0] = du;
+        }
+        if (j >= B.JstrVm2) {
+          const double cff = 0.5 * PW(r_om_v, F.om_v[x0]);
+          const double cff1 = cff * (Drhs[s0] + Drhs[(s0 - TW)]);
+          dv = sVk[s0] * cff1;
+          DVom[s0] = dv;
         }
       }
-    } else {
-      const double cff1 = a.w1_m1;
-      const double cff2 = (8.0 / 12.0) * a.w2_0 - (1.0 / 12.0) * a.w2_p1;
-      TLOOP(i, j) {
-        if (INR(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR)) {
-          if (i >= IstrR && j >= JstrR) {
-            const double v = PW(r_Zt, F.Zt_avg1[x0]) + cff1 * PW(r_zk, zk[x0]);
+      if (INR(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR)) {
+        const bool pz = i >= IstrR && j >= JstrR, pu = i >= Istr && j >= JstrR, pv = i >= IstrR && j >= Jstr;
+        if (amode == 0) {
+          if (pz) F.Zt_avg1[x0] = 0.0;
+          if (pu) { F.DU_avg1[x0] = 0.0; F.DU_avg2[x0] = cA2 * du; }
+          if (pv) { F.DV_avg1[x0] = 0.0; F.DV_avg2[x0] = cA2 * dv; }
+        } else if (amode == 1) {
+          if (pz) {
+            const double v = PW(r_Zt, F.Zt_avg1[x0]) + cA1 * PW(r_zk, zk[x0]);
             if (fuse_last) hb_emit(G, B, F.Zt_avg1, BC_NONE, i, j, v);   // final averages: exchange :821-883
             else F.Zt_avg1[x0] = v;
           }
-          if (i >= Istr && j >= JstrR) {
-            const double v = PW(r_DU1, F.DU_avg1[x0]) + cff1 * DUon[s0];
+          if (pu) {
+            const double v = PW(r_DU1, F.DU_avg1[x0]) + cA1 * du;
             if (fuse_last) hb_emit(G, B, F.DU_avg1, BC_NONE, i, j, v);
             else F.DU_avg1[x0] = v;
-            F.DU_avg2[x0] = PW(r_DU2, F.DU_avg2[x0]) + cff2 * DUon[s0];
+            F.DU_avg2[x0] = PW(r_DU2, F.DU_avg2[x0]) + cA2 * du;
           }
-          if (i >= IstrR && j >= Jstr) {
-            const double v = PW(r_DV1, F.DV_avg1[x0]) + cff1 * DVom[s0];
+          if (pv) {
+            const double v = PW(r_DV1, F.DV_avg1[x0]) + cA1 * dv;
             if (fuse_last) hb_emit(G, B, F.DV_avg1, BC_NONE, i, j, v);
             else F.DV_avg1[x0] = v;
-            F.DV_avg2[x0] = PW(r_DV2, F.DV_avg2[x0]) + cff2 * DVom[s0];
+            F.DV_avg2[x0] = PW(r_DV2, F.DV_avg2[x0]) + cA2 * dv;
           }
+        } else {
+          if (pu) F.DU_avg2[x0] = PW(r_DU2, F.DU_avg2[x0]) + cA2 * du;
+          if (pv) F.DV_avg2[x0] = PW(r_DV2, F.DV_avg2[x0]) + cA2 * dv;
         }
-      }
-    }
-  } else {
-    const double cff2 = (iif == 1) ? a.w2_0 : (5.0 / 12.0) * a.w2_0;
-    TLOOP(i, j) {
-      if (INR(i, j, KMIN(IstrR, Istr), IendR, KMIN(JstrR, Jstr), JendR)) {
-        if (i >= Istr && j >= JstrR) F.DU_avg2[x0] = PW(r_DU2, F.DU_avg2[x0]) + cff2 * DUon[s0];
-        if (i >= IstrR && j >= Jstr) F.DV_avg2[x0] = PW(r_DV2, F.DV_avg2[x0]) + cff2 * DVom[s0];
       }
     }
   }
   if (last) return;            // auxiliary last predictor call :883 (uniform over the grid)
+  KSYNC();
 
-  // free-surface step :886-1000
+  // ---- stage 3: free-surface step :886-1000 ---------------------------------------------------
   {
     const double fac = 1000.0 / G.rho0;
     double cff1, cff2 = 0.0, cff3 = 0.0, cff4, cff5;
@@ -236,7 +260,7 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     else { mode = 2; cff1 = dtfast * 5.0 / 12.0; cff2 = dtfast * 8.0 / 12.0; cff3 = dtfast * 1.0 / 12.0; cff4 = 2.0 / 5.0; cff5 = 1.0 - cff4; }
     TLOOP(i, j) {
       if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
-            const double rhs_zeta = (DUon[s0] - DUon[(s0 + 1)]) + (DVom[s0] - DVom[(s0 + TW)]);
+        const double rhs_zeta = (DUon[s0] - DUon[(s0 + 1)]) + (DVom[s0] - DVom[(s0 + TW)]);
         const double zsv = PW(r_zs, zs[x0]), zkv = PW(r_zk, zk[x0]);
         double zeta_new, zw;
         if (mode == 0) {
@@ -272,292 +296,209 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   }
   KSYNC();
 
-  // pressure gradient (VAR_RHO_2D) :1080-1200
+  // ---- stage 4: right-hand sides and the momentum step, one work item per momentum point ------
+  // Tile accessors relative to s = S2(i,j); the flux helpers below are the reference's expressions
+  // for one entry of its private arrays (UFx, UFe, VFx, VFe, ...), edge replication included.
+#define TU(di, dj) sUk[s + (di) + (dj) * TW]
+#define TV(di, dj) sVk[s + (di) + (dj) * TW]
+#define TDU(di, dj) DUon[s + (di) + (dj) * TW]
+#define TDV(di, dj) DVom[s + (di) + (dj) * TW]
+#define TD(di, dj) Drhs[s + (di) + (dj) * TW]
+#define TPM(di, dj) sPm[s + (di) + (dj) * TW]
+#define TPN(di, dj) sPn[s + (di) + (dj) * TW]
   {
-    const double cff1 = 0.5 * g, cff2 = 1.0 / 3.0;
-    TLOOP(i, j) {
-      if (INR(i, j, KMIN(IstrU, Istr), Iend, Jstr, Jend)) {
-        if (i >= IstrU)
-          rhs_ubar[s0] =
-              cff1 * PW(r_on_u, F.on_u[x0]) *
-              ((sH[(s0 - 1)] + sH[s0]) * (gzeta[(s0 - 1)] - gzeta[s0]) +
-               (sH[(s0 - 1)] - sH[s0]) *
-                   (gzetaSA[(s0 - 1)] + gzetaSA[s0] +
-                    cff2 * (sRhoA[(s0 - 1)] - sRhoA[s0]) * (zwrk[(s0 - 1)] - zwrk[s0])) +
-               (gzeta2[(s0 - 1)] - gzeta2[s0]));
-        if (j >= JstrV)
-          rhs_vbar[s0] =
-              cff1 * PW(r_om_v, F.om_v[x0]) *
-              ((sH[(s0 - TW)] + sH[s0]) * (gzeta[(s0 - TW)] - gzeta[s0]) +
-               (sH[(s0 - TW)] - sH[s0]) *
-                   (gzetaSA[(s0 - TW)] + gzetaSA[s0] +
-                    cff2 * (sRhoA[(s0 - TW)] - sRhoA[s0]) * (zwrk[(s0 - TW)] - zwrk[s0])) +
-               (gzeta2[(s0 - TW)] - gzeta2[s0]));
-      }
-    }
-  }
-  KSYNC();   // group-1 scratch is dead from here on (aliased by grad,Dgrad,UFx,UFe)
-
-  if (G.options & ROMS_UV_ADV) {
-    const double cff = 1.0 / 6.0;
-    // ---- UFx :1249-1290
-    TLOOP(i, j) {
-      if (INR(i, j, B.IstrUm1, B.Iendp1, Jstr, Jend)) {
-        grad[s0] = sUk[(s0 - 1)] - 2.0 * sUk[s0] + sUk[(s0 + 1)];
-        Dgrad[s0] = DUon[(s0 - 1)] - 2.0 * DUon[s0] + DUon[(s0 + 1)];
-      }
-    }
-    KSYNC();
-    if (!G.ewp) {
-      if (B.west) KLOOP1(j, Jstr, Jend) { grad[S2(Istr, j)] = grad[S2(Istr + 1, j)]; Dgrad[S2(Istr, j)] = Dgrad[S2(Istr + 1, j)]; }
-      if (B.east) KLOOP1(j, Jstr, Jend) { grad[S2(Iend + 1, j)] = grad[S2(Iend, j)]; Dgrad[S2(Iend + 1, j)] = Dgrad[S2(Iend, j)]; }
-      KSYNC();
-    }
-    TLOOP(i, j) {
-      if (INR(i, j, IstrU - 1, Iend, Jstr, Jend))
-        UFx[s0] = 0.25 * (sUk[s0] + sUk[(s0 + 1)] - cff * (grad[s0] + grad[(s0 + 1)])) *
-                        (DUon[s0] + DUon[(s0 + 1)] - cff * (Dgrad[s0] + Dgrad[(s0 + 1)]));
-    }
-    KSYNC();
-    // ---- UFe :1292-1330
-    TLOOP(i, j) {
-      if (INR(i, j, IstrU, Iend, B.Jstrm1, B.Jendp1))
-        grad[s0] = sUk[(s0 - TW)] - 2.0 * sUk[s0] + sUk[(s0 + TW)];
-      if (INR(i, j, IstrU - 1, Iend, Jstr, Jend + 1))
-        Dgrad[s0] = DVom[(s0 - 1)] - 2.0 * DVom[s0] + DVom[(s0 + 1)];
-    }
-    KSYNC();
-    if (!G.nsp) {
-      if (B.south) KLOOP1(i, IstrU, Iend) grad[S2(i, Jstr - 1)] = grad[S2(i, Jstr)];
-      if (B.north) KLOOP1(i, IstrU, Iend) grad[S2(i, Jend + 1)] = grad[S2(i, Jend)];
-      KSYNC();
-    }
-    TLOOP(i, j) {
-      if (INR(i, j, IstrU, Iend, Jstr, Jend + 1))
-        UFe[s0] = 0.25 * (sUk[s0] + sUk[(s0 - TW)] - cff * (grad[s0] + grad[(s0 - TW)])) *
-                        (DVom[s0] + DVom[(s0 - 1)] - cff * (Dgrad[s0] + Dgrad[(s0 - 1)]));
-    }
-    KSYNC();
-    // u-momentum advection r.h.s. (UFx,UFe complete)
-    TLOOP(i, j) {
-      if (INR(i, j, IstrU, Iend, Jstr, Jend)) {
-        const double cff1 = UFx[s0] - UFx[(s0 - 1)];
-        const double cff2 = UFe[(s0 + TW)] - UFe[s0];
-        const double fac = cff1 + cff2;
-        rhs_ubar[s0] = rhs_ubar[s0] - fac;
-      }
-    }
-    KSYNC();
-    // ---- VFx :1332-1370
-    TLOOP(i, j) {
-      if (INR(i, j, B.Istrm1, B.Iendp1, JstrV, Jend))
-        grad[s0] = sVk[(s0 - 1)] - 2.0 * sVk[s0] + sVk[(s0 + 1)];
-      if (INR(i, j, Istr, Iend + 1, JstrV - 1, Jend))
-        Dgrad[s0] = DUon[(s0 - TW)] - 2.0 * DUon[s0] + DUon[(s0 + TW)];
-    }
-    KSYNC();
-    if (!G.ewp) {
-      if (B.west) KLOOP1(j, JstrV, Jend) grad[S2(Istr - 1, j)] = grad[S2(Istr, j)];
-      if (B.east) KLOOP1(j, JstrV, Jend) grad[S2(Iend + 1, j)] = grad[S2(Iend, j)];
-      KSYNC();
-    }
-    TLOOP(i, j) {
-      if (INR(i, j, Istr, Iend + 1, JstrV, Jend))
-        VFx[s0] = 0.25 * (sVk[s0] + sVk[(s0 - 1)] - cff * (grad[s0] + grad[(s0 - 1)])) *
-                        (DUon[s0] + DUon[(s0 - TW)] - cff * (Dgrad[s0] + Dgrad[(s0 - TW)]));
-    }
-    KSYNC();
-    // ---- VFe :1372-1410
-    TLOOP(i, j) {
-      if (INR(i, j, Istr, Iend, B.JstrVm1, B.Jendp1)) {
-        grad[s0] = sVk[(s0 - TW)] - 2.0 * sVk[s0] + sVk[(s0 + TW)];
-        Dgrad[s0] = DVom[(s0 - TW)] - 2.0 * DVom[s0] + DVom[(s0 + TW)];
-      }
-    }
-    KSYNC();
-    if (!G.nsp) {
-      if (B.south) KLOOP1(i, Istr, Iend) { grad[S2(i, Jstr)] = grad[S2(i, Jstr + 1)]; Dgrad[S2(i, Jstr)] = Dgrad[S2(i, Jstr + 1)]; }
-      if (B.north) KLOOP1(i, Istr, Iend) { grad[S2(i, Jend + 1)] = grad[S2(i, Jend)]; Dgrad[S2(i, Jend + 1)] = Dgrad[S2(i, Jend)]; }
-      KSYNC();
-    }
-    TLOOP(i, j) {
-      if (INR(i, j, Istr, Iend, JstrV - 1, Jend))
-        VFe[s0] = 0.25 * (sVk[s0] + sVk[(s0 + TW)] - cff * (grad[s0] + grad[(s0 + TW)])) *
-                        (DVom[s0] + DVom[(s0 + TW)] - cff * (Dgrad[s0] + Dgrad[(s0 + TW)]));
-    }
-    KSYNC();
-    TLOOP(i, j) {
-      if (INR(i, j, Istr, Iend, JstrV, Jend)) {
-        const double cff1 = VFx[(s0 + 1)] - VFx[s0];
-        const double cff2 = VFe[s0] - VFe[(s0 - TW)];
-        const double fac = cff1 + cff2;
-        rhs_vbar[s0] = rhs_vbar[s0] - fac;
-      }
-    }
-    KSYNC();
-  }
-
-  if (G.options & ROMS_UV_COR) {
-    // Coriolis :1429-1490
-    TLOOP(i, j) {
-      if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
-        const double cff = 0.5 * Drhs[s0] * PW(r_fomn, F.fomn[x0]);
-        UFx[s0] = cff * (sVk[s0] + sVk[(s0 + TW)]);
-        VFe[s0] = cff * (sUk[s0] + sUk[(s0 + 1)]);
-      }
-    }
-    KSYNC();
-    TLOOP(i, j) {
-      if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
-        if (i >= IstrU && j >= Jstr) {
-          const double fac1 = 0.5 * (UFx[s0] + UFx[(s0 - 1)]);
-          rhs_ubar[s0] = rhs_ubar[s0] + fac1;
-        }
-        if (i >= Istr && j >= JstrV) {
-          const double fac1 = 0.5 * (VFe[s0] + VFe[(s0 - TW)]);
-          rhs_vbar[s0] = rhs_vbar[s0] - fac1;
-        }
-      }
-    }
-    KSYNC();
-  }
-
-  if ((G.options & ROMS_CURVGRID) && (G.options & ROMS_UV_ADV)) {
-    // curvilinear metric terms :1494-1560
-    TLOOP(i, j) {
-      if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
-        const double cff1 = 0.5 * (sVk[s0] + sVk[(s0 + TW)]);
-        const double cff2 = 0.5 * (sUk[s0] + sUk[(s0 + 1)]);
-        const double cff3 = cff1 * PW(r_dndx, F.dndx[x0]);
-        const double cff4 = cff2 * PW(r_dmde, F.dmde[x0]);
-        const double cff = Drhs[s0] * (cff3 - cff4);
-        UFx[s0] = cff * cff1;
-        VFe[s0] = cff * cff2;
-      }
-    }
-    KSYNC();
-    TLOOP(i, j) {
-      if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
-        if (i >= IstrU && j >= Jstr) {
-          const double fac1 = 0.5 * (UFx[s0] + UFx[(s0 - 1)]);
-          rhs_ubar[s0] = rhs_ubar[s0] + fac1;
-        }
-        if (i >= Istr && j >= JstrV) {
-          const double fac1 = 0.5 * (VFe[s0] + VFe[(s0 - TW)]);
-          rhs_vbar[s0] = rhs_vbar[s0] - fac1;
-        }
-      }
-    }
-    KSYNC();
-  }
-
-  if (G.options & ROMS_UV_VIS2) {
-    // harmonic viscosity :1567-1660
-    TLOOP(i, j) {
-      if (INR(i, j, Istr, Iend + 1, Jstr, Jend + 1))
-        Drhs_p[s0] = 0.25 * (Drhs[s0] + Drhs[(s0 - 1)] + Drhs[(s0 - TW)] + Drhs[(s0 - 1 - TW)]);
-      if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
-        const double cff = PW(r_visc2_r, F.visc2_r[x0]) * Drhs[s0] * 0.5 *
-                           (PW(r_pmon_r, F.pmon_r[x0]) * ((sPn[s0] + sPn[(s0 + 1)]) * sUk[(s0 + 1)] -
-                                                               (sPn[(s0 - 1)] + sPn[s0]) * sUk[s0]) -
-                            PW(r_pnom_r, F.pnom_r[x0]) * ((sPm[s0] + sPm[(s0 + TW)]) * sVk[(s0 + TW)] -
-                                                               (sPm[(s0 - TW)] + sPm[s0]) * sVk[s0]));
-        UFx[s0] = PW(r_on_r, F.on_r[x0]) * PW(r_on_r, F.on_r[x0]) * cff;
-        VFe[s0] = PW(r_om_r, F.om_r[x0]) * PW(r_om_r, F.om_r[x0]) * cff;
-      }
-    }
-    KSYNC();
-    TLOOP(i, j) {
-      if (INR(i, j, Istr, Iend + 1, Jstr, Jend + 1)) {
-        const double cff = PW(r_visc2_p, F.visc2_p[x0]) * Drhs_p[s0] * 0.5 *
-                           (PW(r_pmon_p, F.pmon_p[x0]) * ((sPn[(s0 - TW)] + sPn[s0]) * sVk[s0] -
-                                                               (sPn[(s0 - 1 - TW)] + sPn[(s0 - 1)]) * sVk[(s0 - 1)]) +
-                            PW(r_pnom_p, F.pnom_p[x0]) * ((sPm[(s0 - 1)] + sPm[s0]) * sUk[s0] -
-                                                               (sPm[(s0 - 1 - TW)] + sPm[(s0 - TW)]) * sUk[(s0 - TW)]));
-        UFe[s0] = PW(r_om_p, F.om_p[x0]) * PW(r_om_p, F.om_p[x0]) * cff;
-        VFx[s0] = PW(r_on_p, F.on_p[x0]) * PW(r_on_p, F.on_p[x0]) * cff;
-      }
-    }
-    KSYNC();
-    TLOOP(i, j) {
-      if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
-        if (i >= IstrU && j >= Jstr) {
-          const double cff1 = 0.5 * (sPn[(s0 - 1)] + sPn[s0]) * (UFx[s0] - UFx[(s0 - 1)]);
-          const double cff2 = 0.5 * (sPm[(s0 - 1)] + sPm[s0]) * (UFe[(s0 + TW)] - UFe[s0]);
-          const double fac = cff1 + cff2;
-          rhs_ubar[s0] = rhs_ubar[s0] + fac;
-        }
-        if (i >= Istr && j >= JstrV) {
-          const double cff1 = 0.5 * (sPn[(s0 - TW)] + sPn[s0]) * (VFx[(s0 + 1)] - VFx[s0]);
-          const double cff2 = 0.5 * (sPm[(s0 - TW)] + sPm[s0]) * (VFe[s0] - VFe[(s0 - TW)]);
-          const double fac = cff1 - cff2;
-          rhs_vbar[s0] = rhs_vbar[s0] + fac;
-        }
-      }
-    }
-    KSYNC();
-  }
-
-  // coupling with the 3-D forcing :2225-2460, then the momentum step :2488-2670 -- point-wise
-  {
+    const double c6 = 1.0 / 6.0;
+    const bool ADV = (G.options & ROMS_UV_ADV) != 0, COR = (G.options & ROMS_UV_COR) != 0;
+    const bool CURV = ADV && (G.options & ROMS_CURVGRID) != 0, VIS = (G.options & ROMS_UV_VIS2) != 0;
     const double c1 = (iif == 1) ? 0.5 * dtfast : dtfast;
     const double k1 = 0.5 * dtfast * 5.0 / 12.0, k2 = 0.5 * dtfast * 8.0 / 12.0, k3 = 0.5 * dtfast * 1.0 / 12.0;
-    TLOOP(i, j) {
-      if (INR(i, j, KMIN(IstrU, Istr), Iend, KMIN(Jstr, JstrV), Jend)) {
-        if (i >= IstrU && j >= Jstr) {
-          double r = rhs_ubar[s0];
-          if (first) {
-            const double fr = PW(r_rufrc, F.rufrc[x0]) - r;
-            F.rufrc[x0] = fr;
-            if (startup == 0) r = r + fr;
-            else if (startup == 1) r = r + 1.5 * fr - 0.5 * PW(r_ru0n, ru0_new[x0]);
-            else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * PW(r_ru0n, ru0_new[x0]) +
-                     (5.0 / 12.0) * PW(r_ru0s, ru0_stp[x0]);
-            ru0_stp[x0] = fr;
-          } else {
-            r = r + PW(r_rufrc, F.rufrc[x0]);
-          }
-          const double cff = (sPm[s0] + sPm[(s0 - 1)]) * (sPn[s0] + sPn[(s0 - 1)]);
-          const double fac = 1.0 / (Dnew[s0] + Dnew[(s0 - 1)]);
-          const double Dstp_i = sDstp[s0], Dstp_im = sDstp[(s0 - 1)];
-          double ub;
-          if (!corr) ub = (PW(r_us, us[x0]) * (Dstp_i + Dstp_im) + cff * c1 * r) * fac;
-          else ub = (PW(r_us, us[x0]) * (Dstp_i + Dstp_im) +
-                     cff * (k1 * r + k2 * PW(r_rub_s, rub_s[x0]) - k3 * PW(r_rub_p, rub_p[x0]))) * fac;
-          if (fuse) hb_emit(G, B, un, BC_U, i, j, ub);   // u2dbc :2871 + exchange :3043
-          else un[x0] = ub;
-          if (PRED) rub_k[x0] = r;
+    const double pg1 = 0.5 * g, pg2 = 1.0 / 3.0;
+    WLOOP(w) {
+      const int isv = w >= NOWN, c = isv ? w - NOWN : w;
+      const int j = Jstr + c / OW, i = Istr + c - (c / OW) * OW;
+      if (!(isv ? (j >= JstrV) : (i >= IstrU))) continue;
+      const int s = (i - IT0) + (j - JT0) * TW;
+      const long x = (long)X2(i, j);
+      const int d1 = isv ? TW : 1;                   // tile offset from P1 to P0 (across the momentum point)
+      // -- pressure gradient (VAR_RHO_2D) :1080-1200
+      double rhs = pg1 * PW(w_onom, isv ? F.om_v[x] : F.on_u[x]) *
+                   ((sH[s - d1] + sH[s]) * (gzeta[s - d1] - gzeta[s]) +
+                    (sH[s - d1] - sH[s]) * (gzetaSA[s - d1] + gzetaSA[s] +
+                                           pg2 * (sRhoA[s - d1] - sRhoA[s]) * (zwrk[s - d1] - zwrk[s])) +
+                    (gzeta2[s - d1] - gzeta2[s]));
+      if (ADV) {
+        // 4th-order centred advection :1246-1410.  G*(a) = second difference at offset a along the
+        // flux direction, with the closed-edge replication of the reference.
+        if (!isv) {
+          // UFx(i) and UFx(i-1): grad/Dgrad along xi of ubar, DUon
+#define GUX(a_) ({ int q_ = (a_); if (wfix && i + q_ == Istr) q_ += 1; if (efix && i + q_ == Iend + 1) q_ -= 1; \
+                   TU(q_ - 1, 0) - 2.0 * TU(q_, 0) + TU(q_ + 1, 0); })
+#define GDX(a_) ({ int q_ = (a_); if (wfix && i + q_ == Istr) q_ += 1; if (efix && i + q_ == Iend + 1) q_ -= 1; \
+                   TDU(q_ - 1, 0) - 2.0 * TDU(q_, 0) + TDU(q_ + 1, 0); })
+#define UFX(a_) (0.25 * (TU(a_, 0) + TU((a_) + 1, 0) - c6 * (GUX(a_) + GUX((a_) + 1))) *                      \
+                 (TDU(a_, 0) + TDU((a_) + 1, 0) - c6 * (GDX(a_) + GDX((a_) + 1))))
+          // UFe(j) and UFe(j+1): grad along eta of ubar (replicated at closed S/N edges), Dgrad along xi of DVom
+#define GUE(b_) ({ int q_ = (b_); if (sfix && j + q_ == Jstr - 1) q_ += 1; if (nfix && j + q_ == Jend + 1) q_ -= 1; \
+                   TU(0, q_ - 1) - 2.0 * TU(0, q_) + TU(0, q_ + 1); })
+#define GDE(a_, b_) (TDV((a_) - 1, b_) - 2.0 * TDV(a_, b_) + TDV((a_) + 1, b_))
+#define UFE(b_) (0.25 * (TU(0, b_) + TU(0, (b_) - 1) - c6 * (GUE(b_) + GUE((b_) - 1))) *                      \
+                 (TDV(0, b_) + TDV(-1, b_) - c6 * (GDE(0, b_) + GDE(-1, b_))))
+          const double cff1 = UFX(0) - UFX(-1);
+          const double cff2 = UFE(1) - UFE(0);
+          const double fac = cff1 + cff2;
+          rhs = rhs - fac;
+#undef GUX
+#undef GDX
+#undef UFX
+#undef GUE
+#undef GDE
+#undef UFE
+        } else {
+          // VFx(i) and VFx(i+1): grad along xi of vbar (replicated at closed W/E edges), Dgrad along eta of DUon
+#define GVX(a_) ({ int q_ = (a_); if (wfix && i + q_ == Istr - 1) q_ += 1; if (efix && i + q_ == Iend + 1) q_ -= 1; \
+                   TV(q_ - 1, 0) - 2.0 * TV(q_, 0) + TV(q_ + 1, 0); })
+#define GDX(a_, b_) (TDU(a_, (b_) - 1) - 2.0 * TDU(a_, b_) + TDU(a_, (b_) + 1))
+#define VFX(a_) (0.25 * (TV(a_, 0) + TV((a_) - 1, 0) - c6 * (GVX(a_) + GVX((a_) - 1))) *                      \
+                 (TDU(a_, 0) + TDU(a_, -1) - c6 * (GDX(a_, 0) + GDX(a_, -1))))
+          // VFe(j) and VFe(j-1): grad/Dgrad along eta of vbar, DVom
+#define GVE(b_) ({ int q_ = (b_); if (sfix && j + q_ == Jstr) q_ += 1; if (nfix && j + q_ == Jend + 1) q_ -= 1; \
+                   TV(0, q_ - 1) - 2.0 * TV(0, q_) + TV(0, q_ + 1); })
+#define GDE(b_) ({ int q_ = (b_); if (sfix && j + q_ == Jstr) q_ += 1; if (nfix && j + q_ == Jend + 1) q_ -= 1; \
+                   TDV(0, q_ - 1) - 2.0 * TDV(0, q_) + TDV(0, q_ + 1); })
+#define VFE(b_) (0.25 * (TV(0, b_) + TV(0, (b_) + 1) - c6 * (GVE(b_) + GVE((b_) + 1))) *                      \
+                 (TDV(0, b_) + TDV(0, (b_) + 1) - c6 * (GDE(b_) + GDE((b_) + 1))))
+          const double cff1 = VFX(1) - VFX(0);
+          const double cff2 = VFE(0) - VFE(-1);
+          const double fac = cff1 + cff2;
+          rhs = rhs - fac;
+#undef GVX
+#undef GDX
+#undef VFX
+#undef GVE
+#undef GDE
+#undef VFE
         }
-        if (i >= Istr && j >= JstrV) {
-          double r = rhs_vbar[s0];
-          if (first) {
-            const double fr = PW(r_rvfrc, F.rvfrc[x0]) - r;
-            F.rvfrc[x0] = fr;
-            if (startup == 0) r = r + fr;
-            else if (startup == 1) r = r + 1.5 * fr - 0.5 * PW(r_rv0n, rv0_new[x0]);
-            else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * PW(r_rv0n, rv0_new[x0]) +
-                     (5.0 / 12.0) * PW(r_rv0s, rv0_stp[x0]);
-            rv0_stp[x0] = fr;
-          } else {
-            r = r + PW(r_rvfrc, F.rvfrc[x0]);
-          }
-          const double cff = (sPm[s0] + sPm[(s0 - TW)]) * (sPn[s0] + sPn[(s0 - TW)]);
-          const double fac = 1.0 / (Dnew[s0] + Dnew[(s0 - TW)]);
-          const double Dstp_j = sDstp[s0], Dstp_jm = sDstp[(s0 - TW)];
-          double vb;
-          if (!corr) vb = (PW(r_vs, vs[x0]) * (Dstp_j + Dstp_jm) + cff * c1 * r) * fac;
-          else vb = (PW(r_vs, vs[x0]) * (Dstp_j + Dstp_jm) +
-                     cff * (k1 * r + k2 * PW(r_rvb_s, rvb_s[x0]) - k3 * PW(r_rvb_p, rvb_p[x0]))) * fac;
-          if (fuse) hb_emit(G, B, vn, BC_V, i, j, vb);   // v2dbc :2876 + exchange :3043
-          else vn[x0] = vb;
-          if (PRED) rvb_k[x0] = r;
+      }
+      // values at the two rho points of this momentum point: P0 = (i,j), P1 = (i-1,j) | (i,j-1)
+      const int a1 = isv ? 0 : -1, b1 = isv ? -1 : 0;
+      if (COR) {
+        // Coriolis :1429-1490: UFx = cff*(vbar(j)+vbar(j+1)), VFe = cff*(ubar(i)+ubar(i+1)) at rho points
+        const double cf0 = 0.5 * TD(0, 0) * PW(w_fomn0, F.fomn[x]);
+        const double cf1 = 0.5 * TD(a1, b1) * PW(w_fomn1, F.fomn[isv ? x - ni : x - 1]);
+        if (!isv) {
+          const double fac1 = 0.5 * (cf0 * (TV(0, 0) + TV(0, 1)) + cf1 * (TV(-1, 0) + TV(-1, 1)));
+          rhs = rhs + fac1;
+        } else {
+          const double fac1 = 0.5 * (cf0 * (TU(0, 0) + TU(1, 0)) + cf1 * (TU(0, -1) + TU(1, -1)));
+          rhs = rhs - fac1;
         }
+      }
+      if (CURV) {
+        // curvilinear metric terms :1494-1560
+        double t0, t1;
+        {
+          const double cff1 = 0.5 * (TV(0, 0) + TV(0, 1)), cff2 = 0.5 * (TU(0, 0) + TU(1, 0));
+          const double cff3 = cff1 * PW(w_dndx0, F.dndx[x]), cff4 = cff2 * PW(w_dmde0, F.dmde[x]);
+          const double cff = TD(0, 0) * (cff3 - cff4);
+          t0 = isv ? cff * cff2 : cff * cff1;
+        }
+        {
+          const long x1 = isv ? x - ni : x - 1;
+          const double cff1 = 0.5 * (TV(a1, b1) + TV(a1, b1 + 1)), cff2 = 0.5 * (TU(a1, b1) + TU(a1 + 1, b1));
+          const double cff3 = cff1 * PW(w_dndx1, F.dndx[x1]), cff4 = cff2 * PW(w_dmde1, F.dmde[x1]);
+          const double cff = TD(a1, b1) * (cff3 - cff4);
+          t1 = isv ? cff * cff2 : cff * cff1;
+        }
+        const double fac1 = 0.5 * (t0 + t1);
+        if (!isv) rhs = rhs + fac1;
+        else rhs = rhs - fac1;
+      }
+      if (VIS) {
+        // harmonic viscosity :1567-1660: stress at the rho points P0, P1 and the psi points Q0, Q1
+#define STRESS_R(a_, b_, v2_, pmon_, pnom_)                                                                        \
+  ((v2_) * TD(a_, b_) * 0.5 *                                                                                      \
+   ((pmon_) * ((TPN(a_, b_) + TPN((a_) + 1, b_)) * TU((a_) + 1, b_) - (TPN((a_) - 1, b_) + TPN(a_, b_)) * TU(a_, b_)) - \
+    (pnom_) * ((TPM(a_, b_) + TPM(a_, (b_) + 1)) * TV(a_, (b_) + 1) - (TPM(a_, (b_) - 1) + TPM(a_, b_)) * TV(a_, b_))))
+#define DRHS_P(a_, b_) (0.25 * (TD(a_, b_) + TD((a_) - 1, b_) + TD(a_, (b_) - 1) + TD((a_) - 1, (b_) - 1)))
+#define STRESS_P(a_, b_, v2_, pmon_, pnom_)                                                                        \
+  ((v2_) * DRHS_P(a_, b_) * 0.5 *                                                                                  \
+   ((pmon_) * ((TPN(a_, (b_) - 1) + TPN(a_, b_)) * TV(a_, b_) - (TPN((a_) - 1, (b_) - 1) + TPN((a_) - 1, b_)) * TV((a_) - 1, b_)) + \
+    (pnom_) * ((TPM((a_) - 1, b_) + TPM(a_, b_)) * TU(a_, b_) - (TPM((a_) - 1, (b_) - 1) + TPM(a_, (b_) - 1)) * TU(a_, (b_) - 1))))
+        const long x1 = isv ? x - ni : x - 1, q1 = isv ? x + 1 : x + ni;
+        const int qa = isv ? 1 : 0, qb = isv ? 0 : 1;
+        const double sr0 = STRESS_R(0, 0, PW(w_v2r0, F.visc2_r[x]), PW(w_pmr0, F.pmon_r[x]), PW(w_pnr0, F.pnom_r[x]));
+        const double sr1 = STRESS_R(a1, b1, PW(w_v2r1, F.visc2_r[x1]), PW(w_pmr1, F.pmon_r[x1]), PW(w_pnr1, F.pnom_r[x1]));
+        const double sp0 = STRESS_P(0, 0, PW(w_v2p0, F.visc2_p[x]), PW(w_pmp0, F.pmon_p[x]), PW(w_pnp0, F.pnom_p[x]));
+        const double sp1 = STRESS_P(qa, qb, PW(w_v2p1, F.visc2_p[q1]), PW(w_pmp1, F.pmon_p[q1]), PW(w_pnp1, F.pnom_p[q1]));
+        if (!isv) {
+          const double UFx0 = PW(w_onr0, F.on_r[x]) * PW(w_onr0, F.on_r[x]) * sr0;
+          const double UFxm = PW(w_onr1, F.on_r[x1]) * PW(w_onr1, F.on_r[x1]) * sr1;
+          const double UFe0 = PW(w_omp0, F.om_p[x]) * PW(w_omp0, F.om_p[x]) * sp0;
+          const double UFep = PW(w_omp1, F.om_p[q1]) * PW(w_omp1, F.om_p[q1]) * sp1;
+          const double cff1 = 0.5 * (TPN(-1, 0) + TPN(0, 0)) * (UFx0 - UFxm);
+          const double cff2 = 0.5 * (TPM(-1, 0) + TPM(0, 0)) * (UFep - UFe0);
+          const double fac = cff1 + cff2;
+          rhs = rhs + fac;
+        } else {
+          const double VFx0 = PW(w_onp0, F.on_p[x]) * PW(w_onp0, F.on_p[x]) * sp0;
+          const double VFxp = PW(w_onp1, F.on_p[q1]) * PW(w_onp1, F.on_p[q1]) * sp1;
+          const double VFe0 = PW(w_omr0, F.om_r[x]) * PW(w_omr0, F.om_r[x]) * sr0;
+          const double VFem = PW(w_omr1, F.om_r[x1]) * PW(w_omr1, F.om_r[x1]) * sr1;
+          const double cff1 = 0.5 * (TPN(0, -1) + TPN(0, 0)) * (VFxp - VFx0);
+          const double cff2 = 0.5 * (TPM(0, -1) + TPM(0, 0)) * (VFe0 - VFem);
+          const double fac = cff1 - cff2;
+          rhs = rhs + fac;
+        }
+#undef STRESS_R
+#undef DRHS_P
+#undef STRESS_P
+      }
+      // -- coupling with the 3-D forcing :2225-2460, then the momentum step :2488-2670
+      double *frc = isv ? F.rvfrc : F.rufrc;
+      double *r0s = isv ? rv0_stp : ru0_stp;
+      double r = rhs;
+      if (first) {
+        const double fr = PW(w_frc, frc[x]) - r;
+        frc[x] = fr;
+        if (startup == 0) r = r + fr;
+        else if (startup == 1) r = r + 1.5 * fr - 0.5 * PW(w_r0n, (isv ? rv0_new : ru0_new)[x]);
+        else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * PW(w_r0n, (isv ? rv0_new : ru0_new)[x]) +
+                 (5.0 / 12.0) * PW(w_r0s, r0s[x]);
+        r0s[x] = fr;
+      } else {
+        r = r + PW(w_frc, frc[x]);
+      }
+      const double cff = (sPm[s] + sPm[s - d1]) * (sPn[s] + sPn[s - d1]);
+      const double fac = 1.0 / (Dnew[s] + Dnew[s - d1]);
+      const double Dstp0 = sDstp[s], Dstp1 = sDstp[s - d1];
+      const double sv = PW(w_s, (isv ? vs : us)[x]);
+      double b;
+      if (!corr) b = (sv * (Dstp0 + Dstp1) + cff * c1 * r) * fac;
+      else b = (sv * (Dstp0 + Dstp1) +
+                cff * (k1 * r + k2 * PW(w_rs, (isv ? rvb_s : rub_s)[x]) - k3 * PW(w_rp, (isv ? rvb_p : rub_p)[x]))) * fac;
+      // u2dbc/v2dbc :2871-2876 + exchange :3043
+      if (!isv) {
+        if (fuse) hb_emit(G, B, un, BC_U, i, j, b);
+        else un[x] = b;
+        if (PRED) rub_k[x] = r;
+      } else {
+        if (fuse) hb_emit(G, B, vn, BC_V, i, j, b);
+        else vn[x] = b;
+        if (PRED) rvb_k[x] = r;
       }
     }
   }
+#undef TU
+#undef TV
+#undef TDU
+#undef TDV
+#undef TD
+#undef TPM
+#undef TPN
 }
 COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)
 #undef TLOOP
+#undef WLOOP
 #undef PWDECL
 #undef PWLOAD
 #undef PW
