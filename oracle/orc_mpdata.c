@@ -1,0 +1,372 @@
+/* orc_mpdata.c -- TEST INFRASTRUCTURE (oracle): anti-diffusive velocities of MPDATA.
+ *
+ * Restates mpdata_adiff_tile, ROMS/Nonlinear/mpdata_adiff.F:38-1227 (Smolarkiewicz & Margolin
+ * recursive anti-diffusive velocities, third-order cross terms, FCT limiter), options of the
+ * BASELINE applications (no MASKING/WET_DRY/WEC/OMEGA_IMPLICIT).  Pinned bit for bit against the
+ * reference's own object code (tests/test_oracle_vs_ref.py, ref_mpdata_adiff in ref_glue.F90).
+ *
+ * Ta, Ua, Va, oHz are full-size rho-level arrays (X3 indexing), Wa a w-level array (XW); the
+ * reference's private (IminS:ImaxS,JminS:JmaxS) arrays are the same values on the tile's rectangle.
+ */
+#include "orc.h"
+#include <math.h>
+#include <stdlib.h>
+
+#define MAX(a, b) ((a) > (b) ? (a) : (b))
+#define MIN(a, b) ((a) < (b) ? (a) : (b))
+#define SIGN1(x) ((x) >= 0.0 ? 1.0 : -1.0) /* SIGN(1.0,x); x = -0.0 does not occur after the MIN/ABS product below */
+
+static double max12(const double *v, int n) {
+  double m = v[0];
+  for (int q = 1; q < n; q++) m = MAX(m, v[q]);
+  return m;
+}
+static double min12(const double *v, int n) {
+  double m = v[0];
+  for (int q = 1; q < n; q++) m = MIN(m, v[q]);
+  return m;
+}
+
+void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double *Ua, double *Va, double *Wa,
+                      const double *oHz) {
+  ORC_LOCALS(o);
+  const orc_bounds *b = &o->b[tile];
+  const orc_cfg *c = &o->c;
+  const double eps = 1.0E-18, eps2 = 1.0E-10, fac = 1.0;
+  const double dt = c->dt;
+  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend, IstrU = b->IstrU, JstrV = b->JstrV;
+  double *Ta = (double *)Ta_in; /* boundary points of Ta are (re)filled here, as in the reference (intent inout) */
+  const double *pm = o->pm, *pn = o->pn, *omn = o->omn, *om_u = o->om_u, *on_v = o->on_v, *z_r = o->z_r;
+  const double *Huon = o->Huon, *Hvom = o->Hvom, *W = o->W;
+  const double *t3 = o->t + XT(LBi, LBj, 1, 3, itrc);
+  double *odz = (double *)calloc(3 * nij * (size_t)N, sizeof(double));
+  double *beta_dn = odz + nij * (size_t)N, *beta_up = odz + 2 * nij * (size_t)N;
+  double *C = (double *)calloc(2 * ni * (size_t)(N + 1), sizeof(double)), *Wm = C + ni * (size_t)(N + 1);
+#define TA(i, j, k) Ta[X3(i, j, k)]
+#define T3(i, j, k) t3[X3(i, j, k)]
+#define CC_(i, k) C[(size_t)((i) - LBi) + (size_t)(k) * ni]
+#define WM_(i, k) Wm[(size_t)((i) - LBi) + (size_t)(k) * ni]
+
+  /* boundary values of Ta :224-290 */
+  if (!c->EWperiodic) {
+    if (b->west)
+      for (int k = 1; k <= N; k++)
+        for (int j = b->JstrVm2; j <= b->Jendp2i; j++) TA(Istr - 1, j, k) = TA(Istr, j, k);
+    if (b->east)
+      for (int k = 1; k <= N; k++)
+        for (int j = b->JstrVm2; j <= b->Jendp2i; j++) TA(Iend + 1, j, k) = TA(Iend, j, k);
+  }
+  if (!c->NSperiodic) {
+    if (b->south)
+      for (int k = 1; k <= N; k++)
+        for (int i = b->IstrUm2; i <= b->Iendp2i; i++) TA(i, Jstr - 1, k) = TA(i, Jstr, k);
+    if (b->north)
+      for (int k = 1; k <= N; k++)
+        for (int i = b->IstrUm2; i <= b->Iendp2i; i++) TA(i, Jend + 1, k) = TA(i, Jend, k);
+  }
+  if (!(c->EWperiodic || c->NSperiodic)) {
+    for (int k = 1; k <= N; k++) {
+      if (b->west && b->south) TA(Istr - 1, Jstr - 1, k) = 0.5 * (TA(Istr, Jstr - 1, k) + TA(Istr - 1, Jstr, k));
+      if (b->east && b->south) TA(Iend + 1, Jstr - 1, k) = 0.5 * (TA(Iend + 1, Jstr, k) + TA(Iend, Jstr - 1, k));
+      if (b->west && b->north) TA(Istr - 1, Jend + 1, k) = 0.5 * (TA(Istr - 1, Jend, k) + TA(Istr, Jend + 1, k));
+      if (b->east && b->north) TA(Iend + 1, Jend + 1, k) = 0.5 * (TA(Iend + 1, Jend, k) + TA(Iend, Jend + 1, k));
+    }
+  }
+  /* inverse vertical grid spacing :295-302 */
+  for (int k = 1; k <= N - 1; k++)
+    for (int j = b->Jstrm2; j <= b->Jendp2; j++)
+      for (int i = b->Istrm2; i <= b->Iendp2; i++) odz[X3(i, j, k)] = 1.0 / (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]);
+#define ODZ(i, j, k) odz[X3(i, j, k)]
+#define PMN(i, j) (pm[X2(i, j)] * pn[X2(i, j)])
+
+/* the third-order pseudo-velocity polynomial shared by the three directions: P is the component
+ * being built, Q and R the other two; a,b,c the corresponding normalised gradients */
+#define SIGMA(P, Q, R, gp, gq, gr, out, swapbc)                                                                      \
+  do {                                                                                                       \
+    const double PP = (gp) * (gp), QQ = (gq) * (gq), RR = (gr) * (gr), PQ = (gp) * (gq), PR = (gp) * (gr);    \
+    const double sPP = (P) * (P), sQQ = (Q) * (Q), sRR = (R) * (R), sPQ = (P) * (Q), sPR = (P) * (R);         \
+    const double s_alfa = 1.0 / (1.0 - fabs(gp) + eps);                                                      \
+    const double s_beta = -(gp) / ((1.0 - fabs(gp)) * (1.0 - PP) + eps);                                     \
+    const double s_gama = 2.0 * fabs(PP * (gp)) / ((1.0 - fabs(gp)) * (1.0 - PP) * (1.0 - fabs(PP * (gp))) + eps); \
+    const double s_a = -(gq) / ((1.0 - fabs(gp)) * (1.0 - fabs(PQ)) + eps);                                  \
+    const double s_b = PQ / ((1.0 - fabs(gp)) * (1.0 - PP * fabs(gq)) + eps) *                               \
+                       (fabs(gq) / (1.0 - fabs(PQ) + eps) + 2.0 * (gp) / (1.0 - PP + eps));                  \
+    const double s_c = fabs(gp) * QQ / ((1.0 - fabs(gp)) * (1.0 - QQ * fabs(gp)) * (1.0 - fabs(PQ)) + eps);  \
+    const double s_d = -(gr) / ((1.0 - fabs(gp)) * (1.0 - fabs(PR)) + eps);                                  \
+    const double s_e = PR / ((1.0 - fabs(gp)) * (1.0 - PP * fabs(gr)) + eps) *                               \
+                       (fabs(gr) / (1.0 - fabs(PR) + eps) + 2.0 * (gp) / (1.0 - PP + eps));                  \
+    const double s_f = fabs(gp) * RR / ((1.0 - fabs(gp)) * (1.0 - RR * fabs(gp)) * (1.0 - fabs(PR)) + eps);  \
+    /* the eta component of the reference multiplies sig_b with P*Q^2 and sig_c with P^2*Q (:604-606) */     \
+    out = s_alfa * (P) + s_beta * sPP + s_gama * sPP * (P) + s_a * sPQ +                                     \
+          ((swapbc) ? s_b * (P) * sQQ : s_b * sPP * (Q)) + ((swapbc) ? s_c * sPP * (Q) : s_c * (P) * sQQ) +  \
+          s_d * sPR + s_e * sPP * (R) + s_f * (P) * sRR;                                                     \
+  } while (0)
+
+  /* ---- Ua :307-470 */
+  for (int j = JstrV - 1; j <= b->Jendp1; j++) {
+    for (int i = b->IstrUm1; i <= b->Iendp2; i++) {
+      const int k = 1;
+      CC_(i, k) = 0.25 * ((TA(i, j, k + 1) - TA(i, j, k)) * ODZ(i, j, k) + (TA(i - 1, j, k + 1) - TA(i - 1, j, k)) * ODZ(i - 1, j, k)) *
+                  (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)] + z_r[X3(i - 1, j, k + 1)] - z_r[X3(i - 1, j, k)]) /
+                  (TA(i - 1, j, k) + TA(i, j, k) + eps);
+      WM_(i, k) = 0.25 * dt * (W[XW(i - 1, j, k)] * ODZ(i - 1, j, k) * pm[X2(i - 1, j)] * pn[X2(i - 1, j)] +
+                               W[XW(i, j, k)] * ODZ(i, j, k) * pm[X2(i, j)] * pn[X2(i, j)]);
+    }
+    for (int k = 2; k <= N - 1; k++)
+      for (int i = IstrU - 1; i <= b->Iendp2; i++) {
+        CC_(i, k) = 0.0625 * ((TA(i, j, k + 1) - TA(i, j, k)) * ODZ(i, j, k) + (TA(i, j, k) - TA(i, j, k - 1)) * ODZ(i, j, k - 1) +
+                              (TA(i - 1, j, k + 1) - TA(i - 1, j, k)) * ODZ(i - 1, j, k) +
+                              (TA(i - 1, j, k) - TA(i - 1, j, k - 1)) * ODZ(i - 1, j, k - 1)) *
+                    (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k - 1)] + z_r[X3(i - 1, j, k + 1)] - z_r[X3(i - 1, j, k - 1)]) /
+                    (TA(i - 1, j, k) + TA(i, j, k) + eps);
+        WM_(i, k) = 0.25 * dt * ((W[XW(i - 1, j, k - 1)] * ODZ(i - 1, j, k - 1) + W[XW(i - 1, j, k)] * ODZ(i - 1, j, k)) *
+                                     pm[X2(i - 1, j)] * pn[X2(i - 1, j)] +
+                                 (W[XW(i, j, k)] * ODZ(i, j, k) + W[XW(i, j, k - 1)] * ODZ(i, j, k - 1)) * pm[X2(i, j)] *
+                                     pn[X2(i, j)]);
+      }
+    for (int i = IstrU - 1; i <= b->Iendp2; i++) {
+      const int k = N;
+      CC_(i, k) = 0.25 * ((TA(i, j, k) - TA(i, j, k - 1)) * ODZ(i, j, k - 1) + (TA(i - 1, j, k) - TA(i - 1, j, k - 1)) * ODZ(i - 1, j, k - 1)) *
+                  (z_r[X3(i, j, k)] - z_r[X3(i, j, k - 1)] + z_r[X3(i - 1, j, k)] - z_r[X3(i - 1, j, k - 1)]) /
+                  (TA(i - 1, j, k) + TA(i, j, k) + eps);
+      WM_(i, k) = 0.25 * dt * (W[XW(i - 1, j, k - 1)] * ODZ(i - 1, j, k - 1) * pm[X2(i - 1, j)] * pn[X2(i - 1, j)] +
+                               W[XW(i, j, k - 1)] * ODZ(i, j, k - 1) * pm[X2(i, j)] * pn[X2(i, j)]);
+    }
+    for (int k = 1; k <= N; k++)
+      for (int i = IstrU - 1; i <= b->Iendp2; i++) {
+        if (TA(i - 1, j, k) <= 0.0 || TA(i, j, k) <= 0.0 || fabs(TA(i - 1, j, k) - TA(i, j, k)) <= eps2) {
+          Ua[X3(i, j, k)] = 0.0;
+        } else {
+          const double A = (TA(i, j, k) - TA(i - 1, j, k)) / (TA(i, j, k) + TA(i - 1, j, k) + eps);
+          double B = 0.03125 * ((TA(i, j + 1, k) - TA(i, j, k)) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) +
+                                (TA(i, j, k) - TA(i, j - 1, k)) * (pn[X2(i, j - 1)] + pn[X2(i, j)]) +
+                                (TA(i - 1, j + 1, k) - TA(i - 1, j, k)) * (pn[X2(i - 1, j)] + pn[X2(i - 1, j + 1)]) +
+                                (TA(i - 1, j, k) - TA(i - 1, j - 1, k)) * (pn[X2(i - 1, j - 1)] + pn[X2(i - 1, j)]));
+          B = B * (on_v[X2(i, j)] + on_v[X2(i, j + 1)] + on_v[X2(i - 1, j)] + on_v[X2(i - 1, j + 1)]) /
+              (TA(i - 1, j, k) + TA(i, j, k) + eps);
+          const double Um = 0.125 * Huon[X3(i, j, k)] * dt * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * (pn[X2(i, j)] + pn[X2(i - 1, j)]) *
+                            (oHz[X3(i - 1, j, k)] + oHz[X3(i, j, k)]);
+          const double Vm =
+              0.03125 * dt *
+              (Hvom[X3(i - 1, j, k)] * (pm[X2(i - 1, j)] + pm[X2(i - 1, j - 1)]) * (pn[X2(i - 1, j)] + pn[X2(i - 1, j - 1)]) *
+                   (oHz[X3(i - 1, j, k)] + oHz[X3(i - 1, j - 1, k)]) +
+               Hvom[X3(i - 1, j + 1, k)] * (pm[X2(i - 1, j + 1)] + pm[X2(i - 1, j)]) * (pn[X2(i - 1, j + 1)] + pn[X2(i - 1, j)]) *
+                   (oHz[X3(i - 1, j + 1, k)] + oHz[X3(i - 1, j, k)]) +
+               Hvom[X3(i, j, k)] * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) *
+                   (oHz[X3(i, j, k)] + oHz[X3(i, j - 1, k)]) +
+               Hvom[X3(i, j + 1, k)] * (pm[X2(i, j + 1)] + pm[X2(i, j)]) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) *
+                   (oHz[X3(i, j + 1, k)] + oHz[X3(i, j, k)]));
+          const double Cc = CC_(i, k), Wmm = WM_(i, k);
+          const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Cc * Um * Wmm;
+          const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Cc * Vm * Wmm;
+          const double Z = (fabs(Wmm) - Wmm * Wmm) * Cc - A * Um * Wmm - B * Vm * Wmm;
+          double ua;
+          SIGMA(X, Y, Z, A, B, Cc, ua, 0);
+          Ua[X3(i, j, k)] = MIN(fabs(ua), fac * fabs(Um)) * SIGN1(ua);
+        }
+      }
+  }
+  /* ---- Va :472-640 */
+  for (int j = b->JstrVm1; j <= b->Jendp2; j++) {
+    for (int i = IstrU - 1; i <= b->Iendp1; i++) {
+      const int k = 1;
+      CC_(i, k) = 0.25 * ((TA(i, j, k + 1) - TA(i, j, k)) * ODZ(i, j, k) + (TA(i, j - 1, k + 1) - TA(i, j - 1, k)) * ODZ(i, j - 1, k)) *
+                  (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)] + z_r[X3(i, j - 1, k + 1)] - z_r[X3(i, j - 1, k)]) /
+                  (TA(i, j - 1, k) + TA(i, j, k) + eps);
+      WM_(i, k) = 0.25 * dt * (W[XW(i, j - 1, k)] * ODZ(i, j - 1, k) * pm[X2(i, j - 1)] * pn[X2(i, j - 1)] +
+                               W[XW(i, j, k)] * ODZ(i, j, k) * pm[X2(i, j)] * pn[X2(i, j)]);
+    }
+    for (int k = 2; k <= N - 1; k++)
+      for (int i = IstrU - 1; i <= b->Iendp1; i++) {
+        CC_(i, k) = 0.0625 * ((TA(i, j, k + 1) - TA(i, j, k)) * ODZ(i, j, k) + (TA(i, j, k) - TA(i, j, k - 1)) * ODZ(i, j, k - 1) +
+                              (TA(i, j - 1, k + 1) - TA(i, j - 1, k)) * ODZ(i, j - 1, k) +
+                              (TA(i, j - 1, k) - TA(i, j - 1, k - 1)) * ODZ(i, j - 1, k - 1)) *
+                    (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k - 1)] + z_r[X3(i, j - 1, k + 1)] - z_r[X3(i, j - 1, k - 1)]) /
+                    (TA(i, j - 1, k) + TA(i, j, k) + eps);
+        WM_(i, k) = 0.25 * dt * ((W[XW(i, j - 1, k - 1)] * ODZ(i, j - 1, k - 1) + W[XW(i, j - 1, k)] * ODZ(i, j - 1, k)) *
+                                     pm[X2(i, j - 1)] * pn[X2(i, j - 1)] +
+                                 (W[XW(i, j, k)] * ODZ(i, j, k) + W[XW(i, j, k - 1)] * ODZ(i, j, k - 1)) * pm[X2(i, j)] *
+                                     pn[X2(i, j)]);
+      }
+    for (int i = IstrU - 1; i <= b->Iendp1; i++) {
+      const int k = N;
+      CC_(i, k) = 0.25 * ((TA(i, j, k) - TA(i, j, k - 1)) * ODZ(i, j, k - 1) + (TA(i, j - 1, k) - TA(i, j - 1, k - 1)) * ODZ(i, j - 1, k - 1)) *
+                  (z_r[X3(i, j, k)] - z_r[X3(i, j, k - 1)] + z_r[X3(i, j - 1, k)] - z_r[X3(i, j - 1, k - 1)]) /
+                  (TA(i, j - 1, k) + TA(i, j, k) + eps);
+      WM_(i, k) = 0.25 * dt * (W[XW(i, j - 1, k - 1)] * ODZ(i, j - 1, k - 1) * pm[X2(i, j - 1)] * pn[X2(i, j - 1)] +
+                               W[XW(i, j, k - 1)] * ODZ(i, j, k - 1) * pm[X2(i, j)] * pn[X2(i, j)]);
+    }
+    for (int k = 1; k <= N; k++)
+      for (int i = IstrU - 1; i <= b->Iendp1; i++) {
+        if (TA(i, j - 1, k) <= 0.0 || TA(i, j, k) <= 0.0 || fabs(TA(i, j - 1, k) - TA(i, j, k)) <= eps2) {
+          Va[X3(i, j, k)] = 0.0;
+        } else {
+          double A = 0.03125 * ((TA(i + 1, j, k) - TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                                (TA(i, j, k) - TA(i - 1, j, k)) * (pm[X2(i - 1, j)] + pm[X2(i, j)]) +
+                                (TA(i + 1, j - 1, k) - TA(i, j - 1, k)) * (pm[X2(i + 1, j - 1)] + pm[X2(i, j - 1)]) +
+                                (TA(i, j - 1, k) - TA(i - 1, j - 1, k)) * (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]));
+          A = A * (om_u[X2(i, j)] + om_u[X2(i + 1, j)] + om_u[X2(i, j - 1)] + om_u[X2(i + 1, j - 1)]) /
+              (TA(i, j - 1, k) + TA(i, j, k) + eps);
+          const double B = (TA(i, j, k) - TA(i, j - 1, k)) / (TA(i, j, k) + TA(i, j - 1, k) + eps);
+          const double Um =
+              0.03125 * dt *
+              (Huon[X3(i + 1, j, k)] * (pm[X2(i + 1, j)] + pm[X2(i, j)]) * (pn[X2(i + 1, j)] + pn[X2(i, j)]) *
+                   (oHz[X3(i + 1, j, k)] + oHz[X3(i, j, k)]) +
+               Huon[X3(i + 1, j - 1, k)] * (pm[X2(i + 1, j - 1)] + pm[X2(i, j - 1)]) * (pn[X2(i + 1, j - 1)] + pn[X2(i, j - 1)]) *
+                   (oHz[X3(i + 1, j - 1, k)] + oHz[X3(i, j - 1, k)]) +
+               Huon[X3(i, j, k)] * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (pn[X2(i - 1, j)] + pn[X2(i, j)]) *
+                   (oHz[X3(i - 1, j, k)] + oHz[X3(i, j, k)]) +
+               Huon[X3(i, j - 1, k)] * (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]) * (pn[X2(i - 1, j - 1)] + pn[X2(i, j - 1)]) *
+                   (oHz[X3(i - 1, j - 1, k)] + oHz[X3(i, j - 1, k)]));
+          const double Vm = 0.125 * Hvom[X3(i, j, k)] * dt * (pn[X2(i, j - 1)] + pn[X2(i, j)]) * (pm[X2(i, j - 1)] + pm[X2(i, j)]) *
+                            (oHz[X3(i, j - 1, k)] + oHz[X3(i, j, k)]);
+          const double Cc = CC_(i, k), Wmm = WM_(i, k);
+          const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Cc * Um * Wmm;
+          const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Cc * Vm * Wmm;
+          const double Z = (fabs(Wmm) - Wmm * Wmm) * Cc - A * Um * Wmm - B * Vm * Wmm;
+          double va;
+          SIGMA(Y, X, Z, B, A, Cc, va, 1);
+          Va[X3(i, j, k)] = MIN(fabs(va), fac * fabs(Vm)) * SIGN1(va);
+        }
+      }
+  }
+  /* boundary values of Ua, Va (closed walls of the BASELINE configs) :642-720 */
+  if (!c->EWperiodic) {
+    if (b->west)
+      for (int k = 1; k <= N; k++)
+        for (int j = b->Jstrm1; j <= b->Jendp1; j++) Ua[X3(Istr, j, k)] = 0.0;
+    if (b->east)
+      for (int k = 1; k <= N; k++)
+        for (int j = b->Jstrm1; j <= b->Jendp1; j++) Ua[X3(Iend + 1, j, k)] = 0.0;
+  }
+  if (!c->NSperiodic) {
+    if (b->south)
+      for (int k = 1; k <= N; k++)
+        for (int i = b->Istrm1; i <= b->Iendp1; i++) Va[X3(i, Jstr, k)] = 0.0;
+    if (b->north)
+      for (int k = 1; k <= N; k++)
+        for (int i = b->Istrm1; i <= b->Iendp1; i++) Va[X3(i, Jend + 1, k)] = 0.0;
+  }
+  /* ---- Wa :722-860 */
+  for (int j = JstrV - 1; j <= b->Jendp1; j++) {
+    for (int k = 1; k <= N - 1; k++)
+      for (int i = IstrU - 1; i <= b->Iendp1; i++) {
+        if (TA(i, j, k) <= 0.0 || TA(i, j, k + 1) <= 0.0 || fabs(TA(i, j, k) - TA(i, j, k + 1)) <= eps2) {
+          Wa[XW(i, j, k)] = 0.0;
+        } else {
+          const double Cc = (TA(i, j, k + 1) - TA(i, j, k)) / (TA(i, j, k + 1) + TA(i, j, k) + eps);
+          double A = 0.0625 * ((TA(i + 1, j, k + 1) - TA(i, j, k + 1)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                               (TA(i, j, k + 1) - TA(i - 1, j, k + 1)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]) +
+                               (TA(i + 1, j, k) - TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                               (TA(i, j, k) - TA(i - 1, j, k)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]));
+          double B = 0.0625 * ((TA(i, j + 1, k + 1) - TA(i, j, k + 1)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
+                               (TA(i, j, k + 1) - TA(i, j - 1, k + 1)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) +
+                               (TA(i, j + 1, k) - TA(i, j, k)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
+                               (TA(i, j, k) - TA(i, j - 1, k)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]));
+          A = A * (om_u[X2(i + 1, j)] + om_u[X2(i, j)]) / (TA(i, j, k + 1) + TA(i, j, k) + eps);
+          B = B * (on_v[X2(i, j + 1)] + on_v[X2(i, j)]) / (TA(i, j, k + 1) + TA(i, j, k) + eps);
+          const double Um =
+              0.03125 * dt *
+              (Huon[X3(i, j, k)] * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * (pn[X2(i, j)] + pn[X2(i - 1, j)]) *
+                   (oHz[X3(i, j, k)] + oHz[X3(i - 1, j, k)]) +
+               Huon[X3(i, j, k + 1)] * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * (pn[X2(i, j)] + pn[X2(i - 1, j)]) *
+                   (oHz[X3(i, j, k + 1)] + oHz[X3(i - 1, j, k + 1)]) +
+               Huon[X3(i + 1, j, k)] * (pm[X2(i, j)] + pm[X2(i + 1, j)]) * (pn[X2(i, j)] + pn[X2(i + 1, j)]) *
+                   (oHz[X3(i, j, k)] + oHz[X3(i + 1, j, k)]) +
+               Huon[X3(i + 1, j, k + 1)] * (pm[X2(i, j)] + pm[X2(i + 1, j)]) * (pn[X2(i, j)] + pn[X2(i + 1, j)]) *
+                   (oHz[X3(i, j, k + 1)] + oHz[X3(i + 1, j, k + 1)]));
+          const double Vm =
+              0.03125 * dt *
+              (Hvom[X3(i, j, k)] * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) *
+                   (oHz[X3(i, j, k)] + oHz[X3(i, j - 1, k)]) +
+               Hvom[X3(i, j, k + 1)] * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) *
+                   (oHz[X3(i, j, k + 1)] + oHz[X3(i, j - 1, k + 1)]) +
+               Hvom[X3(i, j + 1, k)] * (pm[X2(i, j)] + pm[X2(i, j + 1)]) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) *
+                   (oHz[X3(i, j, k)] + oHz[X3(i, j + 1, k)]) +
+               Hvom[X3(i, j + 1, k + 1)] * (pm[X2(i, j)] + pm[X2(i, j + 1)]) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) *
+                   (oHz[X3(i, j, k + 1)] + oHz[X3(i, j + 1, k + 1)]));
+          const double Wmm = W[XW(i, j, k)] * ODZ(i, j, k) * pm[X2(i, j)] * pn[X2(i, j)] * dt;
+          const double X = (fabs(Um) - Um * Um) * A - B * Um * Vm - Cc * Um * Wmm;
+          const double Y = (fabs(Vm) - Vm * Vm) * B - A * Um * Vm - Cc * Vm * Wmm;
+          const double Z = (fabs(Wmm) - Wmm * Wmm) * Cc - A * Um * Wmm - B * Vm * Wmm;
+          double wa;
+          /* the reference permutes the cross terms for the vertical component: first Y (with B), then X (with A) */
+          SIGMA(Z, Y, X, Cc, B, A, wa, 0);
+          Wa[XW(i, j, k)] = MIN(fabs(wa), fac * fabs(Wmm)) * SIGN1(wa);
+        }
+      }
+    for (int i = IstrU - 1; i <= b->Iendp1; i++) {
+      Wa[XW(i, j, 0)] = 0.0;
+      Wa[XW(i, j, N)] = 0.0;
+    }
+  }
+  /* ---- FCT limiter :862-1150 (no masking: mask_up = mask_dn = 1) */
+  for (int j = JstrV - 1; j <= b->Jendp1; j++)
+    for (int k = 1; k <= N; k++)
+      for (int i = IstrU - 1; i <= b->Iendp1; i++) {
+        double v[14];
+        int n = 0;
+        v[n++] = TA(i - 1, j, k); v[n++] = T3(i - 1, j, k);
+        v[n++] = TA(i, j, k); v[n++] = T3(i, j, k);
+        v[n++] = TA(i + 1, j, k); v[n++] = T3(i + 1, j, k);
+        v[n++] = TA(i, j - 1, k); v[n++] = T3(i, j - 1, k);
+        v[n++] = TA(i, j + 1, k); v[n++] = T3(i, j + 1, k);
+        if (k > 1) { v[n++] = TA(i, j, k - 1); v[n++] = T3(i, j, k - 1); }
+        if (k < N) { v[n++] = TA(i, j, k + 1); v[n++] = T3(i, j, k + 1); }
+        const double Tmax = max12(v, n), Tmin = min12(v, n);
+        double cff1 = TA(i - 1, j, k) * MAX(0.0, Ua[X3(i, j, k)]) - TA(i + 1, j, k) * MIN(0.0, Ua[X3(i + 1, j, k)]) +
+                      TA(i, j - 1, k) * MAX(0.0, Va[X3(i, j, k)]) - TA(i, j + 1, k) * MIN(0.0, Va[X3(i, j + 1, k)]);
+        if (k > 1) cff1 = cff1 + TA(i, j, k - 1) * MAX(0.0, Wa[XW(i, j, k - 1)]);
+        if (k < N) cff1 = cff1 - TA(i, j, k + 1) * MIN(0.0, Wa[XW(i, j, k)]);
+        beta_up[X3(i, j, k)] = (Tmax - TA(i, j, k)) / (cff1 + eps);
+        double cff2 = TA(i, j, k) * MAX(0.0, Ua[X3(i + 1, j, k)]) - TA(i, j, k) * MIN(0.0, Ua[X3(i, j, k)]) +
+                      TA(i, j, k) * MAX(0.0, Va[X3(i, j + 1, k)]) - TA(i, j, k) * MIN(0.0, Va[X3(i, j, k)]);
+        if (k < N) cff2 = cff2 + TA(i, j, k) * MAX(0.0, Wa[XW(i, j, k)]);
+        if (k > 1) cff2 = cff2 - TA(i, j, k) * MIN(0.0, Wa[XW(i, j, k - 1)]);
+        beta_dn[X3(i, j, k)] = (TA(i, j, k) - Tmin) / (cff2 + eps);
+      }
+  {
+    const double cff = 1.0 / dt;
+    for (int k = 1; k <= N; k++) {
+      for (int j = Jstr; j <= Jend; j++)
+        for (int i = IstrU; i <= b->Iendp1; i++) {
+          const double cff1 = MIN(MIN(beta_dn[X3(i - 1, j, k)], beta_up[X3(i, j, k)]), 1.0);
+          const double cff2 = MIN(MIN(beta_up[X3(i - 1, j, k)], beta_dn[X3(i, j, k)]), 1.0);
+          Ua[X3(i, j, k)] = (cff1 * MAX(0.0, Ua[X3(i, j, k)]) + cff2 * MIN(0.0, Ua[X3(i, j, k)])) * cff * om_u[X2(i, j)];
+        }
+      for (int j = JstrV; j <= b->Jendp1; j++)
+        for (int i = Istr; i <= Iend; i++) {
+          const double cff1 = MIN(MIN(beta_dn[X3(i, j - 1, k)], beta_up[X3(i, j, k)]), 1.0);
+          const double cff2 = MIN(MIN(beta_up[X3(i, j - 1, k)], beta_dn[X3(i, j, k)]), 1.0);
+          Va[X3(i, j, k)] = (cff1 * MAX(0.0, Va[X3(i, j, k)]) + cff2 * MIN(0.0, Va[X3(i, j, k)])) * cff * on_v[X2(i, j)];
+        }
+      if (k < N)
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = Istr; i <= Iend; i++) {
+            const double cff1 = MIN(MIN(beta_dn[X3(i, j, k)], beta_up[X3(i, j, k + 1)]), 1.0);
+            const double cff2 = MIN(MIN(beta_up[X3(i, j, k)], beta_dn[X3(i, j, k + 1)]), 1.0);
+            Wa[XW(i, j, k)] = (cff1 * MAX(0.0, Wa[XW(i, j, k)]) + cff2 * MIN(0.0, Wa[XW(i, j, k)])) * cff * omn[X2(i, j)] *
+                              (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]);
+          }
+    }
+  }
+  /* closed walls after the limiter :1152-1220 */
+  if (!c->EWperiodic) {
+    if (b->west)
+      for (int k = 1; k <= N; k++)
+        for (int j = Jstr; j <= Jend; j++) Ua[X3(Istr, j, k)] = 0.0;
+    if (b->east)
+      for (int k = 1; k <= N; k++)
+        for (int j = Jstr; j <= Jend; j++) Ua[X3(Iend + 1, j, k)] = 0.0;
+  }
+  if (!c->NSperiodic) {
+    if (b->south)
+      for (int k = 1; k <= N; k++)
+        for (int i = Istr; i <= Iend; i++) Va[X3(i, Jstr, k)] = 0.0;
+    if (b->north)
+      for (int k = 1; k <= N; k++)
+        for (int i = Istr; i <= Iend; i++) Va[X3(i, Jend + 1, k)] = 0.0;
+  }
+  free(odz);
+  free(C);
+}

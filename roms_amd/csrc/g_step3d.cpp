@@ -1,6 +1,7 @@
 // g_step3d.cpp -- launch sequences of step3d_uv and step3d_t.
 #include "roms_host.h"
 #include "k_step3d.h"
+#include "k_mpdata.h"
 
 static inline KArgs mk(roms_hip_ctx *c, int p0 = 0) {
   KArgs a;
@@ -11,7 +12,6 @@ static inline KArgs mk(roms_hip_ctx *c, int p0 = 0) {
 }
 static inline size_t lds_sz(const DGrid &G) { return (size_t)(G.bw + 6) * (size_t)(G.bh + 6); }
 
-int run_step3d_t_mpdata(roms_hip_ctx *c);   // g_mpdata.cpp
 
 int run_step3d_uv(roms_hip_ctx *c) {
   const DGrid &G = c->G;
@@ -38,12 +38,37 @@ int run_step3d_t(roms_hip_ctx *c) {
   const TB &B = G.T;
   const int N = G.N, nnew = G.nnew;
   bool any_mp = false;
-  for (int it = 0; it < G.NT; it++) any_mp |= (G.hadv[it] == ROMS_MPDATA || G.vadv[it] == ROMS_MPDATA);
-  if (any_mp) return run_step3d_t_mpdata(c);
+  for (int it = 0; it < G.NT; it++) {
+    const bool hm = G.hadv[it] == ROMS_MPDATA, vm = G.vadv[it] == ROMS_MPDATA;
+    if (hm != vm) { set_error("step3d_t: MPDATA must be selected for both Hadvection and Vadvection of a tracer"); return 8; }
+    any_mp |= hm;
+  }
+  if (any_mp && !c->F.mp3[0]) { set_error("step3d_t: MPDATA work arrays missing"); return 8; }
+  if (any_mp) {
+    // exchange of t(nnew) :420: the extended range below reads it at ghost points
+    HaloSpec sp[ROMS_MAXT];
+    int n = 0;
+    for (int it = 1; it <= G.NT; it++)
+      if (G.hadv[it - 1] == ROMS_MPDATA) sp[n++] = {t_lev(c, nnew, it), N, BC_NONE, 'r'};
+    launch_halo_multi(c, sp, n);
+  }
   KArgs a = mk(c);
   // exchange of t(nnew) for HSIMT tracers (:420) only refreshes ghost points that are not read here
   LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
   LAUNCH_THREAD(k_s3t_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);
+  for (int it = 1; it <= G.NT && any_mp; it++) {
+    if (G.hadv[it - 1] != ROMS_MPDATA) continue;
+    MpArgs m;
+    m.G = G; m.Fp = c->d_F; m.itrc = it;
+    const int LmT = B.Iend - B.Istr + 1, MmT = B.Jend - B.Jstr + 1;
+    LAUNCH_THREAD(k_mp_ta, B.Iendp2i - B.IstrUm2 + 1, B.Jendp2i - B.JstrVm2 + 1, N, c->stream, m);
+    LAUNCH_THREAD(k_mp_uva, B.Iendp2 - (B.IstrU - 1) + 1, B.Jendp2 - KMIN(B.JstrV - 1, B.JstrVm1) + 1, 2 * N, c->stream, m);
+    LAUNCH_THREAD(k_mp_wa, B.Iendp1 - (B.IstrU - 1) + 1, B.Jendp1 - (B.JstrV - 1) + 1, N + 1, c->stream, m);
+    LAUNCH_THREAD(k_mp_beta, B.Iendp1 - (B.IstrU - 1) + 1, B.Jendp1 - (B.JstrV - 1) + 1, N, c->stream, m);
+    LAUNCH_THREAD(k_mp_limit, LmT + 1, MmT + 1, N, c->stream, m);
+    LAUNCH_THREAD(k_mp_apply, LmT, MmT, N, c->stream, m);
+    LAUNCH_THREAD(k_mp_vdiff, LmT, MmT, 1, c->stream, m);
+  }
   HaloSpec sp[ROMS_MAXT];
   for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, BC_R, 'r'};   // t3dbc :1858 + exchange :1920
   launch_halo_multi(c, sp, G.NT);

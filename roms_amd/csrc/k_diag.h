@@ -238,17 +238,24 @@ COOP_KERNEL(k_diag_fin, DiagArgs) {
     if (KTID < 256) { mC[KTID] = pC; mS[KTID] = pS; mI[KTID] = (double)pi; mJ[KTID] = (double)pj; mK[KTID] = (double)pk; }
   }
   KSYNC();
-  if (KTID == 0) {
-    const int np = KMIN(KNT, 256);
-    for (int t = 0; t < np; t++) {
-      if (mS[t] > spd) spd = mS[t];
-      const double C = mC[t];
-      const int i = (int)mI[t];
-      if (C > 0.0) {
-        const int j = (int)mJ[t], k = (int)mK[t];
-        if (bC == 0.0 || diag_better(C, j, k, i, bC, bj, bk, bi)) { bC = C; bi = i; bj = j; bk = k; }
+#ifndef ROMS_CPU_EMU
+  // tree merge of the 256 partial results (the ordering relation is total: any merge order)
+  for (int stride = 128; stride >= 1; stride >>= 1) {
+    if (KTID < stride) {
+      const int o = KTID + stride;
+      if (mS[o] > mS[KTID]) mS[KTID] = mS[o];
+      const double C = mC[o];
+      if (C > 0.0 && (mC[KTID] == 0.0 || diag_better(C, (int)mJ[o], (int)mK[o], (int)mI[o], mC[KTID], (int)mJ[KTID],
+                                                     (int)mK[KTID], (int)mI[KTID]))) {
+        mC[KTID] = C; mI[KTID] = mI[o]; mJ[KTID] = mJ[o]; mK[KTID] = mK[o];
       }
     }
+    KSYNC();
+  }
+#endif
+  if (KTID == 0) {
+    if (mS[0] > spd) spd = mS[0];
+    if (mC[0] > 0.0) { bC = mC[0]; bi = (int)mI[0]; bj = (int)mJ[0]; bk = (int)mK[0]; }
     if (bC > 0.0) {
       const int ii = bi - G.LBi;
       bCu = row[ii + 5 * ni]; bCv = row[ii + 6 * ni]; bCw = row[ii + 7 * ni];

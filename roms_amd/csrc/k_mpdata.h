@@ -1,0 +1,395 @@
+// k_mpdata.h -- MPDATA tracer advection of step3d_t (tracers with Hadvection = Vadvection = MPDATA).
+//
+// Replaces, for such tracers:
+//   step3d_t_tile   ROMS/Nonlinear/step3d_t.F  first-order upstream fluxes on the extended range
+//                   :451-470, horizontal step into Ta :873-890, vertical step :995-1010,1246-1290,
+//                   corrected (anti-diffusive) fluxes :1399-1500, plain implicit vertical diffusion
+//                   :1724-1790
+//   mpdata_adiff_tile  ROMS/Nonlinear/mpdata_adiff.F:38-1227
+//
+// All kernels are point-wise (one thread per (i,j,k)); the reference's per-row temporaries C(i,k),
+// Wm(i,k), odz and oHz are functions of the point and are recomputed where they are used.
+// Work arrays (Fields::mp3): 0 Ta (N planes per tracer), 1 Ua, 2 Va, 3 Wa (w-levels), 4 beta_up,
+// 5 beta_dn.
+#pragma once
+#include "roms_ctx.h"
+#include "k_diag3d.h"
+
+struct MpArgs {
+  DGrid G;
+  const Fields *Fp;
+  int itrc;
+};
+
+#define MP_TA(i, j, k) Ta[X3(i, j, k)]
+#define MP_ODZ(i, j, k) (1.0 / (z_r[X3(i, j, (k) + 1)] - z_r[X3(i, j, k)]))
+#define MP_OHZ(i, j, k) (1.0 / Hz[X3(i, j, k)])
+#define MP_SIGN1(x) ((x) >= 0.0 ? 1.0 : -1.0)
+
+// the third-order pseudo-velocity polynomial of mpdata_adiff.F (:405-440, :575-610, :790-830): P is
+// the component being built, Q and R the other two, gp/gq/gr the normalised gradients.  The eta
+// component multiplies sig_b with P*Q^2 and sig_c with P^2*Q (swapbc), as the reference does.
+#define MP_SIGMA(P, Q, R, gp, gq, gr, out, swapbc)                                                          \
+  do {                                                                                                       \
+    const double PP = (gp) * (gp), QQ = (gq) * (gq), RR = (gr) * (gr), PQ = (gp) * (gq), PR = (gp) * (gr);    \
+    const double sPP = (P) * (P), sQQ = (Q) * (Q), sRR = (R) * (R), sPQ = (P) * (Q), sPR = (P) * (R);         \
+    const double s_alfa = 1.0 / (1.0 - fabs(gp) + eps);                                                      \
+    const double s_beta = -(gp) / ((1.0 - fabs(gp)) * (1.0 - PP) + eps);                                     \
+    const double s_gama = 2.0 * fabs(PP * (gp)) / ((1.0 - fabs(gp)) * (1.0 - PP) * (1.0 - fabs(PP * (gp))) + eps); \
+    const double s_a = -(gq) / ((1.0 - fabs(gp)) * (1.0 - fabs(PQ)) + eps);                                  \
+    const double s_b = PQ / ((1.0 - fabs(gp)) * (1.0 - PP * fabs(gq)) + eps) *                               \
+                       (fabs(gq) / (1.0 - fabs(PQ) + eps) + 2.0 * (gp) / (1.0 - PP + eps));                  \
+    const double s_c = fabs(gp) * QQ / ((1.0 - fabs(gp)) * (1.0 - QQ * fabs(gp)) * (1.0 - fabs(PQ)) + eps);  \
+    const double s_d = -(gr) / ((1.0 - fabs(gp)) * (1.0 - fabs(PR)) + eps);                                  \
+    const double s_e = PR / ((1.0 - fabs(gp)) * (1.0 - PP * fabs(gr)) + eps) *                               \
+                       (fabs(gr) / (1.0 - fabs(PR) + eps) + 2.0 * (gp) / (1.0 - PP + eps));                  \
+    const double s_f = fabs(gp) * RR / ((1.0 - fabs(gp)) * (1.0 - RR * fabs(gp)) * (1.0 - fabs(PR)) + eps);  \
+    out = s_alfa * (P) + s_beta * sPP + s_gama * sPP * (P) + s_a * sPQ +                                     \
+          ((swapbc) ? s_b * (P) * sQQ : s_b * sPP * (Q)) + ((swapbc) ? s_c * sPP * (Q) : s_c * (P) * sQQ) +  \
+          s_d * sPR + s_e * sPP * (R) + s_f * (P) * sRR;                                                     \
+  } while (0)
+
+// ---- Ta: first-order upstream horizontal and vertical steps on the extended range ------------
+// index space (IstrUm2:Iendp2i, JstrVm2:Jendp2i, 1:N); also the closed-edge values of Ta that
+// mpdata_adiff fills (:224-290)
+THREAD_KERNEL(k_mp_ta, MpArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const TB &B = G.T;
+  const int i = B.IstrUm2 + gx, j = B.JstrVm2 + gy, k = gz + 1, N = G.N, itrc = a.itrc;
+  if (i > B.Iendp2i || j > B.Jendp2i) return;
+  const double *T3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc), *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);
+  const double *Hu = F.Huon, *Hv = F.Hvom, *W = F.W, *Hz = F.Hz;
+  double *Ta = F.mp3[0] + (size_t)(itrc - 1) * G.nij * N;
+#define MP_FX(ii) (KMAX(Hu[X3(ii, j, k)], 0.0) * T3[X3((ii) - 1, j, k)] + KMIN(Hu[X3(ii, j, k)], 0.0) * T3[X3(ii, j, k)])
+#define MP_FE(jj) (KMAX(Hv[X3(i, jj, k)], 0.0) * T3[X3(i, (jj) - 1, k)] + KMIN(Hv[X3(i, jj, k)], 0.0) * T3[X3(i, jj, k)])
+#define MP_FC(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : KMAX(W[XW(i, j, kk)], 0.0) * T3[X3(i, j, kk)] + KMIN(W[XW(i, j, kk)], 0.0) * T3[X3(i, j, (kk) + 1)])
+  const double cff = G.dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
+  const double cff1 = cff * (MP_FX(i + 1) - MP_FX(i));
+  const double cff2 = cff * (MP_FE(j + 1) - MP_FE(j));
+  const double cff3 = cff1 + cff2;
+  double ta = tn[X3(i, j, k)] - cff3;
+  const double cv = cff * (MP_FC(k) - MP_FC(k - 1));
+  ta = (ta - cv) * MP_OHZ(i, j, k);
+#undef MP_FX
+#undef MP_FE
+#undef MP_FC
+  Ta[X3(i, j, k)] = ta;
+  const bool w = !G.ewp && B.west && i == B.Istr, e = !G.ewp && B.east && i == B.Iend;
+  const bool s = !G.nsp && B.south && j == B.Jstr, n = !G.nsp && B.north && j == B.Jend;
+  if (w) Ta[X3(i - 1, j, k)] = ta;
+  if (e) Ta[X3(i + 1, j, k)] = ta;
+  if (s) Ta[X3(i, j - 1, k)] = ta;
+  if (n) Ta[X3(i, j + 1, k)] = ta;
+  // corners (closed in both directions): 0.5*(edge + edge) of two copies of the same value
+  if (w && s) Ta[X3(i - 1, j - 1, k)] = 0.5 * (ta + ta);
+  if (e && s) Ta[X3(i + 1, j - 1, k)] = 0.5 * (ta + ta);
+  if (w && n) Ta[X3(i - 1, j + 1, k)] = 0.5 * (ta + ta);
+  if (e && n) Ta[X3(i + 1, j + 1, k)] = 0.5 * (ta + ta);
+}
+THREAD_GLOBAL(k_mp_ta, MpArgs)
+
+// ---- Ua (dir 0; index space IstrU-1:Iendp2, JstrV-1:Jendp1) and Va (dir 1; IstrU-1:Iendp1,
+//      JstrVm1:Jendp2), mpdata_adiff.F:307-640, with the closed-wall values :642-720 ------------
+THREAD_KERNEL(k_mp_uva, MpArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const TB &B = G.T;
+  const int N = G.N, itrc = a.itrc;
+  const int dir = gz / N, k = gz % N + 1;
+  const int i = B.IstrU - 1 + gx, j = (dir == 0 ? B.JstrV - 1 : B.JstrVm1) + gy;
+  if (i > (dir == 0 ? B.Iendp2 : B.Iendp1) || j > (dir == 0 ? B.Jendp1 : B.Jendp2)) return;
+  const double eps = 1.0E-18, eps2 = 1.0E-10, fac = 1.0, dt = G.dt;
+  const double *Ta = F.mp3[0] + (size_t)(itrc - 1) * G.nij * N;
+  const double *pm = F.pm, *pn = F.pn, *z_r = F.z_r, *W = F.W, *Hz = F.Hz, *Huon = F.Huon, *Hvom = F.Hvom;
+  const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1;     // the neighbour across the face: (i-di, j-dj)
+  const int im = i - di, jm = j - dj;
+  double *Out = F.mp3[dir == 0 ? 1 : 2];
+  double val;
+  if (MP_TA(im, jm, k) <= 0.0 || MP_TA(i, j, k) <= 0.0 || fabs(MP_TA(im, jm, k) - MP_TA(i, j, k)) <= eps2) {
+    val = 0.0;
+  } else {
+    // vertical gradient C and vertical Courant number Wm at the face (:311-370, :476-535)
+    double Cc, Wmm;
+    if (k == 1) {
+      Cc = 0.25 * ((MP_TA(i, j, k + 1) - MP_TA(i, j, k)) * MP_ODZ(i, j, k) + (MP_TA(im, jm, k + 1) - MP_TA(im, jm, k)) * MP_ODZ(im, jm, k)) *
+           (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)] + z_r[X3(im, jm, k + 1)] - z_r[X3(im, jm, k)]) /
+           (MP_TA(im, jm, k) + MP_TA(i, j, k) + eps);
+      Wmm = 0.25 * dt * (W[XW(im, jm, k)] * MP_ODZ(im, jm, k) * pm[X2(im, jm)] * pn[X2(im, jm)] +
+                         W[XW(i, j, k)] * MP_ODZ(i, j, k) * pm[X2(i, j)] * pn[X2(i, j)]);
+    } else if (k < N) {
+      Cc = 0.0625 * ((MP_TA(i, j, k + 1) - MP_TA(i, j, k)) * MP_ODZ(i, j, k) + (MP_TA(i, j, k) - MP_TA(i, j, k - 1)) * MP_ODZ(i, j, k - 1) +
+                     (MP_TA(im, jm, k + 1) - MP_TA(im, jm, k)) * MP_ODZ(im, jm, k) +
+                     (MP_TA(im, jm, k) - MP_TA(im, jm, k - 1)) * MP_ODZ(im, jm, k - 1)) *
+           (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k - 1)] + z_r[X3(im, jm, k + 1)] - z_r[X3(im, jm, k - 1)]) /
+           (MP_TA(im, jm, k) + MP_TA(i, j, k) + eps);
+      Wmm = 0.25 * dt * ((W[XW(im, jm, k - 1)] * MP_ODZ(im, jm, k - 1) + W[XW(im, jm, k)] * MP_ODZ(im, jm, k)) * pm[X2(im, jm)] *
+                             pn[X2(im, jm)] +
+                         (W[XW(i, j, k)] * MP_ODZ(i, j, k) + W[XW(i, j, k - 1)] * MP_ODZ(i, j, k - 1)) * pm[X2(i, j)] * pn[X2(i, j)]);
+    } else {
+      Cc = 0.25 * ((MP_TA(i, j, k) - MP_TA(i, j, k - 1)) * MP_ODZ(i, j, k - 1) + (MP_TA(im, jm, k) - MP_TA(im, jm, k - 1)) * MP_ODZ(im, jm, k - 1)) *
+           (z_r[X3(i, j, k)] - z_r[X3(i, j, k - 1)] + z_r[X3(im, jm, k)] - z_r[X3(im, jm, k - 1)]) /
+           (MP_TA(im, jm, k) + MP_TA(i, j, k) + eps);
+      Wmm = 0.25 * dt * (W[XW(im, jm, k - 1)] * MP_ODZ(im, jm, k - 1) * pm[X2(im, jm)] * pn[X2(im, jm)] +
+                         W[XW(i, j, k - 1)] * MP_ODZ(i, j, k - 1) * pm[X2(i, j)] * pn[X2(i, j)]);
+    }
+    double A, Bg, Um, Vm;
+    if (dir == 0) {
+      A = (MP_TA(i, j, k) - MP_TA(i - 1, j, k)) / (MP_TA(i, j, k) + MP_TA(i - 1, j, k) + eps);
+      Bg = 0.03125 * ((MP_TA(i, j + 1, k) - MP_TA(i, j, k)) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) +
+                      (MP_TA(i, j, k) - MP_TA(i, j - 1, k)) * (pn[X2(i, j - 1)] + pn[X2(i, j)]) +
+                      (MP_TA(i - 1, j + 1, k) - MP_TA(i - 1, j, k)) * (pn[X2(i - 1, j)] + pn[X2(i - 1, j + 1)]) +
+                      (MP_TA(i - 1, j, k) - MP_TA(i - 1, j - 1, k)) * (pn[X2(i - 1, j - 1)] + pn[X2(i - 1, j)]));
+      Bg = Bg * (F.on_v[X2(i, j)] + F.on_v[X2(i, j + 1)] + F.on_v[X2(i - 1, j)] + F.on_v[X2(i - 1, j + 1)]) /
+           (MP_TA(i - 1, j, k) + MP_TA(i, j, k) + eps);
+      Um = 0.125 * Huon[X3(i, j, k)] * dt * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * (pn[X2(i, j)] + pn[X2(i - 1, j)]) *
+           (MP_OHZ(i - 1, j, k) + MP_OHZ(i, j, k));
+      Vm = 0.03125 * dt *
+           (Hvom[X3(i - 1, j, k)] * (pm[X2(i - 1, j)] + pm[X2(i - 1, j - 1)]) * (pn[X2(i - 1, j)] + pn[X2(i - 1, j - 1)]) *
+                (MP_OHZ(i - 1, j, k) + MP_OHZ(i - 1, j - 1, k)) +
+            Hvom[X3(i - 1, j + 1, k)] * (pm[X2(i - 1, j + 1)] + pm[X2(i - 1, j)]) * (pn[X2(i - 1, j + 1)] + pn[X2(i - 1, j)]) *
+                (MP_OHZ(i - 1, j + 1, k) + MP_OHZ(i - 1, j, k)) +
+            Hvom[X3(i, j, k)] * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) *
+                (MP_OHZ(i, j, k) + MP_OHZ(i, j - 1, k)) +
+            Hvom[X3(i, j + 1, k)] * (pm[X2(i, j + 1)] + pm[X2(i, j)]) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) *
+                (MP_OHZ(i, j + 1, k) + MP_OHZ(i, j, k)));
+    } else {
+      A = 0.03125 * ((MP_TA(i + 1, j, k) - MP_TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                     (MP_TA(i, j, k) - MP_TA(i - 1, j, k)) * (pm[X2(i - 1, j)] + pm[X2(i, j)]) +
+                     (MP_TA(i + 1, j - 1, k) - MP_TA(i, j - 1, k)) * (pm[X2(i + 1, j - 1)] + pm[X2(i, j - 1)]) +
+                     (MP_TA(i, j - 1, k) - MP_TA(i - 1, j - 1, k)) * (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]));
+      A = A * (F.om_u[X2(i, j)] + F.om_u[X2(i + 1, j)] + F.om_u[X2(i, j - 1)] + F.om_u[X2(i + 1, j - 1)]) /
+          (MP_TA(i, j - 1, k) + MP_TA(i, j, k) + eps);
+      Bg = (MP_TA(i, j, k) - MP_TA(i, j - 1, k)) / (MP_TA(i, j, k) + MP_TA(i, j - 1, k) + eps);
+      Um = 0.03125 * dt *
+           (Huon[X3(i + 1, j, k)] * (pm[X2(i + 1, j)] + pm[X2(i, j)]) * (pn[X2(i + 1, j)] + pn[X2(i, j)]) *
+                (MP_OHZ(i + 1, j, k) + MP_OHZ(i, j, k)) +
+            Huon[X3(i + 1, j - 1, k)] * (pm[X2(i + 1, j - 1)] + pm[X2(i, j - 1)]) * (pn[X2(i + 1, j - 1)] + pn[X2(i, j - 1)]) *
+                (MP_OHZ(i + 1, j - 1, k) + MP_OHZ(i, j - 1, k)) +
+            Huon[X3(i, j, k)] * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (pn[X2(i - 1, j)] + pn[X2(i, j)]) *
+                (MP_OHZ(i - 1, j, k) + MP_OHZ(i, j, k)) +
+            Huon[X3(i, j - 1, k)] * (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]) * (pn[X2(i - 1, j - 1)] + pn[X2(i, j - 1)]) *
+                (MP_OHZ(i - 1, j - 1, k) + MP_OHZ(i, j - 1, k)));
+      Vm = 0.125 * Hvom[X3(i, j, k)] * dt * (pn[X2(i, j - 1)] + pn[X2(i, j)]) * (pm[X2(i, j - 1)] + pm[X2(i, j)]) *
+           (MP_OHZ(i, j - 1, k) + MP_OHZ(i, j, k));
+    }
+    const double X = (fabs(Um) - Um * Um) * A - Bg * Um * Vm - Cc * Um * Wmm;
+    const double Y = (fabs(Vm) - Vm * Vm) * Bg - A * Um * Vm - Cc * Vm * Wmm;
+    const double Z = (fabs(Wmm) - Wmm * Wmm) * Cc - A * Um * Wmm - Bg * Vm * Wmm;
+    double r;
+    if (dir == 0) {
+      MP_SIGMA(X, Y, Z, A, Bg, Cc, r, 0);
+      val = KMIN(fabs(r), fac * fabs(Um)) * MP_SIGN1(r);
+    } else {
+      MP_SIGMA(Y, X, Z, Bg, A, Cc, r, 1);
+      val = KMIN(fabs(r), fac * fabs(Vm)) * MP_SIGN1(r);
+    }
+  }
+  // closed walls :642-720 (the wall value replaces whatever was computed there)
+  if (dir == 0) {
+    if (!G.ewp && ((B.west && i == B.Istr) || (B.east && i == B.Iend + 1)) && j >= B.Jstrm1 && j <= B.Jendp1) val = 0.0;
+  } else {
+    if (!G.nsp && ((B.south && j == B.Jstr) || (B.north && j == B.Jend + 1)) && i >= B.Istrm1 && i <= B.Iendp1) val = 0.0;
+  }
+  Out[X3(i, j, k)] = val;
+}
+THREAD_GLOBAL(k_mp_uva, MpArgs)
+
+// ---- Wa, mpdata_adiff.F:722-860; index space (IstrU-1:Iendp1, JstrV-1:Jendp1, 0:N) -----------
+THREAD_KERNEL(k_mp_wa, MpArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const TB &B = G.T;
+  const int N = G.N, itrc = a.itrc;
+  const int i = B.IstrU - 1 + gx, j = B.JstrV - 1 + gy, k = gz;
+  if (i > B.Iendp1 || j > B.Jendp1) return;
+  const double eps = 1.0E-18, eps2 = 1.0E-10, fac = 1.0, dt = G.dt;
+  const double *Ta = F.mp3[0] + (size_t)(itrc - 1) * G.nij * N;
+  const double *pm = F.pm, *pn = F.pn, *z_r = F.z_r, *W = F.W, *Hz = F.Hz, *Huon = F.Huon, *Hvom = F.Hvom;
+  double *Wa = F.mp3[3];
+  double val = 0.0;
+  if (k >= 1 && k <= N - 1 &&
+      !(MP_TA(i, j, k) <= 0.0 || MP_TA(i, j, k + 1) <= 0.0 || fabs(MP_TA(i, j, k) - MP_TA(i, j, k + 1)) <= eps2)) {
+    const double Cc = (MP_TA(i, j, k + 1) - MP_TA(i, j, k)) / (MP_TA(i, j, k + 1) + MP_TA(i, j, k) + eps);
+    double A = 0.0625 * ((MP_TA(i + 1, j, k + 1) - MP_TA(i, j, k + 1)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                         (MP_TA(i, j, k + 1) - MP_TA(i - 1, j, k + 1)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]) +
+                         (MP_TA(i + 1, j, k) - MP_TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                         (MP_TA(i, j, k) - MP_TA(i - 1, j, k)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]));
+    double Bg = 0.0625 * ((MP_TA(i, j + 1, k + 1) - MP_TA(i, j, k + 1)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
+                          (MP_TA(i, j, k + 1) - MP_TA(i, j - 1, k + 1)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) +
+                          (MP_TA(i, j + 1, k) - MP_TA(i, j, k)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
+                          (MP_TA(i, j, k) - MP_TA(i, j - 1, k)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]));
+    A = A * (F.om_u[X2(i + 1, j)] + F.om_u[X2(i, j)]) / (MP_TA(i, j, k + 1) + MP_TA(i, j, k) + eps);
+    Bg = Bg * (F.on_v[X2(i, j + 1)] + F.on_v[X2(i, j)]) / (MP_TA(i, j, k + 1) + MP_TA(i, j, k) + eps);
+    const double Um =
+        0.03125 * dt *
+        (Huon[X3(i, j, k)] * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * (pn[X2(i, j)] + pn[X2(i - 1, j)]) *
+             (MP_OHZ(i, j, k) + MP_OHZ(i - 1, j, k)) +
+         Huon[X3(i, j, k + 1)] * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * (pn[X2(i, j)] + pn[X2(i - 1, j)]) *
+             (MP_OHZ(i, j, k + 1) + MP_OHZ(i - 1, j, k + 1)) +
+         Huon[X3(i + 1, j, k)] * (pm[X2(i, j)] + pm[X2(i + 1, j)]) * (pn[X2(i, j)] + pn[X2(i + 1, j)]) *
+             (MP_OHZ(i, j, k) + MP_OHZ(i + 1, j, k)) +
+         Huon[X3(i + 1, j, k + 1)] * (pm[X2(i, j)] + pm[X2(i + 1, j)]) * (pn[X2(i, j)] + pn[X2(i + 1, j)]) *
+             (MP_OHZ(i, j, k + 1) + MP_OHZ(i + 1, j, k + 1)));
+    const double Vm =
+        0.03125 * dt *
+        (Hvom[X3(i, j, k)] * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) *
+             (MP_OHZ(i, j, k) + MP_OHZ(i, j - 1, k)) +
+         Hvom[X3(i, j, k + 1)] * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) *
+             (MP_OHZ(i, j, k + 1) + MP_OHZ(i, j - 1, k + 1)) +
+         Hvom[X3(i, j + 1, k)] * (pm[X2(i, j)] + pm[X2(i, j + 1)]) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) *
+             (MP_OHZ(i, j, k) + MP_OHZ(i, j + 1, k)) +
+         Hvom[X3(i, j + 1, k + 1)] * (pm[X2(i, j)] + pm[X2(i, j + 1)]) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) *
+             (MP_OHZ(i, j, k + 1) + MP_OHZ(i, j + 1, k + 1)));
+    const double Wmm = W[XW(i, j, k)] * MP_ODZ(i, j, k) * pm[X2(i, j)] * pn[X2(i, j)] * dt;
+    const double X = (fabs(Um) - Um * Um) * A - Bg * Um * Vm - Cc * Um * Wmm;
+    const double Y = (fabs(Vm) - Vm * Vm) * Bg - A * Um * Vm - Cc * Vm * Wmm;
+    const double Z = (fabs(Wmm) - Wmm * Wmm) * Cc - A * Um * Wmm - Bg * Vm * Wmm;
+    double r;
+    MP_SIGMA(Z, Y, X, Cc, Bg, A, r, 0);
+    val = KMIN(fabs(r), fac * fabs(Wmm)) * MP_SIGN1(r);
+  }
+  Wa[XW(i, j, k)] = val;
+}
+THREAD_GLOBAL(k_mp_wa, MpArgs)
+
+// ---- FCT ratios beta_up, beta_dn :862-1090; index space (IstrU-1:Iendp1, JstrV-1:Jendp1, 1:N) -
+THREAD_KERNEL(k_mp_beta, MpArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const TB &B = G.T;
+  const int N = G.N, itrc = a.itrc;
+  const int i = B.IstrU - 1 + gx, j = B.JstrV - 1 + gy, k = gz + 1;
+  if (i > B.Iendp1 || j > B.Jendp1) return;
+  const double eps = 1.0E-18;
+  const double *Ta = F.mp3[0] + (size_t)(itrc - 1) * G.nij * N, *Ua = F.mp3[1], *Va = F.mp3[2], *Wa = F.mp3[3];
+  const double *T3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
+  double Tmax = MP_TA(i - 1, j, k), Tmin = Tmax;
+#define MP_MM(v_) do { const double q_ = (v_); Tmax = KMAX(Tmax, q_); Tmin = KMIN(Tmin, q_); } while (0)
+  MP_MM(T3[X3(i - 1, j, k)]);
+  MP_MM(MP_TA(i, j, k)); MP_MM(T3[X3(i, j, k)]);
+  MP_MM(MP_TA(i + 1, j, k)); MP_MM(T3[X3(i + 1, j, k)]);
+  MP_MM(MP_TA(i, j - 1, k)); MP_MM(T3[X3(i, j - 1, k)]);
+  MP_MM(MP_TA(i, j + 1, k)); MP_MM(T3[X3(i, j + 1, k)]);
+  if (k > 1) { MP_MM(MP_TA(i, j, k - 1)); MP_MM(T3[X3(i, j, k - 1)]); }
+  if (k < N) { MP_MM(MP_TA(i, j, k + 1)); MP_MM(T3[X3(i, j, k + 1)]); }
+#undef MP_MM
+  double cff1 = MP_TA(i - 1, j, k) * KMAX(0.0, Ua[X3(i, j, k)]) - MP_TA(i + 1, j, k) * KMIN(0.0, Ua[X3(i + 1, j, k)]) +
+                MP_TA(i, j - 1, k) * KMAX(0.0, Va[X3(i, j, k)]) - MP_TA(i, j + 1, k) * KMIN(0.0, Va[X3(i, j + 1, k)]);
+  if (k > 1) cff1 = cff1 + MP_TA(i, j, k - 1) * KMAX(0.0, Wa[XW(i, j, k - 1)]);
+  if (k < N) cff1 = cff1 - MP_TA(i, j, k + 1) * KMIN(0.0, Wa[XW(i, j, k)]);
+  F.mp3[4][X3(i, j, k)] = (Tmax - MP_TA(i, j, k)) / (cff1 + eps);
+  double cff2 = MP_TA(i, j, k) * KMAX(0.0, Ua[X3(i + 1, j, k)]) - MP_TA(i, j, k) * KMIN(0.0, Ua[X3(i, j, k)]) +
+                MP_TA(i, j, k) * KMAX(0.0, Va[X3(i, j + 1, k)]) - MP_TA(i, j, k) * KMIN(0.0, Va[X3(i, j, k)]);
+  if (k < N) cff2 = cff2 + MP_TA(i, j, k) * KMAX(0.0, Wa[XW(i, j, k)]);
+  if (k > 1) cff2 = cff2 - MP_TA(i, j, k) * KMIN(0.0, Wa[XW(i, j, k - 1)]);
+  F.mp3[5][X3(i, j, k)] = (MP_TA(i, j, k) - Tmin) / (cff2 + eps);
+}
+THREAD_GLOBAL(k_mp_beta, MpArgs)
+
+// ---- limited anti-diffusive velocities :1100-1220 (in place); index space (Istr:Iend+1, Jstr:Jend+1, 1:N)
+THREAD_KERNEL(k_mp_limit, MpArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const TB &B = G.T;
+  const int N = G.N;
+  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1;
+  double *Ua = F.mp3[1], *Va = F.mp3[2], *Wa = F.mp3[3];
+  const double *bup = F.mp3[4], *bdn = F.mp3[5], *z_r = F.z_r;
+  const double cff = 1.0 / G.dt;
+  if (j <= B.Jend) {
+    if (!G.ewp && ((B.west && i == B.Istr) || (B.east && i == B.Iend + 1))) {
+      Ua[X3(i, j, k)] = 0.0;                                       // closed walls :1152-1185
+    } else if (i >= B.IstrU && i <= B.Iendp1) {
+      const double cff1 = KMIN(KMIN(bdn[X3(i - 1, j, k)], bup[X3(i, j, k)]), 1.0);
+      const double cff2 = KMIN(KMIN(bup[X3(i - 1, j, k)], bdn[X3(i, j, k)]), 1.0);
+      Ua[X3(i, j, k)] = (cff1 * KMAX(0.0, Ua[X3(i, j, k)]) + cff2 * KMIN(0.0, Ua[X3(i, j, k)])) * cff * F.om_u[X2(i, j)];
+    }
+  }
+  if (i <= B.Iend) {
+    if (!G.nsp && ((B.south && j == B.Jstr) || (B.north && j == B.Jend + 1))) {
+      Va[X3(i, j, k)] = 0.0;                                       // :1187-1220
+    } else if (j >= B.JstrV && j <= B.Jendp1) {
+      const double cff1 = KMIN(KMIN(bdn[X3(i, j - 1, k)], bup[X3(i, j, k)]), 1.0);
+      const double cff2 = KMIN(KMIN(bup[X3(i, j - 1, k)], bdn[X3(i, j, k)]), 1.0);
+      Va[X3(i, j, k)] = (cff1 * KMAX(0.0, Va[X3(i, j, k)]) + cff2 * KMIN(0.0, Va[X3(i, j, k)])) * cff * F.on_v[X2(i, j)];
+    }
+  }
+  if (i <= B.Iend && j <= B.Jend && k < N) {
+    const double cff1 = KMIN(KMIN(bdn[X3(i, j, k)], bup[X3(i, j, k + 1)]), 1.0);
+    const double cff2 = KMIN(KMIN(bup[X3(i, j, k)], bdn[X3(i, j, k + 1)]), 1.0);
+    Wa[XW(i, j, k)] = (cff1 * KMAX(0.0, Wa[XW(i, j, k)]) + cff2 * KMIN(0.0, Wa[XW(i, j, k)])) * cff * F.omn[X2(i, j)] *
+                      (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]);
+  }
+}
+THREAD_GLOBAL(k_mp_limit, MpArgs)
+
+// ---- corrected fluxes :1399-1500: t(nnew) = Ta*Hz - div(anti-diffusive fluxes); (Istr:Iend, Jstr:Jend, 1:N)
+THREAD_KERNEL(k_mp_apply, MpArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const TB &B = G.T;
+  const int N = G.N, itrc = a.itrc;
+  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1;
+  const double *Ta = F.mp3[0] + (size_t)(itrc - 1) * G.nij * N, *Ua = F.mp3[1], *Va = F.mp3[2], *Wa = F.mp3[3];
+  const double *Hz = F.Hz;
+  double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);
+#define MP_FX(ii) ((KMAX(Ua[X3(ii, j, k)], 0.0) * MP_TA((ii) - 1, j, k) + KMIN(Ua[X3(ii, j, k)], 0.0) * MP_TA(ii, j, k)) * 0.5 * \
+                   (Hz[X3(ii, j, k)] + Hz[X3((ii) - 1, j, k)]) * F.on_u[X2(ii, j)])
+#define MP_FE(jj) ((KMAX(Va[X3(i, jj, k)], 0.0) * MP_TA(i, (jj) - 1, k) + KMIN(Va[X3(i, jj, k)], 0.0) * MP_TA(i, jj, k)) * 0.5 * \
+                   (Hz[X3(i, jj, k)] + Hz[X3(i, (jj) - 1, k)]) * F.om_v[X2(i, jj)])
+#define MP_FC(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : KMAX(Wa[XW(i, j, kk)], 0.0) * MP_TA(i, j, kk) + KMIN(Wa[XW(i, j, kk)], 0.0) * MP_TA(i, j, (kk) + 1))
+  const double cff = G.dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
+  const double cff1 = cff * (MP_FX(i + 1) - MP_FX(i));
+  const double cff2 = cff * (MP_FE(j + 1) - MP_FE(j));
+  const double cff3 = cff1 + cff2;
+  double t1 = MP_TA(i, j, k) * Hz[X3(i, j, k)] - cff3;
+  const double cv = cff * (MP_FC(k) - MP_FC(k - 1));
+  t1 = t1 - cv;
+#undef MP_FX
+#undef MP_FE
+#undef MP_FC
+  tn[X3(i, j, k)] = t1;
+}
+THREAD_GLOBAL(k_mp_apply, MpArgs)
+
+// ---- implicit vertical diffusion, plain tridiagonal :1724-1790; one thread per column ---------
+THREAD_KERNEL(k_mp_vdiff, MpArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const TB &B = G.T;
+  const int N = G.N, itrc = a.itrc, ltrc = KMIN(G.NAT, itrc);
+  const int i = B.Istr + gx, j = B.Jstr + gy;
+  const double *Hz = F.Hz, *z_r = F.z_r;
+  const double *Akt = F.Akt + (size_t)(ltrc - 1) * G.nij * (N + 1);
+  double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);
+  double *CF = F.mp3[4], *DC = F.mp3[5];            // beta arrays are free now
+  const double cff = -G.dt * G.lambda;
+#define MP_FCD(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : cff * (1.0 / (z_r[X3(i, j, (kk) + 1)] - z_r[X3(i, j, kk)])) * Akt[XW(i, j, kk)])
+  {
+    const double BC1 = Hz[X3(i, j, 1)] - MP_FCD(1) - MP_FCD(0);
+    const double c = 1.0 / BC1;
+    CF[X3(i, j, 1)] = c * MP_FCD(1);
+    DC[X3(i, j, 1)] = c * tn[X3(i, j, 1)];
+  }
+  for (int k = 2; k <= N - 1; k++) {
+    const double BCk = Hz[X3(i, j, k)] - MP_FCD(k) - MP_FCD(k - 1);
+    const double c = 1.0 / (BCk - MP_FCD(k - 1) * CF[X3(i, j, k - 1)]);
+    CF[X3(i, j, k)] = c * MP_FCD(k);
+    DC[X3(i, j, k)] = c * (tn[X3(i, j, k)] - MP_FCD(k - 1) * DC[X3(i, j, k - 1)]);
+  }
+  {
+    const double BCN = Hz[X3(i, j, N)] - MP_FCD(N) - MP_FCD(N - 1);
+    const double d = (tn[X3(i, j, N)] - MP_FCD(N - 1) * DC[X3(i, j, N - 1)]) / (BCN - MP_FCD(N - 1) * CF[X3(i, j, N - 1)]);
+    DC[X3(i, j, N)] = d;
+    tn[X3(i, j, N)] = d;
+  }
+  for (int k = N - 1; k >= 1; k--) {
+    const double d = DC[X3(i, j, k)] - CF[X3(i, j, k)] * DC[X3(i, j, k + 1)];
+    DC[X3(i, j, k)] = d;
+    tn[X3(i, j, k)] = d;
+  }
+#undef MP_FCD
+}
+THREAD_GLOBAL(k_mp_vdiff, MpArgs)

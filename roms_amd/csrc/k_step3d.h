@@ -164,6 +164,7 @@ COOP_KERNEL(k_s3t_h, KArgs) {
   const Fields &F = *a.Fp;
   const TB B = block_bounds(G, bx, by);
   const int k = bz % G.N + 1, itrc = bz / G.N + 1;
+  if (G.hadv[itrc - 1] == ROMS_MPDATA) return;   // k_mpdata.h (uniform over the block)
   const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
   double *FX = lds, *FE = lds + sz, *wk = lds + 2 * sz, *wk2 = lds + 3 * sz;
   const int hs = G.hadv[itrc - 1];
@@ -239,6 +240,7 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
   const Fields &F = *a.Fp;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = G.N;
   const int vs = G.vadv[itrc - 1], ltrc = KMIN(G.NAT, itrc);
+  if (vs == ROMS_MPDATA) return;                 // k_mpdata.h
   const double dt = G.dt, eps1 = 1.0E-12;
   const double *T3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
   double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);

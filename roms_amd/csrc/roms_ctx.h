@@ -158,4 +158,7 @@ struct Fields {
   // oHz/Ta/Ua/Va/Wa of step3d_t, swdk of pre_step3d ...)
   double *wrk3[6];
   double *wrk2[4];
+  // MPDATA work arrays (allocated only when a tracer uses MPDATA): Ta (N planes per tracer), Ua, Va, Wa,
+  // beta_up, beta_dn
+  double *mp3[6];
 };

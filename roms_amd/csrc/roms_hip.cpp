@@ -234,6 +234,16 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     c->allocs.push_back(p);
     c->F.wrk2[k] = (double *)p;
   }
+  {  // MPDATA work arrays
+    bool any_mp = false;
+    for (int it = 0; it < cfg->NT; it++) any_mp |= cfg->hadv[it] == ROMS_MPDATA || cfg->vadv[it] == ROMS_MPDATA;
+    for (int k = 0; k < 6 && any_mp; k++) {
+      void *p = nullptr;
+      if (dmalloc(&p, (size_t)G.nij * (size_t)(G.N + 1) * (k == 0 ? (size_t)G.NT : 1) * sizeof(double))) { roms_hip_destroy(c); return 2; }
+      c->allocs.push_back(p);
+      c->F.mp3[k] = (double *)p;
+    }
+  }
   {  // pointer table for the kernels
 #ifdef ROMS_CPU_EMU
     c->d_F = &c->F;

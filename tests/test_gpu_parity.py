@@ -35,7 +35,9 @@ def _run(tag, hadv, vadv, nsteps):
     return O, H, worst
 
 
-@pytest.mark.parametrize("hadv,vadv", [(("U3", "HSIMT"), ("C4", "HSIMT")), (("U3", "U3"), ("C4", "C4"))])
+@pytest.mark.parametrize("hadv,vadv", [(("U3", "HSIMT"), ("C4", "HSIMT")), (("U3", "U3"), ("C4", "C4")),
+                                       (("MPDATA", "MPDATA"), ("MPDATA", "MPDATA")),
+                                       (("MPDATA", "HSIMT"), ("MPDATA", "HSIMT"))])
 def test_upwelling_small_20_steps(hadv, vadv):
     O, H, worst = _run("upwelling_small", hadv, vadv, 20)
     bad = {k: v for k, v in worst.items() if not (v <= TOL)}
@@ -263,3 +265,13 @@ def test_baseline_size_matches_oracle(workload, nsteps, tol):
     assert abs(d["volume"] - v0) <= 1e-12 * v0
     assert d["volume"] == pytest.approx(O.diag()[3], rel=1e-14)
     run.close()
+
+
+def test_upwelling_mpdata_100_steps():
+    """BASELINE config 2/5 advection: UPWELLING 41x80x16 with MPDATA for both tracers, 100 steps."""
+    O, H, worst = _run("upwelling", ("MPDATA", "MPDATA"), ("MPDATA", "MPDATA"), 100)
+    bad = {k: v for k, v in worst.items() if not (v <= TOL)}
+    assert not bad, bad
+    t = H.download("t")
+    assert np.isfinite(t).all()
+    H.close()

@@ -19,7 +19,9 @@ def emu():
 
 
 @pytest.mark.parametrize("hadv,vadv", [(("U3", "HSIMT"), ("C4", "HSIMT")), (("U3", "U3"), ("C4", "C4")),
-                                       (("C4", "A4"), ("SPLINES", "A4")), (("C2", "SU3"), ("C2", "SU3"))])
+                                       (("C4", "A4"), ("SPLINES", "A4")), (("C2", "SU3"), ("C2", "SU3")),
+                                       (("MPDATA", "MPDATA"), ("MPDATA", "MPDATA")),
+                                       (("MPDATA", "HSIMT"), ("MPDATA", "HSIMT")), (("U3", "MPDATA"), ("C4", "MPDATA"))])
 def test_main3d_sequence_bitwise(emu, hadv, vadv):
     cs = util.case_for("upwelling_small", hadv=hadv, vadv=vadv)
     g = util.load_init("upwelling_small", util.nghost_for(cs))
@@ -36,11 +38,14 @@ def test_main3d_sequence_bitwise(emu, hadv, vadv):
     H.close()
 
 
-def test_closed_basin_all_edges(emu):
+@pytest.mark.parametrize("hadv,vadv,ng", [(("U3", "U3"), ("C4", "C4"), 2),
+                                          (("MPDATA", "MPDATA"), ("MPDATA", "MPDATA"), 3)])
+def test_closed_basin_all_edges(emu, hadv, vadv, ng):
     """Closed western/eastern edges too (all four walls): exercises the non-periodic branches of
-    every kernel (edge replication of curvature terms, corner fills, wall-normal velocities)."""
-    cs = util.case_for("upwelling_small", hadv=("U3", "U3"), vadv=("C4", "C4"))
-    g = util.load_init("upwelling_small", 2)
+    every kernel (edge replication of curvature terms, corner fills, wall-normal velocities; with
+    MPDATA the wall values of Ta, Ua, Va)."""
+    cs = util.case_for("upwelling_small", hadv=hadv, vadv=vadv)
+    g = util.load_init("upwelling_small", ng)
     cs["EWperiodic"] = 0
     # re-embed the periodic fixture (LBi=-2..UBi) into closed-basin arrays (0..Im+1)
     LBi, UBi, LBj, UBj = [int(x) for x in g["bounds"][:4]]

@@ -59,3 +59,61 @@ def test_pinned_kernels_bitwise(hadv, vadv):
     code = SCRIPT % dict(root=ROOT, hadv=hadv, vadv=vadv)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "PINNED-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+MPDATA_SCRIPT = r'''
+import sys, os, ctypes as C, numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import orc, ref
+from tests import cases, util
+cs = cases.upwelling(Lm=14, Mm=18, N=8, hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA"))
+ip, rp = cases.ref_params(cs)
+R = ref.Ref("upwelling", ip, rp); R.initial()
+b = R.bounds(0)
+w = np.stack([R.table(5, 60), R.table(6, 60)])
+O = orc.Oracle(cases.oracle_cfg(cs, R.table(7, 8)[0], b[58], w))
+for n in util.INIT_FIELDS:
+    if R.has(n): O.field(n)[:] = R.get(n)
+for k, n in enumerate(["sc_r", "Cs_r", "sc_w", "Cs_w"]): O.field(n)[:] = R.table(k + 1, O.field(n).size)
+rng = np.random.default_rng(3)
+for n, amp in [("u", 0.05), ("v", 0.05), ("t", 0.3), ("W", 5.0), ("Huon", 50.0), ("Hvom", 50.0)]:
+    a = O.field(n); a[:] += amp * rng.standard_normal(a.size); R.put(n, a)
+LBi, UBi, LBj, UBj = b[0], b[1], b[2], b[3]
+ni, nj, N = UBi - LBi + 1, UBj - LBj + 1, cs["N"]
+Istr, Iend, Jstr, Jend = 1, cs["Lm"], 1, cs["Mm"]
+IminS, ImaxS, JminS, JmaxS = Istr - 3, Iend + 3, Jstr - 3, Jend + 3
+nis, njs = ImaxS - IminS + 1, JmaxS - JminS + 1
+for itrc in (1, 2):
+    # Ta: positive field on the global arrays
+    Tg = (10.0 + 3.0 * rng.random((N, nj, ni)) if itrc == 1 else 35.0 + 0.5 * rng.random((N, nj, ni)))
+    Tg[:, :, 5:9] = Tg[:, :, 5:6]      # some equal neighbours -> the eps2 branch
+    Ts = np.zeros((N, njs, nis))
+    j0, j1 = max(JminS, LBj), min(JmaxS, UBj); i0, i1 = max(IminS, LBi), min(ImaxS, UBi)
+    Ts[:, j0 - JminS:j1 - JminS + 1, i0 - IminS:i1 - IminS + 1] = Tg[:, j0 - LBj:j1 - LBj + 1, i0 - LBi:i1 - LBi + 1]
+    Ua = np.zeros(N * njs * nis); Va = np.zeros_like(Ua); Wa = np.zeros((N + 1) * njs * nis)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    R.L.ref_mpdata_adiff(C.c_int(itrc), P(np.ascontiguousarray(Ts)), P(Ua), P(Va), P(Wa))
+    # oracle
+    oHz = np.zeros((N, nj, ni)); Hz = O.arr("Hz")
+    oHz[:] = 1.0 / np.where(Hz != 0, Hz, 1.0)
+    Uo = np.zeros(N * nj * ni); Vo = np.zeros_like(Uo); Wo = np.zeros((N + 1) * nj * ni)
+    Tgc = np.ascontiguousarray(Tg)
+    O.L.orc_mpdata_adiff(C.c_void_p(O.h), C.c_int(0), C.c_int(itrc), P(Tgc), P(Uo), P(Vo), P(Wo), P(np.ascontiguousarray(oHz)))
+    def crop(a, nk):
+        return a.reshape(nk, njs, nis)[:, j0 - JminS:j1 - JminS + 1, i0 - IminS:i1 - IminS + 1]
+    def cropg(a, nk):
+        return a.reshape(nk, nj, ni)[:, j0 - LBj:j1 - LBj + 1, i0 - LBi:i1 - LBi + 1]
+    for nm, r_, o_, nk in [("Ua", Ua, Uo, N), ("Va", Va, Vo, N), ("Wa", Wa, Wo, N + 1)]:
+        a, bb = crop(r_, nk), cropg(o_, nk)
+        d = np.argwhere(a != bb)
+        assert np.count_nonzero(a) > 500 and len(d) == 0, (itrc, nm, len(d))
+print("MPDATA-PINNED-OK")
+'''
+
+
+def test_mpdata_adiff_bitwise():
+    """mpdata_adiff_tile (mpdata_adiff.F:38): anti-diffusive velocities Ua, Va, Wa with the FCT limiter,
+    both tracers, random positive fields incl. equal neighbours -- oracle vs the reference's object code."""
+    p = subprocess.run([sys.executable, "-c", MPDATA_SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
+                       timeout=600)
+    assert "MPDATA-PINNED-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
