@@ -10,8 +10,8 @@ int run_diag_async(roms_hip_ctx *c, double *d_out) {
   DiagArgs a;
   a.G = G;
   a.Fp = c->d_F;
-  a.col = c->F.wrk3[0];                 // free at this point of the step (vert of wvelocity)
-  a.row = c->F.wrk3[0] + 9 * (size_t)G.nij;
+  a.col = c->d_diagwork;
+  a.row = c->d_diagwork + 9 * (size_t)G.nij;
   a.out = d_out;
   LAUNCH_THREAD(k_diag_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   LAUNCH_COOP(k_diag_row, (B.Iend - B.Istr + DIAG_IW) / DIAG_IW, 1, 1, 256, DIAG_ROW_LDS, c->stream, a);

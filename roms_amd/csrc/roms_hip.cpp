@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
@@ -208,10 +209,19 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   }
 #ifdef ROMS_CPU_EMU
   c->stream = nullptr;
+  c->stream2 = nullptr;
+  c->overlap = false;
 #else
   if (hipfail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return 2; }
+  if (hipfail(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return 2; }
   (void)hipEventCreate(&c->ev0);
   (void)hipEventCreate(&c->ev1);
+  (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+  {
+    const char *e = getenv("ROMS_HIP_OVERLAP");
+    c->overlap = !(e && e[0] == '0');
+  }
 #endif
   // state arrays
   memset(&c->F, 0, sizeof(c->F));
@@ -268,6 +278,10 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     c->allocs.push_back(p);
     c->d_diag = (double *)p;
     c->h_diag = (double *)calloc(16 * (size_t)(G.nj + 8), sizeof(double));
+    void *q = nullptr;
+    if (dmalloc(&q, sizeof(double) * (9 * (size_t)G.nij + 12 * (size_t)G.ni))) { roms_hip_destroy(c); return 2; }
+    c->allocs.push_back(q);
+    c->d_diagwork = (double *)q;
   }
 #ifndef ROMS_CPU_EMU
   // the zero fills above ran on the null stream; the context's stream is non-blocking and would
@@ -292,6 +306,7 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   free(c->h_diag);
 #ifndef ROMS_CPU_EMU
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
 #endif
   delete c;
   return 0;
@@ -337,6 +352,30 @@ extern "C" int roms_hip_download(roms_hip_ctx *c, const char *name, double *host
 extern "C" int roms_hip_sync(roms_hip_ctx *c) { return dsync(c->stream); }
 int fetch_diag(roms_hip_ctx *c, const double *d_out, double *out) { return d2h(out, d_out, 16 * sizeof(double), c->stream); }
 int run_diag_async(roms_hip_ctx *c, double *d_out);   // g_diag.cpp
+
+// ------------------------------------------------------------------------------- side stream
+#ifdef ROMS_CPU_EMU
+void side_begin(roms_hip_ctx *) {}
+void side_end(roms_hip_ctx *) {}
+void side_join(roms_hip_ctx *) {}
+#else
+static bool side_on(roms_hip_ctx *c) { return c->overlap && !c->profile && g_kprof_mode != 1; }
+void side_begin(roms_hip_ctx *c) {
+  if (!side_on(c)) return;
+  (void)hipEventRecord(c->ev_fork, c->stream);
+  (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+  std::swap(c->stream, c->stream2);
+}
+void side_end(roms_hip_ctx *c) {
+  if (!side_on(c)) return;
+  (void)hipEventRecord(c->ev_join, c->stream);   // c->stream is the side stream here
+  std::swap(c->stream, c->stream2);
+}
+void side_join(roms_hip_ctx *c) {
+  if (!side_on(c)) return;
+  (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+}
+#endif
 
 // ------------------------------------------------------------------------------ region timing
 RegionTimer::RegionTimer(roms_hip_ctx *c_, int id_) : c(c_), id(id_) {
@@ -707,15 +746,31 @@ static int main3d_one(roms_hip_ctx *c) {
   DO(roms_hip_rho_eos(c));                                  // :350
   // diag (:355): device-side reduction every ninfo steps; the blow-up test is made on the host
   // when roms_hip_main3d returns (no per-step host synchronisation)
-  if (cf.ninfo > 0 && (s.iic - 1) % cf.ninfo == 0) DO(run_diag_async(c, c->d_diag));
+  const bool do_diag = cf.ninfo > 0 && (s.iic - 1) % cf.ninfo == 0;
+  if (do_diag) {   // reads u, v, rho, wvel ... of this point of the step; overlaps the surface forcing and mixing
+    side_begin(c);
+    r = run_diag_async(c, c->d_diag);
+    side_end(c);
+    if (r) return r;
+  }
   if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));   // :439
   DO(roms_hip_set_vbc(c));                                  // :445
   if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));       // :525
   else if (cf.options & ROMS_LMD_MIXING) DO(roms_hip_lmd_vmix(c)); // :527
   DO(roms_hip_omega(c));                                    // :534
+  if (do_diag) side_join(c);                                // wvelocity overwrites wvel, which diag reads
   DO(roms_hip_wvelocity(c, s.nstp));                        // :535
   DO(roms_hip_set_zeta(c));                                 // :556
-  DO(roms_hip_rhs3d(c));                                    // :632
+  // rhs3d :632 -- t3dmix2 only touches t(nnew): it overlaps prsgrd and rhs3d_tile
+  DO(roms_hip_pre_step3d(c));
+  side_begin(c);
+  r = roms_hip_t3dmix2(c);
+  side_end(c);
+  if (r) return r;
+  DO(roms_hip_prsgrd(c));
+  DO(roms_hip_rhs3d_tile(c));
+  side_join(c);
+  DO(roms_hip_uv3dmix2(c));
   for (int my_iif = 1; my_iif <= cf.nfast + 1; my_iif++) {  // :810-918
     const int next_indx1 = 3 - s.indx1;
     if (!s.predictor && my_iif <= cf.nfast + 1) {

@@ -46,12 +46,21 @@ struct roms_hip_ctx {
   Region regions[96];
   kevent_t ev0, ev1;
   double *d_diag;      // device scratch for diag reductions
+  double *d_diagwork;  // column/row partial results of diag (own buffer: diag overlaps other kernels)
+  kstream_t stream2;   // side stream: kernels of a step that do not depend on each other overlap
+  kevent_t ev_fork, ev_join;
+  bool overlap;        // use the side stream (single-GPU latency hiding on small grids)
   double *h_diag;      // pinned host mirror
   int nblk_diag;
 };
 
 // helpers (roms_hip.cpp)
 void ctx_sync_stepping(roms_hip_ctx *c);           // copy c->s into c->G
+// side-stream helpers (roms_hip.cpp): between side_begin and side_end launches go to the side stream,
+// ordered after everything launched so far; side_join makes the main stream wait for them
+void side_begin(roms_hip_ctx *c);
+void side_end(roms_hip_ctx *c);
+void side_join(roms_hip_ctx *c);
 int ctx_check(roms_hip_ctx *c, const char *what);  // hipGetLastError -> exit_flag style code
 void set_error(const std::string &msg);
 long field_elems(const roms_hip_ctx *c, int kind);
