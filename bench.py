@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- grid-cell-updates/sec of the nonlinear 3-D time step (main3d) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload benchmark1|benchmark2|benchmark3|ns512|upwelling]
+    python bench.py --gpus N --steps K --warmup W [--workload benchmark1|benchmark2|benchmark3|ns512|upwelling|config5]
 
 A "step" is one pass of main3d's STEP_LOOP (ROMS/Nonlinear/main3d.F:216-1148) with the full physics
 of the application (BENCHMARK: nonlinear EOS, KPP, COARE bulk fluxes, geopotential tracer mixing,
@@ -35,6 +35,7 @@ WORKLOADS = {
     "ns512": ("upwelling", 512, 512, 50),       # north_star roofline size (512x512x50); UPWELLING keeps
                                                 # 1 km cells at any size (BENCHMARK's shelf steepens with Mm)
     "upwelling": ("upwelling", 41, 80, 16),
+    "config5": ("upwelling_kpp", 256, 512, 50),  # BASELINE configs[4]: UPWELLING + KPP + MPDATA
 }
 
 # Algorithmic HBM traffic per launch of each kernel, in "words per cell": the number of distinct full
@@ -103,8 +104,12 @@ def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
     from tests import cases
     app, lm, mm, n = WORKLOADS[workload]
     Lm, Mm, N = Lm or lm, Mm or mm, N or n
-    cs = cases.benchmark(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes) if app == "benchmark" else \
-        cases.upwelling(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
+    if app == "benchmark":
+        cs = cases.benchmark(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
+    elif app == "upwelling_kpp":
+        cs = cases.upwelling_kpp(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
+    else:
+        cs = cases.upwelling(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
     return cs
 
 

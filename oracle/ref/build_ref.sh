@@ -12,7 +12,9 @@
 # kernels that USE mod_sources -> mod_netcdf (step2d, omega, pre_step3d,
 # rhs3d, step3d_uv, step3d_t, main3d) are therefore NOT in this library.
 #
-# usage: build_ref.sh upwelling|benchmark
+# usage: build_ref.sh upwelling|benchmark|upwelling_kpp
+# (upwelling_kpp = upwelling.h with the KPP options of benchmark.h switched on from the command
+#  line: the "custom application header" of BASELINE config 5)
 set -e
 APP=${1:-upwelling}
 REF=${ROMS_REF:-/root/reference}
@@ -22,8 +24,13 @@ if [ ! -d "$REF/ROMS" ]; then echo "build_ref: no reference tree at $REF -- skip
 FC=${FC:-amdflang}
 command -v $FC >/dev/null || { echo "build_ref: $FC not found -- skipped"; exit 0; }
 UP=$(echo $APP | tr a-z A-Z)
+HDR=$APP
 EXTRA=""
 [ "$APP" = upwelling ] && EXTRA="-DPERFECT_RESTART"
+if [ "$APP" = upwelling_kpp ]; then
+  UP=UPWELLING; HDR=upwelling
+  EXTRA="-DPERFECT_RESTART -DLMD_MIXING -DLMD_RIMIX -DLMD_CONVEC -DLMD_SKPP -DLMD_NONLOCAL -DRI_SPLINES -DSOLAR_SOURCE -DANA_SRFLUX"
+fi
 WORK=$(mktemp -d /tmp/romsref_${APP}_XXXX)
 trap 'rm -rf "$WORK"' EXIT
 mkdir -p "$OUT"
@@ -31,7 +38,7 @@ cd "$WORK"   # cpp must run from a writable cwd with absolute input paths
 
 pp () {  # pp <abs .F path> -> $WORK/<base>.f90
   local b; b=$(basename "$1"); b=${b%.*}
-  /usr/bin/cpp -P -traditional -w -D$UP -D"ROMS_HEADER=\"$APP.h\"" -D"HEADER=\"$APP.h\"" \
+  /usr/bin/cpp -P -traditional -w -D$UP -D"ROMS_HEADER=\"$HDR.h\"" -D"HEADER=\"$HDR.h\"" \
     -DLINUX -DX86_64 -DGFORTRAN -DNestedGrids=1 \
     -D"ROOT_DIR=\"$REF\"" -D"ANALYTICAL_DIR=\"$REF/ROMS/Functionals\"" -D"HEADER_DIR=\"$REF/ROMS/Include\"" \
     -D'GIT_URL="x"' -D'GIT_REV="x"' -D'MY_OS="Linux"' -D'MY_CPU="x86_64"' -D'MY_FORT="gfortran"' \

@@ -105,13 +105,17 @@ THREAD_KERNEL(k_rho_eos_lin, KArgs) {
   const Fields &F = *a.Fp;
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, N = G.N, nrhs = G.nrhs;
   const bool salt = (G.options & ROMS_SALINITY) != 0;
-  double rhoA = 0.0, rhoS = 0.0;
+  const bool kpp = (G.options & ROMS_LMD_MIXING) != 0;   // BV_FREQUENCY and expansion coefficients :751-780
+  const double gorho0 = G.g / G.rho0;
+  double rhoA = 0.0, rhoS = 0.0, rup = 0.0;
   for (int k = N; k >= 1; k--) {
     double r = G.R0 - G.R0 * G.Tcoef * (F.t[XT(i, j, k, nrhs, 1)] - G.T0);
     if (salt) r = r + G.R0 * G.Scoef * (F.t[XT(i, j, k, nrhs, 2)] - G.S0);
     r = r - 1000.0;
     F.rho[X3(i, j, k)] = r;
     F.pden[X3(i, j, k)] = r;
+    if (kpp && k < N) F.bvf[XW(i, j, k)] = -gorho0 * (rup - r) / (F.z_r[X3(i, j, k + 1)] - F.z_r[X3(i, j, k)]);
+    rup = r;
     const double Hzk = F.Hz[X3(i, j, k)];
     const double cff1 = r * Hzk;
     if (k == N) {
@@ -126,6 +130,10 @@ THREAD_KERNEL(k_rho_eos_lin, KArgs) {
   const double cff1 = 1.0 / (F.z_w[XW(i, j, N)] - F.z_w[XW(i, j, 0)]);
   F.rhoA[X2(i, j)] = cff2 * cff1 * rhoA;
   F.rhoS[X2(i, j)] = 2.0 * cff1 * cff1 * cff2 * rhoS;
+  if (kpp) {
+    F.alpha[X2(i, j)] = fabs(G.Tcoef);
+    F.beta[X2(i, j)] = salt ? fabs(G.Scoef) : 0.0;
+  }
 }
 THREAD_GLOBAL(k_rho_eos_lin, KArgs)
 

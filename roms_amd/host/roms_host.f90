@@ -250,6 +250,12 @@
         CASE ('UPWELLING')
           options=ROMS_UV_ADV+ROMS_UV_COR+ROMS_UV_VIS2+ROMS_TS_DIF2+ROMS_ANA_VMIX+ROMS_SALINITY+              &
      &            ROMS_APP_UPWELLING
+        CASE ('UPWELLING_KPP')
+!  UPWELLING with the KPP closure instead of ANA_VMIX: the "custom application header" of BASELINE
+!  config 5 (upwelling.h with LMD_MIXING, LMD_RIMIX, LMD_CONVEC, LMD_SKPP, LMD_NONLOCAL, RI_SPLINES,
+!  SOLAR_SOURCE and ANA_SRFLUX (zero) in place of ANA_VMIX).
+          options=ROMS_UV_ADV+ROMS_UV_COR+ROMS_UV_VIS2+ROMS_TS_DIF2+ROMS_LMD_MIXING+ROMS_SOLAR_SOURCE+         &
+     &            ROMS_SALINITY+ROMS_APP_UPWELLING
         CASE ('BENCHMARK')
           options=ROMS_UV_ADV+ROMS_UV_COR+ROMS_UV_VIS2+ROMS_TS_DIF2+ROMS_MIX_GEO_TS+ROMS_CURVGRID+            &
      &            ROMS_NONLIN_EOS+ROMS_UV_QDRAG+ROMS_LMD_MIXING+ROMS_BULK_FLUXES+ROMS_SOLAR_SOURCE+            &

@@ -21,6 +21,18 @@ def upwelling(Lm=41, Mm=80, N=16, NtileI=1, NtileJ=1, hadv=("U3", "HSIMT"), vadv
     )
 
 
+def upwelling_kpp(**kw):
+    """UPWELLING with the KPP closure (LMD_MIXING ... SOLAR_SOURCE with zero srflx) instead of ANA_VMIX:
+    the custom application header of BASELINE config 5 (with MPDATA tracers by default)."""
+    kw.setdefault("hadv", ("MPDATA", "MPDATA"))
+    kw.setdefault("vadv", ("MPDATA", "MPDATA"))
+    cs = upwelling(**kw)
+    cs["app"] = "upwelling_kpp"
+    cs["options"] = ("UV_ADV", "UV_COR", "UV_VIS2", "TS_DIF2", "LMD_MIXING", "SOLAR_SOURCE", "SALINITY",
+                     "APP_UPWELLING")
+    return cs
+
+
 def benchmark(Lm=512, Mm=64, N=30, NtileI=1, NtileJ=1, ntimes=200):
     """roms_benchmark1.in"""
     return dict(

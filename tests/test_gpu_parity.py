@@ -280,3 +280,19 @@ def test_upwelling_mpdata_100_steps():
     t = H.download("t")
     assert np.isfinite(t).all()
     H.close()
+
+
+def test_config5_physics_small():
+    """UPWELLING + KPP + MPDATA (BASELINE config 5 physics) on the small grid, 30 steps."""
+    cs = util.case_for("upwelling_kpp_small")
+    g = util.load_init("upwelling_small", 3)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g)
+    O.start()
+    H.start()
+    O.main3d_step(30)
+    H.main3d(30)
+    for n in ("zeta", "u", "v", "t", "W", "Akv", "Akt", "hsbl"):
+        e = util.relrms(H.download(n), O.field(n))
+        assert e <= 1.0e-9, (n, e)
+    H.close()

@@ -67,3 +67,20 @@ def test_closed_basin_all_edges(emu, hadv, vadv, ng):
             assert np.array_equal(H.download(n), O.field(n)), n
     assert np.isfinite(O.diag()[0])
     H.close()
+
+
+def test_upwelling_kpp_mpdata_bitwise(emu):
+    """BASELINE config 5 physics on a small grid: UPWELLING + KPP (linear EOS with bvf/alpha/beta) + MPDATA."""
+    cs = util.case_for("upwelling_kpp_small")
+    g = util.load_init("upwelling_small", 3)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start()
+    H.start()
+    for _ in range(5):
+        O.main3d_step()
+        H.main3d(1)
+        for n in util.PROGNOSTIC:
+            assert np.array_equal(H.download(n), O.field(n)), n
+    assert float(O.field("Akv").max()) > 1.0e-5          # the closure is active
+    H.close()

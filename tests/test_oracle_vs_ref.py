@@ -117,3 +117,51 @@ def test_mpdata_adiff_bitwise():
     p = subprocess.run([sys.executable, "-c", MPDATA_SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
                        timeout=600)
     assert "MPDATA-PINNED-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+KPP_SCRIPT = r'''
+import sys, os, numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import orc, ref
+from tests import cases, util
+cs = cases.upwelling_kpp(Lm=14, Mm=18, N=8)
+ip, rp = cases.ref_params(cs)
+R = ref.Ref("upwelling_kpp", ip, rp); R.initial()
+b = R.bounds(0)
+w = np.stack([R.table(5, 60), R.table(6, 60)])
+O = orc.Oracle(cases.oracle_cfg(cs, R.table(7, 8)[0], b[58], w))
+for n in util.INIT_FIELDS:
+    if R.has(n): O.field(n)[:] = R.get(n)
+for k, n in enumerate(["sc_r", "Cs_r", "sc_w", "Cs_w"]): O.field(n)[:] = R.table(k + 1, O.field(n).size)
+st = O.step
+st.iic = 4; st.iif = 1; st.nstp = 2; st.nnew = 1; st.nrhs = 2; st.kstp = 1; st.knew = 1; st.krhs = 1
+st.predictor = 0; st.time = 900.0; st.tdays = 900.0 / 86400.0
+R.set_stepping(st.iic, st.iif, st.nstp, st.nnew, st.nrhs, st.kstp, st.knew, st.krhs, st.predictor, st.time)
+rng = np.random.default_rng(11)
+for n, amp in [("u", 0.05), ("v", 0.05), ("zeta", 0.1), ("t", 0.05)]:
+    a = O.field(n); a[:] += amp * rng.standard_normal(a.size); R.put(n, a)
+for n, amp in [("sustr", 1e-4), ("svstr", 1e-4), ("stflx", 1e-5), ("bustr", 1e-5), ("bvstr", 1e-5)]:
+    a = O.field(n); a[:] = amp * rng.standard_normal(a.size); R.put(n, a)
+bad = []
+def cmp(tag, names):
+    for n in names:
+        if not R.has(n): continue
+        a, bb = R.get(n), O.field(n)
+        if not np.array_equal(a, bb): bad.append((tag, n, float(np.abs(a - bb).max()), int(np.count_nonzero(a != bb))))
+R.call("set_depth"); O.call("set_depth"); cmp("set_depth", ["Hz", "z_r", "z_w"])
+R.call("rho_eos"); O.call("rho_eos"); cmp("rho_eos", ["rho", "pden", "rhoA", "rhoS", "bvf", "alpha", "beta"])
+R.call("lmd_vmix"); O.call("lmd_vmix"); cmp("lmd_vmix", ["Akv", "Akt", "hsbl", "ghats"])
+print("nonzero bvf", np.count_nonzero(O.field("bvf")), "Akv max", O.field("Akv").max(), "hsbl min", O.field("hsbl").min())
+print("KPP-LINEAR-EOS-PINNED-OK" if not bad else bad)
+'''
+
+
+def test_upwelling_kpp_linear_eos_and_lmd_bitwise():
+    """BASELINE config 5's physics (upwelling.h + the KPP options): linear EOS with BV_FREQUENCY and the
+    expansion coefficients (rho_eos.F:751-780), then lmd_vmix, oracle vs the reference's object code."""
+    from oracle import ref
+    if not ref.available("upwelling_kpp"):
+        pytest.skip("oracle/_ref/libromsref_upwelling_kpp.so not built")
+    p = subprocess.run([sys.executable, "-c", KPP_SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
+                       timeout=600)
+    assert "KPP-LINEAR-EOS-PINNED-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
