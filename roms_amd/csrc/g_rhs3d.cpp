@@ -19,8 +19,13 @@ int run_pre_step3d(roms_hip_ctx *c) {
   const TB &B = G.T;
   if (G.options & ROMS_SOLAR_SOURCE) { int r = run_swdk(c); if (r) return r; }
   KArgs a = mk(c);
-  LAUNCH_COOP(k_pre_t3h, G.nbx, G.nby, G.N * G.NT, 256, 3 * lds_sz(G), c->stream, a);
-  LAUNCH_THREAD(k_pre_t3v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);
+  bool any_col = false;      // tracers with a spline vertical flux keep the two-kernel column path
+  for (int it = 0; it < G.NT; it++) any_col |= G.vadv[it] == ROMS_SPLINES;
+  LAUNCH_THREAD(k_pre_t3, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N * G.NT, c->stream, a);
+  if (any_col) {
+    LAUNCH_COOP(k_pre_t3h, G.nbx, G.nby, G.N * G.NT, 256, 3 * lds_sz(G), c->stream, a);
+    LAUNCH_THREAD(k_pre_t3v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);
+  }
   LAUNCH_THREAD(k_pre_new, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N, c->stream, a);
   HaloSpec sp[ROMS_MAXT];
   for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, 3, it), G.N, BC_R, 'r'};   // t3dbc + exchange :1157-1171
@@ -62,6 +67,7 @@ int run_rhs3d_tile(roms_hip_ctx *c) {
   const TB &B = G.T;
   KArgs a = mk(c);
   LAUNCH_COOP(k_rhs3d_h, G.nbx, G.nby, G.N, 256, RHS3D_NLDS * lds_sz(G), c->stream, a);
-  LAUNCH_THREAD(k_rhs3d_v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  LAUNCH_THREAD(k_rhs3d_v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N, c->stream, a);
+  LAUNCH_THREAD(k_rhs3d_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   return 0;
 }

@@ -54,7 +54,15 @@ int run_step3d_t(roms_hip_ctx *c) {
   }
   KArgs a = mk(c);
   // exchange of t(nnew) for HSIMT tracers (:420) only refreshes ghost points that are not read here
-  LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
+  bool any_pt = false, any_lds = false;   // per tracer: fused point kernel, or the LDS (HSIMT) / column (SPLINES) path
+  for (int it = 0; it < G.NT; it++) {
+    const int hs = G.hadv[it], vs = G.vadv[it];
+    const bool pt = hs != ROMS_HSIMT && hs != ROMS_MPDATA && vs != ROMS_HSIMT && vs != ROMS_MPDATA && vs != ROMS_SPLINES;
+    any_pt |= pt;
+    any_lds |= !pt && hs != ROMS_MPDATA;
+  }
+  if (any_pt) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N * G.NT, c->stream, a);
+  if (any_lds) LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
   LAUNCH_THREAD(k_s3t_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);
   for (int it = 1; it <= G.NT && any_mp; it++) {
     if (G.hadv[it - 1] != ROMS_MPDATA) continue;

@@ -225,16 +225,33 @@ THREAD_KERNEL(k_omega, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  // Both sweeps load eight levels before using them, so that the loads overlap.
+  const double *Huon = F.Huon, *Hvom = F.Hvom, *z_w = F.z_w;
+  double *W = F.W;
   double Wk = 0.0;
-  F.W[XW(i, j, 0)] = 0.0;
-  for (int k = 1; k <= N; k++) {
-    Wk = Wk - (F.Huon[X3(i + 1, j, k)] - F.Huon[X3(i, j, k)] + F.Hvom[X3(i, j + 1, k)] - F.Hvom[X3(i, j, k)]);
-    F.W[XW(i, j, k)] = Wk;
+  W[XW(i, j, 0)] = 0.0;
+  for (int k0 = 1; k0 <= N; k0 += 8) {
+    double d[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int k = KMIN(k0 + m, N);
+      d[m] = Huon[X3(i + 1, j, k)] - Huon[X3(i, j, k)] + Hvom[X3(i, j + 1, k)] - Hvom[X3(i, j, k)];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+      if (k0 + m <= N) { Wk = Wk - d[m]; W[XW(i, j, k0 + m)] = Wk; }
   }
-  const double zw0 = F.z_w[XW(i, j, 0)];
-  const double wrk = Wk / (F.z_w[XW(i, j, N)] - zw0);
-  for (int k = N - 1; k >= 1; k--) F.W[XW(i, j, k)] = F.W[XW(i, j, k)] - wrk * (F.z_w[XW(i, j, k)] - zw0);
-  F.W[XW(i, j, N)] = 0.0;
+  const double zw0 = z_w[XW(i, j, 0)];
+  const double wrk = Wk / (z_w[XW(i, j, N)] - zw0);
+  for (int k0 = N - 1; k0 >= 1; k0 -= 8) {
+    double w[8], z[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const int k = KMAX(k0 - m, 1); w[m] = W[XW(i, j, k)]; z[m] = z_w[XW(i, j, k)]; }
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+      if (k0 - m >= 1) W[XW(i, j, k0 - m)] = w[m] - wrk * (z[m] - zw0);
+  }
+  W[XW(i, j, N)] = 0.0;
 }
 THREAD_GLOBAL(k_omega, KArgs)
 

@@ -98,12 +98,65 @@ KDEV void hadv_flux_lds(const DGrid &G, const TB &B, int scheme, const double *T
   KSYNC();
 }
 
+// The same fluxes for ONE u-face (hadv_fx_pt) or v-face (hadv_fe_pt), read straight from global
+// memory: used by the point-wise fused tracer kernels (k_pre_t3, k_s3t_hv), where every thread
+// evaluates the four face fluxes of its own cell.  T, Hu, Hv point at the level's plane.  The
+// expressions are those of hadv_flux_lds; the closed-edge replication of the first differences
+// (grad(Istr-1) = grad(Istr), grad(Iend+2) = grad(Iend+1)) is applied through the index.
+KDEV double hadv_fx_pt(const DGrid &G, int scheme, const double *T, const double *Hu, int i, int j) {
+  const double hu = Hu[X2(i, j)];
+  if (scheme == ROMS_C2) return hu * 0.5 * (T[X2(i - 1, j)] + T[X2(i, j)]);
+  if (scheme == ROMS_MPDATA || scheme == ROMS_HSIMT) return KMAX(hu, 0.0) * T[X2(i - 1, j)] + KMIN(hu, 0.0) * T[X2(i, j)];
+  const double eps = 1.0E-16, cff1 = 1.0 / 6.0, cff2 = 1.0 / 3.0;
+  const bool wfix = !G.ewp && G.T.west, efix = !G.ewp && G.T.east;
+#define GX_(ii_) ({ int q_ = (ii_); if (wfix && q_ == G.T.Istr - 1) q_ = G.T.Istr; if (efix && q_ == G.T.Iend + 2) q_ = G.T.Iend + 1; \
+                    T[X2(q_, j)] - T[X2(q_ - 1, j)]; })
+  const double gm = GX_(i - 1), g0 = GX_(i), gp = GX_(i + 1);
+#undef GX_
+  double wm, w0;   // wk(i-1), wk(i)
+  if (scheme == ROMS_U3) { wm = g0 - gm; w0 = gp - g0; }
+  else if (scheme == ROMS_A4) {
+    const double cm = 2.0 * g0 * gm, c0 = 2.0 * gp * g0;
+    wm = (cm > eps) ? cm / (g0 + gm) : 0.0;
+    w0 = (c0 > eps) ? c0 / (gp + g0) : 0.0;
+  } else { wm = 0.5 * (g0 + gm); w0 = 0.5 * (gp + g0); }
+  if (scheme == ROMS_U3)
+    return hu * 0.5 * (T[X2(i - 1, j)] + T[X2(i, j)]) - cff1 * (wm * KMAX(hu, 0.0) + w0 * KMIN(hu, 0.0));
+  return hu * 0.5 * (T[X2(i - 1, j)] + T[X2(i, j)] - cff2 * (w0 - wm));
+}
+KDEV double hadv_fe_pt(const DGrid &G, int scheme, const double *T, const double *Hv, int i, int j) {
+  const double hv = Hv[X2(i, j)];
+  if (scheme == ROMS_C2) return hv * 0.5 * (T[X2(i, j - 1)] + T[X2(i, j)]);
+  if (scheme == ROMS_MPDATA || scheme == ROMS_HSIMT) return KMAX(hv, 0.0) * T[X2(i, j - 1)] + KMIN(hv, 0.0) * T[X2(i, j)];
+  const double eps = 1.0E-16, cff1 = 1.0 / 6.0, cff2 = 1.0 / 3.0;
+  const bool sfix = !G.nsp && G.T.south, nfix = !G.nsp && G.T.north;
+#define GE_(jj_) ({ int q_ = (jj_); if (sfix && q_ == G.T.Jstr - 1) q_ = G.T.Jstr; if (nfix && q_ == G.T.Jend + 2) q_ = G.T.Jend + 1; \
+                    T[X2(i, q_)] - T[X2(i, q_ - 1)]; })
+  const double gm = GE_(j - 1), g0 = GE_(j), gp = GE_(j + 1);
+#undef GE_
+  double wm, w0;
+  if (scheme == ROMS_U3) { wm = g0 - gm; w0 = gp - g0; }
+  else if (scheme == ROMS_A4) {
+    const double cm = 2.0 * g0 * gm, c0 = 2.0 * gp * g0;
+    wm = (cm > eps) ? cm / (g0 + gm) : 0.0;
+    w0 = (c0 > eps) ? c0 / (gp + g0) : 0.0;
+  } else { wm = 0.5 * (g0 + gm); w0 = 0.5 * (gp + g0); }
+  if (scheme == ROMS_U3)
+    return hv * 0.5 * (T[X2(i, j - 1)] + T[X2(i, j)]) - cff1 * (wm * KMAX(hv, 0.0) + w0 * KMIN(hv, 0.0));
+  return hv * 0.5 * (T[X2(i, j - 1)] + T[X2(i, j)] - cff2 * (w0 - wm));
+}
+
+// tracers whose predictor (pre_step3d) is done by the fused point kernel k_pre_t3: all but those
+// with a parabolic-spline vertical flux (a column recurrence)
+KDEV bool pre_point_path(const DGrid &G, int itrc) { return G.vadv[itrc - 1] != ROMS_SPLINES; }
+
 // pre_step3d: t(3) = Hz*(cff1*t(nstp)+cff2*t(nnew)) - cff*pm*pn*div(FX,FE); grid.z = (k-1)+N*(itrc-1)
 COOP_KERNEL(k_pre_t3h, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
   const TB B = block_bounds(G, bx, by);
   const int k = bz % G.N + 1, itrc = bz / G.N + 1;
+  if (pre_point_path(G, itrc)) return;            // k_pre_t3 (uniform over the block)
   const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
   double *FX = lds, *FE = lds + sz, *wk = lds + 2 * sz;
   const int hs = G.hadv[itrc - 1];
@@ -182,6 +235,7 @@ THREAD_KERNEL(k_pre_t3v, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = G.N;
+  if (pre_point_path(G, itrc)) return;            // k_pre_t3
   const int vs = G.vadv[itrc - 1];
   const double *T = F.t + XT(G.LBi, G.LBj, 1, G.nstp, itrc);
   double *t3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
@@ -207,6 +261,47 @@ THREAD_KERNEL(k_pre_t3v, KArgs) {
 #undef Wc
 }
 THREAD_GLOBAL(k_pre_t3v, KArgs)
+
+// pre_step3d, tracer predictor t(3) in ONE point-wise kernel (horizontal fluxes :357-625 and vertical
+// flux with the artificial-continuity factor :634-852): index space (Istr:Iend, Jstr:Jend, N*NT).
+// The two steps of the reference touch t(3) at the same point only, so they are fused without
+// changing any operation.
+THREAD_KERNEL(k_pre_t3, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N, k = gz % N + 1, itrc = gz / N + 1;
+  if (!pre_point_path(G, itrc)) return;
+  const int hs = G.hadv[itrc - 1], vs = G.vadv[itrc - 1];
+  const double *T = F.t + XT(G.LBi, G.LBj, 1, G.nstp, itrc);   // level 1
+  const double *Tk = T + (size_t)(k - 1) * G.nij;
+  const double *Hu = F.Huon + X3(G.LBi, G.LBj, k), *Hv = F.Hvom + X3(G.LBi, G.LBj, k);
+  // horizontal
+  const double GammaH = (hs == ROMS_MPDATA || hs == ROMS_HSIMT) ? 0.5 : 1.0 / 6.0;
+  double cff, cff1, cff2;
+  if (G.iic == G.ntfirst) { cff = 0.5 * G.dt; cff1 = 1.0; cff2 = 0.0; }
+  else { cff = (1.0 - GammaH) * G.dt; cff1 = 0.5 + GammaH; cff2 = 0.5 - GammaH; }
+  const double FXp = hadv_fx_pt(G, hs, Tk, Hu, i + 1, j), FX0 = hadv_fx_pt(G, hs, Tk, Hu, i, j);
+  const double FEp = hadv_fe_pt(G, hs, Tk, Hv, i, j + 1), FE0 = hadv_fe_pt(G, hs, Tk, Hv, i, j);
+  const double Hzk = F.Hz[X3(i, j, k)];
+  const double t3h = Hzk * (cff1 * Tk[X2(i, j)] + cff2 * F.t[XT(i, j, k, G.nnew, itrc)]) -
+                     cff * F.pm[X2(i, j)] * F.pn[X2(i, j)] * (FXp - FX0 + FEp - FE0);
+  // vertical
+  const double GammaV = (vs == ROMS_MPDATA || vs == ROMS_HSIMT) ? 0.5 : 1.0 / 6.0;
+  const double cfv = (G.iic == G.ntfirst) ? 0.5 * G.dt : (1.0 - GammaV) * G.dt;
+  const double pmn = F.pm[X2(i, j)] * F.pn[X2(i, j)];
+#define Tc(kk) T[X3(i, j, kk)]
+#define Wc(kk) F.W[XW(i, j, kk)]
+  double FCk, FCm;
+  VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
+  VFLUX_LOCAL(FCm, vs, k - 1, N, Tc, Wc);
+#undef Tc
+#undef Wc
+  const double DC = 1.0 / (Hzk - cfv * pmn * (Hu[X2(i + 1, j)] - Hu[X2(i, j)] + Hv[X2(i, j + 1)] - Hv[X2(i, j)] +
+                                              (F.W[XW(i, j, k)] - F.W[XW(i, j, k - 1)])));
+  const double cfv1 = cfv * pmn;
+  F.t[XT(i, j, k, 3, itrc)] = DC * (t3h - cfv1 * (FCk - FCm));
+}
+THREAD_GLOBAL(k_pre_t3, KArgs)
 
 // pre_step3d: start of t(nnew), u(nnew), v(nnew) -- point-wise in 3-D (all vertical fluxes local);
 // index space (min(Istr,IstrU):Iend, Jstr:Jend, 1:N); F.wrk3[5] = swdk when SOLAR_SOURCE
@@ -332,16 +427,35 @@ THREAD_KERNEL(k_prs_P, KArgs) {
   double dR1, dZ1;   // level k+1
   HARMR(dR1, N);
   HARMZ(dZ1, N);
-  for (int k = N - 1; k >= 1; k--) {
-    double dR0, dZ0;
-    HARMR(dR0, k);
-    HARMZ(dZ0, k);
-    Pk = Pk + HalfGRho * ((rho[X3(i, j, k + 1)] + rho[X3(i, j, k)]) * (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]) -
-                          OneFifth * ((dR1 - dR0) * (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)] - OneTwelfth * (dZ1 + dZ0)) -
-                                      (dZ1 - dZ0) * (rho[X3(i, j, k + 1)] - rho[X3(i, j, k)] - OneTwelfth * (dR1 + dR0))));
-    P[X3(i, j, k)] = Pk;
-    dR1 = dR0;
-    dZ1 = dZ0;
+  // Levels are processed top-down in chunks of six: the chunk's rho and z_r values (levels k0+1 ...
+  // k0-6, clamped) are loaded first, then the recurrence runs on registers.
+  for (int k0 = N - 1; k0 >= 1; k0 -= 6) {
+    double rr[8], zz[8];   // rr[q] = rho(level k0 + 1 - q), q = 0..7
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int kk = KMAX(KMIN(k0 + 1 - q, N), 1);
+      rr[q] = rho[X3(i, j, kk)];
+      zz[q] = z_r[X3(i, j, kk)];
+    }
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      const int k = k0 - m;
+      if (k >= 1) {
+        // raw differences at level k (index m+1 -> level k, m -> level k+1, m+2 -> level k-1)
+        const double r1 = rr[m] - rr[m + 1], z1 = zz[m] - zz[m + 1];                         // raw(k)
+        const double r0 = (k - 1 <= 0) ? rho[X3(i, j, 2)] - rho[X3(i, j, 1)] : rr[m + 1] - rr[m + 2];   // raw(k-1)
+        const double z0 = (k - 1 <= 0) ? z_r[X3(i, j, 2)] - z_r[X3(i, j, 1)] : zz[m + 1] - zz[m + 2];
+        const double c_ = 2.0 * r1 * r0;
+        const double dR0 = (c_ > eps) ? c_ / (r1 + r0) : 0.0;
+        const double dZ0 = 2.0 * z1 * z0 / (z1 + z0);
+        Pk = Pk + HalfGRho * ((rr[m] + rr[m + 1]) * (zz[m] - zz[m + 1]) -
+                              OneFifth * ((dR1 - dR0) * (zz[m] - zz[m + 1] - OneTwelfth * (dZ1 + dZ0)) -
+                                          (dZ1 - dZ0) * (rr[m] - rr[m + 1] - OneTwelfth * (dR1 + dR0))));
+        P[X3(i, j, k)] = Pk;
+        dR1 = dR0;
+        dZ1 = dZ0;
+      }
+    }
   }
 #undef RAWR
 #undef RAWZ
@@ -494,14 +608,29 @@ THREAD_KERNEL(k_uv3dmix2_sum, KArgs) {
   const Fields &F = *a.Fp;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N;
+  // eight levels are loaded before they are added (in order), so that the loads overlap
   if (i >= B.IstrU) {
+    const double *A1 = F.wrk3[1], *A2 = F.wrk3[2];
     double ruf = F.rufrc[X2(i, j)];
-    for (int k = 1; k <= N; k++) ruf = ruf + F.wrk3[1][X3(i, j, k)] + F.wrk3[2][X3(i, j, k)];
+    for (int k0 = 1; k0 <= N; k0 += 8) {
+      double p[8], q[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const int k = KMIN(k0 + m, N); p[m] = A1[X3(i, j, k)]; q[m] = A2[X3(i, j, k)]; }
+#pragma unroll
+      for (int m = 0; m < 8; m++) if (k0 + m <= N) ruf = ruf + p[m] + q[m];
+    }
     F.rufrc[X2(i, j)] = ruf;
   }
   if (j >= B.JstrV) {
+    const double *A3 = F.wrk3[3], *A4 = F.wrk3[4];
     double rvf = F.rvfrc[X2(i, j)];
-    for (int k = 1; k <= N; k++) rvf = rvf + F.wrk3[3][X3(i, j, k)] - F.wrk3[4][X3(i, j, k)];
+    for (int k0 = 1; k0 <= N; k0 += 8) {
+      double p[8], q[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) { const int k = KMIN(k0 + m, N); p[m] = A3[X3(i, j, k)]; q[m] = A4[X3(i, j, k)]; }
+#pragma unroll
+      for (int m = 0; m < 8; m++) if (k0 + m <= N) rvf = rvf + p[m] - q[m];
+    }
     F.rvfrc[X2(i, j)] = rvf;
   }
 }
@@ -638,18 +767,18 @@ COOP_GLOBAL(k_rhs3d_h, KArgs)
 
 // J_LOOP: 4th-order (9/16,1/16) vertical advection, vertical sums rufrc/rvfrc + surface/bottom
 // stress.  One thread per column of (Istr:Iend, Jstr:Jend).
+// vertical advection of momentum :1132-1176, :1282-1325, one thread per point (FC(k) and FC(k-1) are
+// local functions of the column); index space (Istr:Iend, Jstr:Jend, 1:N)
 THREAD_KERNEL(k_rhs3d_v, KArgs) {
-  (void)gz;
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
   const TB &B = G.T;
-  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs;
+  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, N = G.N, nrhs = G.nrhs;
+  if (!(G.options & ROMS_UV_ADV)) return;
   const double *u = F.u + (size_t)(nrhs - 1) * G.nij * N, *v = F.v + (size_t)(nrhs - 1) * G.nij * N, *W = F.W;
   double *ru = F.ru + (size_t)(nrhs - 1) * G.nij * (N + 1), *rv = F.rv + (size_t)(nrhs - 1) * G.nij * (N + 1);
-  const bool adv = (G.options & ROMS_UV_ADV) != 0;
   const double cff1 = 9.0 / 16.0, cff2 = 1.0 / 16.0;
   if (i >= B.IstrU) {
-    // FC(k) for k=0..N (local)
 #define WU(kk) (cff1 * (W[XW(i, j, kk)] + W[XW(i - 1, j, kk)]) - cff2 * (W[XW(i + 1, j, kk)] + W[XW(i - 2, j, kk)]))
 #define FCU(out, kk)                                                                                                   \
   do {                                                                                                                 \
@@ -658,25 +787,13 @@ THREAD_KERNEL(k_rhs3d_v, KArgs) {
     else if ((kk) == 1) out = (cff1 * (u[X3(i, j, 1)] + u[X3(i, j, 2)]) - cff2 * (u[X3(i, j, 1)] + u[X3(i, j, 3)])) * WU(1); \
     else out = (cff1 * (u[X3(i, j, kk)] + u[X3(i, j, (kk) + 1)]) - cff2 * (u[X3(i, j, (kk) - 1)] + u[X3(i, j, (kk) + 2)])) * WU(kk); \
   } while (0)
-    double FCm = 0.0, sum = 0.0;
-    for (int k = 1; k <= N; k++) {
-      double r = ru[XW(i, j, k)];
-      if (adv) {
-        double FCk;
-        FCU(FCk, k);
-        const double cff = FCk - FCm;
-        r = r - cff;
-        ru[XW(i, j, k)] = r;
-        FCm = FCk;
-      }
-      sum = (k == 1) ? r : sum + r;
-    }
+    double FCk, FCm;
+    FCU(FCk, k);
+    FCU(FCm, k - 1);
 #undef FCU
 #undef WU
-    const double cff = F.om_u[X2(i, j)] * F.on_u[X2(i, j)];
-    const double c1 = F.sustr[X2(i, j)] * cff;
-    const double c2 = -F.bustr[X2(i, j)] * cff;
-    F.rufrc[X2(i, j)] = sum + c1 + c2;
+    const double cff = FCk - FCm;
+    ru[XW(i, j, k)] = ru[XW(i, j, k)] - cff;
   }
   if (j >= B.JstrV) {
 #define WV(kk) (cff1 * (W[XW(i, j, kk)] + W[XW(i, j - 1, kk)]) - cff2 * (W[XW(i, j + 1, kk)] + W[XW(i, j - 2, kk)]))
@@ -687,25 +804,52 @@ THREAD_KERNEL(k_rhs3d_v, KArgs) {
     else if ((kk) == 1) out = (cff1 * (v[X3(i, j, 1)] + v[X3(i, j, 2)]) - cff2 * (v[X3(i, j, 1)] + v[X3(i, j, 3)])) * WV(1); \
     else out = (cff1 * (v[X3(i, j, kk)] + v[X3(i, j, (kk) + 1)]) - cff2 * (v[X3(i, j, (kk) - 1)] + v[X3(i, j, (kk) + 2)])) * WV(kk); \
   } while (0)
-    double FCm = 0.0, sum = 0.0;
-    for (int k = 1; k <= N; k++) {
-      double r = rv[XW(i, j, k)];
-      if (adv) {
-        double FCk;
-        FCV(FCk, k);
-        const double cff = FCk - FCm;
-        r = r - cff;
-        rv[XW(i, j, k)] = r;
-        FCm = FCk;
-      }
-      sum = (k == 1) ? r : sum + r;
-    }
+    double FCk, FCm;
+    FCV(FCk, k);
+    FCV(FCm, k - 1);
 #undef FCV
 #undef WV
+    const double cff = FCk - FCm;
+    rv[XW(i, j, k)] = rv[XW(i, j, k)] - cff;
+  }
+}
+THREAD_GLOBAL(k_rhs3d_v, KArgs)
+
+// rufrc, rvfrc = vertical sum of ru, rv (in k order) + surface - bottom stress :1700-1918; one thread
+// per column.  Eight levels are loaded at a time before they are added, so that the loads overlap.
+THREAD_KERNEL(k_rhs3d_sum, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const TB &B = G.T;
+  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs;
+  const double *ru = F.ru + (size_t)(nrhs - 1) * G.nij * (N + 1), *rv = F.rv + (size_t)(nrhs - 1) * G.nij * (N + 1);
+#define COLSUM(sum, A)                                                                     \
+  do {                                                                                     \
+    sum = 0.0;                                                                             \
+    for (int k0 = 1; k0 <= N; k0 += 8) {                                                   \
+      double r_[8];                                                                        \
+      _Pragma("unroll") for (int q = 0; q < 8; q++) r_[q] = A[XW(i, j, KMIN(k0 + q, N))];  \
+      _Pragma("unroll") for (int q = 0; q < 8; q++)                                        \
+        if (k0 + q <= N) sum = (k0 + q == 1) ? r_[q] : sum + r_[q];                        \
+    }                                                                                      \
+  } while (0)
+  if (i >= B.IstrU) {
+    double sum;
+    COLSUM(sum, ru);
+    const double cff = F.om_u[X2(i, j)] * F.on_u[X2(i, j)];
+    const double c1 = F.sustr[X2(i, j)] * cff;
+    const double c2 = -F.bustr[X2(i, j)] * cff;
+    F.rufrc[X2(i, j)] = sum + c1 + c2;
+  }
+  if (j >= B.JstrV) {
+    double sum;
+    COLSUM(sum, rv);
     const double cff = F.om_v[X2(i, j)] * F.on_v[X2(i, j)];
     const double c1 = F.svstr[X2(i, j)] * cff;
     const double c2 = -F.bvstr[X2(i, j)] * cff;
     F.rvfrc[X2(i, j)] = sum + c1 + c2;
   }
+#undef COLSUM
 }
-THREAD_GLOBAL(k_rhs3d_v, KArgs)
+THREAD_GLOBAL(k_rhs3d_sum, KArgs)

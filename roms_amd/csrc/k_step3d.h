@@ -157,6 +157,45 @@ KDEV double hsimt_lim(double grad, double gradu, double Ka, double Kau, double o
   return 0.5 * m * grad * Ka;
 }
 
+// tracers whose corrector advection (horizontal + vertical) is done by the fused point kernel
+// k_s3t_hv: all but HSIMT (limiter on LDS tiles), MPDATA (k_mpdata.h) and spline vertical fluxes
+KDEV bool s3t_point_path(const DGrid &G, int itrc) {
+  const int hs = G.hadv[itrc - 1], vs = G.vadv[itrc - 1];
+  return hs != ROMS_HSIMT && hs != ROMS_MPDATA && vs != ROMS_HSIMT && vs != ROMS_MPDATA && vs != ROMS_SPLINES;
+}
+
+// step3d_t: horizontal :633-915 and vertical :936-1340 advection of t(3) into t(nnew), one point per
+// thread; index space (Istr:Iend, Jstr:Jend, N*NT).  Both steps update t(nnew) at the thread's own
+// point only, so they are fused without changing any operation.
+THREAD_KERNEL(k_s3t_hv, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N, k = gz % N + 1, itrc = gz / N + 1;
+  if (!s3t_point_path(G, itrc)) return;
+  const int hs = G.hadv[itrc - 1], vs = G.vadv[itrc - 1];
+  const double *T3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
+  const double *T3k = T3 + (size_t)(k - 1) * G.nij;
+  const double *Hu = F.Huon + X3(G.LBi, G.LBj, k), *Hv = F.Hvom + X3(G.LBi, G.LBj, k);
+  double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);
+  const double cff = G.dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
+  const double cff1 = cff * (hadv_fx_pt(G, hs, T3k, Hu, i + 1, j) - hadv_fx_pt(G, hs, T3k, Hu, i, j));
+  const double cff2 = cff * (hadv_fe_pt(G, hs, T3k, Hv, i, j + 1) - hadv_fe_pt(G, hs, T3k, Hv, i, j));
+  const double cff3 = cff1 + cff2;
+  double tt = tn[X3(i, j, k)] - cff3;
+#define Tc(kk) T3[X3(i, j, kk)]
+#define Wc(kk) F.W[XW(i, j, kk)]
+  double FCk, FCm;
+  VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
+  VFLUX_LOCAL(FCm, vs, k - 1, N, Tc, Wc);
+#undef Tc
+#undef Wc
+  const double cv = cff * (FCk - FCm);
+  tt = tt - cv;
+  tt = tt * (1.0 / F.Hz[X3(i, j, k)]);
+  tn[X3(i, j, k)] = tt;
+}
+THREAD_GLOBAL(k_s3t_hv, KArgs)
+
 // horizontal advection of t(3) -> t(nnew); grid.z = (k-1)+N*(itrc-1); 4 LDS arrays
 #define S3T_NLDS 4
 COOP_KERNEL(k_s3t_h, KArgs) {
@@ -165,6 +204,7 @@ COOP_KERNEL(k_s3t_h, KArgs) {
   const TB B = block_bounds(G, bx, by);
   const int k = bz % G.N + 1, itrc = bz / G.N + 1;
   if (G.hadv[itrc - 1] == ROMS_MPDATA) return;   // k_mpdata.h (uniform over the block)
+  if (s3t_point_path(G, itrc)) return;           // k_s3t_hv
   const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
   double *FX = lds, *FE = lds + sz, *wk = lds + 2 * sz, *wk2 = lds + 3 * sz;
   const int hs = G.hadv[itrc - 1];
@@ -248,41 +288,43 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
   const double *Akt = F.Akt + (size_t)(ltrc - 1) * G.nij * (N + 1);
   const double pmn_dt = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];   // CF(i,0)
   double CF[ROMS_NPRIV], DC[ROMS_NPRIV];
+  if (!s3t_point_path(G, itrc)) {   // otherwise k_s3t_hv has done the vertical advection already
   if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, T3, 1);
-#define Tc(kk) T3[X3(i, j, kk)]
-#define Wc(kk) W[XW(i, j, kk)]
-  // HSIMT vertical: KaZ, gradZ local functions of the column :1069-1150
-#define KAZ(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : 1.0 - fabs(F.pm[X2(i, j)] * F.pn[X2(i, j)] * dt * W[XW(i, j, kk)] / (z_r[X3(i, j, (kk) + 1)] - z_r[X3(i, j, kk)])))
-#define GZ(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : T3[X3(i, j, (kk) + 1)] - T3[X3(i, j, kk)])
-  double FCm = 0.0;
-  for (int k = 1; k <= N; k++) {
-    double FCk;
-    if (vs == ROMS_SPLINES) FCk = F.wrk3[3][XW(i, j, k)];
-    else if (vs == ROMS_HSIMT) {
-      if (k >= N) FCk = 0.0;
-      else {
-        const double w = W[XW(i, j, k)];
-        if (k == 1 && w >= 0.0) FCk = w * Tc(k);
-        else if (k == N - 1 && w < 0.0) FCk = w * Tc(k + 1);
+  #define Tc(kk) T3[X3(i, j, kk)]
+  #define Wc(kk) W[XW(i, j, kk)]
+    // HSIMT vertical: KaZ, gradZ local functions of the column :1069-1150
+  #define KAZ(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : 1.0 - fabs(F.pm[X2(i, j)] * F.pn[X2(i, j)] * dt * W[XW(i, j, kk)] / (z_r[X3(i, j, (kk) + 1)] - z_r[X3(i, j, kk)])))
+  #define GZ(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : T3[X3(i, j, (kk) + 1)] - T3[X3(i, j, kk)])
+    double FCm = 0.0;
+    for (int k = 1; k <= N; k++) {
+      double FCk;
+      if (vs == ROMS_SPLINES) FCk = F.wrk3[3][XW(i, j, k)];
+      else if (vs == ROMS_HSIMT) {
+        if (k >= N) FCk = 0.0;
         else {
-          const double Ka = KAZ(k), oKa = 1.0 / Ka;
-          double sw;
-          if (w >= 0.0) sw = Tc(k) + hsimt_lim(GZ(k), GZ(k - 1), Ka, KAZ(k - 1), oKa);
-          else sw = Tc(k + 1) - hsimt_lim(GZ(k), GZ(k + 1), Ka, KAZ(k + 1), oKa);
-          FCk = w * sw;
+          const double w = W[XW(i, j, k)];
+          if (k == 1 && w >= 0.0) FCk = w * Tc(k);
+          else if (k == N - 1 && w < 0.0) FCk = w * Tc(k + 1);
+          else {
+            const double Ka = KAZ(k), oKa = 1.0 / Ka;
+            double sw;
+            if (w >= 0.0) sw = Tc(k) + hsimt_lim(GZ(k), GZ(k - 1), Ka, KAZ(k - 1), oKa);
+            else sw = Tc(k + 1) - hsimt_lim(GZ(k), GZ(k + 1), Ka, KAZ(k + 1), oKa);
+            FCk = w * sw;
+          }
         }
-      }
-    } else VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
-    const double cff1 = pmn_dt * (FCk - FCm);
-    double tt = tn[X3(i, j, k)] - cff1;
-    tt = tt * (1.0 / Hz[X3(i, j, k)]);
-    tn[X3(i, j, k)] = tt;
-    FCm = FCk;
+      } else VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
+      const double cff1 = pmn_dt * (FCk - FCm);
+      double tt = tn[X3(i, j, k)] - cff1;
+      tt = tt * (1.0 / Hz[X3(i, j, k)]);
+      tn[X3(i, j, k)] = tt;
+      FCm = FCk;
+    }
+  #undef Tc
+  #undef Wc
+  #undef KAZ
+  #undef GZ
   }
-#undef Tc
-#undef Wc
-#undef KAZ
-#undef GZ
   // implicit vertical diffusion, parabolic splines (SPLINES_VDIFF) :1664-1722
   {
     const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
