@@ -45,6 +45,7 @@ WORKLOADS = {
 ALGO_ARRAYS = {
     #                  3-D  2-D
     "k_step2d":       (0, 44),
+    "k_pre_t3":       (15, 2),     # fused k_pre_t3h + k_pre_t3v: t(3) is written once
     "k_pre_t3h":      (7, 2),
     "k_pre_t3v":      (10, 2),
     "k_pre_new":      (19, 9),
@@ -55,9 +56,11 @@ ALGO_ARRAYS = {
     "k_uv3dmix2_s":   (11, 12),
     "k_uv3dmix2_sum": (4, 4),
     "k_rhs3d_h":      (9, 3),
-    "k_rhs3d_v":      (7, 10),
+    "k_rhs3d_v":      (7, 0),
+    "k_rhs3d_sum":    (2, 10),
     "k_s3uv_col":     (8, 6),
     "k_s3uv_couple":  (9, 8),
+    "k_s3t_hv":       (12, 2),     # fused horizontal + vertical corrector advection, NT tracers
     "k_s3t_h":        (8, 2),
     "k_s3t_col":      (11, 2),
     "k_omega":        (4, 0),
@@ -239,7 +242,7 @@ def main():
                         "avg_launch_us": avg * 1e6, "launches": launches,
                         "algorithmic_bytes_per_launch": nb}
 
-    copy_gbs = run.ctx.copy_probe() if args.copy_probe else None
+    copy_gbs = run.ctx.copy_probe() if (args.copy_probe or rank == 0) else None
     if roofline is not None:
         roofline["measured_copy_GBs"] = copy_gbs
         roofline["traffic"] = pmc_traffic(args.workload, dominant, world)
