@@ -9,6 +9,10 @@ transport on the device context:
           unique id is created on rank 0 and broadcast through torch.distributed
   "dist"  a callback that moves the strips with torch.distributed isend/irecv on host tensors --
           used with the gloo backend and the CPU-emulated kernels by tests/test_tiles.py
+  "dist_staged"  the same callback for the real HIP build: the device strips are staged through host
+          memory (hipMemcpy) around the isend/irecv.  Slow; it exists so that the device-side
+          pack/unpack kernels and the strip geometry can be tested with several ranks sharing ONE
+          GPU (RCCL refuses two ranks on one device)
 
 Weak scaling: `weak=True` replicates the case's Lm x Mm tile NtileI x NtileJ times, i.e. the global
 grid is (Lm*NtileI) x (Mm*NtileJ); `weak=False` splits the case's own grid.
@@ -52,6 +56,8 @@ class TiledRun:
                 self._install_rccl()
             elif transport == "dist":
                 self._install_dist()
+            elif transport == "dist_staged":
+                self._install_dist(staged=True)
             else:
                 raise ValueError(transport)
         self.host.start()
@@ -68,15 +74,32 @@ class TiledRun:
         raw = bytes(t.cpu().tolist())
         self.ctx._ck(L.roms_hip_comm_rccl(self.ctx.h, raw, self.world, self.rank))
 
-    def _install_dist(self):
+    def _install_dist(self, staged=False):
         import torch
         dist = self.dist
+        hip = C.CDLL("libamdhip64.so") if staged else None
+        if hip is not None:
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
         def view(ptr, n):
             return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,)))
 
         def cb(user, ns, sp, sb, sc, st, nr, rp, rb, rc, rt):
             try:
+                if staged:      # device pointers: stage through host arrays
+                    sh = [np.empty(sc[k]) for k in range(ns)]
+                    rh = [np.empty(rc[k]) for k in range(nr)]
+                    for k in range(ns):
+                        if hip.hipMemcpy(sh[k].ctypes.data, sb[k], 8 * sc[k], 2) != 0:     # hipMemcpyDeviceToHost
+                            return 2
+                    reqs = [dist.irecv(torch.from_numpy(rh[k]), src=rp[k], tag=rt[k]) for k in range(nr)]
+                    reqs += [dist.isend(torch.from_numpy(sh[k]), dst=sp[k], tag=st[k]) for k in range(ns)]
+                    for r in reqs:
+                        r.wait()
+                    for k in range(nr):
+                        if hip.hipMemcpy(rb[k], rh[k].ctypes.data, 8 * rc[k], 1) != 0:     # hipMemcpyHostToDevice
+                            return 2
+                    return 0
                 reqs = [dist.irecv(view(rb[k], rc[k]), src=rp[k], tag=rt[k]) for k in range(nr)]
                 reqs += [dist.isend(view(sb[k], sc[k]), dst=sp[k], tag=st[k]) for k in range(ns)]
                 for r in reqs:

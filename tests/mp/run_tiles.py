@@ -22,9 +22,13 @@ def main():
     cs = util.case_for(spec["tag"], **spec.get("kw", {}))
     cs["ninfo"] = 0
     emu = os.path.join(ROOT, "tests", "emu")
-    run = tiling.TiledRun(cs, rank=rank, world=world, dist=dist, transport="dist", weak=False,
-                          tiles=tuple(spec["tiles"]), host_lib=os.path.join(emu, "libroms_host_emu.so"),
-                          hip_lib=os.path.join(emu, "libroms_hip_emu.so"))
+    if spec.get("gpu"):      # real HIP build, all ranks on cuda:0, strips staged through the host
+        run = tiling.TiledRun(cs, rank=rank, world=world, device=0, dist=dist, transport="dist_staged", weak=False,
+                              tiles=tuple(spec["tiles"]))
+    else:
+        run = tiling.TiledRun(cs, rank=rank, world=world, dist=dist, transport="dist", weak=False,
+                              tiles=tuple(spec["tiles"]), host_lib=os.path.join(emu, "libroms_host_emu.so"),
+                              hip_lib=os.path.join(emu, "libroms_hip_emu.so"))
     run.step(spec["steps"], kernels=spec.get("kernels", False))
     res = {n: run.gather(n) for n in spec["fields"]}
     d = run.diag()
