@@ -38,48 +38,104 @@ THREAD_KERNEL(k_s3uv_col, KArgs) {
   else if (G.iic == G.ntfirst + 1) cff = 0.25 * dt * 3.0 / 2.0;
   else cff = 0.25 * dt * 23.0 / 12.0;
   const double DC0 = cff * (F.pm[X2(i, j)] + F.pm[X2(i - di, j - dj)]) * (F.pn[X2(i, j)] + F.pn[X2(i - di, j - dj)]);
-  // time step r.h.s. :345-358  (q = (q + DC0*rq) / Hzk)
-  for (int k = 1; k <= N; k++) {
-    double qq = q[X3(i, j, k)] + DC0 * rq[XW(i, j, k)];
-    qq = qq * (1.0 / HZc(k));
-    q[X3(i, j, k)] = qq;
-  }
-  // implicit vertical viscosity, parabolic splines :361-450
+  // Three sweeps over the column, six levels at a time (a chunk's inputs are loaded first so that
+  // the loads overlap, then the recurrences run on registers):
+  //   up    time step of the r.h.s. :345-358 (q = (q + DC0*rq) / Hz) fused with the forward
+  //         elimination of the implicit viscosity (parabolic splines :361-450)
+  //   down  back-substitution, adding the viscous flux divergence of level k+1 as soon as DC(k) is final
+  //   up    vertical mean :594-730 / :1061-1200 (sums in ascending k, as the reference) and correction
+  const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
   {
-    const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
-    CF[0] = 0.0;
-    DC[0] = 0.0;
-    double Hk = HZc(1), oHk = 1.0 / Hk, qk = q[X3(i, j, 1)];
-    for (int k = 1; k <= N - 1; k++) {
-      const double Hk1 = HZc(k + 1), oHk1 = 1.0 / Hk1, qk1 = q[X3(i, j, k + 1)];
-      const double FCk = c6 * Hk - dt * AKc(k - 1) * oHk;
-      const double CFk = c6 * Hk1 - dt * AKc(k + 1) * oHk1;
-      const double BCk = c3 * (Hk + Hk1) + dt * AKc(k) * (oHk + oHk1);
-      const double cf = 1.0 / (BCk - FCk * CF[k - 1]);
-      CF[k] = cf * CFk;
-      DC[k] = cf * (qk1 - qk - FCk * DC[k - 1]);
-      Hk = Hk1; oHk = oHk1; qk = qk1;
+    double CFm = 0.0, DCm = 0.0;       // CF(k-1), DC(k-1)
+    double qprev = 0.0;                // q'(k0) carried from the previous chunk (its last level)
+    for (int k0 = 1; k0 <= N; k0 += 6) {
+      double hz[7], qq[7], ak[8];      // level k0+q ; ak[q]: w-level k0-1+q
+#pragma unroll
+      for (int qi = 0; qi < 7; qi++) {
+        const int kk = KMIN(k0 + qi, N);
+        hz[qi] = HZc(kk);
+        qq[qi] = q[X3(i, j, kk)] + DC0 * rq[XW(i, j, kk)];
+      }
+#pragma unroll
+      for (int qi = 0; qi < 8; qi++) { const int kk = KMIN(k0 - 1 + qi, N); ak[qi] = AKc(kk); }
+#pragma unroll
+      for (int qi = 0; qi < 7; qi++) qq[qi] = qq[qi] * (1.0 / hz[qi]);
+      if (k0 > 1) qq[0] = qprev;       // already stored by the previous chunk (identical value)
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        const int k = k0 + m;
+        if (k <= N) {
+          if (!(k0 > 1 && m == 0)) q[X3(i, j, k)] = qq[m];
+          if (k <= N - 1) {
+            const double Hk = hz[m], Hk1 = hz[m + 1], oHk = 1.0 / Hk, oHk1 = 1.0 / Hk1;
+            const double FCk = c6 * Hk - dt * ak[m] * oHk;
+            const double CFk = c6 * Hk1 - dt * ak[m + 2] * oHk1;
+            const double BCk = c3 * (Hk + Hk1) + dt * ak[m + 1] * (oHk + oHk1);
+            const double cf = 1.0 / (BCk - FCk * CFm);
+            CFm = cf * CFk;
+            DCm = cf * (qq[m + 1] - qq[m] - FCk * DCm);
+            CF[k] = CFm;
+            DC[k] = DCm;
+          }
+        }
+      }
+      if (k0 + 6 <= N) { q[X3(i, j, k0 + 6)] = qq[6]; qprev = qq[6]; }
     }
-    DC[N] = 0.0;
-    for (int k = N - 1; k >= 1; k--) DC[k] = DC[k] - CF[k] * DC[k + 1];
   }
-  // add the viscous flux divergence, then replace the vertical mean :594-730 / :1061-1200
-  double CF0 = 0.0, DCs = 0.0, DCm = 0.0;   // DCm = DC(k-1)*AK(k-1)
-  for (int k = 1; k <= N; k++) {
-    const double Hk = HZc(k), oHk = 1.0 / Hk;
-    const double DCk = DC[k] * AKc(k);
-    const double c = dt * oHk * (DCk - DCm);
-    const double qq = q[X3(i, j, k)] + c;
-    q[X3(i, j, k)] = qq;
-    DCm = DCk;
-    if (k == 1) { CF0 = Hk; DCs = qq * Hk; }
-    else { CF0 = CF0 + Hk; DCs = DCs + qq * Hk; }
+  {
+    double DCp = 0.0;                  // DC(k+1), final (DC(N) = 0)
+    for (int k0 = N - 1; k0 >= 1; k0 -= 6) {
+      double cf[6], dc[6], ak[7], hz[6], qq[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        const int k = KMAX(k0 - m, 1);
+        cf[m] = CF[k]; dc[m] = DC[k];
+        hz[m] = HZc(k + 1); qq[m] = q[X3(i, j, k + 1)];
+      }
+#pragma unroll
+      for (int qi = 0; qi < 7; qi++) { const int kk = KMAX(k0 + 1 - qi, 1); ak[qi] = AKc(kk); }
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        const int k = k0 - m;
+        if (k >= 1) {
+          const double DCk = dc[m] - cf[m] * DCp;
+          const double up = DCp * ak[m], lo = DCk * ak[m + 1];
+          const double c = dt * (1.0 / hz[m]) * (up - lo);
+          q[X3(i, j, k + 1)] = qq[m] + c;
+          DCp = DCk;
+        }
+      }
+    }
+    const double Hk = HZc(1);
+    const double c = dt * (1.0 / Hk) * (DCp * AKc(1) - 0.0);
+    q[X3(i, j, 1)] = q[X3(i, j, 1)] + c;
+  }
+  double CF0 = 0.0, DCs = 0.0;
+  for (int k0 = 1; k0 <= N; k0 += 8) {
+    double hz[8], qq[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const int kk = KMIN(k0 + m, N); hz[m] = HZc(kk); qq[m] = q[X3(i, j, kk)]; }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int k = k0 + m;
+      if (k <= N) {
+        if (k == 1) { CF0 = hz[m]; DCs = qq[m] * hz[m]; }
+        else { CF0 = CF0 + hz[m]; DCs = DCs + qq[m] * hz[m]; }
+      }
+    }
   }
   const double omn1 = (dir == 0 ? F.on_u : F.om_v)[X2(i, j)];
   const double Davg = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
   const double cff1 = 1.0 / (CF0 * omn1);
   const double corr = (DCs * omn1 - Davg) * cff1;
-  for (int k = 1; k <= N; k++) q[X3(i, j, k)] = q[X3(i, j, k)] - corr;
+  for (int k0 = 1; k0 <= N; k0 += 8) {
+    double qq[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) qq[m] = q[X3(i, j, KMIN(k0 + m, N))];
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+      if (k0 + m <= N) q[X3(i, j, k0 + m)] = qq[m] - corr;
+  }
 #undef AKc
 #undef HZc
 }
@@ -325,30 +381,62 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
   #undef KAZ
   #undef GZ
   }
-  // implicit vertical diffusion, parabolic splines (SPLINES_VDIFF) :1664-1722
+  // implicit vertical diffusion, parabolic splines (SPLINES_VDIFF) :1664-1722.  Two sweeps over the column,
+  // six levels at a time: the levels' inputs are loaded first (the loads overlap), then the recurrence
+  // runs on registers.  The downward sweep does the back-substitution and adds the flux divergence of
+  // level k+1 as soon as DC(k) is final, so t(nnew) is read and written once.
   {
     const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
-    CF[0] = 0.0;
-    DC[0] = 0.0;
-    double Hk = Hz[X3(i, j, 1)], oHk = 1.0 / Hk, tk = tn[X3(i, j, 1)];
-    for (int k = 1; k <= N - 1; k++) {
-      const double Hk1 = Hz[X3(i, j, k + 1)], oHk1 = 1.0 / Hk1, tk1 = tn[X3(i, j, k + 1)];
-      const double FCk = c6 * Hk - dt * Akt[XW(i, j, k - 1)] * oHk;
-      const double CFk = c6 * Hk1 - dt * Akt[XW(i, j, k + 1)] * oHk1;
-      const double BCk = c3 * (Hk + Hk1) + dt * Akt[XW(i, j, k)] * (oHk + oHk1);
-      const double cf = 1.0 / (BCk - FCk * CF[k - 1]);
-      CF[k] = cf * CFk;
-      DC[k] = cf * (tk1 - tk - FCk * DC[k - 1]);
-      Hk = Hk1; oHk = oHk1; tk = tk1;
+    double CFm = 0.0, DCm = 0.0;       // CF(k-1), DC(k-1)
+    for (int k0 = 1; k0 <= N - 1; k0 += 6) {
+      double hz[7], tt[7], ak[8];      // hz[q], tt[q]: level k0+q ; ak[q]: w-level k0-1+q
+#pragma unroll
+      for (int q = 0; q < 7; q++) { const int kk = KMIN(k0 + q, N); hz[q] = Hz[X3(i, j, kk)]; tt[q] = tn[X3(i, j, kk)]; }
+#pragma unroll
+      for (int q = 0; q < 8; q++) ak[q] = Akt[XW(i, j, KMIN(k0 - 1 + q, N))];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        const int k = k0 + m;
+        if (k <= N - 1) {
+          const double Hk = hz[m], Hk1 = hz[m + 1], oHk = 1.0 / Hk, oHk1 = 1.0 / Hk1;
+          const double FCk = c6 * Hk - dt * ak[m] * oHk;
+          const double CFk = c6 * Hk1 - dt * ak[m + 2] * oHk1;
+          const double BCk = c3 * (Hk + Hk1) + dt * ak[m + 1] * (oHk + oHk1);
+          const double cf = 1.0 / (BCk - FCk * CFm);
+          CFm = cf * CFk;
+          DCm = cf * (tt[m + 1] - tt[m] - FCk * DCm);
+          CF[k] = CFm;
+          DC[k] = DCm;
+        }
+      }
     }
-    DC[N] = 0.0;
-    for (int k = N - 1; k >= 1; k--) DC[k] = DC[k] - CF[k] * DC[k + 1];
-    double DCm = 0.0;
-    for (int k = 1; k <= N; k++) {
-      const double DCk = DC[k] * Akt[XW(i, j, k)];
-      const double cff1 = dt * (1.0 / Hz[X3(i, j, k)]) * (DCk - DCm);
-      tn[X3(i, j, k)] = tn[X3(i, j, k)] + cff1;
-      DCm = DCk;
+    double DCp = 0.0;                  // DC(k+1), final (DC(N) = 0)
+    for (int k0 = N - 1; k0 >= 1; k0 -= 6) {
+      double cf[6], dc[6], ak[7], hz[6], tt[6];   // cf,dc: level k0-m ; ak[q]: w-level k0+1-q ; hz,tt: level k0+1-m
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        const int k = KMAX(k0 - m, 1);
+        cf[m] = CF[k]; dc[m] = DC[k];
+        hz[m] = Hz[X3(i, j, k + 1)]; tt[m] = tn[X3(i, j, k + 1)];
+      }
+#pragma unroll
+      for (int q = 0; q < 7; q++) ak[q] = Akt[XW(i, j, KMAX(k0 + 1 - q, 1))];
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        const int k = k0 - m;
+        if (k >= 1) {
+          const double DCk = dc[m] - cf[m] * DCp;
+          const double up = DCp * ak[m], lo = DCk * ak[m + 1];        // DC(k+1)*Akt(k+1), DC(k)*Akt(k)
+          const double cff1 = dt * (1.0 / hz[m]) * (up - lo);
+          tn[X3(i, j, k + 1)] = tt[m] + cff1;
+          DCp = DCk;
+        }
+      }
+    }
+    {   // level 1: DC(0)*Akt(0) = 0
+      const double DCk = DCp * Akt[XW(i, j, 1)];
+      const double cff1 = dt * (1.0 / Hz[X3(i, j, 1)]) * (DCk - 0.0);
+      tn[X3(i, j, 1)] = tn[X3(i, j, 1)] + cff1;
     }
   }
 }
