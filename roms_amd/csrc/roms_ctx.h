@@ -135,30 +135,47 @@ enum { BC_NONE = 0, BC_R = 1, BC_U = 2, BC_V = 3 };
 #define SW_(b) ((b).Iend - (b).Istr + 7)
 #define S2(i, j) ((size_t)((i) - (B.Istr - 3)) + (size_t)((j) - (B.Jstr - 3)) * (size_t)SW_(B))
 
+// Device array pointer as stored in the pointer table.  The table lives in device memory, so to the
+// compiler a pointer loaded from it is a generic (flat) address: every access becomes flat_load /
+// flat_store with a 64-bit VALU address computation.  Typing the stored pointer as global
+// (address space 1) lets the address-space inference turn all accesses derived from it into
+// global_load / global_store with scalar base + 32-bit offset addressing.  Converts to a plain
+// double* everywhere, so kernel code is unaffected.
+#ifdef ROMS_CPU_EMU
+typedef double gdouble_t;
+#else
+typedef __attribute__((address_space(1))) double gdouble_t;
+#endif
+struct GPtr {
+  gdouble_t *p;
+  KHD operator double *() const { return (double *)p; }
+  KHD GPtr &operator=(double *q) { p = (gdouble_t *)q; return *this; }
+};
+
 // All device arrays (reference component names).  Pointers only; passed to kernels through the
 // small per-kernel argument structs.
 struct Fields {
   // mod_grid
-  double *h, *f, *fomn, *pm, *pn, *om_r, *on_r, *om_u, *on_u, *om_v, *on_v, *om_p, *on_p, *omn, *pmon_r, *pnom_r,
-      *pmon_p, *pnom_p, *pmon_u, *pnom_u, *pmon_v, *pnom_v, *dmde, *dndx, *angler, *xr, *yr, *lonr, *latr, *rdrag,
-      *rdrag2;
-  double *Hz, *z_r, *z_w, *Huon, *Hvom;
+  GPtr h, f, fomn, pm, pn, om_r, on_r, om_u, on_u, om_v, on_v, om_p, on_p, omn, pmon_r, pnom_r,
+      pmon_p, pnom_p, pmon_u, pnom_u, pmon_v, pnom_v, dmde, dndx, angler, xr, yr, lonr, latr, rdrag,
+      rdrag2;
+  GPtr Hz, z_r, z_w, Huon, Hvom;
   // mod_ocean
-  double *zeta, *ubar, *vbar, *rzeta, *rubar, *rvbar, *u, *v, *t, *W, *wvel, *rho, *pden, *ru, *rv;
+  GPtr zeta, ubar, vbar, rzeta, rubar, rvbar, u, v, t, W, wvel, rho, pden, ru, rv;
   // mod_coupling
-  double *rhoA, *rhoS, *rufrc, *rvfrc, *Zt_avg1, *DU_avg1, *DU_avg2, *DV_avg1, *DV_avg2;
+  GPtr rhoA, rhoS, rufrc, rvfrc, Zt_avg1, DU_avg1, DU_avg2, DV_avg1, DV_avg2;
   // mod_forces
-  double *sustr, *svstr, *bustr, *bvstr, *stflx, *btflx, *stflux, *btflux, *srflx;
-  double *Uwind, *Vwind, *Tair, *Pair, *Hair, *rain, *cloud, *lhflx, *shflx, *lrflx, *evap;
+  GPtr sustr, svstr, bustr, bvstr, stflx, btflx, stflux, btflux, srflx;
+  GPtr Uwind, Vwind, Tair, Pair, Hair, rain, cloud, lhflx, shflx, lrflx, evap;
   // mod_mixing
-  double *Akv, *Akt, *visc2_r, *visc2_p, *diff2, *bvf, *alpha, *beta, *hsbl, *ghats;
+  GPtr Akv, Akt, visc2_r, visc2_p, diff2, bvf, alpha, beta, hsbl, ghats;
   // s-coordinate tables (device copies)
-  double *sc_r, *Cs_r, *sc_w, *Cs_w;
+  GPtr sc_r, Cs_r, sc_w, Cs_w;
   // work space: private 3-D arrays of the reference kernels (P of prsgrd, vert of wvelocity,
   // oHz/Ta/Ua/Va/Wa of step3d_t, swdk of pre_step3d ...)
-  double *wrk3[6];
-  double *wrk2[4];
+  GPtr wrk3[6];
+  GPtr wrk2[4];
   // MPDATA work arrays (allocated only when a tracer uses MPDATA): Ta (N planes per tracer), Ua, Va, Wa,
   // beta_up, beta_dn
-  double *mp3[6];
+  GPtr mp3[6];
 };
