@@ -13,26 +13,50 @@ int run_step2d(roms_hip_ctx *c) {
   a.w1_m1 = (iif >= 2) ? cf.weight[0][iif - 1] : 0.0;
   a.w2_0 = cf.weight[1][iif];
   a.w2_p1 = (iif + 1 <= ROMS_MAXW) ? cf.weight[1][iif + 1] : 0.0;
-  const size_t tile = (size_t)(G.bw2 + 6) * (size_t)(G.bh2 + 6);
-  const size_t lds = (size_t)STEP2D_NLDS * tile;
-  // every thread owns at most STEP2D_PTS rectangle points (stages 1-3) and STEP2D_PTS of the
-  // 2*bw*bh momentum-point work items (stage 4); one of each where the launch bound (512) allows
-  const size_t need = tile > 2 * (size_t)G.bw2 * (size_t)G.bh2 ? tile : 2 * (size_t)G.bw2 * (size_t)G.bh2;
-  int nthreads = need <= 512 ? (int)((need + 63) / 64) * 64 : 512;
-  if (nthreads < 256) nthreads = 256;
-  if (need > (size_t)STEP2D_PTS * 512) { set_error("k_step2d: sub-tile too large for the launch bound"); return 5; }
-  if (getenv("ROMS_HIP_S2D_THREADS")) nthreads = atoi(getenv("ROMS_HIP_S2D_THREADS"));
-#ifndef ROMS_CPU_EMU
-  static bool big_lds = false;
-  if (lds * sizeof(double) > 64 * 1024 && !big_lds) {   // more than the default dynamic LDS limit
-    if (hipFuncSetAttribute((const void *)k_step2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      set_error("k_step2d: cannot raise the dynamic LDS limit");
-      return 2;
-    }
-    big_lds = true;
+  if (c->m2d_dirty) {   // (re)build the packed metric records after the grid arrays were uploaded
+    PackArgs pa;
+    pa.G = G;
+    pa.Fp = c->d_F;
+    LAUNCH_THREAD(k_pack_m2d, G.ni, G.nj, 1, c->stream, pa);
+    c->m2d_dirty = false;
   }
+  // kernel variant by sub-tile size: up to 32x4, up to 64x8, generic (ROMS_HIP_TILE2D overrides)
+  int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
+  if (getenv("ROMS_HIP_S2D_GENERIC")) variant = 2;
+#ifdef ROMS_CPU_EMU
+  variant = 2;   // the serial emulation has one "thread": only the generic form applies
 #endif
-  LAUNCH_COOP(k_step2d, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
+  const int tw = variant == 0 ? 38 : variant == 1 ? 70 : G.bw2 + 6, th = variant == 0 ? 10 : variant == 1 ? 14 : G.bh2 + 6;
+  const size_t lds = (size_t)STEP2D_NLDS * (size_t)tw * (size_t)th;
+  if (variant == 0) {
+    LAUNCH_COOP_AS(k_step2d, k_step2d_a, G.nbx2, G.nby2, 1, 384, lds, c->stream, a);
+  } else if (variant == 1) {
+#ifndef ROMS_CPU_EMU
+    static bool big_lds = false;
+    if (!big_lds) {   // 118 KB: more than the default dynamic LDS limit
+      if (hipFuncSetAttribute((const void *)k_step2d_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        set_error("k_step2d: cannot raise the dynamic LDS limit");
+        return 2;
+      }
+      big_lds = true;
+    }
+#endif
+    LAUNCH_COOP_AS(k_step2d, k_step2d_b, G.nbx2, G.nby2, 1, 512, lds, c->stream, a);
+  } else {
+    int nthreads = 512;
+    if (getenv("ROMS_HIP_S2D_THREADS")) nthreads = atoi(getenv("ROMS_HIP_S2D_THREADS"));
+#ifndef ROMS_CPU_EMU
+    static bool big_lds_g = false;
+    if (lds * sizeof(double) > 64 * 1024 && !big_lds_g) {
+      if (hipFuncSetAttribute((const void *)k_step2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        set_error("k_step2d: cannot raise the dynamic LDS limit");
+        return 2;
+      }
+      big_lds_g = true;
+    }
+#endif
+    LAUNCH_COOP(k_step2d, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
+  }
   if (G.fuse_halo) return 0;   // the kernel filled the boundary and periodic ghost points itself
   if (iif == G.nfast + 1 && G.predictor) {
     // final fast-time averages :821-883

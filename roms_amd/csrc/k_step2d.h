@@ -24,9 +24,17 @@
 //
 // In single-tile runs with a periodic direction every thread also stores the boundary and periodic
 // images of its values (k_haloblock.h), so no halo launch follows.
+//
+// The kernel is instruction-issue bound (one block of 6-8 waves per CU, long dependent chains), so
+// the body is written to keep integer/address work down: the sub-tile shape and thread count are
+// template constants (LDS offsets become immediates, point <-> thread maps constant divisions), the
+// u- and v-points are separate passes with the direction a compile-time constant, the 13 metric
+// arrays a momentum point needs are read from two packed 64-byte records (k_pack_m2d), and time
+// levels of one array are addressed by index offsets instead of separate base pointers (SGPRs).
 #pragma once
 #include "roms_ctx.h"
 #include "k_haloblock.h"
+
 
 struct Step2dArgs {
   DGrid G;
@@ -36,37 +44,74 @@ struct Step2dArgs {
 };
 
 #define STEP2D_NLDS 15
-#define STEP2D_PTS 2      // rectangle points (stages 1-3) and work items (stage 4) per thread
 
-// Sweep over the sub-tile rectangle with a fixed point -> thread mapping.
+// Packed time-invariant metrics of the momentum stage, one 64-byte record per grid point (a wave reads
+// 4 KB of consecutive records).  Built by k_pack_m2d from the individual arrays, which stay the
+// interface (roms_hip_upload) and the source of truth.
 #ifdef ROMS_CPU_EMU
-// serial emulation: one "thread" visits all points; own-point values are read where they are used
-#define TLOOP(i, j)                                                                                                    \
-  for (int m = 0, i = 0, j = 0, s0 = 0; m < NTILE && ((j = JT0 + m / TW), (i = IT0 + m - (m / TW) * TW), (s0 = m), true); m++) \
-    for (long x0 = (long)X2(i, j), once_ = 1; once_; once_ = 0)
-#define WLOOP(w) for (int w = 0, m = 0; w < NWORK; w++, m++)
-#define PWDECL(name)
-#define PWLOAD(name, expr) ((void)0)
-#define PW(name, expr) (expr)
+struct M2Rec { double v[8]; };
 #else
-#define TLOOP(i, j)                                                                                                    \
-  _Pragma("unroll") for (int m = 0; m < STEP2D_PTS; m++) if (tq[m])                                                    \
-    for (int i = ti[m], j = tj[m], s0 = KTID + m * KNT, x0 = tx[m], once_ = 1; once_; once_ = 0)
-#define WLOOP(w)                                                                                                       \
-  _Pragma("unroll") for (int m = 0; m < STEP2D_PTS; m++)                                                               \
-    for (int w = KTID + m * KNT, once_ = 1; once_ && w < NWORK; once_ = 0)
-#define PWDECL(name) double name[STEP2D_PTS]
-#define PWLOAD(name, expr) name[m] = (expr)
-#define PW(name, expr) name[m]
+struct alignas(64) M2Rec { double v[8]; };   // hipMalloc'ed base, 64-byte records: dwordx4 loads
 #endif
+enum { MR_FOMN = 0, MR_DNDX, MR_DMDE, MR_V2, MR_PMON, MR_PNOM, MR_ON, MR_OM };          // rho points (Fields::m2r)
+enum { MP_V2 = 0, MP_PMON, MP_PNOM, MP_OM, MP_ON, MP_ONU, MP_OMV, MP_SPARE };           // psi points (Fields::m2p)
+
+struct PackArgs {
+  DGrid G;
+  const Fields *Fp;
+};
+THREAD_KERNEL(k_pack_m2d, PackArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = *a.Fp;
+  const size_t x = (size_t)gx + (size_t)gy * (size_t)G.ni;
+  double *r = F.m2r + 8 * x, *p = F.m2p + 8 * x;
+  r[MR_FOMN] = F.fomn[x]; r[MR_DNDX] = F.dndx[x]; r[MR_DMDE] = F.dmde[x]; r[MR_V2] = F.visc2_r[x];
+  r[MR_PMON] = F.pmon_r[x]; r[MR_PNOM] = F.pnom_r[x]; r[MR_ON] = F.on_r[x]; r[MR_OM] = F.om_r[x];
+  p[MP_V2] = F.visc2_p[x]; p[MP_PMON] = F.pmon_p[x]; p[MP_PNOM] = F.pnom_p[x]; p[MP_OM] = F.om_p[x];
+  p[MP_ON] = F.on_p[x]; p[MP_ONU] = F.on_u[x]; p[MP_OMV] = F.om_v[x]; p[MP_SPARE] = 0.0;
+}
+THREAD_GLOBAL(k_pack_m2d, PackArgs)
+
 #define INR(i, j, i0, i1, j0, j1) ((i) >= (i0) && (i) <= (i1) && (j) >= (j0) && (j) <= (j1))
 
-COOP_KERNEL(k_step2d, Step2dArgs) {
+// Template constants: BWC x BHC = largest sub-tile (the actual one may be smaller: edge sub-tiles),
+// NTC threads, PTS rectangle points per thread.  BWC = 0 is the generic form (any sub-tile shape and
+// thread count, run-time loops, no register-resident own-point values); it is also the form the
+// serial CPU emulation (tests/emu) runs.
+//
+// Sweep over the rectangle (IT0:IT0+TW-1, JT0:JT0+TH-1) of a full-size sub-tile: fixed
+// point -> thread mapping q = KTID + m*NT, LDS index s0 = q.
+#define RLOOP(i, j)                                                                                         \
+  _Pragma("unroll") for (int m = 0, q_ = KTID; FIXED ? m < PTS : q_ < NTILE; m++, q_ += NT)                \
+    if (q_ < NTILE)                                                                                         \
+      for (int s0 = q_, jj_ = q_ / TW, j = JT0 + jj_, i = IT0 + q_ - jj_ * TW,                              \
+               x0 = (i - G.LBi) + (j - G.LBj) * ni, once_ = 1; once_; once_ = 0)
+#define PWDECL(name) double name[PTS > 0 ? PTS : 1]
+#define PWLOAD(name, expr) do { if (FIXED) name[m] = (expr); } while (0)
+#define PW(name, expr) (FIXED ? name[m] : (expr))
+// Momentum points: c = interior cell (row-major over BW x BH), isv = 0 its u-point, 1 its v-point.
+// The u-points use threads 0..NOWN-1, the v-points threads VOFF..VOFF+NOWN-1 (VOFF = NOWN when the
+// block has the threads, else 0: then every thread does a u- and a v-point in turn).
+#define WLOOP(isv)                                                                                          \
+  for (int m_ = 0, c = KTID - (isv) * VOFF; FIXED ? m_ < 1 : c < NOWN; m_++, c += NT)                       \
+    if (c >= 0 && c < NOWN)
+#define WDECL(name) double name[WSLOTS]
+#define WLOAD(name, isv, expr) do { if (FIXED) name[VOFF ? 0 : (isv)] = (expr); } while (0)
+#define WV(name, isv, expr) (FIXED ? name[VOFF ? 0 : (isv)] : (expr))
+
+template <int BWC, int BHC, int NTC, int PTS>
+COOP_KERNEL(k_step2d_t, Step2dArgs) {
   (void)bz;
+  constexpr bool FIXED = BWC > 0;
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
   const TB B = block_bounds2(G, bx, by);
-  const size_t sz = (size_t)(G.bw2 + 6) * (size_t)(G.bh2 + 6);
+  const int OW = FIXED ? BWC : G.bw2, OH = FIXED ? BHC : G.bh2, NOWN = OW * OH;
+  const int TW = OW + 6, TH = OH + 6, NTILE = TW * TH, NT = FIXED ? NTC : KNT;
+  constexpr int VOFF = (BWC > 0 && 2 * BWC * BHC <= NTC) ? (BWC * BHC + 63) / 64 * 64 : 0;
+  constexpr int WSLOTS = (BWC > 0 && VOFF == 0) ? 2 : 1;
+  const size_t sz = (size_t)NTILE;
   double *Drhs = lds, *DUon = lds + sz, *DVom = lds + 2 * sz, *Dnew = lds + 3 * sz;
   double *zwrk = lds + 4 * sz, *gzeta = lds + 5 * sz, *gzeta2 = lds + 6 * sz, *gzetaSA = lds + 7 * sz;
   double *sUk = lds + 8 * sz, *sVk = lds + 9 * sz, *sH = lds + 10 * sz, *sPm = lds + 11 * sz, *sPn = lds + 12 * sz,
@@ -77,72 +122,52 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   const int IstrR = B.IstrR, IendR = B.IendR, JstrR = B.JstrR, JendR = B.JendR;
   const int ptsk = 3 - kstp;
   const double dtfast = G.dtfast, g = G.g;
-  const double *zk = F.zeta + (size_t)(krhs - 1) * G.nij, *zs = F.zeta + (size_t)(kstp - 1) * G.nij;
-  const double *uk = F.ubar + (size_t)(krhs - 1) * G.nij, *us = F.ubar + (size_t)(kstp - 1) * G.nij;
-  const double *vk = F.vbar + (size_t)(krhs - 1) * G.nij, *vs = F.vbar + (size_t)(kstp - 1) * G.nij;
+  const int ni = G.ni, nij = (int)G.nij;
+  // time levels of the 2-D state: index offsets into one array
+  const int o_krhs = (krhs - 1) * nij, o_kstp = (kstp - 1) * nij, o_ptsk = (ptsk - 1) * nij;
   double *zn = F.zeta + (size_t)(knew - 1) * G.nij, *un = F.ubar + (size_t)(knew - 1) * G.nij,
          *vn = F.vbar + (size_t)(knew - 1) * G.nij;
-  const double *rz_s = F.rzeta + (size_t)(kstp - 1) * G.nij, *rz_p = F.rzeta + (size_t)(ptsk - 1) * G.nij;
   double *rz_k = F.rzeta + (size_t)(krhs - 1) * G.nij;
-  const double *rub_s = F.rubar + (size_t)(kstp - 1) * G.nij, *rub_p = F.rubar + (size_t)(ptsk - 1) * G.nij;
-  const double *rvb_s = F.rvbar + (size_t)(kstp - 1) * G.nij, *rvb_p = F.rvbar + (size_t)(ptsk - 1) * G.nij;
   double *rub_k = F.rubar + (size_t)(krhs - 1) * G.nij, *rvb_k = F.rvbar + (size_t)(krhs - 1) * G.nij;
-  double *ru0_stp = F.ru + (size_t)(nstp - 1) * G.nij * (size_t)(G.N + 1);   // ru(:,:,0,nstp)
-  double *ru0_new = F.ru + (size_t)(nnew - 1) * G.nij * (size_t)(G.N + 1);
-  double *rv0_stp = F.rv + (size_t)(nstp - 1) * G.nij * (size_t)(G.N + 1);
-  double *rv0_new = F.rv + (size_t)(nnew - 1) * G.nij * (size_t)(G.N + 1);
+  const size_t o_r0s = (size_t)(nstp - 1) * G.nij * (size_t)(G.N + 1);   // ru(:,:,0,nstp)
+  const size_t o_r0n = (size_t)(nnew - 1) * G.nij * (size_t)(G.N + 1);
+  const M2Rec *mr = (const M2Rec *)(double *)F.m2r, *mp = (const M2Rec *)(double *)F.m2p;
   const bool last = iif > G.nfast;                 // auxiliary last predictor call :883
   const bool fuse = G.fuse_halo != 0, fuse_last = fuse && last && PRED;
   const int first = (iif == 1 && PRED);
   const int corr = (!PRED && iif != 1);
   const int startup = (iic == G.ntfirst) ? 0 : ((iic == G.ntfirst + 1) ? 1 : 2);
   const bool wfix = !G.ewp && B.west, efix = !G.ewp && B.east, sfix = !G.nsp && B.south, nfix = !G.nsp && B.north;
-  const int ni = G.ni;
-
-  // sub-tile rectangle (stages 1-3) and work items (stage 4): item w < NOWN is the u-point of interior
-  // cell w, item NOWN + w its v-point
-  const int IT0 = Istr - 3, JT0 = Jstr - 3, TW = Iend - Istr + 7, TH = Jend - Jstr + 7, NTILE = TW * TH;
-  const int OW = Iend - Istr + 1, NOWN = OW * (Jend - Jstr + 1), NWORK = 2 * NOWN;
+  const int IT0 = Istr - 3, JT0 = Jstr - 3;
   const int UBi = G.LBi + G.ni - 1, UBj = G.LBj + G.nj - 1;
-#ifndef ROMS_CPU_EMU
-  int ti[STEP2D_PTS], tj[STEP2D_PTS], tx[STEP2D_PTS];   // point, and its offset in the global 2-D arrays
-  bool tq[STEP2D_PTS];
-#pragma unroll
-  for (int m = 0; m < STEP2D_PTS; m++) {
-    const int q = KTID + m * KNT;
-    tq[m] = q < NTILE;
-    tj[m] = JT0 + q / TW;
-    ti[m] = IT0 + q - (q / TW) * TW;
-    tx[m] = (ti[m] - G.LBi) + (tj[m] - G.LBj) * G.ni;   // may lie outside the array for masked points
-  }
-#endif
+
   // stage 2-3 own-point values
   PWDECL(r_zk); PWDECL(r_zs); PWDECL(r_on_u); PWDECL(r_om_v); PWDECL(r_rhoS);
   PWDECL(r_Zt); PWDECL(r_DU1); PWDECL(r_DU2); PWDECL(r_DV1); PWDECL(r_DV2);
   PWDECL(r_rz_s); PWDECL(r_rz_p);
-  // stage 4 values of a work item: metrics at its two rho points (P0 = own cell, P1 = the cell on the
-  // other side of the momentum point) and its two psi points (Q0 = (i,j), Q1 = next along the face)
-  PWDECL(w_onom); PWDECL(w_fomn0); PWDECL(w_fomn1); PWDECL(w_dndx0); PWDECL(w_dndx1); PWDECL(w_dmde0); PWDECL(w_dmde1);
-  PWDECL(w_v2r0); PWDECL(w_v2r1); PWDECL(w_pmr0); PWDECL(w_pmr1); PWDECL(w_pnr0); PWDECL(w_pnr1);
-  PWDECL(w_onr0); PWDECL(w_onr1); PWDECL(w_omr0); PWDECL(w_omr1);
-  PWDECL(w_v2p0); PWDECL(w_v2p1); PWDECL(w_pmp0); PWDECL(w_pmp1); PWDECL(w_pnp0); PWDECL(w_pnp1);
-  PWDECL(w_omp0); PWDECL(w_omp1); PWDECL(w_onp0); PWDECL(w_onp1);
-  PWDECL(w_s); PWDECL(w_frc); PWDECL(w_rs); PWDECL(w_rp); PWDECL(w_r0n); PWDECL(w_r0s);
+  // stage 4 values of a momentum point: metrics at its two rho points (P0 = own cell, P1 = the cell on
+  // the other side of the momentum point) and its two psi points (Q0 = (i,j), Q1 = next along the face)
+  WDECL(w_onom); WDECL(w_fomn0); WDECL(w_fomn1); WDECL(w_dndx0); WDECL(w_dndx1); WDECL(w_dmde0); WDECL(w_dmde1);
+  WDECL(w_v2r0); WDECL(w_v2r1); WDECL(w_pmr0); WDECL(w_pmr1); WDECL(w_pnr0); WDECL(w_pnr1);
+  WDECL(w_or0); WDECL(w_or1);     // on_r (u-points) | om_r (v-points) at P0, P1
+  WDECL(w_v2p0); WDECL(w_v2p1); WDECL(w_pmp0); WDECL(w_pmp1); WDECL(w_pnp0); WDECL(w_pnp1);
+  WDECL(w_op0); WDECL(w_op1);     // om_p (u-points) | on_p (v-points) at Q0, Q1
+  WDECL(w_s); WDECL(w_frc); WDECL(w_rs); WDECL(w_rp); WDECL(w_r0n); WDECL(w_r0s);
 
   // ---- stage 1: every global read of the kernel ----------------------------------------------
-  TLOOP(i, j) {
+  RLOOP(i, j) {
     if (INR(i, j, G.LBi, UBi, G.LBj, UBj)) {
       // each array is read only as far from the sub-tile as some stage below needs it
       const bool ring2 = INR(i, j, Istr - 2, Iend + 2, Jstr - 2, Jend + 2);
       const bool ring1 = INR(i, j, Istr - 1, Iend + 1, Jstr - 1, Jend + 1);
-      const double zkv = zk[x0], hv = F.h[x0];
+      const double zkv = F.zeta[x0 + o_krhs], hv = F.h[x0];
       Drhs[s0] = zkv + hv;                                    // total depth :600
-      sUk[s0] = uk[x0]; sVk[s0] = vk[x0]; sH[s0] = hv;
+      sUk[s0] = F.ubar[x0 + o_krhs]; sVk[s0] = F.vbar[x0 + o_krhs]; sH[s0] = hv;
       PWLOAD(r_zk, zkv);
       PWLOAD(r_on_u, F.on_u[x0]); PWLOAD(r_om_v, F.om_v[x0]);
       if (ring2) { sPm[s0] = F.pm[x0]; sPn[s0] = F.pn[x0]; }
       if (ring1) {
-        const double zsv = zs[x0];
+        const double zsv = F.zeta[x0 + o_kstp];
         sDstp[s0] = zsv + hv;
         PWLOAD(r_zs, zsv);
         sRhoA[s0] = F.rhoA[x0];
@@ -150,40 +175,43 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
         PWLOAD(r_DV1, F.DV_avg1[x0]); PWLOAD(r_DV2, F.DV_avg2[x0]);
         if (!last) {
           PWLOAD(r_rhoS, F.rhoS[x0]);
-          if (corr) { PWLOAD(r_rz_s, rz_s[x0]); PWLOAD(r_rz_p, rz_p[x0]); }
+          if (corr) { PWLOAD(r_rz_s, F.rzeta[x0 + o_kstp]); PWLOAD(r_rz_p, F.rzeta[x0 + o_ptsk]); }
         }
       }
     } else {
       Drhs[s0] = 0.0; sDstp[s0] = 0.0; sUk[s0] = 0.0; sVk[s0] = 0.0; sH[s0] = 0.0; sPm[s0] = 0.0; sPn[s0] = 0.0; sRhoA[s0] = 0.0;
     }
   }
-  if (!last) {
-    WLOOP(w) {
-      const int isv = w >= NOWN, c = isv ? w - NOWN : w;
-      const int j = Jstr + c / OW, i = Istr + c - (c / OW) * OW;
-      if (isv ? (j >= JstrV) : (i >= IstrU)) {
-        const long x = (long)X2(i, j);
-        const long x1 = isv ? x - ni : x - 1;        // P1: (i,j-1) for a v-point, (i-1,j) for a u-point
-        const long q1 = isv ? x + 1 : x + ni;        // Q1: (i+1,j) for a v-point, (i,j+1) for a u-point
-        PWLOAD(w_onom, isv ? F.om_v[x] : F.on_u[x]);
-        PWLOAD(w_fomn0, F.fomn[x]); PWLOAD(w_fomn1, F.fomn[x1]);
-        PWLOAD(w_dndx0, F.dndx[x]); PWLOAD(w_dndx1, F.dndx[x1]);
-        PWLOAD(w_dmde0, F.dmde[x]); PWLOAD(w_dmde1, F.dmde[x1]);
-        PWLOAD(w_v2r0, F.visc2_r[x]); PWLOAD(w_v2r1, F.visc2_r[x1]);
-        PWLOAD(w_pmr0, F.pmon_r[x]); PWLOAD(w_pmr1, F.pmon_r[x1]);
-        PWLOAD(w_pnr0, F.pnom_r[x]); PWLOAD(w_pnr1, F.pnom_r[x1]);
-        PWLOAD(w_onr0, F.on_r[x]); PWLOAD(w_onr1, F.on_r[x1]);
-        PWLOAD(w_omr0, F.om_r[x]); PWLOAD(w_omr1, F.om_r[x1]);
-        PWLOAD(w_v2p0, F.visc2_p[x]); PWLOAD(w_v2p1, F.visc2_p[q1]);
-        PWLOAD(w_pmp0, F.pmon_p[x]); PWLOAD(w_pmp1, F.pmon_p[q1]);
-        PWLOAD(w_pnp0, F.pnom_p[x]); PWLOAD(w_pnp1, F.pnom_p[q1]);
-        PWLOAD(w_omp0, F.om_p[x]); PWLOAD(w_omp1, F.om_p[q1]);
-        PWLOAD(w_onp0, F.on_p[x]); PWLOAD(w_onp1, F.on_p[q1]);
-        PWLOAD(w_s, isv ? vs[x] : us[x]);
-        PWLOAD(w_frc, isv ? F.rvfrc[x] : F.rufrc[x]);
-        if (corr) { PWLOAD(w_rs, isv ? rvb_s[x] : rub_s[x]); PWLOAD(w_rp, isv ? rvb_p[x] : rub_p[x]); }
-        if (first && startup >= 1) PWLOAD(w_r0n, isv ? rv0_new[x] : ru0_new[x]);
-        if (first && startup >= 2) PWLOAD(w_r0s, isv ? rv0_stp[x] : ru0_stp[x]);
+  if (FIXED && !last) {
+#pragma unroll
+    for (int isv = 0; isv < 2; isv++) {
+      WLOOP(isv) {
+        const int jj = c / OW, j = Jstr + jj, i = Istr + c - jj * OW;
+        if (i > Iend || j > Jend || !(isv ? (j >= JstrV) : (i >= IstrU))) continue;
+        const int x = (i - G.LBi) + (j - G.LBj) * ni;
+        const int x1 = isv ? x - ni : x - 1;        // P1: (i,j-1) for a v-point, (i-1,j) for a u-point
+        const int q1 = isv ? x + 1 : x + ni;        // Q1: (i+1,j) for a v-point, (i,j+1) for a u-point
+        const M2Rec R0 = mr[x], R1 = mr[x1], P0 = mp[x], P1 = mp[q1];
+        WLOAD(w_onom, isv, isv ? P0.v[MP_OMV] : P0.v[MP_ONU]);
+        WLOAD(w_fomn0, isv, R0.v[MR_FOMN]); WLOAD(w_fomn1, isv, R1.v[MR_FOMN]);
+        WLOAD(w_dndx0, isv, R0.v[MR_DNDX]); WLOAD(w_dndx1, isv, R1.v[MR_DNDX]);
+        WLOAD(w_dmde0, isv, R0.v[MR_DMDE]); WLOAD(w_dmde1, isv, R1.v[MR_DMDE]);
+        WLOAD(w_v2r0, isv, R0.v[MR_V2]); WLOAD(w_v2r1, isv, R1.v[MR_V2]);
+        WLOAD(w_pmr0, isv, R0.v[MR_PMON]); WLOAD(w_pmr1, isv, R1.v[MR_PMON]);
+        WLOAD(w_pnr0, isv, R0.v[MR_PNOM]); WLOAD(w_pnr1, isv, R1.v[MR_PNOM]);
+        WLOAD(w_or0, isv, isv ? R0.v[MR_OM] : R0.v[MR_ON]); WLOAD(w_or1, isv, isv ? R1.v[MR_OM] : R1.v[MR_ON]);
+        WLOAD(w_v2p0, isv, P0.v[MP_V2]); WLOAD(w_v2p1, isv, P1.v[MP_V2]);
+        WLOAD(w_pmp0, isv, P0.v[MP_PMON]); WLOAD(w_pmp1, isv, P1.v[MP_PMON]);
+        WLOAD(w_pnp0, isv, P0.v[MP_PNOM]); WLOAD(w_pnp1, isv, P1.v[MP_PNOM]);
+        WLOAD(w_op0, isv, isv ? P0.v[MP_ON] : P0.v[MP_OM]); WLOAD(w_op1, isv, isv ? P1.v[MP_ON] : P1.v[MP_OM]);
+        WLOAD(w_s, isv, (isv ? F.vbar : F.ubar)[x + o_kstp]);
+        WLOAD(w_frc, isv, (isv ? F.rvfrc : F.rufrc)[x]);
+        if (corr) {
+          WLOAD(w_rs, isv, (isv ? F.rvbar : F.rubar)[x + o_kstp]);
+          WLOAD(w_rp, isv, (isv ? F.rvbar : F.rubar)[x + o_ptsk]);
+        }
+        if (first && startup >= 1) WLOAD(w_r0n, isv, (isv ? F.rv : F.ru)[o_r0n + (size_t)x]);
+        if (first && startup >= 2) WLOAD(w_r0s, isv, (isv ? F.rv : F.ru)[o_r0s + (size_t)x]);
       }
     }
   }
@@ -200,7 +228,7 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
       amode = 2;
       cA2 = (iif == 1) ? a.w2_0 : (5.0 / 12.0) * a.w2_0;
     }
-    TLOOP(i, j) {
+    RLOOP(i, j) {
       double du = 0.0, dv = 0.0;
       if (INR(i, j, B.IstrUm2 - 1, B.Iendp2, B.JstrVm2 - 1, B.Jendp2)) {
         if (i >= B.IstrUm2) {
@@ -224,7 +252,7 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
           if (pv) { F.DV_avg1[x0] = 0.0; F.DV_avg2[x0] = cA2 * dv; }
         } else if (amode == 1) {
           if (pz) {
-            const double v = PW(r_Zt, F.Zt_avg1[x0]) + cA1 * PW(r_zk, zk[x0]);
+            const double v = PW(r_Zt, F.Zt_avg1[x0]) + cA1 * PW(r_zk, F.zeta[x0 + o_krhs]);
             if (fuse_last) hb_emit(G, B, F.Zt_avg1, BC_NONE, i, j, v);   // final averages: exchange :821-883
             else F.Zt_avg1[x0] = v;
           }
@@ -258,10 +286,10 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     if (iif == 1) { mode = 0; cff1 = dtfast; cff4 = 0.0; cff5 = 0.0; }
     else if (PRED) { mode = 1; cff1 = 2.0 * dtfast; cff4 = 4.0 / 25.0; cff5 = 1.0 - 2.0 * cff4; }
     else { mode = 2; cff1 = dtfast * 5.0 / 12.0; cff2 = dtfast * 8.0 / 12.0; cff3 = dtfast * 1.0 / 12.0; cff4 = 2.0 / 5.0; cff5 = 1.0 - cff4; }
-    TLOOP(i, j) {
+    RLOOP(i, j) {
       if (INR(i, j, IstrU - 1, Iend, JstrV - 1, Jend)) {
         const double rhs_zeta = (DUon[s0] - DUon[(s0 + 1)]) + (DVom[s0] - DVom[(s0 + TW)]);
-        const double zsv = PW(r_zs, zs[x0]), zkv = PW(r_zk, zk[x0]);
+        const double zsv = PW(r_zs, F.zeta[x0 + o_kstp]), zkv = PW(r_zk, F.zeta[x0 + o_krhs]);
         double zeta_new, zw;
         if (mode == 0) {
           zeta_new = zsv + sPm[s0] * sPn[s0] * cff1 * rhs_zeta;
@@ -271,7 +299,7 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
           zw = cff5 * zkv + cff4 * (zsv + zeta_new);
         } else {
           const double cff = cff1 * rhs_zeta;
-          zeta_new = zsv + sPm[s0] * sPn[s0] * (cff + cff2 * PW(r_rz_s, rz_s[x0]) - cff3 * PW(r_rz_p, rz_p[x0]));
+          zeta_new = zsv + sPm[s0] * sPn[s0] * (cff + cff2 * PW(r_rz_s, F.rzeta[x0 + o_kstp]) - cff3 * PW(r_rz_p, F.rzeta[x0 + o_ptsk]));
           zw = cff5 * zeta_new + cff4 * zkv;
         }
         const double rhoSv = PW(r_rhoS, F.rhoS[x0]);
@@ -313,15 +341,17 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
     const double c1 = (iif == 1) ? 0.5 * dtfast : dtfast;
     const double k1 = 0.5 * dtfast * 5.0 / 12.0, k2 = 0.5 * dtfast * 8.0 / 12.0, k3 = 0.5 * dtfast * 1.0 / 12.0;
     const double pg1 = 0.5 * g, pg2 = 1.0 / 3.0;
-    WLOOP(w) {
-      const int isv = w >= NOWN, c = isv ? w - NOWN : w;
-      const int j = Jstr + c / OW, i = Istr + c - (c / OW) * OW;
-      if (!(isv ? (j >= JstrV) : (i >= IstrU))) continue;
+#pragma unroll
+    for (int isv = 0; isv < 2; isv++) {
+    WLOOP(isv) {
+      const int jj = c / OW, j = Jstr + jj, i = Istr + c - jj * OW;
+      if (i > Iend || j > Jend || !(isv ? (j >= JstrV) : (i >= IstrU))) continue;
       const int s = (i - IT0) + (j - JT0) * TW;
-      const long x = (long)X2(i, j);
+      const int x = (i - G.LBi) + (j - G.LBj) * ni;
+      const int x1 = isv ? x - ni : x - 1, q1 = isv ? x + 1 : x + ni;
       const int d1 = isv ? TW : 1;                   // tile offset from P1 to P0 (across the momentum point)
       // -- pressure gradient (VAR_RHO_2D) :1080-1200
-      double rhs = pg1 * PW(w_onom, isv ? F.om_v[x] : F.on_u[x]) *
+      double rhs = pg1 * WV(w_onom, isv, isv ? mp[x].v[MP_OMV] : mp[x].v[MP_ONU]) *
                    ((sH[s - d1] + sH[s]) * (gzeta[s - d1] - gzeta[s]) +
                     (sH[s - d1] - sH[s]) * (gzetaSA[s - d1] + gzetaSA[s] +
                                            pg2 * (sRhoA[s - d1] - sRhoA[s]) * (zwrk[s - d1] - zwrk[s])) +
@@ -383,8 +413,8 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
       const int a1 = isv ? 0 : -1, b1 = isv ? -1 : 0;
       if (COR) {
         // Coriolis :1429-1490: UFx = cff*(vbar(j)+vbar(j+1)), VFe = cff*(ubar(i)+ubar(i+1)) at rho points
-        const double cf0 = 0.5 * TD(0, 0) * PW(w_fomn0, F.fomn[x]);
-        const double cf1 = 0.5 * TD(a1, b1) * PW(w_fomn1, F.fomn[isv ? x - ni : x - 1]);
+        const double cf0 = 0.5 * TD(0, 0) * WV(w_fomn0, isv, mr[x].v[MR_FOMN]);
+        const double cf1 = 0.5 * TD(a1, b1) * WV(w_fomn1, isv, mr[x1].v[MR_FOMN]);
         if (!isv) {
           const double fac1 = 0.5 * (cf0 * (TV(0, 0) + TV(0, 1)) + cf1 * (TV(-1, 0) + TV(-1, 1)));
           rhs = rhs + fac1;
@@ -398,14 +428,13 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
         double t0, t1;
         {
           const double cff1 = 0.5 * (TV(0, 0) + TV(0, 1)), cff2 = 0.5 * (TU(0, 0) + TU(1, 0));
-          const double cff3 = cff1 * PW(w_dndx0, F.dndx[x]), cff4 = cff2 * PW(w_dmde0, F.dmde[x]);
+          const double cff3 = cff1 * WV(w_dndx0, isv, mr[x].v[MR_DNDX]), cff4 = cff2 * WV(w_dmde0, isv, mr[x].v[MR_DMDE]);
           const double cff = TD(0, 0) * (cff3 - cff4);
           t0 = isv ? cff * cff2 : cff * cff1;
         }
         {
-          const long x1 = isv ? x - ni : x - 1;
           const double cff1 = 0.5 * (TV(a1, b1) + TV(a1, b1 + 1)), cff2 = 0.5 * (TU(a1, b1) + TU(a1 + 1, b1));
-          const double cff3 = cff1 * PW(w_dndx1, F.dndx[x1]), cff4 = cff2 * PW(w_dmde1, F.dmde[x1]);
+          const double cff3 = cff1 * WV(w_dndx1, isv, mr[x1].v[MR_DNDX]), cff4 = cff2 * WV(w_dmde1, isv, mr[x1].v[MR_DMDE]);
           const double cff = TD(a1, b1) * (cff3 - cff4);
           t1 = isv ? cff * cff2 : cff * cff1;
         }
@@ -424,26 +453,30 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
   ((v2_) * DRHS_P(a_, b_) * 0.5 *                                                                                  \
    ((pmon_) * ((TPN(a_, (b_) - 1) + TPN(a_, b_)) * TV(a_, b_) - (TPN((a_) - 1, (b_) - 1) + TPN((a_) - 1, b_)) * TV((a_) - 1, b_)) + \
     (pnom_) * ((TPM((a_) - 1, b_) + TPM(a_, b_)) * TU(a_, b_) - (TPM((a_) - 1, (b_) - 1) + TPM(a_, (b_) - 1)) * TU(a_, (b_) - 1))))
-        const long x1 = isv ? x - ni : x - 1, q1 = isv ? x + 1 : x + ni;
         const int qa = isv ? 1 : 0, qb = isv ? 0 : 1;
-        const double sr0 = STRESS_R(0, 0, PW(w_v2r0, F.visc2_r[x]), PW(w_pmr0, F.pmon_r[x]), PW(w_pnr0, F.pnom_r[x]));
-        const double sr1 = STRESS_R(a1, b1, PW(w_v2r1, F.visc2_r[x1]), PW(w_pmr1, F.pmon_r[x1]), PW(w_pnr1, F.pnom_r[x1]));
-        const double sp0 = STRESS_P(0, 0, PW(w_v2p0, F.visc2_p[x]), PW(w_pmp0, F.pmon_p[x]), PW(w_pnp0, F.pnom_p[x]));
-        const double sp1 = STRESS_P(qa, qb, PW(w_v2p1, F.visc2_p[q1]), PW(w_pmp1, F.pmon_p[q1]), PW(w_pnp1, F.pnom_p[q1]));
+        const double sr0 = STRESS_R(0, 0, WV(w_v2r0, isv, mr[x].v[MR_V2]), WV(w_pmr0, isv, mr[x].v[MR_PMON]), WV(w_pnr0, isv, mr[x].v[MR_PNOM]));
+        const double sr1 = STRESS_R(a1, b1, WV(w_v2r1, isv, mr[x1].v[MR_V2]), WV(w_pmr1, isv, mr[x1].v[MR_PMON]), WV(w_pnr1, isv, mr[x1].v[MR_PNOM]));
+        const double sp0 = STRESS_P(0, 0, WV(w_v2p0, isv, mp[x].v[MP_V2]), WV(w_pmp0, isv, mp[x].v[MP_PMON]), WV(w_pnp0, isv, mp[x].v[MP_PNOM]));
+        const double sp1 = STRESS_P(qa, qb, WV(w_v2p1, isv, mp[q1].v[MP_V2]), WV(w_pmp1, isv, mp[q1].v[MP_PMON]), WV(w_pnp1, isv, mp[q1].v[MP_PNOM]));
+        // on_r (u) | om_r (v) at P0, P1; om_p (u) | on_p (v) at Q0, Q1
+        const double or0 = WV(w_or0, isv, isv ? mr[x].v[MR_OM] : mr[x].v[MR_ON]);
+        const double or1 = WV(w_or1, isv, isv ? mr[x1].v[MR_OM] : mr[x1].v[MR_ON]);
+        const double op0 = WV(w_op0, isv, isv ? mp[x].v[MP_ON] : mp[x].v[MP_OM]);
+        const double op1 = WV(w_op1, isv, isv ? mp[q1].v[MP_ON] : mp[q1].v[MP_OM]);
         if (!isv) {
-          const double UFx0 = PW(w_onr0, F.on_r[x]) * PW(w_onr0, F.on_r[x]) * sr0;
-          const double UFxm = PW(w_onr1, F.on_r[x1]) * PW(w_onr1, F.on_r[x1]) * sr1;
-          const double UFe0 = PW(w_omp0, F.om_p[x]) * PW(w_omp0, F.om_p[x]) * sp0;
-          const double UFep = PW(w_omp1, F.om_p[q1]) * PW(w_omp1, F.om_p[q1]) * sp1;
+          const double UFx0 = or0 * or0 * sr0;
+          const double UFxm = or1 * or1 * sr1;
+          const double UFe0 = op0 * op0 * sp0;
+          const double UFep = op1 * op1 * sp1;
           const double cff1 = 0.5 * (TPN(-1, 0) + TPN(0, 0)) * (UFx0 - UFxm);
           const double cff2 = 0.5 * (TPM(-1, 0) + TPM(0, 0)) * (UFep - UFe0);
           const double fac = cff1 + cff2;
           rhs = rhs + fac;
         } else {
-          const double VFx0 = PW(w_onp0, F.on_p[x]) * PW(w_onp0, F.on_p[x]) * sp0;
-          const double VFxp = PW(w_onp1, F.on_p[q1]) * PW(w_onp1, F.on_p[q1]) * sp1;
-          const double VFe0 = PW(w_omr0, F.om_r[x]) * PW(w_omr0, F.om_r[x]) * sr0;
-          const double VFem = PW(w_omr1, F.om_r[x1]) * PW(w_omr1, F.om_r[x1]) * sr1;
+          const double VFx0 = op0 * op0 * sp0;
+          const double VFxp = op1 * op1 * sp1;
+          const double VFe0 = or0 * or0 * sr0;
+          const double VFem = or1 * or1 * sr1;
           const double cff1 = 0.5 * (TPN(0, -1) + TPN(0, 0)) * (VFxp - VFx0);
           const double cff2 = 0.5 * (TPM(0, -1) + TPM(0, 0)) * (VFe0 - VFem);
           const double fac = cff1 - cff2;
@@ -455,27 +488,28 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
       }
       // -- coupling with the 3-D forcing :2225-2460, then the momentum step :2488-2670
       double *frc = isv ? F.rvfrc : F.rufrc;
-      double *r0s = isv ? rv0_stp : ru0_stp;
+      double *r3 = isv ? F.rv : F.ru;
+      const double *rb = isv ? F.rvbar : F.rubar;
       double r = rhs;
       if (first) {
-        const double fr = PW(w_frc, frc[x]) - r;
+        const double fr = WV(w_frc, isv, frc[x]) - r;
         frc[x] = fr;
         if (startup == 0) r = r + fr;
-        else if (startup == 1) r = r + 1.5 * fr - 0.5 * PW(w_r0n, (isv ? rv0_new : ru0_new)[x]);
-        else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * PW(w_r0n, (isv ? rv0_new : ru0_new)[x]) +
-                 (5.0 / 12.0) * PW(w_r0s, r0s[x]);
-        r0s[x] = fr;
+        else if (startup == 1) r = r + 1.5 * fr - 0.5 * WV(w_r0n, isv, r3[o_r0n + (size_t)x]);
+        else r = r + (23.0 / 12.0) * fr - (16.0 / 12.0) * WV(w_r0n, isv, r3[o_r0n + (size_t)x]) +
+                 (5.0 / 12.0) * WV(w_r0s, isv, r3[o_r0s + (size_t)x]);
+        r3[o_r0s + (size_t)x] = fr;
       } else {
-        r = r + PW(w_frc, frc[x]);
+        r = r + WV(w_frc, isv, frc[x]);
       }
       const double cff = (sPm[s] + sPm[s - d1]) * (sPn[s] + sPn[s - d1]);
       const double fac = 1.0 / (Dnew[s] + Dnew[s - d1]);
       const double Dstp0 = sDstp[s], Dstp1 = sDstp[s - d1];
-      const double sv = PW(w_s, (isv ? vs : us)[x]);
+      const double sv = WV(w_s, isv, (isv ? F.vbar : F.ubar)[x + o_kstp]);
       double b;
       if (!corr) b = (sv * (Dstp0 + Dstp1) + cff * c1 * r) * fac;
       else b = (sv * (Dstp0 + Dstp1) +
-                cff * (k1 * r + k2 * PW(w_rs, (isv ? rvb_s : rub_s)[x]) - k3 * PW(w_rp, (isv ? rvb_p : rub_p)[x]))) * fac;
+                cff * (k1 * r + k2 * WV(w_rs, isv, rb[x + o_kstp]) - k3 * WV(w_rp, isv, rb[x + o_ptsk]))) * fac;
       // u2dbc/v2dbc :2871-2876 + exchange :3043
       if (!isv) {
         if (fuse) hb_emit(G, B, un, BC_U, i, j, b);
@@ -487,6 +521,7 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
         if (PRED) rvb_k[x] = r;
       }
     }
+    }
   }
 #undef TU
 #undef TV
@@ -496,10 +531,21 @@ COOP_KERNEL(k_step2d, Step2dArgs) {
 #undef TPM
 #undef TPN
 }
-COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)
-#undef TLOOP
-#undef WLOOP
+#undef RLOOP
 #undef PWDECL
 #undef PWLOAD
 #undef PW
+#undef WLOOP
+#undef WDECL
+#undef WLOAD
+#undef WV
 #undef INR
+
+// entry points: sub-tiles up to 32x4 (one rectangle point per thread, u- and v-points on different
+// waves), up to 64x8 (two rectangle points per thread), and the generic form
+COOP_KERNEL(k_step2d_a, Step2dArgs) { k_step2d_t_body<32, 4, 384, 1>(a, bx, by, bz, lds); }
+COOP_GLOBAL_LB(k_step2d_a, Step2dArgs, 384)
+COOP_KERNEL(k_step2d_b, Step2dArgs) { k_step2d_t_body<64, 8, 512, 2>(a, bx, by, bz, lds); }
+COOP_GLOBAL_LB(k_step2d_b, Step2dArgs, 512)
+COOP_KERNEL(k_step2d, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0>(a, bx, by, bz, lds); }
+COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)

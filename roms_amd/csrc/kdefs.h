@@ -42,6 +42,9 @@ struct kdim3 { int x, y, z; };
         for (int bx_ = 0; bx_ < (gx); bx_++) name##_body(args, bx_, by_, bz_, lds_.data()); \
   } while (0)
 
+#define LAUNCH_COOP_AS(label, name, gx, gy, gz, nthreads, lds_doubles, stream, args) \
+  LAUNCH_COOP(name, gx, gy, gz, nthreads, lds_doubles, stream, args)
+
 #define THREAD_KERNEL(name, ArgT) static inline void name##_body(const ArgT &a, int gx, int gy, int gz)
 #define THREAD_GLOBAL(name, ArgT)
 #define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
@@ -83,6 +86,12 @@ void kprof_end(int slot, hipStream_t stream);
   } while (0)
 #define LAUNCH_COOP(name, gx, gy, gz, nthreads, lds_doubles, stream, args)               \
   KPROF_WRAP(name, stream,                                                               \
+  hipLaunchKernelGGL(name, dim3((unsigned)(gx), (unsigned)(gy), (unsigned)(gz)), dim3((unsigned)(nthreads)), \
+                     (size_t)(lds_doubles) * sizeof(double), stream, args))
+
+// variant `name` of a kernel reported to the profiler hooks as `label`
+#define LAUNCH_COOP_AS(label, name, gx, gy, gz, nthreads, lds_doubles, stream, args)     \
+  KPROF_WRAP(label, stream,                                                              \
   hipLaunchKernelGGL(name, dim3((unsigned)(gx), (unsigned)(gy), (unsigned)(gz)), dim3((unsigned)(nthreads)), \
                      (size_t)(lds_doubles) * sizeof(double), stream, args))
 

@@ -178,4 +178,6 @@ struct Fields {
   // MPDATA work arrays (allocated only when a tracer uses MPDATA): Ta (N planes per tracer), Ua, Va, Wa,
   // beta_up, beta_dn
   GPtr mp3[6];
+  // packed metrics of the barotropic momentum stage, 8 doubles per grid point (k_step2d.h: M2Rec)
+  GPtr m2r, m2p;
 };

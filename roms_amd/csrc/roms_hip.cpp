@@ -199,6 +199,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   memset(c->regions, 0, sizeof(c->regions));
   memset(&c->comm, 0, sizeof(c->comm));
   c->comm_failed = false;
+  c->m2d_dirty = true;
   {  // neighbours in the reference's tile numbering; a periodic direction wraps around
     const int NI = cfg->NtileI, NJ = cfg->NtileJ, it = cfg->tile % NI, jt = cfg->tile / NI;
     int *nb = c->comm.nbr;
@@ -243,6 +244,12 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     if (dmalloc(&p, (size_t)G.nij * sizeof(double))) { roms_hip_destroy(c); return 2; }
     c->allocs.push_back(p);
     c->F.wrk2[k] = (double *)p;
+  }
+  for (int k = 0; k < 2; k++) {   // packed barotropic metrics, 8 doubles per point
+    void *p = nullptr;
+    if (dmalloc(&p, 8 * (size_t)G.nij * sizeof(double))) { roms_hip_destroy(c); return 2; }
+    c->allocs.push_back(p);
+    (k == 0 ? c->F.m2r : c->F.m2p) = (double *)p;
   }
   {  // MPDATA work arrays
     bool any_mp = false;
@@ -341,6 +348,7 @@ extern "C" int roms_hip_upload(roms_hip_ctx *c, const char *name, const double *
   const FieldDesc *f = find_field(name);
   if (!f) { set_error(std::string("unknown field ") + name); return 8; }
   if (n != field_elems(c, f->kind)) { set_error(std::string("size mismatch for field ") + name); return 8; }
+  if (f->kind == FK_2D) c->m2d_dirty = true;
   return h2d(*(double **)((char *)&c->F + f->offset), host, (size_t)n * sizeof(double), c->stream);
 }
 extern "C" int roms_hip_download(roms_hip_ctx *c, const char *name, double *host, long n) {
