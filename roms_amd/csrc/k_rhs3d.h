@@ -305,100 +305,119 @@ THREAD_GLOBAL(k_pre_t3, KArgs)
 
 // pre_step3d: start of t(nnew), u(nnew), v(nnew) -- point-wise in 3-D (all vertical fluxes local);
 // index space (min(Istr,IstrU):Iend, Jstr:Jend, 1:N); F.wrk3[5] = swdk when SOLAR_SOURCE
+// One thread advances KCH consecutive levels of its column (grid.z = chunk): the vertical fluxes at
+// the KCH+1 interfaces of the chunk are computed once (the level form needs each flux twice), z_r,
+// the tracers and the velocities are loaded once per level, and all index arithmetic that does not
+// depend on the level is done once per chunk.
+#define KCH 5
 THREAD_KERNEL(k_pre_new, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
   const TB &B = G.T;
-  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, N = G.N;
+  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N;
+  const int k0 = gz * KCH + 1;                     // levels k0 .. k0+KCH-1, interfaces k0-1 .. k0+KCH-1
+  if (k0 > N) return;
   const int nstp = G.nstp, nnew = G.nnew, nrhs = G.nrhs, indx = 3 - G.nrhs;
   const double dt = G.dt;
   const double cff3 = dt * (1.0 - G.lambda);
+  const size_t x = X2(i, j), nij = (size_t)G.nij;
+  // clamped level (1..N) and interface (0..N) offsets of the chunk
+  size_t oL[KCH + 2], oW[KCH + 1];                 // level k0-1+q ; interface k0-1+q
+#pragma unroll
+  for (int q = 0; q < KCH + 2; q++) oL[q] = (size_t)(KMIN(KMAX(k0 - 1 + q, 1), N) - 1) * nij;
+#pragma unroll
+  for (int q = 0; q < KCH + 1; q++) oW[q] = (size_t)KMIN(k0 - 1 + q, N) * nij;
+  const double *zr = F.z_r + x;
+  double z[KCH + 2];
+#pragma unroll
+  for (int q = 0; q < KCH + 2; q++) z[q] = zr[oL[q]];
   // ---- tracers :855-935
-  for (int itrc = 1; itrc <= G.NT; itrc++) {
-    const int ltrc = KMIN(G.NAT, itrc);
-    double FCk, FCm;
-#define TFLUX(FCo, kk)                                                                                         \
-  do {                                                                                                         \
-    if ((kk) == 0) FCo = dt * F.btflx[X2T(i, j, itrc)];                                                        \
-    else if ((kk) == N) FCo = dt * F.stflx[X2T(i, j, itrc)];                                                   \
-    else {                                                                                                     \
-      const double c_ = 1.0 / (F.z_r[X3(i, j, (kk) + 1)] - F.z_r[X3(i, j, kk)]);                               \
-      FCo = cff3 * c_ * F.Akt[XW4(i, j, kk, ltrc)] * (F.t[XT(i, j, (kk) + 1, nstp, itrc)] - F.t[XT(i, j, kk, nstp, itrc)]); \
-      if ((G.options & ROMS_LMD_MIXING) && itrc <= G.NAT)                                                      \
-        FCo = FCo - dt * F.Akt[XW4(i, j, kk, itrc)] * F.ghats[XW4(i, j, kk, itrc)];                            \
-      if ((G.options & ROMS_SOLAR_SOURCE) && itrc == 1) FCo = FCo + dt * F.srflx[X2(i, j)] * F.wrk3[5][XW(i, j, kk)]; \
-    }                                                                                                          \
-  } while (0)
-    TFLUX(FCk, k);
-    TFLUX(FCm, k - 1);
-#undef TFLUX
-    const double cff1 = F.Hz[X3(i, j, k)] * F.t[XT(i, j, k, nstp, itrc)];
-    const double cff2 = FCk - FCm;
-    F.t[XT(i, j, k, nnew, itrc)] = cff1 + cff2;
-  }
-  // ---- u :943-1040
-  if (i >= B.IstrU) {
-    double FCk, FCm;
-#define UFLUX(FCo, kk)                                                                                         \
-  do {                                                                                                         \
-    if ((kk) == 0) FCo = dt * F.bustr[X2(i, j)];                                                               \
-    else if ((kk) == N) FCo = dt * F.sustr[X2(i, j)];                                                          \
-    else {                                                                                                     \
-      const double c_ = 1.0 / (F.z_r[X3(i, j, (kk) + 1)] + F.z_r[X3(i - 1, j, (kk) + 1)] - F.z_r[X3(i, j, kk)] - \
-                               F.z_r[X3(i - 1, j, kk)]);                                                       \
-      FCo = cff3 * c_ * (F.u[X4(i, j, (kk) + 1, nstp)] - F.u[X4(i, j, kk, nstp)]) *                            \
-            (F.Akv[XW(i, j, kk)] + F.Akv[XW(i - 1, j, kk)]);                                                   \
-    }                                                                                                          \
-  } while (0)
-    UFLUX(FCk, k);
-    UFLUX(FCm, k - 1);
-#undef UFLUX
-    const double cff = dt * 0.25;
-    const double DC0 = cff * (F.pm[X2(i, j)] + F.pm[X2(i - 1, j)]) * (F.pn[X2(i, j)] + F.pn[X2(i - 1, j)]);
-    const double hu = F.u[X4(i, j, k, nstp)] * 0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i - 1, j, k)]);
-    const double dF = FCk - FCm;
-    double un;
-    if (G.iic == G.ntfirst) un = hu + dF;
-    else if (G.iic == G.ntfirst + 1) {
-      const double c3 = 0.5 * DC0;
-      un = hu - c3 * F.ru[XW4(i, j, k, indx)] + dF;
-    } else {
-      const double c1 = 5.0 / 12.0, c2 = 16.0 / 12.0;
-      un = hu + DC0 * (c1 * F.ru[XW4(i, j, k, nrhs)] - c2 * F.ru[XW4(i, j, k, indx)]) + dF;
+  {
+    double odz[KCH + 1], hz[KCH];
+#pragma unroll
+    for (int q = 0; q < KCH + 1; q++) odz[q] = 1.0 / (z[q + 1] - z[q]);
+#pragma unroll
+    for (int q = 0; q < KCH; q++) hz[q] = F.Hz[x + oL[q + 1]];
+    for (int itrc = 1; itrc <= G.NT; itrc++) {
+      const int ltrc = KMIN(G.NAT, itrc);
+      const double *ts = F.t + x + ((size_t)(nstp - 1) + 3 * (size_t)(itrc - 1)) * nij * (size_t)N;
+      double *tn = F.t + x + ((size_t)(nnew - 1) + 3 * (size_t)(itrc - 1)) * nij * (size_t)N;
+      const double *Akt = F.Akt + x + (size_t)(ltrc - 1) * nij * (size_t)(N + 1);
+      const bool lmd = (G.options & ROMS_LMD_MIXING) && itrc <= G.NAT;
+      const bool sol = (G.options & ROMS_SOLAR_SOURCE) && itrc == 1;
+      double tt[KCH + 2], ak[KCH + 1], FC[KCH + 1];
+#pragma unroll
+      for (int q = 0; q < KCH + 2; q++) tt[q] = ts[oL[q]];
+#pragma unroll
+      for (int q = 0; q < KCH + 1; q++) ak[q] = Akt[oW[q]];
+#pragma unroll
+      for (int q = 0; q < KCH + 1; q++) {
+        const int kk = k0 - 1 + q;
+        if (kk == 0) FC[q] = dt * F.btflx[X2T(i, j, itrc)];
+        else if (kk >= N) FC[q] = dt * F.stflx[X2T(i, j, itrc)];
+        else {
+          double f = cff3 * odz[q] * ak[q] * (tt[q + 1] - tt[q]);
+          if (lmd) f = f - dt * F.Akt[XW4(i, j, kk, itrc)] * F.ghats[XW4(i, j, kk, itrc)];
+          if (sol) f = f + dt * F.srflx[x] * F.wrk3[5][x + oW[q]];
+          FC[q] = f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < KCH; q++) {
+        if (k0 + q <= N) {
+          const double cff1 = hz[q] * tt[q + 1];
+          const double cff2 = FC[q + 1] - FC[q];
+          tn[oL[q + 1]] = cff1 + cff2;
+        }
+      }
     }
-    F.u[X4(i, j, k, nnew)] = un;
   }
-  // ---- v :1045-1145
-  if (j >= B.JstrV) {
-    double FCk, FCm;
-#define VFLUXM(FCo, kk)                                                                                        \
-  do {                                                                                                         \
-    if ((kk) == 0) FCo = dt * F.bvstr[X2(i, j)];                                                               \
-    else if ((kk) == N) FCo = dt * F.svstr[X2(i, j)];                                                          \
-    else {                                                                                                     \
-      const double c_ = 1.0 / (F.z_r[X3(i, j, (kk) + 1)] + F.z_r[X3(i, j - 1, (kk) + 1)] - F.z_r[X3(i, j, kk)] - \
-                               F.z_r[X3(i, j - 1, kk)]);                                                       \
-      FCo = cff3 * c_ * (F.v[X4(i, j, (kk) + 1, nstp)] - F.v[X4(i, j, kk, nstp)]) *                            \
-            (F.Akv[XW(i, j, kk)] + F.Akv[XW(i, j - 1, kk)]);                                                   \
-    }                                                                                                          \
-  } while (0)
-    VFLUXM(FCk, k);
-    VFLUXM(FCm, k - 1);
-#undef VFLUXM
-    const double cff = dt * 0.25;
-    const double DC0 = cff * (F.pm[X2(i, j)] + F.pm[X2(i, j - 1)]) * (F.pn[X2(i, j)] + F.pn[X2(i, j - 1)]);
-    const double hv = F.v[X4(i, j, k, nstp)] * 0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i, j - 1, k)]);
-    const double dF = FCk - FCm;
-    double vn;
-    if (G.iic == G.ntfirst) vn = hv + dF;
-    else if (G.iic == G.ntfirst + 1) {
-      const double c3 = 0.5 * DC0;
-      vn = hv - c3 * F.rv[XW4(i, j, k, indx)] + dF;
-    } else {
-      const double c1 = 5.0 / 12.0, c2 = 16.0 / 12.0;
-      vn = hv + DC0 * (c1 * F.rv[XW4(i, j, k, nrhs)] - c2 * F.rv[XW4(i, j, k, indx)]) + dF;
+  // ---- u :943-1040 (di = 1), v :1045-1145 (dj = 1)
+#pragma unroll
+  for (int dir = 0; dir < 2; dir++) {
+    if (dir == 0 ? (i < B.IstrU) : (j < B.JstrV)) continue;
+    const size_t xm = dir == 0 ? x - 1 : x - (size_t)G.ni;      // (i-1,j) | (i,j-1)
+    const double *qs = (dir == 0 ? F.u : F.v) + x + (size_t)(nstp - 1) * nij * (size_t)N;
+    double *qn = (dir == 0 ? F.u : F.v) + x + (size_t)(nnew - 1) * nij * (size_t)N;
+    const double *r3 = dir == 0 ? F.ru : F.rv;
+    double zm[KCH + 2], qq[KCH + 2], av[KCH + 1], FC[KCH + 1], hz2[KCH];
+#pragma unroll
+    for (int q = 0; q < KCH + 2; q++) { zm[q] = F.z_r[xm + oL[q]]; qq[q] = qs[oL[q]]; }
+#pragma unroll
+    for (int q = 0; q < KCH + 1; q++) av[q] = F.Akv[x + oW[q]] + F.Akv[xm + oW[q]];
+#pragma unroll
+    for (int q = 0; q < KCH; q++) hz2[q] = F.Hz[x + oL[q + 1]] + F.Hz[xm + oL[q + 1]];
+#pragma unroll
+    for (int q = 0; q < KCH + 1; q++) {
+      const int kk = k0 - 1 + q;
+      if (kk == 0) FC[q] = dt * (dir == 0 ? F.bustr : F.bvstr)[x];
+      else if (kk >= N) FC[q] = dt * (dir == 0 ? F.sustr : F.svstr)[x];
+      else {
+        const double c_ = 1.0 / (z[q + 1] + zm[q + 1] - z[q] - zm[q]);
+        FC[q] = cff3 * c_ * (qq[q + 1] - qq[q]) * av[q];
+      }
     }
-    F.v[X4(i, j, k, nnew)] = vn;
+    const double cff = dt * 0.25;
+    const double DC0 = cff * (F.pm[x] + F.pm[xm]) * (F.pn[x] + F.pn[xm]);
+    const size_t o_nrhs = (size_t)(nrhs - 1) * nij * (size_t)(N + 1), o_indx = (size_t)(indx - 1) * nij * (size_t)(N + 1);
+#pragma unroll
+    for (int q = 0; q < KCH; q++) {
+      const int k = k0 + q;
+      if (k <= N) {
+        const double hu = qq[q + 1] * 0.5 * hz2[q];
+        const double dF = FC[q + 1] - FC[q];
+        double un;
+        if (G.iic == G.ntfirst) un = hu + dF;
+        else if (G.iic == G.ntfirst + 1) {
+          const double c3 = 0.5 * DC0;
+          un = hu - c3 * r3[x + oW[q + 1] + o_indx] + dF;
+        } else {
+          const double c1 = 5.0 / 12.0, c2 = 16.0 / 12.0;
+          un = hu + DC0 * (c1 * r3[x + oW[q + 1] + o_nrhs] - c2 * r3[x + oW[q + 1] + o_indx]) + dF;
+        }
+        qn[oL[q + 1]] = un;
+      }
+    }
   }
 }
 THREAD_GLOBAL(k_pre_new, KArgs)

@@ -100,6 +100,11 @@ THREAD_GLOBAL(k_pack_m2d, PackArgs)
 #define WLOAD(name, isv, expr) do { if (FIXED) name[VOFF ? 0 : (isv)] = (expr); } while (0)
 #define WV(name, isv, expr) (FIXED ? name[VOFF ? 0 : (isv)] : (expr))
 
+#ifndef ROMS_CPU_EMU
+#define S2D_TICK(n) do { if (a.G.dbg_stop == 99 && KTID == 0) F.xr[(bx + G.nbx2 * by) * 8 + (n)] = (double)wall_clock64(); } while (0)
+#else
+#define S2D_TICK(n) ((void)0)
+#endif
 template <int BWC, int BHC, int NTC, int PTS>
 COOP_KERNEL(k_step2d_t, Step2dArgs) {
   (void)bz;
@@ -154,6 +159,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
   WDECL(w_op0); WDECL(w_op1);     // om_p (u-points) | on_p (v-points) at Q0, Q1
   WDECL(w_s); WDECL(w_frc); WDECL(w_rs); WDECL(w_rp); WDECL(w_r0n); WDECL(w_r0s);
 
+  S2D_TICK(0);
   // ---- stage 1: every global read of the kernel ----------------------------------------------
   RLOOP(i, j) {
     if (INR(i, j, G.LBi, UBi, G.LBj, UBj)) {
@@ -215,7 +221,9 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
       }
     }
   }
+  S2D_TICK(1);
   KSYNC();
+  S2D_TICK(2);
 
   // ---- stage 2: mass fluxes :600-700 and fast-time averaging :739-880 -------------------------
   {
@@ -277,6 +285,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
   }
   if (last) return;            // auxiliary last predictor call :883 (uniform over the grid)
   KSYNC();
+  S2D_TICK(3);
 
   // ---- stage 3: free-surface step :886-1000 ---------------------------------------------------
   {
@@ -323,6 +332,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
     }
   }
   KSYNC();
+  S2D_TICK(4);
 
   // ---- stage 4: right-hand sides and the momentum step, one work item per momentum point ------
   // Tile accessors relative to s = S2(i,j); the flux helpers below are the reference's expressions
@@ -523,6 +533,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
     }
     }
   }
+  S2D_TICK(5);
 #undef TU
 #undef TV
 #undef TDU
