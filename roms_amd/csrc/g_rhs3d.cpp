@@ -66,8 +66,8 @@ int run_rhs3d_tile(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   KArgs a = mk(c);
-  LAUNCH_COOP(k_rhs3d_h, G.nbx, G.nby, G.N, 256, RHS3D_NLDS * lds_sz(G), c->stream, a);
-  LAUNCH_THREAD(k_rhs3d_v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N, c->stream, a);
+  a.p0 = (G.N + KCH - 1) / KCH;
+  LAUNCH_THREAD(k_rhs3d_pt, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2 * a.p0, c->stream, a);
   LAUNCH_THREAD(k_rhs3d_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   return 0;
 }

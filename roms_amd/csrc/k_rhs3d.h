@@ -656,183 +656,234 @@ THREAD_KERNEL(k_uv3dmix2_sum, KArgs) {
 THREAD_GLOBAL(k_uv3dmix2_sum, KArgs)
 
 // -------------------------------------------------------------------------------- rhs3d_tile
-// K_LOOP: Coriolis, curvilinear terms, third-order upstream horizontal advection of momentum.
-// One block = (sub-tile, k); 8 LDS arrays (the reference's 14 after aliasing).
-#define RHS3D_NLDS 8
-COOP_KERNEL(k_rhs3d_h, KArgs) {
-  const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
-  const TB B = block_bounds(G, bx, by);
-  const int k = bz + 1, nrhs = G.nrhs, N = G.N;
-  const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
-  double *UFx = lds, *UFe = lds + sz, *VFx = lds + 2 * sz, *VFe = lds + 3 * sz;
-  double *w0 = lds + 4 * sz, *w1 = lds + 5 * sz, *w2 = lds + 6 * sz, *w3 = lds + 7 * sz;
-  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend, IstrU = B.IstrU, JstrV = B.JstrV;
-  const double Gadv = -0.25;
-  const double *u = F.u + (size_t)(nrhs - 1) * G.nij * N + (size_t)(k - 1) * G.nij;   // plane
-  const double *v = F.v + (size_t)(nrhs - 1) * G.nij * N + (size_t)(k - 1) * G.nij;
-  const double *Hu = F.Huon + (size_t)(k - 1) * G.nij, *Hv = F.Hvom + (size_t)(k - 1) * G.nij;
-  const double *Hzk = F.Hz + (size_t)(k - 1) * G.nij;
-  double *ru = F.ru + (size_t)(nrhs - 1) * G.nij * (N + 1) + (size_t)k * G.nij;
-  double *rv = F.rv + (size_t)(nrhs - 1) * G.nij * (N + 1) + (size_t)k * G.nij;
-  // the r.h.s. increments are accumulated in registers per owned point in the reference's order
-  if (G.options & ROMS_UV_COR) {
-    KLOOP2(i, j, IstrU - 1, Iend, JstrV - 1, Jend) {
-      const double cff = 0.5 * Hzk[X2(i, j)] * F.fomn[X2(i, j)];
-      UFx[S2(i, j)] = cff * (v[X2(i, j)] + v[X2(i, j + 1)]);
-      VFe[S2(i, j)] = cff * (u[X2(i, j)] + u[X2(i + 1, j)]);
-    }
-    KSYNC();
-    KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
-      if (i >= IstrU) { const double cff1 = 0.5 * (UFx[S2(i, j)] + UFx[S2(i - 1, j)]); ru[X2(i, j)] = ru[X2(i, j)] + cff1; }
-      if (j >= JstrV) { const double cff1 = 0.5 * (VFe[S2(i, j)] + VFe[S2(i, j - 1)]); rv[X2(i, j)] = rv[X2(i, j)] - cff1; }
-    }
-    KSYNC();
-  }
-  if ((G.options & ROMS_CURVGRID) && (G.options & ROMS_UV_ADV)) {
-    KLOOP2(i, j, IstrU - 1, Iend, JstrV - 1, Jend) {
-      const double cff1 = 0.5 * (v[X2(i, j)] + v[X2(i, j + 1)]);
-      const double cff2 = 0.5 * (u[X2(i, j)] + u[X2(i + 1, j)]);
-      const double cff3 = cff1 * F.dndx[X2(i, j)];
-      const double cff4 = cff2 * F.dmde[X2(i, j)];
-      const double cff = Hzk[X2(i, j)] * (cff3 - cff4);
-      UFx[S2(i, j)] = cff * cff1;
-      VFe[S2(i, j)] = cff * cff2;
-    }
-    KSYNC();
-    KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
-      if (i >= IstrU) { const double cff1 = 0.5 * (UFx[S2(i, j)] + UFx[S2(i - 1, j)]); ru[X2(i, j)] = ru[X2(i, j)] + cff1; }
-      if (j >= JstrV) { const double cff1 = 0.5 * (VFe[S2(i, j)] + VFe[S2(i, j - 1)]); rv[X2(i, j)] = rv[X2(i, j)] - cff1; }
-    }
-    KSYNC();
-  }
-  if (!(G.options & ROMS_UV_ADV)) return;
-  // ---- UFx: uxx=w0, Huxx=w1
-  KLOOP2(i, j, B.IstrUm1, B.Iendp1, Jstr, Jend) {
-    w0[S2(i, j)] = u[X2(i - 1, j)] - 2.0 * u[X2(i, j)] + u[X2(i + 1, j)];
-    w1[S2(i, j)] = Hu[X2(i - 1, j)] - 2.0 * Hu[X2(i, j)] + Hu[X2(i + 1, j)];
-  }
-  // ---- UFe prerequisites: uee=w2 on (IstrU:Iend, Jstrm1:Jendp1); Hvxx=w3 on (IstrU-1:Iend, Jstr:Jend+1)
-  KLOOP2(i, j, IstrU, Iend, B.Jstrm1, B.Jendp1) w2[S2(i, j)] = u[X2(i, j - 1)] - 2.0 * u[X2(i, j)] + u[X2(i, j + 1)];
-  KLOOP2(i, j, IstrU - 1, Iend, Jstr, Jend + 1) w3[S2(i, j)] = Hv[X2(i - 1, j)] - 2.0 * Hv[X2(i, j)] + Hv[X2(i + 1, j)];
-  KSYNC();
-  if (!G.ewp) {
-    if (B.west) KLOOP1(j, Jstr, Jend) { w0[S2(Istr, j)] = w0[S2(Istr + 1, j)]; w1[S2(Istr, j)] = w1[S2(Istr + 1, j)]; }
-    if (B.east) KLOOP1(j, Jstr, Jend) { w0[S2(Iend + 1, j)] = w0[S2(Iend, j)]; w1[S2(Iend + 1, j)] = w1[S2(Iend, j)]; }
-  }
-  if (!G.nsp) {
-    if (B.south) KLOOP1(i, IstrU, Iend) w2[S2(i, Jstr - 1)] = w2[S2(i, Jstr)];
-    if (B.north) KLOOP1(i, IstrU, Iend) w2[S2(i, Jend + 1)] = w2[S2(i, Jend)];
-  }
-  KSYNC();
-  KLOOP2(i, j, IstrU - 1, Iend, Jstr, Jend) {
-    const double cff1 = u[X2(i, j)] + u[X2(i + 1, j)];
-    const double cff = (cff1 > 0.0) ? w0[S2(i, j)] : w0[S2(i + 1, j)];
-    UFx[S2(i, j)] = 0.25 * (cff1 + Gadv * cff) * (Hu[X2(i, j)] + Hu[X2(i + 1, j)] + Gadv * 0.5 * (w1[S2(i, j)] + w1[S2(i + 1, j)]));
-  }
-  KLOOP2(i, j, IstrU, Iend, Jstr, Jend + 1) {
-    const double cff1 = u[X2(i, j)] + u[X2(i, j - 1)];
-    const double cff2 = Hv[X2(i, j)] + Hv[X2(i - 1, j)];
-    const double cff = (cff2 > 0.0) ? w2[S2(i, j - 1)] : w2[S2(i, j)];
-    UFe[S2(i, j)] = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * (w3[S2(i, j)] + w3[S2(i - 1, j)]));
-  }
-  KSYNC();
-  // ---- VFx: vxx=w0 on (Istrm1:Iendp1, JstrV:Jend), Huee=w1 on (Istr:Iend+1, JstrV-1:Jend);
-  //      VFe: vee=w2, Hvee=w3 on (Istr:Iend, JstrVm1:Jendp1)
-  KLOOP2(i, j, B.Istrm1, B.Iendp1, JstrV, Jend) w0[S2(i, j)] = v[X2(i - 1, j)] - 2.0 * v[X2(i, j)] + v[X2(i + 1, j)];
-  KLOOP2(i, j, Istr, Iend + 1, JstrV - 1, Jend) w1[S2(i, j)] = Hu[X2(i, j - 1)] - 2.0 * Hu[X2(i, j)] + Hu[X2(i, j + 1)];
-  KLOOP2(i, j, Istr, Iend, B.JstrVm1, B.Jendp1) {
-    w2[S2(i, j)] = v[X2(i, j - 1)] - 2.0 * v[X2(i, j)] + v[X2(i, j + 1)];
-    w3[S2(i, j)] = Hv[X2(i, j - 1)] - 2.0 * Hv[X2(i, j)] + Hv[X2(i, j + 1)];
-  }
-  KSYNC();
-  if (!G.ewp) {
-    if (B.west) KLOOP1(j, JstrV, Jend) w0[S2(Istr - 1, j)] = w0[S2(Istr, j)];
-    if (B.east) KLOOP1(j, JstrV, Jend) w0[S2(Iend + 1, j)] = w0[S2(Iend, j)];
-  }
-  if (!G.nsp) {
-    if (B.south) KLOOP1(i, Istr, Iend) { w2[S2(i, Jstr)] = w2[S2(i, Jstr + 1)]; w3[S2(i, Jstr)] = w3[S2(i, Jstr + 1)]; }
-    if (B.north) KLOOP1(i, Istr, Iend) { w2[S2(i, Jend + 1)] = w2[S2(i, Jend)]; w3[S2(i, Jend + 1)] = w3[S2(i, Jend)]; }
-  }
-  KSYNC();
-  KLOOP2(i, j, Istr, Iend + 1, JstrV, Jend) {
-    const double cff1 = v[X2(i, j)] + v[X2(i - 1, j)];
-    const double cff2 = Hu[X2(i, j)] + Hu[X2(i, j - 1)];
-    const double cff = (cff2 > 0.0) ? w0[S2(i - 1, j)] : w0[S2(i, j)];
-    VFx[S2(i, j)] = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * (w1[S2(i, j)] + w1[S2(i, j - 1)]));
-  }
-  KLOOP2(i, j, Istr, Iend, JstrV - 1, Jend) {
-    const double cff1 = v[X2(i, j)] + v[X2(i, j + 1)];
-    const double cff = (cff1 > 0.0) ? w2[S2(i, j)] : w2[S2(i, j + 1)];
-    VFe[S2(i, j)] = 0.25 * (cff1 + Gadv * cff) * (Hv[X2(i, j)] + Hv[X2(i, j + 1)] + Gadv * 0.5 * (w3[S2(i, j)] + w3[S2(i, j + 1)]));
-  }
-  KSYNC();
-  KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
-    if (i >= IstrU) {
-      const double cff1 = UFx[S2(i, j)] - UFx[S2(i - 1, j)];
-      const double cff2 = UFe[S2(i, j + 1)] - UFe[S2(i, j)];
-      const double cff = cff1 + cff2;
-      ru[X2(i, j)] = ru[X2(i, j)] - cff;
-    }
-    if (j >= JstrV) {
-      const double cff1 = VFx[S2(i + 1, j)] - VFx[S2(i, j)];
-      const double cff2 = VFe[S2(i, j)] - VFe[S2(i, j - 1)];
-      const double cff = cff1 + cff2;
-      rv[X2(i, j)] = rv[X2(i, j)] - cff;
-    }
-  }
-}
-COOP_GLOBAL(k_rhs3d_h, KArgs)
-
-// J_LOOP: 4th-order (9/16,1/16) vertical advection, vertical sums rufrc/rvfrc + surface/bottom
-// stress.  One thread per column of (Istr:Iend, Jstr:Jend).
-// vertical advection of momentum :1132-1176, :1282-1325, one thread per point (FC(k) and FC(k-1) are
-// local functions of the column); index space (Istr:Iend, Jstr:Jend, 1:N)
-THREAD_KERNEL(k_rhs3d_v, KArgs) {
+// K_LOOP (Coriolis :466-520, curvilinear terms :526-590, third-order upstream horizontal advection
+// of momentum :596-1010) and J_LOOP (4th-order vertical advection :1132-1176, :1282-1325) as one
+// point-wise kernel: a thread owns the u-point (grid.z < nchunk) or the v-point of cell (i,j) for a
+// chunk of KCH levels, evaluates the face fluxes around its point directly from global memory with
+// the reference's expressions (closed-edge replication of the second differences through the index)
+// and applies the increments to ru/rv in the reference's order (+Coriolis, +curvilinear,
+// -horizontal advection, -vertical advection) with ONE read and ONE write of ru/rv.
+// p0 = number of chunks.
+THREAD_KERNEL(k_rhs3d_pt, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
   const TB &B = G.T;
-  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, N = G.N, nrhs = G.nrhs;
-  if (!(G.options & ROMS_UV_ADV)) return;
-  const double *u = F.u + (size_t)(nrhs - 1) * G.nij * N, *v = F.v + (size_t)(nrhs - 1) * G.nij * N, *W = F.W;
-  double *ru = F.ru + (size_t)(nrhs - 1) * G.nij * (N + 1), *rv = F.rv + (size_t)(nrhs - 1) * G.nij * (N + 1);
-  const double cff1 = 9.0 / 16.0, cff2 = 1.0 / 16.0;
-  if (i >= B.IstrU) {
-#define WU(kk) (cff1 * (W[XW(i, j, kk)] + W[XW(i - 1, j, kk)]) - cff2 * (W[XW(i + 1, j, kk)] + W[XW(i - 2, j, kk)]))
-#define FCU(out, kk)                                                                                                   \
-  do {                                                                                                                 \
-    if ((kk) <= 0 || (kk) >= N) out = 0.0;                                                                             \
-    else if ((kk) == N - 1) out = (cff1 * (u[X3(i, j, N - 1)] + u[X3(i, j, N)]) - cff2 * (u[X3(i, j, N - 2)] + u[X3(i, j, N)])) * WU(N - 1); \
-    else if ((kk) == 1) out = (cff1 * (u[X3(i, j, 1)] + u[X3(i, j, 2)]) - cff2 * (u[X3(i, j, 1)] + u[X3(i, j, 3)])) * WU(1); \
-    else out = (cff1 * (u[X3(i, j, kk)] + u[X3(i, j, (kk) + 1)]) - cff2 * (u[X3(i, j, (kk) - 1)] + u[X3(i, j, (kk) + 2)])) * WU(kk); \
-  } while (0)
-    double FCk, FCm;
-    FCU(FCk, k);
-    FCU(FCm, k - 1);
-#undef FCU
-#undef WU
-    const double cff = FCk - FCm;
-    ru[XW(i, j, k)] = ru[XW(i, j, k)] - cff;
+  const int nch = a.p0, dir = gz / nch, k0 = (gz - dir * nch) * KCH + 1;
+  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs;
+  if (k0 > N) return;
+  if (dir == 0 ? (i < B.IstrU) : (j < B.JstrV)) return;
+  const bool COR = (G.options & ROMS_UV_COR) != 0, ADV = (G.options & ROMS_UV_ADV) != 0;
+  const bool CURV = ADV && (G.options & ROMS_CURVGRID) != 0;
+  const bool wfix = !G.ewp && B.west, efix = !G.ewp && B.east, sfix = !G.nsp && B.south, nfix = !G.nsp && B.north;
+  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
+  const size_t nij = (size_t)G.nij;
+  const long ni = G.ni;
+  const long x = (long)X2(i, j);
+  const double *u3 = F.u + (size_t)(nrhs - 1) * nij * (size_t)N, *v3 = F.v + (size_t)(nrhs - 1) * nij * (size_t)N;
+  double *r3 = (dir == 0 ? F.ru : F.rv) + (size_t)(nrhs - 1) * nij * (size_t)(N + 1) + x;
+  const double Gadv = -0.25, c916 = 9.0 / 16.0, c116 = 1.0 / 16.0;
+  const long xm = dir == 0 ? x - 1 : x - ni;           // the rho point on the other side: (i-1,j) | (i,j-1)
+  const double fomn0 = F.fomn[x], fomn1 = F.fomn[xm];
+  const double dndx0 = F.dndx[x], dndx1 = F.dndx[xm], dmde0 = F.dmde[x], dmde1 = F.dmde[xm];
+  // ---- vertical advection fluxes at the interfaces k0-1 .. k0+KCH-1 of the chunk
+  double FCV[KCH + 1], qc[KCH];                        // qc: own velocity at the chunk's levels
+  {
+    const double *q3 = (dir == 0 ? u3 : v3) + x;
+    double qq[KCH + 4];                                 // levels k0-2 .. k0+KCH+1 (clamped to 1..N)
+#pragma unroll
+    for (int q = 0; q < KCH + 4; q++) qq[q] = q3[(size_t)(KMIN(KMAX(k0 - 2 + q, 1), N) - 1) * nij];
+#pragma unroll
+    for (int q = 0; q < KCH; q++) qc[q] = qq[q + 2];
+    const long d1 = dir == 0 ? 1 : ni;
+#pragma unroll
+    for (int q = 0; q < KCH + 1; q++) {
+      const int kk = k0 - 1 + q;
+      if (!ADV || kk <= 0 || kk >= N) FCV[q] = 0.0;
+      else {
+        const double *Wk = F.W + x + (size_t)kk * nij;
+        const double ww = c916 * (Wk[0] + Wk[-d1]) - c116 * (Wk[d1] + Wk[-2 * d1]);
+        // levels kk-1, kk, kk+1, kk+2 = qq[q], qq[q+1], qq[q+2], qq[q+3]; at kk = 1 and kk = N-1 the
+        // clamped outer levels are the reference's one-sided forms :1141-1160
+        FCV[q] = (c916 * (qq[q + 1] + qq[q + 2]) - c116 * (qq[q] + qq[q + 3])) * ww;
+      }
+    }
   }
-  if (j >= B.JstrV) {
-#define WV(kk) (cff1 * (W[XW(i, j, kk)] + W[XW(i, j - 1, kk)]) - cff2 * (W[XW(i, j + 1, kk)] + W[XW(i, j - 2, kk)]))
-#define FCV(out, kk)                                                                                                   \
-  do {                                                                                                                 \
-    if ((kk) <= 0 || (kk) >= N) out = 0.0;                                                                             \
-    else if ((kk) == N - 1) out = (cff1 * (v[X3(i, j, N - 1)] + v[X3(i, j, N)]) - cff2 * (v[X3(i, j, N - 2)] + v[X3(i, j, N)])) * WV(N - 1); \
-    else if ((kk) == 1) out = (cff1 * (v[X3(i, j, 1)] + v[X3(i, j, 2)]) - cff2 * (v[X3(i, j, 1)] + v[X3(i, j, 3)])) * WV(1); \
-    else out = (cff1 * (v[X3(i, j, kk)] + v[X3(i, j, (kk) + 1)]) - cff2 * (v[X3(i, j, (kk) - 1)] + v[X3(i, j, (kk) + 2)])) * WV(kk); \
-  } while (0)
-    double FCk, FCm;
-    FCV(FCk, k);
-    FCV(FCm, k - 1);
-#undef FCV
-#undef WV
-    const double cff = FCk - FCm;
-    rv[XW(i, j, k)] = rv[XW(i, j, k)] - cff;
+#pragma unroll
+  for (int q = 0; q < KCH; q++) {
+    const int k = k0 + q;
+    if (k > N) break;
+    const size_t ok = (size_t)(k - 1) * nij;
+    const double *u = u3 + ok + x, *v = v3 + ok + x;   // centred on (i,j): u[di + dj*ni]
+    const double *Hu = F.Huon + ok + x, *Hv = F.Hvom + ok + x;
+    double r = r3[(size_t)k * nij];
+#define U_(di, dj) u[(di) + (dj) * ni]
+#define V_(di, dj) v[(di) + (dj) * ni]
+#define HU_(di, dj) Hu[(di) + (dj) * ni]
+#define HV_(di, dj) Hv[(di) + (dj) * ni]
+    if (dir == 0) {
+      const double uc = qc[q];
+      const double um1 = U_(-1, 0), up1 = U_(1, 0);
+      if (COR || CURV) {
+        const double Hz0 = F.Hz[ok + x], Hz1 = F.Hz[ok + xm];
+        const double v00 = V_(0, 0), v01 = V_(0, 1), vm0 = V_(-1, 0), vm1 = V_(-1, 1);
+        if (COR) {
+          const double cf0 = 0.5 * Hz0 * fomn0, cf1 = 0.5 * Hz1 * fomn1;
+          const double UFx0 = cf0 * (v00 + v01), UFx1 = cf1 * (vm0 + vm1);
+          const double cff1 = 0.5 * (UFx0 + UFx1);
+          r = r + cff1;
+        }
+        if (CURV) {
+          double UFx0, UFx1;
+          {
+            const double cff1 = 0.5 * (v00 + v01), cff2 = 0.5 * (uc + up1);
+            const double cff3 = cff1 * dndx0, cff4 = cff2 * dmde0;
+            const double cff = Hz0 * (cff3 - cff4);
+            UFx0 = cff * cff1;
+          }
+          {
+            const double cff1 = 0.5 * (vm0 + vm1), cff2 = 0.5 * (um1 + uc);
+            const double cff3 = cff1 * dndx1, cff4 = cff2 * dmde1;
+            const double cff = Hz1 * (cff3 - cff4);
+            UFx1 = cff * cff1;
+          }
+          const double cff1 = 0.5 * (UFx0 + UFx1);
+          r = r + cff1;
+        }
+      }
+      if (ADV) {
+        // uxx, Huxx at i-1, i, i+1 (replicated at closed W/E edges :612-640)
+        const double um2 = U_(-2, 0), up2 = U_(2, 0);
+        const double hm2 = HU_(-2, 0), hm1 = HU_(-1, 0), h0 = HU_(0, 0), hp1 = HU_(1, 0), hp2 = HU_(2, 0);
+        double uxm = um2 - 2.0 * um1 + uc, ux0 = um1 - 2.0 * uc + up1, uxp = uc - 2.0 * up1 + up2;
+        double hxm = hm2 - 2.0 * hm1 + h0, hx0 = hm1 - 2.0 * h0 + hp1, hxp = h0 - 2.0 * hp1 + hp2;
+        if (wfix && i - 1 == Istr) { uxm = ux0; hxm = hx0; }
+        if (efix && i + 1 == Iend + 1) { uxp = ux0; hxp = hx0; }
+        double UFx0, UFxm;
+        {
+          const double cff1 = uc + up1;
+          const double cff = (cff1 > 0.0) ? ux0 : uxp;
+          UFx0 = 0.25 * (cff1 + Gadv * cff) * (h0 + hp1 + Gadv * 0.5 * (hx0 + hxp));
+        }
+        {
+          const double cff1 = um1 + uc;
+          const double cff = (cff1 > 0.0) ? uxm : ux0;
+          UFxm = 0.25 * (cff1 + Gadv * cff) * (hm1 + h0 + Gadv * 0.5 * (hxm + hx0));
+        }
+        // uee at j-1, j, j+1 (replicated at closed S/N edges :660-680), Hvxx at (i-1:i, j:j+1)
+        const double u0m1 = U_(0, -1), u0p1 = U_(0, 1);
+        // (the replaced entries are not read beyond the array: a closed edge has one boundary row only)
+        const int jm2 = (sfix && j == Jstr) ? -1 : -2, jp2 = (nfix && j == Jend) ? 1 : 2;
+        double uem = U_(0, jm2) - 2.0 * u0m1 + uc, ue0 = u0m1 - 2.0 * uc + u0p1, uep = uc - 2.0 * u0p1 + U_(0, jp2);
+        if (sfix && j - 1 == Jstr - 1) uem = ue0;
+        if (nfix && j + 1 == Jend + 1) uep = ue0;
+        double UFe0, UFep;
+        {
+          const double hvm2 = HV_(-2, 0), hvm1 = HV_(-1, 0), hv0 = HV_(0, 0), hvp1 = HV_(1, 0);
+          const double cff1 = uc + u0m1;
+          const double cff2 = hv0 + hvm1;
+          const double cff = (cff2 > 0.0) ? uem : ue0;
+          UFe0 = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * ((hvm1 - 2.0 * hv0 + hvp1) + (hvm2 - 2.0 * hvm1 + hv0)));
+        }
+        {
+          const double hvm2 = HV_(-2, 1), hvm1 = HV_(-1, 1), hv0 = HV_(0, 1), hvp1 = HV_(1, 1);
+          const double cff1 = u0p1 + uc;
+          const double cff2 = hv0 + hvm1;
+          const double cff = (cff2 > 0.0) ? ue0 : uep;
+          UFep = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * ((hvm1 - 2.0 * hv0 + hvp1) + (hvm2 - 2.0 * hvm1 + hv0)));
+        }
+        const double cff1 = UFx0 - UFxm;
+        const double cff2 = UFep - UFe0;
+        const double cff = cff1 + cff2;
+        r = r - cff;
+      }
+    } else {
+      const double vc = qc[q];
+      const double v0m1 = V_(0, -1), v0p1 = V_(0, 1);
+      if (COR || CURV) {
+        const double Hz0 = F.Hz[ok + x], Hz1 = F.Hz[ok + xm];
+        const double u00 = U_(0, 0), u10 = U_(1, 0), u0m = U_(0, -1), u1m = U_(1, -1);
+        if (COR) {
+          const double cf0 = 0.5 * Hz0 * fomn0, cf1 = 0.5 * Hz1 * fomn1;
+          const double VFe0 = cf0 * (u00 + u10), VFe1 = cf1 * (u0m + u1m);
+          const double cff1 = 0.5 * (VFe0 + VFe1);
+          r = r - cff1;
+        }
+        if (CURV) {
+          double VFe0, VFe1;
+          {
+            const double cff1 = 0.5 * (vc + v0p1), cff2 = 0.5 * (u00 + u10);
+            const double cff3 = cff1 * dndx0, cff4 = cff2 * dmde0;
+            const double cff = Hz0 * (cff3 - cff4);
+            VFe0 = cff * cff2;
+          }
+          {
+            const double cff1 = 0.5 * (v0m1 + vc), cff2 = 0.5 * (u0m + u1m);
+            const double cff3 = cff1 * dndx1, cff4 = cff2 * dmde1;
+            const double cff = Hz1 * (cff3 - cff4);
+            VFe1 = cff * cff2;
+          }
+          const double cff1 = 0.5 * (VFe0 + VFe1);
+          r = r - cff1;
+        }
+      }
+      if (ADV) {
+        // vxx at i-1, i, i+1 (replicated at closed W/E edges :830-850), Huee at (i:i+1, j-1:j)
+        const double vm1 = V_(-1, 0), vp1 = V_(1, 0);
+        double vxm = V_(-2, 0) - 2.0 * vm1 + vc, vx0 = vm1 - 2.0 * vc + vp1, vxp = vc - 2.0 * vp1 + V_(2, 0);
+        if (wfix && i - 1 == Istr - 1) vxm = vx0;
+        if (efix && i + 1 == Iend + 1) vxp = vx0;
+        double VFx0, VFxp;
+        {
+          const double hm2 = HU_(0, -2), hm1 = HU_(0, -1), h0 = HU_(0, 0), hp1 = HU_(0, 1);
+          const double cff1 = vc + vm1;
+          const double cff2 = h0 + hm1;
+          const double cff = (cff2 > 0.0) ? vxm : vx0;
+          VFx0 = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * ((hm1 - 2.0 * h0 + hp1) + (hm2 - 2.0 * hm1 + h0)));
+        }
+        {
+          const double hm2 = HU_(1, -2), hm1 = HU_(1, -1), h0 = HU_(1, 0), hp1 = HU_(1, 1);
+          const double cff1 = vp1 + vc;
+          const double cff2 = h0 + hm1;
+          const double cff = (cff2 > 0.0) ? vx0 : vxp;
+          VFxp = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * ((hm1 - 2.0 * h0 + hp1) + (hm2 - 2.0 * hm1 + h0)));
+        }
+        // vee, Hvee at j-1, j, j+1 (replicated at closed S/N edges :880-900)
+        const int jp2 = (nfix && j == Jend) ? 1 : 2;   // replaced below, not read beyond the array
+        const double v0m2 = V_(0, -2), v0p2 = V_(0, jp2);
+        const double gm2 = HV_(0, -2), gm1 = HV_(0, -1), g0 = HV_(0, 0), gp1 = HV_(0, 1), gp2 = HV_(0, jp2);
+        double vem = v0m2 - 2.0 * v0m1 + vc, ve0 = v0m1 - 2.0 * vc + v0p1, vep = vc - 2.0 * v0p1 + v0p2;
+        double gem = gm2 - 2.0 * gm1 + g0, ge0 = gm1 - 2.0 * g0 + gp1, gep = g0 - 2.0 * gp1 + gp2;
+        if (sfix && j - 1 == Jstr) { vem = ve0; gem = ge0; }
+        if (nfix && j + 1 == Jend + 1) { vep = ve0; gep = ge0; }
+        double VFe0, VFem;
+        {
+          const double cff1 = vc + v0p1;
+          const double cff = (cff1 > 0.0) ? ve0 : vep;
+          VFe0 = 0.25 * (cff1 + Gadv * cff) * (g0 + gp1 + Gadv * 0.5 * (ge0 + gep));
+        }
+        {
+          const double cff1 = v0m1 + vc;
+          const double cff = (cff1 > 0.0) ? vem : ve0;
+          VFem = 0.25 * (cff1 + Gadv * cff) * (gm1 + g0 + Gadv * 0.5 * (gem + ge0));
+        }
+        const double cff1 = VFxp - VFx0;
+        const double cff2 = VFe0 - VFem;
+        const double cff = cff1 + cff2;
+        r = r - cff;
+      }
+    }
+#undef U_
+#undef V_
+#undef HU_
+#undef HV_
+    if (ADV) {
+      const double cff = FCV[q + 1] - FCV[q];
+      r = r - cff;
+    }
+    r3[(size_t)k * nij] = r;
   }
 }
-THREAD_GLOBAL(k_rhs3d_v, KArgs)
+THREAD_GLOBAL(k_rhs3d_pt, KArgs)
 
 // rufrc, rvfrc = vertical sum of ru, rv (in k order) + surface - bottom stress :1700-1918; one thread
 // per column.  Eight levels are loaded at a time before they are added, so that the loads overlap.
