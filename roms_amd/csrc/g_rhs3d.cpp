@@ -57,7 +57,7 @@ int run_uv3dmix2(roms_hip_ctx *c) {
   const TB &B = G.T;
   if (!(G.options & ROMS_UV_VIS2)) return 0;
   KArgs a = mk(c);
-  LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N, c->stream, a);
+  LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
   LAUNCH_THREAD(k_uv3dmix2_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   return 0;
 }

@@ -565,58 +565,90 @@ THREAD_GLOBAL(k_t3dmix2_s, KArgs)
 // at rho (R) and psi (P) points are evaluated in-line.  The two terms each momentum point adds to
 // rufrc/rvfrc are kept in work arrays and summed over k, in order, by k_uv3dmix2_sum (the reference
 // accumulates rufrc inside its k loop, uv3dmix2_s.h:226-262).
+// A thread does KCH consecutive levels (grid.z = chunk): every product of time-invariant metrics in
+// the stress expressions is formed once per chunk, in the reference's association order.
 THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
   const TB &B = G.T;
-  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, N = G.N, nrhs = G.nrhs, nnew = G.nnew;
-  const double *pm = F.pm, *pn = F.pn, *Hz = F.Hz;
-  const double *u = F.u + (size_t)(nrhs - 1) * G.nij * N, *v = F.v + (size_t)(nrhs - 1) * G.nij * N;
+  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs, nnew = G.nnew;
+  const int k0 = gz * KCH + 1;
+  if (k0 > N) return;
+  const double *pm = F.pm, *pn = F.pn;
   const bool do_u = i >= B.IstrU, do_v = j >= B.JstrV;
-  // cff at rho point (ii,jj) and at psi point (ii,jj)
-#define CFFR(ii, jj)                                                                                                   \
-  (Hz[X3(ii, jj, k)] * 0.5 *                                                                                           \
-   (F.pmon_r[X2(ii, jj)] * ((pn[X2(ii, jj)] + pn[X2((ii) + 1, jj)]) * u[X3((ii) + 1, jj, k)] -                          \
-                            (pn[X2((ii) - 1, jj)] + pn[X2(ii, jj)]) * u[X3(ii, jj, k)]) -                               \
-    F.pnom_r[X2(ii, jj)] * ((pm[X2(ii, jj)] + pm[X2(ii, (jj) + 1)]) * v[X3(ii, (jj) + 1, k)] -                          \
-                            (pm[X2(ii, (jj) - 1)] + pm[X2(ii, jj)]) * v[X3(ii, jj, k)])))
-#define CFFP(ii, jj)                                                                                                   \
-  (0.125 * (Hz[X3((ii) - 1, jj, k)] + Hz[X3(ii, jj, k)] + Hz[X3((ii) - 1, (jj) - 1, k)] + Hz[X3(ii, (jj) - 1, k)]) *    \
-   (F.pmon_p[X2(ii, jj)] * ((pn[X2(ii, (jj) - 1)] + pn[X2(ii, jj)]) * v[X3(ii, jj, k)] -                                \
-                            (pn[X2((ii) - 1, (jj) - 1)] + pn[X2((ii) - 1, jj)]) * v[X3((ii) - 1, jj, k)]) +             \
-    F.pnom_p[X2(ii, jj)] * ((pm[X2((ii) - 1, jj)] + pm[X2(ii, jj)]) * u[X3(ii, jj, k)] -                                \
-                            (pm[X2((ii) - 1, (jj) - 1)] + pm[X2(ii, (jj) - 1)]) * u[X3(ii, (jj) - 1, k)])))
-  const double cR = CFFR(i, j), cP = CFFP(i, j);
-  if (do_u) {
-    const double cRw = CFFR(i - 1, j), cPn = CFFP(i, j + 1);
-    const double UFx1 = F.on_r[X2(i, j)] * F.on_r[X2(i, j)] * F.visc2_r[X2(i, j)] * cR;
-    const double UFx0 = F.on_r[X2(i - 1, j)] * F.on_r[X2(i - 1, j)] * F.visc2_r[X2(i - 1, j)] * cRw;
-    const double UFe1 = F.om_p[X2(i, j + 1)] * F.om_p[X2(i, j + 1)] * F.visc2_p[X2(i, j + 1)] * cPn;
-    const double UFe0 = F.om_p[X2(i, j)] * F.om_p[X2(i, j)] * F.visc2_p[X2(i, j)] * cP;
-    const double cff = G.dt * 0.25 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (pn[X2(i - 1, j)] + pn[X2(i, j)]);
-    const double cff1 = 0.5 * (pn[X2(i - 1, j)] + pn[X2(i, j)]) * (UFx1 - UFx0);
-    const double cff2 = 0.5 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (UFe1 - UFe0);
-    const double cff3 = cff * (cff1 + cff2);
-    F.wrk3[1][X3(i, j, k)] = cff1;
-    F.wrk3[2][X3(i, j, k)] = cff2;
-    F.u[X4(i, j, k, nnew)] = F.u[X4(i, j, k, nnew)] + cff3;
-  }
-  if (do_v) {
-    const double cRs = CFFR(i, j - 1), cPe = CFFP(i + 1, j);
-    const double VFx1 = F.on_p[X2(i + 1, j)] * F.on_p[X2(i + 1, j)] * F.visc2_p[X2(i + 1, j)] * cPe;
-    const double VFx0 = F.on_p[X2(i, j)] * F.on_p[X2(i, j)] * F.visc2_p[X2(i, j)] * cP;
-    const double VFe1 = F.om_r[X2(i, j)] * F.om_r[X2(i, j)] * F.visc2_r[X2(i, j)] * cR;
-    const double VFe0 = F.om_r[X2(i, j - 1)] * F.om_r[X2(i, j - 1)] * F.visc2_r[X2(i, j - 1)] * cRs;
-    const double cff = G.dt * 0.25 * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]);
-    const double cff1 = 0.5 * (pn[X2(i, j - 1)] + pn[X2(i, j)]) * (VFx1 - VFx0);
-    const double cff2 = 0.5 * (pm[X2(i, j - 1)] + pm[X2(i, j)]) * (VFe1 - VFe0);
-    const double cff3 = cff * (cff1 - cff2);
-    F.wrk3[3][X3(i, j, k)] = cff1;
-    F.wrk3[4][X3(i, j, k)] = cff2;
-    F.v[X4(i, j, k, nnew)] = F.v[X4(i, j, k, nnew)] + cff3;
-  }
+  const size_t nij = (size_t)G.nij;
+  const long ni = G.ni, x = (long)X2(i, j);
+  // rho point at offset o: {pmon_r, pn(ii)+pn(ii+1), pn(ii-1)+pn(ii), pnom_r, pm(jj)+pm(jj+1), pm(jj-1)+pm(jj)}
+#define RSET(c, o)                                                                                \
+  const double c##0 = F.pmon_r[o], c##1 = pn[o] + pn[(o) + 1], c##2 = pn[(o) - 1] + pn[o],         \
+               c##3 = F.pnom_r[o], c##4 = pm[o] + pm[(o) + ni], c##5 = pm[(o) - ni] + pm[o]
+  // psi point at offset o: {pmon_p, pn(ii,jj-1)+pn(ii,jj), pn(ii-1,jj-1)+pn(ii-1,jj), pnom_p,
+  //                         pm(ii-1,jj)+pm(ii,jj), pm(ii-1,jj-1)+pm(ii,jj-1)}
+#define PSET(c, o)                                                                                \
+  const double c##0 = F.pmon_p[o], c##1 = pn[(o) - ni] + pn[o], c##2 = pn[(o) - 1 - ni] + pn[(o) - 1], \
+               c##3 = F.pnom_p[o], c##4 = pm[(o) - 1] + pm[o], c##5 = pm[(o) - 1 - ni] + pm[(o) - ni]
+  RSET(r0_, x); PSET(p0_, x);
+  RSET(rw_, x - 1); PSET(pn_, x + ni);     // u-point: rho point (i-1,j), psi point (i,j+1)
+  RSET(rs_, x - ni); PSET(pe_, x + 1);     // v-point: rho point (i,j-1), psi point (i+1,j)
+#undef RSET
+#undef PSET
+  const double fur1 = F.on_r[x] * F.on_r[x] * F.visc2_r[x], fur0 = F.on_r[x - 1] * F.on_r[x - 1] * F.visc2_r[x - 1];
+  const double fup1 = F.om_p[x + ni] * F.om_p[x + ni] * F.visc2_p[x + ni], fup0 = F.om_p[x] * F.om_p[x] * F.visc2_p[x];
+  const double fvp1 = F.on_p[x + 1] * F.on_p[x + 1] * F.visc2_p[x + 1], fvp0 = F.on_p[x] * F.on_p[x] * F.visc2_p[x];
+  const double fvr1 = F.om_r[x] * F.om_r[x] * F.visc2_r[x], fvr0 = F.om_r[x - ni] * F.om_r[x - ni] * F.visc2_r[x - ni];
+  const double ucff = G.dt * 0.25 * (pm[x - 1] + pm[x]) * (pn[x - 1] + pn[x]);
+  const double uc1 = 0.5 * (pn[x - 1] + pn[x]), uc2 = 0.5 * (pm[x - 1] + pm[x]);
+  const double vcff = G.dt * 0.25 * (pm[x] + pm[x - ni]) * (pn[x] + pn[x - ni]);
+  const double vc1 = 0.5 * (pn[x - ni] + pn[x]), vc2 = 0.5 * (pm[x - ni] + pm[x]);
+#pragma unroll
+  for (int q = 0; q < KCH; q++) {
+    const int k = k0 + q;
+    if (k > N) break;
+    const size_t ok = (size_t)(k - 1) * nij;
+    const double *Hz = F.Hz + ok + x;
+    const double *u = F.u + (size_t)(nrhs - 1) * nij * (size_t)N + ok + x, *v = F.v + (size_t)(nrhs - 1) * nij * (size_t)N + ok + x;
+    // stress at rho point with coefficient set c, centred at offset o; at psi point likewise
+#define CFFR(c, o) (Hz[o] * 0.5 * (c##0 * (c##1 * u[(o) + 1] - c##2 * u[o]) - c##3 * (c##4 * v[(o) + ni] - c##5 * v[o])))
+#define CFFP(c, o)                                                                              \
+  (0.125 * (Hz[(o) - 1] + Hz[o] + Hz[(o) - 1 - ni] + Hz[(o) - ni]) *                             \
+   (c##0 * (c##1 * v[o] - c##2 * v[(o) - 1]) + c##3 * (c##4 * u[o] - c##5 * u[(o) - ni])))
+    const double cR = CFFR(r0_, 0), cP = CFFP(p0_, 0);
+    double un = 0.0, vn = 0.0, u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0;
+    if (do_u) {
+      const double cRw = CFFR(rw_, -1), cPn = CFFP(pn_, ni);
+      const double UFx1 = fur1 * cR;
+      const double UFx0 = fur0 * cRw;
+      const double UFe1 = fup1 * cPn;
+      const double UFe0 = fup0 * cP;
+      u1 = uc1 * (UFx1 - UFx0);
+      u2 = uc2 * (UFe1 - UFe0);
+      const double cff3 = ucff * (u1 + u2);
+      un = F.u[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] + cff3;
+    }
+    if (do_v) {
+      const double cRs = CFFR(rs_, -ni), cPe = CFFP(pe_, 1);
+      const double VFx1 = fvp1 * cPe;
+      const double VFx0 = fvp0 * cP;
+      const double VFe1 = fvr1 * cR;
+      const double VFe0 = fvr0 * cRs;
+      v1 = vc1 * (VFx1 - VFx0);
+      v2 = vc2 * (VFe1 - VFe0);
+      const double cff3 = vcff * (v1 - v2);
+      vn = F.v[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] + cff3;
+    }
 #undef CFFR
 #undef CFFP
+    if (do_u) {
+      F.wrk3[1][ok + x] = u1;
+      F.wrk3[2][ok + x] = u2;
+      F.u[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] = un;
+    }
+    if (do_v) {
+      F.wrk3[3][ok + x] = v1;
+      F.wrk3[4][ok + x] = v2;
+      F.v[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] = vn;
+    }
+  }
 }
 THREAD_GLOBAL(k_uv3dmix2_s, KArgs)
 
