@@ -21,7 +21,8 @@ int run_pre_step3d(roms_hip_ctx *c) {
   KArgs a = mk(c);
   bool any_col = false;      // tracers with a spline vertical flux keep the two-kernel column path
   for (int it = 0; it < G.NT; it++) any_col |= G.vadv[it] == ROMS_SPLINES;
-  LAUNCH_THREAD(k_pre_t3, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N * G.NT, c->stream, a);
+  a.p0 = (G.N + KCH - 1) / KCH;
+  LAUNCH_THREAD(k_pre_t3, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
   if (any_col) {
     LAUNCH_COOP(k_pre_t3h, G.nbx, G.nby, G.N * G.NT, 256, 3 * lds_sz(G), c->stream, a);
     LAUNCH_THREAD(k_pre_t3v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);

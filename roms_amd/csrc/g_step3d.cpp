@@ -61,7 +61,8 @@ int run_step3d_t(roms_hip_ctx *c) {
     any_pt |= pt;
     any_lds |= !pt && hs != ROMS_MPDATA;
   }
-  if (any_pt) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N * G.NT, c->stream, a);
+  a.p0 = (N + KCH - 1) / KCH;
+  if (any_pt) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
   if (any_lds) LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
   LAUNCH_THREAD(k_s3t_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);
   for (int it = 1; it <= G.NT && any_mp; it++) {

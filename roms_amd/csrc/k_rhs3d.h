@@ -98,6 +98,8 @@ KDEV void hadv_flux_lds(const DGrid &G, const TB &B, int scheme, const double *T
   KSYNC();
 }
 
+#define KCH 5   // levels per thread of the chunked point-wise kernels (grid.z = chunk)
+
 // The same fluxes for ONE u-face (hadv_fx_pt) or v-face (hadv_fe_pt), read straight from global
 // memory: used by the point-wise fused tracer kernels (k_pre_t3, k_s3t_hv), where every thread
 // evaluates the four face fluxes of its own cell.  T, Hu, Hv point at the level's plane.  The
@@ -205,6 +207,33 @@ COOP_GLOBAL(k_pre_t3h, KArgs)
     }                                                                                              \
   } while (0)
 
+// The same flux from the four column values around interface k (tm1 = T(k-1), t0 = T(k), tp1 = T(k+1),
+// tp2 = T(k+2); values outside 1..N are never used) and w = W(k): for kernels that hold a window of
+// the column in registers.  The one-sided forms at k = 1 and k = N-1 are written relative to k.
+#define VFLUX_REL(FCk, scheme, k, N, tm1, t0, tp1, tp2, w)                                         \
+  do {                                                                                             \
+    if ((k) <= 0 || (k) >= (N)) { FCk = 0.0; }                                                     \
+    else if ((scheme) == ROMS_C2) { FCk = (w) * 0.5 * ((t0) + (tp1)); }                            \
+    else if ((scheme) == ROMS_MPDATA || (scheme) == ROMS_HSIMT) {                                  \
+      const double c1_ = KMAX(w, 0.0), c2_ = KMIN(w, 0.0);                                         \
+      FCk = c1_ * (t0) + c2_ * (tp1);                                                              \
+    } else if ((scheme) == ROMS_A4) {                                                              \
+      const double eps_ = 1.0E-16;                                                                 \
+      const double d1_ = (tp1) - (t0);                                                             \
+      const double d0_ = ((k) - 1 >= 1) ? (t0) - (tm1) : d1_;                                      \
+      const double d2_ = ((k) + 1 <= (N) - 1) ? (tp2) - (tp1) : d1_;                               \
+      const double p0_ = 2.0 * d1_ * d0_, p1_ = 2.0 * d2_ * d1_;                                   \
+      const double CFk_ = (p0_ > eps_) ? p0_ / (d1_ + d0_) : 0.0;                                  \
+      const double CFk1_ = (p1_ > eps_) ? p1_ / (d2_ + d1_) : 0.0;                                 \
+      FCk = (w) * 0.5 * ((t0) + (tp1) - (1.0 / 3.0) * (CFk1_ - CFk_));                             \
+    } else { /* CENTERED4, SPLIT_U3 */                                                             \
+      const double c1_ = 0.5, c2_ = 7.0 / 12.0, c3_ = 1.0 / 12.0;                                  \
+      if ((k) == 1) FCk = (w) * (c1_ * (t0) + c2_ * (tp1) - c3_ * (tp2));                          \
+      else if ((k) == (N) - 1) FCk = (w) * (c1_ * (tp1) + c2_ * (t0) - c3_ * (tm1));               \
+      else FCk = (w) * (c2_ * ((t0) + (tp1)) - c3_ * ((tm1) + (tp2)));                             \
+    }                                                                                              \
+  } while (0)
+
 // Parabolic-spline vertical flux (SPLINES): tridiagonal recurrence; FC kept in the 3-D work
 // array wrk3[3] (w-levels), CF in wrk3[4].  corrector = 0: pre_step3d end conditions
 // (1.5, 0.5, 3, 2); 1: step3d_t (2, 1, 2, 1).
@@ -269,37 +298,47 @@ THREAD_GLOBAL(k_pre_t3v, KArgs)
 THREAD_KERNEL(k_pre_t3, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
-  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N, k = gz % N + 1, itrc = gz / N + 1;
-  if (!pre_point_path(G, itrc)) return;
+  const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * KCH + 1;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  if (k0 > N || !pre_point_path(G, itrc)) return;
   const int hs = G.hadv[itrc - 1], vs = G.vadv[itrc - 1];
+  const size_t nij = (size_t)G.nij, x = X2(i, j);
   const double *T = F.t + XT(G.LBi, G.LBj, 1, G.nstp, itrc);   // level 1
-  const double *Tk = T + (size_t)(k - 1) * G.nij;
-  const double *Hu = F.Huon + X3(G.LBi, G.LBj, k), *Hv = F.Hvom + X3(G.LBi, G.LBj, k);
-  // horizontal
+  const double *tnew = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc) + x;
+  double *t3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc) + x;
   const double GammaH = (hs == ROMS_MPDATA || hs == ROMS_HSIMT) ? 0.5 : 1.0 / 6.0;
   double cff, cff1, cff2;
   if (G.iic == G.ntfirst) { cff = 0.5 * G.dt; cff1 = 1.0; cff2 = 0.0; }
   else { cff = (1.0 - GammaH) * G.dt; cff1 = 0.5 + GammaH; cff2 = 0.5 - GammaH; }
-  const double FXp = hadv_fx_pt(G, hs, Tk, Hu, i + 1, j), FX0 = hadv_fx_pt(G, hs, Tk, Hu, i, j);
-  const double FEp = hadv_fe_pt(G, hs, Tk, Hv, i, j + 1), FE0 = hadv_fe_pt(G, hs, Tk, Hv, i, j);
-  const double Hzk = F.Hz[X3(i, j, k)];
-  const double t3h = Hzk * (cff1 * Tk[X2(i, j)] + cff2 * F.t[XT(i, j, k, G.nnew, itrc)]) -
-                     cff * F.pm[X2(i, j)] * F.pn[X2(i, j)] * (FXp - FX0 + FEp - FE0);
-  // vertical
   const double GammaV = (vs == ROMS_MPDATA || vs == ROMS_HSIMT) ? 0.5 : 1.0 / 6.0;
   const double cfv = (G.iic == G.ntfirst) ? 0.5 * G.dt : (1.0 - GammaV) * G.dt;
-  const double pmn = F.pm[X2(i, j)] * F.pn[X2(i, j)];
-#define Tc(kk) T[X3(i, j, kk)]
-#define Wc(kk) F.W[XW(i, j, kk)]
-  double FCk, FCm;
-  VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
-  VFLUX_LOCAL(FCm, vs, k - 1, N, Tc, Wc);
-#undef Tc
-#undef Wc
-  const double DC = 1.0 / (Hzk - cfv * pmn * (Hu[X2(i + 1, j)] - Hu[X2(i, j)] + Hv[X2(i, j + 1)] - Hv[X2(i, j)] +
-                                              (F.W[XW(i, j, k)] - F.W[XW(i, j, k - 1)])));
-  const double cfv1 = cfv * pmn;
-  F.t[XT(i, j, k, 3, itrc)] = DC * (t3h - cfv1 * (FCk - FCm));
+  const double pmv = F.pm[x], pnv = F.pn[x];
+  const double pmn = pmv * pnv;
+  // column window: levels k0-2 .. k0+KCH+1 (clamped), W at interfaces k0-1 .. k0+KCH-1; vertical fluxes
+  double tt[KCH + 4], ww[KCH + 1], FC[KCH + 1];
+#pragma unroll
+  for (int q = 0; q < KCH + 4; q++) tt[q] = T[x + (size_t)(KMIN(KMAX(k0 - 2 + q, 1), N) - 1) * nij];
+#pragma unroll
+  for (int q = 0; q < KCH + 1; q++) ww[q] = F.W[x + (size_t)KMIN(k0 - 1 + q, N) * nij];
+#pragma unroll
+  for (int q = 0; q < KCH + 1; q++) VFLUX_REL(FC[q], vs, k0 - 1 + q, N, tt[q], tt[q + 1], tt[q + 2], tt[q + 3], ww[q]);
+#pragma unroll
+  for (int q = 0; q < KCH; q++) {
+    const int k = k0 + q;
+    if (k > N) break;
+    const size_t ok = (size_t)(k - 1) * nij;
+    const double *Tk = T + ok;
+    const double *Hu = F.Huon + ok, *Hv = F.Hvom + ok;
+    // horizontal
+    const double FXp = hadv_fx_pt(G, hs, Tk, Hu, i + 1, j), FX0 = hadv_fx_pt(G, hs, Tk, Hu, i, j);
+    const double FEp = hadv_fe_pt(G, hs, Tk, Hv, i, j + 1), FE0 = hadv_fe_pt(G, hs, Tk, Hv, i, j);
+    const double Hzk = F.Hz[ok + x];
+    const double t3h = Hzk * (cff1 * tt[q + 2] + cff2 * tnew[ok]) - cff * pmv * pnv * (FXp - FX0 + FEp - FE0);
+    // vertical
+    const double DC = 1.0 / (Hzk - cfv * pmn * (Hu[X2(i + 1, j)] - Hu[X2(i, j)] + Hv[X2(i, j + 1)] - Hv[X2(i, j)] + (ww[q + 1] - ww[q])));
+    const double cfv1 = cfv * pmn;
+    t3[ok] = DC * (t3h - cfv1 * (FC[q + 1] - FC[q]));
+  }
 }
 THREAD_GLOBAL(k_pre_t3, KArgs)
 
@@ -309,7 +348,6 @@ THREAD_GLOBAL(k_pre_t3, KArgs)
 // the KCH+1 interfaces of the chunk are computed once (the level form needs each flux twice), z_r,
 // the tracers and the velocities are loaded once per level, and all index arithmetic that does not
 // depend on the level is done once per chunk.
-#define KCH 5
 THREAD_KERNEL(k_pre_new, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;

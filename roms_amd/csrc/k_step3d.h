@@ -226,29 +226,38 @@ KDEV bool s3t_point_path(const DGrid &G, int itrc) {
 THREAD_KERNEL(k_s3t_hv, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
-  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N, k = gz % N + 1, itrc = gz / N + 1;
-  if (!s3t_point_path(G, itrc)) return;
+  const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * KCH + 1;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  if (k0 > N || !s3t_point_path(G, itrc)) return;
   const int hs = G.hadv[itrc - 1], vs = G.vadv[itrc - 1];
+  const size_t nij = (size_t)G.nij, x = X2(i, j);
   const double *T3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
-  const double *T3k = T3 + (size_t)(k - 1) * G.nij;
-  const double *Hu = F.Huon + X3(G.LBi, G.LBj, k), *Hv = F.Hvom + X3(G.LBi, G.LBj, k);
-  double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);
-  const double cff = G.dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
-  const double cff1 = cff * (hadv_fx_pt(G, hs, T3k, Hu, i + 1, j) - hadv_fx_pt(G, hs, T3k, Hu, i, j));
-  const double cff2 = cff * (hadv_fe_pt(G, hs, T3k, Hv, i, j + 1) - hadv_fe_pt(G, hs, T3k, Hv, i, j));
-  const double cff3 = cff1 + cff2;
-  double tt = tn[X3(i, j, k)] - cff3;
-#define Tc(kk) T3[X3(i, j, kk)]
-#define Wc(kk) F.W[XW(i, j, kk)]
-  double FCk, FCm;
-  VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
-  VFLUX_LOCAL(FCm, vs, k - 1, N, Tc, Wc);
-#undef Tc
-#undef Wc
-  const double cv = cff * (FCk - FCm);
-  tt = tt - cv;
-  tt = tt * (1.0 / F.Hz[X3(i, j, k)]);
-  tn[X3(i, j, k)] = tt;
+  double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc) + x;
+  const double cff = G.dt * F.pm[x] * F.pn[x];
+  // column window of t(3): levels k0-2 .. k0+KCH+1 (clamped), W at interfaces k0-1 .. k0+KCH-1
+  double tw[KCH + 4], ww[KCH + 1], FC[KCH + 1];
+#pragma unroll
+  for (int q = 0; q < KCH + 4; q++) tw[q] = T3[x + (size_t)(KMIN(KMAX(k0 - 2 + q, 1), N) - 1) * nij];
+#pragma unroll
+  for (int q = 0; q < KCH + 1; q++) ww[q] = F.W[x + (size_t)KMIN(k0 - 1 + q, N) * nij];
+#pragma unroll
+  for (int q = 0; q < KCH + 1; q++) VFLUX_REL(FC[q], vs, k0 - 1 + q, N, tw[q], tw[q + 1], tw[q + 2], tw[q + 3], ww[q]);
+#pragma unroll
+  for (int q = 0; q < KCH; q++) {
+    const int k = k0 + q;
+    if (k > N) break;
+    const size_t ok = (size_t)(k - 1) * nij;
+    const double *T3k = T3 + ok;
+    const double *Hu = F.Huon + ok, *Hv = F.Hvom + ok;
+    const double cff1 = cff * (hadv_fx_pt(G, hs, T3k, Hu, i + 1, j) - hadv_fx_pt(G, hs, T3k, Hu, i, j));
+    const double cff2 = cff * (hadv_fe_pt(G, hs, T3k, Hv, i, j + 1) - hadv_fe_pt(G, hs, T3k, Hv, i, j));
+    const double cff3 = cff1 + cff2;
+    double tt = tn[ok] - cff3;
+    const double cv = cff * (FC[q + 1] - FC[q]);
+    tt = tt - cv;
+    tt = tt * (1.0 / F.Hz[ok + x]);
+    tn[ok] = tt;
+  }
 }
 THREAD_GLOBAL(k_s3t_hv, KArgs)
 
