@@ -39,7 +39,7 @@ int run_prsgrd(roms_hip_ctx *c) {
   const TB &B = G.T;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_prs_P, B.Iend - (B.IstrU - 1) + 1, B.Jend - (B.JstrV - 1) + 1, 1, c->stream, a);
-  LAUNCH_THREAD(k_prs_grad, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N, c->stream, a);
+  LAUNCH_THREAD(k_prs_grad, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
   return 0;
 }
 
@@ -49,7 +49,8 @@ int run_t3dmix2(roms_hip_ctx *c) {
   if (!(G.options & ROMS_TS_DIF2)) return 0;
   if (G.options & ROMS_MIX_GEO_TS) return run_t3dmix2_geo(c);
   KArgs a = mk(c);
-  LAUNCH_THREAD(k_t3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N * G.NT, c->stream, a);
+  a.p0 = (G.N + KCH - 1) / KCH;
+  LAUNCH_THREAD(k_t3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
   return 0;
 }
 

@@ -526,10 +526,14 @@ THREAD_KERNEL(k_prs_grad, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
   const TB &B = G.T;
-  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1, nrhs = G.nrhs;
+  const int i = B.Istr + gx, j = B.Jstr + gy, nrhs = G.nrhs;
   const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0, eps = 1.0E-10;
   const double HalfGRho = 0.5 * (G.g / G.rho0);
   const double *rho = F.rho, *z_r = F.z_r, *Hz = F.Hz, *P = F.wrk3[1];
+#pragma unroll
+  for (int q = 0; q < KCH; q++) {
+  const int k = gz * KCH + 1 + q;
+  if (k > G.N) break;
   if (i >= B.IstrU) {
     // aux(ii)=z_r(ii)-z_r(ii-1), FC(ii)=rho(ii)-rho(ii-1); dZx(ii)=harm(aux(ii),aux(ii+1)) ...
     const double am = z_r[X3(i - 1, j, k)] - z_r[X3(i - 2, j, k)], a0 = z_r[X3(i, j, k)] - z_r[X3(i - 1, j, k)],
@@ -573,6 +577,7 @@ THREAD_KERNEL(k_prs_grad, KArgs) {
                      OneFifth * ((dRx0 - dRxm) * (z_r[X3(i, j, k)] - z_r[X3(i, j - 1, k)] - OneTwelfth * (dZx0 + dZxm)) -
                                  (dZx0 - dZxm) * (rho[X3(i, j, k)] - rho[X3(i, j - 1, k)] - OneTwelfth * (dRx0 + dRxm)))));
   }
+  }
 }
 THREAD_GLOBAL(k_prs_grad, KArgs)
 
@@ -581,20 +586,33 @@ THREAD_GLOBAL(k_prs_grad, KArgs)
 THREAD_KERNEL(k_t3dmix2_s, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = *a.Fp;
-  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz % G.N + 1, itrc = gz / G.N + 1;
+  const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * KCH + 1;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  if (k0 > N) return;
   const int nrhs = G.nrhs, nnew = G.nnew;
-  const double *Hz = F.Hz, *diff2 = F.diff2;
-#define FXm(ii) (0.25 * (diff2[X2T(ii, j, itrc)] + diff2[X2T((ii) - 1, j, itrc)]) * F.pmon_u[X2(ii, j)] * \
-                 (Hz[X3(ii, j, k)] + Hz[X3((ii) - 1, j, k)]) * (F.t[XT(ii, j, k, nrhs, itrc)] - F.t[XT((ii) - 1, j, k, nrhs, itrc)]))
-#define FEm(jj) (0.25 * (diff2[X2T(i, jj, itrc)] + diff2[X2T(i, (jj) - 1, itrc)]) * F.pnom_v[X2(i, jj)] * \
-                 (Hz[X3(i, jj, k)] + Hz[X3(i, (jj) - 1, k)]) * (F.t[XT(i, jj, k, nrhs, itrc)] - F.t[XT(i, (jj) - 1, k, nrhs, itrc)]))
-  const double cff = G.dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
-  const double cff1 = cff * (FXm(i + 1) - FXm(i));
-  const double cff2 = cff * (FEm(j + 1) - FEm(j));
-  const double cff3 = cff1 + cff2;
-  F.t[XT(i, j, k, nnew, itrc)] = F.t[XT(i, j, k, nnew, itrc)] + cff3;
-#undef FXm
-#undef FEm
+  const size_t nij = (size_t)G.nij;
+  const long ni = G.ni, x = (long)X2(i, j);
+  const double *d2 = F.diff2 + (size_t)(itrc - 1) * nij + x;
+  // level-independent factors of the four face fluxes :143-178
+  const double ax0 = 0.25 * (d2[0] + d2[-1]) * F.pmon_u[x], ax1 = 0.25 * (d2[1] + d2[0]) * F.pmon_u[x + 1];
+  const double ae0 = 0.25 * (d2[0] + d2[-ni]) * F.pnom_v[x], ae1 = 0.25 * (d2[ni] + d2[0]) * F.pnom_v[x + ni];
+  const double cff = G.dt * F.pm[x] * F.pn[x];
+  const double *tr = F.t + XT(G.LBi, G.LBj, 1, nrhs, itrc) + x;
+  double *tn = F.t + XT(G.LBi, G.LBj, 1, nnew, itrc) + x;
+  const double *Hz = F.Hz + x;
+#pragma unroll
+  for (int q = 0; q < KCH; q++) {
+    if (k0 + q > N) break;
+    const size_t ok = (size_t)(k0 + q - 1) * nij;
+    const double *H = Hz + ok, *T = tr + ok;
+    const double h0 = H[0], t0 = T[0];
+    const double FX0 = ax0 * (h0 + H[-1]) * (t0 - T[-1]), FX1 = ax1 * (H[1] + h0) * (T[1] - t0);
+    const double FE0 = ae0 * (h0 + H[-ni]) * (t0 - T[-ni]), FE1 = ae1 * (H[ni] + h0) * (T[ni] - t0);
+    const double cff1 = cff * (FX1 - FX0);
+    const double cff2 = cff * (FE1 - FE0);
+    const double cff3 = cff1 + cff2;
+    tn[ok] = tn[ok] + cff3;
+  }
 }
 THREAD_GLOBAL(k_t3dmix2_s, KArgs)
 
