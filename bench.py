@@ -182,6 +182,8 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     from roms_amd import hiplib, hostlib, tiling
+    if os.environ.get("ROMS_HIP_TRACE"):     # debugging aid: every launch synchronous and named on stderr
+        hiplib.kprof(1)
 
     cs = params_for(args.workload, args.Lm, args.Mm, args.N, ntimes=args.steps + args.warmup)
     cs["ninfo"] = 1                          # NINFO of roms_benchmark1.in: diagnostics every step

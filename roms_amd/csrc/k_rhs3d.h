@@ -100,52 +100,61 @@ KDEV void hadv_flux_lds(const DGrid &G, const TB &B, int scheme, const double *T
 
 #define KCH 5   // levels per thread of the chunked point-wise kernels (grid.z = chunk)
 
-// The same fluxes for ONE u-face (hadv_fx_pt) or v-face (hadv_fe_pt), read straight from global
-// memory: used by the point-wise fused tracer kernels (k_pre_t3, k_s3t_hv), where every thread
-// evaluates the four face fluxes of its own cell.  T, Hu, Hv point at the level's plane.  The
-// expressions are those of hadv_flux_lds; the closed-edge replication of the first differences
-// (grad(Istr-1) = grad(Istr), grad(Iend+2) = grad(Iend+1)) is applied through the index.
-KDEV double hadv_fx_pt(const DGrid &G, int scheme, const double *T, const double *Hu, int i, int j) {
-  const double hu = Hu[X2(i, j)];
-  if (scheme == ROMS_C2) return hu * 0.5 * (T[X2(i - 1, j)] + T[X2(i, j)]);
-  if (scheme == ROMS_MPDATA || scheme == ROMS_HSIMT) return KMAX(hu, 0.0) * T[X2(i - 1, j)] + KMIN(hu, 0.0) * T[X2(i, j)];
-  const double eps = 1.0E-16, cff1 = 1.0 / 6.0, cff2 = 1.0 / 3.0;
-  const bool wfix = !G.ewp && G.T.west, efix = !G.ewp && G.T.east;
-#define GX_(ii_) ({ int q_ = (ii_); if (wfix && q_ == G.T.Istr - 1) q_ = G.T.Istr; if (efix && q_ == G.T.Iend + 2) q_ = G.T.Iend + 1; \
-                    T[X2(q_, j)] - T[X2(q_ - 1, j)]; })
-  const double gm = GX_(i - 1), g0 = GX_(i), gp = GX_(i + 1);
-#undef GX_
-  double wm, w0;   // wk(i-1), wk(i)
-  if (scheme == ROMS_U3) { wm = g0 - gm; w0 = gp - g0; }
-  else if (scheme == ROMS_A4) {
-    const double cm = 2.0 * g0 * gm, c0 = 2.0 * gp * g0;
-    wm = (cm > eps) ? cm / (g0 + gm) : 0.0;
-    w0 = (c0 > eps) ? c0 / (gp + g0) : 0.0;
-  } else { wm = 0.5 * (g0 + gm); w0 = 0.5 * (gp + g0); }
-  if (scheme == ROMS_U3)
-    return hu * 0.5 * (T[X2(i - 1, j)] + T[X2(i, j)]) - cff1 * (wm * KMAX(hu, 0.0) + w0 * KMIN(hu, 0.0));
-  return hu * 0.5 * (T[X2(i - 1, j)] + T[X2(i, j)] - cff2 * (w0 - wm));
+// The same fluxes at the four faces of ONE cell (i,j), read straight from global memory: used by the
+// point-wise fused tracer kernels (k_pre_t3, k_s3t_hv).  The five-point row and column of the tracer
+// are loaded once; the first differences grad(ii) = T(ii)-T(ii-1), ii = i-1..i+2, and the three
+// "wk" terms they form are shared by the two faces of a direction.  Expressions are those of
+// hadv_flux_lds; the closed-edge replication (grad(Istr-1) = grad(Istr), grad(Iend+2) = grad(Iend+1),
+// same along eta) is applied to the values.  Tc, Hu, Hv point at (i,j) of the level's plane.
+KDEV double hadv_wk(int scheme, double g0, double g1) {   // wk(m) from grad(m) = g0, grad(m+1) = g1
+  if (scheme == ROMS_U3) return g1 - g0;
+  if (scheme == ROMS_A4) {
+    const double eps = 1.0E-16, c = 2.0 * g1 * g0;
+    return (c > eps) ? c / (g1 + g0) : 0.0;
+  }
+  return 0.5 * (g1 + g0);
 }
-KDEV double hadv_fe_pt(const DGrid &G, int scheme, const double *T, const double *Hv, int i, int j) {
-  const double hv = Hv[X2(i, j)];
-  if (scheme == ROMS_C2) return hv * 0.5 * (T[X2(i, j - 1)] + T[X2(i, j)]);
-  if (scheme == ROMS_MPDATA || scheme == ROMS_HSIMT) return KMAX(hv, 0.0) * T[X2(i, j - 1)] + KMIN(hv, 0.0) * T[X2(i, j)];
-  const double eps = 1.0E-16, cff1 = 1.0 / 6.0, cff2 = 1.0 / 3.0;
-  const bool sfix = !G.nsp && G.T.south, nfix = !G.nsp && G.T.north;
-#define GE_(jj_) ({ int q_ = (jj_); if (sfix && q_ == G.T.Jstr - 1) q_ = G.T.Jstr; if (nfix && q_ == G.T.Jend + 2) q_ = G.T.Jend + 1; \
-                    T[X2(i, q_)] - T[X2(i, q_ - 1)]; })
-  const double gm = GE_(j - 1), g0 = GE_(j), gp = GE_(j + 1);
-#undef GE_
-  double wm, w0;
-  if (scheme == ROMS_U3) { wm = g0 - gm; w0 = gp - g0; }
-  else if (scheme == ROMS_A4) {
-    const double cm = 2.0 * g0 * gm, c0 = 2.0 * gp * g0;
-    wm = (cm > eps) ? cm / (g0 + gm) : 0.0;
-    w0 = (c0 > eps) ? c0 / (gp + g0) : 0.0;
-  } else { wm = 0.5 * (g0 + gm); w0 = 0.5 * (gp + g0); }
-  if (scheme == ROMS_U3)
-    return hv * 0.5 * (T[X2(i, j - 1)] + T[X2(i, j)]) - cff1 * (wm * KMAX(hv, 0.0) + w0 * KMIN(hv, 0.0));
-  return hv * 0.5 * (T[X2(i, j - 1)] + T[X2(i, j)] - cff2 * (w0 - wm));
+KDEV double hadv_face(int scheme, double h, double tm, double t0, double wm, double w0) {
+  const double cff1 = 1.0 / 6.0, cff2 = 1.0 / 3.0;
+  if (scheme == ROMS_U3) return h * 0.5 * (tm + t0) - cff1 * (wm * KMAX(h, 0.0) + w0 * KMIN(h, 0.0));
+  return h * 0.5 * (tm + t0 - cff2 * (w0 - wm));
+}
+KDEV void hadv4_pt(const DGrid &G, int scheme, const double *Tc, const double *Hu, const double *Hv, int i, int j,
+                   double &FX0, double &FXp, double &FE0, double &FEp) {
+  const long ni = G.ni;
+  const double hu0 = Hu[0], hup = Hu[1], hv0 = Hv[0], hvp = Hv[ni];
+  const double tc = Tc[0], tw = Tc[-1], te = Tc[1], ts = Tc[-ni], tn = Tc[ni];
+  if (scheme == ROMS_C2) {
+    FX0 = hu0 * 0.5 * (tw + tc); FXp = hup * 0.5 * (tc + te);
+    FE0 = hv0 * 0.5 * (ts + tc); FEp = hvp * 0.5 * (tc + tn);
+    return;
+  }
+  if (scheme == ROMS_MPDATA || scheme == ROMS_HSIMT) {
+    FX0 = KMAX(hu0, 0.0) * tw + KMIN(hu0, 0.0) * tc; FXp = KMAX(hup, 0.0) * tc + KMIN(hup, 0.0) * te;
+    FE0 = KMAX(hv0, 0.0) * ts + KMIN(hv0, 0.0) * tc; FEp = KMAX(hvp, 0.0) * tc + KMIN(hvp, 0.0) * tn;
+    return;
+  }
+  const bool wfix = !G.ewp && G.T.west && i == G.T.Istr, efix = !G.ewp && G.T.east && i == G.T.Iend;
+  const bool sfix = !G.nsp && G.T.south && j == G.T.Jstr, nfix = !G.nsp && G.T.north && j == G.T.Jend;
+  {
+    const double tww = Tc[-2], tee = Tc[2];
+    double gm = tw - tww, g0 = tc - tw, g1 = te - tc, g2 = tee - te;     // grad(i-1), grad(i), grad(i+1), grad(i+2)
+    if (wfix) gm = g0;
+    if (efix) g2 = g1;
+    const double wkm = hadv_wk(scheme, gm, g0), wk0 = hadv_wk(scheme, g0, g1), wkp = hadv_wk(scheme, g1, g2);
+    FX0 = hadv_face(scheme, hu0, tw, tc, wkm, wk0);
+    FXp = hadv_face(scheme, hup, tc, te, wk0, wkp);
+  }
+  {
+    // a closed edge has one boundary row only: the replaced difference is not read beyond the array
+    const double tss = Tc[sfix ? -ni : -2 * ni], tnn = Tc[nfix ? ni : 2 * ni];
+    double gm = ts - tss, g0 = tc - ts, g1 = tn - tc, g2 = tnn - tn;
+    if (sfix) gm = g0;
+    if (nfix) g2 = g1;
+    const double wkm = hadv_wk(scheme, gm, g0), wk0 = hadv_wk(scheme, g0, g1), wkp = hadv_wk(scheme, g1, g2);
+    FE0 = hadv_face(scheme, hv0, ts, tc, wkm, wk0);
+    FEp = hadv_face(scheme, hvp, tc, tn, wk0, wkp);
+  }
 }
 
 // tracers whose predictor (pre_step3d) is done by the fused point kernel k_pre_t3: all but those
@@ -330,8 +339,8 @@ THREAD_KERNEL(k_pre_t3, KArgs) {
     const double *Tk = T + ok;
     const double *Hu = F.Huon + ok, *Hv = F.Hvom + ok;
     // horizontal
-    const double FXp = hadv_fx_pt(G, hs, Tk, Hu, i + 1, j), FX0 = hadv_fx_pt(G, hs, Tk, Hu, i, j);
-    const double FEp = hadv_fe_pt(G, hs, Tk, Hv, i, j + 1), FE0 = hadv_fe_pt(G, hs, Tk, Hv, i, j);
+    double FX0, FXp, FE0, FEp;
+    hadv4_pt(G, hs, Tk + x, Hu + x, Hv + x, i, j, FX0, FXp, FE0, FEp);
     const double Hzk = F.Hz[ok + x];
     const double t3h = Hzk * (cff1 * tt[q + 2] + cff2 * tnew[ok]) - cff * pmv * pnv * (FXp - FX0 + FEp - FE0);
     // vertical
@@ -644,8 +653,10 @@ THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
   const double c##0 = F.pmon_p[o], c##1 = pn[(o) - ni] + pn[o], c##2 = pn[(o) - 1 - ni] + pn[(o) - 1], \
                c##3 = F.pnom_p[o], c##4 = pm[(o) - 1] + pm[o], c##5 = pm[(o) - 1 - ni] + pm[(o) - ni]
   RSET(r0_, x); PSET(p0_, x);
-  RSET(rw_, x - 1); PSET(pn_, x + ni);     // u-point: rho point (i-1,j), psi point (i,j+1)
-  RSET(rs_, x - ni); PSET(pe_, x + 1);     // v-point: rho point (i,j-1), psi point (i+1,j)
+  // (a point that has no u- or v-point reads its own rho point instead: rows below j-1 may not exist)
+  const long xw = do_u ? x - 1 : x, xs = do_v ? x - ni : x;
+  RSET(rw_, xw); PSET(pn_, x + ni);        // u-point: rho point (i-1,j), psi point (i,j+1)
+  RSET(rs_, xs); PSET(pe_, x + 1);         // v-point: rho point (i,j-1), psi point (i+1,j)
 #undef RSET
 #undef PSET
   const double fur1 = F.on_r[x] * F.on_r[x] * F.visc2_r[x], fur0 = F.on_r[x - 1] * F.on_r[x - 1] * F.visc2_r[x - 1];

@@ -249,8 +249,10 @@ THREAD_KERNEL(k_s3t_hv, KArgs) {
     const size_t ok = (size_t)(k - 1) * nij;
     const double *T3k = T3 + ok;
     const double *Hu = F.Huon + ok, *Hv = F.Hvom + ok;
-    const double cff1 = cff * (hadv_fx_pt(G, hs, T3k, Hu, i + 1, j) - hadv_fx_pt(G, hs, T3k, Hu, i, j));
-    const double cff2 = cff * (hadv_fe_pt(G, hs, T3k, Hv, i, j + 1) - hadv_fe_pt(G, hs, T3k, Hv, i, j));
+    double FX0, FXp, FE0, FEp;
+    hadv4_pt(G, hs, T3k + x, Hu + x, Hv + x, i, j, FX0, FXp, FE0, FEp);
+    const double cff1 = cff * (FXp - FX0);
+    const double cff2 = cff * (FEp - FE0);
     const double cff3 = cff1 + cff2;
     double tt = tn[ok] - cff3;
     const double cv = cff * (FC[q + 1] - FC[q]);
