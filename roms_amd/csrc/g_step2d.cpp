@@ -8,7 +8,7 @@ int run_step2d(roms_hip_ctx *c) {
   const roms_hip_config &cf = c->cfg;
   Step2dArgs a;
   a.G = G;
-  a.Fp = c->d_F;
+  S2F_FILL(a.F, c->F);
   const int iif = G.iif;
   a.w1_m1 = (iif >= 2) ? cf.weight[0][iif - 1] : 0.0;
   a.w2_0 = cf.weight[1][iif];
@@ -21,15 +21,18 @@ int run_step2d(roms_hip_ctx *c) {
     c->m2d_dirty = false;
   }
   // kernel variant by sub-tile size: up to 32x4, up to 64x8, generic (ROMS_HIP_TILE2D overrides)
-  int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
+  int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 32 && G.bh2 <= 8) ? 3 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
   if (getenv("ROMS_HIP_S2D_GENERIC")) variant = 2;
 #ifdef ROMS_CPU_EMU
   variant = 2;   // the serial emulation has one "thread": only the generic form applies
 #endif
-  const int tw = variant == 0 ? 38 : variant == 1 ? 70 : G.bw2 + 6, th = variant == 0 ? 10 : variant == 1 ? 14 : G.bh2 + 6;
+  const int tw = variant == 0 || variant == 3 ? 38 : variant == 1 ? 70 : G.bw2 + 6;
+  const int th = variant == 0 ? 10 : variant == 1 || variant == 3 ? 14 : G.bh2 + 6;
   const size_t lds = (size_t)STEP2D_NLDS * (size_t)tw * (size_t)th;
   if (variant == 0) {
     LAUNCH_COOP_AS(k_step2d, k_step2d_a, G.nbx2, G.nby2, 1, 384, lds, c->stream, a);
+  } else if (variant == 3) {
+    LAUNCH_COOP_AS(k_step2d, k_step2d_c, G.nbx2, G.nby2, 1, 512, lds, c->stream, a);
   } else if (variant == 1) {
 #ifndef ROMS_CPU_EMU
     static bool big_lds = false;

@@ -36,9 +36,26 @@
 #include "k_haloblock.h"
 
 
+// The arrays of the barotropic step, by value in the kernel arguments: the kernel is latency bound and
+// a pointer taken from the device-resident table costs one more dependent memory round trip before
+// the first data load can be issued.
+struct S2Fields {
+  GPtr zeta, ubar, vbar, h, on_u, om_v, pm, pn, rhoA, rhoS, Zt_avg1, DU_avg1, DU_avg2, DV_avg1, DV_avg2,
+      rzeta, rubar, rvbar, rufrc, rvfrc, ru, rv, m2r, m2p, xr;
+};
+#define S2F_FILL(dst, src)                                                                               \
+  do {                                                                                                   \
+    (dst).zeta = (src).zeta; (dst).ubar = (src).ubar; (dst).vbar = (src).vbar; (dst).h = (src).h;        \
+    (dst).on_u = (src).on_u; (dst).om_v = (src).om_v; (dst).pm = (src).pm; (dst).pn = (src).pn;          \
+    (dst).rhoA = (src).rhoA; (dst).rhoS = (src).rhoS; (dst).Zt_avg1 = (src).Zt_avg1;                     \
+    (dst).DU_avg1 = (src).DU_avg1; (dst).DU_avg2 = (src).DU_avg2; (dst).DV_avg1 = (src).DV_avg1;         \
+    (dst).DV_avg2 = (src).DV_avg2; (dst).rzeta = (src).rzeta; (dst).rubar = (src).rubar;                 \
+    (dst).rvbar = (src).rvbar; (dst).rufrc = (src).rufrc; (dst).rvfrc = (src).rvfrc; (dst).ru = (src).ru; \
+    (dst).rv = (src).rv; (dst).m2r = (src).m2r; (dst).m2p = (src).m2p; (dst).xr = (src).xr;              \
+  } while (0)
 struct Step2dArgs {
   DGrid G;
-  const Fields *Fp;   // device-resident table of array pointers (roms_hip_ctx::d_F)
+  S2Fields F;
   double w1_m1;        // weight(1,iif-1)
   double w2_0, w2_p1;  // weight(2,iif), weight(2,iif+1)
 };
@@ -110,7 +127,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
   (void)bz;
   constexpr bool FIXED = BWC > 0;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const S2Fields &F = a.F;
   const TB B = block_bounds2(G, bx, by);
   const int OW = FIXED ? BWC : G.bw2, OH = FIXED ? BHC : G.bh2, NOWN = OW * OH;
   const int TW = OW + 6, TH = OH + 6, NTILE = TW * TH, NT = FIXED ? NTC : KNT;
@@ -558,5 +575,7 @@ COOP_KERNEL(k_step2d_a, Step2dArgs) { k_step2d_t_body<32, 4, 384, 1>(a, bx, by, 
 COOP_GLOBAL_LB(k_step2d_a, Step2dArgs, 384)
 COOP_KERNEL(k_step2d_b, Step2dArgs) { k_step2d_t_body<64, 8, 512, 2>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d_b, Step2dArgs, 512)
+COOP_KERNEL(k_step2d_c, Step2dArgs) { k_step2d_t_body<32, 8, 512, 2>(a, bx, by, bz, lds); }
+COOP_GLOBAL_LB(k_step2d_c, Step2dArgs, 512)
 COOP_KERNEL(k_step2d, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)
