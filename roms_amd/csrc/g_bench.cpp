@@ -10,7 +10,7 @@ static inline size_t lds_sz(const DGrid &G) { return (size_t)(G.bw + 6) * (size_
 static inline KArgs mk(roms_hip_ctx *c) {
   KArgs a;
   a.G = c->G;
-  a.Fp = c->d_F;
+  a.Fv = c->F;
   a.p0 = a.p1 = a.p2 = 0;
   return a;
 }
@@ -45,7 +45,7 @@ int run_swdk(roms_hip_ctx *c) {
   const int J = c->cfg.lmd_Jwt;
   if (J < 1 || J > 9) { set_error("lmd_Jwt out of range"); return 5; }
   SwArgs a;
-  a.G = G; a.Fp = c->d_F;
+  a.G = G; a.Fv = c->F;
   a.fac1 = -1.0 / k_mu1[J - 1]; a.fac2 = -1.0 / k_mu2[J - 1]; a.fac3 = k_r1[J - 1];
   LAUNCH_THREAD(k_swdk, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
   return 0;
@@ -57,7 +57,7 @@ int run_lmd_vmix(roms_hip_ctx *c) {
   const int N = G.N, J = c->cfg.lmd_Jwt;
   if (J < 1 || J > 9) { set_error("lmd_Jwt out of range"); return 5; }
   LmdArgs a;
-  a.G = G; a.Fp = c->d_F;
+  a.G = G; a.Fv = c->F;
   a.fac1 = -1.0 / k_mu1[J - 1]; a.fac2 = -1.0 / k_mu2[J - 1]; a.fac3 = k_r1[J - 1];
   const double lmd_Cstar = 10.0, lmd_Cv = 1.25, lmd_Ric = 0.3, lmd_betaT = -0.2, lmd_cs = 98.96, lmd_epsilon = 0.1,
                vonKar = 0.41;
@@ -78,7 +78,7 @@ int run_bulk_flux(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   BulkArgs a;
-  a.G = G; a.Fp = c->d_F;
+  a.G = G; a.Fv = c->F;
   a.ZW = c->cfg.blk_ZW; a.ZT = c->cfg.blk_ZT; a.ZQ = c->cfg.blk_ZQ;
   LAUNCH_THREAD(k_bulk_pt, B.IendR - (B.Istr - 1) + 1, B.JendR - (B.Jstr - 1) + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_bulk_str, B.IendR - KMIN(B.Istr, B.IstrR) + 1, B.JendR - KMIN(B.Jstr, B.JstrR) + 1, 1, c->stream, a);
@@ -127,7 +127,7 @@ int run_set_data_benchmark(roms_hip_ctx *c) {
   const TB &B = G.T;
   const double pi = 3.14159265358979323846, deg2rad = pi / 180.0;
   SetDataBmArgs a;
-  a.G = G; a.Fp = c->d_F;
+  a.G = G; a.Fv = c->F;
   double yday, hour;
   roms_caldate(G.tdays, &yday, &hour);
   double Dangle = 23.44 * cos((172.0 - yday) * 2.0 * pi / 365.2425);   // ana_srflux.h:215-220

@@ -9,7 +9,7 @@ int run_diag_async(roms_hip_ctx *c, double *d_out) {
   const TB &B = G.T;
   DiagArgs a;
   a.G = G;
-  a.Fp = c->d_F;
+  a.Fv = c->F;
   a.col = c->d_diagwork;
   a.row = c->d_diagwork + 9 * (size_t)G.nij;
   a.out = d_out;

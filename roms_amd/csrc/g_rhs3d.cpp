@@ -5,7 +5,7 @@
 static inline KArgs mk(roms_hip_ctx *c, int p0 = 0, int p1 = 0, int p2 = 0) {
   KArgs a;
   a.G = c->G;
-  a.Fp = c->d_F;
+  a.Fv = c->F;
   a.p0 = p0; a.p1 = p1; a.p2 = p2;
   return a;
 }

@@ -16,7 +16,7 @@ int run_step2d(roms_hip_ctx *c) {
   if (c->m2d_dirty) {   // (re)build the packed metric records after the grid arrays were uploaded
     PackArgs pa;
     pa.G = G;
-    pa.Fp = c->d_F;
+    pa.Fv = c->F;
     LAUNCH_THREAD(k_pack_m2d, G.ni, G.nj, 1, c->stream, pa);
     c->m2d_dirty = false;
   }

@@ -6,7 +6,7 @@
 static inline KArgs mk(roms_hip_ctx *c, int p0 = 0) {
   KArgs a;
   a.G = c->G;
-  a.Fp = c->d_F;
+  a.Fv = c->F;
   a.p0 = p0; a.p1 = 0; a.p2 = 0;
   return a;
 }
@@ -68,7 +68,7 @@ int run_step3d_t(roms_hip_ctx *c) {
   for (int it = 1; it <= G.NT && any_mp; it++) {
     if (G.hadv[it - 1] != ROMS_MPDATA) continue;
     MpArgs m;
-    m.G = G; m.Fp = c->d_F; m.itrc = it;
+    m.G = G; m.Fv = c->F; m.itrc = it;
     const int LmT = B.Iend - B.Istr + 1, MmT = B.Jend - B.Jstr + 1;
     LAUNCH_THREAD(k_mp_ta, B.Iendp2i - B.IstrUm2 + 1, B.Jendp2i - B.JstrVm2 + 1, N, c->stream, m);
     LAUNCH_THREAD(k_mp_uva, B.Iendp2 - (B.IstrU - 1) + 1, B.Jendp2 - KMIN(B.JstrV - 1, B.JstrVm1) + 1, 2 * N, c->stream, m);

@@ -69,7 +69,7 @@ KDEV EosLevel eos_level(double Tt_in, double Ts_in, double Tp) {
 THREAD_KERNEL(k_eos_nl, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, N = G.N, nrhs = G.nrhs;
   const double g = G.g;
   double rhoA = 0.0, rhoS = 0.0;
@@ -125,7 +125,7 @@ THREAD_GLOBAL(k_eos_nl, KArgs)
 #define GEO_NLDS 12
 COOP_KERNEL(k_t3dmix2_geo, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB B = block_bounds(G, bx, by);
   const int k = bz % G.N + 1, itrc = bz / G.N + 1, N = G.N;
   const int nrhs = G.nrhs, nnew = G.nnew;
@@ -266,7 +266,7 @@ KDEV double blk_psit(double ZoL) {
 
 struct BulkArgs {
   DGrid G;
-  const Fields *Fp;   // device-resident table of array pointers (roms_hip_ctx::d_F)
+  Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
   double ZW, ZT, ZQ;
 };
 
@@ -275,7 +275,7 @@ struct BulkArgs {
 THREAD_KERNEL(k_bulk_pt, BulkArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = B.Istr - 1 + gx, j = B.Jstr - 1 + gy, N = G.N, nrhs = G.nrhs;
   const double StefBo = 5.67E-8, emmiss = 0.97, blk_Cpa = 1004.67, blk_Cpw = 4000.0, blk_Rgas = 287.1, blk_Zabl = 600.0,
@@ -388,7 +388,7 @@ THREAD_GLOBAL(k_bulk_pt, BulkArgs)
 THREAD_KERNEL(k_bulk_str, BulkArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = KMIN(B.Istr, B.IstrR) + gx, j = KMIN(B.Jstr, B.JstrR) + gy;
   const double cff = 0.5 / G.rho0;
@@ -400,14 +400,14 @@ THREAD_GLOBAL(k_bulk_str, BulkArgs)
 // -------------------------------------------------------------------------- set_data (BENCHMARK)
 struct SetDataBmArgs {
   DGrid G;
-  const Fields *Fp;   // device-resident table of array pointers (roms_hip_ctx::d_F)
+  Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
   double Dangle, Hangle;   // solar declination and hour angle of this step (host: caldate)
 };
 // index space (IstrT:IendT, JstrT:JendT)
 THREAD_KERNEL(k_set_data_bm, SetDataBmArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy;
   const double deg2rad = 3.14159265358979323846 / 180.0, Csolar = 1353.0, alb_w = 0.06;
   const double cl = 0.6, Ta = 4.0, Ha = 0.8;
@@ -441,13 +441,13 @@ THREAD_GLOBAL(k_set_data_bm, SetDataBmArgs)
 // ---------------------------------------------------------------- solar penetration (pre_step3d)
 struct SwArgs {
   DGrid G;
-  const Fields *Fp;   // device-resident table of array pointers (roms_hip_ctx::d_F)
+  Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
   double fac1, fac2, fac3;   // Zscale/lmd_mu1(Jwt), Zscale/lmd_mu2(Jwt), lmd_r1(Jwt) with Zscale = -1
 };
 // swdk(i,j,k) into wrk3[5] for k = 1..N-1; index space (Istr:Iend, Jstr:Jend, N-1)
 THREAD_KERNEL(k_swdk, SwArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz + 1, N = G.N;
   const double Z = F.z_w[XW(i, j, N)] - F.z_w[XW(i, j, k)];
   F.wrk3[5][XW(i, j, k)] = exp(Z * a.fac1) * a.fac3 + exp(Z * a.fac2) * (1.0 - a.fac3);

@@ -14,7 +14,7 @@
 
 struct DiagArgs {
   DGrid G;
-  const Fields *Fp;   // device-resident table of array pointers (roms_hip_ctx::d_F)
+  Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
   double *col;   // 8 planes of nij doubles: ke2d pe2d C Cu Cv Cw kmax speed
   double *row;   // 12 rows of ni doubles
   double *out;   // 16 doubles
@@ -23,7 +23,7 @@ struct DiagArgs {
 THREAD_KERNEL(k_diag_col, DiagArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N, idia = G.nstp;
   const double g = G.g, dt = G.dt;
   const double *u = F.u + (size_t)(idia - 1) * G.nij * N, *v = F.v + (size_t)(idia - 1) * G.nij * N;

@@ -20,7 +20,7 @@
 
 struct KArgs {
   DGrid G;
-  const Fields *Fp;   // device-resident table of array pointers (roms_hip_ctx::d_F)
+  Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
   int p0, p1, p2;
 };
 
@@ -33,7 +33,7 @@ struct KArgs {
 // index space: (IstrT:IendT, JstrT:JendT, 1:N)
 THREAD_KERNEL(k_set_depth, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, k = gz + 1;
   const double hc = G.hc;
   const double hwater = F.h[X2(i, j)];
@@ -84,7 +84,7 @@ THREAD_GLOBAL(k_set_depth, KArgs)
 // min(IstrP,IstrT), min(JstrT,JstrP)
 THREAD_KERNEL(k_set_massflux, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = KMIN(B.IstrP, B.IstrT) + gx, j = KMIN(B.JstrT, B.JstrP) + gy, k = gz + 1;
   const int nrhs = G.nrhs;
@@ -102,7 +102,7 @@ THREAD_GLOBAL(k_set_massflux, KArgs)
 THREAD_KERNEL(k_rho_eos_lin, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, N = G.N, nrhs = G.nrhs;
   const bool salt = (G.options & ROMS_SALINITY) != 0;
   const bool kpp = (G.options & ROMS_LMD_MIXING) != 0;   // BV_FREQUENCY and expansion coefficients :751-780
@@ -142,7 +142,7 @@ THREAD_GLOBAL(k_rho_eos_lin, KArgs)
 THREAD_KERNEL(k_set_vbc, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = B.IstrR + gx, j = B.JstrR + gy, N = G.N, nrhs = G.nrhs;
   F.stflx[X2T(i, j, 1)] = F.stflux[X2T(i, j, 1)];
@@ -180,7 +180,7 @@ THREAD_GLOBAL(k_set_vbc, KArgs)
 // index space (IstrT:IendT, JstrT:JendT, 1:N-1)
 THREAD_KERNEL(k_ana_vmix, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, k = gz + 1;
   F.Akv[XW(i, j, k)] = 2.0E-03 + 8.0E-03 * exp(F.z_w[XW(i, j, k)] / 150.0);
   F.Akt[XW4(i, j, k, 1)] = G.Akt_bak[0];
@@ -193,7 +193,7 @@ THREAD_GLOBAL(k_ana_vmix, KArgs)
 THREAD_KERNEL(k_set_data_upw, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = KMIN(B.IstrP, B.IstrT) + gx, j = KMIN(B.JstrP, B.JstrT) + gy;
   const double pi = 3.14159265358979323846;
@@ -223,7 +223,7 @@ THREAD_GLOBAL(k_set_data_upw, KArgs)
 THREAD_KERNEL(k_omega, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
   // Both sweeps load eight levels before using them, so that the loads overlap.
   const double *Huon = F.Huon, *Hvom = F.Hvom, *z_w = F.z_w;
@@ -259,7 +259,7 @@ THREAD_GLOBAL(k_omega, KArgs)
 // vert(i,j,k) into F.wrk3[0]; index space (Istr:Iend, Jstr:Jend, 1:N); p0 = Ninp
 THREAD_KERNEL(k_wvel_vert, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz + 1, Ninp = a.p0;
   const double wi = F.u[X4(i, j, k, Ninp)] * (F.z_r[X3(i, j, k)] - F.z_r[X3(i - 1, j, k)]) *
                     (F.pm[X2(i - 1, j)] + F.pm[X2(i, j)]);
@@ -278,7 +278,7 @@ THREAD_GLOBAL(k_wvel_vert, KArgs)
 // wvel(i,j,k), k = 0..N; index space (Istr:Iend, Jstr:Jend, 0:N)
 THREAD_KERNEL(k_wvel, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz, N = G.N;
   const double *vert = F.wrk3[0];
   const double cff1 = 3.0 / 8.0, cff2 = 3.0 / 4.0, cff3 = 1.0 / 8.0, cff4 = 9.0 / 16.0, cff5 = 1.0 / 16.0;
@@ -315,7 +315,7 @@ THREAD_GLOBAL(k_wvel, KArgs)
 THREAD_KERNEL(k_set_zeta, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.IstrR + gx, j = G.T.JstrR + gy;
   const double z = F.Zt_avg1[X2(i, j)];
   F.zeta[X2T(i, j, 1)] = z;
@@ -327,7 +327,7 @@ THREAD_GLOBAL(k_set_zeta, KArgs)
 THREAD_KERNEL(k_copy_zt, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy;
   F.Zt_avg1[X2(i, j)] = F.zeta[X2T(i, j, a.p0)];
 }
@@ -338,7 +338,7 @@ THREAD_GLOBAL(k_copy_zt, KArgs)
 THREAD_KERNEL(k_ini_bar, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = KMIN(B.IstrM, B.IstrB) + gx, j = B.JstrB + gy, N = G.N, nstp = G.nstp, kstp = G.kstp;
   if (i >= B.IstrM && i <= B.IendB) {

@@ -15,7 +15,7 @@
 
 struct LmdArgs {
   DGrid G;
-  const Fields *Fp;   // device-resident table of array pointers (roms_hip_ctx::d_F)
+  Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
   double fac1, fac2, fac3;   // lmd_swfrac coefficients for Zscale = -1 and this Jerlov water type
   double lmd_Cg, Vtc;
 };
@@ -62,7 +62,7 @@ KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const d
 THREAD_KERNEL(k_lmd_interior, LmdArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   LMD_CONSTS;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
   const double eps = 1.0E-14;
@@ -112,7 +112,7 @@ KDEV void lmd_wscale(double Ustar, double zetahat, double Ustar3, double &wm, do
 THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   LMD_CONSTS;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
   const double eps = 1.0E-10, g = G.g, gorho0 = G.g / G.rho0;
@@ -255,7 +255,7 @@ THREAD_GLOBAL(k_lmd_skpp, LmdArgs)
 // convective adjustment: point-wise; index space (Istr:Iend, Jstr:Jend, N-1)
 THREAD_KERNEL(k_lmd_finish, LmdArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   LMD_CONSTS;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz + 1;
   double cff = KMAX(F.bvf[XW(i, j, k)], lmd_bvfcon);

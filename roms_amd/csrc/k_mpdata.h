@@ -17,7 +17,7 @@
 
 struct MpArgs {
   DGrid G;
-  const Fields *Fp;
+  Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
   int itrc;
 };
 
@@ -54,7 +54,7 @@ struct MpArgs {
 // mpdata_adiff fills (:224-290)
 THREAD_KERNEL(k_mp_ta, MpArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = B.IstrUm2 + gx, j = B.JstrVm2 + gy, k = gz + 1, N = G.N, itrc = a.itrc;
   if (i > B.Iendp2i || j > B.Jendp2i) return;
@@ -93,7 +93,7 @@ THREAD_GLOBAL(k_mp_ta, MpArgs)
 //      JstrVm1:Jendp2), mpdata_adiff.F:307-640, with the closed-wall values :642-720 ------------
 THREAD_KERNEL(k_mp_uva, MpArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int N = G.N, itrc = a.itrc;
   const int dir = gz / N, k = gz % N + 1;
@@ -198,7 +198,7 @@ THREAD_GLOBAL(k_mp_uva, MpArgs)
 // ---- Wa, mpdata_adiff.F:722-860; index space (IstrU-1:Iendp1, JstrV-1:Jendp1, 0:N) -----------
 THREAD_KERNEL(k_mp_wa, MpArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int N = G.N, itrc = a.itrc;
   const int i = B.IstrU - 1 + gx, j = B.JstrV - 1 + gy, k = gz;
@@ -256,7 +256,7 @@ THREAD_GLOBAL(k_mp_wa, MpArgs)
 // ---- FCT ratios beta_up, beta_dn :862-1090; index space (IstrU-1:Iendp1, JstrV-1:Jendp1, 1:N) -
 THREAD_KERNEL(k_mp_beta, MpArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int N = G.N, itrc = a.itrc;
   const int i = B.IstrU - 1 + gx, j = B.JstrV - 1 + gy, k = gz + 1;
@@ -290,7 +290,7 @@ THREAD_GLOBAL(k_mp_beta, MpArgs)
 // ---- limited anti-diffusive velocities :1100-1220 (in place); index space (Istr:Iend+1, Jstr:Jend+1, 1:N)
 THREAD_KERNEL(k_mp_limit, MpArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int N = G.N;
   const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1;
@@ -327,7 +327,7 @@ THREAD_GLOBAL(k_mp_limit, MpArgs)
 // ---- corrected fluxes :1399-1500: t(nnew) = Ta*Hz - div(anti-diffusive fluxes); (Istr:Iend, Jstr:Jend, 1:N)
 THREAD_KERNEL(k_mp_apply, MpArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int N = G.N, itrc = a.itrc;
   const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1;
@@ -357,7 +357,7 @@ THREAD_GLOBAL(k_mp_apply, MpArgs)
 THREAD_KERNEL(k_mp_vdiff, MpArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int N = G.N, itrc = a.itrc, ltrc = KMIN(G.NAT, itrc);
   const int i = B.Istr + gx, j = B.Jstr + gy;

@@ -164,7 +164,7 @@ KDEV bool pre_point_path(const DGrid &G, int itrc) { return G.vadv[itrc - 1] != 
 // pre_step3d: t(3) = Hz*(cff1*t(nstp)+cff2*t(nnew)) - cff*pm*pn*div(FX,FE); grid.z = (k-1)+N*(itrc-1)
 COOP_KERNEL(k_pre_t3h, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB B = block_bounds(G, bx, by);
   const int k = bz % G.N + 1, itrc = bz / G.N + 1;
   if (pre_point_path(G, itrc)) return;            // k_pre_t3 (uniform over the block)
@@ -271,7 +271,7 @@ KDEV void vspline_flux(const DGrid &G, const Fields &F, int i, int j, const doub
 // pre_step3d vertical part: one thread per column and tracer; index space (Istr:Iend,Jstr:Jend,NT)
 THREAD_KERNEL(k_pre_t3v, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = G.N;
   if (pre_point_path(G, itrc)) return;            // k_pre_t3
   const int vs = G.vadv[itrc - 1];
@@ -306,7 +306,7 @@ THREAD_GLOBAL(k_pre_t3v, KArgs)
 // changing any operation.
 THREAD_KERNEL(k_pre_t3, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * KCH + 1;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
   if (k0 > N || !pre_point_path(G, itrc)) return;
@@ -359,7 +359,7 @@ THREAD_GLOBAL(k_pre_t3, KArgs)
 // depend on the level is done once per chunk.
 THREAD_KERNEL(k_pre_new, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N;
   const int k0 = gz * KCH + 1;                     // levels k0 .. k0+KCH-1, interfaces k0-1 .. k0+KCH-1
@@ -474,7 +474,7 @@ THREAD_GLOBAL(k_pre_new, KArgs)
 THREAD_KERNEL(k_prs_P, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.IstrU - 1 + gx, j = G.T.JstrV - 1 + gy, N = G.N;
   const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0, eps = 1.0E-10;
   const double g = G.g, GRho = g / G.rho0, HalfGRho = 0.5 * GRho;
@@ -533,7 +533,7 @@ THREAD_GLOBAL(k_prs_P, KArgs)
 // ru,rv(nrhs) from P: point-wise 3-D; index space (min(IstrU,Istr):Iend, min(Jstr,JstrV):Jend, 1:N)
 THREAD_KERNEL(k_prs_grad, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, nrhs = G.nrhs;
   const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0, eps = 1.0E-10;
@@ -594,7 +594,7 @@ THREAD_GLOBAL(k_prs_grad, KArgs)
 // point-wise 3-D; index space (Istr:Iend, Jstr:Jend, N*NT)
 THREAD_KERNEL(k_t3dmix2_s, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * KCH + 1;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
   if (k0 > N) return;
@@ -634,7 +634,7 @@ THREAD_GLOBAL(k_t3dmix2_s, KArgs)
 // the stress expressions is formed once per chunk, in the reference's association order.
 THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs, nnew = G.nnew;
   const int k0 = gz * KCH + 1;
@@ -723,7 +723,7 @@ THREAD_GLOBAL(k_uv3dmix2_s, KArgs)
 THREAD_KERNEL(k_uv3dmix2_sum, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N;
   // eight levels are loaded before they are added (in order), so that the loads overlap
@@ -765,7 +765,7 @@ THREAD_GLOBAL(k_uv3dmix2_sum, KArgs)
 // p0 = number of chunks.
 THREAD_KERNEL(k_rhs3d_pt, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int nch = a.p0, dir = gz / nch, k0 = (gz - dir * nch) * KCH + 1;
   const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs;
@@ -989,7 +989,7 @@ THREAD_GLOBAL(k_rhs3d_pt, KArgs)
 THREAD_KERNEL(k_rhs3d_sum, KArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs;
   const double *ru = F.ru + (size_t)(nrhs - 1) * G.nij * (N + 1), *rv = F.rv + (size_t)(nrhs - 1) * G.nij * (N + 1);

@@ -75,12 +75,12 @@ enum { MP_V2 = 0, MP_PMON, MP_PNOM, MP_OM, MP_ON, MP_ONU, MP_OMV, MP_SPARE };   
 
 struct PackArgs {
   DGrid G;
-  const Fields *Fp;
+  Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
 };
 THREAD_KERNEL(k_pack_m2d, PackArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const size_t x = (size_t)gx + (size_t)gy * (size_t)G.ni;
   double *r = F.m2r + 8 * x, *p = F.m2p + 8 * x;
   r[MR_FOMN] = F.fomn[x]; r[MR_DNDX] = F.dndx[x]; r[MR_DMDE] = F.dmde[x]; r[MR_V2] = F.visc2_r[x];

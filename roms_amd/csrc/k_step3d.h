@@ -19,7 +19,7 @@
 // grid.z = 0: u on (IstrU:Iend, Jstr:Jend); 1: v on (Istr:Iend, JstrV:Jend)
 THREAD_KERNEL(k_s3uv_col, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int dir = gz;
   const int i = (dir == 0 ? B.IstrU : B.Istr) + gx, j = (dir == 0 ? B.Jstr : B.JstrV) + gy;
@@ -145,7 +145,7 @@ THREAD_GLOBAL(k_s3uv_col, KArgs)
 // grid.z = 0: u part on (IstrP:IendT, JstrT:JendT); 1: v part on (IstrT:IendT, Jstr:JendT)
 THREAD_KERNEL(k_s3uv_couple, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB &B = G.T;
   const int dir = gz;
   const int i = (dir == 0 ? B.IstrP : B.IstrT) + gx, j = (dir == 0 ? B.JstrT : B.Jstr) + gy;
@@ -225,7 +225,7 @@ KDEV bool s3t_point_path(const DGrid &G, int itrc) {
 // point only, so they are fused without changing any operation.
 THREAD_KERNEL(k_s3t_hv, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * KCH + 1;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
   if (k0 > N || !s3t_point_path(G, itrc)) return;
@@ -267,7 +267,7 @@ THREAD_GLOBAL(k_s3t_hv, KArgs)
 #define S3T_NLDS 4
 COOP_KERNEL(k_s3t_h, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const TB B = block_bounds(G, bx, by);
   const int k = bz % G.N + 1, itrc = bz / G.N + 1;
   if (G.hadv[itrc - 1] == ROMS_MPDATA) return;   // k_mpdata.h (uniform over the block)
@@ -344,7 +344,7 @@ COOP_GLOBAL(k_s3t_h, KArgs)
 // index space (Istr:Iend, Jstr:Jend, NT).  (MPDATA tracers are handled in k_mpdata.h.)
 THREAD_KERNEL(k_s3t_col, KArgs) {
   const DGrid &G = a.G;
-  const Fields &F = *a.Fp;
+  const Fields &F = a.Fv;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = G.N;
   const int vs = G.vadv[itrc - 1], ltrc = KMIN(G.NAT, itrc);
   if (vs == ROMS_MPDATA) return;                 // k_mpdata.h
