@@ -35,7 +35,8 @@ int run_eos_nonlinear(roms_hip_ctx *c) {
 int run_t3dmix2_geo(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   KArgs a = mk(c);
-  LAUNCH_COOP(k_t3dmix2_geo, G.nbx, G.nby, G.N * G.NT, 256, GEO_NLDS * lds_sz(G), c->stream, a);
+  a.p0 = (G.N + KCH - 1) / KCH;
+  LAUNCH_THREAD(k_t3dmix2_geo, G.T.Iend - G.T.Istr + 1, G.T.Jend - G.T.Jstr + 1, a.p0 * G.NT, c->stream, a);
   return 0;
 }
 

@@ -119,118 +119,108 @@ THREAD_KERNEL(k_eos_nl, KArgs) {
 THREAD_GLOBAL(k_eos_nl, KArgs)
 
 // --------------------------------------------------------------------------------- t3dmix2_geo
-// One block = (sub-tile, rho-level k, tracer).  The reference's two-level rolling buffers become
-// LDS planes for the two rho levels (k, k+1) and the two W levels (k-1, k) that level k needs; the
-// vertical flux FS is evaluated at both W levels by the block itself (no inter-block dependency).
-#define GEO_NLDS 12
-COOP_KERNEL(k_t3dmix2_geo, KArgs) {
+// Point-wise: a thread marches up a chunk of KCH levels of its column (grid.z = chunk + nchunk*(itrc-1),
+// p0 = nchunk) with the reference's two-level rolling buffers (k1, k2) held in registers: the
+// horizontal differences of z_r and t at the four faces of the cell for the rho levels k and k+1, the
+// vertical difference dTdz at the five columns of the stencil for the W levels k-1 and k, and the
+// vertical flux FS(k-1) carried from the level below.  Every expression is the reference's
+// (t3dmix2_geo.h:196-400); the faces shared with neighbouring cells are recomputed, not exchanged.
+struct GeoLev { double zc, zw, ze, zs, zn, tc, tw, te, ts, tn; };                 // z_r, t at (i,j), (i-1,j), (i+1,j), (i,j-1), (i,j+1)
+struct GeoGrad { double zxi, zxp, txi, txp, zej, zep, tej, tep; };                // dZdx, dTdx at faces i, i+1; dZde, dTde at faces j, j+1
+struct GeoTz { double c, w, e, s, n; };                                           // dTdz at the five columns
+KDEV GeoLev geo_load(const double *z, const double *t, long ni) {
+  GeoLev L;
+  L.zc = z[0]; L.zw = z[-1]; L.ze = z[1]; L.zs = z[-ni]; L.zn = z[ni];
+  L.tc = t[0]; L.tw = t[-1]; L.te = t[1]; L.ts = t[-ni]; L.tn = t[ni];
+  return L;
+}
+KDEV GeoGrad geo_grad(const GeoLev &L, double cxi, double cxp, double cej, double cep) {
+  GeoGrad D;
+  D.zxi = cxi * (L.zc - L.zw); D.txi = cxi * (L.tc - L.tw);
+  D.zxp = cxp * (L.ze - L.zc); D.txp = cxp * (L.te - L.tc);
+  D.zej = cej * (L.zc - L.zs); D.tej = cej * (L.tc - L.ts);
+  D.zep = cep * (L.zn - L.zc); D.tep = cep * (L.tn - L.tc);
+  return D;
+}
+KDEV GeoTz geo_tz(const GeoLev &lo, const GeoLev &up, bool zero) {   // W level between rho levels lo and up
+  GeoTz T;
+  if (zero) { T.c = T.w = T.e = T.s = T.n = 0.0; return T; }
+  { const double cff = 1.0 / (up.zc - lo.zc); T.c = cff * (up.tc - lo.tc); }
+  { const double cff = 1.0 / (up.zw - lo.zw); T.w = cff * (up.tw - lo.tw); }
+  { const double cff = 1.0 / (up.ze - lo.ze); T.e = cff * (up.te - lo.te); }
+  { const double cff = 1.0 / (up.zs - lo.zs); T.s = cff * (up.ts - lo.ts); }
+  { const double cff = 1.0 / (up.zn - lo.zn); T.n = cff * (up.tn - lo.tn); }
+  return T;
+}
+// FS at the W level between rho levels k1 (D1) and k2 (D2) :333-372
+KDEV double geo_fs(const GeoGrad &D1, const GeoGrad &D2, double tz, double cff) {
+  double c1 = KMIN(D1.zxi, 0.0), c2 = KMIN(D2.zxp, 0.0), c3 = KMAX(D2.zxi, 0.0), c4 = KMAX(D1.zxp, 0.0);
+  double FS = cff * (c1 * (c1 * tz - D1.txi) + c2 * (c2 * tz - D2.txp) + c3 * (c3 * tz - D2.txi) + c4 * (c4 * tz - D1.txp));
+  c1 = KMIN(D1.zej, 0.0); c2 = KMIN(D2.zep, 0.0); c3 = KMAX(D2.zej, 0.0); c4 = KMAX(D1.zep, 0.0);
+  FS = FS + cff * (c1 * (c1 * tz - D1.tej) + c2 * (c2 * tz - D2.tep) + c3 * (c3 * tz - D2.tej) + c4 * (c4 * tz - D1.tep));
+  return FS;
+}
+THREAD_KERNEL(k_t3dmix2_geo, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
-  const TB B = block_bounds(G, bx, by);
-  const int k = bz % G.N + 1, itrc = bz / G.N + 1, N = G.N;
-  const int nrhs = G.nrhs, nnew = G.nnew;
-  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
-  const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
-  // rho-level planes: index 0 -> level k, 1 -> level k+1 ; W-level planes: 0 -> W level k-1, 1 -> W level k
-  double *dTdx[2] = {lds, lds + sz}, *dZdx[2] = {lds + 2 * sz, lds + 3 * sz}, *dTde[2] = {lds + 4 * sz, lds + 5 * sz},
-         *dZde[2] = {lds + 6 * sz, lds + 7 * sz}, *dTdz[2] = {lds + 8 * sz, lds + 9 * sz};
-  double *FX = lds + 10 * sz, *FE = lds + 11 * sz;
-  const double *t = F.t + XT(G.LBi, G.LBj, 1, nrhs, itrc);   // level 1 of t(nrhs)
-  const double *z_r = F.z_r, *pm = F.pm, *pn = F.pn, *Hz = F.Hz;
-  const double *diff2 = F.diff2 + (size_t)(itrc - 1) * G.nij;
-  for (int l = 0; l < 2; l++) {
-    const int kk = k + l;        // rho level
-    if (kk <= N) {
-      KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend + 1) {
-        if (j <= Jend) {
-          const double cff = 0.5 * (pm[X2(i, j)] + pm[X2(i - 1, j)]);
-          dZdx[l][S2(i, j)] = cff * (z_r[X3(i, j, kk)] - z_r[X3(i - 1, j, kk)]);
-          dTdx[l][S2(i, j)] = cff * (t[X3(i, j, kk)] - t[X3(i - 1, j, kk)]);
-        }
-        if (i <= Iend) {
-          const double cff = 0.5 * (pn[X2(i, j)] + pn[X2(i, j - 1)]);
-          dZde[l][S2(i, j)] = cff * (z_r[X3(i, j, kk)] - z_r[X3(i, j - 1, kk)]);
-          dTde[l][S2(i, j)] = cff * (t[X3(i, j, kk)] - t[X3(i, j - 1, kk)]);
-        }
-      }
-    }
-    const int kw = k - 1 + l;    // W level
-    KLOOP2(i, j, Istr - 1, Iend + 1, Jstr - 1, Jend + 1) {
-      if (kw == 0 || kw == N) dTdz[l][S2(i, j)] = 0.0;
-      else {
-        const double cff = 1.0 / (z_r[X3(i, j, kw + 1)] - z_r[X3(i, j, kw)]);
-        dTdz[l][S2(i, j)] = cff * (t[X3(i, j, kw + 1)] - t[X3(i, j, kw)]);
-      }
-    }
+  const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * KCH + 1;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  if (k0 > N) return;
+  const int k1 = KMIN(k0 + KCH - 1, N);
+  const size_t nij = (size_t)G.nij;
+  const long ni = G.ni, x = (long)X2(i, j);
+  const double *pm = F.pm + x, *pn = F.pn + x;
+  const double *d2 = F.diff2 + (size_t)(itrc - 1) * nij + x;
+  const double cxi = 0.5 * (pm[0] + pm[-1]), cxp = 0.5 * (pm[1] + pm[0]);
+  const double cej = 0.5 * (pn[0] + pn[-ni]), cep = 0.5 * (pn[ni] + pn[0]);
+  const double fxi = 0.25 * (d2[0] + d2[-1]) * F.on_u[x], fxp = 0.25 * (d2[1] + d2[0]) * F.on_u[x + 1];
+  const double fej = 0.25 * (d2[0] + d2[-ni]) * F.om_v[x], fep = 0.25 * (d2[ni] + d2[0]) * F.om_v[x + ni];
+  const double cS = 0.5 * d2[0];
+  const double c = G.dt * pm[0] * pn[0];
+  const double *z = F.z_r + x, *t = F.t + XT(G.LBi, G.LBj, 1, G.nrhs, itrc) + x, *Hz = F.Hz + x;
+  double *tnew = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc) + x;
+  // state below the first level: D(k0-1), Tz and FS at W level k0-1
+  GeoLev Lk = geo_load(z + (size_t)(k0 - 1) * nij, t + (size_t)(k0 - 1) * nij, ni);
+  GeoGrad Dk = geo_grad(Lk, cxi, cxp, cej, cep), Dm = Dk;
+  GeoTz Tm = geo_tz(Lk, Lk, true);
+  double FSm = 0.0;
+  if (k0 > 1) {
+    const GeoLev Lm = geo_load(z + (size_t)(k0 - 2) * nij, t + (size_t)(k0 - 2) * nij, ni);
+    Dm = geo_grad(Lm, cxi, cxp, cej, cep);
+    Tm = geo_tz(Lm, Lk, false);
+    FSm = geo_fs(Dm, Dk, Tm.c, cS);
   }
-  KSYNC();
-  // horizontal fluxes at rho level k: k1 <-> plane 0 (level k, W level k-1), k2 <-> plane 1
-  KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend + 1) {
-    if (j <= Jend) {
-      const double cff = 0.25 * (diff2[X2(i, j)] + diff2[X2(i - 1, j)]) * F.on_u[X2(i, j)];
-      FX[S2(i, j)] = cff * (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]) *
-                     (dTdx[0][S2(i, j)] -
-                      0.5 * (KMIN(dZdx[0][S2(i, j)], 0.0) * (dTdz[0][S2(i - 1, j)] + dTdz[1][S2(i, j)]) +
-                             KMAX(dZdx[0][S2(i, j)], 0.0) * (dTdz[1][S2(i - 1, j)] + dTdz[0][S2(i, j)])));
-    }
-    if (i <= Iend) {
-      const double cff = 0.25 * (diff2[X2(i, j)] + diff2[X2(i, j - 1)]) * F.om_v[X2(i, j)];
-      FE[S2(i, j)] = cff * (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]) *
-                     (dTde[0][S2(i, j)] -
-                      0.5 * (KMIN(dZde[0][S2(i, j)], 0.0) * (dTdz[0][S2(i, j - 1)] + dTdz[1][S2(i, j)]) +
-                             KMAX(dZde[0][S2(i, j)], 0.0) * (dTdz[1][S2(i, j - 1)] + dTdz[0][S2(i, j)])));
-    }
-  }
-  KSYNC();
-  double *tn = F.t + XT(G.LBi, G.LBj, k, nnew, itrc);
-  KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
-    // vertical flux FS at W level k (FS2) and k-1 (FS1).  FS at W level kw couples rho levels kw
-    // (reference "k1") and kw+1 ("k2"): FS(kw) = f(dZdx(.,kw), dZdx(.,kw+1), dTdz(kw), dTdx ...)
-    double FS2 = 0.0, FS1 = 0.0;
-    const double cff = 0.5 * diff2[X2(i, j)];
+  for (int k = k0; k <= k1; k++) {
+    const size_t ok = (size_t)(k - 1) * nij;
+    GeoLev Lp = Lk;
+    GeoGrad Dp = Dk;
+    GeoTz Tk = geo_tz(Lk, Lk, true);
+    double FSk = 0.0;
     if (k < N) {
-      const double tz = dTdz[1][S2(i, j)];
-      double c1 = KMIN(dZdx[0][S2(i, j)], 0.0), c2 = KMIN(dZdx[1][S2(i + 1, j)], 0.0);
-      double c3 = KMAX(dZdx[1][S2(i, j)], 0.0), c4 = KMAX(dZdx[0][S2(i + 1, j)], 0.0);
-      FS2 = cff * (c1 * (c1 * tz - dTdx[0][S2(i, j)]) + c2 * (c2 * tz - dTdx[1][S2(i + 1, j)]) +
-                   c3 * (c3 * tz - dTdx[1][S2(i, j)]) + c4 * (c4 * tz - dTdx[0][S2(i + 1, j)]));
-      c1 = KMIN(dZde[0][S2(i, j)], 0.0); c2 = KMIN(dZde[1][S2(i, j + 1)], 0.0);
-      c3 = KMAX(dZde[1][S2(i, j)], 0.0); c4 = KMAX(dZde[0][S2(i, j + 1)], 0.0);
-      FS2 = FS2 + cff * (c1 * (c1 * tz - dTde[0][S2(i, j)]) + c2 * (c2 * tz - dTde[1][S2(i, j + 1)]) +
-                         c3 * (c3 * tz - dTde[1][S2(i, j)]) + c4 * (c4 * tz - dTde[0][S2(i, j + 1)]));
+      Lp = geo_load(z + ok + nij, t + ok + nij, ni);
+      Dp = geo_grad(Lp, cxi, cxp, cej, cep);
+      Tk = geo_tz(Lk, Lp, false);
+      FSk = geo_fs(Dk, Dp, Tk.c, cS);
     }
-    if (k > 1) {
-      // W level k-1 couples rho levels k-1 ("k1") and k ("k2"); level k-1 differences in-line
-      const int km = k - 1;
-      const double cxi = 0.5 * (pm[X2(i, j)] + pm[X2(i - 1, j)]), cxp = 0.5 * (pm[X2(i + 1, j)] + pm[X2(i, j)]);
-      const double cei = 0.5 * (pn[X2(i, j)] + pn[X2(i, j - 1)]), cep = 0.5 * (pn[X2(i, j + 1)] + pn[X2(i, j)]);
-      const double dZx_i = cxi * (z_r[X3(i, j, km)] - z_r[X3(i - 1, j, km)]);
-      const double dZx_p = cxp * (z_r[X3(i + 1, j, km)] - z_r[X3(i, j, km)]);
-      const double dTx_i = cxi * (t[X3(i, j, km)] - t[X3(i - 1, j, km)]);
-      const double dTx_p = cxp * (t[X3(i + 1, j, km)] - t[X3(i, j, km)]);
-      const double dZe_j = cei * (z_r[X3(i, j, km)] - z_r[X3(i, j - 1, km)]);
-      const double dZe_p = cep * (z_r[X3(i, j + 1, km)] - z_r[X3(i, j, km)]);
-      const double dTe_j = cei * (t[X3(i, j, km)] - t[X3(i, j - 1, km)]);
-      const double dTe_p = cep * (t[X3(i, j + 1, km)] - t[X3(i, j, km)]);
-      const double tz = dTdz[0][S2(i, j)];
-      double c1 = KMIN(dZx_i, 0.0), c2 = KMIN(dZdx[0][S2(i + 1, j)], 0.0);
-      double c3 = KMAX(dZdx[0][S2(i, j)], 0.0), c4 = KMAX(dZx_p, 0.0);
-      FS1 = cff * (c1 * (c1 * tz - dTx_i) + c2 * (c2 * tz - dTdx[0][S2(i + 1, j)]) +
-                   c3 * (c3 * tz - dTdx[0][S2(i, j)]) + c4 * (c4 * tz - dTx_p));
-      c1 = KMIN(dZe_j, 0.0); c2 = KMIN(dZde[0][S2(i, j + 1)], 0.0);
-      c3 = KMAX(dZde[0][S2(i, j)], 0.0); c4 = KMAX(dZe_p, 0.0);
-      FS1 = FS1 + cff * (c1 * (c1 * tz - dTe_j) + c2 * (c2 * tz - dTde[0][S2(i, j + 1)]) +
-                         c3 * (c3 * tz - dTde[0][S2(i, j)]) + c4 * (c4 * tz - dTe_p));
-    }
-    const double c = G.dt * pm[X2(i, j)] * pn[X2(i, j)];
-    const double cff1 = c * (FX[S2(i + 1, j)] - FX[S2(i, j)]);
-    const double cff2 = c * (FE[S2(i, j + 1)] - FE[S2(i, j)]);
-    const double cff3 = G.dt * (FS2 - FS1);
+    // horizontal fluxes at rho level k :253-300 (Tm: W level k-1, Tk: W level k)
+    const double hc = Hz[ok];
+    const double FXi = fxi * (hc + Hz[ok - 1]) *
+                       (Dk.txi - 0.5 * (KMIN(Dk.zxi, 0.0) * (Tm.w + Tk.c) + KMAX(Dk.zxi, 0.0) * (Tk.w + Tm.c)));
+    const double FXp = fxp * (Hz[ok + 1] + hc) *
+                       (Dk.txp - 0.5 * (KMIN(Dk.zxp, 0.0) * (Tm.c + Tk.e) + KMAX(Dk.zxp, 0.0) * (Tk.c + Tm.e)));
+    const double FEj = fej * (hc + Hz[ok - ni]) *
+                       (Dk.tej - 0.5 * (KMIN(Dk.zej, 0.0) * (Tm.s + Tk.c) + KMAX(Dk.zej, 0.0) * (Tk.s + Tm.c)));
+    const double FEp = fep * (Hz[ok + ni] + hc) *
+                       (Dk.tep - 0.5 * (KMIN(Dk.zep, 0.0) * (Tm.c + Tk.n) + KMAX(Dk.zep, 0.0) * (Tk.c + Tm.n)));
+    const double cff1 = c * (FXp - FXi);
+    const double cff2 = c * (FEp - FEj);
+    const double cff3 = G.dt * (FSk - FSm);
     const double cff4 = cff1 + cff2 + cff3;
-    tn[X2(i, j)] = tn[X2(i, j)] + cff4;
+    tnew[ok] = tnew[ok] + cff4;
+    Lk = Lp; Dm = Dk; Dk = Dp; Tm = Tk; FSm = FSk;
   }
 }
-COOP_GLOBAL(k_t3dmix2_geo, KArgs)
+THREAD_GLOBAL(k_t3dmix2_geo, KArgs)
 
 // ------------------------------------------------------------------------------------ bulk_flux
 KDEV double blk_psiu(double ZoL) {

@@ -98,8 +98,6 @@ KDEV void hadv_flux_lds(const DGrid &G, const TB &B, int scheme, const double *T
   KSYNC();
 }
 
-#define KCH 5   // levels per thread of the chunked point-wise kernels (grid.z = chunk)
-
 // The same fluxes at the four faces of ONE cell (i,j), read straight from global memory: used by the
 // point-wise fused tracer kernels (k_pre_t3, k_s3t_hv).  The five-point row and column of the tracer
 // are loaded once; the first differences grad(ii) = T(ii)-T(ii-1), ii = i-1..i+2, and the three
