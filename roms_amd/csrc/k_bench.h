@@ -74,17 +74,31 @@ THREAD_KERNEL(k_eos_nl, KArgs) {
   const double g = G.g;
   double rhoA = 0.0, rhoS = 0.0;
   EosLevel up = {};   // level k+1
-  for (int k = N; k >= 1; k--) {
-    const EosLevel L = eos_level(F.t[XT(i, j, k, nrhs, 1)], F.t[XT(i, j, k, nrhs, 2)], F.z_r[X3(i, j, k)]);
+  double zr_up = 0.0;   // z_r(k+1)
+  // six levels are loaded at a time (the loads overlap), then the column recurrences run on registers
+  for (int k0 = N; k0 >= 1; k0 -= 6) {
+  double c_t1[6], c_t2[6], c_zr[6], c_hz[6], c_zw[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const int kk = KMAX(k0 - q, 1);
+    c_t1[q] = F.t[XT(i, j, kk, nrhs, 1)]; c_t2[q] = F.t[XT(i, j, kk, nrhs, 2)];
+    c_zr[q] = F.z_r[X3(i, j, kk)]; c_hz[q] = F.Hz[X3(i, j, kk)]; c_zw[q] = F.z_w[XW(i, j, kk)];
+  }
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    const int k = k0 - q;
+    if (k < 1) break;
+    const double zr_k = c_zr[q];
+    const EosLevel L = eos_level(c_t1[q], c_t2[q], zr_k);
     F.rho[X3(i, j, k)] = L.den;
     F.pden[X3(i, j, k)] = (L.den1 - 1000.0);
-    const double Hzk = F.Hz[X3(i, j, k)];
+    const double Hzk = c_hz[q];
     const double cff1 = L.den * Hzk;
     if (k == N) {
       rhoS = 0.5 * cff1 * Hzk;
       rhoA = cff1;
       // thermal expansion / saline contraction at the surface :470-500
-      const double Tpr10 = 0.1 * F.z_r[X3(i, j, k)];
+      const double Tpr10 = 0.1 * zr_k;
       const double cff = L.bulk + Tpr10;
       const double c1 = Tpr10 * L.den1;
       const double c2 = L.bulk * cff;
@@ -98,16 +112,18 @@ THREAD_KERNEL(k_eos_nl, KArgs) {
       rhoS = rhoS + Hzk * (rhoA + 0.5 * cff1);
       rhoA = rhoA + cff1;
       // Brunt-Vaisala frequency at W-level k (between k and k+1)
-      const double zw = F.z_w[XW(i, j, k)];
+      const double zw = c_zw[q];
       const double bulk_up = up.bulk0 - zw * (up.bulk1 - up.bulk2 * zw);
       const double bulk_dn = L.bulk0 - zw * (L.bulk1 - L.bulk2 * zw);
       const double c1 = 1.0 / (bulk_up + 0.1 * zw);
       const double c2 = 1.0 / (bulk_dn + 0.1 * zw);
       const double den_up = c1 * (up.den1 * bulk_up);
       const double den_dn = c2 * (L.den1 * bulk_dn);
-      F.bvf[XW(i, j, k)] = -g * (den_up - den_dn) / (0.5 * (den_up + den_dn) * (F.z_r[X3(i, j, k + 1)] - F.z_r[X3(i, j, k)]));
+      F.bvf[XW(i, j, k)] = -g * (den_up - den_dn) / (0.5 * (den_up + den_dn) * (zr_up - zr_k));
     }
     up = L;
+    zr_up = zr_k;
+  }
   }
   F.bvf[XW(i, j, 0)] = 0.0;
   F.bvf[XW(i, j, N)] = 0.0;

@@ -29,32 +29,87 @@ struct LmdArgs {
   (void)lmd_am; (void)lmd_as; (void)lmd_cekman; (void)lmd_cmonob; (void)lmd_cm; (void)lmd_cs;                  \
   (void)lmd_epsilon; (void)lmd_zetam; (void)lmd_zetas; (void)vonKar
 
-// vertical parabolic-spline derivatives of R, U, V at W-points for column (i,j)
+// vertical parabolic-spline derivatives of R, U, V at W-points for column (i,j) :190-260.  Both
+// sweeps take six levels at a time: the inputs of a chunk are loaded first (the loads overlap), then
+// the recurrences run on registers.  with_uv = false computes dR only (FC is rebuilt; dU, dV of the
+// same velocities are already in their work arrays: k_lmd_skpp after k_lmd_interior).
 KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const double *R, double *FC, double *dR,
-                          double *dU, double *dV) {
+                          double *dU, double *dV, bool with_uv) {
   const int N = G.N;
-  const double *Hz = F.Hz;
-  const double *u = F.u + (size_t)(G.nstp - 1) * G.nij * N, *v = F.v + (size_t)(G.nstp - 1) * G.nij * N;
-  FC[XW(i, j, 0)] = 0.0; dR[XW(i, j, 0)] = 0.0; dU[XW(i, j, 0)] = 0.0; dV[XW(i, j, 0)] = 0.0;
+  const size_t nij = (size_t)G.nij, x = X2(i, j);
+  const long ni = G.ni;
+  const double *Hz = F.Hz + x, *Rc = R + x;
+  const double *u = F.u + (size_t)(G.nstp - 1) * nij * (size_t)N + x, *v = F.v + (size_t)(G.nstp - 1) * nij * (size_t)N + x;
+  FC[x] = 0.0; dR[x] = 0.0;
+  if (with_uv) { dU[x] = 0.0; dV[x] = 0.0; }
   double FCm = 0.0, dRm = 0.0, dUm = 0.0, dVm = 0.0;
-  for (int k = 1; k <= N - 1; k++) {
-    const double cff = 1.0 / (2.0 * Hz[X3(i, j, k + 1)] + Hz[X3(i, j, k)] * (2.0 - FCm));
-    FCm = cff * Hz[X3(i, j, k + 1)];
-    dRm = cff * (6.0 * (R[X3(i, j, k + 1)] - R[X3(i, j, k)]) - Hz[X3(i, j, k)] * dRm);
-    dUm = cff * (3.0 * (u[X3(i, j, k + 1)] - u[X3(i, j, k)] + u[X3(i + 1, j, k + 1)] - u[X3(i + 1, j, k)]) -
-                 Hz[X3(i, j, k)] * dUm);
-    dVm = cff * (3.0 * (v[X3(i, j, k + 1)] - v[X3(i, j, k)] + v[X3(i, j + 1, k + 1)] - v[X3(i, j + 1, k)]) -
-                 Hz[X3(i, j, k)] * dVm);
-    FC[XW(i, j, k)] = FCm; dR[XW(i, j, k)] = dRm; dU[XW(i, j, k)] = dUm; dV[XW(i, j, k)] = dVm;
+  for (int k0 = 1; k0 <= N - 1; k0 += 6) {
+    double hz[7], rr[7];      // level k0+q (clamped)
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+      const size_t o = (size_t)(KMIN(k0 + q, N) - 1) * nij;
+      hz[q] = Hz[o]; rr[q] = Rc[o];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const int k = k0 + q;
+      if (k > N - 1) break;
+      const size_t ow = (size_t)k * nij + x;
+      const double cff = 1.0 / (2.0 * hz[q + 1] + hz[q] * (2.0 - FCm));
+      FCm = cff * hz[q + 1];
+      dRm = cff * (6.0 * (rr[q + 1] - rr[q]) - hz[q] * dRm);
+      FC[ow] = FCm; dR[ow] = dRm;
+    }
   }
-  dR[XW(i, j, N)] = 0.0; dU[XW(i, j, N)] = 0.0; dV[XW(i, j, N)] = 0.0;
+  if (with_uv) {
+    // second pass over the column for the two velocity components (FC is recomputed: same values)
+    double FCq = 0.0;
+    for (int k0 = 1; k0 <= N - 1; k0 += 6) {
+      double hz[7], ua[7], ub[7], va[7], vb[7];
+#pragma unroll
+      for (int q = 0; q < 7; q++) {
+        const size_t o = (size_t)(KMIN(k0 + q, N) - 1) * nij;
+        hz[q] = Hz[o]; ua[q] = u[o]; ub[q] = u[o + 1]; va[q] = v[o]; vb[q] = v[o + ni];
+      }
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const int k = k0 + q;
+        if (k > N - 1) break;
+        const size_t ow = (size_t)k * nij + x;
+        const double cff = 1.0 / (2.0 * hz[q + 1] + hz[q] * (2.0 - FCq));
+        FCq = cff * hz[q + 1];
+        dUm = cff * (3.0 * (ua[q + 1] - ua[q] + ub[q + 1] - ub[q]) - hz[q] * dUm);
+        dVm = cff * (3.0 * (va[q + 1] - va[q] + vb[q + 1] - vb[q]) - hz[q] * dVm);
+        dU[ow] = dUm; dV[ow] = dVm;
+      }
+    }
+  }
+  const size_t oN = (size_t)N * nij + x;
+  dR[oN] = 0.0;
+  if (with_uv) { dU[oN] = 0.0; dV[oN] = 0.0; }
   double r1 = 0.0, u1 = 0.0, v1 = 0.0;
-  for (int k = N - 1; k >= 1; k--) {
-    const double fc = FC[XW(i, j, k)];
-    r1 = dR[XW(i, j, k)] - fc * r1;
-    u1 = dU[XW(i, j, k)] - fc * u1;
-    v1 = dV[XW(i, j, k)] - fc * v1;
-    dR[XW(i, j, k)] = r1; dU[XW(i, j, k)] = u1; dV[XW(i, j, k)] = v1;
+  for (int k0 = N - 1; k0 >= 1; k0 -= 6) {
+    double fc[6], dr[6], du[6], dv[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const size_t ow = (size_t)KMAX(k0 - q, 1) * nij + x;
+      fc[q] = FC[ow]; dr[q] = dR[ow];
+      if (with_uv) { du[q] = dU[ow]; dv[q] = dV[ow]; }
+    }
+    (void)du; (void)dv;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const int k = k0 - q;
+      if (k < 1) break;
+      const size_t ow = (size_t)k * nij + x;
+      r1 = dr[q] - fc[q] * r1;
+      dR[ow] = r1;
+      if (with_uv) {
+        u1 = du[q] - fc[q] * u1;
+        v1 = dv[q] - fc[q] * v1;
+        dU[ow] = u1; dV[ow] = v1;
+      }
+    }
   }
 }
 
@@ -67,24 +122,39 @@ THREAD_KERNEL(k_lmd_interior, LmdArgs) {
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
   const double eps = 1.0E-14;
   double *FC = F.wrk3[1], *dR = F.wrk3[2], *dU = F.wrk3[3], *dV = F.wrk3[4];
-  lmd_col_splines(G, F, i, j, F.rho, FC, dR, dU, dV);
-  for (int k = 1; k <= N - 1; k++) {
-    const double du = dU[XW(i, j, k)], dv = dV[XW(i, j, k)];
-    double shear2 = du * du + dv * dv;
-    const double bv = F.bvf[XW(i, j, k)];
-    const double Rig = bv / (shear2 + eps);
-    double cff = KMIN(1.0, KMAX(0.0, Rig) / lmd_Ri0);
-    double nu_sx = 1.0 - cff * cff;
-    nu_sx = nu_sx * nu_sx * nu_sx;
-    shear2 = bv / (Rig + eps);
-    cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
-    nu_sx = cff * nu_sx;
-    cff = 1.0 / sqrt(KMAX(bv, 1.0E-7));
-    const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
-    F.Akv[XW(i, j, k)] = lmd_iwm + lmd_nu0m * nu_sx;
-    const double akt = lmd_iws + lmd_nu0s * nu_sx;
-    F.Akt[XW4(i, j, k, 1)] = akt;
-    F.Akt[XW4(i, j, k, 2)] = akt;
+  lmd_col_splines(G, F, i, j, F.rho, FC, dR, dU, dV, true);
+  const size_t nij = (size_t)G.nij, x = X2(i, j);
+  const size_t oA = nij * (size_t)(N + 1);          // Akt: salt after temperature
+  // the levels are independent: six at a time, loads first
+  for (int k0 = 1; k0 <= N - 1; k0 += 6) {
+    double du_[6], dv_[6], bv_[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const size_t ow = (size_t)KMIN(k0 + q, N - 1) * nij + x;
+      du_[q] = dU[ow]; dv_[q] = dV[ow]; bv_[q] = F.bvf[ow];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const int k = k0 + q;
+      if (k > N - 1) break;
+      const size_t ow = (size_t)k * nij + x;
+      const double du = du_[q], dv = dv_[q];
+      double shear2 = du * du + dv * dv;
+      const double bv = bv_[q];
+      const double Rig = bv / (shear2 + eps);
+      double cff = KMIN(1.0, KMAX(0.0, Rig) / lmd_Ri0);
+      double nu_sx = 1.0 - cff * cff;
+      nu_sx = nu_sx * nu_sx * nu_sx;
+      shear2 = bv / (Rig + eps);
+      cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
+      nu_sx = cff * nu_sx;
+      cff = 1.0 / sqrt(KMAX(bv, 1.0E-7));
+      const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
+      F.Akv[ow] = lmd_iwm + lmd_nu0m * nu_sx;
+      const double akt = lmd_iws + lmd_nu0s * nu_sx;
+      F.Akt[ow] = akt;
+      F.Akt[ow + oA] = akt;
+    }
   }
 }
 THREAD_GLOBAL(k_lmd_interior, LmdArgs)
@@ -130,15 +200,24 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
   const double st1 = F.stflx[X2T(i, j, 1)], st2 = F.stflx[X2T(i, j, 2)], sr = F.srflx[X2(i, j)];
   const double Bo = g * (F.alpha[X2(i, j)] * (st1 - sr) - F.beta[X2(i, j)] * st2);
   const double Bosol = g * F.alpha[X2(i, j)] * sr;
-  for (int k = 0; k <= N; k++) {
-    const double swdk = SWFRAC(zwN - z_w[XW(i, j, k)]);
-    const double bf = (Bo + Bosol * (1.0 - swdk));
-    Bflux[XW(i, j, k)] = bf;
-    const double cff = 1.0 - (0.5 + copysign(0.5, bf));
-    F.ghats[XW4(i, j, k, 1)] = -cff * (st1 - sr + sr * (1.0 - swdk));
-    F.ghats[XW4(i, j, k, 2)] = cff * st2;
+  // (independent levels: four at a time, loads first)
+  for (int k0 = 0; k0 <= N; k0 += 4) {
+    double zw_[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) zw_[q] = z_w[XW(i, j, KMIN(k0 + q, N))];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = k0 + q;
+      if (k > N) break;
+      const double swdk = SWFRAC(zwN - zw_[q]);
+      const double bf = (Bo + Bosol * (1.0 - swdk));
+      Bflux[XW(i, j, k)] = bf;
+      const double cff = 1.0 - (0.5 + copysign(0.5, bf));
+      F.ghats[XW4(i, j, k, 1)] = -cff * (st1 - sr + sr * (1.0 - swdk));
+      F.ghats[XW4(i, j, k, 2)] = cff * st2;
+    }
   }
-  lmd_col_splines(G, F, i, j, pden, FC, dR, dU, dV);
+  lmd_col_splines(G, F, i, j, pden, FC, dR, dU, dV, false);   // dU, dV: from k_lmd_interior (same velocities)
   const double c13 = 1.0 / 3.0, c16 = 1.0 / 6.0;
   const double Rref = pden[X3(i, j, N)] + Hz[X3(i, j, N)] * (c13 * dR[XW(i, j, N)] + c16 * dR[XW(i, j, N - 1)]);
   const double Uref = 0.5 * (u[X3(i, j, N)] + u[X3(i + 1, j, N)]) + Hz[X3(i, j, N)] * (c13 * dU[XW(i, j, N)] + c16 * dU[XW(i, j, N - 1)]);
@@ -147,19 +226,35 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
   double wm = 0.0, ws = 0.0;
   // bulk Richardson number criterion; FC(k) overwrites the spline work array (as the reference)
   FC[XW(i, j, N)] = 0.0;
-  for (int k = N; k >= 1; k--) {
-    const double depth = zwN - z_w[XW(i, j, k - 1)];
-    const double bf = Bflux[XW(i, j, k - 1)];
-    const double sigma = (bf < 0.0) ? KMIN(sl_dpth, depth) : depth;
-    const double zetahat = vonKar * sigma * bf;
-    lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
-    const double Rk = pden[X3(i, j, k)] - Hz[X3(i, j, k)] * (c13 * dR[XW(i, j, k - 1)] + c16 * dR[XW(i, j, k)]);
-    const double Uk = 0.5 * (u[X3(i, j, k)] + u[X3(i + 1, j, k)]) - Hz[X3(i, j, k)] * (c13 * dU[XW(i, j, k - 1)] + c16 * dU[XW(i, j, k)]);
-    const double Vk = 0.5 * (v[X3(i, j, k)] + v[X3(i, j + 1, k)]) - Hz[X3(i, j, k)] * (c13 * dV[XW(i, j, k - 1)] + c16 * dV[XW(i, j, k)]);
-    const double Ritop = -gorho0 * (Rref - Rk) * depth;
-    const double du_ = Uref - Uk, dv_ = Vref - Vk;
-    const double Ribot = du_ * du_ + dv_ * dv_ + a.Vtc * depth * ws * sqrt(fabs(bvf[XW(i, j, k - 1)]));
-    FC[XW(i, j, k - 1)] = Ritop - lmd_Ric * Ribot;
+  // (independent levels: three at a time, loads first)
+  for (int k0 = N; k0 >= 1; k0 -= 3) {
+    double zwm[3], bfm[3], pd[3], hz[3], drm[3], drk[3], uk[3], vk[3], dum[3], duk[3], dvm[3], dvk[3], bvm[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int k = KMAX(k0 - q, 1);
+      zwm[q] = z_w[XW(i, j, k - 1)]; bfm[q] = Bflux[XW(i, j, k - 1)]; pd[q] = pden[X3(i, j, k)]; hz[q] = Hz[X3(i, j, k)];
+      drm[q] = dR[XW(i, j, k - 1)]; drk[q] = dR[XW(i, j, k)];
+      uk[q] = 0.5 * (u[X3(i, j, k)] + u[X3(i + 1, j, k)]); vk[q] = 0.5 * (v[X3(i, j, k)] + v[X3(i, j + 1, k)]);
+      dum[q] = dU[XW(i, j, k - 1)]; duk[q] = dU[XW(i, j, k)]; dvm[q] = dV[XW(i, j, k - 1)]; dvk[q] = dV[XW(i, j, k)];
+      bvm[q] = bvf[XW(i, j, k - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int k = k0 - q;
+      if (k < 1) break;
+      const double depth = zwN - zwm[q];
+      const double bf = bfm[q];
+      const double sigma = (bf < 0.0) ? KMIN(sl_dpth, depth) : depth;
+      const double zetahat = vonKar * sigma * bf;
+      lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+      const double Rk = pd[q] - hz[q] * (c13 * drm[q] + c16 * drk[q]);
+      const double Uk = uk[q] - hz[q] * (c13 * dum[q] + c16 * duk[q]);
+      const double Vk = vk[q] - hz[q] * (c13 * dvm[q] + c16 * dvk[q]);
+      const double Ritop = -gorho0 * (Rref - Rk) * depth;
+      const double du_ = Uref - Uk, dv_ = Vref - Vk;
+      const double Ribot = du_ * du_ + dv_ * dv_ + a.Vtc * depth * ws * sqrt(fabs(bvm[q]));
+      FC[XW(i, j, k - 1)] = Ritop - lmd_Ric * Ribot;
+    }
   }
   int ksbl = 1;
   hsbl = z_w[XW(i, j, 1)];
@@ -226,27 +321,40 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
     Gs1 = Gt1;
     dGs1dS = dGt1dS;
   }
-  for (int k = 1; k <= N - 1; k++) {
-    if (k > ksbl) {
-      const double depth = zwN - z_w[XW(i, j, k)];
-      const double bf = Bflux[XW(i, j, k)];
-      double sigma = (bf < 0.0) ? KMIN(sl_dpth, depth) : depth;
-      const double zetahat = vonKar * sigma * bf;
-      lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
-      sigma = depth / (zbl + eps);
-      const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
-      const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
-      const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;
-      const double Gs = a1 + a2 * Gs1 + a3 * dGs1dS;
-      F.Akv[XW(i, j, k)] = depth * wm * (1.0 + sigma * Gm);
-      F.Akt[XW4(i, j, k, 1)] = depth * ws * (1.0 + sigma * Gt);
-      F.Akt[XW4(i, j, k, 2)] = depth * ws * (1.0 + sigma * Gs);
-      const double cff = a.lmd_Cg * (1.0 - (0.5 + copysign(0.5, bf))) / (zbl * ws + eps);
-      F.ghats[XW4(i, j, k, 1)] = cff * F.ghats[XW4(i, j, k, 1)];
-      F.ghats[XW4(i, j, k, 2)] = cff * F.ghats[XW4(i, j, k, 2)];
-    } else {
-      F.ghats[XW4(i, j, k, 1)] = 0.0;
-      F.ghats[XW4(i, j, k, 2)] = 0.0;
+  // (independent levels: four at a time, loads first)
+  for (int k0 = 1; k0 <= N - 1; k0 += 4) {
+    double zw_[4], bf_[4], g1[4], g2[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = KMIN(k0 + q, N - 1);
+      zw_[q] = z_w[XW(i, j, k)]; bf_[q] = Bflux[XW(i, j, k)];
+      g1[q] = F.ghats[XW4(i, j, k, 1)]; g2[q] = F.ghats[XW4(i, j, k, 2)];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = k0 + q;
+      if (k > N - 1) break;
+      if (k > ksbl) {
+        const double depth = zwN - zw_[q];
+        const double bf = bf_[q];
+        double sigma = (bf < 0.0) ? KMIN(sl_dpth, depth) : depth;
+        const double zetahat = vonKar * sigma * bf;
+        lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+        sigma = depth / (zbl + eps);
+        const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
+        const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
+        const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;
+        const double Gs = a1 + a2 * Gs1 + a3 * dGs1dS;
+        F.Akv[XW(i, j, k)] = depth * wm * (1.0 + sigma * Gm);
+        F.Akt[XW4(i, j, k, 1)] = depth * ws * (1.0 + sigma * Gt);
+        F.Akt[XW4(i, j, k, 2)] = depth * ws * (1.0 + sigma * Gs);
+        const double cff = a.lmd_Cg * (1.0 - (0.5 + copysign(0.5, bf))) / (zbl * ws + eps);
+        F.ghats[XW4(i, j, k, 1)] = cff * g1[q];
+        F.ghats[XW4(i, j, k, 2)] = cff * g2[q];
+      } else {
+        F.ghats[XW4(i, j, k, 1)] = 0.0;
+        F.ghats[XW4(i, j, k, 2)] = 0.0;
+      }
     }
   }
 }
