@@ -159,10 +159,22 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
   const double Davg1 = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
   const double Davg2 = (dir == 0 ? F.DU_avg2 : F.DV_avg2)[X2(i, j)];
   double DC0 = 0.0, CF0 = 0.0, FC0 = 0.0;
-  for (int k = 1; k <= N; k++) {
-    const double DCk = cffm * (Hz[X3(i, j, k)] + Hz[X3(i - di, j - dj, k)]);
-    DC0 = DC0 + DCk;
-    CF0 = CF0 + DCk * q[X3(i, j, k)];
+  const size_t nij = (size_t)G.nij, x = X2(i, j), xm = X2(i - di, j - dj);
+  // every sweep takes eight levels at a time: loads first (they overlap), then the ordered sums
+  for (int k0 = 1; k0 <= N; k0 += 8) {
+    double hs[8], qq[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const size_t o = (size_t)(KMIN(k0 + m, N) - 1) * nij;
+      hs[m] = Hz[o + x] + Hz[o + xm]; qq[m] = q[o + x];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      if (k0 + m > N) break;
+      const double DCk = cffm * hs[m];
+      DC0 = DC0 + DCk;
+      CF0 = CF0 + DCk * qq[m];
+    }
   }
   DC0 = 1.0 / DC0;
   CF0 = DC0 * (CF0 - Davg1);
@@ -181,16 +193,38 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
   }
   if (fix)
     for (int k = 1; k <= N; k++) q[X3(i, j, k)] = q[X3(i, j, k)] - CF0;
-  for (int k = N; k >= 1; k--) {
-    const double DCk = cffm * (Hz[X3(i, j, k)] + Hz[X3(i - di, j - dj, k)]);
-    const double Hn = 0.5 * (Hq[X3(i, j, k)] + q[X3(i, j, k)] * DCk);
-    Hq[X3(i, j, k)] = Hn;
-    FC0 = FC0 + Hn;
+  for (int k0 = N; k0 >= 1; k0 -= 8) {
+    double hs[8], qq[8], hq[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const size_t o = (size_t)(KMAX(k0 - m, 1) - 1) * nij;
+      hs[m] = Hz[o + x] + Hz[o + xm]; qq[m] = q[o + x]; hq[m] = Hq[o + x];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int k = k0 - m;
+      if (k < 1) break;
+      const double DCk = cffm * hs[m];
+      const double Hn = 0.5 * (hq[m] + qq[m] * DCk);
+      Hq[(size_t)(k - 1) * nij + x] = Hn;
+      FC0 = FC0 + Hn;
+    }
   }
   FC0 = DC0 * (FC0 - Davg2);
-  for (int k = 1; k <= N; k++) {
-    const double DCk = cffm * (Hz[X3(i, j, k)] + Hz[X3(i - di, j - dj, k)]);
-    Hq[X3(i, j, k)] = Hq[X3(i, j, k)] - DCk * FC0;
+  for (int k0 = 1; k0 <= N; k0 += 8) {
+    double hs[8], hq[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const size_t o = (size_t)(KMIN(k0 + m, N) - 1) * nij;
+      hs[m] = Hz[o + x] + Hz[o + xm]; hq[m] = Hq[o + x];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int k = k0 + m;
+      if (k > N) break;
+      const double DCk = cffm * hs[m];
+      Hq[(size_t)(k - 1) * nij + x] = hq[m] - DCk * FC0;
+    }
   }
 }
 THREAD_GLOBAL(k_s3uv_couple, KArgs)

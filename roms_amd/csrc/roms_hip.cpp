@@ -358,6 +358,44 @@ extern "C" int roms_hip_download(roms_hip_ctx *c, const char *name, double *host
   return d2h(host, *(double **)((char *)&c->F + f->offset), (size_t)n * sizeof(double), c->stream);
 }
 extern "C" int roms_hip_sync(roms_hip_ctx *c) { return dsync(c->stream); }
+// Measurement aid: n back-to-back launches of the barotropic kernel issued one by one and as one
+// captured hipGraph; microseconds per launch of both forms in out[0], out[1].
+int run_step2d(roms_hip_ctx *c);
+extern "C" int roms_hip_graph_probe(roms_hip_ctx *c, int n, int reps, double *out) {
+#ifdef ROMS_CPU_EMU
+  (void)c; (void)n; (void)reps; (void)out;
+  return 5;
+#else
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float ms = 0.f;
+  for (int w = 0; w < 2; w++) {
+    (void)hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps; r++)
+      for (int k = 0; k < n; k++) if (run_step2d(c)) return 2;
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  out[0] = 1e3 * ms / (double)(n * reps);
+  hipGraph_t g; hipGraphExec_t ge;
+  if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { set_error("capture begin"); return 2; }
+  for (int k = 0; k < n; k++) if (run_step2d(c)) return 2;
+  if (hipStreamEndCapture(c->stream, &g) != hipSuccess) { set_error("capture end"); return 2; }
+  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { set_error("graph instantiate"); return 2; }
+  for (int w = 0; w < 2; w++) {
+    (void)hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps; r++) (void)hipGraphLaunch(ge, c->stream);
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  out[1] = 1e3 * ms / (double)(n * reps);
+  (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return 0;
+#endif
+}
 int fetch_diag(roms_hip_ctx *c, const double *d_out, double *out) { return d2h(out, d_out, 16 * sizeof(double), c->stream); }
 int run_diag_async(roms_hip_ctx *c, double *d_out);   // g_diag.cpp
 
