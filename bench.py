@@ -55,8 +55,7 @@ ALGO_ARRAYS = {
     "k_t3dmix2_geo":  (8, 5),
     "k_uv3dmix2_s":   (11, 12),
     "k_uv3dmix2_sum": (4, 4),
-    "k_rhs3d_h":      (9, 3),
-    "k_rhs3d_v":      (7, 0),
+    "k_rhs3d_pt":     (10, 3),     # u, v, Huon, Hvom, W, Hz read; ru, rv read-modify-write
     "k_rhs3d_sum":    (2, 10),
     "k_s3uv_col":     (8, 6),
     "k_s3uv_couple":  (9, 8),
@@ -67,7 +66,7 @@ ALGO_ARRAYS = {
     "k_eos_nl":       (8, 4),
     "k_rho_eos_lin":  (5, 2),
     "k_lmd_interior": (9, 0),
-    "k_lmd_skpp":     (17, 10),
+    "k_lmd_skpp":     (15, 10),
     "k_lmd_finish":   (7, 0),
     "k_set_depth":    (3, 2),
     "k_set_massflux": (5, 2),
@@ -89,7 +88,7 @@ def pmc_traffic(workload, kernel, world):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json,
     FETCH_SIZE + WRITE_SIZE passes corrected with the calibration factors measured on k_copy_probe, as
     the MI355X guide prescribes).  None if no such profile of this workload is committed (round 1:
-    none)."""
+    see DESIGN.md 6.4)."""
     import glob
     if world != 1:
         return None

@@ -97,27 +97,29 @@ void kprof_end(int slot, hipStream_t stream);
 
 #define THREAD_KERNEL(name, ArgT) static __device__ __forceinline__ void name##_body(const ArgT &a, int gx, int gy, int gz)
 // XCD-aware block order.  MI355X hands consecutive workgroups to its 8 XCDs round-robin (block b ->
-// XCD b % 8), each XCD with its own L2.  The linear block index is therefore decoded as
-//   xcd = b % 8, then (fastest to slowest) level gz, eta-block, group of 8 xi-blocks,
-// with xi-block = 8*group + xcd: all levels and all eta-blocks of one xi-column of blocks run on the
-// same XCD and close in time, so the vertical (k-1..k+2) and eta (j-2..j+2) neighbours a point-wise
-// kernel re-reads hit that XCD's L2; only the two or three xi-halo columns of a 64-wide block come
-// from another XCD.  (Measured with rocprofv3 FETCH_SIZE: profiles/, DESIGN.md.)
+// XCD b % 8), each XCD with its own L2.  The 64x4-point blocks of a launch are numbered eta-fastest
+// (t = xi-block * nby + eta-block) and that list is cut into 8 contiguous segments, one per XCD; the
+// linear block index is decoded as xcd = b % 8, then (fastest to slowest) level gz, position in the
+// XCD's segment.  All levels of a block column and (up to the segment ends) its eta-neighbours run on
+// the same XCD and close in time, so the vertical (k-1..k+2) and eta (j-2..j+2) neighbours a
+// point-wise kernel re-reads hit that XCD's L2, and every XCD gets the same number of blocks whatever
+// the grid shape.  (Measured with rocprofv3 FETCH_SIZE: profiles/, DESIGN.md.)
 #define THREAD_GLOBAL(name, ArgT)                                                        \
   static __global__ void __launch_bounds__(256) name(const ArgT a, int nx, int ny, int nz) {    \
-    const int nby_ = (ny + 3) / 4;                                                       \
-    int r_ = (int)(blockIdx.x >> 3);                                                     \
-    const int xcd_ = (int)(blockIdx.x & 7);                                              \
-    const int gz = r_ % nz; r_ /= nz;                                                    \
-    const int ty_ = r_ % nby_, tx_ = (r_ / nby_) * 8 + xcd_;                             \
+    const int nby_ = (ny + 3) / 4, nt_ = ((nx + 63) / 64) * nby_, seg_ = (nt_ + 7) / 8;  \
+    const int r_ = (int)(blockIdx.x >> 3), xcd_ = (int)(blockIdx.x & 7);                 \
+    const int gz = r_ % nz;                                                              \
+    const int t_ = xcd_ * seg_ + r_ / nz;                                                \
+    if (t_ >= nt_) return;                                                               \
+    const int tx_ = t_ / nby_, ty_ = t_ - tx_ * nby_;                                    \
     const int gx = tx_ * 64 + (int)threadIdx.x;                                          \
     const int gy = ty_ * 4 + (int)threadIdx.y;                                           \
     if (gx < nx && gy < ny) name##_body(a, gx, gy, gz);                                  \
   }
-// 64 lanes along xi (coalesced), 4 rows of eta per block; 1-D grid of 8*ceil(nbx/8)*nby*nz blocks
+// 64 lanes along xi (coalesced), 4 rows of eta per block; 1-D grid of 8*ceil(blocks/8)*nz workgroups
 #define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
   KPROF_WRAP(name, stream,                                                               \
-  hipLaunchKernelGGL(name, dim3((unsigned)(8 * (((((nx) + 63) / 64) + 7) / 8) * (((ny) + 3) / 4) * (nz)), 1, 1), \
+  hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + 3) / 4)) + 7) / 8) * (nz)), 1, 1), \
                      dim3(64, 4, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
 #endif
 
