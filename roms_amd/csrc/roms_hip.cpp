@@ -788,24 +788,37 @@ static int main3d_one(roms_hip_ctx *c) {
     DO(roms_hip_set_depth(c));
     DO(roms_hip_ini_fields(c));
   }
-  DO(roms_hip_set_massflux(c));                             // :348
   DO(roms_hip_rho_eos(c));                                  // :350
   // diag (:355): device-side reduction every ninfo steps; the blow-up test is made on the host
   // when roms_hip_main3d returns (no per-step host synchronisation)
   const bool do_diag = cf.ninfo > 0 && (s.iic - 1) % cf.ninfo == 0;
-  if (do_diag) {   // reads u, v, rho, wvel ... of this point of the step; overlaps the surface forcing and mixing
-    side_begin(c);
-    r = run_diag_async(c, c->d_diag);
-    side_end(c);
-    if (r) return r;
+  // Two independent chains follow: set_massflux (:348) -> omega (:534) -> wvelocity (:535), and the
+  // surface forcing / vertical mixing (:439-527), which needs neither Huon/Hvom nor W.  In a
+  // single-tile run (no halo transport to order) the first chain, behind diag, goes to the side
+  // stream; on a small grid neither chain fills the chip.
+  const bool side_chain = cf.NtileI * cf.NtileJ == 1;
+  side_begin(c);
+  r = 0;
+  if (do_diag) r = run_diag_async(c, c->d_diag);   // reads u, v, rho, wvel ... of this point of the step
+  if (!r && side_chain) {
+    r = roms_hip_set_massflux(c);
+    if (!r) r = roms_hip_omega(c);
+    if (!r) r = roms_hip_wvelocity(c, s.nstp);     // overwrites wvel, which diag reads: same stream, in order
   }
+  side_end(c);
+  if (r) return r;
+  if (!side_chain) DO(roms_hip_set_massflux(c));
   if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));   // :439
   DO(roms_hip_set_vbc(c));                                  // :445
   if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));       // :525
   else if (cf.options & ROMS_LMD_MIXING) DO(roms_hip_lmd_vmix(c)); // :527
-  DO(roms_hip_omega(c));                                    // :534
-  if (do_diag) side_join(c);                                // wvelocity overwrites wvel, which diag reads
-  DO(roms_hip_wvelocity(c, s.nstp));                        // :535
+  if (!side_chain) {
+    DO(roms_hip_omega(c));
+    side_join(c);
+    DO(roms_hip_wvelocity(c, s.nstp));
+  } else {
+    side_join(c);
+  }
   DO(roms_hip_set_zeta(c));                                 // :556
   // rhs3d :632 -- t3dmix2 only touches t(nnew): it overlaps prsgrd and rhs3d_tile
   DO(roms_hip_pre_step3d(c));
