@@ -25,6 +25,7 @@ int run_eos_nonlinear(roms_hip_ctx *c) {
   const int N = c->G.N;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_eos_nl, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
+  if (c->G.fuse3d) return 0;   // the kernel stored the periodic images itself (pt_emit)
   HaloSpec sp[7] = {{c->F.rho, N, BC_NONE, 'r'},  {c->F.pden, N, BC_NONE, 'r'}, {c->F.alpha, 1, BC_NONE, 'r'},
                     {c->F.beta, 1, BC_NONE, 'r'}, {c->F.rhoA, 1, BC_NONE, 'r'}, {c->F.rhoS, 1, BC_NONE, 'r'},
                     {c->F.bvf, N + 1, BC_NONE, 'r'}};

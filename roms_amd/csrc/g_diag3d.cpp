@@ -37,6 +37,7 @@ int run_set_massflux(roms_hip_ctx *c) {
   KArgs a = mk(c);
   const int i0 = KMIN(B.IstrP, B.IstrT), j0 = KMIN(B.JstrT, B.JstrP);
   LAUNCH_THREAD(k_set_massflux, B.IendT - i0 + 1, B.JendT - j0 + 1, N, c->stream, a);
+  if (c->G.fuse3d) return 0;   // the kernel stored the periodic images itself (pt_emit)
   const HaloSpec hs2[] = {
       {c->F.Huon, N, BC_NONE, 'u'},
       {c->F.Hvom, N, BC_NONE, 'v'},
@@ -51,6 +52,7 @@ int run_rho_eos(roms_hip_ctx *c) {
   const int N = c->G.N;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_rho_eos_lin, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
+  if (c->G.fuse3d) return 0;   // the kernel stored the periodic images itself (pt_emit)
   const HaloSpec hs3[] = {
       {c->F.rho, N, BC_NONE, 'r'},
       {c->F.pden, N, BC_NONE, 'r'},
@@ -108,7 +110,7 @@ int run_omega(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_omega, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
-  launch_halo(c, c->F.W, c->G.N + 1, BC_R, 'r');   // bc_w3d_tile
+  if (!c->G.fuse3d) launch_halo(c, c->F.W, c->G.N + 1, BC_R, 'r');   // bc_w3d_tile (fused: pt_emit in the kernel)
   return 0;
 }
 

@@ -19,12 +19,12 @@ int run_step3d_uv(roms_hip_ctx *c) {
   const int N = G.N, nnew = G.nnew;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_s3uv_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
-  {
+  if (!G.fuse3d) {   // (fused: the kernels store the boundary values and periodic images themselves, pt_emit)
     HaloSpec sp[2] = {{uv_lev(c, c->F.u, nnew), N, BC_U, 0}, {uv_lev(c, c->F.v, nnew), N, BC_V, 0}};   // u3dbc/v3dbc :1266,1271
     launch_halo_multi(c, sp, 2);
   }
   LAUNCH_THREAD(k_s3uv_couple, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, c->stream, a);
-  {
+  if (!G.fuse3d) {
     HaloSpec sp[6] = {{uv_lev(c, c->F.u, nnew), N, BC_NONE, 'u'}, {uv_lev(c, c->F.v, nnew), N, BC_NONE, 'v'},
                       {c->F.Huon, N, BC_NONE, 'u'},               {c->F.Hvom, N, BC_NONE, 'v'},
                       {c->F.ubar, 2, BC_NONE, 'u'},               {c->F.vbar, 2, BC_NONE, 'v'}};   // :1763-1830
@@ -78,6 +78,7 @@ int run_step3d_t(roms_hip_ctx *c) {
     LAUNCH_THREAD(k_mp_apply, LmT, MmT, N, c->stream, m);
     LAUNCH_THREAD(k_mp_vdiff, LmT, MmT, 1, c->stream, m);
   }
+  if (G.fuse3d && !any_mp) return 0;   // k_s3t_col stored the boundary values and images (pt_emit)
   HaloSpec sp[ROMS_MAXT];
   for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, BC_R, 'r'};   // t3dbc :1858 + exchange :1920
   launch_halo_multi(c, sp, G.NT);

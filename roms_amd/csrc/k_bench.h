@@ -73,6 +73,7 @@ THREAD_KERNEL(k_eos_nl, KArgs) {
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, N = G.N, nrhs = G.nrhs;
   const double g = G.g;
   double rhoA = 0.0, rhoS = 0.0;
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);
   EosLevel up = {};   // level k+1
   double zr_up = 0.0;   // z_r(k+1)
   // six levels are loaded at a time (the loads overlap), then the column recurrences run on registers
@@ -90,8 +91,8 @@ THREAD_KERNEL(k_eos_nl, KArgs) {
     if (k < 1) break;
     const double zr_k = c_zr[q];
     const EosLevel L = eos_level(c_t1[q], c_t2[q], zr_k);
-    F.rho[X3(i, j, k)] = L.den;
-    F.pden[X3(i, j, k)] = (L.den1 - 1000.0);
+    emit_store(G, P, F.rho + (size_t)(k - 1) * G.nij, L.den);
+    emit_store(G, P, F.pden + (size_t)(k - 1) * G.nij, (L.den1 - 1000.0));
     const double Hzk = c_hz[q];
     const double cff1 = L.den * Hzk;
     if (k == N) {
@@ -106,8 +107,8 @@ THREAD_KERNEL(k_eos_nl, KArgs) {
       const double Tcof = -(L.DbulkDT * c1 + L.Dden1DT * c2);
       const double Scof = (L.DbulkDS * c1 + L.Dden1DS * c2);
       const double o = 1.0 / wrk;
-      F.alpha[X2(i, j)] = o * Tcof;
-      F.beta[X2(i, j)] = o * Scof;
+      emit_store(G, P, F.alpha, o * Tcof);
+      emit_store(G, P, F.beta, o * Scof);
     } else {
       rhoS = rhoS + Hzk * (rhoA + 0.5 * cff1);
       rhoA = rhoA + cff1;
@@ -119,18 +120,19 @@ THREAD_KERNEL(k_eos_nl, KArgs) {
       const double c2 = 1.0 / (bulk_dn + 0.1 * zw);
       const double den_up = c1 * (up.den1 * bulk_up);
       const double den_dn = c2 * (L.den1 * bulk_dn);
-      F.bvf[XW(i, j, k)] = -g * (den_up - den_dn) / (0.5 * (den_up + den_dn) * (zr_up - zr_k));
+      emit_store(G, P, F.bvf + (size_t)k * G.nij,
+                 -g * (den_up - den_dn) / (0.5 * (den_up + den_dn) * (zr_up - zr_k)));
     }
     up = L;
     zr_up = zr_k;
   }
   }
-  F.bvf[XW(i, j, 0)] = 0.0;
-  F.bvf[XW(i, j, N)] = 0.0;
+  emit_store(G, P, F.bvf, 0.0);
+  emit_store(G, P, F.bvf + (size_t)N * G.nij, 0.0);
   const double cff2 = 1.0 / G.rho0;
   const double cff1 = 1.0 / (F.z_w[XW(i, j, N)] - F.z_w[XW(i, j, 0)]);
-  F.rhoA[X2(i, j)] = cff2 * cff1 * rhoA;
-  F.rhoS[X2(i, j)] = 2.0 * cff1 * cff1 * cff2 * rhoS;
+  emit_store(G, P, F.rhoA, cff2 * cff1 * rhoA);
+  emit_store(G, P, F.rhoS, 2.0 * cff1 * cff1 * cff2 * rhoS);
 }
 THREAD_GLOBAL(k_eos_nl, KArgs)
 

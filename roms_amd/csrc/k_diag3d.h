@@ -17,6 +17,7 @@
 // recurrences), lanes along xi so every level of a column is one coalesced wave access.
 #pragma once
 #include "roms_ctx.h"
+#include "k_haloblock.h"
 
 struct KArgs {
   DGrid G;
@@ -90,12 +91,13 @@ THREAD_KERNEL(k_set_massflux, KArgs) {
   const TB &B = G.T;
   const int i = KMIN(B.IstrP, B.IstrT) + gx, j = KMIN(B.JstrT, B.JstrP) + gy, k = gz + 1;
   const int nrhs = G.nrhs;
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);
   if (i >= B.IstrP && i <= B.IendT && j >= B.JstrT && j <= B.JendT)
-    F.Huon[X3(i, j, k)] =
-        0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i - 1, j, k)]) * F.u[X4(i, j, k, nrhs)] * F.on_u[X2(i, j)];
+    emit_store(G, P, F.Huon + (size_t)(k - 1) * G.nij,
+            0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i - 1, j, k)]) * F.u[X4(i, j, k, nrhs)] * F.on_u[X2(i, j)]);
   if (i >= B.IstrT && i <= B.IendT && j >= B.JstrP && j <= B.JendT)
-    F.Hvom[X3(i, j, k)] =
-        0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i, j - 1, k)]) * F.v[X4(i, j, k, nrhs)] * F.om_v[X2(i, j)];
+    emit_store(G, P, F.Hvom + (size_t)(k - 1) * G.nij,
+            0.5 * (F.Hz[X3(i, j, k)] + F.Hz[X3(i, j - 1, k)]) * F.v[X4(i, j, k, nrhs)] * F.om_v[X2(i, j)]);
 }
 THREAD_GLOBAL(k_set_massflux, KArgs)
 
@@ -110,13 +112,15 @@ THREAD_KERNEL(k_rho_eos_lin, KArgs) {
   const bool kpp = (G.options & ROMS_LMD_MIXING) != 0;   // BV_FREQUENCY and expansion coefficients :751-780
   const double gorho0 = G.g / G.rho0;
   double rhoA = 0.0, rhoS = 0.0, rup = 0.0;
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);
   for (int k = N; k >= 1; k--) {
     double r = G.R0 - G.R0 * G.Tcoef * (F.t[XT(i, j, k, nrhs, 1)] - G.T0);
     if (salt) r = r + G.R0 * G.Scoef * (F.t[XT(i, j, k, nrhs, 2)] - G.S0);
     r = r - 1000.0;
-    F.rho[X3(i, j, k)] = r;
-    F.pden[X3(i, j, k)] = r;
-    if (kpp && k < N) F.bvf[XW(i, j, k)] = -gorho0 * (rup - r) / (F.z_r[X3(i, j, k + 1)] - F.z_r[X3(i, j, k)]);
+    emit_store(G, P, F.rho + (size_t)(k - 1) * G.nij, r);
+    emit_store(G, P, F.pden + (size_t)(k - 1) * G.nij, r);
+    if (kpp && k < N)
+      emit_store(G, P, F.bvf + (size_t)k * G.nij, -gorho0 * (rup - r) / (F.z_r[X3(i, j, k + 1)] - F.z_r[X3(i, j, k)]));
     rup = r;
     const double Hzk = F.Hz[X3(i, j, k)];
     const double cff1 = r * Hzk;
@@ -130,11 +134,11 @@ THREAD_KERNEL(k_rho_eos_lin, KArgs) {
   }
   const double cff2 = 1.0 / G.rho0;
   const double cff1 = 1.0 / (F.z_w[XW(i, j, N)] - F.z_w[XW(i, j, 0)]);
-  F.rhoA[X2(i, j)] = cff2 * cff1 * rhoA;
-  F.rhoS[X2(i, j)] = 2.0 * cff1 * cff1 * cff2 * rhoS;
+  emit_store(G, P, F.rhoA, cff2 * cff1 * rhoA);
+  emit_store(G, P, F.rhoS, 2.0 * cff1 * cff1 * cff2 * rhoS);
   if (kpp) {
-    F.alpha[X2(i, j)] = fabs(G.Tcoef);
-    F.beta[X2(i, j)] = salt ? fabs(G.Scoef) : 0.0;
+    emit_store(G, P, F.alpha, fabs(G.Tcoef));
+    emit_store(G, P, F.beta, salt ? fabs(G.Scoef) : 0.0);
   }
 }
 THREAD_GLOBAL(k_rho_eos_lin, KArgs)
@@ -231,7 +235,8 @@ THREAD_KERNEL(k_omega, KArgs) {
   const double *Huon = F.Huon, *Hvom = F.Hvom, *z_w = F.z_w;
   double *W = F.W;
   double Wk = 0.0;
-  W[XW(i, j, 0)] = 0.0;
+  const EmitPlan P = emit_plan(G, BC_R, i, j);                       // bc_w3d_tile + exchange follow here
+  emit_store(G, P, W, 0.0);
   for (int k0 = 1; k0 <= N; k0 += 8) {
     double d[8];
 #pragma unroll
@@ -251,9 +256,9 @@ THREAD_KERNEL(k_omega, KArgs) {
     for (int m = 0; m < 8; m++) { const int k = KMAX(k0 - m, 1); w[m] = W[XW(i, j, k)]; z[m] = z_w[XW(i, j, k)]; }
 #pragma unroll
     for (int m = 0; m < 8; m++)
-      if (k0 - m >= 1) W[XW(i, j, k0 - m)] = w[m] - wrk * (z[m] - zw0);
+      if (k0 - m >= 1) emit_store(G, P, W + (size_t)(k0 - m) * G.nij, w[m] - wrk * (z[m] - zw0));
   }
-  W[XW(i, j, N)] = 0.0;
+  emit_store(G, P, W + (size_t)N * G.nij, 0.0);
 }
 THREAD_GLOBAL(k_omega, KArgs)
 

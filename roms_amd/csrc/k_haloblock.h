@@ -64,3 +64,91 @@ KDEV void hb_emit(const DGrid &G, const TB &B, double *A, int bc, int i, int j, 
     }
   }
 }
+
+// Final stores of a point-wise kernel whose index space is the whole tile.  When the halo launch that
+// would follow is fused (G.fuse3d: single tile, at least one periodic direction) the storing thread
+// also writes the boundary value derived from its point and the periodic images of both.  Which
+// array elements those are depends on (i,j) and the boundary kind only, so a thread works them out
+// once (emit_plan: at most 4 targets = the point and its image along the periodic direction, the
+// boundary point behind a closed edge and its image) and every level costs one store plus, on the few
+// edge lanes, up to three more (emit_store).  Points that a kernel computes outside 1..Lm x 1..Mm
+// (boundary rows, its own ghost columns) store their own value; where such a point coincides with an
+// image, both writers store the same bits (the inputs of a point-wise kernel at a ghost point are the
+// images of its inputs).
+enum { EMIT_COPY = 0, EMIT_GAMMA2 = 1, EMIT_ZERO = 2 };
+// Targets: o0 the point itself; with both directions periodic o1, o2, o3 = its xi image, eta image and
+// corner image; with one periodic direction o1 = its image, o2 = the boundary point derived from it
+// behind the closed edge (value by `kind`), o3 = the image of that.  m: bit q-1 set = target q exists.
+// (Scalar members only: an array indexed at run time would put the plan in scratch memory.)
+struct EmitPlan {
+  int o0, o1, o2, o3;
+  int m, kind;
+};
+KDEV EmitPlan emit_plan(const DGrid &G, int bc, int i, int j) {
+  EmitPlan P;
+  P.o0 = (int)X2(i, j); P.o1 = P.o0; P.o2 = P.o0; P.o3 = P.o0; P.m = 0; P.kind = EMIT_COPY;
+  if (!G.fuse3d || (i > 3 && i < G.Lm - 2 && j > 3 && j < G.Mm - 2)) return P;
+  const TB &B = G.T;
+  int ix = i, jy = j;
+  bool hx = false, hy = false;
+  if (G.ewp) {
+    if (i >= 1 && i <= G.Nghost) { ix = G.Lm + i; hx = true; }
+    else if (i >= G.Lm - 2 && i <= G.Lm) { ix = i - G.Lm; hx = true; }
+  }
+  if (G.nsp) {
+    if (j >= 1 && j <= G.Nghost) { jy = G.Mm + j; hy = true; }
+    else if (j >= G.Mm - 2 && j <= G.Mm) { jy = j - G.Mm; hy = true; }
+  }
+  if (G.ewp && G.nsp) {
+    if (hx) { P.o1 = (int)X2(ix, j); P.m |= 1; }
+    if (hy) { P.o2 = (int)X2(i, jy); P.m |= 2; }
+    if (hx && hy) { P.o3 = (int)X2(ix, jy); P.m |= 4; }
+    return P;
+  }
+  if (hx) { P.o1 = (int)X2(ix, j); P.m |= 1; }
+  if (hy) { P.o1 = (int)X2(i, jy); P.m |= 1; }
+  if (bc == BC_NONE) return P;
+  int di = i, dj = j;
+  bool hd = false;
+  if (!G.nsp) {          // closed southern / northern edge (the rules of hb_emit)
+    if (bc == BC_R) {
+      if (B.south && j == B.Jstr) { dj = j - 1; hd = true; P.kind = EMIT_COPY; }
+      if (B.north && j == B.Jend) { dj = j + 1; hd = true; P.kind = EMIT_COPY; }
+    } else if (bc == BC_U) {
+      if (B.south && j == B.Jstr) { dj = j - 1; hd = true; P.kind = EMIT_GAMMA2; }
+      if (B.north && j == B.Jend) { dj = j + 1; hd = true; P.kind = EMIT_GAMMA2; }
+    } else if (bc == BC_V) {
+      if (B.south && j == B.JstrV) { dj = B.Jstr; hd = true; P.kind = EMIT_ZERO; }
+      if (B.north && j == B.Jend) { dj = j + 1; hd = true; P.kind = EMIT_ZERO; }
+    }
+    if (hd) {
+      P.o2 = (int)X2(i, dj); P.m |= 2;
+      if (hx) { P.o3 = (int)X2(ix, dj); P.m |= 4; }
+    }
+  } else {               // closed western / eastern edge (eta is the periodic direction)
+    if (bc == BC_R) {
+      if (B.west && i == B.Istr) { di = i - 1; hd = true; P.kind = EMIT_COPY; }
+      if (B.east && i == B.Iend) { di = i + 1; hd = true; P.kind = EMIT_COPY; }
+    } else if (bc == BC_U) {
+      if (B.west && i == B.IstrU) { di = B.Istr; hd = true; P.kind = EMIT_ZERO; }
+      if (B.east && i == B.Iend) { di = i + 1; hd = true; P.kind = EMIT_ZERO; }
+    } else if (bc == BC_V) {
+      if (B.west && i == B.Istr) { di = i - 1; hd = true; P.kind = EMIT_GAMMA2; }
+      if (B.east && i == B.Iend) { di = i + 1; hd = true; P.kind = EMIT_GAMMA2; }
+    }
+    if (hd) {
+      P.o2 = (int)X2(di, j); P.m |= 2;
+      if (hy) { P.o3 = (int)X2(di, jy); P.m |= 4; }
+    }
+  }
+  return P;
+}
+KDEV void emit_store(const DGrid &G, const EmitPlan &P, double *A, double v) {
+  A[P.o0] = v;
+  if (P.m) {
+    const double d = P.kind == EMIT_COPY ? v : (P.kind == EMIT_GAMMA2 ? G.gamma2 * v : 0.0);
+    if (P.m & 1) A[P.o1] = v;
+    if (P.m & 2) A[P.o2] = d;
+    if (P.m & 4) A[P.o3] = d;
+  }
+}

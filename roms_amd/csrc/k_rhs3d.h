@@ -321,6 +321,7 @@ THREAD_KERNEL(k_pre_t3, KArgs) {
   const double cfv = (G.iic == G.ntfirst) ? 0.5 * G.dt : (1.0 - GammaV) * G.dt;
   const double pmv = F.pm[x], pnv = F.pn[x];
   const double pmn = pmv * pnv;
+  const EmitPlan P3 = emit_plan(G, BC_R, i, j);
   // column window: levels k0-2 .. k0+KCH+1 (clamped), W at interfaces k0-1 .. k0+KCH-1; vertical fluxes
   double tt[KCH + 4], ww[KCH + 1], FC[KCH + 1];
 #pragma unroll
@@ -344,7 +345,7 @@ THREAD_KERNEL(k_pre_t3, KArgs) {
     // vertical
     const double DC = 1.0 / (Hzk - cfv * pmn * (Hu[X2(i + 1, j)] - Hu[X2(i, j)] + Hv[X2(i, j + 1)] - Hv[X2(i, j)] + (ww[q + 1] - ww[q])));
     const double cfv1 = cfv * pmn;
-    t3[ok] = DC * (t3h - cfv1 * (FC[q + 1] - FC[q]));
+    emit_store(G, P3, t3 - x + ok, DC * (t3h - cfv1 * (FC[q + 1] - FC[q])));     // t3dbc + exchange :1157-1171
   }
 }
 THREAD_GLOBAL(k_pre_t3, KArgs)

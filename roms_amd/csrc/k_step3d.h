@@ -128,13 +128,14 @@ THREAD_KERNEL(k_s3uv_col, KArgs) {
   const double Davg = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
   const double cff1 = 1.0 / (CF0 * omn1);
   const double corr = (DCs * omn1 - Davg) * cff1;
+  const EmitPlan PQ = emit_plan(G, dir == 0 ? BC_U : BC_V, i, j);
   for (int k0 = 1; k0 <= N; k0 += 8) {
     double qq[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) qq[m] = q[X3(i, j, KMIN(k0 + m, N))];
 #pragma unroll
     for (int m = 0; m < 8; m++)
-      if (k0 + m <= N) q[X3(i, j, k0 + m)] = qq[m] - corr;
+      if (k0 + m <= N) emit_store(G, PQ, q + (size_t)(k0 + m - 1) * G.nij, qq[m] - corr);   // u3dbc/v3dbc :1266
   }
 #undef AKc
 #undef HZc
@@ -180,8 +181,9 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
   CF0 = DC0 * (CF0 - Davg1);
   double *bar = dir == 0 ? F.ubar : F.vbar;
   const double b1 = DC0 * Davg1;
-  bar[X2T(i, j, 1)] = b1;
-  bar[X2T(i, j, 2)] = b1;
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);
+  emit_store(G, P, bar, b1);
+  emit_store(G, P, bar + G.nij, b1);
   // boundary columns: remove the mismatch of the vertical mean :1400-1490
   bool fix = false;
   if (dir == 0) {
@@ -192,7 +194,7 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
     if (!G.nsp && (j == 1 || j == G.Mm + 1) && i >= B.Istr && i <= B.Iend) fix = true;
   }
   if (fix)
-    for (int k = 1; k <= N; k++) q[X3(i, j, k)] = q[X3(i, j, k)] - CF0;
+    for (int k = 1; k <= N; k++) emit_store(G, P, q + (size_t)(k - 1) * nij, q[X3(i, j, k)] - CF0);
   for (int k0 = N; k0 >= 1; k0 -= 8) {
     double hs[8], qq[8], hq[8];
 #pragma unroll
@@ -223,7 +225,7 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
       const int k = k0 + m;
       if (k > N) break;
       const double DCk = cffm * hs[m];
-      Hq[(size_t)(k - 1) * nij + x] = hq[m] - DCk * FC0;
+      emit_store(G, P, Hq + (size_t)(k - 1) * nij, hq[m] - DCk * FC0);
     }
   }
 }
@@ -389,6 +391,7 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
   const double *Akt = F.Akt + (size_t)(ltrc - 1) * G.nij * (N + 1);
   const double pmn_dt = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];   // CF(i,0)
   double CF[ROMS_NPRIV], DC[ROMS_NPRIV];
+  const EmitPlan PT = emit_plan(G, BC_R, i, j);
   if (!s3t_point_path(G, itrc)) {   // otherwise k_s3t_hv has done the vertical advection already
   if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, T3, 1);
   #define Tc(kk) T3[X3(i, j, kk)]
@@ -473,7 +476,7 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
           const double DCk = dc[m] - cf[m] * DCp;
           const double up = DCp * ak[m], lo = DCk * ak[m + 1];        // DC(k+1)*Akt(k+1), DC(k)*Akt(k)
           const double cff1 = dt * (1.0 / hz[m]) * (up - lo);
-          tn[X3(i, j, k + 1)] = tt[m] + cff1;
+          emit_store(G, PT, tn + (size_t)k * G.nij, tt[m] + cff1);     // t3dbc :1858 + exchange :1920
           DCp = DCk;
         }
       }
@@ -481,7 +484,7 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
     {   // level 1: DC(0)*Akt(0) = 0
       const double DCk = DCp * Akt[XW(i, j, 1)];
       const double cff1 = dt * (1.0 / Hz[X3(i, j, 1)]) * (DCk - 0.0);
-      tn[X3(i, j, 1)] = tn[X3(i, j, 1)] + cff1;
+      emit_store(G, PT, tn, tn[X3(i, j, 1)] + cff1);
     }
   }
 }

@@ -35,7 +35,8 @@ struct DGrid {
   int nbx, nby;               // thread-block decomposition of the tile for the 3-D COOP kernels
   int bw, bh;                 // max sub-tile extent (LDS scratch is (bw+6) x (bh+6))
   int dbg_stop;
-  int fuse_halo;              // 1: single tile, COOP kernels fill boundary/periodic ghost points themselves
+  int fuse_halo;              // 1: single tile, k_step2d fills boundary/periodic ghost points itself (k_haloblock.h)
+  int fuse3d;                 // 1: the 3-D producers do so too (emit_plan/emit_store); ROMS_HIP_FUSE3D=0 turns it off
   int nbx2, nby2, bw2, bh2;   // the same for the 2-D (barotropic) kernel: smaller sub-tiles, the
                               // 2-D grid alone cannot fill 256 CUs otherwise
   // stepping (mod_stepping)

@@ -189,6 +189,8 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     const char *e = getenv("ROMS_HIP_FUSE_HALO");
     G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && (cfg->EWperiodic || cfg->NSperiodic) && LmT >= 6 && MmT >= 6 &&
                   !(e && e[0] == '0');
+    const char *e3 = getenv("ROMS_HIP_FUSE3D");
+    G.fuse3d = G.fuse_halo && !(e3 && e3[0] == '0');
   }
   G.ntfirst = cfg->ntfirst; G.nfast = cfg->nfast;
   G.dt = cfg->dt; G.dtfast = cfg->dtfast; G.rho0 = cfg->rho0; G.g = cfg->g; G.lambda = cfg->lambda;

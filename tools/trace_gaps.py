@@ -23,3 +23,6 @@ wall = t1 - t0
 print("wall %.1f us, busy %.1f us (%.1f%%), idle %.1f us, launches %d" % (wall / 1e3, busy / 1e3, 100.0 * busy / wall, (wall - busy) / 1e3, len(rows)))
 for n in sorted(dur, key=lambda k: -dur[k])[:25]:
     print("  %-22s n=%5d dur %9.1f us (%.2f us each)  idle before %8.1f us (%.2f each)" % (n[:22], cnt[n], dur[n] / 1e3, dur[n] / 1e3 / cnt[n], gap_before[n] / 1e3, gap_before[n] / 1e3 / cnt[n]))
+print("largest idle-before totals:")
+for n in sorted(gap_before, key=lambda k: -gap_before[k])[:12]:
+    print("  %-22s idle before %8.1f us (%.2f each, n=%d)" % (n[:22], gap_before[n] / 1e3, gap_before[n] / 1e3 / cnt[n], cnt[n]))
