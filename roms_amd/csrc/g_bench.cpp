@@ -69,6 +69,7 @@ int run_lmd_vmix(roms_hip_ctx *c) {
   LAUNCH_THREAD(k_lmd_interior, nx, ny, 1, c->stream, a);
   LAUNCH_THREAD(k_lmd_skpp, nx, ny, 1, c->stream, a);
   LAUNCH_THREAD(k_lmd_finish, nx, ny, N - 1, c->stream, a);
+  if (G.fuse3d) return 0;   // k_lmd_skpp / k_lmd_finish stored the boundary values and images (emit_store)
   HaloSpec sp[3] = {{c->F.hsbl, 1, BC_R, 'r'},                       // bc_r2d_tile lmd_skpp.F:608
                     {c->F.Akv, N + 1, BC_R, 'r'},                    // bc_w3d_tile lmd_vmix.F:740-760
                     {c->F.Akt, (N + 1) * G.NAT, BC_R, 'r'}};
@@ -84,6 +85,7 @@ int run_bulk_flux(roms_hip_ctx *c) {
   a.ZW = c->cfg.blk_ZW; a.ZT = c->cfg.blk_ZT; a.ZQ = c->cfg.blk_ZQ;
   LAUNCH_THREAD(k_bulk_pt, B.IendR - (B.Istr - 1) + 1, B.JendR - (B.Jstr - 1) + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_bulk_str, B.IendR - KMIN(B.Istr, B.IstrR) + 1, B.JendR - KMIN(B.Jstr, B.JstrR) + 1, 1, c->stream, a);
+  if (G.fuse3d) return 0;   // the kernels stored the periodic images themselves (emit_store)
   HaloSpec sp[6] = {{c->F.lrflx, 1, BC_NONE, 'r'},  {c->F.lhflx, 1, BC_NONE, 'r'}, {c->F.shflx, 1, BC_NONE, 'r'},
                     {c->F.stflux, 1, BC_NONE, 'r'}, {c->F.sustr, 1, BC_NONE, 'u'}, {c->F.svstr, 1, BC_NONE, 'v'}};
   launch_halo_multi(c, sp, 6);
@@ -136,6 +138,7 @@ int run_set_data_benchmark(roms_hip_ctx *c) {
   a.Dangle = Dangle * deg2rad;
   a.Hangle = (12.0 - hour) * pi / 12.0;
   LAUNCH_THREAD(k_set_data_bm, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
+  if (G.fuse3d) return 0;   // the kernel stored the periodic images itself (emit_store)
   HaloSpec s1[8] = {{c->F.cloud, 1, BC_NONE, 'r'}, {c->F.Tair, 1, BC_NONE, 'r'},  {c->F.Hair, 1, BC_NONE, 'r'},
                     {c->F.srflx, 1, BC_NONE, 'r'}, {c->F.Uwind, 1, BC_NONE, 'r'}, {c->F.Vwind, 1, BC_NONE, 'r'},
                     {c->F.rain, 1, BC_NONE, 'r'},  {c->F.Pair, 1, BC_NONE, 'r'}};

@@ -70,6 +70,7 @@ int run_set_vbc(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_set_vbc, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, 1, c->stream, a);
+  if (c->G.fuse3d) return 0;   // the kernel stored the boundary values and images itself (emit_store)
   const HaloSpec hs4[] = {
       {c->F.bustr, 1, BC_U, 'u'},   // bc_u2d_tile
       {c->F.bvstr, 1, BC_V, 'v'},   // bc_v2d_tile
@@ -133,7 +134,7 @@ int run_set_zeta(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_set_zeta, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, 1, c->stream, a);
-  launch_halo(c, c->F.zeta, 2, BC_NONE, 'r');
+  if (!c->G.fuse3d) launch_halo(c, c->F.zeta, 2, BC_NONE, 'r');   // (fused: emit_store in the kernel)
   return 0;
 }
 

@@ -384,10 +384,11 @@ THREAD_KERNEL(k_bulk_pt, BulkArgs) {
   if (i >= B.IstrR && j >= B.JstrR) {
     const double Hscale = 1.0 / (G.rho0 * G.Cp);
     const double lr = LRad * Hscale, lh = -LHeat * Hscale, sh = -SHeat * Hscale;
-    F.lrflx[X2(i, j)] = lr;
-    F.lhflx[X2(i, j)] = lh;
-    F.shflx[X2(i, j)] = sh;
-    F.stflux[X2T(i, j, 1)] = (F.srflx[X2(i, j)] + lr + lh + sh);
+    const EmitPlan P = emit_plan(G, BC_NONE, i, j);
+    emit_store(G, P, F.lrflx, lr);
+    emit_store(G, P, F.lhflx, lh);
+    emit_store(G, P, F.shflx, sh);
+    emit_store(G, P, F.stflux, (F.srflx[X2(i, j)] + lr + lh + sh));
   }
 }
 THREAD_GLOBAL(k_bulk_pt, BulkArgs)
@@ -400,8 +401,9 @@ THREAD_KERNEL(k_bulk_str, BulkArgs) {
   const TB &B = G.T;
   const int i = KMIN(B.Istr, B.IstrR) + gx, j = KMIN(B.Jstr, B.JstrR) + gy;
   const double cff = 0.5 / G.rho0;
-  if (i >= B.Istr && j >= B.JstrR) F.sustr[X2(i, j)] = cff * (F.wrk2[0][X2(i - 1, j)] + F.wrk2[0][X2(i, j)]);
-  if (i >= B.IstrR && j >= B.Jstr) F.svstr[X2(i, j)] = cff * (F.wrk2[1][X2(i, j - 1)] + F.wrk2[1][X2(i, j)]);
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);
+  if (i >= B.Istr && j >= B.JstrR) emit_store(G, P, F.sustr, cff * (F.wrk2[0][X2(i - 1, j)] + F.wrk2[0][X2(i, j)]));
+  if (i >= B.IstrR && j >= B.Jstr) emit_store(G, P, F.svstr, cff * (F.wrk2[1][X2(i, j - 1)] + F.wrk2[1][X2(i, j)]));
 }
 THREAD_GLOBAL(k_bulk_str, BulkArgs)
 
@@ -419,9 +421,10 @@ THREAD_KERNEL(k_set_data_bm, SetDataBmArgs) {
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy;
   const double deg2rad = 3.14159265358979323846 / 180.0, Csolar = 1353.0, alb_w = 0.06;
   const double cl = 0.6, Ta = 4.0, Ha = 0.8;
-  F.cloud[X2(i, j)] = cl;
-  F.Tair[X2(i, j)] = Ta;
-  F.Hair[X2(i, j)] = Ha;
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);
+  emit_store(G, P, F.cloud, cl);
+  emit_store(G, P, F.Tair, Ta);
+  emit_store(G, P, F.Hair, Ha);
   const double Rsolar = Csolar / (G.rho0 * G.Cp);
   const double LatRad = F.latr[X2(i, j)] * deg2rad;
   const double cff1 = sin(LatRad) * sin(a.Dangle);
@@ -434,15 +437,15 @@ THREAD_KERNEL(k_set_data_bm, SetDataBmArgs) {
     const double vap_p = e_sat * Ha;
     sr = Rsolar * zenith * zenith * (1.0 - 0.6 * (cl * cl * cl)) / ((zenith + 2.7) * vap_p * 1.0E-3 + 1.085 * zenith + 0.1);
   }
-  F.srflx[X2(i, j)] = (1.0 - alb_w) * sr;
+  emit_store(G, P, F.srflx, (1.0 - alb_w) * sr);
   const double cff = 0.2 * (60.0 + F.latr[X2(i, j)]);
-  F.Uwind[X2(i, j)] = 15.0 * exp(-cff * cff);
-  F.Vwind[X2(i, j)] = 0.0;
-  F.rain[X2(i, j)] = 0.0;
+  emit_store(G, P, F.Uwind, 15.0 * exp(-cff * cff));
+  emit_store(G, P, F.Vwind, 0.0);
+  emit_store(G, P, F.rain, 0.0);
   F.btflux[X2T(i, j, 1)] = 0.0;
-  F.stflux[X2T(i, j, 2)] = 0.0;
+  emit_store(G, P, F.stflux + G.nij, 0.0);
   F.btflux[X2T(i, j, 2)] = 0.0;
-  F.Pair[X2(i, j)] = 1025.0;
+  emit_store(G, P, F.Pair, 1025.0);
 }
 THREAD_GLOBAL(k_set_data_bm, SetDataBmArgs)
 

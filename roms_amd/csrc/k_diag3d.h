@@ -163,9 +163,9 @@ THREAD_KERNEL(k_set_vbc, KArgs) {
                                   F.v[X4(i - 1, j + 1, 1, nrhs)]);
       const double uu = F.u[X4(i, j, 1, nrhs)];
       const double cff2 = sqrt(uu * uu + cff1 * cff1);
-      F.bustr[X2(i, j)] = 0.5 * (F.rdrag2[X2(i - 1, j)] + F.rdrag2[X2(i, j)]) * uu * cff2;
+      emit_store(G, emit_plan(G, BC_U, i, j), F.bustr, 0.5 * (F.rdrag2[X2(i - 1, j)] + F.rdrag2[X2(i, j)]) * uu * cff2);
     } else {
-      F.bustr[X2(i, j)] = 0.5 * (F.rdrag[X2(i - 1, j)] + F.rdrag[X2(i, j)]) * F.u[X4(i, j, 1, nrhs)];
+      emit_store(G, emit_plan(G, BC_U, i, j), F.bustr, 0.5 * (F.rdrag[X2(i - 1, j)] + F.rdrag[X2(i, j)]) * F.u[X4(i, j, 1, nrhs)]);
     }
   }
   if (i >= B.Istr && i <= B.Iend && j >= B.JstrV && j <= B.Jend) {
@@ -174,9 +174,9 @@ THREAD_KERNEL(k_set_vbc, KArgs) {
                                   F.u[X4(i + 1, j - 1, 1, nrhs)]);
       const double vv = F.v[X4(i, j, 1, nrhs)];
       const double cff2 = sqrt(cff1 * cff1 + vv * vv);
-      F.bvstr[X2(i, j)] = 0.5 * (F.rdrag2[X2(i, j - 1)] + F.rdrag2[X2(i, j)]) * vv * cff2;
+      emit_store(G, emit_plan(G, BC_V, i, j), F.bvstr, 0.5 * (F.rdrag2[X2(i, j - 1)] + F.rdrag2[X2(i, j)]) * vv * cff2);
     } else {
-      F.bvstr[X2(i, j)] = 0.5 * (F.rdrag[X2(i, j - 1)] + F.rdrag[X2(i, j)]) * F.v[X4(i, j, 1, nrhs)];
+      emit_store(G, emit_plan(G, BC_V, i, j), F.bvstr, 0.5 * (F.rdrag[X2(i, j - 1)] + F.rdrag[X2(i, j)]) * F.v[X4(i, j, 1, nrhs)]);
     }
   }
 }
@@ -325,8 +325,9 @@ THREAD_KERNEL(k_set_zeta, KArgs) {
   const Fields &F = a.Fv;
   const int i = G.T.IstrR + gx, j = G.T.JstrR + gy;
   const double z = F.Zt_avg1[X2(i, j)];
-  F.zeta[X2T(i, j, 1)] = z;
-  F.zeta[X2T(i, j, 2)] = z;
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);
+  emit_store(G, P, F.zeta, z);
+  emit_store(G, P, F.zeta + G.nij, z);
 }
 THREAD_GLOBAL(k_set_zeta, KArgs)
 

@@ -276,7 +276,7 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
   }
   hsbl = KMIN(hsbl, zwN);
   hsbl = KMAX(hsbl, z_w[XW(i, j, 0)]);
-  F.hsbl[X2(i, j)] = hsbl;
+  emit_store(G, emit_plan(G, BC_R, i, j), F.hsbl, hsbl);     // bc_r2d_tile + exchange lmd_skpp.F:608
   ksbl = 1;
   for (int k = N; k >= 2; k--)
     if (ksbl == 1 && z_w[XW(i, j, k - 1)] < hsbl) ksbl = k;
@@ -370,8 +370,10 @@ THREAD_KERNEL(k_lmd_finish, LmdArgs) {
   cff = KMIN(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
   double nu_sxc = 1.0 - cff * cff;
   nu_sxc = nu_sxc * nu_sxc * nu_sxc;
-  F.Akv[XW(i, j, k)] = F.Akv[XW(i, j, k)] + lmd_nu0c * nu_sxc;
-  F.Akt[XW4(i, j, k, 1)] = F.Akt[XW4(i, j, k, 1)] + lmd_nu0c * nu_sxc;
-  F.Akt[XW4(i, j, k, 2)] = F.Akt[XW4(i, j, k, 2)] + lmd_nu0c * nu_sxc;
+  const EmitPlan P = emit_plan(G, BC_R, i, j);               // bc_w3d_tile + exchange lmd_vmix.F:560-760
+  const size_t ow = (size_t)k * (size_t)G.nij, oA = (size_t)G.nij * (size_t)(G.N + 1);
+  emit_store(G, P, F.Akv + ow, F.Akv[XW(i, j, k)] + lmd_nu0c * nu_sxc);
+  emit_store(G, P, F.Akt + ow, F.Akt[XW4(i, j, k, 1)] + lmd_nu0c * nu_sxc);
+  emit_store(G, P, F.Akt + ow + oA, F.Akt[XW4(i, j, k, 2)] + lmd_nu0c * nu_sxc);
 }
 THREAD_GLOBAL(k_lmd_finish, LmdArgs)
