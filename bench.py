@@ -215,9 +215,12 @@ def main():
             with open(args.breakdown_file, "w") as f:
                 json.dump({k: {"seconds": v[0], "launches": v[1]} for k, v in table.items()}, f, indent=1)
     if dominant:
-        # sample every 8th launch: two event records per launch would otherwise slow the step down
+        # a kernel launched many times per step (the barotropic kernel: back-to-back launches) is timed
+        # in runs of 16 consecutive launches per event pair, every other run: the two event markers
+        # would otherwise inflate a 10-microsecond kernel and slow the timed region down
         launches_per_step = table[dominant][1] // 2
-        hiplib.kprof(2, dominant, stride=8 if launches_per_step >= 16 else 1)
+        many = launches_per_step >= 16
+        hiplib.kprof(2, dominant, stride=2 if many else 1, batch=16 if many else 1)
     barrier_sync()
 
     t0 = time.perf_counter()

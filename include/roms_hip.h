@@ -191,6 +191,13 @@ int roms_hip_kprof(int mode, const char *kernel);
 /* mode 2 only: time every `every`-th launch of the selected kernel (keeps the event overhead out
    of a timed region) */
 int roms_hip_kprof_stride(int every);
+/* mode 2 only: one event pair around `n` consecutive launches of the selected kernel (back-to-back
+   launches, e.g. the barotropic loop): the event markers then do not inflate a short kernel.  A run
+   interrupted by another launch is discarded and the library falls back to one pair per launch. */
+int roms_hip_kprof_batch(int n);
+/* measurement aid: `n` launches of the barotropic kernel issued one by one and as one captured
+   hipGraph, `reps` times each; out[0], out[1] = microseconds per launch of the two forms */
+int roms_hip_graph_probe(roms_hip_ctx *ctx, int n, int reps, double *out);
 int roms_hip_kprof_get(int index, char *name, int name_len, double *seconds, long *calls);
 
 #ifdef __cplusplus

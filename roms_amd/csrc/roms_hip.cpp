@@ -219,8 +219,8 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   if (hipfail(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return 2; }
   (void)hipEventCreate(&c->ev0);
   (void)hipEventCreate(&c->ev1);
-  (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence);
+  (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence);
   {
     const char *e = getenv("ROMS_HIP_OVERLAP");
     c->overlap = !(e && e[0] == '0');
@@ -460,7 +460,10 @@ extern "C" int roms_hip_region_seconds(roms_hip_ctx *c, int region, double *seco
 // every launch with an event pair and waits for it (a breakdown pass; slows the step down).
 // Mode 2 brackets only launches of the selected kernel with event pairs taken from a pool and
 // resolves them when the pool is full or when the table is read: no host synchronisation inside
-// the timed region.
+// the timed region.  roms_hip_kprof_batch(n): one event pair around n consecutive launches of the
+// selected kernel (back-to-back launches of the barotropic loop), so that the two event markers do
+// not inflate a 10-microsecond kernel; a run interrupted by another launch is discarded, and if that
+// happens before any run has completed the mode falls back to one pair per launch.
 #ifndef ROMS_CPU_EMU
 int g_kprof_mode = 0;
 namespace {
@@ -470,8 +473,10 @@ KSlot g_kslot[KMAXSLOT];
 int g_nkslot = 0;
 char g_kselect[48] = "";
 hipEvent_t g_kev[2 * KPOOL];
-int g_kev_slot[KPOOL];
+int g_kev_slot[KPOOL], g_kev_n[KPOOL];
 int g_kev_made = 0, g_kev_used = 0;
+int g_kbatch = 1, g_kb_open = -1, g_kb_count = 0, g_kb_done = 0;
+bool g_kb_broken = false;
 int kslot_of(const char *name) {
   for (int i = 0; i < g_nkslot; i++)
     if (!strcmp(g_kslot[i].name, name)) return i;
@@ -482,22 +487,34 @@ int kslot_of(const char *name) {
   return g_nkslot++;
 }
 void kprof_resolve() {
+  if (g_kb_open >= 0) { g_kev_used = g_kb_open; g_kb_open = -1; }   // an unfinished run is dropped
   for (int i = 0; i < g_kev_used; i++) {
     (void)hipEventSynchronize(g_kev[2 * i + 1]);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, g_kev[2 * i], g_kev[2 * i + 1]);
     g_kslot[g_kev_slot[i]].seconds += 1.0e-3 * (double)ms;
-    g_kslot[g_kev_slot[i]].calls += 1;
+    g_kslot[g_kev_slot[i]].calls += g_kev_n[i];
   }
   g_kev_used = 0;
 }
 }  // namespace
 static int g_kstride = 1, g_kcount = 0;
 extern "C" int roms_hip_kprof_stride(int every) { g_kstride = every > 0 ? every : 1; g_kcount = 0; return 0; }
+extern "C" int roms_hip_kprof_batch(int n) { kprof_resolve(); g_kbatch = n > 0 ? n : 1; g_kb_done = 0; return 0; }
 int kprof_begin(const char *name, hipStream_t stream) {
   if (g_kprof_mode == 2) {
-    if (strcmp(name, g_kselect)) return -1;
-    if (g_kcount++ % g_kstride) return -1;     // sample every g_kstride-th launch of the selected kernel
+    if (strcmp(name, g_kselect)) {
+      if (g_kb_open >= 0) g_kb_broken = true;
+      return -1;
+    }
+    if (g_kbatch > 1) {
+      if (g_kb_open >= 0 && g_kb_broken) {   // interrupted run: dropped; if no run ever completed, per-launch pairs from now on
+        g_kev_used = g_kb_open; g_kb_open = -1;
+        if (!g_kb_done) g_kbatch = 1;
+      }
+      else if (g_kb_open >= 0) return g_kb_open;   // inside a run
+    }
+    if (g_kcount++ % g_kstride) return -1;     // sample every g_kstride-th launch (or run) of the selected kernel
   }
   static const bool trace = getenv("ROMS_HIP_TRACE") != nullptr;   // debugging aid: name every launch
   if (trace) { fprintf(stderr, "launch %s\n", name); fflush(stderr); }
@@ -505,21 +522,30 @@ int kprof_begin(const char *name, hipStream_t stream) {
   if (slot < 0) return -1;
   if (g_kev_used >= KPOOL) kprof_resolve();
   if (g_kev_used >= g_kev_made) {
-    (void)hipEventCreate(&g_kev[2 * g_kev_made]);
-    (void)hipEventCreate(&g_kev[2 * g_kev_made + 1]);
+    (void)hipEventCreateWithFlags(&g_kev[2 * g_kev_made], hipEventDisableSystemFence);
+    (void)hipEventCreateWithFlags(&g_kev[2 * g_kev_made + 1], hipEventDisableSystemFence);
     g_kev_made++;
   }
   int e = g_kev_used++;
   g_kev_slot[e] = slot;
+  g_kev_n[e] = 1;
   (void)hipEventRecord(g_kev[2 * e], stream);
+  if (g_kprof_mode == 2 && g_kbatch > 1) { g_kb_open = e; g_kb_count = 0; g_kb_broken = false; }
   return e;
 }
 void kprof_end(int e, hipStream_t stream) {
+  if (g_kprof_mode == 2 && g_kb_open == e) {
+    if (++g_kb_count < g_kbatch) return;       // the run goes on
+    g_kev_n[e] = g_kbatch;
+    g_kb_open = -1;
+    g_kb_done++;
+  }
   (void)hipEventRecord(g_kev[2 * e + 1], stream);
   if (g_kprof_mode == 1) kprof_resolve();
 }
 extern "C" int roms_hip_kprof(int mode, const char *kernel) {
   kprof_resolve();
+  g_kbatch = 1;
   g_kprof_mode = mode;
   g_nkslot = 0;
   g_kselect[0] = 0;
@@ -537,6 +563,7 @@ extern "C" int roms_hip_kprof_get(int index, char *name, int name_len, double *s
 #else
 extern "C" int roms_hip_kprof(int, const char *) { return 0; }
 extern "C" int roms_hip_kprof_stride(int) { return 0; }
+extern "C" int roms_hip_kprof_batch(int) { return 0; }
 extern "C" int roms_hip_kprof_get(int, char *, int, double *, long *) { return 8; }
 #endif
 
