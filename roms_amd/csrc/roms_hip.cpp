@@ -6,6 +6,7 @@
 #include "k_halo.h"
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -403,14 +404,21 @@ int run_diag_async(roms_hip_ctx *c, double *d_out);   // g_diag.cpp
 
 // ------------------------------------------------------------------------------- side stream
 #ifdef ROMS_CPU_EMU
+void side_mark(roms_hip_ctx *) {}
 void side_begin(roms_hip_ctx *) {}
 void side_end(roms_hip_ctx *) {}
 void side_join(roms_hip_ctx *) {}
 #else
 static bool side_on(roms_hip_ctx *c) { return c->overlap && !c->profile && g_kprof_mode != 1; }
-void side_begin(roms_hip_ctx *c) {
+// side_mark: the fork point on the main stream.  The host then enqueues the main-stream work that
+// follows the fork FIRST and the side-stream work (side_begin .. side_end) after it: the main queue
+// is the critical path and must not wait for the host to finish enqueuing the side chain.
+void side_mark(roms_hip_ctx *c) {
   if (!side_on(c)) return;
   (void)hipEventRecord(c->ev_fork, c->stream);
+}
+void side_begin(roms_hip_ctx *c) {
+  if (!side_on(c)) return;
   (void)hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
   std::swap(c->stream, c->stream2);
 }
@@ -826,6 +834,13 @@ static int main3d_one(roms_hip_ctx *c) {
   // single-tile run (no halo transport to order) the first chain, behind diag, goes to the side
   // stream; on a small grid neither chain fills the chip.
   const bool side_chain = cf.NtileI * cf.NtileJ == 1;
+  side_mark(c);
+  if (side_chain) {          // main stream first (see side_mark)
+    if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));   // :439
+    DO(roms_hip_set_vbc(c));                                  // :445
+    if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));       // :525
+    else if (cf.options & ROMS_LMD_MIXING) DO(roms_hip_lmd_vmix(c)); // :527
+  }
   side_begin(c);
   r = 0;
   if (do_diag) r = run_diag_async(c, c->d_diag);   // reads u, v, rho, wvel ... of this point of the step
@@ -836,12 +851,12 @@ static int main3d_one(roms_hip_ctx *c) {
   }
   side_end(c);
   if (r) return r;
-  if (!side_chain) DO(roms_hip_set_massflux(c));
-  if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));   // :439
-  DO(roms_hip_set_vbc(c));                                  // :445
-  if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));       // :525
-  else if (cf.options & ROMS_LMD_MIXING) DO(roms_hip_lmd_vmix(c)); // :527
   if (!side_chain) {
+    DO(roms_hip_set_massflux(c));
+    if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));
+    DO(roms_hip_set_vbc(c));
+    if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));
+    else if (cf.options & ROMS_LMD_MIXING) DO(roms_hip_lmd_vmix(c));
     DO(roms_hip_omega(c));
     side_join(c);
     DO(roms_hip_wvelocity(c, s.nstp));
@@ -851,12 +866,13 @@ static int main3d_one(roms_hip_ctx *c) {
   DO(roms_hip_set_zeta(c));                                 // :556
   // rhs3d :632 -- t3dmix2 only touches t(nnew): it overlaps prsgrd and rhs3d_tile
   DO(roms_hip_pre_step3d(c));
+  side_mark(c);
+  DO(roms_hip_prsgrd(c));
+  DO(roms_hip_rhs3d_tile(c));
   side_begin(c);
   r = roms_hip_t3dmix2(c);
   side_end(c);
   if (r) return r;
-  DO(roms_hip_prsgrd(c));
-  DO(roms_hip_rhs3d_tile(c));
   side_join(c);
   DO(roms_hip_uv3dmix2(c));
   for (int my_iif = 1; my_iif <= cf.nfast + 1; my_iif++) {  // :810-918
@@ -893,9 +909,15 @@ static int main3d_one(roms_hip_ctx *c) {
 
 extern "C" int roms_hip_main3d(roms_hip_ctx *c, int nsteps) {
   if (!c) return 8;
+  static const bool host_trace = getenv("ROMS_HIP_TRACE_HOST") != nullptr;   // measurement aid: host time to enqueue the steps
+  const auto t0 = std::chrono::steady_clock::now();
   for (int n = 0; n < nsteps; n++) {
     int r = main3d_one(c);
     if (r) return r;
+  }
+  if (host_trace && nsteps > 0) {
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "roms_hip_main3d: %d steps enqueued in %.1f us of host time (%.1f us per step)\n", nsteps, us, us / nsteps);
   }
   if (c->cfg.ninfo > 0 && nsteps > 0) {
     double out[16];

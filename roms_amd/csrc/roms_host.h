@@ -59,6 +59,7 @@ struct roms_hip_ctx {
 void ctx_sync_stepping(roms_hip_ctx *c);           // copy c->s into c->G
 // side-stream helpers (roms_hip.cpp): between side_begin and side_end launches go to the side stream,
 // ordered after everything launched so far; side_join makes the main stream wait for them
+void side_mark(roms_hip_ctx *c);
 void side_begin(roms_hip_ctx *c);
 void side_end(roms_hip_ctx *c);
 void side_join(roms_hip_ctx *c);
