@@ -21,6 +21,7 @@ int run_set_depth(roms_hip_ctx *c) {
   const int N = c->G.N;
   KArgs a = mk(c);
   LAUNCH_THREAD(k_set_depth, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, N, c->stream, a);
+  if (c->G.fuse3d) return 0;   // the kernel stored the periodic images itself (emit_store); h is time-invariant
   const HaloSpec hs1[] = {
       {c->F.h, 1, BC_NONE, 'r'},
       {c->F.z_w, N + 1, BC_NONE, 'r'},

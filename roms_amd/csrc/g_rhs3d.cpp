@@ -70,7 +70,36 @@ int run_rhs3d_tile(roms_hip_ctx *c) {
   const TB &B = G.T;
   KArgs a = mk(c);
   a.p0 = (G.N + KCH - 1) / KCH;
+  a.p1 = 0;
   LAUNCH_THREAD(k_rhs3d_pt, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2 * a.p0, c->stream, a);
+  LAUNCH_THREAD(k_rhs3d_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  return 0;
+}
+
+// The same two routines as the fused main3d sequence launches them: the point-wise kernels of
+// rhs3d_tile and uv3dmix2 are independent (the latter may run on the side stream), and ONE column
+// kernel then forms rufrc/rvfrc from both, in the reference's order of additions.
+int run_rhs3d_pt(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  KArgs a = mk(c);
+  a.p0 = (G.N + KCH - 1) / KCH;
+  LAUNCH_THREAD(k_rhs3d_pt, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2 * a.p0, c->stream, a);
+  return 0;
+}
+int run_uv3dmix2_s(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  if (!(G.options & ROMS_UV_VIS2)) return 0;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
+  return 0;
+}
+int run_rufrc_sums(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  KArgs a = mk(c);
+  a.p1 = (G.options & ROMS_UV_VIS2) ? 1 : 0;
   LAUNCH_THREAD(k_rhs3d_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   return 0;
 }

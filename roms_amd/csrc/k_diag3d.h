@@ -75,10 +75,11 @@ THREAD_KERNEL(k_set_depth, KArgs) {
     const double cff2_r = (cff_r + F.Cs_r[k - 1] * hwater) * hinv;
     zr_k = zt + (zt + hwater) * cff2_r;
   }
-  if (k == 1) F.z_w[XW(i, j, 0)] = zw_km1;
-  F.z_w[XW(i, j, k)] = zw_k;
-  F.z_r[X3(i, j, k)] = zr_k;
-  F.Hz[X3(i, j, k)] = zw_k - zw_km1;
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);                   // exchange of z_w, z_r, Hz :set_depth.F
+  if (k == 1) emit_store(G, P, F.z_w, zw_km1);
+  emit_store(G, P, F.z_w + (size_t)k * G.nij, zw_k);
+  emit_store(G, P, F.z_r + (size_t)(k - 1) * G.nij, zr_k);
+  emit_store(G, P, F.Hz + (size_t)(k - 1) * G.nij, zw_k - zw_km1);
 }
 THREAD_GLOBAL(k_set_depth, KArgs)
 

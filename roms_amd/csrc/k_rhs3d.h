@@ -705,13 +705,13 @@ THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
 #undef CFFR
 #undef CFFP
     if (do_u) {
-      F.wrk3[1][ok + x] = u1;
-      F.wrk3[2][ok + x] = u2;
+      F.wrk3[6][ok + x] = u1;
+      F.wrk3[7][ok + x] = u2;
       F.u[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] = un;
     }
     if (do_v) {
-      F.wrk3[3][ok + x] = v1;
-      F.wrk3[4][ok + x] = v2;
+      F.wrk3[8][ok + x] = v1;
+      F.wrk3[9][ok + x] = v2;
       F.v[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] = vn;
     }
   }
@@ -727,7 +727,7 @@ THREAD_KERNEL(k_uv3dmix2_sum, KArgs) {
   const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N;
   // eight levels are loaded before they are added (in order), so that the loads overlap
   if (i >= B.IstrU) {
-    const double *A1 = F.wrk3[1], *A2 = F.wrk3[2];
+    const double *A1 = F.wrk3[6], *A2 = F.wrk3[7];
     double ruf = F.rufrc[X2(i, j)];
     for (int k0 = 1; k0 <= N; k0 += 8) {
       double p[8], q[8];
@@ -739,7 +739,7 @@ THREAD_KERNEL(k_uv3dmix2_sum, KArgs) {
     F.rufrc[X2(i, j)] = ruf;
   }
   if (j >= B.JstrV) {
-    const double *A3 = F.wrk3[3], *A4 = F.wrk3[4];
+    const double *A3 = F.wrk3[8], *A4 = F.wrk3[9];
     double rvf = F.rvfrc[X2(i, j)];
     for (int k0 = 1; k0 <= N; k0 += 8) {
       double p[8], q[8];
@@ -983,6 +983,7 @@ THREAD_KERNEL(k_rhs3d_pt, KArgs) {
 }
 THREAD_GLOBAL(k_rhs3d_pt, KArgs)
 
+// p1 = 1: the sums of uv3dmix2's viscous terms are added here as well (fused main3d sequence).
 // rufrc, rvfrc = vertical sum of ru, rv (in k order) + surface - bottom stress :1700-1918; one thread
 // per column.  Eight levels are loaded at a time before they are added, so that the loads overlap.
 THREAD_KERNEL(k_rhs3d_sum, KArgs) {
@@ -1008,7 +1009,18 @@ THREAD_KERNEL(k_rhs3d_sum, KArgs) {
     const double cff = F.om_u[X2(i, j)] * F.on_u[X2(i, j)];
     const double c1 = F.sustr[X2(i, j)] * cff;
     const double c2 = -F.bustr[X2(i, j)] * cff;
-    F.rufrc[X2(i, j)] = sum + c1 + c2;
+    double ruf = sum + c1 + c2;
+    if (a.p1) {   // + the viscous terms of uv3dmix2 (k_uv3dmix2_sum), in the same order
+      const double *A1 = F.wrk3[6], *A2 = F.wrk3[7];
+      for (int k0 = 1; k0 <= N; k0 += 8) {
+        double p[8], q[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) { const int k = KMIN(k0 + m, N); p[m] = A1[X3(i, j, k)]; q[m] = A2[X3(i, j, k)]; }
+#pragma unroll
+        for (int m = 0; m < 8; m++) if (k0 + m <= N) ruf = ruf + p[m] + q[m];
+      }
+    }
+    F.rufrc[X2(i, j)] = ruf;
   }
   if (j >= B.JstrV) {
     double sum;
@@ -1016,7 +1028,18 @@ THREAD_KERNEL(k_rhs3d_sum, KArgs) {
     const double cff = F.om_v[X2(i, j)] * F.on_v[X2(i, j)];
     const double c1 = F.svstr[X2(i, j)] * cff;
     const double c2 = -F.bvstr[X2(i, j)] * cff;
-    F.rvfrc[X2(i, j)] = sum + c1 + c2;
+    double rvf = sum + c1 + c2;
+    if (a.p1) {
+      const double *A3 = F.wrk3[8], *A4 = F.wrk3[9];
+      for (int k0 = 1; k0 <= N; k0 += 8) {
+        double p[8], q[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) { const int k = KMIN(k0 + m, N); p[m] = A3[X3(i, j, k)]; q[m] = A4[X3(i, j, k)]; }
+#pragma unroll
+        for (int m = 0; m < 8; m++) if (k0 + m <= N) rvf = rvf + p[m] - q[m];
+      }
+    }
+    F.rvfrc[X2(i, j)] = rvf;
   }
 #undef COLSUM
 }

@@ -235,7 +235,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     c->allocs.push_back(p);
     *(double **)((char *)&c->F + g_fields[k].offset) = (double *)p;
   }
-  for (int k = 0; k < 6; k++) {
+  for (int k = 0; k < 10; k++) {
     void *p = nullptr;
     size_t n = (size_t)G.nij * (size_t)(G.N + 1) * (k == 0 ? (size_t)G.NT : 1);
     if (dmalloc(&p, n * sizeof(double))) { roms_hip_destroy(c); return 2; }
@@ -364,6 +364,9 @@ extern "C" int roms_hip_sync(roms_hip_ctx *c) { return dsync(c->stream); }
 // Measurement aid: n back-to-back launches of the barotropic kernel issued one by one and as one
 // captured hipGraph; microseconds per launch of both forms in out[0], out[1].
 int run_step2d(roms_hip_ctx *c);
+int run_rhs3d_pt(roms_hip_ctx *c);
+int run_uv3dmix2_s(roms_hip_ctx *c);
+int run_rufrc_sums(roms_hip_ctx *c);
 extern "C" int roms_hip_graph_probe(roms_hip_ctx *c, int n, int reps, double *out) {
 #ifdef ROMS_CPU_EMU
   (void)c; (void)n; (void)reps; (void)out;
@@ -868,13 +871,14 @@ static int main3d_one(roms_hip_ctx *c) {
   DO(roms_hip_pre_step3d(c));
   side_mark(c);
   DO(roms_hip_prsgrd(c));
-  DO(roms_hip_rhs3d_tile(c));
-  side_begin(c);
+  DO(run_rhs3d_pt(c));
+  side_begin(c);                      // side stream: t3dmix2 and the point-wise part of uv3dmix2
   r = roms_hip_t3dmix2(c);
+  if (!r) r = run_uv3dmix2_s(c);
   side_end(c);
   if (r) return r;
   side_join(c);
-  DO(roms_hip_uv3dmix2(c));
+  DO(run_rufrc_sums(c));              // rufrc/rvfrc of rhs3d_tile and uv3dmix2 in one kernel
   for (int my_iif = 1; my_iif <= cf.nfast + 1; my_iif++) {  // :810-918
     const int next_indx1 = 3 - s.indx1;
     if (!s.predictor && my_iif <= cf.nfast + 1) {
