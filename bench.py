@@ -56,7 +56,7 @@ ALGO_ARRAYS = {
     "k_uv3dmix2_s":   (11, 12),
     "k_uv3dmix2_sum": (4, 4),
     "k_rhs3d_pt":     (10, 3),     # u, v, Huon, Hvom, W, Hz read; ru, rv read-modify-write
-    "k_rhs3d_sum":    (2, 10),
+    "k_rhs3d_sum":    (6, 10),     # ru, rv and the four viscous terms of uv3dmix2 (fused main3d sequence)
     "k_s3uv_col":     (8, 6),
     "k_s3uv_couple":  (9, 8),
     "k_s3t_hv":       (12, 2),     # fused horizontal + vertical corrector advection, NT tracers
