@@ -17,7 +17,7 @@ int run_t3dmix2_geo(roms_hip_ctx *c);     // g_geo.cpp
 int run_pre_step3d(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
-  if (G.options & ROMS_SOLAR_SOURCE) { int r = run_swdk(c); if (r) return r; }
+  if ((G.options & ROMS_SOLAR_SOURCE) && !c->swdk_ready) { int r = run_swdk(c); if (r) return r; }
   KArgs a = mk(c);
   bool any_col = false;      // tracers with a spline vertical flux keep the two-kernel column path
   for (int it = 0; it < G.NT; it++) any_col |= G.vadv[it] == ROMS_SPLINES;

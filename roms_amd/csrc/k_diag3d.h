@@ -264,7 +264,7 @@ THREAD_KERNEL(k_omega, KArgs) {
 THREAD_GLOBAL(k_omega, KArgs)
 
 // ------------------------------------------------------------------------------ wvelocity
-// vert(i,j,k) into F.wrk3[5] (not [0]: the KPP kernels on the main stream use wrk3[0..4] concurrently); index space (Istr:Iend, Jstr:Jend, 1:N); p0 = Ninp
+// vert(i,j,k) into F.wrk3[6] (the KPP kernels on the main stream use wrk3[0..4] concurrently, swdk is [5]); index space (Istr:Iend, Jstr:Jend, 1:N); p0 = Ninp
 THREAD_KERNEL(k_wvel_vert, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
@@ -279,7 +279,7 @@ THREAD_KERNEL(k_wvel_vert, KArgs) {
   const double wjp = F.v[X4(i, j + 1, k, Ninp)] * (F.z_r[X3(i, j + 1, k)] - F.z_r[X3(i, j, k)]) *
                      (F.pn[X2(i, j)] + F.pn[X2(i, j + 1)]);
   vert = vert + 0.25 * (wj + wjp);
-  F.wrk3[5][X3(i, j, k)] = vert;
+  F.wrk3[6][X3(i, j, k)] = vert;
 }
 THREAD_GLOBAL(k_wvel_vert, KArgs)
 
@@ -288,7 +288,7 @@ THREAD_KERNEL(k_wvel, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz, N = G.N;
-  const double *vert = F.wrk3[5];
+  const double *vert = F.wrk3[6];
   const double cff1 = 3.0 / 8.0, cff2 = 3.0 / 4.0, cff3 = 1.0 / 8.0, cff4 = 9.0 / 16.0, cff5 = 1.0 / 16.0;
   const double zw0 = F.z_w[XW(i, j, 0)];
   const double wrk = (F.DU_avg1[X2(i, j)] - F.DU_avg1[X2(i + 1, j)] + F.DV_avg1[X2(i, j)] - F.DV_avg1[X2(i, j + 1)]) /

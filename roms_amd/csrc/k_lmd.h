@@ -3,8 +3,8 @@
 //   k_lmd_interior  lmd_vmix_tile    ROMS/Nonlinear/lmd_vmix.F:99-460  (LMD_RIMIX, RI_SPLINES)
 //   k_lmd_skpp      lmd_skpp_tile    ROMS/Nonlinear/lmd_skpp.F:98-930  (LMD_SKPP, LMD_NONLOCAL)
 //                   lmd_swfrac_tile  ROMS/Nonlinear/lmd_swfrac.F:6-140
-//   k_lmd_finish    lmd_finish_tile  ROMS/Nonlinear/lmd_vmix.F:465-560 (LMD_CONVEC; the edge fills
-//                                    :560-760 are done by the halo kernel)
+//   (lmd_finish_tile, ROMS/Nonlinear/lmd_vmix.F:465-560, LMD_CONVEC: applied by k_lmd_skpp's last
+//    sweep; the edge fills :560-760 by the storing thread or the halo kernel)
 //
 // Pure column physics: one thread per sigma-column; the per-column work arrays of the reference
 // (FC, dR, dU, dV, Bflux: 0:N) live in 3-D work arrays so that every level access of a wave is
@@ -321,19 +321,28 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
     Gs1 = Gt1;
     dGs1dS = dGt1dS;
   }
-  // (independent levels: four at a time, loads first)
+  // (independent levels: four at a time, loads first).  The convective adjustment of lmd_finish
+  // (lmd_vmix.F:465-560: Akv, Akt += lmd_nu0c*nu_sxc(bvf), point-wise on the final values) is applied
+  // here as the last operation on each level, and the boundary fill / exchange that follows it
+  // (:560-760) is done by the storing thread in fused runs.
+  const EmitPlan PA = emit_plan(G, BC_R, i, j);
+  const size_t nij_ = (size_t)G.nij, x_ = X2(i, j), oA_ = nij_ * (size_t)(N + 1);
   for (int k0 = 1; k0 <= N - 1; k0 += 4) {
-    double zw_[4], bf_[4], g1[4], g2[4];
+    double zw_[4], bf_[4], g1[4], g2[4], av[4], a1_[4], a2_[4], bv[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int k = KMIN(k0 + q, N - 1);
-      zw_[q] = z_w[XW(i, j, k)]; bf_[q] = Bflux[XW(i, j, k)];
-      g1[q] = F.ghats[XW4(i, j, k, 1)]; g2[q] = F.ghats[XW4(i, j, k, 2)];
+      const size_t ow = (size_t)k * nij_ + x_;
+      zw_[q] = z_w[ow]; bf_[q] = Bflux[ow];
+      g1[q] = F.ghats[ow]; g2[q] = F.ghats[ow + oA_];
+      av[q] = F.Akv[ow]; a1_[q] = F.Akt[ow]; a2_[q] = F.Akt[ow + oA_]; bv[q] = bvf[ow];
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int k = k0 + q;
       if (k > N - 1) break;
+      const size_t ow = (size_t)k * nij_;
+      double akv = av[q], akt1 = a1_[q], akt2 = a2_[q];
       if (k > ksbl) {
         const double depth = zwN - zw_[q];
         const double bf = bf_[q];
@@ -345,35 +354,27 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
         const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
         const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;
         const double Gs = a1 + a2 * Gs1 + a3 * dGs1dS;
-        F.Akv[XW(i, j, k)] = depth * wm * (1.0 + sigma * Gm);
-        F.Akt[XW4(i, j, k, 1)] = depth * ws * (1.0 + sigma * Gt);
-        F.Akt[XW4(i, j, k, 2)] = depth * ws * (1.0 + sigma * Gs);
+        akv = depth * wm * (1.0 + sigma * Gm);
+        akt1 = depth * ws * (1.0 + sigma * Gt);
+        akt2 = depth * ws * (1.0 + sigma * Gs);
         const double cff = a.lmd_Cg * (1.0 - (0.5 + copysign(0.5, bf))) / (zbl * ws + eps);
-        F.ghats[XW4(i, j, k, 1)] = cff * g1[q];
-        F.ghats[XW4(i, j, k, 2)] = cff * g2[q];
+        F.ghats[ow + x_] = cff * g1[q];
+        F.ghats[ow + x_ + oA_] = cff * g2[q];
       } else {
-        F.ghats[XW4(i, j, k, 1)] = 0.0;
-        F.ghats[XW4(i, j, k, 2)] = 0.0;
+        F.ghats[ow + x_] = 0.0;
+        F.ghats[ow + x_ + oA_] = 0.0;
       }
+      // lmd_finish :500-540
+      double cff = KMAX(bv[q], lmd_bvfcon);
+      cff = KMIN(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
+      double nu_sxc = 1.0 - cff * cff;
+      nu_sxc = nu_sxc * nu_sxc * nu_sxc;
+      emit_store(G, PA, F.Akv + ow, akv + lmd_nu0c * nu_sxc);
+      emit_store(G, PA, F.Akt + ow, akt1 + lmd_nu0c * nu_sxc);
+      emit_store(G, PA, F.Akt + ow + oA_, akt2 + lmd_nu0c * nu_sxc);
     }
   }
 }
 THREAD_GLOBAL(k_lmd_skpp, LmdArgs)
 
-// convective adjustment: point-wise; index space (Istr:Iend, Jstr:Jend, N-1)
-THREAD_KERNEL(k_lmd_finish, LmdArgs) {
-  const DGrid &G = a.G;
-  const Fields &F = a.Fv;
-  LMD_CONSTS;
-  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz + 1;
-  double cff = KMAX(F.bvf[XW(i, j, k)], lmd_bvfcon);
-  cff = KMIN(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
-  double nu_sxc = 1.0 - cff * cff;
-  nu_sxc = nu_sxc * nu_sxc * nu_sxc;
-  const EmitPlan P = emit_plan(G, BC_R, i, j);               // bc_w3d_tile + exchange lmd_vmix.F:560-760
-  const size_t ow = (size_t)k * (size_t)G.nij, oA = (size_t)G.nij * (size_t)(G.N + 1);
-  emit_store(G, P, F.Akv + ow, F.Akv[XW(i, j, k)] + lmd_nu0c * nu_sxc);
-  emit_store(G, P, F.Akt + ow, F.Akt[XW4(i, j, k, 1)] + lmd_nu0c * nu_sxc);
-  emit_store(G, P, F.Akt + ow + oA, F.Akt[XW4(i, j, k, 2)] + lmd_nu0c * nu_sxc);
-}
-THREAD_GLOBAL(k_lmd_finish, LmdArgs)
+

@@ -203,6 +203,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   memset(&c->comm, 0, sizeof(c->comm));
   c->comm_failed = false;
   c->m2d_dirty = true;
+  c->swdk_ready = false;
   {  // neighbours in the reference's tile numbering; a periodic direction wraps around
     const int NI = cfg->NtileI, NJ = cfg->NtileJ, it = cfg->tile % NI, jt = cfg->tile / NI;
     int *nb = c->comm.nbr;
@@ -367,6 +368,7 @@ int run_step2d(roms_hip_ctx *c);
 int run_rhs3d_pt(roms_hip_ctx *c);
 int run_uv3dmix2_s(roms_hip_ctx *c);
 int run_rufrc_sums(roms_hip_ctx *c);
+int run_swdk(roms_hip_ctx *c);
 extern "C" int roms_hip_graph_probe(roms_hip_ctx *c, int n, int reps, double *out) {
 #ifdef ROMS_CPU_EMU
   (void)c; (void)n; (void)reps; (void)out;
@@ -851,6 +853,8 @@ static int main3d_one(roms_hip_ctx *c) {
     r = roms_hip_set_massflux(c);
     if (!r) r = roms_hip_omega(c);
     if (!r) r = roms_hip_wvelocity(c, s.nstp);     // overwrites wvel, which diag reads: same stream, in order
+    if (!r) r = roms_hip_set_zeta(c);              // :556
+    if (!r && (cf.options & ROMS_SOLAR_SOURCE)) { r = run_swdk(c); c->swdk_ready = r == 0; }   // pre_step3d's first kernel
   }
   side_end(c);
   if (r) return r;
@@ -863,12 +867,13 @@ static int main3d_one(roms_hip_ctx *c) {
     DO(roms_hip_omega(c));
     side_join(c);
     DO(roms_hip_wvelocity(c, s.nstp));
+    DO(roms_hip_set_zeta(c));                               // :556
   } else {
     side_join(c);
   }
-  DO(roms_hip_set_zeta(c));                                 // :556
   // rhs3d :632 -- t3dmix2 only touches t(nnew): it overlaps prsgrd and rhs3d_tile
   DO(roms_hip_pre_step3d(c));
+  c->swdk_ready = false;
   side_mark(c);
   DO(roms_hip_prsgrd(c));
   DO(run_rhs3d_pt(c));
