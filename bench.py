@@ -66,8 +66,7 @@ ALGO_ARRAYS = {
     "k_eos_nl":       (8, 4),
     "k_rho_eos_lin":  (5, 2),
     "k_lmd_interior": (9, 0),
-    "k_lmd_skpp":     (15, 10),
-    "k_lmd_finish":   (7, 0),
+    "k_lmd_skpp":     (18, 10),    # incl. the convective adjustment of lmd_finish (Akv, Akt read-modify-write)
     "k_set_depth":    (3, 2),
     "k_set_massflux": (5, 2),
     "k_diag_col":     (7, 3),

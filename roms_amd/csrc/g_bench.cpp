@@ -69,7 +69,7 @@ int run_lmd_vmix(roms_hip_ctx *c) {
   LAUNCH_THREAD(k_lmd_interior, nx, ny, 1, c->stream, a);
   LAUNCH_THREAD(k_lmd_skpp, nx, ny, 1, c->stream, a);
   // (lmd_finish: fused into k_lmd_skpp's last sweep)
-  if (G.fuse3d) return 0;   // k_lmd_skpp / k_lmd_finish stored the boundary values and images (emit_store)
+  if (G.fuse3d) return 0;   // k_lmd_skpp stored the boundary values and images (emit_store)
   HaloSpec sp[3] = {{c->F.hsbl, 1, BC_R, 'r'},                       // bc_r2d_tile lmd_skpp.F:608
                     {c->F.Akv, N + 1, BC_R, 'r'},                    // bc_w3d_tile lmd_vmix.F:740-760
                     {c->F.Akt, (N + 1) * G.NAT, BC_R, 'r'}};
