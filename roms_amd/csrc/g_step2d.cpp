@@ -23,6 +23,10 @@ int run_step2d(roms_hip_ctx *c) {
   // kernel variant by sub-tile size: up to 32x4, up to 64x8, generic (ROMS_HIP_TILE2D overrides)
   int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 32 && G.bh2 <= 8) ? 3 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
   if (getenv("ROMS_HIP_S2D_GENERIC")) variant = 2;
+  // 64x8 sub-tiles: 1024 threads (one rectangle point and one momentum point per thread) measure 3 %
+  // faster than 512 threads with two each; ROMS_HIP_S2D_1024=0 selects the latter
+  const char *e1024 = getenv("ROMS_HIP_S2D_1024");
+  const bool wide = variant == 1 && !(e1024 && e1024[0] == '0');
 #ifdef ROMS_CPU_EMU
   variant = 2;   // the serial emulation has one "thread": only the generic form applies
 #endif
@@ -44,7 +48,21 @@ int run_step2d(roms_hip_ctx *c) {
       big_lds = true;
     }
 #endif
-    LAUNCH_COOP_AS(k_step2d, k_step2d_b, G.nbx2, G.nby2, 1, 512, lds, c->stream, a);
+    if (wide) {
+#ifndef ROMS_CPU_EMU
+      static bool big_lds_d = false;
+      if (!big_lds_d) {
+        if (hipFuncSetAttribute((const void *)k_step2d_d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+          set_error("k_step2d: cannot raise the dynamic LDS limit");
+          return 2;
+        }
+        big_lds_d = true;
+      }
+#endif
+      LAUNCH_COOP_AS(k_step2d, k_step2d_d, G.nbx2, G.nby2, 1, 1024, lds, c->stream, a);
+    } else {
+      LAUNCH_COOP_AS(k_step2d, k_step2d_b, G.nbx2, G.nby2, 1, 512, lds, c->stream, a);
+    }
   } else {
     int nthreads = 512;
     if (getenv("ROMS_HIP_S2D_THREADS")) nthreads = atoi(getenv("ROMS_HIP_S2D_THREADS"));

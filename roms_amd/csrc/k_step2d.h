@@ -569,12 +569,15 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
 #undef WV
 #undef INR
 
-// entry points: sub-tiles up to 32x4 (one rectangle point per thread, u- and v-points on different
-// waves), up to 64x8 (two rectangle points per thread), and the generic form
+// entry points: sub-tiles up to 32x4 (384 threads: one rectangle point per thread, u- and v-points on
+// different waves), up to 64x8 (1024 threads likewise, or 512 threads with two points each), up to
+// 32x8, and the generic form
 COOP_KERNEL(k_step2d_a, Step2dArgs) { k_step2d_t_body<32, 4, 384, 1>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d_a, Step2dArgs, 384)
 COOP_KERNEL(k_step2d_b, Step2dArgs) { k_step2d_t_body<64, 8, 512, 2>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d_b, Step2dArgs, 512)
+COOP_KERNEL(k_step2d_d, Step2dArgs) { k_step2d_t_body<64, 8, 1024, 1>(a, bx, by, bz, lds); }
+COOP_GLOBAL_LB(k_step2d_d, Step2dArgs, 1024)
 COOP_KERNEL(k_step2d_c, Step2dArgs) { k_step2d_t_body<32, 8, 512, 2>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d_c, Step2dArgs, 512)
 COOP_KERNEL(k_step2d, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0>(a, bx, by, bz, lds); }

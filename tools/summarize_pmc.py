@@ -29,7 +29,7 @@ def counter_avgs(d, counter):
             if r.get("Counter_Name") != counter:
                 continue
             k = r["Kernel_Name"].split("(")[0]
-            if k in ("k_step2d_a", "k_step2d_b", "k_step2d_c"):     # sub-tile variants of one kernel
+            if k in ("k_step2d_a", "k_step2d_b", "k_step2d_c", "k_step2d_d"):     # sub-tile variants of one kernel
                 k = "k_step2d"
             tot[k] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
