@@ -1,5 +1,6 @@
 // g_step3d.cpp -- launch sequences of step3d_uv and step3d_t.
 #include "roms_host.h"
+#include <cstdlib>
 #include "k_step3d.h"
 #include "k_mpdata.h"
 
@@ -64,7 +65,17 @@ int run_step3d_t(roms_hip_ctx *c) {
   a.p0 = (N + KCH - 1) / KCH;
   if (any_pt) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
   if (any_lds) LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
-  LAUNCH_THREAD(k_s3t_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);
+  {
+    const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
+#ifdef ROMS_CPU_EMU
+    LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
+#else
+    const char *er = getenv("ROMS_HIP_COLREGS");
+    const bool regs = !(er && er[0] == '0');
+    if (regs && N == 30) LAUNCH_THREAD_AS(k_s3t_col, k_s3t_col_n30, nx, ny, G.NT, c->stream, a);
+    else LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
+#endif
+  }
   for (int it = 1; it <= G.NT && any_mp; it++) {
     if (G.hadv[it - 1] != ROMS_MPDATA) continue;
     MpArgs m;

@@ -17,7 +17,8 @@
 
 // --------------------------------------------------------------------------------- step3d_uv
 // grid.z = 0: u on (IstrU:Iend, Jstr:Jend); 1: v on (Istr:Iend, JstrV:Jend)
-THREAD_KERNEL(k_s3uv_col, KArgs) {
+template <int NL>
+THREAD_KERNEL(k_s3uv_col_t, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB &B = G.T;
@@ -25,12 +26,12 @@ THREAD_KERNEL(k_s3uv_col, KArgs) {
   const int i = (dir == 0 ? B.IstrU : B.Istr) + gx, j = (dir == 0 ? B.Jstr : B.JstrV) + gy;
   if (i > B.Iend || j > B.Jend) return;
   const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1;
-  const int N = G.N, nrhs = G.nrhs, nnew = G.nnew;
+  const int N = NL ? NL : G.N, nrhs = G.nrhs, nnew = G.nnew;
   const double dt = G.dt;
   double *q = (dir == 0 ? F.u : F.v) + (size_t)(nnew - 1) * G.nij * N;
   const double *rq = (dir == 0 ? F.ru : F.rv) + (size_t)(nrhs - 1) * G.nij * (N + 1);
   const double *Akv = F.Akv, *Hz = F.Hz;
-  double CF[ROMS_NPRIV], DC[ROMS_NPRIV];
+  double CF[NL ? NL + 1 : ROMS_NPRIV], DC[NL ? NL + 1 : ROMS_NPRIV];   // NL > 0: registers (all loops unrolled)
 #define AKc(kk) (0.5 * (Akv[XW(i - di, j - dj, kk)] + Akv[XW(i, j, kk)]))
 #define HZc(kk) (0.5 * (Hz[X3(i - di, j - dj, kk)] + Hz[X3(i, j, kk)]))
   double cff;
@@ -48,7 +49,8 @@ THREAD_KERNEL(k_s3uv_col, KArgs) {
   {
     double CFm = 0.0, DCm = 0.0;       // CF(k-1), DC(k-1)
     double qprev = 0.0;                // q'(k0) carried from the previous chunk (its last level)
-    for (int k0 = 1; k0 <= N; k0 += 6) {
+    _Pragma("unroll") for (int k0 = 1; k0 <= N; k0 += 6) {
+      KSCHED_FENCE();
       double hz[7], qq[7], ak[8];      // level k0+q ; ak[q]: w-level k0-1+q
 #pragma unroll
       for (int qi = 0; qi < 7; qi++) {
@@ -84,7 +86,8 @@ THREAD_KERNEL(k_s3uv_col, KArgs) {
   }
   {
     double DCp = 0.0;                  // DC(k+1), final (DC(N) = 0)
-    for (int k0 = N - 1; k0 >= 1; k0 -= 6) {
+    _Pragma("unroll") for (int k0 = N - 1; k0 >= 1; k0 -= 6) {
+      KSCHED_FENCE();
       double cf[6], dc[6], ak[7], hz[6], qq[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) {
@@ -111,7 +114,7 @@ THREAD_KERNEL(k_s3uv_col, KArgs) {
     q[X3(i, j, 1)] = q[X3(i, j, 1)] + c;
   }
   double CF0 = 0.0, DCs = 0.0;
-  for (int k0 = 1; k0 <= N; k0 += 8) {
+  _Pragma("unroll 1") for (int k0 = 1; k0 <= N; k0 += 8) {
     double hz[8], qq[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) { const int kk = KMIN(k0 + m, N); hz[m] = HZc(kk); qq[m] = q[X3(i, j, kk)]; }
@@ -129,7 +132,7 @@ THREAD_KERNEL(k_s3uv_col, KArgs) {
   const double cff1 = 1.0 / (CF0 * omn1);
   const double corr = (DCs * omn1 - Davg) * cff1;
   const EmitPlan PQ = emit_plan(G, dir == 0 ? BC_U : BC_V, i, j);
-  for (int k0 = 1; k0 <= N; k0 += 8) {
+  _Pragma("unroll 1") for (int k0 = 1; k0 <= N; k0 += 8) {
     double qq[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) qq[m] = q[X3(i, j, KMIN(k0 + m, N))];
@@ -140,6 +143,10 @@ THREAD_KERNEL(k_s3uv_col, KArgs) {
 #undef AKc
 #undef HZc
 }
+// (NL > 0 would keep CF/DC in registers with all sweeps unrolled, as k_s3t_col_n30 does; for this
+// kernel the compiler then needs 464 VGPRs at N = 30 -- one wave per SIMD -- and it runs 1.4x slower
+// than with the private arrays, so only the run-time form is instantiated)
+THREAD_KERNEL(k_s3uv_col, KArgs) { k_s3uv_col_t_body<0>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_s3uv_col, KArgs)
 
 // coupling of 2-D and 3-D momentum, corrected mass fluxes, ubar/vbar(1:2).
@@ -378,10 +385,11 @@ COOP_GLOBAL(k_s3t_h, KArgs)
 
 // vertical advection + implicit vertical diffusion; one thread per column and tracer;
 // index space (Istr:Iend, Jstr:Jend, NT).  (MPDATA tracers are handled in k_mpdata.h.)
-THREAD_KERNEL(k_s3t_col, KArgs) {
+template <int NL>
+THREAD_KERNEL(k_s3t_col_t, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
-  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = G.N;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = NL ? NL : G.N;
   const int vs = G.vadv[itrc - 1], ltrc = KMIN(G.NAT, itrc);
   if (vs == ROMS_MPDATA) return;                 // k_mpdata.h
   const double dt = G.dt, eps1 = 1.0E-12;
@@ -390,7 +398,7 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
   const double *Hz = F.Hz, *W = F.W, *z_r = F.z_r;
   const double *Akt = F.Akt + (size_t)(ltrc - 1) * G.nij * (N + 1);
   const double pmn_dt = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];   // CF(i,0)
-  double CF[ROMS_NPRIV], DC[ROMS_NPRIV];
+  double CF[NL ? NL + 1 : ROMS_NPRIV], DC[NL ? NL + 1 : ROMS_NPRIV];   // NL > 0: registers (the diffusion sweeps are unrolled)
   const EmitPlan PT = emit_plan(G, BC_R, i, j);
   if (!s3t_point_path(G, itrc)) {   // otherwise k_s3t_hv has done the vertical advection already
   if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, T3, 1);
@@ -400,7 +408,7 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
   #define KAZ(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : 1.0 - fabs(F.pm[X2(i, j)] * F.pn[X2(i, j)] * dt * W[XW(i, j, kk)] / (z_r[X3(i, j, (kk) + 1)] - z_r[X3(i, j, kk)])))
   #define GZ(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : T3[X3(i, j, (kk) + 1)] - T3[X3(i, j, kk)])
     double FCm = 0.0;
-    for (int k = 1; k <= N; k++) {
+    _Pragma("unroll 1") for (int k = 1; k <= N; k++) {
       double FCk;
       if (vs == ROMS_SPLINES) FCk = F.wrk3[3][XW(i, j, k)];
       else if (vs == ROMS_HSIMT) {
@@ -436,7 +444,8 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
   {
     const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
     double CFm = 0.0, DCm = 0.0;       // CF(k-1), DC(k-1)
-    for (int k0 = 1; k0 <= N - 1; k0 += 6) {
+    _Pragma("unroll") for (int k0 = 1; k0 <= N - 1; k0 += 6) {
+      KSCHED_FENCE();
       double hz[7], tt[7], ak[8];      // hz[q], tt[q]: level k0+q ; ak[q]: w-level k0-1+q
 #pragma unroll
       for (int q = 0; q < 7; q++) { const int kk = KMIN(k0 + q, N); hz[q] = Hz[X3(i, j, kk)]; tt[q] = tn[X3(i, j, kk)]; }
@@ -459,7 +468,8 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
       }
     }
     double DCp = 0.0;                  // DC(k+1), final (DC(N) = 0)
-    for (int k0 = N - 1; k0 >= 1; k0 -= 6) {
+    _Pragma("unroll") for (int k0 = N - 1; k0 >= 1; k0 -= 6) {
+      KSCHED_FENCE();
       double cf[6], dc[6], ak[7], hz[6], tt[6];   // cf,dc: level k0-m ; ak[q]: w-level k0+1-q ; hz,tt: level k0+1-m
 #pragma unroll
       for (int m = 0; m < 6; m++) {
@@ -488,4 +498,11 @@ THREAD_KERNEL(k_s3t_col, KArgs) {
     }
   }
 }
+// entry points: N = 30 (the BENCHMARK grids) keeps the elimination coefficients CF/DC of the column in
+// registers -- the diffusion sweeps are fully unrolled, 174 VGPRs, no private-memory traffic:
+// 456 -> 263 us on 2048x256x30; at N = 50 the same form needs 256 VGPRs and is slower than the
+// private (scratch) arrays of the run-time form, which every other N uses
+THREAD_KERNEL(k_s3t_col, KArgs) { k_s3t_col_t_body<0>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_s3t_col, KArgs)
+THREAD_KERNEL(k_s3t_col_n30, KArgs) { k_s3t_col_t_body<30>(a, gx, gy, gz); }
+THREAD_GLOBAL(k_s3t_col_n30, KArgs)

@@ -28,6 +28,7 @@
 #define KTID 0
 #define KNT 1
 #define KSYNC() ((void)0)
+#define KSCHED_FENCE() ((void)0)
 typedef void *kstream_t;
 struct kdim3 { int x, y, z; };
 
@@ -45,6 +46,7 @@ struct kdim3 { int x, y, z; };
 #define LAUNCH_COOP_AS(label, name, gx, gy, gz, nthreads, lds_doubles, stream, args) \
   LAUNCH_COOP(name, gx, gy, gz, nthreads, lds_doubles, stream, args)
 
+#define LAUNCH_THREAD_AS(label, name, nx, ny, nz, stream, args) LAUNCH_THREAD(name, nx, ny, nz, stream, args)
 #define THREAD_KERNEL(name, ArgT) static inline void name##_body(const ArgT &a, int gx, int gy, int gz)
 #define THREAD_GLOBAL(name, ArgT)
 #define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
@@ -60,6 +62,9 @@ struct kdim3 { int x, y, z; };
 #define KTID ((int)threadIdx.x)
 #define KNT ((int)blockDim.x)
 #define KSYNC() __syncthreads()
+// nothing is scheduled across this point: keeps the loads of a later chunk of an unrolled column sweep
+// from being hoisted above the earlier chunks (register pressure)
+#define KSCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 typedef hipStream_t kstream_t;
 
 #define COOP_KERNEL(name, ArgT) static __device__ __forceinline__ void name##_body(const ArgT &a, int bx, int by, int bz, double *lds)
@@ -119,6 +124,10 @@ void kprof_end(int slot, hipStream_t stream);
 // 64 lanes along xi (coalesced), 4 rows of eta per block; 1-D grid of 8*ceil(blocks/8)*nz workgroups
 #define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
   KPROF_WRAP(name, stream,                                                               \
+  hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + 3) / 4)) + 7) / 8) * (nz)), 1, 1), \
+                     dim3(64, 4, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
+#define LAUNCH_THREAD_AS(label, name, nx, ny, nz, stream, args)                           \
+  KPROF_WRAP(label, stream,                                                              \
   hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + 3) / 4)) + 7) / 8) * (nz)), 1, 1), \
                      dim3(64, 4, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
 #endif
