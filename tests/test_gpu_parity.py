@@ -239,14 +239,15 @@ def test_bench_under_torchrun_single_rank(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,dims,nsteps,tol", [("benchmark1", None, 4, 1e-12), ("upwelling", None, 12, 1e-11),
                                                        ("ns512", (96, 40, 50), 6, 1e-11),
-                                                       ("benchmark2", (192, 40, 30), 4, 1e-12)])
+                                                       ("benchmark2", (192, 40, 30), 4, 1e-12),
+                                                       ("benchmark2", None, 3, 1e-12)])
 def test_baseline_size_matches_oracle(workload, dims, nsteps, tol):
     """BASELINE.json's own grids (BENCHMARK1 512x64x30 with its full physics; UPWELLING 41x80x16), set
     up by the Fortran host from roms.in values: every prognostic field against the oracle, plus the
     size-independent property the domain offers -- the volume integral is conserved to round-off.
     The two cases with explicit dimensions keep the BASELINE number of levels (50, 30: the kernels have
-    forms specialised on it) and the block/XCD maps of a wide grid on a horizontal size the oracle
-    finishes in seconds."""
+    forms specialised on it) on a horizontal size the oracle finishes in a second; BENCHMARK2
+    1024x128x30 at full size is the smallest grid that takes the 64x8-sub-tile barotropic kernel."""
     import bench
     from roms_amd import tiling
     from oracle import orc
