@@ -939,3 +939,46 @@ extern "C" int roms_hip_main3d(roms_hip_ctx *c, int nsteps) {
   }
   return 0;
 }
+
+// Measurement aid: one whole step captured as a hipGraph (both streams) and replayed `reps` times,
+// against `reps` steps launched kernel by kernel; microseconds per step in out[0] (plain), out[1]
+// (graph).  The replay repeats the captured arguments (the model state it leaves is meaningless).
+extern "C" int roms_hip_graph_step_probe(roms_hip_ctx *c, int reps, double *out) {
+#ifdef ROMS_CPU_EMU
+  (void)c; (void)reps; (void)out;
+  return 5;
+#else
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float ms = 0.f;
+  int r;
+  for (int k = 0; k < 3; k++) if ((r = main3d_one(c))) return r;
+  (void)hipEventRecord(e0, c->stream);
+  for (int k = 0; k < reps; k++) if ((r = main3d_one(c))) return r;
+  (void)hipEventRecord(e1, c->stream);
+  (void)hipEventSynchronize(e1);
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  out[0] = 1e3 * ms / reps;
+  hipGraph_t g; hipGraphExec_t ge;
+  if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { set_error("capture begin"); return 2; }
+  r = main3d_one(c);
+  hipError_t ec = hipStreamEndCapture(c->stream, &g);
+  if (r) return r;
+  if (ec != hipSuccess) { set_error(std::string("capture end: ") + hipGetErrorString(ec)); return 2; }
+  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { set_error("graph instantiate"); return 2; }
+  for (int w = 0; w < 2; w++) {
+    (void)hipEventRecord(e0, c->stream);
+    for (int k = 0; k < reps; k++) (void)hipGraphLaunch(ge, c->stream);
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  out[1] = 1e3 * ms / reps;
+  size_t nn = 0;
+  (void)hipGraphGetNodes(g, nullptr, &nn);
+  out[2] = (double)nn;
+  (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return 0;
+#endif
+}

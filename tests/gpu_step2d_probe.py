@@ -50,3 +50,10 @@ if os.environ.get("GRAPH_PROBE"):
     ctx.set_stepping(iif=2, predictor=1, kstp=2, krhs=1, knew=3)
     r = ctx.L.roms_hip_graph_probe(ctx.h, 59, 20, out)
     print("graph probe rc", r, "us/launch plain %.2f graph %.2f" % (out[0], out[1]))
+
+if os.environ.get("GRAPH_STEP_PROBE"):
+    import ctypes as C
+    out = (C.c_double * 3)()
+    ctx.L.roms_hip_graph_step_probe.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    r = ctx.L.roms_hip_graph_step_probe(ctx.h, 20, out)
+    print("graph step probe rc", r, "us/step plain %.1f graph %.1f nodes %d" % (out[0], out[1], int(out[2])), hiplib.last_error() if r else "")
