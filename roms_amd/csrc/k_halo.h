@@ -113,7 +113,7 @@ COOP_KERNEL(halo_kernel, HaloArgs) {
     if (G.ewp) { Imin = B.Istr; Imax = B.Iend; }
     else { Imin = (gt == 'r' || gt == 'v') ? B.IstrR : B.Istr; Imax = B.IendR; }
     const int ng3 = G.Nghost == 3;
-    if (G.ewp && B.west && B.east) {
+    if (G.ewp && B.west && B.east && G.xloc) {
       KLOOP1(j, Jmin, Jmax) {
         A[X2(Lm + 1, j)] = A[X2(1, j)];
         A[X2(Lm + 2, j)] = A[X2(2, j)];
@@ -123,7 +123,7 @@ COOP_KERNEL(halo_kernel, HaloArgs) {
         A[X2(0, j)] = A[X2(Lm, j)];
       }
     }
-    if (G.nsp && B.south && B.north) {
+    if (G.nsp && B.south && B.north && G.yloc) {
       KLOOP1(i, Imin, Imax) {
         A[X2(i, Mm + 1)] = A[X2(i, 1)];
         A[X2(i, Mm + 2)] = A[X2(i, 2)];
@@ -133,7 +133,7 @@ COOP_KERNEL(halo_kernel, HaloArgs) {
         A[X2(i, 0)] = A[X2(i, Mm)];
       }
     }
-    if (G.ewp && G.nsp && B.sw && B.ne && KTID == 0) {
+    if (G.ewp && G.nsp && B.sw && B.ne && G.xloc && G.yloc && KTID == 0) {
       const int ne = ng3 ? 3 : 2;
       for (int dj = 1; dj <= ne; dj++)
         for (int di = 1; di <= ne; di++) A[X2(Lm + di, Mm + dj)] = A[X2(di, dj)];

@@ -37,6 +37,7 @@ struct DGrid {
   int dbg_stop;
   int fuse_halo;              // 1: single tile, k_step2d fills boundary/periodic ghost points itself (k_haloblock.h)
   int fuse3d;                 // 1: the 3-D producers do so too (emit_plan/emit_store); ROMS_HIP_FUSE3D=0 turns it off
+  int xloc, yloc;             // 1: a periodic direction of this tile wraps onto itself by a local copy (no exchange partner)
   int nbx2, nby2, bw2, bh2;   // the same for the 2-D (barotropic) kernel: smaller sub-tiles, the
                               // 2-D grid alone cannot fill 256 CUs otherwise
   // stepping (mod_stepping)

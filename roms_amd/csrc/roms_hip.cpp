@@ -184,11 +184,29 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
                     cfg->west_edge, cfg->east_edge, cfg->south_edge, cfg->north_edge);
   choose_blocks(G);
   G.dbg_stop = getenv("ROMS_HIP_DBG_STOP") ? atoi(getenv("ROMS_HIP_DBG_STOP")) : 0;
+  {  // neighbours in the reference's tile numbering; a periodic direction wraps around.
+     // ROMS_HIP_SELF_EXCHANGE=1 (test aid): a tile that is alone in a periodic direction exchanges with
+     // ITSELF through the transport instead of copying locally -- the message pattern of a 2-tile
+     // periodic partition (both neighbours the same rank, two messages per pair matched by issue order)
+     // on one GPU, so that the RCCL send/recv path can be exercised without a second device.
+    memset(&c->comm, 0, sizeof(c->comm));
+    const int NI = cfg->NtileI, NJ = cfg->NtileJ, it = cfg->tile % NI, jt = cfg->tile / NI;
+    const char *es = getenv("ROMS_HIP_SELF_EXCHANGE");
+    const bool self = es && es[0] == '1';
+    int *nb = c->comm.nbr;
+    nb[0] = it > 0 ? cfg->tile - 1 : (cfg->EWperiodic && (NI > 1 || self) ? cfg->tile + NI - 1 : -1);
+    nb[1] = it < NI - 1 ? cfg->tile + 1 : (cfg->EWperiodic && (NI > 1 || self) ? cfg->tile - (NI - 1) : -1);
+    nb[2] = jt > 0 ? cfg->tile - NI : (cfg->NSperiodic && (NJ > 1 || self) ? cfg->tile + NI * (NJ - 1) : -1);
+    nb[3] = jt < NJ - 1 ? cfg->tile + NI : (cfg->NSperiodic && (NJ > 1 || self) ? cfg->tile - NI * (NJ - 1) : -1);
+    G.xloc = nb[0] < 0 && nb[1] < 0;
+    G.yloc = nb[2] < 0 && nb[3] < 0;
+    c->has_exchange = nb[0] >= 0 || nb[1] >= 0 || nb[2] >= 0 || nb[3] >= 0;
+  }
   {  // producer-side halo fills need the whole domain on this GPU and edge sub-tiles that own the
      // three source lines of a periodic copy
     const int LmT = cfg->Iend - cfg->Istr + 1, MmT = cfg->Jend - cfg->Jstr + 1;
     const char *e = getenv("ROMS_HIP_FUSE_HALO");
-    G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && (cfg->EWperiodic || cfg->NSperiodic) && LmT >= 6 && MmT >= 6 &&
+    G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && !c->has_exchange && (cfg->EWperiodic || cfg->NSperiodic) && LmT >= 6 && MmT >= 6 &&
                   !(e && e[0] == '0');
     const char *e3 = getenv("ROMS_HIP_FUSE3D");
     G.fuse3d = G.fuse_halo && !(e3 && e3[0] == '0');
@@ -200,18 +218,9 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   G.Vtransform = cfg->Vtransform;
   c->profile = false;
   memset(c->regions, 0, sizeof(c->regions));
-  memset(&c->comm, 0, sizeof(c->comm));
   c->comm_failed = false;
   c->m2d_dirty = true;
   c->swdk_ready = false;
-  {  // neighbours in the reference's tile numbering; a periodic direction wraps around
-    const int NI = cfg->NtileI, NJ = cfg->NtileJ, it = cfg->tile % NI, jt = cfg->tile / NI;
-    int *nb = c->comm.nbr;
-    nb[0] = it > 0 ? cfg->tile - 1 : (cfg->EWperiodic && NI > 1 ? cfg->tile + NI - 1 : -1);
-    nb[1] = it < NI - 1 ? cfg->tile + 1 : (cfg->EWperiodic && NI > 1 ? cfg->tile - (NI - 1) : -1);
-    nb[2] = jt > 0 ? cfg->tile - NI : (cfg->NSperiodic && NJ > 1 ? cfg->tile + NI * (NJ - 1) : -1);
-    nb[3] = jt < NJ - 1 ? cfg->tile + NI : (cfg->NSperiodic && NJ > 1 ? cfg->tile - NI * (NJ - 1) : -1);
-  }
 #ifdef ROMS_CPU_EMU
   c->stream = nullptr;
   c->stream2 = nullptr;
@@ -838,7 +847,7 @@ static int main3d_one(roms_hip_ctx *c) {
   // surface forcing / vertical mixing (:439-527), which needs neither Huon/Hvom nor W.  In a
   // single-tile run (no halo transport to order) the first chain, behind diag, goes to the side
   // stream; on a small grid neither chain fills the chip.
-  const bool side_chain = cf.NtileI * cf.NtileJ == 1;
+  const bool side_chain = !c->has_exchange;
   side_mark(c);
   if (side_chain) {          // main stream first (see side_mark)
     if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));   // :439

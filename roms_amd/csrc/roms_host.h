@@ -35,6 +35,7 @@ struct roms_hip_ctx {
   roms_hip_config cfg;
   TileComm comm;
   bool comm_failed;             // a halo exchange failed (reported by the next ctx_check)
+  bool has_exchange;            // some neighbour is reached through the transport (multi-tile, or the self-exchange test aid)
   bool swdk_ready;              // main3d_one has launched k_swdk already (side stream): run_pre_step3d skips it
   bool m2d_dirty;               // grid arrays uploaded since Fields::m2r/m2p were packed (g_step2d.cpp)
   DGrid G;

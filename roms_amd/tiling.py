@@ -36,7 +36,7 @@ def partition(world):
 
 class TiledRun:
     def __init__(self, cs, rank=0, world=1, device=0, dist=None, transport=None, weak=True,
-                 host_lib=None, hip_lib=None, tiles=None):
+                 host_lib=None, hip_lib=None, tiles=None, self_exchange=False):
         self.rank, self.world, self.dist = rank, world, dist
         self.NtileI, self.NtileJ = tiles or partition(world)
         assert self.NtileI * self.NtileJ == world
@@ -48,8 +48,23 @@ class TiledRun:
         self.case = g
         self.host = hostlib.Host(params=g, lib_path=host_lib, hip_lib_path=hip_lib)
         self.nfast = self.host.dims["nfast"]
-        self.ctx = self.host.device_init(device, tile=rank, start=False)
+        # self_exchange (test aid, single tile): the periodic direction is closed through the halo
+        # transport -- the tile is its own west and east neighbour -- instead of a local copy
+        import os
+        if self_exchange:
+            assert world == 1
+            os.environ["ROMS_HIP_SELF_EXCHANGE"] = "1"
+        try:
+            self.ctx = self.host.device_init(device, tile=rank, start=False)
+        finally:
+            os.environ.pop("ROMS_HIP_SELF_EXCHANGE", None)
         self._cb = None
+        if self_exchange:
+            transport = transport or "rccl"
+            if transport == "rccl":
+                self._install_rccl()
+            else:
+                self._install_dist(staged=(transport == "dist_staged"))
         if world > 1:
             transport = transport or "rccl"
             if transport == "rccl":
@@ -64,14 +79,17 @@ class TiledRun:
 
     # ------------------------------------------------------------------ transports
     def _install_rccl(self):
-        import torch
         L = self.ctx.L
         uid = (C.c_ubyte * 128)()
         if self.rank == 0:
             self.ctx._ck(L.roms_hip_rccl_unique_id(uid))
-        t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda" if torch.cuda.is_available() else "cpu")
-        self.dist.broadcast(t, 0)
-        raw = bytes(t.cpu().tolist())
+        if self.world > 1:
+            import torch
+            t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda" if torch.cuda.is_available() else "cpu")
+            self.dist.broadcast(t, 0)
+            raw = bytes(t.cpu().tolist())
+        else:
+            raw = bytes(uid)
         self.ctx._ck(L.roms_hip_comm_rccl(self.ctx.h, raw, self.world, self.rank))
 
     def _install_dist(self, staged=False):

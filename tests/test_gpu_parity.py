@@ -336,3 +336,42 @@ def test_tiles_on_one_gpu_match_single_tile(tmp_path, tag, kw, tiles, port):
     assert int(got["nexchanges"]) > 50 * steps
     for n in fields:
         assert np.array_equal(got[n], ref[n]), (n, float(np.abs(got[n] - ref[n]).max()))
+
+
+@pytest.mark.gpu
+def test_rccl_self_exchange_matches_local_periodic_copy():
+    """The RCCL send/recv path on ONE GPU: with ROMS_HIP_SELF_EXCHANGE the tile is its own west and east
+    neighbour (the message pattern of a 2-tile periodic partition: two messages per pair of ranks,
+    matched by issue order), so every periodic ghost column travels through pack kernel -> ncclSend /
+    ncclRecv in one group -> unpack kernel instead of the local copy.  Fields must equal the ordinary
+    single-tile run bit for bit.  (Own process: RCCL wants its communicator on a clean HIP state.)"""
+    import subprocess
+    import sys
+    import textwrap
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import bench
+        from roms_amd import tiling
+        cs = bench.params_for("benchmark1", 96, 32, 10)
+        cs["ninfo"] = 1
+        run = tiling.TiledRun(cs, self_exchange=True, transport="rccl")
+        run.step(3)
+        run.sync()
+        nx = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
+        assert nx > 100, nx                    # every exchange point went through RCCL
+        got = {n: run.ctx.download(n).copy() for n in %r}
+        run.close()
+        ref = tiling.TiledRun(cs)
+        ref.step(3)
+        ref.sync()
+        for n, g in got.items():
+            assert np.array_equal(g, ref.ctx.download(n)), n
+        ref.close()
+        print("SELF-EXCHANGE-OK", nx)
+    """) % (ROOT, ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "rho", "Akv", "Huon", "DU_avg1"])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert "SELF-EXCHANGE-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
