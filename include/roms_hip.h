@@ -158,16 +158,22 @@ int roms_hip_region_seconds(roms_hip_ctx *ctx, int region, double *seconds, long
    around [Istr,Iend]x[Jstr,Jend]: three ghost columns/rows on the low side, Nghost on the high
    side (the layout of the reference's periodic arrays), or the boundary points of the domain
    edge.  Wherever the reference calls mp_exchange2d/3d/4d (mp_exchange.F:28,1025,1755) the
-   library packs the strips on the device and moves them with one of two transports, which must
-   be installed before roms_hip_start:
-     roms_hip_comm_rccl      built-in RCCL send/recv on the context's stream (rank = tile);
-                             the 128-byte unique id comes from roms_hip_rccl_unique_id on rank 0
-                             and is distributed by the caller (MPI_Bcast, torch.distributed ...)
+   library applies the boundary conditions and packs the strips on the device (one launch),
+   moves them -- full-height xi strips, full-width eta strips and the corner blocks of the
+   diagonal neighbours in ONE message phase, which leaves the ghost zone exactly as the
+   reference's xi phase followed by its eta phase -- and unpacks (one launch).  Two transports,
+   one of which must be installed before roms_hip_start:
+     roms_hip_comm_rccl      built-in RCCL send/recv on the context's stream (rank = tile), one
+                             group per exchange point; the 128-byte unique id comes from
+                             roms_hip_rccl_unique_id on rank 0 and is distributed by the caller
+                             (MPI_Bcast, torch.distributed ...)
      roms_hip_set_exchange   a caller-supplied function: it receives DEVICE pointers (host
                              pointers in the CPU-emulated test build) after the stream has been
                              synchronised, must complete all sends and receives before it
                              returns, and returns 0 on success.  Message m is matched by
-                             (peer, tag): tags 0/1 = eastward/westward, 2/3 = northward/southward. */
+                             (peer, tag), tag = direction of travel: 0/1 = eastward/westward,
+                             2/3 = northward/southward, 4..7 = NE, NW, SE, SW; messages are
+                             listed in ascending tag order on both sides. */
 typedef int (*roms_hip_exchange_fn)(void *user, int nsend, const int *send_peer, double *const *send_buf,
                                     const long *send_count, const int *send_tag, int nrecv,
                                     const int *recv_peer, double *const *recv_buf, const long *recv_count,

@@ -26,27 +26,30 @@ struct HaloArgs {
   HaloItem it[HALO_MAXITEMS];
 };
 
-COOP_KERNEL(halo_kernel, HaloArgs) {
-  (void)bx; (void)by; (void)lds;
-  const DGrid &G = a.G;
-  const TB &B = G.T;
-  // select this block's item without indexing the kernel-argument array dynamically (a dynamic
-  // index makes the compiler copy the whole argument struct to scratch memory)
+// the plane a block works on: item and plane of block bz, selected without indexing the
+// kernel-argument array dynamically (a dynamic index makes the compiler copy the whole argument
+// struct to scratch memory)
+template <class ArgT>
+KDEV double *halo_plane(const ArgT &a, int bz, int &bc, int &gtype) {
   double *A = nullptr;
-  int bc = BC_NONE, gtype = 0;
-  {
-    int first = 0;
+  bc = BC_NONE; gtype = 0;
+  int first = 0;
 #pragma unroll
-    for (int k = 0; k < HALO_MAXITEMS; k++) {
-      const int nk = k < a.nitems ? a.it[k].nk : 0;
-      if (bz >= first && bz < first + nk) {
-        A = a.it[k].A + (size_t)(bz - first) * (size_t)G.nij;
-        bc = a.it[k].bc;
-        gtype = a.it[k].gtype;
-      }
-      first += nk;
+  for (int k = 0; k < HALO_MAXITEMS; k++) {
+    const int nk = k < a.nitems ? a.it[k].nk : 0;
+    if (bz >= first && bz < first + nk) {
+      A = a.it[k].A + (size_t)(bz - first) * (size_t)a.G.nij;
+      bc = a.it[k].bc;
+      gtype = a.it[k].gtype;
     }
+    first += nk;
   }
+  return A;
+}
+
+// boundary fills and local periodic copies of one plane, by one thread block
+KDEV void halo_fill(const DGrid &G, double *A, int bc, int gtype) {
+  const TB &B = G.T;
   const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
   const int Lm = G.Lm, Mm = G.Mm;
   const double gamma2 = G.gamma2;
@@ -146,6 +149,13 @@ COOP_KERNEL(halo_kernel, HaloArgs) {
     }
   }
 }
+
+COOP_KERNEL(halo_kernel, HaloArgs) {
+  (void)bx; (void)by; (void)lds;
+  int bc, gtype;
+  double *A = halo_plane(a, bz, bc, gtype);
+  halo_fill(a.G, A, bc, gtype);
+}
 COOP_GLOBAL(halo_kernel, HaloArgs)
 
 // ------------------------------------------------------------------------------------------
@@ -153,58 +163,71 @@ COOP_GLOBAL(halo_kernel, HaloArgs)
 // (ROMS/Utility/mp_exchange.F:28-2300) with the strip geometry of the periodic copies above --
 // a tile's three west ghost columns {Istr-3..Istr-1} come from its west neighbour's last three
 // interior columns {Iend-2..Iend}; its Nghost east ghost columns {Iend+1..Iend+Nghost} from the
-// east neighbour's first Nghost interior columns; the same along eta.  Phase 0 moves full-height
-// xi strips, phase 1 full-width eta strips (which then carry the corners), as in the reference.
+// east neighbour's first Nghost interior columns; the same along eta.
 //
-// Message layout: [plane][line][c], c = position across the strip.
+// The reference moves full-height xi strips, then full-width eta strips which carry the corners
+// (two dependent message phases).  Here ONE message phase gives the same ghost zone: full-height
+// xi strips, full-width eta strips and the corner blocks from the four diagonal neighbours go out
+// together; the receiver unpacks xi, then eta, then the corners, so the corner cells end up with
+// the diagonal tile's interior values exactly as after the reference's second phase.  The
+// boundary fills of the exchange point run in the pack launch (same block, same plane), so an
+// exchange point costs two launches and one send/recv group.
+//
+// Directions d: 0 W, 1 E, 2 S, 3 N, 4 SW, 5 SE, 6 NW, 7 NE.
+// Message layout: [plane][row][column] of the rectangle, columns fastest.
 // ------------------------------------------------------------------------------------------
-struct StripArgs {
+struct XchgArgs {
   DGrid G;
   int nitems;
   HaloItem it[HALO_MAXITEMS];
-  int phase;           // 0: xi (west/east neighbours), 1: eta (south/north)
-  int unpack;          // 0: pack own interior columns into send buffers, 1: unpack into ghosts
-  double *lo;          // pack: strip sent to the west/south neighbour ; unpack: received from it
-  double *hi;          // pack: strip sent to the east/north neighbour ; unpack: received from it
+  int unpack;          // 0: (boundary fills and) pack own lines into send buffers, 1: unpack into ghosts
+  int fill;            // pack launch: run halo_fill first
+  double *buf[8];      // pack: message for neighbour d ; unpack: message received from neighbour d (null: none)
 };
 
-COOP_KERNEL(strip_kernel, StripArgs) {
+// rectangle of direction d: source lines of the message sent to neighbour d (unpack = 0) or ghost
+// lines filled by the message from neighbour d (unpack = 1)
+KDEV void xchg_rect(const DGrid &G, int d, int unpack, int &i0, int &i1, int &j0, int &j1) {
+  const TB &B = G.T;
+  const int ng = G.Nghost;
+  const int dx = (d == 0 || d == 4 || d == 6) ? -1 : ((d == 1 || d == 5 || d == 7) ? 1 : 0);
+  const int dy = (d == 2 || d == 4 || d == 5) ? -1 : ((d == 3 || d == 6 || d == 7) ? 1 : 0);
+  if (dx == 0) { i0 = G.LBi; i1 = G.LBi + G.ni - 1; }
+  else if (dx < 0) { i0 = unpack ? B.Istr - 3 : B.Istr; i1 = unpack ? B.Istr - 1 : B.Istr + ng - 1; }
+  else { i0 = unpack ? B.Iend + 1 : B.Iend - 2; i1 = unpack ? B.Iend + ng : B.Iend; }
+  if (dy == 0) { j0 = G.LBj; j1 = G.LBj + G.nj - 1; }
+  else if (dy < 0) { j0 = unpack ? B.Jstr - 3 : B.Jstr; j1 = unpack ? B.Jstr - 1 : B.Jstr + ng - 1; }
+  else { j0 = unpack ? B.Jend + 1 : B.Jend - 2; j1 = unpack ? B.Jend + ng : B.Jend; }
+}
+
+KDEV void xchg_move(const DGrid &G, double *A, double *msg, int bz, int d, int unpack) {
+  if (!msg) return;
+  int i0, i1, j0, j1;
+  xchg_rect(G, d, unpack, i0, i1, j0, j1);
+  const int w = i1 - i0 + 1;
+  double *m = msg + (size_t)bz * (size_t)w * (size_t)(j1 - j0 + 1);
+  if (unpack) KLOOP2(i, j, i0, i1, j0, j1) A[X2(i, j)] = m[(j - j0) * w + (i - i0)];
+  else KLOOP2(i, j, i0, i1, j0, j1) m[(j - j0) * w + (i - i0)] = A[X2(i, j)];
+}
+
+COOP_KERNEL(xchg_kernel, XchgArgs) {
   (void)bx; (void)by; (void)lds;
   const DGrid &G = a.G;
-  const TB &B = G.T;
-  double *A = nullptr;
-  {
-    int first = 0;
+  int bc, gtype;
+  double *A = halo_plane(a, bz, bc, gtype);
+  if (!a.unpack) {
+    if (a.fill) { halo_fill(G, A, bc, gtype); KSYNC(); }
 #pragma unroll
-    for (int k = 0; k < HALO_MAXITEMS; k++) {
-      const int nk = k < a.nitems ? a.it[k].nk : 0;
-      if (bz >= first && bz < first + nk) A = a.it[k].A + (size_t)(bz - first) * (size_t)G.nij;
-      first += nk;
-    }
-  }
-  const int ng = G.Nghost;
-  if (a.phase == 0) {
-    const int nl = G.nj;                       // lines = all local rows
-    double *lo = a.lo ? a.lo + (size_t)bz * (size_t)nl * (a.unpack ? 3 : ng) : nullptr;
-    double *hi = a.hi ? a.hi + (size_t)bz * (size_t)nl * (a.unpack ? ng : 3) : nullptr;
-    if (!a.unpack) {
-      if (lo) KLOOP2(c, l, 0, ng - 1, 0, nl - 1) lo[l * ng + c] = A[X2(B.Istr + c, G.LBj + l)];
-      if (hi) KLOOP2(c, l, 0, 2, 0, nl - 1) hi[l * 3 + c] = A[X2(B.Iend - 2 + c, G.LBj + l)];
-    } else {
-      if (lo) KLOOP2(c, l, 0, 2, 0, nl - 1) A[X2(B.Istr - 3 + c, G.LBj + l)] = lo[l * 3 + c];
-      if (hi) KLOOP2(c, l, 0, ng - 1, 0, nl - 1) A[X2(B.Iend + 1 + c, G.LBj + l)] = hi[l * ng + c];
-    }
+    for (int d = 0; d < 8; d++) xchg_move(G, A, a.buf[d], bz, d, 0);
   } else {
-    const int nl = G.ni;                       // lines = all local columns
-    double *lo = a.lo ? a.lo + (size_t)bz * (size_t)nl * (a.unpack ? 3 : ng) : nullptr;
-    double *hi = a.hi ? a.hi + (size_t)bz * (size_t)nl * (a.unpack ? ng : 3) : nullptr;
-    if (!a.unpack) {
-      if (lo) KLOOP2(l, c, 0, nl - 1, 0, ng - 1) lo[c * nl + l] = A[X2(G.LBi + l, B.Jstr + c)];
-      if (hi) KLOOP2(l, c, 0, nl - 1, 0, 2) hi[c * nl + l] = A[X2(G.LBi + l, B.Jend - 2 + c)];
-    } else {
-      if (lo) KLOOP2(l, c, 0, nl - 1, 0, 2) A[X2(G.LBi + l, B.Jstr - 3 + c)] = lo[c * nl + l];
-      if (hi) KLOOP2(l, c, 0, nl - 1, 0, ng - 1) A[X2(G.LBi + l, B.Jend + 1 + c)] = hi[c * nl + l];
-    }
+    xchg_move(G, A, a.buf[0], bz, 0, 1);
+    xchg_move(G, A, a.buf[1], bz, 1, 1);
+    KSYNC();
+    xchg_move(G, A, a.buf[2], bz, 2, 1);
+    xchg_move(G, A, a.buf[3], bz, 3, 1);
+    KSYNC();
+#pragma unroll
+    for (int d = 4; d < 8; d++) xchg_move(G, A, a.buf[d], bz, d, 1);
   }
 }
-COOP_GLOBAL(strip_kernel, StripArgs)
+COOP_GLOBAL(xchg_kernel, XchgArgs)

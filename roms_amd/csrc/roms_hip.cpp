@@ -194,10 +194,24 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     const char *es = getenv("ROMS_HIP_SELF_EXCHANGE");
     const bool self = es && es[0] == '1';
     int *nb = c->comm.nbr;
-    nb[0] = it > 0 ? cfg->tile - 1 : (cfg->EWperiodic && (NI > 1 || self) ? cfg->tile + NI - 1 : -1);
-    nb[1] = it < NI - 1 ? cfg->tile + 1 : (cfg->EWperiodic && (NI > 1 || self) ? cfg->tile - (NI - 1) : -1);
-    nb[2] = jt > 0 ? cfg->tile - NI : (cfg->NSperiodic && (NJ > 1 || self) ? cfg->tile + NI * (NJ - 1) : -1);
-    nb[3] = jt < NJ - 1 ? cfg->tile + NI : (cfg->NSperiodic && (NJ > 1 || self) ? cfg->tile - NI * (NJ - 1) : -1);
+    // neighbour of tile t one step along xi (dx) and/or eta (dy); -1: none (domain edge, or a
+    // periodic direction this tile closes by a local copy)
+    auto step = [&](int t, int dx, int dy) -> int {
+      if (t < 0) return -1;
+      int i = t % NI, j = t / NI;
+      if (dx) {
+        i += dx;
+        if (i < 0 || i >= NI) { if (!(cfg->EWperiodic && (NI > 1 || self))) return -1; i = (i + NI) % NI; }
+      }
+      if (dy) {
+        j += dy;
+        if (j < 0 || j >= NJ) { if (!(cfg->NSperiodic && (NJ > 1 || self))) return -1; j = (j + NJ) % NJ; }
+      }
+      return i + j * NI;
+    };
+    (void)it; (void)jt;
+    static const int ddx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, ddy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+    for (int d = 0; d < 8; d++) nb[d] = step(cfg->tile, ddx[d], ddy[d]);
     G.xloc = nb[0] < 0 && nb[1] < 0;
     G.yloc = nb[2] < 0 && nb[3] < 0;
     c->has_exchange = nb[0] >= 0 || nb[1] >= 0 || nb[2] >= 0 || nb[3] >= 0;
@@ -321,7 +335,7 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   if (!c) return 0;
   (void)dsync(c->stream);
   for (void *p : c->allocs) dfree(p);
-  for (int k = 0; k < 4; k++) { if (c->comm.sbuf[k]) dfree(c->comm.sbuf[k]); if (c->comm.rbuf[k]) dfree(c->comm.rbuf[k]); }
+  for (int k = 0; k < 8; k++) { if (c->comm.sbuf[k]) dfree(c->comm.sbuf[k]); if (c->comm.rbuf[k]) dfree(c->comm.rbuf[k]); }
   comm_destroy(c);
   free(c->h_diag);
 #ifndef ROMS_CPU_EMU
@@ -672,25 +686,27 @@ extern "C" int roms_hip_set_exchange(roms_hip_ctx *c, roms_hip_exchange_fn fn, v
 }
 extern "C" long roms_hip_exchange_count(roms_hip_ctx *c) { return c ? c->comm.nexchanges : 0; }
 
-// One phase (0: xi, 1: eta) of the strip exchange for the fields of a halo launch.
-static int exchange_phase(roms_hip_ctx *c, const HaloArgs &h, int planes, int phase) {
+// Boundary fills and strip exchange of the fields of one exchange point (multi-tile contexts):
+// fill + pack launch, one group of sends/receives with the up to eight neighbours, unpack launch.
+static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
   TileComm &m = c->comm;
-  const int lo = m.nbr[2 * phase], hi = m.nbr[2 * phase + 1];
-  if (lo < 0 && hi < 0) return 0;
   if (!m.fn && !m.nccl) {
     set_error("multi-tile context without a transport: call roms_hip_comm_rccl or roms_hip_set_exchange first");
     return 8;
   }
   const DGrid &G = c->G;
-  const size_t lines = phase == 0 ? (size_t)G.nj : (size_t)G.ni;
+  const size_t lines = (size_t)(G.ni > G.nj ? G.ni : G.nj);
   const size_t need = (size_t)planes * lines * 3;
   if (need > m.cap) {
     (void)dsync(c->stream);
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 8; k++) {
       if (m.sbuf[k]) dfree(m.sbuf[k]);
       if (m.rbuf[k]) dfree(m.rbuf[k]);
+      m.sbuf[k] = m.rbuf[k] = nullptr;
+      if (m.nbr[k] < 0) continue;
+      const size_t n = k < 4 ? need : (size_t)planes * 9;
       void *p = nullptr, *q = nullptr;
-      if (dmalloc(&p, need * sizeof(double)) || dmalloc(&q, need * sizeof(double))) return 2;
+      if (dmalloc(&p, n * sizeof(double)) || dmalloc(&q, n * sizeof(double))) return 2;
       m.sbuf[k] = (double *)p; m.rbuf[k] = (double *)q;
     }
 #ifndef ROMS_CPU_EMU
@@ -698,25 +714,37 @@ static int exchange_phase(roms_hip_ctx *c, const HaloArgs &h, int planes, int ph
 #endif
     m.cap = need;
   }
-  const long n_lo_out = (long)((size_t)planes * lines * (size_t)G.Nghost);   // my first Nghost lines -> low neighbour
-  const long n_hi_out = (long)((size_t)planes * lines * 3);                  // my last 3 lines      -> high neighbour
-  StripArgs a;
+  // message sizes (k_halo.h:xchg_rect): planes x width along xi x width along eta, a width being all
+  // local lines across the direction of travel, Nghost lines for a message going to the low side
+  // (the receiver's high ghost zone) and three for one going to the high side (its low ghost zone)
+  const int ng = G.Nghost;
+  auto count = [&](int d, bool sending) -> long {
+    const int dx = (d == 0 || d == 4 || d == 6) ? -1 : ((d == 1 || d == 5 || d == 7) ? 1 : 0);
+    const int dy = (d == 2 || d == 4 || d == 5) ? -1 : ((d == 3 || d == 6 || d == 7) ? 1 : 0);
+    // sending to the low side: my first Nghost lines; receiving from the low side: three lines
+    const long wx = dx == 0 ? G.ni : ((dx < 0) == sending ? ng : 3);
+    const long wy = dy == 0 ? G.nj : ((dy < 0) == sending ? ng : 3);
+    return (long)planes * wx * wy;
+  };
+  XchgArgs a;
   a.G = G; a.nitems = h.nitems;
-  for (int k = 0; k < h.nitems; k++) a.it[k] = h.it[k];
-  a.phase = phase; a.unpack = 0;
-  a.lo = lo >= 0 ? m.sbuf[2 * phase] : nullptr;
-  a.hi = hi >= 0 ? m.sbuf[2 * phase + 1] : nullptr;
-  LAUNCH_COOP(strip_kernel, 1, 1, planes, 256, 0, c->stream, a);
-  // sends: [to hi: "upward" strip, to lo: "downward" strip]; receives: [from lo: its upward strip,
-  // from hi: its downward strip].  With this order two messages between the same pair of ranks
-  // (two tiles across a periodic direction) match by issue order as well as by tag.
-  int sp[2], st[2], rp[2], rt[2], ns = 0, nr = 0;
-  double *sb[2], *rb[2];
-  long sc[2], rc[2];
-  if (hi >= 0) { sp[ns] = hi; sb[ns] = m.sbuf[2 * phase + 1]; sc[ns] = n_hi_out; st[ns] = 2 * phase; ns++; }
-  if (lo >= 0) { sp[ns] = lo; sb[ns] = m.sbuf[2 * phase]; sc[ns] = n_lo_out; st[ns] = 2 * phase + 1; ns++; }
-  if (lo >= 0) { rp[nr] = lo; rb[nr] = m.rbuf[2 * phase]; rc[nr] = n_hi_out; rt[nr] = 2 * phase; nr++; }
-  if (hi >= 0) { rp[nr] = hi; rb[nr] = m.rbuf[2 * phase + 1]; rc[nr] = n_lo_out; rt[nr] = 2 * phase + 1; nr++; }
+  for (int k = 0; k < HALO_MAXITEMS; k++) a.it[k] = h.it[k];
+  a.unpack = 0; a.fill = 1;
+  for (int d = 0; d < 8; d++) a.buf[d] = m.nbr[d] >= 0 ? m.sbuf[d] : nullptr;
+  LAUNCH_COOP(xchg_kernel, 1, 1, planes, 256, 0, c->stream, a);
+  // Messages are issued in the order of their tag = direction of travel (0 eastward, 1 westward,
+  // 2 northward, 3 southward, 4 NE, 5 NW, 6 SE, 7 SW): several messages between the same pair of
+  // ranks (small periodic partitions) then match by issue order as well as by tag.
+  static const int opp[8] = {1, 0, 3, 2, 7, 6, 5, 4};
+  int sp[8], st[8], rp[8], rt[8], ns = 0, nr = 0;
+  double *sb[8], *rb[8];
+  long sc[8], rc[8];
+  for (int tag = 0; tag < 8; tag++) {
+    const int to = opp[tag];        // a message travelling in direction `tag` goes to that neighbour ...
+    if (m.nbr[to] >= 0) { sp[ns] = m.nbr[to]; sb[ns] = m.sbuf[to]; sc[ns] = count(to, true); st[ns] = tag; ns++; }
+    const int from = tag;           // ... and arrives from the neighbour on the opposite side
+    if (m.nbr[from] >= 0) { rp[nr] = m.nbr[from]; rb[nr] = m.rbuf[from]; rc[nr] = count(from, false); rt[nr] = tag; nr++; }
+  }
   if (m.fn) {
     int r = dsync(c->stream);
     if (r) return r;
@@ -732,10 +760,9 @@ static int exchange_phase(roms_hip_ctx *c, const HaloArgs &h, int planes, int ph
     if (rcclfail(g_rccl.GroupEnd(), "ncclGroupEnd")) return 2;
 #endif
   }
-  a.unpack = 1;
-  a.lo = lo >= 0 ? m.rbuf[2 * phase] : nullptr;
-  a.hi = hi >= 0 ? m.rbuf[2 * phase + 1] : nullptr;
-  LAUNCH_COOP(strip_kernel, 1, 1, planes, 256, 0, c->stream, a);
+  a.unpack = 1; a.fill = 0;
+  for (int d = 0; d < 8; d++) a.buf[d] = m.nbr[d] >= 0 ? m.rbuf[d] : nullptr;
+  LAUNCH_COOP(xchg_kernel, 1, 1, planes, 256, 0, c->stream, a);
   m.nexchanges++;
   return 0;
 }
@@ -745,13 +772,17 @@ void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n) {
   a.G = c->G;
   a.nitems = n;
   int planes = 0;
+  for (int k = 0; k < HALO_MAXITEMS; k++) { a.it[k].A = nullptr; a.it[k].nk = 0; a.it[k].bc = BC_NONE; a.it[k].gtype = 0; }
   for (int k = 0; k < n; k++) {
     a.it[k].A = sp[k].A; a.it[k].nk = sp[k].nk; a.it[k].bc = sp[k].bc; a.it[k].gtype = (int)sp[k].gtype;
     planes += sp[k].nk;
   }
-  LAUNCH_COOP(halo_kernel, 1, 1, planes, 256, 0, c->stream, a);
-  // neighbouring tiles on other GPUs: xi strips, then eta strips (corners travel with the latter)
-  if (exchange_phase(c, a, planes, 0) || exchange_phase(c, a, planes, 1)) c->comm_failed = true;
+  if (c->has_exchange) {
+    // neighbouring tiles on other GPUs
+    if (exchange_all(c, a, planes)) c->comm_failed = true;
+  } else {
+    LAUNCH_COOP(halo_kernel, 1, 1, planes, 256, 0, c->stream, a);
+  }
 }
 
 // ---------------------------------------------------------------------- per-kernel C entries

@@ -22,8 +22,8 @@ struct Region { double seconds; long calls; };
 
 // inter-tile communication state (multi-GPU runs: one tile per process/GPU)
 struct TileComm {
-  int nbr[4];                   // ranks of the west, east, south, north neighbours (-1: none)
-  double *sbuf[4], *rbuf[4];    // device staging buffers per neighbour
+  int nbr[8];                   // ranks of the W, E, S, N, SW, SE, NW, NE neighbours (-1: none)
+  double *sbuf[8], *rbuf[8];    // device staging buffers per neighbour
   size_t cap;                   // doubles per staging buffer
   roms_hip_exchange_fn fn;      // user transport (MPI, gloo ...) or null
   void *user;

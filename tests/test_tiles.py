@@ -53,6 +53,8 @@ def _interior(cs_dims, a):
     ("upwelling_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 1), 29611),
     ("upwelling_small", dict(hadv=("U3", "U3"), vadv=("C4", "C4")), (1, 2), 29612),
     ("benchmark_small", dict(), (2, 2), 29613),
+    # three ghost lines on the high side (MPDATA), corner blocks from the diagonal tiles
+    ("upwelling_small", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (2, 2), 29614),
 ])
 def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     _emu_libs()
