@@ -11,6 +11,12 @@ static inline KArgs mk(roms_hip_ctx *c, int p0 = 0) {
   a.p0 = p0; a.p1 = 0; a.p2 = 0;
   return a;
 }
+// column kernels with their per-column state in LDS (COL launches): 2*(N+1) doubles per column must
+// fit the 64 KB a block gets without opting in; ROMS_HIP_COLLDS=0 selects the private-memory forms
+static inline bool col_lds(const DGrid &G) {
+  static const char *e = getenv("ROMS_HIP_COLLDS");
+  return !(e && e[0] == '0') && 2 * (G.N + 1) * 64 * sizeof(double) <= 64 * 1024;
+}
 static inline size_t lds_sz(const DGrid &G) { return (size_t)(G.bw + 6) * (size_t)(G.bh + 6); }
 
 
@@ -19,12 +25,16 @@ int run_step3d_uv(roms_hip_ctx *c) {
   const TB &B = G.T;
   const int N = G.N, nnew = G.nnew;
   KArgs a = mk(c);
-  LAUNCH_THREAD(k_s3uv_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+  static const char *ech = getenv("ROMS_HIP_COLCH");
+  if (col_lds(G) && (ech ? ech[0] == '1' : N > 40)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l10, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
+  else if (col_lds(G)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
+  else LAUNCH_THREAD(k_s3uv_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
   if (!G.fuse3d) {   // (fused: the kernels store the boundary values and periodic images themselves, pt_emit)
     HaloSpec sp[2] = {{uv_lev(c, c->F.u, nnew), N, BC_U, 0}, {uv_lev(c, c->F.v, nnew), N, BC_V, 0}};   // u3dbc/v3dbc :1266,1271
     launch_halo_multi(c, sp, 2);
   }
-  LAUNCH_THREAD(k_s3uv_couple, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, c->stream, a);
+  if (col_lds(G)) LAUNCH_COL_AS(k_s3uv_couple, k_s3uv_couple_l, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, 2 * (N + 1), c->stream, a);
+  else LAUNCH_THREAD(k_s3uv_couple, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, c->stream, a);
   if (!G.fuse3d) {
     HaloSpec sp[6] = {{uv_lev(c, c->F.u, nnew), N, BC_NONE, 'u'}, {uv_lev(c, c->F.v, nnew), N, BC_NONE, 'v'},
                       {c->F.Huon, N, BC_NONE, 'u'},               {c->F.Hvom, N, BC_NONE, 'v'},
@@ -68,11 +78,17 @@ int run_step3d_t(roms_hip_ctx *c) {
   {
     const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
 #ifdef ROMS_CPU_EMU
-    LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
+    if (col_lds(G)) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
+    else LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
 #else
     const char *er = getenv("ROMS_HIP_COLREGS");
     const bool regs = !(er && er[0] == '0');
-    if (regs && N == 30) LAUNCH_THREAD_AS(k_s3t_col, k_s3t_col_n30, nx, ny, G.NT, c->stream, a);
+    static const char *el = getenv("ROMS_HIP_S3TLDS");
+    bool hsimt_v = false;
+    for (int it = 0; it < G.NT; it++) hsimt_v |= G.vadv[it] == ROMS_HSIMT;
+    const bool ldsform = col_lds(G) && (el ? el[0] == '1' : (N != 30 || hsimt_v));
+    if (ldsform) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
+    else if (regs && N == 30) LAUNCH_THREAD_AS(k_s3t_col, k_s3t_col_n30, nx, ny, G.NT, c->stream, a);
     else LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
 #endif
   }

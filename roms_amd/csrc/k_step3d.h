@@ -149,6 +149,156 @@ THREAD_KERNEL(k_s3uv_col_t, KArgs) {
 THREAD_KERNEL(k_s3uv_col, KArgs) { k_s3uv_col_t_body<0>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_s3uv_col, KArgs)
 
+// The same kernel with the column state in LDS (COL launch: one wave per block, 2*(N+1) doubles per
+// column): the elimination coefficients CF, DC of the up sweep live in LDS; the down sweep leaves the
+// viscosity-corrected velocity and the layer thickness of each level in the slots it has just
+// consumed (CF(k+1), DC(k+1)), so the vertical-mean sums (ascending k, as the reference) and the
+// final correction run on LDS and every level is written to memory once -- 9 array passes per
+// direction instead of 17 (no private-memory traffic, no re-reads of u/v and Hz for the mean).
+template <int CH>
+COL_KERNEL(k_s3uv_col_lt, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int dir = gz;
+  const int i = (dir == 0 ? B.IstrU : B.Istr) + gx, j = (dir == 0 ? B.Jstr : B.JstrV) + gy;
+  if (i > B.Iend || j > B.Jend) return;
+  const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1;
+  const int N = G.N, nrhs = G.nrhs, nnew = G.nnew;
+  const double dt = G.dt;
+  double *q = (dir == 0 ? F.u : F.v) + (size_t)(nnew - 1) * G.nij * N;
+  const double *rq = (dir == 0 ? F.ru : F.rv) + (size_t)(nrhs - 1) * G.nij * (N + 1);
+  const double *Akv = F.Akv, *Hz = F.Hz;
+  double *L1 = lds, *L2 = lds + (size_t)(N + 1) * KLS;     // level k at [k * KLS]
+#define AKc(kk) (0.5 * (Akv[XW(i - di, j - dj, kk)] + Akv[XW(i, j, kk)]))
+#define HZc(kk) (0.5 * (Hz[X3(i - di, j - dj, kk)] + Hz[X3(i, j, kk)]))
+  double cff;
+  if (G.iic == G.ntfirst) cff = 0.25 * dt;
+  else if (G.iic == G.ntfirst + 1) cff = 0.25 * dt * 3.0 / 2.0;
+  else cff = 0.25 * dt * 23.0 / 12.0;
+  const double DC0 = cff * (F.pm[X2(i, j)] + F.pm[X2(i - di, j - dj)]) * (F.pn[X2(i, j)] + F.pn[X2(i - di, j - dj)]);
+  const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
+  // Both sweeps are software-pipelined: with 2*(N+1) doubles of LDS per column only a few waves fit a
+  // CU, so a wave issues the loads of its next chunk of CH levels before it runs the recurrence on
+  // the current one (raw values wait in registers).
+  double nh0[CH + 1], nh1[CH + 1], nq[CH + 1], nr[CH + 1], na0[CH + 2], na1[CH + 2];
+#define S1_LOAD(kb)                                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int qi = 0; qi < CH + 1; qi++) {                                                 \
+      const int kk = KMIN((kb) + qi, N);                                                               \
+      nh0[qi] = Hz[X3(i - di, j - dj, kk)]; nh1[qi] = Hz[X3(i, j, kk)];                                \
+      nq[qi] = q[X3(i, j, kk)]; nr[qi] = rq[XW(i, j, kk)];                                             \
+    }                                                                                                  \
+    _Pragma("unroll") for (int qi = 0; qi < CH + 2; qi++) {                                                 \
+      const int kk = KMIN((kb) - 1 + qi, N);                                                           \
+      na0[qi] = Akv[XW(i - di, j - dj, kk)]; na1[qi] = Akv[XW(i, j, kk)];                              \
+    }                                                                                                  \
+  } while (0)
+  {
+    double CFm = 0.0, DCm = 0.0;       // CF(k-1), DC(k-1)
+    double qprev = 0.0;                // q'(k0) carried from the previous chunk (its last level)
+    S1_LOAD(1);
+    _Pragma("unroll 1") for (int k0 = 1; k0 <= N; k0 += CH) {
+      double hz[CH + 1], qq[CH + 1], ak[CH + 2];      // level k0+q ; ak[q]: w-level k0-1+q
+#pragma unroll
+      for (int qi = 0; qi < CH + 1; qi++) { hz[qi] = 0.5 * (nh0[qi] + nh1[qi]); qq[qi] = nq[qi] + DC0 * nr[qi]; }
+#pragma unroll
+      for (int qi = 0; qi < CH + 2; qi++) ak[qi] = 0.5 * (na0[qi] + na1[qi]);
+      KSCHED_FENCE();
+      if (k0 + CH <= N) S1_LOAD(k0 + CH);
+      KSCHED_FENCE();
+#pragma unroll
+      for (int qi = 0; qi < CH + 1; qi++) qq[qi] = qq[qi] * (1.0 / hz[qi]);
+      if (k0 > 1) qq[0] = qprev;       // already stored by the previous chunk (identical value)
+#pragma unroll
+      for (int m = 0; m < CH; m++) {
+        const int k = k0 + m;
+        if (k <= N) {
+          if (!(k0 > 1 && m == 0)) q[X3(i, j, k)] = qq[m];
+          if (k <= N - 1) {
+            const double Hk = hz[m], Hk1 = hz[m + 1], oHk = 1.0 / Hk, oHk1 = 1.0 / Hk1;
+            const double FCk = c6 * Hk - dt * ak[m] * oHk;
+            const double CFk = c6 * Hk1 - dt * ak[m + 2] * oHk1;
+            const double BCk = c3 * (Hk + Hk1) + dt * ak[m + 1] * (oHk + oHk1);
+            const double cf = 1.0 / (BCk - FCk * CFm);
+            CFm = cf * CFk;
+            DCm = cf * (qq[m + 1] - qq[m] - FCk * DCm);
+            L1[k * KLS] = CFm;
+            L2[k * KLS] = DCm;
+          }
+        }
+      }
+      if (k0 + CH <= N) { q[X3(i, j, k0 + CH)] = qq[CH]; qprev = qq[CH]; }
+    }
+  }
+#undef S1_LOAD
+  {
+    double DCp = 0.0;                  // DC(k+1), final (DC(N) = 0)
+#define S2_LOAD(kb)                                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int m = 0; m < CH; m++) {                                                    \
+      const int k = KMAX((kb) - m, 1);                                                                 \
+      nh0[m] = Hz[X3(i - di, j - dj, k + 1)]; nh1[m] = Hz[X3(i, j, k + 1)]; nq[m] = q[X3(i, j, k + 1)]; \
+    }                                                                                                  \
+    _Pragma("unroll") for (int qi = 0; qi < CH + 1; qi++) {                                                 \
+      const int kk = KMAX((kb) + 1 - qi, 1);                                                           \
+      na0[qi] = Akv[XW(i - di, j - dj, kk)]; na1[qi] = Akv[XW(i, j, kk)];                              \
+    }                                                                                                  \
+  } while (0)
+    S2_LOAD(N - 1);
+    _Pragma("unroll 1") for (int k0 = N - 1; k0 >= 1; k0 -= CH) {
+      double cf[CH], dc[CH], ak[CH + 1], hz[CH], qq[CH];
+#pragma unroll
+      for (int m = 0; m < CH; m++) {
+        const int k = KMAX(k0 - m, 1);
+        cf[m] = L1[k * KLS]; dc[m] = L2[k * KLS];
+        hz[m] = 0.5 * (nh0[m] + nh1[m]); qq[m] = nq[m];
+      }
+#pragma unroll
+      for (int qi = 0; qi < CH + 1; qi++) ak[qi] = 0.5 * (na0[qi] + na1[qi]);
+      KSCHED_FENCE();
+      if (k0 - CH >= 1) S2_LOAD(k0 - CH);
+      KSCHED_FENCE();
+#pragma unroll
+      for (int m = 0; m < CH; m++) {
+        const int k = k0 - m;
+        if (k >= 1) {
+          const double DCk = dc[m] - cf[m] * DCp;
+          const double up = DCp * ak[m], lo = DCk * ak[m + 1];
+          const double c = dt * (1.0 / hz[m]) * (up - lo);
+          L1[(k + 1) * KLS] = qq[m] + c;      // CF(k+1), DC(k+1) are consumed: the slots take level k+1
+          L2[(k + 1) * KLS] = hz[m];
+          DCp = DCk;
+        }
+      }
+    }
+#undef S2_LOAD
+    const double Hk = HZc(1);
+    const double c = dt * (1.0 / Hk) * (DCp * AKc(1) - 0.0);
+    L1[1 * KLS] = q[X3(i, j, 1)] + c;
+    L2[1 * KLS] = Hk;
+  }
+  double CF0 = 0.0, DCs = 0.0;
+  _Pragma("unroll 4") for (int k = 1; k <= N; k++) {
+    const double h = L2[k * KLS], v = L1[k * KLS];
+    if (k == 1) { CF0 = h; DCs = v * h; }
+    else { CF0 = CF0 + h; DCs = DCs + v * h; }
+  }
+  const double omn1 = (dir == 0 ? F.on_u : F.om_v)[X2(i, j)];
+  const double Davg = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
+  const double cff1 = 1.0 / (CF0 * omn1);
+  const double corr = (DCs * omn1 - Davg) * cff1;
+  const EmitPlan PQ = emit_plan(G, dir == 0 ? BC_U : BC_V, i, j);
+  _Pragma("unroll 4") for (int k = 1; k <= N; k++)
+    emit_store(G, PQ, q + (size_t)(k - 1) * G.nij, L1[k * KLS] - corr);   // u3dbc/v3dbc :1266
+#undef AKc
+#undef HZc
+}
+COL_KERNEL(k_s3uv_col_l, KArgs) { k_s3uv_col_lt_body<6>(a, gx, gy, gz, lds); }
+COL_GLOBAL(k_s3uv_col_l, KArgs)
+COL_KERNEL(k_s3uv_col_l10, KArgs) { k_s3uv_col_lt_body<10>(a, gx, gy, gz, lds); }
+COL_GLOBAL(k_s3uv_col_l10, KArgs)
+
 // coupling of 2-D and 3-D momentum, corrected mass fluxes, ubar/vbar(1:2).
 // grid.z = 0: u part on (IstrP:IendT, JstrT:JendT); 1: v part on (IstrT:IendT, Jstr:JendT)
 THREAD_KERNEL(k_s3uv_couple, KArgs) {
@@ -237,6 +387,112 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
   }
 }
 THREAD_GLOBAL(k_s3uv_couple, KArgs)
+
+// The coupling kernel as a COL launch: the first sweep leaves DC(k) = cffm*(Hz+Hz) and u/v(k) of the
+// column in LDS (2*N doubles per column), the mass-flux sweep replaces the velocity by the new
+// Huon/Hvom, and the last sweep stores the corrected flux: Hz, u/v and Huon/Hvom are read once and
+// Huon/Hvom written once (5 array passes per direction instead of 12).  Loads of the next chunk are
+// issued ahead of the ordered sums.
+COL_KERNEL(k_s3uv_couple_l, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int dir = gz;
+  const int i = (dir == 0 ? B.IstrP : B.IstrT) + gx, j = (dir == 0 ? B.JstrT : B.Jstr) + gy;
+  if (i > B.IendT || j > B.JendT) return;
+  const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1;
+  const int N = G.N, nnew = G.nnew;
+  double *q = (dir == 0 ? F.u : F.v) + (size_t)(nnew - 1) * G.nij * N;
+  double *Hq = dir == 0 ? F.Huon : F.Hvom;
+  const double *Hz = F.Hz;
+  const double cffm = 0.5 * (dir == 0 ? F.on_u : F.om_v)[X2(i, j)];
+  const double Davg1 = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
+  const double Davg2 = (dir == 0 ? F.DU_avg2 : F.DV_avg2)[X2(i, j)];
+  double DC0 = 0.0, CF0 = 0.0, FC0 = 0.0;
+  const size_t nij = (size_t)G.nij, x = X2(i, j), xm = X2(i - di, j - dj);
+  double *LA = lds, *LB = lds + (size_t)(N + 1) * KLS;      // DC(k), u/v(k) -> Huon/Hvom(k) at [k * KLS]
+  constexpr int CH = 8;
+  {
+    double n0[CH], n1[CH], nq[CH];
+#define C1_LOAD(kb)                                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int m = 0; m < CH; m++) {                                                   \
+      const size_t o = (size_t)(KMIN((kb) + m, N) - 1) * nij;                                          \
+      n0[m] = Hz[o + x]; n1[m] = Hz[o + xm]; nq[m] = q[o + x];                                         \
+    }                                                                                                  \
+  } while (0)
+    C1_LOAD(1);
+    _Pragma("unroll 1") for (int k0 = 1; k0 <= N; k0 += CH) {
+      double hs[CH], qq[CH];
+#pragma unroll
+      for (int m = 0; m < CH; m++) { hs[m] = n0[m] + n1[m]; qq[m] = nq[m]; }
+      KSCHED_FENCE();
+      if (k0 + CH <= N) C1_LOAD(k0 + CH);
+      KSCHED_FENCE();
+#pragma unroll
+      for (int m = 0; m < CH; m++) {
+        if (k0 + m > N) break;
+        const double DCk = cffm * hs[m];
+        DC0 = DC0 + DCk;
+        CF0 = CF0 + DCk * qq[m];
+        LA[(k0 + m) * KLS] = DCk;
+        LB[(k0 + m) * KLS] = qq[m];
+      }
+    }
+#undef C1_LOAD
+  }
+  DC0 = 1.0 / DC0;
+  CF0 = DC0 * (CF0 - Davg1);
+  double *bar = dir == 0 ? F.ubar : F.vbar;
+  const double b1 = DC0 * Davg1;
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);
+  emit_store(G, P, bar, b1);
+  emit_store(G, P, bar + G.nij, b1);
+  // boundary columns: remove the mismatch of the vertical mean :1400-1490
+  bool fix = false;
+  if (dir == 0) {
+    if (!G.ewp && ((B.west && i == B.Istr) || (B.east && i == B.Iend + 1))) fix = true;
+    if (!G.nsp && (j == 0 || j == G.Mm + 1) && i >= B.IstrU && i <= B.Iend) fix = true;
+  } else {
+    if (!G.ewp && ((B.west && i == B.Istr - 1) || (B.east && i == B.Iend + 1))) fix = true;
+    if (!G.nsp && (j == 1 || j == G.Mm + 1) && i >= B.Istr && i <= B.Iend) fix = true;
+  }
+  if (fix)
+    for (int k = 1; k <= N; k++) {
+      const double v = LB[k * KLS] - CF0;
+      LB[k * KLS] = v;
+      emit_store(G, P, q + (size_t)(k - 1) * nij, v);
+    }
+  {
+    double nh[CH];
+#define C3_LOAD(kb)                                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int m = 0; m < CH; m++) nh[m] = Hq[(size_t)(KMAX((kb) - m, 1) - 1) * nij + x]; \
+  } while (0)
+    C3_LOAD(N);
+    _Pragma("unroll 1") for (int k0 = N; k0 >= 1; k0 -= CH) {
+      double hq[CH];
+#pragma unroll
+      for (int m = 0; m < CH; m++) hq[m] = nh[m];
+      KSCHED_FENCE();
+      if (k0 - CH >= 1) C3_LOAD(k0 - CH);
+      KSCHED_FENCE();
+#pragma unroll
+      for (int m = 0; m < CH; m++) {
+        const int k = k0 - m;
+        if (k < 1) break;
+        const double Hn = 0.5 * (hq[m] + LB[k * KLS] * LA[k * KLS]);
+        LB[k * KLS] = Hn;
+        FC0 = FC0 + Hn;
+      }
+    }
+#undef C3_LOAD
+  }
+  FC0 = DC0 * (FC0 - Davg2);
+  _Pragma("unroll 4") for (int k = 1; k <= N; k++)
+    emit_store(G, P, Hq + (size_t)(k - 1) * nij, LB[k * KLS] - LA[k * KLS] * FC0);
+}
+COL_GLOBAL(k_s3uv_couple_l, KArgs)
 
 // ---------------------------------------------------------------------------------- step3d_t
 // HSIMT limiter (Wu and Zhu 2010), step3d_t.F:520-560
@@ -498,6 +754,193 @@ THREAD_KERNEL(k_s3t_col_t, KArgs) {
     }
   }
 }
+// The same kernel as a COL launch: CF/DC of the diffusion solve in LDS (2*(N+1) doubles per column, no
+// private-memory traffic), both diffusion sweeps and the HSIMT vertical advection software-pipelined
+// over chunks of CH levels (the loads of the next chunk are in flight while the recurrence runs on
+// the current one); the HSIMT sweep forms KaZ and gradZ of an interface once and keeps the window of
+// the column in registers instead of re-reading t(3), W and z_r for every flux.
+template <int CH>
+COL_KERNEL(k_s3t_col_lt, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, itrc = gz + 1, N = G.N;
+  const int vs = G.vadv[itrc - 1], ltrc = KMIN(G.NAT, itrc);
+  if (vs == ROMS_MPDATA) return;                 // k_mpdata.h
+  const double dt = G.dt;
+  const double *T3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
+  double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);
+  const double *Hz = F.Hz, *W = F.W, *z_r = F.z_r;
+  const double *Akt = F.Akt + (size_t)(ltrc - 1) * G.nij * (N + 1);
+  const double pmn_dt = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];   // CF(i,0)
+  double *L1 = lds, *L2 = lds + (size_t)(N + 1) * KLS;          // CF(k), DC(k) at [k * KLS]
+  const EmitPlan PT = emit_plan(G, BC_R, i, j);
+  if (!s3t_point_path(G, itrc)) {   // otherwise k_s3t_hv has done the vertical advection already
+    if (vs == ROMS_HSIMT) {
+      // :1069-1150.  Window of chunk k0: levels k0-1 .. k0+CH+1 of t(3) and z_r, interfaces k0-1 .. k0+CH of W
+      const double cK = F.pm[X2(i, j)] * F.pn[X2(i, j)] * dt;
+      double ntw[CH + 3], nzw[CH + 3], nww[CH + 2], ntn[CH], nhz[CH];
+#define SA_LOAD(kb)                                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < CH + 3; q++) {                                               \
+      const int lev = KMIN(KMAX((kb) - 1 + q, 1), N);                                                  \
+      ntw[q] = T3[X3(i, j, lev)]; nzw[q] = z_r[X3(i, j, lev)];                                         \
+    }                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < CH + 2; q++) nww[q] = W[XW(i, j, KMIN(KMAX((kb) - 1 + q, 0), N))]; \
+    _Pragma("unroll") for (int m = 0; m < CH; m++) {                                                   \
+      const int k = KMIN((kb) + m, N);                                                                 \
+      ntn[m] = tn[X3(i, j, k)]; nhz[m] = Hz[X3(i, j, k)];                                              \
+    }                                                                                                  \
+  } while (0)
+      double FCm = 0.0;
+      SA_LOAD(1);
+      _Pragma("unroll 1") for (int k0 = 1; k0 <= N; k0 += CH) {
+        double tw[CH + 3], KA[CH + 2], GZ[CH + 2], ww[CH + 2], tv[CH], hz[CH];
+#pragma unroll
+        for (int q = 0; q < CH + 3; q++) tw[q] = ntw[q];
+#pragma unroll
+        for (int q = 0; q < CH + 2; q++) {
+          const int kk = k0 - 1 + q;
+          ww[q] = nww[q];
+          if (kk <= 0 || kk >= N) { KA[q] = 0.0; GZ[q] = 0.0; }
+          else { KA[q] = 1.0 - fabs(cK * nww[q] / (nzw[q + 1] - nzw[q])); GZ[q] = ntw[q + 1] - ntw[q]; }
+        }
+#pragma unroll
+        for (int m = 0; m < CH; m++) { tv[m] = ntn[m]; hz[m] = nhz[m]; }
+        KSCHED_FENCE();
+        if (k0 + CH <= N) SA_LOAD(k0 + CH);
+        KSCHED_FENCE();
+#pragma unroll
+        for (int m = 0; m < CH; m++) {
+          const int k = k0 + m;
+          if (k <= N) {
+            double FCk;
+            if (k >= N) FCk = 0.0;
+            else {
+              const double w = ww[m + 1];
+              if (k == 1 && w >= 0.0) FCk = w * tw[m + 1];
+              else if (k == N - 1 && w < 0.0) FCk = w * tw[m + 2];
+              else {
+                const double Ka = KA[m + 1], oKa = 1.0 / Ka;
+                double sw;
+                if (w >= 0.0) sw = tw[m + 1] + hsimt_lim(GZ[m + 1], GZ[m], Ka, KA[m], oKa);
+                else sw = tw[m + 2] - hsimt_lim(GZ[m + 1], GZ[m + 2], Ka, KA[m + 2], oKa);
+                FCk = w * sw;
+              }
+            }
+            const double cff1 = pmn_dt * (FCk - FCm);
+            double tt = tv[m] - cff1;
+            tt = tt * (1.0 / hz[m]);
+            tn[X3(i, j, k)] = tt;
+            FCm = FCk;
+          }
+        }
+      }
+#undef SA_LOAD
+    } else {
+      if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, T3, 1);
+#define Tc(kk) T3[X3(i, j, kk)]
+#define Wc(kk) W[XW(i, j, kk)]
+      double FCm = 0.0;
+      _Pragma("unroll 1") for (int k = 1; k <= N; k++) {
+        double FCk;
+        if (vs == ROMS_SPLINES) FCk = F.wrk3[3][XW(i, j, k)];
+        else VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
+        const double cff1 = pmn_dt * (FCk - FCm);
+        double tt = tn[X3(i, j, k)] - cff1;
+        tt = tt * (1.0 / Hz[X3(i, j, k)]);
+        tn[X3(i, j, k)] = tt;
+        FCm = FCk;
+      }
+#undef Tc
+#undef Wc
+    }
+  }
+  // implicit vertical diffusion, parabolic splines (SPLINES_VDIFF) :1664-1722
+  {
+    const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
+    double nh[CH + 1], nt[CH + 1], na[CH + 2];
+#define S1_LOAD(kb)                                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < CH + 1; q++) {                                               \
+      const int kk = KMIN((kb) + q, N);                                                                \
+      nh[q] = Hz[X3(i, j, kk)]; nt[q] = tn[X3(i, j, kk)];                                              \
+    }                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < CH + 2; q++) na[q] = Akt[XW(i, j, KMIN((kb) - 1 + q, N))];   \
+  } while (0)
+    double CFm = 0.0, DCm = 0.0;       // CF(k-1), DC(k-1)
+    S1_LOAD(1);
+    _Pragma("unroll 1") for (int k0 = 1; k0 <= N - 1; k0 += CH) {
+      double hz[CH + 1], tt[CH + 1], ak[CH + 2];      // hz[q], tt[q]: level k0+q ; ak[q]: w-level k0-1+q
+#pragma unroll
+      for (int q = 0; q < CH + 1; q++) { hz[q] = nh[q]; tt[q] = nt[q]; }
+#pragma unroll
+      for (int q = 0; q < CH + 2; q++) ak[q] = na[q];
+      KSCHED_FENCE();
+      if (k0 + CH <= N - 1) S1_LOAD(k0 + CH);
+      KSCHED_FENCE();
+#pragma unroll
+      for (int m = 0; m < CH; m++) {
+        const int k = k0 + m;
+        if (k <= N - 1) {
+          const double Hk = hz[m], Hk1 = hz[m + 1], oHk = 1.0 / Hk, oHk1 = 1.0 / Hk1;
+          const double FCk = c6 * Hk - dt * ak[m] * oHk;
+          const double CFk = c6 * Hk1 - dt * ak[m + 2] * oHk1;
+          const double BCk = c3 * (Hk + Hk1) + dt * ak[m + 1] * (oHk + oHk1);
+          const double cf = 1.0 / (BCk - FCk * CFm);
+          CFm = cf * CFk;
+          DCm = cf * (tt[m + 1] - tt[m] - FCk * DCm);
+          L1[k * KLS] = CFm;
+          L2[k * KLS] = DCm;
+        }
+      }
+    }
+#undef S1_LOAD
+#define S2_LOAD(kb)                                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int m = 0; m < CH; m++) {                                                   \
+      const int k = KMAX((kb) - m, 1);                                                                 \
+      nh[m] = Hz[X3(i, j, k + 1)]; nt[m] = tn[X3(i, j, k + 1)];                                        \
+    }                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < CH + 1; q++) na[q] = Akt[XW(i, j, KMAX((kb) + 1 - q, 1))];   \
+  } while (0)
+    double DCp = 0.0;                  // DC(k+1), final (DC(N) = 0)
+    S2_LOAD(N - 1);
+    _Pragma("unroll 1") for (int k0 = N - 1; k0 >= 1; k0 -= CH) {
+      double cf[CH], dc[CH], ak[CH + 1], hz[CH], tt[CH];   // cf,dc: level k0-m ; ak[q]: w-level k0+1-q ; hz,tt: level k0+1-m
+#pragma unroll
+      for (int m = 0; m < CH; m++) {
+        const int k = KMAX(k0 - m, 1);
+        cf[m] = L1[k * KLS]; dc[m] = L2[k * KLS];
+        hz[m] = nh[m]; tt[m] = nt[m];
+      }
+#pragma unroll
+      for (int q = 0; q < CH + 1; q++) ak[q] = na[q];
+      KSCHED_FENCE();
+      if (k0 - CH >= 1) S2_LOAD(k0 - CH);
+      KSCHED_FENCE();
+#pragma unroll
+      for (int m = 0; m < CH; m++) {
+        const int k = k0 - m;
+        if (k >= 1) {
+          const double DCk = dc[m] - cf[m] * DCp;
+          const double up = DCp * ak[m], lo = DCk * ak[m + 1];        // DC(k+1)*Akt(k+1), DC(k)*Akt(k)
+          const double cff1 = dt * (1.0 / hz[m]) * (up - lo);
+          emit_store(G, PT, tn + (size_t)k * G.nij, tt[m] + cff1);     // t3dbc :1858 + exchange :1920
+          DCp = DCk;
+        }
+      }
+    }
+#undef S2_LOAD
+    {   // level 1: DC(0)*Akt(0) = 0
+      const double DCk = DCp * Akt[XW(i, j, 1)];
+      const double cff1 = dt * (1.0 / Hz[X3(i, j, 1)]) * (DCk - 0.0);
+      emit_store(G, PT, tn, tn[X3(i, j, 1)] + cff1);
+    }
+  }
+}
+COL_KERNEL(k_s3t_col_l, KArgs) { k_s3t_col_lt_body<6>(a, gx, gy, gz, lds); }
+COL_GLOBAL(k_s3t_col_l, KArgs)
+
 // entry points: N = 30 (the BENCHMARK grids) keeps the elimination coefficients CF/DC of the column in
 // registers -- the diffusion sweeps are fully unrolled, 174 VGPRs, no private-memory traffic:
 // 456 -> 263 us on 2048x256x30; at N = 50 the same form needs 256 VGPRs and is slower than the

@@ -56,6 +56,20 @@ struct kdim3 { int x, y, z; };
         for (int gx_ = 0; gx_ < (nx); gx_++) name##_body(args, gx_, gy_, gz_);           \
   } while (0)
 
+// COL: one thread per sigma column like THREAD, plus `per_thread` doubles of block-shared (LDS)
+// storage per column, addressed lds[k * KLS]
+#define KLS 1
+#define COL_KERNEL(name, ArgT) static inline void name##_body(const ArgT &a, int gx, int gy, int gz, double *lds)
+#define COL_GLOBAL(name, ArgT)
+#define LAUNCH_COL(name, nx, ny, nz, per_thread, stream, args)                           \
+  do {                                                                                   \
+    std::vector<double> lds_((size_t)(per_thread) + 8);                                  \
+    for (int gz_ = 0; gz_ < (nz); gz_++)                                                 \
+      for (int gy_ = 0; gy_ < (ny); gy_++)                                               \
+        for (int gx_ = 0; gx_ < (nx); gx_++) name##_body(args, gx_, gy_, gz_, lds_.data()); \
+  } while (0)
+#define LAUNCH_COL_AS(label, name, nx, ny, nz, per_thread, stream, args) LAUNCH_COL(name, nx, ny, nz, per_thread, stream, args)
+
 #else  // ------------------------------------------------------------------ HIP / gfx950
 #include <hip/hip_runtime.h>
 #define KDEV __device__ __forceinline__
@@ -130,6 +144,30 @@ void kprof_end(int slot, hipStream_t stream);
   KPROF_WRAP(label, stream,                                                              \
   hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + 3) / 4)) + 7) / 8) * (nz)), 1, 1), \
                      dim3(64, 4, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
+// COL kernels: one thread per sigma column with `per_thread` doubles of LDS each (the elimination
+// coefficients of a tridiagonal solve, a column kept between sweeps).  Blocks are single waves
+// (64 columns along xi, one eta row) so that the LDS footprint of a block stays small and several fit
+// a CU; lds[k * KLS] is level k of the thread's column (consecutive lanes, consecutive banks).  Same
+// XCD-aware block order as THREAD launches.
+#define KLS 64
+#define COL_KERNEL(name, ArgT) static __device__ __forceinline__ void name##_body(const ArgT &a, int gx, int gy, int gz, double *lds)
+#define COL_GLOBAL(name, ArgT)                                                           \
+  static __global__ void __launch_bounds__(64) name(const ArgT a, int nx, int ny, int nz) {     \
+    extern __shared__ double lds_dyn_[];                                                 \
+    const int nt_ = ((nx + 63) / 64) * ny, seg_ = (nt_ + 7) / 8;                         \
+    const int r_ = (int)(blockIdx.x >> 3), xcd_ = (int)(blockIdx.x & 7);                 \
+    const int gz = r_ % nz;                                                              \
+    const int t_ = xcd_ * seg_ + r_ / nz;                                                \
+    if (t_ >= nt_) return;                                                               \
+    const int tx_ = t_ / ny, gy = t_ - tx_ * ny;                                         \
+    const int gx = tx_ * 64 + (int)threadIdx.x;                                          \
+    if (gx < nx) name##_body(a, gx, gy, gz, lds_dyn_ + threadIdx.x);                     \
+  }
+#define LAUNCH_COL_AS(label, name, nx, ny, nz, per_thread, stream, args)                 \
+  KPROF_WRAP(label, stream,                                                              \
+  hipLaunchKernelGGL(name, dim3((unsigned)(8 * (((((nx) + 63) / 64) * (ny) + 7) / 8) * (nz)), 1, 1), \
+                     dim3(64, 1, 1), (size_t)(per_thread) * 64 * sizeof(double), stream, args, (int)(nx), (int)(ny), (int)(nz)))
+#define LAUNCH_COL(name, nx, ny, nz, per_thread, stream, args) LAUNCH_COL_AS(name, name, nx, ny, nz, per_thread, stream, args)
 #endif
 
 // block-strided loop nest over the rectangle [ilo,ihi] x [jlo,jhi] (inclusive), i fastest
