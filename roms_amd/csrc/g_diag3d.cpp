@@ -3,6 +3,7 @@
 // wvelocity, set_zeta, ini_zeta, ini_fields, each followed by the same boundary fills / periodic
 // exchanges the reference issues at the tail of the _tile routine.
 #include "roms_host.h"
+#include <cstdlib>
 #include "k_diag3d.h"
 
 static inline KArgs mk(roms_hip_ctx *c, int p0 = 0, int p1 = 0, int p2 = 0) {
@@ -111,7 +112,12 @@ int run_set_data(roms_hip_ctx *c) {
 int run_omega(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   KArgs a = mk(c);
-  LAUNCH_THREAD(k_omega, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  {
+    static const char *e = getenv("ROMS_HIP_COLLDS");
+    const bool l = !(e && e[0] == '0') && 2 * (c->G.N + 1) * 64 * sizeof(double) <= 64 * 1024;
+    if (l) LAUNCH_COL_AS(k_omega, k_omega_l, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, 2 * (c->G.N + 1), c->stream, a);
+    else LAUNCH_THREAD(k_omega, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  }
   if (!c->G.fuse3d) launch_halo(c, c->F.W, c->G.N + 1, BC_R, 'r');   // bc_w3d_tile (fused: pt_emit in the kernel)
   return 0;
 }

@@ -65,16 +65,14 @@ int run_step3d_t(roms_hip_ctx *c) {
   }
   KArgs a = mk(c);
   // exchange of t(nnew) for HSIMT tracers (:420) only refreshes ghost points that are not read here
-  bool any_pt = false, any_lds = false;   // per tracer: fused point kernel, or the LDS (HSIMT) / column (SPLINES) path
+  bool any_pt = false, any_hsimt = false;   // point kernel: every horizontal scheme but MPDATA and HSIMT (LDS tiles)
   for (int it = 0; it < G.NT; it++) {
-    const int hs = G.hadv[it], vs = G.vadv[it];
-    const bool pt = hs != ROMS_HSIMT && hs != ROMS_MPDATA && vs != ROMS_HSIMT && vs != ROMS_MPDATA && vs != ROMS_SPLINES;
-    any_pt |= pt;
-    any_lds |= !pt && hs != ROMS_MPDATA;
+    any_pt |= G.hadv[it] != ROMS_MPDATA && G.hadv[it] != ROMS_HSIMT;
+    any_hsimt |= G.hadv[it] == ROMS_HSIMT;
   }
   a.p0 = (N + KCH - 1) / KCH;
   if (any_pt) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
-  if (any_lds) LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
+  if (any_hsimt) LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
   {
     const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
 #ifdef ROMS_CPU_EMU

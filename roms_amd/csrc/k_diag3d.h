@@ -263,6 +263,50 @@ THREAD_KERNEL(k_omega, KArgs) {
 }
 THREAD_GLOBAL(k_omega, KArgs)
 
+// COL form: the first sweep keeps W(k) of the column in LDS (N+1 doubles per column), the second one
+// stores the corrected value: W is written once and never read back.
+COL_KERNEL(k_omega_l, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  const double *Huon = F.Huon, *Hvom = F.Hvom, *z_w = F.z_w;
+  double *W = F.W;
+  double Wk = 0.0;
+  const EmitPlan P = emit_plan(G, BC_R, i, j);                       // bc_w3d_tile + exchange follow here
+  emit_store(G, P, W, 0.0);
+  constexpr int CH = 8;
+  double n0[CH], n1[CH], n2[CH], n3[CH], nz[CH];
+#define OM_LOAD(kb)                                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int m = 0; m < CH; m++) {                                                   \
+      const int k = KMIN((kb) + m, N);                                                                 \
+      n0[m] = Huon[X3(i + 1, j, k)]; n1[m] = Huon[X3(i, j, k)];                                        \
+      n2[m] = Hvom[X3(i, j + 1, k)]; n3[m] = Hvom[X3(i, j, k)];                                        \
+      nz[m] = z_w[XW(i, j, k)];                                                                        \
+    }                                                                                                  \
+  } while (0)
+  OM_LOAD(1);
+  const double zw0 = z_w[XW(i, j, 0)];
+  _Pragma("unroll 1") for (int k0 = 1; k0 <= N; k0 += CH) {
+    double d[CH], z[CH];
+#pragma unroll
+    for (int m = 0; m < CH; m++) { d[m] = n0[m] - n1[m] + n2[m] - n3[m]; z[m] = nz[m]; }
+    KSCHED_FENCE();
+    if (k0 + CH <= N) OM_LOAD(k0 + CH);
+    KSCHED_FENCE();
+#pragma unroll
+    for (int m = 0; m < CH; m++)
+      if (k0 + m <= N) { Wk = Wk - d[m]; lds[(k0 + m) * KLS] = Wk; lds[(N + 1 + k0 + m) * KLS] = z[m]; }
+  }
+#undef OM_LOAD
+  const double wrk = Wk / (lds[(N + 1 + N) * KLS] - zw0);
+  _Pragma("unroll 4") for (int k = N - 1; k >= 1; k--)
+    emit_store(G, P, W + (size_t)k * G.nij, lds[k * KLS] - wrk * (lds[(N + 1 + k) * KLS] - zw0));
+  emit_store(G, P, W + (size_t)N * G.nij, 0.0);
+}
+COL_GLOBAL(k_omega_l, KArgs)
+
 // ------------------------------------------------------------------------------ wvelocity
 // vert(i,j,k) into F.wrk3[6] (the KPP kernels on the main stream use wrk3[0..4] concurrently, swdk is [5]); index space (Istr:Iend, Jstr:Jend, 1:N); p0 = Ninp
 THREAD_KERNEL(k_wvel_vert, KArgs) {

@@ -2,7 +2,7 @@
 //
 //   k_s3uv_col     step3d_uv_tile (first J loop)    ROMS/Nonlinear/step3d_uv.F:345-1200
 //   k_s3uv_couple  step3d_uv_tile (second J loop)   ROMS/Nonlinear/step3d_uv.F:1310-1750
-//   k_s3t_h        step3d_t_tile T_LOOP1/K_LOOP     ROMS/Nonlinear/step3d_t.F:432-915
+//   k_s3t_hv       step3d_t_tile T_LOOP1/K_LOOP     ROMS/Nonlinear/step3d_t.F:432-1340 (point-wise)
 //   k_s3t_col      step3d_t_tile T_LOOP2 + J_LOOP2  ROMS/Nonlinear/step3d_t.F:936-1340, :1664-1790
 //
 // Column kernels: one thread per sigma-column, lanes along xi (every k-level access of a wave is
@@ -512,22 +512,35 @@ KDEV double hsimt_lim(double grad, double gradu, double Ka, double Kau, double o
   return 0.5 * m * grad * Ka;
 }
 
-// tracers whose corrector advection (horizontal + vertical) is done by the fused point kernel
-// k_s3t_hv: all but HSIMT (limiter on LDS tiles), MPDATA (k_mpdata.h) and spline vertical fluxes
+// tracers whose corrector advection is done by the point kernel k_s3t_hv: the horizontal step for
+// every scheme but MPDATA (k_mpdata.h) and HSIMT (k_s3t_h: faces shared through LDS), and the
+// vertical step too unless the vertical scheme needs the column (HSIMT, SPLINES: k_s3t_col)
+KDEV bool s3t_hpoint(const DGrid &G, int itrc) { return G.hadv[itrc - 1] != ROMS_MPDATA && G.hadv[itrc - 1] != ROMS_HSIMT; }
 KDEV bool s3t_point_path(const DGrid &G, int itrc) {
   const int hs = G.hadv[itrc - 1], vs = G.vadv[itrc - 1];
-  return hs != ROMS_HSIMT && hs != ROMS_MPDATA && vs != ROMS_HSIMT && vs != ROMS_MPDATA && vs != ROMS_SPLINES;
+  return hs != ROMS_MPDATA && hs != ROMS_HSIMT && vs != ROMS_HSIMT && vs != ROMS_MPDATA && vs != ROMS_SPLINES;
 }
 
+// one HSIMT face flux, step3d_t.F:520-550 (xi) / :598-632 (eta): upstream value + limited correction
+KDEV double hsimt_flux(double h, double tm, double t0, double g0, double gm, double gp, double K0, double Km, double Kp) {
+  const double eps1 = 1.0E-12;
+  const double oKa = (K0 <= eps1) ? 0.0 : 1.0 / KMAX(K0, eps1);
+  double sw;
+  if (h >= 0.0) sw = tm + hsimt_lim(g0, gm, K0, Km, oKa);
+  else sw = t0 - hsimt_lim(g0, gp, K0, Kp, oKa);
+  return sw * h;
+}
 // step3d_t: horizontal :633-915 and vertical :936-1340 advection of t(3) into t(nnew), one point per
 // thread; index space (Istr:Iend, Jstr:Jend, N*NT).  Both steps update t(nnew) at the thread's own
-// point only, so they are fused without changing any operation.
+// point only, so they are fused without changing any operation.  Tracers whose vertical scheme needs
+// the column (HSIMT, SPLINES) get the horizontal step only; k_s3t_col does the rest.
 THREAD_KERNEL(k_s3t_hv, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * KCH + 1;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
-  if (k0 > N || !s3t_point_path(G, itrc)) return;
+  if (k0 > N || !s3t_hpoint(G, itrc)) return;
+  const bool vert = s3t_point_path(G, itrc);
   const int hs = G.hadv[itrc - 1], vs = G.vadv[itrc - 1];
   const size_t nij = (size_t)G.nij, x = X2(i, j);
   const double *T3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
@@ -535,12 +548,14 @@ THREAD_KERNEL(k_s3t_hv, KArgs) {
   const double cff = G.dt * F.pm[x] * F.pn[x];
   // column window of t(3): levels k0-2 .. k0+KCH+1 (clamped), W at interfaces k0-1 .. k0+KCH-1
   double tw[KCH + 4], ww[KCH + 1], FC[KCH + 1];
+  if (vert) {
 #pragma unroll
-  for (int q = 0; q < KCH + 4; q++) tw[q] = T3[x + (size_t)(KMIN(KMAX(k0 - 2 + q, 1), N) - 1) * nij];
+    for (int q = 0; q < KCH + 4; q++) tw[q] = T3[x + (size_t)(KMIN(KMAX(k0 - 2 + q, 1), N) - 1) * nij];
 #pragma unroll
-  for (int q = 0; q < KCH + 1; q++) ww[q] = F.W[x + (size_t)KMIN(k0 - 1 + q, N) * nij];
+    for (int q = 0; q < KCH + 1; q++) ww[q] = F.W[x + (size_t)KMIN(k0 - 1 + q, N) * nij];
 #pragma unroll
-  for (int q = 0; q < KCH + 1; q++) VFLUX_REL(FC[q], vs, k0 - 1 + q, N, tw[q], tw[q + 1], tw[q + 2], tw[q + 3], ww[q]);
+    for (int q = 0; q < KCH + 1; q++) VFLUX_REL(FC[q], vs, k0 - 1 + q, N, tw[q], tw[q + 1], tw[q + 2], tw[q + 3], ww[q]);
+  }
 #pragma unroll
   for (int q = 0; q < KCH; q++) {
     const int k = k0 + q;
@@ -554,85 +569,70 @@ THREAD_KERNEL(k_s3t_hv, KArgs) {
     const double cff2 = cff * (FEp - FE0);
     const double cff3 = cff1 + cff2;
     double tt = tn[ok] - cff3;
-    const double cv = cff * (FC[q + 1] - FC[q]);
-    tt = tt - cv;
-    tt = tt * (1.0 / F.Hz[ok + x]);
+    if (vert) {
+      const double cv = cff * (FC[q + 1] - FC[q]);
+      tt = tt - cv;
+      tt = tt * (1.0 / F.Hz[ok + x]);
+    }
     tn[ok] = tt;
   }
 }
 THREAD_GLOBAL(k_s3t_hv, KArgs)
 
-// horizontal advection of t(3) -> t(nnew); grid.z = (k-1)+N*(itrc-1); 4 LDS arrays
+
+// HSIMT horizontal advection of t(3) -> t(nnew), step3d_t.F:472-632 + :873-915; grid.z = (k-1)+N*(itrc-1).
+// The gradient and KaX/KaE of every face of the sub-tile rectangle (the reference's private arrays) go
+// to four LDS tiles in ONE pass over the inputs; after one barrier every thread evaluates the four face
+// fluxes of its point from the tiles and updates t(nnew) (a flux is evaluated by the two points that
+// share the face -- cheaper than exchanging FX/FE through LDS and two more barriers).  Faces beyond a
+// closed edge are zero (:533-547, :610-624: they are only read where the reference has zeroed them).
 #define S3T_NLDS 4
 COOP_KERNEL(k_s3t_h, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB B = block_bounds(G, bx, by);
   const int k = bz % G.N + 1, itrc = bz / G.N + 1;
-  if (G.hadv[itrc - 1] == ROMS_MPDATA) return;   // k_mpdata.h (uniform over the block)
-  if (s3t_point_path(G, itrc)) return;           // k_s3t_hv
+  if (G.hadv[itrc - 1] != ROMS_HSIMT) return;    // k_s3t_hv / k_mpdata.h (uniform over the block)
   const size_t sz = (size_t)(G.bw + 6) * (size_t)(G.bh + 6);
-  double *FX = lds, *FE = lds + sz, *wk = lds + 2 * sz, *wk2 = lds + 3 * sz;
-  const int hs = G.hadv[itrc - 1];
+  double *gX = lds, *KX = lds + sz, *gE = lds + 2 * sz, *KE = lds + 3 * sz;
   const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
   const double *T3 = F.t + XT(G.LBi, G.LBj, k, 3, itrc);
   const double *Hu = F.Huon + X3(G.LBi, G.LBj, k), *Hv = F.Hvom + X3(G.LBi, G.LBj, k);
   const double *Hzk = F.Hz + X3(G.LBi, G.LBj, k);
-  const double dt = G.dt, eps1 = 1.0E-12;
-  if (hs == ROMS_HSIMT) {
-    // xi direction: gradX = wk, KaX = wk2 on (IstrU-1:Iendp2, Jstr:Jend)  :472-550
-    KLOOP2(i, j, B.IstrU - 1, B.Iendp2, Jstr, Jend) {
+  const double dt = G.dt;
+  const bool wc = !G.ewp && B.west, ec = !G.ewp && B.east, sc = !G.nsp && B.south, nc = !G.nsp && B.north;
+  // xi faces Istr-1 .. Iend+2 on rows Jstr .. Jend; eta faces Jstr-1 .. Jend+2 on columns Istr .. Iend
+  KLOOP2(i, j, Istr - 1, Iend + 2, Jstr, Jend) {
+    if (i >= B.IstrU - 1 && i <= B.Iendp2) {
       const double cff = 0.125 * (F.pm[X2(i - 1, j)] + F.pm[X2(i, j)]) * (F.pn[X2(i - 1, j)] + F.pn[X2(i, j)]) * dt;
       const double cff1 = cff * (1.0 / Hzk[X2(i - 1, j)] + 1.0 / Hzk[X2(i, j)]);
-      wk[S2(i, j)] = T3[X2(i, j)] - T3[X2(i - 1, j)];
-      wk2[S2(i, j)] = 1.0 - fabs(Hu[X2(i, j)] * cff1);
-    }
-    KSYNC();
-    if (!G.ewp) {
-      if (B.west) KLOOP1(j, Jstr, Jend) if (Hu[X2(Istr, j)] >= 0.0) { wk[S2(Istr - 1, j)] = 0.0; wk2[S2(Istr - 1, j)] = 0.0; }
-      if (B.east) KLOOP1(j, Jstr, Jend) if (Hu[X2(Iend + 1, j)] < 0.0) { wk[S2(Iend + 2, j)] = 0.0; wk2[S2(Iend + 2, j)] = 0.0; }
-    }
-    KSYNC();
-    KLOOP2(i, j, Istr, Iend + 1, Jstr, Jend) {
-      const double Ka = wk2[S2(i, j)];
-      const double oKa = (Ka <= eps1) ? 0.0 : 1.0 / KMAX(Ka, eps1);
-      double sw;
-      if (Hu[X2(i, j)] >= 0.0) sw = T3[X2(i - 1, j)] + hsimt_lim(wk[S2(i, j)], wk[S2(i - 1, j)], Ka, wk2[S2(i - 1, j)], oKa);
-      else sw = T3[X2(i, j)] - hsimt_lim(wk[S2(i, j)], wk[S2(i + 1, j)], Ka, wk2[S2(i + 1, j)], oKa);
-      FX[S2(i, j)] = sw * Hu[X2(i, j)];
-    }
-    KSYNC();
-    // eta direction  :552-632
-    KLOOP2(i, j, Istr, Iend, B.JstrV - 1, B.Jendp2) {
+      gX[S2(i, j)] = T3[X2(i, j)] - T3[X2(i - 1, j)];
+      KX[S2(i, j)] = 1.0 - fabs(Hu[X2(i, j)] * cff1);
+    } else if ((wc && i == Istr - 1) || (ec && i == Iend + 2)) { gX[S2(i, j)] = 0.0; KX[S2(i, j)] = 0.0; }
+  }
+  KLOOP2(i, j, Istr, Iend, Jstr - 1, Jend + 2) {
+    if (j >= B.JstrV - 1 && j <= B.Jendp2) {
       const double cff = 0.125 * (F.pn[X2(i, j)] + F.pn[X2(i, j - 1)]) * (F.pm[X2(i, j)] + F.pm[X2(i, j - 1)]) * dt;
       const double cff1 = cff * (1.0 / Hzk[X2(i, j)] + 1.0 / Hzk[X2(i, j - 1)]);
-      wk[S2(i, j)] = T3[X2(i, j)] - T3[X2(i, j - 1)];
-      wk2[S2(i, j)] = 1.0 - fabs(Hv[X2(i, j)] * cff1);
-    }
-    KSYNC();
-    if (!G.nsp) {
-      if (B.south) KLOOP1(i, Istr, Iend) if (Hv[X2(i, Jstr)] >= 0.0) { wk[S2(i, Jstr - 1)] = 0.0; wk2[S2(i, Jstr - 1)] = 0.0; }
-      if (B.north) KLOOP1(i, Istr, Iend) if (Hv[X2(i, Jend + 1)] < 0.0) { wk[S2(i, Jend + 2)] = 0.0; wk2[S2(i, Jend + 2)] = 0.0; }
-    }
-    KSYNC();
-    KLOOP2(i, j, Istr, Iend, Jstr, Jend + 1) {
-      const double Ka = wk2[S2(i, j)];
-      const double oKa = (Ka <= eps1) ? 0.0 : 1.0 / KMAX(Ka, eps1);
-      double sw;
-      if (Hv[X2(i, j)] >= 0.0) sw = T3[X2(i, j - 1)] + hsimt_lim(wk[S2(i, j)], wk[S2(i, j - 1)], Ka, wk2[S2(i, j - 1)], oKa);
-      else sw = T3[X2(i, j)] - hsimt_lim(wk[S2(i, j)], wk[S2(i, j + 1)], Ka, wk2[S2(i, j + 1)], oKa);
-      FE[S2(i, j)] = sw * Hv[X2(i, j)];
-    }
-    KSYNC();
-  } else {
-    hadv_flux_lds(G, B, hs, T3, Hu, Hv, FX, FE, wk);
+      gE[S2(i, j)] = T3[X2(i, j)] - T3[X2(i, j - 1)];
+      KE[S2(i, j)] = 1.0 - fabs(Hv[X2(i, j)] * cff1);
+    } else if ((sc && j == Jstr - 1) || (nc && j == Jend + 2)) { gE[S2(i, j)] = 0.0; KE[S2(i, j)] = 0.0; }
   }
-  // time-step horizontal advection :873-915
+  KSYNC();
   double *tn = F.t + XT(G.LBi, G.LBj, k, G.nnew, itrc);
   KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
+    const double tc = T3[X2(i, j)];
+    const double FX0 = hsimt_flux(Hu[X2(i, j)], T3[X2(i - 1, j)], tc, gX[S2(i, j)], gX[S2(i - 1, j)], gX[S2(i + 1, j)],
+                                  KX[S2(i, j)], KX[S2(i - 1, j)], KX[S2(i + 1, j)]);
+    const double FXp = hsimt_flux(Hu[X2(i + 1, j)], tc, T3[X2(i + 1, j)], gX[S2(i + 1, j)], gX[S2(i, j)], gX[S2(i + 2, j)],
+                                  KX[S2(i + 1, j)], KX[S2(i, j)], KX[S2(i + 2, j)]);
+    const double FE0 = hsimt_flux(Hv[X2(i, j)], T3[X2(i, j - 1)], tc, gE[S2(i, j)], gE[S2(i, j - 1)], gE[S2(i, j + 1)],
+                                  KE[S2(i, j)], KE[S2(i, j - 1)], KE[S2(i, j + 1)]);
+    const double FEp = hsimt_flux(Hv[X2(i, j + 1)], tc, T3[X2(i, j + 1)], gE[S2(i, j + 1)], gE[S2(i, j)], gE[S2(i, j + 2)],
+                                  KE[S2(i, j + 1)], KE[S2(i, j)], KE[S2(i, j + 2)]);
     const double cff = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
-    const double cff1 = cff * (FX[S2(i + 1, j)] - FX[S2(i, j)]);
-    const double cff2 = cff * (FE[S2(i, j + 1)] - FE[S2(i, j)]);
+    const double cff1 = cff * (FXp - FX0);
+    const double cff2 = cff * (FEp - FE0);
     const double cff3 = cff1 + cff2;
     tn[X2(i, j)] = tn[X2(i, j)] - cff3;
   }
