@@ -14,7 +14,7 @@ int run_diag_async(roms_hip_ctx *c, double *d_out) {
   a.row = c->d_diagwork + 9 * (size_t)G.nij;
   a.out = d_out;
   LAUNCH_THREAD(k_diag_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
-  LAUNCH_COOP(k_diag_row, (B.Iend - B.Istr + DIAG_IW) / DIAG_IW, 1, 1, 256, DIAG_ROW_LDS, c->stream, a);
+  LAUNCH_COOP(k_diag_row, (B.Iend - B.Istr + DIAG_IW) / DIAG_IW, 1, 1, 512, DIAG_ROW_LDS, c->stream, a);
   LAUNCH_COOP(k_diag_fin, 1, 1, 1, 256, DIAG_FIN_LDS, c->stream, a);
   return 0;
 }

@@ -67,105 +67,84 @@ KDEV bool diag_better(double C, int j, int k, int i, double C0, int j0, int k0, 
 }
 
 // ---- row stage: block bx owns i = Istr + 64*bx .. +63 -------------------------------------
+// Eight waves: waves 0..2 each add one of the three column products (volume, pe, ke) over the rows in
+// j order, one lane per i -- a row of 64 columns is one coalesced 512-byte read, the reads of the next
+// 32 rows are in flight while the (ordered, dependent) additions of the current 32 run; waves 3..7
+// scan interleaved subsets of the rows for the maxima (8 rows of reads at a time), merged through LDS.
 #define DIAG_IW 64
-#define DIAG_JC 16
-struct DiagBest { double C; int j, k; };
+#define DIAG_JC 32
+#define DIAG_NSUB 5
 COOP_KERNEL(k_diag_row, DiagArgs) {
   (void)by; (void)bz;
   const DGrid &G = a.G;
   const TB &T = G.T;
   const double *col = a.col;
+  double *mC = lds, *mS = lds + DIAG_NSUB * DIAG_IW, *mJ = lds + 2 * DIAG_NSUB * DIAG_IW, *mK = lds + 3 * DIAG_NSUB * DIAG_IW;
   const int i0 = T.Istr + DIAG_IW * bx;
   const int nw = KMIN(DIAG_IW, T.Iend - i0 + 1);
-  double *sK = lds, *sP = lds + DIAG_IW * DIAG_JC, *sV = lds + 2 * DIAG_IW * DIAG_JC;
-  double vol = 0.0, pes = 0.0, kes = 0.0;
-  for (int j0 = T.Jstr; j0 <= T.Jend; j0 += DIAG_JC) {
-    const int nj = KMIN(DIAG_JC, T.Jend - j0 + 1);
-    KSYNC();
-    KLOOP2(di, dj, 0, nw - 1, 0, nj - 1) {
-      const size_t q = X2(i0 + di, j0 + dj);
-      sK[dj * DIAG_IW + di] = col[q];
-      sP[dj * DIAG_IW + di] = col[q + G.nij];
-      sV[dj * DIAG_IW + di] = col[q + 8 * G.nij];
-    }
-    KSYNC();
-    // ordered accumulation: thread di adds rows j0..j0+nj-1 of column i0+di
-#ifdef ROMS_CPU_EMU
-    // serial emulation: the accumulators of all 64 columns live in LDS
-    double *acc = lds + 3 * DIAG_IW * DIAG_JC;
-    if (j0 == T.Jstr) for (int di = 0; di < 3 * DIAG_IW; di++) acc[di] = 0.0;
-    for (int di = 0; di < nw; di++)
-      for (int dj = 0; dj < nj; dj++) {
-        acc[di] = acc[di] + sV[dj * DIAG_IW + di];
-        acc[DIAG_IW + di] = acc[DIAG_IW + di] + sP[dj * DIAG_IW + di];
-        acc[2 * DIAG_IW + di] = acc[2 * DIAG_IW + di] + sK[dj * DIAG_IW + di];
-      }
-#else
-    if (KTID < nw) {
-      // all LDS reads of the chunk are issued before the (ordered, dependent) additions
-      double rv[DIAG_JC], rp[DIAG_JC], rk[DIAG_JC];
-#pragma unroll
-      for (int dj = 0; dj < DIAG_JC; dj++) {
-        const int d = dj < nj ? dj : 0;
-        rv[dj] = sV[d * DIAG_IW + KTID]; rp[dj] = sP[d * DIAG_IW + KTID]; rk[dj] = sK[d * DIAG_IW + KTID];
-      }
-#pragma unroll
-      for (int dj = 0; dj < DIAG_JC; dj++)
-        if (dj < nj) { vol = vol + rv[dj]; pes = pes + rp[dj]; kes = kes + rk[dj]; }
-    }
-#endif
-  }
   double *row = a.row;
   const int ni = G.ni;
-#ifdef ROMS_CPU_EMU
-  {
-    const double *acc = lds + 3 * DIAG_IW * DIAG_JC;
-    for (int di = 0; di < nw; di++) {
-      const int ii = i0 + di - G.LBi;
-      row[ii] = acc[di]; row[ii + ni] = acc[DIAG_IW + di]; row[ii + 2 * ni] = acc[2 * DIAG_IW + di];
-    }
-  }
-#else
-  if (KTID < nw) {
-    const int ii = i0 + KTID - G.LBi;
-    row[ii] = vol; row[ii + ni] = pes; row[ii + 2 * ni] = kes;
-  }
-#endif
-  // maxima: every thread scans a strided subset of rows of one column, then the partial results of
-  // a column are merged (the ordering relation diag_better is total, so the merge order is free)
-  KSYNC();
-  const int nsub = KMAX(1, KNT / DIAG_IW);
-  double *mC = lds;                               // [nsub][64] C, spd ; ints packed as doubles
-  double *mS = lds + 4 * DIAG_IW, *mJ = lds + 8 * DIAG_IW, *mK = lds + 12 * DIAG_IW;
-  for (int t = KTID; t < nsub * DIAG_IW; t += KNT) {
-    const int di = t % DIAG_IW, sub = t / DIAG_IW;
-    double bC = 0.0, spd = 0.0;
-    int bj = 0, bk = 0;
-    if (di < nw) {
-      const int i = i0 + di;
-      for (int j = T.Jstr + sub; j <= T.Jend; j += nsub) {
-        const double C = col[X2(i, j) + 2 * G.nij];
-        const int k = (int)col[X2(i, j) + 6 * G.nij];
-        if (C > 0.0 && (bC == 0.0 || diag_better(C, j, k, i, bC, bj, bk, i))) { bC = C; bj = j; bk = k; }
-        const double s = col[X2(i, j) + 7 * G.nij];
-        if (s > spd) spd = s;
+  for (int t = KTID; t < (3 + DIAG_NSUB) * DIAG_IW; t += KNT) {
+    const int w = t / DIAG_IW, di = t % DIAG_IW;
+    if (di >= nw) continue;
+    const int i = i0 + di, ii = i - G.LBi;
+    if (w < 3) {
+      const double *src = col + (w == 0 ? 8 : (w == 1 ? 1 : 0)) * G.nij;   // volume, pe, ke products
+      double acc = 0.0, nx[DIAG_JC];
+#pragma unroll
+      for (int q = 0; q < DIAG_JC; q++) nx[q] = src[X2(i, KMIN(T.Jstr + q, T.Jend))];
+      for (int j0 = T.Jstr; j0 <= T.Jend; j0 += DIAG_JC) {
+        double cur[DIAG_JC];
+#pragma unroll
+        for (int q = 0; q < DIAG_JC; q++) cur[q] = nx[q];
+        KSCHED_FENCE();
+        if (j0 + DIAG_JC <= T.Jend) {
+#pragma unroll
+          for (int q = 0; q < DIAG_JC; q++) nx[q] = src[X2(i, KMIN(j0 + DIAG_JC + q, T.Jend))];
+        }
+        KSCHED_FENCE();
+#pragma unroll
+        for (int q = 0; q < DIAG_JC; q++)
+          if (j0 + q <= T.Jend) acc = acc + cur[q];
       }
+      row[ii + w * ni] = acc;
+    } else {
+      // maxima: wave w scans the rows j = Jstr + (w-3), step DIAG_NSUB; the partial results of a column
+      // are merged below (the ordering relation diag_better is total, so the merge order is free)
+      const int sub = w - 3;
+      double bC = 0.0, spd = 0.0;
+      int bj = 0, bk = 0;
+      for (int j0 = T.Jstr + sub; j0 <= T.Jend; j0 += 8 * DIAG_NSUB) {
+        double C[8], K[8], S[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const size_t x = X2(i, KMIN(j0 + q * DIAG_NSUB, T.Jend));
+          C[q] = col[x + 2 * G.nij]; K[q] = col[x + 6 * G.nij]; S[q] = col[x + 7 * G.nij];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int j = j0 + q * DIAG_NSUB;
+          if (j > T.Jend) break;
+          const int k = (int)K[q];
+          if (C[q] > 0.0 && (bC == 0.0 || diag_better(C[q], j, k, i, bC, bj, bk, i))) { bC = C[q]; bj = j; bk = k; }
+          if (S[q] > spd) spd = S[q];
+        }
+      }
+      mC[sub * DIAG_IW + di] = bC; mS[sub * DIAG_IW + di] = spd;
+      mJ[sub * DIAG_IW + di] = (double)bj; mK[sub * DIAG_IW + di] = (double)bk;
     }
-    mC[sub * DIAG_IW + di] = bC; mS[sub * DIAG_IW + di] = spd;
-    mJ[sub * DIAG_IW + di] = (double)bj; mK[sub * DIAG_IW + di] = (double)bk;
   }
   KSYNC();
   for (int di = KTID; di < nw; di += KNT) {
-    const int i = i0 + di;
+    const int i = i0 + di, ii = i - G.LBi;
     double bC = 0.0, spd = 0.0;
     int bj = 0, bk = 0;
-    for (int sub = 0; sub < nsub; sub++) {
+    for (int sub = 0; sub < DIAG_NSUB; sub++) {
       const double C = mC[sub * DIAG_IW + di];
       const int j = (int)mJ[sub * DIAG_IW + di], k = (int)mK[sub * DIAG_IW + di];
       if (C > 0.0 && (bC == 0.0 || diag_better(C, j, k, i, bC, bj, bk, i))) { bC = C; bj = j; bk = k; }
       if (mS[sub * DIAG_IW + di] > spd) spd = mS[sub * DIAG_IW + di];
     }
-    const int ii = i - G.LBi;
     row[ii + 3 * ni] = spd;
     row[ii + 4 * ni] = bC;
     if (bC > 0.0) {
@@ -177,8 +156,9 @@ COOP_KERNEL(k_diag_row, DiagArgs) {
     row[ii + 8 * ni] = (double)bj; row[ii + 9 * ni] = (double)bk;
   }
 }
-COOP_GLOBAL(k_diag_row, DiagArgs)
-#define DIAG_ROW_LDS (3 * DIAG_IW * DIAG_JC + 16 * DIAG_IW)
+COOP_GLOBAL_LB(k_diag_row, DiagArgs, 512)
+#define DIAG_ROW_LDS (4 * DIAG_NSUB * DIAG_IW)
+
 
 // ---- final stage: one block ----------------------------------------------------------------
 #define DIAG_FC 1024
@@ -199,29 +179,29 @@ COOP_KERNEL(k_diag_fin, DiagArgs) {
       sV[d] = row[ii]; sP[d] = row[ii + ni]; sK[d] = row[ii + 2 * ni];
     }
     KSYNC();
-    if (KTID == 0) {
-#ifdef ROMS_CPU_EMU
-      for (int d = 0; d < nc; d++) {
-        vol = vol + sV[d];
-        pes = pes + sP[d];
-        kes = kes + sK[d];
-      }
-#else
-      // 16 values at a time: the LDS reads are issued together, the additions stay in order
+    // threads 0, 64 and 128 (three waves) each add one of the three sums in i order, 16 LDS reads at a time
+    for (int t = KTID; t < 192; t += KNT) {
+      if (t % 64 != 0) continue;
+      const int w = t / 64;
+      const double *sp = w == 0 ? sV : (w == 1 ? sP : sK);
+      double acc = w == 0 ? vol : (w == 1 ? pes : kes);
       for (int d0 = 0; d0 < nc; d0 += 16) {
-        double rv[16], rp[16], rk[16];
+        double r[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const int d = d0 + q < nc ? d0 + q : d0;
-          rv[q] = sV[d]; rp[q] = sP[d]; rk[q] = sK[d];
-        }
+        for (int q = 0; q < 16; q++) r[q] = sp[d0 + q < nc ? d0 + q : d0];
 #pragma unroll
         for (int q = 0; q < 16; q++)
-          if (d0 + q < nc) { vol = vol + rv[q]; pes = pes + rp[q]; kes = kes + rk[q]; }
+          if (d0 + q < nc) acc = acc + r[q];
       }
-#endif
+      if (w == 0) vol = acc; else if (w == 1) pes = acc; else kes = acc;
     }
   }
+  // the three sums meet in thread 0 (through LDS, after the staging area is free)
+  KSYNC();
+  for (int t = KTID; t < 192; t += KNT)
+    if (t % 64 == 0) lds[3 * DIAG_FC + t / 64] = t == 0 ? vol : (t == 64 ? pes : kes);
+  KSYNC();
+  vol = lds[3 * DIAG_FC]; pes = lds[3 * DIAG_FC + 1]; kes = lds[3 * DIAG_FC + 2];
   // maxima (order-free): every thread scans a strided subset, thread 0 merges the partial results
   KSYNC();
   double *mC = lds, *mS = lds + 256, *mI = lds + 512, *mJ = lds + 768, *mK = lds + 1024;
@@ -269,4 +249,4 @@ COOP_KERNEL(k_diag_fin, DiagArgs) {
   }
 }
 COOP_GLOBAL(k_diag_fin, DiagArgs)
-#define DIAG_FIN_LDS (3 * DIAG_FC)
+#define DIAG_FIN_LDS (3 * DIAG_FC + 8)
