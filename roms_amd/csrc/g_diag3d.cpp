@@ -131,9 +131,15 @@ int run_wvelocity(roms_hip_ctx *c, int ninp) {
   };
   launch_halo_multi(c, hs7, 2);
   KArgs a = mk(c, ninp);
-  LAUNCH_THREAD(k_wvel_vert, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N, c->stream, a);
-  LAUNCH_THREAD(k_wvel, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N + 1, c->stream, a);
-  launch_halo(c, c->F.wvel, N + 1, BC_R, 'r');     // bc_w3d_tile
+  static const char *ef = getenv("ROMS_HIP_WVELF");
+  if (ef && ef[0] == '0') {
+    LAUNCH_THREAD(k_wvel_vert, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N, c->stream, a);
+    LAUNCH_THREAD(k_wvel, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N + 1, c->stream, a);
+    launch_halo(c, c->F.wvel, N + 1, BC_R, 'r');     // bc_w3d_tile
+    return 0;
+  }
+  LAUNCH_THREAD_AS(k_wvel, k_wvel_f, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (N + KCH) / KCH, c->stream, a);
+  if (!c->G.fuse3d) launch_halo(c, c->F.wvel, N + 1, BC_R, 'r');     // bc_w3d_tile (fused: emit_store in the kernel)
   return 0;
 }
 

@@ -362,6 +362,64 @@ THREAD_KERNEL(k_wvel, KArgs) {
 }
 THREAD_GLOBAL(k_wvel, KArgs)
 
+// wvelocity in one launch: a thread owns KCH consecutive w-levels of its column (grid.z = chunk) and
+// forms vert (:131-160) of the KCH+3 rho-levels they need in registers, instead of a 3-D work array
+// written by one kernel and read four times by the next; it also stores the boundary values and
+// periodic images of wvel in fused single-tile runs (bc_w3d_tile + exchange).  p0 = Ninp
+THREAD_KERNEL(k_wvel_f, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N, Ninp = a.p0;
+  const int k0 = gz * KCH;                         // w-levels k0 .. k0+KCH-1 (0..N)
+  if (k0 > N) return;
+  const double cff1 = 3.0 / 8.0, cff2 = 3.0 / 4.0, cff3 = 1.0 / 8.0, cff4 = 9.0 / 16.0, cff5 = 1.0 / 16.0;
+  const double pmw = F.pm[X2(i - 1, j)] + F.pm[X2(i, j)], pme = F.pm[X2(i, j)] + F.pm[X2(i + 1, j)];
+  const double pns = F.pn[X2(i, j - 1)] + F.pn[X2(i, j)], pnn = F.pn[X2(i, j)] + F.pn[X2(i, j + 1)];
+  double vv[KCH + 3];                              // vert of rho-level k0-1+q (clamped to 1..N)
+#pragma unroll
+  for (int q = 0; q < KCH + 3; q++) {
+    const int k = KMIN(KMAX(k0 - 1 + q, 1), N);
+    const double zc = F.z_r[X3(i, j, k)];
+    const double wi = F.u[X4(i, j, k, Ninp)] * (zc - F.z_r[X3(i - 1, j, k)]) * pmw;
+    const double wip = F.u[X4(i + 1, j, k, Ninp)] * (F.z_r[X3(i + 1, j, k)] - zc) * pme;
+    double vert = 0.25 * (wi + wip);
+    const double wj = F.v[X4(i, j, k, Ninp)] * (zc - F.z_r[X3(i, j - 1, k)]) * pns;
+    const double wjp = F.v[X4(i, j + 1, k, Ninp)] * (F.z_r[X3(i, j + 1, k)] - zc) * pnn;
+    vert = vert + 0.25 * (wj + wjp);
+    vv[q] = vert;
+  }
+  const double zw0 = F.z_w[XW(i, j, 0)];
+  const double wrk = (F.DU_avg1[X2(i, j)] - F.DU_avg1[X2(i + 1, j)] + F.DV_avg1[X2(i, j)] - F.DV_avg1[X2(i, j + 1)]) /
+                     (F.z_w[XW(i, j, N)] - zw0);
+  const double pmn = F.pm[X2(i, j)] * F.pn[X2(i, j)];
+  const EmitPlan P = emit_plan(G, BC_R, i, j);
+#pragma unroll
+  for (int m = 0; m < KCH; m++) {
+    const int k = k0 + m;
+    if (k > N) break;
+    // vv[m] = vert(k-1), vv[m+1] = vert(k), vv[m+2] = vert(k+1), vv[m+3] = vert(k+2)
+    double w;
+    if (k == 0) {
+      const double slope = (F.z_r[X3(i, j, 1)] - zw0) / (F.z_r[X3(i, j, 2)] - F.z_r[X3(i, j, 1)]);
+      w = cff1 * (vv[m + 2] - slope * (vv[m + 3] - vv[m + 2])) + cff2 * vv[m + 2] - cff3 * vv[m + 3];
+    } else if (k == 1) {
+      w = pmn * (F.W[XW(i, j, 1)] + wrk * (F.z_w[XW(i, j, 1)] - zw0)) + cff1 * vv[m + 1] + cff2 * vv[m + 2] - cff3 * vv[m + 3];
+    } else if (k == N) {
+      const double slope = (F.z_w[XW(i, j, N)] - F.z_r[X3(i, j, N)]) / (F.z_r[X3(i, j, N)] - F.z_r[X3(i, j, N - 1)]);
+      w = pmn * wrk * (F.z_w[XW(i, j, N)] - zw0) + cff1 * (vv[m + 1] + slope * (vv[m + 1] - vv[m])) + cff2 * vv[m + 1] -
+          cff3 * vv[m];
+    } else if (k == N - 1) {
+      w = pmn * (F.W[XW(i, j, N - 1)] + wrk * (F.z_w[XW(i, j, N - 1)] - zw0)) + cff1 * vv[m + 2] + cff2 * vv[m + 1] -
+          cff3 * vv[m];
+    } else {
+      w = pmn * (F.W[XW(i, j, k)] + wrk * (F.z_w[XW(i, j, k)] - zw0)) + cff4 * (vv[m + 1] + vv[m + 2]) -
+          cff5 * (vv[m] + vv[m + 3]);
+    }
+    emit_store(G, P, F.wvel + (size_t)k * G.nij, w);
+  }
+}
+THREAD_GLOBAL(k_wvel_f, KArgs)
+
 // ------------------------------------------------------------------------------- set_zeta
 // index space (IstrR:IendR, JstrR:JendR)
 THREAD_KERNEL(k_set_zeta, KArgs) {
