@@ -529,62 +529,60 @@ THREAD_KERNEL(k_prs_P, KArgs) {
 }
 THREAD_GLOBAL(k_prs_P, KArgs)
 
+// harmonic mean of two differences, zero unless they have the same sign (prsgrd32.h:316-330); the
+// reciprocal is formed unconditionally and selected, so that the eight means of a point are
+// straight-line code (the value is the reference's wherever it is used)
+KDEV double prs_harm(double a, double b) {
+  const double c = 2.0 * a * b;
+  const double r = 1.0 / (a + b);
+  const double h = c * r;
+  return (c > 1.0E-10) ? h : 0.0;
+}
 // ru,rv(nrhs) from P: point-wise 3-D; index space (min(IstrU,Istr):Iend, min(Jstr,JstrV):Jend, 1:N)
 THREAD_KERNEL(k_prs_grad, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, nrhs = G.nrhs;
-  const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0, eps = 1.0E-10;
+  const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
   const double HalfGRho = 0.5 * (G.g / G.rho0);
-  const double *rho = F.rho, *z_r = F.z_r, *Hz = F.Hz, *P = F.wrk3[1];
+  const long ni = G.ni;
+  const size_t nij = (size_t)G.nij, x = X2(i, j);
+  const bool doU = i >= B.IstrU, doV = j >= B.JstrV;
+  const double onu = F.on_u[x], omv = F.om_v[x];
+  double *ru = F.ru + (size_t)(nrhs - 1) * nij * (size_t)(G.N + 1) + x, *rv = F.rv + (size_t)(nrhs - 1) * nij * (size_t)(G.N + 1) + x;
 #pragma unroll
   for (int q = 0; q < KCH; q++) {
-  const int k = gz * KCH + 1 + q;
-  if (k > G.N) break;
-  if (i >= B.IstrU) {
-    // aux(ii)=z_r(ii)-z_r(ii-1), FC(ii)=rho(ii)-rho(ii-1); dZx(ii)=harm(aux(ii),aux(ii+1)) ...
-    const double am = z_r[X3(i - 1, j, k)] - z_r[X3(i - 2, j, k)], a0 = z_r[X3(i, j, k)] - z_r[X3(i - 1, j, k)],
-                 ap = z_r[X3(i + 1, j, k)] - z_r[X3(i, j, k)];
-    const double fm = rho[X3(i - 1, j, k)] - rho[X3(i - 2, j, k)], f0 = rho[X3(i, j, k)] - rho[X3(i - 1, j, k)],
-                 fp = rho[X3(i + 1, j, k)] - rho[X3(i, j, k)];
-    double dZx0, dZxm, dRx0, dRxm, cff, cff1, cff2;
-    cff = 2.0 * a0 * ap;
-    if (cff > eps) { cff1 = 1.0 / (a0 + ap); dZx0 = cff * cff1; } else dZx0 = 0.0;
-    cff1 = 2.0 * f0 * fp;
-    if (cff1 > eps) { cff2 = 1.0 / (f0 + fp); dRx0 = cff1 * cff2; } else dRx0 = 0.0;
-    cff = 2.0 * am * a0;
-    if (cff > eps) { cff1 = 1.0 / (am + a0); dZxm = cff * cff1; } else dZxm = 0.0;
-    cff1 = 2.0 * fm * f0;
-    if (cff1 > eps) { cff2 = 1.0 / (fm + f0); dRxm = cff1 * cff2; } else dRxm = 0.0;
-    F.ru[XW4(i, j, k, nrhs)] =
-        F.on_u[X2(i, j)] * 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]) *
-        (P[X3(i - 1, j, k)] - P[X3(i, j, k)] -
-         HalfGRho * ((rho[X3(i, j, k)] + rho[X3(i - 1, j, k)]) * (z_r[X3(i, j, k)] - z_r[X3(i - 1, j, k)]) -
-                     OneFifth * ((dRx0 - dRxm) * (z_r[X3(i, j, k)] - z_r[X3(i - 1, j, k)] - OneTwelfth * (dZx0 + dZxm)) -
-                                 (dZx0 - dZxm) * (rho[X3(i, j, k)] - rho[X3(i - 1, j, k)] - OneTwelfth * (dRx0 + dRxm)))));
-  }
-  if (j >= B.JstrV) {
-    const double am = z_r[X3(i, j - 1, k)] - z_r[X3(i, j - 2, k)], a0 = z_r[X3(i, j, k)] - z_r[X3(i, j - 1, k)],
-                 ap = z_r[X3(i, j + 1, k)] - z_r[X3(i, j, k)];
-    const double fm = rho[X3(i, j - 1, k)] - rho[X3(i, j - 2, k)], f0 = rho[X3(i, j, k)] - rho[X3(i, j - 1, k)],
-                 fp = rho[X3(i, j + 1, k)] - rho[X3(i, j, k)];
-    double dZx0, dZxm, dRx0, dRxm, cff, cff1, cff2;
-    cff = 2.0 * a0 * ap;
-    if (cff > eps) { cff1 = 1.0 / (a0 + ap); dZx0 = cff * cff1; } else dZx0 = 0.0;
-    cff1 = 2.0 * f0 * fp;
-    if (cff1 > eps) { cff2 = 1.0 / (f0 + fp); dRx0 = cff1 * cff2; } else dRx0 = 0.0;
-    cff = 2.0 * am * a0;
-    if (cff > eps) { cff1 = 1.0 / (am + a0); dZxm = cff * cff1; } else dZxm = 0.0;
-    cff1 = 2.0 * fm * f0;
-    if (cff1 > eps) { cff2 = 1.0 / (fm + f0); dRxm = cff1 * cff2; } else dRxm = 0.0;
-    F.rv[XW4(i, j, k, nrhs)] =
-        F.om_v[X2(i, j)] * 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]) *
-        (P[X3(i, j - 1, k)] - P[X3(i, j, k)] -
-         HalfGRho * ((rho[X3(i, j, k)] + rho[X3(i, j - 1, k)]) * (z_r[X3(i, j, k)] - z_r[X3(i, j - 1, k)]) -
-                     OneFifth * ((dRx0 - dRxm) * (z_r[X3(i, j, k)] - z_r[X3(i, j - 1, k)] - OneTwelfth * (dZx0 + dZxm)) -
-                                 (dZx0 - dZxm) * (rho[X3(i, j, k)] - rho[X3(i, j - 1, k)] - OneTwelfth * (dRx0 + dRxm)))));
-  }
+    const int k = gz * KCH + 1 + q;
+    if (k > G.N) break;
+    const size_t ok = (size_t)(k - 1) * nij + x;
+    const double *zr = F.z_r + ok, *rh = F.rho + ok, *Hz = F.Hz + ok, *P = F.wrk3[1] + ok;
+    const double z0 = zr[0], r0 = rh[0], h0 = Hz[0], p0 = P[0];
+    if (doU) {
+      // aux(ii)=z_r(ii)-z_r(ii-1), FC(ii)=rho(ii)-rho(ii-1); dZx(ii)=harm(aux(ii),aux(ii+1)) ...
+      const double zm = zr[-1], rm = rh[-1];
+      const double am = zm - zr[-2], a0 = z0 - zm, ap = zr[1] - z0;
+      const double fm = rm - rh[-2], f0 = r0 - rm, fp = rh[1] - r0;
+      const double dZx0 = prs_harm(a0, ap), dRx0 = prs_harm(f0, fp), dZxm = prs_harm(am, a0), dRxm = prs_harm(fm, f0);
+      ru[(size_t)k * nij] =
+          onu * 0.5 * (h0 + Hz[-1]) *
+          (P[-1] - p0 -
+           HalfGRho * ((r0 + rm) * (z0 - zm) -
+                       OneFifth * ((dRx0 - dRxm) * (z0 - zm - OneTwelfth * (dZx0 + dZxm)) -
+                                   (dZx0 - dZxm) * (r0 - rm - OneTwelfth * (dRx0 + dRxm)))));
+    }
+    if (doV) {
+      const double zm = zr[-ni], rm = rh[-ni];
+      const double am = zm - zr[-2 * ni], a0 = z0 - zm, ap = zr[ni] - z0;
+      const double fm = rm - rh[-2 * ni], f0 = r0 - rm, fp = rh[ni] - r0;
+      const double dZx0 = prs_harm(a0, ap), dRx0 = prs_harm(f0, fp), dZxm = prs_harm(am, a0), dRxm = prs_harm(fm, f0);
+      rv[(size_t)k * nij] =
+          omv * 0.5 * (h0 + Hz[-ni]) *
+          (P[-ni] - p0 -
+           HalfGRho * ((r0 + rm) * (z0 - zm) -
+                       OneFifth * ((dRx0 - dRxm) * (z0 - zm - OneTwelfth * (dZx0 + dZxm)) -
+                                   (dZx0 - dZxm) * (r0 - rm - OneTwelfth * (dRx0 + dRxm)))));
+    }
   }
 }
 THREAD_GLOBAL(k_prs_grad, KArgs)

@@ -22,6 +22,11 @@ from collections import defaultdict
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
+# variants of one kernel (LDS / register forms, chunk sizes) are reported under the kernel's name
+VARIANTS = {"k_s3uv_col_l": "k_s3uv_col", "k_s3uv_col_l10": "k_s3uv_col", "k_s3uv_couple_l": "k_s3uv_couple",
+            "k_s3t_col_l": "k_s3t_col", "k_s3t_col_n30": "k_s3t_col", "k_omega_l": "k_omega", "k_wvel_f": "k_wvel"}
+
+
 def counter_avgs(d, counter):
     tot, disp = defaultdict(float), defaultdict(set)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -31,6 +36,7 @@ def counter_avgs(d, counter):
             k = r["Kernel_Name"].split("(")[0]
             if k in ("k_step2d_a", "k_step2d_b", "k_step2d_c", "k_step2d_d"):     # sub-tile variants of one kernel
                 k = "k_step2d"
+            k = VARIANTS.get(k, k)
             tot[k] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
     return {k: tot[k] / len(disp[k]) for k in tot}, {k: len(disp[k]) for k in tot}
