@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- grid-cell-updates/sec of the nonlinear 3-D time step (main3d) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload benchmark1|benchmark2|benchmark3|ns512|upwelling|config5]
+    python bench.py --gpus N --steps K --warmup W [--workload benchmark1|benchmark2|benchmark3|ns512|ns512u3|upwelling|config5]
 
 A "step" is one pass of main3d's STEP_LOOP (ROMS/Nonlinear/main3d.F:216-1148) with the full physics
 of the application (BENCHMARK: nonlinear EOS, KPP, COARE bulk fluxes, geopotential tracer mixing,
@@ -15,6 +15,8 @@ One JSON line is printed by rank 0 (contract in the task statement) with two ext
                 on the library's stream inside the timed region
   cpu_baseline  the C oracle (oracle/, a scalar port of the reference's algorithm) timed on one host
                 core on a bounded sample of the same workload
+and, as a third, `north_star_pair`: the kernels of "step3d_t + rhs3d" (BASELINE.json north_star) timed in
+the breakdown pass against their 632 algorithmic bytes per cell (meaningful at --workload ns512u3 / ns512).
 """
 import argparse
 import json
@@ -34,6 +36,8 @@ WORKLOADS = {
     "benchmark3": ("benchmark", 2048, 256, 30),
     "ns512": ("upwelling", 512, 512, 50),       # north_star roofline size (512x512x50); UPWELLING keeps
                                                 # 1 km cells at any size (BENCHMARK's shelf steepens with Mm)
+    "ns512u3": ("upwelling_u3c4", 512, 512, 50),  # the same with U3/C4 advection for both tracers: the schemes
+                                                # SURVEY.md 8(d) prices the north-star kernel pair on (79 words/cell)
     "upwelling": ("upwelling", 41, 80, 16),
     "config5": ("upwelling_kpp", 256, 512, 50),  # BASELINE configs[4]: UPWELLING + KPP + MPDATA
 }
@@ -70,9 +74,31 @@ ALGO_ARRAYS = {
     "k_set_depth":    (3, 2),
     "k_set_massflux": (5, 2),
     "k_diag_col":     (7, 3),
-    "k_wvel_vert":    (4, 2),
-    "k_wvel":         (5, 4),
+    "k_wvel":         (6, 4),      # fused wvelocity: u, v, z_r, W, z_w read, wvel written
 }
+
+# North-star kernel pair "step3d_t + rhs3d" (BASELINE.json north_star; SURVEY.md 8(d): rows a4-a8 + a10 =
+# pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2, step3d_t): 79 words = 632 bytes per cell for U3/C4
+# advection and NT = 2.  The kernels of those rows (launch sequences g_rhs3d.cpp, g_step3d.cpp:run_step3d_t):
+PAIR_KERNELS = ("k_swdk", "k_pre_t3", "k_pre_t3h", "k_pre_t3v", "k_pre_new", "k_prs_P", "k_prs_grad", "k_t3dmix2_s",
+                "k_t3dmix2_geo", "k_rhs3d_pt", "k_rhs3d_sum", "k_uv3dmix2_s", "k_uv3dmix2_sum", "k_s3t_hv", "k_s3t_h",
+                "k_s3t_col", "k_mp_ta", "k_mp_uva", "k_mp_wa", "k_mp_beta", "k_mp_limit", "k_mp_apply", "k_mp_vdiff")
+PAIR_BYTES_PER_CELL = 632.0
+
+
+def pair_report(table, steps, cells):
+    """Time of the north-star kernel pair per step from the per-kernel breakdown pass (synchronous HIP
+    events on the library's stream, `steps` steps) against its algorithmic bytes."""
+    us = sum(1e6 * table[k][0] for k in PAIR_KERNELS if k in table) / max(steps, 1)
+    if us <= 0.0:
+        return None
+    gbs = PAIR_BYTES_PER_CELL * cells / (us * 1e-6) / 1e9
+    return {"rows": "SURVEY 8(a) a4-a8 + a10 (pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2, step3d_t)",
+            "kernels": [k for k in PAIR_KERNELS if k in table], "us_per_step": us,
+            "algorithmic_bytes_per_cell": PAIR_BYTES_PER_CELL, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS,
+            "note": "632 B/cell is priced for U3/C4 advection and NT=2; HSIMT/MPDATA tracers and the halo launches of "
+                    "those rows (not counted here) add work"}
 
 
 def algo_bytes(kernel, Lm, Mm, N, launches_per_step_hint=None):
@@ -109,6 +135,8 @@ def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
         cs = cases.benchmark(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
     elif app == "upwelling_kpp":
         cs = cases.upwelling_kpp(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
+    elif app == "upwelling_u3c4":
+        cs = cases.upwelling(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes, hadv=("U3", "U3"), vadv=("C4", "C4"))
     else:
         cs = cases.upwelling(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
     return cs
@@ -200,13 +228,14 @@ def main():
 
     # dominant kernel: per-kernel breakdown over a few extra steps (synchronous events), then the
     # timed region with asynchronous event pairs on that kernel only
-    dominant, table = None, {}
+    dominant, table, pair = None, {}, None
     if not args.no_breakdown:
         hiplib.kprof(1)
         run.step(2)
         run.sync()
         table = hiplib.kprof_table()
         hiplib.kprof(0)
+        pair = pair_report(table, 2, cells_per_rank)
         ranked = sorted(((k, v) for k, v in table.items() if k in ALGO_ARRAYS), key=lambda kv: -kv[1][0])
         if ranked:
             dominant = ranked[0][0]
@@ -263,6 +292,7 @@ def main():
                                    "analytic grid/initial/forcing, full application physics",
                        "tiles": f"{run.NtileI}x{run.NtileJ}", "nfast": run.nfast},
             "roofline": roofline,
+            "north_star_pair": pair,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cs, run.host)

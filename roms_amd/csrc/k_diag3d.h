@@ -25,7 +25,9 @@ struct KArgs {
   int p0, p1, p2;
 };
 
+#ifndef KCH
 #define KCH 5   // levels per thread of the chunked point-wise kernels (grid.z = chunk)
+#endif
 
 #define XT(i, j, k, n, it) (X3(i, j, k) + ((size_t)((n) - 1) + 3 * (size_t)((it) - 1)) * (size_t)G.nij * (size_t)G.N)
 #define X4(i, j, k, n) (X3(i, j, k) + (size_t)((n) - 1) * (size_t)G.nij * (size_t)G.N)

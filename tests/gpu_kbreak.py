@@ -11,8 +11,11 @@ if len(sys.argv) > 4:
     kw = dict(hadv=tuple(sys.argv[3].split(",")), vadv=tuple(sys.argv[4].split(",")))
 app, Lm, Mm, N = bench.WORKLOADS[wl]
 from tests import cases
-fn = {"benchmark": cases.benchmark, "upwelling_kpp": cases.upwelling_kpp, "upwelling": cases.upwelling}[app]
-cs = fn(Lm=Lm, Mm=Mm, N=N, ntimes=n + 10, **kw)
+if kw:
+    fn = {"benchmark": cases.benchmark, "upwelling_kpp": cases.upwelling_kpp, "upwelling": cases.upwelling}[app]
+    cs = fn(Lm=Lm, Mm=Mm, N=N, ntimes=n + 10, **kw)
+else:
+    cs = bench.params_for(wl, ntimes=n + 10)
 cs["ninfo"] = 1
 run = tiling.TiledRun(cs)
 run.step(3); run.sync()
