@@ -375,3 +375,44 @@ def test_rccl_self_exchange_matches_local_periodic_copy():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert "SELF-EXCHANGE-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,dims", [("benchmark1", (96, 32, 30)), ("ns512", (64, 48, 50)), ("config5", (48, 64, 20))])
+def test_column_kernel_forms_agree_bitwise(workload, dims):
+    """The column kernels exist in two forms: COL launches with the column state in LDS (used when
+    2*(N+1) doubles per column fit a 64 KB block) and THREAD launches with private arrays / a work
+    array (any N; ROMS_HIP_COLLDS=0, ROMS_HIP_WVELF=0 select them).  Both must give the same bits.
+    (Own processes: the switches are read once per process.)"""
+    import subprocess
+    import sys
+    import textwrap
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    names = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "wvel", "Huon", "Hvom", "Akv"]
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import bench
+        from roms_amd import tiling
+        cs = bench.params_for(%r, *%r)
+        cs["ninfo"] = 1
+        run = tiling.TiledRun(cs)
+        run.step(4)
+        run.sync()
+        np.savez(sys.argv[1], **{n: run.ctx.download(n) for n in %r})
+        run.close()
+        print("FORM-RUN-OK")
+    """) % (ROOT, workload, tuple(dims), names)
+    import tempfile
+    out = []
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("lds", {}), ("priv", {"ROMS_HIP_COLLDS": "0", "ROMS_HIP_WVELF": "0"})):
+            f = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
+                               env=dict(os.environ, **extra), timeout=600)
+            assert "FORM-RUN-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+            out.append(dict(np.load(f)))
+    for n in names:
+        assert np.isfinite(out[0][n]).all(), n
+        assert np.array_equal(out[0][n], out[1][n]), (n, float(np.abs(out[0][n] - out[1][n]).max()))
