@@ -101,7 +101,8 @@ int run_step3d_t(roms_hip_ctx *c) {
     LAUNCH_THREAD(k_mp_beta, B.Iendp1 - (B.IstrU - 1) + 1, B.Jendp1 - (B.JstrV - 1) + 1, N, c->stream, m);
     LAUNCH_THREAD(k_mp_limit, LmT + 1, MmT + 1, N, c->stream, m);
     LAUNCH_THREAD(k_mp_apply, LmT, MmT, N, c->stream, m);
-    LAUNCH_THREAD(k_mp_vdiff, LmT, MmT, 1, c->stream, m);
+    if (col_lds(G)) LAUNCH_COL_AS(k_mp_vdiff, k_mp_vdiff_l, LmT, MmT, 1, 2 * (N + 1), c->stream, m);
+    else LAUNCH_THREAD(k_mp_vdiff, LmT, MmT, 1, c->stream, m);
   }
   if (G.fuse3d && !any_mp) return 0;   // k_s3t_col stored the boundary values and images (pt_emit)
   HaloSpec sp[ROMS_MAXT];

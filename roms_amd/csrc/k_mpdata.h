@@ -393,3 +393,71 @@ THREAD_KERNEL(k_mp_vdiff, MpArgs) {
 #undef MP_FCD
 }
 THREAD_GLOBAL(k_mp_vdiff, MpArgs)
+
+// COL form: CF/DC of the solve in LDS (2*(N+1) doubles per column) instead of two 3-D work arrays, the
+// loads of the next six levels in flight while the recurrence runs on the current six; t(nnew) is read
+// once and written once.
+COL_KERNEL(k_mp_vdiff_l, MpArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int N = G.N, itrc = a.itrc, ltrc = KMIN(G.NAT, itrc);
+  const int i = B.Istr + gx, j = B.Jstr + gy;
+  const double *Hz = F.Hz, *z_r = F.z_r;
+  const double *Akt = F.Akt + (size_t)(ltrc - 1) * G.nij * (N + 1);
+  double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);
+  double *CF = lds, *DC = lds + (size_t)(N + 1) * KLS;
+  const double cff = -G.dt * G.lambda;
+  constexpr int CH = 6;
+  double nh[CH], nt[CH], nz[CH + 1], na[CH];
+#define VD_LOAD(kb)                                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < CH; q++) {                                                   \
+      const int k = KMIN((kb) + q, N);                                                                 \
+      nh[q] = Hz[X3(i, j, k)]; nt[q] = tn[X3(i, j, k)]; na[q] = Akt[XW(i, j, k)];                      \
+    }                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < CH + 1; q++) nz[q] = z_r[X3(i, j, KMIN((kb) + q, N))];       \
+  } while (0)
+  double FCm = 0.0, CFm = 0.0, DCm = 0.0;     // FCD(k-1), CF(k-1), DC(k-1)
+  VD_LOAD(1);
+  _Pragma("unroll 1") for (int k0 = 1; k0 <= N; k0 += CH) {
+    double hz[CH], tt[CH], zr[CH + 1], ak[CH];
+#pragma unroll
+    for (int q = 0; q < CH; q++) { hz[q] = nh[q]; tt[q] = nt[q]; ak[q] = na[q]; }
+#pragma unroll
+    for (int q = 0; q < CH + 1; q++) zr[q] = nz[q];
+    KSCHED_FENCE();
+    if (k0 + CH <= N) VD_LOAD(k0 + CH);
+    KSCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < CH; q++) {
+      const int k = k0 + q;
+      if (k > N) break;
+      const double FCk = (k >= N) ? 0.0 : cff * (1.0 / (zr[q + 1] - zr[q])) * ak[q];
+      const double BCk = hz[q] - FCk - FCm;
+      if (k == 1) {
+        const double c = 1.0 / BCk;
+        CFm = c * FCk;
+        DCm = c * tt[q];
+      } else if (k <= N - 1) {
+        const double c = 1.0 / (BCk - FCm * CFm);
+        CFm = c * FCk;
+        DCm = c * (tt[q] - FCm * DCm);
+      } else {
+        DCm = (tt[q] - FCm * DCm) / (BCk - FCm * CFm);
+      }
+      CF[k * KLS] = CFm;
+      DC[k * KLS] = DCm;
+      FCm = FCk;
+    }
+  }
+#undef VD_LOAD
+  double d = DC[N * KLS];
+  tn[X3(i, j, N)] = d;
+  _Pragma("unroll 4") for (int k = N - 1; k >= 1; k--) {
+    d = DC[k * KLS] - CF[k * KLS] * d;
+    tn[X3(i, j, k)] = d;
+  }
+}
+COL_GLOBAL(k_mp_vdiff_l, MpArgs)
