@@ -53,6 +53,8 @@ def _interior(cs_dims, a):
     ("upwelling_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 1), 29611),
     ("upwelling_small", dict(hadv=("U3", "U3"), vadv=("C4", "C4")), (1, 2), 29612),
     ("benchmark_small", dict(), (2, 2), 29613),
+    # the 8-GPU partition of bench.py: every neighbour of a tile (sides and diagonals) is a different rank
+    ("benchmark_small", dict(), (4, 2), 29615),
     # three ghost lines on the high side (MPDATA), corner blocks from the diagonal tiles
     ("upwelling_small", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (2, 2), 29614),
 ])
