@@ -94,3 +94,25 @@ def relrms(a, b):
     d = np.sqrt(np.mean((a - b) ** 2))
     s = np.sqrt(np.mean(b ** 2))
     return d / s if s > 0 else d
+
+
+def ns_periodic_case(hadv, vadv, ng, ewp):
+    """upwelling_small with a periodic eta direction (and closed xi walls if not ewp): the EW-periodic
+    fixture re-embedded, ghost rows = periodic images of the interior rows."""
+    cs = case_for("upwelling_small", hadv=hadv, vadv=vadv)
+    g = load_init("upwelling_small", ng)
+    cs["NSperiodic"] = 1
+    cs["EWperiodic"] = ewp
+    LBi, UBi, LBj, UBj = [int(x) for x in g["bounds"][:4]]
+    ni, nj = UBi - LBi + 1, UBj - LBj + 1
+    Lm, Mm = cs["Lm"], cs["Mm"]
+    Im = Lm + ((Lm + 2) // 2 - (Lm + 1) // 2)
+    Jm = Mm + ((Mm + 2) // 2 - (Mm + 1) // 2)
+    rows = [((j - 1) % Mm) + 1 - LBj for j in range(-ng, Jm + ng + 1)]        # source row (old local index)
+    for k, a in list(g.items()):
+        if a.ndim == 1 and a.size >= ni * nj and a.size % (ni * nj) == 0:
+            a = a.reshape(-1, nj, ni)[:, rows, :]
+            if not ewp:
+                a = a[:, :, (0 - LBi):(Im + 1 - LBi) + 1]
+            g[k] = np.ascontiguousarray(a).ravel()
+    return cs, g
