@@ -353,6 +353,63 @@ THREAD_KERNEL(k_mp_apply, MpArgs) {
 }
 THREAD_GLOBAL(k_mp_apply, MpArgs)
 
+// ---- k_mp_limit + k_mp_apply in one kernel: every thread limits the six anti-diffusive velocities
+//      of its cell itself (a face velocity is limited by both cells that share it: same expression,
+//      same bits) instead of a pass that rewrites Ua, Va, Wa in place and a second one that reads them;
+//      Ua, Va, Wa stay unlimited in memory (nothing else reads them).  (Istr:Iend, Jstr:Jend, 1:N)
+THREAD_KERNEL(k_mp_limapply, MpArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int N = G.N, itrc = a.itrc;
+  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1;
+  const double *Ta = F.mp3[0] + (size_t)(itrc - 1) * G.nij * N, *Ua = F.mp3[1], *Va = F.mp3[2], *Wa = F.mp3[3];
+  const double *bup = F.mp3[4], *bdn = F.mp3[5], *z_r = F.z_r, *Hz = F.Hz;
+  double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);
+  const double odt = 1.0 / G.dt;
+  const bool wc = !G.ewp && B.west, ec = !G.ewp && B.east, sc = !G.nsp && B.south, nc = !G.nsp && B.north;
+  const double cff = G.dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
+  // limited Ua at (ii,j,k) :1100-1185, Va at (i,jj,k) :1187-1220, Wa at w-level kk :1130-1150
+#define MP_LU(ii)                                                                                         \
+  (((wc && (ii) == B.Istr) || (ec && (ii) == B.Iend + 1))                                                 \
+       ? 0.0                                                                                              \
+       : (KMIN(KMIN(bdn[X3((ii) - 1, j, k)], bup[X3(ii, j, k)]), 1.0) * KMAX(0.0, Ua[X3(ii, j, k)]) +     \
+          KMIN(KMIN(bup[X3((ii) - 1, j, k)], bdn[X3(ii, j, k)]), 1.0) * KMIN(0.0, Ua[X3(ii, j, k)])) *    \
+             odt * F.om_u[X2(ii, j)])
+#define MP_LV(jj)                                                                                         \
+  (((sc && (jj) == B.Jstr) || (nc && (jj) == B.Jend + 1))                                                 \
+       ? 0.0                                                                                              \
+       : (KMIN(KMIN(bdn[X3(i, (jj) - 1, k)], bup[X3(i, jj, k)]), 1.0) * KMAX(0.0, Va[X3(i, jj, k)]) +     \
+          KMIN(KMIN(bup[X3(i, (jj) - 1, k)], bdn[X3(i, jj, k)]), 1.0) * KMIN(0.0, Va[X3(i, jj, k)])) *    \
+             odt * F.on_v[X2(i, jj)])
+#define MP_LW(kk)                                                                                         \
+  ((KMIN(KMIN(bdn[X3(i, j, kk)], bup[X3(i, j, (kk) + 1)]), 1.0) * KMAX(0.0, Wa[XW(i, j, kk)]) +           \
+    KMIN(KMIN(bup[X3(i, j, kk)], bdn[X3(i, j, (kk) + 1)]), 1.0) * KMIN(0.0, Wa[XW(i, j, kk)])) *          \
+   odt * F.omn[X2(i, j)] * (z_r[X3(i, j, (kk) + 1)] - z_r[X3(i, j, kk)]))
+  const double ua0 = MP_LU(i), ua1 = MP_LU(i + 1), va0 = MP_LV(j), va1 = MP_LV(j + 1);
+  const double ta = MP_TA(i, j, k);
+#define MP_FX(ua_, ii) ((KMAX(ua_, 0.0) * MP_TA((ii) - 1, j, k) + KMIN(ua_, 0.0) * MP_TA(ii, j, k)) * 0.5 * \
+                        (Hz[X3(ii, j, k)] + Hz[X3((ii) - 1, j, k)]) * F.on_u[X2(ii, j)])
+#define MP_FE(va_, jj) ((KMAX(va_, 0.0) * MP_TA(i, (jj) - 1, k) + KMIN(va_, 0.0) * MP_TA(i, jj, k)) * 0.5 * \
+                        (Hz[X3(i, jj, k)] + Hz[X3(i, (jj) - 1, k)]) * F.om_v[X2(i, jj)])
+  const double cff1 = cff * (MP_FX(ua1, i + 1) - MP_FX(ua0, i));
+  const double cff2 = cff * (MP_FE(va1, j + 1) - MP_FE(va0, j));
+  const double cff3 = cff1 + cff2;
+  double t1 = ta * Hz[X3(i, j, k)] - cff3;
+  double fc1 = 0.0, fc0 = 0.0;                     // FC(k), FC(k-1); zero at the bottom and at the surface
+  if (k < N) { const double w = MP_LW(k); fc1 = KMAX(w, 0.0) * ta + KMIN(w, 0.0) * MP_TA(i, j, k + 1); }
+  if (k > 1) { const double w = MP_LW(k - 1); fc0 = KMAX(w, 0.0) * MP_TA(i, j, k - 1) + KMIN(w, 0.0) * ta; }
+  const double cv = cff * (fc1 - fc0);
+  t1 = t1 - cv;
+  tn[X3(i, j, k)] = t1;
+#undef MP_LU
+#undef MP_LV
+#undef MP_LW
+#undef MP_FX
+#undef MP_FE
+}
+THREAD_GLOBAL(k_mp_limapply, MpArgs)
+
 // ---- implicit vertical diffusion, plain tridiagonal :1724-1790; one thread per column ---------
 THREAD_KERNEL(k_mp_vdiff, MpArgs) {
   (void)gz;
