@@ -123,27 +123,30 @@ void kprof_end(int slot, hipStream_t stream);
 // the same XCD and close in time, so the vertical (k-1..k+2) and eta (j-2..j+2) neighbours a
 // point-wise kernel re-reads hit that XCD's L2, and every XCD gets the same number of blocks whatever
 // the grid shape.  (Measured with rocprofv3 FETCH_SIZE: profiles/, DESIGN.md.)
+#ifndef KTY
+#define KTY 4   // eta rows per THREAD block (64 x KTY threads)
+#endif
 #define THREAD_GLOBAL(name, ArgT)                                                        \
   static __global__ void __launch_bounds__(256) name(const ArgT a, int nx, int ny, int nz) {    \
-    const int nby_ = (ny + 3) / 4, nt_ = ((nx + 63) / 64) * nby_, seg_ = (nt_ + 7) / 8;  \
+    const int nby_ = (ny + KTY - 1) / KTY, nt_ = ((nx + 63) / 64) * nby_, seg_ = (nt_ + 7) / 8;  \
     const int r_ = (int)(blockIdx.x >> 3), xcd_ = (int)(blockIdx.x & 7);                 \
     const int gz = r_ % nz;                                                              \
     const int t_ = xcd_ * seg_ + r_ / nz;                                                \
     if (t_ >= nt_) return;                                                               \
     const int tx_ = t_ / nby_, ty_ = t_ - tx_ * nby_;                                    \
     const int gx = tx_ * 64 + (int)threadIdx.x;                                          \
-    const int gy = ty_ * 4 + (int)threadIdx.y;                                           \
+    const int gy = ty_ * KTY + (int)threadIdx.y;                                           \
     if (gx < nx && gy < ny) name##_body(a, gx, gy, gz);                                  \
   }
 // 64 lanes along xi (coalesced), 4 rows of eta per block; 1-D grid of 8*ceil(blocks/8)*nz workgroups
 #define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
   KPROF_WRAP(name, stream,                                                               \
-  hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + 3) / 4)) + 7) / 8) * (nz)), 1, 1), \
-                     dim3(64, 4, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
+  hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + KTY - 1) / KTY)) + 7) / 8) * (nz)), 1, 1), \
+                     dim3(64, KTY, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
 #define LAUNCH_THREAD_AS(label, name, nx, ny, nz, stream, args)                           \
   KPROF_WRAP(label, stream,                                                              \
-  hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + 3) / 4)) + 7) / 8) * (nz)), 1, 1), \
-                     dim3(64, 4, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
+  hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + KTY - 1) / KTY)) + 7) / 8) * (nz)), 1, 1), \
+                     dim3(64, KTY, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
 // COL kernels: one thread per sigma column with `per_thread` doubles of LDS each (the elimination
 // coefficients of a tridiagonal solve, a column kept between sweeps).  Blocks are single waves
 // (64 columns along xi, one eta row) so that the LDS footprint of a block stays small and several fit
