@@ -114,7 +114,7 @@ int run_omega(roms_hip_ctx *c) {
   KArgs a = mk(c);
   {
     static const char *e = getenv("ROMS_HIP_COLLDS");
-    const bool l = !(e && e[0] == '0') && 2 * (c->G.N + 1) * 64 * sizeof(double) <= 64 * 1024;
+    const bool l = !(e && e[0] == '0') && 2 * (c->G.N + 1) * 64 * sizeof(double) < 64 * 1024;
     if (l) LAUNCH_COL_AS(k_omega, k_omega_l, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, 2 * (c->G.N + 1), c->stream, a);
     else LAUNCH_THREAD(k_omega, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   }

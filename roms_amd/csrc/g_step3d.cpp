@@ -15,7 +15,7 @@ static inline KArgs mk(roms_hip_ctx *c, int p0 = 0) {
 // fit the 64 KB a block gets without opting in; ROMS_HIP_COLLDS=0 selects the private-memory forms
 static inline bool col_lds(const DGrid &G) {
   static const char *e = getenv("ROMS_HIP_COLLDS");
-  return !(e && e[0] == '0') && 2 * (G.N + 1) * 64 * sizeof(double) <= 64 * 1024;
+  return !(e && e[0] == '0') && 2 * (G.N + 1) * 64 * sizeof(double) < 64 * 1024;
 }
 static inline size_t lds_sz(const DGrid &G) { return (size_t)(G.bw + 6) * (size_t)(G.bh + 6); }
 

@@ -239,6 +239,11 @@ def test_bench_under_torchrun_single_rank(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,dims,nsteps,tol", [("benchmark1", None, 4, 1e-12), ("upwelling", None, 12, 1e-11),
                                                        ("ns512", (96, 40, 50), 6, 1e-11),
+                                                       # 62 levels: the largest column the LDS (COL) forms take;
+                                                       # 80: beyond it, the private-memory forms; config 5 physics
+                                                       ("ns512", (64, 24, 62), 4, 1e-11),
+                                                       ("benchmark1", (64, 24, 80), 3, 1e-12),
+                                                       ("config5", (48, 40, 80), 3, 1e-11),
                                                        ("benchmark2", (192, 40, 30), 4, 1e-12),
                                                        ("benchmark2", None, 3, 1e-12)])
 def test_baseline_size_matches_oracle(workload, dims, nsteps, tol):
