@@ -579,6 +579,6 @@ COOP_GLOBAL_LB(k_step2d_b, Step2dArgs, 512)
 COOP_KERNEL(k_step2d_d, Step2dArgs) { k_step2d_t_body<64, 8, 1024, 1>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d_d, Step2dArgs, 1024)
 COOP_KERNEL(k_step2d_c, Step2dArgs) { k_step2d_t_body<32, 8, 512, 2>(a, bx, by, bz, lds); }
-COOP_GLOBAL_LB(k_step2d_c, Step2dArgs, 512)
+COOP_GLOBAL_LB2(k_step2d_c, Step2dArgs, 512, 4)   // two blocks of 8 waves per CU: at most 128 VGPRs
 COOP_KERNEL(k_step2d, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)

@@ -35,6 +35,7 @@ struct kdim3 { int x, y, z; };
 #define COOP_KERNEL(name, ArgT) static inline void name##_body(const ArgT &a, int bx, int by, int bz, double *lds)
 #define COOP_GLOBAL(name, ArgT)
 #define COOP_GLOBAL_LB(name, ArgT, maxthreads)
+#define COOP_GLOBAL_LB2(name, ArgT, maxthreads, minwaves)
 #define LAUNCH_COOP(name, gx, gy, gz, nthreads, lds_doubles, stream, args)               \
   do {                                                                                   \
     std::vector<double> lds_((size_t)(lds_doubles) + 8);                                 \
@@ -88,6 +89,12 @@ typedef hipStream_t kstream_t;
 // compiler (instead of its default assumption of 1024) doubles the VGPR budget per thread.
 #define COOP_GLOBAL_LB(name, ArgT, maxthreads)                                           \
   static __global__ void __launch_bounds__(maxthreads) name(const ArgT a) {              \
+    extern __shared__ double lds_dyn_[];                                                 \
+    name##_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds_dyn_);         \
+  }
+// ... with a minimum number of waves per SIMD as well (caps the VGPRs so that that many fit)
+#define COOP_GLOBAL_LB2(name, ArgT, maxthreads, minwaves)                                \
+  static __global__ void __launch_bounds__(maxthreads, minwaves) name(const ArgT a) {    \
     extern __shared__ double lds_dyn_[];                                                 \
     name##_body(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds_dyn_);         \
   }

@@ -131,8 +131,13 @@ static void choose_blocks(DGrid &G) {
   int bw = 32, bh = 8;
   env_tile("ROMS_HIP_TILE3D", bw, bh, 672);              // 12 LDS arrays, 64 KB
   split_tile(LmT, MmT, bw, bh, G.nbx, G.nby, G.bw, G.bh);
-  int bw2 = 64, bh2 = 8;   // measured best of 32x6..64x8 on 1024x128, 2048x256 and 512x512 grids
+  // 64x8 (one block of 1024 threads per CU, 118 KB LDS) on 64 K .. 256 K points; above that 32x8 with
+  // TWO blocks per CU (64 KB LDS, 512 threads compiled for <= 128 VGPRs): a block's load phase overlaps
+  // the other's compute phases -- 2048x256: 74 -> 64 us per launch, 512x512: 38.4 -> 37.1, but
+  // 1024x128: 21 -> 24 (a single round of blocks either way)
+  int bw2 = 64, bh2 = 8;
   if ((long)LmT * MmT <= 64L * 1024L) { bw2 = 32; bh2 = 4; }
+  else if ((long)LmT * MmT >= 256L * 1024L) { bw2 = 32; bh2 = 8; }
   env_tile("ROMS_HIP_TILE2D", bw2, bh2, 1024);            // 19 LDS arrays < 160 KB; 2 points x 512 threads
   split_tile(LmT, MmT, bw2, bh2, G.nbx2, G.nby2, G.bw2, G.bh2);
 }
