@@ -50,6 +50,7 @@ struct kdim3 { int x, y, z; };
 #define LAUNCH_THREAD_AS(label, name, nx, ny, nz, stream, args) LAUNCH_THREAD(name, nx, ny, nz, stream, args)
 #define THREAD_KERNEL(name, ArgT) static inline void name##_body(const ArgT &a, int gx, int gy, int gz)
 #define THREAD_GLOBAL(name, ArgT)
+#define THREAD_GLOBAL_W(name, ArgT, minwaves)
 #define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
   do {                                                                                   \
     for (int gz_ = 0; gz_ < (nz); gz_++)                                                 \
@@ -133,8 +134,13 @@ void kprof_end(int slot, hipStream_t stream);
 #ifndef KTY
 #define KTY 4   // eta rows per THREAD block (64 x KTY threads)
 #endif
-#define THREAD_GLOBAL(name, ArgT)                                                        \
-  static __global__ void __launch_bounds__(256) name(const ArgT a, int nx, int ny, int nz) {    \
+#ifndef KMINW
+#define KMINW 1   // minimum waves per SIMD the THREAD kernels are compiled for (experiment knob)
+#endif
+#define THREAD_GLOBAL(name, ArgT) THREAD_GLOBAL_W(name, ArgT, KMINW)
+// ... compiled for at least `minwaves` waves per SIMD (caps the VGPRs)
+#define THREAD_GLOBAL_W(name, ArgT, minwaves)                                            \
+  static __global__ void __launch_bounds__(256, minwaves) name(const ArgT a, int nx, int ny, int nz) {    \
     const int nby_ = (ny + KTY - 1) / KTY, nt_ = ((nx + 63) / 64) * nby_, seg_ = (nt_ + 7) / 8;  \
     const int r_ = (int)(blockIdx.x >> 3), xcd_ = (int)(blockIdx.x & 7);                 \
     const int gz = r_ % nz;                                                              \
