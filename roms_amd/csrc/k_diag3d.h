@@ -377,19 +377,23 @@ THREAD_KERNEL(k_wvel_f, KArgs) {
   const double cff1 = 3.0 / 8.0, cff2 = 3.0 / 4.0, cff3 = 1.0 / 8.0, cff4 = 9.0 / 16.0, cff5 = 1.0 / 16.0;
   const double pmw = F.pm[X2(i - 1, j)] + F.pm[X2(i, j)], pme = F.pm[X2(i, j)] + F.pm[X2(i + 1, j)];
   const double pns = F.pn[X2(i, j - 1)] + F.pn[X2(i, j)], pnn = F.pn[X2(i, j)] + F.pn[X2(i, j + 1)];
-  double vv[KCH + 3];                              // vert of rho-level k0-1+q (clamped to 1..N)
-#pragma unroll
-  for (int q = 0; q < KCH + 3; q++) {
-    const int k = KMIN(KMAX(k0 - 1 + q, 1), N);
-    const double zc = F.z_r[X3(i, j, k)];
-    const double wi = F.u[X4(i, j, k, Ninp)] * (zc - F.z_r[X3(i - 1, j, k)]) * pmw;
-    const double wip = F.u[X4(i + 1, j, k, Ninp)] * (F.z_r[X3(i + 1, j, k)] - zc) * pme;
-    double vert = 0.25 * (wi + wip);
-    const double wj = F.v[X4(i, j, k, Ninp)] * (zc - F.z_r[X3(i, j - 1, k)]) * pns;
-    const double wjp = F.v[X4(i, j + 1, k, Ninp)] * (F.z_r[X3(i, j + 1, k)] - zc) * pnn;
-    vert = vert + 0.25 * (wj + wjp);
-    vv[q] = vert;
-  }
+  // vert of one rho-level (clamped to 1..N), wvelocity.F:131-160
+#define WV_VERT(out, lev)                                                                              \
+  do {                                                                                                 \
+    const int k_ = KMIN(KMAX(lev, 1), N);                                                              \
+    const double zc = F.z_r[X3(i, j, k_)];                                                             \
+    const double wi = F.u[X4(i, j, k_, Ninp)] * (zc - F.z_r[X3(i - 1, j, k_)]) * pmw;                  \
+    const double wip = F.u[X4(i + 1, j, k_, Ninp)] * (F.z_r[X3(i + 1, j, k_)] - zc) * pme;             \
+    double vert = 0.25 * (wi + wip);                                                                   \
+    const double wj = F.v[X4(i, j, k_, Ninp)] * (zc - F.z_r[X3(i, j - 1, k_)]) * pns;                  \
+    const double wjp = F.v[X4(i, j + 1, k_, Ninp)] * (F.z_r[X3(i, j + 1, k_)] - zc) * pnn;             \
+    vert = vert + 0.25 * (wj + wjp);                                                                   \
+    out = vert;                                                                                        \
+  } while (0)
+  // rolling window of four levels: vm = vert(k-1), v0 = vert(k), v1 = vert(k+1), v2 = vert(k+2) (all
+  // KCH+3 levels of the chunk at once cost 197 VGPRs: two waves per SIMD)
+  double vm, v0, v1, v2;
+  WV_VERT(vm, k0 - 1); WV_VERT(v0, k0); WV_VERT(v1, k0 + 1);
   const double zw0 = F.z_w[XW(i, j, 0)];
   const double wrk = (F.DU_avg1[X2(i, j)] - F.DU_avg1[X2(i + 1, j)] + F.DV_avg1[X2(i, j)] - F.DV_avg1[X2(i, j + 1)]) /
                      (F.z_w[XW(i, j, N)] - zw0);
@@ -399,26 +403,25 @@ THREAD_KERNEL(k_wvel_f, KArgs) {
   for (int m = 0; m < KCH; m++) {
     const int k = k0 + m;
     if (k > N) break;
-    // vv[m] = vert(k-1), vv[m+1] = vert(k), vv[m+2] = vert(k+1), vv[m+3] = vert(k+2)
+    WV_VERT(v2, k + 2);
     double w;
     if (k == 0) {
       const double slope = (F.z_r[X3(i, j, 1)] - zw0) / (F.z_r[X3(i, j, 2)] - F.z_r[X3(i, j, 1)]);
-      w = cff1 * (vv[m + 2] - slope * (vv[m + 3] - vv[m + 2])) + cff2 * vv[m + 2] - cff3 * vv[m + 3];
+      w = cff1 * (v1 - slope * (v2 - v1)) + cff2 * v1 - cff3 * v2;
     } else if (k == 1) {
-      w = pmn * (F.W[XW(i, j, 1)] + wrk * (F.z_w[XW(i, j, 1)] - zw0)) + cff1 * vv[m + 1] + cff2 * vv[m + 2] - cff3 * vv[m + 3];
+      w = pmn * (F.W[XW(i, j, 1)] + wrk * (F.z_w[XW(i, j, 1)] - zw0)) + cff1 * v0 + cff2 * v1 - cff3 * v2;
     } else if (k == N) {
       const double slope = (F.z_w[XW(i, j, N)] - F.z_r[X3(i, j, N)]) / (F.z_r[X3(i, j, N)] - F.z_r[X3(i, j, N - 1)]);
-      w = pmn * wrk * (F.z_w[XW(i, j, N)] - zw0) + cff1 * (vv[m + 1] + slope * (vv[m + 1] - vv[m])) + cff2 * vv[m + 1] -
-          cff3 * vv[m];
+      w = pmn * wrk * (F.z_w[XW(i, j, N)] - zw0) + cff1 * (v0 + slope * (v0 - vm)) + cff2 * v0 - cff3 * vm;
     } else if (k == N - 1) {
-      w = pmn * (F.W[XW(i, j, N - 1)] + wrk * (F.z_w[XW(i, j, N - 1)] - zw0)) + cff1 * vv[m + 2] + cff2 * vv[m + 1] -
-          cff3 * vv[m];
+      w = pmn * (F.W[XW(i, j, N - 1)] + wrk * (F.z_w[XW(i, j, N - 1)] - zw0)) + cff1 * v1 + cff2 * v0 - cff3 * vm;
     } else {
-      w = pmn * (F.W[XW(i, j, k)] + wrk * (F.z_w[XW(i, j, k)] - zw0)) + cff4 * (vv[m + 1] + vv[m + 2]) -
-          cff5 * (vv[m] + vv[m + 3]);
+      w = pmn * (F.W[XW(i, j, k)] + wrk * (F.z_w[XW(i, j, k)] - zw0)) + cff4 * (v0 + v1) - cff5 * (vm + v2);
     }
+    vm = v0; v0 = v1; v1 = v2;
     emit_store(G, P, F.wvel + (size_t)k * G.nij, w);
   }
+#undef WV_VERT
 }
 THREAD_GLOBAL(k_wvel_f, KArgs)
 
