@@ -10,5 +10,5 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --workload $WL --steps $STEPS --warmup 1 --no-cpu-baseline --no-breakdown"
 timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/p1 -o p -- python3 $ARGS > $OUT/p1.log 2>&1
 echo "pass1 exit $?"
-timeout -s KILL 240 rocprofv3 --pmc GRBM_GUI_ACTIVE TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES MemUnitStalled OccupancyPercent --output-format csv -d $OUT/p2 -o p -- python3 $ARGS > $OUT/p2.log 2>&1
-echo "pass2 exit $?"
+# (a second pass with GRBM_GUI_ACTIVE TA_TA_BUSY TA_*_STALLED_BY_TC_CYCLES MemUnitStalled OccupancyPercent
+#  hung rocprofv3 on this pool until the time-out: not collected)
