@@ -1,6 +1,7 @@
 // g_bench.cpp -- launch sequences of the BENCHMARK-only physics: nonlinear EOS, geopotential
 // tracer mixing, KPP vertical mixing, COARE bulk fluxes, analytic atmospheric forcing.
 #include "roms_host.h"
+#include <cstdlib>
 #include "k_bench.h"
 #include "k_lmd.h"
 #include <cmath>
@@ -36,7 +37,14 @@ int run_eos_nonlinear(roms_hip_ctx *c) {
 int run_t3dmix2_geo(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   KArgs a = mk(c);
-  a.p0 = (G.N + KCH - 1) / KCH;
+  static const char *eg = getenv("ROMS_HIP_GEOCH");
+  // levels per thread (every chunk re-reads the two levels below its first one): measured on 2048x256x30
+  // 5: 438, 10: 382, 15: 363, 30: 348 us; on 512x64x30 5: 31, 10: 28, 15: 32, 30: 40 us
+  const long cols = (long)(G.T.Iend - G.T.Istr + 1) * (G.T.Jend - G.T.Jstr + 1);
+  a.p1 = eg ? atoi(eg) : (cols >= 128L * 1024L ? 15 : 10);
+  if (a.p1 < 1) a.p1 = KCH;
+  if (a.p1 > G.N) a.p1 = G.N;
+  a.p0 = (G.N + a.p1 - 1) / a.p1;
   LAUNCH_THREAD(k_t3dmix2_geo, G.T.Iend - G.T.Istr + 1, G.T.Jend - G.T.Jstr + 1, a.p0 * G.NT, c->stream, a);
   return 0;
 }

@@ -178,13 +178,14 @@ KDEV double geo_fs(const GeoGrad &D1, const GeoGrad &D2, double tz, double cff) 
   FS = FS + cff * (c1 * (c1 * tz - D1.tej) + c2 * (c2 * tz - D2.tep) + c3 * (c3 * tz - D2.tej) + c4 * (c4 * tz - D1.tep));
   return FS;
 }
+// (a thread marches a.p1 levels: the two levels below its first one are read again by every chunk)
 THREAD_KERNEL(k_t3dmix2_geo, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
-  const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * KCH + 1;
+  const int nch = a.p0, gch = a.p1, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * gch + 1;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
   if (k0 > N) return;
-  const int k1 = KMIN(k0 + KCH - 1, N);
+  const int k1 = KMIN(k0 + gch - 1, N);
   const size_t nij = (size_t)G.nij;
   const long ni = G.ni, x = (long)X2(i, j);
   const double *pm = F.pm + x, *pn = F.pn + x;
