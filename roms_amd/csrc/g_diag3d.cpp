@@ -138,7 +138,13 @@ int run_wvelocity(roms_hip_ctx *c, int ninp) {
     launch_halo(c, c->F.wvel, N + 1, BC_R, 'r');     // bc_w3d_tile
     return 0;
   }
-  LAUNCH_THREAD_AS(k_wvel, k_wvel_f, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (N + KCH) / KCH, c->stream, a);
+  static const char *ew = getenv("ROMS_HIP_WVELCH");
+  // w-levels per thread (each chunk forms three levels of vert again): measured at 512x512x50 5: 216,
+  // 17: 177, 51: 162 us; 2048x256x30 5: 275, 17: 235, 31: 223; 512x64x30 5: 21.6, 10: 20.5, 17: 25.7
+  const long cols = (long)(B.Iend - B.Istr + 1) * (B.Jend - B.Jstr + 1);
+  a.p1 = ew ? atoi(ew) : (cols >= 128L * 1024L ? N + 1 : 10);
+  if (a.p1 < 1) a.p1 = KCH;
+  LAUNCH_THREAD_AS(k_wvel, k_wvel_f, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (N + a.p1) / a.p1, c->stream, a);
   if (!c->G.fuse3d) launch_halo(c, c->F.wvel, N + 1, BC_R, 'r');     // bc_w3d_tile (fused: emit_store in the kernel)
   return 0;
 }

@@ -371,8 +371,8 @@ THREAD_GLOBAL(k_wvel, KArgs)
 THREAD_KERNEL(k_wvel_f, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
-  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N, Ninp = a.p0;
-  const int k0 = gz * KCH;                         // w-levels k0 .. k0+KCH-1 (0..N)
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N, Ninp = a.p0, wch = a.p1;
+  const int k0 = gz * wch;                         // w-levels k0 .. k0+wch-1 (0..N)
   if (k0 > N) return;
   const double cff1 = 3.0 / 8.0, cff2 = 3.0 / 4.0, cff3 = 1.0 / 8.0, cff4 = 9.0 / 16.0, cff5 = 1.0 / 16.0;
   const double pmw = F.pm[X2(i - 1, j)] + F.pm[X2(i, j)], pme = F.pm[X2(i, j)] + F.pm[X2(i + 1, j)];
@@ -399,9 +399,8 @@ THREAD_KERNEL(k_wvel_f, KArgs) {
                      (F.z_w[XW(i, j, N)] - zw0);
   const double pmn = F.pm[X2(i, j)] * F.pn[X2(i, j)];
   const EmitPlan P = emit_plan(G, BC_R, i, j);
-#pragma unroll
-  for (int m = 0; m < KCH; m++) {
-    const int k = k0 + m;
+  for (int m = 0; m < wch; m++) {                  // (a.p1 w-levels per thread; three levels of vert are
+    const int k = k0 + m;                          //  formed again by the next chunk)
     if (k > N) break;
     WV_VERT(v2, k + 2);
     double w;
