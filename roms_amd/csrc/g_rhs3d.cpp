@@ -1,5 +1,6 @@
 // g_rhs3d.cpp -- launch sequences of pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2.
 #include "roms_host.h"
+#include <cstdlib>
 #include "k_rhs3d.h"
 
 static inline KArgs mk(roms_hip_ctx *c, int p0 = 0, int p1 = 0, int p2 = 0) {
@@ -60,7 +61,15 @@ int run_uv3dmix2(roms_hip_ctx *c) {
   const TB &B = G.T;
   if (!(G.options & ROMS_UV_VIS2)) return 0;
   KArgs a = mk(c);
-  LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
+  { // levels per thread: KCH unrolled on small grids; on large ones a thread marches the column in
+    // ceil(N/30) equal parts (measured, us: 512x512x50 KCH 349, 17: 318, 25: 296, 50: 330;
+    // 2048x256x30 KCH 425, 15: 375, 30: 365; 512x64x30 KCH 29, 10: 30, 25: 45).  ROMS_HIP_UVCH overrides.
+    static const char *eu = getenv("ROMS_HIP_UVCH");
+    const long cols = (long)(B.Iend - B.Istr + 1) * (B.Jend - B.Jstr + 1);
+    const int parts = (G.N + 29) / 30;
+    a.p2 = eu ? atoi(eu) : (cols >= 128L * 1024L ? (G.N + parts - 1) / parts : 0);
+    if (a.p2 > 0) LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
+    else LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a); }
   LAUNCH_THREAD(k_uv3dmix2_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   return 0;
 }
@@ -92,7 +101,15 @@ int run_uv3dmix2_s(roms_hip_ctx *c) {
   const TB &B = G.T;
   if (!(G.options & ROMS_UV_VIS2)) return 0;
   KArgs a = mk(c);
-  LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
+  { // levels per thread: KCH unrolled on small grids; on large ones a thread marches the column in
+    // ceil(N/30) equal parts (measured, us: 512x512x50 KCH 349, 17: 318, 25: 296, 50: 330;
+    // 2048x256x30 KCH 425, 15: 375, 30: 365; 512x64x30 KCH 29, 10: 30, 25: 45).  ROMS_HIP_UVCH overrides.
+    static const char *eu = getenv("ROMS_HIP_UVCH");
+    const long cols = (long)(B.Iend - B.Istr + 1) * (B.Jend - B.Jstr + 1);
+    const int parts = (G.N + 29) / 30;
+    a.p2 = eu ? atoi(eu) : (cols >= 128L * 1024L ? (G.N + parts - 1) / parts : 0);
+    if (a.p2 > 0) LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
+    else LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a); }
   return 0;
 }
 int run_rufrc_sums(roms_hip_ctx *c) {

@@ -629,12 +629,16 @@ THREAD_GLOBAL(k_t3dmix2_s, KArgs)
 // accumulates rufrc inside its k loop, uv3dmix2_s.h:226-262).
 // A thread does KCH consecutive levels (grid.z = chunk): every product of time-invariant metrics in
 // the stress expressions is formed once per chunk, in the reference's association order.
-THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
+// MARCH: a thread marches a.p2 levels in a loop (the level-independent products are formed once for all
+// of them, one level is live at a time) instead of KCH unrolled ones
+template <bool MARCH>
+THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nrhs = G.nrhs, nnew = G.nnew;
-  const int k0 = gz * KCH + 1;
+  const int uch = MARCH ? a.p2 : KCH;
+  const int k0 = gz * uch + 1;
   if (k0 > N) return;
   const double *pm = F.pm, *pn = F.pn;
   const bool do_u = i >= B.IstrU, do_v = j >= B.JstrV;
@@ -665,7 +669,7 @@ THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
   const double vcff = G.dt * 0.25 * (pm[x] + pm[x - ni]) * (pn[x] + pn[x - ni]);
   const double vc1 = 0.5 * (pn[x - ni] + pn[x]), vc2 = 0.5 * (pm[x - ni] + pm[x]);
 #pragma unroll
-  for (int q = 0; q < KCH; q++) {
+  for (int q = 0; q < (MARCH ? uch : KCH); q++) {
     const int k = k0 + q;
     if (k > N) break;
     const size_t ok = (size_t)(k - 1) * nij;
@@ -714,7 +718,10 @@ THREAD_KERNEL(k_uv3dmix2_s, KArgs) {
     }
   }
 }
+THREAD_KERNEL(k_uv3dmix2_s, KArgs) { k_uv3dmix2_t_body<false>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_uv3dmix2_s, KArgs)
+THREAD_KERNEL(k_uv3dmix2_m, KArgs) { k_uv3dmix2_t_body<true>(a, gx, gy, gz); }
+THREAD_GLOBAL(k_uv3dmix2_m, KArgs)
 
 // rufrc/rvfrc: ordered sum over k of the terms stored by k_uv3dmix2_s; one thread per column
 THREAD_KERNEL(k_uv3dmix2_sum, KArgs) {
