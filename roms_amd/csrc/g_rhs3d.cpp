@@ -51,6 +51,14 @@ int run_t3dmix2(roms_hip_ctx *c) {
   if (!(G.options & ROMS_TS_DIF2)) return 0;
   if (G.options & ROMS_MIX_GEO_TS) return run_t3dmix2_geo(c);
   KArgs a = mk(c);
+  static const char *et = getenv("ROMS_HIP_T3CH");
+  // large grids: a thread loops over the column (512x512x50: KCH 228, 10: 216, 25: 211, 50: 210 us)
+  a.p1 = et ? atoi(et) : ((long)(B.Iend - B.Istr + 1) * (B.Jend - B.Jstr + 1) >= 128L * 1024L ? G.N : 0);
+  if (a.p1 > 0) {
+    a.p0 = (G.N + a.p1 - 1) / a.p1;
+    LAUNCH_THREAD_AS(k_t3dmix2_s, k_t3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
+    return 0;
+  }
   a.p0 = (G.N + KCH - 1) / KCH;
   LAUNCH_THREAD(k_t3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
   return 0;

@@ -589,10 +589,13 @@ THREAD_GLOBAL(k_prs_grad, KArgs)
 
 // ------------------------------------------------------------------------------- t3dmix2_s
 // point-wise 3-D; index space (Istr:Iend, Jstr:Jend, N*NT)
-THREAD_KERNEL(k_t3dmix2_s, KArgs) {
+// MARCH: a thread loops over a.p1 levels (large grids) instead of KCH unrolled ones
+template <bool MARCH>
+THREAD_KERNEL(k_t3dmix2_t, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
-  const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * KCH + 1;
+  const int tch = MARCH ? a.p1 : KCH;
+  const int nch = a.p0, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * tch + 1;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
   if (k0 > N) return;
   const int nrhs = G.nrhs, nnew = G.nnew;
@@ -607,7 +610,7 @@ THREAD_KERNEL(k_t3dmix2_s, KArgs) {
   double *tn = F.t + XT(G.LBi, G.LBj, 1, nnew, itrc) + x;
   const double *Hz = F.Hz + x;
 #pragma unroll
-  for (int q = 0; q < KCH; q++) {
+  for (int q = 0; q < (MARCH ? tch : KCH); q++) {
     if (k0 + q > N) break;
     const size_t ok = (size_t)(k0 + q - 1) * nij;
     const double *H = Hz + ok, *T = tr + ok;
@@ -620,7 +623,10 @@ THREAD_KERNEL(k_t3dmix2_s, KArgs) {
     tn[ok] = tn[ok] + cff3;
   }
 }
+THREAD_KERNEL(k_t3dmix2_s, KArgs) { k_t3dmix2_t_body<false>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_t3dmix2_s, KArgs)
+THREAD_KERNEL(k_t3dmix2_m, KArgs) { k_t3dmix2_t_body<true>(a, gx, gy, gz); }
+THREAD_GLOBAL(k_t3dmix2_m, KArgs)
 
 // ------------------------------------------------------------------------------ uv3dmix2_s
 // k_uv3dmix2_s: one thread per (i,j,k) of (Istr:Iend, Jstr:Jend, 1:N); the stress-tensor components

@@ -414,7 +414,7 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
     with tempfile.TemporaryDirectory() as td:
         # third run: the marching forms large grids select (levels per thread of uv3dmix2, wvelocity, t3dmix2_geo)
         for tag, extra in (("lds", {}), ("priv", {"ROMS_HIP_COLLDS": "0", "ROMS_HIP_WVELF": "0"}),
-                           ("march", {"ROMS_HIP_UVCH": "7", "ROMS_HIP_WVELCH": "100", "ROMS_HIP_GEOCH": "7"})):
+                           ("march", {"ROMS_HIP_UVCH": "7", "ROMS_HIP_WVELCH": "100", "ROMS_HIP_GEOCH": "7", "ROMS_HIP_T3CH": "9"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
                                env=dict(os.environ, **extra), timeout=600)
