@@ -85,7 +85,10 @@ int run_step3d_t(roms_hip_ctx *c) {
     bool hsimt_v = false;
     for (int it = 0; it < G.NT; it++) hsimt_v |= G.vadv[it] == ROMS_HSIMT;
     const bool ldsform = col_lds(G) && (el ? el[0] == '1' : (N != 30 || hsimt_v));
-    if (ldsform) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
+    // chunks of 10 levels on tall columns: 542 -> 499 us at N = 50 (ROMS_HIP_S3TCH=0/1 forces a form)
+    static const char *e10 = getenv("ROMS_HIP_S3TCH");
+    if (ldsform && (e10 ? e10[0] == '1' : N > 40)) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l10, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
+    else if (ldsform) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
     else if (regs && N == 30) LAUNCH_THREAD_AS(k_s3t_col, k_s3t_col_n30, nx, ny, G.NT, c->stream, a);
     else LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
 #endif

@@ -940,6 +940,8 @@ COL_KERNEL(k_s3t_col_lt, KArgs) {
 }
 COL_KERNEL(k_s3t_col_l, KArgs) { k_s3t_col_lt_body<6>(a, gx, gy, gz, lds); }
 COL_GLOBAL(k_s3t_col_l, KArgs)
+COL_KERNEL(k_s3t_col_l10, KArgs) { k_s3t_col_lt_body<10>(a, gx, gy, gz, lds); }   // tall columns (N > 40)
+COL_GLOBAL(k_s3t_col_l10, KArgs)
 
 // entry points: N = 30 (the BENCHMARK grids) keeps the elimination coefficients CF/DC of the column in
 // registers -- the diffusion sweeps are fully unrolled, 174 VGPRs, no private-memory traffic:
