@@ -312,6 +312,7 @@ def test_config5_physics_small():
 @pytest.mark.parametrize("tag,kw,tiles,port", [
     ("upwelling_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 1), 29631),
     ("benchmark_small", dict(), (2, 2), 29632),
+    ("benchmark_small", dict(), (4, 2), 29633),      # the 8-rank layout: eight distinct neighbours per tile
 ])
 def test_tiles_on_one_gpu_match_single_tile(tmp_path, tag, kw, tiles, port):
     """The multi-tile device path on real hardware: NtileI x NtileJ processes share cuda:0, the strips
