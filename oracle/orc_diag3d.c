@@ -239,6 +239,12 @@ void orc_set_data(orc_t *o, int tile) {
     for (int j = b->JstrT; j <= b->JendT; j++)
       for (int i = b->IstrT; i <= b->IendT; i++) o->btflux[X2T(i, j, it)] = 0.0;
   }
+  if (o->c.options & ORC_SOLAR_SOURCE) {                 /* ana_srflux.h:270-277 (UPWELLING branch) */
+    const double cff = 1.0 / (o->c.rho0 * o->c.Cp);
+    for (int j = b->JstrT; j <= b->JendT; j++)
+      for (int i = b->IstrT; i <= b->IendT; i++) o->srflx[X2(i, j)] = cff * 150.0;
+    orc_exchange2d(o, b, 'r', o->srflx);
+  }
   double windamp;
   if ((o->s.tdays - o->c.dstart) <= 2.0)
     windamp = -0.1 * sin(pi * (o->s.tdays - o->c.dstart) / 4.0) / o->c.rho0;

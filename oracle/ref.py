@@ -67,9 +67,26 @@ class Ref:
         if n != a.size:
             raise ValueError(f"{name}: size {a.size} != {n}")
 
-    def set_stepping(self, iic, iif, nstp, nnew, nrhs, kstp, knew, krhs, predictor, time):
-        idx = (C.c_int * 16)(iic, iif, nstp, nnew, nrhs, kstp, knew, krhs, int(predictor))
+    def set_stepping(self, iic, iif, nstp, nnew, nrhs, kstp, knew, krhs, predictor, time, indx1=0):
+        idx = (C.c_int * 16)(iic, iif, nstp, nnew, nrhs, kstp, knew, krhs, int(predictor), indx1)
         self.L.ref_set_stepping(idx, C.c_double(time))
+
+    def get_stepping(self):
+        """dict of the reference's mod_stepping indices and time(ng)."""
+        idx = (C.c_int * 16)()
+        tm = C.c_double()
+        self.L.ref_get_stepping(idx, C.byref(tm))
+        names = ["iic", "iif", "nstp", "nnew", "nrhs", "kstp", "knew", "krhs", "predictor", "indx1"]
+        d = {n: int(idx[k]) for k, n in enumerate(names)}
+        d["time"] = tm.value
+        return d
+
+    def main3d(self, nsteps=1):
+        """nsteps passes of main3d's STEP_LOOP made of the reference's own kernels (ref_glue.F90:ref_main3d).
+        Returns [avgke, avgpe, avgkp, volume, max_speed, iic, time, indx1] after the last step."""
+        dg = (C.c_double * 16)()
+        self.L.ref_main3d(C.c_int(nsteps), dg)
+        return list(dg)[:8]
 
     def call(self, name):
         r = self.L.ref_call(name.encode())

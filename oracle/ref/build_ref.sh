@@ -7,14 +7,25 @@
 # (makefile:219,230-238,397-423: cpp -P -traditional, then ROMS/Bin/cpp_clean,
 # then the Fortran compiler) with amdflang in place of gfortran.
 #
-# Only the reference files that compile WITHOUT the NetCDF Fortran module are
-# built (this image has no NetCDF; no stand-in is written for it).  The
-# kernels that USE mod_sources -> mod_netcdf (step2d, omega, pre_step3d,
-# rhs3d, step3d_uv, step3d_t, main3d) are therefore NOT in this library.
+# Only reference code that compiles WITHOUT the NetCDF Fortran module is built
+# (this image has no NetCDF; no stand-in is written for it, nothing is stubbed).
+#
+# mod_sources.F -- USEd by step2d, omega, pre_step3d, step3d_uv, step3d_t -- touches
+# NetCDF in two places: allocate_sources reads the number of point sources from the
+# river file unless the reference's own cpp option ANA_PSOURCE is defined, and
+# check_sources (an input-file inquiry called only by the NetCDF reader get_data)
+# USEs mod_netcdf unconditionally.  The recipe therefore pre-processes THAT ONE FILE
+# with -DANA_PSOURCE and leaves check_sources out of the pre-processed text (sed,
+# below) -- the same "leave out what needs NetCDF" rule the file list applies to
+# whole files, at subroutine granularity.  Every statement that is compiled is the
+# reference's own text; the BASELINE applications have no point sources
+# (LuvSrc = LwSrc = LtracerSrc = .FALSE., mod_scalars.F:4512-4517), so neither
+# routine is ever executed and the six kernels compile to exactly what a NetCDF
+# build of the same application gives.  main3d.F itself (USEs the NetCDF readers
+# and writers) stays out; ref_glue.F90 calls the reference kernels in its order.
 #
 # usage: build_ref.sh upwelling|benchmark|upwelling_kpp
-# (upwelling_kpp = upwelling.h with the KPP options of benchmark.h switched on from the command
-#  line: the "custom application header" of BASELINE config 5)
+# (upwelling_kpp = the custom application header oracle/ref/upwelling_kpp.h of BASELINE config 5)
 set -e
 APP=${1:-upwelling}
 REF=${ROMS_REF:-/root/reference}
@@ -27,9 +38,12 @@ UP=$(echo $APP | tr a-z A-Z)
 HDR=$APP
 EXTRA=""
 [ "$APP" = upwelling ] && EXTRA="-DPERFECT_RESTART"
+HDRPATH="$HDR.h"
 if [ "$APP" = upwelling_kpp ]; then
-  UP=UPWELLING; HDR=upwelling
-  EXTRA="-DPERFECT_RESTART -DLMD_MIXING -DLMD_RIMIX -DLMD_CONVEC -DLMD_SKPP -DLMD_NONLOCAL -DRI_SPLINES -DSOLAR_SOURCE -DANA_SRFLUX"
+  # custom application header (oracle/ref/upwelling_kpp.h) through the makefile's MY_HEADER_DIR
+  # mechanism (makefile:235-236); application flag UPWELLING for the ana_*.h branches
+  UP=UPWELLING; HDR=upwelling_kpp; HDRPATH="$HERE/upwelling_kpp.h"
+  EXTRA=""
 fi
 WORK=$(mktemp -d /tmp/romsref_${APP}_XXXX)
 trap 'rm -rf "$WORK"' EXIT
@@ -38,11 +52,11 @@ cd "$WORK"   # cpp must run from a writable cwd with absolute input paths
 
 pp () {  # pp <abs .F path> -> $WORK/<base>.f90
   local b; b=$(basename "$1"); b=${b%.*}
-  /usr/bin/cpp -P -traditional -w -D$UP -D"ROMS_HEADER=\"$HDR.h\"" -D"HEADER=\"$HDR.h\"" \
+  /usr/bin/cpp -P -traditional -w -D$UP -D"ROMS_HEADER=\"$HDRPATH\"" -D"HEADER=\"$HDR.h\"" \
     -DLINUX -DX86_64 -DGFORTRAN -DNestedGrids=1 \
     -D"ROOT_DIR=\"$REF\"" -D"ANALYTICAL_DIR=\"$REF/ROMS/Functionals\"" -D"HEADER_DIR=\"$REF/ROMS/Include\"" \
     -D'GIT_URL="x"' -D'GIT_REV="x"' -D'MY_OS="Linux"' -D'MY_CPU="x86_64"' -D'MY_FORT="gfortran"' \
-    -D'MY_FC="flang"' -D'MY_FFLAGS="-O2"' $EXTRA \
+    -D'MY_FC="flang"' -D'MY_FFLAGS="-O2"' $EXTRA $XDEF \
     -I$REF/ROMS/Include -I$REF/ROMS/Nonlinear -I$REF/ROMS/Functionals -I$REF/ROMS/Utility \
     -I$REF/ROMS/Drivers -I$REF/Master "$1" > $b.$2
   perl $REF/ROMS/Bin/cpp_clean $b.$2
@@ -58,6 +72,7 @@ FILES="mod_kinds mod_param mod_scalars mod_stepping mod_strings mod_iounits mod_
   metrics ini_hmixcoef stiffness mp_routines ntimestep
   bc_2d bc_3d zetabc u2dbc_im v2dbc_im t3dbc_im u3dbc_im v3dbc_im obc_volcons
   set_depth set_massflux rho_eos prsgrd t3dmix uv3dmix set_vbc set_zeta wvelocity diag ini_fields
+  mod_sources uv_var_change step2d omega pre_step3d rhs3d step3d_uv step3d_t
   mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix bulk_flux analytical"
 TODO=""
 for m in $FILES; do
@@ -66,7 +81,10 @@ for m in $FILES; do
     [ -f $REF/ROMS/$d/$m.F ] && src=$REF/ROMS/$d/$m.F
   done
   [ -z "$src" ] && continue
+  XDEF=""; [ $m = mod_sources ] && XDEF="-DANA_PSOURCE"
   pp $src f90
+  [ $m = mod_sources ] && sed -i '/SUBROUTINE check_sources/,/END SUBROUTINE check_sources/d' $m.f90
+  XDEF=""
   [ $(wc -c < $m.f90) -lt 20 ] && continue      # inactive for this application
   TODO="$TODO $m"
 done

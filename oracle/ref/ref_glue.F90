@@ -12,9 +12,11 @@
 !  nothing here stands in for NetCDF -- the glue only fills the reference's
 !  module variables by hand and calls reference procedures.
 !
-!  Reference kernels that cannot be built here (they USE mod_sources, which
-!  USEs mod_netcdf): step2d, omega, pre_step3d, rhs3d, step3d_uv, step3d_t,
-!  main3d.  Those are restated in the C oracle only ("parity unpinned" rows).
+!  step2d, omega, pre_step3d, rhs3d, step3d_uv, step3d_t ARE built (see
+!  build_ref.sh for how mod_sources.F is compiled without NetCDF).  main3d.F,
+!  set_data.F, initial.F, post_initial.F cannot be (NetCDF readers/writers);
+!  ref_main3d / ref_set_data below call the reference kernels in the order
+!  those files do, citing their lines.
 !
 #include "cppdefs.h"
 #if defined UPWELLING
@@ -243,7 +245,7 @@
 !  The part of "initial" (Nonlinear/initial.F:277-577) that builds here:
 !  set_grid (ana_grid, set_scoord, set_weights, metrics), ini_hmixcoef,
 !  set_depth, ana_initial, set_depth0, set_zeta_timeavg, set_depth,
-!  set_massflux, rho_eos.  (omega is not buildable: see header.)
+!  set_massflux, omega, rho_eos.
 !=======================================================================
 !
       SUBROUTINE ref_initial () bind(C, name="ref_initial")
@@ -254,6 +256,7 @@
       USE set_depth_mod,     ONLY : set_depth0, set_depth
       USE set_massflux_mod,  ONLY : set_massflux
       USE rho_eos_mod,       ONLY : rho_eos
+      USE omega_mod,         ONLY : omega
       integer :: tile
       DO tile=first_tile(ng),last_tile(ng)
         CALL ana_grid (ng, tile, iNLM)
@@ -281,10 +284,203 @@
         CALL set_massflux (ng, tile, iNLM)
       END DO
       DO tile=first_tile(ng),last_tile(ng)
+        CALL omega (ng, tile, iNLM)
         CALL rho_eos (ng, tile, iNLM)
       END DO
       iic(ng)=ntstart(ng)
       END SUBROUTINE ref_initial
+!
+!=======================================================================
+!  The analytical branches of set_data_tile (Nonlinear/set_data.F:187-640)
+!  in that file's order; set_data.F itself USEs the NetCDF field readers.
+!=======================================================================
+!
+      SUBROUTINE ref_set_data (tile)
+      USE analytical_mod
+      integer, intent(in) :: tile
+#ifdef ANA_CLOUD
+      CALL ana_cloud (ng, tile, iNLM)                    ! :197
+#endif
+#ifdef ANA_TAIR
+      CALL ana_tair (ng, tile, iNLM)                     ! :217
+#endif
+#ifdef ANA_HUMIDITY
+      CALL ana_humid (ng, tile, iNLM)                    ! :237
+#endif
+#if defined SHORTWAVE && defined ANA_SRFLUX
+      CALL ana_srflux (ng, tile, iNLM)                   ! :255
+#endif
+#if defined BULK_FLUXES && defined ANA_WINDS
+      CALL ana_winds (ng, tile, iNLM)                    ! :329
+#endif
+#if defined BULK_FLUXES && defined ANA_RAIN
+      CALL ana_rain (ng, tile, iNLM)                     ! :394
+#endif
+#if !defined BULK_FLUXES && defined ANA_STFLUX
+      CALL ana_stflux (ng, tile, iNLM, itemp)            ! :412
+#endif
+#ifdef ANA_BTFLUX
+      CALL ana_btflux (ng, tile, iNLM, itemp)            ! :455
+#endif
+#if defined SALINITY && defined ANA_SSFLUX
+      CALL ana_stflux (ng, tile, iNLM, isalt)            ! :470
+#endif
+#if defined SALINITY && defined ANA_BSFLUX
+      CALL ana_btflux (ng, tile, iNLM, isalt)            ! :519
+#endif
+#if !defined BULK_FLUXES && defined ANA_SMFLUX
+      CALL ana_smflux (ng, tile, iNLM)                   ! :564
+#endif
+#if defined BULK_FLUXES && defined ANA_PAIR
+      CALL ana_pair (ng, tile, iNLM)                     ! :628
+#endif
+      END SUBROUTINE ref_set_data
+!
+!=======================================================================
+!  nsteps passes of main3d's STEP_LOOP (Nonlinear/main3d.F:216-1148) made
+!  of the reference's own kernels: same calls, same tile order.  Returns
+!  the diag numbers of the last step in dg(1:8).
+!=======================================================================
+!
+      SUBROUTINE ref_main3d (nsteps, dg) bind(C, name="ref_main3d")
+      USE set_depth_mod,     ONLY : set_depth
+      USE set_massflux_mod,  ONLY : set_massflux
+      USE rho_eos_mod,       ONLY : rho_eos
+      USE set_vbc_mod,       ONLY : set_vbc
+      USE set_zeta_mod,      ONLY : set_zeta
+      USE wvelocity_mod,     ONLY : wvelocity
+      USE diag_mod,          ONLY : diag
+      USE ini_fields_mod,    ONLY : ini_fields, ini_zeta
+      USE omega_mod,         ONLY : omega
+      USE rhs3d_mod,         ONLY : rhs3d
+      USE step2d_mod,        ONLY : step2d
+      USE step3d_uv_mod,     ONLY : step3d_uv
+      USE step3d_t_mod,      ONLY : step3d_t
+      USE analytical_mod
+#ifdef LMD_MIXING
+      USE lmd_vmix_mod,      ONLY : lmd_vmix
+#endif
+#ifdef BULK_FLUXES
+      USE bulk_flux_mod,     ONLY : bulk_flux
+#endif
+      integer(c_int), value :: nsteps
+      real(c_double), intent(out) :: dg(*)
+      integer :: istep, tile, my_iif, next_indx1
+      DO istep=1,nsteps
+        nstp(ng)=1+MOD(iic(ng)-ntstart(ng),2)              ! :222-229
+        nnew(ng)=3-nstp(ng)
+        nrhs(ng)=nstp(ng)
+        tdays(ng)=time(ng)*sec2day
+        DO tile=first_tile(ng),last_tile(ng),+1            ! :257-259
+          CALL ref_set_data (tile)
+        END DO
+        IF (iic(ng).eq.ntstart(ng)) THEN                   ! :334 post_initial
+          DO tile=first_tile(ng),last_tile(ng),+1          ! post_initial.F:55-58
+            CALL ini_zeta (ng, tile, iNLM)
+            CALL set_depth (ng, tile, iNLM)
+          END DO
+          DO tile=last_tile(ng),first_tile(ng),-1          ! post_initial.F:65-67
+            CALL ini_fields (ng, tile, iNLM)
+          END DO
+        END IF
+        DO tile=first_tile(ng),last_tile(ng),+1            ! :347-359
+          CALL set_massflux (ng, tile, iNLM)
+          CALL rho_eos (ng, tile, iNLM)
+          CALL diag (ng, tile)
+        END DO
+        DO tile=first_tile(ng),last_tile(ng),+1            ! :431-449
+#ifdef BULK_FLUXES
+          CALL bulk_flux (ng, tile)
+#endif
+          CALL set_vbc (ng, tile)
+        END DO
+        DO tile=last_tile(ng),first_tile(ng),-1            ! :523-539
+#if defined ANA_VMIX
+          CALL ana_vmix (ng, tile, iNLM)
+#elif defined LMD_MIXING
+          CALL lmd_vmix (ng, tile)
+#endif
+          CALL omega (ng, tile, iNLM)
+          CALL wvelocity (ng, tile, nstp(ng))
+        END DO
+        DO tile=first_tile(ng),last_tile(ng),+1            ! :554-564
+          CALL set_zeta (ng, tile)
+        END DO
+        DO tile=last_tile(ng),first_tile(ng),-1            ! :630-634
+          CALL rhs3d (ng, tile)
+        END DO
+        LOOP_2D : DO my_iif=1,nfast(ng)+1                  ! :810-918
+          next_indx1=3-indx1(ng)
+          IF (.not.PREDICTOR_2D_STEP(ng).and.                           &
+     &        my_iif.le.(nfast(ng)+1)) THEN
+            PREDICTOR_2D_STEP(ng)=.TRUE.
+            iif(ng)=my_iif
+            IF (iif(ng).eq.1) THEN
+              kstp(ng)=indx1(ng)
+            ELSE
+              kstp(ng)=3-indx1(ng)
+            END IF
+            knew(ng)=3
+            krhs(ng)=indx1(ng)
+          END IF
+          DO tile=last_tile(ng),first_tile(ng),-1          ! :856-858
+            CALL step2d (ng, tile)
+          END DO
+          IF (PREDICTOR_2D_STEP(ng)) THEN                  ! :876-884
+            PREDICTOR_2D_STEP(ng)=.FALSE.
+            knew(ng)=next_indx1
+            kstp(ng)=3-knew(ng)
+            krhs(ng)=3
+            IF (iif(ng).lt.(nfast(ng)+1)) indx1(ng)=next_indx1
+          END IF
+          IF (iif(ng).lt.(nfast(ng)+1)) THEN               ! :894-900
+            DO tile=first_tile(ng),last_tile(ng),+1
+              CALL step2d (ng, tile)
+            END DO
+          END IF
+        END DO LOOP_2D
+        DO tile=last_tile(ng),first_tile(ng),-1            ! :961-965
+          CALL set_depth (ng, tile, iNLM)
+        END DO
+        DO tile=last_tile(ng),first_tile(ng),-1            ! :988-992
+          CALL step3d_uv (ng, tile)
+        END DO
+        DO tile=first_tile(ng),last_tile(ng),+1            ! :1015-1019
+          CALL omega (ng, tile, iNLM)
+        END DO
+        DO tile=last_tile(ng),first_tile(ng),-1            ! :1043-1047
+          CALL step3d_t (ng, tile)
+        END DO
+        iic(ng)=iic(ng)+1                                  ! :1145-1148 (ntimesteps)
+        time(ng)=time(ng)+dt(ng)
+      END DO
+      dg(1)=avgke
+      dg(2)=avgpe
+      dg(3)=avgkp
+      dg(4)=volume
+      dg(5)=max_speed
+      dg(6)=REAL(iic(ng),r8)
+      dg(7)=time(ng)
+      dg(8)=REAL(indx1(ng),r8)
+      END SUBROUTINE ref_main3d
+!
+!  idx out: 1 iic 2 iif 3 nstp 4 nnew 5 nrhs 6 kstp 7 knew 8 krhs
+!           9 PREDICTOR_2D_STEP 10 indx1
+      SUBROUTINE ref_get_stepping (idx, tm) bind(C, name="ref_get_stepping")
+      integer(c_int), intent(out) :: idx(*)
+      real(c_double), intent(out) :: tm
+      idx(1)=iic(ng)
+      idx(2)=iif(ng)
+      idx(3)=nstp(ng)
+      idx(4)=nnew(ng)
+      idx(5)=nrhs(ng)
+      idx(6)=kstp(ng)
+      idx(7)=knew(ng)
+      idx(8)=krhs(ng)
+      idx(9)=MERGE(1,0,PREDICTOR_2D_STEP(ng))
+      idx(10)=indx1(ng)
+      tm=time(ng)
+      END SUBROUTINE ref_get_stepping
 !
 !=======================================================================
 !  Set the time-stepping indices the kernel wrappers read from
@@ -298,6 +494,7 @@
       real(c_double), value :: tm
       iic(ng)=idx(1)
       iif(ng)=idx(2)
+      IF (idx(10).gt.0) indx1(ng)=idx(10)
       nstp(ng)=idx(3)
       nnew(ng)=idx(4)
       nrhs(ng)=idx(5)
@@ -327,6 +524,12 @@
       USE wvelocity_mod,     ONLY : wvelocity
       USE diag_mod,          ONLY : diag
       USE ini_fields_mod,    ONLY : ini_fields, ini_zeta
+      USE omega_mod,         ONLY : omega
+      USE pre_step3d_mod,    ONLY : pre_step3d
+      USE rhs3d_mod,         ONLY : rhs3d
+      USE step2d_mod,        ONLY : step2d
+      USE step3d_uv_mod,     ONLY : step3d_uv
+      USE step3d_t_mod,      ONLY : step3d_t
 #ifdef LMD_MIXING
       USE lmd_vmix_mod,      ONLY : lmd_vmix
 #endif
@@ -365,6 +568,20 @@
             CALL wvelocity (ng, tile, nstp(ng))
           CASE ('diag')
             CALL diag (ng, tile)
+          CASE ('omega')
+            CALL omega (ng, tile, iNLM)
+          CASE ('pre_step3d')
+            CALL pre_step3d (ng, tile)
+          CASE ('rhs3d')
+            CALL rhs3d (ng, tile)
+          CASE ('step2d')
+            CALL step2d (ng, tile)
+          CASE ('step3d_uv')
+            CALL step3d_uv (ng, tile)
+          CASE ('step3d_t')
+            CALL step3d_t (ng, tile)
+          CASE ('set_data')
+            CALL ref_set_data (tile)
           CASE ('ini_zeta')
             CALL ini_zeta (ng, tile, iNLM)
           CASE ('ini_fields')
@@ -669,9 +886,9 @@
           a(9)=avgkp
           a(10)=volume
           a(11)=max_speed
-          a(12)=0.0_r8
-          a(13)=0.0_r8
-          a(14)=0.0_r8
+          a(12)=max_Cu
+          a(13)=max_Cv
+          a(14)=max_Cw
       END SELECT
       END SUBROUTINE ref_get_table
 !

@@ -104,8 +104,9 @@ int run_set_data(roms_hip_ctx *c) {
       {c->F.stflux, 2, BC_NONE, 'r'},
       {c->F.sustr, 1, BC_NONE, 'u'},
       {c->F.svstr, 1, BC_NONE, 'v'},
+      {c->F.srflx, 1, BC_NONE, 'r'},
   };
-  launch_halo_multi(c, hs6, 3);
+  launch_halo_multi(c, hs6, (c->G.options & ROMS_SOLAR_SOURCE) ? 4 : 3);
   return 0;
 }
 

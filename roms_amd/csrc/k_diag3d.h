@@ -211,6 +211,7 @@ THREAD_KERNEL(k_set_data_upw, KArgs) {
     F.stflux[X2T(i, j, 2)] = 0.0;
     F.btflux[X2T(i, j, 1)] = 0.0;
     F.btflux[X2T(i, j, 2)] = 0.0;
+    if (G.options & ROMS_SOLAR_SOURCE) F.srflx[X2(i, j)] = (1.0 / (G.rho0 * G.Cp)) * 150.0;   // ana_srflux.h:270-277
   }
   double windamp;
   if ((G.tdays - G.dstart) <= 2.0) windamp = -0.1 * sin(pi * (G.tdays - G.dstart) / 4.0) / G.rho0;
