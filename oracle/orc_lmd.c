@@ -45,7 +45,7 @@ static void wscale(double Ustar, double zetahat, double Ustar3, double *wm, doub
   } else {
     if (zetapar > lmd_zetam) *wm = vonKar * Ustar * pow(1.0 - 16.0 * zetapar, 0.25);
     else *wm = vonKar * pow(lmd_am * Ustar3 - lmd_cm * zetahat, r3);
-    if (zetapar > lmd_zetas) *ws = vonKar * Ustar * pow(1.0 - 16.0 * zetapar, 0.5);
+    if (zetapar > lmd_zetas) *ws = vonKar * Ustar * sqrt(1.0 - 16.0 * zetapar);   /* **0.5_r8: the correctly rounded sqrt, as the reference build compiles it; pow(x,0.5) is 1 ulp off in rare cases */
     else *ws = vonKar * pow(lmd_as * Ustar3 - lmd_cs * zetahat, r3);
   }
 }

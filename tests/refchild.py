@@ -1,0 +1,198 @@
+"""Child-process bodies of tests/test_oracle_vs_ref.py: the C oracle against the reference's own object
+code (oracle/_ref).  One reference configuration per process.  TEST INFRASTRUCTURE.
+
+usage: python -m tests.refchild <mode> <case tag> [key=value ...]
+  main3d    nsteps=N [hadv=a,b vadv=a,b NtileI=n NtileJ=n tol=x]   whole steps, every state array, every step
+  kernels   [hadv= vadv=]      the six core routines one by one on a randomly perturbed mid-run state
+  physics                      BENCHMARK physics routines one by one on a perturbed state
+"""
+import sys
+
+import numpy as np
+
+from tests import refdrive as rd
+from tests import util
+
+
+def parse(argv):
+    kw = {}
+    for a in argv:
+        k, v = a.split("=")
+        if k in ("hadv", "vadv"):
+            kw[k] = tuple(v.split(","))
+        elif k == "tol":
+            kw[k] = float(v)
+        else:
+            kw[k] = int(v)
+    return kw
+
+
+def _diag_of(O):
+    """the numbers orc_diag left in the oracle during the step just made (main3d.F:355)"""
+    import ctypes as C
+    out = (C.c_double * 16)()
+    O.L.orc_get_diag(C.c_void_p(O.h), out)
+    return out
+
+
+def mode_main3d(tag, kw):
+    """ref_main3d (reference kernels in main3d.F order) against orc_main3d_step."""
+    nsteps = kw.pop("nsteps", 10)
+    tol = kw.pop("tol", 0.0)
+    app, cs = rd.make_case(tag, **kw)
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    O = rd.oracle_from(R, cs)
+    O.start()
+    names = rd.shared_fields(R, O)
+    log = []
+    dlines = []
+    worst = 0.0
+    for s in range(1, nsteps + 1):
+        dg = R.main3d(1)
+        O.main3d_step(1)
+        bad = rd.mismatches(R, O, names)
+        if bad:
+            worst = max(worst, max(b[2] for b in bad))
+            log.append((s, bad[:6]))
+        dlines.append(rd.oracle_diag_line(list(_diag_of(O))))
+    rs = R.get_stepping()
+    ok_step = (rs["iic"] == O.step.iic and rs["indx1"] == O.step.indx1 and rs["time"] == O.step.time)
+    rd.unquiet(saved)
+    printed = rd.diag_lines()
+    ndiag = sum(1 for a, b in zip(printed, dlines) if a == b)
+    moved = float(np.abs(O.field("u")).max())
+    print("fields", len(names), "steps", nsteps, "max|u|", moved, "worst relrms", worst, "stepping", ok_step,
+          "diag lines equal", ndiag, "of", len(printed))
+    if tol == 0.0 and (ndiag != nsteps or len(printed) != nsteps):
+        print("MISMATCH diag lines", [(a, b) for a, b in zip(printed, dlines) if a != b][:3])
+        ok_step = False
+    for entry in log[:5]:
+        print("MISMATCH step", entry)
+    if ok_step and moved > 0 and worst <= tol:
+        print("MAIN3D-OK bitwise" if not log else "MAIN3D-OK within %g" % tol)
+
+
+def perturb(R, O, rng, amps):
+    for n, amp in amps:
+        a = O.field(n)
+        a[:] += amp * rng.standard_normal(a.size)
+        R.put(n, a)
+
+
+def mode_kernels(tag, kw):
+    """step2d (first predictor, a corrector, the last predictor), omega, pre_step3d, rhs3d, step3d_uv,
+    step3d_t on a perturbed state: non-smooth inputs reach the limiter / upstream-switch branches a smooth
+    run never takes."""
+    app, cs = rd.make_case(tag, **kw)
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    O = rd.oracle_from(R, cs)
+    O.start()
+    R.main3d(3)
+    O.main3d_step(3)
+    names = rd.shared_fields(R, O)
+    rng = np.random.default_rng(11)
+    res = []
+    nfast = R.bounds(0)[58]
+
+    def both(kernel, **st):
+        for k, v in st.items():
+            setattr(O.step, k, v)
+        rd.sync_stepping(R, O)
+        R.call(kernel)
+        O.call(kernel)
+        res.append((kernel, dict(st), rd.mismatches(R, O, names)))
+
+    amps = [("u", 0.02), ("v", 0.02), ("zeta", 0.05), ("ubar", 0.01), ("vbar", 0.01), ("Huon", 20.0),
+            ("Hvom", 20.0), ("W", 1.0), ("ru", 1.0), ("rv", 1.0), ("rufrc", 10.0), ("rvfrc", 10.0),
+            ("rzeta", 1e-3), ("rubar", 1.0), ("rvbar", 1.0), ("DU_avg1", 5.0), ("DV_avg1", 5.0),
+            ("DU_avg2", 5.0), ("DV_avg2", 5.0), ("Zt_avg1", 0.01), ("Akv", 1e-4), ("Akt", 1e-5)]
+    perturb(R, O, rng, amps)
+    t = O.field("t")
+    t[:] += 0.05 * rng.standard_normal(t.size) * (t != 0)
+    R.put("t", t)
+    base = dict(iic=4, nstp=2, nnew=1, nrhs=2)
+    both("omega", **base)
+    both("pre_step3d", **base)
+    perturb(R, O, rng, [("W", 0.5)])
+    both("rhs3d", **base)
+    both("step2d", iif=1, predictor=1, indx1=1, kstp=1, knew=3, krhs=1, **base)
+    both("step2d", iif=1, predictor=0, indx1=2, kstp=1, knew=2, krhs=3, **base)
+    both("step2d", iif=2, predictor=1, indx1=2, kstp=1, knew=3, krhs=2, **base)
+    both("step2d", iif=2, predictor=0, indx1=1, kstp=2, knew=1, krhs=3, **base)
+    both("step2d", iif=nfast + 1, predictor=1, indx1=1, kstp=2, knew=3, krhs=1, **base)
+    both("set_depth", **base)
+    both("step3d_uv", iif=nfast + 1, **base)
+    both("omega", **base)
+    both("step3d_t", **base)
+    rd.unquiet(saved)
+    nbad = 0
+    for kernel, st, bad in res:
+        if bad:
+            nbad += 1
+            print("MISMATCH", kernel, st, bad[:6])
+    print("calls", len(res), "fields", len(names))
+    if nbad == 0:
+        print("KERNELS-OK bitwise")
+
+
+def mode_physics(tag, kw):
+    """The physics of the headline bench configuration, routine by routine (Next round #2)."""
+    app, cs = rd.make_case(tag, **kw)
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    O = rd.oracle_from(R, cs)
+    O.start()
+    names = rd.shared_fields(R, O)
+    rng = np.random.default_rng(5)
+    st = dict(iic=4, iif=1, nstp=2, nnew=1, nrhs=2, kstp=1, knew=1, krhs=1, predictor=0, indx1=1,
+              time=4 * cs["dt"] + 0.3 * 86400.0)     # daytime at the BENCHMARK longitudes: srflx > 0
+    for k, v in st.items():
+        setattr(O.step, k, v)
+    O.step.tdays = st["time"] / 86400.0
+    rd.sync_stepping(R, O)
+    perturb(R, O, rng, [("u", 0.05), ("v", 0.05), ("zeta", 0.1), ("ubar", 0.02), ("vbar", 0.02)])
+    t = O.field("t")
+    t[:] += 0.05 * rng.standard_normal(t.size) * (t != 0)
+    R.put("t", t)
+    O.field("Zt_avg1")[:] = O.field("zeta")[:O.ni * O.nj]
+    R.put("Zt_avg1", O.field("Zt_avg1"))
+    perturb(R, O, rng, [("DU_avg1", 5.0), ("DV_avg1", 5.0)])
+    seq = ["set_depth", "set_massflux", "rho_eos", "set_data", "bulk_flux", "set_vbc", "lmd_vmix", "omega",
+           "wvelocity", "set_zeta", "prsgrd", "t3dmix2", "uv3dmix2", "diag"]
+    res = []
+    for k in seq:
+        if k == "bulk_flux" and "BULK_FLUXES" not in cs["options"]:
+            continue
+        if k == "lmd_vmix" and "LMD_MIXING" not in cs["options"]:
+            k = "ana_vmix"
+        R.call(k)
+        if k == "wvelocity":
+            O.call(k, None, st["nstp"])
+        elif k == "diag":
+            od = O.diag()
+        else:
+            O.call(k)
+        res.append((k, rd.mismatches(R, O, names)))
+    # diag.F keeps only avgkp in mod_scalars (the other sums are reset after printing, diag.F:536-552);
+    # the rest is compared through the line it prints (7 significant digits)
+    rt = R.table(7, 14)
+    rd.unquiet(saved)
+    printed = rd.diag_lines()
+    dg_ok = rt[8] == od[2] and len(printed) >= 1 and printed[-1] == rd.oracle_diag_line(od)
+    nbad = 0
+    for k, bad in res:
+        if bad:
+            nbad += 1
+            print("MISMATCH", k, bad[:8])
+    print("diag", "equal" if dg_ok else ("DIFFERENT", rt[8], printed[-1:], rd.oracle_diag_line(od)))
+    print("srflx max", float(O.field("srflx").max()) if "SOLAR_SOURCE" in cs["options"] else None,
+          "Akv max", float(O.field("Akv").max()))
+    if nbad == 0 and dg_ok:
+        print("PHYSICS-OK bitwise")
+
+
+if __name__ == "__main__":
+    mode, tag = sys.argv[1], sys.argv[2]
+    {"main3d": mode_main3d, "kernels": mode_kernels, "physics": mode_physics}[mode](tag, parse(sys.argv[3:]))

@@ -1,0 +1,177 @@
+"""Drive the reference's own object code (oracle/_ref, see oracle/ref/build_ref.sh) next to the C oracle.
+TEST INFRASTRUCTURE; runs only where /root/reference and oracle/_ref exist (the build container).
+
+One reference configuration can live in a process (Fortran module state), so every function here is
+meant to be called from a fresh `python -c` / `python -m` child (tests/test_oracle_vs_ref.py,
+tests/golden/make_golden.py)."""
+import os
+import sys
+
+import numpy as np
+
+from tests import cases, util
+
+# every state array both sides expose (absent ones -- cpp options -- are skipped at run time)
+FIELDS = util.STATE_FIELDS
+CASES = {
+    # tag: (reference library, case constructor kwargs)
+    "upwelling_small": ("upwelling", dict(Lm=14, Mm=18, N=8)),
+    "upwelling": ("upwelling", dict()),
+    "benchmark_small": ("benchmark", dict(Lm=24, Mm=16, N=10)),
+    "benchmark1": ("benchmark", dict()),
+    "upwelling_kpp_small": ("upwelling_kpp", dict(Lm=14, Mm=18, N=8)),
+}
+
+
+_LOG = None
+
+
+def quiet():
+    """send the reference's Fortran stdout (set-up report, diag lines) to a scratch file (fd 1)"""
+    global _LOG
+    import tempfile
+    sys.stdout.flush()
+    f = tempfile.NamedTemporaryFile(prefix="romsref_stdout_", suffix=".log", delete=False)
+    _LOG = f.name
+    saved = os.dup(1)
+    os.dup2(f.fileno(), 1)
+    f.close()
+    return saved
+
+
+def unquiet(saved):
+    os.dup2(saved, 1)
+
+
+def diag_lines():
+    """The `diag` report the reference printed since quiet() (diag.F:473-500, FORMAT 30/40): a list of
+    ((avgke, avgpe, avgkp, volume) as printed strings, (Ci, Cj, Ck), (Cu, Cv, Cw, maxspeed) strings)."""
+    import re
+    out = []
+    if _LOG is None:
+        return out
+    flt = r"[-+]?\d\.\d{6}E[-+]\d{2,3}"
+    with open(_LOG, "rb") as f:
+        lines = [b.decode("latin-1") for b in f.read().split(b"\n")]   # DateTime is unset: arbitrary bytes
+    os.unlink(_LOG)
+    k = 0
+    while k < len(lines) - 1:
+        a = re.findall(flt, lines[k])
+        m = re.search(r"\((\d+),(\d+),(\d+)\)", lines[k + 1])
+        if len(a) >= 4 and m and re.match(r"^\s*\d+\s", lines[k]):
+            b = re.findall(flt, lines[k + 1])
+            out.append((tuple(a[-4:]), tuple(int(x) for x in m.groups()), tuple(b[-4:])))
+            k += 2
+        else:
+            k += 1
+    return out
+
+
+def fmt_e(x):
+    """Fortran 1pe14.6 / 1pe13.6 digits of x"""
+    return "%.6E" % x
+
+
+def oracle_diag_line(od):
+    """orc_diag numbers in the shape of diag_lines() entries"""
+    return (tuple(fmt_e(v) for v in od[:4]), (int(od[8]), int(od[9]), int(od[10])),
+            tuple(fmt_e(v) for v in (od[5], od[6], od[7], od[4])))
+
+
+def make_case(tag, **kw):
+    app, base = CASES[tag]
+    k = dict(base)
+    k.update(kw)
+    ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp)[app]
+    return app, ctor(**k)
+
+
+def reference(app, cs):
+    """Reference state after its `initial` sequence."""
+    from oracle import ref
+    ip, rp = cases.ref_params(cs)
+    R = ref.Ref(app, ip, rp)
+    R.initial()
+    return R
+
+
+def oracle_from(R, cs):
+    """Oracle state holding a copy of the reference's set-up tables and initial arrays."""
+    from oracle import orc
+    b = R.bounds(0)
+    nd = cs["ndtfast"]
+    w = np.stack([R.table(5, 2 * nd), R.table(6, 2 * nd)])
+    O = orc.Oracle(cases.oracle_cfg(cs, R.table(7, 8)[0], b[58], w))
+    for n in util.INIT_FIELDS:
+        if R.has(n):
+            O.field(n)[:] = R.get(n)
+    for k, n in enumerate(["sc_r", "Cs_r", "sc_w", "Cs_w"]):
+        O.field(n)[:] = R.table(k + 1, O.field(n).size)
+    return O
+
+
+def shared_fields(R, O):
+    out = []
+    for n in FIELDS:
+        if not R.has(n):
+            continue
+        try:
+            O.field(n)
+        except KeyError:
+            continue
+        out.append(n)
+    return out
+
+
+def mismatches(R, O, names):
+    """[(field, number of differing doubles, relative RMS)] over `names`."""
+    bad = []
+    for n in names:
+        a, c = R.get(n), O.field(n)
+        if not np.array_equal(a, c):
+            bad.append((n, int(np.count_nonzero(a != c)), float(util.relrms(c, a))))
+    return bad
+
+
+def sync_stepping(R, O):
+    """copy the oracle's stepping indices into the reference's mod_stepping"""
+    s = O.step
+    R.set_stepping(s.iic, s.iif, s.nstp, s.nnew, s.nrhs, s.kstp, s.knew, s.krhs, s.predictor, s.time, s.indx1)
+
+
+def stepping_dict(O):
+    s = O.step
+    return dict(iic=s.iic, iif=s.iif, nstp=s.nstp, nnew=s.nnew, nrhs=s.nrhs, kstp=s.kstp, knew=s.knew,
+                krhs=s.krhs, indx1=s.indx1, predictor=s.predictor, time=s.time)
+
+
+def main3d_sequence(cs, st, first):
+    """The kernel calls of one main3d pass (main3d.F:216-1148) as (kernel name, stepping updates) pairs,
+    for drivers that call the C ABI / the reference wrappers one by one.  `st` = dict with iic, indx1,
+    time; mutated as main3d mutates mod_stepping."""
+    seq = []
+    nstp = 1 + (st["iic"] - 1) % 2
+    st.update(nstp=nstp, nnew=3 - nstp, nrhs=nstp)
+    seq.append(("set_data", dict(st)))
+    if first:
+        seq += [("ini_zeta", dict(st)), ("set_depth", dict(st)), ("ini_fields", dict(st))]
+    seq += [("set_massflux", dict(st)), ("rho_eos", dict(st)), ("diag", dict(st))]
+    if "BULK_FLUXES" in cs["options"]:
+        seq.append(("bulk_flux", dict(st)))
+    seq.append(("set_vbc", dict(st)))
+    seq.append(("ana_vmix" if "ANA_VMIX" in cs["options"] else "lmd_vmix", dict(st)))
+    seq += [("omega", dict(st)), ("wvelocity", dict(st)), ("set_zeta", dict(st)), ("rhs3d", dict(st))]
+    nfast = st["nfast"]
+    for my_iif in range(1, nfast + 2):
+        nxt = 3 - st["indx1"]
+        st.update(predictor=1, iif=my_iif, kstp=st["indx1"] if my_iif == 1 else 3 - st["indx1"], knew=3,
+                  krhs=st["indx1"])
+        seq.append(("step2d", dict(st)))
+        st.update(predictor=0, knew=nxt, kstp=3 - nxt, krhs=3)
+        if my_iif < nfast + 1:
+            st["indx1"] = nxt
+            seq.append(("step2d", dict(st)))
+    seq += [("set_depth", dict(st)), ("step3d_uv", dict(st)), ("omega", dict(st)), ("step3d_t", dict(st))]
+    st["iic"] += 1
+    st["time"] += cs["dt"]
+    return seq

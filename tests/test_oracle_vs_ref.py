@@ -165,3 +165,74 @@ def test_upwelling_kpp_linear_eos_and_lmd_bitwise():
     p = subprocess.run([sys.executable, "-c", KPP_SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
                        timeout=600)
     assert "KPP-LINEAR-EOS-PINNED-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+# ----------------------------------------------------------------------------------------------------
+# The six core routines (step2d, omega, pre_step3d, rhs3d, step3d_uv, step3d_t) and whole main3d passes.
+# Bodies: tests/refchild.py (one reference configuration per process).
+# ----------------------------------------------------------------------------------------------------
+def _child(mode, tag, *args, timeout=900):
+    import resource
+
+    def big_stack():
+        # the reference keeps its private (IminS:ImaxS,JminS:JmaxS,N) work arrays on the stack
+        resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+
+    lib = {"upwelling_kpp_small": "upwelling_kpp"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
+    if not ref.available(lib):
+        pytest.skip(f"oracle/_ref/libromsref_{lib}.so not built here")
+    p = subprocess.run([sys.executable, "-m", "tests.refchild", mode, tag] + list(args), capture_output=True,
+                       text=True, timeout=timeout, cwd=ROOT, preexec_fn=big_stack, errors="replace")
+    return p.stdout[-3000:] + p.stderr[-2000:]
+
+
+MAIN3D_CASES = [
+    # tag, arguments                                                             what it covers
+    ("upwelling_small", ["nsteps=100", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),       # roms_upwelling.in schemes
+    ("upwelling_small", ["nsteps=100", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
+    ("upwelling_small", ["nsteps=30", "hadv=A4,C2", "vadv=SPLINES,C2"]),
+    ("upwelling_small", ["nsteps=30", "hadv=C4,SU3", "vadv=A4,C4"]),
+    ("upwelling_small", ["nsteps=30", "hadv=U3,U3", "vadv=C4,C4"]),
+    ("upwelling_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("upwelling_small", ["nsteps=20", "NtileI=3", "NtileJ=1", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
+    ("benchmark_small", ["nsteps=100"]),                                         # KPP, bulk fluxes, nonlinear EOS
+    ("benchmark_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_kpp_small", ["nsteps=100"]),                                     # BASELINE config 5 physics
+    ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
+    ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
+]
+
+
+@pytest.mark.parametrize("tag,args", MAIN3D_CASES, ids=[t + ":" + "+".join(a) for t, a in MAIN3D_CASES])
+def test_main3d_steps_bitwise(tag, args):
+    """Whole main3d passes: the reference's own kernels called in main3d.F order (ref_glue.F90:ref_main3d)
+    against orc_main3d_step -- every state array compared after every step with array_equal, the stepping
+    indices at the end, and every `diag` line the reference prints (diag.F FORMAT 30/40)."""
+    out = _child("main3d", tag, *args)
+    assert "MAIN3D-OK bitwise" in out, out
+
+
+@pytest.mark.parametrize("tag,args", [
+    ("upwelling_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("upwelling_small", ["hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
+    ("upwelling_small", ["hadv=A4,SU3", "vadv=SPLINES,A4"]),
+    ("upwelling_small", ["hadv=C2,C4", "vadv=C2,C4"]),
+    ("benchmark_small", []),
+    ("upwelling_kpp_small", []),
+])
+def test_core_kernels_bitwise(tag, args):
+    """step2d_tile (step2d_LF_AM3.h:163; first predictor, correctors, last predictor), omega_tile (omega.F:96),
+    pre_step3d_tile (pre_step3d.F:126), rhs3d (rhs3d.F:25 incl. rhs3d_tile :196), step3d_uv_tile
+    (step3d_uv.F:134), step3d_t_tile (step3d_t.F:120): one call each on a randomly perturbed mid-run state."""
+    out = _child("kernels", tag, *args)
+    assert "KERNELS-OK bitwise" in out, out
+
+
+@pytest.mark.parametrize("tag", ["benchmark_small", "upwelling_kpp_small", "upwelling_small"])
+def test_physics_routines_bitwise(tag):
+    """set_depth, set_massflux, rho_eos (rho, pden, rhoA, rhoS, bvf, alpha, beta: rho_eos.F:247-560), the analytic
+    atmosphere + ana_srflux (set_data.F), bulk_flux (bulk_flux.F:208), set_vbc (QDRAG), lmd_vmix, omega,
+    wvelocity, set_zeta, prsgrd32, t3dmix2 (_geo for BENCHMARK: t3dmix2_geo.h:90), uv3dmix2, diag -- each
+    routine's outputs array_equal on a perturbed state; diag through avgkp and its printed line."""
+    out = _child("physics", tag)
+    assert "PHYSICS-OK bitwise" in out, out
