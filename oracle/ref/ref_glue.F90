@@ -257,6 +257,7 @@
       USE set_massflux_mod,  ONLY : set_massflux
       USE rho_eos_mod,       ONLY : rho_eos
       USE omega_mod,         ONLY : omega
+      USE dateclock_mod,     ONLY : time_string
       integer :: tile
       DO tile=first_tile(ng),last_tile(ng)
         CALL ana_grid (ng, tile, iNLM)
@@ -288,6 +289,7 @@
         CALL rho_eos (ng, tile, iNLM)
       END DO
       iic(ng)=ntstart(ng)
+      CALL time_string (time(ng), time_code(ng))           ! initial.F:862
       END SUBROUTINE ref_initial
 !
 !=======================================================================
@@ -363,6 +365,7 @@
 #ifdef BULK_FLUXES
       USE bulk_flux_mod,     ONLY : bulk_flux
 #endif
+      USE dateclock_mod,     ONLY : time_string
       integer(c_int), value :: nsteps
       real(c_double), intent(out) :: dg(*)
       integer :: istep, tile, my_iif, next_indx1
@@ -451,8 +454,9 @@
         DO tile=last_tile(ng),first_tile(ng),-1            ! :1043-1047
           CALL step3d_t (ng, tile)
         END DO
-        iic(ng)=iic(ng)+1                                  ! :1145-1148 (ntimesteps)
+        iic(ng)=iic(ng)+1                                  ! :1145-1148
         time(ng)=time(ng)+dt(ng)
+        CALL time_string (time(ng), time_code(ng))
       END DO
       dg(1)=avgke
       dg(2)=avgpe
@@ -490,6 +494,7 @@
 !=======================================================================
 !
       SUBROUTINE ref_set_stepping (idx, tm) bind(C, name="ref_set_stepping")
+      USE dateclock_mod,     ONLY : time_string
       integer(c_int), intent(in) :: idx(*)
       real(c_double), value :: tm
       iic(ng)=idx(1)
@@ -504,6 +509,7 @@
       PREDICTOR_2D_STEP(ng)=idx(9).ne.0
       time(ng)=tm
       tdays(ng)=time(ng)*sec2day
+      CALL time_string (time(ng), time_code(ng))
       END SUBROUTINE ref_set_stepping
 !
 !=======================================================================

@@ -9,9 +9,16 @@ Fixtures (npz, float64 exact):
   <case>_init.npz     set-up tables and the state after the reference's initial sequence
                       (ana_grid, set_scoord, set_weights, metrics, ini_hmixcoef, set_depth,
                       ana_initial, set_depth0/set_zeta_timeavg/set_depth, set_massflux, rho_eos)
-  <case>_kernels.npz  inputs and outputs of every reference kernel that builds here, run on a
-                      perturbed state (the "pinned" kernels)
+  <case>_steps.npz    the reference's state (reference kernels in main3d.F order, ref_glue.F90:
+                      ref_main3d) after steps 1, 2, 3 and 100, and every diag line it printed
+  <case>_kernels.npz  steps 1 and 2 kernel by kernel: the state before the step, then for every
+                      reference kernel call of main3d the arrays it changed (of the 2*nfast+1
+                      step2d calls the first four and the last are kept)
+  <workload>_sample.npz  BASELINE-size runs (BENCHMARK1/2/3, UPWELLING, 512x512x50, config 5): a
+                      regular (xi,eta) sub-sample, all levels, of the reference's end state
   bounds_*.npz        BOUNDS/DOMAIN tables of get_bounds.F for several tilings
+The GPU-box tests (tests/test_gpu_vs_reference.py) feed these inputs to the C ABI and compare
+with the reference's OWN outputs; only data travels.
 """
 import os
 import subprocess
@@ -87,9 +94,155 @@ def make_bounds():
     print("wrote bounds", spec)
 
 
+KEEP = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "wvel", "Hz", "z_r", "z_w", "Huon", "Hvom", "rho", "ru", "rv",
+        "Zt_avg1", "DU_avg1", "DV_avg1", "DU_avg2", "DV_avg2", "rufrc", "rvfrc", "rzeta", "rubar", "rvbar",
+        "Akv", "Akt", "hsbl", "ghats", "stflx", "sustr", "svstr", "bustr", "bvstr", "srflx", "bvf"]
+
+
+def _kw(args):
+    from tests import refchild
+    return refchild.parse(args)
+
+
+def make_steps(name, tag, args):
+    """<name>_steps.npz: the reference after steps 1, 2, 3 and nsteps."""
+    import json
+    from tests import refdrive as rd
+    kw = _kw(args)
+    nsteps = kw.pop("nsteps", 100)
+    app, cs = rd.make_case(tag, **kw)
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    names = [n for n in KEEP if R.has(n)]
+    out = {}
+    for s in range(1, nsteps + 1):
+        R.main3d(1)
+        if s in (1, 2, 3, nsteps):
+            for n in names:
+                out[f"s{s}_{n}"] = R.get(n)
+    st = R.get_stepping()
+    rd.unquiet(saved)
+    lines = rd.diag_lines()
+    assert len(lines) == nsteps
+    out["meta"] = np.array(json.dumps(dict(tag=tag, case={k: v for k, v in cs.items()}, nsteps=nsteps, fields=names,
+                                           stepping=st, diag=lines, diag_text=rd.diag_text())))
+    np.savez_compressed(os.path.join(HERE, f"{name}_steps.npz"), **out)
+    print(f"wrote {name}_steps.npz ({len(names)} fields x 4 snapshots, {nsteps} diag lines)")
+
+
+def make_kernels(name, tag, args):
+    """<name>_kernels.npz: steps 1 and 2 through the reference's kernel wrappers one call at a time."""
+    import json
+    from tests import refdrive as rd
+    from tests import util
+    kw = _kw(args)
+    app, cs = rd.make_case(tag, **kw)
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    names = [n for n in util.STATE_FIELDS if R.has(n)]
+    nfast = R.bounds(0)[58]
+    st = dict(iic=1, iif=1, nstp=1, nnew=1, nrhs=1, kstp=1, knew=1, krhs=1, predictor=0, indx1=1, time=0.0,
+              nfast=nfast)
+    out, seqs = {}, []
+    snap = {n: R.get(n) for n in names}
+    for step in (1, 2):
+        for n in names:
+            out[f"s{step}_in_{n}"] = snap[n]
+        seq = rd.main3d_sequence(cs, st, first=(step == 1))
+        n2d = [k for k, (kern, _) in enumerate(seq) if kern == "step2d"]
+        keep2d = set(n2d[:4] + n2d[-1:])
+        entries = []
+        for k, (kern, s_) in enumerate(seq):
+            R.set_stepping(s_["iic"], s_.get("iif", 1), s_["nstp"], s_["nnew"], s_["nrhs"], s_.get("kstp", 1),
+                           s_.get("knew", 1), s_.get("krhs", 1), s_.get("predictor", 0), s_["time"], s_["indx1"])
+            R.call(kern)
+            e = dict(k=kern, st={a: b for a, b in s_.items() if a != "nfast"}, saved=False, out=[])
+            if kern != "step2d" or k in keep2d:
+                now = {n: R.get(n) for n in names}
+                e["saved"] = True
+                for n in names:
+                    if not np.array_equal(now[n], snap[n]):
+                        e["out"].append(n)
+                        out[f"s{step}_{k:03d}_{n}"] = now[n]
+                snap = now
+            entries.append(e)
+        seqs.append(entries)
+    rd.unquiet(saved)
+    lines = rd.diag_lines()
+    # the same two steps through ref_main3d (another process wrote <name>_steps.npz): must agree bit for bit
+    chk = np.load(os.path.join(HERE, f"{name}_steps.npz"))
+    for n in KEEP:
+        if f"s2_{n}" in chk.files:
+            assert np.array_equal(chk[f"s2_{n}"], snap[n]), n
+    out["meta"] = np.array(json.dumps(dict(tag=tag, case=cs, fields=names, nfast=nfast, seq=seqs, diag=lines)))
+    np.savez_compressed(os.path.join(HERE, f"{name}_kernels.npz"), **out)
+    print(f"wrote {name}_kernels.npz ({sum(len(e['out']) for q in seqs for e in q)} output arrays)")
+
+
+SAMPLE_FIELDS = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "wvel", "Hz", "rho", "Akv", "Akt", "Huon", "DU_avg1",
+                 "Zt_avg1", "hsbl"]
+
+
+def make_sample(workload, nsteps):
+    """<workload>_sample.npz: the reference's end state at a BASELINE size, sub-sampled."""
+    import json
+    import resource
+    import bench
+    from tests import refdrive as rd
+    resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+    cs = bench.params_for(workload, ntimes=nsteps)
+    app = {"benchmark": "benchmark", "upwelling_kpp": "upwelling_kpp"}.get(cs["app"], "upwelling")
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    R.main3d(nsteps)
+    ni, nj = R.ni, R.nj
+    si, sj = max(1, ni // 48), max(1, nj // 24)
+    ii, jj = np.arange(0, ni, si), np.arange(0, nj, sj)
+    out = dict(ii=ii, jj=jj)
+    names = [n for n in SAMPLE_FIELDS if R.has(n)]
+    for n in names:
+        a = R.get(n).reshape(-1, nj, ni)
+        out[n] = np.ascontiguousarray(a[:, jj][:, :, ii])
+        out[n + "_rms"] = np.sqrt(np.mean(a ** 2))
+    rd.unquiet(saved)
+    lines = rd.diag_lines()
+    out["meta"] = np.array(json.dumps(dict(workload=workload, case=cs, nsteps=nsteps, fields=names, ni=ni, nj=nj,
+                                           diag=lines[-1:])))
+    np.savez_compressed(os.path.join(HERE, f"{workload}_sample.npz"), **out)
+    print(f"wrote {workload}_sample.npz ({len(names)} fields, {len(ii)}x{len(jj)} columns, {nsteps} steps)")
+
+
+STEP_CASES = [
+    # fixture name, refdrive case tag, arguments
+    ("upwelling_small_hsimt", "upwelling_small", ["nsteps=100", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("upwelling_small_mpdata", "upwelling_small", ["nsteps=100", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
+    ("upwelling_small_a4spl", "upwelling_small", ["nsteps=30", "hadv=A4,C2", "vadv=SPLINES,C2"]),
+    ("upwelling_small_c4su3", "upwelling_small", ["nsteps=30", "hadv=C4,SU3", "vadv=A4,C4"]),
+    ("benchmark_small", "benchmark_small", ["nsteps=100"]),
+    ("upwelling_kpp_small", "upwelling_kpp_small", ["nsteps=100"]),
+]
+KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
+SAMPLES = [("upwelling", 100), ("benchmark1", 100), ("benchmark2", 10), ("benchmark3", 4), ("ns512", 4), ("ns512u3", 4),
+           ("config5", 4)]
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--case":
         make_case(sys.argv[2])
+    elif len(sys.argv) > 3 and sys.argv[1] == "--steps":
+        make_steps(sys.argv[2], sys.argv[3], sys.argv[4:])
+    elif len(sys.argv) > 3 and sys.argv[1] == "--kernels":
+        make_kernels(sys.argv[2], sys.argv[3], sys.argv[4:])
+    elif len(sys.argv) > 3 and sys.argv[1] == "--sample":
+        make_sample(sys.argv[2], int(sys.argv[3]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--reference-runs":
+        py = sys.executable
+        for name, tag, args in STEP_CASES:
+            subprocess.check_call([py, __file__, "--steps", name, tag] + args)
+            if name in KERNEL_CASES:
+                subprocess.check_call([py, __file__, "--kernels", name, tag] + [a for a in args if "nsteps" not in a])
+        for wl, n in SAMPLES:
+            subprocess.check_call([py, __file__, "--sample", wl, str(n)])
     elif len(sys.argv) > 2 and sys.argv[1] == "--bounds":
         make_bounds()
     else:

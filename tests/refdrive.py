@@ -24,6 +24,16 @@ CASES = {
 
 
 _LOG = None
+_TEXT = []
+
+
+def _cleanup():
+    if _LOG and os.path.exists(_LOG):
+        os.unlink(_LOG)
+
+
+import atexit
+atexit.register(_cleanup)
 
 
 def quiet():
@@ -61,10 +71,16 @@ def diag_lines():
         if len(a) >= 4 and m and re.match(r"^\s*\d+\s", lines[k]):
             b = re.findall(flt, lines[k + 1])
             out.append((tuple(a[-4:]), tuple(int(x) for x in m.groups()), tuple(b[-4:])))
+            _TEXT.append((lines[k], lines[k + 1]))
             k += 2
         else:
             k += 1
     return out
+
+
+def diag_text():
+    """the two printed lines of every diag report diag_lines() found, verbatim"""
+    return list(_TEXT)
 
 
 def fmt_e(x):

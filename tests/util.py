@@ -116,3 +116,211 @@ def ns_periodic_case(hadv, vadv, ng, ewp):
                 a = a[:, :, (0 - LBi):(Im + 1 - LBi) + 1]
             g[k] = np.ascontiguousarray(a).ravel()
     return cs, g
+
+
+# ------------------------------------------------------------------------------------------------
+# Reference-derived fixtures (tests/golden/*_steps.npz, *_kernels.npz, *_sample.npz, written by
+# tests/golden/make_golden.py from the reference's own object code): loaders and a small adapter so
+# that the same checks run on the oracle (CPU, anywhere) and on the HIP library (GPU box).
+# ------------------------------------------------------------------------------------------------
+def load_fixture(name):
+    import json
+    f = np.load(os.path.join(GOLDEN, name))
+    meta = json.loads(str(f["meta"]))
+    return f, meta
+
+
+def case_from_meta(meta):
+    cs = dict(meta["case"])
+    for k in ("hadv", "vadv", "tnu2", "Akt_bak", "options"):
+        cs[k] = tuple(cs[k])
+    return cs
+
+
+def init_tag(cs):
+    return {(14, 18, 8): "upwelling_small", (24, 16, 10): "benchmark_small", (41, 80, 16): "upwelling"}[
+        (cs["Lm"], cs["Mm"], cs["N"])]
+
+
+class OracleSide:
+    """the C oracle behind the put/get/call surface the fixture checks use"""
+    exact = True
+
+    def __init__(self, cs):
+        self.cs = cs
+        self.g = load_init(init_tag(cs), nghost_for(cs))
+        self.O = make_oracle(cs, self.g)
+        self.O.start()
+
+    def put(self, name, a):
+        self.O.field(name)[:] = a
+
+    def get(self, name):
+        return self.O.field(name)
+
+    def has(self, name):
+        try:
+            self.O.field(name)
+            return True
+        except KeyError:
+            return False
+
+    def stepping(self, st):
+        for k, v in st.items():
+            setattr(self.O.step, k, v)
+        self.O.step.tdays = st["time"] / 86400.0
+
+    def call(self, kernel, st):
+        self.stepping(st)
+        if kernel == "wvelocity":
+            self.O.call(kernel, None, st["nstp"])
+        elif kernel == "diag":
+            self.last_diag = self.O.diag()
+        else:
+            self.O.call(kernel)
+
+    def main3d(self, n):
+        self.O.main3d_step(n)
+
+    def dims(self):
+        return self.O.ni, self.O.nj
+
+    def diag(self):
+        import ctypes as C
+        out = (C.c_double * 16)()
+        self.O.L.orc_get_diag(C.c_void_p(self.O.h), out)
+        return list(out)[:12]
+
+    def close(self):
+        self.O.close()
+
+
+class HipSide:
+    """libroms_hip.so through its C ABI behind the same surface"""
+    exact = False
+
+    def __init__(self, cs, ninfo=1):
+        self.cs = cs
+        self.g = load_init(init_tag(cs), nghost_for(cs))
+        self.H = make_hip(cs, self.g, ninfo=ninfo)
+        self.H.start()
+
+    def put(self, name, a):
+        self.H.upload(name, a)
+
+    def get(self, name):
+        return self.H.download(name)
+
+    def has(self, name):
+        try:
+            self.H.size(name)
+            return True
+        except KeyError:
+            return False
+
+    def stepping(self, st):
+        self.H.set_stepping(**{k: v for k, v in st.items()})
+
+    def call(self, kernel, st):
+        self.stepping(st)
+        if kernel == "wvelocity":
+            self.H.call(kernel, st["nstp"])
+        elif kernel == "diag":
+            self.last_diag = self.H.diag()
+        else:
+            self.H.call(kernel)
+
+    def main3d(self, n):
+        self.H.main3d(n)
+        self.H.sync()
+
+    def dims(self):
+        return self.H.ni, self.H.nj
+
+    def diag(self):
+        return self.H.diag()
+
+    def close(self):
+        self.H.close()
+
+
+def unpadded(a, cs, ni, nj):
+    """View of a state array without the padding column/row beyond Lm+Nghost (Mm+Nghost) that a periodic
+    axis of even length carries (Im = Lm+1, mod_param.F:1633-1636): no exchange fills it and no kernel reads
+    it, so its content is whatever the set-up left there (the cropped 3-ghost-point fixture and a genuine
+    2-ghost-point run differ in it)."""
+    a = a.reshape(-1, nj, ni)
+    ng = nghost_for(cs)
+    if cs["EWperiodic"]:
+        a = a[:, :, :cs["Lm"] + 2 * ng + 1]           # i = -ng .. Lm+ng
+    if cs["NSperiodic"]:
+        a = a[:, :cs["Mm"] + 2 * ng + 1, :]
+    return a
+
+
+def fmt_diag(od):
+    """diag numbers as the reference prints them (diag.F FORMAT 30/40: 1pe14.6, 1pe13.6)"""
+    f = lambda x: "%.6E" % x
+    return [[f(v) for v in od[:4]], [int(od[8]), int(od[9]), int(od[10])], [f(v) for v in (od[5], od[6], od[7], od[4])]]
+
+
+def check_steps_fixture(side, f, meta, tol, tol_loose=None, loose=()):
+    """run meta['nsteps'] main3d passes on `side`; compare with the reference's snapshots after steps
+    1, 2, 3 and the last one.  Returns {field: worst relative RMS}."""
+    worst = {}
+    done = 0
+    ni, nj = side.dims()
+    for s in (1, 2, 3, meta["nsteps"]):
+        side.main3d(s - done)
+        done = s
+        for n in meta["fields"]:
+            if not side.has(n):
+                continue
+            a, r = unpadded(side.get(n), side.cs, ni, nj), unpadded(f[f"s{s}_{n}"], side.cs, ni, nj)
+            if side.exact:
+                assert np.array_equal(a, r), (s, n, relrms(a, r))
+            e = relrms(a, r)
+            worst[n] = max(worst.get(n, 0.0), e)
+            lim = tol_loose if (n in loose and tol_loose is not None) else tol
+            assert e <= lim, (s, n, e)
+        if s == meta["nsteps"]:
+            assert fmt_diag(side.diag())[0][3] == meta["diag"][-1][0][3]      # NET_VOLUME as printed
+    return worst
+
+
+def check_kernels_fixture(side, f, meta, tol):
+    """steps 1 and 2 kernel by kernel: every saved call's changed arrays against the reference's, then the
+    reference's arrays are installed so that the next kernel starts from exactly the reference's input."""
+    worst = {}
+    nd = 0
+    ni, nj = side.dims()
+    for step, entries in enumerate(meta["seq"], start=1):
+        for n in meta["fields"]:
+            if side.has(n):
+                side.put(n, f[f"s{step}_in_{n}"])
+        for k, e in enumerate(entries):
+            side.call(e["k"], e["st"])
+            if e["k"] == "diag":
+                got = fmt_diag(side.last_diag)
+                want = meta["diag"][nd]
+                nd += 1
+                if side.exact:
+                    assert got == [list(want[0]), list(want[1]), list(want[2])], (step, got, want)
+                else:
+                    assert got[0][3] == want[0][3] and got[0][1] == want[0][1], (step, got, want)
+            if not e["saved"]:
+                continue
+            for n in e["out"]:
+                if not side.has(n):
+                    continue
+                r = f[f"s{step}_{k:03d}_{n}"]
+                a = unpadded(side.get(n), side.cs, ni, nj)
+                ru = unpadded(r, side.cs, ni, nj)
+                if side.exact:
+                    assert np.array_equal(a, ru), (step, k, e["k"], n, relrms(a, ru))
+                err = relrms(a, ru)
+                key = e["k"] + ":" + n
+                worst[key] = max(worst.get(key, 0.0), err)
+                assert err <= tol, (step, k, e["k"], n, err)
+                side.put(n, r)
+    return worst
