@@ -201,14 +201,6 @@ int roms_hip_kprof_stride(int every);
    launches, e.g. the barotropic loop): the event markers then do not inflate a short kernel.  A run
    interrupted by another launch is discarded and the library falls back to one pair per launch. */
 int roms_hip_kprof_batch(int n);
-/* measurement aid: `n` launches of the barotropic kernel issued one by one and as one captured
-   hipGraph, `reps` times each; out[0], out[1] = microseconds per launch of the two forms */
-int roms_hip_graph_probe(roms_hip_ctx *ctx, int n, int reps, double *out);
-/* measurement aid: one whole main3d step captured as a hipGraph (both streams) and replayed `reps`
-   times against `reps` steps launched kernel by kernel; out[0], out[1] = microseconds per step,
-   out[2] = number of graph nodes.  The replay repeats the captured arguments: call it on a context
-   whose state is no longer needed. */
-int roms_hip_graph_step_probe(roms_hip_ctx *ctx, int reps, double *out);
 int roms_hip_kprof_get(int index, char *name, int name_len, double *seconds, long *calls);
 
 #ifdef __cplusplus

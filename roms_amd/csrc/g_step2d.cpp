@@ -66,6 +66,7 @@ int run_step2d(roms_hip_ctx *c) {
   } else {
     int nthreads = 512;
     if (getenv("ROMS_HIP_S2D_THREADS")) nthreads = atoi(getenv("ROMS_HIP_S2D_THREADS"));
+    nthreads = KMAX(64, KMIN(512, nthreads / 64 * 64));   // the kernel is compiled for at most 512 threads
 #ifndef ROMS_CPU_EMU
     static bool big_lds_g = false;
     if (lds * sizeof(double) > 64 * 1024 && !big_lds_g) {

@@ -160,6 +160,18 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     set_error("bad tile partition (NtileI, NtileJ, tile)");
     return 5;
   }
+  if (cfg->Nghost != 2 && cfg->Nghost != 3) {
+    // get_bounds.F / inp_par.F:210-216: NghostPoints is 2, or 3 with MPDATA/HSIMT; the strip buffers of
+    // the halo exchange (3 lines per side, 9-point corner blocks) are sized for that
+    set_error("Nghost must be 2 or 3 (NghostPoints of the reference)");
+    return 5;
+  }
+  if (cfg->NtileI * cfg->NtileJ > 1 &&
+      (cfg->Iend - cfg->Istr + 1 < 3 || cfg->Jend - cfg->Jstr + 1 < 3)) {
+    // a strip of three lines is packed from a tile's own points: narrower tiles would send foreign lines
+    set_error("a tile of a multi-tile run must be at least 3 points wide and high");
+    return 5;
+  }
   {  // array bounds must hold the ghost zone the kernels and the strip exchange assume
     const int pw = cfg->west_edge && !cfg->EWperiodic, pe = cfg->east_edge && !cfg->EWperiodic;
     const int ps = cfg->south_edge && !cfg->NSperiodic, pn = cfg->north_edge && !cfg->NSperiodic;
@@ -339,6 +351,13 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
 extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   if (!c) return 0;
   (void)dsync(c->stream);
+#ifndef ROMS_CPU_EMU
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);   // side-stream kernels may still read the arrays
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+#endif
   for (void *p : c->allocs) dfree(p);
   for (int k = 0; k < 8; k++) { if (c->comm.sbuf[k]) dfree(c->comm.sbuf[k]); if (c->comm.rbuf[k]) dfree(c->comm.rbuf[k]); }
   comm_destroy(c);
@@ -390,48 +409,11 @@ extern "C" int roms_hip_download(roms_hip_ctx *c, const char *name, double *host
   return d2h(host, *(double **)((char *)&c->F + f->offset), (size_t)n * sizeof(double), c->stream);
 }
 extern "C" int roms_hip_sync(roms_hip_ctx *c) { return dsync(c->stream); }
-// Measurement aid: n back-to-back launches of the barotropic kernel issued one by one and as one
-// captured hipGraph; microseconds per launch of both forms in out[0], out[1].
 int run_step2d(roms_hip_ctx *c);
 int run_rhs3d_pt(roms_hip_ctx *c);
 int run_uv3dmix2_s(roms_hip_ctx *c);
 int run_rufrc_sums(roms_hip_ctx *c);
 int run_swdk(roms_hip_ctx *c);
-extern "C" int roms_hip_graph_probe(roms_hip_ctx *c, int n, int reps, double *out) {
-#ifdef ROMS_CPU_EMU
-  (void)c; (void)n; (void)reps; (void)out;
-  return 5;
-#else
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  float ms = 0.f;
-  for (int w = 0; w < 2; w++) {
-    (void)hipEventRecord(e0, c->stream);
-    for (int r = 0; r < reps; r++)
-      for (int k = 0; k < n; k++) if (run_step2d(c)) return 2;
-    (void)hipEventRecord(e1, c->stream);
-    (void)hipEventSynchronize(e1);
-    (void)hipEventElapsedTime(&ms, e0, e1);
-  }
-  out[0] = 1e3 * ms / (double)(n * reps);
-  hipGraph_t g; hipGraphExec_t ge;
-  if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { set_error("capture begin"); return 2; }
-  for (int k = 0; k < n; k++) if (run_step2d(c)) return 2;
-  if (hipStreamEndCapture(c->stream, &g) != hipSuccess) { set_error("capture end"); return 2; }
-  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { set_error("graph instantiate"); return 2; }
-  for (int w = 0; w < 2; w++) {
-    (void)hipEventRecord(e0, c->stream);
-    for (int r = 0; r < reps; r++) (void)hipGraphLaunch(ge, c->stream);
-    (void)hipEventRecord(e1, c->stream);
-    (void)hipEventSynchronize(e1);
-    (void)hipEventElapsedTime(&ms, e0, e1);
-  }
-  out[1] = 1e3 * ms / (double)(n * reps);
-  (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  return 0;
-#endif
-}
 int fetch_diag(roms_hip_ctx *c, const double *d_out, double *out) { return d2h(out, d_out, 16 * sizeof(double), c->stream); }
 int run_diag_async(roms_hip_ctx *c, double *d_out);   // g_diag.cpp
 
@@ -893,7 +875,7 @@ static int main3d_one(roms_hip_ctx *c) {
   }
   side_begin(c);
   r = 0;
-  if (do_diag) r = run_diag_async(c, c->d_diag);   // reads u, v, rho, wvel ... of this point of the step
+  if (do_diag) { r = run_diag_async(c, c->d_diag); c->diag_ran = true; }   // reads u, v, rho, wvel ... of this point of the step
   if (!r && side_chain) {
     r = roms_hip_set_massflux(c);
     if (!r) r = roms_hip_omega(c);
@@ -973,11 +955,16 @@ extern "C" int roms_hip_main3d(roms_hip_ctx *c, int nsteps) {
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "roms_hip_main3d: %d steps enqueued in %.1f us of host time (%.1f us per step)\n", nsteps, us, us / nsteps);
   }
-  if (c->cfg.ninfo > 0 && nsteps > 0) {
+  // The reference tests the GLOBALLY reduced energies (diag.F:419-437 mp_reduce, then :510-540).  A tile
+  // of a multi-tile run therefore does not stop on its local numbers -- one rank leaving the step loop
+  // while its neighbours wait in the next exchange would hang them -- the caller reduces roms_hip_diag's
+  // raw sums over the ranks and stops all of them together (roms_amd/tiling.py:TiledRun.check).
+  if (c->diag_ran && c->cfg.NtileI * c->cfg.NtileJ == 1) {   // d_diag holds the report of this call's last NINFO point
+    c->diag_ran = false;
     double out[16];
     int r = fetch_diag(c, c->d_diag, out);
     if (r) return r;
-    if (!(out[0] == out[0] && out[1] == out[1]) || out[4] > 20.0) {   // diag.F:510-540
+    if (!(std::isfinite(out[0]) && std::isfinite(out[1])) || !(out[4] <= 20.0)) {   // diag.F:510-540
       set_error("blow-up: KE/PE not finite or MaxSpeed > 20 m/s");
       return 1;
     }
@@ -985,45 +972,3 @@ extern "C" int roms_hip_main3d(roms_hip_ctx *c, int nsteps) {
   return 0;
 }
 
-// Measurement aid: one whole step captured as a hipGraph (both streams) and replayed `reps` times,
-// against `reps` steps launched kernel by kernel; microseconds per step in out[0] (plain), out[1]
-// (graph).  The replay repeats the captured arguments (the model state it leaves is meaningless).
-extern "C" int roms_hip_graph_step_probe(roms_hip_ctx *c, int reps, double *out) {
-#ifdef ROMS_CPU_EMU
-  (void)c; (void)reps; (void)out;
-  return 5;
-#else
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  float ms = 0.f;
-  int r;
-  for (int k = 0; k < 3; k++) if ((r = main3d_one(c))) return r;
-  (void)hipEventRecord(e0, c->stream);
-  for (int k = 0; k < reps; k++) if ((r = main3d_one(c))) return r;
-  (void)hipEventRecord(e1, c->stream);
-  (void)hipEventSynchronize(e1);
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  out[0] = 1e3 * ms / reps;
-  hipGraph_t g; hipGraphExec_t ge;
-  if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { set_error("capture begin"); return 2; }
-  r = main3d_one(c);
-  hipError_t ec = hipStreamEndCapture(c->stream, &g);
-  if (r) return r;
-  if (ec != hipSuccess) { set_error(std::string("capture end: ") + hipGetErrorString(ec)); return 2; }
-  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { set_error("graph instantiate"); return 2; }
-  for (int w = 0; w < 2; w++) {
-    (void)hipEventRecord(e0, c->stream);
-    for (int k = 0; k < reps; k++) (void)hipGraphLaunch(ge, c->stream);
-    (void)hipEventRecord(e1, c->stream);
-    (void)hipEventSynchronize(e1);
-    (void)hipEventElapsedTime(&ms, e0, e1);
-  }
-  out[1] = 1e3 * ms / reps;
-  size_t nn = 0;
-  (void)hipGraphGetNodes(g, nullptr, &nn);
-  out[2] = (double)nn;
-  (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  return 0;
-#endif
-}

@@ -55,7 +55,7 @@ EXPORTS = ["roms_hip_create", "roms_hip_destroy", "roms_hip_last_error", "roms_h
            "roms_hip_field_size", "roms_hip_upload", "roms_hip_download", "roms_hip_sync",
            "roms_hip_set_stepping", "roms_hip_get_stepping", "roms_hip_wvelocity", "roms_hip_diag",
            "roms_hip_start", "roms_hip_main3d", "roms_hip_profile", "roms_hip_region_seconds",
-           "roms_hip_kprof", "roms_hip_kprof_get", "roms_hip_kprof_stride", "roms_hip_kprof_batch", "roms_hip_graph_probe", "roms_hip_graph_step_probe", "roms_hip_set_exchange", "roms_hip_rccl_unique_id",
+           "roms_hip_kprof", "roms_hip_kprof_get", "roms_hip_kprof_stride", "roms_hip_kprof_batch", "roms_hip_set_exchange", "roms_hip_rccl_unique_id",
            "roms_hip_comm_rccl", "roms_hip_exchange_count", "roms_hip_copy_probe"] + \
           ["roms_hip_" + k for k in KERNELS]
 

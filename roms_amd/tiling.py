@@ -131,8 +131,12 @@ class TiledRun:
         self.ctx._ck(self.ctx.L.roms_hip_set_exchange(self.ctx.h, self._cb, None))
 
     # ------------------------------------------------------------------ running
-    def step(self, n=1, kernels=False):
+    def step(self, n=1, kernels=False, check=False):
+        """n main3d passes.  In a multi-tile run the library leaves the blow-up test (diag.F:510-540) to the
+        globally reduced numbers: check=True makes every rank run it together after the n steps."""
         self.host.run(n, kernels=kernels)
+        if check:
+            self.check()
 
     def sync(self):
         self.ctx.sync()

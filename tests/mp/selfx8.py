@@ -1,7 +1,7 @@
 """Ad-hoc: doubly periodic single tile, every ghost exchange through RCCL with the tile as its own eight
 neighbours (8 sends + 8 receives to the same peer in one group), against the local periodic copies."""
 import os, sys
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import numpy as np
 import bench
 from roms_amd import tiling

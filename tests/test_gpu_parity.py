@@ -567,12 +567,12 @@ def test_rccl_self_exchange_eight_neighbours():
     """A doubly periodic single tile as its own EIGHT neighbours (ROMS_HIP_SELF_EXCHANGE): every exchange
     point is 8 ncclSend + 8 ncclRecv to the same peer in one group -- xi strips, eta strips and the four
     corner blocks, matched by issue order -- and must leave exactly the ghost zone of the local periodic
-    copies.  (tests/gpu_selfx8.py in its own process.)"""
+    copies.  (tests/mp/selfx8.py in its own process.)"""
     import subprocess
     import sys
     ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_selfx8.py")], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mp", "selfx8.py")], capture_output=True, text=True,
                        env=env, timeout=300)
     line = [l for l in r.stdout.splitlines() if l.startswith("SELFX8")]
     assert line, r.stdout[-1500:] + r.stderr[-3000:]

@@ -1,7 +1,7 @@
 """Ad-hoc (not collected by pytest): BENCHMARK1 at full size on the GPU against the oracle.
-python tests/gpu_fullsize_check.py [nsteps]"""
+python tools/gpu_debug/gpu_fullsize_check.py [nsteps]"""
 import os, sys
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import numpy as np
 import bench
 from tests import cases, util

@@ -1,7 +1,7 @@
 """Ad-hoc: per-kernel time per launch (synchronous HIP events) for a workload, optional advection schemes:
-   python tests/gpu_kbreak.py ns512 [steps] [U3,U3 C4,C4] [env K=V ...]"""
+   python tools/gpu_debug/gpu_kbreak.py ns512 [steps] [U3,U3 C4,C4] [env K=V ...]"""
 import os, sys
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import bench
 from roms_amd import hiplib, tiling
 wl = sys.argv[1] if len(sys.argv) > 1 else "ns512"

@@ -1,6 +1,6 @@
 """Ad-hoc: run the first step kernel by kernel and report the first kernel after which a field is not finite."""
 import os, sys
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import numpy as np
 import bench
 from roms_amd import tiling

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import bench
 from roms_amd import tiling
 cs = bench.params_for("upwelling", 512, 64, 30, ntimes=60)

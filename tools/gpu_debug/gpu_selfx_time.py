@@ -1,7 +1,7 @@
 """Ad-hoc: step time with every periodic ghost exchange routed through pack -> RCCL send/recv -> unpack
-(self-exchange test aid, one GPU): python tests/gpu_selfx_time.py [workload] [steps]"""
+(self-exchange test aid, one GPU): python tools/gpu_debug/gpu_selfx_time.py [workload] [steps]"""
 import os, sys, time
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import bench
 from roms_amd import tiling
 wl = sys.argv[1] if len(sys.argv) > 1 else "benchmark1"

@@ -1,6 +1,6 @@
-"""Ad-hoc timing of the barotropic kernel (not a test): python tests/gpu_step2d_probe.py [workload]"""
+"""Ad-hoc timing of the barotropic kernel (not a test): python tools/gpu_debug/gpu_step2d_probe.py [workload]"""
 import os, sys
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import bench
 from roms_amd import hiplib, tiling
 wl = sys.argv[1] if len(sys.argv) > 1 else "benchmark1"
@@ -42,18 +42,3 @@ if os.environ.get("ROMS_HIP_DBG_STOP") == "99":
         for b in (0, 1, 17, nb // 2 + 8, nb - 1):
             print("  block", b, (T[b] - t0).astype(int).tolist())
         print("  mean per stage:", np.round((T - T[:, :1]).mean(axis=0), 1).tolist(), "max end:", int((T[:, 5] - t0).max()), "max start:", int((T[:, 0] - t0).max()))
-
-if os.environ.get("GRAPH_PROBE"):
-    import ctypes as C
-    out = (C.c_double * 2)()
-    ctx.L.roms_hip_graph_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
-    ctx.set_stepping(iif=2, predictor=1, kstp=2, krhs=1, knew=3)
-    r = ctx.L.roms_hip_graph_probe(ctx.h, 59, 20, out)
-    print("graph probe rc", r, "us/launch plain %.2f graph %.2f" % (out[0], out[1]))
-
-if os.environ.get("GRAPH_STEP_PROBE"):
-    import ctypes as C
-    out = (C.c_double * 3)()
-    ctx.L.roms_hip_graph_step_probe.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
-    r = ctx.L.roms_hip_graph_step_probe(ctx.h, 20, out)
-    print("graph step probe rc", r, "us/step plain %.1f graph %.1f nodes %d" % (out[0], out[1], int(out[2])), hiplib.last_error() if r else "")
