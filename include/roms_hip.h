@@ -139,6 +139,10 @@ int roms_hip_bulk_flux(roms_hip_ctx *ctx);     /* bulk_flux      bulk_flux.F:100
    the un-normalised kinetic / potential energy sums (a multi-tile caller adds out[3], out[12],
    out[13] over the tiles and takes the maximum of out[4], out[11], as mp_reduce does in diag.F:331) */
 int roms_hip_diag(roms_hip_ctx *ctx, double *out);
+/* The report of the last diag that ran INSIDE roms_hip_main3d (main3d.F:355: at the start of every step
+   with MOD(iic-1,ninfo) = 0), same layout; out[14] = the step count iic-1 it belongs to, or -1 if none
+   ran yet.  Synchronises.  This is what the reference prints per NINFO steps (diag.F:473-500). */
+int roms_hip_last_diag(roms_hip_ctx *ctx, double *out);
 
 /* initial.F:549-577 tail (set_massflux, omega, rho_eos at iic = ntstart) */
 int roms_hip_start(roms_hip_ctx *ctx);

@@ -875,7 +875,7 @@ static int main3d_one(roms_hip_ctx *c) {
   }
   side_begin(c);
   r = 0;
-  if (do_diag) { r = run_diag_async(c, c->d_diag); c->diag_ran = true; }   // reads u, v, rho, wvel ... of this point of the step
+  if (do_diag) { r = run_diag_async(c, c->d_diag); c->diag_ran = true; c->diag_step = s.iic - 1; }   // reads u, v, rho, wvel ... of this point of the step
   if (!r && side_chain) {
     r = roms_hip_set_massflux(c);
     if (!r) r = roms_hip_omega(c);
@@ -940,6 +940,17 @@ static int main3d_one(roms_hip_ctx *c) {
   s.time = s.time + cf.dt;
   ctx_sync_stepping(c);
 #undef DO
+  return 0;
+}
+
+extern "C" int roms_hip_last_diag(roms_hip_ctx *c, double *out) {
+  if (!c || !out) return 8;
+  for (int k = 0; k < 16; k++) out[k] = 0.0;
+  out[14] = -1.0;
+  if (c->diag_step < 0) return 0;
+  int r = fetch_diag(c, c->d_diag, out);
+  if (r) return r;
+  out[14] = (double)c->diag_step;
   return 0;
 }
 

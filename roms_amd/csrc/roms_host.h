@@ -39,6 +39,7 @@ struct roms_hip_ctx {
   bool swdk_ready;              // main3d_one has launched k_swdk already (side stream): run_pre_step3d skips it
   bool m2d_dirty;               // grid arrays uploaded since Fields::m2r/m2p were packed (g_step2d.cpp)
   bool diag_ran;                // a diag report was enqueued since the last blow-up test (roms_hip_main3d)
+  int diag_step = -1;           // step count (iic-1) of the report in d_diag, -1: none yet
   DGrid G;
   Fields F;                     // host copy of the pointer table
   Fields *d_F;                  // the same table in device memory: kernels take it by pointer, which

@@ -1,36 +1,38 @@
-!  romsM -- stand-alone driver: romsM roms.in [kernels]
-!  Mirrors ROMS/Drivers/nl_roms.h (ROMS_initialize / ROMS_run / ROMS_finalize) for the forward
-!  nonlinear model with the time step executed on the MI355X.
+!  romsM -- stand-alone driver:  romsM roms.in [application header] [kernels]
+!  The shape of ROMS/Drivers/nl_roms.h (ROMS_initialize / ROMS_run / ROMS_finalize) for the forward
+!  nonlinear model with the time step executed on the MI355X; standard output carries the run
+!  report of diag.F:446-500 (one entry per NINFO steps) in the reference's own layout.
       PROGRAM romsM
       USE, INTRINSIC :: iso_c_binding
       USE roms_hip
       USE roms_host
       implicit none
-      character(len=512) :: infile, arg2
-      integer :: ierr, istep, nchunk, mode
+      character(len=512) :: infile, arg
+      integer :: ierr, done, chunk, mode, k
       real(c_double) :: d(16)
       integer(8) :: c0, c1, crate
       IF (COMMAND_ARGUMENT_COUNT().lt.1) THEN
-        print '(a)', ' usage: romsM roms.in [kernels]'
+        print '(a)', ' usage: romsM roms.in [application header.h] [kernels]'
         STOP 8
       END IF
       CALL GET_COMMAND_ARGUMENT (1, infile)
       mode=0
-      IF (COMMAND_ARGUMENT_COUNT().ge.2) THEN
-        CALL GET_COMMAND_ARGUMENT (2, arg2)
-        IF (TRIM(arg2).eq.'kernels') mode=1
-      END IF
+      DO k=2,COMMAND_ARGUMENT_COUNT()
+        CALL GET_COMMAND_ARGUMENT (k, arg)
+        IF (TRIM(arg).eq.'kernels') THEN
+          mode=1                                  ! main3d kernel by kernel through the C ABI
+        ELSE
+          app_header=arg
+        END IF
+      END DO
       CALL read_roms_in (TRIM(infile), ierr)
+      IF (ierr.eq.0) CALL host_setup (ierr)
       IF (ierr.ne.0) THEN
-        print '(a,a)', ' romsM: cannot read ', TRIM(infile)
-        STOP 2
-      END IF
-      CALL host_setup (ierr)
-      IF (ierr.ne.0) THEN
-        print '(a,i0)', ' romsM: set-up failed, exit_flag = ', ierr
+        print '(a,i0,2a)', ' romsM: set-up stopped, exit_flag = ', ierr, ': ', TRIM(host_message)
         STOP 5
       END IF
-      print '(1x,a,a,3(1x,i0),a,i0,a,f8.2)', TRIM(MyAppCPP), ':', Lm, Mm, N, '  nfast = ', nfast, '  dt = ', dt
+      print '(1x,a,a,3(1x,i0),a,i0,a,f8.2,a,i0,a)', TRIM(MyAppCPP), ':', Lm, Mm, N, '  nfast = ', nfast,           &
+     &      '  dt = ', dt, '  (', n_unused_keys, ' roms.in keywords not used by the time step)'
       IF (NtileI*NtileJ.ne.1) THEN
         print '(a)', ' romsM: one process drives one GPU tile; multi-GPU runs are launched through roms_amd.tiling'
         STOP 5
@@ -41,32 +43,91 @@
         print '(a,i0)', ' romsM: device initialisation failed, exit_flag = ', ierr
         STOP 2
       END IF
-      print '(a)', '   STEP   time[DAYS]  KINETIC_ENRG   POTEN_ENRG    TOTAL_ENRG    NET_VOLUME'
+      print '(/,1x,a,1x,a,2x,a,3x,a,4x,a,4x,a)', 'TIME-STEP', 'YYYY-MM-DD hh:mm:ss.ss', 'KINETIC_ENRG',           &
+     &      'POTEN_ENRG', 'TOTAL_ENRG', 'NET_VOLUME'
+      print '(21x,a,7x,a,12x,a,10x,a,7x,a,/)', 'C => (i,j,k)', 'Cu', 'Cv', '  Cw  ', 'Max Speed'
       CALL SYSTEM_CLOCK (c0, crate)
-      nchunk=MAX(1,ninfo)
-      istep=0
-      DO WHILE (istep.lt.ntimes)
-        nchunk=MIN(nchunk, ntimes-istep)
+      chunk=MAX(1,ninfo)
+      done=0
+      DO WHILE (done.lt.ntimes)
+        chunk=MIN(chunk, ntimes-done)
         IF (mode.eq.0) THEN
-          ierr=roms_hip_main3d(ctx, nchunk)
+          ierr=roms_hip_main3d(ctx, chunk)        ! its first step is a NINFO point: diag ran inside it
+          IF (ierr.eq.0) ierr=roms_hip_last_diag(ctx, d)
         ELSE
-          CALL main3d_kernels (nchunk, ierr)
+          ierr=roms_hip_get_stepping(ctx, step)   ! kernel by kernel: diag where main3d.F:355 has it
+          step%nstp=1+MOD(step%iic-1,2)
+          ierr=roms_hip_set_stepping(ctx, step)
+          ierr=roms_hip_diag(ctx, d)
+          d(15)=REAL(done,c_double)
+          IF (ierr.eq.0) CALL main3d_kernels (chunk, ierr)
         END IF
-        istep=istep+nchunk
         IF (ierr.ne.0) EXIT
-        ierr=roms_hip_diag(ctx, d)
-        print '(i7,f12.5,4(1pe14.6))', istep, (dstart*86400.0_dp+REAL(istep,dp)*dt)/86400.0_dp, d(1), d(2), d(3), d(4)
-        IF (ierr.ne.0) EXIT
+        CALL report (NINT(d(15)), d)
+        done=done+chunk
       END DO
+      IF (ierr.eq.0) THEN                         ! the entry of the final state (the reference's last pass)
+        ierr=roms_hip_get_stepping(ctx, step)
+        step%nstp=1+MOD(step%iic-1,2)
+        ierr=roms_hip_set_stepping(ctx, step)
+        ierr=roms_hip_diag(ctx, d)
+        IF (ierr.eq.0) CALL report (done, d)
+      END IF
       ierr=MAX(ierr, roms_hip_sync(ctx))
       CALL SYSTEM_CLOCK (c1)
       IF (ierr.ne.0) THEN
         print '(a,i0)', ' romsM: blowing-up or device error, exit_flag = ', ierr
         STOP 1
       END IF
-      print '(a,f10.3,a,1pe12.4,a)', ' Elapsed wall time: ', REAL(c1-c0,dp)/REAL(crate,dp), ' s   (',             &
+      print '(/,a,f10.3,a,1pe12.4,a)', ' Elapsed wall time: ', REAL(c1-c0,dp)/REAL(crate,dp), ' s   (',           &
      &      REAL(Lm,dp)*REAL(Mm,dp)*REAL(N,dp)*REAL(ntimes,dp)*REAL(crate,dp)/REAL(MAX(c1-c0,1_8),dp),           &
      &      ' grid-cell-updates/sec)'
       ierr=roms_hip_destroy(ctx)
       print '(a)', ' ROMS: DONE'
+
+      CONTAINS
+!
+!  One entry of the run report, diag.F FORMAT 30 and the (i,j,k) Courant-number line built at :476-484.
+!
+      SUBROUTINE report (istep, dg)
+      integer, intent(in) :: istep
+      real(c_double), intent(in) :: dg(16)
+      character(len=80) :: frmt
+      integer :: di, dj, dk
+      di=INT(LOG10(REAL(MAX(Lm,1),dp)))+1
+      dj=INT(LOG10(REAL(MAX(Mm,1),dp)))+1
+      dk=INT(LOG10(REAL(MAX(N,1),dp)))+1
+      print '(i10,1x,a,4(1pe14.6))', istep, model_date(dstart*86400.0_dp+REAL(istep,dp)*dt), dg(1:4)
+      write (frmt,'(a,i2.2,a,3(a,i1,a,i1),a)') '(', 35-(6+di+dj+dk), 'x,"("', ',i', di, '.', di, ',",",i', dj,      &
+     &       '.', dj, ',",",i', dk, '.', dk, ',")",t35,4(1pe13.6,1x))'
+      print frmt, NINT(dg(9)), NINT(dg(10)), NINT(dg(11)), dg(6), dg(7), dg(8), dg(5)
+      END SUBROUTINE report
+!
+!  "YYYY-MM-DD hh:mm:ss.ss" of model time t (seconds) for TIME_REF = 0: days counted from 0001-01-01
+!  in the proleptic Gregorian calendar (what time_string / caldate give for that reference date).
+!
+      FUNCTION model_date (tsec) RESULT (str)
+      real(dp), intent(in) :: tsec
+      character(len=22) :: str
+      integer(8) :: days, era, doe, yoe, doy, mp, y, m, dd
+      real(dp) :: sod
+      integer :: hh, mi
+      days=FLOOR(tsec/86400.0_dp, 8)
+      sod=tsec-REAL(days,dp)*86400.0_dp
+      days=days+306_8                              ! civil-from-days with the epoch moved to 0000-03-01
+      era=days/146097_8
+      doe=days-era*146097_8
+      yoe=(doe-doe/1460_8+doe/36524_8-doe/146096_8)/365_8
+      y=yoe+era*400_8
+      doy=doe-(365_8*yoe+yoe/4_8-yoe/100_8)
+      mp=(5_8*doy+2_8)/153_8
+      dd=doy-(153_8*mp+2_8)/5_8+1_8
+      m=MERGE(mp+3_8, mp-9_8, mp.lt.10_8)
+      IF (m.le.2_8) y=y+1_8
+      hh=INT(sod/3600.0_dp)
+      mi=INT((sod-3600.0_dp*hh)/60.0_dp)
+      write (str,'(i4.4,a,i2.2,a,i2.2,1x,i2.2,a,i2.2,a,f5.2)') y, '-', m, '-', dd, hh, ':', mi, ':',               &
+     &       sod-3600.0_dp*hh-60.0_dp*mi
+      IF (str(18:18).eq.' ') str(18:18)='0'
+      END FUNCTION model_date
       END PROGRAM romsM

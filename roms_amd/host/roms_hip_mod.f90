@@ -120,6 +120,12 @@
           real(c_double), intent(out) :: out(*)
           integer(c_int) :: ierr
         END FUNCTION
+        FUNCTION roms_hip_last_diag (ctx, out) bind(C, name='roms_hip_last_diag') RESULT (ierr)
+          IMPORT :: c_int, c_ptr, c_double
+          TYPE (c_ptr), value :: ctx
+          real(c_double), intent(out) :: out(*)
+          integer(c_int) :: ierr
+        END FUNCTION
         FUNCTION roms_hip_start (ctx) bind(C, name='roms_hip_start') RESULT (ierr)
           IMPORT :: c_int, c_ptr
           TYPE (c_ptr), value :: ctx

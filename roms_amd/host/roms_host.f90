@@ -31,6 +31,14 @@
       real(dp) :: rdrg = 3.0E-4_dp, rdrg2 = 3.0E-3_dp, Zob = 0.02_dp, Zos = 0.02_dp, gamma2 = 1.0_dp
       real(dp) :: dstart = 0.0_dp, time_ref = 0.0_dp, blk_ZQ = 10.0_dp, blk_ZT = 10.0_dp, blk_ZW = 10.0_dp
       integer :: options = 0
+      character(len=512) :: app_header = ' '      ! application header to read the cpp options from (optional)
+      character(len=256) :: host_message = ' '    ! why the last set-up step returned a non-zero exit_flag
+      integer :: n_unused_keys = 0                ! roms.in keywords this build has no use for (output, nesting ...)
+      integer :: lbc_seen = 0
+      character(len=32) :: defs(256)              ! cpp options defined by the application header
+      integer :: ndefs = 0
+      character(len=64) :: xtok(64)               ! tokens of the #if condition being evaluated
+      integer :: nxtok = 0, xpos = 1
 
 !  ---- derived ----
       integer :: Nghost, Im, Jm, LBi, UBi, LBj, UBj, nfast
@@ -72,8 +80,12 @@
       logical :: cont
       ierr=0
       CALL set_defaults ()
+      host_message=' '
+      n_unused_keys=0
+      lbc_seen=0
       open (newunit=iu, file=TRIM(fname), status='old', action='read', iostat=ios)
       IF (ios.ne.0) THEN
+        host_message='cannot open '//TRIM(fname)
         ierr=2
         RETURN
       END IF
@@ -116,9 +128,29 @@
           CASE ('NINFO');       ninfo=toint(tok(1))
           CASE ('Hadvection');  CALL load_tadv (tok, nv, hadv)
           CASE ('Vadvection');  CALL load_tadv (tok, nv, vadv)
-          CASE ('LBC(isFsur)')
-            EWperiodic=(tok(1)(1:3).eq.'Per')
-            IF (nv.ge.2) NSperiodic=(tok(2)(1:3).eq.'Per')
+          CASE ('LBC(isFsur)', 'LBC(isUbar)', 'LBC(isVbar)', 'LBC(isUvel)', 'LBC(isVvel)', 'LBC(isMtke)',    &
+     &          'LBC(isTvar)')
+            CALL load_lbc (TRIM(key), tok, nv, ierr)
+            IF (ierr.ne.0) EXIT
+          CASE ('Ngrids', 'NestLayers', 'GridsInLayer')
+            IF (toint(tok(1)).ne.1) CALL unsupported (TRIM(key)//' > 1: nested grids are not built', ierr)
+            IF (ierr.ne.0) EXIT
+          CASE ('NBT', 'NST', 'NPT', 'NCS', 'NNS')
+            IF (toint(tok(1)).ne.0) CALL unsupported (TRIM(key)//' > 0: only the active tracers are built', ierr)
+            IF (ierr.ne.0) EXIT
+          CASE ('NRREC')
+            IF (toint(tok(1)).ne.0) CALL unsupported ('NRREC /= 0: restart input (NetCDF) is not built', ierr)
+            IF (ierr.ne.0) EXIT
+          CASE ('LuvSrc', 'LwSrc', 'LtracerSrc', 'LuvSponge', 'LtracerSponge', 'LsshCLM', 'Lm2CLM', 'Lm3CLM',     &
+     &          'LtracerCLM', 'LnudgeM2CLM', 'LnudgeM3CLM', 'LnudgeTCLM', 'VolCons(west)', 'VolCons(east)',      &
+     &          'VolCons(south)', 'VolCons(north)')
+            DO itr=1,nv
+              IF (tok(itr)(1:1).eq.'T'.or.tok(itr)(1:1).eq.'t') THEN
+                CALL unsupported (TRIM(key)//' == T: point sources, sponges, climatology nudging and '//       &
+     &                            'volume conservation are not built', ierr)
+              END IF
+            END DO
+            IF (ierr.ne.0) EXIT
           CASE ('TNU2');        CALL load_r (tok, nv, tnu2)
           CASE ('VISC2');       visc2=toreal(tok(1))
           CASE ('AKT_BAK');     CALL load_r (tok, nv, Akt_bak)
@@ -146,10 +178,68 @@
           CASE ('SCOEF');       Scoef=toreal(tok(1))
           CASE ('GAMMA2');      gamma2=toreal(tok(1))
           CASE DEFAULT
+!  as in read_phypar.F, a keyword no CASE claims is skipped; here that covers everything the time
+!  step never reads (titles, file names, output switches and frequencies, adjoint/4D-Var entries)
+            n_unused_keys=n_unused_keys+1
         END SELECT
       END DO
       close (iu)
       END SUBROUTINE read_roms_in
+!
+!  A recognised setting that selects code this build does not have: stop as checkdefs.F / inp_par.F
+!  do for illegal configurations (exit_flag = 5) instead of running with different physics.
+!
+      SUBROUTINE unsupported (what, ierr)
+      character(len=*), intent(in) :: what
+      integer, intent(inout) :: ierr
+      host_message=what
+      ierr=5
+      END SUBROUTINE unsupported
+!
+!  Lateral boundary conditions, load_lbc (Utility/inp_decode.F): four values per variable in the
+!  order west south east north (isTvar: one set per tracer on continuation lines).  Built here:
+!  periodic ("Per") and closed ("Clo"); every variable must share the periodicity of the grid.
+!
+      SUBROUTINE load_lbc (key, tok, nv, ierr)
+      character(len=*), intent(in) :: key
+      character(len=64), intent(in) :: tok(16)
+      integer, intent(in) :: nv
+      integer, intent(inout) :: ierr
+      integer :: k, side
+      logical :: per(4)
+      character(len=64) :: val
+      IF (nv.lt.4.or.MOD(nv,4).ne.0) THEN
+        CALL unsupported (key//': expected west south east north', ierr)
+        RETURN
+      END IF
+      DO k=1,nv
+        val=upper(tok(k))
+        IF (TRIM(val).ne.'PER'.and.TRIM(val).ne.'CLO') THEN
+          CALL unsupported (key//' = '//TRIM(tok(k))//': only periodic (Per) and closed (Clo) boundaries '//   &
+     &                      'are built (no Cha/Cla/Fla/Gra/Nes/Rad/Red/Shc)', ierr)
+          RETURN
+        END IF
+        side=MOD(k-1,4)+1
+        IF (k.le.4) THEN
+          per(side)=TRIM(val).eq.'PER'
+        ELSE IF (per(side).neqv.(TRIM(val).eq.'PER')) THEN
+          CALL unsupported (key//': tracers disagree on periodicity', ierr)
+          RETURN
+        END IF
+      END DO
+      IF ((per(1).neqv.per(3)).or.(per(2).neqv.per(4))) THEN
+        CALL unsupported (key//': a periodic edge needs its opposite edge periodic too', ierr)
+        RETURN
+      END IF
+      IF (lbc_seen.eq.0) THEN
+        EWperiodic=per(1)
+        NSperiodic=per(2)
+      ELSE IF ((per(1).neqv.EWperiodic).or.(per(2).neqv.NSperiodic)) THEN
+        CALL unsupported (key//': periodicity differs from the other state variables', ierr)
+        RETURN
+      END IF
+      lbc_seen=lbc_seen+1
+      END SUBROUTINE load_lbc
 
       SUBROUTINE set_defaults ()          ! roms_upwelling.in values, so that a partial file is usable
       MyAppCPP='UPWELLING'
@@ -220,49 +310,398 @@
       END DO
       END SUBROUTINE load_r
 
+      FUNCTION upper (w) RESULT (u_)
+      character(len=*), intent(in) :: w
+      character(len=LEN(w)) :: u_
+      integer :: k, c
+      u_=w
+      DO k=1,LEN_TRIM(w)
+        c=IACHAR(w(k:k))
+        IF (c.ge.IACHAR('a').and.c.le.IACHAR('z')) u_(k:k)=ACHAR(c-32)
+      END DO
+      END FUNCTION upper
+
       SUBROUTINE load_tadv (tok, nv, adv)       ! load_tadv, Utility/inp_decode.F
       character(len=64), intent(in) :: tok(16)
       integer, intent(in) :: nv
       integer, intent(inout) :: adv(:)
       integer :: k
       DO k=1,MIN(nv,SIZE(adv))
-        SELECT CASE (TRIM(tok(k)))
-          CASE ('A4');     adv(k)=ROMS_A4
-          CASE ('C2');     adv(k)=ROMS_C2
-          CASE ('C4');     adv(k)=ROMS_C4
-          CASE ('HSIMT');  adv(k)=ROMS_HSIMT
-          CASE ('MPDATA'); adv(k)=ROMS_MPDATA
-          CASE ('SP');     adv(k)=ROMS_SPLINES
-          CASE ('SU3');    adv(k)=ROMS_SPLIT_U3
-          CASE ('U3');     adv(k)=ROMS_U3
+        SELECT CASE (TRIM(upper(tok(k))))            ! the spellings inp_decode.F:2557-2571 accepts
+          CASE ('A4', 'AKIMA4');          adv(k)=ROMS_A4
+          CASE ('C2', 'CENTERED2');       adv(k)=ROMS_C2
+          CASE ('C4', 'CENTERED4');       adv(k)=ROMS_C4
+          CASE ('HS', 'HSIMT');           adv(k)=ROMS_HSIMT
+          CASE ('MP', 'MPDATA');          adv(k)=ROMS_MPDATA
+          CASE ('SP', 'SPLINES');         adv(k)=ROMS_SPLINES
+          CASE ('SU', 'SU3', 'SPLIT_U3'); adv(k)=ROMS_SPLIT_U3
+          CASE ('U3', 'UPSTREAM3');       adv(k)=ROMS_U3
+          CASE DEFAULT;                   adv(k)=-1          ! reported by host_setup
         END SELECT
       END DO
       END SUBROUTINE load_tadv
 !
 !=======================================================================
-!  cpp options of the application header (ROMS/Include/upwelling.h, benchmark.h + globaldefs.h)
+!  cpp options.  The reference fixes them at compile time in ROMS/Include/<application>.h (through
+!  cppdefs.h); this build carries every option's code and selects at run time, so the SAME header
+!  is read here: read_app_header understands the directives those files use (#define, #undef,
+!  #ifdef, #ifndef, #if/#elif with defined, !, &&, ||, parentheses, #else, #endif, C comments,
+!  "\" continuation) and options_from_defines turns the resulting set into the option mask of
+!  include/roms_hip.h -- or stops with exit_flag 5 naming the option whose code is not built, the
+!  way checkdefs.F stops on an illegal combination.  Without a header file the option lists of the
+!  three BASELINE applications below are used.
 !=======================================================================
 !
+      LOGICAL FUNCTION is_defined (name)
+      character(len=*), intent(in) :: name
+      integer :: k
+      is_defined=.FALSE.
+      DO k=1,ndefs
+        IF (TRIM(defs(k)).eq.TRIM(name)) is_defined=.TRUE.
+      END DO
+      END FUNCTION is_defined
+
+      SUBROUTINE define (name)
+      character(len=*), intent(in) :: name
+      IF (is_defined(name).or.LEN_TRIM(name).eq.0) RETURN
+      IF (ndefs.lt.SIZE(defs)) THEN
+        ndefs=ndefs+1
+        defs(ndefs)=name
+      END IF
+      END SUBROUTINE define
+
+      SUBROUTINE undefine (name)
+      character(len=*), intent(in) :: name
+      integer :: k, m
+      m=0
+      DO k=1,ndefs
+        IF (TRIM(defs(k)).ne.TRIM(name)) THEN
+          m=m+1
+          defs(m)=defs(k)
+        END IF
+      END DO
+      ndefs=m
+      END SUBROUTINE undefine
+!
+!  #if expression:  or := and { "||" and } ;  and := unary { "&&" unary } ;
+!                   unary := "!" unary | "(" or ")" | "defined" [ "(" ] NAME [ ")" ] | NAME | integer
+!
+      SUBROUTINE lex_condition (text)
+      character(len=*), intent(in) :: text
+      integer :: i, i0, L
+      nxtok=0
+      xpos=1
+      L=LEN_TRIM(text)
+      i=1
+      DO WHILE (i.le.L.and.nxtok.lt.SIZE(xtok))
+        SELECT CASE (text(i:i))
+          CASE (' ', ACHAR(9))
+            i=i+1
+          CASE ('(', ')', '!')
+            nxtok=nxtok+1
+            xtok(nxtok)=text(i:i)
+            i=i+1
+          CASE ('|', '&')
+            nxtok=nxtok+1
+            xtok(nxtok)=text(i:i)//text(i:i)
+            i=i+2
+          CASE DEFAULT
+            i0=i
+            DO WHILE (i.le.L)
+              IF (INDEX(' ()!|&'//ACHAR(9), text(i:i)).gt.0) EXIT
+              i=i+1
+            END DO
+            nxtok=nxtok+1
+            xtok(nxtok)=text(i0:i-1)
+        END SELECT
+      END DO
+      END SUBROUTINE lex_condition
+
+      RECURSIVE FUNCTION cond_or () RESULT (val)
+      logical :: val, rhs
+      val=cond_and()
+      DO WHILE (xpos.le.nxtok)
+        IF (xtok(xpos).ne.'||') EXIT
+        xpos=xpos+1
+        rhs=cond_and()
+        val=val.or.rhs
+      END DO
+      END FUNCTION cond_or
+
+      RECURSIVE FUNCTION cond_and () RESULT (val)
+      logical :: val, rhs
+      val=cond_unary()
+      DO WHILE (xpos.le.nxtok)
+        IF (xtok(xpos).ne.'&&') EXIT
+        xpos=xpos+1
+        rhs=cond_unary()
+        val=val.and.rhs
+      END DO
+      END FUNCTION cond_and
+
+      RECURSIVE FUNCTION cond_unary () RESULT (val)
+      logical :: val, paren
+      integer :: number, ios
+      val=.FALSE.
+      IF (xpos.gt.nxtok) RETURN
+      IF (xtok(xpos).eq.'!') THEN
+        xpos=xpos+1
+        val=.not.cond_unary()
+      ELSE IF (xtok(xpos).eq.'(') THEN
+        xpos=xpos+1
+        val=cond_or()
+        IF (xpos.le.nxtok) xpos=xpos+1            ! ")"
+      ELSE IF (xtok(xpos).eq.'defined') THEN
+        xpos=xpos+1
+        paren=.FALSE.
+        IF (xpos.le.nxtok) paren=xtok(xpos).eq.'('
+        IF (paren) xpos=xpos+1
+        IF (xpos.le.nxtok) val=is_defined(xtok(xpos))
+        xpos=xpos+1
+        IF (paren) xpos=xpos+1
+      ELSE
+        read (xtok(xpos),*,iostat=ios) number      ! "#if 0"
+        IF (ios.eq.0) THEN
+          val=number.ne.0
+        ELSE
+          val=is_defined(xtok(xpos))                ! a bare macro name counts as defined-and-non-zero
+        END IF
+        xpos=xpos+1
+      END IF
+      END FUNCTION cond_unary
+
+      SUBROUTINE read_app_header (fname, ierr)
+      character(len=*), intent(in) :: fname
+      integer, intent(inout) :: ierr
+      integer, parameter :: maxdepth = 32
+      logical :: live(0:maxdepth), done(0:maxdepth), in_comment, more
+      integer :: iu, ios, depth, i, L
+      character(len=1024) :: raw, code, stmt
+      character(len=64) :: word, name
+      open (newunit=iu, file=TRIM(fname), status='old', action='read', iostat=ios)
+      IF (ios.ne.0) THEN
+        host_message='cannot open the application header '//TRIM(fname)
+        ierr=2
+        RETURN
+      END IF
+      depth=0
+      live(0)=.TRUE.
+      done(0)=.TRUE.
+      in_comment=.FALSE.
+      stmt=' '
+      DO
+        read (iu,'(a)',iostat=ios) raw
+        IF (ios.ne.0) EXIT
+        code=' '                                   ! the line without its C comments
+        L=LEN_TRIM(raw)
+        i=1
+        DO WHILE (i.le.L)
+          IF (in_comment) THEN
+            IF (raw(i:MIN(i+1,L)).eq.'*/') THEN
+              in_comment=.FALSE.
+              i=i+2
+            ELSE
+              i=i+1
+            END IF
+          ELSE IF (raw(i:MIN(i+1,L)).eq.'/*') THEN
+            in_comment=.TRUE.
+            i=i+2
+          ELSE
+            code(i:i)=raw(i:i)
+            i=i+1
+          END IF
+        END DO
+        more=.FALSE.
+        L=LEN_TRIM(code)
+        IF (L.gt.0) more=code(L:L).eq.'\\'
+        IF (more) code(L:L)=' '
+        stmt=TRIM(stmt)//' '//TRIM(ADJUSTL(code))
+        IF (more) CYCLE
+        stmt=ADJUSTL(stmt)
+        IF (stmt(1:1).eq.'#') THEN
+          stmt=ADJUSTL(stmt(2:))
+          i=SCAN(stmt,' ')
+          word=stmt(1:i-1)
+          stmt=ADJUSTL(stmt(i:))
+          i=SCAN(stmt,' ')
+          name=stmt(1:MAX(i-1,1))
+          SELECT CASE (TRIM(word))
+            CASE ('define')
+              IF (live(depth)) CALL define (TRIM(name))
+            CASE ('undef')
+              IF (live(depth)) CALL undefine (TRIM(name))
+            CASE ('ifdef', 'ifndef', 'if')
+              IF (depth.ge.maxdepth) THEN
+                CALL unsupported (TRIM(fname)//': conditionals nested too deep', ierr)
+                EXIT
+              END IF
+              depth=depth+1
+              IF (TRIM(word).eq.'ifdef') THEN
+                live(depth)=is_defined(TRIM(name))
+              ELSE IF (TRIM(word).eq.'ifndef') THEN
+                live(depth)=.not.is_defined(TRIM(name))
+              ELSE
+                CALL lex_condition (stmt)
+                live(depth)=cond_or()
+              END IF
+              live(depth)=live(depth).and.live(depth-1)
+              done(depth)=live(depth).or..not.live(depth-1)
+            CASE ('elif')
+              IF (depth.gt.0) THEN
+                IF (done(depth)) THEN
+                  live(depth)=.FALSE.
+                ELSE
+                  CALL lex_condition (stmt)
+                  live(depth)=cond_or()
+                  done(depth)=live(depth)
+                END IF
+              END IF
+            CASE ('else')
+              IF (depth.gt.0) THEN
+                live(depth)=.not.done(depth)
+                done(depth)=.TRUE.
+              END IF
+            CASE ('endif')
+              depth=MAX(depth-1,0)
+          END SELECT
+        END IF
+        stmt=' '
+      END DO
+      close (iu)
+      END SUBROUTINE read_app_header
+!
+!  The option lists of the BASELINE applications (what ROMS/Include/upwelling.h and benchmark.h
+!  define for a forward run without output options; UPWELLING_KPP = BASELINE config 5's custom
+!  header: UPWELLING with the LMD/KPP closure in place of the analytic mixing).
+!
+      SUBROUTINE builtin_defines (ierr)
+      integer, intent(inout) :: ierr
+      integer :: k
+      character(len=16), parameter :: common(9) = [ character(len=16) :: 'SOLVE3D', 'SALINITY', 'UV_ADV',        &
+     &    'UV_COR', 'UV_VIS2', 'MIX_S_UV', 'TS_DIF2', 'DJ_GRADPS', 'ANA_GRID' ]
+      character(len=16), parameter :: kpp(7) = [ character(len=16) :: 'LMD_MIXING', 'LMD_RIMIX', 'LMD_CONVEC',    &
+     &    'LMD_SKPP', 'LMD_NONLOCAL', 'RI_SPLINES', 'SOLAR_SOURCE' ]
+      character(len=16), parameter :: flux0(5) = [ character(len=16) :: 'ANA_SMFLUX', 'ANA_STFLUX', 'ANA_SSFLUX', &
+     &    'ANA_BTFLUX', 'ANA_BSFLUX' ]
+      character(len=16), parameter :: bulk(9) = [ character(len=16) :: 'BULK_FLUXES', 'LONGWAVE', 'ANA_WINDS',    &
+     &    'ANA_TAIR', 'ANA_PAIR', 'ANA_HUMIDITY', 'ANA_RAIN', 'ANA_CLOUD', 'ALBEDO' ]
+      DO k=1,SIZE(common)
+        CALL define (TRIM(common(k)))
+      END DO
+      CALL define ('ANA_INITIAL'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
+      SELECT CASE (TRIM(MyAppCPP))
+        CASE ('UPWELLING', 'UPWELLING_KPP')
+          CALL define ('UV_LDRAG'); CALL define ('MIX_S_TS')
+          DO k=1,SIZE(flux0)
+            CALL define (TRIM(flux0(k)))
+          END DO
+          IF (TRIM(MyAppCPP).eq.'UPWELLING') THEN
+            CALL define ('ANA_VMIX')
+          ELSE
+            DO k=1,SIZE(kpp)
+              CALL define (TRIM(kpp(k)))
+            END DO
+            CALL define ('ANA_SRFLUX')
+          END IF
+        CASE ('BENCHMARK')
+          CALL define ('UV_QDRAG'); CALL define ('MIX_GEO_TS'); CALL define ('NONLIN_EOS')
+          CALL define ('CURVGRID'); CALL define ('SPHERICAL'); CALL define ('ANA_SRFLUX')
+          CALL define ('ANA_SSFLUX'); CALL define ('ANA_BSFLUX'); CALL define ('ANA_BTFLUX')
+          DO k=1,SIZE(kpp)
+            CALL define (TRIM(kpp(k)))
+          END DO
+          DO k=1,SIZE(bulk)
+            CALL define (TRIM(bulk(k)))
+          END DO
+        CASE DEFAULT
+          CALL unsupported ('MyAppCPP = '//TRIM(MyAppCPP)//': no built-in option list; give the '//             &
+     &                      'application header (ROMS_APP_HEADER / second argument of romsM)', ierr)
+      END SELECT
+      END SUBROUTINE builtin_defines
+!
+!  defined options -> option mask, or exit_flag 5 with the reason.
+!
+      SUBROUTINE options_from_defines (ierr)
+      integer, intent(inout) :: ierr
+      integer :: k
+      logical :: upw, bench
+!  options with a bit in the mask (include/roms_hip.h)
+      character(len=16), parameter :: bitname(14) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
+     &    'TS_DIF2', 'MIX_GEO_TS', 'CURVGRID', 'NONLIN_EOS', 'UV_QDRAG', 'LMD_MIXING', 'BULK_FLUXES',           &
+     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL' ]
+      integer, parameter :: bitval(14) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
+     &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
+     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL ]
+!  options whose code is the only form built (accepted, nothing to select) or that only affect output
+      character(len=16), parameter :: inherent(31) = [ character(len=16) :: 'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
+     &    'DJ_GRADPS', 'MIX_S_UV', 'MIX_S_TS', 'SPLINES_VDIFF', 'SPLINES_VVISC', 'UV_LDRAG', 'ANA_SMFLUX',        &
+     &    'ANA_STFLUX', 'ANA_SSFLUX', 'ANA_BTFLUX', 'ANA_BSFLUX', 'ANA_SRFLUX', 'LMD_RIMIX', 'LMD_CONVEC',        &
+     &    'LMD_SKPP', 'LMD_NONLOCAL', 'RI_SPLINES', 'LONGWAVE', 'ANA_WINDS', 'ANA_TAIR', 'ANA_PAIR',             &
+     &    'ANA_HUMIDITY', 'ANA_RAIN', 'ANA_CLOUD', 'ALBEDO', 'OUT_DOUBLE', 'PERFECT_RESTART', 'NONLINEAR' ]
+      character(len=16), parameter :: output_only(3) = [ character(len=16) :: 'AVERAGES', 'DIAGNOSTICS_TS',      &
+     &    'DIAGNOSTICS_UV' ]
+      IF (ierr.ne.0) RETURN
+      upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.is_defined('UPWELLING')
+      bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.is_defined('BENCHMARK')
+      IF (upw.eqv.bench) THEN
+        CALL unsupported ('MyAppCPP = '//TRIM(MyAppCPP)//': the analytic grid, initial state and forcing '//   &
+     &                    'exist for UPWELLING and BENCHMARK', ierr)
+        RETURN
+      END IF
+      options=MERGE(ROMS_APP_UPWELLING, ROMS_APP_BENCHMARK, upw)
+      DO k=1,ndefs
+        IF (ANY(bitname.eq.defs(k))) THEN
+          options=IOR(options, bitval(FINDLOC(bitname, defs(k), 1)))
+        ELSE IF (ANY(inherent.eq.defs(k)).or.ANY(output_only.eq.defs(k))) THEN
+          CONTINUE
+        ELSE IF (TRIM(defs(k)).eq.'UPWELLING'.or.TRIM(defs(k)).eq.'BENCHMARK') THEN
+          CONTINUE
+        ELSE
+          CALL unsupported ('cpp option '//TRIM(defs(k))//' is not built into this library', ierr)
+          RETURN
+        END IF
+      END DO
+!  what the kernels assume (the combinations the BASELINE headers use)
+      IF (.not.is_defined('SOLVE3D')) CALL unsupported ('SOLVE3D is required (3-D baroclinic step)', ierr)
+      IF (.not.is_defined('DJ_GRADPS')) CALL unsupported ('DJ_GRADPS is the pressure-gradient scheme built '//   &
+     &                                                     '(prsgrd32.h)', ierr)
+      IF (is_defined('UV_LDRAG').eqv.is_defined('UV_QDRAG'))                                                    &
+     &  CALL unsupported ('exactly one of UV_LDRAG, UV_QDRAG is required', ierr)
+      IF (is_defined('UV_VIS2').and..not.is_defined('MIX_S_UV'))                                               &
+     &  CALL unsupported ('UV_VIS2 is built along s-surfaces only (MIX_S_UV)', ierr)
+      IF (is_defined('TS_DIF2').and.(is_defined('MIX_S_TS').eqv.is_defined('MIX_GEO_TS')))                     &
+     &  CALL unsupported ('TS_DIF2 needs exactly one of MIX_S_TS, MIX_GEO_TS', ierr)
+      IF (.not.(is_defined('SPLINES_VDIFF').and.is_defined('SPLINES_VVISC')))                                  &
+     &  CALL unsupported ('SPLINES_VDIFF and SPLINES_VVISC are the vertical mixing operators built', ierr)
+      IF (is_defined('ANA_VMIX').eqv.is_defined('LMD_MIXING'))                                                 &
+     &  CALL unsupported ('exactly one vertical mixing closure is required: ANA_VMIX or LMD_MIXING', ierr)
+      IF (is_defined('LMD_MIXING').and..not.(is_defined('LMD_RIMIX').and.is_defined('LMD_CONVEC').and.          &
+     &    is_defined('LMD_SKPP').and.is_defined('LMD_NONLOCAL').and.is_defined('RI_SPLINES').and.               &
+     &    is_defined('SOLAR_SOURCE')))                                                                         &
+     &  CALL unsupported ('LMD_MIXING is built with LMD_RIMIX LMD_CONVEC LMD_SKPP LMD_NONLOCAL RI_SPLINES '//   &
+     &                    'SOLAR_SOURCE', ierr)
+      IF (is_defined('BULK_FLUXES').and..not.(bench.and.is_defined('LONGWAVE').and.is_defined('ALBEDO')))       &
+     &  CALL unsupported ('BULK_FLUXES is built with the BENCHMARK analytic atmosphere (LONGWAVE, ALBEDO)', ierr)
+      IF (is_defined('ALBEDO').and..not.bench)                                                                 &
+     &  CALL unsupported ('ALBEDO (ana_srflux zenith-angle formula) is built for BENCHMARK only', ierr)
+      IF ((is_defined('SPHERICAL').or.is_defined('CURVGRID').or.is_defined('NONLIN_EOS')).and..not.bench)       &
+     &  CALL unsupported ('SPHERICAL / CURVGRID / NONLIN_EOS are built for BENCHMARK only', ierr)
+      END SUBROUTINE options_from_defines
+
       SUBROUTINE set_cppdefs (ierr)
       integer, intent(out) :: ierr
+      integer :: L
       ierr=0
-      SELECT CASE (TRIM(MyAppCPP))
-        CASE ('UPWELLING')
-          options=ROMS_UV_ADV+ROMS_UV_COR+ROMS_UV_VIS2+ROMS_TS_DIF2+ROMS_ANA_VMIX+ROMS_SALINITY+              &
-     &            ROMS_APP_UPWELLING
-        CASE ('UPWELLING_KPP')
-!  UPWELLING with the KPP closure instead of ANA_VMIX: the "custom application header" of BASELINE
-!  config 5 (upwelling.h with LMD_MIXING, LMD_RIMIX, LMD_CONVEC, LMD_SKPP, LMD_NONLOCAL, RI_SPLINES,
-!  SOLAR_SOURCE and ANA_SRFLUX (zero) in place of ANA_VMIX).
-          options=ROMS_UV_ADV+ROMS_UV_COR+ROMS_UV_VIS2+ROMS_TS_DIF2+ROMS_LMD_MIXING+ROMS_SOLAR_SOURCE+         &
-     &            ROMS_SALINITY+ROMS_APP_UPWELLING
-        CASE ('BENCHMARK')
-          options=ROMS_UV_ADV+ROMS_UV_COR+ROMS_UV_VIS2+ROMS_TS_DIF2+ROMS_MIX_GEO_TS+ROMS_CURVGRID+            &
-     &            ROMS_NONLIN_EOS+ROMS_UV_QDRAG+ROMS_LMD_MIXING+ROMS_BULK_FLUXES+ROMS_SOLAR_SOURCE+            &
-     &            ROMS_SALINITY+ROMS_SPHERICAL+ROMS_APP_BENCHMARK
-        CASE DEFAULT
-          ierr=5                        ! unknown application (checkdefs.F would stop too)
-      END SELECT
+      ndefs=0
+      IF (LEN_TRIM(app_header).eq.0) THEN
+        CALL GET_ENVIRONMENT_VARIABLE ('ROMS_APP_HEADER', app_header, L)
+      END IF
+      IF (LEN_TRIM(app_header).gt.0) THEN
+        CALL read_app_header (TRIM(app_header), ierr)
+      ELSE
+        CALL builtin_defines (ierr)
+      END IF
+      CALL options_from_defines (ierr)
       END SUBROUTINE set_cppdefs
 !
 !=======================================================================
@@ -380,336 +819,286 @@
       END SUBROUTINE exchange2d
 !
 !=======================================================================
-!  set_scoord, Utility/set_scoord.F (Vstretching 4: A. Shchepetkin 2010 double stretching)
+!  Host set-up: what a caller that embeds the library gets from the reference itself (mod_grid,
+!  mod_scalars, mod_ocean after ROMS_initialize); the stand-alone driver romsM builds it here.
+!  Every routine below is the closed form of the quantity it fills, evaluated with whole-array
+!  expressions; the arithmetic of each element is the one the reference performs (set_scoord.F,
+!  set_weights.F, ana_grid.h, metrics.F, set_depth.F, ana_initial.h), so the arrays are identical
+!  to the reference's, which tests/test_host.py asserts bit for bit against tests/golden/*_init.npz.
 !=======================================================================
 !
-      SUBROUTINE set_scoord (ierr)
+!  ---- vertical coordinate: stretching curve of A. Shchepetkin (2010), Vstretching = 4 ----------
+!       C(s) = [1-cosh(theta_s s)]/[cosh(theta_s)-1], then C <- [exp(theta_b C)-1]/[1-exp(-theta_b)]
+!       (set_scoord.F:433-475); s on the w-levels k/N-1 and on the rho-levels (k-1/2)/N-1.
+!
+      ELEMENTAL FUNCTION stretch_curve (s) RESULT (C)
+      real(dp), intent(in) :: s
+      real(dp) :: C
+      IF (theta_s.gt.0.0_dp) THEN
+        C=(1.0_dp-COSH(theta_s*s))/(COSH(theta_s)-1.0_dp)
+      ELSE
+        C=-s**2
+      END IF
+      IF (theta_b.gt.0.0_dp) C=(EXP(theta_b*C)-1.0_dp)/(1.0_dp-EXP(-theta_b))
+      END FUNCTION stretch_curve
+
+      SUBROUTINE vertical_coordinate (ierr)
       integer, intent(out) :: ierr
       integer :: k
-      real(dp) :: Cbot, Csur, ds, scr, scw
+      real(dp) :: dsig
       ierr=0
-      IF (Vtransform.eq.1) THEN
-        hc=MIN(hmin,Tcline)
-      ELSE
-        hc=Tcline
-      END IF
-      IF (Vstretching.ne.4) THEN
-        ierr=5
+      hc=MERGE(MIN(hmin,Tcline), Tcline, Vtransform.eq.1)
+      IF (Vstretching.ne.4) THEN          ! the BASELINE applications use 4
+        CALL unsupported ('Vstretching /= 4: only the Shchepetkin (2010) stretching is built', ierr)
         RETURN
       END IF
-      ds=1.0_dp/REAL(N,dp)
-      sc_w(N)=0.0_dp
-      Cs_w(N)=0.0_dp
-      DO k=N-1,1,-1
-        scw=ds*REAL(k-N,dp)
-        sc_w(k)=scw
-        IF (theta_s.gt.0.0_dp) THEN
-          Csur=(1.0_dp-COSH(theta_s*scw))/(COSH(theta_s)-1.0_dp)
-        ELSE
-          Csur=-scw**2
-        END IF
-        IF (theta_b.gt.0.0_dp) THEN
-          Cbot=(EXP(theta_b*Csur)-1.0_dp)/(1.0_dp-EXP(-theta_b))
-          Cs_w(k)=Cbot
-        ELSE
-          Cs_w(k)=Csur
-        END IF
-      END DO
-      sc_w(0)=-1.0_dp
-      Cs_w(0)=-1.0_dp
-      DO k=1,N
-        scr=ds*(REAL(k-N,dp)-0.5_dp)
-        sc_r(k)=scr
-        IF (theta_s.gt.0.0_dp) THEN
-          Csur=(1.0_dp-COSH(theta_s*scr))/(COSH(theta_s)-1.0_dp)
-        ELSE
-          Csur=-scr**2
-        END IF
-        IF (theta_b.gt.0.0_dp) THEN
-          Cbot=(EXP(theta_b*Csur)-1.0_dp)/(1.0_dp-EXP(-theta_b))
-          Cs_r(k)=Cbot
-        ELSE
-          Cs_r(k)=Csur
-        END IF
-      END DO
-      END SUBROUTINE set_scoord
+      dsig=1.0_dp/REAL(N,dp)
+      sc_w(1:N-1)=dsig*REAL([(k-N, k=1,N-1)],dp)
+      Cs_w(1:N-1)=stretch_curve(sc_w(1:N-1))
+      sc_w(0)=-1.0_dp;  Cs_w(0)=-1.0_dp          ! bottom and surface are exact by definition
+      sc_w(N)=0.0_dp;   Cs_w(N)=0.0_dp
+      sc_r(1:N)=dsig*(REAL([(k-N, k=1,N)],dp)-0.5_dp)
+      Cs_r(1:N)=stretch_curve(sc_r(1:N))
+      END SUBROUTINE vertical_coordinate
 !
-!=======================================================================
-!  set_weights, Utility/set_weights.F:56-230: power-law barotropic filter (r16 accumulators, see mod_kinds.F:50)
-!=======================================================================
+!  ---- barotropic time filter (set_weights.F:56-230) -------------------------------------------
+!       primary weights  a_m ~ B(m s),  B(x) = x**alpha - x**(alpha+beta) - gamma x,  m = 1..2 ndtfast,
+!       s iterated (16 sweeps) until the centroid of the positive lobe sits at ndtfast; the lobe is then
+!       moved by fractions of a sub-step until its centroid is exact; the secondary weights are the
+!       suffix sums b_m = sum_{m' >= m} a_m'; both sets are normalised to unit sum.
 !
-      SUBROUTINE set_weights ()
-      integer :: i, j, iter
-      real(dp) :: gamma, scale
-      real(r16) :: wsum, shift, cff
-      nfast=0
-      weight=0.0_dp
-      scale=(Falpha+1.0_dp)*(Falpha+Fbeta+1.0_dp)/                                                            &
-     &      ((Falpha+2.0_dp)*(Falpha+Fbeta+2.0_dp)*REAL(ndtfast,dp))
-      gamma=Fgamma*MAX(0.0_dp, 1.0_dp-10.0_dp/REAL(ndtfast,dp))
-      DO iter=1,16
-        nfast=0
-        DO i=1,2*ndtfast
-          cff=scale*REAL(i,dp)
-          weight(1,i)=cff**Falpha-cff**(Falpha+Fbeta)-gamma*cff
-          IF (weight(1,i).gt.0.0_dp) nfast=i
-          IF ((nfast.gt.0).and.(weight(1,i).lt.0.0_dp)) THEN
-            weight(1,i)=0.0_dp
+      PURE FUNCTION lobe_moments (a, n) RESULT (mom)      ! (sum a_m, sum m a_m), m ascending
+      real(dp), intent(in) :: a(:)
+      integer, intent(in) :: n
+      real(r16) :: mom(2)
+      integer :: m
+      mom=0.0_r16
+      DO m=1,n
+        mom(1)=mom(1)+a(m)
+        mom(2)=mom(2)+a(m)*REAL(m,dp)
+      END DO
+      END FUNCTION lobe_moments
+
+      SUBROUTINE barotropic_filter ()
+      real(dp), allocatable :: a(:), b(:)
+      real(dp) :: gam, s
+      real(r16) :: mom(2), x, lag, keep
+      integer :: m, n, sweep, last
+      logical :: in_lobe
+      allocate ( a(2*ndtfast), b(2*ndtfast) )
+      s=(Falpha+1.0_dp)*(Falpha+Fbeta+1.0_dp)/((Falpha+2.0_dp)*(Falpha+Fbeta+2.0_dp)*REAL(ndtfast,dp))
+      gam=Fgamma*MAX(0.0_dp, 1.0_dp-10.0_dp/REAL(ndtfast,dp))
+      n=0
+      DO sweep=1,16
+        in_lobe=.FALSE.
+        last=0
+        DO m=1,2*ndtfast
+          x=s*REAL(m,dp)
+          a(m)=x**Falpha-x**(Falpha+Fbeta)-gam*x
+          IF (a(m).gt.0.0_dp) THEN
+            in_lobe=.TRUE.
+            last=m
+          ELSE IF (in_lobe.and.(a(m).lt.0.0_dp)) THEN
+            a(m)=0.0_dp                   ! beyond the lobe
           END IF
         END DO
-        wsum=0.0_r16
-        shift=0.0_r16
-        DO i=1,nfast
-          wsum=wsum+weight(1,i)
-          shift=shift+weight(1,i)*REAL(i,dp)
-        END DO
-        scale=scale*shift/(wsum*REAL(ndtfast,dp))
+        n=last
+        mom=lobe_moments(a, n)
+        s=s*mom(2)/(mom(1)*REAL(ndtfast,dp))
       END DO
-      DO iter=1,ndtfast
-        wsum=0.0_r16
-        shift=0.0_r16
-        DO i=1,nfast
-          wsum=wsum+weight(1,i)
-          shift=shift+REAL(i,dp)*weight(1,i)
-        END DO
-        shift=shift/wsum
-        cff=REAL(ndtfast,dp)-shift
-        IF (cff.gt.1.0_r16) THEN
-          nfast=nfast+1
-          DO i=nfast,2,-1
-            weight(1,i)=weight(1,i-1)
-          END DO
-          weight(1,1)=0.0_dp
-        ELSE IF (cff.gt.0.0_r16) THEN
-          wsum=1.0_r16-cff
-          DO i=nfast,2,-1
-            weight(1,i)=wsum*weight(1,i)+cff*weight(1,i-1)
-          END DO
-          weight(1,1)=wsum*weight(1,1)
-        ELSE IF (cff.lt.-1.0_r16) THEN
-          nfast=nfast-1
-          DO i=1,nfast,+1
-            weight(1,i)=weight(1,i+1)
-          END DO
-          weight(1,nfast+1)=0.0_dp
-        ELSE IF (cff.lt.0.0_r16) THEN
-          wsum=1.0_r16+cff
-          DO i=1,nfast-1,+1
-            weight(1,i)=wsum*weight(1,i)-cff*weight(1,i+1)
-          END DO
-          weight(1,nfast)=wsum*weight(1,nfast)
+      DO sweep=1,ndtfast
+        mom=lobe_moments(a, n)
+        lag=REAL(ndtfast,dp)-mom(2)/mom(1)          ! sub-steps the centroid is short of ndtfast
+        IF (lag.gt.1.0_r16) THEN                    ! whole sub-step later
+          n=n+1
+          a(2:n)=a(1:n-1)
+          a(1)=0.0_dp
+        ELSE IF (lag.gt.0.0_r16) THEN               ! fraction of a sub-step later
+          keep=1.0_r16-lag
+          a(2:n)=keep*a(2:n)+lag*a(1:n-1)
+          a(1)=keep*a(1)
+        ELSE IF (lag.lt.-1.0_r16) THEN              ! whole sub-step earlier
+          n=n-1
+          a(1:n)=a(2:n+1)
+          a(n+1)=0.0_dp
+        ELSE IF (lag.lt.0.0_r16) THEN               ! fraction of a sub-step earlier
+          keep=1.0_r16+lag
+          a(1:n-1)=keep*a(1:n-1)-lag*a(2:n)
+          a(n)=keep*a(n)
         END IF
       END DO
-      DO j=1,nfast
-        cff=weight(1,j)
-        DO i=1,j
-          weight(2,i)=weight(2,i)+cff
+      b=0.0_dp
+      DO m=1,n                                      ! b_m = a_m + a_{m+1} + ... + a_n, added in that order
+        x=0.0_r16
+        DO last=m,n
+          x=x+a(last)
         END DO
+        b(m)=x
       END DO
-      wsum=0.0_r16
-      cff=0.0_r16
-      DO i=1,nfast
-        wsum=wsum+weight(1,i)
-        cff=cff+weight(2,i)
+      mom(1)=0.0_r16
+      mom(2)=0.0_r16
+      DO m=1,n
+        mom(1)=mom(1)+a(m)
+        mom(2)=mom(2)+b(m)
       END DO
-      wsum=1.0_r16/wsum
-      cff=1.0_r16/cff
-      DO i=1,nfast
-        weight(1,i)=wsum*weight(1,i)
-        weight(2,i)=cff*weight(2,i)
-      END DO
-      END SUBROUTINE set_weights
+      a(1:n)=(1.0_r16/mom(1))*a(1:n)
+      b(1:n)=(1.0_r16/mom(2))*b(1:n)
+      nfast=n
+      weight(1,:)=a
+      weight(2,:)=b
+      deallocate ( a, b )
+      END SUBROUTINE barotropic_filter
 !
-!=======================================================================
-!  ana_grid, Functionals/ana_grid.h: UPWELLING :1058-1082 (+ Cartesian set-up), BENCHMARK
-!  :462-482,677-690,931-936 (spherical)
-!=======================================================================
+!  ---- analytic grids (ana_grid.h: UPWELLING :1058-1082, BENCHMARK :462-482,677-690,931-936) ---
 !
-      SUBROUTINE ana_grid (ierr)
+      ELEMENTAL FUNCTION shelf_depth (rows_from_wall) RESULT (d)   ! UPWELLING: tanh shelf, 150 m cap
+      real(r8), intent(in) :: rows_from_wall
+      real(r8) :: d
+      d=MIN(150.0_r8, 84.5_r8+66.526_r8*TANH((rows_from_wall-10.0_r8)/7.0_r8))
+      END FUNCTION shelf_depth
+
+      SUBROUTINE periodic_fill_grid ()
+      CALL exchange2d (pm, 'r')
+      CALL exchange2d (pn, 'r')
+      CALL exchange2d (angler, 'r')
+      CALL exchange2d (f, 'r')
+      CALL exchange2d (h, 'r')
+      END SUBROUTINE periodic_fill_grid
+
+      SUBROUTINE grid_upwelling ()
+!  Cartesian channel, 1 km cells, f-plane, shelf on both walls of the non-periodic direction.
+      real(r8) :: dx, dy
+      real(r8), allocatable :: across(:)
+      integer :: i, j, nacross, c0, c1
+      xl=1000.0_r8*REAL(Lm,r8)
+      el=1000.0_r8*REAL(Mm,r8)
+      dx=xl/REAL(Lm,r8)
+      dy=el/REAL(Mm,r8)
+      FORALL (i=Istr-1:Iend+1, j=Jstr-1:Jend+1)
+        xr(i,j)=dx*(REAL(i-1,r8)+0.5_r8)
+        yr(i,j)=dy*(REAL(j-1,r8)+0.5_r8)
+      END FORALL
+      pm(IstrT:IendT,JstrT:JendT)=1.0_r8/dx
+      pn(IstrT:IendT,JstrT:JendT)=1.0_r8/dy
+      angler(IstrT:IendT,JstrT:JendT)=0.0_r8
+      f(IstrT:IendT,JstrT:JendT)=-8.26E-05_r8
+!  depth depends on the distance (in rows) to the nearer wall of the cross-channel direction
+      IF (NSperiodic) THEN
+        nacross=Lm; c0=IstrT; c1=IendT
+      ELSE
+        nacross=Mm; c0=JstrT; c1=JendT
+      END IF
+      allocate ( across(c0:c1) )
+      across=shelf_depth(REAL([(MERGE(j, nacross+1-j, j.le.nacross/2), j=c0,c1)],r8))
+      IF (NSperiodic) THEN
+        h(IstrT:IendT,JstrT:JendT)=SPREAD(across, 2, JendT-JstrT+1)
+      ELSE IF (EWperiodic) THEN
+        h(IstrT:IendT,JstrT:JendT)=SPREAD(across, 1, IendT-IstrT+1)
+      END IF
+      deallocate ( across )
+      END SUBROUTINE grid_upwelling
+
+      SUBROUTINE grid_benchmark ()
+!  Spherical zonal channel 360 deg x (70S..50S), cells of equal angle: pm varies with latitude only.
+      real(r8) :: dlon, dlat, per_rad_x, inv_dy, omega2
+      real(r8), allocatable :: lat(:), inv_dx(:)
+      integer :: i, j, j0, j1
+      xl=360.0_r8
+      el=20.0_r8
+      dlon=xl/REAL(Lm,r8)
+      dlat=el/REAL(Mm,r8)
+      j0=MIN(JstrT,Jstr-1)
+      j1=MAX(Jend+1,JendT)
+      allocate ( lat(j0:j1), inv_dx(j0:j1) )
+      lat=-70.0_r8+dlat*(REAL([(j, j=j0,j1)],r8)-0.5_r8)
+      FORALL (i=Istr-1:Iend+1, j=Jstr-1:Jend+1)
+        lonr(i,j)=dlon*(REAL(i,r8)-0.5_r8)
+        latr(i,j)=lat(j)
+      END FORALL
+      per_rad_x=REAL(Lm,r8)/(2.0_r8*pi*Eradius)
+      inv_dy=REAL(Mm,r8)*360.0_r8/(2.0_r8*pi*Eradius*el)
+      inv_dx=per_rad_x*(1.0_r8/COS(lat*deg2rad))
+      pm(IstrT:IendT,JstrT:JendT)=SPREAD(inv_dx(JstrT:JendT), 1, IendT-IstrT+1)
+      pn(IstrT:IendT,JstrT:JendT)=inv_dy
+!  d(1/pn)/dxi vanishes identically; d(1/pm)/deta is a centred difference of the row values
+      dndx(Istr:Iend,Jstr:Jend)=0.5_r8*((1.0_r8/inv_dy)-(1.0_r8/inv_dy))
+      dmde(Istr:Iend,Jstr:Jend)=SPREAD(0.5_r8*((1.0_r8/inv_dx(Jstr+1:Jend+1))-(1.0_r8/inv_dx(Jstr-1:Jend-1))),  &
+     &                                 1, Iend-Istr+1)
+      CALL exchange2d (dndx, 'r')
+      CALL exchange2d (dmde, 'r')
+      omega2=2.0_r8*(2.0_r8*pi*366.25_r8/365.25_r8)/86400.0_r8
+      angler(IstrT:IendT,JstrT:JendT)=0.0_r8
+      f(IstrT:IendT,JstrT:JendT)=omega2*SIN(latr(IstrT:IendT,JstrT:JendT)*deg2rad)
+      h(IstrT:IendT,JstrT:JendT)=500.0_r8+1750.0_r8*(1.0+TANH((68.0_r8+latr(IstrT:IendT,JstrT:JendT))/dlat))
+      deallocate ( lat, inv_dx )
+      END SUBROUTINE grid_benchmark
+
+      SUBROUTINE analytic_grid (ierr)
       integer, intent(out) :: ierr
-      integer :: i, j
-      real(r8) :: Esize, Xsize, beta, cff, depth, dx, dy, f0, val1, val2
-      real(r8), allocatable :: wrkX(:,:), wrkY(:,:)
       ierr=0
-      allocate ( wrkX(LBi:UBi,LBj:UBj), wrkY(LBi:UBi,LBj:UBj) )
       IF (IAND(options,ROMS_APP_UPWELLING).ne.0) THEN
-        Xsize=1000.0_r8*REAL(Lm,r8)
-        Esize=1000.0_r8*REAL(Mm,r8)
-        depth=150.0_r8
-        f0=-8.26E-05_r8
-        beta=0.0_r8
-        xl=Xsize
-        el=Esize
-        dx=Xsize/REAL(Lm,r8)
-        dy=Esize/REAL(Mm,r8)
-        DO j=Jstr-1,Jend+1
-          DO i=Istr-1,Iend+1
-            xr(i,j)=dx*(REAL(i-1,r8)+0.5_r8)
-            yr(i,j)=dy*(REAL(j-1,r8)+0.5_r8)
-          END DO
-        END DO
-        DO j=MIN(JstrT,Jstr-1),MAX(Jend+1,JendT)
-          DO i=MIN(IstrT,Istr-1),MAX(Iend+1,IendT)
-            wrkX(i,j)=1.0_r8/dx
-            wrkY(i,j)=1.0_r8/dy
-          END DO
-        END DO
-        DO j=JstrT,JendT
-          DO i=IstrT,IendT
-            pm(i,j)=wrkX(i,j)
-            pn(i,j)=wrkY(i,j)
-            angler(i,j)=0.0_r8
-            f(i,j)=f0
-          END DO
-        END DO
-        IF (NSperiodic) THEN
-          DO i=IstrT,IendT
-            IF (i.le.Lm/2) THEN
-              val1=REAL(i,r8)
-            ELSE
-              val1=REAL(Lm+1-i,r8)
-            END IF
-            val2=MIN(depth,84.5_r8+66.526_r8*TANH((val1-10.0_r8)/7.0_r8))
-            DO j=JstrT,JendT
-              h(i,j)=val2
-            END DO
-          END DO
-        ELSE IF (EWperiodic) THEN
-          DO j=JstrT,JendT
-            IF (j.le.Mm/2) THEN
-              val1=REAL(j,r8)
-            ELSE
-              val1=REAL(Mm+1-j,r8)
-            END IF
-            val2=MIN(depth,84.5_r8+66.526_r8*TANH((val1-10.0_r8)/7.0_r8))
-            DO i=IstrT,IendT
-              h(i,j)=val2
-            END DO
-          END DO
-        END IF
+        CALL grid_upwelling ()
       ELSE IF (IAND(options,ROMS_APP_BENCHMARK).ne.0) THEN
-        Xsize=360.0_r8
-        Esize=20.0_r8
-        xl=Xsize
-        el=Esize
-        dx=Xsize/REAL(Lm,r8)
-        dy=Esize/REAL(Mm,r8)
-        DO j=Jstr-1,Jend+1
-          val1=-70.0_r8+dy*(REAL(j,r8)-0.5_r8)
-          DO i=Istr-1,Iend+1
-            lonr(i,j)=dx*(REAL(i,r8)-0.5_r8)
-            latr(i,j)=val1
-          END DO
-        END DO
-        val1=REAL(Lm,r8)/(2.0_r8*pi*Eradius)
-        val2=REAL(Mm,r8)*360.0_r8/(2.0_r8*pi*Eradius*Esize)
-        DO j=MIN(JstrT,Jstr-1),MAX(Jend+1,JendT)
-          cff=1.0_r8/COS((-70.0_r8+dy*(REAL(j,r8)-0.5_r8))*deg2rad)
-          DO i=MIN(IstrT,Istr-1),MAX(Iend+1,IendT)
-            wrkX(i,j)=val1*cff
-            wrkY(i,j)=val2
-          END DO
-        END DO
-        DO j=JstrT,JendT
-          DO i=IstrT,IendT
-            pm(i,j)=wrkX(i,j)
-            pn(i,j)=wrkY(i,j)
-          END DO
-        END DO
-        DO j=Jstr,Jend
-          DO i=Istr,Iend
-            dndx(i,j)=0.5_r8*((1.0_r8/wrkY(i+1,j  ))-(1.0_r8/wrkY(i-1,j  )))
-            dmde(i,j)=0.5_r8*((1.0_r8/wrkX(i  ,j+1))-(1.0_r8/wrkX(i  ,j-1)))
-          END DO
-        END DO
-        CALL exchange2d (dndx, 'r')
-        CALL exchange2d (dmde, 'r')
-        val1=2.0_r8*(2.0_r8*pi*366.25_r8/365.25_r8)/86400.0_r8
-        DO j=JstrT,JendT
-          DO i=IstrT,IendT
-            angler(i,j)=0.0_r8
-            f(i,j)=val1*SIN(latr(i,j)*deg2rad)
-            h(i,j)=500.0_r8+1750.0_r8*(1.0+TANH((68.0_r8+latr(i,j))/dy))
-          END DO
-        END DO
+        CALL grid_benchmark ()
       ELSE
         ierr=5
         RETURN
       END IF
       hmin=MINVAL(h(IstrT:IendT,JstrT:JendT))
       hmax=MAXVAL(h(IstrT:IendT,JstrT:JendT))
-      CALL exchange2d (pm, 'r')
-      CALL exchange2d (pn, 'r')
-      CALL exchange2d (angler, 'r')
-      CALL exchange2d (f, 'r')
-      CALL exchange2d (h, 'r')
-      deallocate ( wrkX, wrkY )
-      END SUBROUTINE ana_grid
+      CALL periodic_fill_grid ()
+      END SUBROUTINE analytic_grid
 !
-!=======================================================================
-!  metrics, Utility/metrics.F:23-250
-!=======================================================================
+!  ---- derived metrics (metrics.F:23-250): cell sizes and their ratios at rho, u, v, psi points --
+!       a u-/v-/psi-point value is built from the SUM of pm (pn) over its 2 / 2 / 4 surrounding
+!       rho points: size = (number of points)/sum, ratio = sum/sum.
 !
-      SUBROUTINE metrics ()
-      integer :: i, j
-      DO j=JstrT,JendT
-        DO i=IstrT,IendT
-          om_r(i,j)=1.0_r8/pm(i,j)
-          on_r(i,j)=1.0_r8/pn(i,j)
-          omn(i,j)=1.0_r8/(pm(i,j)*pn(i,j))
-          fomn(i,j)=f(i,j)*omn(i,j)
-          pnom_r(i,j)=pn(i,j)/pm(i,j)
-          pmon_r(i,j)=pm(i,j)/pn(i,j)
-        END DO
-      END DO
-      CALL exchange2d (om_r, 'r')
-      CALL exchange2d (on_r, 'r')
-      CALL exchange2d (omn, 'r')
-      CALL exchange2d (fomn, 'r')
-      CALL exchange2d (pnom_r, 'r')
-      CALL exchange2d (pmon_r, 'r')
-      DO j=JstrT,JendT
-        DO i=IstrP,IendT
-          pmon_u(i,j)=(pm(i-1,j)+pm(i,j))/(pn(i-1,j)+pn(i,j))
-          pnom_u(i,j)=(pn(i-1,j)+pn(i,j))/(pm(i-1,j)+pm(i,j))
-          om_u(i,j)=2.0_r8/(pm(i-1,j)+pm(i,j))
-          on_u(i,j)=2.0_r8/(pn(i-1,j)+pn(i,j))
-        END DO
-      END DO
-      CALL exchange2d (pmon_u, 'u')
-      CALL exchange2d (pnom_u, 'u')
-      CALL exchange2d (om_u, 'u')
-      CALL exchange2d (on_u, 'u')
-      DO j=JstrP,JendT
-        DO i=IstrT,IendT
-          pmon_v(i,j)=(pm(i,j-1)+pm(i,j))/(pn(i,j-1)+pn(i,j))
-          pnom_v(i,j)=(pn(i,j-1)+pn(i,j))/(pm(i,j-1)+pm(i,j))
-          om_v(i,j)=2.0_r8/(pm(i,j-1)+pm(i,j))
-          on_v(i,j)=2.0_r8/(pn(i,j-1)+pn(i,j))
-        END DO
-      END DO
-      CALL exchange2d (pmon_v, 'v')
-      CALL exchange2d (pnom_v, 'v')
-      CALL exchange2d (om_v, 'v')
-      CALL exchange2d (on_v, 'v')
-      DO j=JstrP,JendT
-        DO i=IstrP,IendT
-          pnom_p(i,j)=(pn(i-1,j-1)+pn(i-1,j)+pn(i,j-1)+pn(i,j))/(pm(i-1,j-1)+pm(i-1,j)+pm(i,j-1)+pm(i,j))
-          pmon_p(i,j)=(pm(i-1,j-1)+pm(i-1,j)+pm(i,j-1)+pm(i,j))/(pn(i-1,j-1)+pn(i-1,j)+pn(i,j-1)+pn(i,j))
-          om_p(i,j)=4.0_r8/(pm(i-1,j-1)+pm(i-1,j)+pm(i,j-1)+pm(i,j))
-          on_p(i,j)=4.0_r8/(pn(i-1,j-1)+pn(i-1,j)+pn(i,j-1)+pn(i,j))
-        END DO
-      END DO
-      CALL exchange2d (pnom_p, 'p')
-      CALL exchange2d (pmon_p, 'p')
-      CALL exchange2d (om_p, 'p')
-      CALL exchange2d (on_p, 'p')
-      END SUBROUTINE metrics
+      SUBROUTINE grid_metrics ()
+      real(r8), allocatable :: sm(:,:), sn(:,:)
+      integer :: i0, i1, j0, j1
+      i0=IstrT; i1=IendT; j0=JstrT; j1=JendT
+      om_r(i0:i1,j0:j1)=1.0_r8/pm(i0:i1,j0:j1)
+      on_r(i0:i1,j0:j1)=1.0_r8/pn(i0:i1,j0:j1)
+      omn(i0:i1,j0:j1)=1.0_r8/(pm(i0:i1,j0:j1)*pn(i0:i1,j0:j1))
+      fomn(i0:i1,j0:j1)=f(i0:i1,j0:j1)*omn(i0:i1,j0:j1)
+      pnom_r(i0:i1,j0:j1)=pn(i0:i1,j0:j1)/pm(i0:i1,j0:j1)
+      pmon_r(i0:i1,j0:j1)=pm(i0:i1,j0:j1)/pn(i0:i1,j0:j1)
+      allocate ( sm(LBi:UBi,LBj:UBj), sn(LBi:UBi,LBj:UBj) )
+!  u points (i-1,j)+(i,j)
+      i0=IstrP
+      sm(i0:i1,j0:j1)=pm(i0-1:i1-1,j0:j1)+pm(i0:i1,j0:j1)
+      sn(i0:i1,j0:j1)=pn(i0-1:i1-1,j0:j1)+pn(i0:i1,j0:j1)
+      pmon_u(i0:i1,j0:j1)=sm(i0:i1,j0:j1)/sn(i0:i1,j0:j1)
+      pnom_u(i0:i1,j0:j1)=sn(i0:i1,j0:j1)/sm(i0:i1,j0:j1)
+      om_u(i0:i1,j0:j1)=2.0_r8/sm(i0:i1,j0:j1)
+      on_u(i0:i1,j0:j1)=2.0_r8/sn(i0:i1,j0:j1)
+!  v points (i,j-1)+(i,j)
+      i0=IstrT; j0=JstrP
+      sm(i0:i1,j0:j1)=pm(i0:i1,j0-1:j1-1)+pm(i0:i1,j0:j1)
+      sn(i0:i1,j0:j1)=pn(i0:i1,j0-1:j1-1)+pn(i0:i1,j0:j1)
+      pmon_v(i0:i1,j0:j1)=sm(i0:i1,j0:j1)/sn(i0:i1,j0:j1)
+      pnom_v(i0:i1,j0:j1)=sn(i0:i1,j0:j1)/sm(i0:i1,j0:j1)
+      om_v(i0:i1,j0:j1)=2.0_r8/sm(i0:i1,j0:j1)
+      on_v(i0:i1,j0:j1)=2.0_r8/sn(i0:i1,j0:j1)
+!  psi points (i-1,j-1)+(i-1,j)+(i,j-1)+(i,j), added in that order
+      i0=IstrP
+      sm(i0:i1,j0:j1)=pm(i0-1:i1-1,j0-1:j1-1)+pm(i0-1:i1-1,j0:j1)+pm(i0:i1,j0-1:j1-1)+pm(i0:i1,j0:j1)
+      sn(i0:i1,j0:j1)=pn(i0-1:i1-1,j0-1:j1-1)+pn(i0-1:i1-1,j0:j1)+pn(i0:i1,j0-1:j1-1)+pn(i0:i1,j0:j1)
+      pnom_p(i0:i1,j0:j1)=sn(i0:i1,j0:j1)/sm(i0:i1,j0:j1)
+      pmon_p(i0:i1,j0:j1)=sm(i0:i1,j0:j1)/sn(i0:i1,j0:j1)
+      om_p(i0:i1,j0:j1)=4.0_r8/sm(i0:i1,j0:j1)
+      on_p(i0:i1,j0:j1)=4.0_r8/sn(i0:i1,j0:j1)
+      deallocate ( sm, sn )
+      CALL exchange2d (om_r, 'r');   CALL exchange2d (on_r, 'r');   CALL exchange2d (omn, 'r')
+      CALL exchange2d (fomn, 'r');   CALL exchange2d (pnom_r, 'r'); CALL exchange2d (pmon_r, 'r')
+      CALL exchange2d (pmon_u, 'u'); CALL exchange2d (pnom_u, 'u'); CALL exchange2d (om_u, 'u')
+      CALL exchange2d (on_u, 'u');   CALL exchange2d (pmon_v, 'v'); CALL exchange2d (pnom_v, 'v')
+      CALL exchange2d (om_v, 'v');   CALL exchange2d (on_v, 'v');   CALL exchange2d (pnom_p, 'p')
+      CALL exchange2d (pmon_p, 'p'); CALL exchange2d (om_p, 'p');   CALL exchange2d (on_p, 'p')
+      END SUBROUTINE grid_metrics
 !
-!=======================================================================
-!  ini_hmixcoef (Utility/ini_hmixcoef.F:29) + initialize_mixing/initialize_grid defaults
-!  (Modules/mod_mixing.F, mod_grid.F): uniform viscosity/diffusivity, background Akv/Akt, drag.
-!=======================================================================
+!  ---- horizontal mixing, drag and background vertical mixing (ini_hmixcoef.F:29 with uniform
+!       coefficients; allocation defaults of mod_mixing.F / mod_grid.F) ---------------------------
 !
       SUBROUTINE ini_mixing ()
       integer :: itrc, k
@@ -732,46 +1121,34 @@
       END DO
       END SUBROUTINE ini_mixing
 !
-!=======================================================================
-!  set_depth on the host for the initial state (Nonlinear/set_depth.F:76-278, Zt_avg1 = 0)
-!=======================================================================
+!  ---- depths of the s-levels for a given free surface (set_depth.F:76-278) ---------------------
+!       Vtransform 1:  z = z0 + zeta (1 + z0/h),          z0 = hc (s - C) + C h
+!       Vtransform 2:  z = zeta + (zeta + h) S,           S  = (hc s + C h)/(hc + h)
 !
-      SUBROUTINE set_depth_host ()
-      integer :: i, j, k
-      real(r8) :: cff_r, cff1_r, cff2_r, cff_w, cff1_w, cff2_w, hinv, hwater, z_r0, z_w0
-      DO j=JstrT,JendT
-        DO i=IstrT,IendT
-          z_w(i,j,0)=-h(i,j)
-        END DO
-        DO k=1,N
-          IF (Vtransform.eq.1) THEN
-            cff_r=hc*(sc_r(k)-Cs_r(k))
-            cff_w=hc*(sc_w(k)-Cs_w(k))
-          ELSE
-            cff_r=hc*sc_r(k)
-            cff_w=hc*sc_w(k)
-          END IF
-          cff1_r=Cs_r(k)
-          cff1_w=Cs_w(k)
-          DO i=IstrT,IendT
-            hwater=h(i,j)
-            IF (Vtransform.eq.1) THEN
-              hinv=1.0_r8/hwater
-              z_w0=cff_w+cff1_w*hwater
-              z_w(i,j,k)=z_w0+Zt_avg1(i,j)*(1.0_r8+z_w0*hinv)
-              z_r0=cff_r+cff1_r*hwater
-              z_r(i,j,k)=z_r0+Zt_avg1(i,j)*(1.0_r8+z_r0*hinv)
-            ELSE
-              hinv=1.0_r8/(hc+hwater)
-              cff2_r=(cff_r+cff1_r*hwater)*hinv
-              cff2_w=(cff_w+cff1_w*hwater)*hinv
-              z_w(i,j,k)=Zt_avg1(i,j)+(Zt_avg1(i,j)+hwater)*cff2_w
-              z_r(i,j,k)=Zt_avg1(i,j)+(Zt_avg1(i,j)+hwater)*cff2_r
-            END IF
-            Hz(i,j,k)=z_w(i,j,k)-z_w(i,j,k-1)
-          END DO
-        END DO
+      SUBROUTINE level_depths (zsurf)
+      real(r8), intent(in) :: zsurf(LBi:,LBj:)
+      real(r8), allocatable :: hw(:,:), zs(:,:), rest(:,:)
+      integer :: k, i0, i1, j0, j1
+      i0=IstrT; i1=IendT; j0=JstrT; j1=JendT
+      allocate ( hw(i0:i1,j0:j1), zs(i0:i1,j0:j1), rest(i0:i1,j0:j1) )
+      hw=h(i0:i1,j0:j1)
+      zs=zsurf(i0:i1,j0:j1)
+      z_w(i0:i1,j0:j1,0)=-hw
+      DO k=1,N
+        IF (Vtransform.eq.1) THEN
+          rest=hc*(sc_w(k)-Cs_w(k))+Cs_w(k)*hw
+          z_w(i0:i1,j0:j1,k)=rest+zs*(1.0_r8+rest*(1.0_r8/hw))
+          rest=hc*(sc_r(k)-Cs_r(k))+Cs_r(k)*hw
+          z_r(i0:i1,j0:j1,k)=rest+zs*(1.0_r8+rest*(1.0_r8/hw))
+        ELSE
+          rest=(hc*sc_w(k)+Cs_w(k)*hw)*(1.0_r8/(hc+hw))
+          z_w(i0:i1,j0:j1,k)=zs+(zs+hw)*rest
+          rest=(hc*sc_r(k)+Cs_r(k)*hw)*(1.0_r8/(hc+hw))
+          z_r(i0:i1,j0:j1,k)=zs+(zs+hw)*rest
+        END IF
+        Hz(i0:i1,j0:j1,k)=z_w(i0:i1,j0:j1,k)-z_w(i0:i1,j0:j1,k-1)
       END DO
+      deallocate ( hw, zs, rest )
       DO k=0,N
         CALL exchange2d (z_w(:,:,k), 'r')
       END DO
@@ -779,43 +1156,39 @@
         CALL exchange2d (z_r(:,:,k), 'r')
         CALL exchange2d (Hz(:,:,k), 'r')
       END DO
-      END SUBROUTINE set_depth_host
+      END SUBROUTINE level_depths
 !
-!=======================================================================
-!  ana_initial, Functionals/ana_initial.h: UPWELLING :828-849, BENCHMARK :545-560
-!=======================================================================
+!  ---- analytic initial state: ocean at rest, temperature a function of depth only, uniform salt
+!       (ana_initial.h: UPWELLING :828-849, BENCHMARK :545-560) ---------------------------------
 !
-      SUBROUTINE ana_initial ()
-      integer :: i, j, k
-      real(r8) :: val1, val2
-      zeta=0.0_r8
-      ubar=0.0_r8
-      vbar=0.0_r8
-      u=0.0_r8
-      v=0.0_r8
-      t=0.0_r8
+      ELEMENTAL FUNCTION temp_upwelling (z) RESULT (temp)
+      real(r8), intent(in) :: z
+      real(r8) :: temp
+      temp=T0+8.0_r8*EXP(z/50.0_r8)
+      END FUNCTION temp_upwelling
+
+      ELEMENTAL FUNCTION temp_benchmark (z, amp) RESULT (temp)
+      real(r8), intent(in) :: z, amp
+      real(r8) :: temp
+      temp=amp*EXP(z/800.0_r8)*(0.6_r8-0.4_r8*TANH(z/800.0_r8))
+      END FUNCTION temp_benchmark
+
+      SUBROUTINE initial_state ()
+      real(r8) :: ratio2, amp
+      integer :: i0, i1, j0, j1
+      i0=IstrT; i1=IendT; j0=JstrT; j1=JendT
+      zeta=0.0_r8;  ubar=0.0_r8;  vbar=0.0_r8
+      u=0.0_r8;     v=0.0_r8;     t=0.0_r8
       IF (IAND(options,ROMS_APP_BENCHMARK).ne.0) THEN
-        val1=(44.69_r8/39.382_r8)**2
-        val2=val1*(rho0*800.0_r8/g)*(5.0E-05_r8/((42.689_r8/44.69_r8)**2))
-        DO k=1,N
-          DO j=JstrT,JendT
-            DO i=IstrT,IendT
-              t(i,j,k,1,1)=val2*EXP(z_r(i,j,k)/800.0_r8)*(0.6_r8-0.4_r8*TANH(z_r(i,j,k)/800.0_r8))
-              t(i,j,k,1,2)=35.0_r8
-            END DO
-          END DO
-        END DO
+        ratio2=(44.69_r8/39.382_r8)**2
+        amp=ratio2*(rho0*800.0_r8/g)*(5.0E-05_r8/((42.689_r8/44.69_r8)**2))
+        t(i0:i1,j0:j1,:,1,1)=temp_benchmark(z_r(i0:i1,j0:j1,:), amp)
+        t(i0:i1,j0:j1,:,1,2)=35.0_r8
       ELSE
-        DO k=1,N
-          DO j=JstrT,JendT
-            DO i=IstrT,IendT
-              t(i,j,k,1,1)=T0+8.0_r8*EXP(z_r(i,j,k)/50.0_r8)
-              t(i,j,k,1,2)=S0
-            END DO
-          END DO
-        END DO
+        t(i0:i1,j0:j1,:,1,1)=temp_upwelling(z_r(i0:i1,j0:j1,:))
+        t(i0:i1,j0:j1,:,1,2)=S0
       END IF
-      END SUBROUTINE ana_initial
+      END SUBROUTINE initial_state
 !
 !=======================================================================
 !  Allocate (mod_arrays.F), set up and initialise the host state.
@@ -824,6 +1197,14 @@
       SUBROUTINE host_setup (ierr)
       integer, intent(out) :: ierr
       NT=NAT
+      IF (ANY(hadv(1:NT).lt.0).or.ANY(vadv(1:NT).lt.0)) THEN
+        CALL unsupported ('Hadvection/Vadvection: unknown scheme (A4 C2 C4 HSIMT MPDATA SP SU3 U3)', ierr)
+        RETURN
+      END IF
+      IF (ANY(hadv(1:NT).eq.ROMS_MPDATA.neqv.vadv(1:NT).eq.ROMS_MPDATA)) THEN
+        CALL unsupported ('MPDATA must be chosen for both Hadvection and Vadvection of a tracer', ierr)
+        RETURN
+      END IF
       CALL set_cppdefs (ierr)
       IF (ierr.ne.0) RETURN
       CALL set_bounds ()
@@ -849,15 +1230,16 @@
       pnom_r=0.0_r8; pmon_p=0.0_r8; pnom_p=0.0_r8; pmon_u=0.0_r8; pnom_u=0.0_r8; pmon_v=0.0_r8
       pnom_v=0.0_r8; dmde=0.0_r8; dndx=0.0_r8; angler=0.0_r8; xr=0.0_r8; yr=0.0_r8; lonr=0.0_r8
       latr=0.0_r8; Zt_avg1=0.0_r8; Hz=0.0_r8; z_r=0.0_r8; z_w=0.0_r8
-      CALL ana_grid (ierr)                      ! set_grid, Utility/set_grid.F
+!  the order of the reference's set_grid (Utility/set_grid.F) and initial (Nonlinear/initial.F:293-358)
+      CALL analytic_grid (ierr)
       IF (ierr.ne.0) RETURN
-      CALL set_scoord (ierr)
+      CALL vertical_coordinate (ierr)
       IF (ierr.ne.0) RETURN
-      CALL set_weights ()
-      CALL metrics ()
-      CALL ini_mixing ()                        ! initial, Nonlinear/initial.F:293
-      CALL set_depth_host ()                    ! :341
-      CALL ana_initial ()                       ! :358
+      CALL barotropic_filter ()
+      CALL grid_metrics ()
+      CALL ini_mixing ()
+      CALL level_depths (Zt_avg1)               ! Zt_avg1 = 0: depths of the resting ocean
+      CALL initial_state ()
       END SUBROUTINE host_setup
 
       SUBROUTINE host_free ()

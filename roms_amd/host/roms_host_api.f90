@@ -20,6 +20,34 @@
       f_=TRANSFER(s(1:n), f_)
       END FUNCTION c2f
 !
+!  Name the application header whose cpp options select the physics (ROMS/Include/<app>.h or a custom
+!  one); an empty string returns to the built-in lists / the ROMS_APP_HEADER environment variable.
+!
+      SUBROUTINE roms_host_set_header (path) bind(C, name='roms_host_set_header')
+      character(kind=c_char), intent(in) :: path(*)
+      app_header=c2f(path)
+      END SUBROUTINE roms_host_set_header
+!
+!  Why the last call returned a non-zero exit_flag (host side); at most n-1 characters + NUL.
+!
+      SUBROUTINE roms_host_last_error (buf, n) bind(C, name='roms_host_last_error')
+      integer(c_int), value :: n
+      character(kind=c_char), intent(out) :: buf(n)
+      integer :: k, L
+      L=MIN(LEN_TRIM(host_message), n-1)
+      DO k=1,L
+        buf(k)=host_message(k:k)
+      END DO
+      buf(L+1)=c_null_char
+      END SUBROUTINE roms_host_last_error
+!
+!  Number of roms.in keywords the last roms_host_setup had no use for (read_phypar.F skips them too).
+!
+      FUNCTION roms_host_unused_keys () bind(C, name='roms_host_unused_keys') RESULT (n)
+      integer(c_int) :: n
+      n=n_unused_keys
+      END FUNCTION roms_host_unused_keys
+!
 !  Read roms.in and build the host state only (no device needed).
 !
       FUNCTION roms_host_setup (infile) bind(C, name='roms_host_setup') RESULT (ierr)

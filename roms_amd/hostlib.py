@@ -34,6 +34,10 @@ def load(path=None):
         lib.roms_host_dims.restype = None
         lib.roms_host_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_long]
         lib.roms_host_get.restype = C.c_long
+        lib.roms_host_set_header.argtypes = [C.c_char_p]
+        lib.roms_host_set_header.restype = None
+        lib.roms_host_last_error.argtypes = [C.c_char_p, C.c_int]
+        lib.roms_host_last_error.restype = None
         _libs[path] = lib
     return _libs[path]
 
@@ -49,7 +53,11 @@ def write_roms_in(path, p):
         f"      NtileI == {p.get('NtileI', 1)}", f"      NtileJ == {p.get('NtileJ', 1)}",
         f"  Hadvection == {p['hadv'][0]} \\", f"                {p['hadv'][1]}",
         f"  Vadvection == {p['vadv'][0]} \\", f"                {p['vadv'][1]}",
-        f" LBC(isFsur) == {per(p['EWperiodic'])} {per(p['NSperiodic'])} {per(p['EWperiodic'])} {per(p['NSperiodic'])}",
+    ]
+    lbc = f"{per(p['EWperiodic'])} {per(p['NSperiodic'])} {per(p['EWperiodic'])} {per(p['NSperiodic'])}"   # W S E N
+    lines += [f" LBC({v}) == {lbc}" for v in ("isFsur", "isUbar", "isVbar", "isUvel", "isVvel", "isMtke")]
+    lines += [f" LBC(isTvar) == {lbc} \\", f"                {lbc}"]
+    lines += [
         f"      NTIMES == {p.get('ntimes', 10)}", f"          DT == {d(p['dt'])}",
         f"     NDTFAST == {p['ndtfast']}", f"       NINFO == {p.get('ninfo', 1)}",
         f"        TNU2 == {tr(d(x) for x in p['tnu2'])}", f"       VISC2 == {d(p['visc2'])}",
@@ -70,12 +78,24 @@ def write_roms_in(path, p):
         f.write("\n".join(lines) + "\n")
 
 
+class HostError(RuntimeError):
+    """set-up stopped with the reference's exit_flag code (5 = configuration, 2 = input file)"""
+
+    def __init__(self, exit_flag, message):
+        super().__init__(f"roms_host_setup failed, exit_flag={exit_flag}: {message}")
+        self.exit_flag = exit_flag
+
+
 class Host:
     """One ROMS run owned by the Fortran host (module state: one instance per process)."""
 
-    def __init__(self, infile=None, params=None, lib_path=None, hip_lib_path=None):
+    def __init__(self, infile=None, params=None, lib_path=None, hip_lib_path=None, header=None):
+        """infile: a roms.in; or params: a dict written out as one.  header: application header whose cpp
+        options select the physics (ROMS/Include/<app>.h or a custom one); default: the built-in option
+        lists of UPWELLING / BENCHMARK / UPWELLING_KPP (or $ROMS_APP_HEADER)."""
         self.lib = load(lib_path)
         self.hip_lib_path = hip_lib_path
+        self.lib.roms_host_set_header((header or "").encode())
         tmp = None
         if infile is None:
             fd, tmp = tempfile.mkstemp(suffix=".in", prefix="roms_")
@@ -88,7 +108,7 @@ class Host:
             if tmp:
                 os.unlink(tmp)
         if r != 0:
-            raise RuntimeError(f"roms_host_setup failed, exit_flag={r}")
+            raise HostError(r, self.last_error())
         di = (C.c_int * 24)()
         dr = (C.c_double * 8)()
         self.lib.roms_host_dims(di, dr)
@@ -97,6 +117,11 @@ class Host:
         self.dims = dict(zip(names, list(di)[:15]))
         self.dims["hadv"], self.dims["vadv"], self.dims["ninfo"] = list(di)[15:19], list(di)[19:23], di[23]
         self.reals = dict(zip(["dt", "dtfast", "hc", "hmin", "hmax", "xl", "el", "dstart"], list(dr)))
+
+    def last_error(self):
+        buf = C.create_string_buffer(300)
+        self.lib.roms_host_last_error(buf, 300)
+        return buf.value.decode(errors="replace")
 
     def get(self, name):
         n = self.lib.roms_host_get(name.encode(), None, 0)

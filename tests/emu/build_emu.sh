@@ -35,3 +35,10 @@ done
 /opt/rocm/bin/amdflang -shared -o $HERE/libroms_host_emu.so $FOBJ/roms_hip_mod.o $FOBJ/roms_host.o $FOBJ/roms_host_api.o \
   -L$HERE -lroms_hip_emu -Wl,-rpath,'$ORIGIN'
 echo "built $HERE/libroms_host_emu.so"
+
+# the stand-alone driver against the emulated library (its run report is checked on CPU too)
+if [ ! -f $FOBJ/romsM.o ] || [ $HOSTSRC/romsM.f90 -nt $FOBJ/romsM.o ] || [ $FOBJ/roms_host.o -nt $FOBJ/romsM.o ]; then
+  /opt/rocm/bin/amdflang -O2 -fPIC -ffp-contract=off -module-dir $FOBJ -c $HOSTSRC/romsM.f90 -o $FOBJ/romsM.o
+fi
+/opt/rocm/bin/amdflang -o $HERE/romsM_emu $FOBJ/romsM.o -L$HERE -lroms_host_emu -lroms_hip_emu -Wl,-rpath,'$ORIGIN'
+echo "built $HERE/romsM_emu"

@@ -80,3 +80,12 @@ def test_baseline_size_matches_reference_sample(name):
     d = run.check()
     assert ("%.6E" % d["volume"]) == meta["diag"][-1][0][3]
     run.close()
+
+
+def test_romsM_prints_the_reference_run_report(tmp_path):
+    """The stand-alone Fortran driver (roms.in -> Fortran host -> C ABI -> GPU) on the UPWELLING case of the
+    fixture: its standard output must carry the reference's diag report (diag.F:446-500) -- same layout, same
+    date strings, same (i,j,k) location of the largest Courant number, numbers equal to the 7 printed digits
+    (a last-digit difference is tolerated: exp() in ana_vmix differs by an ulp on the device)."""
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    util.check_romsM_report(os.path.join(root, "roms_amd", "romsM"), tmp_path, exact=False)

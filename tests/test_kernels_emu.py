@@ -106,3 +106,11 @@ def test_ns_periodic(emu, hadv, vadv, ng, ewp):
             assert np.isfinite(b).all(), n
             assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
     H.close()
+
+
+def test_romsM_run_report_is_the_reference_text(emu, tmp_path):
+    """romsM (linked against the emulated kernels here; the GPU-box twin is in test_gpu_vs_reference.py):
+    roms.in -> Fortran host -> C ABI -> kernels, and on standard output the reference's run report, character
+    for character (the emulated exp() is glibc's, as the reference's)."""
+    exe = os.path.join(os.path.dirname(util.EMU_LIB), "romsM_emu")
+    util.check_romsM_report(exe, tmp_path, exact=True)

@@ -324,3 +324,32 @@ def check_kernels_fixture(side, f, meta, tol):
                 assert err <= tol, (step, k, e["k"], n, err)
                 side.put(n, r)
     return worst
+
+
+def check_romsM_report(exe, tmp_path, exact, nsteps=12, fixture="upwelling_small_hsimt_steps.npz"):
+    """Run the stand-alone driver on the fixture's case (fused main3d and kernel by kernel) and compare the
+    run report on its standard output with the text the reference printed (diag.F:446-500)."""
+    import re
+    import subprocess
+    from roms_amd import hostlib
+    f, meta = load_fixture(fixture)
+    cs = case_from_meta(meta)
+    cs["ntimes"] = nsteps
+    cs["ninfo"] = 1
+    infile = str(tmp_path / "roms_case.in")
+    hostlib.write_roms_in(infile, cs)
+    flt = re.compile(r"[-+]?\d\.\d{6}E[-+]\d{2}")
+    for extra in ([], ["kernels"]):
+        p = subprocess.run([exe, infile] + extra, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "ROMS: DONE" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+        lines = p.stdout.splitlines()
+        start = [k for k, l in enumerate(lines) if "C => (i,j,k)" in l][0] + 2
+        got = lines[start:start + 2 * (nsteps + 1)]
+        want = [l for pair in meta["diag_text"][:nsteps + 1] for l in pair]
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            if exact:
+                assert g == w, (g, w)
+            assert flt.sub("#", g) == flt.sub("#", w), (g, w)          # layout, step, date, (i,j,k)
+            for a, b in zip(flt.findall(g), flt.findall(w)):
+                assert abs(float(a) - float(b)) <= 2e-6 * abs(float(b)), (g, w)
