@@ -7,16 +7,20 @@ A "step" is one pass of main3d's STEP_LOOP (ROMS/Nonlinear/main3d.F:216-1148) wi
 of the application (BENCHMARK: nonlinear EOS, KPP, COARE bulk fluxes, geopotential tracer mixing,
 nfast+1 LF-AM3 barotropic predictor/corrector pairs ...) and the state resident in HBM.  The default
 workload is BASELINE.json configs[1]: BENCHMARK1 512x64x30.  For N > 1 the driver starts one rank per
-GPU (torch.distributed, nccl = RCCL); each rank owns one tile of NtileI x NtileJ = N tiles (weak
-scaling: the per-GPU tile stays 512x64x30 and the global grid grows along xi).
+GPU (torch.distributed, nccl = RCCL); each rank owns one tile of NtileI x NtileJ = N tiles.  The default
+workload then runs BASELINE.json's own multi-GPU configurations: N = 4 -> BENCHMARK2 1024x128x30 in 2x2
+(tile 512x64, the BENCHMARK1 grid: weak scaling), N = 8 -> BENCHMARK3 2048x256x30 in 2x4 (tile 1024x64),
+N = 2 -> two BENCHMARK1 tiles side by side.
 
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
   roofline      dominant kernel: algorithmic bytes / average launch duration measured with HIP events
                 on the library's stream inside the timed region
-  cpu_baseline  the C oracle (oracle/, a scalar port of the reference's algorithm) timed on one host
-                core on a bounded sample of the same workload
-and, as a third, `north_star_pair`: the kernels of "step3d_t + rhs3d" (BASELINE.json north_star) timed in
-the breakdown pass against their 632 algorithmic bytes per cell (meaningful at --workload ns512u3 / ns512).
+  cpu_baseline  the C oracle (oracle/, a port of the reference's algorithm pinned against its object code)
+                timed on ALL host cores (OpenMP threads over shared-memory tiles, the reference's
+                shared-memory mode) on a bounded sample of the same workload
+and two more: `north_star_pair` = the kernels of "step3d_t + rhs3d" (BASELINE.json north_star) timed in the
+breakdown pass of this workload against their 632 algorithmic bytes per cell, and -- default run only --
+`north_star_pair_512x512x50` = the same on the grid the north star names (a 4-step pass after the timed region).
 """
 import argparse
 import json
@@ -128,7 +132,7 @@ def pmc_traffic(workload, kernel, world):
 
 
 def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
-    from tests import cases
+    from roms_amd import cases
     app, lm, mm, n = WORKLOADS[workload]
     Lm, Mm, N = Lm or lm, Mm or mm, N or n
     if app == "benchmark":
@@ -143,32 +147,72 @@ def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
 
 
 def cpu_baseline(cs, H, budget_s=20.0):
-    """Time the oracle (scalar C port, one core) on the same workload, a few steps."""
+    """The reference's algorithm on the host cores of this box: the C oracle (oracle/, a scalar port pinned bit
+    for bit against the reference's object code) with its tile loops run as OpenMP threads -- the reference's
+    shared-memory mode (Drivers/nl_roms.h:304-310) -- one thread per available core.  The domain is cut into
+    NtileJ strips along eta only (NtileI = 1): with tiles along a PERIODIC axis the reference's shared-memory
+    exchange reads neighbour tiles inside the same parallel loop and the result depends on thread timing; strips
+    keep every periodic copy inside one tile, and the threaded run is bit-identical to the serial one
+    (tests/test_oracle.py::test_threaded_tiles_bitwise).  This is the ONLY place bench.py touches oracle/."""
     import numpy as np
     from oracle import orc
-    from tests import cases, util
+    from tests import cases as tcases
+    from roms_amd.hostlib import HOST_FIELDS
     orc.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    strips = max(1, min(cs["Mm"] // 4, 2 * cores))         # >= 4 rows per strip, two strips per thread
+    threads = min(cores, strips)
+    c2 = dict(cs, NtileI=1, NtileJ=strips)
     w = np.stack([H.get("weight1"), H.get("weight2")])
-    O = orc.Oracle(cases.oracle_cfg(cs, H.reals["hc"], H.dims["nfast"], w))
-    from tests.test_host import HOST_FIELDS
+    O = orc.Oracle(tcases.oracle_cfg(c2, H.reals["hc"], H.dims["nfast"], w))
     for n in HOST_FIELDS:
         try:
             O.field(n)[:] = H.get(n)
         except KeyError:
             pass
+    O.set_threads(threads)
     O.start()
     cells = cs["Lm"] * cs["Mm"] * cs["N"]
     t0 = time.perf_counter()
     O.main3d_step(1)                       # first step (start-up branches), also sizes the sample
     t1 = time.perf_counter()
-    nsteps = max(2, min(40, int(budget_s / max(t1 - t0, 1e-3))))
+    nsteps = max(2, min(200, int(budget_s / max(t1 - t0, 1e-3))))
     t0 = time.perf_counter()
     O.main3d_step(nsteps)
     t1 = time.perf_counter()
     O.close()
-    return {"value": cells * nsteps / (t1 - t0), "unit": "grid-cell-updates/sec", "cores": 1, "kind": "port",
+    return {"value": cells * nsteps / (t1 - t0), "unit": "grid-cell-updates/sec", "cores": threads, "kind": "port",
             "sample": f"{cs['app'].upper()} {cs['Lm']}x{cs['Mm']}x{cs['N']}, steps 2..{nsteps + 1} of the same run, "
-                      f"oracle/liborc.so (gcc -O2, scalar, 1 thread), {t1 - t0:.1f} s"}
+                      f"oracle/liborc.so (gcc -O2 -fopenmp), {threads} OpenMP threads over 1x{strips} shared-memory "
+                      f"tiles ({cores} cores available), {t1 - t0:.1f} s"}
+
+
+def north_star_pass(hiplib, tiling, device, steps=4):
+    """UPWELLING 512x512x50 with U3/C4 advection: `steps` steps with synchronous per-kernel HIP events; the
+    kernels of "step3d_t + rhs3d" against their 632 algorithmic bytes per cell, and each of them alone."""
+    cs = params_for("ns512u3", ntimes=steps + 4)
+    cs["ninfo"] = 1
+    run = tiling.TiledRun(cs, device=device)
+    run.step(3)
+    run.sync()
+    hiplib.kprof(1)
+    run.step(steps)
+    run.sync()
+    table = hiplib.kprof_table()
+    hiplib.kprof(0)
+    cells = cs["Lm"] * cs["Mm"] * cs["N"]
+    rep = pair_report(table, steps, cells)
+    per = {}
+    for k in rep["kernels"]:
+        nb = algo_bytes(k, cs["Lm"], cs["Mm"], cs["N"])
+        us = 1e6 * table[k][0] / max(table[k][1], 1)
+        per[k] = {"us_per_launch": us, "launches_per_step": table[k][1] / steps,
+                  "algorithmic_GBs": (nb / us / 1e3) if nb else None}
+    rep["per_kernel"] = per
+    rep["workload"] = "UPWELLING 512x512x50, U3/C4 advection of both tracers (bench.py --workload ns512u3)"
+    run.check()
+    run.close()
+    return rep
 
 
 def main():
@@ -182,6 +226,7 @@ def main():
     ap.add_argument("--N", type=int)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the 512x512x50 pass of the default run")
     ap.add_argument("--breakdown-file", default=None, help="write the per-kernel table (JSON) here")
     ap.add_argument("--copy-probe", action="store_true",
                     help="also time the library's streaming-copy kernel on this workload's 3-D arrays")
@@ -211,9 +256,22 @@ def main():
     if os.environ.get("ROMS_HIP_TRACE"):     # debugging aid: every launch synchronous and named on stderr
         hiplib.kprof(1)
 
-    cs = params_for(args.workload, args.Lm, args.Mm, args.N, ntimes=args.steps + args.warmup)
+    # Multi-GPU runs of the default workload are BASELINE.json's own configurations: BENCHMARK2 1024x128x30 in
+    # NtileI x NtileJ = 2x2 on 4 GPUs (tile 512x64, the BENCHMARK1 grid) and BENCHMARK3 2048x256x30 in 2x4 on 8
+    # (tile 1024x64).  2 GPUs: two BENCHMARK1 tiles side by side (1024x64 in 2x1).  Any other workload / count:
+    # weak scaling of the named grid over roms_amd.tiling.partition(world).
+    baseline_multi = {2: ("benchmark1", (2, 1), True), 4: ("benchmark2", (2, 2), False),
+                      8: ("benchmark3", (2, 4), False)}
+    explicit_dims = bool(args.Lm or args.Mm or args.N)
+    if world in baseline_multi and args.workload == "benchmark1" and not explicit_dims:
+        wl, tiles, weak = baseline_multi[world]
+    else:
+        wl, tiles, weak = args.workload, None, True
+    cs = params_for(wl, args.Lm, args.Mm, args.N, ntimes=args.steps + args.warmup)
     cs["ninfo"] = 1                          # NINFO of roms_benchmark1.in: diagnostics every step
-    run = tiling.TiledRun(cs, rank=rank, world=world, device=local_rank, dist=dist)
+    run = tiling.TiledRun(cs, rank=rank, world=world, device=local_rank, dist=dist, tiles=tiles, weak=weak)
+    if not weak:                             # cs names the global grid: the tile is its NtileI x NtileJ-th part
+        cs = dict(cs, Lm=cs["Lm"] // run.NtileI, Mm=cs["Mm"] // run.NtileJ)
     cells_per_rank = cs["Lm"] * cs["Mm"] * cs["N"]
 
     def barrier_sync():
@@ -299,6 +357,11 @@ def main():
         else:
             out["cpu_baseline"] = None
     run.close()
+    if rank == 0 and world == 1 and args.workload == "benchmark1" and not explicit_dims and not args.no_breakdown \
+            and not args.no_north_star:
+        # BASELINE.json north_star: "step3d_t + rhs3d at 512x512x50" -- a short pass of that grid (UPWELLING
+        # physics, U3/C4 advection: the schemes SURVEY 8(d) prices the pair on) with every kernel timed
+        out["north_star_pair_512x512x50"] = north_star_pass(hiplib, tiling, local_rank)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -100,6 +100,7 @@ typedef struct orc_s {
   orc_step s;
   orc_bounds *b;                        /* NtileI*NtileJ tiles */
   int ntiles;
+  int nthreads;                          /* > 1: the tile loops of orc_main3d_step run as OpenMP threads */
   size_t ni, nj, nij;
   /* s-coordinate */
   double *sc_r, *Cs_r, *sc_w, *Cs_w;    /* sc_r[k-1], sc_w[k] */

@@ -71,6 +71,7 @@ def lib():
         L.orc_main3d_step.argtypes = [C.c_void_p]
         L.orc_start.argtypes = [C.c_void_p]
         L.orc_diag.argtypes = [C.c_void_p]
+        L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -124,6 +125,10 @@ class Oracle:
 
     def start(self):
         self.L.orc_start(self.h)
+
+    def set_threads(self, n):
+        """n > 1: the tile loops of main3d_step run as n OpenMP threads (the reference's shared-memory mode)."""
+        self.L.orc_set_threads(self.h, int(n))
 
     def main3d_step(self, n=1):
         for _ in range(n):

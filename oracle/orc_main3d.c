@@ -3,7 +3,9 @@
  * TEST INFRASTRUCTURE (see orc.h).
  *
  *   orc_main3d_step  main3d     ROMS/Nonlinear/main3d.F:216-1148 (one STEP_LOOP pass;
- *                               LF-AM3 barotropic loop :810-918)       UNPINNED (needs NetCDF)
+ *                               LF-AM3 barotropic loop :810-918)       pinned: the reference's own kernels
+ *                               called in main3d.F order (oracle/ref/ref_glue.F90:ref_main3d),
+ *                               100 steps, every array every step (tests/test_oracle_vs_ref.py)
  *   orc_start        initial    ROMS/Nonlinear/initial.F:549-577 tail: set_massflux,
  *                               omega, rho_eos at iic=ntstart          (driver restated)
  *   orc_diag         diag_tile  ROMS/Nonlinear/diag.F:84-560           pinned (7 digits:
@@ -13,8 +15,18 @@
 #include <math.h>
 #include <stdlib.h>
 
-#define FWD(o, call) for (int tile = 0; tile < (o)->ntiles; tile++) call
-#define REV(o, call) for (int tile = (o)->ntiles - 1; tile >= 0; tile--) call
+/* Tile loops.  The reference runs them as OpenMP shared-memory tiles with a barrier after each loop
+   (Drivers/nl_roms.h:304-310, main3d.F "!$OMP BARRIER"): a tile writes its own range (and its periodic
+   images) and reads what the previous loop left, so the tiles of one loop are independent and any
+   execution order -- ascending, descending, concurrent -- gives the same bits (tests/test_oracle.py).
+   With nthreads > 1 (orc_set_threads, the cpu_baseline leg of bench.py) they run concurrently. */
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define FWD(o, call)                                                                               \
+  ORC_PRAGMA(omp parallel for schedule(static) num_threads((o)->nthreads) if ((o)->nthreads > 1))  \
+  for (int tile = 0; tile < (o)->ntiles; tile++) call
+#define REV(o, call)                                                                               \
+  ORC_PRAGMA(omp parallel for schedule(static) num_threads((o)->nthreads) if ((o)->nthreads > 1))  \
+  for (int tile = (o)->ntiles - 1; tile >= 0; tile--) call
 
 /* diag.F:84 -- global kinetic/potential energy, volume, Courant numbers, max speed.
    out: 0 avgke 1 avgpe 2 avgkp 3 volume 4 maxspeed 5 max_Cu 6 max_Cv 7 max_Cw
@@ -173,5 +185,7 @@ int orc_main3d_step(orc_t *o) {
   s->time = s->time + c->dt;
   return 0;
 }
+
+void orc_set_threads(orc_t *o, int n) { o->nthreads = n < 1 ? 1 : n; }
 
 void orc_get_diag(orc_t *o, double *out) { for (int k = 0; k < 16; k++) out[k] = o->diag[k]; }

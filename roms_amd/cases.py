@@ -1,0 +1,94 @@
+"""The BASELINE applications as parameter dicts (the values of the reference's ROMS/External/roms_upwelling.in
+and roms_benchmark{1,2,3}.in; constants of ROMS/Modules/mod_scalars.F), the form roms_amd.hostlib.write_roms_in
+turns into a roms.in for any grid size.  Used by bench.py, roms_amd.tiling and the tests."""
+import numpy as np
+
+SCHEME = dict(A4=1, C2=2, C4=3, HSIMT=4, MPDATA=5, SPLINES=6, SU3=7, U3=8)
+
+
+def upwelling(Lm=41, Mm=80, N=16, NtileI=1, NtileJ=1, hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"),
+              ntimes=100):
+    """roms_upwelling.in"""
+    return dict(
+        app="upwelling", Lm=Lm, Mm=Mm, N=N, NtileI=NtileI, NtileJ=NtileJ, ndtfast=30, ntimes=ntimes,
+        Vtransform=2, Vstretching=4, EWperiodic=1, NSperiodic=0, hadv=hadv, vadv=vadv, lmd_Jwt=1,
+        dt=300.0, theta_s=3.0, theta_b=0.0, Tcline=25.0, rho0=1025.0, R0=1027.0, T0=14.0, S0=35.0,
+        Tcoef=1.7e-4, Scoef=0.0, visc2=5.0, tnu2=(0.0, 0.0), Akt_bak=(1.0e-6, 1.0e-6), Akv_bak=1.0e-5,
+        rdrg=3.0e-4, rdrg2=3.0e-3, Zob=0.02, Zos=0.02, gamma2=1.0, dstart=0.0,
+        blk_ZQ=10.0, blk_ZT=10.0, blk_ZW=10.0,
+        # cpp options of ROMS/Include/upwelling.h
+        options=("UV_ADV", "UV_COR", "UV_VIS2", "TS_DIF2", "ANA_VMIX", "SALINITY", "APP_UPWELLING"),
+    )
+
+
+def upwelling_kpp(**kw):
+    """UPWELLING with the KPP closure (LMD_MIXING ... SOLAR_SOURCE, ANA_SRFLUX: 150 W/m2) instead of ANA_VMIX:
+    the custom application header of BASELINE config 5, oracle/ref/upwelling_kpp.h (MPDATA tracers by default)."""
+    kw.setdefault("hadv", ("MPDATA", "MPDATA"))
+    kw.setdefault("vadv", ("MPDATA", "MPDATA"))
+    cs = upwelling(**kw)
+    cs["app"] = "upwelling_kpp"
+    cs["options"] = ("UV_ADV", "UV_COR", "UV_VIS2", "TS_DIF2", "LMD_MIXING", "SOLAR_SOURCE", "SALINITY",
+                     "APP_UPWELLING")
+    return cs
+
+
+def benchmark(Lm=512, Mm=64, N=30, NtileI=1, NtileJ=1, ntimes=200):
+    """roms_benchmark1.in"""
+    return dict(
+        app="benchmark", Lm=Lm, Mm=Mm, N=N, NtileI=NtileI, NtileJ=NtileJ, ndtfast=20, ntimes=ntimes,
+        Vtransform=2, Vstretching=4, EWperiodic=1, NSperiodic=0, hadv=("U3", "U3"), vadv=("C4", "C4"),
+        lmd_Jwt=1, dt=150.0, theta_s=0.0, theta_b=0.0, Tcline=400.0, rho0=1025.0, R0=1027.0, T0=10.0,
+        S0=35.0, Tcoef=1.7e-4, Scoef=7.6e-4, visc2=5000.0, tnu2=(500.0, 500.0),
+        Akt_bak=(1.0e-5, 1.0e-5), Akv_bak=1.0e-4, rdrg=3.0e-4, rdrg2=3.0e-3, Zob=0.02, Zos=0.02,
+        gamma2=1.0, dstart=0.0, blk_ZQ=10.0, blk_ZT=10.0, blk_ZW=10.0,
+        options=("UV_ADV", "UV_COR", "UV_VIS2", "TS_DIF2", "MIX_GEO_TS", "CURVGRID", "NONLIN_EOS",
+                 "UV_QDRAG", "LMD_MIXING", "BULK_FLUXES", "SOLAR_SOURCE", "SALINITY", "SPHERICAL",
+                 "APP_BENCHMARK"),
+    )
+
+
+def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
+    """roms_hip_config for a single tile covering the domain (include/roms_hip.h)."""
+    from . import hiplib
+    c = hiplib.Config()
+    c.abi_version, c.device = 1, device
+    c.Lm, c.Mm, c.N, c.NT, c.NAT = cs["Lm"], cs["Mm"], cs["N"], 2, 2
+    hs = [SCHEME[x] for x in cs["hadv"]]
+    vs = [SCHEME[x] for x in cs["vadv"]]
+    c.Nghost = 3 if (hiplib.MPDATA in hs or hiplib.HSIMT in hs) else 2
+    Im = cs["Lm"] + ((cs["Lm"] + 2) // 2 - (cs["Lm"] + 1) // 2)
+    Jm = cs["Mm"] + ((cs["Mm"] + 2) // 2 - (cs["Mm"] + 1) // 2)
+    c.LBi, c.UBi = (-c.Nghost, Im + c.Nghost) if cs["EWperiodic"] else (0, Im + 1)
+    c.LBj, c.UBj = (-c.Nghost, Jm + c.Nghost) if cs["NSperiodic"] else (0, Jm + 1)
+    c.NtileI = c.NtileJ = 1
+    c.tile = 0
+    c.EWperiodic, c.NSperiodic = cs["EWperiodic"], cs["NSperiodic"]
+    opt = 0
+    for name in cs["options"]:
+        opt |= hiplib.OPTIONS[name]
+    c.options = opt
+    for i in range(2):
+        c.hadv[i], c.vadv[i] = hs[i], vs[i]
+    c.Istr, c.Iend, c.Jstr, c.Jend = 1, cs["Lm"], 1, cs["Mm"]
+    c.west_edge = c.east_edge = c.south_edge = c.north_edge = 1
+    c.ntfirst = c.ntstart = 1
+    c.ndtfast, c.nfast, c.ninfo = cs["ndtfast"], nfast, 0
+    c.dt = cs["dt"]
+    c.dtfast = cs["dt"] / float(cs["ndtfast"])
+    w = np.asarray(weight, dtype=np.float64).reshape(2, -1)
+    for k in range(w.shape[1]):
+        c.weight[0][k + 1] = w[0, k]
+        c.weight[1][k + 1] = w[1, k]
+    c.rho0, c.g, c.lambda_, c.gamma2, c.Cp = cs["rho0"], 9.81, 1.0, cs["gamma2"], 3985.0
+    c.R0, c.T0, c.S0, c.Tcoef, c.Scoef = cs["R0"], cs["T0"], cs["S0"], cs["Tcoef"], cs["Scoef"]
+    c.hc, c.Vtransform = hc, cs["Vtransform"]
+    c.rdrg, c.rdrg2, c.Zob = cs["rdrg"], cs["rdrg2"], cs["Zob"]
+    c.Akt_bak[0], c.Akt_bak[1], c.Akv_bak = cs["Akt_bak"][0], cs["Akt_bak"][1], cs["Akv_bak"]
+    c.dstart = cs["dstart"]
+    c.blk_ZQ, c.blk_ZT, c.blk_ZW, c.lmd_Jwt = cs["blk_ZQ"], cs["blk_ZT"], cs["blk_ZW"], cs["lmd_Jwt"]
+    for k in range(cs["N"]):
+        c.sc_r[k], c.Cs_r[k] = sc_r[k], Cs_r[k]
+    for k in range(cs["N"] + 1):
+        c.sc_w[k], c.Cs_w[k] = sc_w[k], Cs_w[k]
+    return c

@@ -15,6 +15,12 @@ from . import build as _build
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libroms_host.so")
 
+# arrays the host set-up owns (roms_host_get names = the reference's mod_grid / mod_ocean / mod_mixing names)
+HOST_FIELDS = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", "on_v", "om_p", "on_p", "omn",
+               "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v", "angler", "xr", "yr",
+               "rdrag", "rdrag2", "visc2_r", "visc2_p", "diff2", "Hz", "z_r", "z_w", "zeta", "ubar", "vbar", "u", "v",
+               "t", "Zt_avg1", "Akv", "Akt", "dmde", "dndx", "lonr", "latr", "sc_r", "Cs_r", "sc_w", "Cs_w"]
+
 _libs = {}
 
 

@@ -9,10 +9,7 @@ import pytest
 
 from tests import util
 
-HOST_FIELDS = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", "on_v", "om_p", "on_p", "omn",
-               "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v", "angler", "xr", "yr",
-               "rdrag", "rdrag2", "visc2_r", "visc2_p", "diff2", "Hz", "z_r", "z_w", "zeta", "ubar", "vbar", "u", "v",
-               "t", "Zt_avg1", "Akv", "Akt", "dmde", "dndx", "lonr", "latr", "sc_r", "Cs_r", "sc_w", "Cs_w"]
+from roms_amd.hostlib import HOST_FIELDS  # noqa: E402  (the arrays the host set-up owns)
 
 
 def _host(cs):

@@ -98,3 +98,24 @@ def test_filter_weights_moments():
     assert abs(w[0].sum() - 1.0) < 1e-13 and abs(w[1].sum() - 1.0) < 1e-13
     assert abs((w[0] * k).sum() / ndtfast - 1.0) < 1e-12
     assert np.all(w[:, nfast:] == 0.0)
+
+
+def test_threaded_tiles_bitwise():
+    """The cpu_baseline leg of bench.py runs the oracle's tile loops as OpenMP threads over eta strips
+    (NtileI = 1).  That run must be the serial one bit for bit -- same strips, one thread -- and, strips
+    keeping every periodic copy inside a tile, also the untiled one."""
+    res = []
+    for ntj, thr in [(1, 1), (4, 1), (4, 4)]:
+        cs = util.case_for("benchmark_small")
+        cs["NtileI"], cs["NtileJ"] = 1, ntj
+        g = util.load_init("benchmark_small", 2)
+        O = util.make_oracle(cs, g)
+        O.set_threads(thr)
+        O.start()
+        O.main3d_step(12)
+        res.append({n: O.field(n).copy() for n in ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Huon", "Akv", "Akt",
+                                                   "hsbl", "stflx", "sustr"]})
+        O.close()
+    for n in res[0]:
+        assert np.array_equal(res[0][n], res[1][n]), ("strips vs untiled", n)
+        assert np.array_equal(res[1][n], res[2][n]), ("threads vs serial", n)
