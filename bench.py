@@ -146,54 +146,97 @@ def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
     return cs
 
 
-def cpu_baseline(cs, H, budget_s=20.0):
-    """The reference's algorithm on the host cores of this box: the C oracle (oracle/, a scalar port pinned bit
-    for bit against the reference's object code) with its tile loops run as OpenMP threads -- the reference's
-    shared-memory mode (Drivers/nl_roms.h:304-310) -- one thread per available core.  The domain is cut into
-    NtileJ strips along eta only (NtileI = 1): with tiles along a PERIODIC axis the reference's shared-memory
-    exchange reads neighbour tiles inside the same parallel loop and the result depends on thread timing; strips
-    keep every periodic copy inside one tile, and the threaded run is bit-identical to the serial one
-    (tests/test_oracle.py::test_threaded_tiles_bitwise).  This is the ONLY place bench.py touches oracle/."""
+def _cpu_replica(args):
+    """One replica of the cpu_baseline workload: the oracle with `threads` OpenMP threads over eta strips."""
+    cs, setup, threads, strips, nsteps, go, done = args
     import numpy as np
     from oracle import orc
     from tests import cases as tcases
-    from roms_amd.hostlib import HOST_FIELDS
-    orc.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    strips = max(1, min(cs["Mm"] // 4, 2 * cores))         # >= 4 rows per strip, two strips per thread
-    threads = min(cores, strips)
     c2 = dict(cs, NtileI=1, NtileJ=strips)
-    w = np.stack([H.get("weight1"), H.get("weight2")])
-    O = orc.Oracle(tcases.oracle_cfg(c2, H.reals["hc"], H.dims["nfast"], w))
-    for n in HOST_FIELDS:
+    O = orc.Oracle(tcases.oracle_cfg(c2, setup["hc"], setup["nfast"], setup["weight"]))
+    for n, a in setup["fields"].items():
         try:
-            O.field(n)[:] = H.get(n)
+            O.field(n)[:] = a
         except KeyError:
             pass
     O.set_threads(threads)
     O.start()
-    cells = cs["Lm"] * cs["Mm"] * cs["N"]
-    t0 = time.perf_counter()
-    O.main3d_step(1)                       # first step (start-up branches), also sizes the sample
-    t1 = time.perf_counter()
-    nsteps = max(2, min(200, int(budget_s / max(t1 - t0, 1e-3))))
+    O.main3d_step(1)                       # first step: start-up branches
+    done.put("ready")
+    go.wait()
     t0 = time.perf_counter()
     O.main3d_step(nsteps)
     t1 = time.perf_counter()
     O.close()
-    return {"value": cells * nsteps / (t1 - t0), "unit": "grid-cell-updates/sec", "cores": threads, "kind": "port",
-            "sample": f"{cs['app'].upper()} {cs['Lm']}x{cs['Mm']}x{cs['N']}, steps 2..{nsteps + 1} of the same run, "
-                      f"oracle/liborc.so (gcc -O2 -fopenmp), {threads} OpenMP threads over 1x{strips} shared-memory "
-                      f"tiles ({cores} cores available), {t1 - t0:.1f} s"}
+    done.put((t0, t1))
 
 
-def north_star_pass(hiplib, tiling, device, steps=4):
+def cpu_baseline(cs, H, budget_s=15.0):
+    """The reference's algorithm on ALL host cores of this box.  The C oracle (oracle/, a port pinned bit for
+    bit against the reference's object code) runs its tile loops as OpenMP threads -- the reference's
+    shared-memory mode (Drivers/nl_roms.h:304-310) -- over NtileJ strips along eta (NtileI = 1: with tiles
+    along a PERIODIC axis the reference's shared-memory exchange reads neighbour tiles inside the same parallel
+    loop and the result depends on thread timing; strips keep every periodic copy inside one tile, and the
+    threaded run is bit-identical to the serial one, tests/test_oracle.py::test_threaded_tiles_bitwise).  A grid
+    with Mm rows feeds at most Mm/4 threads, so the remaining cores run further replicas of the same workload
+    at the same time: value = replicas x cells x steps / wall time of the slowest replica.  This is the ONLY
+    place bench.py touches oracle/."""
+    import multiprocessing as mp
+    import numpy as np
+    from oracle import orc
+    from roms_amd.hostlib import HOST_FIELDS
+    orc.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    strips = max(1, min(cs["Mm"] // 4, cores))             # >= 4 rows per strip
+    threads = strips
+    replicas = max(1, cores // threads)
+    setup = {"hc": H.reals["hc"], "nfast": H.dims["nfast"],
+             "weight": np.stack([H.get("weight1"), H.get("weight2")]), "fields": {}}
+    for n in HOST_FIELDS:
+        try:
+            setup["fields"][n] = H.get(n)
+        except KeyError:
+            pass
+    # size the sample on one replica alone, then run all of them together
+    ctx = mp.get_context("fork")
+    cells = cs["Lm"] * cs["Mm"] * cs["N"]
+    go, done = ctx.Event(), ctx.Queue()
+    probe = ctx.Process(target=_cpu_replica, args=((cs, setup, threads, strips, 2, go, done),))
+    t0 = time.perf_counter()
+    probe.start()
+    done.get()
+    go.set()
+    a, b = done.get()
+    probe.join()
+    per_step = (b - a) / 2
+    nsteps = max(2, min(400, int(budget_s / max(per_step * 1.5, 1e-3))))
+    go, done = ctx.Event(), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_replica, args=((cs, setup, threads, strips, nsteps, go, done),))
+             for _ in range(replicas)]
+    for p in procs:
+        p.start()
+    for _ in procs:
+        done.get()
+    go.set()
+    spans = [done.get() for _ in procs]
+    for p in procs:
+        p.join()
+    wall = max(t[1] for t in spans) - min(t[0] for t in spans)
+    return {"value": replicas * cells * nsteps / wall, "unit": "grid-cell-updates/sec", "cores": replicas * threads,
+            "kind": "port",
+            "sample": f"{cs['app'].upper()} {cs['Lm']}x{cs['Mm']}x{cs['N']}, {nsteps} steps after the first, "
+                      f"oracle/liborc.so (gcc -O2 -fopenmp): {replicas} concurrent replicas x {threads} OpenMP threads "
+                      f"over 1x{strips} shared-memory tiles each ({cores} cores available), {wall:.1f} s; one replica "
+                      f"alone: {cells / per_step:.3g} cell-updates/s"}
+
+
+def north_star_pass(hiplib, tiling, device, steps=6, warmup=24):
     """UPWELLING 512x512x50 with U3/C4 advection: `steps` steps with synchronous per-kernel HIP events; the
     kernels of "step3d_t + rhs3d" against their 632 algorithmic bytes per cell, and each of them alone."""
-    cs = params_for("ns512u3", ntimes=steps + 4)
+    cs = params_for("ns512u3", ntimes=steps + warmup)
     cs["ninfo"] = 1
     run = tiling.TiledRun(cs, device=device)
-    run.step(3)
+    run.step(warmup)                       # past the start-up branches (iic <= 2) and the clock ramp after the CPU leg
     run.sync()
     hiplib.kprof(1)
     run.step(steps)
@@ -242,6 +285,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
+    if torch.cuda.device_count() < 1:        # (counting devices does not initialise the GPU)
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # The CPU leg runs first, before anything initialises the GPU in this process: it forks worker processes.
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from roms_amd import hostlib as _hl
+        cs0 = params_for(args.workload, args.Lm, args.Mm, args.N, ntimes=10)
+        H0 = _hl.Host(params=cs0)
+        try:
+            cpu = cpu_baseline(cs0, H0)
+        finally:
+            H0.finalize()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -352,10 +407,7 @@ def main():
             "roofline": roofline,
             "north_star_pair": pair,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cs, run.host)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu
     run.close()
     if rank == 0 and world == 1 and args.workload == "benchmark1" and not explicit_dims and not args.no_breakdown \
             and not args.no_north_star:
