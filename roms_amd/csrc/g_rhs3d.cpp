@@ -2,6 +2,9 @@
 #include "roms_host.h"
 #include <cstdlib>
 #include "k_rhs3d.h"
+#ifndef ROMS_CPU_EMU
+#include "k_rhs3d_lds.h"
+#endif
 
 static inline KArgs mk(roms_hip_ctx *c, int p0 = 0, int p1 = 0, int p2 = 0) {
   KArgs a;
@@ -82,13 +85,49 @@ int run_uv3dmix2(roms_hip_ctx *c) {
   return 0;
 }
 
-int run_rhs3d_tile(roms_hip_ctx *c) {
+// rhs3d_tile's point-wise part.  Default: the LDS-tiled form (k_rhs3d_lds.h), a block of 64x4 points marching a
+// chunk of levels; ROMS_HIP_RHS3D_LDS=0 (and the serial CPU emulation) take the point-wise form k_rhs3d_pt.
+// Both are reported to the per-kernel timers as k_rhs3d_pt.
+static int launch_rhs3d_point_part(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   KArgs a = mk(c);
+  const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
+#ifndef ROMS_CPU_EMU
+  static const char *el = getenv("ROMS_HIP_RHS3D_LDS"), *ek = getenv("ROMS_HIP_RHS3D_KC");
+  if (!(el && el[0] == '0')) {
+    // levels per chunk: whole columns once the (xi,eta) blocks alone fill the chip (>= 2048 blocks), chunks of
+    // at least 5 levels on smaller grids so that grid.z supplies the blocks
+    const int nt = ((nx + 63) / 64) * ((ny + 3) / 4);
+    int nz = KMAX(1, (2048 + nt - 1) / nt);
+    int kc = KMAX(5, (G.N + nz - 1) / nz);
+    if (ek && atoi(ek) > 0) kc = atoi(ek);
+    kc = KMIN(kc, G.N);
+    nz = (G.N + kc - 1) / kc;
+    a.p0 = kc;
+    static const char *ew = getenv("ROMS_HIP_RHS3D_W");
+    const int w = ew ? atoi(ew) : 3;
+    const dim3 grid((unsigned)(8 * ((nt + 7) / 8) * nz), 1, 1), block(64, 4, 1);
+    const size_t lds = (size_t)RL_LDS_DOUBLES * sizeof(double);
+    // compiled for 3 waves per SIMD (168 VGPRs, three 43.5 KB blocks per CU): 376 us at 512x512x50 against 383
+    // for 2 waves (180 VGPRs, no spill) and 781 for 4 (128 VGPRs, 76 spilled); the point-wise form: 478
+    if (w == 2) KPROF_WRAP(k_rhs3d_pt, c->stream, hipLaunchKernelGGL(k_rhs3d_lds<2>, grid, block, lds, c->stream, a, nx, ny, nz));
+    else KPROF_WRAP(k_rhs3d_pt, c->stream, hipLaunchKernelGGL(k_rhs3d_lds<3>, grid, block, lds, c->stream, a, nx, ny, nz));
+    return 0;
+  }
+#endif
   a.p0 = (G.N + KCH - 1) / KCH;
+  LAUNCH_THREAD(k_rhs3d_pt, nx, ny, 2 * a.p0, c->stream, a);
+  return 0;
+}
+
+int run_rhs3d_tile(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  int r = launch_rhs3d_point_part(c);
+  if (r) return r;
+  KArgs a = mk(c);
   a.p1 = 0;
-  LAUNCH_THREAD(k_rhs3d_pt, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2 * a.p0, c->stream, a);
   LAUNCH_THREAD(k_rhs3d_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   return 0;
 }
@@ -96,14 +135,7 @@ int run_rhs3d_tile(roms_hip_ctx *c) {
 // The same two routines as the fused main3d sequence launches them: the point-wise kernels of
 // rhs3d_tile and uv3dmix2 are independent (the latter may run on the side stream), and ONE column
 // kernel then forms rufrc/rvfrc from both, in the reference's order of additions.
-int run_rhs3d_pt(roms_hip_ctx *c) {
-  const DGrid &G = c->G;
-  const TB &B = G.T;
-  KArgs a = mk(c);
-  a.p0 = (G.N + KCH - 1) / KCH;
-  LAUNCH_THREAD(k_rhs3d_pt, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2 * a.p0, c->stream, a);
-  return 0;
-}
+int run_rhs3d_pt(roms_hip_ctx *c) { return launch_rhs3d_point_part(c); }
 int run_uv3dmix2_s(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;

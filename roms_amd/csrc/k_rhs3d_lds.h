@@ -1,0 +1,331 @@
+// k_rhs3d_lds.h -- rhs3d_tile (ROMS/Nonlinear/rhs3d.F:196-1176: Coriolis, curvilinear terms, third-order
+// upstream horizontal advection, fourth-order centred vertical advection of u and v) with the horizontal
+// neighbourhood of a level staged through LDS.
+//
+// The point-wise form (k_rhs3d.h:k_rhs3d_pt) issues ~30 eight-byte loads per point, level and direction,
+// almost all of them neighbours of the same few arrays (u, v, Huon, Hvom): it is bound by the L1/issue rate,
+// not by HBM (2.2 TB/s algorithmic at 512x512x50).  Here a block of 64x4 points marches a chunk of levels;
+// for each level the (64+4)x(4+4) rectangle of u, v, Huon, Hvom and W is loaded ONCE per block (2.1 loads
+// per point and array instead of 5-9), double-buffered through registers so that the loads of level k+1 are
+// in flight while level k is evaluated from LDS: one barrier per level.  A thread evaluates BOTH momentum
+// points of its cell (the u- and the v-point share most of the neighbourhood) and carries its two vertical
+// flux recurrences in registers.  Every expression is the point-wise kernel's, operand for operand, so the two
+// forms give the same bits (tests/test_gpu_parity.py::test_column_kernel_forms_agree_bitwise, ROMS_HIP_RHS3D_LDS=0
+// selects the point-wise form; the serial CPU emulation of tests/emu has that form only).
+#pragma once
+#include "roms_ctx.h"
+
+#define RL_TW 68                      // tile width:  64 points + 2 on each side
+#define RL_TH 8                       // tile height:  4 points + 2 on each side
+#define RL_NT (RL_TW * RL_TH)         // 544 values per array and level
+#define RL_NA 5                       // u, v, Huon, Hvom, W
+#define RL_LDS_DOUBLES (2 * RL_NA * RL_NT)
+
+template <int MINW>
+static __global__ void __launch_bounds__(256, MINW) k_rhs3d_lds(const KArgs a, int nx, int ny, int nz) {
+  extern __shared__ double lds_dyn_[];
+  // XCD-aware block order of the THREAD launches (kdefs.h): all level chunks of a block column on one XCD
+  const int nby_ = (ny + 3) / 4, nt_ = ((nx + 63) / 64) * nby_, seg_ = (nt_ + 7) / 8;
+  const int r_ = (int)(blockIdx.x >> 3), xcd_ = (int)(blockIdx.x & 7);
+  const int gz = r_ % nz;
+  const int t_ = xcd_ * seg_ + r_ / nz;
+  if (t_ >= nt_) return;
+  const int tbx = t_ / nby_, tby = t_ - tbx * nby_;
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int KC = a.p0;                                   // levels per chunk
+  const int N = G.N, nrhs = G.nrhs;
+  const int k0 = gz * KC + 1, k1 = KMIN(N, k0 + KC - 1);
+  if (k0 > N) return;
+  const int tx = (int)threadIdx.x, ty = (int)threadIdx.y, tid = tx + 64 * ty;
+  const int I0 = B.Istr + tbx * 64, J0 = B.Jstr + tby * 4;     // first point of the block
+  const int i = I0 + tx, j = J0 + ty;
+  const bool inside = i <= B.Iend && j <= B.Jend;
+  const bool du = inside && i >= B.IstrU, dv = inside && j >= B.JstrV;
+  const bool COR = (G.options & ROMS_UV_COR) != 0, ADV = (G.options & ROMS_UV_ADV) != 0;
+  const bool CURV = ADV && (G.options & ROMS_CURVGRID) != 0;
+  const bool wfix = !G.ewp && B.west, efix = !G.ewp && B.east, sfix = !G.nsp && B.south, nfix = !G.nsp && B.north;
+  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
+  const size_t nij = (size_t)G.nij;
+  const long ni = G.ni;
+  const int UBi = G.LBi + G.ni - 1, UBj = G.LBj + G.nj - 1;
+  const double *u3 = F.u + (size_t)(nrhs - 1) * nij * (size_t)N, *v3 = F.v + (size_t)(nrhs - 1) * nij * (size_t)N;
+  const double Gadv = -0.25, c916 = 9.0 / 16.0, c116 = 1.0 / 16.0;
+
+  // ---- tile elements this thread stages (fixed for the whole march): e = tid + m*256 < 544
+  long gofs[3];
+  int sidx[3];
+  bool gok[3];
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    const int e = tid + m * 256;
+    const int row = e / RL_TW, col = e - row * RL_TW;
+    const int gi = I0 - 2 + col, gj = J0 - 2 + row;
+    sidx[m] = e;
+    gok[m] = e < RL_NT && gi >= G.LBi && gi <= UBi && gj >= G.LBj && gj <= UBj;
+    gofs[m] = gok[m] ? (long)X2(gi, gj) : 0;
+  }
+  double st[RL_NA][3];
+  auto stage_load = [&](int k) {          // level k of u, v, Huon, Hvom; interface k of W
+    const size_t ok = (size_t)(k - 1) * nij, okw = (size_t)k * nij;
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      if (gok[m]) {
+        st[0][m] = u3[ok + gofs[m]];
+        st[1][m] = v3[ok + gofs[m]];
+        st[2][m] = F.Huon[ok + gofs[m]];
+        st[3][m] = F.Hvom[ok + gofs[m]];
+        st[4][m] = F.W[okw + gofs[m]];
+      } else {
+        st[0][m] = 0.0; st[1][m] = 0.0; st[2][m] = 0.0; st[3][m] = 0.0; st[4][m] = 0.0;
+      }
+    }
+  };
+  auto stage_store = [&](double *buf) {
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+      if (tid + m * 256 < RL_NT) {
+#pragma unroll
+        for (int q = 0; q < RL_NA; q++) buf[q * RL_NT + sidx[m]] = st[q][m];
+      }
+  };
+
+  // ---- own-point state
+  const long x = inside ? (long)X2(i, j) : (long)X2(B.Istr, B.Jstr);
+  const long xmu = x - 1, xmv = x - ni;                  // the rho point across the u- / v-point
+  double fomn0 = 0, fomn1u = 0, fomn1v = 0, dndx0 = 0, dndx1u = 0, dndx1v = 0, dmde0 = 0, dmde1u = 0, dmde1v = 0;
+  if (inside && (COR || CURV)) {
+    fomn0 = F.fomn[x]; fomn1u = F.fomn[xmu]; fomn1v = F.fomn[xmv];
+    if (CURV) {
+      dndx0 = F.dndx[x]; dndx1u = F.dndx[xmu]; dndx1v = F.dndx[xmv];
+      dmde0 = F.dmde[x]; dmde1u = F.dmde[xmu]; dmde1v = F.dmde[xmv];
+    }
+  }
+  double *r3u = F.ru + (size_t)(nrhs - 1) * nij * (size_t)(N + 1) + x;
+  double *r3v = F.rv + (size_t)(nrhs - 1) * nij * (size_t)(N + 1) + x;
+  // vertical advection: own velocity at levels k-1 .. k+2 (clamped to 1..N), flux through the interface below
+#define RL_Q(p3, kk) (p3)[(size_t)(KMIN(KMAX((kk), 1), N) - 1) * nij + x]
+  double qu[4], qv[4], FCu = 0.0, FCv = 0.0;
+  if (inside) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { qu[q] = RL_Q(u3, k0 - 1 + q); qv[q] = RL_Q(v3, k0 - 1 + q); }
+    const int kk = k0 - 1;                               // flux through the chunk's lowest interface
+    if (ADV && kk > 0 && kk < N) {
+      const double *Wk = F.W + x + (size_t)kk * nij;
+      const double qum = RL_Q(u3, kk - 1), qvm = RL_Q(v3, kk - 1);
+      if (du) {
+        const double ww = c916 * (Wk[0] + Wk[-1]) - c116 * (Wk[1] + Wk[-2]);
+        FCu = (c916 * (qu[0] + qu[1]) - c116 * (qum + qu[2])) * ww;
+      }
+      if (dv) {
+        const double ww = c916 * (Wk[0] + Wk[-ni]) - c116 * (Wk[ni] + Wk[-2 * ni]);
+        FCv = (c916 * (qv[0] + qv[1]) - c116 * (qvm + qv[2])) * ww;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { qu[q] = 0.0; qv[q] = 0.0; }
+  }
+
+  // ---- march
+  stage_load(k0);
+  stage_store(lds_dyn_);
+  __syncthreads();
+  const int s = (ty + 2) * RL_TW + (tx + 2);             // own point in the tile
+#define LU(di, dj) cur[0 * RL_NT + s + (di) + (dj) * RL_TW]
+#define LV(di, dj) cur[1 * RL_NT + s + (di) + (dj) * RL_TW]
+#define LHU(di, dj) cur[2 * RL_NT + s + (di) + (dj) * RL_TW]
+#define LHV(di, dj) cur[3 * RL_NT + s + (di) + (dj) * RL_TW]
+#define LW(di, dj) cur[4 * RL_NT + s + (di) + (dj) * RL_TW]
+  for (int k = k0; k <= k1; k++) {
+    const double *cur = lds_dyn_ + ((k - k0) & 1) * (RL_NA * RL_NT);
+    double *nxt = lds_dyn_ + ((k - k0 + 1) & 1) * (RL_NA * RL_NT);
+    if (k < k1) stage_load(k + 1);                       // in flight while level k is evaluated
+    if (inside) {
+      const size_t ok = (size_t)(k - 1) * nij;
+      double Hz0 = 0.0, Hz1u = 0.0, Hz1v = 0.0;
+      if (COR || CURV) { Hz0 = F.Hz[ok + x]; Hz1u = F.Hz[ok + xmu]; Hz1v = F.Hz[ok + xmv]; }
+      const double qu3 = RL_Q(u3, k + 3), qv3 = RL_Q(v3, k + 3);   // enters the window after this level
+      if (du) {
+        double r = r3u[(size_t)k * nij];
+        const double uc = qu[1];
+        const double um1 = LU(-1, 0), up1 = LU(1, 0);
+        if (COR || CURV) {
+          const double v00 = LV(0, 0), v01 = LV(0, 1), vm0 = LV(-1, 0), vm1 = LV(-1, 1);
+          if (COR) {
+            const double cf0 = 0.5 * Hz0 * fomn0, cf1 = 0.5 * Hz1u * fomn1u;
+            const double UFx0 = cf0 * (v00 + v01), UFx1 = cf1 * (vm0 + vm1);
+            const double cff1 = 0.5 * (UFx0 + UFx1);
+            r = r + cff1;
+          }
+          if (CURV) {
+            double UFx0, UFx1;
+            {
+              const double cff1 = 0.5 * (v00 + v01), cff2 = 0.5 * (uc + up1);
+              const double cff3 = cff1 * dndx0, cff4 = cff2 * dmde0;
+              const double cff = Hz0 * (cff3 - cff4);
+              UFx0 = cff * cff1;
+            }
+            {
+              const double cff1 = 0.5 * (vm0 + vm1), cff2 = 0.5 * (um1 + uc);
+              const double cff3 = cff1 * dndx1u, cff4 = cff2 * dmde1u;
+              const double cff = Hz1u * (cff3 - cff4);
+              UFx1 = cff * cff1;
+            }
+            const double cff1 = 0.5 * (UFx0 + UFx1);
+            r = r + cff1;
+          }
+        }
+        if (ADV) {
+          const double um2 = LU(-2, 0), up2 = LU(2, 0);
+          const double hm2 = LHU(-2, 0), hm1 = LHU(-1, 0), h0 = LHU(0, 0), hp1 = LHU(1, 0), hp2 = LHU(2, 0);
+          double uxm = um2 - 2.0 * um1 + uc, ux0 = um1 - 2.0 * uc + up1, uxp = uc - 2.0 * up1 + up2;
+          double hxm = hm2 - 2.0 * hm1 + h0, hx0 = hm1 - 2.0 * h0 + hp1, hxp = h0 - 2.0 * hp1 + hp2;
+          if (wfix && i - 1 == Istr) { uxm = ux0; hxm = hx0; }
+          if (efix && i + 1 == Iend + 1) { uxp = ux0; hxp = hx0; }
+          double UFx0, UFxm;
+          {
+            const double cff1 = uc + up1;
+            const double cff = (cff1 > 0.0) ? ux0 : uxp;
+            UFx0 = 0.25 * (cff1 + Gadv * cff) * (h0 + hp1 + Gadv * 0.5 * (hx0 + hxp));
+          }
+          {
+            const double cff1 = um1 + uc;
+            const double cff = (cff1 > 0.0) ? uxm : ux0;
+            UFxm = 0.25 * (cff1 + Gadv * cff) * (hm1 + h0 + Gadv * 0.5 * (hxm + hx0));
+          }
+          const double u0m1 = LU(0, -1), u0p1 = LU(0, 1);
+          const int jm2 = (sfix && j == Jstr) ? -1 : -2, jp2 = (nfix && j == Jend) ? 1 : 2;
+          double uem = LU(0, jm2) - 2.0 * u0m1 + uc, ue0 = u0m1 - 2.0 * uc + u0p1, uep = uc - 2.0 * u0p1 + LU(0, jp2);
+          if (sfix && j - 1 == Jstr - 1) uem = ue0;
+          if (nfix && j + 1 == Jend + 1) uep = ue0;
+          double UFe0, UFep;
+          {
+            const double hvm2 = LHV(-2, 0), hvm1 = LHV(-1, 0), hv0 = LHV(0, 0), hvp1 = LHV(1, 0);
+            const double cff1 = uc + u0m1;
+            const double cff2 = hv0 + hvm1;
+            const double cff = (cff2 > 0.0) ? uem : ue0;
+            UFe0 = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * ((hvm1 - 2.0 * hv0 + hvp1) + (hvm2 - 2.0 * hvm1 + hv0)));
+          }
+          {
+            const double hvm2 = LHV(-2, 1), hvm1 = LHV(-1, 1), hv0 = LHV(0, 1), hvp1 = LHV(1, 1);
+            const double cff1 = u0p1 + uc;
+            const double cff2 = hv0 + hvm1;
+            const double cff = (cff2 > 0.0) ? ue0 : uep;
+            UFep = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * ((hvm1 - 2.0 * hv0 + hvp1) + (hvm2 - 2.0 * hvm1 + hv0)));
+          }
+          const double cff1 = UFx0 - UFxm;
+          const double cff2 = UFep - UFe0;
+          const double cff = cff1 + cff2;
+          r = r - cff;
+          // vertical: flux through interface k (above this level) minus the one below
+          double FCtop = 0.0;
+          if (k < N) {
+            const double ww = c916 * (LW(0, 0) + LW(-1, 0)) - c116 * (LW(1, 0) + LW(-2, 0));
+            FCtop = (c916 * (qu[1] + qu[2]) - c116 * (qu[0] + qu[3])) * ww;
+          }
+          const double cffv = FCtop - FCu;
+          r = r - cffv;
+          FCu = FCtop;
+        }
+        r3u[(size_t)k * nij] = r;
+      }
+      if (dv) {
+        double r = r3v[(size_t)k * nij];
+        const double vc = qv[1];
+        const double v0m1 = LV(0, -1), v0p1 = LV(0, 1);
+        if (COR || CURV) {
+          const double u00 = LU(0, 0), u10 = LU(1, 0), u0m = LU(0, -1), u1m = LU(1, -1);
+          if (COR) {
+            const double cf0 = 0.5 * Hz0 * fomn0, cf1 = 0.5 * Hz1v * fomn1v;
+            const double VFe0 = cf0 * (u00 + u10), VFe1 = cf1 * (u0m + u1m);
+            const double cff1 = 0.5 * (VFe0 + VFe1);
+            r = r - cff1;
+          }
+          if (CURV) {
+            double VFe0, VFe1;
+            {
+              const double cff1 = 0.5 * (vc + v0p1), cff2 = 0.5 * (u00 + u10);
+              const double cff3 = cff1 * dndx0, cff4 = cff2 * dmde0;
+              const double cff = Hz0 * (cff3 - cff4);
+              VFe0 = cff * cff2;
+            }
+            {
+              const double cff1 = 0.5 * (v0m1 + vc), cff2 = 0.5 * (u0m + u1m);
+              const double cff3 = cff1 * dndx1v, cff4 = cff2 * dmde1v;
+              const double cff = Hz1v * (cff3 - cff4);
+              VFe1 = cff * cff2;
+            }
+            const double cff1 = 0.5 * (VFe0 + VFe1);
+            r = r - cff1;
+          }
+        }
+        if (ADV) {
+          const double vm1 = LV(-1, 0), vp1 = LV(1, 0);
+          double vxm = LV(-2, 0) - 2.0 * vm1 + vc, vx0 = vm1 - 2.0 * vc + vp1, vxp = vc - 2.0 * vp1 + LV(2, 0);
+          if (wfix && i - 1 == Istr - 1) vxm = vx0;
+          if (efix && i + 1 == Iend + 1) vxp = vx0;
+          double VFx0, VFxp;
+          {
+            const double hm2 = LHU(0, -2), hm1 = LHU(0, -1), h0 = LHU(0, 0), hp1 = LHU(0, 1);
+            const double cff1 = vc + vm1;
+            const double cff2 = h0 + hm1;
+            const double cff = (cff2 > 0.0) ? vxm : vx0;
+            VFx0 = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * ((hm1 - 2.0 * h0 + hp1) + (hm2 - 2.0 * hm1 + h0)));
+          }
+          {
+            const double hm2 = LHU(1, -2), hm1 = LHU(1, -1), h0 = LHU(1, 0), hp1 = LHU(1, 1);
+            const double cff1 = vp1 + vc;
+            const double cff2 = h0 + hm1;
+            const double cff = (cff2 > 0.0) ? vx0 : vxp;
+            VFxp = 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * ((hm1 - 2.0 * h0 + hp1) + (hm2 - 2.0 * hm1 + h0)));
+          }
+          const int jp2 = (nfix && j == Jend) ? 1 : 2;
+          const double v0m2 = LV(0, -2), v0p2 = LV(0, jp2);
+          const double gm2 = LHV(0, -2), gm1 = LHV(0, -1), g0 = LHV(0, 0), gp1 = LHV(0, 1), gp2 = LHV(0, jp2);
+          double vem = v0m2 - 2.0 * v0m1 + vc, ve0 = v0m1 - 2.0 * vc + v0p1, vep = vc - 2.0 * v0p1 + v0p2;
+          double gem = gm2 - 2.0 * gm1 + g0, ge0 = gm1 - 2.0 * g0 + gp1, gep = g0 - 2.0 * gp1 + gp2;
+          if (sfix && j - 1 == Jstr) { vem = ve0; gem = ge0; }
+          if (nfix && j + 1 == Jend + 1) { vep = ve0; gep = ge0; }
+          double VFe0, VFem;
+          {
+            const double cff1 = vc + v0p1;
+            const double cff = (cff1 > 0.0) ? ve0 : vep;
+            VFe0 = 0.25 * (cff1 + Gadv * cff) * (g0 + gp1 + Gadv * 0.5 * (ge0 + gep));
+          }
+          {
+            const double cff1 = v0m1 + vc;
+            const double cff = (cff1 > 0.0) ? vem : ve0;
+            VFem = 0.25 * (cff1 + Gadv * cff) * (gm1 + g0 + Gadv * 0.5 * (gem + ge0));
+          }
+          const double cff1 = VFxp - VFx0;
+          const double cff2 = VFe0 - VFem;
+          const double cff = cff1 + cff2;
+          r = r - cff;
+          double FCtop = 0.0;
+          if (k < N) {
+            const double ww = c916 * (LW(0, 0) + LW(0, -1)) - c116 * (LW(0, 1) + LW(0, -2));
+            FCtop = (c916 * (qv[1] + qv[2]) - c116 * (qv[0] + qv[3])) * ww;
+          }
+          const double cffv = FCtop - FCv;
+          r = r - cffv;
+          FCv = FCtop;
+        }
+        r3v[(size_t)k * nij] = r;
+      }
+      qu[0] = qu[1]; qu[1] = qu[2]; qu[2] = qu[3]; qu[3] = qu3;
+      qv[0] = qv[1]; qv[1] = qv[2]; qv[2] = qv[3]; qv[3] = qv3;
+    }
+    if (k < k1) {
+      stage_store(nxt);
+      __syncthreads();
+    }
+  }
+#undef LU
+#undef LV
+#undef LHU
+#undef LHV
+#undef LW
+#undef RL_Q
+}

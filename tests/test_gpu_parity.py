@@ -508,7 +508,7 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
     import sys
     import textwrap
     ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    names = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "wvel", "Huon", "Hvom", "Akv"]
+    names = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "wvel", "Huon", "Hvom", "Akv", "ru", "rv", "rufrc", "rvfrc"]
     code = textwrap.dedent("""
         import sys
         sys.path.insert(0, %r)
@@ -528,7 +528,9 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
     out = []
     with tempfile.TemporaryDirectory() as td:
         # third run: the marching forms large grids select (levels per thread of uv3dmix2, wvelocity, t3dmix2_geo)
-        for tag, extra in (("lds", {}), ("priv", {"ROMS_HIP_COLLDS": "0", "ROMS_HIP_WVELF": "0"}),
+        # "priv" also takes the point-wise form of rhs3d_tile's advection/Coriolis kernel instead of the LDS-tiled one
+        for tag, extra in (("lds", {}), ("priv", {"ROMS_HIP_COLLDS": "0", "ROMS_HIP_WVELF": "0", "ROMS_HIP_RHS3D_LDS": "0"}),
+                           ("rhs_chunks", {"ROMS_HIP_RHS3D_KC": "7", "ROMS_HIP_RHS3D_W": "2"}),
                            ("march", {"ROMS_HIP_UVCH": "7", "ROMS_HIP_WVELCH": "100", "ROMS_HIP_GEOCH": "7", "ROMS_HIP_T3CH": "9"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
