@@ -30,7 +30,7 @@ int run_eos_nonlinear(roms_hip_ctx *c) {
   HaloSpec sp[7] = {{c->F.rho, N, BC_NONE, 'r'},  {c->F.pden, N, BC_NONE, 'r'}, {c->F.alpha, 1, BC_NONE, 'r'},
                     {c->F.beta, 1, BC_NONE, 'r'}, {c->F.rhoA, 1, BC_NONE, 'r'}, {c->F.rhoS, 1, BC_NONE, 'r'},
                     {c->F.bvf, N + 1, BC_NONE, 'r'}};
-  launch_halo_multi(c, sp, 7);
+  launch_halo_tail(c, sp, 7);
   return 0;
 }
 
@@ -81,7 +81,7 @@ int run_lmd_vmix(roms_hip_ctx *c) {
   HaloSpec sp[3] = {{c->F.hsbl, 1, BC_R, 'r'},                       // bc_r2d_tile lmd_skpp.F:608
                     {c->F.Akv, N + 1, BC_R, 'r'},                    // bc_w3d_tile lmd_vmix.F:740-760
                     {c->F.Akt, (N + 1) * G.NAT, BC_R, 'r'}};
-  launch_halo_multi(c, sp, 3);
+  launch_halo_tail(c, sp, 3);
   return 0;
 }
 

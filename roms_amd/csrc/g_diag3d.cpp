@@ -29,7 +29,7 @@ int run_set_depth(roms_hip_ctx *c) {
       {c->F.z_r, N, BC_NONE, 'r'},
       {c->F.Hz, N, BC_NONE, 'r'},
   };
-  launch_halo_multi(c, hs1, 4);
+  launch_halo_tail(c, hs1, 4);
   return 0;
 }
 
@@ -44,7 +44,7 @@ int run_set_massflux(roms_hip_ctx *c) {
       {c->F.Huon, N, BC_NONE, 'u'},
       {c->F.Hvom, N, BC_NONE, 'v'},
   };
-  launch_halo_multi(c, hs2, 2);
+  launch_halo_tail(c, hs2, 2);
   return 0;
 }
 
@@ -64,7 +64,7 @@ int run_rho_eos(roms_hip_ctx *c) {
       {c->F.beta, 1, BC_NONE, 'r'},
       {c->F.bvf, N + 1, BC_NONE, 'r'},
   };
-  launch_halo_multi(c, hs3, (c->G.options & ROMS_LMD_MIXING) ? 7 : 4);
+  launch_halo_tail(c, hs3, (c->G.options & ROMS_LMD_MIXING) ? 7 : 4);
   return 0;
 }
 
@@ -90,7 +90,7 @@ int run_ana_vmix(roms_hip_ctx *c) {
       {c->F.Akv, N + 1, BC_NONE, 'r'},
       {c->F.Akt, (N + 1) * c->G.NAT, BC_NONE, 'r'},
   };
-  launch_halo_multi(c, hs5, 2);
+  launch_halo_tail(c, hs5, 2);
   return 0;
 }
 
@@ -119,7 +119,10 @@ int run_omega(roms_hip_ctx *c) {
     if (l) LAUNCH_COL_AS(k_omega, k_omega_l, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, 2 * (c->G.N + 1), c->stream, a);
     else LAUNCH_THREAD(k_omega, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   }
-  if (!c->G.fuse3d) launch_halo(c, c->F.W, c->G.N + 1, BC_R, 'r');   // bc_w3d_tile (fused: pt_emit in the kernel)
+  if (!c->G.fuse3d) {   // bc_w3d_tile (fused: pt_emit in the kernel)
+    const HaloSpec hw = {c->F.W, c->G.N + 1, BC_R, 'r'};
+    launch_halo_tail(c, &hw, 1);
+  }
   return 0;
 }
 
@@ -146,7 +149,10 @@ int run_wvelocity(roms_hip_ctx *c, int ninp) {
   a.p1 = ew ? atoi(ew) : (cols >= 128L * 1024L ? N + 1 : 10);
   if (a.p1 < 1) a.p1 = KCH;
   LAUNCH_THREAD_AS(k_wvel, k_wvel_f, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (N + a.p1) / a.p1, c->stream, a);
-  if (!c->G.fuse3d) launch_halo(c, c->F.wvel, N + 1, BC_R, 'r');     // bc_w3d_tile (fused: emit_store in the kernel)
+  if (!c->G.fuse3d) {   // bc_w3d_tile (fused: emit_store in the kernel)
+    const HaloSpec hw = {c->F.wvel, N + 1, BC_R, 'r'};
+    launch_halo_tail(c, &hw, 1);
+  }
   return 0;
 }
 

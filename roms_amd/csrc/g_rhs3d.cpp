@@ -35,7 +35,7 @@ int run_pre_step3d(roms_hip_ctx *c) {
   if (G.fuse3d && !any_col) return 0;   // k_pre_t3 stored the boundary values and images (pt_emit)
   HaloSpec sp[ROMS_MAXT];
   for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, 3, it), G.N, BC_R, 'r'};   // t3dbc + exchange :1157-1171
-  launch_halo_multi(c, sp, G.NT);
+  launch_halo_tail(c, sp, G.NT);
   return 0;
 }
 

@@ -115,6 +115,6 @@ int run_step3d_t(roms_hip_ctx *c) {
   if (G.fuse3d && !any_mp) return 0;   // k_s3t_col stored the boundary values and images (pt_emit)
   HaloSpec sp[ROMS_MAXT];
   for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, BC_R, 'r'};   // t3dbc :1858 + exchange :1920
-  launch_halo_multi(c, sp, G.NT);
+  launch_halo_tail(c, sp, G.NT);
   return 0;
 }

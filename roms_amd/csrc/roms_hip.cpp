@@ -267,6 +267,25 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     const char *e = getenv("ROMS_HIP_OVERLAP");
     c->overlap = !(e && e[0] == '0');
   }
+  c->xstream = nullptr;
+  c->x_async = false;
+  c->x_tail = false;
+  c->x_pending = 0;
+  c->ev_x_next = 0;
+  for (int k = 0; k < 16; k++) c->x_event_of[k] = -1;
+  if (c->has_exchange) {
+    // Default: on when the neighbours are other ranks (an xGMI transfer to hide), off on the one-GPU
+    // self-exchange test path, where the "transfer" is a local copy and the four cross-stream hops of an
+    // asynchronous exchange only cost (measured: BENCHMARK1 2.92 -> 3.24, 512x512x50 10.48 -> 10.65,
+    // BENCHMARK3 13.06 -> 13.19 ms per step).  ROMS_HIP_XASYNC=0/1 forces it (the parity tests run both).
+    const char *e = getenv("ROMS_HIP_XASYNC"), *ep = getenv("ROMS_HIP_XASYNC_PLANES"), *es2 = getenv("ROMS_HIP_SELF_EXCHANGE");
+    const bool selfx = es2 && es2[0] == '1';
+    c->x_async = e ? e[0] != '0' : !selfx;
+    c->x_min_planes = ep ? atoi(ep) : 8;
+    if (hipfail(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return 2; }
+    (void)hipEventCreateWithFlags(&c->ev_xprod, hipEventDisableTiming | hipEventDisableSystemFence);
+    for (int k = 0; k < 32; k++) (void)hipEventCreateWithFlags(&c->ev_x[k], hipEventDisableTiming | hipEventDisableSystemFence);
+  }
 #endif
   // state arrays
   memset(&c->F, 0, sizeof(c->F));
@@ -357,6 +376,12 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->xstream) {
+    (void)hipStreamSynchronize(c->xstream);
+    (void)hipEventDestroy(c->ev_xprod);
+    for (int k = 0; k < 32; k++) (void)hipEventDestroy(c->ev_x[k]);
+    (void)hipStreamDestroy(c->xstream);
+  }
 #endif
   for (void *p : c->allocs) dfree(p);
   for (int k = 0; k < 8; k++) { if (c->comm.sbuf[k]) dfree(c->comm.sbuf[k]); if (c->comm.rbuf[k]) dfree(c->comm.rbuf[k]); }
@@ -400,15 +425,20 @@ extern "C" int roms_hip_upload(roms_hip_ctx *c, const char *name, const double *
   if (!f) { set_error(std::string("unknown field ") + name); return 8; }
   if (n != field_elems(c, f->kind)) { set_error(std::string("size mismatch for field ") + name); return 8; }
   if (f->kind == FK_2D) c->m2d_dirty = true;
+  halo_fence(c, FG_ALL);
   return h2d(*(double **)((char *)&c->F + f->offset), host, (size_t)n * sizeof(double), c->stream);
 }
 extern "C" int roms_hip_download(roms_hip_ctx *c, const char *name, double *host, long n) {
   const FieldDesc *f = find_field(name);
   if (!f) { set_error(std::string("unknown field ") + name); return 8; }
   if (n != field_elems(c, f->kind)) { set_error(std::string("size mismatch for field ") + name); return 8; }
+  halo_fence(c, FG_ALL);
   return d2h(host, *(double **)((char *)&c->F + f->offset), (size_t)n * sizeof(double), c->stream);
 }
-extern "C" int roms_hip_sync(roms_hip_ctx *c) { return dsync(c->stream); }
+extern "C" int roms_hip_sync(roms_hip_ctx *c) {
+  halo_fence(c, FG_ALL);
+  return dsync(c->stream);
+}
 int run_step2d(roms_hip_ctx *c);
 int run_rhs3d_pt(roms_hip_ctx *c);
 int run_uv3dmix2_s(roms_hip_ctx *c);
@@ -673,6 +703,52 @@ extern "C" int roms_hip_set_exchange(roms_hip_ctx *c, roms_hip_exchange_fn fn, v
 }
 extern "C" long roms_hip_exchange_count(roms_hip_ctx *c) { return c ? c->comm.nexchanges : 0; }
 
+// ---- overlap of halo exchanges with compute ------------------------------------------------------
+// field group of a device array (any plane of it)
+static unsigned group_of(const roms_hip_ctx *c, const double *p) {
+  static const struct { const char *name; unsigned g; } map[] = {
+      {"sustr", FG_FLUX}, {"svstr", FG_FLUX}, {"bustr", FG_FLUX}, {"bvstr", FG_FLUX}, {"stflx", FG_FLUX}, {"btflx", FG_FLUX},
+      {"stflux", FG_FLUX}, {"btflux", FG_FLUX}, {"srflx", FG_FLUX}, {"Uwind", FG_FLUX}, {"Vwind", FG_FLUX}, {"Tair", FG_FLUX},
+      {"Pair", FG_FLUX}, {"Hair", FG_FLUX}, {"rain", FG_FLUX}, {"cloud", FG_FLUX}, {"lhflx", FG_FLUX}, {"shflx", FG_FLUX},
+      {"lrflx", FG_FLUX}, {"evap", FG_FLUX},
+      {"rho", FG_RHO}, {"pden", FG_RHO}, {"rhoA", FG_RHO}, {"rhoS", FG_RHO}, {"bvf", FG_RHO}, {"alpha", FG_RHO}, {"beta", FG_RHO},
+      {"Huon", FG_MF}, {"Hvom", FG_MF}, {"W", FG_W}, {"wvel", FG_WVEL},
+      {"Akv", FG_AK}, {"Akt", FG_AK}, {"ghats", FG_AK}, {"hsbl", FG_AK},
+      {"t", FG_T}, {"u", FG_UV}, {"v", FG_UV},
+      {"zeta", FG_2D}, {"ubar", FG_2D}, {"vbar", FG_2D}, {"rzeta", FG_2D}, {"rubar", FG_2D}, {"rvbar", FG_2D},
+      {"Zt_avg1", FG_AVG}, {"DU_avg1", FG_AVG}, {"DU_avg2", FG_AVG}, {"DV_avg1", FG_AVG}, {"DV_avg2", FG_AVG},
+      {"Hz", FG_HZ}, {"z_r", FG_HZ}, {"z_w", FG_HZ},
+      {"ru", FG_R}, {"rv", FG_R}, {"rufrc", FG_R}, {"rvfrc", FG_R}};
+  for (int k = 0; k < g_nfields; k++) {
+    const double *base = *(double *const *)((const char *)&c->F + g_fields[k].offset);
+    if (!base || p < base || p >= base + field_elems(c, g_fields[k].kind)) continue;
+    for (const auto &m : map)
+      if (!strcmp(m.name, g_fields[k].name)) return m.g;
+    return FG_OTHER;
+  }
+  return FG_OTHER;
+}
+void halo_fence(roms_hip_ctx *c, unsigned groups) {
+#ifndef ROMS_CPU_EMU
+  const unsigned need = groups & c->x_pending;
+  if (!need) return;
+  bool waited[32] = {};
+  for (int g = 0; g < 13; g++) {
+    if (!(need & (1u << g))) continue;
+    const int e = c->x_event_of[g];
+    if (e >= 0 && !waited[e]) {
+      // both compute streams: the side stream's kernels are ordered behind the main stream's fork only
+      (void)hipStreamWaitEvent(c->stream, c->ev_x[e], 0);
+      (void)hipStreamWaitEvent(c->stream2, c->ev_x[e], 0);
+      waited[e] = true;
+    }
+  }
+  c->x_pending &= ~need;
+#else
+  (void)c; (void)groups;
+#endif
+}
+
 // Boundary fills and strip exchange of the fields of one exchange point (multi-tile contexts):
 // fill + pack launch, one group of sends/receives with the up to eight neighbours, unpack launch.
 static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
@@ -686,6 +762,9 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
   const size_t need = (size_t)planes * lines * 3;
   if (need > m.cap) {
     (void)dsync(c->stream);
+#ifndef ROMS_CPU_EMU
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);   // an exchange in flight still uses the old buffers
+#endif
     for (int k = 0; k < 8; k++) {
       if (m.sbuf[k]) dfree(m.sbuf[k]);
       if (m.rbuf[k]) dfree(m.rbuf[k]);
@@ -716,9 +795,34 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
   XchgArgs a;
   a.G = G; a.nitems = h.nitems;
   for (int k = 0; k < HALO_MAXITEMS; k++) a.it[k] = h.it[k];
+  // Stream of the exchange.  Asynchronous mode: its own stream, ordered behind everything enqueued on the
+  // compute stream so far (the producing kernel); kernels enqueued afterwards run beside it until one of them
+  // touches a field group of this exchange (halo_fence).  The exchange kernels read the strips of the tile's own
+  // points and write ghost points, boundary points and the buffers only.
+  kstream_t xs = c->stream;
+  unsigned groups = 0;
+  for (int k = 0; k < h.nitems; k++) groups |= group_of(c, h.it[k].A);
+#ifndef ROMS_CPU_EMU
+  // Only exchanges that have something to hide behind go to the exchange stream: the 3-D fields (a cross-stream
+  // dependency costs ~3 us per hop, four hops per exchange; measured on the self-exchange path, BENCHMARK1:
+  // every exchange asynchronous 2.90 -> 3.85 ms per step).  The barotropic exchanges -- each sub-step needs the
+  // previous one's ghost points at once -- stay on the compute stream, behind whatever the exchange stream
+  // still holds (the send/receive buffers and the communicator are shared).
+  const bool async = c->x_async && c->x_tail && planes >= c->x_min_planes && !(groups & (FG_2D | FG_AVG));
+  if (async) {
+    halo_fence(c, groups);            // an earlier exchange of the same fields: keep the two in order on both sides
+    xs = c->xstream;
+    (void)hipEventRecord(c->ev_xprod, c->stream);
+    (void)hipStreamWaitEvent(xs, c->ev_xprod, 0);
+  } else if (c->x_async) {
+    halo_fence(c, FG_ALL);
+  }
+#else
+  const bool async = false;
+#endif
   a.unpack = 0; a.fill = 1;
   for (int d = 0; d < 8; d++) a.buf[d] = m.nbr[d] >= 0 ? m.sbuf[d] : nullptr;
-  LAUNCH_COOP(xchg_kernel, 1, 1, planes, 256, 0, c->stream, a);
+  LAUNCH_COOP(xchg_kernel, 1, 1, planes, 256, 0, xs, a);
   // Messages are issued in the order of their tag = direction of travel (0 eastward, 1 westward,
   // 2 northward, 3 southward, 4 NE, 5 NW, 6 SE, 7 SW): several messages between the same pair of
   // ranks (small periodic partitions) then match by issue order as well as by tag.
@@ -733,7 +837,7 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
     if (m.nbr[from] >= 0) { rp[nr] = m.nbr[from]; rb[nr] = m.rbuf[from]; rc[nr] = count(from, false); rt[nr] = tag; nr++; }
   }
   if (m.fn) {
-    int r = dsync(c->stream);
+    int r = dsync(xs);
     if (r) return r;
     if (m.fn(m.user, ns, sp, sb, sc, st, nr, rp, rb, rc, rt)) { set_error("halo exchange transport failed"); return 2; }
   } else {
@@ -741,15 +845,25 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
     ncclComm_t comm = (ncclComm_t)m.nccl;
     if (rcclfail(g_rccl.GroupStart(), "ncclGroupStart")) return 2;
     for (int k = 0; k < ns; k++)
-      if (rcclfail(g_rccl.Send(sb[k], (size_t)sc[k], ncclDouble, sp[k], comm, c->stream), "ncclSend")) return 2;
+      if (rcclfail(g_rccl.Send(sb[k], (size_t)sc[k], ncclDouble, sp[k], comm, xs), "ncclSend")) return 2;
     for (int k = 0; k < nr; k++)
-      if (rcclfail(g_rccl.Recv(rb[k], (size_t)rc[k], ncclDouble, rp[k], comm, c->stream), "ncclRecv")) return 2;
+      if (rcclfail(g_rccl.Recv(rb[k], (size_t)rc[k], ncclDouble, rp[k], comm, xs), "ncclRecv")) return 2;
     if (rcclfail(g_rccl.GroupEnd(), "ncclGroupEnd")) return 2;
 #endif
   }
   a.unpack = 1; a.fill = 0;
   for (int d = 0; d < 8; d++) a.buf[d] = m.nbr[d] >= 0 ? m.rbuf[d] : nullptr;
-  LAUNCH_COOP(xchg_kernel, 1, 1, planes, 256, 0, c->stream, a);
+  LAUNCH_COOP(xchg_kernel, 1, 1, planes, 256, 0, xs, a);
+#ifndef ROMS_CPU_EMU
+  if (async) {
+    const int e = c->ev_x_next;
+    c->ev_x_next = (e + 1) % 32;
+    (void)hipEventRecord(c->ev_x[e], xs);
+    for (int g = 0; g < 13; g++)
+      if (groups & (1u << g)) c->x_event_of[g] = e;
+    c->x_pending |= groups;
+  }
+#endif
   m.nexchanges++;
   return 0;
 }
@@ -772,37 +886,48 @@ void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n) {
   }
 }
 
+void launch_halo_tail(roms_hip_ctx *c, const HaloSpec *sp, int n) {
+  c->x_tail = true;
+  launch_halo_multi(c, sp, n);
+  c->x_tail = false;
+}
+
 // ---------------------------------------------------------------------- per-kernel C entries
-#define ENTRY(name, region)                                             \
+// `groups`: every field group the routine reads or writes (over-approximated from the reference routine's
+// argument list); an exchange in flight that carries one of them is waited for first (halo_fence), all
+// others keep running beside the routine's kernels.
+#define ENTRY(name, region, groups)                                     \
   extern "C" int roms_hip_##name(roms_hip_ctx *c) {                     \
     if (!c) return 8;                                                   \
     RegionTimer rt(c, region);                                          \
+    halo_fence(c, (groups));                                            \
     int r = run_##name(c);                                              \
     return r ? r : ctx_check(c, #name);                                 \
   }
-ENTRY(set_depth, 12)
-ENTRY(set_massflux, 12)
-ENTRY(rho_eos, 14)
-ENTRY(set_vbc, 6)
-ENTRY(ana_vmix, 18)
-ENTRY(set_data, 4)
-ENTRY(omega, 13)
-ENTRY(set_zeta, 12)
-ENTRY(ini_zeta, 2)
-ENTRY(ini_fields, 2)
-ENTRY(pre_step3d, 22)
-ENTRY(prsgrd, 23)
-ENTRY(t3dmix2, 24)
-ENTRY(uv3dmix2, 30)
-ENTRY(rhs3d_tile, 21)
-ENTRY(step2d, 9)
-ENTRY(step3d_uv, 34)
-ENTRY(step3d_t, 35)
-ENTRY(lmd_vmix, 18)
-ENTRY(bulk_flux, 17)
+ENTRY(set_depth, 12, FG_HZ | FG_AVG)                                        // set_depth.F:76: Zt_avg1 -> Hz, z_r, z_w
+ENTRY(set_massflux, 12, FG_MF | FG_UV | FG_HZ)                              // set_massflux.F:25
+ENTRY(rho_eos, 14, FG_RHO | FG_T | FG_HZ)                                   // rho_eos.F:70
+ENTRY(set_vbc, 6, FG_FLUX | FG_UV | FG_HZ | FG_2D | FG_T)                          // set_vbc.F:27
+ENTRY(ana_vmix, 18, FG_AK | FG_HZ)
+ENTRY(set_data, 4, FG_FLUX)
+ENTRY(omega, 13, FG_W | FG_MF | FG_HZ)                                      // omega.F:96
+ENTRY(set_zeta, 12, FG_2D | FG_AVG)
+ENTRY(ini_zeta, 2, FG_ALL)
+ENTRY(ini_fields, 2, FG_ALL)
+ENTRY(pre_step3d, 22, FG_T | FG_UV | FG_MF | FG_W | FG_AK | FG_HZ | FG_FLUX | FG_R)       // pre_step3d.F:126
+ENTRY(prsgrd, 23, FG_R | FG_RHO | FG_HZ)                                    // prsgrd32.h
+ENTRY(t3dmix2, 24, FG_T | FG_HZ | FG_RHO)
+ENTRY(uv3dmix2, 30, FG_UV | FG_HZ | FG_R)
+ENTRY(rhs3d_tile, 21, FG_R | FG_UV | FG_MF | FG_W | FG_HZ | FG_FLUX)        // rhs3d.F:196
+ENTRY(step2d, 9, FG_2D | FG_AVG | FG_R | FG_RHO)                            // step2d_LF_AM3.h:163
+ENTRY(step3d_uv, 34, FG_UV | FG_MF | FG_2D | FG_AVG | FG_AK | FG_HZ | FG_R | FG_FLUX)     // step3d_uv.F:134
+ENTRY(step3d_t, 35, FG_T | FG_MF | FG_W | FG_AK | FG_HZ | FG_FLUX)          // step3d_t.F:120
+ENTRY(lmd_vmix, 18, FG_AK | FG_RHO | FG_UV | FG_HZ | FG_FLUX | FG_T)        // lmd_vmix.F:45
+ENTRY(bulk_flux, 17, FG_FLUX | FG_T | FG_UV | FG_RHO | FG_HZ)               // bulk_flux.F:100
 
 extern "C" int roms_hip_wvelocity(roms_hip_ctx *c, int ninp) {
   RegionTimer rt(c, 12);
+  halo_fence(c, FG_WVEL | FG_W | FG_UV | FG_HZ | FG_AVG);                   // wvelocity.F:30
   int r = run_wvelocity(c, ninp);
   return r ? r : ctx_check(c, "wvelocity");
 }
@@ -822,6 +947,7 @@ extern "C" int roms_hip_copy_probe(roms_hip_ctx *c, int reps, long *bytes_per_la
 }
 extern "C" int roms_hip_diag(roms_hip_ctx *c, double *out) {
   RegionTimer rt(c, 7);
+  halo_fence(c, FG_UV | FG_RHO | FG_HZ | FG_WVEL);
   return run_diag(c, out);
 }
 
@@ -875,7 +1001,12 @@ static int main3d_one(roms_hip_ctx *c) {
   }
   side_begin(c);
   r = 0;
-  if (do_diag) { r = run_diag_async(c, c->d_diag); c->diag_ran = true; c->diag_step = s.iic - 1; }   // reads u, v, rho, wvel ... of this point of the step
+  if (do_diag) {
+    halo_fence(c, FG_UV | FG_RHO | FG_HZ | FG_WVEL);
+    r = run_diag_async(c, c->d_diag);
+    c->diag_ran = true;
+    c->diag_step = s.iic - 1;
+  }   // reads u, v, rho, wvel ... of this point of the step
   if (!r && side_chain) {
     r = roms_hip_set_massflux(c);
     if (!r) r = roms_hip_omega(c);
@@ -903,13 +1034,16 @@ static int main3d_one(roms_hip_ctx *c) {
   c->swdk_ready = false;
   side_mark(c);
   DO(roms_hip_prsgrd(c));
+  halo_fence(c, FG_R | FG_UV | FG_MF | FG_W | FG_HZ | FG_FLUX);
   DO(run_rhs3d_pt(c));
+  halo_fence(c, FG_UV | FG_HZ | FG_R | FG_T | FG_RHO);
   side_begin(c);                      // side stream: t3dmix2 and the point-wise part of uv3dmix2
   r = roms_hip_t3dmix2(c);
   if (!r) r = run_uv3dmix2_s(c);
   side_end(c);
   if (r) return r;
   side_join(c);
+  halo_fence(c, FG_R | FG_FLUX);
   DO(run_rufrc_sums(c));              // rufrc/rvfrc of rhs3d_tile and uv3dmix2 in one kernel
   for (int my_iif = 1; my_iif <= cf.nfast + 1; my_iif++) {  // :810-918
     const int next_indx1 = 3 - s.indx1;

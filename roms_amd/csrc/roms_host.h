@@ -57,7 +57,39 @@ struct roms_hip_ctx {
   bool overlap;        // use the side stream (single-GPU latency hiding on small grids)
   double *h_diag;      // pinned host mirror
   int nblk_diag;
+  // Halo exchange overlapped with compute (multi-tile contexts, built-in RCCL transport): the exchange of a
+  // group of fields runs on its own stream behind the producing kernel; a later kernel waits for it only if
+  // it touches that group (roms_hip.cpp: halo_fence, entry_groups).
+  kstream_t xstream;
+  kevent_t ev_xprod;            // "producer done" marker: compute stream -> exchange stream
+  kevent_t ev_x[32];            // completion events of exchanges, a rotating pool
+  int ev_x_next;
+  int x_event_of[16];           // per field group: index into ev_x of the last exchange that carried it, -1 none
+  unsigned x_pending;           // field groups with an exchange possibly still in flight
+  bool x_async;
+  bool x_tail;                  // the exchange being launched is the last operation of its routine
+  int x_min_planes;             // exchanges with fewer planes stay on the compute stream
 };
+
+// Field groups of the halo-exchange dependency tracking (a kernel entry names the groups it reads or writes)
+enum {
+  FG_FLUX = 1 << 0,   // surface/bottom forcing and fluxes: sustr .. lrflx, stflx, btflx, srflx, the bulk atmosphere
+  FG_RHO = 1 << 1,    // rho pden rhoA rhoS bvf alpha beta
+  FG_MF = 1 << 2,     // Huon Hvom
+  FG_W = 1 << 3,      // W
+  FG_WVEL = 1 << 4,   // wvel
+  FG_AK = 1 << 5,     // Akv Akt ghats hsbl
+  FG_T = 1 << 6,      // t
+  FG_UV = 1 << 7,     // u v
+  FG_2D = 1 << 8,     // zeta ubar vbar rzeta rubar rvbar
+  FG_AVG = 1 << 9,    // Zt_avg1 DU_avg1 DU_avg2 DV_avg1 DV_avg2
+  FG_HZ = 1 << 10,    // Hz z_r z_w
+  FG_R = 1 << 11,     // ru rv rufrc rvfrc
+  FG_OTHER = 1 << 12, // anything else (grid metrics, work arrays)
+  FG_ALL = (1 << 13) - 1
+};
+// make the compute stream(s) wait for the exchanges in flight that carry any of `groups`
+void halo_fence(roms_hip_ctx *c, unsigned groups);
 
 // helpers (roms_hip.cpp)
 void ctx_sync_stepping(roms_hip_ctx *c);           // copy c->s into c->G
@@ -75,6 +107,9 @@ const FieldDesc *find_field(const char *name);
 // halo / BC launcher (k_halo.h): nk planes starting at A
 struct HaloSpec { double *A; int nk; int bc; char gtype; };
 void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype);
+// the same as the LAST operation of a routine: nothing enqueued later in that routine depends on it, so in a
+// multi-tile run the exchange may go to the exchange stream and overlap the routines that follow (halo_fence)
+void launch_halo_tail(roms_hip_ctx *c, const HaloSpec *sp, int n);
 void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n);   // n <= 8 fields in one launch
 
 // region timing

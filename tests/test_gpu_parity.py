@@ -492,9 +492,12 @@ def test_rccl_self_exchange_matches_local_periodic_copy():
         ref.close()
         print("SELF-EXCHANGE-OK", nx)
     """) % (ROOT, ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "rho", "Akv", "Huon", "DU_avg1"])
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
-    assert "SELF-EXCHANGE-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    # both forms of the exchange: on the compute stream, and (3-D fields) on the exchange stream with the
+    # consumers fenced by field group (roms_hip.cpp: halo_fence)
+    for xasync in ("0", "1"):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ROMS_HIP_XASYNC=xasync)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert "SELF-EXCHANGE-OK" in r.stdout, (xasync, r.stdout[-1500:] + r.stderr[-3000:])
 
 
 @pytest.mark.gpu

@@ -25,7 +25,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 # variants of one kernel (LDS / register forms, chunk sizes) are reported under the kernel's name
 VARIANTS = {"k_s3uv_col_l": "k_s3uv_col", "k_s3uv_col_l10": "k_s3uv_col", "k_s3uv_couple_l": "k_s3uv_couple",
             "k_s3t_col_l": "k_s3t_col", "k_s3t_col_l10": "k_s3t_col", "k_s3t_col_n30": "k_s3t_col",
-            "k_uv3dmix2_m": "k_uv3dmix2_s", "k_t3dmix2_m": "k_t3dmix2_s", "k_mp_vdiff_l": "k_mp_vdiff", "k_mp_limapply": "k_mp_apply", "k_omega_l": "k_omega", "k_wvel_f": "k_wvel"}
+            "k_uv3dmix2_m": "k_uv3dmix2_s", "k_t3dmix2_m": "k_t3dmix2_s", "k_mp_vdiff_l": "k_mp_vdiff", "k_mp_limapply": "k_mp_apply", "k_omega_l": "k_omega", "k_wvel_f": "k_wvel",
+            "k_rhs3d_lds": "k_rhs3d_pt"}
 
 
 def counter_avgs(d, counter):
@@ -34,7 +35,7 @@ def counter_avgs(d, counter):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
             if k in ("k_step2d_a", "k_step2d_b", "k_step2d_c", "k_step2d_d"):     # sub-tile variants of one kernel
                 k = "k_step2d"
             k = VARIANTS.get(k, k)
