@@ -10,13 +10,12 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
  * this library; the product (roms_amd/, libroms_hip.so) never links or calls it.
  *
- * PARITY STATUS per function is stated in each source file header:
- *   "pinned"   = checked against the reference routine itself (oracle/_ref,
- *                tests/test_oracle_vs_ref.py) and committed golden vectors;
- *   "unpinned" = the reference routine needs the NetCDF Fortran module and
- *                cannot be built in this image (step2d, omega, pre_step3d,
- *                rhs3d_tile, step3d_uv, step3d_t); checked only through
- *                properties (tiling invariance, conservation, constancy).
+ * PARITY STATUS: every function is PINNED -- checked bit for bit against the
+ * reference routine itself (oracle/_ref built by oracle/ref/build_ref.sh;
+ * tests/test_oracle_vs_ref.py: routine by routine on perturbed states and as
+ * whole main3d passes over 100 steps) and against the fixtures the reference's
+ * object code wrote (tests/golden/*_steps.npz, *_kernels.npz, *_sample.npz;
+ * tests/test_golden_reference.py, which runs anywhere).
  *
  * Array layout = the reference's (mod_grid.F / mod_ocean.F): column-major,
  * i fastest, lower bounds LBi,LBj; rho-type levels 1..N, w-type levels 0..N.

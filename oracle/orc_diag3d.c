@@ -16,7 +16,7 @@
  *                                        :327-337)                          pinned
  *   orc_set_data      set_data_tile      ROMS/Nonlinear/set_data.F:255-564 ->
  *                                        ana_smflux.h:306-318, ana_stflux.h, ana_btflux.h pinned
- *   orc_omega         omega_tile         ROMS/Nonlinear/omega.F:96-377      UNPINNED
+ *   orc_omega         omega_tile         ROMS/Nonlinear/omega.F:96-377      pinned (round 2)
  *                                        (omega.F USEs mod_sources -> NetCDF)
  */
 #include "orc.h"

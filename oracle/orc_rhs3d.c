@@ -3,12 +3,12 @@
  * rhs3d_tile, uv3dmix2 (the sequence of rhs3d, ROMS/Nonlinear/rhs3d.F:25-193).
  * TEST INFRASTRUCTURE (see orc.h).
  *
- *   orc_pre_step3d  pre_step3d_tile  ROMS/Nonlinear/pre_step3d.F:126-1180  UNPINNED
+ *   orc_pre_step3d  pre_step3d_tile  ROMS/Nonlinear/pre_step3d.F:126-1180  pinned (round 2)
  *   orc_prsgrd      prsgrd32_tile    ROMS/Nonlinear/prsgrd32.h:109-436     pinned
  *   orc_t3dmix2     t3dmix2_s_tile   ROMS/Nonlinear/t3dmix2_s.h:89         pinned
  *                   t3dmix2_geo_tile ROMS/Nonlinear/t3dmix2_geo.h:90 (orc_t3dmix_geo.c) pinned
  *   orc_uv3dmix2    uv3dmix2_s_tile  ROMS/Nonlinear/uv3dmix2_s.h:114       pinned
- *   orc_rhs3d_tile  rhs3d_tile       ROMS/Nonlinear/rhs3d.F:196-1921       UNPINNED
+ *   orc_rhs3d_tile  rhs3d_tile       ROMS/Nonlinear/rhs3d.F:196-1921       pinned (round 2)
  * (pre_step3d.F and rhs3d.F USE mod_sources -> mod_netcdf: not buildable here.)
  */
 #include "orc.h"

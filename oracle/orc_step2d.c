@@ -7,9 +7,9 @@
  * UV_C2ADVECTION :1246-1395), UV_COR, CURVGRID, UV_VIS2; no MASKING/WET_DRY/
  * NESTING/DIAGNOSTICS).  Section references in the body.
  *
- * PARITY: UNPINNED -- step2d.F USEs mod_sources -> mod_netcdf and cannot be
- * built in this image; checked by properties only (tests/test_oracle_props.py).
- * The BC routines it calls (zetabc/u2dbc/v2dbc) are pinned (orc_core.c).
+ * PARITY: pinned bit for bit against step2d_tile of the reference build (first
+ * predictor, correctors, last predictor on perturbed states; every call of 100
+ * main3d passes): tests/test_oracle_vs_ref.py, tests/test_golden_reference.py.
  */
 #include "orc.h"
 #include <stdlib.h>

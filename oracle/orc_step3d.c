@@ -2,8 +2,8 @@
  * orc_step3d.c -- corrector steps for 3-D momentum and tracers.
  * TEST INFRASTRUCTURE (see orc.h).
  *
- *   orc_step3d_uv  step3d_uv_tile  ROMS/Nonlinear/step3d_uv.F:134-1844  UNPINNED
- *   orc_step3d_t   step3d_t_tile   ROMS/Nonlinear/step3d_t.F:120-1974   UNPINNED
+ *   orc_step3d_uv  step3d_uv_tile  ROMS/Nonlinear/step3d_uv.F:134-1844  pinned (round 2)
+ *   orc_step3d_t   step3d_t_tile   ROMS/Nonlinear/step3d_t.F:120-1974   pinned (round 2)
  * (both files USE mod_sources -> mod_netcdf: not buildable in this image).
  * mpdata_adiff_tile, which step3d_t calls, IS pinned (orc_mpdata.c).
  */

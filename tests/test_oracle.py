@@ -1,6 +1,7 @@
 """CPU tests of the oracle (no GPU, no reference tree needed): golden set-up tables, tiling
-invariance, conservation/constancy properties of the kernels whose reference routine cannot be
-built in this image ("unpinned": step2d, omega, pre_step3d, rhs3d_tile, step3d_uv, step3d_t)."""
+invariance, and reference-independent properties of the core kernels (volume conservation, constancy
+of a uniform tracer) that complement the bit-for-bit pins of tests/test_oracle_vs_ref.py and
+tests/test_golden_reference.py."""
 import os
 
 import numpy as np
@@ -52,7 +53,7 @@ def test_initial_depths_match_reference():
 @pytest.mark.parametrize("hadv,vadv", [(("U3", "HSIMT"), ("C4", "HSIMT")), (("U3", "U3"), ("C4", "C4")),
                                        (("C4", "A4"), ("SPLINES", "A4")), (("C2", "SU3"), ("C2", "SU3"))])
 def test_constant_tracer_and_volume(hadv, vadv):
-    """Properties of the unpinned kernels: a uniform tracer (S = 35, no fluxes) stays uniform to
+    """Reference-independent properties: a uniform tracer (S = 35, no fluxes) stays uniform to
     round-off (consistency of omega, pre_step3d, step3d_t with the corrected mass fluxes of
     step3d_uv/step2d) and the total volume is conserved."""
     cs, g, O = _fresh(hadv=hadv, vadv=vadv)
