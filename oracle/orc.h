@@ -14,7 +14,7 @@
  * reference routine itself (oracle/_ref built by oracle/ref/build_ref.sh;
  * tests/test_oracle_vs_ref.py: routine by routine on perturbed states and as
  * whole main3d passes over 100 steps) and against the fixtures the reference's
- * object code wrote (tests/golden/*_steps.npz, *_kernels.npz, *_sample.npz;
+ * object code wrote (tests/golden/<case>_steps.npz, _kernels.npz, _sample.npz;
  * tests/test_golden_reference.py, which runs anywhere).
  *
  * Array layout = the reference's (mod_grid.F / mod_ocean.F): column-major,
