@@ -63,6 +63,8 @@ ALGO_ARRAYS = {
     "k_t3dmix2_geo":  (8, 5),
     "k_uv3dmix2_s":   (11, 12),
     "k_uv3dmix2_sum": (4, 4),
+    "k_uv3dmix2_col": (9, 12),     # large grids: uv3dmix2 + the coupling sums in one kernel: Hz, u, v, ru, rv read,
+                                   # u, v(nnew) read-modify-write; no work arrays
     "k_rhs3d_pt":     (10, 3),     # u, v, Huon, Hvom, W, Hz read; ru, rv read-modify-write
     "k_rhs3d_sum":    (6, 10),     # ru, rv and the four viscous terms of uv3dmix2 (fused main3d sequence)
     "k_s3uv_col":     (8, 6),
@@ -85,7 +87,7 @@ ALGO_ARRAYS = {
 # pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2, step3d_t): 79 words = 632 bytes per cell for U3/C4
 # advection and NT = 2.  The kernels of those rows (launch sequences g_rhs3d.cpp, g_step3d.cpp:run_step3d_t):
 PAIR_KERNELS = ("k_swdk", "k_pre_t3", "k_pre_t3h", "k_pre_t3v", "k_pre_new", "k_prs_P", "k_prs_grad", "k_t3dmix2_s",
-                "k_t3dmix2_geo", "k_rhs3d_pt", "k_rhs3d_sum", "k_uv3dmix2_s", "k_uv3dmix2_sum", "k_s3t_hv", "k_s3t_h",
+                "k_t3dmix2_geo", "k_rhs3d_pt", "k_rhs3d_sum", "k_uv3dmix2_s", "k_uv3dmix2_sum", "k_uv3dmix2_col", "k_s3t_hv", "k_s3t_h",
                 "k_s3t_col", "k_mp_ta", "k_mp_uva", "k_mp_wa", "k_mp_beta", "k_mp_limit", "k_mp_apply", "k_mp_vdiff")
 PAIR_BYTES_PER_CELL = 632.0
 

@@ -4,6 +4,7 @@
 #include "k_rhs3d.h"
 #ifndef ROMS_CPU_EMU
 #include "k_rhs3d_lds.h"
+#include "k_uv3dmix2_col.h"
 #endif
 
 static inline KArgs mk(roms_hip_ctx *c, int p0 = 0, int p1 = 0, int p2 = 0) {
@@ -151,6 +152,28 @@ int run_uv3dmix2_s(roms_hip_ctx *c) {
     if (a.p2 > 0) LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
     else LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a); }
   return 0;
+}
+// uv3dmix2 and the coupling sums of rhs3d_tile as one column-marching kernel (k_uv3dmix2_col.h): large grids
+// only.  Returns -1 when the form does not apply (the caller then takes k_uv3dmix2_s + k_rhs3d_sum).
+int run_uv3dmix2_col(roms_hip_ctx *c) {
+#ifdef ROMS_CPU_EMU
+  (void)c;
+  return -1;
+#else
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  if (!(G.options & ROMS_UV_VIS2)) return -1;
+  static const char *e = getenv("ROMS_HIP_UVCOL");
+  const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
+  const bool big = (long)nx * ny >= 128L * 1024L;
+  if (e ? e[0] == '0' : !big) return -1;
+  KArgs a = mk(c);
+  const int nt = ((nx + 63) / 64) * ((ny + 3) / 4);
+  KPROF_WRAP(k_uv3dmix2_col, c->stream,
+             hipLaunchKernelGGL(k_uv3dmix2_col, dim3((unsigned)(8 * ((nt + 7) / 8)), 1, 1), dim3(64, 4, 1),
+                                (size_t)UC_LDS_DOUBLES * sizeof(double), c->stream, a, nx, ny));
+  return 0;
+#endif
 }
 int run_rufrc_sums(roms_hip_ctx *c) {
   const DGrid &G = c->G;

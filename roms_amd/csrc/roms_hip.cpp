@@ -443,6 +443,7 @@ int run_step2d(roms_hip_ctx *c);
 int run_rhs3d_pt(roms_hip_ctx *c);
 int run_uv3dmix2_s(roms_hip_ctx *c);
 int run_rufrc_sums(roms_hip_ctx *c);
+int run_uv3dmix2_col(roms_hip_ctx *c);
 int run_swdk(roms_hip_ctx *c);
 int fetch_diag(roms_hip_ctx *c, const double *d_out, double *out) { return d2h(out, d_out, 16 * sizeof(double), c->stream); }
 int run_diag_async(roms_hip_ctx *c, double *d_out);   // g_diag.cpp
@@ -1037,14 +1038,22 @@ static int main3d_one(roms_hip_ctx *c) {
   halo_fence(c, FG_R | FG_UV | FG_MF | FG_W | FG_HZ | FG_FLUX);
   DO(run_rhs3d_pt(c));
   halo_fence(c, FG_UV | FG_HZ | FG_R | FG_T | FG_RHO);
-  side_begin(c);                      // side stream: t3dmix2 and the point-wise part of uv3dmix2
+  // large grids: uv3dmix2 and the coupling sums as one column-marching kernel behind rhs3d_tile's point part
+  // (it starts from the vertical sums of ru, rv); otherwise uv3dmix2's point-wise part on the side stream
+  // beside prsgrd/rhs3d_tile and ONE column kernel for the sums of both.  t3dmix2: side stream either way.
+  halo_fence(c, FG_FLUX);
+  const int rcol = run_uv3dmix2_col(c);
+  if (rcol > 0) return rcol;
+  side_begin(c);
   r = roms_hip_t3dmix2(c);
-  if (!r) r = run_uv3dmix2_s(c);
+  if (!r && rcol < 0) r = run_uv3dmix2_s(c);
   side_end(c);
   if (r) return r;
   side_join(c);
-  halo_fence(c, FG_R | FG_FLUX);
-  DO(run_rufrc_sums(c));              // rufrc/rvfrc of rhs3d_tile and uv3dmix2 in one kernel
+  if (rcol < 0) {
+    halo_fence(c, FG_R | FG_FLUX);
+    DO(run_rufrc_sums(c));            // rufrc/rvfrc of rhs3d_tile and uv3dmix2 in one kernel
+  }
   for (int my_iif = 1; my_iif <= cf.nfast + 1; my_iif++) {  // :810-918
     const int next_indx1 = 3 - s.indx1;
     if (!s.predictor && my_iif <= cf.nfast + 1) {

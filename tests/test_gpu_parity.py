@@ -534,6 +534,8 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
         # "priv" also takes the point-wise form of rhs3d_tile's advection/Coriolis kernel instead of the LDS-tiled one
         for tag, extra in (("lds", {}), ("priv", {"ROMS_HIP_COLLDS": "0", "ROMS_HIP_WVELF": "0", "ROMS_HIP_RHS3D_LDS": "0"}),
                            ("rhs_chunks", {"ROMS_HIP_RHS3D_KC": "7", "ROMS_HIP_RHS3D_W": "2"}),
+                           # uv3dmix2 + coupling sums as one column-marching kernel (the form of >= 128 K columns)
+                           ("uvcol", {"ROMS_HIP_UVCOL": "1"}),
                            ("march", {"ROMS_HIP_UVCH": "7", "ROMS_HIP_WVELCH": "100", "ROMS_HIP_GEOCH": "7", "ROMS_HIP_T3CH": "9"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
