@@ -232,6 +232,19 @@ def cpu_baseline(cs, H, budget_s=15.0):
                       f"alone: {cells / per_step:.3g} cell-updates/s"}
 
 
+def multi_gpu_plan(world, workload, explicit_dims):
+    """(workload, (NtileI, NtileJ) or None, weak) of a run on `world` GPUs.  The default workload on 2/4/8 GPUs is
+    BASELINE.json's own multi-GPU configuration: BENCHMARK2 1024x128x30 in NtileI x NtileJ = 2x2 on 4 GPUs (tile
+    512x64, the BENCHMARK1 grid: weak scaling) and BENCHMARK3 2048x256x30 in 2x4 on 8 (tile 1024x64); on 2 GPUs two
+    BENCHMARK1 tiles side by side (1024x64 in 2x1).  Any other workload / GPU count / explicit --Lm --Mm --N: weak
+    scaling of the named grid over roms_amd.tiling.partition(world) (weak = True: the named grid is the tile)."""
+    baseline_multi = {2: ("benchmark1", (2, 1), True), 4: ("benchmark2", (2, 2), False),
+                      8: ("benchmark3", (2, 4), False)}
+    if world in baseline_multi and workload == "benchmark1" and not explicit_dims:
+        return baseline_multi[world]
+    return workload, None, True
+
+
 def north_star_pass(hiplib, tiling, device, steps=6, warmup=24):
     """UPWELLING 512x512x50 with U3/C4 advection: `steps` steps with synchronous per-kernel HIP events; the
     kernels of "step3d_t + rhs3d" against their 632 algorithmic bytes per cell, and each of them alone."""
@@ -313,17 +326,8 @@ def main():
     if os.environ.get("ROMS_HIP_TRACE"):     # debugging aid: every launch synchronous and named on stderr
         hiplib.kprof(1)
 
-    # Multi-GPU runs of the default workload are BASELINE.json's own configurations: BENCHMARK2 1024x128x30 in
-    # NtileI x NtileJ = 2x2 on 4 GPUs (tile 512x64, the BENCHMARK1 grid) and BENCHMARK3 2048x256x30 in 2x4 on 8
-    # (tile 1024x64).  2 GPUs: two BENCHMARK1 tiles side by side (1024x64 in 2x1).  Any other workload / count:
-    # weak scaling of the named grid over roms_amd.tiling.partition(world).
-    baseline_multi = {2: ("benchmark1", (2, 1), True), 4: ("benchmark2", (2, 2), False),
-                      8: ("benchmark3", (2, 4), False)}
     explicit_dims = bool(args.Lm or args.Mm or args.N)
-    if world in baseline_multi and args.workload == "benchmark1" and not explicit_dims:
-        wl, tiles, weak = baseline_multi[world]
-    else:
-        wl, tiles, weak = args.workload, None, True
+    wl, tiles, weak = multi_gpu_plan(world, args.workload, explicit_dims)
     cs = params_for(wl, args.Lm, args.Mm, args.N, ntimes=args.steps + args.warmup)
     cs["ninfo"] = 1                          # NINFO of roms_benchmark1.in: diagnostics every step
     run = tiling.TiledRun(cs, rank=rank, world=world, device=local_rank, dist=dist, tiles=tiles, weak=weak)

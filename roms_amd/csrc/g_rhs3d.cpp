@@ -19,10 +19,12 @@ static inline size_t lds_sz(const DGrid &G) { return (size_t)(G.bw + 6) * (size_
 int run_swdk(roms_hip_ctx *c);            // g_lmd.cpp: solar penetration fractions into wrk3[5]
 int run_t3dmix2_geo(roms_hip_ctx *c);     // g_geo.cpp
 
-int run_pre_step3d(roms_hip_ctx *c) {
+// The tracer predictor of pre_step3d (pre_step3d.F:357-852: t(3) from t(nstp), t(nnew), Hz, Huon, Hvom, W) is
+// independent of the surface forcing and the vertical mixing; on small grids the fused main3d sequence
+// launches it early, on the side stream behind omega, beside the bulk-flux / KPP chain (c->pre_t3_ready).
+int run_pre_t3(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
-  if ((G.options & ROMS_SOLAR_SOURCE) && !c->swdk_ready) { int r = run_swdk(c); if (r) return r; }
   KArgs a = mk(c);
   bool any_col = false;      // tracers with a spline vertical flux keep the two-kernel column path
   for (int it = 0; it < G.NT; it++) any_col |= G.vadv[it] == ROMS_SPLINES;
@@ -32,11 +34,20 @@ int run_pre_step3d(roms_hip_ctx *c) {
     LAUNCH_COOP(k_pre_t3h, G.nbx, G.nby, G.N * G.NT, 256, 3 * lds_sz(G), c->stream, a);
     LAUNCH_THREAD(k_pre_t3v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);
   }
-  LAUNCH_THREAD(k_pre_new, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
   if (G.fuse3d && !any_col) return 0;   // k_pre_t3 stored the boundary values and images (pt_emit)
   HaloSpec sp[ROMS_MAXT];
   for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, 3, it), G.N, BC_R, 'r'};   // t3dbc + exchange :1157-1171
-  launch_halo_tail(c, sp, G.NT);
+  launch_halo_multi(c, sp, G.NT);
+  return 0;
+}
+
+int run_pre_step3d(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  if ((G.options & ROMS_SOLAR_SOURCE) && !c->swdk_ready) { int r = run_swdk(c); if (r) return r; }
+  if (!c->pre_t3_ready) { int r = run_pre_t3(c); if (r) return r; }     // (k_pre_new overwrites the t(nnew) it reads)
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_pre_new, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
   return 0;
 }
 

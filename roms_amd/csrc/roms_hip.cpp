@@ -252,6 +252,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   c->comm_failed = false;
   c->m2d_dirty = true;
   c->swdk_ready = false;
+  c->pre_t3_ready = false;
 #ifdef ROMS_CPU_EMU
   c->stream = nullptr;
   c->stream2 = nullptr;
@@ -445,6 +446,7 @@ int run_uv3dmix2_s(roms_hip_ctx *c);
 int run_rufrc_sums(roms_hip_ctx *c);
 int run_uv3dmix2_col(roms_hip_ctx *c);
 int run_swdk(roms_hip_ctx *c);
+int run_pre_t3(roms_hip_ctx *c);
 int fetch_diag(roms_hip_ctx *c, const double *d_out, double *out) { return d2h(out, d_out, 16 * sizeof(double), c->stream); }
 int run_diag_async(roms_hip_ctx *c, double *d_out);   // g_diag.cpp
 
@@ -1014,6 +1016,11 @@ static int main3d_one(roms_hip_ctx *c) {
     if (!r) r = roms_hip_wvelocity(c, s.nstp);     // overwrites wvel, which diag reads: same stream, in order
     if (!r) r = roms_hip_set_zeta(c);              // :556
     if (!r && (cf.options & ROMS_SOLAR_SOURCE)) { r = run_swdk(c); c->swdk_ready = r == 0; }   // pre_step3d's first kernel
+    // small grids: the tracer predictor of pre_step3d too (it needs W, not the mixing coefficients) -- the
+    // bulk-flux / KPP chain on the main stream is a string of column kernels that leave most of the chip idle
+    static const char *ept = getenv("ROMS_HIP_EARLY_T3");
+    const bool early = ept ? ept[0] != '0' : (long)(c->G.T.Iend - c->G.T.Istr + 1) * (c->G.T.Jend - c->G.T.Jstr + 1) <= 64L * 1024L;
+    if (!r && early) { r = run_pre_t3(c); c->pre_t3_ready = r == 0; }
   }
   side_end(c);
   if (r) return r;
@@ -1033,6 +1040,7 @@ static int main3d_one(roms_hip_ctx *c) {
   // rhs3d :632 -- t3dmix2 only touches t(nnew): it overlaps prsgrd and rhs3d_tile
   DO(roms_hip_pre_step3d(c));
   c->swdk_ready = false;
+  c->pre_t3_ready = false;
   side_mark(c);
   DO(roms_hip_prsgrd(c));
   halo_fence(c, FG_R | FG_UV | FG_MF | FG_W | FG_HZ | FG_FLUX);

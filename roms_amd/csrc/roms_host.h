@@ -37,6 +37,7 @@ struct roms_hip_ctx {
   bool comm_failed;             // a halo exchange failed (reported by the next ctx_check)
   bool has_exchange;            // some neighbour is reached through the transport (multi-tile, or the self-exchange test aid)
   bool swdk_ready;              // main3d_one has launched k_swdk already (side stream): run_pre_step3d skips it
+  bool pre_t3_ready;            // main3d_one has launched the tracer predictor of pre_step3d already (side stream)
   bool m2d_dirty;               // grid arrays uploaded since Fields::m2r/m2p were packed (g_step2d.cpp)
   bool diag_ran;                // a diag report was enqueued since the last blow-up test (roms_hip_main3d)
   int diag_step = -1;           // step count (iic-1) of the report in d_diag, -1: none yet

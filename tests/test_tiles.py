@@ -77,3 +77,22 @@ def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
 def test_partition_rule():
     from roms_amd import tiling
     assert [tiling.partition(n) for n in (1, 2, 4, 8, 6)] == [(1, 1), (2, 1), (2, 2), (4, 2), (3, 2)]
+
+
+def test_bench_multi_gpu_plan_is_the_baseline_configs():
+    """bench.py --gpus N of the default workload runs BASELINE.json's own multi-GPU configurations; the tile
+    each rank gets follows from the reference's partition rule (get_bounds.F:972-1042)."""
+    import bench
+    from roms_amd import tiling
+    assert bench.multi_gpu_plan(1, "benchmark1", False) == ("benchmark1", None, True)
+    assert bench.multi_gpu_plan(2, "benchmark1", False) == ("benchmark1", (2, 1), True)
+    assert bench.multi_gpu_plan(4, "benchmark1", False) == ("benchmark2", (2, 2), False)
+    assert bench.multi_gpu_plan(8, "benchmark1", False) == ("benchmark3", (2, 4), False)
+    assert bench.multi_gpu_plan(8, "ns512", False) == ("ns512", None, True)
+    assert bench.multi_gpu_plan(4, "benchmark1", True) == ("benchmark1", None, True)
+    for world, (glm, gmm), tile in [(4, (1024, 128), (512, 64)), (8, (2048, 256), (1024, 64))]:
+        wl, tiles, weak = bench.multi_gpu_plan(world, "benchmark1", False)
+        cs = bench.params_for(wl)
+        assert (cs["Lm"], cs["Mm"]) == (glm, gmm) and tiles[0] * tiles[1] == world
+        assert (cs["Lm"] // tiles[0], cs["Mm"] // tiles[1]) == tile
+    assert tiling.partition(8) == (4, 2) and tiling.partition(2) == (2, 1)
