@@ -77,6 +77,7 @@ ALGO_ARRAYS = {
     "k_rho_eos_lin":  (5, 2),
     "k_lmd_interior": (9, 0),
     "k_lmd_skpp":     (18, 10),    # incl. the convective adjustment of lmd_finish (Akv, Akt read-modify-write)
+    "k_lmd_col":      (21, 12),    # N <= 30: lmd_vmix as one column kernel, spline columns in LDS
     "k_set_depth":    (3, 2),
     "k_set_massflux": (5, 2),
     "k_diag_col":     (7, 3),
@@ -148,6 +149,27 @@ def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
     return cs
 
 
+def usable_cores():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a container can
+    show 256 CPUs and be allowed 16 of them; OpenMP teams sized by the mask then crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def _cpu_replica(args):
     """One replica of the cpu_baseline workload: the oracle with `threads` OpenMP threads over eta strips."""
     cs, setup, threads, strips, nsteps, go, done = args
@@ -184,11 +206,13 @@ def cpu_baseline(cs, H, budget_s=15.0):
     at the same time: value = replicas x cells x steps / wall time of the slowest replica.  This is the ONLY
     place bench.py touches oracle/."""
     import multiprocessing as mp
+    import queue as _queue
     import numpy as np
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # idle OpenMP threads sleep: replicas share the cores
     from oracle import orc
     from roms_amd.hostlib import HOST_FIELDS
     orc.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     strips = max(1, min(cs["Mm"] // 4, cores))             # >= 4 rows per strip
     threads = strips
     replicas = max(1, cores // threads)
@@ -204,23 +228,39 @@ def cpu_baseline(cs, H, budget_s=15.0):
     cells = cs["Lm"] * cs["Mm"] * cs["N"]
     go, done = ctx.Event(), ctx.Queue()
     probe = ctx.Process(target=_cpu_replica, args=((cs, setup, threads, strips, 2, go, done),))
-    t0 = time.perf_counter()
     probe.start()
-    done.get()
-    go.set()
-    a, b = done.get()
+    try:
+        done.get(timeout=120)
+        go.set()
+        a, b = done.get(timeout=120)
+    except _queue.Empty:               # never block the benchmark on its reported baseline
+        probe.terminate()
+        return {"value": None, "unit": "grid-cell-updates/sec", "cores": threads, "kind": "port",
+                "sample": "the oracle did not finish 3 steps in 120 s on this host: no CPU baseline"}
     probe.join()
     per_step = (b - a) / 2
+    solo = {"value": cells / per_step, "unit": "grid-cell-updates/sec", "cores": threads, "kind": "port",
+            "sample": f"{cs['app'].upper()} {cs['Lm']}x{cs['Mm']}x{cs['N']}, 2 steps after the first, oracle/liborc.so "
+                      f"(gcc -O2 -fopenmp), {threads} OpenMP threads over 1x{strips} shared-memory tiles "
+                      f"({cores} cores usable), {b - a:.1f} s"}
+    if replicas == 1 and per_step * 2 >= 5.0:
+        return solo
     nsteps = max(2, min(400, int(budget_s / max(per_step * 1.5, 1e-3))))
     go, done = ctx.Event(), ctx.Queue()
     procs = [ctx.Process(target=_cpu_replica, args=((cs, setup, threads, strips, nsteps, go, done),))
              for _ in range(replicas)]
     for p in procs:
         p.start()
-    for _ in procs:
-        done.get()
-    go.set()
-    spans = [done.get() for _ in procs]
+    try:
+        for _ in procs:
+            done.get(timeout=180)
+        go.set()
+        spans = [done.get(timeout=max(60.0, 6.0 * budget_s)) for _ in procs]
+    except _queue.Empty:               # oversubscribed or throttled host: report the one replica that was timed
+        for p in procs:
+            p.terminate()
+        solo["sample"] += f"; {replicas} concurrent replicas did not finish in time and were stopped"
+        return solo
     for p in procs:
         p.join()
     wall = max(t[1] for t in spans) - min(t[0] for t in spans)

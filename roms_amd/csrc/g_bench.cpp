@@ -74,8 +74,14 @@ int run_lmd_vmix(roms_hip_ctx *c) {
   a.lmd_Cg = lmd_Cstar * vonKar * pow(lmd_cs * vonKar * lmd_epsilon, 1.0 / 3.0);          // mod_scalars.F:2862
   a.Vtc = lmd_Cv * sqrt(-lmd_betaT) / (sqrt(lmd_cs * lmd_epsilon) * lmd_Ric * vonKar * vonKar);
   const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
-  LAUNCH_THREAD(k_lmd_interior, nx, ny, 1, c->stream, a);
-  LAUNCH_THREAD(k_lmd_skpp, nx, ny, 1, c->stream, a);
+  static const char *elc = getenv("ROMS_HIP_LMDCOL");
+  const bool col = !(elc && elc[0] == '0') && (size_t)4 * (N + 1) * 64 * sizeof(double) < 64 * 1024;
+  if (col) {
+    LAUNCH_COL(k_lmd_col, nx, ny, 1, 4 * (N + 1), c->stream, a);
+  } else {
+    LAUNCH_THREAD(k_lmd_interior, nx, ny, 1, c->stream, a);
+    LAUNCH_THREAD(k_lmd_skpp, nx, ny, 1, c->stream, a);
+  }
   // (lmd_finish: fused into k_lmd_skpp's last sweep)
   if (G.fuse3d) return 0;   // k_lmd_skpp stored the boundary values and images (emit_store)
   HaloSpec sp[3] = {{c->F.hsbl, 1, BC_R, 'r'},                       // bc_r2d_tile lmd_skpp.F:608

@@ -33,15 +33,24 @@ struct LmdArgs {
 // sweeps take six levels at a time: the inputs of a chunk are loaded first (the loads overlap), then
 // the recurrences run on registers.  with_uv = false computes dR only (FC is rebuilt; dU, dV of the
 // same velocities are already in their work arrays: k_lmd_skpp after k_lmd_interior).
-KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const double *R, double *FC, double *dR,
-                          double *dU, double *dV, bool with_uv) {
+// Where a column's spline work arrays live: level k of the column is A[off + k*ks].  Global form: the 3-D
+// work arrays wrk3[1..4] (ks = nij, off = the column's offset); COL form (k_lmd_col): LDS, ks = KLS, off = 0
+// on a pointer already advanced to the thread's lane.  Bflux (wrk3[0]) stays in memory in both forms.
+struct LmdWk {
+  double *FC, *dR, *dU, *dV;
+  size_t ks, off;
+};
+#define WKI(k) (w.off + (size_t)(k) * w.ks)
+
+KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const double *R, const LmdWk &w, bool with_uv) {
+  double *FC = w.FC, *dR = w.dR, *dU = w.dU, *dV = w.dV;
   const int N = G.N;
   const size_t nij = (size_t)G.nij, x = X2(i, j);
   const long ni = G.ni;
   const double *Hz = F.Hz + x, *Rc = R + x;
   const double *u = F.u + (size_t)(G.nstp - 1) * nij * (size_t)N + x, *v = F.v + (size_t)(G.nstp - 1) * nij * (size_t)N + x;
-  FC[x] = 0.0; dR[x] = 0.0;
-  if (with_uv) { dU[x] = 0.0; dV[x] = 0.0; }
+  FC[WKI(0)] = 0.0; dR[WKI(0)] = 0.0;
+  if (with_uv) { dU[WKI(0)] = 0.0; dV[WKI(0)] = 0.0; }
   double FCm = 0.0, dRm = 0.0, dUm = 0.0, dVm = 0.0;
   for (int k0 = 1; k0 <= N - 1; k0 += 6) {
     double hz[7], rr[7];      // level k0+q (clamped)
@@ -54,7 +63,7 @@ KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const d
     for (int q = 0; q < 6; q++) {
       const int k = k0 + q;
       if (k > N - 1) break;
-      const size_t ow = (size_t)k * nij + x;
+      const size_t ow = WKI(k);
       const double cff = 1.0 / (2.0 * hz[q + 1] + hz[q] * (2.0 - FCm));
       FCm = cff * hz[q + 1];
       dRm = cff * (6.0 * (rr[q + 1] - rr[q]) - hz[q] * dRm);
@@ -75,7 +84,7 @@ KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const d
       for (int q = 0; q < 6; q++) {
         const int k = k0 + q;
         if (k > N - 1) break;
-        const size_t ow = (size_t)k * nij + x;
+        const size_t ow = WKI(k);
         const double cff = 1.0 / (2.0 * hz[q + 1] + hz[q] * (2.0 - FCq));
         FCq = cff * hz[q + 1];
         dUm = cff * (3.0 * (ua[q + 1] - ua[q] + ub[q + 1] - ub[q]) - hz[q] * dUm);
@@ -84,7 +93,7 @@ KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const d
       }
     }
   }
-  const size_t oN = (size_t)N * nij + x;
+  const size_t oN = WKI(N);
   dR[oN] = 0.0;
   if (with_uv) { dU[oN] = 0.0; dV[oN] = 0.0; }
   double r1 = 0.0, u1 = 0.0, v1 = 0.0;
@@ -92,7 +101,7 @@ KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const d
     double fc[6], dr[6], du[6], dv[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) {
-      const size_t ow = (size_t)KMAX(k0 - q, 1) * nij + x;
+      const size_t ow = WKI(KMAX(k0 - q, 1));
       fc[q] = FC[ow]; dr[q] = dR[ow];
       if (with_uv) { du[q] = dU[ow]; dv[q] = dV[ow]; }
     }
@@ -101,7 +110,7 @@ KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const d
     for (int q = 0; q < 6; q++) {
       const int k = k0 - q;
       if (k < 1) break;
-      const size_t ow = (size_t)k * nij + x;
+      const size_t ow = WKI(k);
       r1 = dr[q] - fc[q] * r1;
       dR[ow] = r1;
       if (with_uv) {
@@ -114,15 +123,14 @@ KDEV void lmd_col_splines(const DGrid &G, const Fields &F, int i, int j, const d
 }
 
 // interior mixing: index space (Istr:Iend, Jstr:Jend)
-THREAD_KERNEL(k_lmd_interior, LmdArgs) {
-  (void)gz;
+KDEV void lmd_interior_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   LMD_CONSTS;
-  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  const int N = G.N;
   const double eps = 1.0E-14;
-  double *FC = F.wrk3[1], *dR = F.wrk3[2], *dU = F.wrk3[3], *dV = F.wrk3[4];
-  lmd_col_splines(G, F, i, j, F.rho, FC, dR, dU, dV, true);
+  double *dU = w.dU, *dV = w.dV;
+  lmd_col_splines(G, F, i, j, F.rho, w, true);
   const size_t nij = (size_t)G.nij, x = X2(i, j);
   const size_t oA = nij * (size_t)(N + 1);          // Akt: salt after temperature
   // the levels are independent: six at a time, loads first
@@ -131,7 +139,7 @@ THREAD_KERNEL(k_lmd_interior, LmdArgs) {
 #pragma unroll
     for (int q = 0; q < 6; q++) {
       const size_t ow = (size_t)KMIN(k0 + q, N - 1) * nij + x;
-      du_[q] = dU[ow]; dv_[q] = dV[ow]; bv_[q] = F.bvf[ow];
+      du_[q] = dU[WKI(KMIN(k0 + q, N - 1))]; dv_[q] = dV[WKI(KMIN(k0 + q, N - 1))]; bv_[q] = F.bvf[ow];
     }
 #pragma unroll
     for (int q = 0; q < 6; q++) {
@@ -157,6 +165,13 @@ THREAD_KERNEL(k_lmd_interior, LmdArgs) {
     }
   }
 }
+THREAD_KERNEL(k_lmd_interior, LmdArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy;
+  const LmdWk w = {a.Fv.wrk3[1], a.Fv.wrk3[2], a.Fv.wrk3[3], a.Fv.wrk3[4], (size_t)G.nij, X2(i, j)};
+  lmd_interior_col(a, i, j, w);
+}
 THREAD_GLOBAL(k_lmd_interior, LmdArgs)
 
 KDEV void lmd_wscale(double Ustar, double zetahat, double Ustar3, double &wm, double &ws) {
@@ -179,16 +194,15 @@ KDEV void lmd_wscale(double Ustar, double zetahat, double Ustar3, double &wm, do
 
 // surface boundary layer: index space (Istr:Iend, Jstr:Jend).  hsbl is written on the interior;
 // its boundary fill / exchange (bc_r2d_tile, lmd_skpp.F:608) follows in the halo kernel.
-THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
-  (void)gz;
+KDEV void lmd_skpp_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   LMD_CONSTS;
-  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  const int N = G.N;
   const double eps = 1.0E-10, g = G.g, gorho0 = G.g / G.rho0;
   const double *z_w = F.z_w, *Hz = F.Hz, *pden = F.pden, *bvf = F.bvf;
   const double *u = F.u + (size_t)(G.nstp - 1) * G.nij * N, *v = F.v + (size_t)(G.nstp - 1) * G.nij * N;
-  double *FC = F.wrk3[1], *dR = F.wrk3[2], *dU = F.wrk3[3], *dV = F.wrk3[4], *Bflux = F.wrk3[0];
+  double *FC = w.FC, *dR = w.dR, *dU = w.dU, *dV = w.dV, *Bflux = F.wrk3[0];
   const double zwN = z_w[XW(i, j, N)];
   double hsbl = F.hsbl[X2(i, j)];
   double sl_dpth = lmd_epsilon * (zwN - hsbl);
@@ -217,15 +231,15 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
       F.ghats[XW4(i, j, k, 2)] = cff * st2;
     }
   }
-  lmd_col_splines(G, F, i, j, pden, FC, dR, dU, dV, false);   // dU, dV: from k_lmd_interior (same velocities)
+  lmd_col_splines(G, F, i, j, pden, w, false);   // dU, dV: from the interior part (same velocities)
   const double c13 = 1.0 / 3.0, c16 = 1.0 / 6.0;
-  const double Rref = pden[X3(i, j, N)] + Hz[X3(i, j, N)] * (c13 * dR[XW(i, j, N)] + c16 * dR[XW(i, j, N - 1)]);
-  const double Uref = 0.5 * (u[X3(i, j, N)] + u[X3(i + 1, j, N)]) + Hz[X3(i, j, N)] * (c13 * dU[XW(i, j, N)] + c16 * dU[XW(i, j, N - 1)]);
-  const double Vref = 0.5 * (v[X3(i, j, N)] + v[X3(i, j + 1, N)]) + Hz[X3(i, j, N)] * (c13 * dV[XW(i, j, N)] + c16 * dV[XW(i, j, N - 1)]);
+  const double Rref = pden[X3(i, j, N)] + Hz[X3(i, j, N)] * (c13 * dR[WKI(N)] + c16 * dR[WKI(N - 1)]);
+  const double Uref = 0.5 * (u[X3(i, j, N)] + u[X3(i + 1, j, N)]) + Hz[X3(i, j, N)] * (c13 * dU[WKI(N)] + c16 * dU[WKI(N - 1)]);
+  const double Vref = 0.5 * (v[X3(i, j, N)] + v[X3(i, j + 1, N)]) + Hz[X3(i, j, N)] * (c13 * dV[WKI(N)] + c16 * dV[WKI(N - 1)]);
   const double Ustar3 = Ustar * Ustar * Ustar;
   double wm = 0.0, ws = 0.0;
   // bulk Richardson number criterion; FC(k) overwrites the spline work array (as the reference)
-  FC[XW(i, j, N)] = 0.0;
+  FC[WKI(N)] = 0.0;
   // (independent levels: three at a time, loads first)
   for (int k0 = N; k0 >= 1; k0 -= 3) {
     double zwm[3], bfm[3], pd[3], hz[3], drm[3], drk[3], uk[3], vk[3], dum[3], duk[3], dvm[3], dvk[3], bvm[3];
@@ -233,9 +247,9 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
     for (int q = 0; q < 3; q++) {
       const int k = KMAX(k0 - q, 1);
       zwm[q] = z_w[XW(i, j, k - 1)]; bfm[q] = Bflux[XW(i, j, k - 1)]; pd[q] = pden[X3(i, j, k)]; hz[q] = Hz[X3(i, j, k)];
-      drm[q] = dR[XW(i, j, k - 1)]; drk[q] = dR[XW(i, j, k)];
+      drm[q] = dR[WKI(k - 1)]; drk[q] = dR[WKI(k)];
       uk[q] = 0.5 * (u[X3(i, j, k)] + u[X3(i + 1, j, k)]); vk[q] = 0.5 * (v[X3(i, j, k)] + v[X3(i, j + 1, k)]);
-      dum[q] = dU[XW(i, j, k - 1)]; duk[q] = dU[XW(i, j, k)]; dvm[q] = dV[XW(i, j, k - 1)]; dvk[q] = dV[XW(i, j, k)];
+      dum[q] = dU[WKI(k - 1)]; duk[q] = dU[WKI(k)]; dvm[q] = dV[WKI(k - 1)]; dvk[q] = dV[WKI(k)];
       bvm[q] = bvf[XW(i, j, k - 1)];
     }
 #pragma unroll
@@ -253,15 +267,15 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
       const double Ritop = -gorho0 * (Rref - Rk) * depth;
       const double du_ = Uref - Uk, dv_ = Vref - Vk;
       const double Ribot = du_ * du_ + dv_ * dv_ + a.Vtc * depth * ws * sqrt(fabs(bvm[q]));
-      FC[XW(i, j, k - 1)] = Ritop - lmd_Ric * Ribot;
+      FC[WKI(k - 1)] = Ritop - lmd_Ric * Ribot;
     }
   }
   int ksbl = 1;
   hsbl = z_w[XW(i, j, 1)];
   for (int k = N; k >= 2; k--) {
-    const double fkm = FC[XW(i, j, k - 1)];
+    const double fkm = FC[WKI(k - 1)];
     if (ksbl == 1 && fkm > 0.0) {
-      const double fk = FC[XW(i, j, k)];
+      const double fk = FC[WKI(k)];
       hsbl = (z_w[XW(i, j, k)] * fkm - z_w[XW(i, j, k - 1)] * fk) / (fkm - fk);
       ksbl = k;
     }
@@ -375,6 +389,30 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
     }
   }
 }
+THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy;
+  const LmdWk w = {a.Fv.wrk3[1], a.Fv.wrk3[2], a.Fv.wrk3[3], a.Fv.wrk3[4], (size_t)G.nij, X2(i, j)};
+  lmd_skpp_col(a, i, j, w);
+}
 THREAD_GLOBAL(k_lmd_skpp, LmdArgs)
+
+// lmd_vmix as ONE column kernel (COL launch): interior mixing, then the surface boundary layer of the same
+// column, with the four spline work columns (FC, dR, dU, dV: 4*(N+1) doubles) in LDS instead of four 3-D work
+// arrays -- they were 2.2-2.6x the algorithmic traffic of the two kernels -- and dU, dV handed from the first
+// part to the second without leaving the chip.  Same functions, same order: bit-identical to the two-kernel
+// form (the thread reads back the Akv, Akt it stored itself).  Used while 4*(N+1) doubles per column fit the 64 KB
+// a wave-sized block gets (N <= 30); ROMS_HIP_LMDCOL=0 selects the two kernels.
+COL_KERNEL(k_lmd_col, LmdArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy;
+  const size_t n1 = (size_t)(G.N + 1) * KLS;
+  const LmdWk w = {lds, lds + n1, lds + 2 * n1, lds + 3 * n1, (size_t)KLS, 0};
+  lmd_interior_col(a, i, j, w);
+  lmd_skpp_col(a, i, j, w);
+}
+COL_GLOBAL(k_lmd_col, LmdArgs)
 
 

@@ -536,6 +536,8 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
                            ("rhs_chunks", {"ROMS_HIP_RHS3D_KC": "7", "ROMS_HIP_RHS3D_W": "2"}),
                            # uv3dmix2 + coupling sums as one column-marching kernel (the form of >= 128 K columns)
                            ("uvcol", {"ROMS_HIP_UVCOL": "1"}),
+                           # KPP as two kernels with the spline columns in 3-D work arrays instead of one COL kernel
+                           ("lmd2", {"ROMS_HIP_LMDCOL": "0"}),
                            ("march", {"ROMS_HIP_UVCH": "7", "ROMS_HIP_WVELCH": "100", "ROMS_HIP_GEOCH": "7", "ROMS_HIP_T3CH": "9"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
