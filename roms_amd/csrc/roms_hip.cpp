@@ -264,6 +264,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   (void)hipEventCreate(&c->ev1);
   (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence);
   (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence);
+  (void)hipEventCreateWithFlags(&c->ev_point, hipEventDisableTiming | hipEventDisableSystemFence);
   {
     const char *e = getenv("ROMS_HIP_OVERLAP");
     c->overlap = !(e && e[0] == '0');
@@ -377,6 +378,7 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_point) (void)hipEventDestroy(c->ev_point);
   if (c->xstream) {
     (void)hipStreamSynchronize(c->xstream);
     (void)hipEventDestroy(c->ev_xprod);
@@ -456,6 +458,8 @@ void side_mark(roms_hip_ctx *) {}
 void side_begin(roms_hip_ctx *) {}
 void side_end(roms_hip_ctx *) {}
 void side_join(roms_hip_ctx *) {}
+void side_point(roms_hip_ctx *) {}
+void side_join_point(roms_hip_ctx *) {}
 #else
 static bool side_on(roms_hip_ctx *c) { return c->overlap && !c->profile && g_kprof_mode != 1; }
 // side_mark: the fork point on the main stream.  The host then enqueues the main-stream work that
@@ -478,6 +482,16 @@ void side_end(roms_hip_ctx *c) {
 void side_join(roms_hip_ctx *c) {
   if (!side_on(c)) return;
   (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+}
+// a join point in the middle of a side region: side_point (called between side_begin and side_end) marks it,
+// side_join_point makes the main stream wait for the side work enqueued before the mark only
+void side_point(roms_hip_ctx *c) {
+  if (!side_on(c)) return;
+  (void)hipEventRecord(c->ev_point, c->stream);   // c->stream is the side stream here
+}
+void side_join_point(roms_hip_ctx *c) {
+  if (!side_on(c)) return;
+  (void)hipStreamWaitEvent(c->stream, c->ev_point, 0);
 }
 #endif
 
@@ -1004,16 +1018,18 @@ static int main3d_one(roms_hip_ctx *c) {
   }
   side_begin(c);
   r = 0;
-  if (do_diag) {
+  auto diag_now = [&]() {            // reads u, v, rho, wvel ... of this point of the step
+    if (!do_diag) return 0;
     halo_fence(c, FG_UV | FG_RHO | FG_HZ | FG_WVEL);
-    r = run_diag_async(c, c->d_diag);
     c->diag_ran = true;
     c->diag_step = s.iic - 1;
-  }   // reads u, v, rho, wvel ... of this point of the step
-  if (!r && side_chain) {
+    return run_diag_async(c, c->d_diag);
+  };
+  if (side_chain) {
+    // what pre_step3d waits for comes first; diag and wvelocity -- nothing on the main stream reads their
+    // results before the next step -- follow behind the partial join point (side_point)
     r = roms_hip_set_massflux(c);
     if (!r) r = roms_hip_omega(c);
-    if (!r) r = roms_hip_wvelocity(c, s.nstp);     // overwrites wvel, which diag reads: same stream, in order
     if (!r) r = roms_hip_set_zeta(c);              // :556
     if (!r && (cf.options & ROMS_SOLAR_SOURCE)) { r = run_swdk(c); c->swdk_ready = r == 0; }   // pre_step3d's first kernel
     // small grids: the tracer predictor of pre_step3d too (it needs W, not the mixing coefficients) -- the
@@ -1021,6 +1037,11 @@ static int main3d_one(roms_hip_ctx *c) {
     static const char *ept = getenv("ROMS_HIP_EARLY_T3");
     const bool early = ept ? ept[0] != '0' : (long)(c->G.T.Iend - c->G.T.Istr + 1) * (c->G.T.Jend - c->G.T.Jstr + 1) <= 64L * 1024L;
     if (!r && early) { r = run_pre_t3(c); c->pre_t3_ready = r == 0; }
+    side_point(c);
+    if (!r) r = diag_now();
+    if (!r) r = roms_hip_wvelocity(c, s.nstp);     // overwrites wvel, which diag reads: same stream, in order
+  } else {
+    r = diag_now();
   }
   side_end(c);
   if (r) return r;
@@ -1035,7 +1056,7 @@ static int main3d_one(roms_hip_ctx *c) {
     DO(roms_hip_wvelocity(c, s.nstp));
     DO(roms_hip_set_zeta(c));                               // :556
   } else {
-    side_join(c);
+    side_join_point(c);               // (diag and wvelocity are picked up by the next join, before the barotropic loop)
   }
   // rhs3d :632 -- t3dmix2 only touches t(nnew): it overlaps prsgrd and rhs3d_tile
   DO(roms_hip_pre_step3d(c));

@@ -54,7 +54,7 @@ struct roms_hip_ctx {
   double *d_diag;      // device scratch for diag reductions
   double *d_diagwork;  // column/row partial results of diag (own buffer: diag overlaps other kernels)
   kstream_t stream2;   // side stream: kernels of a step that do not depend on each other overlap
-  kevent_t ev_fork, ev_join;
+  kevent_t ev_fork, ev_join, ev_point;
   bool overlap;        // use the side stream (single-GPU latency hiding on small grids)
   double *h_diag;      // pinned host mirror
   int nblk_diag;
@@ -100,6 +100,8 @@ void side_mark(roms_hip_ctx *c);
 void side_begin(roms_hip_ctx *c);
 void side_end(roms_hip_ctx *c);
 void side_join(roms_hip_ctx *c);
+void side_point(roms_hip_ctx *c);
+void side_join_point(roms_hip_ctx *c);
 int ctx_check(roms_hip_ctx *c, const char *what);  // hipGetLastError -> exit_flag style code
 void set_error(const std::string &msg);
 long field_elems(const roms_hip_ctx *c, int kind);
