@@ -144,6 +144,15 @@ int roms_hip_diag(roms_hip_ctx *ctx, double *out);
    ran yet.  Synchronises.  This is what the reference prints per NINFO steps (diag.F:473-500). */
 int roms_hip_last_diag(roms_hip_ctx *ctx, double *out);
 
+/* The BOUNDS(ng)/DOMAIN(ng) entries of this context's tile as the library derived them from the config
+   (get_bounds.F:1044-1884; mod_param.F:88-175 lists the members): out must hold 54 ints,
+     LBi UBi LBj UBj  Istr Iend Jstr Jend  IstrR IendR JstrR JendR  IstrU JstrV  IstrB IendB IstrM  JstrB JendB
+     JstrM  IstrP IendP JstrP JendP  IstrT IendT JstrT JendT  Istrm3 Istrm2 Istrm1 IstrUm2 IstrUm1  Iendp1
+     Iendp2 Iendp2i Iendp3  Jstrm3 Jstrm2 Jstrm1 JstrVm2 JstrVm1  Jendp1 Jendp2 Jendp2i Jendp3
+     Western Eastern Southern Northern _Edge  SouthWest SouthEast NorthWest NorthEast _Corner (0/1).
+   For a caller that wants to assert its own BOUNDS against the library's before the first step. */
+int roms_hip_get_bounds(roms_hip_ctx *ctx, int *out);
+
 /* initial.F:549-577 tail (set_massflux, omega, rho_eos at iic = ntstart) */
 int roms_hip_start(roms_hip_ctx *ctx);
 /* nsteps passes of main3d's STEP_LOOP (main3d.F:216-1148) with the state resident on

@@ -1126,6 +1126,19 @@ extern "C" int roms_hip_last_diag(roms_hip_ctx *c, double *out) {
   return 0;
 }
 
+extern "C" int roms_hip_get_bounds(roms_hip_ctx *c, int *out) {
+  if (!c || !out) return 8;
+  const TB &b = c->G.T;
+  const int v[54] = {c->G.LBi, c->G.LBi + c->G.ni - 1, c->G.LBj, c->G.LBj + c->G.nj - 1,
+    b.Istr, b.Iend, b.Jstr, b.Jend, b.IstrR, b.IendR, b.JstrR, b.JendR, b.IstrU, b.JstrV, b.IstrB, b.IendB, b.IstrM,
+    b.JstrB, b.JendB, b.JstrM, b.IstrP, b.IendP, b.JstrP, b.JendP, b.IstrT, b.IendT, b.JstrT, b.JendT,
+    b.Istrm3, b.Istrm2, b.Istrm1, b.IstrUm2, b.IstrUm1, b.Iendp1, b.Iendp2, b.Iendp2i, b.Iendp3,
+    b.Jstrm3, b.Jstrm2, b.Jstrm1, b.JstrVm2, b.JstrVm1, b.Jendp1, b.Jendp2, b.Jendp2i, b.Jendp3,
+    b.west, b.east, b.south, b.north, b.sw, b.se, b.nw, b.ne};
+  for (int k = 0; k < 54; k++) out[k] = v[k];
+  return 0;
+}
+
 extern "C" int roms_hip_main3d(roms_hip_ctx *c, int nsteps) {
   if (!c) return 8;
   static const bool host_trace = getenv("ROMS_HIP_TRACE_HOST") != nullptr;   // measurement aid: host time to enqueue the steps

@@ -126,6 +126,12 @@
           real(c_double), intent(out) :: out(*)
           integer(c_int) :: ierr
         END FUNCTION
+        FUNCTION roms_hip_get_bounds (ctx, out) bind(C, name='roms_hip_get_bounds') RESULT (ierr)
+          IMPORT :: c_int, c_ptr
+          TYPE (c_ptr), value :: ctx
+          integer(c_int), intent(out) :: out(54)
+          integer(c_int) :: ierr
+        END FUNCTION
         FUNCTION roms_hip_start (ctx) bind(C, name='roms_hip_start') RESULT (ierr)
           IMPORT :: c_int, c_ptr
           TYPE (c_ptr), value :: ctx

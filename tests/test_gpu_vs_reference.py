@@ -89,3 +89,9 @@ def test_romsM_prints_the_reference_run_report(tmp_path):
     (a last-digit difference is tolerated: exp() in ana_vmix differs by an ulp on the device)."""
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     util.check_romsM_report(os.path.join(root, "roms_amd", "romsM"), tmp_path, exact=False)
+
+
+def test_partition_matches_reference_get_bounds():
+    """Host tile rectangles + the library's derived BOUNDS/DOMAIN entries (roms_hip_get_bounds) == the tables
+    get_bounds.F wrote for the UPWELLING tilings and BENCHMARK1 1x1 / 2x2, BENCHMARK3 2x4."""
+    assert util.check_tile_bounds() >= 30

@@ -114,3 +114,10 @@ def test_romsM_run_report_is_the_reference_text(emu, tmp_path):
     for character (the emulated exp() is glibc's, as the reference's)."""
     exe = os.path.join(os.path.dirname(util.EMU_LIB), "romsM_emu")
     util.check_romsM_report(exe, tmp_path, exact=True)
+
+
+def test_product_partition_matches_reference_get_bounds(emu):
+    """The host's tile rectangles and the library's derived BOUNDS/DOMAIN entries == get_bounds.F's tables for
+    UPWELLING 1x1/2x2/2x4/3x3 and BENCHMARK1 1x1, BENCHMARK1 2x2, BENCHMARK3 2x4 (tests/golden/bounds_*.npz)."""
+    host = os.path.join(os.path.dirname(emu), "libroms_host_emu.so")
+    assert util.check_tile_bounds(host_lib=host, hip_lib=emu) >= 30

@@ -15,19 +15,22 @@ def test_bounds_tables_match_reference_get_bounds():
     from oracle import orc
     n = 0
     for f in sorted(os.listdir(util.GOLDEN)):
-        if not f.startswith("bounds_upwelling"):
+        if not f.startswith("bounds_"):
             continue
         z = np.load(os.path.join(util.GOLDEN, f))
         _, app, dims, tiling, hs = f[:-4].split("_")
         Lm, Mm = [int(x) for x in dims.split("x")]
         nti, ntj = [int(x) for x in tiling.split("x")]
-        cs = cases.upwelling(Lm=Lm, Mm=Mm, NtileI=nti, NtileJ=ntj, hadv=("U3", hs), vadv=("C4", hs))
+        kw = dict(Lm=Lm, Mm=Mm, NtileI=nti, NtileJ=ntj)
+        if app == "upwelling":
+            kw.update(hadv=("U3", hs), vadv=("C4", hs))
+        cs = getattr(cases, app)(**kw)
         O = orc.Oracle(cases.oracle_cfg(cs, 25.0, 42, np.zeros((2, 60))))
         for t in range(nti * ntj):
             assert O.bounds(t) == [int(x) for x in z["table"][t][:54]], (f, t)
             n += 1
         O.close()
-    assert n >= 4
+    assert n >= 30
 
 
 def _fresh(tag="upwelling_small", **kw):

@@ -353,3 +353,39 @@ def check_romsM_report(exe, tmp_path, exact, nsteps=12, fixture="upwelling_small
             assert flt.sub("#", g) == flt.sub("#", w), (g, w)          # layout, step, date, (i,j,k)
             for a, b in zip(flt.findall(g), flt.findall(w)):
                 assert abs(float(a) - float(b)) <= 2e-6 * abs(float(b)), (g, w)
+
+
+def check_tile_bounds(host_lib=None, hip_lib=None, device=0, only=None):
+    """Every BOUNDS/DOMAIN table the reference's get_bounds.F wrote (tests/golden/bounds_*.npz, shared-memory
+    tiles) against the PRODUCT's partition: the host's tile rectangle (roms_host.f90:device_init) and the 50
+    derived entries the library computes from it (roms_ctx.h:make_bounds, through roms_hip_get_bounds).  The
+    array bounds LBi..UBj are compared at the domain edges only: a rank's arrays cover its tile, the
+    shared-memory reference's the whole domain."""
+    from roms_amd import hostlib
+    n = 0
+    for f in sorted(os.listdir(GOLDEN)):
+        if not f.startswith("bounds_") or (only and only not in f):
+            continue
+        z = np.load(os.path.join(GOLDEN, f))
+        _, app, dims, tiling, hs = f[:-4].split("_")
+        Lm, Mm = [int(x) for x in dims.split("x")]
+        nti, ntj = [int(x) for x in tiling.split("x")]
+        kw = dict(Lm=Lm, Mm=Mm, NtileI=nti, NtileJ=ntj)
+        if app == "upwelling":
+            kw.update(hadv=("U3", hs), vadv=("C4", hs))
+        cs = getattr(cases, app)(**kw)
+        for t in range(nti * ntj):
+            H = hostlib.Host(params=cs, lib_path=host_lib, hip_lib_path=hip_lib)
+            ctx = H.device_init(device, tile=t, start=False)
+            want = [int(x) for x in z["table"][t][:54]]
+            got = ctx.bounds()
+            assert got[4:] == want[4:], (f, t, [(k, a, b) for k, (a, b) in enumerate(zip(got, want)) if a != b])
+            assert [H.tile[k] for k in ("Istr", "Iend", "Jstr", "Jend")] == want[4:8], (f, t)
+            w, e, s_, n_ = want[46:50]
+            for k, edge in ((0, w), (1, e), (2, s_), (3, n_)):
+                if edge:
+                    assert got[k] == want[k], (f, t, k)
+            assert got[0] <= want[29] and got[1] >= want[34] and got[2] <= want[38] and got[3] >= want[43], (f, t)   # Istrm2..Jendp2
+            n += 1
+            H.finalize()
+    return n
