@@ -75,7 +75,9 @@ int run_lmd_vmix(roms_hip_ctx *c) {
   a.Vtc = lmd_Cv * sqrt(-lmd_betaT) / (sqrt(lmd_cs * lmd_epsilon) * lmd_Ric * vonKar * vonKar);
   const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
   static const char *elc = getenv("ROMS_HIP_LMDCOL");
-  const bool col = !(elc && elc[0] == '0') && (size_t)4 * (N + 1) * 64 * sizeof(double) < 64 * 1024;
+  // one COL kernel with the spline columns in LDS (63 KB per wave at N = 30) when the chain waits for KPP; beside
+  // the barotropic loop (c->late_pre) its LDS would keep k_step2d's blocks off the CUs: the two-kernel form then
+  const bool col = (elc ? elc[0] != '0' : !c->late_pre) && (size_t)4 * (N + 1) * 64 * sizeof(double) < 64 * 1024;
   if (col) {
     LAUNCH_COL(k_lmd_col, nx, ny, 1, 4 * (N + 1), c->stream, a);
   } else {

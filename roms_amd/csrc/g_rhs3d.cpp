@@ -47,7 +47,10 @@ int run_pre_step3d(roms_hip_ctx *c) {
   if ((G.options & ROMS_SOLAR_SOURCE) && !c->swdk_ready) { int r = run_swdk(c); if (r) return r; }
   if (!c->pre_t3_ready) { int r = run_pre_t3(c); if (r) return r; }     // (k_pre_new overwrites the t(nnew) it reads)
   KArgs a = mk(c);
+  a.p1 = c->late_pre ? 1 : 0;
   LAUNCH_THREAD(k_pre_new, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
+  if (c->late_pre && (G.options & ROMS_UV_VIS2))     // the update of u,v(nnew) k_uv3dmix2_s left out
+    LAUNCH_THREAD(k_uv3dmix2_apply, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
   return 0;
 }
 
@@ -55,6 +58,7 @@ int run_prsgrd(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   KArgs a = mk(c);
+  a.p1 = c->late_pre ? 1 : 0;
   LAUNCH_THREAD(k_prs_P, B.Iend - (B.IstrU - 1) + 1, B.Jend - (B.JstrV - 1) + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_prs_grad, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
   return 0;
@@ -91,6 +95,7 @@ int run_uv3dmix2(roms_hip_ctx *c) {
     const long cols = (long)(B.Iend - B.Istr + 1) * (B.Jend - B.Jstr + 1);
     const int parts = (G.N + 29) / 30;
     a.p2 = eu ? atoi(eu) : (cols >= 128L * 1024L ? (G.N + parts - 1) / parts : 0);
+    a.p1 = c->late_pre ? 1 : 0;
     if (a.p2 > 0) LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
     else LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a); }
   LAUNCH_THREAD(k_uv3dmix2_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);

@@ -311,7 +311,7 @@ COL_KERNEL(k_omega_l, KArgs) {
 COL_GLOBAL(k_omega_l, KArgs)
 
 // ------------------------------------------------------------------------------ wvelocity
-// vert(i,j,k) into F.wrk3[6] (the KPP kernels on the main stream use wrk3[0..4] concurrently, swdk is [5]); index space (Istr:Iend, Jstr:Jend, 1:N); p0 = Ninp
+// vert(i,j,k) into F.wrk3[10] (KPP uses wrk3[0..4], swdk is [5], uv3dmix2 [6..9], any of which may run beside this); index space (Istr:Iend, Jstr:Jend, 1:N); p0 = Ninp
 THREAD_KERNEL(k_wvel_vert, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
@@ -326,7 +326,7 @@ THREAD_KERNEL(k_wvel_vert, KArgs) {
   const double wjp = F.v[X4(i, j + 1, k, Ninp)] * (F.z_r[X3(i, j + 1, k)] - F.z_r[X3(i, j, k)]) *
                      (F.pn[X2(i, j)] + F.pn[X2(i, j + 1)]);
   vert = vert + 0.25 * (wj + wjp);
-  F.wrk3[6][X3(i, j, k)] = vert;
+  F.wrk3[10][X3(i, j, k)] = vert;
 }
 THREAD_GLOBAL(k_wvel_vert, KArgs)
 
@@ -335,7 +335,7 @@ THREAD_KERNEL(k_wvel, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy, k = gz, N = G.N;
-  const double *vert = F.wrk3[6];
+  const double *vert = F.wrk3[10];
   const double cff1 = 3.0 / 8.0, cff2 = 3.0 / 4.0, cff3 = 1.0 / 8.0, cff4 = 9.0 / 16.0, cff5 = 1.0 / 16.0;
   const double zw0 = F.z_w[XW(i, j, 0)];
   const double wrk = (F.DU_avg1[X2(i, j)] - F.DU_avg1[X2(i + 1, j)] + F.DV_avg1[X2(i, j)] - F.DV_avg1[X2(i, j + 1)]) /

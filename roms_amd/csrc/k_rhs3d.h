@@ -459,7 +459,9 @@ THREAD_KERNEL(k_pre_new, KArgs) {
           un = hu - c3 * r3[x + oW[q + 1] + o_indx] + dF;
         } else {
           const double c1 = 5.0 / 12.0, c2 = 16.0 / 12.0;
-          un = hu + DC0 * (c1 * r3[x + oW[q + 1] + o_nrhs] - c2 * r3[x + oW[q + 1] + o_indx]) + dF;
+          // a.p1: prsgrd has run already (deferred predictor) and k_prs_grad kept the bracket in wrk3[11|12]
+          if (a.p1) un = hu + DC0 * F.wrk3[11 + dir][x + oL[q + 1]] + dF;
+          else un = hu + DC0 * (c1 * r3[x + oW[q + 1] + o_nrhs] - c2 * r3[x + oW[q + 1] + o_indx]) + dF;
         }
         qn[oL[q + 1]] = un;
       }
@@ -551,6 +553,11 @@ THREAD_KERNEL(k_prs_grad, KArgs) {
   const bool doU = i >= B.IstrU, doV = j >= B.JstrV;
   const double onu = F.on_u[x], omv = F.om_v[x];
   double *ru = F.ru + (size_t)(nrhs - 1) * nij * (size_t)(G.N + 1) + x, *rv = F.rv + (size_t)(nrhs - 1) * nij * (size_t)(G.N + 1) + x;
+  // a.p1 (deferred momentum predictor, see main3d_one): pre_step3d.F:1008,1110 combines ru(nrhs) of two steps
+  // ago with ru(indx); this kernel is about to overwrite the former, so it leaves the combination -- the very
+  // sub-expression of k_pre_new, same operations -- in wrk3[11] (u) and wrk3[12] (v)
+  const bool keep = a.p1 != 0 && G.iic >= G.ntfirst + 2;
+  const long d_indx = (long)(3 - 2 * nrhs) * (long)(nij * (size_t)(G.N + 1));   // from time level nrhs to indx = 3 - nrhs
 #pragma unroll
   for (int q = 0; q < KCH; q++) {
     const int k = gz * KCH + 1 + q;
@@ -558,6 +565,11 @@ THREAD_KERNEL(k_prs_grad, KArgs) {
     const size_t ok = (size_t)(k - 1) * nij + x;
     const double *zr = F.z_r + ok, *rh = F.rho + ok, *Hz = F.Hz + ok, *P = F.wrk3[1] + ok;
     const double z0 = zr[0], r0 = rh[0], h0 = Hz[0], p0 = P[0];
+    if (keep) {
+      const double c1 = 5.0 / 12.0, c2 = 16.0 / 12.0;
+      if (doU) F.wrk3[11][ok] = c1 * ru[(long)((size_t)k * nij)] - c2 * ru[(long)((size_t)k * nij) + d_indx];
+      if (doV) F.wrk3[12][ok] = c1 * rv[(long)((size_t)k * nij)] - c2 * rv[(long)((size_t)k * nij) + d_indx];
+    }
     if (doU) {
       // aux(ii)=z_r(ii)-z_r(ii-1), FC(ii)=rho(ii)-rho(ii-1); dZx(ii)=harm(aux(ii),aux(ii+1)) ...
       const double zm = zr[-1], rm = rh[-1];
@@ -646,6 +658,9 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
   const int uch = MARCH ? a.p2 : KCH;
   const int k0 = gz * uch + 1;
   if (k0 > N) return;
+  // a.p1: only the terms are stored (they feed rufrc/rvfrc, which the barotropic loop waits for); the update of
+  // u,v(nnew) -- which needs pre_step3d's predictor first -- is k_uv3dmix2_apply's, later (main3d_one)
+  const bool defer = a.p1 != 0;
   const double *pm = F.pm, *pn = F.pn;
   const bool do_u = i >= B.IstrU, do_v = j >= B.JstrV;
   const size_t nij = (size_t)G.nij;
@@ -696,8 +711,10 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
       const double UFe0 = fup0 * cP;
       u1 = uc1 * (UFx1 - UFx0);
       u2 = uc2 * (UFe1 - UFe0);
-      const double cff3 = ucff * (u1 + u2);
-      un = F.u[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] + cff3;
+      if (!defer) {
+        const double cff3 = ucff * (u1 + u2);
+        un = F.u[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] + cff3;
+      }
     }
     if (do_v) {
       const double cRs = CFFR(rs_, -ni), cPe = CFFP(pe_, 1);
@@ -707,20 +724,22 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
       const double VFe0 = fvr0 * cRs;
       v1 = vc1 * (VFx1 - VFx0);
       v2 = vc2 * (VFe1 - VFe0);
-      const double cff3 = vcff * (v1 - v2);
-      vn = F.v[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] + cff3;
+      if (!defer) {
+        const double cff3 = vcff * (v1 - v2);
+        vn = F.v[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] + cff3;
+      }
     }
 #undef CFFR
 #undef CFFP
     if (do_u) {
       F.wrk3[6][ok + x] = u1;
       F.wrk3[7][ok + x] = u2;
-      F.u[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] = un;
+      if (!defer) F.u[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] = un;
     }
     if (do_v) {
       F.wrk3[8][ok + x] = v1;
       F.wrk3[9][ok + x] = v2;
-      F.v[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] = vn;
+      if (!defer) F.v[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] = vn;
     }
   }
 }
@@ -728,6 +747,39 @@ THREAD_KERNEL(k_uv3dmix2_s, KArgs) { k_uv3dmix2_t_body<false>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_uv3dmix2_s, KArgs)
 THREAD_KERNEL(k_uv3dmix2_m, KArgs) { k_uv3dmix2_t_body<true>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_uv3dmix2_m, KArgs)
+
+// u,v(nnew) = u,v(nnew) + cff3 of uv3dmix2_s.h:226-262 from the stored terms (deferred form of k_uv3dmix2_s): the
+// same product and sum as there; index space (Istr:Iend, Jstr:Jend, chunks of KCH levels)
+THREAD_KERNEL(k_uv3dmix2_apply, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nnew = G.nnew;
+  const double *pm = F.pm, *pn = F.pn;
+  const bool do_u = i >= B.IstrU, do_v = j >= B.JstrV;
+  const size_t nij = (size_t)G.nij;
+  const long ni = G.ni, x = (long)X2(i, j);
+  const double ucff = G.dt * 0.25 * (pm[x - 1] + pm[x]) * (pn[x - 1] + pn[x]);
+  const double vcff = G.dt * 0.25 * (pm[x] + pm[x - ni]) * (pn[x] + pn[x - ni]);
+  double *un = F.u + (size_t)(nnew - 1) * nij * (size_t)N + x, *vn = F.v + (size_t)(nnew - 1) * nij * (size_t)N + x;
+#pragma unroll
+  for (int q = 0; q < KCH; q++) {
+    const int k = gz * KCH + 1 + q;
+    if (k > N) break;
+    const size_t ok = (size_t)(k - 1) * nij;
+    if (do_u) {
+      const double u1 = F.wrk3[6][ok + x], u2 = F.wrk3[7][ok + x];
+      const double cff3 = ucff * (u1 + u2);
+      un[ok] = un[ok] + cff3;
+    }
+    if (do_v) {
+      const double v1 = F.wrk3[8][ok + x], v2 = F.wrk3[9][ok + x];
+      const double cff3 = vcff * (v1 - v2);
+      vn[ok] = vn[ok] + cff3;
+    }
+  }
+}
+THREAD_GLOBAL(k_uv3dmix2_apply, KArgs)
 
 // rufrc/rvfrc: ordered sum over k of the terms stored by k_uv3dmix2_s; one thread per column
 THREAD_KERNEL(k_uv3dmix2_sum, KArgs) {

@@ -125,6 +125,9 @@ THREAD_GLOBAL(k_pack_m2d, PackArgs)
 template <int BWC, int BHC, int NTC, int PTS>
 COOP_KERNEL(k_step2d_t, Step2dArgs) {
   (void)bz;
+#ifndef ROMS_CPU_EMU
+  __builtin_amdgcn_s_setprio(3);   // beside other kernels (main3d_late) these waves are the step's critical path
+#endif
   constexpr bool FIXED = BWC > 0;
   const DGrid &G = a.G;
   const S2Fields &F = a.F;

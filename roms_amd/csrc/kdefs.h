@@ -152,14 +152,17 @@ void kprof_end(int slot, hipStream_t stream);
     if (gx < nx && gy < ny) name##_body(a, gx, gy, gz);                                  \
   }
 // 64 lanes along xi (coalesced), 4 rows of eta per block; 1-D grid of 8*ceil(blocks/8)*nz workgroups
+// g_thread_ballast: bytes of (unused) dynamic LDS a THREAD launch asks for -- caps its blocks per CU, so that
+// kernels placed beside the barotropic loop leave every CU room for a block of k_step2d (main3d_late)
+extern size_t g_thread_ballast;
 #define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
   KPROF_WRAP(name, stream,                                                               \
   hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + KTY - 1) / KTY)) + 7) / 8) * (nz)), 1, 1), \
-                     dim3(64, KTY, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
+                     dim3(64, KTY, 1), g_thread_ballast, stream, args, (int)(nx), (int)(ny), (int)(nz)))
 #define LAUNCH_THREAD_AS(label, name, nx, ny, nz, stream, args)                           \
   KPROF_WRAP(label, stream,                                                              \
   hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + KTY - 1) / KTY)) + 7) / 8) * (nz)), 1, 1), \
-                     dim3(64, KTY, 1), 0, stream, args, (int)(nx), (int)(ny), (int)(nz)))
+                     dim3(64, KTY, 1), g_thread_ballast, stream, args, (int)(nx), (int)(ny), (int)(nz)))
 // COL kernels: one thread per sigma column with `per_thread` doubles of LDS each (the elimination
 // coefficients of a tridiagonal solve, a column kept between sweeps).  Blocks are single waves
 // (64 columns along xi, one eta row) so that the LDS footprint of a block stays small and several fit

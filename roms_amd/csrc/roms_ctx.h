@@ -175,7 +175,8 @@ struct Fields {
   GPtr sc_r, Cs_r, sc_w, Cs_w;
   // work space: private 3-D arrays of the reference kernels (P of prsgrd, vert of wvelocity,
   // oHz/Ta/Ua/Va/Wa of step3d_t, swdk of pre_step3d ...)
-  GPtr wrk3[10];   // [6..9]: the four viscous terms of uv3dmix2 (its kernel overlaps prsgrd/rhs3d, which use [1])
+  GPtr wrk3[13];   // [1] P of prsgrd, [0..4] KPP, [3..4] spline fluxes, [5] swdk, [6..9] the four viscous terms of
+                   // uv3dmix2, [10] wvelocity, [11..12] the old ru/rv bracket of the deferred momentum predictor
   GPtr wrk2[4];
   // MPDATA work arrays (allocated only when a tracer uses MPDATA): Ta (N planes per tracer), Ua, Va, Wa,
   // beta_up, beta_dn

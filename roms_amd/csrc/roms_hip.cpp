@@ -253,18 +253,25 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   c->m2d_dirty = true;
   c->swdk_ready = false;
   c->pre_t3_ready = false;
+  c->stream3 = nullptr;
+  c->late_pre = false;
+  for (int e = 0; e < 8; e++) c->ev_lane[e] = nullptr;
 #ifdef ROMS_CPU_EMU
   c->stream = nullptr;
   c->stream2 = nullptr;
   c->overlap = false;
 #else
-  if (hipfail(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return 2; }
-  if (hipfail(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return 2; }
+  int prio_lo = 0, prio_hi = 0;
+  if (getenv("ROMS_HIP_PRIO")) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // (least, greatest)
+  if (hipfail(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate")) { delete c; return 2; }
+  if (hipfail(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi), "hipStreamCreate")) { delete c; return 2; }
   (void)hipEventCreate(&c->ev0);
   (void)hipEventCreate(&c->ev1);
   (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence);
   (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence);
   (void)hipEventCreateWithFlags(&c->ev_point, hipEventDisableTiming | hipEventDisableSystemFence);
+  if (hipfail(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_lo), "hipStreamCreate")) { delete c; return 2; }
+  for (int e = 0; e < 8; e++) (void)hipEventCreateWithFlags(&c->ev_lane[e], hipEventDisableTiming | hipEventDisableSystemFence);
   {
     const char *e = getenv("ROMS_HIP_OVERLAP");
     c->overlap = !(e && e[0] == '0');
@@ -297,7 +304,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     c->allocs.push_back(p);
     *(double **)((char *)&c->F + g_fields[k].offset) = (double *)p;
   }
-  for (int k = 0; k < 10; k++) {
+  for (int k = 0; k < 13; k++) {
     void *p = nullptr;
     size_t n = (size_t)G.nij * (size_t)(G.N + 1) * (k == 0 ? (size_t)G.NT : 1);
     if (dmalloc(&p, n * sizeof(double))) { roms_hip_destroy(c); return 2; }
@@ -374,11 +381,13 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   (void)dsync(c->stream);
 #ifndef ROMS_CPU_EMU
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);   // side-stream kernels may still read the arrays
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_point) (void)hipEventDestroy(c->ev_point);
+  for (int e = 0; e < 8; e++) if (c->ev_lane[e]) (void)hipEventDestroy(c->ev_lane[e]);
   if (c->xstream) {
     (void)hipStreamSynchronize(c->xstream);
     (void)hipEventDestroy(c->ev_xprod);
@@ -393,6 +402,7 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
 #ifndef ROMS_CPU_EMU
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
 #endif
   delete c;
   return 0;
@@ -460,6 +470,9 @@ void side_end(roms_hip_ctx *) {}
 void side_join(roms_hip_ctx *) {}
 void side_point(roms_hip_ctx *) {}
 void side_join_point(roms_hip_ctx *) {}
+bool lanes_on(roms_hip_ctx *) { return false; }
+void lane_record(roms_hip_ctx *, int) {}
+void lane_wait(roms_hip_ctx *, int) {}
 #else
 static bool side_on(roms_hip_ctx *c) { return c->overlap && !c->profile && g_kprof_mode != 1; }
 // side_mark: the fork point on the main stream.  The host then enqueues the main-stream work that
@@ -492,6 +505,19 @@ void side_point(roms_hip_ctx *c) {
 void side_join_point(roms_hip_ctx *c) {
   if (!side_on(c)) return;
   (void)hipStreamWaitEvent(c->stream, c->ev_point, 0);
+}
+// Lanes (main3d_one's late-predictor schedule): the caller points c->stream at the stream a kernel is to run on;
+// lane_record marks the current position of that stream with event e, lane_wait makes it wait for event e.
+// Without side streams (profiling, per-kernel timing, ROMS_HIP_OVERLAP=0) c->stream never changes and both do
+// nothing: the host's enqueue order is a valid serial order.
+bool lanes_on(roms_hip_ctx *c) { return side_on(c); }
+void lane_record(roms_hip_ctx *c, int e) {
+  if (!side_on(c)) return;
+  (void)hipEventRecord(c->ev_lane[e], c->stream);
+}
+void lane_wait(roms_hip_ctx *c, int e) {
+  if (!side_on(c)) return;
+  (void)hipStreamWaitEvent(c->stream, c->ev_lane[e], 0);
 }
 #endif
 
@@ -984,6 +1010,142 @@ extern "C" int roms_hip_start(roms_hip_ctx *c) {
   return 0;
 }
 
+// the barotropic loop (main3d.F:810-918), then set_depth, step3d_uv, omega, step3d_t (:963-1045) and the
+// step counters (:1145-1148); join_late >= 0: the main stream waits for lane event join_late in between
+static int baro_and_corrector(roms_hip_ctx *c, int join_late = -1) {
+  roms_hip_stepping &s = c->s;
+  const roms_hip_config &cf = c->cfg;
+  int r;
+#define DO(call) do { if ((r = (call))) return r; } while (0)
+  for (int my_iif = 1; my_iif <= cf.nfast + 1; my_iif++) {  // :810-918
+    const int next_indx1 = 3 - s.indx1;
+    if (!s.predictor && my_iif <= cf.nfast + 1) {
+      s.predictor = 1;
+      s.iif = my_iif;
+      s.kstp = (s.iif == 1) ? s.indx1 : 3 - s.indx1;
+      s.knew = 3;
+      s.krhs = s.indx1;
+    }
+    ctx_sync_stepping(c);
+    DO(roms_hip_step2d(c));
+    if (s.predictor) {
+      s.predictor = 0;
+      s.knew = next_indx1;
+      s.kstp = 3 - s.knew;
+      s.krhs = 3;
+      if (s.iif < cf.nfast + 1) s.indx1 = next_indx1;
+    }
+    ctx_sync_stepping(c);
+    if (s.iif < cf.nfast + 1) DO(roms_hip_step2d(c));
+  }
+  if (join_late >= 0) lane_wait(c, join_late);
+  DO(roms_hip_set_depth(c));                                // :963
+  DO(roms_hip_step3d_uv(c));                                // :990
+  DO(roms_hip_omega(c));                                    // :1017
+  DO(roms_hip_step3d_t(c));                                 // :1045
+  s.iic = s.iic + 1;                                        // :1145-1148
+  s.time = s.time + cf.dt;
+  ctx_sync_stepping(c);
+#undef DO
+  return 0;
+}
+
+#ifndef ROMS_CPU_EMU
+size_t g_thread_ballast = 0;
+#endif
+
+// diag (main3d.F:355) as a device-side reduction into c->d_diag; the caller has placed it on a stream
+static int enqueue_diag(roms_hip_ctx *c) {
+  halo_fence(c, FG_UV | FG_RHO | FG_HZ | FG_WVEL);
+  c->diag_ran = true;
+  c->diag_step = c->s.iic - 1;
+  return run_diag_async(c, c->d_diag);
+}
+
+// The rest of a step from rho_eos on, single tile, small and medium grids (below the size from which uv3dmix2 is
+// the column-marching kernel): the LATE-PREDICTOR schedule.  On such grids the step is a chain of kernels that
+// each leave most of the chip idle, 59 of them the barotropic sub-steps.  What the barotropic loop needs from the
+// 3-D part is only rufrc/rvfrc (prsgrd -> rhs3d_tile, the uv3dmix2 terms, the surface/bottom stresses), rhoA/rhoS
+// (rho_eos) and zeta (set_zeta); the vertical mixing coefficients, pre_step3d (which needs them) and t3dmix2 feed
+// step3d_uv/step3d_t, which follow the loop.  So three streams:
+//   main   rho_eos, bulk_flux, set_vbc, uv3dmix2 (terms only), the rufrc sums, THE LOOP, set_depth ... step3d_t
+//   S      set_massflux, omega, set_zeta, prsgrd, rhs3d_tile (point part)
+//   X      diag, wvelocity (it reads DU_avg1, which the loop resets: the loop waits for it); then, BESIDE the loop:
+//          ana_vmix | lmd_vmix, pre_step3d, t3dmix2
+// pre_step3d therefore runs after prsgrd/rhs3d_tile/uv3dmix2 instead of before them (main3d.F:632 -> rhs3d.F
+// calls them in that order).  Two read-before-overwrite dependences of the reference order are kept explicitly:
+// pre_step3d.F:1008,1110 reads ru,rv(nrhs) of two steps ago, which prsgrd overwrites (k_prs_grad keeps the
+// bracket they enter, wrk3[11..12]); uv3dmix2_s.h:226-262 adds to the u,v(nnew) pre_step3d sets
+// (k_uv3dmix2_s stores its terms only, k_uv3dmix2_apply adds them behind k_pre_new).  Same operations on the same
+// operands: bit-identical to the reference order (tests/test_gpu_parity.py, ROMS_HIP_LATE_PRE=0 is that order).
+// Without side streams the enqueue order below is itself a valid serial order.
+static int main3d_late(roms_hip_ctx *c, bool do_diag) {
+  roms_hip_stepping &s = c->s;
+  const roms_hip_config &cf = c->cfg;
+  int r;
+  enum { E_FORK = 0, E_EOS, E_VBC, E_W, E_D, E_X, E_UV, E_L };
+  kstream_t M = c->stream, S = c->stream2, X = c->stream3;
+  const bool on = lanes_on(c);
+  struct Back {
+    roms_hip_ctx *c; kstream_t m;
+    ~Back() { c->stream = m; c->late_pre = false; c->swdk_ready = false; c->pre_t3_ready = false; }
+  } back{c, M};
+  auto to = [&](kstream_t q) { if (on) c->stream = q; };
+#define DO(call) do { if ((r = (call))) return r; } while (0)
+  c->late_pre = true;
+  lane_record(c, E_FORK);
+  DO(roms_hip_rho_eos(c));                                  // :350
+  lane_record(c, E_EOS);
+  if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));   // :439
+  DO(roms_hip_set_vbc(c));                                  // :445
+  lane_record(c, E_VBC);
+  to(S);
+  lane_wait(c, E_FORK);
+  DO(roms_hip_set_massflux(c));                             // :348
+  DO(roms_hip_omega(c));                                    // :534
+  lane_record(c, E_W);
+  DO(roms_hip_set_zeta(c));                                 // :556
+  lane_wait(c, E_EOS);
+  DO(roms_hip_prsgrd(c));                                   // rhs3d.F: prsgrd, rhs3d_tile
+  DO(run_rhs3d_pt(c));
+  lane_record(c, E_D);
+  to(X);
+  lane_wait(c, E_EOS);
+  if (do_diag) DO(enqueue_diag(c));                         // :355
+  lane_wait(c, E_W);
+  DO(roms_hip_wvelocity(c, s.nstp));                        // :535
+  lane_record(c, E_X);
+  to(M);
+  DO(run_uv3dmix2_s(c));                                    // the terms of uv3dmix2 (c->late_pre)
+  lane_record(c, E_UV);
+  lane_wait(c, E_D);
+  DO(run_rufrc_sums(c));
+  lane_wait(c, E_X);
+  to(X);                                                    // beside the barotropic loop
+#ifndef ROMS_CPU_EMU
+  static const char *eb = getenv("ROMS_HIP_LATE_BALLAST");
+  struct Ballast { ~Ballast() { g_thread_ballast = 0; } } ballast;
+  if (on) g_thread_ballast = eb ? (size_t)atol(eb) : 0;
+#endif
+  lane_wait(c, E_VBC);
+  lane_wait(c, E_D);                                        // (the two-kernel KPP form reuses prsgrd's work array)
+  if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));        // :525
+  else if (cf.options & ROMS_LMD_MIXING) DO(roms_hip_lmd_vmix(c)); // :527
+  if (cf.options & ROMS_SOLAR_SOURCE) { DO(run_swdk(c)); c->swdk_ready = true; }
+  DO(run_pre_t3(c));
+  c->pre_t3_ready = true;
+  lane_wait(c, E_UV);
+  DO(roms_hip_pre_step3d(c));                               // k_pre_new (+ k_uv3dmix2_apply)
+  DO(roms_hip_t3dmix2(c));
+  lane_record(c, E_L);
+  to(M);
+#ifndef ROMS_CPU_EMU
+  g_thread_ballast = 0;
+#endif
+#undef DO
+  return baro_and_corrector(c, E_L);
+}
+
 // one pass of STEP_LOOP, main3d.F:216-1148
 static int main3d_one(roms_hip_ctx *c) {
   roms_hip_stepping &s = c->s;
@@ -1000,10 +1162,21 @@ static int main3d_one(roms_hip_ctx *c) {
     DO(roms_hip_set_depth(c));
     DO(roms_hip_ini_fields(c));
   }
-  DO(roms_hip_rho_eos(c));                                  // :350
   // diag (:355): device-side reduction every ninfo steps; the blow-up test is made on the host
   // when roms_hip_main3d returns (no per-step host synchronisation)
   const bool do_diag = cf.ninfo > 0 && (s.iic - 1) % cf.ninfo == 0;
+  {
+    static const char *elate = getenv("ROMS_HIP_LATE_PRE"), *euc = getenv("ROMS_HIP_UVCOL");
+    const long cols = (long)(c->G.T.Iend - c->G.T.Istr + 1) * (c->G.T.Jend - c->G.T.Jstr + 1);
+#ifdef ROMS_CPU_EMU
+    const bool uvcol = false;
+    (void)euc; (void)cols;
+#else
+    const bool uvcol = (cf.options & ROMS_UV_VIS2) && (euc ? euc[0] != '0' : cols >= 128L * 1024L);   // run_uv3dmix2_col's rule
+#endif
+    if (!c->has_exchange && !uvcol && !(elate && elate[0] == '0')) return main3d_late(c, do_diag);
+  }
+  DO(roms_hip_rho_eos(c));                                  // :350
   // Two independent chains follow: set_massflux (:348) -> omega (:534) -> wvelocity (:535), and the
   // surface forcing / vertical mixing (:439-527), which needs neither Huon/Hvom nor W.  In a
   // single-tile run (no halo transport to order) the first chain, behind diag, goes to the side
@@ -1018,13 +1191,7 @@ static int main3d_one(roms_hip_ctx *c) {
   }
   side_begin(c);
   r = 0;
-  auto diag_now = [&]() {            // reads u, v, rho, wvel ... of this point of the step
-    if (!do_diag) return 0;
-    halo_fence(c, FG_UV | FG_RHO | FG_HZ | FG_WVEL);
-    c->diag_ran = true;
-    c->diag_step = s.iic - 1;
-    return run_diag_async(c, c->d_diag);
-  };
+  auto diag_now = [&]() { return do_diag ? enqueue_diag(c) : 0; };   // reads u, v, rho, wvel ... of this point of the step
   if (side_chain) {
     // what pre_step3d waits for comes first; diag and wvelocity -- nothing on the main stream reads their
     // results before the next step -- follow behind the partial join point (side_point)
@@ -1083,36 +1250,8 @@ static int main3d_one(roms_hip_ctx *c) {
     halo_fence(c, FG_R | FG_FLUX);
     DO(run_rufrc_sums(c));            // rufrc/rvfrc of rhs3d_tile and uv3dmix2 in one kernel
   }
-  for (int my_iif = 1; my_iif <= cf.nfast + 1; my_iif++) {  // :810-918
-    const int next_indx1 = 3 - s.indx1;
-    if (!s.predictor && my_iif <= cf.nfast + 1) {
-      s.predictor = 1;
-      s.iif = my_iif;
-      s.kstp = (s.iif == 1) ? s.indx1 : 3 - s.indx1;
-      s.knew = 3;
-      s.krhs = s.indx1;
-    }
-    ctx_sync_stepping(c);
-    DO(roms_hip_step2d(c));
-    if (s.predictor) {
-      s.predictor = 0;
-      s.knew = next_indx1;
-      s.kstp = 3 - s.knew;
-      s.krhs = 3;
-      if (s.iif < cf.nfast + 1) s.indx1 = next_indx1;
-    }
-    ctx_sync_stepping(c);
-    if (s.iif < cf.nfast + 1) DO(roms_hip_step2d(c));
-  }
-  DO(roms_hip_set_depth(c));                                // :963
-  DO(roms_hip_step3d_uv(c));                                // :990
-  DO(roms_hip_omega(c));                                    // :1017
-  DO(roms_hip_step3d_t(c));                                 // :1045
-  s.iic = s.iic + 1;                                        // :1145-1148
-  s.time = s.time + cf.dt;
-  ctx_sync_stepping(c);
 #undef DO
-  return 0;
+  return baro_and_corrector(c);
 }
 
 extern "C" int roms_hip_last_diag(roms_hip_ctx *c, double *out) {

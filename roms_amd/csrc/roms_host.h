@@ -38,6 +38,8 @@ struct roms_hip_ctx {
   bool has_exchange;            // some neighbour is reached through the transport (multi-tile, or the self-exchange test aid)
   bool swdk_ready;              // main3d_one has launched k_swdk already (side stream): run_pre_step3d skips it
   bool pre_t3_ready;            // main3d_one has launched the tracer predictor of pre_step3d already (side stream)
+  bool late_pre;                // main3d_one runs pre_step3d BEHIND prsgrd/rhs3d_tile/uv3dmix2 (beside the barotropic loop):
+                                // k_prs_grad keeps the old ru/rv bracket, k_uv3dmix2_s only stores its terms, k_pre_new uses both
   bool m2d_dirty;               // grid arrays uploaded since Fields::m2r/m2p were packed (g_step2d.cpp)
   bool diag_ran;                // a diag report was enqueued since the last blow-up test (roms_hip_main3d)
   int diag_step = -1;           // step count (iic-1) of the report in d_diag, -1: none yet
@@ -54,7 +56,9 @@ struct roms_hip_ctx {
   double *d_diag;      // device scratch for diag reductions
   double *d_diagwork;  // column/row partial results of diag (own buffer: diag overlaps other kernels)
   kstream_t stream2;   // side stream: kernels of a step that do not depend on each other overlap
+  kstream_t stream3;   // second side stream (main3d_one, small grids: diag/wvelocity, then the kernels that run beside the barotropic loop)
   kevent_t ev_fork, ev_join, ev_point;
+  kevent_t ev_lane[8];
   bool overlap;        // use the side stream (single-GPU latency hiding on small grids)
   double *h_diag;      // pinned host mirror
   int nblk_diag;
@@ -102,6 +106,9 @@ void side_end(roms_hip_ctx *c);
 void side_join(roms_hip_ctx *c);
 void side_point(roms_hip_ctx *c);
 void side_join_point(roms_hip_ctx *c);
+bool lanes_on(roms_hip_ctx *c);
+void lane_record(roms_hip_ctx *c, int e);
+void lane_wait(roms_hip_ctx *c, int e);
 int ctx_check(roms_hip_ctx *c, const char *what);  // hipGetLastError -> exit_flag style code
 void set_error(const std::string &msg);
 long field_elems(const roms_hip_ctx *c, int kind);

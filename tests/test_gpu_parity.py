@@ -537,7 +537,11 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
                            # uv3dmix2 + coupling sums as one column-marching kernel (the form of >= 128 K columns)
                            ("uvcol", {"ROMS_HIP_UVCOL": "1"}),
                            # KPP as two kernels with the spline columns in 3-D work arrays instead of one COL kernel
-                           ("lmd2", {"ROMS_HIP_LMDCOL": "0"}),
+                           ("lmd2", {"ROMS_HIP_LMDCOL": "0"}), ("lmdcol", {"ROMS_HIP_LMDCOL": "1"}),
+                           # the reference's order of a step (pre_step3d before prsgrd/rhs3d_tile, everything before the
+                           # barotropic loop) instead of the late-predictor schedule on three streams; the latter serial
+                           ("refsched", {"ROMS_HIP_LATE_PRE": "0"}), ("serial", {"ROMS_HIP_OVERLAP": "0"}),
+                           ("late_knobs", {"ROMS_HIP_LATE_BALLAST": "53248", "ROMS_HIP_PRIO": "1"}),
                            ("march", {"ROMS_HIP_UVCH": "7", "ROMS_HIP_WVELCH": "100", "ROMS_HIP_GEOCH": "7", "ROMS_HIP_T3CH": "9"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,

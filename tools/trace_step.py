@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""One time step of a rocprofv3 kernel trace as a timeline: python tools/trace_step.py <kernel_trace.csv> [anchor kernel]
+
+Prints every kernel between two consecutive launches of the anchor (default k_set_data_bm / first kernel of a
+step) in the steady-state half of the trace: start, end (us from the anchor), name, queue."""
+import csv, sys
+rows = []
+for r in csv.DictReader(open(sys.argv[1])):
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0], r.get("Queue_Id", "?")))
+rows.sort()
+anchor = sys.argv[2] if len(sys.argv) > 2 else "k_set_data_bm"
+idx = [i for i, r in enumerate(rows) if r[2] == anchor]
+a, b = idx[len(idx) // 2], idx[len(idx) // 2 + 1]
+t0 = rows[a][0]
+qs = sorted({r[3] for r in rows[a:b]})
+n2d = 0
+for s, e, n, q in rows[a:b + 1]:
+    if n.startswith("k_step2d"):
+        n2d += 1
+        if 2 < n2d < 58:
+            continue
+    print("%9.1f %9.1f %7.1f  %s%-22s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, "      " * qs.index(q), n[:22]))
