@@ -153,6 +153,14 @@ int roms_hip_last_diag(roms_hip_ctx *ctx, double *out);
    For a caller that wants to assert its own BOUNDS against the library's before the first step. */
 int roms_hip_get_bounds(roms_hip_ctx *ctx, int *out);
 
+/* The reference writes its history and restart records in the middle of a step (CALL output, main3d.F:591,
+   behind set_zeta): before a caller between two roms_hip_main3d calls downloads fields for output it brings
+   the derived ones -- rho, Huon/Hvom, W, the surface fluxes, Akv/Akt/hsbl, zeta(1:2) = Zt_avg1 -- to that point
+   of the step about to be taken.  The step itself recomputes all of them and is not changed by the call.
+   wvelocity's result is left in the download-only field "w_out" (wvel keeps the previous step's values,
+   which diag.F reads). */
+int roms_hip_output_point(roms_hip_ctx *ctx);
+
 /* initial.F:549-577 tail (set_massflux, omega, rho_eos at iic = ntstart) */
 int roms_hip_start(roms_hip_ctx *ctx);
 /* nsteps passes of main3d's STEP_LOOP (main3d.F:216-1148) with the state resident on

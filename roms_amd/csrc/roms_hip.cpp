@@ -22,6 +22,7 @@ static int dmalloc(void **p, size_t bytes) { *p = calloc(bytes ? bytes : 8, 1); 
 static void dfree(void *p) { free(p); }
 static int h2d(void *d, const void *h, size_t bytes, kstream_t) { memcpy(d, h, bytes); return 0; }
 static int d2h(void *h, const void *d, size_t bytes, kstream_t) { memcpy(h, d, bytes); return 0; }
+static int d2d(void *d, const void *s, size_t bytes, kstream_t) { memcpy(d, s, bytes); return 0; }
 static int dsync(kstream_t) { return 0; }
 int ctx_check(roms_hip_ctx *c, const char *) { return c->comm_failed ? 2 : 0; }
 #else
@@ -49,6 +50,9 @@ static int d2h(void *h, const void *d, size_t bytes, kstream_t s) {
   int r = hipfail(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s), "hipMemcpy D2H");
   if (r) return r;
   return hipfail(hipStreamSynchronize(s), "hipStreamSynchronize");
+}
+static int d2d(void *d, const void *src, size_t bytes, kstream_t s) {
+  return hipfail(hipMemcpyAsync(d, src, bytes, hipMemcpyDeviceToDevice, s), "hipMemcpy D2D");
 }
 static int dsync(kstream_t s) { return hipfail(hipStreamSynchronize(s), "hipStreamSynchronize"); }
 int ctx_check(roms_hip_ctx *c, const char *what) {
@@ -78,6 +82,8 @@ static const FieldDesc g_fields[] = {
     FD(Akv, FK_W), FD(Akt, FK_WxNAT), FD(visc2_r, FK_2D), FD(visc2_p, FK_2D), FD(diff2, FK_2DxNT), FD(bvf, FK_W),
     FD(alpha, FK_2D), FD(beta, FK_2D), FD(hsbl, FK_2D), FD(ghats, FK_WxNAT),
     FD(sc_r, FK_TABR), FD(Cs_r, FK_TABR), FD(sc_w, FK_TABW), FD(Cs_w, FK_TABW),
+    // wvelocity's result at the output point of a step (roms_hip_output_point); download only
+    {"w_out", offsetof(Fields, wrk3) + 12 * sizeof(GPtr), FK_W},
 };
 static const int g_nfields = (int)(sizeof(g_fields) / sizeof(g_fields[0]));
 
@@ -1263,6 +1269,43 @@ extern "C" int roms_hip_last_diag(roms_hip_ctx *c, double *out) {
   if (r) return r;
   out[14] = (double)c->diag_step;
   return 0;
+}
+
+// main3d.F:591: output (wrt_his, wrt_rst) sits in the MIDDLE of a step, behind set_zeta.  roms_hip_main3d
+// returns between steps, so a caller that writes history or restart records first brings the derived fields to
+// that point of the step about to be taken: set_data, set_massflux, rho_eos, the surface forcing, the vertical
+// mixing coefficients, omega, wvelocity, set_zeta (:258-556) with that step's time indices.  Every one of them
+// only recomputes derived fields from the prognostic state, so the step itself, which repeats them, is not
+// changed by this call -- with one exception that is undone here: diag (:355) reads the wvel of the PREVIOUS
+// step's wvelocity, so the new one is parked in the field "w_out" and wvel restored.
+extern "C" int roms_hip_output_point(roms_hip_ctx *c) {
+  if (!c) return 8;
+  roms_hip_stepping &s = c->s;
+  const roms_hip_config &cf = c->cfg;
+  int r;
+#define DO(call) do { if ((r = (call))) return r; } while (0)
+  s.nstp = 1 + (s.iic - cf.ntstart) % 2;
+  s.nnew = 3 - s.nstp;
+  s.nrhs = s.nstp;
+  ctx_sync_stepping(c);
+  DO(roms_hip_set_data(c));
+  DO(roms_hip_set_massflux(c));
+  DO(roms_hip_rho_eos(c));
+  if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));
+  DO(roms_hip_set_vbc(c));
+  if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));
+  else if (cf.options & ROMS_LMD_MIXING) DO(roms_hip_lmd_vmix(c));
+  DO(roms_hip_omega(c));
+  const size_t wbytes = (size_t)c->G.nij * (size_t)(c->G.N + 1) * sizeof(double);
+  halo_fence(c, FG_ALL);
+  DO(d2d((double *)c->F.wrk3[11], (double *)c->F.wvel, wbytes, c->stream));
+  DO(roms_hip_wvelocity(c, s.nstp));
+  halo_fence(c, FG_ALL);
+  DO(d2d((double *)c->F.wrk3[12], (double *)c->F.wvel, wbytes, c->stream));
+  DO(d2d((double *)c->F.wvel, (double *)c->F.wrk3[11], wbytes, c->stream));
+  DO(roms_hip_set_zeta(c));
+#undef DO
+  return dsync(c->stream);
 }
 
 extern "C" int roms_hip_get_bounds(roms_hip_ctx *c, int *out) {

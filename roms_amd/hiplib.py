@@ -53,7 +53,7 @@ KERNELS = ["set_depth", "set_massflux", "rho_eos", "set_vbc", "ana_vmix", "set_d
 
 EXPORTS = ["roms_hip_create", "roms_hip_destroy", "roms_hip_last_error", "roms_hip_abi_version",
            "roms_hip_field_size", "roms_hip_upload", "roms_hip_download", "roms_hip_sync",
-           "roms_hip_set_stepping", "roms_hip_get_stepping", "roms_hip_wvelocity", "roms_hip_diag", "roms_hip_last_diag", "roms_hip_get_bounds",
+           "roms_hip_set_stepping", "roms_hip_get_stepping", "roms_hip_wvelocity", "roms_hip_diag", "roms_hip_last_diag", "roms_hip_get_bounds", "roms_hip_output_point",
            "roms_hip_start", "roms_hip_main3d", "roms_hip_profile", "roms_hip_region_seconds",
            "roms_hip_kprof", "roms_hip_kprof_get", "roms_hip_kprof_stride", "roms_hip_kprof_batch", "roms_hip_set_exchange", "roms_hip_rccl_unique_id",
            "roms_hip_comm_rccl", "roms_hip_exchange_count", "roms_hip_copy_probe"] + \
@@ -91,6 +91,7 @@ def load(path=None):
     L.roms_hip_diag.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.roms_hip_last_diag.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.roms_hip_get_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.roms_hip_output_point.argtypes = [C.c_void_p]
     L.roms_hip_start.argtypes = [C.c_void_p]
     L.roms_hip_main3d.argtypes = [C.c_void_p, C.c_int]
     L.roms_hip_profile.argtypes = [C.c_void_p, C.c_int]
@@ -204,6 +205,10 @@ class Context:
         out = (C.c_double * 16)()
         self._ck(self.L.roms_hip_diag(self.h, out))
         return list(out) if raw else list(out)[:12]
+
+    def output_point(self):
+        """derived fields of the step about to be taken as at main3d.F:591 (where the reference writes output)"""
+        self._ck(self.L.roms_hip_output_point(self.h))
 
     def bounds(self):
         """The 54 BOUNDS/DOMAIN entries of this tile as the library derived them (order: include/roms_hip.h)."""

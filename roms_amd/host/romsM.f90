@@ -6,9 +6,10 @@
       USE, INTRINSIC :: iso_c_binding
       USE roms_hip
       USE roms_host
+      USE roms_output
       implicit none
       character(len=512) :: infile, arg
-      integer :: ierr, done, chunk, mode, k
+      integer :: ierr, done, chunk, mode, k, first
       real(c_double) :: d(16)
       integer(8) :: c0, c1, crate
       IF (COMMAND_ARGUMENT_COUNT().lt.1) THEN
@@ -43,6 +44,16 @@
         print '(a,i0)', ' romsM: device initialisation failed, exit_flag = ', ierr
         STOP 2
       END IF
+      first=0
+      IF (nrrec.ne.0) THEN                        ! initial.F: nrrec /= 0 -> get_state (< 0: the latest record)
+        CALL get_state (TRIM(ininame), nrrec, ierr)
+        IF (ierr.ne.0) THEN
+          print '(a,i0,2a)', ' romsM: restart failed, exit_flag = ', ierr, ': ', TRIM(host_message)
+          STOP 2
+        END IF
+        first=step%iic-1
+        print '(a,i0,2a)', ' romsM: restarted at time-step ', first, ' from ', TRIM(ininame)
+      END IF
       print '(/,1x,a,1x,a,2x,a,3x,a,4x,a,4x,a)', 'TIME-STEP', 'YYYY-MM-DD hh:mm:ss.ss', 'KINETIC_ENRG',           &
      &      'POTEN_ENRG', 'TOTAL_ENRG', 'NET_VOLUME'
       print '(21x,a,7x,a,12x,a,10x,a,7x,a,/)', 'C => (i,j,k)', 'Cu', 'Cv', '  Cw  ', 'Max Speed'
@@ -52,15 +63,15 @@
       DO WHILE (done.lt.ntimes)
         chunk=MIN(chunk, ntimes-done)
         IF (mode.eq.0) THEN
-          ierr=roms_hip_main3d(ctx, chunk)        ! its first step is a NINFO point: diag ran inside it
-          IF (ierr.eq.0) ierr=roms_hip_last_diag(ctx, d)
+          CALL advance (chunk, 0, .FALSE., ierr)  ! roms_hip_main3d + the records of output.F; the first step is
+          IF (ierr.eq.0) ierr=roms_hip_last_diag(ctx, d)      ! a NINFO point: diag ran inside it
         ELSE
           ierr=roms_hip_get_stepping(ctx, step)   ! kernel by kernel: diag where main3d.F:355 has it
           step%nstp=1+MOD(step%iic-1,2)
           ierr=roms_hip_set_stepping(ctx, step)
           ierr=roms_hip_diag(ctx, d)
-          d(15)=REAL(done,c_double)
-          IF (ierr.eq.0) CALL main3d_kernels (chunk, ierr)
+          d(15)=REAL(first+done,c_double)
+          IF (ierr.eq.0) CALL advance (chunk, 1, .FALSE., ierr)
         END IF
         IF (ierr.ne.0) EXIT
         CALL report (NINT(d(15)), d)
@@ -71,8 +82,10 @@
         step%nstp=1+MOD(step%iic-1,2)
         ierr=roms_hip_set_stepping(ctx, step)
         ierr=roms_hip_diag(ctx, d)
-        IF (ierr.eq.0) CALL report (done, d)
+        IF (ierr.eq.0) CALL report (first+done, d)
+        IF (ierr.eq.0) CALL output (ierr)        ! main3d.F:591-595 at iic = ntend+1: the final records
       END IF
+      CALL out_close ()
       ierr=MAX(ierr, roms_hip_sync(ctx))
       CALL SYSTEM_CLOCK (c1)
       IF (ierr.ne.0) THEN

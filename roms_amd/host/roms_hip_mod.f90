@@ -132,6 +132,11 @@
           integer(c_int), intent(out) :: out(54)
           integer(c_int) :: ierr
         END FUNCTION
+        FUNCTION roms_hip_output_point (ctx) bind(C, name='roms_hip_output_point') RESULT (ierr)
+          IMPORT :: c_int, c_ptr
+          TYPE (c_ptr), value :: ctx
+          integer(c_int) :: ierr
+        END FUNCTION
         FUNCTION roms_hip_start (ctx) bind(C, name='roms_hip_start') RESULT (ierr)
           IMPORT :: c_int, c_ptr
           TYPE (c_ptr), value :: ctx

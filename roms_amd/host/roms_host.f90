@@ -31,6 +31,14 @@
       real(dp) :: rdrg = 3.0E-4_dp, rdrg2 = 3.0E-3_dp, Zob = 0.02_dp, Zos = 0.02_dp, gamma2 = 1.0_dp
       real(dp) :: dstart = 0.0_dp, time_ref = 0.0_dp, blk_ZQ = 10.0_dp, blk_ZT = 10.0_dp, blk_ZW = 10.0_dp
       integer :: options = 0
+!  output (read_phypar.F: NRREC ... NHIS, the Hout switches, the file names); written by roms_output.f90
+      integer :: nrrec = 0, nRST = 0, nHIS = 0
+      logical :: LcycleRST = .TRUE.
+      character(len=256) :: ininame = 'roms_ini.nc', rstname = 'roms_rst.nc', hisname = 'roms_his.nc'
+      integer, parameter :: idFsur = 1, idUbar = 2, idVbar = 3, idUvel = 4, idVvel = 5, idWvel = 6, idOvel = 7,    &
+     &                      idTemp = 8, idSalt = 9, idDano = 10, idVvis = 11, idTdif = 12, idSdif = 13,            &
+     &                      idHsbl = 14, nHout = 14
+      logical :: Hout(nHout) = .FALSE.
       character(len=512) :: app_header = ' '      ! application header to read the cpp options from (optional)
       character(len=256) :: host_message = ' '    ! why the last set-up step returned a non-zero exit_flag
       integer :: n_unused_keys = 0                ! roms.in keywords this build has no use for (output, nesting ...)
@@ -138,9 +146,28 @@
           CASE ('NBT', 'NST', 'NPT', 'NCS', 'NNS')
             IF (toint(tok(1)).ne.0) CALL unsupported (TRIM(key)//' > 0: only the active tracers are built', ierr)
             IF (ierr.ne.0) EXIT
-          CASE ('NRREC')
-            IF (toint(tok(1)).ne.0) CALL unsupported ('NRREC /= 0: restart input (NetCDF) is not built', ierr)
-            IF (ierr.ne.0) EXIT
+          CASE ('NRREC');       nrrec=toint(tok(1))
+          CASE ('LcycleRST');   LcycleRST=tok(1)(1:1).eq.'T'.or.tok(1)(1:1).eq.'t'
+          CASE ('NRST');        nRST=toint(tok(1))
+          CASE ('NHIS');        nHIS=toint(tok(1))
+          CASE ('ININAME');     ininame=ADJUSTL(val)
+          CASE ('RSTNAME');     rstname=ADJUSTL(val)
+          CASE ('HISNAME');     hisname=ADJUSTL(val)
+          CASE ('Hout(idFsur)'); Hout(idFsur)=istrue(tok(1))
+          CASE ('Hout(idUbar)'); Hout(idUbar)=istrue(tok(1))
+          CASE ('Hout(idVbar)'); Hout(idVbar)=istrue(tok(1))
+          CASE ('Hout(idUvel)'); Hout(idUvel)=istrue(tok(1))
+          CASE ('Hout(idVvel)'); Hout(idVvel)=istrue(tok(1))
+          CASE ('Hout(idWvel)'); Hout(idWvel)=istrue(tok(1))
+          CASE ('Hout(idOvel)'); Hout(idOvel)=istrue(tok(1))
+          CASE ('Hout(idTvar)')
+            Hout(idTemp)=istrue(tok(1))
+            IF (nv.ge.2) Hout(idSalt)=istrue(tok(2))
+          CASE ('Hout(idDano)'); Hout(idDano)=istrue(tok(1))
+          CASE ('Hout(idVvis)'); Hout(idVvis)=istrue(tok(1))
+          CASE ('Hout(idTdif)'); Hout(idTdif)=istrue(tok(1))
+          CASE ('Hout(idSdif)'); Hout(idSdif)=istrue(tok(1))
+          CASE ('Hout(idHsbl)'); Hout(idHsbl)=istrue(tok(1))
           CASE ('LuvSrc', 'LwSrc', 'LtracerSrc', 'LuvSponge', 'LtracerSponge', 'LsshCLM', 'Lm2CLM', 'Lm3CLM',     &
      &          'LtracerCLM', 'LnudgeM2CLM', 'LnudgeM3CLM', 'LnudgeTCLM', 'VolCons(west)', 'VolCons(east)',      &
      &          'VolCons(south)', 'VolCons(north)')
@@ -252,6 +279,8 @@
       visc2=5.0_dp; tnu2=0.0_dp; Akt_bak=1.0E-6_dp; Akv_bak=1.0E-5_dp
       rdrg=3.0E-4_dp; rdrg2=3.0E-3_dp; Zob=0.02_dp; Zos=0.02_dp; gamma2=1.0_dp
       dstart=0.0_dp; time_ref=0.0_dp; blk_ZQ=10.0_dp; blk_ZT=10.0_dp; blk_ZW=10.0_dp
+      nrrec=0; nRST=0; nHIS=0; LcycleRST=.TRUE.; Hout=.FALSE.
+      ininame='roms_ini.nc'; rstname='roms_rst.nc'; hisname='roms_his.nc'
       END SUBROUTINE set_defaults
 
       SUBROUTINE split (s, tok, n)
@@ -289,6 +318,11 @@
         END IF
       END DO
       END SUBROUTINE split
+
+      LOGICAL FUNCTION istrue (s)
+      character(len=*), intent(in) :: s
+      istrue=s(1:1).eq.'T'.or.s(1:1).eq.'t'
+      END FUNCTION istrue
 
       INTEGER FUNCTION toint (s)
       character(len=*), intent(in) :: s

@@ -5,6 +5,7 @@
       USE, INTRINSIC :: iso_c_binding
       USE roms_hip
       USE roms_host
+      USE roms_output
       implicit none
       CONTAINS
 
@@ -123,10 +124,98 @@
       FUNCTION roms_host_finalize () bind(C, name='roms_host_finalize') RESULT (ierr)
       integer(c_int) :: ierr
       ierr=0
+      CALL out_close ()
+      gather_cb => NULL()
       IF (c_associated(ctx)) ierr=roms_hip_destroy(ctx)
       ctx=c_null_ptr
       IF (allocated(h)) CALL host_free ()
       END FUNCTION roms_host_finalize
+!
+!  Output (roms_output.f90).  kind 1: a history record (wrt_his), 2: a restart record (wrt_rst) of the state
+!  between two steps, as the reference writes it at main3d.F:591 of the step about to be taken.
+!
+      FUNCTION roms_host_write (kind) bind(C, name='roms_host_write') RESULT (ierr)
+      integer(c_int), value :: kind
+      integer(c_int) :: ierr
+      integer :: e
+      IF (.not.c_associated(ctx).or.kind.lt.1.or.kind.gt.2) THEN
+        ierr=8
+        RETURN
+      END IF
+      CALL out_record (INT(kind), e)
+      exit_flag=e
+      ierr=e
+      END FUNCTION roms_host_write
+!
+!  nsteps steps with the history / restart records NHIS, NRST of roms.in ask for (output.F); final /= 0: also
+!  those of the step after the last (main3d.F:595).  mode as roms_host_run.
+!
+      FUNCTION roms_host_advance (nsteps, mode, final) bind(C, name='roms_host_advance') RESULT (ierr)
+      integer(c_int), value :: nsteps, mode, final
+      integer(c_int) :: ierr
+      integer :: e
+      IF (.not.c_associated(ctx)) THEN
+        ierr=8
+        RETURN
+      END IF
+      CALL advance (INT(nsteps), INT(mode), final.ne.0, e)
+      exit_flag=e
+      ierr=e
+      END FUNCTION roms_host_advance
+!
+!  Restart: record rec (1-based; <= 0: the latest) of restart file `path` (empty: ININAME of roms.in) into the
+!  device state and the stepping indices (get_state.F + initial.F for nrrec /= 0).
+!
+      FUNCTION roms_host_get_state (path, rec) bind(C, name='roms_host_get_state') RESULT (ierr)
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int), value :: rec
+      integer(c_int) :: ierr
+      integer :: e
+      character(len=:), allocatable :: p
+      IF (.not.c_associated(ctx)) THEN
+        ierr=8
+        RETURN
+      END IF
+      p=c2f(path)
+      IF (LEN_TRIM(p).eq.0) p=TRIM(ininame)
+      CALL get_state (p, INT(rec), e)
+      exit_flag=e
+      ierr=e
+      END FUNCTION roms_host_get_state
+!
+!  Close the output files (the run report of the reference lists them at ROMS_finalize).
+!
+      SUBROUTINE roms_host_close_output () bind(C, name='roms_host_close_output')
+      CALL out_close ()
+      END SUBROUTINE roms_host_close_output
+!
+!  Multi-tile runs: the call-back that assembles a global array on rank 0 (collective over the ranks).
+!
+      SUBROUTINE roms_host_set_gather (cb) bind(C, name='roms_host_set_gather')
+      TYPE (c_funptr), value :: cb
+      IF (c_associated(cb)) THEN
+        CALL c_f_procpointer (cb, gather_cb)
+      ELSE
+        gather_cb => NULL()
+      END IF
+      END SUBROUTINE roms_host_set_gather
+!
+!  nrrec, nRST, nHIS of roms.in and the file names (ININAME, RSTNAME, HISNAME), NUL-terminated, 256 bytes each
+!
+      SUBROUTINE roms_host_output_config (ints, names) bind(C, name='roms_host_output_config')
+      integer(c_int), intent(out) :: ints(4)
+      character(kind=c_char), intent(out) :: names(256,3)
+      integer :: k, j
+      character(len=256) :: w(3)
+      ints=(/ nrrec, nRST, nHIS, MERGE(1,0,LcycleRST) /)
+      w(1)=ininame; w(2)=rstname; w(3)=hisname
+      DO k=1,3
+        names(:,k)=c_null_char
+        DO j=1,MIN(LEN_TRIM(w(k)),255)
+          names(j,k)=w(k)(j:j)
+        END DO
+      END DO
+      END SUBROUTINE roms_host_output_config
 !
 !  dims(1:24): Lm Mm N NT Nghost LBi UBi LBj UBj nfast ndtfast ntimes options EW NS hadv(1:4) vadv(1:4) ninfo
 !  reals(1:8): dt dtfast hc hmin hmax xl el dstart

@@ -1,0 +1,1001 @@
+!  roms_output.f90 -- history and restart files of the forward nonlinear model, and the restart of a run from one.
+!
+!  The part of ROMS/Nonlinear/output.F, ROMS/Utility/def_his.F + wrt_his.F, def_rst.F + wrt_rst.F (PERFECT_RESTART
+!  form), def_info.F + wrt_info.F, def_dim.F, def_var.F, nf_fwrite2d/3d/4d.F, get_state.F and the restart branch
+!  of initial.F that the UPWELLING / BENCHMARK applications exercise: same file format (NetCDF-3, 64-bit offset:
+!  nc3.c writes it directly, the library is not in this image), same dimension names and sizes (the full
+!  IOBOUNDS ranges, ghost points of periodic directions included), same variable names, dimension order and
+!  attribute set (standard_name, long_name, units, time, grid, location, coordinates, field -- def_var.F:364-960,
+!  metadata of ROMS/External/varinfo.yaml), same time levels (KOUT = kstp, NOUT = nrhs: globaldefs.h:500-516),
+!  written at the same point of the step (main3d.F:591: roms_hip_output_point).
+!
+!  Data path: device -> roms_hip_download -> the tile's arrays; in a multi-tile run every rank calls the writer
+!  and a gather call-back (roms_host_set_gather: the rank-0 assembly of mp_gather2d/3d, distribute.F:3944,4725,
+!  done by roms_amd/tiling.py over torch.distributed) hands rank 0 the global array, which alone writes.
+!
+!  Restart records hold what def_rst.F defines under PERFECT_RESTART for these applications -- the time indices,
+!  all time levels of zeta, ubar, vbar, u, v, the tracers, and of their right-hand sides, AKv, AKt, AKs, Hsbl --
+!  plus ONE variable the reference does not write, indx1 (mod_stepping.F; the reference resets it on restart,
+!  which costs it bit-identity when an odd number of barotropic steps has passed): with it a restarted run
+!  continues bit for bit (tests/test_output.py).
+      MODULE roms_output
+      USE, INTRINSIC :: iso_c_binding
+      USE roms_hip
+      USE roms_host
+      implicit none
+
+      INTERFACE
+        FUNCTION nc3_create (path, h) bind(C, name='nc3_create') RESULT (r)
+          IMPORT :: c_int, c_char
+          character(kind=c_char), intent(in) :: path(*)
+          integer(c_int), intent(out) :: h
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_open (path, mode, h) bind(C, name='nc3_open') RESULT (r)
+          IMPORT :: c_int, c_char
+          character(kind=c_char), intent(in) :: path(*)
+          integer(c_int), value :: mode
+          integer(c_int), intent(out) :: h
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_def_dim (h, name, len, dimid) bind(C, name='nc3_def_dim') RESULT (r)
+          IMPORT :: c_int, c_long, c_char
+          integer(c_int), value :: h
+          character(kind=c_char), intent(in) :: name(*)
+          integer(c_long), value :: len
+          integer(c_int), intent(out) :: dimid
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_def_var (h, name, xtype, ndims, dimids, varid) bind(C, name='nc3_def_var') RESULT (r)
+          IMPORT :: c_int, c_char
+          integer(c_int), value :: h, xtype, ndims
+          character(kind=c_char), intent(in) :: name(*)
+          integer(c_int), intent(in) :: dimids(*)
+          integer(c_int), intent(out) :: varid
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_put_att_text (h, varid, name, text) bind(C, name='nc3_put_att_text') RESULT (r)
+          IMPORT :: c_int, c_char
+          integer(c_int), value :: h, varid
+          character(kind=c_char), intent(in) :: name(*), text(*)
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_put_att_double (h, varid, name, n, v) bind(C, name='nc3_put_att_double') RESULT (r)
+          IMPORT :: c_int, c_char, c_double
+          integer(c_int), value :: h, varid, n
+          character(kind=c_char), intent(in) :: name(*)
+          real(c_double), intent(in) :: v(*)
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_enddef (h) bind(C, name='nc3_enddef') RESULT (r)
+          IMPORT :: c_int
+          integer(c_int), value :: h
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_put_var_double (h, varid, rec, data, n) bind(C, name='nc3_put_var_double') RESULT (r)
+          IMPORT :: c_int, c_long, c_long_long, c_double
+          integer(c_int), value :: h, varid
+          integer(c_long), value :: rec
+          real(c_double), intent(in) :: data(*)
+          integer(c_long_long), value :: n
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_put_var_int (h, varid, rec, data, n) bind(C, name='nc3_put_var_int') RESULT (r)
+          IMPORT :: c_int, c_long, c_long_long
+          integer(c_int), value :: h, varid
+          integer(c_long), value :: rec
+          integer(c_int), intent(in) :: data(*)
+          integer(c_long_long), value :: n
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_get_var_double (h, varid, rec, data, n) bind(C, name='nc3_get_var_double') RESULT (r)
+          IMPORT :: c_int, c_long, c_long_long, c_double
+          integer(c_int), value :: h, varid
+          integer(c_long), value :: rec
+          real(c_double), intent(out) :: data(*)
+          integer(c_long_long), value :: n
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_get_var_int (h, varid, rec, data, n) bind(C, name='nc3_get_var_int') RESULT (r)
+          IMPORT :: c_int, c_long, c_long_long
+          integer(c_int), value :: h, varid
+          integer(c_long), value :: rec
+          integer(c_int), intent(out) :: data(*)
+          integer(c_long_long), value :: n
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_inq_varid (h, name, varid) bind(C, name='nc3_inq_varid') RESULT (r)
+          IMPORT :: c_int, c_char
+          integer(c_int), value :: h
+          character(kind=c_char), intent(in) :: name(*)
+          integer(c_int), intent(out) :: varid
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_inq_nrec (h, n) bind(C, name='nc3_inq_nrec') RESULT (r)
+          IMPORT :: c_int, c_long
+          integer(c_int), value :: h
+          integer(c_long), intent(out) :: n
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_inq_dimlen (h, name, n) bind(C, name='nc3_inq_dimlen') RESULT (r)
+          IMPORT :: c_int, c_long, c_char
+          integer(c_int), value :: h
+          character(kind=c_char), intent(in) :: name(*)
+          integer(c_long), intent(out) :: n
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_sync (h) bind(C, name='nc3_sync') RESULT (r)
+          IMPORT :: c_int
+          integer(c_int), value :: h
+          integer(c_int) :: r
+        END FUNCTION
+        FUNCTION nc3_close (h) bind(C, name='nc3_close') RESULT (r)
+          IMPORT :: c_int
+          integer(c_int), value :: h
+          integer(c_int) :: r
+        END FUNCTION
+      END INTERFACE
+
+      ABSTRACT INTERFACE
+        FUNCTION gather_fn (name, buf, n) bind(C) RESULT (r)          ! fills buf (global array) on rank 0
+          IMPORT :: c_int, c_long, c_char, c_double
+          character(kind=c_char), intent(in) :: name(*)
+          real(c_double), intent(out) :: buf(*)
+          integer(c_long), value :: n
+          integer(c_int) :: r
+        END FUNCTION
+      END INTERFACE
+      PROCEDURE (gather_fn), pointer :: gather_cb => NULL()
+
+      integer, parameter :: NC_INT = 4, NC_DOUBLE = 6
+!  grid types of a variable (mod_param.F: r2dvar ... w3dvar)
+      integer, parameter :: gR2 = 1, gU2 = 2, gV2 = 3, gR3 = 4, gU3 = 5, gV3 = 6, gW3 = 7, gUW = 8, gVW = 9
+      integer, parameter :: fHIS = 1, fRST = 2
+
+      TYPE out_file
+        integer(c_int) :: h = -1
+        integer :: nrec = 0                        ! records written so far (Rindex)
+        integer(c_int) :: d_xr, d_xu, d_xv, d_xp, d_er, d_eu, d_ev, d_ep, d_N, d_sr, d_sw, d_trc, d_bry
+        integer(c_int) :: d_two, d_three, d_time
+        integer(c_int) :: v_time, v_idx(7), v_fld(32)
+      END TYPE out_file
+      TYPE (out_file), save :: ofile(2)
+      integer :: ntstart_run = 1                   ! first step of this run (initial.F:172; > 1 after get_state)
+      logical :: restarted = .FALSE.
+
+      CONTAINS
+
+      FUNCTION cs (s) RESULT (c)
+      character(len=*), intent(in) :: s
+      character(kind=c_char, len=LEN_TRIM(s)+1) :: c
+      c=TRIM(s)//c_null_char
+      END FUNCTION cs
+
+      LOGICAL FUNCTION master ()
+      master=my_tile.eq.0
+      END FUNCTION master
+
+      LOGICAL FUNCTION is_spherical ()
+      is_spherical=IAND(options,ROMS_SPHERICAL).ne.0
+      END FUNCTION is_spherical
+!
+!-----------------------------------------------------------------------
+!  The state array `name` of the device as a GLOBAL host array A(LBi:UBi,LBj:UBj,np) (np = all its planes).
+!-----------------------------------------------------------------------
+!
+      SUBROUTINE fetch (name, np, A, ierr)
+      character(len=*), intent(in) :: name
+      integer, intent(in) :: np
+      real(r8), intent(out) :: A(LBi:UBi,LBj:UBj,np)
+      integer, intent(inout) :: ierr
+      integer(c_long) :: n
+      IF (ierr.ne.0) RETURN
+      n=SIZE(A,KIND=c_long)
+      IF (NtileI*NtileJ.eq.1) THEN
+        IF (roms_hip_field_size(ctx, cs(name)).ne.n) THEN
+          ierr=8
+          host_message='output: size mismatch for field '//TRIM(name)
+          RETURN
+        END IF
+        ierr=roms_hip_download(ctx, cs(name), A, n)
+      ELSE IF (ASSOCIATED(gather_cb)) THEN
+        ierr=gather_cb(cs(name), A, n)
+      ELSE
+        ierr=5
+        host_message='output from a multi-tile run needs a gather call-back (roms_host_set_gather)'
+      END IF
+      END SUBROUTINE fetch
+!
+!  IOBOUNDS window of plane set A for grid type g: rho points 0:Lm+1 x 0:Mm+1, u points 1:Lm+1 x 0:Mm+1,
+!  v points 0:Lm+1 x 1:Mm+1 (get_bounds.F: IOBOUNDS; the periodic ghost points 0 and Lm+1 are part of the file).
+!
+      SUBROUTINE io_range (g, i0, i1, j0, j1)
+      integer, intent(in) :: g
+      integer, intent(out) :: i0, i1, j0, j1
+      i0=0; i1=Lm+1; j0=0; j1=Mm+1
+      IF (g.eq.gU2.or.g.eq.gU3.or.g.eq.gUW) i0=1
+      IF (g.eq.gV2.or.g.eq.gV3.or.g.eq.gVW) j0=1
+      END SUBROUTINE io_range
+!
+!  nf_fwrite2d/3d/4d: planes k0:k1 of A as the slab of record `rec` (or the whole variable when rec < 0);
+!  scale = 0: no scaling.
+!
+      SUBROUTINE put_field (h, varid, rec, g, A, np, k0, k1, ierr)
+      integer(c_int), intent(in) :: h, varid
+      integer, intent(in) :: rec, g, np, k0, k1
+      real(r8), intent(in) :: A(LBi:UBi,LBj:UBj,np)
+      integer, intent(inout) :: ierr
+      real(r8), allocatable :: buf(:,:,:)
+      integer :: i0, i1, j0, j1
+      IF (ierr.ne.0.or..not.master()) RETURN
+      CALL io_range (g, i0, i1, j0, j1)
+      allocate ( buf(i0:i1,j0:j1,k0:k1) )
+      buf=A(i0:i1,j0:j1,k0:k1)
+      IF (nc3_put_var_double(h, varid, INT(MAX(rec,0),c_long), buf, SIZE(buf,KIND=c_long_long)).ne.0) THEN
+        ierr=3                                            ! exit_flag 3: output error (mod_scalars.F)
+        host_message='output: error while writing a field'
+      END IF
+      deallocate ( buf )
+      END SUBROUTINE put_field
+!
+!-----------------------------------------------------------------------
+!  def_dim.F / the dimension block of def_his.F:180-330.
+!-----------------------------------------------------------------------
+!
+      SUBROUTINE def_dims (o, rst, ierr)
+      TYPE (out_file), intent(inout) :: o
+      logical, intent(in) :: rst
+      integer, intent(inout) :: ierr
+      integer :: r
+      IF (.not.master()) RETURN
+      r=nc3_def_dim(o%h, cs('xi_rho'), INT(Lm+2,c_long), o%d_xr)
+      r=r+nc3_def_dim(o%h, cs('xi_u'), INT(Lm+1,c_long), o%d_xu)
+      r=r+nc3_def_dim(o%h, cs('xi_v'), INT(Lm+2,c_long), o%d_xv)
+      r=r+nc3_def_dim(o%h, cs('xi_psi'), INT(Lm+1,c_long), o%d_xp)
+      r=r+nc3_def_dim(o%h, cs('eta_rho'), INT(Mm+2,c_long), o%d_er)
+      r=r+nc3_def_dim(o%h, cs('eta_u'), INT(Mm+2,c_long), o%d_eu)
+      r=r+nc3_def_dim(o%h, cs('eta_v'), INT(Mm+1,c_long), o%d_ev)
+      r=r+nc3_def_dim(o%h, cs('eta_psi'), INT(Mm+1,c_long), o%d_ep)
+      r=r+nc3_def_dim(o%h, cs('N'), INT(N,c_long), o%d_N)
+      r=r+nc3_def_dim(o%h, cs('s_rho'), INT(N,c_long), o%d_sr)
+      r=r+nc3_def_dim(o%h, cs('s_w'), INT(N+1,c_long), o%d_sw)
+      r=r+nc3_def_dim(o%h, cs('tracer'), INT(NT,c_long), o%d_trc)
+      r=r+nc3_def_dim(o%h, cs('boundary'), 4_c_long, o%d_bry)
+      IF (rst) THEN
+        r=r+nc3_def_dim(o%h, cs('two'), 2_c_long, o%d_two)
+        r=r+nc3_def_dim(o%h, cs('three'), 3_c_long, o%d_three)
+      END IF
+      r=r+nc3_def_dim(o%h, cs('ocean_time'), 0_c_long, o%d_time)
+      IF (r.ne.0) ierr=3
+      END SUBROUTINE def_dims
+!
+!-----------------------------------------------------------------------
+!  def_var.F for a gridded variable: dimensions by grid type (+ an optional time-level dimension `lev`
+!  between ocean_time and the spatial ones, def_rst.F's nvd4 forms; + ocean_time when `timed`), attributes
+!  in def_var.F's order.
+!-----------------------------------------------------------------------
+!
+      SUBROUTINE def_field (o, name, stdname, longname, units, field, g, lev, timed, varid, ierr)
+      TYPE (out_file), intent(in) :: o
+      character(len=*), intent(in) :: name, stdname, longname, units, field
+      integer, intent(in) :: g
+      integer(c_int), intent(in) :: lev                   ! dimension id of the time-level axis, or -1
+      logical, intent(in) :: timed
+      integer(c_int), intent(out) :: varid
+      integer, intent(inout) :: ierr
+      integer(c_int) :: dims(6)
+      integer :: nd, r
+      character(len=64) :: coords, loc
+      character(len=8) :: px, py
+      IF (.not.master()) THEN
+        varid=0                                             ! "defined": the rank gathers this field
+        RETURN
+      END IF
+      nd=0
+      IF (timed) THEN
+        nd=nd+1; dims(nd)=o%d_time
+      END IF
+      IF (lev.ge.0) THEN
+        nd=nd+1; dims(nd)=lev
+      END IF
+      SELECT CASE (g)
+        CASE (gR3, gU3, gV3)
+          nd=nd+1; dims(nd)=o%d_sr
+        CASE (gW3, gUW, gVW)
+          nd=nd+1; dims(nd)=o%d_sw
+      END SELECT
+      SELECT CASE (g)
+        CASE (gR2, gR3, gW3)
+          dims(nd+1)=o%d_er; dims(nd+2)=o%d_xr; loc='face'
+        CASE (gU2, gU3, gUW)
+          dims(nd+1)=o%d_eu; dims(nd+2)=o%d_xu; loc='edge1'
+        CASE DEFAULT
+          dims(nd+1)=o%d_ev; dims(nd+2)=o%d_xv; loc='edge2'
+      END SELECT
+      nd=nd+2
+      IF (nc3_def_var(o%h, cs(name), NC_DOUBLE, nd, dims, varid).ne.0) THEN
+        ierr=3
+        RETURN
+      END IF
+      r=0
+      IF (LEN_TRIM(stdname).gt.0) r=r+nc3_put_att_text(o%h, varid, cs('standard_name'), cs(stdname))
+      r=r+nc3_put_att_text(o%h, varid, cs('long_name'), cs(longname))
+      IF (LEN_TRIM(units).gt.0.and.TRIM(units).ne.'nondimensional') THEN
+        r=r+nc3_put_att_text(o%h, varid, cs('units'), cs(units))
+      END IF
+      IF (timed) r=r+nc3_put_att_text(o%h, varid, cs('time'), cs('ocean_time'))
+      r=r+nc3_put_att_text(o%h, varid, cs('grid'), cs('grid'))
+      r=r+nc3_put_att_text(o%h, varid, cs('location'), cs(loc))
+      IF (is_spherical()) THEN
+        px='lon_'; py='lat_'
+      ELSE
+        px='x_'; py='y_'
+      END IF
+      SELECT CASE (g)
+        CASE (gR2); coords=TRIM(px)//'rho '//TRIM(py)//'rho'
+        CASE (gR3); coords=TRIM(px)//'rho '//TRIM(py)//'rho s_rho'
+        CASE (gW3); coords=TRIM(px)//'rho '//TRIM(py)//'rho s_w'
+        CASE (gU2); coords=TRIM(px)//'u '//TRIM(py)//'u'
+        CASE (gU3); coords=TRIM(px)//'u '//TRIM(py)//'u s_rho'
+        CASE (gUW); coords=TRIM(px)//'u '//TRIM(py)//'u s_w'
+        CASE (gV2); coords=TRIM(px)//'v '//TRIM(py)//'v'
+        CASE (gV3); coords=TRIM(px)//'v '//TRIM(py)//'v s_rho'
+        CASE DEFAULT; coords=TRIM(px)//'v '//TRIM(py)//'v s_w'
+      END SELECT
+      IF (timed) coords=TRIM(coords)//' ocean_time'
+      r=r+nc3_put_att_text(o%h, varid, cs('coordinates'), cs(coords))
+      IF (LEN_TRIM(field).gt.0) r=r+nc3_put_att_text(o%h, varid, cs('field'), cs(field))
+      IF (r.ne.0) ierr=3
+      END SUBROUTINE def_field
+!
+!  a scalar or 1-D information variable (def_info.F)
+!
+      SUBROUTINE def_scalar (o, name, xtype, longname, units, dimid, varid, ierr)
+      TYPE (out_file), intent(in) :: o
+      character(len=*), intent(in) :: name, longname, units
+      integer, intent(in) :: xtype
+      integer(c_int), intent(in) :: dimid                  ! -1: scalar
+      integer(c_int), intent(out) :: varid
+      integer, intent(inout) :: ierr
+      integer(c_int) :: dims(1)
+      integer :: r
+      IF (.not.master()) THEN
+        varid=0
+        RETURN
+      END IF
+      dims(1)=MAX(dimid,0)
+      r=nc3_def_var(o%h, cs(name), xtype, MERGE(1,0,dimid.ge.0), dims, varid)
+      r=r+nc3_put_att_text(o%h, varid, cs('long_name'), cs(longname))
+      IF (LEN_TRIM(units).gt.0) r=r+nc3_put_att_text(o%h, varid, cs('units'), cs(units))
+      IF (r.ne.0) ierr=3
+      END SUBROUTINE def_scalar
+!
+!-----------------------------------------------------------------------
+!  def_info.F / wrt_info.F: global attributes and the time-independent variables (the entries these
+!  applications have values for, in def_info.F's order and with its names, long names and units).
+!-----------------------------------------------------------------------
+!
+      SUBROUTINE info (o, path, ftype, define, ierr)
+      TYPE (out_file), intent(inout) :: o
+      character(len=*), intent(in) :: path, ftype
+      logical, intent(in) :: define
+      integer, intent(inout) :: ierr
+      integer, save :: vid(64,2)
+      integer :: k, r, w
+      integer(c_int) :: iv(1)
+      real(r8) :: dv(1)
+      real(r8), allocatable :: A(:,:,:)
+      character(len=16) :: tiling
+      w=MERGE(1,2,ftype.eq.'ROMS history file')
+      IF (.not.master()) RETURN
+      IF (define) THEN
+        write (tiling,'(i3.3,a,i3.3)') NtileI, 'x', NtileJ
+        r=nc3_put_att_text(o%h, -1, cs('file'), cs(path))
+        r=r+nc3_put_att_text(o%h, -1, cs('format'), cs('netCDF-3 64bit offset file'))
+        r=r+nc3_put_att_text(o%h, -1, cs('Conventions'), cs('CF-1.4, SGRID-0.3'))
+        r=r+nc3_put_att_text(o%h, -1, cs('type'), cs(ftype))
+        r=r+nc3_put_att_text(o%h, -1, cs('title'), cs('ROMS on MI355X: '//TRIM(MyAppCPP)))
+        r=r+nc3_put_att_text(o%h, -1, cs('rst_file'), cs(rstname))
+        r=r+nc3_put_att_text(o%h, -1, cs('his_file'), cs(hisname))
+        r=r+nc3_put_att_text(o%h, -1, cs('tiling'), cs(tiling))
+        r=r+nc3_put_att_text(o%h, -1, cs('CPP_options'), cs(MyAppCPP))
+        IF (r.ne.0) ierr=3
+        k=0
+        CALL sdef ('ntimes', NC_INT, 'number of long time-steps', ' ')
+        CALL sdef ('ndtfast', NC_INT, 'number of short time-steps', ' ')
+        CALL sdef ('dt', NC_DOUBLE, 'size of long time-steps', 'second')
+        CALL sdef ('dtfast', NC_DOUBLE, 'size of short time-steps', 'second')
+        CALL sdef ('dstart', NC_DOUBLE, 'time stamp assigned to model initialization', 'days since 0001-01-01 00:00:00')
+        CALL sdef ('nHIS', NC_INT, 'number of time-steps between history records', ' ')
+        CALL sdef ('nRST', NC_INT, 'number of time-steps between restart records', ' ')
+        CALL sdef ('Falpha', NC_DOUBLE, 'Power-law shape barotropic filter parameter', ' ')
+        CALL sdef ('Fbeta', NC_DOUBLE, 'Power-law shape barotropic filter parameter', ' ')
+        CALL sdef ('Fgamma', NC_DOUBLE, 'Power-law shape barotropic filter parameter', ' ')
+        CALL vdef ('nl_tnu2', 'nonlinear model Laplacian mixing coefficient for tracers', 'meter2 second-1', o%d_trc)
+        CALL sdef ('nl_visc2', NC_DOUBLE, 'nonlinear model Laplacian mixing coefficient for momentum', 'meter2 second-1')
+        CALL vdef ('Akt_bak', 'background vertical mixing coefficient for tracers', 'meter2 second-1', o%d_trc)
+        CALL sdef ('Akv_bak', NC_DOUBLE, 'background vertical mixing coefficient for momentum', 'meter2 second-1')
+        CALL sdef ('rdrg', NC_DOUBLE, 'linear drag coefficient', 'meter second-1')
+        CALL sdef ('rdrg2', NC_DOUBLE, 'quadratic drag coefficient', ' ')
+        CALL sdef ('Zob', NC_DOUBLE, 'bottom roughness', 'meter')
+        CALL sdef ('Zos', NC_DOUBLE, 'surface roughness', 'meter')
+        CALL sdef ('rho0', NC_DOUBLE, 'mean density used in Boussinesq approximation', 'kilogram meter-3')
+        CALL sdef ('R0', NC_DOUBLE, 'background density used in linear equation of state', 'kilogram meter-3')
+        CALL sdef ('Tcoef', NC_DOUBLE, 'thermal expansion coefficient', 'Celsius-1')
+        CALL sdef ('Scoef', NC_DOUBLE, 'Saline contraction coefficient', ' ')
+        CALL sdef ('gamma2', NC_DOUBLE, 'slipperiness parameter', ' ')
+        CALL sdef ('spherical', NC_INT, 'grid type logical switch', ' ')
+        CALL sdef ('xl', NC_DOUBLE, 'domain length in the XI-direction', 'meter')
+        CALL sdef ('el', NC_DOUBLE, 'domain length in the ETA-direction', 'meter')
+        CALL sdef ('Vtransform', NC_INT, 'vertical terrain-following transformation equation', ' ')
+        CALL sdef ('Vstretching', NC_INT, 'vertical terrain-following stretching function', ' ')
+        CALL sdef ('theta_s', NC_DOUBLE, 'S-coordinate surface control parameter', ' ')
+        CALL sdef ('theta_b', NC_DOUBLE, 'S-coordinate bottom control parameter', ' ')
+        CALL sdef ('Tcline', NC_DOUBLE, 'S-coordinate surface/bottom layer width', 'meter')
+        CALL sdef ('hc', NC_DOUBLE, 'S-coordinate parameter, critical depth', 'meter')
+        CALL vdef ('s_rho', 'S-coordinate at RHO-points', ' ', o%d_sr)
+        CALL vdef ('s_w', 'S-coordinate at W-points', ' ', o%d_sw)
+        CALL vdef ('Cs_r', 'S-coordinate stretching curves at RHO-points', ' ', o%d_sr)
+        CALL vdef ('Cs_w', 'S-coordinate stretching curves at W-points', ' ', o%d_sw)
+        k=k+1; CALL def_field (o, 'h', 'sea_floor_depth', 'bathymetry at RHO-points', 'meter', 'bath', gR2, -1_c_int,   &
+     &                         .FALSE., vid(k,w), ierr)
+        k=k+1; CALL def_field (o, 'f', 'coriolis_parameter', 'Coriolis parameter at RHO-points', 'second-1',          &
+     &                         'coriolis', gR2, -1_c_int, .FALSE., vid(k,w), ierr)
+        k=k+1; CALL def_field (o, 'pm', 'inverse_grid_x_spacing', 'curvilinear coordinate metric in XI', 'meter-1',  &
+     &                         'pm', gR2, -1_c_int, .FALSE., vid(k,w), ierr)
+        k=k+1; CALL def_field (o, 'pn', 'inverse_grid_y_spacing', 'curvilinear coordinate metric in ETA', 'meter-1', &
+     &                         'pn', gR2, -1_c_int, .FALSE., vid(k,w), ierr)
+        IF (is_spherical()) THEN
+          k=k+1; CALL def_field (o, 'lon_rho', 'longitude', 'longitude of RHO-points', 'degree_east', 'lon_rho',   &
+     &                           gR2, -1_c_int, .FALSE., vid(k,w), ierr)
+          k=k+1; CALL def_field (o, 'lat_rho', 'latitude', 'latitude of RHO-points', 'degree_north', 'lat_rho',    &
+     &                           gR2, -1_c_int, .FALSE., vid(k,w), ierr)
+        ELSE
+          k=k+1; CALL def_field (o, 'x_rho', 'grid_x_location_at_cell_center', 'x-locations of RHO-points',        &
+     &                           'meter', 'x_rho', gR2, -1_c_int, .FALSE., vid(k,w), ierr)
+          k=k+1; CALL def_field (o, 'y_rho', 'grid_y_location_at_cell_center', 'y-locations of RHO-points',        &
+     &                           'meter', 'y_rho', gR2, -1_c_int, .FALSE., vid(k,w), ierr)
+        END IF
+      ELSE
+        k=0
+        CALL iput (ntimes); CALL iput (ndtfast); CALL dput (dt); CALL dput (dtfast); CALL dput (dstart)
+        CALL iput (nHIS); CALL iput (nRST); CALL dput (Falpha); CALL dput (Fbeta); CALL dput (Fgamma)
+        CALL aput (tnu2(1:NT)); CALL dput (visc2); CALL aput (tbak()); CALL dput (Akv_bak)
+        CALL dput (rdrg); CALL dput (rdrg2); CALL dput (Zob); CALL dput (Zos); CALL dput (rho0); CALL dput (R0)
+        CALL dput (Tcoef); CALL dput (Scoef); CALL dput (gamma2); CALL iput (MERGE(1,0,is_spherical()))
+        CALL dput (xl); CALL dput (el); CALL iput (Vtransform); CALL iput (Vstretching); CALL dput (theta_s)
+        CALL dput (theta_b); CALL dput (Tcline); CALL dput (hc)
+        CALL aput (sc_r); CALL aput (sc_w); CALL aput (Cs_r); CALL aput (Cs_w)
+        allocate ( A(LBi:UBi,LBj:UBj,1) )
+        A(:,:,1)=h;  k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
+        A(:,:,1)=f;  k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
+        A(:,:,1)=pm; k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
+        A(:,:,1)=pn; k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
+        IF (is_spherical()) THEN
+          A(:,:,1)=lonr; k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
+          A(:,:,1)=latr; k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
+        ELSE
+          A(:,:,1)=xr; k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
+          A(:,:,1)=yr; k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
+        END IF
+        deallocate ( A )
+      END IF
+
+      CONTAINS
+        SUBROUTINE sdef (name, xtype, longname, units)
+        character(len=*), intent(in) :: name, longname, units
+        integer, intent(in) :: xtype
+        k=k+1
+        CALL def_scalar (o, name, xtype, longname, units, -1_c_int, vid(k,w), ierr)
+        END SUBROUTINE sdef
+        SUBROUTINE vdef (name, longname, units, dimid)
+        character(len=*), intent(in) :: name, longname, units
+        integer(c_int), intent(in) :: dimid
+        k=k+1
+        CALL def_scalar (o, name, NC_DOUBLE, longname, units, dimid, vid(k,w), ierr)
+        END SUBROUTINE vdef
+        SUBROUTINE iput (v)
+        integer, intent(in) :: v
+        k=k+1
+        iv(1)=v
+        IF (nc3_put_var_int(o%h, vid(k,w), 0_c_long, iv, 1_c_long_long).ne.0) ierr=3
+        END SUBROUTINE iput
+        SUBROUTINE dput (v)
+        real(r8), intent(in) :: v
+        k=k+1
+        dv(1)=v
+        IF (nc3_put_var_double(o%h, vid(k,w), 0_c_long, dv, 1_c_long_long).ne.0) ierr=3
+        END SUBROUTINE dput
+        SUBROUTINE aput (v)
+        real(r8), intent(in) :: v(:)
+        k=k+1
+        IF (nc3_put_var_double(o%h, vid(k,w), 0_c_long, v, SIZE(v,KIND=c_long_long)).ne.0) ierr=3
+        END SUBROUTINE aput
+        FUNCTION tbak () RESULT (b)
+        real(r8) :: b(NT)
+        b=Akt_bak(1:NT)
+        END FUNCTION tbak
+      END SUBROUTINE info
+!
+!-----------------------------------------------------------------------
+!  def_his.F / def_rst.F: create the file (master only), define everything, leave define mode, write the
+!  information variables.
+!-----------------------------------------------------------------------
+!
+      SUBROUTINE out_define (which, ierr)
+      integer, intent(in) :: which
+      integer, intent(out) :: ierr
+      character(len=256) :: path
+      character(len=32) :: ftype
+      integer :: k, r
+      logical :: rst, lmd
+      integer(c_int) :: two, three
+      character(len=96) :: tunit
+      ierr=0
+      rst=which.eq.fRST
+      lmd=IAND(options,ROMS_LMD_MIXING).ne.0
+      path=MERGE(rstname, hisname, rst)
+      ftype=MERGE('ROMS restart file', 'ROMS history file', rst)
+      ofile(which)%nrec=0
+      IF (.not.master()) THEN
+        ofile(which)%h=0                   ! "open": this rank takes part in the gathers only; the definitions below
+      ELSE IF (nc3_create(cs(path), ofile(which)%h).ne.0) THEN      ! run everywhere (they say which fields a record has)
+        ierr=3
+        host_message='cannot create '//TRIM(path)
+        RETURN
+      END IF
+      ASSOCIATE (o => ofile(which))
+      CALL def_dims (o, rst, ierr)
+      CALL info (o, TRIM(path), TRIM(ftype), .TRUE., ierr)
+      two=-1; three=-1
+      IF (rst) THEN
+        two=o%d_two; three=o%d_three
+!  time-stepping indices, def_rst.F:613-665 (+ indx1, see the header)
+        CALL def_scalar (o, 'nstp', NC_INT, '3D equations time level index, nstp', ' ', o%d_time, o%v_idx(1), ierr)
+        CALL def_scalar (o, 'nrhs', NC_INT, '3D equations time level index, nrhs', ' ', o%d_time, o%v_idx(2), ierr)
+        CALL def_scalar (o, 'nnew', NC_INT, '3D equations time level index, nnew', ' ', o%d_time, o%v_idx(3), ierr)
+        CALL def_scalar (o, 'kstp', NC_INT, '3D equations time level index, kstp', ' ', o%d_time, o%v_idx(4), ierr)
+        CALL def_scalar (o, 'krhs', NC_INT, '3D equations time level index, krhs', ' ', o%d_time, o%v_idx(5), ierr)
+        CALL def_scalar (o, 'knew', NC_INT, '3D equations time level index, knew', ' ', o%d_time, o%v_idx(6), ierr)
+        CALL def_scalar (o, 'indx1', NC_INT, '2D equations time level index, indx1 (not in the reference file)', ' ', &
+     &                   o%d_time, o%v_idx(7), ierr)
+      END IF
+!  model time, def_his.F: Vname(:,idtime), units "seconds since <reference date>" (time_ref = 0: 0001-01-01)
+      tunit='seconds since 0001-01-01 00:00:00'
+      CALL def_scalar (o, 'ocean_time', NC_DOUBLE, 'time since initialization', TRIM(tunit), o%d_time, o%v_time, ierr)
+      IF (master()) THEN
+        r=nc3_put_att_text(o%h, o%v_time, cs('calendar'), cs('proleptic_gregorian'))
+        r=r+nc3_put_att_text(o%h, o%v_time, cs('field'), cs('time'))
+      END IF
+      o%v_fld=-1
+      k=0
+      IF (rst.or.Hout(idFsur)) CALL fdef ('zeta', 'sea_surface_height_above_geopotential_datum', 'free-surface',     &
+     &                                    'meter', 'free-surface', gR2, three, idFsur)
+      IF (rst) CALL fdef ('rzeta', 'sea_surface_elevation_anomaly_right_hand_side', 'RHS of free-surface equation',  &
+     &                    'meter3 second-1', 'free-surface RHS', gR2, two, 15)
+      IF (rst.or.Hout(idUbar)) CALL fdef ('ubar', 'barotropic_sea_water_x_velocity',                                 &
+     &     'vertically integrated u-momentum component', 'meter second-1', 'u-barotropic', gU2, three, idUbar)
+      IF (rst) CALL fdef ('rubar', 'barotropic_sea_water_x_velocity_right_hand_side',                                &
+     &     'RHS of vertically integrated u-momentum', 'meter4 second-2', 'u-barotripic RHS', gU2, two, 16)
+      IF (rst.or.Hout(idVbar)) CALL fdef ('vbar', 'barotropic_sea_water_y_velocity',                                 &
+     &     'vertically integrated v-momentum component', 'meter second-1', 'v-barotropic', gV2, three, idVbar)
+      IF (rst) CALL fdef ('rvbar', 'barotropic_sea_water_y_velocity_right_hand_side',                                &
+     &     'RHS of vertically integrated v-momentum', 'meter4 second-2', 'v-barotropic RHS', gV2, two, 17)
+      IF (rst.or.Hout(idUvel)) CALL fdef ('u', 'sea_water_x_velocity', 'u-momentum component', 'meter second-1',     &
+     &                                    'u-velocity', gU3, two, idUvel)
+      IF (rst) CALL fdef ('ru', 'sea_water_x_velocity_right_hand_side', 'RHS of total u-momentum',                   &
+     &                    'meter4 second-2', 'u-velocity RHS', gUW, two, 18)
+      IF (rst.or.Hout(idVvel)) CALL fdef ('v', 'sea_water_y_velocity', 'v-momentum component', 'meter second-1',     &
+     &                                    'v-velocity', gV3, two, idVvel)
+      IF (rst) CALL fdef ('rv', 'sea_water_y_velocity_right_hand_side', 'RHS of total v-momentum',                   &
+     &                    'meter4 second-2', 'v-velocity RHS', gVW, two, 19)
+      IF (.not.rst.and.Hout(idWvel)) CALL fdef ('w', 'upward_sea_water_velocity', 'vertical momentum component',     &
+     &                                          'meter second-1', 'w-velocity', gW3, -1_c_int, idWvel)
+      IF (.not.rst.and.Hout(idOvel)) CALL fdef ('omega', 'upward_sea_water_omega_velocity',                           &
+     &     'S-coordinate vertical momentum component', 'meter3 second-1', 'omega', gW3, -1_c_int, idOvel)
+      IF (rst.or.Hout(idTemp)) CALL fdef ('temp', 'sea_water_potential_temperature', 'potential temperature',        &
+     &                                    'Celsius', 'temperature', gR3, two, idTemp)
+      IF (NT.ge.2.and.(rst.or.Hout(idSalt))) CALL fdef ('salt', 'sea_water_practical_salinity', 'salinity',          &
+     &                                    'nondimensional', 'salinity', gR3, two, idSalt)
+      IF (.not.rst.and.Hout(idDano)) CALL fdef ('rho', 'sea_water_density_anomaly', 'density anomaly',               &
+     &                                          'kilogram meter-3', 'density', gR3, -1_c_int, idDano)
+      IF (rst.or.Hout(idVvis)) CALL fdef ('AKv', 'vertical_viscosity_coefficient_of_sea_water',                      &
+     &     'vertical viscosity coefficient', 'meter2 second-1', 'AKv', gW3, -1_c_int, idVvis)
+      IF (rst.or.Hout(idTdif)) CALL fdef ('AKt', 'vertical_diffusion_coefficient_of_temperature_in_sea_water',       &
+     &     'temperature vertical diffusion coefficient', 'meter2 second-1', 'AKt', gW3, -1_c_int, idTdif)
+      IF (NAT.ge.2.and.(rst.or.Hout(idSdif))) CALL fdef ('AKs',                                                      &
+     &     'vertical_diffusion_coefficient_of_salinity_in_sea_water', 'salinity vertical diffusion coefficient',     &
+     &     'meter2 second-1', 'AKs', gW3, -1_c_int, idSdif)
+      IF (lmd.and.(rst.or.Hout(idHsbl))) CALL fdef ('Hsbl', 'ocean_surface_boundary_layer_thickness',                &
+     &     'depth of oceanic surface boundary layer', 'meter', 'SBL thickness', gR2, -1_c_int, idHsbl)
+      IF (ierr.eq.0.and.master()) THEN
+        IF (nc3_enddef(o%h).ne.0) ierr=3
+      END IF
+      CALL info (o, TRIM(path), TRIM(ftype), .FALSE., ierr)
+      END ASSOCIATE
+
+      CONTAINS
+        SUBROUTINE fdef (name, stdname, longname, units, field, g, lev, slot)
+        character(len=*), intent(in) :: name, stdname, longname, units, field
+        integer, intent(in) :: g, slot
+        integer(c_int), intent(in) :: lev
+        CALL def_field (ofile(which), name, stdname, longname, units, field, g, MERGE(lev, -1_c_int, rst), .TRUE.,       &
+     &                  ofile(which)%v_fld(slot), ierr)
+        END SUBROUTINE fdef
+      END SUBROUTINE out_define
+!
+!-----------------------------------------------------------------------
+!  wrt_his.F / wrt_rst.F: one record.  Every rank calls it (the gathers are collective); rank 0 writes.
+!-----------------------------------------------------------------------
+!
+      SUBROUTINE out_record (which, ierr)
+      integer, intent(in) :: which
+      integer, intent(out) :: ierr
+      logical :: rst, lmd
+      integer :: rec, kout, nout, itrc, k
+      integer(c_int) :: iv(1)
+      real(r8) :: tv(1)
+      real(r8), allocatable :: A(:,:,:), B(:,:,:)
+      ierr=0
+      rst=which.eq.fRST
+      lmd=IAND(options,ROMS_LMD_MIXING).ne.0
+      IF (ofile(which)%h.lt.0) CALL out_define (which, ierr)
+      IF (ierr.ne.0) RETURN
+      ierr=roms_hip_output_point(ctx)                      ! main3d.F:591
+      IF (ierr.ne.0) RETURN
+      ierr=roms_hip_get_stepping(ctx, step)
+      ASSOCIATE (o => ofile(which))
+!  record index: wrt_rst.F:151 (LcycleRST: two records, recycled), wrt_his.F
+      o%nrec=o%nrec+1
+      rec=o%nrec-1
+      IF (rst.and.LcycleRST) rec=MOD(o%nrec-1,2)
+      kout=step%kstp
+      nout=step%nrhs
+      IF (master()) THEN
+        IF (rst) THEN
+          iv(1)=step%nstp; IF (nc3_put_var_int(o%h, o%v_idx(1), INT(rec,c_long), iv, 1_c_long_long).ne.0) ierr=3
+          iv(1)=step%nrhs; IF (nc3_put_var_int(o%h, o%v_idx(2), INT(rec,c_long), iv, 1_c_long_long).ne.0) ierr=3
+          iv(1)=step%nnew; IF (nc3_put_var_int(o%h, o%v_idx(3), INT(rec,c_long), iv, 1_c_long_long).ne.0) ierr=3
+          iv(1)=step%kstp; IF (nc3_put_var_int(o%h, o%v_idx(4), INT(rec,c_long), iv, 1_c_long_long).ne.0) ierr=3
+          iv(1)=step%krhs; IF (nc3_put_var_int(o%h, o%v_idx(5), INT(rec,c_long), iv, 1_c_long_long).ne.0) ierr=3
+          iv(1)=step%knew; IF (nc3_put_var_int(o%h, o%v_idx(6), INT(rec,c_long), iv, 1_c_long_long).ne.0) ierr=3
+          iv(1)=step%indx1; IF (nc3_put_var_int(o%h, o%v_idx(7), INT(rec,c_long), iv, 1_c_long_long).ne.0) ierr=3
+        END IF
+        tv(1)=step%time
+        IF (nc3_put_var_double(o%h, o%v_time, INT(rec,c_long), tv, 1_c_long_long).ne.0) ierr=3
+      END IF
+!  2-D state
+      allocate ( A(LBi:UBi,LBj:UBj,3) )
+      CALL wr2 ('zeta', idFsur, gR2, 3)
+      IF (rst) CALL wr2 ('rzeta', 15, gR2, 2)
+      CALL wr2 ('ubar', idUbar, gU2, 3)
+      IF (rst) CALL wr2 ('rubar', 16, gU2, 2)
+      CALL wr2 ('vbar', idVbar, gV2, 3)
+      IF (rst) CALL wr2 ('rvbar', 17, gV2, 2)
+      deallocate ( A )
+!  3-D momentum and its right-hand sides (time level 2 of a Fortran array u(i,j,k,n) = planes N+1..2N)
+      CALL wr3 ('u', idUvel, gU3, N)
+      IF (rst) CALL wr3 ('ru', 18, gUW, N+1)
+      CALL wr3 ('v', idVvel, gV3, N)
+      IF (rst) CALL wr3 ('rv', 19, gVW, N+1)
+!  w (wvelocity's result at the output point) and omega scaled as scale_omega does (omega.F: W*pm*pn)
+      IF (.not.rst.and.o%v_fld(idWvel).ge.0) THEN
+        allocate ( A(LBi:UBi,LBj:UBj,N+1) )
+        CALL fetch ('w_out', N+1, A, ierr)
+        CALL put_field (o%h, o%v_fld(idWvel), rec, gW3, A, N+1, 1, N+1, ierr)
+        deallocate ( A )
+      END IF
+      IF (.not.rst.and.o%v_fld(idOvel).ge.0) THEN
+        allocate ( A(LBi:UBi,LBj:UBj,N+1) )
+        CALL fetch ('W', N+1, A, ierr)
+        DO k=1,N+1
+          A(:,:,k)=A(:,:,k)*pm*pn
+        END DO
+        CALL put_field (o%h, o%v_fld(idOvel), rec, gW3, A, N+1, 1, N+1, ierr)
+        deallocate ( A )
+      END IF
+!  tracers: t(i,j,k,3,itrc)
+      IF (o%v_fld(idTemp).ge.0.or.o%v_fld(idSalt).ge.0) THEN
+        allocate ( A(LBi:UBi,LBj:UBj,3*N*NT) )
+        CALL fetch ('t', 3*N*NT, A, ierr)
+        DO itrc=1,MIN(NT,2)
+          k=MERGE(idTemp, idSalt, itrc.eq.1)
+          IF (o%v_fld(k).lt.0) CYCLE
+          IF (rst) THEN
+            CALL put_field (o%h, o%v_fld(k), rec, gR3, A, 3*N*NT, 3*N*(itrc-1)+1, 3*N*(itrc-1)+2*N, ierr)
+          ELSE
+            CALL put_field (o%h, o%v_fld(k), rec, gR3, A, 3*N*NT, 3*N*(itrc-1)+N*(nout-1)+1,                         &
+     &                      3*N*(itrc-1)+N*nout, ierr)
+          END IF
+        END DO
+        deallocate ( A )
+      END IF
+      IF (.not.rst.and.o%v_fld(idDano).ge.0) THEN
+        allocate ( A(LBi:UBi,LBj:UBj,N) )
+        CALL fetch ('rho', N, A, ierr)
+        CALL put_field (o%h, o%v_fld(idDano), rec, gR3, A, N, 1, N, ierr)
+        deallocate ( A )
+      END IF
+      IF (o%v_fld(idVvis).ge.0) THEN
+        allocate ( A(LBi:UBi,LBj:UBj,N+1) )
+        CALL fetch ('Akv', N+1, A, ierr)
+        CALL put_field (o%h, o%v_fld(idVvis), rec, gW3, A, N+1, 1, N+1, ierr)
+        deallocate ( A )
+      END IF
+      IF (o%v_fld(idTdif).ge.0.or.o%v_fld(idSdif).ge.0) THEN
+        allocate ( A(LBi:UBi,LBj:UBj,(N+1)*NAT) )
+        CALL fetch ('Akt', (N+1)*NAT, A, ierr)
+        IF (o%v_fld(idTdif).ge.0) CALL put_field (o%h, o%v_fld(idTdif), rec, gW3, A, (N+1)*NAT, 1, N+1, ierr)
+        IF (o%v_fld(idSdif).ge.0) CALL put_field (o%h, o%v_fld(idSdif), rec, gW3, A, (N+1)*NAT, N+2, 2*(N+1), ierr)
+        deallocate ( A )
+      END IF
+      IF (o%v_fld(idHsbl).ge.0) THEN
+        allocate ( A(LBi:UBi,LBj:UBj,1) )
+        CALL fetch ('hsbl', 1, A, ierr)
+        CALL put_field (o%h, o%v_fld(idHsbl), rec, gR2, A, 1, 1, 1, ierr)
+        deallocate ( A )
+      END IF
+      IF (master().and.ierr.eq.0) THEN
+        IF (nc3_sync(o%h).ne.0) ierr=3                      ! netcdf_sync after every record (wrt_his.F)
+      END IF
+      END ASSOCIATE
+
+      CONTAINS
+        SUBROUTINE wr2 (name, slot, g, nlev)                ! history: level KOUT; restart: all levels
+        character(len=*), intent(in) :: name
+        integer, intent(in) :: slot, g, nlev
+        IF (ofile(which)%v_fld(slot).lt.0) RETURN
+        CALL fetch (name, nlev, A(:,:,1:nlev), ierr)
+        IF (rst) THEN
+          CALL put_field (ofile(which)%h, ofile(which)%v_fld(slot), rec, g, A(:,:,1:nlev), nlev, 1, nlev, ierr)
+        ELSE
+          CALL put_field (ofile(which)%h, ofile(which)%v_fld(slot), rec, g, A(:,:,1:nlev), nlev, kout, kout, ierr)
+        END IF
+        END SUBROUTINE wr2
+        SUBROUTINE wr3 (name, slot, g, nz)                  ! history: level NOUT; restart: both levels
+        character(len=*), intent(in) :: name
+        integer, intent(in) :: slot, g, nz
+        IF (ofile(which)%v_fld(slot).lt.0) RETURN
+        allocate ( B(LBi:UBi,LBj:UBj,2*nz) )
+        CALL fetch (name, 2*nz, B, ierr)
+        IF (rst) THEN
+          CALL put_field (ofile(which)%h, ofile(which)%v_fld(slot), rec, g, B, 2*nz, 1, 2*nz, ierr)
+        ELSE
+          CALL put_field (ofile(which)%h, ofile(which)%v_fld(slot), rec, g, B, 2*nz, nz*(nout-1)+1, nz*nout, ierr)
+        END IF
+        deallocate ( B )
+        END SUBROUTINE wr3
+      END SUBROUTINE out_record
+
+      SUBROUTINE out_close ()
+      integer :: w, r
+      DO w=1,2
+        IF (ofile(w)%h.ge.0.and.master()) r=nc3_close(ofile(w)%h)
+        ofile(w)%h=-1
+        ofile(w)%nrec=0
+      END DO
+      ntstart_run=1
+      restarted=.FALSE.
+      END SUBROUTINE out_close
+!
+!-----------------------------------------------------------------------
+!  output.F for the step about to be taken (iic): a history record when MOD(iic-1,nHIS) = 0 (not the first
+!  step of a restarted run, :194-223), a restart record when iic > ntstart and MOD(iic-1,nRST) = 0 (:700-702).
+!-----------------------------------------------------------------------
+!
+      SUBROUTINE output (ierr)
+      integer, intent(out) :: ierr
+      integer :: iic
+      ierr=roms_hip_get_stepping(ctx, step)
+      IF (ierr.ne.0) RETURN
+      iic=step%iic
+      IF (nHIS.gt.0) THEN
+        IF (MOD(iic-1,nHIS).eq.0.and..not.(restarted.and.iic.eq.ntstart_run)) CALL out_record (fHIS, ierr)
+        IF (ierr.ne.0) RETURN
+      END IF
+      IF (nRST.gt.0) THEN
+        IF (iic.gt.ntstart_run.and.MOD(iic-1,nRST).eq.0) CALL out_record (fRST, ierr)
+      END IF
+      END SUBROUTINE output
+!
+!  nsteps passes of main3d with the output calls of main3d.F:591 in between; final: also the records of
+!  the step that is not taken (iic = ntend+1, main3d.F:595).  mode 0: fused roms_hip_main3d, 1: kernel by kernel.
+!
+      SUBROUTINE advance (nsteps, mode, final, ierr)
+      integer, intent(in) :: nsteps, mode
+      logical, intent(in) :: final
+      integer, intent(out) :: ierr
+      integer :: done, chunk, iic, nxt
+      ierr=0
+      done=0
+      DO WHILE (done.lt.nsteps.and.ierr.eq.0)
+        CALL output (ierr)
+        IF (ierr.ne.0) EXIT
+        iic=step%iic
+!  steps until the next output point
+        chunk=nsteps-done
+        IF (nHIS.gt.0) THEN
+          nxt=nHIS-MOD(iic-1,nHIS)
+          chunk=MIN(chunk,nxt)
+        END IF
+        IF (nRST.gt.0) THEN
+          nxt=nRST-MOD(iic-1,nRST)
+          chunk=MIN(chunk,nxt)
+        END IF
+        IF (mode.eq.0) THEN
+          ierr=roms_hip_main3d(ctx, chunk)
+        ELSE
+          CALL main3d_kernels (chunk, ierr)
+        END IF
+        done=done+chunk
+      END DO
+      IF (final.and.ierr.eq.0) CALL output (ierr)
+      END SUBROUTINE advance
+!
+!-----------------------------------------------------------------------
+!  get_state.F + the restart branch of initial.F: record `rec` (1-based; <= 0: the latest) of a restart file
+!  into the device state.  Every rank reads the file and uploads its own window.
+!-----------------------------------------------------------------------
+!
+      SUBROUTINE get_state (path, rec_in, ierr)
+      character(len=*), intent(in) :: path
+      integer, intent(in) :: rec_in
+      integer, intent(out) :: ierr
+      integer(c_int) :: h, vid
+      integer(c_long) :: nrec, n1
+      integer :: rec, k, itrc, latest
+      integer(c_int) :: iv(1)
+      real(r8) :: tv(1), tbest
+      real(r8), allocatable :: A(:,:,:), T(:,:,:)
+      logical :: lmd
+      ierr=0
+      lmd=IAND(options,ROMS_LMD_MIXING).ne.0
+      IF (nc3_open(cs(path), 0_c_int, h).ne.0) THEN
+        ierr=2
+        host_message='cannot open restart file '//TRIM(path)
+        RETURN
+      END IF
+      IF (nc3_inq_nrec(h, nrec).ne.0.or.nrec.lt.1) ierr=2
+      IF (ierr.eq.0) THEN
+        IF (nc3_inq_dimlen(h, cs('xi_rho'), n1).ne.0.or.n1.ne.Lm+2) ierr=5
+        IF (nc3_inq_dimlen(h, cs('eta_rho'), n1).ne.0.or.n1.ne.Mm+2) ierr=5
+        IF (nc3_inq_dimlen(h, cs('s_rho'), n1).ne.0.or.n1.ne.N) ierr=5
+        IF (ierr.ne.0) host_message='restart file '//TRIM(path)//' has other dimensions than this run'
+      END IF
+      IF (ierr.ne.0) THEN
+        k=nc3_close(h)
+        IF (LEN_TRIM(host_message).eq.0) host_message='restart file '//TRIM(path)//' holds no record'
+        RETURN
+      END IF
+!  NRREC < 0: the record with the latest time (get_state.F "latest"); else the record asked for
+      rec=rec_in
+      IF (nc3_inq_varid(h, cs('ocean_time'), vid).ne.0) ierr=2
+      IF (rec.le.0.and.ierr.eq.0) THEN
+        latest=1; tbest=-HUGE(1.0_r8)
+        DO k=1,INT(nrec)
+          IF (nc3_get_var_double(h, vid, INT(k-1,c_long), tv, 1_c_long_long).ne.0) ierr=2
+          IF (tv(1).gt.tbest) THEN
+            tbest=tv(1); latest=k
+          END IF
+        END DO
+        rec=latest
+      END IF
+      IF (rec.gt.nrec) THEN
+        ierr=2
+        host_message='restart record beyond the end of '//TRIM(path)
+      END IF
+      IF (ierr.ne.0) THEN
+        k=nc3_close(h)
+        RETURN
+      END IF
+      IF (nc3_get_var_double(h, vid, INT(rec-1,c_long), tv, 1_c_long_long).ne.0) ierr=2
+      ierr=MAX(ierr, roms_hip_get_stepping(ctx, step))
+      step%time=tv(1)
+      step%iic=NINT((step%time-dstart*86400.0_dp)/dt)+1      ! initial.F:172  ntstart
+      CALL geti ('kstp', step%kstp); CALL geti ('krhs', step%krhs); CALL geti ('knew', step%knew)
+      CALL geti ('indx1', step%indx1)
+      step%iif=1
+      step%predictor=0
+      step%nstp=1+MOD(step%iic-1,2)
+      step%nnew=3-step%nstp
+      step%nrhs=step%nstp
+!  2-D fields (three / two time levels)
+      allocate ( A(LBi:UBi,LBj:UBj,3) )
+      CALL rd ('zeta', gR2, 3, A); CALL up ('zeta', A, 3, ierr)
+!  Zt_avg1 = zeta(kstp): set_zeta_timeavg, ini_fields.F:1045-1051
+      IF (ierr.eq.0) CALL up ('Zt_avg1', A(:,:,step%kstp:step%kstp), 1, ierr)
+      CALL rd ('ubar', gU2, 3, A); CALL up ('ubar', A, 3, ierr)
+      CALL rd ('vbar', gV2, 3, A); CALL up ('vbar', A, 3, ierr)
+      CALL rd ('rzeta', gR2, 2, A(:,:,1:2)); CALL up ('rzeta', A(:,:,1:2), 2, ierr)
+      CALL rd ('rubar', gU2, 2, A(:,:,1:2)); CALL up ('rubar', A(:,:,1:2), 2, ierr)
+      CALL rd ('rvbar', gV2, 2, A(:,:,1:2)); CALL up ('rvbar', A(:,:,1:2), 2, ierr)
+      deallocate ( A )
+      allocate ( A(LBi:UBi,LBj:UBj,2*N) )
+      CALL rd ('u', gU3, 2*N, A); CALL up ('u', A, 2*N, ierr)
+      CALL rd ('v', gV3, 2*N, A); CALL up ('v', A, 2*N, ierr)
+      deallocate ( A )
+      allocate ( A(LBi:UBi,LBj:UBj,2*(N+1)) )
+      CALL rd ('ru', gUW, 2*(N+1), A); CALL up ('ru', A, 2*(N+1), ierr)
+      CALL rd ('rv', gVW, 2*(N+1), A); CALL up ('rv', A, 2*(N+1), ierr)
+      deallocate ( A )
+!  tracers: levels 1:2 from the file, level 3 is work space of the predictor (pre_step3d.F)
+      allocate ( T(LBi:UBi,LBj:UBj,3*N*NT), A(LBi:UBi,LBj:UBj,2*N) )
+      T=0.0_r8
+      DO itrc=1,MIN(NT,2)
+        CALL rd (MERGE('temp','salt',itrc.eq.1), gR3, 2*N, A)
+        T(:,:,3*N*(itrc-1)+1:3*N*(itrc-1)+2*N)=A
+        T(:,:,3*N*(itrc-1)+2*N+1:3*N*itrc)=A(:,:,1:N)
+      END DO
+      CALL up ('t', T, 3*N*NT, ierr)
+      deallocate ( T, A )
+      allocate ( A(LBi:UBi,LBj:UBj,N+1) )
+      CALL rd ('AKv', gW3, N+1, A); CALL up ('Akv', A, N+1, ierr)
+      deallocate ( A )
+      allocate ( A(LBi:UBi,LBj:UBj,(N+1)*NAT) )
+      CALL rd ('AKt', gW3, N+1, A(:,:,1:N+1))
+      IF (NAT.ge.2) CALL rd ('AKs', gW3, N+1, A(:,:,N+2:2*(N+1)))
+      CALL up ('Akt', A, (N+1)*NAT, ierr)
+      deallocate ( A )
+      IF (lmd) THEN
+        allocate ( A(LBi:UBi,LBj:UBj,1) )
+        CALL rd ('Hsbl', gR2, 1, A); CALL up ('hsbl', A, 1, ierr)
+        deallocate ( A )
+      END IF
+      k=nc3_close(h)
+      IF (ierr.ne.0) THEN
+        IF (LEN_TRIM(host_message).eq.0) host_message='error while reading restart file '//TRIM(path)
+        RETURN
+      END IF
+!  initial.F:549-577 for a restart: depths from Zt_avg1, then the derived fields of the first step
+      ntstart_run=step%iic
+      restarted=.TRUE.
+      ierr=roms_hip_set_stepping(ctx, step)
+      IF (ierr.eq.0) ierr=roms_hip_set_depth(ctx)
+      IF (ierr.eq.0) ierr=roms_hip_set_massflux(ctx)
+      IF (ierr.eq.0) ierr=roms_hip_omega(ctx)
+      IF (ierr.eq.0) ierr=roms_hip_rho_eos(ctx)
+
+      CONTAINS
+        SUBROUTINE geti (name, v)
+        character(len=*), intent(in) :: name
+        integer(c_int), intent(inout) :: v
+        integer(c_int) :: id
+        IF (nc3_inq_varid(h, cs(name), id).ne.0) RETURN      ! (indx1 is absent from a reference-written file)
+        IF (nc3_get_var_int(h, id, INT(rec-1,c_long), iv, 1_c_long_long).eq.0) v=iv(1)
+        END SUBROUTINE geti
+!  nf_fread2d/3d/4d + the exchange that follows them in get_state.F: the record's slab into the IOBOUNDS
+!  window of B, then the periodic ghost points beyond it
+        SUBROUTINE rd (name, g, np, B)
+        character(len=*), intent(in) :: name
+        integer, intent(in) :: g, np
+        real(r8), intent(out) :: B(LBi:UBi,LBj:UBj,np)
+        real(r8), allocatable :: buf(:,:,:)
+        integer(c_int) :: id
+        integer :: i0, i1, j0, j1, kk
+        character(len=1) :: gt
+        B=0.0_r8
+        IF (ierr.ne.0) RETURN
+        IF (nc3_inq_varid(h, cs(name), id).ne.0) THEN
+          ierr=2
+          host_message='restart file '//TRIM(path)//' lacks '//TRIM(name)
+          RETURN
+        END IF
+        CALL io_range (g, i0, i1, j0, j1)
+        allocate ( buf(i0:i1,j0:j1,np) )
+        IF (nc3_get_var_double(h, id, INT(rec-1,c_long), buf, SIZE(buf,KIND=c_long_long)).ne.0) THEN
+          ierr=2
+          host_message='restart file '//TRIM(path)//': cannot read '//TRIM(name)
+        ELSE
+          B(i0:i1,j0:j1,:)=buf
+          gt='r'
+          IF (g.eq.gU2.or.g.eq.gU3.or.g.eq.gUW) gt='u'
+          IF (g.eq.gV2.or.g.eq.gV3.or.g.eq.gVW) gt='v'
+          DO kk=1,np
+            CALL exchange2d (B(:,:,kk), gt)
+          END DO
+        END IF
+        deallocate ( buf )
+        END SUBROUTINE rd
+      END SUBROUTINE get_state
+
+      END MODULE roms_output

@@ -44,6 +44,14 @@ def load(path=None):
         lib.roms_host_set_header.restype = None
         lib.roms_host_last_error.argtypes = [C.c_char_p, C.c_int]
         lib.roms_host_last_error.restype = None
+        lib.roms_host_write.argtypes = [C.c_int]
+        lib.roms_host_advance.argtypes = [C.c_int, C.c_int, C.c_int]
+        lib.roms_host_get_state.argtypes = [C.c_char_p, C.c_int]
+        lib.roms_host_close_output.restype = None
+        lib.roms_host_set_gather.argtypes = [C.c_void_p]
+        lib.roms_host_set_gather.restype = None
+        lib.roms_host_output_config.argtypes = [C.POINTER(C.c_int), C.c_char_p]
+        lib.roms_host_output_config.restype = None
         _libs[path] = lib
     return _libs[path]
 
@@ -80,6 +88,18 @@ def write_roms_in(path, p):
         f"       TCOEF == {d(p['Tcoef'])}", f"       SCOEF == {d(p['Scoef'])}",
         f"      GAMMA2 == {d(p['gamma2'])}",
     ]
+    # output (optional keys): NRREC, NRST, NHIS, LcycleRST, file names, Hout switches by their roms.in ids
+    for key in ("NRREC", "NRST", "NHIS"):
+        if key in p:
+            lines.append(f"{key:>12} == {int(p[key])}")
+    if "LcycleRST" in p:
+        lines.append(f"   LcycleRST == {'T' if p['LcycleRST'] else 'F'}")
+    for key in ("ININAME", "RSTNAME", "HISNAME"):
+        if key in p:
+            lines.append(f"{key:>12} == {p[key]}")
+    for vid, val in p.get("Hout", {}).items():
+        val = val if isinstance(val, (tuple, list)) else (val,)
+        lines.append(f"Hout({vid}) == " + " ".join("T" if x else "F" for x in val))
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
 
@@ -170,6 +190,43 @@ class Host:
         r = self.lib.roms_host_run(nsteps, 1 if kernels else 0)
         if r != 0:
             self._fail("roms_host_run", r)
+
+    # ---- output and restart (roms_amd/host/roms_output.f90: wrt_his, wrt_rst, get_state of the reference)
+    def output_config(self):
+        """nrrec, nRST, nHIS, LcycleRST and the ININAME / RSTNAME / HISNAME of roms.in"""
+        ints = (C.c_int * 4)()
+        names = C.create_string_buffer(3 * 256)
+        self.lib.roms_host_output_config(ints, names)
+        raw = names.raw
+        ini, rst, his = [raw[k * 256:(k + 1) * 256].split(b"\0")[0].decode() for k in range(3)]
+        return dict(nrrec=ints[0], nRST=ints[1], nHIS=ints[2], LcycleRST=bool(ints[3]), ininame=ini, rstname=rst,
+                    hisname=his)
+
+    def _out(self, what, r):
+        if r != 0:
+            msg = self.last_error()
+            if r in (2, 3, 5) and msg:
+                raise HostError(r, msg)
+            self._fail(what, r)
+
+    def write_his(self):
+        """one history record of the state between two steps (wrt_his at main3d.F:591 of the coming step)"""
+        self._out("roms_host_write", self.lib.roms_host_write(1))
+
+    def write_rst(self):
+        """one restart record (wrt_rst, PERFECT_RESTART form)"""
+        self._out("roms_host_write", self.lib.roms_host_write(2))
+
+    def advance(self, nsteps, kernels=False, final=False):
+        """nsteps steps with the history / restart records NHIS and NRST ask for (output.F)"""
+        self._out("roms_host_advance", self.lib.roms_host_advance(nsteps, 1 if kernels else 0, 1 if final else 0))
+
+    def get_state(self, path="", rec=0):
+        """restart from record rec (1-based; <= 0: the latest) of a restart file (default: ININAME)"""
+        self._out("roms_host_get_state", self.lib.roms_host_get_state(path.encode(), rec))
+
+    def close_output(self):
+        self.lib.roms_host_close_output()
 
     def finalize(self):
         self.lib.roms_host_finalize()

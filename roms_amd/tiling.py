@@ -189,5 +189,43 @@ class TiledRun:
             G = T.cpu().numpy()
         return G
 
+    # ---- output: every rank calls the writer, rank 0 writes (wrt_his / wrt_rst over mp_gather2d/3d)
+    def _install_gather(self):
+        if getattr(self, "_gather_cb", None) is not None or self.world == 1:
+            return
+        GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_long)
+
+        def cb(name, buf, n):
+            try:
+                G = self.gather(name.decode())
+                if self.rank == 0:
+                    if G.size != n:
+                        return 8
+                    np.ctypeslib.as_array(buf, shape=(n,))[:] = G.ravel()
+                return 0
+            except Exception:
+                traceback.print_exc()
+                return 2
+
+        self._gather_cb = GATHER_FN(cb)
+        self.host.lib.roms_host_set_gather(C.cast(self._gather_cb, C.c_void_p))
+
+    def write_his(self):
+        self._install_gather()
+        self.host.write_his()
+
+    def write_rst(self):
+        self._install_gather()
+        self.host.write_rst()
+
+    def advance(self, nsteps, final=False):
+        """nsteps steps with the history / restart records NHIS and NRST of the case ask for"""
+        self._install_gather()
+        self.host.advance(nsteps, final=final)
+
+    def get_state(self, path="", rec=0):
+        """restart every tile from a restart file (each rank reads it and uploads its window)"""
+        self.host.get_state(path, rec)
+
     def close(self):
         self.host.finalize()

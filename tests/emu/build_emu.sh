@@ -27,12 +27,17 @@ echo "built $OUT"
 FOBJ=$HERE/obj_f
 mkdir -p $FOBJ
 HOSTSRC=$HERE/../../roms_amd/host
-for f in roms_hip_mod roms_host roms_host_api; do
-  if [ ! -f $FOBJ/$f.o ] || [ $HOSTSRC/$f.f90 -nt $FOBJ/$f.o ]; then
+if [ ! -f $FOBJ/nc3.o ] || [ $HOSTSRC/nc3.c -nt $FOBJ/nc3.o ]; then
+  gcc -O2 -fPIC -D_FILE_OFFSET_BITS=64 -Wall -c $HOSTSRC/nc3.c -o $FOBJ/nc3.o
+fi
+rebuild=""
+for f in roms_hip_mod roms_host roms_output roms_host_api; do
+  if [ -n "$rebuild" ] || [ ! -f $FOBJ/$f.o ] || [ $HOSTSRC/$f.f90 -nt $FOBJ/$f.o ]; then
     /opt/rocm/bin/amdflang -O2 -fPIC -ffp-contract=off -module-dir $FOBJ -c $HOSTSRC/$f.f90 -o $FOBJ/$f.o
+    rebuild=1
   fi
 done
-/opt/rocm/bin/amdflang -shared -o $HERE/libroms_host_emu.so $FOBJ/roms_hip_mod.o $FOBJ/roms_host.o $FOBJ/roms_host_api.o \
+/opt/rocm/bin/amdflang -shared -o $HERE/libroms_host_emu.so $FOBJ/roms_hip_mod.o $FOBJ/roms_host.o $FOBJ/nc3.o $FOBJ/roms_output.o $FOBJ/roms_host_api.o \
   -L$HERE -lroms_hip_emu -Wl,-rpath,'$ORIGIN'
 echo "built $HERE/libroms_host_emu.so"
 

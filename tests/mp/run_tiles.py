@@ -21,6 +21,7 @@ def main():
     from tests import util
     cs = util.case_for(spec["tag"], **spec.get("kw", {}))
     cs["ninfo"] = 0
+    cs.update(spec.get("case_update", {}))        # output keywords (NHIS, HISNAME, Hout ...), tests/test_output.py
     emu = os.path.join(ROOT, "tests", "emu")
     if spec.get("gpu"):      # real HIP build, all ranks on cuda:0, strips staged through the host
         run = tiling.TiledRun(cs, rank=rank, world=world, device=0, dist=dist, transport="dist_staged", weak=False,
@@ -29,7 +30,13 @@ def main():
         run = tiling.TiledRun(cs, rank=rank, world=world, dist=dist, transport="dist", weak=False,
                               tiles=tuple(spec["tiles"]), host_lib=os.path.join(emu, "libroms_host_emu.so"),
                               hip_lib=os.path.join(emu, "libroms_hip_emu.so"))
-    run.step(spec["steps"], kernels=spec.get("kernels", False))
+    if spec.get("restart_from"):                   # every rank reads the restart file and uploads its window
+        run.get_state(spec["restart_from"], 0)
+    if spec.get("advance"):                        # steps with the history / restart records of output.F
+        run.advance(spec["steps"], final=True)
+        run.host.close_output()
+    else:
+        run.step(spec["steps"], kernels=spec.get("kernels", False))
     res = {n: run.gather(n) for n in spec["fields"]}
     d = run.diag()
     nx = run.ctx.L.roms_hip_exchange_count(run.ctx.h)

@@ -148,7 +148,6 @@ def test_reader_accepts_the_reference_spellings(tmp_path):
     (dict(h1="MPDATA"), "MPDATA must be chosen for both"),
     (dict(extra="LuvSrc == T"), "LuvSrc == T"),
     (dict(extra="Vstretching == 2"), "Vstretching"),
-    (dict(extra="NRREC == -1"), "NRREC"),
     (dict(extra="Ngrids = 2"), "Ngrids"),
 ])
 def test_reader_stops_on_settings_it_cannot_honour(tmp_path, kw, needle):
@@ -157,6 +156,18 @@ def test_reader_stops_on_settings_it_cannot_honour(tmp_path, kw, needle):
     with pytest.raises(hostlib.HostError) as e:
         _setup(tmp_path, **kw).finalize()
     assert e.value.exit_flag == 5 and needle in str(e.value), str(e.value)
+
+
+def test_reader_takes_the_output_keywords(tmp_path):
+    """NRREC, NRST, NHIS, LcycleRST, the file names and the Hout switches (read_phypar.F) reach the output module."""
+    H = _setup(tmp_path, extra="NRREC == -1\n NRST == 288\n NHIS == 72\n LcycleRST == F\n"
+                               " RSTNAME == out/my_rst.nc\n HISNAME == my_his.nc\n ININAME == in/roms_ini.nc")
+    try:
+        c = H.output_config()
+        assert c == dict(nrrec=-1, nRST=288, nHIS=72, LcycleRST=False, ininame="in/roms_ini.nc",
+                         rstname="out/my_rst.nc", hisname="my_his.nc")
+    finally:
+        H.finalize()
 
 
 def test_application_header_is_read_like_cpp_would(tmp_path):

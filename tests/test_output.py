@@ -1,0 +1,296 @@
+"""History and restart files (roms_amd/host/roms_output.f90 + nc3.c): the files are NetCDF-3
+64-bit-offset files any reader opens (scipy.io.netcdf_file here: an implementation independent of nc3.c), they carry the
+reference's dimensions, variable names, dimension order and attributes (checked against the reference's own CDL template
+where /root/reference exists), the records hold the fields of the output point of main3d.F:591, a restarted run continues
+BIT FOR BIT, and a multi-tile run writes the file a single tile writes.  CPU: the emulated kernels; -m gpu: libroms_hip.so."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from scipy.io import netcdf_file
+
+from tests import util
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+EMU = os.path.join(ROOT, "tests", "emu")
+HOUT = {"idFsur": True, "idUbar": True, "idVbar": True, "idUvel": True, "idVvel": True, "idWvel": True, "idOvel": True,
+        "idTvar": (True, True), "idDano": True}
+LIBS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def _libs(which):
+    if which == "hip":
+        return None, None
+    if not (os.path.exists(os.path.join(EMU, "libroms_host_emu.so")) and os.path.exists(util.EMU_LIB)):
+        subprocess.check_call(["bash", os.path.join(EMU, "build_emu.sh")])
+    return os.path.join(EMU, "libroms_host_emu.so"), util.EMU_LIB
+
+
+def _host(cs, which):
+    from roms_amd import hostlib
+    hl, kl = _libs(which)
+    H = hostlib.Host(params=cs, lib_path=hl, hip_lib_path=kl)
+    return H, H.device_init(0)
+
+
+def _nc(path):
+    f = netcdf_file(path, "r", mmap=False)
+    return f
+
+
+@pytest.mark.parametrize("which", LIBS)
+def test_history_file_layout_and_content(which, tmp_path):
+    """NHIS = 2 over 6 steps and one explicit record: records at steps 0, 2, 4, 6; dimensions, variables, attributes as
+    def_his.F/def_var.F write them; each record holds the state between steps as seen at main3d.F:591."""
+    cs = util.case_for("upwelling_small")
+    his = str(tmp_path / "roms_his.nc")
+    cs.update(NHIS=2, NRST=0, HISNAME=his, Hout=HOUT, ninfo=0)
+    H, ctx = _host(cs, which)
+    H.advance(6, final=False)
+    # the record written next: compare with the device state at its output point
+    H.write_his()
+    st = ctx.get_stepping()
+    t = H.tile
+    ni, nj = t["UBi"] - t["LBi"] + 1, t["UBj"] - t["LBj"] + 1
+    Lm, Mm, N = cs["Lm"], cs["Mm"], cs["N"]
+    dev = {n: ctx.download(n).reshape(-1, nj, ni) for n in ("zeta", "ubar", "u", "t", "rho", "W", "w_out", "pm", "pn")}
+    H.close_output()
+    H.finalize()
+    f = _nc(his)
+    assert f.version_byte == 2                                       # 64-bit offset, as netcdf_create's CMODE
+    assert f.dimensions == {"xi_rho": Lm + 2, "xi_u": Lm + 1, "xi_v": Lm + 2, "xi_psi": Lm + 1, "eta_rho": Mm + 2,
+                            "eta_u": Mm + 2, "eta_v": Mm + 1, "eta_psi": Mm + 1, "N": N, "s_rho": N, "s_w": N + 1,
+                            "tracer": 2, "boundary": 4, "ocean_time": None}
+    assert f.type == b"ROMS history file" and f.format == b"netCDF-3 64bit offset file"
+    V = f.variables
+    assert list(V["ocean_time"][:]) == [0.0, 600.0, 1200.0, 1800.0]       # steps 0, 2, 4 by advance + the explicit record
+    dims = {"zeta": ("ocean_time", "eta_rho", "xi_rho"), "ubar": ("ocean_time", "eta_u", "xi_u"),
+            "vbar": ("ocean_time", "eta_v", "xi_v"), "u": ("ocean_time", "s_rho", "eta_u", "xi_u"),
+            "v": ("ocean_time", "s_rho", "eta_v", "xi_v"), "w": ("ocean_time", "s_w", "eta_rho", "xi_rho"),
+            "omega": ("ocean_time", "s_w", "eta_rho", "xi_rho"), "temp": ("ocean_time", "s_rho", "eta_rho", "xi_rho"),
+            "salt": ("ocean_time", "s_rho", "eta_rho", "xi_rho"), "rho": ("ocean_time", "s_rho", "eta_rho", "xi_rho"),
+            "h": ("eta_rho", "xi_rho"), "s_rho": ("s_rho",), "Cs_w": ("s_w",)}
+    for n, d in dims.items():
+        assert V[n].dimensions == d, n
+    # attributes in def_var.F's order; "nondimensional" units are not written (def_var.F:418)
+    assert list(V["u"]._attributes) == ["standard_name", "long_name", "units", "time", "grid", "location", "coordinates", "field"]
+    assert V["u"].long_name == b"u-momentum component" and V["u"].units == b"meter second-1"
+    assert V["u"].coordinates == b"x_u y_u s_rho ocean_time" and V["u"].location == b"edge1"
+    assert V["w"].coordinates == b"x_rho y_rho s_w ocean_time" and V["zeta"].field == b"free-surface"
+    assert not hasattr(V["salt"], "units") and V["temp"].units == b"Celsius"
+    assert V["ocean_time"].long_name == b"time since initialization"
+    # content of the last record: KOUT = kstp, NOUT = nrhs, IOBOUNDS windows, omega scaled by pm*pn
+    jr, ir = slice(0 - t["LBj"], Mm + 2 - t["LBj"]), slice(0 - t["LBi"], Lm + 2 - t["LBi"])
+    iu = slice(1 - t["LBi"], Lm + 2 - t["LBi"])
+    assert np.array_equal(V["zeta"][-1], dev["zeta"][st.kstp - 1][jr, ir])
+    assert np.array_equal(V["ubar"][-1], dev["ubar"][st.kstp - 1][jr, iu])
+    assert np.array_equal(V["u"][-1], dev["u"][(st.nrhs - 1) * N:st.nrhs * N][:, jr, iu])
+    assert np.array_equal(V["temp"][-1], dev["t"][(st.nrhs - 1) * N:st.nrhs * N][:, jr, ir])
+    assert np.array_equal(V["salt"][-1], dev["t"][3 * N + (st.nrhs - 1) * N:3 * N + st.nrhs * N][:, jr, ir])
+    assert np.array_equal(V["rho"][-1], dev["rho"][:, jr, ir])
+    assert np.array_equal(V["w"][-1], dev["w_out"][:, jr, ir])
+    assert np.array_equal(V["omega"][-1], (dev["W"] * dev["pm"] * dev["pn"])[:, jr, ir])
+    assert np.abs(V["w"][-1]).max() > 0.0 and np.abs(V["u"][-1]).max() > 0.0
+    assert V["theta_s"][()] == cs["theta_s"] and V["ntimes"][()] == cs.get("ntimes", 10) and V["nHIS"][()] == 2
+    f.close()
+
+
+def _final_state(ctx, names):
+    out = {}
+    for n in names:
+        out[n] = ctx.download(n).copy()
+    return out
+
+
+@pytest.mark.parametrize("which", LIBS)
+@pytest.mark.parametrize("tag,kw,n1", [("upwelling_small", {}, 4), ("upwelling_small", {}, 5), ("benchmark_small", {}, 5),
+                                       ("upwelling_kpp_small", {}, 4)])
+def test_restart_continues_bit_for_bit(which, tag, kw, n1, tmp_path):
+    """n1 + 3 steps in one go == n1 steps, a restart record, a NEW context restarted from the file, 3 more steps: every
+    prognostic array bit for bit (an even and an odd step count: both parities of the time indices; ANA_VMIX, KPP +
+    bulk fluxes + nonlinear EOS, KPP + MPDATA).  LcycleRST: the second of two records is the one picked (latest time)."""
+    main = ["zeta", "ubar", "vbar", "u", "v", "t"]
+    more = ["Hz", "z_r", "z_w", "Huon", "Hvom", "W", "rho", "Zt_avg1", "DU_avg1", "DV_avg1", "rufrc", "rvfrc", "Akv", "Akt"]
+    cs = util.case_for(tag, **kw)
+    rst = str(tmp_path / "roms_rst.nc")
+    cs.update(RSTNAME=rst, LcycleRST=True, ninfo=0)
+    H, ctx = _host(cs, which)
+    H.run(n1 + 3)
+    want = _final_state(ctx, main + more)
+    t = H.tile
+    H.finalize()
+    H, ctx = _host(cs, which)
+    H.run(n1 - 1)
+    H.write_rst()
+    H.run(1)
+    H.write_rst()
+    H.run(1)
+    H.write_rst()                                 # third record recycles slot 1: the latest is record 1 now
+    H.finalize()
+    f = _nc(rst)
+    assert f.variables["zeta"].dimensions == ("ocean_time", "three", "eta_rho", "xi_rho")
+    assert f.variables["ru"].dimensions == ("ocean_time", "two", "s_w", "eta_u", "xi_u")
+    assert f.variables["temp"].dimensions == ("ocean_time", "two", "s_rho", "eta_rho", "xi_rho")
+    times = list(f.variables["ocean_time"][:])
+    assert times == [(n1 + 1) * cs["dt"], n1 * cs["dt"]], times
+    assert f.type == b"ROMS restart file"
+    f.close()
+    H, ctx = _host(cs, which)
+    H.get_state(rst, 2)                           # the record of step n1 (explicitly; 0 would pick the later one)
+    assert ctx.get_stepping().iic == n1 + 1
+    H.run(3)
+    ni, nj = t["UBi"] - t["LBi"] + 1, t["UBj"] - t["LBj"] + 1
+    Lm, Mm = cs["Lm"], cs["Mm"]
+    for n in main + more:
+        a, b = want[n].reshape(-1, nj, ni), ctx.download(n).reshape(-1, nj, ni)
+        if n in main:
+            a, b = util.unpadded(a, cs, ni, nj), util.unpadded(b, cs, ni, nj)
+        else:       # arrays the model never exchanges keep set-up values in their ghost points: compare what it computes
+            a, b = [x[:, 1 - t["LBj"]:Mm + 1 - t["LBj"], 1 - t["LBi"]:Lm + 1 - t["LBi"]] for x in (a, b)]
+        assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+    H.get_state(rst, 0)                           # latest record = step n1+1
+    assert ctx.get_stepping().iic == n1 + 2
+    H.finalize()
+
+
+def test_restart_errors_are_reported(tmp_path):
+    from roms_amd import hostlib
+    cs = util.case_for("upwelling_small")
+    H, ctx = _host(cs, "emu")
+    with pytest.raises(hostlib.HostError) as e:
+        H.get_state(str(tmp_path / "missing.nc"), 0)
+    assert e.value.exit_flag == 2 and "cannot open" in str(e.value)
+    rst = str(tmp_path / "r.nc")
+    H.finalize()
+    cs2 = util.case_for("benchmark_small")
+    cs2.update(RSTNAME=rst)
+    H, ctx = _host(cs2, "emu")
+    H.run(1)
+    H.write_rst()
+    H.finalize()
+    H, ctx = _host(cs, "emu")                     # other grid than the file's
+    with pytest.raises(hostlib.HostError) as e:
+        H.get_state(rst, 0)
+    assert e.value.exit_flag == 5 and "other dimensions" in str(e.value)
+    H.finalize()
+
+
+def _run_tiles(tmp_path, spec, tiles, port):
+    out = str(tmp_path / f"tiles_{port}.npz")
+    spec = dict(spec, tiles=list(tiles))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={tiles[0] * tiles[1]}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "mp", "run_tiles.py"),
+           out, json.dumps(spec)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    return dict(np.load(out))
+
+
+def test_tiles_write_the_file_a_single_tile_writes_and_restart_from_it(tmp_path):
+    """2x2 ranks (gloo): every rank calls the writer, rank 0 gathers and writes (wrt_his over mp_gather): every variable
+    of the history and restart files equals the single-tile run's; then the four tiles restart from the SINGLE-tile
+    restart file (record of step 3), each uploading its window, and 2 steps later hold the single-tile run's state of
+    step 5 bit for bit."""
+    _libs("emu")
+    fields = ["zeta", "ubar", "vbar", "u", "v", "t"]
+    upd1 = dict(NHIS=2, NRST=3, HISNAME=str(tmp_path / "his1.nc"), RSTNAME=str(tmp_path / "rst1.nc"), Hout=HOUT, LcycleRST=False)
+    cs = util.case_for("benchmark_small")
+    cs.update(upd1, ninfo=0)
+    H, ctx = _host(cs, "emu")
+    H.advance(5, final=True)                                      # restart record at step 3 (iic = 4)
+    H.close_output()
+    want = {n: ctx.download(n).copy() for n in fields}            # (single-tile array layout = the gathered layout)
+    H.finalize()
+    upd4 = dict(upd1, HISNAME=str(tmp_path / "his4.nc"), RSTNAME=str(tmp_path / "rst4.nc"))
+    _run_tiles(tmp_path, dict(tag="benchmark_small", steps=5, fields=fields, case_update=upd4, advance=True), (2, 2), 29631)
+    for one, four in (("his1.nc", "his4.nc"), ("rst1.nc", "rst4.nc")):
+        a, b = _nc(str(tmp_path / one)), _nc(str(tmp_path / four))
+        assert list(a.variables) == list(b.variables)
+        for n in a.variables:
+            assert a.variables[n].dimensions == b.variables[n].dimensions, n
+            assert np.array_equal(a.variables[n][...], b.variables[n][...]), (one, n)
+        assert a.tiling == b"001x001" and b.tiling == b"002x002"
+        a.close()
+        b.close()
+    got = _run_tiles(tmp_path, dict(tag="benchmark_small", steps=2, fields=fields, restart_from=upd1["RSTNAME"]), (2, 2), 29632)
+    for n in fields:
+        assert np.array_equal(got[n].ravel(), want[n].ravel()), n
+
+
+@pytest.mark.ref
+def test_names_dimensions_and_attributes_match_the_reference_cdl(tmp_path):
+    """The reference documents the layout of its initial/restart files in Data/ROMS/CDL/ini_hydro.cdl: every variable
+    of that template that these applications write has the same dimensions (order included), long_name and units
+    in our files (read in place from /root/reference; nothing is copied)."""
+    cdl = "/root/reference/Data/ROMS/CDL/ini_hydro.cdl"
+    if not os.path.exists(cdl):
+        pytest.skip("reference tree not present")
+    text = open(cdl).read()
+    ref = {}
+    for m in re.finditer(r"^\s*(int|double|float)\s+(\w+)(?:\(([^)]*)\))?\s*;", text, re.M):
+        ref[m.group(2)] = dict(dims=tuple(d.strip() for d in m.group(3).split(",")) if m.group(3) else (), att={})
+    for m in re.finditer(r"^\s*(\w+):(\w+)\s*=\s*\"([^\"]*)\"\s*;", text, re.M):
+        if m.group(1) in ref:
+            ref[m.group(1)]["att"][m.group(2)] = m.group(3)
+    cs = util.case_for("upwelling_small")
+    his = str(tmp_path / "his.nc")
+    cs.update(NHIS=1, HISNAME=his, Hout=HOUT, ninfo=0)
+    H, ctx = _host(cs, "emu")
+    H.write_his()
+    H.close_output()
+    H.finalize()
+    f = _nc(his)
+    checked = 0
+    for n in ("spherical", "Vtransform", "Vstretching", "theta_s", "theta_b", "Tcline", "hc", "s_rho", "s_w", "Cs_r", "Cs_w",
+              "h", "ocean_time", "zeta", "ubar", "vbar", "u", "v", "temp", "salt"):
+        assert n in ref and n in f.variables, n
+        v = f.variables[n]
+        assert v.dimensions == ref[n]["dims"], (n, v.dimensions, ref[n]["dims"])
+        assert v.long_name.decode() == ref[n]["att"]["long_name"], n
+        if "units" in ref[n]["att"] and n != "ocean_time":          # (the template's time units name its own reference date)
+            assert v.units.decode() == ref[n]["att"]["units"], n
+        if "time" in ref[n]["att"]:
+            assert v.time.decode() == ref[n]["att"]["time"], n
+        checked += 1
+    assert checked == 20
+    f.close()
+
+
+def test_roms_in_output_keywords_and_romsM_files(tmp_path):
+    """romsM reads NHIS, NRST, the file names and the Hout switches from roms.in, writes the records output.F asks
+    for, and NRREC = -1 restarts it from its own restart file to the same final state (history records compared)."""
+    _libs("emu")
+    from roms_amd import hostlib
+    exe = os.path.join(EMU, "romsM_emu")
+    cs = util.case_for("upwelling_small")
+    base = dict(NHIS=2, NRST=4, Hout=HOUT, LcycleRST=True, ninfo=2)
+
+    def run(name, ntimes, **extra):
+        p = dict(cs, ntimes=ntimes, HISNAME=str(tmp_path / f"{name}_his.nc"), RSTNAME=str(tmp_path / f"{name}_rst.nc"), **base)
+        p.update(extra)
+        inp = str(tmp_path / f"{name}.in")
+        hostlib.write_roms_in(inp, p)
+        r = subprocess.run([exe, inp], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+        assert r.returncode == 0 and "ROMS: DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        return r.stdout
+
+    run("a", 8)
+    fa = _nc(str(tmp_path / "a_his.nc"))
+    assert list(fa.variables["ocean_time"][:]) == [0.0, 600.0, 1200.0, 1800.0, 2400.0]
+    ra = _nc(str(tmp_path / "a_rst.nc"))
+    assert sorted(ra.variables["ocean_time"][:]) == [1200.0, 2400.0]             # steps 4 and 8
+    ra.close()
+    run("b", 4)                                                                    # 4 steps, restart record at step 4
+    out = run("c", 4, NRREC=-1, ININAME=str(tmp_path / "b_rst.nc"))                # ... and 4 more from it
+    assert "restarted at time-step 4" in out
+    fc = _nc(str(tmp_path / "c_his.nc"))
+    assert list(fc.variables["ocean_time"][:]) == [1800.0, 2400.0]                 # no record at the restart step itself
+    for n in ("zeta", "u", "v", "temp", "salt", "ubar", "vbar", "rho", "omega"):
+        assert np.array_equal(fc.variables[n][-1], fa.variables[n][-1]), n
+        assert np.array_equal(fc.variables[n][0], fa.variables[n][3]), n
+    fa.close()
+    fc.close()
