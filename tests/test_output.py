@@ -294,3 +294,24 @@ def test_roms_in_output_keywords_and_romsM_files(tmp_path):
         assert np.array_equal(fc.variables[n][0], fa.variables[n][3]), n
     fa.close()
     fc.close()
+
+
+@pytest.mark.parametrize("which", LIBS)
+def test_writing_records_does_not_change_the_run(which, tmp_path):
+    """roms_hip_output_point recomputes derived fields only: a run that writes a history and a restart record before
+    every step ends in the state -- and prints the diag numbers -- of a run that writes nothing."""
+    names = ["zeta", "ubar", "vbar", "u", "v", "t", "wvel", "W", "rho", "Akv", "Hz", "DU_avg1"]
+    cs = util.case_for("benchmark_small")
+    cs.update(ninfo=1)
+    H, ctx = _host(cs, which)
+    H.run(5)
+    want = _final_state(ctx, names)
+    dwant = ctx.last_diag()
+    H.finalize()
+    cs.update(NHIS=1, NRST=1, HISNAME=str(tmp_path / "h.nc"), RSTNAME=str(tmp_path / "r.nc"), Hout=HOUT)
+    H, ctx = _host(cs, which)
+    H.advance(5)
+    for n in names:
+        assert np.array_equal(ctx.download(n), want[n]), n
+    assert ctx.last_diag() == dwant
+    H.finalize()
