@@ -432,6 +432,16 @@ def main():
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_us": avg * 1e6, "launches": launches,
                         "algorithmic_bytes_per_launch": nb}
+            if dominant in table and table[dominant][1] > 0:
+                # the same kernel with nothing else on the chip (synchronous per-kernel pass before the timed
+                # region; each launch bracketed by two event markers, which add ~1 us to a 10 us kernel)
+                iso = table[dominant][0] / table[dominant][1]
+                roofline["isolated_launch_us"] = iso * 1e6
+                roofline["frac_isolated"] = nb / iso / 1e9 / HBM_PEAK_GBS
+                roofline["note"] = ("avg_launch_us is measured inside the timed region, where on grids below 128 K "
+                                    "columns the vertical-mixing / predictor kernels run beside the barotropic "
+                                    "loop on other streams (late-predictor schedule, DESIGN.md 4): the launches "
+                                    "that share the chip take 12-20 us, the step as a whole is 3-8 % shorter")
 
     copy_gbs = run.ctx.copy_probe() if (args.copy_probe or rank == 0) else None
     if roofline is not None:
