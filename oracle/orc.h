@@ -122,6 +122,7 @@ typedef struct orc_s {
   int *ksbl;
   /* diag results: avgke, avgpe, avgkp, volume, max_speed, Cu_max ... */
   double diag[16];
+  void *avg;                             /* time-averaged fields (orc_avg.c), NULL until orc_set_avg_window */
 } orc_t;
 
 /* ---- index helpers (valid inside functions that define LBi,LBj,ni,nij,N) ---- */
@@ -191,6 +192,13 @@ void orc_lmd_vmix(orc_t *o, int tile);
 void orc_bulk_flux(orc_t *o, int tile);
 void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta, double *Ua, double *Va,
                       double *Wa, const double *oHz);
+
+/* time averages: set_avg.F (orc_avg.c); fields "avg_zeta" ... "avg_HvomT" through orc_avg_field */
+void orc_set_avg_window(orc_t *o, int nAVG, int ntsAVG, int nrrec, int ntstart);
+void orc_set_avg(orc_t *o, int tile);
+double *orc_avg_field(orc_t *o, const char *name, long *nel);
+double orc_avg_time(const orc_t *o);
+void orc_avg_free(orc_t *o);
 
 /* one baroclinic step, main3d.F:216-1148 */
 int orc_main3d_step(orc_t *o);

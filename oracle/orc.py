@@ -123,6 +123,10 @@ class Oracle:
         for t in tiles:
             f(C.c_void_p(self.h), C.c_int(t), *[C.c_int(a) for a in args])
 
+    def set_avg_window(self, nAVG, ntsAVG=1, nrrec=0, ntstart=1):
+        """allocate the time-averaged fields ("avg_zeta" ... "avg_HvomT") and set the window of set_avg.F"""
+        self.L.orc_set_avg_window(C.c_void_p(self.h), int(nAVG), int(ntsAVG), int(nrrec), int(ntstart))
+
     def start(self):
         self.L.orc_start(self.h)
 

@@ -175,6 +175,7 @@ orc_t *orc_create(const orc_cfg *cfg) {
 void orc_destroy(orc_t *o) {
   if (!o) return;
   for (size_t k = 0; k < NFIELDS; k++) free(*(double **)((char *)o + fields[k].off));
+  orc_avg_free(o);
   free(o->ksbl);
   free(o->b);
   free(o);
@@ -186,8 +187,7 @@ double *orc_field(orc_t *o, const char *name, long *nel) {
       if (nel) *nel = (long)field_size(o, fields[k].kind);
       return *(double **)((char *)o + fields[k].off);
     }
-  if (nel) *nel = -1;
-  return NULL;
+  return orc_avg_field(o, name, nel);
 }
 
 orc_step *orc_stepping(orc_t *o) { return &o->s; }

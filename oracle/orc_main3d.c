@@ -155,6 +155,7 @@ int orc_main3d_step(orc_t *o) {
   else if (c->options & ORC_LMD_MIXING) { REV(o, orc_lmd_vmix(o, tile)); } /* :527 */
   REV(o, { orc_omega(o, tile); orc_wvelocity(o, tile, s->nstp); });     /* :534-535 */
   FWD(o, orc_set_zeta(o, tile));                                        /* :556 */
+  if (o->avg) { FWD(o, orc_set_avg(o, tile)); }                         /* :562 (AVERAGES) */
   REV(o, orc_rhs3d(o, tile));                                           /* :632 */
   /* barotropic loop :810-918 */
   for (int my_iif = 1; my_iif <= c->nfast + 1; my_iif++) {

@@ -45,6 +45,11 @@ if [ "$APP" = upwelling_kpp ]; then
   UP=UPWELLING; HDR=upwelling_kpp; HDRPATH="$HERE/upwelling_kpp.h"
   EXTRA=""
 fi
+if [ "$APP" = upwelling_avg ]; then
+  # the UPWELLING case with AVERAGES (oracle/ref/upwelling_avg.h): pins set_avg.F
+  UP=UPWELLING; HDR=upwelling_avg; HDRPATH="$HERE/upwelling_avg.h"
+  EXTRA=""
+fi
 WORK=$(mktemp -d /tmp/romsref_${APP}_XXXX)
 trap 'rm -rf "$WORK"' EXIT
 mkdir -p "$OUT"
@@ -73,7 +78,8 @@ FILES="mod_kinds mod_param mod_scalars mod_stepping mod_strings mod_iounits mod_
   bc_2d bc_3d zetabc u2dbc_im v2dbc_im t3dbc_im u3dbc_im v3dbc_im obc_volcons
   set_depth set_massflux rho_eos prsgrd t3dmix uv3dmix set_vbc set_zeta wvelocity diag ini_fields
   mod_sources uv_var_change step2d omega pre_step3d rhs3d step3d_uv step3d_t
-  mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix bulk_flux analytical"
+  mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix bulk_flux analytical
+  mod_average uv_rotate vorticity set_avg"
 TODO=""
 for m in $FILES; do
   src=""

@@ -40,6 +40,9 @@
       USE mod_mixing
       USE mod_boundary
       USE mod_clima
+#ifdef AVERAGES
+      USE mod_average
+#endif
       implicit none
       integer, parameter :: ng = 1
       CONTAINS
@@ -200,6 +203,22 @@
      &                    LBi, UBi, LBj, UBj, LBij, UBij)
       CALL allocate_mixing (ng, LBi, UBi, LBj, UBj)
       CALL allocate_ocean (ng, LBi, UBi, LBj, UBj)
+#ifdef AVERAGES
+!  the Aout switches of roms_upwelling.in (:786-899), then the arrays they ask for
+      Aout(idFsur,ng)=.TRUE.; Aout(idUbar,ng)=.TRUE.; Aout(idVbar,ng)=.TRUE.
+      Aout(idUvel,ng)=.TRUE.; Aout(idVvel,ng)=.TRUE.; Aout(idWvel,ng)=.TRUE.; Aout(idOvel,ng)=.TRUE.
+      Aout(idDano,ng)=.TRUE.
+      Aout(idHUav,ng)=.TRUE.; Aout(idHVav,ng)=.TRUE.; Aout(idUUav,ng)=.TRUE.; Aout(idUVav,ng)=.TRUE.
+      Aout(idVVav,ng)=.TRUE.; Aout(idU2av,ng)=.TRUE.; Aout(idV2av,ng)=.TRUE.; Aout(idZZav,ng)=.TRUE.
+      DO tile=1,NT(ng)
+        Aout(idTvar(tile),ng)=.TRUE.; Aout(idTTav(tile),ng)=.TRUE.; Aout(idUTav(tile),ng)=.TRUE.
+        Aout(idVTav(tile),ng)=.TRUE.; Aout(iHUTav(tile),ng)=.TRUE.; Aout(iHVTav(tile),ng)=.TRUE.
+      END DO
+      CALL allocate_average (ng, LBi, UBi, LBj, UBj)
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL initialize_average (ng, tile)
+      END DO
+#endif
       DO tile=first_tile(ng),last_tile(ng)
         CALL initialize_boundary (ng, tile, 0)
         CALL initialize_coupling (ng, tile, 0)
@@ -493,6 +512,14 @@
 !       9 PREDICTOR_2D_STEP
 !=======================================================================
 !
+      SUBROUTINE ref_set_avg_window (n_avg, nts_avg, nrrec_in, ntstart_in) bind(C, name="ref_set_avg_window")
+      integer(c_int), value :: n_avg, nts_avg, nrrec_in, ntstart_in
+      nAVG(ng)=n_avg
+      ntsAVG(ng)=nts_avg
+      nrrec(ng)=nrrec_in
+      ntstart(ng)=ntstart_in
+      END SUBROUTINE ref_set_avg_window
+
       SUBROUTINE ref_set_stepping (idx, tm) bind(C, name="ref_set_stepping")
       USE dateclock_mod,     ONLY : time_string
       integer(c_int), intent(in) :: idx(*)
@@ -542,6 +569,9 @@
 #ifdef BULK_FLUXES
       USE bulk_flux_mod,     ONLY : bulk_flux
 #endif
+#ifdef AVERAGES
+      USE set_avg_mod,       ONLY : set_avg
+#endif
       character(kind=c_char), intent(in) :: cname(*)
       integer(c_int) :: ierr
       character(len=32) :: name
@@ -554,6 +584,10 @@
       ierr=0
       DO tile=first_tile(ng),last_tile(ng)
         SELECT CASE (TRIM(name))
+#ifdef AVERAGES
+          CASE ('set_avg')
+            CALL set_avg (ng, tile)
+#endif
           CASE ('set_depth')
             CALL set_depth (ng, tile, iNLM)
           CASE ('set_massflux')
@@ -1015,6 +1049,30 @@
 #endif
 #ifdef SHORTWAVE
         F2('srflx',FORCES(ng)%srflx)
+#endif
+#ifdef AVERAGES
+        F2('avg_zeta',AVERAGE(ng)%avgzeta)
+        F2('avg_ubar',AVERAGE(ng)%avgu2d)
+        F2('avg_vbar',AVERAGE(ng)%avgv2d)
+        F2('avg_u',AVERAGE(ng)%avgu3d)
+        F2('avg_v',AVERAGE(ng)%avgv3d)
+        F2('avg_omega',AVERAGE(ng)%avgw3d)
+        F2('avg_w',AVERAGE(ng)%avgwvel)
+        F2('avg_rho',AVERAGE(ng)%avgrho)
+        F2('avg_t',AVERAGE(ng)%avgt)
+        F2('avg_ZZ',AVERAGE(ng)%avgZZ)
+        F2('avg_U2',AVERAGE(ng)%avgU2)
+        F2('avg_V2',AVERAGE(ng)%avgV2)
+        F2('avg_UU',AVERAGE(ng)%avgUU)
+        F2('avg_VV',AVERAGE(ng)%avgVV)
+        F2('avg_UV',AVERAGE(ng)%avgUV)
+        F2('avg_Huon',AVERAGE(ng)%avgHuon)
+        F2('avg_Hvom',AVERAGE(ng)%avgHvom)
+        F2('avg_TT',AVERAGE(ng)%avgTT)
+        F2('avg_UT',AVERAGE(ng)%avgUT)
+        F2('avg_VT',AVERAGE(ng)%avgVT)
+        F2('avg_HuonT',AVERAGE(ng)%avgHuonT)
+        F2('avg_HvomT',AVERAGE(ng)%avgHvomT)
 #endif
 #ifdef BULK_FLUXES
         F2('Uwind',FORCES(ng)%Uwind)

@@ -193,6 +193,60 @@ def mode_physics(tag, kw):
         print("PHYSICS-OK bitwise")
 
 
+AVG_FIELDS = ["avg_zeta", "avg_ubar", "avg_vbar", "avg_u", "avg_v", "avg_omega", "avg_w", "avg_rho", "avg_t", "avg_ZZ",
+              "avg_U2", "avg_V2", "avg_UU", "avg_VV", "avg_UV", "avg_Huon", "avg_Hvom", "avg_TT", "avg_UT", "avg_VT",
+              "avg_HuonT", "avg_HvomT"]
+
+
+def mode_avg(tag, kw):
+    """set_avg.F (the reference built with AVERAGES, oracle/ref/upwelling_avg.h) against orc_set_avg: both sides
+    step kernel by kernel in main3d's order with set_avg behind set_zeta (main3d.F:562); all 22 time-averaged
+    arrays after every call -- the set, accumulate and convert phases of several windows."""
+    nsteps, nAVG, ntsAVG = kw.pop("nsteps", 9), kw.pop("nAVG", 3), kw.pop("ntsAVG", 1)
+    app, cs = rd.make_case(tag, **kw)
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    O = rd.oracle_from(R, cs)
+    O.start()
+    R.L.ref_set_avg_window(nAVG, ntsAVG, 0, 1)
+    O.set_avg_window(nAVG, ntsAVG, 0, 1)
+    nfast = R.bounds(0)[58]
+    st = dict(iic=1, iif=1, nstp=1, nnew=1, nrhs=1, kstp=1, knew=1, krhs=1, predictor=0, indx1=1, time=0.0, nfast=nfast)
+    names = rd.shared_fields(R, O)
+    log, ncmp, nonzero = [], 0, 0
+    for step in range(1, nsteps + 1):
+        for kern, s_ in rd.main3d_sequence(cs, st, first=(step == 1)):
+            for k, v in s_.items():
+                if k != "nfast":
+                    setattr(O.step, k, v)
+            O.step.tdays = s_["time"] / 86400.0
+            rd.sync_stepping(R, O)
+            R.call(kern)
+            if kern == "wvelocity":
+                O.call(kern, None, s_["nstp"])
+            elif kern == "diag":
+                O.diag()
+            else:
+                O.call(kern)
+            if kern == "set_zeta":
+                R.call("set_avg")
+                O.call("set_avg")
+                bad = rd.mismatches(R, O, AVG_FIELDS)
+                ncmp += 1
+                nonzero += int(np.abs(O.field("avg_UV")).max() > 0.0)
+                if bad:
+                    log.append((step, bad[:6]))
+    bad_state = rd.mismatches(R, O, names)
+    rd.unquiet(saved)
+    print("steps", nsteps, "nAVG", nAVG, "ntsAVG", ntsAVG, "set_avg calls compared", ncmp, "with data", nonzero)
+    for e in log[:5]:
+        print("MISMATCH step", e)
+    if bad_state:
+        print("MISMATCH state", bad_state[:6])
+    if not log and not bad_state and nonzero >= nsteps - ntsAVG - 1:
+        print("AVG-OK bitwise")
+
+
 if __name__ == "__main__":
     mode, tag = sys.argv[1], sys.argv[2]
-    {"main3d": mode_main3d, "kernels": mode_kernels, "physics": mode_physics}[mode](tag, parse(sys.argv[3:]))
+    {"main3d": mode_main3d, "kernels": mode_kernels, "physics": mode_physics, "avg": mode_avg}[mode](tag, parse(sys.argv[3:]))

@@ -20,6 +20,8 @@ CASES = {
     "benchmark_small": ("benchmark", dict(Lm=24, Mm=16, N=10)),
     "benchmark1": ("benchmark", dict()),
     "upwelling_kpp_small": ("upwelling_kpp", dict(Lm=14, Mm=18, N=8)),
+    # the UPWELLING case built WITH its time-averaged output (oracle/ref/upwelling_avg.h): pins set_avg.F
+    "upwelling_avg_small": ("upwelling_avg", dict(Lm=14, Mm=18, N=8)),
 }
 
 
@@ -98,7 +100,8 @@ def make_case(tag, **kw):
     app, base = CASES[tag]
     k = dict(base)
     k.update(kw)
-    ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp)[app]
+    ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
+                upwelling_avg=cases.upwelling)[app]
     return app, ctor(**k)
 
 

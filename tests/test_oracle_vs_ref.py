@@ -236,3 +236,13 @@ def test_physics_routines_bitwise(tag):
     routine's outputs array_equal on a perturbed state; diag through avgkp and its printed line."""
     out = _child("physics", tag)
     assert "PHYSICS-OK bitwise" in out, out
+
+
+@pytest.mark.parametrize("args", [["nsteps=9", "nAVG=3", "ntsAVG=1"], ["nsteps=8", "nAVG=2", "ntsAVG=3"],
+                                  ["nsteps=5", "nAVG=1", "ntsAVG=1"]])
+def test_set_avg_bitwise(args):
+    """set_avg_tile (set_avg.F:96) for the Aout switches of roms_upwelling.in -- the reference built from
+    oracle/ref/upwelling_avg.h (UPWELLING with AVERAGES) against orc_set_avg, all 22 time-averaged arrays after
+    every call: the set, accumulate and convert (scale + periodic refill) phases of several windows."""
+    out = _child("avg", "upwelling_avg_small", *args)
+    assert "AVG-OK bitwise" in out, out
