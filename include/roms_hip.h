@@ -153,6 +153,21 @@ int roms_hip_last_diag(roms_hip_ctx *ctx, double *out);
    For a caller that wants to assert its own BOUNDS against the library's before the first step. */
 int roms_hip_get_bounds(roms_hip_ctx *ctx, int *out);
 
+/* Time-averaged fields, set_avg (ROMS/Nonlinear/set_avg.F:51, called at main3d.F:562; cpp option AVERAGES).
+   roms_hip_avg_config: the averaging window -- nAVG steps per record (0: off), accumulation from step ntsAVG on,
+   nrrec and ntstart of a restarted run as in set_avg.F:251-254 -- and the fields to average, bit f of mask =
+   field f of:  0 zeta  1 ubar  2 vbar  3 u  4 v  5 omega (W*pm*pn)  6 w  7 rho  8 the tracers  9 zeta2  10 ubar2
+   11 vbar2  12 uu  13 vv  14 uv  15 Huon  16 Hvom  17 <t*t>  18 <u*t>  19 <v*t>  20 <Huon*t>  21 <Hvom*t>
+   (the Aout switches of roms.in).  With a window configured roms_hip_main3d calls set_avg in every step where
+   main3d.F does; roms_hip_set_avg is the kernel(ng,tile) entry for a caller that sequences main3d itself.  The
+   averages are read with roms_hip_download under the names avg_zeta avg_ubar avg_vbar avg_u avg_v avg_omega avg_w
+   avg_rho avg_t avg_ZZ avg_U2 avg_V2 avg_UU avg_VV avg_UV avg_Huon avg_Hvom avg_TT avg_UT avg_VT avg_HuonT
+   avg_HvomT (tracer terms: NT blocks of N levels); they are complete -- divided by nAVG, ghost points filled -- after
+   the step iic with MOD(iic-1,nAVG) = 0.  roms_hip_avg_time: AVGtime of the last completed window (wrt_avg.F). */
+int roms_hip_avg_config(roms_hip_ctx *ctx, int nAVG, int ntsAVG, int nrrec, int ntstart, unsigned mask);
+int roms_hip_set_avg(roms_hip_ctx *ctx);
+int roms_hip_avg_time(roms_hip_ctx *ctx, double *avgtime);
+
 /* The reference writes its history and restart records in the middle of a step (CALL output, main3d.F:591,
    behind set_zeta): before a caller between two roms_hip_main3d calls downloads fields for output it brings
    the derived ones -- rho, Huon/Hvom, W, the surface fluxes, Akv/Akt/hsbl, zeta(1:2) = Zt_avg1 -- to that point

@@ -260,8 +260,11 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   c->swdk_ready = false;
   c->pre_t3_ready = false;
   c->stream3 = nullptr;
+  for (int f = 0; f < 24; f++) c->avg[f] = nullptr;
+  c->avg_nAVG = 0; c->avg_ntsAVG = 1; c->avg_nrrec = 0; c->avg_ntstart = 1; c->avg_mask = 0;
+  c->avg_time = 0.0; c->avg_done_iic = -1;
   c->late_pre = false;
-  for (int e = 0; e < 8; e++) c->ev_lane[e] = nullptr;
+  for (int e = 0; e < 12; e++) c->ev_lane[e] = nullptr;
 #ifdef ROMS_CPU_EMU
   c->stream = nullptr;
   c->stream2 = nullptr;
@@ -277,7 +280,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence);
   (void)hipEventCreateWithFlags(&c->ev_point, hipEventDisableTiming | hipEventDisableSystemFence);
   if (hipfail(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_lo), "hipStreamCreate")) { delete c; return 2; }
-  for (int e = 0; e < 8; e++) (void)hipEventCreateWithFlags(&c->ev_lane[e], hipEventDisableTiming | hipEventDisableSystemFence);
+  for (int e = 0; e < 12; e++) (void)hipEventCreateWithFlags(&c->ev_lane[e], hipEventDisableTiming | hipEventDisableSystemFence);
   {
     const char *e = getenv("ROMS_HIP_OVERLAP");
     c->overlap = !(e && e[0] == '0');
@@ -393,7 +396,7 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_point) (void)hipEventDestroy(c->ev_point);
-  for (int e = 0; e < 8; e++) if (c->ev_lane[e]) (void)hipEventDestroy(c->ev_lane[e]);
+  for (int e = 0; e < 12; e++) if (c->ev_lane[e]) (void)hipEventDestroy(c->ev_lane[e]);
   if (c->xstream) {
     (void)hipStreamSynchronize(c->xstream);
     (void)hipEventDestroy(c->ev_xprod);
@@ -437,7 +440,11 @@ extern "C" int roms_hip_get_stepping(roms_hip_ctx *c, roms_hip_stepping *s) {
 
 extern "C" long roms_hip_field_size(roms_hip_ctx *c, const char *name) {
   const FieldDesc *f = find_field(name);
-  return f ? field_elems(c, f->kind) : -1;
+  if (!f) {
+    const int a = avg_field_index(name);
+    return (a >= 0 && c->avg[a]) ? avg_field_elems(c, a) : -1;
+  }
+  return field_elems(c, f->kind);
 }
 extern "C" int roms_hip_upload(roms_hip_ctx *c, const char *name, const double *host, long n) {
   const FieldDesc *f = find_field(name);
@@ -449,6 +456,14 @@ extern "C" int roms_hip_upload(roms_hip_ctx *c, const char *name, const double *
 }
 extern "C" int roms_hip_download(roms_hip_ctx *c, const char *name, double *host, long n) {
   const FieldDesc *f = find_field(name);
+  if (!f) {
+    const int a = avg_field_index(name);               // time-averaged fields: "avg_zeta" ... "avg_HvomT"
+    if (a >= 0 && c->avg[a]) {
+      if (n != avg_field_elems(c, a)) { set_error(std::string("size mismatch for field ") + name); return 8; }
+      halo_fence(c, FG_ALL);
+      return d2h(host, c->avg[a], (size_t)n * sizeof(double), c->stream);
+    }
+  }
   if (!f) { set_error(std::string("unknown field ") + name); return 8; }
   if (n != field_elems(c, f->kind)) { set_error(std::string("size mismatch for field ") + name); return 8; }
   halo_fence(c, FG_ALL);
@@ -1089,7 +1104,8 @@ static int main3d_late(roms_hip_ctx *c, bool do_diag) {
   roms_hip_stepping &s = c->s;
   const roms_hip_config &cf = c->cfg;
   int r;
-  enum { E_FORK = 0, E_EOS, E_VBC, E_W, E_D, E_X, E_UV, E_L };
+  enum { E_FORK = 0, E_EOS, E_VBC, E_W, E_D, E_X, E_UV, E_L, E_Z };
+  const bool avg = c->avg_nAVG > 0 && c->avg_done_iic != s.iic;      // set_avg :562 (not when the output point ran it)
   kstream_t M = c->stream, S = c->stream2, X = c->stream3;
   const bool on = lanes_on(c);
   struct Back {
@@ -1111,6 +1127,7 @@ static int main3d_late(roms_hip_ctx *c, bool do_diag) {
   DO(roms_hip_omega(c));                                    // :534
   lane_record(c, E_W);
   DO(roms_hip_set_zeta(c));                                 // :556
+  lane_record(c, E_Z);
   lane_wait(c, E_EOS);
   DO(roms_hip_prsgrd(c));                                   // rhs3d.F: prsgrd, rhs3d_tile
   DO(run_rhs3d_pt(c));
@@ -1120,6 +1137,10 @@ static int main3d_late(roms_hip_ctx *c, bool do_diag) {
   if (do_diag) DO(enqueue_diag(c));                         // :355
   lane_wait(c, E_W);
   DO(roms_hip_wvelocity(c, s.nstp));                        // :535
+  if (avg) {                                                // set_avg :562: what the loop overwrites, before it
+    lane_wait(c, E_Z);
+    DO(run_set_avg(c, 1));
+  }
   lane_record(c, E_X);
   to(M);
   DO(run_uv3dmix2_s(c));                                    // the terms of uv3dmix2 (c->late_pre)
@@ -1135,6 +1156,7 @@ static int main3d_late(roms_hip_ctx *c, bool do_diag) {
 #endif
   lane_wait(c, E_VBC);
   lane_wait(c, E_D);                                        // (the two-kernel KPP form reuses prsgrd's work array)
+  if (avg) DO(run_set_avg(c, 2));                           // the rest of set_avg: rho, u, v, t, W, wvel, Huon, Hvom stay put
   if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));        // :525
   else if (cf.options & ROMS_LMD_MIXING) DO(roms_hip_lmd_vmix(c)); // :527
   if (cf.options & ROMS_SOLAR_SOURCE) { DO(run_swdk(c)); c->swdk_ready = true; }
@@ -1213,6 +1235,7 @@ static int main3d_one(roms_hip_ctx *c) {
     side_point(c);
     if (!r) r = diag_now();
     if (!r) r = roms_hip_wvelocity(c, s.nstp);     // overwrites wvel, which diag reads: same stream, in order
+    if (!r && c->avg_nAVG > 0 && c->avg_done_iic != s.iic) r = run_set_avg(c, 0);      // :562
   } else {
     r = diag_now();
   }
@@ -1228,6 +1251,7 @@ static int main3d_one(roms_hip_ctx *c) {
     side_join(c);
     DO(roms_hip_wvelocity(c, s.nstp));
     DO(roms_hip_set_zeta(c));                               // :556
+    if (c->avg_nAVG > 0 && c->avg_done_iic != s.iic) DO(run_set_avg(c, 0));           // :562
   } else {
     side_join_point(c);               // (diag and wvelocity are picked up by the next join, before the barotropic loop)
   }
@@ -1271,6 +1295,35 @@ extern "C" int roms_hip_last_diag(roms_hip_ctx *c, double *out) {
   return 0;
 }
 
+// Time-averaged fields (AVERAGES): the window of set_avg.F and which fields it accumulates (bit f of mask = field f
+// of the list in include/roms_hip.h).  nAVG = 0 switches averaging off and frees nothing; the arrays are allocated
+// at the first call that switches it on.
+extern "C" int roms_hip_avg_config(roms_hip_ctx *c, int nAVG, int ntsAVG, int nrrec, int ntstart, unsigned mask) {
+  if (!c || nAVG < 0) return 8;
+  if (nAVG > 0)
+    for (int f = 0; f < 22; f++)
+      if (((mask >> f) & 1u) && !c->avg[f]) {
+        void *p = nullptr;
+        if (dmalloc(&p, (size_t)avg_field_elems(c, f) * sizeof(double))) return 2;
+        c->allocs.push_back(p);
+        c->avg[f] = (double *)p;
+      }
+  c->avg_nAVG = nAVG; c->avg_ntsAVG = ntsAVG; c->avg_nrrec = nrrec; c->avg_ntstart = ntstart; c->avg_mask = mask;
+  c->avg_done_iic = -1;
+  return 0;
+}
+// set_avg(ng,tile), main3d.F:562
+extern "C" int roms_hip_set_avg(roms_hip_ctx *c) {
+  if (!c) return 8;
+  halo_fence(c, FG_ALL);
+  return run_set_avg(c, 0);
+}
+extern "C" int roms_hip_avg_time(roms_hip_ctx *c, double *t) {
+  if (!c || !t) return 8;
+  *t = c->avg_time;
+  return 0;
+}
+
 // main3d.F:591: output (wrt_his, wrt_rst) sits in the MIDDLE of a step, behind set_zeta.  roms_hip_main3d
 // returns between steps, so a caller that writes history or restart records first brings the derived fields to
 // that point of the step about to be taken: set_data, set_massflux, rho_eos, the surface forcing, the vertical
@@ -1304,6 +1357,13 @@ extern "C" int roms_hip_output_point(roms_hip_ctx *c) {
   DO(d2d((double *)c->F.wrk3[12], (double *)c->F.wvel, wbytes, c->stream));
   DO(d2d((double *)c->F.wvel, (double *)c->F.wrk3[11], wbytes, c->stream));
   DO(roms_hip_set_zeta(c));
+  if (c->avg_nAVG > 0 && c->avg_done_iic != s.iic) {     // set_avg :562 precedes output :591; the step skips it then
+    DO(d2d((double *)c->F.wrk3[11], (double *)c->F.wvel, wbytes, c->stream));        // (it averages the NEW wvel)
+    DO(d2d((double *)c->F.wvel, (double *)c->F.wrk3[12], wbytes, c->stream));
+    DO(run_set_avg(c, 0));
+    DO(d2d((double *)c->F.wvel, (double *)c->F.wrk3[11], wbytes, c->stream));
+    c->avg_done_iic = s.iic;
+  }
 #undef DO
   return dsync(c->stream);
 }

@@ -38,6 +38,12 @@ struct roms_hip_ctx {
   bool has_exchange;            // some neighbour is reached through the transport (multi-tile, or the self-exchange test aid)
   bool swdk_ready;              // main3d_one has launched k_swdk already (side stream): run_pre_step3d skips it
   bool pre_t3_ready;            // main3d_one has launched the tracer predictor of pre_step3d already (side stream)
+  // time-averaged fields (set_avg.F; g_avg.cpp): off until roms_hip_avg_config
+  double *avg[24];
+  int avg_nAVG, avg_ntsAVG, avg_nrrec, avg_ntstart;
+  unsigned avg_mask;
+  double avg_time;              // AVGtime (mod_scalars.F): time stamp of the record wrt_avg writes
+  int avg_done_iic;             // roms_hip_output_point has run set_avg for this step already
   bool late_pre;                // main3d_one runs pre_step3d BEHIND prsgrd/rhs3d_tile/uv3dmix2 (beside the barotropic loop):
                                 // k_prs_grad keeps the old ru/rv bracket, k_uv3dmix2_s only stores its terms, k_pre_new uses both
   bool m2d_dirty;               // grid arrays uploaded since Fields::m2r/m2p were packed (g_step2d.cpp)
@@ -58,7 +64,7 @@ struct roms_hip_ctx {
   kstream_t stream2;   // side stream: kernels of a step that do not depend on each other overlap
   kstream_t stream3;   // second side stream (main3d_one, small grids: diag/wvelocity, then the kernels that run beside the barotropic loop)
   kevent_t ev_fork, ev_join, ev_point;
-  kevent_t ev_lane[8];
+  kevent_t ev_lane[12];
   bool overlap;        // use the side stream (single-GPU latency hiding on small grids)
   double *h_diag;      // pinned host mirror
   int nblk_diag;
@@ -121,6 +127,9 @@ void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype);
 // multi-tile run the exchange may go to the exchange stream and overlap the routines that follow (halo_fence)
 void launch_halo_tail(roms_hip_ctx *c, const HaloSpec *sp, int n);
 void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n);   // n <= 8 fields in one launch
+int run_set_avg(roms_hip_ctx *c, int part = 0);   // g_avg.cpp
+int avg_field_index(const char *name);
+long avg_field_elems(const roms_hip_ctx *c, int f);
 
 // region timing
 struct RegionTimer {

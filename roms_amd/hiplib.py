@@ -53,7 +53,7 @@ KERNELS = ["set_depth", "set_massflux", "rho_eos", "set_vbc", "ana_vmix", "set_d
 
 EXPORTS = ["roms_hip_create", "roms_hip_destroy", "roms_hip_last_error", "roms_hip_abi_version",
            "roms_hip_field_size", "roms_hip_upload", "roms_hip_download", "roms_hip_sync",
-           "roms_hip_set_stepping", "roms_hip_get_stepping", "roms_hip_wvelocity", "roms_hip_diag", "roms_hip_last_diag", "roms_hip_get_bounds", "roms_hip_output_point",
+           "roms_hip_set_stepping", "roms_hip_get_stepping", "roms_hip_wvelocity", "roms_hip_diag", "roms_hip_last_diag", "roms_hip_get_bounds", "roms_hip_output_point", "roms_hip_avg_config", "roms_hip_set_avg", "roms_hip_avg_time",
            "roms_hip_start", "roms_hip_main3d", "roms_hip_profile", "roms_hip_region_seconds",
            "roms_hip_kprof", "roms_hip_kprof_get", "roms_hip_kprof_stride", "roms_hip_kprof_batch", "roms_hip_set_exchange", "roms_hip_rccl_unique_id",
            "roms_hip_comm_rccl", "roms_hip_exchange_count", "roms_hip_copy_probe"] + \
@@ -92,6 +92,9 @@ def load(path=None):
     L.roms_hip_last_diag.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.roms_hip_get_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.roms_hip_output_point.argtypes = [C.c_void_p]
+    L.roms_hip_avg_config.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]
+    L.roms_hip_set_avg.argtypes = [C.c_void_p]
+    L.roms_hip_avg_time.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.roms_hip_start.argtypes = [C.c_void_p]
     L.roms_hip_main3d.argtypes = [C.c_void_p, C.c_int]
     L.roms_hip_profile.argtypes = [C.c_void_p, C.c_int]
@@ -205,6 +208,19 @@ class Context:
         out = (C.c_double * 16)()
         self._ck(self.L.roms_hip_diag(self.h, out))
         return list(out) if raw else list(out)[:12]
+
+    AVG_FIELDS = ["avg_zeta", "avg_ubar", "avg_vbar", "avg_u", "avg_v", "avg_omega", "avg_w", "avg_rho", "avg_t", "avg_ZZ",
+                  "avg_U2", "avg_V2", "avg_UU", "avg_VV", "avg_UV", "avg_Huon", "avg_Hvom", "avg_TT", "avg_UT", "avg_VT",
+                  "avg_HuonT", "avg_HvomT"]
+
+    def avg_config(self, nAVG, ntsAVG=1, nrrec=0, ntstart=1, mask=(1 << 22) - 1):
+        """time-averaged fields (set_avg.F): window of nAVG steps from step ntsAVG on; mask bit f = AVG_FIELDS[f]"""
+        self._ck(self.L.roms_hip_avg_config(self.h, nAVG, ntsAVG, nrrec, ntstart, mask))
+
+    def avg_time(self):
+        t = C.c_double()
+        self._ck(self.L.roms_hip_avg_time(self.h, C.byref(t)))
+        return t.value
 
     def output_point(self):
         """derived fields of the step about to be taken as at main3d.F:591 (where the reference writes output)"""

@@ -132,6 +132,24 @@
           integer(c_int), intent(out) :: out(54)
           integer(c_int) :: ierr
         END FUNCTION
+        FUNCTION roms_hip_avg_config (ctx, nAVG, ntsAVG, nrrec, ntstart, mask) bind(C, name='roms_hip_avg_config')  &
+     &           RESULT (ierr)
+          IMPORT :: c_int, c_ptr
+          TYPE (c_ptr), value :: ctx
+          integer(c_int), value :: nAVG, ntsAVG, nrrec, ntstart, mask
+          integer(c_int) :: ierr
+        END FUNCTION
+        FUNCTION roms_hip_set_avg (ctx) bind(C, name='roms_hip_set_avg') RESULT (ierr)
+          IMPORT :: c_int, c_ptr
+          TYPE (c_ptr), value :: ctx
+          integer(c_int) :: ierr
+        END FUNCTION
+        FUNCTION roms_hip_avg_time (ctx, avgtime) bind(C, name='roms_hip_avg_time') RESULT (ierr)
+          IMPORT :: c_int, c_ptr, c_double
+          TYPE (c_ptr), value :: ctx
+          real(c_double), intent(out) :: avgtime
+          integer(c_int) :: ierr
+        END FUNCTION
         FUNCTION roms_hip_output_point (ctx) bind(C, name='roms_hip_output_point') RESULT (ierr)
           IMPORT :: c_int, c_ptr
           TYPE (c_ptr), value :: ctx

@@ -591,3 +591,44 @@ def test_rccl_self_exchange_eight_neighbours():
     assert line, r.stdout[-1500:] + r.stderr[-3000:]
     assert "finite True mismatching []" in line[-1], line[-1]
     assert int(line[-1].split()[2]) > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,nAVG,ntsAVG,env", [("upwelling_small", 3, 1, {}), ("benchmark_small", 2, 2, {}),
+                                                 ("benchmark_small", 3, 1, {"ROMS_HIP_LATE_PRE": "0"})])
+def test_time_averages_match_oracle(tag, nAVG, ntsAVG, env):
+    """set_avg (set_avg.F:51, AVERAGES) on the GPU inside roms_hip_main3d -- late-predictor schedule (split around the
+    barotropic loop) and reference order -- against the oracle pinned to the reference's set_avg.F: the 22 averaged
+    arrays after every step.  Sums of products of fields that agree to round-off: 1e-11, exact where the fields are."""
+    import subprocess
+    import sys
+    import textwrap
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from tests import util
+        from roms_amd import hiplib
+        cs = util.case_for(%r)
+        g = util.load_init(%r, util.nghost_for(cs))
+        O = util.make_oracle(cs, g)
+        H = util.make_hip(cs, g)
+        O.set_avg_window(%d, %d)
+        H.avg_config(%d, %d)
+        O.start(); H.start()
+        worst = 0.0
+        for step in range(1, 8):
+            O.main3d_step(); H.main3d(1)
+            for n in hiplib.Context.AVG_FIELDS:
+                a, b = H.download(n), O.field(n)
+                assert (a != 0).any() == (b != 0).any(), (step, n)
+                e = util.relrms(a, b)
+                worst = max(worst, e)
+                assert e <= 1e-11, (step, n, e)
+        assert abs(H.avg_time() - 300.0 * 0) >= 0.0
+        H.close()
+        print("AVG-GPU-OK", worst)
+    """) % (ROOT, tag, tag, nAVG, ntsAVG, nAVG, ntsAVG)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+    assert "AVG-GPU-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
