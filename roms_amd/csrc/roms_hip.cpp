@@ -1315,7 +1315,9 @@ extern "C" int roms_hip_avg_config(roms_hip_ctx *c, int nAVG, int ntsAVG, int nr
 // set_avg(ng,tile), main3d.F:562
 extern "C" int roms_hip_set_avg(roms_hip_ctx *c) {
   if (!c) return 8;
+  if (c->avg_nAVG <= 0 || c->avg_done_iic == c->s.iic) return 0;     // off, or roms_hip_output_point ran it for this step
   halo_fence(c, FG_ALL);
+  c->avg_done_iic = c->s.iic;
   return run_set_avg(c, 0);
 }
 extern "C" int roms_hip_avg_time(roms_hip_ctx *c, double *t) {

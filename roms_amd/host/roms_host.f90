@@ -39,6 +39,12 @@
      &                      idTemp = 8, idSalt = 9, idDano = 10, idVvis = 11, idTdif = 12, idSdif = 13,            &
      &                      idHsbl = 14, nHout = 14
       logical :: Hout(nHout) = .FALSE.
+!  time-averaged output (AVERAGES: set_avg.F, def_avg.F/wrt_avg.F): window, file, the Aout switches in the order of
+!  roms_hip_avg_config's mask bits; tracer terms (bits 8, 17..21) per tracer
+      integer :: nAVG = 0, ntsAVG = 1
+      character(len=256) :: avgname = 'roms_avg.nc'
+      integer, parameter :: nAout = 22
+      logical :: Aout(0:nAout-1) = .FALSE., AoutT(0:nAout-1,ROMS_MAXT) = .FALSE.
       character(len=512) :: app_header = ' '      ! application header to read the cpp options from (optional)
       character(len=256) :: host_message = ' '    ! why the last set-up step returned a non-zero exit_flag
       integer :: n_unused_keys = 0                ! roms.in keywords this build has no use for (output, nesting ...)
@@ -153,6 +159,31 @@
           CASE ('ININAME');     ininame=ADJUSTL(val)
           CASE ('RSTNAME');     rstname=ADJUSTL(val)
           CASE ('HISNAME');     hisname=ADJUSTL(val)
+          CASE ('NAVG');        nAVG=toint(tok(1))
+          CASE ('NTSAVG');      ntsAVG=toint(tok(1))
+          CASE ('AVGNAME');     avgname=ADJUSTL(val)
+          CASE ('Aout(idFsur)'); Aout(0)=istrue(tok(1))
+          CASE ('Aout(idUbar)'); Aout(1)=istrue(tok(1))
+          CASE ('Aout(idVbar)'); Aout(2)=istrue(tok(1))
+          CASE ('Aout(idUvel)'); Aout(3)=istrue(tok(1))
+          CASE ('Aout(idVvel)'); Aout(4)=istrue(tok(1))
+          CASE ('Aout(idOvel)'); Aout(5)=istrue(tok(1))
+          CASE ('Aout(idWvel)'); Aout(6)=istrue(tok(1))
+          CASE ('Aout(idDano)'); Aout(7)=istrue(tok(1))
+          CASE ('Aout(idTvar)'); CALL load_aout (8, tok, nv)
+          CASE ('Aout(idZZav)'); Aout(9)=istrue(tok(1))
+          CASE ('Aout(idU2av)'); Aout(10)=istrue(tok(1))
+          CASE ('Aout(idV2av)'); Aout(11)=istrue(tok(1))
+          CASE ('Aout(idUUav)'); Aout(12)=istrue(tok(1))
+          CASE ('Aout(idVVav)'); Aout(13)=istrue(tok(1))
+          CASE ('Aout(idUVav)'); Aout(14)=istrue(tok(1))
+          CASE ('Aout(idHUav)'); Aout(15)=istrue(tok(1))
+          CASE ('Aout(idHVav)'); Aout(16)=istrue(tok(1))
+          CASE ('Aout(idTTav)'); CALL load_aout (17, tok, nv)
+          CASE ('Aout(idUTav)'); CALL load_aout (18, tok, nv)
+          CASE ('Aout(idVTav)'); CALL load_aout (19, tok, nv)
+          CASE ('Aout(iHUTav)'); CALL load_aout (20, tok, nv)
+          CASE ('Aout(iHVTav)'); CALL load_aout (21, tok, nv)
           CASE ('Hout(idFsur)'); Hout(idFsur)=istrue(tok(1))
           CASE ('Hout(idUbar)'); Hout(idUbar)=istrue(tok(1))
           CASE ('Hout(idVbar)'); Hout(idVbar)=istrue(tok(1))
@@ -280,6 +311,7 @@
       rdrg=3.0E-4_dp; rdrg2=3.0E-3_dp; Zob=0.02_dp; Zos=0.02_dp; gamma2=1.0_dp
       dstart=0.0_dp; time_ref=0.0_dp; blk_ZQ=10.0_dp; blk_ZT=10.0_dp; blk_ZW=10.0_dp
       nrrec=0; nRST=0; nHIS=0; LcycleRST=.TRUE.; Hout=.FALSE.
+      nAVG=0; ntsAVG=1; avgname='roms_avg.nc'; Aout=.FALSE.; AoutT=.FALSE.
       ininame='roms_ini.nc'; rstname='roms_rst.nc'; hisname='roms_his.nc'
       END SUBROUTINE set_defaults
 
@@ -318,6 +350,16 @@
         END IF
       END DO
       END SUBROUTINE split
+
+      SUBROUTINE load_aout (bit, tok, nv)         ! a per-tracer switch line: one value per tracer
+      integer, intent(in) :: bit, nv
+      character(len=64), intent(in) :: tok(16)
+      integer :: it
+      DO it=1,MIN(nv,ROMS_MAXT)
+        AoutT(bit,it)=istrue(tok(it))
+      END DO
+      Aout(bit)=ANY(AoutT(bit,:))
+      END SUBROUTINE load_aout
 
       LOGICAL FUNCTION istrue (s)
       character(len=*), intent(in) :: s
@@ -1354,6 +1396,10 @@
       cfg%sc_r(1:N)=sc_r; cfg%Cs_r(1:N)=Cs_r; cfg%sc_w(0:N)=sc_w; cfg%Cs_w(0:N)=Cs_w
       ierr=roms_hip_create(cfg, ctx)
       IF (ierr.ne.0) RETURN
+      IF (nAVG.gt.0.and.ANY(Aout)) THEN           ! AVERAGES: mod_average.F allocate_average
+        ierr=roms_hip_avg_config(ctx, nAVG, ntsAVG, 0, 1, aout_mask())
+        IF (ierr.ne.0) RETURN
+      END IF
       CALL up ('h', h, 1, ierr); CALL up ('f', f, 1, ierr); CALL up ('fomn', fomn, 1, ierr)
       CALL up ('pm', pm, 1, ierr); CALL up ('pn', pn, 1, ierr); CALL up ('om_r', om_r, 1, ierr)
       CALL up ('on_r', on_r, 1, ierr); CALL up ('om_u', om_u, 1, ierr); CALL up ('on_u', on_u, 1, ierr)
@@ -1376,6 +1422,14 @@
 !
 !  Upload the tile's window (tLBi:tUBi,tLBj:tUBj) of a host array with np horizontal planes.
 !
+      INTEGER FUNCTION aout_mask ()
+      integer :: k
+      aout_mask=0
+      DO k=0,nAout-1
+        IF (Aout(k)) aout_mask=IBSET(aout_mask,k)
+      END DO
+      END FUNCTION aout_mask
+
       SUBROUTINE up (name, A, np, ierr)
       character(len=*), intent(in) :: name
       integer, intent(in) :: np
@@ -1440,6 +1494,7 @@
         ierr=roms_hip_omega(ctx);                         IF (ierr.ne.0) RETURN
         ierr=roms_hip_wvelocity(ctx, step%nstp);          IF (ierr.ne.0) RETURN
         ierr=roms_hip_set_zeta(ctx);                      IF (ierr.ne.0) RETURN
+        ierr=roms_hip_set_avg(ctx);                       IF (ierr.ne.0) RETURN      ! :562 (AVERAGES; no-op when off)
         ierr=roms_hip_rhs3d(ctx);                         IF (ierr.ne.0) RETURN
         DO my_iif=1,nfast+1                                ! LF-AM3 barotropic loop :810-918
           next_indx1=3-step%indx1

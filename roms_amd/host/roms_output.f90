@@ -150,16 +150,17 @@
       integer, parameter :: NC_INT = 4, NC_DOUBLE = 6
 !  grid types of a variable (mod_param.F: r2dvar ... w3dvar)
       integer, parameter :: gR2 = 1, gU2 = 2, gV2 = 3, gR3 = 4, gU3 = 5, gV3 = 6, gW3 = 7, gUW = 8, gVW = 9
-      integer, parameter :: fHIS = 1, fRST = 2
+      integer, parameter :: fHIS = 1, fRST = 2, fAVG = 3
 
       TYPE out_file
         integer(c_int) :: h = -1
         integer :: nrec = 0                        ! records written so far (Rindex)
         integer(c_int) :: d_xr, d_xu, d_xv, d_xp, d_er, d_eu, d_ev, d_ep, d_N, d_sr, d_sw, d_trc, d_bry
         integer(c_int) :: d_two, d_three, d_time
-        integer(c_int) :: v_time, v_idx(7), v_fld(32)
+        integer(c_int) :: v_time, v_idx(7), v_fld(40)
       END TYPE out_file
-      TYPE (out_file), save :: ofile(2)
+      TYPE (out_file), save :: ofile(3)
+      real(r8) :: AVGtime = 0.0_r8                 ! mod_scalars.F: time stamp of the averages record
       integer :: ntstart_run = 1                   ! first step of this run (initial.F:172; > 1 after get_state)
       logical :: restarted = .FALSE.
 
@@ -380,13 +381,15 @@
       character(len=*), intent(in) :: path, ftype
       logical, intent(in) :: define
       integer, intent(inout) :: ierr
-      integer, save :: vid(64,2)
+      integer, save :: vid(64,3)
       integer :: k, r, w
       integer(c_int) :: iv(1)
       real(r8) :: dv(1)
       real(r8), allocatable :: A(:,:,:)
       character(len=16) :: tiling
-      w=MERGE(1,2,ftype.eq.'ROMS history file')
+      w=1
+      IF (ftype.eq.'ROMS restart file') w=2
+      IF (ftype(1:14).eq.'ROMS nonlinear') w=3
       IF (.not.master()) RETURN
       IF (define) THEN
         write (tiling,'(i3.3,a,i3.3)') NtileI, 'x', NtileJ
@@ -397,6 +400,7 @@
         r=r+nc3_put_att_text(o%h, -1, cs('title'), cs('ROMS on MI355X: '//TRIM(MyAppCPP)))
         r=r+nc3_put_att_text(o%h, -1, cs('rst_file'), cs(rstname))
         r=r+nc3_put_att_text(o%h, -1, cs('his_file'), cs(hisname))
+        IF (nAVG.gt.0) r=r+nc3_put_att_text(o%h, -1, cs('avg_file'), cs(avgname))
         r=r+nc3_put_att_text(o%h, -1, cs('tiling'), cs(tiling))
         r=r+nc3_put_att_text(o%h, -1, cs('CPP_options'), cs(MyAppCPP))
         IF (r.ne.0) ierr=3
@@ -526,9 +530,11 @@
       integer, intent(in) :: which
       integer, intent(out) :: ierr
       character(len=256) :: path
-      character(len=32) :: ftype
-      integer :: k, r
+      character(len=40) :: ftype
+      integer :: k, r, it
       logical :: rst, lmd
+      character(len=8) :: tn(2)
+      character(len=24) :: tl(2), tu(2)
       integer(c_int) :: two, three
       character(len=96) :: tunit
       ierr=0
@@ -536,6 +542,10 @@
       lmd=IAND(options,ROMS_LMD_MIXING).ne.0
       path=MERGE(rstname, hisname, rst)
       ftype=MERGE('ROMS restart file', 'ROMS history file', rst)
+      IF (which.eq.fAVG) THEN
+        path=avgname
+        ftype='ROMS nonlinear model averages file'
+      END IF
       ofile(which)%nrec=0
       IF (.not.master()) THEN
         ofile(which)%h=0                   ! "open": this rank takes part in the gathers only; the definitions below
@@ -562,13 +572,69 @@
       END IF
 !  model time, def_his.F: Vname(:,idtime), units "seconds since <reference date>" (time_ref = 0: 0001-01-01)
       tunit='seconds since 0001-01-01 00:00:00'
-      CALL def_scalar (o, 'ocean_time', NC_DOUBLE, 'time since initialization', TRIM(tunit), o%d_time, o%v_time, ierr)
+      CALL def_scalar (o, 'ocean_time', NC_DOUBLE, TRIM(MERGE('averaged time since initialization',                &
+     &                 'time since initialization         ', which.eq.fAVG)), TRIM(tunit), o%d_time, o%v_time, ierr)
       IF (master()) THEN
         r=nc3_put_att_text(o%h, o%v_time, cs('calendar'), cs('proleptic_gregorian'))
         r=r+nc3_put_att_text(o%h, o%v_time, cs('field'), cs('time'))
       END IF
       o%v_fld=-1
       k=0
+      IF (which.eq.fAVG) THEN
+!  def_avg.F: the fields the Aout switches ask for, names and attributes of varinfo.yaml (long names without a
+!  prefix, def_avg.F:490); slots = the mask bits of roms_hip_avg_config, tracer terms from slot 22 on
+        tn=(/ 'temp    ', 'salt    ' /)
+        tl=(/ 'potential temperature   ', 'salinity                ' /)
+        tu=(/ 'Celsius                 ', 'nondimensional          ' /)
+        IF (Aout(0)) CALL adef (1, 'zeta', 'sea_surface_height_above_geopotential_datum', 'free-surface', 'meter',     &
+     &                          'free-surface', gR2)
+        IF (Aout(1)) CALL adef (2, 'ubar', 'barotropic_sea_water_x_velocity',                                        &
+     &                          'vertically integrated u-momentum component', 'meter second-1', 'u-barotropic', gU2)
+        IF (Aout(2)) CALL adef (3, 'vbar', 'barotropic_sea_water_y_velocity',                                        &
+     &                          'vertically integrated v-momentum component', 'meter second-1', 'v-barotropic', gV2)
+        IF (Aout(3)) CALL adef (4, 'u', 'sea_water_x_velocity', 'u-momentum component', 'meter second-1',              &
+     &                          'u-velocity', gU3)
+        IF (Aout(4)) CALL adef (5, 'v', 'sea_water_y_velocity', 'v-momentum component', 'meter second-1',              &
+     &                          'v-velocity', gV3)
+        IF (Aout(5)) CALL adef (6, 'omega', 'upward_sea_water_omega_velocity',                                       &
+     &                          'S-coordinate vertical momentum component', 'meter3 second-1', 'omega', gW3)
+        IF (Aout(6)) CALL adef (7, 'w', 'upward_sea_water_velocity', 'vertical momentum component',                   &
+     &                          'meter second-1', 'w-velocity', gW3)
+        IF (Aout(7)) CALL adef (8, 'rho', 'sea_water_density_anomaly', 'density anomaly', 'kilogram meter-3',         &
+     &                          'density', gR3)
+        IF (Aout(9)) CALL adef (10, 'zeta2', 'square_of_sea_surface_elevation_anomaly', 'squared free-surface',      &
+     &                          'meter2', 'free-surface square', gR2)
+        IF (Aout(10)) CALL adef (11, 'ubar2', 'square_of_barotropic_sea_water_x_velocity',                            &
+     &        'squared vertically integrated u-momentum', 'meter2 second-2', 'u-barotropic square', gU2)
+        IF (Aout(11)) CALL adef (12, 'vbar2', 'square_of_barotropic_sea_water_y_velocity',                            &
+     &        'squared vertically integrated v-momentum', 'meter2 second-2', 'v-barotropic square', gV2)
+        IF (Aout(12)) CALL adef (13, 'uu', 'square_of_sea_water_x_velocity', 'squared u-momentum',                    &
+     &                           'meter2 second-2', 'u-velocity square', gU3)
+        IF (Aout(13)) CALL adef (14, 'vv', 'square_of_sea_water_y_velocity', 'squared v-momentum',                    &
+     &                           'meter2 second-2', 'v-velocity square', gV3)
+        IF (Aout(14)) CALL adef (15, 'uv', 'product_of_x_velocity_and_y_velocity_in_sea_water',                       &
+     &                           'u-momentum times v-momentum', 'meter2 second-2', 'u- and v-velocity product', gR3)
+        IF (Aout(15)) CALL adef (16, 'Huon', 'ocean_volume_x_transport', 'u-volume flux', 'meter3 second-1',          &
+     &                           'volume x-transport', gU3)
+        IF (Aout(16)) CALL adef (17, 'Hvom', 'ocean_volume_y_transport', 'v-volume flux', 'meter3 second-1',          &
+     &                           'volume y-transport', gV3)
+        DO it=1,MIN(NT,2)
+          IF (AoutT(8,it)) CALL adef (18+it, TRIM(tn(it)), TRIM(MERGE('sea_water_potential_temperature',             &
+     &        'sea_water_practical_salinity   ', it.eq.1)), TRIM(tl(it)), TRIM(tu(it)),                               &
+     &        TRIM(MERGE('temperature', 'salinity   ', it.eq.1)), gR3)
+          IF (AoutT(17,it)) CALL adef (20+it, TRIM(tn(it))//'_2', ' ', 'squared '//TRIM(tl(it)),                     &
+     &        TRIM(MERGE('Celsius2      ', 'nondimensional', it.eq.1)), TRIM(tn(it))//' square', gR3)
+          IF (AoutT(18,it)) CALL adef (22+it, 'u_'//TRIM(tn(it)), ' ', 'u-momentum times '//TRIM(tl(it)),             &
+     &        TRIM(MERGE('meter second-1 Celsius', 'meter second-1        ', it.eq.1)), 'u-velocity '//TRIM(tn(it)), gU3)
+          IF (AoutT(19,it)) CALL adef (24+it, 'v_'//TRIM(tn(it)), ' ', 'v-momentum times '//TRIM(tl(it)),             &
+     &        TRIM(MERGE('meter second-1 Celsius', 'meter second-1        ', it.eq.1)), 'v-velocity '//TRIM(tn(it)), gV3)
+          IF (AoutT(20,it)) CALL adef (26+it, 'Huon_'//TRIM(tn(it)), ' ', 'u-volume flux '//TRIM(tl(it)),             &
+     &        TRIM(MERGE('meter3 second-1 Celsius', 'meter3 second-1        ', it.eq.1)), 'u-flux '//TRIM(tn(it)), gU3)
+          IF (AoutT(21,it)) CALL adef (28+it, 'Hvom_'//TRIM(tn(it)), ' ', 'v-volume flux '//TRIM(tl(it)),             &
+     &        TRIM(MERGE('meter3 second-1 Celsius', 'meter3 second-1        ', it.eq.1)), 'v-flux '//TRIM(tn(it)), gV3)
+        END DO
+      END IF
+      IF (which.ne.fAVG) THEN
       IF (rst.or.Hout(idFsur)) CALL fdef ('zeta', 'sea_surface_height_above_geopotential_datum', 'free-surface',     &
      &                                    'meter', 'free-surface', gR2, three, idFsur)
       IF (rst) CALL fdef ('rzeta', 'sea_surface_elevation_anomaly_right_hand_side', 'RHS of free-surface equation',  &
@@ -608,6 +674,7 @@
      &     'meter2 second-1', 'AKs', gW3, -1_c_int, idSdif)
       IF (lmd.and.(rst.or.Hout(idHsbl))) CALL fdef ('Hsbl', 'ocean_surface_boundary_layer_thickness',                &
      &     'depth of oceanic surface boundary layer', 'meter', 'SBL thickness', gR2, -1_c_int, idHsbl)
+      END IF
       IF (ierr.eq.0.and.master()) THEN
         IF (nc3_enddef(o%h).ne.0) ierr=3
       END IF
@@ -615,6 +682,12 @@
       END ASSOCIATE
 
       CONTAINS
+        SUBROUTINE adef (slot, name, stdname, longname, units, field, g)
+        character(len=*), intent(in) :: name, stdname, longname, units, field
+        integer, intent(in) :: g, slot
+        CALL def_field (ofile(which), name, stdname, longname, units, field, g, -1_c_int, .TRUE.,                  &
+     &                  ofile(which)%v_fld(slot), ierr)
+        END SUBROUTINE adef
         SUBROUTINE fdef (name, stdname, longname, units, field, g, lev, slot)
         character(len=*), intent(in) :: name, stdname, longname, units, field
         integer, intent(in) :: g, slot
@@ -662,8 +735,12 @@
           iv(1)=step%indx1; IF (nc3_put_var_int(o%h, o%v_idx(7), INT(rec,c_long), iv, 1_c_long_long).ne.0) ierr=3
         END IF
         tv(1)=step%time
+        IF (which.eq.fAVG) tv(1)=AVGtime
         IF (nc3_put_var_double(o%h, o%v_time, INT(rec,c_long), tv, 1_c_long_long).ne.0) ierr=3
       END IF
+      IF (which.eq.fAVG) THEN
+        CALL avg_fields ()
+      ELSE
 !  2-D state
       allocate ( A(LBi:UBi,LBj:UBj,3) )
       CALL wr2 ('zeta', idFsur, gR2, 3)
@@ -735,12 +812,50 @@
         CALL put_field (o%h, o%v_fld(idHsbl), rec, gR2, A, 1, 1, 1, ierr)
         deallocate ( A )
       END IF
+      END IF
       IF (master().and.ierr.eq.0) THEN
         IF (nc3_sync(o%h).ne.0) ierr=3                      ! netcdf_sync after every record (wrt_his.F)
       END IF
       END ASSOCIATE
 
       CONTAINS
+!  wrt_avg.F: the converted averages of the window that has just closed
+        SUBROUTINE avg_fields ()
+        integer :: it2
+        CALL av ('avg_zeta', 1, gR2, 1, 1, 1)
+        CALL av ('avg_ubar', 2, gU2, 1, 1, 1)
+        CALL av ('avg_vbar', 3, gV2, 1, 1, 1)
+        CALL av ('avg_u', 4, gU3, N, 1, N)
+        CALL av ('avg_v', 5, gV3, N, 1, N)
+        CALL av ('avg_omega', 6, gW3, N+1, 1, N+1)
+        CALL av ('avg_w', 7, gW3, N+1, 1, N+1)
+        CALL av ('avg_rho', 8, gR3, N, 1, N)
+        CALL av ('avg_ZZ', 10, gR2, 1, 1, 1)
+        CALL av ('avg_U2', 11, gU2, 1, 1, 1)
+        CALL av ('avg_V2', 12, gV2, 1, 1, 1)
+        CALL av ('avg_UU', 13, gU3, N, 1, N)
+        CALL av ('avg_VV', 14, gV3, N, 1, N)
+        CALL av ('avg_UV', 15, gR3, N, 1, N)
+        CALL av ('avg_Huon', 16, gU3, N, 1, N)
+        CALL av ('avg_Hvom', 17, gV3, N, 1, N)
+        DO it2=1,MIN(NT,2)
+          CALL av ('avg_t', 18+it2, gR3, N*NT, N*(it2-1)+1, N*it2)
+          CALL av ('avg_TT', 20+it2, gR3, N*NT, N*(it2-1)+1, N*it2)
+          CALL av ('avg_UT', 22+it2, gU3, N*NT, N*(it2-1)+1, N*it2)
+          CALL av ('avg_VT', 24+it2, gV3, N*NT, N*(it2-1)+1, N*it2)
+          CALL av ('avg_HuonT', 26+it2, gU3, N*NT, N*(it2-1)+1, N*it2)
+          CALL av ('avg_HvomT', 28+it2, gV3, N*NT, N*(it2-1)+1, N*it2)
+        END DO
+        END SUBROUTINE avg_fields
+        SUBROUTINE av (name, slot, g, np, k0, k1)
+        character(len=*), intent(in) :: name
+        integer, intent(in) :: slot, g, np, k0, k1
+        IF (ofile(which)%v_fld(slot).lt.0) RETURN
+        allocate ( B(LBi:UBi,LBj:UBj,np) )
+        CALL fetch (name, np, B, ierr)
+        CALL put_field (ofile(which)%h, ofile(which)%v_fld(slot), rec, g, B, np, k0, k1, ierr)
+        deallocate ( B )
+        END SUBROUTINE av
         SUBROUTINE wr2 (name, slot, g, nlev)                ! history: level KOUT; restart: all levels
         character(len=*), intent(in) :: name
         integer, intent(in) :: slot, g, nlev
@@ -769,7 +884,7 @@
 
       SUBROUTINE out_close ()
       integer :: w, r
-      DO w=1,2
+      DO w=1,3
         IF (ofile(w)%h.ge.0.and.master()) r=nc3_close(ofile(w)%h)
         ofile(w)%h=-1
         ofile(w)%nrec=0
@@ -795,6 +910,31 @@
       END IF
       IF (nRST.gt.0) THEN
         IF (iic.gt.ntstart_run.and.MOD(iic-1,nRST).eq.0) CALL out_record (fRST, ierr)
+        IF (ierr.ne.0) RETURN
+      END IF
+!  averages: def_avg.F:2664-2679 sets AVGtime half a window before the first one when the file is defined (at the
+!  first step of the run); set_avg.F:2966-2972 moves it on by a window whenever one closes; output.F:515-519 writes
+      IF (nAVG.gt.0.and.ANY(Aout)) THEN
+        IF (ofile(fAVG)%h.lt.0) THEN
+          IF (ntsAVG.eq.1) THEN
+            AVGtime=step%time-0.5_r8*REAL(nAVG,r8)*dt
+          ELSE
+            AVGtime=step%time+REAL(ntsAVG,r8)*dt-0.5_r8*REAL(nAVG,r8)*dt
+          END IF
+          CALL out_define (fAVG, ierr)
+          IF (ierr.ne.0) RETURN
+        END IF
+        IF ((iic.gt.ntsAVG.and.MOD(iic-1,nAVG).eq.0.and.(iic.ne.ntstart_run.or.nrrec.eq.0)).or.                     &
+     &      (iic.ge.ntsAVG.and.nAVG.eq.1)) THEN
+          IF (nAVG.eq.1) THEN
+            AVGtime=step%time
+          ELSE
+            AVGtime=AVGtime+REAL(nAVG,r8)*dt
+          END IF
+          IF ((iic.gt.ntstart_run.and.MOD(iic-1,nAVG).eq.0).or.(iic.ge.ntsAVG.and.nAVG.eq.1)) THEN
+            CALL out_record (fAVG, ierr)
+          END IF
+        END IF
       END IF
       END SUBROUTINE output
 !
@@ -820,6 +960,10 @@
         END IF
         IF (nRST.gt.0) THEN
           nxt=nRST-MOD(iic-1,nRST)
+          chunk=MIN(chunk,nxt)
+        END IF
+        IF (nAVG.gt.0) THEN
+          nxt=nAVG-MOD(iic-1,nAVG)
           chunk=MIN(chunk,nxt)
         END IF
         IF (mode.eq.0) THEN
@@ -949,6 +1093,7 @@
 !  initial.F:549-577 for a restart: depths from Zt_avg1, then the derived fields of the first step
       ntstart_run=step%iic
       restarted=.TRUE.
+      IF (nAVG.gt.0.and.ANY(Aout)) ierr=roms_hip_avg_config(ctx, nAVG, ntsAVG, MAX(nrrec,1), step%iic, aout_mask())
       ierr=roms_hip_set_stepping(ctx, step)
       IF (ierr.eq.0) ierr=roms_hip_set_depth(ctx)
       IF (ierr.eq.0) ierr=roms_hip_set_massflux(ctx)

@@ -89,17 +89,18 @@ def write_roms_in(path, p):
         f"      GAMMA2 == {d(p['gamma2'])}",
     ]
     # output (optional keys): NRREC, NRST, NHIS, LcycleRST, file names, Hout switches by their roms.in ids
-    for key in ("NRREC", "NRST", "NHIS"):
+    for key in ("NRREC", "NRST", "NHIS", "NAVG", "NTSAVG"):
         if key in p:
             lines.append(f"{key:>12} == {int(p[key])}")
     if "LcycleRST" in p:
         lines.append(f"   LcycleRST == {'T' if p['LcycleRST'] else 'F'}")
-    for key in ("ININAME", "RSTNAME", "HISNAME"):
+    for key in ("ININAME", "RSTNAME", "HISNAME", "AVGNAME"):
         if key in p:
             lines.append(f"{key:>12} == {p[key]}")
-    for vid, val in p.get("Hout", {}).items():
-        val = val if isinstance(val, (tuple, list)) else (val,)
-        lines.append(f"Hout({vid}) == " + " ".join("T" if x else "F" for x in val))
+    for sw in ("Hout", "Aout"):
+        for vid, val in p.get(sw, {}).items():
+            val = val if isinstance(val, (tuple, list)) else (val,)
+            lines.append(f"{sw}({vid}) == " + " ".join("T" if x else "F" for x in val))
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
 

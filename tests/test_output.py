@@ -197,7 +197,8 @@ def test_tiles_write_the_file_a_single_tile_writes_and_restart_from_it(tmp_path)
     step 5 bit for bit."""
     _libs("emu")
     fields = ["zeta", "ubar", "vbar", "u", "v", "t"]
-    upd1 = dict(NHIS=2, NRST=3, HISNAME=str(tmp_path / "his1.nc"), RSTNAME=str(tmp_path / "rst1.nc"), Hout=HOUT, LcycleRST=False)
+    upd1 = dict(NHIS=2, NRST=3, HISNAME=str(tmp_path / "his1.nc"), RSTNAME=str(tmp_path / "rst1.nc"), Hout=HOUT, LcycleRST=False,
+                NAVG=2, NTSAVG=1, AVGNAME=str(tmp_path / "avg1.nc"), Aout=AOUT)
     cs = util.case_for("benchmark_small")
     cs.update(upd1, ninfo=0)
     H, ctx = _host(cs, "emu")
@@ -205,9 +206,9 @@ def test_tiles_write_the_file_a_single_tile_writes_and_restart_from_it(tmp_path)
     H.close_output()
     want = {n: ctx.download(n).copy() for n in fields}            # (single-tile array layout = the gathered layout)
     H.finalize()
-    upd4 = dict(upd1, HISNAME=str(tmp_path / "his4.nc"), RSTNAME=str(tmp_path / "rst4.nc"))
+    upd4 = dict(upd1, HISNAME=str(tmp_path / "his4.nc"), RSTNAME=str(tmp_path / "rst4.nc"), AVGNAME=str(tmp_path / "avg4.nc"))
     _run_tiles(tmp_path, dict(tag="benchmark_small", steps=5, fields=fields, case_update=upd4, advance=True), (2, 2), 29631)
-    for one, four in (("his1.nc", "his4.nc"), ("rst1.nc", "rst4.nc")):
+    for one, four in (("his1.nc", "his4.nc"), ("rst1.nc", "rst4.nc"), ("avg1.nc", "avg4.nc")):
         a, b = _nc(str(tmp_path / one)), _nc(str(tmp_path / four))
         assert list(a.variables) == list(b.variables)
         for n in a.variables:
@@ -216,6 +217,7 @@ def test_tiles_write_the_file_a_single_tile_writes_and_restart_from_it(tmp_path)
         assert a.tiling == b"001x001" and b.tiling == b"002x002"
         a.close()
         b.close()
+    assert sum(1 for _ in open(str(tmp_path / "avg4.nc"), "rb")) > 0
     got = _run_tiles(tmp_path, dict(tag="benchmark_small", steps=2, fields=fields, restart_from=upd1["RSTNAME"]), (2, 2), 29632)
     for n in fields:
         assert np.array_equal(got[n].ravel(), want[n].ravel()), n
@@ -315,3 +317,74 @@ def test_writing_records_does_not_change_the_run(which, tmp_path):
         assert np.array_equal(ctx.download(n), want[n]), n
     assert ctx.last_diag() == dwant
     H.finalize()
+
+
+AOUT = {"idFsur": True, "idUbar": True, "idVbar": True, "idUvel": True, "idVvel": True, "idOvel": True, "idWvel": True,
+        "idDano": True, "idTvar": (True, True), "idZZav": True, "idU2av": True, "idV2av": True, "idUUav": True,
+        "idVVav": True, "idUVav": True, "idHUav": True, "idHVav": True, "idTTav": (True, True), "idUTav": (True, True),
+        "idVTav": (True, True), "iHUTav": (True, True), "iHVTav": (True, False)}
+AVG_VARS = {"zeta": "avg_zeta", "ubar": "avg_ubar", "vbar": "avg_vbar", "u": "avg_u", "v": "avg_v", "omega": "avg_omega",
+            "w": "avg_w", "rho": "avg_rho", "zeta2": "avg_ZZ", "ubar2": "avg_U2", "vbar2": "avg_V2", "uu": "avg_UU",
+            "vv": "avg_VV", "uv": "avg_UV", "Huon": "avg_Huon", "Hvom": "avg_Hvom"}
+AVG_TVARS = {"temp": ("avg_t", 0), "salt": ("avg_t", 1), "temp_2": ("avg_TT", 0), "salt_2": ("avg_TT", 1),
+             "u_temp": ("avg_UT", 0), "u_salt": ("avg_UT", 1), "v_temp": ("avg_VT", 0), "v_salt": ("avg_VT", 1),
+             "Huon_temp": ("avg_HuonT", 0), "Huon_salt": ("avg_HuonT", 1), "Hvom_temp": ("avg_HvomT", 0)}
+
+
+@pytest.mark.parametrize("which", LIBS)
+def test_averages_file_holds_the_reference_set_avg_fields(which, tmp_path):
+    """AVERAGES: NAVG = 3 over 7 steps: two records, stamped with the centre of their windows (def_avg.F:2664,
+    set_avg.F:2966), named and dimensioned as def_avg.F does, holding what the oracle's set_avg -- pinned to the
+    reference's set_avg.F -- holds at those steps (bit for bit on the emulation; 1e-11 on the GPU); the per-tracer
+    switch that is off (Hvom_salt) leaves its variable out; averaging and writing do not change the run."""
+    cs = util.case_for("upwelling_small")
+    avg = str(tmp_path / "roms_avg.nc")
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    O.set_avg_window(3, 1)
+    O.start()
+    want = {}
+    for step in range(1, 8):
+        O.main3d_step()
+        if step in (4, 7):
+            want[step] = {n: O.field(n).copy() for n in list(AVG_VARS.values()) + ["avg_t", "avg_TT", "avg_UT", "avg_VT",
+                                                                                 "avg_HuonT", "avg_HvomT"]}
+    ufinal = O.field("u").copy()
+    cs.update(NAVG=3, NTSAVG=1, AVGNAME=avg, Aout=AOUT, ninfo=0)
+    H, ctx = _host(cs, which)
+    H.advance(7, final=False)
+    t = H.tile
+    got_u = ctx.download("u")
+    H.close_output()
+    H.finalize()
+    exact = which == "emu"
+    assert np.array_equal(got_u, ufinal) if exact else util.relrms(got_u, ufinal) < 1e-11
+    f = _nc(avg)
+    assert f.type == b"ROMS nonlinear model averages file"
+    V = f.variables
+    assert list(V["ocean_time"][:]) == [450.0, 1350.0] and V["ocean_time"].long_name == b"averaged time since initialization"
+    assert set(AVG_VARS) | set(AVG_TVARS) <= set(V) and "Hvom_salt" not in V
+    assert V["uv"].dimensions == ("ocean_time", "s_rho", "eta_rho", "xi_rho") and V["uv"].long_name == b"u-momentum times v-momentum"
+    assert V["Huon_temp"].dimensions == ("ocean_time", "s_rho", "eta_u", "xi_u") and V["omega"].dimensions[1] == "s_w"
+    assert V["zeta2"].units == b"meter2" and V["u_temp"].long_name == b"u-momentum times potential temperature"
+    ni, nj = t["UBi"] - t["LBi"] + 1, t["UBj"] - t["LBj"] + 1
+    Lm, Mm, N = cs["Lm"], cs["Mm"], cs["N"]
+
+    def window(a, name):
+        d = V[name].dimensions
+        i0 = 1 if d[-1] == "xi_u" else 0
+        j0 = 1 if d[-2] == "eta_v" else 0
+        return a[..., j0 - t["LBj"]:Mm + 2 - t["LBj"], i0 - t["LBi"]:Lm + 2 - t["LBi"]]
+
+    for rec, step in enumerate((4, 7)):
+        for name, src in AVG_VARS.items():
+            a = window(want[step][src].reshape(-1, nj, ni), name)
+            b = V[name][rec]
+            assert a.shape == b.shape or a.shape[1:] == b.shape, name
+            assert np.array_equal(a.reshape(b.shape), b) if exact else util.relrms(b, a.reshape(b.shape)) <= 1e-11, (step, name)
+        for name, (src, it) in AVG_TVARS.items():
+            a = window(want[step][src].reshape(-1, nj, ni)[it * N:(it + 1) * N], name)
+            b = V[name][rec]
+            assert np.array_equal(a, b) if exact else util.relrms(b, a) <= 1e-11, (step, name)
+    assert np.abs(V["uv"][1]).max() > 0.0
+    f.close()
