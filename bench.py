@@ -322,6 +322,9 @@ def main():
     ap.add_argument("--Lm", type=int)
     ap.add_argument("--Mm", type=int)
     ap.add_argument("--N", type=int)
+    ap.add_argument("--averages", type=int, default=0, metavar="NAVG",
+                    help="measurement aid: time-average the 22 default Aout fields over windows of NAVG steps "
+                         "(AVERAGES of the stock upwelling.h; off in the headline run, as in roms_benchmark*.in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 512x512x50 pass of the default run")
@@ -371,6 +374,8 @@ def main():
     cs = params_for(wl, args.Lm, args.Mm, args.N, ntimes=args.steps + args.warmup)
     cs["ninfo"] = 1                          # NINFO of roms_benchmark1.in: diagnostics every step
     run = tiling.TiledRun(cs, rank=rank, world=world, device=local_rank, dist=dist, tiles=tiles, weak=weak)
+    if args.averages > 0:
+        run.ctx.avg_config(args.averages)
     if not weak:                             # cs names the global grid: the tile is its NtileI x NtileJ-th part
         cs = dict(cs, Lm=cs["Lm"] // run.NtileI, Mm=cs["Mm"] // run.NtileJ)
     cells_per_rank = cs["Lm"] * cs["Mm"] * cs["N"]
