@@ -222,6 +222,34 @@ STEP_CASES = [
     ("upwelling_kpp_small", "upwelling_kpp_small", ["nsteps=100"]),
 ]
 KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
+def make_avg():
+    """upwelling_small_avg.npz: the 22 time-averaged arrays of the reference's set_avg.F (reference built with AVERAGES,
+    oracle/ref/upwelling_avg.h) after the window-closing steps 4 and 7 of a run with nAVG = 3, ntsAVG = 1 -- stepped
+    through the reference's kernel wrappers in main3d's order with set_avg behind set_zeta (main3d.F:562)."""
+    from tests import refdrive as rd
+    from tests import refchild
+    app, cs = rd.make_case("upwelling_avg_small")
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    R.L.ref_set_avg_window(3, 1, 0, 1)
+    nfast = R.bounds(0)[58]
+    st = dict(iic=1, iif=1, nstp=1, nnew=1, nrhs=1, kstp=1, knew=1, krhs=1, predictor=0, indx1=1, time=0.0, nfast=nfast)
+    out = {}
+    for step in range(1, 8):
+        for kern, s_ in rd.main3d_sequence(cs, st, first=(step == 1)):
+            R.set_stepping(s_["iic"], s_.get("iif", 1), s_["nstp"], s_["nnew"], s_["nrhs"], s_.get("kstp", 1),
+                           s_.get("knew", 1), s_.get("krhs", 1), s_.get("predictor", 0), s_["time"], s_["indx1"])
+            R.call(kern)
+            if kern == "set_zeta":
+                R.call("set_avg")
+                if step in (4, 7):
+                    for n in refchild.AVG_FIELDS:
+                        out[f"s{step}_{n}"] = R.get(n)
+    os.dup2(saved, 1)
+    np.savez_compressed(os.path.join(HERE, "upwelling_small_avg.npz"), nAVG=3, ntsAVG=1, **out)
+    print("wrote upwelling_small_avg.npz", len(out), "arrays")
+
+
 SAMPLES = [("upwelling", 100), ("benchmark1", 100), ("benchmark2", 10), ("benchmark3", 4), ("ns512", 4), ("ns512u3", 4),
            ("config5", 4)]
 
@@ -235,8 +263,11 @@ if __name__ == "__main__":
         make_kernels(sys.argv[2], sys.argv[3], sys.argv[4:])
     elif len(sys.argv) > 3 and sys.argv[1] == "--sample":
         make_sample(sys.argv[2], int(sys.argv[3]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--avg":
+        make_avg()
     elif len(sys.argv) > 1 and sys.argv[1] == "--reference-runs":
         py = sys.executable
+        subprocess.check_call([py, __file__, "--avg"])
         for name, tag, args in STEP_CASES:
             subprocess.check_call([py, __file__, "--steps", name, tag] + args)
             if name in KERNEL_CASES:

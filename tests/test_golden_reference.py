@@ -5,6 +5,7 @@ Bit-exact: the oracle restates the reference's arithmetic operation by operation
 import glob
 import os
 
+import numpy as np
 import pytest
 
 from tests import util
@@ -77,3 +78,23 @@ def test_host_setup_plus_oracle_reproduce_reference_sample(name, nsteps):
         d = list(dg)
         assert np.isfinite(d[:4]).all() and ("%.6E" % d[3])[:6] == meta["diag"][-1][0][3][:6]   # volume, 5 digits
     O.close()
+
+
+def test_oracle_set_avg_matches_reference_fixture():
+    """tests/golden/upwelling_small_avg.npz: the 22 time-averaged arrays the reference's own set_avg.F held after the
+    window-closing steps 4 and 7 (nAVG = 3; written by make_golden.py --avg from the reference built with AVERAGES):
+    the oracle's, bit for bit, anywhere."""
+    z = np.load(os.path.join(util.GOLDEN, "upwelling_small_avg.npz"))
+    cs = util.case_for("upwelling_small")
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    O.set_avg_window(int(z["nAVG"]), int(z["ntsAVG"]))
+    O.start()
+    n = 0
+    for step in range(1, 8):
+        O.main3d_step()
+        for key in z.files:
+            if key.startswith(f"s{step}_"):
+                assert np.array_equal(O.field(key[3:]), z[key]), key
+                n += 1
+    assert n == 44

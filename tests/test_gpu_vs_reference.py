@@ -95,3 +95,25 @@ def test_partition_matches_reference_get_bounds():
     """Host tile rectangles + the library's derived BOUNDS/DOMAIN entries (roms_hip_get_bounds) == the tables
     get_bounds.F wrote for the UPWELLING tilings and BENCHMARK1 1x1 / 2x2, BENCHMARK3 2x4."""
     assert util.check_tile_bounds() >= 30
+
+
+def test_time_averages_match_reference_fixture():
+    """set_avg on the GPU (inside roms_hip_main3d) against the arrays the reference's set_avg.F held at the
+    window-closing steps 4 and 7 (tests/golden/upwelling_small_avg.npz): 1e-11 (sums of products of fields that
+    agree with the reference to round-off)."""
+    z = np.load(os.path.join(util.GOLDEN, "upwelling_small_avg.npz"))
+    cs = util.case_for("upwelling_small")
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    H = util.make_hip(cs, g)
+    H.avg_config(int(z["nAVG"]), int(z["ntsAVG"]))
+    H.start()
+    n = 0
+    for step in range(1, 8):
+        H.main3d(1)
+        for key in z.files:
+            if key.startswith(f"s{step}_"):
+                a, b = H.download(key[3:]), z[key]
+                assert util.relrms(a, b) <= 1e-11, (key, util.relrms(a, b))
+                n += 1
+    assert n == 44
+    H.close()
