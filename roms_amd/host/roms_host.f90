@@ -774,6 +774,9 @@
       END IF
       IF (LEN_TRIM(app_header).gt.0) THEN
         CALL read_app_header (TRIM(app_header), ierr)
+!  time-averaged output is a cpp option of the application (AVERAGES, e.g. the stock upwelling.h has it,
+!  benchmark.h has not): a header without it switches NAVG of roms.in off, as the reference build would
+        IF (ierr.eq.0.and..not.is_defined('AVERAGES')) nAVG=0
       ELSE
         CALL builtin_defines (ierr)
       END IF

@@ -200,16 +200,17 @@
       END IF
       END SUBROUTINE roms_host_set_gather
 !
-!  nrrec, nRST, nHIS of roms.in and the file names (ININAME, RSTNAME, HISNAME), NUL-terminated, 256 bytes each
+!  nrrec, nRST, nHIS, LcycleRST, nAVG, ntsAVG of roms.in and the file names (ININAME, RSTNAME, HISNAME, AVGNAME),
+!  NUL-terminated, 256 bytes each
 !
       SUBROUTINE roms_host_output_config (ints, names) bind(C, name='roms_host_output_config')
-      integer(c_int), intent(out) :: ints(4)
-      character(kind=c_char), intent(out) :: names(256,3)
+      integer(c_int), intent(out) :: ints(6)
+      character(kind=c_char), intent(out) :: names(256,4)
       integer :: k, j
-      character(len=256) :: w(3)
-      ints=(/ nrrec, nRST, nHIS, MERGE(1,0,LcycleRST) /)
-      w(1)=ininame; w(2)=rstname; w(3)=hisname
-      DO k=1,3
+      character(len=256) :: w(4)
+      ints=(/ nrrec, nRST, nHIS, MERGE(1,0,LcycleRST), nAVG, ntsAVG /)
+      w(1)=ininame; w(2)=rstname; w(3)=hisname; w(4)=avgname
+      DO k=1,4
         names(:,k)=c_null_char
         DO j=1,MIN(LEN_TRIM(w(k)),255)
           names(j,k)=w(k)(j:j)

@@ -195,13 +195,13 @@ class Host:
     # ---- output and restart (roms_amd/host/roms_output.f90: wrt_his, wrt_rst, get_state of the reference)
     def output_config(self):
         """nrrec, nRST, nHIS, LcycleRST and the ININAME / RSTNAME / HISNAME of roms.in"""
-        ints = (C.c_int * 4)()
-        names = C.create_string_buffer(3 * 256)
+        ints = (C.c_int * 6)()
+        names = C.create_string_buffer(4 * 256)
         self.lib.roms_host_output_config(ints, names)
         raw = names.raw
-        ini, rst, his = [raw[k * 256:(k + 1) * 256].split(b"\0")[0].decode() for k in range(3)]
-        return dict(nrrec=ints[0], nRST=ints[1], nHIS=ints[2], LcycleRST=bool(ints[3]), ininame=ini, rstname=rst,
-                    hisname=his)
+        ini, rst, his, avg = [raw[k * 256:(k + 1) * 256].split(b"\0")[0].decode() for k in range(4)]
+        return dict(nrrec=ints[0], nRST=ints[1], nHIS=ints[2], LcycleRST=bool(ints[3]), nAVG=ints[4], ntsAVG=ints[5],
+                    ininame=ini, rstname=rst, hisname=his, avgname=avg)
 
     def _out(self, what, r):
         if r != 0:

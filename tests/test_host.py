@@ -164,8 +164,8 @@ def test_reader_takes_the_output_keywords(tmp_path):
                                " RSTNAME == out/my_rst.nc\n HISNAME == my_his.nc\n ININAME == in/roms_ini.nc")
     try:
         c = H.output_config()
-        assert c == dict(nrrec=-1, nRST=288, nHIS=72, LcycleRST=False, ininame="in/roms_ini.nc",
-                         rstname="out/my_rst.nc", hisname="my_his.nc")
+        assert c == dict(nrrec=-1, nRST=288, nHIS=72, LcycleRST=False, nAVG=0, ntsAVG=1, ininame="in/roms_ini.nc",
+                         rstname="out/my_rst.nc", hisname="my_his.nc", avgname="roms_avg.nc")
     finally:
         H.finalize()
 
@@ -282,5 +282,11 @@ def test_reference_input_files_and_headers_read_in_place(name, app, dims):
     H = hostlib.Host(infile=ext, header=f"/root/reference/ROMS/Include/{app}.h")
     try:
         assert H.dims["options"] == builtin
+        # output: both .in files ask for averages every 72 steps; only upwelling.h defines AVERAGES
+        c = H.output_config()
+        assert (c["nHIS"], c["nRST"], c["LcycleRST"], c["nrrec"]) == ((72, 288, True, 0) if app == "upwelling" else
+                                                                      (1000, 1000, True, 0))
+        assert c["nAVG"] == (72 if app == "upwelling" else 0) and c["avgname"] == "roms_avg.nc"   # NAVG == 1000 in the
+        # BENCHMARK inputs, but benchmark.h has no AVERAGES
     finally:
         H.finalize()
