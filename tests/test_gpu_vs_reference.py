@@ -117,3 +117,38 @@ def test_time_averages_match_reference_fixture():
                 n += 1
     assert n == 44
     H.close()
+
+
+def test_romsM_runs_the_shipped_upwelling_case_with_all_its_files(tmp_path):
+    """The UPWELLING test case as the reference ships it -- 1440 steps of 300 s, NHIS = 72, NRST = 288 (recycled),
+    NAVG = 72, the Hout/Aout switches of roms_upwelling.in, AVERAGES from upwelling.h's option list -- through the
+    stand-alone driver on the GPU: 21 history records, the last two restart records, 20 averages records stamped at
+    their window centres; the 5-day solution is finite, has spun up an upwelling circulation and conserves volume."""
+    import subprocess
+    from scipy.io import netcdf_file
+    from roms_amd import hostlib, cases
+    from tests.test_output import HOUT, AOUT
+    exe = os.path.join(os.path.dirname(hostlib.LIB), "romsM")
+    cs = cases.upwelling(ntimes=1440)
+    cs.update(NHIS=72, NRST=288, LcycleRST=True, NAVG=72, NTSAVG=1, Hout=HOUT, Aout=AOUT, ninfo=72)
+    inp = str(tmp_path / "roms_upwelling.in")
+    hostlib.write_roms_in(inp, cs)
+    r = subprocess.run([exe, inp], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0 and "ROMS: DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    his = netcdf_file(str(tmp_path / "roms_his.nc"), "r", mmap=False)
+    t = his.variables["ocean_time"][:]
+    assert len(t) == 21 and t[0] == 0.0 and t[-1] == 1440 * 300.0 and np.all(np.diff(t) == 72 * 300.0)
+    u, zeta, temp = his.variables["u"][-1], his.variables["zeta"][-1], his.variables["temp"][-1]
+    assert np.isfinite(u).all() and 0.05 < np.abs(u).max() < 2.0                 # wind-driven along-shore jet
+    assert 5.0 < temp.min() and temp.max() < 25.0
+    assert abs(zeta[1:-1, 1:-1].mean()) < 1e-6                                    # volume conserved (closed N/S, periodic E/W)
+    rst = netcdf_file(str(tmp_path / "roms_rst.nc"), "r", mmap=False)
+    assert sorted(rst.variables["ocean_time"][:]) == [1152 * 300.0, 1440 * 300.0]
+    avg = netcdf_file(str(tmp_path / "roms_avg.nc"), "r", mmap=False)
+    ta = avg.variables["ocean_time"][:]
+    assert len(ta) == 20 and ta[0] == 36 * 300.0 and np.all(np.diff(ta) == 72 * 300.0)
+    # the average of the last window lies between the history records that bracket it
+    za, z0, z1 = avg.variables["temp"][-1], his.variables["temp"][-2], his.variables["temp"][-1]
+    assert np.abs(za - 0.5 * (z0 + z1)).max() < 0.5
+    for f in (his, rst, avg):
+        f.close()
