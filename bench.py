@@ -53,7 +53,8 @@ WORKLOADS = {
 ALGO_ARRAYS = {
     #                  3-D  2-D
     "k_step2d":       (0, 44),
-    "k_pre_t3":       (15, 2),     # fused k_pre_t3h + k_pre_t3v: t(3) is written once
+    "k_pre_t3":       (10, 2),     # t(nstp), t(nnew) read and t(3) written per tracer; Hz, Huon, Hvom, W read ONCE for both
+                                   # tracers (LDS-tiled form from 64 K columns; the point-wise form re-reads them: 15)
     "k_pre_t3h":      (7, 2),
     "k_pre_t3v":      (10, 2),
     "k_pre_new":      (19, 9),
@@ -69,7 +70,8 @@ ALGO_ARRAYS = {
     "k_rhs3d_sum":    (6, 10),     # ru, rv and the four viscous terms of uv3dmix2 (fused main3d sequence)
     "k_s3uv_col":     (8, 6),
     "k_s3uv_couple":  (9, 8),
-    "k_s3t_hv":       (12, 2),     # fused horizontal + vertical corrector advection, NT tracers
+    "k_s3t_hv":       (10, 2),     # t(3) read, t(nnew) read-modify-write per tracer; Huon, Hvom, W, Hz once (LDS-tiled form;
+                                   # the point-wise form re-reads them per tracer: 12)
     "k_s3t_h":        (8, 2),
     "k_s3t_col":      (11, 2),
     "k_omega":        (4, 0),

@@ -4,6 +4,7 @@
 #include "k_rhs3d.h"
 #ifndef ROMS_CPU_EMU
 #include "k_rhs3d_lds.h"
+#include "k_tadv_lds.h"
 #include "k_uv3dmix2_col.h"
 #endif
 
@@ -19,6 +20,51 @@ static inline size_t lds_sz(const DGrid &G) { return (size_t)(G.bw + 6) * (size_
 int run_swdk(roms_hip_ctx *c);            // g_lmd.cpp: solar penetration fractions into wrk3[5]
 int run_t3dmix2_geo(roms_hip_ctx *c);     // g_geo.cpp
 
+// The LDS-tiled form of the two tracer-advection point kernels (k_tadv_lds.h): mode 0 = k_pre_t3, 1 = k_s3t_hv.
+// Applies when every tracer takes the point path of that kernel and NT <= 2; false: the caller launches the
+// point-wise form (ROMS_HIP_TADV_LDS=0 forces that; the CPU emulation has it only).
+bool launch_tadv_lds(roms_hip_ctx *c, int mode) {
+#ifdef ROMS_CPU_EMU
+  (void)c; (void)mode;
+  return false;
+#else
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  static const char *el = getenv("ROMS_HIP_TADV_LDS"), *ek = getenv("ROMS_HIP_TADV_KC");
+  if (G.NT > TL_MAXT) return false;
+  const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
+  if (el ? el[0] == '0' : (long)nx * ny < 64L * 1024L) return false;
+  // mode 0: k_pre_t3's tracers are all those without a spline vertical flux (MPDATA/HSIMT tracers take the
+  // first-order upstream predictor there); mode 1: the tracers of k_s3t_hv (every horizontal scheme but MPDATA and
+  // HSIMT) -- the others are left to k_mpdata.h / k_s3t_h and skipped here (a.p1 = mask of the block's tracers)
+  int mask = 0;
+  for (int it = 0; it < G.NT; it++) {
+    const int hs = G.hadv[it], vs = G.vadv[it];
+    if (mode == 0 && vs == ROMS_SPLINES) return false;
+    if (mode == 0 || (hs != ROMS_MPDATA && hs != ROMS_HSIMT)) mask |= 1 << it;
+  }
+  if (!mask) return false;
+  KArgs a = mk(c);
+  a.p1 = mask;
+  const int nt = ((nx + 63) / 64) * ((ny + 3) / 4);
+  int nz = KMAX(1, (2048 + nt - 1) / nt);
+  int kc = KMAX(5, (G.N + nz - 1) / nz);
+  if (ek && atoi(ek) > 0) kc = atoi(ek);
+  kc = KMIN(kc, G.N);
+  nz = (G.N + kc - 1) / kc;
+  a.p0 = kc;
+  const dim3 grid((unsigned)(8 * ((nt + 7) / 8) * nz), 1, 1), block(64, 4, 1);
+  const size_t lds = (size_t)TL_LDS_DOUBLES * sizeof(double);
+  static const char *ew = getenv("ROMS_HIP_TADV_W");
+  const int w = ew ? atoi(ew) : (mode == 0 ? 2 : 3);
+  if (mode == 0 && w == 2) KPROF_WRAP(k_pre_t3, c->stream, hipLaunchKernelGGL((k_tadv_lds<0, 2>), grid, block, lds, c->stream, a, nx, ny, nz));
+  else if (mode == 0) KPROF_WRAP(k_pre_t3, c->stream, hipLaunchKernelGGL((k_tadv_lds<0, 3>), grid, block, lds, c->stream, a, nx, ny, nz));
+  else if (w == 2) KPROF_WRAP(k_s3t_hv, c->stream, hipLaunchKernelGGL((k_tadv_lds<1, 2>), grid, block, lds, c->stream, a, nx, ny, nz));
+  else KPROF_WRAP(k_s3t_hv, c->stream, hipLaunchKernelGGL((k_tadv_lds<1, 3>), grid, block, lds, c->stream, a, nx, ny, nz));
+  return true;
+#endif
+}
+
 // The tracer predictor of pre_step3d (pre_step3d.F:357-852: t(3) from t(nstp), t(nnew), Hz, Huon, Hvom, W) is
 // independent of the surface forcing and the vertical mixing; on small grids the fused main3d sequence
 // launches it early, on the side stream behind omega, beside the bulk-flux / KPP chain (c->pre_t3_ready).
@@ -28,8 +74,10 @@ int run_pre_t3(roms_hip_ctx *c) {
   KArgs a = mk(c);
   bool any_col = false;      // tracers with a spline vertical flux keep the two-kernel column path
   for (int it = 0; it < G.NT; it++) any_col |= G.vadv[it] == ROMS_SPLINES;
-  a.p0 = (G.N + KCH - 1) / KCH;
-  LAUNCH_THREAD(k_pre_t3, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
+  if (!launch_tadv_lds(c, 0)) {
+    a.p0 = (G.N + KCH - 1) / KCH;
+    LAUNCH_THREAD(k_pre_t3, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
+  }
   if (any_col) {
     LAUNCH_COOP(k_pre_t3h, G.nbx, G.nby, G.N * G.NT, 256, 3 * lds_sz(G), c->stream, a);
     LAUNCH_THREAD(k_pre_t3v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);

@@ -71,7 +71,7 @@ int run_step3d_t(roms_hip_ctx *c) {
     any_hsimt |= G.hadv[it] == ROMS_HSIMT;
   }
   a.p0 = (N + KCH - 1) / KCH;
-  if (any_pt) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
+  if (any_pt && !launch_tadv_lds(c, 1)) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
   if (any_hsimt) LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
   {
     const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;

@@ -117,10 +117,10 @@ KDEV double hadv_face(int scheme, double h, double tm, double t0, double wm, dou
   if (scheme == ROMS_U3) return h * 0.5 * (tm + t0) - cff1 * (wm * KMAX(h, 0.0) + w0 * KMIN(h, 0.0));
   return h * 0.5 * (tm + t0 - cff2 * (w0 - wm));
 }
-KDEV void hadv4_pt(const DGrid &G, int scheme, const double *Tc, const double *Hu, const double *Hv, int i, int j,
-                   double &FX0, double &FXp, double &FE0, double &FEp) {
-  const long ni = G.ni;
-  const double hu0 = Hu[0], hup = Hu[1], hv0 = Hv[0], hvp = Hv[ni];
+// the four face fluxes of point (i,j) from the tracer at Tc[a + b*ni] (ni = row stride of the array Tc points
+// into: the model array, or an LDS tile) and the mass fluxes through the faces
+KDEV void hadv4_core(const DGrid &G, int scheme, const double *Tc, const long ni, const double hu0, const double hup,
+                     const double hv0, const double hvp, int i, int j, double &FX0, double &FXp, double &FE0, double &FEp) {
   const double tc = Tc[0], tw = Tc[-1], te = Tc[1], ts = Tc[-ni], tn = Tc[ni];
   if (scheme == ROMS_C2) {
     FX0 = hu0 * 0.5 * (tw + tc); FXp = hup * 0.5 * (tc + te);
@@ -153,6 +153,10 @@ KDEV void hadv4_pt(const DGrid &G, int scheme, const double *Tc, const double *H
     FE0 = hadv_face(scheme, hv0, ts, tc, wkm, wk0);
     FEp = hadv_face(scheme, hvp, tc, tn, wk0, wkp);
   }
+}
+KDEV void hadv4_pt(const DGrid &G, int scheme, const double *Tc, const double *Hu, const double *Hv, int i, int j,
+                   double &FX0, double &FXp, double &FE0, double &FEp) {
+  hadv4_core(G, scheme, Tc, (long)G.ni, Hu[0], Hu[1], Hv[0], Hv[G.ni], i, j, FX0, FXp, FE0, FEp);
 }
 
 // tracers whose predictor (pre_step3d) is done by the fused point kernel k_pre_t3: all but those

@@ -128,6 +128,7 @@ void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype);
 void launch_halo_tail(roms_hip_ctx *c, const HaloSpec *sp, int n);
 void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n);   // n <= 8 fields in one launch
 int run_set_avg(roms_hip_ctx *c, int part = 0);   // g_avg.cpp
+bool launch_tadv_lds(roms_hip_ctx *c, int mode);  // g_rhs3d.cpp
 int avg_field_index(const char *name);
 long avg_field_elems(const roms_hip_ctx *c, int f);
 

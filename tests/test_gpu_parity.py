@@ -542,6 +542,9 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
                            # barotropic loop) instead of the late-predictor schedule on three streams; the latter serial
                            ("refsched", {"ROMS_HIP_LATE_PRE": "0"}), ("serial", {"ROMS_HIP_OVERLAP": "0"}),
                            ("late_knobs", {"ROMS_HIP_LATE_BALLAST": "53248", "ROMS_HIP_PRIO": "1"}),
+                           # tracer advection of pre_step3d / step3d_t: LDS-tiled marching kernels (k_tadv_lds.h; the
+                           # default from 64 K columns up) against the point-wise forms these small grids take
+                           ("tadv_lds", {"ROMS_HIP_TADV_LDS": "1"}), ("tadv_lds_kc", {"ROMS_HIP_TADV_LDS": "1", "ROMS_HIP_TADV_KC": "7"}),
                            ("march", {"ROMS_HIP_UVCH": "7", "ROMS_HIP_WVELCH": "100", "ROMS_HIP_GEOCH": "7", "ROMS_HIP_T3CH": "9"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
