@@ -171,11 +171,12 @@ static int launch_rhs3d_point_part(roms_hip_ctx *c) {
     nz = (G.N + kc - 1) / kc;
     a.p0 = kc;
     static const char *ew = getenv("ROMS_HIP_RHS3D_W");
-    const int w = ew ? atoi(ew) : 3;
+    const int w = ew ? atoi(ew) : 2;
     const dim3 grid((unsigned)(8 * ((nt + 7) / 8) * nz), 1, 1), block(64, 4, 1);
     const size_t lds = (size_t)RL_LDS_DOUBLES * sizeof(double);
-    // compiled for 3 waves per SIMD (168 VGPRs, three 43.5 KB blocks per CU): 376 us at 512x512x50 against 383
-    // for 2 waves (180 VGPRs, no spill) and 781 for 4 (128 VGPRs, 76 spilled); the point-wise form: 478
+    // compiled for 2 waves per SIMD (198 VGPRs with the own-point values of the next level in flight): 300 us at
+    // 512x512x50; 3 waves (168 VGPRs) spill 33 of them: 521 us; before the own-point loads were taken a level
+    // ahead: 366 (3 waves) / 383 (2 waves); the point-wise form: 478
     if (w == 2) KPROF_WRAP(k_rhs3d_pt, c->stream, hipLaunchKernelGGL(k_rhs3d_lds<2>, grid, block, lds, c->stream, a, nx, ny, nz));
     else KPROF_WRAP(k_rhs3d_pt, c->stream, hipLaunchKernelGGL(k_rhs3d_lds<3>, grid, block, lds, c->stream, a, nx, ny, nz));
     return 0;

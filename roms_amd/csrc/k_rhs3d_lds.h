@@ -138,17 +138,27 @@ static __global__ void __launch_bounds__(256, MINW) k_rhs3d_lds(const KArgs a, i
 #define LHU(di, dj) cur[2 * RL_NT + s + (di) + (dj) * RL_TW]
 #define LHV(di, dj) cur[3 * RL_NT + s + (di) + (dj) * RL_TW]
 #define LW(di, dj) cur[4 * RL_NT + s + (di) + (dj) * RL_TW]
+  // own-point values of a level are loaded one level ahead, like the tiles (pn_*: level k+1 while k is evaluated)
+  double pn_Hz0 = 0.0, pn_Hz1u = 0.0, pn_Hz1v = 0.0, pn_qu3 = 0.0, pn_qv3 = 0.0, pn_ru = 0.0, pn_rv = 0.0;
+  auto own_load = [&](int k) {
+    const size_t ok = (size_t)(k - 1) * nij;
+    if (COR || CURV) { pn_Hz0 = F.Hz[ok + x]; pn_Hz1u = F.Hz[ok + xmu]; pn_Hz1v = F.Hz[ok + xmv]; }
+    pn_qu3 = RL_Q(u3, k + 3); pn_qv3 = RL_Q(v3, k + 3);
+    if (du) pn_ru = r3u[(size_t)k * nij];
+    if (dv) pn_rv = r3v[(size_t)k * nij];
+  };
+  if (inside) own_load(k0);
   for (int k = k0; k <= k1; k++) {
     const double *cur = lds_dyn_ + ((k - k0) & 1) * (RL_NA * RL_NT);
     double *nxt = lds_dyn_ + ((k - k0 + 1) & 1) * (RL_NA * RL_NT);
-    if (k < k1) stage_load(k + 1);                       // in flight while level k is evaluated
+    const double Hz0 = pn_Hz0, Hz1u = pn_Hz1u, Hz1v = pn_Hz1v, qu3 = pn_qu3, qv3 = pn_qv3, ru_k = pn_ru, rv_k = pn_rv;
+    if (k < k1) {
+      stage_load(k + 1);                                 // in flight while level k is evaluated
+      if (inside) own_load(k + 1);
+    }
     if (inside) {
-      const size_t ok = (size_t)(k - 1) * nij;
-      double Hz0 = 0.0, Hz1u = 0.0, Hz1v = 0.0;
-      if (COR || CURV) { Hz0 = F.Hz[ok + x]; Hz1u = F.Hz[ok + xmu]; Hz1v = F.Hz[ok + xmv]; }
-      const double qu3 = RL_Q(u3, k + 3), qv3 = RL_Q(v3, k + 3);   // enters the window after this level
       if (du) {
-        double r = r3u[(size_t)k * nij];
+        double r = ru_k;
         const double uc = qu[1];
         const double um1 = LU(-1, 0), up1 = LU(1, 0);
         if (COR || CURV) {
@@ -232,7 +242,7 @@ static __global__ void __launch_bounds__(256, MINW) k_rhs3d_lds(const KArgs a, i
         r3u[(size_t)k * nij] = r;
       }
       if (dv) {
-        double r = r3v[(size_t)k * nij];
+        double r = rv_k;
         const double vc = qv[1];
         const double v0m1 = LV(0, -1), v0p1 = LV(0, 1);
         if (COR || CURV) {
