@@ -7,16 +7,13 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 import bench
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from summarize_pmc import VARIANTS
+from summarize_pmc import canon
 
 rnd, stag, ttag, Lm, Mm, N = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
 tr = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{ttag}_traffic.json")))["kernels"]
 rows = {}
 for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{rnd}_{stag}_kernel_stats.csv"))):
-    k = r["Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
-    if k.startswith("k_step2d_"):
-        k = "k_step2d"
-    k = VARIANTS.get(k, k)
+    k = canon(r["Name"])
     c, t = rows.get(k, (0, 0.0))
     rows[k] = (c + int(r["Calls"]), t + float(r["TotalDurationNs"]))
 print("| kernel | avg µs | algorithmic MB | GB/s | of 8 TB/s | HBM traffic / algorithmic | pair |")

@@ -29,16 +29,26 @@ VARIANTS = {"k_s3uv_col_l": "k_s3uv_col", "k_s3uv_col_l10": "k_s3uv_col", "k_s3u
             "k_rhs3d_lds": "k_rhs3d_pt"}
 
 
+def canon(raw):
+    """rocprofv3 kernel name -> the name DESIGN.md / bench.py use for the kernel"""
+    k = raw.split("(")[0].replace("void ", "").strip()
+    if k.startswith("k_tadv_lds<0"):          # LDS-tiled tracer advection: mode 0 = pre_step3d's predictor,
+        return "k_pre_t3"
+    if k.startswith("k_tadv_lds<1"):          # 1 = step3d_t's corrector advection
+        return "k_s3t_hv"
+    k = k.split("<")[0].strip()
+    if k in ("k_step2d_a", "k_step2d_b", "k_step2d_c", "k_step2d_d"):     # sub-tile variants of one kernel
+        k = "k_step2d"
+    return VARIANTS.get(k, k)
+
+
 def counter_avgs(d, counter):
     tot, disp = defaultdict(float), defaultdict(set)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
-            if k in ("k_step2d_a", "k_step2d_b", "k_step2d_c", "k_step2d_d"):     # sub-tile variants of one kernel
-                k = "k_step2d"
-            k = VARIANTS.get(k, k)
+            k = canon(r["Kernel_Name"])
             tot[k] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
     return {k: tot[k] / len(disp[k]) for k in tot}, {k: len(disp[k]) for k in tot}
