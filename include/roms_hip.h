@@ -45,6 +45,7 @@ enum {
   ROMS_UV_QDRAG = 1 << 7, ROMS_LMD_MIXING = 1 << 8, ROMS_BULK_FLUXES = 1 << 9,
   ROMS_SOLAR_SOURCE = 1 << 10, ROMS_ANA_VMIX = 1 << 11, ROMS_SALINITY = 1 << 12,
   ROMS_SPHERICAL = 1 << 13,
+  ROMS_UV_LOGDRAG = 1 << 14,        /* logarithmic bottom drag from Zob (set_vbc.F:591-635); else UV_QDRAG / UV_LDRAG */
   ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21
 };
 

@@ -39,6 +39,7 @@ enum {
   ORC_CURVGRID = 1 << 5, ORC_NONLIN_EOS = 1 << 6, ORC_UV_QDRAG = 1 << 7, /* else UV_LDRAG */
   ORC_LMD_MIXING = 1 << 8, ORC_BULK_FLUXES = 1 << 9, ORC_SOLAR_SOURCE = 1 << 10,
   ORC_ANA_VMIX = 1 << 11, ORC_SALINITY = 1 << 12, ORC_SPHERICAL = 1 << 13,
+  ORC_UV_LOGDRAG = 1 << 14,  /* set_vbc.F:591-635 */
   ORC_APP_UPWELLING = 1 << 20, ORC_APP_BENCHMARK = 1 << 21
 };
 

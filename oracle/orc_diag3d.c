@@ -173,7 +173,33 @@ void orc_set_vbc(orc_t *o, int tile) {
       o->stflx[X2T(i, j, 2)] = EmP * t[XT(i, j, N, nrhs, 2)];
       o->btflx[X2T(i, j, 2)] = o->btflx[X2T(i, j, 2)] * t[XT(i, j, 1, nrhs, 2)];
     }
-  if (o->c.options & ORC_UV_QDRAG) {
+  if (o->c.options & ORC_UV_LOGDRAG) {
+    /* logarithmic bottom stress set_vbc.F:591-635; ZoBot = Zob (mod_grid.F:1380), Cdb_min, Cdb_max, vonKar of
+       mod_scalars.F:469,772-773 */
+    const double vonKar = 0.41, Cdb_min = 0.000001, Cdb_max = 0.5;
+    double *wrk = (double *)calloc(nij, sizeof(double));
+    for (int j = b->JstrV - 1; j <= b->Jend; j++)
+      for (int i = b->IstrU - 1; i <= b->Iend; i++) {
+        const double cff1 = 1.0 / log((o->z_r[X3(i, j, 1)] - o->z_w[XW(i, j, 0)]) / o->c.Zob);
+        const double cff2 = vonKar * vonKar * cff1 * cff1;
+        wrk[X2(i, j)] = fmin(Cdb_max, fmax(Cdb_min, cff2));
+      }
+    for (int j = b->Jstr; j <= b->Jend; j++)
+      for (int i = b->IstrU; i <= b->Iend; i++) {
+        const double cff1 = 0.25 * (v[X4(i, j, 1, nrhs)] + v[X4(i, j + 1, 1, nrhs)] +
+                                    v[X4(i - 1, j, 1, nrhs)] + v[X4(i - 1, j + 1, 1, nrhs)]);
+        const double cff2 = sqrt(u[X4(i, j, 1, nrhs)] * u[X4(i, j, 1, nrhs)] + cff1 * cff1);
+        o->bustr[X2(i, j)] = 0.5 * (wrk[X2(i - 1, j)] + wrk[X2(i, j)]) * u[X4(i, j, 1, nrhs)] * cff2;
+      }
+    for (int j = b->JstrV; j <= b->Jend; j++)
+      for (int i = b->Istr; i <= b->Iend; i++) {
+        const double cff1 = 0.25 * (u[X4(i, j, 1, nrhs)] + u[X4(i + 1, j, 1, nrhs)] +
+                                    u[X4(i, j - 1, 1, nrhs)] + u[X4(i + 1, j - 1, 1, nrhs)]);
+        const double cff2 = sqrt(cff1 * cff1 + v[X4(i, j, 1, nrhs)] * v[X4(i, j, 1, nrhs)]);
+        o->bvstr[X2(i, j)] = 0.5 * (wrk[X2(i, j - 1)] + wrk[X2(i, j)]) * v[X4(i, j, 1, nrhs)] * cff2;
+      }
+    free(wrk);
+  } else if (o->c.options & ORC_UV_QDRAG) {
     /* quadratic bottom drag set_vbc.F:178 */
     for (int j = b->Jstr; j <= b->Jend; j++)
       for (int i = b->IstrU; i <= b->Iend; i++) {

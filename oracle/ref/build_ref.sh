@@ -45,6 +45,11 @@ if [ "$APP" = upwelling_kpp ]; then
   UP=UPWELLING; HDR=upwelling_kpp; HDRPATH="$HERE/upwelling_kpp.h"
   EXTRA=""
 fi
+if [ "$APP" = upwelling_logdrag ]; then
+  # the UPWELLING case with UV_LOGDRAG (oracle/ref/upwelling_logdrag.h): pins the logarithmic bottom stress
+  UP=UPWELLING; HDR=upwelling_logdrag; HDRPATH="$HERE/upwelling_logdrag.h"
+  EXTRA=""
+fi
 if [ "$APP" = upwelling_avg ]; then
   # the UPWELLING case with AVERAGES (oracle/ref/upwelling_avg.h): pins set_avg.F
   UP=UPWELLING; HDR=upwelling_avg; HDRPATH="$HERE/upwelling_avg.h"

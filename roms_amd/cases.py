@@ -33,6 +33,15 @@ def upwelling_kpp(**kw):
     return cs
 
 
+def upwelling_logdrag(**kw):
+    """UPWELLING with the logarithmic bottom drag (UV_LOGDRAG, Zob = 0.02 m) instead of UV_LDRAG: the custom
+    application header oracle/ref/upwelling_logdrag.h"""
+    cs = upwelling(**kw)
+    cs["app"] = "upwelling_logdrag"
+    cs["options"] = tuple(cs["options"]) + ("UV_LOGDRAG",)
+    return cs
+
+
 def benchmark(Lm=512, Mm=64, N=30, NtileI=1, NtileJ=1, ntimes=200):
     """roms_benchmark1.in"""
     return dict(

@@ -159,9 +159,21 @@ THREAD_KERNEL(k_set_vbc, KArgs) {
   const double EmP = F.stflux[X2T(i, j, 2)];
   F.stflx[X2T(i, j, 2)] = EmP * F.t[XT(i, j, N, nrhs, 2)];
   F.btflx[X2T(i, j, 2)] = F.btflx[X2T(i, j, 2)] * F.t[XT(i, j, 1, nrhs, 2)];
-  const bool qdrag = (G.options & ROMS_UV_QDRAG) != 0;
+  const bool qdrag = (G.options & ROMS_UV_QDRAG) != 0, logdrag = (G.options & ROMS_UV_LOGDRAG) != 0;
+  // UV_LOGDRAG :591-601: drag coefficient of a rho point from the height of its lowest level above the bed
+  // (the reference's private array wrk; a momentum point evaluates it at its two rho points)
+#define CDB_LOG(ii, jj) ({                                                                          \
+    const double c1_ = 1.0 / log((F.z_r[X3(ii, jj, 1)] - F.z_w[XW(ii, jj, 0)]) / G.Zob);             \
+    const double c2_ = 0.41 * 0.41 * c1_ * c1_;                                                      \
+    fmin(0.5, fmax(0.000001, c2_)); })
   if (i >= B.IstrU && i <= B.Iend && j >= B.Jstr && j <= B.Jend) {
-    if (qdrag) {
+    if (logdrag) {
+      const double cff1 = 0.25 * (F.v[X4(i, j, 1, nrhs)] + F.v[X4(i, j + 1, 1, nrhs)] + F.v[X4(i - 1, j, 1, nrhs)] +
+                                  F.v[X4(i - 1, j + 1, 1, nrhs)]);
+      const double uu = F.u[X4(i, j, 1, nrhs)];
+      const double cff2 = sqrt(uu * uu + cff1 * cff1);
+      emit_store(G, emit_plan(G, BC_U, i, j), F.bustr, 0.5 * (CDB_LOG(i - 1, j) + CDB_LOG(i, j)) * uu * cff2);
+    } else if (qdrag) {
       const double cff1 = 0.25 * (F.v[X4(i, j, 1, nrhs)] + F.v[X4(i, j + 1, 1, nrhs)] + F.v[X4(i - 1, j, 1, nrhs)] +
                                   F.v[X4(i - 1, j + 1, 1, nrhs)]);
       const double uu = F.u[X4(i, j, 1, nrhs)];
@@ -172,7 +184,13 @@ THREAD_KERNEL(k_set_vbc, KArgs) {
     }
   }
   if (i >= B.Istr && i <= B.Iend && j >= B.JstrV && j <= B.Jend) {
-    if (qdrag) {
+    if (logdrag) {
+      const double cff1 = 0.25 * (F.u[X4(i, j, 1, nrhs)] + F.u[X4(i + 1, j, 1, nrhs)] + F.u[X4(i, j - 1, 1, nrhs)] +
+                                  F.u[X4(i + 1, j - 1, 1, nrhs)]);
+      const double vv = F.v[X4(i, j, 1, nrhs)];
+      const double cff2 = sqrt(cff1 * cff1 + vv * vv);
+      emit_store(G, emit_plan(G, BC_V, i, j), F.bvstr, 0.5 * (CDB_LOG(i, j - 1) + CDB_LOG(i, j)) * vv * cff2);
+    } else if (qdrag) {
       const double cff1 = 0.25 * (F.u[X4(i, j, 1, nrhs)] + F.u[X4(i + 1, j, 1, nrhs)] + F.u[X4(i, j - 1, 1, nrhs)] +
                                   F.u[X4(i + 1, j - 1, 1, nrhs)]);
       const double vv = F.v[X4(i, j, 1, nrhs)];
@@ -182,6 +200,7 @@ THREAD_KERNEL(k_set_vbc, KArgs) {
       emit_store(G, emit_plan(G, BC_V, i, j), F.bvstr, 0.5 * (F.rdrag[X2(i, j - 1)] + F.rdrag[X2(i, j)]) * F.v[X4(i, j, 1, nrhs)]);
     }
   }
+#undef CDB_LOG
 }
 THREAD_GLOBAL(k_set_vbc, KArgs)
 

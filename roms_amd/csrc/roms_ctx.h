@@ -47,6 +47,7 @@ struct DGrid {
   // scalars
   double dt, dtfast, rho0, g, lambda, gamma2, Cp, R0, T0, S0, Tcoef, Scoef, hc, dstart;
   double Akt_bak[ROMS_MAXT], Akv_bak;
+  double Zob;                 // bottom roughness (UV_LOGDRAG: GRID%ZoBot = Zob, mod_grid.F:1380)
   int Vtransform;
 };
 

@@ -251,7 +251,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   G.ntfirst = cfg->ntfirst; G.nfast = cfg->nfast;
   G.dt = cfg->dt; G.dtfast = cfg->dtfast; G.rho0 = cfg->rho0; G.g = cfg->g; G.lambda = cfg->lambda;
   G.gamma2 = cfg->gamma2; G.Cp = cfg->Cp; G.R0 = cfg->R0; G.T0 = cfg->T0; G.S0 = cfg->S0; G.Tcoef = cfg->Tcoef;
-  G.Scoef = cfg->Scoef; G.hc = cfg->hc; G.dstart = cfg->dstart; G.Akv_bak = cfg->Akv_bak;
+  G.Scoef = cfg->Scoef; G.hc = cfg->hc; G.dstart = cfg->dstart; G.Akv_bak = cfg->Akv_bak; G.Zob = cfg->Zob;
   G.Vtransform = cfg->Vtransform;
   c->profile = false;
   memset(c->regions, 0, sizeof(c->regions));

@@ -666,12 +666,13 @@
       END DO
       CALL define ('ANA_INITIAL'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
       SELECT CASE (TRIM(MyAppCPP))
-        CASE ('UPWELLING', 'UPWELLING_KPP')
-          CALL define ('UV_LDRAG'); CALL define ('MIX_S_TS')
+        CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG')      ! (_LOGDRAG: oracle/ref/upwelling_logdrag.h)
+          CALL define (TRIM(MERGE('UV_LOGDRAG', 'UV_LDRAG  ', TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG')))
+          CALL define ('MIX_S_TS')
           DO k=1,SIZE(flux0)
             CALL define (TRIM(flux0(k)))
           END DO
-          IF (TRIM(MyAppCPP).eq.'UPWELLING') THEN
+          IF (TRIM(MyAppCPP).ne.'UPWELLING_KPP') THEN
             CALL define ('ANA_VMIX')
           ELSE
             DO k=1,SIZE(kpp)
@@ -702,12 +703,12 @@
       integer :: k
       logical :: upw, bench
 !  options with a bit in the mask (include/roms_hip.h)
-      character(len=16), parameter :: bitname(14) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
+      character(len=16), parameter :: bitname(15) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
      &    'TS_DIF2', 'MIX_GEO_TS', 'CURVGRID', 'NONLIN_EOS', 'UV_QDRAG', 'LMD_MIXING', 'BULK_FLUXES',           &
-     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL' ]
-      integer, parameter :: bitval(14) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
+     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG' ]
+      integer, parameter :: bitval(15) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
      &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
-     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL ]
+     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG ]
 !  options whose code is the only form built (accepted, nothing to select) or that only affect output
       character(len=16), parameter :: inherent(31) = [ character(len=16) :: 'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
      &    'DJ_GRADPS', 'MIX_S_UV', 'MIX_S_TS', 'SPLINES_VDIFF', 'SPLINES_VVISC', 'UV_LDRAG', 'ANA_SMFLUX',        &
@@ -717,7 +718,8 @@
       character(len=16), parameter :: output_only(3) = [ character(len=16) :: 'AVERAGES', 'DIAGNOSTICS_TS',      &
      &    'DIAGNOSTICS_UV' ]
       IF (ierr.ne.0) RETURN
-      upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.is_defined('UPWELLING')
+      upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
+     &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.is_defined('UPWELLING')
       bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.is_defined('BENCHMARK')
       IF (upw.eqv.bench) THEN
         CALL unsupported ('MyAppCPP = '//TRIM(MyAppCPP)//': the analytic grid, initial state and forcing '//   &
@@ -741,8 +743,8 @@
       IF (.not.is_defined('SOLVE3D')) CALL unsupported ('SOLVE3D is required (3-D baroclinic step)', ierr)
       IF (.not.is_defined('DJ_GRADPS')) CALL unsupported ('DJ_GRADPS is the pressure-gradient scheme built '//   &
      &                                                     '(prsgrd32.h)', ierr)
-      IF (is_defined('UV_LDRAG').eqv.is_defined('UV_QDRAG'))                                                    &
-     &  CALL unsupported ('exactly one of UV_LDRAG, UV_QDRAG is required', ierr)
+      IF (COUNT((/ is_defined('UV_LDRAG'), is_defined('UV_QDRAG'), is_defined('UV_LOGDRAG') /)).ne.1)           &
+     &  CALL unsupported ('exactly one of UV_LDRAG, UV_QDRAG, UV_LOGDRAG is required', ierr)
       IF (is_defined('UV_VIS2').and..not.is_defined('MIX_S_UV'))                                               &
      &  CALL unsupported ('UV_VIS2 is built along s-surfaces only (MIX_S_UV)', ierr)
       IF (is_defined('TS_DIF2').and.(is_defined('MIX_S_TS').eqv.is_defined('MIX_GEO_TS')))                     &

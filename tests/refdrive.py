@@ -22,6 +22,8 @@ CASES = {
     "upwelling_kpp_small": ("upwelling_kpp", dict(Lm=14, Mm=18, N=8)),
     # the UPWELLING case built WITH its time-averaged output (oracle/ref/upwelling_avg.h): pins set_avg.F
     "upwelling_avg_small": ("upwelling_avg", dict(Lm=14, Mm=18, N=8)),
+    # UPWELLING with the logarithmic bottom drag (oracle/ref/upwelling_logdrag.h)
+    "upwelling_logdrag_small": ("upwelling_logdrag", dict(Lm=14, Mm=18, N=8)),
 }
 
 
@@ -101,7 +103,7 @@ def make_case(tag, **kw):
     k = dict(base)
     k.update(kw)
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
-                upwelling_avg=cases.upwelling)[app]
+                upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag)[app]
     return app, ctor(**k)
 
 

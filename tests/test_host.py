@@ -158,6 +158,23 @@ def test_reader_stops_on_settings_it_cannot_honour(tmp_path, kw, needle):
     assert e.value.exit_flag == 5 and needle in str(e.value), str(e.value)
 
 
+def test_logdrag_header_selects_the_option(tmp_path):
+    """a custom application header with UV_LOGDRAG (oracle/ref/upwelling_logdrag.h is one) sets its bit; two drag
+    laws at once stop the set-up"""
+    from roms_amd import hiplib, hostlib
+    hdr = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "oracle", "ref", "upwelling_logdrag.h"))
+    H = _setup(tmp_path, header=hdr)
+    try:
+        assert H.dims["options"] & hiplib.OPTIONS["UV_LOGDRAG"] and not H.dims["options"] & hiplib.OPTIONS["UV_QDRAG"]
+    finally:
+        H.finalize()
+    bad = tmp_path / "two_drags.h"
+    bad.write_text(open(hdr).read() + "\n#define UV_LDRAG\n")
+    with pytest.raises(hostlib.HostError) as e:
+        _setup(tmp_path, header=str(bad)).finalize()
+    assert e.value.exit_flag == 5 and "UV_LOGDRAG" in str(e.value)
+
+
 def test_reader_takes_the_output_keywords(tmp_path):
     """NRREC, NRST, NHIS, LcycleRST, the file names and the Hout switches (read_phypar.F) reach the output module."""
     H = _setup(tmp_path, extra="NRREC == -1\n NRST == 288\n NHIS == 72\n LcycleRST == F\n"
@@ -228,7 +245,7 @@ def test_application_header_is_read_like_cpp_would(tmp_path):
 
 @pytest.mark.parametrize("line,needle", [("#define TS_DIF4", "TS_DIF4"), ("#define GLS_MIXING", "GLS_MIXING"),
                                          ("#define MASKING", "MASKING"), ("#undef DJ_GRADPS", "DJ_GRADPS"),
-                                         ("#define UV_QDRAG", "exactly one of UV_LDRAG, UV_QDRAG")])
+                                         ("#define UV_QDRAG", "exactly one of UV_LDRAG, UV_QDRAG, UV_LOGDRAG")])
 def test_application_header_with_unbuilt_options_stops(tmp_path, line, needle):
     """An option whose code is not in the library (biharmonic mixing, GLS, masking, another pressure-gradient
     scheme ...) is a configuration error (exit_flag 5), never a silent no-op."""

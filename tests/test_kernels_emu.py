@@ -86,6 +86,27 @@ def test_upwelling_kpp_mpdata_bitwise(emu):
     H.close()
 
 
+def test_logarithmic_bottom_drag_bitwise(emu):
+    """UV_LOGDRAG (set_vbc.F:591-635; oracle pinned to the reference built from oracle/ref/upwelling_logdrag.h):
+    the kernel's branch against the oracle's over 6 steps, and it does differ from the linear drag."""
+    cs = util.case_for("upwelling_logdrag_small")
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start()
+    H.start()
+    for _ in range(6):
+        O.main3d_step()
+        H.main3d(1)
+        for n in util.PROGNOSTIC:
+            assert np.array_equal(H.download(n), O.field(n)), n
+    lin = util.make_oracle(util.case_for("upwelling_small", hadv=cs["hadv"], vadv=cs["vadv"]), g)
+    lin.start()
+    lin.main3d_step(6)
+    assert np.abs(lin.field("bustr") - O.field("bustr")).max() > 1e-9
+    H.close()
+
+
 @pytest.mark.parametrize("hadv,vadv,ng,ewp", [(("U3", "U3"), ("C4", "C4"), 2, 1), (("U3", "HSIMT"), ("C4", "HSIMT"), 3, 1),
                                               (("U3", "U3"), ("C4", "C4"), 2, 0)])
 def test_ns_periodic(emu, hadv, vadv, ng, ewp):

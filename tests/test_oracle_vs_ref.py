@@ -178,7 +178,8 @@ def _child(mode, tag, *args, timeout=900):
         # the reference keeps its private (IminS:ImaxS,JminS:JmaxS,N) work arrays on the stack
         resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
 
-    lib = {"upwelling_kpp_small": "upwelling_kpp"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
+    lib = {"upwelling_kpp_small": "upwelling_kpp", "upwelling_avg_small": "upwelling_avg",
+           "upwelling_logdrag_small": "upwelling_logdrag"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
     if not ref.available(lib):
         pytest.skip(f"oracle/_ref/libromsref_{lib}.so not built here")
     p = subprocess.run([sys.executable, "-m", "tests.refchild", mode, tag] + list(args), capture_output=True,
@@ -198,6 +199,7 @@ MAIN3D_CASES = [
     ("benchmark_small", ["nsteps=100"]),                                         # KPP, bulk fluxes, nonlinear EOS
     ("benchmark_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("upwelling_kpp_small", ["nsteps=100"]),                                     # BASELINE config 5 physics
+    ("upwelling_logdrag_small", ["nsteps=40"]),                                  # UV_LOGDRAG (set_vbc.F:591-635)
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
     ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
 ]
@@ -228,7 +230,7 @@ def test_core_kernels_bitwise(tag, args):
     assert "KERNELS-OK bitwise" in out, out
 
 
-@pytest.mark.parametrize("tag", ["benchmark_small", "upwelling_kpp_small", "upwelling_small"])
+@pytest.mark.parametrize("tag", ["benchmark_small", "upwelling_kpp_small", "upwelling_small", "upwelling_logdrag_small"])
 def test_physics_routines_bitwise(tag):
     """set_depth, set_massflux, rho_eos (rho, pden, rhoA, rhoS, bvf, alpha, beta: rho_eos.F:247-560), the analytic
     atmosphere + ana_srflux (set_data.F), bulk_flux (bulk_flux.F:208), set_vbc (QDRAG), lmd_vmix, omega,
