@@ -210,7 +210,18 @@ int roms_hip_region_seconds(roms_hip_ctx *ctx, int region, double *seconds, long
                              returns, and returns 0 on success.  Message m is matched by
                              (peer, tag), tag = direction of travel: 0/1 = eastward/westward,
                              2/3 = northward/southward, 4..7 = NE, NW, SE, SW; messages are
-                             listed in ascending tag order on both sides. */
+                             listed in ascending tag order on both sides.
+     roms_hip_comm_peer      built-in mailbox transport (round 2): every rank owns a slab of uncached
+                             device memory holding, per direction, two receive buffers and an arrival
+                             word; the neighbours map it (hipIpcOpenMemHandle: xGMI peer access) and
+                             their PACK kernel stores the strips straight into it, the last block
+                             releasing the arrival words; the receiver's UNPACK kernel waits for its
+                             eight words and copies the strips into the ghost zone.  An exchange point
+                             is two launches -- no send/receive calls, no staging copy.  The 128-byte
+                             blob of roms_hip_peer_export of every rank (rank order) is distributed
+                             by the caller and handed to roms_hip_comm_peer.  A message that does not
+                             arrive within ROMS_HIP_PEER_TIMEOUT seconds (default 20) fails the next
+                             call with exit_flag 2. */
 typedef int (*roms_hip_exchange_fn)(void *user, int nsend, const int *send_peer, double *const *send_buf,
                                     const long *send_count, const int *send_tag, int nrecv,
                                     const int *recv_peer, double *const *recv_buf, const long *recv_count,
@@ -218,6 +229,8 @@ typedef int (*roms_hip_exchange_fn)(void *user, int nsend, const int *send_peer,
 int roms_hip_set_exchange(roms_hip_ctx *ctx, roms_hip_exchange_fn fn, void *user);
 int roms_hip_rccl_unique_id(void *id128);
 int roms_hip_comm_rccl(roms_hip_ctx *ctx, const void *id128, int nranks, int rank);
+int roms_hip_peer_export(roms_hip_ctx *ctx, void *blob128);
+int roms_hip_comm_peer(roms_hip_ctx *ctx, const void *blobs128, int nranks, int rank);
 /* number of halo exchanges performed so far (0 for a single-tile context) */
 long roms_hip_exchange_count(roms_hip_ctx *ctx);
 

@@ -231,3 +231,191 @@ COOP_KERNEL(xchg_kernel, XchgArgs) {
   }
 }
 COOP_GLOBAL(xchg_kernel, XchgArgs)
+
+#ifndef ROMS_CPU_EMU
+// ------------------------------------------------------------------------------------------
+// Mailbox transport (roms_hip_comm_peer): the same pack / unpack bodies, with the neighbours'
+// receive slots (mapped over xGMI) as the pack targets.  Ordering:
+//   pack    one block per plane: strips -> the neighbours' slots, waits until its stores are acknowledged,
+//           then writes this exchange's number into the plane's arrival word at each neighbour.
+//   unpack  the first eight threads of a block poll the plane's arrival words until they have reached this
+//           exchange's number, then the block copies its plane.
+// Slots alternate with the parity of the exchange number: a neighbour can be at most one exchange
+// ahead (its pack s+1 follows its unpack s, which needs my pack s), so the slot of exchange s is
+// rewritten by exchange s+2 only, which the neighbour issues after it has seen my pack s+1 -- and that
+// follows my unpack s in stream order.  The slab is uncached memory (what RCCL uses for its own
+// peer buffers): stores land in the owner's HBM, its loads never hit a stale line.
+// ------------------------------------------------------------------------------------------
+struct PeerSync {
+  unsigned long long seq;          // number of this exchange on its channel (1, 2, ...)
+  unsigned long long *word[8];     // arrival words, one per plane -- pack: neighbour d's for my message; unpack: mine for neighbour d's
+  unsigned long long *err;         // unpack: host word, set when a message did not arrive in time
+  long long timeout;               // in wall_clock64 ticks (100 MHz)
+};
+struct XchgPeerArgs { XchgArgs x; PeerSync s; };
+
+// Strips to / from a mailbox slot.  Slot accesses go past the caches in both directions -- stores with
+// system scope (sc0 sc1: written through), loads from the uncached slab -- so that neither side needs a cache
+// writeback or invalidate around the exchange (a __threadfence_system() per block made an exchange point 35 us:
+// it writes the whole dirty L2 back, and the acquire empties it under the barotropic kernel).  A load from
+// uncached memory is a full HBM round trip and gfx9 returns loads and stores through one in-order counter, so
+// a thread first issues ALL its loads -- the strips of the eight directions of a plane taken as one list,
+// PEER_U elements per thread -- and only then stores (dependent load/store pairs, 14 per thread: 15 us per launch).
+#define PEER_U 8
+struct PeerList { int n[8], i0[8], j0[8], w[8], tot; double *m[8]; };
+template <int UNPACK>
+KDEV void peer_list(const XchgArgs &xa, PeerList &L) {
+  const DGrid &G = xa.G;
+  L.tot = 0;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    int i0, i1, j0, j1;
+    xchg_rect(G, d, UNPACK, i0, i1, j0, j1);
+    L.i0[d] = i0; L.j0[d] = j0; L.w[d] = i1 - i0 + 1;
+    L.m[d] = xa.buf[d];
+    L.n[d] = L.m[d] ? L.w[d] * (j1 - j0 + 1) : 0;
+    L.tot += L.n[d];
+  }
+}
+// element q of the list: direction, address in that direction's slot, index in the plane.  Static indices only
+// (a run-time index into the tables sends them to scratch memory: 42 us per launch).
+KDEV void peer_elem(const DGrid &G, const PeerList &L, int bz, int q, int &d, double *&m, int &x, int &ii, int &jj) {
+  int r = q, w = 1, i0 = 0, j0 = 0, n = 0;
+  d = 8; m = nullptr;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const bool here = d == 8 && r < L.n[e];
+    if (here) { d = e; w = L.w[e]; i0 = L.i0[e]; j0 = L.j0[e]; n = L.n[e]; m = L.m[e]; }
+    if (d == 8) r -= L.n[e];
+  }
+  const int j = r / w;
+  ii = i0 + r - j * w; jj = j0 + j;
+  x = (int)X2(ii, jj);
+  m += (size_t)bz * (size_t)n + r;
+}
+// Unpacking without ordering.  The reference's xi phase followed by its eta phase -- here: xi strips, then eta
+// strips, then corner blocks -- leaves in a cell the value of the LAST message that covers it; the rectangles
+// overlap in the corner blocks only (a diagonal neighbour exists exactly where both adjacent ones do).  Each
+// element is therefore written unless a later message covers its cell, and no barrier separates the three groups.
+KDEV bool peer_covered_later(const DGrid &G, const PeerList &L, int d, int i, int j) {
+  const TB &B = G.T;
+  const int ng = G.Nghost;
+  if (d < 2) return (L.m[2] && j >= B.Jstr - 3 && j <= B.Jstr - 1) || (L.m[3] && j >= B.Jend + 1 && j <= B.Jend + ng);
+  if (d < 4) {
+    const bool low = i >= B.Istr - 3 && i <= B.Istr - 1, high = i >= B.Iend + 1 && i <= B.Iend + ng;
+    return d == 2 ? ((L.m[4] && low) || (L.m[5] && high)) : ((L.m[6] && low) || (L.m[7] && high));
+  }
+  return false;
+}
+// the general form (a plane's strips exceed PEER_U elements per thread): direction by direction
+template <int UNPACK>
+KDEV void peer_move(const DGrid &G, const PeerList &L, double *A, double *msg, int bz, int d) {
+  if (!msg) return;
+  int i0, i1, j0, j1;
+  xchg_rect(G, d, UNPACK, i0, i1, j0, j1);
+  const int w = i1 - i0 + 1, n = w * (j1 - j0 + 1), nt = (int)blockDim.x;
+  double *m = msg + (size_t)bz * (size_t)n;
+  for (int q0 = (int)threadIdx.x; q0 < n; q0 += 4 * nt) {
+    double v[4];
+    size_t x[4];
+    bool keep[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int q = q0 + u * nt;
+      if (q < n) {
+        const int j = q / w;
+        x[u] = X2(i0 + q - j * w, j0 + j);
+        keep[u] = !(UNPACK && peer_covered_later(G, L, d, i0 + q - j * w, j0 + j));
+        v[u] = UNPACK ? __builtin_nontemporal_load(&m[q]) : A[x[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int q = q0 + u * nt;
+      if (q < n) {
+        if (UNPACK) { if (keep[u]) A[x[u]] = v[u]; }
+        else __hip_atomic_store(&m[q], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(1024) xchg_peer_pack(const XchgPeerArgs a) {
+  const int tid = (int)threadIdx.x, bz = (int)blockIdx.z, nt = (int)blockDim.x;
+  const DGrid &G = a.x.G;
+  int bc, gtype;
+  double *A = halo_plane(a.x, bz, bc, gtype);
+  if (a.x.fill && (G.T.west || G.T.east || G.T.south || G.T.north)) { halo_fill(G, A, bc, gtype); __syncthreads(); }
+  PeerList L;
+  peer_list<0>(a.x, L);
+  if (L.tot <= PEER_U * nt) {
+    double v[PEER_U];
+    double *mm[PEER_U];
+#pragma unroll
+    for (int u = 0; u < PEER_U; u++) {
+      const int q = tid + u * nt;
+      if (q < L.tot) { int d, x, i, j; peer_elem(G, L, bz, q, d, mm[u], x, i, j); v[u] = A[x]; }
+    }
+#pragma unroll
+    for (int u = 0; u < PEER_U; u++) {
+      const int q = tid + u * nt;
+      if (q < L.tot) __hip_atomic_store(mm[u], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 8; d++) peer_move<0>(G, L, A, a.x.buf[d], bz, d);
+  }
+  // every store of this block has been acknowledged before the plane's arrival words are written
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 8; d++)      // (static indices: a run-time index makes the compiler copy the arguments to scratch)
+    if (tid == d && a.s.word[d]) __hip_atomic_store(a.s.word[d] + bz, a.s.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static __global__ void __launch_bounds__(1024) xchg_peer_unpack(const XchgPeerArgs a) {
+  const int tid = (int)threadIdx.x, bz = (int)blockIdx.z, nt = (int)blockDim.x;
+  const DGrid &G = a.x.G;
+  int bc, gtype;
+  double *A = halo_plane(a.x, bz, bc, gtype);
+  unsigned long long *word = nullptr;
+#pragma unroll
+  for (int d = 0; d < 8; d++)
+    if (tid == d) word = a.s.word[d];
+  if (word) {
+    const long long t0 = (long long)wall_clock64();
+    while (__hip_atomic_load(word + bz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.s.seq) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((long long)wall_clock64() - t0 > a.s.timeout) {
+        __hip_atomic_store(a.s.err, a.s.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  PeerList L;
+  peer_list<1>(a.x, L);
+  if (L.tot <= PEER_U * nt) {
+    double v[PEER_U];
+    int xx[PEER_U];
+#pragma unroll
+    for (int u = 0; u < PEER_U; u++) {
+      const int q = tid + u * nt;
+      xx[u] = -1;
+      if (q < L.tot) {
+        double *m;
+        int d, x, i, j;
+        peer_elem(G, L, bz, q, d, m, x, i, j);
+        v[u] = __builtin_nontemporal_load(m);
+        if (!peer_covered_later(G, L, d, i, j)) xx[u] = x;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PEER_U; u++)
+      if (xx[u] >= 0) A[xx[u]] = v[u];
+    return;
+  }
+#pragma unroll
+  for (int d = 0; d < 8; d++) peer_move<1>(G, L, A, a.x.buf[d], bz, d);
+}
+#endif

@@ -57,6 +57,11 @@ static int d2d(void *d, const void *src, size_t bytes, kstream_t s) {
 static int dsync(kstream_t s) { return hipfail(hipStreamSynchronize(s), "hipStreamSynchronize"); }
 int ctx_check(roms_hip_ctx *c, const char *what) {
   if (c->comm_failed) return 2;
+  if (c->comm.peer_err && *(volatile unsigned long long *)c->comm.peer_err) {
+    set_error("mailbox transport: a neighbour's strips did not arrive in time (exchange " +
+              std::to_string(*(volatile unsigned long long *)c->comm.peer_err) + "); ROMS_HIP_PEER_TIMEOUT sets the limit in seconds");
+    return 2;
+  }
   return hipfail(hipGetLastError(), what);
 }
 #endif
@@ -692,6 +697,7 @@ void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype) {
 // ---- transports ---------------------------------------------------------------------------
 #ifndef ROMS_CPU_EMU
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 namespace {
 struct RcclApi {
@@ -747,11 +753,107 @@ extern "C" int roms_hip_comm_rccl(roms_hip_ctx *c, const void *id128, int nranks
   c->comm.nccl = (void *)comm;
   return 0;
 }
+// ---- mailbox transport: receive slots in uncached device memory, mapped by the neighbours ----
+namespace {
+struct PeerBlob {              // 128 bytes, what roms_hip_peer_export hands out
+  hipIpcMemHandle_t handle;    // 64 bytes
+  long long pid;
+  unsigned long long raw;      // the slab's address in the exporting process (neighbour contexts of the same process)
+  unsigned long long bytes;
+  int device, planes;
+  unsigned magic, pad[7];
+};
+static_assert(sizeof(PeerBlob) == 128, "PeerBlob size");
+const unsigned PEER_MAGIC = 0x524d5042u;
+const size_t PEER_TABLE = 0, PEER_WORDS = 1024;   // slot table; arrival words [channel][direction][plane]; slots from the next 4 KB boundary
+const int g_opp[8] = {1, 0, 3, 2, 7, 6, 5, 4};
+}  // namespace
+extern "C" int roms_hip_peer_export(roms_hip_ctx *c, void *blob128) {
+  if (!c || !blob128) return 8;
+  TileComm &m = c->comm;
+  if (!m.peer_slab) {
+    const DGrid &G = c->G;
+    const char *ep = getenv("ROMS_HIP_PEER_PLANES");
+    m.peer_planes = ep ? atoi(ep) : 8 * (G.N + 1);
+    size_t off = (PEER_WORDS + (size_t)16 * m.peer_planes * sizeof(unsigned long long) + 4095) & ~(size_t)4095;
+    for (int ch = 0; ch < 2; ch++)
+      for (int par = 0; par < 2; par++)
+        for (int d = 0; d < 8; d++) {
+          m.peer_off[ch][par][d] = off;
+          if (m.nbr[d] < 0) continue;
+          const size_t w = d < 2 ? (size_t)3 * G.nj : (d < 4 ? (size_t)3 * G.ni : 9);
+          off += ((size_t)m.peer_planes * w * sizeof(double) + 255) & ~(size_t)255;
+        }
+    m.peer_bytes = off;
+    if (hipfail(hipExtMallocWithFlags(&m.peer_slab, m.peer_bytes, hipDeviceMallocUncached), "hipExtMallocWithFlags (mailbox slab)")) return 2;
+    if (hipfail(hipMemset(m.peer_slab, 0, m.peer_bytes), "hipMemset")) return 2;
+    if (hipfail(hipMemcpy((char *)m.peer_slab + PEER_TABLE, m.peer_off, sizeof(m.peer_off), hipMemcpyHostToDevice), "hipMemcpy")) return 2;
+    if (hipfail(hipHostMalloc((void **)&m.peer_err, sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc")) return 2;
+    *m.peer_err = 0;
+    if (hipfail(hipDeviceSynchronize(), "hipDeviceSynchronize")) return 2;
+  }
+  PeerBlob b;
+  memset(&b, 0, sizeof(b));
+  if (hipfail(hipIpcGetMemHandle(&b.handle, m.peer_slab), "hipIpcGetMemHandle")) return 2;
+  b.pid = (long long)getpid();
+  b.raw = (unsigned long long)(uintptr_t)m.peer_slab;
+  b.bytes = m.peer_bytes;
+  b.device = c->cfg.device; b.planes = m.peer_planes; b.magic = PEER_MAGIC;
+  memcpy(blob128, &b, sizeof(b));
+  return 0;
+}
+extern "C" int roms_hip_comm_peer(roms_hip_ctx *c, const void *blobs128, int nranks, int rank) {
+  if (!c || !blobs128) return 8;
+  TileComm &m = c->comm;
+  if (nranks != c->cfg.NtileI * c->cfg.NtileJ || rank != c->cfg.tile) {
+    set_error("roms_hip_comm_peer: need nranks == NtileI*NtileJ and rank == tile");
+    return 5;
+  }
+  if (!m.peer_slab) { set_error("roms_hip_comm_peer: call roms_hip_peer_export on every rank first"); return 8; }
+  const PeerBlob *B = (const PeerBlob *)blobs128;
+  void *mapped[8] = {};
+  for (int d = 0; d < 8; d++) {
+    m.peer_map[d] = nullptr; m.peer_opened[d] = false;
+    const int r = m.nbr[d];
+    if (r < 0) continue;
+    if (r >= nranks || B[r].magic != PEER_MAGIC) { set_error("roms_hip_comm_peer: bad blob for a neighbour rank"); return 8; }
+    if (B[r].planes != m.peer_planes) { set_error("roms_hip_comm_peer: ranks differ in slot capacity"); return 5; }
+    for (int e = 0; e < d; e++)
+      if (m.nbr[e] == r) { m.peer_map[d] = m.peer_map[e]; break; }
+    if (!m.peer_map[d]) {
+      if (B[r].pid == (long long)getpid()) m.peer_map[d] = (void *)(uintptr_t)B[r].raw;   // a context of this process (or myself)
+      else {
+        if (hipfail(hipIpcOpenMemHandle(&m.peer_map[d], B[r].handle, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle (neighbour's mailbox)")) return 2;
+        m.peer_opened[d] = true;
+      }
+    }
+    size_t table[2][2][8];
+    if (hipfail(hipMemcpy(table, (char *)m.peer_map[d] + PEER_TABLE, sizeof(table), hipMemcpyDeviceToHost), "hipMemcpy (neighbour's slot table)")) return 2;
+    for (int ch = 0; ch < 2; ch++)
+      for (int par = 0; par < 2; par++) m.peer_noff[d][ch][par] = table[ch][par][g_opp[d]];
+  }
+  (void)mapped;
+  m.peer_seq[0] = m.peer_seq[1] = 0;
+  m.peer_on = true;
+  { const char *et = getenv("ROMS_HIP_PEER_THREADS"); c->peer_threads = et ? atoi(et) : 1024; }
+  return 0;
+}
 static void comm_destroy(roms_hip_ctx *c) {
   if (c->comm.nccl && g_rccl.lib) (void)g_rccl.CommDestroy((ncclComm_t)c->comm.nccl);
   c->comm.nccl = nullptr;
+  TileComm &m = c->comm;
+  for (int d = 0; d < 8; d++)
+    if (m.peer_opened[d]) { (void)hipIpcCloseMemHandle(m.peer_map[d]); m.peer_opened[d] = false; }
+  if (m.peer_slab) (void)hipFree(m.peer_slab);
+  if (m.peer_err) (void)hipHostFree(m.peer_err);
+  m.peer_slab = nullptr; m.peer_err = nullptr; m.peer_on = false;
 }
 #else
+extern "C" int roms_hip_peer_export(roms_hip_ctx *, void *) { set_error("the mailbox transport is not part of the CPU-emulated test build"); return 2; }
+extern "C" int roms_hip_comm_peer(roms_hip_ctx *, const void *, int, int) {
+  set_error("the mailbox transport is not part of the CPU-emulated test build");
+  return 2;
+}
 extern "C" int roms_hip_rccl_unique_id(void *) { set_error("RCCL is not part of the CPU-emulated test build"); return 2; }
 extern "C" int roms_hip_comm_rccl(roms_hip_ctx *, const void *, int, int) {
   set_error("RCCL is not part of the CPU-emulated test build");
@@ -817,14 +919,18 @@ void halo_fence(roms_hip_ctx *c, unsigned groups) {
 // fill + pack launch, one group of sends/receives with the up to eight neighbours, unpack launch.
 static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
   TileComm &m = c->comm;
-  if (!m.fn && !m.nccl) {
-    set_error("multi-tile context without a transport: call roms_hip_comm_rccl or roms_hip_set_exchange first");
+  if (!m.fn && !m.nccl && !m.peer_on) {
+    set_error("multi-tile context without a transport: call roms_hip_comm_rccl, roms_hip_comm_peer or roms_hip_set_exchange first");
     return 8;
   }
   const DGrid &G = c->G;
   const size_t lines = (size_t)(G.ni > G.nj ? G.ni : G.nj);
   const size_t need = (size_t)planes * lines * 3;
-  if (need > m.cap) {
+  if (m.peer_on && planes > m.peer_planes) {
+    set_error("mailbox transport: an exchange point carries more planes than a slot holds (ROMS_HIP_PEER_PLANES)");
+    return 8;
+  }
+  if (need > m.cap && !m.peer_on) {
     (void)dsync(c->stream);
 #ifndef ROMS_CPU_EMU
     if (c->xstream) (void)hipStreamSynchronize(c->xstream);   // an exchange in flight still uses the old buffers
@@ -884,6 +990,34 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
 #else
   const bool async = false;
 #endif
+#ifndef ROMS_CPU_EMU
+  if (m.peer_on) {
+    // two launches: the pack kernel stores into the neighbours' slots and releases their arrival words, the
+    // unpack kernel waits for mine (k_halo.h:xchg_peer_pack/unpack)
+    const int ch = async ? 1 : 0;
+    const unsigned long long seq = ++m.peer_seq[ch];
+    const int par = (int)(seq & 1);
+    static long long timeout = 0;
+    if (!timeout) { const char *et = getenv("ROMS_HIP_PEER_TIMEOUT"); timeout = (long long)((et ? atof(et) : 20.0) * 1.0e8); }
+    XchgPeerArgs pa;
+    pa.x = a;
+    pa.s.seq = seq; pa.s.err = m.peer_err; pa.s.timeout = timeout;
+    pa.x.unpack = 0; pa.x.fill = 1;
+    for (int d = 0; d < 8; d++) {
+      const bool on = m.nbr[d] >= 0;
+      pa.x.buf[d] = on ? (double *)((char *)m.peer_map[d] + m.peer_noff[d][ch][par]) : nullptr;
+      pa.s.word[d] = on ? (unsigned long long *)((char *)m.peer_map[d] + PEER_WORDS) + (size_t)(ch * 8 + g_opp[d]) * m.peer_planes : nullptr;
+    }
+    KPROF_WRAP(xchg_peer_pack, xs, hipLaunchKernelGGL(xchg_peer_pack, dim3(1, 1, (unsigned)planes), dim3(c->peer_threads), 0, xs, pa));
+    pa.x.unpack = 1; pa.x.fill = 0;
+    for (int d = 0; d < 8; d++) {
+      const bool on = m.nbr[d] >= 0;
+      pa.x.buf[d] = on ? (double *)((char *)m.peer_slab + m.peer_off[ch][par][d]) : nullptr;
+      pa.s.word[d] = on ? (unsigned long long *)((char *)m.peer_slab + PEER_WORDS) + (size_t)(ch * 8 + d) * m.peer_planes : nullptr;
+    }
+    KPROF_WRAP(xchg_peer_unpack, xs, hipLaunchKernelGGL(xchg_peer_unpack, dim3(1, 1, (unsigned)planes), dim3(c->peer_threads), 0, xs, pa));
+  } else {
+#endif
   a.unpack = 0; a.fill = 1;
   for (int d = 0; d < 8; d++) a.buf[d] = m.nbr[d] >= 0 ? m.sbuf[d] : nullptr;
   LAUNCH_COOP(xchg_kernel, 1, 1, planes, 256, 0, xs, a);
@@ -919,6 +1053,7 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
   for (int d = 0; d < 8; d++) a.buf[d] = m.nbr[d] >= 0 ? m.rbuf[d] : nullptr;
   LAUNCH_COOP(xchg_kernel, 1, 1, planes, 256, 0, xs, a);
 #ifndef ROMS_CPU_EMU
+  }
   if (async) {
     const int e = c->ev_x_next;
     c->ev_x_next = (e + 1) % 32;

@@ -28,12 +28,24 @@ struct TileComm {
   roms_hip_exchange_fn fn;      // user transport (MPI, gloo ...) or null
   void *user;
   void *nccl;                   // ncclComm_t of the built-in RCCL transport or null
+  // mailbox transport (roms_hip_comm_peer): my slab, the neighbours' slabs as mapped here, slot tables
+  void *peer_slab;              // uncached device memory: slot table, arrival words [channel][direction][plane], then the receive buffers [channel][parity][direction]
+  size_t peer_bytes;
+  int peer_planes;              // capacity of a slot in planes
+  size_t peer_off[2][2][8];     // byte offsets of MY slots (same table in the slab's header for the neighbours)
+  void *peer_map[8];            // neighbour d's slab in this process's address space (null: none)
+  size_t peer_noff[8][2][2];    // offset in neighbour d's slab of the slot my message to it goes into (its direction opp[d])
+  bool peer_opened[8];          // mapped with hipIpcOpenMemHandle (closed at destroy)
+  unsigned long long peer_seq[2];   // exchanges issued per channel (0: compute stream, 1: exchange stream)
+  unsigned long long *peer_err; // pinned host word: set by an unpack kernel whose message did not arrive in time
+  bool peer_on;
   long nexchanges;
 };
 
 struct roms_hip_ctx {
   roms_hip_config cfg;
   TileComm comm;
+  int peer_threads;             // block size of the mailbox pack/unpack kernels
   bool comm_failed;             // a halo exchange failed (reported by the next ctx_check)
   bool has_exchange;            // some neighbour is reached through the transport (multi-tile, or the self-exchange test aid)
   bool swdk_ready;              // main3d_one has launched k_swdk already (side stream): run_pre_step3d skips it

@@ -5,6 +5,8 @@ moves ghost strips with mp_exchange2d/3d/4d.  Here every rank builds the (cheap,
 set-up with the Fortran host, uploads only its tile's window to its GPU and installs a halo
 transport on the device context:
 
+  "peer"  the library's mailbox transport: neighbours' receive slots mapped over xGMI (hipIpc), two launches per
+          exchange point, no send/receive calls
   "rccl"  the library's built-in RCCL send/recv on its own HIP stream (multi-GPU runs); the RCCL
           unique id is created on rank 0 and broadcast through torch.distributed
   "dist"  a callback that moves the strips with torch.distributed isend/irecv on host tensors --
@@ -63,12 +65,16 @@ class TiledRun:
             transport = transport or "rccl"
             if transport == "rccl":
                 self._install_rccl()
+            elif transport == "peer":
+                self._install_peer()
             else:
                 self._install_dist(staged=(transport == "dist_staged"))
         if world > 1:
             transport = transport or "rccl"
             if transport == "rccl":
                 self._install_rccl()
+            elif transport == "peer":
+                self._install_peer()
             elif transport == "dist":
                 self._install_dist()
             elif transport == "dist_staged":
@@ -91,6 +97,25 @@ class TiledRun:
         else:
             raw = bytes(uid)
         self.ctx._ck(L.roms_hip_comm_rccl(self.ctx.h, raw, self.world, self.rank))
+
+    def _install_peer(self):
+        """The mailbox transport (include/roms_hip.h:roms_hip_comm_peer): every rank exports its slab, the 128-byte
+        blobs travel through torch.distributed, each rank maps its neighbours' slabs."""
+        L = self.ctx.L
+        blob = (C.c_ubyte * 128)()
+        self.ctx._ck(L.roms_hip_peer_export(self.ctx.h, blob))
+        if self.world > 1:
+            import torch
+            dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+            mine = torch.tensor(list(blob), dtype=torch.uint8, device=dev)
+            every = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(every, mine)
+            raw = b"".join(bytes(t.cpu().tolist()) for t in every)
+        else:
+            raw = bytes(blob)
+        self.ctx._ck(L.roms_hip_comm_peer(self.ctx.h, raw, self.world, self.rank))
+        if self.world > 1:
+            self.dist.barrier()          # nobody starts before every slab is mapped
 
     def _install_dist(self, staged=False):
         import torch

@@ -24,7 +24,7 @@ def main():
     cs.update(spec.get("case_update", {}))        # output keywords (NHIS, HISNAME, Hout ...), tests/test_output.py
     emu = os.path.join(ROOT, "tests", "emu")
     if spec.get("gpu"):      # real HIP build, all ranks on cuda:0, strips staged through the host
-        run = tiling.TiledRun(cs, rank=rank, world=world, device=0, dist=dist, transport="dist_staged", weak=False,
+        run = tiling.TiledRun(cs, rank=rank, world=world, device=0, dist=dist, transport=spec.get("transport", "dist_staged"), weak=False,
                               tiles=tuple(spec["tiles"]))
     else:
         run = tiling.TiledRun(cs, rank=rank, world=world, dist=dist, transport="dist", weak=False,
