@@ -231,6 +231,12 @@ int roms_hip_rccl_unique_id(void *id128);
 int roms_hip_comm_rccl(roms_hip_ctx *ctx, const void *id128, int nranks, int rank);
 int roms_hip_peer_export(roms_hip_ctx *ctx, void *blob128);
 int roms_hip_comm_peer(roms_hip_ctx *ctx, const void *blobs128, int nranks, int rank);
+/* self-check of the installed transport: `reps` exchanges of a work plane coded with the global indices of its
+   points; every ghost point received from a neighbour must hold the code of the point it images.  0, or exit_flag 2
+   with the first wrong point in roms_hip_last_error.  roms_hip_comm_reset removes the installed transport (after a
+   failed probe the caller may install another one). */
+int roms_hip_exchange_probe(roms_hip_ctx *ctx, int reps);
+int roms_hip_comm_reset(roms_hip_ctx *ctx);
 /* number of halo exchanges performed so far (0 for a single-tile context) */
 long roms_hip_exchange_count(roms_hip_ctx *ctx);
 

@@ -1085,6 +1085,75 @@ void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n) {
   }
 }
 
+// Self-check of the installed transport: `reps` exchanges of a work plane whose own points carry a code of their
+// global indices and of the repetition; afterwards every ghost point that comes from a neighbour's own points must
+// hold the code of the point it images (tile arrays are indexed globally, so that is its own index, wrapped where the
+// domain is periodic).  Multi-GPU runs call it once after installing a transport (roms_amd/tiling.py): a mapping that
+// does not carry the data, a stale cache line or a lost message shows up here, with a message, not in the fields.
+extern "C" int roms_hip_exchange_probe(roms_hip_ctx *c, int reps) {
+  if (!c) return 8;
+  if (!c->has_exchange) return 0;
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  const TileComm &m = c->comm;
+  const size_t n = (size_t)G.ni * (size_t)G.nj;
+  std::vector<double> h(n), g(n);
+  double *A = c->F.wrk2[0];
+  auto at = [&](int i, int j) -> size_t { return (size_t)(i - G.LBi) + (size_t)(j - G.LBj) * (size_t)G.ni; };
+  auto code = [&](int i, int j, int rep) -> double {
+    if (i < 1) i += G.Lm; else if (i > G.Lm) i -= G.Lm;
+    if (j < 1) j += G.Mm; else if (j > G.Mm) j -= G.Mm;
+    return (double)rep * 67108864.0 + (double)j * 8192.0 + (double)i;
+  };
+  const int ng = G.Nghost;
+  for (int rep = 1; rep <= reps; rep++) {
+    for (size_t k = 0; k < n; k++) h[k] = -1.0;
+    for (int j = B.Jstr; j <= B.Jend; j++)
+      for (int i = B.Istr; i <= B.Iend; i++) h[at(i, j)] = code(i, j, rep);
+    int r = h2d(A, h.data(), n * sizeof(double), c->stream);
+    if (r) return r;
+    HaloSpec sp = {A, 1, BC_NONE, 'r'};
+    launch_halo_multi(c, &sp, 1);
+    r = ctx_check(c, "exchange probe");
+    if (r) return r;
+    r = d2h(g.data(), A, n * sizeof(double), c->stream);
+    if (r) return r;
+    r = ctx_check(c, "exchange probe");
+    if (r) return r;
+    for (int d = 0; d < 8; d++) {
+      if (m.nbr[d] < 0) continue;
+      const int dx = (d == 0 || d == 4 || d == 6) ? -1 : ((d == 1 || d == 5 || d == 7) ? 1 : 0);
+      const int dy = (d == 2 || d == 4 || d == 5) ? -1 : ((d == 3 || d == 6 || d == 7) ? 1 : 0);
+      const int i0 = dx == 0 ? B.Istr : (dx < 0 ? B.Istr - 3 : B.Iend + 1), i1 = dx == 0 ? B.Iend : (dx < 0 ? B.Istr - 1 : B.Iend + ng);
+      const int j0 = dy == 0 ? B.Jstr : (dy < 0 ? B.Jstr - 3 : B.Jend + 1), j1 = dy == 0 ? B.Jend : (dy < 0 ? B.Jstr - 1 : B.Jend + ng);
+      for (int j = j0; j <= j1; j++)
+        for (int i = i0; i <= i1; i++)
+          if (g[at(i, j)] != code(i, j, rep)) {
+            char msg[256];
+            snprintf(msg, sizeof(msg), "exchange probe: tile %d, repetition %d, ghost point (%d,%d) from neighbour %d (rank %d) holds %.17g, expected %.17g",
+                     c->cfg.tile, rep, i, j, d, m.nbr[d], g[at(i, j)], code(i, j, rep));
+            set_error(msg);
+            return 2;
+          }
+    }
+  }
+  return 0;
+}
+
+// Back to no transport (a failed probe: the caller installs another one).  The mailbox slab stays allocated.
+extern "C" int roms_hip_comm_reset(roms_hip_ctx *c) {
+  if (!c) return 8;
+  (void)dsync(c->stream);
+#ifndef ROMS_CPU_EMU
+  if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+  if (c->comm.peer_err) *c->comm.peer_err = 0;
+#endif
+  c->comm.peer_on = false;
+  c->comm.fn = nullptr;
+  c->comm_failed = false;
+  return 0;
+}
+
 void launch_halo_tail(roms_hip_ctx *c, const HaloSpec *sp, int n) {
   c->x_tail = true;
   launch_halo_multi(c, sp, n);

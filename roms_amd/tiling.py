@@ -7,6 +7,8 @@ transport on the device context:
 
   "peer"  the library's mailbox transport: neighbours' receive slots mapped over xGMI (hipIpc), two launches per
           exchange point, no send/receive calls
+  "auto"  (default for world > 1; ROMS_HIP_TRANSPORT overrides) "peer" if every rank can map its neighbours and the
+          index-coded probe exchange (roms_hip_exchange_probe) arrives intact everywhere, else "rccl"
   "rccl"  the library's built-in RCCL send/recv on its own HIP stream (multi-GPU runs); the RCCL
           unique id is created on rank 0 and broadcast through torch.distributed
   "dist"  a callback that moves the strips with torch.distributed isend/irecv on host tensors --
@@ -70,8 +72,10 @@ class TiledRun:
             else:
                 self._install_dist(staged=(transport == "dist_staged"))
         if world > 1:
-            transport = transport or "rccl"
-            if transport == "rccl":
+            transport = transport or os.environ.get("ROMS_HIP_TRANSPORT", "auto")
+            if transport == "auto":
+                transport = self._install_auto()
+            elif transport == "rccl":
                 self._install_rccl()
             elif transport == "peer":
                 self._install_peer()
@@ -81,9 +85,48 @@ class TiledRun:
                 self._install_dist(staged=True)
             else:
                 raise ValueError(transport)
+        self.transport = transport
         self.host.start()
 
     # ------------------------------------------------------------------ transports
+    def _all_ok(self, ok):
+        """True when every rank says so."""
+        import torch
+        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def probe(self, reps=4):
+        """roms_hip_exchange_probe on every rank: index-coded planes through the installed transport."""
+        L = self.ctx.L
+        rc = L.roms_hip_exchange_probe(self.ctx.h, reps)
+        return rc == 0, (L.roms_hip_last_error() or b"").decode() if rc else ""
+
+    def _install_auto(self):
+        """The mailbox transport where it works -- every rank could map its neighbours' slabs and the index-coded probe
+        planes arrived intact on all of them -- otherwise the RCCL send/recv groups, probed the same way.  Both are
+        device-to-device transports of this library; which one runs is reported in `self.transport`."""
+        import sys
+        ok, why = True, ""
+        try:
+            self._install_peer()
+        except hiplib.RomsHipError as e:
+            ok, why = False, str(e)
+        if self._all_ok(ok):
+            ok, why = self.probe()
+            if self._all_ok(ok):
+                return "peer"
+        if self.rank == 0 or why:
+            print(f"[roms_amd] rank {self.rank}: mailbox transport not usable ({why or 'another rank failed'}); using RCCL send/recv",
+                  file=sys.stderr, flush=True)
+        self.ctx._ck(self.ctx.L.roms_hip_comm_reset(self.ctx.h))
+        self._install_rccl()
+        ok, why = self.probe()
+        if not self._all_ok(ok):
+            raise hiplib.RomsHipError("exit_flag=2: " + (why or "halo exchange probe failed on another rank"))
+        return "rccl"
+
     def _install_rccl(self):
         L = self.ctx.L
         uid = (C.c_ubyte * 128)()
@@ -103,7 +146,8 @@ class TiledRun:
         blobs travel through torch.distributed, each rank maps its neighbours' slabs."""
         L = self.ctx.L
         blob = (C.c_ubyte * 128)()
-        self.ctx._ck(L.roms_hip_peer_export(self.ctx.h, blob))
+        rc = L.roms_hip_peer_export(self.ctx.h, blob)      # (a failure is raised after the collective below)
+        err = (L.roms_hip_last_error() or b"").decode() if rc else ""
         if self.world > 1:
             import torch
             dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
@@ -113,9 +157,13 @@ class TiledRun:
             raw = b"".join(bytes(t.cpu().tolist()) for t in every)
         else:
             raw = bytes(blob)
-        self.ctx._ck(L.roms_hip_comm_peer(self.ctx.h, raw, self.world, self.rank))
+        if rc == 0:
+            rc = L.roms_hip_comm_peer(self.ctx.h, raw, self.world, self.rank)
+            err = (L.roms_hip_last_error() or b"").decode() if rc else ""
         if self.world > 1:
             self.dist.barrier()          # nobody starts before every slab is mapped
+        if rc:
+            raise hiplib.RomsHipError(f"exit_flag={rc}: {err}")
 
     def _install_dist(self, staged=False):
         import torch

@@ -30,6 +30,9 @@ def main():
         run = tiling.TiledRun(cs, rank=rank, world=world, dist=dist, transport="dist", weak=False,
                               tiles=tuple(spec["tiles"]), host_lib=os.path.join(emu, "libroms_host_emu.so"),
                               hip_lib=os.path.join(emu, "libroms_hip_emu.so"))
+    if spec.get("probe"):                          # the transport's self-check before anything else moves
+        ok, why = run.probe(3)
+        assert ok, why
     if spec.get("restart_from"):                   # every rank reads the restart file and uploads its window
         run.get_state(spec["restart_from"], 0)
     if spec.get("advance"):                        # steps with the history / restart records of output.F
@@ -41,6 +44,7 @@ def main():
     d = run.diag()
     nx = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
     if rank == 0:
+        print("TRANSPORT", getattr(run, "transport", None), flush=True)
         np.savez(out, nexchanges=nx, diag=np.array([d["avgke"], d["avgpe"], d["volume"], d["maxspeed"]]), **res)
     run.close()
     dist.barrier()

@@ -1,5 +1,6 @@
-"""Ad-hoc: doubly periodic single tile, every ghost exchange through RCCL with the tile as its own eight
-neighbours (8 sends + 8 receives to the same peer in one group), against the local periodic copies."""
+"""Doubly periodic single tile, every ghost exchange through the transport given on the command line (rccl: 8 sends
++ 8 receives to the same peer in one group; peer: the mailbox slots) with the tile as its own eight neighbours,
+against the local periodic copies."""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import numpy as np
@@ -9,7 +10,7 @@ cs = bench.params_for("upwelling", 48, 40, 10)
 cs["NSperiodic"] = 1
 cs["ninfo"] = 1
 names = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "Huon", "Hvom"]
-run = tiling.TiledRun(cs, self_exchange=True, transport="rccl")
+run = tiling.TiledRun(cs, self_exchange=True, transport=sys.argv[1] if len(sys.argv) > 1 else "rccl")
 run.step(3); run.sync()
 nx = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
 got = {n: run.ctx.download(n).copy() for n in names}

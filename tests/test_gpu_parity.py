@@ -666,3 +666,85 @@ def test_logarithmic_bottom_drag_matches_oracle():
 def hiplib_options():
     from roms_amd import hiplib
     return hiplib.OPTIONS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"ROMS_HIP_XASYNC": "1"}, {"ROMS_HIP_PEER_THREADS": "64"}])
+def test_mailbox_self_exchange_matches_local_periodic_copy(env):
+    """The mailbox transport (include/roms_hip.h:roms_hip_comm_peer) on one GPU with the tile as its own neighbours:
+    west/east (BENCHMARK walls north and south: boundary fills before the pack) and all eight (doubly periodic);
+    on the compute stream, with the 3-D exchanges on the exchange stream (second channel of slots), and with blocks
+    too small for the all-loads-first form (the general loops).  Fields equal the local periodic copies bit for bit."""
+    import subprocess
+    import sys
+    import textwrap
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import bench
+        from roms_amd import tiling
+        cs = bench.params_for("benchmark1", 96, 32, 10)
+        cs["ninfo"] = 1
+        run = tiling.TiledRun(cs, self_exchange=True, transport="peer")
+        run.step(3)
+        run.sync()
+        nx = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
+        assert nx > 100, nx
+        got = {n: run.ctx.download(n).copy() for n in %r}
+        run.close()
+        ref = tiling.TiledRun(cs)
+        ref.step(3)
+        ref.sync()
+        for n, g in got.items():
+            assert np.array_equal(g, ref.ctx.download(n)), n
+        ref.close()
+        print("MAILBOX-SELF-OK", nx)
+    """) % (ROOT, ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "rho", "Akv", "Huon", "DU_avg1"])
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=300)
+    assert "MAILBOX-SELF-OK" in r.stdout, (env, r.stdout[-1500:] + r.stderr[-3000:])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mp", "selfx8.py"), "peer"], capture_output=True, text=True,
+                       env=e, timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("SELFX8")]
+    assert line and "finite True mismatching []" in line[-1], (env, r.stdout[-1500:] + r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,kw,tiles,port", [("upwelling_small", {}, (2, 1), 29731), ("benchmark_small", {}, (2, 2), 29732),
+                                                ("upwelling_small", {"hadv": ("MPDATA", "MPDATA"), "vadv": ("MPDATA", "MPDATA")}, (2, 2), 29733),
+                                                ("benchmark_small", {}, (4, 2), 29734)])
+def test_mailbox_tiles_on_one_gpu_match_single_tile(tmp_path, tag, kw, tiles, port):
+    """The mailbox transport between PROCESSES: NtileI x NtileJ ranks share cuda:0, every rank maps its neighbours'
+    slabs with hipIpcOpenMemHandle, the pack kernels store into them, the unpack kernels wait for the arrival words
+    (kernels of different processes run side by side on the device).  Gathered fields equal the single-tile GPU run
+    bit for bit.  Over xGMI the same code path runs with one GPU per rank (not available to this test)."""
+    import json
+    import subprocess
+    import sys
+    from roms_amd import tiling
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    fields = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "Huon", "rho", "Akv", "DU_avg1"]
+    steps = 4
+    cs = util.case_for(tag, **kw)
+    cs["ninfo"] = 0
+    run = tiling.TiledRun(cs, weak=False)
+    run.step(steps)
+    ref = {n: run.gather(n) for n in fields}
+    run.close()
+    out = str(tmp_path / "tiles_gpu.npz")
+    # "auto" on the first case: the mailbox must pass the index-coded probe and be the transport chosen
+    spec = dict(tag=tag, kw=kw, steps=steps, tiles=list(tiles), fields=fields, gpu=True, probe=True,
+                transport="auto" if tiles == (2, 1) else "peer")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={tiles[0] * tiles[1]}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "mp", "run_tiles.py"), out, json.dumps(spec)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", ROMS_HIP_PEER_TIMEOUT="10"))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "TRANSPORT peer" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    got = dict(np.load(out))
+    assert int(got["nexchanges"]) > 50 * steps
+    for n in fields:
+        assert np.array_equal(got[n], ref[n]), (n, float(np.abs(got[n] - ref[n]).max()))

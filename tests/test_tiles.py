@@ -35,7 +35,7 @@ def _single(tag, kw, steps):
 
 def _tiled(tmp_path, tag, kw, steps, tiles, port, kernels=False):
     out = str(tmp_path / f"tiles_{tiles[0]}x{tiles[1]}.npz")
-    spec = dict(tag=tag, kw=kw, steps=steps, tiles=list(tiles), fields=FIELDS, kernels=kernels)
+    spec = dict(tag=tag, kw=kw, steps=steps, tiles=list(tiles), fields=FIELDS, kernels=kernels, probe=True)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={tiles[0] * tiles[1]}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "mp", "run_tiles.py"), out, json.dumps(spec)]
