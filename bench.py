@@ -466,7 +466,8 @@ def main():
             "config": {"workload": f"{cs['app'].upper()} {run.global_Lm}x{run.global_Mm}x{cs['N']} "
                                    f"(tile {cs['Lm']}x{cs['Mm']}x{cs['N']} per GPU), dt={cs['dt']:g}s ndtfast={cs['ndtfast']}, "
                                    "analytic grid/initial/forcing, full application physics",
-                       "tiles": f"{run.NtileI}x{run.NtileJ}", "nfast": run.nfast},
+                       "tiles": f"{run.NtileI}x{run.NtileJ}", "nfast": run.nfast,
+                       "halo_transport": getattr(run, "transport", None) if world > 1 else "none (single tile)"},
             "roofline": roofline,
             "north_star_pair": pair,
         }

@@ -301,4 +301,8 @@ class TiledRun:
         self.host.get_state(path, rec)
 
     def close(self):
+        if self.world > 1 and getattr(self, "transport", None) == "peer":
+            # the neighbours' kernels store into this rank's slab: nobody frees it while a neighbour may still be running
+            self.ctx.sync()
+            self.dist.barrier()
         self.host.finalize()
