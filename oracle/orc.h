@@ -40,6 +40,7 @@ enum {
   ORC_LMD_MIXING = 1 << 8, ORC_BULK_FLUXES = 1 << 9, ORC_SOLAR_SOURCE = 1 << 10,
   ORC_ANA_VMIX = 1 << 11, ORC_SALINITY = 1 << 12, ORC_SPHERICAL = 1 << 13,
   ORC_UV_LOGDRAG = 1 << 14,  /* set_vbc.F:591-635 */
+  ORC_MASKING = 1 << 15,     /* land/sea masks rmask, umask, vmask, pmask (mod_grid.F) */
   ORC_APP_UPWELLING = 1 << 20, ORC_APP_BENCHMARK = 1 << 21
 };
 
@@ -107,7 +108,8 @@ typedef struct orc_s {
   /* mod_grid 2-D */
   double *h, *f, *fomn, *pm, *pn, *om_r, *on_r, *om_u, *on_u, *om_v, *on_v, *om_p, *on_p,
       *omn, *pmon_r, *pnom_r, *pmon_p, *pnom_p, *pmon_u, *pnom_u, *pmon_v, *pnom_v,
-      *dmde, *dndx, *angler, *xr, *yr, *lonr, *latr, *rdrag, *rdrag2;
+      *dmde, *dndx, *angler, *xr, *yr, *lonr, *latr, *rdrag, *rdrag2,
+      *rmask, *umask, *vmask, *pmask;      /* MASKING: 1 water, 0 land (pmask: 2 no-slip); all 1 otherwise */
   /* mod_grid 3-D */
   double *Hz, *z_r, *z_w, *Huon, *Hvom;
   /* mod_ocean */

@@ -120,7 +120,7 @@ static const fdesc fields[] = {
   FD(omn, K2), FD(pmon_r, K2), FD(pnom_r, K2), FD(pmon_p, K2), FD(pnom_p, K2),
   FD(pmon_u, K2), FD(pnom_u, K2), FD(pmon_v, K2), FD(pnom_v, K2), FD(dmde, K2), FD(dndx, K2),
   FD(angler, K2), FD(xr, K2), FD(yr, K2), FD(lonr, K2), FD(latr, K2), FD(rdrag, K2),
-  FD(rdrag2, K2),
+  FD(rdrag2, K2), FD(rmask, K2), FD(umask, K2), FD(vmask, K2), FD(pmask, K2),
   FD(Hz, KR), FD(z_r, KR), FD(z_w, KW), FD(Huon, KR), FD(Hvom, KR),
   FD(zeta, K2x3), FD(ubar, K2x3), FD(vbar, K2x3), FD(rzeta, K2x2), FD(rubar, K2x2),
   FD(rvbar, K2x2), FD(u, KRx2), FD(v, KRx2), FD(t, KTR), FD(W, KW), FD(wvel, KW),
@@ -168,6 +168,7 @@ orc_t *orc_create(const orc_cfg *cfg) {
   for (int t = 0; t < o->ntiles; t++) orc_tile_bounds(&o->c, t, &o->b[t]);
   for (size_t k = 0; k < NFIELDS; k++)
     *(double **)((char *)o + fields[k].off) = dalloc(field_size(o, fields[k].kind));
+  for (size_t k = 0; k < o->nij; k++) o->rmask[k] = o->umask[k] = o->vmask[k] = o->pmask[k] = 1.0;   /* all water */
   o->ksbl = (int *)calloc(o->nij, sizeof(int));
   return o;
 }
@@ -320,8 +321,9 @@ void orc_bc_u2d(const orc_t *o, const orc_bounds *b, double *A) {
   }
   if (!o->c.NSperiodic) {
     int Imin = o->c.EWperiodic ? b->IstrU : b->Istr, Imax = o->c.EWperiodic ? b->Iend : b->IendR;
-    if (b->north) for (int i = Imin; i <= Imax; i++) A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)];
-    if (b->south) for (int i = Imin; i <= Imax; i++) A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)];
+    const double *M = (o->c.options & ORC_MASKING) ? o->umask : NULL;   /* bc_2d.F:252,278 */
+    if (b->north) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
+    if (b->south) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
   }
   if (!(o->c.EWperiodic || o->c.NSperiodic)) {
     if (b->sw) A[X2(Istr, Jstr - 1)] = 0.5 * (A[X2(Istr + 1, Jstr - 1)] + A[X2(Istr, Jstr)]);
@@ -339,8 +341,9 @@ void orc_bc_v2d(const orc_t *o, const orc_bounds *b, double *A) {
   const double gamma2 = o->c.gamma2;
   if (!o->c.EWperiodic) {
     int Jmin = o->c.NSperiodic ? b->JstrV : b->Jstr, Jmax = o->c.NSperiodic ? b->Jend : b->JendR;
-    if (b->east) for (int j = Jmin; j <= Jmax; j++) A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)];
-    if (b->west) for (int j = Jmin; j <= Jmax; j++) A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)];
+    const double *M = (o->c.options & ORC_MASKING) ? o->vmask : NULL;   /* bc_2d.F:392,418 */
+    if (b->east) for (int j = Jmin; j <= Jmax; j++) { A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
+    if (b->west) for (int j = Jmin; j <= Jmax; j++) { A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
   }
   if (!o->c.NSperiodic) {
     if (b->north) for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = 0.0;
@@ -361,13 +364,14 @@ void orc_zetabc(const orc_t *o, const orc_bounds *b, int kout) {
   double *A = o->zeta + (size_t)(kout - 1) * o->nij;
   ORC_LOCALS(o);
   const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
+  const double *M = (o->c.options & ORC_MASKING) ? o->rmask : NULL;   /* MASKING: value * rmask(ghost point), zetabc.F:264 */
   if (!o->c.EWperiodic) {
-    if (b->west) for (int j = Jstr; j <= Jend; j++) A[X2(Istr - 1, j)] = A[X2(Istr, j)];
-    if (b->east) for (int j = Jstr; j <= Jend; j++) A[X2(Iend + 1, j)] = A[X2(Iend, j)];
+    if (b->west) for (int j = Jstr; j <= Jend; j++) { A[X2(Istr - 1, j)] = A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
+    if (b->east) for (int j = Jstr; j <= Jend; j++) { A[X2(Iend + 1, j)] = A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
   }
   if (!o->c.NSperiodic) {
-    if (b->south) for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr - 1)] = A[X2(i, Jstr)];
-    if (b->north) for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
+    if (b->south) for (int i = Istr; i <= Iend; i++) { A[X2(i, Jstr - 1)] = A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
+    if (b->north) for (int i = Istr; i <= Iend; i++) { A[X2(i, Jend + 1)] = A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
   }
   if (!(o->c.EWperiodic || o->c.NSperiodic)) {
     if (b->sw) A[X2(Istr - 1, Jstr - 1)] = 0.5 * (A[X2(Istr, Jstr - 1)] + A[X2(Istr - 1, Jstr)]);
@@ -389,8 +393,9 @@ static void ubc_plane(const orc_t *o, const orc_bounds *b, double *A) {
   }
   if (!o->c.NSperiodic) {
     int Imin = o->c.EWperiodic ? b->IstrU : b->Istr, Imax = o->c.EWperiodic ? b->Iend : b->IendR;
-    if (b->south) for (int i = Imin; i <= Imax; i++) A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)];
-    if (b->north) for (int i = Imin; i <= Imax; i++) A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)];
+    const double *M = (o->c.options & ORC_MASKING) ? o->umask : NULL;   /* u2dbc_im.F:989, u3dbc_im.F:520 */
+    if (b->south) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
+    if (b->north) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
   }
   if (!(o->c.EWperiodic || o->c.NSperiodic)) {
     if (b->sw) A[X2(Istr, Jstr - 1)] = 0.5 * (A[X2(Istr + 1, Jstr - 1)] + A[X2(Istr, Jstr)]);
@@ -407,8 +412,9 @@ static void vbc_plane(const orc_t *o, const orc_bounds *b, double *A) {
   const double gamma2 = o->c.gamma2;
   if (!o->c.EWperiodic) {
     int Jmin = o->c.NSperiodic ? b->JstrV : b->Jstr, Jmax = o->c.NSperiodic ? b->Jend : b->JendR;
-    if (b->west) for (int j = Jmin; j <= Jmax; j++) A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)];
-    if (b->east) for (int j = Jmin; j <= Jmax; j++) A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)];
+    const double *M = (o->c.options & ORC_MASKING) ? o->vmask : NULL;   /* v2dbc_im.F:1048, v3dbc_im.F */
+    if (b->west) for (int j = Jmin; j <= Jmax; j++) { A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
+    if (b->east) for (int j = Jmin; j <= Jmax; j++) { A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
   }
   if (!o->c.NSperiodic) {
     if (b->south) for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr)] = 0.0;
@@ -444,13 +450,14 @@ void orc_t3dbc(const orc_t *o, const orc_bounds *b, int nout, int itrc) {
     double *A = o->t + (((size_t)(nout - 1) + 3 * (size_t)(itrc - 1)) * N + k) * o->nij;
     const int LBi = o->c.LBi, LBj = o->c.LBj;
     const size_t ni = o->ni;
+    const double *M = (o->c.options & ORC_MASKING) ? o->rmask : NULL;   /* t3dbc_im.F:214 */
     if (!o->c.EWperiodic) {
-      if (b->west) for (int j = Jstr; j <= Jend; j++) A[X2(Istr - 1, j)] = A[X2(Istr, j)];
-      if (b->east) for (int j = Jstr; j <= Jend; j++) A[X2(Iend + 1, j)] = A[X2(Iend, j)];
+      if (b->west) for (int j = Jstr; j <= Jend; j++) { A[X2(Istr - 1, j)] = A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
+      if (b->east) for (int j = Jstr; j <= Jend; j++) { A[X2(Iend + 1, j)] = A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
     }
     if (!o->c.NSperiodic) {
-      if (b->south) for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr - 1)] = A[X2(i, Jstr)];
-      if (b->north) for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
+      if (b->south) for (int i = Istr; i <= Iend; i++) { A[X2(i, Jstr - 1)] = A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
+      if (b->north) for (int i = Istr; i <= Iend; i++) { A[X2(i, Jend + 1)] = A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
     }
     if (!(o->c.EWperiodic || o->c.NSperiodic)) {
       if (b->sw) A[X2(Istr - 1, Jstr - 1)] = 0.5 * (A[X2(Istr, Jstr - 1)] + A[X2(Istr - 1, Jstr)]);

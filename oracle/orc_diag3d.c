@@ -110,6 +110,7 @@ void orc_rho_eos(orc_t *o, int tile) {
         double r = R0 - R0 * Tcoef * (t[XT(i, j, k, nrhs, 1)] - T0);
         if (o->c.options & ORC_SALINITY) r = r + R0 * Scoef * (t[XT(i, j, k, nrhs, 2)] - S0);
         r = r - 1000.0;
+        if (o->c.options & ORC_MASKING) r = r * o->rmask[X2(i, j)];                         /* rho_eos.F:718 */
         rho[X3(i, j, k)] = r;
         pden[X3(i, j, k)] = r;
       }
@@ -171,6 +172,7 @@ void orc_set_vbc(orc_t *o, int tile) {
     for (int i = b->IstrR; i <= b->IendR; i++) {
       double EmP = o->stflux[X2T(i, j, 2)];
       o->stflx[X2T(i, j, 2)] = EmP * t[XT(i, j, N, nrhs, 2)];
+      if (o->c.options & ORC_MASKING) o->stflx[X2T(i, j, 2)] = o->rmask[X2(i, j)] * o->stflx[X2T(i, j, 2)];   /* set_vbc.F:399 */
       o->btflx[X2T(i, j, 2)] = o->btflx[X2T(i, j, 2)] * t[XT(i, j, 1, nrhs, 2)];
     }
   if (o->c.options & ORC_UV_LOGDRAG) {
@@ -397,7 +399,11 @@ void orc_ini_zeta(orc_t *o, int tile) {
   ORC_LOCALS(o);
   const orc_bounds *b = &o->b[tile];
   const int kstp = o->s.kstp;
-  /* the load zeta(kstp)=zeta(kstp) over IstrB:IendB is an identity without masks */
+  /* the load zeta(kstp)=zeta(kstp) over IstrB:IendB is an identity without masks; with them :838-849 */
+  if (o->c.options & ORC_MASKING)
+    for (int j = b->JstrB; j <= b->JendB; j++)
+      for (int i = b->IstrB; i <= b->IendB; i++)
+        o->zeta[X2T(i, j, kstp)] = o->zeta[X2T(i, j, kstp)] * o->rmask[X2(i, j)];
   orc_zetabc(o, b, kstp);
   orc_exchange2d(o, b, 'r', o->zeta + (size_t)(kstp - 1) * nij);
   for (int j = b->JstrT; j <= b->JendT; j++)
@@ -411,6 +417,14 @@ void orc_ini_fields(orc_t *o, int tile) {
   const orc_bounds *b = &o->b[tile];
   const int nstp = o->s.nstp, kstp = o->s.kstp;
   double *u = o->u, *v = o->v, *Hz = o->Hz;
+  const int msk = (o->c.options & ORC_MASKING) != 0;
+  if (msk)                                     /* the loads u(nstp)=u(nstp), v(nstp)=v(nstp) with masks :286-312 */
+    for (int j = b->JstrB; j <= b->JendB; j++)
+      for (int k = 1; k <= N; k++) {
+        for (int i = b->IstrM; i <= b->IendB; i++) u[X4(i, j, k, nstp)] = u[X4(i, j, k, nstp)] * o->umask[X2(i, j)];
+        if (j >= b->JstrM)
+          for (int i = b->IstrB; i <= b->IendB; i++) v[X4(i, j, k, nstp)] = v[X4(i, j, k, nstp)] * o->vmask[X2(i, j)];
+      }
   orc_u3dbc(o, b, nstp);
   orc_v3dbc(o, b, nstp);
   orc_exchange3d(o, b, 'u', u + (size_t)(nstp - 1) * nij * N, N);
@@ -429,6 +443,7 @@ void orc_ini_fields(orc_t *o, int tile) {
     for (int i = b->IstrM; i <= b->IendB; i++) {
       double cff1 = 1.0 / DCx(i, 0);
       double cff2 = CF[i - LBi] * cff1;
+      if (msk) cff2 = cff2 * o->umask[X2(i, j)];                          /* :376 */
       o->ubar[X2T(i, j, kstp)] = cff2;
     }
     if (j >= b->JstrM) {
@@ -442,6 +457,7 @@ void orc_ini_fields(orc_t *o, int tile) {
       for (int i = b->IstrB; i <= b->IendB; i++) {
         double cff1 = 1.0 / DCx(i, 0);
         double cff2 = CF[i - LBi] * cff1;
+        if (msk) cff2 = cff2 * o->vmask[X2(i, j)];                        /* :400 */
         o->vbar[X2T(i, j, kstp)] = cff2;
       }
     }
@@ -453,6 +469,12 @@ void orc_ini_fields(orc_t *o, int tile) {
   orc_v2dbc(o, b, kstp);
   orc_exchange2d(o, b, 'u', o->ubar + (size_t)(kstp - 1) * nij);
   orc_exchange2d(o, b, 'v', o->vbar + (size_t)(kstp - 1) * nij);
+  if (msk)                                                                /* t(nstp) * rmask :546-556 */
+    for (int it = 1; it <= o->c.NT; it++)
+      for (int k = 1; k <= N; k++)
+        for (int j = b->JstrB; j <= b->JendB; j++)
+          for (int i = b->IstrB; i <= b->IendB; i++)
+            o->t[XT(i, j, k, nstp, it)] = o->t[XT(i, j, k, nstp, it)] * o->rmask[X2(i, j)];
   for (int it = 1; it <= o->c.NT; it++) orc_t3dbc(o, b, nstp, it);
   for (int it = 1; it <= o->c.NT; it++)
     orc_exchange3d(o, b, 'r', o->t + ((size_t)(nstp - 1) + 3 * (size_t)(it - 1)) * nij * N, N);

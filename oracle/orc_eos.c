@@ -24,6 +24,7 @@ static const double A00 = +1.909256e+04, A01 = +2.098925e+02, A02 = -3.041638e+0
   V02 = -1.65460e-06, W00 = +4.8314e-04;
 
 void orc_eos_nonlinear(orc_t *o, int tile) {
+  const int msk = (o->c.options & ORC_MASKING) != 0;
   ORC_LOCALS(o);
   const orc_bounds *b = &o->b[tile];
   const int nrhs = o->s.nrhs;
@@ -77,6 +78,7 @@ void orc_eos_nonlinear(orc_t *o, int tile) {
         cff = 1.0 / (CX(bulk, i, k) + Tpr10);
         CX(den, i, k) = CX(den1, i, k) * CX(bulk, i, k) * cff;
         CX(den, i, k) = CX(den, i, k) - 1000.0;
+        if (msk) CX(den, i, k) = CX(den, i, k) * o->rmask[X2(i, j)];                       /* rho_eos.F:357 */
       }
     for (int i = b->IstrT; i <= b->IendT; i++) {
       cff1 = CX(den, i, N) * Hz[X3(i, j, N)];
@@ -128,6 +130,7 @@ void orc_eos_nonlinear(orc_t *o, int tile) {
       for (int i = b->IstrT; i <= b->IendT; i++) {
         o->rho[X3(i, j, k)] = CX(den, i, k);
         o->pden[X3(i, j, k)] = (CX(den1, i, k) - 1000.0);
+        if (msk) o->pden[X3(i, j, k)] = o->pden[X3(i, j, k)] * o->rmask[X2(i, j)];        /* :479 */
       }
   }
   free(W);

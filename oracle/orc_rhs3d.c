@@ -59,7 +59,10 @@ void orc_hadv_flux(const orc_t *o, const orc_bounds *b, int scheme, const double
   } else {
     /* AKIMA4, CENTERED4, SPLIT_U3, UPSTREAM3 */
     for (int j = Jstr; j <= Jend; j++)
-      for (int i = b->Istrm1; i <= b->Iendp2; i++) FX[X2(i, j)] = T[X2(i, j)] - T[X2(i - 1, j)];
+      for (int i = b->Istrm1; i <= b->Iendp2; i++) {
+        FX[X2(i, j)] = T[X2(i, j)] - T[X2(i - 1, j)];
+        if (o->c.options & ORC_MASKING) FX[X2(i, j)] = FX[X2(i, j)] * o->umask[X2(i, j)];   /* pre_step3d.F:411, step3d_t.F:646 */
+      }
     if (!o->c.EWperiodic) {
       if (b->west) for (int j = Jstr; j <= Jend; j++) FX[X2(Istr - 1, j)] = FX[X2(Istr, j)];
       if (b->east) for (int j = Jstr; j <= Jend; j++) FX[X2(Iend + 2, j)] = FX[X2(Iend + 1, j)];
@@ -89,7 +92,10 @@ void orc_hadv_flux(const orc_t *o, const orc_bounds *b, int scheme, const double
                          (T[X2(i - 1, j)] + T[X2(i, j)] - cff2 * (grad[X2(i, j)] - grad[X2(i - 1, j)]));
       }
     for (int j = b->Jstrm1; j <= b->Jendp2; j++)
-      for (int i = Istr; i <= Iend; i++) FE[X2(i, j)] = T[X2(i, j)] - T[X2(i, j - 1)];
+      for (int i = Istr; i <= Iend; i++) {
+        FE[X2(i, j)] = T[X2(i, j)] - T[X2(i, j - 1)];
+        if (o->c.options & ORC_MASKING) FE[X2(i, j)] = FE[X2(i, j)] * o->vmask[X2(i, j)];   /* pre_step3d.F:476, step3d_t.F:710 */
+      }
     if (!o->c.NSperiodic) {
       if (b->south) for (int i = Istr; i <= Iend; i++) FE[X2(i, Jstr - 1)] = FE[X2(i, Jstr)];
       if (b->north) for (int i = Istr; i <= Iend; i++) FE[X2(i, Jend + 2)] = FE[X2(i, Jend + 1)];
@@ -476,6 +482,10 @@ void orc_prsgrd(orc_t *o, int tile) {
       for (int i = IstrU - 1; i <= Iend + 1; i++) {
         aux[X2(i, j)] = z_r[X3(i, j, k)] - z_r[X3(i - 1, j, k)];
         FC[X2(i, j)] = rho[X3(i, j, k)] - rho[X3(i - 1, j, k)];
+        if (o->c.options & ORC_MASKING) {                                                   /* prsgrd32.h:316,320 */
+          aux[X2(i, j)] = aux[X2(i, j)] * o->umask[X2(i, j)];
+          FC[X2(i, j)] = FC[X2(i, j)] * o->umask[X2(i, j)];
+        }
       }
     for (int j = Jstr; j <= Jend; j++)
       for (int i = IstrU - 1; i <= Iend; i++) {
@@ -509,6 +519,10 @@ void orc_prsgrd(orc_t *o, int tile) {
       for (int i = Istr; i <= Iend; i++) {
         aux[X2(i, j)] = z_r[X3(i, j, k)] - z_r[X3(i, j - 1, k)];
         FC[X2(i, j)] = rho[X3(i, j, k)] - rho[X3(i, j - 1, k)];
+        if (o->c.options & ORC_MASKING) {                                                   /* prsgrd32.h:380,384 */
+          aux[X2(i, j)] = aux[X2(i, j)] * o->vmask[X2(i, j)];
+          FC[X2(i, j)] = FC[X2(i, j)] * o->vmask[X2(i, j)];
+        }
       }
     for (int j = JstrV - 1; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -559,12 +573,14 @@ void orc_t3dmix2(orc_t *o, int tile) {
           cff = 0.25 * (diff2[X2T(i, j, itrc)] + diff2[X2T(i - 1, j, itrc)]) * o->pmon_u[X2(i, j)];
           FX[X2(i, j)] = cff * (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]) *
                          (t[XT(i, j, k, nrhs, itrc)] - t[XT(i - 1, j, k, nrhs, itrc)]);
+          if (o->c.options & ORC_MASKING) FX[X2(i, j)] = FX[X2(i, j)] * o->umask[X2(i, j)];   /* t3dmix2_s.h:236 */
         }
       for (int j = Jstr; j <= Jend + 1; j++)
         for (int i = Istr; i <= Iend; i++) {
           cff = 0.25 * (diff2[X2T(i, j, itrc)] + diff2[X2T(i, j - 1, itrc)]) * o->pnom_v[X2(i, j)];
           FE[X2(i, j)] = cff * (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]) *
                          (t[XT(i, j, k, nrhs, itrc)] - t[XT(i, j - 1, k, nrhs, itrc)]);
+          if (o->c.options & ORC_MASKING) FE[X2(i, j)] = FE[X2(i, j)] * o->vmask[X2(i, j)];   /* t3dmix2_s.h:276 */
         }
       for (int j = Jstr; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {
@@ -610,6 +626,7 @@ void orc_uv3dmix2(orc_t *o, int tile) {
                                       (pn[X2(i - 1, j - 1)] + pn[X2(i - 1, j)]) * v[X4(i - 1, j, k, nrhs)]) +
                o->pnom_p[X2(i, j)] * ((pm[X2(i - 1, j)] + pm[X2(i, j)]) * u[X4(i, j, k, nrhs)] -
                                       (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]) * u[X4(i, j - 1, k, nrhs)]));
+        if (o->c.options & ORC_MASKING) cff = cff * o->pmask[X2(i, j)];                       /* uv3dmix2_s.h:273 */
         UFe[X2(i, j)] = om_p[X2(i, j)] * om_p[X2(i, j)] * o->visc2_p[X2(i, j)] * cff;
         VFx[X2(i, j)] = on_p[X2(i, j)] * on_p[X2(i, j)] * o->visc2_p[X2(i, j)] * cff;
       }

@@ -26,6 +26,7 @@ void orc_step2d(orc_t *o, int tile) {
   const int IstrU = b->IstrU, JstrV = b->JstrV, IstrR = b->IstrR, IendR = b->IendR,
             JstrR = b->JstrR, JendR = b->JendR;
   const int ptsk = 3 - kstp;
+  const int msk = (c->options & ORC_MASKING) != 0;
   const double dtfast = c->dtfast, g = c->g, rho0 = c->rho0;
   double *zeta = o->zeta, *ubar = o->ubar, *vbar = o->vbar;
   double *rzeta = o->rzeta, *rubar = o->rubar, *rvbar = o->rvbar;
@@ -122,6 +123,7 @@ void orc_step2d(orc_t *o, int tile) {
       for (int i = IstrU - 1; i <= Iend; i++) {
         rhs_zeta[X2(i, j)] = (DUon[X2(i, j)] - DUon[X2(i + 1, j)]) + (DVom[X2(i, j)] - DVom[X2(i, j + 1)]);
         zeta_new[X2(i, j)] = Z(i, j, kstp) + pm[X2(i, j)] * pn[X2(i, j)] * cff1 * rhs_zeta[X2(i, j)];
+        if (msk) zeta_new[X2(i, j)] = zeta_new[X2(i, j)] * o->rmask[X2(i, j)];               /* :907,933 */
         Dnew[X2(i, j)] = zeta_new[X2(i, j)] + h[X2(i, j)];
         zwrk[X2(i, j)] = 0.5 * (Z(i, j, kstp) + zeta_new[X2(i, j)]);
         gzeta[X2(i, j)] = (fac + rhoS[X2(i, j)]) * zwrk[X2(i, j)];
@@ -136,6 +138,7 @@ void orc_step2d(orc_t *o, int tile) {
       for (int i = IstrU - 1; i <= Iend; i++) {
         rhs_zeta[X2(i, j)] = (DUon[X2(i, j)] - DUon[X2(i + 1, j)]) + (DVom[X2(i, j)] - DVom[X2(i, j + 1)]);
         zeta_new[X2(i, j)] = Z(i, j, kstp) + pm[X2(i, j)] * pn[X2(i, j)] * cff1 * rhs_zeta[X2(i, j)];
+        if (msk) zeta_new[X2(i, j)] = zeta_new[X2(i, j)] * o->rmask[X2(i, j)];               /* :907,933 */
         Dnew[X2(i, j)] = zeta_new[X2(i, j)] + h[X2(i, j)];
         zwrk[X2(i, j)] = cff5 * Z(i, j, krhs) + cff4 * (Z(i, j, kstp) + zeta_new[X2(i, j)]);
         gzeta[X2(i, j)] = (fac + rhoS[X2(i, j)]) * zwrk[X2(i, j)];
@@ -154,6 +157,7 @@ void orc_step2d(orc_t *o, int tile) {
         zeta_new[X2(i, j)] = Z(i, j, kstp) + pm[X2(i, j)] * pn[X2(i, j)] *
                                                  (cff + cff2 * rzeta[X2T(i, j, kstp)] -
                                                   cff3 * rzeta[X2T(i, j, ptsk)]);
+        if (msk) zeta_new[X2(i, j)] = zeta_new[X2(i, j)] * o->rmask[X2(i, j)];               /* :964 */
         Dnew[X2(i, j)] = zeta_new[X2(i, j)] + h[X2(i, j)];
         zwrk[X2(i, j)] = cff5 * zeta_new[X2(i, j)] + cff4 * Z(i, j, krhs);
         gzeta[X2(i, j)] = (fac + rhoS[X2(i, j)]) * zwrk[X2(i, j)];
@@ -355,6 +359,7 @@ void orc_step2d(orc_t *o, int tile) {
                                       (pn[X2(i - 1, j - 1)] + pn[X2(i - 1, j)]) * VB(i - 1, j, krhs)) +
                o->pnom_p[X2(i, j)] * ((pm[X2(i - 1, j)] + pm[X2(i, j)]) * UB(i, j, krhs) -
                                       (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]) * UB(i, j - 1, krhs)));
+        if (msk) cff = cff * o->pmask[X2(i, j)];                                            /* :1613 */
         UFe[X2(i, j)] = om_p[X2(i, j)] * om_p[X2(i, j)] * cff;
         VFx[X2(i, j)] = on_p[X2(i, j)] * on_p[X2(i, j)] * cff;
       }
@@ -439,6 +444,7 @@ void orc_step2d(orc_t *o, int tile) {
         fac = 1.0 / (Dnew[X2(i, j)] + Dnew[X2(i - 1, j)]);
         UB(i, j, knew) = (UB(i, j, kstp) * (Dstp[X2(i, j)] + Dstp[X2(i - 1, j)]) +
                           cff * cff1 * rhs_ubar[X2(i, j)]) * fac;
+        if (msk) UB(i, j, knew) = UB(i, j, knew) * o->umask[X2(i, j)];                      /* :2515,2578 */
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -446,6 +452,7 @@ void orc_step2d(orc_t *o, int tile) {
         fac = 1.0 / (Dnew[X2(i, j)] + Dnew[X2(i, j - 1)]);
         VB(i, j, knew) = (VB(i, j, kstp) * (Dstp[X2(i, j)] + Dstp[X2(i, j - 1)]) +
                           cff * cff1 * rhs_vbar[X2(i, j)]) * fac;
+        if (msk) VB(i, j, knew) = VB(i, j, knew) * o->vmask[X2(i, j)];                      /* :2544,2601 */
       }
   } else if (CORR) {
     cff1 = 0.5 * dtfast * 5.0 / 12.0;
@@ -458,6 +465,7 @@ void orc_step2d(orc_t *o, int tile) {
         UB(i, j, knew) = (UB(i, j, kstp) * (Dstp[X2(i, j)] + Dstp[X2(i - 1, j)]) +
                           cff * (cff1 * rhs_ubar[X2(i, j)] + cff2 * rubar[X2T(i, j, kstp)] -
                                  cff3 * rubar[X2T(i, j, ptsk)])) * fac;
+        if (msk) UB(i, j, knew) = UB(i, j, knew) * o->umask[X2(i, j)];                      /* :2633 */
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -466,6 +474,7 @@ void orc_step2d(orc_t *o, int tile) {
         VB(i, j, knew) = (VB(i, j, kstp) * (Dstp[X2(i, j)] + Dstp[X2(i, j - 1)]) +
                           cff * (cff1 * rhs_vbar[X2(i, j)] + cff2 * rvbar[X2T(i, j, kstp)] -
                                  cff3 * rvbar[X2T(i, j, ptsk)])) * fac;
+        if (msk) VB(i, j, knew) = VB(i, j, knew) * o->vmask[X2(i, j)];                      /* :2658 */
       }
   }
   if (PRED) {

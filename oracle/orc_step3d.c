@@ -26,6 +26,7 @@ void orc_step3d_uv(orc_t *o, int tile) {
   const orc_bounds *b = &o->b[tile];
   const orc_cfg *c = &o->c;
   const int nrhs = o->s.nrhs, nnew = o->s.nnew, iic = o->s.iic;
+  const int msk = (c->options & ORC_MASKING) != 0;
   const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
   const int IstrU = b->IstrU, JstrV = b->JstrV;
   const double dt = c->dt;
@@ -108,7 +109,10 @@ void orc_step3d_uv(orc_t *o, int tile) {
         CX(DC, i, 0) = (CX(DC, i, 0) * omn1[X2(i, j)] - Davg[X2(i, j)]) * cff1;
       }
       for (int k = 1; k <= N; k++)
-        for (int i = i0; i <= Iend; i++) q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] - CX(DC, i, 0);
+        for (int i = i0; i <= Iend; i++) {
+          q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] - CX(DC, i, 0);
+          if (msk) q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] * (dir == 0 ? o->umask : o->vmask)[X2(i, j)];   /* step3d_uv.F:717,1184 */
+        }
     }
   }
 
@@ -132,17 +136,17 @@ void orc_step3d_uv(orc_t *o, int tile) {
       o->ubar[X2T(i, j, 2)] = o->ubar[X2T(i, j, 1)];
     }
     if (!c->EWperiodic) {
-      if (b->west) for (int k = 1; k <= N; k++) u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] - CX(CF, Istr, 0);
+      if (b->west) for (int k = 1; k <= N; k++) { u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] - CX(CF, Istr, 0); if (msk) u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] * o->umask[X2(Istr, j)]; }
       if (b->east)
-        for (int k = 1; k <= N; k++) u[X4(Iend + 1, j, k, nnew)] = u[X4(Iend + 1, j, k, nnew)] - CX(CF, Iend + 1, 0);
+        for (int k = 1; k <= N; k++) { u[X4(Iend + 1, j, k, nnew)] = u[X4(Iend + 1, j, k, nnew)] - CX(CF, Iend + 1, 0); if (msk) u[X4(Iend + 1, j, k, nnew)] = u[X4(Iend + 1, j, k, nnew)] * o->umask[X2(Iend + 1, j)]; }
     }
     if (!c->NSperiodic) {
       if (j == 0)
         for (int k = 1; k <= N; k++)
-          for (int i = IstrU; i <= Iend; i++) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] - CX(CF, i, 0);
+          for (int i = IstrU; i <= Iend; i++) { u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] * o->umask[X2(i, j)]; }
       if (j == c->Mm + 1)
         for (int k = 1; k <= N; k++)
-          for (int i = IstrU; i <= Iend; i++) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] - CX(CF, i, 0);
+          for (int i = IstrU; i <= Iend; i++) { u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] * o->umask[X2(i, j)]; }
     }
     for (int k = N; k >= 1; k--)
       for (int i = b->IstrP; i <= b->IendT; i++) {
@@ -170,17 +174,17 @@ void orc_step3d_uv(orc_t *o, int tile) {
       }
       if (!c->EWperiodic) {
         if (b->west)
-          for (int k = 1; k <= N; k++) v[X4(Istr - 1, j, k, nnew)] = v[X4(Istr - 1, j, k, nnew)] - CX(CF, Istr - 1, 0);
+          for (int k = 1; k <= N; k++) { v[X4(Istr - 1, j, k, nnew)] = v[X4(Istr - 1, j, k, nnew)] - CX(CF, Istr - 1, 0); if (msk) v[X4(Istr - 1, j, k, nnew)] = v[X4(Istr - 1, j, k, nnew)] * o->vmask[X2(Istr - 1, j)]; }
         if (b->east)
-          for (int k = 1; k <= N; k++) v[X4(Iend + 1, j, k, nnew)] = v[X4(Iend + 1, j, k, nnew)] - CX(CF, Iend + 1, 0);
+          for (int k = 1; k <= N; k++) { v[X4(Iend + 1, j, k, nnew)] = v[X4(Iend + 1, j, k, nnew)] - CX(CF, Iend + 1, 0); if (msk) v[X4(Iend + 1, j, k, nnew)] = v[X4(Iend + 1, j, k, nnew)] * o->vmask[X2(Iend + 1, j)]; }
       }
       if (!c->NSperiodic) {
         if (j == 1)
           for (int k = 1; k <= N; k++)
-            for (int i = Istr; i <= Iend; i++) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] - CX(CF, i, 0);
+            for (int i = Istr; i <= Iend; i++) { v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] * o->vmask[X2(i, j)]; }
         if (j == c->Mm + 1)
           for (int k = 1; k <= N; k++)
-            for (int i = Istr; i <= Iend; i++) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] - CX(CF, i, 0);
+            for (int i = Istr; i <= Iend; i++) { v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] * o->vmask[X2(i, j)]; }
       }
       for (int k = N; k >= 1; k--)
         for (int i = b->IstrT; i <= b->IendT; i++) {
@@ -232,6 +236,7 @@ void orc_step3d_t(orc_t *o, int tile) {
   const orc_bounds *b = &o->b[tile];
   const orc_cfg *c = &o->c;
   const int nnew = o->s.nnew;
+  const int msk = (c->options & ORC_MASKING) != 0;
   const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
   const int IstrU = b->IstrU, JstrV = b->JstrV;
   const double dt = c->dt, eps1 = 1.0E-12;
@@ -309,6 +314,7 @@ void orc_step3d_t(orc_t *o, int tile) {
             cff1 = cff * (oH[X2(i - 1, j)] + oH[X2(i, j)]);
             GX(i) = T3[X2(i, j)] - T3[X2(i - 1, j)];
             KX(i) = 1.0 - fabs(Hu[X2(i, j)] * cff1);
+            if (msk) { GX(i) = GX(i) * o->umask[X2(i, j)]; KX(i) = KX(i) * o->umask[X2(i, j)]; }   /* :491 */
           }
           if (!c->EWperiodic) {
             if (b->west && Hu[X2(Istr, j)] >= 0.0) { GX(Istr - 1) = 0.0; KX(Istr - 1) = 0.0; }
@@ -318,10 +324,15 @@ void orc_step3d_t(orc_t *o, int tile) {
             double sw_xi;
             if (KX(i) <= eps1) OKX(i) = 0.0;
             else OKX(i) = 1.0 / MAX(KX(i), eps1);
-            if (Hu[X2(i, j)] >= 0.0)
-              sw_xi = T3[X2(i - 1, j)] + hsimt_lim(c, GX(i), GX(i - 1), KX(i), KX(i - 1), OKX(i));
-            else
-              sw_xi = T3[X2(i, j)] - hsimt_lim(c, GX(i), GX(i + 1), KX(i), KX(i + 1), OKX(i));
+            if (Hu[X2(i, j)] >= 0.0) {
+              cff = hsimt_lim(c, GX(i), GX(i - 1), KX(i), KX(i - 1), OKX(i));
+              if (msk) cff = cff * o->rmask[X2(MAX(i - 2, 0), j)];                               /* :530 */
+              sw_xi = T3[X2(i - 1, j)] + cff;
+            } else {
+              cff = hsimt_lim(c, GX(i), GX(i + 1), KX(i), KX(i + 1), OKX(i));
+              if (msk) cff = cff * o->rmask[X2(MIN(i + 1, c->Lm + 1), j)];                       /* :549 */
+              sw_xi = T3[X2(i, j)] - cff;
+            }
             FX[X2(i, j)] = sw_xi * Hu[X2(i, j)];
           }
         }
@@ -337,6 +348,7 @@ void orc_step3d_t(orc_t *o, int tile) {
             cff1 = cff * (oH[X2(i, j)] + oH[X2(i, j - 1)]);
             GE(j) = T3[X2(i, j)] - T3[X2(i, j - 1)];
             KE(j) = 1.0 - fabs(Hv[X2(i, j)] * cff1);
+            if (msk) { GE(j) = GE(j) * o->vmask[X2(i, j)]; KE(j) = KE(j) * o->vmask[X2(i, j)]; }   /* :566 */
           }
           if (!c->NSperiodic) {
             if (b->south && Hv[X2(i, Jstr)] >= 0.0) { GE(Jstr - 1) = 0.0; KE(Jstr - 1) = 0.0; }
@@ -346,10 +358,15 @@ void orc_step3d_t(orc_t *o, int tile) {
             double sw_eta;
             if (KE(j) <= eps1) OKE(j) = 0.0;
             else OKE(j) = 1.0 / MAX(KE(j), eps1);
-            if (Hv[X2(i, j)] >= 0.0)
-              sw_eta = T3[X2(i, j - 1)] + hsimt_lim(c, GE(j), GE(j - 1), KE(j), KE(j - 1), OKE(j));
-            else
-              sw_eta = T3[X2(i, j)] - hsimt_lim(c, GE(j), GE(j + 1), KE(j), KE(j + 1), OKE(j));
+            if (Hv[X2(i, j)] >= 0.0) {
+              cff = hsimt_lim(c, GE(j), GE(j - 1), KE(j), KE(j - 1), OKE(j));
+              if (msk) cff = cff * o->rmask[X2(i, MAX(j - 2, 0))];                               /* :605 */
+              sw_eta = T3[X2(i, j - 1)] + cff;
+            } else {
+              cff = hsimt_lim(c, GE(j), GE(j + 1), KE(j), KE(j + 1), OKE(j));
+              if (msk) cff = cff * o->rmask[X2(i, MIN(j + 1, c->Mm + 1))];                       /* :624 */
+              sw_eta = T3[X2(i, j)] - cff;
+            }
             FE[X2(i, j)] = sw_eta * Hv[X2(i, j)];
           }
         }
@@ -568,6 +585,11 @@ void orc_step3d_t(orc_t *o, int tile) {
   /* lateral BCs and exchange :1858-1920 */
   for (int itrc = 1; itrc <= c->NT; itrc++) {
     orc_t3dbc(o, b, nnew, itrc);
+    if (msk)                                                             /* land/sea mask :1880-1890 */
+      for (int k = 1; k <= N; k++)
+        for (int j = b->JstrR; j <= b->JendR; j++)
+          for (int i = b->IstrR; i <= b->IendR; i++)
+            t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] * o->rmask[X2(i, j)];
     orc_exchange3d(o, b, 'r', t + XT(LBi, LBj, 1, nnew, itrc), N);
   }
   free(CF);

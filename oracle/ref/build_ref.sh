@@ -50,6 +50,11 @@ if [ "$APP" = upwelling_logdrag ]; then
   UP=UPWELLING; HDR=upwelling_logdrag; HDRPATH="$HERE/upwelling_logdrag.h"
   EXTRA=""
 fi
+if [ "$APP" = upwelling_mask ]; then
+  # the UPWELLING case with MASKING (oracle/ref/upwelling_mask.h): pins the land/sea mask branches
+  UP=UPWELLING; HDR=upwelling_mask; HDRPATH="$HERE/upwelling_mask.h"
+  EXTRA="-I$HERE/functionals"     # the user analytical file ana_mask.h of this application
+fi
 if [ "$APP" = upwelling_avg ]; then
   # the UPWELLING case with AVERAGES (oracle/ref/upwelling_avg.h): pins set_avg.F
   UP=UPWELLING; HDR=upwelling_avg; HDRPATH="$HERE/upwelling_avg.h"

@@ -718,6 +718,10 @@
       CALL mpdata_adiff_tile (ng, tile,                                 &
      &                        LBi, UBi, LBj, UBj,                       &
      &                        IminS, ImaxS, JminS, JmaxS,               &
+#ifdef MASKING
+     &                        GRID(ng)%rmask, GRID(ng)%umask,           &
+     &                        GRID(ng)%vmask,                           &
+#endif
      &                        GRID(ng)%pm, GRID(ng)%pn, GRID(ng)%omn,   &
      &                        GRID(ng)%om_u, GRID(ng)%on_v,             &
      &                        GRID(ng)%z_r, oHz,                        &
@@ -976,6 +980,12 @@
         F2('pnom_u',GRID(ng)%pnom_u)
         F2('pmon_v',GRID(ng)%pmon_v)
         F2('pnom_v',GRID(ng)%pnom_v)
+#ifdef MASKING
+        F2('rmask',GRID(ng)%rmask)
+        F2('umask',GRID(ng)%umask)
+        F2('vmask',GRID(ng)%vmask)
+        F2('pmask',GRID(ng)%pmask)
+#endif
         F2('grdscl',GRID(ng)%grdscl)
         F2('xr',GRID(ng)%xr)
         F2('yr',GRID(ng)%yr)

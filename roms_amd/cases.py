@@ -42,6 +42,49 @@ def upwelling_logdrag(**kw):
     return cs
 
 
+def upwelling_mask(**kw):
+    """UPWELLING with land/sea masking (MASKING): an island and a headland on the southern wall (`land_mask`); the
+    custom application header oracle/ref/upwelling_mask.h"""
+    cs = upwelling(**kw)
+    cs["app"] = "upwelling_mask"
+    cs["options"] = tuple(cs["options"]) + ("MASKING",)
+    return cs
+
+
+def land_mask(cs, LBi, UBi, LBj, UBj):
+    """rmask, umask, vmask, pmask of the masked test cases on arrays (LBi:UBi, LBj:UBj), Fortran order [j, i] here.
+    Land: an island of 3 x 3 cells east of Lm/3 around Mm/2, and a headland two cells wide at 2 Lm/3 from the
+    southern wall to Mm/4 (wall row included).  The xi direction wraps where the case is periodic.  u, v masks are the
+    products of the two adjacent rho masks (ana_mask.h:224-233); the psi mask is the slipperiness mask metrics.F:527-583
+    derives from rmask: 1 with at most one land cell among the four around the point, 2 (no-slip) where the two land
+    cells share a side of it, 0 otherwise."""
+    import numpy as np
+    Lm, Mm = cs["Lm"], cs["Mm"]
+    i = np.arange(LBi, UBi + 1)[None, :] * np.ones((UBj - LBj + 1, 1), dtype=int)
+    j = np.arange(LBj, UBj + 1)[:, None] * np.ones((1, UBi - LBi + 1), dtype=int)
+    if cs.get("EWperiodic"):
+        i = (i - 1) % Lm + 1
+    if cs.get("NSperiodic"):
+        j = (j - 1) % Mm + 1
+    i0, j0, i1 = Lm // 3 + 1, Mm // 2, 2 * Lm // 3 + 1
+    land = ((i >= i0) & (i <= i0 + 2) & (j >= j0) & (j <= j0 + 2)) | ((i >= i1) & (i <= i1 + 1) & (j <= Mm // 4))
+    r = np.where(land, 0.0, 1.0)
+    u, v, p = np.ones_like(r), np.ones_like(r), np.ones_like(r)
+    u[:, 1:] = r[:, :-1] * r[:, 1:]
+    v[1:, :] = r[:-1, :] * r[1:, :]
+    a, b, c, d = r[1:, :-1], r[1:, 1:], r[:-1, :-1], r[:-1, 1:]      # (i-1,j) (i,j) (i-1,j-1) (i,j-1)
+    nland = 4 - (a + b + c + d)
+    side = ((a + b == 0) | (c + d == 0) | (a + c == 0) | (b + d == 0)) & (nland == 2)
+    p[1:, 1:] = np.where(nland <= 1, 1.0, np.where(side, 2.0, 0.0))
+    # metrics.F computes psi points IstrP:IendP x JstrP:JendP and exchanges the periodic images; the outermost
+    # line of the array on each side is never written (0, and never read)
+    ii = np.arange(LBi, UBi + 1)
+    jj = np.arange(LBj, UBj + 1)
+    p[:, (ii == LBi) | (ii == UBi) if cs.get("EWperiodic") else (ii < 1) | (ii > Lm + 1)] = 0.0
+    p[(jj == LBj) | (jj == UBj) if cs.get("NSperiodic") else (jj < 1) | (jj > Mm + 1), :] = 0.0
+    return dict(rmask=r, umask=u, vmask=v, pmask=p)
+
+
 def benchmark(Lm=512, Mm=64, N=30, NtileI=1, NtileJ=1, ntimes=200):
     """roms_benchmark1.in"""
     return dict(

@@ -24,6 +24,8 @@ CASES = {
     "upwelling_avg_small": ("upwelling_avg", dict(Lm=14, Mm=18, N=8)),
     # UPWELLING with the logarithmic bottom drag (oracle/ref/upwelling_logdrag.h)
     "upwelling_logdrag_small": ("upwelling_logdrag", dict(Lm=14, Mm=18, N=8)),
+    # UPWELLING with land/sea masking (oracle/ref/upwelling_mask.h; the masks are cases.land_mask)
+    "upwelling_mask_small": ("upwelling_mask", dict(Lm=14, Mm=18, N=8)),
 }
 
 
@@ -103,7 +105,8 @@ def make_case(tag, **kw):
     k = dict(base)
     k.update(kw)
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
-                upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag)[app]
+                upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
+                upwelling_mask=cases.upwelling_mask)[app]
     return app, ctor(**k)
 
 
@@ -112,6 +115,10 @@ def reference(app, cs):
     from oracle import ref
     ip, rp = cases.ref_params(cs)
     R = ref.Ref(app, ip, rp)
+    if "MASKING" in cs["options"]:      # the masks are input data (a grid file's mask_rho ...): set before `initial`
+        for n, a in cases.land_mask(cs, R.LBi, R.UBi, R.LBj, R.UBj).items():
+            if n != "pmask":            # metrics.F derives the slipperiness mask itself
+                R.put(n, a)
     R.initial()
     return R
 

@@ -12,7 +12,8 @@ INIT_FIELDS = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om
                "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v", "angler", "xr", "yr",
                "rdrag", "visc2_r", "visc2_p", "diff2", "Hz", "z_r", "z_w", "Huon", "Hvom", "zeta", "ubar", "vbar",
                "u", "v", "t", "rho", "pden", "rhoA", "rhoS", "Zt_avg1", "Akv", "Akt",
-               "dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta", "hsbl"]
+               "dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta", "hsbl",
+               "rmask", "umask", "vmask", "pmask"]
 STATE_FIELDS = INIT_FIELDS + ["rzeta", "rubar", "rvbar", "W", "wvel", "ru", "rv", "rufrc", "rvfrc", "DU_avg1",
                               "DU_avg2", "DV_avg1", "DV_avg2", "sustr", "svstr", "bustr", "bvstr", "stflx", "btflx",
                               "stflux", "btflux", "srflx", "ghats", "Uwind", "Vwind", "Tair", "Pair", "Hair", "rain",
@@ -56,6 +57,8 @@ def case_for(tag, **kw):
         return cases.upwelling_kpp(Lm=14, Mm=18, N=8, **kw)
     if tag == "benchmark_small":
         return cases.benchmark(Lm=24, Mm=16, N=10, **kw)
+    if tag == "upwelling_mask_small":
+        return cases.upwelling_mask(Lm=14, Mm=18, N=8, **kw)
     if tag == "upwelling_logdrag_small":
         return cases.upwelling_logdrag(Lm=14, Mm=18, N=8, **kw)
     raise KeyError(tag)
