@@ -46,6 +46,9 @@ enum {
   ROMS_SOLAR_SOURCE = 1 << 10, ROMS_ANA_VMIX = 1 << 11, ROMS_SALINITY = 1 << 12,
   ROMS_SPHERICAL = 1 << 13,
   ROMS_UV_LOGDRAG = 1 << 14,        /* logarithmic bottom drag from Zob (set_vbc.F:591-635); else UV_QDRAG / UV_LDRAG */
+  ROMS_MASKING = 1 << 15,           /* land/sea masks: arrays "rmask", "umask", "vmask", "pmask" (mod_grid.F), all water until
+                                       uploaded; with the UPWELLING-type physics (ANA_VMIX, linear EOS); not with MPDATA, KPP,
+                                       bulk fluxes, MIX_GEO_TS or AVERAGES (exit_flag 5) */
   ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21
 };
 

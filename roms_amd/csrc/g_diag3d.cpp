@@ -167,7 +167,11 @@ int run_set_zeta(roms_hip_ctx *c) {
 int run_ini_zeta(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   const int kstp = c->G.kstp;
-  launch_halo(c, lev2d(c, c->F.zeta, kstp), 1, BC_R, 'r');   // zetabc_tile + exchange
+  if (c->G.masking) {
+    KArgs m = mk(c, 0);
+    LAUNCH_THREAD(k_ini_mask, B.IendB - KMIN(B.IstrM, B.IstrB) + 1, B.JendB - B.JstrB + 1, 1, c->stream, m);
+  }
+  launch_halo(c, lev2d(c, c->F.zeta, kstp), 1, bc_rstate(c), 'r');   // zetabc_tile + exchange
   KArgs a = mk(c, kstp);
   LAUNCH_THREAD(k_copy_zt, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
   launch_halo(c, c->F.Zt_avg1, 1, BC_NONE, 'r');
@@ -177,6 +181,10 @@ int run_ini_zeta(roms_hip_ctx *c) {
 int run_ini_fields(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   const int N = c->G.N, nstp = c->G.nstp, kstp = c->G.kstp;
+  if (c->G.masking) {
+    KArgs m = mk(c, 1);
+    LAUNCH_THREAD(k_ini_mask, B.IendB - KMIN(B.IstrM, B.IstrB) + 1, B.JendB - B.JstrB + 1, N, c->stream, m);
+  }
   const HaloSpec hs8[] = {
       {uv_lev(c, c->F.u, nstp), N, BC_U, 'u'},     // u3dbc_tile + exchange_u3d
       {uv_lev(c, c->F.v, nstp), N, BC_V, 'v'},
@@ -190,9 +198,13 @@ int run_ini_fields(roms_hip_ctx *c) {
       {lev2d(c, c->F.vbar, kstp), 1, BC_V, 'v'},
   };
   launch_halo_multi(c, hs9, 2);
+  if (c->G.masking) {
+    KArgs m = mk(c, 2);
+    LAUNCH_THREAD(k_ini_mask, B.IendB - KMIN(B.IstrM, B.IstrB) + 1, B.JendB - B.JstrB + 1, N * c->G.NT, c->stream, m);
+  }
   {
     HaloSpec ht[ROMS_MAXT];
-    for (int it = 1; it <= c->G.NT; it++) ht[it - 1] = HaloSpec{t_lev(c, nstp, it), N, BC_R, 'r'};   // t3dbc + exchange
+    for (int it = 1; it <= c->G.NT; it++) ht[it - 1] = HaloSpec{t_lev(c, nstp, it), N, bc_rstate(c), 'r'};   // t3dbc + exchange
     launch_halo_multi(c, ht, c->G.NT);
   }
   return 0;

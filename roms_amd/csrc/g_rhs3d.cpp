@@ -84,7 +84,7 @@ int run_pre_t3(roms_hip_ctx *c) {
   }
   if (G.fuse3d && !any_col) return 0;   // k_pre_t3 stored the boundary values and images (pt_emit)
   HaloSpec sp[ROMS_MAXT];
-  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, 3, it), G.N, BC_R, 'r'};   // t3dbc + exchange :1157-1171
+  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, 3, it), G.N, bc_rstate(c), 'r'};   // t3dbc + exchange :1157-1171
   launch_halo_multi(c, sp, G.NT);
   return 0;
 }
@@ -227,7 +227,7 @@ int run_uv3dmix2_col(roms_hip_ctx *c) {
 #else
   const DGrid &G = c->G;
   const TB &B = G.T;
-  if (!(G.options & ROMS_UV_VIS2)) return -1;
+  if (!(G.options & ROMS_UV_VIS2) || G.masking) return -1;   // (the column form carries no land/sea masks)
   static const char *e = getenv("ROMS_HIP_UVCOL");
   const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
   const bool big = (long)nx * ny >= 128L * 1024L;

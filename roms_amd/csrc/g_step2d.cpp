@@ -88,7 +88,7 @@ int run_step2d(roms_hip_ctx *c) {
   if (iif > G.nfast) return 0;
   HaloSpec sp[4];
   int n = 0;
-  sp[n++] = {lev2d(c, c->F.zeta, G.knew), 1, BC_R, 'r'};                        // zetabc :1057 + exchange :1068
+  sp[n++] = {lev2d(c, c->F.zeta, G.knew), 1, bc_rstate(c), 'r'};                        // zetabc :1057 + exchange :1068
   if (G.predictor) sp[n++] = {lev2d(c, c->F.rzeta, G.krhs), 1, BC_NONE, 'r'};   // :1030
   sp[n++] = {lev2d(c, c->F.ubar, G.knew), 1, BC_U, 'u'};                        // u2dbc :2871 + exchange :3043
   sp[n++] = {lev2d(c, c->F.vbar, G.knew), 1, BC_V, 'v'};                        // v2dbc :2876

@@ -114,7 +114,7 @@ int run_step3d_t(roms_hip_ctx *c) {
   }
   if (G.fuse3d && !any_mp) return 0;   // k_s3t_col stored the boundary values and images (pt_emit)
   HaloSpec sp[ROMS_MAXT];
-  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, BC_R, 'r'};   // t3dbc :1858 + exchange :1920
+  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, bc_rstate(c, true), 'r'};   // t3dbc :1858 + exchange :1920
   launch_halo_tail(c, sp, G.NT);
   return 0;
 }

@@ -120,6 +120,7 @@ THREAD_KERNEL(k_rho_eos_lin, KArgs) {
     double r = G.R0 - G.R0 * G.Tcoef * (F.t[XT(i, j, k, nrhs, 1)] - G.T0);
     if (salt) r = r + G.R0 * G.Scoef * (F.t[XT(i, j, k, nrhs, 2)] - G.S0);
     r = r - 1000.0;
+    if (G.masking) r = r * F.rmask[X2(i, j)];                                             // rho_eos.F:718
     emit_store(G, P, F.rho + (size_t)(k - 1) * G.nij, r);
     emit_store(G, P, F.pden + (size_t)(k - 1) * G.nij, r);
     if (kpp && k < N)
@@ -158,6 +159,7 @@ THREAD_KERNEL(k_set_vbc, KArgs) {
   F.btflx[X2T(i, j, 1)] = F.btflux[X2T(i, j, 1)];
   const double EmP = F.stflux[X2T(i, j, 2)];
   F.stflx[X2T(i, j, 2)] = EmP * F.t[XT(i, j, N, nrhs, 2)];
+  if (G.masking) F.stflx[X2T(i, j, 2)] = F.rmask[X2(i, j)] * F.stflx[X2T(i, j, 2)];      // set_vbc.F:399
   F.btflx[X2T(i, j, 2)] = F.btflx[X2T(i, j, 2)] * F.t[XT(i, j, 1, nrhs, 2)];
   const bool qdrag = (G.options & ROMS_UV_QDRAG) != 0, logdrag = (G.options & ROMS_UV_LOGDRAG) != 0;
   // UV_LOGDRAG :591-601: drag coefficient of a rho point from the height of its lowest level above the bed
@@ -484,7 +486,9 @@ THREAD_KERNEL(k_ini_bar, KArgs) {
       CF0 = CF0 + DCk * F.u[X4(i, j, k, nstp)];
     }
     const double cff1 = 1.0 / DC0;
-    F.ubar[X2T(i, j, kstp)] = CF0 * cff1;
+    double cff2 = CF0 * cff1;
+    if (G.masking) cff2 = cff2 * F.umask[X2(i, j)];                     // ini_fields.F:376
+    F.ubar[X2T(i, j, kstp)] = cff2;
   }
   if (j >= B.JstrM && i >= B.IstrB && i <= B.IendB) {
     double DC0 = 0.0, CF0 = 0.0;
@@ -494,10 +498,33 @@ THREAD_KERNEL(k_ini_bar, KArgs) {
       CF0 = CF0 + DCk * F.v[X4(i, j, k, nstp)];
     }
     const double cff1 = 1.0 / DC0;
-    F.vbar[X2T(i, j, kstp)] = CF0 * cff1;
+    double cff2 = CF0 * cff1;
+    if (G.masking) cff2 = cff2 * F.vmask[X2(i, j)];                     // ini_fields.F:400
+    F.vbar[X2T(i, j, kstp)] = cff2;
   }
 }
 THREAD_GLOBAL(k_ini_bar, KArgs)
+
+// MASKING: the loads of ini_zeta / ini_fields that are identities without masks -- zeta(kstp)*rmask (ini_fields.F:838-849;
+// p0 = 0), u(nstp)*umask, v(nstp)*vmask (:286-312; p0 = 1), t(nstp,itrc)*rmask (:546-556; p0 = 2).
+// index space: (min(IstrM,IstrB):IendB, JstrB:JendB, levels)
+THREAD_KERNEL(k_ini_mask, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int i = KMIN(B.IstrM, B.IstrB) + gx, j = B.JstrB + gy, nstp = G.nstp, kstp = G.kstp;
+  if (a.p0 == 0) {
+    if (i >= B.IstrB && i <= B.IendB) F.zeta[X2T(i, j, kstp)] = F.zeta[X2T(i, j, kstp)] * F.rmask[X2(i, j)];
+  } else if (a.p0 == 1) {
+    const int k = gz + 1;
+    if (i >= B.IstrM && i <= B.IendB) F.u[X4(i, j, k, nstp)] = F.u[X4(i, j, k, nstp)] * F.umask[X2(i, j)];
+    if (j >= B.JstrM && i >= B.IstrB && i <= B.IendB) F.v[X4(i, j, k, nstp)] = F.v[X4(i, j, k, nstp)] * F.vmask[X2(i, j)];
+  } else {
+    const int k = gz % G.N + 1, it = gz / G.N + 1;
+    if (i >= B.IstrB && i <= B.IendB) F.t[XT(i, j, k, nstp, it)] = F.t[XT(i, j, k, nstp, it)] * F.rmask[X2(i, j)];
+  }
+}
+THREAD_GLOBAL(k_ini_mask, KArgs)
 
 // ------------------------------------------------------------------------------ bandwidth probe
 // Plain streaming copy of 3-D work arrays with the access pattern of the point-wise kernels

@@ -48,13 +48,25 @@ KDEV double *halo_plane(const ArgT &a, int bz, int &bc, int &gtype) {
 }
 
 // boundary fills and local periodic copies of one plane, by one thread block
-KDEV void halo_fill(const DGrid &G, double *A, int bc, int gtype) {
+KDEV void halo_fill(const DGrid &G, double *A, int bcf, int gtype) {
   const TB &B = G.T;
   const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
   const int Lm = G.Lm, Mm = G.Mm;
   const double gamma2 = G.gamma2;
+  const int bc = bcf & BC_KIND;
+  // MASKING: the value stored at a boundary point times the mask of THAT point (roms_ctx.h: BC_MASKF, BC_MASKALL)
+  const bool mskr = G.masking && (bcf & BC_MASKF), msku = G.masking && bc == BC_U, mskv = G.masking && bc == BC_V;
   // ---- phase 1: edges of closed boundaries
-  if (bc == BC_R) {
+  if (bc == BC_R && mskr) {
+    if (!G.ewp) {
+      if (B.west) KLOOP1(j, Jstr, Jend) A[X2(Istr - 1, j)] = A[X2(Istr, j)] * G.rmask[X2(Istr - 1, j)];
+      if (B.east) KLOOP1(j, Jstr, Jend) A[X2(Iend + 1, j)] = A[X2(Iend, j)] * G.rmask[X2(Iend + 1, j)];
+    }
+    if (!G.nsp) {
+      if (B.south) KLOOP1(i, Istr, Iend) A[X2(i, Jstr - 1)] = A[X2(i, Jstr)] * G.rmask[X2(i, Jstr - 1)];
+      if (B.north) KLOOP1(i, Istr, Iend) A[X2(i, Jend + 1)] = A[X2(i, Jend)] * G.rmask[X2(i, Jend + 1)];
+    }
+  } else if (bc == BC_R) {
     if (!G.ewp) {
       if (B.west) KLOOP1(j, Jstr, Jend) A[X2(Istr - 1, j)] = A[X2(Istr, j)];
       if (B.east) KLOOP1(j, Jstr, Jend) A[X2(Iend + 1, j)] = A[X2(Iend, j)];
@@ -71,14 +83,24 @@ KDEV void halo_fill(const DGrid &G, double *A, int bc, int gtype) {
     KSYNC();
     if (!G.nsp) {
       const int Imin = G.ewp ? B.IstrU : B.Istr, Imax = G.ewp ? B.Iend : B.IendR;
-      if (B.south) KLOOP1(i, Imin, Imax) A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)];
-      if (B.north) KLOOP1(i, Imin, Imax) A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)];
+      if (msku) {
+        if (B.south) KLOOP1(i, Imin, Imax) A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)] * G.umask[X2(i, Jstr - 1)];
+        if (B.north) KLOOP1(i, Imin, Imax) A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)] * G.umask[X2(i, Jend + 1)];
+      } else {
+        if (B.south) KLOOP1(i, Imin, Imax) A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)];
+        if (B.north) KLOOP1(i, Imin, Imax) A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)];
+      }
     }
   } else if (bc == BC_V) {
     if (!G.ewp) {
       const int Jmin = G.nsp ? B.JstrV : B.Jstr, Jmax = G.nsp ? B.Jend : B.JendR;
-      if (B.west) KLOOP1(j, Jmin, Jmax) A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)];
-      if (B.east) KLOOP1(j, Jmin, Jmax) A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)];
+      if (mskv) {
+        if (B.west) KLOOP1(j, Jmin, Jmax) A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)] * G.vmask[X2(Istr - 1, j)];
+        if (B.east) KLOOP1(j, Jmin, Jmax) A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)] * G.vmask[X2(Iend + 1, j)];
+      } else {
+        if (B.west) KLOOP1(j, Jmin, Jmax) A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)];
+        if (B.east) KLOOP1(j, Jmin, Jmax) A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)];
+      }
     }
     KSYNC();
     if (!G.nsp) {
@@ -107,6 +129,11 @@ KDEV void halo_fill(const DGrid &G, double *A, int bc, int gtype) {
     }
   }
   KSYNC();
+  // ---- MASKING: the whole plane times rmask, boundary points included (step3d_t.F:1880-1890)
+  if (G.masking && (bcf & BC_MASKALL)) {
+    KLOOP2(i, j, B.IstrR, B.IendR, B.JstrR, B.JendR) A[X2(i, j)] = A[X2(i, j)] * G.rmask[X2(i, j)];
+    KSYNC();
+  }
   // ---- phase 3: periodic ghost copies (single tile in the periodic direction)
   if (gtype != 0 && (G.ewp || G.nsp)) {
     const int gt = gtype;

@@ -49,7 +49,8 @@ KDEV void hadv_flux_lds(const DGrid &G, const TB &B, int scheme, const double *T
   }
   const double cff1 = 1.0 / 6.0, cff2 = 1.0 / 3.0;
   // ---- xi direction
-  KLOOP2(i, j, B.Istrm1, B.Iendp2, Jstr, Jend) FX[S2(i, j)] = T[X2(i, j)] - T[X2(i - 1, j)];
+  if (G.masking) KLOOP2(i, j, B.Istrm1, B.Iendp2, Jstr, Jend) FX[S2(i, j)] = (T[X2(i, j)] - T[X2(i - 1, j)]) * G.umask[X2(i, j)];   // pre_step3d.F:411
+  else KLOOP2(i, j, B.Istrm1, B.Iendp2, Jstr, Jend) FX[S2(i, j)] = T[X2(i, j)] - T[X2(i - 1, j)];
   KSYNC();
   if (!G.ewp) {
     if (B.west) KLOOP1(j, Jstr, Jend) FX[S2(Istr - 1, j)] = FX[S2(Istr, j)];
@@ -73,7 +74,8 @@ KDEV void hadv_flux_lds(const DGrid &G, const TB &B, int scheme, const double *T
   }
   KSYNC();
   // ---- eta direction
-  KLOOP2(i, j, Istr, Iend, B.Jstrm1, B.Jendp2) FE[S2(i, j)] = T[X2(i, j)] - T[X2(i, j - 1)];
+  if (G.masking) KLOOP2(i, j, Istr, Iend, B.Jstrm1, B.Jendp2) FE[S2(i, j)] = (T[X2(i, j)] - T[X2(i, j - 1)]) * G.vmask[X2(i, j)];   // pre_step3d.F:476
+  else KLOOP2(i, j, Istr, Iend, B.Jstrm1, B.Jendp2) FE[S2(i, j)] = T[X2(i, j)] - T[X2(i, j - 1)];
   KSYNC();
   if (!G.nsp) {
     if (B.south) KLOOP1(i, Istr, Iend) FE[S2(i, Jstr - 1)] = FE[S2(i, Jstr)];
@@ -137,6 +139,10 @@ KDEV void hadv4_core(const DGrid &G, int scheme, const double *Tc, const long ni
   {
     const double tww = Tc[-2], tee = Tc[2];
     double gm = tw - tww, g0 = tc - tw, g1 = te - tc, g2 = tee - te;     // grad(i-1), grad(i), grad(i+1), grad(i+2)
+    if (G.masking) {                                                      // FX*umask before the edge replication (pre_step3d.F:411)
+      const double *um = G.umask + X2(i, j);
+      gm = gm * um[-1]; g0 = g0 * um[0]; g1 = g1 * um[1]; g2 = g2 * um[efix ? 1 : 2];
+    }
     if (wfix) gm = g0;
     if (efix) g2 = g1;
     const double wkm = hadv_wk(scheme, gm, g0), wk0 = hadv_wk(scheme, g0, g1), wkp = hadv_wk(scheme, g1, g2);
@@ -147,6 +153,11 @@ KDEV void hadv4_core(const DGrid &G, int scheme, const double *Tc, const long ni
     // a closed edge has one boundary row only: the replaced difference is not read beyond the array
     const double tss = Tc[sfix ? -ni : -2 * ni], tnn = Tc[nfix ? ni : 2 * ni];
     double gm = ts - tss, g0 = tc - ts, g1 = tn - tc, g2 = tnn - tn;
+    if (G.masking) {                                                      // FE*vmask (pre_step3d.F:476)
+      const double *vm = G.vmask + X2(i, j);
+      const long gn = (long)G.ni;
+      gm = gm * vm[-gn]; g0 = g0 * vm[0]; g1 = g1 * vm[gn]; g2 = g2 * vm[nfix ? gn : 2 * gn];
+    }
     if (sfix) gm = g0;
     if (nfix) g2 = g1;
     const double wkm = hadv_wk(scheme, gm, g0), wk0 = hadv_wk(scheme, g0, g1), wkp = hadv_wk(scheme, g1, g2);
@@ -562,6 +573,12 @@ THREAD_KERNEL(k_prs_grad, KArgs) {
   // sub-expression of k_pre_new, same operations -- in wrk3[11] (u) and wrk3[12] (v)
   const bool keep = a.p1 != 0 && G.iic >= G.ntfirst + 2;
   const long d_indx = (long)(3 - 2 * nrhs) * (long)(nij * (size_t)(G.N + 1));   // from time level nrhs to indx = 3 - nrhs
+  // MASKING (prsgrd32.h:316-320, 380-384): the differences that enter the harmonic means carry umask / vmask
+  double mum = 1.0, mu0 = 1.0, mup = 1.0, mvm = 1.0, mv0 = 1.0, mvp = 1.0;
+  if (G.masking) {
+    mum = F.umask[x - 1]; mu0 = F.umask[x]; mup = F.umask[x + 1];
+    mvm = F.vmask[x - ni]; mv0 = F.vmask[x]; mvp = F.vmask[x + ni];
+  }
 #pragma unroll
   for (int q = 0; q < KCH; q++) {
     const int k = gz * KCH + 1 + q;
@@ -577,8 +594,9 @@ THREAD_KERNEL(k_prs_grad, KArgs) {
     if (doU) {
       // aux(ii)=z_r(ii)-z_r(ii-1), FC(ii)=rho(ii)-rho(ii-1); dZx(ii)=harm(aux(ii),aux(ii+1)) ...
       const double zm = zr[-1], rm = rh[-1];
-      const double am = zm - zr[-2], a0 = z0 - zm, ap = zr[1] - z0;
-      const double fm = rm - rh[-2], f0 = r0 - rm, fp = rh[1] - r0;
+      double am = zm - zr[-2], a0 = z0 - zm, ap = zr[1] - z0;
+      double fm = rm - rh[-2], f0 = r0 - rm, fp = rh[1] - r0;
+      if (G.masking) { am = am * mum; a0 = a0 * mu0; ap = ap * mup; fm = fm * mum; f0 = f0 * mu0; fp = fp * mup; }
       const double dZx0 = prs_harm(a0, ap), dRx0 = prs_harm(f0, fp), dZxm = prs_harm(am, a0), dRxm = prs_harm(fm, f0);
       ru[(size_t)k * nij] =
           onu * 0.5 * (h0 + Hz[-1]) *
@@ -589,8 +607,9 @@ THREAD_KERNEL(k_prs_grad, KArgs) {
     }
     if (doV) {
       const double zm = zr[-ni], rm = rh[-ni];
-      const double am = zm - zr[-2 * ni], a0 = z0 - zm, ap = zr[ni] - z0;
-      const double fm = rm - rh[-2 * ni], f0 = r0 - rm, fp = rh[ni] - r0;
+      double am = zm - zr[-2 * ni], a0 = z0 - zm, ap = zr[ni] - z0;
+      double fm = rm - rh[-2 * ni], f0 = r0 - rm, fp = rh[ni] - r0;
+      if (G.masking) { am = am * mvm; a0 = a0 * mv0; ap = ap * mvp; fm = fm * mvm; f0 = f0 * mv0; fp = fp * mvp; }
       const double dZx0 = prs_harm(a0, ap), dRx0 = prs_harm(f0, fp), dZxm = prs_harm(am, a0), dRxm = prs_harm(fm, f0);
       rv[(size_t)k * nij] =
           omv * 0.5 * (h0 + Hz[-ni]) *
@@ -625,14 +644,18 @@ THREAD_KERNEL(k_t3dmix2_t, KArgs) {
   const double *tr = F.t + XT(G.LBi, G.LBj, 1, nrhs, itrc) + x;
   double *tn = F.t + XT(G.LBi, G.LBj, 1, nnew, itrc) + x;
   const double *Hz = F.Hz + x;
+  // MASKING (t3dmix2_s.h:236,276): face fluxes times umask / vmask of the face
+  double mx0 = 1.0, mx1 = 1.0, me0 = 1.0, me1 = 1.0;
+  if (G.masking) { mx0 = F.umask[x]; mx1 = F.umask[x + 1]; me0 = F.vmask[x]; me1 = F.vmask[x + ni]; }
 #pragma unroll
   for (int q = 0; q < (MARCH ? tch : KCH); q++) {
     if (k0 + q > N) break;
     const size_t ok = (size_t)(k0 + q - 1) * nij;
     const double *H = Hz + ok, *T = tr + ok;
     const double h0 = H[0], t0 = T[0];
-    const double FX0 = ax0 * (h0 + H[-1]) * (t0 - T[-1]), FX1 = ax1 * (H[1] + h0) * (T[1] - t0);
-    const double FE0 = ae0 * (h0 + H[-ni]) * (t0 - T[-ni]), FE1 = ae1 * (H[ni] + h0) * (T[ni] - t0);
+    double FX0 = ax0 * (h0 + H[-1]) * (t0 - T[-1]), FX1 = ax1 * (H[1] + h0) * (T[1] - t0);
+    double FE0 = ae0 * (h0 + H[-ni]) * (t0 - T[-ni]), FE1 = ae1 * (H[ni] + h0) * (T[ni] - t0);
+    if (G.masking) { FX0 = FX0 * mx0; FX1 = FX1 * mx1; FE0 = FE0 * me0; FE1 = FE1 * me1; }
     const double cff1 = cff * (FX1 - FX0);
     const double cff2 = cff * (FE1 - FE0);
     const double cff3 = cff1 + cff2;
@@ -705,10 +728,14 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
 #define CFFP(c, o)                                                                              \
   (0.125 * (Hz[(o) - 1] + Hz[o] + Hz[(o) - 1 - ni] + Hz[(o) - ni]) *                             \
    (c##0 * (c##1 * v[o] - c##2 * v[(o) - 1]) + c##3 * (c##4 * u[o] - c##5 * u[(o) - ni])))
-    const double cR = CFFR(r0_, 0), cP = CFFP(p0_, 0);
+    const double cR = CFFR(r0_, 0);
+    double cP = CFFP(p0_, 0);
+    if (G.masking) cP = cP * F.pmask[x];                                   // uv3dmix2_s.h:273
     double un = 0.0, vn = 0.0, u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0;
     if (do_u) {
-      const double cRw = CFFR(rw_, -1), cPn = CFFP(pn_, ni);
+      const double cRw = CFFR(rw_, -1);
+      double cPn = CFFP(pn_, ni);
+      if (G.masking) cPn = cPn * F.pmask[x + ni];
       const double UFx1 = fur1 * cR;
       const double UFx0 = fur0 * cRw;
       const double UFe1 = fup1 * cPn;
@@ -721,7 +748,9 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
       }
     }
     if (do_v) {
-      const double cRs = CFFR(rs_, -ni), cPe = CFFP(pe_, 1);
+      const double cRs = CFFR(rs_, -ni);
+      double cPe = CFFP(pe_, 1);
+      if (G.masking) cPe = cPe * F.pmask[x + 1];
       const double VFx1 = fvp1 * cPe;
       const double VFx0 = fvp0 * cP;
       const double VFe1 = fvr1 * cR;

@@ -131,6 +131,7 @@ THREAD_KERNEL(k_s3uv_col_t, KArgs) {
   const double Davg = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
   const double cff1 = 1.0 / (CF0 * omn1);
   const double corr = (DCs * omn1 - Davg) * cff1;
+  const double qmask = G.masking ? (dir == 0 ? F.umask : F.vmask)[X2(i, j)] : 1.0;   // step3d_uv.F:717,1184
   const EmitPlan PQ = emit_plan(G, dir == 0 ? BC_U : BC_V, i, j);
   _Pragma("unroll 1") for (int k0 = 1; k0 <= N; k0 += 8) {
     double qq[8];
@@ -138,7 +139,7 @@ THREAD_KERNEL(k_s3uv_col_t, KArgs) {
     for (int m = 0; m < 8; m++) qq[m] = q[X3(i, j, KMIN(k0 + m, N))];
 #pragma unroll
     for (int m = 0; m < 8; m++)
-      if (k0 + m <= N) emit_store(G, PQ, q + (size_t)(k0 + m - 1) * G.nij, qq[m] - corr);   // u3dbc/v3dbc :1266
+      if (k0 + m <= N) emit_store(G, PQ, q + (size_t)(k0 + m - 1) * G.nij, G.masking ? (qq[m] - corr) * qmask : qq[m] - corr);   // :717; u3dbc/v3dbc :1266
   }
 #undef AKc
 #undef HZc
@@ -288,9 +289,10 @@ COL_KERNEL(k_s3uv_col_lt, KArgs) {
   const double Davg = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
   const double cff1 = 1.0 / (CF0 * omn1);
   const double corr = (DCs * omn1 - Davg) * cff1;
+  const double qmask = G.masking ? (dir == 0 ? F.umask : F.vmask)[X2(i, j)] : 1.0;   // step3d_uv.F:717,1184
   const EmitPlan PQ = emit_plan(G, dir == 0 ? BC_U : BC_V, i, j);
   _Pragma("unroll 4") for (int k = 1; k <= N; k++)
-    emit_store(G, PQ, q + (size_t)(k - 1) * G.nij, L1[k * KLS] - corr);   // u3dbc/v3dbc :1266
+    emit_store(G, PQ, q + (size_t)(k - 1) * G.nij, G.masking ? (L1[k * KLS] - corr) * qmask : L1[k * KLS] - corr);   // :717; u3dbc/v3dbc :1266
 #undef AKc
 #undef HZc
 }
@@ -350,8 +352,10 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
     if (!G.ewp && ((B.west && i == B.Istr - 1) || (B.east && i == B.Iend + 1))) fix = true;
     if (!G.nsp && (j == 1 || j == G.Mm + 1) && i >= B.Istr && i <= B.Iend) fix = true;
   }
-  if (fix)
-    for (int k = 1; k <= N; k++) emit_store(G, P, q + (size_t)(k - 1) * nij, q[X3(i, j, k)] - CF0);
+  if (fix) {
+    const double qmask = G.masking ? (dir == 0 ? F.umask : F.vmask)[X2(i, j)] : 1.0;   // step3d_uv.F:1400-1495, 1623-1720
+    for (int k = 1; k <= N; k++) emit_store(G, P, q + (size_t)(k - 1) * nij, G.masking ? (q[X3(i, j, k)] - CF0) * qmask : q[X3(i, j, k)] - CF0);
+  }
   for (int k0 = N; k0 >= 1; k0 -= 8) {
     double hs[8], qq[8], hq[8];
 #pragma unroll
@@ -459,7 +463,8 @@ COL_KERNEL(k_s3uv_couple_l, KArgs) {
   }
   if (fix)
     for (int k = 1; k <= N; k++) {
-      const double v = LB[k * KLS] - CF0;
+      double v = LB[k * KLS] - CF0;
+      if (G.masking) v = v * (dir == 0 ? F.umask : F.vmask)[X2(i, j)];                 // step3d_uv.F:1400-1495, 1623-1720
       LB[k * KLS] = v;
       emit_store(G, P, q + (size_t)(k - 1) * nij, v);
     }
@@ -522,12 +527,14 @@ KDEV bool s3t_point_path(const DGrid &G, int itrc) {
 }
 
 // one HSIMT face flux, step3d_t.F:520-550 (xi) / :598-632 (eta): upstream value + limited correction
-KDEV double hsimt_flux(double h, double tm, double t0, double g0, double gm, double gp, double K0, double Km, double Kp) {
+// mL, mR (MASKING, :530,549): rmask two points upstream of the face for either flow direction; 1 otherwise (x*1 = x)
+KDEV double hsimt_flux(double h, double tm, double t0, double g0, double gm, double gp, double K0, double Km, double Kp,
+                       double mL = 1.0, double mR = 1.0) {
   const double eps1 = 1.0E-12;
   const double oKa = (K0 <= eps1) ? 0.0 : 1.0 / KMAX(K0, eps1);
   double sw;
-  if (h >= 0.0) sw = tm + hsimt_lim(g0, gm, K0, Km, oKa);
-  else sw = t0 - hsimt_lim(g0, gp, K0, Kp, oKa);
+  if (h >= 0.0) sw = tm + hsimt_lim(g0, gm, K0, Km, oKa) * mL;
+  else sw = t0 - hsimt_lim(g0, gp, K0, Kp, oKa) * mR;
   return sw * h;
 }
 // step3d_t: horizontal :633-915 and vertical :936-1340 advection of t(3) into t(nnew), one point per
@@ -608,6 +615,7 @@ COOP_KERNEL(k_s3t_h, KArgs) {
       const double cff1 = cff * (1.0 / Hzk[X2(i - 1, j)] + 1.0 / Hzk[X2(i, j)]);
       gX[S2(i, j)] = T3[X2(i, j)] - T3[X2(i - 1, j)];
       KX[S2(i, j)] = 1.0 - fabs(Hu[X2(i, j)] * cff1);
+      if (G.masking) { gX[S2(i, j)] = gX[S2(i, j)] * F.umask[X2(i, j)]; KX[S2(i, j)] = KX[S2(i, j)] * F.umask[X2(i, j)]; }   // :491
     } else if ((wc && i == Istr - 1) || (ec && i == Iend + 2)) { gX[S2(i, j)] = 0.0; KX[S2(i, j)] = 0.0; }
   }
   KLOOP2(i, j, Istr, Iend, Jstr - 1, Jend + 2) {
@@ -616,20 +624,29 @@ COOP_KERNEL(k_s3t_h, KArgs) {
       const double cff1 = cff * (1.0 / Hzk[X2(i, j)] + 1.0 / Hzk[X2(i, j - 1)]);
       gE[S2(i, j)] = T3[X2(i, j)] - T3[X2(i, j - 1)];
       KE[S2(i, j)] = 1.0 - fabs(Hv[X2(i, j)] * cff1);
+      if (G.masking) { gE[S2(i, j)] = gE[S2(i, j)] * F.vmask[X2(i, j)]; KE[S2(i, j)] = KE[S2(i, j)] * F.vmask[X2(i, j)]; }   // :566
     } else if ((sc && j == Jstr - 1) || (nc && j == Jend + 2)) { gE[S2(i, j)] = 0.0; KE[S2(i, j)] = 0.0; }
   }
   KSYNC();
   double *tn = F.t + XT(G.LBi, G.LBj, k, G.nnew, itrc);
   KLOOP2(i, j, Istr, Iend, Jstr, Jend) {
     const double tc = T3[X2(i, j)];
+    // MASKING: rmask(MAX(f-2,0)) / rmask(MIN(f+1,Lm+1)) for the face f = i, i+1 (j, j+1 along eta)
+    double xL0 = 1.0, xR0 = 1.0, xLp = 1.0, xRp = 1.0, eL0 = 1.0, eR0 = 1.0, eLp = 1.0, eRp = 1.0;
+    if (G.masking) {
+      xL0 = F.rmask[X2(KMAX(i - 2, 0), j)]; xR0 = F.rmask[X2(KMIN(i + 1, G.Lm + 1), j)];
+      xLp = F.rmask[X2(KMAX(i - 1, 0), j)]; xRp = F.rmask[X2(KMIN(i + 2, G.Lm + 1), j)];
+      eL0 = F.rmask[X2(i, KMAX(j - 2, 0))]; eR0 = F.rmask[X2(i, KMIN(j + 1, G.Mm + 1))];
+      eLp = F.rmask[X2(i, KMAX(j - 1, 0))]; eRp = F.rmask[X2(i, KMIN(j + 2, G.Mm + 1))];
+    }
     const double FX0 = hsimt_flux(Hu[X2(i, j)], T3[X2(i - 1, j)], tc, gX[S2(i, j)], gX[S2(i - 1, j)], gX[S2(i + 1, j)],
-                                  KX[S2(i, j)], KX[S2(i - 1, j)], KX[S2(i + 1, j)]);
+                                  KX[S2(i, j)], KX[S2(i - 1, j)], KX[S2(i + 1, j)], xL0, xR0);
     const double FXp = hsimt_flux(Hu[X2(i + 1, j)], tc, T3[X2(i + 1, j)], gX[S2(i + 1, j)], gX[S2(i, j)], gX[S2(i + 2, j)],
-                                  KX[S2(i + 1, j)], KX[S2(i, j)], KX[S2(i + 2, j)]);
+                                  KX[S2(i + 1, j)], KX[S2(i, j)], KX[S2(i + 2, j)], xLp, xRp);
     const double FE0 = hsimt_flux(Hv[X2(i, j)], T3[X2(i, j - 1)], tc, gE[S2(i, j)], gE[S2(i, j - 1)], gE[S2(i, j + 1)],
-                                  KE[S2(i, j)], KE[S2(i, j - 1)], KE[S2(i, j + 1)]);
+                                  KE[S2(i, j)], KE[S2(i, j - 1)], KE[S2(i, j + 1)], eL0, eR0);
     const double FEp = hsimt_flux(Hv[X2(i, j + 1)], tc, T3[X2(i, j + 1)], gE[S2(i, j + 1)], gE[S2(i, j)], gE[S2(i, j + 2)],
-                                  KE[S2(i, j + 1)], KE[S2(i, j)], KE[S2(i, j + 2)]);
+                                  KE[S2(i, j + 1)], KE[S2(i, j)], KE[S2(i, j + 2)], eLp, eRp);
     const double cff = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
     const double cff1 = cff * (FXp - FX0);
     const double cff2 = cff * (FEp - FE0);

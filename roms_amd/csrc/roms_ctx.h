@@ -48,6 +48,10 @@ struct DGrid {
   double dt, dtfast, rho0, g, lambda, gamma2, Cp, R0, T0, S0, Tcoef, Scoef, hc, dstart;
   double Akt_bak[ROMS_MAXT], Akv_bak;
   double Zob;                 // bottom roughness (UV_LOGDRAG: GRID%ZoBot = Zob, mod_grid.F:1380)
+  // MASKING (mod_grid.F rmask, umask, vmask, pmask): land/sea masks, 1 water / 0 land (pmask 2: no-slip); the arrays
+  // are Fields::rmask ... (upload names "rmask", "umask", "vmask", "pmask"), here for the kernels that get no Fields
+  int masking;
+  const double *rmask, *umask, *vmask, *pmask;
   int Vtransform;
 };
 
@@ -129,6 +133,12 @@ KHD TB block_bounds2(const DGrid &G, int bx, int by) { return block_bounds_n(G, 
 
 // boundary-fill kinds of the halo code (k_halo.h, k_haloblock.h)
 enum { BC_NONE = 0, BC_R = 1, BC_U = 2, BC_V = 3 };
+// MASKING, added to BC_R by the launch sequences of a masked run (never seen by the fused-halo paths, which a masked
+// run does not take): BC_MASKF = the gradient value at a closed edge is multiplied by rmask of the boundary point
+// (zetabc.F:264, t3dbc_im.F:214; bc_r2d/bc_w3d fills carry no mask), BC_MASKALL = after the fills the whole plane
+// IstrR:IendR x JstrR:JendR is multiplied by rmask (step3d_t.F:1880-1890).  The slip values of BC_U / BC_V are
+// always multiplied by umask / vmask of the boundary point in a masked run (u2dbc_im.F:989, bc_2d.F:252 ...).
+enum { BC_MASKF = 16, BC_MASKALL = 32, BC_KIND = 15 };
 
 // ------------------------------------------------------------------ indexing (reference layout)
 #define X2(i, j) ((size_t)((i) - G.LBi) + (size_t)((j) - G.LBj) * (size_t)G.ni)
@@ -161,7 +171,7 @@ struct Fields {
   // mod_grid
   GPtr h, f, fomn, pm, pn, om_r, on_r, om_u, on_u, om_v, on_v, om_p, on_p, omn, pmon_r, pnom_r,
       pmon_p, pnom_p, pmon_u, pnom_u, pmon_v, pnom_v, dmde, dndx, angler, xr, yr, lonr, latr, rdrag,
-      rdrag2;
+      rdrag2, rmask, umask, vmask, pmask;
   GPtr Hz, z_r, z_w, Huon, Hvom;
   // mod_ocean
   GPtr zeta, ubar, vbar, rzeta, rubar, rvbar, u, v, t, W, wvel, rho, pden, ru, rv;

@@ -74,6 +74,7 @@ static const FieldDesc g_fields[] = {
     FD(omn, FK_2D), FD(pmon_r, FK_2D), FD(pnom_r, FK_2D), FD(pmon_p, FK_2D), FD(pnom_p, FK_2D), FD(pmon_u, FK_2D),
     FD(pnom_u, FK_2D), FD(pmon_v, FK_2D), FD(pnom_v, FK_2D), FD(dmde, FK_2D), FD(dndx, FK_2D), FD(angler, FK_2D),
     FD(xr, FK_2D), FD(yr, FK_2D), FD(lonr, FK_2D), FD(latr, FK_2D), FD(rdrag, FK_2D), FD(rdrag2, FK_2D),
+    FD(rmask, FK_2D), FD(umask, FK_2D), FD(vmask, FK_2D), FD(pmask, FK_2D),
     FD(Hz, FK_R), FD(z_r, FK_R), FD(z_w, FK_W), FD(Huon, FK_R), FD(Hvom, FK_R),
     FD(zeta, FK_2Dx3), FD(ubar, FK_2Dx3), FD(vbar, FK_2Dx3), FD(rzeta, FK_2Dx2), FD(rubar, FK_2Dx2),
     FD(rvbar, FK_2Dx2), FD(u, FK_Rx2), FD(v, FK_Rx2), FD(t, FK_T), FD(W, FK_W), FD(wvel, FK_W), FD(rho, FK_R),
@@ -248,8 +249,9 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
      // three source lines of a periodic copy
     const int LmT = cfg->Iend - cfg->Istr + 1, MmT = cfg->Jend - cfg->Jstr + 1;
     const char *e = getenv("ROMS_HIP_FUSE_HALO");
+    // (a masked run takes the separate halo launches: the boundary values carry the mask of the boundary point)
     G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && !c->has_exchange && (cfg->EWperiodic || cfg->NSperiodic) && LmT >= 6 && MmT >= 6 &&
-                  !(e && e[0] == '0');
+                  !(e && e[0] == '0') && !(cfg->options & ROMS_MASKING);
     const char *e3 = getenv("ROMS_HIP_FUSE3D");
     G.fuse3d = G.fuse_halo && !(e3 && e3[0] == '0');
   }
@@ -317,6 +319,13 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     if (dmalloc(&p, (size_t)field_elems(c, g_fields[k].kind) * sizeof(double))) { roms_hip_destroy(c); return 2; }
     c->allocs.push_back(p);
     *(double **)((char *)&c->F + g_fields[k].offset) = (double *)p;
+  }
+  {  // land/sea masks: all water until uploaded
+    std::vector<double> ones((size_t)G.nij, 1.0);
+    for (double *m : {(double *)c->F.rmask, (double *)c->F.umask, (double *)c->F.vmask, (double *)c->F.pmask})
+      if (h2d(m, ones.data(), ones.size() * sizeof(double), c->stream)) { roms_hip_destroy(c); return 2; }
+    c->G.rmask = c->F.rmask; c->G.umask = c->F.umask; c->G.vmask = c->F.vmask; c->G.pmask = c->F.pmask;
+    c->G.masking = (cfg->options & ROMS_MASKING) != 0;
   }
   for (int k = 0; k < 13; k++) {
     void *p = nullptr;
@@ -1406,7 +1415,8 @@ static int main3d_one(roms_hip_ctx *c) {
 #else
     const bool uvcol = (cf.options & ROMS_UV_VIS2) && (euc ? euc[0] != '0' : cols >= 128L * 1024L);   // run_uv3dmix2_col's rule
 #endif
-    if (!c->has_exchange && !uvcol && !(elate && elate[0] == '0')) return main3d_late(c, do_diag);
+    // (a masked run keeps the reference order: its boundary fills are separate launches on the compute stream)
+    if (!c->has_exchange && !uvcol && !c->G.masking && !(elate && elate[0] == '0')) return main3d_late(c, do_diag);
   }
   DO(roms_hip_rho_eos(c));                                  // :350
   // Two independent chains follow: set_massflux (:348) -> omega (:534) -> wvelocity (:535), and the

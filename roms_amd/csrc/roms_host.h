@@ -134,6 +134,11 @@ const FieldDesc *find_field(const char *name);
 
 // halo / BC launcher (k_halo.h): nk planes starting at A
 struct HaloSpec { double *A; int nk; int bc; char gtype; };
+// boundary kind of the state variables zeta and t (zetabc.F, t3dbc_im.F): the gradient value carries rmask of the boundary point
+// in a masked run; `all`: and the whole plane is multiplied by rmask afterwards (step3d_t.F:1880)
+inline int bc_rstate(const roms_hip_ctx *c, bool all = false) {
+  return c->G.masking ? (BC_R | BC_MASKF | (all ? BC_MASKALL : 0)) : BC_R;
+}
 void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype);
 // the same as the LAST operation of a routine: nothing enqueued later in that routine depends on it, so in a
 // multi-tile run the exchange may go to the exchange stream and overlap the routines that follow (halo_fence)

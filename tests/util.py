@@ -75,6 +75,17 @@ def make_oracle(cs, g):
     return O
 
 
+def with_masks(cs, g):
+    """the initial state `g` with the land/sea masks of cases.land_mask on its array bounds (the masks are input
+    data of a MASKING case, like h)"""
+    g = dict(g)
+    LBi, UBi, LBj, UBj = [int(x) for x in g["bounds"][:4]]
+    assert g["h"].size == (UBi - LBi + 1) * (UBj - LBj + 1)
+    for n, a in cases.land_mask(cs, LBi, UBi, LBj, UBj).items():
+        g[n] = np.ascontiguousarray(a).ravel()
+    return g
+
+
 def make_hip(cs, g, lib_path=None, device=0, ninfo=0):
     from roms_amd import hiplib
     cfg = cases.hip_cfg(cs, float(g["scalars"][0]), int(g["bounds"][58]), g["weight"], g["sc_r"], g["Cs_r"],
