@@ -184,6 +184,18 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     set_error("a tile of a multi-tile run must be at least 3 points wide and high");
     return 5;
   }
+  if (cfg->options & ROMS_MASKING) {
+    // the masked branches built so far: the UPWELLING-type physics (analytic or uploaded vertical mixing, linear
+    // equation of state, wind/flux forcing).  What is not there is a configuration error, never a silent change.
+    bool mp = false;
+    for (int it = 0; it < cfg->NT; it++) mp |= cfg->hadv[it] == ROMS_MPDATA || cfg->vadv[it] == ROMS_MPDATA;
+    const char *what = mp ? "MPDATA (mpdata_adiff.F masks)"
+                       : (cfg->options & ROMS_LMD_MIXING) ? "LMD_MIXING (lmd_skpp.F masks)"
+                       : (cfg->options & ROMS_BULK_FLUXES) ? "BULK_FLUXES (bulk_flux.F masks)"
+                       : (cfg->options & ROMS_MIX_GEO_TS) ? "MIX_GEO_TS (t3dmix2_geo.h masks)"
+                       : (cfg->options & ROMS_NONLIN_EOS) ? "NONLIN_EOS (rho_eos.F:357,479 masks)" : nullptr;
+    if (what) { set_error(std::string("MASKING is not built together with ") + what); return 5; }
+  }
   {  // array bounds must hold the ghost zone the kernels and the strip exchange assume
     const int pw = cfg->west_edge && !cfg->EWperiodic, pe = cfg->east_edge && !cfg->EWperiodic;
     const int ps = cfg->south_edge && !cfg->NSperiodic, pn = cfg->north_edge && !cfg->NSperiodic;
@@ -1514,6 +1526,10 @@ extern "C" int roms_hip_last_diag(roms_hip_ctx *c, double *out) {
 // at the first call that switches it on.
 extern "C" int roms_hip_avg_config(roms_hip_ctx *c, int nAVG, int ntsAVG, int nrrec, int ntstart, unsigned mask) {
   if (!c || nAVG < 0) return 8;
+  if (nAVG > 0 && c->G.masking) {
+    set_error("AVERAGES is not built together with MASKING (set_avg.F: masked vorticity and rotation, time-averaged masks)");
+    return 5;
+  }
   if (nAVG > 0)
     for (int f = 0; f < 22; f++)
       if (((mask >> f) & 1u) && !c->avg[f]) {

@@ -16,7 +16,7 @@
       integer(c_int), parameter :: ROMS_UV_ADV = 1, ROMS_UV_COR = 2, ROMS_UV_VIS2 = 4, ROMS_TS_DIF2 = 8,      &
      &   ROMS_MIX_GEO_TS = 16, ROMS_CURVGRID = 32, ROMS_NONLIN_EOS = 64, ROMS_UV_QDRAG = 128,                  &
      &   ROMS_LMD_MIXING = 256, ROMS_BULK_FLUXES = 512, ROMS_SOLAR_SOURCE = 1024, ROMS_ANA_VMIX = 2048,        &
-     &   ROMS_SALINITY = 4096, ROMS_SPHERICAL = 8192, ROMS_UV_LOGDRAG = 16384,                                 &
+     &   ROMS_SALINITY = 4096, ROMS_SPHERICAL = 8192, ROMS_UV_LOGDRAG = 16384, ROMS_MASKING = 32768,                                 &
      &   ROMS_APP_UPWELLING = 1048576, ROMS_APP_BENCHMARK = 2097152
 
       TYPE, bind(C) :: roms_hip_config

@@ -69,6 +69,7 @@
       real(r8), allocatable, target :: pnom_u(:,:), pmon_v(:,:), pnom_v(:,:), dmde(:,:), dndx(:,:), angler(:,:)
       real(r8), allocatable, target :: xr(:,:), yr(:,:), lonr(:,:), latr(:,:), rdrag(:,:), rdrag2(:,:)
       real(r8), allocatable, target :: visc2_r(:,:), visc2_p(:,:), diff2(:,:,:)
+      real(r8), allocatable, target :: rmask(:,:), umask(:,:), vmask(:,:), pmask(:,:)     ! MASKING (all water otherwise)
       real(r8), allocatable, target :: Hz(:,:,:), z_r(:,:,:), z_w(:,:,:)
       real(r8), allocatable, target :: zeta(:,:,:), ubar(:,:,:), vbar(:,:,:), u(:,:,:,:), v(:,:,:,:), t(:,:,:,:,:)
       real(r8), allocatable, target :: Akv(:,:,:), Akt(:,:,:,:), Zt_avg1(:,:)
@@ -666,7 +667,8 @@
       END DO
       CALL define ('ANA_INITIAL'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
       SELECT CASE (TRIM(MyAppCPP))
-        CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG')      ! (_LOGDRAG: oracle/ref/upwelling_logdrag.h)
+        CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK')   ! (oracle/ref/upwelling_logdrag.h, _mask.h)
+          IF (TRIM(MyAppCPP).eq.'UPWELLING_MASK') CALL define ('MASKING')
           CALL define (TRIM(MERGE('UV_LOGDRAG', 'UV_LDRAG  ', TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG')))
           CALL define ('MIX_S_TS')
           DO k=1,SIZE(flux0)
@@ -703,12 +705,12 @@
       integer :: k
       logical :: upw, bench
 !  options with a bit in the mask (include/roms_hip.h)
-      character(len=16), parameter :: bitname(15) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
+      character(len=16), parameter :: bitname(16) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
      &    'TS_DIF2', 'MIX_GEO_TS', 'CURVGRID', 'NONLIN_EOS', 'UV_QDRAG', 'LMD_MIXING', 'BULK_FLUXES',           &
-     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG' ]
-      integer, parameter :: bitval(15) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
+     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG', 'MASKING' ]
+      integer, parameter :: bitval(16) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
      &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
-     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG ]
+     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING ]
 !  options whose code is the only form built (accepted, nothing to select) or that only affect output
       character(len=16), parameter :: inherent(31) = [ character(len=16) :: 'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
      &    'DJ_GRADPS', 'MIX_S_UV', 'MIX_S_TS', 'SPLINES_VDIFF', 'SPLINES_VVISC', 'UV_LDRAG', 'ANA_SMFLUX',        &
@@ -719,7 +721,7 @@
      &    'DIAGNOSTICS_UV' ]
       IF (ierr.ne.0) RETURN
       upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
-     &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.is_defined('UPWELLING')
+     &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING')
       bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.is_defined('BENCHMARK')
       IF (upw.eqv.bench) THEN
         CALL unsupported ('MyAppCPP = '//TRIM(MyAppCPP)//': the analytic grid, initial state and forcing '//   &
@@ -764,6 +766,12 @@
      &  CALL unsupported ('ALBEDO (ana_srflux zenith-angle formula) is built for BENCHMARK only', ierr)
       IF ((is_defined('SPHERICAL').or.is_defined('CURVGRID').or.is_defined('NONLIN_EOS')).and..not.bench)       &
      &  CALL unsupported ('SPHERICAL / CURVGRID / NONLIN_EOS are built for BENCHMARK only', ierr)
+!  MASKING: the analytic land of this host (island + headland, SUBROUTINE analytic_masks) goes with the UPWELLING grid; the
+!  masked branches exist for its physics (the library refuses the rest: roms_hip_create)
+      IF (is_defined('MASKING').and.(.not.upw.or.is_defined('LMD_MIXING').or.is_defined('AVERAGES').or.       &
+     &    ANY(hadv(1:NAT).eq.ROMS_MPDATA)))                                                                    &
+     &  CALL unsupported ('MASKING is built for the UPWELLING physics with ANA_VMIX, without MPDATA and '//     &
+     &                    'without AVERAGES', ierr)
       END SUBROUTINE options_from_defines
 
       SUBROUTINE set_cppdefs (ierr)
@@ -1301,7 +1309,8 @@
      &           dmde(LBi:UBi,LBj:UBj), dndx(LBi:UBi,LBj:UBj), angler(LBi:UBi,LBj:UBj), xr(LBi:UBi,LBj:UBj),   &
      &           yr(LBi:UBi,LBj:UBj), lonr(LBi:UBi,LBj:UBj), latr(LBi:UBi,LBj:UBj), rdrag(LBi:UBi,LBj:UBj),    &
      &           rdrag2(LBi:UBi,LBj:UBj), visc2_r(LBi:UBi,LBj:UBj), visc2_p(LBi:UBi,LBj:UBj),                  &
-     &           diff2(LBi:UBi,LBj:UBj,NT), Zt_avg1(LBi:UBi,LBj:UBj) )
+     &           diff2(LBi:UBi,LBj:UBj,NT), Zt_avg1(LBi:UBi,LBj:UBj), rmask(LBi:UBi,LBj:UBj),                  &
+     &           umask(LBi:UBi,LBj:UBj), vmask(LBi:UBi,LBj:UBj), pmask(LBi:UBi,LBj:UBj) )
       allocate ( Hz(LBi:UBi,LBj:UBj,N), z_r(LBi:UBi,LBj:UBj,N), z_w(LBi:UBi,LBj:UBj,0:N),                     &
      &           zeta(LBi:UBi,LBj:UBj,3), ubar(LBi:UBi,LBj:UBj,3), vbar(LBi:UBi,LBj:UBj,3),                    &
      &           u(LBi:UBi,LBj:UBj,N,2), v(LBi:UBi,LBj:UBj,N,2), t(LBi:UBi,LBj:UBj,N,3,NT),                    &
@@ -1317,18 +1326,60 @@
       CALL vertical_coordinate (ierr)
       IF (ierr.ne.0) RETURN
       CALL barotropic_filter ()
+      CALL analytic_masks ()
       CALL grid_metrics ()
       CALL ini_mixing ()
       CALL level_depths (Zt_avg1)               ! Zt_avg1 = 0: depths of the resting ocean
       CALL initial_state ()
       END SUBROUTINE host_setup
 
+!
+!  Land/sea masks of a MASKING run (all water otherwise).  The reference reads them from its grid file (or
+!  ana_mask.h of an application); this host has the land of its masked test case: an island of 3 x 3 cells east of
+!  Lm/3 around Mm/2 and a headland two cells wide at 2 Lm/3 from the southern wall (wall row included) to Mm/4,
+!  xi wrapped where periodic.  u, v masks: product of the two rho masks across the face (ana_mask.h:224-233).
+!  psi mask: the slipperiness mask metrics.F:527-583 derives -- 1 with at most one land cell among the four
+!  around the point, 2 (no-slip) where the two land cells share a side of it, 0 otherwise -- on the points that
+!  routine computes (IstrP:IendP, JstrP:JendP and their periodic images); the outermost lines keep 0.
+!
+      SUBROUTINE analytic_masks ()
+      integer :: i, j, iw, jw, i0, j0, i1, nl
+      real(r8) :: a, b, c, d
+      rmask=1.0_r8; umask=1.0_r8; vmask=1.0_r8; pmask=1.0_r8
+      IF (.not.is_defined('MASKING')) RETURN
+      i0=Lm/3+1; j0=Mm/2; i1=2*Lm/3+1
+      DO j=LBj,UBj
+        DO i=LBi,UBi
+          iw=MERGE(MODULO(i-1,Lm)+1, i, EWperiodic)
+          jw=MERGE(MODULO(j-1,Mm)+1, j, NSperiodic)
+          IF ((iw.ge.i0.and.iw.le.i0+2.and.jw.ge.j0.and.jw.le.j0+2).or.                                       &
+     &        (iw.ge.i1.and.iw.le.i1+1.and.jw.le.Mm/4)) rmask(i,j)=0.0_r8
+        END DO
+      END DO
+      umask(LBi+1:UBi,:)=rmask(LBi:UBi-1,:)*rmask(LBi+1:UBi,:)
+      vmask(:,LBj+1:UBj)=rmask(:,LBj:UBj-1)*rmask(:,LBj+1:UBj)
+      pmask=0.0_r8
+      DO j=LBj+1,UBj
+        DO i=LBi+1,UBi
+          IF (MERGE(i.eq.UBi, i.lt.1.or.i.gt.Lm+1, EWperiodic)) CYCLE
+          IF (MERGE(j.eq.UBj, j.lt.1.or.j.gt.Mm+1, NSperiodic)) CYCLE
+          a=rmask(i-1,j); b=rmask(i,j); c=rmask(i-1,j-1); d=rmask(i,j-1)
+          nl=4-NINT(a+b+c+d)
+          IF (nl.le.1) THEN
+            pmask(i,j)=1.0_r8
+          ELSE IF (nl.eq.2.and.(a+b.eq.0.0_r8.or.c+d.eq.0.0_r8.or.a+c.eq.0.0_r8.or.b+d.eq.0.0_r8)) THEN
+            pmask(i,j)=2.0_r8
+          END IF
+        END DO
+      END DO
+      END SUBROUTINE analytic_masks
+
       SUBROUTINE host_free ()
       deallocate ( weight, sc_r, Cs_r, sc_w, Cs_w )
       deallocate ( h, f, fomn, pm, pn, om_r, on_r, om_u, on_u, om_v, on_v, om_p, on_p, omn, pmon_r, pnom_r,    &
      &             pmon_p, pnom_p, pmon_u, pnom_u, pmon_v, pnom_v, dmde, dndx, angler, xr, yr, lonr, latr,    &
      &             rdrag, rdrag2, visc2_r, visc2_p, diff2, Zt_avg1, Hz, z_r, z_w, zeta, ubar, vbar, u, v, t,  &
-     &             Akv, Akt )
+     &             Akv, Akt, rmask, umask, vmask, pmask )
       END SUBROUTINE host_free
 !
 !=======================================================================
@@ -1419,6 +1470,10 @@
       CALL up ('rdrag2', rdrag2, 1, ierr); CALL up ('visc2_r', visc2_r, 1, ierr)
       CALL up ('visc2_p', visc2_p, 1, ierr); CALL up ('diff2', diff2, NT, ierr)
       CALL up ('Zt_avg1', Zt_avg1, 1, ierr)
+      IF (is_defined('MASKING')) THEN
+        CALL up ('rmask', rmask, 1, ierr); CALL up ('umask', umask, 1, ierr)
+        CALL up ('vmask', vmask, 1, ierr); CALL up ('pmask', pmask, 1, ierr)
+      END IF
       CALL up ('Hz', Hz, N, ierr); CALL up ('z_r', z_r, N, ierr); CALL up ('z_w', z_w, N+1, ierr)
       CALL up ('zeta', zeta, 3, ierr); CALL up ('ubar', ubar, 3, ierr); CALL up ('vbar', vbar, 3, ierr)
       CALL up ('u', u, 2*N, ierr); CALL up ('v', v, 2*N, ierr); CALL up ('t', t, 3*N*NT, ierr)

@@ -274,6 +274,10 @@
         CASE ('latr');    CALL put (RESHAPE(latr,(/SIZE(latr)/)))
         CASE ('rdrag');   CALL put (RESHAPE(rdrag,(/SIZE(rdrag)/)))
         CASE ('rdrag2');  CALL put (RESHAPE(rdrag2,(/SIZE(rdrag2)/)))
+        CASE ('rmask');   CALL put (RESHAPE(rmask,(/SIZE(rmask)/)))
+        CASE ('umask');   CALL put (RESHAPE(umask,(/SIZE(umask)/)))
+        CASE ('vmask');   CALL put (RESHAPE(vmask,(/SIZE(vmask)/)))
+        CASE ('pmask');   CALL put (RESHAPE(pmask,(/SIZE(pmask)/)))
         CASE ('visc2_r'); CALL put (RESHAPE(visc2_r,(/SIZE(visc2_r)/)))
         CASE ('visc2_p'); CALL put (RESHAPE(visc2_p,(/SIZE(visc2_p)/)))
         CASE ('diff2');   CALL put (RESHAPE(diff2,(/SIZE(diff2)/)))

@@ -163,6 +163,10 @@
       real(r8) :: AVGtime = 0.0_r8                 ! mod_scalars.F: time stamp of the averages record
       integer :: ntstart_run = 1                   ! first step of this run (initial.F:172; > 1 after get_state)
       logical :: restarted = .FALSE.
+!  MASKING: history and averages fields carry _FillValue = spval and land points are written as spval (nf_fwrite2d.F,
+!  mod_scalars.F spval); the restart file keeps the computed values (PERFECT_RESTART)
+      real(r8), parameter :: spval = 1.0E+37_r8
+      logical :: land_fill = .FALSE., def_fill = .FALSE.
 
       CONTAINS
 
@@ -179,6 +183,9 @@
       LOGICAL FUNCTION is_spherical ()
       is_spherical=IAND(options,ROMS_SPHERICAL).ne.0
       END FUNCTION is_spherical
+      LOGICAL FUNCTION is_masked ()
+      is_masked=IAND(options,ROMS_MASKING).ne.0
+      END FUNCTION is_masked
 !
 !-----------------------------------------------------------------------
 !  The state array `name` of the device as a GLOBAL host array A(LBi:UBi,LBj:UBj,np) (np = all its planes).
@@ -227,11 +234,23 @@
       real(r8), intent(in) :: A(LBi:UBi,LBj:UBj,np)
       integer, intent(inout) :: ierr
       real(r8), allocatable :: buf(:,:,:)
-      integer :: i0, i1, j0, j1
+      integer :: i0, i1, j0, j1, k
       IF (ierr.ne.0.or..not.master()) RETURN
       CALL io_range (g, i0, i1, j0, j1)
       allocate ( buf(i0:i1,j0:j1,k0:k1) )
       buf=A(i0:i1,j0:j1,k0:k1)
+      IF (land_fill) THEN                                 ! MASKING: land points of a history field = spval (nf_fwrite2d.F)
+        DO k=k0,k1
+          SELECT CASE (g)
+            CASE (gR2, gR3, gW3)
+              WHERE (rmask(i0:i1,j0:j1).lt.0.5_r8) buf(:,:,k)=spval
+            CASE (gU2, gU3, gUW)
+              WHERE (umask(i0:i1,j0:j1).lt.0.5_r8) buf(:,:,k)=spval
+            CASE DEFAULT
+              WHERE (vmask(i0:i1,j0:j1).lt.0.5_r8) buf(:,:,k)=spval
+          END SELECT
+        END DO
+      END IF
       IF (nc3_put_var_double(h, varid, INT(MAX(rec,0),c_long), buf, SIZE(buf,KIND=c_long_long)).ne.0) THEN
         ierr=3                                            ! exit_flag 3: output error (mod_scalars.F)
         host_message='output: error while writing a field'
@@ -325,6 +344,7 @@
         r=r+nc3_put_att_text(o%h, varid, cs('units'), cs(units))
       END IF
       IF (timed) r=r+nc3_put_att_text(o%h, varid, cs('time'), cs('ocean_time'))
+      IF (timed.and.def_fill) r=r+nc3_put_att_double(o%h, varid, cs('_FillValue'), 1_c_int, (/ spval /))
       r=r+nc3_put_att_text(o%h, varid, cs('grid'), cs('grid'))
       r=r+nc3_put_att_text(o%h, varid, cs('location'), cs(loc))
       IF (is_spherical()) THEN
@@ -460,6 +480,14 @@
           k=k+1; CALL def_field (o, 'y_rho', 'grid_y_location_at_cell_center', 'y-locations of RHO-points',        &
      &                           'meter', 'y_rho', gR2, -1_c_int, .FALSE., vid(k,w), ierr)
         END IF
+        IF (is_masked()) THEN                               ! def_info.F under MASKING (mask_psi: no psi grid here)
+          k=k+1; CALL def_field (o, 'mask_rho', 'land_sea_mask_at_cell_center', 'mask on RHO-points',              &
+     &                           'nondimensional', 'mask_rho', gR2, -1_c_int, .FALSE., vid(k,w), ierr)
+          k=k+1; CALL def_field (o, 'mask_u', 'land_sea_mask_at_cell_y_edges', 'mask on U-points',                 &
+     &                           'nondimensional', 'mask_u', gU2, -1_c_int, .FALSE., vid(k,w), ierr)
+          k=k+1; CALL def_field (o, 'mask_v', 'land_sea_mask_at_cell_x_edges', 'mask on V-points',                 &
+     &                           'nondimensional', 'mask_v', gV2, -1_c_int, .FALSE., vid(k,w), ierr)
+        END IF
       ELSE
         k=0
         CALL iput (ntimes); CALL iput (ndtfast); CALL dput (dt); CALL dput (dtfast); CALL dput (dstart)
@@ -481,6 +509,11 @@
         ELSE
           A(:,:,1)=xr; k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
           A(:,:,1)=yr; k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
+        END IF
+        IF (is_masked()) THEN
+          A(:,:,1)=rmask; k=k+1; CALL put_field (o%h, vid(k,w), -1, gR2, A, 1, 1, 1, ierr)
+          A(:,:,1)=umask; k=k+1; CALL put_field (o%h, vid(k,w), -1, gU2, A, 1, 1, 1, ierr)
+          A(:,:,1)=vmask; k=k+1; CALL put_field (o%h, vid(k,w), -1, gV2, A, 1, 1, 1, ierr)
         END IF
         deallocate ( A )
       END IF
@@ -554,6 +587,7 @@
         host_message='cannot create '//TRIM(path)
         RETURN
       END IF
+      def_fill=is_masked().and..not.rst
       ASSOCIATE (o => ofile(which))
       CALL def_dims (o, rst, ierr)
       CALL info (o, TRIM(path), TRIM(ftype), .TRUE., ierr)
@@ -680,6 +714,7 @@
       END IF
       CALL info (o, TRIM(path), TRIM(ftype), .FALSE., ierr)
       END ASSOCIATE
+      def_fill=.FALSE.
 
       CONTAINS
         SUBROUTINE adef (slot, name, stdname, longname, units, field, g)
@@ -717,6 +752,7 @@
       ierr=roms_hip_output_point(ctx)                      ! main3d.F:591
       IF (ierr.ne.0) RETURN
       ierr=roms_hip_get_stepping(ctx, step)
+      land_fill=is_masked().and..not.rst
       ASSOCIATE (o => ofile(which))
 !  record index: wrt_rst.F:151 (LcycleRST: two records, recycled), wrt_his.F
       o%nrec=o%nrec+1
@@ -817,6 +853,7 @@
         IF (nc3_sync(o%h).ne.0) ierr=3                      ! netcdf_sync after every record (wrt_his.F)
       END IF
       END ASSOCIATE
+      land_fill=.FALSE.
 
       CONTAINS
 !  wrt_avg.F: the converted averages of the window that has just closed

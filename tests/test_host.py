@@ -97,13 +97,13 @@ def test_host_needs_device_for_run():
 # must not run silently with different physics here.
 # ---------------------------------------------------------------------------------------------------
 BASE_IN = """
-    MyAppCPP = UPWELLING
+    MyAppCPP = %(app)s
           Lm == 14
           Mm == 18
            N == 8
    Hadvection == %(h1)s  \\
                  %(h2)s
-   Vadvection == C4 \\
+   Vadvection == %(v1)s \\
                  C4
    LBC(isFsur) ==   %(fs)s
    LBC(isUbar) ==   %(ub)s
@@ -119,7 +119,7 @@ ad_LBC(isFsur) ==   Rad     Rad     Rad     Rad
           DT == 300.0d0
      NDTFAST == 30
 """
-GOOD = dict(h1="U3", h2="U3", fs="Per Clo Per Clo", ub="Per Clo Per Clo", tv="Per Clo Per Clo", extra="")
+GOOD = dict(app="UPWELLING", v1="C4", h1="U3", h2="U3", fs="Per Clo Per Clo", ub="Per Clo Per Clo", tv="Per Clo Per Clo", extra="")
 
 
 def _setup(tmp_path, header=None, **kw):
@@ -156,6 +156,29 @@ def test_reader_stops_on_settings_it_cannot_honour(tmp_path, kw, needle):
     with pytest.raises(hostlib.HostError) as e:
         _setup(tmp_path, **kw).finalize()
     assert e.value.exit_flag == 5 and needle in str(e.value), str(e.value)
+
+
+def test_masking_option_and_analytic_masks(tmp_path):
+    """MASKING: built-in application UPWELLING_MASK and oracle/ref/upwelling_mask.h as header both set the bit; the
+    host's analytic land (roms_host.f90:analytic_masks, psi mask by the rule of metrics.F) equals tests' cases.land_mask,
+    which the reference's own metrics.F output was compared with (tests/refdrive.py); unsupported company stops the set-up."""
+    from roms_amd import hiplib, hostlib
+    from tests import cases
+    hdr = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "oracle", "ref", "upwelling_mask.h"))
+    for kw in (dict(header=hdr), dict(app="UPWELLING_MASK")):
+        H = _setup(tmp_path, **kw)
+        try:
+            assert H.dims["options"] & hiplib.OPTIONS["MASKING"]
+            cs = dict(Lm=H.dims["Lm"], Mm=H.dims["Mm"], EWperiodic=H.dims["EWper"], NSperiodic=H.dims["NSper"])
+            m = cases.land_mask(cs, H.dims["LBi"], H.dims["UBi"], H.dims["LBj"], H.dims["UBj"])
+            for n, a in m.items():
+                assert np.array_equal(H.get(n), a.ravel()), n
+            assert (m["rmask"] == 0).sum() > 10 and (m["pmask"] == 2).sum() > 4
+        finally:
+            H.finalize()
+    with pytest.raises(hostlib.HostError) as e:
+        _setup(tmp_path, app="UPWELLING_MASK", h1="MPDATA", v1="MPDATA").finalize()
+    assert e.value.exit_flag == 5 and "MASKING" in str(e.value)
 
 
 def test_logdrag_header_selects_the_option(tmp_path):

@@ -140,6 +140,23 @@ def test_land_sea_masking_bitwise(emu, hadv, vadv):
     H.close()
 
 
+def test_masked_run_through_the_fortran_host_matches_the_oracle(emu):
+    """roms.in (MyAppCPP = UPWELLING_MASK) -> Fortran host (its own analytic land, option surface, uploads) -> C ABI ->
+    kernels: the same bits as the oracle driven with tests' cases.land_mask, 6 steps."""
+    from roms_amd import hostlib
+    cs = util.case_for("upwelling_mask_small", hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"))
+    g = util.with_masks(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    O = util.make_oracle(cs, g)
+    O.start()
+    O.main3d_step(6)
+    H = hostlib.Host(params=dict(cs, ninfo=0), lib_path=os.path.join(os.path.dirname(emu), "libroms_host_emu.so"), hip_lib_path=emu)
+    ctx = H.device_init()
+    H.run(6)
+    for n in ("zeta", "u", "v", "t", "ubar", "vbar", "rho", "W"):
+        assert np.array_equal(ctx.download(n), O.field(n)), n
+    H.finalize()
+
+
 @pytest.mark.parametrize("hadv,vadv,ng,ewp", [(("U3", "U3"), ("C4", "C4"), 2, 1), (("U3", "HSIMT"), ("C4", "HSIMT"), 3, 1),
                                               (("U3", "U3"), ("C4", "C4"), 2, 0)])
 def test_ns_periodic(emu, hadv, vadv, ng, ewp):

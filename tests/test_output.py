@@ -388,3 +388,58 @@ def test_averages_file_holds_the_reference_set_avg_fields(which, tmp_path):
             assert np.array_equal(a, b) if exact else util.relrms(b, a) <= 1e-11, (step, name)
     assert np.abs(V["uv"][1]).max() > 0.0
     f.close()
+
+
+@pytest.mark.parametrize("which", LIBS)
+def test_masked_run_history_and_restart(which, tmp_path):
+    """MASKING: the history file carries mask_rho, mask_u, mask_v (def_info.F), its fields have _FillValue = 1e37 and
+    land points written as 1e37 (nf_fwrite2d.F) with the water points equal to the device state; the restart file keeps
+    the computed values and a run restarted from it continues bit for bit."""
+    from tests import cases
+    cs = util.case_for("upwelling_mask_small", hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"))
+    his, rst = str(tmp_path / "his.nc"), str(tmp_path / "rst.nc")
+    cs.update(NHIS=3, NRST=3, HISNAME=his, RSTNAME=rst, Hout=HOUT, ninfo=0, LcycleRST=False)
+    H, ctx = _host(cs, which)
+    H.advance(6, final=True)
+    t = H.tile
+    m = cases.land_mask(cs, t["LBi"], t["UBi"], t["LBj"], t["UBj"])
+    # (zeta is left out: the final record is taken at the output point of step 7, behind its set_zeta)
+    end = {n: ctx.download(n).copy() for n in ("u", "v", "t", "ubar", "vbar")}
+    H.close_output()
+    H.finalize()
+    f = _nc(his)
+    V = f.variables
+    i0 = 0 - t["LBi"]                                         # file columns 0..Lm+1 within the periodic array
+    Lm, Mm = cs["Lm"], cs["Mm"]
+    mr = m["rmask"][:Mm + 2, i0:i0 + Lm + 2]
+    assert np.array_equal(V["mask_rho"][:], mr) and V["mask_u"].shape == (Mm + 2, Lm + 1) and V["mask_v"].shape == (Mm + 1, Lm + 2)
+    assert np.array_equal(V["mask_u"][:], m["umask"][:Mm + 2, i0 + 1:i0 + Lm + 2]) and np.array_equal(V["mask_v"][:], m["vmask"][1:Mm + 2, i0:i0 + Lm + 2])
+    for n in ("zeta", "temp", "u"):
+        assert V[n]._FillValue == 1.0e37
+    z = V["zeta"][:]
+    assert z.shape[0] == 3 and (z[:, mr == 0] == 1.0e37).all() and (np.abs(z[:, mr == 1]) < 10).all()
+    ni = t["UBi"] - t["LBi"] + 1
+    tt = V["temp"][:]
+    inner = np.zeros_like(mr, dtype=bool)
+    inner[:, 1:Lm + 1] = True                                 # (the periodic image columns of record 0 hold the uploaded values)
+    assert (tt[:, :, mr == 0] == 1.0e37).all() and (tt[:, :, (mr == 1) & inner] > 5).all()
+    uu = V["u"][:]
+    mu = m["umask"][:Mm + 2, i0 + 1:i0 + Lm + 2]
+    assert (uu[:, :, mu == 0] == 1.0e37).all() and (np.abs(uu[:, :, mu == 1]) < 1).all()
+    f.close()
+    r = _nc(rst)
+    assert "_FillValue" not in r.variables["zeta"]._attributes and not (r.variables["zeta"][:] == 1.0e37).any()
+    assert (r.variables["temp"][:][..., mr == 0] == 0).all()            # land: the masked model value
+    nrec = r.variables["ocean_time"].shape[0]
+    r.close()
+    # restart from the record written at step 3 and run to step 6: the same bits
+    cs2 = dict(cs, NRREC=1, ININAME=rst, NHIS=0, NRST=0, ntimes=6)
+    H2, ctx2 = _host(cs2, which)
+    H2.get_state(rst, 1)
+    H2.advance(3, final=False)
+    nj = t["UBj"] - t["LBj"] + 1
+    for n, a in end.items():
+        a, b = a.reshape(-1, nj, ni), ctx2.download(n).reshape(-1, nj, ni)
+        assert np.array_equal(util.unpadded(a, cs, ni, nj), util.unpadded(b, cs, ni, nj)), n
+    H2.finalize()
+    assert nrec == 2

@@ -57,6 +57,8 @@ def _interior(cs_dims, a):
     ("benchmark_small", dict(), (4, 2), 29615),
     # three ghost lines on the high side (MPDATA), corner blocks from the diagonal tiles
     ("upwelling_small", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (2, 2), 29614),
+    # MASKING: the island straddles the tile boundaries, the headland sits on the southern wall of one tile
+    ("upwelling_mask_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 2), 29616),
 ])
 def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     _emu_libs()
