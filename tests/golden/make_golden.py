@@ -220,6 +220,8 @@ STEP_CASES = [
     ("upwelling_small_c4su3", "upwelling_small", ["nsteps=30", "hadv=C4,SU3", "vadv=A4,C4"]),
     ("benchmark_small", "benchmark_small", ["nsteps=100"]),
     ("upwelling_kpp_small", "upwelling_kpp_small", ["nsteps=100"]),
+    # MASKING: the reference built with oracle/ref/upwelling_mask.h, land of cases.land_mask
+    ("upwelling_mask_small", "upwelling_mask_small", ["nsteps=60", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
 ]
 KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
 def make_avg():

@@ -165,6 +165,8 @@ class OracleSide:
     def __init__(self, cs):
         self.cs = cs
         self.g = load_init(init_tag(cs), nghost_for(cs))
+        if "MASKING" in cs["options"]:          # the masks are input data of the case (cases.land_mask)
+            self.g = with_masks(cs, self.g)
         self.O = make_oracle(cs, self.g)
         self.O.start()
 
@@ -218,6 +220,8 @@ class HipSide:
     def __init__(self, cs, ninfo=1):
         self.cs = cs
         self.g = load_init(init_tag(cs), nghost_for(cs))
+        if "MASKING" in cs["options"]:          # the masks are input data of the case (cases.land_mask)
+            self.g = with_masks(cs, self.g)
         self.H = make_hip(cs, self.g, ninfo=ninfo)
         self.H.start()
 
