@@ -22,7 +22,7 @@ int run_step2d(roms_hip_ctx *c) {
   }
   // kernel variant by sub-tile size: up to 32x4, up to 64x8, generic (ROMS_HIP_TILE2D overrides)
   int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 32 && G.bh2 <= 8) ? 3 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
-  if (getenv("ROMS_HIP_S2D_GENERIC")) variant = 2;
+  if (getenv("ROMS_HIP_S2D_GENERIC") || G.masking) variant = 2;   // (the generic form carries the land/sea masks)
   // 64x8 sub-tiles: 1024 threads (one rectangle point and one momentum point per thread) measure 3 %
   // faster than 512 threads with two each; ROMS_HIP_S2D_1024=0 selects the latter
   const char *e1024 = getenv("ROMS_HIP_S2D_1024");

@@ -129,6 +129,9 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
   __builtin_amdgcn_s_setprio(3);   // beside other kernels (main3d_late) these waves are the step's critical path
 #endif
   constexpr bool FIXED = BWC > 0;
+  // MASKING runs take the generic form (g_step2d.cpp): the fixed-shape instantiations compile the mask products away
+  // (with them k_step2d_c spilled 36 VGPRs instead of 14 and an unmasked 512x512x50 step took 7 % longer)
+  const bool MSK = !FIXED && a.G.masking;
   const DGrid &G = a.G;
   const S2Fields &F = a.F;
   const TB B = block_bounds2(G, bx, by);
@@ -326,7 +329,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
           const double cff = cff1 * rhs_zeta;
           zeta_new = zsv + sPm[s0] * sPn[s0] * (cff + cff2 * PW(r_rz_s, F.rzeta[x0 + o_kstp]) - cff3 * PW(r_rz_p, F.rzeta[x0 + o_ptsk]));
         }
-        if (G.masking) zeta_new = zeta_new * G.rmask[x0];                      // :907,933,964
+        if (MSK) zeta_new = zeta_new * G.rmask[x0];                      // :907,933,964
         if (mode == 0) zw = 0.5 * (zsv + zeta_new);
         else if (mode == 1) zw = cff5 * zkv + cff4 * (zsv + zeta_new);
         else zw = cff5 * zeta_new + cff4 * zkv;
@@ -487,7 +490,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
         const double sr1 = STRESS_R(a1, b1, WV(w_v2r1, isv, mr[x1].v[MR_V2]), WV(w_pmr1, isv, mr[x1].v[MR_PMON]), WV(w_pnr1, isv, mr[x1].v[MR_PNOM]));
         double sp0 = STRESS_P(0, 0, WV(w_v2p0, isv, mp[x].v[MP_V2]), WV(w_pmp0, isv, mp[x].v[MP_PMON]), WV(w_pnp0, isv, mp[x].v[MP_PNOM]));
         double sp1 = STRESS_P(qa, qb, WV(w_v2p1, isv, mp[q1].v[MP_V2]), WV(w_pmp1, isv, mp[q1].v[MP_PMON]), WV(w_pnp1, isv, mp[q1].v[MP_PNOM]));
-        if (G.masking) { sp0 = sp0 * G.pmask[x]; sp1 = sp1 * G.pmask[q1]; }   // :1613
+        if (MSK) { sp0 = sp0 * G.pmask[x]; sp1 = sp1 * G.pmask[q1]; }   // :1613
         // on_r (u) | om_r (v) at P0, P1; om_p (u) | on_p (v) at Q0, Q1
         const double or0 = WV(w_or0, isv, isv ? mr[x].v[MR_OM] : mr[x].v[MR_ON]);
         const double or1 = WV(w_or1, isv, isv ? mr[x1].v[MR_OM] : mr[x1].v[MR_ON]);
@@ -540,7 +543,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
       if (!corr) b = (sv * (Dstp0 + Dstp1) + cff * c1 * r) * fac;
       else b = (sv * (Dstp0 + Dstp1) +
                 cff * (k1 * r + k2 * WV(w_rs, isv, rb[x + o_kstp]) - k3 * WV(w_rp, isv, rb[x + o_ptsk]))) * fac;
-      if (G.masking) b = b * (isv ? G.vmask : G.umask)[x];                      // :2515-2660
+      if (MSK) b = b * (isv ? G.vmask : G.umask)[x];                      // :2515-2660
       // u2dbc/v2dbc :2871-2876 + exchange :3043
       if (!isv) {
         if (fuse) hb_emit(G, B, un, BC_U, i, j, b);
