@@ -105,6 +105,7 @@ void orc_bulk_flux(orc_t *o, int tile) {
   const orc_bounds *b = &o->b[tile];
   const orc_cfg *c = &o->c;
   const int nrhs = o->s.nrhs;
+  const int msk = (c->options & ORC_MASKING) != 0;
   const int Istr = b->Istr, Jstr = b->Jstr, IendR = b->IendR, JendR = b->JendR;
   const double eps = 1.0E-20, r3 = 1.0 / 3.0, g = c->g;
   const double ZW = c->blk_ZW, ZT = c->blk_ZT, ZQ = c->blk_ZQ;
@@ -132,6 +133,7 @@ void orc_bulk_flux(orc_t *o, int tile) {
       LRad[X2(i, j)] = -emmiss * StefBo *
                        (cff1 * (0.39 - 0.05 * sqrt(vap_p)) * (1.0 - 0.6823 * o->cloud[X2(i, j)] * o->cloud[X2(i, j)]) +
                         cff2 * 4.0 * (TseaK - TairK));
+      if (msk) LRad[X2(i, j)] = LRad[X2(i, j)] * o->rmask[X2(i, j)];                      /* bulk_flux.F:635 */
       /* specific humidities */
       cff = (1.0007 + 3.46E-6 * PairM) * 6.1121 * exp(17.502 * TairC / (240.97 + TairC));
       const double Qair = 0.62197 * (cff / (PairM - 0.378 * cff + eps));
@@ -202,14 +204,18 @@ void orc_bulk_flux(orc_t *o, int tile) {
       const double wet_bulb = 1.0 / (1.0 + 0.622 * (cff * Hlv * diffw) / (blk_Cpa * diffh));
       const double Hsr = fabs(o->rain[X2(i, j)]) * wet_bulb * blk_Cpw * ((TseaC - TairC) + (Qsea - Q) * Hlv / blk_Cpa);
       SHeat[X2(i, j)] = (Hs + Hsr);
+      if (msk) SHeat[X2(i, j)] = SHeat[X2(i, j)] * o->rmask[X2(i, j)];                    /* :977 */
       const double Hl = -Hlv * rhoAir * Wstar * Qstar;
       const double upvel = -1.61 * Wstar * Qstar - (1.0 + 1.61 * Q) * Wstar * Tstar / TairK;
       const double Hlw = rhoAir * Hlv * upvel * Q;
       LHeat[X2(i, j)] = (Hl + Hlw);
+      if (msk) LHeat[X2(i, j)] = LHeat[X2(i, j)] * o->rmask[X2(i, j)];                    /* :1006 */
       const double Taur = 0.85 * fabs(o->rain[X2(i, j)]) * Wmag;
       cff = rhoAir * (Wstar * Wstar + Taur / rhoAir) / (Wmag + eps);
       Taux[X2(i, j)] = cff * Uair;
+      if (msk) Taux[X2(i, j)] = Taux[X2(i, j)] * o->rmask[X2(i, j)];                      /* :1030 */
       Tauy[X2(i, j)] = cff * Vair;
+      if (msk) Tauy[X2(i, j)] = Tauy[X2(i, j)] * o->rmask[X2(i, j)];                      /* :1037 */
     }
   Hscale = 1.0 / (c->rho0 * c->Cp);
   for (int j = b->JstrR; j <= JendR; j++)
@@ -218,12 +224,19 @@ void orc_bulk_flux(orc_t *o, int tile) {
       o->lhflx[X2(i, j)] = -LHeat[X2(i, j)] * Hscale;
       o->shflx[X2(i, j)] = -SHeat[X2(i, j)] * Hscale;
       o->stflux[X2T(i, j, 1)] = (o->srflx[X2(i, j)] + o->lrflx[X2(i, j)] + o->lhflx[X2(i, j)] + o->shflx[X2(i, j)]);
+      if (msk) o->stflux[X2T(i, j, 1)] = o->stflux[X2T(i, j, 1)] * o->rmask[X2(i, j)];    /* :1259 */
     }
   const double cff = 0.5 / c->rho0;
   for (int j = b->JstrR; j <= JendR; j++)
-    for (int i = Istr; i <= IendR; i++) o->sustr[X2(i, j)] = cff * (Taux[X2(i - 1, j)] + Taux[X2(i, j)]);
+    for (int i = Istr; i <= IendR; i++) {
+      o->sustr[X2(i, j)] = cff * (Taux[X2(i - 1, j)] + Taux[X2(i, j)]);
+      if (msk) o->sustr[X2(i, j)] = o->sustr[X2(i, j)] * o->umask[X2(i, j)];              /* :1295 */
+    }
   for (int j = Jstr; j <= JendR; j++)
-    for (int i = b->IstrR; i <= IendR; i++) o->svstr[X2(i, j)] = cff * (Tauy[X2(i, j - 1)] + Tauy[X2(i, j)]);
+    for (int i = b->IstrR; i <= IendR; i++) {
+      o->svstr[X2(i, j)] = cff * (Tauy[X2(i, j - 1)] + Tauy[X2(i, j)]);
+      if (msk) o->svstr[X2(i, j)] = o->svstr[X2(i, j)] * o->vmask[X2(i, j)];              /* :1310 */
+    }
   free(S);
   (void)rhow;
   orc_exchange2d(o, b, 'r', o->lrflx);

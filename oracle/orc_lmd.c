@@ -116,6 +116,7 @@ static void lmd_interior(orc_t *o, const orc_bounds *b) {
 
 static void lmd_skpp(orc_t *o, const orc_bounds *b) {
   ORC_LOCALS(o);
+  const int msk = (o->c.options & ORC_MASKING) != 0;
   const int nstp = o->s.nstp;
   const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
   const double eps = 1.0E-10, g = o->c.g, gorho0 = o->c.g / o->c.rho0;
@@ -141,6 +142,7 @@ static void lmd_skpp(orc_t *o, const orc_bounds *b) {
     for (int i = Istr; i <= Iend; i++) {
       const double a = 0.5 * (sustr[X2(i, j)] + sustr[X2(i + 1, j)]), c = 0.5 * (svstr[X2(i, j)] + svstr[X2(i, j + 1)]);
       Ustar[X2(i, j)] = sqrt(sqrt(a * a + c * c));
+      if (msk) Ustar[X2(i, j)] = Ustar[X2(i, j)] * o->rmask[X2(i, j)];                    /* lmd_skpp.F:273 */
     }
   for (int j = Jstr; j <= Jend; j++)
     for (int i = Istr; i <= Iend; i++) {
@@ -155,6 +157,7 @@ static void lmd_skpp(orc_t *o, const orc_bounds *b) {
     for (int j = Jstr; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
         Bflux[XW(i, j, k)] = (Bo[X2(i, j)] + Bosol[X2(i, j)] * (1.0 - swdk[X2(i, j)]));
+        if (msk) Bflux[XW(i, j, k)] = Bflux[XW(i, j, k)] * o->rmask[X2(i, j)];            /* :317 */
         cff = 1.0 - (0.5 + copysign(0.5, Bflux[XW(i, j, k)]));
         ghats[XW4(i, j, k, 1)] = -cff * (stflx[X2T(i, j, 1)] - srflx[X2(i, j)] + srflx[X2(i, j)] * (1.0 - swdk[X2(i, j)]));
         ghats[XW4(i, j, k, 2)] = cff * stflx[X2T(i, j, 2)];
@@ -204,10 +207,16 @@ static void lmd_skpp(orc_t *o, const orc_bounds *b) {
         }
   }
   for (int j = Jstr; j <= Jend; j++)
-    for (int i = Istr; i <= Iend; i++) zgrid[X2(i, j)] = z_w[XW(i, j, N)] - hsbl[X2(i, j)];
+    for (int i = Istr; i <= Iend; i++) {
+      zgrid[X2(i, j)] = z_w[XW(i, j, N)] - hsbl[X2(i, j)];
+      if (msk) zgrid[X2(i, j)] = zgrid[X2(i, j)] * o->rmask[X2(i, j)];                    /* :563,670 */
+    }
   orc_lmd_swfrac(o, b, -1.0, zgrid, swdk);
   for (int j = Jstr; j <= Jend; j++)
-    for (int i = Istr; i <= Iend; i++) Bfsfc[X2(i, j)] = (Bo[X2(i, j)] + Bosol[X2(i, j)] * (1.0 - swdk[X2(i, j)]));
+    for (int i = Istr; i <= Iend; i++) {
+      Bfsfc[X2(i, j)] = (Bo[X2(i, j)] + Bosol[X2(i, j)] * (1.0 - swdk[X2(i, j)]));
+      if (msk) Bfsfc[X2(i, j)] = Bfsfc[X2(i, j)] * o->rmask[X2(i, j)];                    /* :575,682 */
+    }
   /* stable-case limits: Ekman and Monin-Obukhov depths */
   for (int j = Jstr; j <= Jend; j++)
     for (int i = Istr; i <= Iend; i++) {
@@ -221,6 +230,7 @@ static void lmd_skpp(orc_t *o, const orc_bounds *b) {
       }
       hsbl[X2(i, j)] = MIN(hsbl[X2(i, j)], z_w[XW(i, j, N)]);
       hsbl[X2(i, j)] = MAX(hsbl[X2(i, j)], z_w[XW(i, j, 0)]);
+      if (msk) hsbl[X2(i, j)] = hsbl[X2(i, j)] * o->rmask[X2(i, j)];                      /* :596 */
     }
   orc_bc_r2d(o, b, hsbl);
   for (int j = Jstr; j <= Jend; j++)
@@ -230,10 +240,16 @@ static void lmd_skpp(orc_t *o, const orc_bounds *b) {
         if (ksbl[X2(i, j)] == 1 && z_w[XW(i, j, k - 1)] < hsbl[X2(i, j)]) ksbl[X2(i, j)] = k;
     }
   for (int j = Jstr; j <= Jend; j++)
-    for (int i = Istr; i <= Iend; i++) zgrid[X2(i, j)] = z_w[XW(i, j, N)] - hsbl[X2(i, j)];
+    for (int i = Istr; i <= Iend; i++) {
+      zgrid[X2(i, j)] = z_w[XW(i, j, N)] - hsbl[X2(i, j)];
+      if (msk) zgrid[X2(i, j)] = zgrid[X2(i, j)] * o->rmask[X2(i, j)];                    /* :563,670 */
+    }
   orc_lmd_swfrac(o, b, -1.0, zgrid, swdk);
   for (int j = Jstr; j <= Jend; j++)
-    for (int i = Istr; i <= Iend; i++) Bfsfc[X2(i, j)] = (Bo[X2(i, j)] + Bosol[X2(i, j)] * (1.0 - swdk[X2(i, j)]));
+    for (int i = Istr; i <= Iend; i++) {
+      Bfsfc[X2(i, j)] = (Bo[X2(i, j)] + Bosol[X2(i, j)] * (1.0 - swdk[X2(i, j)]));
+      if (msk) Bfsfc[X2(i, j)] = Bfsfc[X2(i, j)] * o->rmask[X2(i, j)];                    /* :575,682 */
+    }
   /* turbulent velocity scales at the boundary layer depth */
   for (int j = Jstr; j <= Jend; j++)
     for (int i = Istr; i <= Iend; i++) {
@@ -263,25 +279,31 @@ static void lmd_skpp(orc_t *o, const orc_bounds *b) {
         K_bl = cff_dn * Akv[XW(i, j, k)] + cff_up * Akv[XW(i, j, k - 1)];
         dK_bl = cff * (Akv[XW(i, j, k)] - Akv[XW(i, j, k - 1)]);
         Gm1[X2(i, j)] = K_bl / (zbl * wm[X2(i, j)] + eps);
+        if (msk) Gm1[X2(i, j)] = Gm1[X2(i, j)] * o->rmask[X2(i, j)];                      /* :755,800 */
         dGm1dS[X2(i, j)] = MIN(0.0, -dK_bl / (wm[X2(i, j)] + eps) - K_bl * f1[X2(i, j)]);
         K_bl = cff_dn * Akt[XW4(i, j, k, 1)] + cff_up * Akt[XW4(i, j, k - 1, 1)];
         dK_bl = cff * (Akt[XW4(i, j, k, 1)] - Akt[XW4(i, j, k - 1, 1)]);
         Gt1[X2(i, j)] = K_bl / (zbl * ws[X2(i, j)] + eps);
+        if (msk) Gt1[X2(i, j)] = Gt1[X2(i, j)] * o->rmask[X2(i, j)];                      /* :766,809 */
         dGt1dS[X2(i, j)] = MIN(0.0, -dK_bl / (ws[X2(i, j)] + eps) - K_bl * f1[X2(i, j)]);
         K_bl = cff_dn * Akt[XW4(i, j, k, 2)] + cff_up * Akt[XW4(i, j, k - 1, 2)];
         dK_bl = cff * (Akt[XW4(i, j, k, 2)] - Akt[XW4(i, j, k - 1, 2)]);
         Gs1[X2(i, j)] = K_bl / (zbl * ws[X2(i, j)] + eps);
+        if (msk) Gs1[X2(i, j)] = Gs1[X2(i, j)] * o->rmask[X2(i, j)];                      /* :778 */
         dGs1dS[X2(i, j)] = MIN(0.0, -dK_bl / (ws[X2(i, j)] + eps) - K_bl * f1[X2(i, j)]);
       } else {
         ksbl[X2(i, j)] = 0;
         const double a = 0.5 * (o->bustr[X2(i, j)] + o->bustr[X2(i + 1, j)]),
                      c = 0.5 * (o->bvstr[X2(i, j)] + o->bvstr[X2(i, j + 1)]);
-        const double Ustarb = sqrt(sqrt(a * a + c * c));
+        double Ustarb = sqrt(sqrt(a * a + c * c));
+        if (msk) Ustarb = Ustarb * o->rmask[X2(i, j)];                                    /* :794 */
         dK_bl = vonKar * Ustarb;
         K_bl = dK_bl * (hsbl[X2(i, j)] - z_w[XW(i, j, 0)]);
         Gm1[X2(i, j)] = K_bl / (zbl * wm[X2(i, j)] + eps);
+        if (msk) Gm1[X2(i, j)] = Gm1[X2(i, j)] * o->rmask[X2(i, j)];                      /* :755,800 */
         dGm1dS[X2(i, j)] = MIN(0.0, -dK_bl / (wm[X2(i, j)] + eps) - K_bl * f1[X2(i, j)]);
         Gt1[X2(i, j)] = K_bl / (zbl * ws[X2(i, j)] + eps);
+        if (msk) Gt1[X2(i, j)] = Gt1[X2(i, j)] * o->rmask[X2(i, j)];                      /* :766,809 */
         dGt1dS[X2(i, j)] = MIN(0.0, -dK_bl / (ws[X2(i, j)] + eps) - K_bl * f1[X2(i, j)]);
         Gs1[X2(i, j)] = Gt1[X2(i, j)];
         dGs1dS[X2(i, j)] = dGt1dS[X2(i, j)];
@@ -302,6 +324,7 @@ static void lmd_skpp(orc_t *o, const orc_bounds *b) {
           const double zetahat = vonKar * sigma * Bflux[XW(i, j, k)];
           wscale(Us, zetahat, Ustar3, &wm[X2(i, j)], &ws[X2(i, j)]);
           sigma = depth / (zbl + eps);
+          if (msk) sigma = sigma * o->rmask[X2(i, j)];                                    /* :867 */
           const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
           const double Gm = a1 + a2 * Gm1[X2(i, j)] + a3 * dGm1dS[X2(i, j)];
           const double Gt = a1 + a2 * Gt1[X2(i, j)] + a3 * dGt1dS[X2(i, j)];

@@ -55,6 +55,11 @@ if [ "$APP" = upwelling_mask ]; then
   UP=UPWELLING; HDR=upwelling_mask; HDRPATH="$HERE/upwelling_mask.h"
   EXTRA="-I$HERE/functionals"     # the user analytical file ana_mask.h of this application
 fi
+if [ "$APP" = benchmark_mask ]; then
+  # the BENCHMARK case with MASKING (oracle/ref/benchmark_mask.h): pins the masked KPP / bulk-flux / EOS / geopotential-mixing branches
+  UP=BENCHMARK; HDR=benchmark_mask; HDRPATH="$HERE/benchmark_mask.h"
+  EXTRA="-I$HERE/functionals"
+fi
 if [ "$APP" = upwelling_avg ]; then
   # the UPWELLING case with AVERAGES (oracle/ref/upwelling_avg.h): pins set_avg.F
   UP=UPWELLING; HDR=upwelling_avg; HDRPATH="$HERE/upwelling_avg.h"

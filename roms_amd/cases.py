@@ -51,6 +51,15 @@ def upwelling_mask(**kw):
     return cs
 
 
+def benchmark_mask(**kw):
+    """BENCHMARK (KPP, bulk fluxes, nonlinear EOS, geopotential mixing) with land/sea masking: the custom application
+    header oracle/ref/benchmark_mask.h, land of `land_mask`"""
+    cs = benchmark(**kw)
+    cs["app"] = "benchmark_mask"
+    cs["options"] = tuple(cs["options"]) + ("MASKING",)
+    return cs
+
+
 def land_mask(cs, LBi, UBi, LBj, UBj):
     """rmask, umask, vmask, pmask of the masked test cases on arrays (LBi:UBi, LBj:UBj), Fortran order [j, i] here.
     Land: an island of 3 x 3 cells east of Lm/3 around Mm/2, and a headland two cells wide at 2 Lm/3 from the

@@ -26,6 +26,7 @@ CASES = {
     "upwelling_logdrag_small": ("upwelling_logdrag", dict(Lm=14, Mm=18, N=8)),
     # UPWELLING with land/sea masking (oracle/ref/upwelling_mask.h; the masks are cases.land_mask)
     "upwelling_mask_small": ("upwelling_mask", dict(Lm=14, Mm=18, N=8)),
+    "benchmark_mask_small": ("benchmark_mask", dict(Lm=24, Mm=16, N=10)),
 }
 
 
@@ -106,7 +107,7 @@ def make_case(tag, **kw):
     k.update(kw)
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
-                upwelling_mask=cases.upwelling_mask)[app]
+                upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask)[app]
     return app, ctor(**k)
 
 

@@ -179,7 +179,8 @@ def _child(mode, tag, *args, timeout=900):
         resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
 
     lib = {"upwelling_kpp_small": "upwelling_kpp", "upwelling_avg_small": "upwelling_avg",
-           "upwelling_logdrag_small": "upwelling_logdrag", "upwelling_mask_small": "upwelling_mask"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
+           "upwelling_logdrag_small": "upwelling_logdrag", "upwelling_mask_small": "upwelling_mask",
+           "benchmark_mask_small": "benchmark_mask"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
     if not ref.available(lib):
         pytest.skip(f"oracle/_ref/libromsref_{lib}.so not built here")
     p = subprocess.run([sys.executable, "-m", "tests.refchild", mode, tag] + list(args), capture_output=True,
@@ -203,6 +204,8 @@ MAIN3D_CASES = [
     ("upwelling_mask_small", ["nsteps=60", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),   # MASKING: island + headland
     ("upwelling_mask_small", ["nsteps=30", "hadv=A4,C4", "vadv=SPLINES,C4"]),
     ("upwelling_mask_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("benchmark_mask_small", ["nsteps=60"]),                                     # MASKING with KPP, bulk fluxes, nonlinear EOS, geopotential mixing
+    ("benchmark_mask_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
     ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
 ]
@@ -226,6 +229,7 @@ def test_main3d_steps_bitwise(tag, args):
     ("upwelling_kpp_small", []),
     ("upwelling_mask_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     ("upwelling_mask_small", ["hadv=C4,A4", "vadv=C4,A4"]),
+    ("benchmark_mask_small", []),
 ])
 def test_core_kernels_bitwise(tag, args):
     """step2d_tile (step2d_LF_AM3.h:163; first predictor, correctors, last predictor), omega_tile (omega.F:96),
@@ -236,7 +240,7 @@ def test_core_kernels_bitwise(tag, args):
 
 
 @pytest.mark.parametrize("tag", ["benchmark_small", "upwelling_kpp_small", "upwelling_small", "upwelling_logdrag_small",
-                                 "upwelling_mask_small"])
+                                 "upwelling_mask_small", "benchmark_mask_small"])
 def test_physics_routines_bitwise(tag):
     """set_depth, set_massflux, rho_eos (rho, pden, rhoA, rhoS, bvf, alpha, beta: rho_eos.F:247-560), the analytic
     atmosphere + ana_srflux (set_data.F), bulk_flux (bulk_flux.F:208), set_vbc (QDRAG), lmd_vmix, omega,

@@ -57,6 +57,8 @@ def case_for(tag, **kw):
         return cases.upwelling_kpp(Lm=14, Mm=18, N=8, **kw)
     if tag == "benchmark_small":
         return cases.benchmark(Lm=24, Mm=16, N=10, **kw)
+    if tag == "benchmark_mask_small":
+        return cases.benchmark_mask(Lm=24, Mm=16, N=10, **kw)
     if tag == "upwelling_mask_small":
         return cases.upwelling_mask(Lm=14, Mm=18, N=8, **kw)
     if tag == "upwelling_logdrag_small":
