@@ -90,9 +90,10 @@ THREAD_KERNEL(k_eos_nl, KArgs) {
     const int k = k0 - q;
     if (k < 1) break;
     const double zr_k = c_zr[q];
-    const EosLevel L = eos_level(c_t1[q], c_t2[q], zr_k);
+    EosLevel L = eos_level(c_t1[q], c_t2[q], zr_k);
+    if (G.masking) L.den = L.den * F.rmask[X2(i, j)];                                    // rho_eos.F:357
     emit_store(G, P, F.rho + (size_t)(k - 1) * G.nij, L.den);
-    emit_store(G, P, F.pden + (size_t)(k - 1) * G.nij, (L.den1 - 1000.0));
+    emit_store(G, P, F.pden + (size_t)(k - 1) * G.nij, G.masking ? (L.den1 - 1000.0) * F.rmask[X2(i, j)] : (L.den1 - 1000.0));   // :479
     const double Hzk = c_hz[q];
     const double cff1 = L.den * Hzk;
     if (k == N) {
@@ -190,8 +191,11 @@ THREAD_KERNEL(k_t3dmix2_geo, KArgs) {
   const long ni = G.ni, x = (long)X2(i, j);
   const double *pm = F.pm + x, *pn = F.pn + x;
   const double *d2 = F.diff2 + (size_t)(itrc - 1) * nij + x;
-  const double cxi = 0.5 * (pm[0] + pm[-1]), cxp = 0.5 * (pm[1] + pm[0]);
-  const double cej = 0.5 * (pn[0] + pn[-ni]), cep = 0.5 * (pn[ni] + pn[0]);
+  double cxi = 0.5 * (pm[0] + pm[-1]), cxp = 0.5 * (pm[1] + pm[0]);
+  double cej = 0.5 * (pn[0] + pn[-ni]), cep = 0.5 * (pn[ni] + pn[0]);
+  if (G.masking) {                                   // t3dmix2_geo.h:229,261
+    cxi = cxi * F.umask[x]; cxp = cxp * F.umask[x + 1]; cej = cej * F.vmask[x]; cep = cep * F.vmask[x + ni];
+  }
   const double fxi = 0.25 * (d2[0] + d2[-1]) * F.on_u[x], fxp = 0.25 * (d2[1] + d2[0]) * F.on_u[x + 1];
   const double fej = 0.25 * (d2[0] + d2[-ni]) * F.om_v[x], fep = 0.25 * (d2[ni] + d2[0]) * F.om_v[x + ni];
   const double cS = 0.5 * d2[0];
@@ -373,23 +377,29 @@ THREAD_KERNEL(k_bulk_pt, BulkArgs) {
   const double wet_bulb = 1.0 / (1.0 + 0.622 * (cff * Hlv * diffw) / (blk_Cpa * diffh));
   const double rn = fabs(F.rain[X2(i, j)]);
   const double Hsr = rn * wet_bulb * blk_Cpw * ((TseaC - TairC) + (Qsea - Q) * Hlv / blk_Cpa);
-  const double SHeat = (Hs + Hsr);
+  double SHeat = (Hs + Hsr);
   const double Hl = -Hlv * rhoAir * Wstar * Qstar;
   const double upvel = -1.61 * Wstar * Qstar - (1.0 + 1.61 * Q) * Wstar * Tstar / TairK;
   const double Hlw = rhoAir * Hlv * upvel * Q;
-  const double LHeat = (Hl + Hlw);
+  double LHeat = (Hl + Hlw);
   const double Taur = 0.85 * rn * Wmag;
   cff = rhoAir * (Wstar * Wstar + Taur / rhoAir) / (Wmag + eps);
-  F.wrk2[0][X2(i, j)] = cff * Uair;
-  F.wrk2[1][X2(i, j)] = cff * Vair;
+  double Taux = cff * Uair, Tauy = cff * Vair, LRadm = LRad;
+  if (G.masking) {                                   // bulk_flux.F:635,977,1006,1030,1037
+    const double rm = F.rmask[X2(i, j)];
+    LRadm = LRadm * rm; SHeat = SHeat * rm; LHeat = LHeat * rm; Taux = Taux * rm; Tauy = Tauy * rm;
+  }
+  F.wrk2[0][X2(i, j)] = Taux;
+  F.wrk2[1][X2(i, j)] = Tauy;
   if (i >= B.IstrR && j >= B.JstrR) {
     const double Hscale = 1.0 / (G.rho0 * G.Cp);
-    const double lr = LRad * Hscale, lh = -LHeat * Hscale, sh = -SHeat * Hscale;
+    const double lr = LRadm * Hscale, lh = -LHeat * Hscale, sh = -SHeat * Hscale;
     const EmitPlan P = emit_plan(G, BC_NONE, i, j);
     emit_store(G, P, F.lrflx, lr);
     emit_store(G, P, F.lhflx, lh);
     emit_store(G, P, F.shflx, sh);
-    emit_store(G, P, F.stflux, (F.srflx[X2(i, j)] + lr + lh + sh));
+    const double st = (F.srflx[X2(i, j)] + lr + lh + sh);
+    emit_store(G, P, F.stflux, G.masking ? st * F.rmask[X2(i, j)] : st);                 // :1259
   }
 }
 THREAD_GLOBAL(k_bulk_pt, BulkArgs)
@@ -403,8 +413,14 @@ THREAD_KERNEL(k_bulk_str, BulkArgs) {
   const int i = KMIN(B.Istr, B.IstrR) + gx, j = KMIN(B.Jstr, B.JstrR) + gy;
   const double cff = 0.5 / G.rho0;
   const EmitPlan P = emit_plan(G, BC_NONE, i, j);
-  if (i >= B.Istr && j >= B.JstrR) emit_store(G, P, F.sustr, cff * (F.wrk2[0][X2(i - 1, j)] + F.wrk2[0][X2(i, j)]));
-  if (i >= B.IstrR && j >= B.Jstr) emit_store(G, P, F.svstr, cff * (F.wrk2[1][X2(i, j - 1)] + F.wrk2[1][X2(i, j)]));
+  if (i >= B.Istr && j >= B.JstrR) {
+    const double s = cff * (F.wrk2[0][X2(i - 1, j)] + F.wrk2[0][X2(i, j)]);
+    emit_store(G, P, F.sustr, G.masking ? s * F.umask[X2(i, j)] : s);                    // :1295
+  }
+  if (i >= B.IstrR && j >= B.Jstr) {
+    const double s = cff * (F.wrk2[1][X2(i, j - 1)] + F.wrk2[1][X2(i, j)]);
+    emit_store(G, P, F.svstr, G.masking ? s * F.vmask[X2(i, j)] : s);                    // :1310
+  }
 }
 THREAD_GLOBAL(k_bulk_str, BulkArgs)
 

@@ -211,6 +211,10 @@ KDEV void lmd_skpp_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
     const double sa = 0.5 * (F.sustr[X2(i, j)] + F.sustr[X2(i + 1, j)]), sc = 0.5 * (F.svstr[X2(i, j)] + F.svstr[X2(i, j + 1)]);
     Ustar = sqrt(sqrt(sa * sa + sc * sc));
   }
+  // MASKING (lmd_skpp.F:273-867): rmask of the column; every product below is the reference's statement
+  const bool msk = G.masking != 0;
+  const double rm = msk ? F.rmask[X2(i, j)] : 1.0;
+  if (msk) Ustar = Ustar * rm;
   const double st1 = F.stflx[X2T(i, j, 1)], st2 = F.stflx[X2T(i, j, 2)], sr = F.srflx[X2(i, j)];
   const double Bo = g * (F.alpha[X2(i, j)] * (st1 - sr) - F.beta[X2(i, j)] * st2);
   const double Bosol = g * F.alpha[X2(i, j)] * sr;
@@ -224,7 +228,8 @@ KDEV void lmd_skpp_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
       const int k = k0 + q;
       if (k > N) break;
       const double swdk = SWFRAC(zwN - zw_[q]);
-      const double bf = (Bo + Bosol * (1.0 - swdk));
+      double bf = (Bo + Bosol * (1.0 - swdk));
+      if (msk) bf = bf * rm;                                   // :317
       Bflux[XW(i, j, k)] = bf;
       const double cff = 1.0 - (0.5 + copysign(0.5, bf));
       F.ghats[XW4(i, j, k, 1)] = -cff * (st1 - sr + sr * (1.0 - swdk));
@@ -280,7 +285,8 @@ KDEV void lmd_skpp_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
       ksbl = k;
     }
   }
-  double Bfsfc = (Bo + Bosol * (1.0 - SWFRAC(zwN - hsbl)));
+  double Bfsfc = (Bo + Bosol * (1.0 - SWFRAC(msk ? (zwN - hsbl) * rm : zwN - hsbl)));   // zgrid*rmask :563
+  if (msk) Bfsfc = Bfsfc * rm;                                 // :575
   if (Ustar > 0.0 && Bfsfc > 0.0) {
     const double hekman = lmd_cekman * Ustar / KMAX(fabs(F.f[X2(i, j)]), eps);
     const double hmonob = lmd_cmonob * Ustar * Ustar * Ustar / KMAX(vonKar * Bfsfc, eps);
@@ -290,11 +296,13 @@ KDEV void lmd_skpp_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
   }
   hsbl = KMIN(hsbl, zwN);
   hsbl = KMAX(hsbl, z_w[XW(i, j, 0)]);
+  if (msk) hsbl = hsbl * rm;                                   // :596
   emit_store(G, emit_plan(G, BC_R, i, j), F.hsbl, hsbl);     // bc_r2d_tile + exchange lmd_skpp.F:608
   ksbl = 1;
   for (int k = N; k >= 2; k--)
     if (ksbl == 1 && z_w[XW(i, j, k - 1)] < hsbl) ksbl = k;
-  Bfsfc = (Bo + Bosol * (1.0 - SWFRAC(zwN - hsbl)));
+  Bfsfc = (Bo + Bosol * (1.0 - SWFRAC(msk ? (zwN - hsbl) * rm : zwN - hsbl)));          // :670
+  if (msk) Bfsfc = Bfsfc * rm;                                 // :682
   sl_dpth = lmd_epsilon * (zwN - hsbl);
   {
     const double cff = (Bfsfc > 0.0) ? 1.0 : lmd_epsilon;
@@ -313,24 +321,30 @@ KDEV void lmd_skpp_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
     double K_bl = cff_dn * F.Akv[XW(i, j, k)] + cff_up * F.Akv[XW(i, j, k - 1)];
     double dK_bl = cff * (F.Akv[XW(i, j, k)] - F.Akv[XW(i, j, k - 1)]);
     Gm1 = K_bl / (zbl * wm + eps);
+    if (msk) Gm1 = Gm1 * rm;                                   // :755,800
     dGm1dS = KMIN(0.0, -dK_bl / (wm + eps) - K_bl * f1);
     K_bl = cff_dn * F.Akt[XW4(i, j, k, 1)] + cff_up * F.Akt[XW4(i, j, k - 1, 1)];
     dK_bl = cff * (F.Akt[XW4(i, j, k, 1)] - F.Akt[XW4(i, j, k - 1, 1)]);
     Gt1 = K_bl / (zbl * ws + eps);
+    if (msk) Gt1 = Gt1 * rm;                                   // :766,809
     dGt1dS = KMIN(0.0, -dK_bl / (ws + eps) - K_bl * f1);
     K_bl = cff_dn * F.Akt[XW4(i, j, k, 2)] + cff_up * F.Akt[XW4(i, j, k - 1, 2)];
     dK_bl = cff * (F.Akt[XW4(i, j, k, 2)] - F.Akt[XW4(i, j, k - 1, 2)]);
     Gs1 = K_bl / (zbl * ws + eps);
+    if (msk) Gs1 = Gs1 * rm;                                   // :778
     dGs1dS = KMIN(0.0, -dK_bl / (ws + eps) - K_bl * f1);
   } else {
     ksbl = 0;
     const double ba = 0.5 * (F.bustr[X2(i, j)] + F.bustr[X2(i + 1, j)]), bc = 0.5 * (F.bvstr[X2(i, j)] + F.bvstr[X2(i, j + 1)]);
-    const double Ustarb = sqrt(sqrt(ba * ba + bc * bc));
+    double Ustarb = sqrt(sqrt(ba * ba + bc * bc));
+    if (msk) Ustarb = Ustarb * rm;                             // :794
     const double dK_bl = vonKar * Ustarb;
     const double K_bl = dK_bl * (hsbl - z_w[XW(i, j, 0)]);
     Gm1 = K_bl / (zbl * wm + eps);
+    if (msk) Gm1 = Gm1 * rm;                                   // :755,800
     dGm1dS = KMIN(0.0, -dK_bl / (wm + eps) - K_bl * f1);
     Gt1 = K_bl / (zbl * ws + eps);
+    if (msk) Gt1 = Gt1 * rm;                                   // :766,809
     dGt1dS = KMIN(0.0, -dK_bl / (ws + eps) - K_bl * f1);
     Gs1 = Gt1;
     dGs1dS = dGt1dS;
@@ -364,6 +378,7 @@ KDEV void lmd_skpp_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
         const double zetahat = vonKar * sigma * bf;
         lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
         sigma = depth / (zbl + eps);
+        if (msk) sigma = sigma * rm;                           // :867
         const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
         const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
         const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;

@@ -185,16 +185,11 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     return 5;
   }
   if (cfg->options & ROMS_MASKING) {
-    // the masked branches built so far: the UPWELLING-type physics (analytic or uploaded vertical mixing, linear
-    // equation of state, wind/flux forcing).  What is not there is a configuration error, never a silent change.
+    // the masked branches exist for every physics option of the library except MPDATA (mpdata_adiff.F has 111 masked
+    // statements of its own).  What is not there is a configuration error, never a silent change.
     bool mp = false;
     for (int it = 0; it < cfg->NT; it++) mp |= cfg->hadv[it] == ROMS_MPDATA || cfg->vadv[it] == ROMS_MPDATA;
-    const char *what = mp ? "MPDATA (mpdata_adiff.F masks)"
-                       : (cfg->options & ROMS_LMD_MIXING) ? "LMD_MIXING (lmd_skpp.F masks)"
-                       : (cfg->options & ROMS_BULK_FLUXES) ? "BULK_FLUXES (bulk_flux.F masks)"
-                       : (cfg->options & ROMS_MIX_GEO_TS) ? "MIX_GEO_TS (t3dmix2_geo.h masks)"
-                       : (cfg->options & ROMS_NONLIN_EOS) ? "NONLIN_EOS (rho_eos.F:357,479 masks)" : nullptr;
-    if (what) { set_error(std::string("MASKING is not built together with ") + what); return 5; }
+    if (mp) { set_error("MASKING is not built together with MPDATA (mpdata_adiff.F masks)"); return 5; }
   }
   {  // array bounds must hold the ghost zone the kernels and the strip exchange assume
     const int pw = cfg->west_edge && !cfg->EWperiodic, pe = cfg->east_edge && !cfg->EWperiodic;

@@ -682,7 +682,8 @@
             END DO
             CALL define ('ANA_SRFLUX')
           END IF
-        CASE ('BENCHMARK')
+        CASE ('BENCHMARK', 'BENCHMARK_MASK')                          ! (_MASK: oracle/ref/benchmark_mask.h)
+          IF (TRIM(MyAppCPP).eq.'BENCHMARK_MASK') CALL define ('MASKING')
           CALL define ('UV_QDRAG'); CALL define ('MIX_GEO_TS'); CALL define ('NONLIN_EOS')
           CALL define ('CURVGRID'); CALL define ('SPHERICAL'); CALL define ('ANA_SRFLUX')
           CALL define ('ANA_SSFLUX'); CALL define ('ANA_BSFLUX'); CALL define ('ANA_BTFLUX')
@@ -722,7 +723,7 @@
       IF (ierr.ne.0) RETURN
       upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
      &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING')
-      bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.is_defined('BENCHMARK')
+      bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.TRIM(MyAppCPP).eq.'BENCHMARK_MASK'.or.is_defined('BENCHMARK')
       IF (upw.eqv.bench) THEN
         CALL unsupported ('MyAppCPP = '//TRIM(MyAppCPP)//': the analytic grid, initial state and forcing '//   &
      &                    'exist for UPWELLING and BENCHMARK', ierr)
@@ -768,10 +769,8 @@
      &  CALL unsupported ('SPHERICAL / CURVGRID / NONLIN_EOS are built for BENCHMARK only', ierr)
 !  MASKING: the analytic land of this host (island + headland, SUBROUTINE analytic_masks) goes with the UPWELLING grid; the
 !  masked branches exist for its physics (the library refuses the rest: roms_hip_create)
-      IF (is_defined('MASKING').and.(.not.upw.or.is_defined('LMD_MIXING').or.is_defined('AVERAGES').or.       &
-     &    ANY(hadv(1:NAT).eq.ROMS_MPDATA)))                                                                    &
-     &  CALL unsupported ('MASKING is built for the UPWELLING physics with ANA_VMIX, without MPDATA and '//     &
-     &                    'without AVERAGES', ierr)
+      IF (is_defined('MASKING').and.(is_defined('AVERAGES').or.ANY(hadv(1:NAT).eq.ROMS_MPDATA)))               &
+     &  CALL unsupported ('MASKING is built without MPDATA and without AVERAGES', ierr)
       END SUBROUTINE options_from_defines
 
       SUBROUTINE set_cppdefs (ierr)

@@ -222,6 +222,7 @@ STEP_CASES = [
     ("upwelling_kpp_small", "upwelling_kpp_small", ["nsteps=100"]),
     # MASKING: the reference built with oracle/ref/upwelling_mask.h, land of cases.land_mask
     ("upwelling_mask_small", "upwelling_mask_small", ["nsteps=60", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("benchmark_mask_small", "benchmark_mask_small", ["nsteps=60"]),      # oracle/ref/benchmark_mask.h
 ]
 KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
 def make_avg():

@@ -751,9 +751,12 @@ def test_mailbox_tiles_on_one_gpu_match_single_tile(tmp_path, tag, kw, tiles, po
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hadv,vadv,env", [(("U3", "HSIMT"), ("C4", "HSIMT"), {}), (("A4", "C4"), ("SPLINES", "C4"), {}),
-                                           (("U3", "U3"), ("C4", "C4"), {"ROMS_HIP_COLLDS": "0", "ROMS_HIP_TADV_LDS": "1"})])
-def test_land_sea_masking_matches_oracle(hadv, vadv, env):
+@pytest.mark.parametrize("tag,hadv,vadv,env", [
+    ("upwelling_mask_small", ("U3", "HSIMT"), ("C4", "HSIMT"), {}), ("upwelling_mask_small", ("A4", "C4"), ("SPLINES", "C4"), {}),
+    ("upwelling_mask_small", ("U3", "U3"), ("C4", "C4"), {"ROMS_HIP_COLLDS": "0", "ROMS_HIP_TADV_LDS": "1"}),
+    # the BENCHMARK physics: nonlinear EOS, bulk fluxes, KPP (both kernel forms), geopotential mixing
+    ("benchmark_mask_small", ("U3", "U3"), ("C4", "C4"), {}), ("benchmark_mask_small", ("U3", "U3"), ("C4", "C4"), {"ROMS_HIP_LMDCOL": "0"})])
+def test_land_sea_masking_matches_oracle(tag, hadv, vadv, env):
     """MASKING on the GPU (island + headland; the oracle is pinned bit for bit to the reference built with
     oracle/ref/upwelling_mask.h): 40 steps at the north-star tolerance, land stays land; the LDS-tiled advection kernels
     and the private-array column kernels as well (own process: the switches are read once)."""
@@ -766,8 +769,9 @@ def test_land_sea_masking_matches_oracle(hadv, vadv, env):
         sys.path.insert(0, %r)
         import numpy as np
         from tests import util
-        cs = util.case_for("upwelling_mask_small", hadv=%r, vadv=%r)
-        g = util.with_masks(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+        tag, hadv, vadv = %r, %r, %r
+        cs = util.case_for(tag, **(dict(hadv=hadv, vadv=vadv) if tag.startswith("upwelling") else {}))
+        g = util.with_masks(cs, util.load_init(util.init_tag(cs), util.nghost_for(cs)))
         O = util.make_oracle(cs, g)
         H = util.make_hip(cs, g)
         O.start(); H.start()
@@ -787,6 +791,6 @@ def test_land_sea_masking_matches_oracle(hadv, vadv, env):
         assert np.abs(H.download("u")).max() > 1e-3
         H.close()
         print("MASK-GPU-OK", worst)
-    """) % (ROOT, tuple(hadv), tuple(vadv))
+    """) % (ROOT, tag, tuple(hadv), tuple(vadv))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
     assert "MASK-GPU-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

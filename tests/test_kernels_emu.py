@@ -140,6 +140,37 @@ def test_land_sea_masking_bitwise(emu, hadv, vadv):
     H.close()
 
 
+def test_land_sea_masking_benchmark_physics_bitwise(emu):
+    """MASKING with the BENCHMARK physics (oracle pinned to the reference built from oracle/ref/benchmark_mask.h): the
+    masked branches of the nonlinear EOS, the COARE bulk fluxes, KPP (surface boundary layer) and the geopotential
+    tracer mixing kernels against the oracle's over 8 steps, bit for bit; directly and through the Fortran host
+    (MyAppCPP = BENCHMARK_MASK: its own analytic land)."""
+    from roms_amd import hostlib
+    cs = util.case_for("benchmark_mask_small")
+    g = util.with_masks(cs, util.load_init("benchmark_small", util.nghost_for(cs)))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start()
+    H.start()
+    for _ in range(8):
+        O.main3d_step()
+        H.main3d(1)
+        for n in util.PROGNOSTIC:
+            a, b = H.download(n), O.field(n)
+            assert np.isfinite(b).all(), n
+            assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+    land = g["rmask"] == 0
+    for n in ("rho", "hsbl", "stflx", "t"):
+        assert not H.download(n).reshape(-1, land.size)[:, land].any(), n
+    H.close()
+    Hh = hostlib.Host(params=dict(cs, ninfo=0), lib_path=os.path.join(os.path.dirname(emu), "libroms_host_emu.so"), hip_lib_path=emu)
+    ctx = Hh.device_init()
+    Hh.run(8)
+    for n in ("zeta", "u", "v", "t", "rho", "Akv", "hsbl"):
+        assert np.array_equal(ctx.download(n), O.field(n)), n
+    Hh.finalize()
+
+
 def test_masked_run_through_the_fortran_host_matches_the_oracle(emu):
     """roms.in (MyAppCPP = UPWELLING_MASK) -> Fortran host (its own analytic land, option surface, uploads) -> C ABI ->
     kernels: the same bits as the oracle driven with tests' cases.land_mask, 6 steps."""
