@@ -48,7 +48,7 @@ enum {
   ROMS_UV_LOGDRAG = 1 << 14,        /* logarithmic bottom drag from Zob (set_vbc.F:591-635); else UV_QDRAG / UV_LDRAG */
   ROMS_MASKING = 1 << 15,           /* land/sea masks: arrays "rmask", "umask", "vmask", "pmask" (mod_grid.F), all water until
                                        uploaded; every physics option of the library carries its masked branches except MPDATA
-                                       and AVERAGES (exit_flag 5) */
+                                       (exit_flag 5) */
   ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21
 };
 

@@ -60,6 +60,11 @@ if [ "$APP" = benchmark_mask ]; then
   UP=BENCHMARK; HDR=benchmark_mask; HDRPATH="$HERE/benchmark_mask.h"
   EXTRA="-I$HERE/functionals"
 fi
+if [ "$APP" = upwelling_avg_mask ]; then
+  # AVERAGES + MASKING (oracle/ref/upwelling_avg_mask.h)
+  UP=UPWELLING; HDR=upwelling_avg_mask; HDRPATH="$HERE/upwelling_avg_mask.h"
+  EXTRA="-I$HERE/functionals"
+fi
 if [ "$APP" = upwelling_avg ]; then
   # the UPWELLING case with AVERAGES (oracle/ref/upwelling_avg.h): pins set_avg.F
   UP=UPWELLING; HDR=upwelling_avg; HDRPATH="$HERE/upwelling_avg.h"

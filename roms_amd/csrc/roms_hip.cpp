@@ -1521,10 +1521,8 @@ extern "C" int roms_hip_last_diag(roms_hip_ctx *c, double *out) {
 // at the first call that switches it on.
 extern "C" int roms_hip_avg_config(roms_hip_ctx *c, int nAVG, int ntsAVG, int nrrec, int ntstart, unsigned mask) {
   if (!c || nAVG < 0) return 8;
-  if (nAVG > 0 && c->G.masking) {
-    set_error("AVERAGES is not built together with MASKING (set_avg.F: masked vorticity and rotation, time-averaged masks)");
-    return 5;
-  }
+  // (MASKING: the 22 fields built carry no mask arithmetic of their own -- set_avg.F masks the rotated and vorticity
+  // fields only -- and accumulate the masked state; pinned with oracle/ref/upwelling_avg_mask.h)
   if (nAVG > 0)
     for (int f = 0; f < 22; f++)
       if (((mask >> f) & 1u) && !c->avg[f]) {

@@ -769,8 +769,8 @@
      &  CALL unsupported ('SPHERICAL / CURVGRID / NONLIN_EOS are built for BENCHMARK only', ierr)
 !  MASKING: the analytic land of this host (island + headland, SUBROUTINE analytic_masks) goes with the UPWELLING grid; the
 !  masked branches exist for its physics (the library refuses the rest: roms_hip_create)
-      IF (is_defined('MASKING').and.(is_defined('AVERAGES').or.ANY(hadv(1:NAT).eq.ROMS_MPDATA)))               &
-     &  CALL unsupported ('MASKING is built without MPDATA and without AVERAGES', ierr)
+      IF (is_defined('MASKING').and.ANY(hadv(1:NAT).eq.ROMS_MPDATA))                                           &
+     &  CALL unsupported ('MASKING is built without MPDATA (mpdata_adiff.F masks)', ierr)
       END SUBROUTINE options_from_defines
 
       SUBROUTINE set_cppdefs (ierr)

@@ -27,6 +27,7 @@ CASES = {
     # UPWELLING with land/sea masking (oracle/ref/upwelling_mask.h; the masks are cases.land_mask)
     "upwelling_mask_small": ("upwelling_mask", dict(Lm=14, Mm=18, N=8)),
     "benchmark_mask_small": ("benchmark_mask", dict(Lm=24, Mm=16, N=10)),
+    "upwelling_avg_mask_small": ("upwelling_avg_mask", dict(Lm=14, Mm=18, N=8)),      # AVERAGES + MASKING
 }
 
 
@@ -107,7 +108,8 @@ def make_case(tag, **kw):
     k.update(kw)
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
-                upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask)[app]
+                upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
+                upwelling_avg_mask=cases.upwelling_mask)[app]
     return app, ctor(**k)
 
 

@@ -180,7 +180,7 @@ def _child(mode, tag, *args, timeout=900):
 
     lib = {"upwelling_kpp_small": "upwelling_kpp", "upwelling_avg_small": "upwelling_avg",
            "upwelling_logdrag_small": "upwelling_logdrag", "upwelling_mask_small": "upwelling_mask",
-           "benchmark_mask_small": "benchmark_mask"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
+           "benchmark_mask_small": "benchmark_mask", "upwelling_avg_mask_small": "upwelling_avg_mask"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
     if not ref.available(lib):
         pytest.skip(f"oracle/_ref/libromsref_{lib}.so not built here")
     p = subprocess.run([sys.executable, "-m", "tests.refchild", mode, tag] + list(args), capture_output=True,
@@ -257,4 +257,12 @@ def test_set_avg_bitwise(args):
     oracle/ref/upwelling_avg.h (UPWELLING with AVERAGES) against orc_set_avg, all 22 time-averaged arrays after
     every call: the set, accumulate and convert (scale + periodic refill) phases of several windows."""
     out = _child("avg", "upwelling_avg_small", *args)
+    assert "AVG-OK bitwise" in out, out
+
+
+def test_set_avg_on_a_masked_run_bitwise():
+    """AVERAGES together with MASKING (reference built from oracle/ref/upwelling_avg_mask.h): the 22 averaged arrays of
+    roms_upwelling.in carry no mask arithmetic of their own (set_avg.F uses masks for rotated and vorticity fields only),
+    the masked state they accumulate does -- all of them after every call of two windows."""
+    out = _child("avg", "upwelling_avg_mask_small", "nsteps=7", "nAVG=3", "ntsAVG=1")
     assert "AVG-OK bitwise" in out, out

@@ -443,3 +443,40 @@ def test_masked_run_history_and_restart(which, tmp_path):
         assert np.array_equal(util.unpadded(a, cs, ni, nj), util.unpadded(b, cs, ni, nj)), n
     H2.finalize()
     assert nrec == 2
+
+
+@pytest.mark.parametrize("which", LIBS)
+def test_averages_file_of_a_masked_run(which, tmp_path):
+    """AVERAGES with MASKING: the records hold the oracle's time averages (pinned to the reference built from
+    oracle/ref/upwelling_avg_mask.h) on the water points and 1e37 on land (nf_fwrite2d.F), with _FillValue."""
+    from tests import cases
+    cs = util.case_for("upwelling_mask_small", hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"))
+    avg = str(tmp_path / "roms_avg.nc")
+    g = util.with_masks(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    O = util.make_oracle(cs, g)
+    O.set_avg_window(3, 1)
+    O.start()
+    O.main3d_step(4)
+    want = {n: O.field(n).copy() for n in ("avg_zeta", "avg_u", "avg_t", "avg_UV")}
+    cs.update(NAVG=3, NTSAVG=1, AVGNAME=avg, Aout=AOUT, ninfo=0)
+    H, ctx = _host(cs, which)
+    H.advance(4, final=False)
+    t = H.tile
+    H.close_output()
+    H.finalize()
+    exact = which == "emu"
+    V = _nc(avg).variables
+    ni, nj = t["UBi"] - t["LBi"] + 1, t["UBj"] - t["LBj"] + 1
+    Lm, Mm, N = cs["Lm"], cs["Mm"], cs["N"]
+    m = cases.land_mask(cs, t["LBi"], t["UBi"], t["LBj"], t["UBj"])
+    i0 = -t["LBi"]
+    mr, mu = m["rmask"][:Mm + 2, i0:i0 + Lm + 2], m["umask"][:Mm + 2, i0 + 1:i0 + Lm + 2]
+    for name, src, mk, c0 in (("zeta", "avg_zeta", mr, 0), ("u", "avg_u", mu, 1), ("temp", "avg_t", mr, 0), ("uv", "avg_UV", mr, 0)):
+        a = want[src].reshape(-1, nj, ni)[:, :Mm + 2, i0 + c0:i0 + Lm + 2]
+        if name == "temp":
+            a = a[:N]
+        b = V[name][0].reshape(a.shape)
+        assert V[name]._FillValue == 1.0e37 and (b[:, mk == 0] == 1.0e37).all(), name
+        w = mk == 1
+        assert np.array_equal(a[:, w], b[:, w]) if exact else util.relrms(b[:, w], a[:, w]) <= 1e-11, name
+    assert np.abs(V["uv"][0][:, mr == 1]).max() > 0.0
