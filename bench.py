@@ -38,6 +38,7 @@ WORKLOADS = {
     "benchmark1": ("benchmark", 512, 64, 30),
     "benchmark2": ("benchmark", 1024, 128, 30),
     "benchmark3": ("benchmark", 2048, 256, 30),
+    "benchmark1_mask": ("benchmark_mask", 512, 64, 30),   # BENCHMARK1 with the host's analytic land: cost of a MASKING run
     "ns512": ("upwelling", 512, 512, 50),       # north_star roofline size (512x512x50); UPWELLING keeps
                                                 # 1 km cells at any size (BENCHMARK's shelf steepens with Mm)
     "ns512u3": ("upwelling_u3c4", 512, 512, 50),  # the same with U3/C4 advection for both tracers: the schemes
@@ -142,6 +143,8 @@ def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
     Lm, Mm, N = Lm or lm, Mm or mm, N or n
     if app == "benchmark":
         cs = cases.benchmark(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
+    elif app == "benchmark_mask":       # BENCHMARK with the host's analytic land (MASKING)
+        cs = cases.benchmark_mask(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
     elif app == "upwelling_kpp":
         cs = cases.upwelling_kpp(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
     elif app == "upwelling_u3c4":

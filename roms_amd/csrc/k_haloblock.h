@@ -33,7 +33,9 @@ KDEV void hb_mirror(const DGrid &G, double *A, int i, int j, double v) {
       if (a < nx && b < ny) A[X2(xs[a], ys[b])] = v;
 }
 
-KDEV void hb_emit(const DGrid &G, const TB &B, double *A, int bc, int i, int j, double v) {
+// M (MASKING): the mask array of A's grid type, or null -- the gradient / slip value stored at a boundary point is
+// multiplied by the mask of THAT point (zetabc.F:264, u2dbc_im.F:989, v2dbc_im.F:1048); zero values stay zero
+KDEV void hb_emit(const DGrid &G, const TB &B, double *A, int bc, int i, int j, double v, const double *M = nullptr) {
   // points further than three lines from every domain edge have no image (Nghost <= 3; the boundary
   // fills read the first/last interior line): whole waves of interior sub-tiles take this exit
   if (i > 3 && i < G.Lm - 2 && j > 3 && j < G.Mm - 2) { A[X2(i, j)] = v; return; }
@@ -41,11 +43,11 @@ KDEV void hb_emit(const DGrid &G, const TB &B, double *A, int bc, int i, int j, 
   if (bc == BC_NONE) return;
   if (!G.nsp) {          // closed southern / northern edge
     if (bc == BC_R) {
-      if (B.south && j == B.Jstr) hb_mirror(G, A, i, j - 1, v);
-      if (B.north && j == B.Jend) hb_mirror(G, A, i, j + 1, v);
+      if (B.south && j == B.Jstr) hb_mirror(G, A, i, j - 1, M ? v * M[X2(i, j - 1)] : v);
+      if (B.north && j == B.Jend) hb_mirror(G, A, i, j + 1, M ? v * M[X2(i, j + 1)] : v);
     } else if (bc == BC_U) {
-      if (B.south && j == B.Jstr) hb_mirror(G, A, i, j - 1, G.gamma2 * v);
-      if (B.north && j == B.Jend) hb_mirror(G, A, i, j + 1, G.gamma2 * v);
+      if (B.south && j == B.Jstr) hb_mirror(G, A, i, j - 1, M ? G.gamma2 * v * M[X2(i, j - 1)] : G.gamma2 * v);
+      if (B.north && j == B.Jend) hb_mirror(G, A, i, j + 1, M ? G.gamma2 * v * M[X2(i, j + 1)] : G.gamma2 * v);
     } else if (bc == BC_V) {
       if (B.south && j == B.JstrV) hb_mirror(G, A, i, B.Jstr, 0.0);
       if (B.north && j == B.Jend) hb_mirror(G, A, i, j + 1, 0.0);
@@ -53,14 +55,14 @@ KDEV void hb_emit(const DGrid &G, const TB &B, double *A, int bc, int i, int j, 
   }
   if (!G.ewp) {          // closed western / eastern edge
     if (bc == BC_R) {
-      if (B.west && i == B.Istr) hb_mirror(G, A, i - 1, j, v);
-      if (B.east && i == B.Iend) hb_mirror(G, A, i + 1, j, v);
+      if (B.west && i == B.Istr) hb_mirror(G, A, i - 1, j, M ? v * M[X2(i - 1, j)] : v);
+      if (B.east && i == B.Iend) hb_mirror(G, A, i + 1, j, M ? v * M[X2(i + 1, j)] : v);
     } else if (bc == BC_U) {
       if (B.west && i == B.IstrU) hb_mirror(G, A, B.Istr, j, 0.0);
       if (B.east && i == B.Iend) hb_mirror(G, A, i + 1, j, 0.0);
     } else if (bc == BC_V) {
-      if (B.west && i == B.Istr) hb_mirror(G, A, i - 1, j, G.gamma2 * v);
-      if (B.east && i == B.Iend) hb_mirror(G, A, i + 1, j, G.gamma2 * v);
+      if (B.west && i == B.Istr) hb_mirror(G, A, i - 1, j, M ? G.gamma2 * v * M[X2(i - 1, j)] : G.gamma2 * v);
+      if (B.east && i == B.Iend) hb_mirror(G, A, i + 1, j, M ? G.gamma2 * v * M[X2(i + 1, j)] : G.gamma2 * v);
     }
   }
 }

@@ -343,7 +343,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
         if (i >= Istr && j >= Jstr) {
           // zetabc :1057 + exchange :1068, rzeta exchange :1030
           if (fuse) {
-            hb_emit(G, B, zn, BC_R, i, j, zeta_new);
+            hb_emit(G, B, zn, BC_R, i, j, zeta_new, MSK ? G.rmask : nullptr);
             if (PRED) hb_emit(G, B, rz_k, BC_NONE, i, j, rhs_zeta);
           } else {
             zn[x0] = zeta_new;
@@ -546,11 +546,11 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
       if (MSK) b = b * (isv ? G.vmask : G.umask)[x];                      // :2515-2660
       // u2dbc/v2dbc :2871-2876 + exchange :3043
       if (!isv) {
-        if (fuse) hb_emit(G, B, un, BC_U, i, j, b);
+        if (fuse) hb_emit(G, B, un, BC_U, i, j, b, MSK ? G.umask : nullptr);
         else un[x] = b;
         if (PRED) rub_k[x] = r;
       } else {
-        if (fuse) hb_emit(G, B, vn, BC_V, i, j, b);
+        if (fuse) hb_emit(G, B, vn, BC_V, i, j, b, MSK ? G.vmask : nullptr);
         else vn[x] = b;
         if (PRED) rvb_k[x] = r;
       }

@@ -256,11 +256,12 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
      // three source lines of a periodic copy
     const int LmT = cfg->Iend - cfg->Istr + 1, MmT = cfg->Jend - cfg->Jstr + 1;
     const char *e = getenv("ROMS_HIP_FUSE_HALO");
-    // (a masked run takes the separate halo launches: the boundary values carry the mask of the boundary point)
     G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && !c->has_exchange && (cfg->EWperiodic || cfg->NSperiodic) && LmT >= 6 && MmT >= 6 &&
-                  !(e && e[0] == '0') && !(cfg->options & ROMS_MASKING);
+                  !(e && e[0] == '0');
     const char *e3 = getenv("ROMS_HIP_FUSE3D");
-    G.fuse3d = G.fuse_halo && !(e3 && e3[0] == '0');
+    // (a masked run: the barotropic kernel's boundary stores carry the mask of the boundary point, hb_emit; the 3-D
+    // producers take the separate halo launches -- their emit_plan knows no mask)
+    G.fuse3d = G.fuse_halo && !(e3 && e3[0] == '0') && !(cfg->options & ROMS_MASKING);
   }
   G.ntfirst = cfg->ntfirst; G.nfast = cfg->nfast;
   G.dt = cfg->dt; G.dtfast = cfg->dtfast; G.rho0 = cfg->rho0; G.g = cfg->g; G.lambda = cfg->lambda;
