@@ -828,7 +828,6 @@ extern "C" int roms_hip_comm_peer(roms_hip_ctx *c, const void *blobs128, int nra
   }
   if (!m.peer_slab) { set_error("roms_hip_comm_peer: call roms_hip_peer_export on every rank first"); return 8; }
   const PeerBlob *B = (const PeerBlob *)blobs128;
-  void *mapped[8] = {};
   for (int d = 0; d < 8; d++) {
     m.peer_map[d] = nullptr; m.peer_opened[d] = false;
     const int r = m.nbr[d];
@@ -849,7 +848,6 @@ extern "C" int roms_hip_comm_peer(roms_hip_ctx *c, const void *blobs128, int nra
     for (int ch = 0; ch < 2; ch++)
       for (int par = 0; par < 2; par++) m.peer_noff[d][ch][par] = table[ch][par][g_opp[d]];
   }
-  (void)mapped;
   m.peer_seq[0] = m.peer_seq[1] = 0;
   m.peer_on = true;
   { const char *et = getenv("ROMS_HIP_PEER_THREADS"); c->peer_threads = et ? atoi(et) : 1024; }
