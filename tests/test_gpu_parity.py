@@ -714,7 +714,10 @@ def test_mailbox_self_exchange_matches_local_periodic_copy(env):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,kw,tiles,port", [("upwelling_small", {}, (2, 1), 29731), ("benchmark_small", {}, (2, 2), 29732),
                                                 ("upwelling_small", {"hadv": ("MPDATA", "MPDATA"), "vadv": ("MPDATA", "MPDATA")}, (2, 2), 29733),
-                                                ("benchmark_small", {}, (4, 2), 29734)])
+                                                ("benchmark_small", {}, (4, 2), 29734),
+                                                # MASKING: the masked boundary fills run inside the mailbox pack kernel
+                                                ("upwelling_mask_small", {"hadv": ("U3", "HSIMT"), "vadv": ("C4", "HSIMT")}, (2, 2), 29735),
+                                                ("benchmark_mask_small", {}, (2, 2), 29736)])
 def test_mailbox_tiles_on_one_gpu_match_single_tile(tmp_path, tag, kw, tiles, port):
     """The mailbox transport between PROCESSES: NtileI x NtileJ ranks share cuda:0, every rank maps its neighbours'
     slabs with hipIpcOpenMemHandle, the pack kernels store into them, the unpack kernels wait for the arrival words
