@@ -1422,7 +1422,8 @@ static int main3d_one(roms_hip_ctx *c) {
     const bool uvcol = (cf.options & ROMS_UV_VIS2) && (euc ? euc[0] != '0' : cols >= 128L * 1024L);   // run_uv3dmix2_col's rule
 #endif
     // (a masked run keeps the reference order: its boundary fills are separate launches on the compute stream)
-    if (!c->has_exchange && !uvcol && !c->G.masking && !(elate && elate[0] == '0')) return main3d_late(c, do_diag);
+    static const char *elm = getenv("ROMS_HIP_LATE_MASK");
+    if (!c->has_exchange && !uvcol && (!c->G.masking || (elm && elm[0] == '1')) && !(elate && elate[0] == '0')) return main3d_late(c, do_diag);
   }
   DO(roms_hip_rho_eos(c));                                  // :350
   // Two independent chains follow: set_massflux (:348) -> omega (:534) -> wvelocity (:535), and the
