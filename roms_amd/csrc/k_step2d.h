@@ -122,16 +122,16 @@ THREAD_GLOBAL(k_pack_m2d, PackArgs)
 #else
 #define S2D_TICK(n) ((void)0)
 #endif
-template <int BWC, int BHC, int NTC, int PTS>
+template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0)>
 COOP_KERNEL(k_step2d_t, Step2dArgs) {
   (void)bz;
 #ifndef ROMS_CPU_EMU
   __builtin_amdgcn_s_setprio(3);   // beside other kernels (main3d_late) these waves are the step's critical path
 #endif
   constexpr bool FIXED = BWC > 0;
-  // MASKING runs take the generic form (g_step2d.cpp): the fixed-shape instantiations compile the mask products away
-  // (with them k_step2d_c spilled 36 VGPRs instead of 14 and an unmasked 512x512x50 step took 7 % longer)
-  const bool MSK = !FIXED && a.G.masking;
+  // MASKING runs take the generic form or k_step2d_am (g_step2d.cpp): the other fixed-shape instantiations compile the
+  // mask products away (with them k_step2d_c spilled 36 VGPRs instead of 14 and an unmasked 512x512x50 step took 7 % longer)
+  const bool MSK = MK && a.G.masking;                 // MK: this instantiation carries the mask products
   const DGrid &G = a.G;
   const S2Fields &F = a.F;
   const TB B = block_bounds2(G, bx, by);
@@ -581,6 +581,8 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
 // 32x8, and the generic form
 COOP_KERNEL(k_step2d_a, Step2dArgs) { k_step2d_t_body<32, 4, 384, 1>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d_a, Step2dArgs, 384)
+COOP_KERNEL(k_step2d_am, Step2dArgs) { k_step2d_t_body<32, 4, 384, 1, true>(a, bx, by, bz, lds); }   // the same with land/sea masks
+COOP_GLOBAL_LB(k_step2d_am, Step2dArgs, 384)
 COOP_KERNEL(k_step2d_b, Step2dArgs) { k_step2d_t_body<64, 8, 512, 2>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d_b, Step2dArgs, 512)
 COOP_KERNEL(k_step2d_d, Step2dArgs) { k_step2d_t_body<64, 8, 1024, 1>(a, bx, by, bz, lds); }
