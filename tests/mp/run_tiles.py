@@ -27,7 +27,7 @@ def main():
         run = tiling.TiledRun(cs, rank=rank, world=world, device=0, dist=dist, transport=spec.get("transport", "dist_staged"), weak=False,
                               tiles=tuple(spec["tiles"]))
     else:
-        run = tiling.TiledRun(cs, rank=rank, world=world, dist=dist, transport="dist", weak=False,
+        run = tiling.TiledRun(cs, rank=rank, world=world, dist=dist, transport=spec.get("transport_cpu", "dist"), weak=False,
                               tiles=tuple(spec["tiles"]), host_lib=os.path.join(emu, "libroms_host_emu.so"),
                               hip_lib=os.path.join(emu, "libroms_hip_emu.so"))
     if spec.get("probe"):                          # the transport's self-check before anything else moves

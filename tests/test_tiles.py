@@ -98,3 +98,18 @@ def test_bench_multi_gpu_plan_is_the_baseline_configs():
         assert (cs["Lm"], cs["Mm"]) == (glm, gmm) and tiles[0] * tiles[1] == world
         assert (cs["Lm"] // tiles[0], cs["Mm"] // tiles[1]) == tile
     assert tiling.partition(8) == (4, 2) and tiling.partition(2) == (2, 1)
+
+
+def test_automatic_transport_fails_cleanly_without_a_device_transport(tmp_path):
+    """transport="auto" (tiling.py: mailbox, else RCCL, each behind collectives of all ranks) where neither exists -- the
+    emulated build: every rank gets the library's message, none hangs in a collective the other has left."""
+    import json
+    import sys
+    _emu_libs()
+    spec = dict(tag="upwelling_small", kw={}, steps=1, tiles=[2, 1], fields=["zeta"], transport_cpu="auto")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(ROOT, "tests", "mp", "run_tiles.py"), str(tmp_path / "x.npz"), json.dumps(spec)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert p.returncode != 0
+    out = p.stdout + p.stderr
+    assert "mailbox transport not usable" in out and "RCCL is not part of the CPU-emulated test build" in out, out[-3000:]
