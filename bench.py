@@ -318,6 +318,23 @@ def north_star_pass(hiplib, tiling, device, steps=6, warmup=24):
     return rep
 
 
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without torch.distributed.run: start the N ranks as CHILD processes (one per GPU,
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), relay their
+    output and return the exit code.  Nothing in this (parent) process has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, ROMS_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -334,6 +351,12 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 512x512x50 pass of the default run")
     ap.add_argument("--breakdown-file", default=None, help="write the per-kernel table (JSON) here")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test aid: all ranks of a --gpus N run on device 0, halo strips staged through the host (gloo)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check: start the ranks, join a gloo group, report, stop (needs no GPU)")
+    ap.add_argument("--transport", default=None, choices=["auto", "peer", "rccl", "dist_staged"],
+                    help="halo transport of a multi-GPU run (default: ROMS_HIP_TRANSPORT or the library's default)")
     ap.add_argument("--copy-probe", action="store_true",
                     help="also time the library's streaming-copy kernel on this workload's 3-D arrays")
     args = ap.parse_args()
@@ -342,15 +365,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N with N > 1 must be started by torch.distributed.run "
-                             "(one rank per GPU); see the module docstring")
+        if world == 1 and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            # started plainly (`python bench.py --gpus N`): this process only LAUNCHES -- one rank per GPU as child
+            # processes of torch.distributed.run, before anything here has touched the GPU (never an exec) -- and
+            # relays rank 0's JSON line and the exit code
+            raise SystemExit(self_launch(args.gpus))
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    import torch
-    if torch.cuda.device_count() < 1:        # (counting devices does not initialise the GPU)
+    if args.dry_launch:
+        # launcher / rendezvous check (runs without a GPU): every rank joins a gloo group, rank 0 reports
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import torch
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch": "ok", "n_gpus": world, "rank_sum": int(t.item()),
+                              "self_launched": os.environ.get("ROMS_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        dist.destroy_process_group()
+        return
+
+    if not os.path.exists("/dev/kfd"):
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    # The CPU leg runs first, before anything initialises the GPU in this process: it forks worker processes.
+    # The CPU leg runs first, before anything initialises the GPU in this process (it forks worker processes;
+    # even counting devices may open the driver on some ROCm builds).
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from roms_amd import hostlib as _hl
@@ -360,15 +401,23 @@ def main():
             cpu = cpu_baseline(cs0, H0)
         finally:
             H0.finalize()
-    if not torch.cuda.is_available():
+    import torch
+    if torch.cuda.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # --share-gpu (test aid): every rank on device 0, strips staged through the host (RCCL refuses two ranks on one
+    # device): the multi-rank path of this script on a 1-GPU box
+    device = 0 if args.share_gpu else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):   # started by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+    local_rank = device
 
     from roms_amd import hiplib, hostlib, tiling
     if os.environ.get("ROMS_HIP_TRACE"):     # debugging aid: every launch synchronous and named on stderr
@@ -378,7 +427,13 @@ def main():
     wl, tiles, weak = multi_gpu_plan(world, args.workload, explicit_dims)
     cs = params_for(wl, args.Lm, args.Mm, args.N, ntimes=args.steps + args.warmup)
     cs["ninfo"] = 1                          # NINFO of roms_benchmark1.in: diagnostics every step
-    run = tiling.TiledRun(cs, rank=rank, world=world, device=local_rank, dist=dist, tiles=tiles, weak=weak)
+    transport = args.transport or ("dist_staged" if (args.share_gpu and world > 1) else None)
+    try:
+        run = tiling.TiledRun(cs, rank=rank, world=world, device=local_rank, dist=dist, tiles=tiles, weak=weak,
+                              transport=transport)
+    except hiplib.RomsHipError as e:         # no usable halo transport (both probes failed): say why, stop all ranks
+        print(f"bench.py rank {rank}: {e}", file=sys.stderr, flush=True)
+        raise SystemExit(3)
     if args.averages > 0:
         run.ctx.avg_config(args.averages)
     if not weak:                             # cs names the global grid: the tile is its NtileI x NtileJ-th part
@@ -391,6 +446,7 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+    red_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu"
 
     run.step(args.warmup)
     barrier_sync()
@@ -426,7 +482,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -470,7 +526,10 @@ def main():
                                    f"(tile {cs['Lm']}x{cs['Mm']}x{cs['N']} per GPU), dt={cs['dt']:g}s ndtfast={cs['ndtfast']}, "
                                    "analytic grid/initial/forcing, full application physics",
                        "tiles": f"{run.NtileI}x{run.NtileJ}", "nfast": run.nfast,
-                       "halo_transport": getattr(run, "transport", None) if world > 1 else "none (single tile)"},
+                       "halo_transport": getattr(run, "transport", None) if world > 1 else "none (single tile)",
+                       "rccl_ranks": run.rccl_ranks() if world > 1 else None,
+                       "transport_probes": getattr(run, "probe_log", None) if world > 1 else None,
+                       "exchanges_per_step": run.exchanges_per_step(args.steps) if world > 1 else 0},
             "roofline": roofline,
             "north_star_pair": pair,
         }

@@ -242,6 +242,8 @@ int roms_hip_exchange_probe(roms_hip_ctx *ctx, int reps);
 int roms_hip_comm_reset(roms_hip_ctx *ctx);
 /* number of halo exchanges performed so far (0 for a single-tile context) */
 long roms_hip_exchange_count(roms_hip_ctx *ctx);
+/* ranks of the built-in RCCL communicator of this context (ncclCommCount); 0: roms_hip_comm_rccl was not called */
+long roms_hip_rccl_ranks(roms_hip_ctx *ctx);
 
 /* measurement aid: `reps` launches of a plain streaming copy (kernel k_copy_probe) between two 3-D
    work arrays; *bytes_per_launch = bytes read + written by one launch.  Timed by the caller with

@@ -722,6 +722,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *);
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
   ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*CommCount)(const ncclComm_t, int *);
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   ncclResult_t (*GroupStart)();
@@ -738,7 +739,7 @@ int rccl_load() {
   if (!h) for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
   if (!h) { set_error(std::string("cannot load RCCL: ") + dlerror()); return 2; }
 #define RSYM(f) *(void **)(&g_rccl.f) = dlsym(h, "nccl" #f); if (!g_rccl.f) { set_error("RCCL symbol nccl" #f " missing"); return 2; }
-  RSYM(GetUniqueId) RSYM(CommInitRank) RSYM(CommDestroy) RSYM(Send) RSYM(Recv) RSYM(GroupStart) RSYM(GroupEnd)
+  RSYM(GetUniqueId) RSYM(CommInitRank) RSYM(CommDestroy) RSYM(CommCount) RSYM(Send) RSYM(Recv) RSYM(GroupStart) RSYM(GroupEnd)
   RSYM(GetErrorString)
 #undef RSYM
   g_rccl.lib = h;
@@ -769,6 +770,12 @@ extern "C" int roms_hip_comm_rccl(roms_hip_ctx *c, const void *id128, int nranks
   if (rcclfail(g_rccl.CommInitRank(&comm, nranks, id, rank), "ncclCommInitRank")) return 2;
   c->comm.nccl = (void *)comm;
   return 0;
+}
+extern "C" long roms_hip_rccl_ranks(roms_hip_ctx *c) {
+  if (!c || !c->comm.nccl || !g_rccl.lib) return 0;
+  int n = 0;
+  if (g_rccl.CommCount((ncclComm_t)c->comm.nccl, &n) != ncclSuccess) return -1;
+  return n;
 }
 // ---- mailbox transport: receive slots in uncached device memory, mapped by the neighbours ----
 namespace {
@@ -869,6 +876,7 @@ extern "C" int roms_hip_comm_peer(roms_hip_ctx *, const void *, int, int) {
   set_error("the mailbox transport is not part of the CPU-emulated test build");
   return 2;
 }
+extern "C" long roms_hip_rccl_ranks(roms_hip_ctx *) { return 0; }
 extern "C" int roms_hip_rccl_unique_id(void *) { set_error("RCCL is not part of the CPU-emulated test build"); return 2; }
 extern "C" int roms_hip_comm_rccl(roms_hip_ctx *, const void *, int, int) {
   set_error("RCCL is not part of the CPU-emulated test build");

@@ -590,7 +590,7 @@
         END DO
         more=.FALSE.
         L=LEN_TRIM(code)
-        IF (L.gt.0) more=code(L:L).eq.'\\'
+        IF (L.gt.0) more=code(L:L).eq.ACHAR(92)              ! a backslash (one character: no escape processing)
         IF (more) code(L:L)=' '
         stmt=TRIM(stmt)//' '//TRIM(ADJUSTL(code))
         IF (more) CYCLE

@@ -63,6 +63,8 @@ class TiledRun:
         finally:
             os.environ.pop("ROMS_HIP_SELF_EXCHANGE", None)
         self._cb = None
+        self.probe_log = []
+        self._x0 = None
         if self_exchange:
             transport = transport or "rccl"
             if transport == "rccl":
@@ -116,7 +118,9 @@ class TiledRun:
         if self._all_ok(ok):
             ok, why = self.probe()
             if self._all_ok(ok):
+                self.probe_log.append({"transport": "peer", "ok": True})
                 return "peer"
+        self.probe_log.append({"transport": "peer", "ok": False, "why": why or "another rank failed"})
         if self.rank == 0 or why:
             print(f"[roms_amd] rank {self.rank}: mailbox transport not usable ({why or 'another rank failed'}); using RCCL send/recv",
                   file=sys.stderr, flush=True)
@@ -124,8 +128,24 @@ class TiledRun:
         self._install_rccl()
         ok, why = self.probe()
         if not self._all_ok(ok):
-            raise hiplib.RomsHipError("exit_flag=2: " + (why or "halo exchange probe failed on another rank"))
+            self.probe_log.append({"transport": "rccl", "ok": False, "why": why or "another rank failed"})
+            raise hiplib.RomsHipError("exit_flag=2: no usable halo transport: " + "; ".join(
+                f"{p['transport']}: {p.get('why', 'ok')}" for p in self.probe_log))
+        self.probe_log.append({"transport": "rccl", "ok": True})
         return "rccl"
+
+    def rccl_ranks(self):
+        """Ranks of the library's RCCL communicator (ncclCommCount), 0 when the built-in RCCL transport is not installed."""
+        fn = getattr(self.ctx.L, "roms_hip_rccl_ranks", None)
+        return int(fn(self.ctx.h)) if fn is not None else None
+
+    def exchanges_per_step(self, nsteps):
+        """exchange points per main3d pass since the first call of this function (roms_hip_exchange_count)"""
+        n = int(self.ctx.L.roms_hip_exchange_count(self.ctx.h))
+        if self._x0 is None:
+            self._x0 = n
+            return None
+        return (n - self._x0) / max(nsteps, 1)
 
     def _install_rccl(self):
         L = self.ctx.L

@@ -797,3 +797,24 @@ def test_land_sea_masking_matches_oracle(tag, hadv, vadv, env):
     """) % (ROOT, tag, tuple(hadv), tuple(vadv))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
     assert "MASK-GPU-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_started_plainly_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it: the script starts its two ranks itself (child processes of
+    torch.distributed.run) and prints ONE line with n_gpus = 2.  Both ranks share cuda:0 here (--share-gpu: strips staged
+    through the host, RCCL needs one GPU per rank); on a multi-GPU node the same command runs one rank per GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3",
+                        "--warmup", "2", "--Lm", "96", "--Mm", "32", "--N", "10", "--no-breakdown"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["tiles"] == "2x1"
+    assert d["config"]["halo_transport"] == "dist_staged" and d["config"]["exchanges_per_step"] > 20

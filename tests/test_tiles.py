@@ -113,3 +113,23 @@ def test_automatic_transport_fails_cleanly_without_a_device_transport(tmp_path):
     assert p.returncode != 0
     out = p.stdout + p.stderr
     assert "mailbox transport not usable" in out and "RCCL is not part of the CPU-emulated test build" in out, out[-3000:]
+
+
+def test_bench_starts_its_own_ranks_when_run_plainly():
+    """`python bench.py --gpus 2` without torch.distributed.run (WORLD_SIZE unset): the script starts its ranks as child
+    processes itself and relays rank 0's line.  --dry-launch stops after the rendezvous (no GPU needed here)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d == {"launch": "ok", "n_gpus": 2, "rank_sum": 3, "self_launched": True}
+
+
+def test_bench_refuses_a_mismatched_world():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stdout + p.stderr)
