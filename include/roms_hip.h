@@ -134,6 +134,12 @@ int roms_hip_uv3dmix2(roms_hip_ctx *ctx);      /* uv3dmix2       uv3dmix2_s.h:40
 int roms_hip_rhs3d_tile(roms_hip_ctx *ctx);    /* rhs3d_tile     rhs3d.F:196         */
 int roms_hip_rhs3d(roms_hip_ctx *ctx);         /* rhs3d          rhs3d.F:25 (the five above in order) */
 int roms_hip_step2d(roms_hip_ctx *ctx);        /* step2d         step2d_LF_AM3.h:18  */
+/* step2d twice -- the predictor (main3d.F:839) and the corrector (:888) of ONE fast step 2 <= iif <= nfast -- as one
+   launch.  The stepping is the PREDICTOR call's (predictor = 1, knew = 3, krhs = indx1, kstp = 3-indx1); afterwards the
+   caller advances the indices as if it had made both calls.  The corrector's zeta/ubar/vbar(knew) stay in a staging
+   level inside the library until the NEXT roms_hip_step2d_pair / roms_hip_step2d (a predictor call, krhs = that level:
+   the auxiliary last call at the latest) commits them; roms_hip_main3d sequences this itself.  Same bits as two calls. */
+int roms_hip_step2d_pair(roms_hip_ctx *ctx);
 int roms_hip_step3d_uv(roms_hip_ctx *ctx);     /* step3d_uv      step3d_uv.F:40      */
 int roms_hip_step3d_t(roms_hip_ctx *ctx);      /* step3d_t       step3d_t.F:40       */
 int roms_hip_lmd_vmix(roms_hip_ctx *ctx);      /* lmd_vmix       lmd_vmix.F:45       */

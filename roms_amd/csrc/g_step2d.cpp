@@ -2,6 +2,7 @@
 #include "roms_host.h"
 #include <cstdlib>
 #include "k_step2d.h"
+#include "k_step2d_pair.h"
 
 int run_step2d(roms_hip_ctx *c) {
   const DGrid &G = c->G;
@@ -13,6 +14,11 @@ int run_step2d(roms_hip_ctx *c) {
   a.w1_m1 = (iif >= 2) ? cf.weight[0][iif - 1] : 0.0;
   a.w2_0 = cf.weight[1][iif];
   a.w2_p1 = (iif + 1 <= ROMS_MAXW) ? cf.weight[1][iif + 1] : 0.0;
+  // behind a pair launch the krhs level is still staged: read it there and commit it (k_step2d_pair.h)
+  a.lev_in = c->b2_stage ? c->b2_stage : G.krhs;
+  a.commit = c->b2_stage ? 1 : 0;
+  if (c->b2_stage && !(G.predictor && G.krhs != 3)) { set_error("step2d: a staged pair result can only be followed by a predictor call"); return 8; }
+  c->b2_stage = 0;
   if (c->m2d_dirty) {   // (re)build the packed metric records after the grid arrays were uploaded
     PackArgs pa;
     pa.G = G;
@@ -93,6 +99,93 @@ int run_step2d(roms_hip_ctx *c) {
   if (G.predictor) sp[n++] = {lev2d(c, c->F.rzeta, G.krhs), 1, BC_NONE, 'r'};   // :1030
   sp[n++] = {lev2d(c, c->F.ubar, G.knew), 1, BC_U, 'u'};                        // u2dbc :2871 + exchange :3043
   sp[n++] = {lev2d(c, c->F.vbar, G.knew), 1, BC_V, 'v'};                        // v2dbc :2876
+  launch_halo_multi(c, sp, n);
+  return 0;
+}
+
+
+// ---- predictor + corrector of one fast step as one launch (k_step2d_pair.h) ----------------------------------
+static size_t pair_lds_doubles(int bw2, int bh2) { return (size_t)S2P_NLDS * (size_t)(bw2 + 2 * S2P_RIM) * (size_t)(bh2 + 2 * S2P_RIM); }
+// ROMS_HIP_PAIR=0/1 forces; default: tiles whose barotropic sub-tiles are the 32x4 ones (up to 64 K points)
+bool step2d_pair_usable(const roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const char *e = getenv("ROMS_HIP_PAIR");
+  if (e && e[0] == '0') return false;
+  const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
+  if (LmT < 8 || MmT < 8) return false;                                  // the rim (5 | 4 lines) comes from the neighbour's / the tile's own points
+  if (pair_lds_doubles(G.bw2, G.bh2) * sizeof(double) > 160 * 1024) return false;
+  if (c->has_exchange) return false;                                     // (multi-tile: needs the wide exchange, below)
+  if (e && e[0] == '1') return true;
+  return G.bw2 <= 32 && G.bh2 <= 4;
+}
+
+int run_step2d_pair(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const roms_hip_config &cf = c->cfg;
+  const int iif = G.iif;
+  if (!G.predictor || iif < 2 || iif > G.nfast || G.knew != 3 || G.krhs == 3) { set_error("step2d_pair: needs the stepping of a predictor call, 2 <= iif <= nfast"); return 8; }
+  Step2dPairArgs a;
+  a.G = G;
+  S2F_FILL(a.F, c->F);
+  a.w1_m1 = cf.weight[0][iif - 1];
+  a.w2_0 = cf.weight[1][iif];
+  a.w2_p1 = (iif + 1 <= ROMS_MAXW) ? cf.weight[1][iif + 1] : 0.0;
+  a.lev_in = c->b2_stage ? c->b2_stage : G.krhs;
+  a.commit = c->b2_stage ? 1 : 0;
+  a.lev_out = c->b2_stage == 4 ? 5 : 4;
+  a.wrapx = G.ewp && G.xloc;
+  a.wrapy = G.nsp && G.yloc;
+  if (c->m2d_dirty) {
+    PackArgs pa;
+    pa.G = G;
+    pa.Fv = c->F;
+    LAUNCH_THREAD(k_pack_m2d, G.ni, G.nj, 1, c->stream, pa);
+    c->m2d_dirty = false;
+  }
+  const bool fixed = G.bw2 <= 32 && G.bh2 <= 4 && !G.masking && !getenv("ROMS_HIP_S2D_GENERIC");
+#ifdef ROMS_CPU_EMU
+  const size_t lds = pair_lds_doubles(G.bw2, G.bh2);
+  LAUNCH_COOP(k_step2d_pair, G.nbx2, G.nby2, 1, 1, lds, c->stream, a);
+#else
+  static bool big_a = false, big_g = false;
+  if (fixed) {
+    const size_t lds = pair_lds_doubles(32, 4);
+    if (!big_a) {
+      if (hipFuncSetAttribute((const void *)k_step2d_pair_a, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        set_error("k_step2d_pair: cannot raise the dynamic LDS limit");
+        return 2;
+      }
+      big_a = true;
+    }
+    LAUNCH_COOP_AS(k_step2d_pair, k_step2d_pair_a, G.nbx2, G.nby2, 1, 640, lds, c->stream, a);
+  } else {
+    const size_t lds = pair_lds_doubles(G.bw2, G.bh2);
+    if (!big_g) {
+      if (hipFuncSetAttribute((const void *)k_step2d_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        set_error("k_step2d_pair: cannot raise the dynamic LDS limit");
+        return 2;
+      }
+      big_g = true;
+    }
+    LAUNCH_COOP(k_step2d_pair, G.nbx2, G.nby2, 1, 512, lds, c->stream, a);
+  }
+#endif
+  c->b2_stage = a.lev_out;
+  if (G.fuse_halo) return 0;        // the kernel stored the boundary values and periodic images itself
+  // closed basin: zetabc / u2dbc / v2dbc of the corrector's result (staged); the predictor's level 3 and rzeta(krhs) as
+  // the per-call sequence leaves them
+  const size_t nij = (size_t)G.nij;
+  HaloSpec sp[7];
+  int n = 0;
+  sp[n++] = {c->F.zeta + (size_t)(a.lev_out - 1) * nij, 1, bc_rstate(c), 'r'};
+  sp[n++] = {c->F.ubar + (size_t)(a.lev_out - 1) * nij, 1, BC_U, 'u'};
+  sp[n++] = {c->F.vbar + (size_t)(a.lev_out - 1) * nij, 1, BC_V, 'v'};
+  if (iif >= G.nfast - 1) {
+    sp[n++] = {lev2d(c, c->F.zeta, 3), 1, bc_rstate(c), 'r'};
+    sp[n++] = {lev2d(c, c->F.rzeta, G.krhs), 1, BC_NONE, 'r'};
+    sp[n++] = {lev2d(c, c->F.ubar, 3), 1, BC_U, 'u'};
+    sp[n++] = {lev2d(c, c->F.vbar, 3), 1, BC_V, 'v'};
+  }
   launch_halo_multi(c, sp, n);
   return 0;
 }

@@ -58,6 +58,8 @@ struct Step2dArgs {
   S2Fields F;
   double w1_m1;        // weight(1,iif-1)
   double w2_0, w2_p1;  // weight(2,iif), weight(2,iif+1)
+  int lev_in;          // physical level of zeta/ubar/vbar(krhs): G.krhs, or the staging level the pair kernel left its result in
+  int commit;          // (the auxiliary last call behind a pair) copy that level to the logical level G.krhs: k_step2d_pair.h
 };
 
 #define STEP2D_NLDS 15
@@ -152,7 +154,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
   const double dtfast = G.dtfast, g = G.g;
   const int ni = G.ni, nij = (int)G.nij;
   // time levels of the 2-D state: index offsets into one array
-  const int o_krhs = (krhs - 1) * nij, o_kstp = (kstp - 1) * nij, o_ptsk = (ptsk - 1) * nij;
+  const int o_krhs = (a.lev_in - 1) * nij, o_kstp = (kstp - 1) * nij, o_ptsk = (ptsk - 1) * nij;
   double *zn = F.zeta + (size_t)(knew - 1) * G.nij, *un = F.ubar + (size_t)(knew - 1) * G.nij,
          *vn = F.vbar + (size_t)(knew - 1) * G.nij;
   double *rz_k = F.rzeta + (size_t)(krhs - 1) * G.nij;
@@ -191,7 +193,23 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
       const bool ring1 = INR(i, j, Istr - 1, Iend + 1, Jstr - 1, Jend + 1);
       const double zkv = F.zeta[x0 + o_krhs], hv = F.h[x0];
       Drhs[s0] = zkv + hv;                                    // total depth :600
-      sUk[s0] = F.ubar[x0 + o_krhs]; sVk[s0] = F.vbar[x0 + o_krhs]; sH[s0] = hv;
+      const double ukv = F.ubar[x0 + o_krhs], vkv = F.vbar[x0 + o_krhs];
+      sUk[s0] = ukv; sVk[s0] = vkv; sH[s0] = hv;
+      if (a.commit) {
+        // the last pair's result, staged by k_step2d_pair: now the logical level krhs (own points; the tile's boundary and
+        // ghost points by its edge blocks)
+        double *zl = F.zeta + (size_t)(krhs - 1) * G.nij, *ul = F.ubar + (size_t)(krhs - 1) * G.nij, *vl = F.vbar + (size_t)(krhs - 1) * G.nij;
+        const bool own = INR(i, j, Istr, Iend, Jstr, Jend);
+        if (fuse) {
+          if (own) {
+            hb_emit(G, B, zl, BC_R, i, j, zkv, MSK ? G.rmask : nullptr);
+            if (i >= IstrU) hb_emit(G, B, ul, BC_U, i, j, ukv, MSK ? G.umask : nullptr);
+            if (j >= JstrV) hb_emit(G, B, vl, BC_V, i, j, vkv, MSK ? G.vmask : nullptr);
+          }
+        } else if (own || !INR(i, j, G.T.Istr, G.T.Iend, G.T.Jstr, G.T.Jend)) {
+          zl[x0] = zkv; ul[x0] = ukv; vl[x0] = vkv;
+        }
+      }
       PWLOAD(r_zk, zkv);
       PWLOAD(r_on_u, F.on_u[x0]); PWLOAD(r_om_v, F.om_v[x0]);
       if (ring2) { sPm[s0] = F.pm[x0]; sPn[s0] = F.pn[x0]; }

@@ -272,6 +272,8 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   memset(c->regions, 0, sizeof(c->regions));
   c->comm_failed = false;
   c->m2d_dirty = true;
+  c->b2_stage = 0;
+  c->pair_on = step2d_pair_usable(c);
   c->swdk_ready = false;
   c->pre_t3_ready = false;
   c->stream3 = nullptr;
@@ -324,7 +326,9 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   memset(&c->F, 0, sizeof(c->F));
   for (int k = 0; k < g_nfields; k++) {
     void *p = nullptr;
-    if (dmalloc(&p, (size_t)field_elems(c, g_fields[k].kind) * sizeof(double))) { roms_hip_destroy(c); return 2; }
+    // (zeta, ubar, vbar: two more levels than the caller sees -- the staging levels of the pair kernel, k_step2d_pair.h)
+    const size_t ne = (size_t)field_elems(c, g_fields[k].kind) + (g_fields[k].kind == FK_2Dx3 ? 2 * (size_t)G.nij : 0);
+    if (dmalloc(&p, ne * sizeof(double))) { roms_hip_destroy(c); return 2; }
     c->allocs.push_back(p);
     *(double **)((char *)&c->F + g_fields[k].offset) = (double *)p;
   }
@@ -495,7 +499,6 @@ extern "C" int roms_hip_sync(roms_hip_ctx *c) {
   halo_fence(c, FG_ALL);
   return dsync(c->stream);
 }
-int run_step2d(roms_hip_ctx *c);
 int run_rhs3d_pt(roms_hip_ctx *c);
 int run_uv3dmix2_s(roms_hip_ctx *c);
 int run_rufrc_sums(roms_hip_ctx *c);
@@ -1211,6 +1214,7 @@ ENTRY(t3dmix2, 24, FG_T | FG_HZ | FG_RHO)
 ENTRY(uv3dmix2, 30, FG_UV | FG_HZ | FG_R)
 ENTRY(rhs3d_tile, 21, FG_R | FG_UV | FG_MF | FG_W | FG_HZ | FG_FLUX)        // rhs3d.F:196
 ENTRY(step2d, 9, FG_2D | FG_AVG | FG_R | FG_RHO)                            // step2d_LF_AM3.h:163
+ENTRY(step2d_pair, 9, FG_2D | FG_AVG | FG_R | FG_RHO)                       // step2d_LF_AM3.h:163, predictor + corrector of one fast step
 ENTRY(step3d_uv, 34, FG_UV | FG_MF | FG_2D | FG_AVG | FG_AK | FG_HZ | FG_R | FG_FLUX)     // step3d_uv.F:134
 ENTRY(step3d_t, 35, FG_T | FG_MF | FG_W | FG_AK | FG_HZ | FG_FLUX)          // step3d_t.F:120
 ENTRY(lmd_vmix, 18, FG_AK | FG_RHO | FG_UV | FG_HZ | FG_FLUX | FG_T)        // lmd_vmix.F:45
@@ -1275,7 +1279,13 @@ static int baro_and_corrector(roms_hip_ctx *c, int join_late = -1) {
       s.krhs = s.indx1;
     }
     ctx_sync_stepping(c);
-    DO(roms_hip_step2d(c));
+    // fast steps 2 .. nfast: predictor and corrector in one launch (k_step2d_pair.h); the first step (forward Euler start,
+    // conversion of the 3-D forcing) and the auxiliary last call keep the per-call kernel
+    static const int pair_from = getenv("ROMS_HIP_PAIR_FROM") ? atoi(getenv("ROMS_HIP_PAIR_FROM")) : 2;     // (debugging aids)
+    static const int pair_to = getenv("ROMS_HIP_PAIR_TO") ? atoi(getenv("ROMS_HIP_PAIR_TO")) : 1 << 30;
+    const bool pair = c->pair_on && s.predictor && s.iif >= 2 && s.iif <= cf.nfast && s.iif >= pair_from && s.iif <= pair_to;
+    if (pair) DO(roms_hip_step2d_pair(c));
+    else DO(roms_hip_step2d(c));
     if (s.predictor) {
       s.predictor = 0;
       s.knew = next_indx1;
@@ -1284,7 +1294,7 @@ static int baro_and_corrector(roms_hip_ctx *c, int join_late = -1) {
       if (s.iif < cf.nfast + 1) s.indx1 = next_indx1;
     }
     ctx_sync_stepping(c);
-    if (s.iif < cf.nfast + 1) DO(roms_hip_step2d(c));
+    if (s.iif < cf.nfast + 1 && !pair) DO(roms_hip_step2d(c));
   }
   if (join_late >= 0) lane_wait(c, join_late);
   DO(roms_hip_set_depth(c));                                // :963

@@ -59,6 +59,10 @@ struct roms_hip_ctx {
   bool late_pre;                // main3d_one runs pre_step3d BEHIND prsgrd/rhs3d_tile/uv3dmix2 (beside the barotropic loop):
                                 // k_prs_grad keeps the old ru/rv bracket, k_uv3dmix2_s only stores its terms, k_pre_new uses both
   bool m2d_dirty;               // grid arrays uploaded since Fields::m2r/m2p were packed (g_step2d.cpp)
+  // barotropic predictor+corrector pairs as one launch (k_step2d_pair.h)
+  bool pair_on;                 // roms_hip_main3d runs the fast steps iif >= 2 as pairs
+  int b2_stage;                 // physical level (4 | 5) of zeta/ubar/vbar holding the last pair's result, not yet committed
+                                // to its logical level; 0: none
   bool diag_ran;                // a diag report was enqueued since the last blow-up test (roms_hip_main3d)
   int diag_step = -1;           // step count (iic-1) of the report in d_diag, -1: none yet
   DGrid G;
@@ -174,6 +178,8 @@ int run_t3dmix2(roms_hip_ctx *c);
 int run_uv3dmix2(roms_hip_ctx *c);
 int run_rhs3d_tile(roms_hip_ctx *c);
 int run_step2d(roms_hip_ctx *c);
+int run_step2d_pair(roms_hip_ctx *c);     // predictor (c->G = its stepping) + corrector of one fast step
+bool step2d_pair_usable(const roms_hip_ctx *c);
 int run_step3d_uv(roms_hip_ctx *c);
 int run_step3d_t(roms_hip_ctx *c);
 int run_lmd_vmix(roms_hip_ctx *c);

@@ -289,11 +289,14 @@ def test_baseline_size_matches_oracle(workload, dims, nsteps, tol):
 
 STEP2D_FORMS = [
     # name, environment                                                kernel instantiated (g_step2d.cpp)
-    ("a_32x4", {}),                                                    # k_step2d_a: 32x4 sub-tiles, 384 threads
+    ("a_32x4", {"ROMS_HIP_PAIR": "0"}),                                # k_step2d_a: 32x4 sub-tiles, 384 threads, one launch per call
+    ("pair_a_32x4", {}),                                               # k_step2d_pair_a: predictor + corrector per launch (the default here)
+    ("pair_generic", {"ROMS_HIP_S2D_GENERIC": "1"}),                   # k_step2d_pair, run-time sub-tile shape
+    ("pair_generic_24x6", {"ROMS_HIP_S2D_GENERIC": "1", "ROMS_HIP_PAIR": "1", "ROMS_HIP_TILE2D": "24x6"}),
     ("c_32x8", {"ROMS_HIP_TILE2D": "32x8"}),                           # k_step2d_c: two blocks per CU (>= 256 K points)
     ("d_64x8", {"ROMS_HIP_TILE2D": "64x8"}),                           # k_step2d_d: 1024 threads (64 K .. 256 K points)
     ("b_64x8", {"ROMS_HIP_TILE2D": "64x8", "ROMS_HIP_S2D_1024": "0"}),  # k_step2d_b: 512 threads, two points each
-    ("generic", {"ROMS_HIP_S2D_GENERIC": "1"}),                        # run-time sub-tile shape
+    ("generic", {"ROMS_HIP_S2D_GENERIC": "1", "ROMS_HIP_PAIR": "0"}),  # run-time sub-tile shape
     ("generic_48x6", {"ROMS_HIP_S2D_GENERIC": "1", "ROMS_HIP_TILE2D": "48x6"}),
 ]
 
