@@ -4,6 +4,31 @@
 #include "k_step2d.h"
 #include "k_step2d_pair.h"
 
+// (Re)build the packed metric records after the grid arrays were uploaded.  A multi-tile context that runs the pair
+// kernel first fills the WIDE ghost lines of the time-invariant 2-D fields the barotropic kernels read (the caller's
+// windows carry 3 | Nghost lines): every rank reaches its first step2d call with m2d_dirty set, so the exchanges match.
+static void pack_metrics(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  if (c->static_wide_dirty && c->pair_mt) {
+    Fields &F = c->F;
+    const HaloSpec a[8] = {{F.h, 1, BC_NONE, 'r'}, {F.pm, 1, BC_NONE, 'r'}, {F.pn, 1, BC_NONE, 'r'}, {F.on_u, 1, BC_NONE, 'u'},
+                           {F.om_v, 1, BC_NONE, 'v'}, {F.fomn, 1, BC_NONE, 'r'}, {F.dndx, 1, BC_NONE, 'r'}, {F.dmde, 1, BC_NONE, 'r'}};
+    const HaloSpec b[8] = {{F.visc2_r, 1, BC_NONE, 'r'}, {F.pmon_r, 1, BC_NONE, 'r'}, {F.pnom_r, 1, BC_NONE, 'r'}, {F.on_r, 1, BC_NONE, 'r'},
+                           {F.om_r, 1, BC_NONE, 'r'}, {F.visc2_p, 1, BC_NONE, 'p'}, {F.pmon_p, 1, BC_NONE, 'p'}, {F.pnom_p, 1, BC_NONE, 'p'}};
+    const HaloSpec d[6] = {{F.om_p, 1, BC_NONE, 'p'}, {F.on_p, 1, BC_NONE, 'p'}, {F.rmask, 1, BC_NONE, 'r'}, {F.umask, 1, BC_NONE, 'u'},
+                           {F.vmask, 1, BC_NONE, 'v'}, {F.pmask, 1, BC_NONE, 'p'}};
+    launch_halo_wide(c, a, 8);
+    launch_halo_wide(c, b, 8);
+    launch_halo_wide(c, d, G.masking ? 6 : 2);
+  }
+  c->static_wide_dirty = false;
+  PackArgs pa;
+  pa.G = G;
+  pa.Fv = c->F;
+  LAUNCH_THREAD(k_pack_m2d, G.ni, G.nj, 1, c->stream, pa);
+  c->m2d_dirty = false;
+}
+
 int run_step2d(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const roms_hip_config &cf = c->cfg;
@@ -19,13 +44,7 @@ int run_step2d(roms_hip_ctx *c) {
   a.commit = c->b2_stage ? 1 : 0;
   if (c->b2_stage && !(G.predictor && G.krhs != 3)) { set_error("step2d: a staged pair result can only be followed by a predictor call"); return 8; }
   c->b2_stage = 0;
-  if (c->m2d_dirty) {   // (re)build the packed metric records after the grid arrays were uploaded
-    PackArgs pa;
-    pa.G = G;
-    pa.Fv = c->F;
-    LAUNCH_THREAD(k_pack_m2d, G.ni, G.nj, 1, c->stream, pa);
-    c->m2d_dirty = false;
-  }
+  if (c->m2d_dirty) pack_metrics(c);
   // kernel variant by sub-tile size: up to 32x4, up to 64x8, generic (ROMS_HIP_TILE2D overrides)
   int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 32 && G.bh2 <= 8) ? 3 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
   if (getenv("ROMS_HIP_S2D_GENERIC") || (G.masking && variant != 0)) variant = 2;   // (masks: k_step2d_am or the generic form)
@@ -93,12 +112,24 @@ int run_step2d(roms_hip_ctx *c) {
     launch_halo_multi(c, sp, 3);
   }
   if (iif > G.nfast) return 0;
-  HaloSpec sp[4];
+  HaloSpec sp[8];
   int n = 0;
   sp[n++] = {lev2d(c, c->F.zeta, G.knew), 1, bc_rstate(c), 'r'};                        // zetabc :1057 + exchange :1068
   if (G.predictor) sp[n++] = {lev2d(c, c->F.rzeta, G.krhs), 1, BC_NONE, 'r'};   // :1030
   sp[n++] = {lev2d(c, c->F.ubar, G.knew), 1, BC_U, 'u'};                        // u2dbc :2871 + exchange :3043
   sp[n++] = {lev2d(c, c->F.vbar, G.knew), 1, BC_V, 'v'};                        // v2dbc :2876
+  if (c->pair_on && c->pair_mt && !G.predictor && iif == 1 && G.nfast >= 2) {
+    // the pairs follow (k_step2d_pair.h): this exchange carries the wide strips, and with them what the first pair reads
+    // on its rim besides the level just written -- its kstp level (this call's kstp) and the fast-time-constant forcing
+    // the first predictor left in rufrc, rvfrc
+    sp[n++] = {lev2d(c, c->F.zeta, G.kstp), 1, BC_NONE, 'r'};
+    sp[n++] = {lev2d(c, c->F.ubar, G.kstp), 1, BC_NONE, 'u'};
+    sp[n++] = {lev2d(c, c->F.vbar, G.kstp), 1, BC_NONE, 'v'};
+    sp[n++] = {c->F.rufrc, 1, BC_NONE, 'u'};
+    sp[n++] = {c->F.rvfrc, 1, BC_NONE, 'v'};
+    launch_halo_wide(c, sp, n);
+    return 0;
+  }
   launch_halo_multi(c, sp, n);
   return 0;
 }
@@ -114,7 +145,7 @@ bool step2d_pair_usable(const roms_hip_ctx *c) {
   const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
   if (LmT < 8 || MmT < 8) return false;                                  // the rim (5 | 4 lines) comes from the neighbour's / the tile's own points
   if (pair_lds_doubles(G.bw2, G.bh2) * sizeof(double) > 160 * 1024) return false;
-  if (c->has_exchange) return false;                                     // (multi-tile: needs the wide exchange, below)
+  if (c->has_exchange && !c->pair_mt) return false;                      // multi-tile: needs the wide ghost zone (roms_hip_create)
   if (e && e[0] == '1') return true;
   return G.bw2 <= 32 && G.bh2 <= 4;
 }
@@ -135,13 +166,7 @@ int run_step2d_pair(roms_hip_ctx *c) {
   a.lev_out = c->b2_stage == 4 ? 5 : 4;
   a.wrapx = G.ewp && G.xloc;
   a.wrapy = G.nsp && G.yloc;
-  if (c->m2d_dirty) {
-    PackArgs pa;
-    pa.G = G;
-    pa.Fv = c->F;
-    LAUNCH_THREAD(k_pack_m2d, G.ni, G.nj, 1, c->stream, pa);
-    c->m2d_dirty = false;
-  }
+  if (c->m2d_dirty) pack_metrics(c);
   const bool fixed = G.bw2 <= 32 && G.bh2 <= 4 && !G.masking && !getenv("ROMS_HIP_S2D_GENERIC");
 #ifdef ROMS_CPU_EMU
   const size_t lds = pair_lds_doubles(G.bw2, G.bh2);
@@ -186,6 +211,6 @@ int run_step2d_pair(roms_hip_ctx *c) {
     sp[n++] = {lev2d(c, c->F.ubar, 3), 1, BC_U, 'u'};
     sp[n++] = {lev2d(c, c->F.vbar, 3), 1, BC_V, 'v'};
   }
-  launch_halo_multi(c, sp, n);
+  launch_halo_wide(c, sp, n);       // (multi-tile: strips B2D_GL | B2D_GH lines wide; a closed basin on one tile: boundary fills only)
   return 0;
 }

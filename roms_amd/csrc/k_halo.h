@@ -185,6 +185,20 @@ COOP_KERNEL(halo_kernel, HaloArgs) {
 }
 COOP_GLOBAL(halo_kernel, HaloArgs)
 
+// Caller layout <-> library layout (roms_hip.cpp:relayout): plane gz of the caller's window, point (gx,gy) of it
+struct RelayoutArgs {
+  double *lib, *win;
+  int to_lib, ni, cni, di, dj;
+  long nij, cnij;
+};
+THREAD_KERNEL(k_relayout, RelayoutArgs) {
+  const size_t w = (size_t)gx + (size_t)gy * (size_t)a.cni + (size_t)gz * (size_t)a.cnij;
+  const size_t l = (size_t)(gx + a.di) + (size_t)(gy + a.dj) * (size_t)a.ni + (size_t)gz * (size_t)a.nij;
+  if (a.to_lib) a.lib[l] = a.win[w];
+  else a.win[w] = a.lib[l];
+}
+THREAD_GLOBAL(k_relayout, RelayoutArgs)
+
 // ------------------------------------------------------------------------------------------
 // Inter-tile halo strips (multi-GPU): the data movement of mp_exchange2d/3d/4d
 // (ROMS/Utility/mp_exchange.F:28-2300) with the strip geometry of the periodic copies above --
@@ -216,15 +230,15 @@ struct XchgArgs {
 // lines filled by the message from neighbour d (unpack = 1)
 KDEV void xchg_rect(const DGrid &G, int d, int unpack, int &i0, int &i1, int &j0, int &j1) {
   const TB &B = G.T;
-  const int ng = G.Nghost;
+  const int gl = G.xgl, gh = G.xgh;       // ghost lines filled on the low | high side: 3 | Nghost, or B2D_GL | B2D_GH
   const int dx = (d == 0 || d == 4 || d == 6) ? -1 : ((d == 1 || d == 5 || d == 7) ? 1 : 0);
   const int dy = (d == 2 || d == 4 || d == 5) ? -1 : ((d == 3 || d == 6 || d == 7) ? 1 : 0);
   if (dx == 0) { i0 = G.LBi; i1 = G.LBi + G.ni - 1; }
-  else if (dx < 0) { i0 = unpack ? B.Istr - 3 : B.Istr; i1 = unpack ? B.Istr - 1 : B.Istr + ng - 1; }
-  else { i0 = unpack ? B.Iend + 1 : B.Iend - 2; i1 = unpack ? B.Iend + ng : B.Iend; }
+  else if (dx < 0) { i0 = unpack ? B.Istr - gl : B.Istr; i1 = unpack ? B.Istr - 1 : B.Istr + gh - 1; }
+  else { i0 = unpack ? B.Iend + 1 : B.Iend - gl + 1; i1 = unpack ? B.Iend + gh : B.Iend; }
   if (dy == 0) { j0 = G.LBj; j1 = G.LBj + G.nj - 1; }
-  else if (dy < 0) { j0 = unpack ? B.Jstr - 3 : B.Jstr; j1 = unpack ? B.Jstr - 1 : B.Jstr + ng - 1; }
-  else { j0 = unpack ? B.Jend + 1 : B.Jend - 2; j1 = unpack ? B.Jend + ng : B.Jend; }
+  else if (dy < 0) { j0 = unpack ? B.Jstr - gl : B.Jstr; j1 = unpack ? B.Jstr - 1 : B.Jstr + gh - 1; }
+  else { j0 = unpack ? B.Jend + 1 : B.Jend - gl + 1; j1 = unpack ? B.Jend + gh : B.Jend; }
 }
 
 KDEV void xchg_move(const DGrid &G, double *A, double *msg, int bz, int d, int unpack) {
@@ -326,10 +340,10 @@ KDEV void peer_elem(const DGrid &G, const PeerList &L, int bz, int q, int &d, do
 // element is therefore written unless a later message covers its cell, and no barrier separates the three groups.
 KDEV bool peer_covered_later(const DGrid &G, const PeerList &L, int d, int i, int j) {
   const TB &B = G.T;
-  const int ng = G.Nghost;
-  if (d < 2) return (L.m[2] && j >= B.Jstr - 3 && j <= B.Jstr - 1) || (L.m[3] && j >= B.Jend + 1 && j <= B.Jend + ng);
+  const int gl = G.xgl, gh = G.xgh;
+  if (d < 2) return (L.m[2] && j >= B.Jstr - gl && j <= B.Jstr - 1) || (L.m[3] && j >= B.Jend + 1 && j <= B.Jend + gh);
   if (d < 4) {
-    const bool low = i >= B.Istr - 3 && i <= B.Istr - 1, high = i >= B.Iend + 1 && i <= B.Iend + ng;
+    const bool low = i >= B.Istr - gl && i <= B.Istr - 1, high = i >= B.Iend + 1 && i <= B.Iend + gh;
     return d == 2 ? ((L.m[4] && low) || (L.m[5] && high)) : ((L.m[6] && low) || (L.m[7] && high));
   }
   return false;

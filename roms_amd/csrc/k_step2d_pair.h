@@ -341,8 +341,13 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
             if (i >= B.IstrU) hb_emit(G, B, ulog, BC_U, i, j, ukv, MSK ? G.umask : nullptr);
             if (j >= B.JstrV) hb_emit(G, B, vlog, BC_V, i, j, vkv, MSK ? G.vmask : nullptr);
           }
-        } else if (own || !INR(i, j, T.Istr, T.Iend, T.Jstr, T.Jend)) {
-          zlog[x0] = zkv; ulog[x0] = ukv; vlog[x0] = vkv;      // own points; boundary and ghost points of the tile by its edge blocks
+        } else if ((own || !INR(i, j, T.Istr, T.Iend, T.Jstr, T.Jend)) && INR(i, j, G.LBi, UBi, G.LBj, UBj) &&
+                   (!wrapx || (i >= -2 && i <= G.Lm + G.Nghost)) && (!wrapy || (j >= -2 && j <= G.Mm + G.Nghost))) {
+          // own points; boundary and ghost points of the tile by its edge blocks -- at the point's own place in the array
+          // (where the tile closes a periodic direction on itself the value was READ at the wrapped index: its image; the
+          // reference's periodic ghost zone is -2:0 and Lm+1:Lm+Nghost, the padding column beyond is never written)
+          const int xu = (i - G.LBi) + (j - G.LBj) * ni;
+          zlog[xu] = zkv; ulog[xu] = ukv; vlog[xu] = vkv;
         }
       }
     } else {

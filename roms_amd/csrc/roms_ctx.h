@@ -38,6 +38,8 @@ struct DGrid {
   int fuse_halo;              // 1: single tile, k_step2d fills boundary/periodic ghost points itself (k_haloblock.h)
   int fuse3d;                 // 1: the 3-D producers do so too (emit_plan/emit_store); ROMS_HIP_FUSE3D=0 turns it off
   int xloc, yloc;             // 1: a periodic direction of this tile wraps onto itself by a local copy (no exchange partner)
+  int xgl, xgh;               // ghost lines a strip exchange fills on the low | high side of a tile: 3 | Nghost (the reference's
+                              // periodic layout), or B2D_GL | B2D_GH for the exchanges behind the barotropic pair kernel
   int nbx2, nby2, bw2, bh2;   // the same for the 2-D (barotropic) kernel: smaller sub-tiles, the
                               // 2-D grid alone cannot fill 256 CUs otherwise
   // stepping (mod_stepping)
@@ -130,6 +132,11 @@ KHD TB block_bounds_n(const DGrid &G, int nbx, int nby, int bx, int by) {
 }
 KHD TB block_bounds(const DGrid &G, int bx, int by) { return block_bounds_n(G, G.nbx, G.nby, bx, by); }
 KHD TB block_bounds2(const DGrid &G, int bx, int by) { return block_bounds_n(G, G.nbx2, G.nby2, bx, by); }
+
+// ghost lines the barotropic pair kernel reads beyond the tile (k_step2d_pair.h): each of its two step2d calls consumes
+// three lines on the low side and two on the high side, so a pair needs 5 | 4 (2-D fields of a multi-tile run)
+#define B2D_GL 5
+#define B2D_GH 4
 
 // boundary-fill kinds of the halo code (k_halo.h, k_haloblock.h)
 enum { BC_NONE = 0, BC_R = 1, BC_U = 2, BC_V = 3 };

@@ -93,23 +93,30 @@ static const FieldDesc g_fields[] = {
 };
 static const int g_nfields = (int)(sizeof(g_fields) / sizeof(g_fields[0]));
 
-long field_elems(const roms_hip_ctx *c, int kind) {
-  const long p = c->G.nij, N = c->G.N, NT = c->G.NT, NAT = c->G.NAT;
+int field_planes(const roms_hip_ctx *c, int kind) {
+  const int N = c->G.N, NT = c->G.NT, NAT = c->G.NAT;
   switch (kind) {
-    case FK_2D: return p;
-    case FK_R: return p * N;
-    case FK_W: return p * (N + 1);
-    case FK_2Dx3: return p * 3;
-    case FK_2Dx2: return p * 2;
-    case FK_Rx2: return p * N * 2;
-    case FK_T: return p * N * 3 * NT;
-    case FK_Wx2: return p * (N + 1) * 2;
-    case FK_2DxNT: return p * NT;
-    case FK_WxNAT: return p * (N + 1) * NAT;
-    case FK_TABR: return N;
-    case FK_TABW: return N + 1;
+    case FK_2D: return 1;
+    case FK_R: return N;
+    case FK_W: return N + 1;
+    case FK_2Dx3: return 3;
+    case FK_2Dx2: return 2;
+    case FK_Rx2: return N * 2;
+    case FK_T: return N * 3 * NT;
+    case FK_Wx2: return (N + 1) * 2;
+    case FK_2DxNT: return NT;
+    case FK_WxNAT: return (N + 1) * NAT;
   }
   return -1;
+}
+static long table_elems(const roms_hip_ctx *c, int kind) { return kind == FK_TABR ? c->G.N : (kind == FK_TABW ? c->G.N + 1 : -1); }
+long field_elems(const roms_hip_ctx *c, int kind) {
+  const int np = field_planes(c, kind);
+  return np < 0 ? table_elems(c, kind) : (long)np * c->G.nij;
+}
+long field_elems_caller(const roms_hip_ctx *c, int kind) {
+  const int np = field_planes(c, kind);
+  return np < 0 ? table_elems(c, kind) : (long)np * (long)c->cni * (long)c->cnj;
 }
 
 const FieldDesc *find_field(const char *name) {
@@ -210,9 +217,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   c->cfg = *cfg;
   DGrid &G = c->G;
   memset(&G, 0, sizeof(G));
-  G.LBi = cfg->LBi; G.LBj = cfg->LBj;
-  G.ni = cfg->UBi - cfg->LBi + 1; G.nj = cfg->UBj - cfg->LBj + 1;
-  G.nij = (long)G.ni * G.nj;
+  // (array bounds: below, once the neighbours are known)
   G.N = cfg->N; G.NT = cfg->NT; G.NAT = cfg->NAT; G.Lm = cfg->Lm; G.Mm = cfg->Mm; G.Nghost = cfg->Nghost;
   G.ewp = cfg->EWperiodic; G.nsp = cfg->NSperiodic; G.options = cfg->options;
   for (int i = 0; i < ROMS_MAXT; i++) { G.hadv[i] = cfg->hadv[i]; G.vadv[i] = cfg->vadv[i]; G.Akt_bak[i] = cfg->Akt_bak[i]; }
@@ -251,6 +256,33 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     G.xloc = nb[0] < 0 && nb[1] < 0;
     G.yloc = nb[2] < 0 && nb[3] < 0;
     c->has_exchange = nb[0] >= 0 || nb[1] >= 0 || nb[2] >= 0 || nb[3] >= 0;
+    // Array bounds.  The caller's LBi:UBi x LBj:UBj (the reference layout) is what upload / download move.  A multi-tile
+    // context that runs the barotropic steps as predictor+corrector pairs (k_step2d_pair.h) keeps a wider ghost zone
+    // towards every neighbouring tile -- B2D_GL | B2D_GH lines -- in ALL its arrays (one index rule for every kernel);
+    // the 2-D exchanges behind the pairs fill it, every other exchange fills the inner 3 | Nghost lines as before.
+    // Every rank takes the same decision: it depends on the partition only (the narrowest tile must own the lines it sends).
+    c->cLBi = cfg->LBi; c->cLBj = cfg->LBj;
+    c->cni = cfg->UBi - cfg->LBi + 1; c->cnj = cfg->UBj - cfg->LBj + 1;
+    int LB_i = cfg->LBi, UB_i = cfg->UBi, LB_j = cfg->LBj, UB_j = cfg->UBj;
+    {
+      const char *ep = getenv("ROMS_HIP_PAIR");
+      const bool shape_ok = ep && ep[0] == '1' ? true : (G.bw2 <= 32 && G.bh2 <= 4);
+      const int wmin = KMIN(edge_subtile(cfg->Lm, NI), (cfg->Lm + NI - 1) / NI), hmin = KMIN(edge_subtile(cfg->Mm, NJ), (cfg->Mm + NJ - 1) / NJ);
+      c->pair_mt = c->has_exchange && !(ep && ep[0] == '0') && shape_ok && wmin >= 8 && hmin >= 8;
+      if (c->pair_mt) {
+        if (nb[0] >= 0) LB_i = KMIN(LB_i, cfg->Istr - B2D_GL);
+        if (nb[1] >= 0) UB_i = KMAX(UB_i, cfg->Iend + B2D_GH);
+        if (nb[2] >= 0) LB_j = KMIN(LB_j, cfg->Jstr - B2D_GL);
+        if (nb[3] >= 0) UB_j = KMAX(UB_j, cfg->Jend + B2D_GH);
+      }
+    }
+    G.LBi = LB_i; G.LBj = LB_j;
+    G.ni = UB_i - LB_i + 1; G.nj = UB_j - LB_j + 1;
+    G.nij = (long)G.ni * G.nj;
+    c->wide = G.LBi != c->cLBi || G.LBj != c->cLBj || G.ni != c->cni || G.nj != c->cnj;
+    c->stage_buf = nullptr; c->stage_cap = 0;
+    c->static_wide_dirty = c->pair_mt;
+    G.xgl = 3; G.xgh = cfg->Nghost;
   }
   {  // producer-side halo fills need the whole domain on this GPU and edge sub-tiles that own the
      // three source lines of a periodic copy
@@ -305,6 +337,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   c->xstream = nullptr;
   c->x_async = false;
   c->x_tail = false;
+  c->x_wide = false;
   c->x_pending = 0;
   c->ev_x_next = 0;
   for (int k = 0; k < 16; k++) c->x_event_of[k] = -1;
@@ -431,6 +464,7 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   }
 #endif
   for (void *p : c->allocs) dfree(p);
+  if (c->stage_buf) dfree(c->stage_buf);
   for (int k = 0; k < 8; k++) { if (c->comm.sbuf[k]) dfree(c->comm.sbuf[k]); if (c->comm.rbuf[k]) dfree(c->comm.rbuf[k]); }
   comm_destroy(c);
   free(c->h_diag);
@@ -468,32 +502,64 @@ extern "C" long roms_hip_field_size(roms_hip_ctx *c, const char *name) {
   const FieldDesc *f = find_field(name);
   if (!f) {
     const int a = avg_field_index(name);
-    return (a >= 0 && c->avg[a]) ? avg_field_elems(c, a) : -1;
+    return (a >= 0 && c->avg[a]) ? avg_field_elems(c, a) / c->G.nij * ((long)c->cni * c->cnj) : -1;
   }
-  return field_elems(c, f->kind);
+  return field_elems_caller(c, f->kind);
+}
+// Caller layout <-> library layout (c->wide): `np` planes through a device staging buffer in the caller's layout.
+// to_lib: the caller's window is copied into the library's arrays (the ghost lines beyond it keep their contents);
+// otherwise the window is cut out of them.
+static int relayout(roms_hip_ctx *c, double *lib, int np, bool to_lib, const double *host_in, double *host_out) {
+  const size_t cn = (size_t)c->cni * (size_t)c->cnj * (size_t)np;
+  if (cn > c->stage_cap) {
+    if (c->stage_buf) { (void)dsync(c->stream); dfree(c->stage_buf); c->stage_buf = nullptr; c->stage_cap = 0; }
+    void *p = nullptr;
+    if (dmalloc(&p, cn * sizeof(double))) return 2;
+    c->stage_buf = (double *)p; c->stage_cap = cn;
+  }
+  RelayoutArgs a;
+  a.lib = lib; a.win = c->stage_buf; a.to_lib = to_lib ? 1 : 0;
+  a.ni = c->G.ni; a.nij = c->G.nij; a.cni = c->cni; a.cnij = (long)c->cni * c->cnj;
+  a.di = c->cLBi - c->G.LBi; a.dj = c->cLBj - c->G.LBj;
+  if (to_lib) {
+    int r = h2d(c->stage_buf, host_in, cn * sizeof(double), c->stream);
+    if (r) return r;
+    LAUNCH_THREAD(k_relayout, c->cni, c->cnj, np, c->stream, a);
+    return dsync(c->stream);
+  }
+  LAUNCH_THREAD(k_relayout, c->cni, c->cnj, np, c->stream, a);
+  return d2h(host_out, c->stage_buf, cn * sizeof(double), c->stream);
 }
 extern "C" int roms_hip_upload(roms_hip_ctx *c, const char *name, const double *host, long n) {
   const FieldDesc *f = find_field(name);
   if (!f) { set_error(std::string("unknown field ") + name); return 8; }
-  if (n != field_elems(c, f->kind)) { set_error(std::string("size mismatch for field ") + name); return 8; }
-  if (f->kind == FK_2D) c->m2d_dirty = true;
+  if (n != field_elems_caller(c, f->kind)) { set_error(std::string("size mismatch for field ") + name); return 8; }
+  if (f->kind == FK_2D) { c->m2d_dirty = true; c->static_wide_dirty = c->pair_mt; }
   halo_fence(c, FG_ALL);
-  return h2d(*(double **)((char *)&c->F + f->offset), host, (size_t)n * sizeof(double), c->stream);
+  double *dst = *(double **)((char *)&c->F + f->offset);
+  const int np = field_planes(c, f->kind);
+  if (c->wide && np > 0) return relayout(c, dst, np, true, host, nullptr);
+  return h2d(dst, host, (size_t)n * sizeof(double), c->stream);
 }
 extern "C" int roms_hip_download(roms_hip_ctx *c, const char *name, double *host, long n) {
   const FieldDesc *f = find_field(name);
   if (!f) {
     const int a = avg_field_index(name);               // time-averaged fields: "avg_zeta" ... "avg_HvomT"
     if (a >= 0 && c->avg[a]) {
-      if (n != avg_field_elems(c, a)) { set_error(std::string("size mismatch for field ") + name); return 8; }
+      const int np = (int)(avg_field_elems(c, a) / c->G.nij);
+      if (n != (long)np * c->cni * c->cnj) { set_error(std::string("size mismatch for field ") + name); return 8; }
       halo_fence(c, FG_ALL);
+      if (c->wide) return relayout(c, c->avg[a], np, false, nullptr, host);
       return d2h(host, c->avg[a], (size_t)n * sizeof(double), c->stream);
     }
   }
   if (!f) { set_error(std::string("unknown field ") + name); return 8; }
-  if (n != field_elems(c, f->kind)) { set_error(std::string("size mismatch for field ") + name); return 8; }
+  if (n != field_elems_caller(c, f->kind)) { set_error(std::string("size mismatch for field ") + name); return 8; }
   halo_fence(c, FG_ALL);
-  return d2h(host, *(double **)((char *)&c->F + f->offset), (size_t)n * sizeof(double), c->stream);
+  double *src = *(double **)((char *)&c->F + f->offset);
+  const int np = field_planes(c, f->kind);
+  if (c->wide && np > 0) return relayout(c, src, np, false, nullptr, host);
+  return d2h(host, src, (size_t)n * sizeof(double), c->stream);
 }
 extern "C" int roms_hip_sync(roms_hip_ctx *c) {
   halo_fence(c, FG_ALL);
@@ -808,7 +874,8 @@ extern "C" int roms_hip_peer_export(roms_hip_ctx *c, void *blob128) {
         for (int d = 0; d < 8; d++) {
           m.peer_off[ch][par][d] = off;
           if (m.nbr[d] < 0) continue;
-          const size_t w = d < 2 ? (size_t)3 * G.nj : (d < 4 ? (size_t)3 * G.ni : 9);
+          const size_t gw = c->pair_mt ? (size_t)B2D_GL : 3;       // widest strip an exchange point carries
+          const size_t w = d < 2 ? gw * G.nj : (d < 4 ? gw * G.ni : gw * gw);
           off += ((size_t)m.peer_planes * w * sizeof(double) + 255) & ~(size_t)255;
         }
     m.peer_bytes = off;
@@ -949,9 +1016,10 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
     set_error("multi-tile context without a transport: call roms_hip_comm_rccl, roms_hip_comm_peer or roms_hip_set_exchange first");
     return 8;
   }
-  const DGrid &G = c->G;
+  const DGrid &G = h.G;                    // (c->G with the strip widths of this exchange point)
   const size_t lines = (size_t)(G.ni > G.nj ? G.ni : G.nj);
-  const size_t need = (size_t)planes * lines * 3;
+  const size_t gw = c->pair_mt ? (size_t)B2D_GL : 3;
+  const size_t need = (size_t)planes * lines * gw;
   if (m.peer_on && planes > m.peer_planes) {
     set_error("mailbox transport: an exchange point carries more planes than a slot holds (ROMS_HIP_PEER_PLANES)");
     return 8;
@@ -966,7 +1034,7 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
       if (m.rbuf[k]) dfree(m.rbuf[k]);
       m.sbuf[k] = m.rbuf[k] = nullptr;
       if (m.nbr[k] < 0) continue;
-      const size_t n = k < 4 ? need : (size_t)planes * 9;
+      const size_t n = k < 4 ? need : (size_t)planes * gw * gw;
       void *p = nullptr, *q = nullptr;
       if (dmalloc(&p, n * sizeof(double)) || dmalloc(&q, n * sizeof(double))) return 2;
       m.sbuf[k] = (double *)p; m.rbuf[k] = (double *)q;
@@ -979,13 +1047,13 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
   // message sizes (k_halo.h:xchg_rect): planes x width along xi x width along eta, a width being all
   // local lines across the direction of travel, Nghost lines for a message going to the low side
   // (the receiver's high ghost zone) and three for one going to the high side (its low ghost zone)
-  const int ng = G.Nghost;
+  const int gl = G.xgl, gh = G.xgh;
   auto count = [&](int d, bool sending) -> long {
     const int dx = (d == 0 || d == 4 || d == 6) ? -1 : ((d == 1 || d == 5 || d == 7) ? 1 : 0);
     const int dy = (d == 2 || d == 4 || d == 5) ? -1 : ((d == 3 || d == 6 || d == 7) ? 1 : 0);
-    // sending to the low side: my first Nghost lines; receiving from the low side: three lines
-    const long wx = dx == 0 ? G.ni : ((dx < 0) == sending ? ng : 3);
-    const long wy = dy == 0 ? G.nj : ((dy < 0) == sending ? ng : 3);
+    // sending to the low side: my first gh lines (the receiver's HIGH ghost zone); receiving from the low side: gl lines
+    const long wx = dx == 0 ? G.ni : ((dx < 0) == sending ? gh : gl);
+    const long wy = dy == 0 ? G.nj : ((dy < 0) == sending ? gh : gl);
     return (long)planes * wx * wy;
   };
   XchgArgs a;
@@ -1096,6 +1164,7 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
 void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n) {
   HaloArgs a;
   a.G = c->G;
+  if (c->x_wide && c->pair_mt) { a.G.xgl = B2D_GL; a.G.xgh = B2D_GH; }
   a.nitems = n;
   int planes = 0;
   for (int k = 0; k < HALO_MAXITEMS; k++) { a.it[k].A = nullptr; a.it[k].nk = 0; a.it[k].bc = BC_NONE; a.it[k].gtype = 0; }
@@ -1116,52 +1185,70 @@ void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n) {
 // hold the code of the point it images (tile arrays are indexed globally, so that is its own index, wrapped where the
 // domain is periodic).  Multi-GPU runs call it once after installing a transport (roms_amd/tiling.py): a mapping that
 // does not carry the data, a stale cache line or a lost message shows up here, with a message, not in the fields.
-extern "C" int roms_hip_exchange_probe(roms_hip_ctx *c, int reps) {
-  if (!c) return 8;
-  if (!c->has_exchange) return 0;
+// The probe covers what production uses (several planes per exchange: the slot / arrival-word indexing of the mailbox;
+// both strip widths; the exchange stream's channel where asynchronous exchanges are on).
+static int probe_once(roms_hip_ctx *c, int rep, int planes, bool wide, bool tail) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   const TileComm &m = c->comm;
   const size_t n = (size_t)G.ni * (size_t)G.nj;
-  std::vector<double> h(n), g(n);
-  double *A = c->F.wrk2[0];
+  std::vector<double> h(n * planes), g(n * planes);
+  double *A = c->F.wrk3[0];                 // a 3-D work array: `planes` consecutive planes
   auto at = [&](int i, int j) -> size_t { return (size_t)(i - G.LBi) + (size_t)(j - G.LBj) * (size_t)G.ni; };
-  auto code = [&](int i, int j, int rep) -> double {
+  auto code = [&](int i, int j, int k) -> double {
     if (i < 1) i += G.Lm; else if (i > G.Lm) i -= G.Lm;
     if (j < 1) j += G.Mm; else if (j > G.Mm) j -= G.Mm;
-    return (double)rep * 67108864.0 + (double)j * 8192.0 + (double)i;
+    return ((double)rep * 64.0 + (double)k) * 67108864.0 + (double)j * 8192.0 + (double)i;
   };
-  const int ng = G.Nghost;
-  for (int rep = 1; rep <= reps; rep++) {
-    for (size_t k = 0; k < n; k++) h[k] = -1.0;
+  const int gl = wide ? B2D_GL : 3, gh = wide ? B2D_GH : G.Nghost;
+  for (int k = 0; k < planes; k++) {
+    for (size_t q = 0; q < n; q++) h[q + n * k] = -1.0;
     for (int j = B.Jstr; j <= B.Jend; j++)
-      for (int i = B.Istr; i <= B.Iend; i++) h[at(i, j)] = code(i, j, rep);
-    int r = h2d(A, h.data(), n * sizeof(double), c->stream);
-    if (r) return r;
-    HaloSpec sp = {A, 1, BC_NONE, 'r'};
-    launch_halo_multi(c, &sp, 1);
-    r = ctx_check(c, "exchange probe");
-    if (r) return r;
-    r = d2h(g.data(), A, n * sizeof(double), c->stream);
-    if (r) return r;
-    r = ctx_check(c, "exchange probe");
-    if (r) return r;
+      for (int i = B.Istr; i <= B.Iend; i++) h[at(i, j) + n * k] = code(i, j, k);
+  }
+  int r = h2d(A, h.data(), n * planes * sizeof(double), c->stream);
+  if (r) return r;
+  HaloSpec sp = {A, planes, BC_NONE, 'r'};
+  if (wide) launch_halo_wide(c, &sp, 1);
+  else if (tail) launch_halo_tail(c, &sp, 1);
+  else launch_halo_multi(c, &sp, 1);
+  halo_fence(c, FG_ALL);
+  r = ctx_check(c, "exchange probe");
+  if (r) return r;
+  r = d2h(g.data(), A, n * planes * sizeof(double), c->stream);
+  if (r) return r;
+  r = ctx_check(c, "exchange probe");
+  if (r) return r;
+  for (int k = 0; k < planes; k++)
     for (int d = 0; d < 8; d++) {
       if (m.nbr[d] < 0) continue;
       const int dx = (d == 0 || d == 4 || d == 6) ? -1 : ((d == 1 || d == 5 || d == 7) ? 1 : 0);
       const int dy = (d == 2 || d == 4 || d == 5) ? -1 : ((d == 3 || d == 6 || d == 7) ? 1 : 0);
-      const int i0 = dx == 0 ? B.Istr : (dx < 0 ? B.Istr - 3 : B.Iend + 1), i1 = dx == 0 ? B.Iend : (dx < 0 ? B.Istr - 1 : B.Iend + ng);
-      const int j0 = dy == 0 ? B.Jstr : (dy < 0 ? B.Jstr - 3 : B.Jend + 1), j1 = dy == 0 ? B.Jend : (dy < 0 ? B.Jstr - 1 : B.Jend + ng);
+      const int i0 = dx == 0 ? B.Istr : (dx < 0 ? B.Istr - gl : B.Iend + 1), i1 = dx == 0 ? B.Iend : (dx < 0 ? B.Istr - 1 : B.Iend + gh);
+      const int j0 = dy == 0 ? B.Jstr : (dy < 0 ? B.Jstr - gl : B.Jend + 1), j1 = dy == 0 ? B.Jend : (dy < 0 ? B.Jstr - 1 : B.Jend + gh);
       for (int j = j0; j <= j1; j++)
         for (int i = i0; i <= i1; i++)
-          if (g[at(i, j)] != code(i, j, rep)) {
-            char msg[256];
-            snprintf(msg, sizeof(msg), "exchange probe: tile %d, repetition %d, ghost point (%d,%d) from neighbour %d (rank %d) holds %.17g, expected %.17g",
-                     c->cfg.tile, rep, i, j, d, m.nbr[d], g[at(i, j)], code(i, j, rep));
+          if (g[at(i, j) + n * k] != code(i, j, k)) {
+            char msg[320];
+            snprintf(msg, sizeof(msg), "exchange probe: tile %d, repetition %d (%d planes, strips %d|%d lines%s), plane %d, ghost point (%d,%d) from neighbour %d (rank %d) holds %.17g, expected %.17g",
+                     c->cfg.tile, rep, planes, gl, gh, tail ? ", exchange stream" : "", k, i, j, d, m.nbr[d], g[at(i, j) + n * k], code(i, j, k));
             set_error(msg);
             return 2;
           }
     }
+  return 0;
+}
+extern "C" int roms_hip_exchange_probe(roms_hip_ctx *c, int reps) {
+  if (!c) return 8;
+  if (!c->has_exchange) return 0;
+  const int np3 = KMAX(c->x_min_planes, KMIN(c->G.N, 12));      // enough planes for the exchange stream's channel
+  for (int rep = 1; rep <= reps; rep++) {
+    int r;
+    if ((r = probe_once(c, rep, 1, false, false))) return r;                   // one 2-D plane, compute stream
+    if ((r = probe_once(c, rep, 4, false, false))) return r;                   // a barotropic exchange point: four planes
+    if ((r = probe_once(c, rep, np3, false, true))) return r;                  // a 3-D exchange point (exchange stream where it is on)
+    if (c->pair_mt && (r = probe_once(c, rep, 3, true, false))) return r;      // the wide strips behind a pair
+    if (c->pair_mt && (r = probe_once(c, rep, 8, true, false))) return r;
   }
   return 0;
 }
@@ -1180,6 +1267,11 @@ extern "C" int roms_hip_comm_reset(roms_hip_ctx *c) {
   return 0;
 }
 
+void launch_halo_wide(roms_hip_ctx *c, const HaloSpec *sp, int n) {
+  c->x_wide = true;                       // the exchange being launched carries B2D_GL | B2D_GH lines
+  launch_halo_multi(c, sp, n);
+  c->x_wide = false;
+}
 void launch_halo_tail(roms_hip_ctx *c, const HaloSpec *sp, int n) {
   c->x_tail = true;
   launch_halo_multi(c, sp, n);
@@ -1614,7 +1706,7 @@ extern "C" int roms_hip_output_point(roms_hip_ctx *c) {
 extern "C" int roms_hip_get_bounds(roms_hip_ctx *c, int *out) {
   if (!c || !out) return 8;
   const TB &b = c->G.T;
-  const int v[54] = {c->G.LBi, c->G.LBi + c->G.ni - 1, c->G.LBj, c->G.LBj + c->G.nj - 1,
+  const int v[54] = {c->cLBi, c->cLBi + c->cni - 1, c->cLBj, c->cLBj + c->cnj - 1,     // (the caller's bounds)
     b.Istr, b.Iend, b.Jstr, b.Jend, b.IstrR, b.IendR, b.JstrR, b.JendR, b.IstrU, b.JstrV, b.IstrB, b.IendB, b.IstrM,
     b.JstrB, b.JendB, b.JstrM, b.IstrP, b.IendP, b.JstrP, b.JendP, b.IstrT, b.IendT, b.JstrT, b.JendT,
     b.Istrm3, b.Istrm2, b.Istrm1, b.IstrUm2, b.IstrUm1, b.Iendp1, b.Iendp2, b.Iendp2i, b.Iendp3,

@@ -60,6 +60,15 @@ struct roms_hip_ctx {
                                 // k_prs_grad keeps the old ru/rv bracket, k_uv3dmix2_s only stores its terms, k_pre_new uses both
   bool m2d_dirty;               // grid arrays uploaded since Fields::m2r/m2p were packed (g_step2d.cpp)
   // barotropic predictor+corrector pairs as one launch (k_step2d_pair.h)
+  // Multi-tile runs with the pair kernel keep their arrays with a WIDER ghost zone than the caller's LBi:UBi x LBj:UBj
+  // (B2D_GL | B2D_GH lines towards every neighbouring tile): c->G describes the library's layout, cLB*/cn* the caller's;
+  // upload / download repack (roms_hip.cpp:relayout)
+  int cLBi, cLBj, cni, cnj;
+  bool wide;                    // the two layouts differ
+  bool pair_mt;                 // multi-tile context set up for the pair kernel (wide 2-D exchanges)
+  double *stage_buf;            // device staging of upload / download in the caller's layout
+  size_t stage_cap;
+  bool static_wide_dirty;       // the wide ghost lines of the time-invariant 2-D fields have not been exchanged yet
   bool pair_on;                 // roms_hip_main3d runs the fast steps iif >= 2 as pairs
   int b2_stage;                 // physical level (4 | 5) of zeta/ubar/vbar holding the last pair's result, not yet committed
                                 // to its logical level; 0: none
@@ -95,6 +104,7 @@ struct roms_hip_ctx {
   unsigned x_pending;           // field groups with an exchange possibly still in flight
   bool x_async;
   bool x_tail;                  // the exchange being launched is the last operation of its routine
+  bool x_wide;                  // ... carries the wide strips of the barotropic pair kernel (launch_halo_wide)
   int x_min_planes;             // exchanges with fewer planes stay on the compute stream
 };
 
@@ -133,7 +143,9 @@ void lane_record(roms_hip_ctx *c, int e);
 void lane_wait(roms_hip_ctx *c, int e);
 int ctx_check(roms_hip_ctx *c, const char *what);  // hipGetLastError -> exit_flag style code
 void set_error(const std::string &msg);
-long field_elems(const roms_hip_ctx *c, int kind);
+long field_elems(const roms_hip_ctx *c, int kind);          // in the library's layout (allocation)
+long field_elems_caller(const roms_hip_ctx *c, int kind);   // in the caller's layout (what upload / download move)
+int field_planes(const roms_hip_ctx *c, int kind);          // horizontal planes of a field, -1: a table without horizontal extent
 const FieldDesc *find_field(const char *name);
 
 // halo / BC launcher (k_halo.h): nk planes starting at A
@@ -148,6 +160,7 @@ void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype);
 // multi-tile run the exchange may go to the exchange stream and overlap the routines that follow (halo_fence)
 void launch_halo_tail(roms_hip_ctx *c, const HaloSpec *sp, int n);
 void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n);   // n <= 8 fields in one launch
+void launch_halo_wide(roms_hip_ctx *c, const HaloSpec *sp, int n);    // ... with strips B2D_GL | B2D_GH lines wide (pair kernel)
 int run_set_avg(roms_hip_ctx *c, int part = 0);   // g_avg.cpp
 bool launch_tadv_lds(roms_hip_ctx *c, int mode);  // g_rhs3d.cpp
 int avg_field_index(const char *name);

@@ -267,11 +267,14 @@ class TiledRun:
         d = self.host.dims
         G = np.zeros((a.shape[0], d["UBj"] - d["LBj"] + 1, d["UBi"] - d["LBi"] + 1))
         it, jt = t["tile"] % self.NtileI, t["tile"] // self.NtileI
-        # own range: interior, extended to the array edge on domain edges (boundary + periodic ghosts)
-        i0 = t["LBi"] if it == 0 else t["Istr"]
-        i1 = t["UBi"] if it == self.NtileI - 1 else t["Iend"]
-        j0 = t["LBj"] if jt == 0 else t["Jstr"]
-        j1 = t["UBj"] if jt == self.NtileJ - 1 else t["Jend"]
+        # own range: interior, extended on domain edges to what the reference defines there -- the boundary points of a
+        # closed edge, the ghost points -2:0 and Lm+1:Lm+Nghost of a periodic one -- not to the padding line of an even
+        # Lm / Mm behind them (mod_param.F:1633-1636: allocated, never computed)
+        ng = d["Nghost"]
+        i0 = max(t["LBi"], -2 if d["EWper"] else 0) if it == 0 else t["Istr"]
+        i1 = min(t["UBi"], d["Lm"] + (ng if d["EWper"] else 1)) if it == self.NtileI - 1 else t["Iend"]
+        j0 = max(t["LBj"], -2 if d["NSper"] else 0) if jt == 0 else t["Jstr"]
+        j1 = min(t["UBj"], d["Mm"] + (ng if d["NSper"] else 1)) if jt == self.NtileJ - 1 else t["Jend"]
         G[:, j0 - d["LBj"]:j1 - d["LBj"] + 1, i0 - d["LBi"]:i1 - d["LBi"] + 1] = \
             a[:, j0 - t["LBj"]:j1 - t["LBj"] + 1, i0 - t["LBi"]:i1 - t["LBi"] + 1]
         if self.world > 1:

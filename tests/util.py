@@ -61,6 +61,13 @@ def case_for(tag, **kw):
         return cases.benchmark_mask(Lm=24, Mm=16, N=10, **kw)
     if tag == "upwelling_mask_small":
         return cases.upwelling_mask(Lm=14, Mm=18, N=8, **kw)
+    # grids whose 2x2 / 4x2 tiles are large enough (>= 8 points) for the barotropic pair kernel with its wide strips
+    if tag == "upwelling_mid":
+        return cases.upwelling(Lm=34, Mm=40, N=6, **kw)
+    if tag == "benchmark_mid":
+        return cases.benchmark(Lm=48, Mm=34, N=6, **kw)
+    if tag == "upwelling_mask_mid":
+        return cases.upwelling_mask(Lm=34, Mm=40, N=6, **kw)
     if tag == "upwelling_logdrag_small":
         return cases.upwelling_logdrag(Lm=14, Mm=18, N=8, **kw)
     raise KeyError(tag)
