@@ -159,6 +159,18 @@ int run_wvelocity(roms_hip_ctx *c, int ninp) {
 int run_set_zeta(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   KArgs a = mk(c);
+  static const char *ezx = getenv("ROMS_HIP_SETZETA_X");
+  if (c->has_exchange && !(ezx && ezx[0] == '0')) {
+    // Zt_avg1 carries valid ghost lines (exchanged with the final fast-time averages; ini_zeta at the first step): copy
+    // them with the tile -- three lines on the low side, Nghost on the high side, the boundary line of a closed edge --
+    // and no exchange follows (set_zeta.F:100-118 exchanges zeta(1:2), whose ghost lines then hold the same values)
+    const DGrid &G = c->G;
+    const int i0 = (B.west && !G.ewp) ? B.IstrR : B.Istr - 3, i1 = (B.east && !G.ewp) ? B.IendR : B.Iend + G.Nghost;
+    const int j0 = (B.south && !G.nsp) ? B.JstrR : B.Jstr - 3, j1 = (B.north && !G.nsp) ? B.JendR : B.Jend + G.Nghost;
+    a.p0 = i0; a.p1 = j0;
+    LAUNCH_THREAD(k_set_zeta_x, i1 - i0 + 1, j1 - j0 + 1, 1, c->stream, a);
+    return 0;
+  }
   LAUNCH_THREAD(k_set_zeta, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, 1, c->stream, a);
   if (!c->G.fuse3d) launch_halo(c, c->F.zeta, 2, BC_NONE, 'r');   // (fused: emit_store in the kernel)
   return 0;

@@ -166,6 +166,7 @@ int run_step2d_pair(roms_hip_ctx *c) {
   a.lev_out = c->b2_stage == 4 ? 5 : 4;
   a.wrapx = G.ewp && G.xloc;
   a.wrapy = G.nsp && G.yloc;
+  a.tail = G.nfast - iif;
   if (c->m2d_dirty) pack_metrics(c);
   const bool fixed = G.bw2 <= 32 && G.bh2 <= 4 && !G.masking && !getenv("ROMS_HIP_S2D_GENERIC");
 #ifdef ROMS_CPU_EMU

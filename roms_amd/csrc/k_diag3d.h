@@ -460,6 +460,20 @@ THREAD_KERNEL(k_set_zeta, KArgs) {
 }
 THREAD_GLOBAL(k_set_zeta, KArgs)
 
+// The same on a rectangle with origin (p0, p1), plain stores: a multi-tile context copies the ghost lines of Zt_avg1 with
+// the tile (they are valid: the final fast-time averages were exchanged, step2d_LF_AM3.h:821-883) instead of
+// exchanging zeta(1:2) again behind the copy
+THREAD_KERNEL(k_set_zeta_x, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const int i = a.p0 + gx, j = a.p1 + gy;
+  const double z = F.Zt_avg1[X2(i, j)];
+  F.zeta[X2(i, j)] = z;
+  F.zeta[X2(i, j) + G.nij] = z;
+}
+THREAD_GLOBAL(k_set_zeta_x, KArgs)
+
 // Zt_avg1 = zeta(kstp) on (IstrT:IendT, JstrT:JendT); p0 = kstp
 THREAD_KERNEL(k_copy_zt, KArgs) {
   (void)gz;

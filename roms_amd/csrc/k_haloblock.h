@@ -67,6 +67,51 @@ KDEV void hb_emit(const DGrid &G, const TB &B, double *A, int bc, int i, int j, 
   }
 }
 
+// The same with the periodic images optional (k_step2d_pair.h: while the pairs follow each other nobody reads the
+// periodic ghost points -- the kernel reads its rim at the wrapped own points -- so only the last launches store them;
+// the boundary values derived at a closed edge are stored every time, the next launch reads them).  Straight-line: at
+// most one image along each periodic direction (Lm, Mm >= 6), offsets instead of index lists.
+KDEV void hb_put(const DGrid &G, double *A, int i, int j, double v, bool images) {
+  const int x = (int)X2(i, j);
+  A[x] = v;
+  if (!images) return;
+  int dxo = 0, dyo = 0;
+  if (G.ewp) { if (i >= 1 && i <= G.Nghost) dxo = G.Lm; else if (i >= G.Lm - 2 && i <= G.Lm) dxo = -G.Lm; }
+  if (G.nsp) { if (j >= 1 && j <= G.Nghost) dyo = G.Mm * G.ni; else if (j >= G.Mm - 2 && j <= G.Mm) dyo = -G.Mm * G.ni; }
+  if (dxo) A[x + dxo] = v;
+  if (dyo) A[x + dyo] = v;
+  if (dxo && dyo) A[x + dxo + dyo] = v;
+}
+KDEV void hb_emit2(const DGrid &G, const TB &B, double *A, int bc, int i, int j, double v, const double *M, bool images) {
+  if (i > 3 && i < G.Lm - 2 && j > 3 && j < G.Mm - 2) { A[X2(i, j)] = v; return; }
+  hb_put(G, A, i, j, v, images);
+  if (bc == BC_NONE) return;
+  if (!G.nsp) {          // closed southern / northern edge
+    if (bc == BC_R) {
+      if (B.south && j == B.Jstr) hb_put(G, A, i, j - 1, M ? v * M[X2(i, j - 1)] : v, images);
+      if (B.north && j == B.Jend) hb_put(G, A, i, j + 1, M ? v * M[X2(i, j + 1)] : v, images);
+    } else if (bc == BC_U) {
+      if (B.south && j == B.Jstr) hb_put(G, A, i, j - 1, M ? G.gamma2 * v * M[X2(i, j - 1)] : G.gamma2 * v, images);
+      if (B.north && j == B.Jend) hb_put(G, A, i, j + 1, M ? G.gamma2 * v * M[X2(i, j + 1)] : G.gamma2 * v, images);
+    } else if (bc == BC_V) {
+      if (B.south && j == B.JstrV) hb_put(G, A, i, B.Jstr, 0.0, images);
+      if (B.north && j == B.Jend) hb_put(G, A, i, j + 1, 0.0, images);
+    }
+  }
+  if (!G.ewp) {          // closed western / eastern edge
+    if (bc == BC_R) {
+      if (B.west && i == B.Istr) hb_put(G, A, i - 1, j, M ? v * M[X2(i - 1, j)] : v, images);
+      if (B.east && i == B.Iend) hb_put(G, A, i + 1, j, M ? v * M[X2(i + 1, j)] : v, images);
+    } else if (bc == BC_U) {
+      if (B.west && i == B.IstrU) hb_put(G, A, B.Istr, j, 0.0, images);
+      if (B.east && i == B.Iend) hb_put(G, A, i + 1, j, 0.0, images);
+    } else if (bc == BC_V) {
+      if (B.west && i == B.Istr) hb_put(G, A, i - 1, j, M ? G.gamma2 * v * M[X2(i - 1, j)] : G.gamma2 * v, images);
+      if (B.east && i == B.Iend) hb_put(G, A, i + 1, j, M ? G.gamma2 * v * M[X2(i + 1, j)] : G.gamma2 * v, images);
+    }
+  }
+}
+
 // Final stores of a point-wise kernel whose index space is the whole tile.  When the halo launch that
 // would follow is fused (G.fuse3d: single tile, at least one periodic direction) the storing thread
 // also writes the boundary value derived from its point and the periodic images of both.  Which

@@ -36,6 +36,9 @@ struct Step2dPairArgs {
   int lev_out;         // staging level the corrector's result goes to
   int commit;          // lev_in is a staging level: copy it to the logical level G.krhs
   int wrapx, wrapy;    // rim indices beyond the tile wrap onto the tile's own points
+  int tail;            // pairs still to follow this one: 0 = the last (iif = nfast).  What nobody reads before the loop ends is
+                       // stored by the last launches only: level 3 (the predictor's result) by the last one; periodic images of
+                       // the committed level and of the staged result by the last one, of rzeta(krhs) by the last two
 };
 
 #define S2P_NLDS 19
@@ -301,6 +304,7 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
   const int o_ptc = (kstp - 1) * nij;                                      // corrector: ptsk = 3 - kstp_C = the predictor's kstp
   const M2Rec *mr = (const M2Rec *)(double *)F.m2r, *mp = (const M2Rec *)(double *)F.m2p;
   const bool fuse = G.fuse_halo != 0;
+  const bool img0 = a.tail == 0, img1 = a.tail <= 1, store3 = a.tail == 0 || !fuse;
   const int IT0 = B.Istr - S2P_RIM, JT0 = B.Jstr - S2P_RIM;
   const bool ADV = (G.options & ROMS_UV_ADV) != 0, COR = (G.options & ROMS_UV_COR) != 0;
   const bool CURV = ADV && (G.options & ROMS_CURVGRID) != 0, VIS = (G.options & ROMS_UV_VIS2) != 0;
@@ -308,6 +312,7 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
   (void)iif;
 
   PWDECL(r_zk); PWDECL(r_zs); PWDECL(r_on_u); PWDECL(r_om_v); PWDECL(r_rhoS);
+  PWDECL(r_on_u1); PWDECL(r_om_v1);      // on_u(i+1,j), om_v(i,j+1): the free-surface stage forms the fluxes of its far faces itself
   PWDECL(r_Zt); PWDECL(r_DU1); PWDECL(r_DU2); PWDECL(r_DV1); PWDECL(r_DV2); PWDECL(r_rz_p);
   S2Met wm[WSLOTS];
   WDECL(w_s); WDECL(w_frc); WDECL(w_rp); WDECL(w_rP); WDECL(w_pk0); WDECL(w_pk1);
@@ -326,6 +331,7 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
       sRhoA[s0] = F.rhoA[x0];
       PWSET(r_zk, zkv); PWSET(r_zs, zsv);
       PWSET(r_on_u, F.on_u[x0]); PWSET(r_om_v, F.om_v[x0]); PWSET(r_rhoS, F.rhoS[x0]);
+      if (INR(i, j, E.IstrU - 1, E.Iend, E.JstrV - 1, E.Jend)) { PWSET(r_on_u1, F.on_u[GIDX(i + 1, j)]); PWSET(r_om_v1, F.om_v[GIDX(i, j + 1)]); }
       const bool own = INR(i, j, B.Istr, B.Iend, B.Jstr, B.Jend);
       const bool ownR = INR(i, j, KMIN(B.IstrR, B.Istr), B.IendR, KMIN(B.JstrR, B.Jstr), B.JendR);
       if (ownR) {
@@ -337,9 +343,9 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
         // the previous pair's result, staged: now the logical level krhs (nobody reads that level in this launch)
         if (fuse) {
           if (own) {
-            hb_emit(G, B, zlog, BC_R, i, j, zkv, MSK ? G.rmask : nullptr);
-            if (i >= B.IstrU) hb_emit(G, B, ulog, BC_U, i, j, ukv, MSK ? G.umask : nullptr);
-            if (j >= B.JstrV) hb_emit(G, B, vlog, BC_V, i, j, vkv, MSK ? G.vmask : nullptr);
+            hb_emit2(G, B, zlog, BC_R, i, j, zkv, MSK ? G.rmask : nullptr, img0);
+            if (i >= B.IstrU) hb_emit2(G, B, ulog, BC_U, i, j, ukv, MSK ? G.umask : nullptr, img0);
+            if (j >= B.JstrV) hb_emit2(G, B, vlog, BC_V, i, j, vkv, MSK ? G.vmask : nullptr, img0);
           }
         } else if ((own || !INR(i, j, T.Istr, T.Iend, T.Jstr, T.Jend)) && INR(i, j, G.LBi, UBi, G.LBj, UBj) &&
                    (!wrapx || (i >= -2 && i <= G.Lm + G.Nghost)) && (!wrapy || (j >= -2 && j <= G.Mm + G.Nghost))) {
@@ -376,9 +382,14 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
   S2P_TICK(2);
 
   // ================================ PREDICTOR on the enlarged sub-tile ==========================
-  // ---- stage 2: mass fluxes :600-700 and fast-time averaging :739-880 (own points) ------------
+  // ---- stages 2+3: mass fluxes :600-700, fast-time averaging :739-880 (own points), free-surface step :886-1000
+  //      (leap-frog, 2*dtfast).  A point forms the fluxes of its own west/south faces (kept in LDS for the momentum
+  //      stage) AND those of its east/north faces -- the neighbour's expression, same bits -- so no barrier separates
+  //      the fluxes from the free surface.
   {
     const double cA1 = a.w1_m1, cA2 = (8.0 / 12.0) * a.w2_0 - (1.0 / 12.0) * a.w2_p1;
+    const double fac = 1000.0 / G.rho0;
+    const double cff1z = 2.0 * dtfast, cff4 = 4.0 / 25.0, cff5 = 1.0 - 2.0 * cff4;
     RLOOP(i, j) {
       double du = 0.0, dv = 0.0;
       if (INR(i, j, E.IstrUm2 - 1, E.Iendp2, E.JstrVm2 - 1, E.Jendp2)) {
@@ -411,19 +422,21 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
           PWSET(r_DV2, v2);
         }
       }
-    }
-  }
-  KSYNC();
-  S2P_TICK(3);
-  // ---- stage 3: free-surface step :886-1000 (leap-frog, 2*dtfast) -----------------------------
-  {
-    const double fac = 1000.0 / G.rho0;
-    const double cff1 = 2.0 * dtfast, cff4 = 4.0 / 25.0, cff5 = 1.0 - 2.0 * cff4;
-    RLOOP(i, j) {
       if (INR(i, j, E.IstrU - 1, E.Iend, E.JstrV - 1, E.Jend)) {
-        const double rhs_zeta = (DUon[s0] - DUon[(s0 + 1)]) + (DVom[s0] - DVom[(s0 + TW)]);
+        double du1, dv1;     // DUon(i+1,j), DVom(i,j+1)
+        {
+          const double cff = 0.5 * PW(r_on_u1, F.on_u[GIDX(i + 1, j)]);
+          const double cff1 = cff * (D0[(s0 + 1)] + D0[s0]);
+          du1 = U0[(s0 + 1)] * cff1;
+        }
+        {
+          const double cff = 0.5 * PW(r_om_v1, F.om_v[GIDX(i, j + 1)]);
+          const double cff1 = cff * (D0[(s0 + TW)] + D0[s0]);
+          dv1 = V0[(s0 + TW)] * cff1;
+        }
+        const double rhs_zeta = (du - du1) + (dv - dv1);
         const double zsv = PW(r_zs, F.zeta[x0 + o_kstp]), zkv = PW(r_zk, F.zeta[x0 + o_in]);
-        double zeta_new = zsv + sPm[s0] * sPn[s0] * cff1 * rhs_zeta;
+        double zeta_new = zsv + sPm[s0] * sPn[s0] * cff1z * rhs_zeta;
         if (MSK) zeta_new = zeta_new * G.rmask[x0];
         const double zw = cff5 * zkv + cff4 * (zsv + zeta_new);
         const double rhoSv = PW(r_rhoS, F.rhoS[x0]);
@@ -437,8 +450,8 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (INR(i, j, B.Istr, B.Iend, B.Jstr, B.Jend)) {
           if (fuse) {
-            hb_emit(G, B, zn3, BC_R, i, j, zeta_new, MSK ? G.rmask : nullptr);
-            hb_emit(G, B, rz_k, BC_NONE, i, j, rhs_zeta);
+            if (store3) hb_emit2(G, B, zn3, BC_R, i, j, zeta_new, MSK ? G.rmask : nullptr, true);
+            hb_emit2(G, B, rz_k, BC_NONE, i, j, rhs_zeta, nullptr, img1);
           } else {
             zn3[x0] = zeta_new;
             rz_k[x0] = rhs_zeta;
@@ -450,6 +463,7 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
     }
   }
   KSYNC();
+  S2P_TICK(3);
   S2P_TICK(4);
   // ---- stage 4: momentum on the enlarged sub-tile :1080-2670 ----------------------------------
   {
@@ -491,11 +505,11 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
         const bool own = INR(i, j, B.Istr, B.Iend, B.Jstr, B.Jend) && (isv ? (j >= B.JstrV) : (i >= B.IstrU));
         if (own) {
           if (!isv) {
-            if (fuse) hb_emit(G, B, un3, BC_U, i, j, b, MSK ? G.umask : nullptr);
+            if (fuse) { if (store3) hb_emit2(G, B, un3, BC_U, i, j, b, MSK ? G.umask : nullptr, true); }
             else un3[x] = b;
             rub_k[x] = r;
           } else {
-            if (fuse) hb_emit(G, B, vn3, BC_V, i, j, b, MSK ? G.vmask : nullptr);
+            if (fuse) { if (store3) hb_emit2(G, B, vn3, BC_V, i, j, b, MSK ? G.vmask : nullptr, true); }
             else vn3[x] = b;
             rvb_k[x] = r;
           }
@@ -568,22 +582,24 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
   S2P_TICK(6);
   // ================================ CORRECTOR on the own sub-tile ===============================
   // krhs = 3: D1 = zeta(3)+h, U1, V1 (LDS); kstp = the predictor's krhs: D0, U0, V0; ptsk = the predictor's kstp
-  // ---- stage 2: mass fluxes and the fast-time average of the corrector's fluxes ----------------
+  // ---- stages 2+3: mass fluxes, the fast-time average of the corrector's fluxes, free-surface step (AM3) --------
   {
     const double cA2 = (5.0 / 12.0) * a.w2_0;
+    const double fac = 1000.0 / G.rho0;
+    const double cff1 = dtfast * 5.0 / 12.0, cff2 = dtfast * 8.0 / 12.0, cff3 = dtfast * 1.0 / 12.0, cff4 = 2.0 / 5.0, cff5 = 1.0 - cff4;
     RLOOP(i, j) {
       double du = 0.0, dv = 0.0;
       if (INR(i, j, B.IstrUm2 - 1, B.Iendp2, B.JstrVm2 - 1, B.Jendp2)) {
         if (i >= B.IstrUm2) {
           const double cff = 0.5 * PW(r_on_u, F.on_u[x0]);
-          const double cff1 = cff * (D1[s0] + D1[(s0 - 1)]);
-          du = U1[s0] * cff1;
+          const double cff1f = cff * (D1[s0] + D1[(s0 - 1)]);
+          du = U1[s0] * cff1f;
           DUon[s0] = du;
         }
         if (j >= B.JstrVm2) {
           const double cff = 0.5 * PW(r_om_v, F.om_v[x0]);
-          const double cff1 = cff * (D1[s0] + D1[(s0 - TW)]);
-          dv = V1[s0] * cff1;
+          const double cff1f = cff * (D1[s0] + D1[(s0 - TW)]);
+          dv = V1[s0] * cff1f;
           DVom[s0] = dv;
         }
       }
@@ -592,17 +608,19 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
         if (pu) F.DU_avg2[x0] = PW(r_DU2, F.DU_avg2[x0]) + cA2 * du;
         if (pv) F.DV_avg2[x0] = PW(r_DV2, F.DV_avg2[x0]) + cA2 * dv;
       }
-    }
-  }
-  KSYNC();
-  S2P_TICK(7);
-  // ---- stage 3: free-surface step (AM3 corrector) ----------------------------------------------
-  {
-    const double fac = 1000.0 / G.rho0;
-    const double cff1 = dtfast * 5.0 / 12.0, cff2 = dtfast * 8.0 / 12.0, cff3 = dtfast * 1.0 / 12.0, cff4 = 2.0 / 5.0, cff5 = 1.0 - cff4;
-    RLOOP(i, j) {
       if (INR(i, j, B.IstrU - 1, B.Iend, B.JstrV - 1, B.Jend)) {
-        const double rhs_zeta = (DUon[s0] - DUon[(s0 + 1)]) + (DVom[s0] - DVom[(s0 + TW)]);
+        double du1, dv1;
+        {
+          const double cff = 0.5 * PW(r_on_u1, F.on_u[GIDX(i + 1, j)]);
+          const double cff1f = cff * (D1[(s0 + 1)] + D1[s0]);
+          du1 = U1[(s0 + 1)] * cff1f;
+        }
+        {
+          const double cff = 0.5 * PW(r_om_v1, F.om_v[GIDX(i, j + 1)]);
+          const double cff1f = cff * (D1[(s0 + TW)] + D1[s0]);
+          dv1 = V1[(s0 + TW)] * cff1f;
+        }
+        const double rhs_zeta = (du - du1) + (dv - dv1);
         const double zsv = PW(r_zk, F.zeta[x0 + o_in]), zkv = Z1[s0];
         const double cff = cff1 * rhs_zeta;
         double zeta_new = zsv + sPm[s0] * sPn[s0] * (cff + cff2 * RZ1[s0] - cff3 * PW(r_rz_p, F.rzeta[x0 + o_ptc]));
@@ -616,13 +634,14 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
         gzeta2[s0] = gz * zw;
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (i >= B.Istr && j >= B.Jstr) {
-          if (fuse) hb_emit(G, B, zout, BC_R, i, j, zeta_new, MSK ? G.rmask : nullptr);
+          if (fuse) hb_emit2(G, B, zout, BC_R, i, j, zeta_new, MSK ? G.rmask : nullptr, img0);
           else zout[x0] = zeta_new;
         }
       }
     }
   }
   KSYNC();
+  S2P_TICK(7);
   S2P_TICK(8);
   // ---- stage 4: momentum on the own sub-tile ----------------------------------------------------
   {
@@ -662,10 +681,10 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
         double b = (sv * (Dstp0 + Dstp1) + cff * (k1 * r + k2 * rs - k3 * rp)) * fac;
         if (MSK) b = b * (isv ? G.vmask : G.umask)[x];
         if (!isv) {
-          if (fuse) hb_emit(G, B, uout, BC_U, i, j, b, MSK ? G.umask : nullptr);
+          if (fuse) hb_emit2(G, B, uout, BC_U, i, j, b, MSK ? G.umask : nullptr, img0);
           else uout[x] = b;
         } else {
-          if (fuse) hb_emit(G, B, vout, BC_V, i, j, b, MSK ? G.vmask : nullptr);
+          if (fuse) hb_emit2(G, B, vout, BC_V, i, j, b, MSK ? G.vmask : nullptr, img0);
           else vout[x] = b;
         }
       }

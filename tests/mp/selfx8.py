@@ -13,11 +13,11 @@ names = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "Huon", "Hvom"]
 run = tiling.TiledRun(cs, self_exchange=True, transport=sys.argv[1] if len(sys.argv) > 1 else "rccl")
 run.step(3); run.sync()
 nx = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
-got = {n: run.ctx.download(n).copy() for n in names}
+got = {n: run.gather(n).copy() for n in names}     # (every point the reference defines, not the padding line)
 run.close()
 ref = tiling.TiledRun(cs)
 ref.step(3); ref.sync()
-bad = [n for n in names if not np.array_equal(got[n], ref.ctx.download(n))]
+bad = [n for n in names if not np.array_equal(got[n], ref.gather(n))]
 fin = all(np.isfinite(got[n]).all() for n in names)
 ref.close()
 print("SELFX8 exchanges", nx, "finite", fin, "mismatching", bad)

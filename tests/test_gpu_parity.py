@@ -490,13 +490,13 @@ def test_rccl_self_exchange_matches_local_periodic_copy():
         run.sync()
         nx = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
         assert nx > 100, nx                    # every exchange point went through RCCL
-        got = {n: run.ctx.download(n).copy() for n in %r}
+        got = {n: run.gather(n).copy() for n in %r}       # (gather: every point the reference defines, not the padding line)
         run.close()
         ref = tiling.TiledRun(cs)
         ref.step(3)
         ref.sync()
         for n, g in got.items():
-            assert np.array_equal(g, ref.ctx.download(n)), n
+            assert np.array_equal(g, ref.gather(n)), n
         ref.close()
         print("SELF-EXCHANGE-OK", nx)
     """) % (ROOT, ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "rho", "Akv", "Huon", "DU_avg1"])
@@ -700,13 +700,13 @@ def test_mailbox_self_exchange_matches_local_periodic_copy(env):
         run.sync()
         nx = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
         assert nx > 100, nx
-        got = {n: run.ctx.download(n).copy() for n in %r}
+        got = {n: run.gather(n).copy() for n in %r}       # (gather: every point the reference defines, not the padding line)
         run.close()
         ref = tiling.TiledRun(cs)
         ref.step(3)
         ref.sync()
         for n, g in got.items():
-            assert np.array_equal(g, ref.ctx.download(n)), n
+            assert np.array_equal(g, ref.gather(n)), n
         ref.close()
         print("MAILBOX-SELF-OK", nx)
     """) % (ROOT, ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "rho", "Akv", "Huon", "DU_avg1"])
