@@ -48,6 +48,7 @@ int run_step2d(roms_hip_ctx *c) {
   // kernel variant by sub-tile size: up to 32x4, up to 64x8, generic (ROMS_HIP_TILE2D overrides)
   int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 32 && G.bh2 <= 8) ? 3 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
   if (getenv("ROMS_HIP_S2D_GENERIC") || (G.masking && variant != 0)) variant = 2;   // (masks: k_step2d_am or the generic form)
+  if (a.commit && (variant != 0 || G.masking)) variant = 2;       // behind a pair launch: k_step2d_ac or the generic form commit the staged level
   // 64x8 sub-tiles: 1024 threads (one rectangle point and one momentum point per thread) measure 3 %
   // faster than 512 threads with two each; ROMS_HIP_S2D_1024=0 selects the latter
   const char *e1024 = getenv("ROMS_HIP_S2D_1024");
@@ -60,6 +61,7 @@ int run_step2d(roms_hip_ctx *c) {
   const size_t lds = (size_t)STEP2D_NLDS * (size_t)tw * (size_t)th;
   if (variant == 0) {
     if (G.masking) LAUNCH_COOP_AS(k_step2d, k_step2d_am, G.nbx2, G.nby2, 1, 384, lds, c->stream, a);
+    else if (a.commit) LAUNCH_COOP_AS(k_step2d, k_step2d_ac, G.nbx2, G.nby2, 1, 384, lds, c->stream, a);
     else LAUNCH_COOP_AS(k_step2d, k_step2d_a, G.nbx2, G.nby2, 1, 384, lds, c->stream, a);
   } else if (variant == 3) {
     LAUNCH_COOP_AS(k_step2d, k_step2d_c, G.nbx2, G.nby2, 1, 512, lds, c->stream, a);

@@ -414,6 +414,94 @@ static __global__ void __launch_bounds__(1024) xchg_peer_pack(const XchgPeerArgs
     if (tid == d && a.s.word[d]) __hip_atomic_store(a.s.word[d] + bz, a.s.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Pack and unpack of one exchange point in ONE launch (round 3): a block stores its plane's strips into the neighbours'
+// slots and releases their arrival words, then waits for its own words and copies the received strips into the ghost
+// zone.  Every rank's kernel packs before it waits, so the kernels of neighbouring ranks -- resident at the same time
+// on their GPUs, one block per plane -- cannot wait for each other in a cycle.  Saves one launch (about 5 us of the
+// 11 us of an exchange point on one MI355X).
+struct XchgPeerBothArgs {
+  XchgArgs x;                      // items; buf[d] = neighbour d's slot for my message (pack)
+  double *ubuf[8];                 // my slot for neighbour d's message (unpack)
+  PeerSync sp, su;                 // arrival words: the neighbours' (pack), mine (unpack)
+};
+static __global__ void __launch_bounds__(1024) xchg_peer_both(const XchgPeerBothArgs a) {
+  const int tid = (int)threadIdx.x, bz = (int)blockIdx.z, nt = (int)blockDim.x;
+  const DGrid &G = a.x.G;
+  int bc, gtype;
+  double *A = halo_plane(a.x, bz, bc, gtype);
+  if (a.x.fill && (G.T.west || G.T.east || G.T.south || G.T.north)) { halo_fill(G, A, bc, gtype); __syncthreads(); }
+  {
+    PeerList L;
+    peer_list<0>(a.x, L);
+    if (L.tot <= PEER_U * nt) {
+      double v[PEER_U];
+      double *mm[PEER_U];
+#pragma unroll
+      for (int u = 0; u < PEER_U; u++) {
+        const int q = tid + u * nt;
+        if (q < L.tot) { int d, x, i, j; peer_elem(G, L, bz, q, d, mm[u], x, i, j); v[u] = A[x]; }
+      }
+#pragma unroll
+      for (int u = 0; u < PEER_U; u++) {
+        const int q = tid + u * nt;
+        if (q < L.tot) __hip_atomic_store(mm[u], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 8; d++) peer_move<0>(G, L, A, a.x.buf[d], bz, d);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned long long *word = nullptr;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    if (tid == d && a.sp.word[d]) __hip_atomic_store(a.sp.word[d] + bz, a.sp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == d) word = a.su.word[d];
+  }
+  if (word) {
+    const long long t0 = (long long)wall_clock64();
+    while (__hip_atomic_load(word + bz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.su.seq) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((long long)wall_clock64() - t0 > a.su.timeout) {
+        __hip_atomic_store(a.su.err, a.su.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  XchgArgs xu;
+  xu.G = a.x.G; xu.nitems = a.x.nitems; xu.unpack = 1; xu.fill = 0;
+#pragma unroll
+  for (int k = 0; k < HALO_MAXITEMS; k++) xu.it[k] = a.x.it[k];
+#pragma unroll
+  for (int d = 0; d < 8; d++) xu.buf[d] = a.ubuf[d];
+  PeerList L;
+  peer_list<1>(xu, L);
+  if (L.tot <= PEER_U * nt) {
+    double v[PEER_U];
+    int xx[PEER_U];
+#pragma unroll
+    for (int u = 0; u < PEER_U; u++) {
+      const int q = tid + u * nt;
+      xx[u] = -1;
+      if (q < L.tot) {
+        double *m;
+        int d, x, i, j;
+        peer_elem(G, L, bz, q, d, m, x, i, j);
+        v[u] = __builtin_nontemporal_load(m);
+        if (!peer_covered_later(G, L, d, i, j)) xx[u] = x;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PEER_U; u++)
+      if (xx[u] >= 0) A[xx[u]] = v[u];
+    return;
+  }
+#pragma unroll
+  for (int d = 0; d < 8; d++) peer_move<1>(G, L, A, xu.buf[d], bz, d);
+}
+
 static __global__ void __launch_bounds__(1024) xchg_peer_unpack(const XchgPeerArgs a) {
   const int tid = (int)threadIdx.x, bz = (int)blockIdx.z, nt = (int)blockDim.x;
   const DGrid &G = a.x.G;

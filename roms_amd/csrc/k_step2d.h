@@ -106,9 +106,11 @@ THREAD_GLOBAL(k_pack_m2d, PackArgs)
     if (q_ < NTILE)                                                                                         \
       for (int s0 = q_, jj_ = q_ / TW, j = JT0 + jj_, i = IT0 + q_ - jj_ * TW,                              \
                x0 = (i - G.LBi) + (j - G.LBj) * ni, once_ = 1; once_; once_ = 0)
-#define PWDECL(name) double name[PTS > 0 ? PTS : 1]
-#define PWLOAD(name, expr) do { if (FIXED) name[m] = (expr); } while (0)
-#define PW(name, expr) (FIXED ? name[m] : (expr))
+// (PWR: rectangle points per thread whose own-point values stay in registers; the others re-read them where a stage needs
+// them -- the 32x8 form has 532 rectangle points on 512 threads: a second register set for 20 threads made it spill)
+#define PWDECL(name) double name[PWR > 0 ? PWR : 1]
+#define PWLOAD(name, expr) do { if (FIXED && m < PWR) name[m] = (expr); } while (0)
+#define PW(name, expr) ((FIXED && m < PWR) ? name[m < PWR ? m : 0] : (expr))
 // Momentum points: c = interior cell (row-major over BW x BH), isv = 0 its u-point, 1 its v-point.
 // The u-points use threads 0..NOWN-1, the v-points threads VOFF..VOFF+NOWN-1 (VOFF = NOWN when the
 // block has the threads, else 0: then every thread does a u- and a v-point in turn).
@@ -124,7 +126,7 @@ THREAD_GLOBAL(k_pack_m2d, PackArgs)
 #else
 #define S2D_TICK(n) ((void)0)
 #endif
-template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0)>
+template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0), bool CM = (BWC == 0), int PWR = PTS>
 COOP_KERNEL(k_step2d_t, Step2dArgs) {
   (void)bz;
 #ifndef ROMS_CPU_EMU
@@ -195,7 +197,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
       Drhs[s0] = zkv + hv;                                    // total depth :600
       const double ukv = F.ubar[x0 + o_krhs], vkv = F.vbar[x0 + o_krhs];
       sUk[s0] = ukv; sVk[s0] = vkv; sH[s0] = hv;
-      if (a.commit) {
+      if (CM && a.commit) {      // (CM: only the instantiations a pair launch can precede carry this code)
         // the last pair's result, staged by k_step2d_pair: now the logical level krhs (own points; the tile's boundary and
         // ghost points by its edge blocks)
         double *zl = F.zeta + (size_t)(krhs - 1) * G.nij, *ul = F.ubar + (size_t)(krhs - 1) * G.nij, *vl = F.vbar + (size_t)(krhs - 1) * G.nij;
@@ -599,13 +601,15 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
 // 32x8, and the generic form
 COOP_KERNEL(k_step2d_a, Step2dArgs) { k_step2d_t_body<32, 4, 384, 1>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d_a, Step2dArgs, 384)
+COOP_KERNEL(k_step2d_ac, Step2dArgs) { k_step2d_t_body<32, 4, 384, 1, false, true>(a, bx, by, bz, lds); }   // ... behind a pair launch: commits the staged level
+COOP_GLOBAL_LB(k_step2d_ac, Step2dArgs, 384)
 COOP_KERNEL(k_step2d_am, Step2dArgs) { k_step2d_t_body<32, 4, 384, 1, true>(a, bx, by, bz, lds); }   // the same with land/sea masks
 COOP_GLOBAL_LB(k_step2d_am, Step2dArgs, 384)
 COOP_KERNEL(k_step2d_b, Step2dArgs) { k_step2d_t_body<64, 8, 512, 2>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d_b, Step2dArgs, 512)
 COOP_KERNEL(k_step2d_d, Step2dArgs) { k_step2d_t_body<64, 8, 1024, 1>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d_d, Step2dArgs, 1024)
-COOP_KERNEL(k_step2d_c, Step2dArgs) { k_step2d_t_body<32, 8, 512, 2>(a, bx, by, bz, lds); }
+COOP_KERNEL(k_step2d_c, Step2dArgs) { k_step2d_t_body<32, 8, 512, 2, false, false, 1>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB2(k_step2d_c, Step2dArgs, 512, 4)   // two blocks of 8 waves per CU: at most 128 VGPRs
 COOP_KERNEL(k_step2d, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)

@@ -1093,6 +1093,23 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
     const int par = (int)(seq & 1);
     static long long timeout = 0;
     if (!timeout) { const char *et = getenv("ROMS_HIP_PEER_TIMEOUT"); timeout = (long long)((et ? atof(et) : 20.0) * 1.0e8); }
+    static const char *eboth = getenv("ROMS_HIP_PEER_BOTH");
+    if (!(eboth && eboth[0] == '0')) {
+      // pack and unpack in one launch (k_halo.h:xchg_peer_both)
+      XchgPeerBothArgs ba;
+      ba.x = a;
+      ba.x.unpack = 0; ba.x.fill = 1;
+      ba.sp.seq = seq; ba.sp.err = m.peer_err; ba.sp.timeout = timeout;
+      ba.su = ba.sp;
+      for (int d = 0; d < 8; d++) {
+        const bool on = m.nbr[d] >= 0;
+        ba.x.buf[d] = on ? (double *)((char *)m.peer_map[d] + m.peer_noff[d][ch][par]) : nullptr;
+        ba.sp.word[d] = on ? (unsigned long long *)((char *)m.peer_map[d] + PEER_WORDS) + (size_t)(ch * 8 + g_opp[d]) * m.peer_planes : nullptr;
+        ba.ubuf[d] = on ? (double *)((char *)m.peer_slab + m.peer_off[ch][par][d]) : nullptr;
+        ba.su.word[d] = on ? (unsigned long long *)((char *)m.peer_slab + PEER_WORDS) + (size_t)(ch * 8 + d) * m.peer_planes : nullptr;
+      }
+      KPROF_WRAP(xchg_peer_both, xs, hipLaunchKernelGGL(xchg_peer_both, dim3(1, 1, (unsigned)planes), dim3(c->peer_threads), 0, xs, ba));
+    } else {
     XchgPeerArgs pa;
     pa.x = a;
     pa.s.seq = seq; pa.s.err = m.peer_err; pa.s.timeout = timeout;
@@ -1110,6 +1127,7 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
       pa.s.word[d] = on ? (unsigned long long *)((char *)m.peer_slab + PEER_WORDS) + (size_t)(ch * 8 + d) * m.peer_planes : nullptr;
     }
     KPROF_WRAP(xchg_peer_unpack, xs, hipLaunchKernelGGL(xchg_peer_unpack, dim3(1, 1, (unsigned)planes), dim3(c->peer_threads), 0, xs, pa));
+    }
   } else {
 #endif
   a.unpack = 0; a.fill = 1;
