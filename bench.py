@@ -54,6 +54,9 @@ WORKLOADS = {
 ALGO_ARRAYS = {
     #                  3-D  2-D
     "k_step2d":       (0, 44),
+    "k_step2d_pair":  (0, 88),     # predictor + corrector of one fast step in one launch (k_step2d_pair.h): two step2d
+                                   # calls' worth of SURVEY 8(d)'s unit -- the 44 2-D words each call moves in the reference
+                                   # -- although the fused kernel itself reads the state once
     "k_pre_t3":       (10, 2),     # t(nstp), t(nnew) read and t(3) written per tracer; Hz, Huon, Hvom, W read ONCE for both
                                    # tracers (LDS-tiled form from 64 K columns; the point-wise form re-reads them: 15)
     "k_pre_t3h":      (7, 2),
@@ -109,6 +112,16 @@ def pair_report(table, steps, cells):
             "frac": gbs / HBM_PEAK_GBS,
             "note": "632 B/cell is priced for U3/C4 advection and NT=2; HSIMT/MPDATA tracers and the halo launches of "
                     "those rows (not counted here) add work"}
+
+
+def whole_step_bytes_per_cell(cs, nfast):
+    """SURVEY.md 8(d)'s unfused-kernel model of one baroclinic step, bytes per cell: 166 3-D words with BENCHMARK
+    physics (KPP, bulk fluxes, nonlinear EOS, geopotential mixing) or 127 with UPWELLING's, plus the barotropic
+    engine's 48 2-D passes per step2d call x (2 nfast + 1) calls spread over N levels."""
+    words3d = 166.0 if cs["app"].startswith("benchmark") else 127.0
+    if cs["app"] == "upwelling_kpp":         # BASELINE config 5: + lmd_vmix/skpp/finish (34), MPDATA (about 32 per tracer)
+        words3d += 34.0 + 64.0
+    return 8.0 * (words3d + 48.0 * (2 * nfast + 1) / cs["N"])
 
 
 def algo_bytes(kernel, Lm, Mm, N, launches_per_step_hint=None):
@@ -501,6 +514,10 @@ def main():
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_us": avg * 1e6, "launches": launches,
                         "algorithmic_bytes_per_launch": nb}
+            # the whole step against the same peak: SURVEY 8(d)'s bytes per cell-update x cells / step time
+            wsb = whole_step_bytes_per_cell(cs, run.nfast)
+            roofline["whole_step_bytes_per_cell"] = wsb
+            roofline["whole_step_frac"] = wsb * cells_per_rank * args.steps / elapsed / 1e9 / HBM_PEAK_GBS
             if dominant in table and table[dominant][1] > 0:
                 # the same kernel with nothing else on the chip (synchronous per-kernel pass before the timed
                 # region; each launch bracketed by two event markers, which add ~1 us to a 10 us kernel)

@@ -32,8 +32,10 @@
         print '(a,i0,2a)', ' romsM: set-up stopped, exit_flag = ', ierr, ': ', TRIM(host_message)
         STOP 5
       END IF
+      CALL echo_cppdefs (6)                       ! checkdefs.F:56-59
+      print '(a)', ' '
       print '(1x,a,a,3(1x,i0),a,i0,a,f8.2,a,i0,a)', TRIM(MyAppCPP), ':', Lm, Mm, N, '  nfast = ', nfast,           &
-     &      '  dt = ', dt, '  (', n_unused_keys, ' roms.in keywords not used by the time step)'
+     &      '  dt = ', dt, '  (', n_inert_keys, ' roms.in keywords inert for the time step)'
       IF (NtileI*NtileJ.ne.1) THEN
         print '(a)', ' romsM: one process drives one GPU tile; multi-GPU runs are launched through roms_amd.tiling'
         STOP 5

@@ -47,7 +47,12 @@
       logical :: Aout(0:nAout-1) = .FALSE., AoutT(0:nAout-1,ROMS_MAXT) = .FALSE.
       character(len=512) :: app_header = ' '      ! application header to read the cpp options from (optional)
       character(len=256) :: host_message = ' '    ! why the last set-up step returned a non-zero exit_flag
-      integer :: n_unused_keys = 0                ! roms.in keywords this build has no use for (output, nesting ...)
+      character(len=256) :: title = ' '            ! TITLE of roms.in (echoed beside the application name, checkdefs.F:61)
+      integer :: n_unused_keys = 0                ! roms.in keywords this build has no use for = n_inert_keys + n_unknown_keys
+      integer :: n_inert_keys = 0                 ! ... that the reference's reader knows and that cannot change this build's time
+                                                  !     step (docs/ROMS_IN_KEYWORDS.md; roms_in_inert.inc)
+      integer :: n_unknown_keys = 0               ! ... that the reference's reader (read_phypar.F) does not know either
+      character(len=64) :: first_unknown_key = ' ' 
       integer :: lbc_seen = 0
       character(len=32) :: defs(256)              ! cpp options defined by the application header
       integer :: ndefs = 0
@@ -97,6 +102,9 @@
       CALL set_defaults ()
       host_message=' '
       n_unused_keys=0
+      n_inert_keys=0
+      n_unknown_keys=0
+      first_unknown_key=' '
       lbc_seen=0
       open (newunit=iu, file=TRIM(fname), status='old', action='read', iostat=ios)
       IF (ios.ne.0) THEN
@@ -131,6 +139,7 @@
         IF (nv.eq.0) CYCLE
         SELECT CASE (TRIM(key))
           CASE ('MyAppCPP');    MyAppCPP=tok(1)
+          CASE ('TITLE');       title=ADJUSTL(val)
           CASE ('Lm');          Lm=toint(tok(1))
           CASE ('Mm');          Mm=toint(tok(1))
           CASE ('N');           N=toint(tok(1))
@@ -236,12 +245,25 @@
           CASE ('TCOEF');       Tcoef=toreal(tok(1))
           CASE ('SCOEF');       Scoef=toreal(tok(1))
           CASE ('GAMMA2');      gamma2=toreal(tok(1))
+!  Every other keyword of the reference's reader (read_phypar.F has 612): classified keyword by keyword as unable to
+!  change the forward time step of this build -- output selection, file names, the parameters of other drivers and of
+!  cpp options the library does not carry (a header that defines one is stopped by options_from_defines).  The list
+!  is generated (tools/roms_in_keywords.py -> docs/ROMS_IN_KEYWORDS.md, roms_in_inert.inc).
+          INCLUDE 'roms_in_inert.inc'
           CASE DEFAULT
-!  as in read_phypar.F, a keyword no CASE claims is skipped; here that covers everything the time
-!  step never reads (titles, file names, output switches and frequencies, adjoint/4D-Var entries)
-            n_unused_keys=n_unused_keys+1
+!  not a keyword of the reference's reader either (it skips such lines silently, read_phypar.F has no CASE DEFAULT).
+!  Its own input files carry a few (Aout(idBath), Qout(idUVwc), Dout(M2fsgr) ..., ad_AKT_BAK): members of the output
+!  selection and adjoint families, inert by family; anything else is counted as unknown.
+            IF (key(1:5).eq.'Hout('.or.key(1:5).eq.'Qout('.or.key(1:5).eq.'Aout('.or.key(1:5).eq.'Dout('.or.        &
+     &          key(1:3).eq.'ad_') THEN
+              n_inert_keys=n_inert_keys+1
+            ELSE
+              n_unknown_keys=n_unknown_keys+1
+              IF (LEN_TRIM(first_unknown_key).eq.0) first_unknown_key=key
+            END IF
         END SELECT
       END DO
+      n_unused_keys=n_inert_keys+n_unknown_keys
       close (iu)
       END SUBROUTINE read_roms_in
 !
@@ -772,6 +794,35 @@
       IF (is_defined('MASKING').and.ANY(hadv(1:NAT).eq.ROMS_MPDATA))                                           &
      &  CALL unsupported ('MASKING is built without MPDATA (mpdata_adiff.F masks)', ierr)
       END SUBROUTINE options_from_defines
+
+!
+!  " Activated C-preprocessing Options:" of the reference's run report (checkdefs.F:56-59, FORMAT 20 = (1x,a,t27,a)): the
+!  application and its title, then every active option checkdefs.F has a line for, in its order -- the options of the
+!  application header (or the built-in list) plus what globaldefs.h derives for any forward run of this kind
+!  (ASSUMED_SHAPE, DOUBLE_PRECISION, NONLINEAR, POWER_LAW, PROFILE; RHO_SURF and VAR_RHO_2D with SOLVE3D; the analytic
+!  momentum / heat fluxes drop out under BULK_FLUXES, globaldefs.h:993-1001).
+!
+      SUBROUTINE echo_cppdefs (iu)
+      integer, intent(in) :: iu
+      INCLUDE 'checkdefs_text.inc'
+      integer :: k
+      logical :: on
+      write (iu,'(/,a,/)') ' Activated C-preprocessing Options:'
+      write (iu,'(1x,a,t27,a)') TRIM(ADJUSTL(MyAppCPP)), TRIM(ADJUSTL(title))
+      DO k=1,n_cpp_text
+        SELECT CASE (TRIM(cpp_text_name(k)))
+          CASE ('ASSUMED_SHAPE', 'DOUBLE_PRECISION', 'NONLINEAR', 'POWER_LAW', 'PROFILE')
+            on=.TRUE.
+          CASE ('RHO_SURF', 'VAR_RHO_2D')
+            on=is_defined('SOLVE3D')
+          CASE ('ANA_SMFLUX', 'ANA_STFLUX')
+            on=is_defined(TRIM(cpp_text_name(k))).and..not.is_defined('BULK_FLUXES')
+          CASE DEFAULT
+            on=is_defined(TRIM(cpp_text_name(k)))
+        END SELECT
+        IF (on) write (iu,'(1x,a,t27,a)') TRIM(cpp_text_name(k)), TRIM(cpp_text(k))
+      END DO
+      END SUBROUTINE echo_cppdefs
 
       SUBROUTINE set_cppdefs (ierr)
       integer, intent(out) :: ierr

@@ -49,6 +49,35 @@
       n=n_unused_keys
       END FUNCTION roms_host_unused_keys
 !
+!  ... of those, the ones the reference's reader does not know either (the others are classified inert,
+!  docs/ROMS_IN_KEYWORDS.md); buf receives the first such keyword.
+!
+      FUNCTION roms_host_unknown_keys (buf, n) bind(C, name='roms_host_unknown_keys') RESULT (nk)
+      integer(c_int), value :: n
+      character(kind=c_char), intent(out) :: buf(n)
+      integer(c_int) :: nk
+      integer :: k, L
+      L=MIN(LEN_TRIM(first_unknown_key), n-1)
+      DO k=1,L
+        buf(k)=first_unknown_key(k:k)
+      END DO
+      buf(L+1)=c_null_char
+      nk=n_unknown_keys
+      END FUNCTION roms_host_unknown_keys
+!
+!  The " Activated C-preprocessing Options:" block of the run report (checkdefs.F:56-59) of the last set-up, into a file.
+!
+      FUNCTION roms_host_echo_cppdefs (path) bind(C, name='roms_host_echo_cppdefs') RESULT (ierr)
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int) :: ierr
+      integer :: iu, ios
+      open (newunit=iu, file=c2f(path), status='replace', action='write', iostat=ios)
+      ierr=MERGE(0, 2, ios.eq.0)
+      IF (ios.ne.0) RETURN
+      CALL echo_cppdefs (iu)
+      close (iu)
+      END FUNCTION roms_host_echo_cppdefs
+!
 !  Read roms.in and build the host state only (no device needed).
 !
       FUNCTION roms_host_setup (infile) bind(C, name='roms_host_setup') RESULT (ierr)

@@ -333,3 +333,101 @@ def test_reference_input_files_and_headers_read_in_place(name, app, dims):
         # BENCHMARK inputs, but benchmark.h has no AVERAGES
     finally:
         H.finalize()
+
+
+def _unknown_keys(H):
+    import ctypes as C
+    buf = C.create_string_buffer(80)
+    n = H.lib.roms_host_unknown_keys(buf, 80)
+    return n, buf.value.decode()
+
+
+@pytest.mark.ref
+def test_every_reference_input_file_is_read_without_skipping_a_physics_keyword():
+    """Every ROMS/External/roms_*.in of the reference (read where it lies): the set-up either completes or stops with
+    exit_flag 5 and a reason (an application / option / boundary condition this build does not have) -- and in both cases
+    every keyword of the file is one the reader honours, checks or has classified as unable to change the forward time
+    step (docs/ROMS_IN_KEYWORDS.md: all 612 keywords of read_phypar.F).  A keyword outside that table would be skipped
+    silently: none may occur."""
+    import glob
+    from roms_amd import hostlib
+    files = sorted(glob.glob("/root/reference/ROMS/External/roms_*.in"))
+    if not files:
+        pytest.skip("no reference tree here")
+    assert len(files) >= 30
+    done, stopped = [], []
+    for f in files:
+        try:
+            H = hostlib.Host(infile=f)
+        except hostlib.HostError as e:
+            assert e.exit_flag == 5 and len(str(e)) > 40, (f, str(e))
+            stopped.append(os.path.basename(f))
+            lib = hostlib.load(None)
+            H = None
+        else:
+            done.append(os.path.basename(f))
+        import ctypes as C
+        buf = C.create_string_buffer(80)
+        n = hostlib.load(None).roms_host_unknown_keys(buf, 80)
+        assert n == 0, (f, n, buf.value.decode())
+        if H is not None:
+            H.finalize()
+    assert {"roms_upwelling.in", "roms_benchmark1.in", "roms_benchmark2.in", "roms_benchmark3.in"} <= set(done)
+    assert len(stopped) > 20          # the other applications of the reference: analytic set-ups this host does not have
+
+
+@pytest.mark.ref
+def test_keyword_table_covers_the_reference_reader():
+    """docs/ROMS_IN_KEYWORDS.md lists every CASE of ROMS/Utility/read_phypar.F, and the generated include the reader
+    compiles holds exactly the keywords classified inert."""
+    import re
+    src = "/root/reference/ROMS/Utility/read_phypar.F"
+    if not os.path.exists(src):
+        pytest.skip("no reference tree here")
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    keys = set(re.findall(r"CASE \('([A-Za-z0-9_()%]*)'", open(src).read()))
+    rows = re.findall(r"^\| `([^`]+)` \| (\w+) \|", open(os.path.join(root, "docs", "ROMS_IN_KEYWORDS.md")).read(), re.M)
+    assert {k for k, _ in rows} == keys and len(rows) == len(keys) == 612
+    inc = set(re.findall(r"'([^']+)'", "".join(l for l in open(os.path.join(root, "roms_amd", "host", "roms_in_inert.inc"))
+                                                 if l.lstrip().startswith("CASE"))))
+    assert inc == {k for k, c in rows if c == "inert"}
+    reader = open(os.path.join(root, "roms_amd", "host", "roms_host.f90")).read()
+    for k, c in rows:
+        if c in ("honoured", "checked"):
+            assert f"'{k}'" in reader, k
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("app", ["upwelling", "benchmark"])
+def test_option_echo_is_the_reference_report(tmp_path, app):
+    """romsM's " Activated C-preprocessing Options:" block (roms_host.f90:echo_cppdefs) for the reference's own
+    application header: the options are those cpp leaves defined after cppdefs.h + globaldefs.h (cpp -dM, run here)
+    that checkdefs.F has a line for, in checkdefs.F's order, each with checkdefs.F's text."""
+    import re
+    import subprocess
+    from roms_amd import hostlib
+    inc = "/root/reference/ROMS/Include"
+    if not os.path.isdir(inc):
+        pytest.skip("no reference tree here")
+    src = open("/root/reference/ROMS/Utility/checkdefs.F").read()
+    pairs = re.findall(r"WRITE \(stdout,20\) '([A-Z0-9_]+)',\s*&\s*\n\s*&\s*'((?:[^']|'')*)'", src)
+    order = [p[0] for p in pairs]
+    A = app.upper()
+    out = subprocess.run(["/usr/bin/cpp", "-P", "-traditional", "-w", "-dM", f"-D{A}", f'-DROMS_HEADER="{app}.h"',
+                          f'-DHEADER="{app}.h"', "-DNONLINEAR", f"-I{inc}", f"{inc}/cppdefs.h"], capture_output=True, text=True,
+                         cwd=str(tmp_path)).stdout
+    macros = {l.split()[1] for l in out.splitlines() if l.startswith("#define")}
+    want = [(n, t) for n, t in pairs if n in macros]
+    assert len(want) > 25
+    name = "roms_upwelling.in" if app == "upwelling" else "roms_benchmark1.in"
+    H = hostlib.Host(infile="/root/reference/ROMS/External/" + name, header=f"{inc}/{app}.h")
+    try:
+        f = str(tmp_path / "echo.txt")
+        assert H.lib.roms_host_echo_cppdefs(f.encode()) == 0
+        lines = [l.rstrip("\n") for l in open(f)]
+    finally:
+        H.finalize()
+    assert lines[1] == " Activated C-preprocessing Options:" and lines[0] == "" and lines[2] == ""
+    assert lines[3].split()[0] == A
+    got = [(l[1:26].strip(), l[26:].strip()) for l in lines[4:] if l.strip()]
+    assert got == want, (got, want)

@@ -37,8 +37,10 @@ def canon(raw):
     if k.startswith("k_tadv_lds<1"):          # 1 = step3d_t's corrector advection
         return "k_s3t_hv"
     k = k.split("<")[0].strip()
-    if k in ("k_step2d_a", "k_step2d_b", "k_step2d_c", "k_step2d_d"):     # sub-tile variants of one kernel
+    if k in ("k_step2d_a", "k_step2d_ac", "k_step2d_am", "k_step2d_b", "k_step2d_c", "k_step2d_d"):     # sub-tile variants of one kernel
         k = "k_step2d"
+    if k in ("k_step2d_pair_a",):
+        k = "k_step2d_pair"
     return VARIANTS.get(k, k)
 
 
