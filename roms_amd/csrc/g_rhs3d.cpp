@@ -96,6 +96,17 @@ int run_pre_step3d(roms_hip_ctx *c) {
   if (!c->pre_t3_ready) { int r = run_pre_t3(c); if (r) return r; }     // (k_pre_new overwrites the t(nnew) it reads)
   KArgs a = mk(c);
   a.p1 = c->late_pre ? 1 : 0;
+  // large grids: the marching form (every level read once; the chunked form re-reads two levels per chunk of five)
+  static const char *epm = getenv("ROMS_HIP_PRENEW_MARCH");
+  const long cols = (long)(B.Iend - B.Istr + 1) * (B.Jend - B.Jstr + 1);
+  if (epm ? epm[0] != '0' : cols >= 128L * 1024L) {
+    static const char *epp = getenv("ROMS_HIP_PRENEW_PARTS");       // (test aid: parts of the column per thread)
+    const int parts = epp ? KMAX(1, atoi(epp)) : 1;
+    a.p2 = (G.N + parts - 1) / parts;
+    a.p2 = (a.p2 + KCH - 1) / KCH * KCH;                     // whole groups
+    if (G.NT <= 2) LAUNCH_THREAD_AS(k_pre_new, k_pre_new_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
+    else LAUNCH_THREAD_AS(k_pre_new, k_pre_new_m4, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
+  } else
   LAUNCH_THREAD(k_pre_new, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
   if (c->late_pre && (G.options & ROMS_UV_VIS2))     // the update of u,v(nnew) k_uv3dmix2_s left out
     LAUNCH_THREAD(k_uv3dmix2_apply, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);

@@ -485,6 +485,192 @@ THREAD_KERNEL(k_pre_new, KArgs) {
 }
 THREAD_GLOBAL(k_pre_new, KArgs)
 
+// The same as a MARCH (large grids): a thread owns the whole column (or one of a.p2-level parts of it) and walks it in
+// groups of KCH levels, carrying the last level's values and the fluxes through the last interface in registers.  The
+// chunked form above re-reads two levels of every column array per chunk of five (its HBM traffic measures 1.38 times the
+// algorithmic bytes, at the practical HBM ceiling); here every level is read once.  Same expressions, same operands:
+// same bits (tests/test_gpu_parity.py::test_column_kernel_forms_agree_bitwise, ROMS_HIP_PRENEW_MARCH=0/1).
+template <int MT>
+THREAD_KERNEL(k_pre_new_mt, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, NT = G.NT;
+  const int ka = gz * a.p2 + 1, kb = KMIN(N, ka + a.p2 - 1);
+  if (ka > N) return;
+  const int nstp = G.nstp, nnew = G.nnew, nrhs = G.nrhs, indx = 3 - G.nrhs;
+  const double dt = G.dt;
+  const double cff3 = dt * (1.0 - G.lambda);
+  const size_t x = X2(i, j), nij = (size_t)G.nij;
+  const bool doU = i >= B.IstrU, doV = j >= B.JstrV;
+  const size_t xmu = doU ? x - 1 : x, xmv = doV ? x - (size_t)G.ni : x;
+  const bool LMD = (G.options & ROMS_LMD_MIXING) != 0, SOL = (G.options & ROMS_SOLAR_SOURCE) != 0;
+  const double *zr = F.z_r;
+  const double *ts[MT], *Akt[MT], *gh[MT];
+  double *tn[MT];
+#pragma unroll
+  for (int it = 0; it < MT; it++) {
+    const int itc = KMIN(it, NT - 1), ltrc = KMIN(G.NAT, itc + 1);
+    ts[it] = F.t + x + ((size_t)(nstp - 1) + 3 * (size_t)itc) * nij * (size_t)N;
+    tn[it] = F.t + x + ((size_t)(nnew - 1) + 3 * (size_t)itc) * nij * (size_t)N;
+    Akt[it] = F.Akt + x + (size_t)(ltrc - 1) * nij * (size_t)(N + 1);
+    gh[it] = F.ghats + x + (size_t)itc * nij * (size_t)(N + 1);
+  }
+  const double *us = F.u + x + (size_t)(nstp - 1) * nij * (size_t)N, *vs = F.v + x + (size_t)(nstp - 1) * nij * (size_t)N;
+  double *un_ = F.u + x + (size_t)(nnew - 1) * nij * (size_t)N, *vn_ = F.v + x + (size_t)(nnew - 1) * nij * (size_t)N;
+  const size_t o_nrhs = (size_t)(nrhs - 1) * nij * (size_t)(N + 1), o_indx = (size_t)(indx - 1) * nij * (size_t)(N + 1);
+  const double srf = SOL ? F.srflx[x] : 0.0;
+  const double cffq = dt * 0.25;
+  const double DC0u = doU ? cffq * (F.pm[x] + F.pm[xmu]) * (F.pn[x] + F.pn[xmu]) : 0.0;
+  const double DC0v = doV ? cffq * (F.pm[x] + F.pm[xmv]) * (F.pn[x] + F.pn[xmv]) : 0.0;
+#define LV_(kk) ((size_t)((kk) - 1) * nij)        /* level offset */
+#define IF_(kk) ((size_t)(kk) * nij)              /* interface offset */
+  // carried: the values of level kc (the group's first level) and the fluxes through the interface below it
+  double zc = zr[x + LV_(ka)], zcu = zr[xmu + LV_(ka)], zcv = zr[xmv + LV_(ka)];
+  double tc[MT], FCt[MT], qcu = us[LV_(ka)], qcv = vs[LV_(ka)], FCu, FCv;
+#pragma unroll
+  for (int it = 0; it < MT; it++) tc[it] = it < NT ? ts[it][LV_(ka)] : 0.0;
+  if (ka == 1) {
+#pragma unroll
+    for (int it = 0; it < MT; it++) FCt[it] = it < NT ? dt * F.btflx[X2T(i, j, it + 1)] : 0.0;
+    FCu = dt * F.bustr[x];
+    FCv = dt * F.bvstr[x];
+  } else {            // a part that starts inside the column: the flux through interface ka-1 from levels ka-1, ka
+    const int kk = ka - 1;
+    const double z0 = zr[x + LV_(kk)];
+    const double odz = 1.0 / (zc - z0);
+#pragma unroll
+    for (int it = 0; it < MT; it++) {
+      FCt[it] = 0.0;
+      if (it < NT) {
+        const double ak = Akt[it][IF_(kk)];
+        double f = cff3 * odz * ak * (tc[it] - ts[it][LV_(kk)]);
+        if (LMD && it + 1 <= G.NAT) f = f - dt * ak * gh[it][IF_(kk)];
+        if (SOL && it == 0) f = f + dt * srf * F.wrk3[5][x + IF_(kk)];
+        FCt[it] = f;
+      }
+    }
+    {
+      const double c_ = 1.0 / (zc + zcu - z0 - zr[xmu + LV_(kk)]);
+      FCu = cff3 * c_ * (qcu - us[LV_(kk)]) * (F.Akv[x + IF_(kk)] + F.Akv[xmu + IF_(kk)]);
+    }
+    {
+      const double c_ = 1.0 / (zc + zcv - z0 - zr[xmv + LV_(kk)]);
+      FCv = cff3 * c_ * (qcv - vs[LV_(kk)]) * (F.Akv[x + IF_(kk)] + F.Akv[xmv + IF_(kk)]);
+    }
+  }
+  _Pragma("unroll 1") for (int k0 = ka; k0 <= kb; k0 += KCH) {
+    // loads of the group: levels k0+1 .. k0+KCH (the level above each of its interfaces), thicknesses and r.h.s. of its own
+    // levels k0 .. k0+KCH-1, mixing coefficients of its interfaces k0 .. k0+KCH-1
+    double zn[KCH], znu[KCH], znv[KCH], tnx[MT][KCH], qnu[KCH], qnv[KCH];
+    double hz[KCH], hzu[KCH], hzv[KCH], akt[MT][KCH], ght[MT][KCH], swd[KCH], avu[KCH], avv[KCH];
+    double ru1[KCH], ru2[KCH], rv1[KCH], rv2[KCH];
+#pragma unroll
+    for (int q = 0; q < KCH; q++) {
+      const int kl = KMIN(k0 + q, N), kn = KMIN(k0 + q + 1, N), ki = KMIN(k0 + q, N);
+      zn[q] = zr[x + LV_(kn)]; znu[q] = zr[xmu + LV_(kn)]; znv[q] = zr[xmv + LV_(kn)];
+      qnu[q] = us[LV_(kn)]; qnv[q] = vs[LV_(kn)];
+      hz[q] = F.Hz[x + LV_(kl)]; hzu[q] = F.Hz[xmu + LV_(kl)]; hzv[q] = F.Hz[xmv + LV_(kl)];
+      const double akv0 = F.Akv[x + IF_(ki)];
+      avu[q] = akv0 + F.Akv[xmu + IF_(ki)];
+      avv[q] = akv0 + F.Akv[xmv + IF_(ki)];
+      swd[q] = SOL ? F.wrk3[5][x + IF_(ki)] : 0.0;
+#pragma unroll
+      for (int it = 0; it < MT; it++) {
+        tnx[it][q] = it < NT ? ts[it][LV_(kn)] : 0.0;
+        akt[it][q] = it < NT ? Akt[it][IF_(ki)] : 0.0;
+        ght[it][q] = (LMD && it < NT && it + 1 <= G.NAT) ? gh[it][IF_(ki)] : 0.0;
+      }
+      if (G.iic == G.ntfirst) { ru1[q] = 0.0; ru2[q] = 0.0; rv1[q] = 0.0; rv2[q] = 0.0; }
+      else if (G.iic != G.ntfirst + 1 && a.p1) {
+        ru1[q] = F.wrk3[11][x + LV_(kl)]; rv1[q] = F.wrk3[12][x + LV_(kl)]; ru2[q] = 0.0; rv2[q] = 0.0;
+      } else {
+        ru1[q] = F.ru[x + IF_(kl) + o_nrhs]; ru2[q] = F.ru[x + IF_(kl) + o_indx];
+        rv1[q] = F.rv[x + IF_(kl) + o_nrhs]; rv2[q] = F.rv[x + IF_(kl) + o_indx];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < KCH; q++) {
+      const int k = k0 + q;                     // level k, interface k above it
+      if (k <= kb) {
+        const double zl = q == 0 ? zc : zn[q - 1], zlu = q == 0 ? zcu : znu[q - 1], zlv = q == 0 ? zcv : znv[q - 1];
+        const double qlu = q == 0 ? qcu : qnu[q - 1], qlv = q == 0 ? qcv : qnv[q - 1];
+        // ---- tracers :855-935
+        const double odz = 1.0 / (zn[q] - zl);
+#pragma unroll
+        for (int it = 0; it < MT; it++) {
+          if (it < NT) {
+            const double tl = q == 0 ? tc[it] : tnx[it][q - 1];
+            double f;
+            if (k >= N) f = dt * F.stflx[X2T(i, j, it + 1)];
+            else {
+              f = cff3 * odz * akt[it][q] * (tnx[it][q] - tl);
+              if (LMD && it + 1 <= G.NAT) f = f - dt * akt[it][q] * ght[it][q];
+              if (SOL && it == 0) f = f + dt * srf * swd[q];
+            }
+            const double cff1 = hz[q] * tl;
+            const double cff2 = f - FCt[it];
+            tn[it][LV_(k)] = cff1 + cff2;
+            FCt[it] = f;
+          }
+        }
+        // ---- u :943-1040, v :1045-1145
+        if (doU) {
+          double f;
+          if (k >= N) f = dt * F.sustr[x];
+          else {
+            const double c_ = 1.0 / (zn[q] + znu[q] - zl - zlu);
+            f = cff3 * c_ * (qnu[q] - qlu) * avu[q];
+          }
+          const double hu = qlu * 0.5 * (hz[q] + hzu[q]);
+          const double dF = f - FCu;
+          double un;
+          if (G.iic == G.ntfirst) un = hu + dF;
+          else if (G.iic == G.ntfirst + 1) { const double c3 = 0.5 * DC0u; un = hu - c3 * ru2[q] + dF; }
+          else {
+            const double c1 = 5.0 / 12.0, c2 = 16.0 / 12.0;
+            if (a.p1) un = hu + DC0u * ru1[q] + dF;
+            else un = hu + DC0u * (c1 * ru1[q] - c2 * ru2[q]) + dF;
+          }
+          un_[LV_(k)] = un;
+          FCu = f;
+        }
+        if (doV) {
+          double f;
+          if (k >= N) f = dt * F.svstr[x];
+          else {
+            const double c_ = 1.0 / (zn[q] + znv[q] - zl - zlv);
+            f = cff3 * c_ * (qnv[q] - qlv) * avv[q];
+          }
+          const double hv = qlv * 0.5 * (hz[q] + hzv[q]);
+          const double dF = f - FCv;
+          double vn;
+          if (G.iic == G.ntfirst) vn = hv + dF;
+          else if (G.iic == G.ntfirst + 1) { const double c3 = 0.5 * DC0v; vn = hv - c3 * rv2[q] + dF; }
+          else {
+            const double c1 = 5.0 / 12.0, c2 = 16.0 / 12.0;
+            if (a.p1) vn = hv + DC0v * rv1[q] + dF;
+            else vn = hv + DC0v * (c1 * rv1[q] - c2 * rv2[q]) + dF;
+          }
+          vn_[LV_(k)] = vn;
+          FCv = f;
+        }
+      }
+    }
+    // carry the group's last "level above" over
+    zc = zn[KCH - 1]; zcu = znu[KCH - 1]; zcv = znv[KCH - 1]; qcu = qnu[KCH - 1]; qcv = qnv[KCH - 1];
+#pragma unroll
+    for (int it = 0; it < MT; it++) tc[it] = tnx[it][KCH - 1];
+  }
+#undef LV_
+#undef IF_
+}
+// (MT: tracers the register arrays are sized for)
+THREAD_KERNEL(k_pre_new_m, KArgs) { k_pre_new_mt_body<2>(a, gx, gy, gz); }
+THREAD_GLOBAL(k_pre_new_m, KArgs)
+THREAD_KERNEL(k_pre_new_m4, KArgs) { k_pre_new_mt_body<ROMS_MAXT>(a, gx, gy, gz); }
+THREAD_GLOBAL(k_pre_new_m4, KArgs)
+
 // -------------------------------------------------------------------------------- prsgrd32
 // P(i,j,k) into F.wrk3[1]; one thread per column of (IstrU-1:Iend, JstrV-1:Jend)
 THREAD_KERNEL(k_prs_P, KArgs) {

@@ -553,7 +553,11 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
                            # tracer advection of pre_step3d / step3d_t: LDS-tiled marching kernels (k_tadv_lds.h; the
                            # default from 64 K columns up) against the point-wise forms these small grids take
                            ("tadv_lds", {"ROMS_HIP_TADV_LDS": "1"}), ("tadv_lds_kc", {"ROMS_HIP_TADV_LDS": "1", "ROMS_HIP_TADV_KC": "7"}),
-                           ("march", {"ROMS_HIP_UVCH": "7", "ROMS_HIP_WVELCH": "100", "ROMS_HIP_GEOCH": "7", "ROMS_HIP_T3CH": "9"})):
+                           ("march", {"ROMS_HIP_UVCH": "7", "ROMS_HIP_WVELCH": "100", "ROMS_HIP_GEOCH": "7", "ROMS_HIP_T3CH": "9"}),
+                           # pre_step3d's k_pre_new as a march over the column (the form of >= 128 K columns), whole
+                           # columns and parts of them
+                           ("prenew_march", {"ROMS_HIP_PRENEW_MARCH": "1"}),
+                           ("prenew_march_parts", {"ROMS_HIP_PRENEW_MARCH": "1", "ROMS_HIP_PRENEW_PARTS": "3"})):
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
                                env=dict(os.environ, **extra), timeout=600)
