@@ -47,8 +47,8 @@ enum {
   ROMS_SPHERICAL = 1 << 13,
   ROMS_UV_LOGDRAG = 1 << 14,        /* logarithmic bottom drag from Zob (set_vbc.F:591-635); else UV_QDRAG / UV_LDRAG */
   ROMS_MASKING = 1 << 15,           /* land/sea masks: arrays "rmask", "umask", "vmask", "pmask" (mod_grid.F), all water until
-                                       uploaded; every physics option of the library carries its masked branches except MPDATA
-                                       (exit_flag 5) */
+                                       uploaded; every physics option of the library carries its masked branches (MPDATA's
+                                       mpdata_adiff.F blocks included) */
   ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21
 };
 

@@ -2,7 +2,9 @@
  *
  * Restates mpdata_adiff_tile, ROMS/Nonlinear/mpdata_adiff.F:38-1227 (Smolarkiewicz & Margolin
  * recursive anti-diffusive velocities, third-order cross terms, FCT limiter), options of the
- * BASELINE applications (no MASKING/WET_DRY/WEC/OMEGA_IMPLICIT).  Pinned bit for bit against the
+ * BASELINE applications (no WET_DRY/WEC/OMEGA_IMPLICIT) and, since round 3, MASKING (the 13 masked blocks of the
+ * file: the cross-gradient terms carry the mask of the face they difference over, the pseudo-velocities the mask of
+ * their own point, the FCT extrema skip land: mask_up / mask_dn :945-960).  Pinned bit for bit against the
  * reference's own object code (tests/test_oracle_vs_ref.py, ref_mpdata_adiff in ref_glue.F90).
  *
  * Ta, Ua, Va, oHz are full-size rho-level arrays (X3 indexing), Wa a w-level array (XW); the
@@ -39,6 +41,15 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
   const double *pm = o->pm, *pn = o->pn, *omn = o->omn, *om_u = o->om_u, *on_v = o->on_v, *z_r = o->z_r;
   const double *Huon = o->Huon, *Hvom = o->Hvom, *W = o->W;
   const double *t3 = o->t + XT(LBi, LBj, 1, 3, itrc);
+  const int msk = (c->options & ORC_MASKING) != 0;
+  const double *rmask = o->rmask, *umask = o->umask, *vmask = o->vmask;
+  const double Large = 1.0E+20;                     /* mod_scalars.F */
+#define UM_(i, j) (msk ? umask[X2(i, j)] : 1.0)
+#define VM_(i, j) (msk ? vmask[X2(i, j)] : 1.0)
+#define RM_(i, j) (msk ? rmask[X2(i, j)] : 1.0)
+/* mask_up = rmask; mask_dn = MAX(1, MIN(Large, (1-rmask)*Large)) :950-953 (both 1 without MASKING) */
+#define MUP_(i, j) (msk ? rmask[X2(i, j)] : 1.0)
+#define MDN_(i, j) (msk ? MAX(1.0, MIN(Large, (1.0 - rmask[X2(i, j)]) * Large)) : 1.0)
   double *odz = (double *)calloc(3 * nij * (size_t)N, sizeof(double));
   double *beta_dn = odz + nij * (size_t)N, *beta_up = odz + 2 * nij * (size_t)N;
   double *C = (double *)calloc(2 * ni * (size_t)(N + 1), sizeof(double)), *Wm = C + ni * (size_t)(N + 1);
@@ -138,10 +149,17 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
           Ua[X3(i, j, k)] = 0.0;
         } else {
           const double A = (TA(i, j, k) - TA(i - 1, j, k)) / (TA(i, j, k) + TA(i - 1, j, k) + eps);
-          double B = 0.03125 * ((TA(i, j + 1, k) - TA(i, j, k)) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) +
-                                (TA(i, j, k) - TA(i, j - 1, k)) * (pn[X2(i, j - 1)] + pn[X2(i, j)]) +
-                                (TA(i - 1, j + 1, k) - TA(i - 1, j, k)) * (pn[X2(i - 1, j)] + pn[X2(i - 1, j + 1)]) +
-                                (TA(i - 1, j, k) - TA(i - 1, j - 1, k)) * (pn[X2(i - 1, j - 1)] + pn[X2(i - 1, j)]));
+          double B;
+          if (msk)          /* :353-362 */
+            B = 0.03125 * ((TA(i, j + 1, k) - TA(i, j, k)) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) * vmask[X2(i, j + 1)] +
+                           (TA(i, j, k) - TA(i, j - 1, k)) * (pn[X2(i, j - 1)] + pn[X2(i, j)]) * vmask[X2(i, j)] +
+                           (TA(i - 1, j + 1, k) - TA(i - 1, j, k)) * (pn[X2(i - 1, j)] + pn[X2(i - 1, j + 1)]) * vmask[X2(i - 1, j + 1)] +
+                           (TA(i - 1, j, k) - TA(i - 1, j - 1, k)) * (pn[X2(i - 1, j - 1)] + pn[X2(i - 1, j)]) * vmask[X2(i - 1, j)]);
+          else
+            B = 0.03125 * ((TA(i, j + 1, k) - TA(i, j, k)) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) +
+                           (TA(i, j, k) - TA(i, j - 1, k)) * (pn[X2(i, j - 1)] + pn[X2(i, j)]) +
+                           (TA(i - 1, j + 1, k) - TA(i - 1, j, k)) * (pn[X2(i - 1, j)] + pn[X2(i - 1, j + 1)]) +
+                           (TA(i - 1, j, k) - TA(i - 1, j - 1, k)) * (pn[X2(i - 1, j - 1)] + pn[X2(i - 1, j)]));
           B = B * (on_v[X2(i, j)] + on_v[X2(i, j + 1)] + on_v[X2(i - 1, j)] + on_v[X2(i - 1, j + 1)]) /
               (TA(i - 1, j, k) + TA(i, j, k) + eps);
           const double Um = 0.125 * Huon[X3(i, j, k)] * dt * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * (pn[X2(i, j)] + pn[X2(i - 1, j)]) *
@@ -163,6 +181,7 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
           double ua;
           SIGMA(X, Y, Z, A, B, Cc, ua, 0);
           Ua[X3(i, j, k)] = MIN(fabs(ua), fac * fabs(Um)) * SIGN1(ua);
+          if (msk) Ua[X3(i, j, k)] = Ua[X3(i, j, k)] * umask[X2(i, j)];          /* :460 */
         }
       }
   }
@@ -201,10 +220,17 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
         if (TA(i, j - 1, k) <= 0.0 || TA(i, j, k) <= 0.0 || fabs(TA(i, j - 1, k) - TA(i, j, k)) <= eps2) {
           Va[X3(i, j, k)] = 0.0;
         } else {
-          double A = 0.03125 * ((TA(i + 1, j, k) - TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
-                                (TA(i, j, k) - TA(i - 1, j, k)) * (pm[X2(i - 1, j)] + pm[X2(i, j)]) +
-                                (TA(i + 1, j - 1, k) - TA(i, j - 1, k)) * (pm[X2(i + 1, j - 1)] + pm[X2(i, j - 1)]) +
-                                (TA(i, j - 1, k) - TA(i - 1, j - 1, k)) * (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]));
+          double A;
+          if (msk)          /* :573-582 */
+            A = 0.03125 * ((TA(i + 1, j, k) - TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) * umask[X2(i + 1, j)] +
+                           (TA(i, j, k) - TA(i - 1, j, k)) * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * umask[X2(i, j)] +
+                           (TA(i + 1, j - 1, k) - TA(i, j - 1, k)) * (pm[X2(i + 1, j - 1)] + pm[X2(i, j - 1)]) * umask[X2(i + 1, j - 1)] +
+                           (TA(i, j - 1, k) - TA(i - 1, j - 1, k)) * (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]) * umask[X2(i, j - 1)]);
+          else
+            A = 0.03125 * ((TA(i + 1, j, k) - TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                           (TA(i, j, k) - TA(i - 1, j, k)) * (pm[X2(i - 1, j)] + pm[X2(i, j)]) +
+                           (TA(i + 1, j - 1, k) - TA(i, j - 1, k)) * (pm[X2(i + 1, j - 1)] + pm[X2(i, j - 1)]) +
+                           (TA(i, j - 1, k) - TA(i - 1, j - 1, k)) * (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]));
           A = A * (om_u[X2(i, j)] + om_u[X2(i + 1, j)] + om_u[X2(i, j - 1)] + om_u[X2(i + 1, j - 1)]) /
               (TA(i, j - 1, k) + TA(i, j, k) + eps);
           const double B = (TA(i, j, k) - TA(i, j - 1, k)) / (TA(i, j, k) + TA(i, j - 1, k) + eps);
@@ -227,6 +253,7 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
           double va;
           SIGMA(Y, X, Z, B, A, Cc, va, 1);
           Va[X3(i, j, k)] = MIN(fabs(va), fac * fabs(Vm)) * SIGN1(va);
+          if (msk) Va[X3(i, j, k)] = Va[X3(i, j, k)] * vmask[X2(i, j)];          /* :683 */
         }
       }
   }
@@ -255,14 +282,26 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
           Wa[XW(i, j, k)] = 0.0;
         } else {
           const double Cc = (TA(i, j, k + 1) - TA(i, j, k)) / (TA(i, j, k + 1) + TA(i, j, k) + eps);
-          double A = 0.0625 * ((TA(i + 1, j, k + 1) - TA(i, j, k + 1)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
-                               (TA(i, j, k + 1) - TA(i - 1, j, k + 1)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]) +
-                               (TA(i + 1, j, k) - TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
-                               (TA(i, j, k) - TA(i - 1, j, k)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]));
-          double B = 0.0625 * ((TA(i, j + 1, k + 1) - TA(i, j, k + 1)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
-                               (TA(i, j, k + 1) - TA(i, j - 1, k + 1)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) +
-                               (TA(i, j + 1, k) - TA(i, j, k)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
-                               (TA(i, j, k) - TA(i, j - 1, k)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]));
+          double A, B;
+          if (msk) {        /* :777-794 */
+            A = 0.0625 * ((TA(i + 1, j, k + 1) - TA(i, j, k + 1)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) * umask[X2(i + 1, j)] +
+                          (TA(i, j, k + 1) - TA(i - 1, j, k + 1)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * umask[X2(i, j)] +
+                          (TA(i + 1, j, k) - TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) * umask[X2(i + 1, j)] +
+                          (TA(i, j, k) - TA(i - 1, j, k)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * umask[X2(i, j)]);
+            B = 0.0625 * ((TA(i, j + 1, k + 1) - TA(i, j, k + 1)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) * vmask[X2(i, j + 1)] +
+                          (TA(i, j, k + 1) - TA(i, j - 1, k + 1)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) * vmask[X2(i, j)] +
+                          (TA(i, j + 1, k) - TA(i, j, k)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) * vmask[X2(i, j + 1)] +
+                          (TA(i, j, k) - TA(i, j - 1, k)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) * vmask[X2(i, j)]);
+          } else {
+            A = 0.0625 * ((TA(i + 1, j, k + 1) - TA(i, j, k + 1)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                          (TA(i, j, k + 1) - TA(i - 1, j, k + 1)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]) +
+                          (TA(i + 1, j, k) - TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                          (TA(i, j, k) - TA(i - 1, j, k)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]));
+            B = 0.0625 * ((TA(i, j + 1, k + 1) - TA(i, j, k + 1)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
+                          (TA(i, j, k + 1) - TA(i, j - 1, k + 1)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) +
+                          (TA(i, j + 1, k) - TA(i, j, k)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
+                          (TA(i, j, k) - TA(i, j - 1, k)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]));
+          }
           A = A * (om_u[X2(i + 1, j)] + om_u[X2(i, j)]) / (TA(i, j, k + 1) + TA(i, j, k) + eps);
           B = B * (on_v[X2(i, j + 1)] + on_v[X2(i, j)]) / (TA(i, j, k + 1) + TA(i, j, k) + eps);
           const double Um =
@@ -293,6 +332,7 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
           /* the reference permutes the cross terms for the vertical component: first Y (with B), then X (with A) */
           SIGMA(Z, Y, X, Cc, B, A, wa, 0);
           Wa[XW(i, j, k)] = MIN(fabs(wa), fac * fabs(Wmm)) * SIGN1(wa);
+          if (msk) Wa[XW(i, j, k)] = Wa[XW(i, j, k)] * rmask[X2(i, j)];          /* :924 */
         }
       }
     for (int i = IstrU - 1; i <= b->Iendp1; i++) {
@@ -300,20 +340,22 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
       Wa[XW(i, j, N)] = 0.0;
     }
   }
-  /* ---- FCT limiter :862-1150 (no masking: mask_up = mask_dn = 1) */
+  /* ---- FCT limiter :862-1150; Tmax over values * mask_up, Tmin over values * mask_dn :962-1100 */
   for (int j = JstrV - 1; j <= b->Jendp1; j++)
     for (int k = 1; k <= N; k++)
       for (int i = IstrU - 1; i <= b->Iendp1; i++) {
-        double v[14];
+        double v[14], vd[14];
         int n = 0;
-        v[n++] = TA(i - 1, j, k); v[n++] = T3(i - 1, j, k);
-        v[n++] = TA(i, j, k); v[n++] = T3(i, j, k);
-        v[n++] = TA(i + 1, j, k); v[n++] = T3(i + 1, j, k);
-        v[n++] = TA(i, j - 1, k); v[n++] = T3(i, j - 1, k);
-        v[n++] = TA(i, j + 1, k); v[n++] = T3(i, j + 1, k);
-        if (k > 1) { v[n++] = TA(i, j, k - 1); v[n++] = T3(i, j, k - 1); }
-        if (k < N) { v[n++] = TA(i, j, k + 1); v[n++] = T3(i, j, k + 1); }
-        const double Tmax = max12(v, n), Tmin = min12(v, n);
+#define PUSH_(val, ii, jj) do { vd[n] = (val) * MDN_(ii, jj); v[n++] = (val) * MUP_(ii, jj); } while (0)
+        PUSH_(TA(i - 1, j, k), i - 1, j); PUSH_(T3(i - 1, j, k), i - 1, j);
+        PUSH_(TA(i, j, k), i, j); PUSH_(T3(i, j, k), i, j);
+        PUSH_(TA(i + 1, j, k), i + 1, j); PUSH_(T3(i + 1, j, k), i + 1, j);
+        PUSH_(TA(i, j - 1, k), i, j - 1); PUSH_(T3(i, j - 1, k), i, j - 1);
+        PUSH_(TA(i, j + 1, k), i, j + 1); PUSH_(T3(i, j + 1, k), i, j + 1);
+        if (k > 1) { PUSH_(TA(i, j, k - 1), i, j); PUSH_(T3(i, j, k - 1), i, j); }
+        if (k < N) { PUSH_(TA(i, j, k + 1), i, j); PUSH_(T3(i, j, k + 1), i, j); }
+#undef PUSH_
+        const double Tmax = max12(v, n), Tmin = min12(vd, n);
         double cff1 = TA(i - 1, j, k) * MAX(0.0, Ua[X3(i, j, k)]) - TA(i + 1, j, k) * MIN(0.0, Ua[X3(i + 1, j, k)]) +
                       TA(i, j - 1, k) * MAX(0.0, Va[X3(i, j, k)]) - TA(i, j + 1, k) * MIN(0.0, Va[X3(i, j + 1, k)]);
         if (k > 1) cff1 = cff1 + TA(i, j, k - 1) * MAX(0.0, Wa[XW(i, j, k - 1)]);
@@ -333,12 +375,14 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
           const double cff1 = MIN(MIN(beta_dn[X3(i - 1, j, k)], beta_up[X3(i, j, k)]), 1.0);
           const double cff2 = MIN(MIN(beta_up[X3(i - 1, j, k)], beta_dn[X3(i, j, k)]), 1.0);
           Ua[X3(i, j, k)] = (cff1 * MAX(0.0, Ua[X3(i, j, k)]) + cff2 * MIN(0.0, Ua[X3(i, j, k)])) * cff * om_u[X2(i, j)];
+          if (msk) Ua[X3(i, j, k)] = Ua[X3(i, j, k)] * umask[X2(i, j)];        /* :1114 */
         }
       for (int j = JstrV; j <= b->Jendp1; j++)
         for (int i = Istr; i <= Iend; i++) {
           const double cff1 = MIN(MIN(beta_dn[X3(i, j - 1, k)], beta_up[X3(i, j, k)]), 1.0);
           const double cff2 = MIN(MIN(beta_up[X3(i, j - 1, k)], beta_dn[X3(i, j, k)]), 1.0);
           Va[X3(i, j, k)] = (cff1 * MAX(0.0, Va[X3(i, j, k)]) + cff2 * MIN(0.0, Va[X3(i, j, k)])) * cff * on_v[X2(i, j)];
+          if (msk) Va[X3(i, j, k)] = Va[X3(i, j, k)] * vmask[X2(i, j)];        /* :1129 */
         }
       if (k < N)
         for (int j = Jstr; j <= Jend; j++)
@@ -347,6 +391,7 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
             const double cff2 = MIN(MIN(beta_up[X3(i, j, k)], beta_dn[X3(i, j, k + 1)]), 1.0);
             Wa[XW(i, j, k)] = (cff1 * MAX(0.0, Wa[XW(i, j, k)]) + cff2 * MIN(0.0, Wa[XW(i, j, k)])) * cff * omn[X2(i, j)] *
                               (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]);
+            if (msk) Wa[XW(i, j, k)] = Wa[XW(i, j, k)] * rmask[X2(i, j)];      /* :1145 */
           }
     }
   }

@@ -136,6 +136,12 @@ THREAD_KERNEL(k_mp_uva, MpArgs) {
     double A, Bg, Um, Vm;
     if (dir == 0) {
       A = (MP_TA(i, j, k) - MP_TA(i - 1, j, k)) / (MP_TA(i, j, k) + MP_TA(i - 1, j, k) + eps);
+      if (G.masking)        // mpdata_adiff.F:353-362: each cross difference carries the mask of the face it spans
+        Bg = 0.03125 * ((MP_TA(i, j + 1, k) - MP_TA(i, j, k)) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) * G.vmask[X2(i, j + 1)] +
+                        (MP_TA(i, j, k) - MP_TA(i, j - 1, k)) * (pn[X2(i, j - 1)] + pn[X2(i, j)]) * G.vmask[X2(i, j)] +
+                        (MP_TA(i - 1, j + 1, k) - MP_TA(i - 1, j, k)) * (pn[X2(i - 1, j)] + pn[X2(i - 1, j + 1)]) * G.vmask[X2(i - 1, j + 1)] +
+                        (MP_TA(i - 1, j, k) - MP_TA(i - 1, j - 1, k)) * (pn[X2(i - 1, j - 1)] + pn[X2(i - 1, j)]) * G.vmask[X2(i - 1, j)]);
+      else
       Bg = 0.03125 * ((MP_TA(i, j + 1, k) - MP_TA(i, j, k)) * (pn[X2(i, j)] + pn[X2(i, j + 1)]) +
                       (MP_TA(i, j, k) - MP_TA(i, j - 1, k)) * (pn[X2(i, j - 1)] + pn[X2(i, j)]) +
                       (MP_TA(i - 1, j + 1, k) - MP_TA(i - 1, j, k)) * (pn[X2(i - 1, j)] + pn[X2(i - 1, j + 1)]) +
@@ -154,6 +160,12 @@ THREAD_KERNEL(k_mp_uva, MpArgs) {
             Hvom[X3(i, j + 1, k)] * (pm[X2(i, j + 1)] + pm[X2(i, j)]) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) *
                 (MP_OHZ(i, j + 1, k) + MP_OHZ(i, j, k)));
     } else {
+      if (G.masking)        // :573-582
+        A = 0.03125 * ((MP_TA(i + 1, j, k) - MP_TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) * G.umask[X2(i + 1, j)] +
+                       (MP_TA(i, j, k) - MP_TA(i - 1, j, k)) * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * G.umask[X2(i, j)] +
+                       (MP_TA(i + 1, j - 1, k) - MP_TA(i, j - 1, k)) * (pm[X2(i + 1, j - 1)] + pm[X2(i, j - 1)]) * G.umask[X2(i + 1, j - 1)] +
+                       (MP_TA(i, j - 1, k) - MP_TA(i - 1, j - 1, k)) * (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]) * G.umask[X2(i, j - 1)]);
+      else
       A = 0.03125 * ((MP_TA(i + 1, j, k) - MP_TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
                      (MP_TA(i, j, k) - MP_TA(i - 1, j, k)) * (pm[X2(i - 1, j)] + pm[X2(i, j)]) +
                      (MP_TA(i + 1, j - 1, k) - MP_TA(i, j - 1, k)) * (pm[X2(i + 1, j - 1)] + pm[X2(i, j - 1)]) +
@@ -180,9 +192,11 @@ THREAD_KERNEL(k_mp_uva, MpArgs) {
     if (dir == 0) {
       MP_SIGMA(X, Y, Z, A, Bg, Cc, r, 0);
       val = KMIN(fabs(r), fac * fabs(Um)) * MP_SIGN1(r);
+      if (G.masking) val = val * G.umask[X2(i, j)];       // :460
     } else {
       MP_SIGMA(Y, X, Z, Bg, A, Cc, r, 1);
       val = KMIN(fabs(r), fac * fabs(Vm)) * MP_SIGN1(r);
+      if (G.masking) val = val * G.vmask[X2(i, j)];       // :683
     }
   }
   // closed walls :642-720 (the wall value replaces whatever was computed there)
@@ -211,14 +225,26 @@ THREAD_KERNEL(k_mp_wa, MpArgs) {
   if (k >= 1 && k <= N - 1 &&
       !(MP_TA(i, j, k) <= 0.0 || MP_TA(i, j, k + 1) <= 0.0 || fabs(MP_TA(i, j, k) - MP_TA(i, j, k + 1)) <= eps2)) {
     const double Cc = (MP_TA(i, j, k + 1) - MP_TA(i, j, k)) / (MP_TA(i, j, k + 1) + MP_TA(i, j, k) + eps);
-    double A = 0.0625 * ((MP_TA(i + 1, j, k + 1) - MP_TA(i, j, k + 1)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
-                         (MP_TA(i, j, k + 1) - MP_TA(i - 1, j, k + 1)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]) +
-                         (MP_TA(i + 1, j, k) - MP_TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
-                         (MP_TA(i, j, k) - MP_TA(i - 1, j, k)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]));
-    double Bg = 0.0625 * ((MP_TA(i, j + 1, k + 1) - MP_TA(i, j, k + 1)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
-                          (MP_TA(i, j, k + 1) - MP_TA(i, j - 1, k + 1)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) +
-                          (MP_TA(i, j + 1, k) - MP_TA(i, j, k)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
-                          (MP_TA(i, j, k) - MP_TA(i, j - 1, k)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]));
+    double A, Bg;
+    if (G.masking) {        // :777-794
+      A = 0.0625 * ((MP_TA(i + 1, j, k + 1) - MP_TA(i, j, k + 1)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) * G.umask[X2(i + 1, j)] +
+                    (MP_TA(i, j, k + 1) - MP_TA(i - 1, j, k + 1)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * G.umask[X2(i, j)] +
+                    (MP_TA(i + 1, j, k) - MP_TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) * G.umask[X2(i + 1, j)] +
+                    (MP_TA(i, j, k) - MP_TA(i - 1, j, k)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]) * G.umask[X2(i, j)]);
+      Bg = 0.0625 * ((MP_TA(i, j + 1, k + 1) - MP_TA(i, j, k + 1)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) * G.vmask[X2(i, j + 1)] +
+                     (MP_TA(i, j, k + 1) - MP_TA(i, j - 1, k + 1)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) * G.vmask[X2(i, j)] +
+                     (MP_TA(i, j + 1, k) - MP_TA(i, j, k)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) * G.vmask[X2(i, j + 1)] +
+                     (MP_TA(i, j, k) - MP_TA(i, j - 1, k)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) * G.vmask[X2(i, j)]);
+    } else {
+      A = 0.0625 * ((MP_TA(i + 1, j, k + 1) - MP_TA(i, j, k + 1)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                    (MP_TA(i, j, k + 1) - MP_TA(i - 1, j, k + 1)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]) +
+                    (MP_TA(i + 1, j, k) - MP_TA(i, j, k)) * (pm[X2(i + 1, j)] + pm[X2(i, j)]) +
+                    (MP_TA(i, j, k) - MP_TA(i - 1, j, k)) * (pm[X2(i, j)] + pm[X2(i - 1, j)]));
+      Bg = 0.0625 * ((MP_TA(i, j + 1, k + 1) - MP_TA(i, j, k + 1)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
+                     (MP_TA(i, j, k + 1) - MP_TA(i, j - 1, k + 1)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) +
+                     (MP_TA(i, j + 1, k) - MP_TA(i, j, k)) * (pn[X2(i, j + 1)] + pn[X2(i, j)]) +
+                     (MP_TA(i, j, k) - MP_TA(i, j - 1, k)) * (pn[X2(i, j)] + pn[X2(i, j - 1)]));
+    }
     A = A * (F.om_u[X2(i + 1, j)] + F.om_u[X2(i, j)]) / (MP_TA(i, j, k + 1) + MP_TA(i, j, k) + eps);
     Bg = Bg * (F.on_v[X2(i, j + 1)] + F.on_v[X2(i, j)]) / (MP_TA(i, j, k + 1) + MP_TA(i, j, k) + eps);
     const double Um =
@@ -248,6 +274,7 @@ THREAD_KERNEL(k_mp_wa, MpArgs) {
     double r;
     MP_SIGMA(Z, Y, X, Cc, Bg, A, r, 0);
     val = KMIN(fabs(r), fac * fabs(Wmm)) * MP_SIGN1(r);
+    if (G.masking) val = val * G.rmask[X2(i, j)];         // :924
   }
   Wa[XW(i, j, k)] = val;
 }
@@ -264,16 +291,27 @@ THREAD_KERNEL(k_mp_beta, MpArgs) {
   const double eps = 1.0E-18;
   const double *Ta = F.mp3[0] + (size_t)(itrc - 1) * G.nij * N, *Ua = F.mp3[1], *Va = F.mp3[2], *Wa = F.mp3[3];
   const double *T3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
-  double Tmax = MP_TA(i - 1, j, k), Tmin = Tmax;
-#define MP_MM(v_) do { const double q_ = (v_); Tmax = KMAX(Tmax, q_); Tmin = KMIN(Tmin, q_); } while (0)
-  MP_MM(T3[X3(i - 1, j, k)]);
-  MP_MM(MP_TA(i, j, k)); MP_MM(T3[X3(i, j, k)]);
-  MP_MM(MP_TA(i + 1, j, k)); MP_MM(T3[X3(i + 1, j, k)]);
-  MP_MM(MP_TA(i, j - 1, k)); MP_MM(T3[X3(i, j - 1, k)]);
-  MP_MM(MP_TA(i, j + 1, k)); MP_MM(T3[X3(i, j + 1, k)]);
-  if (k > 1) { MP_MM(MP_TA(i, j, k - 1)); MP_MM(T3[X3(i, j, k - 1)]); }
-  if (k < N) { MP_MM(MP_TA(i, j, k + 1)); MP_MM(T3[X3(i, j, k + 1)]); }
+  // extrema over the point's neighbourhood :962-1100: Tmax over value * mask_up, Tmin over value * mask_dn, where
+  // mask_up = rmask and mask_dn = MAX(1, MIN(Large, (1 - rmask) * Large)) keep land out of both (:945-960; both 1
+  // without MASKING)
+  const bool msk = G.masking != 0;
+  const double Large = 1.0E+20;
+#define MP_UP(ii, jj) (msk ? G.rmask[X2(ii, jj)] : 1.0)
+#define MP_DN(ii, jj) (msk ? KMAX(1.0, KMIN(Large, (1.0 - G.rmask[X2(ii, jj)]) * Large)) : 1.0)
+  double Tmax, Tmin;
+  { const double q_ = MP_TA(i - 1, j, k); Tmax = msk ? q_ * MP_UP(i - 1, j) : q_; Tmin = msk ? q_ * MP_DN(i - 1, j) : q_; }
+#define MP_MM(v_, ii, jj) do { const double q_ = (v_); Tmax = KMAX(Tmax, msk ? q_ * MP_UP(ii, jj) : q_); \
+                               Tmin = KMIN(Tmin, msk ? q_ * MP_DN(ii, jj) : q_); } while (0)
+  MP_MM(T3[X3(i - 1, j, k)], i - 1, j);
+  MP_MM(MP_TA(i, j, k), i, j); MP_MM(T3[X3(i, j, k)], i, j);
+  MP_MM(MP_TA(i + 1, j, k), i + 1, j); MP_MM(T3[X3(i + 1, j, k)], i + 1, j);
+  MP_MM(MP_TA(i, j - 1, k), i, j - 1); MP_MM(T3[X3(i, j - 1, k)], i, j - 1);
+  MP_MM(MP_TA(i, j + 1, k), i, j + 1); MP_MM(T3[X3(i, j + 1, k)], i, j + 1);
+  if (k > 1) { MP_MM(MP_TA(i, j, k - 1), i, j); MP_MM(T3[X3(i, j, k - 1)], i, j); }
+  if (k < N) { MP_MM(MP_TA(i, j, k + 1), i, j); MP_MM(T3[X3(i, j, k + 1)], i, j); }
 #undef MP_MM
+#undef MP_UP
+#undef MP_DN
   double cff1 = MP_TA(i - 1, j, k) * KMAX(0.0, Ua[X3(i, j, k)]) - MP_TA(i + 1, j, k) * KMIN(0.0, Ua[X3(i + 1, j, k)]) +
                 MP_TA(i, j - 1, k) * KMAX(0.0, Va[X3(i, j, k)]) - MP_TA(i, j + 1, k) * KMIN(0.0, Va[X3(i, j + 1, k)]);
   if (k > 1) cff1 = cff1 + MP_TA(i, j, k - 1) * KMAX(0.0, Wa[XW(i, j, k - 1)]);
@@ -304,6 +342,7 @@ THREAD_KERNEL(k_mp_limit, MpArgs) {
       const double cff1 = KMIN(KMIN(bdn[X3(i - 1, j, k)], bup[X3(i, j, k)]), 1.0);
       const double cff2 = KMIN(KMIN(bup[X3(i - 1, j, k)], bdn[X3(i, j, k)]), 1.0);
       Ua[X3(i, j, k)] = (cff1 * KMAX(0.0, Ua[X3(i, j, k)]) + cff2 * KMIN(0.0, Ua[X3(i, j, k)])) * cff * F.om_u[X2(i, j)];
+      if (G.masking) Ua[X3(i, j, k)] = Ua[X3(i, j, k)] * G.umask[X2(i, j)];     // :1114
     }
   }
   if (i <= B.Iend) {
@@ -313,6 +352,7 @@ THREAD_KERNEL(k_mp_limit, MpArgs) {
       const double cff1 = KMIN(KMIN(bdn[X3(i, j - 1, k)], bup[X3(i, j, k)]), 1.0);
       const double cff2 = KMIN(KMIN(bup[X3(i, j - 1, k)], bdn[X3(i, j, k)]), 1.0);
       Va[X3(i, j, k)] = (cff1 * KMAX(0.0, Va[X3(i, j, k)]) + cff2 * KMIN(0.0, Va[X3(i, j, k)])) * cff * F.on_v[X2(i, j)];
+      if (G.masking) Va[X3(i, j, k)] = Va[X3(i, j, k)] * G.vmask[X2(i, j)];     // :1129
     }
   }
   if (i <= B.Iend && j <= B.Jend && k < N) {
@@ -320,6 +360,7 @@ THREAD_KERNEL(k_mp_limit, MpArgs) {
     const double cff2 = KMIN(KMIN(bup[X3(i, j, k)], bdn[X3(i, j, k + 1)]), 1.0);
     Wa[XW(i, j, k)] = (cff1 * KMAX(0.0, Wa[XW(i, j, k)]) + cff2 * KMIN(0.0, Wa[XW(i, j, k)])) * cff * F.omn[X2(i, j)] *
                       (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]);
+    if (G.masking) Wa[XW(i, j, k)] = Wa[XW(i, j, k)] * G.rmask[X2(i, j)];       // :1145
   }
 }
 THREAD_GLOBAL(k_mp_limit, MpArgs)
@@ -375,17 +416,17 @@ THREAD_KERNEL(k_mp_limapply, MpArgs) {
        ? 0.0                                                                                              \
        : (KMIN(KMIN(bdn[X3((ii) - 1, j, k)], bup[X3(ii, j, k)]), 1.0) * KMAX(0.0, Ua[X3(ii, j, k)]) +     \
           KMIN(KMIN(bup[X3((ii) - 1, j, k)], bdn[X3(ii, j, k)]), 1.0) * KMIN(0.0, Ua[X3(ii, j, k)])) *    \
-             odt * F.om_u[X2(ii, j)])
+             odt * F.om_u[X2(ii, j)] * (G.masking ? G.umask[X2(ii, j)] : 1.0))
 #define MP_LV(jj)                                                                                         \
   (((sc && (jj) == B.Jstr) || (nc && (jj) == B.Jend + 1))                                                 \
        ? 0.0                                                                                              \
        : (KMIN(KMIN(bdn[X3(i, (jj) - 1, k)], bup[X3(i, jj, k)]), 1.0) * KMAX(0.0, Va[X3(i, jj, k)]) +     \
           KMIN(KMIN(bup[X3(i, (jj) - 1, k)], bdn[X3(i, jj, k)]), 1.0) * KMIN(0.0, Va[X3(i, jj, k)])) *    \
-             odt * F.on_v[X2(i, jj)])
+             odt * F.on_v[X2(i, jj)] * (G.masking ? G.vmask[X2(i, jj)] : 1.0))
 #define MP_LW(kk)                                                                                         \
   ((KMIN(KMIN(bdn[X3(i, j, kk)], bup[X3(i, j, (kk) + 1)]), 1.0) * KMAX(0.0, Wa[XW(i, j, kk)]) +           \
     KMIN(KMIN(bup[X3(i, j, kk)], bdn[X3(i, j, (kk) + 1)]), 1.0) * KMIN(0.0, Wa[XW(i, j, kk)])) *          \
-   odt * F.omn[X2(i, j)] * (z_r[X3(i, j, (kk) + 1)] - z_r[X3(i, j, kk)]))
+   odt * F.omn[X2(i, j)] * (z_r[X3(i, j, (kk) + 1)] - z_r[X3(i, j, kk)]) * (G.masking ? G.rmask[X2(i, j)] : 1.0))
   const double ua0 = MP_LU(i), ua1 = MP_LU(i + 1), va0 = MP_LV(j), va1 = MP_LV(j + 1);
   const double ta = MP_TA(i, j, k);
 #define MP_FX(ua_, ii) ((KMAX(ua_, 0.0) * MP_TA((ii) - 1, j, k) + KMIN(ua_, 0.0) * MP_TA(ii, j, k)) * 0.5 * \

@@ -191,13 +191,6 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     set_error("a tile of a multi-tile run must be at least 3 points wide and high");
     return 5;
   }
-  if (cfg->options & ROMS_MASKING) {
-    // the masked branches exist for every physics option of the library except MPDATA (mpdata_adiff.F has 111 masked
-    // statements of its own).  What is not there is a configuration error, never a silent change.
-    bool mp = false;
-    for (int it = 0; it < cfg->NT; it++) mp |= cfg->hadv[it] == ROMS_MPDATA || cfg->vadv[it] == ROMS_MPDATA;
-    if (mp) { set_error("MASKING is not built together with MPDATA (mpdata_adiff.F masks)"); return 5; }
-  }
   {  // array bounds must hold the ghost zone the kernels and the strip exchange assume
     const int pw = cfg->west_edge && !cfg->EWperiodic, pe = cfg->east_edge && !cfg->EWperiodic;
     const int ps = cfg->south_edge && !cfg->NSperiodic, pn = cfg->north_edge && !cfg->NSperiodic;

@@ -790,9 +790,7 @@
       IF ((is_defined('SPHERICAL').or.is_defined('CURVGRID').or.is_defined('NONLIN_EOS')).and..not.bench)       &
      &  CALL unsupported ('SPHERICAL / CURVGRID / NONLIN_EOS are built for BENCHMARK only', ierr)
 !  MASKING: the analytic land of this host (island + headland, SUBROUTINE analytic_masks) goes with the UPWELLING grid; the
-!  masked branches exist for its physics (the library refuses the rest: roms_hip_create)
-      IF (is_defined('MASKING').and.ANY(hadv(1:NAT).eq.ROMS_MPDATA))                                           &
-     &  CALL unsupported ('MASKING is built without MPDATA (mpdata_adiff.F masks)', ierr)
+!  masked branches exist for all of its physics, MPDATA's included (mpdata_adiff.F's 13 masked blocks)
       END SUBROUTINE options_from_defines
 
 !

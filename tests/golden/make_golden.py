@@ -233,6 +233,8 @@ STEP_CASES = [
     # MASKING: the reference built with oracle/ref/upwelling_mask.h, land of cases.land_mask
     ("upwelling_mask_small", "upwelling_mask_small", ["nsteps=60", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     ("benchmark_mask_small", "benchmark_mask_small", ["nsteps=60"]),      # oracle/ref/benchmark_mask.h
+    # MASKING with MPDATA: mpdata_adiff.F's masked blocks
+    ("upwelling_mask_small_mpdata", "upwelling_mask_small", ["nsteps=60", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
 ]
 KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
 def make_avg():

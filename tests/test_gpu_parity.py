@@ -730,6 +730,7 @@ def test_mailbox_self_exchange_matches_local_periodic_copy(env):
                                                 # MASKING: the masked boundary fills run inside the mailbox pack kernel
                                                 ("upwelling_mask_small", {"hadv": ("U3", "HSIMT"), "vadv": ("C4", "HSIMT")}, (2, 2), 29735),
                                                 ("benchmark_mask_small", {}, (2, 2), 29736),
+                                                ("upwelling_mask_small", {"hadv": ("MPDATA", "MPDATA"), "vadv": ("MPDATA", "MPDATA")}, (2, 2), 29741),
                                                 # the pair kernel's wide strips through the mailbox (tiles of 8 points and more)
                                                 ("benchmark_mid", {}, (2, 2), 29737), ("benchmark_mid", {}, (4, 2), 29738),
                                                 ("upwelling_mask_mid", {"hadv": ("U3", "HSIMT"), "vadv": ("C4", "HSIMT")}, (2, 2), 29739),
@@ -772,6 +773,9 @@ def test_mailbox_tiles_on_one_gpu_match_single_tile(tmp_path, tag, kw, tiles, po
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,hadv,vadv,env", [
     ("upwelling_mask_small", ("U3", "HSIMT"), ("C4", "HSIMT"), {}), ("upwelling_mask_small", ("A4", "C4"), ("SPLINES", "C4"), {}),
+    # MPDATA's masked anti-diffusive velocities and limiter (mpdata_adiff.F), both limiter kernel forms
+    ("upwelling_mask_small", ("MPDATA", "MPDATA"), ("MPDATA", "MPDATA"), {}),
+    ("upwelling_mask_small", ("MPDATA", "MPDATA"), ("MPDATA", "MPDATA"), {"ROMS_HIP_MPFUSE": "0"}),
     ("upwelling_mask_small", ("U3", "U3"), ("C4", "C4"), {"ROMS_HIP_COLLDS": "0", "ROMS_HIP_TADV_LDS": "1"}),
     # the BENCHMARK physics: nonlinear EOS, bulk fluxes, KPP (both kernel forms), geopotential mixing
     ("benchmark_mask_small", ("U3", "U3"), ("C4", "C4"), {}), ("benchmark_mask_small", ("U3", "U3"), ("C4", "C4"), {"ROMS_HIP_LMDCOL": "0"})])

@@ -161,7 +161,7 @@ def test_reader_stops_on_settings_it_cannot_honour(tmp_path, kw, needle):
 def test_masking_option_and_analytic_masks(tmp_path):
     """MASKING: built-in application UPWELLING_MASK and oracle/ref/upwelling_mask.h as header both set the bit; the
     host's analytic land (roms_host.f90:analytic_masks, psi mask by the rule of metrics.F) equals tests' cases.land_mask,
-    which the reference's own metrics.F output was compared with (tests/refdrive.py); unsupported company stops the set-up."""
+    which the reference's own metrics.F output was compared with (tests/refdrive.py); MPDATA goes with it."""
     from roms_amd import hiplib, hostlib
     from tests import cases
     hdr = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "oracle", "ref", "upwelling_mask.h"))
@@ -176,9 +176,12 @@ def test_masking_option_and_analytic_masks(tmp_path):
             assert (m["rmask"] == 0).sum() > 10 and (m["pmask"] == 2).sum() > 4
         finally:
             H.finalize()
-    with pytest.raises(hostlib.HostError) as e:
-        _setup(tmp_path, app="UPWELLING_MASK", h1="MPDATA", v1="MPDATA").finalize()
-    assert e.value.exit_flag == 5 and "MASKING" in str(e.value)
+    # MPDATA under MASKING is built too (mpdata_adiff.F's masked blocks): the set-up goes through
+    H = _setup(tmp_path, app="UPWELLING_MASK", h1="MPDATA", v1="MPDATA")
+    try:
+        assert H.dims["options"] & hiplib.OPTIONS["MASKING"]
+    finally:
+        H.finalize()
 
 
 def test_logdrag_header_selects_the_option(tmp_path):

@@ -107,11 +107,12 @@ def test_logarithmic_bottom_drag_bitwise(emu):
     H.close()
 
 
-@pytest.mark.parametrize("hadv,vadv", [(("U3", "HSIMT"), ("C4", "HSIMT")), (("A4", "C4"), ("SPLINES", "C4")), (("C2", "SU3"), ("C2", "A4"))])
+@pytest.mark.parametrize("hadv,vadv", [(("U3", "HSIMT"), ("C4", "HSIMT")), (("A4", "C4"), ("SPLINES", "C4")), (("C2", "SU3"), ("C2", "A4")),
+                                       (("MPDATA", "MPDATA"), ("MPDATA", "MPDATA")), (("U3", "MPDATA"), ("C4", "MPDATA"))])
 def test_land_sea_masking_bitwise(emu, hadv, vadv):
     """MASKING (island + headland of cases.land_mask; oracle pinned to the reference built from oracle/ref/upwelling_mask.h):
     every masked kernel branch -- barotropic step, closed-boundary fills, EOS, pressure gradient, advection incl. HSIMT,
-    mixing, step3d_uv/t, the first-step loads of ini_fields -- against the oracle's over 8 steps, bit for bit; land
+    mixing, step3d_uv/t, MPDATA's anti-diffusive velocities and limiter, the first-step loads of ini_fields -- against the oracle's over 8 steps, bit for bit; land
     stays land (u, v, zeta, rho zero there) and the run differs from the unmasked one."""
     cs = util.case_for("upwelling_mask_small", hadv=hadv, vadv=vadv)
     g = util.with_masks(cs, util.load_init("upwelling_small", util.nghost_for(cs)))

@@ -204,6 +204,8 @@ MAIN3D_CASES = [
     ("upwelling_mask_small", ["nsteps=60", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),   # MASKING: island + headland
     ("upwelling_mask_small", ["nsteps=30", "hadv=A4,C4", "vadv=SPLINES,C4"]),
     ("upwelling_mask_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("upwelling_mask_small", ["nsteps=40", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),   # mpdata_adiff.F's 13 masked blocks
+    ("upwelling_mask_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
     ("benchmark_mask_small", ["nsteps=60"]),                                     # MASKING with KPP, bulk fluxes, nonlinear EOS, geopotential mixing
     ("benchmark_mask_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
@@ -229,6 +231,7 @@ def test_main3d_steps_bitwise(tag, args):
     ("upwelling_kpp_small", []),
     ("upwelling_mask_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     ("upwelling_mask_small", ["hadv=C4,A4", "vadv=C4,A4"]),
+    ("upwelling_mask_small", ["hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
     ("benchmark_mask_small", []),
 ])
 def test_core_kernels_bitwise(tag, args):

@@ -59,6 +59,8 @@ def _interior(cs_dims, a):
     ("upwelling_small", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (2, 2), 29614),
     # MASKING: the island straddles the tile boundaries, the headland sits on the southern wall of one tile
     ("upwelling_mask_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 2), 29616),
+    # MASKING with MPDATA: the masked cross-gradient terms read umask/vmask in the ghost lines
+    ("upwelling_mask_small", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (2, 2), 29622),
     # tiles of 8 points and more: the barotropic steps run as predictor+corrector pairs (k_step2d_pair.h) with one exchange of
     # 5 | 4 lines per pair -- 2x2 (corner blocks of the wide strips), the 8-rank layout, three ghost lines + MPDATA, MASKING
     ("benchmark_mid", dict(), (2, 2), 29617),
