@@ -41,7 +41,8 @@ enum {
   ORC_ANA_VMIX = 1 << 11, ORC_SALINITY = 1 << 12, ORC_SPHERICAL = 1 << 13,
   ORC_UV_LOGDRAG = 1 << 14,  /* set_vbc.F:591-635 */
   ORC_MASKING = 1 << 15,     /* land/sea masks rmask, umask, vmask, pmask (mod_grid.F) */
-  ORC_APP_UPWELLING = 1 << 20, ORC_APP_BENCHMARK = 1 << 21
+  ORC_RADIATION_2D = 1 << 16, /* tangential phase speed in the radiation conditions (zetabc.F:157 ...) */
+  ORC_APP_UPWELLING = 1 << 20, ORC_APP_BENCHMARK = 1 << 21, ORC_APP_KELVIN = 1 << 22
 };
 
 /* loop bounds of one tile: BOUNDS(ng)%xxx(tile), get_bounds.F:1044-1884 */
@@ -62,6 +63,15 @@ typedef struct {
 
 #define ORC_MAXT 4
 #define ORC_MAXW 512
+
+/* lateral boundary conditions, LBC(ibry,ivar,ng) of mod_param.F / load_lbc (inp_decode.F): edge index 0..3 =
+   iwest, isouth, ieast, inorth (mod_scalars.F); variable index isFsur .. isTvar(itrc) */
+enum { ORC_IWEST = 0, ORC_ISOUTH = 1, ORC_IEAST = 2, ORC_INORTH = 3 };
+enum { ORC_ISFSUR = 0, ORC_ISUBAR = 1, ORC_ISVBAR = 2, ORC_ISUVEL = 3, ORC_ISVVEL = 4, ORC_ISTVAR = 5 };
+#define ORC_NLBC (ORC_ISTVAR + ORC_MAXT)
+/* kinds (the roms.in keywords Clo Per Gra Cla Rad RadNud Che Cha Fla Shc); 0 = closed unless the direction is periodic */
+enum { ORC_LBC_DEFAULT = 0, ORC_LBC_CLO = 1, ORC_LBC_PER = 2, ORC_LBC_GRA = 3, ORC_LBC_CLA = 4, ORC_LBC_RAD = 5,
+       ORC_LBC_RADNUD = 6, ORC_LBC_CHE = 7, ORC_LBC_CHI = 8, ORC_LBC_FLA = 9, ORC_LBC_SHC = 10 };
 
 typedef struct {
   /* sizes */
@@ -85,6 +95,11 @@ typedef struct {
   double blk_ZQ, blk_ZT, blk_ZW;
   int lmd_Jwt;
   double cc1, cc2, cc3;                 /* HSIMT constants mod_scalars.F */
+  /* open boundaries: kinds and the nudging time scales [1/s] of the radiation+nudging conditions
+     (FSobc_in/out ... Tobc_in/out, inp_par.F after read_phypar: Znudg, M2nudg, M3nudg, Tnudg, obcfac) */
+  int lbc[4][ORC_NLBC];
+  double FSobc_in[4], FSobc_out[4], M2obc_in[4], M2obc_out[4], M3obc_in[4], M3obc_out[4];
+  double Tobc_in[ORC_MAXT][4], Tobc_out[ORC_MAXT][4];
 } orc_cfg;
 
 /* time-level state of main3d / mod_stepping */
@@ -108,7 +123,7 @@ typedef struct orc_s {
   /* mod_grid 2-D */
   double *h, *f, *fomn, *pm, *pn, *om_r, *on_r, *om_u, *on_u, *om_v, *on_v, *om_p, *on_p,
       *omn, *pmon_r, *pnom_r, *pmon_p, *pnom_p, *pmon_u, *pnom_u, *pmon_v, *pnom_v,
-      *dmde, *dndx, *angler, *xr, *yr, *lonr, *latr, *rdrag, *rdrag2,
+      *dmde, *dndx, *angler, *xr, *yr, *xp, *yp, *lonr, *latr, *rdrag, *rdrag2,
       *rmask, *umask, *vmask, *pmask;      /* MASKING: 1 water, 0 land (pmask: 2 no-slip); all 1 otherwise */
   /* mod_grid 3-D */
   double *Hz, *z_r, *z_w, *Huon, *Hvom;
@@ -123,6 +138,10 @@ typedef struct orc_s {
   /* mod_mixing */
   double *Akv, *Akt, *visc2_r, *visc2_p, *diff2, *bvf, *alpha, *beta, *hsbl, *ghats;
   int *ksbl;
+  /* mod_boundary: BOUNDARY(ng)%zeta_west(LBj:UBj) ... t_north(LBi:UBi,N,NT): the open-boundary data of this step (inputs) */
+  double *zeta_west, *zeta_south, *zeta_east, *zeta_north, *ubar_west, *ubar_south, *ubar_east, *ubar_north,
+      *vbar_west, *vbar_south, *vbar_east, *vbar_north, *u_west, *u_south, *u_east, *u_north,
+      *v_west, *v_south, *v_east, *v_north, *t_west, *t_south, *t_east, *t_north;
   /* diag results: avgke, avgpe, avgkp, volume, max_speed, Cu_max ... */
   double diag[16];
   void *avg;                             /* time-averaged fields (orc_avg.c), NULL until orc_set_avg_window */
@@ -168,6 +187,12 @@ void orc_v2dbc(const orc_t *o, const orc_bounds *b, int kout);
 void orc_t3dbc(const orc_t *o, const orc_bounds *b, int nout, int itrc);
 void orc_u3dbc(const orc_t *o, const orc_bounds *b, int nout);
 void orc_v3dbc(const orc_t *o, const orc_bounds *b, int nout);
+void orc_bc2d(orc_t *o, int tile, int kout);   /* zetabc, u2dbc, v2dbc of one tile (tests) */
+void orc_bc3d(orc_t *o, int tile, int nout);   /* t3dbc of every tracer; u3dbc, v3dbc when nout <= 2 (tests) */
+
+int orc_lbc(const orc_t *o, int edge, int var);              /* kind with the default resolved (periodic / closed) */
+int orc_lbc_acquire(const orc_t *o, int edge, int var);     /* LBC(edge,var)%acquire as load_lbc sets it (inp_decode.F:1616-1660) */
+int orc_lbc_open(const orc_t *o);                             /* any edge of any variable other than closed / periodic */
 
 /* kernels (tile = 0..ntiles-1) */
 void orc_set_depth(orc_t *o, int tile);

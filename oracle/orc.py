@@ -16,7 +16,13 @@ A4, C2, C4, HSIMT, MPDATA, SPLINES, SPLIT_U3, U3 = range(1, 9)
 SCHEMES = dict(A4=A4, C2=C2, C4=C4, HSIMT=HSIMT, MPDATA=MPDATA, SPLINES=SPLINES, SU3=SPLIT_U3, U3=U3)
 UV_ADV, UV_COR, UV_VIS2, TS_DIF2, MIX_GEO_TS, CURVGRID, NONLIN_EOS, UV_QDRAG, LMD_MIXING, \
     BULK_FLUXES, SOLAR_SOURCE, ANA_VMIX, SALINITY, SPHERICAL, UV_LOGDRAG, MASKING = [1 << k for k in range(16)]
-APP_UPWELLING, APP_BENCHMARK = 1 << 20, 1 << 21
+RADIATION_2D = 1 << 16
+APP_UPWELLING, APP_BENCHMARK, APP_KELVIN = 1 << 20, 1 << 21, 1 << 22
+# lateral boundary conditions (orc.h): edges, variables, kinds
+IWEST, ISOUTH, IEAST, INORTH = range(4)
+ISFSUR, ISUBAR, ISVBAR, ISUVEL, ISVVEL, ISTVAR = range(6)
+NLBC = ISTVAR + MAXT
+LBC_KINDS = dict(Clo=1, Per=2, Gra=3, Cla=4, Rad=5, RadNud=6, Che=7, Cha=8, Fla=9, Shc=10)
 
 
 class Cfg(C.Structure):
@@ -34,6 +40,10 @@ class Cfg(C.Structure):
         ("Akt_bak", C.c_double * MAXT), ("Akv_bak", C.c_double), ("dstart", C.c_double),
         ("blk_ZQ", C.c_double), ("blk_ZT", C.c_double), ("blk_ZW", C.c_double),
         ("lmd_Jwt", C.c_int), ("cc1", C.c_double), ("cc2", C.c_double), ("cc3", C.c_double),
+        ("lbc", (C.c_int * NLBC) * 4),
+        ("FSobc_in", C.c_double * 4), ("FSobc_out", C.c_double * 4), ("M2obc_in", C.c_double * 4),
+        ("M2obc_out", C.c_double * 4), ("M3obc_in", C.c_double * 4), ("M3obc_out", C.c_double * 4),
+        ("Tobc_in", (C.c_double * 4) * MAXT), ("Tobc_out", (C.c_double * 4) * MAXT),
     ]
 
 

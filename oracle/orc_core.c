@@ -112,14 +112,15 @@ static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(doub
 
 typedef struct { const char *name; size_t off; int kind; } fdesc;
 /* kind: number of 2-D planes as a function of N, NT: see field_planes() */
-enum { K2 = 0, KR, KW, K2x3, K2x2, KRx2, KTR, KWx2, K2xNT, KWxNAT, KTAB_R, KTAB_W };
+enum { K2 = 0, KR, KW, K2x3, K2x2, KRx2, KTR, KWx2, K2xNT, KWxNAT, KTAB_R, KTAB_W,
+       KBJ, KBI, KBJN, KBIN, KBJT, KBIT };   /* boundary data: (LBj:UBj) / (LBi:UBi) [, N [, NT]] */
 #define FD(nm, kind) { #nm, offsetof(orc_t, nm), kind }
 static const fdesc fields[] = {
   FD(h, K2), FD(f, K2), FD(fomn, K2), FD(pm, K2), FD(pn, K2), FD(om_r, K2), FD(on_r, K2),
   FD(om_u, K2), FD(on_u, K2), FD(om_v, K2), FD(on_v, K2), FD(om_p, K2), FD(on_p, K2),
   FD(omn, K2), FD(pmon_r, K2), FD(pnom_r, K2), FD(pmon_p, K2), FD(pnom_p, K2),
   FD(pmon_u, K2), FD(pnom_u, K2), FD(pmon_v, K2), FD(pnom_v, K2), FD(dmde, K2), FD(dndx, K2),
-  FD(angler, K2), FD(xr, K2), FD(yr, K2), FD(lonr, K2), FD(latr, K2), FD(rdrag, K2),
+  FD(angler, K2), FD(xr, K2), FD(yr, K2), FD(xp, K2), FD(yp, K2), FD(lonr, K2), FD(latr, K2), FD(rdrag, K2),
   FD(rdrag2, K2), FD(rmask, K2), FD(umask, K2), FD(vmask, K2), FD(pmask, K2),
   FD(Hz, KR), FD(z_r, KR), FD(z_w, KW), FD(Huon, KR), FD(Hvom, KR),
   FD(zeta, K2x3), FD(ubar, K2x3), FD(vbar, K2x3), FD(rzeta, K2x2), FD(rubar, K2x2),
@@ -134,6 +135,12 @@ static const fdesc fields[] = {
   FD(Akv, KW), FD(Akt, KWxNAT), FD(visc2_r, K2), FD(visc2_p, K2), FD(diff2, K2xNT),
   FD(bvf, KW), FD(alpha, K2), FD(beta, K2), FD(hsbl, K2), FD(ghats, KWxNAT),
   FD(sc_r, KTAB_R), FD(Cs_r, KTAB_R), FD(sc_w, KTAB_W), FD(Cs_w, KTAB_W),
+  FD(zeta_west, KBJ), FD(zeta_east, KBJ), FD(zeta_south, KBI), FD(zeta_north, KBI),
+  FD(ubar_west, KBJ), FD(ubar_east, KBJ), FD(ubar_south, KBI), FD(ubar_north, KBI),
+  FD(vbar_west, KBJ), FD(vbar_east, KBJ), FD(vbar_south, KBI), FD(vbar_north, KBI),
+  FD(u_west, KBJN), FD(u_east, KBJN), FD(u_south, KBIN), FD(u_north, KBIN),
+  FD(v_west, KBJN), FD(v_east, KBJN), FD(v_south, KBIN), FD(v_north, KBIN),
+  FD(t_west, KBJT), FD(t_east, KBJT), FD(t_south, KBIT), FD(t_north, KBIT),
 };
 #define NFIELDS (sizeof(fields) / sizeof(fields[0]))
 
@@ -152,6 +159,12 @@ static size_t field_size(const orc_t *o, int kind) {
     case KWxNAT: return p * (N + 1) * NAT;
     case KTAB_R: return N;
     case KTAB_W: return N + 1;
+    case KBJ: return o->nj;
+    case KBI: return o->ni;
+    case KBJN: return o->nj * N;
+    case KBIN: return o->ni * N;
+    case KBJT: return o->nj * N * NT;
+    case KBIT: return o->ni * N * NT;
   }
   return 0;
 }
@@ -310,20 +323,32 @@ void orc_bc_w3d(const orc_t *o, const orc_bounds *b, double *A, int nk) {
   orc_exchange3d(o, b, 'w', A, nk);
 }
 
-/* bc_u2d_tile bc_2d.F:164 with LBC(:,isBu2d)%closed on non-periodic edges */
+/* bc_u2d_tile bc_2d.F:164: LBC(:,isBu2d = isUbar)%closed, else zero gradient (:201-290) */
 void orc_bc_u2d(const orc_t *o, const orc_bounds *b, double *A) {
   ORC_LOCALS(o);
   const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
   const double gamma2 = o->c.gamma2;
   if (!o->c.EWperiodic) {
-    if (b->east) for (int j = Jstr; j <= Jend; j++) A[X2(Iend + 1, j)] = 0.0;
-    if (b->west) for (int j = Jstr; j <= Jend; j++) A[X2(Istr, j)] = 0.0;
+    if (b->east) {
+      if (orc_lbc(o, ORC_IEAST, ORC_ISUBAR) == ORC_LBC_CLO) for (int j = Jstr; j <= Jend; j++) A[X2(Iend + 1, j)] = 0.0;
+      else for (int j = Jstr; j <= Jend; j++) A[X2(Iend + 1, j)] = A[X2(Iend, j)];
+    }
+    if (b->west) {
+      if (orc_lbc(o, ORC_IWEST, ORC_ISUBAR) == ORC_LBC_CLO) for (int j = Jstr; j <= Jend; j++) A[X2(Istr, j)] = 0.0;
+      else for (int j = Jstr; j <= Jend; j++) A[X2(Istr, j)] = A[X2(Istr + 1, j)];
+    }
   }
   if (!o->c.NSperiodic) {
     int Imin = o->c.EWperiodic ? b->IstrU : b->Istr, Imax = o->c.EWperiodic ? b->Iend : b->IendR;
     const double *M = (o->c.options & ORC_MASKING) ? o->umask : NULL;   /* bc_2d.F:252,278 */
-    if (b->north) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
-    if (b->south) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
+    if (b->north) {
+      if (orc_lbc(o, ORC_INORTH, ORC_ISUBAR) == ORC_LBC_CLO) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
+      else for (int i = b->IstrU; i <= Iend; i++) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
+    }
+    if (b->south) {
+      if (orc_lbc(o, ORC_ISOUTH, ORC_ISUBAR) == ORC_LBC_CLO) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
+      else for (int i = b->IstrU; i <= Iend; i++) A[X2(i, Jstr - 1)] = A[X2(i, Jstr)];
+    }
   }
   if (!(o->c.EWperiodic || o->c.NSperiodic)) {
     if (b->sw) A[X2(Istr, Jstr - 1)] = 0.5 * (A[X2(Istr + 1, Jstr - 1)] + A[X2(Istr, Jstr)]);
@@ -334,7 +359,7 @@ void orc_bc_u2d(const orc_t *o, const orc_bounds *b, double *A) {
   orc_exchange2d(o, b, 'u', A);
 }
 
-/* bc_v2d_tile bc_2d.F:342 */
+/* bc_v2d_tile bc_2d.F:342: LBC(:,isBv2d = isVbar)%closed, else zero gradient (:380-470) */
 void orc_bc_v2d(const orc_t *o, const orc_bounds *b, double *A) {
   ORC_LOCALS(o);
   const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
@@ -342,12 +367,24 @@ void orc_bc_v2d(const orc_t *o, const orc_bounds *b, double *A) {
   if (!o->c.EWperiodic) {
     int Jmin = o->c.NSperiodic ? b->JstrV : b->Jstr, Jmax = o->c.NSperiodic ? b->Jend : b->JendR;
     const double *M = (o->c.options & ORC_MASKING) ? o->vmask : NULL;   /* bc_2d.F:392,418 */
-    if (b->east) for (int j = Jmin; j <= Jmax; j++) { A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
-    if (b->west) for (int j = Jmin; j <= Jmax; j++) { A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
+    if (b->east) {
+      if (orc_lbc(o, ORC_IEAST, ORC_ISVBAR) == ORC_LBC_CLO) for (int j = Jmin; j <= Jmax; j++) { A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
+      else for (int j = b->JstrV; j <= Jend; j++) A[X2(Iend + 1, j)] = A[X2(Iend, j)];
+    }
+    if (b->west) {
+      if (orc_lbc(o, ORC_IWEST, ORC_ISVBAR) == ORC_LBC_CLO) for (int j = Jmin; j <= Jmax; j++) { A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
+      else for (int j = b->JstrV; j <= Jend; j++) A[X2(Istr - 1, j)] = A[X2(Istr, j)];
+    }
   }
   if (!o->c.NSperiodic) {
-    if (b->north) for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = 0.0;
-    if (b->south) for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr)] = 0.0;
+    if (b->north) {
+      if (orc_lbc(o, ORC_INORTH, ORC_ISVBAR) == ORC_LBC_CLO) for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = 0.0;
+      else for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
+    }
+    if (b->south) {
+      if (orc_lbc(o, ORC_ISOUTH, ORC_ISVBAR) == ORC_LBC_CLO) for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr)] = 0.0;
+      else for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr)] = A[X2(i, Jstr + 1)];
+    }
   }
   if (!(o->c.EWperiodic || o->c.NSperiodic)) {
     if (b->sw) A[X2(Istr - 1, Jstr)] = 0.5 * (A[X2(Istr, Jstr)] + A[X2(Istr - 1, Jstr + 1)]);
@@ -358,112 +395,4 @@ void orc_bc_v2d(const orc_t *o, const orc_bounds *b, double *A) {
   orc_exchange2d(o, b, 'v', A);
 }
 
-/* ------------------------------------------- lateral BCs of the state (closed) */
-/* zetabc_tile zetabc.F:60 -- closed: zero gradient (:577-590 etc.), corners */
-void orc_zetabc(const orc_t *o, const orc_bounds *b, int kout) {
-  double *A = o->zeta + (size_t)(kout - 1) * o->nij;
-  ORC_LOCALS(o);
-  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
-  const double *M = (o->c.options & ORC_MASKING) ? o->rmask : NULL;   /* MASKING: value * rmask(ghost point), zetabc.F:264 */
-  if (!o->c.EWperiodic) {
-    if (b->west) for (int j = Jstr; j <= Jend; j++) { A[X2(Istr - 1, j)] = A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
-    if (b->east) for (int j = Jstr; j <= Jend; j++) { A[X2(Iend + 1, j)] = A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
-  }
-  if (!o->c.NSperiodic) {
-    if (b->south) for (int i = Istr; i <= Iend; i++) { A[X2(i, Jstr - 1)] = A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
-    if (b->north) for (int i = Istr; i <= Iend; i++) { A[X2(i, Jend + 1)] = A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
-  }
-  if (!(o->c.EWperiodic || o->c.NSperiodic)) {
-    if (b->sw) A[X2(Istr - 1, Jstr - 1)] = 0.5 * (A[X2(Istr, Jstr - 1)] + A[X2(Istr - 1, Jstr)]);
-    if (b->se) A[X2(Iend + 1, Jstr - 1)] = 0.5 * (A[X2(Iend, Jstr - 1)] + A[X2(Iend + 1, Jstr)]);
-    if (b->nw) A[X2(Istr - 1, Jend + 1)] = 0.5 * (A[X2(Istr - 1, Jend)] + A[X2(Istr, Jend + 1)]);
-    if (b->ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend + 1, Jend)] + A[X2(Iend, Jend + 1)]);
-  }
-}
-
-/* u-type closed BC on one plane: normal component zero at W/E walls,
-   gamma2 slip at S/N walls (u2dbc_im.F:51, u3dbc_im.F:50) */
-static void ubc_plane(const orc_t *o, const orc_bounds *b, double *A) {
-  ORC_LOCALS(o);
-  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
-  const double gamma2 = o->c.gamma2;
-  if (!o->c.EWperiodic) {
-    if (b->west) for (int j = Jstr; j <= Jend; j++) A[X2(Istr, j)] = 0.0;
-    if (b->east) for (int j = Jstr; j <= Jend; j++) A[X2(Iend + 1, j)] = 0.0;
-  }
-  if (!o->c.NSperiodic) {
-    int Imin = o->c.EWperiodic ? b->IstrU : b->Istr, Imax = o->c.EWperiodic ? b->Iend : b->IendR;
-    const double *M = (o->c.options & ORC_MASKING) ? o->umask : NULL;   /* u2dbc_im.F:989, u3dbc_im.F:520 */
-    if (b->south) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
-    if (b->north) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
-  }
-  if (!(o->c.EWperiodic || o->c.NSperiodic)) {
-    if (b->sw) A[X2(Istr, Jstr - 1)] = 0.5 * (A[X2(Istr + 1, Jstr - 1)] + A[X2(Istr, Jstr)]);
-    if (b->se) A[X2(Iend + 1, Jstr - 1)] = 0.5 * (A[X2(Iend, Jstr - 1)] + A[X2(Iend + 1, Jstr)]);
-    if (b->nw) A[X2(Istr, Jend + 1)] = 0.5 * (A[X2(Istr, Jend)] + A[X2(Istr + 1, Jend + 1)]);
-    if (b->ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend + 1, Jend)] + A[X2(Iend, Jend + 1)]);
-  }
-}
-
-/* v-type closed BC (v2dbc_im.F:52, v3dbc_im.F:50) */
-static void vbc_plane(const orc_t *o, const orc_bounds *b, double *A) {
-  ORC_LOCALS(o);
-  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
-  const double gamma2 = o->c.gamma2;
-  if (!o->c.EWperiodic) {
-    int Jmin = o->c.NSperiodic ? b->JstrV : b->Jstr, Jmax = o->c.NSperiodic ? b->Jend : b->JendR;
-    const double *M = (o->c.options & ORC_MASKING) ? o->vmask : NULL;   /* v2dbc_im.F:1048, v3dbc_im.F */
-    if (b->west) for (int j = Jmin; j <= Jmax; j++) { A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
-    if (b->east) for (int j = Jmin; j <= Jmax; j++) { A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
-  }
-  if (!o->c.NSperiodic) {
-    if (b->south) for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr)] = 0.0;
-    if (b->north) for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = 0.0;
-  }
-  if (!(o->c.EWperiodic || o->c.NSperiodic)) {
-    if (b->sw) A[X2(Istr - 1, Jstr)] = 0.5 * (A[X2(Istr, Jstr)] + A[X2(Istr - 1, Jstr + 1)]);
-    if (b->se) A[X2(Iend + 1, Jstr)] = 0.5 * (A[X2(Iend, Jstr)] + A[X2(Iend + 1, Jstr + 1)]);
-    if (b->nw) A[X2(Istr - 1, Jend + 1)] = 0.5 * (A[X2(Istr - 1, Jend)] + A[X2(Istr, Jend + 1)]);
-    if (b->ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend + 1, Jend)] + A[X2(Iend, Jend + 1)]);
-  }
-}
-
-void orc_u2dbc(const orc_t *o, const orc_bounds *b, int kout) {
-  ubc_plane(o, b, o->ubar + (size_t)(kout - 1) * o->nij);
-}
-void orc_v2dbc(const orc_t *o, const orc_bounds *b, int kout) {
-  vbc_plane(o, b, o->vbar + (size_t)(kout - 1) * o->nij);
-}
-void orc_u3dbc(const orc_t *o, const orc_bounds *b, int nout) {
-  const size_t N = (size_t)o->c.N;
-  for (size_t k = 0; k < N; k++) ubc_plane(o, b, o->u + ((size_t)(nout - 1) * N + k) * o->nij);
-}
-void orc_v3dbc(const orc_t *o, const orc_bounds *b, int nout) {
-  const size_t N = (size_t)o->c.N;
-  for (size_t k = 0; k < N; k++) vbc_plane(o, b, o->v + ((size_t)(nout - 1) * N + k) * o->nij);
-}
-/* t3dbc_tile t3dbc_im.F:50 -- closed: zero gradient (:477-490), corners */
-void orc_t3dbc(const orc_t *o, const orc_bounds *b, int nout, int itrc) {
-  const size_t N = (size_t)o->c.N;
-  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
-  for (size_t k = 0; k < N; k++) {
-    double *A = o->t + (((size_t)(nout - 1) + 3 * (size_t)(itrc - 1)) * N + k) * o->nij;
-    const int LBi = o->c.LBi, LBj = o->c.LBj;
-    const size_t ni = o->ni;
-    const double *M = (o->c.options & ORC_MASKING) ? o->rmask : NULL;   /* t3dbc_im.F:214 */
-    if (!o->c.EWperiodic) {
-      if (b->west) for (int j = Jstr; j <= Jend; j++) { A[X2(Istr - 1, j)] = A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
-      if (b->east) for (int j = Jstr; j <= Jend; j++) { A[X2(Iend + 1, j)] = A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
-    }
-    if (!o->c.NSperiodic) {
-      if (b->south) for (int i = Istr; i <= Iend; i++) { A[X2(i, Jstr - 1)] = A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
-      if (b->north) for (int i = Istr; i <= Iend; i++) { A[X2(i, Jend + 1)] = A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
-    }
-    if (!(o->c.EWperiodic || o->c.NSperiodic)) {
-      if (b->sw) A[X2(Istr - 1, Jstr - 1)] = 0.5 * (A[X2(Istr, Jstr - 1)] + A[X2(Istr - 1, Jstr)]);
-      if (b->se) A[X2(Iend + 1, Jstr - 1)] = 0.5 * (A[X2(Iend, Jstr - 1)] + A[X2(Iend + 1, Jstr)]);
-      if (b->nw) A[X2(Istr - 1, Jend + 1)] = 0.5 * (A[X2(Istr - 1, Jend)] + A[X2(Istr, Jend + 1)]);
-      if (b->ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend + 1, Jend)] + A[X2(Iend, Jend + 1)]);
-    }
-  }
-}
+/* the lateral boundary conditions of the state (zetabc.F ... t3dbc_im.F), closed and open: orc_obc.c */

@@ -274,7 +274,8 @@ void orc_set_data(orc_t *o, int tile) {
     orc_exchange2d(o, b, 'r', o->srflx);
   }
   double windamp;
-  if ((o->s.tdays - o->c.dstart) <= 2.0)
+  if (!(o->c.options & ORC_APP_UPWELLING)) windamp = 0.0;      /* KELVIN: the default branch of ana_smflux.h, no wind */
+  else if ((o->s.tdays - o->c.dstart) <= 2.0)
     windamp = -0.1 * sin(pi * (o->s.tdays - o->c.dstart) / 4.0) / o->c.rho0;
   else
     windamp = -0.1 / o->c.rho0;
@@ -291,6 +292,41 @@ void orc_set_data(orc_t *o, int tile) {
   }
   orc_exchange2d(o, b, 'u', o->sustr);
   orc_exchange2d(o, b, 'v', o->svstr);
+  if (o->c.options & ORC_APP_KELVIN) {
+    /* set_data.F:881,1003: ana_fsobc.h:85-105 and ana_m2obc.h:169-200, KELVIN branches -- an M2 Kelvin wave of unit
+       amplitude at the western edge, its image after one channel length at the eastern one (the eastern formulas index
+       f, h and yp with this tile's Istr-1 / Iend exactly as the reference does) */
+    const double g = o->c.g, time = o->s.time;
+    const double fac = 1.0, omega = 2.0 * pi / (12.42 * 3600.0);
+    const int Istr = b->Istr, Iend = b->Iend;
+    if (orc_lbc_acquire(o, ORC_IWEST, ORC_ISFSUR) && b->west)
+      for (int j = b->JstrT; j <= b->JendT; j++) {
+        const double val = fac * exp(-o->f[X2(Istr - 1, j)] * o->yp[X2(Istr - 1, j)] / sqrt(g * o->h[X2(Istr - 1, j)]));
+        o->zeta_west[j - LBj] = val * cos(omega * time);
+      }
+    if (orc_lbc_acquire(o, ORC_IEAST, ORC_ISFSUR) && b->east)
+      for (int j = b->JstrT; j <= b->JendT; j++) {
+        const double cff = 1.0 / sqrt(g * o->h[X2(Istr - 1, j)]);
+        const double val = fac * exp(-o->f[X2(Istr - 1, j)] * o->yp[X2(Iend, j)] * cff);
+        o->zeta_east[j - LBj] = val * cos(omega * o->xp[X2(Iend, j)] * cff - omega * time);
+      }
+    const double val0 = fac * sin(omega * time);
+    if (orc_lbc_acquire(o, ORC_IWEST, ORC_ISUBAR) && orc_lbc_acquire(o, ORC_IWEST, ORC_ISVBAR) && b->west) {
+      for (int j = b->JstrT; j <= b->JendT; j++) {
+        const double cff = sqrt(g * o->h[X2(Istr - 1, j)]);
+        o->ubar_west[j - LBj] = (val0 * cff / o->h[X2(Istr - 1, j)]) * exp(-o->f[X2(Istr - 1, j)] * o->yp[X2(Istr - 1, j)] / cff);
+      }
+      for (int j = b->JstrP; j <= b->JendT; j++) o->vbar_west[j - LBj] = 0.0;
+    }
+    if (orc_lbc_acquire(o, ORC_IEAST, ORC_ISUBAR) && orc_lbc_acquire(o, ORC_IEAST, ORC_ISVBAR) && b->east) {
+      for (int j = b->JstrT; j <= b->JendT; j++) {
+        const double cff = sqrt(g * o->h[X2(Iend, j)]);
+        const double val = fac * exp(-o->f[X2(Iend, j)] * o->yp[X2(Istr - 1, j)] / cff);
+        o->ubar_east[j - LBj] = (val * cff / o->h[X2(Iend, j)]) * sin(omega * o->xp[X2(Iend, j)] / cff - omega * time);
+      }
+      for (int j = b->JstrP; j <= b->JendT; j++) o->vbar_east[j - LBj] = 0.0;
+    }
+  }
 }
 
 /* ----------------------------------------------------------------- omega */
@@ -400,11 +436,18 @@ void orc_ini_zeta(orc_t *o, int tile) {
   const orc_bounds *b = &o->b[tile];
   const int kstp = o->s.kstp;
   /* the load zeta(kstp)=zeta(kstp) over IstrB:IendB is an identity without masks; with them :838-849 */
+  /* radiation / Chapman conditions need the boundary values of the initial state: the load then covers them and no
+     condition is applied (ini_fields.F:830-871) */
+  int keep = 0;
+  for (int e = 0; e < 4; e++) {
+    const int k = orc_lbc(o, e, ORC_ISFSUR);
+    keep |= k == ORC_LBC_RAD || k == ORC_LBC_RADNUD || k == ORC_LBC_CHE || k == ORC_LBC_CHI;
+  }
   if (o->c.options & ORC_MASKING)
-    for (int j = b->JstrB; j <= b->JendB; j++)
-      for (int i = b->IstrB; i <= b->IendB; i++)
+    for (int j = keep ? b->JstrT : b->JstrB; j <= (keep ? b->JendT : b->JendB); j++)
+      for (int i = keep ? b->IstrT : b->IstrB; i <= (keep ? b->IendT : b->IendB); i++)
         o->zeta[X2T(i, j, kstp)] = o->zeta[X2T(i, j, kstp)] * o->rmask[X2(i, j)];
-  orc_zetabc(o, b, kstp);
+  if (!keep) orc_zetabc(o, b, kstp);
   orc_exchange2d(o, b, 'r', o->zeta + (size_t)(kstp - 1) * nij);
   for (int j = b->JstrT; j <= b->JendT; j++)
     for (int i = b->IstrT; i <= b->IendT; i++) o->Zt_avg1[X2(i, j)] = o->zeta[X2T(i, j, kstp)];
@@ -465,8 +508,18 @@ void orc_ini_fields(orc_t *o, int tile) {
 #undef DCx
   free(DC);
   free(CF);
-  orc_u2dbc(o, b, kstp);
-  orc_v2dbc(o, b, kstp);
+  {   /* not with radiation or Flather conditions on the barotropic momentum (ini_fields.F:412-425) */
+    int keep = 0;
+    for (int e = 0; e < 4; e++)
+      for (int var = ORC_ISUBAR; var <= ORC_ISVBAR; var++) {
+        const int k = orc_lbc(o, e, var);
+        keep |= k == ORC_LBC_RAD || k == ORC_LBC_RADNUD || k == ORC_LBC_FLA;
+      }
+    if (!keep) {
+      orc_u2dbc(o, b, kstp);
+      orc_v2dbc(o, b, kstp);
+    }
+  }
   orc_exchange2d(o, b, 'u', o->ubar + (size_t)(kstp - 1) * nij);
   orc_exchange2d(o, b, 'v', o->vbar + (size_t)(kstp - 1) * nij);
   if (msk)                                                                /* t(nstp) * rmask :546-556 */

@@ -258,21 +258,24 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
       }
   }
   /* boundary values of Ua, Va (closed walls of the BASELINE configs) :642-720 */
+  /* LBC(:,isBu3d = isUvel)%closed: no flow; any other kind: zero gradient (:696-760) */
+  const int cw = orc_lbc(o, ORC_IWEST, ORC_ISUVEL) == ORC_LBC_CLO, ce = orc_lbc(o, ORC_IEAST, ORC_ISUVEL) == ORC_LBC_CLO;
+  const int cs = orc_lbc(o, ORC_ISOUTH, ORC_ISVVEL) == ORC_LBC_CLO, cn = orc_lbc(o, ORC_INORTH, ORC_ISVVEL) == ORC_LBC_CLO;
   if (!c->EWperiodic) {
     if (b->west)
       for (int k = 1; k <= N; k++)
-        for (int j = b->Jstrm1; j <= b->Jendp1; j++) Ua[X3(Istr, j, k)] = 0.0;
+        for (int j = b->Jstrm1; j <= b->Jendp1; j++) Ua[X3(Istr, j, k)] = cw ? 0.0 : Ua[X3(Istr + 1, j, k)];
     if (b->east)
       for (int k = 1; k <= N; k++)
-        for (int j = b->Jstrm1; j <= b->Jendp1; j++) Ua[X3(Iend + 1, j, k)] = 0.0;
+        for (int j = b->Jstrm1; j <= b->Jendp1; j++) Ua[X3(Iend + 1, j, k)] = ce ? 0.0 : Ua[X3(Iend, j, k)];
   }
   if (!c->NSperiodic) {
     if (b->south)
       for (int k = 1; k <= N; k++)
-        for (int i = b->Istrm1; i <= b->Iendp1; i++) Va[X3(i, Jstr, k)] = 0.0;
+        for (int i = b->Istrm1; i <= b->Iendp1; i++) Va[X3(i, Jstr, k)] = cs ? 0.0 : Va[X3(i, Jstr + 1, k)];
     if (b->north)
       for (int k = 1; k <= N; k++)
-        for (int i = b->Istrm1; i <= b->Iendp1; i++) Va[X3(i, Jend + 1, k)] = 0.0;
+        for (int i = b->Istrm1; i <= b->Iendp1; i++) Va[X3(i, Jend + 1, k)] = cn ? 0.0 : Va[X3(i, Jend, k)];
   }
   /* ---- Wa :722-860 */
   for (int j = JstrV - 1; j <= b->Jendp1; j++) {
@@ -399,18 +402,18 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
   if (!c->EWperiodic) {
     if (b->west)
       for (int k = 1; k <= N; k++)
-        for (int j = Jstr; j <= Jend; j++) Ua[X3(Istr, j, k)] = 0.0;
+        for (int j = Jstr; j <= Jend; j++) Ua[X3(Istr, j, k)] = cw ? 0.0 : Ua[X3(Istr + 1, j, k)];
     if (b->east)
       for (int k = 1; k <= N; k++)
-        for (int j = Jstr; j <= Jend; j++) Ua[X3(Iend + 1, j, k)] = 0.0;
+        for (int j = Jstr; j <= Jend; j++) Ua[X3(Iend + 1, j, k)] = ce ? 0.0 : Ua[X3(Iend, j, k)];
   }
   if (!c->NSperiodic) {
     if (b->south)
       for (int k = 1; k <= N; k++)
-        for (int i = Istr; i <= Iend; i++) Va[X3(i, Jstr, k)] = 0.0;
+        for (int i = Istr; i <= Iend; i++) Va[X3(i, Jstr, k)] = cs ? 0.0 : Va[X3(i, Jstr + 1, k)];
     if (b->north)
       for (int k = 1; k <= N; k++)
-        for (int i = Istr; i <= Iend; i++) Va[X3(i, Jend + 1, k)] = 0.0;
+        for (int i = Istr; i <= Iend; i++) Va[X3(i, Jend + 1, k)] = cn ? 0.0 : Va[X3(i, Jend, k)];
   }
   free(odz);
   free(C);

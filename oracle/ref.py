@@ -21,8 +21,8 @@ class Ref:
         self.L = C.CDLL(os.path.join(HERE, "_ref", f"libromsref_{app}.so"))
         self.L.ref_field.restype = C.c_long
         self.L.ref_call.restype = C.c_int
-        ip = (C.c_int * 32)(*ipar)
-        rp = (C.c_double * 32)(*rpar)
+        ip = (C.c_int * 64)(*ipar)
+        rp = (C.c_double * 96)(*rpar)
         self.L.ref_configure(ip, rp)
         b = self.bounds(0)
         self.LBi, self.UBi, self.LBj, self.UBj = b[:4]

@@ -24,7 +24,7 @@
 # build of the same application gives.  main3d.F itself (USEs the NetCDF readers
 # and writers) stays out; ref_glue.F90 calls the reference kernels in its order.
 #
-# usage: build_ref.sh upwelling|benchmark|upwelling_kpp
+# usage: build_ref.sh upwelling|benchmark|upwelling_kpp|...|kelvin|kelvin_splines
 # (upwelling_kpp = the custom application header oracle/ref/upwelling_kpp.h of BASELINE config 5)
 set -e
 APP=${1:-upwelling}
@@ -64,6 +64,11 @@ if [ "$APP" = upwelling_avg_mask ]; then
   # AVERAGES + MASKING (oracle/ref/upwelling_avg_mask.h)
   UP=UPWELLING; HDR=upwelling_avg_mask; HDRPATH="$HERE/upwelling_avg_mask.h"
   EXTRA="-I$HERE/functionals"
+fi
+if [ "$APP" = kelvin_splines ]; then
+  # the KELVIN case (open boundaries) with the spline vertical solvers (oracle/ref/kelvin_splines.h)
+  UP=KELVIN; HDR=kelvin_splines; HDRPATH="$HERE/kelvin_splines.h"
+  EXTRA=""
 fi
 if [ "$APP" = upwelling_avg ]; then
   # the UPWELLING case with AVERAGES (oracle/ref/upwelling_avg.h): pins set_avg.F

@@ -127,6 +127,70 @@
         END DO
       END DO
 !
+!  Open boundaries: ipar(17+4*(v-1)+(ibry-1)) = kind of variable v (1 isFsur, 2 isUbar, 3 isVbar, 4 isUvel,
+!  5 isVvel, 6.. isTvar) at edge ibry (iwest, isouth, ieast, inorth), coded as oracle/orc.h does (0 = leave the
+!  default above; 1 Clo 2 Per 3 Gra 4 Cla 5 Rad 6 RadNud 7 Che 8 Cha 9 Fla 10 Shc); flags as load_lbc sets them
+!  for the roms.in keywords (Utility/inp_decode.F:1616-1660).
+!
+      DO itrc=1,5+NT(ng)
+        SELECT CASE (itrc)
+          CASE (1); ivar=isFsur
+          CASE (2); ivar=isUbar
+          CASE (3); ivar=isVbar
+          CASE (4); ivar=isUvel
+          CASE (5); ivar=isVvel
+          CASE DEFAULT; ivar=isTvar(itrc-5)
+        END SELECT
+        DO ibry=1,4
+          tile=ipar(17+4*(MIN(itrc,7)-1)+(ibry-1))
+          IF (tile.ne.0) THEN
+            LBC(ibry,ivar,ng)%closed=.FALSE.
+            LBC(ibry,ivar,ng)%periodic=.FALSE.
+          END IF
+          SELECT CASE (tile)
+            CASE (1); LBC(ibry,ivar,ng)%closed=.TRUE.
+            CASE (2); LBC(ibry,ivar,ng)%periodic=.TRUE.
+            CASE (3); LBC(ibry,ivar,ng)%gradient=.TRUE.
+            CASE (4); LBC(ibry,ivar,ng)%clamped=.TRUE.
+                      LBC(ibry,ivar,ng)%acquire=.TRUE.
+            CASE (5); LBC(ibry,ivar,ng)%radiation=.TRUE.
+            CASE (6); LBC(ibry,ivar,ng)%radiation=.TRUE.
+                      LBC(ibry,ivar,ng)%nudging=.TRUE.
+                      LBC(ibry,ivar,ng)%acquire=.TRUE.
+            CASE (7); LBC(ibry,ivar,ng)%Chapman_explicit=.TRUE.
+            CASE (8); LBC(ibry,ivar,ng)%Chapman_implicit=.TRUE.
+            CASE (9); LBC(ibry,ivar,ng)%Flather=.TRUE.
+                      LBC(ibry,ivar,ng)%acquire=.TRUE.
+                      LBC(ibry,isFsur,ng)%acquire=.TRUE.
+            CASE (10); LBC(ibry,ivar,ng)%Shchepetkin=.TRUE.
+                      LBC(ibry,ivar,ng)%acquire=.TRUE.
+                      LBC(ibry,isFsur,ng)%acquire=.TRUE.
+          END SELECT
+        END DO
+      END DO
+!  the test feeds boundary data of every variable: have all of mod_boundary's arrays allocated
+      IF (ipar(45).ne.0) THEN
+        DO ivar=1,nLBCvar
+          DO ibry=1,4
+            LBC(ibry,ivar,ng)%acquire=.TRUE.
+          END DO
+        END DO
+      END IF
+!  nudging time scales (1/s) as inp_par.F:726-752 derives them: rpar(26+(ibry-1)+4*q), q = 0 FSobc_in, 1 FSobc_out,
+!  2 M2obc_in, 3 M2obc_out, 4 M3obc_in, 5 M3obc_out, 6 Tobc_in(1), 7 Tobc_out(1), 8 Tobc_in(2), 9 Tobc_out(2)
+      DO ibry=1,4
+        FSobc_in (ng,ibry)=rpar(26+(ibry-1))
+        FSobc_out(ng,ibry)=rpar(30+(ibry-1))
+        M2obc_in (ng,ibry)=rpar(34+(ibry-1))
+        M2obc_out(ng,ibry)=rpar(38+(ibry-1))
+        M3obc_in (ng,ibry)=rpar(42+(ibry-1))
+        M3obc_out(ng,ibry)=rpar(46+(ibry-1))
+        DO itrc=1,NT(ng)
+          Tobc_in (itrc,ng,ibry)=rpar(50+8*(MIN(itrc,2)-1)+(ibry-1))
+          Tobc_out(itrc,ng,ibry)=rpar(54+8*(MIN(itrc,2)-1)+(ibry-1))
+        END DO
+      END DO
+!
 !  Physical parameters (read_phypar).
 !
       ntimes(ng)=ipar(7)
@@ -354,6 +418,12 @@
 #endif
 #if defined BULK_FLUXES && defined ANA_PAIR
       CALL ana_pair (ng, tile, iNLM)                     ! :628
+#endif
+#ifdef ANA_FSOBC
+      CALL ana_fsobc (ng, tile, iNLM)                    ! :881
+#endif
+#ifdef ANA_M2OBC
+      CALL ana_m2obc (ng, tile, iNLM)                    ! :1003
 #endif
       END SUBROUTINE ref_set_data
 !
@@ -988,6 +1058,8 @@
 #endif
         F2('grdscl',GRID(ng)%grdscl)
         F2('xr',GRID(ng)%xr)
+        F2('xp',GRID(ng)%xp)
+        F2('yp',GRID(ng)%yp)
         F2('yr',GRID(ng)%yr)
         F2('angler',GRID(ng)%angler)
 #ifdef CURVGRID
@@ -1099,6 +1171,32 @@
         F2('evap',FORCES(ng)%evap)
 #endif
 #endif
+!  open-boundary data (mod_boundary.F; pointers, associated where LBC(...)%acquire)
+#define FB(nm,arr) CASE (nm); IF (associated(arr)) THEN; nel=SIZE(arr); CALL cp2(arr,SIZE(arr),dir,buf); END IF
+        FB('zeta_west',BOUNDARY(ng)%zeta_west)
+        FB('zeta_east',BOUNDARY(ng)%zeta_east)
+        FB('zeta_south',BOUNDARY(ng)%zeta_south)
+        FB('zeta_north',BOUNDARY(ng)%zeta_north)
+        FB('ubar_west',BOUNDARY(ng)%ubar_west)
+        FB('ubar_east',BOUNDARY(ng)%ubar_east)
+        FB('ubar_south',BOUNDARY(ng)%ubar_south)
+        FB('ubar_north',BOUNDARY(ng)%ubar_north)
+        FB('vbar_west',BOUNDARY(ng)%vbar_west)
+        FB('vbar_east',BOUNDARY(ng)%vbar_east)
+        FB('vbar_south',BOUNDARY(ng)%vbar_south)
+        FB('vbar_north',BOUNDARY(ng)%vbar_north)
+        FB('u_west',BOUNDARY(ng)%u_west)
+        FB('u_east',BOUNDARY(ng)%u_east)
+        FB('u_south',BOUNDARY(ng)%u_south)
+        FB('u_north',BOUNDARY(ng)%u_north)
+        FB('v_west',BOUNDARY(ng)%v_west)
+        FB('v_east',BOUNDARY(ng)%v_east)
+        FB('v_south',BOUNDARY(ng)%v_south)
+        FB('v_north',BOUNDARY(ng)%v_north)
+        FB('t_west',BOUNDARY(ng)%t_west)
+        FB('t_east',BOUNDARY(ng)%t_east)
+        FB('t_south',BOUNDARY(ng)%t_south)
+        FB('t_north',BOUNDARY(ng)%t_north)
       END SELECT
       END FUNCTION ref_field
 

@@ -4,6 +4,62 @@ turns into a roms.in for any grid size.  Used by bench.py, roms_amd.tiling and t
 import numpy as np
 
 SCHEME = dict(A4=1, C2=2, C4=3, HSIMT=4, MPDATA=5, SPLINES=6, SU3=7, U3=8)
+# lateral boundary conditions: the LBC(isFsur) ... LBC(isTvar) lines of roms.in, one keyword per edge in the file's
+# order west, south, east, north (`lbc` of a case dict: variable -> four keywords; absent = closed or periodic)
+LBC_VARS = ("zeta", "ubar", "vbar", "u", "v", "temp", "salt")
+LBC_KINDS = dict(Clo=1, Per=2, Gra=3, Cla=4, Rad=5, RadNud=6, Che=7, Cha=8, Fla=9, Shc=10)
+
+
+def lbc_codes(cs):
+    """[variable][edge] kind codes of include/roms_hip.h (ROMS_LBC_*), 0 where the case says nothing"""
+    out = []
+    for v in LBC_VARS:
+        kw = cs.get("lbc", {}).get(v)
+        out.append([LBC_KINDS[k] for k in kw] if kw else [0, 0, 0, 0])
+    return out
+
+
+def obc_scales(cs):
+    """FSobc_in/out, M2obc_in/out, M3obc_in/out [edge] and Tobc_in/out [tracer][edge] in 1/s from the roms.in values
+    ZNUDG, M2NUDG, M3NUDG, TNUDG (days) and OBCFAC, as Utility/inp_par.F:696-752 derives them (set on edges whose
+    condition nudges, zero elsewhere)"""
+    inv = lambda d: 1.0 / (d * 86400.0) if d > 0.0 else 0.0
+    fac = cs.get("obcfac", 0.0)
+    Z, M2, M3 = inv(cs.get("Znudg", 0.0)), inv(cs.get("M2nudg", 0.0)), inv(cs.get("M3nudg", 0.0))
+    T = [inv(x) for x in cs.get("Tnudg", (0.0, 0.0))]
+    code = lbc_codes(cs)
+    nud = lambda v, e: code[v][e] == LBC_KINDS["RadNud"]
+    o = dict(FSobc_in=[0.0] * 4, FSobc_out=[0.0] * 4, M2obc_in=[0.0] * 4, M2obc_out=[0.0] * 4, M3obc_in=[0.0] * 4,
+             M3obc_out=[0.0] * 4, Tobc_in=[[0.0] * 4, [0.0] * 4], Tobc_out=[[0.0] * 4, [0.0] * 4])
+    for e in range(4):
+        if nud(0, e):
+            o["FSobc_out"][e], o["FSobc_in"][e] = Z, fac * Z
+        if nud(1, e) or nud(2, e):
+            o["M2obc_out"][e], o["M2obc_in"][e] = M2, fac * M2
+        if nud(3, e) or nud(4, e):
+            o["M3obc_out"][e], o["M3obc_in"][e] = M3, fac * M3
+        for it in range(2):
+            if nud(5 + it, e):
+                o["Tobc_out"][it][e], o["Tobc_in"][it][e] = T[it], fac * T[it]
+    return o
+
+
+def kelvin(Lm=50, Mm=30, N=10, NtileI=1, NtileJ=1, ntimes=96, lbc=None):
+    """roms_kelvin.in (ROMS/Include/kelvin.h): a Kelvin wave forced through the western boundary of a flat channel --
+    Chapman / Flather conditions west, radiation east (RADIATION_2D), closed walls south and north.  The second tracer
+    is carried passively (the library has two tracers; the reference application has NAT = 1)."""
+    open_ = ("Rad", "Clo", "Rad", "Clo")
+    return dict(
+        app="kelvin", Lm=Lm, Mm=Mm, N=N, NtileI=NtileI, NtileJ=NtileJ, ndtfast=60, ntimes=ntimes,
+        Vtransform=2, Vstretching=4, EWperiodic=0, NSperiodic=0, hadv=("U3", "U3"), vadv=("C4", "C4"), lmd_Jwt=1,
+        dt=900.0, theta_s=0.0, theta_b=0.0, Tcline=1.0e16, rho0=1025.0, R0=1027.0, T0=10.0, S0=35.0,
+        Tcoef=1.7e-4, Scoef=7.6e-4, visc2=0.0, tnu2=(20.0, 0.0), Akt_bak=(1.0e-6, 1.0e-6), Akv_bak=1.0e-5,
+        rdrg=3.0e-4, rdrg2=3.0e-3, Zob=0.02, Zos=0.02, gamma2=1.0, dstart=0.0,
+        blk_ZQ=10.0, blk_ZT=10.0, blk_ZW=10.0,
+        options=("UV_ADV", "UV_COR", "UV_QDRAG", "UV_VIS2", "TS_DIF2", "RADIATION_2D", "APP_KELVIN"),
+        lbc=lbc if lbc is not None else dict(zeta=("Cha", "Clo", "Rad", "Clo"), ubar=("Fla", "Clo", "Rad", "Clo"),
+                                             vbar=("Fla", "Clo", "Rad", "Clo"), u=open_, v=open_, temp=open_, salt=open_),
+    )
 
 
 def upwelling(Lm=41, Mm=80, N=16, NtileI=1, NtileJ=1, hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"),

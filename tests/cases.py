@@ -2,7 +2,7 @@
 the oracle (oracle/orc.h) and of the reference glue (oracle/ref/ref_glue.F90).  TEST INFRASTRUCTURE."""
 import numpy as np
 
-from roms_amd.cases import SCHEME, benchmark, hip_cfg, upwelling, upwelling_kpp, upwelling_logdrag, upwelling_mask, benchmark_mask, land_mask  # noqa: F401  (re-exported)
+from roms_amd.cases import SCHEME, benchmark, hip_cfg, upwelling, upwelling_kpp, upwelling_logdrag, upwelling_mask, benchmark_mask, land_mask, kelvin, lbc_codes, obc_scales  # noqa: F401  (re-exported)
 
 
 def ref_params(cs):
@@ -15,7 +15,24 @@ def ref_params(cs):
             cs["S0"], cs["Tcoef"], cs["Scoef"], cs["visc2"], cs["tnu2"][0], cs["tnu2"][1],
             cs["Akt_bak"][0], cs["Akt_bak"][1], cs["Akv_bak"], cs["rdrg"], cs["rdrg2"], cs["Zob"],
             cs["Zos"], cs["gamma2"], cs["dstart"], cs["blk_ZQ"], cs["blk_ZT"], cs["blk_ZW"]]
-    return ipar + [0] * (32 - len(ipar)), rpar + [0.0] * (32 - len(rpar))
+    ipar = ipar + [0] * (64 - len(ipar))
+    rpar = rpar + [0.0] * (96 - len(rpar))
+    # open boundaries (ref_glue.F90:ref_configure): kinds from ipar(17), nudging scales from rpar(26); ipar(45): all
+    # of mod_boundary's arrays allocated (the test feeds boundary data)
+    code = lbc_codes(cs)
+    for v in range(7):
+        for e in range(4):
+            ipar[16 + 4 * v + e] = code[v][e]
+    ipar[44] = 1 if cs.get("bry_all") else 0
+    sc = obc_scales(cs)
+    for q, n in enumerate(["FSobc_in", "FSobc_out", "M2obc_in", "M2obc_out", "M3obc_in", "M3obc_out"]):
+        for e in range(4):
+            rpar[25 + 4 * q + e] = sc[n][e]
+    for it in range(2):
+        for e in range(4):
+            rpar[49 + 8 * it + e] = sc["Tobc_in"][it][e]
+            rpar[53 + 8 * it + e] = sc["Tobc_out"][it][e]
+    return ipar, rpar
 
 
 def oracle_cfg(cs, hc, nfast, weight):
@@ -51,6 +68,16 @@ def oracle_cfg(cs, hc, nfast, weight):
     c.dstart = cs["dstart"]
     c.blk_ZQ, c.blk_ZT, c.blk_ZW, c.lmd_Jwt = cs["blk_ZQ"], cs["blk_ZT"], cs["blk_ZW"], cs["lmd_Jwt"]
     c.cc1, c.cc2, c.cc3 = 0.25, 0.5, 1.0 / 12.0
+    code = lbc_codes(cs)
+    sc = obc_scales(cs)
+    for e in range(4):
+        for v in range(5):
+            c.lbc[e][v] = code[v][e]
+        for it in range(2):
+            c.lbc[e][5 + it] = code[5 + it][e]
+            c.Tobc_in[it][e], c.Tobc_out[it][e] = sc["Tobc_in"][it][e], sc["Tobc_out"][it][e]
+        for n in ("FSobc_in", "FSobc_out", "M2obc_in", "M2obc_out", "M3obc_in", "M3obc_out"):
+            getattr(c, n)[e] = sc[n][e]
     return c
 
 

@@ -5,6 +5,7 @@ usage: python -m tests.refchild <mode> <case tag> [key=value ...]
   main3d    nsteps=N [hadv=a,b vadv=a,b NtileI=n NtileJ=n tol=x]   whole steps, every state array, every step
   kernels   [hadv= vadv=]      the six core routines one by one on a randomly perturbed mid-run state
   physics                      BENCHMARK physics routines one by one on a perturbed state
+  obc       preset=A..F        zetabc, u2dbc, v2dbc, u3dbc, v3dbc, t3dbc with open-boundary kinds on all four edges
 """
 import sys
 
@@ -20,6 +21,8 @@ def parse(argv):
         k, v = a.split("=")
         if k in ("hadv", "vadv"):
             kw[k] = tuple(v.split(","))
+        elif k == "preset":
+            kw[k] = v
         elif k == "tol":
             kw[k] = float(v)
         else:
@@ -137,6 +140,90 @@ def mode_kernels(tag, kw):
         print("KERNELS-OK bitwise")
 
 
+# kinds per variable and edge (west, south, east, north) of the routine-level open-boundary tests: every kind of every
+# routine appears on every edge in one preset or another
+OBC_PRESETS = {
+    "A": dict(zeta=("Cha",) * 4, ubar=("Fla",) * 4, vbar=("Fla",) * 4, u=("Rad",) * 4, v=("Rad",) * 4, temp=("Rad",) * 4, salt=("Rad",) * 4),
+    "B": dict(zeta=("Che",) * 4, ubar=("Shc",) * 4, vbar=("Shc",) * 4, u=("Gra",) * 4, v=("Gra",) * 4, temp=("Cla",) * 4, salt=("Gra",) * 4),
+    "C": dict(zeta=("Rad",) * 4, ubar=("Rad",) * 4, vbar=("Rad",) * 4, u=("RadNud",) * 4, v=("RadNud",) * 4, temp=("RadNud",) * 4, salt=("RadNud",) * 4),
+    "D": dict(zeta=("RadNud",) * 4, ubar=("RadNud",) * 4, vbar=("RadNud",) * 4, u=("Cla",) * 4, v=("Cla",) * 4, temp=("Gra",) * 4, salt=("Cla",) * 4),
+    "E": dict(zeta=("Cla",) * 4, ubar=("Cla",) * 4, vbar=("Cla",) * 4, u=("Clo",) * 4, v=("Clo",) * 4, temp=("Clo",) * 4, salt=("Clo",) * 4),
+    # a different kind on every edge
+    "F": dict(zeta=("Cha", "Rad", "Gra", "Clo"), ubar=("Fla", "Rad", "Shc", "Clo"), vbar=("Shc", "Clo", "Rad", "Fla"),
+              u=("Rad", "Clo", "Gra", "Cla"), v=("Clo", "Rad", "Cla", "Gra"), temp=("Rad", "Cla", "Clo", "Gra"), salt=("Gra", "RadNud", "Rad", "Clo")),
+    "G": dict(zeta=("Clo", "Cha", "Rad", "Che"), ubar=("Gra", "Fla", "Clo", "Shc"), vbar=("Rad", "Gra", "Fla", "Clo"),
+              u=("Gra", "Rad", "Clo", "RadNud"), v=("Rad", "Gra", "RadNud", "Clo"), temp=("Clo", "Rad", "Gra", "Cla"), salt=("Rad", "Clo", "Cla", "Gra")),
+}
+BRY = [n + "_" + e for n in ("zeta", "ubar", "vbar", "u", "v", "t") for e in ("west", "east", "south", "north")]
+
+
+def mode_obc(tag, kw):
+    """The six boundary-condition routines of the reference (zetabc_tile, u2dbc_tile, v2dbc_tile through ref_bc2d;
+    t3dbc_tile, u3dbc_tile, v3dbc_tile through ref_bc3d) against the oracle's on a random state with random boundary
+    data, for the stepping variants that select `know` and `dt2d` (zetabc.F:100-112)."""
+    import ctypes as C
+    preset = kw.pop("preset")
+    kw["lbc"] = OBC_PRESETS[preset]
+    kw.update(bry_all=1, Znudg=0.5, M2nudg=0.25, M3nudg=2.0, Tnudg=(1.0, 3.0), obcfac=4.0)
+    app, cs = rd.make_case(tag, **kw)
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    O = rd.oracle_from(R, cs)
+    O.start()
+    names = [n for n in rd.shared_fields(R, O) if n in ("zeta", "ubar", "vbar", "u", "v", "t")]
+    rng = np.random.default_rng(5)
+    res = []
+    nb = 0
+    for n in BRY:
+        a = O.field(n)
+        a[:] = rng.standard_normal(a.size) * (0.05 if n[0] in "zuv" else 1.0) + (10.0 if n[0] == "t" else 0.0)
+        if R.has(n):
+            R.put(n, a)
+            nb += 1
+    for var, amp, base in (("zeta", 0.2, 0.0), ("ubar", 0.1, 0.0), ("vbar", 0.1, 0.0), ("u", 0.1, 0.0), ("v", 0.1, 0.0), ("t", 0.5, 10.0)):
+        a = O.field(var)
+        a[:] = base + amp * rng.standard_normal(a.size)
+        R.put(var, a)
+    for n in ("sustr", "svstr", "bustr", "bvstr"):
+        a = O.field(n)
+        a[:] = 1e-4 * rng.standard_normal(a.size)
+        R.put(n, a)
+    a = O.field("h")                      # (an application's analytic depth need not cover the rim of a grid it was not made for)
+    a[:] = 40.0 + 10.0 * rng.random(a.size)
+    R.put("h", a)
+
+    def both(what, lev, **st):
+        for k, v in st.items():
+            setattr(O.step, k, v)
+        rd.sync_stepping(R, O)
+        if what == "bc2d":
+            R.L.ref_bc2d(C.c_int(lev))
+        else:
+            R.L.ref_bc3d(C.c_int(lev))
+        for tile in range(cs["NtileI"] * cs["NtileJ"]):
+            getattr(O.L, "orc_" + what)(C.c_void_p(O.h), C.c_int(tile), C.c_int(lev))
+        res.append((what, lev, dict(st), rd.mismatches(R, O, names)))
+
+    base = dict(iic=4, nstp=2, nnew=1, nrhs=2)
+    both("bc2d", 3, iif=1, predictor=1, indx1=1, kstp=1, knew=3, krhs=1, **base)
+    both("bc2d", 2, iif=1, predictor=0, indx1=2, kstp=1, knew=2, krhs=3, **base)
+    both("bc2d", 3, iif=2, predictor=1, indx1=2, kstp=1, knew=3, krhs=2, **base)
+    both("bc2d", 1, iif=2, predictor=0, indx1=1, kstp=2, knew=1, krhs=3, **base)
+    both("bc3d", 1, **base)
+    both("bc3d", 3, **base)
+    both("bc3d", 2, iic=5, nstp=1, nnew=2, nrhs=1)
+    rd.unquiet(saved)
+    nbad = 0
+    # (to stderr: the reference's own set-up report is still in the Fortran unit's buffer and reaches stdout at exit)
+    for what, lev, st, bad in res:
+        if bad:
+            nbad += 1
+            print("MISMATCH", what, lev, st, bad[:6], file=sys.stderr)
+    print("calls", len(res), "fields", len(names), "boundary arrays", nb, file=sys.stderr)
+    if nbad == 0 and nb == 24 and len(names) == 6:
+        print("OBC-OK bitwise", file=sys.stderr)
+
+
 def mode_physics(tag, kw):
     """The physics of the headline bench configuration, routine by routine (Next round #2)."""
     app, cs = rd.make_case(tag, **kw)
@@ -249,4 +336,4 @@ def mode_avg(tag, kw):
 
 if __name__ == "__main__":
     mode, tag = sys.argv[1], sys.argv[2]
-    {"main3d": mode_main3d, "kernels": mode_kernels, "physics": mode_physics, "avg": mode_avg}[mode](tag, parse(sys.argv[3:]))
+    {"main3d": mode_main3d, "kernels": mode_kernels, "physics": mode_physics, "avg": mode_avg, "obc": mode_obc}[mode](tag, parse(sys.argv[3:]))

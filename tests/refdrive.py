@@ -28,6 +28,13 @@ CASES = {
     "upwelling_mask_small": ("upwelling_mask", dict(Lm=14, Mm=18, N=8)),
     "benchmark_mask_small": ("benchmark_mask", dict(Lm=24, Mm=16, N=10)),
     "upwelling_avg_mask_small": ("upwelling_avg_mask", dict(Lm=14, Mm=18, N=8)),      # AVERAGES + MASKING
+    # open boundaries: the reference's own KELVIN application (ROMS/Include/kelvin.h, RADIATION_2D) ...
+    "kelvin": ("kelvin_splines", dict()),
+    "kelvin_small": ("kelvin_splines", dict(Lm=16, Mm=12, N=6)),
+    "kelvin_plain_small": ("kelvin", dict(Lm=16, Mm=12, N=6)),          # kelvin.h as shipped (BC routines only)
+    # ... and closed-basin variants of the other libraries for the routine-level tests (no RADIATION_2D; MASKING)
+    "upwelling_obc_small": ("upwelling", dict(Lm=14, Mm=18, N=8)),
+    "upwelling_mask_obc_small": ("upwelling_mask", dict(Lm=14, Mm=18, N=8)),
 }
 
 
@@ -105,12 +112,21 @@ def oracle_diag_line(od):
 def make_case(tag, **kw):
     app, base = CASES[tag]
     k = dict(base)
-    k.update(kw)
+    k.update({a: b for a, b in kw.items() if a not in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac")})
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
                 upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
-                upwelling_avg_mask=cases.upwelling_mask)[app]
-    return app, ctor(**k)
+                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin)[app]
+    lbc = k.pop("lbc", None)
+    cs = ctor(**k)
+    if tag.endswith("_obc_small"):
+        cs["EWperiodic"] = 0                 # all four edges are boundaries
+    if lbc is not None:
+        cs["lbc"] = lbc
+    for n in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac"):
+        if n in kw:
+            cs[n] = kw[n]
+    return app, cs
 
 
 def reference(app, cs):

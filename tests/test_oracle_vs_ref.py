@@ -180,7 +180,9 @@ def _child(mode, tag, *args, timeout=900):
 
     lib = {"upwelling_kpp_small": "upwelling_kpp", "upwelling_avg_small": "upwelling_avg",
            "upwelling_logdrag_small": "upwelling_logdrag", "upwelling_mask_small": "upwelling_mask",
-           "benchmark_mask_small": "benchmark_mask", "upwelling_avg_mask_small": "upwelling_avg_mask"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
+           "benchmark_mask_small": "benchmark_mask", "upwelling_avg_mask_small": "upwelling_avg_mask",
+           "kelvin": "kelvin_splines", "kelvin_small": "kelvin_splines", "kelvin_plain_small": "kelvin",
+           "upwelling_obc_small": "upwelling", "upwelling_mask_obc_small": "upwelling_mask"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
     if not ref.available(lib):
         pytest.skip(f"oracle/_ref/libromsref_{lib}.so not built here")
     p = subprocess.run([sys.executable, "-m", "tests.refchild", mode, tag] + list(args), capture_output=True,
@@ -208,6 +210,10 @@ MAIN3D_CASES = [
     ("upwelling_mask_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
     ("benchmark_mask_small", ["nsteps=60"]),                                     # MASKING with KPP, bulk fluxes, nonlinear EOS, geopotential mixing
     ("benchmark_mask_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # open boundaries: the reference's KELVIN application (Cha / Fla west, Rad east, RADIATION_2D; analytic boundary data)
+    ("kelvin_small", ["nsteps=60"]),
+    ("kelvin_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("kelvin", ["nsteps=96"]),                                                   # roms_kelvin.in, full size and length
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
     ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
 ]
@@ -240,6 +246,23 @@ def test_core_kernels_bitwise(tag, args):
     (step3d_uv.F:134), step3d_t_tile (step3d_t.F:120): one call each on a randomly perturbed mid-run state."""
     out = _child("kernels", tag, *args)
     assert "KERNELS-OK bitwise" in out, out
+
+
+OBC_CASES = [(t, p, a) for t in ("kelvin_plain_small", "upwelling_obc_small", "upwelling_mask_obc_small") for p in "ABCDEFG" for a in ([],)] + \
+            [("kelvin_plain_small", p, ["NtileI=2", "NtileJ=2"]) for p in "FG"]
+
+
+@pytest.mark.parametrize("tag,preset,args", OBC_CASES, ids=[f"{t}:{p}" + ("+tiles" if a else "") for t, p, a in OBC_CASES])
+def test_open_boundary_routines_bitwise(tag, preset, args):
+    """zetabc_tile, u2dbc_tile, v2dbc_tile, u3dbc_tile, v3dbc_tile, t3dbc_tile of the reference against the oracle's
+    (oracle/orc_obc.c) on a random state with random boundary data: radiation with and without nudging, Chapman explicit
+    and implicit, Flather, Shchepetkin, clamped, gradient and closed, every kind on every edge (tests/refchild.py:
+    OBC_PRESETS), for the four stepping variants that select `know` and `dt2d` and the three 3-D time-level pairs; with
+    RADIATION_2D (the reference's kelvin.h), without it (UPWELLING's library on a closed-basin grid), under MASKING, and
+    on 2x2 tiles.  Includes the reference's southern free-surface radiation branch, which differences towards the boundary
+    row (zetabc.F:455,486-487)."""
+    out = _child("obc", tag, "preset=" + preset, *args)
+    assert "OBC-OK bitwise" in out, out[-1500:]
 
 
 @pytest.mark.parametrize("tag", ["benchmark_small", "upwelling_kpp_small", "upwelling_small", "upwelling_logdrag_small",

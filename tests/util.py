@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 EMU_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libroms_hip_emu.so")
 
 INIT_FIELDS = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", "on_v", "om_p", "on_p", "omn",
-               "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v", "angler", "xr", "yr",
+               "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v", "angler", "xr", "yr", "xp", "yp",
                "rdrag", "visc2_r", "visc2_p", "diff2", "Hz", "z_r", "z_w", "Huon", "Hvom", "zeta", "ubar", "vbar",
                "u", "v", "t", "rho", "pden", "rhoA", "rhoS", "Zt_avg1", "Akv", "Akt",
                "dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta", "hsbl",
