@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ROMS_HIP_ABI_VERSION 1
+#define ROMS_HIP_ABI_VERSION 2    /* 2: lateral boundary conditions (lbc ... Tobc_out) appended to roms_hip_config */
 #define ROMS_MAXT 4              /* max tracers handled (NT) */
 #define ROMS_MAXW 512            /* max 2*ndtfast */
 
@@ -49,8 +49,22 @@ enum {
   ROMS_MASKING = 1 << 15,           /* land/sea masks: arrays "rmask", "umask", "vmask", "pmask" (mod_grid.F), all water until
                                        uploaded; every physics option of the library carries its masked branches (MPDATA's
                                        mpdata_adiff.F blocks included) */
-  ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21
+  ROMS_RADIATION_2D = 1 << 16,      /* tangential phase speed in the radiation conditions (zetabc.F:157, u2dbc_im.F:188 ...) */
+  ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21,
+  ROMS_APP_KELVIN = 1 << 22         /* no wind, no surface fluxes (the default branches of ana_smflux.h, ana_stflux.h) */
 };
+
+/* Lateral boundary conditions: LBC(ibry,ivar,ng) of mod_param.F, the LBC(isFsur) ... LBC(isTvar) lines of roms.in
+   (load_lbc, Utility/inp_decode.F:1560-1680).  Edge index = the reference's iwest, isouth, ieast, inorth minus one;
+   variable index isFsur ... isTvar(itrc).  Kind 0 = closed, or periodic where the direction is (what every caller of
+   ABI version 1 had).  Built: zetabc.F, u2dbc_im.F, v2dbc_im.F, u3dbc_im.F, v3dbc_im.F, t3dbc_im.F with the kinds below;
+   `Red`, `Nes`, `Mix` and nudging with climatology coefficients are not (roms_hip_create: exit_flag 5). */
+enum { ROMS_IWEST = 0, ROMS_ISOUTH = 1, ROMS_IEAST = 2, ROMS_INORTH = 3 };
+enum { ROMS_ISFSUR = 0, ROMS_ISUBAR = 1, ROMS_ISVBAR = 2, ROMS_ISUVEL = 3, ROMS_ISVVEL = 4, ROMS_ISTVAR = 5 };
+#define ROMS_NLBC (ROMS_ISTVAR + ROMS_MAXT)
+enum { ROMS_LBC_DEFAULT = 0, ROMS_LBC_CLO = 1, ROMS_LBC_PER = 2, ROMS_LBC_GRA = 3, ROMS_LBC_CLA = 4, ROMS_LBC_RAD = 5,
+       ROMS_LBC_RADNUD = 6, ROMS_LBC_CHE = 7 /* Chapman explicit */, ROMS_LBC_CHI = 8 /* Chapman implicit, `Cha` */,
+       ROMS_LBC_FLA = 9, ROMS_LBC_SHC = 10 };
 
 /* Everything the kernels read from mod_param / mod_scalars / BOUNDS(ng) / DOMAIN(ng)
    for ONE tile (= one GPU).  Filled by the host (inp_par + get_bounds restatement). */
@@ -83,6 +97,13 @@ typedef struct roms_hip_config {
   double blk_ZQ, blk_ZT, blk_ZW;
   int lmd_Jwt;
   double sc_r[256], Cs_r[256], sc_w[257], Cs_w[257];   /* SCALARS(ng)%sc_r(1:N) -> [k-1]; sc_w(0:N) -> [k] */
+  /* open boundaries (ABI version 2).  lbc[edge][variable] = ROMS_LBC_*; the nudging time scales [1/s] of the
+     radiation + nudging conditions as inp_par.F:726-752 derives them from ZNUDG, M2NUDG, M3NUDG, TNUDG and OBCFAC.
+     The boundary data BOUNDARY(ng)%zeta_west(LBj:UBj) ... t_north(LBi:UBi,N,NT) of mod_boundary.F are uploaded under
+     those names ("zeta_west", "ubar_east", "u_south", "t_north" ...) whenever the caller's set_data has new values. */
+  int lbc[4][ROMS_NLBC];
+  double FSobc_in[4], FSobc_out[4], M2obc_in[4], M2obc_out[4], M3obc_in[4], M3obc_out[4];
+  double Tobc_in[ROMS_MAXT][4], Tobc_out[ROMS_MAXT][4];
 } roms_hip_config;
 
 /* time indices of mod_stepping.F / mod_scalars.F that the kernel wrappers read */

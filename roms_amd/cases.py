@@ -169,7 +169,7 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
     """roms_hip_config for a single tile covering the domain (include/roms_hip.h)."""
     from . import hiplib
     c = hiplib.Config()
-    c.abi_version, c.device = 1, device
+    c.abi_version, c.device = 2, device
     c.Lm, c.Mm, c.N, c.NT, c.NAT = cs["Lm"], cs["Mm"], cs["N"], 2, 2
     hs = [SCHEME[x] for x in cs["hadv"]]
     vs = [SCHEME[x] for x in cs["vadv"]]
@@ -204,6 +204,14 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
     c.Akt_bak[0], c.Akt_bak[1], c.Akv_bak = cs["Akt_bak"][0], cs["Akt_bak"][1], cs["Akv_bak"]
     c.dstart = cs["dstart"]
     c.blk_ZQ, c.blk_ZT, c.blk_ZW, c.lmd_Jwt = cs["blk_ZQ"], cs["blk_ZT"], cs["blk_ZW"], cs["lmd_Jwt"]
+    code, sc = lbc_codes(cs), obc_scales(cs)
+    for e in range(4):
+        for v in range(7):
+            c.lbc[e][v] = code[v][e]
+        for n in ("FSobc_in", "FSobc_out", "M2obc_in", "M2obc_out", "M3obc_in", "M3obc_out"):
+            getattr(c, n)[e] = sc[n][e]
+        for it in range(2):
+            c.Tobc_in[it][e], c.Tobc_out[it][e] = sc["Tobc_in"][it][e], sc["Tobc_out"][it][e]
     for k in range(cs["N"]):
         c.sc_r[k], c.Cs_r[k] = sc_r[k], Cs_r[k]
     for k in range(cs["N"] + 1):

@@ -73,9 +73,10 @@ int run_set_vbc(roms_hip_ctx *c) {
   KArgs a = mk(c);
   LAUNCH_THREAD(k_set_vbc, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, 1, c->stream, a);
   if (c->G.fuse3d) return 0;   // the kernel stored the boundary values and images itself (emit_store)
+  // bc_u2d_tile / bc_v2d_tile: closed, or zero gradient where LBC(:,isUbar / isVbar) is not (bc_2d.F:201-290; BC_LBC2D)
   const HaloSpec hs4[] = {
-      {c->F.bustr, 1, BC_U, 'u'},   // bc_u2d_tile
-      {c->F.bvstr, 1, BC_V, 'v'},   // bc_v2d_tile
+      {c->F.bustr, 1, BC_U | (c->G.obc ? BC_LBC2D : 0), 'u'},
+      {c->F.bvstr, 1, BC_V | (c->G.obc ? BC_LBC2D : 0), 'v'},
   };
   launch_halo_multi(c, hs4, 2);
   return 0;
@@ -107,6 +108,22 @@ int run_set_data(roms_hip_ctx *c) {
       {c->F.srflx, 1, BC_NONE, 'r'},
   };
   launch_halo_multi(c, hs6, (c->G.options & ROMS_SOLAR_SOURCE) ? 4 : 3);
+  if (c->G.options & ROMS_APP_KELVIN) {     // ANA_FSOBC, ANA_M2OBC: the boundary data of this step (other applications upload theirs)
+    auto acquire = [&](int e, int v) {
+      const int k = lbc_kind(c->cfg, e, v);
+      if (k == ROMS_LBC_CLA || k == ROMS_LBC_RADNUD || k == ROMS_LBC_FLA || k == ROMS_LBC_SHC) return true;
+      if (v == ROMS_ISFSUR)
+        for (int q = ROMS_ISUBAR; q <= ROMS_ISVBAR; q++) {
+          const int kq = lbc_kind(c->cfg, e, q);
+          if (kq == ROMS_LBC_FLA || kq == ROMS_LBC_SHC) return true;
+        }
+      return false;
+    };
+    KArgs k = mk(c, (acquire(ROMS_IWEST, ROMS_ISFSUR) ? 1 : 0) | (acquire(ROMS_IEAST, ROMS_ISFSUR) ? 2 : 0) |
+                       (acquire(ROMS_IWEST, ROMS_ISUBAR) && acquire(ROMS_IWEST, ROMS_ISVBAR) ? 4 : 0) |
+                       (acquire(ROMS_IEAST, ROMS_ISUBAR) && acquire(ROMS_IEAST, ROMS_ISVBAR) ? 8 : 0));
+    LAUNCH_THREAD(k_set_data_kelvin, B.JendT - KMIN(B.JstrP, B.JstrT) + 1, 1, 1, c->stream, k);
+  }
   return 0;
 }
 
@@ -179,11 +196,20 @@ int run_set_zeta(roms_hip_ctx *c) {
 int run_ini_zeta(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   const int kstp = c->G.kstp;
-  if (c->G.masking) {
-    KArgs m = mk(c, 0);
-    LAUNCH_THREAD(k_ini_mask, B.IendB - KMIN(B.IstrM, B.IstrB) + 1, B.JendB - B.JstrB + 1, 1, c->stream, m);
+  // radiation / Chapman conditions need the boundary values of the initial state: the load then covers them and no
+  // condition is applied (ini_fields.F:830-871)
+  bool keep = false;
+  for (int e = 0; e < 4; e++) {
+    const int k = lbc_kind(c->cfg, e, ROMS_ISFSUR);
+    keep |= k == ROMS_LBC_RAD || k == ROMS_LBC_RADNUD || k == ROMS_LBC_CHE || k == ROMS_LBC_CHI;
   }
-  launch_halo(c, lev2d(c, c->F.zeta, kstp), 1, bc_rstate(c), 'r');   // zetabc_tile + exchange
+  if (c->G.masking) {
+    KArgs m = mk(c, keep ? 3 : 0);
+    if (keep) LAUNCH_THREAD(k_ini_mask, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, m);
+    else LAUNCH_THREAD(k_ini_mask, B.IendB - KMIN(B.IstrM, B.IstrB) + 1, B.JendB - B.JstrB + 1, 1, c->stream, m);
+  }
+  if (c->G.obc && !keep) { int r = run_obc2d(c, kstp, 1); if (r) return r; }
+  launch_halo(c, lev2d(c, c->F.zeta, kstp), 1, (c->G.obc || keep) ? BC_NONE : bc_rstate(c), 'r');   // zetabc_tile + exchange
   KArgs a = mk(c, kstp);
   LAUNCH_THREAD(k_copy_zt, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
   launch_halo(c, c->F.Zt_avg1, 1, BC_NONE, 'r');
@@ -197,26 +223,38 @@ int run_ini_fields(roms_hip_ctx *c) {
     KArgs m = mk(c, 1);
     LAUNCH_THREAD(k_ini_mask, B.IendB - KMIN(B.IstrM, B.IstrB) + 1, B.JendB - B.JstrB + 1, N, c->stream, m);
   }
+  if (c->G.obc) { int r = run_obc3d_uv(c, nstp); if (r) return r; }
   const HaloSpec hs8[] = {
-      {uv_lev(c, c->F.u, nstp), N, BC_U, 'u'},     // u3dbc_tile + exchange_u3d
-      {uv_lev(c, c->F.v, nstp), N, BC_V, 'v'},
+      {uv_lev(c, c->F.u, nstp), N, obc_bc(c, BC_U), 'u'},     // u3dbc_tile + exchange_u3d
+      {uv_lev(c, c->F.v, nstp), N, obc_bc(c, BC_V), 'v'},
   };
   launch_halo_multi(c, hs8, 2);
   KArgs a = mk(c);
   const int i0 = KMIN(B.IstrM, B.IstrB);
   LAUNCH_THREAD(k_ini_bar, B.IendB - i0 + 1, B.JendB - B.JstrB + 1, 1, c->stream, a);
-  const HaloSpec hs9[] = {
-      {lev2d(c, c->F.ubar, kstp), 1, BC_U, 'u'},   // u2dbc_tile + exchange
-      {lev2d(c, c->F.vbar, kstp), 1, BC_V, 'v'},
-  };
-  launch_halo_multi(c, hs9, 2);
+  {
+    // not with radiation or Flather conditions on the barotropic momentum (ini_fields.F:412-425)
+    bool keep = false;
+    for (int e = 0; e < 4; e++)
+      for (int v = ROMS_ISUBAR; v <= ROMS_ISVBAR; v++) {
+        const int k = lbc_kind(c->cfg, e, v);
+        keep |= k == ROMS_LBC_RAD || k == ROMS_LBC_RADNUD || k == ROMS_LBC_FLA;
+      }
+    if (c->G.obc && !keep) { int r = run_obc2d(c, kstp, 6); if (r) return r; }
+    const HaloSpec hs9[] = {
+        {lev2d(c, c->F.ubar, kstp), 1, (c->G.obc || keep) ? BC_NONE : BC_U, 'u'},   // u2dbc_tile + exchange
+        {lev2d(c, c->F.vbar, kstp), 1, (c->G.obc || keep) ? BC_NONE : BC_V, 'v'},
+    };
+    launch_halo_multi(c, hs9, 2);
+  }
   if (c->G.masking) {
     KArgs m = mk(c, 2);
     LAUNCH_THREAD(k_ini_mask, B.IendB - KMIN(B.IstrM, B.IstrB) + 1, B.JendB - B.JstrB + 1, N * c->G.NT, c->stream, m);
   }
   {
     HaloSpec ht[ROMS_MAXT];
-    for (int it = 1; it <= c->G.NT; it++) ht[it - 1] = HaloSpec{t_lev(c, nstp, it), N, bc_rstate(c), 'r'};   // t3dbc + exchange
+    if (c->G.obc) for (int it = 1; it <= c->G.NT; it++) { int r = run_obc3d_t(c, nstp, it); if (r) return r; }
+    for (int it = 1; it <= c->G.NT; it++) ht[it - 1] = HaloSpec{t_lev(c, nstp, it), N, obc_bc(c, bc_rstate(c)), 'r'};   // t3dbc + exchange
     launch_halo_multi(c, ht, c->G.NT);
   }
   return 0;

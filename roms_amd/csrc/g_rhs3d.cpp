@@ -84,7 +84,8 @@ int run_pre_t3(roms_hip_ctx *c) {
   }
   if (G.fuse3d && !any_col) return 0;   // k_pre_t3 stored the boundary values and images (pt_emit)
   HaloSpec sp[ROMS_MAXT];
-  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, 3, it), G.N, bc_rstate(c), 'r'};   // t3dbc + exchange :1157-1171
+  if (G.obc) for (int it = 1; it <= G.NT; it++) { int r = run_obc3d_t(c, 3, it); if (r) return r; }
+  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, 3, it), G.N, obc_bc(c, bc_rstate(c)), 'r'};   // t3dbc + exchange :1157-1171
   launch_halo_multi(c, sp, G.NT);
   return 0;
 }

@@ -114,12 +114,13 @@ int run_step2d(roms_hip_ctx *c) {
     launch_halo_multi(c, sp, 3);
   }
   if (iif > G.nfast) return 0;
+  if (G.obc) { int r = run_obc2d(c, G.knew); if (r) return r; }                  // zetabc, u2dbc, v2dbc with open edges (k_obc.h)
   HaloSpec sp[8];
   int n = 0;
-  sp[n++] = {lev2d(c, c->F.zeta, G.knew), 1, bc_rstate(c), 'r'};                        // zetabc :1057 + exchange :1068
+  sp[n++] = {lev2d(c, c->F.zeta, G.knew), 1, obc_bc(c, bc_rstate(c)), 'r'};             // zetabc :1057 + exchange :1068
   if (G.predictor) sp[n++] = {lev2d(c, c->F.rzeta, G.krhs), 1, BC_NONE, 'r'};   // :1030
-  sp[n++] = {lev2d(c, c->F.ubar, G.knew), 1, BC_U, 'u'};                        // u2dbc :2871 + exchange :3043
-  sp[n++] = {lev2d(c, c->F.vbar, G.knew), 1, BC_V, 'v'};                        // v2dbc :2876
+  sp[n++] = {lev2d(c, c->F.ubar, G.knew), 1, obc_bc(c, BC_U), 'u'};             // u2dbc :2871 + exchange :3043
+  sp[n++] = {lev2d(c, c->F.vbar, G.knew), 1, obc_bc(c, BC_V), 'v'};             // v2dbc :2876
   if (c->pair_on && c->pair_mt && !G.predictor && iif == 1 && G.nfast >= 2) {
     // the pairs follow (k_step2d_pair.h): this exchange carries the wide strips, and with them what the first pair reads
     // on its rim besides the level just written -- its kstp level (this call's kstp) and the fast-time-constant forcing
@@ -144,6 +145,7 @@ bool step2d_pair_usable(const roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const char *e = getenv("ROMS_HIP_PAIR");
   if (e && e[0] == '0') return false;
+  if (G.obc) return false;                                               // open boundaries: zetabc/u2dbc/v2dbc between the two calls (k_obc.h)
   const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
   if (LmT < 8 || MmT < 8) return false;                                  // the rim (5 | 4 lines) comes from the neighbour's / the tile's own points
   if (pair_lds_doubles(G.bw2, G.bh2) * sizeof(double) > 160 * 1024) return false;

@@ -30,8 +30,11 @@ int run_step3d_uv(roms_hip_ctx *c) {
   else if (col_lds(G)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
   else LAUNCH_THREAD(k_s3uv_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
   if (!G.fuse3d) {   // (fused: the kernels store the boundary values and periodic images themselves, pt_emit)
-    HaloSpec sp[2] = {{uv_lev(c, c->F.u, nnew), N, BC_U, 0}, {uv_lev(c, c->F.v, nnew), N, BC_V, 0}};   // u3dbc/v3dbc :1266,1271
-    launch_halo_multi(c, sp, 2);
+    if (G.obc) { int r = run_obc3d_uv(c, nnew); if (r) return r; }
+    else {
+      HaloSpec sp[2] = {{uv_lev(c, c->F.u, nnew), N, BC_U, 0}, {uv_lev(c, c->F.v, nnew), N, BC_V, 0}};   // u3dbc/v3dbc :1266,1271
+      launch_halo_multi(c, sp, 2);
+    }
   }
   if (col_lds(G)) LAUNCH_COL_AS(k_s3uv_couple, k_s3uv_couple_l, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, 2 * (N + 1), c->stream, a);
   else LAUNCH_THREAD(k_s3uv_couple, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, c->stream, a);
@@ -114,7 +117,8 @@ int run_step3d_t(roms_hip_ctx *c) {
   }
   if (G.fuse3d && !any_mp) return 0;   // k_s3t_col stored the boundary values and images (pt_emit)
   HaloSpec sp[ROMS_MAXT];
-  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, bc_rstate(c, true), 'r'};   // t3dbc :1858 + exchange :1920
+  if (G.obc) for (int it = 1; it <= G.NT; it++) { int r = run_obc3d_t(c, nnew, it); if (r) return r; }
+  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, obc_bc(c, bc_rstate(c, true)), 'r'};   // t3dbc :1858 + exchange :1920
   launch_halo_tail(c, sp, G.NT);
   return 0;
 }

@@ -235,7 +235,8 @@ THREAD_KERNEL(k_set_data_upw, KArgs) {
     if (G.options & ROMS_SOLAR_SOURCE) F.srflx[X2(i, j)] = (1.0 / (G.rho0 * G.Cp)) * 150.0;   // ana_srflux.h:270-277
   }
   double windamp;
-  if ((G.tdays - G.dstart) <= 2.0) windamp = -0.1 * sin(pi * (G.tdays - G.dstart) / 4.0) / G.rho0;
+  if (!(G.options & ROMS_APP_UPWELLING)) windamp = 0.0;      // (KELVIN: the default branch of ana_smflux.h)
+  else if ((G.tdays - G.dstart) <= 2.0) windamp = -0.1 * sin(pi * (G.tdays - G.dstart) / 4.0) / G.rho0;
   else windamp = -0.1 / G.rho0;
   const bool urange = i >= B.IstrP && i <= B.IendT && j >= B.JstrT && j <= B.JendT;
   const bool vrange = i >= B.IstrT && i <= B.IendT && j >= B.JstrP && j <= B.JendT;
@@ -248,6 +249,49 @@ THREAD_KERNEL(k_set_data_upw, KArgs) {
   }
 }
 THREAD_GLOBAL(k_set_data_upw, KArgs)
+
+// Analytic open-boundary data of the KELVIN application: ana_fsobc.h:85-105, ana_m2obc.h:169-200 (set_data.F:881,1003) --
+// an M2 Kelvin wave of unit amplitude at the western edge, its image one channel length on at the eastern one.  The
+// eastern formulas index f, h and yp with this tile's Istr-1 / Iend exactly as the reference does.  One thread per j.
+// a.p0: bits 0..3 = LBC(iwest,isFsur)%acquire, LBC(ieast,isFsur)%acquire, west / east momentum data acquired.
+THREAD_KERNEL(k_set_data_kelvin, KArgs) {
+  (void)gy; (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int j = KMIN(B.JstrP, B.JstrT) + gx;
+  if (j > B.JendT) return;
+  const double pi = 3.14159265358979323846;
+  const double g = G.g, time = G.time, fac = 1.0, omega = 2.0 * pi / (12.42 * 3600.0);
+  const int Istr = B.Istr, Iend = B.Iend, jl = j - G.LBj;
+  double *zw = F.bry[0], *ze = F.bry[1], *uw = F.bry[4], *ue = F.bry[5], *vw = F.bry[8], *ve = F.bry[9];
+  if ((a.p0 & 1) && B.west && j >= B.JstrT) {
+    const double val = fac * exp(-F.f[X2(Istr - 1, j)] * F.yp[X2(Istr - 1, j)] / sqrt(g * F.h[X2(Istr - 1, j)]));
+    zw[jl] = val * cos(omega * time);
+  }
+  if ((a.p0 & 2) && B.east && j >= B.JstrT) {
+    const double cff = 1.0 / sqrt(g * F.h[X2(Istr - 1, j)]);
+    const double val = fac * exp(-F.f[X2(Istr - 1, j)] * F.yp[X2(Iend, j)] * cff);
+    ze[jl] = val * cos(omega * F.xp[X2(Iend, j)] * cff - omega * time);
+  }
+  const double val0 = fac * sin(omega * time);
+  if ((a.p0 & 4) && B.west) {
+    if (j >= B.JstrT) {
+      const double cff = sqrt(g * F.h[X2(Istr - 1, j)]);
+      uw[jl] = (val0 * cff / F.h[X2(Istr - 1, j)]) * exp(-F.f[X2(Istr - 1, j)] * F.yp[X2(Istr - 1, j)] / cff);
+    }
+    if (j >= B.JstrP) vw[jl] = 0.0;
+  }
+  if ((a.p0 & 8) && B.east) {
+    if (j >= B.JstrT) {
+      const double cff = sqrt(g * F.h[X2(Iend, j)]);
+      const double val = fac * exp(-F.f[X2(Iend, j)] * F.yp[X2(Istr - 1, j)] / cff);
+      ue[jl] = (val * cff / F.h[X2(Iend, j)]) * sin(omega * F.xp[X2(Iend, j)] / cff - omega * time);
+    }
+    if (j >= B.JstrP) ve[jl] = 0.0;
+  }
+}
+THREAD_GLOBAL(k_set_data_kelvin, KArgs)
 
 // ---------------------------------------------------------------------------------- omega
 // one thread per column (Istr:Iend, Jstr:Jend)
@@ -527,7 +571,10 @@ THREAD_KERNEL(k_ini_mask, KArgs) {
   const Fields &F = a.Fv;
   const TB &B = G.T;
   const int i = KMIN(B.IstrM, B.IstrB) + gx, j = B.JstrB + gy, nstp = G.nstp, kstp = G.kstp;
-  if (a.p0 == 0) {
+  if (a.p0 == 3) {     // free surface with radiation / Chapman conditions: the boundary points too (ini_fields.F:830-849; index space IstrT:IendT x JstrT:JendT)
+    const int it = B.IstrT + gx, jt = B.JstrT + gy;
+    if (it <= B.IendT && jt <= B.JendT) F.zeta[X2T(it, jt, kstp)] = F.zeta[X2T(it, jt, kstp)] * F.rmask[X2(it, jt)];
+  } else if (a.p0 == 0) {
     if (i >= B.IstrB && i <= B.IendB) F.zeta[X2T(i, j, kstp)] = F.zeta[X2T(i, j, kstp)] * F.rmask[X2(i, j)];
   } else if (a.p0 == 1) {
     const int k = gz + 1;

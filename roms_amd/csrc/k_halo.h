@@ -75,6 +75,44 @@ KDEV void halo_fill(const DGrid &G, double *A, int bcf, int gtype) {
       if (B.south) KLOOP1(i, Istr, Iend) A[X2(i, Jstr - 1)] = A[X2(i, Jstr)];
       if (B.north) KLOOP1(i, Istr, Iend) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
     }
+  } else if (bc == BC_U && (bcf & BC_LBC2D)) {
+    // bc_u2d_tile with open edges (bc_2d.F:197-290): closed where LBC(edge,isUbar) is, else zero gradient over the
+    // open condition's own range
+    const int cl = G.lbc_closed >> (4 * ROMS_ISUBAR);
+    if (!G.ewp) {
+      if (B.east) { if (cl & (1 << ROMS_IEAST)) KLOOP1(j, Jstr, Jend) A[X2(Iend + 1, j)] = 0.0; else KLOOP1(j, Jstr, Jend) A[X2(Iend + 1, j)] = A[X2(Iend, j)]; }
+      if (B.west) { if (cl & (1 << ROMS_IWEST)) KLOOP1(j, Jstr, Jend) A[X2(Istr, j)] = 0.0; else KLOOP1(j, Jstr, Jend) A[X2(Istr, j)] = A[X2(Istr + 1, j)]; }
+    }
+    KSYNC();
+    if (!G.nsp) {
+      const int Imin = G.ewp ? B.IstrU : B.Istr, Imax = G.ewp ? B.Iend : B.IendR;
+      if (B.north) {
+        if (cl & (1 << ROMS_INORTH)) KLOOP1(i, Imin, Imax) A[X2(i, Jend + 1)] = msku ? gamma2 * A[X2(i, Jend)] * G.umask[X2(i, Jend + 1)] : gamma2 * A[X2(i, Jend)];
+        else KLOOP1(i, B.IstrU, Iend) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
+      }
+      if (B.south) {
+        if (cl & (1 << ROMS_ISOUTH)) KLOOP1(i, Imin, Imax) A[X2(i, Jstr - 1)] = msku ? gamma2 * A[X2(i, Jstr)] * G.umask[X2(i, Jstr - 1)] : gamma2 * A[X2(i, Jstr)];
+        else KLOOP1(i, B.IstrU, Iend) A[X2(i, Jstr - 1)] = A[X2(i, Jstr)];
+      }
+    }
+  } else if (bc == BC_V && (bcf & BC_LBC2D)) {
+    const int cl = G.lbc_closed >> (4 * ROMS_ISVBAR);
+    if (!G.ewp) {
+      const int Jmin = G.nsp ? B.JstrV : B.Jstr, Jmax = G.nsp ? B.Jend : B.JendR;
+      if (B.east) {
+        if (cl & (1 << ROMS_IEAST)) KLOOP1(j, Jmin, Jmax) A[X2(Iend + 1, j)] = mskv ? gamma2 * A[X2(Iend, j)] * G.vmask[X2(Iend + 1, j)] : gamma2 * A[X2(Iend, j)];
+        else KLOOP1(j, B.JstrV, Jend) A[X2(Iend + 1, j)] = A[X2(Iend, j)];
+      }
+      if (B.west) {
+        if (cl & (1 << ROMS_IWEST)) KLOOP1(j, Jmin, Jmax) A[X2(Istr - 1, j)] = mskv ? gamma2 * A[X2(Istr, j)] * G.vmask[X2(Istr - 1, j)] : gamma2 * A[X2(Istr, j)];
+        else KLOOP1(j, B.JstrV, Jend) A[X2(Istr - 1, j)] = A[X2(Istr, j)];
+      }
+    }
+    KSYNC();
+    if (!G.nsp) {
+      if (B.north) { if (cl & (1 << ROMS_INORTH)) KLOOP1(i, Istr, Iend) A[X2(i, Jend + 1)] = 0.0; else KLOOP1(i, Istr, Iend) A[X2(i, Jend + 1)] = A[X2(i, Jend)]; }
+      if (B.south) { if (cl & (1 << ROMS_ISOUTH)) KLOOP1(i, Istr, Iend) A[X2(i, Jstr)] = 0.0; else KLOOP1(i, Istr, Iend) A[X2(i, Jstr)] = A[X2(i, Jstr + 1)]; }
+    }
   } else if (bc == BC_U) {
     if (!G.ewp) {
       if (B.west) KLOOP1(j, Jstr, Jend) A[X2(Istr, j)] = 0.0;

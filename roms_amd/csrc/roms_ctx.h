@@ -55,6 +55,10 @@ struct DGrid {
   int masking;
   const double *rmask, *umask, *vmask, *pmask;
   int Vtransform;
+  // open boundaries: 1 if any edge of any variable is neither closed nor periodic (k_obc.h does the state's boundary
+  // conditions then, and nothing is fused into the producers); bit (4*variable + edge) of lbc_closed set where
+  // LBC(edge,variable)%closed (bc_2d.F:201, mpdata_adiff.F:698: closed, or else zero gradient)
+  int obc, lbc_closed;
 };
 
 #ifdef ROMS_CPU_EMU
@@ -145,7 +149,8 @@ enum { BC_NONE = 0, BC_R = 1, BC_U = 2, BC_V = 3 };
 // (zetabc.F:264, t3dbc_im.F:214; bc_r2d/bc_w3d fills carry no mask), BC_MASKALL = after the fills the whole plane
 // IstrR:IendR x JstrR:JendR is multiplied by rmask (step3d_t.F:1880-1890).  The slip values of BC_U / BC_V are
 // always multiplied by umask / vmask of the boundary point in a masked run (u2dbc_im.F:989, bc_2d.F:252 ...).
-enum { BC_MASKF = 16, BC_MASKALL = 32, BC_KIND = 15 };
+enum { BC_MASKF = 16, BC_MASKALL = 32, BC_KIND = 15,
+       BC_LBC2D = 64 };   // bc_u2d / bc_v2d of a context with open edges: closed where LBC(:,isUbar / isVbar) is, else zero gradient
 
 // ------------------------------------------------------------------ indexing (reference layout)
 #define X2(i, j) ((size_t)((i) - G.LBi) + (size_t)((j) - G.LBj) * (size_t)G.ni)
@@ -177,7 +182,7 @@ struct GPtr {
 struct Fields {
   // mod_grid
   GPtr h, f, fomn, pm, pn, om_r, on_r, om_u, on_u, om_v, on_v, om_p, on_p, omn, pmon_r, pnom_r,
-      pmon_p, pnom_p, pmon_u, pnom_u, pmon_v, pnom_v, dmde, dndx, angler, xr, yr, lonr, latr, rdrag,
+      pmon_p, pnom_p, pmon_u, pnom_u, pmon_v, pnom_v, dmde, dndx, angler, xr, yr, xp, yp, lonr, latr, rdrag,
       rdrag2, rmask, umask, vmask, pmask;
   GPtr Hz, z_r, z_w, Huon, Hvom;
   // mod_ocean
@@ -201,4 +206,8 @@ struct Fields {
   GPtr mp3[6];
   // packed metrics of the barotropic momentum stage, 8 doubles per grid point (k_step2d.h: M2Rec)
   GPtr m2r, m2p;
+  // open-boundary data, BOUNDARY(ng)%zeta_west ... t_north of mod_boundary.F: [6 * edge-order + ...] = variable
+  // (zeta, ubar, vbar, u, v, t) * 4 + (west, east, south, north); west/east lines (LBj:UBj [,N [,NT]]) in the caller's
+  // bounds, south/north (LBi:UBi ...)
+  GPtr bry[24];
 };

@@ -73,7 +73,7 @@ static const FieldDesc g_fields[] = {
     FD(om_u, FK_2D), FD(on_u, FK_2D), FD(om_v, FK_2D), FD(on_v, FK_2D), FD(om_p, FK_2D), FD(on_p, FK_2D),
     FD(omn, FK_2D), FD(pmon_r, FK_2D), FD(pnom_r, FK_2D), FD(pmon_p, FK_2D), FD(pnom_p, FK_2D), FD(pmon_u, FK_2D),
     FD(pnom_u, FK_2D), FD(pmon_v, FK_2D), FD(pnom_v, FK_2D), FD(dmde, FK_2D), FD(dndx, FK_2D), FD(angler, FK_2D),
-    FD(xr, FK_2D), FD(yr, FK_2D), FD(lonr, FK_2D), FD(latr, FK_2D), FD(rdrag, FK_2D), FD(rdrag2, FK_2D),
+    FD(xr, FK_2D), FD(yr, FK_2D), FD(xp, FK_2D), FD(yp, FK_2D), FD(lonr, FK_2D), FD(latr, FK_2D), FD(rdrag, FK_2D), FD(rdrag2, FK_2D),
     FD(rmask, FK_2D), FD(umask, FK_2D), FD(vmask, FK_2D), FD(pmask, FK_2D),
     FD(Hz, FK_R), FD(z_r, FK_R), FD(z_w, FK_W), FD(Huon, FK_R), FD(Hvom, FK_R),
     FD(zeta, FK_2Dx3), FD(ubar, FK_2Dx3), FD(vbar, FK_2Dx3), FD(rzeta, FK_2Dx2), FD(rubar, FK_2Dx2),
@@ -90,6 +90,15 @@ static const FieldDesc g_fields[] = {
     FD(sc_r, FK_TABR), FD(Cs_r, FK_TABR), FD(sc_w, FK_TABW), FD(Cs_w, FK_TABW),
     // wvelocity's result at the output point of a step (roms_hip_output_point); download only
     {"w_out", offsetof(Fields, wrk3) + 12 * sizeof(GPtr), FK_W},
+    // open-boundary data (mod_boundary.F), inputs like the forcing
+#define FB(nm, idx, kind) {nm, offsetof(Fields, bry) + (idx) * sizeof(GPtr), kind}
+    FB("zeta_west", 0, FK_BJ), FB("zeta_east", 1, FK_BJ), FB("zeta_south", 2, FK_BI), FB("zeta_north", 3, FK_BI),
+    FB("ubar_west", 4, FK_BJ), FB("ubar_east", 5, FK_BJ), FB("ubar_south", 6, FK_BI), FB("ubar_north", 7, FK_BI),
+    FB("vbar_west", 8, FK_BJ), FB("vbar_east", 9, FK_BJ), FB("vbar_south", 10, FK_BI), FB("vbar_north", 11, FK_BI),
+    FB("u_west", 12, FK_BJN), FB("u_east", 13, FK_BJN), FB("u_south", 14, FK_BIN), FB("u_north", 15, FK_BIN),
+    FB("v_west", 16, FK_BJN), FB("v_east", 17, FK_BJN), FB("v_south", 18, FK_BIN), FB("v_north", 19, FK_BIN),
+    FB("t_west", 20, FK_BJT), FB("t_east", 21, FK_BJT), FB("t_south", 22, FK_BIT), FB("t_north", 23, FK_BIT),
+#undef FB
 };
 static const int g_nfields = (int)(sizeof(g_fields) / sizeof(g_fields[0]));
 
@@ -109,7 +118,20 @@ int field_planes(const roms_hip_ctx *c, int kind) {
   }
   return -1;
 }
-static long table_elems(const roms_hip_ctx *c, int kind) { return kind == FK_TABR ? c->G.N : (kind == FK_TABW ? c->G.N + 1 : -1); }
+static long table_elems(const roms_hip_ctx *c, int kind) {
+  const long N = c->G.N, NT = c->G.NT, nj = c->cnj, ni = c->cni;
+  switch (kind) {
+    case FK_TABR: return N;
+    case FK_TABW: return N + 1;
+    case FK_BJ: return nj;
+    case FK_BI: return ni;
+    case FK_BJN: return nj * N;
+    case FK_BIN: return ni * N;
+    case FK_BJT: return nj * N * NT;
+    case FK_BIT: return ni * N * NT;
+  }
+  return -1;
+}
 long field_elems(const roms_hip_ctx *c, int kind) {
   const int np = field_planes(c, kind);
   return np < 0 ? table_elems(c, kind) : (long)np * c->G.nij;
@@ -217,6 +239,36 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   G.T = make_bounds(cfg->Lm, cfg->Mm, cfg->EWperiodic, cfg->NSperiodic, cfg->Istr, cfg->Iend, cfg->Jstr, cfg->Jend,
                     cfg->west_edge, cfg->east_edge, cfg->south_edge, cfg->north_edge);
   choose_blocks(G);
+  {  // lateral boundary conditions: what is built, and the two summaries the kernels read
+    G.obc = 0; G.lbc_closed = 0;
+    for (int e = 0; e < 4; e++)
+      for (int v = 0; v < ROMS_ISTVAR + cfg->NT; v++) {
+        const int k = lbc_kind(*cfg, e, v);
+        bool ok = k >= ROMS_LBC_CLO && k <= ROMS_LBC_SHC;
+        if (k == ROMS_LBC_PER && cfg->lbc[e][v] != ROMS_LBC_DEFAULT && !((e == ROMS_IWEST || e == ROMS_IEAST) ? cfg->EWperiodic : cfg->NSperiodic)) ok = false;
+        if ((k == ROMS_LBC_CHE || k == ROMS_LBC_CHI) && v != ROMS_ISFSUR) ok = false;               // Chapman: free surface only
+        if ((k == ROMS_LBC_FLA || k == ROMS_LBC_SHC) && v != ROMS_ISUBAR && v != ROMS_ISVBAR) ok = false;   // 2-D momentum only
+        if (!ok) {
+          set_error("lateral boundary condition not built: lbc[" + std::to_string(e) + "][" + std::to_string(v) + "] = " + std::to_string(cfg->lbc[e][v]) +
+                    " (built: Clo Per Gra Cla Rad RadNud, Che/Cha for the free surface, Fla/Shc for ubar/vbar)");
+          return 5;
+        }
+        if (k == ROMS_LBC_CLO) G.lbc_closed |= 1 << (4 * v + e);
+        if (k != ROMS_LBC_CLO && k != ROMS_LBC_PER) G.obc = 1;
+      }
+  }
+  if (G.obc) {
+    // mpdata_adiff.F:696-760,1158-1220 gives the anti-diffusive velocities a zero-gradient value at an open edge; the
+    // MPDATA kernels carry the closed-wall form only
+    for (int it = 0; it < cfg->NT; it++)
+      if (cfg->hadv[it] == ROMS_MPDATA || cfg->vadv[it] == ROMS_MPDATA)
+        for (int e = 0; e < 4; e++)
+          if (!(G.lbc_closed & (1 << (4 * ((e == ROMS_IWEST || e == ROMS_IEAST) ? ROMS_ISUVEL : ROMS_ISVVEL) + e))) &&
+              lbc_kind(*cfg, e, ROMS_ISUVEL) != ROMS_LBC_PER) {
+            set_error("MPDATA is not built together with an open boundary of the 3-D momentum (mpdata_adiff.F:696-760)");
+            return 5;
+          }
+  }
   G.dbg_stop = getenv("ROMS_HIP_DBG_STOP") ? atoi(getenv("ROMS_HIP_DBG_STOP")) : 0;
   {  // neighbours in the reference's tile numbering; a periodic direction wraps around.
      // ROMS_HIP_SELF_EXCHANGE=1 (test aid): a tile that is alone in a periodic direction exchanges with
@@ -261,7 +313,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
       const char *ep = getenv("ROMS_HIP_PAIR");
       const bool shape_ok = ep && ep[0] == '1' ? true : (G.bw2 <= 32 && G.bh2 <= 4);
       const int wmin = KMIN(edge_subtile(cfg->Lm, NI), (cfg->Lm + NI - 1) / NI), hmin = KMIN(edge_subtile(cfg->Mm, NJ), (cfg->Mm + NJ - 1) / NJ);
-      c->pair_mt = c->has_exchange && !(ep && ep[0] == '0') && shape_ok && wmin >= 8 && hmin >= 8;
+      c->pair_mt = c->has_exchange && !(ep && ep[0] == '0') && shape_ok && wmin >= 8 && hmin >= 8 && !G.obc;   // (open boundaries: per-call kernels, k_obc.h)
       if (c->pair_mt) {
         if (nb[0] >= 0) LB_i = KMIN(LB_i, cfg->Istr - B2D_GL);
         if (nb[1] >= 0) UB_i = KMAX(UB_i, cfg->Iend + B2D_GH);
@@ -282,7 +334,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     const int LmT = cfg->Iend - cfg->Istr + 1, MmT = cfg->Jend - cfg->Jstr + 1;
     const char *e = getenv("ROMS_HIP_FUSE_HALO");
     G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && !c->has_exchange && (cfg->EWperiodic || cfg->NSperiodic) && LmT >= 6 && MmT >= 6 &&
-                  !(e && e[0] == '0');
+                  !(e && e[0] == '0') && !G.obc;
     const char *e3 = getenv("ROMS_HIP_FUSE3D");
     // (a masked run: the barotropic kernel's boundary stores carry the mask of the boundary point, hb_emit; the 3-D
     // producers take the separate halo launches -- their emit_plan knows no mask)

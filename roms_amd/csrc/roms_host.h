@@ -16,7 +16,8 @@ struct FieldDesc {
   int kind;        // plane count rule, see field_planes()
 };
 
-enum { FK_2D = 0, FK_R, FK_W, FK_2Dx3, FK_2Dx2, FK_Rx2, FK_T, FK_Wx2, FK_2DxNT, FK_WxNAT, FK_TABR, FK_TABW };
+enum { FK_2D = 0, FK_R, FK_W, FK_2Dx3, FK_2Dx2, FK_Rx2, FK_T, FK_Wx2, FK_2DxNT, FK_WxNAT, FK_TABR, FK_TABW,
+       FK_BJ, FK_BI, FK_BJN, FK_BIN, FK_BJT, FK_BIT };   // boundary lines (LBj:UBj) / (LBi:UBi) [, N [, NT]] in the caller's bounds
 
 struct Region { double seconds; long calls; };
 
@@ -128,6 +129,15 @@ enum {
 // make the compute stream(s) wait for the exchanges in flight that carry any of `groups`
 void halo_fence(roms_hip_ctx *c, unsigned groups);
 
+// LBC(edge, variable) with the default resolved: periodic where the direction is, else closed unless the caller chose a kind
+inline int lbc_kind(const roms_hip_config &cf, int edge, int var) {
+  if ((edge == ROMS_IWEST || edge == ROMS_IEAST) ? cf.EWperiodic : cf.NSperiodic) return ROMS_LBC_PER;
+  return cf.lbc[edge][var] == ROMS_LBC_DEFAULT ? ROMS_LBC_CLO : cf.lbc[edge][var];
+}
+int run_obc2d(roms_hip_ctx *c, int kout, unsigned vars = 7);     // zetabc (1), u2dbc (2), v2dbc (4) of level kout (g_obc.cpp)
+int run_obc3d_uv(roms_hip_ctx *c, int nout);                     // u3dbc, v3dbc
+int run_obc3d_t(roms_hip_ctx *c, int nout, int itrc);            // t3dbc of tracer itrc (1-based)
+
 // helpers (roms_hip.cpp)
 void ctx_sync_stepping(roms_hip_ctx *c);           // copy c->s into c->G
 // side-stream helpers (roms_hip.cpp): between side_begin and side_end launches go to the side stream,
@@ -155,6 +165,9 @@ struct HaloSpec { double *A; int nk; int bc; char gtype; };
 inline int bc_rstate(const roms_hip_ctx *c, bool all = false) {
   return c->G.masking ? (BC_R | BC_MASKF | (all ? BC_MASKALL : 0)) : BC_R;
 }
+// a context with open edges applies the state's boundary conditions in k_obc launches (g_obc.cpp): its halo launches
+// keep the flags (BC_MASKALL) and the exchange, not the fill
+inline int obc_bc(const roms_hip_ctx *c, int bc) { return c->G.obc ? (bc & ~BC_KIND) : bc; }
 void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype);
 // the same as the LAST operation of a routine: nothing enqueued later in that routine depends on it, so in a
 // multi-tile run the exchange may go to the exchange stream and overlap the routines that follow (halo_fence)

@@ -12,7 +12,11 @@ SCHEMES = dict(A4=A4, C2=C2, C4=C4, HSIMT=HSIMT, MPDATA=MPDATA, SPLINES=SPLINES,
 OPTIONS = {name: 1 << k for k, name in enumerate(
     ["UV_ADV", "UV_COR", "UV_VIS2", "TS_DIF2", "MIX_GEO_TS", "CURVGRID", "NONLIN_EOS", "UV_QDRAG",
      "LMD_MIXING", "BULK_FLUXES", "SOLAR_SOURCE", "ANA_VMIX", "SALINITY", "SPHERICAL", "UV_LOGDRAG", "MASKING"])}
-OPTIONS.update(APP_UPWELLING=1 << 20, APP_BENCHMARK=1 << 21)
+OPTIONS.update(RADIATION_2D=1 << 16, APP_UPWELLING=1 << 20, APP_BENCHMARK=1 << 21, APP_KELVIN=1 << 22)
+# lateral boundary conditions (include/roms_hip.h): lbc[edge][variable], ROMS_LBC_* kinds
+NLBC = 5 + MAXT
+LBC_KINDS = dict(Clo=1, Per=2, Gra=3, Cla=4, Rad=5, RadNud=6, Che=7, Cha=8, Fla=9, Shc=10)
+BRY_FIELDS = [v + "_" + e for v in ("zeta", "ubar", "vbar", "u", "v", "t") for e in ("west", "east", "south", "north")]
 
 
 class Config(C.Structure):
@@ -37,6 +41,10 @@ class Config(C.Structure):
         ("blk_ZQ", C.c_double), ("blk_ZT", C.c_double), ("blk_ZW", C.c_double), ("lmd_Jwt", C.c_int),
         ("sc_r", C.c_double * 256), ("Cs_r", C.c_double * 256), ("sc_w", C.c_double * 257),
         ("Cs_w", C.c_double * 257),
+        ("lbc", (C.c_int * NLBC) * 4),
+        ("FSobc_in", C.c_double * 4), ("FSobc_out", C.c_double * 4), ("M2obc_in", C.c_double * 4),
+        ("M2obc_out", C.c_double * 4), ("M3obc_in", C.c_double * 4), ("M3obc_out", C.c_double * 4),
+        ("Tobc_in", (C.c_double * 4) * MAXT), ("Tobc_out", (C.c_double * 4) * MAXT),
     ]
 
 

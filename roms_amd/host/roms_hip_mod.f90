@@ -17,7 +17,10 @@
      &   ROMS_MIX_GEO_TS = 16, ROMS_CURVGRID = 32, ROMS_NONLIN_EOS = 64, ROMS_UV_QDRAG = 128,                  &
      &   ROMS_LMD_MIXING = 256, ROMS_BULK_FLUXES = 512, ROMS_SOLAR_SOURCE = 1024, ROMS_ANA_VMIX = 2048,        &
      &   ROMS_SALINITY = 4096, ROMS_SPHERICAL = 8192, ROMS_UV_LOGDRAG = 16384, ROMS_MASKING = 32768,                                 &
-     &   ROMS_APP_UPWELLING = 1048576, ROMS_APP_BENCHMARK = 2097152
+     &   ROMS_RADIATION_2D = 65536, ROMS_APP_UPWELLING = 1048576, ROMS_APP_BENCHMARK = 2097152, ROMS_APP_KELVIN = 4194304
+      integer(c_int), parameter :: ROMS_NLBC = 5+ROMS_MAXT
+      integer(c_int), parameter :: ROMS_LBC_CLO = 1, ROMS_LBC_PER = 2, ROMS_LBC_GRA = 3, ROMS_LBC_CLA = 4, ROMS_LBC_RAD = 5,      &
+     &   ROMS_LBC_RADNUD = 6, ROMS_LBC_CHE = 7, ROMS_LBC_CHI = 8, ROMS_LBC_FLA = 9, ROMS_LBC_SHC = 10
 
       TYPE, bind(C) :: roms_hip_config
         integer(c_int) :: abi_version, device
@@ -43,6 +46,11 @@
         real(c_double) :: blk_ZQ, blk_ZT, blk_ZW
         integer(c_int) :: lmd_Jwt
         real(c_double) :: sc_r(256), Cs_r(256), sc_w(0:256), Cs_w(0:256)
+!  open boundaries: lbc(variable, edge) = C's lbc[edge][variable] (variable 1 isFsur ... 6.. isTvar; edge 1 west, 2 south,
+!  3 east, 4 north), nudging time scales (edge) and (edge, tracer)
+        integer(c_int) :: lbc(ROMS_NLBC,4)
+        real(c_double) :: FSobc_in(4), FSobc_out(4), M2obc_in(4), M2obc_out(4), M3obc_in(4), M3obc_out(4)
+        real(c_double) :: Tobc_in(4,ROMS_MAXT), Tobc_out(4,ROMS_MAXT)
       END TYPE roms_hip_config
 
       TYPE, bind(C) :: roms_hip_stepping

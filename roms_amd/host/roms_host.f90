@@ -1471,7 +1471,7 @@
       tUBi=MERGE(UBi, tIend+Nghost, te)
       tLBj=MERGE(LBj, tJstr-1-Nghost, ts)
       tUBj=MERGE(UBj, tJend+Nghost, tn)
-      cfg%abi_version=1
+      cfg%abi_version=2
       cfg%device=device
       cfg%Lm=Lm; cfg%Mm=Mm; cfg%N=N; cfg%NT=NT; cfg%NAT=NAT; cfg%Nghost=Nghost
       cfg%LBi=tLBi; cfg%UBi=tUBi; cfg%LBj=tLBj; cfg%UBj=tUBj

@@ -35,7 +35,8 @@ GRID2D = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", 
           "rdrag", "visc2_r", "visc2_p", "diff2"]
 STATE = ["Hz", "z_r", "z_w", "Huon", "Hvom", "zeta", "ubar", "vbar", "u", "v", "t", "rho", "pden", "rhoA", "rhoS",
          "Zt_avg1", "Akv", "Akt"]
-EXTRA = {"benchmark": ["dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta", "hsbl"]}
+EXTRA = {"benchmark": ["dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta", "hsbl"],
+         "kelvin": ["xp", "yp", "rdrag2"]}
 ALLSTATE = STATE + ["rzeta", "rubar", "rvbar", "W", "wvel", "ru", "rv", "rufrc", "rvfrc", "DU_avg1", "DU_avg2",
                     "DV_avg1", "DV_avg2", "sustr", "svstr", "bustr", "bvstr", "stflx", "btflx", "stflux", "btflux"]
 
@@ -54,11 +55,11 @@ def make_case(case):
     from tests import cases
     tag, kw = case.split(":") if ":" in case else (case, "")
     kwargs = eval("dict(%s)" % kw) if kw else {}
-    app = "benchmark" if tag.startswith("benchmark") else "upwelling"
+    app = "benchmark" if tag.startswith("benchmark") else "kelvin" if tag.startswith("kelvin") else "upwelling"
     cs = getattr(cases, app)(**kwargs)
     ip, rp = cases.ref_params(cs)
     saved = quiet()
-    R = ref.Ref(app, ip, rp)
+    R = ref.Ref("kelvin_splines" if app == "kelvin" else app, ip, rp)   # (kelvin: oracle/ref/kelvin_splines.h)
     R.initial()
     b = R.bounds(0)
     N, nd = cs["N"], cs["ndtfast"]
@@ -235,6 +236,8 @@ STEP_CASES = [
     ("benchmark_mask_small", "benchmark_mask_small", ["nsteps=60"]),      # oracle/ref/benchmark_mask.h
     # MASKING with MPDATA: mpdata_adiff.F's masked blocks
     ("upwelling_mask_small_mpdata", "upwelling_mask_small", ["nsteps=60", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
+    # open boundaries: the reference's KELVIN application (oracle/ref/kelvin_splines.h)
+    ("kelvin_small", "kelvin_small", ["nsteps=96"]),
 ]
 KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
 def make_avg():
@@ -294,7 +297,8 @@ if __name__ == "__main__":
         make_bounds()
     else:
         py = sys.executable
-        for case in ["upwelling", "upwelling_small:Lm=14,Mm=18,N=8", "benchmark_small:Lm=24,Mm=16,N=10"]:
+        for case in ["upwelling", "upwelling_small:Lm=14,Mm=18,N=8", "benchmark_small:Lm=24,Mm=16,N=10",
+                     "kelvin_small:Lm=16,Mm=12,N=6", "kelvin"]:
             subprocess.check_call([py, __file__, "--case", case])
         for spec in ["upwelling,41,80,1,1,HSIMT", "upwelling,41,80,2,2,HSIMT", "upwelling,41,80,2,4,U3",
                      "upwelling,41,80,3,3,U3", "benchmark,512,64,1,1,U3", "benchmark,512,64,2,2,U3",

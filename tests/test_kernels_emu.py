@@ -248,3 +248,68 @@ def test_time_averages_bitwise(emu, tag, nAVG, ntsAVG):
             assert np.array_equal(H.download(n), O.field(n)), (step, n)
     assert np.abs(H.download("avg_UV")).max() > 0.0
     H.close()
+
+
+OBC_VARIANTS = {
+    # the reference's KELVIN application as shipped (roms_kelvin.in): Chapman / Flather west, radiation east, walls south / north
+    "kelvin": None,
+    # the other kinds on the open edges, nudging towards uploaded boundary data
+    "mixed": dict(zeta=("Che", "Clo", "RadNud", "Clo"), ubar=("Shc", "Clo", "RadNud", "Clo"), vbar=("Shc", "Clo", "Gra", "Clo"),
+                  u=("RadNud", "Clo", "Gra", "Clo"), v=("Gra", "Clo", "RadNud", "Clo"), temp=("RadNud", "Clo", "Cla", "Clo"),
+                  salt=("Cla", "Clo", "Gra", "Clo")),
+    # all four edges open
+    "four": dict(zeta=("Cha", "Rad", "Rad", "Che"), ubar=("Fla", "Rad", "Rad", "Shc"), vbar=("Fla", "Rad", "Rad", "Shc"),
+                 u=("Rad", "Rad", "Rad", "Gra"), v=("Rad", "Rad", "Rad", "Gra"), temp=("Rad", "Gra", "Rad", "Rad"),
+                 salt=("Gra", "Rad", "Rad", "Rad")),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(OBC_VARIANTS))
+def test_open_boundaries_bitwise(emu, variant):
+    """Open boundaries (k_obc.h: zetabc, u2dbc, v2dbc, u3dbc, v3dbc, t3dbc with radiation, Chapman, Flather, Shchepetkin,
+    clamped, gradient conditions; the oracle is pinned to the reference routines and to whole runs of the reference's
+    KELVIN application): the Kelvin wave entering through the western boundary, 12 steps against the oracle, bit for bit;
+    the boundary really is open (the wave arrives: |u| grows from rest)."""
+    kw = {} if OBC_VARIANTS[variant] is None else dict(lbc=OBC_VARIANTS[variant])
+    cs = util.case_for("kelvin_small", **kw)
+    if variant == "mixed":
+        cs.update(Znudg=0.5, M2nudg=0.25, M3nudg=2.0, Tnudg=(1.0, 3.0), obcfac=4.0)
+    g = util.load_init("kelvin_small", util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    if variant != "kelvin":      # boundary data the analytic KELVIN functions do not provide: uploaded, as a caller's set_data would
+        rng = np.random.default_rng(3)
+        from roms_amd import hiplib
+        for n in hiplib.BRY_FIELDS:
+            if n.startswith(("u_", "v_", "t_")) or n.endswith(("south", "north")):
+                a = O.field(n)
+                a[:] = (10.0 if n[0] == "t" else 0.0) + 0.01 * rng.standard_normal(a.size)
+                H.upload(n, a)
+    O.start()
+    H.start()
+    for _ in range(12):
+        O.main3d_step()
+        H.main3d(1)
+        for n in util.PROGNOSTIC:
+            a, b = H.download(n), O.field(n)
+            assert np.isfinite(b).all(), n
+            assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+    assert np.abs(O.field("u")).max() > 0.05
+    H.close()
+
+
+def test_open_boundary_kinds_the_library_does_not_have_stop():
+    """roms_hip_create: exit_flag 5 with the reason for a kind that is not built, never a silent closed wall"""
+    from roms_amd import hiplib
+    cs = util.case_for("kelvin_small")
+    g = util.load_init("kelvin_small", util.nghost_for(cs))
+    for lbc, needle in ((dict(zeta=("Fla", "Clo", "Rad", "Clo")), "not built"), (dict(u=("Cha", "Clo", "Rad", "Clo")), "not built")):
+        cs["lbc"] = lbc
+        with pytest.raises(hiplib.RomsHipError) as e:
+            util.make_hip(cs, g, util.EMU_LIB)
+        assert "exit_flag=5" in str(e.value) and needle in str(e.value), str(e.value)
+    cs = util.case_for("kelvin_small", lbc=dict(u=("Rad", "Clo", "Rad", "Clo")))
+    cs["hadv"] = cs["vadv"] = ("MPDATA", "MPDATA")
+    with pytest.raises(hiplib.RomsHipError) as e:
+        util.make_hip(cs, g, util.EMU_LIB)      # (a closed basin: the arrays do not depend on the number of ghost points)
+    assert "exit_flag=5" in str(e.value) and "MPDATA" in str(e.value)

@@ -68,6 +68,10 @@ def case_for(tag, **kw):
         return cases.benchmark(Lm=48, Mm=34, N=6, **kw)
     if tag == "upwelling_mask_mid":
         return cases.upwelling_mask(Lm=34, Mm=40, N=6, **kw)
+    if tag == "kelvin_small":
+        return cases.kelvin(Lm=16, Mm=12, N=6, **kw)
+    if tag == "kelvin":
+        return cases.kelvin(**kw)
     if tag == "upwelling_logdrag_small":
         return cases.upwelling_logdrag(Lm=14, Mm=18, N=8, **kw)
     raise KeyError(tag)
@@ -159,11 +163,14 @@ def case_from_meta(meta):
     cs = dict(meta["case"])
     for k in ("hadv", "vadv", "tnu2", "Akt_bak", "options"):
         cs[k] = tuple(cs[k])
+    if "lbc" in cs:
+        cs["lbc"] = {v: tuple(k) for v, k in cs["lbc"].items()}
     return cs
 
 
 def init_tag(cs):
-    return {(14, 18, 8): "upwelling_small", (24, 16, 10): "benchmark_small", (41, 80, 16): "upwelling"}[
+    return {(14, 18, 8): "upwelling_small", (24, 16, 10): "benchmark_small", (41, 80, 16): "upwelling",
+            (16, 12, 6): "kelvin_small", (50, 30, 10): "kelvin"}[
         (cs["Lm"], cs["Mm"], cs["N"])]
 
 
@@ -312,8 +319,10 @@ def check_steps_fixture(side, f, meta, tol, tol_loose=None, loose=()):
             worst[n] = max(worst.get(n, 0.0), e)
             lim = tol_loose if (n in loose and tol_loose is not None) else tol
             assert e <= lim, (s, n, e)
-        if s == meta["nsteps"]:
-            assert fmt_diag(side.diag())[0][3] == meta["diag"][-1][0][3]      # NET_VOLUME as printed
+        if s == meta["nsteps"] and "lbc" not in side.cs:
+            # NET_VOLUME as printed: the line of step n reports the state BEFORE that step, the same number in a closed
+            # or periodic basin; with open boundaries the volume changes from step to step and the fields above stand alone
+            assert fmt_diag(side.diag())[0][3] == meta["diag"][-1][0][3]
     return worst
 
 
