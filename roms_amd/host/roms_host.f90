@@ -54,6 +54,11 @@
       integer :: n_unknown_keys = 0               ! ... that the reference's reader (read_phypar.F) does not know either
       character(len=64) :: first_unknown_key = ' ' 
       integer :: lbc_seen = 0
+!  lateral boundary conditions: lbc(variable, edge) = ROMS_LBC_* (variable 1 isFsur, 2 isUbar, 3 isVbar, 4 isUvel, 5 isVvel,
+!  6.. isTvar; edge 1 west, 2 south, 3 east, 4 north: the order of a roms.in LBC line), 0 = nothing said; the nudging
+!  time scales of roms.in in days (ZNUDG M2NUDG M3NUDG TNUDG) and OBCFAC
+      integer :: lbc(ROMS_NLBC,4) = 0
+      real(dp) :: Znudg = 0.0_dp, M2nudg = 0.0_dp, M3nudg = 0.0_dp, Tnudg(ROMS_MAXT) = 0.0_dp, obcfac = 0.0_dp
       character(len=32) :: defs(256)              ! cpp options defined by the application header
       integer :: ndefs = 0
       character(len=64) :: xtok(64)               ! tokens of the #if condition being evaluated
@@ -73,6 +78,7 @@
       real(r8), allocatable, target :: pmon_r(:,:), pnom_r(:,:), pmon_p(:,:), pnom_p(:,:), pmon_u(:,:)
       real(r8), allocatable, target :: pnom_u(:,:), pmon_v(:,:), pnom_v(:,:), dmde(:,:), dndx(:,:), angler(:,:)
       real(r8), allocatable, target :: xr(:,:), yr(:,:), lonr(:,:), latr(:,:), rdrag(:,:), rdrag2(:,:)
+      real(r8), allocatable, target :: xp(:,:), yp(:,:)          ! psi-point coordinates (the KELVIN boundary data read them)
       real(r8), allocatable, target :: visc2_r(:,:), visc2_p(:,:), diff2(:,:,:)
       real(r8), allocatable, target :: rmask(:,:), umask(:,:), vmask(:,:), pmask(:,:)     ! MASKING (all water otherwise)
       real(r8), allocatable, target :: Hz(:,:,:), z_r(:,:,:), z_w(:,:,:)
@@ -245,6 +251,11 @@
           CASE ('TCOEF');       Tcoef=toreal(tok(1))
           CASE ('SCOEF');       Scoef=toreal(tok(1))
           CASE ('GAMMA2');      gamma2=toreal(tok(1))
+          CASE ('ZNUDG');       Znudg=toreal(tok(1))
+          CASE ('M2NUDG');      M2nudg=toreal(tok(1))
+          CASE ('M3NUDG');      M3nudg=toreal(tok(1))
+          CASE ('TNUDG');       CALL load_r (tok, nv, Tnudg)
+          CASE ('OBCFAC');      obcfac=toreal(tok(1))
 !  Every other keyword of the reference's reader (read_phypar.F has 612): classified keyword by keyword as unable to
 !  change the forward time step of this build -- output selection, file names, the parameters of other drivers and of
 !  cpp options the library does not carry (a header that defines one is stopped by options_from_defines).  The list
@@ -277,36 +288,58 @@
       ierr=5
       END SUBROUTINE unsupported
 !
-!  Lateral boundary conditions, load_lbc (Utility/inp_decode.F): four values per variable in the
-!  order west south east north (isTvar: one set per tracer on continuation lines).  Built here:
-!  periodic ("Per") and closed ("Clo"); every variable must share the periodicity of the grid.
+!  Lateral boundary conditions, load_lbc (Utility/inp_decode.F:1560-1680): four keywords per variable in the order west
+!  south east north (isTvar: one set per tracer on continuation lines).  Built: Per Clo Gra Cla Rad RadNud, Che / Cha for
+!  the free surface, Fla / Shc for the 2-D momentum (the library checks the pairing); every variable must share the
+!  periodicity of the grid.  isMtke (no TKE closure here) is read and not used.
 !
       SUBROUTINE load_lbc (key, tok, nv, ierr)
       character(len=*), intent(in) :: key
       character(len=64), intent(in) :: tok(16)
       integer, intent(in) :: nv
       integer, intent(inout) :: ierr
-      integer :: k, side
+      integer :: k, side, ivar, code
       logical :: per(4)
       character(len=64) :: val
       IF (nv.lt.4.or.MOD(nv,4).ne.0) THEN
         CALL unsupported (key//': expected west south east north', ierr)
         RETURN
       END IF
+      SELECT CASE (key)
+        CASE ('LBC(isFsur)'); ivar=1
+        CASE ('LBC(isUbar)'); ivar=2
+        CASE ('LBC(isVbar)'); ivar=3
+        CASE ('LBC(isUvel)'); ivar=4
+        CASE ('LBC(isVvel)'); ivar=5
+        CASE ('LBC(isTvar)'); ivar=6
+        CASE DEFAULT;         ivar=0
+      END SELECT
       DO k=1,nv
         val=upper(tok(k))
-        IF (TRIM(val).ne.'PER'.and.TRIM(val).ne.'CLO') THEN
-          CALL unsupported (key//' = '//TRIM(tok(k))//': only periodic (Per) and closed (Clo) boundaries '//   &
-     &                      'are built (no Cha/Cla/Fla/Gra/Nes/Rad/Red/Shc)', ierr)
-          RETURN
-        END IF
+        SELECT CASE (TRIM(val))
+          CASE ('CLO');    code=ROMS_LBC_CLO
+          CASE ('PER');    code=ROMS_LBC_PER
+          CASE ('GRA');    code=ROMS_LBC_GRA
+          CASE ('CLA');    code=ROMS_LBC_CLA
+          CASE ('RAD');    code=ROMS_LBC_RAD
+          CASE ('RADNUD'); code=ROMS_LBC_RADNUD
+          CASE ('CHE');    code=ROMS_LBC_CHE
+          CASE ('CHA');    code=ROMS_LBC_CHI
+          CASE ('FLA');    code=ROMS_LBC_FLA
+          CASE ('SHC');    code=ROMS_LBC_SHC
+          CASE DEFAULT
+            CALL unsupported (key//' = '//TRIM(tok(k))//': built are Per Clo Gra Cla Rad RadNud Che Cha Fla Shc '//   &
+     &                        '(no Red, Nes, Mix)', ierr)
+            RETURN
+        END SELECT
         side=MOD(k-1,4)+1
         IF (k.le.4) THEN
-          per(side)=TRIM(val).eq.'PER'
-        ELSE IF (per(side).neqv.(TRIM(val).eq.'PER')) THEN
+          per(side)=code.eq.ROMS_LBC_PER
+        ELSE IF (per(side).neqv.(code.eq.ROMS_LBC_PER)) THEN
           CALL unsupported (key//': tracers disagree on periodicity', ierr)
           RETURN
         END IF
+        IF (ivar.gt.0.and.ivar+(k-1)/4.le.ROMS_NLBC) lbc(ivar+(k-1)/4,side)=code
       END DO
       IF ((per(1).neqv.per(3)).or.(per(2).neqv.per(4))) THEN
         CALL unsupported (key//': a periodic edge needs its opposite edge periodic too', ierr)
@@ -328,6 +361,7 @@
       ntimes=100; ndtfast=30; ninfo=1; Vtransform=2; Vstretching=4; lmd_Jwt=1
       hadv=ROMS_U3; vadv=ROMS_C4
       EWperiodic=.TRUE.; NSperiodic=.FALSE.
+      lbc=0; Znudg=0.0_dp; M2nudg=0.0_dp; M3nudg=0.0_dp; Tnudg=0.0_dp; obcfac=0.0_dp
       dt=300.0_dp; theta_s=3.0_dp; theta_b=0.0_dp; Tcline=25.0_dp; rho0=1025.0_dp
       R0=1027.0_dp; T0=14.0_dp; S0=35.0_dp; Tcoef=1.7E-4_dp; Scoef=0.0_dp
       visc2=5.0_dp; tnu2=0.0_dp; Akt_bak=1.0E-6_dp; Akv_bak=1.0E-5_dp
@@ -687,6 +721,20 @@
       DO k=1,SIZE(common)
         CALL define (TRIM(common(k)))
       END DO
+      IF (TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES') THEN
+!  ROMS/Include/kelvin.h; KELVIN_SPLINES = oracle/ref/kelvin_splines.h: the same with the spline vertical solvers (the
+!  plain tridiagonal forms kelvin.h selects are not built: options_from_defines stops KELVIN itself with that reason)
+        ndefs=0
+        CALL define ('UV_ADV'); CALL define ('UV_COR'); CALL define ('UV_QDRAG'); CALL define ('UV_VIS2')
+        CALL define ('MIX_S_UV'); CALL define ('DJ_GRADPS'); CALL define ('TS_DIF2'); CALL define ('MIX_S_TS')
+        CALL define ('SOLVE3D'); CALL define ('RADIATION_2D'); CALL define ('ANA_GRID'); CALL define ('ANA_INITIAL')
+        CALL define ('ANA_FSOBC'); CALL define ('ANA_M2OBC'); CALL define ('ANA_SMFLUX'); CALL define ('ANA_STFLUX')
+        CALL define ('ANA_SRFLUX'); CALL define ('ANA_BTFLUX')
+        IF (TRIM(MyAppCPP).eq.'KELVIN_SPLINES') THEN
+          CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
+        END IF
+        RETURN
+      END IF
       CALL define ('ANA_INITIAL'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
       SELECT CASE (TRIM(MyAppCPP))
         CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK')   ! (oracle/ref/upwelling_logdrag.h, _mask.h)
@@ -726,16 +774,17 @@
       SUBROUTINE options_from_defines (ierr)
       integer, intent(inout) :: ierr
       integer :: k
-      logical :: upw, bench
+      logical :: upw, bench, kelv
 !  options with a bit in the mask (include/roms_hip.h)
-      character(len=16), parameter :: bitname(16) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
+      character(len=16), parameter :: bitname(17) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
      &    'TS_DIF2', 'MIX_GEO_TS', 'CURVGRID', 'NONLIN_EOS', 'UV_QDRAG', 'LMD_MIXING', 'BULK_FLUXES',           &
-     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG', 'MASKING' ]
-      integer, parameter :: bitval(16) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
+     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG', 'MASKING', 'RADIATION_2D' ]
+      integer, parameter :: bitval(17) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
      &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
-     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING ]
+     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D ]
 !  options whose code is the only form built (accepted, nothing to select) or that only affect output
-      character(len=16), parameter :: inherent(31) = [ character(len=16) :: 'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
+      character(len=16), parameter :: inherent(33) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC',            &
+     &    'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
      &    'DJ_GRADPS', 'MIX_S_UV', 'MIX_S_TS', 'SPLINES_VDIFF', 'SPLINES_VVISC', 'UV_LDRAG', 'ANA_SMFLUX',        &
      &    'ANA_STFLUX', 'ANA_SSFLUX', 'ANA_BTFLUX', 'ANA_BSFLUX', 'ANA_SRFLUX', 'LMD_RIMIX', 'LMD_CONVEC',        &
      &    'LMD_SKPP', 'LMD_NONLOCAL', 'RI_SPLINES', 'LONGWAVE', 'ANA_WINDS', 'ANA_TAIR', 'ANA_PAIR',             &
@@ -746,18 +795,19 @@
       upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
      &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING')
       bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.TRIM(MyAppCPP).eq.'BENCHMARK_MASK'.or.is_defined('BENCHMARK')
-      IF (upw.eqv.bench) THEN
+      kelv=TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES'.or.is_defined('KELVIN')
+      IF (COUNT((/ upw, bench, kelv /)).ne.1) THEN
         CALL unsupported ('MyAppCPP = '//TRIM(MyAppCPP)//': the analytic grid, initial state and forcing '//   &
-     &                    'exist for UPWELLING and BENCHMARK', ierr)
+     &                    'exist for UPWELLING, BENCHMARK and KELVIN', ierr)
         RETURN
       END IF
-      options=MERGE(ROMS_APP_UPWELLING, ROMS_APP_BENCHMARK, upw)
+      options=MERGE(ROMS_APP_UPWELLING, MERGE(ROMS_APP_BENCHMARK, ROMS_APP_KELVIN, bench), upw)
       DO k=1,ndefs
         IF (ANY(bitname.eq.defs(k))) THEN
           options=IOR(options, bitval(FINDLOC(bitname, defs(k), 1)))
         ELSE IF (ANY(inherent.eq.defs(k)).or.ANY(output_only.eq.defs(k))) THEN
           CONTINUE
-        ELSE IF (TRIM(defs(k)).eq.'UPWELLING'.or.TRIM(defs(k)).eq.'BENCHMARK') THEN
+        ELSE IF (TRIM(defs(k)).eq.'UPWELLING'.or.TRIM(defs(k)).eq.'BENCHMARK'.or.TRIM(defs(k)).eq.'KELVIN') THEN
           CONTINUE
         ELSE
           CALL unsupported ('cpp option '//TRIM(defs(k))//' is not built into this library', ierr)
@@ -776,8 +826,13 @@
      &  CALL unsupported ('TS_DIF2 needs exactly one of MIX_S_TS, MIX_GEO_TS', ierr)
       IF (.not.(is_defined('SPLINES_VDIFF').and.is_defined('SPLINES_VVISC')))                                  &
      &  CALL unsupported ('SPLINES_VDIFF and SPLINES_VVISC are the vertical mixing operators built', ierr)
-      IF (is_defined('ANA_VMIX').eqv.is_defined('LMD_MIXING'))                                                 &
-     &  CALL unsupported ('exactly one vertical mixing closure is required: ANA_VMIX or LMD_MIXING', ierr)
+      IF (is_defined('ANA_VMIX').and.is_defined('LMD_MIXING'))                                                 &
+     &  CALL unsupported ('at most one vertical mixing closure: ANA_VMIX or LMD_MIXING (neither: the background '//   &
+     &                    'coefficients AKV_BAK, AKT_BAK, as in KELVIN)', ierr)
+      IF (.not.kelv.and..not.(is_defined('ANA_VMIX').or.is_defined('LMD_MIXING')))                              &
+     &  CALL unsupported ('a vertical mixing closure is required: ANA_VMIX or LMD_MIXING', ierr)
+      IF ((is_defined('ANA_FSOBC').or.is_defined('ANA_M2OBC')).and..not.kelv)                                   &
+     &  CALL unsupported ('ANA_FSOBC / ANA_M2OBC (analytic boundary data) are built for KELVIN only', ierr)
       IF (is_defined('LMD_MIXING').and..not.(is_defined('LMD_RIMIX').and.is_defined('LMD_CONVEC').and.          &
      &    is_defined('LMD_SKPP').and.is_defined('LMD_NONLOCAL').and.is_defined('RI_SPLINES').and.               &
      &    is_defined('SOLAR_SOURCE')))                                                                         &
@@ -1170,10 +1225,34 @@
       deallocate ( lat, inv_dx )
       END SUBROUTINE grid_benchmark
 
+      SUBROUTINE grid_kelvin ()
+!  ana_grid.h:286-291 with the generic Cartesian branch :515-533, :886-891, :1130-1136: a flat channel of 20 km cells,
+!  100 m deep, f-plane
+      real(r8) :: dx, dy
+      integer :: i, j
+      xl=20000.0_r8*REAL(Lm,r8)
+      el=20000.0_r8*REAL(Mm,r8)
+      dx=xl/REAL(Lm,r8)
+      dy=el/REAL(Mm,r8)
+      FORALL (i=Istr-1:Iend+1, j=Jstr-1:Jend+1)
+        xp(i,j)=dx*REAL(i-1,r8)
+        xr(i,j)=dx*(REAL(i-1,r8)+0.5_r8)
+        yp(i,j)=dy*REAL(j-1,r8)
+        yr(i,j)=dy*(REAL(j-1,r8)+0.5_r8)
+      END FORALL
+      pm(IstrT:IendT,JstrT:JendT)=1.0_r8/dx
+      pn(IstrT:IendT,JstrT:JendT)=1.0_r8/dy
+      angler(IstrT:IendT,JstrT:JendT)=0.0_r8
+      f(IstrT:IendT,JstrT:JendT)=1.0E-04_r8
+      h(IstrT:IendT,JstrT:JendT)=100.0_r8
+      END SUBROUTINE grid_kelvin
+
       SUBROUTINE analytic_grid (ierr)
       integer, intent(out) :: ierr
       ierr=0
-      IF (IAND(options,ROMS_APP_UPWELLING).ne.0) THEN
+      IF (IAND(options,ROMS_APP_KELVIN).ne.0) THEN
+        CALL grid_kelvin ()
+      ELSE IF (IAND(options,ROMS_APP_UPWELLING).ne.0) THEN
         CALL grid_upwelling ()
       ELSE IF (IAND(options,ROMS_APP_BENCHMARK).ne.0) THEN
         CALL grid_benchmark ()
@@ -1321,6 +1400,9 @@
         amp=ratio2*(rho0*800.0_r8/g)*(5.0E-05_r8/((42.689_r8/44.69_r8)**2))
         t(i0:i1,j0:j1,:,1,1)=temp_benchmark(z_r(i0:i1,j0:j1,:), amp)
         t(i0:i1,j0:j1,:,1,2)=35.0_r8
+      ELSE IF (IAND(options,ROMS_APP_KELVIN).ne.0) THEN
+!  ana_initial.h: the default branch, T0 everywhere; no SALINITY: the second tracer (carried passively) stays zero
+        t(i0:i1,j0:j1,:,1,1)=T0
       ELSE
         t(i0:i1,j0:j1,:,1,1)=temp_upwelling(z_r(i0:i1,j0:j1,:))
         t(i0:i1,j0:j1,:,1,2)=S0
@@ -1333,6 +1415,13 @@
 !
       SUBROUTINE host_setup (ierr)
       integer, intent(out) :: ierr
+      IF (NAT.eq.1) THEN
+!  (an application without salinity, NAT = 1: the library steps two tracers; the second one is carried passively -- zero,
+!  the advection schemes, diffusivities and boundary conditions of the first)
+        NAT=2
+        hadv(2)=hadv(1); vadv(2)=vadv(1); tnu2(2)=0.0_dp
+        lbc(7,:)=lbc(6,:); Tnudg(2)=Tnudg(1)
+      END IF
       NT=NAT
       IF (ANY(hadv(1:NT).lt.0).or.ANY(vadv(1:NT).lt.0)) THEN
         CALL unsupported ('Hadvection/Vadvection: unknown scheme (A4 C2 C4 HSIMT MPDATA SP SU3 U3)', ierr)
@@ -1355,6 +1444,7 @@
      &           pmon_p(LBi:UBi,LBj:UBj), pnom_p(LBi:UBi,LBj:UBj), pmon_u(LBi:UBi,LBj:UBj),                    &
      &           pnom_u(LBi:UBi,LBj:UBj), pmon_v(LBi:UBi,LBj:UBj), pnom_v(LBi:UBi,LBj:UBj),                    &
      &           dmde(LBi:UBi,LBj:UBj), dndx(LBi:UBi,LBj:UBj), angler(LBi:UBi,LBj:UBj), xr(LBi:UBi,LBj:UBj),   &
+     &           xp(LBi:UBi,LBj:UBj), yp(LBi:UBi,LBj:UBj),                                                     &
      &           yr(LBi:UBi,LBj:UBj), lonr(LBi:UBi,LBj:UBj), latr(LBi:UBi,LBj:UBj), rdrag(LBi:UBi,LBj:UBj),    &
      &           rdrag2(LBi:UBi,LBj:UBj), visc2_r(LBi:UBi,LBj:UBj), visc2_p(LBi:UBi,LBj:UBj),                  &
      &           diff2(LBi:UBi,LBj:UBj,NT), Zt_avg1(LBi:UBi,LBj:UBj), rmask(LBi:UBi,LBj:UBj),                  &
@@ -1366,7 +1456,7 @@
       h=0.0_r8; f=0.0_r8; fomn=0.0_r8; pm=0.0_r8; pn=0.0_r8; om_r=0.0_r8; on_r=0.0_r8; om_u=0.0_r8
       on_u=0.0_r8; om_v=0.0_r8; on_v=0.0_r8; om_p=0.0_r8; on_p=0.0_r8; omn=0.0_r8; pmon_r=0.0_r8
       pnom_r=0.0_r8; pmon_p=0.0_r8; pnom_p=0.0_r8; pmon_u=0.0_r8; pnom_u=0.0_r8; pmon_v=0.0_r8
-      pnom_v=0.0_r8; dmde=0.0_r8; dndx=0.0_r8; angler=0.0_r8; xr=0.0_r8; yr=0.0_r8; lonr=0.0_r8
+      pnom_v=0.0_r8; dmde=0.0_r8; dndx=0.0_r8; angler=0.0_r8; xr=0.0_r8; yr=0.0_r8; lonr=0.0_r8; xp=0.0_r8; yp=0.0_r8
       latr=0.0_r8; Zt_avg1=0.0_r8; Hz=0.0_r8; z_r=0.0_r8; z_w=0.0_r8
 !  the order of the reference's set_grid (Utility/set_grid.F) and initial (Nonlinear/initial.F:293-358)
       CALL analytic_grid (ierr)
@@ -1425,7 +1515,7 @@
       SUBROUTINE host_free ()
       deallocate ( weight, sc_r, Cs_r, sc_w, Cs_w )
       deallocate ( h, f, fomn, pm, pn, om_r, on_r, om_u, on_u, om_v, on_v, om_p, on_p, omn, pmon_r, pnom_r,    &
-     &             pmon_p, pnom_p, pmon_u, pnom_u, pmon_v, pnom_v, dmde, dndx, angler, xr, yr, lonr, latr,    &
+     &             pmon_p, pnom_p, pmon_u, pnom_u, pmon_v, pnom_v, dmde, dndx, angler, xr, yr, xp, yp, lonr, latr, &
      &             rdrag, rdrag2, visc2_r, visc2_p, diff2, Zt_avg1, Hz, z_r, z_w, zeta, ubar, vbar, u, v, t,  &
      &             Akv, Akt, rmask, umask, vmask, pmask )
       END SUBROUTINE host_free
@@ -1434,6 +1524,40 @@
 !  Device context: fill roms_hip_config, upload the state, run the tail of "initial".
 !=======================================================================
 !
+!  lbc and the nudging time scales (1/s) of the radiation + nudging conditions, as inp_par.F:696-752 derives them from
+!  ZNUDG, M2NUDG, M3NUDG, TNUDG (days) and OBCFAC: on the edges whose condition nudges, zero elsewhere
+      SUBROUTINE boundary_config (cfg)
+      TYPE (roms_hip_config), intent(inout) :: cfg
+      integer :: e, itrc
+      real(dp) :: Zn, M2n, M3n, Tn(ROMS_MAXT)
+      cfg%lbc=lbc
+      Zn=0.0_dp; M2n=0.0_dp; M3n=0.0_dp; Tn=0.0_dp
+      IF (Znudg.gt.0.0_dp) Zn=1.0_dp/(Znudg*86400.0_dp)
+      IF (M2nudg.gt.0.0_dp) M2n=1.0_dp/(M2nudg*86400.0_dp)
+      IF (M3nudg.gt.0.0_dp) M3n=1.0_dp/(M3nudg*86400.0_dp)
+      DO itrc=1,NT
+        IF (Tnudg(itrc).gt.0.0_dp) Tn(itrc)=1.0_dp/(Tnudg(itrc)*86400.0_dp)
+      END DO
+      cfg%FSobc_in=0.0_dp; cfg%FSobc_out=0.0_dp; cfg%M2obc_in=0.0_dp; cfg%M2obc_out=0.0_dp
+      cfg%M3obc_in=0.0_dp; cfg%M3obc_out=0.0_dp; cfg%Tobc_in=0.0_dp; cfg%Tobc_out=0.0_dp
+      DO e=1,4
+        IF (lbc(1,e).eq.ROMS_LBC_RADNUD) THEN
+          cfg%FSobc_out(e)=Zn; cfg%FSobc_in(e)=obcfac*Zn
+        END IF
+        IF (lbc(2,e).eq.ROMS_LBC_RADNUD.or.lbc(3,e).eq.ROMS_LBC_RADNUD) THEN
+          cfg%M2obc_out(e)=M2n; cfg%M2obc_in(e)=obcfac*M2n
+        END IF
+        IF (lbc(4,e).eq.ROMS_LBC_RADNUD.or.lbc(5,e).eq.ROMS_LBC_RADNUD) THEN
+          cfg%M3obc_out(e)=M3n; cfg%M3obc_in(e)=obcfac*M3n
+        END IF
+        DO itrc=1,NT
+          IF (lbc(5+itrc,e).eq.ROMS_LBC_RADNUD) THEN
+            cfg%Tobc_out(e,itrc)=Tn(itrc); cfg%Tobc_in(e,itrc)=obcfac*Tn(itrc)
+          END IF
+        END DO
+      END DO
+      END SUBROUTINE boundary_config
+
       SUBROUTINE device_init (device, tile, ierr)
       integer, intent(in) :: device, tile
       integer, intent(out) :: ierr
@@ -1497,6 +1621,7 @@
       cfg%dstart=dstart
       cfg%blk_ZQ=blk_ZQ; cfg%blk_ZT=blk_ZT; cfg%blk_ZW=blk_ZW; cfg%lmd_Jwt=lmd_Jwt
       cfg%sc_r=0.0_dp; cfg%Cs_r=0.0_dp; cfg%sc_w=0.0_dp; cfg%Cs_w=0.0_dp
+      CALL boundary_config (cfg)
       cfg%sc_r(1:N)=sc_r; cfg%Cs_r(1:N)=Cs_r; cfg%sc_w(0:N)=sc_w; cfg%Cs_w(0:N)=Cs_w
       ierr=roms_hip_create(cfg, ctx)
       IF (ierr.ne.0) RETURN
@@ -1514,6 +1639,7 @@
       CALL up ('pnom_u', pnom_u, 1, ierr); CALL up ('pmon_v', pmon_v, 1, ierr)
       CALL up ('pnom_v', pnom_v, 1, ierr); CALL up ('dmde', dmde, 1, ierr); CALL up ('dndx', dndx, 1, ierr)
       CALL up ('angler', angler, 1, ierr); CALL up ('xr', xr, 1, ierr); CALL up ('yr', yr, 1, ierr)
+      CALL up ('xp', xp, 1, ierr); CALL up ('yp', yp, 1, ierr)
       CALL up ('lonr', lonr, 1, ierr); CALL up ('latr', latr, 1, ierr); CALL up ('rdrag', rdrag, 1, ierr)
       CALL up ('rdrag2', rdrag2, 1, ierr); CALL up ('visc2_r', visc2_r, 1, ierr)
       CALL up ('visc2_p', visc2_p, 1, ierr); CALL up ('diff2', diff2, NT, ierr)

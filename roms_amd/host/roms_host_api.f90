@@ -299,6 +299,8 @@
         CASE ('angler');  CALL put (RESHAPE(angler,(/SIZE(angler)/)))
         CASE ('xr');      CALL put (RESHAPE(xr,(/SIZE(xr)/)))
         CASE ('yr');      CALL put (RESHAPE(yr,(/SIZE(yr)/)))
+        CASE ('xp');      CALL put (RESHAPE(xp,(/SIZE(xp)/)))
+        CASE ('yp');      CALL put (RESHAPE(yp,(/SIZE(yp)/)))
         CASE ('lonr');    CALL put (RESHAPE(lonr,(/SIZE(lonr)/)))
         CASE ('latr');    CALL put (RESHAPE(latr,(/SIZE(latr)/)))
         CASE ('rdrag');   CALL put (RESHAPE(rdrag,(/SIZE(rdrag)/)))

@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libroms_host.so")
 
 # arrays the host set-up owns (roms_host_get names = the reference's mod_grid / mod_ocean / mod_mixing names)
 HOST_FIELDS = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", "on_v", "om_p", "on_p", "omn",
-               "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v", "angler", "xr", "yr",
+               "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v", "angler", "xr", "yr", "xp", "yp",
                "rdrag", "rdrag2", "visc2_r", "visc2_p", "diff2", "Hz", "z_r", "z_w", "zeta", "ubar", "vbar", "u", "v",
                "t", "Zt_avg1", "Akv", "Akt", "dmde", "dndx", "lonr", "latr", "sc_r", "Cs_r", "sc_w", "Cs_w"]
 
@@ -62,15 +62,23 @@ def write_roms_in(path, p):
     d = lambda x: repr(float(x)).replace("e", "d") if "e" in repr(float(x)) else repr(float(x)) + "d0"
     per = lambda f: "Per" if f else "Clo"
     lines = [
-        f"    MyAppCPP = {p['app'].upper()}",
+        f"    MyAppCPP = {'KELVIN_SPLINES' if p['app'] == 'kelvin' else p['app'].upper()}",   # (kelvin: oracle/ref/kelvin_splines.h)
         f"          Lm == {p['Lm']}", f"          Mm == {p['Mm']}", f"           N == {p['N']}",
         f"      NtileI == {p.get('NtileI', 1)}", f"      NtileJ == {p.get('NtileJ', 1)}",
         f"  Hadvection == {p['hadv'][0]} \\", f"                {p['hadv'][1]}",
         f"  Vadvection == {p['vadv'][0]} \\", f"                {p['vadv'][1]}",
     ]
     lbc = f"{per(p['EWperiodic'])} {per(p['NSperiodic'])} {per(p['EWperiodic'])} {per(p['NSperiodic'])}"   # W S E N
-    lines += [f" LBC({v}) == {lbc}" for v in ("isFsur", "isUbar", "isVbar", "isUvel", "isVvel", "isMtke")]
-    lines += [f" LBC(isTvar) == {lbc} \\", f"                {lbc}"]
+    # open boundaries: `lbc` of the case (variable -> the four keywords of its LBC line), else closed / periodic
+    kinds = lambda v: " ".join(p.get("lbc", {}).get(v, ())) or lbc
+    lines += [f" LBC({n}) == {kinds(v)}" for n, v in (("isFsur", "zeta"), ("isUbar", "ubar"), ("isVbar", "vbar"), ("isUvel", "u"),
+                                                      ("isVvel", "v"), ("isMtke", "-"))]
+    lines += [f" LBC(isTvar) == {kinds('temp')} \\", f"                {kinds('salt')}"]
+    for key, name in (("Znudg", "ZNUDG"), ("M2nudg", "M2NUDG"), ("M3nudg", "M3NUDG"), ("obcfac", "OBCFAC")):
+        if key in p:
+            lines.append(f"{name:>12} == {d(p[key])}")
+    if "Tnudg" in p:
+        lines.append(f"       TNUDG == {tr(d(x) for x in p['Tnudg'])}")
     lines += [
         f"      NTIMES == {p.get('ntimes', 10)}", f"          DT == {d(p['dt'])}",
         f"     NDTFAST == {p['ndtfast']}", f"       NINFO == {p.get('ninfo', 1)}",

@@ -772,7 +772,9 @@ def test_mailbox_self_exchange_matches_local_periodic_copy(env):
                                                 # the pair kernel's wide strips through the mailbox (tiles of 8 points and more)
                                                 ("benchmark_mid", {}, (2, 2), 29737), ("benchmark_mid", {}, (4, 2), 29738),
                                                 ("upwelling_mask_mid", {"hadv": ("U3", "HSIMT"), "vadv": ("C4", "HSIMT")}, (2, 2), 29739),
-                                                ("upwelling_mid", {"hadv": ("MPDATA", "MPDATA"), "vadv": ("MPDATA", "MPDATA")}, (1, 2), 29740)])
+                                                ("upwelling_mid", {"hadv": ("MPDATA", "MPDATA"), "vadv": ("MPDATA", "MPDATA")}, (1, 2), 29740),
+                                                # open boundaries: k_obc on tiles that hold part of an open edge
+                                                ("kelvin_small", {}, (2, 2), 29742)])
 def test_mailbox_tiles_on_one_gpu_match_single_tile(tmp_path, tag, kw, tiles, port):
     """The mailbox transport between PROCESSES: NtileI x NtileJ ranks share cuda:0, every rank maps its neighbours'
     slabs with hipIpcOpenMemHandle, the pack kernels store into them, the unpack kernels wait for the arrival words

@@ -21,7 +21,7 @@ def _host(cs):
     return hostlib.Host(params=cs)
 
 
-@pytest.mark.parametrize("tag", ["upwelling", "upwelling_small", "benchmark_small"])
+@pytest.mark.parametrize("tag", ["upwelling", "upwelling_small", "benchmark_small", "kelvin_small", "kelvin"])
 def test_host_setup_matches_reference(tag):
     cs = util.case_for(tag)
     g = util.load_init(tag, util.nghost_for(cs))
@@ -139,10 +139,11 @@ def test_reader_accepts_the_reference_spellings(tmp_path):
 
 
 @pytest.mark.parametrize("kw,needle", [
-    (dict(fs="Cha Clo Cha Clo"), "LBC(isFsur) = Cha"),                       # open boundary: zetabc.F:121 not built
-    (dict(ub="Per Clo Per Fla"), "LBC(isUbar) = Fla"),
+    (dict(fs="Red Clo Red Clo"), "LBC(isFsur) = Red"),                       # reduced physics: not built
+    (dict(ub="Per Clo Per Nes"), "LBC(isUbar) = Nes"),                        # nesting
     (dict(ub="Clo Clo Clo Clo"), "periodicity differs"),                      # per-variable periodicity
-    (dict(tv="Per Rad Per Clo"), "LBC(isTvar) = Rad"),                        # the salinity line
+    (dict(fs="Cha Clo Cha Clo"), "periodicity differs"),                      # an open edge is not a periodic one
+    (dict(tv="Per Mix Per Clo"), "LBC(isTvar) = Mix"),                        # the salinity line
     (dict(fs="Per Clo Clo Clo"), "opposite edge"),
     (dict(h1="WENO5"), "unknown scheme"),
     (dict(h1="MPDATA"), "MPDATA must be chosen for both"),
@@ -434,3 +435,41 @@ def test_option_echo_is_the_reference_report(tmp_path, app):
     assert lines[3].split()[0] == A
     got = [(l[1:26].strip(), l[26:].strip()) for l in lines[4:] if l.strip()]
     assert got == want, (got, want)
+
+
+def test_open_boundaries_through_the_host(tmp_path):
+    """LBC lines with open kinds reach the library's configuration (load_lbc, inp_decode.F:1616-1660); the nudging time
+    scales follow inp_par.F:696-752; the reference's KELVIN application as shipped (kelvin.h: no SPLINES_VDIFF /
+    SPLINES_VVISC) stops with the reason, its variant with the spline solvers (oracle/ref/kelvin_splines.h, built in as
+    KELVIN_SPLINES) sets up, also from the reference's own roms_kelvin.in (NAT = 1: the second tracer rides along)."""
+    from roms_amd import hostlib
+    cs = util.case_for("kelvin_small")
+    H = hostlib.Host(params=cs)
+    try:
+        assert H.dims["EWper"] == 0 and H.dims["NSper"] == 0
+        assert H.dims["options"] & hiplib_opt("RADIATION_2D") and H.dims["options"] & hiplib_opt("APP_KELVIN")
+    finally:
+        H.finalize()
+    f = tmp_path / "k.in"
+    hostlib.write_roms_in(str(f), dict(cs, app="kelvin"))
+    text = f.read_text().replace("KELVIN_SPLINES", "KELVIN")
+    f.write_text(text)
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.Host(infile=str(f)).finalize()
+    assert e.value.exit_flag == 5 and "SPLINES_VDIFF" in str(e.value)
+    ref_in = "/root/reference/ROMS/External/roms_kelvin.in"
+    if os.path.exists(ref_in):
+        hdr = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "oracle", "ref", "kelvin_splines.h"))
+        H = hostlib.Host(infile=ref_in, header=hdr)
+        try:
+            assert (H.dims["Lm"], H.dims["Mm"], H.dims["N"]) == (50, 30, 10) and H.dims["ntimes"] == 96
+            g = util.load_init("kelvin", 2)
+            for n in ("h", "f", "pm", "pn", "z_r", "t", "xp", "yp"):
+                assert np.array_equal(H.get(n), g[n]), n
+        finally:
+            H.finalize()
+
+
+def hiplib_opt(name):
+    from roms_amd import hiplib
+    return hiplib.OPTIONS[name]

@@ -68,6 +68,10 @@ def _interior(cs_dims, a):
     ("upwelling_mid", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (2, 2), 29619),
     ("upwelling_mask_mid", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 2), 29620),
     ("upwelling_mid", dict(hadv=("U3", "U3"), vadv=("C4", "C4")), (1, 2), 29621),
+    # open boundaries (the reference's KELVIN application): the western and eastern conditions read along the edge across
+    # the tile boundary (the tangential differences of the radiation condition), corner tiles hold both kinds of edge
+    ("kelvin_small", dict(), (2, 2), 29623),
+    ("kelvin_small", dict(), (1, 2), 29624),
 ])
 def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     _emu_libs()
