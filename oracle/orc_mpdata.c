@@ -258,7 +258,8 @@ void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta_in, double 
       }
   }
   /* boundary values of Ua, Va (closed walls of the BASELINE configs) :642-720 */
-  /* LBC(:,isBu3d = isUvel)%closed: no flow; any other kind: zero gradient (:696-760) */
+  /* LBC(:,isBu3d = isUvel)%closed: no flow; any other kind: zero gradient (:696-760).  (The zero-gradient form is restated
+     from the text only: no pinned case runs MPDATA beside an open edge, and the library refuses that combination.) */
   const int cw = orc_lbc(o, ORC_IWEST, ORC_ISUVEL) == ORC_LBC_CLO, ce = orc_lbc(o, ORC_IEAST, ORC_ISUVEL) == ORC_LBC_CLO;
   const int cs = orc_lbc(o, ORC_ISOUTH, ORC_ISVVEL) == ORC_LBC_CLO, cn = orc_lbc(o, ORC_INORTH, ORC_ISVVEL) == ORC_LBC_CLO;
   if (!c->EWperiodic) {
