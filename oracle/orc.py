@@ -16,7 +16,7 @@ A4, C2, C4, HSIMT, MPDATA, SPLINES, SPLIT_U3, U3 = range(1, 9)
 SCHEMES = dict(A4=A4, C2=C2, C4=C4, HSIMT=HSIMT, MPDATA=MPDATA, SPLINES=SPLINES, SU3=SPLIT_U3, U3=U3)
 UV_ADV, UV_COR, UV_VIS2, TS_DIF2, MIX_GEO_TS, CURVGRID, NONLIN_EOS, UV_QDRAG, LMD_MIXING, \
     BULK_FLUXES, SOLAR_SOURCE, ANA_VMIX, SALINITY, SPHERICAL, UV_LOGDRAG, MASKING = [1 << k for k in range(16)]
-RADIATION_2D = 1 << 16
+RADIATION_2D, PLAIN_VDIFF, PLAIN_VVISC = 1 << 16, 1 << 17, 1 << 18
 APP_UPWELLING, APP_BENCHMARK, APP_KELVIN = 1 << 20, 1 << 21, 1 << 22
 # lateral boundary conditions (orc.h): edges, variables, kinds
 IWEST, ISOUTH, IEAST, INORTH = range(4)

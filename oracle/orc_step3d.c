@@ -64,8 +64,45 @@ void orc_step3d_uv(orc_t *o, int tile) {
       for (int k = 1; k <= N; k++)
         for (int i = i0; i <= Iend; i++) {
           q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] + CX(DC, i, 0) * rq[XW4(i, j, k, nrhs)];
-          q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] * CX(oHz, i, k);
+          if (!(c->options & ORC_PLAIN_VVISC)) q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] * CX(oHz, i, k);
         }
+      if (c->options & ORC_PLAIN_VVISC) {
+        /* without SPLINES_VVISC :436-500 (v: :903-967): off-diagonal coefficients lambda*dt*Akv/dz at W points, the
+           tridiagonal system for Hz*u, back substitution */
+        const double *z_r = o->z_r;
+        cff = -c->lambda * dt / 0.5;
+        for (int k = 1; k <= N - 1; k++)
+          for (int i = i0; i <= Iend; i++) {
+            cff1 = 1.0 / (z_r[X3(i, j, k + 1)] + z_r[X3(i - di, j - dj, k + 1)] - z_r[X3(i, j, k)] - z_r[X3(i - di, j - dj, k)]);
+            CX(FC, i, k) = cff * cff1 * CX(AK, i, k);
+          }
+        for (int i = i0; i <= Iend; i++) { CX(FC, i, 0) = 0.0; CX(FC, i, N) = 0.0; }
+        for (int k = 1; k <= N; k++)
+          for (int i = i0; i <= Iend; i++) {
+            CX(DC, i, k) = q[X4(i, j, k, nnew)];
+            CX(BC, i, k) = CX(Hzk, i, k) - CX(FC, i, k) - CX(FC, i, k - 1);
+          }
+        for (int i = i0; i <= Iend; i++) {
+          cff = 1.0 / CX(BC, i, 1);
+          CX(CF, i, 1) = cff * CX(FC, i, 1);
+          CX(DC, i, 1) = cff * CX(DC, i, 1);
+        }
+        for (int k = 2; k <= N - 1; k++)
+          for (int i = i0; i <= Iend; i++) {
+            cff = 1.0 / (CX(BC, i, k) - CX(FC, i, k - 1) * CX(CF, i, k - 1));
+            CX(CF, i, k) = cff * CX(FC, i, k);
+            CX(DC, i, k) = cff * (CX(DC, i, k) - CX(FC, i, k - 1) * CX(DC, i, k - 1));
+          }
+        for (int i = i0; i <= Iend; i++) {
+          CX(DC, i, N) = (CX(DC, i, N) - CX(FC, i, N - 1) * CX(DC, i, N - 1)) / (CX(BC, i, N) - CX(FC, i, N - 1) * CX(CF, i, N - 1));
+          q[X4(i, j, N, nnew)] = CX(DC, i, N);
+        }
+        for (int k = N - 1; k >= 1; k--)
+          for (int i = i0; i <= Iend; i++) {
+            CX(DC, i, k) = CX(DC, i, k) - CX(CF, i, k) * CX(DC, i, k + 1);
+            q[X4(i, j, k, nnew)] = CX(DC, i, k);
+          }
+      } else {
       /* implicit vertical viscosity, parabolic splines (SPLINES_VVISC) :361-450 */
       cff1 = 1.0 / 6.0;
       for (int k = 1; k <= N - 1; k++)
@@ -92,6 +129,7 @@ void orc_step3d_uv(orc_t *o, int tile) {
           cff = dt * CX(oHz, i, k) * (CX(DC, i, k) - CX(DC, i, k - 1));
           q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] + cff;
         }
+      }
       /* replace vertical mean with the barotropic one :594-730 / :1061-1200 */
       for (int i = i0; i <= Iend; i++) {
         CX(CF, i, 0) = CX(Hzk, i, 1);
@@ -459,7 +497,8 @@ void orc_step3d_t(orc_t *o, int tile) {
           for (int i = Istr; i <= Iend; i++) {
             cff1 = CX(CF, i, 0) * (CX(FC, i, k) - CX(FC, i, k - 1));
             t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] - cff1;
-            t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] * oHz[X3(i, j, k)];
+            if (!(c->options & ORC_PLAIN_VDIFF))                      /* SPLINES_VDIFF: to Tunits :1354-1356 */
+              t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] * oHz[X3(i, j, k)];
           }
       }
     }
@@ -515,7 +554,7 @@ void orc_step3d_t(orc_t *o, int tile) {
   for (int j = Jstr; j <= Jend; j++)
     for (int itrc = 1; itrc <= c->NT; itrc++) {
       const int ltrc = MIN(c->NAT, itrc);
-      if (!(c->hadv[itrc - 1] == ORC_MPDATA && c->vadv[itrc - 1] == ORC_MPDATA)) {
+      if (!(c->hadv[itrc - 1] == ORC_MPDATA && c->vadv[itrc - 1] == ORC_MPDATA) && !(c->options & ORC_PLAIN_VDIFF)) {
         /* parabolic splines (SPLINES_VDIFF) */
         cff1 = 1.0 / 6.0;
         for (int k = 1; k <= N - 1; k++)
@@ -544,7 +583,7 @@ void orc_step3d_t(orc_t *o, int tile) {
             t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] + cff1;
           }
       } else {
-        /* plain tridiagonal (MPDATA tracers) :1724-1790 */
+        /* plain tridiagonal :1724-1790 (MPDATA tracers; every tracer without SPLINES_VDIFF) */
         cff = -dt * c->lambda;
         for (int k = 1; k <= N - 1; k++)
           for (int i = Istr; i <= Iend; i++) {

@@ -44,7 +44,7 @@ def obc_scales(cs):
     return o
 
 
-def kelvin(Lm=50, Mm=30, N=10, NtileI=1, NtileJ=1, ntimes=96, lbc=None):
+def kelvin(Lm=50, Mm=30, N=10, NtileI=1, NtileJ=1, ntimes=96, lbc=None, plain=False):
     """roms_kelvin.in (ROMS/Include/kelvin.h): a Kelvin wave forced through the western boundary of a flat channel --
     Chapman / Flather conditions west, radiation east (RADIATION_2D), closed walls south and north.  The second tracer
     is carried passively (the library has two tracers; the reference application has NAT = 1)."""
@@ -56,7 +56,9 @@ def kelvin(Lm=50, Mm=30, N=10, NtileI=1, NtileJ=1, ntimes=96, lbc=None):
         Tcoef=1.7e-4, Scoef=7.6e-4, visc2=0.0, tnu2=(20.0, 0.0), Akt_bak=(1.0e-6, 1.0e-6), Akv_bak=1.0e-5,
         rdrg=3.0e-4, rdrg2=3.0e-3, Zob=0.02, Zos=0.02, gamma2=1.0, dstart=0.0,
         blk_ZQ=10.0, blk_ZT=10.0, blk_ZW=10.0,
-        options=("UV_ADV", "UV_COR", "UV_QDRAG", "UV_VIS2", "TS_DIF2", "RADIATION_2D", "APP_KELVIN"),
+        # plain: kelvin.h as shipped, without SPLINES_VDIFF / SPLINES_VVISC (the plain tridiagonal vertical solvers)
+        options=("UV_ADV", "UV_COR", "UV_QDRAG", "UV_VIS2", "TS_DIF2", "RADIATION_2D", "APP_KELVIN") +
+                (("PLAIN_VDIFF", "PLAIN_VVISC") if plain else ()),
         lbc=lbc if lbc is not None else dict(zeta=("Cha", "Clo", "Rad", "Clo"), ubar=("Fla", "Clo", "Rad", "Clo"),
                                              vbar=("Fla", "Clo", "Rad", "Clo"), u=open_, v=open_, temp=open_, salt=open_),
     )

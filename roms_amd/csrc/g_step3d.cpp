@@ -26,7 +26,8 @@ int run_step3d_uv(roms_hip_ctx *c) {
   const int N = G.N, nnew = G.nnew;
   KArgs a = mk(c);
   static const char *ech = getenv("ROMS_HIP_COLCH");
-  if (col_lds(G) && (ech ? ech[0] == '1' : N > 40)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l10, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
+  if (G.options & ROMS_PLAIN_VVISC) LAUNCH_THREAD(k_s3uv_col_p, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);   // without SPLINES_VVISC
+  else if (col_lds(G) && (ech ? ech[0] == '1' : N > 40)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l10, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
   else if (col_lds(G)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
   else LAUNCH_THREAD(k_s3uv_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
   if (!G.fuse3d) {   // (fused: the kernels store the boundary values and periodic images themselves, pt_emit)
@@ -74,7 +75,8 @@ int run_step3d_t(roms_hip_ctx *c) {
     any_hsimt |= G.hadv[it] == ROMS_HSIMT;
   }
   a.p0 = (N + KCH - 1) / KCH;
-  if (any_pt && !launch_tadv_lds(c, 1)) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
+  const bool plain = (G.options & ROMS_PLAIN_VDIFF) != 0;    // without SPLINES_VDIFF: the straightforward kernel forms, then k_mp_vdiff
+  if (any_pt && (plain || !launch_tadv_lds(c, 1))) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
   if (any_hsimt) LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
   {
     const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
@@ -90,7 +92,8 @@ int run_step3d_t(roms_hip_ctx *c) {
     const bool ldsform = col_lds(G) && (el ? el[0] == '1' : (N != 30 || hsimt_v));
     // chunks of 10 levels on tall columns: 542 -> 499 us at N = 50 (ROMS_HIP_S3TCH=0/1 forces a form)
     static const char *e10 = getenv("ROMS_HIP_S3TCH");
-    if (ldsform && (e10 ? e10[0] == '1' : N > 40)) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l10, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
+    if (plain) LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
+    else if (ldsform && (e10 ? e10[0] == '1' : N > 40)) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l10, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
     else if (ldsform) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
     else if (regs && N == 30) LAUNCH_THREAD_AS(k_s3t_col, k_s3t_col_n30, nx, ny, G.NT, c->stream, a);
     else LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
@@ -115,7 +118,15 @@ int run_step3d_t(roms_hip_ctx *c) {
     if (col_lds(G)) LAUNCH_COL_AS(k_mp_vdiff, k_mp_vdiff_l, LmT, MmT, 1, 2 * (N + 1), c->stream, m);
     else LAUNCH_THREAD(k_mp_vdiff, LmT, MmT, 1, c->stream, m);
   }
-  if (G.fuse3d && !any_mp) return 0;   // k_s3t_col stored the boundary values and images (pt_emit)
+  for (int it = 1; it <= G.NT && plain; it++) {        // step3d_t.F:1722-1790 for every tracer that is not MPDATA's (done above)
+    if (G.hadv[it - 1] == ROMS_MPDATA) continue;
+    MpArgs m;
+    m.G = G; m.Fv = c->F; m.itrc = it;
+    const int LmT = B.Iend - B.Istr + 1, MmT = B.Jend - B.Jstr + 1;
+    if (col_lds(G)) LAUNCH_COL_AS(k_mp_vdiff, k_mp_vdiff_l, LmT, MmT, 1, 2 * (N + 1), c->stream, m);
+    else LAUNCH_THREAD(k_mp_vdiff, LmT, MmT, 1, c->stream, m);
+  }
+  if (G.fuse3d && !any_mp && !plain) return 0;   // k_s3t_col stored the boundary values and images (pt_emit)
   HaloSpec sp[ROMS_MAXT];
   if (G.obc) for (int it = 1; it <= G.NT; it++) { int r = run_obc3d_t(c, nnew, it); if (r) return r; }
   for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, obc_bc(c, bc_rstate(c, true)), 'r'};   // t3dbc :1858 + exchange :1920

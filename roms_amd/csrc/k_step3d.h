@@ -150,6 +150,74 @@ THREAD_KERNEL(k_s3uv_col_t, KArgs) {
 THREAD_KERNEL(k_s3uv_col, KArgs) { k_s3uv_col_t_body<0>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_s3uv_col, KArgs)
 
+// The same routine WITHOUT SPLINES_VVISC (step3d_uv.F:436-500 for u, :903-967 for v; the reference's KELVIN application):
+// the r.h.s. step leaves Hz*u, the implicit viscosity is the plain tridiagonal system BC(k) = Hzk(k) - FC(k) - FC(k-1),
+// FC(k) = -lambda*dt/0.5 * Akv(k) / (z_r(k+1) + z_r'(k+1) - z_r(k) - z_r'(k)) of the two columns either side of the
+// velocity point; back substitution gives the velocity.  One thread per column, the elimination coefficients in private
+// memory (not a BASELINE path: the straightforward form).
+THREAD_KERNEL(k_s3uv_col_p, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int dir = gz;
+  const int i = (dir == 0 ? B.IstrU : B.Istr) + gx, j = (dir == 0 ? B.Jstr : B.JstrV) + gy;
+  if (i > B.Iend || j > B.Jend) return;
+  const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1;
+  const int N = G.N, nrhs = G.nrhs, nnew = G.nnew;
+  const double dt = G.dt;
+  double *q = (dir == 0 ? F.u : F.v) + (size_t)(nnew - 1) * G.nij * N;
+  const double *rq = (dir == 0 ? F.ru : F.rv) + (size_t)(nrhs - 1) * G.nij * (N + 1);
+  const double *Akv = F.Akv, *Hz = F.Hz, *z_r = F.z_r;
+  double CF[ROMS_NPRIV], DC[ROMS_NPRIV];
+#define AKc(kk) (0.5 * (Akv[XW(i - di, j - dj, kk)] + Akv[XW(i, j, kk)]))
+#define HZc(kk) (0.5 * (Hz[X3(i - di, j - dj, kk)] + Hz[X3(i, j, kk)]))
+#define FCc(kk) (((kk) <= 0 || (kk) >= N) ? 0.0 : cfv * (1.0 / (z_r[X3(i, j, (kk) + 1)] + z_r[X3(i - di, j - dj, (kk) + 1)] - z_r[X3(i, j, kk)] - z_r[X3(i - di, j - dj, kk)])) * AKc(kk))
+  double cff;
+  if (G.iic == G.ntfirst) cff = 0.25 * dt;
+  else if (G.iic == G.ntfirst + 1) cff = 0.25 * dt * 3.0 / 2.0;
+  else cff = 0.25 * dt * 23.0 / 12.0;
+  const double DC0 = cff * (F.pm[X2(i, j)] + F.pm[X2(i - di, j - dj)]) * (F.pn[X2(i, j)] + F.pn[X2(i - di, j - dj)]);
+  const double cfv = -G.lambda * dt / 0.5;
+  {
+    const double BC1 = HZc(1) - FCc(1) - FCc(0);
+    const double c = 1.0 / BC1;
+    CF[1] = c * FCc(1);
+    DC[1] = c * (q[X3(i, j, 1)] + DC0 * rq[XW(i, j, 1)]);
+  }
+  for (int k = 2; k <= N - 1; k++) {
+    const double FCm = FCc(k - 1), FCk = FCc(k);
+    const double BCk = HZc(k) - FCk - FCm;
+    const double c = 1.0 / (BCk - FCm * CF[k - 1]);
+    CF[k] = c * FCk;
+    DC[k] = c * ((q[X3(i, j, k)] + DC0 * rq[XW(i, j, k)]) - FCm * DC[k - 1]);
+  }
+  {
+    const double FCm = FCc(N - 1);
+    const double BCN = HZc(N) - FCc(N) - FCm;
+    DC[N] = ((q[X3(i, j, N)] + DC0 * rq[XW(i, j, N)]) - FCm * DC[N - 1]) / (BCN - FCm * CF[N - 1]);
+  }
+  for (int k = N - 1; k >= 1; k--) DC[k] = DC[k] - CF[k] * DC[k + 1];
+  // vertical mean :594-730 / :1061-1200 (sums in ascending k) and correction
+  double CF0 = 0.0, DCs = 0.0;
+  for (int k = 1; k <= N; k++) {
+    const double h = HZc(k);
+    if (k == 1) { CF0 = h; DCs = DC[k] * h; }
+    else { CF0 = CF0 + h; DCs = DCs + DC[k] * h; }
+  }
+  const double omn1 = (dir == 0 ? F.on_u : F.om_v)[X2(i, j)];
+  const double Davg = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
+  const double cff1 = 1.0 / (CF0 * omn1);
+  const double corr = (DCs * omn1 - Davg) * cff1;
+  const double qmask = G.masking ? (dir == 0 ? F.umask : F.vmask)[X2(i, j)] : 1.0;
+  const EmitPlan PQ = emit_plan(G, dir == 0 ? BC_U : BC_V, i, j);
+  for (int k = 1; k <= N; k++)
+    emit_store(G, PQ, q + (size_t)(k - 1) * G.nij, G.masking ? (DC[k] - corr) * qmask : DC[k] - corr);
+#undef AKc
+#undef HZc
+#undef FCc
+}
+THREAD_GLOBAL(k_s3uv_col_p, KArgs)
+
 // The same kernel with the column state in LDS (COL launch: one wave per block, 2*(N+1) doubles per
 // column): the elimination coefficients CF, DC of the up sweep live in LDS; the down sweep leaves the
 // viscosity-corrected velocity and the layer thickness of each level in the slots it has just
@@ -579,7 +647,7 @@ THREAD_KERNEL(k_s3t_hv, KArgs) {
     if (vert) {
       const double cv = cff * (FC[q + 1] - FC[q]);
       tt = tt - cv;
-      tt = tt * (1.0 / F.Hz[ok + x]);
+      if (!(G.options & ROMS_PLAIN_VDIFF)) tt = tt * (1.0 / F.Hz[ok + x]);   // SPLINES_VDIFF: to tracer units :1354-1356
     }
     tn[ok] = tt;
   }
@@ -701,7 +769,7 @@ THREAD_KERNEL(k_s3t_col_t, KArgs) {
       } else VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
       const double cff1 = pmn_dt * (FCk - FCm);
       double tt = tn[X3(i, j, k)] - cff1;
-      tt = tt * (1.0 / Hz[X3(i, j, k)]);
+      if (!(G.options & ROMS_PLAIN_VDIFF)) tt = tt * (1.0 / Hz[X3(i, j, k)]);
       tn[X3(i, j, k)] = tt;
       FCm = FCk;
     }
@@ -710,6 +778,7 @@ THREAD_KERNEL(k_s3t_col_t, KArgs) {
   #undef KAZ
   #undef GZ
   }
+  if (G.options & ROMS_PLAIN_VDIFF) return;     // without SPLINES_VDIFF the plain tridiagonal solve follows (k_mp_vdiff)
   // implicit vertical diffusion, parabolic splines (SPLINES_VDIFF) :1664-1722.  Two sweeps over the column,
   // six levels at a time: the levels' inputs are loaded first (the loads overlap), then the recurrence
   // runs on registers.  The downward sweep does the back-substitution and adds the flux divergence of
@@ -846,7 +915,7 @@ COL_KERNEL(k_s3t_col_lt, KArgs) {
             }
             const double cff1 = pmn_dt * (FCk - FCm);
             double tt = tv[m] - cff1;
-            tt = tt * (1.0 / hz[m]);
+            if (!(G.options & ROMS_PLAIN_VDIFF)) tt = tt * (1.0 / hz[m]);
             tn[X3(i, j, k)] = tt;
             FCm = FCk;
           }
@@ -864,7 +933,7 @@ COL_KERNEL(k_s3t_col_lt, KArgs) {
         else VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
         const double cff1 = pmn_dt * (FCk - FCm);
         double tt = tn[X3(i, j, k)] - cff1;
-        tt = tt * (1.0 / Hz[X3(i, j, k)]);
+        if (!(G.options & ROMS_PLAIN_VDIFF)) tt = tt * (1.0 / Hz[X3(i, j, k)]);
         tn[X3(i, j, k)] = tt;
         FCm = FCk;
       }
@@ -872,6 +941,7 @@ COL_KERNEL(k_s3t_col_lt, KArgs) {
 #undef Wc
     }
   }
+  if (G.options & ROMS_PLAIN_VDIFF) return;     // (k_mp_vdiff follows)
   // implicit vertical diffusion, parabolic splines (SPLINES_VDIFF) :1664-1722
   {
     const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;

@@ -439,7 +439,9 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   {  // MPDATA work arrays
     bool any_mp = false;
     for (int it = 0; it < cfg->NT; it++) any_mp |= cfg->hadv[it] == ROMS_MPDATA || cfg->vadv[it] == ROMS_MPDATA;
-    for (int k = 0; k < 6 && any_mp; k++) {
+    const bool plain = (cfg->options & ROMS_PLAIN_VDIFF) != 0;   // k_mp_vdiff's two work arrays (the form without LDS)
+    for (int k = 0; k < 6; k++) {
+      if (!(any_mp || (plain && k >= 4))) continue;
       void *p = nullptr;
       if (dmalloc(&p, (size_t)G.nij * (size_t)(G.N + 1) * (k == 0 ? (size_t)G.NT : 1) * sizeof(double))) { roms_hip_destroy(c); return 2; }
       c->allocs.push_back(p);

@@ -722,8 +722,8 @@
         CALL define (TRIM(common(k)))
       END DO
       IF (TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES') THEN
-!  ROMS/Include/kelvin.h; KELVIN_SPLINES = oracle/ref/kelvin_splines.h: the same with the spline vertical solvers (the
-!  plain tridiagonal forms kelvin.h selects are not built: options_from_defines stops KELVIN itself with that reason)
+!  ROMS/Include/kelvin.h (plain tridiagonal vertical solvers); KELVIN_SPLINES = oracle/ref/kelvin_splines.h: the same with
+!  the spline vertical solvers of UPWELLING and BENCHMARK
         ndefs=0
         CALL define ('UV_ADV'); CALL define ('UV_COR'); CALL define ('UV_QDRAG'); CALL define ('UV_VIS2')
         CALL define ('MIX_S_UV'); CALL define ('DJ_GRADPS'); CALL define ('TS_DIF2'); CALL define ('MIX_S_TS')
@@ -824,8 +824,11 @@
      &  CALL unsupported ('UV_VIS2 is built along s-surfaces only (MIX_S_UV)', ierr)
       IF (is_defined('TS_DIF2').and.(is_defined('MIX_S_TS').eqv.is_defined('MIX_GEO_TS')))                     &
      &  CALL unsupported ('TS_DIF2 needs exactly one of MIX_S_TS, MIX_GEO_TS', ierr)
-      IF (.not.(is_defined('SPLINES_VDIFF').and.is_defined('SPLINES_VVISC')))                                  &
-     &  CALL unsupported ('SPLINES_VDIFF and SPLINES_VVISC are the vertical mixing operators built', ierr)
+!  without SPLINES_VDIFF / SPLINES_VVISC: the plain tridiagonal vertical solvers (step3d_t.F:1722-1790, step3d_uv.F:436-500)
+      IF (.not.is_defined('SPLINES_VDIFF')) options=IOR(options, ROMS_PLAIN_VDIFF)
+      IF (.not.is_defined('SPLINES_VVISC')) options=IOR(options, ROMS_PLAIN_VVISC)
+      IF (.not.is_defined('SPLINES_VDIFF').and.ANY(hadv(1:NAT).eq.ROMS_MPDATA))                                &
+     &  CALL unsupported ('MPDATA is built with SPLINES_VDIFF only', ierr)
       IF (is_defined('ANA_VMIX').and.is_defined('LMD_MIXING'))                                                 &
      &  CALL unsupported ('at most one vertical mixing closure: ANA_VMIX or LMD_MIXING (neither: the background '//   &
      &                    'coefficients AKV_BAK, AKT_BAK, as in KELVIN)', ierr)

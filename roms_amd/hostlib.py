@@ -62,7 +62,8 @@ def write_roms_in(path, p):
     d = lambda x: repr(float(x)).replace("e", "d") if "e" in repr(float(x)) else repr(float(x)) + "d0"
     per = lambda f: "Per" if f else "Clo"
     lines = [
-        f"    MyAppCPP = {'KELVIN_SPLINES' if p['app'] == 'kelvin' else p['app'].upper()}",   # (kelvin: oracle/ref/kelvin_splines.h)
+        # (kelvin: ROMS/Include/kelvin.h when the case asks for the plain vertical solvers, else oracle/ref/kelvin_splines.h)
+        f"    MyAppCPP = {('KELVIN' if 'PLAIN_VDIFF' in p.get('options', ()) else 'KELVIN_SPLINES') if p['app'] == 'kelvin' else p['app'].upper()}",
         f"          Lm == {p['Lm']}", f"          Mm == {p['Mm']}", f"           N == {p['N']}",
         f"      NtileI == {p.get('NtileI', 1)}", f"      NtileJ == {p.get('NtileJ', 1)}",
         f"  Hadvection == {p['hadv'][0]} \\", f"                {p['hadv'][1]}",

@@ -238,6 +238,7 @@ STEP_CASES = [
     ("upwelling_mask_small_mpdata", "upwelling_mask_small", ["nsteps=60", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
     # open boundaries: the reference's KELVIN application (oracle/ref/kelvin_splines.h)
     ("kelvin_small", "kelvin_small", ["nsteps=96"]),
+    ("kelvin_plain_small", "kelvin_plain_small", ["nsteps=96"]),     # ROMS/Include/kelvin.h as shipped: plain vertical solvers
 ]
 KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
 def make_avg():

@@ -31,7 +31,8 @@ CASES = {
     # open boundaries: the reference's own KELVIN application (ROMS/Include/kelvin.h, RADIATION_2D) ...
     "kelvin": ("kelvin_splines", dict()),
     "kelvin_small": ("kelvin_splines", dict(Lm=16, Mm=12, N=6)),
-    "kelvin_plain_small": ("kelvin", dict(Lm=16, Mm=12, N=6)),          # kelvin.h as shipped (BC routines only)
+    "kelvin_plain_small": ("kelvin", dict(Lm=16, Mm=12, N=6, plain=True)),   # kelvin.h as shipped: the plain vertical solvers
+    "kelvin_plain": ("kelvin", dict(plain=True)),
     # ... and closed-basin variants of the other libraries for the routine-level tests (no RADIATION_2D; MASKING)
     "upwelling_obc_small": ("upwelling", dict(Lm=14, Mm=18, N=8)),
     "upwelling_mask_obc_small": ("upwelling_mask", dict(Lm=14, Mm=18, N=8)),

@@ -681,7 +681,7 @@ def hiplib_options():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["kelvin", "mixed", "four"])
+@pytest.mark.parametrize("variant", ["kelvin", "plain", "mixed", "four"])
 def test_open_boundaries_match_oracle(variant):
     """Open boundaries on the GPU (k_obc.h): the reference's KELVIN application -- Chapman / Flather west, radiation east,
     RADIATION_2D, analytic boundary data computed on the device -- and the other kinds (Chapman explicit, Shchepetkin,
@@ -691,13 +691,13 @@ def test_open_boundaries_match_oracle(variant):
     from roms_amd import hiplib
     from tests.test_kernels_emu import OBC_VARIANTS
     kw = {} if OBC_VARIANTS[variant] is None else dict(lbc=OBC_VARIANTS[variant])
-    cs = util.case_for("kelvin_small", **kw)
+    cs = util.case_for("kelvin_plain_small" if variant == "plain" else "kelvin_small", **kw)
     if variant == "mixed":
         cs.update(Znudg=0.5, M2nudg=0.25, M3nudg=2.0, Tnudg=(1.0, 3.0), obcfac=4.0)
     g = util.load_init("kelvin_small", util.nghost_for(cs))
     O = util.make_oracle(cs, g)
     H = util.make_hip(cs, g)
-    if variant != "kelvin":
+    if variant not in ("kelvin", "plain"):
         rng = np.random.default_rng(3)
         for n in hiplib.BRY_FIELDS:
             if n.startswith(("u_", "v_", "t_")) or n.endswith(("south", "north")):

@@ -89,6 +89,8 @@ def test_romsM_prints_the_reference_run_report(tmp_path):
     (a last-digit difference is tolerated: exp() in ana_vmix differs by an ulp on the device)."""
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     util.check_romsM_report(os.path.join(root, "roms_amd", "romsM"), tmp_path, exact=False)
+    # the reference's KELVIN application as shipped (open boundaries, plain vertical solvers)
+    util.check_romsM_report(os.path.join(root, "roms_amd", "romsM"), tmp_path, exact=False, fixture="kelvin_plain_small_steps.npz")
 
 
 def test_partition_matches_reference_get_bounds():

@@ -439,9 +439,10 @@ def test_option_echo_is_the_reference_report(tmp_path, app):
 
 def test_open_boundaries_through_the_host(tmp_path):
     """LBC lines with open kinds reach the library's configuration (load_lbc, inp_decode.F:1616-1660); the nudging time
-    scales follow inp_par.F:696-752; the reference's KELVIN application as shipped (kelvin.h: no SPLINES_VDIFF /
-    SPLINES_VVISC) stops with the reason, its variant with the spline solvers (oracle/ref/kelvin_splines.h, built in as
-    KELVIN_SPLINES) sets up, also from the reference's own roms_kelvin.in (NAT = 1: the second tracer rides along)."""
+    scales follow inp_par.F:696-752; the reference's KELVIN application sets up as shipped (kelvin.h: no SPLINES_VDIFF /
+    SPLINES_VVISC -> the plain vertical solvers) and in its variant with the spline solvers (oracle/ref/kelvin_splines.h,
+    built in as KELVIN_SPLINES), also from the reference's own roms_kelvin.in and kelvin.h (NAT = 1: the second tracer
+    rides along)."""
     from roms_amd import hostlib
     cs = util.case_for("kelvin_small")
     H = hostlib.Host(params=cs)
@@ -450,19 +451,18 @@ def test_open_boundaries_through_the_host(tmp_path):
         assert H.dims["options"] & hiplib_opt("RADIATION_2D") and H.dims["options"] & hiplib_opt("APP_KELVIN")
     finally:
         H.finalize()
-    f = tmp_path / "k.in"
-    hostlib.write_roms_in(str(f), dict(cs, app="kelvin"))
-    text = f.read_text().replace("KELVIN_SPLINES", "KELVIN")
-    f.write_text(text)
-    with pytest.raises(hostlib.HostError) as e:
-        hostlib.Host(infile=str(f)).finalize()
-    assert e.value.exit_flag == 5 and "SPLINES_VDIFF" in str(e.value)
+    # as shipped (ROMS/Include/kelvin.h: no SPLINES_VDIFF / SPLINES_VVISC): the plain vertical solvers are selected
+    H = hostlib.Host(params=util.case_for("kelvin_plain_small"))
+    try:
+        assert H.dims["options"] & hiplib_opt("PLAIN_VDIFF") and H.dims["options"] & hiplib_opt("PLAIN_VVISC")
+    finally:
+        H.finalize()
     ref_in = "/root/reference/ROMS/External/roms_kelvin.in"
     if os.path.exists(ref_in):
-        hdr = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "oracle", "ref", "kelvin_splines.h"))
-        H = hostlib.Host(infile=ref_in, header=hdr)
+        H = hostlib.Host(infile=ref_in, header="/root/reference/ROMS/Include/kelvin.h")
         try:
             assert (H.dims["Lm"], H.dims["Mm"], H.dims["N"]) == (50, 30, 10) and H.dims["ntimes"] == 96
+            assert H.dims["options"] & hiplib_opt("PLAIN_VDIFF") and H.dims["options"] & hiplib_opt("RADIATION_2D")
             g = util.load_init("kelvin", 2)
             for n in ("h", "f", "pm", "pn", "z_r", "t", "xp", "yp"):
                 assert np.array_equal(H.get(n), g[n]), n

@@ -217,6 +217,9 @@ def test_romsM_run_report_is_the_reference_text(emu, tmp_path):
     for character (the emulated exp() is glibc's, as the reference's)."""
     exe = os.path.join(os.path.dirname(util.EMU_LIB), "romsM_emu")
     util.check_romsM_report(exe, tmp_path, exact=True)
+    # the reference's KELVIN application (open boundaries), as shipped and with the spline vertical solvers
+    util.check_romsM_report(exe, tmp_path, exact=True, fixture="kelvin_plain_small_steps.npz")
+    util.check_romsM_report(exe, tmp_path, exact=True, fixture="kelvin_small_steps.npz")
 
 
 def test_product_partition_matches_reference_get_bounds(emu):
@@ -253,6 +256,8 @@ def test_time_averages_bitwise(emu, tag, nAVG, ntsAVG):
 OBC_VARIANTS = {
     # the reference's KELVIN application as shipped (roms_kelvin.in): Chapman / Flather west, radiation east, walls south / north
     "kelvin": None,
+    # ... with the plain tridiagonal vertical solvers kelvin.h itself selects (no SPLINES_VDIFF / SPLINES_VVISC)
+    "plain": None,
     # the other kinds on the open edges, nudging towards uploaded boundary data
     "mixed": dict(zeta=("Che", "Clo", "RadNud", "Clo"), ubar=("Shc", "Clo", "RadNud", "Clo"), vbar=("Shc", "Clo", "Gra", "Clo"),
                   u=("RadNud", "Clo", "Gra", "Clo"), v=("Gra", "Clo", "RadNud", "Clo"), temp=("RadNud", "Clo", "Cla", "Clo"),
@@ -271,13 +276,13 @@ def test_open_boundaries_bitwise(emu, variant):
     KELVIN application): the Kelvin wave entering through the western boundary, 12 steps against the oracle, bit for bit;
     the boundary really is open (the wave arrives: |u| grows from rest)."""
     kw = {} if OBC_VARIANTS[variant] is None else dict(lbc=OBC_VARIANTS[variant])
-    cs = util.case_for("kelvin_small", **kw)
+    cs = util.case_for("kelvin_plain_small" if variant == "plain" else "kelvin_small", **kw)
     if variant == "mixed":
         cs.update(Znudg=0.5, M2nudg=0.25, M3nudg=2.0, Tnudg=(1.0, 3.0), obcfac=4.0)
     g = util.load_init("kelvin_small", util.nghost_for(cs))
     O = util.make_oracle(cs, g)
     H = util.make_hip(cs, g, emu)
-    if variant != "kelvin":      # boundary data the analytic KELVIN functions do not provide: uploaded, as a caller's set_data would
+    if variant not in ("kelvin", "plain"):      # boundary data the analytic KELVIN functions do not provide: uploaded, as a caller's set_data would
         rng = np.random.default_rng(3)
         from roms_amd import hiplib
         for n in hiplib.BRY_FIELDS:

@@ -181,7 +181,7 @@ def _child(mode, tag, *args, timeout=900):
     lib = {"upwelling_kpp_small": "upwelling_kpp", "upwelling_avg_small": "upwelling_avg",
            "upwelling_logdrag_small": "upwelling_logdrag", "upwelling_mask_small": "upwelling_mask",
            "benchmark_mask_small": "benchmark_mask", "upwelling_avg_mask_small": "upwelling_avg_mask",
-           "kelvin": "kelvin_splines", "kelvin_small": "kelvin_splines", "kelvin_plain_small": "kelvin",
+           "kelvin": "kelvin_splines", "kelvin_small": "kelvin_splines", "kelvin_plain_small": "kelvin", "kelvin_plain": "kelvin",
            "upwelling_obc_small": "upwelling", "upwelling_mask_obc_small": "upwelling_mask"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
     if not ref.available(lib):
         pytest.skip(f"oracle/_ref/libromsref_{lib}.so not built here")
@@ -214,6 +214,10 @@ MAIN3D_CASES = [
     ("kelvin_small", ["nsteps=60"]),
     ("kelvin_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("kelvin", ["nsteps=96"]),                                                   # roms_kelvin.in, full size and length
+    # ... and as shipped (ROMS/Include/kelvin.h: no SPLINES_VDIFF / SPLINES_VVISC -- the plain tridiagonal vertical solvers)
+    ("kelvin_plain_small", ["nsteps=60"]),
+    ("kelvin_plain_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("kelvin_plain", ["nsteps=96"]),
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
     ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
 ]

@@ -72,6 +72,10 @@ def case_for(tag, **kw):
         return cases.kelvin(Lm=16, Mm=12, N=6, **kw)
     if tag == "kelvin":
         return cases.kelvin(**kw)
+    if tag == "kelvin_plain_small":      # ROMS/Include/kelvin.h as shipped: no SPLINES_VDIFF / SPLINES_VVISC
+        return cases.kelvin(Lm=16, Mm=12, N=6, plain=True, **kw)
+    if tag == "kelvin_plain":
+        return cases.kelvin(plain=True, **kw)
     if tag == "upwelling_logdrag_small":
         return cases.upwelling_logdrag(Lm=14, Mm=18, N=8, **kw)
     raise KeyError(tag)
