@@ -515,9 +515,11 @@
             knew(ng)=3
             krhs(ng)=indx1(ng)
           END IF
-          DO tile=last_tile(ng),first_tile(ng),-1          ! :856-858
-            CALL step2d (ng, tile)
-          END DO
+          IF (my_iif.le.(nfast(ng)+1)) THEN                ! :853-859
+            DO tile=last_tile(ng),first_tile(ng),-1
+              CALL step2d (ng, tile)
+            END DO
+          END IF
           IF (PREDICTOR_2D_STEP(ng)) THEN                  ! :876-884
             PREDICTOR_2D_STEP(ng)=.FALSE.
             knew(ng)=next_indx1

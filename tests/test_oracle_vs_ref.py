@@ -296,3 +296,94 @@ def test_set_avg_on_a_masked_run_bitwise():
     the masked state they accumulate does -- all of them after every call of two windows."""
     out = _child("avg", "upwelling_avg_mask_small", "nsteps=7", "nAVG=3", "ntsAVG=1")
     assert "AVG-OK bitwise" in out, out
+
+
+# ----------------------------------------------------------------------------------------------------
+# main3d.F itself cannot be compiled here (it USEs the NetCDF readers and writers); the fixtures and the main3d
+# tests above are driven by oracle/ref/ref_glue.F90:ref_main3d, which calls the reference's kernels in main3d's
+# order.  That order is checked against the TEXT of main3d.F / post_initial.F, pre-processed for each application the
+# way build_ref.sh pre-processes the sources: a change of the glue (or of the reference) that reorders, drops or
+# adds a kernel call, or flips the direction of a tile loop, fails here.
+# ----------------------------------------------------------------------------------------------------
+def _cpp(path, up, hdrpath, extra=()):
+    REF = "/root/reference"
+    cmd = ["/usr/bin/cpp", "-P", "-traditional", "-w", f"-D{up}", f'-DROMS_HEADER="{hdrpath}"', '-DHEADER="x.h"',
+           "-DLINUX", "-DX86_64", "-DGFORTRAN", "-DNestedGrids=1", f'-DROOT_DIR="{REF}"',
+           f'-DANALYTICAL_DIR="{REF}/ROMS/Functionals"', f'-DHEADER_DIR="{REF}/ROMS/Include"', '-DGIT_URL="x"', '-DGIT_REV="x"',
+           '-DMY_OS="Linux"', '-DMY_CPU="x86_64"', '-DMY_FORT="gfortran"', '-DMY_FC="flang"', '-DMY_FFLAGS="-O2"', *extra,
+           f"-I{REF}/ROMS/Include", f"-I{REF}/ROMS/Nonlinear", f"-I{REF}/ROMS/Functionals", f"-I{REF}/ROMS/Utility",
+           f"-I{REF}/ROMS/Drivers", f"-I{REF}/Master", path]
+    return subprocess.run(cmd, capture_output=True, text=True, check=True).stdout
+
+
+def _tile_calls(text, start, end):
+    """[(direction of the enclosing tile loop, routine)] of the `CALL name (ng, tile` statements between two markers"""
+    import re
+    body = text[text.index(start):]
+    body = body[:body.index(end)]
+    seq, direction = [], None
+    for line in body.splitlines():
+        s = line.strip()
+        m = re.match(r"DO tile=(first|last)_tile\(ng\)", s)
+        if m:
+            direction = "+" if m.group(1) == "first" else "-"
+        m = re.match(r"CALL (\w+) \((?:ng, )?tile", s)
+        if m:
+            seq.append((direction, m.group(1)))
+    return seq
+
+
+@pytest.mark.parametrize("up,hdr,extra", [
+    ("UPWELLING", "upwelling.h", ("-DPERFECT_RESTART",)), ("BENCHMARK", "benchmark.h", ()), ("KELVIN", "kelvin.h", ()),
+    ("UPWELLING", os.path.join(ROOT, "oracle", "ref", "upwelling_kpp.h"), ()),
+    ("BENCHMARK", os.path.join(ROOT, "oracle", "ref", "benchmark_mask.h"), ()),
+    ("KELVIN", os.path.join(ROOT, "oracle", "ref", "kelvin_splines.h"), ()),
+])
+def test_glue_calls_the_kernels_in_the_order_of_main3d_F(up, hdr, extra):
+    if not os.path.isdir("/root/reference/ROMS"):
+        pytest.skip("needs the reference tree")
+    ref = _tile_calls(_cpp("/root/reference/ROMS/Nonlinear/main3d.F", up, hdr, extra), "STEP_LOOP : DO istep", "END DO STEP_LOOP")
+    post = _tile_calls(_cpp("/root/reference/ROMS/Nonlinear/post_initial.F", up, hdr, extra), "SUBROUTINE post_initial", "END SUBROUTINE post_initial")
+    glue = _tile_calls(_cpp(os.path.join(ROOT, "oracle", "ref", "ref_glue.F90"), up, hdr, extra), "SUBROUTINE ref_main3d", "END SUBROUTINE ref_main3d")
+    glue = [(d, "set_data" if n == "ref_set_data" else n) for d, n in glue]
+    assert len(ref) >= 15 and ("-", "step2d") in ref and ("+", "step2d") in ref
+    # the glue inlines post_initial (main3d.F:334) where main3d.F calls it: behind set_data of the first step
+    k = glue.index(("+", "ini_zeta"))
+    inlined = glue[k:k + len(post)]
+    assert inlined == post, (inlined, post)
+    assert glue[:k] + glue[k + len(post):] == ref, (glue, ref)
+
+
+def _index_statements(text, start, end):
+    """the statements of the barotropic loop's index state machine (main3d.F:810-918), continuation lines joined, blanks dropped"""
+    import re
+    body = text[text.index(start):]
+    body = body[:body.index(end)]
+    joined, cur = [], ""
+    for line in body.splitlines():
+        s = line.strip()
+        if not s or s.startswith("!"):
+            continue
+        s = s.split("!")[0].strip()              # (trailing comments: the glue cites main3d.F lines)
+        if s.startswith("&"):
+            cur += s[1:].strip()
+            continue
+        if cur:
+            joined.append(cur)
+        cur = s.rstrip("&").strip()
+    joined.append(cur)
+    keep = re.compile(r"^(IF \(|ELSE|END IF|next_indx1=|PREDICTOR_2D_STEP\(ng\)=|iif\(ng\)=|kstp\(ng\)=|knew\(ng\)=|krhs\(ng\)=|indx1\(ng\)=)")
+    return [re.sub(r"\s+", "", s) for s in joined if keep.match(s)]
+
+
+def test_glue_steps_the_barotropic_indices_as_main3d_F_does():
+    """kstp / knew / krhs / indx1 / iif / PREDICTOR_2D_STEP through the 2*nfast+1 step2d calls: statement for statement
+    the text of main3d.F's LOOP_2D (the oracle's and the library's state machines are compared with this glue at run time)."""
+    if not os.path.isdir("/root/reference/ROMS"):
+        pytest.skip("needs the reference tree")
+    ref = _index_statements(_cpp("/root/reference/ROMS/Nonlinear/main3d.F", "UPWELLING", "upwelling.h", ("-DPERFECT_RESTART",)),
+                            "LOOP_2D : DO my_iif", "END DO LOOP_2D")
+    glue = _index_statements(_cpp(os.path.join(ROOT, "oracle", "ref", "ref_glue.F90"), "UPWELLING", "upwelling.h", ("-DPERFECT_RESTART",)),
+                             "LOOP_2D : DO my_iif", "END DO LOOP_2D")
+    assert len(ref) >= 12 and "knew(ng)=3" in ref
+    assert glue == ref, (glue, ref)
