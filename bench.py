@@ -361,6 +361,7 @@ def main():
                     help="measurement aid: time-average the 22 default Aout fields over windows of NAVG steps "
                          "(AVERAGES of the stock upwelling.h; off in the headline run, as in roms_benchmark*.in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 512x512x50 pass of the default run")
     ap.add_argument("--breakdown-file", default=None, help="write the per-kernel table (JSON) here")
@@ -401,19 +402,38 @@ def main():
         dist.destroy_process_group()
         return
 
+    if args.cpu_leg:
+        # (child of the run below) the CPU leg alone: the host set-up, the oracle on the host cores, one JSON line
+        from roms_amd import hostlib as _hl
+        cs0 = params_for(args.workload, args.Lm, args.Mm, args.N, ntimes=10)
+        H0 = _hl.Host(params=cs0)
+        try:
+            print(json.dumps(cpu_baseline(cs0, H0, budget_s=float(os.environ.get("ROMS_BENCH_CPU_BUDGET", "15")))), flush=True)
+        finally:
+            H0.finalize()
+        return
     if not os.path.exists("/dev/kfd"):
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # The CPU leg runs first, before anything initialises the GPU in this process (it forks worker processes;
     # even counting devices may open the driver on some ROCm builds).
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from roms_amd import hostlib as _hl
-        cs0 = params_for(args.workload, args.Lm, args.Mm, args.N, ntimes=10)
-        H0 = _hl.Host(params=cs0)
+        # In a process of its own: it forks worker processes, and it loads the host library -- with it the system's HIP
+        # runtime -- which must not happen in THIS process before torch has loaded the runtime it ships (two HIP runtimes
+        # in one process: the second one finds no device)
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", "--workload", args.workload]
+        for k in ("Lm", "Mm", "N"):
+            if getattr(args, k):
+                cmd += [f"--{k}", str(getattr(args, k))]
         try:
-            cpu = cpu_baseline(cs0, H0)
-        finally:
-            H0.finalize()
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            cpu = json.loads(lines[-1]) if p.returncode == 0 and lines else None
+            if cpu is None:
+                print("bench.py: the CPU baseline leg failed: " + (p.stderr.strip().splitlines() or ["?"])[-1], file=sys.stderr)
+        except (subprocess.TimeoutExpired, ValueError) as e:     # never block the benchmark on its reported baseline
+            print(f"bench.py: the CPU baseline leg failed: {e}", file=sys.stderr)
     import torch
     if torch.cuda.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")

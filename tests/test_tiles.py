@@ -146,3 +146,15 @@ def test_bench_refuses_a_mismatched_world():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
                        capture_output=True, text=True, timeout=120, env=env)
     assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stdout + p.stderr)
+
+
+def test_bench_cpu_leg_runs_in_its_own_process():
+    """bench.py times the CPU baseline in a child process (`--cpu-leg`): the leg loads the host library -- and with it the
+    system's HIP runtime -- which must not be in the benchmark's own process before torch has loaded the runtime it
+    ships (a default `python bench.py` found no device afterwards).  The child prints one JSON object."""
+    env = dict(os.environ, ROMS_BENCH_CPU_BUDGET="1", OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-leg", "--Lm", "24", "--Mm", "16", "--N", "6"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["kind"] == "port" and d["value"] > 0 and d["cores"] >= 1 and "oracle/liborc.so" in d["sample"]
