@@ -53,7 +53,8 @@ enum {
   ROMS_PLAIN_VDIFF = 1 << 17,       /* SPLINES_VDIFF is NOT defined: plain tridiagonal vertical diffusion of every tracer (step3d_t.F:1722-1790) */
   ROMS_PLAIN_VVISC = 1 << 18,       /* SPLINES_VVISC is NOT defined: plain tridiagonal vertical viscosity (step3d_uv.F:436-500, :903-967) */
   ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21,
-  ROMS_APP_KELVIN = 1 << 22         /* no wind, no surface fluxes (the default branches of ana_smflux.h, ana_stflux.h) */
+  ROMS_APP_KELVIN = 1 << 22,        /* no wind, no surface fluxes (the default branches of ana_smflux.h, ana_stflux.h) */
+  ROMS_APP_SEAMOUNT = 1 << 23, ROMS_APP_GRAV_ADJ = 1 << 24   /* likewise unforced (set_data has nothing to do) */
 };
 
 /* Lateral boundary conditions: LBC(ibry,ivar,ng) of mod_param.F, the LBC(isFsur) ... LBC(isTvar) lines of roms.in

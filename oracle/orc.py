@@ -17,7 +17,7 @@ SCHEMES = dict(A4=A4, C2=C2, C4=C4, HSIMT=HSIMT, MPDATA=MPDATA, SPLINES=SPLINES,
 UV_ADV, UV_COR, UV_VIS2, TS_DIF2, MIX_GEO_TS, CURVGRID, NONLIN_EOS, UV_QDRAG, LMD_MIXING, \
     BULK_FLUXES, SOLAR_SOURCE, ANA_VMIX, SALINITY, SPHERICAL, UV_LOGDRAG, MASKING = [1 << k for k in range(16)]
 RADIATION_2D, PLAIN_VDIFF, PLAIN_VVISC = 1 << 16, 1 << 17, 1 << 18
-APP_UPWELLING, APP_BENCHMARK, APP_KELVIN = 1 << 20, 1 << 21, 1 << 22
+APP_UPWELLING, APP_BENCHMARK, APP_KELVIN, APP_SEAMOUNT, APP_GRAV_ADJ = 1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 24
 # lateral boundary conditions (orc.h): edges, variables, kinds
 IWEST, ISOUTH, IEAST, INORTH = range(4)
 ISFSUR, ISUBAR, ISVBAR, ISUVEL, ISVVEL, ISTVAR = range(6)

@@ -65,6 +65,16 @@ if [ "$APP" = upwelling_avg_mask ]; then
   UP=UPWELLING; HDR=upwelling_avg_mask; HDRPATH="$HERE/upwelling_avg_mask.h"
   EXTRA="-I$HERE/functionals"
 fi
+if [ "$APP" = seamount ]; then
+  # the SEAMOUNT case without the user diagnostics hook ANA_DIAG (oracle/ref/seamount_nodiag.h)
+  UP=SEAMOUNT; HDR=seamount_nodiag; HDRPATH="$HERE/seamount_nodiag.h"
+  EXTRA=""
+fi
+if [ "$APP" = grav_adj ]; then
+  # the GRAV_ADJ case without its output options AVERAGES / DIAGNOSTICS_TS / DIAGNOSTICS_UV (oracle/ref/grav_adj_nodiag.h)
+  UP=GRAV_ADJ; HDR=grav_adj_nodiag; HDRPATH="$HERE/grav_adj_nodiag.h"
+  EXTRA=""
+fi
 if [ "$APP" = kelvin_splines ]; then
   # the KELVIN case (open boundaries) with the spline vertical solvers (oracle/ref/kelvin_splines.h)
   UP=KELVIN; HDR=kelvin_splines; HDRPATH="$HERE/kelvin_splines.h"

@@ -64,6 +64,35 @@ def kelvin(Lm=50, Mm=30, N=10, NtileI=1, NtileJ=1, ntimes=96, lbc=None, plain=Fa
     )
 
 
+def seamount(Lm=49, Mm=48, N=13, NtileI=1, NtileJ=1, ntimes=100):
+    """roms_seamount.in (ROMS/Include/seamount.h): the pressure-gradient test -- a resting stratified ocean over a tall
+    Gaussian seamount in a periodic channel; no forcing, no-slip walls (GAMMA2 = -1), quadratic drag, Akima advection,
+    harmonic mixing along geopotentials (zero coefficients), background vertical mixing."""
+    return dict(
+        app="seamount", Lm=Lm, Mm=Mm, N=N, NtileI=NtileI, NtileJ=NtileJ, ndtfast=20, ntimes=ntimes,
+        Vtransform=2, Vstretching=4, EWperiodic=1, NSperiodic=0, hadv=("A4", "A4"), vadv=("A4", "A4"), lmd_Jwt=1,
+        dt=60.0, theta_s=6.5, theta_b=2.0, Tcline=100.0, rho0=1025.0, R0=1027.0, T0=10.0, S0=32.0,
+        Tcoef=1.7e-4, Scoef=7.6e-4, visc2=0.0, tnu2=(0.0, 0.0), Akt_bak=(1.0e-6, 1.0e-6), Akv_bak=1.0e-5,
+        rdrg=3.0e-4, rdrg2=3.0e-3, Zob=0.02, Zos=0.02, gamma2=-1.0, dstart=0.0,
+        blk_ZQ=10.0, blk_ZT=10.0, blk_ZW=10.0,
+        options=("UV_ADV", "UV_COR", "UV_QDRAG", "UV_VIS2", "TS_DIF2", "MIX_GEO_TS", "APP_SEAMOUNT"),
+    )
+
+
+def grav_adj(Lm=128, Mm=4, N=40, NtileI=1, NtileJ=1, ntimes=100):
+    """roms_grav_adj.in (ROMS/Include/grav_adj.h): the lock-exchange (gravitational adjustment) test -- warm water left of
+    the middle of a closed flat channel, periodic across; MPDATA tracers, no rotation, no drag."""
+    return dict(
+        app="grav_adj", Lm=Lm, Mm=Mm, N=N, NtileI=NtileI, NtileJ=NtileJ, ndtfast=20, ntimes=ntimes,
+        Vtransform=2, Vstretching=4, EWperiodic=0, NSperiodic=1, hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA"), lmd_Jwt=1,
+        dt=50.0, theta_s=0.0, theta_b=0.0, Tcline=1.0e16, rho0=1025.0, R0=1025.0, T0=5.0, S0=35.0,
+        Tcoef=9.756e-4, Scoef=0.0, visc2=5.0, tnu2=(0.0, 0.0), Akt_bak=(1.0e-6, 1.0e-6), Akv_bak=1.0e-5,
+        rdrg=0.0, rdrg2=0.0, Zob=0.02, Zos=0.02, gamma2=1.0, dstart=0.0,
+        blk_ZQ=10.0, blk_ZT=10.0, blk_ZW=10.0,
+        options=("UV_ADV", "UV_VIS2", "TS_DIF2", "APP_GRAV_ADJ"),
+    )
+
+
 def upwelling(Lm=41, Mm=80, N=16, NtileI=1, NtileJ=1, hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"),
               ntimes=100):
     """roms_upwelling.in"""

@@ -70,8 +70,12 @@
         ELSE
           ierr=roms_hip_get_stepping(ctx, step)   ! kernel by kernel: diag where main3d.F:355 has it
           step%nstp=1+MOD(step%iic-1,2)
+          step%nnew=3-step%nstp                   ! main3d.F:222-229
+          step%nrhs=step%nstp
           ierr=roms_hip_set_stepping(ctx, step)
-          ierr=roms_hip_diag(ctx, d)
+          ierr=roms_hip_set_massflux(ctx)         ! main3d.F:348-355: diag follows set_massflux and rho_eos of the pass
+          IF (ierr.eq.0) ierr=roms_hip_rho_eos(ctx)      ! (the step repeats them: same inputs, same results)
+          IF (ierr.eq.0) ierr=roms_hip_diag(ctx, d)
           d(15)=REAL(first+done,c_double)
           IF (ierr.eq.0) CALL advance (chunk, 1, .FALSE., ierr)
         END IF
@@ -82,8 +86,12 @@
       IF (ierr.eq.0) THEN                         ! the entry of the final state (the reference's last pass)
         ierr=roms_hip_get_stepping(ctx, step)
         step%nstp=1+MOD(step%iic-1,2)
+        step%nnew=3-step%nstp
+        step%nrhs=step%nstp
         ierr=roms_hip_set_stepping(ctx, step)
-        ierr=roms_hip_diag(ctx, d)
+        ierr=roms_hip_set_massflux(ctx)           ! the reference's last pass: set_massflux, rho_eos, diag (main3d.F:348-355)
+        IF (ierr.eq.0) ierr=roms_hip_rho_eos(ctx)
+        IF (ierr.eq.0) ierr=roms_hip_diag(ctx, d)
         IF (ierr.eq.0) CALL report (first+done, d)
         IF (ierr.eq.0) CALL output (ierr)        ! main3d.F:591-595 at iic = ntend+1: the final records
       END IF

@@ -18,7 +18,8 @@
      &   ROMS_LMD_MIXING = 256, ROMS_BULK_FLUXES = 512, ROMS_SOLAR_SOURCE = 1024, ROMS_ANA_VMIX = 2048,        &
      &   ROMS_SALINITY = 4096, ROMS_SPHERICAL = 8192, ROMS_UV_LOGDRAG = 16384, ROMS_MASKING = 32768,                                 &
      &   ROMS_RADIATION_2D = 65536, ROMS_PLAIN_VDIFF = 131072, ROMS_PLAIN_VVISC = 262144,                                   &
-     &   ROMS_APP_UPWELLING = 1048576, ROMS_APP_BENCHMARK = 2097152, ROMS_APP_KELVIN = 4194304
+     &   ROMS_APP_UPWELLING = 1048576, ROMS_APP_BENCHMARK = 2097152, ROMS_APP_KELVIN = 4194304, ROMS_APP_SEAMOUNT = 8388608,   &
+     &   ROMS_APP_GRAV_ADJ = 16777216
       integer(c_int), parameter :: ROMS_NLBC = 5+ROMS_MAXT
       integer(c_int), parameter :: ROMS_LBC_CLO = 1, ROMS_LBC_PER = 2, ROMS_LBC_GRA = 3, ROMS_LBC_CLA = 4, ROMS_LBC_RAD = 5,      &
      &   ROMS_LBC_RADNUD = 6, ROMS_LBC_CHE = 7, ROMS_LBC_CHI = 8, ROMS_LBC_FLA = 9, ROMS_LBC_SHC = 10

@@ -721,6 +721,20 @@
       DO k=1,SIZE(common)
         CALL define (TRIM(common(k)))
       END DO
+      IF (TRIM(MyAppCPP).eq.'SEAMOUNT'.or.TRIM(MyAppCPP).eq.'GRAV_ADJ') THEN
+!  ROMS/Include/seamount.h, grav_adj.h (their output options AVERAGES / DIAGNOSTICS_* / ANA_DIAG select no time-stepping code)
+        ndefs=0
+        CALL define ('UV_ADV'); CALL define ('UV_VIS2'); CALL define ('MIX_S_UV'); CALL define ('DJ_GRADPS')
+        CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC'); CALL define ('TS_DIF2'); CALL define ('SOLVE3D')
+        CALL define ('ANA_GRID'); CALL define ('ANA_INITIAL'); CALL define ('ANA_SMFLUX'); CALL define ('ANA_STFLUX')
+        CALL define ('ANA_BTFLUX')
+        IF (TRIM(MyAppCPP).eq.'SEAMOUNT') THEN
+          CALL define ('UV_COR'); CALL define ('UV_QDRAG'); CALL define ('MIX_GEO_TS')
+        ELSE
+          CALL define ('UV_LDRAG'); CALL define ('MIX_S_TS'); CALL define ('OUT_DOUBLE')
+        END IF
+        RETURN
+      END IF
       IF (TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES') THEN
 !  ROMS/Include/kelvin.h (plain tridiagonal vertical solvers); KELVIN_SPLINES = oracle/ref/kelvin_splines.h: the same with
 !  the spline vertical solvers of UPWELLING and BENCHMARK
@@ -774,7 +788,7 @@
       SUBROUTINE options_from_defines (ierr)
       integer, intent(inout) :: ierr
       integer :: k
-      logical :: upw, bench, kelv
+      logical :: upw, bench, kelv, seam, grav
 !  options with a bit in the mask (include/roms_hip.h)
       character(len=16), parameter :: bitname(17) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
      &    'TS_DIF2', 'MIX_GEO_TS', 'CURVGRID', 'NONLIN_EOS', 'UV_QDRAG', 'LMD_MIXING', 'BULK_FLUXES',           &
@@ -796,18 +810,27 @@
      &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING')
       bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.TRIM(MyAppCPP).eq.'BENCHMARK_MASK'.or.is_defined('BENCHMARK')
       kelv=TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES'.or.is_defined('KELVIN')
-      IF (COUNT((/ upw, bench, kelv /)).ne.1) THEN
+      seam=TRIM(MyAppCPP).eq.'SEAMOUNT'.or.is_defined('SEAMOUNT')
+      grav=TRIM(MyAppCPP).eq.'GRAV_ADJ'.or.is_defined('GRAV_ADJ')
+      IF (COUNT((/ upw, bench, kelv, seam, grav /)).ne.1) THEN
         CALL unsupported ('MyAppCPP = '//TRIM(MyAppCPP)//': the analytic grid, initial state and forcing '//   &
-     &                    'exist for UPWELLING, BENCHMARK and KELVIN', ierr)
+     &                    'exist for UPWELLING, BENCHMARK, KELVIN, SEAMOUNT and GRAV_ADJ', ierr)
         RETURN
       END IF
-      options=MERGE(ROMS_APP_UPWELLING, MERGE(ROMS_APP_BENCHMARK, ROMS_APP_KELVIN, bench), upw)
+      IF (upw) options=ROMS_APP_UPWELLING
+      IF (bench) options=ROMS_APP_BENCHMARK
+      IF (kelv) options=ROMS_APP_KELVIN
+      IF (seam) options=ROMS_APP_SEAMOUNT
+      IF (grav) options=ROMS_APP_GRAV_ADJ
       DO k=1,ndefs
         IF (ANY(bitname.eq.defs(k))) THEN
           options=IOR(options, bitval(FINDLOC(bitname, defs(k), 1)))
         ELSE IF (ANY(inherent.eq.defs(k)).or.ANY(output_only.eq.defs(k))) THEN
           CONTINUE
-        ELSE IF (TRIM(defs(k)).eq.'UPWELLING'.or.TRIM(defs(k)).eq.'BENCHMARK'.or.TRIM(defs(k)).eq.'KELVIN') THEN
+        ELSE IF (TRIM(defs(k)).eq.'UPWELLING'.or.TRIM(defs(k)).eq.'BENCHMARK'.or.TRIM(defs(k)).eq.'KELVIN'.or.            &
+     &           TRIM(defs(k)).eq.'SEAMOUNT'.or.TRIM(defs(k)).eq.'GRAV_ADJ') THEN
+          CONTINUE
+        ELSE IF (TRIM(defs(k)).eq.'ANA_DIAG') THEN        ! the user diagnostics hook (ana_diag.h): output of its own, not built
           CONTINUE
         ELSE
           CALL unsupported ('cpp option '//TRIM(defs(k))//' is not built into this library', ierr)
@@ -832,7 +855,7 @@
       IF (is_defined('ANA_VMIX').and.is_defined('LMD_MIXING'))                                                 &
      &  CALL unsupported ('at most one vertical mixing closure: ANA_VMIX or LMD_MIXING (neither: the background '//   &
      &                    'coefficients AKV_BAK, AKT_BAK, as in KELVIN)', ierr)
-      IF (.not.kelv.and..not.(is_defined('ANA_VMIX').or.is_defined('LMD_MIXING')))                              &
+      IF (.not.(kelv.or.seam.or.grav).and..not.(is_defined('ANA_VMIX').or.is_defined('LMD_MIXING')))            &
      &  CALL unsupported ('a vertical mixing closure is required: ANA_VMIX or LMD_MIXING', ierr)
       IF ((is_defined('ANA_FSOBC').or.is_defined('ANA_M2OBC')).and..not.kelv)                                   &
      &  CALL unsupported ('ANA_FSOBC / ANA_M2OBC (analytic boundary data) are built for KELVIN only', ierr)
@@ -1250,10 +1273,45 @@
       h(IstrT:IendT,JstrT:JendT)=100.0_r8
       END SUBROUTINE grid_kelvin
 
+      SUBROUTINE grid_cartesian (Xsize, Esize, depth, f0)
+!  the generic Cartesian branch of ana_grid.h (:515-533 coordinates, :886-891 f-plane, :1130-1136 flat bottom)
+      real(r8), intent(in) :: Xsize, Esize, depth, f0
+      real(r8) :: dx, dy
+      integer :: i, j
+      xl=Xsize
+      el=Esize
+      dx=Xsize/REAL(Lm,r8)
+      dy=Esize/REAL(Mm,r8)
+      FORALL (i=Istr-1:Iend+1, j=Jstr-1:Jend+1)
+        xp(i,j)=dx*REAL(i-1,r8)
+        xr(i,j)=dx*(REAL(i-1,r8)+0.5_r8)
+        yp(i,j)=dy*REAL(j-1,r8)
+        yr(i,j)=dy*(REAL(j-1,r8)+0.5_r8)
+      END FORALL
+      pm(IstrT:IendT,JstrT:JendT)=1.0_r8/dx
+      pn(IstrT:IendT,JstrT:JendT)=1.0_r8/dy
+      angler(IstrT:IendT,JstrT:JendT)=0.0_r8
+      f(IstrT:IendT,JstrT:JendT)=f0
+      h(IstrT:IendT,JstrT:JendT)=depth
+      END SUBROUTINE grid_cartesian
+
+      ELEMENTAL FUNCTION seamount_depth (x, y) RESULT (d)      ! ana_grid.h:1032-1039: a Gaussian seamount 4500 m tall, 40 km wide
+      real(r8), intent(in) :: x, y
+      real(r8) :: d, val1, val2
+      val1=(x-0.5_r8*320.0E+03_r8)/40000.0_r8
+      val2=(y-0.5_r8*320.0E+03_r8)/40000.0_r8
+      d=5000.0_r8-4500.0_r8*EXP(-(val1*val1+val2*val2))
+      END FUNCTION seamount_depth
+
       SUBROUTINE analytic_grid (ierr)
       integer, intent(out) :: ierr
       ierr=0
-      IF (IAND(options,ROMS_APP_KELVIN).ne.0) THEN
+      IF (IAND(options,ROMS_APP_SEAMOUNT).ne.0) THEN            ! ana_grid.h:346-352
+        CALL grid_cartesian (320.0E+03_r8, 320.0E+03_r8, 5000.0_r8, 0.0_r8)
+        h(IstrT:IendT,JstrT:JendT)=seamount_depth(xr(IstrT:IendT,JstrT:JendT), yr(IstrT:IendT,JstrT:JendT))
+      ELSE IF (IAND(options,ROMS_APP_GRAV_ADJ).ne.0) THEN       ! :298-304
+        CALL grid_cartesian (64.0E+03_r8, REAL(Mm,r8)*64.0E+03_r8/REAL(Lm,r8), 20.0_r8, 0.0_r8)
+      ELSE IF (IAND(options,ROMS_APP_KELVIN).ne.0) THEN
         CALL grid_kelvin ()
       ELSE IF (IAND(options,ROMS_APP_UPWELLING).ne.0) THEN
         CALL grid_upwelling ()
@@ -1403,6 +1461,11 @@
         amp=ratio2*(rho0*800.0_r8/g)*(5.0E-05_r8/((42.689_r8/44.69_r8)**2))
         t(i0:i1,j0:j1,:,1,1)=temp_benchmark(z_r(i0:i1,j0:j1,:), amp)
         t(i0:i1,j0:j1,:,1,2)=35.0_r8
+      ELSE IF (IAND(options,ROMS_APP_SEAMOUNT).ne.0) THEN      ! ana_initial.h:809-816
+        t(i0:i1,j0:j1,:,1,1)=T0+7.5_r8*EXP(z_r(i0:i1,j0:j1,:)/1000.0_r8)
+      ELSE IF (IAND(options,ROMS_APP_GRAV_ADJ).ne.0) THEN      ! :672-686: warm water in the left half
+        t(i0:MIN((Lm+1)/2,i1),j0:j1,:,1,1)=T0+5.0_r8
+        t(MAX((Lm+1)/2+1,i0):i1,j0:j1,:,1,1)=T0
       ELSE IF (IAND(options,ROMS_APP_KELVIN).ne.0) THEN
 !  ana_initial.h: the default branch, T0 everywhere; no SALINITY: the second tracer (carried passively) stays zero
         t(i0:i1,j0:j1,:,1,1)=T0

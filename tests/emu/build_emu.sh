@@ -7,6 +7,8 @@
 # loaded by the roms_amd package: the product has no CPU fallback.
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd)
+exec 9>"$HERE/.build.lock"      # one build at a time (pytest-xdist workers each run this from a module fixture)
+flock 9
 SRC=$HERE/../../roms_amd/csrc
 OUT=$HERE/libroms_hip_emu.so
 DEFS="${ROMS_DEFS:-}"

@@ -36,7 +36,7 @@ GRID2D = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", 
 STATE = ["Hz", "z_r", "z_w", "Huon", "Hvom", "zeta", "ubar", "vbar", "u", "v", "t", "rho", "pden", "rhoA", "rhoS",
          "Zt_avg1", "Akv", "Akt"]
 EXTRA = {"benchmark": ["dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta", "hsbl"],
-         "kelvin": ["xp", "yp", "rdrag2"]}
+         "kelvin": ["xp", "yp", "rdrag2"], "seamount": ["rdrag2"]}
 ALLSTATE = STATE + ["rzeta", "rubar", "rvbar", "W", "wvel", "ru", "rv", "rufrc", "rvfrc", "DU_avg1", "DU_avg2",
                     "DV_avg1", "DV_avg2", "sustr", "svstr", "bustr", "bvstr", "stflx", "btflx", "stflux", "btflux"]
 
@@ -55,7 +55,8 @@ def make_case(case):
     from tests import cases
     tag, kw = case.split(":") if ":" in case else (case, "")
     kwargs = eval("dict(%s)" % kw) if kw else {}
-    app = "benchmark" if tag.startswith("benchmark") else "kelvin" if tag.startswith("kelvin") else "upwelling"
+    app = ("benchmark" if tag.startswith("benchmark") else "kelvin" if tag.startswith("kelvin") else
+           "seamount" if tag.startswith("seamount") else "grav_adj" if tag.startswith("grav_adj") else "upwelling")
     cs = getattr(cases, app)(**kwargs)
     ip, rp = cases.ref_params(cs)
     saved = quiet()
@@ -239,6 +240,9 @@ STEP_CASES = [
     # open boundaries: the reference's KELVIN application (oracle/ref/kelvin_splines.h)
     ("kelvin_small", "kelvin_small", ["nsteps=96"]),
     ("kelvin_plain_small", "kelvin_plain_small", ["nsteps=96"]),     # ROMS/Include/kelvin.h as shipped: plain vertical solvers
+    # two more of the reference's test applications: SEAMOUNT (pressure-gradient test) and GRAV_ADJ (lock exchange, MPDATA)
+    ("seamount_small", "seamount_small", ["nsteps=100"]),
+    ("grav_adj_small", "grav_adj_small", ["nsteps=100"]),
 ]
 KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
 def make_avg():
@@ -299,7 +303,8 @@ if __name__ == "__main__":
     else:
         py = sys.executable
         for case in ["upwelling", "upwelling_small:Lm=14,Mm=18,N=8", "benchmark_small:Lm=24,Mm=16,N=10",
-                     "kelvin_small:Lm=16,Mm=12,N=6", "kelvin"]:
+                     "kelvin_small:Lm=16,Mm=12,N=6", "kelvin", "seamount_small:Lm=20,Mm=18,N=8", "seamount",
+                     "grav_adj_small:Lm=32,Mm=4,N=10", "grav_adj"]:
             subprocess.check_call([py, __file__, "--case", case])
         for spec in ["upwelling,41,80,1,1,HSIMT", "upwelling,41,80,2,2,HSIMT", "upwelling,41,80,2,4,U3",
                      "upwelling,41,80,3,3,U3", "benchmark,512,64,1,1,U3", "benchmark,512,64,2,2,U3",

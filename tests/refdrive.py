@@ -29,6 +29,11 @@ CASES = {
     "benchmark_mask_small": ("benchmark_mask", dict(Lm=24, Mm=16, N=10)),
     "upwelling_avg_mask_small": ("upwelling_avg_mask", dict(Lm=14, Mm=18, N=8)),      # AVERAGES + MASKING
     # open boundaries: the reference's own KELVIN application (ROMS/Include/kelvin.h, RADIATION_2D) ...
+    # more of the reference's own test applications (ROMS/Include/seamount.h, grav_adj.h as shipped)
+    "seamount": ("seamount", dict()),
+    "seamount_small": ("seamount", dict(Lm=20, Mm=18, N=8)),
+    "grav_adj": ("grav_adj", dict()),
+    "grav_adj_small": ("grav_adj", dict(Lm=32, Mm=4, N=10)),
     "kelvin": ("kelvin_splines", dict()),
     "kelvin_small": ("kelvin_splines", dict(Lm=16, Mm=12, N=6)),
     "kelvin_plain_small": ("kelvin", dict(Lm=16, Mm=12, N=6, plain=True)),   # kelvin.h as shipped: the plain vertical solvers
@@ -117,7 +122,7 @@ def make_case(tag, **kw):
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
                 upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
-                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin)[app]
+                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, seamount=cases.seamount, grav_adj=cases.grav_adj)[app]
     lbc = k.pop("lbc", None)
     cs = ctor(**k)
     if tag.endswith("_obc_small"):

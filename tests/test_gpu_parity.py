@@ -681,6 +681,27 @@ def hiplib_options():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small"])
+def test_more_reference_applications_match_oracle(tag):
+    """SEAMOUNT and GRAV_ADJ (the reference's own test applications, oracle pinned bit for bit): 40 steps on the GPU at the
+    north-star tolerance."""
+    cs = util.case_for(tag)
+    g = util.load_init(tag, util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g)
+    O.start()
+    H.start()
+    O.main3d_step(40)
+    H.main3d(40)
+    for n in util.PROGNOSTIC:
+        a, b = H.download(n), O.field(n)
+        assert np.isfinite(a).all(), n
+        assert util.relrms(a, b) <= 1e-10, (n, util.relrms(a, b))
+    assert np.abs(O.field("u")).max() > 1e-4
+    H.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["kelvin", "plain", "mixed", "four"])
 def test_open_boundaries_match_oracle(variant):
     """Open boundaries on the GPU (k_obc.h): the reference's KELVIN application -- Chapman / Flather west, radiation east,

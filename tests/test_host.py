@@ -21,7 +21,8 @@ def _host(cs):
     return hostlib.Host(params=cs)
 
 
-@pytest.mark.parametrize("tag", ["upwelling", "upwelling_small", "benchmark_small", "kelvin_small", "kelvin"])
+@pytest.mark.parametrize("tag", ["upwelling", "upwelling_small", "benchmark_small", "kelvin_small", "kelvin", "seamount_small",
+                                 "seamount", "grav_adj_small", "grav_adj"])
 def test_host_setup_matches_reference(tag):
     cs = util.case_for(tag)
     g = util.load_init(tag, util.nghost_for(cs))
@@ -473,3 +474,21 @@ def test_open_boundaries_through_the_host(tmp_path):
 def hiplib_opt(name):
     from roms_amd import hiplib
     return hiplib.OPTIONS[name]
+
+
+@pytest.mark.parametrize("app,dims", [("seamount", (49, 48, 13)), ("grav_adj", (128, 4, 40))])
+def test_reference_test_applications_from_their_own_files(app, dims):
+    """ROMS/External/roms_<app>.in with ROMS/Include/<app>.h, both read in place: the set-up equals the reference's (the
+    fixture its `initial` wrote); the headers' output options (AVERAGES, DIAGNOSTICS_*, ANA_DIAG) select no time-stepping code."""
+    from roms_amd import hostlib
+    ref_in, ref_h = f"/root/reference/ROMS/External/roms_{app}.in", f"/root/reference/ROMS/Include/{app}.h"
+    if not os.path.exists(ref_in):
+        pytest.skip("needs the reference tree")
+    H = hostlib.Host(infile=ref_in, header=ref_h)
+    try:
+        assert (H.dims["Lm"], H.dims["Mm"], H.dims["N"]) == dims
+        g = util.load_init(app, H.dims["Nghost"])
+        for n in ("h", "f", "pm", "pn", "z_r", "z_w", "t", "Hz", "sc_r", "Cs_r"):
+            assert np.array_equal(H.get(n), g[n]), n
+    finally:
+        H.finalize()

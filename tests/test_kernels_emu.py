@@ -220,6 +220,9 @@ def test_romsM_run_report_is_the_reference_text(emu, tmp_path):
     # the reference's KELVIN application (open boundaries), as shipped and with the spline vertical solvers
     util.check_romsM_report(exe, tmp_path, exact=True, fixture="kelvin_plain_small_steps.npz")
     util.check_romsM_report(exe, tmp_path, exact=True, fixture="kelvin_small_steps.npz")
+    # SEAMOUNT and GRAV_ADJ
+    util.check_romsM_report(exe, tmp_path, exact=True, fixture="seamount_small_steps.npz")
+    util.check_romsM_report(exe, tmp_path, exact=True, fixture="grav_adj_small_steps.npz")
 
 
 def test_product_partition_matches_reference_get_bounds(emu):
@@ -318,3 +321,26 @@ def test_open_boundary_kinds_the_library_does_not_have_stop():
     with pytest.raises(hiplib.RomsHipError) as e:
         util.make_hip(cs, g, util.EMU_LIB)      # (a closed basin: the arrays do not depend on the number of ghost points)
     assert "exit_flag=5" in str(e.value) and "MPDATA" in str(e.value)
+
+
+@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small"])
+def test_more_reference_applications_bitwise(emu, tag):
+    """SEAMOUNT (ROMS/Include/seamount.h: no-slip walls GAMMA2 = -1, Akima advection, harmonic mixing along geopotentials
+    without KPP, quadratic drag, no vertical mixing closure) and GRAV_ADJ (grav_adj.h: the lock exchange -- MPDATA tracers in
+    a closed channel four points wide and periodic across, no rotation, no drag), both pinned bit for bit to the reference:
+    12 steps against the oracle, bit for bit; the fronts move."""
+    cs = util.case_for(tag)
+    g = util.load_init(tag, util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start()
+    H.start()
+    for _ in range(12):
+        O.main3d_step()
+        H.main3d(1)
+        for n in util.PROGNOSTIC:
+            a, b = H.download(n), O.field(n)
+            assert np.isfinite(b).all(), n
+            assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+    assert np.abs(O.field("u")).max() > 1e-4
+    H.close()

@@ -182,7 +182,8 @@ def _child(mode, tag, *args, timeout=900):
            "upwelling_logdrag_small": "upwelling_logdrag", "upwelling_mask_small": "upwelling_mask",
            "benchmark_mask_small": "benchmark_mask", "upwelling_avg_mask_small": "upwelling_avg_mask",
            "kelvin": "kelvin_splines", "kelvin_small": "kelvin_splines", "kelvin_plain_small": "kelvin", "kelvin_plain": "kelvin",
-           "upwelling_obc_small": "upwelling", "upwelling_mask_obc_small": "upwelling_mask"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
+           "upwelling_obc_small": "upwelling", "upwelling_mask_obc_small": "upwelling_mask", "seamount": "seamount",
+           "seamount_small": "seamount", "grav_adj": "grav_adj", "grav_adj_small": "grav_adj"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
     if not ref.available(lib):
         pytest.skip(f"oracle/_ref/libromsref_{lib}.so not built here")
     p = subprocess.run([sys.executable, "-m", "tests.refchild", mode, tag] + list(args), capture_output=True,
@@ -218,6 +219,14 @@ MAIN3D_CASES = [
     ("kelvin_plain_small", ["nsteps=60"]),
     ("kelvin_plain_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("kelvin_plain", ["nsteps=96"]),
+    # two more of the reference's test applications: SEAMOUNT (no-slip walls, Akima advection, geopotential mixing without
+    # KPP, quadratic drag, no closure) and GRAV_ADJ (lock exchange: MPDATA in a closed channel periodic across, no rotation)
+    ("seamount_small", ["nsteps=60"]),
+    ("seamount_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("seamount", ["nsteps=20"]),                                                 # roms_seamount.in, full size
+    ("grav_adj_small", ["nsteps=60"]),
+    ("grav_adj_small", ["nsteps=20", "NtileI=2", "NtileJ=1"]),
+    ("grav_adj", ["nsteps=40"]),                                                 # roms_grav_adj.in, full size
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
     ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
 ]

@@ -72,6 +72,9 @@ def _interior(cs_dims, a):
     # the tile boundary (the tangential differences of the radiation condition), corner tiles hold both kinds of edge
     ("kelvin_small", dict(), (2, 2), 29623),
     ("kelvin_small", dict(), (1, 2), 29624),
+    # SEAMOUNT (no-slip walls) and GRAV_ADJ (MPDATA, closed in xi, periodic and four points wide in eta: tiles along xi)
+    ("seamount_small", dict(), (2, 2), 29625),
+    ("grav_adj_small", dict(), (2, 1), 29626),
 ])
 def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     _emu_libs()

@@ -68,6 +68,14 @@ def case_for(tag, **kw):
         return cases.benchmark(Lm=48, Mm=34, N=6, **kw)
     if tag == "upwelling_mask_mid":
         return cases.upwelling_mask(Lm=34, Mm=40, N=6, **kw)
+    if tag == "seamount_small":
+        return cases.seamount(Lm=20, Mm=18, N=8, **kw)
+    if tag == "seamount":
+        return cases.seamount(**kw)
+    if tag == "grav_adj_small":
+        return cases.grav_adj(Lm=32, Mm=4, N=10, **kw)
+    if tag == "grav_adj":
+        return cases.grav_adj(**kw)
     if tag == "kelvin_small":
         return cases.kelvin(Lm=16, Mm=12, N=6, **kw)
     if tag == "kelvin":
@@ -174,7 +182,8 @@ def case_from_meta(meta):
 
 def init_tag(cs):
     return {(14, 18, 8): "upwelling_small", (24, 16, 10): "benchmark_small", (41, 80, 16): "upwelling",
-            (16, 12, 6): "kelvin_small", (50, 30, 10): "kelvin"}[
+            (16, 12, 6): "kelvin_small", (50, 30, 10): "kelvin", (20, 18, 8): "seamount_small", (49, 48, 13): "seamount",
+            (32, 4, 10): "grav_adj_small", (128, 4, 40): "grav_adj"}[
         (cs["Lm"], cs["Mm"], cs["N"])]
 
 
