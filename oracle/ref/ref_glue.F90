@@ -622,8 +622,12 @@
       USE set_massflux_mod,  ONLY : set_massflux
       USE rho_eos_mod,       ONLY : rho_eos
       USE prsgrd_mod,        ONLY : prsgrd
+#ifdef TS_DIF2
       USE t3dmix2_mod,       ONLY : t3dmix2
+#endif
+#ifdef UV_VIS2
       USE uv3dmix2_mod,      ONLY : uv3dmix2
+#endif
       USE set_vbc_mod,       ONLY : set_vbc
       USE set_zeta_mod,      ONLY : set_zeta
       USE wvelocity_mod,     ONLY : wvelocity
@@ -668,10 +672,14 @@
             CALL rho_eos (ng, tile, iNLM)
           CASE ('prsgrd')
             CALL prsgrd (ng, tile)
+#ifdef TS_DIF2
           CASE ('t3dmix2')
             CALL t3dmix2 (ng, tile)
+#endif
+#ifdef UV_VIS2
           CASE ('uv3dmix2')
             CALL uv3dmix2 (ng, tile)
+#endif
           CASE ('set_vbc')
             CALL set_vbc (ng, tile)
           CASE ('set_zeta')
@@ -1113,9 +1121,13 @@
         F2('btflux',FORCES(ng)%btflux)
         F2('Akv',MIXING(ng)%Akv)
         F2('Akt',MIXING(ng)%Akt)
+#ifdef UV_VIS2
         F2('visc2_r',MIXING(ng)%visc2_r)
         F2('visc2_p',MIXING(ng)%visc2_p)
+#endif
+#ifdef TS_DIF2
         F2('diff2',MIXING(ng)%diff2)
+#endif
         F2('rdrag',GRID(ng)%rdrag)
 #ifdef UV_QDRAG
         F2('rdrag2',GRID(ng)%rdrag2)
