@@ -201,6 +201,12 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     set_error("bad tile partition (NtileI, NtileJ, tile)");
     return 5;
   }
+  if ((cfg->options & (ROMS_UV_ADV | ROMS_UV_VIS2 | ROMS_TS_DIF2)) != (ROMS_UV_ADV | ROMS_UV_VIS2 | ROMS_TS_DIF2)) {
+    // every application the library is pinned with has them; a build of the reference without them (WINDBASIN) was
+    // found to differ from the checker at 1e-17 from a state of rest: refused rather than run unpinned
+    set_error("options: UV_ADV, UV_VIS2 and TS_DIF2 are required (zero coefficients switch the mixing off)");
+    return 5;
+  }
   if (cfg->Nghost != 2 && cfg->Nghost != 3) {
     // get_bounds.F / inp_par.F:210-216: NghostPoints is 2, or 3 with MPDATA/HSIMT; the strip buffers of
     // the halo exchange (3 lines per side, 9-point corner blocks) are sized for that

@@ -843,6 +843,11 @@
      &                                                     '(prsgrd32.h)', ierr)
       IF (COUNT((/ is_defined('UV_LDRAG'), is_defined('UV_QDRAG'), is_defined('UV_LOGDRAG') /)).ne.1)           &
      &  CALL unsupported ('exactly one of UV_LDRAG, UV_QDRAG, UV_LOGDRAG is required', ierr)
+!  every pinned application has momentum advection and harmonic mixing of momentum and tracers compiled in; without them
+!  the reference was found to differ from the restatement this library is checked against (WINDBASIN from rest: exact
+!  zeros there, 1e-17 here), so those builds are refused rather than run unpinned
+      IF (.not.(is_defined('UV_ADV').and.is_defined('UV_VIS2').and.is_defined('TS_DIF2')))                    &
+     &  CALL unsupported ('UV_ADV, UV_VIS2 and TS_DIF2 are required (the library is pinned to the reference with them)', ierr)
       IF (is_defined('UV_VIS2').and..not.is_defined('MIX_S_UV'))                                               &
      &  CALL unsupported ('UV_VIS2 is built along s-surfaces only (MIX_S_UV)', ierr)
       IF (is_defined('TS_DIF2').and.(is_defined('MIX_S_TS').eqv.is_defined('MIX_GEO_TS')))                     &

@@ -147,6 +147,7 @@ def test_reader_accepts_the_reference_spellings(tmp_path):
     (dict(tv="Per Mix Per Clo"), "LBC(isTvar) = Mix"),                        # the salinity line
     (dict(fs="Per Clo Clo Clo"), "opposite edge"),
     (dict(h1="WENO5"), "unknown scheme"),
+    (dict(header="windbasin"), "UV_ADV, UV_VIS2 and TS_DIF2 are required"),      # a reference application without them: not pinned, refused
     (dict(h1="MPDATA"), "MPDATA must be chosen for both"),
     (dict(extra="LuvSrc == T"), "LuvSrc == T"),
     (dict(extra="Vstretching == 2"), "Vstretching"),
@@ -155,6 +156,11 @@ def test_reader_accepts_the_reference_spellings(tmp_path):
 def test_reader_stops_on_settings_it_cannot_honour(tmp_path, kw, needle):
     """exit_flag 5 with the reason, as checkdefs.F / inp_par.F stop on illegal configurations."""
     from roms_amd import hostlib
+    if kw.get("header") == "windbasin":          # the UPWELLING options without momentum advection
+        src = os.path.join(os.path.dirname(__file__), "..", "oracle", "ref", "upwelling_logdrag.h")
+        hdr = tmp_path / "no_uv_adv.h"
+        hdr.write_text("\n".join(l for l in open(src).read().splitlines() if "UV_ADV" not in l) + "\n")
+        kw = dict(header=str(hdr))
     with pytest.raises(hostlib.HostError) as e:
         _setup(tmp_path, **kw).finalize()
     assert e.value.exit_flag == 5 and needle in str(e.value), str(e.value)
