@@ -383,7 +383,8 @@ def test_every_reference_input_file_is_read_without_skipping_a_physics_keyword()
         assert n == 0, (f, n, buf.value.decode())
         if H is not None:
             H.finalize()
-    assert {"roms_upwelling.in", "roms_benchmark1.in", "roms_benchmark2.in", "roms_benchmark3.in"} <= set(done)
+    assert {"roms_upwelling.in", "roms_benchmark1.in", "roms_benchmark2.in", "roms_benchmark3.in", "roms_kelvin.in",
+            "roms_seamount.in", "roms_grav_adj.in"} <= set(done)
     assert len(stopped) > 20          # the other applications of the reference: analytic set-ups this host does not have
 
 
