@@ -52,6 +52,8 @@ enum {
   ROMS_RADIATION_2D = 1 << 16,      /* tangential phase speed in the radiation conditions (zetabc.F:157, u2dbc_im.F:188 ...) */
   ROMS_PLAIN_VDIFF = 1 << 17,       /* SPLINES_VDIFF is NOT defined: plain tridiagonal vertical diffusion of every tracer (step3d_t.F:1722-1790) */
   ROMS_PLAIN_VVISC = 1 << 18,       /* SPLINES_VVISC is NOT defined: plain tridiagonal vertical viscosity (step3d_uv.F:436-500, :903-967) */
+  ROMS_PRSGRD31 = 1 << 19,          /* DJ_GRADPS is NOT defined: the standard density Jacobian prsgrd31.h (prsgrd.F:22-26) */
+  ROMS_WJ_GRADP = 1 << 27,          /* ... in its weighted form, prsgrd31.h:232-250 */
   ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21,
   ROMS_APP_KELVIN = 1 << 22,        /* no wind, no surface fluxes (the default branches of ana_smflux.h, ana_stflux.h) */
   ROMS_APP_SEAMOUNT = 1 << 23, ROMS_APP_GRAV_ADJ = 1 << 24   /* likewise unforced (set_data has nothing to do) */

@@ -43,7 +43,9 @@ enum {
   ORC_MASKING = 1 << 15,     /* land/sea masks rmask, umask, vmask, pmask (mod_grid.F) */
   ORC_RADIATION_2D = 1 << 16, /* tangential phase speed in the radiation conditions (zetabc.F:157 ...) */
   ORC_PLAIN_VDIFF = 1 << 17,  /* SPLINES_VDIFF NOT defined: plain tridiagonal vertical diffusion for every tracer (step3d_t.F:1722-1790) */
-  ORC_PLAIN_VVISC = 1 << 18,  /* SPLINES_VVISC NOT defined: plain tridiagonal vertical viscosity (step3d_uv.F:436-500) */
+  ORC_PLAIN_VVISC = 1 << 18,
+  ORC_PRSGRD31 = 1 << 19,     /* DJ_GRADPS NOT defined: the standard density Jacobian, prsgrd31.h */
+  ORC_WJ_GRADP = 1 << 27,     /* ... in its weighted form (Song 1998), prsgrd31.h:232-250 */  /* SPLINES_VVISC NOT defined: plain tridiagonal vertical viscosity (step3d_uv.F:436-500) */
   ORC_APP_UPWELLING = 1 << 20, ORC_APP_BENCHMARK = 1 << 21, ORC_APP_KELVIN = 1 << 22, ORC_APP_SEAMOUNT = 1 << 23, ORC_APP_GRAV_ADJ = 1 << 24   /* (no forcing: the default branches of ana_smflux.h ...) */
 };
 

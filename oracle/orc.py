@@ -16,7 +16,8 @@ A4, C2, C4, HSIMT, MPDATA, SPLINES, SPLIT_U3, U3 = range(1, 9)
 SCHEMES = dict(A4=A4, C2=C2, C4=C4, HSIMT=HSIMT, MPDATA=MPDATA, SPLINES=SPLINES, SU3=SPLIT_U3, U3=U3)
 UV_ADV, UV_COR, UV_VIS2, TS_DIF2, MIX_GEO_TS, CURVGRID, NONLIN_EOS, UV_QDRAG, LMD_MIXING, \
     BULK_FLUXES, SOLAR_SOURCE, ANA_VMIX, SALINITY, SPHERICAL, UV_LOGDRAG, MASKING = [1 << k for k in range(16)]
-RADIATION_2D, PLAIN_VDIFF, PLAIN_VVISC = 1 << 16, 1 << 17, 1 << 18
+RADIATION_2D, PLAIN_VDIFF, PLAIN_VVISC, PRSGRD31 = 1 << 16, 1 << 17, 1 << 18, 1 << 19
+WJ_GRADP = 1 << 27
 APP_UPWELLING, APP_BENCHMARK, APP_KELVIN, APP_SEAMOUNT, APP_GRAV_ADJ = 1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 24
 # lateral boundary conditions (orc.h): edges, variables, kinds
 IWEST, ISOUTH, IEAST, INORTH = range(4)
@@ -57,7 +58,10 @@ def build(force=False):
     so = os.path.join(HERE, "liborc.so")
     srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h"))]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-s", "-C", HERE, "-j4"])
+        import fcntl
+        with open(os.path.join(HERE, ".build.lock"), "w") as lock:      # one build at a time (pytest-xdist workers)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-s", "-C", HERE, "-j4"])
     return so
 
 

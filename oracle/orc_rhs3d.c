@@ -421,7 +421,67 @@ void orc_pre_step3d(orc_t *o, int tile) {
 }
 
 /* ---------------------------------------------------------------- prsgrd32 */
+/* prsgrd31_tile, prsgrd31.h:95-380: the standard density Jacobian (WJ_GRADP: weighted, Song 1998), RHO_SURF; the
+   pressure-gradient scheme of an application that defines none of DJ_GRADPS, PJ_GRADP, PJ_GRADPQ2, PJ_GRADPQ4 */
+static void orc_prsgrd31(orc_t *o, int tile) {
+  ORC_LOCALS(o);
+  const orc_bounds *b = &o->b[tile];
+  const int nrhs = o->s.nrhs;
+  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend, IstrU = b->IstrU, JstrV = b->JstrV;
+  const double g = o->c.g, rho0 = o->c.rho0;
+  const double fac1 = 0.5 * g / rho0, fac2 = 1000.0 * g / rho0, fac3 = 0.25 * g / rho0;
+  const int wj = (o->c.options & ORC_WJ_GRADP) != 0;
+  double *rho = o->rho, *z_r = o->z_r, *z_w = o->z_w, *Hz = o->Hz, *ru = o->ru, *rv = o->rv;
+  double *phi = (double *)malloc(sizeof(double) * o->ni);
+  for (int j = Jstr; j <= Jend; j++)
+    for (int dir = 0; dir < 2; dir++) {
+      if (dir == 1 && j < JstrV) break;
+      const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1, i0 = dir == 0 ? IstrU : Istr;
+      double *rq = dir == 0 ? ru : rv;
+      const double *omn = dir == 0 ? o->on_u : o->om_v;
+#define PH(i) phi[(i) - LBi]
+#define Rm(k) rho[X3(i - di, j - dj, k)]
+#define Rc(k) rho[X3(i, j, k)]
+#define Zm(k) z_r[X3(i - di, j - dj, k)]
+#define Zc(k) z_r[X3(i, j, k)]
+      for (int i = i0; i <= Iend; i++) {
+        double cff1 = z_w[XW(i, j, N)] - Zc(N) + z_w[XW(i - di, j - dj, N)] - Zm(N);
+        PH(i) = fac1 * (Rc(N) - Rm(N)) * cff1;
+        PH(i) = PH(i) + (fac2 + fac1 * (Rc(N) + Rm(N))) * (z_w[XW(i, j, N)] - z_w[XW(i - di, j - dj, N)]);    /* RHO_SURF */
+        rq[XW4(i, j, N, nrhs)] = -0.5 * (Hz[X3(i, j, N)] + Hz[X3(i - di, j - dj, N)]) * PH(i) * omn[X2(i, j)];
+      }
+      for (int k = N - 1; k >= 1; k--)
+        for (int i = i0; i <= Iend; i++) {
+          double cff1, cff2, cff3, cff4;
+          if (wj) {
+            cff1 = 1.0 / ((Zc(k + 1) - Zc(k)) * (Zm(k + 1) - Zm(k)));
+            cff2 = Zc(k) - Zm(k) + Zc(k + 1) - Zm(k + 1);
+            cff3 = Zc(k + 1) - Zc(k) - Zm(k + 1) + Zm(k);
+            const double gamma = 0.125 * cff1 * cff2 * cff3;
+            cff1 = (1.0 + gamma) * (Rc(k + 1) - Rm(k + 1)) + (1.0 - gamma) * (Rc(k) - Rm(k));
+            cff2 = Rc(k + 1) + Rm(k + 1) - Rc(k) - Rm(k);
+            cff3 = Zc(k + 1) + Zm(k + 1) - Zc(k) - Zm(k);
+            cff4 = (1.0 + gamma) * (Zc(k + 1) - Zm(k + 1)) + (1.0 - gamma) * (Zc(k) - Zm(k));
+          } else {
+            cff1 = Rc(k + 1) - Rm(k + 1) + Rc(k) - Rm(k);
+            cff2 = Rc(k + 1) + Rm(k + 1) - Rc(k) - Rm(k);
+            cff3 = Zc(k + 1) + Zm(k + 1) - Zc(k) - Zm(k);
+            cff4 = Zc(k + 1) - Zm(k + 1) + Zc(k) - Zm(k);
+          }
+          PH(i) = PH(i) + fac3 * (cff1 * cff3 - cff2 * cff4);
+          rq[XW4(i, j, k, nrhs)] = -0.5 * (Hz[X3(i, j, k)] + Hz[X3(i - di, j - dj, k)]) * PH(i) * omn[X2(i, j)];
+        }
+#undef PH
+#undef Rm
+#undef Rc
+#undef Zm
+#undef Zc
+    }
+  free(phi);
+}
+
 void orc_prsgrd(orc_t *o, int tile) {
+  if (o->c.options & ORC_PRSGRD31) { orc_prsgrd31(o, tile); return; }
   ORC_LOCALS(o);
   const orc_bounds *b = &o->b[tile];
   const int nrhs = o->s.nrhs;

@@ -65,6 +65,11 @@ if [ "$APP" = upwelling_avg_mask ]; then
   UP=UPWELLING; HDR=upwelling_avg_mask; HDRPATH="$HERE/upwelling_avg_mask.h"
   EXTRA="-I$HERE/functionals"
 fi
+if [ "$APP" = upwelling_prs31 ] || [ "$APP" = upwelling_wjgradp ]; then
+  # UPWELLING with the standard density Jacobian prsgrd31.h (no DJ_GRADPS; _wjgradp: WJ_GRADP, its weighted form)
+  UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
+  EXTRA=""
+fi
 if [ "$APP" = seamount ]; then
   # the SEAMOUNT case without the user diagnostics hook ANA_DIAG (oracle/ref/seamount_nodiag.h)
   UP=SEAMOUNT; HDR=seamount_nodiag; HDRPATH="$HERE/seamount_nodiag.h"

@@ -129,6 +129,15 @@ def upwelling_logdrag(**kw):
     return cs
 
 
+def upwelling_prs31(wj=False, **kw):
+    """UPWELLING with the standard density Jacobian (prsgrd31.h: no DJ_GRADPS; wj: WJ_GRADP, the weighted form): the custom
+    application headers oracle/ref/upwelling_prs31.h, upwelling_wjgradp.h"""
+    cs = upwelling(**kw)
+    cs["app"] = "upwelling_wjgradp" if wj else "upwelling_prs31"
+    cs["options"] = tuple(cs["options"]) + ("PRSGRD31",) + (("WJ_GRADP",) if wj else ())
+    return cs
+
+
 def upwelling_mask(**kw):
     """UPWELLING with land/sea masking (MASKING): an island and a headland on the southern wall (`land_mask`); the
     custom application header oracle/ref/upwelling_mask.h"""

@@ -118,6 +118,10 @@ int run_prsgrd(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   KArgs a = mk(c);
+  if (G.options & ROMS_PRSGRD31) {     // no DJ_GRADPS: prsgrd31.h (the reference order of main3d: roms_hip.cpp keeps the late-predictor schedule off)
+    LAUNCH_THREAD(k_prs31, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+    return 0;
+  }
   a.p1 = c->late_pre ? 1 : 0;
   LAUNCH_THREAD(k_prs_P, B.Iend - (B.IstrU - 1) + 1, B.Jend - (B.JstrV - 1) + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_prs_grad, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);

@@ -671,6 +671,61 @@ THREAD_GLOBAL(k_pre_new_m, KArgs)
 THREAD_KERNEL(k_pre_new_m4, KArgs) { k_pre_new_mt_body<ROMS_MAXT>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_pre_new_m4, KArgs)
 
+// -------------------------------------------------------------------------------- prsgrd31
+// The standard density Jacobian (prsgrd31.h:95-380; WJ_GRADP: weighted), RHO_SURF: one thread per velocity column,
+// grid.z = 0: ru on (IstrU:Iend, Jstr:Jend), 1: rv on (Istr:Iend, JstrV:Jend); phix / phie integrated from the surface
+// down.  The scheme of an application that defines no DJ_GRADPS (not a BASELINE path: the straightforward form).
+THREAD_KERNEL(k_prs31, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int dir = gz;
+  const int i = (dir == 0 ? B.IstrU : B.Istr) + gx, j = (dir == 0 ? B.Jstr : B.JstrV) + gy;
+  if (i > B.Iend || j > B.Jend) return;
+  const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1, N = G.N;
+  const double fac1 = 0.5 * G.g / G.rho0, fac2 = 1000.0 * G.g / G.rho0, fac3 = 0.25 * G.g / G.rho0;
+  const bool wj = (G.options & ROMS_WJ_GRADP) != 0;
+  const double *rho = F.rho, *z_r = F.z_r, *z_w = F.z_w, *Hz = F.Hz;
+  double *rq = (dir == 0 ? F.ru : F.rv) + (size_t)(G.nrhs - 1) * G.nij * (N + 1);
+  const double omn = (dir == 0 ? F.on_u : F.om_v)[X2(i, j)];
+#define Rm(k) rho[X3(i - di, j - dj, k)]
+#define Rc(k) rho[X3(i, j, k)]
+#define Zm(k) z_r[X3(i - di, j - dj, k)]
+#define Zc(k) z_r[X3(i, j, k)]
+  double phi;
+  {
+    const double cff1 = z_w[XW(i, j, N)] - Zc(N) + z_w[XW(i - di, j - dj, N)] - Zm(N);
+    phi = fac1 * (Rc(N) - Rm(N)) * cff1;
+    phi = phi + (fac2 + fac1 * (Rc(N) + Rm(N))) * (z_w[XW(i, j, N)] - z_w[XW(i - di, j - dj, N)]);
+    rq[XW(i, j, N)] = -0.5 * (Hz[X3(i, j, N)] + Hz[X3(i - di, j - dj, N)]) * phi * omn;
+  }
+  for (int k = N - 1; k >= 1; k--) {
+    double cff1, cff2, cff3, cff4;
+    if (wj) {
+      cff1 = 1.0 / ((Zc(k + 1) - Zc(k)) * (Zm(k + 1) - Zm(k)));
+      cff2 = Zc(k) - Zm(k) + Zc(k + 1) - Zm(k + 1);
+      cff3 = Zc(k + 1) - Zc(k) - Zm(k + 1) + Zm(k);
+      const double gamma = 0.125 * cff1 * cff2 * cff3;
+      cff1 = (1.0 + gamma) * (Rc(k + 1) - Rm(k + 1)) + (1.0 - gamma) * (Rc(k) - Rm(k));
+      cff2 = Rc(k + 1) + Rm(k + 1) - Rc(k) - Rm(k);
+      cff3 = Zc(k + 1) + Zm(k + 1) - Zc(k) - Zm(k);
+      cff4 = (1.0 + gamma) * (Zc(k + 1) - Zm(k + 1)) + (1.0 - gamma) * (Zc(k) - Zm(k));
+    } else {
+      cff1 = Rc(k + 1) - Rm(k + 1) + Rc(k) - Rm(k);
+      cff2 = Rc(k + 1) + Rm(k + 1) - Rc(k) - Rm(k);
+      cff3 = Zc(k + 1) + Zm(k + 1) - Zc(k) - Zm(k);
+      cff4 = Zc(k + 1) - Zm(k + 1) + Zc(k) - Zm(k);
+    }
+    phi = phi + fac3 * (cff1 * cff3 - cff2 * cff4);
+    rq[XW(i, j, k)] = -0.5 * (Hz[X3(i, j, k)] + Hz[X3(i - di, j - dj, k)]) * phi * omn;
+  }
+#undef Rm
+#undef Rc
+#undef Zm
+#undef Zc
+}
+THREAD_GLOBAL(k_prs31, KArgs)
+
 // -------------------------------------------------------------------------------- prsgrd32
 // P(i,j,k) into F.wrk3[1]; one thread per column of (IstrU-1:Iend, JstrV-1:Jend)
 THREAD_KERNEL(k_prs_P, KArgs) {

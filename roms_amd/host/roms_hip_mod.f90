@@ -17,7 +17,7 @@
      &   ROMS_MIX_GEO_TS = 16, ROMS_CURVGRID = 32, ROMS_NONLIN_EOS = 64, ROMS_UV_QDRAG = 128,                  &
      &   ROMS_LMD_MIXING = 256, ROMS_BULK_FLUXES = 512, ROMS_SOLAR_SOURCE = 1024, ROMS_ANA_VMIX = 2048,        &
      &   ROMS_SALINITY = 4096, ROMS_SPHERICAL = 8192, ROMS_UV_LOGDRAG = 16384, ROMS_MASKING = 32768,                                 &
-     &   ROMS_RADIATION_2D = 65536, ROMS_PLAIN_VDIFF = 131072, ROMS_PLAIN_VVISC = 262144,                                   &
+     &   ROMS_RADIATION_2D = 65536, ROMS_PLAIN_VDIFF = 131072, ROMS_PLAIN_VVISC = 262144, ROMS_PRSGRD31 = 524288, ROMS_WJ_GRADP = 134217728,                                   &
      &   ROMS_APP_UPWELLING = 1048576, ROMS_APP_BENCHMARK = 2097152, ROMS_APP_KELVIN = 4194304, ROMS_APP_SEAMOUNT = 8388608,   &
      &   ROMS_APP_GRAV_ADJ = 16777216
       integer(c_int), parameter :: ROMS_NLBC = 5+ROMS_MAXT

@@ -22,7 +22,12 @@ for f in $SRC/*.cpp; do
   objs="$objs $o"
 done
 wait
-g++ -shared -Wl,-Bsymbolic -o $OUT $objs
+# link only when something changed, into a temporary name that replaces the library in one step: other test processes may
+# be loading it meanwhile
+newer () { for o in "${@:2}"; do [ "$o" -nt "$1" ] && return 0; done; [ ! -f "$1" ]; }
+if newer $OUT $objs; then
+  g++ -shared -Wl,-Bsymbolic -o $OUT.tmp.$$ $objs && mv -f $OUT.tmp.$$ $OUT
+fi
 echo "built $OUT"
 
 # Fortran host driver linked against the emulated library (multi-tile CPU tests)
@@ -39,13 +44,19 @@ for f in roms_hip_mod roms_host roms_output roms_host_api; do
     rebuild=1
   fi
 done
-/opt/rocm/bin/amdflang -shared -o $HERE/libroms_host_emu.so $FOBJ/roms_hip_mod.o $FOBJ/roms_host.o $FOBJ/nc3.o $FOBJ/roms_output.o $FOBJ/roms_host_api.o \
-  -L$HERE -lroms_hip_emu -Wl,-rpath,'$ORIGIN'
+HOBJS="$FOBJ/roms_hip_mod.o $FOBJ/roms_host.o $FOBJ/nc3.o $FOBJ/roms_output.o $FOBJ/roms_host_api.o"
+if newer $HERE/libroms_host_emu.so $HOBJS $OUT; then
+  /opt/rocm/bin/amdflang -shared -o $HERE/libroms_host_emu.so.tmp.$$ $HOBJS -L$HERE -lroms_hip_emu -Wl,-rpath,'$ORIGIN' && \
+    mv -f $HERE/libroms_host_emu.so.tmp.$$ $HERE/libroms_host_emu.so
+fi
 echo "built $HERE/libroms_host_emu.so"
 
 # the stand-alone driver against the emulated library (its run report is checked on CPU too)
 if [ ! -f $FOBJ/romsM.o ] || [ $HOSTSRC/romsM.f90 -nt $FOBJ/romsM.o ] || [ $FOBJ/roms_host.o -nt $FOBJ/romsM.o ]; then
   /opt/rocm/bin/amdflang -O2 -fPIC -ffp-contract=off -module-dir $FOBJ -c $HOSTSRC/romsM.f90 -o $FOBJ/romsM.o
 fi
-/opt/rocm/bin/amdflang -o $HERE/romsM_emu $FOBJ/romsM.o -L$HERE -lroms_host_emu -lroms_hip_emu -Wl,-rpath,'$ORIGIN'
+if newer $HERE/romsM_emu $FOBJ/romsM.o $HERE/libroms_host_emu.so $OUT; then
+  /opt/rocm/bin/amdflang -o $HERE/romsM_emu.tmp.$$ $FOBJ/romsM.o -L$HERE -lroms_host_emu -lroms_hip_emu -Wl,-rpath,'$ORIGIN' && \
+    mv -f $HERE/romsM_emu.tmp.$$ $HERE/romsM_emu
+fi
 echo "built $HERE/romsM_emu"

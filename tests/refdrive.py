@@ -30,6 +30,9 @@ CASES = {
     "upwelling_avg_mask_small": ("upwelling_avg_mask", dict(Lm=14, Mm=18, N=8)),      # AVERAGES + MASKING
     # open boundaries: the reference's own KELVIN application (ROMS/Include/kelvin.h, RADIATION_2D) ...
     # more of the reference's own test applications (ROMS/Include/seamount.h, grav_adj.h as shipped)
+    # the standard density Jacobian (prsgrd31.h), plain and weighted (WJ_GRADP)
+    "upwelling_prs31_small": ("upwelling_prs31", dict(Lm=14, Mm=18, N=8)),
+    "upwelling_wjgradp_small": ("upwelling_wjgradp", dict(Lm=14, Mm=18, N=8, wj=True)),
     "seamount": ("seamount", dict()),
     "seamount_small": ("seamount", dict(Lm=20, Mm=18, N=8)),
     "grav_adj": ("grav_adj", dict()),
@@ -122,7 +125,8 @@ def make_case(tag, **kw):
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
                 upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
-                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, seamount=cases.seamount, grav_adj=cases.grav_adj)[app]
+                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, seamount=cases.seamount, grav_adj=cases.grav_adj, upwelling_prs31=cases.upwelling_prs31,
+                upwelling_wjgradp=cases.upwelling_prs31)[app]
     lbc = k.pop("lbc", None)
     cs = ctor(**k)
     if tag.endswith("_obc_small"):

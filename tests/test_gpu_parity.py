@@ -681,12 +681,12 @@ def hiplib_options():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small"])
+@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "upwelling_prs31_small", "upwelling_wjgradp_small"])
 def test_more_reference_applications_match_oracle(tag):
     """SEAMOUNT and GRAV_ADJ (the reference's own test applications, oracle pinned bit for bit): 40 steps on the GPU at the
     north-star tolerance."""
     cs = util.case_for(tag)
-    g = util.load_init(tag, util.nghost_for(cs))
+    g = util.load_init("upwelling_small" if tag.startswith("upwelling") else tag, util.nghost_for(cs))   # (prsgrd31.h / WJ_GRADP variants of UPWELLING)
     O = util.make_oracle(cs, g)
     H = util.make_hip(cs, g)
     O.start()

@@ -344,3 +344,22 @@ def test_more_reference_applications_bitwise(emu, tag):
             assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
     assert np.abs(O.field("u")).max() > 1e-4
     H.close()
+
+
+@pytest.mark.parametrize("tag", ["upwelling_prs31_small", "upwelling_wjgradp_small"])
+def test_standard_density_jacobian_bitwise(emu, tag):
+    """prsgrd31.h (an application without DJ_GRADPS; WJ_GRADP: the weighted form), k_prs31: 8 steps against the oracle
+    (pinned to the reference built from oracle/ref/upwelling_prs31.h / upwelling_wjgradp.h), bit for bit; the result differs
+    from the prsgrd32.h run."""
+    cs = util.case_for(tag)
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O32 = util.make_oracle(util.case_for("upwelling_small"), g)
+    O.start(); H.start(); O32.start()
+    for _ in range(8):
+        O.main3d_step(); H.main3d(1); O32.main3d_step()
+        for n in util.PROGNOSTIC:
+            assert np.array_equal(H.download(n), O.field(n)), n
+    assert not np.array_equal(O.field("u"), O32.field("u"))
+    H.close()

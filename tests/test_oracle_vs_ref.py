@@ -183,7 +183,8 @@ def _child(mode, tag, *args, timeout=900):
            "benchmark_mask_small": "benchmark_mask", "upwelling_avg_mask_small": "upwelling_avg_mask",
            "kelvin": "kelvin_splines", "kelvin_small": "kelvin_splines", "kelvin_plain_small": "kelvin", "kelvin_plain": "kelvin",
            "upwelling_obc_small": "upwelling", "upwelling_mask_obc_small": "upwelling_mask", "seamount": "seamount",
-           "seamount_small": "seamount", "grav_adj": "grav_adj", "grav_adj_small": "grav_adj"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
+           "seamount_small": "seamount", "grav_adj": "grav_adj", "grav_adj_small": "grav_adj",
+           "upwelling_prs31_small": "upwelling_prs31", "upwelling_wjgradp_small": "upwelling_wjgradp"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
     if not ref.available(lib):
         pytest.skip(f"oracle/_ref/libromsref_{lib}.so not built here")
     p = subprocess.run([sys.executable, "-m", "tests.refchild", mode, tag] + list(args), capture_output=True,
@@ -227,6 +228,10 @@ MAIN3D_CASES = [
     ("grav_adj_small", ["nsteps=60"]),
     ("grav_adj_small", ["nsteps=20", "NtileI=2", "NtileJ=1"]),
     ("grav_adj", ["nsteps=40"]),                                                 # roms_grav_adj.in, full size
+    # the standard density Jacobian prsgrd31.h (no DJ_GRADPS), plain and weighted (WJ_GRADP)
+    ("upwelling_prs31_small", ["nsteps=60"]),
+    ("upwelling_wjgradp_small", ["nsteps=60"]),
+    ("upwelling_prs31_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
     ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
 ]

@@ -68,6 +68,10 @@ def case_for(tag, **kw):
         return cases.benchmark(Lm=48, Mm=34, N=6, **kw)
     if tag == "upwelling_mask_mid":
         return cases.upwelling_mask(Lm=34, Mm=40, N=6, **kw)
+    if tag == "upwelling_prs31_small":
+        return cases.upwelling_prs31(Lm=14, Mm=18, N=8, **kw)
+    if tag == "upwelling_wjgradp_small":
+        return cases.upwelling_prs31(wj=True, Lm=14, Mm=18, N=8, **kw)
     if tag == "seamount_small":
         return cases.seamount(Lm=20, Mm=18, N=8, **kw)
     if tag == "seamount":
