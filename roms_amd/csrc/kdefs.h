@@ -154,7 +154,7 @@ void kprof_end(int slot, hipStream_t stream);
 // 64 lanes along xi (coalesced), 4 rows of eta per block; 1-D grid of 8*ceil(blocks/8)*nz workgroups
 // g_thread_ballast: bytes of (unused) dynamic LDS a THREAD launch asks for -- caps its blocks per CU, so that
 // kernels placed beside the barotropic loop leave every CU room for a block of k_step2d (main3d_late)
-extern size_t g_thread_ballast;
+extern thread_local size_t g_thread_ballast;   // (per host thread: several contexts may be driven from one process)
 #define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
   KPROF_WRAP(name, stream,                                                               \
   hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + KTY - 1) / KTY)) + 7) / 8) * (nz)), 1, 1), \

@@ -1472,7 +1472,7 @@ static int baro_and_corrector(roms_hip_ctx *c, int join_late = -1) {
 }
 
 #ifndef ROMS_CPU_EMU
-size_t g_thread_ballast = 0;
+thread_local size_t g_thread_ballast = 0;
 #endif
 
 // diag (main3d.F:355) as a device-side reduction into c->d_diag; the caller has placed it on a stream

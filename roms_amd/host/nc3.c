@@ -121,11 +121,13 @@ static int r_atts(FILE *fp, nc_att *a, int *n) {
   int32_t tag, cnt;
   if (r_i32(fp, &tag) || r_i32(fp, &cnt)) return -1;
   if (tag == 0 && cnt == 0) { *n = 0; return 0; }
-  if (tag != TAG_ATT || cnt > NC3_MAXATT) return -1;
+  if (tag != TAG_ATT || cnt < 0) return -1;
+  if (cnt > NC3_MAXATT) return -10;             /* more attributes than this reader holds: its own code (nc3_open: -11) */
   for (int k = 0; k < cnt; k++) {
     int32_t type, len;
     char padbuf[4];
     if (r_name(fp, a[k].name) || r_i32(fp, &type) || r_i32(fp, &len)) return -1;
+    if (len < 0 || type < 1 || type > 6) return -1;       /* a corrupt or foreign header: never a negative allocation */
     a[k].type = type; a[k].n = len;
     a[k].val = calloc((size_t)len + 1, (size_t)tsize(type));
     if (!a[k].val || r_vals(fp, type, a[k].val, len)) return -1;
@@ -308,6 +310,15 @@ int nc3_close(int h) {
 
 /* ------------------------------------------------------------------ reading */
 /* mode 0: read only; 1: read and append/overwrite records of an existing file */
+/* a header this reader rejects: close the file and free whatever attribute values were already read.  -9: not a (sound)
+   NetCDF-3 file; -11: a sound file with more dimensions, variables or attributes than NC3_MAX* holds */
+static int open_fail(nc_file *f, int code) {
+  fclose(f->fp);
+  for (int k = 0; k < NC3_MAXATT; k++) free(f->gatt[k].val);
+  for (int v = 0; v < NC3_MAXVAR; v++) for (int k = 0; k < NC3_MAXATT; k++) free(f->var[v].att[k].val);
+  memset(f, 0, sizeof(*f));
+  return code;
+}
 int nc3_open(const char *path, int mode, int *h) {
   for (int k = 0; k < NC3_MAXFILE; k++)
     if (!files[k].used) {
@@ -318,31 +329,35 @@ int nc3_open(const char *path, int mode, int *h) {
       f->fp = fopen(path, mode ? "r+b" : "rb");
       if (!f->fp) return -2;
       f->recdim = -1;
-      if (fread(magic, 1, 4, f->fp) != 4 || memcmp(magic, "CDF", 3) || (magic[3] != 1 && magic[3] != 2)) { fclose(f->fp); return -9; }
+      if (fread(magic, 1, 4, f->fp) != 4 || memcmp(magic, "CDF", 3) || (magic[3] != 1 && magic[3] != 2)) return open_fail(f, -9);
       const int cdf2 = magic[3] == 2;
-      if (r_i32(f->fp, &nrec) || r_i32(f->fp, &tag) || r_i32(f->fp, &cnt)) { fclose(f->fp); return -9; }
+      if (r_i32(f->fp, &nrec) || r_i32(f->fp, &tag) || r_i32(f->fp, &cnt)) return open_fail(f, -9);
       f->numrecs = nrec;
-      if (!((tag == TAG_DIM && cnt <= NC3_MAXDIM) || (tag == 0 && cnt == 0))) { fclose(f->fp); return -9; }
+      if (tag == TAG_DIM && cnt > NC3_MAXDIM) return open_fail(f, -11);          /* limits of this reader exceeded */
+      if (!((tag == TAG_DIM && cnt >= 0) || (tag == 0 && cnt == 0))) return open_fail(f, -9);
       f->ndim = cnt;
       for (int d = 0; d < cnt; d++) {
         int32_t len;
-        if (r_name(f->fp, f->dim[d].name) || r_i32(f->fp, &len)) { fclose(f->fp); return -9; }
+        if (r_name(f->fp, f->dim[d].name) || r_i32(f->fp, &len) || len < 0) return open_fail(f, -9);
         f->dim[d].len = len;
         if (len == 0) f->recdim = d;
       }
-      if (r_atts(f->fp, f->gatt, &f->ngatt)) { fclose(f->fp); return -9; }
-      if (r_i32(f->fp, &tag) || r_i32(f->fp, &cnt) || !((tag == TAG_VAR && cnt <= NC3_MAXVAR) || (tag == 0 && cnt == 0))) { fclose(f->fp); return -9; }
+      { const int ra = r_atts(f->fp, f->gatt, &f->ngatt); if (ra) return open_fail(f, ra == -10 ? -11 : -9); }
+      if (r_i32(f->fp, &tag) || r_i32(f->fp, &cnt)) return open_fail(f, -9);
+      if (tag == TAG_VAR && cnt > NC3_MAXVAR) return open_fail(f, -11);
+      if (!((tag == TAG_VAR && cnt >= 0) || (tag == 0 && cnt == 0))) return open_fail(f, -9);
       f->nvar = cnt;
       for (int v = 0; v < cnt; v++) {
         nc_var *x = &f->var[v];
         int32_t nd, type, vs;
-        if (r_name(f->fp, x->name) || r_i32(f->fp, &nd) || nd > 6) { fclose(f->fp); return -9; }
+        if (r_name(f->fp, x->name) || r_i32(f->fp, &nd) || nd < 0 || nd > 6) return open_fail(f, -9);
         x->ndims = nd;
-        for (int d = 0; d < nd; d++) { int32_t id; if (r_i32(f->fp, &id)) { fclose(f->fp); return -9; } x->dimid[d] = id; }
-        if (r_atts(f->fp, x->att, &x->natt) || r_i32(f->fp, &type) || r_i32(f->fp, &vs)) { fclose(f->fp); return -9; }
+        for (int d = 0; d < nd; d++) { int32_t id; if (r_i32(f->fp, &id) || id < 0 || id >= f->ndim) return open_fail(f, -9); x->dimid[d] = id; }
+        { const int ra = r_atts(f->fp, x->att, &x->natt); if (ra) return open_fail(f, ra == -10 ? -11 : -9); }
+        if (r_i32(f->fp, &type) || r_i32(f->fp, &vs) || type < 1 || type > 6) return open_fail(f, -9);
         x->type = type;
-        if (cdf2) { int64_t b; if (r_i64(f->fp, &b)) { fclose(f->fp); return -9; } x->begin = b; }
-        else { int32_t b; if (r_i32(f->fp, &b)) { fclose(f->fp); return -9; } x->begin = b; }
+        if (cdf2) { int64_t b; if (r_i64(f->fp, &b)) return open_fail(f, -9); x->begin = b; }
+        else { int32_t b; if (r_i32(f->fp, &b)) return open_fail(f, -9); x->begin = b; }
         x->isrec = nd > 0 && f->dim[x->dimid[0]].len == 0;
         long long n = 1;
         for (int d = x->isrec ? 1 : 0; d < nd; d++) n *= f->dim[x->dimid[d]].len;

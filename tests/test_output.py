@@ -179,6 +179,47 @@ def test_restart_errors_are_reported(tmp_path):
     H.finalize()
 
 
+def test_nc3_reader_rejects_unsound_headers(tmp_path):
+    """nc3.c reads files it did not write (initial and restart files handed to the run): a header with negative counts or
+    lengths, or an unknown type, is refused with -9 before any allocation is sized from it; a sound header with more
+    dimensions than the reader holds gets its own code, -11."""
+    import ctypes as C
+    import struct
+    hl, _ = _libs("emu")
+    lib = C.CDLL(hl)
+    lib.nc3_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+
+    def name(s):
+        b = s.encode()
+        return struct.pack(">i", len(b)) + b + b"\0" * (-len(b) % 4)
+
+    def opened(body):
+        f = tmp_path / "h.nc"
+        f.write_bytes(b"CDF\x02" + body)
+        h = C.c_int(-1)
+        r = lib.nc3_open(str(f).encode(), 0, C.byref(h))
+        if r == 0:
+            lib.nc3_close(h)
+        return r
+
+    DIM, VAR, ATT = 10, 11, 12
+    i = lambda *v: struct.pack(">%di" % len(v), *v)
+    absent = i(0, 0)
+    one_dim = i(DIM, 1) + name("xi_rho") + i(4)
+    assert opened(i(0) + one_dim + absent + absent) == 0
+    assert opened(i(0) + i(DIM, -1)) == -9
+    assert opened(i(0) + i(DIM, 1) + name("xi_rho") + i(-4)) == -9
+    assert opened(i(0) + one_dim + i(ATT, -2)) == -9
+    assert opened(i(0) + one_dim + i(ATT, 1) + name("title") + i(2, -5)) == -9                 # NC_CHAR, negative length
+    assert opened(i(0) + one_dim + i(ATT, 1) + name("title") + i(9, 1) + i(0)) == -9             # no such type
+    assert opened(i(0) + one_dim + absent + i(VAR, 1) + name("h") + i(-1)) == -9                 # negative rank
+    assert opened(i(0) + one_dim + absent + i(VAR, 1) + name("h") + i(1, 3)) == -9               # dimension id out of range
+    assert opened(i(0) + one_dim + absent + i(VAR, -3)) == -9
+    assert opened(i(0) + i(DIM, 100000)) == -11
+    for k in range(40):                                                                          # every slot is free again
+        assert opened(i(0) + one_dim + i(ATT, 1) + name("title") + i(2, 3) + b"abc\0" + i(VAR, 1) + name("h") + i(7)) == -9
+
+
 def _run_tiles(tmp_path, spec, tiles, port):
     out = str(tmp_path / f"tiles_{port}.npz")
     spec = dict(spec, tiles=list(tiles))
