@@ -46,8 +46,15 @@ enum {
   ORC_PLAIN_VVISC = 1 << 18,
   ORC_PRSGRD31 = 1 << 19,     /* DJ_GRADPS NOT defined: the standard density Jacobian, prsgrd31.h */
   ORC_WJ_GRADP = 1 << 27,     /* ... in its weighted form (Song 1998), prsgrd31.h:232-250 */  /* SPLINES_VVISC NOT defined: plain tridiagonal vertical viscosity (step3d_uv.F:436-500) */
+  ORC_GLS_MIXING = 1 << 25,   /* generic length-scale closure: gls_prestep.F, gls_corstep.F (its compile-time forms: cfg.gls_flags) */
   ORC_APP_UPWELLING = 1 << 20, ORC_APP_BENCHMARK = 1 << 21, ORC_APP_KELVIN = 1 << 22, ORC_APP_SEAMOUNT = 1 << 23, ORC_APP_GRAV_ADJ = 1 << 24   /* (no forcing: the default branches of ana_smflux.h ...) */
 };
+
+/* compile-time forms of GLS_MIXING (cppdefs.h names), cfg.gls_flags */
+enum { ORC_GLS_CANUTO_A = 1, ORC_GLS_CANUTO_B = 2, ORC_GLS_KANTHA_CLAYSON = 4,   /* none of the three: Galperin */
+       ORC_GLS_N2S2_HORAVG = 8, ORC_GLS_RI_SPLINES = 16,
+       ORC_GLS_K_C2ADVECTION = 32, ORC_GLS_K_C4ADVECTION = 64,                   /* neither: third-order upstream */
+       ORC_GLS_CHARNOK = 128, ORC_GLS_CRAIG_BANNER = 256 };
 
 /* loop bounds of one tile: BOUNDS(ng)%xxx(tile), get_bounds.F:1044-1884 */
 typedef struct {
@@ -104,6 +111,10 @@ typedef struct {
   int lbc[4][ORC_NLBC];
   double FSobc_in[4], FSobc_out[4], M2obc_in[4], M2obc_out[4], M3obc_in[4], M3obc_out[4];
   double Tobc_in[ORC_MAXT][4], Tobc_out[ORC_MAXT][4];
+  /* GLS_MIXING: the GLS_* block of roms.in (read_phypar.F), Akk_bak, Akp_bak, Zos, the surface-flux constants */
+  int gls_flags;
+  double gls_p, gls_m, gls_n, gls_Kmin, gls_Pmin, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp;
+  double Akk_bak, Akp_bak, Zos, charnok_alpha, crgban_cw;
 } orc_cfg;
 
 /* time-level state of main3d / mod_stepping */
@@ -141,6 +152,7 @@ typedef struct orc_s {
   double *Uwind, *Vwind, *Tair, *Pair, *Hair, *rain, *cloud, *lhflx, *shflx, *lrflx, *evap;
   /* mod_mixing */
   double *Akv, *Akt, *visc2_r, *visc2_p, *diff2, *bvf, *alpha, *beta, *hsbl, *ghats;
+  double *tke, *gls, *Lscale, *Akk, *Akp;   /* GLS_MIXING: tke, gls(i,j,0:N,3); Lscale, Akk, Akp(i,j,0:N) */
   int *ksbl;
   /* mod_boundary: BOUNDARY(ng)%zeta_west(LBj:UBj) ... t_north(LBi:UBi,N,NT): the open-boundary data of this step (inputs) */
   double *zeta_west, *zeta_south, *zeta_east, *zeta_north, *ubar_west, *ubar_south, *ubar_east, *ubar_north,
@@ -222,6 +234,8 @@ void orc_step3d_t(orc_t *o, int tile);
 void orc_diag(orc_t *o);
 void orc_lmd_vmix(orc_t *o, int tile);
 void orc_bulk_flux(orc_t *o, int tile);
+void orc_gls_prestep(orc_t *o, int tile);
+void orc_gls_corstep(orc_t *o, int tile);
 void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta, double *Ua, double *Va,
                       double *Wa, const double *oHz);
 

@@ -18,6 +18,9 @@ UV_ADV, UV_COR, UV_VIS2, TS_DIF2, MIX_GEO_TS, CURVGRID, NONLIN_EOS, UV_QDRAG, LM
     BULK_FLUXES, SOLAR_SOURCE, ANA_VMIX, SALINITY, SPHERICAL, UV_LOGDRAG, MASKING = [1 << k for k in range(16)]
 RADIATION_2D, PLAIN_VDIFF, PLAIN_VVISC, PRSGRD31 = 1 << 16, 1 << 17, 1 << 18, 1 << 19
 WJ_GRADP = 1 << 27
+GLS_MIXING = 1 << 25
+GLS_FLAGS = {"CANUTO_A": 1, "CANUTO_B": 2, "KANTHA_CLAYSON": 4, "N2S2_HORAVG": 8, "RI_SPLINES": 16,
+             "K_C2ADVECTION": 32, "K_C4ADVECTION": 64, "CHARNOK": 128, "CRAIG_BANNER": 256}
 APP_UPWELLING, APP_BENCHMARK, APP_KELVIN, APP_SEAMOUNT, APP_GRAV_ADJ = 1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 24
 # lateral boundary conditions (orc.h): edges, variables, kinds
 IWEST, ISOUTH, IEAST, INORTH = range(4)
@@ -45,6 +48,12 @@ class Cfg(C.Structure):
         ("FSobc_in", C.c_double * 4), ("FSobc_out", C.c_double * 4), ("M2obc_in", C.c_double * 4),
         ("M2obc_out", C.c_double * 4), ("M3obc_in", C.c_double * 4), ("M3obc_out", C.c_double * 4),
         ("Tobc_in", (C.c_double * 4) * MAXT), ("Tobc_out", (C.c_double * 4) * MAXT),
+        ("gls_flags", C.c_int),
+        ("gls_p", C.c_double), ("gls_m", C.c_double), ("gls_n", C.c_double), ("gls_Kmin", C.c_double),
+        ("gls_Pmin", C.c_double), ("gls_cmu0", C.c_double), ("gls_c1", C.c_double), ("gls_c2", C.c_double),
+        ("gls_c3m", C.c_double), ("gls_c3p", C.c_double), ("gls_sigk", C.c_double), ("gls_sigp", C.c_double),
+        ("Akk_bak", C.c_double), ("Akp_bak", C.c_double), ("Zos", C.c_double), ("charnok_alpha", C.c_double),
+        ("crgban_cw", C.c_double),
     ]
 
 

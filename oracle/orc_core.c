@@ -112,7 +112,7 @@ static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(doub
 
 typedef struct { const char *name; size_t off; int kind; } fdesc;
 /* kind: number of 2-D planes as a function of N, NT: see field_planes() */
-enum { K2 = 0, KR, KW, K2x3, K2x2, KRx2, KTR, KWx2, K2xNT, KWxNAT, KTAB_R, KTAB_W,
+enum { K2 = 0, KR, KW, KWx3, K2x3, K2x2, KRx2, KTR, KWx2, K2xNT, KWxNAT, KTAB_R, KTAB_W,
        KBJ, KBI, KBJN, KBIN, KBJT, KBIT };   /* boundary data: (LBj:UBj) / (LBi:UBi) [, N [, NT]] */
 #define FD(nm, kind) { #nm, offsetof(orc_t, nm), kind }
 static const fdesc fields[] = {
@@ -134,6 +134,7 @@ static const fdesc fields[] = {
   FD(cloud, K2), FD(lhflx, K2), FD(shflx, K2), FD(lrflx, K2), FD(evap, K2),
   FD(Akv, KW), FD(Akt, KWxNAT), FD(visc2_r, K2), FD(visc2_p, K2), FD(diff2, K2xNT),
   FD(bvf, KW), FD(alpha, K2), FD(beta, K2), FD(hsbl, K2), FD(ghats, KWxNAT),
+  FD(tke, KWx3), FD(gls, KWx3), FD(Lscale, KW), FD(Akk, KW), FD(Akp, KW),
   FD(sc_r, KTAB_R), FD(Cs_r, KTAB_R), FD(sc_w, KTAB_W), FD(Cs_w, KTAB_W),
   FD(zeta_west, KBJ), FD(zeta_east, KBJ), FD(zeta_south, KBI), FD(zeta_north, KBI),
   FD(ubar_west, KBJ), FD(ubar_east, KBJ), FD(ubar_south, KBI), FD(ubar_north, KBI),
@@ -150,6 +151,7 @@ static size_t field_size(const orc_t *o, int kind) {
     case K2: return p;
     case KR: return p * N;
     case KW: return p * (N + 1);
+    case KWx3: return p * (N + 1) * 3;
     case K2x3: return p * 3;
     case K2x2: return p * 2;
     case KRx2: return p * N * 2;

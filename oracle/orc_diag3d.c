@@ -131,13 +131,16 @@ void orc_rho_eos(orc_t *o, int tile) {
       rhoA[X2(i, j)] = cff2 * cff1 * rhoA[X2(i, j)];
       rhoS[X2(i, j)] = 2.0 * cff1 * cff1 * cff2 * rhoS[X2(i, j)];
     }
-    if (o->c.options & ORC_LMD_MIXING) {
-      /* BV_FREQUENCY :751-764 and LMD_SKPP expansion coefficients :766-780 of the linear EOS */
+    if (o->c.options & (ORC_LMD_MIXING | ORC_GLS_MIXING)) {
+      /* BV_FREQUENCY (LMD_MIXING, GLS_MIXING: globaldefs.h) :751-764 of the linear EOS */
       const double gorho0 = o->c.g / o->c.rho0;
       for (int k = 1; k <= N - 1; k++)
         for (int i = b->IstrT; i <= b->IendT; i++)
           o->bvf[XW(i, j, k)] = -gorho0 * (rho[X3(i, j, k + 1)] - rho[X3(i, j, k)]) /
                                 (o->z_r[X3(i, j, k + 1)] - o->z_r[X3(i, j, k)]);
+    }
+    if (o->c.options & ORC_LMD_MIXING) {
+      /* LMD_SKPP expansion coefficients :766-780 */
       for (int i = b->IstrT; i <= b->IendT; i++) {
         o->alpha[X2(i, j)] = fabs(Tcoef);
         o->beta[X2(i, j)] = (o->c.options & ORC_SALINITY) ? fabs(Scoef) : 0.0;
@@ -152,7 +155,7 @@ void orc_rho_eos(orc_t *o, int tile) {
   }
   orc_exchange2d(o, b, 'r', rhoA);
   orc_exchange2d(o, b, 'r', rhoS);
-  if (o->c.options & ORC_LMD_MIXING) orc_exchange3d(o, b, 'w', o->bvf, N + 1);
+  if (o->c.options & (ORC_LMD_MIXING | ORC_GLS_MIXING)) orc_exchange3d(o, b, 'w', o->bvf, N + 1);
 }
 
 /* --------------------------------------------------------------- set_vbc */

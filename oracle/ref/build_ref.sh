@@ -70,6 +70,17 @@ if [ "$APP" = upwelling_prs31 ] || [ "$APP" = upwelling_wjgradp ]; then
   UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
   EXTRA=""
 fi
+if [ "$APP" = upwelling_gls ]; then
+  # the shipped upwelling.h with the generic length-scale closure switched on as a user does (-DGLS_MIXING: upwelling.h
+  # then selects KANTHA_CLAYSON, N2S2_HORAVG, RI_SPLINES)
+  UP=UPWELLING; HDR=upwelling; HDRPATH="upwelling.h"
+  EXTRA="-DPERFECT_RESTART -DGLS_MIXING"
+fi
+if [ "$APP" = upwelling_gls_ca ] || [ "$APP" = upwelling_gls_cb ] || [ "$APP" = upwelling_gls_gal ]; then
+  # GLS_MIXING in its other compile-time forms (oracle/ref/upwelling_gls_*.h; _ca is masked)
+  UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
+  EXTRA="-I$HERE/functionals"
+fi
 if [ "$APP" = seamount ]; then
   # the SEAMOUNT case without the user diagnostics hook ANA_DIAG (oracle/ref/seamount_nodiag.h)
   UP=SEAMOUNT; HDR=seamount_nodiag; HDRPATH="$HERE/seamount_nodiag.h"
@@ -118,7 +129,7 @@ FILES="mod_kinds mod_param mod_scalars mod_stepping mod_strings mod_iounits mod_
   bc_2d bc_3d zetabc u2dbc_im v2dbc_im t3dbc_im u3dbc_im v3dbc_im obc_volcons
   set_depth set_massflux rho_eos prsgrd t3dmix uv3dmix set_vbc set_zeta wvelocity diag ini_fields
   mod_sources uv_var_change step2d omega pre_step3d rhs3d step3d_uv step3d_t
-  mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix bulk_flux analytical
+  mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix gls_prestep gls_corstep tkebc_im bulk_flux analytical
   mod_average uv_rotate vorticity set_avg"
 TODO=""
 for m in $FILES; do

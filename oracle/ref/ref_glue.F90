@@ -231,6 +231,27 @@
 #if defined LMD_SKPP || defined SOLAR_SOURCE
       lmd_Jwt(ng)=ipar(16)
 #endif
+#ifdef GLS_MIXING
+!  the GLS_* block of roms.in (read_phypar.F): rpar(66..)
+      gls_p(ng)=rpar(66)
+      gls_m(ng)=rpar(67)
+      gls_n(ng)=rpar(68)
+      gls_Kmin(ng)=rpar(69)
+      gls_Pmin(ng)=rpar(70)
+      gls_cmu0(ng)=rpar(71)
+      gls_c1(ng)=rpar(72)
+      gls_c2(ng)=rpar(73)
+      gls_c3m(ng)=rpar(74)
+      gls_c3p(ng)=rpar(75)
+      gls_sigk(ng)=rpar(76)
+      gls_sigp(ng)=rpar(77)
+      Akk_bak(ng)=rpar(78)
+      Akp_bak(ng)=rpar(79)
+      charnok_alpha(ng)=rpar(80)
+      zos_hsig_alpha(ng)=rpar(81)
+      sz_alpha(ng)=rpar(82)
+      crgban_cw(ng)=rpar(83)
+#endif
 !
 !  What inp_par does after read_phypar (Utility/inp_par.F:210-226,...).
 !
@@ -451,6 +472,10 @@
 #ifdef LMD_MIXING
       USE lmd_vmix_mod,      ONLY : lmd_vmix
 #endif
+#ifdef GLS_MIXING
+      USE gls_prestep_mod,   ONLY : gls_prestep
+      USE gls_corstep_mod,   ONLY : gls_corstep
+#endif
 #ifdef BULK_FLUXES
       USE bulk_flux_mod,     ONLY : bulk_flux
 #endif
@@ -498,8 +523,11 @@
         DO tile=first_tile(ng),last_tile(ng),+1            ! :554-564
           CALL set_zeta (ng, tile)
         END DO
-        DO tile=last_tile(ng),first_tile(ng),-1            ! :630-634
+        DO tile=last_tile(ng),first_tile(ng),-1            ! :630-639
           CALL rhs3d (ng, tile)
+#ifdef GLS_MIXING
+          CALL gls_prestep (ng, tile)
+#endif
         END DO
         LOOP_2D : DO my_iif=1,nfast(ng)+1                  ! :810-918
           next_indx1=3-indx1(ng)
@@ -539,8 +567,11 @@
         DO tile=last_tile(ng),first_tile(ng),-1            ! :988-992
           CALL step3d_uv (ng, tile)
         END DO
-        DO tile=first_tile(ng),last_tile(ng),+1            ! :1015-1019
+        DO tile=first_tile(ng),last_tile(ng),+1            ! :1015-1023
           CALL omega (ng, tile, iNLM)
+#ifdef GLS_MIXING
+          CALL gls_corstep (ng, tile)
+#endif
         END DO
         DO tile=last_tile(ng),first_tile(ng),-1            ! :1043-1047
           CALL step3d_t (ng, tile)
@@ -642,6 +673,10 @@
 #ifdef LMD_MIXING
       USE lmd_vmix_mod,      ONLY : lmd_vmix
 #endif
+#ifdef GLS_MIXING
+      USE gls_prestep_mod,   ONLY : gls_prestep
+      USE gls_corstep_mod,   ONLY : gls_corstep
+#endif
 #ifdef BULK_FLUXES
       USE bulk_flux_mod,     ONLY : bulk_flux
 #endif
@@ -742,6 +777,12 @@
 #ifdef LMD_MIXING
           CASE ('lmd_vmix')
             CALL lmd_vmix (ng, tile)
+#endif
+#ifdef GLS_MIXING
+          CASE ('gls_prestep')
+            CALL gls_prestep (ng, tile)
+          CASE ('gls_corstep')
+            CALL gls_corstep (ng, tile)
 #endif
           CASE DEFAULT
             ierr=-1
@@ -1138,6 +1179,13 @@
 #ifdef NONLIN_EOS
         F2('alpha',MIXING(ng)%alpha)
         F2('beta',MIXING(ng)%beta)
+#endif
+#ifdef GLS_MIXING
+        F2('tke',MIXING(ng)%tke)
+        F2('gls',MIXING(ng)%gls)
+        F2('Lscale',MIXING(ng)%Lscale)
+        F2('Akk',MIXING(ng)%Akk)
+        F2('Akp',MIXING(ng)%Akp)
 #endif
 #ifdef LMD_SKPP
         F2('hsbl',MIXING(ng)%hsbl)

@@ -138,6 +138,38 @@ def upwelling_prs31(wj=False, **kw):
     return cs
 
 
+# the parameter sets of the generic length-scale closure suggested in the reference's input files
+# (ROMS/External/roms_upwelling.in:1992-2006): p, m, n, Kmin, Pmin, cmu0, c1, c2, c3m, c3p, sigk, sigp
+GLS_SETS = {
+    "k-kl": (0.0, 1.0, 1.0, 5.0e-6, 5.0e-6, 0.5544, 0.9, 0.52, 2.5, 1.0, 1.96, 1.96),
+    "k-epsilon": (3.0, 1.5, -1.0, 7.6e-6, 1.0e-12, 0.5477, 1.44, 1.92, -0.4, 1.0, 1.0, 1.30),
+    "k-omega": (-1.0, 0.5, -1.0, 7.6e-6, 1.0e-12, 0.5477, 0.555, 0.833, -0.6, 1.0, 2.0, 2.0),
+    "gen": (2.0, 1.0, -0.67, 1.0e-8, 1.0e-8, 0.5544, 1.00, 1.22, 0.1, 1.0, 0.8, 1.07),
+}
+GLS_NAMES = ("gls_p", "gls_m", "gls_n", "gls_Kmin", "gls_Pmin", "gls_cmu0", "gls_c1", "gls_c2", "gls_c3m", "gls_c3p",
+             "gls_sigk", "gls_sigp")
+# the compile-time forms: library name of oracle/ref/build_ref.sh -> cpp options beside GLS_MIXING
+GLS_FORMS = {
+    "upwelling_gls": ("KANTHA_CLAYSON", "N2S2_HORAVG", "RI_SPLINES"),          # upwelling.h as shipped, -DGLS_MIXING
+    "upwelling_gls_ca": ("CANUTO_A", "N2S2_HORAVG", "RI_SPLINES"),             # + MASKING
+    "upwelling_gls_cb": ("CANUTO_B", "K_C2ADVECTION", "CHARNOK", "CRAIG_BANNER"),
+    "upwelling_gls_gal": ("K_C4ADVECTION", "RI_SPLINES"),
+}
+
+
+def upwelling_gls(form="upwelling_gls", closure="k-epsilon", **kw):
+    """UPWELLING with the generic length-scale closure (GLS_MIXING) instead of ANA_VMIX: upwelling.h built with
+    -DGLS_MIXING, or one of the custom headers oracle/ref/upwelling_gls_*.h; `closure`: a column of GLS_SETS"""
+    cs = upwelling(**kw)
+    cs["app"] = form
+    cs["options"] = tuple(o for o in cs["options"] if o != "ANA_VMIX") + ("GLS_MIXING",) + \
+        (("MASKING",) if form == "upwelling_gls_ca" else ())
+    cs["gls_flags"] = GLS_FORMS[form]
+    cs.update(dict(zip(GLS_NAMES, GLS_SETS[closure])))
+    cs.update(Akk_bak=5.0e-6, Akp_bak=5.0e-6, charnok_alpha=1400.0, zos_hsig_alpha=0.5, sz_alpha=0.25, crgban_cw=100.0)
+    return cs
+
+
 def upwelling_mask(**kw):
     """UPWELLING with land/sea masking (MASKING): an island and a headland on the southern wall (`land_mask`); the
     custom application header oracle/ref/upwelling_mask.h"""
@@ -205,6 +237,18 @@ def benchmark(Lm=512, Mm=64, N=30, NtileI=1, NtileJ=1, ntimes=200):
     )
 
 
+def gls_cfg(c, cs, flag_table):
+    """the GLS_MIXING tail of a configuration record (roms_hip_config / orc_cfg)"""
+    c.Zos = cs["Zos"]
+    if "gls_flags" not in cs:
+        return
+    c.gls_flags = 0
+    for n in cs["gls_flags"]:
+        c.gls_flags |= flag_table[n]
+    for n in GLS_NAMES + ("Akk_bak", "Akp_bak", "charnok_alpha", "crgban_cw"):
+        setattr(c, n, cs[n])
+
+
 def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
     """roms_hip_config for a single tile covering the domain (include/roms_hip.h)."""
     from . import hiplib
@@ -252,6 +296,7 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
             getattr(c, n)[e] = sc[n][e]
         for it in range(2):
             c.Tobc_in[it][e], c.Tobc_out[it][e] = sc["Tobc_in"][it][e], sc["Tobc_out"][it][e]
+    gls_cfg(c, cs, hiplib.GLS_FLAGS)
     for k in range(cs["N"]):
         c.sc_r[k], c.Cs_r[k] = sc_r[k], Cs_r[k]
     for k in range(cs["N"] + 1):

@@ -33,6 +33,12 @@ CASES = {
     # the standard density Jacobian (prsgrd31.h), plain and weighted (WJ_GRADP)
     "upwelling_prs31_small": ("upwelling_prs31", dict(Lm=14, Mm=18, N=8)),
     "upwelling_wjgradp_small": ("upwelling_wjgradp", dict(Lm=14, Mm=18, N=8, wj=True)),
+    # the generic length-scale closure: upwelling.h with -DGLS_MIXING, and its other compile-time forms
+    "upwelling_gls_small": ("upwelling_gls", dict(Lm=14, Mm=18, N=8)),
+    "upwelling_gls_kw_small": ("upwelling_gls", dict(Lm=14, Mm=18, N=8, closure="k-omega")),
+    "upwelling_gls_ca_small": ("upwelling_gls_ca", dict(Lm=14, Mm=18, N=8, form="upwelling_gls_ca", closure="gen")),
+    "upwelling_gls_cb_small": ("upwelling_gls_cb", dict(Lm=14, Mm=18, N=8, form="upwelling_gls_cb", closure="k-kl")),
+    "upwelling_gls_gal_small": ("upwelling_gls_gal", dict(Lm=14, Mm=18, N=8, form="upwelling_gls_gal", closure="k-omega")),
     "seamount": ("seamount", dict()),
     "seamount_small": ("seamount", dict(Lm=20, Mm=18, N=8)),
     "grav_adj": ("grav_adj", dict()),
@@ -126,7 +132,8 @@ def make_case(tag, **kw):
                 upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
                 upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
                 upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, seamount=cases.seamount, grav_adj=cases.grav_adj, upwelling_prs31=cases.upwelling_prs31,
-                upwelling_wjgradp=cases.upwelling_prs31)[app]
+                upwelling_wjgradp=cases.upwelling_prs31, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
+                upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls)[app]
     lbc = k.pop("lbc", None)
     cs = ctor(**k)
     if tag.endswith("_obc_small"):

@@ -232,6 +232,18 @@ MAIN3D_CASES = [
     ("upwelling_prs31_small", ["nsteps=60"]),
     ("upwelling_wjgradp_small", ["nsteps=60"]),
     ("upwelling_prs31_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # the generic length-scale closure (gls_prestep.F, gls_corstep.F, tkebc_im.F): upwelling.h built with -DGLS_MIXING
+    # (Kantha-Clayson, N2S2_HORAVG, RI_SPLINES; k-epsilon and k-omega parameters of roms_upwelling.in), and the other
+    # compile-time forms: Canuto A under MASKING ("gen" parameters), Canuto B with K_C2ADVECTION, CHARNOK, CRAIG_BANNER
+    # (k-kl parameters: the wall function), Galperin with K_C4ADVECTION (k-omega)
+    ("upwelling_gls_small", ["nsteps=100"]),
+    ("upwelling_gls_kw_small", ["nsteps=60"]),
+    ("upwelling_gls_ca_small", ["nsteps=100"]),
+    ("upwelling_gls_cb_small", ["nsteps=100"]),
+    ("upwelling_gls_gal_small", ["nsteps=60"]),
+    ("upwelling_gls_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_gls_ca_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_gls_cb_small", ["nsteps=20", "NtileI=3", "NtileJ=1", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
     ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
 ]
