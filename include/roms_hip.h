@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define ROMS_HIP_ABI_VERSION 2    /* 2: lateral boundary conditions (lbc ... Tobc_out) appended to roms_hip_config */
+#define ROMS_HIP_ABI_VERSION 3    /* 2: lateral boundary conditions (lbc ... Tobc_out) appended to roms_hip_config;
+                                     3: the generic length-scale closure (gls_flags ... lbc_tke) appended */
 #define ROMS_MAXT 4              /* max tracers handled (NT) */
 #define ROMS_MAXW 512            /* max 2*ndtfast */
 
@@ -54,10 +55,20 @@ enum {
   ROMS_PLAIN_VVISC = 1 << 18,       /* SPLINES_VVISC is NOT defined: plain tridiagonal vertical viscosity (step3d_uv.F:436-500, :903-967) */
   ROMS_PRSGRD31 = 1 << 19,          /* DJ_GRADPS is NOT defined: the standard density Jacobian prsgrd31.h (prsgrd.F:22-26) */
   ROMS_WJ_GRADP = 1 << 27,          /* ... in its weighted form, prsgrd31.h:232-250 */
+  ROMS_GLS_MIXING = 1 << 25,        /* generic length-scale vertical closure (gls_prestep.F, gls_corstep.F); its compile-time
+                                       forms in roms_hip_config.gls_flags, its roms.in parameters beside them */
   ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21,
   ROMS_APP_KELVIN = 1 << 22,        /* no wind, no surface fluxes (the default branches of ana_smflux.h, ana_stflux.h) */
   ROMS_APP_SEAMOUNT = 1 << 23, ROMS_APP_GRAV_ADJ = 1 << 24   /* likewise unforced (set_data has nothing to do) */
 };
+
+/* GLS_MIXING: the cpp options that select a form of gls_prestep.F / gls_corstep.F (cppdefs.h names).  Stability
+   functions: CANUTO_A | CANUTO_B | KANTHA_CLAYSON, none = Galperin (gls_corstep.F:1120-1165, mod_scalars.F:1764-1796,
+   :4715-4766); advection of tke and gls: K_C2ADVECTION | K_C4ADVECTION, none = third-order upstream.  ZOS_HSIG and
+   TKE_WAVEDISS (wave fields), LIMIT_VDIFF / LIMIT_VVISC are not built (the host stops on them). */
+enum { ROMS_GLS_CANUTO_A = 1, ROMS_GLS_CANUTO_B = 2, ROMS_GLS_KANTHA_CLAYSON = 4, ROMS_GLS_N2S2_HORAVG = 8,
+       ROMS_GLS_RI_SPLINES = 16, ROMS_GLS_K_C2ADVECTION = 32, ROMS_GLS_K_C4ADVECTION = 64, ROMS_GLS_CHARNOK = 128,
+       ROMS_GLS_CRAIG_BANNER = 256 };
 
 /* Lateral boundary conditions: LBC(ibry,ivar,ng) of mod_param.F, the LBC(isFsur) ... LBC(isTvar) lines of roms.in
    (load_lbc, Utility/inp_decode.F:1560-1680).  Edge index = the reference's iwest, isouth, ieast, inorth minus one;
@@ -109,6 +120,13 @@ typedef struct roms_hip_config {
   int lbc[4][ROMS_NLBC];
   double FSobc_in[4], FSobc_out[4], M2obc_in[4], M2obc_out[4], M3obc_in[4], M3obc_out[4];
   double Tobc_in[ROMS_MAXT][4], Tobc_out[ROMS_MAXT][4];
+  /* GLS_MIXING (ABI version 3): ROMS_GLS_* flags; GLS_P ... GLS_SIGP, AKK_BAK, AKP_BAK, Zos, CHARNOK_ALPHA, CRGBAN_CW of
+     roms.in (read_phypar.F); LBC(isMtke) per edge: closed, gradient or periodic (tkebc_im.F; its radiation condition
+     is not built).  State arrays "tke", "gls" (i,j,0:N,3), "Lscale", "Akk", "Akp" (i,j,0:N) of mod_mixing.F. */
+  int gls_flags;
+  double gls_p, gls_m, gls_n, gls_Kmin, gls_Pmin, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp;
+  double Akk_bak, Akp_bak, Zos, charnok_alpha, crgban_cw;
+  int lbc_tke[4];
 } roms_hip_config;
 
 /* time indices of mod_stepping.F / mod_scalars.F that the kernel wrappers read */
@@ -170,6 +188,8 @@ int roms_hip_step3d_uv(roms_hip_ctx *ctx);     /* step3d_uv      step3d_uv.F:40 
 int roms_hip_step3d_t(roms_hip_ctx *ctx);      /* step3d_t       step3d_t.F:40       */
 int roms_hip_lmd_vmix(roms_hip_ctx *ctx);      /* lmd_vmix       lmd_vmix.F:45       */
 int roms_hip_bulk_flux(roms_hip_ctx *ctx);     /* bulk_flux      bulk_flux.F:100     */
+int roms_hip_gls_prestep(roms_hip_ctx *ctx);   /* gls_prestep    gls_prestep.F:42  (main3d.F:636, behind rhs3d)  */
+int roms_hip_gls_corstep(roms_hip_ctx *ctx);   /* gls_corstep    gls_corstep.F:52  (main3d.F:1021, behind omega) */
 /* diag diag.F:30 -- synchronises; out must hold 16 doubles: out[0..11] = avgke avgpe avgkp volume
    maxspeed max_Cu max_Cv max_Cw max_Ci max_Cj max_Ck max_C of this context's tile, out[12..13] =
    the un-normalised kinetic / potential energy sums (a multi-tile caller adds out[3], out[12],

@@ -253,7 +253,7 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
     """roms_hip_config for a single tile covering the domain (include/roms_hip.h)."""
     from . import hiplib
     c = hiplib.Config()
-    c.abi_version, c.device = 2, device
+    c.abi_version, c.device = 3, device
     c.Lm, c.Mm, c.N, c.NT, c.NAT = cs["Lm"], cs["Mm"], cs["N"], 2, 2
     hs = [SCHEME[x] for x in cs["hadv"]]
     vs = [SCHEME[x] for x in cs["vadv"]]

@@ -60,11 +60,11 @@ int run_rho_eos(roms_hip_ctx *c) {
       {c->F.pden, N, BC_NONE, 'r'},
       {c->F.rhoA, 1, BC_NONE, 'r'},
       {c->F.rhoS, 1, BC_NONE, 'r'},
-      {c->F.alpha, 1, BC_NONE, 'r'},      // LMD_MIXING only (:766-780, :751-764)
+      {c->F.bvf, N + 1, BC_NONE, 'r'},    // BV_FREQUENCY: LMD_MIXING, GLS_MIXING (:751-764)
+      {c->F.alpha, 1, BC_NONE, 'r'},      // LMD_MIXING only (:766-780)
       {c->F.beta, 1, BC_NONE, 'r'},
-      {c->F.bvf, N + 1, BC_NONE, 'r'},
   };
-  launch_halo_tail(c, hs3, (c->G.options & ROMS_LMD_MIXING) ? 7 : 4);
+  launch_halo_tail(c, hs3, (c->G.options & ROMS_LMD_MIXING) ? 7 : ((c->G.options & ROMS_GLS_MIXING) ? 5 : 4));
   return 0;
 }
 

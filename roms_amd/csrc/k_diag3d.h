@@ -112,7 +112,8 @@ THREAD_KERNEL(k_rho_eos_lin, KArgs) {
   const Fields &F = a.Fv;
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, N = G.N, nrhs = G.nrhs;
   const bool salt = (G.options & ROMS_SALINITY) != 0;
-  const bool kpp = (G.options & ROMS_LMD_MIXING) != 0;   // BV_FREQUENCY and expansion coefficients :751-780
+  const bool kpp = (G.options & ROMS_LMD_MIXING) != 0;   // expansion coefficients :766-780
+  const bool bvq = (G.options & (ROMS_LMD_MIXING | ROMS_GLS_MIXING)) != 0;   // BV_FREQUENCY :751-764
   const double gorho0 = G.g / G.rho0;
   double rhoA = 0.0, rhoS = 0.0, rup = 0.0;
   const EmitPlan P = emit_plan(G, BC_NONE, i, j);
@@ -123,7 +124,7 @@ THREAD_KERNEL(k_rho_eos_lin, KArgs) {
     if (G.masking) r = r * F.rmask[X2(i, j)];                                             // rho_eos.F:718
     emit_store(G, P, F.rho + (size_t)(k - 1) * G.nij, r);
     emit_store(G, P, F.pden + (size_t)(k - 1) * G.nij, r);
-    if (kpp && k < N)
+    if (bvq && k < N)
       emit_store(G, P, F.bvf + (size_t)k * G.nij, -gorho0 * (rup - r) / (F.z_r[X3(i, j, k + 1)] - F.z_r[X3(i, j, k)]));
     rup = r;
     const double Hzk = F.Hz[X3(i, j, k)];

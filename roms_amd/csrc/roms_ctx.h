@@ -194,6 +194,7 @@ struct Fields {
   GPtr Uwind, Vwind, Tair, Pair, Hair, rain, cloud, lhflx, shflx, lrflx, evap;
   // mod_mixing
   GPtr Akv, Akt, visc2_r, visc2_p, diff2, bvf, alpha, beta, hsbl, ghats;
+  GPtr tke, gls, Lscale, Akk, Akp;   // GLS_MIXING: tke, gls (i,j,0:N,3); Lscale, Akk, Akp (i,j,0:N)
   // s-coordinate tables (device copies)
   GPtr sc_r, Cs_r, sc_w, Cs_w;
   // work space: private 3-D arrays of the reference kernels (P of prsgrd, vert of wvelocity,

@@ -87,6 +87,7 @@ static const FieldDesc g_fields[] = {
     FD(cloud, FK_2D), FD(lhflx, FK_2D), FD(shflx, FK_2D), FD(lrflx, FK_2D), FD(evap, FK_2D),
     FD(Akv, FK_W), FD(Akt, FK_WxNAT), FD(visc2_r, FK_2D), FD(visc2_p, FK_2D), FD(diff2, FK_2DxNT), FD(bvf, FK_W),
     FD(alpha, FK_2D), FD(beta, FK_2D), FD(hsbl, FK_2D), FD(ghats, FK_WxNAT),
+    FD(tke, FK_Wx3), FD(gls, FK_Wx3), FD(Lscale, FK_W), FD(Akk, FK_W), FD(Akp, FK_W),
     FD(sc_r, FK_TABR), FD(Cs_r, FK_TABR), FD(sc_w, FK_TABW), FD(Cs_w, FK_TABW),
     // wvelocity's result at the output point of a step (roms_hip_output_point); download only
     {"w_out", offsetof(Fields, wrk3) + 12 * sizeof(GPtr), FK_W},
@@ -113,6 +114,7 @@ int field_planes(const roms_hip_ctx *c, int kind) {
     case FK_Rx2: return N * 2;
     case FK_T: return N * 3 * NT;
     case FK_Wx2: return (N + 1) * 2;
+    case FK_Wx3: return (N + 1) * 3;
     case FK_2DxNT: return NT;
     case FK_WxNAT: return (N + 1) * NAT;
   }
@@ -206,6 +208,30 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     // found to differ from the checker at 1e-17 from a state of rest: refused rather than run unpinned
     set_error("options: UV_ADV, UV_VIS2 and TS_DIF2 are required (zero coefficients switch the mixing off)");
     return 5;
+  }
+  if (cfg->options & ROMS_GLS_MIXING) {     // gls_prestep.F, gls_corstep.F: one closure, one form of it, sane parameters
+    const int st = cfg->gls_flags & (ROMS_GLS_CANUTO_A | ROMS_GLS_CANUTO_B | ROMS_GLS_KANTHA_CLAYSON);
+    const int ad = cfg->gls_flags & (ROMS_GLS_K_C2ADVECTION | ROMS_GLS_K_C4ADVECTION);
+    if ((cfg->options & (ROMS_ANA_VMIX | ROMS_LMD_MIXING)) || (st & (st - 1)) || (ad & (ad - 1))) {
+      set_error("GLS_MIXING: choose one vertical closure, at most one of CANUTO_A / CANUTO_B / KANTHA_CLAYSON and at most one of K_C2ADVECTION / K_C4ADVECTION");
+      return 5;
+    }
+    if (!(cfg->gls_n != 0.0) || !(cfg->gls_cmu0 > 0.0) || !(cfg->gls_Kmin > 0.0) || !(cfg->gls_Pmin > 0.0) || !(cfg->gls_sigk > 0.0) ||
+        !(cfg->gls_sigp > 0.0)) {
+      set_error("GLS_MIXING: GLS_N must not be zero; GLS_CMU0, GLS_Kmin, GLS_Pmin, GLS_SIGK, GLS_SIGP must be positive");
+      return 5;
+    }
+    for (int e = 0; e < 4; e++) {
+      const int k = cfg->lbc_tke[e];
+      if (!(k == ROMS_LBC_DEFAULT || k == ROMS_LBC_CLO || k == ROMS_LBC_GRA || k == ROMS_LBC_PER)) {
+        set_error("LBC(isMtke): closed, gradient and periodic are built (tkebc_im.F); the radiation condition is not");
+        return 5;
+      }
+      if ((k == ROMS_LBC_PER) != (((e == ROMS_IWEST || e == ROMS_IEAST) ? cfg->EWperiodic : cfg->NSperiodic) != 0) && k != ROMS_LBC_DEFAULT) {
+        set_error("LBC(isMtke): periodic where, and only where, the direction is");
+        return 5;
+      }
+    }
   }
   if (cfg->Nghost != 2 && cfg->Nghost != 3) {
     // get_bounds.F / inp_par.F:210-216: NghostPoints is 2, or 3 with MPDATA/HSIMT; the strip buffers of
@@ -1025,7 +1051,7 @@ static unsigned group_of(const roms_hip_ctx *c, const double *p) {
       {"lrflx", FG_FLUX}, {"evap", FG_FLUX},
       {"rho", FG_RHO}, {"pden", FG_RHO}, {"rhoA", FG_RHO}, {"rhoS", FG_RHO}, {"bvf", FG_RHO}, {"alpha", FG_RHO}, {"beta", FG_RHO},
       {"Huon", FG_MF}, {"Hvom", FG_MF}, {"W", FG_W}, {"wvel", FG_WVEL},
-      {"Akv", FG_AK}, {"Akt", FG_AK}, {"ghats", FG_AK}, {"hsbl", FG_AK},
+      {"Akv", FG_AK}, {"Akt", FG_AK}, {"ghats", FG_AK}, {"hsbl", FG_AK}, {"tke", FG_AK}, {"gls", FG_AK},
       {"t", FG_T}, {"u", FG_UV}, {"v", FG_UV},
       {"zeta", FG_2D}, {"ubar", FG_2D}, {"vbar", FG_2D}, {"rzeta", FG_2D}, {"rubar", FG_2D}, {"rvbar", FG_2D},
       {"Zt_avg1", FG_AVG}, {"DU_avg1", FG_AVG}, {"DU_avg2", FG_AVG}, {"DV_avg1", FG_AVG}, {"DV_avg2", FG_AVG},
@@ -1382,6 +1408,8 @@ ENTRY(step3d_uv, 34, FG_UV | FG_MF | FG_2D | FG_AVG | FG_AK | FG_HZ | FG_R | FG_
 ENTRY(step3d_t, 35, FG_T | FG_MF | FG_W | FG_AK | FG_HZ | FG_FLUX)          // step3d_t.F:120
 ENTRY(lmd_vmix, 18, FG_AK | FG_RHO | FG_UV | FG_HZ | FG_FLUX | FG_T)        // lmd_vmix.F:45
 ENTRY(bulk_flux, 17, FG_FLUX | FG_T | FG_UV | FG_RHO | FG_HZ)               // bulk_flux.F:100
+ENTRY(gls_prestep, 18, FG_AK | FG_MF | FG_W | FG_HZ)                         // gls_prestep.F:42
+ENTRY(gls_corstep, 18, FG_AK | FG_MF | FG_W | FG_HZ | FG_UV | FG_RHO | FG_FLUX)   // gls_corstep.F:52
 
 extern "C" int roms_hip_wvelocity(roms_hip_ctx *c, int ninp) {
   RegionTimer rt(c, 12);
@@ -1463,6 +1491,7 @@ static int baro_and_corrector(roms_hip_ctx *c, int join_late = -1) {
   DO(roms_hip_set_depth(c));                                // :963
   DO(roms_hip_step3d_uv(c));                                // :990
   DO(roms_hip_omega(c));                                    // :1017
+  if (cf.options & ROMS_GLS_MIXING) DO(roms_hip_gls_corstep(c));   // :1021
   DO(roms_hip_step3d_t(c));                                 // :1045
   s.iic = s.iic + 1;                                        // :1145-1148
   s.time = s.time + cf.dt;
@@ -1606,7 +1635,7 @@ static int main3d_one(roms_hip_ctx *c) {
     static const char *elm = getenv("ROMS_HIP_LATE_MASK");
     // (prsgrd31: the late schedule relies on k_prs_grad keeping the previous ru/rv bracket for the deferred predictor)
     if (!c->has_exchange && !uvcol && (!c->G.masking || (elm && elm[0] == '1')) && !(elate && elate[0] == '0') &&
-        !(cf.options & ROMS_PRSGRD31)) return main3d_late(c, do_diag);
+        !(cf.options & (ROMS_PRSGRD31 | ROMS_GLS_MIXING))) return main3d_late(c, do_diag);   // (GLS: its two routines keep the reference's places)
   }
   DO(roms_hip_rho_eos(c));                                  // :350
   // Two independent chains follow: set_massflux (:348) -> omega (:534) -> wvelocity (:535), and the
@@ -1684,6 +1713,7 @@ static int main3d_one(roms_hip_ctx *c) {
     halo_fence(c, FG_R | FG_FLUX);
     DO(run_rufrc_sums(c));            // rufrc/rvfrc of rhs3d_tile and uv3dmix2 in one kernel
   }
+  if (cf.options & ROMS_GLS_MIXING) DO(roms_hip_gls_prestep(c));   // :636
 #undef DO
   return baro_and_corrector(c);
 }

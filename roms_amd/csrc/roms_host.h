@@ -17,7 +17,7 @@ struct FieldDesc {
 };
 
 enum { FK_2D = 0, FK_R, FK_W, FK_2Dx3, FK_2Dx2, FK_Rx2, FK_T, FK_Wx2, FK_2DxNT, FK_WxNAT, FK_TABR, FK_TABW,
-       FK_BJ, FK_BI, FK_BJN, FK_BIN, FK_BJT, FK_BIT };   // boundary lines (LBj:UBj) / (LBi:UBi) [, N [, NT]] in the caller's bounds
+       FK_BJ, FK_BI, FK_BJN, FK_BIN, FK_BJT, FK_BIT, FK_Wx3 };   // boundary lines (LBj:UBj) / (LBi:UBi) [, N [, NT]] in the caller's bounds
 
 struct Region { double seconds; long calls; };
 
@@ -210,6 +210,8 @@ int run_step3d_uv(roms_hip_ctx *c);
 int run_step3d_t(roms_hip_ctx *c);
 int run_lmd_vmix(roms_hip_ctx *c);
 int run_bulk_flux(roms_hip_ctx *c);
+int run_gls_prestep(roms_hip_ctx *c);
+int run_gls_corstep(roms_hip_ctx *c);
 int run_diag(roms_hip_ctx *c, double *out);
 int run_copy_probe(roms_hip_ctx *c, int reps);
 

@@ -12,7 +12,10 @@ SCHEMES = dict(A4=A4, C2=C2, C4=C4, HSIMT=HSIMT, MPDATA=MPDATA, SPLINES=SPLINES,
 OPTIONS = {name: 1 << k for k, name in enumerate(
     ["UV_ADV", "UV_COR", "UV_VIS2", "TS_DIF2", "MIX_GEO_TS", "CURVGRID", "NONLIN_EOS", "UV_QDRAG",
      "LMD_MIXING", "BULK_FLUXES", "SOLAR_SOURCE", "ANA_VMIX", "SALINITY", "SPHERICAL", "UV_LOGDRAG", "MASKING"])}
-OPTIONS.update(RADIATION_2D=1 << 16, PLAIN_VDIFF=1 << 17, PLAIN_VVISC=1 << 18, PRSGRD31=1 << 19, WJ_GRADP=1 << 27, APP_UPWELLING=1 << 20, APP_BENCHMARK=1 << 21, APP_KELVIN=1 << 22, APP_SEAMOUNT=1 << 23, APP_GRAV_ADJ=1 << 24)
+OPTIONS.update(RADIATION_2D=1 << 16, PLAIN_VDIFF=1 << 17, PLAIN_VVISC=1 << 18, PRSGRD31=1 << 19, WJ_GRADP=1 << 27, APP_UPWELLING=1 << 20, APP_BENCHMARK=1 << 21, APP_KELVIN=1 << 22, APP_SEAMOUNT=1 << 23, APP_GRAV_ADJ=1 << 24, GLS_MIXING=1 << 25)
+# the compile-time forms of GLS_MIXING (roms_hip_config.gls_flags)
+GLS_FLAGS = dict(CANUTO_A=1, CANUTO_B=2, KANTHA_CLAYSON=4, N2S2_HORAVG=8, RI_SPLINES=16, K_C2ADVECTION=32, K_C4ADVECTION=64,
+                 CHARNOK=128, CRAIG_BANNER=256)
 # lateral boundary conditions (include/roms_hip.h): lbc[edge][variable], ROMS_LBC_* kinds
 NLBC = 5 + MAXT
 LBC_KINDS = dict(Clo=1, Per=2, Gra=3, Cla=4, Rad=5, RadNud=6, Che=7, Cha=8, Fla=9, Shc=10)
@@ -45,6 +48,12 @@ class Config(C.Structure):
         ("FSobc_in", C.c_double * 4), ("FSobc_out", C.c_double * 4), ("M2obc_in", C.c_double * 4),
         ("M2obc_out", C.c_double * 4), ("M3obc_in", C.c_double * 4), ("M3obc_out", C.c_double * 4),
         ("Tobc_in", (C.c_double * 4) * MAXT), ("Tobc_out", (C.c_double * 4) * MAXT),
+        ("gls_flags", C.c_int),
+        ("gls_p", C.c_double), ("gls_m", C.c_double), ("gls_n", C.c_double), ("gls_Kmin", C.c_double),
+        ("gls_Pmin", C.c_double), ("gls_cmu0", C.c_double), ("gls_c1", C.c_double), ("gls_c2", C.c_double),
+        ("gls_c3m", C.c_double), ("gls_c3p", C.c_double), ("gls_sigk", C.c_double), ("gls_sigp", C.c_double),
+        ("Akk_bak", C.c_double), ("Akp_bak", C.c_double), ("Zos", C.c_double), ("charnok_alpha", C.c_double),
+        ("crgban_cw", C.c_double), ("lbc_tke", C.c_int * 4),
     ]
 
 
@@ -57,7 +66,7 @@ class Stepping(C.Structure):
 
 KERNELS = ["set_depth", "set_massflux", "rho_eos", "set_vbc", "ana_vmix", "set_data", "omega", "set_zeta",
            "ini_zeta", "ini_fields", "pre_step3d", "prsgrd", "t3dmix2", "uv3dmix2", "rhs3d_tile", "rhs3d",
-           "step2d", "step2d_pair", "step3d_uv", "step3d_t", "lmd_vmix", "bulk_flux"]
+           "step2d", "step2d_pair", "step3d_uv", "step3d_t", "lmd_vmix", "bulk_flux", "gls_prestep", "gls_corstep"]
 
 EXPORTS = ["roms_hip_create", "roms_hip_destroy", "roms_hip_last_error", "roms_hip_abi_version",
            "roms_hip_field_size", "roms_hip_upload", "roms_hip_download", "roms_hip_sync",

@@ -19,7 +19,10 @@
      &   ROMS_SALINITY = 4096, ROMS_SPHERICAL = 8192, ROMS_UV_LOGDRAG = 16384, ROMS_MASKING = 32768,                                 &
      &   ROMS_RADIATION_2D = 65536, ROMS_PLAIN_VDIFF = 131072, ROMS_PLAIN_VVISC = 262144, ROMS_PRSGRD31 = 524288, ROMS_WJ_GRADP = 134217728,                                   &
      &   ROMS_APP_UPWELLING = 1048576, ROMS_APP_BENCHMARK = 2097152, ROMS_APP_KELVIN = 4194304, ROMS_APP_SEAMOUNT = 8388608,   &
-     &   ROMS_APP_GRAV_ADJ = 16777216
+     &   ROMS_APP_GRAV_ADJ = 16777216, ROMS_GLS_MIXING = 33554432
+      integer(c_int), parameter :: ROMS_GLS_CANUTO_A = 1, ROMS_GLS_CANUTO_B = 2, ROMS_GLS_KANTHA_CLAYSON = 4,              &
+     &   ROMS_GLS_N2S2_HORAVG = 8, ROMS_GLS_RI_SPLINES = 16, ROMS_GLS_K_C2ADVECTION = 32, ROMS_GLS_K_C4ADVECTION = 64,     &
+     &   ROMS_GLS_CHARNOK = 128, ROMS_GLS_CRAIG_BANNER = 256
       integer(c_int), parameter :: ROMS_NLBC = 5+ROMS_MAXT
       integer(c_int), parameter :: ROMS_LBC_CLO = 1, ROMS_LBC_PER = 2, ROMS_LBC_GRA = 3, ROMS_LBC_CLA = 4, ROMS_LBC_RAD = 5,      &
      &   ROMS_LBC_RADNUD = 6, ROMS_LBC_CHE = 7, ROMS_LBC_CHI = 8, ROMS_LBC_FLA = 9, ROMS_LBC_SHC = 10
@@ -53,6 +56,12 @@
         integer(c_int) :: lbc(ROMS_NLBC,4)
         real(c_double) :: FSobc_in(4), FSobc_out(4), M2obc_in(4), M2obc_out(4), M3obc_in(4), M3obc_out(4)
         real(c_double) :: Tobc_in(4,ROMS_MAXT), Tobc_out(4,ROMS_MAXT)
+!  GLS_MIXING (ABI version 3): ROMS_GLS_* flags, the GLS_* block of roms.in, LBC(isMtke) per edge
+        integer(c_int) :: gls_flags
+        real(c_double) :: gls_p, gls_m, gls_n, gls_Kmin, gls_Pmin, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk,    &
+     &                    gls_sigp
+        real(c_double) :: Akk_bak, Akp_bak, Zos, charnok_alpha, crgban_cw
+        integer(c_int) :: lbc_tke(4)
       END TYPE roms_hip_config
 
       TYPE, bind(C) :: roms_hip_stepping
@@ -256,6 +265,16 @@
           TYPE (c_ptr), value :: ctx
           integer(c_int) :: ierr
         END FUNCTION
+        FUNCTION roms_hip_gls_prestep (ctx) bind(C, name='roms_hip_gls_prestep') RESULT (ierr)
+          IMPORT :: c_ptr, c_int
+          type(c_ptr), value :: ctx
+          integer(c_int) :: ierr
+        END FUNCTION roms_hip_gls_prestep
+        FUNCTION roms_hip_gls_corstep (ctx) bind(C, name='roms_hip_gls_corstep') RESULT (ierr)
+          IMPORT :: c_ptr, c_int
+          type(c_ptr), value :: ctx
+          integer(c_int) :: ierr
+        END FUNCTION roms_hip_gls_corstep
         FUNCTION roms_hip_bulk_flux (ctx) bind(C, name='roms_hip_bulk_flux') RESULT (ierr)
           IMPORT :: c_int, c_ptr
           TYPE (c_ptr), value :: ctx

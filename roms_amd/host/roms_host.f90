@@ -31,6 +31,13 @@
       real(dp) :: rdrg = 3.0E-4_dp, rdrg2 = 3.0E-3_dp, Zob = 0.02_dp, Zos = 0.02_dp, gamma2 = 1.0_dp
       real(dp) :: dstart = 0.0_dp, time_ref = 0.0_dp, blk_ZQ = 10.0_dp, blk_ZT = 10.0_dp, blk_ZW = 10.0_dp
       integer :: options = 0
+!  GLS_MIXING: the compile-time form (ROMS_GLS_* flags from the application header), the GLS_* block of roms.in
+!  (defaults: the k-epsilon column of roms_upwelling.in), LBC(isMtke) per edge (west south east north)
+      integer :: gls_flags = 0, lbc_tke(4) = 0
+      real(dp) :: gls_p = 3.0_dp, gls_m = 1.5_dp, gls_n = -1.0_dp, gls_Kmin = 7.6E-6_dp, gls_Pmin = 1.0E-12_dp
+      real(dp) :: gls_cmu0 = 0.5477_dp, gls_c1 = 1.44_dp, gls_c2 = 1.92_dp, gls_c3m = -0.4_dp, gls_c3p = 1.0_dp
+      real(dp) :: gls_sigk = 1.0_dp, gls_sigp = 1.30_dp, Akk_bak = 5.0E-6_dp, Akp_bak = 5.0E-6_dp
+      real(dp) :: charnok_alpha = 1400.0_dp, crgban_cw = 100.0_dp
 !  output (read_phypar.F: NRREC ... NHIS, the Hout switches, the file names); written by roms_output.f90
       integer :: nrrec = 0, nRST = 0, nHIS = 0
       logical :: LcycleRST = .TRUE.
@@ -233,6 +240,22 @@
           CASE ('RDRG2');       rdrg2=toreal(tok(1))
           CASE ('Zob');         Zob=toreal(tok(1))
           CASE ('Zos');         Zos=toreal(tok(1))
+          CASE ('AKK_BAK');     Akk_bak=toreal(tok(1))
+          CASE ('AKP_BAK');     Akp_bak=toreal(tok(1))
+          CASE ('GLS_P');       gls_p=toreal(tok(1))
+          CASE ('GLS_M');       gls_m=toreal(tok(1))
+          CASE ('GLS_N');       gls_n=toreal(tok(1))
+          CASE ('GLS_Kmin');    gls_Kmin=toreal(tok(1))
+          CASE ('GLS_Pmin');    gls_Pmin=toreal(tok(1))
+          CASE ('GLS_CMU0');    gls_cmu0=toreal(tok(1))
+          CASE ('GLS_C1');      gls_c1=toreal(tok(1))
+          CASE ('GLS_C2');      gls_c2=toreal(tok(1))
+          CASE ('GLS_C3M');     gls_c3m=toreal(tok(1))
+          CASE ('GLS_C3P');     gls_c3p=toreal(tok(1))
+          CASE ('GLS_SIGK');    gls_sigk=toreal(tok(1))
+          CASE ('GLS_SIGP');    gls_sigp=toreal(tok(1))
+          CASE ('CHARNOK_ALPHA'); charnok_alpha=toreal(tok(1))
+          CASE ('CRGBAN_CW');   crgban_cw=toreal(tok(1))
           CASE ('BLK_ZQ');      blk_ZQ=toreal(tok(1))
           CASE ('BLK_ZT');      blk_ZT=toreal(tok(1))
           CASE ('BLK_ZW');      blk_ZW=toreal(tok(1))
@@ -291,7 +314,7 @@
 !  Lateral boundary conditions, load_lbc (Utility/inp_decode.F:1560-1680): four keywords per variable in the order west
 !  south east north (isTvar: one set per tracer on continuation lines).  Built: Per Clo Gra Cla Rad RadNud, Che / Cha for
 !  the free surface, Fla / Shc for the 2-D momentum (the library checks the pairing); every variable must share the
-!  periodicity of the grid.  isMtke (no TKE closure here) is read and not used.
+!  periodicity of the grid.  isMtke: the turbulent fields of GLS_MIXING (closed, gradient or periodic: tkebc_im.F).
 !
       SUBROUTINE load_lbc (key, tok, nv, ierr)
       character(len=*), intent(in) :: key
@@ -340,6 +363,7 @@
           RETURN
         END IF
         IF (ivar.gt.0.and.ivar+(k-1)/4.le.ROMS_NLBC) lbc(ivar+(k-1)/4,side)=code
+        IF (key.eq.'LBC(isMtke)'.and.k.le.4) lbc_tke(side)=code
       END DO
       IF ((per(1).neqv.per(3)).or.(per(2).neqv.per(4))) THEN
         CALL unsupported (key//': a periodic edge needs its opposite edge periodic too', ierr)
@@ -367,6 +391,9 @@
       visc2=5.0_dp; tnu2=0.0_dp; Akt_bak=1.0E-6_dp; Akv_bak=1.0E-5_dp
       rdrg=3.0E-4_dp; rdrg2=3.0E-3_dp; Zob=0.02_dp; Zos=0.02_dp; gamma2=1.0_dp
       dstart=0.0_dp; time_ref=0.0_dp; blk_ZQ=10.0_dp; blk_ZT=10.0_dp; blk_ZW=10.0_dp
+      gls_flags=0; lbc_tke=0; gls_p=3.0_dp; gls_m=1.5_dp; gls_n=-1.0_dp; gls_Kmin=7.6E-6_dp; gls_Pmin=1.0E-12_dp
+      gls_cmu0=0.5477_dp; gls_c1=1.44_dp; gls_c2=1.92_dp; gls_c3m=-0.4_dp; gls_c3p=1.0_dp; gls_sigk=1.0_dp; gls_sigp=1.30_dp
+      Akk_bak=5.0E-6_dp; Akp_bak=5.0E-6_dp; charnok_alpha=1400.0_dp; crgban_cw=100.0_dp
       nrrec=0; nRST=0; nHIS=0; LcycleRST=.TRUE.; Hout=.FALSE.
       nAVG=0; ntsAVG=1; avgname='roms_avg.nc'; Aout=.FALSE.; AoutT=.FALSE.
       ininame='roms_ini.nc'; rstname='roms_rst.nc'; hisname='roms_his.nc'
@@ -758,7 +785,9 @@
           DO k=1,SIZE(flux0)
             CALL define (TRIM(flux0(k)))
           END DO
-          IF (TRIM(MyAppCPP).ne.'UPWELLING_KPP') THEN
+          IF (is_defined('GLS_MIXING')) THEN                         ! upwelling.h:57-63 (-DGLS_MIXING: ROMS_CPP_FLAGS)
+            CALL define ('KANTHA_CLAYSON'); CALL define ('N2S2_HORAVG'); CALL define ('RI_SPLINES')
+          ELSE IF (TRIM(MyAppCPP).ne.'UPWELLING_KPP') THEN
             CALL define ('ANA_VMIX')
           ELSE
             DO k=1,SIZE(kpp)
@@ -790,12 +819,12 @@
       integer :: k
       logical :: upw, bench, kelv, seam, grav
 !  options with a bit in the mask (include/roms_hip.h)
-      character(len=16), parameter :: bitname(17) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
+      character(len=16), parameter :: bitname(18) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
      &    'TS_DIF2', 'MIX_GEO_TS', 'CURVGRID', 'NONLIN_EOS', 'UV_QDRAG', 'LMD_MIXING', 'BULK_FLUXES',           &
-     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG', 'MASKING', 'RADIATION_2D' ]
-      integer, parameter :: bitval(17) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
+     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG', 'MASKING', 'RADIATION_2D', 'GLS_MIXING' ]
+      integer, parameter :: bitval(18) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
      &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
-     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D ]
+     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D, ROMS_GLS_MIXING ]
 !  options whose code is the only form built (accepted, nothing to select) or that only affect output
       character(len=16), parameter :: inherent(34) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', &
      &    'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
@@ -805,6 +834,12 @@
      &    'ANA_HUMIDITY', 'ANA_RAIN', 'ANA_CLOUD', 'ALBEDO', 'OUT_DOUBLE', 'PERFECT_RESTART', 'NONLINEAR' ]
       character(len=16), parameter :: output_only(3) = [ character(len=16) :: 'AVERAGES', 'DIAGNOSTICS_TS',      &
      &    'DIAGNOSTICS_UV' ]
+!  the compile-time forms of GLS_MIXING (gls_prestep.F, gls_corstep.F): flags of roms_hip_config%gls_flags
+      character(len=16), parameter :: glsname(9) = [ character(len=16) :: 'CANUTO_A', 'CANUTO_B', 'KANTHA_CLAYSON',  &
+     &    'N2S2_HORAVG', 'RI_SPLINES', 'K_C2ADVECTION', 'K_C4ADVECTION', 'CHARNOK', 'CRAIG_BANNER' ]
+      integer, parameter :: glsval(9) = [ ROMS_GLS_CANUTO_A, ROMS_GLS_CANUTO_B, ROMS_GLS_KANTHA_CLAYSON,              &
+     &    ROMS_GLS_N2S2_HORAVG, ROMS_GLS_RI_SPLINES, ROMS_GLS_K_C2ADVECTION, ROMS_GLS_K_C4ADVECTION,                  &
+     &    ROMS_GLS_CHARNOK, ROMS_GLS_CRAIG_BANNER ]
       IF (ierr.ne.0) RETURN
       upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
      &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING')
@@ -817,6 +852,7 @@
      &                    'exist for UPWELLING, BENCHMARK, KELVIN, SEAMOUNT and GRAV_ADJ', ierr)
         RETURN
       END IF
+      gls_flags=0
       IF (upw) options=ROMS_APP_UPWELLING
       IF (bench) options=ROMS_APP_BENCHMARK
       IF (kelv) options=ROMS_APP_KELVIN
@@ -825,6 +861,8 @@
       DO k=1,ndefs
         IF (ANY(bitname.eq.defs(k))) THEN
           options=IOR(options, bitval(FINDLOC(bitname, defs(k), 1)))
+        ELSE IF (ANY(glsname.eq.defs(k)).and.(is_defined('GLS_MIXING').or.TRIM(defs(k)).eq.'RI_SPLINES')) THEN
+          IF (is_defined('GLS_MIXING')) gls_flags=IOR(gls_flags, glsval(FINDLOC(glsname, defs(k), 1)))
         ELSE IF (ANY(inherent.eq.defs(k)).or.ANY(output_only.eq.defs(k))) THEN
           CONTINUE
         ELSE IF (TRIM(defs(k)).eq.'UPWELLING'.or.TRIM(defs(k)).eq.'BENCHMARK'.or.TRIM(defs(k)).eq.'KELVIN'.or.            &
@@ -861,11 +899,22 @@
       IF (.not.is_defined('SPLINES_VVISC')) options=IOR(options, ROMS_PLAIN_VVISC)
       IF (.not.is_defined('SPLINES_VDIFF').and.ANY(hadv(1:NAT).eq.ROMS_MPDATA))                                &
      &  CALL unsupported ('MPDATA is built with SPLINES_VDIFF only', ierr)
-      IF (is_defined('ANA_VMIX').and.is_defined('LMD_MIXING'))                                                 &
-     &  CALL unsupported ('at most one vertical mixing closure: ANA_VMIX or LMD_MIXING (neither: the background '//   &
-     &                    'coefficients AKV_BAK, AKT_BAK, as in KELVIN)', ierr)
-      IF (.not.(kelv.or.seam.or.grav).and..not.(is_defined('ANA_VMIX').or.is_defined('LMD_MIXING')))            &
-     &  CALL unsupported ('a vertical mixing closure is required: ANA_VMIX or LMD_MIXING', ierr)
+      IF (COUNT((/ is_defined('ANA_VMIX'), is_defined('LMD_MIXING'), is_defined('GLS_MIXING') /)).gt.1)         &
+     &  CALL unsupported ('at most one vertical mixing closure: ANA_VMIX, LMD_MIXING or GLS_MIXING (none: the '//      &
+     &                    'background coefficients AKV_BAK, AKT_BAK, as in KELVIN)', ierr)
+      IF (.not.(kelv.or.seam.or.grav).and..not.(is_defined('ANA_VMIX').or.is_defined('LMD_MIXING').or.           &
+     &    is_defined('GLS_MIXING')))                                                                            &
+     &  CALL unsupported ('a vertical mixing closure is required: ANA_VMIX, LMD_MIXING or GLS_MIXING', ierr)
+!  GLS_MIXING: the stability functions, the smoothing, the shear form, the advection of the turbulent fields and the two
+!  surface-flux options are run-time flags of the library; the wave-dependent forms and the limiters are not built
+      IF (is_defined('GLS_MIXING').and.(is_defined('ZOS_HSIG').or.is_defined('TKE_WAVEDISS').or.                 &
+     &    is_defined('LIMIT_VDIFF').or.is_defined('LIMIT_VVISC')))                                              &
+     &  CALL unsupported ('GLS_MIXING: ZOS_HSIG, TKE_WAVEDISS (wave fields) and LIMIT_VDIFF / LIMIT_VVISC are not built', ierr)
+      IF (is_defined('GLS_MIXING').and.COUNT((/ is_defined('CANUTO_A'), is_defined('CANUTO_B'),                  &
+     &    is_defined('KANTHA_CLAYSON') /)).gt.1)                                                                &
+     &  CALL unsupported ('GLS_MIXING: at most one of CANUTO_A, CANUTO_B, KANTHA_CLAYSON (none: Galperin)', ierr)
+      IF (is_defined('GLS_MIXING').and.is_defined('K_C2ADVECTION').and.is_defined('K_C4ADVECTION'))              &
+     &  CALL unsupported ('GLS_MIXING: at most one of K_C2ADVECTION, K_C4ADVECTION', ierr)
       IF ((is_defined('ANA_FSOBC').or.is_defined('ANA_M2OBC')).and..not.kelv)                                   &
      &  CALL unsupported ('ANA_FSOBC / ANA_M2OBC (analytic boundary data) are built for KELVIN only', ierr)
       IF (is_defined('LMD_MIXING').and..not.(is_defined('LMD_RIMIX').and.is_defined('LMD_CONVEC').and.          &
@@ -914,11 +963,22 @@
 
       SUBROUTINE set_cppdefs (ierr)
       integer, intent(out) :: ierr
-      integer :: L
+      integer :: L, k, nf
+      character(len=512) :: flags
+      character(len=64) :: ftok(16)
       ierr=0
       ndefs=0
       IF (LEN_TRIM(app_header).eq.0) THEN
         CALL GET_ENVIRONMENT_VARIABLE ('ROMS_APP_HEADER', app_header, L)
+      END IF
+!  options given on the compiler command line of a reference build (MY_CPP_FLAGS of its build script, e.g. "-DGLS_MIXING"
+!  to switch the closure of upwelling.h): ROMS_CPP_FLAGS, defined before the header is read
+      CALL GET_ENVIRONMENT_VARIABLE ('ROMS_CPP_FLAGS', flags, L)
+      IF (L.gt.0) THEN
+        CALL split (flags, ftok, nf)
+        DO k=1,nf
+          IF (ftok(k)(1:2).eq.'-D'.and.LEN_TRIM(ftok(k)).gt.2) CALL define (TRIM(ftok(k)(3:)))
+        END DO
       END IF
       IF (LEN_TRIM(app_header).gt.0) THEN
         CALL read_app_header (TRIM(app_header), ierr)
@@ -1639,6 +1699,7 @@
       TYPE (roms_hip_config) :: cfg
       integer :: i, itile, jtile, chunk, margin
       logical :: tw, te, ts, tn
+      real(r8), allocatable :: gw(:,:,:)
       ierr=0
       IF (tile.lt.0.or.tile.ge.NtileI*NtileJ) THEN
         ierr=5
@@ -1670,7 +1731,7 @@
       tUBi=MERGE(UBi, tIend+Nghost, te)
       tLBj=MERGE(LBj, tJstr-1-Nghost, ts)
       tUBj=MERGE(UBj, tJend+Nghost, tn)
-      cfg%abi_version=2
+      cfg%abi_version=3
       cfg%device=device
       cfg%Lm=Lm; cfg%Mm=Mm; cfg%N=N; cfg%NT=NT; cfg%NAT=NAT; cfg%Nghost=Nghost
       cfg%LBi=tLBi; cfg%UBi=tUBi; cfg%LBj=tLBj; cfg%UBj=tUBj
@@ -1695,6 +1756,11 @@
       cfg%Akt_bak=Akt_bak; cfg%Akv_bak=Akv_bak
       cfg%dstart=dstart
       cfg%blk_ZQ=blk_ZQ; cfg%blk_ZT=blk_ZT; cfg%blk_ZW=blk_ZW; cfg%lmd_Jwt=lmd_Jwt
+      cfg%gls_flags=gls_flags; cfg%lbc_tke=lbc_tke
+      cfg%gls_p=gls_p; cfg%gls_m=gls_m; cfg%gls_n=gls_n; cfg%gls_Kmin=gls_Kmin; cfg%gls_Pmin=gls_Pmin
+      cfg%gls_cmu0=gls_cmu0; cfg%gls_c1=gls_c1; cfg%gls_c2=gls_c2; cfg%gls_c3m=gls_c3m; cfg%gls_c3p=gls_c3p
+      cfg%gls_sigk=gls_sigk; cfg%gls_sigp=gls_sigp; cfg%Akk_bak=Akk_bak; cfg%Akp_bak=Akp_bak
+      cfg%Zos=Zos; cfg%charnok_alpha=charnok_alpha; cfg%crgban_cw=crgban_cw
       cfg%sc_r=0.0_dp; cfg%Cs_r=0.0_dp; cfg%sc_w=0.0_dp; cfg%Cs_w=0.0_dp
       CALL boundary_config (cfg)
       cfg%sc_r(1:N)=sc_r; cfg%Cs_r(1:N)=Cs_r; cfg%sc_w(0:N)=sc_w; cfg%Cs_w(0:N)=Cs_w
@@ -1727,6 +1793,20 @@
       CALL up ('zeta', zeta, 3, ierr); CALL up ('ubar', ubar, 3, ierr); CALL up ('vbar', vbar, 3, ierr)
       CALL up ('u', u, 2*N, ierr); CALL up ('v', v, 2*N, ierr); CALL up ('t', t, 3*N*NT, ierr)
       CALL up ('Akv', Akv, N+1, ierr); CALL up ('Akt', Akt, (N+1)*NAT, ierr)
+      IF (IAND(options,ROMS_GLS_MIXING).ne.0) THEN       ! initialize_mixing, mod_mixing.F:1490-1515
+        allocate ( gw(LBi:UBi,LBj:UBj,3*(N+1)) )
+        gw=gls_Kmin
+        CALL up ('tke', gw, 3*(N+1), ierr)
+        gw=gls_Pmin
+        CALL up ('gls', gw, 3*(N+1), ierr)
+        gw=0.0_r8
+        CALL up ('Lscale', gw(:,:,1:N+1), N+1, ierr)
+        gw(:,:,2:N)=Akk_bak
+        CALL up ('Akk', gw(:,:,1:N+1), N+1, ierr)
+        gw(:,:,2:N)=Akp_bak
+        CALL up ('Akp', gw(:,:,1:N+1), N+1, ierr)
+        deallocate ( gw )
+      END IF
       END SUBROUTINE device_init
 !
 !  Upload the tile's window (tLBi:tUBi,tLBj:tUBj) of a host array with np horizontal planes.
@@ -1805,6 +1885,8 @@
         ierr=roms_hip_set_zeta(ctx);                      IF (ierr.ne.0) RETURN
         ierr=roms_hip_set_avg(ctx);                       IF (ierr.ne.0) RETURN      ! :562 (AVERAGES; no-op when off)
         ierr=roms_hip_rhs3d(ctx);                         IF (ierr.ne.0) RETURN
+        IF (IAND(options,ROMS_GLS_MIXING).ne.0) ierr=roms_hip_gls_prestep(ctx)         ! :636
+        IF (ierr.ne.0) RETURN
         DO my_iif=1,nfast+1                                ! LF-AM3 barotropic loop :810-918
           next_indx1=3-step%indx1
           IF (step%predictor.eq.0) THEN
@@ -1835,6 +1917,8 @@
         ierr=roms_hip_set_depth(ctx);                     IF (ierr.ne.0) RETURN
         ierr=roms_hip_step3d_uv(ctx);                     IF (ierr.ne.0) RETURN
         ierr=roms_hip_omega(ctx);                         IF (ierr.ne.0) RETURN
+        IF (IAND(options,ROMS_GLS_MIXING).ne.0) ierr=roms_hip_gls_corstep(ctx)         ! :1021
+        IF (ierr.ne.0) RETURN
         ierr=roms_hip_step3d_t(ctx);                      IF (ierr.ne.0) RETURN
         step%iic=step%iic+1
         step%time=step%time+dt

@@ -63,7 +63,7 @@ def write_roms_in(path, p):
     per = lambda f: "Per" if f else "Clo"
     lines = [
         # (kelvin: ROMS/Include/kelvin.h when the case asks for the plain vertical solvers, else oracle/ref/kelvin_splines.h)
-        f"    MyAppCPP = {('KELVIN' if 'PLAIN_VDIFF' in p.get('options', ()) else 'KELVIN_SPLINES') if p['app'] == 'kelvin' else p['app'].upper()}",
+        f"    MyAppCPP = {('KELVIN' if 'PLAIN_VDIFF' in p.get('options', ()) else 'KELVIN_SPLINES') if p['app'] == 'kelvin' else ('UPWELLING' if p['app'].startswith('upwelling_gls') else p['app'].upper())}",
         f"         NAT =  {p.get('NAT', 2)}",
         f"          Lm == {p['Lm']}", f"          Mm == {p['Mm']}", f"           N == {p['N']}",
         f"      NtileI == {p.get('NtileI', 1)}", f"      NtileJ == {p.get('NtileJ', 1)}",
@@ -98,6 +98,12 @@ def write_roms_in(path, p):
         f"       TCOEF == {d(p['Tcoef'])}", f"       SCOEF == {d(p['Scoef'])}",
         f"      GAMMA2 == {d(p['gamma2'])}",
     ]
+    if "gls_flags" in p:       # the generic length-scale closure: its roms.in block (the cpp form comes from the header / ROMS_CPP_FLAGS)
+        for key, name in (("Akk_bak", "AKK_BAK"), ("Akp_bak", "AKP_BAK"), ("gls_p", "GLS_P"), ("gls_m", "GLS_M"), ("gls_n", "GLS_N"),
+                          ("gls_Kmin", "GLS_Kmin"), ("gls_Pmin", "GLS_Pmin"), ("gls_cmu0", "GLS_CMU0"), ("gls_c1", "GLS_C1"),
+                          ("gls_c2", "GLS_C2"), ("gls_c3m", "GLS_C3M"), ("gls_c3p", "GLS_C3P"), ("gls_sigk", "GLS_SIGK"),
+                          ("gls_sigp", "GLS_SIGP"), ("charnok_alpha", "CHARNOK_ALPHA"), ("crgban_cw", "CRGBAN_CW")):
+            lines.append(f"{name:>14} == {d(p[key])}")
     # output (optional keys): NRREC, NRST, NHIS, LcycleRST, file names, Hout switches by their roms.in ids
     for key in ("NRREC", "NRST", "NHIS", "NAVG", "NTSAVG"):
         if key in p:

@@ -702,6 +702,36 @@ def test_more_reference_applications_match_oracle(tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["upwelling_gls_small", "upwelling_gls_small:k-omega", "upwelling_gls_ca_small:gen",
+                                 "upwelling_gls_cb_small:k-kl", "upwelling_gls_gal_small:k-omega"])
+def test_generic_length_scale_closure_matches_oracle(tag):
+    """GLS_MIXING on the GPU (k_gls.h) in the five forms the oracle is pinned in (tests/test_oracle_vs_ref.py: whole runs
+    of the reference built from upwelling.h -DGLS_MIXING and from oracle/ref/upwelling_gls_*.h, bit for bit): 60 steps.
+    The closure raises its variables to real powers (`pow`: the device's and libm's differ in the last bits) and clips
+    them, so the turbulent fields are held to 1e-8, the right-hand sides (differences of large terms) to 1e-9 and the
+    circulation itself to the north-star tolerance 1e-10; the closure is active."""
+    cs = util.case_for(tag)
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    if "MASKING" in cs["options"]:
+        g = util.with_masks(cs, g)
+    g = util.with_gls(cs, g)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g)
+    O.start()
+    H.start()
+    O.main3d_step(60)
+    H.main3d(60)
+    turb = ("tke", "gls", "Lscale", "Akk", "Akp", "Akv", "Akt")
+    rhs = ("rzeta", "rubar", "rvbar", "ru", "rv", "rufrc", "rvfrc")
+    for n in util.PROGNOSTIC:
+        a, b = H.download(n), O.field(n)
+        assert np.isfinite(a).all(), n
+        assert util.relrms(a, b) <= (1e-8 if n in turb else (1e-9 if n in rhs else 1e-10)), (n, util.relrms(a, b))
+    assert O.field("Akv").max() > 2 * cs["Akv_bak"] and np.abs(O.field("u")).max() > 1e-3
+    H.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["kelvin", "plain", "mixed", "four"])
 def test_open_boundaries_match_oracle(variant):
     """Open boundaries on the GPU (k_obc.h): the reference's KELVIN application -- Chapman / Flather west, radiation east,

@@ -363,3 +363,64 @@ def test_standard_density_jacobian_bitwise(emu, tag):
             assert np.array_equal(H.download(n), O.field(n)), n
     assert not np.array_equal(O.field("u"), O32.field("u"))
     H.close()
+
+
+GLS_TAGS = ["upwelling_gls_small", "upwelling_gls_small:k-omega", "upwelling_gls_ca_small:gen", "upwelling_gls_cb_small:k-kl",
+            "upwelling_gls_gal_small:k-omega"]
+
+
+@pytest.mark.parametrize("tag", GLS_TAGS)
+def test_generic_length_scale_closure_bitwise(emu, tag):
+    """GLS_MIXING (k_gls.h: gls_prestep.F, gls_corstep.F, tkebc_im.F) in its five pinned forms -- Kantha-Clayson (upwelling.h
+    with -DGLS_MIXING; k-epsilon and k-omega parameters), Canuto A under MASKING ("gen"), Canuto B with K_C2ADVECTION,
+    CHARNOK and CRAIG_BANNER (k-kl: the wall function), Galperin with K_C4ADVECTION: 12 steps against the oracle, every
+    array bit for bit (the emulated build calls the same libm `pow` as the oracle); the closure is active (Akv leaves
+    its background value)."""
+    cs = util.case_for(tag)
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    if "MASKING" in cs["options"]:
+        g = util.with_masks(cs, g)
+    g = util.with_gls(cs, g)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start(); H.start()
+    for _ in range(12):
+        O.main3d_step(); H.main3d(1)
+        for n in util.PROGNOSTIC:
+            a, b = H.download(n), O.field(n)
+            assert np.isfinite(b).all(), n
+            assert np.array_equal(a, b), (n, int(np.count_nonzero(a != b)), float(np.abs(a - b).max()))
+    assert O.field("Akv").max() > 2 * cs["Akv_bak"]
+    H.close()
+
+
+@pytest.mark.parametrize("tag", GLS_TAGS)
+def test_generic_length_scale_closure_through_the_fortran_host(emu, tag, monkeypatch):
+    """roms.in (the GLS_* block, AKK_BAK, AKP_BAK, CHARNOK_ALPHA, CRGBAN_CW, LBC(isMtke)) and the application header ->
+    Fortran host (option surface, initialize_mixing's values for tke, gls, Akk, Akp, Lscale) -> C ABI -> kernels: the
+    oracle's bits after 8 steps.  The shipped upwelling.h form is selected as a user of the reference does, by -DGLS_MIXING
+    on the cpp command line (ROMS_CPP_FLAGS, with the built-in UPWELLING list); the others by their headers under
+    oracle/ref/; the kernel-by-kernel sequence (main3d_kernels: gls_prestep behind rhs3d, gls_corstep behind omega) gives
+    the same bits as the fused entry."""
+    from roms_amd import hostlib
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cs = util.case_for(tag)
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    if "MASKING" in cs["options"]:
+        g = util.with_masks(cs, g)
+    O = util.make_oracle(cs, util.with_gls(cs, g))
+    O.start()
+    O.main3d_step(8)
+    header = None
+    if cs["app"] == "upwelling_gls":
+        monkeypatch.setenv("ROMS_CPP_FLAGS", "-DGLS_MIXING")
+    else:
+        header = os.path.join(root, "oracle", "ref", cs["app"] + ".h")
+    for kernels in (False, True):
+        H = hostlib.Host(params=dict(cs, ninfo=0), lib_path=os.path.join(os.path.dirname(emu), "libroms_host_emu.so"),
+                         hip_lib_path=emu, header=header)
+        ctx = H.device_init()
+        H.run(8, kernels=kernels)
+        for n in ("zeta", "u", "v", "t", "Akv", "Akt", "tke", "gls", "Lscale", "Akk", "Akp"):
+            assert np.array_equal(ctx.download(n), O.field(n)), (n, kernels)
+        H.finalize()

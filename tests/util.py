@@ -88,9 +88,31 @@ def case_for(tag, **kw):
         return cases.kelvin(Lm=16, Mm=12, N=6, plain=True, **kw)
     if tag == "kelvin_plain":
         return cases.kelvin(plain=True, **kw)
+    if tag.startswith("upwelling_gls"):
+        # upwelling_gls[_ca|_cb|_gal]_small[:closure]: the compile-time forms of GLS_MIXING (cases.GLS_FORMS) on the small grid
+        name, _, closure = tag.partition(":")
+        form = name[:-len("_small")]
+        return cases.upwelling_gls(form=form, closure=closure or "k-epsilon", Lm=14, Mm=18, N=8, **kw)
     if tag == "upwelling_logdrag_small":
         return cases.upwelling_logdrag(Lm=14, Mm=18, N=8, **kw)
     raise KeyError(tag)
+
+
+def with_gls(cs, g):
+    """the initial state `g` with the arrays of the generic length-scale closure as initialize_mixing leaves them
+    (mod_mixing.F:1490-1515): tke = GLS_Kmin, gls = GLS_Pmin on all three time levels, Lscale = 0, Akk = AKK_BAK and
+    Akp = AKP_BAK inside the column, zero at its ends"""
+    g = dict(g)
+    LBi, UBi, LBj, UBj = [int(x) for x in g["bounds"][:4]]
+    nij, N = (UBi - LBi + 1) * (UBj - LBj + 1), cs["N"]
+    g["tke"] = np.full(nij * (N + 1) * 3, cs["gls_Kmin"])
+    g["gls"] = np.full(nij * (N + 1) * 3, cs["gls_Pmin"])
+    g["Lscale"] = np.zeros(nij * (N + 1))
+    for n, v in (("Akk", cs["Akk_bak"]), ("Akp", cs["Akp_bak"])):
+        a = np.full((N + 1, nij), v)
+        a[0] = a[N] = 0.0
+        g[n] = a.ravel()
+    return g
 
 
 def make_oracle(cs, g):

@@ -21,7 +21,8 @@ REF = "/root/reference/ROMS/Utility/read_phypar.F"
 HONOURED = """TITLE MyAppCPP Lm Mm N NAT NtileI NtileJ NTIMES DT NDTFAST NINFO Hadvection Vadvection NRREC LcycleRST NRST NHIS
 ININAME RSTNAME HISNAME NAVG NTSAVG AVGNAME TNU2 VISC2 AKT_BAK AKV_BAK RDRG RDRG2 Zob Zos BLK_ZQ BLK_ZT BLK_ZW WTYPE
 Vtransform Vstretching THETA_S THETA_B TCLINE RHO0 DSTART TIME_REF R0 T0 S0 TCOEF SCOEF GAMMA2
-TNUDG ZNUDG M2NUDG M3NUDG OBCFAC""".split()
+TNUDG ZNUDG M2NUDG M3NUDG OBCFAC
+AKK_BAK AKP_BAK GLS_P GLS_M GLS_N GLS_Kmin GLS_Pmin GLS_CMU0 GLS_C1 GLS_C2 GLS_C3M GLS_C3P GLS_SIGK GLS_SIGP CHARNOK_ALPHA CRGBAN_CW""".split()
 HONOURED += ["LBC(isFsur)", "LBC(isUbar)", "LBC(isVbar)", "LBC(isUvel)", "LBC(isVvel)", "LBC(isMtke)", "LBC(isTvar)"]
 HONOURED_PREFIX = ["Aout(", "Hout("]        # the switches the averages / history writers know; the others are inert (below)
 HONOURED_AOUT = "idFsur idUbar idVbar idUvel idVvel idOvel idWvel idDano idTvar idZZav idU2av idV2av idUUav idVVav idUVav idHUav idHVav idTTav idUTav idVTav iHUTav iHVTav".split()
@@ -45,13 +46,14 @@ INERT_RULES = [   # (regex, why)
     (r"^PIO_|^NC_", "parallel / compressed NetCDF I-O settings"),
     (r"^(NDEF|LDEFOUT|NDIA|NSTA|NFLT|NQCK|NXTR|NTSDIA|ExtractFlag|NBCFILES|NCLMFILES|NFFILES|NUSER|USER|TITLE|VARNAME)", "output frequency / bookkeeping"),
     (r"^ad_|^(NADJ|NTLM|NSFF|NOBC|Nouter|Ninner|Nintervals|Nsaddle|NEV|NCV|Ritz_tol|MaxIterGST|LmultiGST|LrstGST|NGST|LcycleADJ|LcycleTLM|NTIMES_ANA|NTIMES_FCT|ERstr|ERend|DstrS|DendS|KstrS|KendS)$|^(Lstate|Fstate|SO_sdev|SO_decay)", "adjoint / tangent linear / 4D-Var / stability drivers: not the nonlinear forward step"),
-    (r"^GLS_|^(AKK_BAK|AKP_BAK|TKENU2|TKENU4|CHARNOK_ALPHA|ZOS_HSIG_ALPHA|SZ_ALPHA|CRGBAN_CW|WEC_ALPHA|AKT_LIMIT|AKV_LIMIT|BVF_BAK)$", "parameters of closures the library does not carry (GLS_MIXING, MY25_MIXING, BVF_MIXING, WEC): a header defining one is stopped (exit_flag 5)"),
+    (r"^(TKENU2|TKENU4)$", "lateral mixing of the turbulent fields: no code of gls_prestep.F / gls_corstep.F reads them"),
+    (r"^(ZOS_HSIG_ALPHA|SZ_ALPHA|WEC_ALPHA|AKT_LIMIT|AKV_LIMIT|BVF_BAK)$", "parameters of options the library does not carry (ZOS_HSIG, TKE_WAVEDISS, WEC, LIMIT_VDIFF / LIMIT_VVISC, BVF_MIXING): a header defining one is stopped (exit_flag 5)"),
     (r"^(TNU4|VISC4)$", "biharmonic mixing coefficients: read only under TS_DIF4 / UV_VIS4, which the header reader stops"),
     (r"^(DCRIT)$", "wetting and drying depth: WET_DRY is stopped by the header reader"),
     (r"^(LEVSFRC|LEVBFRC)$", "BODYFORCE levels: BODYFORCE is stopped by the header reader"),
     (r"^(Lnodal|TIDE_START)$", "tidal forcing: not built (SSH_TIDES / UV_TIDES stopped by the header reader)"),
     (r"^(Nbed)$", "sediment bed layers: SEDIMENT is not built"),
-    (r"^LBC\(", "boundary conditions of variables this build does not step (TKE of GLS/MY25, Stokes drift, ...)"),
+    (r"^LBC\(", "boundary conditions of variables this build does not step (Stokes drift, ...)"),
     (r"^ad_LBC\(|^ad_VolCons\(", "adjoint boundary conditions"),
 ]
 
