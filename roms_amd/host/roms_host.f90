@@ -778,7 +778,18 @@
       END IF
       CALL define ('ANA_INITIAL'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
       SELECT CASE (TRIM(MyAppCPP))
-        CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK')   ! (oracle/ref/upwelling_logdrag.h, _mask.h)
+        CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK',  &  ! (oracle/ref/upwelling_logdrag.h, _mask.h)
+     &        'UPWELLING_GLS', 'UPWELLING_GLS_CA', 'UPWELLING_GLS_CB', 'UPWELLING_GLS_GAL')
+!  UPWELLING_GLS = upwelling.h built with -DGLS_MIXING; _CA, _CB, _GAL = oracle/ref/upwelling_gls_ca.h, _cb.h, _gal.h: the
+!  other compile-time forms of the closure the library is pinned in
+          IF (MyAppCPP(1:13).eq.'UPWELLING_GLS') CALL define ('GLS_MIXING')
+          IF (TRIM(MyAppCPP).eq.'UPWELLING_GLS_CA') THEN
+            CALL define ('MASKING'); CALL define ('CANUTO_A'); CALL define ('N2S2_HORAVG'); CALL define ('RI_SPLINES')
+          ELSE IF (TRIM(MyAppCPP).eq.'UPWELLING_GLS_CB') THEN
+            CALL define ('CANUTO_B'); CALL define ('K_C2ADVECTION'); CALL define ('CHARNOK'); CALL define ('CRAIG_BANNER')
+          ELSE IF (TRIM(MyAppCPP).eq.'UPWELLING_GLS_GAL') THEN
+            CALL define ('K_C4ADVECTION'); CALL define ('RI_SPLINES')
+          END IF
           IF (TRIM(MyAppCPP).eq.'UPWELLING_MASK') CALL define ('MASKING')
           CALL define (TRIM(MERGE('UV_LOGDRAG', 'UV_LDRAG  ', TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG')))
           CALL define ('MIX_S_TS')
@@ -786,7 +797,9 @@
             CALL define (TRIM(flux0(k)))
           END DO
           IF (is_defined('GLS_MIXING')) THEN                         ! upwelling.h:57-63 (-DGLS_MIXING: ROMS_CPP_FLAGS)
-            CALL define ('KANTHA_CLAYSON'); CALL define ('N2S2_HORAVG'); CALL define ('RI_SPLINES')
+            IF (TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_GLS') THEN
+              CALL define ('KANTHA_CLAYSON'); CALL define ('N2S2_HORAVG'); CALL define ('RI_SPLINES')
+            END IF
           ELSE IF (TRIM(MyAppCPP).ne.'UPWELLING_KPP') THEN
             CALL define ('ANA_VMIX')
           ELSE
@@ -842,7 +855,8 @@
      &    ROMS_GLS_CHARNOK, ROMS_GLS_CRAIG_BANNER ]
       IF (ierr.ne.0) RETURN
       upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
-     &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING')
+     &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING').or.    &
+     &    MyAppCPP(1:13).eq.'UPWELLING_GLS'
       bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.TRIM(MyAppCPP).eq.'BENCHMARK_MASK'.or.is_defined('BENCHMARK')
       kelv=TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES'.or.is_defined('KELVIN')
       seam=TRIM(MyAppCPP).eq.'SEAMOUNT'.or.is_defined('SEAMOUNT')

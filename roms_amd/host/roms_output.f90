@@ -708,6 +708,19 @@
      &     'meter2 second-1', 'AKs', gW3, -1_c_int, idSdif)
       IF (lmd.and.(rst.or.Hout(idHsbl))) CALL fdef ('Hsbl', 'ocean_surface_boundary_layer_thickness',                &
      &     'depth of oceanic surface boundary layer', 'meter', 'SBL thickness', gR2, -1_c_int, idHsbl)
+!  GLS_MIXING: the closure's state (def_rst.F under PERFECT_RESTART: idMtke, idMtls with their three time levels;
+!  idVmLS, idVmKK, idVmKP), names and attributes of varinfo.yaml
+      IF (rst.and.IAND(options,ROMS_GLS_MIXING).ne.0) THEN
+        CALL fdef ('tke', 'specific_turbulent_kinetic_energy_of_sea_water', 'turbulent kinetic energy',              &
+     &             'meter2 second-2', 'TKE', gW3, three, 20)
+        CALL fdef ('gls', ' ', 'turbulent generic length scale', 'meter3 second-2', 'GLS', gW3, three, 21)
+        CALL fdef ('Lscale', 'turbulent_mixing_length_of_sea_water', 'vertical mixing turbulent length scale',       &
+     &             'meter', 'Lscale', gW3, -1_c_int, 22)
+        CALL fdef ('AKk', ' ', 'turbulent kinetic energy vertical diffusion coefficient', 'meter2 second-1', 'AKk',  &
+     &             gW3, -1_c_int, 23)
+        CALL fdef ('AKp', ' ', 'turbulent generic statistical field vertical diffusion coefficient',                &
+     &             'meter2 second-1', 'AKp', gW3, -1_c_int, 24)
+      END IF
       END IF
       IF (ierr.eq.0.and.master()) THEN
         IF (nc3_enddef(o%h).ne.0) ierr=3
@@ -846,6 +859,20 @@
         allocate ( A(LBi:UBi,LBj:UBj,1) )
         CALL fetch ('hsbl', 1, A, ierr)
         CALL put_field (o%h, o%v_fld(idHsbl), rec, gR2, A, 1, 1, 1, ierr)
+        deallocate ( A )
+      END IF
+      IF (rst.and.o%v_fld(20).ge.0) THEN                  ! GLS_MIXING
+        allocate ( A(LBi:UBi,LBj:UBj,3*(N+1)) )
+        CALL fetch ('tke', 3*(N+1), A, ierr)
+        CALL put_field (o%h, o%v_fld(20), rec, gW3, A, 3*(N+1), 1, 3*(N+1), ierr)
+        CALL fetch ('gls', 3*(N+1), A, ierr)
+        CALL put_field (o%h, o%v_fld(21), rec, gW3, A, 3*(N+1), 1, 3*(N+1), ierr)
+        CALL fetch ('Lscale', N+1, A(:,:,1:N+1), ierr)
+        CALL put_field (o%h, o%v_fld(22), rec, gW3, A(:,:,1:N+1), N+1, 1, N+1, ierr)
+        CALL fetch ('Akk', N+1, A(:,:,1:N+1), ierr)
+        CALL put_field (o%h, o%v_fld(23), rec, gW3, A(:,:,1:N+1), N+1, 1, N+1, ierr)
+        CALL fetch ('Akp', N+1, A(:,:,1:N+1), ierr)
+        CALL put_field (o%h, o%v_fld(24), rec, gW3, A(:,:,1:N+1), N+1, 1, N+1, ierr)
         deallocate ( A )
       END IF
       END IF
@@ -1120,6 +1147,15 @@
       IF (lmd) THEN
         allocate ( A(LBi:UBi,LBj:UBj,1) )
         CALL rd ('Hsbl', gR2, 1, A); CALL up ('hsbl', A, 1, ierr)
+        deallocate ( A )
+      END IF
+      IF (IAND(options,ROMS_GLS_MIXING).ne.0) THEN
+        allocate ( A(LBi:UBi,LBj:UBj,3*(N+1)) )
+        CALL rd ('tke', gW3, 3*(N+1), A); CALL up ('tke', A, 3*(N+1), ierr)
+        CALL rd ('gls', gW3, 3*(N+1), A); CALL up ('gls', A, 3*(N+1), ierr)
+        CALL rd ('Lscale', gW3, N+1, A(:,:,1:N+1)); CALL up ('Lscale', A(:,:,1:N+1), N+1, ierr)
+        CALL rd ('AKk', gW3, N+1, A(:,:,1:N+1)); CALL up ('Akk', A(:,:,1:N+1), N+1, ierr)
+        CALL rd ('AKp', gW3, N+1, A(:,:,1:N+1)); CALL up ('Akp', A(:,:,1:N+1), N+1, ierr)
         deallocate ( A )
       END IF
       k=nc3_close(h)

@@ -63,7 +63,7 @@ def write_roms_in(path, p):
     per = lambda f: "Per" if f else "Clo"
     lines = [
         # (kelvin: ROMS/Include/kelvin.h when the case asks for the plain vertical solvers, else oracle/ref/kelvin_splines.h)
-        f"    MyAppCPP = {('KELVIN' if 'PLAIN_VDIFF' in p.get('options', ()) else 'KELVIN_SPLINES') if p['app'] == 'kelvin' else ('UPWELLING' if p['app'].startswith('upwelling_gls') else p['app'].upper())}",
+        f"    MyAppCPP = {('KELVIN' if 'PLAIN_VDIFF' in p.get('options', ()) else 'KELVIN_SPLINES') if p['app'] == 'kelvin' else p['app'].upper()}",
         f"         NAT =  {p.get('NAT', 2)}",
         f"          Lm == {p['Lm']}", f"          Mm == {p['Mm']}", f"           N == {p['N']}",
         f"      NtileI == {p.get('NtileI', 1)}", f"      NtileJ == {p.get('NtileJ', 1)}",

@@ -98,7 +98,8 @@ def make_bounds():
 
 KEEP = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "wvel", "Hz", "z_r", "z_w", "Huon", "Hvom", "rho", "ru", "rv",
         "Zt_avg1", "DU_avg1", "DV_avg1", "DU_avg2", "DV_avg2", "rufrc", "rvfrc", "rzeta", "rubar", "rvbar",
-        "Akv", "Akt", "hsbl", "ghats", "stflx", "sustr", "svstr", "bustr", "bvstr", "srflx", "bvf"]
+        "Akv", "Akt", "hsbl", "ghats", "stflx", "sustr", "svstr", "bustr", "bvstr", "srflx", "bvf",
+        "tke", "gls", "Lscale", "Akk", "Akp"]
 
 
 def _kw(args):
@@ -243,6 +244,11 @@ STEP_CASES = [
     # two more of the reference's test applications: SEAMOUNT (pressure-gradient test) and GRAV_ADJ (lock exchange, MPDATA)
     ("seamount_small", "seamount_small", ["nsteps=100"]),
     ("grav_adj_small", "grav_adj_small", ["nsteps=100"]),
+    # the generic length-scale closure: upwelling.h -DGLS_MIXING (Kantha-Clayson, k-epsilon), Canuto A masked ("gen"),
+    # Canuto B with CHARNOK / CRAIG_BANNER / K_C2ADVECTION (k-kl)
+    ("upwelling_gls_small", "upwelling_gls_small", ["nsteps=60"]),
+    ("upwelling_gls_ca_small", "upwelling_gls_ca_small", ["nsteps=60"]),
+    ("upwelling_gls_cb_small", "upwelling_gls_cb_small", ["nsteps=60"]),
 ]
 KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
 def make_avg():

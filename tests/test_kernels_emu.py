@@ -223,6 +223,8 @@ def test_romsM_run_report_is_the_reference_text(emu, tmp_path):
     # SEAMOUNT and GRAV_ADJ
     util.check_romsM_report(exe, tmp_path, exact=True, fixture="seamount_small_steps.npz")
     util.check_romsM_report(exe, tmp_path, exact=True, fixture="grav_adj_small_steps.npz")
+    util.check_romsM_report(exe, tmp_path, exact=True, fixture="upwelling_gls_small_steps.npz")       # GLS_MIXING
+    util.check_romsM_report(exe, tmp_path, exact=True, fixture="upwelling_gls_cb_small_steps.npz")
 
 
 def test_product_partition_matches_reference_get_bounds(emu):
@@ -411,16 +413,19 @@ def test_generic_length_scale_closure_through_the_fortran_host(emu, tag, monkeyp
     O = util.make_oracle(cs, util.with_gls(cs, g))
     O.start()
     O.main3d_step(8)
-    header = None
+    # three ways to say which form: the built-in list of the application name, the header, -DGLS_MIXING beside the shipped one
+    ways = [dict(params=dict(cs, ninfo=0)), dict(params=dict(cs, ninfo=0), kernels=True)]
     if cs["app"] == "upwelling_gls":
-        monkeypatch.setenv("ROMS_CPP_FLAGS", "-DGLS_MIXING")
+        ways.append(dict(params=dict(cs, ninfo=0, app="upwelling"), flags="-DGLS_MIXING"))
     else:
-        header = os.path.join(root, "oracle", "ref", cs["app"] + ".h")
-    for kernels in (False, True):
-        H = hostlib.Host(params=dict(cs, ninfo=0), lib_path=os.path.join(os.path.dirname(emu), "libroms_host_emu.so"),
-                         hip_lib_path=emu, header=header)
+        ways.append(dict(params=dict(cs, ninfo=0, app="upwelling"), header=os.path.join(root, "oracle", "ref", cs["app"] + ".h")))
+    for w in ways:
+        if "flags" in w:
+            monkeypatch.setenv("ROMS_CPP_FLAGS", w["flags"])
+        H = hostlib.Host(params=w["params"], lib_path=os.path.join(os.path.dirname(emu), "libroms_host_emu.so"),
+                         hip_lib_path=emu, header=w.get("header"))
         ctx = H.device_init()
-        H.run(8, kernels=kernels)
+        H.run(8, kernels=w.get("kernels", False))
         for n in ("zeta", "u", "v", "t", "Akv", "Akt", "tke", "gls", "Lscale", "Akk", "Akp"):
-            assert np.array_equal(ctx.download(n), O.field(n)), (n, kernels)
+            assert np.array_equal(ctx.download(n), O.field(n)), (n, w.keys())
         H.finalize()

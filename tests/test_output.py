@@ -108,14 +108,18 @@ def _final_state(ctx, names):
 
 @pytest.mark.parametrize("which", LIBS)
 @pytest.mark.parametrize("tag,kw,n1", [("upwelling_small", {}, 4), ("upwelling_small", {}, 5), ("benchmark_small", {}, 5),
-                                       ("upwelling_kpp_small", {}, 4)])
+                                       ("upwelling_kpp_small", {}, 4), ("upwelling_gls_small", {}, 4),
+                                       ("upwelling_gls_cb_small:k-kl", {}, 5)])
 def test_restart_continues_bit_for_bit(which, tag, kw, n1, tmp_path):
     """n1 + 3 steps in one go == n1 steps, a restart record, a NEW context restarted from the file, 3 more steps: every
     prognostic array bit for bit (an even and an odd step count: both parities of the time indices; ANA_VMIX, KPP +
-    bulk fluxes + nonlinear EOS, KPP + MPDATA).  LcycleRST: the second of two records is the one picked (latest time)."""
+    bulk fluxes + nonlinear EOS, KPP + MPDATA; GLS_MIXING, whose tke and gls travel with their three time levels beside
+    Lscale, AKk, AKp).  LcycleRST: the second of two records is the one picked (latest time)."""
     main = ["zeta", "ubar", "vbar", "u", "v", "t"]
     more = ["Hz", "z_r", "z_w", "Huon", "Hvom", "W", "rho", "Zt_avg1", "DU_avg1", "DV_avg1", "rufrc", "rvfrc", "Akv", "Akt"]
     cs = util.case_for(tag, **kw)
+    if "gls_flags" in cs:
+        more = more + ["tke", "gls", "Lscale", "Akk", "Akp"]
     rst = str(tmp_path / "roms_rst.nc")
     cs.update(RSTNAME=rst, LcycleRST=True, ninfo=0)
     H, ctx = _host(cs, which)
@@ -138,6 +142,9 @@ def test_restart_continues_bit_for_bit(which, tag, kw, n1, tmp_path):
     times = list(f.variables["ocean_time"][:])
     assert times == [(n1 + 1) * cs["dt"], n1 * cs["dt"]], times
     assert f.type == b"ROMS restart file"
+    if "gls_flags" in cs:
+        assert f.variables["tke"].dimensions == ("ocean_time", "three", "s_w", "eta_rho", "xi_rho")
+        assert f.variables["AKp"].dimensions == ("ocean_time", "s_w", "eta_rho", "xi_rho")
     f.close()
     H, ctx = _host(cs, which)
     H.get_state(rst, 2)                           # the record of step n1 (explicitly; 0 would pick the later one)

@@ -14,11 +14,16 @@ from tests import util
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 EMU = os.path.join(ROOT, "tests", "emu")
 FIELDS = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "Huon", "Hvom", "rho", "Akv", "DU_avg1", "Zt_avg1"]
+GLS_FIELDS = ["tke", "gls", "Akt", "Akk", "Akp", "Lscale"]
 
 
 def _emu_libs():
     if not (os.path.exists(os.path.join(EMU, "libroms_host_emu.so")) and os.path.exists(util.EMU_LIB)):
         subprocess.check_call(["bash", os.path.join(EMU, "build_emu.sh")])
+
+
+def _fields(tag):
+    return FIELDS + (GLS_FIELDS if tag.startswith("upwelling_gls") else [])
 
 
 def _single(tag, kw, steps):
@@ -27,7 +32,7 @@ def _single(tag, kw, steps):
     cs["ninfo"] = 0
     run = tiling.TiledRun(cs, weak=False, host_lib=os.path.join(EMU, "libroms_host_emu.so"), hip_lib=util.EMU_LIB)
     run.step(steps)
-    res = {n: run.gather(n) for n in FIELDS}
+    res = {n: run.gather(n) for n in _fields(tag)}
     d = run.diag()
     run.close()
     return res, d
@@ -35,7 +40,7 @@ def _single(tag, kw, steps):
 
 def _tiled(tmp_path, tag, kw, steps, tiles, port, kernels=False):
     out = str(tmp_path / f"tiles_{tiles[0]}x{tiles[1]}.npz")
-    spec = dict(tag=tag, kw=kw, steps=steps, tiles=list(tiles), fields=FIELDS, kernels=kernels, probe=True)
+    spec = dict(tag=tag, kw=kw, steps=steps, tiles=list(tiles), fields=_fields(tag), kernels=kernels, probe=True)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={tiles[0] * tiles[1]}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "mp", "run_tiles.py"), out, json.dumps(spec)]
@@ -75,6 +80,11 @@ def _interior(cs_dims, a):
     # SEAMOUNT (no-slip walls) and GRAV_ADJ (MPDATA, closed in xi, periodic and four points wide in eta: tiles along xi)
     ("seamount_small", dict(), (2, 2), 29625),
     ("grav_adj_small", dict(), (2, 1), 29626),
+    # GLS_MIXING: tke, gls (index 3 behind gls_prestep, nnew behind gls_corstep), Akv, Akt travel; the smoothing of N2 and
+    # shear reads them and the work array across the tile boundary; masked (Canuto A) and with MPDATA's three ghost lines
+    ("upwelling_gls_small", dict(), (2, 2), 29627),
+    ("upwelling_gls_ca_small:gen", dict(), (2, 2), 29628),
+    ("upwelling_gls_cb_small:k-kl", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (1, 2), 29629),
 ])
 def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     _emu_libs()
@@ -82,7 +92,7 @@ def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     ref, dref = _single(tag, kw, steps)
     got = _tiled(tmp_path, tag, kw, steps, tiles, port)
     assert int(got["nexchanges"]) > 30 * steps          # the strips really travelled
-    for n in FIELDS:
+    for n in _fields(tag):
         a, b = got[n], ref[n]
         assert a.shape == b.shape, n
         # compare everything the single-tile run defines; ghost entries that no kernel reads are

@@ -199,8 +199,9 @@ def load_fixture(name):
 
 def case_from_meta(meta):
     cs = dict(meta["case"])
-    for k in ("hadv", "vadv", "tnu2", "Akt_bak", "options"):
-        cs[k] = tuple(cs[k])
+    for k in ("hadv", "vadv", "tnu2", "Akt_bak", "options", "gls_flags"):
+        if k in cs:
+            cs[k] = tuple(cs[k])
     if "lbc" in cs:
         cs["lbc"] = {v: tuple(k) for v, k in cs["lbc"].items()}
     return cs
@@ -222,6 +223,8 @@ class OracleSide:
         self.g = load_init(init_tag(cs), nghost_for(cs))
         if "MASKING" in cs["options"]:          # the masks are input data of the case (cases.land_mask)
             self.g = with_masks(cs, self.g)
+        if "gls_flags" in cs:                    # initialize_mixing's values of the closure's arrays
+            self.g = with_gls(cs, self.g)
         self.O = make_oracle(cs, self.g)
         self.O.start()
 
@@ -277,6 +280,8 @@ class HipSide:
         self.g = load_init(init_tag(cs), nghost_for(cs))
         if "MASKING" in cs["options"]:          # the masks are input data of the case (cases.land_mask)
             self.g = with_masks(cs, self.g)
+        if "gls_flags" in cs:
+            self.g = with_gls(cs, self.g)
         self.H = make_hip(cs, self.g, ninfo=ninfo)
         self.H.start()
 
