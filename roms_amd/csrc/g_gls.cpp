@@ -85,7 +85,7 @@ int run_gls_prestep(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   const GlsArgs a = gls_args(c);
-  LAUNCH_THREAD(k_gls_pre, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  LAUNCH_THREAD(k_gls_pre, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
   const size_t lev = (size_t)G.nij * (size_t)(G.N + 1);
   HaloSpec sp[2] = {{c->F.tke + 2 * lev, G.N + 1, bc_rstate(c), 'r'}, {c->F.gls + 2 * lev, G.N + 1, bc_rstate(c), 'r'}};
   launch_halo_tail(c, sp, 2);
@@ -98,7 +98,9 @@ int run_gls_corstep(roms_hip_ctx *c) {
   const TB &B = G.T;
   const GlsArgs a = gls_args(c);
   LAUNCH_THREAD(k_gls_shear, B.Iendp1 - B.Istrm1 + 1, B.Jendp1 - B.Jstrm1 + 1, 1, c->stream, a);
-  LAUNCH_THREAD(k_gls_cor, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  LAUNCH_THREAD(k_gls_adv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
+  LAUNCH_THREAD(k_gls_solve, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  LAUNCH_THREAD(k_gls_coef, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
   const size_t lev = (size_t)G.nij * (size_t)(G.N + 1);
   HaloSpec sp[4] = {{c->F.tke + (size_t)(G.nnew - 1) * lev, G.N + 1, bc_rstate(c), 'r'},
                     {c->F.gls + (size_t)(G.nnew - 1) * lev, G.N + 1, bc_rstate(c), 'r'},

@@ -1,12 +1,15 @@
 // k_gls.h -- generic length-scale vertical turbulence closure (GLS_MIXING).
 //   k_gls_pre     gls_prestep_tile   ROMS/Nonlinear/gls_prestep.F:95-446    tke, gls at n+1/2 (index 3); Hz*tke(nstp) into nnew
 //   k_gls_shear   gls_corstep_tile   ROMS/Nonlinear/gls_corstep.F:345-400   squared vertical shear at W-points (RI_SPLINES or not)
-//   k_gls_cor     gls_corstep_tile   ROMS/Nonlinear/gls_corstep.F:404-1190  N2S2_HORAVG, advection, production, dissipation,
-//                                                                            the two tridiagonal systems, stability functions,
+//   k_gls_adv     gls_corstep_tile   ROMS/Nonlinear/gls_corstep.F:404-900   N2S2_HORAVG, advection, production, dissipation
+//   k_gls_solve   gls_corstep_tile   ROMS/Nonlinear/gls_corstep.F:912-1050  surface / bottom values, the two tridiagonal systems
+//   k_gls_coef    gls_corstep_tile   ROMS/Nonlinear/gls_corstep.F:1058-1165 limits, length scale, stability functions,
 //                                                                            Akv, Akt, Akk, Akp, Lscale
 // The compile-time forms of the reference (CANUTO_A | CANUTO_B | KANTHA_CLAYSON | Galperin, N2S2_HORAVG, RI_SPLINES,
-// K_C2ADVECTION | K_C4ADVECTION | third-order upstream, CHARNOK, CRAIG_BANNER) are run-time flags here.  One thread per
-// column; the columns of the implicit steps live in private memory (not a BASELINE path: the straightforward form).
+// K_C2ADVECTION | K_C4ADVECTION | third-order upstream, CHARNOK, CRAIG_BANNER) are run-time flags here.  Everything
+// that is local to a W-point -- and that is where the closure's real powers (`pow`, a long dependent chain) are -- runs as
+// one thread per point, so that thousands of them hide each other's latency; only the two tridiagonal sweeps run one
+// thread per column (measured at 512x512x50: 2.56 ms as one column kernel).
 // The lateral conditions (tkebc_im.F closed / gradient, the edge copies of Akv and Akt :1196-1280) and the exchanges
 // are halo launches behind the kernels (g_gls.cpp).
 #pragma once
@@ -69,12 +72,13 @@ KDEV double gls_vflux(const double *A, size_t nij, double CF, int k, int N, bool
 }
 
 // ------------------------------------------------------------------------------ gls_prestep
+// one thread per W-point (i,j,k), k = 1 + gz = 1..N-1: the four horizontal fluxes and the two vertical ones of the point are
+// formed where they are used (the reference's XF, FX ... FCL, Hz_half work arrays do not exist)
 THREAD_KERNEL(k_gls_pre, GlsArgs) {
-  (void)gz;
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB &B = G.T;
-  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nstp = G.nstp, nnew = G.nnew;
+  const int i = B.Istr + gx, j = B.Jstr + gy, k = 1 + gz, N = G.N, nstp = G.nstp, nnew = G.nnew;
   const size_t nij = (size_t)G.nij, lev = nij * (size_t)(N + 1);
   const bool c2 = (a.flags & ROMS_GLS_K_C2ADVECTION) != 0;
   const int mode = c2 ? 0 : 1;
@@ -89,32 +93,27 @@ THREAD_KERNEL(k_gls_pre, GlsArgs) {
   double *tk3 = F.tke + 2 * lev, *gl3 = F.gls + 2 * lev, *tkn = F.tke + (size_t)(nnew - 1) * lev, *gln = F.gls + (size_t)(nnew - 1) * lev;
   const double cff4 = cff3 * F.pm[X2(i, j)] * F.pn[X2(i, j)];
   const double *tkc = tk + X2(i, j), *glc = gl + X2(i, j);        // the column, level k at [k * nij]
-  // vertical fluxes through rho-level k (carried upwards: level k+1 of one pass is level k of the next)
-  double CFk = 0.5 * (W[XW(i, j, 1)] + W[XW(i, j, 0)]);
-  double FCk = gls_vflux(tkc, nij, CFk, 1, N, c2), FLk = gls_vflux(glc, nij, CFk, 1, N, c2);
-  for (int k = 1; k <= N - 1; k++) {
-    const double *tkk = tk + (size_t)k * nij, *glk = gl + (size_t)k * nij;
-    const double XF0 = 0.5 * (Huon[X3(i, j, k)] + Huon[X3(i, j, k + 1)]), XF1 = 0.5 * (Huon[X3(i + 1, j, k)] + Huon[X3(i + 1, j, k + 1)]);
-    const double EF0 = 0.5 * (Hvom[X3(i, j, k)] + Hvom[X3(i, j, k + 1)]), EF1 = 0.5 * (Hvom[X3(i, j + 1, k)] + Hvom[X3(i, j + 1, k + 1)]);
-    const double FX0 = gls_hflux(G, tkk, XF0, i, j, 0, mode), FX1 = gls_hflux(G, tkk, XF1, i + 1, j, 0, mode);
-    const double FE0 = gls_hflux(G, tkk, EF0, i, j, 1, mode), FE1 = gls_hflux(G, tkk, EF1, i, j + 1, 1, mode);
-    const double LX0 = gls_hflux(G, glk, XF0, i, j, 0, mode), LX1 = gls_hflux(G, glk, XF1, i + 1, j, 0, mode);
-    const double LE0 = gls_hflux(G, glk, EF0, i, j, 1, mode), LE1 = gls_hflux(G, glk, EF1, i, j + 1, 1, mode);
-    const double cff = 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j, k + 1)]);
-    double Hzh = cff - cff4 * (XF1 - XF0 + EF1 - EF0);                                   // :318-335
-    double t3 = cff * (cff1 * tkk[X2(i, j)] + cff2 * tki[XW(i, j, k)]) - cff4 * (FX1 - FX0 + FE1 - FE0);
-    double g3 = cff * (cff1 * glk[X2(i, j)] + cff2 * gli[XW(i, j, k)]) - cff4 * (LX1 - LX0 + LE1 - LE0);
-    const double tn = cff * tkk[X2(i, j)], gn = cff * glk[X2(i, j)];
-    const double CF1 = 0.5 * (W[XW(i, j, k + 1)] + W[XW(i, j, k)]);                       // :339-437
-    const double FC1 = gls_vflux(tkc, nij, CF1, k + 1, N, c2), FL1 = gls_vflux(glc, nij, CF1, k + 1, N, c2);
-    Hzh = Hzh - cff4 * (CF1 - CFk);
-    const double oH = 1.0 / Hzh;
-    t3 = oH * (t3 - cff4 * (FC1 - FCk));
-    g3 = oH * (g3 - cff4 * (FL1 - FLk));
-    tk3[XW(i, j, k)] = t3; gl3[XW(i, j, k)] = g3;
-    tkn[XW(i, j, k)] = tn; gln[XW(i, j, k)] = gn;
-    CFk = CF1; FCk = FC1; FLk = FL1;
-  }
+  const double *tkk = tk + (size_t)k * nij, *glk = gl + (size_t)k * nij;
+  const double XF0 = 0.5 * (Huon[X3(i, j, k)] + Huon[X3(i, j, k + 1)]), XF1 = 0.5 * (Huon[X3(i + 1, j, k)] + Huon[X3(i + 1, j, k + 1)]);
+  const double EF0 = 0.5 * (Hvom[X3(i, j, k)] + Hvom[X3(i, j, k + 1)]), EF1 = 0.5 * (Hvom[X3(i, j + 1, k)] + Hvom[X3(i, j + 1, k + 1)]);
+  const double FX0 = gls_hflux(G, tkk, XF0, i, j, 0, mode), FX1 = gls_hflux(G, tkk, XF1, i + 1, j, 0, mode);
+  const double FE0 = gls_hflux(G, tkk, EF0, i, j, 1, mode), FE1 = gls_hflux(G, tkk, EF1, i, j + 1, 1, mode);
+  const double LX0 = gls_hflux(G, glk, XF0, i, j, 0, mode), LX1 = gls_hflux(G, glk, XF1, i + 1, j, 0, mode);
+  const double LE0 = gls_hflux(G, glk, EF0, i, j, 1, mode), LE1 = gls_hflux(G, glk, EF1, i, j + 1, 1, mode);
+  const double cff = 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j, k + 1)]);
+  double Hzh = cff - cff4 * (XF1 - XF0 + EF1 - EF0);                                   // :318-335
+  double t3 = cff * (cff1 * tkk[X2(i, j)] + cff2 * tki[XW(i, j, k)]) - cff4 * (FX1 - FX0 + FE1 - FE0);
+  double g3 = cff * (cff1 * glk[X2(i, j)] + cff2 * gli[XW(i, j, k)]) - cff4 * (LX1 - LX0 + LE1 - LE0);
+  const double tn = cff * tkk[X2(i, j)], gn = cff * glk[X2(i, j)];
+  const double CFk = 0.5 * (W[XW(i, j, k)] + W[XW(i, j, k - 1)]), CF1 = 0.5 * (W[XW(i, j, k + 1)] + W[XW(i, j, k)]);   // :339-437
+  const double FCk = gls_vflux(tkc, nij, CFk, k, N, c2), FLk = gls_vflux(glc, nij, CFk, k, N, c2);
+  const double FC1 = gls_vflux(tkc, nij, CF1, k + 1, N, c2), FL1 = gls_vflux(glc, nij, CF1, k + 1, N, c2);
+  Hzh = Hzh - cff4 * (CF1 - CFk);
+  const double oH = 1.0 / Hzh;
+  t3 = oH * (t3 - cff4 * (FC1 - FCk));
+  g3 = oH * (g3 - cff4 * (FL1 - FLk));
+  tk3[XW(i, j, k)] = t3; gl3[XW(i, j, k)] = g3;
+  tkn[XW(i, j, k)] = tn; gln[XW(i, j, k)] = gn;
 }
 THREAD_GLOBAL(k_gls_pre, GlsArgs)
 
@@ -178,66 +177,100 @@ KDEV void gls_n2s2(const GlsArgs &a, int i, int j, int k, double &bu, double &sh
   sh = 0.25 * (s0[0] + s0[1] + s0[2] + s0[3]);
 }
 
-// ------------------------------------------------------------------------------ gls_corstep: the column
-THREAD_KERNEL(k_gls_cor, GlsArgs) {
+// ------------------------------------------------------------------------------ gls_corstep: advection, production, dissipation
+// One thread per W-point (i,j,k), k = 1 + gz = 1..N-1 (:490-900): tke, gls(nnew) -- Hz*tke(nstp) from gls_prestep -- advanced by
+// the horizontal and vertical advection of the half-step values (index 3) and by shear / buoyancy production; the diagonals
+// BCK, BCP of the two implicit systems (dissipation, the vertical mixing of the turbulent fields) into F.wrk3[0], F.wrk3[1].
+// Everything here is local to the point, and it holds two of the closure's real powers (four with the wall function).
+#define GLS_FCK(k) (((k) <= 1 || (k) >= N) ? 0.0 : cfd * (Akk[XW(i, j, k)] + Akk[XW(i, j, (k) - 1)]) / Hz[X3(i, j, k)])
+#define GLS_FCP(k) (((k) <= 1 || (k) >= N) ? 0.0 : cfd * (Akp[XW(i, j, k)] + Akp[XW(i, j, (k) - 1)]) / Hz[X3(i, j, k)])
+THREAD_KERNEL(k_gls_adv, GlsArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int i = B.Istr + gx, j = B.Jstr + gy, k = 1 + gz, N = G.N, nstp = G.nstp, nnew = G.nnew;
+  const size_t nij = (size_t)G.nij, lev = nij * (size_t)(N + 1);
+  const int flags = a.flags;
+  const bool c2 = (flags & ROMS_GLS_K_C2ADVECTION) != 0;
+  const int mode = c2 ? 0 : ((flags & ROMS_GLS_K_C4ADVECTION) ? 1 : 2);
+  const double vonKar = 0.41, dt = G.dt, Kmin = a.Kmin, Pmin = a.Pmin;
+  const double *Huon = F.Huon, *Hvom = F.Hvom, *Hz = F.Hz, *W = F.W, *z_w = F.z_w, *Akv = F.Akv, *Akt = F.Akt, *Akk = F.Akk, *Akp = F.Akp;
+  const double *tko = F.tke + (size_t)(nstp - 1) * lev, *glo = F.gls + (size_t)(nstp - 1) * lev;
+  const double *tk3 = F.tke + 2 * lev, *gl3 = F.gls + 2 * lev;
+  double *tkn = F.tke + (size_t)(nnew - 1) * lev, *gln = F.gls + (size_t)(nnew - 1) * lev;
+  const double pmn = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
+  const double *tc = tk3 + X2(i, j), *gc = gl3 + X2(i, j);
+  const double *tkk = tk3 + (size_t)k * nij, *glk = gl3 + (size_t)k * nij;
+  const double XF0 = 0.5 * (Huon[X3(i, j, k)] + Huon[X3(i, j, k + 1)]), XF1 = 0.5 * (Huon[X3(i + 1, j, k)] + Huon[X3(i + 1, j, k + 1)]);
+  const double EF0 = 0.5 * (Hvom[X3(i, j, k)] + Hvom[X3(i, j, k + 1)]), EF1 = 0.5 * (Hvom[X3(i, j + 1, k)] + Hvom[X3(i, j + 1, k + 1)]);
+  const double FXK0 = gls_hflux(G, tkk, XF0, i, j, 0, mode), FXK1 = gls_hflux(G, tkk, XF1, i + 1, j, 0, mode);
+  const double FEK0 = gls_hflux(G, tkk, EF0, i, j, 1, mode), FEK1 = gls_hflux(G, tkk, EF1, i, j + 1, 1, mode);
+  const double FXP0 = gls_hflux(G, glk, XF0, i, j, 0, mode), FXP1 = gls_hflux(G, glk, XF1, i + 1, j, 0, mode);
+  const double FEP0 = gls_hflux(G, glk, EF0, i, j, 1, mode), FEP1 = gls_hflux(G, glk, EF1, i, j + 1, 1, mode);
+  double t = tkn[XW(i, j, k)] - pmn * (FXK1 - FXK0 + FEK1 - FEK0);                     // :664-678
+  t = KMAX(t, Kmin);
+  double p = gln[XW(i, j, k)] - pmn * (FXP1 - FXP0 + FEP1 - FEP0);
+  p = KMAX(p, Pmin);
+  // vertical advection :684-776 (K_C2ADVECTION: cff = 0.25*(W+W), flux cff*(A(k)+A(k-1)): the factor one half of the
+  // second-order flux is carried by cff -- a power of two, the product is the same)
+  const double CFk = 0.5 * (W[XW(i, j, k)] + W[XW(i, j, k - 1)]), CF1 = 0.5 * (W[XW(i, j, k + 1)] + W[XW(i, j, k)]);
+  const double FCk = gls_vflux(tc, nij, CFk, k, N, c2), FPk = gls_vflux(gc, nij, CFk, k, N, c2);
+  const double FC1 = gls_vflux(tc, nij, CF1, k + 1, N, c2), FP1 = gls_vflux(gc, nij, CF1, k + 1, N, c2);
+  t = t - pmn * (FC1 - FCk);
+  t = KMAX(t, Kmin);
+  p = p - pmn * (FP1 - FPk);
+  p = KMAX(p, Pmin);
+  // production and dissipation :804-900
+  double strat2, shr2;
+  gls_n2s2(a, i, j, k, strat2, shr2);
+  const double gls_c3 = strat2 > 0.0 ? a.c3m : a.c3p;
+  const double dAkt = Akt[XW(i, j, k)] - G.Akt_bak[0], dAkv = Akv[XW(i, j, k)] - G.Akv_bak;
+  double Kprod = shr2 * dAkv - strat2 * dAkt;
+  double Pprod = a.c1 * shr2 * dAkv - gls_c3 * strat2 * dAkt;
+  double cff1 = 1.0;
+  if (Kprod < 0.0) { Kprod = Kprod + strat2 * dAkt; cff1 = 0.0; }
+  double cff2 = 1.0;
+  if (Pprod < 0.0) { Pprod = Pprod + gls_c3 * strat2 * dAkt; cff2 = 0.0; }
+  const double cff = 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j, k + 1)]);
+  const double tks = tko[XW(i, j, k)], gss = glo[XW(i, j, k)];
+  t = t + dt * cff * Kprod;
+  p = p + dt * cff * Pprod * gss / KMAX(tks, Kmin);
+  double wall_fac = 1.0;
+  if (a.Lmy25) {
+    const double p1 = pow(gss, a.exp1), p2 = pow(tks, -a.texp1);
+    const double wb = p1 * a.cmu_fac1 * p2 * (1.0 / (z_w[XW(i, j, k)] - z_w[XW(i, j, 0)]));
+    const double ws = p1 * a.cmu_fac1 * p2 * (1.0 / (z_w[XW(i, j, N)] - z_w[XW(i, j, k)]));
+    wall_fac = 1.0 + a.E2 / (vonKar * vonKar) * (wb * wb) + 0.25 / (vonKar * vonKar) * (ws * ws);
+  }
+  const double pg = pow(gss, -a.exp1), pt = pow(tks, a.texp2);
+  const double cfd = -0.5 * dt;
+  const double FCKk = GLS_FCK(k), FCK1 = GLS_FCK(k + 1), FCPk = GLS_FCP(k), FCP1 = GLS_FCP(k + 1);
+  tkn[XW(i, j, k)] = t;
+  gln[XW(i, j, k)] = p;
+  F.wrk3[0][XW(i, j, k)] = cff * (1.0 + dt * pg * a.cmu_fac2 * pt + dt * (1.0 - cff1) * strat2 * dAkt / tks) - FCKk - FCK1;
+  F.wrk3[1][XW(i, j, k)] = cff * (1.0 + dt * a.c2 * wall_fac * pg * a.cmu_fac2 * pt + dt * (1.0 - cff2) * gls_c3 * strat2 * dAkt / tks) - FCPk - FCP1;
+}
+THREAD_GLOBAL(k_gls_adv, GlsArgs)
+
+// ------------------------------------------------------------------------------ gls_corstep: the two implicit systems
+// One thread per column (:912-1050): the surface and bottom values, then the tridiagonal systems of tke and of gls (the
+// second one's surface and bottom fluxes need the SOLVED tke), each eliminated from the top down and substituted back
+// upwards in private memory; the solved columns go back into tke, gls(nnew), the end values of the five coefficient
+// arrays are set (:1167-1180).  No real powers inside the sweeps.
+THREAD_KERNEL(k_gls_solve, GlsArgs) {
   (void)gz;
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB &B = G.T;
-  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nstp = G.nstp, nnew = G.nnew, NAT = G.NAT;
+  const int i = B.Istr + gx, j = B.Jstr + gy, N = G.N, nnew = G.nnew, NAT = G.NAT;
   const size_t nij = (size_t)G.nij, lev = nij * (size_t)(N + 1);
   const int flags = a.flags;
-  const bool c2 = (flags & ROMS_GLS_K_C2ADVECTION) != 0, crgban = (flags & ROMS_GLS_CRAIG_BANNER) != 0;
-  const int mode = c2 ? 0 : ((flags & ROMS_GLS_K_C4ADVECTION) ? 1 : 2);
-  const double eps = 1.0E-10, vonKar = 0.41, dt = G.dt;
-  const double Kmin = a.Kmin, Pmin = a.Pmin, gls_m = a.gls_m, gls_n = a.gls_n;
-  const double *Huon = F.Huon, *Hvom = F.Hvom, *Hz = F.Hz, *W = F.W, *z_w = F.z_w;
-  const double *tko = F.tke + (size_t)(nstp - 1) * lev, *glo = F.gls + (size_t)(nstp - 1) * lev;
-  const double *tk3 = F.tke + 2 * lev, *gl3 = F.gls + 2 * lev;
+  const bool crgban = (flags & ROMS_GLS_CRAIG_BANNER) != 0;
+  const double vonKar = 0.41, dt = G.dt, Kmin = a.Kmin, Pmin = a.Pmin, gls_m = a.gls_m, gls_n = a.gls_n;
+  const double *Hz = F.Hz, *BCK = F.wrk3[0], *BCP = F.wrk3[1];
   double *tkn = F.tke + (size_t)(nnew - 1) * lev, *gln = F.gls + (size_t)(nnew - 1) * lev;
-  double *Akv = F.Akv, *Akt = F.Akt, *Akk = F.Akk, *Akp = F.Akp, *Lscale = F.Lscale;
-  double T[ROMS_NPRIV], P[ROMS_NPRIV], CF[ROMS_NPRIV], BCP[ROMS_NPRIV];
-  const double pmn = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];
-  // advection :490-776
-  {
-    const double *tc = tk3 + X2(i, j), *gc = gl3 + X2(i, j);
-    double CFk = c2 ? 0.25 * (W[XW(i, j, 1)] + W[XW(i, j, 0)]) : 0.5 * (W[XW(i, j, 0)] + W[XW(i, j, 1)]);
-    // (K_C2ADVECTION: cff = 0.25*(W+W), flux cff*(A(k)+A(k-1)) -- the factor one half of gls_vflux's second-order branch
-    // is carried by cff; a power of two, the product is the same)
-    double FCk, FPk;
-    if (c2) { FCk = CFk * (tc[nij] + tc[0]); FPk = CFk * (gc[nij] + gc[0]); }
-    else { FCk = gls_vflux(tc, nij, CFk, 1, N, false); FPk = gls_vflux(gc, nij, CFk, 1, N, false); }
-    for (int k = 1; k <= N - 1; k++) {
-      const double *tkk = tk3 + (size_t)k * nij, *glk = gl3 + (size_t)k * nij;
-      const double hu0 = Huon[X3(i, j, k)] + Huon[X3(i, j, k + 1)], hu1 = Huon[X3(i + 1, j, k)] + Huon[X3(i + 1, j, k + 1)];
-      const double hv0 = Hvom[X3(i, j, k)] + Hvom[X3(i, j, k + 1)], hv1 = Hvom[X3(i, j + 1, k)] + Hvom[X3(i, j + 1, k + 1)];
-      const double XF0 = 0.5 * hu0, XF1 = 0.5 * hu1, EF0 = 0.5 * hv0, EF1 = 0.5 * hv1;
-      const double FXK0 = gls_hflux(G, tkk, XF0, i, j, 0, mode), FXK1 = gls_hflux(G, tkk, XF1, i + 1, j, 0, mode);
-      const double FEK0 = gls_hflux(G, tkk, EF0, i, j, 1, mode), FEK1 = gls_hflux(G, tkk, EF1, i, j + 1, 1, mode);
-      const double FXP0 = gls_hflux(G, glk, XF0, i, j, 0, mode), FXP1 = gls_hflux(G, glk, XF1, i + 1, j, 0, mode);
-      const double FEP0 = gls_hflux(G, glk, EF0, i, j, 1, mode), FEP1 = gls_hflux(G, glk, EF1, i, j + 1, 1, mode);
-      double t = tkn[XW(i, j, k)] - pmn * (FXK1 - FXK0 + FEK1 - FEK0);
-      t = KMAX(t, Kmin);
-      double p = gln[XW(i, j, k)] - pmn * (FXP1 - FXP0 + FEP1 - FEP0);
-      p = KMAX(p, Pmin);
-      double CF1, FC1, FP1;
-      if (c2) {
-        CF1 = 0.25 * (W[XW(i, j, k + 1)] + W[XW(i, j, k)]);
-        FC1 = CF1 * (tc[(size_t)(k + 1) * nij] + tc[(size_t)k * nij]);
-        FP1 = CF1 * (gc[(size_t)(k + 1) * nij] + gc[(size_t)k * nij]);
-      } else {
-        CF1 = (k + 1 == N) ? 0.5 * (W[XW(i, j, N)] + W[XW(i, j, N - 1)]) : 0.5 * (W[XW(i, j, k + 1)] + W[XW(i, j, k)]);
-        FC1 = gls_vflux(tc, nij, CF1, k + 1, N, false);
-        FP1 = gls_vflux(gc, nij, CF1, k + 1, N, false);
-      }
-      t = t - pmn * (FC1 - FCk);
-      T[k] = KMAX(t, Kmin);
-      p = p - pmn * (FP1 - FPk);
-      P[k] = KMAX(p, Pmin);
-      FCk = FC1; FPk = FP1;
-    }
-  }
-  // surface and bottom values :912-955
+  double *Akv = F.Akv, *Akt = F.Akt, *Akk = F.Akk, *Akp = F.Akp;
+  double T[ROMS_NPRIV], CF[ROMS_NPRIV];
   const double su = F.sustr[X2(i, j)] + F.sustr[X2(i + 1, j)], sv = F.svstr[X2(i, j)] + F.svstr[X2(i, j + 1)];
   const double bu_ = F.bustr[X2(i, j)] + F.bustr[X2(i + 1, j)], bv_ = F.bvstr[X2(i, j)] + F.bvstr[X2(i, j + 1)];
   const double sstr = 0.5 * sqrt(su * su + sv * sv), bstr = 0.5 * sqrt(bu_ * bu_ + bv_ * bv_);
@@ -247,55 +280,23 @@ THREAD_KERNEL(k_gls_cor, GlsArgs) {
   const double glsN = KMAX(a.cmu0p * pow(tkeN, gls_m) * pow(a.L_sft * Zos_eff, gls_n), Pmin);
   const double gls0 = KMAX(a.fac4 * pow(vonKar * a.Zob_min, gls_n) * pow(tke0, gls_m), Pmin);
   const double tke_fluxt = crgban ? dt * a.crgban_cw * pow(sstr, 1.5) : 0.0;
-  // vertical mixing of the turbulent fields :786-800: FCK(k), FCP(k), k = 2..N-1; zero at 1 and N
-#define FCKc(k) (((k) <= 1 || (k) >= N) ? 0.0 : cfd * (Akk[XW(i, j, k)] + Akk[XW(i, j, (k) - 1)]) / Hz[X3(i, j, k)])
-#define FCPc(k) (((k) <= 1 || (k) >= N) ? 0.0 : cfd * (Akp[XW(i, j, k)] + Akp[XW(i, j, (k) - 1)]) / Hz[X3(i, j, k)])
   const double cfd = -0.5 * dt;
-  // production, dissipation :804-900, with the elimination of the tke system :959-985 from the top down
-  {
-    double FCK1 = FCKc(N);      // FCK(k+1)
-    double FCP1 = FCPc(N);
-    for (int k = N - 1; k >= 1; k--) {
-      double strat2, shr2;
-      gls_n2s2(a, i, j, k, strat2, shr2);
-      const double gls_c3 = strat2 > 0.0 ? a.c3m : a.c3p;
-      const double dAkt = Akt[XW(i, j, k)] - G.Akt_bak[0], dAkv = Akv[XW(i, j, k)] - G.Akv_bak;
-      double Kprod = shr2 * dAkv - strat2 * dAkt;
-      double Pprod = a.c1 * shr2 * dAkv - gls_c3 * strat2 * dAkt;
-      double cff1 = 1.0;
-      if (Kprod < 0.0) { Kprod = Kprod + strat2 * dAkt; cff1 = 0.0; }
-      double cff2 = 1.0;
-      if (Pprod < 0.0) { Pprod = Pprod + gls_c3 * strat2 * dAkt; cff2 = 0.0; }
-      const double cff = 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j, k + 1)]);
-      const double tks = tko[XW(i, j, k)], gss = glo[XW(i, j, k)];
-      T[k] = T[k] + dt * cff * Kprod;
-      P[k] = P[k] + dt * cff * Pprod * gss / KMAX(tks, Kmin);
-      double wall_fac = 1.0;
-      if (a.Lmy25) {
-        const double p1 = pow(gss, a.exp1), p2 = pow(tks, -a.texp1);
-        const double wb = p1 * a.cmu_fac1 * p2 * (1.0 / (z_w[XW(i, j, k)] - z_w[XW(i, j, 0)]));
-        const double ws = p1 * a.cmu_fac1 * p2 * (1.0 / (z_w[XW(i, j, N)] - z_w[XW(i, j, k)]));
-        wall_fac = 1.0 + a.E2 / (vonKar * vonKar) * (wb * wb) + 0.25 / (vonKar * vonKar) * (ws * ws);
-      }
-      const double pg = pow(gss, -a.exp1), pt = pow(tks, a.texp2);
-      const double FCKk = FCKc(k), FCPk = FCPc(k);
-      const double BCK = cff * (1.0 + dt * pg * a.cmu_fac2 * pt + dt * (1.0 - cff1) * strat2 * dAkt / tks) - FCKk - FCK1;
-      BCP[k] = cff * (1.0 + dt * a.c2 * wall_fac * pg * a.cmu_fac2 * pt + dt * (1.0 - cff2) * gls_c3 * strat2 * dAkt / tks) - FCPk - FCP1;
-      if (k == N - 1) {
-        const double c = 1.0 / BCK;
-        CF[k] = c * FCKk;
-        T[k] = c * (T[k] + tke_fluxt);
-      } else {
-        const double c = 1.0 / (BCK - CF[k + 1] * FCK1);
-        CF[k] = c * FCKk;
-        T[k] = c * (T[k] - FCK1 * T[k + 1]);
-      }
-      FCK1 = FCKk; FCP1 = FCPk;
+  {   // tke :959-990
+    double FCK1 = GLS_FCK(N - 1);
+    double c = 1.0 / BCK[XW(i, j, N - 1)];
+    CF[N - 1] = c * FCK1;
+    T[N - 1] = c * (tkn[XW(i, j, N - 1)] + tke_fluxt);
+    for (int k = N - 2; k >= 1; k--) {
+      const double FCKk = GLS_FCK(k);
+      c = 1.0 / (BCK[XW(i, j, k)] - CF[k + 1] * FCK1);
+      CF[k] = c * FCKk;
+      T[k] = c * (tkn[XW(i, j, k)] - FCK1 * T[k + 1]);
+      FCK1 = FCKk;
     }
+    tkn[XW(i, j, 1)] = T[1];
+    for (int k = 2; k <= N - 1; k++) { T[k] = T[k] - CF[k] * T[k - 1]; tkn[XW(i, j, k)] = T[k]; }
   }
-  for (int k = 2; k <= N - 1; k++) T[k] = T[k] - CF[k] * T[k - 1];
-  // the gls system :994-1050
-  {
+  {   // gls :994-1050
     double cff = 0.5 * (tkeN + T[N - 1]);
     double gls_fluxt = dt * a.fac3 * pow(cff, gls_m) * pow(a.L_sft, gls_n) * pow(Zos_eff + 0.5 * Hz[X3(i, j, N)], gls_n - 1.0) *
                        0.5 * (Akp[XW(i, j, N)] + Akp[XW(i, j, N - 1)]);
@@ -305,71 +306,20 @@ THREAD_KERNEL(k_gls_cor, GlsArgs) {
     cff = 0.5 * (tke0 + T[1]);
     const double gls_fluxb = dt * a.fac2 * pow(cff, gls_m) * pow(0.5 * Hz[X3(i, j, 1)] + a.Zob_min, gls_n - 1.0) *
                              0.5 * (Akp[XW(i, j, 0)] + Akp[XW(i, j, 1)]);
-    double c = 1.0 / BCP[N - 1];
-    CF[N - 1] = c * FCPc(N - 1);
-    P[N - 1] = c * (P[N - 1] - gls_fluxt);
+    double FCP1 = GLS_FCP(N - 1);
+    double c = 1.0 / BCP[XW(i, j, N - 1)];
+    CF[N - 1] = c * FCP1;
+    T[N - 1] = c * (gln[XW(i, j, N - 1)] - gls_fluxt);
     for (int k = N - 2; k >= 1; k--) {
-      const double FCP1 = FCPc(k + 1);
-      c = 1.0 / (BCP[k] - CF[k + 1] * FCP1);
-      CF[k] = c * FCPc(k);
-      P[k] = c * (P[k] - FCP1 * P[k + 1]);
+      const double FCPk = GLS_FCP(k);
+      c = 1.0 / (BCP[XW(i, j, k)] - CF[k + 1] * FCP1);
+      CF[k] = c * FCPk;
+      T[k] = c * (gln[XW(i, j, k)] - FCP1 * T[k + 1]);
+      FCP1 = FCPk;
     }
-    P[1] = P[1] - c * gls_fluxb;
-    for (int k = 2; k <= N - 1; k++) P[k] = P[k] - CF[k] * P[k - 1];
-  }
-#undef FCKc
-#undef FCPc
-  // mixing coefficients :1058-1190
-  const bool canuto = (flags & (ROMS_GLS_CANUTO_A | ROMS_GLS_CANUTO_B)) != 0, kc = (flags & ROMS_GLS_KANTHA_CLAYSON) != 0;
-  for (int k = 1; k <= N - 1; k++) {
-    double strat2, shr2;
-    gls_n2s2(a, i, j, k, strat2, shr2);
-    const double tn = KMAX(T[k], Kmin);
-    double gn = KMAX(P[k], Pmin);
-    const double lim = a.fac5 * pow(tn, a.texp4) * pow(sqrt(KMAX(0.0, strat2)) + eps, -gls_n);
-    gn = gls_n >= 0.0 ? KMIN(gn, lim) : KMAX(gn, lim);
-    const double Ls_unlmt = KMAX(eps, pow(gn, a.exp1) * a.cmu_fac1 * pow(tn, -a.texp1));
-    const double Ls_lmt = strat2 > 0.0 ? KMIN(Ls_unlmt, sqrt(0.56 * tn / (KMAX(0.0, strat2) + eps))) : Ls_unlmt;
-    gn = KMAX(a.cmu0p * pow(tn, gls_m) * pow(Ls_lmt, gls_n), Pmin);
-    double Gh = KMIN(a.Gh0, -strat2 * Ls_lmt * Ls_lmt / (2.0 * tn));
-    Gh = KMIN(Gh, Gh - ((Gh - a.Ghcri) * (Gh - a.Ghcri)) / (Gh + a.Gh0 - 2.0 * a.Ghcri));
-    Gh = KMAX(Gh, a.Ghmin);
-    double Sm, Sh;
-    if (canuto) {
-      const double f6 = a.fac6;
-      double Gm = (a.b0 / f6 - a.b1 * Gh + a.b3 * f6 * (Gh * Gh)) / (a.b2 - a.b4 * f6 * Gh);
-      Gm = KMIN(Gm, shr2 * Ls_lmt * Ls_lmt / (2.0 * tn));
-      const double cff = a.b0 - a.b1 * f6 * Gh + a.b2 * f6 * Gm + a.b3 * (f6 * f6) * (Gh * Gh) - a.b4 * (f6 * f6) * Gh * Gm + a.b5 * (f6 * f6) * Gm * Gm;
-      Sm = (a.s0 - a.s1 * f6 * Gh + a.s2 * f6 * Gm) / cff;
-      Sh = (a.s4 - a.s5 * f6 * Gh + a.s6 * f6 * Gm) / cff;
-      Sm = KMAX(Sm, 0.0);
-      Sh = KMAX(Sh, 0.0);
-      Sm = Sm * a.sqrt2 / a.cmu0c;
-      Sh = Sh * a.sqrt2 / a.cmu0c;
-    } else if (kc) {
-      const double cff = 1.0 - a.Sh2 * Gh;
-      Sh = a.Sh1 / cff;
-      Sm = (a.B1pm1o3 + a.Sm4 * Sh * Gh) / (1.0 - a.Sm2 * Gh);
-    } else {
-      const double cff = 1.0 - a.Sh2 * Gh;
-      Sh = a.Sh1 / cff;
-      Sm = (a.Sm3 + Sh * Gh * a.Sm4) / (1.0 - a.Sm2 * Gh);
-    }
-    const double ql = a.sqrt2 * 0.5 * (Ls_lmt * sqrt(tn) + Lscale[XW(i, j, k)] * sqrt(tko[XW(i, j, k)]));
-    const double akv = G.Akv_bak + Sm * ql;
-    Akv[XW(i, j, k)] = akv;
-    for (int it = 0; it < NAT; it++) Akt[XW(i, j, k) + (size_t)it * lev] = G.Akt_bak[it] + Sh * ql;
-    Akk[XW(i, j, k)] = a.Akk_bak + Sm * ql / a.sigk;
-    if (crgban) {
-      const double Pprod = a.c1 * shr2 * akv;
-      const double cff = a.cmu_fac2 * pow(tn, 1.5 + a.texp1) * pow(gn, -1.0 / gls_n);
-      const double cff2 = KMIN(Pprod / cff, 1.0);
-      const double sig_eff = cff2 * a.sigp + (1.0 - cff2) * a.sigp_cb;
-      Akp[XW(i, j, k)] = a.Akp_bak + Sm * ql / sig_eff;
-    } else Akp[XW(i, j, k)] = a.Akp_bak + Sm * ql * a.ogls_sigp;
-    Lscale[XW(i, j, k)] = Ls_lmt;
-    tkn[XW(i, j, k)] = tn;
-    gln[XW(i, j, k)] = gn;
+    T[1] = T[1] - c * gls_fluxb;
+    gln[XW(i, j, 1)] = T[1];
+    for (int k = 2; k <= N - 1; k++) { T[k] = T[k] - CF[k] * T[k - 1]; gln[XW(i, j, k)] = T[k]; }
   }
   tkn[XW(i, j, N)] = tkeN; tkn[XW(i, j, 0)] = tke0;
   gln[XW(i, j, N)] = glsN; gln[XW(i, j, 0)] = gls0;
@@ -379,4 +329,73 @@ THREAD_KERNEL(k_gls_cor, GlsArgs) {
   Akp[XW(i, j, N)] = a.Akp_bak + akvN * a.ogls_sigp; Akp[XW(i, j, 0)] = a.Akp_bak + akv0 / a.sigp;
   for (int it = 0; it < NAT; it++) { Akt[XW(i, j, N) + (size_t)it * lev] = G.Akt_bak[it]; Akt[XW(i, j, 0) + (size_t)it * lev] = G.Akt_bak[it]; }
 }
-THREAD_GLOBAL(k_gls_cor, GlsArgs)
+THREAD_GLOBAL(k_gls_solve, GlsArgs)
+#undef GLS_FCK
+#undef GLS_FCP
+
+// ------------------------------------------------------------------------------ gls_corstep: the mixing coefficients
+// One thread per W-point (i,j,k), k = 1 + gz = 1..N-1 (:1058-1165): limits of tke and gls, the length scale, the stability
+// functions, Akv, Akt, Akk, Akp, Lscale -- six real powers per point, local to it.
+THREAD_KERNEL(k_gls_coef, GlsArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int i = B.Istr + gx, j = B.Jstr + gy, k = 1 + gz, N = G.N, nstp = G.nstp, nnew = G.nnew, NAT = G.NAT;
+  const size_t nij = (size_t)G.nij, lev = nij * (size_t)(N + 1);
+  const int flags = a.flags;
+  const bool crgban = (flags & ROMS_GLS_CRAIG_BANNER) != 0;
+  const bool canuto = (flags & (ROMS_GLS_CANUTO_A | ROMS_GLS_CANUTO_B)) != 0, kc = (flags & ROMS_GLS_KANTHA_CLAYSON) != 0;
+  const double eps = 1.0E-10, Kmin = a.Kmin, Pmin = a.Pmin, gls_m = a.gls_m, gls_n = a.gls_n;
+  const double *tko = F.tke + (size_t)(nstp - 1) * lev;
+  double *tkn = F.tke + (size_t)(nnew - 1) * lev, *gln = F.gls + (size_t)(nnew - 1) * lev;
+  double *Akv = F.Akv, *Akt = F.Akt, *Akk = F.Akk, *Akp = F.Akp, *Lscale = F.Lscale;
+  double strat2, shr2;
+  gls_n2s2(a, i, j, k, strat2, shr2);
+  const double tn = KMAX(tkn[XW(i, j, k)], Kmin);
+  double gn = KMAX(gln[XW(i, j, k)], Pmin);
+  const double lim = a.fac5 * pow(tn, a.texp4) * pow(sqrt(KMAX(0.0, strat2)) + eps, -gls_n);
+  gn = gls_n >= 0.0 ? KMIN(gn, lim) : KMAX(gn, lim);
+  const double Ls_unlmt = KMAX(eps, pow(gn, a.exp1) * a.cmu_fac1 * pow(tn, -a.texp1));
+  const double Ls_lmt = strat2 > 0.0 ? KMIN(Ls_unlmt, sqrt(0.56 * tn / (KMAX(0.0, strat2) + eps))) : Ls_unlmt;
+  gn = KMAX(a.cmu0p * pow(tn, gls_m) * pow(Ls_lmt, gls_n), Pmin);
+  double Gh = KMIN(a.Gh0, -strat2 * Ls_lmt * Ls_lmt / (2.0 * tn));
+  Gh = KMIN(Gh, Gh - ((Gh - a.Ghcri) * (Gh - a.Ghcri)) / (Gh + a.Gh0 - 2.0 * a.Ghcri));
+  Gh = KMAX(Gh, a.Ghmin);
+  double Sm, Sh;
+  if (canuto) {
+    const double f6 = a.fac6;
+    double Gm = (a.b0 / f6 - a.b1 * Gh + a.b3 * f6 * (Gh * Gh)) / (a.b2 - a.b4 * f6 * Gh);
+    Gm = KMIN(Gm, shr2 * Ls_lmt * Ls_lmt / (2.0 * tn));
+    const double cff = a.b0 - a.b1 * f6 * Gh + a.b2 * f6 * Gm + a.b3 * (f6 * f6) * (Gh * Gh) - a.b4 * (f6 * f6) * Gh * Gm + a.b5 * (f6 * f6) * Gm * Gm;
+    Sm = (a.s0 - a.s1 * f6 * Gh + a.s2 * f6 * Gm) / cff;
+    Sh = (a.s4 - a.s5 * f6 * Gh + a.s6 * f6 * Gm) / cff;
+    Sm = KMAX(Sm, 0.0);
+    Sh = KMAX(Sh, 0.0);
+    Sm = Sm * a.sqrt2 / a.cmu0c;
+    Sh = Sh * a.sqrt2 / a.cmu0c;
+  } else if (kc) {
+    const double cff = 1.0 - a.Sh2 * Gh;
+    Sh = a.Sh1 / cff;
+    Sm = (a.B1pm1o3 + a.Sm4 * Sh * Gh) / (1.0 - a.Sm2 * Gh);
+  } else {
+    const double cff = 1.0 - a.Sh2 * Gh;
+    Sh = a.Sh1 / cff;
+    Sm = (a.Sm3 + Sh * Gh * a.Sm4) / (1.0 - a.Sm2 * Gh);
+  }
+  const double ql = a.sqrt2 * 0.5 * (Ls_lmt * sqrt(tn) + Lscale[XW(i, j, k)] * sqrt(tko[XW(i, j, k)]));
+  const double akv = G.Akv_bak + Sm * ql;
+  Akv[XW(i, j, k)] = akv;
+  for (int it = 0; it < NAT; it++) Akt[XW(i, j, k) + (size_t)it * lev] = G.Akt_bak[it] + Sh * ql;
+  Akk[XW(i, j, k)] = a.Akk_bak + Sm * ql / a.sigk;
+  if (crgban) {
+    const double Pprod = a.c1 * shr2 * akv;
+    const double cff = a.cmu_fac2 * pow(tn, 1.5 + a.texp1) * pow(gn, -1.0 / gls_n);
+    const double cff2 = KMIN(Pprod / cff, 1.0);
+    const double sig_eff = cff2 * a.sigp + (1.0 - cff2) * a.sigp_cb;
+    Akp[XW(i, j, k)] = a.Akp_bak + Sm * ql / sig_eff;
+  } else Akp[XW(i, j, k)] = a.Akp_bak + Sm * ql * a.ogls_sigp;
+  Lscale[XW(i, j, k)] = Ls_lmt;
+  tkn[XW(i, j, k)] = tn;
+  gln[XW(i, j, k)] = gn;
+}
+THREAD_GLOBAL(k_gls_coef, GlsArgs)
