@@ -55,6 +55,7 @@ enum {
   ROMS_PLAIN_VVISC = 1 << 18,       /* SPLINES_VVISC is NOT defined: plain tridiagonal vertical viscosity (step3d_uv.F:436-500, :903-967) */
   ROMS_PRSGRD31 = 1 << 19,          /* DJ_GRADPS is NOT defined: the standard density Jacobian prsgrd31.h (prsgrd.F:22-26) */
   ROMS_WJ_GRADP = 1 << 27,          /* ... in its weighted form, prsgrd31.h:232-250 */
+  ROMS_PRSGRD40 = 1 << 26,          /* PJ_GRADP: the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h */
   ROMS_GLS_MIXING = 1 << 25,        /* generic length-scale vertical closure (gls_prestep.F, gls_corstep.F); its compile-time
                                        forms in roms_hip_config.gls_flags, its roms.in parameters beside them */
   ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21,

@@ -46,6 +46,7 @@ enum {
   ORC_PLAIN_VVISC = 1 << 18,
   ORC_PRSGRD31 = 1 << 19,     /* DJ_GRADPS NOT defined: the standard density Jacobian, prsgrd31.h */
   ORC_WJ_GRADP = 1 << 27,     /* ... in its weighted form (Song 1998), prsgrd31.h:232-250 */  /* SPLINES_VVISC NOT defined: plain tridiagonal vertical viscosity (step3d_uv.F:436-500) */
+  ORC_PRSGRD40 = 1 << 26,     /* PJ_GRADP: the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h */
   ORC_GLS_MIXING = 1 << 25,   /* generic length-scale closure: gls_prestep.F, gls_corstep.F (its compile-time forms: cfg.gls_flags) */
   ORC_APP_UPWELLING = 1 << 20, ORC_APP_BENCHMARK = 1 << 21, ORC_APP_KELVIN = 1 << 22, ORC_APP_SEAMOUNT = 1 << 23, ORC_APP_GRAV_ADJ = 1 << 24   /* (no forcing: the default branches of ana_smflux.h ...) */
 };

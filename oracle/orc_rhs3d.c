@@ -480,7 +480,51 @@ static void orc_prsgrd31(orc_t *o, int tile) {
   free(phi);
 }
 
+/* prsgrd40_tile, prsgrd40.h:186-290: finite-volume pressure gradient (Lin 1997), PJ_GRADP */
+static void orc_prsgrd40(orc_t *o, int tile) {
+  ORC_LOCALS(o);
+  const orc_bounds *b = &o->b[tile];
+  const int nrhs = o->s.nrhs;
+  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend, IstrU = b->IstrU, JstrV = b->JstrV;
+  const double g = o->c.g, rho0 = o->c.rho0;
+  double *rho = o->rho, *z_w = o->z_w, *Hz = o->Hz, *ru = o->ru, *rv = o->rv;
+  double *P = (double *)calloc(nij * (size_t)(N + 1), sizeof(double)), *FX = (double *)calloc(nij * (size_t)(N + 1), sizeof(double));
+  double *FC = (double *)calloc(ni * (size_t)(N + 1), sizeof(double));
+  for (int j = JstrV - 1; j <= Jend; j++) {
+    for (int i = IstrU - 1; i <= Iend; i++) P[XW(i, j, N)] = 0.0;
+    for (int k = N; k >= 1; k--)
+      for (int i = IstrU - 1; i <= Iend; i++) {
+        P[XW(i, j, k - 1)] = P[XW(i, j, k)] + Hz[X3(i, j, k)] * rho[X3(i, j, k)];
+        FX[XW(i, j, k)] = 0.5 * Hz[X3(i, j, k)] * (P[XW(i, j, k)] + P[XW(i, j, k - 1)]);
+      }
+    if (j >= Jstr) {
+      for (int i = IstrU; i <= Iend; i++) CX(FC, i, N) = 0.0;
+      const double cff = 0.5 * g, cff1 = g / rho0;
+      for (int k = N; k >= 1; k--)
+        for (int i = IstrU; i <= Iend; i++) {
+          const double dh = z_w[XW(i, j, k - 1)] - z_w[XW(i - 1, j, k - 1)];
+          CX(FC, i, k - 1) = 0.5 * dh * (P[XW(i, j, k - 1)] + P[XW(i - 1, j, k - 1)]);
+          ru[XW4(i, j, k, nrhs)] = (cff * (Hz[X3(i - 1, j, k)] + Hz[X3(i, j, k)]) * (z_w[XW(i - 1, j, N)] - z_w[XW(i, j, N)]) +
+                                    cff1 * (FX[XW(i - 1, j, k)] - FX[XW(i, j, k)] + CX(FC, i, k) - CX(FC, i, k - 1))) * o->on_u[X2(i, j)];
+        }
+    }
+    if (j >= JstrV) {
+      for (int i = Istr; i <= Iend; i++) CX(FC, i, N) = 0.0;
+      const double cff = 0.5 * g, cff1 = g / rho0;
+      for (int k = N; k >= 1; k--)
+        for (int i = Istr; i <= Iend; i++) {
+          const double dh = z_w[XW(i, j, k - 1)] - z_w[XW(i, j - 1, k - 1)];
+          CX(FC, i, k - 1) = 0.5 * dh * (P[XW(i, j, k - 1)] + P[XW(i, j - 1, k - 1)]);
+          rv[XW4(i, j, k, nrhs)] = (cff * (Hz[X3(i, j - 1, k)] + Hz[X3(i, j, k)]) * (z_w[XW(i, j - 1, N)] - z_w[XW(i, j, N)]) +
+                                    cff1 * (FX[XW(i, j - 1, k)] - FX[XW(i, j, k)] + CX(FC, i, k) - CX(FC, i, k - 1))) * o->om_v[X2(i, j)];
+        }
+    }
+  }
+  free(P); free(FX); free(FC);
+}
+
 void orc_prsgrd(orc_t *o, int tile) {
+  if (o->c.options & ORC_PRSGRD40) { orc_prsgrd40(o, tile); return; }
   if (o->c.options & ORC_PRSGRD31) { orc_prsgrd31(o, tile); return; }
   ORC_LOCALS(o);
   const orc_bounds *b = &o->b[tile];

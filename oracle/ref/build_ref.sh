@@ -65,8 +65,8 @@ if [ "$APP" = upwelling_avg_mask ]; then
   UP=UPWELLING; HDR=upwelling_avg_mask; HDRPATH="$HERE/upwelling_avg_mask.h"
   EXTRA="-I$HERE/functionals"
 fi
-if [ "$APP" = upwelling_prs31 ] || [ "$APP" = upwelling_wjgradp ]; then
-  # UPWELLING with the standard density Jacobian prsgrd31.h (no DJ_GRADPS; _wjgradp: WJ_GRADP, its weighted form)
+if [ "$APP" = upwelling_prs31 ] || [ "$APP" = upwelling_wjgradp ] || [ "$APP" = upwelling_prs40 ]; then
+  # UPWELLING with the standard density Jacobian prsgrd31.h (no DJ_GRADPS; _wjgradp: WJ_GRADP, its weighted form); _prs40: PJ_GRADP, prsgrd40.h
   UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
   EXTRA=""
 fi

@@ -129,6 +129,15 @@ def upwelling_logdrag(**kw):
     return cs
 
 
+def upwelling_prs40(**kw):
+    """UPWELLING with the finite-volume pressure Jacobian of Lin (1997) (prsgrd40.h: PJ_GRADP): the custom application
+    header oracle/ref/upwelling_prs40.h"""
+    cs = upwelling(**kw)
+    cs["app"] = "upwelling_prs40"
+    cs["options"] = tuple(cs["options"]) + ("PRSGRD40",)
+    return cs
+
+
 def upwelling_prs31(wj=False, **kw):
     """UPWELLING with the standard density Jacobian (prsgrd31.h: no DJ_GRADPS; wj: WJ_GRADP, the weighted form): the custom
     application headers oracle/ref/upwelling_prs31.h, upwelling_wjgradp.h"""

@@ -118,6 +118,10 @@ int run_prsgrd(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   KArgs a = mk(c);
+  if (G.options & ROMS_PRSGRD40) {     // PJ_GRADP: prsgrd40.h
+    LAUNCH_THREAD(k_prs40, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+    return 0;
+  }
   if (G.options & ROMS_PRSGRD31) {     // no DJ_GRADPS: prsgrd31.h (the reference order of main3d: roms_hip.cpp keeps the late-predictor schedule off)
     LAUNCH_THREAD(k_prs31, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
     return 0;

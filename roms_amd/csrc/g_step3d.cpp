@@ -25,8 +25,10 @@ int run_step3d_uv(roms_hip_ctx *c) {
   const TB &B = G.T;
   const int N = G.N, nnew = G.nnew;
   KArgs a = mk(c);
-  static const char *ech = getenv("ROMS_HIP_COLCH");
+  static const char *ech = getenv("ROMS_HIP_COLCH"), *ereg = getenv("ROMS_HIP_UVREG");
   if (G.options & ROMS_PLAIN_VVISC) LAUNCH_THREAD(k_s3uv_col_p, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);   // without SPLINES_VVISC
+  else if (col_lds(G) && !(ereg && ereg[0] == '0') && N <= 32) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_r32, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
+  else if (col_lds(G) && !(ereg && ereg[0] == '0') && N <= 52) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_r52, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
   else if (col_lds(G) && (ech ? ech[0] == '1' : N > 40)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l10, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
   else if (col_lds(G)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
   else LAUNCH_THREAD(k_s3uv_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);

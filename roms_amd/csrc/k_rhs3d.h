@@ -726,6 +726,36 @@ THREAD_KERNEL(k_prs31, KArgs) {
 }
 THREAD_GLOBAL(k_prs31, KArgs)
 
+// -------------------------------------------------------------------------------- prsgrd40
+// The finite-volume pressure Jacobian of Lin (1997) (prsgrd40.h:186-290; PJ_GRADP): one thread per velocity column,
+// grid.z = 0: ru on (IstrU:Iend, Jstr:Jend), 1: rv on (Istr:Iend, JstrV:Jend); the pressure integrals P of the two
+// columns either side are carried down from the surface (recomputed per direction: no work array).  Not a BASELINE path.
+THREAD_KERNEL(k_prs40, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int dir = gz;
+  const int i = (dir == 0 ? B.IstrU : B.Istr) + gx, j = (dir == 0 ? B.Jstr : B.JstrV) + gy;
+  if (i > B.Iend || j > B.Jend) return;
+  const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1, N = G.N;
+  const double cff = 0.5 * G.g, cff1 = G.g / G.rho0;
+  const double *rho = F.rho, *z_w = F.z_w, *Hz = F.Hz;
+  double *rq = (dir == 0 ? F.ru : F.rv) + (size_t)(G.nrhs - 1) * G.nij * (N + 1);
+  const double omn = (dir == 0 ? F.on_u : F.om_v)[X2(i, j)];
+  const double dzeta = z_w[XW(i - di, j - dj, N)] - z_w[XW(i, j, N)];
+  double Pc = 0.0, Pm = 0.0, FCk = 0.0;          // P(i,j,k), P(i-1,j,k) | P(i,j-1,k); FC(k)
+  for (int k = N; k >= 1; k--) {
+    const double Hc = Hz[X3(i, j, k)], Hm = Hz[X3(i - di, j - dj, k)];
+    const double Pc1 = Pc + Hc * rho[X3(i, j, k)], Pm1 = Pm + Hm * rho[X3(i - di, j - dj, k)];     // level k-1
+    const double FXc = 0.5 * Hc * (Pc + Pc1), FXm = 0.5 * Hm * (Pm + Pm1);
+    const double dh = z_w[XW(i, j, k - 1)] - z_w[XW(i - di, j - dj, k - 1)];
+    const double FC1 = 0.5 * dh * (Pc1 + Pm1);
+    rq[XW(i, j, k)] = (cff * (Hm + Hc) * dzeta + cff1 * (FXm - FXc + FCk - FC1)) * omn;
+    Pc = Pc1; Pm = Pm1; FCk = FC1;
+  }
+}
+THREAD_GLOBAL(k_prs40, KArgs)
+
 // -------------------------------------------------------------------------------- prsgrd32
 // P(i,j,k) into F.wrk3[1]; one thread per column of (IstrU-1:Iend, JstrV-1:Jend)
 THREAD_KERNEL(k_prs_P, KArgs) {

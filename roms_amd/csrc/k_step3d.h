@@ -369,6 +369,118 @@ COL_GLOBAL(k_s3uv_col_l, KArgs)
 COL_KERNEL(k_s3uv_col_l10, KArgs) { k_s3uv_col_lt_body<10>(a, gx, gy, gz, lds); }
 COL_GLOBAL(k_s3uv_col_l10, KArgs)
 
+// The same kernel with the averaged thickness, viscosity and the r.h.s.-stepped velocity of EVERY level kept in registers
+// between the sweeps (all loops unrolled over NMAX >= N levels, chunks of CH for the loads of the up sweep): the down
+// sweep re-reads nothing and the intermediate velocity is never written -- 5 array passes per direction instead of 9.
+// One wave per SIMD (3*NMAX doubles of registers per lane); CF, DC of the elimination stay in LDS as above.
+template <int NMAX, int CH>
+COL_KERNEL(k_s3uv_col_rt, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int dir = gz;
+  const int i = (dir == 0 ? B.IstrU : B.Istr) + gx, j = (dir == 0 ? B.Jstr : B.JstrV) + gy;
+  if (i > B.Iend || j > B.Jend) return;
+  const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1;
+  const int N = G.N, nrhs = G.nrhs, nnew = G.nnew;
+  const double dt = G.dt;
+  double *q = (dir == 0 ? F.u : F.v) + (size_t)(nnew - 1) * G.nij * N;
+  const double *rq = (dir == 0 ? F.ru : F.rv) + (size_t)(nrhs - 1) * G.nij * (N + 1);
+  const double *Akv = F.Akv, *Hz = F.Hz;
+  double *L1 = lds, *L2 = lds + (size_t)(N + 1) * KLS;     // level k at [k * KLS]
+  double cff;
+  if (G.iic == G.ntfirst) cff = 0.25 * dt;
+  else if (G.iic == G.ntfirst + 1) cff = 0.25 * dt * 3.0 / 2.0;
+  else cff = 0.25 * dt * 23.0 / 12.0;
+  const double DC0 = cff * (F.pm[X2(i, j)] + F.pm[X2(i - di, j - dj)]) * (F.pn[X2(i, j)] + F.pn[X2(i - di, j - dj)]);
+  const double c6 = 1.0 / 6.0, c3 = 1.0 / 3.0;
+  constexpr int NCH = (NMAX + CH - 1) / CH;
+  double HZ[NCH * CH + 2], AK[NCH * CH + 2], QQ[NCH * CH + 2];      // level k at [k]; AK: w-level k at [k]
+  double nh0[CH], nh1[CH], nq[CH], nr[CH], na0[CH], na1[CH];
+  // raw values of levels kb .. kb+CH-1 (clamped to N); w-levels kb .. kb+CH-1
+#define S1_LOAD(kb)                                                                                    \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int qi = 0; qi < CH; qi++) {                                                \
+      const int kk = KMIN((kb) + qi, N);                                                               \
+      nh0[qi] = Hz[X3(i - di, j - dj, kk)]; nh1[qi] = Hz[X3(i, j, kk)];                                \
+      nq[qi] = q[X3(i, j, kk)]; nr[qi] = rq[XW(i, j, kk)];                                             \
+      na0[qi] = Akv[XW(i - di, j - dj, kk)]; na1[qi] = Akv[XW(i, j, kk)];                              \
+    }                                                                                                  \
+  } while (0)
+  AK[0] = 0.5 * (Akv[XW(i - di, j - dj, 0)] + Akv[XW(i, j, 0)]);
+  S1_LOAD(1);
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int k0 = 1 + c * CH;
+    if (k0 <= N) {
+#pragma unroll
+      for (int m = 0; m < CH; m++) {
+        HZ[k0 + m] = 0.5 * (nh0[m] + nh1[m]);
+        QQ[k0 + m] = nq[m] + DC0 * nr[m];
+        AK[k0 + m] = 0.5 * (na0[m] + na1[m]);
+      }
+      KSCHED_FENCE();
+      if (k0 + CH <= N) S1_LOAD(k0 + CH);
+      KSCHED_FENCE();
+#pragma unroll
+      for (int m = 0; m < CH; m++) QQ[k0 + m] = QQ[k0 + m] * (1.0 / HZ[k0 + m]);
+    }
+  }
+#undef S1_LOAD
+  {
+    double CFm = 0.0, DCm = 0.0;       // CF(k-1), DC(k-1)
+#pragma unroll
+    for (int k = 1; k <= NMAX; k++) {
+      if (k <= N - 1) {
+        const double Hk = HZ[k], Hk1 = HZ[k + 1], oHk = 1.0 / Hk, oHk1 = 1.0 / Hk1;
+        const double FCk = c6 * Hk - dt * AK[k - 1] * oHk;
+        const double CFk = c6 * Hk1 - dt * AK[k + 1] * oHk1;
+        const double BCk = c3 * (Hk + Hk1) + dt * AK[k] * (oHk + oHk1);
+        const double cf = 1.0 / (BCk - FCk * CFm);
+        CFm = cf * CFk;
+        DCm = cf * (QQ[k + 1] - QQ[k] - FCk * DCm);
+        L1[k * KLS] = CFm;
+        L2[k * KLS] = DCm;
+      }
+    }
+  }
+  {
+    double DCp = 0.0;                  // DC(k+1), final (DC(N) = 0)
+#pragma unroll
+    for (int k = NMAX; k >= 1; k--) {
+      if (k <= N - 1) {
+        const double DCk = L2[k * KLS] - L1[k * KLS] * DCp;
+        const double up = DCp * AK[k + 1], lo = DCk * AK[k];
+        const double c = dt * (1.0 / HZ[k + 1]) * (up - lo);
+        L1[(k + 1) * KLS] = QQ[k + 1] + c;      // CF(k+1), DC(k+1) are consumed: the slots take level k+1
+        L2[(k + 1) * KLS] = HZ[k + 1];
+        DCp = DCk;
+      }
+    }
+    const double c = dt * (1.0 / HZ[1]) * (DCp * AK[1] - 0.0);
+    L1[1 * KLS] = QQ[1] + c;
+    L2[1 * KLS] = HZ[1];
+  }
+  double CF0 = 0.0, DCs = 0.0;
+  _Pragma("unroll 4") for (int k = 1; k <= N; k++) {
+    const double h = L2[k * KLS], v = L1[k * KLS];
+    if (k == 1) { CF0 = h; DCs = v * h; }
+    else { CF0 = CF0 + h; DCs = DCs + v * h; }
+  }
+  const double omn1 = (dir == 0 ? F.on_u : F.om_v)[X2(i, j)];
+  const double Davg = (dir == 0 ? F.DU_avg1 : F.DV_avg1)[X2(i, j)];
+  const double cff1 = 1.0 / (CF0 * omn1);
+  const double corr = (DCs * omn1 - Davg) * cff1;
+  const double qmask = G.masking ? (dir == 0 ? F.umask : F.vmask)[X2(i, j)] : 1.0;   // step3d_uv.F:717,1184
+  const EmitPlan PQ = emit_plan(G, dir == 0 ? BC_U : BC_V, i, j);
+  _Pragma("unroll 4") for (int k = 1; k <= N; k++)
+    emit_store(G, PQ, q + (size_t)(k - 1) * G.nij, G.masking ? (L1[k * KLS] - corr) * qmask : L1[k * KLS] - corr);   // :717; u3dbc/v3dbc :1266
+}
+COL_KERNEL(k_s3uv_col_r32, KArgs) { k_s3uv_col_rt_body<32, 6>(a, gx, gy, gz, lds); }
+COL_GLOBAL(k_s3uv_col_r32, KArgs)
+COL_KERNEL(k_s3uv_col_r52, KArgs) { k_s3uv_col_rt_body<52, 6>(a, gx, gy, gz, lds); }
+COL_GLOBAL(k_s3uv_col_r52, KArgs)
+
 // coupling of 2-D and 3-D momentum, corrected mass fluxes, ubar/vbar(1:2).
 // grid.z = 0: u part on (IstrP:IendT, JstrT:JendT); 1: v part on (IstrT:IendT, Jstr:JendT)
 THREAD_KERNEL(k_s3uv_couple, KArgs) {

@@ -1635,7 +1635,7 @@ static int main3d_one(roms_hip_ctx *c) {
     static const char *elm = getenv("ROMS_HIP_LATE_MASK");
     // (prsgrd31: the late schedule relies on k_prs_grad keeping the previous ru/rv bracket for the deferred predictor)
     if (!c->has_exchange && !uvcol && (!c->G.masking || (elm && elm[0] == '1')) && !(elate && elate[0] == '0') &&
-        !(cf.options & (ROMS_PRSGRD31 | ROMS_GLS_MIXING))) return main3d_late(c, do_diag);   // (GLS: its two routines keep the reference's places)
+        !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_GLS_MIXING))) return main3d_late(c, do_diag);   // (GLS: its two routines keep the reference's places)
   }
   DO(roms_hip_rho_eos(c));                                  // :350
   // Two independent chains follow: set_massflux (:348) -> omega (:534) -> wvelocity (:535), and the

@@ -839,7 +839,7 @@
      &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
      &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D, ROMS_GLS_MIXING ]
 !  options whose code is the only form built (accepted, nothing to select) or that only affect output
-      character(len=16), parameter :: inherent(34) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', &
+      character(len=16), parameter :: inherent(35) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', 'PJ_GRADP', &
      &    'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
      &    'DJ_GRADPS', 'MIX_S_UV', 'MIX_S_TS', 'SPLINES_VDIFF', 'SPLINES_VVISC', 'UV_LDRAG', 'ANA_SMFLUX',        &
      &    'ANA_STFLUX', 'ANA_SSFLUX', 'ANA_BTFLUX', 'ANA_BSFLUX', 'ANA_SRFLUX', 'LMD_RIMIX', 'LMD_CONVEC',        &
@@ -893,10 +893,15 @@
       IF (.not.is_defined('SOLVE3D')) CALL unsupported ('SOLVE3D is required (3-D baroclinic step)', ierr)
 !  the pressure-gradient scheme (prsgrd.F:16-26): DJ_GRADPS -> prsgrd32.h; none of the four options -> prsgrd31.h, WJ_GRADP its
 !  weighted form
-      IF (is_defined('PJ_GRADP').or.is_defined('PJ_GRADPQ2').or.is_defined('PJ_GRADPQ4'))                      &
-     &  CALL unsupported ('PJ_GRADP / PJ_GRADPQ2 / PJ_GRADPQ4 (prsgrd40/42/44.h) are not built', ierr)
-      IF (.not.is_defined('DJ_GRADPS')) options=IOR(options, ROMS_PRSGRD31)
-      IF (.not.is_defined('DJ_GRADPS').and.is_defined('WJ_GRADP')) options=IOR(options, ROMS_WJ_GRADP)
+!  (prsgrd.F tests PJ_GRADPQ4, PJ_GRADPQ2, PJ_GRADP, DJ_GRADPS in this order)
+      IF (is_defined('PJ_GRADPQ2').or.is_defined('PJ_GRADPQ4'))                                                &
+     &  CALL unsupported ('PJ_GRADPQ2 / PJ_GRADPQ4 (prsgrd42/44.h) are not built', ierr)
+      IF (is_defined('PJ_GRADP')) THEN
+        options=IOR(options, ROMS_PRSGRD40)
+      ELSE IF (.not.is_defined('DJ_GRADPS')) THEN
+        options=IOR(options, ROMS_PRSGRD31)
+        IF (is_defined('WJ_GRADP')) options=IOR(options, ROMS_WJ_GRADP)
+      END IF
       IF (COUNT((/ is_defined('UV_LDRAG'), is_defined('UV_QDRAG'), is_defined('UV_LOGDRAG') /)).ne.1)           &
      &  CALL unsupported ('exactly one of UV_LDRAG, UV_QDRAG, UV_LOGDRAG is required', ierr)
 !  every pinned application has momentum advection and harmonic mixing of momentum and tracers compiled in; without them

@@ -33,6 +33,7 @@ CASES = {
     # the standard density Jacobian (prsgrd31.h), plain and weighted (WJ_GRADP)
     "upwelling_prs31_small": ("upwelling_prs31", dict(Lm=14, Mm=18, N=8)),
     "upwelling_wjgradp_small": ("upwelling_wjgradp", dict(Lm=14, Mm=18, N=8, wj=True)),
+    "upwelling_prs40_small": ("upwelling_prs40", dict(Lm=14, Mm=18, N=8)),          # PJ_GRADP, prsgrd40.h
     # the generic length-scale closure: upwelling.h with -DGLS_MIXING, and its other compile-time forms
     "upwelling_gls_small": ("upwelling_gls", dict(Lm=14, Mm=18, N=8)),
     "upwelling_gls_kw_small": ("upwelling_gls", dict(Lm=14, Mm=18, N=8, closure="k-omega")),
@@ -132,7 +133,7 @@ def make_case(tag, **kw):
                 upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
                 upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
                 upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, seamount=cases.seamount, grav_adj=cases.grav_adj, upwelling_prs31=cases.upwelling_prs31,
-                upwelling_wjgradp=cases.upwelling_prs31, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
+                upwelling_wjgradp=cases.upwelling_prs31, upwelling_prs40=cases.upwelling_prs40, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls)[app]
     lbc = k.pop("lbc", None)
     cs = ctor(**k)

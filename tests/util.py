@@ -70,6 +70,8 @@ def case_for(tag, **kw):
         return cases.upwelling_mask(Lm=34, Mm=40, N=6, **kw)
     if tag == "upwelling_prs31_small":
         return cases.upwelling_prs31(Lm=14, Mm=18, N=8, **kw)
+    if tag == "upwelling_prs40_small":
+        return cases.upwelling_prs40(Lm=14, Mm=18, N=8, **kw)
     if tag == "upwelling_wjgradp_small":
         return cases.upwelling_prs31(wj=True, Lm=14, Mm=18, N=8, **kw)
     if tag == "seamount_small":
