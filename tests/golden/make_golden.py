@@ -246,6 +246,7 @@ STEP_CASES = [
     ("grav_adj_small", "grav_adj_small", ["nsteps=100"]),
     # the generic length-scale closure: upwelling.h -DGLS_MIXING (Kantha-Clayson, k-epsilon), Canuto A masked ("gen"),
     # Canuto B with CHARNOK / CRAIG_BANNER / K_C2ADVECTION (k-kl)
+    ("upwelling_small_prs40", "upwelling_prs40_small", ["nsteps=60"]),       # PJ_GRADP, prsgrd40.h
     ("upwelling_gls_small", "upwelling_gls_small", ["nsteps=60"]),
     ("upwelling_gls_ca_small", "upwelling_gls_ca_small", ["nsteps=60"]),
     ("upwelling_gls_cb_small", "upwelling_gls_cb_small", ["nsteps=60"]),

@@ -684,7 +684,7 @@ def hiplib_options():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "upwelling_prs31_small", "upwelling_wjgradp_small"])
+@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "upwelling_prs31_small", "upwelling_wjgradp_small", "upwelling_prs40_small"])
 def test_more_reference_applications_match_oracle(tag):
     """SEAMOUNT and GRAV_ADJ (the reference's own test applications, oracle pinned bit for bit): 40 steps on the GPU at the
     north-star tolerance."""

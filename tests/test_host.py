@@ -193,7 +193,7 @@ def test_masking_option_and_analytic_masks(tmp_path):
 
 
 def test_pressure_gradient_scheme_follows_the_header(tmp_path):
-    """prsgrd.F:16-26: DJ_GRADPS -> prsgrd32.h; none of the options -> prsgrd31.h (WJ_GRADP: weighted); the PJ schemes stop"""
+    """prsgrd.F:16-26: DJ_GRADPS -> prsgrd32.h; none of the options -> prsgrd31.h (WJ_GRADP: weighted); PJ_GRADP -> prsgrd40.h; the quadratic PJ schemes stop"""
     from roms_amd import hiplib, hostlib
     ref = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "oracle", "ref"))
     for hdr, p31, wj in (("upwelling_prs31.h", True, False), ("upwelling_wjgradp.h", True, True), ("upwelling_logdrag.h", False, False)):
@@ -202,6 +202,11 @@ def test_pressure_gradient_scheme_follows_the_header(tmp_path):
             assert bool(H.dims["options"] & hiplib.OPTIONS["PRSGRD31"]) == p31 and bool(H.dims["options"] & hiplib.OPTIONS["WJ_GRADP"]) == wj
         finally:
             H.finalize()
+    H = _setup(tmp_path, header=os.path.join(ref, "upwelling_prs40.h"))          # PJ_GRADP -> prsgrd40.h
+    try:
+        assert H.dims["options"] & hiplib.OPTIONS["PRSGRD40"] and not H.dims["options"] & hiplib.OPTIONS["PRSGRD31"]
+    finally:
+        H.finalize()
     bad = tmp_path / "pj.h"
     bad.write_text(open(os.path.join(ref, "upwelling_prs31.h")).read() + "\n#define PJ_GRADPQ4\n")
     with pytest.raises(hostlib.HostError) as e:
@@ -298,7 +303,7 @@ def test_application_header_is_read_like_cpp_would(tmp_path):
 
 
 @pytest.mark.parametrize("line,needle", [("#define TS_DIF4", "TS_DIF4"), ("#define GLS_MIXING", "GLS_MIXING"),
-                                         ("#define WET_DRY", "WET_DRY"), ("#define PJ_GRADP", "PJ_GRADP"),
+                                         ("#define WET_DRY", "WET_DRY"), ("#define PJ_GRADPQ2", "PJ_GRADPQ2"),
                                          ("#define UV_QDRAG", "exactly one of UV_LDRAG, UV_QDRAG, UV_LOGDRAG")])
 def test_application_header_with_unbuilt_options_stops(tmp_path, line, needle):
     """An option whose code is not in the library (biharmonic mixing, GLS, wetting and drying, another pressure-gradient

@@ -232,6 +232,9 @@ MAIN3D_CASES = [
     ("upwelling_prs31_small", ["nsteps=60"]),
     ("upwelling_wjgradp_small", ["nsteps=60"]),
     ("upwelling_prs31_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h (PJ_GRADP)
+    ("upwelling_prs40_small", ["nsteps=60"]),
+    ("upwelling_prs40_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     # the generic length-scale closure (gls_prestep.F, gls_corstep.F, tkebc_im.F): upwelling.h built with -DGLS_MIXING
     # (Kantha-Clayson, N2S2_HORAVG, RI_SPLINES; k-epsilon and k-omega parameters of roms_upwelling.in), and the other
     # compile-time forms: Canuto A under MASKING ("gen" parameters), Canuto B with K_C2ADVECTION, CHARNOK, CRAIG_BANNER
