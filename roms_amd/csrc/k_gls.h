@@ -29,39 +29,49 @@ struct GlsArgs {
   double Gh0, Ghcri, Ghmin, E2, s0, s1, s2, s4, s5, s6, b0, b1, b2, b3, b4, b5, B1pm1o3, Sh1, Sh2, Sm2, Sm3, Sm4;
 };
 
-// difference of A across the u-point (i,j) (dir 0) or the v-point (dir 1), masked; beyond a physical edge of the domain
-// the value next to it (gls_prestep.F:229-245, gls_corstep.F:524-540)
-KDEV double gls_grad(const DGrid &G, const double *A, int i, int j, int dir) {
+// The horizontal advection of a W-point along one direction (gls_prestep.F:218-302, gls_corstep.F:490-660): the five values
+// A(p-2 .. p+2) of its line are loaded once; from them the masked differences across the four u- (v-) points p-1 .. p+2
+// and the fluxes through the point's two faces.  Beyond a physical edge of the domain the difference next to it is
+// repeated (gls_prestep.F:229-245): grad(Istr-1) = grad(Istr), grad(Iend+2) = grad(Iend+1) -- the values beyond are not read.
+struct GlsEdge { bool lo, hi; double mk[4]; };     // mk: umask | vmask at p-1, p, p+1, p+2 (1 where not needed)
+KDEV GlsEdge gls_edge(const DGrid &G, int i, int j, int dir) {
   const TB &B = G.T;
-  if (dir == 0) {
-    if (!G.ewp) {
-      if (B.west && i == B.Istr - 1) i = B.Istr;
-      if (B.east && i == B.Iend + 2) i = B.Iend + 1;
-    }
-    const double d = A[X2(i, j)] - A[X2(i - 1, j)];
-    return G.masking ? d * G.umask[X2(i, j)] : d;
-  }
-  if (!G.nsp) {
-    if (B.south && j == B.Jstr - 1) j = B.Jstr;
-    if (B.north && j == B.Jend + 2) j = B.Jend + 1;
-  }
-  const double d = A[X2(i, j)] - A[X2(i, j - 1)];
-  return G.masking ? d * G.vmask[X2(i, j)] : d;
-}
-// advective flux of A through the u-point / v-point (i,j) of one level; H2 = the mass flux there (half the sum of the
-// two rho-levels either side).  mode 0: centred second order, 1: centred fourth order, 2: third order upstream
-KDEV double gls_hflux(const DGrid &G, const double *A, double H2, int i, int j, int dir, int mode) {
+  GlsEdge e;
   const int di = dir == 0 ? 1 : 0, dj = 1 - di;
-  const double sum = A[X2(i - di, j - dj)] + A[X2(i, j)];
-  if (mode == 0) return H2 * 0.5 * sum;
+  if (dir == 0) { e.lo = !G.ewp && B.west && i == B.Istr; e.hi = !G.ewp && B.east && i == B.Iend; }
+  else { e.lo = !G.nsp && B.south && j == B.Jstr; e.hi = !G.nsp && B.north && j == B.Jend; }
+  e.mk[0] = e.mk[1] = e.mk[2] = e.mk[3] = 1.0;
+  if (G.masking) {
+    const double *m = dir == 0 ? G.umask : G.vmask;
+    if (!e.lo) e.mk[0] = m[X2(i - di, j - dj)];
+    e.mk[1] = m[X2(i, j)];
+    e.mk[2] = m[X2(i + di, j + dj)];
+    if (!e.hi) e.mk[3] = m[X2(i + 2 * di, j + 2 * dj)];
+  }
+  return e;
+}
+// Flo: through the face between p-1 and p (mass flux Hlo), Fhi: between p and p+1.  mode 0: centred second order,
+// 1: centred fourth order, 2: third order upstream
+KDEV void gls_hflux2(const DGrid &G, const GlsEdge &e, const double *A, double Hlo, double Hhi, int i, int j, int dir, int mode,
+                     double &Flo, double &Fhi) {
+  const int di = dir == 0 ? 1 : 0, dj = 1 - di;
+  const double am1 = A[X2(i - di, j - dj)], a0 = A[X2(i, j)], ap1 = A[X2(i + di, j + dj)];
+  const double slo = am1 + a0, shi = a0 + ap1;
+  if (mode == 0) { Flo = Hlo * 0.5 * slo; Fhi = Hhi * 0.5 * shi; return; }
+  const double am2 = e.lo ? am1 : A[X2(i - 2 * di, j - 2 * dj)], ap2 = e.hi ? ap1 : A[X2(i + 2 * di, j + 2 * dj)];
+  double gm1 = am1 - am2, g0 = a0 - am1, gp1 = ap1 - a0, gp2 = ap2 - ap1;
+  if (G.masking) { gm1 = gm1 * e.mk[0]; g0 = g0 * e.mk[1]; gp1 = gp1 * e.mk[2]; gp2 = gp2 * e.mk[3]; }
+  if (e.lo) gm1 = g0;
+  if (e.hi) gp2 = gp1;
   if (mode == 1) {
     const double cff = 1.0 / 6.0;
-    return H2 * 0.5 * (sum - cff * (gls_grad(G, A, i + di, j + dj, dir) - gls_grad(G, A, i - di, j - dj, dir)));
+    Flo = Hlo * 0.5 * (slo - cff * (gp1 - gm1));
+    Fhi = Hhi * 0.5 * (shi - cff * (gp2 - g0));
+    return;
   }
   const double Gadv = 1.0 / 3.0;
-  const double g0 = gls_grad(G, A, i, j, dir);
-  const double curv = H2 > 0.0 ? g0 - gls_grad(G, A, i - di, j - dj, dir) : gls_grad(G, A, i + di, j + dj, dir) - g0;
-  return H2 * 0.5 * (sum - Gadv * curv);
+  Flo = Hlo * 0.5 * (slo - Gadv * (Hlo > 0.0 ? g0 - gm1 : gp1 - g0));
+  Fhi = Hhi * 0.5 * (shi - Gadv * (Hhi > 0.0 ? gp1 - g0 : gp2 - gp1));
 }
 // vertical advective flux of the W-point column A (A[k * nij]: level k) through the rho-level k; CF = the velocity there
 KDEV double gls_vflux(const double *A, size_t nij, double CF, int k, int N, bool c2) {
@@ -96,10 +106,12 @@ THREAD_KERNEL(k_gls_pre, GlsArgs) {
   const double *tkk = tk + (size_t)k * nij, *glk = gl + (size_t)k * nij;
   const double XF0 = 0.5 * (Huon[X3(i, j, k)] + Huon[X3(i, j, k + 1)]), XF1 = 0.5 * (Huon[X3(i + 1, j, k)] + Huon[X3(i + 1, j, k + 1)]);
   const double EF0 = 0.5 * (Hvom[X3(i, j, k)] + Hvom[X3(i, j, k + 1)]), EF1 = 0.5 * (Hvom[X3(i, j + 1, k)] + Hvom[X3(i, j + 1, k + 1)]);
-  const double FX0 = gls_hflux(G, tkk, XF0, i, j, 0, mode), FX1 = gls_hflux(G, tkk, XF1, i + 1, j, 0, mode);
-  const double FE0 = gls_hflux(G, tkk, EF0, i, j, 1, mode), FE1 = gls_hflux(G, tkk, EF1, i, j + 1, 1, mode);
-  const double LX0 = gls_hflux(G, glk, XF0, i, j, 0, mode), LX1 = gls_hflux(G, glk, XF1, i + 1, j, 0, mode);
-  const double LE0 = gls_hflux(G, glk, EF0, i, j, 1, mode), LE1 = gls_hflux(G, glk, EF1, i, j + 1, 1, mode);
+  const GlsEdge ex = gls_edge(G, i, j, 0), ee = gls_edge(G, i, j, 1);
+  double FX0, FX1, FE0, FE1, LX0, LX1, LE0, LE1;
+  gls_hflux2(G, ex, tkk, XF0, XF1, i, j, 0, mode, FX0, FX1);
+  gls_hflux2(G, ee, tkk, EF0, EF1, i, j, 1, mode, FE0, FE1);
+  gls_hflux2(G, ex, glk, XF0, XF1, i, j, 0, mode, LX0, LX1);
+  gls_hflux2(G, ee, glk, EF0, EF1, i, j, 1, mode, LE0, LE1);
   const double cff = 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j, k + 1)]);
   double Hzh = cff - cff4 * (XF1 - XF0 + EF1 - EF0);                                   // :318-335
   double t3 = cff * (cff1 * tkk[X2(i, j)] + cff2 * tki[XW(i, j, k)]) - cff4 * (FX1 - FX0 + FE1 - FE0);
@@ -203,10 +215,12 @@ THREAD_KERNEL(k_gls_adv, GlsArgs) {
   const double *tkk = tk3 + (size_t)k * nij, *glk = gl3 + (size_t)k * nij;
   const double XF0 = 0.5 * (Huon[X3(i, j, k)] + Huon[X3(i, j, k + 1)]), XF1 = 0.5 * (Huon[X3(i + 1, j, k)] + Huon[X3(i + 1, j, k + 1)]);
   const double EF0 = 0.5 * (Hvom[X3(i, j, k)] + Hvom[X3(i, j, k + 1)]), EF1 = 0.5 * (Hvom[X3(i, j + 1, k)] + Hvom[X3(i, j + 1, k + 1)]);
-  const double FXK0 = gls_hflux(G, tkk, XF0, i, j, 0, mode), FXK1 = gls_hflux(G, tkk, XF1, i + 1, j, 0, mode);
-  const double FEK0 = gls_hflux(G, tkk, EF0, i, j, 1, mode), FEK1 = gls_hflux(G, tkk, EF1, i, j + 1, 1, mode);
-  const double FXP0 = gls_hflux(G, glk, XF0, i, j, 0, mode), FXP1 = gls_hflux(G, glk, XF1, i + 1, j, 0, mode);
-  const double FEP0 = gls_hflux(G, glk, EF0, i, j, 1, mode), FEP1 = gls_hflux(G, glk, EF1, i, j + 1, 1, mode);
+  const GlsEdge ex = gls_edge(G, i, j, 0), ee = gls_edge(G, i, j, 1);
+  double FXK0, FXK1, FEK0, FEK1, FXP0, FXP1, FEP0, FEP1;
+  gls_hflux2(G, ex, tkk, XF0, XF1, i, j, 0, mode, FXK0, FXK1);
+  gls_hflux2(G, ee, tkk, EF0, EF1, i, j, 1, mode, FEK0, FEK1);
+  gls_hflux2(G, ex, glk, XF0, XF1, i, j, 0, mode, FXP0, FXP1);
+  gls_hflux2(G, ee, glk, EF0, EF1, i, j, 1, mode, FEP0, FEP1);
   double t = tkn[XW(i, j, k)] - pmn * (FXK1 - FXK0 + FEK1 - FEK0);                     // :664-678
   t = KMAX(t, Kmin);
   double p = gln[XW(i, j, k)] - pmn * (FXP1 - FXP0 + FEP1 - FEP0);
