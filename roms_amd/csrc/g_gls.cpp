@@ -2,6 +2,7 @@
 // gls_corstep (main3d.F:1021); the closure's derived constants (gls_corstep.F:250-340, mod_scalars.F:4715-4766).
 #include "roms_host.h"
 #include <cmath>
+#include <cstdlib>
 #include "k_gls.h"
 
 static GlsArgs gls_args(roms_hip_ctx *c) {
@@ -99,7 +100,10 @@ int run_gls_corstep(roms_hip_ctx *c) {
   const GlsArgs a = gls_args(c);
   LAUNCH_THREAD(k_gls_shear, B.Iendp1 - B.Istrm1 + 1, B.Jendp1 - B.Jstrm1 + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_gls_adv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
-  LAUNCH_THREAD(k_gls_solve, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  static const char *ecl = getenv("ROMS_HIP_COLLDS");
+  if (!(ecl && ecl[0] == '0') && (size_t)2 * (G.N + 1) * 64 * sizeof(double) < 64 * 1024)
+    LAUNCH_COL(k_gls_solve_l, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, 2 * (G.N + 1), c->stream, a);
+  else LAUNCH_THREAD(k_gls_solve, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_gls_coef, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
   const size_t lev = (size_t)G.nij * (size_t)(G.N + 1);
   HaloSpec sp[4] = {{c->F.tke + (size_t)(G.nnew - 1) * lev, G.N + 1, bc_rstate(c), 'r'},

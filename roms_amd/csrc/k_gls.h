@@ -271,8 +271,8 @@ THREAD_GLOBAL(k_gls_adv, GlsArgs)
 // second one's surface and bottom fluxes need the SOLVED tke), each eliminated from the top down and substituted back
 // upwards in private memory; the solved columns go back into tke, gls(nnew), the end values of the five coefficient
 // arrays are set (:1167-1180).  No real powers inside the sweeps.
-THREAD_KERNEL(k_gls_solve, GlsArgs) {
-  (void)gz;
+template <int TS>
+KDEV void gls_solve_body(const GlsArgs &a, int gx, int gy, double *T, double *CF) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB &B = G.T;
@@ -284,7 +284,6 @@ THREAD_KERNEL(k_gls_solve, GlsArgs) {
   const double *Hz = F.Hz, *BCK = F.wrk3[0], *BCP = F.wrk3[1];
   double *tkn = F.tke + (size_t)(nnew - 1) * lev, *gln = F.gls + (size_t)(nnew - 1) * lev;
   double *Akv = F.Akv, *Akt = F.Akt, *Akk = F.Akk, *Akp = F.Akp;
-  double T[ROMS_NPRIV], CF[ROMS_NPRIV];
   const double su = F.sustr[X2(i, j)] + F.sustr[X2(i + 1, j)], sv = F.svstr[X2(i, j)] + F.svstr[X2(i, j + 1)];
   const double bu_ = F.bustr[X2(i, j)] + F.bustr[X2(i + 1, j)], bv_ = F.bvstr[X2(i, j)] + F.bvstr[X2(i, j + 1)];
   const double sstr = 0.5 * sqrt(su * su + sv * sv), bstr = 0.5 * sqrt(bu_ * bu_ + bv_ * bv_);
@@ -298,42 +297,42 @@ THREAD_KERNEL(k_gls_solve, GlsArgs) {
   {   // tke :959-990
     double FCK1 = GLS_FCK(N - 1);
     double c = 1.0 / BCK[XW(i, j, N - 1)];
-    CF[N - 1] = c * FCK1;
-    T[N - 1] = c * (tkn[XW(i, j, N - 1)] + tke_fluxt);
+    CF[(N - 1) * TS] = c * FCK1;
+    T[(N - 1) * TS] = c * (tkn[XW(i, j, N - 1)] + tke_fluxt);
     for (int k = N - 2; k >= 1; k--) {
       const double FCKk = GLS_FCK(k);
-      c = 1.0 / (BCK[XW(i, j, k)] - CF[k + 1] * FCK1);
-      CF[k] = c * FCKk;
-      T[k] = c * (tkn[XW(i, j, k)] - FCK1 * T[k + 1]);
+      c = 1.0 / (BCK[XW(i, j, k)] - CF[(k + 1) * TS] * FCK1);
+      CF[(k) * TS] = c * FCKk;
+      T[(k) * TS] = c * (tkn[XW(i, j, k)] - FCK1 * T[(k + 1) * TS]);
       FCK1 = FCKk;
     }
-    tkn[XW(i, j, 1)] = T[1];
-    for (int k = 2; k <= N - 1; k++) { T[k] = T[k] - CF[k] * T[k - 1]; tkn[XW(i, j, k)] = T[k]; }
+    tkn[XW(i, j, 1)] = T[(1) * TS];
+    for (int k = 2; k <= N - 1; k++) { T[(k) * TS] = T[(k) * TS] - CF[(k) * TS] * T[(k - 1) * TS]; tkn[XW(i, j, k)] = T[(k) * TS]; }
   }
   {   // gls :994-1050
-    double cff = 0.5 * (tkeN + T[N - 1]);
+    double cff = 0.5 * (tkeN + T[(N - 1) * TS]);
     double gls_fluxt = dt * a.fac3 * pow(cff, gls_m) * pow(a.L_sft, gls_n) * pow(Zos_eff + 0.5 * Hz[X3(i, j, N)], gls_n - 1.0) *
                        0.5 * (Akp[XW(i, j, N)] + Akp[XW(i, j, N - 1)]);
     if (crgban)
       gls_fluxt = gls_fluxt - dt * gls_m * a.cmu0p * pow(cff, gls_m - 1.0) * pow((Zos_eff + 0.5 * Hz[X3(i, j, N)]) * a.L_sft, gls_n) *
                                   a.sigk * a.ogls_sigp * a.crgban_cw * pow(sstr, 1.5);
-    cff = 0.5 * (tke0 + T[1]);
+    cff = 0.5 * (tke0 + T[(1) * TS]);
     const double gls_fluxb = dt * a.fac2 * pow(cff, gls_m) * pow(0.5 * Hz[X3(i, j, 1)] + a.Zob_min, gls_n - 1.0) *
                              0.5 * (Akp[XW(i, j, 0)] + Akp[XW(i, j, 1)]);
     double FCP1 = GLS_FCP(N - 1);
     double c = 1.0 / BCP[XW(i, j, N - 1)];
-    CF[N - 1] = c * FCP1;
-    T[N - 1] = c * (gln[XW(i, j, N - 1)] - gls_fluxt);
+    CF[(N - 1) * TS] = c * FCP1;
+    T[(N - 1) * TS] = c * (gln[XW(i, j, N - 1)] - gls_fluxt);
     for (int k = N - 2; k >= 1; k--) {
       const double FCPk = GLS_FCP(k);
-      c = 1.0 / (BCP[XW(i, j, k)] - CF[k + 1] * FCP1);
-      CF[k] = c * FCPk;
-      T[k] = c * (gln[XW(i, j, k)] - FCP1 * T[k + 1]);
+      c = 1.0 / (BCP[XW(i, j, k)] - CF[(k + 1) * TS] * FCP1);
+      CF[(k) * TS] = c * FCPk;
+      T[(k) * TS] = c * (gln[XW(i, j, k)] - FCP1 * T[(k + 1) * TS]);
       FCP1 = FCPk;
     }
-    T[1] = T[1] - c * gls_fluxb;
-    gln[XW(i, j, 1)] = T[1];
-    for (int k = 2; k <= N - 1; k++) { T[k] = T[k] - CF[k] * T[k - 1]; gln[XW(i, j, k)] = T[k]; }
+    T[(1) * TS] = T[(1) * TS] - c * gls_fluxb;
+    gln[XW(i, j, 1)] = T[(1) * TS];
+    for (int k = 2; k <= N - 1; k++) { T[(k) * TS] = T[(k) * TS] - CF[(k) * TS] * T[(k - 1) * TS]; gln[XW(i, j, k)] = T[(k) * TS]; }
   }
   tkn[XW(i, j, N)] = tkeN; tkn[XW(i, j, 0)] = tke0;
   gln[XW(i, j, N)] = glsN; gln[XW(i, j, 0)] = gls0;
@@ -343,7 +342,19 @@ THREAD_KERNEL(k_gls_solve, GlsArgs) {
   Akp[XW(i, j, N)] = a.Akp_bak + akvN * a.ogls_sigp; Akp[XW(i, j, 0)] = a.Akp_bak + akv0 / a.sigp;
   for (int it = 0; it < NAT; it++) { Akt[XW(i, j, N) + (size_t)it * lev] = G.Akt_bak[it]; Akt[XW(i, j, 0) + (size_t)it * lev] = G.Akt_bak[it]; }
 }
+// the sweeps in private memory (any N) ...
+THREAD_KERNEL(k_gls_solve, GlsArgs) {
+  (void)gz;
+  double T[ROMS_NPRIV], CF[ROMS_NPRIV];
+  gls_solve_body<1>(a, gx, gy, T, CF);
+}
 THREAD_GLOBAL(k_gls_solve, GlsArgs)
+// ... or in LDS, 2*(N+1) doubles per column (COL launch, as k_s3uv_col_l)
+COL_KERNEL(k_gls_solve_l, GlsArgs) {
+  (void)gz;
+  gls_solve_body<KLS>(a, gx, gy, lds, lds + (size_t)(a.G.N + 1) * KLS);
+}
+COL_GLOBAL(k_gls_solve_l, GlsArgs)
 #undef GLS_FCK
 #undef GLS_FCP
 
