@@ -56,6 +56,9 @@ enum {
   ROMS_PRSGRD31 = 1 << 19,          /* DJ_GRADPS is NOT defined: the standard density Jacobian prsgrd31.h (prsgrd.F:22-26) */
   ROMS_WJ_GRADP = 1 << 27,          /* ... in its weighted form, prsgrd31.h:232-250 */
   ROMS_PRSGRD40 = 1 << 26,          /* PJ_GRADP: the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h */
+  ROMS_MY25_MIXING = 1 << 28,       /* Mellor-Yamada level 2.5 closure (my25_prestep.F, my25_corstep.F): the entries roms_hip_gls_prestep /
+                                       _corstep run it; KANTHA_CLAYSON, N2S2_HORAVG, RI_SPLINES, K_C2/K_C4ADVECTION in gls_flags; GLS_Kmin, GLS_Pmin
+                                       (start values) and AKK_BAK from the same roms.in block */
   ROMS_GLS_MIXING = 1 << 25,        /* generic length-scale vertical closure (gls_prestep.F, gls_corstep.F); its compile-time
                                        forms in roms_hip_config.gls_flags, its roms.in parameters beside them */
   ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21,
@@ -189,8 +192,8 @@ int roms_hip_step3d_uv(roms_hip_ctx *ctx);     /* step3d_uv      step3d_uv.F:40 
 int roms_hip_step3d_t(roms_hip_ctx *ctx);      /* step3d_t       step3d_t.F:40       */
 int roms_hip_lmd_vmix(roms_hip_ctx *ctx);      /* lmd_vmix       lmd_vmix.F:45       */
 int roms_hip_bulk_flux(roms_hip_ctx *ctx);     /* bulk_flux      bulk_flux.F:100     */
-int roms_hip_gls_prestep(roms_hip_ctx *ctx);   /* gls_prestep    gls_prestep.F:42  (main3d.F:636, behind rhs3d)  */
-int roms_hip_gls_corstep(roms_hip_ctx *ctx);   /* gls_corstep    gls_corstep.F:52  (main3d.F:1021, behind omega) */
+int roms_hip_gls_prestep(roms_hip_ctx *ctx);   /* gls_prestep    gls_prestep.F:42  (main3d.F:636, behind rhs3d); MY25_MIXING: my25_prestep.F:42 (:634)  */
+int roms_hip_gls_corstep(roms_hip_ctx *ctx);   /* gls_corstep    gls_corstep.F:52  (main3d.F:1021, behind omega); MY25_MIXING: my25_corstep.F:52 (:1019) */
 /* diag diag.F:30 -- synchronises; out must hold 16 doubles: out[0..11] = avgke avgpe avgkp volume
    maxspeed max_Cu max_Cv max_Cw max_Ci max_Cj max_Ck max_C of this context's tile, out[12..13] =
    the un-normalised kinetic / potential energy sums (a multi-tile caller adds out[3], out[12],

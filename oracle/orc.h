@@ -47,6 +47,8 @@ enum {
   ORC_PRSGRD31 = 1 << 19,     /* DJ_GRADPS NOT defined: the standard density Jacobian, prsgrd31.h */
   ORC_WJ_GRADP = 1 << 27,     /* ... in its weighted form (Song 1998), prsgrd31.h:232-250 */  /* SPLINES_VVISC NOT defined: plain tridiagonal vertical viscosity (step3d_uv.F:436-500) */
   ORC_PRSGRD40 = 1 << 26,     /* PJ_GRADP: the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h */
+  ORC_MY25_MIXING = 1 << 28,  /* Mellor-Yamada level 2.5 closure: my25_prestep.F, my25_corstep.F (options KANTHA_CLAYSON, N2S2_HORAVG,
+                                 RI_SPLINES, K_C2ADVECTION | K_C4ADVECTION in cfg.gls_flags; start values GLS_Kmin, GLS_Pmin; AKK_BAK) */
   ORC_GLS_MIXING = 1 << 25,   /* generic length-scale closure: gls_prestep.F, gls_corstep.F (its compile-time forms: cfg.gls_flags) */
   ORC_APP_UPWELLING = 1 << 20, ORC_APP_BENCHMARK = 1 << 21, ORC_APP_KELVIN = 1 << 22, ORC_APP_SEAMOUNT = 1 << 23, ORC_APP_GRAV_ADJ = 1 << 24   /* (no forcing: the default branches of ana_smflux.h ...) */
 };
@@ -237,6 +239,8 @@ void orc_lmd_vmix(orc_t *o, int tile);
 void orc_bulk_flux(orc_t *o, int tile);
 void orc_gls_prestep(orc_t *o, int tile);
 void orc_gls_corstep(orc_t *o, int tile);
+void orc_my25_prestep(orc_t *o, int tile);
+void orc_my25_corstep(orc_t *o, int tile);
 void orc_mpdata_adiff(orc_t *o, int tile, int itrc, const double *Ta, double *Ua, double *Va,
                       double *Wa, const double *oHz);
 

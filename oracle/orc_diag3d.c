@@ -131,7 +131,7 @@ void orc_rho_eos(orc_t *o, int tile) {
       rhoA[X2(i, j)] = cff2 * cff1 * rhoA[X2(i, j)];
       rhoS[X2(i, j)] = 2.0 * cff1 * cff1 * cff2 * rhoS[X2(i, j)];
     }
-    if (o->c.options & (ORC_LMD_MIXING | ORC_GLS_MIXING)) {
+    if (o->c.options & (ORC_LMD_MIXING | ORC_GLS_MIXING | ORC_MY25_MIXING)) {
       /* BV_FREQUENCY (LMD_MIXING, GLS_MIXING: globaldefs.h) :751-764 of the linear EOS */
       const double gorho0 = o->c.g / o->c.rho0;
       for (int k = 1; k <= N - 1; k++)
@@ -155,7 +155,7 @@ void orc_rho_eos(orc_t *o, int tile) {
   }
   orc_exchange2d(o, b, 'r', rhoA);
   orc_exchange2d(o, b, 'r', rhoS);
-  if (o->c.options & (ORC_LMD_MIXING | ORC_GLS_MIXING)) orc_exchange3d(o, b, 'w', o->bvf, N + 1);
+  if (o->c.options & (ORC_LMD_MIXING | ORC_GLS_MIXING | ORC_MY25_MIXING)) orc_exchange3d(o, b, 'w', o->bvf, N + 1);
 }
 
 /* --------------------------------------------------------------- set_vbc */

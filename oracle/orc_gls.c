@@ -230,8 +230,95 @@ void orc_gls_prestep(orc_t *o, int tile) {
   free(Hz_half); free(p2); free(CF);
 }
 
-/* gls_corstep_tile, gls_corstep.F:114 */
-void orc_gls_corstep(orc_t *o, int tile) {
+#define TK(i, j, k, n) tke[XW4(i, j, k, n)]
+#define GL(i, j, k, n) gls[XW4(i, j, k, n)]
+#define SH(i, j, k) shear2[XW(i, j, k)]
+#define BU(i, j, k) buoy2[XW(i, j, k)]
+/* my25_corstep.F:585-750 for one row j: vertical mixing of the turbulent fields, production, dissipation, the two
+   tridiagonal systems (boundary values inside them), length scale, stability functions, Akv, Akt, Akk, Lscale */
+static void my25_column(orc_t *o, const orc_bounds *b, int j, const double *shear2, const double *buoy2, double *BCK, double *BCP,
+                        double *CF, double *FCK) {
+  ORC_LOCALS(o);
+  const orc_cfg *c = &o->c;
+  const int Istr = b->Istr, Iend = b->Iend, NAT = c->NAT, nstp = o->s.nstp, nnew = o->s.nnew;
+  const int kc = (c->gls_flags & ORC_GLS_KANTHA_CLAYSON) != 0;
+  const double eps = 1.0E-10, vonKar = 0.41, dt = c->dt;
+  const double my_B1 = 16.6, my_E1 = 1.8, my_E2 = 1.33, my_Gh0 = 0.0233, my_Sq = 0.2, my_lmax = 0.53, my_qmin = 1.0E-8;
+  const double my_B1p2o3 = pow(my_B1, 2.0 / 3.0);
+  gls_consts q;
+  orc_gls_consts(c->gls_flags, &q);
+  double *tke = o->tke, *gls = o->gls, *Akv = o->Akv, *Akt = o->Akt, *Akk = o->Akk, *Lscale = o->Lscale;
+  const double *Hz = o->Hz, *z_w = o->z_w, *sustr = o->sustr, *svstr = o->svstr, *bustr = o->bustr, *bvstr = o->bvstr;
+  {
+    const double cff = -0.5 * dt;
+    for (int k = 1; k <= N; k++)
+      for (int i = Istr; i <= Iend; i++) {
+        CX(FCK, i, k) = cff * (Akk[XW(i, j, k)] + Akk[XW(i, j, k - 1)]) / Hz[X3(i, j, k)];
+        CX(CF, i, k) = 0.0;
+      }
+  }
+  const double cff3 = my_E2 / (vonKar * vonKar);
+  for (int k = 1; k <= N - 1; k++)
+    for (int i = Istr; i <= Iend; i++) {
+      const double bu = BU(i, j, k);
+      const double strat2 = (bu > -5.0E-5 && bu < 0.0) ? 0.0 : bu;
+      const double Qprod = SH(i, j, k) * (Akv[XW(i, j, k)] - c->Akv_bak) - strat2 * (Akt[XW4(i, j, k, 1)] - c->Akt_bak[0]);
+      const double Ls_unlmt = MAX(eps, GL(i, j, k, nstp) / (MAX(TK(i, j, k, nstp), eps)));
+      const double cff1 = 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j, k + 1)]);
+      TK(i, j, k, nnew) = TK(i, j, k, nnew) + dt * cff1 * Qprod * 2.0;
+      GL(i, j, k, nnew) = GL(i, j, k, nnew) + dt * cff1 * Qprod * my_E1 * Ls_unlmt;
+      const double Qdiss = dt * sqrt(TK(i, j, k, nstp)) / (my_B1 * Ls_unlmt);
+      const double cff = Ls_unlmt * (1.0 / (z_w[XW(i, j, N)] - z_w[XW(i, j, k)]) + 1.0 / (z_w[XW(i, j, k)] - z_w[XW(i, j, 0)]));
+      const double Wscale = 1.0 + cff3 * cff * cff;
+      CX(BCK, i, k) = cff1 * (1.0 + 2.0 * Qdiss) - CX(FCK, i, k) - CX(FCK, i, k + 1);
+      CX(BCP, i, k) = cff1 * (1.0 + Wscale * Qdiss) - CX(FCK, i, k) - CX(FCK, i, k + 1);
+    }
+  for (int i = Istr; i <= Iend; i++) {
+    TK(i, j, N, nnew) = my_B1p2o3 * 0.5 * sqrt((sustr[X2(i, j)] + sustr[X2(i + 1, j)]) * (sustr[X2(i, j)] + sustr[X2(i + 1, j)]) +
+                                               (svstr[X2(i, j)] + svstr[X2(i, j + 1)]) * (svstr[X2(i, j)] + svstr[X2(i, j + 1)]));
+    GL(i, j, N, nnew) = 0.0;
+    TK(i, j, 0, nnew) = my_B1p2o3 * 0.5 * sqrt((bustr[X2(i, j)] + bustr[X2(i + 1, j)]) * (bustr[X2(i, j)] + bustr[X2(i + 1, j)]) +
+                                               (bvstr[X2(i, j)] + bvstr[X2(i, j + 1)]) * (bvstr[X2(i, j)] + bvstr[X2(i, j + 1)]));
+    GL(i, j, 0, nnew) = 0.0;
+  }
+  for (int f = 0; f < 2; f++) {          /* the tke system with BCK, the gls system with BCP; both with FCK */
+    double *A = (f == 0 ? tke : gls) + (size_t)(nnew - 1) * nij * (N + 1);
+    const double *BC = f == 0 ? BCK : BCP;
+    for (int i = Istr; i <= Iend; i++) {
+      const double cff = 1.0 / CX(BC, i, N - 1);
+      CX(CF, i, N - 1) = cff * CX(FCK, i, N - 1);
+      A[XW(i, j, N - 1)] = cff * (A[XW(i, j, N - 1)] - CX(FCK, i, N) * A[XW(i, j, N)]);
+    }
+    for (int k = N - 2; k >= 1; k--)
+      for (int i = Istr; i <= Iend; i++) {
+        const double cff = 1.0 / (CX(BC, i, k) - CX(CF, i, k + 1) * CX(FCK, i, k + 1));
+        CX(CF, i, k) = cff * CX(FCK, i, k);
+        A[XW(i, j, k)] = cff * (A[XW(i, j, k)] - CX(FCK, i, k + 1) * A[XW(i, j, k + 1)]);
+      }
+    for (int k = 1; k <= N - 1; k++)
+      for (int i = Istr; i <= Iend; i++) A[XW(i, j, k)] = A[XW(i, j, k)] - CX(CF, i, k) * A[XW(i, j, k - 1)];
+  }
+  for (int k = 1; k <= N - 1; k++)
+    for (int i = Istr; i <= Iend; i++) {
+      TK(i, j, k, nnew) = MAX(TK(i, j, k, nnew), my_qmin);
+      GL(i, j, k, nnew) = MAX(GL(i, j, k, nnew), my_qmin);
+      const double Ls_unlmt = GL(i, j, k, nnew) / TK(i, j, k, nnew);
+      const double Ls_lmt = MIN(Ls_unlmt, my_lmax * sqrt(TK(i, j, k, nnew) / (MAX(0.0, BU(i, j, k)) + eps)));
+      const double Gh = MIN(my_Gh0, -BU(i, j, k) * Ls_lmt * Ls_lmt / TK(i, j, k, nnew));
+      const double cff = 1.0 - q.my_Sh2 * Gh;
+      const double Sh = q.my_Sh1 / cff;
+      const double Sm = kc ? (q.my_B1pm1o3 + Sh * Gh * q.my_Sm4) / (1.0 - q.my_Sm2 * Gh) : (q.my_Sm3 + Sh * Gh * q.my_Sm4) / (1.0 - q.my_Sm2 * Gh);
+      const double ql = 0.5 * (Ls_lmt * sqrt(TK(i, j, k, nnew)) + Lscale[XW(i, j, k)] * sqrt(TK(i, j, k, nstp)));
+      Akv[XW(i, j, k)] = c->Akv_bak + ql * Sm;
+      for (int it = 1; it <= NAT; it++) Akt[XW4(i, j, k, it)] = c->Akt_bak[it - 1] + ql * Sh;
+      Akk[XW(i, j, k)] = c->Akk_bak + ql * my_Sq;
+      Lscale[XW(i, j, k)] = Ls_lmt;
+    }
+}
+
+/* gls_corstep_tile, gls_corstep.F:114; my25: my25_corstep_tile, my25_corstep.F:114 (the same shear, smoothing and
+   advection code; its own production / dissipation, boundary values, stability functions and edge copies) */
+static void corstep(orc_t *o, int tile, int my25) {
   ORC_LOCALS(o);
   const orc_bounds *b = &o->b[tile];
   const orc_cfg *c = &o->c;
@@ -286,10 +373,6 @@ void orc_gls_corstep(orc_t *o, int tile) {
   const double gls_fac5 = pow(0.56, 0.5 * gls_n) * pow(gls_cmu0, gls_p);
   const double gls_fac6 = 8.0 / pow(gls_cmu0, 6.0);
   const double gls_exp1 = 1.0 / gls_n, tke_exp1 = gls_m / gls_n, tke_exp2 = 0.5 + gls_m / gls_n, tke_exp4 = gls_m + 0.5 * gls_n;
-#define TK(i, j, k, n) tke[XW4(i, j, k, n)]
-#define GL(i, j, k, n) gls[XW4(i, j, k, n)]
-#define SH(i, j, k) shear2[XW(i, j, k)]
-#define BU(i, j, k) buoy2[XW(i, j, k)]
   /* vertical shear at W-points :345-400 */
   if (flags & ORC_GLS_RI_SPLINES) {
     for (int j = b->Jstrm1; j <= b->Jendp1; j++) {
@@ -432,9 +515,9 @@ void orc_gls_corstep(orc_t *o, int tile) {
       for (int i = Istr; i <= Iend; i++) {
         const double cff = dt * pm[X2(i, j)] * pn[X2(i, j)];
         TK(i, j, k, nnew) = TK(i, j, k, nnew) - cff * (FXK[X2(i + 1, j)] - FXK[X2(i, j)] + FEK[X2(i, j + 1)] - FEK[X2(i, j)]);
-        TK(i, j, k, nnew) = MAX(TK(i, j, k, nnew), gls_Kmin);
+        if (!my25) TK(i, j, k, nnew) = MAX(TK(i, j, k, nnew), gls_Kmin);
         GL(i, j, k, nnew) = GL(i, j, k, nnew) - cff * (FXP[X2(i + 1, j)] - FXP[X2(i, j)] + FEP[X2(i, j + 1)] - FEP[X2(i, j)]);
-        GL(i, j, k, nnew) = MAX(GL(i, j, k, nnew), gls_Pmin);
+        if (!my25) GL(i, j, k, nnew) = MAX(GL(i, j, k, nnew), gls_Pmin);
       }
   }
   double *Zos_eff = (double *)calloc(5 * ni, sizeof(double)), *tke_fluxt = Zos_eff + ni, *tke_fluxb = Zos_eff + 2 * ni,
@@ -472,10 +555,11 @@ void orc_gls_corstep(orc_t *o, int tile) {
       for (int i = Istr; i <= Iend; i++) {
         const double cff = dt * pm[X2(i, j)] * pn[X2(i, j)];
         TK(i, j, k, nnew) = TK(i, j, k, nnew) - cff * (CX(FCK, i, k + 1) - CX(FCK, i, k));
-        TK(i, j, k, nnew) = MAX(TK(i, j, k, nnew), gls_Kmin);
+        if (!my25) TK(i, j, k, nnew) = MAX(TK(i, j, k, nnew), gls_Kmin);
         GL(i, j, k, nnew) = GL(i, j, k, nnew) - cff * (CX(FCP, i, k + 1) - CX(FCP, i, k));
-        GL(i, j, k, nnew) = MAX(GL(i, j, k, nnew), gls_Pmin);
+        if (!my25) GL(i, j, k, nnew) = MAX(GL(i, j, k, nnew), gls_Pmin);
       }
+    if (my25) { my25_column(o, b, j, shear2, buoy2, BCK, BCP, CF, FCK); continue; }
     /* vertical mixing of the turbulent fields :786-800 */
     {
       const double cff = -0.5 * dt;
@@ -645,7 +729,8 @@ void orc_gls_corstep(orc_t *o, int tile) {
     for (int f = 0; f <= NAT; f++) {
       double *A = f == 0 ? Akv + XW(LBi, LBj, k) : Akt + XW4(LBi, LBj, k, f);
       if (b->west) for (int j = Jstr; j <= Jend; j++) A[X2(Istr - 1, j)] = A[X2(Istr, j)];
-      if (b->east) for (int j = Jstr; j <= Jend; j++) A[X2(Iend + 1, j)] = A[X2(Iend, j)];
+      /* my25_corstep.F:786-792 copies to Iend-1, an interior column, and leaves Iend+1 as it was: restated as it stands */
+      if (b->east) for (int j = Jstr; j <= Jend; j++) A[X2(my25 ? Iend - 1 : Iend + 1, j)] = A[X2(Iend, j)];
       if (b->south) for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr - 1)] = A[X2(i, Jstr)];
       if (b->north) for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
       if (b->sw) A[X2(Istr - 1, Jstr - 1)] = 0.5 * (A[X2(Istr, Jstr - 1)] + A[X2(Istr - 1, Jstr)]);
@@ -662,3 +747,8 @@ void orc_gls_corstep(orc_t *o, int tile) {
   }
   free(shear2); free(p2); free(cw); free(Zos_eff);
 }
+
+void orc_gls_corstep(orc_t *o, int tile) { corstep(o, tile, 0); }
+/* MY25_MIXING: my25_prestep.F is gls_prestep.F word for word */
+void orc_my25_prestep(orc_t *o, int tile) { orc_gls_prestep(o, tile); }
+void orc_my25_corstep(orc_t *o, int tile) { corstep(o, tile, 1); }

@@ -157,7 +157,8 @@ int orc_main3d_step(orc_t *o) {
   FWD(o, orc_set_zeta(o, tile));                                        /* :556 */
   if (o->avg) { FWD(o, orc_set_avg(o, tile)); }                         /* :562 (AVERAGES) */
   REV(o, orc_rhs3d(o, tile));                                           /* :632 */
-  if (c->options & ORC_GLS_MIXING) { REV(o, orc_gls_prestep(o, tile)); }  /* :636 */
+  if (c->options & ORC_MY25_MIXING) { REV(o, orc_my25_prestep(o, tile)); }  /* :634 */
+  else if (c->options & ORC_GLS_MIXING) { REV(o, orc_gls_prestep(o, tile)); }  /* :636 */
   /* barotropic loop :810-918 */
   for (int my_iif = 1; my_iif <= c->nfast + 1; my_iif++) {
     int next_indx1 = 3 - s->indx1;
@@ -182,7 +183,8 @@ int orc_main3d_step(orc_t *o) {
   REV(o, orc_set_depth(o, tile));                                       /* :963 */
   REV(o, orc_step3d_uv(o, tile));                                       /* :990 */
   FWD(o, orc_omega(o, tile));                                           /* :1017 */
-  if (c->options & ORC_GLS_MIXING) { FWD(o, orc_gls_corstep(o, tile)); } /* :1021 */
+  if (c->options & ORC_MY25_MIXING) { FWD(o, orc_my25_corstep(o, tile)); } /* :1019 */
+  else if (c->options & ORC_GLS_MIXING) { FWD(o, orc_gls_corstep(o, tile)); } /* :1021 */
   REV(o, orc_step3d_t(o, tile));                                        /* :1045 */
   s->iic = s->iic + 1;                                                  /* :1145-1148 */
   s->time = s->time + c->dt;

@@ -76,6 +76,16 @@ if [ "$APP" = upwelling_gls ]; then
   UP=UPWELLING; HDR=upwelling; HDRPATH="upwelling.h"
   EXTRA="-DPERFECT_RESTART -DGLS_MIXING"
 fi
+if [ "$APP" = upwelling_my25 ]; then
+  # the shipped upwelling.h with the Mellor-Yamada 2.5 closure switched on (-DMY25_MIXING: KANTHA_CLAYSON, N2S2_HORAVG, RI_SPLINES)
+  UP=UPWELLING; HDR=upwelling; HDRPATH="upwelling.h"
+  EXTRA="-DPERFECT_RESTART -DMY25_MIXING"
+fi
+if [ "$APP" = upwelling_my25_gal ]; then
+  # MY25_MIXING with Galperin's stability functions, K_C4ADVECTION, plain shear, no smoothing (oracle/ref/upwelling_my25_gal.h)
+  UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
+  EXTRA=""
+fi
 if [ "$APP" = upwelling_gls_ca ] || [ "$APP" = upwelling_gls_cb ] || [ "$APP" = upwelling_gls_gal ]; then
   # GLS_MIXING in its other compile-time forms (oracle/ref/upwelling_gls_*.h; _ca is masked)
   UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
@@ -129,7 +139,7 @@ FILES="mod_kinds mod_param mod_scalars mod_stepping mod_strings mod_iounits mod_
   bc_2d bc_3d zetabc u2dbc_im v2dbc_im t3dbc_im u3dbc_im v3dbc_im obc_volcons
   set_depth set_massflux rho_eos prsgrd t3dmix uv3dmix set_vbc set_zeta wvelocity diag ini_fields
   mod_sources uv_var_change step2d omega pre_step3d rhs3d step3d_uv step3d_t
-  mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix gls_prestep gls_corstep tkebc_im bulk_flux analytical
+  mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix gls_prestep gls_corstep my25_prestep my25_corstep tkebc_im bulk_flux analytical
   mod_average uv_rotate vorticity set_avg"
 TODO=""
 for m in $FILES; do

@@ -231,7 +231,7 @@
 #if defined LMD_SKPP || defined SOLAR_SOURCE
       lmd_Jwt(ng)=ipar(16)
 #endif
-#ifdef GLS_MIXING
+#if defined GLS_MIXING || defined MY25_MIXING
 !  the GLS_* block of roms.in (read_phypar.F): rpar(66..)
       gls_p(ng)=rpar(66)
       gls_m(ng)=rpar(67)
@@ -476,6 +476,10 @@
       USE gls_prestep_mod,   ONLY : gls_prestep
       USE gls_corstep_mod,   ONLY : gls_corstep
 #endif
+#ifdef MY25_MIXING
+      USE my25_prestep_mod,  ONLY : my25_prestep
+      USE my25_corstep_mod,  ONLY : my25_corstep
+#endif
 #ifdef BULK_FLUXES
       USE bulk_flux_mod,     ONLY : bulk_flux
 #endif
@@ -525,7 +529,9 @@
         END DO
         DO tile=last_tile(ng),first_tile(ng),-1            ! :630-639
           CALL rhs3d (ng, tile)
-#ifdef GLS_MIXING
+#ifdef MY25_MIXING
+          CALL my25_prestep (ng, tile)
+#elif defined GLS_MIXING
           CALL gls_prestep (ng, tile)
 #endif
         END DO
@@ -569,7 +575,9 @@
         END DO
         DO tile=first_tile(ng),last_tile(ng),+1            ! :1015-1023
           CALL omega (ng, tile, iNLM)
-#ifdef GLS_MIXING
+#ifdef MY25_MIXING
+          CALL my25_corstep (ng, tile)
+#elif defined GLS_MIXING
           CALL gls_corstep (ng, tile)
 #endif
         END DO
@@ -676,6 +684,10 @@
 #ifdef GLS_MIXING
       USE gls_prestep_mod,   ONLY : gls_prestep
       USE gls_corstep_mod,   ONLY : gls_corstep
+#endif
+#ifdef MY25_MIXING
+      USE my25_prestep_mod,  ONLY : my25_prestep
+      USE my25_corstep_mod,  ONLY : my25_corstep
 #endif
 #ifdef BULK_FLUXES
       USE bulk_flux_mod,     ONLY : bulk_flux
@@ -1180,11 +1192,13 @@
         F2('alpha',MIXING(ng)%alpha)
         F2('beta',MIXING(ng)%beta)
 #endif
-#ifdef GLS_MIXING
+#if defined GLS_MIXING || defined MY25_MIXING
         F2('tke',MIXING(ng)%tke)
         F2('gls',MIXING(ng)%gls)
         F2('Lscale',MIXING(ng)%Lscale)
         F2('Akk',MIXING(ng)%Akk)
+#endif
+#ifdef GLS_MIXING
         F2('Akp',MIXING(ng)%Akp)
 #endif
 #ifdef LMD_SKPP

@@ -179,6 +179,19 @@ def upwelling_gls(form="upwelling_gls", closure="k-epsilon", **kw):
     return cs
 
 
+def upwelling_my25(form="upwelling_my25", **kw):
+    """UPWELLING with the Mellor-Yamada level 2.5 closure (MY25_MIXING): upwelling.h built with -DMY25_MIXING
+    (KANTHA_CLAYSON, N2S2_HORAVG, RI_SPLINES), or oracle/ref/upwelling_my25_gal.h (Galperin, K_C4ADVECTION).  The closure
+    takes GLS_Kmin, GLS_Pmin (start values) and AKK_BAK from the roms.in block it shares with GLS_MIXING."""
+    cs = upwelling(**kw)
+    cs["app"] = form
+    cs["options"] = tuple(o for o in cs["options"] if o != "ANA_VMIX") + ("MY25_MIXING",)
+    cs["gls_flags"] = ("KANTHA_CLAYSON", "N2S2_HORAVG", "RI_SPLINES") if form == "upwelling_my25" else ("K_C4ADVECTION",)
+    cs.update(dict(zip(GLS_NAMES, GLS_SETS["k-kl"])))
+    cs.update(Akk_bak=5.0e-6, Akp_bak=5.0e-6, charnok_alpha=1400.0, zos_hsig_alpha=0.5, sz_alpha=0.25, crgban_cw=100.0)
+    return cs
+
+
 def upwelling_mask(**kw):
     """UPWELLING with land/sea masking (MASKING): an island and a headland on the southern wall (`land_mask`); the
     custom application header oracle/ref/upwelling_mask.h"""

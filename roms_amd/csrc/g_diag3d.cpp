@@ -64,7 +64,7 @@ int run_rho_eos(roms_hip_ctx *c) {
       {c->F.alpha, 1, BC_NONE, 'r'},      // LMD_MIXING only (:766-780)
       {c->F.beta, 1, BC_NONE, 'r'},
   };
-  launch_halo_tail(c, hs3, (c->G.options & ROMS_LMD_MIXING) ? 7 : ((c->G.options & ROMS_GLS_MIXING) ? 5 : 4));
+  launch_halo_tail(c, hs3, (c->G.options & ROMS_LMD_MIXING) ? 7 : ((c->G.options & (ROMS_GLS_MIXING | ROMS_MY25_MIXING)) ? 5 : 4));
   return 0;
 }
 

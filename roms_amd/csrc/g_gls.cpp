@@ -12,6 +12,8 @@ static GlsArgs gls_args(roms_hip_ctx *c) {
   a.Fv = c->F;
   const int flags = cf.gls_flags;
   a.flags = flags;
+  a.my25 = (cf.options & ROMS_MY25_MIXING) != 0;
+  a.my_B1p2o3 = pow(16.6, 2.0 / 3.0);            // mod_scalars.F:4753
   const double vonKar = 0.41, gls_p = cf.gls_p, gls_m = cf.gls_m, gls_n = cf.gls_n, cmu0 = cf.gls_cmu0;
   a.gls_m = gls_m; a.gls_n = gls_n; a.Kmin = cf.gls_Kmin; a.Pmin = cf.gls_Pmin; a.cmu0 = cmu0;
   a.c1 = cf.gls_c1; a.c2 = cf.gls_c2; a.c3m = cf.gls_c3m; a.c3p = cf.gls_c3p; a.sigk = cf.gls_sigk; a.sigp = cf.gls_sigp;
@@ -106,10 +108,19 @@ int run_gls_corstep(roms_hip_ctx *c) {
   else LAUNCH_THREAD(k_gls_solve, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_gls_coef, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
   const size_t lev = (size_t)G.nij * (size_t)(G.N + 1);
+  const bool my25 = a.my25 != 0;
+  if (my25) {       // my25_corstep.F:774-850: its own edge copies (the eastern one lands on Iend-1), then only the exchanges
+    KArgs e;
+    e.G = c->G; e.Fv = c->F; e.p0 = 0; e.p2 = 0;
+    const int np = (G.N + 1) * (1 + G.NAT), nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
+    e.p1 = 0; LAUNCH_THREAD(k_my25_edges, ny, 1, np, c->stream, e);
+    e.p1 = 1; LAUNCH_THREAD(k_my25_edges, nx, 1, np, c->stream, e);
+    e.p1 = 2; LAUNCH_THREAD(k_my25_edges, 1, 1, np, c->stream, e);
+  }
   HaloSpec sp[4] = {{c->F.tke + (size_t)(G.nnew - 1) * lev, G.N + 1, bc_rstate(c), 'r'},
                     {c->F.gls + (size_t)(G.nnew - 1) * lev, G.N + 1, bc_rstate(c), 'r'},
-                    {c->F.Akv, G.N + 1, BC_R, 'r'},
-                    {c->F.Akt, (G.N + 1) * G.NAT, BC_R, 'r'}};
+                    {c->F.Akv, G.N + 1, my25 ? BC_NONE : BC_R, 'r'},
+                    {c->F.Akt, (G.N + 1) * G.NAT, my25 ? BC_NONE : BC_R, 'r'}};
   launch_halo_tail(c, sp, 4);
   return 0;
 }

@@ -113,7 +113,7 @@ THREAD_KERNEL(k_rho_eos_lin, KArgs) {
   const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, N = G.N, nrhs = G.nrhs;
   const bool salt = (G.options & ROMS_SALINITY) != 0;
   const bool kpp = (G.options & ROMS_LMD_MIXING) != 0;   // expansion coefficients :766-780
-  const bool bvq = (G.options & (ROMS_LMD_MIXING | ROMS_GLS_MIXING)) != 0;   // BV_FREQUENCY :751-764
+  const bool bvq = (G.options & (ROMS_LMD_MIXING | ROMS_GLS_MIXING | ROMS_MY25_MIXING)) != 0;   // BV_FREQUENCY :751-764
   const double gorho0 = G.g / G.rho0;
   double rhoA = 0.0, rhoS = 0.0, rup = 0.0;
   const EmitPlan P = emit_plan(G, BC_NONE, i, j);

@@ -19,12 +19,12 @@
 struct GlsArgs {
   DGrid G;
   Fields Fv;
-  int flags, Lmy25;
+  int flags, Lmy25, my25;     // my25: the Mellor-Yamada 2.5 closure (my25_corstep.F) on the same kernels
   double gls_m, gls_n, Kmin, Pmin, cmu0, c1, c2, c3m, c3p, sigk, sigp, Akk_bak, Akp_bak;
   double Zos_min, Zob_min, charnok_alpha, crgban_cw;
   // gls_corstep.F:250-340
   double L_sft, sigp_cb, ogls_sigp, sqrt2, cmu_fac1, cmu_fac2, cmu_fac3, cmu_fac4, fac2, fac3, fac4, fac5, fac6,
-      exp1, texp1, texp2, texp4, cmu0p /* cmu0**p */, cmu0c /* cmu0**3 */, crg23 /* crgban_cw**(2/3) */;
+      exp1, texp1, texp2, texp4, cmu0p /* cmu0**p */, cmu0c /* cmu0**3 */, crg23 /* crgban_cw**(2/3) */, my_B1p2o3 /* B1**(2/3) */;
   // stability functions: mod_scalars.F:1764-1796, :4715-4766
   double Gh0, Ghcri, Ghmin, E2, s0, s1, s2, s4, s5, s6, b0, b1, b2, b3, b4, b5, B1pm1o3, Sh1, Sh2, Sm2, Sm3, Sm4;
 };
@@ -221,22 +221,44 @@ THREAD_KERNEL(k_gls_adv, GlsArgs) {
   gls_hflux2(G, ee, tkk, EF0, EF1, i, j, 1, mode, FEK0, FEK1);
   gls_hflux2(G, ex, glk, XF0, XF1, i, j, 0, mode, FXP0, FXP1);
   gls_hflux2(G, ee, glk, EF0, EF1, i, j, 1, mode, FEP0, FEP1);
+  const bool my25 = a.my25 != 0;           // (my25_corstep.F:503-577 does not clip the advected fields)
   double t = tkn[XW(i, j, k)] - pmn * (FXK1 - FXK0 + FEK1 - FEK0);                     // :664-678
-  t = KMAX(t, Kmin);
+  if (!my25) t = KMAX(t, Kmin);
   double p = gln[XW(i, j, k)] - pmn * (FXP1 - FXP0 + FEP1 - FEP0);
-  p = KMAX(p, Pmin);
+  if (!my25) p = KMAX(p, Pmin);
   // vertical advection :684-776 (K_C2ADVECTION: cff = 0.25*(W+W), flux cff*(A(k)+A(k-1)): the factor one half of the
   // second-order flux is carried by cff -- a power of two, the product is the same)
   const double CFk = 0.5 * (W[XW(i, j, k)] + W[XW(i, j, k - 1)]), CF1 = 0.5 * (W[XW(i, j, k + 1)] + W[XW(i, j, k)]);
   const double FCk = gls_vflux(tc, nij, CFk, k, N, c2), FPk = gls_vflux(gc, nij, CFk, k, N, c2);
   const double FC1 = gls_vflux(tc, nij, CF1, k + 1, N, c2), FP1 = gls_vflux(gc, nij, CF1, k + 1, N, c2);
   t = t - pmn * (FC1 - FCk);
-  t = KMAX(t, Kmin);
+  if (!my25) t = KMAX(t, Kmin);
   p = p - pmn * (FP1 - FPk);
-  p = KMAX(p, Pmin);
-  // production and dissipation :804-900
+  if (!my25) p = KMAX(p, Pmin);
   double strat2, shr2;
   gls_n2s2(a, i, j, k, strat2, shr2);
+  if (my25) {       // my25_corstep.F:585-636: one mixing coefficient (Akk) for both fields, FCK(k) for k = 1..N
+    const double my_B1 = 16.6, my_E1 = 1.8, my_E2 = 1.33, eps = 1.0E-10;
+    const double cfd = -0.5 * dt, cff3 = my_E2 / (vonKar * vonKar);
+    const double FCKk = cfd * (Akk[XW(i, j, k)] + Akk[XW(i, j, k - 1)]) / Hz[X3(i, j, k)];
+    const double FCK1 = cfd * (Akk[XW(i, j, k + 1)] + Akk[XW(i, j, k)]) / Hz[X3(i, j, k + 1)];
+    if (strat2 > -5.0E-5 && strat2 < 0.0) strat2 = 0.0;
+    const double Qprod = shr2 * (Akv[XW(i, j, k)] - G.Akv_bak) - strat2 * (Akt[XW(i, j, k)] - G.Akt_bak[0]);
+    const double tks = tko[XW(i, j, k)], gss = glo[XW(i, j, k)];
+    const double Ls_unlmt = KMAX(eps, gss / (KMAX(tks, eps)));
+    const double cff1 = 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j, k + 1)]);
+    t = t + dt * cff1 * Qprod * 2.0;
+    p = p + dt * cff1 * Qprod * my_E1 * Ls_unlmt;
+    const double Qdiss = dt * sqrt(tks) / (my_B1 * Ls_unlmt);
+    const double cff = Ls_unlmt * (1.0 / (z_w[XW(i, j, N)] - z_w[XW(i, j, k)]) + 1.0 / (z_w[XW(i, j, k)] - z_w[XW(i, j, 0)]));
+    const double Wscale = 1.0 + cff3 * cff * cff;
+    tkn[XW(i, j, k)] = t;
+    gln[XW(i, j, k)] = p;
+    F.wrk3[0][XW(i, j, k)] = cff1 * (1.0 + 2.0 * Qdiss) - FCKk - FCK1;
+    F.wrk3[1][XW(i, j, k)] = cff1 * (1.0 + Wscale * Qdiss) - FCKk - FCK1;
+    return;
+  }
+  // production and dissipation :804-900
   const double gls_c3 = strat2 > 0.0 ? a.c3m : a.c3p;
   const double dAkt = Akt[XW(i, j, k)] - G.Akt_bak[0], dAkv = Akv[XW(i, j, k)] - G.Akv_bak;
   double Kprod = shr2 * dAkv - strat2 * dAkt;
@@ -287,6 +309,31 @@ KDEV void gls_solve_body(const GlsArgs &a, int gx, int gy, double *T, double *CF
   const double su = F.sustr[X2(i, j)] + F.sustr[X2(i + 1, j)], sv = F.svstr[X2(i, j)] + F.svstr[X2(i, j + 1)];
   const double bu_ = F.bustr[X2(i, j)] + F.bustr[X2(i + 1, j)], bv_ = F.bvstr[X2(i, j)] + F.bvstr[X2(i, j + 1)];
   const double sstr = 0.5 * sqrt(su * su + sv * sv), bstr = 0.5 * sqrt(bu_ * bu_ + bv_ * bv_);
+  if (a.my25) {     // my25_corstep.F:645-700: boundary values inside the systems, the substitution starts at level 1
+    const double cfd = -0.5 * dt;
+#define MY_FCK(k) (cfd * (Akk[XW(i, j, k)] + Akk[XW(i, j, (k) - 1)]) / Hz[X3(i, j, k)])
+    for (int f = 0; f < 2; f++) {
+      double *A = f == 0 ? tkn : gln;
+      const double *BC = f == 0 ? BCK : BCP;
+      const double AN = f == 0 ? a.my_B1p2o3 * sstr : 0.0, A0 = f == 0 ? a.my_B1p2o3 * bstr : 0.0;
+      double FCK1 = MY_FCK(N - 1);
+      double c = 1.0 / BC[XW(i, j, N - 1)];
+      CF[(N - 1) * TS] = c * FCK1;
+      T[(N - 1) * TS] = c * (A[XW(i, j, N - 1)] - MY_FCK(N) * AN);
+      for (int k = N - 2; k >= 1; k--) {
+        const double FCKk = MY_FCK(k);
+        c = 1.0 / (BC[XW(i, j, k)] - CF[(k + 1) * TS] * FCK1);
+        CF[(k) * TS] = c * FCKk;
+        T[(k) * TS] = c * (A[XW(i, j, k)] - FCK1 * T[(k + 1) * TS]);
+        FCK1 = FCKk;
+      }
+      T[0] = A0;
+      for (int k = 1; k <= N - 1; k++) { T[(k) * TS] = T[(k) * TS] - CF[(k) * TS] * T[(k - 1) * TS]; A[XW(i, j, k)] = T[(k) * TS]; }
+      A[XW(i, j, N)] = AN; A[XW(i, j, 0)] = A0;
+    }
+#undef MY_FCK
+    return;
+  }
   const double tkeN = crgban ? KMAX(a.cmu_fac4 * sstr * a.crg23, Kmin) : KMAX(a.cmu_fac3 * sstr, Kmin);
   const double tke0 = KMAX(a.cmu_fac3 * bstr, Kmin);
   const double Zos_eff = (flags & ROMS_GLS_CHARNOK) ? KMAX(a.charnok_alpha / G.g * sstr, a.Zos_min) : a.Zos_min;
@@ -376,6 +423,24 @@ THREAD_KERNEL(k_gls_coef, GlsArgs) {
   double *Akv = F.Akv, *Akt = F.Akt, *Akk = F.Akk, *Akp = F.Akp, *Lscale = F.Lscale;
   double strat2, shr2;
   gls_n2s2(a, i, j, k, strat2, shr2);
+  if (a.my25) {     // my25_corstep.F:706-750
+    const double my_Gh0 = 0.0233, my_Sq = 0.2, my_lmax = 0.53, my_qmin = 1.0E-8;
+    const double tn = KMAX(tkn[XW(i, j, k)], my_qmin), gn = KMAX(gln[XW(i, j, k)], my_qmin);
+    const double Ls_unlmt = gn / tn;
+    const double Ls_lmt = KMIN(Ls_unlmt, my_lmax * sqrt(tn / (KMAX(0.0, strat2) + eps)));
+    const double Gh = KMIN(my_Gh0, -strat2 * Ls_lmt * Ls_lmt / tn);
+    const double cff = 1.0 - a.Sh2 * Gh;
+    const double Sh = a.Sh1 / cff;
+    const double Sm = kc ? (a.B1pm1o3 + Sh * Gh * a.Sm4) / (1.0 - a.Sm2 * Gh) : (a.Sm3 + Sh * Gh * a.Sm4) / (1.0 - a.Sm2 * Gh);
+    const double ql = 0.5 * (Ls_lmt * sqrt(tn) + Lscale[XW(i, j, k)] * sqrt(tko[XW(i, j, k)]));
+    Akv[XW(i, j, k)] = G.Akv_bak + ql * Sm;
+    for (int it = 0; it < NAT; it++) Akt[XW(i, j, k) + (size_t)it * lev] = G.Akt_bak[it] + ql * Sh;
+    Akk[XW(i, j, k)] = a.Akk_bak + ql * my_Sq;
+    Lscale[XW(i, j, k)] = Ls_lmt;
+    tkn[XW(i, j, k)] = tn;
+    gln[XW(i, j, k)] = gn;
+    return;
+  }
   const double tn = KMAX(tkn[XW(i, j, k)], Kmin);
   double gn = KMAX(gln[XW(i, j, k)], Pmin);
   const double lim = a.fac5 * pow(tn, a.texp4) * pow(sqrt(KMAX(0.0, strat2)) + eps, -gls_n);
@@ -424,3 +489,38 @@ THREAD_KERNEL(k_gls_coef, GlsArgs) {
   gln[XW(i, j, k)] = gn;
 }
 THREAD_GLOBAL(k_gls_coef, GlsArgs)
+
+// ------------------------------------------------------------------------------ my25_corstep: lateral conditions of Akv, Akt
+// my25_corstep.F:774-850 as it stands: the copy at the eastern edge goes to the interior column Iend-1 (not to Iend+1, which
+// keeps its old value), the south-east and north-east corners then read that old value.  One thread per (edge point, plane);
+// p0 planes; launched over max(nx, ny) + 4 threads: edges first (this kernel, A.p1 = 0), corners after (p1 = 1).
+THREAD_KERNEL(k_my25_edges, KArgs) {
+  const DGrid &G = a.G;
+  const TB &B = G.T;
+  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
+  (void)gy;
+  const int N = G.N, np = (N + 1) * (1 + G.NAT);
+  const int pl = gz;                               // plane: Akv 0..N, then Akt
+  if (pl >= np) return;
+  double *A = (pl <= N ? a.Fv.Akv + (size_t)pl * G.nij : a.Fv.Akt + (size_t)(pl - N - 1) * G.nij);
+  if (a.p1 == 0) {
+    const int j = Jstr + gx, i = Istr + gx;
+    if (j <= Jend) {
+      if (B.west) A[X2(Istr - 1, j)] = A[X2(Istr, j)];
+      if (B.east) A[X2(Iend - 1, j)] = A[X2(Iend, j)];
+    }
+    (void)i;
+  } else if (a.p1 == 1) {
+    const int i = Istr + gx;
+    if (i <= Iend) {
+      if (B.south) A[X2(i, Jstr - 1)] = A[X2(i, Jstr)];
+      if (B.north) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
+    }
+  } else if (gx == 0) {
+    if (B.sw) A[X2(Istr - 1, Jstr - 1)] = 0.5 * (A[X2(Istr, Jstr - 1)] + A[X2(Istr - 1, Jstr)]);
+    if (B.se) A[X2(Iend + 1, Jstr - 1)] = 0.5 * (A[X2(Iend, Jstr - 1)] + A[X2(Iend + 1, Jstr)]);
+    if (B.nw) A[X2(Istr - 1, Jend + 1)] = 0.5 * (A[X2(Istr, Jend + 1)] + A[X2(Istr - 1, Jend)]);
+    if (B.ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend, Jend + 1)] + A[X2(Iend + 1, Jend)]);
+  }
+}
+THREAD_GLOBAL(k_my25_edges, KArgs)

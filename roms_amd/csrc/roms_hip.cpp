@@ -209,15 +209,16 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     set_error("options: UV_ADV, UV_VIS2 and TS_DIF2 are required (zero coefficients switch the mixing off)");
     return 5;
   }
-  if (cfg->options & ROMS_GLS_MIXING) {     // gls_prestep.F, gls_corstep.F: one closure, one form of it, sane parameters
+  if ((cfg->options & ROMS_GLS_MIXING) && (cfg->options & ROMS_MY25_MIXING)) { set_error("GLS_MIXING and MY25_MIXING exclude each other"); return 5; }
+  if (cfg->options & (ROMS_GLS_MIXING | ROMS_MY25_MIXING)) {     // gls_prestep.F, gls_corstep.F (my25_*.F): one closure, one form of it, sane parameters
     const int st = cfg->gls_flags & (ROMS_GLS_CANUTO_A | ROMS_GLS_CANUTO_B | ROMS_GLS_KANTHA_CLAYSON);
     const int ad = cfg->gls_flags & (ROMS_GLS_K_C2ADVECTION | ROMS_GLS_K_C4ADVECTION);
     if ((cfg->options & (ROMS_ANA_VMIX | ROMS_LMD_MIXING)) || (st & (st - 1)) || (ad & (ad - 1))) {
       set_error("GLS_MIXING: choose one vertical closure, at most one of CANUTO_A / CANUTO_B / KANTHA_CLAYSON and at most one of K_C2ADVECTION / K_C4ADVECTION");
       return 5;
     }
-    if (!(cfg->gls_n != 0.0) || !(cfg->gls_cmu0 > 0.0) || !(cfg->gls_Kmin > 0.0) || !(cfg->gls_Pmin > 0.0) || !(cfg->gls_sigk > 0.0) ||
-        !(cfg->gls_sigp > 0.0)) {
+    if (!(cfg->options & ROMS_MY25_MIXING) && (!(cfg->gls_n != 0.0) || !(cfg->gls_cmu0 > 0.0) || !(cfg->gls_Kmin > 0.0) || !(cfg->gls_Pmin > 0.0) || !(cfg->gls_sigk > 0.0) ||
+        !(cfg->gls_sigp > 0.0))) {
       set_error("GLS_MIXING: GLS_N must not be zero; GLS_CMU0, GLS_Kmin, GLS_Pmin, GLS_SIGK, GLS_SIGP must be positive");
       return 5;
     }
@@ -1491,7 +1492,7 @@ static int baro_and_corrector(roms_hip_ctx *c, int join_late = -1) {
   DO(roms_hip_set_depth(c));                                // :963
   DO(roms_hip_step3d_uv(c));                                // :990
   DO(roms_hip_omega(c));                                    // :1017
-  if (cf.options & ROMS_GLS_MIXING) DO(roms_hip_gls_corstep(c));   // :1021
+  if (cf.options & (ROMS_GLS_MIXING | ROMS_MY25_MIXING)) DO(roms_hip_gls_corstep(c));   // :1019-1021
   DO(roms_hip_step3d_t(c));                                 // :1045
   s.iic = s.iic + 1;                                        // :1145-1148
   s.time = s.time + cf.dt;
@@ -1635,7 +1636,7 @@ static int main3d_one(roms_hip_ctx *c) {
     static const char *elm = getenv("ROMS_HIP_LATE_MASK");
     // (prsgrd31: the late schedule relies on k_prs_grad keeping the previous ru/rv bracket for the deferred predictor)
     if (!c->has_exchange && !uvcol && (!c->G.masking || (elm && elm[0] == '1')) && !(elate && elate[0] == '0') &&
-        !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_GLS_MIXING))) return main3d_late(c, do_diag);   // (GLS: its two routines keep the reference's places)
+        !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_GLS_MIXING | ROMS_MY25_MIXING))) return main3d_late(c, do_diag);   // (GLS: its two routines keep the reference's places)
   }
   DO(roms_hip_rho_eos(c));                                  // :350
   // Two independent chains follow: set_massflux (:348) -> omega (:534) -> wvelocity (:535), and the
@@ -1713,7 +1714,7 @@ static int main3d_one(roms_hip_ctx *c) {
     halo_fence(c, FG_R | FG_FLUX);
     DO(run_rufrc_sums(c));            // rufrc/rvfrc of rhs3d_tile and uv3dmix2 in one kernel
   }
-  if (cf.options & ROMS_GLS_MIXING) DO(roms_hip_gls_prestep(c));   // :636
+  if (cf.options & (ROMS_GLS_MIXING | ROMS_MY25_MIXING)) DO(roms_hip_gls_prestep(c));   // :634-636
 #undef DO
   return baro_and_corrector(c);
 }

@@ -779,10 +779,13 @@
       CALL define ('ANA_INITIAL'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
       SELECT CASE (TRIM(MyAppCPP))
         CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK',  &  ! (oracle/ref/upwelling_logdrag.h, _mask.h)
-     &        'UPWELLING_GLS', 'UPWELLING_GLS_CA', 'UPWELLING_GLS_CB', 'UPWELLING_GLS_GAL')
+     &        'UPWELLING_GLS', 'UPWELLING_GLS_CA', 'UPWELLING_GLS_CB', 'UPWELLING_GLS_GAL', 'UPWELLING_MY25',         &
+     &        'UPWELLING_MY25_GAL')
 !  UPWELLING_GLS = upwelling.h built with -DGLS_MIXING; _CA, _CB, _GAL = oracle/ref/upwelling_gls_ca.h, _cb.h, _gal.h: the
 !  other compile-time forms of the closure the library is pinned in
           IF (MyAppCPP(1:13).eq.'UPWELLING_GLS') CALL define ('GLS_MIXING')
+          IF (MyAppCPP(1:14).eq.'UPWELLING_MY25') CALL define ('MY25_MIXING')     ! (upwelling.h -DMY25_MIXING; _GAL: oracle/ref/upwelling_my25_gal.h)
+          IF (TRIM(MyAppCPP).eq.'UPWELLING_MY25_GAL') CALL define ('K_C4ADVECTION')
           IF (TRIM(MyAppCPP).eq.'UPWELLING_GLS_CA') THEN
             CALL define ('MASKING'); CALL define ('CANUTO_A'); CALL define ('N2S2_HORAVG'); CALL define ('RI_SPLINES')
           ELSE IF (TRIM(MyAppCPP).eq.'UPWELLING_GLS_CB') THEN
@@ -796,8 +799,8 @@
           DO k=1,SIZE(flux0)
             CALL define (TRIM(flux0(k)))
           END DO
-          IF (is_defined('GLS_MIXING')) THEN                         ! upwelling.h:57-63 (-DGLS_MIXING: ROMS_CPP_FLAGS)
-            IF (TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_GLS') THEN
+          IF (is_defined('GLS_MIXING').or.is_defined('MY25_MIXING')) THEN   ! upwelling.h:57-63 (-DGLS_MIXING | -DMY25_MIXING: ROMS_CPP_FLAGS)
+            IF (TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_GLS'.or.TRIM(MyAppCPP).eq.'UPWELLING_MY25') THEN
               CALL define ('KANTHA_CLAYSON'); CALL define ('N2S2_HORAVG'); CALL define ('RI_SPLINES')
             END IF
           ELSE IF (TRIM(MyAppCPP).ne.'UPWELLING_KPP') THEN
@@ -832,12 +835,12 @@
       integer :: k
       logical :: upw, bench, kelv, seam, grav
 !  options with a bit in the mask (include/roms_hip.h)
-      character(len=16), parameter :: bitname(18) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
+      character(len=16), parameter :: bitname(19) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
      &    'TS_DIF2', 'MIX_GEO_TS', 'CURVGRID', 'NONLIN_EOS', 'UV_QDRAG', 'LMD_MIXING', 'BULK_FLUXES',           &
-     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG', 'MASKING', 'RADIATION_2D', 'GLS_MIXING' ]
-      integer, parameter :: bitval(18) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
+     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG', 'MASKING', 'RADIATION_2D', 'GLS_MIXING', 'MY25_MIXING' ]
+      integer, parameter :: bitval(19) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
      &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
-     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D, ROMS_GLS_MIXING ]
+     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D, ROMS_GLS_MIXING, ROMS_MY25_MIXING ]
 !  options whose code is the only form built (accepted, nothing to select) or that only affect output
       character(len=16), parameter :: inherent(35) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', 'PJ_GRADP', &
      &    'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
@@ -856,7 +859,7 @@
       IF (ierr.ne.0) RETURN
       upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
      &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING').or.    &
-     &    MyAppCPP(1:13).eq.'UPWELLING_GLS'
+     &    MyAppCPP(1:13).eq.'UPWELLING_GLS'.or.MyAppCPP(1:14).eq.'UPWELLING_MY25'
       bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.TRIM(MyAppCPP).eq.'BENCHMARK_MASK'.or.is_defined('BENCHMARK')
       kelv=TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES'.or.is_defined('KELVIN')
       seam=TRIM(MyAppCPP).eq.'SEAMOUNT'.or.is_defined('SEAMOUNT')
@@ -875,8 +878,10 @@
       DO k=1,ndefs
         IF (ANY(bitname.eq.defs(k))) THEN
           options=IOR(options, bitval(FINDLOC(bitname, defs(k), 1)))
-        ELSE IF (ANY(glsname.eq.defs(k)).and.(is_defined('GLS_MIXING').or.TRIM(defs(k)).eq.'RI_SPLINES')) THEN
-          IF (is_defined('GLS_MIXING')) gls_flags=IOR(gls_flags, glsval(FINDLOC(glsname, defs(k), 1)))
+        ELSE IF (ANY(glsname.eq.defs(k)).and.(is_defined('GLS_MIXING').or.is_defined('MY25_MIXING').or.          &
+     &           TRIM(defs(k)).eq.'RI_SPLINES')) THEN
+          IF (is_defined('GLS_MIXING').or.is_defined('MY25_MIXING'))                                            &
+     &      gls_flags=IOR(gls_flags, glsval(FINDLOC(glsname, defs(k), 1)))
         ELSE IF (ANY(inherent.eq.defs(k)).or.ANY(output_only.eq.defs(k))) THEN
           CONTINUE
         ELSE IF (TRIM(defs(k)).eq.'UPWELLING'.or.TRIM(defs(k)).eq.'BENCHMARK'.or.TRIM(defs(k)).eq.'KELVIN'.or.            &
@@ -918,14 +923,18 @@
       IF (.not.is_defined('SPLINES_VVISC')) options=IOR(options, ROMS_PLAIN_VVISC)
       IF (.not.is_defined('SPLINES_VDIFF').and.ANY(hadv(1:NAT).eq.ROMS_MPDATA))                                &
      &  CALL unsupported ('MPDATA is built with SPLINES_VDIFF only', ierr)
-      IF (COUNT((/ is_defined('ANA_VMIX'), is_defined('LMD_MIXING'), is_defined('GLS_MIXING') /)).gt.1)         &
-     &  CALL unsupported ('at most one vertical mixing closure: ANA_VMIX, LMD_MIXING or GLS_MIXING (none: the '//      &
+      IF (COUNT((/ is_defined('ANA_VMIX'), is_defined('LMD_MIXING'), is_defined('GLS_MIXING'),                   &
+     &             is_defined('MY25_MIXING') /)).gt.1)                                                         &
+     &  CALL unsupported ('at most one vertical mixing closure: ANA_VMIX, LMD_MIXING, GLS_MIXING or MY25_MIXING (none: the '//      &
      &                    'background coefficients AKV_BAK, AKT_BAK, as in KELVIN)', ierr)
       IF (.not.(kelv.or.seam.or.grav).and..not.(is_defined('ANA_VMIX').or.is_defined('LMD_MIXING').or.           &
-     &    is_defined('GLS_MIXING')))                                                                            &
+     &    is_defined('GLS_MIXING').or.is_defined('MY25_MIXING')))                                                                            &
      &  CALL unsupported ('a vertical mixing closure is required: ANA_VMIX, LMD_MIXING or GLS_MIXING', ierr)
 !  GLS_MIXING: the stability functions, the smoothing, the shear form, the advection of the turbulent fields and the two
 !  surface-flux options are run-time flags of the library; the wave-dependent forms and the limiters are not built
+      IF (is_defined('MY25_MIXING').and.(is_defined('CANUTO_A').or.is_defined('CANUTO_B').or.is_defined('CHARNOK').or.  &
+     &    is_defined('CRAIG_BANNER').or.is_defined('LIMIT_VDIFF').or.is_defined('LIMIT_VVISC')))                  &
+     &  CALL unsupported ('MY25_MIXING takes KANTHA_CLAYSON, N2S2_HORAVG, RI_SPLINES, K_C2ADVECTION, K_C4ADVECTION', ierr)
       IF (is_defined('GLS_MIXING').and.(is_defined('ZOS_HSIG').or.is_defined('TKE_WAVEDISS').or.                 &
      &    is_defined('LIMIT_VDIFF').or.is_defined('LIMIT_VVISC')))                                              &
      &  CALL unsupported ('GLS_MIXING: ZOS_HSIG, TKE_WAVEDISS (wave fields) and LIMIT_VDIFF / LIMIT_VVISC are not built', ierr)
@@ -1812,7 +1821,7 @@
       CALL up ('zeta', zeta, 3, ierr); CALL up ('ubar', ubar, 3, ierr); CALL up ('vbar', vbar, 3, ierr)
       CALL up ('u', u, 2*N, ierr); CALL up ('v', v, 2*N, ierr); CALL up ('t', t, 3*N*NT, ierr)
       CALL up ('Akv', Akv, N+1, ierr); CALL up ('Akt', Akt, (N+1)*NAT, ierr)
-      IF (IAND(options,ROMS_GLS_MIXING).ne.0) THEN       ! initialize_mixing, mod_mixing.F:1490-1515
+      IF (IAND(options,IOR(ROMS_GLS_MIXING,ROMS_MY25_MIXING)).ne.0) THEN       ! initialize_mixing, mod_mixing.F:1490-1515
         allocate ( gw(LBi:UBi,LBj:UBj,3*(N+1)) )
         gw=gls_Kmin
         CALL up ('tke', gw, 3*(N+1), ierr)
@@ -1904,7 +1913,7 @@
         ierr=roms_hip_set_zeta(ctx);                      IF (ierr.ne.0) RETURN
         ierr=roms_hip_set_avg(ctx);                       IF (ierr.ne.0) RETURN      ! :562 (AVERAGES; no-op when off)
         ierr=roms_hip_rhs3d(ctx);                         IF (ierr.ne.0) RETURN
-        IF (IAND(options,ROMS_GLS_MIXING).ne.0) ierr=roms_hip_gls_prestep(ctx)         ! :636
+        IF (IAND(options,IOR(ROMS_GLS_MIXING,ROMS_MY25_MIXING)).ne.0) ierr=roms_hip_gls_prestep(ctx)         ! :634-636
         IF (ierr.ne.0) RETURN
         DO my_iif=1,nfast+1                                ! LF-AM3 barotropic loop :810-918
           next_indx1=3-step%indx1
@@ -1936,7 +1945,7 @@
         ierr=roms_hip_set_depth(ctx);                     IF (ierr.ne.0) RETURN
         ierr=roms_hip_step3d_uv(ctx);                     IF (ierr.ne.0) RETURN
         ierr=roms_hip_omega(ctx);                         IF (ierr.ne.0) RETURN
-        IF (IAND(options,ROMS_GLS_MIXING).ne.0) ierr=roms_hip_gls_corstep(ctx)         ! :1021
+        IF (IAND(options,IOR(ROMS_GLS_MIXING,ROMS_MY25_MIXING)).ne.0) ierr=roms_hip_gls_corstep(ctx)         ! :1019-1021
         IF (ierr.ne.0) RETURN
         ierr=roms_hip_step3d_t(ctx);                      IF (ierr.ne.0) RETURN
         step%iic=step%iic+1

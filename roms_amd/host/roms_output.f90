@@ -710,7 +710,7 @@
      &     'depth of oceanic surface boundary layer', 'meter', 'SBL thickness', gR2, -1_c_int, idHsbl)
 !  GLS_MIXING: the closure's state (def_rst.F under PERFECT_RESTART: idMtke, idMtls with their three time levels;
 !  idVmLS, idVmKK, idVmKP), names and attributes of varinfo.yaml
-      IF (rst.and.IAND(options,ROMS_GLS_MIXING).ne.0) THEN
+      IF (rst.and.IAND(options,IOR(ROMS_GLS_MIXING,ROMS_MY25_MIXING)).ne.0) THEN
         CALL fdef ('tke', 'specific_turbulent_kinetic_energy_of_sea_water', 'turbulent kinetic energy',              &
      &             'meter2 second-2', 'TKE', gW3, three, 20)
         CALL fdef ('gls', ' ', 'turbulent generic length scale', 'meter3 second-2', 'GLS', gW3, three, 21)
@@ -1149,7 +1149,7 @@
         CALL rd ('Hsbl', gR2, 1, A); CALL up ('hsbl', A, 1, ierr)
         deallocate ( A )
       END IF
-      IF (IAND(options,ROMS_GLS_MIXING).ne.0) THEN
+      IF (IAND(options,IOR(ROMS_GLS_MIXING,ROMS_MY25_MIXING)).ne.0) THEN
         allocate ( A(LBi:UBi,LBj:UBj,3*(N+1)) )
         CALL rd ('tke', gW3, 3*(N+1), A); CALL up ('tke', A, 3*(N+1), ierr)
         CALL rd ('gls', gW3, 3*(N+1), A); CALL up ('gls', A, 3*(N+1), ierr)

@@ -250,6 +250,7 @@ STEP_CASES = [
     ("upwelling_gls_small", "upwelling_gls_small", ["nsteps=60"]),
     ("upwelling_gls_ca_small", "upwelling_gls_ca_small", ["nsteps=60"]),
     ("upwelling_gls_cb_small", "upwelling_gls_cb_small", ["nsteps=60"]),
+    ("upwelling_my25_small", "upwelling_my25_small", ["nsteps=60"]),            # MY25_MIXING: upwelling.h -DMY25_MIXING
 ]
 KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
 def make_avg():

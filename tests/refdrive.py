@@ -40,6 +40,9 @@ CASES = {
     "upwelling_gls_ca_small": ("upwelling_gls_ca", dict(Lm=14, Mm=18, N=8, form="upwelling_gls_ca", closure="gen")),
     "upwelling_gls_cb_small": ("upwelling_gls_cb", dict(Lm=14, Mm=18, N=8, form="upwelling_gls_cb", closure="k-kl")),
     "upwelling_gls_gal_small": ("upwelling_gls_gal", dict(Lm=14, Mm=18, N=8, form="upwelling_gls_gal", closure="k-omega")),
+    # the Mellor-Yamada 2.5 closure: upwelling.h with -DMY25_MIXING, and with Galperin's functions / K_C4ADVECTION
+    "upwelling_my25_small": ("upwelling_my25", dict(Lm=14, Mm=18, N=8)),
+    "upwelling_my25_gal_small": ("upwelling_my25_gal", dict(Lm=14, Mm=18, N=8, form="upwelling_my25_gal")),
     "seamount": ("seamount", dict()),
     "seamount_small": ("seamount", dict(Lm=20, Mm=18, N=8)),
     "grav_adj": ("grav_adj", dict()),
@@ -134,7 +137,8 @@ def make_case(tag, **kw):
                 upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
                 upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, seamount=cases.seamount, grav_adj=cases.grav_adj, upwelling_prs31=cases.upwelling_prs31,
                 upwelling_wjgradp=cases.upwelling_prs31, upwelling_prs40=cases.upwelling_prs40, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
-                upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls)[app]
+                upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
+                upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]
     lbc = k.pop("lbc", None)
     cs = ctor(**k)
     if tag.endswith("_obc_small"):

@@ -247,6 +247,13 @@ MAIN3D_CASES = [
     ("upwelling_gls_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("upwelling_gls_ca_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("upwelling_gls_cb_small", ["nsteps=20", "NtileI=3", "NtileJ=1", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
+    # the Mellor-Yamada level 2.5 closure (my25_prestep.F = gls_prestep.F; my25_corstep.F with its own production, boundary
+    # values, stability functions -- and its eastern edge copy onto Iend-1, restated as it stands): upwelling.h built with
+    # -DMY25_MIXING (Kantha-Clayson, smoothing, spline shear) and oracle/ref/upwelling_my25_gal.h (Galperin, K_C4ADVECTION)
+    ("upwelling_my25_small", ["nsteps=60"]),
+    ("upwelling_my25_gal_small", ["nsteps=60"]),
+    ("upwelling_my25_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_my25_gal_small", ["nsteps=20", "NtileI=3", "NtileJ=1", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
     ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
 ]

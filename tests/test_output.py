@@ -109,7 +109,7 @@ def _final_state(ctx, names):
 @pytest.mark.parametrize("which", LIBS)
 @pytest.mark.parametrize("tag,kw,n1", [("upwelling_small", {}, 4), ("upwelling_small", {}, 5), ("benchmark_small", {}, 5),
                                        ("upwelling_kpp_small", {}, 4), ("upwelling_gls_small", {}, 4),
-                                       ("upwelling_gls_cb_small:k-kl", {}, 5)])
+                                       ("upwelling_gls_cb_small:k-kl", {}, 5), ("upwelling_my25_small", {}, 4)])
 def test_restart_continues_bit_for_bit(which, tag, kw, n1, tmp_path):
     """n1 + 3 steps in one go == n1 steps, a restart record, a NEW context restarted from the file, 3 more steps: every
     prognostic array bit for bit (an even and an odd step count: both parities of the time indices; ANA_VMIX, KPP +

@@ -23,7 +23,7 @@ def _emu_libs():
 
 
 def _fields(tag):
-    return FIELDS + (GLS_FIELDS if tag.startswith("upwelling_gls") else [])
+    return FIELDS + (GLS_FIELDS if tag.startswith(("upwelling_gls", "upwelling_my25")) else [])
 
 
 def _single(tag, kw, steps):
@@ -85,6 +85,8 @@ def _interior(cs_dims, a):
     ("upwelling_gls_small", dict(), (2, 2), 29627),
     ("upwelling_gls_ca_small:gen", dict(), (2, 2), 29628),
     ("upwelling_gls_cb_small:k-kl", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (1, 2), 29629),
+    # MY25_MIXING: the eastern tiles carry my25_corstep.F's copy onto the interior column Iend-1
+    ("upwelling_my25_small", dict(), (2, 2), 29630),
 ])
 def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     _emu_libs()

@@ -90,6 +90,8 @@ def case_for(tag, **kw):
         return cases.kelvin(Lm=16, Mm=12, N=6, plain=True, **kw)
     if tag == "kelvin_plain":
         return cases.kelvin(plain=True, **kw)
+    if tag in ("upwelling_my25_small", "upwelling_my25_gal_small"):
+        return cases.upwelling_my25(form=tag[:-len("_small")], Lm=14, Mm=18, N=8, **kw)
     if tag.startswith("upwelling_gls"):
         # upwelling_gls[_ca|_cb|_gal]_small[:closure]: the compile-time forms of GLS_MIXING (cases.GLS_FORMS) on the small grid
         name, _, closure = tag.partition(":")
