@@ -20,7 +20,8 @@ One JSON line is printed by rank 0 (contract in the task statement) with two ext
                 shared-memory mode) on a bounded sample of the same workload
 and two more: `north_star_pair` = the kernels of "step3d_t + rhs3d" (BASELINE.json north_star) timed in the
 breakdown pass of this workload against their 632 algorithmic bytes per cell, and -- default run only --
-`north_star_pair_512x512x50` = the same on the grid the north star names (a 4-step pass after the timed region).
+`north_star_pair_512x512x50` = the same on the grid the north star names (a 6-step pass after the timed region), and
+`north_star_pair_512x512x50_stock` = that grid with the tracer schemes of the shipped roms_upwelling.in (HSIMT salinity).
 """
 import argparse
 import json
@@ -303,10 +304,12 @@ def multi_gpu_plan(world, workload, explicit_dims):
     return workload, None, True
 
 
-def north_star_pass(hiplib, tiling, device, steps=6, warmup=24):
-    """UPWELLING 512x512x50 with U3/C4 advection: `steps` steps with synchronous per-kernel HIP events; the
-    kernels of "step3d_t + rhs3d" against their 632 algorithmic bytes per cell, and each of them alone."""
-    cs = params_for("ns512u3", ntimes=steps + warmup)
+def north_star_pass(hiplib, tiling, device, steps=6, warmup=24, workload="ns512u3"):
+    """UPWELLING 512x512x50 with U3/C4 advection (workload ns512u3), or with the schemes of the shipped roms_upwelling.in
+    (ns512: HSIMT salinity): `steps` steps with synchronous per-kernel HIP events; the kernels of "step3d_t + rhs3d"
+    against their 632 algorithmic bytes per cell, and each of them alone.  (A single-tile run stores the boundary values
+    and periodic images inside the producing kernels: those rows have no separate halo launches to add.)"""
+    cs = params_for(workload, ntimes=steps + warmup)
     cs["ninfo"] = 1
     run = tiling.TiledRun(cs, device=device)
     run.step(warmup)                       # past the start-up branches (iic <= 2) and the clock ramp after the CPU leg
@@ -325,7 +328,9 @@ def north_star_pass(hiplib, tiling, device, steps=6, warmup=24):
         per[k] = {"us_per_launch": us, "launches_per_step": table[k][1] / steps,
                   "algorithmic_GBs": (nb / us / 1e3) if nb else None}
     rep["per_kernel"] = per
-    rep["workload"] = "UPWELLING 512x512x50, U3/C4 advection of both tracers (bench.py --workload ns512u3)"
+    rep["workload"] = ("UPWELLING 512x512x50, U3/C4 advection of both tracers (bench.py --workload ns512u3)" if workload == "ns512u3" else
+                       "UPWELLING 512x512x50, the schemes of roms_upwelling.in: U3/C4 temperature, HSIMT salinity (bench.py --workload ns512); "
+                       "priced on the same 632 B/cell, which HSIMT's extra passes exceed")
     run.check()
     run.close()
     return rep
@@ -580,6 +585,7 @@ def main():
         # BASELINE.json north_star: "step3d_t + rhs3d at 512x512x50" -- a short pass of that grid (UPWELLING
         # physics, U3/C4 advection: the schemes SURVEY 8(d) prices the pair on) with every kernel timed
         out["north_star_pair_512x512x50"] = north_star_pass(hiplib, tiling, local_rank)
+        out["north_star_pair_512x512x50_stock"] = north_star_pass(hiplib, tiling, local_rank, steps=4, warmup=8, workload="ns512")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
