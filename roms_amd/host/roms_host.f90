@@ -46,6 +46,7 @@
      &                      idTemp = 8, idSalt = 9, idDano = 10, idVvis = 11, idTdif = 12, idSdif = 13,            &
      &                      idHsbl = 14, nHout = 14
       logical :: Hout(nHout) = .FALSE.
+      logical :: HoutMtke = .FALSE., HoutMtls = .FALSE.   ! Hout(idMtke), Hout(idMtls): tke; gls and Lscale (GLS_MIXING, MY25_MIXING)
 !  time-averaged output (AVERAGES: set_avg.F, def_avg.F/wrt_avg.F): window, file, the Aout switches in the order of
 !  roms_hip_avg_config's mask bits; tracer terms (bits 8, 17..21) per tracer
       integer :: nAVG = 0, ntsAVG = 1
@@ -222,6 +223,8 @@
           CASE ('Hout(idTdif)'); Hout(idTdif)=istrue(tok(1))
           CASE ('Hout(idSdif)'); Hout(idSdif)=istrue(tok(1))
           CASE ('Hout(idHsbl)'); Hout(idHsbl)=istrue(tok(1))
+          CASE ('Hout(idMtke)'); HoutMtke=istrue(tok(1))
+          CASE ('Hout(idMtls)'); HoutMtls=istrue(tok(1))
           CASE ('LuvSrc', 'LwSrc', 'LtracerSrc', 'LuvSponge', 'LtracerSponge', 'LsshCLM', 'Lm2CLM', 'Lm3CLM',     &
      &          'LtracerCLM', 'LnudgeM2CLM', 'LnudgeM3CLM', 'LnudgeTCLM', 'VolCons(west)', 'VolCons(east)',      &
      &          'VolCons(south)', 'VolCons(north)')
@@ -394,7 +397,7 @@
       gls_flags=0; lbc_tke=0; gls_p=3.0_dp; gls_m=1.5_dp; gls_n=-1.0_dp; gls_Kmin=7.6E-6_dp; gls_Pmin=1.0E-12_dp
       gls_cmu0=0.5477_dp; gls_c1=1.44_dp; gls_c2=1.92_dp; gls_c3m=-0.4_dp; gls_c3p=1.0_dp; gls_sigk=1.0_dp; gls_sigp=1.30_dp
       Akk_bak=5.0E-6_dp; Akp_bak=5.0E-6_dp; charnok_alpha=1400.0_dp; crgban_cw=100.0_dp
-      nrrec=0; nRST=0; nHIS=0; LcycleRST=.TRUE.; Hout=.FALSE.
+      nrrec=0; nRST=0; nHIS=0; LcycleRST=.TRUE.; Hout=.FALSE.; HoutMtke=.FALSE.; HoutMtls=.FALSE.
       nAVG=0; ntsAVG=1; avgname='roms_avg.nc'; Aout=.FALSE.; AoutT=.FALSE.
       ininame='roms_ini.nc'; rstname='roms_rst.nc'; hisname='roms_his.nc'
       END SUBROUTINE set_defaults

@@ -708,18 +708,20 @@
      &     'meter2 second-1', 'AKs', gW3, -1_c_int, idSdif)
       IF (lmd.and.(rst.or.Hout(idHsbl))) CALL fdef ('Hsbl', 'ocean_surface_boundary_layer_thickness',                &
      &     'depth of oceanic surface boundary layer', 'meter', 'SBL thickness', gR2, -1_c_int, idHsbl)
-!  GLS_MIXING: the closure's state (def_rst.F under PERFECT_RESTART: idMtke, idMtls with their three time levels;
-!  idVmLS, idVmKK, idVmKP), names and attributes of varinfo.yaml
-      IF (rst.and.IAND(options,IOR(ROMS_GLS_MIXING,ROMS_MY25_MIXING)).ne.0) THEN
-        CALL fdef ('tke', 'specific_turbulent_kinetic_energy_of_sea_water', 'turbulent kinetic energy',              &
-     &             'meter2 second-2', 'TKE', gW3, three, 20)
-        CALL fdef ('gls', ' ', 'turbulent generic length scale', 'meter3 second-2', 'GLS', gW3, three, 21)
-        CALL fdef ('Lscale', 'turbulent_mixing_length_of_sea_water', 'vertical mixing turbulent length scale',       &
-     &             'meter', 'Lscale', gW3, -1_c_int, 22)
-        CALL fdef ('AKk', ' ', 'turbulent kinetic energy vertical diffusion coefficient', 'meter2 second-1', 'AKk',  &
-     &             gW3, -1_c_int, 23)
-        CALL fdef ('AKp', ' ', 'turbulent generic statistical field vertical diffusion coefficient',                &
-     &             'meter2 second-1', 'AKp', gW3, -1_c_int, 24)
+!  GLS_MIXING, MY25_MIXING: the closure's state -- in a restart file all of it (def_rst.F under PERFECT_RESTART: idMtke,
+!  idMtls with their three time levels; idVmLS, idVmKK, idVmKP), in a history file tke under Hout(idMtke), gls and Lscale
+!  under Hout(idMtls) (wrt_his.F:1315-1400); names and attributes of varinfo.yaml
+      IF (IAND(options,IOR(ROMS_GLS_MIXING,ROMS_MY25_MIXING)).ne.0) THEN
+        IF (rst.or.HoutMtke) CALL fdef ('tke', 'turbulent_kinetic_energy_due_to_vertical_mixing_of_sea_water',          &
+     &       'turbulent kinetic energy', 'meter2 second-2', 'TKE', gW3, three, 20)
+        IF (rst.or.HoutMtls) CALL fdef ('gls', 'turbulent_mixing_generic_length_of_sea_water',                          &
+     &       'turbulent generic length scale', 'meter3 second-2', 'GLS', gW3, three, 21)
+        IF (rst.or.HoutMtls) CALL fdef ('Lscale', 'turbulent_length_scale_due_to_vertical_mixing_of_sea_water',         &
+     &       'vertical mixing turbulent length scale', 'meter', 'Lscale', gW3, -1_c_int, 22)
+        IF (rst) CALL fdef ('AKk', 'vertical_diffusion_coefficient_of_turbulent_kinetic_energy_of_sea_water',            &
+     &       'Turbulent kinetic energy vertical diffusion coefficient', 'meter2 second-1', 'AKk', gW3, -1_c_int, 23)
+        IF (rst) CALL fdef ('AKp', 'vertical_diffusion_coefficient_of_turbulent_length_scale_of_sea_water',              &
+     &       'Turbulent length scale vertical diffusion coefficient', 'meter2 second-1', 'AKp', gW3, -1_c_int, 24)
       END IF
       END IF
       IF (ierr.eq.0.and.master()) THEN
@@ -861,18 +863,32 @@
         CALL put_field (o%h, o%v_fld(idHsbl), rec, gR2, A, 1, 1, 1, ierr)
         deallocate ( A )
       END IF
-      IF (rst.and.o%v_fld(20).ge.0) THEN                  ! GLS_MIXING
+      IF (o%v_fld(20).ge.0.or.o%v_fld(21).ge.0) THEN      ! GLS_MIXING, MY25_MIXING (history: time level NOUT)
         allocate ( A(LBi:UBi,LBj:UBj,3*(N+1)) )
-        CALL fetch ('tke', 3*(N+1), A, ierr)
-        CALL put_field (o%h, o%v_fld(20), rec, gW3, A, 3*(N+1), 1, 3*(N+1), ierr)
-        CALL fetch ('gls', 3*(N+1), A, ierr)
-        CALL put_field (o%h, o%v_fld(21), rec, gW3, A, 3*(N+1), 1, 3*(N+1), ierr)
-        CALL fetch ('Lscale', N+1, A(:,:,1:N+1), ierr)
-        CALL put_field (o%h, o%v_fld(22), rec, gW3, A(:,:,1:N+1), N+1, 1, N+1, ierr)
-        CALL fetch ('Akk', N+1, A(:,:,1:N+1), ierr)
-        CALL put_field (o%h, o%v_fld(23), rec, gW3, A(:,:,1:N+1), N+1, 1, N+1, ierr)
-        CALL fetch ('Akp', N+1, A(:,:,1:N+1), ierr)
-        CALL put_field (o%h, o%v_fld(24), rec, gW3, A(:,:,1:N+1), N+1, 1, N+1, ierr)
+        IF (o%v_fld(20).ge.0) THEN
+          CALL fetch ('tke', 3*(N+1), A, ierr)
+          IF (rst) THEN
+            CALL put_field (o%h, o%v_fld(20), rec, gW3, A, 3*(N+1), 1, 3*(N+1), ierr)
+          ELSE
+            CALL put_field (o%h, o%v_fld(20), rec, gW3, A, 3*(N+1), (N+1)*(nout-1)+1, (N+1)*nout, ierr)
+          END IF
+        END IF
+        IF (o%v_fld(21).ge.0) THEN
+          CALL fetch ('gls', 3*(N+1), A, ierr)
+          IF (rst) THEN
+            CALL put_field (o%h, o%v_fld(21), rec, gW3, A, 3*(N+1), 1, 3*(N+1), ierr)
+          ELSE
+            CALL put_field (o%h, o%v_fld(21), rec, gW3, A, 3*(N+1), (N+1)*(nout-1)+1, (N+1)*nout, ierr)
+          END IF
+          CALL fetch ('Lscale', N+1, A(:,:,1:N+1), ierr)
+          CALL put_field (o%h, o%v_fld(22), rec, gW3, A(:,:,1:N+1), N+1, 1, N+1, ierr)
+        END IF
+        IF (rst) THEN
+          CALL fetch ('Akk', N+1, A(:,:,1:N+1), ierr)
+          CALL put_field (o%h, o%v_fld(23), rec, gW3, A(:,:,1:N+1), N+1, 1, N+1, ierr)
+          CALL fetch ('Akp', N+1, A(:,:,1:N+1), ierr)
+          CALL put_field (o%h, o%v_fld(24), rec, gW3, A(:,:,1:N+1), N+1, 1, N+1, ierr)
+        END IF
         deallocate ( A )
       END IF
       END IF

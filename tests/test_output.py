@@ -186,6 +186,37 @@ def test_restart_errors_are_reported(tmp_path):
     H.finalize()
 
 
+@pytest.mark.parametrize("which", LIBS)
+def test_history_file_of_a_gls_run_holds_the_turbulent_fields(which, tmp_path):
+    """Hout(idMtke) -> tke, Hout(idMtls) -> gls and Lscale (wrt_his.F:1315-1400: level NOUT of the three, names and
+    attributes of varinfo.yaml); the records equal the device arrays at the output points."""
+    cs = util.case_for("upwelling_gls_small")
+    his = str(tmp_path / "roms_his.nc")
+    cs.update(NHIS=3, NRST=0, HISNAME=his, Hout=dict(HOUT, idMtke=True, idMtls=True), ninfo=0)
+    H, ctx = _host(cs, which)
+    H.advance(6, final=True)
+    t = H.tile
+    st = ctx.get_stepping()
+    N = cs["N"]
+    ni, nj = t["UBi"] - t["LBi"] + 1, t["UBj"] - t["LBj"] + 1
+    tke = ctx.download("tke").reshape(3, N + 1, nj, ni)
+    Ls = ctx.download("Lscale").reshape(N + 1, nj, ni)
+    H.close_output()
+    H.finalize()
+    f = _nc(his)
+    assert f.variables["tke"].dimensions == ("ocean_time", "s_w", "eta_rho", "xi_rho")
+    assert f.variables["tke"].long_name == b"turbulent kinetic energy" and f.variables["gls"].units == b"meter3 second-2"
+    assert f.variables["Lscale"].field == b"Lscale, scalar, series" or b"Lscale" in f.variables["Lscale"].field
+    rec = f.variables["tke"][:]
+    assert rec.shape[0] == 3 and rec[0].max() == pytest.approx(cs["gls_Kmin"])          # the initial record
+    Lm, Mm = cs["Lm"], cs["Mm"]
+    got = rec[-1][:, 1:Mm + 1, 1:Lm + 1]                                              # the record of step 6
+    want = tke[st.nrhs - 1][:, 1 - t["LBj"]:Mm + 1 - t["LBj"], 1 - t["LBi"]:Lm + 1 - t["LBi"]]
+    assert np.array_equal(got, want) and Ls.max() > 0.0
+    assert np.array_equal(f.variables["Lscale"][-1][:, 1:Mm + 1, 1:Lm + 1], Ls[:, 1 - t["LBj"]:Mm + 1 - t["LBj"], 1 - t["LBi"]:Lm + 1 - t["LBi"]])
+    f.close()
+
+
 def test_nc3_reader_rejects_unsound_headers(tmp_path):
     """nc3.c reads files it did not write (initial and restart files handed to the run): a header with negative counts or
     lengths, or an unknown type, is refused with -9 before any allocation is sized from it; a sound header with more

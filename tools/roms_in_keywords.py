@@ -26,7 +26,7 @@ AKK_BAK AKP_BAK GLS_P GLS_M GLS_N GLS_Kmin GLS_Pmin GLS_CMU0 GLS_C1 GLS_C2 GLS_C
 HONOURED += ["LBC(isFsur)", "LBC(isUbar)", "LBC(isVbar)", "LBC(isUvel)", "LBC(isVvel)", "LBC(isMtke)", "LBC(isTvar)"]
 HONOURED_PREFIX = ["Aout(", "Hout("]        # the switches the averages / history writers know; the others are inert (below)
 HONOURED_AOUT = "idFsur idUbar idVbar idUvel idVvel idOvel idWvel idDano idTvar idZZav idU2av idV2av idUUav idVVav idUVav idHUav idHVav idTTav idUTav idVTav iHUTav iHVTav".split()
-HONOURED_HOUT = "idFsur idUbar idVbar idUvel idVvel idWvel idOvel idTvar idDano idVvis idTdif idSdif idHsbl".split()
+HONOURED_HOUT = "idFsur idUbar idVbar idUvel idVvel idWvel idOvel idTvar idDano idVvis idTdif idSdif idHsbl idMtke idMtls".split()
 
 CHECKED = {
     "Ngrids": "must be 1 (nesting is not built)", "NestLayers": "must be 1", "GridsInLayer": "must be 1",
