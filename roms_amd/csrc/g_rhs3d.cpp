@@ -46,14 +46,14 @@ bool launch_tadv_lds(roms_hip_ctx *c, int mode) {
   if (!mask) return false;
   KArgs a = mk(c);
   a.p1 = mask;
-  const int nt = ((nx + 63) / 64) * ((ny + 3) / 4);
+  const int nt = ((nx + TL_BX - 1) / TL_BX) * ((ny + TL_BY - 1) / TL_BY);
   int nz = KMAX(1, (2048 + nt - 1) / nt);
   int kc = KMAX(5, (G.N + nz - 1) / nz);
   if (ek && atoi(ek) > 0) kc = atoi(ek);
   kc = KMIN(kc, G.N);
   nz = (G.N + kc - 1) / kc;
   a.p0 = kc;
-  const dim3 grid((unsigned)(8 * ((nt + 7) / 8) * nz), 1, 1), block(64, 4, 1);
+  const dim3 grid((unsigned)(8 * ((nt + 7) / 8) * nz), 1, 1), block(TL_BX, TL_BY, 1);
   const size_t lds = (size_t)TL_LDS_DOUBLES * sizeof(double);
   static const char *ew = getenv("ROMS_HIP_TADV_W");
   const int w = ew ? atoi(ew) : (mode == 0 ? 2 : 3);

@@ -14,8 +14,13 @@
 #pragma once
 #include "roms_ctx.h"
 
-#define TL_TW 68
-#define TL_TH 8
+#ifndef TL_BX
+#define TL_BX 64                        // interior of a block: TL_BX x TL_BY points, 256 threads
+#define TL_BY 4
+#endif
+#define TL_TW (TL_BX + 4)
+#define TL_TH (TL_BY + 4)
+#define TL_NLD ((TL_TW * TL_TH + 255) / 256)   // staged loads per thread, tracer and level
 #define TL_NT (TL_TW * TL_TH)           // 544 values per tracer and level
 #define TL_MAXT 2                       // tracers per block (NT <= 2: temperature and salinity)
 #define TL_LDS_DOUBLES (2 * TL_MAXT * TL_NT)
@@ -23,7 +28,7 @@
 template <int MODE, int MINW>
 static __global__ void __launch_bounds__(256, MINW) k_tadv_lds(const KArgs a, int nx, int ny, int nz) {
   extern __shared__ double lds_dyn_[];
-  const int nby_ = (ny + 3) / 4, nt_ = ((nx + 63) / 64) * nby_, seg_ = (nt_ + 7) / 8;
+  const int nby_ = (ny + TL_BY - 1) / TL_BY, nt_ = ((nx + TL_BX - 1) / TL_BX) * nby_, seg_ = (nt_ + 7) / 8;
   const int r_ = (int)(blockIdx.x >> 3), xcd_ = (int)(blockIdx.x & 7);
   const int gz = r_ % nz;
   const int t_ = xcd_ * seg_ + r_ / nz;
@@ -35,8 +40,8 @@ static __global__ void __launch_bounds__(256, MINW) k_tadv_lds(const KArgs a, in
   const int KC = a.p0, N = G.N, NT = G.NT;
   const int k0 = gz * KC + 1, k1 = KMIN(N, k0 + KC - 1);
   if (k0 > N) return;
-  const int tx = (int)threadIdx.x, ty = (int)threadIdx.y, tid = tx + 64 * ty;
-  const int I0 = B.Istr + tbx * 64, J0 = B.Jstr + tby * 4;
+  const int tx = (int)threadIdx.x, ty = (int)threadIdx.y, tid = tx + TL_BX * ty;
+  const int I0 = B.Istr + tbx * TL_BX, J0 = B.Jstr + tby * TL_BY;
   const int i = I0 + tx, j = J0 + ty;
   const bool inside = i <= B.Iend && j <= B.Jend;
   const size_t nij = (size_t)G.nij;
@@ -47,27 +52,27 @@ static __global__ void __launch_bounds__(256, MINW) k_tadv_lds(const KArgs a, in
 #pragma unroll
   for (int it = 0; it < TL_MAXT; it++) Tsrc[it] = F.t + XT(G.LBi, G.LBj, 1, MODE == 0 ? G.nstp : 3, KMIN(it + 1, NT));
 
-  long gofs[3];
-  bool gok[3];
+  long gofs[TL_NLD];
+  bool gok[TL_NLD];
 #pragma unroll
-  for (int m = 0; m < 3; m++) {
+  for (int m = 0; m < TL_NLD; m++) {
     const int e = tid + m * 256;
     const int row = e / TL_TW, col = e - row * TL_TW;
     const int gi = I0 - 2 + col, gj = J0 - 2 + row;
     gok[m] = e < TL_NT && gi >= G.LBi && gi <= UBi && gj >= G.LBj && gj <= UBj;
     gofs[m] = gok[m] ? (long)X2(gi, gj) : 0;
   }
-  double st[TL_MAXT][3];
+  double st[TL_MAXT][TL_NLD];
   auto stage_load = [&](int k) {
     const size_t ok = (size_t)(k - 1) * nij;
 #pragma unroll
     for (int it = 0; it < TL_MAXT; it++)
 #pragma unroll
-      for (int m = 0; m < 3; m++) st[it][m] = (gok[m] && it < NT) ? Tsrc[it][ok + gofs[m]] : 0.0;
+      for (int m = 0; m < TL_NLD; m++) st[it][m] = (gok[m] && it < NT) ? Tsrc[it][ok + gofs[m]] : 0.0;
   };
   auto stage_store = [&](double *buf) {
 #pragma unroll
-    for (int m = 0; m < 3; m++)
+    for (int m = 0; m < TL_NLD; m++)
       if (tid + m * 256 < TL_NT) {
 #pragma unroll
         for (int it = 0; it < TL_MAXT; it++) buf[it * TL_NT + tid + m * 256] = st[it][m];
