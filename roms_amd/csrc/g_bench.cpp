@@ -25,7 +25,14 @@ int run_eos_nonlinear(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   const int N = c->G.N;
   KArgs a = mk(c);
-  LAUNCH_THREAD(k_eos_nl, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
+  const int nxe = B.IendT - B.IstrT + 1, nye = B.JendT - B.JstrT + 1;
+  static const char *ept = getenv("ROMS_HIP_EOSPT");
+  if (ept ? ept[0] != '0' : (long)nxe * nye <= 64L * 1024L) {       // few columns: chunks of five levels per thread + the column sums
+    static const char *ekc = getenv("ROMS_HIP_EOSKC");
+    a.p0 = ekc && atoi(ekc) > 0 ? atoi(ekc) : 5;
+    LAUNCH_THREAD(k_eos_nl_pt, nxe, nye, (N + a.p0 - 1) / a.p0, c->stream, a);
+    LAUNCH_THREAD(k_eos_sum, nxe, nye, 1, c->stream, a);
+  } else LAUNCH_THREAD(k_eos_nl, nxe, nye, 1, c->stream, a);
   if (c->G.fuse3d) return 0;   // the kernel stored the periodic images itself (pt_emit)
   HaloSpec sp[7] = {{c->F.rho, N, BC_NONE, 'r'},  {c->F.pden, N, BC_NONE, 'r'}, {c->F.alpha, 1, BC_NONE, 'r'},
                     {c->F.beta, 1, BC_NONE, 'r'}, {c->F.rhoA, 1, BC_NONE, 'r'}, {c->F.rhoS, 1, BC_NONE, 'r'},

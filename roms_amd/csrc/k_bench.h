@@ -137,6 +137,87 @@ THREAD_KERNEL(k_eos_nl, KArgs) {
 }
 THREAD_GLOBAL(k_eos_nl, KArgs)
 
+// The same routine for grids with too few columns to fill the chip (BENCHMARK1: 33 K columns = two waves per CU of a
+// kernel that evaluates a 40-term polynomial per level): one thread per column and CHUNK of p0 levels (grid.z = chunk,
+// counted from the surface), the level above the chunk evaluated once more for the chunk's uppermost Brunt-Vaisala
+// value; the two vertical integrals rhoA, rhoS -- a recurrence over the whole column -- are k_eos_sum's.  Same bits.
+THREAD_KERNEL(k_eos_nl_pt, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, N = G.N, nrhs = G.nrhs, KC = a.p0;
+  const int k1 = N - gz * KC, k0 = KMAX(k1 - KC + 1, 1);
+  if (k1 < 1) return;
+  const double g = G.g;
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);
+  EosLevel up = {};
+  double zr_up = 0.0;
+  if (k1 < N) {
+    zr_up = F.z_r[X3(i, j, k1 + 1)];
+    up = eos_level(F.t[XT(i, j, k1 + 1, nrhs, 1)], F.t[XT(i, j, k1 + 1, nrhs, 2)], zr_up);
+  }
+  for (int k = k1; k >= k0; k--) {
+    const double zr_k = F.z_r[X3(i, j, k)];
+    EosLevel L = eos_level(F.t[XT(i, j, k, nrhs, 1)], F.t[XT(i, j, k, nrhs, 2)], zr_k);
+    if (G.masking) L.den = L.den * F.rmask[X2(i, j)];                                    // rho_eos.F:357
+    emit_store(G, P, F.rho + (size_t)(k - 1) * G.nij, L.den);
+    emit_store(G, P, F.pden + (size_t)(k - 1) * G.nij, G.masking ? (L.den1 - 1000.0) * F.rmask[X2(i, j)] : (L.den1 - 1000.0));   // :479
+    if (k == N) {
+      const double Tpr10 = 0.1 * zr_k;
+      const double cff = L.bulk + Tpr10;
+      const double c1 = Tpr10 * L.den1;
+      const double c2 = L.bulk * cff;
+      const double wrk = (L.den + 1000.0) * cff * cff;
+      const double Tcof = -(L.DbulkDT * c1 + L.Dden1DT * c2);
+      const double Scof = (L.DbulkDS * c1 + L.Dden1DS * c2);
+      const double o = 1.0 / wrk;
+      emit_store(G, P, F.alpha, o * Tcof);
+      emit_store(G, P, F.beta, o * Scof);
+      emit_store(G, P, F.bvf + (size_t)N * G.nij, 0.0);
+    } else {
+      const double zw = F.z_w[XW(i, j, k)];
+      const double bulk_up = up.bulk0 - zw * (up.bulk1 - up.bulk2 * zw);
+      const double bulk_dn = L.bulk0 - zw * (L.bulk1 - L.bulk2 * zw);
+      const double c1 = 1.0 / (bulk_up + 0.1 * zw);
+      const double c2 = 1.0 / (bulk_dn + 0.1 * zw);
+      const double den_up = c1 * (up.den1 * bulk_up);
+      const double den_dn = c2 * (L.den1 * bulk_dn);
+      emit_store(G, P, F.bvf + (size_t)k * G.nij, -g * (den_up - den_dn) / (0.5 * (den_up + den_dn) * (zr_up - zr_k)));
+    }
+    up = L;
+    zr_up = zr_k;
+  }
+  if (k0 == 1) emit_store(G, P, F.bvf, 0.0);
+}
+THREAD_GLOBAL(k_eos_nl_pt, KArgs)
+
+// rhoA, rhoS (rho_eos.F:382-420) from the rho that k_eos_nl_pt stored: the recurrence from the surface down
+THREAD_KERNEL(k_eos_sum, KArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, N = G.N;
+  const EmitPlan P = emit_plan(G, BC_NONE, i, j);
+  double rhoA = 0.0, rhoS = 0.0;
+  for (int k0 = N; k0 >= 1; k0 -= 6) {
+    double c_r[6], c_hz[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) { const int kk = KMAX(k0 - q, 1); c_r[q] = F.rho[X3(i, j, kk)]; c_hz[q] = F.Hz[X3(i, j, kk)]; }
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const int k = k0 - q;
+      if (k < 1) break;
+      const double Hzk = c_hz[q], cff1 = c_r[q] * Hzk;
+      if (k == N) { rhoS = 0.5 * cff1 * Hzk; rhoA = cff1; }
+      else { rhoS = rhoS + Hzk * (rhoA + 0.5 * cff1); rhoA = rhoA + cff1; }
+    }
+  }
+  const double cff2 = 1.0 / G.rho0;
+  const double cff1 = 1.0 / (F.z_w[XW(i, j, N)] - F.z_w[XW(i, j, 0)]);
+  emit_store(G, P, F.rhoA, cff2 * cff1 * rhoA);
+  emit_store(G, P, F.rhoS, 2.0 * cff1 * cff1 * cff2 * rhoS);
+}
+THREAD_GLOBAL(k_eos_sum, KArgs)
+
 // --------------------------------------------------------------------------------- t3dmix2_geo
 // Point-wise: a thread marches up a chunk of KCH levels of its column (grid.z = chunk + nchunk*(itrc-1),
 // p0 = nchunk) with the reference's two-level rolling buffers (k1, k2) held in registers: the

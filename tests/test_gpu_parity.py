@@ -547,6 +547,8 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
                            # step3d_uv's column kernel with CF, DC in LDS and every level re-read in the down sweep (the form
                            # before the register-resident one, k_s3uv_col_rt)
                            ("uvlds", {"ROMS_HIP_UVREG": "0"}),
+                           # nonlinear EOS as one thread per column (the form of large grids) instead of chunks of five levels
+                           ("eoscol", {"ROMS_HIP_EOSPT": "0"}),
                            # KPP as two kernels with the spline columns in 3-D work arrays instead of one COL kernel
                            ("lmd2", {"ROMS_HIP_LMDCOL": "0"}), ("lmdcol", {"ROMS_HIP_LMDCOL": "1"}),
                            # the reference's order of a step (pre_step3d before prsgrd/rhs3d_tile, everything before the
