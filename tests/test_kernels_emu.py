@@ -431,3 +431,18 @@ def test_generic_length_scale_closure_through_the_fortran_host(emu, tag, monkeyp
         for n in ("zeta", "u", "v", "t", "Akv", "Akt", "tke", "gls", "Lscale", "Akk", "Akp"):
             assert np.array_equal(ctx.download(n), O.field(n)), (n, w.keys())
         H.finalize()
+
+
+def test_generic_length_scale_closure_with_open_boundaries(emu):
+    """KELVIN (Chapman / Flather / radiation edges, k_obc.h) with GLS_MIXING: 20 steps, every array the oracle's bits; the
+    bottom stress of the Kelvin wave drives the closure hard (Akv four orders above its background)."""
+    cs, g = util.kelvin_gls_case()
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start(); H.start()
+    for _ in range(20):
+        O.main3d_step(); H.main3d(1)
+        for n in util.PROGNOSTIC:
+            assert np.array_equal(H.download(n), O.field(n)), n
+    assert O.field("Akv").max() > 1e4 * cs["Akv_bak"]
+    H.close()
