@@ -739,8 +739,8 @@ def test_generic_length_scale_closure_matches_oracle(tag):
 
 @pytest.mark.gpu
 def test_generic_length_scale_closure_with_open_boundaries_matches_oracle():
-    """KELVIN's open boundaries with GLS_MIXING on the GPU, 40 steps: the closure is driven hard here (Akv four orders
-    above its background), the device `pow` differs from libm's in the last bits: turbulent fields 1e-7, circulation 1e-9."""
+    """KELVIN's open boundaries with GLS_MIXING on the GPU, 40 steps: the closure is driven hard here (Akv three to four
+    orders above its background), the device `pow` differs from libm's in the last bits: turbulent fields 1e-7, circulation 1e-9."""
     cs, g = util.kelvin_gls_case()
     O = util.make_oracle(cs, g)
     H = util.make_hip(cs, g)
@@ -753,7 +753,7 @@ def test_generic_length_scale_closure_with_open_boundaries_matches_oracle():
         a, b = H.download(n), O.field(n)
         assert np.isfinite(a).all(), n
         assert util.relrms(a, b) <= (1e-7 if n in turb else 1e-9), (n, util.relrms(a, b))
-    assert O.field("Akv").max() > 1e4 * cs["Akv_bak"]
+    assert O.field("Akv").max() > 1e3 * cs["Akv_bak"]
     H.close()
 
 
