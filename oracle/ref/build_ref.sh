@@ -101,6 +101,11 @@ if [ "$APP" = grav_adj ]; then
   UP=GRAV_ADJ; HDR=grav_adj_nodiag; HDRPATH="$HERE/grav_adj_nodiag.h"
   EXTRA=""
 fi
+if [ "$APP" = kelvin_gls ]; then
+  # KELVIN (open boundaries, spline solvers) with GLS_MIXING (oracle/ref/kelvin_gls.h): tkebc next to radiating edges
+  UP=KELVIN; HDR=kelvin_gls; HDRPATH="$HERE/kelvin_gls.h"
+  EXTRA=""
+fi
 if [ "$APP" = kelvin_splines ]; then
   # the KELVIN case (open boundaries) with the spline vertical solvers (oracle/ref/kelvin_splines.h)
   UP=KELVIN; HDR=kelvin_splines; HDRPATH="$HERE/kelvin_splines.h"

@@ -179,6 +179,18 @@ def upwelling_gls(form="upwelling_gls", closure="k-epsilon", **kw):
     return cs
 
 
+def kelvin_gls(**kw):
+    """KELVIN (open boundaries) with the generic length-scale closure (Canuto A, smoothing, spline shear; k-epsilon):
+    the custom application header oracle/ref/kelvin_gls.h"""
+    cs = kelvin(**kw)
+    cs["app"] = "kelvin_gls"
+    cs["options"] = tuple(cs["options"]) + ("GLS_MIXING",)
+    cs["gls_flags"] = ("CANUTO_A", "N2S2_HORAVG", "RI_SPLINES")
+    cs.update(dict(zip(GLS_NAMES, GLS_SETS["k-epsilon"])))
+    cs.update(Akk_bak=5.0e-6, Akp_bak=5.0e-6, charnok_alpha=1400.0, zos_hsig_alpha=0.5, sz_alpha=0.25, crgban_cw=100.0)
+    return cs
+
+
 def upwelling_my25(form="upwelling_my25", **kw):
     """UPWELLING with the Mellor-Yamada level 2.5 closure (MY25_MIXING): upwelling.h built with -DMY25_MIXING
     (KANTHA_CLAYSON, N2S2_HORAVG, RI_SPLINES), or oracle/ref/upwelling_my25_gal.h (Galperin, K_C4ADVECTION).  The closure

@@ -49,6 +49,7 @@ CASES = {
     "grav_adj_small": ("grav_adj", dict(Lm=32, Mm=4, N=10)),
     "kelvin": ("kelvin_splines", dict()),
     "kelvin_small": ("kelvin_splines", dict(Lm=16, Mm=12, N=6)),
+    "kelvin_gls_small": ("kelvin_gls", dict(Lm=16, Mm=12, N=6)),       # open boundaries + GLS_MIXING (oracle/ref/kelvin_gls.h)
     "kelvin_plain_small": ("kelvin", dict(Lm=16, Mm=12, N=6, plain=True)),   # kelvin.h as shipped: the plain vertical solvers
     "kelvin_plain": ("kelvin", dict(plain=True)),
     # ... and closed-basin variants of the other libraries for the routine-level tests (no RADIATION_2D; MASKING)
@@ -135,7 +136,7 @@ def make_case(tag, **kw):
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
                 upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
-                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, seamount=cases.seamount, grav_adj=cases.grav_adj, upwelling_prs31=cases.upwelling_prs31,
+                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, upwelling_prs31=cases.upwelling_prs31,
                 upwelling_wjgradp=cases.upwelling_prs31, upwelling_prs40=cases.upwelling_prs40, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
                 upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]

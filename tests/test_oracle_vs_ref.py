@@ -254,6 +254,10 @@ MAIN3D_CASES = [
     ("upwelling_my25_gal_small", ["nsteps=60"]),
     ("upwelling_my25_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("upwelling_my25_gal_small", ["nsteps=20", "NtileI=3", "NtileJ=1", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
+    # open boundaries together with GLS_MIXING (oracle/ref/kelvin_gls.h): tkebc's zero-gradient edges beside radiating ones,
+    # the closure driven by the Kelvin wave's bottom stress
+    ("kelvin_gls_small", ["nsteps=60"]),
+    ("kelvin_gls_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
     ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
 ]

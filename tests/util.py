@@ -122,12 +122,8 @@ def with_gls(cs, g):
 def kelvin_gls_case():
     """the KELVIN application (open boundaries: Chapman / Flather west, radiation east) with the generic length-scale
     closure in place of its background coefficients -- the combination of k_obc.h and k_gls.h, tkebc's zero-gradient
-    edges next to radiating ones (the oracle is pinned for each of the two parts, not for this combination)"""
-    cs = case_for("kelvin_small")
-    cs["options"] = tuple(cs["options"]) + ("GLS_MIXING",)
-    cs["gls_flags"] = ("CANUTO_A", "N2S2_HORAVG", "RI_SPLINES")
-    cs.update(dict(zip(cases.GLS_NAMES, cases.GLS_SETS["k-epsilon"])))
-    cs.update(Akk_bak=5.0e-6, Akp_bak=5.0e-6, charnok_alpha=1400.0, zos_hsig_alpha=0.5, sz_alpha=0.25, crgban_cw=100.0)
+    edges next to radiating ones (pinned: the reference built from oracle/ref/kelvin_gls.h)"""
+    cs = cases.kelvin_gls(Lm=16, Mm=12, N=6)
     return cs, with_gls(cs, load_init("kelvin_small", nghost_for(cs)))
 
 
