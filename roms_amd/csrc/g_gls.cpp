@@ -102,8 +102,9 @@ int run_gls_corstep(roms_hip_ctx *c) {
   const GlsArgs a = gls_args(c);
   LAUNCH_THREAD(k_gls_shear, B.Iendp1 - B.Istrm1 + 1, B.Jendp1 - B.Jstrm1 + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_gls_adv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
-  static const char *ecl = getenv("ROMS_HIP_COLLDS");
-  if (!(ecl && ecl[0] == '0') && (size_t)2 * (G.N + 1) * 64 * sizeof(double) < 64 * 1024)
+  // the sweeps in private memory: 412 us at 512x512x50; in LDS (COL launch, three waves per CU at N = 50): 691 us -- opt-in only
+  static const char *ecl = getenv("ROMS_HIP_GLSLDS");
+  if (ecl && ecl[0] == '1' && (size_t)2 * (G.N + 1) * 64 * sizeof(double) < 64 * 1024)
     LAUNCH_COL(k_gls_solve_l, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, 2 * (G.N + 1), c->stream, a);
   else LAUNCH_THREAD(k_gls_solve, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_gls_coef, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
