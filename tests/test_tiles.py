@@ -56,15 +56,12 @@ def _interior(cs_dims, a):
 
 @pytest.mark.parametrize("tag,kw,tiles,port", [
     ("upwelling_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 1), 29611),
-    ("upwelling_small", dict(hadv=("U3", "U3"), vadv=("C4", "C4")), (1, 2), 29612),
-    ("benchmark_small", dict(), (2, 2), 29613),
     # the 8-GPU partition of bench.py: every neighbour of a tile (sides and diagonals) is a different rank
     ("benchmark_small", dict(), (4, 2), 29615),
     # three ghost lines on the high side (MPDATA), corner blocks from the diagonal tiles
     ("upwelling_small", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (2, 2), 29614),
-    # MASKING: the island straddles the tile boundaries, the headland sits on the southern wall of one tile
-    ("upwelling_mask_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 2), 29616),
-    # MASKING with MPDATA: the masked cross-gradient terms read umask/vmask in the ghost lines
+    # MASKING (the island straddles the tile boundaries, the headland sits on the southern wall of one tile) with MPDATA: the
+    # masked cross-gradient terms read umask/vmask in the ghost lines (plain MASKING on 2x2 tiles: upwelling_mask_mid below)
     ("upwelling_mask_small", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (2, 2), 29622),
     # tiles of 8 points and more: the barotropic steps run as predictor+corrector pairs (k_step2d_pair.h) with one exchange of
     # 5 | 4 lines per pair -- 2x2 (corner blocks of the wide strips), the 8-rank layout, three ghost lines + MPDATA, MASKING
@@ -76,7 +73,6 @@ def _interior(cs_dims, a):
     # open boundaries (the reference's KELVIN application): the western and eastern conditions read along the edge across
     # the tile boundary (the tangential differences of the radiation condition), corner tiles hold both kinds of edge
     ("kelvin_small", dict(), (2, 2), 29623),
-    ("kelvin_small", dict(), (1, 2), 29624),
     # SEAMOUNT (no-slip walls) and GRAV_ADJ (MPDATA, closed in xi, periodic and four points wide in eta: tiles along xi)
     ("seamount_small", dict(), (2, 2), 29625),
     ("grav_adj_small", dict(), (2, 1), 29626),
