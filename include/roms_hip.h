@@ -59,6 +59,8 @@ enum {
   ROMS_MY25_MIXING = 1 << 28,       /* Mellor-Yamada level 2.5 closure (my25_prestep.F, my25_corstep.F): the entries roms_hip_gls_prestep /
                                        _corstep run it; KANTHA_CLAYSON, N2S2_HORAVG, RI_SPLINES, K_C2/K_C4ADVECTION in gls_flags; GLS_Kmin, GLS_Pmin
                                        (start values) and AKK_BAK from the same roms.in block */
+  ROMS_MIX_ISO_TS = 1 << 29,        /* harmonic tracer mixing along isopycnic surfaces, t3dmix2_iso.h (its default slope treatment) */
+  ROMS_APP_OVERFLOW = 1 << 30,      /* the OVERFLOW application: unforced, like SEAMOUNT and GRAV_ADJ */
   ROMS_GLS_MIXING = 1 << 25,        /* generic length-scale vertical closure (gls_prestep.F, gls_corstep.F); its compile-time
                                        forms in roms_hip_config.gls_flags, its roms.in parameters beside them */
   ROMS_APP_UPWELLING = 1 << 20, ROMS_APP_BENCHMARK = 1 << 21,

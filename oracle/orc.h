@@ -49,6 +49,8 @@ enum {
   ORC_PRSGRD40 = 1 << 26,     /* PJ_GRADP: the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h */
   ORC_MY25_MIXING = 1 << 28,  /* Mellor-Yamada level 2.5 closure: my25_prestep.F, my25_corstep.F (options KANTHA_CLAYSON, N2S2_HORAVG,
                                  RI_SPLINES, K_C2ADVECTION | K_C4ADVECTION in cfg.gls_flags; start values GLS_Kmin, GLS_Pmin; AKK_BAK) */
+  ORC_MIX_ISO_TS = 1 << 29,   /* harmonic tracer mixing along isopycnic surfaces, t3dmix2_iso.h (else MIX_GEO_TS or MIX_S_TS) */
+  ORC_APP_OVERFLOW = 1 << 30, /* the OVERFLOW application: unforced, like SEAMOUNT and GRAV_ADJ */
   ORC_GLS_MIXING = 1 << 25,   /* generic length-scale closure: gls_prestep.F, gls_corstep.F (its compile-time forms: cfg.gls_flags) */
   ORC_APP_UPWELLING = 1 << 20, ORC_APP_BENCHMARK = 1 << 21, ORC_APP_KELVIN = 1 << 22, ORC_APP_SEAMOUNT = 1 << 23, ORC_APP_GRAV_ADJ = 1 << 24   /* (no forcing: the default branches of ana_smflux.h ...) */
 };

@@ -21,6 +21,8 @@ WJ_GRADP = 1 << 27
 GLS_MIXING = 1 << 25
 PRSGRD40 = 1 << 26
 MY25_MIXING = 1 << 28
+MIX_ISO_TS = 1 << 29
+APP_OVERFLOW = 1 << 30
 GLS_FLAGS = {"CANUTO_A": 1, "CANUTO_B": 2, "KANTHA_CLAYSON": 4, "N2S2_HORAVG": 8, "RI_SPLINES": 16,
              "K_C2ADVECTION": 32, "K_C4ADVECTION": 64, "CHARNOK": 128, "CRAIG_BANNER": 256}
 APP_UPWELLING, APP_BENCHMARK, APP_KELVIN, APP_SEAMOUNT, APP_GRAV_ADJ = 1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 24

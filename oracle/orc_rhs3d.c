@@ -19,6 +19,7 @@
 #define MIN(a, b) ((a) < (b) ? (a) : (b))
 
 void orc_t3dmix2_geo(orc_t *o, int tile);                       /* orc_t3dmix_geo.c */
+void orc_t3dmix2_iso(orc_t *o, int tile);
 void orc_lmd_swfrac(const orc_t *o, const orc_bounds *b, double Zscale, const double *Z,
                     double *swdk);                               /* orc_lmd.c */
 
@@ -663,6 +664,7 @@ void orc_prsgrd(orc_t *o, int tile) {
 void orc_t3dmix2(orc_t *o, int tile) {
   if (!(o->c.options & ORC_TS_DIF2)) return;
   if (o->c.options & ORC_MIX_GEO_TS) { orc_t3dmix2_geo(o, tile); return; }
+  if (o->c.options & ORC_MIX_ISO_TS) { orc_t3dmix2_iso(o, tile); return; }
   ORC_LOCALS(o);
   const orc_bounds *b = &o->b[tile];
   const int nrhs = o->s.nrhs, nnew = o->s.nnew;

@@ -1,10 +1,12 @@
 /*
- * orc_t3dmix_geo.c -- harmonic tracer mixing along geopotential surfaces.
+ * orc_t3dmix_geo.c -- harmonic tracer mixing along geopotential surfaces, and along isopycnic surfaces.
  * TEST INFRASTRUCTURE (see orc.h).
  *
  * Follows t3dmix2_geo_tile, ROMS/Nonlinear/t3dmix2_geo.h:90-420 (rotated mixing tensor with the
  * two-level k1/k2 rolling buffers of the reference).
- * PARITY: pinned (t3dmix.F builds in oracle/_ref).
+ * orc_t3dmix2_iso: t3dmix2_iso_tile, ROMS/Nonlinear/t3dmix2_iso.h:95-440 (MIX_ISO_TS; the default slope treatment:
+ * none of TS_MIX_MAX_SLOPE, TS_MIX_MIN_STRAT, TS_MIX_STABILITY, TS_MIX_CLIMA).
+ * PARITY: pinned (t3dmix.F builds in oracle/_ref: BENCHMARK for the geopotential form, OVERFLOW for the isopycnic one).
  */
 #include "orc.h"
 #include <stdlib.h>
@@ -93,6 +95,104 @@ void orc_t3dmix2_geo(orc_t *o, int tile) {
                                         cff2 * (cff2 * L2(dTdz, i, j, k2) - L2(dTde, i, j + 1, k2)) +
                                         cff3 * (cff3 * L2(dTdz, i, j, k2) - L2(dTde, i, j, k2)) +
                                         cff4 * (cff4 * L2(dTdz, i, j, k2) - L2(dTde, i, j + 1, k1)));
+            }
+        }
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff = dt * pm[X2(i, j)] * pn[X2(i, j)];
+            cff1 = cff * (FX[X2(i + 1, j)] - FX[X2(i, j)]);
+            cff2 = cff * (FE[X2(i, j + 1)] - FE[X2(i, j)]);
+            cff3 = dt * (L2(FS, i, j, k2) - L2(FS, i, j, k1));
+            cff4 = cff1 + cff2 + cff3;
+            t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] + cff4;
+          }
+      }
+    }
+  }
+  free(S);
+}
+
+void orc_t3dmix2_iso(orc_t *o, int tile) {
+  ORC_LOCALS(o);
+  const orc_bounds *b = &o->b[tile];
+  const int nrhs = o->s.nrhs, nnew = o->s.nnew;
+  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
+  const double dt = o->c.dt, eps = 0.5;
+  double *t = o->t, *z_r = o->z_r, *Hz = o->Hz, *pm = o->pm, *pn = o->pn, *diff2 = o->diff2, *pden = o->pden;
+  double *S = (double *)calloc(14 * nij, sizeof(double));
+  double *FE = S, *FX = S + nij, *FS = S + 2 * nij, *dTdr = S + 4 * nij, *dTdx = S + 6 * nij,
+         *dTde = S + 8 * nij, *dRdx = S + 10 * nij, *dRde = S + 12 * nij;
+  double cff, cff1, cff2, cff3, cff4;
+  for (int itrc = 1; itrc <= o->c.NT; itrc++) {
+    int k1, k2 = 1;
+    for (int k = 0; k <= N; k++) {
+      k1 = k2;
+      k2 = 3 - k1;
+      if (k < N) {
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = Istr; i <= Iend + 1; i++) {
+            cff = 0.5 * (pm[X2(i, j)] + pm[X2(i - 1, j)]);
+            if (o->c.options & ORC_MASKING) cff = cff * o->umask[X2(i, j)];
+            L2(dRdx, i, j, k2) = cff * (pden[X3(i, j, k + 1)] - pden[X3(i - 1, j, k + 1)]);
+            L2(dTdx, i, j, k2) = cff * (t[XT(i, j, k + 1, nrhs, itrc)] - t[XT(i - 1, j, k + 1, nrhs, itrc)]);
+          }
+        for (int j = Jstr; j <= Jend + 1; j++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff = 0.5 * (pn[X2(i, j)] + pn[X2(i, j - 1)]);
+            if (o->c.options & ORC_MASKING) cff = cff * o->vmask[X2(i, j)];
+            L2(dRde, i, j, k2) = cff * (pden[X3(i, j, k + 1)] - pden[X3(i, j - 1, k + 1)]);
+            L2(dTde, i, j, k2) = cff * (t[XT(i, j, k + 1, nrhs, itrc)] - t[XT(i, j - 1, k + 1, nrhs, itrc)]);
+          }
+      }
+      if (k == 0 || k == N) {
+        for (int j = Jstr - 1; j <= Jend + 1; j++)
+          for (int i = Istr - 1; i <= Iend + 1; i++) { L2(dTdr, i, j, k2) = 0.0; L2(FS, i, j, k2) = 0.0; }
+      } else {
+        for (int j = Jstr - 1; j <= Jend + 1; j++)
+          for (int i = Istr - 1; i <= Iend + 1; i++) {
+            cff1 = MAX(pden[X3(i, j, k)] - pden[X3(i, j, k + 1)], eps);
+            cff = -1.0 / cff1;
+            L2(dTdr, i, j, k2) = cff * (t[XT(i, j, k + 1, nrhs, itrc)] - t[XT(i, j, k, nrhs, itrc)]);
+            L2(FS, i, j, k2) = cff * (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]);
+          }
+      }
+      if (k > 0) {
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = Istr; i <= Iend + 1; i++) {
+            cff = 0.25 * (diff2[X2T(i, j, itrc)] + diff2[X2T(i - 1, j, itrc)]) * o->on_u[X2(i, j)];
+            FX[X2(i, j)] = cff * (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]) *
+                           (L2(dTdx, i, j, k1) -
+                            0.5 * (MAX(L2(dRdx, i, j, k1), 0.0) * (L2(dTdr, i - 1, j, k1) + L2(dTdr, i, j, k2)) +
+                                   MIN(L2(dRdx, i, j, k1), 0.0) * (L2(dTdr, i - 1, j, k2) + L2(dTdr, i, j, k1))));
+          }
+        for (int j = Jstr; j <= Jend + 1; j++)
+          for (int i = Istr; i <= Iend; i++) {
+            cff = 0.25 * (diff2[X2T(i, j, itrc)] + diff2[X2T(i, j - 1, itrc)]) * o->om_v[X2(i, j)];
+            FE[X2(i, j)] = cff * (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]) *
+                           (L2(dTde, i, j, k1) -
+                            0.5 * (MAX(L2(dRde, i, j, k1), 0.0) * (L2(dTdr, i, j - 1, k1) + L2(dTdr, i, j, k2)) +
+                                   MIN(L2(dRde, i, j, k1), 0.0) * (L2(dTdr, i, j - 1, k2) + L2(dTdr, i, j, k1))));
+          }
+        if (k < N) {
+          for (int j = Jstr; j <= Jend; j++)
+            for (int i = Istr; i <= Iend; i++) {
+              cff1 = MAX(L2(dRdx, i, j, k1), 0.0);
+              cff2 = MAX(L2(dRdx, i + 1, j, k2), 0.0);
+              cff3 = MIN(L2(dRdx, i, j, k2), 0.0);
+              cff4 = MIN(L2(dRdx, i + 1, j, k1), 0.0);
+              cff = cff1 * (cff1 * L2(dTdr, i, j, k2) - L2(dTdx, i, j, k1)) +
+                    cff2 * (cff2 * L2(dTdr, i, j, k2) - L2(dTdx, i + 1, j, k2)) +
+                    cff3 * (cff3 * L2(dTdr, i, j, k2) - L2(dTdx, i, j, k2)) +
+                    cff4 * (cff4 * L2(dTdr, i, j, k2) - L2(dTdx, i + 1, j, k1));
+              cff1 = MAX(L2(dRde, i, j, k1), 0.0);
+              cff2 = MAX(L2(dRde, i, j + 1, k2), 0.0);
+              cff3 = MIN(L2(dRde, i, j, k2), 0.0);
+              cff4 = MIN(L2(dRde, i, j + 1, k1), 0.0);
+              cff = cff + cff1 * (cff1 * L2(dTdr, i, j, k2) - L2(dTde, i, j, k1)) +
+                    cff2 * (cff2 * L2(dTdr, i, j, k2) - L2(dTde, i, j + 1, k2)) +
+                    cff3 * (cff3 * L2(dTdr, i, j, k2) - L2(dTde, i, j, k2)) +
+                    cff4 * (cff4 * L2(dTdr, i, j, k2) - L2(dTde, i, j + 1, k1));
+              L2(FS, i, j, k2) = 0.5 * cff * diff2[X2T(i, j, itrc)] * L2(FS, i, j, k2);
             }
         }
         for (int j = Jstr; j <= Jend; j++)

@@ -96,6 +96,11 @@ if [ "$APP" = seamount ]; then
   UP=SEAMOUNT; HDR=seamount_nodiag; HDRPATH="$HERE/seamount_nodiag.h"
   EXTRA=""
 fi
+if [ "$APP" = overflow ]; then
+  # the OVERFLOW case (MIX_ISO_TS: t3dmix2_iso.h) without its output option AVERAGES (oracle/ref/overflow_noavg.h)
+  UP=OVERFLOW; HDR=overflow_noavg; HDRPATH="$HERE/overflow_noavg.h"
+  EXTRA=""
+fi
 if [ "$APP" = grav_adj ]; then
   # the GRAV_ADJ case without its output options AVERAGES / DIAGNOSTICS_TS / DIAGNOSTICS_UV (oracle/ref/grav_adj_nodiag.h)
   UP=GRAV_ADJ; HDR=grav_adj_nodiag; HDRPATH="$HERE/grav_adj_nodiag.h"

@@ -93,6 +93,21 @@ def grav_adj(Lm=128, Mm=4, N=40, NtileI=1, NtileJ=1, ntimes=100):
     )
 
 
+def overflow(Lm=4, Mm=128, N=20, NtileI=1, NtileJ=1, ntimes=100):
+    """roms_overflow.in (ROMS/Include/overflow.h): cold dense water released at the top of a slope in a closed channel four
+    points wide; tracer mixing along isopycnic surfaces (MIX_ISO_TS), spline vertical advection, the 1994 s-coordinate
+    (Vtransform 1, Vstretching 1), no rotation, no forcing, no closure."""
+    return dict(
+        app="overflow", Lm=Lm, Mm=Mm, N=N, NtileI=NtileI, NtileJ=NtileJ, ndtfast=20, ntimes=ntimes,
+        Vtransform=1, Vstretching=1, EWperiodic=0, NSperiodic=0, hadv=("U3", "U3"), vadv=("SPLINES", "SPLINES"), lmd_Jwt=1,
+        dt=20.0, theta_s=3.0, theta_b=1.0, Tcline=50.0, rho0=1025.0, R0=1030.0, T0=5.0, S0=0.0,
+        Tcoef=1.7e-4, Scoef=0.0, visc2=5.0, tnu2=(5.0, 0.0), Akt_bak=(0.0, 0.0), Akv_bak=0.0,
+        rdrg=0.0, rdrg2=0.0, Zob=0.0, Zos=0.0, gamma2=1.0, dstart=0.0,
+        blk_ZQ=10.0, blk_ZT=10.0, blk_ZW=10.0,
+        options=("UV_ADV", "UV_COR", "UV_QDRAG", "UV_VIS2", "TS_DIF2", "MIX_ISO_TS", "APP_OVERFLOW"),
+    )
+
+
 def upwelling(Lm=41, Mm=80, N=16, NtileI=1, NtileJ=1, hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"),
               ntimes=100):
     """roms_upwelling.in"""

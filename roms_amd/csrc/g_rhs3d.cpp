@@ -136,7 +136,7 @@ int run_t3dmix2(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   if (!(G.options & ROMS_TS_DIF2)) return 0;
-  if (G.options & ROMS_MIX_GEO_TS) return run_t3dmix2_geo(c);
+  if (G.options & (ROMS_MIX_GEO_TS | ROMS_MIX_ISO_TS)) return run_t3dmix2_geo(c);     // (the isopycnic form: the same marching kernel on pden)
   KArgs a = mk(c);
   static const char *et = getenv("ROMS_HIP_T3CH");
   // large grids: a thread loops over the column (512x512x50: KCH 228, 10: 216, 25: 211, 50: 210 us)

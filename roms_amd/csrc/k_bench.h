@@ -326,6 +326,94 @@ THREAD_KERNEL(k_t3dmix2_geo, KArgs) {
 }
 THREAD_GLOBAL(k_t3dmix2_geo, KArgs)
 
+// --------------------------------------------------------------------------------- t3dmix2_iso
+// Harmonic tracer mixing along isopycnic surfaces (MIX_ISO_TS; t3dmix2_iso.h:200-440, its default slope treatment): the
+// same marching kernel as k_t3dmix2_geo with the potential density in the place of the depth -- the gradients of pden at
+// the four faces, dT/drho at the five columns (the stratification floored at eps = 0.5), the vertical flux scaled by the
+// layer thickness over the density step -- and MAX / MIN exchanged in the slope selections (:348-400).
+KDEV GeoTz iso_tr(const GeoLev &lo, const GeoLev &up, bool zero) {   // dTdr at the W level between rho levels lo and up (z*: pden)
+  GeoTz T;
+  if (zero) { T.c = T.w = T.e = T.s = T.n = 0.0; return T; }
+  const double eps = 0.5;
+  { const double cff = -1.0 / KMAX(lo.zc - up.zc, eps); T.c = cff * (up.tc - lo.tc); }
+  { const double cff = -1.0 / KMAX(lo.zw - up.zw, eps); T.w = cff * (up.tw - lo.tw); }
+  { const double cff = -1.0 / KMAX(lo.ze - up.ze, eps); T.e = cff * (up.te - lo.te); }
+  { const double cff = -1.0 / KMAX(lo.zs - up.zs, eps); T.s = cff * (up.ts - lo.ts); }
+  { const double cff = -1.0 / KMAX(lo.zn - up.zn, eps); T.n = cff * (up.tn - lo.tn); }
+  return T;
+}
+// FS at the W level between rho levels k1 (D1) and k2 (D2) :386-415; fac = -(z_r(k2)-z_r(k1)) / max(pden(k1)-pden(k2), eps)
+KDEV double iso_fs(const GeoGrad &D1, const GeoGrad &D2, double tr, double d2c, double fac) {
+  double c1 = KMAX(D1.zxi, 0.0), c2 = KMAX(D2.zxp, 0.0), c3 = KMIN(D2.zxi, 0.0), c4 = KMIN(D1.zxp, 0.0);
+  double cff = c1 * (c1 * tr - D1.txi) + c2 * (c2 * tr - D2.txp) + c3 * (c3 * tr - D2.txi) + c4 * (c4 * tr - D1.txp);
+  c1 = KMAX(D1.zej, 0.0); c2 = KMAX(D2.zep, 0.0); c3 = KMIN(D2.zej, 0.0); c4 = KMIN(D1.zep, 0.0);
+  cff = cff + c1 * (c1 * tr - D1.tej) + c2 * (c2 * tr - D2.tep) + c3 * (c3 * tr - D2.tej) + c4 * (c4 * tr - D1.tep);
+  return 0.5 * cff * d2c * fac;
+}
+THREAD_KERNEL(k_t3dmix2_iso, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const int nch = a.p0, gch = a.p1, itrc = gz / nch + 1, k0 = (gz - (itrc - 1) * nch) * gch + 1;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy, N = G.N;
+  if (k0 > N) return;
+  const int k1 = KMIN(k0 + gch - 1, N);
+  const size_t nij = (size_t)G.nij;
+  const long ni = G.ni, x = (long)X2(i, j);
+  const double *pm = F.pm + x, *pn = F.pn + x;
+  const double *d2 = F.diff2 + (size_t)(itrc - 1) * nij + x;
+  double cxi = 0.5 * (pm[0] + pm[-1]), cxp = 0.5 * (pm[1] + pm[0]);
+  double cej = 0.5 * (pn[0] + pn[-ni]), cep = 0.5 * (pn[ni] + pn[0]);
+  if (G.masking) {
+    cxi = cxi * F.umask[x]; cxp = cxp * F.umask[x + 1]; cej = cej * F.vmask[x]; cep = cep * F.vmask[x + ni];
+  }
+  const double fxi = 0.25 * (d2[0] + d2[-1]) * F.on_u[x], fxp = 0.25 * (d2[1] + d2[0]) * F.on_u[x + 1];
+  const double fej = 0.25 * (d2[0] + d2[-ni]) * F.om_v[x], fep = 0.25 * (d2[ni] + d2[0]) * F.om_v[x + ni];
+  const double c = G.dt * pm[0] * pn[0], eps = 0.5;
+  const double *r = F.pden + x, *zr = F.z_r + x, *t = F.t + XT(G.LBi, G.LBj, 1, G.nrhs, itrc) + x, *Hz = F.Hz + x;
+  double *tnew = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc) + x;
+#define ISO_FAC(klo) ((-1.0 / KMAX(r[(size_t)((klo) - 1) * nij] - r[(size_t)(klo) * nij], eps)) * (zr[(size_t)(klo) * nij] - zr[(size_t)((klo) - 1) * nij]))
+  GeoLev Lk = geo_load(r + (size_t)(k0 - 1) * nij, t + (size_t)(k0 - 1) * nij, ni);
+  GeoGrad Dk = geo_grad(Lk, cxi, cxp, cej, cep), Dm = Dk;
+  GeoTz Tm = iso_tr(Lk, Lk, true);
+  double FSm = 0.0;
+  if (k0 > 1) {
+    const GeoLev Lm = geo_load(r + (size_t)(k0 - 2) * nij, t + (size_t)(k0 - 2) * nij, ni);
+    Dm = geo_grad(Lm, cxi, cxp, cej, cep);
+    Tm = iso_tr(Lm, Lk, false);
+    FSm = iso_fs(Dm, Dk, Tm.c, d2[0], ISO_FAC(k0 - 1));
+  }
+  for (int k = k0; k <= k1; k++) {
+    const size_t ok = (size_t)(k - 1) * nij;
+    GeoLev Lp = Lk;
+    GeoGrad Dp = Dk;
+    GeoTz Tk = iso_tr(Lk, Lk, true);
+    double FSk = 0.0;
+    if (k < N) {
+      Lp = geo_load(r + ok + nij, t + ok + nij, ni);
+      Dp = geo_grad(Lp, cxi, cxp, cej, cep);
+      Tk = iso_tr(Lk, Lp, false);
+      FSk = iso_fs(Dk, Dp, Tk.c, d2[0], ISO_FAC(k));
+    }
+    const double hc = Hz[ok];
+    const double FXi = fxi * (hc + Hz[ok - 1]) *
+                       (Dk.txi - 0.5 * (KMAX(Dk.zxi, 0.0) * (Tm.w + Tk.c) + KMIN(Dk.zxi, 0.0) * (Tk.w + Tm.c)));
+    const double FXp = fxp * (Hz[ok + 1] + hc) *
+                       (Dk.txp - 0.5 * (KMAX(Dk.zxp, 0.0) * (Tm.c + Tk.e) + KMIN(Dk.zxp, 0.0) * (Tk.c + Tm.e)));
+    const double FEj = fej * (hc + Hz[ok - ni]) *
+                       (Dk.tej - 0.5 * (KMAX(Dk.zej, 0.0) * (Tm.s + Tk.c) + KMIN(Dk.zej, 0.0) * (Tk.s + Tm.c)));
+    const double FEp = fep * (Hz[ok + ni] + hc) *
+                       (Dk.tep - 0.5 * (KMAX(Dk.zep, 0.0) * (Tm.c + Tk.n) + KMIN(Dk.zep, 0.0) * (Tk.c + Tm.n)));
+    const double cff1 = c * (FXp - FXi);
+    const double cff2 = c * (FEp - FEj);
+    const double cff3 = G.dt * (FSk - FSm);
+    const double cff4 = cff1 + cff2 + cff3;
+    tnew[ok] = tnew[ok] + cff4;
+    Lk = Lp; Dm = Dk; Dk = Dp; Tm = Tk; FSm = FSk;
+  }
+#undef ISO_FAC
+}
+THREAD_GLOBAL(k_t3dmix2_iso, KArgs)
+
 // ------------------------------------------------------------------------------------ bulk_flux
 KDEV double blk_psiu(double ZoL) {
   const double pi = 3.14159265358979323846, r3 = 1.0 / 3.0;

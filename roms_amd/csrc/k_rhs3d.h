@@ -292,7 +292,7 @@ THREAD_KERNEL(k_pre_t3v, KArgs) {
   double *t3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
   const double Gamma = (vs == ROMS_MPDATA || vs == ROMS_HSIMT) ? 0.5 : 1.0 / 6.0;
   const double cff = (G.iic == G.ntfirst) ? 0.5 * G.dt : (1.0 - Gamma) * G.dt;
-  const double pmn = F.pm[X2(i, j)] * F.pn[X2(i, j)];
+  const double cpmn = cff * F.pm[X2(i, j)] * F.pn[X2(i, j)];   // cff*pm*pn in the reference's order (:830, :845)
   if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, T, 0);
 #define Tc(kk) T[X3(i, j, kk)]
 #define Wc(kk) F.W[XW(i, j, kk)]
@@ -302,9 +302,9 @@ THREAD_KERNEL(k_pre_t3v, KArgs) {
     if (vs == ROMS_SPLINES) FCk = F.wrk3[3][XW(i, j, k)];
     else VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
     const double DC = 1.0 / (F.Hz[X3(i, j, k)] -
-                             cff * pmn * (F.Huon[X3(i + 1, j, k)] - F.Huon[X3(i, j, k)] + F.Hvom[X3(i, j + 1, k)] -
+                             cpmn * (F.Huon[X3(i + 1, j, k)] - F.Huon[X3(i, j, k)] + F.Hvom[X3(i, j + 1, k)] -
                                           F.Hvom[X3(i, j, k)] + (F.W[XW(i, j, k)] - F.W[XW(i, j, k - 1)])));
-    const double cff1 = cff * pmn;
+    const double cff1 = cpmn;
     t3[X3(i, j, k)] = DC * (t3[X3(i, j, k)] - cff1 * (FCk - FCm));
     FCm = FCk;
   }
@@ -335,7 +335,7 @@ THREAD_KERNEL(k_pre_t3, KArgs) {
   const double GammaV = (vs == ROMS_MPDATA || vs == ROMS_HSIMT) ? 0.5 : 1.0 / 6.0;
   const double cfv = (G.iic == G.ntfirst) ? 0.5 * G.dt : (1.0 - GammaV) * G.dt;
   const double pmv = F.pm[x], pnv = F.pn[x];
-  const double pmn = pmv * pnv;
+  const double cfv1 = cfv * pmv * pnv;   // cff*pm*pn in the reference's order (:830, :845)
   const EmitPlan P3 = emit_plan(G, BC_R, i, j);
   // column window: levels k0-2 .. k0+KCH+1 (clamped), W at interfaces k0-1 .. k0+KCH-1; vertical fluxes
   double tt[KCH + 4], ww[KCH + 1], FC[KCH + 1];
@@ -358,8 +358,7 @@ THREAD_KERNEL(k_pre_t3, KArgs) {
     const double Hzk = F.Hz[ok + x];
     const double t3h = Hzk * (cff1 * tt[q + 2] + cff2 * tnew[ok]) - cff * pmv * pnv * (FXp - FX0 + FEp - FE0);
     // vertical
-    const double DC = 1.0 / (Hzk - cfv * pmn * (Hu[X2(i + 1, j)] - Hu[X2(i, j)] + Hv[X2(i, j + 1)] - Hv[X2(i, j)] + (ww[q + 1] - ww[q])));
-    const double cfv1 = cfv * pmn;
+    const double DC = 1.0 / (Hzk - cfv1 * (Hu[X2(i + 1, j)] - Hu[X2(i, j)] + Hv[X2(i, j + 1)] - Hv[X2(i, j)] + (ww[q + 1] - ww[q])));
     emit_store(G, P3, t3 - x + ok, DC * (t3h - cfv1 * (FC[q + 1] - FC[q])));     // t3dbc + exchange :1157-1171
   }
 }

@@ -82,7 +82,6 @@ static __global__ void __launch_bounds__(256, MINW) k_tadv_lds(const KArgs a, in
   // ---- own column
   const long x = inside ? (long)X2(i, j) : (long)X2(B.Istr, B.Jstr);
   const double pmv = F.pm[x], pnv = F.pn[x];
-  const double pmn = pmv * pnv;
   const double cffc = G.dt * pmv * pnv;                  // corrector: cff = dt*pm*pn
   int hs[TL_MAXT], vs[TL_MAXT];
   bool vert[TL_MAXT];
@@ -174,8 +173,8 @@ static __global__ void __launch_bounds__(256, MINW) k_tadv_lds(const KArgs a, in
         if (MODE == 0) {
           double *t3 = F.t + XT(G.LBi, G.LBj, 1, 3, it + 1);
           const double t3h = Hzk * (cff1p[it] * tq[it][1] + cff2p[it] * c_told[it]) - cffp[it] * pmv * pnv * (FXp - FX0 + FEp - FE0);
-          const double DC = 1.0 / (Hzk - cfv[it] * pmn * (hup - hu0 + hvp - hv0 + (w0 - wm)));
-          const double cfv1 = cfv[it] * pmn;
+          const double cfv1 = cfv[it] * pmv * pnv;       // cff*pm*pn in the reference's order (:830, :845)
+          const double DC = 1.0 / (Hzk - cfv1 * (hup - hu0 + hvp - hv0 + (w0 - wm)));
           emit_store(G, P3, t3 + ok, DC * (t3h - cfv1 * (FCk - FCm[it])));      // t3dbc + exchange :1157-1171
         } else {
           double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, it + 1) + x;

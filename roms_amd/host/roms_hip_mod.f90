@@ -19,7 +19,8 @@
      &   ROMS_SALINITY = 4096, ROMS_SPHERICAL = 8192, ROMS_UV_LOGDRAG = 16384, ROMS_MASKING = 32768,                                 &
      &   ROMS_RADIATION_2D = 65536, ROMS_PLAIN_VDIFF = 131072, ROMS_PLAIN_VVISC = 262144, ROMS_PRSGRD31 = 524288, ROMS_WJ_GRADP = 134217728,                                   &
      &   ROMS_APP_UPWELLING = 1048576, ROMS_APP_BENCHMARK = 2097152, ROMS_APP_KELVIN = 4194304, ROMS_APP_SEAMOUNT = 8388608,   &
-     &   ROMS_APP_GRAV_ADJ = 16777216, ROMS_GLS_MIXING = 33554432, ROMS_PRSGRD40 = 67108864, ROMS_MY25_MIXING = 268435456
+     &   ROMS_APP_GRAV_ADJ = 16777216, ROMS_GLS_MIXING = 33554432, ROMS_PRSGRD40 = 67108864, ROMS_MY25_MIXING = 268435456, ROMS_MIX_ISO_TS = 536870912,          &
+     &   ROMS_APP_OVERFLOW = 1073741824
       integer(c_int), parameter :: ROMS_GLS_CANUTO_A = 1, ROMS_GLS_CANUTO_B = 2, ROMS_GLS_KANTHA_CLAYSON = 4,              &
      &   ROMS_GLS_N2S2_HORAVG = 8, ROMS_GLS_RI_SPLINES = 16, ROMS_GLS_K_C2ADVECTION = 32, ROMS_GLS_K_C4ADVECTION = 64,     &
      &   ROMS_GLS_CHARNOK = 128, ROMS_GLS_CRAIG_BANNER = 256

@@ -765,6 +765,15 @@
         END IF
         RETURN
       END IF
+      IF (TRIM(MyAppCPP).eq.'OVERFLOW') THEN
+!  ROMS/Include/overflow.h (its output option AVERAGES selects no time-stepping code)
+        ndefs=0
+        CALL define ('UV_ADV'); CALL define ('UV_COR'); CALL define ('UV_QDRAG'); CALL define ('UV_VIS2')
+        CALL define ('MIX_S_UV'); CALL define ('DJ_GRADPS'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
+        CALL define ('TS_DIF2'); CALL define ('MIX_ISO_TS'); CALL define ('SOLVE3D'); CALL define ('ANA_GRID')
+        CALL define ('ANA_INITIAL'); CALL define ('ANA_SMFLUX'); CALL define ('ANA_STFLUX'); CALL define ('ANA_BTFLUX')
+        RETURN
+      END IF
       IF (TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES') THEN
 !  ROMS/Include/kelvin.h (plain tridiagonal vertical solvers); KELVIN_SPLINES = oracle/ref/kelvin_splines.h: the same with
 !  the spline vertical solvers of UPWELLING and BENCHMARK
@@ -836,14 +845,14 @@
       SUBROUTINE options_from_defines (ierr)
       integer, intent(inout) :: ierr
       integer :: k
-      logical :: upw, bench, kelv, seam, grav
+      logical :: upw, bench, kelv, seam, grav, ovf
 !  options with a bit in the mask (include/roms_hip.h)
-      character(len=16), parameter :: bitname(19) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
+      character(len=16), parameter :: bitname(20) = [ character(len=16) :: 'UV_ADV', 'UV_COR', 'UV_VIS2',       &
      &    'TS_DIF2', 'MIX_GEO_TS', 'CURVGRID', 'NONLIN_EOS', 'UV_QDRAG', 'LMD_MIXING', 'BULK_FLUXES',           &
-     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG', 'MASKING', 'RADIATION_2D', 'GLS_MIXING', 'MY25_MIXING' ]
-      integer, parameter :: bitval(19) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
+     &    'SOLAR_SOURCE', 'ANA_VMIX', 'SALINITY', 'SPHERICAL', 'UV_LOGDRAG', 'MASKING', 'RADIATION_2D', 'GLS_MIXING', 'MY25_MIXING', 'MIX_ISO_TS' ]
+      integer, parameter :: bitval(20) = [ ROMS_UV_ADV, ROMS_UV_COR, ROMS_UV_VIS2, ROMS_TS_DIF2, ROMS_MIX_GEO_TS, &
      &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
-     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D, ROMS_GLS_MIXING, ROMS_MY25_MIXING ]
+     &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D, ROMS_GLS_MIXING, ROMS_MY25_MIXING, ROMS_MIX_ISO_TS ]
 !  options whose code is the only form built (accepted, nothing to select) or that only affect output
       character(len=16), parameter :: inherent(35) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', 'PJ_GRADP', &
      &    'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
@@ -867,9 +876,10 @@
       kelv=TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES'.or.is_defined('KELVIN')
       seam=TRIM(MyAppCPP).eq.'SEAMOUNT'.or.is_defined('SEAMOUNT')
       grav=TRIM(MyAppCPP).eq.'GRAV_ADJ'.or.is_defined('GRAV_ADJ')
-      IF (COUNT((/ upw, bench, kelv, seam, grav /)).ne.1) THEN
+      ovf=TRIM(MyAppCPP).eq.'OVERFLOW'.or.is_defined('OVERFLOW')
+      IF (COUNT((/ upw, bench, kelv, seam, grav, ovf /)).ne.1) THEN
         CALL unsupported ('MyAppCPP = '//TRIM(MyAppCPP)//': the analytic grid, initial state and forcing '//   &
-     &                    'exist for UPWELLING, BENCHMARK, KELVIN, SEAMOUNT and GRAV_ADJ', ierr)
+     &                    'exist for UPWELLING, BENCHMARK, KELVIN, SEAMOUNT, GRAV_ADJ and OVERFLOW', ierr)
         RETURN
       END IF
       gls_flags=0
@@ -878,6 +888,7 @@
       IF (kelv) options=ROMS_APP_KELVIN
       IF (seam) options=ROMS_APP_SEAMOUNT
       IF (grav) options=ROMS_APP_GRAV_ADJ
+      IF (ovf) options=ROMS_APP_OVERFLOW
       DO k=1,ndefs
         IF (ANY(bitname.eq.defs(k))) THEN
           options=IOR(options, bitval(FINDLOC(bitname, defs(k), 1)))
@@ -888,7 +899,7 @@
         ELSE IF (ANY(inherent.eq.defs(k)).or.ANY(output_only.eq.defs(k))) THEN
           CONTINUE
         ELSE IF (TRIM(defs(k)).eq.'UPWELLING'.or.TRIM(defs(k)).eq.'BENCHMARK'.or.TRIM(defs(k)).eq.'KELVIN'.or.            &
-     &           TRIM(defs(k)).eq.'SEAMOUNT'.or.TRIM(defs(k)).eq.'GRAV_ADJ') THEN
+     &           TRIM(defs(k)).eq.'SEAMOUNT'.or.TRIM(defs(k)).eq.'GRAV_ADJ'.or.TRIM(defs(k)).eq.'OVERFLOW') THEN
           CONTINUE
         ELSE IF (TRIM(defs(k)).eq.'ANA_DIAG') THEN        ! the user diagnostics hook (ana_diag.h): output of its own, not built
           CONTINUE
@@ -919,8 +930,11 @@
      &  CALL unsupported ('UV_ADV, UV_VIS2 and TS_DIF2 are required (the library is pinned to the reference with them)', ierr)
       IF (is_defined('UV_VIS2').and..not.is_defined('MIX_S_UV'))                                               &
      &  CALL unsupported ('UV_VIS2 is built along s-surfaces only (MIX_S_UV)', ierr)
-      IF (is_defined('TS_DIF2').and.(is_defined('MIX_S_TS').eqv.is_defined('MIX_GEO_TS')))                     &
-     &  CALL unsupported ('TS_DIF2 needs exactly one of MIX_S_TS, MIX_GEO_TS', ierr)
+      IF (is_defined('TS_DIF2').and.COUNT((/ is_defined('MIX_S_TS'), is_defined('MIX_GEO_TS'), is_defined('MIX_ISO_TS') /)).ne.1) &
+     &  CALL unsupported ('TS_DIF2 needs exactly one of MIX_S_TS, MIX_GEO_TS, MIX_ISO_TS', ierr)
+      IF (is_defined('MIX_ISO_TS').and.(is_defined('TS_MIX_MAX_SLOPE').or.is_defined('TS_MIX_MIN_STRAT').or.          &
+     &    is_defined('TS_MIX_STABILITY').or.is_defined('TS_MIX_CLIMA').or.is_defined('DIFF_3DCOEF')))                 &
+     &  CALL unsupported ('MIX_ISO_TS is built in its default slope treatment (no TS_MIX_*, no DIFF_3DCOEF)', ierr)
 !  without SPLINES_VDIFF / SPLINES_VVISC: the plain tridiagonal vertical solvers (step3d_t.F:1722-1790, step3d_uv.F:436-500)
       IF (.not.is_defined('SPLINES_VDIFF')) options=IOR(options, ROMS_PLAIN_VDIFF)
       IF (.not.is_defined('SPLINES_VVISC')) options=IOR(options, ROMS_PLAIN_VVISC)
@@ -930,7 +944,7 @@
      &             is_defined('MY25_MIXING') /)).gt.1)                                                         &
      &  CALL unsupported ('at most one vertical mixing closure: ANA_VMIX, LMD_MIXING, GLS_MIXING or MY25_MIXING (none: the '//      &
      &                    'background coefficients AKV_BAK, AKT_BAK, as in KELVIN)', ierr)
-      IF (.not.(kelv.or.seam.or.grav).and..not.(is_defined('ANA_VMIX').or.is_defined('LMD_MIXING').or.           &
+      IF (.not.(kelv.or.seam.or.grav.or.ovf).and..not.(is_defined('ANA_VMIX').or.is_defined('LMD_MIXING').or.           &
      &    is_defined('GLS_MIXING').or.is_defined('MY25_MIXING')))                                                                            &
      &  CALL unsupported ('a vertical mixing closure is required: ANA_VMIX, LMD_MIXING or GLS_MIXING', ierr)
 !  GLS_MIXING: the stability functions, the smoothing, the shear form, the advection of the turbulent fields and the two
@@ -1163,11 +1177,31 @@
       SUBROUTINE vertical_coordinate (ierr)
       integer, intent(out) :: ierr
       integer :: k
-      real(dp) :: dsig
+      real(dp) :: dsig, c1, c2
       ierr=0
       hc=MERGE(MIN(hmin,Tcline), Tcline, Vtransform.eq.1)
+      IF (Vstretching.eq.1) THEN          ! Song and Haidvogel (1994), set_scoord.F:184-240 (the OVERFLOW application)
+        IF (theta_s.ne.0.0_dp) THEN
+          c1=1.0_dp/SINH(theta_s)
+          c2=0.5_dp/TANH(0.5_dp*theta_s)
+        END IF
+        sc_w(0)=-1.0_dp;  Cs_w(0)=-1.0_dp
+        dsig=1.0_dp/REAL(N,dp)
+        DO k=1,N
+          sc_w(k)=dsig*REAL(k-N,dp)
+          sc_r(k)=dsig*(REAL(k-N,dp)-0.5_dp)
+          IF (theta_s.ne.0.0_dp) THEN
+            Cs_w(k)=(1.0_dp-theta_b)*c1*SINH(theta_s*sc_w(k))+theta_b*(c2*TANH(theta_s*(sc_w(k)+0.5_dp))-0.5_dp)
+            Cs_r(k)=(1.0_dp-theta_b)*c1*SINH(theta_s*sc_r(k))+theta_b*(c2*TANH(theta_s*(sc_r(k)+0.5_dp))-0.5_dp)
+          ELSE
+            Cs_w(k)=sc_w(k)
+            Cs_r(k)=sc_r(k)
+          END IF
+        END DO
+        RETURN
+      END IF
       IF (Vstretching.ne.4) THEN          ! the BASELINE applications use 4
-        CALL unsupported ('Vstretching /= 4: only the Shchepetkin (2010) stretching is built', ierr)
+        CALL unsupported ('Vstretching: built are 1 (Song and Haidvogel 1994) and 4 (Shchepetkin 2010)', ierr)
         RETURN
       END IF
       dsig=1.0_dp/REAL(N,dp)
@@ -1403,12 +1437,21 @@
       d=5000.0_r8-4500.0_r8*EXP(-(val1*val1+val2*val2))
       END FUNCTION seamount_depth
 
+      ELEMENTAL FUNCTION overflow_depth (y) RESULT (d)         ! ana_grid.h:1004-1011
+      real(r8), intent(in) :: y
+      real(r8) :: d
+      d=200.0_r8+0.5_r8*(4000.0_r8-200.0_r8)*(1.0_r8+TANH((y-100000.0_r8)/20000.0_r8))
+      END FUNCTION overflow_depth
+
       SUBROUTINE analytic_grid (ierr)
       integer, intent(out) :: ierr
       ierr=0
       IF (IAND(options,ROMS_APP_SEAMOUNT).ne.0) THEN            ! ana_grid.h:346-352
         CALL grid_cartesian (320.0E+03_r8, 320.0E+03_r8, 5000.0_r8, 0.0_r8)
         h(IstrT:IendT,JstrT:JendT)=seamount_depth(xr(IstrT:IendT,JstrT:JendT), yr(IstrT:IendT,JstrT:JendT))
+      ELSE IF (IAND(options,ROMS_APP_OVERFLOW).ne.0) THEN       ! :328-333, :1004-1011: a tanh slope from 200 m down to 4000 m
+        CALL grid_cartesian (4.0E+03_r8, 200.0E+03_r8, 4000.0_r8, 0.0_r8)
+        h(IstrT:IendT,JstrT:JendT)=overflow_depth(yr(IstrT:IendT,JstrT:JendT))
       ELSE IF (IAND(options,ROMS_APP_GRAV_ADJ).ne.0) THEN       ! :298-304
         CALL grid_cartesian (64.0E+03_r8, REAL(Mm,r8)*64.0E+03_r8/REAL(Lm,r8), 20.0_r8, 0.0_r8)
       ELSE IF (IAND(options,ROMS_APP_KELVIN).ne.0) THEN
@@ -1552,7 +1595,7 @@
 
       SUBROUTINE initial_state ()
       real(r8) :: ratio2, amp
-      integer :: i0, i1, j0, j1
+      integer :: i0, i1, j0, j1, k
       i0=IstrT; i1=IendT; j0=JstrT; j1=JendT
       zeta=0.0_r8;  ubar=0.0_r8;  vbar=0.0_r8
       u=0.0_r8;     v=0.0_r8;     t=0.0_r8
@@ -1563,6 +1606,10 @@
         t(i0:i1,j0:j1,:,1,2)=35.0_r8
       ELSE IF (IAND(options,ROMS_APP_SEAMOUNT).ne.0) THEN      ! ana_initial.h:809-816
         t(i0:i1,j0:j1,:,1,1)=T0+7.5_r8*EXP(z_r(i0:i1,j0:j1,:)/1000.0_r8)
+      ELSE IF (IAND(options,ROMS_APP_OVERFLOW).ne.0) THEN      ! :778-787: cold water on the shelf, T0 -> 0 across y = 60 km
+        DO k=1,N
+          t(i0:i1,j0:j1,k,1,1)=T0-0.5_r8*T0*(1.0_r8+TANH((yr(i0:i1,j0:j1)-60000.0_r8)/2000.0_r8))
+        END DO
       ELSE IF (IAND(options,ROMS_APP_GRAV_ADJ).ne.0) THEN      ! :672-686: warm water in the left half
         t(i0:MIN((Lm+1)/2,i1),j0:j1,:,1,1)=T0+5.0_r8
         t(MAX((Lm+1)/2+1,i0):i1,j0:j1,:,1,1)=T0

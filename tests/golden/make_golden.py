@@ -56,7 +56,8 @@ def make_case(case):
     tag, kw = case.split(":") if ":" in case else (case, "")
     kwargs = eval("dict(%s)" % kw) if kw else {}
     app = ("benchmark" if tag.startswith("benchmark") else "kelvin" if tag.startswith("kelvin") else
-           "seamount" if tag.startswith("seamount") else "grav_adj" if tag.startswith("grav_adj") else "upwelling")
+           "seamount" if tag.startswith("seamount") else "grav_adj" if tag.startswith("grav_adj") else
+           "overflow" if tag.startswith("overflow") else "upwelling")
     cs = getattr(cases, app)(**kwargs)
     ip, rp = cases.ref_params(cs)
     saved = quiet()
@@ -251,6 +252,7 @@ STEP_CASES = [
     ("upwelling_gls_ca_small", "upwelling_gls_ca_small", ["nsteps=60"]),
     ("upwelling_gls_cb_small", "upwelling_gls_cb_small", ["nsteps=60"]),
     ("upwelling_my25_small", "upwelling_my25_small", ["nsteps=60"]),            # MY25_MIXING: upwelling.h -DMY25_MIXING
+    ("overflow_small", "overflow_small", ["nsteps=60"]),                        # OVERFLOW: overflow.h (MIX_ISO_TS, Vtransform 1)
 ]
 KERNEL_CASES = ["upwelling_small_hsimt", "upwelling_small_mpdata", "benchmark_small", "upwelling_kpp_small"]
 def make_avg():

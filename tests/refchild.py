@@ -64,7 +64,7 @@ def mode_main3d(tag, kw):
     rd.unquiet(saved)
     printed = rd.diag_lines()
     ndiag = sum(1 for a, b in zip(printed, dlines) if a == b)
-    moved = float(np.abs(O.field("u")).max())
+    moved = float(max(np.abs(O.field("u")).max(), np.abs(O.field("v")).max()))      # (OVERFLOW flows along eta only)
     print("fields", len(names), "steps", nsteps, "max|u|", moved, "worst relrms", worst, "stepping", ok_step,
           "diag lines equal", ndiag, "of", len(printed))
     if tol == 0.0 and (ndiag != nsteps or len(printed) != nsteps):

@@ -45,6 +45,8 @@ CASES = {
     "upwelling_my25_gal_small": ("upwelling_my25_gal", dict(Lm=14, Mm=18, N=8, form="upwelling_my25_gal")),
     "seamount": ("seamount", dict()),
     "seamount_small": ("seamount", dict(Lm=20, Mm=18, N=8)),
+    "overflow": ("overflow", dict()),                              # roms_overflow.in: MIX_ISO_TS, Vtransform 1 / Vstretching 1
+    "overflow_small": ("overflow", dict(Lm=4, Mm=40, N=10)),
     "grav_adj": ("grav_adj", dict()),
     "grav_adj_small": ("grav_adj", dict(Lm=32, Mm=4, N=10)),
     "kelvin": ("kelvin_splines", dict()),
@@ -95,7 +97,7 @@ def diag_lines():
     out = []
     if _LOG is None:
         return out
-    flt = r"[-+]?\d\.\d{6}E[-+]\d{2,3}"
+    flt = r"[-+]?\d\.\d{6}(?:E[-+]\d{2}|[-+]\d{3})"       # 1pe14.6: a three-digit exponent drops the E (3.489962-286)
     with open(_LOG, "rb") as f:
         lines = [b.decode("latin-1") for b in f.read().split(b"\n")]   # DateTime is unset: arbitrary bytes
     os.unlink(_LOG)
@@ -120,7 +122,9 @@ def diag_text():
 
 def fmt_e(x):
     """Fortran 1pe14.6 / 1pe13.6 digits of x"""
-    return "%.6E" % x
+    s = "%.6E" % x
+    m, e = s.split("E")
+    return s if len(e) == 3 else m + e          # as Fortran's 1pe14.6 prints a three-digit exponent: 3.489962-286
 
 
 def oracle_diag_line(od):
@@ -136,7 +140,7 @@ def make_case(tag, **kw):
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
                 upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
-                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, upwelling_prs31=cases.upwelling_prs31,
+                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31,
                 upwelling_wjgradp=cases.upwelling_prs31, upwelling_prs40=cases.upwelling_prs40, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
                 upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]

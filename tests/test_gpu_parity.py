@@ -686,7 +686,7 @@ def hiplib_options():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "upwelling_prs31_small", "upwelling_wjgradp_small", "upwelling_prs40_small"])
+@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "overflow_small", "upwelling_prs31_small", "upwelling_wjgradp_small", "upwelling_prs40_small"])
 def test_more_reference_applications_match_oracle(tag):
     """SEAMOUNT and GRAV_ADJ (the reference's own test applications, oracle pinned bit for bit): 40 steps on the GPU at the
     north-star tolerance."""
@@ -701,8 +701,9 @@ def test_more_reference_applications_match_oracle(tag):
     for n in util.PROGNOSTIC:
         a, b = H.download(n), O.field(n)
         assert np.isfinite(a).all(), n
-        assert util.relrms(a, b) <= 1e-10, (n, util.relrms(a, b))
-    assert np.abs(O.field("u")).max() > 1e-4
+        # (OVERFLOW is uniform along xi: u, ubar, Huon, ru ... hold rounding noise of 1e-20 only, compared absolutely)
+        assert util.relrms(a, b) <= 1e-10 or (tag == "overflow_small" and np.abs(a - b).max() <= 1e-15), (n, util.relrms(a, b))
+    assert max(np.abs(O.field("u")).max(), np.abs(O.field("v")).max()) > 1e-4
     H.close()
 
 

@@ -22,7 +22,7 @@ def _host(cs):
 
 
 @pytest.mark.parametrize("tag", ["upwelling", "upwelling_small", "benchmark_small", "kelvin_small", "kelvin", "seamount_small",
-                                 "seamount", "grav_adj_small", "grav_adj"])
+                                 "seamount", "grav_adj_small", "grav_adj", "overflow_small", "overflow"])
 def test_host_setup_matches_reference(tag):
     cs = util.case_for(tag)
     g = util.load_init(tag, util.nghost_for(cs))
@@ -406,7 +406,7 @@ def test_every_reference_input_file_is_read_without_skipping_a_physics_keyword()
         if H is not None:
             H.finalize()
     assert {"roms_upwelling.in", "roms_benchmark1.in", "roms_benchmark2.in", "roms_benchmark3.in", "roms_kelvin.in",
-            "roms_seamount.in", "roms_grav_adj.in"} <= set(done)
+            "roms_seamount.in", "roms_grav_adj.in", "roms_overflow.in"} <= set(done)
     assert len(stopped) > 20          # the other applications of the reference: analytic set-ups this host does not have
 
 
@@ -505,7 +505,7 @@ def hiplib_opt(name):
     return hiplib.OPTIONS[name]
 
 
-@pytest.mark.parametrize("app,dims", [("seamount", (49, 48, 13)), ("grav_adj", (128, 4, 40))])
+@pytest.mark.parametrize("app,dims", [("seamount", (49, 48, 13)), ("grav_adj", (128, 4, 40)), ("overflow", (4, 128, 20))])
 def test_reference_test_applications_from_their_own_files(app, dims):
     """ROMS/External/roms_<app>.in with ROMS/Include/<app>.h, both read in place: the set-up equals the reference's (the
     fixture its `initial` wrote); the headers' output options (AVERAGES, DIAGNOSTICS_*, ANA_DIAG) select no time-stepping code."""

@@ -183,7 +183,7 @@ def _child(mode, tag, *args, timeout=900):
            "benchmark_mask_small": "benchmark_mask", "upwelling_avg_mask_small": "upwelling_avg_mask",
            "kelvin": "kelvin_splines", "kelvin_small": "kelvin_splines", "kelvin_plain_small": "kelvin", "kelvin_plain": "kelvin",
            "upwelling_obc_small": "upwelling", "upwelling_mask_obc_small": "upwelling_mask", "seamount": "seamount",
-           "seamount_small": "seamount", "grav_adj": "grav_adj", "grav_adj_small": "grav_adj",
+           "seamount_small": "seamount", "grav_adj": "grav_adj", "grav_adj_small": "grav_adj", "overflow": "overflow", "overflow_small": "overflow",
            "upwelling_prs31_small": "upwelling_prs31", "upwelling_wjgradp_small": "upwelling_wjgradp"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
     if not ref.available(lib):
         pytest.skip(f"oracle/_ref/libromsref_{lib}.so not built here")
@@ -227,6 +227,10 @@ MAIN3D_CASES = [
     ("seamount", ["nsteps=20"]),                                                 # roms_seamount.in, full size
     ("grav_adj_small", ["nsteps=60"]),
     ("grav_adj_small", ["nsteps=20", "NtileI=2", "NtileJ=1"]),
+    # OVERFLOW (overflow.h as shipped but AVERAGES): MIX_ISO_TS through t3dmix2_iso.h, Vtransform 1 / Vstretching 1
+    ("overflow_small", ["nsteps=60"]),
+    ("overflow_small", ["nsteps=30", "NtileI=1", "NtileJ=2"]),
+    ("overflow", ["nsteps=30"]),                                                 # roms_overflow.in, full size
     ("grav_adj", ["nsteps=40"]),                                                 # roms_grav_adj.in, full size
     # the standard density Jacobian prsgrd31.h (no DJ_GRADPS), plain and weighted (WJ_GRADP)
     ("upwelling_prs31_small", ["nsteps=60"]),

@@ -83,6 +83,9 @@ def _interior(cs_dims, a):
     ("upwelling_gls_cb_small:k-kl", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA")), (1, 2), 29629),
     # MY25_MIXING: the eastern tiles carry my25_corstep.F's copy onto the interior column Iend-1
     ("upwelling_my25_small", dict(), (2, 2), 29630),
+    # OVERFLOW (closed channel four points wide, tiles along eta): MIX_ISO_TS reads the density and the tracer slopes across the
+    # tile boundary
+    ("overflow_small", dict(), (1, 2), 29631),
 ])
 def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     _emu_libs()

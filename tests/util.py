@@ -82,6 +82,10 @@ def case_for(tag, **kw):
         return cases.grav_adj(Lm=32, Mm=4, N=10, **kw)
     if tag == "grav_adj":
         return cases.grav_adj(**kw)
+    if tag == "overflow_small":          # OVERFLOW (overflow.h): MIX_ISO_TS, Vtransform 1 / Vstretching 1
+        return cases.overflow(Lm=4, Mm=40, N=10, **kw)
+    if tag == "overflow":
+        return cases.overflow(**kw)
     if tag == "kelvin_small":
         return cases.kelvin(Lm=16, Mm=12, N=6, **kw)
     if tag == "kelvin":
@@ -222,7 +226,8 @@ def case_from_meta(meta):
 def init_tag(cs):
     return {(14, 18, 8): "upwelling_small", (24, 16, 10): "benchmark_small", (41, 80, 16): "upwelling",
             (16, 12, 6): "kelvin_small", (50, 30, 10): "kelvin", (20, 18, 8): "seamount_small", (49, 48, 13): "seamount",
-            (32, 4, 10): "grav_adj_small", (128, 4, 40): "grav_adj"}[
+            (32, 4, 10): "grav_adj_small", (128, 4, 40): "grav_adj",
+            (4, 40, 10): "overflow_small", (4, 128, 20): "overflow"}[
         (cs["Lm"], cs["Mm"], cs["N"])]
 
 
