@@ -209,6 +209,11 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     set_error("options: UV_ADV, UV_VIS2 and TS_DIF2 are required (zero coefficients switch the mixing off)");
     return 5;
   }
+  if ((cfg->options & ROMS_MIX_GEO_TS) && (cfg->options & ROMS_MIX_ISO_TS)) { set_error("MIX_GEO_TS and MIX_ISO_TS exclude each other"); return 5; }
+  if ((cfg->options & ROMS_MIX_ISO_TS) && (cfg->options & (ROMS_MASKING | ROMS_NONLIN_EOS))) {   // (only the pinned combination is offered)
+    set_error("MIX_ISO_TS is pinned to the reference with the linear equation of state and without MASKING only (OVERFLOW)");
+    return 5;
+  }
   if ((cfg->options & ROMS_GLS_MIXING) && (cfg->options & ROMS_MY25_MIXING)) { set_error("GLS_MIXING and MY25_MIXING exclude each other"); return 5; }
   if (cfg->options & (ROMS_GLS_MIXING | ROMS_MY25_MIXING)) {     // gls_prestep.F, gls_corstep.F (my25_*.F): one closure, one form of it, sane parameters
     const int st = cfg->gls_flags & (ROMS_GLS_CANUTO_A | ROMS_GLS_CANUTO_B | ROMS_GLS_KANTHA_CLAYSON);

@@ -326,6 +326,20 @@ def test_open_boundary_kinds_the_library_does_not_have_stop():
     assert "exit_flag=5" in str(e.value) and "MPDATA" in str(e.value)
 
 
+def test_isopycnic_mixing_only_in_its_pinned_combination():
+    """MIX_ISO_TS (t3dmix2_iso.h) is pinned to the reference through OVERFLOW -- linear equation of state, no land: with
+    NONLIN_EOS, MASKING or MIX_GEO_TS beside it roms_hip_create stops with exit_flag 5 and the reason."""
+    from roms_amd import hiplib
+    g = util.load_init("overflow_small", 2)
+    for extra, needle in (("NONLIN_EOS", "pinned"), ("MASKING", "pinned"), ("MIX_GEO_TS", "exclude")):
+        cs = util.case_for("overflow_small")
+        cs["options"] = tuple(cs["options"]) + (extra,)
+        gg = util.with_masks(cs, g) if extra == "MASKING" else g
+        with pytest.raises(hiplib.RomsHipError) as e:
+            util.make_hip(cs, gg, util.EMU_LIB)
+        assert "exit_flag=5" in str(e.value) and needle in str(e.value), str(e.value)
+
+
 @pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "overflow_small"])
 def test_more_reference_applications_bitwise(emu, tag):
     """SEAMOUNT (ROMS/Include/seamount.h: no-slip walls GAMMA2 = -1, Akima advection, harmonic mixing along geopotentials
