@@ -686,7 +686,23 @@ def hiplib_options():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "overflow_small", "upwelling_prs31_small", "upwelling_wjgradp_small", "upwelling_prs40_small"])
+def test_isopycnic_mixing_is_refused_on_the_device_until_parity_green():
+    """OVERFLOW / MIX_ISO_TS: oracle pinned to the reference and kernels bit-identical under emulation, but the device run
+    deviates (t 1e-6 after one step, not reproducible run to run -- open): roms_hip_create refuses it."""
+    from roms_amd import hiplib
+    cs = util.case_for("overflow_small")
+    g = util.load_init("overflow_small", 2)
+    with pytest.raises(hiplib.RomsHipError) as e:
+        util.make_hip(cs, g)
+    assert "exit_flag=5" in str(e.value) and "MIX_ISO_TS" in str(e.value)
+
+
+XI_PARTNER = dict(u="v", ubar="vbar", Huon="Hvom", ru="rv", DU_avg1="DV_avg1", DU_avg2="DV_avg2", rufrc="rvfrc", rubar="rvbar",
+                  sustr="svstr", bustr="bvstr")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "upwelling_prs31_small", "upwelling_wjgradp_small", "upwelling_prs40_small"])
 def test_more_reference_applications_match_oracle(tag):
     """SEAMOUNT and GRAV_ADJ (the reference's own test applications, oracle pinned bit for bit): 40 steps on the GPU at the
     north-star tolerance."""
@@ -701,8 +717,13 @@ def test_more_reference_applications_match_oracle(tag):
     for n in util.PROGNOSTIC:
         a, b = H.download(n), O.field(n)
         assert np.isfinite(a).all(), n
-        # (OVERFLOW is uniform along xi: u, ubar, Huon, ru ... hold rounding noise of 1e-20 only, compared absolutely)
-        assert util.relrms(a, b) <= 1e-10 or (tag == "overflow_small" and np.abs(a - b).max() <= 1e-15), (n, util.relrms(a, b))
+        if tag == "overflow_small" and n in XI_PARTNER:
+            # OVERFLOW is uniform along xi: the xi-components hold rounding noise only (1e-20 of the eta-components), which
+            # differs between libm/FMA orders -- they are compared on the scale of their eta partners
+            scale = np.abs(O.field(XI_PARTNER[n])).max()
+            assert np.abs(a - b).max() <= 1e-10 * scale, (n, float(np.abs(a - b).max()), float(scale))
+            continue
+        assert util.relrms(a, b) <= 1e-10, (n, util.relrms(a, b))
     assert max(np.abs(O.field("u")).max(), np.abs(O.field("v")).max()) > 1e-4
     H.close()
 
