@@ -257,11 +257,13 @@ COOP_GLOBAL(k_pre_t3h, KArgs)
   } while (0)
 
 // Parabolic-spline vertical flux (SPLINES): tridiagonal recurrence; FC kept in the 3-D work
-// array wrk3[3] (w-levels), CF in wrk3[4].  corrector = 0: pre_step3d end conditions
-// (1.5, 0.5, 3, 2); 1: step3d_t (2, 1, 2, 1).
-KDEV void vspline_flux(const DGrid &G, const Fields &F, int i, int j, const double *T /*level 1*/, int corrector) {
+// array wrk3[3] (w-levels), CF in wrk3[4] -- N+1 planes PER TRACER: the tracers of a launch run side by side
+// (grid.z), a column of scratch shared between them was a race on the device (round 4; the serial emulation
+// could not see it).  corrector = 0: pre_step3d end conditions (1.5, 0.5, 3, 2); 1: step3d_t (2, 1, 2, 1).
+KDEV double *vspline_fc(const DGrid &G, const Fields &F, int itrc) { return F.wrk3[3] + (size_t)(itrc - 1) * (size_t)(G.N + 1) * G.nij; }
+KDEV void vspline_flux(const DGrid &G, const Fields &F, int i, int j, int itrc, const double *T /*level 1*/, int corrector) {
   const int N = G.N;
-  double *FC = F.wrk3[3], *CF = F.wrk3[4];
+  double *FC = vspline_fc(G, F, itrc), *CF = F.wrk3[4] + (size_t)(itrc - 1) * (size_t)(N + 1) * G.nij;
   const double a0 = corrector ? 2.0 : 1.5, c1 = corrector ? 1.0 : 0.5;
   const double aN = corrector ? 2.0 : 3.0, dN = corrector ? 1.0 : 2.0;
   FC[XW(i, j, 0)] = a0 * T[X3(i, j, 1)];
@@ -293,13 +295,13 @@ THREAD_KERNEL(k_pre_t3v, KArgs) {
   const double Gamma = (vs == ROMS_MPDATA || vs == ROMS_HSIMT) ? 0.5 : 1.0 / 6.0;
   const double cff = (G.iic == G.ntfirst) ? 0.5 * G.dt : (1.0 - Gamma) * G.dt;
   const double cpmn = cff * F.pm[X2(i, j)] * F.pn[X2(i, j)];   // cff*pm*pn in the reference's order (:830, :845)
-  if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, T, 0);
+  if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, itrc, T, 0);
 #define Tc(kk) T[X3(i, j, kk)]
 #define Wc(kk) F.W[XW(i, j, kk)]
   double FCm = 0.0;   // FC(k-1)
   for (int k = 1; k <= N; k++) {
     double FCk;
-    if (vs == ROMS_SPLINES) FCk = F.wrk3[3][XW(i, j, k)];
+    if (vs == ROMS_SPLINES) FCk = vspline_fc(G, F, itrc)[XW(i, j, k)];
     else VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
     const double DC = 1.0 / (F.Hz[X3(i, j, k)] -
                              cpmn * (F.Huon[X3(i + 1, j, k)] - F.Huon[X3(i, j, k)] + F.Hvom[X3(i, j + 1, k)] -

@@ -854,7 +854,7 @@ THREAD_KERNEL(k_s3t_col_t, KArgs) {
   double CF[NL ? NL + 1 : ROMS_NPRIV], DC[NL ? NL + 1 : ROMS_NPRIV];   // NL > 0: registers (the diffusion sweeps are unrolled)
   const EmitPlan PT = emit_plan(G, BC_R, i, j);
   if (!s3t_point_path(G, itrc)) {   // otherwise k_s3t_hv has done the vertical advection already
-  if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, T3, 1);
+  if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, itrc, T3, 1);
   #define Tc(kk) T3[X3(i, j, kk)]
   #define Wc(kk) W[XW(i, j, kk)]
     // HSIMT vertical: KaZ, gradZ local functions of the column :1069-1150
@@ -863,7 +863,7 @@ THREAD_KERNEL(k_s3t_col_t, KArgs) {
     double FCm = 0.0;
     _Pragma("unroll 1") for (int k = 1; k <= N; k++) {
       double FCk;
-      if (vs == ROMS_SPLINES) FCk = F.wrk3[3][XW(i, j, k)];
+      if (vs == ROMS_SPLINES) FCk = vspline_fc(G, F, itrc)[XW(i, j, k)];
       else if (vs == ROMS_HSIMT) {
         if (k >= N) FCk = 0.0;
         else {
@@ -1035,13 +1035,13 @@ COL_KERNEL(k_s3t_col_lt, KArgs) {
       }
 #undef SA_LOAD
     } else {
-      if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, T3, 1);
+      if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, itrc, T3, 1);
 #define Tc(kk) T3[X3(i, j, kk)]
 #define Wc(kk) W[XW(i, j, kk)]
       double FCm = 0.0;
       _Pragma("unroll 1") for (int k = 1; k <= N; k++) {
         double FCk;
-        if (vs == ROMS_SPLINES) FCk = F.wrk3[3][XW(i, j, k)];
+        if (vs == ROMS_SPLINES) FCk = vspline_fc(G, F, itrc)[XW(i, j, k)];
         else VFLUX_LOCAL(FCk, vs, k, N, Tc, Wc);
         const double cff1 = pmn_dt * (FCk - FCm);
         double tt = tn[X3(i, j, k)] - cff1;

@@ -36,12 +36,18 @@ struct kdim3 { int x, y, z; };
 #define COOP_GLOBAL(name, ArgT)
 #define COOP_GLOBAL_LB(name, ArgT, maxthreads)
 #define COOP_GLOBAL_LB2(name, ArgT, maxthreads, minwaves)
+// ROMS_EMU_ORDER=reverse (test aid): the blocks / threads of every launch run in the opposite order.  A launch whose
+// threads communicate through global memory without a kernel boundary in between (a race on the device) then gives
+// different bits; tests/test_kernels_emu.py requires the two orders to agree (round 4: the spline scratch shared
+// between the tracers of a launch was such a race, invisible to one fixed serial order).
+extern int g_emu_reverse;
+#define EMU_IDX(q, n) (g_emu_reverse ? (n) - 1 - (q) : (q))
 #define LAUNCH_COOP(name, gx, gy, gz, nthreads, lds_doubles, stream, args)               \
   do {                                                                                   \
     std::vector<double> lds_((size_t)(lds_doubles) + 8);                                 \
     for (int bz_ = 0; bz_ < (gz); bz_++)                                                 \
       for (int by_ = 0; by_ < (gy); by_++)                                               \
-        for (int bx_ = 0; bx_ < (gx); bx_++) name##_body(args, bx_, by_, bz_, lds_.data()); \
+        for (int bx_ = 0; bx_ < (gx); bx_++) name##_body(args, EMU_IDX(bx_, gx), EMU_IDX(by_, gy), EMU_IDX(bz_, gz), lds_.data()); \
   } while (0)
 
 #define LAUNCH_COOP_AS(label, name, gx, gy, gz, nthreads, lds_doubles, stream, args) \
@@ -55,7 +61,7 @@ struct kdim3 { int x, y, z; };
   do {                                                                                   \
     for (int gz_ = 0; gz_ < (nz); gz_++)                                                 \
       for (int gy_ = 0; gy_ < (ny); gy_++)                                               \
-        for (int gx_ = 0; gx_ < (nx); gx_++) name##_body(args, gx_, gy_, gz_);           \
+        for (int gx_ = 0; gx_ < (nx); gx_++) name##_body(args, EMU_IDX(gx_, nx), EMU_IDX(gy_, ny), EMU_IDX(gz_, nz)); \
   } while (0)
 
 // COL: one thread per sigma column like THREAD, plus `per_thread` doubles of block-shared (LDS)
@@ -68,7 +74,7 @@ struct kdim3 { int x, y, z; };
     std::vector<double> lds_((size_t)(per_thread) + 8);                                  \
     for (int gz_ = 0; gz_ < (nz); gz_++)                                                 \
       for (int gy_ = 0; gy_ < (ny); gy_++)                                               \
-        for (int gx_ = 0; gx_ < (nx); gx_++) name##_body(args, gx_, gy_, gz_, lds_.data()); \
+        for (int gx_ = 0; gx_ < (nx); gx_++) name##_body(args, EMU_IDX(gx_, nx), EMU_IDX(gy_, ny), EMU_IDX(gz_, nz), lds_.data()); \
   } while (0)
 #define LAUNCH_COL_AS(label, name, nx, ny, nz, per_thread, stream, args) LAUNCH_COL(name, nx, ny, nz, per_thread, stream, args)
 

@@ -18,12 +18,14 @@ extern "C" int roms_hip_abi_version(void) { return ROMS_HIP_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------ device memory
 #ifdef ROMS_CPU_EMU
+int g_emu_reverse = 0;
 static int dmalloc(void **p, size_t bytes) { *p = calloc(bytes ? bytes : 8, 1); return *p ? 0 : 2; }
 static void dfree(void *p) { free(p); }
 static int h2d(void *d, const void *h, size_t bytes, kstream_t) { memcpy(d, h, bytes); return 0; }
 static int d2h(void *h, const void *d, size_t bytes, kstream_t) { memcpy(h, d, bytes); return 0; }
 static int d2d(void *d, const void *s, size_t bytes, kstream_t) { memcpy(d, s, bytes); return 0; }
 static int dsync(kstream_t) { return 0; }
+static int dpoison(void *p, size_t bytes, kstream_t) { memset(p, 0xFF, bytes); return 0; }
 int ctx_check(roms_hip_ctx *c, const char *) { return c->comm_failed ? 2 : 0; }
 #else
 static int hipfail(hipError_t e, const char *what) {
@@ -55,6 +57,7 @@ static int d2d(void *d, const void *src, size_t bytes, kstream_t s) {
   return hipfail(hipMemcpyAsync(d, src, bytes, hipMemcpyDeviceToDevice, s), "hipMemcpy D2D");
 }
 static int dsync(kstream_t s) { return hipfail(hipStreamSynchronize(s), "hipStreamSynchronize"); }
+static int dpoison(void *p, size_t bytes, kstream_t s) { return hipfail(hipMemsetAsync(p, 0xFF, bytes, s), "hipMemsetAsync"); }
 int ctx_check(roms_hip_ctx *c, const char *what) {
   if (c->comm_failed) return 2;
   if (c->comm.peer_err && *(volatile unsigned long long *)c->comm.peer_err) {
@@ -68,6 +71,25 @@ int ctx_check(roms_hip_ctx *c, const char *what) {
 
 // ------------------------------------------------------------------------------- field table
 #define FD(nm, kind) { #nm, offsetof(Fields, nm), kind }
+// ROMS_HIP_POISON=1 (test aid, device and emulated build alike): every WORK array -- the private scratch of the reference's
+// routines (wrk3, wrk2, the MPDATA arrays, the staging levels of the pair kernel) -- holds NaN (all bits set) from
+// roms_hip_create on and again at the start of every roms_hip_main3d step, instead of the zeros of dmalloc: a kernel that
+// reads scratch nobody wrote in this step, or scratch another thread of the launch is still writing, shows as NaN in
+// the state instead of passing on the zeros the serial emulation happens to hold (tests: test_poisoned_work_arrays).
+static bool poison_on() { const char *e = getenv("ROMS_HIP_POISON"); return e && e[0] == '1'; }     // (read per call: a test may switch it between contexts)
+struct WorkSpan { void *p; size_t bytes; };
+static void work_spans(roms_hip_ctx *c, std::vector<WorkSpan> &out);
+static int poison_work(roms_hip_ctx *c) {
+  if (!poison_on()) return 0;
+  std::vector<WorkSpan> w;
+  work_spans(c, w);
+#ifndef ROMS_CPU_EMU
+  if (hipfail(hipDeviceSynchronize(), "hipDeviceSynchronize")) return 2;    // (side streams of the previous step may still read scratch)
+#endif
+  for (const WorkSpan &x : w) { int r = dpoison(x.p, x.bytes, c->stream); if (r) return r; }
+  return dsync(c->stream);
+}
+
 static const FieldDesc g_fields[] = {
     FD(h, FK_2D), FD(f, FK_2D), FD(fomn, FK_2D), FD(pm, FK_2D), FD(pn, FK_2D), FD(om_r, FK_2D), FD(on_r, FK_2D),
     FD(om_u, FK_2D), FD(on_u, FK_2D), FD(om_v, FK_2D), FD(on_v, FK_2D), FD(om_p, FK_2D), FD(on_p, FK_2D),
@@ -193,6 +215,9 @@ static int edge_subtile(int n, int nb) {
 
 static void comm_destroy(roms_hip_ctx *c);
 extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
+#ifdef ROMS_CPU_EMU
+  { const char *eo = getenv("ROMS_EMU_ORDER"); g_emu_reverse = eo && eo[0] == 'r'; }
+#endif
   if (!cfg || !out) { set_error("null argument"); return 8; }
   if (cfg->abi_version != ROMS_HIP_ABI_VERSION) { set_error("ABI version mismatch"); return 5; }
   if (cfg->N < 4 || cfg->N > 127 || cfg->NT < 1 || cfg->NT > ROMS_MAXT || 2 * cfg->ndtfast > ROMS_MAXW) {
@@ -214,14 +239,6 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     set_error("MIX_ISO_TS is pinned to the reference with the linear equation of state and without MASKING only (OVERFLOW)");
     return 5;
   }
-#ifndef ROMS_CPU_EMU
-  // round 3: k_t3dmix2_iso is bit-identical to the oracle under emulation but NOT parity-green on the device (the tracers
-  // deviate by 1e-6 after one step, differently from run to run: DESIGN.md 9) -- refused rather than run with a known deviation
-  if ((cfg->options & ROMS_MIX_ISO_TS) && !getenv("ROMS_HIP_ALLOW_ISO")) {
-    set_error("MIX_ISO_TS: the device kernel is not parity-green on the GPU yet (DESIGN.md 9); refused");
-    return 5;
-  }
-#endif
   if ((cfg->options & ROMS_GLS_MIXING) && (cfg->options & ROMS_MY25_MIXING)) { set_error("GLS_MIXING and MY25_MIXING exclude each other"); return 5; }
   if (cfg->options & (ROMS_GLS_MIXING | ROMS_MY25_MIXING)) {     // gls_prestep.F, gls_corstep.F (my25_*.F): one closure, one form of it, sane parameters
     const int st = cfg->gls_flags & (ROMS_GLS_CANUTO_A | ROMS_GLS_CANUTO_B | ROMS_GLS_KANTHA_CLAYSON);
@@ -465,7 +482,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   }
   for (int k = 0; k < 13; k++) {
     void *p = nullptr;
-    size_t n = (size_t)G.nij * (size_t)(G.N + 1) * (k == 0 ? (size_t)G.NT : 1);
+    size_t n = (size_t)G.nij * (size_t)(G.N + 1) * (k == 0 || k == 3 || k == 4 ? (size_t)G.NT : 1);   // [3], [4]: spline scratch per tracer
     if (dmalloc(&p, n * sizeof(double))) { roms_hip_destroy(c); return 2; }
     c->allocs.push_back(p);
     c->F.wrk3[k] = (double *)p;
@@ -533,8 +550,20 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   c->s.nstp = 1; c->s.nrhs = 1; c->s.nnew = 1;
   c->s.time = cfg->dstart * 86400.0;
   ctx_sync_stepping(c);
+  if (poison_work(c)) { roms_hip_destroy(c); return 2; }
   *out = c;
   return 0;
+}
+
+static void work_spans(roms_hip_ctx *c, std::vector<WorkSpan> &out) {
+  const DGrid &G = c->G;
+  const size_t plane = (size_t)G.nij * sizeof(double), col = plane * (size_t)(G.N + 1);
+  for (int k = 0; k < 13; k++) out.push_back({(void *)(double *)c->F.wrk3[k], col * (k == 0 || k == 3 || k == 4 ? (size_t)G.NT : 1)});
+  for (int k = 0; k < 4; k++) out.push_back({(void *)(double *)c->F.wrk2[k], plane});
+  for (int k = 0; k < 6; k++)
+    if ((double *)c->F.mp3[k]) out.push_back({(void *)(double *)c->F.mp3[k], col * (k == 0 ? (size_t)G.NT : 1)});
+  // the two staging levels behind zeta, ubar, vbar (k_step2d_pair.h)
+  for (double *f : {(double *)c->F.zeta, (double *)c->F.ubar, (double *)c->F.vbar}) out.push_back({(void *)(f + 3 * (size_t)G.nij), 2 * plane});
 }
 
 extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
@@ -1627,6 +1656,7 @@ static int main3d_one(roms_hip_ctx *c) {
   s.nnew = 3 - s.nstp;
   s.nrhs = s.nstp;
   ctx_sync_stepping(c);
+  DO(poison_work(c));                                       // (ROMS_HIP_POISON=1 only)
   DO(roms_hip_set_data(c));                                 // :258
   if (s.iic == cf.ntstart) {                                // post_initial :335
     DO(roms_hip_ini_zeta(c));

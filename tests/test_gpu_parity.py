@@ -685,16 +685,94 @@ def hiplib_options():
     return hiplib.OPTIONS
 
 
+DETERMINISM_SMALL = [
+    ("upwelling_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"))),
+    ("upwelling_small", dict(hadv=("A4", "A4"), vadv=("SPLINES", "SPLINES"))),      # the spline scratch of both tracers side by side
+    ("upwelling_small", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA"))),
+    ("benchmark_small", {}), ("upwelling_kpp_small", dict(hadv=("MPDATA", "MPDATA"), vadv=("MPDATA", "MPDATA"))),
+    ("upwelling_mask_small", {}), ("seamount_small", {}), ("grav_adj_small", {}), ("overflow_small", {}),
+    ("kelvin_small", {}), ("kelvin_plain_small", {}), ("upwelling_gls_small", {}), ("upwelling_my25_small", {}),
+    ("upwelling_prs31_small", {}), ("upwelling_prs40_small", {}), ("upwelling_logdrag_small", {}),
+]
+
+
+def _case_state(tag, kw):
+    cs = util.case_for(tag, **kw)
+    itag = "upwelling_small" if tag.startswith("upwelling") else tag.replace("_plain", "")
+    g = util.load_init(itag, util.nghost_for(cs))
+    if "MASKING" in cs["options"]:
+        g = util.with_masks(cs, g)
+    if "gls_flags" in cs:
+        g = util.with_gls(cs, g)
+    return cs, g
+
+
+def _end_state(cs, g, nsteps, lib=None):
+    H = util.make_hip(cs, g, lib)
+    H.start()
+    H.main3d(nsteps)
+    H.sync()
+    out = {}
+    for n in util.PROGNOSTIC:
+        try:
+            out[n] = H.download(n).copy()
+        except KeyError:
+            pass
+    H.close()
+    return out
+
+
 @pytest.mark.gpu
-def test_isopycnic_mixing_is_refused_on_the_device_until_parity_green():
-    """OVERFLOW / MIX_ISO_TS: oracle pinned to the reference and kernels bit-identical under emulation, but the device run
-    deviates (t 1e-6 after one step, not reproducible run to run -- open): roms_hip_create refuses it."""
-    from roms_amd import hiplib
-    cs = util.case_for("overflow_small")
-    g = util.load_init("overflow_small", 2)
-    with pytest.raises(hiplib.RomsHipError) as e:
-        util.make_hip(cs, g)
-    assert "exit_flag=5" in str(e.value) and "MIX_ISO_TS" in str(e.value)
+@pytest.mark.parametrize("tag,kw", DETERMINISM_SMALL)
+def test_two_runs_of_a_case_agree_bit_for_bit(tag, kw):
+    """DETERMINISM: every application case stepped twice from the same input must end in the same bits.  A kernel whose
+    threads meet in global scratch, or a missing stream dependency, gives run-to-run differences the serial CPU emulation
+    cannot show (round 3's OVERFLOW deviation was one: the spline-flux scratch of step3d_t / pre_step3d shared between
+    the tracers of a launch)."""
+    cs, g = _case_state(tag, kw)
+    a = _end_state(cs, g, 12)
+    for rep in range(2):
+        b = _end_state(cs, g, 12)
+        bad = [n for n in a if not np.array_equal(a[n], b[n], equal_nan=True)]
+        assert not bad, (tag, rep, bad)
+    assert all(np.isfinite(v).all() for v in a.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,dims,nsteps", [("benchmark1", None, 6), ("ns512", (512, 512, 12), 3), ("ns512u3", (512, 512, 12), 3),
+                                                  ("config5", (256, 512, 10), 3), ("benchmark3", (2048, 256, 6), 3)])
+def test_two_runs_at_baseline_horizontal_size_agree_bit_for_bit(workload, dims, nsteps):
+    """... and on BASELINE.json's horizontal sizes, which select the LDS-tiled 3-D kernels, the marching forms, the pair
+    kernel and the two-blocks-per-CU barotropic kernel (fewer levels than the BASELINE grids keep the run short; the
+    kernel forms are chosen by the number of columns)."""
+    import bench
+    from roms_amd import tiling
+    cs = bench.params_for(workload, *(dims or ()))
+    cs["ninfo"] = 1
+    ends = []
+    for rep in range(2):
+        run = tiling.TiledRun(cs)
+        run.step(nsteps)
+        ends.append({n: run.ctx.download(n).copy() for n in ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "rho", "Akv", "Akt", "Huon", "DU_avg1", "ru", "rv"]})
+        run.close()
+    bad = [n for n in ends[0] if not np.array_equal(ends[0][n], ends[1][n])]
+    assert not bad, (workload, bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,kw", DETERMINISM_SMALL)
+def test_poisoned_work_arrays_change_nothing(tag, kw, monkeypatch):
+    """ROMS_HIP_POISON=1: the library's work arrays (private scratch of the reference's routines, the staging levels of the
+    pair kernel) hold NaN at create and again at the start of every step.  A kernel that reads scratch nobody wrote in
+    this step would put NaN into the state; every small application case must end in the bits of the unpoisoned run."""
+    cs, g = _case_state(tag, kw)
+    monkeypatch.setenv("ROMS_HIP_POISON", "0")
+    a = _end_state(cs, g, 6)
+    monkeypatch.setenv("ROMS_HIP_POISON", "1")
+    b = _end_state(cs, g, 6)
+    for n in a:
+        assert np.isfinite(b[n]).all(), (tag, n, "NaN from poisoned scratch")
+        assert np.array_equal(a[n], b[n]), (tag, kw, n)
 
 
 XI_PARTNER = dict(u="v", ubar="vbar", Huon="Hvom", ru="rv", DU_avg1="DV_avg1", DU_avg2="DV_avg2", rufrc="rvfrc", rubar="rvbar",
@@ -702,10 +780,10 @@ XI_PARTNER = dict(u="v", ubar="vbar", Huon="Hvom", ru="rv", DU_avg1="DV_avg1", D
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "upwelling_prs31_small", "upwelling_wjgradp_small", "upwelling_prs40_small"])
+@pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "overflow_small", "upwelling_prs31_small", "upwelling_wjgradp_small", "upwelling_prs40_small"])
 def test_more_reference_applications_match_oracle(tag):
-    """SEAMOUNT and GRAV_ADJ (the reference's own test applications, oracle pinned bit for bit): 40 steps on the GPU at the
-    north-star tolerance."""
+    """SEAMOUNT, GRAV_ADJ and OVERFLOW (the reference's own test applications, oracle pinned bit for bit; OVERFLOW with
+    MIX_ISO_TS and spline vertical advection of both tracers): 40 steps on the GPU at the north-star tolerance."""
     cs = util.case_for(tag)
     g = util.load_init("upwelling_small" if tag.startswith("upwelling") else tag, util.nghost_for(cs))   # (prsgrd31.h / WJ_GRADP variants of UPWELLING)
     O = util.make_oracle(cs, g)

@@ -21,9 +21,7 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-# (overflow_small_steps.npz: MIX_ISO_TS is refused on the device until its kernel is parity-green there -- DESIGN.md 9; the
-# fixture is checked against the oracle, the emulated kernels and romsM on the CPU)
-STEPS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(util.GOLDEN, "*_steps.npz")) if "overflow" not in p)
+STEPS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(util.GOLDEN, "*_steps.npz")))
 KERNELS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(util.GOLDEN, "*_kernels.npz")))
 SAMPLES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(util.GOLDEN, "*_sample.npz")))
 NORTH_STAR = ("u", "v", "W", "wvel", "t", "zeta", "ubar", "vbar")

@@ -461,3 +461,27 @@ def test_generic_length_scale_closure_with_open_boundaries(emu):
             assert np.array_equal(H.download(n), O.field(n)), n
     assert O.field("Akv").max() > 1e4 * cs["Akv_bak"]
     H.close()
+
+
+def _determinism_cases():
+    from tests.test_gpu_parity import DETERMINISM_SMALL
+    return DETERMINISM_SMALL
+
+
+@pytest.mark.parametrize("tag,kw", _determinism_cases())
+def test_launch_order_and_poisoned_scratch_change_nothing(emu, tag, kw, monkeypatch):
+    """Two aids of the emulated build against the defect class a serial emulation hides (round 4): ROMS_EMU_ORDER=reverse
+    runs the blocks / threads of every launch in the opposite order -- a launch whose threads exchange values through
+    global memory depends on the order; ROMS_HIP_POISON=1 fills the work arrays with NaN at create and at every step --
+    a read of scratch nobody wrote shows.  Both must leave every bit of every application case where it was."""
+    from tests.test_gpu_parity import _case_state, _end_state
+    cs, g = _case_state(tag, kw)
+    a = _end_state(cs, g, 4, emu)
+    for env in (dict(ROMS_EMU_ORDER="reverse"), dict(ROMS_HIP_POISON="1"), dict(ROMS_EMU_ORDER="reverse", ROMS_HIP_POISON="1")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        b = _end_state(cs, g, 4, emu)
+        for k in env:
+            monkeypatch.delenv(k)
+        for n in a:
+            assert np.array_equal(a[n], b[n], equal_nan=True), (tag, env, n)
