@@ -177,10 +177,12 @@ typedef struct orc_s {
 #define XT(i, j, k, n, it) (X3(i, j, k) + ((size_t)((n) - 1) + 3 * (size_t)((it) - 1)) * nij * N)
 #define X2T(i, j, n) (X2(i, j) + (size_t)((n) - 1) * nij)                /* zeta(i,j,n) ... */
 
+void orc_check_step(const orc_t *o, const char *who);          /* aborts on a stepping index outside its array extent */
 #define ORC_LOCALS(o)                                                        \
   const int LBi = (o)->c.LBi, LBj = (o)->c.LBj, N = (o)->c.N;                \
   const size_t ni = (o)->ni, nij = (o)->nij;                                 \
-  (void)LBi; (void)LBj; (void)N; (void)ni; (void)nij
+  (void)LBi; (void)LBj; (void)N; (void)ni; (void)nij;                        \
+  orc_check_step((o), __func__)
 
 /* ---- API ---- */
 orc_t *orc_create(const orc_cfg *cfg);

@@ -14,6 +14,7 @@
  * PARITY: pinned (all of these reference routines build in oracle/_ref).
  */
 #include "orc.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -185,6 +186,9 @@ orc_t *orc_create(const orc_cfg *cfg) {
     *(double **)((char *)o + fields[k].off) = dalloc(field_size(o, fields[k].kind));
   for (size_t k = 0; k < o->nij; k++) o->rmask[k] = o->umask[k] = o->vmask[k] = o->pmask[k] = 1.0;   /* all water */
   o->ksbl = (int *)calloc(o->nij, sizeof(int));
+  /* the stepping indices of a state nobody has stepped yet: all 1 (what roms_hip_create sets); every routine checks
+     them on entry (ORC_LOCALS -> orc_check_step), so a caller that forgot one reads a defined time level */
+  o->s.iif = 1; o->s.indx1 = 1; o->s.kstp = o->s.krhs = o->s.knew = 1; o->s.nstp = o->s.nrhs = o->s.nnew = 1;
   return o;
 }
 
@@ -207,6 +211,18 @@ double *orc_field(orc_t *o, const char *name, long *nel) {
 }
 
 orc_step *orc_stepping(orc_t *o) { return &o->s; }
+
+/* time-level indices outside the arrays' extents (nstp, nnew, nrhs: 1..2, the tracer predictor level 3 is never a stepping
+   index; kstp, knew, krhs: 1..3) would read or write before / behind an array: stop at once, with the routine's name */
+void orc_check_step(const orc_t *o, const char *who) {
+  const orc_step *s = &o->s;
+  if (s->nstp < 1 || s->nstp > 2 || s->nnew < 1 || s->nnew > 2 || s->nrhs < 1 || s->nrhs > 2 || s->kstp < 1 || s->kstp > 3 ||
+      s->knew < 1 || s->knew > 3 || s->krhs < 1 || s->krhs > 3 || s->indx1 < 1 || s->indx1 > 2) {
+    fprintf(stderr, "oracle: %s called with a stepping index out of range (nstp %d nnew %d nrhs %d kstp %d knew %d krhs %d indx1 %d)\n",
+            who, s->nstp, s->nnew, s->nrhs, s->kstp, s->knew, s->krhs, s->indx1);
+    abort();
+  }
+}
 orc_cfg *orc_config(orc_t *o) { return &o->c; }
 
 void orc_get_bounds(orc_t *o, int tile, int *out) {

@@ -78,7 +78,7 @@ KDEV void halo_fill(const DGrid &G, double *A, int bcf, int gtype) {
   } else if (bc == BC_U && (bcf & BC_LBC2D)) {
     // bc_u2d_tile with open edges (bc_2d.F:197-290): closed where LBC(edge,isUbar) is, else zero gradient over the
     // open condition's own range
-    const int cl = G.lbc_closed >> (4 * ROMS_ISUBAR);
+    const int cl = (int)(G.lbc_closed >> (4 * ROMS_ISUBAR));
     if (!G.ewp) {
       if (B.east) { if (cl & (1 << ROMS_IEAST)) KLOOP1(j, Jstr, Jend) A[X2(Iend + 1, j)] = 0.0; else KLOOP1(j, Jstr, Jend) A[X2(Iend + 1, j)] = A[X2(Iend, j)]; }
       if (B.west) { if (cl & (1 << ROMS_IWEST)) KLOOP1(j, Jstr, Jend) A[X2(Istr, j)] = 0.0; else KLOOP1(j, Jstr, Jend) A[X2(Istr, j)] = A[X2(Istr + 1, j)]; }
@@ -96,7 +96,7 @@ KDEV void halo_fill(const DGrid &G, double *A, int bcf, int gtype) {
       }
     }
   } else if (bc == BC_V && (bcf & BC_LBC2D)) {
-    const int cl = G.lbc_closed >> (4 * ROMS_ISVBAR);
+    const int cl = (int)(G.lbc_closed >> (4 * ROMS_ISVBAR));
     if (!G.ewp) {
       const int Jmin = G.nsp ? B.JstrV : B.Jstr, Jmax = G.nsp ? B.Jend : B.JendR;
       if (B.east) {

@@ -30,7 +30,7 @@ static __global__ void __launch_bounds__(256, MINW) k_rhs3d_lds(const KArgs a, i
   const int gz = r_ % nz;
   const int t_ = xcd_ * seg_ + r_ / nz;
   if (t_ >= nt_) return;
-  const int tbx = t_ / nby_, tby = t_ - tbx * nby_;
+  KTILE_XY(t_, (nx + 63) / 64, nby_, tbx, tby);
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB &B = G.T;

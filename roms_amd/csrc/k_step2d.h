@@ -138,6 +138,9 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
   const bool MSK = MK && a.G.masking;                 // MK: this instantiation carries the mask products
   const DGrid &G = a.G;
   const S2Fields &F = a.F;
+#ifndef ROMS_CPU_EMU
+  xcd_remap2(G, bx, by);
+#endif
   const TB B = block_bounds2(G, bx, by);
   const int OW = FIXED ? BWC : G.bw2, OH = FIXED ? BHC : G.bh2, NOWN = OW * OH;
   const int TW = OW + 6, TH = OH + 6, NTILE = TW * TH, NT = FIXED ? NTC : KNT;

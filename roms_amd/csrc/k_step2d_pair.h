@@ -267,6 +267,9 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
   const bool MSK = MK && a.G.masking;
   const DGrid &G = a.G;
   const S2Fields &F = a.F;
+#ifndef ROMS_CPU_EMU
+  xcd_remap2(G, bx, by);
+#endif
   const TB B = block_bounds2(G, bx, by);
   const bool wrapx = a.wrapx != 0, wrapy = a.wrapy != 0;
   // the enlarged sub-tile of the predictor phase

@@ -26,7 +26,7 @@ static __global__ void __launch_bounds__(256, 3) k_uv3dmix2_col(const KArgs a, i
   const int r_ = (int)(blockIdx.x >> 3), xcd_ = (int)(blockIdx.x & 7);
   const int t_ = xcd_ * seg_ + r_;
   if (t_ >= nt_) return;
-  const int tbx = t_ / nby_, tby = t_ - tbx * nby_;
+  KTILE_XY(t_, (nx + 63) / 64, nby_, tbx, tby);
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB &B = G.T;

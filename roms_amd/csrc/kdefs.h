@@ -143,6 +143,20 @@ void kprof_end(int slot, hipStream_t stream);
 #ifndef KMINW
 #define KMINW 1   // minimum waves per SIMD the THREAD kernels are compiled for (experiment knob)
 #endif
+// tile number -> (xi block, eta block): KXIFAST 1 (default since round 4) = xi-fastest: an XCD's segment is a band of whole
+// rows of blocks, so the xi-neighbours of a block -- whose stencil reads share the 128-byte lines at the block's ends --
+// and its eta-neighbours run on the same XCD, and a row of single-wave COL blocks reads whole array rows; 0 = eta-fastest
+// (rounds 1-3: an XCD's segment was a 64-point-wide strip, every stencil array fetched 6 lines per row for 4).  Measured
+// (rocprofv3, 512x512x50): HBM traffic of the LDS-tiled kernels 1.46-1.53 -> 1.23-1.41 x algorithmic, of the point and
+// column kernels 1.2 -> 1.05; serial step 90.4 -> 88.2 ms / 13 steps, BENCHMARK3 115.3 -> 108.9 ms / 11 steps.
+#ifndef KXIFAST
+#define KXIFAST 1
+#endif
+#if KXIFAST
+#define KTILE_XY(t_, nbx_, nby_, tx_, ty_) const int ty_ = (t_) / (nbx_), tx_ = (t_) - ty_ * (nbx_)
+#else
+#define KTILE_XY(t_, nbx_, nby_, tx_, ty_) const int tx_ = (t_) / (nby_), ty_ = (t_) - tx_ * (nby_)
+#endif
 #define THREAD_GLOBAL(name, ArgT) THREAD_GLOBAL_W(name, ArgT, KMINW)
 // ... compiled for at least `minwaves` waves per SIMD (caps the VGPRs)
 #define THREAD_GLOBAL_W(name, ArgT, minwaves)                                            \
@@ -152,7 +166,7 @@ void kprof_end(int slot, hipStream_t stream);
     const int gz = r_ % nz;                                                              \
     const int t_ = xcd_ * seg_ + r_ / nz;                                                \
     if (t_ >= nt_) return;                                                               \
-    const int tx_ = t_ / nby_, ty_ = t_ - tx_ * nby_;                                    \
+    KTILE_XY(t_, (nx + 63) / 64, nby_, tx_, ty_);                                        \
     const int gx = tx_ * 64 + (int)threadIdx.x;                                          \
     const int gy = ty_ * KTY + (int)threadIdx.y;                                           \
     if (gx < nx && gy < ny) name##_body(a, gx, gy, gz);                                  \
@@ -184,7 +198,7 @@ extern thread_local size_t g_thread_ballast;   // (per host thread: several cont
     const int gz = r_ % nz;                                                              \
     const int t_ = xcd_ * seg_ + r_ / nz;                                                \
     if (t_ >= nt_) return;                                                               \
-    const int tx_ = t_ / ny, gy = t_ - tx_ * ny;                                         \
+    KTILE_XY(t_, (nx + 63) / 64, ny, tx_, gy);                                           \
     const int gx = tx_ * 64 + (int)threadIdx.x;                                          \
     if (gx < nx) name##_body(a, gx, gy, gz, lds_dyn_ + threadIdx.x);                     \
   }

@@ -40,6 +40,7 @@ struct DGrid {
   int xloc, yloc;             // 1: a periodic direction of this tile wraps onto itself by a local copy (no exchange partner)
   int xgl, xgh;               // ghost lines a strip exchange fills on the low | high side of a tile: 3 | Nghost (the reference's
                               // periodic layout), or B2D_GL | B2D_GH for the exchanges behind the barotropic pair kernel
+  int xmap2;                  // barotropic launches: block -> sub-tile through xcd_remap2 (below)
   int nbx2, nby2, bw2, bh2;   // the same for the 2-D (barotropic) kernel: smaller sub-tiles, the
                               // 2-D grid alone cannot fill 256 CUs otherwise
   // stepping (mod_stepping)
@@ -58,7 +59,8 @@ struct DGrid {
   // open boundaries: 1 if any edge of any variable is neither closed nor periodic (k_obc.h does the state's boundary
   // conditions then, and nothing is fused into the producers); bit (4*variable + edge) of lbc_closed set where
   // LBC(edge,variable)%closed (bc_2d.F:201, mpdata_adiff.F:698: closed, or else zero gradient)
-  int obc, lbc_closed;
+  int obc;
+  unsigned long long lbc_closed;     // (64 bits: 4 edges x (ROMS_ISTVAR + NT) variables)
 };
 
 #ifdef ROMS_CPU_EMU
@@ -136,6 +138,19 @@ KHD TB block_bounds_n(const DGrid &G, int nbx, int nby, int bx, int by) {
 }
 KHD TB block_bounds(const DGrid &G, int bx, int by) { return block_bounds_n(G, G.nbx, G.nby, bx, by); }
 KHD TB block_bounds2(const DGrid &G, int bx, int by) { return block_bounds_n(G, G.nbx2, G.nby2, bx, by); }
+// XCD-aware block order of the barotropic launches (round 4).  The hardware hands workgroup b = bx + nbx2*by to XCD
+// b % 8, so with the plain order the xi-neighbours of a sub-tile sit on seven OTHER L2s and every block fetches the
+// 128-byte lines at the two ends of its 38-point rows for itself.  Remapped, the sub-tiles (numbered xi-fastest) are
+// cut into 8 contiguous segments -- whole rows of sub-tiles -- one per XCD: the blocks resident on an XCD at a time are
+// neighbours in xi AND eta, and the rim lines they share are fetched into that L2 once.  Only the assignment of blocks
+// to sub-tiles changes (same bits).  xmap2 is set when the number of sub-tiles is a multiple of 8.
+KHD void xcd_remap2(const DGrid &G, int &bx, int &by) {
+  if (!G.xmap2) return;
+  const int lin = bx + G.nbx2 * by, seg = (G.nbx2 * G.nby2) >> 3;
+  const int t = (lin & 7) * seg + (lin >> 3);
+  by = t / G.nbx2;
+  bx = t - by * G.nbx2;
+}
 
 // ghost lines the barotropic pair kernel reads beyond the tile (k_step2d_pair.h): each of its two step2d calls consumes
 // three lines on the low side and two on the high side, so a pair needs 5 | 4 (2-D fields of a multi-tile run)

@@ -205,6 +205,7 @@ static void choose_blocks(DGrid &G) {
   else if ((long)LmT * MmT >= 256L * 1024L) { bw2 = 32; bh2 = 8; }
   env_tile("ROMS_HIP_TILE2D", bw2, bh2, 1024);            // 19 LDS arrays < 160 KB; 2 points x 512 threads
   split_tile(LmT, MmT, bw2, bh2, G.nbx2, G.nby2, G.bw2, G.bh2);
+  { const char *ex = getenv("ROMS_HIP_S2D_XCD"); G.xmap2 = ((G.nbx2 * G.nby2) % 8 == 0 && G.nbx2 * G.nby2 >= 16 && !(ex && ex[0] == '0')) ? 1 : 0; }
 }
 // narrowest first/last sub-tile of a tile_bounds_2d partition of n points into nb pieces
 static int edge_subtile(int n, int nb) {
@@ -316,7 +317,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
                     " (built: Clo Per Gra Cla Rad RadNud, Che/Cha for the free surface, Fla/Shc for ubar/vbar)");
           return 5;
         }
-        if (k == ROMS_LBC_CLO) G.lbc_closed |= 1 << (4 * v + e);
+        if (k == ROMS_LBC_CLO) G.lbc_closed |= 1ull << (4 * v + e);
         if (k != ROMS_LBC_CLO && k != ROMS_LBC_PER) G.obc = 1;
       }
   }
@@ -326,7 +327,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     for (int it = 0; it < cfg->NT; it++)
       if (cfg->hadv[it] == ROMS_MPDATA || cfg->vadv[it] == ROMS_MPDATA)
         for (int e = 0; e < 4; e++)
-          if (!(G.lbc_closed & (1 << (4 * ((e == ROMS_IWEST || e == ROMS_IEAST) ? ROMS_ISUVEL : ROMS_ISVVEL) + e))) &&
+          if (!(G.lbc_closed & (1ull << (4 * ((e == ROMS_IWEST || e == ROMS_IEAST) ? ROMS_ISUVEL : ROMS_ISVVEL) + e))) &&
               lbc_kind(*cfg, e, ROMS_ISUVEL) != ROMS_LBC_PER) {
             set_error("MPDATA is not built together with an open boundary of the 3-D momentum (mpdata_adiff.F:696-760)");
             return 5;
@@ -1333,7 +1334,11 @@ static int probe_once(roms_hip_ctx *c, int rep, int planes, bool wide, bool tail
   const TileComm &m = c->comm;
   const size_t n = (size_t)G.ni * (size_t)G.nj;
   std::vector<double> h(n * planes), g(n * planes);
-  double *A = c->F.wrk3[0];                 // a 3-D work array: `planes` consecutive planes
+  // a buffer of its own, `planes` consecutive planes (round 3 borrowed wrk3[0], whose (N+1)*NT planes a shallow grid or a
+  // large ROMS_HIP_XASYNC_PLANES overran)
+  struct Buf { void *p = nullptr; ~Buf() { if (p) { dfree(p); } } } buf;
+  if (dmalloc(&buf.p, n * (size_t)planes * sizeof(double))) return 2;
+  double *A = (double *)buf.p;
   auto at = [&](int i, int j) -> size_t { return (size_t)(i - G.LBi) + (size_t)(j - G.LBj) * (size_t)G.ni; };
   auto code = [&](int i, int j, int k) -> double {
     if (i < 1) i += G.Lm; else if (i > G.Lm) i -= G.Lm;

@@ -43,11 +43,11 @@ def test_initial_depths_match_reference():
     """set_depth (pinned): recomputing Hz, z_r, z_w from the golden h reproduces the reference."""
     cs, g, O = _fresh()
     O.step.nstp = 1
+    O.step.nrhs = 1          # (before set_massflux, which reads u, v(nrhs))
     O.call("set_depth")
     for n in ["Hz", "z_r", "z_w"]:
         assert np.array_equal(O.field(n), g[n]), n
     O.call("set_massflux")
-    O.step.nrhs = 1
     O.call("rho_eos")
     for n in ["rho", "rhoA", "rhoS", "Huon", "Hvom"]:
         assert np.array_equal(O.field(n), g[n]), n
