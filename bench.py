@@ -89,7 +89,21 @@ ALGO_ARRAYS = {
     "k_set_massflux": (5, 2),
     "k_diag_col":     (7, 3),
     "k_wvel":         (6, 4),      # fused wvelocity: u, v, z_r, W, z_w read, wvel written
+    # MPDATA (BASELINE config 5), PER TRACER -- the launch sequence runs once per MPDATA tracer (g_step3d.cpp); SURVEY 8(a)
+    # a10 prices the first-order step + corrected fluxes at +16 words, a11 (mpdata_adiff) at about 10 per tracer:
+    "k_mp_ta":        (7, 2),      # t(3), t(nnew), Huon, Hvom, W, Hz read; Ta written
+    "k_mp_uva":       (7, 4),      # Ta, Huon, Hvom, W, Hz read; Ua, Va written (both directions in one launch)
+    "k_mp_wa":        (6, 2),      # Ta, Huon, Hvom, W, Hz read; Wa written
+    "k_mp_beta":      (8, 2),      # Ta, t(3), Ua, Va, Wa, Hz read; beta_up, beta_dn written
+    "k_mp_apply":     (9, 3),      # (k_mp_limapply) Ta, Ua, Va, Wa, beta_up, beta_dn, Hz, z_r read; t(nnew) written
+    "k_mp_vdiff":     (4, 1),      # t(nnew) read and written, Hz, Akt read (plain implicit vertical diffusion :1724-1790)
 }
+# what the FUSED barotropic pair kernel itself must move once per launch: 2-D words.  Read: zeta, ubar,
+# vbar at two levels (6), h, pm, pn, on_u, om_v (5), rhoA, rhoS (2), the five fast-time averages (5), rzeta/rubar/rvbar of
+# the older level (3), rufrc, rvfrc (2), the 13 metric arrays of the momentum stage; written: the five averages, the
+# r.h.s. level krhs (3), the staged corrector result (3), the committed level (3) -- 50 words against the 88 of two
+# step2d calls in SURVEY 8(d)'s per-call unit.  roofline.achieved keeps SURVEY's unit; roofline.achieved_fused this one.
+FUSED_2D_WORDS = {"k_step2d_pair": 50}
 
 # North-star kernel pair "step3d_t + rhs3d" (BASELINE.json north_star; SURVEY.md 8(d): rows a4-a8 + a10 =
 # pre_step3d, prsgrd, t3dmix2, rhs3d_tile, uv3dmix2, step3d_t): 79 words = 632 bytes per cell for U3/C4
@@ -506,12 +520,14 @@ def main():
             with open(args.breakdown_file, "w") as f:
                 json.dump({k: {"seconds": v[0], "launches": v[1]} for k, v in table.items()}, f, indent=1)
     if dominant:
-        # a kernel launched many times per step (the barotropic kernel: back-to-back launches) is timed
-        # in runs of 16 consecutive launches per event pair, every other run: the two event markers
-        # would otherwise inflate a 10-microsecond kernel and slow the timed region down
-        launches_per_step = table[dominant][1] // 2
-        many = launches_per_step >= 16
-        hiplib.kprof(2, dominant, stride=2 if many else 1, batch=16 if many else 1)
+        # every launch of the dominant kernel inside the timed region carries a start / stop event pair filled by the
+        # launch itself (kprof mode 3: the dispatch's own begin / end timestamps, i.e. the duration rocprofv3 reports;
+        # rounds 1-3 bracketed runs of 16 launches with marker events, which counted the gaps between launches too
+        # and read 24 % above rocprofv3); all launches of one step in ten are sampled: a pair on EVERY launch of every
+        # step slows the step by 6 %
+        lps = max(1, table[dominant][1] // 2)                     # launches per step (the breakdown pass ran 2 steps)
+        every = int(os.environ.get("ROMS_BENCH_KSTEPS", "10" if args.steps >= 20 else "1"))
+        hiplib.kprof(3, dominant, window=(lps, lps * every))
     barrier_sync()
 
     if world > 1:
@@ -535,10 +551,18 @@ def main():
             avg = sec / launches
             nb = algo_bytes(dominant, cs["Lm"], cs["Mm"], cs["N"])
             achieved = nb / avg / 1e9
+            fused = FUSED_2D_WORDS.get(dominant)
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_us": avg * 1e6, "launches": launches,
+                        "avg_launch_method": "hipExtLaunchKernel start/stop events on every launch of the kernel in one step out of ten inside "
+                                             "the timed region (dispatch begin -> end, as rocprofv3 --kernel-trace)",
                         "algorithmic_bytes_per_launch": nb}
+            if fused:           # the bytes the fused kernel itself moves (it reads the state once for both calls)
+                fb = 8.0 * cs["Lm"] * cs["Mm"] * fused
+                roofline["fused_kernel_bytes_per_launch"] = fb
+                roofline["achieved_fused"] = fb / avg / 1e9
+                roofline["frac_fused"] = fb / avg / 1e9 / HBM_PEAK_GBS
             # the whole step against the same peak: SURVEY 8(d)'s bytes per cell-update x cells / step time
             wsb = whole_step_bytes_per_cell(cs, run.nfast)
             roofline["whole_step_bytes_per_cell"] = wsb
@@ -562,15 +586,24 @@ def main():
     out = None
     if rank == 0:
         value = cells_per_rank * world * args.steps / elapsed
+        # the tile of this run against the tile of the N = 1 line of the same workload: BASELINE's own 8-GPU configuration
+        # (BENCHMARK3 in 2x4) has a 1024x64 tile, twice the 512x64 of BENCHMARK1 -- a scaling curve must be normalised
+        # by cells per GPU, which the line therefore states
+        n1 = WORKLOADS[args.workload]
+        n1_tile = (args.Lm or n1[1], args.Mm or n1[2], args.N or n1[3])
+        tile = (cs["Lm"], cs["Mm"], cs["N"])
+        ratio = (tile[0] * tile[1] * tile[2]) / float(n1_tile[0] * n1_tile[1] * n1_tile[2])
+        scaling = "weak" if abs(ratio - 1.0) < 1e-9 else f"weak (tile x{ratio:g} vs n=1)"
         out = {
             "metric": "grid-cell-updates/sec", "value": value, "unit": "grid-cell-updates/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{cs['app'].upper()} {run.global_Lm}x{run.global_Mm}x{cs['N']} "
                                    f"(tile {cs['Lm']}x{cs['Mm']}x{cs['N']} per GPU), dt={cs['dt']:g}s ndtfast={cs['ndtfast']}, "
                                    "analytic grid/initial/forcing, full application physics",
                        "tiles": f"{run.NtileI}x{run.NtileJ}", "nfast": run.nfast,
+                       "tile": "%dx%dx%d" % tile, "n1_tile": "%dx%dx%d" % n1_tile, "cells_per_gpu": cells_per_rank,
                        "halo_transport": getattr(run, "transport", None) if world > 1 else "none (single tile)",
                        "rccl_ranks": run.rccl_ranks() if world > 1 else None,
                        "transport_probes": getattr(run, "probe_log", None) if world > 1 else None,

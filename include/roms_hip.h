@@ -310,12 +310,18 @@ int roms_hip_copy_probe(roms_hip_ctx *ctx, int reps, long *bytes_per_launch);
 
 /* per-kernel device timing with HIP events on the library's stream (process-wide table):
    mode 0 off; 1 = every launch, synchronous (breakdown pass); 2 = only launches of `kernel`,
-   asynchronous event pairs resolved when the table is read (usable inside a timed region).
+   asynchronous event pairs resolved when the table is read (usable inside a timed region);
+   3 = only launches of `kernel`, the pair filled by the launch itself (hipExtLaunchKernel's start /
+   stop events: the dispatch's own begin and end timestamps, the duration rocprofv3 reports -- no
+   marker packets, the gaps between back-to-back launches are not counted).
    roms_hip_kprof resets the table; roms_hip_kprof_get enumerates it (returns 8 past the end). */
 int roms_hip_kprof(int mode, const char *kernel);
-/* mode 2 only: time every `every`-th launch of the selected kernel (keeps the event overhead out
+/* modes 2 and 3: time every `every`-th launch of the selected kernel (keeps the event overhead out
    of a timed region) */
 int roms_hip_kprof_stride(int every);
+/* mode 3: time `on` consecutive launches of the selected kernel out of every `period` (e.g. all launches of one step
+   in ten: every position of a loop is sampled equally, at a tenth of the cost) */
+int roms_hip_kprof_window(int on, int period);
 /* mode 2 only: one event pair around `n` consecutive launches of the selected kernel (back-to-back
    launches, e.g. the barotropic loop): the event markers then do not inflate a short kernel.  A run
    interrupted by another launch is discarded and the library falls back to one pair per launch. */

@@ -57,10 +57,10 @@ bool launch_tadv_lds(roms_hip_ctx *c, int mode) {
   const size_t lds = (size_t)TL_LDS_DOUBLES * sizeof(double);
   static const char *ew = getenv("ROMS_HIP_TADV_W");
   const int w = ew ? atoi(ew) : (mode == 0 ? 2 : 3);
-  if (mode == 0 && w == 2) KPROF_WRAP(k_pre_t3, c->stream, hipLaunchKernelGGL((k_tadv_lds<0, 2>), grid, block, lds, c->stream, a, nx, ny, nz));
-  else if (mode == 0) KPROF_WRAP(k_pre_t3, c->stream, hipLaunchKernelGGL((k_tadv_lds<0, 3>), grid, block, lds, c->stream, a, nx, ny, nz));
-  else if (w == 2) KPROF_WRAP(k_s3t_hv, c->stream, hipLaunchKernelGGL((k_tadv_lds<1, 2>), grid, block, lds, c->stream, a, nx, ny, nz));
-  else KPROF_WRAP(k_s3t_hv, c->stream, hipLaunchKernelGGL((k_tadv_lds<1, 3>), grid, block, lds, c->stream, a, nx, ny, nz));
+  if (mode == 0 && w == 2) KPROF_WRAP(k_pre_t3, c->stream, ROMS_LAUNCH((k_tadv_lds<0, 2>), grid, block, lds, c->stream, a, nx, ny, nz));
+  else if (mode == 0) KPROF_WRAP(k_pre_t3, c->stream, ROMS_LAUNCH((k_tadv_lds<0, 3>), grid, block, lds, c->stream, a, nx, ny, nz));
+  else if (w == 2) KPROF_WRAP(k_s3t_hv, c->stream, ROMS_LAUNCH((k_tadv_lds<1, 2>), grid, block, lds, c->stream, a, nx, ny, nz));
+  else KPROF_WRAP(k_s3t_hv, c->stream, ROMS_LAUNCH((k_tadv_lds<1, 3>), grid, block, lds, c->stream, a, nx, ny, nz));
   return true;
 #endif
 }
@@ -197,8 +197,8 @@ static int launch_rhs3d_point_part(roms_hip_ctx *c) {
     // compiled for 2 waves per SIMD (198 VGPRs with the own-point values of the next level in flight): 300 us at
     // 512x512x50; 3 waves (168 VGPRs) spill 33 of them: 521 us; before the own-point loads were taken a level
     // ahead: 366 (3 waves) / 383 (2 waves); the point-wise form: 478
-    if (w == 2) KPROF_WRAP(k_rhs3d_pt, c->stream, hipLaunchKernelGGL(k_rhs3d_lds<2>, grid, block, lds, c->stream, a, nx, ny, nz));
-    else KPROF_WRAP(k_rhs3d_pt, c->stream, hipLaunchKernelGGL(k_rhs3d_lds<3>, grid, block, lds, c->stream, a, nx, ny, nz));
+    if (w == 2) KPROF_WRAP(k_rhs3d_pt, c->stream, ROMS_LAUNCH(k_rhs3d_lds<2>, grid, block, lds, c->stream, a, nx, ny, nz));
+    else KPROF_WRAP(k_rhs3d_pt, c->stream, ROMS_LAUNCH(k_rhs3d_lds<3>, grid, block, lds, c->stream, a, nx, ny, nz));
     return 0;
   }
 #endif
@@ -255,7 +255,7 @@ int run_uv3dmix2_col(roms_hip_ctx *c) {
   KArgs a = mk(c);
   const int nt = ((nx + 63) / 64) * ((ny + 3) / 4);
   KPROF_WRAP(k_uv3dmix2_col, c->stream,
-             hipLaunchKernelGGL(k_uv3dmix2_col, dim3((unsigned)(8 * ((nt + 7) / 8)), 1, 1), dim3(64, 4, 1),
+             ROMS_LAUNCH(k_uv3dmix2_col, dim3((unsigned)(8 * ((nt + 7) / 8)), 1, 1), dim3(64, 4, 1),
                                 (size_t)UC_LDS_DOUBLES * sizeof(double), c->stream, a, nx, ny));
   return 0;
 #endif

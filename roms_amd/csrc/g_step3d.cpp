@@ -80,7 +80,9 @@ int run_step3d_t(roms_hip_ctx *c) {
   const bool plain = (G.options & ROMS_PLAIN_VDIFF) != 0;    // without SPLINES_VDIFF: the straightforward kernel forms, then k_mp_vdiff
   if (any_pt && (plain || !launch_tadv_lds(c, 1))) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
   if (any_hsimt) LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
-  {
+  bool any_col = false;        // (a launch whose tracers are all MPDATA's would return at once: k_mpdata.h does their column work)
+  for (int it = 0; it < G.NT; it++) any_col |= G.vadv[it] != ROMS_MPDATA;
+  if (any_col) {
     const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
 #ifdef ROMS_CPU_EMU
     if (col_lds(G)) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l, nx, ny, G.NT, 2 * (N + 1), c->stream, a);

@@ -80,6 +80,7 @@ extern int g_emu_reverse;
 
 #else  // ------------------------------------------------------------------ HIP / gfx950
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #define KDEV __device__ __forceinline__
 #define KTID ((int)threadIdx.x)
 #define KNT ((int)blockDim.x)
@@ -109,6 +110,13 @@ typedef hipStream_t kstream_t;
 // per-kernel HIP-event timing (roms_hip_kprof, roms_hip.cpp): mode 0 off, 1 every launch
 // (synchronous), 2 launches of one selected kernel (asynchronous event pairs)
 extern int g_kprof_mode;
+// every launch goes through hipExtLaunchKernelGGL: with the two events null it IS hipLaunchKernelGGL; kprof mode 3 hands
+// the selected kernel a start / stop event pair, which the runtime fills from the dispatch packet's own begin / end
+// timestamps -- the kernel's duration as rocprofv3 reports it, no marker packets in the queue, no gaps between launches
+// counted (bench.py: roofline.avg_launch_us)
+extern thread_local hipEvent_t g_kp_start, g_kp_stop;
+#define ROMS_LAUNCH(kern, grid, block, lds, stream, ...) \
+  hipExtLaunchKernelGGL(kern, grid, block, lds, stream, g_kp_start, g_kp_stop, 0, __VA_ARGS__)
 int kprof_begin(const char *name, hipStream_t stream);
 void kprof_end(int slot, hipStream_t stream);
 #define KPROF_WRAP(name, stream, launch)                                                 \
@@ -119,13 +127,13 @@ void kprof_end(int slot, hipStream_t stream);
   } while (0)
 #define LAUNCH_COOP(name, gx, gy, gz, nthreads, lds_doubles, stream, args)               \
   KPROF_WRAP(name, stream,                                                               \
-  hipLaunchKernelGGL(name, dim3((unsigned)(gx), (unsigned)(gy), (unsigned)(gz)), dim3((unsigned)(nthreads)), \
+  ROMS_LAUNCH(name, dim3((unsigned)(gx), (unsigned)(gy), (unsigned)(gz)), dim3((unsigned)(nthreads)), \
                      (size_t)(lds_doubles) * sizeof(double), stream, args))
 
 // variant `name` of a kernel reported to the profiler hooks as `label`
 #define LAUNCH_COOP_AS(label, name, gx, gy, gz, nthreads, lds_doubles, stream, args)     \
   KPROF_WRAP(label, stream,                                                              \
-  hipLaunchKernelGGL(name, dim3((unsigned)(gx), (unsigned)(gy), (unsigned)(gz)), dim3((unsigned)(nthreads)), \
+  ROMS_LAUNCH(name, dim3((unsigned)(gx), (unsigned)(gy), (unsigned)(gz)), dim3((unsigned)(nthreads)), \
                      (size_t)(lds_doubles) * sizeof(double), stream, args))
 
 #define THREAD_KERNEL(name, ArgT) static __device__ __forceinline__ void name##_body(const ArgT &a, int gx, int gy, int gz)
@@ -177,11 +185,11 @@ void kprof_end(int slot, hipStream_t stream);
 extern thread_local size_t g_thread_ballast;   // (per host thread: several contexts may be driven from one process)
 #define LAUNCH_THREAD(name, nx, ny, nz, stream, args)                                    \
   KPROF_WRAP(name, stream,                                                               \
-  hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + KTY - 1) / KTY)) + 7) / 8) * (nz)), 1, 1), \
+  ROMS_LAUNCH(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + KTY - 1) / KTY)) + 7) / 8) * (nz)), 1, 1), \
                      dim3(64, KTY, 1), g_thread_ballast, stream, args, (int)(nx), (int)(ny), (int)(nz)))
 #define LAUNCH_THREAD_AS(label, name, nx, ny, nz, stream, args)                           \
   KPROF_WRAP(label, stream,                                                              \
-  hipLaunchKernelGGL(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + KTY - 1) / KTY)) + 7) / 8) * (nz)), 1, 1), \
+  ROMS_LAUNCH(name, dim3((unsigned)(8 * ((((((nx) + 63) / 64) * (((ny) + KTY - 1) / KTY)) + 7) / 8) * (nz)), 1, 1), \
                      dim3(64, KTY, 1), g_thread_ballast, stream, args, (int)(nx), (int)(ny), (int)(nz)))
 // COL kernels: one thread per sigma column with `per_thread` doubles of LDS each (the elimination
 // coefficients of a tridiagonal solve, a column kept between sweeps).  Blocks are single waves
@@ -204,7 +212,7 @@ extern thread_local size_t g_thread_ballast;   // (per host thread: several cont
   }
 #define LAUNCH_COL_AS(label, name, nx, ny, nz, per_thread, stream, args)                 \
   KPROF_WRAP(label, stream,                                                              \
-  hipLaunchKernelGGL(name, dim3((unsigned)(8 * (((((nx) + 63) / 64) * (ny) + 7) / 8) * (nz)), 1, 1), \
+  ROMS_LAUNCH(name, dim3((unsigned)(8 * (((((nx) + 63) / 64) * (ny) + 7) / 8) * (nz)), 1, 1), \
                      dim3(64, 1, 1), (size_t)(per_thread) * 64 * sizeof(double), stream, args, (int)(nx), (int)(ny), (int)(nz)))
 #define LAUNCH_COL(name, nx, ny, nz, per_thread, stream, args) LAUNCH_COL_AS(name, name, nx, ny, nz, per_thread, stream, args)
 #endif

@@ -797,6 +797,7 @@ extern "C" int roms_hip_region_seconds(roms_hip_ctx *c, int region, double *seco
 // happens before any run has completed the mode falls back to one pair per launch.
 #ifndef ROMS_CPU_EMU
 int g_kprof_mode = 0;
+thread_local hipEvent_t g_kp_start = nullptr, g_kp_stop = nullptr;
 namespace {
 struct KSlot { char name[48]; double seconds; long calls; };
 const int KMAXSLOT = 128, KPOOL = 8192;
@@ -829,10 +830,14 @@ void kprof_resolve() {
   g_kev_used = 0;
 }
 }  // namespace
-static int g_kstride = 1, g_kcount = 0;
-extern "C" int roms_hip_kprof_stride(int every) { g_kstride = every > 0 ? every : 1; g_kcount = 0; return 0; }
+static int g_kstride = 1, g_kcount = 0, g_kwin = 1;
+extern "C" int roms_hip_kprof_stride(int every) { g_kstride = every > 0 ? every : 1; g_kcount = 0; g_kwin = 1; return 0; }
+extern "C" int roms_hip_kprof_window(int on, int period) { g_kstride = period > 0 ? period : 1; g_kwin = on > 0 ? on : 1; g_kcount = 0; return 0; }
 extern "C" int roms_hip_kprof_batch(int n) { kprof_resolve(); g_kbatch = n > 0 ? n : 1; g_kb_done = 0; return 0; }
 int kprof_begin(const char *name, hipStream_t stream) {
+  if (g_kprof_mode == 3) {
+    if (strcmp(name, g_kselect) || (g_kcount++ % g_kstride) >= g_kwin) return -1;
+  }
   if (g_kprof_mode == 2) {
     if (strcmp(name, g_kselect)) {
       if (g_kb_open >= 0) g_kb_broken = true;
@@ -860,11 +865,13 @@ int kprof_begin(const char *name, hipStream_t stream) {
   int e = g_kev_used++;
   g_kev_slot[e] = slot;
   g_kev_n[e] = 1;
+  if (g_kprof_mode == 3) { g_kp_start = g_kev[2 * e]; g_kp_stop = g_kev[2 * e + 1]; return e; }   // the launch itself fills the pair
   (void)hipEventRecord(g_kev[2 * e], stream);
   if (g_kprof_mode == 2 && g_kbatch > 1) { g_kb_open = e; g_kb_count = 0; g_kb_broken = false; }
   return e;
 }
 void kprof_end(int e, hipStream_t stream) {
+  if (g_kprof_mode == 3) { g_kp_start = nullptr; g_kp_stop = nullptr; return; }
   if (g_kprof_mode == 2 && g_kb_open == e) {
     if (++g_kb_count < g_kbatch) return;       // the run goes on
     g_kev_n[e] = g_kbatch;
@@ -894,6 +901,7 @@ extern "C" int roms_hip_kprof_get(int index, char *name, int name_len, double *s
 #else
 extern "C" int roms_hip_kprof(int, const char *) { return 0; }
 extern "C" int roms_hip_kprof_stride(int) { return 0; }
+extern "C" int roms_hip_kprof_window(int, int) { return 0; }
 extern "C" int roms_hip_kprof_batch(int) { return 0; }
 extern "C" int roms_hip_kprof_get(int, char *, int, double *, long *) { return 8; }
 #endif
@@ -1231,7 +1239,7 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
         ba.ubuf[d] = on ? (double *)((char *)m.peer_slab + m.peer_off[ch][par][d]) : nullptr;
         ba.su.word[d] = on ? (unsigned long long *)((char *)m.peer_slab + PEER_WORDS) + (size_t)(ch * 8 + d) * m.peer_planes : nullptr;
       }
-      KPROF_WRAP(xchg_peer_both, xs, hipLaunchKernelGGL(xchg_peer_both, dim3(1, 1, (unsigned)planes), dim3(c->peer_threads), 0, xs, ba));
+      KPROF_WRAP(xchg_peer_both, xs, ROMS_LAUNCH(xchg_peer_both, dim3(1, 1, (unsigned)planes), dim3(c->peer_threads), 0, xs, ba));
     } else {
     XchgPeerArgs pa;
     pa.x = a;
@@ -1242,14 +1250,14 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
       pa.x.buf[d] = on ? (double *)((char *)m.peer_map[d] + m.peer_noff[d][ch][par]) : nullptr;
       pa.s.word[d] = on ? (unsigned long long *)((char *)m.peer_map[d] + PEER_WORDS) + (size_t)(ch * 8 + g_opp[d]) * m.peer_planes : nullptr;
     }
-    KPROF_WRAP(xchg_peer_pack, xs, hipLaunchKernelGGL(xchg_peer_pack, dim3(1, 1, (unsigned)planes), dim3(c->peer_threads), 0, xs, pa));
+    KPROF_WRAP(xchg_peer_pack, xs, ROMS_LAUNCH(xchg_peer_pack, dim3(1, 1, (unsigned)planes), dim3(c->peer_threads), 0, xs, pa));
     pa.x.unpack = 1; pa.x.fill = 0;
     for (int d = 0; d < 8; d++) {
       const bool on = m.nbr[d] >= 0;
       pa.x.buf[d] = on ? (double *)((char *)m.peer_slab + m.peer_off[ch][par][d]) : nullptr;
       pa.s.word[d] = on ? (unsigned long long *)((char *)m.peer_slab + PEER_WORDS) + (size_t)(ch * 8 + d) * m.peer_planes : nullptr;
     }
-    KPROF_WRAP(xchg_peer_unpack, xs, hipLaunchKernelGGL(xchg_peer_unpack, dim3(1, 1, (unsigned)planes), dim3(c->peer_threads), 0, xs, pa));
+    KPROF_WRAP(xchg_peer_unpack, xs, ROMS_LAUNCH(xchg_peer_unpack, dim3(1, 1, (unsigned)planes), dim3(c->peer_threads), 0, xs, pa));
     }
   } else {
 #endif

@@ -25,7 +25,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 # variants of one kernel (LDS / register forms, chunk sizes) are reported under the kernel's name
 VARIANTS = {"k_s3uv_col_l": "k_s3uv_col", "k_s3uv_col_l10": "k_s3uv_col", "k_s3uv_col_r32": "k_s3uv_col", "k_s3uv_col_r52": "k_s3uv_col", "k_s3uv_couple_l": "k_s3uv_couple",
             "k_s3t_col_l": "k_s3t_col", "k_s3t_col_l10": "k_s3t_col", "k_s3t_col_n30": "k_s3t_col",
-            "k_uv3dmix2_m": "k_uv3dmix2_s", "k_t3dmix2_m": "k_t3dmix2_s", "k_mp_vdiff_l": "k_mp_vdiff", "k_mp_limapply": "k_mp_apply", "k_omega_l": "k_omega", "k_wvel_f": "k_wvel",
+            "k_uv3dmix2_m": "k_uv3dmix2_s", "k_t3dmix2_m": "k_t3dmix2_s", "k_mp_vdiff_l": "k_mp_vdiff", "k_mp_limapply": "k_mp_apply", "k_lmd_col2": "k_lmd_col", "k_omega_l": "k_omega", "k_wvel_f": "k_wvel",
             "k_rhs3d_lds": "k_rhs3d_pt", "k_pre_new_m": "k_pre_new", "k_pre_new_m4": "k_pre_new"}
 
 
