@@ -328,7 +328,11 @@ def north_star_pass(hiplib, tiling, device, steps=6, warmup=24, workload="ns512u
     run = tiling.TiledRun(cs, device=device)
     run.step(warmup)                       # past the start-up branches (iic <= 2) and the clock ramp after the CPU leg
     run.sync()
-    hiplib.kprof(1)
+    # kprof mode 4: every launch carries the start / stop events hipExtLaunchKernel fills from the dispatch's own
+    # timestamps, one stream -- the per-kernel durations a serial `rocprofv3 --kernel-trace --stats` run reports
+    # (profiles/r04_ns512*_serial_kernel_stats.csv); rounds 1-3 bracketed every launch with marker events and a host
+    # synchronisation, which read 4 % higher
+    hiplib.kprof(4)
     run.step(steps)
     run.sync()
     table = hiplib.kprof_table()

@@ -313,7 +313,9 @@ int roms_hip_copy_probe(roms_hip_ctx *ctx, int reps, long *bytes_per_launch);
    asynchronous event pairs resolved when the table is read (usable inside a timed region);
    3 = only launches of `kernel`, the pair filled by the launch itself (hipExtLaunchKernel's start /
    stop events: the dispatch's own begin and end timestamps, the duration rocprofv3 reports -- no
-   marker packets, the gaps between back-to-back launches are not counted).
+   marker packets, the gaps between back-to-back launches are not counted); 4 = every launch of every kernel
+   that way, asynchronous, the side streams off as in mode 1 (each kernel's own duration, as a serial
+   rocprofv3 --kernel-trace run reports it).
    roms_hip_kprof resets the table; roms_hip_kprof_get enumerates it (returns 8 past the end). */
 int roms_hip_kprof(int mode, const char *kernel);
 /* modes 2 and 3: time every `every`-th launch of the selected kernel (keeps the event overhead out

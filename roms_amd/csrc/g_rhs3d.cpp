@@ -37,11 +37,25 @@ bool launch_tadv_lds(roms_hip_ctx *c, int mode) {
   // mode 0: k_pre_t3's tracers are all those without a spline vertical flux (MPDATA/HSIMT tracers take the
   // first-order upstream predictor there); mode 1: the tracers of k_s3t_hv (every horizontal scheme but MPDATA and
   // HSIMT) -- the others are left to k_mpdata.h / k_s3t_h and skipped here (a.p1 = mask of the block's tracers)
+  // mode 1, round 4: tracers with an HSIMT horizontal and / or vertical step ride along (template HS: 1/Hz, Huon, Hvom staged
+  // too; k_s3t_h and the HSIMT sweep of k_s3t_col are then not needed for them) -- not with MASKING (k_s3t_h carries
+  // the masked forms); ROMS_HIP_HSIMT_LDS=0 keeps the round-3 kernels
+  static const char *ehs = getenv("ROMS_HIP_HSIMT_LDS");
+  bool any_hs = false;
+  for (int it = 0; it < G.NT; it++) any_hs |= G.hadv[it] == ROMS_HSIMT || G.vadv[it] == ROMS_HSIMT;
+  const bool HS = mode == 1 && any_hs && !G.masking && !(ehs && ehs[0] == '0');
   int mask = 0;
+  c->tadv_hdone = 0; c->tadv_vdone = 0;
   for (int it = 0; it < G.NT; it++) {
     const int hs = G.hadv[it], vs = G.vadv[it];
     if (mode == 0 && vs == ROMS_SPLINES) return false;
-    if (mode == 0 || (hs != ROMS_MPDATA && hs != ROMS_HSIMT)) mask |= 1 << it;
+    if (mode == 0 || (hs != ROMS_MPDATA && (hs != ROMS_HSIMT || HS))) mask |= 1 << it;
+    if (HS && ((mask >> it) & 1)) {
+      if (hs == ROMS_HSIMT) c->tadv_hdone |= 1 << it;
+      // the kernel's vertical step covers every local scheme (HSIMT included); what k_s3t_col would otherwise do for a
+      // tracer off the point path
+      if ((hs == ROMS_HSIMT || vs == ROMS_HSIMT) && vs != ROMS_MPDATA && vs != ROMS_SPLINES) c->tadv_vdone |= 1 << it;
+    }
   }
   if (!mask) return false;
   KArgs a = mk(c);
@@ -54,10 +68,14 @@ bool launch_tadv_lds(roms_hip_ctx *c, int mode) {
   nz = (G.N + kc - 1) / kc;
   a.p0 = kc;
   const dim3 grid((unsigned)(8 * ((nt + 7) / 8) * nz), 1, 1), block(TL_BX, TL_BY, 1);
-  const size_t lds = (size_t)TL_LDS_DOUBLES * sizeof(double);
+  const size_t lds = (size_t)(HS ? TL_LDS_DOUBLES_HS : TL_LDS_DOUBLES) * sizeof(double);
   static const char *ew = getenv("ROMS_HIP_TADV_W");
-  const int w = ew ? atoi(ew) : (mode == 0 ? 2 : 3);
-  if (mode == 0 && w == 2) KPROF_WRAP(k_pre_t3, c->stream, ROMS_LAUNCH((k_tadv_lds<0, 2>), grid, block, lds, c->stream, a, nx, ny, nz));
+  const int w = ew ? atoi(ew) : ((mode == 0 || HS) ? 2 : 3);      // (HS: 256 VGPRs at two waves per SIMD, 22 spilled; three waves spill 123)
+  if (HS) {
+    if (w == 2) KPROF_WRAP(k_s3t_hv, c->stream, ROMS_LAUNCH((k_tadv_lds<1, 2, true>), grid, block, lds, c->stream, a, nx, ny, nz));
+    else KPROF_WRAP(k_s3t_hv, c->stream, ROMS_LAUNCH((k_tadv_lds<1, 3, true>), grid, block, lds, c->stream, a, nx, ny, nz));
+  }
+  else if (mode == 0 && w == 2) KPROF_WRAP(k_pre_t3, c->stream, ROMS_LAUNCH((k_tadv_lds<0, 2>), grid, block, lds, c->stream, a, nx, ny, nz));
   else if (mode == 0) KPROF_WRAP(k_pre_t3, c->stream, ROMS_LAUNCH((k_tadv_lds<0, 3>), grid, block, lds, c->stream, a, nx, ny, nz));
   else if (w == 2) KPROF_WRAP(k_s3t_hv, c->stream, ROMS_LAUNCH((k_tadv_lds<1, 2>), grid, block, lds, c->stream, a, nx, ny, nz));
   else KPROF_WRAP(k_s3t_hv, c->stream, ROMS_LAUNCH((k_tadv_lds<1, 3>), grid, block, lds, c->stream, a, nx, ny, nz));

@@ -78,8 +78,14 @@ int run_step3d_t(roms_hip_ctx *c) {
   }
   a.p0 = (N + KCH - 1) / KCH;
   const bool plain = (G.options & ROMS_PLAIN_VDIFF) != 0;    // without SPLINES_VDIFF: the straightforward kernel forms, then k_mp_vdiff
-  if (any_pt && (plain || !launch_tadv_lds(c, 1))) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
-  if (any_hsimt) LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
+  c->tadv_hdone = 0; c->tadv_vdone = 0;
+  if ((any_pt || any_hsimt) && (plain || !launch_tadv_lds(c, 1))) {
+    c->tadv_hdone = 0; c->tadv_vdone = 0;
+    if (any_pt) LAUNCH_THREAD(k_s3t_hv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
+  }
+  // (k_tadv_lds with HS has done the HSIMT tracers: c->tadv_hdone; all of them or none)
+  if (any_hsimt && !c->tadv_hdone) LAUNCH_COOP(k_s3t_h, G.nbx, G.nby, N * G.NT, 256, S3T_NLDS * lds_sz(G), c->stream, a);
+  a.p1 = c->tadv_vdone;                                      // k_s3t_col: tracers whose vertical advection is done
   bool any_col = false;        // (a launch whose tracers are all MPDATA's would return at once: k_mpdata.h does their column work)
   for (int it = 0; it < G.NT; it++) any_col |= G.vadv[it] != ROMS_MPDATA;
   if (any_col) {
@@ -92,7 +98,7 @@ int run_step3d_t(roms_hip_ctx *c) {
     const bool regs = !(er && er[0] == '0');
     static const char *el = getenv("ROMS_HIP_S3TLDS");
     bool hsimt_v = false;
-    for (int it = 0; it < G.NT; it++) hsimt_v |= G.vadv[it] == ROMS_HSIMT;
+    for (int it = 0; it < G.NT; it++) hsimt_v |= G.vadv[it] == ROMS_HSIMT && !((c->tadv_vdone >> it) & 1);
     const bool ldsform = col_lds(G) && (el ? el[0] == '1' : (N != 30 || hsimt_v));
     // chunks of 10 levels on tall columns: 542 -> 499 us at N = 50 (ROMS_HIP_S3TCH=0/1 forces a form)
     static const char *e10 = getenv("ROMS_HIP_S3TCH");

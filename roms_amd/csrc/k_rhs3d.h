@@ -170,6 +170,34 @@ KDEV void hadv4_pt(const DGrid &G, int scheme, const double *Tc, const double *H
   hadv4_core(G, scheme, Tc, (long)G.ni, Hu[0], Hu[1], Hv[0], Hv[G.ni], i, j, FX0, FXp, FE0, FEp);
 }
 
+// HSIMT limiter (Wu and Zhu 2010), step3d_t.F:520-560
+KDEV double hsimt_lim(double grad, double gradu, double Ka, double Kau, double oKa) {
+  const double eps1 = 1.0E-12, cc1 = 0.25, cc2 = 0.5, cc3 = 1.0 / 12.0;
+  double r, rka;
+  if (fabs(grad) <= eps1) { r = 0.0; rka = 0.0; }
+  else { r = gradu / grad; rka = Kau * oKa; }
+  const double a1 = cc1 * Ka + cc2 - cc3 * oKa;
+  const double b1 = -cc1 * Ka + cc2 + cc3 * oKa;
+  const double beta = a1 + b1 * r;
+  double m = 2.0;
+  const double x = 2.0 * r * rka;
+  if (x < m) m = x;
+  if (beta < m) m = beta;
+  if (m < 0.0) m = 0.0;
+  return 0.5 * m * grad * Ka;
+}
+
+// one HSIMT face flux, step3d_t.F:520-550 (xi) / :598-632 (eta): upstream value + limited correction
+// mL, mR (MASKING, :530,549): rmask two points upstream of the face for either flow direction; 1 otherwise (x*1 = x)
+KDEV double hsimt_flux(double h, double tm, double t0, double g0, double gm, double gp, double K0, double Km, double Kp,
+                       double mL = 1.0, double mR = 1.0) {
+  const double eps1 = 1.0E-12;
+  const double oKa = (K0 <= eps1) ? 0.0 : 1.0 / KMAX(K0, eps1);
+  double sw;
+  if (h >= 0.0) sw = tm + hsimt_lim(g0, gm, K0, Km, oKa) * mL;
+  else sw = t0 - hsimt_lim(g0, gp, K0, Kp, oKa) * mR;
+  return sw * h;
+}
 // tracers whose predictor (pre_step3d) is done by the fused point kernel k_pre_t3: all but those
 // with a parabolic-spline vertical flux (a column recurrence)
 KDEV bool pre_point_path(const DGrid &G, int itrc) { return G.vadv[itrc - 1] != ROMS_SPLINES; }

@@ -680,23 +680,6 @@ COL_KERNEL(k_s3uv_couple_l, KArgs) {
 COL_GLOBAL(k_s3uv_couple_l, KArgs)
 
 // ---------------------------------------------------------------------------------- step3d_t
-// HSIMT limiter (Wu and Zhu 2010), step3d_t.F:520-560
-KDEV double hsimt_lim(double grad, double gradu, double Ka, double Kau, double oKa) {
-  const double eps1 = 1.0E-12, cc1 = 0.25, cc2 = 0.5, cc3 = 1.0 / 12.0;
-  double r, rka;
-  if (fabs(grad) <= eps1) { r = 0.0; rka = 0.0; }
-  else { r = gradu / grad; rka = Kau * oKa; }
-  const double a1 = cc1 * Ka + cc2 - cc3 * oKa;
-  const double b1 = -cc1 * Ka + cc2 + cc3 * oKa;
-  const double beta = a1 + b1 * r;
-  double m = 2.0;
-  const double x = 2.0 * r * rka;
-  if (x < m) m = x;
-  if (beta < m) m = beta;
-  if (m < 0.0) m = 0.0;
-  return 0.5 * m * grad * Ka;
-}
-
 // tracers whose corrector advection is done by the point kernel k_s3t_hv: the horizontal step for
 // every scheme but MPDATA (k_mpdata.h) and HSIMT (k_s3t_h: faces shared through LDS), and the
 // vertical step too unless the vertical scheme needs the column (HSIMT, SPLINES: k_s3t_col)
@@ -706,17 +689,6 @@ KDEV bool s3t_point_path(const DGrid &G, int itrc) {
   return hs != ROMS_MPDATA && hs != ROMS_HSIMT && vs != ROMS_HSIMT && vs != ROMS_MPDATA && vs != ROMS_SPLINES;
 }
 
-// one HSIMT face flux, step3d_t.F:520-550 (xi) / :598-632 (eta): upstream value + limited correction
-// mL, mR (MASKING, :530,549): rmask two points upstream of the face for either flow direction; 1 otherwise (x*1 = x)
-KDEV double hsimt_flux(double h, double tm, double t0, double g0, double gm, double gp, double K0, double Km, double Kp,
-                       double mL = 1.0, double mR = 1.0) {
-  const double eps1 = 1.0E-12;
-  const double oKa = (K0 <= eps1) ? 0.0 : 1.0 / KMAX(K0, eps1);
-  double sw;
-  if (h >= 0.0) sw = tm + hsimt_lim(g0, gm, K0, Km, oKa) * mL;
-  else sw = t0 - hsimt_lim(g0, gp, K0, Kp, oKa) * mR;
-  return sw * h;
-}
 // step3d_t: horizontal :633-915 and vertical :936-1340 advection of t(3) into t(nnew), one point per
 // thread; index space (Istr:Iend, Jstr:Jend, N*NT).  Both steps update t(nnew) at the thread's own
 // point only, so they are fused without changing any operation.  Tracers whose vertical scheme needs
@@ -853,7 +825,7 @@ THREAD_KERNEL(k_s3t_col_t, KArgs) {
   const double pmn_dt = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];   // CF(i,0)
   double CF[NL ? NL + 1 : ROMS_NPRIV], DC[NL ? NL + 1 : ROMS_NPRIV];   // NL > 0: registers (the diffusion sweeps are unrolled)
   const EmitPlan PT = emit_plan(G, BC_R, i, j);
-  if (!s3t_point_path(G, itrc)) {   // otherwise k_s3t_hv has done the vertical advection already
+  if (!s3t_point_path(G, itrc) && !((a.p1 >> (itrc - 1)) & 1)) {   // otherwise k_s3t_hv has done the vertical advection already (a.p1: its HSIMT form, k_tadv_lds.h)
   if (vs == ROMS_SPLINES) vspline_flux(G, F, i, j, itrc, T3, 1);
   #define Tc(kk) T3[X3(i, j, kk)]
   #define Wc(kk) W[XW(i, j, kk)]
@@ -972,7 +944,7 @@ COL_KERNEL(k_s3t_col_lt, KArgs) {
   const double pmn_dt = dt * F.pm[X2(i, j)] * F.pn[X2(i, j)];   // CF(i,0)
   double *L1 = lds, *L2 = lds + (size_t)(N + 1) * KLS;          // CF(k), DC(k) at [k * KLS]
   const EmitPlan PT = emit_plan(G, BC_R, i, j);
-  if (!s3t_point_path(G, itrc)) {   // otherwise k_s3t_hv has done the vertical advection already
+  if (!s3t_point_path(G, itrc) && !((a.p1 >> (itrc - 1)) & 1)) {   // otherwise k_s3t_hv has done the vertical advection already (a.p1: its HSIMT form, k_tadv_lds.h)
     if (vs == ROMS_HSIMT) {
       // :1069-1150.  Window of chunk k0: levels k0-1 .. k0+CH+1 of t(3) and z_r, interfaces k0-1 .. k0+CH of W
       const double cK = F.pm[X2(i, j)] * F.pn[X2(i, j)] * dt;

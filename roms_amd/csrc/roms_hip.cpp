@@ -709,7 +709,7 @@ bool lanes_on(roms_hip_ctx *) { return false; }
 void lane_record(roms_hip_ctx *, int) {}
 void lane_wait(roms_hip_ctx *, int) {}
 #else
-static bool side_on(roms_hip_ctx *c) { return c->overlap && !c->profile && g_kprof_mode != 1; }
+static bool side_on(roms_hip_ctx *c) { return c->overlap && !c->profile && g_kprof_mode != 1 && g_kprof_mode != 4; }
 // side_mark: the fork point on the main stream.  The host then enqueues the main-stream work that
 // follows the fork FIRST and the side-stream work (side_begin .. side_end) after it: the main queue
 // is the critical path and must not wait for the host to finish enqueuing the side chain.
@@ -838,6 +838,8 @@ int kprof_begin(const char *name, hipStream_t stream) {
   if (g_kprof_mode == 3) {
     if (strcmp(name, g_kselect) || (g_kcount++ % g_kstride) >= g_kwin) return -1;
   }
+  // mode 4: EVERY launch carries a start / stop pair filled by the launch itself (asynchronous; the side streams are
+  // off as in mode 1, so a kernel's duration is its own)
   if (g_kprof_mode == 2) {
     if (strcmp(name, g_kselect)) {
       if (g_kb_open >= 0) g_kb_broken = true;
@@ -865,13 +867,13 @@ int kprof_begin(const char *name, hipStream_t stream) {
   int e = g_kev_used++;
   g_kev_slot[e] = slot;
   g_kev_n[e] = 1;
-  if (g_kprof_mode == 3) { g_kp_start = g_kev[2 * e]; g_kp_stop = g_kev[2 * e + 1]; return e; }   // the launch itself fills the pair
+  if (g_kprof_mode == 3 || g_kprof_mode == 4) { g_kp_start = g_kev[2 * e]; g_kp_stop = g_kev[2 * e + 1]; return e; }   // the launch itself fills the pair
   (void)hipEventRecord(g_kev[2 * e], stream);
   if (g_kprof_mode == 2 && g_kbatch > 1) { g_kb_open = e; g_kb_count = 0; g_kb_broken = false; }
   return e;
 }
 void kprof_end(int e, hipStream_t stream) {
-  if (g_kprof_mode == 3) { g_kp_start = nullptr; g_kp_stop = nullptr; return; }
+  if (g_kprof_mode == 3 || g_kprof_mode == 4) { g_kp_start = nullptr; g_kp_stop = nullptr; return; }
   if (g_kprof_mode == 2 && g_kb_open == e) {
     if (++g_kb_count < g_kbatch) return;       // the run goes on
     g_kev_n[e] = g_kbatch;

@@ -50,6 +50,7 @@ struct roms_hip_ctx {
   bool comm_failed;             // a halo exchange failed (reported by the next ctx_check)
   bool has_exchange;            // some neighbour is reached through the transport (multi-tile, or the self-exchange test aid)
   bool swdk_ready;              // main3d_one has launched k_swdk already (side stream): run_pre_step3d skips it
+  int tadv_hdone = 0, tadv_vdone = 0;   // step3d_t: tracers whose HSIMT horizontal step / whose vertical advection the LDS-tiled kernel did (k_tadv_lds.h, HS)
   bool pre_t3_ready;            // main3d_one has launched the tracer predictor of pre_step3d already (side stream)
   // time-averaged fields (set_avg.F; g_avg.cpp): off until roms_hip_avg_config
   double *avg[24];

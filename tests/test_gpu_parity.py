@@ -558,6 +558,9 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
                            # tracer advection of pre_step3d / step3d_t: LDS-tiled marching kernels (k_tadv_lds.h; the
                            # default from 64 K columns up) against the point-wise forms these small grids take
                            ("tadv_lds", {"ROMS_HIP_TADV_LDS": "1"}), ("tadv_lds_kc", {"ROMS_HIP_TADV_LDS": "1", "ROMS_HIP_TADV_KC": "7"}),
+                           # ... with the HSIMT tracers left to k_s3t_h and the HSIMT sweep of k_s3t_col (the round-3 split)
+                           ("tadv_lds_nohs", {"ROMS_HIP_TADV_LDS": "1", "ROMS_HIP_HSIMT_LDS": "0"}),
+                           ("tadv_lds_w3", {"ROMS_HIP_TADV_LDS": "1", "ROMS_HIP_TADV_W": "3", "ROMS_HIP_TADV_KC": "11"}),
                            ("march", {"ROMS_HIP_UVCH": "7", "ROMS_HIP_WVELCH": "100", "ROMS_HIP_GEOCH": "7", "ROMS_HIP_T3CH": "9"}),
                            # pre_step3d's k_pre_new as a march over the column (the form of >= 128 K columns), whole
                            # columns and parts of them
