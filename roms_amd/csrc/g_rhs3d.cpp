@@ -92,18 +92,32 @@ int run_pre_t3(roms_hip_ctx *c) {
   KArgs a = mk(c);
   bool any_col = false;      // tracers with a spline vertical flux keep the two-kernel column path
   for (int it = 0; it < G.NT; it++) any_col |= G.vadv[it] == ROMS_SPLINES;
-  if (!launch_tadv_lds(c, 0)) {
-    a.p0 = (G.N + KCH - 1) / KCH;
-    LAUNCH_THREAD(k_pre_t3, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
+  auto point_part = [&]() {
+    if (!launch_tadv_lds(c, 0)) {
+      KArgs b = mk(c);
+      b.p0 = (G.N + KCH - 1) / KCH;
+      LAUNCH_THREAD(k_pre_t3, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, b.p0 * G.NT, c->stream, b);
+    }
+  };
+  HaloSpec sp[ROMS_MAXT];
+  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, 3, it), G.N, obc_bc(c, bc_rstate(c)), 'r'};   // t3dbc + exchange :1157-1171
+  if (c->rim_split && !any_col && !G.obc && !G.fuse3d) {
+    // multi-tile, round 4: the points the strip exchange packs first, the exchange on its own stream behind them, the
+    // interior beside it (nothing reads t(3) before step3d_t: FG_T3)
+    c->G.region = 1; point_part();
+    c->G.region = 0; launch_halo_tail(c, sp, G.NT);
+    c->G.region = 2; point_part();
+    c->G.region = 0;
+    return 0;
   }
+  point_part();
   if (any_col) {
+    a.p0 = (G.N + KCH - 1) / KCH;
     LAUNCH_COOP(k_pre_t3h, G.nbx, G.nby, G.N * G.NT, 256, 3 * lds_sz(G), c->stream, a);
     LAUNCH_THREAD(k_pre_t3v, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.NT, c->stream, a);
   }
   if (G.fuse3d && !any_col) return 0;   // k_pre_t3 stored the boundary values and images (pt_emit)
-  HaloSpec sp[ROMS_MAXT];
   if (G.obc) for (int it = 1; it <= G.NT; it++) { int r = run_obc3d_t(c, 3, it); if (r) return r; }
-  for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, 3, it), G.N, obc_bc(c, bc_rstate(c)), 'r'};   // t3dbc + exchange :1157-1171
   launch_halo_multi(c, sp, G.NT);
   return 0;
 }

@@ -39,14 +39,24 @@ int run_step3d_uv(roms_hip_ctx *c) {
       launch_halo_multi(c, sp, 2);
     }
   }
-  if (col_lds(G)) LAUNCH_COL_AS(k_s3uv_couple, k_s3uv_couple_l, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, 2 * (N + 1), c->stream, a);
-  else LAUNCH_THREAD(k_s3uv_couple, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, c->stream, a);
-  if (!G.fuse3d) {
-    HaloSpec sp[6] = {{uv_lev(c, c->F.u, nnew), N, BC_NONE, 'u'}, {uv_lev(c, c->F.v, nnew), N, BC_NONE, 'v'},
-                      {c->F.Huon, N, BC_NONE, 'u'},               {c->F.Hvom, N, BC_NONE, 'v'},
-                      {c->F.ubar, 2, BC_NONE, 'u'},               {c->F.vbar, 2, BC_NONE, 'v'}};   // :1763-1830
-    launch_halo_multi(c, sp, 6);
+  auto couple = [&]() {
+    if (col_lds(G)) LAUNCH_COL_AS(k_s3uv_couple, k_s3uv_couple_l, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, 2 * (N + 1), c->stream, a);
+    else LAUNCH_THREAD(k_s3uv_couple, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, c->stream, a);
+  };
+  HaloSpec sp[6] = {{uv_lev(c, c->F.u, nnew), N, BC_NONE, 'u'}, {uv_lev(c, c->F.v, nnew), N, BC_NONE, 'v'},
+                    {c->F.Huon, N, BC_NONE, 'u'},               {c->F.Hvom, N, BC_NONE, 'v'},
+                    {c->F.ubar, 2, BC_NONE, 'u'},               {c->F.vbar, 2, BC_NONE, 'v'}};   // :1763-1830
+  if (c->rim_split && !G.fuse3d) {
+    // multi-tile, round 4: the columns the exchange packs first, the exchange (u, v, Huon, Hvom and ubar, vbar(1:2): every
+    // reader of the 2-D state fences FG_2D) on its own stream behind them, the interior columns beside it
+    a.G.region = 1; couple();
+    c->x_2d_ok = true; launch_halo_tail(c, sp, 6); c->x_2d_ok = false;
+    a.G.region = 2; couple();
+    a.G.region = 0;
+    return 0;
   }
+  couple();
+  if (!G.fuse3d) launch_halo_multi(c, sp, 6);
   return 0;
 }
 
@@ -88,6 +98,7 @@ int run_step3d_t(roms_hip_ctx *c) {
   a.p1 = c->tadv_vdone;                                      // k_s3t_col: tracers whose vertical advection is done
   bool any_col = false;        // (a launch whose tracers are all MPDATA's would return at once: k_mpdata.h does their column work)
   for (int it = 0; it < G.NT; it++) any_col |= G.vadv[it] != ROMS_MPDATA;
+  auto column_part = [&]() {
   if (any_col) {
     const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
 #ifdef ROMS_CPU_EMU
@@ -109,6 +120,19 @@ int run_step3d_t(roms_hip_ctx *c) {
     else LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
 #endif
   }
+  };
+  HaloSpec spt[ROMS_MAXT];
+  for (int it = 1; it <= G.NT; it++) spt[it - 1] = {t_lev(c, nnew, it), N, obc_bc(c, bc_rstate(c, true)), 'r'};   // t3dbc :1858 + exchange :1920
+  if (c->rim_split && any_col && !any_mp && !plain && !G.obc && !G.fuse3d && !G.masking) {
+    // multi-tile, round 4: the columns the exchange packs first, the exchange of t(nnew) on its own stream, the rest beside it
+    // (not with MASKING: its fill multiplies the WHOLE plane by rmask, step3d_t.F:1880-1890, interior included)
+    a.G.region = 1; column_part();
+    launch_halo_tail(c, spt, G.NT);
+    a.G.region = 2; column_part();
+    a.G.region = 0;
+    return 0;
+  }
+  column_part();
   for (int it = 1; it <= G.NT && any_mp; it++) {
     if (G.hadv[it - 1] != ROMS_MPDATA) continue;
     MpArgs m;

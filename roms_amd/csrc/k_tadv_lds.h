@@ -68,6 +68,10 @@ static __global__ void __launch_bounds__(256, MINW) k_tadv_lds(const KArgs a, in
   if (t_ >= nt_) return;
   KTILE_XY(t_, (nx + TL_BX - 1) / TL_BX, nby_, tbx, tby);
   const DGrid &G = a.G;
+  if (G.region) {            // rim / interior split: a block belongs to the rim if any of its points does (block-uniform: barriers follow)
+    const bool rim = tbx * TL_BX < G.rimw || tbx * TL_BX + TL_BX - 1 >= nx - G.rimw || tby * TL_BY < G.rimw || tby * TL_BY + TL_BY - 1 >= ny - G.rimw;
+    if ((G.region == 1) != rim) return;
+  }
   const Fields &F = a.Fv;
   const TB &B = G.T;
   const int KC = a.p0, N = G.N, NT = G.NT;

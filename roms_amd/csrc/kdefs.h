@@ -165,6 +165,14 @@ void kprof_end(int slot, hipStream_t stream);
 #else
 #define KTILE_XY(t_, nbx_, nby_, tx_, ty_) const int tx_ = (t_) / (nby_), ty_ = (t_) - tx_ * (nby_)
 #endif
+// rim / interior split (DGrid::region): does the point (gx,gy) of an nx x ny index space belong to this launch?
+// (argument structs without a DGrid -- the streaming copy, the relayout kernel -- always run whole)
+template <class A> KDEV auto kregion_of(const A &a, int) -> decltype((void)a.G.region, int()) { return a.G.region; }
+template <class A> KDEV int kregion_of(const A &, long) { return 0; }
+template <class A> KDEV auto krimw_of(const A &a, int) -> decltype((void)a.G.rimw, int()) { return a.G.rimw; }
+template <class A> KDEV int krimw_of(const A &, long) { return 0; }
+#define KREGION_RIM(w_, gx_, gy_, nx_, ny_) ((gx_) < (w_) || (gx_) >= (nx_) - (w_) || (gy_) < (w_) || (gy_) >= (ny_) - (w_))
+#define KREGION_OK(a_, gx_, gy_, nx_, ny_) (kregion_of(a_, 0) == 0 || ((kregion_of(a_, 0) == 1) == KREGION_RIM(krimw_of(a_, 0), gx_, gy_, nx_, ny_)))
 #define THREAD_GLOBAL(name, ArgT) THREAD_GLOBAL_W(name, ArgT, KMINW)
 // ... compiled for at least `minwaves` waves per SIMD (caps the VGPRs)
 #define THREAD_GLOBAL_W(name, ArgT, minwaves)                                            \
@@ -177,7 +185,7 @@ void kprof_end(int slot, hipStream_t stream);
     KTILE_XY(t_, (nx + 63) / 64, nby_, tx_, ty_);                                        \
     const int gx = tx_ * 64 + (int)threadIdx.x;                                          \
     const int gy = ty_ * KTY + (int)threadIdx.y;                                           \
-    if (gx < nx && gy < ny) name##_body(a, gx, gy, gz);                                  \
+    if (gx < nx && gy < ny && KREGION_OK(a, gx, gy, nx, ny)) name##_body(a, gx, gy, gz); \
   }
 // 64 lanes along xi (coalesced), 4 rows of eta per block; 1-D grid of 8*ceil(blocks/8)*nz workgroups
 // g_thread_ballast: bytes of (unused) dynamic LDS a THREAD launch asks for -- caps its blocks per CU, so that
@@ -208,7 +216,7 @@ extern thread_local size_t g_thread_ballast;   // (per host thread: several cont
     if (t_ >= nt_) return;                                                               \
     KTILE_XY(t_, (nx + 63) / 64, ny, tx_, gy);                                           \
     const int gx = tx_ * 64 + (int)threadIdx.x;                                          \
-    if (gx < nx) name##_body(a, gx, gy, gz, lds_dyn_ + threadIdx.x);                     \
+    if (gx < nx && KREGION_OK(a, gx, gy, nx, ny)) name##_body(a, gx, gy, gz, lds_dyn_ + threadIdx.x); \
   }
 #define LAUNCH_COL_AS(label, name, nx, ny, nz, per_thread, stream, args)                 \
   KPROF_WRAP(label, stream,                                                              \

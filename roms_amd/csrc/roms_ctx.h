@@ -35,6 +35,11 @@ struct DGrid {
   int nbx, nby;               // thread-block decomposition of the tile for the 3-D COOP kernels
   int bw, bh;                 // max sub-tile extent (LDS scratch is (bw+6) x (bh+6))
   int dbg_stop;
+  // rim / interior split of a 3-D producer in front of its strip exchange (multi-tile contexts, round 4): 0 = the whole
+  // index space; 1 = only the points within `rimw` lines of the edge of the launch's (xi,eta) index space -- what the
+  // exchange packs and its boundary fills read --, 2 = only the others (kdefs.h: THREAD / COL launches decide per thread,
+  // the LDS-tiled kernels per block)
+  int region, rimw;
   int fuse_halo;              // 1: single tile, k_step2d fills boundary/periodic ghost points itself (k_haloblock.h)
   int fuse3d;                 // 1: the 3-D producers do so too (emit_plan/emit_store); ROMS_HIP_FUSE3D=0 turns it off
   int xloc, yloc;             // 1: a periodic direction of this tile wraps onto itself by a local copy (no exchange partner)

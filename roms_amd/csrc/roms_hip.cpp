@@ -392,6 +392,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     c->stage_buf = nullptr; c->stage_cap = 0;
     c->static_wide_dirty = c->pair_mt;
     G.xgl = 3; G.xgh = cfg->Nghost;
+    G.region = 0; G.rimw = 5;
   }
   {  // producer-side halo fills need the whole domain on this GPU and edge sub-tiles that own the
      // three source lines of a periodic copy
@@ -445,6 +446,8 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   }
   c->xstream = nullptr;
   c->x_async = false;
+  c->rim_split = false;
+  c->x_2d_ok = false;
   c->x_tail = false;
   c->x_wide = false;
   c->x_pending = 0;
@@ -458,6 +461,14 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     const char *e = getenv("ROMS_HIP_XASYNC"), *ep = getenv("ROMS_HIP_XASYNC_PLANES"), *es2 = getenv("ROMS_HIP_SELF_EXCHANGE");
     const bool selfx = es2 && es2[0] == '1';
     c->x_async = e ? e[0] != '0' : !selfx;
+    // rim / interior split of the 3-D producers (g_rhs3d.cpp:run_pre_t3, g_step3d.cpp): by default from 128 K columns up.
+    // Measured on one MI355X through the mailbox (every exchange device-local, so there is nothing to hide and the
+    // split shows only its cost -- one more launch and two cross-stream hops per exchange point): 512x64x30 tile
+    // 1.49 -> 1.69 ms per step, 512x512x50 7.84 -> 7.91; a 3-D exchange point of the large tile moves ~5 MB (xGMI:
+    // tens of microseconds), of the small one 0.4 MB.  ROMS_HIP_RIM=0/1 forces it; the tile tests run it on.
+    { const char *er = getenv("ROMS_HIP_RIM");
+      const long cols = (long)(G.T.Iend - G.T.Istr + 1) * (G.T.Jend - G.T.Jstr + 1);
+      c->rim_split = c->x_async && (er ? er[0] != '0' : cols >= 128L * 1024L); }
     c->x_min_planes = ep ? atoi(ep) : 8;
     if (hipfail(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return 2; }
     (void)hipEventCreateWithFlags(&c->ev_xprod, hipEventDisableTiming | hipEventDisableSystemFence);
@@ -1114,6 +1125,10 @@ static unsigned group_of(const roms_hip_ctx *c, const double *p) {
   for (int k = 0; k < g_nfields; k++) {
     const double *base = *(double *const *)((const char *)&c->F + g_fields[k].offset);
     if (!base || p < base || p >= base + field_elems(c, g_fields[k].kind)) continue;
+    if (!strcmp(g_fields[k].name, "t")) {                   // the predictor level t(:,:,:,3,:) is a group of its own
+      const size_t lev = (size_t)(p - base) / ((size_t)c->G.nij * (size_t)c->G.N) % 3;
+      return lev == 2 ? FG_T3 : FG_T;
+    }
     for (const auto &m : map)
       if (!strcmp(m.name, g_fields[k].name)) return m.g;
     return FG_OTHER;
@@ -1125,7 +1140,7 @@ void halo_fence(roms_hip_ctx *c, unsigned groups) {
   const unsigned need = groups & c->x_pending;
   if (!need) return;
   bool waited[32] = {};
-  for (int g = 0; g < 13; g++) {
+  for (int g = 0; g < FG_NGROUPS; g++) {
     if (!(need & (1u << g))) continue;
     const int e = c->x_event_of[g];
     if (e >= 0 && !waited[e]) {
@@ -1205,7 +1220,7 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
   // every exchange asynchronous 2.90 -> 3.85 ms per step).  The barotropic exchanges -- each sub-step needs the
   // previous one's ghost points at once -- stay on the compute stream, behind whatever the exchange stream
   // still holds (the send/receive buffers and the communicator are shared).
-  const bool async = c->x_async && c->x_tail && planes >= c->x_min_planes && !(groups & (FG_2D | FG_AVG));
+  const bool async = c->x_async && c->x_tail && planes >= c->x_min_planes && !(groups & ((c->x_2d_ok ? 0 : FG_2D) | FG_AVG));
   if (async) {
     halo_fence(c, groups);            // an earlier exchange of the same fields: keep the two in order on both sides
     xs = c->xstream;
@@ -1303,7 +1318,7 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
     const int e = c->ev_x_next;
     c->ev_x_next = (e + 1) % 32;
     (void)hipEventRecord(c->ev_x[e], xs);
-    for (int g = 0; g < 13; g++)
+    for (int g = 0; g < FG_NGROUPS; g++)
       if (groups & (1u << g)) c->x_event_of[g] = e;
     c->x_pending |= groups;
   }
@@ -1455,7 +1470,7 @@ ENTRY(omega, 13, FG_W | FG_MF | FG_HZ)                                      // o
 ENTRY(set_zeta, 12, FG_2D | FG_AVG)
 ENTRY(ini_zeta, 2, FG_ALL)
 ENTRY(ini_fields, 2, FG_ALL)
-ENTRY(pre_step3d, 22, FG_T | FG_UV | FG_MF | FG_W | FG_AK | FG_HZ | FG_FLUX | FG_R)       // pre_step3d.F:126
+ENTRY(pre_step3d, 22, FG_T | FG_T3 | FG_UV | FG_MF | FG_W | FG_AK | FG_HZ | FG_FLUX | FG_R)       // pre_step3d.F:126
 ENTRY(prsgrd, 23, FG_R | FG_RHO | FG_HZ)                                    // prsgrd32.h
 ENTRY(t3dmix2, 24, FG_T | FG_HZ | FG_RHO)
 ENTRY(uv3dmix2, 30, FG_UV | FG_HZ | FG_R)
@@ -1463,7 +1478,7 @@ ENTRY(rhs3d_tile, 21, FG_R | FG_UV | FG_MF | FG_W | FG_HZ | FG_FLUX)        // r
 ENTRY(step2d, 9, FG_2D | FG_AVG | FG_R | FG_RHO)                            // step2d_LF_AM3.h:163
 ENTRY(step2d_pair, 9, FG_2D | FG_AVG | FG_R | FG_RHO)                       // step2d_LF_AM3.h:163, predictor + corrector of one fast step
 ENTRY(step3d_uv, 34, FG_UV | FG_MF | FG_2D | FG_AVG | FG_AK | FG_HZ | FG_R | FG_FLUX)     // step3d_uv.F:134
-ENTRY(step3d_t, 35, FG_T | FG_MF | FG_W | FG_AK | FG_HZ | FG_FLUX)          // step3d_t.F:120
+ENTRY(step3d_t, 35, FG_T | FG_T3 | FG_MF | FG_W | FG_AK | FG_HZ | FG_FLUX)          // step3d_t.F:120
 ENTRY(lmd_vmix, 18, FG_AK | FG_RHO | FG_UV | FG_HZ | FG_FLUX | FG_T)        // lmd_vmix.F:45
 ENTRY(bulk_flux, 17, FG_FLUX | FG_T | FG_UV | FG_RHO | FG_HZ)               // bulk_flux.F:100
 ENTRY(gls_prestep, 18, FG_AK | FG_MF | FG_W | FG_HZ)                         // gls_prestep.F:42
@@ -1471,7 +1486,7 @@ ENTRY(gls_corstep, 18, FG_AK | FG_MF | FG_W | FG_HZ | FG_UV | FG_RHO | FG_FLUX) 
 
 extern "C" int roms_hip_wvelocity(roms_hip_ctx *c, int ninp) {
   RegionTimer rt(c, 12);
-  halo_fence(c, FG_WVEL | FG_W | FG_UV | FG_HZ | FG_AVG);                   // wvelocity.F:30
+  halo_fence(c, FG_WVEL | FG_W | FG_UV | FG_HZ | FG_AVG | FG_2D);           // wvelocity.F:30
   int r = run_wvelocity(c, ninp);
   return r ? r : ctx_check(c, "wvelocity");
 }
@@ -1491,7 +1506,7 @@ extern "C" int roms_hip_copy_probe(roms_hip_ctx *c, int reps, long *bytes_per_la
 }
 extern "C" int roms_hip_diag(roms_hip_ctx *c, double *out) {
   RegionTimer rt(c, 7);
-  halo_fence(c, FG_UV | FG_RHO | FG_HZ | FG_WVEL);
+  halo_fence(c, FG_UV | FG_RHO | FG_HZ | FG_WVEL | FG_2D);
   return run_diag(c, out);
 }
 
@@ -1564,7 +1579,7 @@ thread_local size_t g_thread_ballast = 0;
 
 // diag (main3d.F:355) as a device-side reduction into c->d_diag; the caller has placed it on a stream
 static int enqueue_diag(roms_hip_ctx *c) {
-  halo_fence(c, FG_UV | FG_RHO | FG_HZ | FG_WVEL);
+  halo_fence(c, FG_UV | FG_RHO | FG_HZ | FG_WVEL | FG_2D);
   c->diag_ran = true;
   c->diag_step = c->s.iic - 1;
   return run_diag_async(c, c->d_diag);

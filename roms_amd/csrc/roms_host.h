@@ -105,7 +105,9 @@ struct roms_hip_ctx {
   int x_event_of[16];           // per field group: index into ev_x of the last exchange that carried it, -1 none
   unsigned x_pending;           // field groups with an exchange possibly still in flight
   bool x_async;
+  bool rim_split;               // 3-D producers in front of an asynchronous exchange run rim first, interior beside the exchange (round 4)
   bool x_tail;                  // the exchange being launched is the last operation of its routine
+  bool x_2d_ok;                 // ... may go to the exchange stream although it carries 2-D state (step3d_uv: every reader of ubar, vbar fences FG_2D)
   bool x_wide;                  // ... carries the wide strips of the barotropic pair kernel (launch_halo_wide)
   int x_min_planes;             // exchanges with fewer planes stay on the compute stream
 };
@@ -125,7 +127,9 @@ enum {
   FG_HZ = 1 << 10,    // Hz z_r z_w
   FG_R = 1 << 11,     // ru rv rufrc rvfrc
   FG_OTHER = 1 << 12, // anything else (grid metrics, work arrays)
-  FG_ALL = (1 << 13) - 1
+  FG_T3 = 1 << 13,    // t(:,:,:,3,:), the tracer predictor: exchanged behind pre_step3d, read by step3d_t only (round 4)
+  FG_NGROUPS = 14,
+  FG_ALL = (1 << 14) - 1
 };
 // make the compute stream(s) wait for the exchanges in flight that carry any of `groups`
 void halo_fence(roms_hip_ctx *c, unsigned groups);

@@ -458,7 +458,8 @@ def test_tiles_on_one_gpu_match_single_tile(tmp_path, tag, kw, tiles, port):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={tiles[0] * tiles[1]}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "mp", "run_tiles.py"), out, json.dumps(spec)]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    # ROMS_HIP_RIM=1: the rim / interior split of the 3-D producers in front of their exchanges (default from 128 K columns)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="1", ROMS_HIP_RIM="1"))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     got = dict(np.load(out))
     assert int(got["nexchanges"]) > 30 * steps
@@ -981,7 +982,10 @@ def test_mailbox_tiles_on_one_gpu_match_single_tile(tmp_path, tag, kw, tiles, po
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "mp", "run_tiles.py"), out, json.dumps(spec)]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", ROMS_HIP_PEER_TIMEOUT="10"))
+                       env=dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", ROMS_HIP_PEER_TIMEOUT="10",
+                                # the rim / interior split of the 3-D producers (default from 128 K columns); on the larger
+                                # tiles also the LDS-tiled advection kernels, whose split is by block
+                                ROMS_HIP_RIM="1", **({"ROMS_HIP_TADV_LDS": "1"} if tag.endswith("_mid") else {})))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "TRANSPORT peer" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
     got = dict(np.load(out))
