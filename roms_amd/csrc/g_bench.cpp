@@ -85,9 +85,9 @@ int run_lmd_vmix(roms_hip_ctx *c) {
   static const char *elc = getenv("ROMS_HIP_LMDCOL");
   // one COL kernel with the spline columns in LDS (63 KB per wave at N = 30) when the chain waits for KPP; beside
   // the barotropic loop (c->late_pre) its LDS would keep k_step2d's blocks off the CUs: the two-kernel form then
-  const bool col = (elc ? elc[0] != '0' : !c->late_pre) && (size_t)4 * (N + 1) * 64 * sizeof(double) < 64 * 1024;
+  const bool col = (elc ? elc[0] != '0' : !c->late_pre) && (size_t)3 * (N + 1) * 64 * sizeof(double) < 64 * 1024;
   if (col) {
-    LAUNCH_COL(k_lmd_col, nx, ny, 1, 4 * (N + 1), c->stream, a);
+    LAUNCH_COL(k_lmd_col, nx, ny, 1, 3 * (N + 1), c->stream, a);
   } else {
     LAUNCH_THREAD(k_lmd_interior, nx, ny, 1, c->stream, a);
     LAUNCH_THREAD(k_lmd_skpp, nx, ny, 1, c->stream, a);

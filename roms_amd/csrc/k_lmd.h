@@ -414,20 +414,331 @@ THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
 THREAD_GLOBAL(k_lmd_skpp, LmdArgs)
 
 // lmd_vmix as ONE column kernel (COL launch): interior mixing, then the surface boundary layer of the same
-// column, with the four spline work columns (FC, dR, dU, dV: 4*(N+1) doubles) in LDS instead of four 3-D work
-// arrays -- they were 2.2-2.6x the algorithmic traffic of the two kernels -- and dU, dV handed from the first
-// part to the second without leaving the chip.  Same functions, same order: bit-identical to the two-kernel
-// form (the thread reads back the Akv, Akt it stored itself).  Used while 4*(N+1) doubles per column fit the 64 KB
-// a wave-sized block gets (N <= 30); ROMS_HIP_LMDCOL=0 selects the two kernels.
+// column, with the spline work columns in LDS instead of four 3-D work arrays -- they were 2.2-2.6x the algorithmic
+// traffic of the two kernels.  Round 4: THREE columns of LDS instead of four, and fewer passes over memory --
+//   * the interior part needs no density spline at all (lmd_vmix.F forms dR, but with BV_FREQUENCY its Richardson number
+//     takes bvf): one forward sweep builds FC, dU, dV together (FC is the same recurrence in every sweep);
+//   * the boundary-layer part reads dU, dV only through the squared shear between the reference level and level k
+//     (lmd_skpp.F:420-470): it is formed right behind the interior part and overwrites dU in place (descending: entry k
+//     needs dU(k-1), dU(k)), which frees dV's column for the density spline dR;
+//   * Bflux is a function of z_w (two exponentials): it is re-evaluated where the reference re-reads its work array,
+//     and the preliminary ghats of :330-340 are formed where the final ones are, instead of being stored and read back.
+// Three waves per CU instead of two (47.6 KB per wave at N = 30) and 28 instead of 37 array passes.  Every value is
+// computed by the two-kernel form's expression on the same operands: same bits (tests: test_column_kernel_forms...,
+// ROMS_HIP_LMDCOL=0 selects the two kernels, which tall columns -- 3*(N+1) doubles per column beyond 64 KB -- keep).
+KDEV void lmd_col_fused(const LmdArgs &a, int i, int j, double *lds) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  LMD_CONSTS;
+  const int N = G.N;
+  const size_t n1 = (size_t)(N + 1) * KLS;
+  double *FC = lds, *dU = lds + n1, *dV = lds + 2 * n1;        // dU -> SH (squared shear), dV -> dR later
+#define LK(k) ((size_t)(k) * KLS)
+  const size_t nij = (size_t)G.nij, x = X2(i, j);
+  const long ni = G.ni;
+  const double *Hz = F.Hz + x;
+  const double *u = F.u + (size_t)(G.nstp - 1) * nij * (size_t)N + x, *v = F.v + (size_t)(G.nstp - 1) * nij * (size_t)N + x;
+  // ---------------------------------------------------------------- interior part (lmd_interior_col)
+  {
+    const double eps = 1.0E-14;
+    FC[LK(0)] = 0.0; dU[LK(0)] = 0.0; dV[LK(0)] = 0.0;
+    double FCq = 0.0, dUm = 0.0, dVm = 0.0;
+    for (int k0 = 1; k0 <= N - 1; k0 += 6) {
+      double hz[7], ua[7], ub[7], va[7], vb[7];
+#pragma unroll
+      for (int q = 0; q < 7; q++) {
+        const size_t o = (size_t)(KMIN(k0 + q, N) - 1) * nij;
+        hz[q] = Hz[o]; ua[q] = u[o]; ub[q] = u[o + 1]; va[q] = v[o]; vb[q] = v[o + ni];
+      }
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const int k = k0 + q;
+        if (k > N - 1) break;
+        const double cff = 1.0 / (2.0 * hz[q + 1] + hz[q] * (2.0 - FCq));
+        FCq = cff * hz[q + 1];
+        dUm = cff * (3.0 * (ua[q + 1] - ua[q] + ub[q + 1] - ub[q]) - hz[q] * dUm);
+        dVm = cff * (3.0 * (va[q + 1] - va[q] + vb[q + 1] - vb[q]) - hz[q] * dVm);
+        FC[LK(k)] = FCq; dU[LK(k)] = dUm; dV[LK(k)] = dVm;
+      }
+    }
+    dU[LK(N)] = 0.0; dV[LK(N)] = 0.0;
+    double u1 = 0.0, v1 = 0.0;
+    for (int k = N - 1; k >= 1; k--) {
+      const double fc = FC[LK(k)];
+      u1 = dU[LK(k)] - fc * u1;
+      v1 = dV[LK(k)] - fc * v1;
+      dU[LK(k)] = u1; dV[LK(k)] = v1;
+    }
+    const size_t oA = nij * (size_t)(N + 1);
+    for (int k0 = 1; k0 <= N - 1; k0 += 6) {
+      double bv_[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) bv_[q] = F.bvf[(size_t)KMIN(k0 + q, N - 1) * nij + x];
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const int k = k0 + q;
+        if (k > N - 1) break;
+        const size_t ow = (size_t)k * nij + x;
+        const double du = dU[LK(k)], dv = dV[LK(k)];
+        double shear2 = du * du + dv * dv;
+        const double bv = bv_[q];
+        const double Rig = bv / (shear2 + eps);
+        double cff = KMIN(1.0, KMAX(0.0, Rig) / lmd_Ri0);
+        double nu_sx = 1.0 - cff * cff;
+        nu_sx = nu_sx * nu_sx * nu_sx;
+        shear2 = bv / (Rig + eps);
+        cff = shear2 * shear2 / (shear2 * shear2 + 16.0E-10);
+        nu_sx = cff * nu_sx;
+        cff = 1.0 / sqrt(KMAX(bv, 1.0E-7));
+        const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
+        F.Akv[ow] = lmd_iwm + lmd_nu0m * nu_sx;
+        const double akt = lmd_iws + lmd_nu0s * nu_sx;
+        F.Akt[ow] = akt;
+        F.Akt[ow + oA] = akt;
+      }
+    }
+  }
+  // ---------------------------------------------------------------- boundary-layer part (lmd_skpp_col)
+  const double eps = 1.0E-10, g = G.g, gorho0 = G.g / G.rho0;
+  const double *z_w = F.z_w, *pden = F.pden, *bvf = F.bvf;
+  const double c13 = 1.0 / 3.0, c16 = 1.0 / 6.0;
+  const double HzN = F.Hz[X3(i, j, N)];
+  const double Uref = 0.5 * (u[(size_t)(N - 1) * nij] + u[(size_t)(N - 1) * nij + 1]) + HzN * (c13 * dU[LK(N)] + c16 * dU[LK(N - 1)]);
+  const double Vref = 0.5 * (v[(size_t)(N - 1) * nij] + v[(size_t)(N - 1) * nij + ni]) + HzN * (c13 * dV[LK(N)] + c16 * dV[LK(N - 1)]);
+  {   // squared shear between the reference level and level k, in the place of dU (descending: dU(k-1) is still intact)
+    double *SH = dU;
+    for (int k0 = N; k0 >= 1; k0 -= 3) {
+      double hz[3], uk[3], vk[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const size_t o = (size_t)(KMAX(k0 - q, 1) - 1) * nij;
+        hz[q] = Hz[o]; uk[q] = 0.5 * (u[o] + u[o + 1]); vk[q] = 0.5 * (v[o] + v[o + ni]);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int k = k0 - q;
+        if (k < 1) break;
+        const double Uk = uk[q] - hz[q] * (c13 * dU[LK(k - 1)] + c16 * dU[LK(k)]);
+        const double Vk = vk[q] - hz[q] * (c13 * dV[LK(k - 1)] + c16 * dV[LK(k)]);
+        const double du_ = Uref - Uk, dv_ = Vref - Vk;
+        SH[LK(k)] = du_ * du_ + dv_ * dv_;
+      }
+    }
+  }
+  double *SH = dU, *dR = dV;
+  const double zwN = z_w[XW(i, j, N)];
+  double hsbl = F.hsbl[X2(i, j)];
+  double sl_dpth = lmd_epsilon * (zwN - hsbl);
+  double Ustar;
+  {
+    const double sa = 0.5 * (F.sustr[X2(i, j)] + F.sustr[X2(i + 1, j)]), sc = 0.5 * (F.svstr[X2(i, j)] + F.svstr[X2(i, j + 1)]);
+    Ustar = sqrt(sqrt(sa * sa + sc * sc));
+  }
+  const bool msk = G.masking != 0;
+  const double rm = msk ? F.rmask[X2(i, j)] : 1.0;
+  if (msk) Ustar = Ustar * rm;
+  const double st1 = F.stflx[X2T(i, j, 1)], st2 = F.stflx[X2T(i, j, 2)], sr = F.srflx[X2(i, j)];
+  const double Bo = g * (F.alpha[X2(i, j)] * (st1 - sr) - F.beta[X2(i, j)] * st2);
+  const double Bosol = g * F.alpha[X2(i, j)] * sr;
+  // Bflux(k) and the preliminary ghats(k) of :300-340 as functions of z_w(k)
+#define LMD_BF(zw_, swdk_, bf_)                                                                \
+  const double swdk_ = SWFRAC(zwN - (zw_));                                                    \
+  double bf_ = (Bo + Bosol * (1.0 - swdk_));                                                   \
+  if (msk) bf_ = bf_ * rm
+  for (int kk = 0; kk <= N; kk += N) {       // levels 0 and N keep the preliminary ghats (the last sweep covers 1 .. N-1)
+    LMD_BF(z_w[XW(i, j, kk)], swdk, bf);
+    const double cff = 1.0 - (0.5 + copysign(0.5, bf));
+    F.ghats[XW4(i, j, kk, 1)] = -cff * (st1 - sr + sr * (1.0 - swdk));
+    F.ghats[XW4(i, j, kk, 2)] = cff * st2;
+  }
+  {   // density spline: FC again (the same recurrence), dR in dV's place
+    const double *Rc = pden + x;
+    FC[LK(0)] = 0.0; dR[LK(0)] = 0.0;
+    double FCm = 0.0, dRm = 0.0;
+    for (int k0 = 1; k0 <= N - 1; k0 += 6) {
+      double hz[7], rr[7];
+#pragma unroll
+      for (int q = 0; q < 7; q++) {
+        const size_t o = (size_t)(KMIN(k0 + q, N) - 1) * nij;
+        hz[q] = Hz[o]; rr[q] = Rc[o];
+      }
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const int k = k0 + q;
+        if (k > N - 1) break;
+        const double cff = 1.0 / (2.0 * hz[q + 1] + hz[q] * (2.0 - FCm));
+        FCm = cff * hz[q + 1];
+        dRm = cff * (6.0 * (rr[q + 1] - rr[q]) - hz[q] * dRm);
+        FC[LK(k)] = FCm; dR[LK(k)] = dRm;
+      }
+    }
+    dR[LK(N)] = 0.0;
+    double r1 = 0.0;
+    for (int k = N - 1; k >= 1; k--) {
+      r1 = dR[LK(k)] - FC[LK(k)] * r1;
+      dR[LK(k)] = r1;
+    }
+  }
+  const double Rref = pden[X3(i, j, N)] + HzN * (c13 * dR[LK(N)] + c16 * dR[LK(N - 1)]);
+  const double Ustar3 = Ustar * Ustar * Ustar;
+  double wm = 0.0, ws = 0.0;
+  FC[LK(N)] = 0.0;
+  for (int k0 = N; k0 >= 1; k0 -= 3) {
+    double zwm[3], pd[3], hz[3], bvm[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int k = KMAX(k0 - q, 1);
+      zwm[q] = z_w[XW(i, j, k - 1)]; pd[q] = pden[X3(i, j, k)]; hz[q] = Hz[(size_t)(k - 1) * nij];
+      bvm[q] = bvf[XW(i, j, k - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int k = k0 - q;
+      if (k < 1) break;
+      const double depth = zwN - zwm[q];
+      LMD_BF(zwm[q], swdk, bf);
+      (void)swdk;
+      const double sigma = (bf < 0.0) ? KMIN(sl_dpth, depth) : depth;
+      const double zetahat = vonKar * sigma * bf;
+      lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+      const double Rk = pd[q] - hz[q] * (c13 * dR[LK(k - 1)] + c16 * dR[LK(k)]);
+      const double Ritop = -gorho0 * (Rref - Rk) * depth;
+      const double Ribot = SH[LK(k)] + a.Vtc * depth * ws * sqrt(fabs(bvm[q]));
+      FC[LK(k - 1)] = Ritop - lmd_Ric * Ribot;
+    }
+  }
+  int ksbl = 1;
+  hsbl = z_w[XW(i, j, 1)];
+  for (int k = N; k >= 2; k--) {
+    const double fkm = FC[LK(k - 1)];
+    if (ksbl == 1 && fkm > 0.0) {
+      const double fk = FC[LK(k)];
+      hsbl = (z_w[XW(i, j, k)] * fkm - z_w[XW(i, j, k - 1)] * fk) / (fkm - fk);
+      ksbl = k;
+    }
+  }
+  double Bfsfc = (Bo + Bosol * (1.0 - SWFRAC(msk ? (zwN - hsbl) * rm : zwN - hsbl)));   // zgrid*rmask :563
+  if (msk) Bfsfc = Bfsfc * rm;                                 // :575
+  if (Ustar > 0.0 && Bfsfc > 0.0) {
+    const double hekman = lmd_cekman * Ustar / KMAX(fabs(F.f[X2(i, j)]), eps);
+    const double hmonob = lmd_cmonob * Ustar * Ustar * Ustar / KMAX(vonKar * Bfsfc, eps);
+    double m = KMIN(hekman, hmonob);
+    m = KMIN(m, zwN - hsbl);
+    hsbl = (zwN - m);
+  }
+  hsbl = KMIN(hsbl, zwN);
+  hsbl = KMAX(hsbl, z_w[XW(i, j, 0)]);
+  if (msk) hsbl = hsbl * rm;                                   // :596
+  emit_store(G, emit_plan(G, BC_R, i, j), F.hsbl, hsbl);     // bc_r2d_tile + exchange lmd_skpp.F:608
+  ksbl = 1;
+  for (int k = N; k >= 2; k--)
+    if (ksbl == 1 && z_w[XW(i, j, k - 1)] < hsbl) ksbl = k;
+  Bfsfc = (Bo + Bosol * (1.0 - SWFRAC(msk ? (zwN - hsbl) * rm : zwN - hsbl)));          // :670
+  if (msk) Bfsfc = Bfsfc * rm;                                 // :682
+  sl_dpth = lmd_epsilon * (zwN - hsbl);
+  {
+    const double cff = (Bfsfc > 0.0) ? 1.0 : lmd_epsilon;
+    const double sigma = cff * (zwN - hsbl);
+    const double zetahat = vonKar * sigma * Bfsfc;
+    lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+  }
+  const double f1 = 5.0 * KMAX(0.0, Bfsfc) * vonKar / (Ustar * Ustar * Ustar * Ustar + eps);
+  const double zbl = zwN - hsbl;
+  double Gm1, Gt1, Gs1, dGm1dS, dGt1dS, dGs1dS;
+  if (hsbl > z_w[XW(i, j, 1)]) {
+    const int k = ksbl;
+    const double cff = 1.0 / (z_w[XW(i, j, k)] - z_w[XW(i, j, k - 1)]);
+    const double cff_dn = cff * (hsbl - z_w[XW(i, j, k - 1)]);
+    const double cff_up = cff * (z_w[XW(i, j, k)] - hsbl);
+    double K_bl = cff_dn * F.Akv[XW(i, j, k)] + cff_up * F.Akv[XW(i, j, k - 1)];
+    double dK_bl = cff * (F.Akv[XW(i, j, k)] - F.Akv[XW(i, j, k - 1)]);
+    Gm1 = K_bl / (zbl * wm + eps);
+    if (msk) Gm1 = Gm1 * rm;                                   // :755,800
+    dGm1dS = KMIN(0.0, -dK_bl / (wm + eps) - K_bl * f1);
+    K_bl = cff_dn * F.Akt[XW4(i, j, k, 1)] + cff_up * F.Akt[XW4(i, j, k - 1, 1)];
+    dK_bl = cff * (F.Akt[XW4(i, j, k, 1)] - F.Akt[XW4(i, j, k - 1, 1)]);
+    Gt1 = K_bl / (zbl * ws + eps);
+    if (msk) Gt1 = Gt1 * rm;                                   // :766,809
+    dGt1dS = KMIN(0.0, -dK_bl / (ws + eps) - K_bl * f1);
+    K_bl = cff_dn * F.Akt[XW4(i, j, k, 2)] + cff_up * F.Akt[XW4(i, j, k - 1, 2)];
+    dK_bl = cff * (F.Akt[XW4(i, j, k, 2)] - F.Akt[XW4(i, j, k - 1, 2)]);
+    Gs1 = K_bl / (zbl * ws + eps);
+    if (msk) Gs1 = Gs1 * rm;                                   // :778
+    dGs1dS = KMIN(0.0, -dK_bl / (ws + eps) - K_bl * f1);
+  } else {
+    ksbl = 0;
+    const double ba = 0.5 * (F.bustr[X2(i, j)] + F.bustr[X2(i + 1, j)]), bc = 0.5 * (F.bvstr[X2(i, j)] + F.bvstr[X2(i, j + 1)]);
+    double Ustarb = sqrt(sqrt(ba * ba + bc * bc));
+    if (msk) Ustarb = Ustarb * rm;                             // :794
+    const double dK_bl = vonKar * Ustarb;
+    const double K_bl = dK_bl * (hsbl - z_w[XW(i, j, 0)]);
+    Gm1 = K_bl / (zbl * wm + eps);
+    if (msk) Gm1 = Gm1 * rm;                                   // :755,800
+    dGm1dS = KMIN(0.0, -dK_bl / (wm + eps) - K_bl * f1);
+    Gt1 = K_bl / (zbl * ws + eps);
+    if (msk) Gt1 = Gt1 * rm;                                   // :766,809
+    dGt1dS = KMIN(0.0, -dK_bl / (ws + eps) - K_bl * f1);
+    Gs1 = Gt1;
+    dGs1dS = dGt1dS;
+  }
+  const EmitPlan PA = emit_plan(G, BC_R, i, j);
+  const size_t oA_ = nij * (size_t)(N + 1);
+  for (int k0 = 1; k0 <= N - 1; k0 += 4) {
+    double zw_[4], av[4], a1_[4], a2_[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = KMIN(k0 + q, N - 1);
+      const size_t ow = (size_t)k * nij + x;
+      zw_[q] = z_w[ow];
+      av[q] = F.Akv[ow]; a1_[q] = F.Akt[ow]; a2_[q] = F.Akt[ow + oA_]; bv[q] = bvf[ow];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = k0 + q;
+      if (k > N - 1) break;
+      const size_t ow = (size_t)k * nij;
+      double akv = av[q], akt1 = a1_[q], akt2 = a2_[q];
+      if (k > ksbl) {
+        const double depth = zwN - zw_[q];
+        LMD_BF(zw_[q], swdk, bf);
+        // the preliminary ghats of :330-340 (what the two-kernel form stores first and reads back here)
+        const double cffp = 1.0 - (0.5 + copysign(0.5, bf));
+        const double g1 = -cffp * (st1 - sr + sr * (1.0 - swdk)), g2 = cffp * st2;
+        double sigma = (bf < 0.0) ? KMIN(sl_dpth, depth) : depth;
+        const double zetahat = vonKar * sigma * bf;
+        lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+        sigma = depth / (zbl + eps);
+        if (msk) sigma = sigma * rm;                           // :867
+        const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
+        const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
+        const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;
+        const double Gs = a1 + a2 * Gs1 + a3 * dGs1dS;
+        akv = depth * wm * (1.0 + sigma * Gm);
+        akt1 = depth * ws * (1.0 + sigma * Gt);
+        akt2 = depth * ws * (1.0 + sigma * Gs);
+        const double cff = a.lmd_Cg * (1.0 - (0.5 + copysign(0.5, bf))) / (zbl * ws + eps);
+        F.ghats[ow + x] = cff * g1;
+        F.ghats[ow + x + oA_] = cff * g2;
+      } else {
+        F.ghats[ow + x] = 0.0;
+        F.ghats[ow + x + oA_] = 0.0;
+      }
+      // lmd_finish :500-540
+      double cff = KMAX(bv[q], lmd_bvfcon);
+      cff = KMIN(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
+      double nu_sxc = 1.0 - cff * cff;
+      nu_sxc = nu_sxc * nu_sxc * nu_sxc;
+      emit_store(G, PA, F.Akv + ow, akv + lmd_nu0c * nu_sxc);
+      emit_store(G, PA, F.Akt + ow, akt1 + lmd_nu0c * nu_sxc);
+      emit_store(G, PA, F.Akt + ow + oA_, akt2 + lmd_nu0c * nu_sxc);
+    }
+  }
+#undef LMD_BF
+#undef LK
+}
 COL_KERNEL(k_lmd_col, LmdArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  const int i = G.T.Istr + gx, j = G.T.Jstr + gy;
-  const size_t n1 = (size_t)(G.N + 1) * KLS;
-  const LmdWk w = {lds, lds + n1, lds + 2 * n1, lds + 3 * n1, (size_t)KLS, 0};
-  lmd_interior_col(a, i, j, w);
-  lmd_skpp_col(a, i, j, w);
+  lmd_col_fused(a, G.T.Istr + gx, G.T.Jstr + gy, lds);
 }
 COL_GLOBAL(k_lmd_col, LmdArgs)
-
-
