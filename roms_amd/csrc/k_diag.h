@@ -219,18 +219,32 @@ COOP_KERNEL(k_diag_fin, DiagArgs) {
   }
   KSYNC();
 #ifndef ROMS_CPU_EMU
-  // tree merge of the 256 partial results (the ordering relation is total: any merge order)
-  for (int stride = 128; stride >= 1; stride >>= 1) {
-    if (KTID < stride) {
-      const int o = KTID + stride;
-      if (mS[o] > mS[KTID]) mS[KTID] = mS[o];
-      const double C = mC[o];
-      if (C > 0.0 && (mC[KTID] == 0.0 || diag_better(C, (int)mJ[o], (int)mK[o], (int)mI[o], mC[KTID], (int)mJ[KTID],
-                                                     (int)mK[KTID], (int)mI[KTID]))) {
-        mC[KTID] = C; mI[KTID] = mI[o]; mJ[KTID] = mJ[o]; mK[KTID] = mK[o];
+  // merge of the 256 partial results with WAVEFRONT SHUFFLES (round 4; rounds 1-3: an LDS tree, eight barrier rounds): the
+  // ordering relation is total and max() is exact, so any merge order gives the same bits.  Each of the four waves
+  // folds its 64 candidates in six butterfly steps (__shfl_xor: lane l takes lane l^m's candidate and keeps the better
+  // one -- both lanes of a pair end with the same winner), lane 0 of each wave publishes it, thread 0 folds the four.
+  if (KTID < 256) {
+    double wC = mC[KTID], wS = mS[KTID];
+    int wi = (int)mI[KTID], wj = (int)mJ[KTID], wk = (int)mK[KTID];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const double oC = __shfl_xor(wC, m, 64), oS = __shfl_xor(wS, m, 64);
+      const int oi = __shfl_xor(wi, m, 64), oj = __shfl_xor(wj, m, 64), ok = __shfl_xor(wk, m, 64);
+      if (oS > wS) wS = oS;
+      if (oC > 0.0 && (wC == 0.0 || diag_better(oC, oj, ok, oi, wC, wj, wk, wi))) { wC = oC; wi = oi; wj = oj; wk = ok; }
+    }
+    KSYNC();                           // (every thread < 256 has read its own entry; the block has 256 threads)
+    if ((KTID & 63) == 0) { const int w = KTID >> 6; mC[w] = wC; mS[w] = wS; mI[w] = (double)wi; mJ[w] = (double)wj; mK[w] = (double)wk; }
+    KSYNC();
+    if (KTID == 0) {
+      for (int o = 1; o < 4; o++) {
+        if (mS[o] > mS[0]) mS[0] = mS[o];
+        const double C = mC[o];
+        if (C > 0.0 && (mC[0] == 0.0 || diag_better(C, (int)mJ[o], (int)mK[o], (int)mI[o], mC[0], (int)mJ[0], (int)mK[0], (int)mI[0]))) {
+          mC[0] = C; mI[0] = mI[o]; mJ[0] = mJ[o]; mK[0] = mK[o];
+        }
       }
     }
-    KSYNC();
   }
 #endif
   if (KTID == 0) {
