@@ -84,7 +84,8 @@ ALGO_ARRAYS = {
     "k_rho_eos_lin":  (5, 2),
     "k_lmd_interior": (9, 0),
     "k_lmd_skpp":     (18, 10),    # incl. the convective adjustment of lmd_finish (Akv, Akt read-modify-write)
-    "k_lmd_col":      (21, 12),    # N <= 30: lmd_vmix as one column kernel, spline columns in LDS
+    "k_lmd_col":      (21, 12),    # N <= 41: lmd_vmix as one column kernel, spline columns in LDS
+    "k_lmd_fused":    (21, 12),    # the same column function with its three work columns in 3-D work arrays
     "k_set_depth":    (3, 2),
     "k_set_massflux": (5, 2),
     "k_diag_col":     (7, 3),

@@ -83,11 +83,18 @@ int run_lmd_vmix(roms_hip_ctx *c) {
   a.Vtc = lmd_Cv * sqrt(-lmd_betaT) / (sqrt(lmd_cs * lmd_epsilon) * lmd_Ric * vonKar * vonKar);
   const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
   static const char *elc = getenv("ROMS_HIP_LMDCOL");
-  // one COL kernel with the spline columns in LDS (63 KB per wave at N = 30) when the chain waits for KPP; beside
-  // the barotropic loop (c->late_pre) its LDS would keep k_step2d's blocks off the CUs: the two-kernel form then
-  const bool col = (elc ? elc[0] != '0' : !c->late_pre) && (size_t)3 * (N + 1) * 64 * sizeof(double) < 64 * 1024;
-  if (col) {
+  // ROMS_HIP_LMDCOL: 1 = one COL kernel with the three spline columns in LDS (47.6 KB per wave at N = 30) -- the default when
+  // the chain waits for KPP; beside the barotropic loop (c->late_pre) its LDS would keep k_step2d's blocks off the CUs, and
+  // columns taller than 41 levels would leave two waves per CU: 0 = the two kernels of rounds 1-3 (the default there);
+  // 2 = the new column function as ONE THREAD kernel with its three columns in 3-D work arrays -- measured (round 4):
+  // config 5 572 us against 389 + 187, BENCHMARK1 step 1.008 against 1.004 ms: no gain, the recurrences wait for their
+  // own work-array round trips whichever way the passes are arranged; kept as a tested form, not the default
+  const bool fits = (size_t)3 * (N + 1) * 64 * sizeof(double) < 64 * 1024;
+  const int form = elc ? atoi(elc) : ((!c->late_pre && fits) ? 1 : 0);
+  if (form == 1 && fits) {
     LAUNCH_COL(k_lmd_col, nx, ny, 1, 3 * (N + 1), c->stream, a);
+  } else if (form != 0) {
+    LAUNCH_THREAD(k_lmd_fused, nx, ny, 1, c->stream, a);
   } else {
     LAUNCH_THREAD(k_lmd_interior, nx, ny, 1, c->stream, a);
     LAUNCH_THREAD(k_lmd_skpp, nx, ny, 1, c->stream, a);

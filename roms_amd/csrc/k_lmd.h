@@ -426,14 +426,15 @@ THREAD_GLOBAL(k_lmd_skpp, LmdArgs)
 // Three waves per CU instead of two (47.6 KB per wave at N = 30) and 28 instead of 37 array passes.  Every value is
 // computed by the two-kernel form's expression on the same operands: same bits (tests: test_column_kernel_forms...,
 // ROMS_HIP_LMDCOL=0 selects the two kernels, which tall columns -- 3*(N+1) doubles per column beyond 64 KB -- keep).
-KDEV void lmd_col_fused(const LmdArgs &a, int i, int j, double *lds) {
+// (the three work columns: level k of a column at W0[k * ks], W1[...], W2[...] -- LDS with ks = KLS in the COL kernel,
+//  three 3-D work arrays with ks = nij in the THREAD form that tall columns and the launches beside the barotropic loop take)
+KDEV void lmd_col_fused(const LmdArgs &a, int i, int j, double *W0, double *W1, double *W2, size_t ks) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   LMD_CONSTS;
   const int N = G.N;
-  const size_t n1 = (size_t)(N + 1) * KLS;
-  double *FC = lds, *dU = lds + n1, *dV = lds + 2 * n1;        // dU -> SH (squared shear), dV -> dR later
-#define LK(k) ((size_t)(k) * KLS)
+  double *FC = W0, *dU = W1, *dV = W2;        // dU -> SH (squared shear), dV -> dR later
+#define LK(k) ((size_t)(k) * ks)
   const size_t nij = (size_t)G.nij, x = X2(i, j);
   const long ni = G.ni;
   const double *Hz = F.Hz + x;
@@ -739,6 +740,17 @@ KDEV void lmd_col_fused(const LmdArgs &a, int i, int j, double *lds) {
 COL_KERNEL(k_lmd_col, LmdArgs) {
   (void)gz;
   const DGrid &G = a.G;
-  lmd_col_fused(a, G.T.Istr + gx, G.T.Jstr + gy, lds);
+  const size_t n1 = (size_t)(G.N + 1) * KLS;
+  lmd_col_fused(a, G.T.Istr + gx, G.T.Jstr + gy, lds, lds + n1, lds + 2 * n1, (size_t)KLS);
 }
 COL_GLOBAL(k_lmd_col, LmdArgs)
+// the same column function with its three work columns in the 3-D work arrays wrk3[1..3] (any N; many waves per CU, 14
+// work-array passes on top of the 28): replaces k_lmd_interior + k_lmd_skpp (ROMS_HIP_LMDCOL=0 still selects those)
+THREAD_KERNEL(k_lmd_fused, LmdArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy;
+  const size_t x = X2(i, j);
+  lmd_col_fused(a, i, j, a.Fv.wrk3[1] + x, a.Fv.wrk3[2] + x, a.Fv.wrk3[3] + x, (size_t)G.nij);
+}
+THREAD_GLOBAL(k_lmd_fused, LmdArgs)
