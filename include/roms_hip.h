@@ -297,6 +297,10 @@ int roms_hip_comm_peer(roms_hip_ctx *ctx, const void *blobs128, int nranks, int 
    with the first wrong point in roms_hip_last_error.  roms_hip_comm_reset removes the installed transport (after a
    failed probe the caller may install another one). */
 int roms_hip_exchange_probe(roms_hip_ctx *ctx, int reps);
+/* soak test: `reps` exchange points back to back without a host synchronisation in between (narrow, tail and wide
+   strips in turn), every plane coded with its repetition and verified on the device: an exchange that delivers the
+   PREVIOUS repetition's strips -- a slot read too early, a stale line -- is counted.  0, or exit_flag 2. */
+int roms_hip_exchange_soak(roms_hip_ctx *ctx, int reps);
 int roms_hip_comm_reset(roms_hip_ctx *ctx);
 /* number of halo exchanges performed so far (0 for a single-tile context) */
 long roms_hip_exchange_count(roms_hip_ctx *ctx);

@@ -586,3 +586,54 @@ static __global__ void __launch_bounds__(1024) xchg_peer_unpack(const XchgPeerAr
   for (int d = 0; d < 8; d++) peer_move<1>(G, L, A, a.x.buf[d], bz, d);
 }
 #endif
+
+
+// ---------------------------------------------------------------------------------------------- exchange soak (self-check)
+// roms_hip_exchange_soak: a production-like stream of exchanges with NO host synchronisation in between -- fill the own
+// points of `planes` work planes with a code of (global i, j, plane, repetition), exchange, count on the DEVICE the ghost
+// points that do not hold the code of the point they image, fill for the next repetition ...  A slot read before the
+// neighbour's strips of THIS repetition have landed, or a stale line, holds the previous repetition's code and is counted.
+struct SoakArgs {
+  DGrid G;
+  double *A;
+  unsigned long long *bad;        // bad[0]: mismatching ghost points so far; bad[1..3]: rep, packed (i,j), plane of the first
+  int planes, rep, gl, gh;
+  int nbr[8];
+};
+KDEV double soak_code(const DGrid &G, int i, int j, int k, int rep) {
+  if (i < 1) i += G.Lm; else if (i > G.Lm) i -= G.Lm;
+  if (j < 1) j += G.Mm; else if (j > G.Mm) j -= G.Mm;
+  return ((double)(rep & 0xFFFF) * 64.0 + (double)k) * 67108864.0 + (double)j * 8192.0 + (double)i;
+}
+THREAD_KERNEL(k_soak_fill, SoakArgs) {           // index space: the whole array (ni x nj x planes)
+  const DGrid &G = a.G;
+  const int i = G.LBi + gx, j = G.LBj + gy;
+  const TB &B = G.T;
+  const bool own = i >= B.Istr && i <= B.Iend && j >= B.Jstr && j <= B.Jend;
+  a.A[(size_t)gz * G.nij + X2(i, j)] = own ? soak_code(G, i, j, gz, a.rep) : -1.0;
+}
+THREAD_GLOBAL(k_soak_fill, SoakArgs)
+THREAD_KERNEL(k_soak_check, SoakArgs) {          // index space: the whole array; ghost points that image a neighbour's own points
+  const DGrid &G = a.G;
+  const int i = G.LBi + gx, j = G.LBj + gy;
+  const TB &B = G.T;
+  const int dx = i < B.Istr ? -1 : (i > B.Iend ? 1 : 0), dy = j < B.Jstr ? -1 : (j > B.Jend ? 1 : 0);
+  if (dx == 0 && dy == 0) return;
+  if ((dx < 0 && i < B.Istr - a.gl) || (dx > 0 && i > B.Iend + a.gh) || (dy < 0 && j < B.Jstr - a.gl) || (dy > 0 && j > B.Jend + a.gh)) return;
+  // direction index as in roms_hip.cpp: 0 W, 1 E, 2 S, 3 N, 4 SW, 5 SE, 6 NW, 7 NE
+  const int d = dy == 0 ? (dx < 0 ? 0 : 1) : (dx == 0 ? (dy < 0 ? 2 : 3) : (dy < 0 ? (dx < 0 ? 4 : 5) : (dx < 0 ? 6 : 7)));
+  if (a.nbr[d] < 0) return;
+  const double v = a.A[(size_t)gz * G.nij + X2(i, j)];
+  if (v != soak_code(G, i, j, gz, a.rep)) {
+#ifdef ROMS_CPU_EMU
+    if (a.bad[0]++ == 0) {
+#else
+    if (atomicAdd(a.bad, 1ull) == 0) {
+#endif
+      a.bad[1] = (unsigned long long)a.rep;
+      a.bad[2] = ((unsigned long long)(unsigned)(i + 4096) << 32) | (unsigned)(j + 4096);
+      a.bad[3] = (unsigned long long)gz;
+    }
+  }
+}
+THREAD_GLOBAL(k_soak_check, SoakArgs)

@@ -1423,6 +1423,54 @@ extern "C" int roms_hip_exchange_probe(roms_hip_ctx *c, int reps) {
   return 0;
 }
 
+// Soak test of the installed transport (round 4): `reps` exchange points issued back to back WITHOUT a host synchronisation
+// in between, as a run issues them -- planes coded with (i, j, plane, repetition) by a kernel, exchanged (narrow strips,
+// every third repetition as a tail exchange on the exchange stream, every fourth with the wide strips where the pair
+// engine is on), verified by a kernel that counts wrong ghost points on the device.  What the index-coded probe above
+// cannot see -- a slot read before this repetition's strips have landed, a reordered store, a stale cache line under a
+// stream of exchanges -- shows as the previous repetition's code.  0, or exit_flag 2 with the first wrong point.
+extern "C" int roms_hip_exchange_soak(roms_hip_ctx *c, int reps) {
+  if (!c) return 8;
+  if (!c->has_exchange) return 0;
+  const DGrid &G = c->G;
+  const int planes = KMAX(c->x_min_planes, KMIN(G.N, 12));
+  struct Buf { void *p = nullptr; ~Buf() { if (p) { dfree(p); } } } buf, cnt;
+  if (dmalloc(&buf.p, (size_t)G.nij * (size_t)planes * sizeof(double)) || dmalloc(&cnt.p, 4 * sizeof(unsigned long long))) return 2;
+  SoakArgs a;
+  a.G = G; a.A = (double *)buf.p; a.bad = (unsigned long long *)cnt.p; a.planes = planes;
+  for (int d = 0; d < 8; d++) a.nbr[d] = c->comm.nbr[d];
+  for (int rep = 1; rep <= reps; rep++) {
+    const bool wide = c->pair_mt && rep % 4 == 0, tail = !wide && rep % 3 == 0;
+    const int np = wide ? KMIN(planes, 8) : planes;
+    a.rep = rep;
+    a.gl = wide ? B2D_GL : 3; a.gh = wide ? B2D_GH : G.Nghost;
+    halo_fence(c, FG_ALL);                     // (the planes are reused: the previous tail exchange must have unpacked)
+    LAUNCH_THREAD(k_soak_fill, G.ni, G.nj, np, c->stream, a);
+    HaloSpec sp = {a.A, np, BC_NONE, 'r'};
+    static const char *efault = getenv("ROMS_HIP_SOAK_FAULT");          // (test of the test: one exchange is left out)
+    if (efault && efault[0] == '1' && rep == (reps + 1) / 2) { /* nothing arrives in this repetition */ }
+    else if (wide) launch_halo_wide(c, &sp, 1);
+    else if (tail) launch_halo_tail(c, &sp, 1);
+    else launch_halo_multi(c, &sp, 1);
+    halo_fence(c, FG_ALL);                     // a stream dependency, not a host synchronisation
+    LAUNCH_THREAD(k_soak_check, G.ni, G.nj, np, c->stream, a);
+    if (c->comm_failed) break;
+  }
+  int r = ctx_check(c, "exchange soak");
+  if (r) return r;
+  unsigned long long bad[4] = {0, 0, 0, 0};
+  r = d2h(bad, cnt.p, sizeof(bad), c->stream);
+  if (r) return r;
+  if (bad[0]) {
+    char msg[256];
+    snprintf(msg, sizeof(msg), "exchange soak: tile %d: %llu wrong ghost points in %d back-to-back exchanges; first: repetition %llu, point (%d,%d), plane %llu",
+             c->cfg.tile, bad[0], reps, bad[1], (int)(bad[2] >> 32) - 4096, (int)(bad[2] & 0xFFFFFFFFu) - 4096, bad[3]);
+    set_error(msg);
+    return 2;
+  }
+  return 0;
+}
+
 // Back to no transport (a failed probe: the caller installs another one).  The mailbox slab stays allocated.
 extern "C" int roms_hip_comm_reset(roms_hip_ctx *c) {
   if (!c) return 8;

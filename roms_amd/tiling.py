@@ -99,10 +99,14 @@ class TiledRun:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return bool(int(t.item()))
 
-    def probe(self, reps=4):
-        """roms_hip_exchange_probe on every rank: index-coded planes through the installed transport."""
+    def probe(self, reps=4, soak=200):
+        """roms_hip_exchange_probe on every rank: index-coded planes through the installed transport; then (round 4)
+        roms_hip_exchange_soak: `soak` exchange points back to back without a host synchronisation, each repetition coded
+        and verified on the device -- ordering under a stream of exchanges, which the single probe exchanges cannot see."""
         L = self.ctx.L
         rc = L.roms_hip_exchange_probe(self.ctx.h, reps)
+        if rc == 0 and soak:
+            rc = L.roms_hip_exchange_soak(self.ctx.h, int(soak))
         return rc == 0, (L.roms_hip_last_error() or b"").decode() if rc else ""
 
     def _install_auto(self):

@@ -142,6 +142,24 @@ def test_automatic_transport_fails_cleanly_without_a_device_transport(tmp_path):
     assert "mailbox transport not usable" in out and "RCCL is not part of the CPU-emulated test build" in out, out[-3000:]
 
 
+def test_exchange_soak_passes_and_detects_a_missing_exchange(tmp_path):
+    """roms_hip_exchange_soak (round 4): 200 exchange points back to back without a host synchronisation, every repetition
+    coded and verified by a kernel -- it passes on two ranks through the callback transport, and with ONE exchange left
+    out (ROMS_HIP_SOAK_FAULT=1: the ghost zone keeps what the fill left there) it stops with the first wrong point."""
+    import json
+    import sys
+    _emu_libs()
+    spec = dict(tag="upwelling_mid", kw={}, steps=1, tiles=[2, 1], fields=["zeta"], probe=True)
+    for fault, port in (("0", 29643), ("1", 29644)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "tests", "mp", "run_tiles.py"), str(tmp_path / "x.npz"), json.dumps(spec)]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1", ROMS_HIP_SOAK_FAULT=fault))
+        if fault == "0":
+            assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        else:
+            assert p.returncode != 0 and "exchange soak" in p.stdout + p.stderr, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_bench_starts_its_own_ranks_when_run_plainly():
     """`python bench.py --gpus 2` without torch.distributed.run (WORLD_SIZE unset): the script starts its ranks as child
     processes itself and relays rank 0's line.  --dry-launch stops after the rendezvous (no GPU needed here)."""
