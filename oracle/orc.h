@@ -166,6 +166,7 @@ typedef struct orc_s {
   /* diag results: avgke, avgpe, avgkp, volume, max_speed, Cu_max ... */
   double diag[16];
   void *avg;                             /* time-averaged fields (orc_avg.c), NULL until orc_set_avg_window */
+  void *dia;                             /* per-term tracer tendencies, DIAGNOSTICS_TS (orc_diags.c), NULL until orc_set_dia_window */
 } orc_t;
 
 /* ---- index helpers (valid inside functions that define LBi,LBj,ni,nij,N) ---- */
@@ -254,6 +255,17 @@ void orc_set_avg(orc_t *o, int tile);
 double *orc_avg_field(orc_t *o, const char *name, long *nel);
 double orc_avg_time(const orc_t *o);
 void orc_avg_free(orc_t *o);
+
+/* per-term tracer tendencies (DIAGNOSTICS_TS): mod_diags.F, set_diags.F (orc_diags.c); fields "DiaTwrk", "DiaTrc", "dia_zeta" */
+enum { ORC_DIA_HADV = 0, ORC_DIA_XADV, ORC_DIA_YADV, ORC_DIA_VADV, ORC_DIA_HDIF, ORC_DIA_XDIF, ORC_DIA_YDIF, ORC_DIA_SDIF,
+       ORC_DIA_VDIF, ORC_DIA_RATE, ORC_DIA_NTERMS };
+int orc_set_dia_window(orc_t *o, int nDIA, int ntsDIA, int nrrec, int ntstart);   /* 0, or 5: MPDATA tracers are not covered */
+void orc_set_diags(orc_t *o, int tile);
+double *orc_dia_wrk(orc_t *o, int term, int itrc);       /* DiaTwrk(:,:,:,itrc,term), NULL when off / absent */
+double *orc_dia_field(orc_t *o, const char *name, long *nel);
+int orc_dia_ndt(const orc_t *o);
+double orc_dia_time(const orc_t *o);
+void orc_dia_free(orc_t *o);
 
 /* one baroclinic step, main3d.F:216-1148 */
 int orc_main3d_step(orc_t *o);

@@ -105,7 +105,7 @@ def lib():
 
 TILE_KERNELS = ["set_depth", "set_massflux", "rho_eos", "set_vbc", "ana_vmix", "set_data", "omega",
                 "set_zeta", "ini_zeta", "ini_fields", "pre_step3d", "prsgrd", "t3dmix2", "uv3dmix2",
-                "rhs3d_tile", "rhs3d", "step2d", "step3d_uv", "step3d_t", "lmd_vmix", "bulk_flux"]
+                "rhs3d_tile", "rhs3d", "step2d", "step3d_uv", "step3d_t", "lmd_vmix", "bulk_flux", "set_diags"]
 
 
 class Oracle:
@@ -153,6 +153,12 @@ class Oracle:
     def set_avg_window(self, nAVG, ntsAVG=1, nrrec=0, ntstart=1):
         """allocate the time-averaged fields ("avg_zeta" ... "avg_HvomT") and set the window of set_avg.F"""
         self.L.orc_set_avg_window(C.c_void_p(self.h), int(nAVG), int(ntsAVG), int(nrrec), int(ntstart))
+
+    def set_dia_window(self, nDIA, ntsDIA=1, nrrec=0, ntstart=1):
+        """allocate the per-term tracer tendencies ("DiaTwrk", "DiaTrc", "dia_zeta") and set the window of set_diags.F"""
+        r = self.L.orc_set_dia_window(C.c_void_p(self.h), int(nDIA), int(ntsDIA), int(nrrec), int(ntstart))
+        if r:
+            raise ValueError("DIAGNOSTICS_TS with MPDATA tracers is not covered by the oracle")
 
     def start(self):
         self.L.orc_start(self.h)

@@ -196,6 +196,7 @@ void orc_destroy(orc_t *o) {
   if (!o) return;
   for (size_t k = 0; k < NFIELDS; k++) free(*(double **)((char *)o + fields[k].off));
   orc_avg_free(o);
+  orc_dia_free(o);
   free(o->ksbl);
   free(o->b);
   free(o);
@@ -207,7 +208,8 @@ double *orc_field(orc_t *o, const char *name, long *nel) {
       if (nel) *nel = (long)field_size(o, fields[k].kind);
       return *(double **)((char *)o + fields[k].off);
     }
-  return orc_avg_field(o, name, nel);
+  { long n = -1; double *p = orc_avg_field(o, name, &n); if (p) { if (nel) *nel = n; return p; } }
+  return orc_dia_field(o, name, nel);
 }
 
 orc_step *orc_stepping(orc_t *o) { return &o->s; }

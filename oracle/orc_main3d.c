@@ -156,6 +156,7 @@ int orc_main3d_step(orc_t *o) {
   REV(o, { orc_omega(o, tile); orc_wvelocity(o, tile, s->nstp); });     /* :534-535 */
   FWD(o, orc_set_zeta(o, tile));                                        /* :556 */
   if (o->avg) { FWD(o, orc_set_avg(o, tile)); }                         /* :562 (AVERAGES) */
+  if (o->dia) { FWD(o, orc_set_diags(o, tile)); }                       /* :559 (DIAGNOSTICS) */
   REV(o, orc_rhs3d(o, tile));                                           /* :632 */
   if (c->options & ORC_MY25_MIXING) { REV(o, orc_my25_prestep(o, tile)); }  /* :634 */
   else if (c->options & ORC_GLS_MIXING) { REV(o, orc_gls_prestep(o, tile)); }  /* :636 */

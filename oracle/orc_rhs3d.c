@@ -320,6 +320,10 @@ void orc_pre_step3d(orc_t *o, int tile) {
           cff1 = Hz[X3(i, j, k)] * t[XT(i, j, k, nstp, itrc)];
           cff2 = CX(FC, i, k) - CX(FC, i, k - 1);
           t[XT(i, j, k, nnew, itrc)] = cff1 + cff2;
+          if (o->dia) {                                                 /* DIAGNOSTICS_TS pre_step3d.F:925-928 */
+            orc_dia_wrk(o, ORC_DIA_RATE, itrc)[X3(i, j, k)] = cff1;
+            orc_dia_wrk(o, ORC_DIA_VDIF, itrc)[X3(i, j, k)] = cff2;
+          }
         }
     }
   }
@@ -695,6 +699,11 @@ void orc_t3dmix2(orc_t *o, int tile) {
           cff2 = cff * (FE[X2(i, j + 1)] - FE[X2(i, j)]);
           cff3 = cff1 + cff2;
           t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] + cff3;
+          if (o->dia) {                                                 /* DIAGNOSTICS_TS t3dmix2_s.h:293-297 */
+            orc_dia_wrk(o, ORC_DIA_XDIF, itrc)[X3(i, j, k)] = cff1;
+            orc_dia_wrk(o, ORC_DIA_YDIF, itrc)[X3(i, j, k)] = cff2;
+            orc_dia_wrk(o, ORC_DIA_HDIF, itrc)[X3(i, j, k)] = cff3;
+          }
         }
     }
   free(FX);

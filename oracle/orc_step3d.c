@@ -432,6 +432,11 @@ void orc_step3d_t(orc_t *o, int tile) {
             cff2 = cff * (FE[X2(i, j + 1)] - FE[X2(i, j)]);
             cff3 = cff1 + cff2;
             t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] - cff3;
+            if (o->dia) {                                               /* DIAGNOSTICS_TS :908-912 */
+              orc_dia_wrk(o, ORC_DIA_XADV, itrc)[X3(i, j, k)] = -cff1;
+              orc_dia_wrk(o, ORC_DIA_YADV, itrc)[X3(i, j, k)] = -cff2;
+              orc_dia_wrk(o, ORC_DIA_HADV, itrc)[X3(i, j, k)] = -cff3;
+            }
           }
       }
     }
@@ -499,6 +504,13 @@ void orc_step3d_t(orc_t *o, int tile) {
             t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] - cff1;
             if (!(c->options & ORC_PLAIN_VDIFF))                      /* SPLINES_VDIFF: to Tunits :1354-1356 */
               t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] * oHz[X3(i, j, k)];
+            if (o->dia) {                                               /* DIAGNOSTICS_TS :1357-1362: every term to Tunits */
+              orc_dia_wrk(o, ORC_DIA_VADV, itrc)[X3(i, j, k)] = -cff1;
+              for (int term = 0; term < ORC_DIA_NTERMS; term++) {
+                double *D = orc_dia_wrk(o, term, itrc);
+                if (D) D[X3(i, j, k)] = D[X3(i, j, k)] * oHz[X3(i, j, k)];
+              }
+            }
           }
       }
     }
@@ -581,6 +593,10 @@ void orc_step3d_t(orc_t *o, int tile) {
             CX(DC, i, k) = CX(DC, i, k) * Akt[XW4(i, j, k, ltrc)];
             cff1 = dt * oHz[X3(i, j, k)] * (CX(DC, i, k) - CX(DC, i, k - 1));
             t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] + cff1;
+            if (o->dia) {                                               /* DIAGNOSTICS_TS :1716-1719 */
+              double *D = orc_dia_wrk(o, ORC_DIA_VDIF, itrc);
+              D[X3(i, j, k)] = D[X3(i, j, k)] + cff1;
+            }
           }
       } else {
         /* plain tridiagonal :1724-1790 (MPDATA tracers; every tracer without SPLINES_VDIFF) */
@@ -629,6 +645,12 @@ void orc_step3d_t(orc_t *o, int tile) {
         for (int j = b->JstrR; j <= b->JendR; j++)
           for (int i = b->IstrR; i <= b->IendR; i++)
             t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] * o->rmask[X2(i, j)];
+    if (o->dia) {                                                        /* DIAGNOSTICS_TS :1892-1904: time rate of change */
+      double *D = orc_dia_wrk(o, ORC_DIA_RATE, itrc);
+      for (int k = 1; k <= N; k++)
+        for (int j = b->JstrR; j <= b->JendR; j++)
+          for (int i = b->IstrR; i <= b->IendR; i++) D[X3(i, j, k)] = t[XT(i, j, k, nnew, itrc)] - D[X3(i, j, k)];
+    }
     orc_exchange3d(o, b, 'r', t + XT(LBi, LBj, 1, nnew, itrc), N);
   }
   free(CF);

@@ -105,6 +105,12 @@ void orc_t3dmix2_geo(orc_t *o, int tile) {
             cff3 = dt * (L2(FS, i, j, k2) - L2(FS, i, j, k1));
             cff4 = cff1 + cff2 + cff3;
             t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] + cff4;
+            if (o->dia) {                                               /* DIAGNOSTICS_TS t3dmix2_geo.h:409-414, t3dmix2_iso.h:428-433 */
+              orc_dia_wrk(o, ORC_DIA_XDIF, itrc)[X3(i, j, k)] = cff1;
+              orc_dia_wrk(o, ORC_DIA_YDIF, itrc)[X3(i, j, k)] = cff2;
+              orc_dia_wrk(o, ORC_DIA_SDIF, itrc)[X3(i, j, k)] = cff3;
+              orc_dia_wrk(o, ORC_DIA_HDIF, itrc)[X3(i, j, k)] = cff4;
+            }
           }
       }
     }
@@ -203,6 +209,12 @@ void orc_t3dmix2_iso(orc_t *o, int tile) {
             cff3 = dt * (L2(FS, i, j, k2) - L2(FS, i, j, k1));
             cff4 = cff1 + cff2 + cff3;
             t[XT(i, j, k, nnew, itrc)] = t[XT(i, j, k, nnew, itrc)] + cff4;
+            if (o->dia) {                                               /* DIAGNOSTICS_TS t3dmix2_geo.h:409-414, t3dmix2_iso.h:428-433 */
+              orc_dia_wrk(o, ORC_DIA_XDIF, itrc)[X3(i, j, k)] = cff1;
+              orc_dia_wrk(o, ORC_DIA_YDIF, itrc)[X3(i, j, k)] = cff2;
+              orc_dia_wrk(o, ORC_DIA_SDIF, itrc)[X3(i, j, k)] = cff3;
+              orc_dia_wrk(o, ORC_DIA_HDIF, itrc)[X3(i, j, k)] = cff4;
+            }
           }
       }
     }

@@ -116,6 +116,12 @@ if [ "$APP" = kelvin_splines ]; then
   UP=KELVIN; HDR=kelvin_splines; HDRPATH="$HERE/kelvin_splines.h"
   EXTRA=""
 fi
+if [ "$APP" = upwelling_diag ]; then
+  # ROMS/Include/upwelling.h AS SHIPPED (no PERFECT_RESTART): AVERAGES, DIAGNOSTICS_TS, DIAGNOSTICS_UV -- pins the per-term
+  # tendencies of mod_diags.F / set_diags.F
+  UP=UPWELLING; HDR=upwelling; HDRPATH="upwelling.h"
+  EXTRA=""
+fi
 if [ "$APP" = upwelling_avg ]; then
   # the UPWELLING case with AVERAGES (oracle/ref/upwelling_avg.h): pins set_avg.F
   UP=UPWELLING; HDR=upwelling_avg; HDRPATH="$HERE/upwelling_avg.h"
@@ -150,7 +156,7 @@ FILES="mod_kinds mod_param mod_scalars mod_stepping mod_strings mod_iounits mod_
   set_depth set_massflux rho_eos prsgrd t3dmix uv3dmix set_vbc set_zeta wvelocity diag ini_fields
   mod_sources uv_var_change step2d omega pre_step3d rhs3d step3d_uv step3d_t
   mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix gls_prestep gls_corstep my25_prestep my25_corstep tkebc_im bulk_flux analytical
-  mod_average uv_rotate vorticity set_avg"
+  mod_average uv_rotate vorticity set_avg mod_diags set_diags"
 TODO=""
 for m in $FILES; do
   src=""

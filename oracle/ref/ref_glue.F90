@@ -43,6 +43,9 @@
 #ifdef AVERAGES
       USE mod_average
 #endif
+#ifdef DIAGNOSTICS
+      USE mod_diags
+#endif
       implicit none
       integer, parameter :: ng = 1
       CONTAINS
@@ -302,6 +305,13 @@
       CALL allocate_average (ng, LBi, UBi, LBj, UBj)
       DO tile=first_tile(ng),last_tile(ng)
         CALL initialize_average (ng, tile)
+      END DO
+#endif
+#ifdef DIAGNOSTICS
+!  the per-term tendencies of mod_diags.F (upwelling.h as shipped: DIAGNOSTICS_TS, DIAGNOSTICS_UV)
+      CALL allocate_diags (ng, LBi, UBi, LBj, UBj)
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL initialize_diags (ng, tile)
       END DO
 #endif
       DO tile=first_tile(ng),last_tile(ng)
@@ -631,6 +641,14 @@
       ntstart(ng)=ntstart_in
       END SUBROUTINE ref_set_avg_window
 
+      SUBROUTINE ref_set_dia_window (n_dia, nts_dia, nrrec_in, ntstart_in) bind(C, name="ref_set_dia_window")
+      integer(c_int), value :: n_dia, nts_dia, nrrec_in, ntstart_in
+      nDIA(ng)=n_dia
+      ntsDIA(ng)=nts_dia
+      nrrec(ng)=nrrec_in
+      ntstart(ng)=ntstart_in
+      END SUBROUTINE ref_set_dia_window
+
       SUBROUTINE ref_set_stepping (idx, tm) bind(C, name="ref_set_stepping")
       USE dateclock_mod,     ONLY : time_string
       integer(c_int), intent(in) :: idx(*)
@@ -695,6 +713,9 @@
 #ifdef AVERAGES
       USE set_avg_mod,       ONLY : set_avg
 #endif
+#ifdef DIAGNOSTICS
+      EXTERNAL set_diags                         ! (set_diags.F is not a module)
+#endif
       character(kind=c_char), intent(in) :: cname(*)
       integer(c_int) :: ierr
       character(len=32) :: name
@@ -710,6 +731,10 @@
 #ifdef AVERAGES
           CASE ('set_avg')
             CALL set_avg (ng, tile)
+#endif
+#ifdef DIAGNOSTICS
+          CASE ('set_diags')
+            CALL set_diags (ng, tile)
 #endif
           CASE ('set_depth')
             CALL set_depth (ng, tile, iNLM)
@@ -1207,6 +1232,11 @@
 #endif
 #ifdef SHORTWAVE
         F2('srflx',FORCES(ng)%srflx)
+#endif
+#ifdef DIAGNOSTICS_TS
+        F2('DiaTwrk',DIAGS(ng)%DiaTwrk)
+        F2('DiaTrc',DIAGS(ng)%DiaTrc)
+        F2('dia_zeta',DIAGS(ng)%avgzeta)
 #endif
 #ifdef AVERAGES
         F2('avg_zeta',AVERAGE(ng)%avgzeta)

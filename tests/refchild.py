@@ -334,6 +334,59 @@ def mode_avg(tag, kw):
         print("AVG-OK bitwise")
 
 
+DIA_FIELDS = ["DiaTwrk", "DiaTrc", "dia_zeta"]
+
+
+def mode_dia(tag, kw):
+    """DIAGNOSTICS_TS (the reference built from upwelling.h as shipped) against the oracle: both sides step kernel by kernel
+    in main3d's order with set_diags behind set_zeta (main3d.F:559); DiaTwrk after every kernel, DiaTrc / avgzeta after
+    every set_diags -- the set, accumulate and convert phases of several windows."""
+    nsteps, nDIA, ntsDIA = kw.pop("nsteps", 9), kw.pop("nDIA", 3), kw.pop("ntsDIA", 1)
+    app, cs = rd.make_case(tag, **kw)
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    O = rd.oracle_from(R, cs)
+    O.start()
+    R.L.ref_set_dia_window(nDIA, ntsDIA, 0, 1)
+    O.set_dia_window(nDIA, ntsDIA, 0, 1)
+    nfast = R.bounds(0)[58]
+    st = dict(iic=1, iif=1, nstp=1, nnew=1, nrhs=1, kstp=1, knew=1, krhs=1, predictor=0, indx1=1, time=0.0, nfast=nfast)
+    names = rd.shared_fields(R, O)
+    log, ncmp, nonzero = [], 0, 0
+    for step in range(1, nsteps + 1):
+        for kern, s_ in rd.main3d_sequence(cs, st, first=(step == 1)):
+            for k, v in s_.items():
+                if k != "nfast":
+                    setattr(O.step, k, v)
+            O.step.tdays = s_["time"] / 86400.0
+            rd.sync_stepping(R, O)
+            R.call(kern)
+            if kern == "wvelocity":
+                O.call(kern, None, s_["nstp"])
+            elif kern == "diag":
+                O.diag()
+            else:
+                O.call(kern)
+            if kern == "set_zeta":
+                R.call("set_diags")
+                O.call("set_diags")
+                ncmp += 1
+                nonzero += int(np.abs(O.field("DiaTrc")).max() > 0.0)
+            if kern in ("set_zeta", "rhs3d", "step3d_t"):
+                bad = rd.mismatches(R, O, DIA_FIELDS)
+                if bad:
+                    log.append((step, kern, bad[:6]))
+    bad_state = rd.mismatches(R, O, names)
+    rd.unquiet(saved)
+    print("steps", nsteps, "nDIA", nDIA, "ntsDIA", ntsDIA, "set_diags calls compared", ncmp, "with data", nonzero)
+    for e in log[:5]:
+        print("MISMATCH", e)
+    if bad_state:
+        print("MISMATCH state", bad_state[:6])
+    if not log and not bad_state and nonzero >= nsteps - ntsDIA - 1:
+        print("DIA-OK bitwise")
+
+
 if __name__ == "__main__":
     mode, tag = sys.argv[1], sys.argv[2]
-    {"main3d": mode_main3d, "kernels": mode_kernels, "physics": mode_physics, "avg": mode_avg, "obc": mode_obc}[mode](tag, parse(sys.argv[3:]))
+    {"main3d": mode_main3d, "kernels": mode_kernels, "physics": mode_physics, "avg": mode_avg, "dia": mode_dia, "obc": mode_obc}[mode](tag, parse(sys.argv[3:]))

@@ -22,6 +22,8 @@ CASES = {
     "upwelling_kpp_small": ("upwelling_kpp", dict(Lm=14, Mm=18, N=8)),
     # the UPWELLING case built WITH its time-averaged output (oracle/ref/upwelling_avg.h): pins set_avg.F
     "upwelling_avg_small": ("upwelling_avg", dict(Lm=14, Mm=18, N=8)),
+    # ROMS/Include/upwelling.h AS SHIPPED (AVERAGES, DIAGNOSTICS_TS, DIAGNOSTICS_UV): pins the per-term tracer tendencies
+    "upwelling_diag_small": ("upwelling_diag", dict(Lm=14, Mm=18, N=8)),
     # UPWELLING with the logarithmic bottom drag (oracle/ref/upwelling_logdrag.h)
     "upwelling_logdrag_small": ("upwelling_logdrag", dict(Lm=14, Mm=18, N=8)),
     # UPWELLING with land/sea masking (oracle/ref/upwelling_mask.h; the masks are cases.land_mask)
@@ -138,7 +140,7 @@ def make_case(tag, **kw):
     k = dict(base)
     k.update({a: b for a, b in kw.items() if a not in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac")})
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
-                upwelling_avg=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
+                upwelling_avg=cases.upwelling, upwelling_diag=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
                 upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
                 upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31,
                 upwelling_wjgradp=cases.upwelling_prs31, upwelling_prs40=cases.upwelling_prs40, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,

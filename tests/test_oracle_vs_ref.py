@@ -178,7 +178,7 @@ def _child(mode, tag, *args, timeout=900):
         # the reference keeps its private (IminS:ImaxS,JminS:JmaxS,N) work arrays on the stack
         resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
 
-    lib = {"upwelling_kpp_small": "upwelling_kpp", "upwelling_avg_small": "upwelling_avg",
+    lib = {"upwelling_kpp_small": "upwelling_kpp", "upwelling_avg_small": "upwelling_avg", "upwelling_diag_small": "upwelling_diag",
            "upwelling_logdrag_small": "upwelling_logdrag", "upwelling_mask_small": "upwelling_mask",
            "benchmark_mask_small": "benchmark_mask", "upwelling_avg_mask_small": "upwelling_avg_mask",
            "kelvin": "kelvin_splines", "kelvin_small": "kelvin_splines", "kelvin_plain_small": "kelvin", "kelvin_plain": "kelvin",
@@ -332,6 +332,18 @@ def test_set_avg_bitwise(args):
     every call: the set, accumulate and convert (scale + periodic refill) phases of several windows."""
     out = _child("avg", "upwelling_avg_small", *args)
     assert "AVG-OK bitwise" in out, out
+
+
+@pytest.mark.parametrize("args", [["nsteps=9", "nDIA=3", "ntsDIA=1"], ["nsteps=8", "nDIA=2", "ntsDIA=3", "hadv=U3,U3", "vadv=C4,C4"],
+                                  ["nsteps=6", "nDIA=1", "ntsDIA=1", "hadv=A4,C2", "vadv=SPLINES,C2"],
+                                  ["nsteps=6", "nDIA=2", "ntsDIA=1", "NtileI=2", "NtileJ=2"]])
+def test_set_diags_bitwise(args):
+    """DIAGNOSTICS_TS: the per-term tracer tendencies -- DiaTwrk as pre_step3d.F:925, t3dmix2_s.h:293, step3d_t.F:908-912,
+    1357-1362, 1716-1719, 1892-1904 leave it after EVERY kernel of the step, and DiaTrc / avgzeta of set_diags.F (set,
+    accumulate, convert phases of several windows) -- the reference built from ROMS/Include/upwelling.h AS SHIPPED
+    (oracle/ref/build_ref.sh upwelling_diag: AVERAGES, DIAGNOSTICS_TS, DIAGNOSTICS_UV) against the oracle, array_equal."""
+    out = _child("dia", "upwelling_diag_small", *args)
+    assert "DIA-OK bitwise" in out, out
 
 
 def test_set_avg_on_a_masked_run_bitwise():
