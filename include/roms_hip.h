@@ -229,6 +229,16 @@ int roms_hip_get_bounds(roms_hip_ctx *ctx, int *out);
 int roms_hip_avg_config(roms_hip_ctx *ctx, int nAVG, int ntsAVG, int nrrec, int ntstart, unsigned mask);
 int roms_hip_set_avg(roms_hip_ctx *ctx);
 int roms_hip_avg_time(roms_hip_ctx *ctx, double *avgtime);
+/* DIAGNOSTICS_TS (ROMS/Modules/mod_diags.F, ROMS/Utility/set_diags.F; main3d.F:559): per-term tracer tendencies.
+   roms_hip_dia_config allocates DIAGS(ng)%DiaTwrk / DiaTrc (i,j,k,itrc,idiag; term order of mod_scalars.F:4246-4262:
+   hadv, xadv, yadv, vadv, [hdif, xdif, ydif, [sdif,]] vdif, rate) and avgzeta, and sets the window nDIA / ntsDIA (nrrec,
+   ntstart of a restart); from then on the kernels of pre_step3d, t3dmix2 and step3d_t store their terms
+   (pre_step3d.F:925, t3dmix2_s.h:293, t3dmix2_geo.h:409, t3dmix2_iso.h:428, step3d_t.F:908, :1357, :1716, :1892),
+   roms_hip_main3d / roms_hip_output_point call set_diags where main3d.F does, and "DiaTwrk", "DiaTrc", "dia_zeta" can be
+   downloaded.  exit_flag 5: MPDATA tracers, applications without SPLINES_VDIFF.  DIAGNOSTICS_UV is not built. */
+int roms_hip_dia_config(roms_hip_ctx *ctx, int nDIA, int ntsDIA, int nrrec, int ntstart);
+int roms_hip_set_diags(roms_hip_ctx *ctx);
+int roms_hip_dia_time(roms_hip_ctx *ctx, double *DIAtime);
 
 /* The reference writes its history and restart records in the middle of a step (CALL output, main3d.F:591,
    behind set_zeta): before a caller between two roms_hip_main3d calls downloads fields for output it brings

@@ -32,6 +32,7 @@ bool launch_tadv_lds(roms_hip_ctx *c, int mode) {
   const TB &B = G.T;
   static const char *el = getenv("ROMS_HIP_TADV_LDS"), *ek = getenv("ROMS_HIP_TADV_KC");
   if (G.NT > TL_MAXT) return false;
+  if (G.dia_ts) return false;                 // DIAGNOSTICS_TS: the point kernels carry the DiaTwrk stores
   const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
   if (el ? el[0] == '0' : (long)nx * ny < 64L * 1024L) return false;
   // mode 0: k_pre_t3's tracers are all those without a spline vertical flux (MPDATA/HSIMT tracers take the
@@ -132,7 +133,7 @@ int run_pre_step3d(roms_hip_ctx *c) {
   // large grids: the marching form (every level read once; the chunked form re-reads two levels per chunk of five)
   static const char *epm = getenv("ROMS_HIP_PRENEW_MARCH");
   const long cols = (long)(B.Iend - B.Istr + 1) * (B.Jend - B.Jstr + 1);
-  if (epm ? epm[0] != '0' : cols >= 128L * 1024L) {
+  if (!G.dia_ts && (epm ? epm[0] != '0' : cols >= 128L * 1024L)) {      // (DIAGNOSTICS_TS: the chunked form stores the terms)
     static const char *epp = getenv("ROMS_HIP_PRENEW_PARTS");       // (test aid: parts of the column per thread)
     const int parts = epp ? KMAX(1, atoi(epp)) : 1;
     a.p2 = (G.N + parts - 1) / parts;
@@ -173,7 +174,7 @@ int run_t3dmix2(roms_hip_ctx *c) {
   static const char *et = getenv("ROMS_HIP_T3CH");
   // large grids: a thread loops over the column (512x512x50: KCH 228, 10: 216, 25: 211, 50: 210 us)
   a.p1 = et ? atoi(et) : ((long)(B.Iend - B.Istr + 1) * (B.Jend - B.Jstr + 1) >= 128L * 1024L ? G.N : 0);
-  if (a.p1 > 0) {
+  if (a.p1 > 0) {      // (both forms store the DIAGNOSTICS_TS terms: one template)
     a.p0 = (G.N + a.p1 - 1) / a.p1;
     LAUNCH_THREAD_AS(k_t3dmix2_s, k_t3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, a.p0 * G.NT, c->stream, a);
     return 0;

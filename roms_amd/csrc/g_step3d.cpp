@@ -102,7 +102,7 @@ int run_step3d_t(roms_hip_ctx *c) {
   if (any_col) {
     const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
 #ifdef ROMS_CPU_EMU
-    if (col_lds(G)) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
+    if (col_lds(G) && !G.dia_ts) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
     else LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
 #else
     const char *er = getenv("ROMS_HIP_COLREGS");
@@ -113,7 +113,7 @@ int run_step3d_t(roms_hip_ctx *c) {
     const bool ldsform = col_lds(G) && (el ? el[0] == '1' : (N != 30 || hsimt_v));
     // chunks of 10 levels on tall columns: 542 -> 499 us at N = 50 (ROMS_HIP_S3TCH=0/1 forces a form)
     static const char *e10 = getenv("ROMS_HIP_S3TCH");
-    if (plain) LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);
+    if (plain || G.dia_ts) LAUNCH_THREAD(k_s3t_col, nx, ny, G.NT, c->stream, a);      // (DIAGNOSTICS_TS: the form that stores the terms)
     else if (ldsform && (e10 ? e10[0] == '1' : N > 40)) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l10, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
     else if (ldsform) LAUNCH_COL_AS(k_s3t_col, k_s3t_col_l, nx, ny, G.NT, 2 * (N + 1), c->stream, a);
     else if (regs && N == 30) LAUNCH_THREAD_AS(k_s3t_col, k_s3t_col_n30, nx, ny, G.NT, c->stream, a);
@@ -123,7 +123,7 @@ int run_step3d_t(roms_hip_ctx *c) {
   };
   HaloSpec spt[ROMS_MAXT];
   for (int it = 1; it <= G.NT; it++) spt[it - 1] = {t_lev(c, nnew, it), N, obc_bc(c, bc_rstate(c, true)), 'r'};   // t3dbc :1858 + exchange :1920
-  if (c->rim_split && any_col && !any_mp && !plain && !G.obc && !G.fuse3d && !G.masking) {
+  if (c->rim_split && any_col && !any_mp && !plain && !G.obc && !G.fuse3d && !G.masking && !G.dia_ts) {
     // multi-tile, round 4: the columns the exchange packs first, the exchange of t(nnew) on its own stream, the rest beside it
     // (not with MASKING: its fill multiplies the WHOLE plane by rmask, step3d_t.F:1880-1890, interior included)
     a.G.region = 1; column_part();
@@ -160,10 +160,11 @@ int run_step3d_t(roms_hip_ctx *c) {
     if (col_lds(G)) LAUNCH_COL_AS(k_mp_vdiff, k_mp_vdiff_l, LmT, MmT, 1, 2 * (N + 1), c->stream, m);
     else LAUNCH_THREAD(k_mp_vdiff, LmT, MmT, 1, c->stream, m);
   }
-  if (G.fuse3d && !any_mp && !plain) return 0;   // k_s3t_col stored the boundary values and images (pt_emit)
+  if (G.fuse3d && !any_mp && !plain) return run_dia_rate(c);   // k_s3t_col stored the boundary values and images (pt_emit); DIAGNOSTICS_TS: the rate term :1892-1904
   HaloSpec sp[ROMS_MAXT];
   if (G.obc) for (int it = 1; it <= G.NT; it++) { int r = run_obc3d_t(c, nnew, it); if (r) return r; }
   for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, obc_bc(c, bc_rstate(c, true)), 'r'};   // t3dbc :1858 + exchange :1920
   launch_halo_tail(c, sp, G.NT);
+  if (G.dia_ts) { halo_fence(c, FG_T); return run_dia_rate(c); }     // the rate term reads the boundary values t3dbc has just set
   return 0;
 }

@@ -321,6 +321,12 @@ THREAD_KERNEL(k_t3dmix2_geo, KArgs) {
     const double cff3 = G.dt * (FSk - FSm);
     const double cff4 = cff1 + cff2 + cff3;
     tnew[ok] = tnew[ok] + cff4;
+    if (G.dia_ts) {                                            // DIAGNOSTICS_TS t3dmix2_geo.h:409-414 / t3dmix2_iso.h:428-433
+      dia_wrk(G, F, DIA_XDIF, itrc)[ok + x] = cff1;
+      dia_wrk(G, F, DIA_YDIF, itrc)[ok + x] = cff2;
+      dia_wrk(G, F, DIA_SDIF, itrc)[ok + x] = cff3;
+      dia_wrk(G, F, DIA_HDIF, itrc)[ok + x] = cff4;
+    }
     Lk = Lp; Dm = Dk; Dk = Dp; Tm = Tk; FSm = FSk;
   }
 }
@@ -408,6 +414,12 @@ THREAD_KERNEL(k_t3dmix2_iso, KArgs) {
     const double cff3 = G.dt * (FSk - FSm);
     const double cff4 = cff1 + cff2 + cff3;
     tnew[ok] = tnew[ok] + cff4;
+    if (G.dia_ts) {                                            // DIAGNOSTICS_TS t3dmix2_geo.h:409-414 / t3dmix2_iso.h:428-433
+      dia_wrk(G, F, DIA_XDIF, itrc)[ok + x] = cff1;
+      dia_wrk(G, F, DIA_YDIF, itrc)[ok + x] = cff2;
+      dia_wrk(G, F, DIA_SDIF, itrc)[ok + x] = cff3;
+      dia_wrk(G, F, DIA_HDIF, itrc)[ok + x] = cff4;
+    }
     Lk = Lp; Dm = Dk; Dk = Dp; Tm = Tk; FSm = FSk;
   }
 #undef ISO_FAC

@@ -458,6 +458,10 @@ THREAD_KERNEL(k_pre_new, KArgs) {
           const double cff1 = hz[q] * tt[q + 1];
           const double cff2 = FC[q + 1] - FC[q];
           tn[oL[q + 1]] = cff1 + cff2;
+          if (G.dia_ts) {                                      // DIAGNOSTICS_TS pre_step3d.F:925-928
+            dia_wrk(G, F, DIA_RATE, itrc)[x + oL[q + 1]] = cff1;
+            dia_wrk(G, F, DIA_VDIF, itrc)[x + oL[q + 1]] = cff2;
+          }
         }
       }
     }
@@ -960,6 +964,11 @@ THREAD_KERNEL(k_t3dmix2_t, KArgs) {
     const double cff2 = cff * (FE1 - FE0);
     const double cff3 = cff1 + cff2;
     tn[ok] = tn[ok] + cff3;
+    if (G.dia_ts) {                                            // DIAGNOSTICS_TS t3dmix2_s.h:293-297
+      dia_wrk(G, F, DIA_XDIF, itrc)[ok + x] = cff1;
+      dia_wrk(G, F, DIA_YDIF, itrc)[ok + x] = cff2;
+      dia_wrk(G, F, DIA_HDIF, itrc)[ok + x] = cff3;
+    }
   }
 }
 THREAD_KERNEL(k_t3dmix2_s, KArgs) { k_t3dmix2_t_body<false>(a, gx, gy, gz); }

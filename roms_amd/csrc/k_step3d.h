@@ -689,6 +689,17 @@ KDEV bool s3t_point_path(const DGrid &G, int itrc) {
   return hs != ROMS_MPDATA && hs != ROMS_HSIMT && vs != ROMS_HSIMT && vs != ROMS_MPDATA && vs != ROMS_SPLINES;
 }
 
+// DIAGNOSTICS_TS, step3d_t.F:1357-1362: the vertical-advection term of a point, then EVERY term of the point to tracer
+// units (times 1/Hz: the horizontal terms, the diffusion terms of t3dmix2, the rate and vertical-diffusion parts
+// pre_step3d left there)
+KDEV void dia_vadv_convert(const DGrid &G, const Fields &F, int itrc, size_t at, double vadv, double oHz) {
+  dia_wrk(G, F, DIA_VADV, itrc)[at] = vadv;
+#pragma unroll
+  for (int term = 0; term < DIA_NTERMS; term++) {
+    double *D = dia_wrk(G, F, term, itrc);
+    if (D) D[at] = D[at] * oHz;
+  }
+}
 // step3d_t: horizontal :633-915 and vertical :936-1340 advection of t(3) into t(nnew), one point per
 // thread; index space (Istr:Iend, Jstr:Jend, N*NT).  Both steps update t(nnew) at the thread's own
 // point only, so they are fused without changing any operation.  Tracers whose vertical scheme needs
@@ -728,10 +739,16 @@ THREAD_KERNEL(k_s3t_hv, KArgs) {
     const double cff2 = cff * (FEp - FE0);
     const double cff3 = cff1 + cff2;
     double tt = tn[ok] - cff3;
+    if (G.dia_ts) {                                            // DIAGNOSTICS_TS :908-912
+      dia_wrk(G, F, DIA_XADV, itrc)[ok + x] = -cff1;
+      dia_wrk(G, F, DIA_YADV, itrc)[ok + x] = -cff2;
+      dia_wrk(G, F, DIA_HADV, itrc)[ok + x] = -cff3;
+    }
     if (vert) {
       const double cv = cff * (FC[q + 1] - FC[q]);
       tt = tt - cv;
       if (!(G.options & ROMS_PLAIN_VDIFF)) tt = tt * (1.0 / F.Hz[ok + x]);   // SPLINES_VDIFF: to tracer units :1354-1356
+      if (G.dia_ts) dia_vadv_convert(G, F, itrc, ok + x, -cv, 1.0 / F.Hz[ok + x]);      // :1357-1362
     }
     tn[ok] = tt;
   }
@@ -804,6 +821,11 @@ COOP_KERNEL(k_s3t_h, KArgs) {
     const double cff2 = cff * (FEp - FE0);
     const double cff3 = cff1 + cff2;
     tn[X2(i, j)] = tn[X2(i, j)] - cff3;
+    if (G.dia_ts) {                                            // DIAGNOSTICS_TS :908-912
+      dia_wrk(G, F, DIA_XADV, itrc)[X3(i, j, k)] = -cff1;
+      dia_wrk(G, F, DIA_YADV, itrc)[X3(i, j, k)] = -cff2;
+      dia_wrk(G, F, DIA_HADV, itrc)[X3(i, j, k)] = -cff3;
+    }
   }
 }
 COOP_GLOBAL(k_s3t_h, KArgs)
@@ -855,6 +877,7 @@ THREAD_KERNEL(k_s3t_col_t, KArgs) {
       double tt = tn[X3(i, j, k)] - cff1;
       if (!(G.options & ROMS_PLAIN_VDIFF)) tt = tt * (1.0 / Hz[X3(i, j, k)]);
       tn[X3(i, j, k)] = tt;
+      if (G.dia_ts) dia_vadv_convert(G, F, itrc, X3(i, j, k), -cff1, 1.0 / Hz[X3(i, j, k)]);      // DIAGNOSTICS_TS :1357-1362
       FCm = FCk;
     }
   #undef Tc
@@ -913,6 +936,7 @@ THREAD_KERNEL(k_s3t_col_t, KArgs) {
           const double up = DCp * ak[m], lo = DCk * ak[m + 1];        // DC(k+1)*Akt(k+1), DC(k)*Akt(k)
           const double cff1 = dt * (1.0 / hz[m]) * (up - lo);
           emit_store(G, PT, tn + (size_t)k * G.nij, tt[m] + cff1);     // t3dbc :1858 + exchange :1920
+          if (G.dia_ts) { double *D = dia_wrk(G, F, DIA_VDIF, itrc) + X3(i, j, k + 1); *D = *D + cff1; }   // :1716-1719
           DCp = DCk;
         }
       }
@@ -921,6 +945,7 @@ THREAD_KERNEL(k_s3t_col_t, KArgs) {
       const double DCk = DCp * Akt[XW(i, j, 1)];
       const double cff1 = dt * (1.0 / Hz[X3(i, j, 1)]) * (DCk - 0.0);
       emit_store(G, PT, tn, tn[X3(i, j, 1)] + cff1);
+      if (G.dia_ts) { double *D = dia_wrk(G, F, DIA_VDIF, itrc) + X3(i, j, 1); *D = *D + cff1; }
     }
   }
 }

@@ -40,6 +40,9 @@ struct DGrid {
   // exchange packs and its boundary fills read --, 2 = only the others (kdefs.h: THREAD / COL launches decide per thread,
   // the LDS-tiled kernels per block)
   int region, rimw;
+  // DIAGNOSTICS_TS (mod_diags.F): 0 = off; else NDT, the number of tracer terms; dia_idx[term] = the reference's 1-based
+  // index of the term (0 = absent for this option set), terms in the order of the enum below
+  int dia_ts, dia_idx[10];
   int fuse_halo;              // 1: single tile, k_step2d fills boundary/periodic ghost points itself (k_haloblock.h)
   int fuse3d;                 // 1: the 3-D producers do so too (emit_plan/emit_store); ROMS_HIP_FUSE3D=0 turns it off
   int xloc, yloc;             // 1: a periodic direction of this tile wraps onto itself by a local copy (no exchange partner)
@@ -197,6 +200,8 @@ struct GPtr {
   KHD GPtr &operator=(double *q) { p = (gdouble_t *)q; return *this; }
 };
 
+enum { DIA_HADV = 0, DIA_XADV, DIA_YADV, DIA_VADV, DIA_HDIF, DIA_XDIF, DIA_YDIF, DIA_SDIF, DIA_VDIF, DIA_RATE, DIA_NTERMS };
+
 // All device arrays (reference component names).  Pointers only; passed to kernels through the
 // small per-kernel argument structs.
 struct Fields {
@@ -222,6 +227,8 @@ struct Fields {
   GPtr wrk3[13];   // [1] P of prsgrd, [0..4] KPP, [3..4] spline fluxes, [5] swdk, [6..9] the four viscous terms of
                    // uv3dmix2, [10] wvelocity, [11..12] the old ru/rv bracket of the deferred momentum predictor
   GPtr wrk2[4];
+  // DIAGNOSTICS_TS: DIAGS(ng)%DiaTwrk, DiaTrc (i,j,k,itrc,idiag), avgzeta (allocated by roms_hip_dia_config)
+  GPtr DiaTwrk, DiaTrc, dia_zeta;
   // MPDATA work arrays (allocated only when a tracer uses MPDATA): Ta (N planes per tracer), Ua, Va, Wa,
   // beta_up, beta_dn
   GPtr mp3[6];
@@ -232,3 +239,9 @@ struct Fields {
   // bounds, south/north (LBi:UBi ...)
   GPtr bry[24];
 };
+
+// DiaTwrk(:,:,:,itrc,term): level 1 of the term's block; nullptr when the diagnostics are off or the term is absent
+KHD double *dia_wrk(const DGrid &G, const Fields &F, int term, int itrc) {
+  if (!G.dia_ts || !G.dia_idx[term]) return nullptr;
+  return (double *)F.DiaTwrk + ((size_t)(itrc - 1) + (size_t)G.NT * (size_t)(G.dia_idx[term] - 1)) * (size_t)G.N * (size_t)G.nij;
+}

@@ -419,6 +419,8 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   c->swdk_ready = false;
   c->pre_t3_ready = false;
   c->stream3 = nullptr;
+  c->G.dia_ts = 0;
+  for (int k = 0; k < 10; k++) c->G.dia_idx[k] = 0;
   for (int f = 0; f < 24; f++) c->avg[f] = nullptr;
   c->avg_nAVG = 0; c->avg_ntsAVG = 1; c->avg_nrrec = 0; c->avg_ntstart = 1; c->avg_mask = 0;
   c->avg_time = 0.0; c->avg_done_iic = -1;
@@ -632,9 +634,20 @@ extern "C" int roms_hip_get_stepping(roms_hip_ctx *c, roms_hip_stepping *s) {
   return 0;
 }
 
+// DIAGNOSTICS_TS arrays ("DiaTwrk", "DiaTrc": N*NT*NDT planes; "dia_zeta": one): device pointer and planes, or nullptr
+static double *dia_field(roms_hip_ctx *c, const char *name, int *np) {
+  if (!c->G.dia_ts) return nullptr;
+  const int n = c->G.N * c->G.NT * c->G.dia_ts;
+  if (!strcmp(name, "DiaTwrk")) { *np = n; return (double *)c->F.DiaTwrk; }
+  if (!strcmp(name, "DiaTrc")) { *np = n; return (double *)c->F.DiaTrc; }
+  if (!strcmp(name, "dia_zeta")) { *np = 1; return (double *)c->F.dia_zeta; }
+  return nullptr;
+}
 extern "C" long roms_hip_field_size(roms_hip_ctx *c, const char *name) {
   const FieldDesc *f = find_field(name);
   if (!f) {
+    int dnp = 0;
+    if (dia_field(c, name, &dnp)) return (long)dnp * c->cni * c->cnj;
     const int a = avg_field_index(name);
     return (a >= 0 && c->avg[a]) ? avg_field_elems(c, a) / c->G.nij * ((long)c->cni * c->cnj) : -1;
   }
@@ -678,6 +691,14 @@ extern "C" int roms_hip_upload(roms_hip_ctx *c, const char *name, const double *
 extern "C" int roms_hip_download(roms_hip_ctx *c, const char *name, double *host, long n) {
   const FieldDesc *f = find_field(name);
   if (!f) {
+    int dnp = 0;
+    double *dp = dia_field(c, name, &dnp);             // per-term tracer tendencies: "DiaTwrk", "DiaTrc", "dia_zeta"
+    if (dp) {
+      if (n != (long)dnp * c->cni * c->cnj) { set_error(std::string("size mismatch for field ") + name); return 8; }
+      halo_fence(c, FG_ALL);
+      if (c->wide) return relayout(c, dp, dnp, false, nullptr, host);
+      return d2h(host, dp, (size_t)n * sizeof(double), c->stream);
+    }
     const int a = avg_field_index(name);               // time-averaged fields: "avg_zeta" ... "avg_HvomT"
     if (a >= 0 && c->avg[a]) {
       const int np = (int)(avg_field_elems(c, a) / c->G.nij);
@@ -1756,7 +1777,7 @@ static int main3d_one(roms_hip_ctx *c) {
     // (a masked run keeps the reference order: its boundary fills are separate launches on the compute stream)
     static const char *elm = getenv("ROMS_HIP_LATE_MASK");
     // (prsgrd31: the late schedule relies on k_prs_grad keeping the previous ru/rv bracket for the deferred predictor)
-    if (!c->has_exchange && !uvcol && (!c->G.masking || (elm && elm[0] == '1')) && !(elate && elate[0] == '0') &&
+    if (!c->has_exchange && !uvcol && !c->G.dia_ts && (!c->G.masking || (elm && elm[0] == '1')) && !(elate && elate[0] == '0') &&
         !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_GLS_MIXING | ROMS_MY25_MIXING))) return main3d_late(c, do_diag);   // (GLS: its two routines keep the reference's places)
   }
   DO(roms_hip_rho_eos(c));                                  // :350
@@ -1791,6 +1812,7 @@ static int main3d_one(roms_hip_ctx *c) {
     if (!r) r = diag_now();
     if (!r) r = roms_hip_wvelocity(c, s.nstp);     // overwrites wvel, which diag reads: same stream, in order
     if (!r && c->avg_nAVG > 0 && c->avg_done_iic != s.iic) r = run_set_avg(c, 0);      // :562
+    if (!r && c->G.dia_ts && c->dia_nDIA > 0 && c->dia_done_iic != s.iic) r = run_set_diags(c);   // :559
   } else {
     r = diag_now();
   }
@@ -1807,6 +1829,7 @@ static int main3d_one(roms_hip_ctx *c) {
     DO(roms_hip_wvelocity(c, s.nstp));
     DO(roms_hip_set_zeta(c));                               // :556
     if (c->avg_nAVG > 0 && c->avg_done_iic != s.iic) DO(run_set_avg(c, 0));           // :562
+    if (c->G.dia_ts && c->dia_nDIA > 0 && c->dia_done_iic != s.iic) DO(run_set_diags(c));   // :559
   } else {
     side_join_point(c);               // (diag and wvelocity are picked up by the next join, before the barotropic loop)
   }
@@ -1878,6 +1901,51 @@ extern "C" int roms_hip_set_avg(roms_hip_ctx *c) {
   c->avg_done_iic = c->s.iic;
   return run_set_avg(c, 0);
 }
+// Per-term tracer tendencies (DIAGNOSTICS_TS of the application header): allocates DIAGS(ng)%DiaTwrk / DiaTrc / avgzeta
+// (mod_diags.F:104-228) and sets the window of set_diags.F (nDIA, ntsDIA; nrrec, ntstart of a restart).  From then on the
+// kernels of pre_step3d, t3dmix2 and step3d_t store their terms, roms_hip_main3d calls set_diags where main3d.F:559 does,
+// and "DiaTwrk", "DiaTrc", "dia_zeta" can be downloaded.  nDIA = 0 switches the accumulation off (the terms stay on).
+// Refused (exit_flag 5): MPDATA tracers (their Dhadv / Dvadv path, step3d_t.F:881-895, :1254), the plain vertical diffusion.
+extern "C" int roms_hip_dia_config(roms_hip_ctx *c, int nDIA, int ntsDIA, int nrrec, int ntstart) {
+  if (!c || nDIA < 0 || ntsDIA < 1) return 8;
+  DGrid &G = c->G;
+  for (int it = 0; it < G.NT; it++)
+    if (G.hadv[it] == ROMS_MPDATA || G.vadv[it] == ROMS_MPDATA) { set_error("DIAGNOSTICS_TS: tracers advected with MPDATA are not built (step3d_t.F:881-895)"); return 5; }
+  if (G.options & ROMS_PLAIN_VDIFF) { set_error("DIAGNOSTICS_TS: built for SPLINES_VDIFF only"); return 5; }
+  if (!G.dia_ts) {
+    int ic = 4, ndt = 6;
+    for (int k = 0; k < 10; k++) G.dia_idx[k] = 0;
+    G.dia_idx[DIA_HADV] = 1; G.dia_idx[DIA_XADV] = 2; G.dia_idx[DIA_YADV] = 3; G.dia_idx[DIA_VADV] = 4;      // mod_scalars.F:4246-4262
+    if (G.options & ROMS_TS_DIF2) {
+      G.dia_idx[DIA_HDIF] = ic + 1; G.dia_idx[DIA_XDIF] = ic + 2; G.dia_idx[DIA_YDIF] = ic + 3; ic += 3; ndt += 3;
+      if (G.options & (ROMS_MIX_GEO_TS | ROMS_MIX_ISO_TS)) { G.dia_idx[DIA_SDIF] = ic + 1; ic += 1; ndt += 1; }
+    }
+    G.dia_idx[DIA_VDIF] = ic + 1; G.dia_idx[DIA_RATE] = ic + 2;
+    const size_t n = (size_t)G.nij * (size_t)G.N * (size_t)G.NT * (size_t)ndt;
+    void *p = nullptr, *q = nullptr, *z = nullptr;
+    if (dmalloc(&p, n * sizeof(double)) || dmalloc(&q, n * sizeof(double)) || dmalloc(&z, (size_t)G.nij * sizeof(double))) return 2;
+    c->allocs.push_back(p); c->allocs.push_back(q); c->allocs.push_back(z);
+    c->F.DiaTwrk = (double *)p; c->F.DiaTrc = (double *)q; c->F.dia_zeta = (double *)z;
+#ifndef ROMS_CPU_EMU
+    if (hipfail(hipDeviceSynchronize(), "hipDeviceSynchronize")) return 2;
+#endif
+    G.dia_ts = ndt;
+  }
+  c->dia_nDIA = nDIA; c->dia_ntsDIA = ntsDIA; c->dia_nrrec = nrrec; c->dia_ntstart = ntstart; c->dia_done_iic = -1;
+  return 0;
+}
+// set_diags(ng,tile), main3d.F:559
+extern "C" int roms_hip_set_diags(roms_hip_ctx *c) {
+  if (!c) return 8;
+  if (!c->G.dia_ts || c->dia_nDIA <= 0 || c->dia_done_iic == c->s.iic) return 0;
+  c->dia_done_iic = c->s.iic;
+  return run_set_diags(c);
+}
+extern "C" int roms_hip_dia_time(roms_hip_ctx *c, double *t) {
+  if (!c || !t) return 8;
+  *t = c->dia_time;
+  return 0;
+}
 extern "C" int roms_hip_avg_time(roms_hip_ctx *c, double *t) {
   if (!c || !t) return 8;
   *t = c->avg_time;
@@ -1923,6 +1991,10 @@ extern "C" int roms_hip_output_point(roms_hip_ctx *c) {
     DO(run_set_avg(c, 0));
     DO(d2d((double *)c->F.wvel, (double *)c->F.wrk3[11], wbytes, c->stream));
     c->avg_done_iic = s.iic;
+  }
+  if (c->G.dia_ts && c->dia_nDIA > 0 && c->dia_done_iic != s.iic) {   // set_diags :559 precedes output too
+    DO(run_set_diags(c));
+    c->dia_done_iic = s.iic;
   }
 #undef DO
   return dsync(c->stream);

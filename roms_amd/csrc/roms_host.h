@@ -58,6 +58,9 @@ struct roms_hip_ctx {
   unsigned avg_mask;
   double avg_time;              // AVGtime (mod_scalars.F): time stamp of the record wrt_avg writes
   int avg_done_iic;             // roms_hip_output_point has run set_avg for this step already
+  // per-term tracer tendencies (DIAGNOSTICS_TS; g_dia.cpp): off until roms_hip_dia_config
+  int dia_nDIA = 0, dia_ntsDIA = 1, dia_nrrec = 0, dia_ntstart = 1, dia_done_iic = -1;
+  double dia_time = 0.0;        // DIAtime (mod_scalars.F)
   bool late_pre;                // main3d_one runs pre_step3d BEHIND prsgrd/rhs3d_tile/uv3dmix2 (beside the barotropic loop):
                                 // k_prs_grad keeps the old ru/rv bracket, k_uv3dmix2_s only stores its terms, k_pre_new uses both
   bool m2d_dirty;               // grid arrays uploaded since Fields::m2r/m2p were packed (g_step2d.cpp)
@@ -180,6 +183,8 @@ void launch_halo_tail(roms_hip_ctx *c, const HaloSpec *sp, int n);
 void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n);   // n <= 8 fields in one launch
 void launch_halo_wide(roms_hip_ctx *c, const HaloSpec *sp, int n);    // ... with strips B2D_GL | B2D_GH lines wide (pair kernel)
 int run_set_avg(roms_hip_ctx *c, int part = 0);   // g_avg.cpp
+int run_set_diags(roms_hip_ctx *c);               // g_dia.cpp
+int run_dia_rate(roms_hip_ctx *c);
 bool launch_tadv_lds(roms_hip_ctx *c, int mode);  // g_rhs3d.cpp
 int avg_field_index(const char *name);
 long avg_field_elems(const roms_hip_ctx *c, int f);

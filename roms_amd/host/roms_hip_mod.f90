@@ -164,6 +164,19 @@
           TYPE (c_ptr), value :: ctx
           integer(c_int) :: ierr
         END FUNCTION
+        FUNCTION roms_hip_dia_config (ctx, nDIA, ntsDIA, nrrec, ntstart) bind(C, name='roms_hip_dia_config')      &
+     &                               RESULT (ierr)
+          IMPORT :: c_ptr, c_int
+          type(c_ptr), value :: ctx
+          integer(c_int), value :: nDIA, ntsDIA, nrrec, ntstart
+          integer(c_int) :: ierr
+        END FUNCTION roms_hip_dia_config
+        FUNCTION roms_hip_dia_time (ctx, diatime) bind(C, name='roms_hip_dia_time') RESULT (ierr)
+          IMPORT :: c_ptr, c_int, c_double
+          type(c_ptr), value :: ctx
+          real(c_double), intent(out) :: diatime
+          integer(c_int) :: ierr
+        END FUNCTION roms_hip_dia_time
         FUNCTION roms_hip_avg_time (ctx, avgtime) bind(C, name='roms_hip_avg_time') RESULT (ierr)
           IMPORT :: c_int, c_ptr, c_double
           TYPE (c_ptr), value :: ctx

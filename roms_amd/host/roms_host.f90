@@ -51,6 +51,11 @@
 !  roms_hip_avg_config's mask bits; tracer terms (bits 8, 17..21) per tracer
       integer :: nAVG = 0, ntsAVG = 1
       character(len=256) :: avgname = 'roms_avg.nc'
+!  per-term tracer tendencies (DIAGNOSTICS_TS: mod_diags.F, set_diags.F, def_diags.F/wrt_diags.F): window, file, the
+!  Dout(iT...) switches per tracer in the library's term order (hadv xadv yadv vadv hdif xdif ydif sdif vdif rate)
+      integer :: nDIA = 0, ntsDIA = 1
+      character(len=256) :: dianame = 'roms_dia.nc'
+      logical :: DoutT(0:9,ROMS_MAXT) = .FALSE.
       integer, parameter :: nAout = 22
       logical :: Aout(0:nAout-1) = .FALSE., AoutT(0:nAout-1,ROMS_MAXT) = .FALSE.
       character(len=512) :: app_header = ' '      ! application header to read the cpp options from (optional)
@@ -186,6 +191,19 @@
           CASE ('NAVG');        nAVG=toint(tok(1))
           CASE ('NTSAVG');      ntsAVG=toint(tok(1))
           CASE ('AVGNAME');     avgname=ADJUSTL(val)
+          CASE ('NDIA');        nDIA=toint(tok(1))
+          CASE ('NTSDIA');      ntsDIA=toint(tok(1))
+          CASE ('DIANAME');     dianame=ADJUSTL(val)
+          CASE ('Dout(iThadv)'); CALL load_dout (0, tok, nv)
+          CASE ('Dout(iTxadv)'); CALL load_dout (1, tok, nv)
+          CASE ('Dout(iTyadv)'); CALL load_dout (2, tok, nv)
+          CASE ('Dout(iTvadv)'); CALL load_dout (3, tok, nv)
+          CASE ('Dout(iThdif)'); CALL load_dout (4, tok, nv)
+          CASE ('Dout(iTxdif)'); CALL load_dout (5, tok, nv)
+          CASE ('Dout(iTydif)'); CALL load_dout (6, tok, nv)
+          CASE ('Dout(iTsdif)'); CALL load_dout (7, tok, nv)
+          CASE ('Dout(iTvdif)'); CALL load_dout (8, tok, nv)
+          CASE ('Dout(iTrate)'); CALL load_dout (9, tok, nv)
           CASE ('Aout(idFsur)'); Aout(0)=istrue(tok(1))
           CASE ('Aout(idUbar)'); Aout(1)=istrue(tok(1))
           CASE ('Aout(idVbar)'); Aout(2)=istrue(tok(1))
@@ -399,6 +417,7 @@
       Akk_bak=5.0E-6_dp; Akp_bak=5.0E-6_dp; charnok_alpha=1400.0_dp; crgban_cw=100.0_dp
       nrrec=0; nRST=0; nHIS=0; LcycleRST=.TRUE.; Hout=.FALSE.; HoutMtke=.FALSE.; HoutMtls=.FALSE.
       nAVG=0; ntsAVG=1; avgname='roms_avg.nc'; Aout=.FALSE.; AoutT=.FALSE.
+      nDIA=0; ntsDIA=1; dianame='roms_dia.nc'; DoutT=.FALSE.
       ininame='roms_ini.nc'; rstname='roms_rst.nc'; hisname='roms_his.nc'
       END SUBROUTINE set_defaults
 
@@ -437,6 +456,15 @@
         END IF
       END DO
       END SUBROUTINE split
+
+      SUBROUTINE load_dout (term, tok, nv)        ! Dout(iT...): one value per tracer
+      integer, intent(in) :: term, nv
+      character(len=64), intent(in) :: tok(16)
+      integer :: it
+      DO it=1,MIN(nv,ROMS_MAXT)
+        DoutT(term,it)=istrue(tok(it))
+      END DO
+      END SUBROUTINE load_dout
 
       SUBROUTINE load_aout (bit, tok, nv)         ! a per-tracer switch line: one value per tracer
       integer, intent(in) :: bit, nv
@@ -1030,10 +1058,14 @@
 !  time-averaged output is a cpp option of the application (AVERAGES, e.g. the stock upwelling.h has it,
 !  benchmark.h has not): a header without it switches NAVG of roms.in off, as the reference build would
         IF (ierr.eq.0.and..not.is_defined('AVERAGES')) nAVG=0
+!  ... and so are the per-term tracer tendencies (DIAGNOSTICS_TS, stock upwelling.h:32): NDIA counts only with it
+        IF (ierr.eq.0.and..not.is_defined('DIAGNOSTICS_TS')) nDIA=0
       ELSE
         CALL builtin_defines (ierr)
       END IF
       CALL options_from_defines (ierr)
+!  (tracers advected with MPDATA: their Dhadv / Dvadv work arrays are not built -- no diagnostics file for such a run)
+      IF (ANY(hadv(1:NT).eq.ROMS_MPDATA)) nDIA=0
       END SUBROUTINE set_cppdefs
 !
 !=======================================================================
@@ -1846,6 +1878,10 @@
       IF (ierr.ne.0) RETURN
       IF (nAVG.gt.0.and.ANY(Aout)) THEN           ! AVERAGES: mod_average.F allocate_average
         ierr=roms_hip_avg_config(ctx, nAVG, ntsAVG, 0, 1, aout_mask())
+        IF (ierr.ne.0) RETURN
+      END IF
+      IF (nDIA.gt.0) THEN                          ! DIAGNOSTICS_TS: mod_diags.F allocate_diags
+        ierr=roms_hip_dia_config(ctx, nDIA, ntsDIA, 0, 1)
         IF (ierr.ne.0) RETURN
       END IF
       CALL up ('h', h, 1, ierr); CALL up ('f', f, 1, ierr); CALL up ('fomn', fomn, 1, ierr)

@@ -150,7 +150,7 @@
       integer, parameter :: NC_INT = 4, NC_DOUBLE = 6
 !  grid types of a variable (mod_param.F: r2dvar ... w3dvar)
       integer, parameter :: gR2 = 1, gU2 = 2, gV2 = 3, gR3 = 4, gU3 = 5, gV3 = 6, gW3 = 7, gUW = 8, gVW = 9
-      integer, parameter :: fHIS = 1, fRST = 2, fAVG = 3
+      integer, parameter :: fHIS = 1, fRST = 2, fAVG = 3, fDIA = 4
 
       TYPE out_file
         integer(c_int) :: h = -1
@@ -159,8 +159,9 @@
         integer(c_int) :: d_two, d_three, d_time
         integer(c_int) :: v_time, v_idx(7), v_fld(40)
       END TYPE out_file
-      TYPE (out_file), save :: ofile(3)
+      TYPE (out_file), save :: ofile(4)
       real(r8) :: AVGtime = 0.0_r8                 ! mod_scalars.F: time stamp of the averages record
+      real(r8) :: DIAtime = 0.0_r8                 ! ... of the diagnostics record (def_diags.F:944-949, set_diags.F:379-383)
       integer :: ntstart_run = 1                   ! first step of this run (initial.F:172; > 1 after get_state)
       logical :: restarted = .FALSE.
 !  MASKING: history and averages fields carry _FillValue = spval and land points are written as spval (nf_fwrite2d.F,
@@ -579,6 +580,10 @@
         path=avgname
         ftype='ROMS nonlinear model averages file'
       END IF
+      IF (which.eq.fDIA) THEN
+        path=dianame
+        ftype='ROMS diagnostics file'
+      END IF
       ofile(which)%nrec=0
       IF (.not.master()) THEN
         ofile(which)%h=0                   ! "open": this rank takes part in the gathers only; the definitions below
@@ -607,7 +612,8 @@
 !  model time, def_his.F: Vname(:,idtime), units "seconds since <reference date>" (time_ref = 0: 0001-01-01)
       tunit='seconds since 0001-01-01 00:00:00'
       CALL def_scalar (o, 'ocean_time', NC_DOUBLE, TRIM(MERGE('averaged time since initialization',                &
-     &                 'time since initialization         ', which.eq.fAVG)), TRIM(tunit), o%d_time, o%v_time, ierr)
+     &                 'time since initialization         ', which.eq.fAVG.or.which.eq.fDIA)), TRIM(tunit), o%d_time,   &
+     &                 o%v_time, ierr)
       IF (master()) THEN
         r=nc3_put_att_text(o%h, o%v_time, cs('calendar'), cs('proleptic_gregorian'))
         r=r+nc3_put_att_text(o%h, o%v_time, cs('field'), cs('time'))
@@ -668,7 +674,26 @@
      &        TRIM(MERGE('meter3 second-1 Celsius', 'meter3 second-1        ', it.eq.1)), 'v-flux '//TRIM(tn(it)), gV3)
         END DO
       END IF
-      IF (which.ne.fAVG) THEN
+      IF (which.eq.fDIA) THEN
+!  def_diags.F:470-595 for DIAGNOSTICS_TS: the free surface and, per tracer, the terms the Dout(iT...) switches ask for;
+!  names and attributes as mod_ncparam.F:2630-2900 composes them from the tracer's entry of varinfo.yaml and the term's
+!  (variable "<tracer><suffix>", long name "<tracer long name>, <term>", units "<tracer units> second-1", field
+!  "<tracer> <term field>", standard name sea_water_<tracer>_tendency...); slots 1 = zeta, 1 + 10*(itrc-1) + term
+        tn=(/ 'temp    ', 'salt    ' /)
+        tl=(/ 'potential temperature   ', 'salinity                ' /)
+        tu=(/ 'Celsius                 ', 'nondimensional          ' /)
+        CALL adef (1, 'zeta', 'sea_surface_height_above_geopotential_datum', 'free-surface', 'meter', 'free-surface', gR2)
+        DO it=1,MIN(NT,2)
+          DO k=0,9
+            IF (.not.DoutT(k,it).or.dia_term_index(k).eq.0) CYCLE
+            CALL adef (2+10*(it-1)+k, TRIM(tn(it))//TRIM(dia_suffix(k)),                                               &
+     &                 'sea_water_'//TRIM(MERGE('potential_temperature', 'salinity             ', it.eq.1))//           &
+     &                 TRIM(dia_std(k)), TRIM(tl(it))//', '//TRIM(dia_long(k)),                                          &
+     &                 TRIM(MERGE('Celsius second-1', 'second-1        ', it.eq.1)), TRIM(tn(it))//' '//TRIM(dia_fld(k)), gR3)
+          END DO
+        END DO
+      END IF
+      IF (which.ne.fAVG.and.which.ne.fDIA) THEN
       IF (rst.or.Hout(idFsur)) CALL fdef ('zeta', 'sea_surface_height_above_geopotential_datum', 'free-surface',     &
      &                                    'meter', 'free-surface', gR2, three, idFsur)
       IF (rst) CALL fdef ('rzeta', 'sea_surface_elevation_anomaly_right_hand_side', 'RHS of free-surface equation',  &
@@ -787,10 +812,13 @@
         END IF
         tv(1)=step%time
         IF (which.eq.fAVG) tv(1)=AVGtime
+        IF (which.eq.fDIA) tv(1)=DIAtime
         IF (nc3_put_var_double(o%h, o%v_time, INT(rec,c_long), tv, 1_c_long_long).ne.0) ierr=3
       END IF
       IF (which.eq.fAVG) THEN
         CALL avg_fields ()
+      ELSE IF (which.eq.fDIA) THEN
+        CALL dia_fields ()
       ELSE
 !  2-D state
       allocate ( A(LBi:UBi,LBj:UBj,3) )
@@ -927,6 +955,25 @@
           CALL av ('avg_HvomT', 28+it2, gV3, N*NT, N*(it2-1)+1, N*it2)
         END DO
         END SUBROUTINE avg_fields
+!  wrt_diags.F:270-314: avgzeta, then DiaTrc(:,:,:,itrc,idiag) times 1/dt for every term asked for
+        SUBROUTINE dia_fields ()
+        integer :: it2, kt, id, npl
+        CALL av ('dia_zeta', 1, gR2, 1, 1, 1)
+        npl=N*NT*dia_ndt()
+        IF (.not.ANY(ofile(which)%v_fld(2:21).ge.0)) RETURN
+        allocate ( B(LBi:UBi,LBj:UBj,npl) )
+        CALL fetch ('DiaTrc', npl, B, ierr)
+        B=B*(1.0_r8/dt)
+        DO it2=1,MIN(NT,2)
+          DO kt=0,9
+            id=dia_term_index(kt)
+            IF (id.eq.0.or.ofile(which)%v_fld(2+10*(it2-1)+kt).lt.0) CYCLE
+            CALL put_field (ofile(which)%h, ofile(which)%v_fld(2+10*(it2-1)+kt), rec, gR3, B, npl,                      &
+     &                      N*((it2-1)+NT*(id-1))+1, N*((it2-1)+NT*(id-1))+N, ierr)
+          END DO
+        END DO
+        deallocate ( B )
+        END SUBROUTINE dia_fields
         SUBROUTINE av (name, slot, g, np, k0, k1)
         character(len=*), intent(in) :: name
         integer, intent(in) :: slot, g, np, k0, k1
@@ -964,7 +1011,7 @@
 
       SUBROUTINE out_close ()
       integer :: w, r
-      DO w=1,3
+      DO w=1,SIZE(ofile)
         IF (ofile(w)%h.ge.0.and.master()) r=nc3_close(ofile(w)%h)
         ofile(w)%h=-1
         ofile(w)%nrec=0
@@ -1016,7 +1063,92 @@
           END IF
         END IF
       END IF
+!  diagnostics (DIAGNOSTICS_TS): the same bookkeeping for the diagnostics file (def_diags.F:944-949, set_diags.F:369-383,
+!  output.F: wrt_diags when the window closes)
+      IF (nDIA.gt.0) THEN
+        IF (ofile(fDIA)%h.lt.0) THEN
+          IF (ntsDIA.eq.1) THEN
+            DIAtime=step%time-0.5_r8*REAL(nDIA,r8)*dt
+          ELSE
+            DIAtime=step%time+REAL(ntsDIA,r8)*dt-0.5_r8*REAL(nDIA,r8)*dt
+          END IF
+          CALL out_define (fDIA, ierr)
+          IF (ierr.ne.0) RETURN
+        END IF
+        IF ((iic.gt.ntsDIA.and.MOD(iic-1,nDIA).eq.0.and.(iic.ne.ntstart_run.or.nrrec.eq.0)).or.                     &
+     &      (iic.ge.ntsDIA.and.nDIA.eq.1)) THEN
+          IF (nDIA.eq.1) THEN
+            DIAtime=step%time
+          ELSE
+            DIAtime=DIAtime+REAL(nDIA,r8)*dt
+          END IF
+          IF ((iic.gt.ntstart_run.and.MOD(iic-1,nDIA).eq.0).or.(iic.ge.ntsDIA.and.nDIA.eq.1)) THEN
+            CALL out_record (fDIA, ierr)
+          END IF
+        END IF
+      END IF
       END SUBROUTINE output
+!
+!  the tracer terms of DIAGNOSTICS_TS in the library's order (include/roms_hip.h) -- index in DiaTrc (mod_scalars.F:4246-4262:
+!  0 = the option set has no such term), variable suffix and attribute fragments of varinfo.yaml
+      INTEGER FUNCTION dia_ndt ()
+      dia_ndt=6
+      IF (IAND(options,ROMS_TS_DIF2).ne.0) THEN
+        dia_ndt=9
+        IF (IAND(options,IOR(ROMS_MIX_GEO_TS,ROMS_MIX_ISO_TS)).ne.0) dia_ndt=10
+      END IF
+      END FUNCTION dia_ndt
+      INTEGER FUNCTION dia_term_index (k)
+      integer, intent(in) :: k
+      integer :: ic
+      logical :: dif, rot
+      dif=IAND(options,ROMS_TS_DIF2).ne.0
+      rot=dif.and.IAND(options,IOR(ROMS_MIX_GEO_TS,ROMS_MIX_ISO_TS)).ne.0
+      ic=4
+      IF (dif) ic=7
+      IF (rot) ic=8
+      SELECT CASE (k)
+        CASE (0:3); dia_term_index=k+1
+        CASE (4:6); dia_term_index=MERGE(k+1, 0, dif)
+        CASE (7);   dia_term_index=MERGE(8, 0, rot)
+        CASE (8);   dia_term_index=ic+1
+        CASE DEFAULT; dia_term_index=ic+2
+      END SELECT
+      END FUNCTION dia_term_index
+      FUNCTION dia_suffix (k) RESULT (s)
+      integer, intent(in) :: k
+      character(len=8) :: s
+      character(len=8), parameter :: t(0:9) = [ character(len=8) :: '_hadv', '_xadv', '_yadv', '_vadv', '_hdiff', '_xdiff',  &
+     &                                          '_ydiff', '_sdiff', '_vdiff', '_rate' ]
+      s=t(k)
+      END FUNCTION dia_suffix
+      FUNCTION dia_std (k) RESULT (s)
+      integer, intent(in) :: k
+      character(len=48) :: s
+      character(len=48), parameter :: t(0:9) = [ character(len=48) :: '_tendency_due_to_horizontal_advection',             &
+     &   '_tendency_due_to_horizontal_x_advection', '_tendency_due_to_horizontal_y_advection',                            &
+     &   '_tendency_due_to_vertical_advection', '_tendency_due_to_horizontal_diffusion',                                  &
+     &   '_tendency_due_to_horizontal_x_diffusion', '_tendency_due_to_horizontal_y_diffusion',                            &
+     &   '_tendency_due_to_horizontal_s_diffusion', '_tendency_due_to_vertical_diffusion', '_tendency' ]
+      s=t(k)
+      END FUNCTION dia_std
+      FUNCTION dia_long (k) RESULT (s)
+      integer, intent(in) :: k
+      character(len=48) :: s
+      character(len=48), parameter :: t(0:9) = [ character(len=48) :: 'horizontal advection term',                         &
+     &   'horizontal XI-advection term', 'horizontal ETA-advection term', 'vertical advection term',                      &
+     &   'horizontal diffusion term', 'horizontal XI-diffusion term', 'horizontal ETA-diffusion term',                     &
+     &   'horizontal S-diffusion rotated tensor term', 'vertical diffusion term', 'time rate of change' ]
+      s=t(k)
+      END FUNCTION dia_long
+      FUNCTION dia_fld (k) RESULT (s)
+      integer, intent(in) :: k
+      character(len=24) :: s
+      character(len=24), parameter :: t(0:9) = [ character(len=24) :: 'horizontal advection', 'x-advection', 'y-advection',  &
+     &   'vertical advection', 'horizontal diffusion', 'x-diffusion', 'y-difusion', 's-diffusion', 'vertical diffusion',    &
+     &   'acceleration' ]
+      s=t(k)
+      END FUNCTION dia_fld
 !
 !  nsteps passes of main3d with the output calls of main3d.F:591 in between; final: also the records of
 !  the step that is not taken (iic = ntend+1, main3d.F:595).  mode 0: fused roms_hip_main3d, 1: kernel by kernel.
@@ -1044,6 +1176,10 @@
         END IF
         IF (nAVG.gt.0) THEN
           nxt=nAVG-MOD(iic-1,nAVG)
+          chunk=MIN(chunk,nxt)
+        END IF
+        IF (nDIA.gt.0) THEN
+          nxt=nDIA-MOD(iic-1,nDIA)
           chunk=MIN(chunk,nxt)
         END IF
         IF (mode.eq.0) THEN

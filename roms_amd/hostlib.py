@@ -105,15 +105,15 @@ def write_roms_in(path, p):
                           ("gls_sigp", "GLS_SIGP"), ("charnok_alpha", "CHARNOK_ALPHA"), ("crgban_cw", "CRGBAN_CW")):
             lines.append(f"{name:>14} == {d(p[key])}")
     # output (optional keys): NRREC, NRST, NHIS, LcycleRST, file names, Hout switches by their roms.in ids
-    for key in ("NRREC", "NRST", "NHIS", "NAVG", "NTSAVG"):
+    for key in ("NRREC", "NRST", "NHIS", "NAVG", "NTSAVG", "NDIA", "NTSDIA"):
         if key in p:
             lines.append(f"{key:>12} == {int(p[key])}")
     if "LcycleRST" in p:
         lines.append(f"   LcycleRST == {'T' if p['LcycleRST'] else 'F'}")
-    for key in ("ININAME", "RSTNAME", "HISNAME", "AVGNAME"):
+    for key in ("ININAME", "RSTNAME", "HISNAME", "AVGNAME", "DIANAME"):
         if key in p:
             lines.append(f"{key:>12} == {p[key]}")
-    for sw in ("Hout", "Aout"):
+    for sw in ("Hout", "Aout", "Dout"):
         for vid, val in p.get(sw, {}).items():
             val = val if isinstance(val, (tuple, list)) else (val,)
             lines.append(f"{sw}({vid}) == " + " ".join("T" if x else "F" for x in val))

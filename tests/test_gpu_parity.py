@@ -781,6 +781,47 @@ def test_poisoned_work_arrays_change_nothing(tag, kw, monkeypatch):
         assert np.array_equal(a[n], b[n]), (tag, kw, n)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,kw,nDIA,ntsDIA", [
+    ("upwelling_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), 3, 1),
+    ("upwelling_small", dict(hadv=("A4", "C2"), vadv=("SPLINES", "C2")), 2, 2),
+    ("benchmark_small", {}, 2, 1), ("overflow_small", {}, 1, 1), ("upwelling_mask_small", {}, 3, 1)])
+def test_tracer_diagnostics_match_oracle(tag, kw, nDIA, ntsDIA, monkeypatch):
+    """DIAGNOSTICS_TS (mod_diags.F, set_diags.F; the stores in pre_step3d.F, step3d_t.F, t3dmix2_*.h) on the GPU against the
+    oracle pinned to the reference: DiaTwrk, DiaTrc and avgzeta after every step of several windows -- terms are
+    differences of fields that agree to round-off: 1e-10 of the largest term, exact where the run has no transcendentals;
+    the prognostic fields are the bits of the run without diagnostics; a second run with poisoned work arrays gives the
+    same bits (the term stores are per-tracer: no shared scratch)."""
+    cs, g = _case_state(tag, kw)
+    plain = _end_state(cs, g, 7)
+    ends = []
+    for poison in ("0", "1"):
+        monkeypatch.setenv("ROMS_HIP_POISON", poison)
+        O = util.make_oracle(cs, g)
+        H = util.make_hip(cs, g)
+        O.set_dia_window(nDIA, ntsDIA)
+        H.dia_config(nDIA, ntsDIA)
+        O.start()
+        H.start()
+        seen = 0
+        for step in range(1, 8):
+            O.main3d_step()
+            H.main3d(1)
+            for n in ("DiaTwrk", "DiaTrc", "dia_zeta"):
+                a, b = H.download(n), O.field(n)
+                scale = max(np.abs(b).max(), 1e-300)
+                assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-10 * scale, (tag, step, n, np.abs(a - b).max() / scale)
+            seen += int(np.abs(O.field("DiaTrc")).max() > 0.0)
+        assert seen >= 4
+        H.sync()
+        ends.append({n: H.download(n).copy() for n in ("DiaTwrk", "DiaTrc", "dia_zeta", "t", "u", "zeta")})
+        H.close()
+    for n in ends[0]:
+        assert np.array_equal(ends[0][n], ends[1][n]), (tag, n, "poisoned scratch / run-to-run difference")
+    for n in ("t", "u", "zeta"):
+        assert np.array_equal(ends[0][n], plain[n]), (tag, n, "the diagnostics changed the run")
+
+
 XI_PARTNER = dict(u="v", ubar="vbar", Huon="Hvom", ru="rv", DU_avg1="DV_avg1", DU_avg2="DV_avg2", rufrc="rvfrc", rubar="rvbar",
                   sustr="svstr", bustr="bvstr")
 

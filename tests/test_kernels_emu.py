@@ -485,3 +485,33 @@ def test_launch_order_and_poisoned_scratch_change_nothing(emu, tag, kw, monkeypa
             monkeypatch.delenv(k)
         for n in a:
             assert np.array_equal(a[n], b[n], equal_nan=True), (tag, env, n)
+
+
+@pytest.mark.parametrize("tag,kw,nDIA,ntsDIA", [
+    ("upwelling_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), 3, 1),           # roms_upwelling.in's schemes
+    ("upwelling_small", dict(hadv=("A4", "C2"), vadv=("SPLINES", "C2")), 2, 2),
+    ("benchmark_small", {}, 2, 1),                                                           # geopotential mixing: the S-diffusion term
+    ("overflow_small", {}, 1, 1),                                                            # isopycnic mixing, both tracers on splines
+    ("upwelling_mask_small", {}, 3, 1)])
+def test_tracer_diagnostics_bitwise(emu, tag, kw, nDIA, ntsDIA):
+    """DIAGNOSTICS_TS on the emulated kernels: DiaTwrk, DiaTrc and avgzeta after every step of several windows against the
+    oracle (pinned to the reference built from upwelling.h as shipped: tests/test_oracle_vs_ref.py::test_set_diags_bitwise),
+    bit for bit; the prognostic fields unchanged by the switch."""
+    from tests.test_gpu_parity import _case_state
+    cs, g = _case_state(tag, kw)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.set_dia_window(nDIA, ntsDIA)
+    H.dia_config(nDIA, ntsDIA)
+    O.start()
+    H.start()
+    seen = 0
+    for step in range(1, 8):
+        O.main3d_step()
+        H.main3d(1)
+        for n in ("DiaTwrk", "DiaTrc", "dia_zeta", "t", "u", "zeta"):
+            a, b = H.download(n), O.field(n)
+            assert np.array_equal(a, b), (tag, step, n, int((a != b).sum()))
+        seen += int(np.abs(O.field("DiaTrc")).max() > 0.0)
+    assert seen >= 4
+    H.close()

@@ -271,13 +271,14 @@ def _run_tiles(tmp_path, spec, tiles, port):
 
 def test_tiles_write_the_file_a_single_tile_writes_and_restart_from_it(tmp_path):
     """2x2 ranks (gloo): every rank calls the writer, rank 0 gathers and writes (wrt_his over mp_gather): every variable
-    of the history and restart files equals the single-tile run's; then the four tiles restart from the SINGLE-tile
+    of the history, restart, averages and diagnostics files equals the single-tile run's; then the four tiles restart from the SINGLE-tile
     restart file (record of step 3), each uploading its window, and 2 steps later hold the single-tile run's state of
     step 5 bit for bit."""
     _libs("emu")
     fields = ["zeta", "ubar", "vbar", "u", "v", "t"]
     upd1 = dict(NHIS=2, NRST=3, HISNAME=str(tmp_path / "his1.nc"), RSTNAME=str(tmp_path / "rst1.nc"), Hout=HOUT, LcycleRST=False,
-                NAVG=2, NTSAVG=1, AVGNAME=str(tmp_path / "avg1.nc"), Aout=AOUT)
+                NAVG=2, NTSAVG=1, AVGNAME=str(tmp_path / "avg1.nc"), Aout=AOUT,
+                NDIA=2, NTSDIA=1, DIANAME=str(tmp_path / "dia1.nc"), Dout=DOUT)
     cs = util.case_for("benchmark_small")
     cs.update(upd1, ninfo=0)
     H, ctx = _host(cs, "emu")
@@ -285,9 +286,10 @@ def test_tiles_write_the_file_a_single_tile_writes_and_restart_from_it(tmp_path)
     H.close_output()
     want = {n: ctx.download(n).copy() for n in fields}            # (single-tile array layout = the gathered layout)
     H.finalize()
-    upd4 = dict(upd1, HISNAME=str(tmp_path / "his4.nc"), RSTNAME=str(tmp_path / "rst4.nc"), AVGNAME=str(tmp_path / "avg4.nc"))
+    upd4 = dict(upd1, HISNAME=str(tmp_path / "his4.nc"), RSTNAME=str(tmp_path / "rst4.nc"), AVGNAME=str(tmp_path / "avg4.nc"),
+                DIANAME=str(tmp_path / "dia4.nc"))
     _run_tiles(tmp_path, dict(tag="benchmark_small", steps=5, fields=fields, case_update=upd4, advance=True), (2, 2), 29631)
-    for one, four in (("his1.nc", "his4.nc"), ("rst1.nc", "rst4.nc"), ("avg1.nc", "avg4.nc")):
+    for one, four in (("his1.nc", "his4.nc"), ("rst1.nc", "rst4.nc"), ("avg1.nc", "avg4.nc"), ("dia1.nc", "dia4.nc")):
         a, b = _nc(str(tmp_path / one)), _nc(str(tmp_path / four))
         assert list(a.variables) == list(b.variables)
         for n in a.variables:
@@ -466,6 +468,73 @@ def test_averages_file_holds_the_reference_set_avg_fields(which, tmp_path):
             b = V[name][rec]
             assert np.array_equal(a, b) if exact else util.relrms(b, a) <= 1e-11, (step, name)
     assert np.abs(V["uv"][1]).max() > 0.0
+    f.close()
+
+
+DOUT = {"iTrate": (True, True), "iThadv": (True, True), "iTxadv": (True, False), "iTyadv": (True, True), "iTvadv": (True, True),
+        "iThdif": (True, True), "iTxdif": (True, True), "iTydif": (True, True), "iTsdif": (True, True), "iTvdif": (True, True)}
+DIA_TERMS = ("hadv", "xadv", "yadv", "vadv", "hdiff", "xdiff", "ydiff", "sdiff", "vdiff", "rate")
+
+
+@pytest.mark.parametrize("which", LIBS)
+@pytest.mark.parametrize("tag,ndt", [("upwelling_small", 9), ("benchmark_small", 10)])
+def test_diagnostics_file_holds_the_reference_set_diags_terms(which, tag, ndt, tmp_path):
+    """DIAGNOSTICS_TS: NDIA = 3 over 7 steps: two records stamped with the centre of their windows (def_diags.F:944,
+    set_diags.F:379), holding zeta and, per tracer and Dout(iT...) switch, DiaTrc / dt (wrt_diags.F:285-310) as the oracle's
+    set_diags -- pinned to the reference's -- holds them at those steps; named as mod_ncparam.F composes the names from
+    varinfo.yaml; temp_sdiff only where the mixing tensor is rotated; the switch that is off (salt_xadv) leaves its
+    variable out; the terms of a window close: rate = hadv + vadv + hdiff + vdiff; the run itself is unchanged."""
+    cs = util.case_for(tag)
+    dia = str(tmp_path / "roms_dia.nc")
+    g = util.load_init(tag, util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    O.set_dia_window(3, 1)
+    O.start()
+    want = {}
+    for step in range(1, 8):
+        O.main3d_step()
+        if step in (4, 7):
+            want[step] = {n: O.field(n).copy() for n in ("DiaTrc", "dia_zeta")}
+    ufinal = O.field("u").copy()
+    cs.update(NDIA=3, NTSDIA=1, DIANAME=dia, Dout=DOUT, ninfo=0)
+    H, ctx = _host(cs, which)
+    H.advance(7, final=False)
+    t = H.tile
+    got_u = ctx.download("u")
+    H.close_output()
+    H.finalize()
+    exact = which == "emu"
+    assert np.array_equal(got_u, ufinal) if exact else util.relrms(got_u, ufinal) < 1e-11
+    f = _nc(dia)
+    assert f.type == b"ROMS diagnostics file"
+    V = f.variables
+    assert list(V["ocean_time"][:]) == [1.5 * cs["dt"], 4.5 * cs["dt"]]
+    assert V["ocean_time"].long_name == b"averaged time since initialization"
+    terms = [x for x in DIA_TERMS if ndt == 10 or x != "sdiff"]
+    names = {f"{tr}_{x}" for tr in ("temp", "salt") for x in terms} - {"salt_xadv"}
+    assert names | {"zeta"} <= set(V) and "salt_xadv" not in V and ("temp_sdiff" in V) == (ndt == 10)
+    assert V["temp_hadv"].dimensions == ("ocean_time", "s_rho", "eta_rho", "xi_rho")
+    assert V["temp_hadv"].long_name == b"potential temperature, horizontal advection term"
+    assert V["temp_rate"].units == b"Celsius second-1" and V["salt_vdiff"].long_name == b"salinity, vertical diffusion term"
+    ni, nj = t["UBi"] - t["LBi"] + 1, t["UBj"] - t["LBj"] + 1
+    Lm, Mm, N = cs["Lm"], cs["Mm"], cs["N"]
+    win = lambda a: a[..., 0 - t["LBj"]:Mm + 2 - t["LBj"], 0 - t["LBi"]:Lm + 2 - t["LBi"]]
+    order = [x for x in DIA_TERMS[:4]] + ([x for x in DIA_TERMS[4:7]]) + (["sdiff"] if ndt == 10 else []) + ["vdiff", "rate"]
+    for rec, step in enumerate((4, 7)):
+        a = win(want[step]["dia_zeta"].reshape(nj, ni))
+        assert np.array_equal(a, V["zeta"][rec]) if exact else util.relrms(V["zeta"][rec], a) <= 1e-11
+        D = want[step]["DiaTrc"].reshape(ndt, 2, N, nj, ni)
+        for it, tr in enumerate(("temp", "salt")):
+            for k, x in enumerate(order):
+                if f"{tr}_{x}" not in names:
+                    continue
+                a = win(D[k, it]) * (1.0 / cs["dt"])
+                b = V[f"{tr}_{x}"][rec]
+                assert np.array_equal(a, b) if exact else np.abs(b - a).max() <= 1e-11 * max(np.abs(a).max(), 1e-30), (step, tr, x)
+        # the budget of the window closes (interior points)
+        r = V["temp_rate"][rec][:, 1:-1, 1:-1]
+        s = sum(V[f"temp_{x}"][rec][:, 1:-1, 1:-1] for x in ("hadv", "vadv", "hdiff", "vdiff"))
+        assert np.abs(r).max() > 0.0 and np.abs(r - s).max() <= 1e-9 * np.abs(r).max()
     f.close()
 
 

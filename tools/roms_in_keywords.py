@@ -19,7 +19,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 REF = "/root/reference/ROMS/Utility/read_phypar.F"
 
 HONOURED = """TITLE MyAppCPP Lm Mm N NAT NtileI NtileJ NTIMES DT NDTFAST NINFO Hadvection Vadvection NRREC LcycleRST NRST NHIS
-ININAME RSTNAME HISNAME NAVG NTSAVG AVGNAME TNU2 VISC2 AKT_BAK AKV_BAK RDRG RDRG2 Zob Zos BLK_ZQ BLK_ZT BLK_ZW WTYPE
+ININAME RSTNAME HISNAME NAVG NTSAVG AVGNAME NDIA NTSDIA DIANAME TNU2 VISC2 AKT_BAK AKV_BAK RDRG RDRG2 Zob Zos BLK_ZQ BLK_ZT BLK_ZW WTYPE
 Vtransform Vstretching THETA_S THETA_B TCLINE RHO0 DSTART TIME_REF R0 T0 S0 TCOEF SCOEF GAMMA2
 TNUDG ZNUDG M2NUDG M3NUDG OBCFAC
 AKK_BAK AKP_BAK GLS_P GLS_M GLS_N GLS_Kmin GLS_Pmin GLS_CMU0 GLS_C1 GLS_C2 GLS_C3M GLS_C3P GLS_SIGK GLS_SIGP CHARNOK_ALPHA CRGBAN_CW""".split()
@@ -69,6 +69,8 @@ def classify(k):
     m = re.match(r"^(Aout|Hout)\((\w+)\)$", k)
     if m and m.group(2) in (HONOURED_AOUT if m.group(1) == "Aout" else HONOURED_HOUT):
         return "honoured", "switch of the averages / history writer (roms_output.f90)"
+    if re.match(r"^Dout\(iT(rate|hadv|xadv|yadv|vadv|hdif|xdif|ydif|sdif|vdif)\)$", k):
+        return "honoured", "switch of the diagnostics writer, tracer terms (DIAGNOSTICS_TS; roms_output.f90)"
     if k in CHECKED:
         return "checked", CHECKED[k]
     for rx, why in INERT_RULES:
