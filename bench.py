@@ -306,6 +306,46 @@ def cpu_baseline(cs, H, budget_s=15.0):
                       f"alone: {cells / per_step:.3g} cell-updates/s"}
 
 
+def reference_leg(workload, cs, budget_s=12.0):
+    """The reference's OWN object code (oracle/_ref/libromsref_<app>.so: the reference's Fortran where it lies, built by
+    oracle/ref/build_ref.sh in the build container; it travels to the GPU box as a built library, its sources do not) on ONE
+    host core: main3d steps 2..n of the same workload, n sized to `budget_s` from the time of step 1.  In a process of its
+    own (the reference keeps its state in Fortran modules).  None when the library is absent."""
+    import subprocess
+    app = {"benchmark": "benchmark", "upwelling_kpp": "upwelling_kpp"}.get(cs["app"], "upwelling")
+    root = os.path.dirname(os.path.abspath(__file__))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", f"libromsref_{app}.so")):
+        return None
+    code = (
+        "import sys, json, time, resource\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))\n"
+        "import bench\n"
+        "from tests import refdrive as rd\n"
+        f"cs = bench.params_for({workload!r}, {cs['Lm']}, {cs['Mm']}, {cs['N']}, ntimes=400)\n"
+        "saved = rd.quiet()\n"
+        f"R = rd.reference({app!r}, cs)\n"
+        "t0 = time.perf_counter(); R.main3d(1); t1 = time.perf_counter()\n"
+        f"n = max(2, min(200, int({budget_s} / max(t1 - t0, 1e-4))))\n"
+        "R.main3d(n); t2 = time.perf_counter()\n"
+        "rd.unquiet(saved)\n"
+        "print(json.dumps(dict(n=n, first=t1 - t0, span=t2 - t1)))\n")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"value": None, "kind": "reference", "sample": "the reference library did not run here: " +
+                    (p.stderr.strip().splitlines() or ["?"])[-1][:200]}
+        r = json.loads(lines[-1])
+    except (subprocess.TimeoutExpired, ValueError) as e:
+        return {"value": None, "kind": "reference", "sample": f"the reference library did not run here: {e}"}
+    cells = cs["Lm"] * cs["Mm"] * cs["N"]
+    return {"value": cells * r["n"] / r["span"], "unit": "grid-cell-updates/sec", "cores": 1, "kind": "reference",
+            "sample": f"{cs['app'].upper()} {cs['Lm']}x{cs['Mm']}x{cs['N']}, main3d steps 2..{r['n'] + 1} of the reference's own "
+                      f"object code (oracle/_ref/libromsref_{app}.so, amdflang -O2, serial), {r['span']:.1f} s"}
+
+
 def multi_gpu_plan(world, workload, explicit_dims):
     """(workload, (NtileI, NtileJ) or None, weak) of a run on `world` GPUs.  The default workload on 2/4/8 GPUs is
     BASELINE.json's own multi-GPU configuration: BENCHMARK2 1024x128x30 in NtileI x NtileJ = 2x2 on 4 GPUs (tile
@@ -432,9 +472,14 @@ def main():
         cs0 = params_for(args.workload, args.Lm, args.Mm, args.N, ntimes=10)
         H0 = _hl.Host(params=cs0)
         try:
-            print(json.dumps(cpu_baseline(cs0, H0, budget_s=float(os.environ.get("ROMS_BENCH_CPU_BUDGET", "15")))), flush=True)
+            cb = cpu_baseline(cs0, H0, budget_s=float(os.environ.get("ROMS_BENCH_CPU_BUDGET", "15")))
         finally:
             H0.finalize()
+        # ... and the reference's own Fortran on one core beside it (after the port's replicas: the cores are idle again)
+        ref1 = reference_leg(args.workload, cs0, budget_s=float(os.environ.get("ROMS_BENCH_REF_BUDGET", "12")))
+        if ref1 is not None:
+            cb["reference_1core"] = ref1
+        print(json.dumps(cb), flush=True)
         return
     if not os.path.exists("/dev/kfd"):
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
