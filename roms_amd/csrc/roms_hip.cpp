@@ -1808,11 +1808,13 @@ static int main3d_one(roms_hip_ctx *c) {
     static const char *ept = getenv("ROMS_HIP_EARLY_T3");
     const bool early = ept ? ept[0] != '0' : (long)(c->G.T.Iend - c->G.T.Istr + 1) * (c->G.T.Jend - c->G.T.Jstr + 1) <= 64L * 1024L;
     if (!r && early) { r = run_pre_t3(c); c->pre_t3_ready = r == 0; }
+    // set_diags :559 reads the terms of the PREVIOUS step in DiaTwrk, which pre_step3d (main stream, behind the partial
+    // join) starts to overwrite: it runs ahead of the join point, not beside it like set_avg
+    if (!r && c->G.dia_ts && c->dia_nDIA > 0 && c->dia_done_iic != s.iic) r = run_set_diags(c);
     side_point(c);
     if (!r) r = diag_now();
     if (!r) r = roms_hip_wvelocity(c, s.nstp);     // overwrites wvel, which diag reads: same stream, in order
     if (!r && c->avg_nAVG > 0 && c->avg_done_iic != s.iic) r = run_set_avg(c, 0);      // :562
-    if (!r && c->G.dia_ts && c->dia_nDIA > 0 && c->dia_done_iic != s.iic) r = run_set_diags(c);   // :559
   } else {
     r = diag_now();
   }

@@ -283,6 +283,39 @@ def make_avg():
     print("wrote upwelling_small_avg.npz", len(out), "arrays")
 
 
+def make_dia():
+    """upwelling_small_dia.npz: DiaTwrk, DiaTrc and avgzeta of the reference's set_diags.F (reference built from
+    ROMS/Include/upwelling.h AS SHIPPED -- DIAGNOSTICS_TS defined -- oracle/ref/build_ref.sh upwelling_diag) after steps 4
+    and 7 of a run with nDIA = 3, ntsDIA = 1 (the window-closing calls: DiaTrc converted, ghost points filled), and DiaTwrk
+    at the end of step 5 (the raw terms of one step) -- stepped through the reference's kernel wrappers in main3d's order
+    with set_diags behind set_zeta (main3d.F:559)."""
+    from tests import refdrive as rd
+    from tests import refchild
+    app, cs = rd.make_case("upwelling_diag_small")
+    saved = rd.quiet()
+    R = rd.reference(app, cs)
+    R.L.ref_set_dia_window(3, 1, 0, 1)
+    nfast = R.bounds(0)[58]
+    st = dict(iic=1, iif=1, nstp=1, nnew=1, nrhs=1, kstp=1, knew=1, krhs=1, predictor=0, indx1=1, time=0.0, nfast=nfast)
+    out = {}
+    for step in range(1, 8):
+        for kern, s_ in rd.main3d_sequence(cs, st, first=(step == 1)):
+            R.set_stepping(s_["iic"], s_.get("iif", 1), s_["nstp"], s_["nnew"], s_["nrhs"], s_.get("kstp", 1),
+                           s_.get("knew", 1), s_.get("krhs", 1), s_.get("predictor", 0), s_["time"], s_["indx1"])
+            R.call(kern)
+            if kern == "set_zeta":
+                R.call("set_diags")
+                if step in (4, 7):
+                    for n in ("DiaTrc", "dia_zeta"):
+                        out[f"s{step}_{n}"] = R.get(n)
+        if step == 5:
+            out["e5_DiaTwrk"] = R.get("DiaTwrk")
+            out["e5_t"] = R.get("t")
+    os.dup2(saved, 1)
+    np.savez_compressed(os.path.join(HERE, "upwelling_small_dia.npz"), nDIA=3, ntsDIA=1, **out)
+    print("wrote upwelling_small_dia.npz", len(out), "arrays", float(np.abs(out["s7_DiaTrc"]).max()))
+
+
 # (round 3: the full-size cases run 12 steps -- past the start-up branches iic <= ntfirst + 1, into the AB3 steady state)
 SAMPLES = [("upwelling", 100), ("benchmark1", 100), ("benchmark2", 12), ("benchmark3", 12), ("ns512", 12), ("ns512u3", 12),
            ("config5", 12)]
@@ -299,9 +332,12 @@ if __name__ == "__main__":
         make_sample(sys.argv[2], int(sys.argv[3]))
     elif len(sys.argv) > 1 and sys.argv[1] == "--avg":
         make_avg()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--dia":
+        make_dia()
     elif len(sys.argv) > 1 and sys.argv[1] == "--reference-runs":
         py = sys.executable
         subprocess.check_call([py, __file__, "--avg"])
+        subprocess.check_call([py, __file__, "--dia"])
         for name, tag, args in STEP_CASES:
             subprocess.check_call([py, __file__, "--steps", name, tag] + args)
             if name in KERNEL_CASES:

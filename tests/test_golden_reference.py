@@ -98,3 +98,23 @@ def test_oracle_set_avg_matches_reference_fixture():
                 assert np.array_equal(O.field(key[3:]), z[key]), key
                 n += 1
     assert n == 44
+
+
+def test_oracle_set_diags_matches_reference_fixture():
+    """tests/golden/upwelling_small_dia.npz: the per-term tracer tendencies the reference's own set_diags.F held after the
+    window-closing steps 4 and 7 (nDIA = 3), and the raw terms DiaTwrk at the end of step 5 (written by make_golden.py --dia
+    from the reference built from upwelling.h as shipped, DIAGNOSTICS_TS on): the oracle's, bit for bit, anywhere."""
+    z = np.load(os.path.join(util.GOLDEN, "upwelling_small_dia.npz"))
+    cs = util.case_for("upwelling_small")
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    O.set_dia_window(int(z["nDIA"]), int(z["ntsDIA"]))
+    O.start()
+    n = 0
+    for step in range(1, 8):
+        O.main3d_step()
+        for key in z.files:
+            if key.startswith(f"s{step}_") or key.startswith(f"e{step}_"):
+                assert np.array_equal(O.field(key[3:]), z[key]), key
+                n += 1
+    assert n == 6 and np.abs(z["s7_DiaTrc"]).max() > 0.0

@@ -121,18 +121,41 @@ def test_time_averages_match_reference_fixture():
     H.close()
 
 
+def test_tracer_diagnostics_match_reference_fixture():
+    """DIAGNOSTICS_TS on the GPU (term stores in the tracer kernels, set_diags inside roms_hip_main3d) against the arrays the
+    reference's own code held (tests/golden/upwelling_small_dia.npz: DiaTrc and avgzeta at the window-closing steps 4 and
+    7, the raw terms DiaTwrk at the end of step 5): 1e-10 of the largest term."""
+    z = np.load(os.path.join(util.GOLDEN, "upwelling_small_dia.npz"))
+    cs = util.case_for("upwelling_small")
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    H = util.make_hip(cs, g)
+    H.dia_config(int(z["nDIA"]), int(z["ntsDIA"]))
+    H.start()
+    n = 0
+    for step in range(1, 8):
+        H.main3d(1)
+        for key in z.files:
+            if key.startswith(f"s{step}_") or key.startswith(f"e{step}_"):
+                a, b = H.download(key[3:]), z[key]
+                assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max(), (key, np.abs(a - b).max() / np.abs(b).max())
+                n += 1
+    assert n == 6
+    H.close()
+
+
 def test_romsM_runs_the_shipped_upwelling_case_with_all_its_files(tmp_path):
     """The UPWELLING test case as the reference ships it -- 1440 steps of 300 s, NHIS = 72, NRST = 288 (recycled),
     NAVG = 72, the Hout/Aout switches of roms_upwelling.in, AVERAGES from upwelling.h's option list -- through the
-    stand-alone driver on the GPU: 21 history records, the last two restart records, 20 averages records stamped at
-    their window centres; the 5-day solution is finite, has spun up an upwelling circulation and conserves volume."""
+    stand-alone driver on the GPU: 21 history records, the last two restart records, 20 averages and 20 diagnostics records
+    stamped at their window centres; the 5-day solution is finite, has spun up an upwelling circulation and conserves volume."""
     import subprocess
     from scipy.io import netcdf_file
     from roms_amd import hostlib, cases
-    from tests.test_output import HOUT, AOUT
+    from tests.test_output import HOUT, AOUT, DOUT
     exe = os.path.join(os.path.dirname(hostlib.LIB), "romsM")
     cs = cases.upwelling(ntimes=1440)
-    cs.update(NHIS=72, NRST=288, LcycleRST=True, NAVG=72, NTSAVG=1, Hout=HOUT, Aout=AOUT, ninfo=72)
+    cs.update(NHIS=72, NRST=288, LcycleRST=True, NAVG=72, NTSAVG=1, Hout=HOUT, Aout=AOUT, ninfo=72,
+              NDIA=72, NTSDIA=1, Dout=DOUT)
     inp = str(tmp_path / "roms_upwelling.in")
     hostlib.write_roms_in(inp, cs)
     r = subprocess.run([exe, inp], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
@@ -152,5 +175,18 @@ def test_romsM_runs_the_shipped_upwelling_case_with_all_its_files(tmp_path):
     # the average of the last window lies between the history records that bracket it
     za, z0, z1 = avg.variables["temp"][-1], his.variables["temp"][-2], his.variables["temp"][-1]
     assert np.abs(za - 0.5 * (z0 + z1)).max() < 0.5
-    for f in (his, rst, avg):
+    # ... and the diagnostics file (DIAGNOSTICS_TS of upwelling.h, NDIA = 72): 20 records at the window centres; the terms
+    # of the last window close the temperature budget, and the mean rate of change is, to the change of the layer thicknesses, the
+    # change between the history records that bracket the window
+    dia = netcdf_file(str(tmp_path / "roms_dia.nc"), "r", mmap=False)
+    td = dia.variables["ocean_time"][:]
+    assert len(td) == 20 and td[0] == 36 * 300.0 and np.all(np.diff(td) == 72 * 300.0)
+    V = dia.variables
+    rate = V["temp_rate"][-1][:, 1:-1, 1:-1]
+    budget = sum(V[f"temp_{x}"][-1][:, 1:-1, 1:-1] for x in ("hadv", "vadv", "hdiff", "vdiff"))
+    assert np.abs(rate).max() > 0.0 and np.abs(rate - budget).max() <= 1e-9 * np.abs(rate).max()
+    assert np.abs(V["temp_hadv"][-1] - V["temp_xadv"][-1] - V["temp_yadv"][-1]).max() <= 1e-12 * np.abs(V["temp_hadv"][-1]).max()
+    dT = (z1 - z0)[:, 1:-1, 1:-1] / (72 * 300.0)
+    assert np.abs(rate - dT).max() <= 0.05 * max(np.abs(dT).max(), 1e-12)      # (the terms are thickness-weighted: step3d_t.F:1383-1411)
+    for f in (his, rst, avg, dia):
         f.close()
