@@ -281,13 +281,9 @@ THREAD_KERNEL(k_mp_wa, MpArgs) {
 THREAD_GLOBAL(k_mp_wa, MpArgs)
 
 // ---- FCT ratios beta_up, beta_dn :862-1090; index space (IstrU-1:Iendp1, JstrV-1:Jendp1, 1:N) -
-THREAD_KERNEL(k_mp_beta, MpArgs) {
-  const DGrid &G = a.G;
-  const Fields &F = a.Fv;
-  const TB &B = G.T;
-  const int N = G.N, itrc = a.itrc;
-  const int i = B.IstrU - 1 + gx, j = B.JstrV - 1 + gy, k = gz + 1;
-  if (i > B.Iendp1 || j > B.Jendp1) return;
+// the two ratios of one point (the expressions of :862-1090 for entry (i,j,k))
+KDEV void mp_beta_pt(const DGrid &G, const Fields &F, int itrc, int i, int j, int k, double &b_up, double &b_dn) {
+  const int N = G.N;
   const double eps = 1.0E-18;
   const double *Ta = F.mp3[0] + (size_t)(itrc - 1) * G.nij * N, *Ua = F.mp3[1], *Va = F.mp3[2], *Wa = F.mp3[3];
   const double *T3 = F.t + XT(G.LBi, G.LBj, 1, 3, itrc);
@@ -316,12 +312,23 @@ THREAD_KERNEL(k_mp_beta, MpArgs) {
                 MP_TA(i, j - 1, k) * KMAX(0.0, Va[X3(i, j, k)]) - MP_TA(i, j + 1, k) * KMIN(0.0, Va[X3(i, j + 1, k)]);
   if (k > 1) cff1 = cff1 + MP_TA(i, j, k - 1) * KMAX(0.0, Wa[XW(i, j, k - 1)]);
   if (k < N) cff1 = cff1 - MP_TA(i, j, k + 1) * KMIN(0.0, Wa[XW(i, j, k)]);
-  F.mp3[4][X3(i, j, k)] = (Tmax - MP_TA(i, j, k)) / (cff1 + eps);
+  b_up = (Tmax - MP_TA(i, j, k)) / (cff1 + eps);
   double cff2 = MP_TA(i, j, k) * KMAX(0.0, Ua[X3(i + 1, j, k)]) - MP_TA(i, j, k) * KMIN(0.0, Ua[X3(i, j, k)]) +
                 MP_TA(i, j, k) * KMAX(0.0, Va[X3(i, j + 1, k)]) - MP_TA(i, j, k) * KMIN(0.0, Va[X3(i, j, k)]);
   if (k < N) cff2 = cff2 + MP_TA(i, j, k) * KMAX(0.0, Wa[XW(i, j, k)]);
   if (k > 1) cff2 = cff2 - MP_TA(i, j, k) * KMIN(0.0, Wa[XW(i, j, k - 1)]);
-  F.mp3[5][X3(i, j, k)] = (MP_TA(i, j, k) - Tmin) / (cff2 + eps);
+  b_dn = (MP_TA(i, j, k) - Tmin) / (cff2 + eps);
+}
+THREAD_KERNEL(k_mp_beta, MpArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const TB &B = G.T;
+  const int i = B.IstrU - 1 + gx, j = B.JstrV - 1 + gy, k = gz + 1;
+  if (i > B.Iendp1 || j > B.Jendp1) return;
+  double bu, bd;
+  mp_beta_pt(G, F, a.itrc, i, j, k, bu, bd);
+  F.mp3[4][X3(i, j, k)] = bu;
+  F.mp3[5][X3(i, j, k)] = bd;
 }
 THREAD_GLOBAL(k_mp_beta, MpArgs)
 
@@ -398,14 +405,13 @@ THREAD_GLOBAL(k_mp_apply, MpArgs)
 //      of its cell itself (a face velocity is limited by both cells that share it: same expression,
 //      same bits) instead of a pass that rewrites Ua, Va, Wa in place and a second one that reads them;
 //      Ua, Va, Wa stay unlimited in memory (nothing else reads them).  (Istr:Iend, Jstr:Jend, 1:N)
-THREAD_KERNEL(k_mp_limapply, MpArgs) {
-  const DGrid &G = a.G;
-  const Fields &F = a.Fv;
+// BUP(ii, jj, kk), BDN(ii, jj, kk): the FCT ratios of a point -- the arrays of k_mp_beta, or the LDS levels of k_mp_limfused
+template <class FU, class FD>
+KDEV void mp_limapply_pt(const DGrid &G, const Fields &F, int itrc, int i, int j, int k, FU BUP, FD BDN) {
   const TB &B = G.T;
-  const int N = G.N, itrc = a.itrc;
-  const int i = B.Istr + gx, j = B.Jstr + gy, k = gz + 1;
+  const int N = G.N;
   const double *Ta = F.mp3[0] + (size_t)(itrc - 1) * G.nij * N, *Ua = F.mp3[1], *Va = F.mp3[2], *Wa = F.mp3[3];
-  const double *bup = F.mp3[4], *bdn = F.mp3[5], *z_r = F.z_r, *Hz = F.Hz;
+  const double *z_r = F.z_r, *Hz = F.Hz;
   double *tn = F.t + XT(G.LBi, G.LBj, 1, G.nnew, itrc);
   const double odt = 1.0 / G.dt;
   const bool wc = !G.ewp && B.west, ec = !G.ewp && B.east, sc = !G.nsp && B.south, nc = !G.nsp && B.north;
@@ -414,18 +420,18 @@ THREAD_KERNEL(k_mp_limapply, MpArgs) {
 #define MP_LU(ii)                                                                                         \
   (((wc && (ii) == B.Istr) || (ec && (ii) == B.Iend + 1))                                                 \
        ? 0.0                                                                                              \
-       : (KMIN(KMIN(bdn[X3((ii) - 1, j, k)], bup[X3(ii, j, k)]), 1.0) * KMAX(0.0, Ua[X3(ii, j, k)]) +     \
-          KMIN(KMIN(bup[X3((ii) - 1, j, k)], bdn[X3(ii, j, k)]), 1.0) * KMIN(0.0, Ua[X3(ii, j, k)])) *    \
+       : (KMIN(KMIN(BDN((ii) - 1, j, k), BUP(ii, j, k)), 1.0) * KMAX(0.0, Ua[X3(ii, j, k)]) +     \
+          KMIN(KMIN(BUP((ii) - 1, j, k), BDN(ii, j, k)), 1.0) * KMIN(0.0, Ua[X3(ii, j, k)])) *    \
              odt * F.om_u[X2(ii, j)] * (G.masking ? G.umask[X2(ii, j)] : 1.0))
 #define MP_LV(jj)                                                                                         \
   (((sc && (jj) == B.Jstr) || (nc && (jj) == B.Jend + 1))                                                 \
        ? 0.0                                                                                              \
-       : (KMIN(KMIN(bdn[X3(i, (jj) - 1, k)], bup[X3(i, jj, k)]), 1.0) * KMAX(0.0, Va[X3(i, jj, k)]) +     \
-          KMIN(KMIN(bup[X3(i, (jj) - 1, k)], bdn[X3(i, jj, k)]), 1.0) * KMIN(0.0, Va[X3(i, jj, k)])) *    \
+       : (KMIN(KMIN(BDN(i, (jj) - 1, k), BUP(i, jj, k)), 1.0) * KMAX(0.0, Va[X3(i, jj, k)]) +     \
+          KMIN(KMIN(BUP(i, (jj) - 1, k), BDN(i, jj, k)), 1.0) * KMIN(0.0, Va[X3(i, jj, k)])) *    \
              odt * F.on_v[X2(i, jj)] * (G.masking ? G.vmask[X2(i, jj)] : 1.0))
 #define MP_LW(kk)                                                                                         \
-  ((KMIN(KMIN(bdn[X3(i, j, kk)], bup[X3(i, j, (kk) + 1)]), 1.0) * KMAX(0.0, Wa[XW(i, j, kk)]) +           \
-    KMIN(KMIN(bup[X3(i, j, kk)], bdn[X3(i, j, (kk) + 1)]), 1.0) * KMIN(0.0, Wa[XW(i, j, kk)])) *          \
+  ((KMIN(KMIN(BDN(i, j, kk), BUP(i, j, (kk) + 1)), 1.0) * KMAX(0.0, Wa[XW(i, j, kk)]) +           \
+    KMIN(KMIN(BUP(i, j, kk), BDN(i, j, (kk) + 1)), 1.0) * KMIN(0.0, Wa[XW(i, j, kk)])) *          \
    odt * F.omn[X2(i, j)] * (z_r[X3(i, j, (kk) + 1)] - z_r[X3(i, j, kk)]) * (G.masking ? G.rmask[X2(i, j)] : 1.0))
   const double ua0 = MP_LU(i), ua1 = MP_LU(i + 1), va0 = MP_LV(j), va1 = MP_LV(j + 1);
   const double ta = MP_TA(i, j, k);
@@ -448,6 +454,14 @@ THREAD_KERNEL(k_mp_limapply, MpArgs) {
 #undef MP_LW
 #undef MP_FX
 #undef MP_FE
+}
+THREAD_KERNEL(k_mp_limapply, MpArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const double *bup = F.mp3[4], *bdn = F.mp3[5];
+  mp_limapply_pt(G, F, a.itrc, G.T.Istr + gx, G.T.Jstr + gy, gz + 1,
+                 [&](int ii, int jj, int kk) { return bup[X3(ii, jj, kk)]; },
+                 [&](int ii, int jj, int kk) { return bdn[X3(ii, jj, kk)]; });
 }
 THREAD_GLOBAL(k_mp_limapply, MpArgs)
 

@@ -569,6 +569,7 @@ def test_column_kernel_forms_agree_bitwise(workload, dims):
                            # columns and parts of them
                            ("prenew_march", {"ROMS_HIP_PRENEW_MARCH": "1"}),
                            ("prenew_march_parts", {"ROMS_HIP_PRENEW_MARCH": "1", "ROMS_HIP_PRENEW_PARTS": "3"})):
+
             f = os.path.join(td, tag + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True,
                                env=dict(os.environ, **extra), timeout=600)
