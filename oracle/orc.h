@@ -167,6 +167,7 @@ typedef struct orc_s {
   double diag[16];
   void *avg;                             /* time-averaged fields (orc_avg.c), NULL until orc_set_avg_window */
   void *dia;                             /* per-term tracer tendencies, DIAGNOSTICS_TS (orc_diags.c), NULL until orc_set_dia_window */
+  struct orc_diauv *duv;                 /* per-term momentum tendencies, DIAGNOSTICS_UV (orc_diags_uv.c), NULL until orc_set_diauv */
 } orc_t;
 
 /* ---- index helpers (valid inside functions that define LBi,LBj,ni,nij,N) ---- */
@@ -203,6 +204,8 @@ void orc_exchange3d(const orc_t *o, const orc_bounds *b, char grid, double *A, i
 void orc_bc_r2d(const orc_t *o, const orc_bounds *b, double *A);
 void orc_bc_u2d(const orc_t *o, const orc_bounds *b, double *A);
 void orc_bc_v2d(const orc_t *o, const orc_bounds *b, double *A);
+void orc_bc_u3d(const orc_t *o, const orc_bounds *b, double *A, int nk);
+void orc_bc_v3d(const orc_t *o, const orc_bounds *b, double *A, int nk);
 void orc_bc_w3d(const orc_t *o, const orc_bounds *b, double *A, int nk);
 /* state BCs: zetabc.F u2dbc_im.F v2dbc_im.F t3dbc_im.F u3dbc_im.F v3dbc_im.F */
 void orc_zetabc(const orc_t *o, const orc_bounds *b, int kout);
@@ -266,6 +269,30 @@ double *orc_dia_field(orc_t *o, const char *name, long *nel);
 int orc_dia_ndt(const orc_t *o);
 double orc_dia_time(const orc_t *o);
 void orc_dia_free(orc_t *o);
+/* per-term momentum tendencies (DIAGNOSTICS_UV): mod_diags.F:174-222, the term indices of mod_scalars.F:4264-4377 for the
+   option set (1-based, 0 = the option set has no such term), arrays laid out as the reference's */
+typedef struct orc_diauv {
+  int NDM2d, NDM3d, NDrhs;
+  int M2fcor, M2hadv, M2xadv, M2yadv, M2hvis, M2xvis, M2yvis, M2pgrd, M2sstr, M2bstr, M2rate;
+  int M3fcor, M3vadv, M3hadv, M3xadv, M3yadv, M3pgrd, M3vvis, M3hvis, M3xvis, M3yvis, M3rate;
+  double *U2wrk, *V2wrk;       /* (i,j,NDM2d) */
+  double *RUbar, *RVbar;       /* (i,j,2,NDM2d-1) */
+  double *U2int, *V2int;       /* (i,j,NDM2d) */
+  double *RUfrc, *RVfrc;       /* (i,j,3,NDM2d-1) */
+  double *U3wrk, *V3wrk;       /* (i,j,N,NDM3d) */
+  double *RU, *RV;             /* (i,j,N,2,NDrhs) */
+  double *U2d, *V2d, *U3d, *V3d;   /* the accumulated output of set_diags */
+} orc_diauv;
+int orc_set_diauv(orc_t *o);                 /* allocate (the window is the one of orc_set_dia_window) */
+void orc_diauv_free(orc_t *o);
+void orc_set_diags_uv(orc_t *o, int tile, int init, int accum, int convert, double fac);
+double *orc_diauv_field(orc_t *o, const char *name, long *nel);
+/* element (i,j[,k]) of term `id` (1-based) of the arrays above; ORC_LOCALS in scope */
+#define DU2(a, i, j, id) (a)[X2(i, j) + (size_t)((id) - 1) * nij]
+#define DUB(a, i, j, lev, id) (a)[X2(i, j) + (size_t)((lev) - 1 + 2 * ((id) - 1)) * nij]
+#define DUF(a, i, j, lev, id) (a)[X2(i, j) + (size_t)((lev) - 1 + 3 * ((id) - 1)) * nij]
+#define DU3(a, i, j, k, id) (a)[X3(i, j, k) + (size_t)((id) - 1) * (size_t)N * nij]
+#define DUR(a, i, j, k, lev, id) (a)[X3(i, j, k) + (size_t)((lev) - 1 + 2 * ((id) - 1)) * (size_t)N * nij]
 
 /* one baroclinic step, main3d.F:216-1148 */
 int orc_main3d_step(orc_t *o);

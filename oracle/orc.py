@@ -154,11 +154,14 @@ class Oracle:
         """allocate the time-averaged fields ("avg_zeta" ... "avg_HvomT") and set the window of set_avg.F"""
         self.L.orc_set_avg_window(C.c_void_p(self.h), int(nAVG), int(ntsAVG), int(nrrec), int(ntstart))
 
-    def set_dia_window(self, nDIA, ntsDIA=1, nrrec=0, ntstart=1):
-        """allocate the per-term tracer tendencies ("DiaTwrk", "DiaTrc", "dia_zeta") and set the window of set_diags.F"""
+    def set_dia_window(self, nDIA, ntsDIA=1, nrrec=0, ntstart=1, uv=False):
+        """allocate the per-term tracer tendencies ("DiaTwrk", "DiaTrc", "dia_zeta") and set the window of set_diags.F;
+        uv: the momentum terms too (DIAGNOSTICS_UV: "DiaU2wrk", "DiaU3wrk", "DiaRU", "DiaRUfrc", ... "DiaU2d", "DiaU3d")"""
         r = self.L.orc_set_dia_window(C.c_void_p(self.h), int(nDIA), int(ntsDIA), int(nrrec), int(ntstart))
         if r:
             raise ValueError("DIAGNOSTICS_TS with MPDATA tracers is not covered by the oracle")
+        if uv:
+            self.L.orc_set_diauv(C.c_void_p(self.h))
 
     def start(self):
         self.L.orc_start(self.h)

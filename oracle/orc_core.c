@@ -344,17 +344,17 @@ void orc_bc_w3d(const orc_t *o, const orc_bounds *b, double *A, int nk) {
 }
 
 /* bc_u2d_tile bc_2d.F:164: LBC(:,isBu2d = isUbar)%closed, else zero gradient (:201-290) */
-void orc_bc_u2d(const orc_t *o, const orc_bounds *b, double *A) {
+static void bc_u_plane(const orc_t *o, const orc_bounds *b, double *A, int ORC_ISUBAR_) {
   ORC_LOCALS(o);
   const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
   const double gamma2 = o->c.gamma2;
   if (!o->c.EWperiodic) {
     if (b->east) {
-      if (orc_lbc(o, ORC_IEAST, ORC_ISUBAR) == ORC_LBC_CLO) for (int j = Jstr; j <= Jend; j++) A[X2(Iend + 1, j)] = 0.0;
+      if (orc_lbc(o, ORC_IEAST, ORC_ISUBAR_) == ORC_LBC_CLO) for (int j = Jstr; j <= Jend; j++) A[X2(Iend + 1, j)] = 0.0;
       else for (int j = Jstr; j <= Jend; j++) A[X2(Iend + 1, j)] = A[X2(Iend, j)];
     }
     if (b->west) {
-      if (orc_lbc(o, ORC_IWEST, ORC_ISUBAR) == ORC_LBC_CLO) for (int j = Jstr; j <= Jend; j++) A[X2(Istr, j)] = 0.0;
+      if (orc_lbc(o, ORC_IWEST, ORC_ISUBAR_) == ORC_LBC_CLO) for (int j = Jstr; j <= Jend; j++) A[X2(Istr, j)] = 0.0;
       else for (int j = Jstr; j <= Jend; j++) A[X2(Istr, j)] = A[X2(Istr + 1, j)];
     }
   }
@@ -362,11 +362,11 @@ void orc_bc_u2d(const orc_t *o, const orc_bounds *b, double *A) {
     int Imin = o->c.EWperiodic ? b->IstrU : b->Istr, Imax = o->c.EWperiodic ? b->Iend : b->IendR;
     const double *M = (o->c.options & ORC_MASKING) ? o->umask : NULL;   /* bc_2d.F:252,278 */
     if (b->north) {
-      if (orc_lbc(o, ORC_INORTH, ORC_ISUBAR) == ORC_LBC_CLO) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
+      if (orc_lbc(o, ORC_INORTH, ORC_ISUBAR_) == ORC_LBC_CLO) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jend + 1)] = gamma2 * A[X2(i, Jend)]; if (M) A[X2(i, Jend + 1)] = A[X2(i, Jend + 1)] * M[X2(i, Jend + 1)]; }
       else for (int i = b->IstrU; i <= Iend; i++) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
     }
     if (b->south) {
-      if (orc_lbc(o, ORC_ISOUTH, ORC_ISUBAR) == ORC_LBC_CLO) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
+      if (orc_lbc(o, ORC_ISOUTH, ORC_ISUBAR_) == ORC_LBC_CLO) for (int i = Imin; i <= Imax; i++) { A[X2(i, Jstr - 1)] = gamma2 * A[X2(i, Jstr)]; if (M) A[X2(i, Jstr - 1)] = A[X2(i, Jstr - 1)] * M[X2(i, Jstr - 1)]; }
       else for (int i = b->IstrU; i <= Iend; i++) A[X2(i, Jstr - 1)] = A[X2(i, Jstr)];
     }
   }
@@ -376,11 +376,10 @@ void orc_bc_u2d(const orc_t *o, const orc_bounds *b, double *A) {
     if (b->nw) A[X2(Istr, Jend + 1)] = 0.5 * (A[X2(Istr, Jend)] + A[X2(Istr + 1, Jend + 1)]);
     if (b->ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend + 1, Jend)] + A[X2(Iend, Jend + 1)]);
   }
-  orc_exchange2d(o, b, 'u', A);
 }
 
 /* bc_v2d_tile bc_2d.F:342: LBC(:,isBv2d = isVbar)%closed, else zero gradient (:380-470) */
-void orc_bc_v2d(const orc_t *o, const orc_bounds *b, double *A) {
+static void bc_v_plane(const orc_t *o, const orc_bounds *b, double *A, int ORC_ISVBAR_) {
   ORC_LOCALS(o);
   const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
   const double gamma2 = o->c.gamma2;
@@ -388,21 +387,21 @@ void orc_bc_v2d(const orc_t *o, const orc_bounds *b, double *A) {
     int Jmin = o->c.NSperiodic ? b->JstrV : b->Jstr, Jmax = o->c.NSperiodic ? b->Jend : b->JendR;
     const double *M = (o->c.options & ORC_MASKING) ? o->vmask : NULL;   /* bc_2d.F:392,418 */
     if (b->east) {
-      if (orc_lbc(o, ORC_IEAST, ORC_ISVBAR) == ORC_LBC_CLO) for (int j = Jmin; j <= Jmax; j++) { A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
+      if (orc_lbc(o, ORC_IEAST, ORC_ISVBAR_) == ORC_LBC_CLO) for (int j = Jmin; j <= Jmax; j++) { A[X2(Iend + 1, j)] = gamma2 * A[X2(Iend, j)]; if (M) A[X2(Iend + 1, j)] = A[X2(Iend + 1, j)] * M[X2(Iend + 1, j)]; }
       else for (int j = b->JstrV; j <= Jend; j++) A[X2(Iend + 1, j)] = A[X2(Iend, j)];
     }
     if (b->west) {
-      if (orc_lbc(o, ORC_IWEST, ORC_ISVBAR) == ORC_LBC_CLO) for (int j = Jmin; j <= Jmax; j++) { A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
+      if (orc_lbc(o, ORC_IWEST, ORC_ISVBAR_) == ORC_LBC_CLO) for (int j = Jmin; j <= Jmax; j++) { A[X2(Istr - 1, j)] = gamma2 * A[X2(Istr, j)]; if (M) A[X2(Istr - 1, j)] = A[X2(Istr - 1, j)] * M[X2(Istr - 1, j)]; }
       else for (int j = b->JstrV; j <= Jend; j++) A[X2(Istr - 1, j)] = A[X2(Istr, j)];
     }
   }
   if (!o->c.NSperiodic) {
     if (b->north) {
-      if (orc_lbc(o, ORC_INORTH, ORC_ISVBAR) == ORC_LBC_CLO) for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = 0.0;
+      if (orc_lbc(o, ORC_INORTH, ORC_ISVBAR_) == ORC_LBC_CLO) for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = 0.0;
       else for (int i = Istr; i <= Iend; i++) A[X2(i, Jend + 1)] = A[X2(i, Jend)];
     }
     if (b->south) {
-      if (orc_lbc(o, ORC_ISOUTH, ORC_ISVBAR) == ORC_LBC_CLO) for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr)] = 0.0;
+      if (orc_lbc(o, ORC_ISOUTH, ORC_ISVBAR_) == ORC_LBC_CLO) for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr)] = 0.0;
       else for (int i = Istr; i <= Iend; i++) A[X2(i, Jstr)] = A[X2(i, Jstr + 1)];
     }
   }
@@ -412,7 +411,18 @@ void orc_bc_v2d(const orc_t *o, const orc_bounds *b, double *A) {
     if (b->nw) A[X2(Istr - 1, Jend + 1)] = 0.5 * (A[X2(Istr - 1, Jend)] + A[X2(Istr, Jend + 1)]);
     if (b->ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend + 1, Jend)] + A[X2(Iend, Jend + 1)]);
   }
-  orc_exchange2d(o, b, 'v', A);
+}
+
+void orc_bc_u2d(const orc_t *o, const orc_bounds *b, double *A) { bc_u_plane(o, b, A, ORC_ISUBAR); orc_exchange2d(o, b, 'u', A); }
+void orc_bc_v2d(const orc_t *o, const orc_bounds *b, double *A) { bc_v_plane(o, b, A, ORC_ISVBAR); orc_exchange2d(o, b, 'v', A); }
+/* bc_u3d_tile, bc_v3d_tile bc_3d.F:164, :367: the same level by level with LBC(:,isBu3d = isUvel) / (:,isBv3d = isVvel) */
+void orc_bc_u3d(const orc_t *o, const orc_bounds *b, double *A, int nk) {
+  for (int k = 0; k < nk; k++) bc_u_plane(o, b, A + (size_t)k * o->nij, ORC_ISUVEL);
+  orc_exchange3d(o, b, 'u', A, nk);
+}
+void orc_bc_v3d(const orc_t *o, const orc_bounds *b, double *A, int nk) {
+  for (int k = 0; k < nk; k++) bc_v_plane(o, b, A + (size_t)k * o->nij, ORC_ISVVEL);
+  orc_exchange3d(o, b, 'v', A, nk);
 }
 
 /* the lateral boundary conditions of the state (zetabc.F ... t3dbc_im.F), closed and open: orc_obc.c */

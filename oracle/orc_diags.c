@@ -52,6 +52,7 @@ int orc_set_dia_window(orc_t *o, int nDIA, int ntsDIA, int nrrec, int ntstart) {
 }
 void orc_dia_free(orc_t *o) {
   dia_state *s = (dia_state *)o->dia;
+  orc_diauv_free(o);
   if (!s) return;
   free(s->wrk); free(s->trc); free(s->avgzeta); free(s);
   o->dia = NULL;
@@ -70,8 +71,7 @@ double *orc_dia_field(orc_t *o, const char *name, long *nel) {
     if (!strcmp(name, "DiaTrc")) { if (nel) *nel = n; return s->trc; }
     if (!strcmp(name, "dia_zeta")) { if (nel) *nel = (long)o->nij; return s->avgzeta; }
   }
-  if (nel) *nel = -1;
-  return NULL;
+  return orc_diauv_field(o, name, nel);
 }
 double orc_dia_time(const orc_t *o) { return o->dia ? ((const dia_state *)o->dia)->diatime : 0.0; }
 
@@ -87,6 +87,7 @@ void orc_set_diags(orc_t *o, int tile) {
   const int accum = !init && iic > ntsDIA;
   const int convert = (iic > ntsDIA && (iic - 1) % nDIA == 0 && (iic != s->ntstart || s->nrrec == 0)) || (iic >= ntsDIA && nDIA == 1);
   const size_t blk = (size_t)N * nij;
+  orc_set_diags_uv(o, tile, init, accum, convert, 1.0 / (double)nDIA);       /* the momentum terms (orc_diags_uv.c) */
   if (init || accum) {
     for (int j = b->JstrR; j <= b->JendR; j++)
       for (int i = b->IstrR; i <= b->IendR; i++)

@@ -351,6 +351,12 @@ void orc_pre_step3d(orc_t *o, int tile) {
           cff1 = u[X4(i, j, k, nstp)] * 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]);
           cff2 = CX(FC, i, k) - CX(FC, i, k - 1);
           u[X4(i, j, k, nnew)] = cff1 + cff2;
+          if (o->duv) {                                                          /* pre_step3d.F:979-984 */
+            const orc_diauv *d = o->duv;
+            for (int id = 1; id <= d->M3pgrd; id++) DU3(d->U3wrk, i, j, k, id) = 0.0;
+            DU3(d->U3wrk, i, j, k, d->M3vvis) = cff2;
+            DU3(d->U3wrk, i, j, k, d->M3rate) = cff1;
+          }
         }
     } else if (iic == c->ntfirst + 1) {
       for (int k = 1; k <= N; k++)
@@ -359,6 +365,12 @@ void orc_pre_step3d(orc_t *o, int tile) {
           cff2 = CX(FC, i, k) - CX(FC, i, k - 1);
           cff3 = 0.5 * CX(DC, i, 0);
           u[X4(i, j, k, nnew)] = cff1 - cff3 * ru[XW4(i, j, k, indx)] + cff2;
+          if (o->duv) {                                                          /* :998-1007 */
+            const orc_diauv *d = o->duv;
+            for (int id = 1; id <= d->M3pgrd; id++) DU3(d->U3wrk, i, j, k, id) = -cff3 * DUR(d->RU, i, j, k, indx, id);
+            DU3(d->U3wrk, i, j, k, d->M3vvis) = cff2;
+            DU3(d->U3wrk, i, j, k, d->M3rate) = cff1;
+          }
         }
     } else {
       cff1 = 5.0 / 12.0;
@@ -369,6 +381,13 @@ void orc_pre_step3d(orc_t *o, int tile) {
           cff4 = CX(FC, i, k) - CX(FC, i, k - 1);
           u[X4(i, j, k, nnew)] =
               cff3 + CX(DC, i, 0) * (cff1 * ru[XW4(i, j, k, nrhs)] - cff2 * ru[XW4(i, j, k, indx)]) + cff4;
+          if (o->duv) {                                                          /* :1022-1035 */
+            const orc_diauv *d = o->duv;
+            for (int id = 1; id <= d->M3pgrd; id++)
+              DU3(d->U3wrk, i, j, k, id) = CX(DC, i, 0) * (cff1 * DUR(d->RU, i, j, k, nrhs, id) - cff2 * DUR(d->RU, i, j, k, indx, id));
+            DU3(d->U3wrk, i, j, k, d->M3vvis) = cff4;
+            DU3(d->U3wrk, i, j, k, d->M3rate) = cff3;
+          }
         }
     }
     if (j >= JstrV) {
@@ -392,6 +411,12 @@ void orc_pre_step3d(orc_t *o, int tile) {
             cff1 = v[X4(i, j, k, nstp)] * 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]);
             cff2 = CX(FC, i, k) - CX(FC, i, k - 1);
             v[X4(i, j, k, nnew)] = cff1 + cff2;
+            if (o->duv) {                                                          /* pre_step3d.F:979-984 */
+              const orc_diauv *d = o->duv;
+              for (int id = 1; id <= d->M3pgrd; id++) DU3(d->V3wrk, i, j, k, id) = 0.0;
+              DU3(d->V3wrk, i, j, k, d->M3vvis) = cff2;
+              DU3(d->V3wrk, i, j, k, d->M3rate) = cff1;
+            }
           }
       } else if (iic == c->ntfirst + 1) {
         for (int k = 1; k <= N; k++)
@@ -400,6 +425,12 @@ void orc_pre_step3d(orc_t *o, int tile) {
             cff2 = CX(FC, i, k) - CX(FC, i, k - 1);
             cff3 = 0.5 * CX(DC, i, 0);
             v[X4(i, j, k, nnew)] = cff1 - cff3 * rv[XW4(i, j, k, indx)] + cff2;
+            if (o->duv) {                                                          /* :998-1007 */
+              const orc_diauv *d = o->duv;
+              for (int id = 1; id <= d->M3pgrd; id++) DU3(d->V3wrk, i, j, k, id) = -cff3 * DUR(d->RV, i, j, k, indx, id);
+              DU3(d->V3wrk, i, j, k, d->M3vvis) = cff2;
+              DU3(d->V3wrk, i, j, k, d->M3rate) = cff1;
+            }
           }
       } else {
         cff1 = 5.0 / 12.0;
@@ -410,6 +441,13 @@ void orc_pre_step3d(orc_t *o, int tile) {
             cff4 = CX(FC, i, k) - CX(FC, i, k - 1);
             v[X4(i, j, k, nnew)] =
                 cff3 + CX(DC, i, 0) * (cff1 * rv[XW4(i, j, k, nrhs)] - cff2 * rv[XW4(i, j, k, indx)]) + cff4;
+            if (o->duv) {                                                          /* :1022-1035 */
+              const orc_diauv *d = o->duv;
+              for (int id = 1; id <= d->M3pgrd; id++)
+                DU3(d->V3wrk, i, j, k, id) = CX(DC, i, 0) * (cff1 * DUR(d->RV, i, j, k, nrhs, id) - cff2 * DUR(d->RV, i, j, k, indx, id));
+              DU3(d->V3wrk, i, j, k, d->M3vvis) = cff4;
+              DU3(d->V3wrk, i, j, k, d->M3rate) = cff3;
+            }
           }
       }
     }
@@ -528,9 +566,25 @@ static void orc_prsgrd40(orc_t *o, int tile) {
   free(P); free(FX); free(FC);
 }
 
+static void orc_prsgrd32(orc_t *o, int tile);
 void orc_prsgrd(orc_t *o, int tile) {
-  if (o->c.options & ORC_PRSGRD40) { orc_prsgrd40(o, tile); return; }
-  if (o->c.options & ORC_PRSGRD31) { orc_prsgrd31(o, tile); return; }
+  if (o->c.options & ORC_PRSGRD40) orc_prsgrd40(o, tile);
+  else if (o->c.options & ORC_PRSGRD31) orc_prsgrd31(o, tile);
+  else orc_prsgrd32(o, tile);
+  if (o->duv) {        /* DIAGNOSTICS_UV: DiaRU(i,j,k,nrhs,M3pgrd) = ru(i,j,k,nrhs) where every scheme assigns it (prsgrd32.h:364, :428) */
+    ORC_LOCALS(o);
+    const orc_bounds *b = &o->b[tile];
+    const orc_diauv *d = o->duv;
+    const int nrhs = o->s.nrhs;
+    for (int k = 1; k <= N; k++) {
+      for (int j = b->Jstr; j <= b->Jend; j++)
+        for (int i = b->IstrU; i <= b->Iend; i++) DUR(d->RU, i, j, k, nrhs, d->M3pgrd) = o->ru[XW4(i, j, k, nrhs)];
+      for (int j = b->JstrV; j <= b->Jend; j++)
+        for (int i = b->Istr; i <= b->Iend; i++) DUR(d->RV, i, j, k, nrhs, d->M3pgrd) = o->rv[XW4(i, j, k, nrhs)];
+    }
+  }
+}
+static void orc_prsgrd32(orc_t *o, int tile) {
   ORC_LOCALS(o);
   const orc_bounds *b = &o->b[tile];
   const int nrhs = o->s.nrhs;
@@ -753,6 +807,15 @@ void orc_uv3dmix2(orc_t *o, int tile) {
         cff3 = cff * (cff1 + cff2);
         o->rufrc[X2(i, j)] = o->rufrc[X2(i, j)] + cff1 + cff2;
         u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] + cff3;
+        if (o->duv) {                                                            /* uv3dmix2_s.h:303-308 */
+          const orc_diauv *d = o->duv;
+          DUF(d->RUfrc, i, j, 3, d->M2hvis) = DUF(d->RUfrc, i, j, 3, d->M2hvis) + cff1 + cff2;
+          DUF(d->RUfrc, i, j, 3, d->M2xvis) = DUF(d->RUfrc, i, j, 3, d->M2xvis) + cff1;
+          DUF(d->RUfrc, i, j, 3, d->M2yvis) = DUF(d->RUfrc, i, j, 3, d->M2yvis) + cff2;
+          DU3(d->U3wrk, i, j, k, d->M3hvis) = cff3;
+          DU3(d->U3wrk, i, j, k, d->M3xvis) = cff * cff1;
+          DU3(d->U3wrk, i, j, k, d->M3yvis) = cff * cff2;
+        }
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -762,6 +825,15 @@ void orc_uv3dmix2(orc_t *o, int tile) {
         cff3 = cff * (cff1 - cff2);
         o->rvfrc[X2(i, j)] = o->rvfrc[X2(i, j)] + cff1 - cff2;
         v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] + cff3;
+        if (o->duv) {                                                            /* :321-326 */
+          const orc_diauv *d = o->duv;
+          DUF(d->RVfrc, i, j, 3, d->M2hvis) = DUF(d->RVfrc, i, j, 3, d->M2hvis) + cff1 - cff2;
+          DUF(d->RVfrc, i, j, 3, d->M2xvis) = DUF(d->RVfrc, i, j, 3, d->M2xvis) + cff1;
+          DUF(d->RVfrc, i, j, 3, d->M2yvis) = DUF(d->RVfrc, i, j, 3, d->M2yvis) - cff2;
+          DU3(d->V3wrk, i, j, k, d->M3hvis) = cff3;
+          DU3(d->V3wrk, i, j, k, d->M3xvis) = cff * cff1;
+          DU3(d->V3wrk, i, j, k, d->M3yvis) = -cff * cff2;
+        }
       }
   }
   free(UFe);
@@ -784,6 +856,9 @@ void orc_rhs3d_tile(orc_t *o, int tile) {
          *UFe = S + 5 * nij, *VFx = S + 6 * nij, *VFe = S + 7 * nij, *uee = S + 8 * nij,
          *uxx = S + 9 * nij, *vee = S + 10 * nij, *vxx = S + 11 * nij;
   double *FC = (double *)calloc(ni * (size_t)(N + 1), sizeof(double));
+  const orc_diauv *d = o->duv;                      /* DIAGNOSTICS_UV: the stores of rhs3d.F under that option */
+  const int curv = (c->options & ORC_CURVGRID) && (c->options & ORC_UV_ADV);
+  double *Uwrk = d && curv ? (double *)calloc(2 * nij, sizeof(double)) : NULL, *Vwrk = Uwrk ? Uwrk + nij : NULL;
 #define U(i, j, k) u[X4(i, j, k, nrhs)]
 #define V(i, j, k) v[X4(i, j, k, nrhs)]
 #define RU(i, j, k) ru[XW4(i, j, k, nrhs)]
@@ -801,11 +876,13 @@ void orc_rhs3d_tile(orc_t *o, int tile) {
         for (int i = IstrU; i <= Iend; i++) {
           cff1 = 0.5 * (UFx[X2(i, j)] + UFx[X2(i - 1, j)]);
           RU(i, j, k) = RU(i, j, k) + cff1;
+          if (d) DUR(d->RU, i, j, k, nrhs, d->M3fcor) = cff1;                     /* :520 */
         }
       for (int j = JstrV; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {
           cff1 = 0.5 * (VFe[X2(i, j)] + VFe[X2(i, j - 1)]);
           RV(i, j, k) = RV(i, j, k) - cff1;
+          if (d) DUR(d->RV, i, j, k, nrhs, d->M3fcor) = -cff1;                    /* :529 */
         }
     }
     if ((c->options & ORC_CURVGRID) && (c->options & ORC_UV_ADV)) {
@@ -819,16 +896,33 @@ void orc_rhs3d_tile(orc_t *o, int tile) {
           cff = Hz[X3(i, j, k)] * (cff3 - cff4);
           UFx[X2(i, j)] = cff * cff1;
           VFe[X2(i, j)] = cff * cff2;
+          if (d) {                                                                /* :601-604 */
+            cff = Hz[X3(i, j, k)] * cff4;
+            Uwrk[X2(i, j)] = -cff * cff1;
+            Vwrk[X2(i, j)] = -cff * cff2;
+          }
         }
       for (int j = Jstr; j <= Jend; j++)
         for (int i = IstrU; i <= Iend; i++) {
           cff1 = 0.5 * (UFx[X2(i, j)] + UFx[X2(i - 1, j)]);
           RU(i, j, k) = RU(i, j, k) + cff1;
+          if (d) {                                                                /* :617-625 */
+            cff2 = 0.5 * (Uwrk[X2(i, j)] + Uwrk[X2(i - 1, j)]);
+            DUR(d->RU, i, j, k, nrhs, d->M3xadv) = cff1 - cff2;
+            DUR(d->RU, i, j, k, nrhs, d->M3yadv) = cff2;
+            DUR(d->RU, i, j, k, nrhs, d->M3hadv) = cff1;
+          }
         }
       for (int j = JstrV; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {
           cff1 = 0.5 * (VFe[X2(i, j)] + VFe[X2(i, j - 1)]);
           RV(i, j, k) = RV(i, j, k) - cff1;
+          if (d) {                                                                /* :635-643 */
+            cff2 = 0.5 * (Vwrk[X2(i, j)] + Vwrk[X2(i, j - 1)]);
+            DUR(d->RV, i, j, k, nrhs, d->M3xadv) = -cff1 + cff2;
+            DUR(d->RV, i, j, k, nrhs, d->M3yadv) = -cff2;
+            DUR(d->RV, i, j, k, nrhs, d->M3hadv) = -cff1;
+          }
         }
     }
     if (!(c->options & ORC_UV_ADV)) continue;
@@ -929,6 +1023,17 @@ void orc_rhs3d_tile(orc_t *o, int tile) {
         cff2 = UFe[X2(i, j + 1)] - UFe[X2(i, j)];
         cff = cff1 + cff2;
         RU(i, j, k) = RU(i, j, k) - cff;
+        if (d) {                                                                  /* :971-980 */
+          if (curv) {
+            DUR(d->RU, i, j, k, nrhs, d->M3xadv) = DUR(d->RU, i, j, k, nrhs, d->M3xadv) - cff1;
+            DUR(d->RU, i, j, k, nrhs, d->M3yadv) = DUR(d->RU, i, j, k, nrhs, d->M3yadv) - cff2;
+            DUR(d->RU, i, j, k, nrhs, d->M3hadv) = DUR(d->RU, i, j, k, nrhs, d->M3hadv) - cff;
+          } else {
+            DUR(d->RU, i, j, k, nrhs, d->M3xadv) = -cff1;
+            DUR(d->RU, i, j, k, nrhs, d->M3yadv) = -cff2;
+            DUR(d->RU, i, j, k, nrhs, d->M3hadv) = -cff;
+          }
+        }
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -936,6 +1041,17 @@ void orc_rhs3d_tile(orc_t *o, int tile) {
         cff2 = VFe[X2(i, j)] - VFe[X2(i, j - 1)];
         cff = cff1 + cff2;
         RV(i, j, k) = RV(i, j, k) - cff;
+        if (d) {                                                                  /* :990-999 */
+          if (curv) {
+            DUR(d->RV, i, j, k, nrhs, d->M3xadv) = DUR(d->RV, i, j, k, nrhs, d->M3xadv) - cff1;
+            DUR(d->RV, i, j, k, nrhs, d->M3yadv) = DUR(d->RV, i, j, k, nrhs, d->M3yadv) - cff2;
+            DUR(d->RV, i, j, k, nrhs, d->M3hadv) = DUR(d->RV, i, j, k, nrhs, d->M3hadv) - cff;
+          } else {
+            DUR(d->RV, i, j, k, nrhs, d->M3xadv) = -cff1;
+            DUR(d->RV, i, j, k, nrhs, d->M3yadv) = -cff2;
+            DUR(d->RV, i, j, k, nrhs, d->M3hadv) = -cff;
+          }
+        }
       }
   }
 
@@ -963,6 +1079,7 @@ void orc_rhs3d_tile(orc_t *o, int tile) {
         for (int i = IstrU; i <= Iend; i++) {
           cff = CX(FC, i, k) - CX(FC, i, k - 1);
           RU(i, j, k) = RU(i, j, k) - cff;
+          if (d) DUR(d->RU, i, j, k, nrhs, d->M3vadv) = -cff;                      /* :1173 */
         }
       if (j >= JstrV) {
         for (int k = 2; k <= N - 2; k++)
@@ -984,32 +1101,66 @@ void orc_rhs3d_tile(orc_t *o, int tile) {
           for (int i = Istr; i <= Iend; i++) {
             cff = CX(FC, i, k) - CX(FC, i, k - 1);
             RV(i, j, k) = RV(i, j, k) - cff;
+            if (d) DUR(d->RV, i, j, k, nrhs, d->M3vadv) = -cff;                    /* :1323 */
           }
       }
     }
     for (int i = IstrU; i <= Iend; i++) o->rufrc[X2(i, j)] = RU(i, j, 1);
     for (int k = 2; k <= N; k++)
       for (int i = IstrU; i <= Iend; i++) o->rufrc[X2(i, j)] = o->rufrc[X2(i, j)] + RU(i, j, k);
+    if (d) {                                            /* :1712-1790: the vertical sums of the terms, level 3 of DiaRUfrc */
+      const int m3[5] = {d->M3pgrd, d->M3fcor, d->M3xadv, d->M3yadv, d->M3hadv};
+      const int m2[5] = {d->M2pgrd, d->M2fcor, d->M2xadv, d->M2yadv, d->M2hadv};
+      for (int q = 0; q < 5; q++) {
+        if (!m3[q]) continue;
+        for (int i = IstrU; i <= Iend; i++) DUF(d->RUfrc, i, j, 3, m2[q]) = DUR(d->RU, i, j, 1, nrhs, m3[q]);
+        for (int k = 2; k <= N; k++)
+          for (int i = IstrU; i <= Iend; i++)
+            DUF(d->RUfrc, i, j, 3, m2[q]) = DUF(d->RUfrc, i, j, 3, m2[q]) + DUR(d->RU, i, j, k, nrhs, m3[q]);
+      }
+      if (d->M2hvis)
+        for (int i = IstrU; i <= Iend; i++) {
+          DUF(d->RUfrc, i, j, 3, d->M2xvis) = 0.0; DUF(d->RUfrc, i, j, 3, d->M2yvis) = 0.0; DUF(d->RUfrc, i, j, 3, d->M2hvis) = 0.0;
+        }
+    }
     for (int i = IstrU; i <= Iend; i++) {
       cff = o->om_u[X2(i, j)] * o->on_u[X2(i, j)];
       cff1 = o->sustr[X2(i, j)] * cff;
       cff2 = -o->bustr[X2(i, j)] * cff;
       o->rufrc[X2(i, j)] = o->rufrc[X2(i, j)] + cff1 + cff2;
+      if (d) { DUF(d->RUfrc, i, j, 3, d->M2sstr) = cff1; DUF(d->RUfrc, i, j, 3, d->M2bstr) = cff2; }    /* :1807 */
     }
     if (j >= JstrV) {
       for (int i = Istr; i <= Iend; i++) o->rvfrc[X2(i, j)] = RV(i, j, 1);
       for (int k = 2; k <= N; k++)
         for (int i = Istr; i <= Iend; i++) o->rvfrc[X2(i, j)] = o->rvfrc[X2(i, j)] + RV(i, j, k);
+      if (d) {                                          /* :1819-1896 */
+        const int m3[5] = {d->M3pgrd, d->M3fcor, d->M3xadv, d->M3yadv, d->M3hadv};
+        const int m2[5] = {d->M2pgrd, d->M2fcor, d->M2xadv, d->M2yadv, d->M2hadv};
+        for (int q = 0; q < 5; q++) {
+          if (!m3[q]) continue;
+          for (int i = Istr; i <= Iend; i++) DUF(d->RVfrc, i, j, 3, m2[q]) = DUR(d->RV, i, j, 1, nrhs, m3[q]);
+          for (int k = 2; k <= N; k++)
+            for (int i = Istr; i <= Iend; i++)
+              DUF(d->RVfrc, i, j, 3, m2[q]) = DUF(d->RVfrc, i, j, 3, m2[q]) + DUR(d->RV, i, j, k, nrhs, m3[q]);
+        }
+        if (d->M2hvis)
+          for (int i = Istr; i <= Iend; i++) {
+            DUF(d->RVfrc, i, j, 3, d->M2xvis) = 0.0; DUF(d->RVfrc, i, j, 3, d->M2yvis) = 0.0; DUF(d->RVfrc, i, j, 3, d->M2hvis) = 0.0;
+          }
+      }
       for (int i = Istr; i <= Iend; i++) {
         cff = o->om_v[X2(i, j)] * o->on_v[X2(i, j)];
         cff1 = o->svstr[X2(i, j)] * cff;
         cff2 = -o->bvstr[X2(i, j)] * cff;
         o->rvfrc[X2(i, j)] = o->rvfrc[X2(i, j)] + cff1 + cff2;
+        if (d) { DUF(d->RVfrc, i, j, 3, d->M2sstr) = cff1; DUF(d->RVfrc, i, j, 3, d->M2bstr) = cff2; }  /* :1913 */
       }
     }
   }
   free(S);
   free(FC);
+  free(Uwrk);
 #undef U
 #undef V
 #undef RU

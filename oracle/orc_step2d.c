@@ -44,6 +44,11 @@ void orc_step2d(orc_t *o, int tile) {
          *gzeta = S + 12 * nij, *gzeta2 = S + 13 * nij, *gzetaSA = S + 14 * nij,
          *rhs_ubar = S + 15 * nij, *rhs_vbar = S + 16 * nij, *rhs_zeta = S + 17 * nij,
          *zeta_new = S + 18 * nij, *zwrk = S + 19 * nij;
+  /* DIAGNOSTICS_UV: DiaU2rhs, DiaV2rhs(IminS:ImaxS,JminS:JmaxS,NDM2d-1), Uwrk, Vwrk :597-601 */
+  const orc_diauv *d = o->duv;
+  double *U2rhs = d ? (double *)calloc((size_t)(2 * d->NDM2d + 2) * nij, sizeof(double)) : NULL;
+  double *V2rhs = d ? U2rhs + (size_t)d->NDM2d * nij : NULL, *Uwrk = d ? U2rhs + (size_t)(2 * d->NDM2d) * nij : NULL,
+         *Vwrk = d ? Uwrk + nij : NULL;
 #define Z(i, j, n) zeta[X2T(i, j, n)]
 #define UB(i, j, n) ubar[X2T(i, j, n)]
 #define VB(i, j, n) vbar[X2T(i, j, n)]
@@ -187,6 +192,7 @@ void orc_step2d(orc_t *o, int tile) {
                (gzetaSA[X2(i - 1, j)] + gzetaSA[X2(i, j)] +
                 cff2 * (rhoA[X2(i - 1, j)] - rhoA[X2(i, j)]) * (zwrk[X2(i - 1, j)] - zwrk[X2(i, j)])) +
            (gzeta2[X2(i - 1, j)] - gzeta2[X2(i, j)]));
+    if (d) for (int i = IstrU; i <= Iend; i++) DU2(U2rhs, i, j, d->M2pgrd) = rhs_ubar[X2(i, j)];       /* :1122 */
     if (j >= JstrV)
       for (int i = Istr; i <= Iend; i++)
         rhs_vbar[X2(i, j)] =
@@ -196,6 +202,7 @@ void orc_step2d(orc_t *o, int tile) {
                  (gzetaSA[X2(i, j - 1)] + gzetaSA[X2(i, j)] +
                   cff2 * (rhoA[X2(i, j - 1)] - rhoA[X2(i, j)]) * (zwrk[X2(i, j - 1)] - zwrk[X2(i, j)])) +
              (gzeta2[X2(i, j - 1)] - gzeta2[X2(i, j)]));
+    if (d && j >= JstrV) for (int i = Istr; i <= Iend; i++) DU2(V2rhs, i, j, d->M2pgrd) = rhs_vbar[X2(i, j)];   /* :1180 */
   }
 
   if (c->options & ORC_UV_ADV) {
@@ -281,6 +288,7 @@ void orc_step2d(orc_t *o, int tile) {
         cff2 = UFe[X2(i, j + 1)] - UFe[X2(i, j)];
         fac = cff1 + cff2;
         rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] - fac;
+        if (d) { DU2(U2rhs, i, j, d->M2xadv) = -cff1; DU2(U2rhs, i, j, d->M2yadv) = -cff2; DU2(U2rhs, i, j, d->M2hadv) = -fac; }   /* :1405 */
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -288,6 +296,7 @@ void orc_step2d(orc_t *o, int tile) {
         cff2 = VFe[X2(i, j)] - VFe[X2(i, j - 1)];
         fac = cff1 + cff2;
         rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] - fac;
+        if (d) { DU2(V2rhs, i, j, d->M2xadv) = -cff1; DU2(V2rhs, i, j, d->M2yadv) = -cff2; DU2(V2rhs, i, j, d->M2hadv) = -fac; }   /* :1418 */
       }
   }
 
@@ -303,11 +312,13 @@ void orc_step2d(orc_t *o, int tile) {
       for (int i = IstrU; i <= Iend; i++) {
         fac1 = 0.5 * (UFx[X2(i, j)] + UFx[X2(i - 1, j)]);
         rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] + fac1;
+        if (d) DU2(U2rhs, i, j, d->M2fcor) = fac1;                                    /* :1446 */
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
         fac1 = 0.5 * (VFe[X2(i, j)] + VFe[X2(i, j - 1)]);
         rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] - fac1;
+        if (d) DU2(V2rhs, i, j, d->M2fcor) = -fac1;                                   /* :1455 */
       }
   }
 
@@ -322,16 +333,33 @@ void orc_step2d(orc_t *o, int tile) {
         cff = Drhs[X2(i, j)] * (cff3 - cff4);
         UFx[X2(i, j)] = cff * cff1;
         VFe[X2(i, j)] = cff * cff2;
+        if (d) {                                                                      /* :1529-1531 */
+          cff = Drhs[X2(i, j)] * cff4;
+          Uwrk[X2(i, j)] = -cff * cff1;
+          Vwrk[X2(i, j)] = -cff * cff2;
+        }
       }
     for (int j = Jstr; j <= Jend; j++)
       for (int i = IstrU; i <= Iend; i++) {
         fac1 = 0.5 * (UFx[X2(i, j)] + UFx[X2(i - 1, j)]);
         rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] + fac1;
+        if (d) {                                                                      /* :1544-1547 */
+          const double fac2 = 0.5 * (Uwrk[X2(i, j)] + Uwrk[X2(i - 1, j)]);
+          DU2(U2rhs, i, j, d->M2xadv) = DU2(U2rhs, i, j, d->M2xadv) + fac1 - fac2;
+          DU2(U2rhs, i, j, d->M2yadv) = DU2(U2rhs, i, j, d->M2yadv) + fac2;
+          DU2(U2rhs, i, j, d->M2hadv) = DU2(U2rhs, i, j, d->M2hadv) + fac1;
+        }
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
         fac1 = 0.5 * (VFe[X2(i, j)] + VFe[X2(i, j - 1)]);
         rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] - fac1;
+        if (d) {                                                                      /* :1556-1559 */
+          const double fac2 = 0.5 * (Vwrk[X2(i, j)] + Vwrk[X2(i, j - 1)]);
+          DU2(V2rhs, i, j, d->M2xadv) = DU2(V2rhs, i, j, d->M2xadv) - fac1 + fac2;
+          DU2(V2rhs, i, j, d->M2yadv) = DU2(V2rhs, i, j, d->M2yadv) - fac2;
+          DU2(V2rhs, i, j, d->M2hadv) = DU2(V2rhs, i, j, d->M2hadv) - fac1;
+        }
       }
   }
 
@@ -369,6 +397,7 @@ void orc_step2d(orc_t *o, int tile) {
         cff2 = 0.5 * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * (UFe[X2(i, j + 1)] - UFe[X2(i, j)]);
         fac = cff1 + cff2;
         rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] + fac;
+        if (d) { DU2(U2rhs, i, j, d->M2hvis) = fac; DU2(U2rhs, i, j, d->M2xvis) = cff1; DU2(U2rhs, i, j, d->M2yvis) = cff2; }      /* :1633 */
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -376,6 +405,7 @@ void orc_step2d(orc_t *o, int tile) {
         cff2 = 0.5 * (pm[X2(i, j - 1)] + pm[X2(i, j)]) * (VFe[X2(i, j)] - VFe[X2(i, j - 1)]);
         fac = cff1 - cff2;
         rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] + fac;
+        if (d) { DU2(V2rhs, i, j, d->M2hvis) = fac; DU2(V2rhs, i, j, d->M2xvis) = cff1; DU2(V2rhs, i, j, d->M2yvis) = -cff2; }     /* :1646 */
       }
   }
 
@@ -387,12 +417,34 @@ void orc_step2d(orc_t *o, int tile) {
           rufrc[X2(i, j)] = rufrc[X2(i, j)] - rhs_ubar[X2(i, j)];
           rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] + rufrc[X2(i, j)];
           ru[XW4(i, j, 0, nstp)] = rufrc[X2(i, j)];
+          if (d) {
+            for (int id = 1; id <= d->M2pgrd; id++) {
+              DUF(d->RUfrc, i, j, 3, id) = DUF(d->RUfrc, i, j, 3, id) - DU2(U2rhs, i, j, id);
+              DU2(U2rhs, i, j, id) = DU2(U2rhs, i, j, id) + DUF(d->RUfrc, i, j, 3, id);
+              DUF(d->RUfrc, i, j, nstp, id) = DUF(d->RUfrc, i, j, 3, id);
+            }
+            DU2(U2rhs, i, j, d->M2sstr) = DUF(d->RUfrc, i, j, 3, d->M2sstr);
+            DUF(d->RUfrc, i, j, nstp, d->M2sstr) = DUF(d->RUfrc, i, j, 3, d->M2sstr);
+            DU2(U2rhs, i, j, d->M2bstr) = DUF(d->RUfrc, i, j, 3, d->M2bstr);
+            DUF(d->RUfrc, i, j, nstp, d->M2bstr) = DUF(d->RUfrc, i, j, 3, d->M2bstr);
+          }
         }
       for (int j = JstrV; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {
           rvfrc[X2(i, j)] = rvfrc[X2(i, j)] - rhs_vbar[X2(i, j)];
           rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] + rvfrc[X2(i, j)];
           rv[XW4(i, j, 0, nstp)] = rvfrc[X2(i, j)];
+          if (d) {
+            for (int id = 1; id <= d->M2pgrd; id++) {
+              DUF(d->RVfrc, i, j, 3, id) = DUF(d->RVfrc, i, j, 3, id) - DU2(V2rhs, i, j, id);
+              DU2(V2rhs, i, j, id) = DU2(V2rhs, i, j, id) + DUF(d->RVfrc, i, j, 3, id);
+              DUF(d->RVfrc, i, j, nstp, id) = DUF(d->RVfrc, i, j, 3, id);
+            }
+            DU2(V2rhs, i, j, d->M2sstr) = DUF(d->RVfrc, i, j, 3, d->M2sstr);
+            DUF(d->RVfrc, i, j, nstp, d->M2sstr) = DUF(d->RVfrc, i, j, 3, d->M2sstr);
+            DU2(V2rhs, i, j, d->M2bstr) = DUF(d->RVfrc, i, j, 3, d->M2bstr);
+            DUF(d->RVfrc, i, j, nstp, d->M2bstr) = DUF(d->RVfrc, i, j, 3, d->M2bstr);
+          }
         }
     } else if (iic == c->ntfirst + 1) {
       for (int j = Jstr; j <= Jend; j++)
@@ -400,12 +452,34 @@ void orc_step2d(orc_t *o, int tile) {
           rufrc[X2(i, j)] = rufrc[X2(i, j)] - rhs_ubar[X2(i, j)];
           rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] + 1.5 * rufrc[X2(i, j)] - 0.5 * ru[XW4(i, j, 0, nnew)];
           ru[XW4(i, j, 0, nstp)] = rufrc[X2(i, j)];
+          if (d) {
+            for (int id = 1; id <= d->M2pgrd; id++) {
+              DUF(d->RUfrc, i, j, 3, id) = DUF(d->RUfrc, i, j, 3, id) - DU2(U2rhs, i, j, id);
+              DU2(U2rhs, i, j, id) = DU2(U2rhs, i, j, id) + 1.5 * DUF(d->RUfrc, i, j, 3, id) - 0.5 * DUF(d->RUfrc, i, j, nnew, id);
+              DUF(d->RUfrc, i, j, nstp, id) = DUF(d->RUfrc, i, j, 3, id);
+            }
+            DU2(U2rhs, i, j, d->M2sstr) = 1.5 * DUF(d->RUfrc, i, j, 3, d->M2sstr) - 0.5 * DUF(d->RUfrc, i, j, nnew, d->M2sstr);
+            DUF(d->RUfrc, i, j, nstp, d->M2sstr) = DUF(d->RUfrc, i, j, 3, d->M2sstr);
+            DU2(U2rhs, i, j, d->M2bstr) = 1.5 * DUF(d->RUfrc, i, j, 3, d->M2bstr) - 0.5 * DUF(d->RUfrc, i, j, nnew, d->M2bstr);
+            DUF(d->RUfrc, i, j, nstp, d->M2bstr) = DUF(d->RUfrc, i, j, 3, d->M2bstr);
+          }
         }
       for (int j = JstrV; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {
           rvfrc[X2(i, j)] = rvfrc[X2(i, j)] - rhs_vbar[X2(i, j)];
           rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] + 1.5 * rvfrc[X2(i, j)] - 0.5 * rv[XW4(i, j, 0, nnew)];
           rv[XW4(i, j, 0, nstp)] = rvfrc[X2(i, j)];
+          if (d) {
+            for (int id = 1; id <= d->M2pgrd; id++) {
+              DUF(d->RVfrc, i, j, 3, id) = DUF(d->RVfrc, i, j, 3, id) - DU2(V2rhs, i, j, id);
+              DU2(V2rhs, i, j, id) = DU2(V2rhs, i, j, id) + 1.5 * DUF(d->RVfrc, i, j, 3, id) - 0.5 * DUF(d->RVfrc, i, j, nnew, id);
+              DUF(d->RVfrc, i, j, nstp, id) = DUF(d->RVfrc, i, j, 3, id);
+            }
+            DU2(V2rhs, i, j, d->M2sstr) = 1.5 * DUF(d->RVfrc, i, j, 3, d->M2sstr) - 0.5 * DUF(d->RVfrc, i, j, nnew, d->M2sstr);
+            DUF(d->RVfrc, i, j, nstp, d->M2sstr) = DUF(d->RVfrc, i, j, 3, d->M2sstr);
+            DU2(V2rhs, i, j, d->M2bstr) = 1.5 * DUF(d->RVfrc, i, j, 3, d->M2bstr) - 0.5 * DUF(d->RVfrc, i, j, nnew, d->M2bstr);
+            DUF(d->RVfrc, i, j, nstp, d->M2bstr) = DUF(d->RVfrc, i, j, 3, d->M2bstr);
+          }
         }
     } else {
       cff1 = 23.0 / 12.0;
@@ -417,6 +491,17 @@ void orc_step2d(orc_t *o, int tile) {
           rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] + cff1 * rufrc[X2(i, j)] -
                                cff2 * ru[XW4(i, j, 0, nnew)] + cff3 * ru[XW4(i, j, 0, nstp)];
           ru[XW4(i, j, 0, nstp)] = rufrc[X2(i, j)];
+          if (d) {
+            for (int id = 1; id <= d->M2pgrd; id++) {
+              DUF(d->RUfrc, i, j, 3, id) = DUF(d->RUfrc, i, j, 3, id) - DU2(U2rhs, i, j, id);
+              DU2(U2rhs, i, j, id) = DU2(U2rhs, i, j, id) + cff1 * DUF(d->RUfrc, i, j, 3, id) - cff2 * DUF(d->RUfrc, i, j, nnew, id) + cff3 * DUF(d->RUfrc, i, j, nstp, id);
+              DUF(d->RUfrc, i, j, nstp, id) = DUF(d->RUfrc, i, j, 3, id);
+            }
+            DU2(U2rhs, i, j, d->M2sstr) = cff1 * DUF(d->RUfrc, i, j, 3, d->M2sstr) - cff2 * DUF(d->RUfrc, i, j, nnew, d->M2sstr) + cff3 * DUF(d->RUfrc, i, j, nstp, d->M2sstr);
+            DUF(d->RUfrc, i, j, nstp, d->M2sstr) = DUF(d->RUfrc, i, j, 3, d->M2sstr);
+            DU2(U2rhs, i, j, d->M2bstr) = cff1 * DUF(d->RUfrc, i, j, 3, d->M2bstr) - cff2 * DUF(d->RUfrc, i, j, nnew, d->M2bstr) + cff3 * DUF(d->RUfrc, i, j, nstp, d->M2bstr);
+            DUF(d->RUfrc, i, j, nstp, d->M2bstr) = DUF(d->RUfrc, i, j, 3, d->M2bstr);
+          }
         }
       for (int j = JstrV; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {
@@ -424,13 +509,38 @@ void orc_step2d(orc_t *o, int tile) {
           rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] + cff1 * rvfrc[X2(i, j)] -
                                cff2 * rv[XW4(i, j, 0, nnew)] + cff3 * rv[XW4(i, j, 0, nstp)];
           rv[XW4(i, j, 0, nstp)] = rvfrc[X2(i, j)];
+          if (d) {
+            for (int id = 1; id <= d->M2pgrd; id++) {
+              DUF(d->RVfrc, i, j, 3, id) = DUF(d->RVfrc, i, j, 3, id) - DU2(V2rhs, i, j, id);
+              DU2(V2rhs, i, j, id) = DU2(V2rhs, i, j, id) + cff1 * DUF(d->RVfrc, i, j, 3, id) - cff2 * DUF(d->RVfrc, i, j, nnew, id) + cff3 * DUF(d->RVfrc, i, j, nstp, id);
+              DUF(d->RVfrc, i, j, nstp, id) = DUF(d->RVfrc, i, j, 3, id);
+            }
+            DU2(V2rhs, i, j, d->M2sstr) = cff1 * DUF(d->RVfrc, i, j, 3, d->M2sstr) - cff2 * DUF(d->RVfrc, i, j, nnew, d->M2sstr) + cff3 * DUF(d->RVfrc, i, j, nstp, d->M2sstr);
+            DUF(d->RVfrc, i, j, nstp, d->M2sstr) = DUF(d->RVfrc, i, j, 3, d->M2sstr);
+            DU2(V2rhs, i, j, d->M2bstr) = cff1 * DUF(d->RVfrc, i, j, 3, d->M2bstr) - cff2 * DUF(d->RVfrc, i, j, nnew, d->M2bstr) + cff3 * DUF(d->RVfrc, i, j, nstp, d->M2bstr);
+            DUF(d->RVfrc, i, j, nstp, d->M2bstr) = DUF(d->RVfrc, i, j, 3, d->M2bstr);
+          }
         }
     }
   } else {
     for (int j = Jstr; j <= Jend; j++)
-      for (int i = IstrU; i <= Iend; i++) rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] + rufrc[X2(i, j)];
+      for (int i = IstrU; i <= Iend; i++) {
+        rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] + rufrc[X2(i, j)];
+        if (d) {                                                                      /* :2430-2435 */
+          for (int id = 1; id <= d->M2pgrd; id++) DU2(U2rhs, i, j, id) = DU2(U2rhs, i, j, id) + DUF(d->RUfrc, i, j, 3, id);
+          DU2(U2rhs, i, j, d->M2sstr) = DUF(d->RUfrc, i, j, 3, d->M2sstr);
+          DU2(U2rhs, i, j, d->M2bstr) = DUF(d->RUfrc, i, j, 3, d->M2bstr);
+        }
+      }
     for (int j = JstrV; j <= Jend; j++)
-      for (int i = Istr; i <= Iend; i++) rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] + rvfrc[X2(i, j)];
+      for (int i = Istr; i <= Iend; i++) {
+        rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] + rvfrc[X2(i, j)];
+        if (d) {                                                                      /* :2447-2452 */
+          for (int id = 1; id <= d->M2pgrd; id++) DU2(V2rhs, i, j, id) = DU2(V2rhs, i, j, id) + DUF(d->RVfrc, i, j, 3, id);
+          DU2(V2rhs, i, j, d->M2sstr) = DUF(d->RVfrc, i, j, 3, d->M2sstr);
+          DU2(V2rhs, i, j, d->M2bstr) = DUF(d->RVfrc, i, j, 3, d->M2bstr);
+        }
+      }
   }
 
   /* momentum time step :2488-2670 */
@@ -477,6 +587,61 @@ void orc_step2d(orc_t *o, int tile) {
         if (msk) VB(i, j, knew) = VB(i, j, knew) * o->vmask[X2(i, j)];                      /* :2658 */
       }
   }
+  if (d) {
+    /* "Time step 2D momentum diagnostic terms" :2676-2743 (SOLVE3D): integrated over the fast steps with the corrector's
+       weights, converted to mass-flux units and averaged with weight(1,iif) for the coupling with the 3-D terms */
+    const int nd = d->NDM2d - 1;
+    if (msk)
+      for (int id = 1; id <= nd; id++) {
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = IstrU; i <= Iend; i++) DU2(U2rhs, i, j, id) = DU2(U2rhs, i, j, id) * o->umask[X2(i, j)];
+        for (int j = JstrV; j <= Jend; j++)
+          for (int i = Istr; i <= Iend; i++) DU2(V2rhs, i, j, id) = DU2(V2rhs, i, j, id) * o->vmask[X2(i, j)];
+      }
+    fac = c->weight[0][iif];
+    if (iif == 1 && CORR) {
+      cff1 = 0.5 * dtfast;
+      for (int id = 1; id <= nd; id++) {
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = IstrU; i <= Iend; i++) {
+            DU2(d->U2int, i, j, id) = cff1 * DU2(U2rhs, i, j, id);
+            DU2(d->U2wrk, i, j, id) = DU2(d->U2int, i, j, id) * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * fac;
+          }
+        for (int j = JstrV; j <= Jend; j++)
+          for (int i = Istr; i <= Iend; i++) {
+            DU2(d->V2int, i, j, id) = cff1 * DU2(V2rhs, i, j, id);
+            DU2(d->V2wrk, i, j, id) = DU2(d->V2int, i, j, id) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) * fac;
+          }
+      }
+    } else if (CORR) {
+      cff1 = 0.5 * dtfast * 5.0 / 12.0;
+      cff2 = 0.5 * dtfast * 8.0 / 12.0;
+      cff3 = 0.5 * dtfast * 1.0 / 12.0;
+      for (int id = 1; id <= nd; id++) {
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = IstrU; i <= Iend; i++) {
+            DU2(d->U2int, i, j, id) = DU2(d->U2int, i, j, id) +
+                                      (cff1 * DU2(U2rhs, i, j, id) + cff2 * DUB(d->RUbar, i, j, kstp, id) -
+                                       cff3 * DUB(d->RUbar, i, j, ptsk, id));
+            DU2(d->U2wrk, i, j, id) = DU2(d->U2wrk, i, j, id) + DU2(d->U2int, i, j, id) * (pm[X2(i - 1, j)] + pm[X2(i, j)]) * fac;
+          }
+        for (int j = JstrV; j <= Jend; j++)
+          for (int i = Istr; i <= Iend; i++) {
+            DU2(d->V2int, i, j, id) = DU2(d->V2int, i, j, id) +
+                                      (cff1 * DU2(V2rhs, i, j, id) + cff2 * DUB(d->RVbar, i, j, kstp, id) -
+                                       cff3 * DUB(d->RVbar, i, j, ptsk, id));
+            DU2(d->V2wrk, i, j, id) = DU2(d->V2wrk, i, j, id) + DU2(d->V2int, i, j, id) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) * fac;
+          }
+      }
+    }
+    if (PRED)                                                                         /* :2852-2863 */
+      for (int id = 1; id <= nd; id++) {
+        for (int j = Jstr; j <= Jend; j++)
+          for (int i = IstrU; i <= Iend; i++) DUB(d->RUbar, i, j, krhs, id) = DU2(U2rhs, i, j, id);
+        for (int j = JstrV; j <= Jend; j++)
+          for (int i = Istr; i <= Iend; i++) DUB(d->RVbar, i, j, krhs, id) = DU2(V2rhs, i, j, id);
+      }
+  }
   if (PRED) {
     for (int j = Jstr; j <= Jend; j++)
       for (int i = IstrU; i <= Iend; i++) rubar[X2T(i, j, krhs)] = rhs_ubar[X2(i, j)];
@@ -488,6 +653,7 @@ void orc_step2d(orc_t *o, int tile) {
   orc_exchange2d(o, b, 'u', ubar + (size_t)(knew - 1) * nij);         /* :3043 */
   orc_exchange2d(o, b, 'v', vbar + (size_t)(knew - 1) * nij);
   free(S);
+  free(U2rhs);
 #undef Z
 #undef UB
 #undef VB

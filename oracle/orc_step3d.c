@@ -38,6 +38,7 @@ void orc_step3d_uv(orc_t *o, int tile) {
   double *AK = (double *)calloc(7 * cs, sizeof(double));
   double *BC = AK + cs, *CF = AK + 2 * cs, *DC = AK + 3 * cs, *FC = AK + 4 * cs, *Hzk = AK + 5 * cs,
          *oHz = AK + 6 * cs;
+  double *Dwrk = o->duv ? (double *)calloc((size_t)o->duv->NDM2d * ni, sizeof(double)) : NULL;   /* Dwrk(IminS:ImaxS,NDM2d) */
 
   for (int j = Jstr; j <= Jend; j++) {
     for (int dir = 0; dir < 2; dir++) {
@@ -47,6 +48,10 @@ void orc_step3d_uv(orc_t *o, int tile) {
       const int di = dir == 0 ? 1 : 0, dj = dir == 0 ? 0 : 1;
       double *q = dir == 0 ? u : v;
       double *rq = dir == 0 ? ru : rv;
+      /* DIAGNOSTICS_UV: the terms of this direction */
+      const orc_diauv *d = o->duv;
+      double *W3 = d ? (dir == 0 ? d->U3wrk : d->V3wrk) : NULL, *RQ = d ? (dir == 0 ? d->RU : d->RV) : NULL;
+      double *W2 = d ? (dir == 0 ? d->U2wrk : d->V2wrk) : NULL;
       for (int i = i0; i <= Iend; i++) {
         CX(AK, i, 0) = 0.5 * (Akv[XW(i - di, j - dj, 0)] + Akv[XW(i, j, 0)]);
         for (int k = 1; k <= N; k++) {
@@ -65,6 +70,17 @@ void orc_step3d_uv(orc_t *o, int tile) {
         for (int i = i0; i <= Iend; i++) {
           q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] + CX(DC, i, 0) * rq[XW4(i, j, k, nrhs)];
           if (!(c->options & ORC_PLAIN_VVISC)) q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] * CX(oHz, i, k);
+          if (d) {                                                               /* step3d_uv.F:365-375, :831-842 */
+            for (int id = 1; id <= d->M3pgrd; id++)
+              DU3(W3, i, j, k, id) = (DU3(W3, i, j, k, id) + CX(DC, i, 0) * DUR(RQ, i, j, k, nrhs, id)) * CX(oHz, i, k);
+            if (d->M3hvis) {
+              DU3(W3, i, j, k, d->M3xvis) = DU3(W3, i, j, k, d->M3xvis) * CX(oHz, i, k);
+              DU3(W3, i, j, k, d->M3yvis) = DU3(W3, i, j, k, d->M3yvis) * CX(oHz, i, k);
+              DU3(W3, i, j, k, d->M3hvis) = DU3(W3, i, j, k, d->M3hvis) * CX(oHz, i, k);
+            }
+            DU3(W3, i, j, k, d->M3vvis) = DU3(W3, i, j, k, d->M3vvis) * CX(oHz, i, k);
+            DU3(W3, i, j, k, d->M3rate) = DU3(W3, i, j, k, d->M3rate) * CX(oHz, i, k);      /* :381 */
+          }
         }
       if (c->options & ORC_PLAIN_VVISC) {
         /* without SPLINES_VVISC :436-500 (v: :903-967): off-diagonal coefficients lambda*dt*Akv/dz at W points, the
@@ -94,13 +110,17 @@ void orc_step3d_uv(orc_t *o, int tile) {
             CX(DC, i, k) = cff * (CX(DC, i, k) - CX(FC, i, k - 1) * CX(DC, i, k - 1));
           }
         for (int i = i0; i <= Iend; i++) {
+          const double wrkN = d ? q[X4(i, j, N, nnew)] * CX(oHz, i, N) : 0.0;     /* :483 */
           CX(DC, i, N) = (CX(DC, i, N) - CX(FC, i, N - 1) * CX(DC, i, N - 1)) / (CX(BC, i, N) - CX(FC, i, N - 1) * CX(CF, i, N - 1));
           q[X4(i, j, N, nnew)] = CX(DC, i, N);
+          if (d) DU3(W3, i, j, N, d->M3vvis) = DU3(W3, i, j, N, d->M3vvis) + q[X4(i, j, N, nnew)] - wrkN;     /* :489 */
         }
         for (int k = N - 1; k >= 1; k--)
           for (int i = i0; i <= Iend; i++) {
+            const double wrkk = d ? q[X4(i, j, k, nnew)] * CX(oHz, i, k) : 0.0;   /* :496 */
             CX(DC, i, k) = CX(DC, i, k) - CX(CF, i, k) * CX(DC, i, k + 1);
             q[X4(i, j, k, nnew)] = CX(DC, i, k);
+            if (d) DU3(W3, i, j, k, d->M3vvis) = DU3(W3, i, j, k, d->M3vvis) + q[X4(i, j, k, nnew)] - wrkk;   /* :501 */
           }
       } else {
       /* implicit vertical viscosity, parabolic splines (SPLINES_VVISC) :361-450 */
@@ -128,6 +148,7 @@ void orc_step3d_uv(orc_t *o, int tile) {
           CX(DC, i, k) = CX(DC, i, k) * CX(AK, i, k);
           cff = dt * CX(oHz, i, k) * (CX(DC, i, k) - CX(DC, i, k - 1));
           q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] + cff;
+          if (d) DU3(W3, i, j, k, d->M3vvis) = DU3(W3, i, j, k, d->M3vvis) + cff;    /* :435 */
         }
       }
       /* replace vertical mean with the barotropic one :594-730 / :1061-1200 */
@@ -142,15 +163,44 @@ void orc_step3d_uv(orc_t *o, int tile) {
         }
       const double *omn1 = dir == 0 ? on_u : om_v;
       const double *Davg = dir == 0 ? o->DU_avg1 : o->DV_avg1;
+      /* DIAGNOSTICS_UV :604-708 (:1071-1175): the vertical means of the 3-D terms that have a 2-D counterpart, minus the
+         fast-time integrated 2-D terms -- Dwrk(i,M2...) */
+      int m2[9], m3[9], nm = 0;
+      if (d) {
+        m2[nm] = d->M2pgrd; m3[nm++] = d->M3pgrd;
+        m2[nm] = d->M2bstr; m3[nm++] = d->M3vvis;
+        if (d->M3fcor) { m2[nm] = d->M2fcor; m3[nm++] = d->M3fcor; }
+        if (d->M3hvis) { m2[nm] = d->M2xvis; m3[nm++] = d->M3xvis; m2[nm] = d->M2yvis; m3[nm++] = d->M3yvis; m2[nm] = d->M2hvis; m3[nm++] = d->M3hvis; }
+        if (d->M3hadv) { m2[nm] = d->M2xadv; m3[nm++] = d->M3xadv; m2[nm] = d->M2yadv; m3[nm++] = d->M3yadv; m2[nm] = d->M2hadv; m3[nm++] = d->M3hadv; }
+        for (int q_ = 0; q_ < nm; q_++) {
+          for (int i = i0; i <= Iend; i++) Dwrk[(size_t)(m2[q_] - 1) * ni + (size_t)(i - LBi)] = DU3(W3, i, j, 1, m3[q_]) * CX(Hzk, i, 1);
+          for (int k = 2; k <= N; k++)
+            for (int i = i0; i <= Iend; i++)
+              Dwrk[(size_t)(m2[q_] - 1) * ni + (size_t)(i - LBi)] = Dwrk[(size_t)(m2[q_] - 1) * ni + (size_t)(i - LBi)] + DU3(W3, i, j, k, m3[q_]) * CX(Hzk, i, k);
+        }
+      }
       for (int i = i0; i <= Iend; i++) {
         cff1 = 1.0 / (CX(CF, i, 0) * omn1[X2(i, j)]);
         CX(DC, i, 0) = (CX(DC, i, 0) * omn1[X2(i, j)] - Davg[X2(i, j)]) * cff1;
+        if (d) {                                                                 /* :701-707 */
+          for (int id = 1; id <= d->M2pgrd; id++)
+            Dwrk[(size_t)(id - 1) * ni + (size_t)(i - LBi)] = (Dwrk[(size_t)(id - 1) * ni + (size_t)(i - LBi)] * omn1[X2(i, j)] - DU2(W2, i, j, id)) * cff1;
+          Dwrk[(size_t)(d->M2bstr - 1) * ni + (size_t)(i - LBi)] =
+              (Dwrk[(size_t)(d->M2bstr - 1) * ni + (size_t)(i - LBi)] * omn1[X2(i, j)] - DU2(W2, i, j, d->M2bstr) - DU2(W2, i, j, d->M2sstr)) * cff1;
+        }
       }
       for (int k = 1; k <= N; k++)
         for (int i = i0; i <= Iend; i++) {
           q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] - CX(DC, i, 0);
           if (msk) q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] * (dir == 0 ? o->umask : o->vmask)[X2(i, j)];   /* step3d_uv.F:717,1184 */
+          if (d)                                                                 /* :733-760 */
+            for (int q_ = 0; q_ < nm; q_++)
+              DU3(W3, i, j, k, m3[q_]) = DU3(W3, i, j, k, m3[q_]) - Dwrk[(size_t)(m2[q_] - 1) * ni + (size_t)(i - LBi)];
         }
+      if (d && msk)                                                              /* :783-791, :1250-1258 */
+        for (int k = 1; k <= N; k++)
+          for (int i = i0; i <= Iend; i++)
+            for (int id = 1; id <= d->NDM3d; id++) DU3(W3, i, j, k, id) = DU3(W3, i, j, k, id) * (dir == 0 ? o->umask : o->vmask)[X2(i, j)];
     }
   }
 
@@ -168,10 +218,24 @@ void orc_step3d_uv(orc_t *o, int tile) {
         CX(CF, i, 0) = CX(CF, i, 0) + CX(DC, i, k) * u[X4(i, j, k, nnew)];
       }
     for (int i = b->IstrP; i <= b->IendT; i++) {
+      cff1 = CX(DC, i, 0);                                                       /* intermediate :1342 */
       CX(DC, i, 0) = 1.0 / CX(DC, i, 0);
       CX(CF, i, 0) = CX(DC, i, 0) * (CX(CF, i, 0) - o->DU_avg1[X2(i, j)]);
       o->ubar[X2T(i, j, 1)] = CX(DC, i, 0) * o->DU_avg1[X2(i, j)];
       o->ubar[X2T(i, j, 2)] = o->ubar[X2T(i, j, 1)];
+      if (o->duv) {                                                              /* :1364-1365 */
+        const orc_diauv *d = o->duv;
+        DU2(d->U2wrk, i, j, d->M2rate) = o->ubar[X2T(i, j, 1)] - DU2(d->U2int, i, j, d->M2rate) * CX(DC, i, 0);
+        DU2(d->U2int, i, j, d->M2rate) = o->ubar[X2T(i, j, 1)] * cff1;
+      }
+    }
+    if (o->duv) {                                                                /* :1373-1380: mass flux -> velocity */
+      const orc_diauv *d = o->duv;
+      for (int id = 1; id <= d->NDM2d - 1; id++)
+        for (int i = b->IstrP; i <= b->IendT; i++) {
+          DU2(d->U2wrk, i, j, id) = CX(DC, i, 0) * DU2(d->U2wrk, i, j, id);
+          if (msk) DU2(d->U2wrk, i, j, id) = DU2(d->U2wrk, i, j, id) * o->umask[X2(i, j)];
+        }
     }
     if (!c->EWperiodic) {
       if (b->west) for (int k = 1; k <= N; k++) { u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] - CX(CF, Istr, 0); if (msk) u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] * o->umask[X2(Istr, j)]; }
@@ -190,6 +254,7 @@ void orc_step3d_uv(orc_t *o, int tile) {
       for (int i = b->IstrP; i <= b->IendT; i++) {
         Huon[X3(i, j, k)] = 0.5 * (Huon[X3(i, j, k)] + u[X4(i, j, k, nnew)] * CX(DC, i, k));
         CX(FC, i, 0) = CX(FC, i, 0) + Huon[X3(i, j, k)];
+        if (o->duv) DU3(o->duv->U3wrk, i, j, k, o->duv->M3rate) = u[X4(i, j, k, nnew)] - DU3(o->duv->U3wrk, i, j, k, o->duv->M3rate);   /* :1517 */
       }
     for (int i = b->IstrP; i <= b->IendT; i++) CX(FC, i, 0) = CX(DC, i, 0) * (CX(FC, i, 0) - o->DU_avg2[X2(i, j)]);
     for (int k = 1; k <= N; k++)
@@ -205,10 +270,24 @@ void orc_step3d_uv(orc_t *o, int tile) {
           CX(CF, i, 0) = CX(CF, i, 0) + CX(DC, i, k) * v[X4(i, j, k, nnew)];
         }
       for (int i = b->IstrT; i <= b->IendT; i++) {
+        cff1 = CX(DC, i, 0);                                                     /* intermediate :1562 */
         CX(DC, i, 0) = 1.0 / CX(DC, i, 0);
         CX(CF, i, 0) = CX(DC, i, 0) * (CX(CF, i, 0) - o->DV_avg1[X2(i, j)]);
         o->vbar[X2T(i, j, 1)] = CX(DC, i, 0) * o->DV_avg1[X2(i, j)];
         o->vbar[X2T(i, j, 2)] = o->vbar[X2T(i, j, 1)];
+        if (o->duv) {                                                            /* :1584-1586 */
+          const orc_diauv *d = o->duv;
+          DU2(d->V2wrk, i, j, d->M2rate) = o->vbar[X2T(i, j, 1)] - DU2(d->V2int, i, j, d->M2rate) * CX(DC, i, 0);
+          DU2(d->V2int, i, j, d->M2rate) = o->vbar[X2T(i, j, 1)] * cff1;
+        }
+      }
+      if (o->duv) {                                                              /* :1596-1603 */
+        const orc_diauv *d = o->duv;
+        for (int id = 1; id <= d->NDM2d - 1; id++)
+          for (int i = b->IstrT; i <= b->IendT; i++) {
+            DU2(d->V2wrk, i, j, id) = CX(DC, i, 0) * DU2(d->V2wrk, i, j, id);
+            if (msk) DU2(d->V2wrk, i, j, id) = DU2(d->V2wrk, i, j, id) * o->vmask[X2(i, j)];
+          }
       }
       if (!c->EWperiodic) {
         if (b->west)
@@ -228,6 +307,7 @@ void orc_step3d_uv(orc_t *o, int tile) {
         for (int i = b->IstrT; i <= b->IendT; i++) {
           Hvom[X3(i, j, k)] = 0.5 * (Hvom[X3(i, j, k)] + v[X4(i, j, k, nnew)] * CX(DC, i, k));
           CX(FC, i, 0) = CX(FC, i, 0) + Hvom[X3(i, j, k)];
+          if (o->duv) DU3(o->duv->V3wrk, i, j, k, o->duv->M3rate) = v[X4(i, j, k, nnew)] - DU3(o->duv->V3wrk, i, j, k, o->duv->M3rate);   /* :1742 */
         }
       for (int i = b->IstrT; i <= b->IendT; i++)
         CX(FC, i, 0) = CX(DC, i, 0) * (CX(FC, i, 0) - o->DV_avg2[X2(i, j)]);
@@ -245,6 +325,7 @@ void orc_step3d_uv(orc_t *o, int tile) {
     orc_exchange2d(o, b, 'v', o->vbar + (size_t)k * nij);
   }
   free(AK);
+  free(Dwrk);
 }
 
 /* ---------------------------------------------------------------- step3d_t */

@@ -1238,6 +1238,24 @@
         F2('DiaTrc',DIAGS(ng)%DiaTrc)
         F2('dia_zeta',DIAGS(ng)%avgzeta)
 #endif
+#ifdef DIAGNOSTICS_UV
+        F2('DiaU2wrk',DIAGS(ng)%DiaU2wrk)
+        F2('DiaV2wrk',DIAGS(ng)%DiaV2wrk)
+        F2('DiaRUbar',DIAGS(ng)%DiaRUbar)
+        F2('DiaRVbar',DIAGS(ng)%DiaRVbar)
+        F2('DiaU2int',DIAGS(ng)%DiaU2int)
+        F2('DiaV2int',DIAGS(ng)%DiaV2int)
+        F2('DiaRUfrc',DIAGS(ng)%DiaRUfrc)
+        F2('DiaRVfrc',DIAGS(ng)%DiaRVfrc)
+        F2('DiaU3wrk',DIAGS(ng)%DiaU3wrk)
+        F2('DiaV3wrk',DIAGS(ng)%DiaV3wrk)
+        F2('DiaRU',DIAGS(ng)%DiaRU)
+        F2('DiaRV',DIAGS(ng)%DiaRV)
+        F2('DiaU2d',DIAGS(ng)%DiaU2d)
+        F2('DiaV2d',DIAGS(ng)%DiaV2d)
+        F2('DiaU3d',DIAGS(ng)%DiaU3d)
+        F2('DiaV3d',DIAGS(ng)%DiaV3d)
+#endif
 #ifdef AVERAGES
         F2('avg_zeta',AVERAGE(ng)%avgzeta)
         F2('avg_ubar',AVERAGE(ng)%avgu2d)

@@ -335,20 +335,23 @@ def mode_avg(tag, kw):
 
 
 DIA_FIELDS = ["DiaTwrk", "DiaTrc", "dia_zeta"]
+DIAUV_FIELDS = ["DiaRU", "DiaRV", "DiaRUfrc", "DiaRVfrc", "DiaU3wrk", "DiaV3wrk", "DiaU2wrk", "DiaV2wrk", "DiaU2int", "DiaV2int",
+                "DiaRUbar", "DiaRVbar", "DiaU2d", "DiaV2d", "DiaU3d", "DiaV3d"]
 
 
 def mode_dia(tag, kw):
     """DIAGNOSTICS_TS (the reference built from upwelling.h as shipped) against the oracle: both sides step kernel by kernel
     in main3d's order with set_diags behind set_zeta (main3d.F:559); DiaTwrk after every kernel, DiaTrc / avgzeta after
     every set_diags -- the set, accumulate and convert phases of several windows."""
-    nsteps, nDIA, ntsDIA = kw.pop("nsteps", 9), kw.pop("nDIA", 3), kw.pop("ntsDIA", 1)
+    nsteps, nDIA, ntsDIA, uv = kw.pop("nsteps", 9), kw.pop("nDIA", 3), kw.pop("ntsDIA", 1), kw.pop("uv", 0)
     app, cs = rd.make_case(tag, **kw)
     saved = rd.quiet()
     R = rd.reference(app, cs)
     O = rd.oracle_from(R, cs)
     O.start()
     R.L.ref_set_dia_window(nDIA, ntsDIA, 0, 1)
-    O.set_dia_window(nDIA, ntsDIA, 0, 1)
+    O.set_dia_window(nDIA, ntsDIA, 0, 1, uv=bool(uv))
+    fields = DIA_FIELDS + (DIAUV_FIELDS if uv else [])
     nfast = R.bounds(0)[58]
     st = dict(iic=1, iif=1, nstp=1, nnew=1, nrhs=1, kstp=1, knew=1, krhs=1, predictor=0, indx1=1, time=0.0, nfast=nfast)
     names = rd.shared_fields(R, O)
@@ -372,8 +375,8 @@ def mode_dia(tag, kw):
                 O.call("set_diags")
                 ncmp += 1
                 nonzero += int(np.abs(O.field("DiaTrc")).max() > 0.0)
-            if kern in ("set_zeta", "rhs3d", "step3d_t"):
-                bad = rd.mismatches(R, O, DIA_FIELDS)
+            if kern in ("set_zeta", "rhs3d", "step3d_t") or (uv and kern in ("step2d", "step3d_uv")):
+                bad = rd.mismatches(R, O, fields)
                 if bad:
                     log.append((step, kern, bad[:6]))
     bad_state = rd.mismatches(R, O, names)

@@ -346,6 +346,18 @@ def test_set_diags_bitwise(args):
     assert "DIA-OK bitwise" in out, out
 
 
+@pytest.mark.parametrize("args", [["nsteps=9", "nDIA=3", "ntsDIA=1", "uv=1"], ["nsteps=6", "nDIA=2", "ntsDIA=2", "hadv=U3,U3", "vadv=C4,C4", "uv=1"],
+                                  ["nsteps=6", "nDIA=2", "ntsDIA=1", "NtileI=2", "NtileJ=2", "uv=1"]])
+def test_set_diags_uv_bitwise(args):
+    """DIAGNOSTICS_UV: the per-term momentum tendencies of the reference built from upwelling.h AS SHIPPED -- DiaRU / DiaRV
+    (the two levels of every 3-D right-hand-side term), their vertical sums DiaRUfrc / DiaRVfrc, DiaU3wrk / DiaV3wrk,
+    the fast-time arrays DiaRUbar, DiaU2int, DiaU2wrk (and V) and the accumulated output DiaU2d, DiaU3d (and V) -- against
+    the oracle (orc_diags_uv.c and its hooks in prsgrd, rhs3d, uv3dmix2, pre_step3d, step2d, step3d_uv) after rhs3d, after
+    EVERY step2d call, after step3d_uv, step3d_t and set_diags of several windows: array_equal, 16 arrays."""
+    out = _child("dia", "upwelling_diag_small", *args)
+    assert "DIA-OK bitwise" in out, out
+
+
 def test_set_avg_on_a_masked_run_bitwise():
     """AVERAGES together with MASKING (reference built from oracle/ref/upwelling_avg_mask.h): the 22 averaged arrays of
     roms_upwelling.in carry no mask arithmetic of their own (set_avg.F uses masks for rotated and vorticity fields only),
