@@ -238,6 +238,12 @@ int roms_hip_avg_time(roms_hip_ctx *ctx, double *avgtime);
    downloaded.  exit_flag 5: MPDATA tracers, applications without SPLINES_VDIFF.  DIAGNOSTICS_UV is not built. */
 int roms_hip_dia_config(roms_hip_ctx *ctx, int nDIA, int ntsDIA, int nrrec, int ntstart);
 int roms_hip_set_diags(roms_hip_ctx *ctx);
+/* DIAGNOSTICS_UV (mod_diags.F:174-222; the DiaU2rhs / DiaRU / DiaU3wrk statements of step2d_LF_AM3.h, rhs3d.F, prsgrd32.h,
+   uv3dmix2_s.h, pre_step3d.F, step3d_uv.F): per-term momentum tendencies.  After roms_hip_dia_config (whose window it shares):
+   allocates DIAGS(ng)%DiaU2wrk, DiaV2wrk, DiaRUbar, DiaRVbar, DiaU2int, DiaV2int, DiaRUfrc, DiaRVfrc, DiaU3wrk, DiaV3wrk,
+   DiaRU, DiaRV, DiaU2d, DiaV2d, DiaU3d, DiaV3d -- downloadable under these names, laid out as the reference's, term order
+   of mod_scalars.F:4264-4377 -- and switches the term stores on; set_diags accumulates DiaU2d ... DiaV3d. */
+int roms_hip_diauv_config(roms_hip_ctx *ctx);
 int roms_hip_dia_time(roms_hip_ctx *ctx, double *DIAtime);
 
 /* The reference writes its history and restart records in the middle of a step (CALL output, main3d.F:591,

@@ -31,6 +31,7 @@ int run_set_diags(roms_hip_ctx *c) {
   const int np = G.N * G.NT * G.dia_ts;
   DiaArgs a = mk(c);
   halo_fence(c, FG_2D | FG_T);
+  if (init || accum) { int r = run_set_diags_uv(c, init ? 1 : 0, 0.0); if (r) return r; }
   if (init || accum) {
     a.init = init ? 1 : 0;
     LAUNCH_THREAD(k_dia_acc, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, np + 1, c->stream, a);
@@ -38,6 +39,7 @@ int run_set_diags(roms_hip_ctx *c) {
   if (convert) {
     c->dia_time = nDIA == 1 ? c->s.time : c->dia_time + (double)nDIA * c->cfg.dt;     // DIAtime :379-383
     a.fac = 1.0 / (double)nDIA;
+    { int r = run_set_diags_uv(c, 2, a.fac); if (r) return r; }
     LAUNCH_THREAD(k_dia_scale, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, np + 1, c->stream, a);
     // "periodic or gradient boundary conditions for output purposes" :576-615: exchange of avgzeta, bc_r3d_tile of every term
     HaloSpec z = {c->F.dia_zeta, 1, BC_NONE, 'r'};

@@ -1,0 +1,102 @@
+// g_duv.cpp -- DIAGNOSTICS_UV: allocation and term indices of the per-term momentum tendencies (mod_diags.F:174-222,
+// mod_scalars.F:4264-4377, mod_param.F:1559-1603), the launches of k_duv.h and the momentum part of set_diags
+// (set_diags.F:192-235, :319-360, :541-572, :617-650).
+#include "roms_host.h"
+#include <cstring>
+#include "k_duv.h"
+
+static KArgs mk(roms_hip_ctx *c) {
+  KArgs a;
+  a.G = c->G; a.Fv = c->F; a.p0 = 0; a.p1 = 0; a.p2 = 0;
+  return a;
+}
+
+// roms_hip_diauv_config: the term indices and array sizes of the option set (the arrays: one block, roms_ctx.h: duv_*)
+int duv_config(roms_hip_ctx *c) {
+  DGrid &G = c->G;
+  if (G.dia_uv) return 0;
+  if (G.options & ROMS_PLAIN_VVISC) { set_error("DIAGNOSTICS_UV: the plain tridiagonal vertical viscosity (no SPLINES_VVISC) is not built with its diagnostics (step3d_uv.F:436-505)"); return 5; }
+  if (G.options & (ROMS_GLS_MIXING | ROMS_MY25_MIXING)) { /* (no momentum terms of their own) */ }
+  const bool cor = G.options & ROMS_UV_COR, adv = G.options & ROMS_UV_ADV, vis = G.options & ROMS_UV_VIS2;
+  for (int k = 0; k < 12; k++) { G.m2[k] = 0; G.m3[k] = 0; }
+  int ic = 0;
+  if (cor) { G.m2[M2FCOR] = ic + 1; ic += 1; }
+  if (adv) { G.m2[M2HADV] = ic + 1; G.m2[M2XADV] = ic + 2; G.m2[M2YADV] = ic + 3; ic += 3; }
+  if (vis) { G.m2[M2HVIS] = ic + 1; G.m2[M2XVIS] = ic + 2; G.m2[M2YVIS] = ic + 3; ic += 3; }
+  G.m2[M2PGRD] = ic + 1; G.m2[M2SSTR] = ic + 2; G.m2[M2BSTR] = ic + 3;
+  G.ndm2 = (short)(4 + (adv ? 3 : 0) + (cor ? 1 : 0) + (vis ? 3 : 0));
+  G.m2[M2RATE] = (signed char)G.ndm2;
+  ic = 0;
+  if (cor) { G.m3[M3FCOR] = ic + 1; ic += 1; }
+  if (adv) { G.m3[M3VADV] = ic + 1; G.m3[M3HADV] = ic + 2; G.m3[M3XADV] = ic + 3; G.m3[M3YADV] = ic + 4; ic += 4; }
+  G.m3[M3PGRD] = ic + 1; G.m3[M3VVIS] = ic + 2;
+  if (vis) { G.m3[M3HVIS] = ic + 3; G.m3[M3XVIS] = ic + 4; G.m3[M3YVIS] = ic + 5; }
+  G.ndm3 = (short)(3 + (adv ? 4 : 0) + (cor ? 1 : 0) + (vis ? 3 : 0));
+  G.ndrhs = (short)(1 + (adv ? 4 : 0) + (cor ? 1 : 0));
+  G.m3[M3RATE] = (signed char)G.ndm3;
+  return 0;                                          // (the caller allocates duv_planes(G) planes, zero-filled as initialize_diags does)
+}
+
+// "DiaU2wrk" ... "DiaV3d": device pointer and number of planes, or nullptr
+double *duv_field(roms_hip_ctx *c, const char *name, int *np) {
+  const DGrid &G = c->G;
+  if (!G.dia_uv || strncmp(name, "Dia", 3)) return nullptr;
+  const Fields &F = c->F;
+  const int N = G.N, n2 = G.ndm2, n3 = G.ndm3, nr = G.ndrhs;
+  const struct { const char *n; double *p; int planes; } T[] = {
+      {"DiaU2wrk", duv_2wrk(G, F, 0, 1), n2}, {"DiaV2wrk", duv_2wrk(G, F, 1, 1), n2},
+      {"DiaRUbar", duv_rbar(G, F, 0, 1, 1), 2 * (n2 - 1)}, {"DiaRVbar", duv_rbar(G, F, 1, 1, 1), 2 * (n2 - 1)},
+      {"DiaU2int", duv_2int(G, F, 0, 1), n2}, {"DiaV2int", duv_2int(G, F, 1, 1), n2},
+      {"DiaRUfrc", duv_rfrc(G, F, 0, 1, 1), 3 * (n2 - 1)}, {"DiaRVfrc", duv_rfrc(G, F, 1, 1, 1), 3 * (n2 - 1)},
+      {"DiaU2d", duv_2d(G, F, 0, 1), n2}, {"DiaV2d", duv_2d(G, F, 1, 1), n2},
+      {"DiaU3wrk", duv_3wrk(G, F, 0, 1), N * n3}, {"DiaV3wrk", duv_3wrk(G, F, 1, 1), N * n3},
+      {"DiaRU", duv_r3(G, F, 0, 1, 1), N * 2 * nr}, {"DiaRV", duv_r3(G, F, 1, 1, 1), N * 2 * nr},
+      {"DiaU3d", duv_3d(G, F, 0, 1), N * n3}, {"DiaV3d", duv_3d(G, F, 1, 1), N * n3}};
+  for (size_t k = 0; k < sizeof(T) / sizeof(T[0]); k++)
+    if (!strcmp(name, T[k].n)) { *np = T[k].planes; return T[k].p; }
+  return nullptr;
+}
+
+int run_duv_pgrd(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  if (!G.dia_uv) return 0;
+  const TB &B = G.T;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_duv_pgrd, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N, c->stream, a);
+  return 0;
+}
+int run_duv_frc(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  if (!G.dia_uv) return 0;
+  const TB &B = G.T;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_duv_frc, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+  return 0;
+}
+int run_duv_s3uv(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  KArgs a = mk(c);
+  LAUNCH_THREAD_AS(k_s3uv_col, k_duv_s3uv, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+  return 0;
+}
+
+// the momentum part of set_diags_tile; phase: 1 set, 0 add, 2 convert (+ bc_u2d / bc_v2d / bc_u3d / bc_v3d and the exchange)
+int run_set_diags_uv(roms_hip_ctx *c, int phase, double fac) {
+  const DGrid &G = c->G;
+  if (!G.dia_uv) return 0;
+  const TB &B = G.T;
+  DuvArgs a;
+  a.G = G; a.Fv = c->F; a.init = phase; a.fac = fac;
+  LAUNCH_THREAD(k_duv_acc, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, 2 * G.ndm2 + 2 * G.ndm3 * G.N, c->stream, a);
+  if (phase == 2) {
+    const int bu = G.obc ? (BC_U | BC_LBC2D) : BC_U, bv = G.obc ? (BC_V | BC_LBC2D) : BC_V;
+    HaloSpec s2[2] = {{duv_2d(G, c->F, 0, 1), G.ndm2, bu, 'u'}, {duv_2d(G, c->F, 1, 1), G.ndm2, bv, 'v'}};
+    launch_halo_multi(c, s2, 2);
+    for (int id = 1; id <= G.ndm3; id++) {
+      HaloSpec s3[2] = {{duv_3d(G, c->F, 0, id), G.N, bu, 'u'}, {duv_3d(G, c->F, 1, id), G.N, bv, 'v'}};
+      launch_halo_multi(c, s3, 2);
+    }
+  }
+  return 0;
+}

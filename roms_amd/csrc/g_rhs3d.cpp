@@ -133,7 +133,7 @@ int run_pre_step3d(roms_hip_ctx *c) {
   // large grids: the marching form (every level read once; the chunked form re-reads two levels per chunk of five)
   static const char *epm = getenv("ROMS_HIP_PRENEW_MARCH");
   const long cols = (long)(B.Iend - B.Istr + 1) * (B.Jend - B.Jstr + 1);
-  if (!G.dia_ts && (epm ? epm[0] != '0' : cols >= 128L * 1024L)) {      // (DIAGNOSTICS_TS: the chunked form stores the terms)
+  if (!G.dia_ts && !G.dia_uv && (epm ? epm[0] != '0' : cols >= 128L * 1024L)) {      // (DIAGNOSTICS_TS | _UV: the chunked form stores the terms)
     static const char *epp = getenv("ROMS_HIP_PRENEW_PARTS");       // (test aid: parts of the column per thread)
     const int parts = epp ? KMAX(1, atoi(epp)) : 1;
     a.p2 = (G.N + parts - 1) / parts;
@@ -153,16 +153,16 @@ int run_prsgrd(roms_hip_ctx *c) {
   KArgs a = mk(c);
   if (G.options & ROMS_PRSGRD40) {     // PJ_GRADP: prsgrd40.h
     LAUNCH_THREAD(k_prs40, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
-    return 0;
+    return run_duv_pgrd(c);
   }
   if (G.options & ROMS_PRSGRD31) {     // no DJ_GRADPS: prsgrd31.h (the reference order of main3d: roms_hip.cpp keeps the late-predictor schedule off)
     LAUNCH_THREAD(k_prs31, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
-    return 0;
+    return run_duv_pgrd(c);
   }
   a.p1 = c->late_pre ? 1 : 0;
   LAUNCH_THREAD(k_prs_P, B.Iend - (B.IstrU - 1) + 1, B.Jend - (B.JstrV - 1) + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_prs_grad, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
-  return 0;
+  return run_duv_pgrd(c);                          // DIAGNOSTICS_UV: DiaRU(M3pgrd) = ru as prsgrd leaves it
 }
 
 int run_t3dmix2(roms_hip_ctx *c) {
@@ -200,7 +200,7 @@ int run_uv3dmix2(roms_hip_ctx *c) {
     if (a.p2 > 0) LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
     else LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a); }
   LAUNCH_THREAD(k_uv3dmix2_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
-  return 0;
+  return run_duv_frc(c);                           // DIAGNOSTICS_UV: the vertical sums of the terms and the viscous terms
 }
 
 // rhs3d_tile's point-wise part.  Default: the LDS-tiled form (k_rhs3d_lds.h), a block of 64x4 points marching a
@@ -213,7 +213,7 @@ static int launch_rhs3d_point_part(roms_hip_ctx *c) {
   const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
 #ifndef ROMS_CPU_EMU
   static const char *el = getenv("ROMS_HIP_RHS3D_LDS"), *ek = getenv("ROMS_HIP_RHS3D_KC");
-  if (!(el && el[0] == '0')) {
+  if (!(el && el[0] == '0') && !G.dia_uv) {
     // levels per chunk: whole columns once the (xi,eta) blocks alone fill the chip (>= 2048 blocks), chunks of
     // at least 5 levels on smaller grids so that grid.z supplies the blocks
     const int nt = ((nx + 63) / 64) * ((ny + 3) / 4);
@@ -236,7 +236,8 @@ static int launch_rhs3d_point_part(roms_hip_ctx *c) {
   }
 #endif
   a.p0 = (G.N + KCH - 1) / KCH;
-  LAUNCH_THREAD(k_rhs3d_pt, nx, ny, 2 * a.p0, c->stream, a);
+  if (G.dia_uv) LAUNCH_THREAD_AS(k_rhs3d_pt, k_rhs3d_pt_duv, nx, ny, 2 * a.p0, c->stream, a);   // DIAGNOSTICS_UV: with the term stores
+  else LAUNCH_THREAD(k_rhs3d_pt, nx, ny, 2 * a.p0, c->stream, a);
   return 0;
 }
 
@@ -248,6 +249,7 @@ int run_rhs3d_tile(roms_hip_ctx *c) {
   KArgs a = mk(c);
   a.p1 = 0;
   LAUNCH_THREAD(k_rhs3d_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
+  if (!(G.options & ROMS_UV_VIS2)) return run_duv_frc(c);      // (with UV_VIS2: behind uv3dmix2, whose per-level terms it sums)
   return 0;
 }
 
@@ -280,7 +282,7 @@ int run_uv3dmix2_col(roms_hip_ctx *c) {
 #else
   const DGrid &G = c->G;
   const TB &B = G.T;
-  if (!(G.options & ROMS_UV_VIS2) || G.masking) return -1;   // (the column form carries no land/sea masks)
+  if (!(G.options & ROMS_UV_VIS2) || G.masking || G.dia_uv) return -1;   // (the column form carries no land/sea masks and leaves no per-level terms)
   static const char *e = getenv("ROMS_HIP_UVCOL");
   const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
   const bool big = (long)nx * ny >= 128L * 1024L;
@@ -299,5 +301,5 @@ int run_rufrc_sums(roms_hip_ctx *c) {
   KArgs a = mk(c);
   a.p1 = (G.options & ROMS_UV_VIS2) ? 1 : 0;
   LAUNCH_THREAD(k_rhs3d_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
-  return 0;
+  return run_duv_frc(c);
 }

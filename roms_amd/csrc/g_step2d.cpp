@@ -37,6 +37,7 @@ int run_step2d(roms_hip_ctx *c) {
   S2F_FILL(a.F, c->F);
   const int iif = G.iif;
   a.w1_m1 = (iif >= 2) ? cf.weight[0][iif - 1] : 0.0;
+  a.w1_0 = cf.weight[0][iif];
   a.w2_0 = cf.weight[1][iif];
   a.w2_p1 = (iif + 1 <= ROMS_MAXW) ? cf.weight[1][iif + 1] : 0.0;
   // behind a pair launch the krhs level is still staged: read it there and commit it (k_step2d_pair.h)
@@ -48,7 +49,8 @@ int run_step2d(roms_hip_ctx *c) {
   // kernel variant by sub-tile size: up to 32x4, up to 64x8, generic (ROMS_HIP_TILE2D overrides)
   int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 32 && G.bh2 <= 8) ? 3 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
   if (getenv("ROMS_HIP_S2D_GENERIC") || (G.masking && variant != 0)) variant = 2;   // (masks: k_step2d_am or the generic form)
-  if (a.commit && (variant != 0 || G.masking)) variant = 2;       // behind a pair launch: k_step2d_ac or the generic form commit the staged level
+  if (a.commit && (variant != 0 || G.masking)) variant = 2;
+  if (G.dia_uv) variant = 2;                                      // DIAGNOSTICS_UV: the generic form carries the term stores (k_step2d_duv)       // behind a pair launch: k_step2d_ac or the generic form commit the staged level
   // 64x8 sub-tiles: 1024 threads (one rectangle point and one momentum point per thread) measure 3 %
   // faster than 512 threads with two each; ROMS_HIP_S2D_1024=0 selects the latter
   const char *e1024 = getenv("ROMS_HIP_S2D_1024");
@@ -105,6 +107,19 @@ int run_step2d(roms_hip_ctx *c) {
       big_lds_g = true;
     }
 #endif
+    if (G.dia_uv) {
+#ifndef ROMS_CPU_EMU
+      static bool big_lds_u = false;
+      if (lds * sizeof(double) > 64 * 1024 && !big_lds_u) {
+        if (hipFuncSetAttribute((const void *)k_step2d_duv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+          set_error("k_step2d: cannot raise the dynamic LDS limit");
+          return 2;
+        }
+        big_lds_u = true;
+      }
+#endif
+      LAUNCH_COOP_AS(k_step2d, k_step2d_duv, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
+    } else
     LAUNCH_COOP(k_step2d, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
   }
   if (G.fuse_halo) return 0;   // the kernel filled the boundary and periodic ghost points itself
@@ -146,6 +161,7 @@ bool step2d_pair_usable(const roms_hip_ctx *c) {
   const char *e = getenv("ROMS_HIP_PAIR");
   if (e && e[0] == '0') return false;
   if (G.obc) return false;                                               // open boundaries: zetabc/u2dbc/v2dbc between the two calls (k_obc.h)
+  if (G.dia_uv) return false;                                            // DIAGNOSTICS_UV: the per-call kernel carries the term stores
   const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
   if (LmT < 8 || MmT < 8) return false;                                  // the rim (5 | 4 lines) comes from the neighbour's / the tile's own points
   if (pair_lds_doubles(G.bw2, G.bh2) * sizeof(double) > 160 * 1024) return false;

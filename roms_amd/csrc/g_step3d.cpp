@@ -26,7 +26,8 @@ int run_step3d_uv(roms_hip_ctx *c) {
   const int N = G.N, nnew = G.nnew;
   KArgs a = mk(c);
   static const char *ech = getenv("ROMS_HIP_COLCH"), *ereg = getenv("ROMS_HIP_UVREG");
-  if (G.options & ROMS_PLAIN_VVISC) LAUNCH_THREAD(k_s3uv_col_p, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);   // without SPLINES_VVISC
+  if (G.dia_uv) { int r = run_duv_s3uv(c); if (r) return r; }          // DIAGNOSTICS_UV: the column kernel with the diagnostic statements (k_duv.h)
+  else if (G.options & ROMS_PLAIN_VVISC) LAUNCH_THREAD(k_s3uv_col_p, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);   // without SPLINES_VVISC
   else if (col_lds(G) && !(ereg && ereg[0] == '0') && N <= 32) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_r32, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
   else if (col_lds(G) && !(ereg && ereg[0] == '0') && N <= 52) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_r52, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
   else if (col_lds(G) && (ech ? ech[0] == '1' : N > 40)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l10, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
@@ -40,7 +41,7 @@ int run_step3d_uv(roms_hip_ctx *c) {
     }
   }
   auto couple = [&]() {
-    if (col_lds(G)) LAUNCH_COL_AS(k_s3uv_couple, k_s3uv_couple_l, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, 2 * (N + 1), c->stream, a);
+    if (col_lds(G) && !G.dia_uv) LAUNCH_COL_AS(k_s3uv_couple, k_s3uv_couple_l, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, 2 * (N + 1), c->stream, a);
     else LAUNCH_THREAD(k_s3uv_couple, B.IendT - KMIN(B.IstrP, B.IstrT) + 1, B.JendT - KMIN(B.JstrT, B.Jstr) + 1, 2, c->stream, a);
   };
   HaloSpec sp[6] = {{uv_lev(c, c->F.u, nnew), N, BC_NONE, 'u'}, {uv_lev(c, c->F.v, nnew), N, BC_NONE, 'v'},

@@ -512,6 +512,18 @@ THREAD_KERNEL(k_pre_new, KArgs) {
           else un = hu + DC0 * (c1 * r3[x + oW[q + 1] + o_nrhs] - c2 * r3[x + oW[q + 1] + o_indx]) + dF;
         }
         qn[oL[q + 1]] = un;
+        if (G.dia_uv) {                                        // DIAGNOSTICS_UV pre_step3d.F:979-1035, :1083-1139
+          const size_t at = x + oL[q + 1];
+          for (int id = 1; id <= G.m3[M3PGRD]; id++) {
+            double w;
+            if (G.iic == G.ntfirst) w = 0.0;
+            else if (G.iic == G.ntfirst + 1) { const double c3 = 0.5 * DC0; w = -c3 * duv_r3(G, F, dir, indx, id)[at]; }
+            else { const double c1 = 5.0 / 12.0, c2 = 16.0 / 12.0; w = DC0 * (c1 * duv_r3(G, F, dir, nrhs, id)[at] - c2 * duv_r3(G, F, dir, indx, id)[at]); }
+            duv_3wrk(G, F, dir, id)[at] = w;
+          }
+          duv_3wrk(G, F, dir, G.m3[M3VVIS])[at] = dF;
+          duv_3wrk(G, F, dir, G.m3[M3RATE])[at] = hu;
+        }
       }
     }
   }
@@ -1167,7 +1179,8 @@ THREAD_GLOBAL(k_uv3dmix2_sum, KArgs)
 // and applies the increments to ru/rv in the reference's order (+Coriolis, +curvilinear,
 // -horizontal advection, -vertical advection) with ONE read and ONE write of ru/rv.
 // p0 = number of chunks.
-THREAD_KERNEL(k_rhs3d_pt, KArgs) {
+template <bool DUV>
+THREAD_KERNEL(k_rhs3d_pt_t, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB &B = G.T;
@@ -1219,6 +1232,7 @@ THREAD_KERNEL(k_rhs3d_pt, KArgs) {
     const double *u = u3 + ok + x, *v = v3 + ok + x;   // centred on (i,j): u[di + dj*ni]
     const double *Hu = F.Huon + ok + x, *Hv = F.Hvom + ok + x;
     double r = r3[(size_t)k * nij];
+    double d_cor = 0.0, d_x = 0.0, d_y = 0.0, d_h = 0.0, d_v = 0.0;   // DUV: the terms of this point as the reference stores them
 #define U_(di, dj) u[(di) + (dj) * ni]
 #define V_(di, dj) v[(di) + (dj) * ni]
 #define HU_(di, dj) Hu[(di) + (dj) * ni]
@@ -1234,23 +1248,27 @@ THREAD_KERNEL(k_rhs3d_pt, KArgs) {
           const double UFx0 = cf0 * (v00 + v01), UFx1 = cf1 * (vm0 + vm1);
           const double cff1 = 0.5 * (UFx0 + UFx1);
           r = r + cff1;
+          if (DUV) d_cor = cff1;
         }
         if (CURV) {
-          double UFx0, UFx1;
+          double UFx0, UFx1, Uw0 = 0.0, Uw1 = 0.0;
           {
             const double cff1 = 0.5 * (v00 + v01), cff2 = 0.5 * (uc + up1);
             const double cff3 = cff1 * dndx0, cff4 = cff2 * dmde0;
             const double cff = Hz0 * (cff3 - cff4);
             UFx0 = cff * cff1;
+            if (DUV) { const double c_ = Hz0 * cff4; Uw0 = -c_ * cff1; }      // Uwrk :601-603
           }
           {
             const double cff1 = 0.5 * (vm0 + vm1), cff2 = 0.5 * (um1 + uc);
             const double cff3 = cff1 * dndx1, cff4 = cff2 * dmde1;
             const double cff = Hz1 * (cff3 - cff4);
             UFx1 = cff * cff1;
+            if (DUV) { const double c_ = Hz1 * cff4; Uw1 = -c_ * cff1; }
           }
           const double cff1 = 0.5 * (UFx0 + UFx1);
           r = r + cff1;
+          if (DUV) { const double cff2 = 0.5 * (Uw0 + Uw1); d_x = cff1 - cff2; d_y = cff2; d_h = cff1; }   // :617-625
         }
       }
       if (ADV) {
@@ -1298,6 +1316,10 @@ THREAD_KERNEL(k_rhs3d_pt, KArgs) {
         const double cff2 = UFep - UFe0;
         const double cff = cff1 + cff2;
         r = r - cff;
+        if (DUV) {                                             // :971-980
+          if (CURV) { d_x = d_x - cff1; d_y = d_y - cff2; d_h = d_h - cff; }
+          else { d_x = -cff1; d_y = -cff2; d_h = -cff; }
+        }
       }
     } else {
       const double vc = qc[q];
@@ -1310,23 +1332,27 @@ THREAD_KERNEL(k_rhs3d_pt, KArgs) {
           const double VFe0 = cf0 * (u00 + u10), VFe1 = cf1 * (u0m + u1m);
           const double cff1 = 0.5 * (VFe0 + VFe1);
           r = r - cff1;
+          if (DUV) d_cor = -cff1;
         }
         if (CURV) {
-          double VFe0, VFe1;
+          double VFe0, VFe1, Vw0 = 0.0, Vw1 = 0.0;
           {
             const double cff1 = 0.5 * (vc + v0p1), cff2 = 0.5 * (u00 + u10);
             const double cff3 = cff1 * dndx0, cff4 = cff2 * dmde0;
             const double cff = Hz0 * (cff3 - cff4);
             VFe0 = cff * cff2;
+            if (DUV) { const double c_ = Hz0 * cff4; Vw0 = -c_ * cff2; }      // Vwrk :601-604
           }
           {
             const double cff1 = 0.5 * (v0m1 + vc), cff2 = 0.5 * (u0m + u1m);
             const double cff3 = cff1 * dndx1, cff4 = cff2 * dmde1;
             const double cff = Hz1 * (cff3 - cff4);
             VFe1 = cff * cff2;
+            if (DUV) { const double c_ = Hz1 * cff4; Vw1 = -c_ * cff2; }
           }
           const double cff1 = 0.5 * (VFe0 + VFe1);
           r = r - cff1;
+          if (DUV) { const double cff2 = 0.5 * (Vw0 + Vw1); d_x = -cff1 + cff2; d_y = -cff2; d_h = -cff1; }   // :635-643
         }
       }
       if (ADV) {
@@ -1373,6 +1399,10 @@ THREAD_KERNEL(k_rhs3d_pt, KArgs) {
         const double cff2 = VFe0 - VFem;
         const double cff = cff1 + cff2;
         r = r - cff;
+        if (DUV) {                                             // :990-999
+          if (CURV) { d_x = d_x - cff1; d_y = d_y - cff2; d_h = d_h - cff; }
+          else { d_x = -cff1; d_y = -cff2; d_h = -cff; }
+        }
       }
     }
 #undef U_
@@ -1382,11 +1412,25 @@ THREAD_KERNEL(k_rhs3d_pt, KArgs) {
     if (ADV) {
       const double cff = FCV[q + 1] - FCV[q];
       r = r - cff;
+      if (DUV) d_v = -cff;
     }
     r3[(size_t)k * nij] = r;
+    if (DUV) {                                                 // DIAGNOSTICS_UV: DiaRU | DiaRV(i,j,k,nrhs,...) rhs3d.F:520-999, :1173, :1323
+      const size_t at = ok + (size_t)x;
+      if (COR) duv_r3(G, F, dir, nrhs, G.m3[M3FCOR])[at] = d_cor;
+      if (ADV) {
+        duv_r3(G, F, dir, nrhs, G.m3[M3XADV])[at] = d_x;
+        duv_r3(G, F, dir, nrhs, G.m3[M3YADV])[at] = d_y;
+        duv_r3(G, F, dir, nrhs, G.m3[M3HADV])[at] = d_h;
+        duv_r3(G, F, dir, nrhs, G.m3[M3VADV])[at] = d_v;
+      }
+    }
   }
 }
+THREAD_KERNEL(k_rhs3d_pt, KArgs) { k_rhs3d_pt_t_body<false>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_rhs3d_pt, KArgs)
+THREAD_KERNEL(k_rhs3d_pt_duv, KArgs) { k_rhs3d_pt_t_body<true>(a, gx, gy, gz); }   // ... with the momentum diagnostics' stores
+THREAD_GLOBAL(k_rhs3d_pt_duv, KArgs)
 
 // p1 = 1: the sums of uv3dmix2's viscous terms are added here as well (fused main3d sequence).
 // rufrc, rvfrc = vertical sum of ru, rv (in k order) + surface - bottom stress :1700-1918; one thread

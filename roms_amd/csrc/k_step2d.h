@@ -41,7 +41,7 @@
 // the first data load can be issued.
 struct S2Fields {
   GPtr zeta, ubar, vbar, h, on_u, om_v, pm, pn, rhoA, rhoS, Zt_avg1, DU_avg1, DU_avg2, DV_avg1, DV_avg2,
-      rzeta, rubar, rvbar, rufrc, rvfrc, ru, rv, m2r, m2p, xr;
+      rzeta, rubar, rvbar, rufrc, rvfrc, ru, rv, m2r, m2p, xr, duv;
 };
 #define S2F_FILL(dst, src)                                                                               \
   do {                                                                                                   \
@@ -52,11 +52,13 @@ struct S2Fields {
     (dst).DV_avg2 = (src).DV_avg2; (dst).rzeta = (src).rzeta; (dst).rubar = (src).rubar;                 \
     (dst).rvbar = (src).rvbar; (dst).rufrc = (src).rufrc; (dst).rvfrc = (src).rvfrc; (dst).ru = (src).ru; \
     (dst).rv = (src).rv; (dst).m2r = (src).m2r; (dst).m2p = (src).m2p; (dst).xr = (src).xr;              \
+    (dst).duv = (src).duv;                                                                               \
   } while (0)
 struct Step2dArgs {
   DGrid G;
   S2Fields F;
   double w1_m1;        // weight(1,iif-1)
+  double w1_0;         // weight(1,iif): the fast-time average of the momentum diagnostics (DIAGNOSTICS_UV, :2707)
   double w2_0, w2_p1;  // weight(2,iif), weight(2,iif+1)
   int lev_in;          // physical level of zeta/ubar/vbar(krhs): G.krhs, or the staging level the pair kernel left its result in
   int commit;          // (the auxiliary last call behind a pair) copy that level to the logical level G.krhs: k_step2d_pair.h
@@ -126,7 +128,7 @@ THREAD_GLOBAL(k_pack_m2d, PackArgs)
 #else
 #define S2D_TICK(n) ((void)0)
 #endif
-template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0), bool CM = (BWC == 0), int PWR = PTS>
+template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0), bool CM = (BWC == 0), int PWR = PTS, bool DUV = false>
 COOP_KERNEL(k_step2d_t, Step2dArgs) {
   (void)bz;
 #ifndef ROMS_CPU_EMU
@@ -411,6 +413,9 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
                     (sH[s - d1] - sH[s]) * (gzetaSA[s - d1] + gzetaSA[s] +
                                            pg2 * (sRhoA[s - d1] - sRhoA[s]) * (zwrk[s - d1] - zwrk[s])) +
                     (gzeta2[s - d1] - gzeta2[s]));
+      // DIAGNOSTICS_UV (DUV instantiation only): DiaU2rhs | DiaV2rhs(i,j,1:NDM2d-1) of this point, step2d_LF_AM3.h:1122-2472
+      double dr[12];
+      if (DUV) { for (int q_ = 0; q_ < 12; q_++) dr[q_] = 0.0; dr[G.m2[M2PGRD]] = rhs; }
       if (ADV) {
         // 4th-order centred advection :1246-1410.  G*(a) = second difference at offset a along the
         // flux direction, with the closed-edge replication of the reference.
@@ -432,6 +437,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
           const double cff2 = UFE(1) - UFE(0);
           const double fac = cff1 + cff2;
           rhs = rhs - fac;
+          if (DUV) { dr[G.m2[M2XADV]] = -cff1; dr[G.m2[M2YADV]] = -cff2; dr[G.m2[M2HADV]] = -fac; }       // :1405
 #undef GUX
 #undef GDX
 #undef UFX
@@ -456,6 +462,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
           const double cff2 = VFE(0) - VFE(-1);
           const double fac = cff1 + cff2;
           rhs = rhs - fac;
+          if (DUV) { dr[G.m2[M2XADV]] = -cff1; dr[G.m2[M2YADV]] = -cff2; dr[G.m2[M2HADV]] = -fac; }       // :1418
 #undef GVX
 #undef GDX
 #undef VFX
@@ -473,29 +480,38 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
         if (!isv) {
           const double fac1 = 0.5 * (cf0 * (TV(0, 0) + TV(0, 1)) + cf1 * (TV(-1, 0) + TV(-1, 1)));
           rhs = rhs + fac1;
+          if (DUV) dr[G.m2[M2FCOR]] = fac1;                                                                // :1446
         } else {
           const double fac1 = 0.5 * (cf0 * (TU(0, 0) + TU(1, 0)) + cf1 * (TU(0, -1) + TU(1, -1)));
           rhs = rhs - fac1;
+          if (DUV) dr[G.m2[M2FCOR]] = -fac1;                                                               // :1455
         }
       }
       if (CURV) {
         // curvilinear metric terms :1494-1560
-        double t0, t1;
+        double t0, t1, w0 = 0.0, w1 = 0.0;               // w: Uwrk | Vwrk at P0, P1 (:1529-1531)
         {
           const double cff1 = 0.5 * (TV(0, 0) + TV(0, 1)), cff2 = 0.5 * (TU(0, 0) + TU(1, 0));
           const double cff3 = cff1 * WV(w_dndx0, isv, mr[x].v[MR_DNDX]), cff4 = cff2 * WV(w_dmde0, isv, mr[x].v[MR_DMDE]);
           const double cff = TD(0, 0) * (cff3 - cff4);
           t0 = isv ? cff * cff2 : cff * cff1;
+          if (DUV) { const double c_ = TD(0, 0) * cff4; w0 = isv ? -c_ * cff2 : -c_ * cff1; }
         }
         {
           const double cff1 = 0.5 * (TV(a1, b1) + TV(a1, b1 + 1)), cff2 = 0.5 * (TU(a1, b1) + TU(a1 + 1, b1));
           const double cff3 = cff1 * WV(w_dndx1, isv, mr[x1].v[MR_DNDX]), cff4 = cff2 * WV(w_dmde1, isv, mr[x1].v[MR_DMDE]);
           const double cff = TD(a1, b1) * (cff3 - cff4);
           t1 = isv ? cff * cff2 : cff * cff1;
+          if (DUV) { const double c_ = TD(a1, b1) * cff4; w1 = isv ? -c_ * cff2 : -c_ * cff1; }
         }
         const double fac1 = 0.5 * (t0 + t1);
         if (!isv) rhs = rhs + fac1;
         else rhs = rhs - fac1;
+        if (DUV) {                                        // :1544-1559
+          const double fac2 = 0.5 * (w0 + w1);
+          if (!isv) { dr[G.m2[M2XADV]] = dr[G.m2[M2XADV]] + fac1 - fac2; dr[G.m2[M2YADV]] = dr[G.m2[M2YADV]] + fac2; dr[G.m2[M2HADV]] = dr[G.m2[M2HADV]] + fac1; }
+          else { dr[G.m2[M2XADV]] = dr[G.m2[M2XADV]] - fac1 + fac2; dr[G.m2[M2YADV]] = dr[G.m2[M2YADV]] - fac2; dr[G.m2[M2HADV]] = dr[G.m2[M2HADV]] - fac1; }
+        }
       }
       if (VIS) {
         // harmonic viscosity :1567-1660: stress at the rho points P0, P1 and the psi points Q0, Q1
@@ -528,6 +544,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
           const double cff2 = 0.5 * (TPM(-1, 0) + TPM(0, 0)) * (UFep - UFe0);
           const double fac = cff1 + cff2;
           rhs = rhs + fac;
+          if (DUV) { dr[G.m2[M2HVIS]] = fac; dr[G.m2[M2XVIS]] = cff1; dr[G.m2[M2YVIS]] = cff2; }           // :1633
         } else {
           const double VFx0 = op0 * op0 * sp0;
           const double VFxp = op1 * op1 * sp1;
@@ -537,6 +554,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
           const double cff2 = 0.5 * (TPM(0, -1) + TPM(0, 0)) * (VFe0 - VFem);
           const double fac = cff1 - cff2;
           rhs = rhs + fac;
+          if (DUV) { dr[G.m2[M2HVIS]] = fac; dr[G.m2[M2XVIS]] = cff1; dr[G.m2[M2YVIS]] = -cff2; }          // :1646
         }
 #undef STRESS_R
 #undef DRHS_P
@@ -557,6 +575,55 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
         r3[o_r0s + (size_t)x] = fr;
       } else {
         r = r + WV(w_frc, isv, frc[x]);
+      }
+      if (DUV) {
+        // coupling of the terms with their 3-D vertical sums DiaRUfrc (:2249-2455), then their fast-time integration
+        // (:2676-2743) and the predictor's copy for the next corrector (:2852-2863)
+        const int dir = isv, Mp = G.m2[M2PGRD], Ms = G.m2[M2SSTR], Mb = G.m2[M2BSTR], nd = G.ndm2 - 1;
+        if (first) {
+          const double c1_ = startup == 0 ? 1.0 : (startup == 1 ? 1.5 : 23.0 / 12.0);
+          const double c2_ = startup == 1 ? 0.5 : 16.0 / 12.0, c3_ = 5.0 / 12.0;
+          for (int id = 1; id <= nd; id++) {
+            if (id > Mp && id != Ms && id != Mb) continue;
+            double *f3 = duv_rfrc(G, F, dir, 3, id) + x, *fn = duv_rfrc(G, F, dir, nnew, id) + x, *fs = duv_rfrc(G, F, dir, nstp, id) + x;
+            double v3 = *f3;
+            if (id <= Mp) { v3 = v3 - dr[id]; *f3 = v3; }
+            // (the reference's left-to-right sums: DiaU2rhs + cff1*frc(3) - cff2*frc(nnew) + cff3*frc(nstp))
+            if (id <= Mp) {
+              if (startup == 0) dr[id] = dr[id] + v3;
+              else if (startup == 1) dr[id] = dr[id] + c1_ * v3 - c2_ * *fn;
+              else dr[id] = dr[id] + c1_ * v3 - c2_ * *fn + c3_ * *fs;
+            } else {
+              if (startup == 0) dr[id] = v3;
+              else if (startup == 1) dr[id] = c1_ * v3 - c2_ * *fn;
+              else dr[id] = c1_ * v3 - c2_ * *fn + c3_ * *fs;
+            }
+            *fs = v3;
+          }
+        } else {
+          for (int id = 1; id <= Mp; id++) dr[id] = dr[id] + duv_rfrc(G, F, dir, 3, id)[x];
+          dr[Ms] = duv_rfrc(G, F, dir, 3, Ms)[x];
+          dr[Mb] = duv_rfrc(G, F, dir, 3, Mb)[x];
+        }
+        if (MSK) { const double m_ = (isv ? G.vmask : G.umask)[x]; for (int id = 1; id <= nd; id++) dr[id] = dr[id] * m_; }
+        if (!PRED) {
+          const double facw = a.w1_0;
+          const double pmn = isv ? (sPn[s] + sPn[s - d1]) : (sPm[s - d1] + sPm[s]);
+          for (int id = 1; id <= nd; id++) {
+            double *I = duv_2int(G, F, dir, id) + x, *W = duv_2wrk(G, F, dir, id) + x;
+            if (iif == 1) {
+              const double v = 0.5 * dtfast * dr[id];
+              *I = v;
+              *W = v * pmn * facw;
+            } else {
+              const double v = *I + (k1 * dr[id] + k2 * duv_rbar(G, F, dir, kstp, id)[x] - k3 * duv_rbar(G, F, dir, ptsk, id)[x]);
+              *I = v;
+              *W = *W + v * pmn * facw;
+            }
+          }
+        } else {
+          for (int id = 1; id <= nd; id++) duv_rbar(G, F, dir, krhs, id)[x] = dr[id];
+        }
       }
       const double cff = (sPm[s] + sPm[s - d1]) * (sPn[s] + sPn[s - d1]);
       const double fac = 1.0 / (Dnew[s] + Dnew[s - d1]);
@@ -616,3 +683,5 @@ COOP_KERNEL(k_step2d_c, Step2dArgs) { k_step2d_t_body<32, 8, 512, 2, false, fals
 COOP_GLOBAL_LB2(k_step2d_c, Step2dArgs, 512, 4)   // two blocks of 8 waves per CU: at most 128 VGPRs
 COOP_KERNEL(k_step2d, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)
+COOP_KERNEL(k_step2d_duv, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0, true, true, 0, true>(a, bx, by, bz, lds); }   // ... with the momentum diagnostics (DIAGNOSTICS_UV)
+COOP_GLOBAL_LB(k_step2d_duv, Step2dArgs, 512)

@@ -516,6 +516,7 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
       CF0 = CF0 + DCk * qq[m];
     }
   }
+  const double Dsum = DC0;                            // "intermediate" :1342, :1562
   DC0 = 1.0 / DC0;
   CF0 = DC0 * (CF0 - Davg1);
   double *bar = dir == 0 ? F.ubar : F.vbar;
@@ -523,6 +524,16 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
   const EmitPlan P = emit_plan(G, BC_NONE, i, j);
   emit_store(G, P, bar, b1);
   emit_store(G, P, bar + G.nij, b1);
+  if (G.dia_uv) {                                      // DIAGNOSTICS_UV :1364-1380, :1584-1603
+    double *Wr = duv_2wrk(G, F, dir, G.m2[M2RATE]) + x, *Ir = duv_2int(G, F, dir, G.m2[M2RATE]) + x;
+    *Wr = b1 - *Ir * DC0;
+    *Ir = b1 * Dsum;
+    const double qm = G.masking ? (dir == 0 ? F.umask : F.vmask)[x] : 1.0;
+    for (int id = 1; id <= G.ndm2 - 1; id++) {
+      double *W = duv_2wrk(G, F, dir, id) + x;
+      *W = G.masking ? DC0 * *W * qm : DC0 * *W;
+    }
+  }
   // boundary columns: remove the mismatch of the vertical mean :1400-1490
   bool fix = false;
   if (dir == 0) {
@@ -551,6 +562,10 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
       const double Hn = 0.5 * (hq[m] + qq[m] * DCk);
       Hq[(size_t)(k - 1) * nij + x] = Hn;
       FC0 = FC0 + Hn;
+      if (G.dia_uv) {                                  // :1517, :1742
+        double *Wr = duv_3wrk(G, F, dir, G.m3[M3RATE]) + x + (size_t)(k - 1) * nij;
+        *Wr = qq[m] - *Wr;
+      }
     }
   }
   FC0 = DC0 * (FC0 - Davg2);

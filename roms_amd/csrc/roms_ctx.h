@@ -43,6 +43,11 @@ struct DGrid {
   // DIAGNOSTICS_TS (mod_diags.F): 0 = off; else NDT, the number of tracer terms; dia_idx[term] = the reference's 1-based
   // index of the term (0 = absent for this option set), terms in the order of the enum below
   int dia_ts, dia_idx[10];
+  // DIAGNOSTICS_UV (mod_diags.F:174-222): 0 = off; m2 / m3[term] = the reference's 1-based index of a 2-D / 3-D momentum
+  // term for the option set (mod_scalars.F:4264-4377), 0 = absent; ndm2 = NDM2d, ndm3 = NDM3d, ndrhs = NDrhs
+  int dia_uv;
+  signed char m2[12], m3[12];
+  short ndm2, ndm3, ndrhs;
   int fuse_halo;              // 1: single tile, k_step2d fills boundary/periodic ghost points itself (k_haloblock.h)
   int fuse3d;                 // 1: the 3-D producers do so too (emit_plan/emit_store); ROMS_HIP_FUSE3D=0 turns it off
   int xloc, yloc;             // 1: a periodic direction of this tile wraps onto itself by a local copy (no exchange partner)
@@ -200,6 +205,9 @@ struct GPtr {
   KHD GPtr &operator=(double *q) { p = (gdouble_t *)q; return *this; }
 };
 
+// terms of the momentum diagnostics (DIAGNOSTICS_UV), slots of DGrid::m2 / m3
+enum { M2FCOR = 0, M2HADV, M2XADV, M2YADV, M2HVIS, M2XVIS, M2YVIS, M2PGRD, M2SSTR, M2BSTR, M2RATE, M2NTERMS };
+enum { M3FCOR = 0, M3VADV, M3HADV, M3XADV, M3YADV, M3PGRD, M3VVIS, M3HVIS, M3XVIS, M3YVIS, M3RATE, M3NTERMS };
 enum { DIA_HADV = 0, DIA_XADV, DIA_YADV, DIA_VADV, DIA_HDIF, DIA_XDIF, DIA_YDIF, DIA_SDIF, DIA_VDIF, DIA_RATE, DIA_NTERMS };
 
 // All device arrays (reference component names).  Pointers only; passed to kernels through the
@@ -229,6 +237,8 @@ struct Fields {
   GPtr wrk2[4];
   // DIAGNOSTICS_TS: DIAGS(ng)%DiaTwrk, DiaTrc (i,j,k,itrc,idiag), avgzeta (allocated by roms_hip_dia_config)
   GPtr DiaTwrk, DiaTrc, dia_zeta;
+  // DIAGNOSTICS_UV: ONE allocation holding DIAGS(ng)%DiaU2wrk ... DiaV3d in the order of duv_* below (roms_hip_diauv_config)
+  GPtr duv;
   // MPDATA work arrays (allocated only when a tracer uses MPDATA): Ta (N planes per tracer), Ua, Va, Wa,
   // beta_up, beta_dn
   GPtr mp3[6];
@@ -240,6 +250,34 @@ struct Fields {
   GPtr bry[24];
 };
 
+// DIAGNOSTICS_UV: the arrays of mod_diags.F inside Fields::duv, each laid out as the reference's (dir 0 = U, 1 = V; id, lev
+// 1-based).  2-D block, planes of nij: DiaU2wrk | DiaV2wrk (NDM2d each), DiaRUbar | DiaRVbar (2 x (NDM2d-1)), DiaU2int |
+// DiaV2int (NDM2d), DiaRUfrc | DiaRVfrc (3 x (NDM2d-1)), DiaU2d | DiaV2d (NDM2d); then blocks of N planes: DiaU3wrk | DiaV3wrk
+// (NDM3d), DiaRU | DiaRV (2 x NDrhs), DiaU3d | DiaV3d (NDM3d).
+KHD size_t duv_planes2(const DGrid &G) { return (size_t)(6 * G.ndm2 + 10 * (G.ndm2 - 1)); }
+KHD size_t duv_planes(const DGrid &G) { return duv_planes2(G) + (size_t)G.N * (size_t)(4 * G.ndm3 + 4 * G.ndrhs); }
+template <class FT> KHD double *duv_2wrk(const DGrid &G, const FT &F, int dir, int id) { return (double *)F.duv + (size_t)(dir * G.ndm2 + id - 1) * G.nij; }
+template <class FT> KHD double *duv_rbar(const DGrid &G, const FT &F, int dir, int lev, int id) {
+  return (double *)F.duv + (size_t)(2 * G.ndm2 + dir * 2 * (G.ndm2 - 1) + (lev - 1) + 2 * (id - 1)) * G.nij;
+}
+template <class FT> KHD double *duv_2int(const DGrid &G, const FT &F, int dir, int id) {
+  return (double *)F.duv + (size_t)(2 * G.ndm2 + 4 * (G.ndm2 - 1) + dir * G.ndm2 + id - 1) * G.nij;
+}
+template <class FT> KHD double *duv_rfrc(const DGrid &G, const FT &F, int dir, int lev, int id) {
+  return (double *)F.duv + (size_t)(4 * G.ndm2 + 4 * (G.ndm2 - 1) + dir * 3 * (G.ndm2 - 1) + (lev - 1) + 3 * (id - 1)) * G.nij;
+}
+template <class FT> KHD double *duv_2d(const DGrid &G, const FT &F, int dir, int id) {
+  return (double *)F.duv + (size_t)(4 * G.ndm2 + 10 * (G.ndm2 - 1) + dir * G.ndm2 + id - 1) * G.nij;
+}
+template <class FT> KHD double *duv_3wrk(const DGrid &G, const FT &F, int dir, int id) {
+  return (double *)F.duv + (duv_planes2(G) + (size_t)G.N * (size_t)(dir * G.ndm3 + id - 1)) * G.nij;
+}
+template <class FT> KHD double *duv_r3(const DGrid &G, const FT &F, int dir, int lev, int id) {
+  return (double *)F.duv + (duv_planes2(G) + (size_t)G.N * (size_t)(2 * G.ndm3 + dir * 2 * G.ndrhs + (lev - 1) + 2 * (id - 1))) * G.nij;
+}
+template <class FT> KHD double *duv_3d(const DGrid &G, const FT &F, int dir, int id) {
+  return (double *)F.duv + (duv_planes2(G) + (size_t)G.N * (size_t)(2 * G.ndm3 + 4 * G.ndrhs + dir * G.ndm3 + id - 1)) * G.nij;
+}
 // DiaTwrk(:,:,:,itrc,term): level 1 of the term's block; nullptr when the diagnostics are off or the term is absent
 KHD double *dia_wrk(const DGrid &G, const Fields &F, int term, int itrc) {
   if (!G.dia_ts || !G.dia_idx[term]) return nullptr;

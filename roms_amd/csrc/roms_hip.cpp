@@ -420,6 +420,9 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   c->pre_t3_ready = false;
   c->stream3 = nullptr;
   c->G.dia_ts = 0;
+  c->G.dia_uv = 0; c->G.ndm2 = 0; c->G.ndm3 = 0; c->G.ndrhs = 0;
+  for (int k = 0; k < 12; k++) { c->G.m2[k] = 0; c->G.m3[k] = 0; }
+  c->F.duv = nullptr;
   for (int k = 0; k < 10; k++) c->G.dia_idx[k] = 0;
   for (int f = 0; f < 24; f++) c->avg[f] = nullptr;
   c->avg_nAVG = 0; c->avg_ntsAVG = 1; c->avg_nrrec = 0; c->avg_ntstart = 1; c->avg_mask = 0;
@@ -641,7 +644,7 @@ static double *dia_field(roms_hip_ctx *c, const char *name, int *np) {
   if (!strcmp(name, "DiaTwrk")) { *np = n; return (double *)c->F.DiaTwrk; }
   if (!strcmp(name, "DiaTrc")) { *np = n; return (double *)c->F.DiaTrc; }
   if (!strcmp(name, "dia_zeta")) { *np = 1; return (double *)c->F.dia_zeta; }
-  return nullptr;
+  return duv_field(c, name, np);                     // DIAGNOSTICS_UV: "DiaU2wrk" ... "DiaV3d" (g_duv.cpp)
 }
 extern "C" long roms_hip_field_size(roms_hip_ctx *c, const char *name) {
   const FieldDesc *f = find_field(name);
@@ -1777,7 +1780,7 @@ static int main3d_one(roms_hip_ctx *c) {
     // (a masked run keeps the reference order: its boundary fills are separate launches on the compute stream)
     static const char *elm = getenv("ROMS_HIP_LATE_MASK");
     // (prsgrd31: the late schedule relies on k_prs_grad keeping the previous ru/rv bracket for the deferred predictor)
-    if (!c->has_exchange && !uvcol && !c->G.dia_ts && (!c->G.masking || (elm && elm[0] == '1')) && !(elate && elate[0] == '0') &&
+    if (!c->has_exchange && !uvcol && !c->G.dia_ts && !c->G.dia_uv && (!c->G.masking || (elm && elm[0] == '1')) && !(elate && elate[0] == '0') &&
         !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_GLS_MIXING | ROMS_MY25_MIXING))) return main3d_late(c, do_diag);   // (GLS: its two routines keep the reference's places)
   }
   DO(roms_hip_rho_eos(c));                                  // :350
@@ -1937,6 +1940,24 @@ extern "C" int roms_hip_dia_config(roms_hip_ctx *c, int nDIA, int ntsDIA, int nr
   return 0;
 }
 // set_diags(ng,tile), main3d.F:559
+// Per-term momentum tendencies (DIAGNOSTICS_UV): allocates DIAGS(ng)%DiaU2wrk ... DiaV3d (mod_diags.F:174-222) and switches
+// the term stores of prsgrd, rhs3d, uv3dmix2, pre_step3d, step2d and step3d_uv on; the window is roms_hip_dia_config's (call
+// that first), set_diags accumulates "DiaU2d", "DiaV2d", "DiaU3d", "DiaV3d".  Refused (exit_flag 5): no SPLINES_VVISC.
+extern "C" int roms_hip_diauv_config(roms_hip_ctx *c) {
+  if (!c) return 8;
+  if (!c->G.dia_ts) { set_error("roms_hip_diauv_config: call roms_hip_dia_config first (the window of set_diags is shared)"); return 8; }
+  halo_fence(c, FG_ALL);
+  if (c->G.dia_uv) return 0;
+  int r = duv_config(c);
+  if (r) return r;
+  void *p = nullptr;
+  if (dmalloc(&p, duv_planes(c->G) * (size_t)c->G.nij * sizeof(double))) return 2;
+  c->allocs.push_back(p);
+  c->F.duv = (double *)p;
+  c->G.dia_uv = 1;
+  c->pair_on = step2d_pair_usable(c);                // (the per-call barotropic kernel carries the term stores)
+  return 0;
+}
 extern "C" int roms_hip_set_diags(roms_hip_ctx *c) {
   if (!c) return 8;
   if (!c->G.dia_ts || c->dia_nDIA <= 0 || c->dia_done_iic == c->s.iic) return 0;

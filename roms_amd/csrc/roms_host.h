@@ -183,7 +183,14 @@ void launch_halo_tail(roms_hip_ctx *c, const HaloSpec *sp, int n);
 void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n);   // n <= 8 fields in one launch
 void launch_halo_wide(roms_hip_ctx *c, const HaloSpec *sp, int n);    // ... with strips B2D_GL | B2D_GH lines wide (pair kernel)
 int run_set_avg(roms_hip_ctx *c, int part = 0);   // g_avg.cpp
-int run_set_diags(roms_hip_ctx *c);               // g_dia.cpp
+int run_set_diags(roms_hip_ctx *c);
+// DIAGNOSTICS_UV (g_duv.cpp)
+int duv_config(roms_hip_ctx *c);
+double *duv_field(roms_hip_ctx *c, const char *name, int *np);
+int run_duv_pgrd(roms_hip_ctx *c);
+int run_duv_frc(roms_hip_ctx *c);
+int run_duv_s3uv(roms_hip_ctx *c);
+int run_set_diags_uv(roms_hip_ctx *c, int phase, double fac);               // g_dia.cpp
 int run_dia_rate(roms_hip_ctx *c);
 bool launch_tadv_lds(roms_hip_ctx *c, int mode);  // g_rhs3d.cpp
 int avg_field_index(const char *name);

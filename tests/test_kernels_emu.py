@@ -515,3 +515,37 @@ def test_tracer_diagnostics_bitwise(emu, tag, kw, nDIA, ntsDIA):
         seen += int(np.abs(O.field("DiaTrc")).max() > 0.0)
     assert seen >= 4
     H.close()
+
+
+DIAUV_FIELDS = ["DiaRU", "DiaRV", "DiaRUfrc", "DiaRVfrc", "DiaU3wrk", "DiaV3wrk", "DiaU2wrk", "DiaV2wrk", "DiaU2int", "DiaV2int",
+                "DiaRUbar", "DiaRVbar", "DiaU2d", "DiaV2d", "DiaU3d", "DiaV3d"]
+
+
+@pytest.mark.parametrize("tag,kw,nDIA,ntsDIA", [
+    ("upwelling_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), 3, 1),           # the option set pinned to the reference
+    ("upwelling_small", dict(hadv=("U3", "U3"), vadv=("C4", "C4")), 2, 2),
+    ("benchmark_small", {}, 2, 1),                                                           # curvilinear terms, quadratic drag, KPP
+    ("upwelling_mask_small", {}, 3, 1)])                                                     # land/sea masks
+def test_momentum_diagnostics_bitwise(emu, tag, kw, nDIA, ntsDIA):
+    """DIAGNOSTICS_UV on the emulated kernels: the sixteen arrays of mod_diags.F (the two levels of every 3-D right-hand-side
+    term, their vertical sums, the fast-time integrals of the 2-D terms, DiaU3wrk / DiaU2wrk and the accumulated output)
+    after every step of several windows against the oracle (pinned to the reference built from upwelling.h as shipped:
+    tests/test_oracle_vs_ref.py::test_set_diags_uv_bitwise), bit for bit; the prognostic fields unchanged by the switch."""
+    from tests.test_gpu_parity import _case_state
+    cs, g = _case_state(tag, kw)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.set_dia_window(nDIA, ntsDIA, uv=True)
+    H.dia_config(nDIA, ntsDIA, uv=True)
+    O.start()
+    H.start()
+    seen = 0
+    for step in range(1, 8):
+        O.main3d_step()
+        H.main3d(1)
+        for n in DIAUV_FIELDS + ["DiaTwrk", "DiaTrc", "t", "u", "v", "ubar", "zeta"]:
+            a, b = H.download(n), O.field(n)
+            assert np.array_equal(a, b), (tag, step, n, int((a != b).sum()), float(np.abs(a - b).max()))
+        seen += int(np.abs(O.field("DiaU3d")).max() > 0.0)
+    assert seen >= 4
+    H.close()
