@@ -171,6 +171,11 @@
           integer(c_int), value :: nDIA, ntsDIA, nrrec, ntstart
           integer(c_int) :: ierr
         END FUNCTION roms_hip_dia_config
+        FUNCTION roms_hip_diauv_config (ctx) bind(C, name='roms_hip_diauv_config') RESULT (ierr)
+          IMPORT :: c_ptr, c_int
+          type(c_ptr), value :: ctx
+          integer(c_int) :: ierr
+        END FUNCTION roms_hip_diauv_config
         FUNCTION roms_hip_dia_time (ctx, diatime) bind(C, name='roms_hip_dia_time') RESULT (ierr)
           IMPORT :: c_ptr, c_int, c_double
           type(c_ptr), value :: ctx

@@ -56,6 +56,9 @@
       integer :: nDIA = 0, ntsDIA = 1
       character(len=256) :: dianame = 'roms_dia.nc'
       logical :: DoutT(0:9,ROMS_MAXT) = .FALSE.
+!  Dout(M2...), Dout(M3...): the momentum terms (DIAGNOSTICS_UV), in the library's order (roms_ctx.h: M2FCOR ... M2RATE,
+!  M3FCOR ... M3RATE); diag_uv: the application header defines DIAGNOSTICS_UV
+      logical :: DoutM2(0:10) = .FALSE., DoutM3(0:10) = .FALSE., diag_uv = .FALSE.
       integer, parameter :: nAout = 22
       logical :: Aout(0:nAout-1) = .FALSE., AoutT(0:nAout-1,ROMS_MAXT) = .FALSE.
       character(len=512) :: app_header = ' '      ! application header to read the cpp options from (optional)
@@ -204,6 +207,28 @@
           CASE ('Dout(iTsdif)'); CALL load_dout (7, tok, nv)
           CASE ('Dout(iTvdif)'); CALL load_dout (8, tok, nv)
           CASE ('Dout(iTrate)'); CALL load_dout (9, tok, nv)
+          CASE ('Dout(M2fcor)'); DoutM2(0)=istrue(tok(1))
+          CASE ('Dout(M2hadv)'); DoutM2(1)=istrue(tok(1))
+          CASE ('Dout(M2xadv)'); DoutM2(2)=istrue(tok(1))
+          CASE ('Dout(M2yadv)'); DoutM2(3)=istrue(tok(1))
+          CASE ('Dout(M2hvis)'); DoutM2(4)=istrue(tok(1))
+          CASE ('Dout(M2xvis)'); DoutM2(5)=istrue(tok(1))
+          CASE ('Dout(M2yvis)'); DoutM2(6)=istrue(tok(1))
+          CASE ('Dout(M2pgrd)'); DoutM2(7)=istrue(tok(1))
+          CASE ('Dout(M2sstr)'); DoutM2(8)=istrue(tok(1))
+          CASE ('Dout(M2bstr)'); DoutM2(9)=istrue(tok(1))
+          CASE ('Dout(M2rate)'); DoutM2(10)=istrue(tok(1))
+          CASE ('Dout(M3fcor)'); DoutM3(0)=istrue(tok(1))
+          CASE ('Dout(M3vadv)'); DoutM3(1)=istrue(tok(1))
+          CASE ('Dout(M3hadv)'); DoutM3(2)=istrue(tok(1))
+          CASE ('Dout(M3xadv)'); DoutM3(3)=istrue(tok(1))
+          CASE ('Dout(M3yadv)'); DoutM3(4)=istrue(tok(1))
+          CASE ('Dout(M3pgrd)'); DoutM3(5)=istrue(tok(1))
+          CASE ('Dout(M3vvis)'); DoutM3(6)=istrue(tok(1))
+          CASE ('Dout(M3hvis)'); DoutM3(7)=istrue(tok(1))
+          CASE ('Dout(M3xvis)'); DoutM3(8)=istrue(tok(1))
+          CASE ('Dout(M3yvis)'); DoutM3(9)=istrue(tok(1))
+          CASE ('Dout(M3rate)'); DoutM3(10)=istrue(tok(1))
           CASE ('Aout(idFsur)'); Aout(0)=istrue(tok(1))
           CASE ('Aout(idUbar)'); Aout(1)=istrue(tok(1))
           CASE ('Aout(idVbar)'); Aout(2)=istrue(tok(1))
@@ -417,7 +442,7 @@
       Akk_bak=5.0E-6_dp; Akp_bak=5.0E-6_dp; charnok_alpha=1400.0_dp; crgban_cw=100.0_dp
       nrrec=0; nRST=0; nHIS=0; LcycleRST=.TRUE.; Hout=.FALSE.; HoutMtke=.FALSE.; HoutMtls=.FALSE.
       nAVG=0; ntsAVG=1; avgname='roms_avg.nc'; Aout=.FALSE.; AoutT=.FALSE.
-      nDIA=0; ntsDIA=1; dianame='roms_dia.nc'; DoutT=.FALSE.
+      nDIA=0; ntsDIA=1; dianame='roms_dia.nc'; DoutT=.FALSE.; DoutM2=.FALSE.; DoutM3=.FALSE.; diag_uv=.FALSE.
       ininame='roms_ini.nc'; rstname='roms_rst.nc'; hisname='roms_his.nc'
       END SUBROUTINE set_defaults
 
@@ -1060,8 +1085,10 @@
         IF (ierr.eq.0.and..not.is_defined('AVERAGES')) nAVG=0
 !  ... and so are the per-term tracer tendencies (DIAGNOSTICS_TS, stock upwelling.h:32): NDIA counts only with it
         IF (ierr.eq.0.and..not.is_defined('DIAGNOSTICS_TS')) nDIA=0
+        diag_uv=is_defined('DIAGNOSTICS_UV')
       ELSE
         CALL builtin_defines (ierr)
+        diag_uv=ANY(DoutM2).or.ANY(DoutM3)           ! (the built-in option lists: the switches of roms.in decide)
       END IF
       CALL options_from_defines (ierr)
 !  (tracers advected with MPDATA: their Dhadv / Dvadv work arrays are not built -- no diagnostics file for such a run)
@@ -1883,6 +1910,13 @@
       IF (nDIA.gt.0) THEN                          ! DIAGNOSTICS_TS: mod_diags.F allocate_diags
         ierr=roms_hip_dia_config(ctx, nDIA, ntsDIA, 0, 1)
         IF (ierr.ne.0) RETURN
+!  DIAGNOSTICS_UV: the momentum terms beside them (without SPLINES_VVISC the library has no such terms: tracer terms only)
+        IF (diag_uv.and.(ANY(DoutM2).or.ANY(DoutM3)).and.IAND(options,ROMS_PLAIN_VVISC).eq.0) THEN
+          ierr=roms_hip_diauv_config(ctx)
+          IF (ierr.ne.0) RETURN
+        ELSE
+          diag_uv=.FALSE.
+        END IF
       END IF
       CALL up ('h', h, 1, ierr); CALL up ('f', f, 1, ierr); CALL up ('fomn', fomn, 1, ierr)
       CALL up ('pm', pm, 1, ierr); CALL up ('pn', pn, 1, ierr); CALL up ('om_r', om_r, 1, ierr)

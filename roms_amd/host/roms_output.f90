@@ -157,7 +157,7 @@
         integer :: nrec = 0                        ! records written so far (Rindex)
         integer(c_int) :: d_xr, d_xu, d_xv, d_xp, d_er, d_eu, d_ev, d_ep, d_N, d_sr, d_sw, d_trc, d_bry
         integer(c_int) :: d_two, d_three, d_time
-        integer(c_int) :: v_time, v_idx(7), v_fld(40)
+        integer(c_int) :: v_time, v_idx(7), v_fld(80)
       END TYPE out_file
       TYPE (out_file), save :: ofile(4)
       real(r8) :: AVGtime = 0.0_r8                 ! mod_scalars.F: time stamp of the averages record
@@ -683,6 +683,30 @@
         tl=(/ 'potential temperature   ', 'salinity                ' /)
         tu=(/ 'Celsius                 ', 'nondimensional          ' /)
         CALL adef (1, 'zeta', 'sea_surface_height_above_geopotential_datum', 'free-surface', 'meter', 'free-surface', gR2)
+!  DIAGNOSTICS_UV, def_diags.F:488-566: per term in the reference's index order ubar_<term>, vbar_<term>, then u_, v_ (slots
+!  22 + 11*dir + term and 44 + 11*dir + term)
+        IF (diag_uv) THEN
+          DO r=1,duv_nd(2)
+            DO k=0,10
+              IF (duv_index(2,k).ne.r.or..not.DoutM2(k)) CYCLE
+              CALL adef (22+k, 'ubar_'//TRIM(duv_suffix(2,k)), 'barotropic_sea_water_x_velocity_tendency'//                &
+     &                   TRIM(duv_std(2,k)), '2D u-momentum, '//TRIM(duv_long(2,k)), 'meter second-2',                     &
+     &                   'u-barotropic '//TRIM(duv_fld(2,k,0)), gU2)
+              CALL adef (33+k, 'vbar_'//TRIM(duv_suffix(2,k)), 'barotropic_sea_water_y_velocity_tendency'//                &
+     &                   TRIM(duv_std(2,k)), '2D v-momentum, '//TRIM(duv_long(2,k)), 'meter second-2',                     &
+     &                   'v-barotropic '//TRIM(duv_fld(2,k,1)), gV2)
+            END DO
+          END DO
+          DO r=1,duv_nd(3)
+            DO k=0,10
+              IF (duv_index(3,k).ne.r.or..not.DoutM3(k)) CYCLE
+              CALL adef (44+k, 'u_'//TRIM(duv_suffix(3,k)), 'sea_water_x_velocity_tendency'//TRIM(duv_std(3,k)),         &
+     &                   '3D u-momentum, '//TRIM(duv_long(3,k)), 'meter second-2', 'u-velocity '//TRIM(duv_fld(3,k,0)), gU3)
+              CALL adef (55+k, 'v_'//TRIM(duv_suffix(3,k)), 'sea_water_y_velocity_tendency'//TRIM(duv_std(3,k)),         &
+     &                   '3D v-momentum, '//TRIM(duv_long(3,k)), 'meter second-2', 'v-velocity '//TRIM(duv_fld(3,k,1)), gV3)
+            END DO
+          END DO
+        END IF
         DO it=1,MIN(NT,2)
           DO k=0,9
             IF (.not.DoutT(k,it).or.dia_term_index(k).eq.0) CYCLE
@@ -959,6 +983,38 @@
         SUBROUTINE dia_fields ()
         integer :: it2, kt, id, npl
         CALL av ('dia_zeta', 1, gR2, 1, 1, 1)
+!  the momentum terms (DIAGNOSTICS_UV): DiaU2d, DiaV2d(:,:,idiag), DiaU3d, DiaV3d(:,:,:,idiag) times 1/dt (wrt_diags.F:177-260)
+        IF (diag_uv) THEN
+          IF (ANY(ofile(which)%v_fld(22:43).ge.0)) THEN
+            npl=duv_nd(2)
+            allocate ( B(LBi:UBi,LBj:UBj,npl) )
+            DO it2=0,1
+              CALL fetch (MERGE('DiaU2d', 'DiaV2d', it2.eq.0), npl, B, ierr)
+              B=B*(1.0_r8/dt)
+              DO kt=0,10
+                id=duv_index(2,kt)
+                IF (id.eq.0.or.ofile(which)%v_fld(22+11*it2+kt).lt.0) CYCLE
+                CALL put_field (ofile(which)%h, ofile(which)%v_fld(22+11*it2+kt), rec, MERGE(gU2, gV2, it2.eq.0), B, npl, id, id, ierr)
+              END DO
+            END DO
+            deallocate ( B )
+          END IF
+          IF (ANY(ofile(which)%v_fld(44:65).ge.0)) THEN
+            npl=N*duv_nd(3)
+            allocate ( B(LBi:UBi,LBj:UBj,npl) )
+            DO it2=0,1
+              CALL fetch (MERGE('DiaU3d', 'DiaV3d', it2.eq.0), npl, B, ierr)
+              B=B*(1.0_r8/dt)
+              DO kt=0,10
+                id=duv_index(3,kt)
+                IF (id.eq.0.or.ofile(which)%v_fld(44+11*it2+kt).lt.0) CYCLE
+                CALL put_field (ofile(which)%h, ofile(which)%v_fld(44+11*it2+kt), rec, MERGE(gU3, gV3, it2.eq.0), B, npl,        &
+     &                          N*(id-1)+1, N*id, ierr)
+              END DO
+            END DO
+            deallocate ( B )
+          END IF
+        END IF
         npl=N*NT*dia_ndt()
         IF (.not.ANY(ofile(which)%v_fld(2:21).ge.0)) RETURN
         allocate ( B(LBi:UBi,LBj:UBj,npl) )
@@ -1149,6 +1205,108 @@
      &   'acceleration' ]
       s=t(k)
       END FUNCTION dia_fld
+!
+!  the momentum terms of DIAGNOSTICS_UV in the library's order (roms_ctx.h: M2FCOR ... M2RATE | M3FCOR ... M3RATE): number of
+!  terms (mod_param.F:1559-1603), index in DiaU2d | DiaU3d (mod_scalars.F:4264-4377; 0 = the option set has no such term),
+!  variable suffix and attribute fragments of varinfo.yaml.  d = 2 | 3.
+      INTEGER FUNCTION duv_nd (d)
+      integer, intent(in) :: d
+      logical :: cor, adv, vis
+      cor=IAND(options,ROMS_UV_COR).ne.0; adv=IAND(options,ROMS_UV_ADV).ne.0; vis=IAND(options,ROMS_UV_VIS2).ne.0
+      IF (d.eq.2) THEN
+        duv_nd=4+MERGE(3,0,adv)+MERGE(1,0,cor)+MERGE(3,0,vis)
+      ELSE
+        duv_nd=3+MERGE(4,0,adv)+MERGE(1,0,cor)+MERGE(3,0,vis)
+      END IF
+      END FUNCTION duv_nd
+      INTEGER FUNCTION duv_index (d, k)
+      integer, intent(in) :: d, k
+      logical :: cor, adv, vis
+      integer :: ic, i0, ia, iv
+      cor=IAND(options,ROMS_UV_COR).ne.0; adv=IAND(options,ROMS_UV_ADV).ne.0; vis=IAND(options,ROMS_UV_VIS2).ne.0
+      duv_index=0
+      ic=0
+      i0=0; ia=0; iv=0
+      IF (cor) THEN
+        i0=ic+1; ic=ic+1
+      END IF
+      IF (d.eq.2) THEN
+        IF (adv) THEN
+          ia=ic; ic=ic+3
+        END IF
+        IF (vis) THEN
+          iv=ic; ic=ic+3
+        END IF
+        SELECT CASE (k)
+          CASE (0); duv_index=i0
+          CASE (1:3); IF (adv) duv_index=ia+k
+          CASE (4:6); IF (vis) duv_index=iv+k-3
+          CASE (7); duv_index=ic+1
+          CASE (8); duv_index=ic+2
+          CASE (9); duv_index=ic+3
+          CASE (10); duv_index=duv_nd(2)
+        END SELECT
+      ELSE
+        IF (adv) THEN
+          ia=ic; ic=ic+4
+        END IF
+        SELECT CASE (k)
+          CASE (0); duv_index=i0
+          CASE (1:4); IF (adv) duv_index=ia+k
+          CASE (5); duv_index=ic+1
+          CASE (6); duv_index=ic+2
+          CASE (7:9); IF (vis) duv_index=ic+k-4
+          CASE (10); duv_index=duv_nd(3)
+        END SELECT
+      END IF
+      END FUNCTION duv_index
+      FUNCTION duv_suffix (d, k) RESULT (s)
+      integer, intent(in) :: d, k
+      character(len=8) :: s
+      character(len=8), parameter :: t2(0:10) = [ character(len=8) :: 'cor', 'hadv', 'xadv', 'yadv', 'hvisc', 'xvisc', 'yvisc',   &
+     &                                            'prsgrd', 'sstr', 'bstr', 'accel' ]
+      character(len=8), parameter :: t3(0:10) = [ character(len=8) :: 'cor', 'vadv', 'hadv', 'xadv', 'yadv', 'prsgrd', 'vvisc',    &
+     &                                            'hvisc', 'xvisc', 'yvisc', 'accel' ]
+      s=MERGE(t2(k), t3(k), d.eq.2)
+      END FUNCTION duv_suffix
+      FUNCTION duv_std (d, k) RESULT (s)
+      integer, intent(in) :: d, k
+      character(len=40) :: s
+      character(len=40), parameter :: t2(0:10) = [ character(len=40) :: '_due_to_coriolis', '_due_to_horizontal_advection',      &
+     &   '_due_to_horizontal_x_advection', '_due_to_horizontal_y_advection', '_due_to_horizontal_viscosity',                     &
+     &   '_due_to_horizontal_x_viscosity', '_due_to_horizontal_y_viscosity', '_due_to_pressure_gradient',                         &
+     &   '_due_to_surface_stress', '_due_to_bottom_stress', '' ]
+      character(len=40), parameter :: t3(0:10) = [ character(len=40) :: '_due_to_coriolis', '_due_to_vertical_advection',        &
+     &   '_due_to_horizontal_advection', '_due_to_horizontal_x_advection', '_due_to_horizontal_y_advection',                     &
+     &   '_due_to_pressure_gradient', '_due_to_vertical_viscosity', '_due_to_horizontal_viscosity',                              &
+     &   '_due_to_horizontal_x_viscosity', '_due_to_horizontal_y_viscosity', '' ]
+      s=MERGE(t2(k), t3(k), d.eq.2)
+      END FUNCTION duv_std
+      FUNCTION duv_long (d, k) RESULT (s)
+      integer, intent(in) :: d, k
+      character(len=32) :: s
+      character(len=32), parameter :: t2(0:10) = [ character(len=32) :: 'Coriolis term', 'horizontal advection term',             &
+     &   'horizontal XI-advection term', 'horizontal ETA-advection term', 'horizontal viscosity term',                            &
+     &   'horizontal XI-viscosity term', 'horizontal ETA-viscosity term', 'pressure gradient term', 'surface stress term',      &
+     &   'bottom stress term', 'acceleration term' ]
+      character(len=32), parameter :: t3(0:10) = [ character(len=32) :: 'Coriolis term', 'vertical advection term',              &
+     &   'horizontal advection term', 'horizontal XI-advection term', 'horizontal ETA-advection term', 'pressure gradient term', &
+     &   'vertical viscosity term', 'horizontal viscosity term', 'horizontal XI-viscosity term',                                 &
+     &   'horizontal ETA-viscosity term', 'acceleration term' ]
+      s=MERGE(t2(k), t3(k), d.eq.2)
+      END FUNCTION duv_long
+      FUNCTION duv_fld (d, k, dir) RESULT (s)
+      integer, intent(in) :: d, k, dir
+      character(len=24) :: s
+      character(len=24), parameter :: t2(0:10) = [ character(len=24) :: 'coriolis', 'horizontal advection', 'x-advection',        &
+     &   'y-advection', 'horizontal viscosity', 'x-viscosity', 'y-viscosity', 'pressure gradient', 'surface stress',             &
+     &   'bottom stress', 'acceleration' ]
+      character(len=24), parameter :: t3(0:10) = [ character(len=24) :: 'coriolis', 'vertical advection', 'horizontal advection', &
+     &   'x-advection', 'y-advection', 'pressure gradient', 'vertical viscosity', 'horizontal viscosity', 'x-viscosity',         &
+     &   'y-viscosity', 'acceleration' ]
+      s=MERGE(t2(k), t3(k), d.eq.2)
+      IF (d.eq.3.and.k.eq.6.and.dir.eq.0) s='vertical-viscosity'      ! (varinfo.yaml: u_vvisc's field, as it is spelled there)
+      END FUNCTION duv_fld
 !
 !  nsteps passes of main3d with the output calls of main3d.F:591 in between; final: also the records of
 !  the step that is not taken (iic = ntend+1, main3d.F:595).  mode 0: fused roms_hip_main3d, 1: kernel by kernel.

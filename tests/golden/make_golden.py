@@ -284,7 +284,8 @@ def make_avg():
 
 
 def make_dia():
-    """upwelling_small_dia.npz: DiaTwrk, DiaTrc and avgzeta of the reference's set_diags.F (reference built from
+    """upwelling_small_dia.npz (DIAGNOSTICS_TS and DIAGNOSTICS_UV): DiaTwrk, DiaTrc, avgzeta and the accumulated momentum
+    terms DiaU2d, DiaV2d, DiaU3d, DiaV3d (+ DiaU3wrk, DiaV2wrk of one step) of the reference's set_diags.F (reference built from
     ROMS/Include/upwelling.h AS SHIPPED -- DIAGNOSTICS_TS defined -- oracle/ref/build_ref.sh upwelling_diag) after steps 4
     and 7 of a run with nDIA = 3, ntsDIA = 1 (the window-closing calls: DiaTrc converted, ghost points filled), and DiaTwrk
     at the end of step 5 (the raw terms of one step) -- stepped through the reference's kernel wrappers in main3d's order
@@ -306,10 +307,12 @@ def make_dia():
             if kern == "set_zeta":
                 R.call("set_diags")
                 if step in (4, 7):
-                    for n in ("DiaTrc", "dia_zeta"):
+                    for n in ("DiaTrc", "dia_zeta", "DiaU2d", "DiaV2d", "DiaU3d", "DiaV3d"):
                         out[f"s{step}_{n}"] = R.get(n)
         if step == 5:
             out["e5_DiaTwrk"] = R.get("DiaTwrk")
+            out["e5_DiaU3wrk"] = R.get("DiaU3wrk")
+            out["e5_DiaV2wrk"] = R.get("DiaV2wrk")
             out["e5_t"] = R.get("t")
     os.dup2(saved, 1)
     np.savez_compressed(os.path.join(HERE, "upwelling_small_dia.npz"), nDIA=3, ntsDIA=1, **out)

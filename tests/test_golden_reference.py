@@ -108,7 +108,7 @@ def test_oracle_set_diags_matches_reference_fixture():
     cs = util.case_for("upwelling_small")
     g = util.load_init("upwelling_small", util.nghost_for(cs))
     O = util.make_oracle(cs, g)
-    O.set_dia_window(int(z["nDIA"]), int(z["ntsDIA"]))
+    O.set_dia_window(int(z["nDIA"]), int(z["ntsDIA"]), uv=True)       # ... and the momentum terms (DIAGNOSTICS_UV)
     O.start()
     n = 0
     for step in range(1, 8):
@@ -117,4 +117,4 @@ def test_oracle_set_diags_matches_reference_fixture():
             if key.startswith(f"s{step}_") or key.startswith(f"e{step}_"):
                 assert np.array_equal(O.field(key[3:]), z[key]), key
                 n += 1
-    assert n == 6 and np.abs(z["s7_DiaTrc"]).max() > 0.0
+    assert n == 16 and np.abs(z["s7_DiaTrc"]).max() > 0.0 and np.abs(z["s7_DiaU3d"]).max() > 0.0

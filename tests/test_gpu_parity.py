@@ -823,6 +823,44 @@ def test_tracer_diagnostics_match_oracle(tag, kw, nDIA, ntsDIA, monkeypatch):
         assert np.array_equal(ends[0][n], plain[n]), (tag, n, "the diagnostics changed the run")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,kw,nDIA,ntsDIA", [
+    ("upwelling_small", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), 3, 1), ("benchmark_small", {}, 2, 1),
+    ("upwelling_mask_small", {}, 3, 1)])
+def test_momentum_diagnostics_match_oracle(tag, kw, nDIA, ntsDIA, monkeypatch):
+    """DIAGNOSTICS_UV on the GPU (the stores in k_pre_new, k_rhs3d_pt_duv, k_step2d_duv, k_s3uv_couple; k_duv_*) against the
+    oracle pinned to the reference: the sixteen arrays of mod_diags.F after every step of several windows, 1e-10 of the
+    largest entry of each array (exact where the run has no transcendentals); the prognostic fields are the bits of the
+    run without diagnostics; a second run with poisoned work arrays gives the same bits."""
+    from tests.test_kernels_emu import DIAUV_FIELDS
+    cs, g = _case_state(tag, kw)
+    plain = _end_state(cs, g, 7)
+    ends = []
+    for poison in ("0", "1"):
+        monkeypatch.setenv("ROMS_HIP_POISON", poison)
+        O = util.make_oracle(cs, g)
+        H = util.make_hip(cs, g)
+        O.set_dia_window(nDIA, ntsDIA, uv=True)
+        H.dia_config(nDIA, ntsDIA, uv=True)
+        O.start()
+        H.start()
+        for step in range(1, 8):
+            O.main3d_step()
+            H.main3d(1)
+            for n in DIAUV_FIELDS:
+                a, b = H.download(n), O.field(n)
+                scale = max(np.abs(b).max(), 1e-300)
+                assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-10 * scale, (tag, step, n, np.abs(a - b).max() / scale)
+        assert np.abs(O.field("DiaU3d")).max() > 0.0 and np.abs(O.field("DiaV2d")).max() > 0.0
+        H.sync()
+        ends.append({n: H.download(n).copy() for n in DIAUV_FIELDS + ["t", "u", "v", "zeta"]})
+        H.close()
+    for n in ends[0]:
+        assert np.array_equal(ends[0][n], ends[1][n]), (tag, n, "poisoned scratch / run-to-run difference")
+    for n in ("t", "u", "v", "zeta"):
+        assert np.array_equal(ends[0][n], plain[n]), (tag, n, "the diagnostics changed the run")
+
+
 XI_PARTNER = dict(u="v", ubar="vbar", Huon="Hvom", ru="rv", DU_avg1="DV_avg1", DU_avg2="DV_avg2", rufrc="rvfrc", rubar="rvbar",
                   sustr="svstr", bustr="bvstr")
 

@@ -129,7 +129,7 @@ def test_tracer_diagnostics_match_reference_fixture():
     cs = util.case_for("upwelling_small")
     g = util.load_init("upwelling_small", util.nghost_for(cs))
     H = util.make_hip(cs, g)
-    H.dia_config(int(z["nDIA"]), int(z["ntsDIA"]))
+    H.dia_config(int(z["nDIA"]), int(z["ntsDIA"]), uv=True)           # ... and the momentum terms (DIAGNOSTICS_UV)
     H.start()
     n = 0
     for step in range(1, 8):
@@ -139,7 +139,7 @@ def test_tracer_diagnostics_match_reference_fixture():
                 a, b = H.download(key[3:]), z[key]
                 assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max(), (key, np.abs(a - b).max() / np.abs(b).max())
                 n += 1
-    assert n == 6
+    assert n == 16
     H.close()
 
 
@@ -151,11 +151,11 @@ def test_romsM_runs_the_shipped_upwelling_case_with_all_its_files(tmp_path):
     import subprocess
     from scipy.io import netcdf_file
     from roms_amd import hostlib, cases
-    from tests.test_output import HOUT, AOUT, DOUT
+    from tests.test_output import HOUT, AOUT, DOUT, DOUT_UV
     exe = os.path.join(os.path.dirname(hostlib.LIB), "romsM")
     cs = cases.upwelling(ntimes=1440)
     cs.update(NHIS=72, NRST=288, LcycleRST=True, NAVG=72, NTSAVG=1, Hout=HOUT, Aout=AOUT, ninfo=72,
-              NDIA=72, NTSDIA=1, Dout=DOUT)
+              NDIA=72, NTSDIA=1, Dout=dict(DOUT, **DOUT_UV))
     inp = str(tmp_path / "roms_upwelling.in")
     hostlib.write_roms_in(inp, cs)
     r = subprocess.run([exe, inp], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
@@ -186,6 +186,10 @@ def test_romsM_runs_the_shipped_upwelling_case_with_all_its_files(tmp_path):
     budget = sum(V[f"temp_{x}"][-1][:, 1:-1, 1:-1] for x in ("hadv", "vadv", "hdiff", "vdiff"))
     assert np.abs(rate).max() > 0.0 and np.abs(rate - budget).max() <= 1e-9 * np.abs(rate).max()
     assert np.abs(V["temp_hadv"][-1] - V["temp_xadv"][-1] - V["temp_yadv"][-1]).max() <= 1e-12 * np.abs(V["temp_hadv"][-1]).max()
+    # ... and the momentum terms (DIAGNOSTICS_UV): the 3-D u budget of the last window closes
+    ur = V["u_accel"][-1][:, 1:-1, 1:-1]
+    ub = sum(V[f"u_{x}"][-1][:, 1:-1, 1:-1] for x in ("cor", "vadv", "hadv", "prsgrd", "vvisc", "hvisc"))
+    assert np.abs(ur).max() > 0.0 and np.abs(ur - ub).max() <= 1e-8 * max(np.abs(V[f"u_{x}"][-1]).max() for x in ("cor", "prsgrd", "vvisc"))
     dT = (z1 - z0)[:, 1:-1, 1:-1] / (72 * 300.0)
     assert np.abs(rate - dT).max() <= 0.05 * max(np.abs(dT).max(), 1e-12)      # (the terms are thickness-weighted: step3d_t.F:1383-1411)
     for f in (his, rst, avg, dia):

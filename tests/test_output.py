@@ -278,7 +278,7 @@ def test_tiles_write_the_file_a_single_tile_writes_and_restart_from_it(tmp_path)
     fields = ["zeta", "ubar", "vbar", "u", "v", "t"]
     upd1 = dict(NHIS=2, NRST=3, HISNAME=str(tmp_path / "his1.nc"), RSTNAME=str(tmp_path / "rst1.nc"), Hout=HOUT, LcycleRST=False,
                 NAVG=2, NTSAVG=1, AVGNAME=str(tmp_path / "avg1.nc"), Aout=AOUT,
-                NDIA=2, NTSDIA=1, DIANAME=str(tmp_path / "dia1.nc"), Dout=DOUT)
+                NDIA=2, NTSDIA=1, DIANAME=str(tmp_path / "dia1.nc"), Dout=dict(DOUT, **DOUT_UV))
     cs = util.case_for("benchmark_small")
     cs.update(upd1, ninfo=0)
     H, ctx = _host(cs, "emu")
@@ -474,6 +474,13 @@ def test_averages_file_holds_the_reference_set_avg_fields(which, tmp_path):
 DOUT = {"iTrate": (True, True), "iThadv": (True, True), "iTxadv": (True, False), "iTyadv": (True, True), "iTvadv": (True, True),
         "iThdif": (True, True), "iTxdif": (True, True), "iTydif": (True, True), "iTsdif": (True, True), "iTvdif": (True, True)}
 DIA_TERMS = ("hadv", "xadv", "yadv", "vadv", "hdiff", "xdiff", "ydiff", "sdiff", "vdiff", "rate")
+# DIAGNOSTICS_UV: Dout(M2...) / Dout(M3...) of roms_upwelling.in (u_yvisc switched off) and the variable suffixes in the
+# reference's index order for UV_COR + UV_ADV + UV_VIS2 (mod_scalars.F:4264-4377)
+DOUT_UV = {f"M2{k}": True for k in ("rate", "pgrd", "fcor", "hadv", "xadv", "yadv", "hvis", "xvis", "yvis", "sstr", "bstr")}
+DOUT_UV.update({f"M3{k}": True for k in ("rate", "pgrd", "fcor", "hadv", "xadv", "yadv", "vadv", "hvis", "xvis", "vvis")})
+DOUT_UV["M3yvis"] = False
+M2_ORDER = ("cor", "hadv", "xadv", "yadv", "hvisc", "xvisc", "yvisc", "prsgrd", "sstr", "bstr", "accel")
+M3_ORDER = ("cor", "vadv", "hadv", "xadv", "yadv", "prsgrd", "vvisc", "hvisc", "xvisc", "yvisc", "accel")
 
 
 @pytest.mark.parametrize("which", LIBS)
@@ -496,7 +503,17 @@ def test_diagnostics_file_holds_the_reference_set_diags_terms(which, tag, ndt, t
         if step in (4, 7):
             want[step] = {n: O.field(n).copy() for n in ("DiaTrc", "dia_zeta")}
     ufinal = O.field("u").copy()
-    cs.update(NDIA=3, NTSDIA=1, DIANAME=dia, Dout=DOUT, ninfo=0)
+    O.close()
+    # ... and the momentum terms (DIAGNOSTICS_UV) of a second oracle run
+    O = util.make_oracle(cs, g)
+    O.set_dia_window(3, 1, uv=True)
+    O.start()
+    for step in range(1, 8):
+        O.main3d_step()
+        if step in (4, 7):
+            want[step].update({n: O.field(n).copy() for n in ("DiaU2d", "DiaV2d", "DiaU3d", "DiaV3d")})
+    assert np.array_equal(O.field("u"), ufinal)                # the terms do not change the run
+    cs.update(NDIA=3, NTSDIA=1, DIANAME=dia, Dout=dict(DOUT, **DOUT_UV), ninfo=0)
     H, ctx = _host(cs, which)
     H.advance(7, final=False)
     t = H.tile
@@ -516,6 +533,13 @@ def test_diagnostics_file_holds_the_reference_set_diags_terms(which, tag, ndt, t
     assert V["temp_hadv"].dimensions == ("ocean_time", "s_rho", "eta_rho", "xi_rho")
     assert V["temp_hadv"].long_name == b"potential temperature, horizontal advection term"
     assert V["temp_rate"].units == b"Celsius second-1" and V["salt_vdiff"].long_name == b"salinity, vertical diffusion term"
+    assert V["ubar_prsgrd"].dimensions == ("ocean_time", "eta_u", "xi_u") and V["v_vvisc"].dimensions == ("ocean_time", "s_rho", "eta_v", "xi_v")
+    assert V["ubar_accel"].long_name == b"2D u-momentum, acceleration term" and V["u_cor"].units == b"meter second-2"
+    assert V["v_xadv"].standard_name == b"sea_water_y_velocity_tendency_due_to_horizontal_x_advection"
+    assert V["u_vvisc"].field == b"u-velocity vertical-viscosity" and V["vbar_sstr"].field == b"v-barotropic surface stress"
+    # the variables come in def_diags.F's order: zeta, the 2-D momentum terms (u, v per term), the 3-D ones, the tracers
+    names_in_file = [n for n in V if n.split("_")[0] in ("ubar", "vbar", "u", "v", "temp", "salt") and "_" in n]
+    assert names_in_file[:4] == ["ubar_cor", "vbar_cor", "ubar_hadv", "vbar_hadv"] and names_in_file.index("u_cor") < names_in_file.index("temp_hadv")
     ni, nj = t["UBi"] - t["LBi"] + 1, t["UBj"] - t["LBj"] + 1
     Lm, Mm, N = cs["Lm"], cs["Mm"], cs["N"]
     win = lambda a: a[..., 0 - t["LBj"]:Mm + 2 - t["LBj"], 0 - t["LBi"]:Lm + 2 - t["LBi"]]
@@ -531,6 +555,19 @@ def test_diagnostics_file_holds_the_reference_set_diags_terms(which, tag, ndt, t
                 a = win(D[k, it]) * (1.0 / cs["dt"])
                 b = V[f"{tr}_{x}"][rec]
                 assert np.array_equal(a, b) if exact else np.abs(b - a).max() <= 1e-11 * max(np.abs(a).max(), 1e-30), (step, tr, x)
+        # momentum terms: DiaU2d / DiaV2d / DiaU3d / DiaV3d times 1/dt, named <ubar|vbar|u|v>_<term>
+        for (name, src, morder, lev) in (("ubar", "DiaU2d", M2_ORDER, 1), ("vbar", "DiaV2d", M2_ORDER, 1), ("u", "DiaU3d", M3_ORDER, N),
+                                         ("v", "DiaV3d", M3_ORDER, N)):
+            D = want[step][src].reshape(len(morder), lev, nj, ni)
+            i0, j0 = (1, 0) if name in ("ubar", "u") else (0, 1)
+            for k, x in enumerate(morder):
+                if (name, x) == ("u", "yvisc") or (name, x) == ("v", "yvisc"):
+                    assert f"{name}_{x}" not in V
+                    continue
+                a = D[k][:, j0 - t["LBj"]:Mm + 2 - t["LBj"], i0 - t["LBi"]:Lm + 2 - t["LBi"]] * (1.0 / cs["dt"])
+                b = V[f"{name}_{x}"][rec]
+                a = a.reshape(b.shape)
+                assert np.array_equal(a, b) if exact else np.abs(b - a).max() <= 1e-10 * max(np.abs(a).max(), 1e-30), (step, name, x)
         # the budget of the window closes (interior points)
         r = V["temp_rate"][rec][:, 1:-1, 1:-1]
         s = sum(V[f"temp_{x}"][rec][:, 1:-1, 1:-1] for x in ("hadv", "vadv", "hdiff", "vdiff"))

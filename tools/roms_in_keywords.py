@@ -71,6 +71,9 @@ def classify(k):
         return "honoured", "switch of the averages / history writer (roms_output.f90)"
     if re.match(r"^Dout\(iT(rate|hadv|xadv|yadv|vadv|hdif|xdif|ydif|sdif|vdif)\)$", k):
         return "honoured", "switch of the diagnostics writer, tracer terms (DIAGNOSTICS_TS; roms_output.f90)"
+    if re.match(r"^Dout\(M2(rate|pgrd|fcor|hadv|xadv|yadv|hvis|xvis|yvis|sstr|bstr)\)$", k) or \
+       re.match(r"^Dout\(M3(rate|pgrd|fcor|hadv|xadv|yadv|vadv|hvis|xvis|yvis|vvis)\)$", k):
+        return "honoured", "switch of the diagnostics writer, momentum terms (DIAGNOSTICS_UV; roms_output.f90)"
     if k in CHECKED:
         return "checked", CHECKED[k]
     for rx, why in INERT_RULES:
