@@ -49,8 +49,8 @@ int run_step2d(roms_hip_ctx *c) {
   // kernel variant by sub-tile size: up to 32x4, up to 64x8, generic (ROMS_HIP_TILE2D overrides)
   int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 32 && G.bh2 <= 8) ? 3 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
   if (getenv("ROMS_HIP_S2D_GENERIC") || (G.masking && variant != 0)) variant = 2;   // (masks: k_step2d_am or the generic form)
-  if (a.commit && (variant != 0 || G.masking)) variant = 2;
-  if (G.dia_uv) variant = 2;                                      // DIAGNOSTICS_UV: the generic form carries the term stores (k_step2d_duv)       // behind a pair launch: k_step2d_ac or the generic form commit the staged level
+  if (a.commit && (variant != 0 || G.masking)) variant = 2;       // behind a pair launch: k_step2d_ac or the generic form commit the staged level
+  if (G.dia_uv) variant = 2;                                      // DIAGNOSTICS_UV: the generic form carries the term stores (k_step2d_duv)
   // 64x8 sub-tiles: 1024 threads (one rectangle point and one momentum point per thread) measure 3 %
   // faster than 512 threads with two each; ROMS_HIP_S2D_1024=0 selects the latter
   const char *e1024 = getenv("ROMS_HIP_S2D_1024");
@@ -175,6 +175,7 @@ int run_step2d_pair(roms_hip_ctx *c) {
   const roms_hip_config &cf = c->cfg;
   const int iif = G.iif;
   if (!G.predictor || iif < 2 || iif > G.nfast || G.knew != 3 || G.krhs == 3) { set_error("step2d_pair: needs the stepping of a predictor call, 2 <= iif <= nfast"); return 8; }
+  if (G.dia_uv) { set_error("step2d_pair: the momentum diagnostics (DIAGNOSTICS_UV) are carried by the per-call kernel"); return 8; }
   Step2dPairArgs a;
   a.G = G;
   S2F_FILL(a.F, c->F);
