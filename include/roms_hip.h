@@ -238,6 +238,11 @@ int roms_hip_avg_time(roms_hip_ctx *ctx, double *avgtime);
    downloaded.  exit_flag 5: MPDATA tracers, applications without SPLINES_VDIFF.  DIAGNOSTICS_UV is not built. */
 int roms_hip_dia_config(roms_hip_ctx *ctx, int nDIA, int ntsDIA, int nrrec, int ntstart);
 int roms_hip_set_diags(roms_hip_ctx *ctx);
+/* Biharmonic horizontal mixing along s-surfaces (UV_VIS4 + MIX_S_UV: uv3dmix4_s.h:119-627 and step2d_LF_AM3.h:1653-1920;
+   TS_DIF4 + MIX_S_TS: t3dmix4_s.h:94-478): between roms_hip_create and roms_hip_start.  Upload "visc4_r", "visc4_p", "diff4"
+   (the SQUARE ROOTS of VISC4, TNU4: inp_par.F:634, read_phypar.F:7840) and leave "visc2_r", "visc2_p", "diff2" zero.  UV_VIS4
+   needs Nghost = 3 (inp_par.F:214). */
+int roms_hip_mix4_config(roms_hip_ctx *ctx, int uv_vis4, int ts_dif4);
 /* DIAGNOSTICS_UV (mod_diags.F:174-222; the DiaU2rhs / DiaRU / DiaU3wrk statements of step2d_LF_AM3.h, rhs3d.F, prsgrd32.h,
    uv3dmix2_s.h, pre_step3d.F, step3d_uv.F): per-term momentum tendencies.  After roms_hip_dia_config (whose window it shares):
    allocates DIAGS(ng)%DiaU2wrk, DiaV2wrk, DiaRUbar, DiaRVbar, DiaU2int, DiaV2int, DiaRUfrc, DiaRVfrc, DiaU3wrk, DiaV3wrk,

@@ -157,6 +157,8 @@ typedef struct orc_s {
   double *Uwind, *Vwind, *Tair, *Pair, *Hair, *rain, *cloud, *lhflx, *shflx, *lrflx, *evap;
   /* mod_mixing */
   double *Akv, *Akt, *visc2_r, *visc2_p, *diff2, *bvf, *alpha, *beta, *hsbl, *ghats;
+  double *visc4_r, *visc4_p, *diff4;     /* UV_VIS4 / TS_DIF4: square roots of the biharmonic coefficients (inp_par.F:634) */
+  int uv_vis4, ts_dif4;                  /* biharmonic mixing along s-surfaces switched on (orc_set_mix4; orc_mix4.c) */
   double *tke, *gls, *Lscale, *Akk, *Akp;   /* GLS_MIXING: tke, gls(i,j,0:N,3); Lscale, Akk, Akp(i,j,0:N) */
   int *ksbl;
   /* mod_boundary: BOUNDARY(ng)%zeta_west(LBj:UBj) ... t_north(LBi:UBi,N,NT): the open-boundary data of this step (inputs) */
@@ -283,6 +285,11 @@ typedef struct orc_diauv {
   double *RU, *RV;             /* (i,j,N,2,NDrhs) */
   double *U2d, *V2d, *U3d, *V3d;   /* the accumulated output of set_diags */
 } orc_diauv;
+/* biharmonic horizontal mixing along s-surfaces (UV_VIS4 + MIX_S_UV, TS_DIF4 + MIX_S_TS): orc_mix4.c */
+void orc_set_mix4(orc_t *o, int uv_vis4, int ts_dif4);
+void orc_t3dmix4(orc_t *o, int tile);
+void orc_uv3dmix4(orc_t *o, int tile);
+void orc_step2d_vis4(orc_t *o, const orc_bounds *b, int krhs, const double *Drhs, double *rhs_ubar, double *rhs_vbar, double *U2rhs, double *V2rhs);
 int orc_set_diauv(orc_t *o);                 /* allocate (the window is the one of orc_set_dia_window) */
 void orc_diauv_free(orc_t *o);
 void orc_set_diags_uv(orc_t *o, int tile, int init, int accum, int convert, double fac);

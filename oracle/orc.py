@@ -163,6 +163,11 @@ class Oracle:
         if uv:
             self.L.orc_set_diauv(C.c_void_p(self.h))
 
+    def set_mix4(self, uv_vis4, ts_dif4):
+        """biharmonic mixing along s-surfaces on (UV_VIS4 | TS_DIF4): fields "visc4_r", "visc4_p", "diff4" hold the square
+        roots of the coefficients"""
+        self.L.orc_set_mix4(C.c_void_p(self.h), int(uv_vis4), int(ts_dif4))
+
     def start(self):
         self.L.orc_start(self.h)
 

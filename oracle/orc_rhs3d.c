@@ -1172,6 +1172,8 @@ void orc_rhs3d(orc_t *o, int tile) {
   orc_pre_step3d(o, tile);
   orc_prsgrd(o, tile);
   orc_t3dmix2(o, tile);
+  orc_t3dmix4(o, tile);              /* rhs3d.F:141-153: TS_DIF4 behind TS_DIF2 */
   orc_rhs3d_tile(o, tile);
   orc_uv3dmix2(o, tile);
+  orc_uv3dmix4(o, tile);             /* :170-178 */
 }

@@ -409,6 +409,8 @@ void orc_step2d(orc_t *o, int tile) {
       }
   }
 
+  if (o->uv_vis4) orc_step2d_vis4(o, b, krhs, Drhs, rhs_ubar, rhs_vbar, U2rhs, V2rhs);   /* UV_VIS4 :1653-1920 (orc_mix4.c) */
+
   /* coupling with the 3-D momentum forcing :2225-2460 */
   if (iif == 1 && PRED) {
     if (iic == c->ntfirst) {

@@ -70,6 +70,11 @@ if [ "$APP" = upwelling_prs31 ] || [ "$APP" = upwelling_wjgradp ] || [ "$APP" = 
   UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
   EXTRA=""
 fi
+if [ "$APP" = upwelling_bih ]; then
+  # UPWELLING with biharmonic mixing (oracle/ref/upwelling_bih.h: UV_VIS4, TS_DIF4 along s-surfaces)
+  UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
+  EXTRA=""
+fi
 if [ "$APP" = upwelling_gls ]; then
   # the shipped upwelling.h with the generic length-scale closure switched on as a user does (-DGLS_MIXING: upwelling.h
   # then selects KANTHA_CLAYSON, N2S2_HORAVG, RI_SPLINES)

@@ -215,6 +215,14 @@
       nl_visc2(ng)=rpar(11)
       nl_tnu2(1,ng)=rpar(12)
       nl_tnu2(2,ng)=rpar(13)
+#ifdef UV_VIS4
+!  (biharmonic variants: rpar(11:13) are VISC4 and TNU4 of roms.in; inp_par.F:634 and read_phypar.F:7840 take their square roots)
+      nl_visc4(ng)=SQRT(ABS(rpar(11)))
+#endif
+#ifdef TS_DIF4
+      nl_tnu4(1,ng)=SQRT(ABS(rpar(12)))
+      nl_tnu4(2,ng)=SQRT(ABS(rpar(13)))
+#endif
       Akt_bak(1,ng)=rpar(14)
       Akt_bak(2,ng)=rpar(15)
       Akv_bak(ng)=rpar(16)
@@ -260,6 +268,9 @@
 !
       ThreeGhostPoints=ANY(Hadvection(:,:)%MPDATA).or.                  &
      &                 ANY(Hadvection(:,:)%HSIMT)
+#ifdef UV_VIS4
+      ThreeGhostPoints=.TRUE.                        ! inp_par.F:214-216
+#endif
       IF (ThreeGhostPoints) THEN
         NghostPoints=3
       ELSE
@@ -1202,6 +1213,13 @@
 #ifdef UV_VIS2
         F2('visc2_r',MIXING(ng)%visc2_r)
         F2('visc2_p',MIXING(ng)%visc2_p)
+#endif
+#ifdef UV_VIS4
+        F2('visc4_r',MIXING(ng)%visc4_r)
+        F2('visc4_p',MIXING(ng)%visc4_p)
+#endif
+#ifdef TS_DIF4
+        F2('diff4',MIXING(ng)%diff4)
 #endif
 #ifdef TS_DIF2
         F2('diff2',MIXING(ng)%diff2)

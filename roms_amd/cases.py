@@ -153,6 +153,16 @@ def upwelling_prs40(**kw):
     return cs
 
 
+def upwelling_bih(visc4=4.0e8, tnu4=(2.0e7, 1.0e7), **kw):
+    """UPWELLING with biharmonic mixing of momentum and tracers along s-surfaces (UV_VIS4, TS_DIF4: the custom application
+    header oracle/ref/upwelling_bih.h) in place of the harmonic operators; VISC4, TNU4 [m4/s] as roms.in gives them"""
+    cs = upwelling(**kw)
+    cs["app"] = "upwelling_bih"
+    cs["options"] = tuple(o for o in cs["options"] if o not in ("UV_VIS2", "TS_DIF2"))
+    cs["mix4"], cs["visc4"], cs["tnu4"] = (1, 1), visc4, tuple(tnu4)
+    return cs
+
+
 def upwelling_prs31(wj=False, **kw):
     """UPWELLING with the standard density Jacobian (prsgrd31.h: no DJ_GRADPS; wj: WJ_GRADP, the weighted form): the custom
     application headers oracle/ref/upwelling_prs31.h, upwelling_wjgradp.h"""
@@ -306,7 +316,7 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
     c.Lm, c.Mm, c.N, c.NT, c.NAT = cs["Lm"], cs["Mm"], cs["N"], 2, 2
     hs = [SCHEME[x] for x in cs["hadv"]]
     vs = [SCHEME[x] for x in cs["vadv"]]
-    c.Nghost = 3 if (hiplib.MPDATA in hs or hiplib.HSIMT in hs) else 2
+    c.Nghost = 3 if (hiplib.MPDATA in hs or hiplib.HSIMT in hs or cs.get("mix4", (0, 0))[0]) else 2     # inp_par.F:210-223
     Im = cs["Lm"] + ((cs["Lm"] + 2) // 2 - (cs["Lm"] + 1) // 2)
     Jm = cs["Mm"] + ((cs["Mm"] + 2) // 2 - (cs["Mm"] + 1) // 2)
     c.LBi, c.UBi = (-c.Nghost, Im + c.Nghost) if cs["EWperiodic"] else (0, Im + 1)
@@ -317,6 +327,8 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
     opt = 0
     for name in cs["options"]:
         opt |= hiplib.OPTIONS[name]
+    if "mix4" in cs:        # biharmonic cases: the library keeps its harmonic operators (zero coefficients add exact zeros)
+        opt |= hiplib.OPTIONS["UV_VIS2"] | hiplib.OPTIONS["TS_DIF2"]
     c.options = opt
     for i in range(2):
         c.hadv[i], c.vadv[i] = hs[i], vs[i]

@@ -2,6 +2,7 @@
 #include "roms_host.h"
 #include <cstdlib>
 #include "k_rhs3d.h"
+#include "k_mix4.h"
 #ifndef ROMS_CPU_EMU
 #include "k_rhs3d_lds.h"
 #include "k_tadv_lds.h"
@@ -165,10 +166,27 @@ int run_prsgrd(roms_hip_ctx *c) {
   return run_duv_pgrd(c);                          // DIAGNOSTICS_UV: DiaRU(M3pgrd) = ru as prsgrd leaves it
 }
 
+// biharmonic operators (k_mix4.h): t3dmix4 behind t3dmix2 (rhs3d.F:107-115); uv3dmix4 in uv3dmix2's place (:181-189; with
+// UV_VIS4 the harmonic coefficients are zero and its kernel is skipped: its terms would be exact zeros)
+static void launch_t3dmix4(roms_hip_ctx *c) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_t3dmix4, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N * G.NT, c->stream, a);
+}
+static void launch_uv3dmix4(roms_hip_ctx *c, int defer) {
+  const DGrid &G = c->G;
+  const TB &B = G.T;
+  KArgs a = mk(c);
+  LAUNCH_THREAD(k_uv4_lap, B.Iend - B.Istr + 3, B.Jend - B.Jstr + 3, G.N, c->stream, a);
+  a.p1 = defer;
+  LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix4_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
+}
 int run_t3dmix2(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   if (!(G.options & ROMS_TS_DIF2)) return 0;
+  if (G.ts_dif4) { launch_t3dmix4(c); return 0; }      // (TS_DIF4: diff2 is zero, t3dmix2 would add exact zeros)
   if (G.options & (ROMS_MIX_GEO_TS | ROMS_MIX_ISO_TS)) return run_t3dmix2_geo(c);     // (the isopycnic form: the same marching kernel on pden)
   KArgs a = mk(c);
   static const char *et = getenv("ROMS_HIP_T3CH");
@@ -189,6 +207,8 @@ int run_uv3dmix2(roms_hip_ctx *c) {
   const TB &B = G.T;
   if (!(G.options & ROMS_UV_VIS2)) return 0;
   KArgs a = mk(c);
+  if (G.uv_vis4) launch_uv3dmix4(c, c->late_pre ? 1 : 0);
+  else
   { // levels per thread: KCH unrolled on small grids; on large ones a thread marches the column in
     // ceil(N/30) equal parts (measured, us: 512x512x50 KCH 349, 17: 318, 25: 296, 50: 330;
     // 2048x256x30 KCH 425, 15: 375, 30: 365; 512x64x30 KCH 29, 10: 30, 25: 45).  ROMS_HIP_UVCH overrides.
@@ -262,6 +282,7 @@ int run_uv3dmix2_s(roms_hip_ctx *c) {
   const TB &B = G.T;
   if (!(G.options & ROMS_UV_VIS2)) return 0;
   KArgs a = mk(c);
+  if (G.uv_vis4) { launch_uv3dmix4(c, 0); return 0; }
   { // levels per thread: KCH unrolled on small grids; on large ones a thread marches the column in
     // ceil(N/30) equal parts (measured, us: 512x512x50 KCH 349, 17: 318, 25: 296, 50: 330;
     // 2048x256x30 KCH 425, 15: 375, 30: 365; 512x64x30 KCH 29, 10: 30, 25: 45).  ROMS_HIP_UVCH overrides.
@@ -282,7 +303,7 @@ int run_uv3dmix2_col(roms_hip_ctx *c) {
 #else
   const DGrid &G = c->G;
   const TB &B = G.T;
-  if (!(G.options & ROMS_UV_VIS2) || G.masking || G.dia_uv) return -1;   // (the column form carries no land/sea masks and leaves no per-level terms)
+  if (!(G.options & ROMS_UV_VIS2) || G.masking || G.dia_uv || G.uv_vis4) return -1;   // (the column form carries no land/sea masks and leaves no per-level terms)
   static const char *e = getenv("ROMS_HIP_UVCOL");
   const int nx = B.Iend - B.Istr + 1, ny = B.Jend - B.Jstr + 1;
   const bool big = (long)nx * ny >= 128L * 1024L;

@@ -50,7 +50,7 @@ int run_step2d(roms_hip_ctx *c) {
   int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 32 && G.bh2 <= 8) ? 3 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
   if (getenv("ROMS_HIP_S2D_GENERIC") || (G.masking && variant != 0)) variant = 2;   // (masks: k_step2d_am or the generic form)
   if (a.commit && (variant != 0 || G.masking)) variant = 2;       // behind a pair launch: k_step2d_ac or the generic form commit the staged level
-  if (G.dia_uv) variant = 2;                                      // DIAGNOSTICS_UV: the generic form carries the term stores (k_step2d_duv)
+  if (G.dia_uv || G.uv_vis4) variant = 2;                         // (UV_VIS4: the generic form carries the biharmonic block, k_step2d_vis4)                                      // DIAGNOSTICS_UV: the generic form carries the term stores (k_step2d_duv)
   // 64x8 sub-tiles: 1024 threads (one rectangle point and one momentum point per thread) measure 3 %
   // faster than 512 threads with two each; ROMS_HIP_S2D_1024=0 selects the latter
   const char *e1024 = getenv("ROMS_HIP_S2D_1024");
@@ -60,7 +60,7 @@ int run_step2d(roms_hip_ctx *c) {
 #endif
   const int tw = variant == 0 || variant == 3 ? 38 : variant == 1 ? 70 : G.bw2 + 6;
   const int th = variant == 0 ? 10 : variant == 1 || variant == 3 ? 14 : G.bh2 + 6;
-  const size_t lds = (size_t)STEP2D_NLDS * (size_t)tw * (size_t)th;
+  const size_t lds = (size_t)(STEP2D_NLDS + (G.uv_vis4 ? 2 : 0)) * (size_t)tw * (size_t)th;   // (+ LapU, LapV)
   if (variant == 0) {
     if (G.masking) LAUNCH_COOP_AS(k_step2d, k_step2d_am, G.nbx2, G.nby2, 1, 384, lds, c->stream, a);
     else if (a.commit) LAUNCH_COOP_AS(k_step2d, k_step2d_ac, G.nbx2, G.nby2, 1, 384, lds, c->stream, a);
@@ -107,7 +107,19 @@ int run_step2d(roms_hip_ctx *c) {
       big_lds_g = true;
     }
 #endif
-    if (G.dia_uv) {
+    if (G.uv_vis4) {
+#ifndef ROMS_CPU_EMU
+      static bool big_lds_4 = false;
+      if (lds * sizeof(double) > 64 * 1024 && !big_lds_4) {
+        if (hipFuncSetAttribute((const void *)k_step2d_vis4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+          set_error("k_step2d: cannot raise the dynamic LDS limit");
+          return 2;
+        }
+        big_lds_4 = true;
+      }
+#endif
+      LAUNCH_COOP_AS(k_step2d, k_step2d_vis4, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
+    } else if (G.dia_uv) {
 #ifndef ROMS_CPU_EMU
       static bool big_lds_u = false;
       if (lds * sizeof(double) > 64 * 1024 && !big_lds_u) {
@@ -162,6 +174,7 @@ bool step2d_pair_usable(const roms_hip_ctx *c) {
   if (e && e[0] == '0') return false;
   if (G.obc) return false;                                               // open boundaries: zetabc/u2dbc/v2dbc between the two calls (k_obc.h)
   if (G.dia_uv) return false;                                            // DIAGNOSTICS_UV: the per-call kernel carries the term stores
+  if (G.uv_vis4) return false;                                           // UV_VIS4: the per-call generic kernel carries the biharmonic block
   const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
   if (LmT < 8 || MmT < 8) return false;                                  // the rim (5 | 4 lines) comes from the neighbour's / the tile's own points
   if (pair_lds_doubles(G.bw2, G.bh2) * sizeof(double) > 160 * 1024) return false;

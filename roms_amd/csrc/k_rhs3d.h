@@ -997,7 +997,9 @@ THREAD_GLOBAL(k_t3dmix2_m, KArgs)
 // the stress expressions is formed once per chunk, in the reference's association order.
 // MARCH: a thread marches a.p2 levels in a loop (the level-independent products are formed once for all
 // of them, one level is live at a time) instead of KCH unrolled ones
-template <bool MARCH>
+// VIS4: the SECOND harmonic operator of uv3dmix4_s.h:526-622 -- the same stress tensor of (LapU, LapV) (k_mix4.h: k_uv4_lap)
+// with visc4 in place of visc2; its terms are stored negated (u - cff3 == u + (-cff3), rufrc - cff1 - cff2 likewise)
+template <bool MARCH, bool VIS4 = false>
 THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
@@ -1029,10 +1031,11 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
   RSET(rs_, xs); PSET(pe_, x + 1);         // v-point: rho point (i,j-1), psi point (i+1,j)
 #undef RSET
 #undef PSET
-  const double fur1 = F.on_r[x] * F.on_r[x] * F.visc2_r[x], fur0 = F.on_r[x - 1] * F.on_r[x - 1] * F.visc2_r[x - 1];
-  const double fup1 = F.om_p[x + ni] * F.om_p[x + ni] * F.visc2_p[x + ni], fup0 = F.om_p[x] * F.om_p[x] * F.visc2_p[x];
-  const double fvp1 = F.on_p[x + 1] * F.on_p[x + 1] * F.visc2_p[x + 1], fvp0 = F.on_p[x] * F.on_p[x] * F.visc2_p[x];
-  const double fvr1 = F.om_r[x] * F.om_r[x] * F.visc2_r[x], fvr0 = F.om_r[x - ni] * F.om_r[x - ni] * F.visc2_r[x - ni];
+  const double *v_r = VIS4 ? (const double *)F.visc4_r : (const double *)F.visc2_r, *v_p = VIS4 ? (const double *)F.visc4_p : (const double *)F.visc2_p;
+  const double fur1 = F.on_r[x] * F.on_r[x] * v_r[x], fur0 = F.on_r[x - 1] * F.on_r[x - 1] * v_r[x - 1];
+  const double fup1 = F.om_p[x + ni] * F.om_p[x + ni] * v_p[x + ni], fup0 = F.om_p[x] * F.om_p[x] * v_p[x];
+  const double fvp1 = F.on_p[x + 1] * F.on_p[x + 1] * v_p[x + 1], fvp0 = F.on_p[x] * F.on_p[x] * v_p[x];
+  const double fvr1 = F.om_r[x] * F.om_r[x] * v_r[x], fvr0 = F.om_r[x - ni] * F.om_r[x - ni] * v_r[x - ni];
   const double ucff = G.dt * 0.25 * (pm[x - 1] + pm[x]) * (pn[x - 1] + pn[x]);
   const double uc1 = 0.5 * (pn[x - 1] + pn[x]), uc2 = 0.5 * (pm[x - 1] + pm[x]);
   const double vcff = G.dt * 0.25 * (pm[x] + pm[x - ni]) * (pn[x] + pn[x - ni]);
@@ -1043,7 +1046,8 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
     if (k > N) break;
     const size_t ok = (size_t)(k - 1) * nij;
     const double *Hz = F.Hz + ok + x;
-    const double *u = F.u + (size_t)(nrhs - 1) * nij * (size_t)N + ok + x, *v = F.v + (size_t)(nrhs - 1) * nij * (size_t)N + ok + x;
+    const double *u = VIS4 ? (const double *)F.lap4 + ok + x : F.u + (size_t)(nrhs - 1) * nij * (size_t)N + ok + x;
+    const double *v = VIS4 ? (const double *)F.lap4 + (size_t)N * nij + ok + x : F.v + (size_t)(nrhs - 1) * nij * (size_t)N + ok + x;
     // stress at rho point with coefficient set c, centred at offset o; at psi point likewise
 #define CFFR(c, o) (Hz[o] * 0.5 * (c##0 * (c##1 * u[(o) + 1] - c##2 * u[o]) - c##3 * (c##4 * v[(o) + ni] - c##5 * v[o])))
 #define CFFP(c, o)                                                                              \
@@ -1063,6 +1067,7 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
       const double UFe0 = fup0 * cP;
       u1 = uc1 * (UFx1 - UFx0);
       u2 = uc2 * (UFe1 - UFe0);
+      if (VIS4) { u1 = -u1; u2 = -u2; }
       if (!defer) {
         const double cff3 = ucff * (u1 + u2);
         un = F.u[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] + cff3;
@@ -1078,6 +1083,7 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
       const double VFe0 = fvr0 * cRs;
       v1 = vc1 * (VFx1 - VFx0);
       v2 = vc2 * (VFe1 - VFe0);
+      if (VIS4) { v1 = -v1; v2 = -v2; }
       if (!defer) {
         const double cff3 = vcff * (v1 - v2);
         vn = F.v[(size_t)(nnew - 1) * nij * (size_t)N + ok + x] + cff3;
@@ -1099,6 +1105,8 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
 }
 THREAD_KERNEL(k_uv3dmix2_s, KArgs) { k_uv3dmix2_t_body<false>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_uv3dmix2_s, KArgs)
+THREAD_KERNEL(k_uv3dmix4_s, KArgs) { k_uv3dmix2_t_body<false, true>(a, gx, gy, gz); }   // uv3dmix4_s.h's second operator
+THREAD_GLOBAL(k_uv3dmix4_s, KArgs)
 THREAD_KERNEL(k_uv3dmix2_m, KArgs) { k_uv3dmix2_t_body<true>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_uv3dmix2_m, KArgs)
 

@@ -87,9 +87,9 @@ THREAD_KERNEL(k_pack_m2d, PackArgs) {
   const Fields &F = a.Fv;
   const size_t x = (size_t)gx + (size_t)gy * (size_t)G.ni;
   double *r = F.m2r + 8 * x, *p = F.m2p + 8 * x;
-  r[MR_FOMN] = F.fomn[x]; r[MR_DNDX] = F.dndx[x]; r[MR_DMDE] = F.dmde[x]; r[MR_V2] = F.visc2_r[x];
+  r[MR_FOMN] = F.fomn[x]; r[MR_DNDX] = F.dndx[x]; r[MR_DMDE] = F.dmde[x]; r[MR_V2] = G.uv_vis4 ? F.visc4_r[x] : F.visc2_r[x];   // (UV_VIS4: the biharmonic coefficient in its place)
   r[MR_PMON] = F.pmon_r[x]; r[MR_PNOM] = F.pnom_r[x]; r[MR_ON] = F.on_r[x]; r[MR_OM] = F.om_r[x];
-  p[MP_V2] = F.visc2_p[x]; p[MP_PMON] = F.pmon_p[x]; p[MP_PNOM] = F.pnom_p[x]; p[MP_OM] = F.om_p[x];
+  p[MP_V2] = G.uv_vis4 ? F.visc4_p[x] : F.visc2_p[x]; p[MP_PMON] = F.pmon_p[x]; p[MP_PNOM] = F.pnom_p[x]; p[MP_OM] = F.om_p[x];
   p[MP_ON] = F.on_p[x]; p[MP_ONU] = F.on_u[x]; p[MP_OMV] = F.om_v[x]; p[MP_SPARE] = 0.0;
 }
 THREAD_GLOBAL(k_pack_m2d, PackArgs)
@@ -128,7 +128,11 @@ THREAD_GLOBAL(k_pack_m2d, PackArgs)
 #else
 #define S2D_TICK(n) ((void)0)
 #endif
-template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0), bool CM = (BWC == 0), int PWR = PTS, bool DUV = false>
+// VIS4 (generic form only): the UV_VIS4 block of step2d_LF_AM3.h:1653-1920 -- two more LDS tiles hold the first harmonic
+// operator LapU, LapV of ubar, vbar(krhs) on the sub-tile + 1 with its closed / gradient conditions and corner values; the
+// momentum stage then forms the same stress tensor of (LapU, LapV) times the total depth.  The packed metric records carry
+// visc4 in the place of visc2 (g_step2d.cpp:pack_metrics).
+template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0), bool CM = (BWC == 0), int PWR = PTS, bool DUV = false, bool VIS4 = false>
 COOP_KERNEL(k_step2d_t, Step2dArgs) {
   (void)bz;
 #ifndef ROMS_CPU_EMU
@@ -153,6 +157,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
   double *zwrk = lds + 4 * sz, *gzeta = lds + 5 * sz, *gzeta2 = lds + 6 * sz, *gzetaSA = lds + 7 * sz;
   double *sUk = lds + 8 * sz, *sVk = lds + 9 * sz, *sH = lds + 10 * sz, *sPm = lds + 11 * sz, *sPn = lds + 12 * sz,
          *sRhoA = lds + 13 * sz, *sDstp = lds + 14 * sz;
+  double *sLU = VIS4 ? lds + 15 * sz : nullptr, *sLV = VIS4 ? lds + 16 * sz : nullptr;
   const int krhs = G.krhs, kstp = G.kstp, knew = G.knew, nstp = G.nstp, nnew = G.nnew, iif = G.iif, iic = G.iic;
   const bool PRED = G.predictor != 0;
   const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend, IstrU = B.IstrU, JstrV = B.JstrV;
@@ -219,7 +224,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
       }
       PWLOAD(r_zk, zkv);
       PWLOAD(r_on_u, F.on_u[x0]); PWLOAD(r_om_v, F.om_v[x0]);
-      if (ring2) { sPm[s0] = F.pm[x0]; sPn[s0] = F.pn[x0]; }
+      if (ring2 || VIS4) { sPm[s0] = F.pm[x0]; sPn[s0] = F.pn[x0]; }      // (UV_VIS4: the first operator on the sub-tile + 1 reads pm, pn three points out)
       if (ring1) {
         const double zsv = F.zeta[x0 + o_kstp];
         sDstp[s0] = zsv + hv;
@@ -381,6 +386,89 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
   KSYNC();
   S2D_TICK(4);
 
+  if (VIS4) {
+    // ---- stage 3b (UV_VIS4): first harmonic operator of ubar, vbar(krhs) :1667-1722, no thickness in it
+    const int clu = (int)((G.lbc_closed >> (4 * ROMS_ISUBAR)) & 15ull), clv = (int)((G.lbc_closed >> (4 * ROMS_ISVBAR)) & 15ull);
+    const double gamma2 = G.gamma2;
+#define SU_(o) sUk[s0 + (o)]
+#define SV_(o) sVk[s0 + (o)]
+#define SPM_(o) sPm[s0 + (o)]
+#define SPN_(o) sPn[s0 + (o)]
+    // stress at the rho point at tile offset o (record r), at the psi point at tile offset o (record p)
+#define S4R(o, r) ((r).v[MR_V2] * 0.5 *                                                                              \
+                   ((r).v[MR_PMON] * ((SPN_(o) + SPN_((o) + 1)) * SU_((o) + 1) - (SPN_((o) - 1) + SPN_(o)) * SU_(o)) -      \
+                    (r).v[MR_PNOM] * ((SPM_(o) + SPM_((o) + TW)) * SV_((o) + TW) - (SPM_((o) - TW) + SPM_(o)) * SV_(o))))
+#define S4P(o, p) ((p).v[MP_V2] * 0.5 *                                                                              \
+                   ((p).v[MP_PMON] * ((SPN_((o) - TW) + SPN_(o)) * SV_(o) - (SPN_((o) - 1 - TW) + SPN_((o) - 1)) * SV_((o) - 1)) +   \
+                    (p).v[MP_PNOM] * ((SPM_((o) - 1) + SPM_(o)) * SU_(o) - (SPM_((o) - 1 - TW) + SPM_((o) - TW)) * SU_((o) - TW))))
+    RLOOP(i, j) {
+      const bool inU = INR(i, j, IstrU - 1, Iend + 1, Jstr - 1, Jend + 1), inV = INR(i, j, Istr - 1, Iend + 1, JstrV - 1, Jend + 1);
+      if (inU || inV) {
+        const M2Rec r0 = mr[x0], p0 = mp[x0];
+        const double cR0 = S4R(0, r0);
+        double cP0 = S4P(0, p0);
+        if (MSK) cP0 = cP0 * G.pmask[x0];
+        if (inU) {
+          const M2Rec rw = mr[x0 - 1], pn_ = mp[x0 + ni];
+          const double cRw = S4R(-1, rw);
+          double cPn = S4P(TW, pn_);
+          if (MSK) cPn = cPn * G.pmask[x0 + ni];
+          const double UFx1 = r0.v[MR_ON] * r0.v[MR_ON] * cR0, UFx0 = rw.v[MR_ON] * rw.v[MR_ON] * cRw;
+          const double UFe1 = pn_.v[MP_OM] * pn_.v[MP_OM] * cPn, UFe0 = p0.v[MP_OM] * p0.v[MP_OM] * cP0;
+          sLU[s0] = 0.125 * (SPM_(-1) + SPM_(0)) * (SPN_(-1) + SPN_(0)) *
+                    ((SPN_(-1) + SPN_(0)) * (UFx1 - UFx0) + (SPM_(-1) + SPM_(0)) * (UFe1 - UFe0));
+        }
+        if (inV) {
+          const M2Rec rs = mr[x0 - ni], pe = mp[x0 + 1];
+          const double cRs = S4R(-TW, rs);
+          double cPe = S4P(1, pe);
+          if (MSK) cPe = cPe * G.pmask[x0 + 1];
+          const double VFx1 = pe.v[MP_ON] * pe.v[MP_ON] * cPe, VFx0 = p0.v[MP_ON] * p0.v[MP_ON] * cP0;
+          const double VFe1 = r0.v[MR_OM] * r0.v[MR_OM] * cR0, VFe0 = rs.v[MR_OM] * rs.v[MR_OM] * cRs;
+          sLV[s0] = 0.125 * (SPM_(0) + SPM_(-TW)) * (SPN_(0) + SPN_(-TW)) *
+                    ((SPN_(-TW) + SPN_(0)) * (VFx1 - VFx0) - (SPM_(-TW) + SPM_(0)) * (VFe1 - VFe0));
+        }
+      }
+    }
+#undef S4R
+#undef S4P
+#undef SU_
+#undef SV_
+#undef SPM_
+#undef SPN_
+    KSYNC();
+    // conditions of the first operator at the edges of the domain :1728-1810 (sources: values no condition touches) ...
+    if (wfix || efix || sfix || nfix) {
+      RLOOP(i, j) {
+        const bool cu = ((wfix && i == Istr) || (efix && i == Iend + 1)) && ((sfix && j == Jstr - 1) || (nfix && j == Jend + 1));
+        const bool cv = ((wfix && i == Istr - 1) || (efix && i == Iend + 1)) && ((sfix && j == Jstr) || (nfix && j == Jend + 1));
+        if (!cu && INR(i, j, IstrU - 1, Iend + 1, Jstr - 1, Jend + 1)) {
+          if (wfix && i == Istr) sLU[s0] = (clu & (1 << ROMS_IWEST)) ? 0.0 : sLU[s0 + 1];
+          else if (efix && i == Iend + 1) sLU[s0] = (clu & (1 << ROMS_IEAST)) ? 0.0 : sLU[s0 - 1];
+          else if (sfix && j == Jstr - 1) sLU[s0] = (clu & (1 << ROMS_ISOUTH)) ? gamma2 * sLU[s0 + TW] : 0.0;
+          else if (nfix && j == Jend + 1) sLU[s0] = (clu & (1 << ROMS_INORTH)) ? gamma2 * sLU[s0 - TW] : 0.0;
+        }
+        if (!cv && INR(i, j, Istr - 1, Iend + 1, JstrV - 1, Jend + 1)) {
+          if (wfix && i == Istr - 1) sLV[s0] = (clv & (1 << ROMS_IWEST)) ? gamma2 * sLV[s0 + 1] : 0.0;
+          else if (efix && i == Iend + 1) sLV[s0] = (clv & (1 << ROMS_IEAST)) ? gamma2 * sLV[s0 - 1] : 0.0;
+          else if (sfix && j == Jstr) sLV[s0] = (clv & (1 << ROMS_ISOUTH)) ? 0.0 : sLV[s0 + TW];
+          else if (nfix && j == Jend + 1) sLV[s0] = (clv & (1 << ROMS_INORTH)) ? 0.0 : sLV[s0 - TW];
+        }
+      }
+      KSYNC();
+      // ... and the corner values :1812-1853
+      if (!(G.ewp || G.nsp)) {
+        RLOOP(i, j) {
+          const int di = (wfix && i == Istr) ? 1 : ((efix && i == Iend + 1) ? -1 : 0), dj = (sfix && j == Jstr - 1) ? 1 : ((nfix && j == Jend + 1) ? -1 : 0);
+          if (di && dj) sLU[s0] = 0.5 * (sLU[s0 + di] + sLU[s0 + dj * TW]);
+          const int ei = (wfix && i == Istr - 1) ? 1 : ((efix && i == Iend + 1) ? -1 : 0), ej = (sfix && j == Jstr) ? 1 : ((nfix && j == Jend + 1) ? -1 : 0);
+          if (ei && ej) sLV[s0] = 0.5 * (sLV[s0 + ej * TW] + sLV[s0 + ei]);
+        }
+        KSYNC();
+      }
+    }
+  }
+
   // ---- stage 4: right-hand sides and the momentum step, one work item per momentum point ------
   // Tile accessors relative to s = S2(i,j); the flux helpers below are the reference's expressions
   // for one entry of its private arrays (UFx, UFe, VFx, VFe, ...), edge replication included.
@@ -513,7 +601,46 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
           else { dr[G.m2[M2XADV]] = dr[G.m2[M2XADV]] - fac1 + fac2; dr[G.m2[M2YADV]] = dr[G.m2[M2YADV]] - fac2; dr[G.m2[M2HADV]] = dr[G.m2[M2HADV]] - fac1; }
         }
       }
-      if (VIS) {
+      if (VIS4) {
+        // biharmonic viscosity, second operator :1856-1921: the stress tensor of (LapU, LapV) times the total depth
+#define TLU(di, dj) sLU[s + (di) + (dj) * TW]
+#define TLV(di, dj) sLV[s + (di) + (dj) * TW]
+#define STRESS_R4(a_, b_, v2_, pmon_, pnom_)                                                                       \
+  ((v2_) * TD(a_, b_) * 0.5 *                                                                                      \
+   ((pmon_) * ((TPN(a_, b_) + TPN((a_) + 1, b_)) * TLU((a_) + 1, b_) - (TPN((a_) - 1, b_) + TPN(a_, b_)) * TLU(a_, b_)) - \
+    (pnom_) * ((TPM(a_, b_) + TPM(a_, (b_) + 1)) * TLV(a_, (b_) + 1) - (TPM(a_, (b_) - 1) + TPM(a_, b_)) * TLV(a_, b_))))
+#define DRHS_P4(a_, b_) (0.25 * (TD(a_, b_) + TD((a_) - 1, b_) + TD(a_, (b_) - 1) + TD((a_) - 1, (b_) - 1)))
+#define STRESS_P4(a_, b_, v2_, pmon_, pnom_)                                                                       \
+  ((v2_) * DRHS_P4(a_, b_) * 0.5 *                                                                                 \
+   ((pmon_) * ((TPN(a_, (b_) - 1) + TPN(a_, b_)) * TLV(a_, b_) - (TPN((a_) - 1, (b_) - 1) + TPN((a_) - 1, b_)) * TLV((a_) - 1, b_)) + \
+    (pnom_) * ((TPM((a_) - 1, b_) + TPM(a_, b_)) * TLU(a_, b_) - (TPM((a_) - 1, (b_) - 1) + TPM(a_, (b_) - 1)) * TLU(a_, (b_) - 1))))
+        const int qa = isv ? 1 : 0, qb = isv ? 0 : 1;
+        const double sr0 = STRESS_R4(0, 0, mr[x].v[MR_V2], mr[x].v[MR_PMON], mr[x].v[MR_PNOM]);
+        const double sr1 = STRESS_R4(a1, b1, mr[x1].v[MR_V2], mr[x1].v[MR_PMON], mr[x1].v[MR_PNOM]);
+        double sp0 = STRESS_P4(0, 0, mp[x].v[MP_V2], mp[x].v[MP_PMON], mp[x].v[MP_PNOM]);
+        double sp1 = STRESS_P4(qa, qb, mp[q1].v[MP_V2], mp[q1].v[MP_PMON], mp[q1].v[MP_PNOM]);
+        if (MSK) { sp0 = sp0 * G.pmask[x]; sp1 = sp1 * G.pmask[q1]; }
+        const double or0 = isv ? mr[x].v[MR_OM] : mr[x].v[MR_ON], or1 = isv ? mr[x1].v[MR_OM] : mr[x1].v[MR_ON];
+        const double op0 = isv ? mp[x].v[MP_ON] : mp[x].v[MP_OM], op1 = isv ? mp[q1].v[MP_ON] : mp[q1].v[MP_OM];
+        if (!isv) {
+          const double UFx0 = or0 * or0 * sr0, UFxm = or1 * or1 * sr1, UFe0 = op0 * op0 * sp0, UFep = op1 * op1 * sp1;
+          const double cff1 = 0.5 * (TPN(-1, 0) + TPN(0, 0)) * (UFx0 - UFxm);
+          const double cff2 = 0.5 * (TPM(-1, 0) + TPM(0, 0)) * (UFep - UFe0);
+          const double fac = cff1 + cff2;
+          rhs = rhs - fac;
+        } else {
+          const double VFx0 = op0 * op0 * sp0, VFxp = op1 * op1 * sp1, VFe0 = or0 * or0 * sr0, VFem = or1 * or1 * sr1;
+          const double cff1 = 0.5 * (TPN(0, -1) + TPN(0, 0)) * (VFxp - VFx0);
+          const double cff2 = 0.5 * (TPM(0, -1) + TPM(0, 0)) * (VFe0 - VFem);
+          const double fac = cff1 - cff2;
+          rhs = rhs - fac;
+        }
+#undef TLU
+#undef TLV
+#undef STRESS_R4
+#undef DRHS_P4
+#undef STRESS_P4
+      } else if (VIS) {
         // harmonic viscosity :1567-1660: stress at the rho points P0, P1 and the psi points Q0, Q1
 #define STRESS_R(a_, b_, v2_, pmon_, pnom_)                                                                        \
   ((v2_) * TD(a_, b_) * 0.5 *                                                                                      \
@@ -683,5 +810,7 @@ COOP_KERNEL(k_step2d_c, Step2dArgs) { k_step2d_t_body<32, 8, 512, 2, false, fals
 COOP_GLOBAL_LB2(k_step2d_c, Step2dArgs, 512, 4)   // two blocks of 8 waves per CU: at most 128 VGPRs
 COOP_KERNEL(k_step2d, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0>(a, bx, by, bz, lds); }
 COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)
+COOP_KERNEL(k_step2d_vis4, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0, true, true, 0, false, true>(a, bx, by, bz, lds); }   // ... with the biharmonic viscosity (UV_VIS4)
+COOP_GLOBAL_LB(k_step2d_vis4, Step2dArgs, 512)
 COOP_KERNEL(k_step2d_duv, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0, true, true, 0, true>(a, bx, by, bz, lds); }   // ... with the momentum diagnostics (DIAGNOSTICS_UV)
 COOP_GLOBAL_LB(k_step2d_duv, Step2dArgs, 512)

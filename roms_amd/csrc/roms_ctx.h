@@ -46,6 +46,9 @@ struct DGrid {
   // DIAGNOSTICS_UV (mod_diags.F:174-222): 0 = off; m2 / m3[term] = the reference's 1-based index of a 2-D / 3-D momentum
   // term for the option set (mod_scalars.F:4264-4377), 0 = absent; ndm2 = NDM2d, ndm3 = NDM3d, ndrhs = NDrhs
   int dia_uv;
+  // biharmonic horizontal mixing along s-surfaces switched on (roms_hip_mix4_config): UV_VIS4 + MIX_S_UV (uv3dmix4_s.h,
+  // step2d_LF_AM3.h:1653-1920), TS_DIF4 + MIX_S_TS (t3dmix4_s.h); coefficient arrays visc4_r, visc4_p, diff4
+  int uv_vis4, ts_dif4;
   signed char m2[12], m3[12];
   short ndm2, ndm3, ndrhs;
   int fuse_halo;              // 1: single tile, k_step2d fills boundary/periodic ghost points itself (k_haloblock.h)
@@ -227,6 +230,8 @@ struct Fields {
   GPtr Uwind, Vwind, Tair, Pair, Hair, rain, cloud, lhflx, shflx, lrflx, evap;
   // mod_mixing
   GPtr Akv, Akt, visc2_r, visc2_p, diff2, bvf, alpha, beta, hsbl, ghats;
+  GPtr visc4_r, visc4_p, diff4;        // square roots of the biharmonic coefficients (inp_par.F:634, read_phypar.F:7840)
+  GPtr lap4;                           // UV_VIS4: LapU | LapV of uv3dmix4_s.h (2 x N planes), allocated by roms_hip_mix4_config
   GPtr tke, gls, Lscale, Akk, Akp;   // GLS_MIXING: tke, gls (i,j,0:N,3); Lscale, Akk, Akp (i,j,0:N)
   // s-coordinate tables (device copies)
   GPtr sc_r, Cs_r, sc_w, Cs_w;

@@ -107,7 +107,7 @@ static const FieldDesc g_fields[] = {
     FD(btflx, FK_2DxNT), FD(stflux, FK_2DxNT), FD(btflux, FK_2DxNT), FD(srflx, FK_2D),
     FD(Uwind, FK_2D), FD(Vwind, FK_2D), FD(Tair, FK_2D), FD(Pair, FK_2D), FD(Hair, FK_2D), FD(rain, FK_2D),
     FD(cloud, FK_2D), FD(lhflx, FK_2D), FD(shflx, FK_2D), FD(lrflx, FK_2D), FD(evap, FK_2D),
-    FD(Akv, FK_W), FD(Akt, FK_WxNAT), FD(visc2_r, FK_2D), FD(visc2_p, FK_2D), FD(diff2, FK_2DxNT), FD(bvf, FK_W),
+    FD(Akv, FK_W), FD(Akt, FK_WxNAT), FD(visc2_r, FK_2D), FD(visc2_p, FK_2D), FD(diff2, FK_2DxNT), FD(visc4_r, FK_2D), FD(visc4_p, FK_2D), FD(diff4, FK_2DxNT), FD(bvf, FK_W),
     FD(alpha, FK_2D), FD(beta, FK_2D), FD(hsbl, FK_2D), FD(ghats, FK_WxNAT),
     FD(tke, FK_Wx3), FD(gls, FK_Wx3), FD(Lscale, FK_W), FD(Akk, FK_W), FD(Akp, FK_W),
     FD(sc_r, FK_TABR), FD(Cs_r, FK_TABR), FD(sc_w, FK_TABW), FD(Cs_w, FK_TABW),
@@ -421,6 +421,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   c->stream3 = nullptr;
   c->G.dia_ts = 0;
   c->G.dia_uv = 0; c->G.ndm2 = 0; c->G.ndm3 = 0; c->G.ndrhs = 0;
+  c->G.uv_vis4 = 0; c->G.ts_dif4 = 0; c->F.lap4 = nullptr;
   for (int k = 0; k < 12; k++) { c->G.m2[k] = 0; c->G.m3[k] = 0; }
   c->F.duv = nullptr;
   for (int k = 0; k < 10; k++) c->G.dia_idx[k] = 0;
@@ -1780,7 +1781,7 @@ static int main3d_one(roms_hip_ctx *c) {
     // (a masked run keeps the reference order: its boundary fills are separate launches on the compute stream)
     static const char *elm = getenv("ROMS_HIP_LATE_MASK");
     // (prsgrd31: the late schedule relies on k_prs_grad keeping the previous ru/rv bracket for the deferred predictor)
-    if (!c->has_exchange && !uvcol && !c->G.dia_ts && !c->G.dia_uv && (!c->G.masking || (elm && elm[0] == '1')) && !(elate && elate[0] == '0') &&
+    if (!c->has_exchange && !uvcol && !c->G.dia_ts && !c->G.dia_uv && !c->G.uv_vis4 && !c->G.ts_dif4 && (!c->G.masking || (elm && elm[0] == '1')) && !(elate && elate[0] == '0') &&
         !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_GLS_MIXING | ROMS_MY25_MIXING))) return main3d_late(c, do_diag);   // (GLS: its two routines keep the reference's places)
   }
   DO(roms_hip_rho_eos(c));                                  // :350
@@ -1914,6 +1915,7 @@ extern "C" int roms_hip_set_avg(roms_hip_ctx *c) {
 extern "C" int roms_hip_dia_config(roms_hip_ctx *c, int nDIA, int ntsDIA, int nrrec, int ntstart) {
   if (!c || nDIA < 0 || ntsDIA < 1) return 8;
   DGrid &G = c->G;
+  if (G.uv_vis4 || G.ts_dif4) { set_error("DIAGNOSTICS_TS: the diagnostic statements of the biharmonic operators are not built"); return 5; }
   for (int it = 0; it < G.NT; it++)
     if (G.hadv[it] == ROMS_MPDATA || G.vadv[it] == ROMS_MPDATA) { set_error("DIAGNOSTICS_TS: tracers advected with MPDATA are not built (step3d_t.F:881-895)"); return 5; }
   if (G.options & ROMS_PLAIN_VDIFF) { set_error("DIAGNOSTICS_TS: built for SPLINES_VDIFF only"); return 5; }
@@ -1940,6 +1942,31 @@ extern "C" int roms_hip_dia_config(roms_hip_ctx *c, int nDIA, int ntsDIA, int nr
   return 0;
 }
 // set_diags(ng,tile), main3d.F:559
+// Biharmonic horizontal mixing along s-surfaces (UV_VIS4 + MIX_S_UV, TS_DIF4 + MIX_S_TS of the application header): the harmonic
+// operators applied twice -- uv3dmix4_s.h, the UV_VIS4 block of step2d_LF_AM3.h:1653-1920, t3dmix4_s.h.  Between
+// roms_hip_create and roms_hip_start; the caller uploads "visc4_r", "visc4_p", "diff4" = the SQUARE ROOTS of VISC4 / TNU4
+// (inp_par.F:634) and leaves the harmonic coefficient arrays at zero (the harmonic operators then add exact zeros).
+// Refused (exit_flag 5): together with the geopotential / isopycnic tracer operators, open boundaries, the per-term
+// diagnostics (their biharmonic statements are not built).
+extern "C" int roms_hip_mix4_config(roms_hip_ctx *c, int uv_vis4, int ts_dif4) {
+  if (!c) return 8;
+  DGrid &G = c->G;
+  if (!uv_vis4 && !ts_dif4) { G.uv_vis4 = G.ts_dif4 = 0; return 0; }
+  if (ts_dif4 && (G.options & (ROMS_MIX_GEO_TS | ROMS_MIX_ISO_TS))) { set_error("TS_DIF4: along s-surfaces only (MIX_S_TS; t3dmix4_geo.h / _iso.h are not built)"); return 5; }
+  if (G.obc) { set_error("UV_VIS4 / TS_DIF4 with open boundaries: the gradient conditions of the first harmonic operator are not built on the device"); return 5; }
+  if (G.dia_ts || G.dia_uv) { set_error("UV_VIS4 / TS_DIF4: the per-term diagnostics of the biharmonic operators are not built"); return 5; }
+  if (G.Nghost < 3 && uv_vis4) { set_error("UV_VIS4 needs three ghost points (inp_par.F:214-223)"); return 5; }
+  if (uv_vis4 && !c->F.lap4) {
+    void *p = nullptr;
+    if (dmalloc(&p, (size_t)2 * G.N * G.nij * sizeof(double))) return 2;
+    c->allocs.push_back(p);
+    c->F.lap4 = (double *)p;
+  }
+  G.uv_vis4 = uv_vis4 != 0; G.ts_dif4 = ts_dif4 != 0;
+  c->m2d_dirty = true;                               // (the packed barotropic metrics carry visc4 in place of visc2)
+  c->pair_on = step2d_pair_usable(c);
+  return 0;
+}
 // Per-term momentum tendencies (DIAGNOSTICS_UV): allocates DIAGS(ng)%DiaU2wrk ... DiaV3d (mod_diags.F:174-222) and switches
 // the term stores of prsgrd, rhs3d, uv3dmix2, pre_step3d, step2d and step3d_uv on; the window is roms_hip_dia_config's (call
 // that first), set_diags accumulates "DiaU2d", "DiaV2d", "DiaU3d", "DiaV3d".  Refused (exit_flag 5): no SPLINES_VVISC.

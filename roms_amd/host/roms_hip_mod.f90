@@ -171,6 +171,12 @@
           integer(c_int), value :: nDIA, ntsDIA, nrrec, ntstart
           integer(c_int) :: ierr
         END FUNCTION roms_hip_dia_config
+        FUNCTION roms_hip_mix4_config (ctx, uv_vis4, ts_dif4) bind(C, name='roms_hip_mix4_config') RESULT (ierr)
+          IMPORT :: c_ptr, c_int
+          type(c_ptr), value :: ctx
+          integer(c_int), value :: uv_vis4, ts_dif4
+          integer(c_int) :: ierr
+        END FUNCTION roms_hip_mix4_config
         FUNCTION roms_hip_diauv_config (ctx) bind(C, name='roms_hip_diauv_config') RESULT (ierr)
           IMPORT :: c_ptr, c_int
           type(c_ptr), value :: ctx

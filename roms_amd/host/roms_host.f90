@@ -27,6 +27,9 @@
       logical :: EWperiodic = .TRUE., NSperiodic = .FALSE.
       real(dp) :: dt = 300.0_dp, theta_s = 3.0_dp, theta_b = 0.0_dp, Tcline = 25.0_dp, rho0 = 1025.0_dp
       real(dp) :: R0 = 1027.0_dp, T0 = 14.0_dp, S0 = 35.0_dp, Tcoef = 1.7E-4_dp, Scoef = 0.0_dp
+!  UV_VIS4 / TS_DIF4 (biharmonic mixing along s-surfaces): VISC4, TNU4 of roms.in [m4/s]; mix4(1:2): the header defines them
+      real(dp) :: visc4 = 0.0_dp, tnu4(ROMS_MAXT) = 0.0_dp
+      logical :: mix4(2) = .FALSE.
       real(dp) :: visc2 = 5.0_dp, tnu2(ROMS_MAXT) = 0.0_dp, Akt_bak(ROMS_MAXT) = 1.0E-6_dp, Akv_bak = 1.0E-5_dp
       real(dp) :: rdrg = 3.0E-4_dp, rdrg2 = 3.0E-3_dp, Zob = 0.02_dp, Zos = 0.02_dp, gamma2 = 1.0_dp
       real(dp) :: dstart = 0.0_dp, time_ref = 0.0_dp, blk_ZQ = 10.0_dp, blk_ZT = 10.0_dp, blk_ZW = 10.0_dp
@@ -280,6 +283,8 @@
             IF (ierr.ne.0) EXIT
           CASE ('TNU2');        CALL load_r (tok, nv, tnu2)
           CASE ('VISC2');       visc2=toreal(tok(1))
+          CASE ('TNU4');        CALL load_r (tok, nv, tnu4)
+          CASE ('VISC4');       visc4=toreal(tok(1))
           CASE ('AKT_BAK');     CALL load_r (tok, nv, Akt_bak)
           CASE ('AKV_BAK');     Akv_bak=toreal(tok(1))
           CASE ('RDRG');        rdrg=toreal(tok(1))
@@ -435,6 +440,7 @@
       dt=300.0_dp; theta_s=3.0_dp; theta_b=0.0_dp; Tcline=25.0_dp; rho0=1025.0_dp
       R0=1027.0_dp; T0=14.0_dp; S0=35.0_dp; Tcoef=1.7E-4_dp; Scoef=0.0_dp
       visc2=5.0_dp; tnu2=0.0_dp; Akt_bak=1.0E-6_dp; Akv_bak=1.0E-5_dp
+      visc4=0.0_dp; tnu4=0.0_dp; mix4=.FALSE.
       rdrg=3.0E-4_dp; rdrg2=3.0E-3_dp; Zob=0.02_dp; Zos=0.02_dp; gamma2=1.0_dp
       dstart=0.0_dp; time_ref=0.0_dp; blk_ZQ=10.0_dp; blk_ZT=10.0_dp; blk_ZW=10.0_dp
       gls_flags=0; lbc_tke=0; gls_p=3.0_dp; gls_m=1.5_dp; gls_n=-1.0_dp; gls_Kmin=7.6E-6_dp; gls_Pmin=1.0E-12_dp
@@ -802,8 +808,13 @@
       character(len=16), parameter :: bulk(9) = [ character(len=16) :: 'BULK_FLUXES', 'LONGWAVE', 'ANA_WINDS',    &
      &    'ANA_TAIR', 'ANA_PAIR', 'ANA_HUMIDITY', 'ANA_RAIN', 'ANA_CLOUD', 'ALBEDO' ]
       DO k=1,SIZE(common)
+!  (UPWELLING_BIH = oracle/ref/upwelling_bih.h: biharmonic mixing along s-surfaces in place of the harmonic operators)
+        IF (TRIM(MyAppCPP).eq.'UPWELLING_BIH'.and.(TRIM(common(k)).eq.'UV_VIS2'.or.TRIM(common(k)).eq.'TS_DIF2')) CYCLE
         CALL define (TRIM(common(k)))
       END DO
+      IF (TRIM(MyAppCPP).eq.'UPWELLING_BIH') THEN
+        CALL define ('UV_VIS4'); CALL define ('TS_DIF4')
+      END IF
       IF (TRIM(MyAppCPP).eq.'SEAMOUNT'.or.TRIM(MyAppCPP).eq.'GRAV_ADJ') THEN
 !  ROMS/Include/seamount.h, grav_adj.h (their output options AVERAGES / DIAGNOSTICS_* / ANA_DIAG select no time-stepping code)
         ndefs=0
@@ -843,7 +854,7 @@
       END IF
       CALL define ('ANA_INITIAL'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
       SELECT CASE (TRIM(MyAppCPP))
-        CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK',  &  ! (oracle/ref/upwelling_logdrag.h, _mask.h)
+        CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK', 'UPWELLING_BIH',  &  ! (oracle/ref/upwelling_logdrag.h, _mask.h, _bih.h)
      &        'UPWELLING_GLS', 'UPWELLING_GLS_CA', 'UPWELLING_GLS_CB', 'UPWELLING_GLS_GAL', 'UPWELLING_MY25',         &
      &        'UPWELLING_MY25_GAL')
 !  UPWELLING_GLS = upwelling.h built with -DGLS_MIXING; _CA, _CB, _GAL = oracle/ref/upwelling_gls_ca.h, _cb.h, _gal.h: the
@@ -924,6 +935,7 @@
       IF (ierr.ne.0) RETURN
       upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
      &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING').or.    &
+     &    TRIM(MyAppCPP).eq.'UPWELLING_BIH'.or.                                                                     &
      &    MyAppCPP(1:13).eq.'UPWELLING_GLS'.or.MyAppCPP(1:14).eq.'UPWELLING_MY25'
       bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.TRIM(MyAppCPP).eq.'BENCHMARK_MASK'.or.is_defined('BENCHMARK')
       kelv=TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES'.or.is_defined('KELVIN')
@@ -956,6 +968,8 @@
           CONTINUE
         ELSE IF (TRIM(defs(k)).eq.'ANA_DIAG') THEN        ! the user diagnostics hook (ana_diag.h): output of its own, not built
           CONTINUE
+        ELSE IF (TRIM(defs(k)).eq.'UV_VIS4'.or.TRIM(defs(k)).eq.'TS_DIF4') THEN   ! biharmonic mixing: roms_hip_mix4_config (below)
+          CONTINUE
         ELSE
           CALL unsupported ('cpp option '//TRIM(defs(k))//' is not built into this library', ierr)
           RETURN
@@ -979,11 +993,24 @@
 !  every pinned application has momentum advection and harmonic mixing of momentum and tracers compiled in; without them
 !  the reference was found to differ from the restatement this library is checked against (WINDBASIN from rest: exact
 !  zeros there, 1e-17 here), so those builds are refused rather than run unpinned
-      IF (.not.(is_defined('UV_ADV').and.is_defined('UV_VIS2').and.is_defined('TS_DIF2')))                    &
-     &  CALL unsupported ('UV_ADV, UV_VIS2 and TS_DIF2 are required (the library is pinned to the reference with them)', ierr)
+!  UV_VIS4 / TS_DIF4 (round 4): the biharmonic operators along s-surfaces IN PLACE of the harmonic ones -- the library keeps
+!  its harmonic kernels with zero coefficients (they add exact zeros) and runs uv3dmix4_s.h / t3dmix4_s.h / the UV_VIS4
+!  block of step2d behind roms_hip_mix4_config
+      mix4(1)=is_defined('UV_VIS4')
+      mix4(2)=is_defined('TS_DIF4')
+      IF ((mix4(1).and.is_defined('UV_VIS2')).or.(mix4(2).and.is_defined('TS_DIF2')))                          &
+     &  CALL unsupported ('harmonic and biharmonic mixing of the same field together (UV_VIS2 + UV_VIS4, TS_DIF2 + TS_DIF4) '// &
+     &                    'are not built', ierr)
+      IF (mix4(1).and..not.is_defined('MIX_S_UV')) CALL unsupported ('UV_VIS4 is built along s-surfaces only (MIX_S_UV)', ierr)
+      IF (mix4(2).and..not.is_defined('MIX_S_TS')) CALL unsupported ('TS_DIF4 is built along s-surfaces only (MIX_S_TS)', ierr)
+      IF (mix4(1)) options=IOR(options, ROMS_UV_VIS2)
+      IF (mix4(2)) options=IOR(options, ROMS_TS_DIF2)
+      IF (.not.(is_defined('UV_ADV').and.(is_defined('UV_VIS2').or.mix4(1)).and.(is_defined('TS_DIF2').or.mix4(2))))       &
+     &  CALL unsupported ('UV_ADV, UV_VIS2 | UV_VIS4 and TS_DIF2 | TS_DIF4 are required (the library is pinned to the '//  &
+     &                    'reference with them)', ierr)
       IF (is_defined('UV_VIS2').and..not.is_defined('MIX_S_UV'))                                               &
      &  CALL unsupported ('UV_VIS2 is built along s-surfaces only (MIX_S_UV)', ierr)
-      IF (is_defined('TS_DIF2').and.COUNT((/ is_defined('MIX_S_TS'), is_defined('MIX_GEO_TS'), is_defined('MIX_ISO_TS') /)).ne.1) &
+      IF ((is_defined('TS_DIF2').or.mix4(2)).and.COUNT((/ is_defined('MIX_S_TS'), is_defined('MIX_GEO_TS'), is_defined('MIX_ISO_TS') /)).ne.1) &
      &  CALL unsupported ('TS_DIF2 needs exactly one of MIX_S_TS, MIX_GEO_TS, MIX_ISO_TS', ierr)
       IF (is_defined('MIX_ISO_TS').and.(is_defined('TS_MIX_MAX_SLOPE').or.is_defined('TS_MIX_MIN_STRAT').or.          &
      &    is_defined('TS_MIX_STABILITY').or.is_defined('TS_MIX_CLIMA').or.is_defined('DIFF_3DCOEF')))                 &
@@ -1102,7 +1129,7 @@
 !=======================================================================
 !
       SUBROUTINE set_bounds ()
-      IF (ANY(hadv(1:NT).eq.ROMS_MPDATA).or.ANY(hadv(1:NT).eq.ROMS_HSIMT)) THEN
+      IF (ANY(hadv(1:NT).eq.ROMS_MPDATA).or.ANY(hadv(1:NT).eq.ROMS_HSIMT).or.mix4(1)) THEN      ! (UV_VIS4: inp_par.F:214-216)
         Nghost=3
       ELSE
         Nghost=2
@@ -1588,6 +1615,13 @@
       DO itrc=1,NT
         diff2(:,:,itrc)=tnu2(itrc)
       END DO
+!  biharmonic mixing in place of the harmonic one: zero harmonic coefficients (the biharmonic ones are uploaded in
+!  device_init as the square roots inp_par.F:634 / read_phypar.F:7840 take)
+      IF (mix4(1)) THEN
+        visc2_r=0.0_dp
+        visc2_p=0.0_dp
+      END IF
+      IF (mix4(2)) diff2=0.0_dp
       rdrag=rdrg
       rdrag2=rdrg2
       Akv=0.0_r8
@@ -1903,6 +1937,10 @@
       cfg%sc_r(1:N)=sc_r; cfg%Cs_r(1:N)=Cs_r; cfg%sc_w(0:N)=sc_w; cfg%Cs_w(0:N)=Cs_w
       ierr=roms_hip_create(cfg, ctx)
       IF (ierr.ne.0) RETURN
+      IF (ANY(mix4)) THEN                          ! UV_VIS4 / TS_DIF4
+        ierr=roms_hip_mix4_config(ctx, MERGE(1,0,mix4(1)), MERGE(1,0,mix4(2)))
+        IF (ierr.ne.0) RETURN
+      END IF
       IF (nAVG.gt.0.and.ANY(Aout)) THEN           ! AVERAGES: mod_average.F allocate_average
         ierr=roms_hip_avg_config(ctx, nAVG, ntsAVG, 0, 1, aout_mask())
         IF (ierr.ne.0) RETURN
@@ -1932,6 +1970,7 @@
       CALL up ('lonr', lonr, 1, ierr); CALL up ('latr', latr, 1, ierr); CALL up ('rdrag', rdrag, 1, ierr)
       CALL up ('rdrag2', rdrag2, 1, ierr); CALL up ('visc2_r', visc2_r, 1, ierr)
       CALL up ('visc2_p', visc2_p, 1, ierr); CALL up ('diff2', diff2, NT, ierr)
+      IF (ANY(mix4)) CALL up_mix4 (ierr)
       CALL up ('Zt_avg1', Zt_avg1, 1, ierr)
       IF (is_defined('MASKING')) THEN
         CALL up ('rmask', rmask, 1, ierr); CALL up ('umask', umask, 1, ierr)
@@ -1966,6 +2005,23 @@
         IF (Aout(k)) aout_mask=IBSET(aout_mask,k)
       END DO
       END FUNCTION aout_mask
+
+!  UV_VIS4 / TS_DIF4: visc4_r = visc4_p = SQRT(ABS(VISC4)), diff4(:,:,itrc) = SQRT(ABS(TNU4(itrc))) everywhere (inp_par.F:634,
+!  read_phypar.F:7840, ini_hmixcoef.F:270-296: uniform coefficients, no VISC_GRID / DIFF_GRID scaling)
+      SUBROUTINE up_mix4 (ierr)
+      integer, intent(inout) :: ierr
+      real(r8), allocatable :: W(:,:,:)
+      integer :: itrc
+      allocate ( W(LBi:UBi,LBj:UBj,NT) )
+      W(:,:,1)=SQRT(ABS(visc4))
+      CALL up ('visc4_r', W(:,:,1:1), 1, ierr)
+      CALL up ('visc4_p', W(:,:,1:1), 1, ierr)
+      DO itrc=1,NT
+        W(:,:,itrc)=SQRT(ABS(tnu4(itrc)))
+      END DO
+      CALL up ('diff4', W, NT, ierr)
+      deallocate ( W )
+      END SUBROUTINE up_mix4
 
       SUBROUTINE up (name, A, np, ierr)
       character(len=*), intent(in) :: name

@@ -2,7 +2,7 @@
 the oracle (oracle/orc.h) and of the reference glue (oracle/ref/ref_glue.F90).  TEST INFRASTRUCTURE."""
 import numpy as np
 
-from roms_amd.cases import SCHEME, benchmark, hip_cfg, upwelling, upwelling_kpp, upwelling_logdrag, upwelling_mask, benchmark_mask, land_mask, kelvin, seamount, grav_adj, overflow, upwelling_prs31, upwelling_prs40, upwelling_gls, upwelling_my25, kelvin_gls, gls_cfg, GLS_NAMES, GLS_SETS, lbc_codes, obc_scales  # noqa: F401  (re-exported)
+from roms_amd.cases import SCHEME, benchmark, hip_cfg, upwelling, upwelling_kpp, upwelling_logdrag, upwelling_mask, benchmark_mask, land_mask, kelvin, seamount, grav_adj, overflow, upwelling_prs31, upwelling_bih, upwelling_prs40, upwelling_gls, upwelling_my25, kelvin_gls, gls_cfg, GLS_NAMES, GLS_SETS, lbc_codes, obc_scales  # noqa: F401  (re-exported)
 
 
 def ref_params(cs):
@@ -12,7 +12,11 @@ def ref_params(cs):
             SCHEME[cs["hadv"][0]], SCHEME[cs["vadv"][0]], SCHEME[cs["hadv"][1]], SCHEME[cs["vadv"][1]],
             cs["lmd_Jwt"]]
     rpar = [cs["dt"], cs["theta_s"], cs["theta_b"], cs["Tcline"], cs["rho0"], cs["R0"], cs["T0"],
-            cs["S0"], cs["Tcoef"], cs["Scoef"], cs["visc2"], cs["tnu2"][0], cs["tnu2"][1],
+            cs["S0"], cs["Tcoef"], cs["Scoef"],
+            # (biharmonic variants, cs["mix4"]: VISC4 and TNU4 of roms.in in the same slots, ref_glue.F90:ref_configure)
+            cs["visc4"] if cs.get("mix4", (0, 0))[0] else cs["visc2"],
+            cs["tnu4"][0] if cs.get("mix4", (0, 0))[1] else cs["tnu2"][0],
+            cs["tnu4"][1] if cs.get("mix4", (0, 0))[1] else cs["tnu2"][1],
             cs["Akt_bak"][0], cs["Akt_bak"][1], cs["Akv_bak"], cs["rdrg"], cs["rdrg2"], cs["Zob"],
             cs["Zos"], cs["gamma2"], cs["dstart"], cs["blk_ZQ"], cs["blk_ZT"], cs["blk_ZW"]]
     ipar = ipar + [0] * (64 - len(ipar))
@@ -46,7 +50,7 @@ def oracle_cfg(cs, hc, nfast, weight):
     c.Lm, c.Mm, c.N, c.NT, c.NAT = cs["Lm"], cs["Mm"], cs["N"], 2, 2
     hs = [SCHEME[x] for x in cs["hadv"]]
     vs = [SCHEME[x] for x in cs["vadv"]]
-    c.Nghost = 3 if (orc.MPDATA in hs or orc.HSIMT in hs) else 2
+    c.Nghost = 3 if (orc.MPDATA in hs or orc.HSIMT in hs or cs.get("mix4", (0, 0))[0]) else 2     # inp_par.F:210-223
     c.NtileI, c.NtileJ = cs["NtileI"], cs["NtileJ"]
     c.EWperiodic, c.NSperiodic = cs["EWperiodic"], cs["NSperiodic"]
     opt = 0

@@ -248,6 +248,7 @@ STEP_CASES = [
     # the generic length-scale closure: upwelling.h -DGLS_MIXING (Kantha-Clayson, k-epsilon), Canuto A masked ("gen"),
     # Canuto B with CHARNOK / CRAIG_BANNER / K_C2ADVECTION (k-kl)
     ("upwelling_small_prs40", "upwelling_prs40_small", ["nsteps=60"]),       # PJ_GRADP, prsgrd40.h
+    ("upwelling_small_bih", "upwelling_bih_small", ["nsteps=60"]),           # UV_VIS4 + TS_DIF4 along s-surfaces (upwelling_bih.h)
     ("upwelling_gls_small", "upwelling_gls_small", ["nsteps=60"]),
     ("upwelling_gls_ca_small", "upwelling_gls_ca_small", ["nsteps=60"]),
     ("upwelling_gls_cb_small", "upwelling_gls_cb_small", ["nsteps=60"]),

@@ -147,7 +147,7 @@ def test_reader_accepts_the_reference_spellings(tmp_path):
     (dict(tv="Per Mix Per Clo"), "LBC(isTvar) = Mix"),                        # the salinity line
     (dict(fs="Per Clo Clo Clo"), "opposite edge"),
     (dict(h1="WENO5"), "unknown scheme"),
-    (dict(header="windbasin"), "UV_ADV, UV_VIS2 and TS_DIF2 are required"),      # a reference application without them: not pinned, refused
+    (dict(header="windbasin"), "UV_ADV, UV_VIS2 | UV_VIS4 and TS_DIF2 | TS_DIF4 are required"),      # a reference application without them: not pinned, refused
     (dict(h1="MPDATA"), "MPDATA must be chosen for both"),
     (dict(extra="LuvSrc == T"), "LuvSrc == T"),
     (dict(extra="Vstretching == 2"), "Vstretching"),
@@ -316,6 +316,35 @@ def test_application_header_with_unbuilt_options_stops(tmp_path, line, needle):
     with pytest.raises(hostlib.HostError) as e:
         _setup(tmp_path, header=str(hdr)).finalize()
     assert e.value.exit_flag == 5 and needle in str(e.value), str(e.value)
+
+
+def test_biharmonic_header_and_keywords_drive_the_run_the_oracle_makes():
+    """oracle/ref/upwelling_bih.h (UV_VIS4 + TS_DIF4 along s-surfaces, the header the reference build the oracle is pinned to
+    was made from) read in place, VISC4 / TNU4 from roms.in: three ghost points (inp_par.F:214), the harmonic coefficients
+    zero, and six steps of the emulated kernels through the Fortran host equal the oracle's bit for bit -- the built-in
+    UPWELLING_BIH option list likewise."""
+    from roms_amd import hostlib
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    emu = os.path.join(root, "tests", "emu")
+    if not os.path.exists(os.path.join(emu, "libroms_host_emu.so")):
+        pytest.skip("emulation not built")
+    cs = util.case_for("upwelling_bih_small")
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    O.start()
+    O.main3d_step(6)
+    for params, header in ((dict(cs, ninfo=0), None), (dict(cs, ninfo=0, app="upwelling"), os.path.join(root, "oracle", "ref", "upwelling_bih.h"))):
+        H = hostlib.Host(params=params, lib_path=os.path.join(emu, "libroms_host_emu.so"), hip_lib_path=util.EMU_LIB, header=header)
+        try:
+            assert H.dims["Nghost"] == 3
+            assert np.all(H.get("visc2_r") == 0.0) and np.all(H.get("diff2") == 0.0)
+            ctx = H.device_init(0)
+            assert np.array_equal(ctx.download("visc4_r"), np.full(ctx.download("visc4_r").shape, np.sqrt(cs["visc4"])))
+            H.run(6)
+            for n in ("u", "v", "t", "zeta", "ubar"):
+                assert np.array_equal(ctx.download(n), O.field(n)), (header, n)
+        finally:
+            H.finalize()
 
 
 def test_custom_header_of_config5_gives_the_kpp_options():

@@ -239,6 +239,11 @@ MAIN3D_CASES = [
     # the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h (PJ_GRADP)
     ("upwelling_prs40_small", ["nsteps=60"]),
     ("upwelling_prs40_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # biharmonic mixing along s-surfaces (oracle/ref/upwelling_bih.h: UV_VIS4, TS_DIF4): uv3dmix4_s.h, t3dmix4_s.h and the
+    # UV_VIS4 block of step2d_LF_AM3.h; three ghost points (inp_par.F:214)
+    ("upwelling_bih_small", ["nsteps=60"]),
+    ("upwelling_bih_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_bih_small", ["nsteps=20", "hadv=U3,U3", "vadv=C4,C4"]),
     # the generic length-scale closure (gls_prestep.F, gls_corstep.F, tkebc_im.F): upwelling.h built with -DGLS_MIXING
     # (Kantha-Clayson, N2S2_HORAVG, RI_SPLINES; k-epsilon and k-omega parameters of roms_upwelling.in), and the other
     # compile-time forms: Canuto A under MASKING ("gen" parameters), Canuto B with K_C2ADVECTION, CHARNOK, CRAIG_BANNER

@@ -86,6 +86,9 @@ def _interior(cs_dims, a):
     # OVERFLOW (closed channel four points wide, tiles along eta): MIX_ISO_TS reads the density and the tracer slopes across the
     # tile boundary
     ("overflow_small", dict(), (1, 2), 29631),
+    # biharmonic mixing (UV_VIS4, TS_DIF4): the first harmonic operator is formed from the neighbour's points across the tile
+    # boundary (three ghost lines), its closed-edge conditions and corner values on the edge tiles only
+    ("upwelling_bih_mid", dict(), (2, 2), 29633),
 ])
 def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     _emu_libs()

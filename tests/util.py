@@ -10,7 +10,7 @@ EMU_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libro
 
 INIT_FIELDS = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om_v", "on_v", "om_p", "on_p", "omn",
                "pmon_r", "pnom_r", "pmon_p", "pnom_p", "pmon_u", "pnom_u", "pmon_v", "pnom_v", "angler", "xr", "yr", "xp", "yp",
-               "rdrag", "visc2_r", "visc2_p", "diff2", "Hz", "z_r", "z_w", "Huon", "Hvom", "zeta", "ubar", "vbar",
+               "rdrag", "visc2_r", "visc2_p", "diff2", "visc4_r", "visc4_p", "diff4", "Hz", "z_r", "z_w", "Huon", "Hvom", "zeta", "ubar", "vbar",
                "u", "v", "t", "rho", "pden", "rhoA", "rhoS", "Zt_avg1", "Akv", "Akt",
                "dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta", "hsbl",
                "rmask", "umask", "vmask", "pmask", "tke", "gls", "Lscale", "Akk", "Akp"]
@@ -45,7 +45,7 @@ def load_init(tag, nghost=None):
 
 
 def nghost_for(cs):
-    return 3 if any(x in ("HSIMT", "MPDATA") for x in cs["hadv"]) else 2
+    return 3 if (any(x in ("HSIMT", "MPDATA") for x in cs["hadv"]) or cs.get("mix4", (0, 0))[0]) else 2     # inp_par.F:210-223
 
 
 def case_for(tag, **kw):
@@ -72,6 +72,10 @@ def case_for(tag, **kw):
         return cases.upwelling_prs31(Lm=14, Mm=18, N=8, **kw)
     if tag == "upwelling_prs40_small":
         return cases.upwelling_prs40(Lm=14, Mm=18, N=8, **kw)
+    if tag == "upwelling_bih_small":
+        return cases.upwelling_bih(Lm=14, Mm=18, N=8, **kw)
+    if tag == "upwelling_bih_mid":
+        return cases.upwelling_bih(Lm=34, Mm=40, N=6, **kw)
     if tag == "upwelling_wjgradp_small":
         return cases.upwelling_prs31(wj=True, Lm=14, Mm=18, N=8, **kw)
     if tag == "seamount_small":
@@ -139,6 +143,10 @@ def make_oracle(cs, g):
             O.field(n)[:] = g[n]
     for n in ["sc_r", "Cs_r", "sc_w", "Cs_w"]:
         O.field(n)[:] = g[n]
+    if "mix4" in cs:       # biharmonic mixing: uniform square roots of VISC4 / TNU4 (inp_par.F:634, ini_hmixcoef.F:270-296)
+        O.set_mix4(*cs["mix4"])
+        O.field("visc4_r")[:] = np.sqrt(abs(cs["visc4"])); O.field("visc4_p")[:] = np.sqrt(abs(cs["visc4"]))
+        O.field("diff4").reshape(2, -1)[:] = np.sqrt(np.abs(np.array(cs["tnu4"])))[:, None]
     return O
 
 
@@ -159,9 +167,16 @@ def make_hip(cs, g, lib_path=None, device=0, ninfo=0):
                         g["sc_w"], g["Cs_w"], device=device)
     cfg.ninfo = ninfo
     H = hiplib.Context(cfg, lib_path)
+    if "mix4" in cs:
+        H.mix4_config(*cs["mix4"])
     for n in INIT_FIELDS:
         if n in g:
             H.upload(n, g[n])
+    if "mix4" in cs:       # ... and the harmonic coefficients zero (the library's harmonic operators then add exact zeros)
+        nij = np.asarray(g["h"]).size
+        H.upload("visc4_r", np.full(nij, np.sqrt(abs(cs["visc4"])))); H.upload("visc4_p", np.full(nij, np.sqrt(abs(cs["visc4"]))))
+        H.upload("diff4", np.repeat(np.sqrt(np.abs(np.array(cs["tnu4"]))), nij))
+        H.upload("visc2_r", np.zeros(nij)); H.upload("visc2_p", np.zeros(nij)); H.upload("diff2", np.zeros(2 * nij))
     return H
 
 
@@ -215,7 +230,7 @@ def load_fixture(name):
 
 def case_from_meta(meta):
     cs = dict(meta["case"])
-    for k in ("hadv", "vadv", "tnu2", "Akt_bak", "options", "gls_flags"):
+    for k in ("hadv", "vadv", "tnu2", "tnu4", "mix4", "Akt_bak", "options", "gls_flags"):
         if k in cs:
             cs[k] = tuple(cs[k])
     if "lbc" in cs:

@@ -19,7 +19,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 REF = "/root/reference/ROMS/Utility/read_phypar.F"
 
 HONOURED = """TITLE MyAppCPP Lm Mm N NAT NtileI NtileJ NTIMES DT NDTFAST NINFO Hadvection Vadvection NRREC LcycleRST NRST NHIS
-ININAME RSTNAME HISNAME NAVG NTSAVG AVGNAME NDIA NTSDIA DIANAME TNU2 VISC2 AKT_BAK AKV_BAK RDRG RDRG2 Zob Zos BLK_ZQ BLK_ZT BLK_ZW WTYPE
+ININAME RSTNAME HISNAME NAVG NTSAVG AVGNAME NDIA NTSDIA DIANAME TNU2 VISC2 TNU4 VISC4 AKT_BAK AKV_BAK RDRG RDRG2 Zob Zos BLK_ZQ BLK_ZT BLK_ZW WTYPE
 Vtransform Vstretching THETA_S THETA_B TCLINE RHO0 DSTART TIME_REF R0 T0 S0 TCOEF SCOEF GAMMA2
 TNUDG ZNUDG M2NUDG M3NUDG OBCFAC
 AKK_BAK AKP_BAK GLS_P GLS_M GLS_N GLS_Kmin GLS_Pmin GLS_CMU0 GLS_C1 GLS_C2 GLS_C3M GLS_C3P GLS_SIGK GLS_SIGP CHARNOK_ALPHA CRGBAN_CW""".split()
@@ -48,7 +48,6 @@ INERT_RULES = [   # (regex, why)
     (r"^ad_|^(NADJ|NTLM|NSFF|NOBC|Nouter|Ninner|Nintervals|Nsaddle|NEV|NCV|Ritz_tol|MaxIterGST|LmultiGST|LrstGST|NGST|LcycleADJ|LcycleTLM|NTIMES_ANA|NTIMES_FCT|ERstr|ERend|DstrS|DendS|KstrS|KendS)$|^(Lstate|Fstate|SO_sdev|SO_decay)", "adjoint / tangent linear / 4D-Var / stability drivers: not the nonlinear forward step"),
     (r"^(TKENU2|TKENU4)$", "lateral mixing of the turbulent fields: no code of gls_prestep.F / gls_corstep.F reads them"),
     (r"^(ZOS_HSIG_ALPHA|SZ_ALPHA|WEC_ALPHA|AKT_LIMIT|AKV_LIMIT|BVF_BAK)$", "parameters of options the library does not carry (ZOS_HSIG, TKE_WAVEDISS, WEC, LIMIT_VDIFF / LIMIT_VVISC, BVF_MIXING): a header defining one is stopped (exit_flag 5)"),
-    (r"^(TNU4|VISC4)$", "biharmonic mixing coefficients: read only under TS_DIF4 / UV_VIS4, which the header reader stops"),
     (r"^(DCRIT)$", "wetting and drying depth: WET_DRY is stopped by the header reader"),
     (r"^(LEVSFRC|LEVBFRC)$", "BODYFORCE levels: BODYFORCE is stopped by the header reader"),
     (r"^(Lnodal|TIDE_START)$", "tidal forcing: not built (SSH_TIDES / UV_TIDES stopped by the header reader)"),
