@@ -17,7 +17,7 @@ tag = os.environ.get("HUNT_TAG", "overflow_small")
 cs = util.case_for(tag)
 if os.environ.get("HUNT_MIX"):
     cs["options"] = tuple(os.environ["HUNT_MIX"] if o == "MIX_ISO_TS" else o for o in cs["options"])
-g = util.load_init(tag, util.nghost_for(cs))
+g = util.load_init(os.environ.get("HUNT_INIT", tag), util.nghost_for(cs))
 if os.environ.get("HUNT_KPROF"):
     from roms_amd import hiplib
     hiplib.kprof(int(os.environ["HUNT_KPROF"]))
