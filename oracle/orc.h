@@ -157,6 +157,9 @@ typedef struct orc_s {
   double *Uwind, *Vwind, *Tair, *Pair, *Hair, *rain, *cloud, *lhflx, *shflx, *lrflx, *evap;
   /* mod_mixing */
   double *Akv, *Akt, *visc2_r, *visc2_p, *diff2, *bvf, *alpha, *beta, *hsbl, *ghats;
+  /* WET_DRY (wetdry.F): time-dependent masks; rmask_wet_avg: sum of the rho mask over the fast steps; *_full: wet mask x land mask */
+  double *rmask_wet, *umask_wet, *vmask_wet, *pmask_wet, *rmask_full, *umask_full, *vmask_full, *pmask_full, *rmask_wet_avg;
+  int wet_dry; double Dcrit;             /* switched on by orc_set_wetdry (DCRIT of roms.in, read_phypar.F:1021) */
   double *visc4_r, *visc4_p, *diff4;     /* UV_VIS4 / TS_DIF4: square roots of the biharmonic coefficients (inp_par.F:634) */
   int uv_vis4, ts_dif4;                  /* biharmonic mixing along s-surfaces switched on (orc_set_mix4; orc_mix4.c) */
   double *tke, *gls, *Lscale, *Akk, *Akp;   /* GLS_MIXING: tke, gls(i,j,0:N,3); Lscale, Akk, Akp(i,j,0:N) */
@@ -187,6 +190,14 @@ void orc_check_step(const orc_t *o, const char *who);          /* aborts on a st
   const size_t ni = (o)->ni, nij = (o)->nij;                                 \
   (void)LBi; (void)LBj; (void)N; (void)ni; (void)nij;                        \
   orc_check_step((o), __func__)
+
+/* WET_DRY: the factor the barotropic step applies to a momentum point (step2d_LF_AM3.h:2208-2210 ...): the mask itself
+   where it is 0 or +-2... in the reference's words "cff7": 0.5*mask*cff5 + cff6*(1-cff5) */
+static inline double orc_wd_fac(double mw, double val) {
+  const double cff5 = __builtin_fabs(__builtin_fabs(mw) - 1.0);
+  const double cff6 = 0.5 + __builtin_copysign(0.5, val) * mw;
+  return 0.5 * mw * cff5 + cff6 * (1.0 - cff5);
+}
 
 /* ---- API ---- */
 orc_t *orc_create(const orc_cfg *cfg);
@@ -224,6 +235,9 @@ int orc_lbc_acquire(const orc_t *o, int edge, int var);     /* LBC(edge,var)%acq
 int orc_lbc_open(const orc_t *o);                             /* any edge of any variable other than closed / periodic */
 
 /* kernels (tile = 0..ntiles-1) */
+void orc_set_wetdry(orc_t *o, double Dcrit);                 /* WET_DRY on (orc_wetdry.c) */
+void orc_wetdry_ini(orc_t *o, int tile);                     /* wetdry_ini_tile, wetdry.F:355-490 (initial.F:467) */
+void orc_wetdry_tile(orc_t *o, int tile);                    /* wetdry_tile, wetdry.F:93-351 (called by step2d) */
 void orc_set_depth(orc_t *o, int tile);
 void orc_set_massflux(orc_t *o, int tile);
 void orc_rho_eos(orc_t *o, int tile);

@@ -168,6 +168,12 @@ class Oracle:
         roots of the coefficients"""
         self.L.orc_set_mix4(C.c_void_p(self.h), int(uv_vis4), int(ts_dif4))
 
+    def set_wetdry(self, Dcrit):
+        """wetting and drying on (WET_DRY, wetdry.F): fields "rmask_wet", "umask_wet", "vmask_wet", "pmask_wet",
+        "rmask_full" ..., "rmask_wet_avg"; call("wetdry_ini") sets the initial masks (initial.F:467)"""
+        self.L.orc_set_wetdry.argtypes = [C.c_void_p, C.c_double]
+        self.L.orc_set_wetdry(C.c_void_p(self.h), float(Dcrit))
+
     def start(self):
         self.L.orc_start(self.h)
 

@@ -123,6 +123,8 @@ static const fdesc fields[] = {
   FD(pmon_u, K2), FD(pnom_u, K2), FD(pmon_v, K2), FD(pnom_v, K2), FD(dmde, K2), FD(dndx, K2),
   FD(angler, K2), FD(xr, K2), FD(yr, K2), FD(xp, K2), FD(yp, K2), FD(lonr, K2), FD(latr, K2), FD(rdrag, K2),
   FD(rdrag2, K2), FD(rmask, K2), FD(umask, K2), FD(vmask, K2), FD(pmask, K2),
+  FD(rmask_wet, K2), FD(umask_wet, K2), FD(vmask_wet, K2), FD(pmask_wet, K2), FD(rmask_full, K2), FD(umask_full, K2),
+  FD(vmask_full, K2), FD(pmask_full, K2), FD(rmask_wet_avg, K2),
   FD(Hz, KR), FD(z_r, KR), FD(z_w, KW), FD(Huon, KR), FD(Hvom, KR),
   FD(zeta, K2x3), FD(ubar, K2x3), FD(vbar, K2x3), FD(rzeta, K2x2), FD(rubar, K2x2),
   FD(rvbar, K2x2), FD(u, KRx2), FD(v, KRx2), FD(t, KTR), FD(W, KW), FD(wvel, KW),
@@ -185,6 +187,7 @@ orc_t *orc_create(const orc_cfg *cfg) {
   for (size_t k = 0; k < NFIELDS; k++)
     *(double **)((char *)o + fields[k].off) = dalloc(field_size(o, fields[k].kind));
   for (size_t k = 0; k < o->nij; k++) o->rmask[k] = o->umask[k] = o->vmask[k] = o->pmask[k] = 1.0;   /* all water */
+  for (size_t k = 0; k < o->nij; k++) o->rmask_wet[k] = o->umask_wet[k] = o->vmask_wet[k] = o->pmask_wet[k] = 0.0;   /* IniVal, mod_grid.F:1428-1431 */
   o->ksbl = (int *)calloc(o->nij, sizeof(int));
   /* the stepping indices of a state nobody has stepped yet: all 1 (what roms_hip_create sets); every routine checks
      them on entry (ORC_LOCALS -> orc_check_step), so a caller that forgot one reads a defined time level */

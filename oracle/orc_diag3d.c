@@ -34,7 +34,10 @@ void orc_set_depth(orc_t *o, int tile) {
   double *h = o->h, *Zt_avg1 = o->Zt_avg1, *Hz = o->Hz, *z_r = o->z_r, *z_w = o->z_w;
   if (o->c.Vtransform == 1) {
     for (int j = b->JstrT; j <= b->JendT; j++) {
-      for (int i = b->IstrT; i <= b->IendT; i++) z_w[XW(i, j, 0)] = -h[X2(i, j)];
+      for (int i = b->IstrT; i <= b->IendT; i++) {
+        if (o->wet_dry && h[X2(i, j)] == 0.0) h[X2(i, j)] = 1.0E-14;      /* set_depth.F:150-154,195-199 */
+        z_w[XW(i, j, 0)] = -h[X2(i, j)];
+      }
       for (int k = 1; k <= N; k++) {
         double cff_r = hc * (o->sc_r[k - 1] - o->Cs_r[k - 1]);
         double cff_w = hc * (o->sc_w[k] - o->Cs_w[k]);
@@ -52,7 +55,10 @@ void orc_set_depth(orc_t *o, int tile) {
     }
   } else {
     for (int j = b->JstrT; j <= b->JendT; j++) {
-      for (int i = b->IstrT; i <= b->IendT; i++) z_w[XW(i, j, 0)] = -h[X2(i, j)];
+      for (int i = b->IstrT; i <= b->IendT; i++) {
+        if (o->wet_dry && h[X2(i, j)] == 0.0) h[X2(i, j)] = 1.0E-14;      /* set_depth.F:150-154,195-199 */
+        z_w[XW(i, j, 0)] = -h[X2(i, j)];
+      }
       for (int k = 1; k <= N; k++) {
         double cff_r = hc * o->sc_r[k - 1];
         double cff_w = hc * o->sc_w[k];
@@ -170,12 +176,17 @@ void orc_set_vbc(orc_t *o, int tile) {
     for (int i = b->IstrR; i <= b->IendR; i++) {
       o->stflx[X2T(i, j, 1)] = o->stflux[X2T(i, j, 1)];
       o->btflx[X2T(i, j, 1)] = o->btflux[X2T(i, j, 1)];
+      if (o->wet_dry) {                                                   /* set_vbc.F:307-308 */
+        o->stflx[X2T(i, j, 1)] = o->stflx[X2T(i, j, 1)] * o->rmask_wet[X2(i, j)];
+        o->btflx[X2T(i, j, 1)] = o->btflx[X2T(i, j, 1)] * o->rmask_wet[X2(i, j)];
+      }
     }
   for (int j = b->JstrR; j <= b->JendR; j++)
     for (int i = b->IstrR; i <= b->IendR; i++) {
       double EmP = o->stflux[X2T(i, j, 2)];
       o->stflx[X2T(i, j, 2)] = EmP * t[XT(i, j, N, nrhs, 2)];
-      if (o->c.options & ORC_MASKING) o->stflx[X2T(i, j, 2)] = o->rmask[X2(i, j)] * o->stflx[X2T(i, j, 2)];   /* set_vbc.F:399 */
+      if (o->wet_dry) o->stflx[X2T(i, j, 2)] = o->rmask_wet[X2(i, j)] * o->stflx[X2T(i, j, 2)];                /* set_vbc.F:397 */
+      else if (o->c.options & ORC_MASKING) o->stflx[X2T(i, j, 2)] = o->rmask[X2(i, j)] * o->stflx[X2T(i, j, 2)];   /* set_vbc.F:399 */
       o->btflx[X2T(i, j, 2)] = o->btflx[X2T(i, j, 2)] * t[XT(i, j, 1, nrhs, 2)];
     }
   if (o->c.options & ORC_UV_LOGDRAG) {
@@ -231,6 +242,21 @@ void orc_set_vbc(orc_t *o, int tile) {
       for (int i = b->Istr; i <= b->Iend; i++)
         o->bvstr[X2(i, j)] = 0.5 * (o->rdrag[X2(i, j - 1)] + o->rdrag[X2(i, j)]) *
                              v[X4(i, j, 1, nrhs)];
+  }
+  if (o->wet_dry) {
+    /* LIMIT_BSTRESS (globaldefs.h:160 switches it on with WET_DRY), set_vbc.F:580-590 and :611-616, :649-654, :682-687:
+       the bottom stress may slow the bottom layer down within 0.75 of a step but not reverse it */
+    const double cff = 0.75 / o->c.dt;
+    for (int j = b->Jstr; j <= b->Jend; j++)
+      for (int i = b->IstrU; i <= b->Iend; i++) {
+        const double cff3 = cff * 0.5 * (o->Hz[X3(i - 1, j, 1)] + o->Hz[X3(i, j, 1)]);
+        o->bustr[X2(i, j)] = copysign(1.0, o->bustr[X2(i, j)]) * fmin(fabs(o->bustr[X2(i, j)]), fabs(u[X4(i, j, 1, nrhs)]) * cff3);
+      }
+    for (int j = b->JstrV; j <= b->Jend; j++)
+      for (int i = b->Istr; i <= b->Iend; i++) {
+        const double cff3 = cff * 0.5 * (o->Hz[X3(i, j - 1, 1)] + o->Hz[X3(i, j, 1)]);
+        o->bvstr[X2(i, j)] = copysign(1.0, o->bvstr[X2(i, j)]) * fmin(fabs(o->bvstr[X2(i, j)]), fabs(v[X4(i, j, 1, nrhs)]) * cff3);
+      }
   }
   orc_bc_u2d(o, b, o->bustr);
   orc_bc_v2d(o, b, o->bvstr);
@@ -446,10 +472,14 @@ void orc_ini_zeta(orc_t *o, int tile) {
     const int k = orc_lbc(o, e, ORC_ISFSUR);
     keep |= k == ORC_LBC_RAD || k == ORC_LBC_RADNUD || k == ORC_LBC_CHE || k == ORC_LBC_CHI;
   }
-  if (o->c.options & ORC_MASKING)
+  if ((o->c.options & ORC_MASKING) || o->wet_dry)
     for (int j = keep ? b->JstrT : b->JstrB; j <= (keep ? b->JendT : b->JendB); j++)
-      for (int i = keep ? b->IstrT : b->IstrB; i <= (keep ? b->IendT : b->IendB); i++)
-        o->zeta[X2T(i, j, kstp)] = o->zeta[X2T(i, j, kstp)] * o->rmask[X2(i, j)];
+      for (int i = keep ? b->IstrT : b->IstrB; i <= (keep ? b->IendT : b->IendB); i++) {
+        double cff1 = o->zeta[X2T(i, j, kstp)];
+        if (o->c.options & ORC_MASKING) cff1 = cff1 * o->rmask[X2(i, j)];
+        if (o->wet_dry && cff1 <= (o->Dcrit - o->h[X2(i, j)])) cff1 = o->Dcrit - o->h[X2(i, j)];   /* :850-851 */
+        o->zeta[X2T(i, j, kstp)] = cff1;
+      }
   if (!keep) orc_zetabc(o, b, kstp);
   orc_exchange2d(o, b, 'r', o->zeta + (size_t)(kstp - 1) * nij);
   for (int j = b->JstrT; j <= b->JendT; j++)
@@ -464,12 +494,18 @@ void orc_ini_fields(orc_t *o, int tile) {
   const int nstp = o->s.nstp, kstp = o->s.kstp;
   double *u = o->u, *v = o->v, *Hz = o->Hz;
   const int msk = (o->c.options & ORC_MASKING) != 0;
-  if (msk)                                     /* the loads u(nstp)=u(nstp), v(nstp)=v(nstp) with masks :286-312 */
+  if (msk || o->wet_dry)                       /* the loads u(nstp)=u(nstp), v(nstp)=v(nstp) with masks :286-312 */
     for (int j = b->JstrB; j <= b->JendB; j++)
       for (int k = 1; k <= N; k++) {
-        for (int i = b->IstrM; i <= b->IendB; i++) u[X4(i, j, k, nstp)] = u[X4(i, j, k, nstp)] * o->umask[X2(i, j)];
+        for (int i = b->IstrM; i <= b->IendB; i++) {
+          if (msk) u[X4(i, j, k, nstp)] = u[X4(i, j, k, nstp)] * o->umask[X2(i, j)];
+          if (o->wet_dry) u[X4(i, j, k, nstp)] = u[X4(i, j, k, nstp)] * o->umask_wet[X2(i, j)];   /* :294 */
+        }
         if (j >= b->JstrM)
-          for (int i = b->IstrB; i <= b->IendB; i++) v[X4(i, j, k, nstp)] = v[X4(i, j, k, nstp)] * o->vmask[X2(i, j)];
+          for (int i = b->IstrB; i <= b->IendB; i++) {
+            if (msk) v[X4(i, j, k, nstp)] = v[X4(i, j, k, nstp)] * o->vmask[X2(i, j)];
+            if (o->wet_dry) v[X4(i, j, k, nstp)] = v[X4(i, j, k, nstp)] * o->vmask_wet[X2(i, j)];   /* :308 */
+          }
       }
   orc_u3dbc(o, b, nstp);
   orc_v3dbc(o, b, nstp);
@@ -490,6 +526,7 @@ void orc_ini_fields(orc_t *o, int tile) {
       double cff1 = 1.0 / DCx(i, 0);
       double cff2 = CF[i - LBi] * cff1;
       if (msk) cff2 = cff2 * o->umask[X2(i, j)];                          /* :376 */
+      if (o->wet_dry) cff2 = cff2 * o->umask_wet[X2(i, j)];               /* :379 */
       o->ubar[X2T(i, j, kstp)] = cff2;
     }
     if (j >= b->JstrM) {
@@ -504,6 +541,7 @@ void orc_ini_fields(orc_t *o, int tile) {
         double cff1 = 1.0 / DCx(i, 0);
         double cff2 = CF[i - LBi] * cff1;
         if (msk) cff2 = cff2 * o->vmask[X2(i, j)];                        /* :400 */
+        if (o->wet_dry) cff2 = cff2 * o->vmask_wet[X2(i, j)];             /* :403 */
         o->vbar[X2T(i, j, kstp)] = cff2;
       }
     }

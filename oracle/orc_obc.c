@@ -208,12 +208,14 @@ void orc_zetabc(const orc_t *o, const orc_bounds *b, int kout) {
         val = rad_point(o, &E, Zn, Zo, i, j, fm, kind == ORC_LBC_RADNUD, o->c.FSobc_in[E.e], o->c.FSobc_out[E.e], dt2d, bv, E.e == ORC_ISOUTH);
       } else if (kind == ORC_LBC_CHE) {               /* :186-204 */
         const double cff = dt2d * pmn[X2(i1, j1)];
-        const double cff1 = sqrt(g * (o->h[X2(i1, j1)] + Zn[X2(i1, j1)]));
+        const double dep = o->h[X2(i1, j1)] + Zn[X2(i1, j1)];
+        const double cff1 = sqrt(g * (o->wet_dry ? (dep > o->Dcrit ? dep : o->Dcrit) : dep));   /* WET_DRY: MAX(..., Dcrit) :190-192 */
         const double Cx = cff * cff1;
         val = (1.0 - Cx) * Zn[X2(i, j)] + Cx * Zn[X2(i1, j1)];
       } else if (kind == ORC_LBC_CHI) {               /* :208-227 */
         const double cff = dt2d * pmn[X2(i1, j1)];
-        const double cff1 = sqrt(g * (o->h[X2(i1, j1)] + Zn[X2(i1, j1)]));
+        const double dep = o->h[X2(i1, j1)] + Zn[X2(i1, j1)];
+        const double cff1 = sqrt(g * (o->wet_dry ? (dep > o->Dcrit ? dep : o->Dcrit) : dep));   /* WET_DRY: MAX(..., Dcrit) :190-192 */
         const double Cx = cff * cff1;
         const double cff2 = 1.0 / (1.0 + Cx);
         val = cff2 * (Zn[X2(i, j)] + Cx * Zo[X2(i1, j1)]);
@@ -227,6 +229,27 @@ void orc_zetabc(const orc_t *o, const orc_bounds *b, int kout) {
     }
   }
   corners_r(o, b, Zo);
+  if (o->wet_dry) {
+    /* "Ensure that water level on boundary cells is above bed elevation" zetabc.F:783-874 (every kind of condition) */
+    const double cff = o->Dcrit - eps;
+    const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
+#define WDZ(i, j) if (Zo[X2(i, j)] <= (o->Dcrit - o->h[X2(i, j)])) Zo[X2(i, j)] = cff - o->h[X2(i, j)]
+    if (!o->c.EWperiodic) {
+      if (b->west) for (int j = Jstr; j <= Jend; j++) { WDZ(Istr - 1, j); }
+      if (b->east) for (int j = Jstr; j <= Jend; j++) { WDZ(Iend + 1, j); }
+    }
+    if (!o->c.NSperiodic) {
+      if (b->south) for (int i = Istr; i <= Iend; i++) { WDZ(i, Jstr - 1); }
+      if (b->north) for (int i = Istr; i <= Iend; i++) { WDZ(i, Jend + 1); }
+    }
+    if (!(o->c.EWperiodic || o->c.NSperiodic)) {
+      if (b->south && b->west) { WDZ(Istr - 1, Jstr - 1); }
+      if (b->south && b->east) { WDZ(Iend + 1, Jstr - 1); }
+      if (b->north && b->west) { WDZ(Istr - 1, Jend + 1); }
+      if (b->north && b->east) { WDZ(Iend + 1, Jend + 1); }
+    }
+#undef WDZ
+  }
 }
 
 /* ------------------------------------------------------------------------ u2dbc_tile / v2dbc_tile (one function) */
@@ -294,7 +317,7 @@ static void uv2dbc(const orc_t *o, const orc_bounds *b, int kout, char grid) {
           const double Cx = sqrt(g * cff);
           val = bv + sgn * (Cx * (0.5 * (Zn[lo] + Zn[hi]) - zbry[s - lb]));
         } else {                                                /* Shchepetkin :296-369,647-720 */
-          const double cff = 0.5 * (o->h[lo] + o->h[hi]);
+          const double cff = o->wet_dry ? 0.5 * (o->h[lo] + Zn[lo] + o->h[hi] + Zn[hi]) : 0.5 * (o->h[lo] + o->h[hi]);   /* WET_DRY :339-347 */
           const double cff1 = sqrt(g / cff);
           const double Cx = dt2d * cff1 * cff * 0.5 * (pmn[lo] + pmn[hi]);
           double Zx = (0.5 + Cx) * Zn[in] + (0.5 - Cx) * Zn[out];
@@ -323,6 +346,45 @@ static void uv2dbc(const orc_t *o, const orc_bounds *b, int kout, char grid) {
   }
   if (isU) corners_u(o, b, Qo);
   else corners_v(o, b, Qo);
+  if (o->wet_dry) {
+    /* "Impose wetting and drying conditions" u2dbc_im.F:1190-1318, v2dbc_im.F:1239-1367, AS WRITTEN: the factor of the
+       barotropic step from the wet mask and the value at one point (mi,mj) applied to the value at (ti,tj) -- the same
+       point everywhere except v2dbc's western edge (mask and sign at Istr-1, product stored at Istr, v2dbc_im.F:1250-1255) */
+    const double *mw = isU ? o->umask_wet : o->vmask_wet;
+    const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
+#define WDP(mi, mj, ti, tj) Qo[X2(ti, tj)] = Qo[X2(ti, tj)] * orc_wd_fac(mw[X2(mi, mj)], Qo[X2(mi, mj)])
+    if (!o->c.EWperiodic) {
+      if (b->west) {
+        if (isU) for (int j = Jstr; j <= Jend; j++) WDP(Istr, j, Istr, j);
+        else for (int j = b->JstrV; j <= Jend; j++) WDP(Istr - 1, j, Istr, j);
+      }
+      if (b->east) {
+        if (isU) for (int j = Jstr; j <= Jend; j++) WDP(Iend + 1, j, Iend + 1, j);
+        else for (int j = b->JstrV; j <= Jend; j++) WDP(Iend + 1, j, Iend + 1, j);
+      }
+    }
+    if (!o->c.NSperiodic) {
+      if (b->south) {
+        if (isU) for (int i = b->IstrU; i <= Iend; i++) WDP(i, Jstr - 1, i, Jstr - 1);
+        else for (int i = Istr; i <= Iend; i++) WDP(i, Jstr, i, Jstr);
+      }
+      if (b->north) for (int i = Istr; i <= Iend; i++) WDP(i, Jend + 1, i, Jend + 1);
+    }
+    if (!(o->c.EWperiodic || o->c.NSperiodic)) {
+      if (isU) {
+        if (b->south && b->west) WDP(Istr, Jstr - 1, Istr, Jstr - 1);
+        if (b->south && b->east) WDP(Iend + 1, Jstr - 1, Iend + 1, Jstr - 1);
+        if (b->north && b->west) WDP(Istr, Jend + 1, Istr, Jend + 1);
+        if (b->north && b->east) WDP(Iend + 1, Jend + 1, Iend + 1, Jend + 1);
+      } else {
+        if (b->south && b->west) WDP(Istr - 1, Jstr, Istr - 1, Jstr);
+        if (b->south && b->east) WDP(Iend + 1, Jstr, Iend + 1, Jstr);
+        if (b->north && b->west) WDP(Istr - 1, Jend + 1, Istr - 1, Jend + 1);
+        if (b->north && b->east) WDP(Iend + 1, Jend + 1, Iend + 1, Jend + 1);
+      }
+    }
+#undef WDP
+  }
 }
 void orc_u2dbc(const orc_t *o, const orc_bounds *b, int kout) { uv2dbc(o, b, kout, 'u'); }
 void orc_v2dbc(const orc_t *o, const orc_bounds *b, int kout) { uv2dbc(o, b, kout, 'v'); }
@@ -375,6 +437,7 @@ static void bc3d(const orc_t *o, const orc_bounds *b, int nout, char grid, int i
             const int i = EI(&E, s), j = EJ(&E, s);
             Qo[X2(i, j)] = gamma2 * Qo[X2(i + E.di, j + E.dj)];
             if (msk) Qo[X2(i, j)] = Qo[X2(i, j)] * qmask[X2(i, j)];
+            if (o->wet_dry) Qo[X2(i, j)] = Qo[X2(i, j)] * (grid == 'u' ? o->umask_wet : o->vmask_wet)[X2(i, j)];   /* u3dbc_im.F:523 */
           }
         }
         continue;
@@ -388,6 +451,10 @@ static void bc3d(const orc_t *o, const orc_bounds *b, int nout, char grid, int i
         else if (kind == ORC_LBC_CLA) val = bry[s - lb];
         else val = Qo[X2(i + E.di, j + E.dj)];                  /* gradient; tracers: closed too (t3dbc_im.F:205-218) */
         if (msk) val = val * qmask[X2(i, j)];
+        /* WET_DRY: u3dbc_im.F:174,193,212 ... -- every open kind on every edge but u's gradient condition at the southern edge,
+           which the reference guards with "WET_MASK" (u3dbc_im.F:496), a name nothing defines */
+        if (o->wet_dry && grid != 'r' && !(grid == 'u' && E.e == ORC_ISOUTH && kind == ORC_LBC_GRA))
+          val = val * (grid == 'u' ? o->umask_wet : o->vmask_wet)[X2(i, j)];
         Qo[X2(i, j)] = val;
       }
     }

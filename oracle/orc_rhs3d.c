@@ -309,7 +309,8 @@ void orc_pre_step3d(orc_t *o, int tile) {
         /* SOLAR_SOURCE :890-900 */
         for (int k = 1; k <= N - 1; k++)
           for (int i = Istr; i <= Iend; i++)
-            CX(FC, i, k) = CX(FC, i, k) + dt * o->srflx[X2(i, j)] * swdk[XW(i, j, k)];
+            if (o->wet_dry) CX(FC, i, k) = CX(FC, i, k) + dt * o->srflx[X2(i, j)] * o->rmask_wet[X2(i, j)] * swdk[XW(i, j, k)];   /* pre_step3d.F:903 */
+            else CX(FC, i, k) = CX(FC, i, k) + dt * o->srflx[X2(i, j)] * swdk[XW(i, j, k)];
       }
       for (int i = Istr; i <= Iend; i++) {
         CX(FC, i, 0) = dt * o->btflx[X2T(i, j, itrc)];
@@ -664,7 +665,7 @@ static void orc_prsgrd32(orc_t *o, int tile) {
         } else dRx[X2(i, j)] = 0.0;
       }
     for (int j = Jstr; j <= Jend; j++)
-      for (int i = IstrU; i <= Iend; i++)
+      for (int i = IstrU; i <= Iend; i++) {
         ru[XW4(i, j, k, nrhs)] =
             o->on_u[X2(i, j)] * 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]) *
             (P[X3(i - 1, j, k)] - P[X3(i, j, k)] -
@@ -675,6 +676,8 @@ static void orc_prsgrd32(orc_t *o, int tile) {
                                      (dZx[X2(i, j)] - dZx[X2(i - 1, j)]) *
                                          (rho[X3(i, j, k)] - rho[X3(i - 1, j, k)] -
                                           OneTwelfth * (dRx[X2(i, j)] + dRx[X2(i - 1, j)])))));
+        if (o->wet_dry) ru[XW4(i, j, k, nrhs)] = ru[XW4(i, j, k, nrhs)] * o->umask_wet[X2(i, j)];   /* prsgrd32.h:362 */
+      }
   }
   /* ETA-component */
   for (int k = N; k >= 1; k--) {
@@ -701,7 +704,7 @@ static void orc_prsgrd32(orc_t *o, int tile) {
         } else dRx[X2(i, j)] = 0.0;
       }
     for (int j = JstrV; j <= Jend; j++)
-      for (int i = Istr; i <= Iend; i++)
+      for (int i = Istr; i <= Iend; i++) {
         rv[XW4(i, j, k, nrhs)] =
             o->om_v[X2(i, j)] * 0.5 * (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]) *
             (P[X3(i, j - 1, k)] - P[X3(i, j, k)] -
@@ -712,6 +715,8 @@ static void orc_prsgrd32(orc_t *o, int tile) {
                                      (dZx[X2(i, j)] - dZx[X2(i, j - 1)]) *
                                          (rho[X3(i, j, k)] - rho[X3(i, j - 1, k)] -
                                           OneTwelfth * (dRx[X2(i, j)] + dRx[X2(i, j - 1)])))));
+        if (o->wet_dry) rv[XW4(i, j, k, nrhs)] = rv[XW4(i, j, k, nrhs)] * o->vmask_wet[X2(i, j)];   /* prsgrd32.h:426 */
+      }
   }
   free(P);
   free(dR);
@@ -738,6 +743,7 @@ void orc_t3dmix2(orc_t *o, int tile) {
           FX[X2(i, j)] = cff * (Hz[X3(i, j, k)] + Hz[X3(i - 1, j, k)]) *
                          (t[XT(i, j, k, nrhs, itrc)] - t[XT(i - 1, j, k, nrhs, itrc)]);
           if (o->c.options & ORC_MASKING) FX[X2(i, j)] = FX[X2(i, j)] * o->umask[X2(i, j)];   /* t3dmix2_s.h:236 */
+          if (o->wet_dry) FX[X2(i, j)] = FX[X2(i, j)] * o->umask_wet[X2(i, j)];               /* :239 */
         }
       for (int j = Jstr; j <= Jend + 1; j++)
         for (int i = Istr; i <= Iend; i++) {
@@ -745,6 +751,7 @@ void orc_t3dmix2(orc_t *o, int tile) {
           FE[X2(i, j)] = cff * (Hz[X3(i, j, k)] + Hz[X3(i, j - 1, k)]) *
                          (t[XT(i, j, k, nrhs, itrc)] - t[XT(i, j - 1, k, nrhs, itrc)]);
           if (o->c.options & ORC_MASKING) FE[X2(i, j)] = FE[X2(i, j)] * o->vmask[X2(i, j)];   /* t3dmix2_s.h:276 */
+          if (o->wet_dry) FE[X2(i, j)] = FE[X2(i, j)] * o->vmask_wet[X2(i, j)];               /* :279 */
         }
       for (int j = Jstr; j <= Jend; j++)
         for (int i = Istr; i <= Iend; i++) {
@@ -796,6 +803,7 @@ void orc_uv3dmix2(orc_t *o, int tile) {
                o->pnom_p[X2(i, j)] * ((pm[X2(i - 1, j)] + pm[X2(i, j)]) * u[X4(i, j, k, nrhs)] -
                                       (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]) * u[X4(i, j - 1, k, nrhs)]));
         if (o->c.options & ORC_MASKING) cff = cff * o->pmask[X2(i, j)];                       /* uv3dmix2_s.h:273 */
+        if (o->wet_dry) cff = cff * o->pmask_wet[X2(i, j)];                                   /* :276 */
         UFe[X2(i, j)] = om_p[X2(i, j)] * om_p[X2(i, j)] * o->visc2_p[X2(i, j)] * cff;
         VFx[X2(i, j)] = on_p[X2(i, j)] * on_p[X2(i, j)] * o->visc2_p[X2(i, j)] * cff;
       }
@@ -1105,6 +1113,9 @@ void orc_rhs3d_tile(orc_t *o, int tile) {
           }
       }
     }
+    if (o->wet_dry)                                      /* rhs3d.F:1709,1750 */
+      for (int k = 1; k <= N; k++)
+        for (int i = IstrU; i <= Iend; i++) RU(i, j, k) = RU(i, j, k) * o->umask_wet[X2(i, j)];
     for (int i = IstrU; i <= Iend; i++) o->rufrc[X2(i, j)] = RU(i, j, 1);
     for (int k = 2; k <= N; k++)
       for (int i = IstrU; i <= Iend; i++) o->rufrc[X2(i, j)] = o->rufrc[X2(i, j)] + RU(i, j, k);
@@ -1128,9 +1139,13 @@ void orc_rhs3d_tile(orc_t *o, int tile) {
       cff1 = o->sustr[X2(i, j)] * cff;
       cff2 = -o->bustr[X2(i, j)] * cff;
       o->rufrc[X2(i, j)] = o->rufrc[X2(i, j)] + cff1 + cff2;
+      if (o->wet_dry) o->rufrc[X2(i, j)] = o->rufrc[X2(i, j)] * o->umask_wet[X2(i, j)];            /* :1804 */
       if (d) { DUF(d->RUfrc, i, j, 3, d->M2sstr) = cff1; DUF(d->RUfrc, i, j, 3, d->M2bstr) = cff2; }    /* :1807 */
     }
     if (j >= JstrV) {
+      if (o->wet_dry)                                    /* :1815,1856 */
+        for (int k = 1; k <= N; k++)
+          for (int i = Istr; i <= Iend; i++) RV(i, j, k) = RV(i, j, k) * o->vmask_wet[X2(i, j)];
       for (int i = Istr; i <= Iend; i++) o->rvfrc[X2(i, j)] = RV(i, j, 1);
       for (int k = 2; k <= N; k++)
         for (int i = Istr; i <= Iend; i++) o->rvfrc[X2(i, j)] = o->rvfrc[X2(i, j)] + RV(i, j, k);
@@ -1154,6 +1169,7 @@ void orc_rhs3d_tile(orc_t *o, int tile) {
         cff1 = o->svstr[X2(i, j)] * cff;
         cff2 = -o->bvstr[X2(i, j)] * cff;
         o->rvfrc[X2(i, j)] = o->rvfrc[X2(i, j)] + cff1 + cff2;
+        if (o->wet_dry) o->rvfrc[X2(i, j)] = o->rvfrc[X2(i, j)] * o->vmask_wet[X2(i, j)];          /* :1910 */
         if (d) { DUF(d->RVfrc, i, j, 3, d->M2sstr) = cff1; DUF(d->RVfrc, i, j, 3, d->M2bstr) = cff2; }  /* :1913 */
       }
     }

@@ -118,6 +118,7 @@ void orc_step2d(orc_t *o, int tile) {
     orc_exchange2d(o, b, 'u', o->DU_avg1);
     orc_exchange2d(o, b, 'v', o->DV_avg1);
   }
+  if (o->wet_dry) orc_wetdry_tile(o, tile);                              /* new wet/dry masks :863 */
   if (iif > c->nfast) { free(S); return; }
 
   /* free-surface step :886-1000 */
@@ -171,7 +172,10 @@ void orc_step2d(orc_t *o, int tile) {
       }
   }
   for (int j = Jstr; j <= Jend; j++)
-    for (int i = Istr; i <= Iend; i++) Z(i, j, knew) = zeta_new[X2(i, j)];
+    for (int i = Istr; i <= Iend; i++) {
+      Z(i, j, knew) = zeta_new[X2(i, j)];
+      if (o->wet_dry && msk) Z(i, j, knew) = Z(i, j, knew) + (o->Dcrit - h[X2(i, j)]) * (1.0 - o->rmask[X2(i, j)]);   /* :992 */
+    }
   if (PRED) {
     for (int j = Jstr; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) rzeta[X2T(i, j, krhs)] = rhs_zeta[X2(i, j)];
@@ -388,6 +392,7 @@ void orc_step2d(orc_t *o, int tile) {
                o->pnom_p[X2(i, j)] * ((pm[X2(i - 1, j)] + pm[X2(i, j)]) * UB(i, j, krhs) -
                                       (pm[X2(i - 1, j - 1)] + pm[X2(i, j - 1)]) * UB(i, j - 1, krhs)));
         if (msk) cff = cff * o->pmask[X2(i, j)];                                            /* :1613 */
+        if (o->wet_dry) cff = cff * o->pmask_wet[X2(i, j)];                                 /* :1617 */
         UFe[X2(i, j)] = om_p[X2(i, j)] * om_p[X2(i, j)] * cff;
         VFx[X2(i, j)] = on_p[X2(i, j)] * on_p[X2(i, j)] * cff;
       }
@@ -411,6 +416,12 @@ void orc_step2d(orc_t *o, int tile) {
 
   if (o->uv_vis4) orc_step2d_vis4(o, b, krhs, Drhs, rhs_ubar, rhs_vbar, U2rhs, V2rhs);   /* UV_VIS4 :1653-1920 (orc_mix4.c) */
 
+  if (o->wet_dry) {                                                      /* :2205-2222 */
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = IstrU; i <= Iend; i++) rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] * orc_wd_fac(o->umask_wet[X2(i, j)], rhs_ubar[X2(i, j)]);
+    for (int j = JstrV; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] * orc_wd_fac(o->vmask_wet[X2(i, j)], rhs_vbar[X2(i, j)]);
+  }
   /* coupling with the 3-D momentum forcing :2225-2460 */
   if (iif == 1 && PRED) {
     if (iic == c->ntfirst) {
@@ -557,6 +568,12 @@ void orc_step2d(orc_t *o, int tile) {
         UB(i, j, knew) = (UB(i, j, kstp) * (Dstp[X2(i, j)] + Dstp[X2(i - 1, j)]) +
                           cff * cff1 * rhs_ubar[X2(i, j)]) * fac;
         if (msk) UB(i, j, knew) = UB(i, j, knew) * o->umask[X2(i, j)];                      /* :2515,2578 */
+        if (o->wet_dry) {                                                                   /* :2518-2529, 2581-2587 */
+          const double cff7 = orc_wd_fac(o->umask_wet[X2(i, j)], UB(i, j, knew));
+          UB(i, j, knew) = UB(i, j, knew) * cff7;
+          rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] * cff7;
+          if (iif == 1 && PRED) { rufrc[X2(i, j)] = rufrc[X2(i, j)] * cff7; ru[XW4(i, j, 0, nstp)] = rufrc[X2(i, j)]; }
+        }
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -565,6 +582,12 @@ void orc_step2d(orc_t *o, int tile) {
         VB(i, j, knew) = (VB(i, j, kstp) * (Dstp[X2(i, j)] + Dstp[X2(i, j - 1)]) +
                           cff * cff1 * rhs_vbar[X2(i, j)]) * fac;
         if (msk) VB(i, j, knew) = VB(i, j, knew) * o->vmask[X2(i, j)];                      /* :2544,2601 */
+        if (o->wet_dry) {                                                                   /* :2547-2558, 2604-2610 */
+          const double cff7 = orc_wd_fac(o->vmask_wet[X2(i, j)], VB(i, j, knew));
+          VB(i, j, knew) = VB(i, j, knew) * cff7;
+          rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] * cff7;
+          if (iif == 1 && PRED) { rvfrc[X2(i, j)] = rvfrc[X2(i, j)] * cff7; rv[XW4(i, j, 0, nstp)] = rvfrc[X2(i, j)]; }
+        }
       }
   } else if (CORR) {
     cff1 = 0.5 * dtfast * 5.0 / 12.0;
@@ -578,6 +601,11 @@ void orc_step2d(orc_t *o, int tile) {
                           cff * (cff1 * rhs_ubar[X2(i, j)] + cff2 * rubar[X2T(i, j, kstp)] -
                                  cff3 * rubar[X2T(i, j, ptsk)])) * fac;
         if (msk) UB(i, j, knew) = UB(i, j, knew) * o->umask[X2(i, j)];                      /* :2633 */
+        if (o->wet_dry) {                                                                   /* :2636-2642 */
+          const double cff7 = orc_wd_fac(o->umask_wet[X2(i, j)], UB(i, j, knew));
+          UB(i, j, knew) = UB(i, j, knew) * cff7;
+          rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] * cff7;
+        }
       }
     for (int j = JstrV; j <= Jend; j++)
       for (int i = Istr; i <= Iend; i++) {
@@ -587,6 +615,11 @@ void orc_step2d(orc_t *o, int tile) {
                           cff * (cff1 * rhs_vbar[X2(i, j)] + cff2 * rvbar[X2T(i, j, kstp)] -
                                  cff3 * rvbar[X2T(i, j, ptsk)])) * fac;
         if (msk) VB(i, j, knew) = VB(i, j, knew) * o->vmask[X2(i, j)];                      /* :2658 */
+        if (o->wet_dry) {                                                                   /* :2661-2667 */
+          const double cff7 = orc_wd_fac(o->vmask_wet[X2(i, j)], VB(i, j, knew));
+          VB(i, j, knew) = VB(i, j, knew) * cff7;
+          rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] * cff7;
+        }
       }
   }
   if (d) {

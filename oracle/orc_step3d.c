@@ -193,6 +193,12 @@ void orc_step3d_uv(orc_t *o, int tile) {
         for (int i = i0; i <= Iend; i++) {
           q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] - CX(DC, i, 0);
           if (msk) q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] * (dir == 0 ? o->umask : o->vmask)[X2(i, j)];   /* step3d_uv.F:717,1184 */
+          if (o->wet_dry) {                                                      /* :720-721, :1187-1188 */
+            const double mw = (dir == 0 ? o->umask_wet : o->vmask_wet)[X2(i, j)];
+            double *rq = dir == 0 ? o->ru : o->rv;
+            q[X4(i, j, k, nnew)] = q[X4(i, j, k, nnew)] * mw;
+            rq[XW4(i, j, k, o->s.nrhs)] = rq[XW4(i, j, k, o->s.nrhs)] * mw;
+          }
           if (d)                                                                 /* :733-760 */
             for (int q_ = 0; q_ < nm; q_++)
               DU3(W3, i, j, k, m3[q_]) = DU3(W3, i, j, k, m3[q_]) - Dwrk[(size_t)(m2[q_] - 1) * ni + (size_t)(i - LBi)];
@@ -222,6 +228,7 @@ void orc_step3d_uv(orc_t *o, int tile) {
       CX(DC, i, 0) = 1.0 / CX(DC, i, 0);
       CX(CF, i, 0) = CX(DC, i, 0) * (CX(CF, i, 0) - o->DU_avg1[X2(i, j)]);
       o->ubar[X2T(i, j, 1)] = CX(DC, i, 0) * o->DU_avg1[X2(i, j)];
+      if (o->wet_dry) o->ubar[X2T(i, j, 1)] = o->ubar[X2T(i, j, 1)] * o->umask_wet[X2(i, j)];   /* :1359 */
       o->ubar[X2T(i, j, 2)] = o->ubar[X2T(i, j, 1)];
       if (o->duv) {                                                              /* :1364-1365 */
         const orc_diauv *d = o->duv;
@@ -238,17 +245,17 @@ void orc_step3d_uv(orc_t *o, int tile) {
         }
     }
     if (!c->EWperiodic) {
-      if (b->west) for (int k = 1; k <= N; k++) { u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] - CX(CF, Istr, 0); if (msk) u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] * o->umask[X2(Istr, j)]; }
+      if (b->west) for (int k = 1; k <= N; k++) { u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] - CX(CF, Istr, 0); if (msk) u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] * o->umask[X2(Istr, j)]; if (o->wet_dry) u[X4(Istr, j, k, nnew)] = u[X4(Istr, j, k, nnew)] * o->umask_wet[X2(Istr, j)]; }
       if (b->east)
-        for (int k = 1; k <= N; k++) { u[X4(Iend + 1, j, k, nnew)] = u[X4(Iend + 1, j, k, nnew)] - CX(CF, Iend + 1, 0); if (msk) u[X4(Iend + 1, j, k, nnew)] = u[X4(Iend + 1, j, k, nnew)] * o->umask[X2(Iend + 1, j)]; }
+        for (int k = 1; k <= N; k++) { u[X4(Iend + 1, j, k, nnew)] = u[X4(Iend + 1, j, k, nnew)] - CX(CF, Iend + 1, 0); if (msk) u[X4(Iend + 1, j, k, nnew)] = u[X4(Iend + 1, j, k, nnew)] * o->umask[X2(Iend + 1, j)]; if (o->wet_dry) u[X4(Iend + 1, j, k, nnew)] = u[X4(Iend + 1, j, k, nnew)] * o->umask_wet[X2(Iend + 1, j)]; }
     }
     if (!c->NSperiodic) {
       if (j == 0)
         for (int k = 1; k <= N; k++)
-          for (int i = IstrU; i <= Iend; i++) { u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] * o->umask[X2(i, j)]; }
+          for (int i = IstrU; i <= Iend; i++) { u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] * o->umask[X2(i, j)]; if (o->wet_dry) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] * o->umask_wet[X2(i, j)]; }
       if (j == c->Mm + 1)
         for (int k = 1; k <= N; k++)
-          for (int i = IstrU; i <= Iend; i++) { u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] * o->umask[X2(i, j)]; }
+          for (int i = IstrU; i <= Iend; i++) { u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] * o->umask[X2(i, j)]; if (o->wet_dry) u[X4(i, j, k, nnew)] = u[X4(i, j, k, nnew)] * o->umask_wet[X2(i, j)]; }
     }
     for (int k = N; k >= 1; k--)
       for (int i = b->IstrP; i <= b->IendT; i++) {
@@ -274,6 +281,7 @@ void orc_step3d_uv(orc_t *o, int tile) {
         CX(DC, i, 0) = 1.0 / CX(DC, i, 0);
         CX(CF, i, 0) = CX(DC, i, 0) * (CX(CF, i, 0) - o->DV_avg1[X2(i, j)]);
         o->vbar[X2T(i, j, 1)] = CX(DC, i, 0) * o->DV_avg1[X2(i, j)];
+        if (o->wet_dry) o->vbar[X2T(i, j, 1)] = o->vbar[X2T(i, j, 1)] * o->vmask_wet[X2(i, j)];   /* :1579 */
         o->vbar[X2T(i, j, 2)] = o->vbar[X2T(i, j, 1)];
         if (o->duv) {                                                            /* :1584-1586 */
           const orc_diauv *d = o->duv;
@@ -291,17 +299,17 @@ void orc_step3d_uv(orc_t *o, int tile) {
       }
       if (!c->EWperiodic) {
         if (b->west)
-          for (int k = 1; k <= N; k++) { v[X4(Istr - 1, j, k, nnew)] = v[X4(Istr - 1, j, k, nnew)] - CX(CF, Istr - 1, 0); if (msk) v[X4(Istr - 1, j, k, nnew)] = v[X4(Istr - 1, j, k, nnew)] * o->vmask[X2(Istr - 1, j)]; }
+          for (int k = 1; k <= N; k++) { v[X4(Istr - 1, j, k, nnew)] = v[X4(Istr - 1, j, k, nnew)] - CX(CF, Istr - 1, 0); if (msk) v[X4(Istr - 1, j, k, nnew)] = v[X4(Istr - 1, j, k, nnew)] * o->vmask[X2(Istr - 1, j)]; if (o->wet_dry) v[X4(Istr - 1, j, k, nnew)] = v[X4(Istr - 1, j, k, nnew)] * o->vmask_wet[X2(Istr - 1, j)]; }
         if (b->east)
-          for (int k = 1; k <= N; k++) { v[X4(Iend + 1, j, k, nnew)] = v[X4(Iend + 1, j, k, nnew)] - CX(CF, Iend + 1, 0); if (msk) v[X4(Iend + 1, j, k, nnew)] = v[X4(Iend + 1, j, k, nnew)] * o->vmask[X2(Iend + 1, j)]; }
+          for (int k = 1; k <= N; k++) { v[X4(Iend + 1, j, k, nnew)] = v[X4(Iend + 1, j, k, nnew)] - CX(CF, Iend + 1, 0); if (msk) v[X4(Iend + 1, j, k, nnew)] = v[X4(Iend + 1, j, k, nnew)] * o->vmask[X2(Iend + 1, j)]; if (o->wet_dry) v[X4(Iend + 1, j, k, nnew)] = v[X4(Iend + 1, j, k, nnew)] * o->vmask_wet[X2(Iend + 1, j)]; }
       }
       if (!c->NSperiodic) {
         if (j == 1)
           for (int k = 1; k <= N; k++)
-            for (int i = Istr; i <= Iend; i++) { v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] * o->vmask[X2(i, j)]; }
+            for (int i = Istr; i <= Iend; i++) { v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] * o->vmask[X2(i, j)]; if (o->wet_dry) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] * o->vmask_wet[X2(i, j)]; }
         if (j == c->Mm + 1)
           for (int k = 1; k <= N; k++)
-            for (int i = Istr; i <= Iend; i++) { v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] * o->vmask[X2(i, j)]; }
+            for (int i = Istr; i <= Iend; i++) { v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] - CX(CF, i, 0); if (msk) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] * o->vmask[X2(i, j)]; if (o->wet_dry) v[X4(i, j, k, nnew)] = v[X4(i, j, k, nnew)] * o->vmask_wet[X2(i, j)]; }
       }
       for (int k = N; k >= 1; k--)
         for (int i = b->IstrT; i <= b->IendT; i++) {

@@ -75,6 +75,11 @@ if [ "$APP" = upwelling_bih ]; then
   UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
   EXTRA=""
 fi
+if [ "$APP" = upwelling_wetdry ]; then
+  # UPWELLING with MASKING + WET_DRY (oracle/ref/upwelling_wetdry.h): pins wetdry.F and the WET_DRY branches
+  UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
+  EXTRA="-I$HERE/functionals"
+fi
 if [ "$APP" = upwelling_gls ]; then
   # the shipped upwelling.h with the generic length-scale closure switched on as a user does (-DGLS_MIXING: upwelling.h
   # then selects KANTHA_CLAYSON, N2S2_HORAVG, RI_SPLINES)
@@ -159,7 +164,7 @@ FILES="mod_kinds mod_param mod_scalars mod_stepping mod_strings mod_iounits mod_
   metrics ini_hmixcoef stiffness mp_routines ntimestep
   bc_2d bc_3d zetabc u2dbc_im v2dbc_im t3dbc_im u3dbc_im v3dbc_im obc_volcons
   set_depth set_massflux rho_eos prsgrd t3dmix uv3dmix set_vbc set_zeta wvelocity diag ini_fields
-  mod_sources uv_var_change step2d omega pre_step3d rhs3d step3d_uv step3d_t
+  mod_sources uv_var_change wetdry step2d omega pre_step3d rhs3d step3d_uv step3d_t
   mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix gls_prestep gls_corstep my25_prestep my25_corstep tkebc_im bulk_flux analytical
   mod_average uv_rotate vorticity set_avg mod_diags set_diags"
 TODO=""

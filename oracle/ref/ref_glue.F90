@@ -234,6 +234,10 @@
       dstart=rpar(22)
       time_ref=0.0_dp
       CALL ref_clock (time_ref)
+#ifdef WET_DRY
+!  DCRIT of roms.in (read_phypar.F:1021)
+      Dcrit(ng)=rpar(84)
+#endif
 #ifdef BULK_FLUXES
       blk_ZQ(ng)=rpar(23)
       blk_ZT(ng)=rpar(24)
@@ -383,6 +387,9 @@
       USE rho_eos_mod,       ONLY : rho_eos
       USE omega_mod,         ONLY : omega
       USE dateclock_mod,     ONLY : time_string
+#ifdef WET_DRY
+      USE wetdry_mod,        ONLY : wetdry
+#endif
       integer :: tile
       DO tile=first_tile(ng),last_tile(ng)
         CALL ana_grid (ng, tile, iNLM)
@@ -401,6 +408,11 @@
       DO tile=first_tile(ng),last_tile(ng)
         CALL ana_initial (ng, tile, iNLM)
       END DO
+#ifdef WET_DRY
+      DO tile=first_tile(ng),last_tile(ng)
+        CALL wetdry (ng, tile, 1, .TRUE.)                  ! initial.F:467
+      END DO
+#endif
       DO tile=first_tile(ng),last_tile(ng)
         CALL set_depth0 (ng, tile, iNLM)
         CALL set_zeta_timeavg (ng, tile, iNLM)
@@ -707,6 +719,9 @@
       USE step2d_mod,        ONLY : step2d
       USE step3d_uv_mod,     ONLY : step3d_uv
       USE step3d_t_mod,      ONLY : step3d_t
+#ifdef WET_DRY
+      USE wetdry_mod,        ONLY : wetdry
+#endif
 #ifdef LMD_MIXING
       USE lmd_vmix_mod,      ONLY : lmd_vmix
 #endif
@@ -746,6 +761,11 @@
 #ifdef DIAGNOSTICS
           CASE ('set_diags')
             CALL set_diags (ng, tile)
+#endif
+#ifdef WET_DRY
+          CASE ('wetdry')
+!  initial.F:467 -- the initial wet/dry masks
+            CALL wetdry (ng, tile, kstp(ng), .TRUE.)
 #endif
           CASE ('set_depth')
             CALL set_depth (ng, tile, iNLM)
@@ -890,6 +910,10 @@
 #ifdef MASKING
      &                        GRID(ng)%rmask, GRID(ng)%umask,           &
      &                        GRID(ng)%vmask,                           &
+#endif
+#ifdef WET_DRY
+     &                        GRID(ng)%rmask_wet, GRID(ng)%umask_wet,   &
+     &                        GRID(ng)%vmask_wet,                       &
 #endif
      &                        GRID(ng)%pm, GRID(ng)%pn, GRID(ng)%omn,   &
      &                        GRID(ng)%om_u, GRID(ng)%on_v,             &
@@ -1154,6 +1178,17 @@
         F2('umask',GRID(ng)%umask)
         F2('vmask',GRID(ng)%vmask)
         F2('pmask',GRID(ng)%pmask)
+#endif
+#ifdef WET_DRY
+        F2('rmask_wet',GRID(ng)%rmask_wet)
+        F2('umask_wet',GRID(ng)%umask_wet)
+        F2('vmask_wet',GRID(ng)%vmask_wet)
+        F2('pmask_wet',GRID(ng)%pmask_wet)
+        F2('rmask_full',GRID(ng)%rmask_full)
+        F2('umask_full',GRID(ng)%umask_full)
+        F2('vmask_full',GRID(ng)%vmask_full)
+        F2('pmask_full',GRID(ng)%pmask_full)
+        F2('rmask_wet_avg',GRID(ng)%rmask_wet_avg)
 #endif
         F2('grdscl',GRID(ng)%grdscl)
         F2('xr',GRID(ng)%xr)

@@ -238,6 +238,41 @@ def upwelling_mask(**kw):
     return cs
 
 
+def upwelling_wetdry(Dcrit=0.1, **kw):
+    """UPWELLING with land/sea masking and wetting and drying (MASKING + WET_DRY): the custom application header
+    oracle/ref/upwelling_wetdry.h.  The land is `land_mask`; the bathymetry and the initial free surface are
+    `wetdry_depth`: a beach that rises above the still water level towards the northern wall, and a ridge of water
+    in the deep part that runs up it.  Dcrit: DCRIT of roms.in, the depth below which a cell counts as dry."""
+    cs = upwelling(**kw)
+    cs["app"] = "upwelling_wetdry"
+    cs["options"] = tuple(cs["options"]) + ("MASKING",)
+    cs["wet_dry"] = 1
+    cs["Dcrit"] = Dcrit
+    return cs
+
+
+def wetdry_depth(cs, LBi, UBi, LBj, UBj):
+    """h and the initial zeta of the wetting/drying test case on arrays (LBi:UBi, LBj:UBj), [j, i] here: depth 10 m south
+    of row Mm/3, from there a plane beach to -0.3 m (30 cm above the still water level) at the northern wall, roughened
+    by 5 cm x ((7 i + 3 j) mod 5) so that the shore line is two-dimensional; zeta: a ridge 0.4 m high, 4 rows either
+    side of row Mm/4.  Only +, -, *, / and min/max of exactly representable numbers: numpy and the Fortran host
+    (roms_host.f90:wetdry_depths) produce the same doubles."""
+    import numpy as np
+    Lm, Mm = cs["Lm"], cs["Mm"]
+    i = np.arange(LBi, UBi + 1)[None, :] * np.ones((UBj - LBj + 1, 1), dtype=int)
+    j = np.arange(LBj, UBj + 1)[:, None] * np.ones((1, UBi - LBi + 1), dtype=int)
+    if cs.get("EWperiodic"):
+        i = (i - 1) % Lm + 1
+    if cs.get("NSperiodic"):
+        j = (j - 1) % Mm + 1
+    j0 = Mm // 3
+    ramp = np.minimum(1.0, np.maximum(0.0, (j - j0).astype(float) / float(Mm + 1 - j0)))
+    h = 10.0 - 10.3 * ramp + 0.05 * ((7 * i + 3 * j) % 5).astype(float)
+    js = Mm // 4
+    zeta = 0.4 * np.maximum(0.0, 1.0 - np.abs(j - js).astype(float) / 4.0)
+    return dict(h=h, zeta=zeta)
+
+
 def benchmark_mask(**kw):
     """BENCHMARK (KPP, bulk fluxes, nonlinear EOS, geopotential mixing) with land/sea masking: the custom application
     header oracle/ref/benchmark_mask.h, land of `land_mask`"""

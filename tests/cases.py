@@ -2,7 +2,7 @@
 the oracle (oracle/orc.h) and of the reference glue (oracle/ref/ref_glue.F90).  TEST INFRASTRUCTURE."""
 import numpy as np
 
-from roms_amd.cases import SCHEME, benchmark, hip_cfg, upwelling, upwelling_kpp, upwelling_logdrag, upwelling_mask, benchmark_mask, land_mask, kelvin, seamount, grav_adj, overflow, upwelling_prs31, upwelling_bih, upwelling_prs40, upwelling_gls, upwelling_my25, kelvin_gls, gls_cfg, GLS_NAMES, GLS_SETS, lbc_codes, obc_scales  # noqa: F401  (re-exported)
+from roms_amd.cases import SCHEME, benchmark, hip_cfg, upwelling, upwelling_kpp, upwelling_logdrag, upwelling_mask, upwelling_wetdry, wetdry_depth, benchmark_mask, land_mask, kelvin, seamount, grav_adj, overflow, upwelling_prs31, upwelling_bih, upwelling_prs40, upwelling_gls, upwelling_my25, kelvin_gls, gls_cfg, GLS_NAMES, GLS_SETS, lbc_codes, obc_scales  # noqa: F401  (re-exported)
 
 
 def ref_params(cs):
@@ -36,6 +36,7 @@ def ref_params(cs):
         for e in range(4):
             rpar[49 + 8 * it + e] = sc["Tobc_in"][it][e]
             rpar[53 + 8 * it + e] = sc["Tobc_out"][it][e]
+    rpar[83] = cs.get("Dcrit", 0.0)     # ref_glue.F90: rpar(84), DCRIT (WET_DRY builds)
     if "gls_flags" in cs:               # ref_glue.F90: rpar(66..83)
         for k, n in enumerate(GLS_NAMES + ("Akk_bak", "Akp_bak", "charnok_alpha", "zos_hsig_alpha", "sz_alpha", "crgban_cw")):
             rpar[65 + k] = cs[n]

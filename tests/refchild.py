@@ -190,6 +190,12 @@ def mode_obc(tag, kw):
         R.put(n, a)
     a = O.field("h")                      # (an application's analytic depth need not cover the rim of a grid it was not made for)
     a[:] = 40.0 + 10.0 * rng.random(a.size)
+    if cs.get("wet_dry"):                 # shallow: the free surface matters in the phase speeds (Shchepetkin, WET_DRY form); and
+        a[:] = 1.5 + 0.5 * rng.random(a.size)   # every value the wet masks take at velocity points (wetdry_mask_tile: 0, +-1, 2)
+        for n in ("umask_wet", "vmask_wet"):
+            m = O.field(n)
+            m[:] = rng.choice(np.array([0.0, 1.0, -1.0, 2.0]), m.size)
+            R.put(n, m)
     R.put("h", a)
 
     def both(what, lev, **st):

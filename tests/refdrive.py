@@ -29,6 +29,9 @@ CASES = {
     # UPWELLING with land/sea masking (oracle/ref/upwelling_mask.h; the masks are cases.land_mask)
     "upwelling_mask_small": ("upwelling_mask", dict(Lm=14, Mm=18, N=8)),
     "benchmark_mask_small": ("benchmark_mask", dict(Lm=24, Mm=16, N=10)),
+    # UPWELLING with MASKING + WET_DRY (oracle/ref/upwelling_wetdry.h; bathymetry and initial ridge: cases.wetdry_depth)
+    "upwelling_wetdry_small": ("upwelling_wetdry", dict(Lm=14, Mm=18, N=8)),
+    "upwelling_wetdry_obc_small": ("upwelling_wetdry", dict(Lm=14, Mm=18, N=8)),      # closed basin: all four walls
     "upwelling_avg_mask_small": ("upwelling_avg_mask", dict(Lm=14, Mm=18, N=8)),      # AVERAGES + MASKING
     # open boundaries: the reference's own KELVIN application (ROMS/Include/kelvin.h, RADIATION_2D) ...
     # more of the reference's own test applications (ROMS/Include/seamount.h, grav_adj.h as shipped)
@@ -143,7 +146,7 @@ def make_case(tag, **kw):
     k.update({a: b for a, b in kw.items() if a not in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac")})
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_diag=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
-                upwelling_mask=cases.upwelling_mask, benchmark_mask=cases.benchmark_mask,
+                upwelling_mask=cases.upwelling_mask, upwelling_wetdry=cases.upwelling_wetdry, benchmark_mask=cases.benchmark_mask,
                 upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih,
                 upwelling_wjgradp=cases.upwelling_prs31, upwelling_prs40=cases.upwelling_prs40, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
@@ -170,6 +173,15 @@ def reference(app, cs):
             if n != "pmask":            # metrics.F derives the slipperiness mask itself
                 R.put(n, a)
     R.initial()
+    if cs.get("wet_dry"):               # bathymetry and initial free surface of the wetting/drying case, then initial.F:467
+        for n, a in cases.wetdry_depth(cs, R.LBi, R.UBi, R.LBj, R.UBj).items():
+            if n == "zeta":
+                z = R.get("zeta").reshape(3, -1)
+                z[:] = a.reshape(1, -1)
+                R.put("zeta", z)
+            else:
+                R.put(n, a)
+        R.call("wetdry")
     return R
 
 
@@ -182,7 +194,9 @@ def oracle_from(R, cs):
     O = orc.Oracle(cases.oracle_cfg(cs, R.table(7, 8)[0], b[58], w))
     if "mix4" in cs:
         O.set_mix4(*cs["mix4"])
-    for n in util.INIT_FIELDS:
+    if cs.get("wet_dry"):
+        O.set_wetdry(cs["Dcrit"])
+    for n in util.INIT_FIELDS + (util.WET_FIELDS if cs.get("wet_dry") else []):
         if R.has(n):
             O.field(n)[:] = R.get(n)
     for k, n in enumerate(["sc_r", "Cs_r", "sc_w", "Cs_w"]):
@@ -192,7 +206,7 @@ def oracle_from(R, cs):
 
 def shared_fields(R, O):
     out = []
-    for n in FIELDS:
+    for n in FIELDS + util.WET_FIELDS:
         if not R.has(n):
             continue
         try:

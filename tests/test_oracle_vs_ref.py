@@ -184,7 +184,7 @@ def _child(mode, tag, *args, timeout=900):
            "kelvin": "kelvin_splines", "kelvin_small": "kelvin_splines", "kelvin_plain_small": "kelvin", "kelvin_plain": "kelvin",
            "upwelling_obc_small": "upwelling", "upwelling_mask_obc_small": "upwelling_mask", "seamount": "seamount",
            "seamount_small": "seamount", "grav_adj": "grav_adj", "grav_adj_small": "grav_adj", "overflow": "overflow", "overflow_small": "overflow",
-           "upwelling_prs31_small": "upwelling_prs31", "upwelling_wjgradp_small": "upwelling_wjgradp"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
+           "upwelling_wetdry_small": "upwelling_wetdry", "upwelling_wetdry_obc_small": "upwelling_wetdry", "upwelling_prs31_small": "upwelling_prs31", "upwelling_wjgradp_small": "upwelling_wjgradp"}.get(tag, "benchmark" if tag.startswith("benchmark") else "upwelling")
     if not ref.available(lib):
         pytest.skip(f"oracle/_ref/libromsref_{lib}.so not built here")
     p = subprocess.run([sys.executable, "-m", "tests.refchild", mode, tag] + list(args), capture_output=True,
@@ -244,6 +244,14 @@ MAIN3D_CASES = [
     ("upwelling_bih_small", ["nsteps=60"]),
     ("upwelling_bih_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("upwelling_bih_small", ["nsteps=20", "hadv=U3,U3", "vadv=C4,C4"]),
+    # wetting and drying (oracle/ref/upwelling_wetdry.h: MASKING + WET_DRY): wetdry.F, the WET_DRY branches of step2d, rhs3d,
+    # prsgrd32, t3dmix2_s, uv3dmix2_s, step3d_uv, set_vbc (LIMIT_BSTRESS), ini_fields, zetabc / u2dbc / v2dbc / u3dbc / v3dbc;
+    # a beach that dries above the still water level, a ridge of water running up it; _obc: a closed basin (all four walls)
+    ("upwelling_wetdry_small", ["nsteps=60"]),
+    ("upwelling_wetdry_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_wetdry_small", ["nsteps=30", "hadv=U3,U3", "vadv=C4,C4"]),
+    ("upwelling_wetdry_obc_small", ["nsteps=40"]),
+    ("upwelling_wetdry_obc_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     # the generic length-scale closure (gls_prestep.F, gls_corstep.F, tkebc_im.F): upwelling.h built with -DGLS_MIXING
     # (Kantha-Clayson, N2S2_HORAVG, RI_SPLINES; k-epsilon and k-omega parameters of roms_upwelling.in), and the other
     # compile-time forms: Canuto A under MASKING ("gen" parameters), Canuto B with K_C2ADVECTION, CHARNOK, CRAIG_BANNER
@@ -292,6 +300,8 @@ def test_main3d_steps_bitwise(tag, args):
     ("upwelling_mask_small", ["hadv=C4,A4", "vadv=C4,A4"]),
     ("upwelling_mask_small", ["hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
     ("benchmark_mask_small", []),
+    ("upwelling_wetdry_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("upwelling_wetdry_obc_small", ["hadv=A4,C4", "vadv=SPLINES,C4"]),
 ])
 def test_core_kernels_bitwise(tag, args):
     """step2d_tile (step2d_LF_AM3.h:163; first predictor, correctors, last predictor), omega_tile (omega.F:96),
@@ -302,7 +312,8 @@ def test_core_kernels_bitwise(tag, args):
 
 
 OBC_CASES = [(t, p, a) for t in ("kelvin_plain_small", "upwelling_obc_small", "upwelling_mask_obc_small") for p in "ABCDEFG" for a in ([],)] + \
-            [("kelvin_plain_small", p, ["NtileI=2", "NtileJ=2"]) for p in "FG"]
+            [("kelvin_plain_small", p, ["NtileI=2", "NtileJ=2"]) for p in "FG"] + \
+            [("upwelling_wetdry_obc_small", p, a) for p in "ABEFG" for a in ([],)] + [("upwelling_wetdry_obc_small", "F", ["NtileI=2", "NtileJ=2"])]
 
 
 @pytest.mark.parametrize("tag,preset,args", OBC_CASES, ids=[f"{t}:{p}" + ("+tiles" if a else "") for t, p, a in OBC_CASES])

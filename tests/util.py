@@ -14,6 +14,9 @@ INIT_FIELDS = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om
                "u", "v", "t", "rho", "pden", "rhoA", "rhoS", "Zt_avg1", "Akv", "Akt",
                "dmde", "dndx", "lonr", "latr", "rdrag2", "bvf", "alpha", "beta", "hsbl",
                "rmask", "umask", "vmask", "pmask", "tke", "gls", "Lscale", "Akk", "Akp"]
+# WET_DRY cases only (wetdry.F): the time-dependent masks
+WET_FIELDS = ["rmask_wet", "umask_wet", "vmask_wet", "pmask_wet", "rmask_full", "umask_full", "vmask_full", "pmask_full",
+              "rmask_wet_avg"]
 STATE_FIELDS = INIT_FIELDS + ["rzeta", "rubar", "rvbar", "W", "wvel", "ru", "rv", "rufrc", "rvfrc", "DU_avg1",
                               "DU_avg2", "DV_avg1", "DV_avg2", "sustr", "svstr", "bustr", "bvstr", "stflx", "btflx",
                               "stflux", "btflux", "srflx", "ghats", "Uwind", "Vwind", "Tair", "Pair", "Hair", "rain",
