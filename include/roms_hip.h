@@ -243,6 +243,20 @@ int roms_hip_set_diags(roms_hip_ctx *ctx);
    (the SQUARE ROOTS of VISC4, TNU4: inp_par.F:634, read_phypar.F:7840) and leave "visc2_r", "visc2_p", "diff2" zero.  UV_VIS4
    needs Nghost = 3 (inp_par.F:214). */
 int roms_hip_mix4_config(roms_hip_ctx *ctx, int uv_vis4, int ts_dif4);
+/* Wetting and drying (WET_DRY: ROMS/Nonlinear/wetdry.F:93-900 and the WET_DRY branches of step2d_LF_AM3.h:863,992,1617,
+   2205-2222,2518-2667, prsgrd32.h:362,426, rhs3d.F:1709-1910, t3dmix2_s.h:239,279, uv3dmix2_s.h:276, step3d_uv.F:720-721,
+   1187-1188,1359,1579 and its boundary rows, set_vbc.F:307-308,397 with LIMIT_BSTRESS :611-699 (globaldefs.h:160),
+   ini_fields.F:294-403,850, zetabc.F:783-874, u2dbc_im.F:1190-1318, v2dbc_im.F:1239-1367, u3dbc_im.F:523,681): between
+   roms_hip_create and roms_hip_start; Dcrit = DCRIT of roms.in (read_phypar.F:1021), the total depth below which a cell is
+   dry.  Needs ROMS_MASKING (globaldefs.h:152 defines it with WET_DRY).  The masks are the fields "rmask_wet", "umask_wet",
+   "vmask_wet", "pmask_wet" (of the fast steps while they run, time-averaged for the 3-D step behind them), "rmask_full",
+   "umask_full", "vmask_full", "pmask_full" (wet x land: what the output files mask with) and "rmask_wet_avg".
+   roms_hip_wetdry_ini: the initial masks from zeta(kstp) (initial.F:467; wetdry.F:355-490), before the first step.
+   exit_flag 5 where the reference's WET_DRY statements are not built on the device: open boundaries, MPDATA, BULK_FLUXES,
+   SOLAR_SOURCE, the closures (LMD / GLS / MY25), geopotential / isopycnic / biharmonic mixing, prsgrd31 / prsgrd40,
+   no SPLINES_VVISC, averages, diagnostics. */
+int roms_hip_wetdry_config(roms_hip_ctx *ctx, double Dcrit);
+int roms_hip_wetdry_ini(roms_hip_ctx *ctx);
 /* DIAGNOSTICS_UV (mod_diags.F:174-222; the DiaU2rhs / DiaRU / DiaU3wrk statements of step2d_LF_AM3.h, rhs3d.F, prsgrd32.h,
    uv3dmix2_s.h, pre_step3d.F, step3d_uv.F): per-term momentum tendencies.  After roms_hip_dia_config (whose window it shares):
    allocates DIAGS(ng)%DiaU2wrk, DiaV2wrk, DiaRUbar, DiaRVbar, DiaU2int, DiaV2int, DiaRUfrc, DiaRVfrc, DiaU3wrk, DiaV3wrk,

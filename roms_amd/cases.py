@@ -303,6 +303,10 @@ def land_mask(cs, LBi, UBi, LBj, UBj):
     u, v, p = np.ones_like(r), np.ones_like(r), np.ones_like(r)
     u[:, 1:] = r[:, :-1] * r[:, 1:]
     v[1:, :] = r[:-1, :] * r[1:, :]
+    if cs.get("EWperiodic"):            # (the first line of the array: its lower neighbour is the periodic image)
+        u[:, 0] = r[:, Lm - 1] * r[:, 0]
+    if cs.get("NSperiodic"):
+        v[0, :] = r[Mm - 1, :] * r[0, :]
     a, b, c, d = r[1:, :-1], r[1:, 1:], r[:-1, :-1], r[:-1, 1:]      # (i-1,j) (i,j) (i-1,j-1) (i,j-1)
     nland = 4 - (a + b + c + d)
     side = ((a + b == 0) | (c + d == 0) | (a + c == 0) | (b + d == 0)) & (nland == 2)

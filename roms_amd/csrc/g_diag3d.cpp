@@ -209,7 +209,7 @@ int run_ini_zeta(roms_hip_ctx *c) {
     else LAUNCH_THREAD(k_ini_mask, B.IendB - KMIN(B.IstrM, B.IstrB) + 1, B.JendB - B.JstrB + 1, 1, c->stream, m);
   }
   if (c->G.obc && !keep) { int r = run_obc2d(c, kstp, 1); if (r) return r; }
-  launch_halo(c, lev2d(c, c->F.zeta, kstp), 1, (c->G.obc || keep) ? BC_NONE : bc_rstate(c), 'r');   // zetabc_tile + exchange
+  launch_halo(c, lev2d(c, c->F.zeta, kstp), 1, (c->G.obc || keep) ? BC_NONE : (bc_rstate(c) | (c->G.wet_dry ? BC_WET2 : 0)), 'r');   // zetabc_tile + exchange
   KArgs a = mk(c, kstp);
   LAUNCH_THREAD(k_copy_zt, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
   launch_halo(c, c->F.Zt_avg1, 1, BC_NONE, 'r');
@@ -225,8 +225,8 @@ int run_ini_fields(roms_hip_ctx *c) {
   }
   if (c->G.obc) { int r = run_obc3d_uv(c, nstp); if (r) return r; }
   const HaloSpec hs8[] = {
-      {uv_lev(c, c->F.u, nstp), N, obc_bc(c, BC_U), 'u'},     // u3dbc_tile + exchange_u3d
-      {uv_lev(c, c->F.v, nstp), N, obc_bc(c, BC_V), 'v'},
+      {uv_lev(c, c->F.u, nstp), N, obc_bc(c, BC_U) | (c->G.wet_dry ? BC_WET3 : 0), 'u'},     // u3dbc_tile + exchange_u3d
+      {uv_lev(c, c->F.v, nstp), N, obc_bc(c, BC_V) | (c->G.wet_dry ? BC_WET3 : 0), 'v'},
   };
   launch_halo_multi(c, hs8, 2);
   KArgs a = mk(c);
@@ -242,8 +242,8 @@ int run_ini_fields(roms_hip_ctx *c) {
       }
     if (c->G.obc && !keep) { int r = run_obc2d(c, kstp, 6); if (r) return r; }
     const HaloSpec hs9[] = {
-        {lev2d(c, c->F.ubar, kstp), 1, (c->G.obc || keep) ? BC_NONE : BC_U, 'u'},   // u2dbc_tile + exchange
-        {lev2d(c, c->F.vbar, kstp), 1, (c->G.obc || keep) ? BC_NONE : BC_V, 'v'},
+        {lev2d(c, c->F.ubar, kstp), 1, (c->G.obc || keep) ? BC_NONE : (BC_U | (c->G.wet_dry ? BC_WET2 : 0)), 'u'},   // u2dbc_tile + exchange
+        {lev2d(c, c->F.vbar, kstp), 1, (c->G.obc || keep) ? BC_NONE : (BC_V | (c->G.wet_dry ? BC_WET2 : 0)), 'v'},
     };
     launch_halo_multi(c, hs9, 2);
   }

@@ -163,6 +163,7 @@ int run_prsgrd(roms_hip_ctx *c) {
   a.p1 = c->late_pre ? 1 : 0;
   LAUNCH_THREAD(k_prs_P, B.Iend - (B.IstrU - 1) + 1, B.Jend - (B.JstrV - 1) + 1, 1, c->stream, a);
   LAUNCH_THREAD(k_prs_grad, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a);
+  if (G.wet_dry) { int r = run_wd_scale3(c); if (r) return r; }     // WET_DRY: ru, rv times the wet masks (prsgrd32.h:362,426)
   return run_duv_pgrd(c);                          // DIAGNOSTICS_UV: DiaRU(M3pgrd) = ru as prsgrd leaves it
 }
 
@@ -266,6 +267,7 @@ int run_rhs3d_tile(roms_hip_ctx *c) {
   const TB &B = G.T;
   int r = launch_rhs3d_point_part(c);
   if (r) return r;
+  if (G.wet_dry) { r = run_wd_scale3(c); if (r) return r; }         // WET_DRY: ru, rv(k) times the wet masks, then their sums (rhs3d.F:1709,1750)
   KArgs a = mk(c);
   a.p1 = 0;
   LAUNCH_THREAD(k_rhs3d_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
@@ -319,6 +321,7 @@ int run_uv3dmix2_col(roms_hip_ctx *c) {
 int run_rufrc_sums(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
+  if (G.wet_dry) { int r = run_wd_scale3(c); if (r) return r; }
   KArgs a = mk(c);
   a.p1 = (G.options & ROMS_UV_VIS2) ? 1 : 0;
   LAUNCH_THREAD(k_rhs3d_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);

@@ -50,6 +50,10 @@ int run_step2d(roms_hip_ctx *c) {
   int variant = (G.bw2 <= 32 && G.bh2 <= 4) ? 0 : (G.bw2 <= 32 && G.bh2 <= 8) ? 3 : (G.bw2 <= 64 && G.bh2 <= 8) ? 1 : 2;
   if (getenv("ROMS_HIP_S2D_GENERIC") || (G.masking && variant != 0)) variant = 2;   // (masks: k_step2d_am or the generic form)
   if (a.commit && (variant != 0 || G.masking)) variant = 2;       // behind a pair launch: k_step2d_ac or the generic form commit the staged level
+  if (G.wet_dry) {                                                // WET_DRY: the masks of this call first (step2d_LF_AM3.h:863; behind the last fast
+    variant = 2;                                                  // step: after the averages, below); the generic form carries the branches (k_step2d_wd)
+    if (iif <= G.nfast) { int r = run_wetdry(c, 0); if (r) return r; }
+  }
   if (G.dia_uv || G.uv_vis4) variant = 2;                         // (UV_VIS4: the generic form carries the biharmonic block, k_step2d_vis4)                                      // DIAGNOSTICS_UV: the generic form carries the term stores (k_step2d_duv)
   // 64x8 sub-tiles: 1024 threads (one rectangle point and one momentum point per thread) measure 3 %
   // faster than 512 threads with two each; ROMS_HIP_S2D_1024=0 selects the latter
@@ -131,6 +135,18 @@ int run_step2d(roms_hip_ctx *c) {
       }
 #endif
       LAUNCH_COOP_AS(k_step2d, k_step2d_duv, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
+    } else if (G.wet_dry) {
+#ifndef ROMS_CPU_EMU
+      static bool big_lds_w = false;
+      if (lds * sizeof(double) > 64 * 1024 && !big_lds_w) {
+        if (hipFuncSetAttribute((const void *)k_step2d_wd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+          set_error("k_step2d: cannot raise the dynamic LDS limit");
+          return 2;
+        }
+        big_lds_w = true;
+      }
+#endif
+      LAUNCH_COOP_AS(k_step2d, k_step2d_wd, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
     } else
     LAUNCH_COOP(k_step2d, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
   }
@@ -139,15 +155,17 @@ int run_step2d(roms_hip_ctx *c) {
     // final fast-time averages :821-883
     HaloSpec sp[3] = {{c->F.Zt_avg1, 1, BC_NONE, 'r'}, {c->F.DU_avg1, 1, BC_NONE, 'u'}, {c->F.DV_avg1, 1, BC_NONE, 'v'}};
     launch_halo_multi(c, sp, 3);
+    if (G.wet_dry) { int r = run_wetdry(c, 1); if (r) return r; }     // the time-averaged masks of the 3-D step (wetdry.F:250-349)
   }
   if (iif > G.nfast) return 0;
   if (G.obc) { int r = run_obc2d(c, G.knew); if (r) return r; }                  // zetabc, u2dbc, v2dbc with open edges (k_obc.h)
   HaloSpec sp[8];
   int n = 0;
-  sp[n++] = {lev2d(c, c->F.zeta, G.knew), 1, obc_bc(c, bc_rstate(c)), 'r'};             // zetabc :1057 + exchange :1068
+  const int wet = G.wet_dry ? BC_WET2 : 0;                                             // (+ the wetting/drying conditions at the end of zetabc / u2dbc / v2dbc)
+  sp[n++] = {lev2d(c, c->F.zeta, G.knew), 1, obc_bc(c, bc_rstate(c)) | wet, 'r'};       // zetabc :1057 + exchange :1068
   if (G.predictor) sp[n++] = {lev2d(c, c->F.rzeta, G.krhs), 1, BC_NONE, 'r'};   // :1030
-  sp[n++] = {lev2d(c, c->F.ubar, G.knew), 1, obc_bc(c, BC_U), 'u'};             // u2dbc :2871 + exchange :3043
-  sp[n++] = {lev2d(c, c->F.vbar, G.knew), 1, obc_bc(c, BC_V), 'v'};             // v2dbc :2876
+  sp[n++] = {lev2d(c, c->F.ubar, G.knew), 1, obc_bc(c, BC_U) | wet, 'u'};       // u2dbc :2871 + exchange :3043
+  sp[n++] = {lev2d(c, c->F.vbar, G.knew), 1, obc_bc(c, BC_V) | wet, 'v'};       // v2dbc :2876
   if (c->pair_on && c->pair_mt && !G.predictor && iif == 1 && G.nfast >= 2) {
     // the pairs follow (k_step2d_pair.h): this exchange carries the wide strips, and with them what the first pair reads
     // on its rim besides the level just written -- its kstp level (this call's kstp) and the fast-time-constant forcing
@@ -175,6 +193,7 @@ bool step2d_pair_usable(const roms_hip_ctx *c) {
   if (G.obc) return false;                                               // open boundaries: zetabc/u2dbc/v2dbc between the two calls (k_obc.h)
   if (G.dia_uv) return false;                                            // DIAGNOSTICS_UV: the per-call kernel carries the term stores
   if (G.uv_vis4) return false;                                           // UV_VIS4: the per-call generic kernel carries the biharmonic block
+  if (G.wet_dry) return false;                                           // WET_DRY: new masks in front of every call
   const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
   if (LmT < 8 || MmT < 8) return false;                                  // the rim (5 | 4 lines) comes from the neighbour's / the tile's own points
   if (pair_lds_doubles(G.bw2, G.bh2) * sizeof(double) > 160 * 1024) return false;

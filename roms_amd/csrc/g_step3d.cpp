@@ -25,6 +25,13 @@ int run_step3d_uv(roms_hip_ctx *c) {
   const TB &B = G.T;
   const int N = G.N, nnew = G.nnew;
   KArgs a = mk(c);
+  if (G.wet_dry) {
+    // WET_DRY: the new velocity times the land mask, then times the wet mask (step3d_uv.F:717-720 ...): the kernels get the
+    // product of the two as their mask (k_wd_eff: the same bits)
+    int r = run_wd_eff(c);
+    if (r) return r;
+    a.Fv.umask = (double *)c->F.wd_eff; a.Fv.vmask = (double *)c->F.wd_eff + G.nij;
+  }
   static const char *ech = getenv("ROMS_HIP_COLCH"), *ereg = getenv("ROMS_HIP_UVREG");
   if (G.dia_uv) { int r = run_duv_s3uv(c); if (r) return r; }          // DIAGNOSTICS_UV: the column kernel with the diagnostic statements (k_duv.h)
   else if (G.options & ROMS_PLAIN_VVISC) LAUNCH_THREAD(k_s3uv_col_p, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);   // without SPLINES_VVISC
@@ -33,10 +40,12 @@ int run_step3d_uv(roms_hip_ctx *c) {
   else if (col_lds(G) && (ech ? ech[0] == '1' : N > 40)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l10, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
   else if (col_lds(G)) LAUNCH_COL_AS(k_s3uv_col, k_s3uv_col_l, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, 2 * (N + 1), c->stream, a);
   else LAUNCH_THREAD(k_s3uv_col, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+  if (G.wet_dry) { int r = run_wd_scale3(c); if (r) return r; }        // ... and ru, rv(nrhs) times the wet mask (:721, :1188)
   if (!G.fuse3d) {   // (fused: the kernels store the boundary values and periodic images themselves, pt_emit)
     if (G.obc) { int r = run_obc3d_uv(c, nnew); if (r) return r; }
     else {
-      HaloSpec sp[2] = {{uv_lev(c, c->F.u, nnew), N, BC_U, 0}, {uv_lev(c, c->F.v, nnew), N, BC_V, 0}};   // u3dbc/v3dbc :1266,1271
+      const int wet = G.wet_dry ? BC_WET3 : 0;
+      HaloSpec sp[2] = {{uv_lev(c, c->F.u, nnew), N, BC_U | wet, 0}, {uv_lev(c, c->F.v, nnew), N, BC_V | wet, 0}};   // u3dbc/v3dbc :1266,1271
       launch_halo_multi(c, sp, 2);
     }
   }

@@ -158,9 +158,14 @@ THREAD_KERNEL(k_set_vbc, KArgs) {
   const int i = B.IstrR + gx, j = B.JstrR + gy, N = G.N, nrhs = G.nrhs;
   F.stflx[X2T(i, j, 1)] = F.stflux[X2T(i, j, 1)];
   F.btflx[X2T(i, j, 1)] = F.btflux[X2T(i, j, 1)];
+  if (G.wet_dry) {                                                                         // WET_DRY set_vbc.F:307-308
+    F.stflx[X2T(i, j, 1)] = F.stflx[X2T(i, j, 1)] * F.rmask_wet[X2(i, j)];
+    F.btflx[X2T(i, j, 1)] = F.btflx[X2T(i, j, 1)] * F.rmask_wet[X2(i, j)];
+  }
   const double EmP = F.stflux[X2T(i, j, 2)];
   F.stflx[X2T(i, j, 2)] = EmP * F.t[XT(i, j, N, nrhs, 2)];
-  if (G.masking) F.stflx[X2T(i, j, 2)] = F.rmask[X2(i, j)] * F.stflx[X2T(i, j, 2)];      // set_vbc.F:399
+  if (G.wet_dry) F.stflx[X2T(i, j, 2)] = F.rmask_wet[X2(i, j)] * F.stflx[X2T(i, j, 2)];   // :397
+  else if (G.masking) F.stflx[X2T(i, j, 2)] = F.rmask[X2(i, j)] * F.stflx[X2T(i, j, 2)];      // set_vbc.F:399
   F.btflx[X2T(i, j, 2)] = F.btflx[X2T(i, j, 2)] * F.t[XT(i, j, 1, nrhs, 2)];
   const bool qdrag = (G.options & ROMS_UV_QDRAG) != 0, logdrag = (G.options & ROMS_UV_LOGDRAG) != 0;
   // UV_LOGDRAG :591-601: drag coefficient of a rho point from the height of its lowest level above the bed
@@ -169,21 +174,26 @@ THREAD_KERNEL(k_set_vbc, KArgs) {
     const double c1_ = 1.0 / log((F.z_r[X3(ii, jj, 1)] - F.z_w[XW(ii, jj, 0)]) / G.Zob);             \
     const double c2_ = 0.41 * 0.41 * c1_ * c1_;                                                      \
     fmin(0.5, fmax(0.000001, c2_)); })
+  // LIMIT_BSTRESS (globaldefs.h:160 defines it with WET_DRY), set_vbc.F:580-590 and :611-616, :649-654, :682-687: the stress may
+  // slow the bottom layer down within 0.75 of a step, not reverse it
+#define WD_LIMIT(val, vel, hz0, hz1) ({                                                              \
+    const double v_ = (val);                                                                         \
+    G.wet_dry ? copysign(1.0, v_) * fmin(fabs(v_), fabs(vel) * ((0.75 / G.dt) * 0.5 * ((hz0) + (hz1)))) : v_; })
   if (i >= B.IstrU && i <= B.Iend && j >= B.Jstr && j <= B.Jend) {
     if (logdrag) {
       const double cff1 = 0.25 * (F.v[X4(i, j, 1, nrhs)] + F.v[X4(i, j + 1, 1, nrhs)] + F.v[X4(i - 1, j, 1, nrhs)] +
                                   F.v[X4(i - 1, j + 1, 1, nrhs)]);
       const double uu = F.u[X4(i, j, 1, nrhs)];
       const double cff2 = sqrt(uu * uu + cff1 * cff1);
-      emit_store(G, emit_plan(G, BC_U, i, j), F.bustr, 0.5 * (CDB_LOG(i - 1, j) + CDB_LOG(i, j)) * uu * cff2);
+      emit_store(G, emit_plan(G, BC_U, i, j), F.bustr, WD_LIMIT(0.5 * (CDB_LOG(i - 1, j) + CDB_LOG(i, j)) * uu * cff2, F.u[X4(i, j, 1, nrhs)], F.Hz[X3(i - 1, j, 1)], F.Hz[X3(i, j, 1)]));
     } else if (qdrag) {
       const double cff1 = 0.25 * (F.v[X4(i, j, 1, nrhs)] + F.v[X4(i, j + 1, 1, nrhs)] + F.v[X4(i - 1, j, 1, nrhs)] +
                                   F.v[X4(i - 1, j + 1, 1, nrhs)]);
       const double uu = F.u[X4(i, j, 1, nrhs)];
       const double cff2 = sqrt(uu * uu + cff1 * cff1);
-      emit_store(G, emit_plan(G, BC_U, i, j), F.bustr, 0.5 * (F.rdrag2[X2(i - 1, j)] + F.rdrag2[X2(i, j)]) * uu * cff2);
+      emit_store(G, emit_plan(G, BC_U, i, j), F.bustr, WD_LIMIT(0.5 * (F.rdrag2[X2(i - 1, j)] + F.rdrag2[X2(i, j)]) * uu * cff2, F.u[X4(i, j, 1, nrhs)], F.Hz[X3(i - 1, j, 1)], F.Hz[X3(i, j, 1)]));
     } else {
-      emit_store(G, emit_plan(G, BC_U, i, j), F.bustr, 0.5 * (F.rdrag[X2(i - 1, j)] + F.rdrag[X2(i, j)]) * F.u[X4(i, j, 1, nrhs)]);
+      emit_store(G, emit_plan(G, BC_U, i, j), F.bustr, WD_LIMIT(0.5 * (F.rdrag[X2(i - 1, j)] + F.rdrag[X2(i, j)]) * F.u[X4(i, j, 1, nrhs)], F.u[X4(i, j, 1, nrhs)], F.Hz[X3(i - 1, j, 1)], F.Hz[X3(i, j, 1)]));
     }
   }
   if (i >= B.Istr && i <= B.Iend && j >= B.JstrV && j <= B.Jend) {
@@ -192,18 +202,19 @@ THREAD_KERNEL(k_set_vbc, KArgs) {
                                   F.u[X4(i + 1, j - 1, 1, nrhs)]);
       const double vv = F.v[X4(i, j, 1, nrhs)];
       const double cff2 = sqrt(cff1 * cff1 + vv * vv);
-      emit_store(G, emit_plan(G, BC_V, i, j), F.bvstr, 0.5 * (CDB_LOG(i, j - 1) + CDB_LOG(i, j)) * vv * cff2);
+      emit_store(G, emit_plan(G, BC_V, i, j), F.bvstr, WD_LIMIT(0.5 * (CDB_LOG(i, j - 1) + CDB_LOG(i, j)) * vv * cff2, F.v[X4(i, j, 1, nrhs)], F.Hz[X3(i, j - 1, 1)], F.Hz[X3(i, j, 1)]));
     } else if (qdrag) {
       const double cff1 = 0.25 * (F.u[X4(i, j, 1, nrhs)] + F.u[X4(i + 1, j, 1, nrhs)] + F.u[X4(i, j - 1, 1, nrhs)] +
                                   F.u[X4(i + 1, j - 1, 1, nrhs)]);
       const double vv = F.v[X4(i, j, 1, nrhs)];
       const double cff2 = sqrt(cff1 * cff1 + vv * vv);
-      emit_store(G, emit_plan(G, BC_V, i, j), F.bvstr, 0.5 * (F.rdrag2[X2(i, j - 1)] + F.rdrag2[X2(i, j)]) * vv * cff2);
+      emit_store(G, emit_plan(G, BC_V, i, j), F.bvstr, WD_LIMIT(0.5 * (F.rdrag2[X2(i, j - 1)] + F.rdrag2[X2(i, j)]) * vv * cff2, F.v[X4(i, j, 1, nrhs)], F.Hz[X3(i, j - 1, 1)], F.Hz[X3(i, j, 1)]));
     } else {
-      emit_store(G, emit_plan(G, BC_V, i, j), F.bvstr, 0.5 * (F.rdrag[X2(i, j - 1)] + F.rdrag[X2(i, j)]) * F.v[X4(i, j, 1, nrhs)]);
+      emit_store(G, emit_plan(G, BC_V, i, j), F.bvstr, WD_LIMIT(0.5 * (F.rdrag[X2(i, j - 1)] + F.rdrag[X2(i, j)]) * F.v[X4(i, j, 1, nrhs)], F.v[X4(i, j, 1, nrhs)], F.Hz[X3(i, j - 1, 1)], F.Hz[X3(i, j, 1)]));
     }
   }
 #undef CDB_LOG
+#undef WD_LIMIT
 }
 THREAD_GLOBAL(k_set_vbc, KArgs)
 
@@ -547,6 +558,7 @@ THREAD_KERNEL(k_ini_bar, KArgs) {
     const double cff1 = 1.0 / DC0;
     double cff2 = CF0 * cff1;
     if (G.masking) cff2 = cff2 * F.umask[X2(i, j)];                     // ini_fields.F:376
+    if (G.wet_dry) cff2 = cff2 * F.umask_wet[X2(i, j)];                 // :379
     F.ubar[X2T(i, j, kstp)] = cff2;
   }
   if (j >= B.JstrM && i >= B.IstrB && i <= B.IendB) {
@@ -559,6 +571,7 @@ THREAD_KERNEL(k_ini_bar, KArgs) {
     const double cff1 = 1.0 / DC0;
     double cff2 = CF0 * cff1;
     if (G.masking) cff2 = cff2 * F.vmask[X2(i, j)];                     // ini_fields.F:400
+    if (G.wet_dry) cff2 = cff2 * F.vmask_wet[X2(i, j)];                 // :403
     F.vbar[X2T(i, j, kstp)] = cff2;
   }
 }
@@ -576,11 +589,23 @@ THREAD_KERNEL(k_ini_mask, KArgs) {
     const int it = B.IstrT + gx, jt = B.JstrT + gy;
     if (it <= B.IendT && jt <= B.JendT) F.zeta[X2T(it, jt, kstp)] = F.zeta[X2T(it, jt, kstp)] * F.rmask[X2(it, jt)];
   } else if (a.p0 == 0) {
-    if (i >= B.IstrB && i <= B.IendB) F.zeta[X2T(i, j, kstp)] = F.zeta[X2T(i, j, kstp)] * F.rmask[X2(i, j)];
+    if (i >= B.IstrB && i <= B.IendB) {
+      double cff1 = F.zeta[X2T(i, j, kstp)] * F.rmask[X2(i, j)];
+      if (G.wet_dry && cff1 <= (G.Dcrit - F.h[X2(i, j)])) cff1 = G.Dcrit - F.h[X2(i, j)];       // WET_DRY ini_fields.F:850-851
+      F.zeta[X2T(i, j, kstp)] = cff1;
+    }
   } else if (a.p0 == 1) {
     const int k = gz + 1;
-    if (i >= B.IstrM && i <= B.IendB) F.u[X4(i, j, k, nstp)] = F.u[X4(i, j, k, nstp)] * F.umask[X2(i, j)];
-    if (j >= B.JstrM && i >= B.IstrB && i <= B.IendB) F.v[X4(i, j, k, nstp)] = F.v[X4(i, j, k, nstp)] * F.vmask[X2(i, j)];
+    if (i >= B.IstrM && i <= B.IendB) {
+      double q = F.u[X4(i, j, k, nstp)] * F.umask[X2(i, j)];
+      if (G.wet_dry) q = q * F.umask_wet[X2(i, j)];                                             // :294
+      F.u[X4(i, j, k, nstp)] = q;
+    }
+    if (j >= B.JstrM && i >= B.IstrB && i <= B.IendB) {
+      double q = F.v[X4(i, j, k, nstp)] * F.vmask[X2(i, j)];
+      if (G.wet_dry) q = q * F.vmask_wet[X2(i, j)];                                             // :308
+      F.v[X4(i, j, k, nstp)] = q;
+    }
   } else {
     const int k = gz % G.N + 1, it = gz / G.N + 1;
     if (i >= B.IstrB && i <= B.IendB) F.t[XT(i, j, k, nstp, it)] = F.t[XT(i, j, k, nstp, it)] * F.rmask[X2(i, j)];

@@ -963,6 +963,8 @@ THREAD_KERNEL(k_t3dmix2_t, KArgs) {
   // MASKING (t3dmix2_s.h:236,276): face fluxes times umask / vmask of the face
   double mx0 = 1.0, mx1 = 1.0, me0 = 1.0, me1 = 1.0;
   if (G.masking) { mx0 = F.umask[x]; mx1 = F.umask[x + 1]; me0 = F.vmask[x]; me1 = F.vmask[x + ni]; }
+  double wx0 = 1.0, wx1 = 1.0, we0 = 1.0, we1 = 1.0;
+  if (G.wet_dry) { wx0 = F.umask_wet[x]; wx1 = F.umask_wet[x + 1]; we0 = F.vmask_wet[x]; we1 = F.vmask_wet[x + ni]; }
 #pragma unroll
   for (int q = 0; q < (MARCH ? tch : KCH); q++) {
     if (k0 + q > N) break;
@@ -971,7 +973,10 @@ THREAD_KERNEL(k_t3dmix2_t, KArgs) {
     const double h0 = H[0], t0 = T[0];
     double FX0 = ax0 * (h0 + H[-1]) * (t0 - T[-1]), FX1 = ax1 * (H[1] + h0) * (T[1] - t0);
     double FE0 = ae0 * (h0 + H[-ni]) * (t0 - T[-ni]), FE1 = ae1 * (H[ni] + h0) * (T[ni] - t0);
-    if (G.masking) { FX0 = FX0 * mx0; FX1 = FX1 * mx1; FE0 = FE0 * me0; FE1 = FE1 * me1; }
+    if (G.masking) {
+      FX0 = FX0 * mx0; FX1 = FX1 * mx1; FE0 = FE0 * me0; FE1 = FE1 * me1;
+      if (G.wet_dry) { FX0 = FX0 * wx0; FX1 = FX1 * wx1; FE0 = FE0 * we0; FE1 = FE1 * we1; }   // WET_DRY t3dmix2_s.h:239,279
+    }
     const double cff1 = cff * (FX1 - FX0);
     const double cff2 = cff * (FE1 - FE0);
     const double cff3 = cff1 + cff2;
@@ -1056,11 +1061,13 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
     const double cR = CFFR(r0_, 0);
     double cP = CFFP(p0_, 0);
     if (G.masking) cP = cP * F.pmask[x];                                   // uv3dmix2_s.h:273
+    if (G.masking && G.wet_dry) cP = cP * F.pmask_wet[x];                  // :276
     double un = 0.0, vn = 0.0, u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0;
     if (do_u) {
       const double cRw = CFFR(rw_, -1);
       double cPn = CFFP(pn_, ni);
       if (G.masking) cPn = cPn * F.pmask[x + ni];
+      if (G.masking && G.wet_dry) cPn = cPn * F.pmask_wet[x + ni];
       const double UFx1 = fur1 * cR;
       const double UFx0 = fur0 * cRw;
       const double UFe1 = fup1 * cPn;
@@ -1077,6 +1084,7 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
       const double cRs = CFFR(rs_, -ni);
       double cPe = CFFP(pe_, 1);
       if (G.masking) cPe = cPe * F.pmask[x + 1];
+      if (G.masking && G.wet_dry) cPe = cPe * F.pmask_wet[x + 1];
       const double VFx1 = fvp1 * cPe;
       const double VFx0 = fvp0 * cP;
       const double VFe1 = fvr1 * cR;
@@ -1467,6 +1475,7 @@ THREAD_KERNEL(k_rhs3d_sum, KArgs) {
     const double c1 = F.sustr[X2(i, j)] * cff;
     const double c2 = -F.bustr[X2(i, j)] * cff;
     double ruf = sum + c1 + c2;
+    if (G.wet_dry) ruf = ruf * F.umask_wet[X2(i, j)];                     // WET_DRY rhs3d.F:1804 (ru(k) times the mask: k_wd_scale3 ahead)
     if (a.p1) {   // + the viscous terms of uv3dmix2 (k_uv3dmix2_sum), in the same order
       const double *A1 = F.wrk3[6], *A2 = F.wrk3[7];
       for (int k0 = 1; k0 <= N; k0 += 8) {
@@ -1486,6 +1495,7 @@ THREAD_KERNEL(k_rhs3d_sum, KArgs) {
     const double c1 = F.svstr[X2(i, j)] * cff;
     const double c2 = -F.bvstr[X2(i, j)] * cff;
     double rvf = sum + c1 + c2;
+    if (G.wet_dry) rvf = rvf * F.vmask_wet[X2(i, j)];                     // :1910
     if (a.p1) {
       const double *A3 = F.wrk3[8], *A4 = F.wrk3[9];
       for (int k0 = 1; k0 <= N; k0 += 8) {

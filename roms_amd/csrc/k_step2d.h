@@ -132,7 +132,7 @@ THREAD_GLOBAL(k_pack_m2d, PackArgs)
 // operator LapU, LapV of ubar, vbar(krhs) on the sub-tile + 1 with its closed / gradient conditions and corner values; the
 // momentum stage then forms the same stress tensor of (LapU, LapV) times the total depth.  The packed metric records carry
 // visc4 in the place of visc2 (g_step2d.cpp:pack_metrics).
-template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0), bool CM = (BWC == 0), int PWR = PTS, bool DUV = false, bool VIS4 = false>
+template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0), bool CM = (BWC == 0), int PWR = PTS, bool DUV = false, bool VIS4 = false, bool WD = false>
 COOP_KERNEL(k_step2d_t, Step2dArgs) {
   (void)bz;
 #ifndef ROMS_CPU_EMU
@@ -376,7 +376,8 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
             hb_emit(G, B, zn, BC_R, i, j, zeta_new, MSK ? G.rmask : nullptr);
             if (PRED) hb_emit(G, B, rz_k, BC_NONE, i, j, rhs_zeta);
           } else {
-            zn[x0] = zeta_new;
+            // WET_DRY: "depth > Dcrit for masked cells" :992-995 (the shared level only; Dnew keeps zeta_new)
+            zn[x0] = (WD && MSK) ? zeta_new + (G.Dcrit - sH[s0]) * (1.0 - G.rmask[x0]) : zeta_new;
             if (PRED) rz_k[x0] = rhs_zeta;
           }
         }
@@ -657,6 +658,7 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
         double sp0 = STRESS_P(0, 0, WV(w_v2p0, isv, mp[x].v[MP_V2]), WV(w_pmp0, isv, mp[x].v[MP_PMON]), WV(w_pnp0, isv, mp[x].v[MP_PNOM]));
         double sp1 = STRESS_P(qa, qb, WV(w_v2p1, isv, mp[q1].v[MP_V2]), WV(w_pmp1, isv, mp[q1].v[MP_PMON]), WV(w_pnp1, isv, mp[q1].v[MP_PNOM]));
         if (MSK) { sp0 = sp0 * G.pmask[x]; sp1 = sp1 * G.pmask[q1]; }   // :1613
+        if (WD) { sp0 = sp0 * G.pmask_wet[x]; sp1 = sp1 * G.pmask_wet[q1]; }   // :1617
         // on_r (u) | om_r (v) at P0, P1; om_p (u) | on_p (v) at Q0, Q1
         const double or0 = WV(w_or0, isv, isv ? mr[x].v[MR_OM] : mr[x].v[MR_ON]);
         const double or1 = WV(w_or1, isv, isv ? mr[x1].v[MR_OM] : mr[x1].v[MR_ON]);
@@ -692,8 +694,11 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
       double *r3 = isv ? F.rv : F.ru;
       const double *rb = isv ? F.rvbar : F.rubar;
       double r = rhs;
+      const double mwet = WD ? (isv ? G.vmask_wet : G.umask_wet)[x] : 1.0;
+      if (WD) r = r * wd_fac(mwet, r);                                    // :2205-2222
+      double fr = 0.0;
       if (first) {
-        const double fr = WV(w_frc, isv, frc[x]) - r;
+        fr = WV(w_frc, isv, frc[x]) - r;
         frc[x] = fr;
         if (startup == 0) r = r + fr;
         else if (startup == 1) r = r + 1.5 * fr - 0.5 * WV(w_r0n, isv, r3[o_r0n + (size_t)x]);
@@ -761,6 +766,12 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
       else b = (sv * (Dstp0 + Dstp1) +
                 cff * (k1 * r + k2 * WV(w_rs, isv, rb[x + o_kstp]) - k3 * WV(w_rp, isv, rb[x + o_ptsk]))) * fac;
       if (MSK) b = b * (isv ? G.vmask : G.umask)[x];                      // :2515-2660
+      if (WD) {                                                           // :2518-2529 ... :2661-2667
+        const double cff7 = wd_fac(mwet, b);
+        b = b * cff7;
+        r = r * cff7;
+        if (first) { const double f2 = fr * cff7; frc[x] = f2; r3[o_r0s + (size_t)x] = f2; }
+      }
       // u2dbc/v2dbc :2871-2876 + exchange :3043
       if (!isv) {
         if (fuse) hb_emit(G, B, un, BC_U, i, j, b, MSK ? G.umask : nullptr);
@@ -812,5 +823,7 @@ COOP_KERNEL(k_step2d, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0>(a, bx, by, bz, l
 COOP_GLOBAL_LB(k_step2d, Step2dArgs, 512)
 COOP_KERNEL(k_step2d_vis4, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0, true, true, 0, false, true>(a, bx, by, bz, lds); }   // ... with the biharmonic viscosity (UV_VIS4)
 COOP_GLOBAL_LB(k_step2d_vis4, Step2dArgs, 512)
+COOP_KERNEL(k_step2d_wd, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0, true, true, 0, false, false, true>(a, bx, by, bz, lds); }   // ... with wetting and drying (WET_DRY)
+COOP_GLOBAL_LB(k_step2d_wd, Step2dArgs, 512)
 COOP_KERNEL(k_step2d_duv, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0, true, true, 0, true>(a, bx, by, bz, lds); }   // ... with the momentum diagnostics (DIAGNOSTICS_UV)
 COOP_GLOBAL_LB(k_step2d_duv, Step2dArgs, 512)

@@ -520,7 +520,8 @@ THREAD_KERNEL(k_s3uv_couple, KArgs) {
   DC0 = 1.0 / DC0;
   CF0 = DC0 * (CF0 - Davg1);
   double *bar = dir == 0 ? F.ubar : F.vbar;
-  const double b1 = DC0 * Davg1;
+  double b1 = DC0 * Davg1;
+  if (G.wet_dry) b1 = b1 * (dir == 0 ? G.umask_wet : G.vmask_wet)[X2(i, j)];      // WET_DRY step3d_uv.F:1359, :1579
   const EmitPlan P = emit_plan(G, BC_NONE, i, j);
   emit_store(G, P, bar, b1);
   emit_store(G, P, bar + G.nij, b1);
@@ -643,7 +644,8 @@ COL_KERNEL(k_s3uv_couple_l, KArgs) {
   DC0 = 1.0 / DC0;
   CF0 = DC0 * (CF0 - Davg1);
   double *bar = dir == 0 ? F.ubar : F.vbar;
-  const double b1 = DC0 * Davg1;
+  double b1 = DC0 * Davg1;
+  if (G.wet_dry) b1 = b1 * (dir == 0 ? G.umask_wet : G.vmask_wet)[X2(i, j)];      // WET_DRY step3d_uv.F:1359, :1579
   const EmitPlan P = emit_plan(G, BC_NONE, i, j);
   emit_store(G, P, bar, b1);
   emit_store(G, P, bar + G.nij, b1);

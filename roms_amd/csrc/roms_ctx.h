@@ -71,6 +71,11 @@ struct DGrid {
   // are Fields::rmask ... (upload names "rmask", "umask", "vmask", "pmask"), here for the kernels that get no Fields
   int masking;
   const double *rmask, *umask, *vmask, *pmask;
+  // WET_DRY (wetdry.F; roms_hip_wetdry_config): time-dependent wet/dry masks rmask_wet ... (Fields::rmask_wet ...; here for
+  // the kernels that get no Fields), Dcrit = DCRIT of roms.in, hbath = h
+  int wet_dry;
+  double Dcrit;
+  const double *rmask_wet, *umask_wet, *vmask_wet, *pmask_wet, *hbath;
   int Vtransform;
   // open boundaries: 1 if any edge of any variable is neither closed nor periodic (k_obc.h does the state's boundary
   // conditions then, and nothing is fused into the producers); bit (4*variable + edge) of lbc_closed set where
@@ -84,6 +89,14 @@ struct DGrid {
 #else
 #define KHD __host__ __device__ __forceinline__
 #endif
+
+// WET_DRY: the factor the barotropic step applies at a velocity point (step2d_LF_AM3.h:2208-2210, 2519-2521 ...): the reference's
+// cff7 = 0.5*mask*cff5 + cff6*(1-cff5), cff5 = ABS(ABS(mask)-1), cff6 = 0.5 + DSIGN(0.5, value)*mask
+KHD double wd_fac(double mw, double val) {
+  const double cff5 = fabs(fabs(mw) - 1.0);
+  const double cff6 = 0.5 + copysign(0.5, val) * mw;
+  return 0.5 * mw * cff5 + cff6 * (1.0 - cff5);
+}
 
 // var_bounds for the rectangle [i0,i1]x[j0,j1]; w/e/s/n: the rectangle touches that edge of the
 // global domain.
@@ -181,7 +194,11 @@ enum { BC_NONE = 0, BC_R = 1, BC_U = 2, BC_V = 3 };
 // IstrR:IendR x JstrR:JendR is multiplied by rmask (step3d_t.F:1880-1890).  The slip values of BC_U / BC_V are
 // always multiplied by umask / vmask of the boundary point in a masked run (u2dbc_im.F:989, bc_2d.F:252 ...).
 enum { BC_MASKF = 16, BC_MASKALL = 32, BC_KIND = 15,
-       BC_LBC2D = 64 };   // bc_u2d / bc_v2d of a context with open edges: closed where LBC(:,isUbar / isVbar) is, else zero gradient
+       BC_LBC2D = 64,    // bc_u2d / bc_v2d of a context with open edges: closed where LBC(:,isUbar / isVbar) is, else zero gradient
+       // WET_DRY: BC_WET2 = the "wetting and drying conditions" at the end of zetabc.F:783-874 (BC_R), u2dbc_im.F:1190-1318
+       // (BC_U), v2dbc_im.F:1239-1367 (BC_V); BC_WET3 = the slip value of u3dbc / v3dbc times the wet mask of the boundary
+       // point (u3dbc_im.F:523,681, v3dbc_im.F:...)
+       BC_WET2 = 128, BC_WET3 = 256 };   // bc_u2d / bc_v2d of a context with open edges: closed where LBC(:,isUbar / isVbar) is, else zero gradient
 
 // ------------------------------------------------------------------ indexing (reference layout)
 #define X2(i, j) ((size_t)((i) - G.LBi) + (size_t)((j) - G.LBj) * (size_t)G.ni)
@@ -231,6 +248,10 @@ struct Fields {
   // mod_mixing
   GPtr Akv, Akt, visc2_r, visc2_p, diff2, bvf, alpha, beta, hsbl, ghats;
   GPtr visc4_r, visc4_p, diff4;        // square roots of the biharmonic coefficients (inp_par.F:634, read_phypar.F:7840)
+  // WET_DRY (wetdry.F): wet/dry masks of the fast steps / the 3-D step, wet x land masks for output, the sum of the rho
+  // mask over the fast steps (allocated by roms_hip_wetdry_config)
+  GPtr rmask_wet, umask_wet, vmask_wet, pmask_wet, rmask_full, umask_full, vmask_full, pmask_full, rmask_wet_avg;
+  GPtr wd_eff;                         // umask*umask_wet | vmask*vmask_wet as step3d_uv finds them (2 planes; k_wd_eff)
   GPtr lap4;                           // UV_VIS4: LapU | LapV of uv3dmix4_s.h (2 x N planes), allocated by roms_hip_mix4_config
   GPtr tke, gls, Lscale, Akk, Akp;   // GLS_MIXING: tke, gls (i,j,0:N,3); Lscale, Akk, Akp (i,j,0:N)
   // s-coordinate tables (device copies)

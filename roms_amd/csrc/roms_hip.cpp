@@ -97,6 +97,8 @@ static const FieldDesc g_fields[] = {
     FD(pnom_u, FK_2D), FD(pmon_v, FK_2D), FD(pnom_v, FK_2D), FD(dmde, FK_2D), FD(dndx, FK_2D), FD(angler, FK_2D),
     FD(xr, FK_2D), FD(yr, FK_2D), FD(xp, FK_2D), FD(yp, FK_2D), FD(lonr, FK_2D), FD(latr, FK_2D), FD(rdrag, FK_2D), FD(rdrag2, FK_2D),
     FD(rmask, FK_2D), FD(umask, FK_2D), FD(vmask, FK_2D), FD(pmask, FK_2D),
+    FD(rmask_wet, FK_2D), FD(umask_wet, FK_2D), FD(vmask_wet, FK_2D), FD(pmask_wet, FK_2D), FD(rmask_full, FK_2D), FD(umask_full, FK_2D),
+    FD(vmask_full, FK_2D), FD(pmask_full, FK_2D), FD(rmask_wet_avg, FK_2D),      // WET_DRY (wetdry.F)
     FD(Hz, FK_R), FD(z_r, FK_R), FD(z_w, FK_W), FD(Huon, FK_R), FD(Hvom, FK_R),
     FD(zeta, FK_2Dx3), FD(ubar, FK_2Dx3), FD(vbar, FK_2Dx3), FD(rzeta, FK_2Dx2), FD(rubar, FK_2Dx2),
     FD(rvbar, FK_2Dx2), FD(u, FK_Rx2), FD(v, FK_Rx2), FD(t, FK_T), FD(W, FK_W), FD(wvel, FK_W), FD(rho, FK_R),
@@ -421,7 +423,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   c->stream3 = nullptr;
   c->G.dia_ts = 0;
   c->G.dia_uv = 0; c->G.ndm2 = 0; c->G.ndm3 = 0; c->G.ndrhs = 0;
-  c->G.uv_vis4 = 0; c->G.ts_dif4 = 0; c->F.lap4 = nullptr;
+  c->G.uv_vis4 = 0; c->G.ts_dif4 = 0; c->F.lap4 = nullptr; c->F.wd_eff = nullptr;
   for (int k = 0; k < 12; k++) { c->G.m2[k] = 0; c->G.m3[k] = 0; }
   c->F.duv = nullptr;
   for (int k = 0; k < 10; k++) c->G.dia_idx[k] = 0;
@@ -497,6 +499,8 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
       if (h2d(m, ones.data(), ones.size() * sizeof(double), c->stream)) { roms_hip_destroy(c); return 2; }
     c->G.rmask = c->F.rmask; c->G.umask = c->F.umask; c->G.vmask = c->F.vmask; c->G.pmask = c->F.pmask;
     c->G.masking = (cfg->options & ROMS_MASKING) != 0;
+    c->G.wet_dry = 0; c->G.Dcrit = 0.0; c->G.hbath = c->F.h;
+    c->G.rmask_wet = c->F.rmask_wet; c->G.umask_wet = c->F.umask_wet; c->G.vmask_wet = c->F.vmask_wet; c->G.pmask_wet = c->F.pmask_wet;
   }
   for (int k = 0; k < 13; k++) {
     void *p = nullptr;
@@ -1966,6 +1970,49 @@ extern "C" int roms_hip_mix4_config(roms_hip_ctx *c, int uv_vis4, int ts_dif4) {
   c->m2d_dirty = true;                               // (the packed barotropic metrics carry visc4 in place of visc2)
   c->pair_on = step2d_pair_usable(c);
   return 0;
+}
+// Wetting and drying (WET_DRY, ROMS/Nonlinear/wetdry.F): switches on the time-dependent masks "rmask_wet", "umask_wet",
+// "vmask_wet", "pmask_wet" (set per fast step by k_wetdry in front of the barotropic kernel, time-averaged for the 3-D step
+// behind the last one), "rmask_full" ... (wet x land, for output) and every WET_DRY branch of the path: step2d_LF_AM3.h
+// (:992, :1617, :2205-2222, :2518-2667), prsgrd32.h:362,426, rhs3d.F:1709-1910, t3dmix2_s.h:239,279, uv3dmix2_s.h:276,
+// step3d_uv.F:720-721,1187-1188,1359,1579 and its boundary rows, set_vbc.F:307-308,397 and LIMIT_BSTRESS (globaldefs.h:160),
+// ini_fields.F:294-403,850, zetabc.F:783-874, u2dbc_im.F:1190-1318, v2dbc_im.F:1239-1367, u3dbc_im.F:523,681.  Dcrit = DCRIT of
+// roms.in.  roms_hip_wetdry_ini sets the initial masks (initial.F:467).  Call between roms_hip_create and roms_hip_start.
+// Refused (exit_flag 5) where the reference's WET_DRY statements are not built on the device: no MASKING (globaldefs.h:152
+// switches it on), open boundaries, MPDATA, BULK_FLUXES, SOLAR_SOURCE, the closures (KPP, GLS, MY2.5), geopotential / isopycnic
+// / biharmonic mixing, the pressure Jacobians other than prsgrd32, averages and diagnostics.
+extern "C" int roms_hip_wetdry_config(roms_hip_ctx *c, double Dcrit) {
+  if (!c) return 8;
+  DGrid &G = c->G;
+  const int opt = G.options;
+  if (!G.masking) { set_error("WET_DRY: needs MASKING (globaldefs.h:152-154 defines it with WET_DRY)"); return 5; }
+  if (G.obc) { set_error("WET_DRY with open boundaries: the WET_DRY forms of the open conditions (zetabc.F:190, u2dbc_im.F:339, u3dbc_im.F:174 ...) are not built on the device"); return 5; }
+  for (int it = 0; it < G.NT; it++)
+    if (G.hadv[it] == ROMS_MPDATA || G.vadv[it] == ROMS_MPDATA) { set_error("WET_DRY with MPDATA tracers: mpdata_adiff.F's wet masks are not built"); return 5; }
+  if (opt & (ROMS_BULK_FLUXES | ROMS_SOLAR_SOURCE | ROMS_LMD_MIXING | ROMS_GLS_MIXING | ROMS_MY25_MIXING)) {
+    set_error("WET_DRY: not built together with BULK_FLUXES / SOLAR_SOURCE / LMD_MIXING / GLS_MIXING / MY25_MIXING (bulk_flux.F's and pre_step3d.F:903's wet masks; the closures are not pinned under WET_DRY)");
+    return 5;
+  }
+  if ((opt & (ROMS_MIX_GEO_TS | ROMS_MIX_ISO_TS)) || G.uv_vis4 || G.ts_dif4) { set_error("WET_DRY: horizontal mixing along s-surfaces, harmonic only (t3dmix2_s.h, uv3dmix2_s.h)"); return 5; }
+  if (opt & (ROMS_PRSGRD31 | ROMS_PRSGRD40)) { set_error("WET_DRY: the density Jacobian prsgrd32.h only (DJ_GRADPS)"); return 5; }
+  if (opt & (ROMS_PLAIN_VVISC)) { set_error("WET_DRY: SPLINES_VVISC only"); return 5; }
+  if (G.dia_ts || G.dia_uv || c->avg_nAVG > 0) { set_error("WET_DRY: the wet/dry masks of set_avg.F / set_diags.F are not built"); return 5; }
+  if (!c->F.wd_eff) {
+    void *p = nullptr;
+    if (dmalloc(&p, (size_t)2 * G.nij * sizeof(double))) return 2;
+    c->allocs.push_back(p);
+    c->F.wd_eff = (double *)p;
+  }
+  G.wet_dry = 1; G.Dcrit = Dcrit;
+  G.fuse_halo = 0; G.fuse3d = 0;                        // (the wetting/drying conditions follow the boundary fills: separate launches)
+  c->pair_on = step2d_pair_usable(c);
+  return 0;
+}
+extern "C" int roms_hip_wetdry_ini(roms_hip_ctx *c) {
+  if (!c) return 8;
+  if (!c->G.wet_dry) { set_error("roms_hip_wetdry_ini: call roms_hip_wetdry_config first"); return 8; }
+  ctx_sync_stepping(c);
+  return run_wetdry(c, 2);
 }
 // Per-term momentum tendencies (DIAGNOSTICS_UV): allocates DIAGS(ng)%DiaU2wrk ... DiaV3d (mod_diags.F:174-222) and switches
 // the term stores of prsgrd, rhs3d, uv3dmix2, pre_step3d, step2d and step3d_uv on; the window is roms_hip_dia_config's (call

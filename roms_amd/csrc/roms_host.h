@@ -184,6 +184,10 @@ void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n);   // n <= 8 
 void launch_halo_wide(roms_hip_ctx *c, const HaloSpec *sp, int n);    // ... with strips B2D_GL | B2D_GH lines wide (pair kernel)
 int run_set_avg(roms_hip_ctx *c, int part = 0);   // g_avg.cpp
 int run_set_diags(roms_hip_ctx *c);
+// WET_DRY (g_wetdry.cpp)
+int run_wetdry(roms_hip_ctx *c, int mode);
+int run_wd_scale3(roms_hip_ctx *c);
+int run_wd_eff(roms_hip_ctx *c);
 // DIAGNOSTICS_UV (g_duv.cpp)
 int duv_config(roms_hip_ctx *c);
 double *duv_field(roms_hip_ctx *c, const char *name, int *np);

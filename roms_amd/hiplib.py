@@ -72,7 +72,7 @@ EXPORTS = ["roms_hip_create", "roms_hip_destroy", "roms_hip_last_error", "roms_h
            "roms_hip_field_size", "roms_hip_upload", "roms_hip_download", "roms_hip_sync",
            "roms_hip_set_stepping", "roms_hip_get_stepping", "roms_hip_wvelocity", "roms_hip_diag", "roms_hip_last_diag", "roms_hip_get_bounds", "roms_hip_output_point", "roms_hip_avg_config", "roms_hip_set_avg", "roms_hip_avg_time",
            "roms_hip_start", "roms_hip_main3d", "roms_hip_profile", "roms_hip_region_seconds",
-           "roms_hip_kprof", "roms_hip_kprof_get", "roms_hip_kprof_stride", "roms_hip_kprof_window", "roms_hip_exchange_soak", "roms_hip_dia_config", "roms_hip_diauv_config", "roms_hip_mix4_config", "roms_hip_set_diags", "roms_hip_dia_time", "roms_hip_kprof_batch", "roms_hip_set_exchange", "roms_hip_rccl_unique_id",
+           "roms_hip_kprof", "roms_hip_kprof_get", "roms_hip_kprof_stride", "roms_hip_kprof_window", "roms_hip_exchange_soak", "roms_hip_dia_config", "roms_hip_diauv_config", "roms_hip_mix4_config", "roms_hip_wetdry_config", "roms_hip_wetdry_ini", "roms_hip_set_diags", "roms_hip_dia_time", "roms_hip_kprof_batch", "roms_hip_set_exchange", "roms_hip_rccl_unique_id",
            "roms_hip_comm_rccl", "roms_hip_peer_export", "roms_hip_comm_peer", "roms_hip_exchange_probe", "roms_hip_comm_reset", "roms_hip_exchange_count", "roms_hip_rccl_ranks", "roms_hip_copy_probe"] + \
           ["roms_hip_" + k for k in KERNELS]
 
@@ -253,6 +253,14 @@ class Context:
     def mix4_config(self, uv_vis4, ts_dif4):
         """biharmonic mixing along s-surfaces on (UV_VIS4 | TS_DIF4); upload "visc4_r", "visc4_p", "diff4" (square roots)"""
         self._ck(self.L.roms_hip_mix4_config(self.h, int(uv_vis4), int(ts_dif4)))
+
+    def wetdry_config(self, Dcrit):
+        """wetting and drying on (WET_DRY, wetdry.F); Dcrit: DCRIT of roms.in.  wetdry_ini() sets the initial masks."""
+        self.L.roms_hip_wetdry_config.argtypes = [C.c_void_p, C.c_double]
+        self._ck(self.L.roms_hip_wetdry_config(self.h, float(Dcrit)))
+
+    def wetdry_ini(self):
+        self._ck(self.L.roms_hip_wetdry_ini(self.h))
 
     def avg_time(self):
         t = C.c_double()

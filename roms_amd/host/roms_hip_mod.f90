@@ -177,6 +177,17 @@
           integer(c_int), value :: uv_vis4, ts_dif4
           integer(c_int) :: ierr
         END FUNCTION roms_hip_mix4_config
+        FUNCTION roms_hip_wetdry_config (ctx, Dcrit) bind(C, name='roms_hip_wetdry_config') RESULT (ierr)
+          IMPORT :: c_ptr, c_int, c_double
+          type(c_ptr), value :: ctx
+          real(c_double), value :: Dcrit
+          integer(c_int) :: ierr
+        END FUNCTION roms_hip_wetdry_config
+        FUNCTION roms_hip_wetdry_ini (ctx) bind(C, name='roms_hip_wetdry_ini') RESULT (ierr)
+          IMPORT :: c_ptr, c_int
+          type(c_ptr), value :: ctx
+          integer(c_int) :: ierr
+        END FUNCTION roms_hip_wetdry_ini
         FUNCTION roms_hip_diauv_config (ctx) bind(C, name='roms_hip_diauv_config') RESULT (ierr)
           IMPORT :: c_ptr, c_int
           type(c_ptr), value :: ctx

@@ -30,6 +30,8 @@
 !  UV_VIS4 / TS_DIF4 (biharmonic mixing along s-surfaces): VISC4, TNU4 of roms.in [m4/s]; mix4(1:2): the header defines them
       real(dp) :: visc4 = 0.0_dp, tnu4(ROMS_MAXT) = 0.0_dp
       logical :: mix4(2) = .FALSE.
+      real(dp) :: Dcrit = 0.10_dp              ! DCRIT of roms.in (WET_DRY; read_phypar.F:1021)
+      logical :: wet_dry = .FALSE.
       real(dp) :: visc2 = 5.0_dp, tnu2(ROMS_MAXT) = 0.0_dp, Akt_bak(ROMS_MAXT) = 1.0E-6_dp, Akv_bak = 1.0E-5_dp
       real(dp) :: rdrg = 3.0E-4_dp, rdrg2 = 3.0E-3_dp, Zob = 0.02_dp, Zos = 0.02_dp, gamma2 = 1.0_dp
       real(dp) :: dstart = 0.0_dp, time_ref = 0.0_dp, blk_ZQ = 10.0_dp, blk_ZT = 10.0_dp, blk_ZW = 10.0_dp
@@ -285,6 +287,7 @@
           CASE ('VISC2');       visc2=toreal(tok(1))
           CASE ('TNU4');        CALL load_r (tok, nv, tnu4)
           CASE ('VISC4');       visc4=toreal(tok(1))
+          CASE ('DCRIT');       Dcrit=toreal(tok(1))
           CASE ('AKT_BAK');     CALL load_r (tok, nv, Akt_bak)
           CASE ('AKV_BAK');     Akv_bak=toreal(tok(1))
           CASE ('RDRG');        rdrg=toreal(tok(1))
@@ -441,6 +444,7 @@
       R0=1027.0_dp; T0=14.0_dp; S0=35.0_dp; Tcoef=1.7E-4_dp; Scoef=0.0_dp
       visc2=5.0_dp; tnu2=0.0_dp; Akt_bak=1.0E-6_dp; Akv_bak=1.0E-5_dp
       visc4=0.0_dp; tnu4=0.0_dp; mix4=.FALSE.
+      Dcrit=0.10_dp; wet_dry=.FALSE.
       rdrg=3.0E-4_dp; rdrg2=3.0E-3_dp; Zob=0.02_dp; Zos=0.02_dp; gamma2=1.0_dp
       dstart=0.0_dp; time_ref=0.0_dp; blk_ZQ=10.0_dp; blk_ZT=10.0_dp; blk_ZW=10.0_dp
       gls_flags=0; lbc_tke=0; gls_p=3.0_dp; gls_m=1.5_dp; gls_n=-1.0_dp; gls_Kmin=7.6E-6_dp; gls_Pmin=1.0E-12_dp
@@ -854,7 +858,7 @@
       END IF
       CALL define ('ANA_INITIAL'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
       SELECT CASE (TRIM(MyAppCPP))
-        CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK', 'UPWELLING_BIH',  &  ! (oracle/ref/upwelling_logdrag.h, _mask.h, _bih.h)
+        CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK', 'UPWELLING_BIH', 'UPWELLING_WETDRY',  &  ! (oracle/ref/upwelling_logdrag.h, _mask.h, _bih.h, _wetdry.h)
      &        'UPWELLING_GLS', 'UPWELLING_GLS_CA', 'UPWELLING_GLS_CB', 'UPWELLING_GLS_GAL', 'UPWELLING_MY25',         &
      &        'UPWELLING_MY25_GAL')
 !  UPWELLING_GLS = upwelling.h built with -DGLS_MIXING; _CA, _CB, _GAL = oracle/ref/upwelling_gls_ca.h, _cb.h, _gal.h: the
@@ -870,6 +874,9 @@
             CALL define ('K_C4ADVECTION'); CALL define ('RI_SPLINES')
           END IF
           IF (TRIM(MyAppCPP).eq.'UPWELLING_MASK') CALL define ('MASKING')
+          IF (TRIM(MyAppCPP).eq.'UPWELLING_WETDRY') THEN
+            CALL define ('MASKING'); CALL define ('WET_DRY')
+          END IF
           CALL define (TRIM(MERGE('UV_LOGDRAG', 'UV_LDRAG  ', TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG')))
           CALL define ('MIX_S_TS')
           DO k=1,SIZE(flux0)
@@ -935,7 +942,7 @@
       IF (ierr.ne.0) RETURN
       upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
      &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING').or.    &
-     &    TRIM(MyAppCPP).eq.'UPWELLING_BIH'.or.                                                                     &
+     &    TRIM(MyAppCPP).eq.'UPWELLING_BIH'.or.TRIM(MyAppCPP).eq.'UPWELLING_WETDRY'.or.                             &
      &    MyAppCPP(1:13).eq.'UPWELLING_GLS'.or.MyAppCPP(1:14).eq.'UPWELLING_MY25'
       bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.TRIM(MyAppCPP).eq.'BENCHMARK_MASK'.or.is_defined('BENCHMARK')
       kelv=TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES'.or.is_defined('KELVIN')
@@ -947,6 +954,9 @@
      &                    'exist for UPWELLING, BENCHMARK, KELVIN, SEAMOUNT, GRAV_ADJ and OVERFLOW', ierr)
         RETURN
       END IF
+!  WET_DRY switches MASKING on (globaldefs.h:152-154) and, inside set_vbc, LIMIT_BSTRESS (:160-162)
+      wet_dry=is_defined('WET_DRY')
+      IF (wet_dry.and..not.is_defined('MASKING')) CALL define ('MASKING')
       gls_flags=0
       IF (upw) options=ROMS_APP_UPWELLING
       IF (bench) options=ROMS_APP_BENCHMARK
@@ -970,6 +980,8 @@
           CONTINUE
         ELSE IF (TRIM(defs(k)).eq.'UV_VIS4'.or.TRIM(defs(k)).eq.'TS_DIF4') THEN   ! biharmonic mixing: roms_hip_mix4_config (below)
           CONTINUE
+        ELSE IF (TRIM(defs(k)).eq.'WET_DRY'.or.TRIM(defs(k)).eq.'LIMIT_BSTRESS') THEN   ! wetting and drying: roms_hip_wetdry_config
+          IF (.not.wet_dry) CALL unsupported ('LIMIT_BSTRESS is built as part of WET_DRY only (globaldefs.h:160)', ierr)
         ELSE
           CALL unsupported ('cpp option '//TRIM(defs(k))//' is not built into this library', ierr)
           RETURN
@@ -1775,7 +1787,28 @@
       CALL ini_mixing ()
       CALL level_depths (Zt_avg1)               ! Zt_avg1 = 0: depths of the resting ocean
       CALL initial_state ()
+      IF (TRIM(MyAppCPP).eq.'UPWELLING_WETDRY') CALL wetdry_depths ()
       END SUBROUTINE host_setup
+!
+!  The wetting/drying test application UPWELLING_WETDRY (oracle/ref/upwelling_wetdry.h; roms_amd/cases.py:wetdry_depth holds the
+!  same numbers): depth 10 m south of row Mm/3, from there a plane beach to -0.3 m (above the still water level) at the northern
+!  wall, roughened by 5 cm x MOD(7 i + 3 j, 5); initial free surface: a ridge 0.4 m high, 4 rows either side of row Mm/4.  The
+!  reference would read such a bathymetry and initial state from its grid and initial NetCDF files.  (The temperature profile
+!  stays the one of the UPWELLING depths, level by level.)
+      SUBROUTINE wetdry_depths ()
+      integer :: i, j, iw, jw, j0, js
+      real(r8) :: ramp
+      j0=Mm/3; js=Mm/4
+      DO j=LBj,UBj
+        DO i=LBi,UBi
+          iw=MERGE(MODULO(i-1,Lm)+1, i, EWperiodic)
+          jw=MERGE(MODULO(j-1,Mm)+1, j, NSperiodic)
+          ramp=MIN(1.0_r8, MAX(0.0_r8, REAL(jw-j0,r8)/REAL(Mm+1-j0,r8)))
+          h(i,j)=10.0_r8-10.3_r8*ramp+0.05_r8*REAL(MODULO(7*iw+3*jw,5),r8)
+          zeta(i,j,:)=0.4_r8*MAX(0.0_r8, 1.0_r8-ABS(REAL(jw-js,r8))/4.0_r8)
+        END DO
+      END DO
+      END SUBROUTINE wetdry_depths
 
 !
 !  Land/sea masks of a MASKING run (all water otherwise).  The reference reads them from its grid file (or
@@ -1802,6 +1835,9 @@
       END DO
       umask(LBi+1:UBi,:)=rmask(LBi:UBi-1,:)*rmask(LBi+1:UBi,:)
       vmask(:,LBj+1:UBj)=rmask(:,LBj:UBj-1)*rmask(:,LBj+1:UBj)
+!  (the first line of the array in a periodic direction: its lower neighbour is the periodic image)
+      IF (EWperiodic) umask(LBi,:)=rmask(LBi+Lm-1,:)*rmask(LBi,:)
+      IF (NSperiodic) vmask(:,LBj)=rmask(:,LBj+Mm-1)*rmask(:,LBj)
       pmask=0.0_r8
       DO j=LBj+1,UBj
         DO i=LBi+1,UBi
@@ -1941,6 +1977,10 @@
         ierr=roms_hip_mix4_config(ctx, MERGE(1,0,mix4(1)), MERGE(1,0,mix4(2)))
         IF (ierr.ne.0) RETURN
       END IF
+      IF (wet_dry) THEN                           ! WET_DRY: wetdry.F and its branches
+        ierr=roms_hip_wetdry_config(ctx, Dcrit)
+        IF (ierr.ne.0) RETURN
+      END IF
       IF (nAVG.gt.0.and.ANY(Aout)) THEN           ! AVERAGES: mod_average.F allocate_average
         ierr=roms_hip_avg_config(ctx, nAVG, ntsAVG, 0, 1, aout_mask())
         IF (ierr.ne.0) RETURN
@@ -1994,6 +2034,7 @@
         CALL up ('Akp', gw(:,:,1:N+1), N+1, ierr)
         deallocate ( gw )
       END IF
+      IF (wet_dry.and.ierr.eq.0) ierr=roms_hip_wetdry_ini(ctx)       ! the initial wet/dry masks from zeta(1) (initial.F:467)
       END SUBROUTINE device_init
 !
 !  Upload the tile's window (tLBi:tUBi,tLBj:tUBj) of a host array with np horizontal planes.

@@ -86,6 +86,7 @@ def write_roms_in(path, p):
         f"     NDTFAST == {p['ndtfast']}", f"       NINFO == {p.get('ninfo', 1)}",
         f"        TNU2 == {tr(d(x) for x in p['tnu2'])}", f"       VISC2 == {d(p['visc2'])}",
         f"        TNU4 == {tr(d(x) for x in p.get('tnu4', (0.0, 0.0)))}", f"       VISC4 == {d(p.get('visc4', 0.0))}",
+        f"       DCRIT == {d(p.get('Dcrit', 0.10))}",
         f"     AKT_BAK == {tr(d(x) for x in p['Akt_bak'])}", f"     AKV_BAK == {d(p['Akv_bak'])}",
         f"        RDRG == {d(p['rdrg'])}", f"       RDRG2 == {d(p['rdrg2'])}",
         f"         Zob == {d(p['Zob'])}", f"         Zos == {d(p['Zos'])}",

@@ -700,6 +700,7 @@ DETERMINISM_SMALL = [
     ("upwelling_mask_small", {}), ("seamount_small", {}), ("grav_adj_small", {}), ("overflow_small", {}),
     ("kelvin_small", {}), ("kelvin_plain_small", {}), ("upwelling_gls_small", {}), ("upwelling_my25_small", {}),
     ("upwelling_prs31_small", {}), ("upwelling_prs40_small", {}), ("upwelling_logdrag_small", {}), ("upwelling_bih_small", {}),
+    ("upwelling_wetdry_small", {}),
 ]
 
 
@@ -707,7 +708,9 @@ def _case_state(tag, kw):
     cs = util.case_for(tag, **kw)
     itag = "upwelling_small" if tag.startswith("upwelling") else tag.replace("_plain", "")
     g = util.load_init(itag, util.nghost_for(cs))
-    if "MASKING" in cs["options"]:
+    if cs.get("wet_dry"):
+        g = util.with_wetdry(cs, g)
+    elif "MASKING" in cs["options"]:
         g = util.with_masks(cs, g)
     if "gls_flags" in cs:
         g = util.with_gls(cs, g)
@@ -1128,6 +1131,39 @@ def test_land_sea_masking_matches_oracle(tag, hadv, vadv, env):
     """) % (ROOT, tag, tuple(hadv), tuple(vadv))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
     assert "MASK-GPU-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hadv,vadv,ewp", [(("U3", "HSIMT"), ("C4", "HSIMT"), 1), (("U3", "U3"), ("C4", "C4"), 0)])
+def test_wetting_and_drying_matches_oracle(hadv, vadv, ewp):
+    """WET_DRY on the GPU (the beach and the ridge of water of cases.wetdry_depth; the oracle is pinned bit for bit to the
+    reference built from oracle/ref/upwelling_wetdry.h): 30 steps, periodic channel and closed basin -- the wet/dry masks of the
+    3-D step EQUAL to the oracle's after every step (they are decisions, not numbers), the state at the north-star tolerance;
+    cells flip between wet and dry on the way."""
+    cs = util.case_for("upwelling_wetdry_small", hadv=hadv, vadv=vadv)
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    if not ewp:
+        cs["EWperiodic"] = 0
+        g = util.closed_basin_state(cs, g)
+    g = util.with_wetdry(cs, g)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g)
+    for n in util.WET_FIELDS[:8]:
+        assert np.array_equal(H.download(n), O.field(n)), n
+    O.start(); H.start()
+    flips, prev = 0, O.field("rmask_wet").copy()
+    for step in range(30):
+        O.main3d_step(); H.main3d(1)
+        for n in util.WET_FIELDS:
+            assert np.array_equal(H.download(n), O.field(n)), (step, n)
+        flips += int((O.field("rmask_wet") != prev).sum()); prev = O.field("rmask_wet").copy()
+    for n in util.PROGNOSTIC:
+        a, b = H.download(n), O.field(n)
+        assert np.isfinite(b).all(), n
+        e = util.relrms(a, b)
+        assert e <= (1e-10 if n in ("zeta", "u", "v", "t", "W", "wvel", "ubar", "vbar", "Hz", "rho") else 1e-8), (n, e)
+    assert flips > 0 and np.abs(H.download("u")).max() > 1e-3
+    H.close()
 
 
 @pytest.mark.gpu

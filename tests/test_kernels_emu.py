@@ -141,6 +141,70 @@ def test_land_sea_masking_bitwise(emu, hadv, vadv):
     H.close()
 
 
+@pytest.mark.parametrize("hadv,vadv,ewp", [(("U3", "HSIMT"), ("C4", "HSIMT"), 1), (("A4", "C4"), ("SPLINES", "C4"), 1), (("U3", "U3"), ("C4", "C4"), 0)])
+def test_wetting_and_drying_bitwise(emu, hadv, vadv, ewp):
+    """WET_DRY (a beach that dries above the still water level and a ridge of water that runs up it, cases.wetdry_depth; oracle
+    pinned to the reference built from oracle/ref/upwelling_wetdry.h): the masks of every fast step and the time-averaged ones
+    (k_wetdry), the wet/dry branches of the barotropic kernel, of prsgrd / rhs3d / t3dmix2 / uv3dmix2 / step3d_uv / set_vbc with
+    the bottom-stress limiter, the first-step loads and the wetting/drying conditions of the boundary routines -- periodic
+    channel and closed basin (all four walls: v2dbc's western edge as written) -- against the oracle over 30 steps, bit for bit;
+    cells flip between wet and dry on the way."""
+    cs = util.case_for("upwelling_wetdry_small", hadv=hadv, vadv=vadv)
+    if ewp:
+        g = util.with_wetdry(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    else:
+        cs["EWperiodic"] = 0
+        g = util.with_wetdry(cs, util.closed_basin_state(cs, util.load_init("upwelling_small", util.nghost_for(cs))))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.call("wetdry_ini")
+    H.wetdry_ini()
+    for n in util.WET_FIELDS[:8]:
+        assert np.array_equal(H.download(n), O.field(n)), n
+    O.start()
+    H.start()
+    flips = 0
+    prev = O.field("rmask_wet").copy()
+    for _ in range(30):
+        O.main3d_step()
+        H.main3d(1)
+        for n in util.PROGNOSTIC + util.WET_FIELDS:
+            a, b = H.download(n), O.field(n)
+            assert np.isfinite(b).all(), n
+            assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+        flips += int((O.field("rmask_wet") != prev).sum())
+        prev = O.field("rmask_wet").copy()
+    assert flips > 0 and np.abs(H.download("u")).max() > 0
+    dry = O.field("rmask_wet") == 0
+    assert dry.sum() > (g["rmask"] == 0).sum()                      # more than the land is dry
+    H.close()
+
+
+def test_wetting_and_drying_through_the_fortran_host_matches_the_oracle(emu):
+    """roms.in (MyAppCPP = UPWELLING_WETDRY, DCRIT) -> Fortran host (WET_DRY switches MASKING on; its analytic beach and ridge of
+    water; roms_hip_wetdry_config / _ini) -> C ABI -> kernels: the host's bathymetry and initial free surface are the numbers of
+    cases.wetdry_depth, and 12 steps give the same bits as the oracle started from the state the host uploaded."""
+    from roms_amd import hostlib
+    cs = util.case_for("upwelling_wetdry_small", hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"))
+    g = util.with_wetdry(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    H = hostlib.Host(params=dict(cs, ninfo=0), lib_path=os.path.join(os.path.dirname(emu), "libroms_host_emu.so"), hip_lib_path=emu)
+    ctx = H.device_init()
+    assert np.array_equal(ctx.download("h"), g["h"]) and np.array_equal(ctx.download("zeta"), g["zeta"])
+    assert np.array_equal(ctx.download("rmask"), g["rmask"])
+    g2 = dict(g)
+    for n in util.INIT_FIELDS + util.WET_FIELDS:
+        if n in g or n in util.WET_FIELDS:
+            g2[n] = ctx.download(n)
+    O = util.make_oracle(cs, g2)
+    O.start()
+    O.main3d_step(12)
+    H.run(12)
+    for n in ("zeta", "u", "v", "t", "ubar", "vbar", "rho", "W", "rmask_wet", "umask_wet", "vmask_wet", "pmask_wet", "rmask_full"):
+        assert np.array_equal(ctx.download(n), O.field(n)), n
+    assert (O.field("rmask_wet") == 0).sum() > (g["rmask"] == 0).sum()
+    H.finalize()
+
+
 def test_land_sea_masking_benchmark_physics_bitwise(emu):
     """MASKING with the BENCHMARK physics (oracle pinned to the reference built from oracle/ref/benchmark_mask.h): the
     masked branches of the nonlinear EOS, the COARE bulk fluxes, KPP (surface boundary layer) and the geopotential

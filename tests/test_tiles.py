@@ -89,6 +89,9 @@ def _interior(cs_dims, a):
     # biharmonic mixing (UV_VIS4, TS_DIF4): the first harmonic operator is formed from the neighbour's points across the tile
     # boundary (three ghost lines), its closed-edge conditions and corner values on the edge tiles only
     ("upwelling_bih_mid", dict(), (2, 2), 29633),
+    # WET_DRY: the wet/dry masks of a tile's ghost points are computed from the exchanged free surface (no exchange of masks);
+    # the shore line crosses the tile boundaries, the averaged masks read DU_avg1 / DV_avg1 in the ghost lines
+    ("upwelling_wetdry_mid", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 2), 29634),
 ])
 def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     _emu_libs()

@@ -64,6 +64,10 @@ def case_for(tag, **kw):
         return cases.benchmark_mask(Lm=24, Mm=16, N=10, **kw)
     if tag == "upwelling_mask_small":
         return cases.upwelling_mask(Lm=14, Mm=18, N=8, **kw)
+    if tag == "upwelling_wetdry_small":
+        return cases.upwelling_wetdry(Lm=14, Mm=18, N=8, **kw)
+    if tag == "upwelling_wetdry_mid":
+        return cases.upwelling_wetdry(Lm=34, Mm=40, N=6, **kw)
     # grids whose 2x2 / 4x2 tiles are large enough (>= 8 points) for the barotropic pair kernel with its wide strips
     if tag == "upwelling_mid":
         return cases.upwelling(Lm=34, Mm=40, N=6, **kw)
@@ -141,11 +145,15 @@ def kelvin_gls_case():
 def make_oracle(cs, g):
     from oracle import orc
     O = orc.Oracle(cases.oracle_cfg(cs, float(g["scalars"][0]), int(g["bounds"][58]), g["weight"]))
-    for n in INIT_FIELDS:
+    if cs.get("wet_dry"):
+        O.set_wetdry(cs["Dcrit"])
+    for n in INIT_FIELDS + (WET_FIELDS if cs.get("wet_dry") else []):
         if n in g:
             O.field(n)[:] = g[n]
     for n in ["sc_r", "Cs_r", "sc_w", "Cs_w"]:
         O.field(n)[:] = g[n]
+    if cs.get("wet_dry") and "rmask_wet" not in g:
+        O.call("wetdry_ini")                # initial.F:467
     if "mix4" in cs:       # biharmonic mixing: uniform square roots of VISC4 / TNU4 (inp_par.F:634, ini_hmixcoef.F:270-296)
         O.set_mix4(*cs["mix4"])
         O.field("visc4_r")[:] = np.sqrt(abs(cs["visc4"])); O.field("visc4_p")[:] = np.sqrt(abs(cs["visc4"]))
@@ -164,6 +172,36 @@ def with_masks(cs, g):
     return g
 
 
+def closed_basin_state(cs, g):
+    """the EW-periodic fixture `g` re-embedded into closed-basin arrays (0..Im+1 along xi) for a case with EWperiodic = 0;
+    bounds[0:2] follow"""
+    g = dict(g)
+    LBi, UBi, LBj, UBj = [int(x) for x in g["bounds"][:4]]
+    ni, nj = UBi - LBi + 1, UBj - LBj + 1
+    Lm = cs["Lm"]
+    Im = Lm + ((Lm + 2) // 2 - (Lm + 1) // 2)
+    for k, a in list(g.items()):
+        if a.ndim == 1 and a.size >= ni * nj and a.size % (ni * nj) == 0:
+            a = a.reshape(-1, nj, ni)[:, :, (0 - LBi):(Im + 1 - LBi) + 1]
+            g[k] = np.ascontiguousarray(a).ravel()
+    b = g["bounds"].copy()
+    b[0] = 0; b[1] = Im + 1
+    g["bounds"] = b
+    return g
+
+
+def with_wetdry(cs, g):
+    """the initial state `g` (an UPWELLING fixture) as the wetting/drying test case: the land of cases.land_mask, the beach
+    and the ridge of water of cases.wetdry_depth (h and all three levels of zeta); the wet/dry masks follow from these through
+    wetdry_ini on either side (initial.F:467)"""
+    g = with_masks(cs, g)
+    LBi, UBi, LBj, UBj = [int(x) for x in g["bounds"][:4]]
+    d = cases.wetdry_depth(cs, LBi, UBi, LBj, UBj)
+    g["h"] = np.ascontiguousarray(d["h"]).ravel()
+    g["zeta"] = np.tile(np.ascontiguousarray(d["zeta"]).ravel(), 3)
+    return g
+
+
 def make_hip(cs, g, lib_path=None, device=0, ninfo=0):
     from roms_amd import hiplib
     cfg = cases.hip_cfg(cs, float(g["scalars"][0]), int(g["bounds"][58]), g["weight"], g["sc_r"], g["Cs_r"],
@@ -172,9 +210,13 @@ def make_hip(cs, g, lib_path=None, device=0, ninfo=0):
     H = hiplib.Context(cfg, lib_path)
     if "mix4" in cs:
         H.mix4_config(*cs["mix4"])
-    for n in INIT_FIELDS:
+    if cs.get("wet_dry"):
+        H.wetdry_config(cs["Dcrit"])
+    for n in INIT_FIELDS + (WET_FIELDS if cs.get("wet_dry") else []):
         if n in g:
             H.upload(n, g[n])
+    if cs.get("wet_dry") and "rmask_wet" not in g:
+        H.wetdry_ini()                      # initial.F:467
     if "mix4" in cs:       # ... and the harmonic coefficients zero (the library's harmonic operators then add exact zeros)
         nij = np.asarray(g["h"]).size
         H.upload("visc4_r", np.full(nij, np.sqrt(abs(cs["visc4"])))); H.upload("visc4_p", np.full(nij, np.sqrt(abs(cs["visc4"]))))

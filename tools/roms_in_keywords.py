@@ -19,7 +19,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 REF = "/root/reference/ROMS/Utility/read_phypar.F"
 
 HONOURED = """TITLE MyAppCPP Lm Mm N NAT NtileI NtileJ NTIMES DT NDTFAST NINFO Hadvection Vadvection NRREC LcycleRST NRST NHIS
-ININAME RSTNAME HISNAME NAVG NTSAVG AVGNAME NDIA NTSDIA DIANAME TNU2 VISC2 TNU4 VISC4 AKT_BAK AKV_BAK RDRG RDRG2 Zob Zos BLK_ZQ BLK_ZT BLK_ZW WTYPE
+ININAME RSTNAME HISNAME NAVG NTSAVG AVGNAME NDIA NTSDIA DIANAME TNU2 VISC2 TNU4 VISC4 DCRIT AKT_BAK AKV_BAK RDRG RDRG2 Zob Zos BLK_ZQ BLK_ZT BLK_ZW WTYPE
 Vtransform Vstretching THETA_S THETA_B TCLINE RHO0 DSTART TIME_REF R0 T0 S0 TCOEF SCOEF GAMMA2
 TNUDG ZNUDG M2NUDG M3NUDG OBCFAC
 AKK_BAK AKP_BAK GLS_P GLS_M GLS_N GLS_Kmin GLS_Pmin GLS_CMU0 GLS_C1 GLS_C2 GLS_C3M GLS_C3P GLS_SIGK GLS_SIGP CHARNOK_ALPHA CRGBAN_CW""".split()
