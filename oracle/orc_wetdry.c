@@ -134,8 +134,9 @@ void orc_wetdry_ini(orc_t *o, int tile) {
   const int kstp = o->s.kstp;
   double *wetdry = (double *)calloc(nij, sizeof(double));
   wd_local(o, b, o->zeta + (size_t)(kstp - 1) * nij, wetdry);
-  wd_avg_mask(o, b, wetdry, o->ubar + (size_t)(kstp - 1) * nij, o->vbar + (size_t)(kstp - 1) * nij);   /* :408 */
-  wd_mask(o, b, wetdry);                                                                                 /* :415 */
+  /* SOLVE3D: the masks of the 3-D step's form, with ubar, vbar(kstp) for the direction of the flow :466-472 (the #else branch,
+     wetdry_mask_tile, is the 2-D model's) */
+  wd_avg_mask(o, b, wetdry, o->ubar + (size_t)(kstp - 1) * nij, o->vbar + (size_t)(kstp - 1) * nij);
   wd_full(o, b);
   free(wetdry);
 }

@@ -6,7 +6,8 @@
 //              mode 1  wetdry_tile behind the last fast step (:250-349): the rho mask = AINT(rmask_wet_avg / (2 nfast)), the
 //                      masks of wetdry_avg_mask_tile (:723-900: a face between a wet and a dry cell is open in the direction
 //                      of the time-averaged transport DU_avg1 | DV_avg1), then the wet x land masks *_full
-//              mode 2  wetdry_ini_tile (:355-490, initial.F:467): the masks of mode 0 and *_full
+//              mode 2  wetdry_ini_tile (:355-490, initial.F:467): the masks in the form of mode 1 from zeta(kstp), with ubar, vbar(kstp)
+//                      for the direction of the flow (the SOLVE3D branch :466-472), and *_full
 //   k_wd_scale3        ru | rv(:,:,k,nrhs) times umask_wet | vmask_wet (prsgrd32.h:362,426; step3d_uv.F:721,1188)
 //
 // One thread per point of the ARRAY (ghost points included): a mask at a ghost point is computed from the free surface at
@@ -81,8 +82,8 @@ THREAD_KERNEL(k_wetdry, WdArgs) {
   if (hasx) {
     double m = wx + w0;
     if (m == 1.0) m = wx - w0;
-    if (mode == 1) {                                                              // :765-778
-      const double du = F.DU_avg1[x];
+    if (mode != 0) {                                                              // :765-778
+      const double du = mode == 1 ? F.DU_avg1[x] : F.ubar[(size_t)(G.kstp - 1) * (size_t)G.nij + x];
       const double cff5 = fabs(fabs(m) - 1.0), cff6 = 0.5 + copysign(0.5, du) * m;
       m = 0.5 * m * cff5 + cff6 * (1.0 - cff5);
       if (du == 0.0 && (wx + w0) <= 1.0) m = 0.0;                                 // "catch lone ponds"
@@ -92,8 +93,8 @@ THREAD_KERNEL(k_wetdry, WdArgs) {
   if (hasy) {
     double m = wy + w0;
     if (m == 1.0) m = wy - w0;
-    if (mode == 1) {                                                              // :784-798
-      const double dv = F.DV_avg1[x];
+    if (mode != 0) {                                                              // :784-798
+      const double dv = mode == 1 ? F.DV_avg1[x] : F.vbar[(size_t)(G.kstp - 1) * (size_t)G.nij + x];
       const double cff5 = fabs(fabs(m) - 1.0), cff6 = 0.5 + copysign(0.5, dv) * m;
       m = 0.5 * m * cff5 + cff6 * (1.0 - cff5);
       if (dv == 0.0 && (wy + w0) <= 1.0) m = 0.0;

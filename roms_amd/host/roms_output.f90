@@ -168,6 +168,7 @@
 !  mod_scalars.F spval); the restart file keeps the computed values (PERFECT_RESTART)
       real(r8), parameter :: spval = 1.0E+37_r8
       logical :: land_fill = .FALSE., def_fill = .FALSE.
+      real(r8), allocatable :: wfull(:,:,:)     ! WET_DRY: rmask_full | umask_full | vmask_full of the record being written
 
       CONTAINS
 
@@ -184,6 +185,21 @@
       LOGICAL FUNCTION is_spherical ()
       is_spherical=IAND(options,ROMS_SPHERICAL).ne.0
       END FUNCTION is_spherical
+!  wet/dry mask of a psi point from the four rho values around it (wetdry.F:806-861): 1 with at most one dry cell, 2 where
+!  two dry cells share a side of the point, 0 otherwise
+      REAL(r8) FUNCTION psi_wet (a, b, c, d)
+      real(r8), intent(in) :: a, b, c, d             ! (i-1,j) (i,j) (i-1,j-1) (i,j-1)
+      integer :: nw
+      nw=COUNT((/ a, b, c, d /).gt.0.5_r8)
+      psi_wet=0.0_r8
+      IF (nw.ge.3) THEN
+        psi_wet=1.0_r8
+      ELSE IF (nw.eq.2) THEN
+        IF ((b.lt.0.5_r8.and.d.lt.0.5_r8).or.(a.lt.0.5_r8.and.c.lt.0.5_r8).or.                                          &
+     &      (c.lt.0.5_r8.and.d.lt.0.5_r8).or.(a.lt.0.5_r8.and.b.lt.0.5_r8)) psi_wet=2.0_r8
+      END IF
+      END FUNCTION psi_wet
+!
       LOGICAL FUNCTION is_masked ()
       is_masked=IAND(options,ROMS_MASKING).ne.0
       END FUNCTION is_masked
@@ -240,7 +256,18 @@
       CALL io_range (g, i0, i1, j0, j1)
       allocate ( buf(i0:i1,j0:j1,k0:k1) )
       buf=A(i0:i1,j0:j1,k0:k1)
-      IF (land_fill) THEN                                 ! MASKING: land points of a history field = spval (nf_fwrite2d.F)
+      IF (land_fill.and.allocated(wfull)) THEN            ! WET_DRY: the wet x land masks rmask_full ... of this record (wrt_his.F: Amask = rmask_full)
+        DO k=k0,k1
+          SELECT CASE (g)
+            CASE (gR2, gR3, gW3)
+              WHERE (wfull(i0:i1,j0:j1,1).lt.0.5_r8) buf(:,:,k)=spval
+            CASE (gU2, gU3, gUW)
+              WHERE (wfull(i0:i1,j0:j1,2).lt.0.5_r8) buf(:,:,k)=spval
+            CASE DEFAULT
+              WHERE (wfull(i0:i1,j0:j1,3).lt.0.5_r8) buf(:,:,k)=spval
+          END SELECT
+        END DO
+      ELSE IF (land_fill) THEN                            ! MASKING: land points of a history field = spval (nf_fwrite2d.F)
         DO k=k0,k1
           SELECT CASE (g)
             CASE (gR2, gR3, gW3)
@@ -718,6 +745,14 @@
         END DO
       END IF
       IF (which.ne.fAVG.and.which.ne.fDIA) THEN
+      IF (wet_dry) THEN                                   ! def_his.F / def_rst.F under WET_DRY (varinfo.yaml: idRwet, idUwet, idVwet; no psi grid here)
+        CALL def_field (ofile(which), 'wetdry_mask_rho', 'wet_dry_mask_at_cell_center', 'wet/dry mask on RHO-points',    &
+     &                  'nondimensional', 'wet-dry rho-mask', gR2, -1_c_int, .TRUE., ofile(which)%v_fld(77), ierr)
+        CALL def_field (ofile(which), 'wetdry_mask_u', 'wet_dry_mask_at_cell_y_edges', 'wet/dry mask on U-points',       &
+     &                  'nondimensional', 'wet-dry u-mask', gU2, -1_c_int, .TRUE., ofile(which)%v_fld(78), ierr)
+        CALL def_field (ofile(which), 'wetdry_mask_v', 'wet_dry_mask_at_cell_x_edges', 'wet/dry mask on V-points',       &
+     &                  'nondimensional', 'wet-dry v-mask', gV2, -1_c_int, .TRUE., ofile(which)%v_fld(79), ierr)
+      END IF
       IF (rst.or.Hout(idFsur)) CALL fdef ('zeta', 'sea_surface_height_above_geopotential_datum', 'free-surface',     &
      &                                    'meter', 'free-surface', gR2, three, idFsur)
       IF (rst) CALL fdef ('rzeta', 'sea_surface_elevation_anomaly_right_hand_side', 'RHS of free-surface equation',  &
@@ -844,6 +879,21 @@
       ELSE IF (which.eq.fDIA) THEN
         CALL dia_fields ()
       ELSE
+!  WET_DRY: the wet/dry masks of this record, written without fill values (wrt_his.F:269-310), and the wet x land masks
+!  the other fields of the record are filled with
+      IF (wet_dry) THEN
+        IF (.not.allocated(wfull)) allocate ( wfull(LBi:UBi,LBj:UBj,3) )
+        allocate ( A(LBi:UBi,LBj:UBj,1) )
+        land_fill=.FALSE.
+        CALL fetch ('rmask_wet', 1, A, ierr); CALL put_field (o%h, o%v_fld(77), rec, gR2, A, 1, 1, 1, ierr)
+        CALL fetch ('umask_wet', 1, A, ierr); CALL put_field (o%h, o%v_fld(78), rec, gU2, A, 1, 1, 1, ierr)
+        CALL fetch ('vmask_wet', 1, A, ierr); CALL put_field (o%h, o%v_fld(79), rec, gV2, A, 1, 1, 1, ierr)
+        CALL fetch ('rmask_full', 1, A, ierr); wfull(:,:,1)=A(:,:,1)
+        CALL fetch ('umask_full', 1, A, ierr); wfull(:,:,2)=A(:,:,1)
+        CALL fetch ('vmask_full', 1, A, ierr); wfull(:,:,3)=A(:,:,1)
+        land_fill=is_masked().and..not.rst
+        deallocate ( A )
+      END IF
 !  2-D state
       allocate ( A(LBi:UBi,LBj:UBj,3) )
       CALL wr2 ('zeta', idFsur, gR2, 3)
@@ -1361,7 +1411,7 @@
       integer, intent(out) :: ierr
       integer(c_int) :: h, vid
       integer(c_long) :: nrec, n1
-      integer :: rec, k, itrc, latest
+      integer :: rec, k, itrc, latest, i, j
       integer(c_int) :: iv(1)
       real(r8) :: tv(1), tbest
       real(r8), allocatable :: A(:,:,:), T(:,:,:)
@@ -1427,6 +1477,20 @@
       CALL rd ('rzeta', gR2, 2, A(:,:,1:2)); CALL up ('rzeta', A(:,:,1:2), 2, ierr)
       CALL rd ('rubar', gU2, 2, A(:,:,1:2)); CALL up ('rubar', A(:,:,1:2), 2, ierr)
       CALL rd ('rvbar', gV2, 2, A(:,:,1:2)); CALL up ('rvbar', A(:,:,1:2), 2, ierr)
+      IF (wet_dry) THEN
+!  WET_DRY: the wet/dry masks of the record (get_wetdry.F, initial.F:455); the psi mask -- this writer has no psi grid --
+!  follows from the rho mask as wetdry_avg_mask_tile derives it (wetdry.F:806-861)
+        CALL rd ('wetdry_mask_rho', gR2, 1, A(:,:,1:1)); CALL up ('rmask_wet', A(:,:,1:1), 1, ierr)
+        A(:,:,2)=0.0_r8
+        DO j=LBj+1,UBj
+          DO i=LBi+1,UBi
+            A(i,j,2)=psi_wet(A(i-1,j,1), A(i,j,1), A(i-1,j-1,1), A(i,j-1,1))
+          END DO
+        END DO
+        CALL up ('pmask_wet', A(:,:,2:2), 1, ierr)
+        CALL rd ('wetdry_mask_u', gU2, 1, A(:,:,1:1)); CALL up ('umask_wet', A(:,:,1:1), 1, ierr)
+        CALL rd ('wetdry_mask_v', gV2, 1, A(:,:,1:1)); CALL up ('vmask_wet', A(:,:,1:1), 1, ierr)
+      END IF
       deallocate ( A )
       allocate ( A(LBi:UBi,LBj:UBj,2*N) )
       CALL rd ('u', gU3, 2*N, A); CALL up ('u', A, 2*N, ierr)

@@ -100,7 +100,8 @@ def make_bounds():
 KEEP = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "wvel", "Hz", "z_r", "z_w", "Huon", "Hvom", "rho", "ru", "rv",
         "Zt_avg1", "DU_avg1", "DV_avg1", "DU_avg2", "DV_avg2", "rufrc", "rvfrc", "rzeta", "rubar", "rvbar",
         "Akv", "Akt", "hsbl", "ghats", "stflx", "sustr", "svstr", "bustr", "bvstr", "srflx", "bvf",
-        "tke", "gls", "Lscale", "Akk", "Akp"]
+        "tke", "gls", "Lscale", "Akk", "Akp",
+        "rmask_wet", "umask_wet", "vmask_wet", "pmask_wet", "rmask_full", "umask_full", "vmask_full", "pmask_full", "rmask_wet_avg"]
 
 
 def _kw(args):
@@ -249,6 +250,7 @@ STEP_CASES = [
     # Canuto B with CHARNOK / CRAIG_BANNER / K_C2ADVECTION (k-kl)
     ("upwelling_small_prs40", "upwelling_prs40_small", ["nsteps=60"]),       # PJ_GRADP, prsgrd40.h
     ("upwelling_small_bih", "upwelling_bih_small", ["nsteps=60"]),           # UV_VIS4 + TS_DIF4 along s-surfaces (upwelling_bih.h)
+    ("upwelling_small_wetdry", "upwelling_wetdry_small", ["nsteps=60"]),     # MASKING + WET_DRY (upwelling_wetdry.h; cases.wetdry_depth)
     ("upwelling_gls_small", "upwelling_gls_small", ["nsteps=60"]),
     ("upwelling_gls_ca_small", "upwelling_gls_ca_small", ["nsteps=60"]),
     ("upwelling_gls_cb_small", "upwelling_gls_cb_small", ["nsteps=60"]),

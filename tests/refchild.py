@@ -116,6 +116,8 @@ def mode_kernels(tag, kw):
     t[:] += 0.05 * rng.standard_normal(t.size) * (t != 0)
     R.put("t", t)
     base = dict(iic=4, nstp=2, nnew=1, nrhs=2)
+    if cs.get("wet_dry"):                 # the initial masks from the perturbed free surface and barotropic flow (initial.F:467)
+        both("wetdry", kstp=1, **base)
     both("omega", **base)
     both("pre_step3d", **base)
     perturb(R, O, rng, [("W", 0.5)])

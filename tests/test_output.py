@@ -633,6 +633,45 @@ def test_masked_run_history_and_restart(which, tmp_path):
 
 
 @pytest.mark.parametrize("which", LIBS)
+def test_wetting_and_drying_history_and_restart(which, tmp_path):
+    """WET_DRY: the history file carries wetdry_mask_rho, _u, _v of every record (def_his.F / wrt_his.F under WET_DRY, names and
+    attributes of varinfo.yaml) and its fields are filled with 1e37 where the wet x land mask of THAT record is zero (dry cells
+    as well as land); a run restarted from the restart file (masks read back, get_wetdry.F) continues bit for bit."""
+    cs = util.case_for("upwelling_wetdry_small", hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"))
+    his, rst = str(tmp_path / "his.nc"), str(tmp_path / "rst.nc")
+    cs.update(NHIS=5, NRST=5, HISNAME=his, RSTNAME=rst, Hout=HOUT, ninfo=0, LcycleRST=False)
+    H, ctx = _host(cs, which)
+    H.advance(10, final=True)
+    t = H.tile
+    end = {n: ctx.download(n).copy() for n in ("u", "v", "t", "ubar", "vbar", "rmask_wet", "umask_wet")}
+    H.close_output()
+    H.finalize()
+    f = _nc(his)
+    V = f.variables
+    Lm, Mm = cs["Lm"], cs["Mm"]
+    assert V["wetdry_mask_rho"].shape == (3, Mm + 2, Lm + 2) and V["wetdry_mask_u"].shape == (3, Mm + 2, Lm + 1) and V["wetdry_mask_v"].shape == (3, Mm + 1, Lm + 2)
+    assert V["wetdry_mask_rho"].long_name == b"wet/dry mask on RHO-points" and V["wetdry_mask_u"].field.startswith(b"wet-dry u-mask")
+    wr, mr = V["wetdry_mask_rho"][:], V["mask_rho"][:]
+    assert set(np.unique(wr)) <= {0.0, 1.0} and (wr[:, mr == 0] == 0).all()
+    assert ((wr == 0) & (mr[None] == 1)).sum() > 0                     # dry water cells: the beach
+    z = V["zeta"][:]
+    full = wr * mr[None]
+    assert (z[full == 0] == 1.0e37).all() and (np.abs(z[full == 1]) < 10).all()
+    tt = V["temp"][:]
+    assert (tt[:, :, :, :][np.broadcast_to((full == 0)[:, None], tt.shape)] == 1.0e37).all()
+    f.close()
+    cs2 = dict(cs, NRREC=1, ININAME=rst, NHIS=0, NRST=0, ntimes=10)
+    H2, ctx2 = _host(cs2, which)
+    H2.get_state(rst, 1)
+    H2.advance(5, final=False)
+    ni, nj = t["UBi"] - t["LBi"] + 1, t["UBj"] - t["LBj"] + 1
+    for n, a in end.items():
+        a, b = a.reshape(-1, nj, ni), ctx2.download(n).reshape(-1, nj, ni)
+        assert np.array_equal(util.unpadded(a, cs, ni, nj), util.unpadded(b, cs, ni, nj)), n
+    H2.finalize()
+
+
+@pytest.mark.parametrize("which", LIBS)
 def test_averages_file_of_a_masked_run(which, tmp_path):
     """AVERAGES with MASKING: the records hold the oracle's time averages (pinned to the reference built from
     oracle/ref/upwelling_avg_mask.h) on the water points and 1e37 on land (nf_fwrite2d.F), with _FillValue."""

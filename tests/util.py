@@ -299,7 +299,7 @@ class OracleSide:
         self.cs = cs
         self.g = load_init(init_tag(cs), nghost_for(cs))
         if "MASKING" in cs["options"]:          # the masks are input data of the case (cases.land_mask)
-            self.g = with_masks(cs, self.g)
+            self.g = with_wetdry(cs, self.g) if cs.get("wet_dry") else with_masks(cs, self.g)
         if "gls_flags" in cs:                    # initialize_mixing's values of the closure's arrays
             self.g = with_gls(cs, self.g)
         self.O = make_oracle(cs, self.g)
@@ -356,7 +356,7 @@ class HipSide:
         self.cs = cs
         self.g = load_init(init_tag(cs), nghost_for(cs))
         if "MASKING" in cs["options"]:          # the masks are input data of the case (cases.land_mask)
-            self.g = with_masks(cs, self.g)
+            self.g = with_wetdry(cs, self.g) if cs.get("wet_dry") else with_masks(cs, self.g)
         if "gls_flags" in cs:
             self.g = with_gls(cs, self.g)
         self.H = make_hip(cs, self.g, ninfo=ninfo)
