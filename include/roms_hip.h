@@ -252,7 +252,8 @@ int roms_hip_mix4_config(roms_hip_ctx *ctx, int uv_vis4, int ts_dif4);
    "vmask_wet", "pmask_wet" (of the fast steps while they run, time-averaged for the 3-D step behind them), "rmask_full",
    "umask_full", "vmask_full", "pmask_full" (wet x land: what the output files mask with) and "rmask_wet_avg".
    roms_hip_wetdry_ini: the initial masks from zeta(kstp) (initial.F:467; wetdry.F:355-490), before the first step.
-   exit_flag 5 where the reference's WET_DRY statements are not built on the device: open boundaries, MPDATA, BULK_FLUXES,
+   Open boundaries take the WET_DRY forms of zetabc.F:190 (Chapman), u2dbc_im.F:339 (Shchepetkin), u3dbc_im.F:174 ...
+   exit_flag 5 where the reference's WET_DRY statements are not built on the device: MPDATA, BULK_FLUXES,
    SOLAR_SOURCE, the closures (LMD / GLS / MY25), geopotential / isopycnic / biharmonic mixing, prsgrd31 / prsgrd40,
    no SPLINES_VVISC, averages, diagnostics. */
 int roms_hip_wetdry_config(roms_hip_ctx *ctx, double Dcrit);

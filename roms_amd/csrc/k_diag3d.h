@@ -587,7 +587,11 @@ THREAD_KERNEL(k_ini_mask, KArgs) {
   const int i = KMIN(B.IstrM, B.IstrB) + gx, j = B.JstrB + gy, nstp = G.nstp, kstp = G.kstp;
   if (a.p0 == 3) {     // free surface with radiation / Chapman conditions: the boundary points too (ini_fields.F:830-849; index space IstrT:IendT x JstrT:JendT)
     const int it = B.IstrT + gx, jt = B.JstrT + gy;
-    if (it <= B.IendT && jt <= B.JendT) F.zeta[X2T(it, jt, kstp)] = F.zeta[X2T(it, jt, kstp)] * F.rmask[X2(it, jt)];
+    if (it <= B.IendT && jt <= B.JendT) {
+      double cff1 = F.zeta[X2T(it, jt, kstp)] * F.rmask[X2(it, jt)];
+      if (G.wet_dry && cff1 <= (G.Dcrit - F.h[X2(it, jt)])) cff1 = G.Dcrit - F.h[X2(it, jt)];    // WET_DRY ini_fields.F:850-851
+      F.zeta[X2T(it, jt, kstp)] = cff1;
+    }
   } else if (a.p0 == 0) {
     if (i >= B.IstrB && i <= B.IendB) {
       double cff1 = F.zeta[X2T(i, j, kstp)] * F.rmask[X2(i, j)];

@@ -47,6 +47,75 @@ KDEV double *halo_plane(const ArgT &a, int bz, int &bc, int &gtype) {
   return A;
 }
 
+// WET_DRY, barotropic state: the conditions at the end of zetabc.F:783-874 ("water level on boundary cells above bed
+// elevation"), u2dbc_im.F:1190-1318 and v2dbc_im.F:1239-1367 AS WRITTEN, whatever the kind of boundary condition: the factor
+// of the barotropic step from the wet mask and the value at one point, applied at that point -- except v2dbc's western edge,
+// which takes mask and sign at Istr-1 and scales the value at Istr (v2dbc_im.F:1250-1255), and u2dbc's northern edge, whose
+// loop starts at Istr (:1243).  By one thread block, behind the edge fills and corner values (halo_fill below, k_obc.h).
+KDEV void wet_tail2(const DGrid &G, double *A, int bc) {
+  const TB &B = G.T;
+  const int Istr = B.Istr, Iend = B.Iend, Jstr = B.Jstr, Jend = B.Jend;
+  if (bc == BC_R) {
+    const double cff = G.Dcrit - 1.0E-20;
+#define WDZ_(i_, j_) do { const size_t q_ = X2(i_, j_); if (A[q_] <= (G.Dcrit - G.hbath[q_])) A[q_] = cff - G.hbath[q_]; } while (0)
+    if (!G.ewp) {
+      if (B.west) KLOOP1(j, Jstr, Jend) WDZ_(Istr - 1, j);
+      if (B.east) KLOOP1(j, Jstr, Jend) WDZ_(Iend + 1, j);
+    }
+    if (!G.nsp) {
+      if (B.south) KLOOP1(i, Istr, Iend) WDZ_(i, Jstr - 1);
+      if (B.north) KLOOP1(i, Istr, Iend) WDZ_(i, Jend + 1);
+    }
+    if (!(G.ewp || G.nsp) && KTID == 0) {
+      if (B.sw) WDZ_(Istr - 1, Jstr - 1);
+      if (B.se) WDZ_(Iend + 1, Jstr - 1);
+      if (B.nw) WDZ_(Istr - 1, Jend + 1);
+      if (B.ne) WDZ_(Iend + 1, Jend + 1);
+    }
+#undef WDZ_
+  } else if (bc == BC_U || bc == BC_V) {
+    const double *mw = bc == BC_U ? G.umask_wet : G.vmask_wet;
+#define WDP_(mi, mj, ti, tj) do { const size_t m_ = X2(mi, mj), t_ = X2(ti, tj); A[t_] = A[t_] * wd_fac(mw[m_], A[m_]); } while (0)
+    if (bc == BC_U) {
+      if (!G.ewp) {
+        if (B.west) KLOOP1(j, Jstr, Jend) WDP_(Istr, j, Istr, j);
+        if (B.east) KLOOP1(j, Jstr, Jend) WDP_(Iend + 1, j, Iend + 1, j);
+      }
+      KSYNC();
+      if (!G.nsp) {
+        if (B.south) KLOOP1(i, B.IstrU, Iend) WDP_(i, Jstr - 1, i, Jstr - 1);
+        if (B.north) KLOOP1(i, Istr, Iend) WDP_(i, Jend + 1, i, Jend + 1);
+      }
+      KSYNC();
+      if (!(G.ewp || G.nsp) && KTID == 0) {
+        if (B.sw) WDP_(Istr, Jstr - 1, Istr, Jstr - 1);
+        if (B.se) WDP_(Iend + 1, Jstr - 1, Iend + 1, Jstr - 1);
+        if (B.nw) WDP_(Istr, Jend + 1, Istr, Jend + 1);
+        if (B.ne) WDP_(Iend + 1, Jend + 1, Iend + 1, Jend + 1);
+      }
+    } else {
+      if (!G.ewp) {
+        if (B.west) KLOOP1(j, B.JstrV, Jend) WDP_(Istr - 1, j, Istr, j);
+        if (B.east) KLOOP1(j, B.JstrV, Jend) WDP_(Iend + 1, j, Iend + 1, j);
+      }
+      KSYNC();
+      if (!G.nsp) {
+        if (B.south) KLOOP1(i, Istr, Iend) WDP_(i, Jstr, i, Jstr);
+        if (B.north) KLOOP1(i, Istr, Iend) WDP_(i, Jend + 1, i, Jend + 1);
+      }
+      KSYNC();
+      if (!(G.ewp || G.nsp) && KTID == 0) {
+        if (B.sw) WDP_(Istr - 1, Jstr, Istr - 1, Jstr);
+        if (B.se) WDP_(Iend + 1, Jstr, Iend + 1, Jstr);
+        if (B.nw) WDP_(Istr - 1, Jend + 1, Istr - 1, Jend + 1);
+        if (B.ne) WDP_(Iend + 1, Jend + 1, Iend + 1, Jend + 1);
+      }
+    }
+#undef WDP_
+  }
+  KSYNC();
+}
+
 // boundary fills and local periodic copies of one plane, by one thread block
 KDEV void halo_fill(const DGrid &G, double *A, int bcf, int gtype) {
   const TB &B = G.T;
@@ -180,71 +249,7 @@ KDEV void halo_fill(const DGrid &G, double *A, int bcf, int gtype) {
     }
   }
   KSYNC();
-  // ---- WET_DRY, barotropic state: the conditions at the end of zetabc.F:783-874 ("water level on boundary cells above
-  // bed elevation"), u2dbc_im.F:1190-1318 and v2dbc_im.F:1239-1367 AS WRITTEN: the factor of the barotropic step from the
-  // wet mask and the value at one point, applied at that point -- except v2dbc's western edge, which takes mask and sign at
-  // Istr-1 and scales the value at Istr (v2dbc_im.F:1250-1255), and u2dbc's northern edge, whose loop starts at Istr (:1243)
-  if (G.wet_dry && (bcf & BC_WET2)) {
-    if (bc == BC_R) {
-      const double cff = G.Dcrit - 1.0E-20;
-#define WDZ_(i_, j_) do { const size_t q_ = X2(i_, j_); if (A[q_] <= (G.Dcrit - G.hbath[q_])) A[q_] = cff - G.hbath[q_]; } while (0)
-      if (!G.ewp) {
-        if (B.west) KLOOP1(j, Jstr, Jend) WDZ_(Istr - 1, j);
-        if (B.east) KLOOP1(j, Jstr, Jend) WDZ_(Iend + 1, j);
-      }
-      if (!G.nsp) {
-        if (B.south) KLOOP1(i, Istr, Iend) WDZ_(i, Jstr - 1);
-        if (B.north) KLOOP1(i, Istr, Iend) WDZ_(i, Jend + 1);
-      }
-      if (!(G.ewp || G.nsp) && KTID == 0) {
-        if (B.sw) WDZ_(Istr - 1, Jstr - 1);
-        if (B.se) WDZ_(Iend + 1, Jstr - 1);
-        if (B.nw) WDZ_(Istr - 1, Jend + 1);
-        if (B.ne) WDZ_(Iend + 1, Jend + 1);
-      }
-#undef WDZ_
-    } else if (bc == BC_U || bc == BC_V) {
-      const double *mw = bc == BC_U ? G.umask_wet : G.vmask_wet;
-#define WDP_(mi, mj, ti, tj) do { const size_t m_ = X2(mi, mj), t_ = X2(ti, tj); A[t_] = A[t_] * wd_fac(mw[m_], A[m_]); } while (0)
-      if (bc == BC_U) {
-        if (!G.ewp) {
-          if (B.west) KLOOP1(j, Jstr, Jend) WDP_(Istr, j, Istr, j);
-          if (B.east) KLOOP1(j, Jstr, Jend) WDP_(Iend + 1, j, Iend + 1, j);
-        }
-        KSYNC();
-        if (!G.nsp) {
-          if (B.south) KLOOP1(i, B.IstrU, Iend) WDP_(i, Jstr - 1, i, Jstr - 1);
-          if (B.north) KLOOP1(i, Istr, Iend) WDP_(i, Jend + 1, i, Jend + 1);
-        }
-        KSYNC();
-        if (!(G.ewp || G.nsp) && KTID == 0) {
-          if (B.sw) WDP_(Istr, Jstr - 1, Istr, Jstr - 1);
-          if (B.se) WDP_(Iend + 1, Jstr - 1, Iend + 1, Jstr - 1);
-          if (B.nw) WDP_(Istr, Jend + 1, Istr, Jend + 1);
-          if (B.ne) WDP_(Iend + 1, Jend + 1, Iend + 1, Jend + 1);
-        }
-      } else {
-        if (!G.ewp) {
-          if (B.west) KLOOP1(j, B.JstrV, Jend) WDP_(Istr - 1, j, Istr, j);
-          if (B.east) KLOOP1(j, B.JstrV, Jend) WDP_(Iend + 1, j, Iend + 1, j);
-        }
-        KSYNC();
-        if (!G.nsp) {
-          if (B.south) KLOOP1(i, Istr, Iend) WDP_(i, Jstr, i, Jstr);
-          if (B.north) KLOOP1(i, Istr, Iend) WDP_(i, Jend + 1, i, Jend + 1);
-        }
-        KSYNC();
-        if (!(G.ewp || G.nsp) && KTID == 0) {
-          if (B.sw) WDP_(Istr - 1, Jstr, Istr - 1, Jstr);
-          if (B.se) WDP_(Iend + 1, Jstr, Iend + 1, Jstr);
-          if (B.nw) WDP_(Istr - 1, Jend + 1, Istr - 1, Jend + 1);
-          if (B.ne) WDP_(Iend + 1, Jend + 1, Iend + 1, Jend + 1);
-        }
-      }
-#undef WDP_
-    }
-    KSYNC();
-  }
+  if (G.wet_dry && (bcf & BC_WET2)) wet_tail2(G, A, bc);          // WET_DRY: the wetting/drying conditions of zetabc / u2dbc / v2dbc
   // ---- MASKING: the whole plane times rmask, boundary points included (step3d_t.F:1880-1890)
   if (G.masking && (bcf & BC_MASKALL)) {
     KLOOP2(i, j, B.IstrR, B.IendR, B.JstrR, B.JendR) A[X2(i, j)] = A[X2(i, j)] * G.rmask[X2(i, j)];

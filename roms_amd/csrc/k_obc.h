@@ -23,6 +23,7 @@
 // reproduces it.
 #pragma once
 #include "roms_ctx.h"
+#include "k_halo.h"          // wet_tail2
 
 struct ObcItem {
   double *Qo;            // first plane of the level being set (kout / nout)
@@ -125,6 +126,7 @@ KDEV void obc_edge_fill(const ObcArgs &a, const ObcItem &it, const ObcEdge &E, d
         const int i = E.i0 + E.ti * s, j = E.j0 + E.tj * s;
         double v = gamma2 * Qo[X2(i + E.di, j + E.dj)];
         if (msk) v = v * qmask[X2(i, j)];
+        if (G.wet_dry && !it.is2d) v = v * (grid == 'u' ? G.umask_wet : G.vmask_wet)[X2(i, j)];      // WET_DRY u3dbc_im.F:523,681
         Qo[X2(i, j)] = v;
       }
     }
@@ -148,7 +150,8 @@ KDEV void obc_edge_fill(const ObcArgs &a, const ObcItem &it, const ObcEdge &E, d
       val = bv;
     } else if (kind == ROMS_LBC_CHE || kind == ROMS_LBC_CHI) {       // free surface, zetabc.F:186-227
       const double cff = dtn * pmn[X2(i1, j1)];
-      const double cff1 = sqrt(g * (a.h[X2(i1, j1)] + Qn[X2(i1, j1)]));
+      const double dep = a.h[X2(i1, j1)] + Qn[X2(i1, j1)];
+      const double cff1 = sqrt(g * (G.wet_dry ? (dep > G.Dcrit ? dep : G.Dcrit) : dep));            // WET_DRY: MAX(..., Dcrit) zetabc.F:190-192
       const double Cx = cff * cff1;
       if (kind == ROMS_LBC_CHE) val = (1.0 - Cx) * Qn[X2(i, j)] + Cx * Qn[X2(i1, j1)];
       else { const double cff2 = 1.0 / (1.0 + Cx); val = cff2 * (Qn[X2(i, j)] + Cx * Qo[X2(i1, j1)]); }
@@ -164,7 +167,7 @@ KDEV void obc_edge_fill(const ObcArgs &a, const ObcItem &it, const ObcEdge &E, d
         const double d = Cx * (0.5 * (Zn[lo] + Zn[hi]) - zb);
         val = low ? bv - d : bv + d;
       } else {                                                       // Shchepetkin :296-369, :647-720
-        const double cff = 0.5 * (a.h[lo] + a.h[hi]);
+        const double cff = G.wet_dry ? 0.5 * (a.h[lo] + Zn[lo] + a.h[hi] + Zn[hi]) : 0.5 * (a.h[lo] + a.h[hi]);   // WET_DRY u2dbc_im.F:339-347
         const double cff1 = sqrt(g / cff);
         const double Cx = dtn * cff1 * cff * 0.5 * (pmn[lo] + pmn[hi]);
         double Zx = (0.5 + Cx) * Zn[in] + (0.5 - Cx) * Zn[out];
@@ -191,6 +194,10 @@ KDEV void obc_edge_fill(const ObcArgs &a, const ObcItem &it, const ObcEdge &E, d
       val = Qo[X2(i1, j1)];
     }
     if (msk) val = val * qmask[X2(i, j)];
+    // WET_DRY: every open kind of u3dbc / v3dbc times the wet mask of the boundary point (u3dbc_im.F:174,193,212 ...), but u's
+    // gradient condition at the southern edge: the reference guards that one with "WET_MASK" (u3dbc_im.F:496), a name nothing defines
+    if (G.wet_dry && !it.is2d && grid != 'r' && !(grid == 'u' && E.e == ROMS_ISOUTH && kind == ROMS_LBC_GRA))
+      val = val * (grid == 'u' ? G.umask_wet : G.vmask_wet)[X2(i, j)];
     Qo[X2(i, j)] = val;
   }
 }
@@ -239,6 +246,10 @@ COOP_KERNEL(k_obc, ObcArgs) {
           if (B.nw) A[X2(Istr - 1, Jend + 1)] = 0.5 * (A[X2(Istr - 1, Jend)] + A[X2(Istr, Jend + 1)]);
           if (B.ne) A[X2(Iend + 1, Jend + 1)] = 0.5 * (A[X2(Iend + 1, Jend)] + A[X2(Iend, Jend + 1)]);
         }
+      }
+      if (G.wet_dry && it.is2d) {       // WET_DRY: the wetting/drying conditions at the end of zetabc / u2dbc / v2dbc (k_halo.h)
+        KSYNC();
+        wet_tail2(G, Qo, it.grid == 'r' ? BC_R : it.grid == 'u' ? BC_U : BC_V);
       }
     }
     first += nk;

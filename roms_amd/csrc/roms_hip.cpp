@@ -1978,15 +1978,15 @@ extern "C" int roms_hip_mix4_config(roms_hip_ctx *c, int uv_vis4, int ts_dif4) {
 // step3d_uv.F:720-721,1187-1188,1359,1579 and its boundary rows, set_vbc.F:307-308,397 and LIMIT_BSTRESS (globaldefs.h:160),
 // ini_fields.F:294-403,850, zetabc.F:783-874, u2dbc_im.F:1190-1318, v2dbc_im.F:1239-1367, u3dbc_im.F:523,681.  Dcrit = DCRIT of
 // roms.in.  roms_hip_wetdry_ini sets the initial masks (initial.F:467).  Call between roms_hip_create and roms_hip_start.
+// Open boundaries: the WET_DRY forms of zetabc.F:190 (Chapman), u2dbc_im.F:339 (Shchepetkin), u3dbc_im.F:174 ... in k_obc.h.
 // Refused (exit_flag 5) where the reference's WET_DRY statements are not built on the device: no MASKING (globaldefs.h:152
-// switches it on), open boundaries, MPDATA, BULK_FLUXES, SOLAR_SOURCE, the closures (KPP, GLS, MY2.5), geopotential / isopycnic
+// switches it on), MPDATA, BULK_FLUXES, SOLAR_SOURCE, the closures (KPP, GLS, MY2.5), geopotential / isopycnic
 // / biharmonic mixing, the pressure Jacobians other than prsgrd32, averages and diagnostics.
 extern "C" int roms_hip_wetdry_config(roms_hip_ctx *c, double Dcrit) {
   if (!c) return 8;
   DGrid &G = c->G;
   const int opt = G.options;
   if (!G.masking) { set_error("WET_DRY: needs MASKING (globaldefs.h:152-154 defines it with WET_DRY)"); return 5; }
-  if (G.obc) { set_error("WET_DRY with open boundaries: the WET_DRY forms of the open conditions (zetabc.F:190, u2dbc_im.F:339, u3dbc_im.F:174 ...) are not built on the device"); return 5; }
   for (int it = 0; it < G.NT; it++)
     if (G.hadv[it] == ROMS_MPDATA || G.vadv[it] == ROMS_MPDATA) { set_error("WET_DRY with MPDATA tracers: mpdata_adiff.F's wet masks are not built"); return 5; }
   if (opt & (ROMS_BULK_FLUXES | ROMS_SOLAR_SOURCE | ROMS_LMD_MIXING | ROMS_GLS_MIXING | ROMS_MY25_MIXING)) {

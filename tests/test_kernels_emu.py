@@ -180,6 +180,51 @@ def test_wetting_and_drying_bitwise(emu, hadv, vadv, ewp):
     H.close()
 
 
+WD_OBC = {
+    # open western and eastern edges, walls south and north (the beach ends at the northern wall)
+    "we": dict(zeta=("Che", "Clo", "Rad", "Clo"), ubar=("Shc", "Clo", "Rad", "Clo"), vbar=("Shc", "Clo", "Gra", "Clo"),
+               u=("RadNud", "Clo", "Gra", "Clo"), v=("Gra", "Clo", "RadNud", "Clo"), temp=("RadNud", "Clo", "Cla", "Clo"),
+               salt=("Cla", "Clo", "Gra", "Clo")),
+    # all four edges open: the northern one lies on the dry beach (zetabc's "water level above bed elevation"), u's gradient
+    # condition at the southern edge is the one the reference leaves without the wet mask
+    "four": dict(zeta=("Cha", "Gra", "Che", "Cla"), ubar=("Fla", "Gra", "Shc", "Rad"), vbar=("Fla", "Shc", "Gra", "Rad"),
+                 u=("Gra", "Gra", "Rad", "Cla"), v=("Rad", "Gra", "Gra", "Gra"), temp=("Rad", "Gra", "Gra", "Rad"),
+                 salt=("Gra", "Rad", "Rad", "Gra")),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(WD_OBC))
+def test_wetting_and_drying_with_open_boundaries_bitwise(emu, variant):
+    """WET_DRY together with open boundaries (k_obc.h: Chapman with MAX(depth, Dcrit), Shchepetkin with the free surface in its
+    depth, the wet masks on every open kind of u3dbc / v3dbc but the one the reference guards with an undefined name, the
+    wetting/drying conditions behind zetabc / u2dbc / v2dbc; the oracle's routines are pinned to the reference's under every
+    kind, tests/test_oracle_vs_ref.py): 20 steps against the oracle, bit for bit, masks included."""
+    cs = util.case_for("upwelling_wetdry_small", hadv=("U3", "U3"), vadv=("C4", "C4"))
+    cs["EWperiodic"] = 0
+    cs["lbc"] = WD_OBC[variant]
+    cs.update(Znudg=0.5, M2nudg=0.25, M3nudg=2.0, Tnudg=(1.0, 3.0), obcfac=4.0)
+    g = util.with_wetdry(cs, util.closed_basin_state(cs, util.load_init("upwelling_small", util.nghost_for(cs))))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    rng = np.random.default_rng(3)
+    from roms_amd import hiplib
+    for n in hiplib.BRY_FIELDS:
+        a = O.field(n)
+        a[:] = (15.0 if n[0] == "t" else 0.0) + 0.01 * rng.standard_normal(a.size)
+        H.upload(n, a)
+    O.start()
+    H.start()
+    for _ in range(20):
+        O.main3d_step()
+        H.main3d(1)
+        for n in util.PROGNOSTIC + util.WET_FIELDS:
+            a, b = H.download(n), O.field(n)
+            assert np.isfinite(b).all(), n
+            assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
+    assert np.abs(O.field("u")).max() > 0.01 and (O.field("rmask_wet") == 0).sum() > (g["rmask"] == 0).sum()
+    H.close()
+
+
 def test_wetting_and_drying_through_the_fortran_host_matches_the_oracle(emu):
     """roms.in (MyAppCPP = UPWELLING_WETDRY, DCRIT) -> Fortran host (WET_DRY switches MASKING on; its analytic beach and ridge of
     water; roms_hip_wetdry_config / _ini) -> C ABI -> kernels: the host's bathymetry and initial free surface are the numbers of
