@@ -127,8 +127,8 @@ typedef struct roms_hip_config {
   double FSobc_in[4], FSobc_out[4], M2obc_in[4], M2obc_out[4], M3obc_in[4], M3obc_out[4];
   double Tobc_in[ROMS_MAXT][4], Tobc_out[ROMS_MAXT][4];
   /* GLS_MIXING (ABI version 3): ROMS_GLS_* flags; GLS_P ... GLS_SIGP, AKK_BAK, AKP_BAK, Zos, CHARNOK_ALPHA, CRGBAN_CW of
-     roms.in (read_phypar.F); LBC(isMtke) per edge: closed, gradient or periodic (tkebc_im.F; its radiation condition
-     is not built).  State arrays "tke", "gls" (i,j,0:N,3), "Lscale", "Akk", "Akp" (i,j,0:N) of mod_mixing.F. */
+     roms.in (read_phypar.F); LBC(isMtke) per edge: closed, gradient, radiation or periodic (tkebc_im.F:46-700; radiation with
+     GLS_MIXING, not with MY25_MIXING).  State arrays "tke", "gls" (i,j,0:N,3), "Lscale", "Akk", "Akp" (i,j,0:N) of mod_mixing.F. */
   int gls_flags;
   double gls_p, gls_m, gls_n, gls_Kmin, gls_Pmin, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp;
   double Akk_bak, Akp_bak, Zos, charnok_alpha, crgban_cw;

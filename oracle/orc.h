@@ -120,6 +120,7 @@ typedef struct {
   int gls_flags;
   double gls_p, gls_m, gls_n, gls_Kmin, gls_Pmin, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp;
   double Akk_bak, Akp_bak, Zos, charnok_alpha, crgban_cw;
+  int lbc_tke[4];                       /* LBC(isMtke) [iwest, isouth, ieast, inorth]: 0 = closed / periodic as the direction is; ORC_LBC_GRA, ORC_LBC_RAD (tkebc_im.F) */
 } orc_cfg;
 
 /* time-level state of main3d / mod_stepping */
@@ -222,6 +223,7 @@ void orc_bc_v3d(const orc_t *o, const orc_bounds *b, double *A, int nk);
 void orc_bc_w3d(const orc_t *o, const orc_bounds *b, double *A, int nk);
 /* state BCs: zetabc.F u2dbc_im.F v2dbc_im.F t3dbc_im.F u3dbc_im.F v3dbc_im.F */
 void orc_zetabc(const orc_t *o, const orc_bounds *b, int kout);
+void orc_tkebc(const orc_t *o, const orc_bounds *b, int nout);   /* tkebc_im.F */
 void orc_u2dbc(const orc_t *o, const orc_bounds *b, int kout);
 void orc_v2dbc(const orc_t *o, const orc_bounds *b, int kout);
 void orc_t3dbc(const orc_t *o, const orc_bounds *b, int nout, int itrc);

@@ -71,36 +71,8 @@ static void orc_gls_consts(int flags, gls_consts *q) {
   }
 }
 
-/* tkebc_im.F: zero gradient at closed and gradient edges (:188-232 ...), corners :640-700 */
-static void tkebc(const orc_t *o, const orc_bounds *b, int nout) {
-  ORC_LOCALS(o);
-  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
-  const int ewp = o->c.EWperiodic, nsp = o->c.NSperiodic;
-  const double *rmask = o->rmask;
-  for (int f = 0; f < 2; f++) {
-    double *A = (f == 0 ? o->tke : o->gls) + (size_t)(nout - 1) * nij * (N + 1);
-    /* (the reference sets tke then gls per point; the two fields are independent) */
-    if (b->west && !ewp)
-      for (int k = 0; k <= N; k++)
-        for (int j = Jstr; j <= Jend; j++) A[XW(Istr - 1, j, k)] = A[XW(Istr, j, k)] * rmask[X2(Istr - 1, j)];
-    if (b->east && !ewp)
-      for (int k = 0; k <= N; k++)
-        for (int j = Jstr; j <= Jend; j++) A[XW(Iend + 1, j, k)] = A[XW(Iend, j, k)] * rmask[X2(Iend + 1, j)];
-    if (b->south && !nsp)
-      for (int k = 0; k <= N; k++)
-        for (int i = Istr; i <= Iend; i++) A[XW(i, Jstr - 1, k)] = A[XW(i, Jstr, k)] * rmask[X2(i, Jstr - 1)];
-    if (b->north && !nsp)
-      for (int k = 0; k <= N; k++)
-        for (int i = Istr; i <= Iend; i++) A[XW(i, Jend + 1, k)] = A[XW(i, Jend, k)] * rmask[X2(i, Jend + 1)];
-    if (!(ewp || nsp))
-      for (int k = 0; k <= N; k++) {
-        if (b->sw) A[XW(Istr - 1, Jstr - 1, k)] = 0.5 * (A[XW(Istr, Jstr - 1, k)] + A[XW(Istr - 1, Jstr, k)]);
-        if (b->se) A[XW(Iend + 1, Jstr - 1, k)] = 0.5 * (A[XW(Iend, Jstr - 1, k)] + A[XW(Iend + 1, Jstr, k)]);
-        if (b->nw) A[XW(Istr - 1, Jend + 1, k)] = 0.5 * (A[XW(Istr, Jend + 1, k)] + A[XW(Istr - 1, Jend, k)]);
-        if (b->ne) A[XW(Iend + 1, Jend + 1, k)] = 0.5 * (A[XW(Iend, Jend + 1, k)] + A[XW(Iend + 1, Jend, k)]);
-      }
-  }
-}
+/* tkebc_im.F: oracle/orc_obc.c (radiation, gradient and closed edges) */
+static void tkebc(const orc_t *o, const orc_bounds *b, int nout) { orc_tkebc(o, b, nout); }
 
 /* gls_prestep_tile, gls_prestep.F:95 */
 void orc_gls_prestep(orc_t *o, int tile) {

@@ -463,6 +463,38 @@ static void bc3d(const orc_t *o, const orc_bounds *b, int nout, char grid, int i
     else corners_r(o, b, Qo);
   }
 }
+/* tkebc_tile, tkebc_im.F:46-700: turbulent kinetic energy and length-scale variable at level nout, W-points 0..N --
+   radiation (:98-186 ...: the scheme of t3dbc without nudging, differences of level nstp), zero gradient at gradient and
+   closed edges (:188-232), corners :640-700 */
+void orc_tkebc(const orc_t *o, const orc_bounds *b, int nout) {
+  ORC_LOCALS(o);
+  const int nstp = o->s.nstp;
+  const int msk = (o->c.options & ORC_MASKING) != 0;
+  static const int order[4] = { ORC_IWEST, ORC_IEAST, ORC_ISOUTH, ORC_INORTH };
+  for (int f = 0; f < 2; f++) {
+    double *A = f == 0 ? o->tke : o->gls;
+    for (int k = 0; k <= N; k++) {
+      double *Qo = A + ((size_t)(nout - 1) * (N + 1) + (size_t)k) * nij;
+      const double *Qn = A + ((size_t)(nstp - 1) * (N + 1) + (size_t)k) * nij;
+      for (int q = 0; q < 4; q++) {
+        edge_t E;
+        if (!edge_setup(o, b, order[q], 'r', &E)) continue;
+        const int kind = o->c.lbc_tke[E.e];
+        const double *fm = msk ? (E.ti ? o->umask : o->vmask) : NULL;
+        for (int s = E.s0; s <= E.s1; s++) {
+          const int i = EI(&E, s), j = EJ(&E, s);
+          double val;
+          if (kind == ORC_LBC_RAD) val = rad_point(o, &E, Qn, Qo, i, j, fm, 0, 0.0, 0.0, o->c.dt, 0.0, 0);
+          else val = Qo[X2(i + E.di, j + E.dj)];
+          if (msk) val = val * o->rmask[X2(i, j)];
+          Qo[X2(i, j)] = val;
+        }
+      }
+      corners_r(o, b, Qo);
+    }
+  }
+}
+
 void orc_u3dbc(const orc_t *o, const orc_bounds *b, int nout) { bc3d(o, b, nout, 'u', 0); }
 void orc_v3dbc(const orc_t *o, const orc_bounds *b, int nout) { bc3d(o, b, nout, 'v', 0); }
 void orc_t3dbc(const orc_t *o, const orc_bounds *b, int nout, int itrc) { bc3d(o, b, nout, 'r', itrc); }

@@ -130,6 +130,18 @@
         END DO
       END DO
 !
+#if defined GLS_MIXING || defined MY25_MIXING
+!  LBC(isMtke): ipar(46:49) at iwest, isouth, ieast, inorth (0 = the default above, 1 Clo, 3 Gra, 5 Rad: tkebc_im.F)
+      DO ibry=1,4
+        IF (ipar(45+ibry).ne.0) THEN
+          LBC(ibry,isMtke,ng)%closed=ipar(45+ibry).eq.1
+          LBC(ibry,isMtke,ng)%periodic=.FALSE.
+          LBC(ibry,isMtke,ng)%gradient=ipar(45+ibry).eq.3
+          LBC(ibry,isMtke,ng)%radiation=ipar(45+ibry).eq.5
+        END IF
+      END DO
+#endif
+!
 !  Open boundaries: ipar(17+4*(v-1)+(ibry-1)) = kind of variable v (1 isFsur, 2 isUbar, 3 isVbar, 4 isUvel,
 !  5 isVvel, 6.. isTvar) at edge ibry (iwest, isouth, ieast, inorth), coded as oracle/orc.h does (0 = leave the
 !  default above; 1 Clo 2 Per 3 Gra 4 Cla 5 Rad 6 RadNud 7 Che 8 Cha 9 Fla 10 Shc); flags as load_lbc sets them

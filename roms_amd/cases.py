@@ -345,6 +345,8 @@ def gls_cfg(c, cs, flag_table):
         c.gls_flags |= flag_table[n]
     for n in GLS_NAMES + ("Akk_bak", "Akp_bak", "charnok_alpha", "crgban_cw"):
         setattr(c, n, cs[n])
+    for e, k in enumerate(cs.get("lbc_tke", ())):        # LBC(isMtke) (west, south, east, north): "Clo", "Gra", "Rad", "Per"
+        c.lbc_tke[e] = LBC_KINDS[k]
 
 
 def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):

@@ -83,6 +83,11 @@ static GlsArgs gls_args(roms_hip_ctx *c) {
   return a;
 }
 
+static bool tke_radiates(const roms_hip_ctx *c) {
+  for (int e = 0; e < 4; e++) if (c->cfg.lbc_tke[e] == ROMS_LBC_RAD) return true;
+  return false;
+}
+
 // gls_prestep_tile gls_prestep.F:95; tkebc_tile (index 3) and the exchanges :441-466
 int run_gls_prestep(roms_hip_ctx *c) {
   const DGrid &G = c->G;
@@ -90,7 +95,10 @@ int run_gls_prestep(roms_hip_ctx *c) {
   const GlsArgs a = gls_args(c);
   LAUNCH_THREAD(k_gls_pre, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, G.N - 1, c->stream, a);
   const size_t lev = (size_t)G.nij * (size_t)(G.N + 1);
-  HaloSpec sp[2] = {{c->F.tke + 2 * lev, G.N + 1, bc_rstate(c), 'r'}, {c->F.gls + 2 * lev, G.N + 1, bc_rstate(c), 'r'}};
+  const bool rad = tke_radiates(c);                   // LBC(isMtke) radiation on an edge: tkebc through k_obc.h, then only the exchange
+  if (rad) { int r = run_obc_tke(c, 3); if (r) return r; }
+  const int bc = rad ? (bc_rstate(c) & ~BC_KIND) : bc_rstate(c);
+  HaloSpec sp[2] = {{c->F.tke + 2 * lev, G.N + 1, bc, 'r'}, {c->F.gls + 2 * lev, G.N + 1, bc, 'r'}};
   launch_halo_tail(c, sp, 2);
   return 0;
 }
@@ -118,8 +126,11 @@ int run_gls_corstep(roms_hip_ctx *c) {
     e.p1 = 1; LAUNCH_THREAD(k_my25_edges, nx, 1, np, c->stream, e);
     e.p1 = 2; LAUNCH_THREAD(k_my25_edges, 1, 1, np, c->stream, e);
   }
-  HaloSpec sp[4] = {{c->F.tke + (size_t)(G.nnew - 1) * lev, G.N + 1, bc_rstate(c), 'r'},
-                    {c->F.gls + (size_t)(G.nnew - 1) * lev, G.N + 1, bc_rstate(c), 'r'},
+  const bool rad = tke_radiates(c);
+  if (rad) { int r = run_obc_tke(c, G.nnew); if (r) return r; }
+  const int bck = rad ? (bc_rstate(c) & ~BC_KIND) : bc_rstate(c);
+  HaloSpec sp[4] = {{c->F.tke + (size_t)(G.nnew - 1) * lev, G.N + 1, bck, 'r'},
+                    {c->F.gls + (size_t)(G.nnew - 1) * lev, G.N + 1, bck, 'r'},
                     {c->F.Akv, G.N + 1, my25 ? BC_NONE : BC_R, 'r'},
                     {c->F.Akt, (G.N + 1) * G.NAT, my25 ? BC_NONE : BC_R, 'r'}};
   launch_halo_tail(c, sp, 4);

@@ -78,3 +78,26 @@ int run_obc3d_t(roms_hip_ctx *c, int nout, int itrc) {
   LAUNCH_COOP(k_obc, 1, 1, G.N, 256, 0, c->stream, a);
   return 0;
 }
+
+// tkebc_tile (tkebc_im.F:46-700) of level nout when an edge radiates: tke and gls, W-points 0..N, kinds of LBC(isMtke)
+// (radiation: the scheme of t3dbc without nudging, differences of level nstp; zero gradient at gradient and closed edges)
+int run_obc_tke(roms_hip_ctx *c, int nout) {
+  const DGrid &G = c->G;
+  const roms_hip_config &cf = c->cfg;
+  ObcArgs a;
+  obc_common(c, a);
+  a.dtn = G.dt;
+  const size_t lev = (size_t)G.nij * (size_t)(G.N + 1);
+  static const double zero[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int q = 0; q < 2; q++) {
+    double *A = q == 0 ? (double *)c->F.tke : (double *)c->F.gls;
+    obc_item(c, a.it[q], A + (size_t)(nout - 1) * lev, A + (size_t)(G.nstp - 1) * lev, G.N + 1, 'r', 0, ROMS_ISTVAR, 5, zero, zero, 0);
+    for (int e = 0; e < 4; e++) {
+      a.it[q].kind[e] = cf.lbc_tke[e] == ROMS_LBC_RAD ? ROMS_LBC_RAD : ROMS_LBC_GRA;
+      a.it[q].bry[e] = nullptr; a.it[q].bstride[e] = 0;
+    }
+  }
+  a.nitems = 2;
+  LAUNCH_COOP(k_obc, 1, 1, 2 * (G.N + 1), 256, 0, c->stream, a);
+  return 0;
+}

@@ -218,7 +218,8 @@ int run_uv3dmix2(roms_hip_ctx *c) {
     const int parts = (G.N + 29) / 30;
     a.p2 = eu ? atoi(eu) : (cols >= 128L * 1024L ? (G.N + parts - 1) / parts : 0);
     a.p1 = c->late_pre ? 1 : 0;
-    if (a.p2 > 0) LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
+    if (G.wet_dry) { a.p2 = 0; LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_wd, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a); }
+    else if (a.p2 > 0) LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
     else LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a); }
   LAUNCH_THREAD(k_uv3dmix2_sum, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
   return run_duv_frc(c);                           // DIAGNOSTICS_UV: the vertical sums of the terms and the viscous terms
@@ -292,7 +293,8 @@ int run_uv3dmix2_s(roms_hip_ctx *c) {
     const long cols = (long)(B.Iend - B.Istr + 1) * (B.Jend - B.Jstr + 1);
     const int parts = (G.N + 29) / 30;
     a.p2 = eu ? atoi(eu) : (cols >= 128L * 1024L ? (G.N + parts - 1) / parts : 0);
-    if (a.p2 > 0) LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
+    if (G.wet_dry) { a.p2 = 0; LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_wd, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a); }
+    else if (a.p2 > 0) LAUNCH_THREAD_AS(k_uv3dmix2_s, k_uv3dmix2_m, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + a.p2 - 1) / a.p2, c->stream, a);
     else LAUNCH_THREAD(k_uv3dmix2_s, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, (G.N + KCH - 1) / KCH, c->stream, a); }
   return 0;
 }

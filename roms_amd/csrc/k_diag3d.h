@@ -20,8 +20,9 @@
 #include "k_haloblock.h"
 
 struct KArgs {
+  Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip);
+                     // FIRST: their offsets in the argument block then do not move when DGrid grows (measured: DESIGN.md 6)
   DGrid G;
-  Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
   int p0, p1, p2;
 };
 

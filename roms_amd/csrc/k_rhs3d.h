@@ -1004,7 +1004,9 @@ THREAD_GLOBAL(k_t3dmix2_m, KArgs)
 // of them, one level is live at a time) instead of KCH unrolled ones
 // VIS4: the SECOND harmonic operator of uv3dmix4_s.h:526-622 -- the same stress tensor of (LapU, LapV) (k_mix4.h: k_uv4_lap)
 // with visc4 in place of visc2; its terms are stored negated (u - cff3 == u + (-cff3), rufrc - cff1 - cff2 likewise)
-template <bool MARCH, bool VIS4 = false>
+// WD: the wet mask of the psi points behind the land mask (uv3dmix2_s.h:276) -- an instantiation of its own (k_uv3dmix2_wd): four
+// more registers in the default ones would cost them a wave per SIMD (168 -> 172 VGPRs)
+template <bool MARCH, bool VIS4 = false, bool WD = false>
 THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
@@ -1061,13 +1063,13 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
     const double cR = CFFR(r0_, 0);
     double cP = CFFP(p0_, 0);
     if (G.masking) cP = cP * F.pmask[x];                                   // uv3dmix2_s.h:273
-    if (G.masking && G.wet_dry) cP = cP * F.pmask_wet[x];                  // :276
+    if (WD && G.masking) cP = cP * F.pmask_wet[x];                  // :276
     double un = 0.0, vn = 0.0, u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0;
     if (do_u) {
       const double cRw = CFFR(rw_, -1);
       double cPn = CFFP(pn_, ni);
       if (G.masking) cPn = cPn * F.pmask[x + ni];
-      if (G.masking && G.wet_dry) cPn = cPn * F.pmask_wet[x + ni];
+      if (WD && G.masking) cPn = cPn * F.pmask_wet[x + ni];
       const double UFx1 = fur1 * cR;
       const double UFx0 = fur0 * cRw;
       const double UFe1 = fup1 * cPn;
@@ -1084,7 +1086,7 @@ THREAD_KERNEL(k_uv3dmix2_t, KArgs) {
       const double cRs = CFFR(rs_, -ni);
       double cPe = CFFP(pe_, 1);
       if (G.masking) cPe = cPe * F.pmask[x + 1];
-      if (G.masking && G.wet_dry) cPe = cPe * F.pmask_wet[x + 1];
+      if (WD && G.masking) cPe = cPe * F.pmask_wet[x + 1];
       const double VFx1 = fvp1 * cPe;
       const double VFx0 = fvp0 * cP;
       const double VFe1 = fvr1 * cR;
@@ -1117,6 +1119,8 @@ THREAD_KERNEL(k_uv3dmix4_s, KArgs) { k_uv3dmix2_t_body<false, true>(a, gx, gy, g
 THREAD_GLOBAL(k_uv3dmix4_s, KArgs)
 THREAD_KERNEL(k_uv3dmix2_m, KArgs) { k_uv3dmix2_t_body<true>(a, gx, gy, gz); }
 THREAD_GLOBAL(k_uv3dmix2_m, KArgs)
+THREAD_KERNEL(k_uv3dmix2_wd, KArgs) { k_uv3dmix2_t_body<false, false, true>(a, gx, gy, gz); }   // WET_DRY
+THREAD_GLOBAL(k_uv3dmix2_wd, KArgs)
 
 // u,v(nnew) = u,v(nnew) + cff3 of uv3dmix2_s.h:226-262 from the stored terms (deferred form of k_uv3dmix2_s): the
 // same product and sum as there; index space (Istr:Iend, Jstr:Jend, chunks of KCH levels)

@@ -40,17 +40,6 @@ struct DGrid {
   // exchange packs and its boundary fills read --, 2 = only the others (kdefs.h: THREAD / COL launches decide per thread,
   // the LDS-tiled kernels per block)
   int region, rimw;
-  // DIAGNOSTICS_TS (mod_diags.F): 0 = off; else NDT, the number of tracer terms; dia_idx[term] = the reference's 1-based
-  // index of the term (0 = absent for this option set), terms in the order of the enum below
-  int dia_ts, dia_idx[10];
-  // DIAGNOSTICS_UV (mod_diags.F:174-222): 0 = off; m2 / m3[term] = the reference's 1-based index of a 2-D / 3-D momentum
-  // term for the option set (mod_scalars.F:4264-4377), 0 = absent; ndm2 = NDM2d, ndm3 = NDM3d, ndrhs = NDrhs
-  int dia_uv;
-  // biharmonic horizontal mixing along s-surfaces switched on (roms_hip_mix4_config): UV_VIS4 + MIX_S_UV (uv3dmix4_s.h,
-  // step2d_LF_AM3.h:1653-1920), TS_DIF4 + MIX_S_TS (t3dmix4_s.h); coefficient arrays visc4_r, visc4_p, diff4
-  int uv_vis4, ts_dif4;
-  signed char m2[12], m3[12];
-  short ndm2, ndm3, ndrhs;
   int fuse_halo;              // 1: single tile, k_step2d fills boundary/periodic ghost points itself (k_haloblock.h)
   int fuse3d;                 // 1: the 3-D producers do so too (emit_plan/emit_store); ROMS_HIP_FUSE3D=0 turns it off
   int xloc, yloc;             // 1: a periodic direction of this tile wraps onto itself by a local copy (no exchange partner)
@@ -71,17 +60,30 @@ struct DGrid {
   // are Fields::rmask ... (upload names "rmask", "umask", "vmask", "pmask"), here for the kernels that get no Fields
   int masking;
   const double *rmask, *umask, *vmask, *pmask;
-  // WET_DRY (wetdry.F; roms_hip_wetdry_config): time-dependent wet/dry masks rmask_wet ... (Fields::rmask_wet ...; here for
-  // the kernels that get no Fields), Dcrit = DCRIT of roms.in, hbath = h
-  int wet_dry;
-  double Dcrit;
-  const double *rmask_wet, *umask_wet, *vmask_wet, *pmask_wet, *hbath;
   int Vtransform;
   // open boundaries: 1 if any edge of any variable is neither closed nor periodic (k_obc.h does the state's boundary
   // conditions then, and nothing is fused into the producers); bit (4*variable + edge) of lbc_closed set where
   // LBC(edge,variable)%closed (bc_2d.F:201, mpdata_adiff.F:698: closed, or else zero gradient)
   int obc;
   unsigned long long lbc_closed;     // (64 bits: 4 edges x (ROMS_ISTVAR + NT) variables)
+  // ---- members of later rounds, kept BEHIND the ones above: a kernel fetches its arguments through the scalar cache, and the
+  // members the hot kernels read stay packed in the cache lines they were measured in (profiles/)
+  // DIAGNOSTICS_TS (mod_diags.F): 0 = off; else NDT, the number of tracer terms; dia_idx[term] = the reference's 1-based
+  // index of the term (0 = absent for this option set), terms in the order of the enum below
+  int dia_ts, dia_idx[10];
+  // DIAGNOSTICS_UV (mod_diags.F:174-222): 0 = off; m2 / m3[term] = the reference's 1-based index of a 2-D / 3-D momentum
+  // term for the option set (mod_scalars.F:4264-4377), 0 = absent; ndm2 = NDM2d, ndm3 = NDM3d, ndrhs = NDrhs
+  int dia_uv;
+  // biharmonic horizontal mixing along s-surfaces switched on (roms_hip_mix4_config): UV_VIS4 + MIX_S_UV (uv3dmix4_s.h,
+  // step2d_LF_AM3.h:1653-1920), TS_DIF4 + MIX_S_TS (t3dmix4_s.h); coefficient arrays visc4_r, visc4_p, diff4
+  int uv_vis4, ts_dif4;
+  signed char m2[12], m3[12];
+  short ndm2, ndm3, ndrhs;
+  // WET_DRY (wetdry.F; roms_hip_wetdry_config): time-dependent wet/dry masks rmask_wet ... (Fields::rmask_wet ...; here for
+  // the kernels that get no Fields), Dcrit = DCRIT of roms.in, hbath = h
+  int wet_dry;
+  double Dcrit;
+  const double *rmask_wet, *umask_wet, *vmask_wet, *pmask_wet, *hbath;
 };
 
 #ifdef ROMS_CPU_EMU
@@ -247,12 +249,6 @@ struct Fields {
   GPtr Uwind, Vwind, Tair, Pair, Hair, rain, cloud, lhflx, shflx, lrflx, evap;
   // mod_mixing
   GPtr Akv, Akt, visc2_r, visc2_p, diff2, bvf, alpha, beta, hsbl, ghats;
-  GPtr visc4_r, visc4_p, diff4;        // square roots of the biharmonic coefficients (inp_par.F:634, read_phypar.F:7840)
-  // WET_DRY (wetdry.F): wet/dry masks of the fast steps / the 3-D step, wet x land masks for output, the sum of the rho
-  // mask over the fast steps (allocated by roms_hip_wetdry_config)
-  GPtr rmask_wet, umask_wet, vmask_wet, pmask_wet, rmask_full, umask_full, vmask_full, pmask_full, rmask_wet_avg;
-  GPtr wd_eff;                         // umask*umask_wet | vmask*vmask_wet as step3d_uv finds them (2 planes; k_wd_eff)
-  GPtr lap4;                           // UV_VIS4: LapU | LapV of uv3dmix4_s.h (2 x N planes), allocated by roms_hip_mix4_config
   GPtr tke, gls, Lscale, Akk, Akp;   // GLS_MIXING: tke, gls (i,j,0:N,3); Lscale, Akk, Akp (i,j,0:N)
   // s-coordinate tables (device copies)
   GPtr sc_r, Cs_r, sc_w, Cs_w;
@@ -261,10 +257,6 @@ struct Fields {
   GPtr wrk3[13];   // [1] P of prsgrd, [0..4] KPP, [3..4] spline fluxes, [5] swdk, [6..9] the four viscous terms of
                    // uv3dmix2, [10] wvelocity, [11..12] the old ru/rv bracket of the deferred momentum predictor
   GPtr wrk2[4];
-  // DIAGNOSTICS_TS: DIAGS(ng)%DiaTwrk, DiaTrc (i,j,k,itrc,idiag), avgzeta (allocated by roms_hip_dia_config)
-  GPtr DiaTwrk, DiaTrc, dia_zeta;
-  // DIAGNOSTICS_UV: ONE allocation holding DIAGS(ng)%DiaU2wrk ... DiaV3d in the order of duv_* below (roms_hip_diauv_config)
-  GPtr duv;
   // MPDATA work arrays (allocated only when a tracer uses MPDATA): Ta (N planes per tracer), Ua, Va, Wa,
   // beta_up, beta_dn
   GPtr mp3[6];
@@ -274,6 +266,17 @@ struct Fields {
   // (zeta, ubar, vbar, u, v, t) * 4 + (west, east, south, north); west/east lines (LBj:UBj [,N [,NT]]) in the caller's
   // bounds, south/north (LBi:UBi ...)
   GPtr bry[24];
+  // ---- arrays of later rounds, behind the ones above (see DGrid)
+  GPtr visc4_r, visc4_p, diff4;        // square roots of the biharmonic coefficients (inp_par.F:634, read_phypar.F:7840)
+  // WET_DRY (wetdry.F): wet/dry masks of the fast steps / the 3-D step, wet x land masks for output, the sum of the rho
+  // mask over the fast steps (allocated by roms_hip_wetdry_config)
+  GPtr rmask_wet, umask_wet, vmask_wet, pmask_wet, rmask_full, umask_full, vmask_full, pmask_full, rmask_wet_avg;
+  GPtr wd_eff;                         // umask*umask_wet | vmask*vmask_wet as step3d_uv finds them (2 planes; k_wd_eff)
+  GPtr lap4;                           // UV_VIS4: LapU | LapV of uv3dmix4_s.h (2 x N planes), allocated by roms_hip_mix4_config
+  // DIAGNOSTICS_TS: DIAGS(ng)%DiaTwrk, DiaTrc (i,j,k,itrc,idiag), avgzeta (allocated by roms_hip_dia_config)
+  GPtr DiaTwrk, DiaTrc, dia_zeta;
+  // DIAGNOSTICS_UV: ONE allocation holding DIAGS(ng)%DiaU2wrk ... DiaV3d in the order of duv_* below (roms_hip_diauv_config)
+  GPtr duv;
 };
 
 // DIAGNOSTICS_UV: the arrays of mod_diags.F inside Fields::duv, each laid out as the reference's (dir 0 = U, 1 = V; id, lev

@@ -97,8 +97,6 @@ static const FieldDesc g_fields[] = {
     FD(pnom_u, FK_2D), FD(pmon_v, FK_2D), FD(pnom_v, FK_2D), FD(dmde, FK_2D), FD(dndx, FK_2D), FD(angler, FK_2D),
     FD(xr, FK_2D), FD(yr, FK_2D), FD(xp, FK_2D), FD(yp, FK_2D), FD(lonr, FK_2D), FD(latr, FK_2D), FD(rdrag, FK_2D), FD(rdrag2, FK_2D),
     FD(rmask, FK_2D), FD(umask, FK_2D), FD(vmask, FK_2D), FD(pmask, FK_2D),
-    FD(rmask_wet, FK_2D), FD(umask_wet, FK_2D), FD(vmask_wet, FK_2D), FD(pmask_wet, FK_2D), FD(rmask_full, FK_2D), FD(umask_full, FK_2D),
-    FD(vmask_full, FK_2D), FD(pmask_full, FK_2D), FD(rmask_wet_avg, FK_2D),      // WET_DRY (wetdry.F)
     FD(Hz, FK_R), FD(z_r, FK_R), FD(z_w, FK_W), FD(Huon, FK_R), FD(Hvom, FK_R),
     FD(zeta, FK_2Dx3), FD(ubar, FK_2Dx3), FD(vbar, FK_2Dx3), FD(rzeta, FK_2Dx2), FD(rubar, FK_2Dx2),
     FD(rvbar, FK_2Dx2), FD(u, FK_Rx2), FD(v, FK_Rx2), FD(t, FK_T), FD(W, FK_W), FD(wvel, FK_W), FD(rho, FK_R),
@@ -109,7 +107,7 @@ static const FieldDesc g_fields[] = {
     FD(btflx, FK_2DxNT), FD(stflux, FK_2DxNT), FD(btflux, FK_2DxNT), FD(srflx, FK_2D),
     FD(Uwind, FK_2D), FD(Vwind, FK_2D), FD(Tair, FK_2D), FD(Pair, FK_2D), FD(Hair, FK_2D), FD(rain, FK_2D),
     FD(cloud, FK_2D), FD(lhflx, FK_2D), FD(shflx, FK_2D), FD(lrflx, FK_2D), FD(evap, FK_2D),
-    FD(Akv, FK_W), FD(Akt, FK_WxNAT), FD(visc2_r, FK_2D), FD(visc2_p, FK_2D), FD(diff2, FK_2DxNT), FD(visc4_r, FK_2D), FD(visc4_p, FK_2D), FD(diff4, FK_2DxNT), FD(bvf, FK_W),
+    FD(Akv, FK_W), FD(Akt, FK_WxNAT), FD(visc2_r, FK_2D), FD(visc2_p, FK_2D), FD(diff2, FK_2DxNT), FD(bvf, FK_W),
     FD(alpha, FK_2D), FD(beta, FK_2D), FD(hsbl, FK_2D), FD(ghats, FK_WxNAT),
     FD(tke, FK_Wx3), FD(gls, FK_Wx3), FD(Lscale, FK_W), FD(Akk, FK_W), FD(Akp, FK_W),
     FD(sc_r, FK_TABR), FD(Cs_r, FK_TABR), FD(sc_w, FK_TABW), FD(Cs_w, FK_TABW),
@@ -124,6 +122,11 @@ static const FieldDesc g_fields[] = {
     FB("v_west", 16, FK_BJN), FB("v_east", 17, FK_BJN), FB("v_south", 18, FK_BIN), FB("v_north", 19, FK_BIN),
     FB("t_west", 20, FK_BJT), FB("t_east", 21, FK_BJT), FB("t_south", 22, FK_BIT), FB("t_north", 23, FK_BIT),
 #undef FB
+    // (arrays of later rounds at the END of the table: the table's order is the order of allocation, and the layout of the
+    // arrays of the hot path relative to one another is part of what profiles/ measured)
+    FD(visc4_r, FK_2D), FD(visc4_p, FK_2D), FD(diff4, FK_2DxNT),                     // UV_VIS4 / TS_DIF4
+    FD(rmask_wet, FK_2D), FD(umask_wet, FK_2D), FD(vmask_wet, FK_2D), FD(pmask_wet, FK_2D), FD(rmask_full, FK_2D), FD(umask_full, FK_2D),
+    FD(vmask_full, FK_2D), FD(pmask_full, FK_2D), FD(rmask_wet_avg, FK_2D),      // WET_DRY (wetdry.F)
 };
 static const int g_nfields = (int)(sizeof(g_fields) / sizeof(g_fields[0]));
 
@@ -257,8 +260,12 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     }
     for (int e = 0; e < 4; e++) {
       const int k = cfg->lbc_tke[e];
-      if (!(k == ROMS_LBC_DEFAULT || k == ROMS_LBC_CLO || k == ROMS_LBC_GRA || k == ROMS_LBC_PER)) {
-        set_error("LBC(isMtke): closed, gradient and periodic are built (tkebc_im.F); the radiation condition is not");
+      if (!(k == ROMS_LBC_DEFAULT || k == ROMS_LBC_CLO || k == ROMS_LBC_GRA || k == ROMS_LBC_PER || k == ROMS_LBC_RAD)) {
+        set_error("LBC(isMtke): closed, gradient, radiation and periodic are the kinds of tkebc_im.F");
+        return 5;
+      }
+      if (k == ROMS_LBC_RAD && (cfg->options & ROMS_MY25_MIXING)) {
+        set_error("LBC(isMtke) radiation with MY25_MIXING: my25_corstep.F's own edge copies are built for its closed / gradient form only");
         return 5;
       }
       if ((k == ROMS_LBC_PER) != (((e == ROMS_IWEST || e == ROMS_IEAST) ? cfg->EWperiodic : cfg->NSperiodic) != 0) && k != ROMS_LBC_DEFAULT) {

@@ -185,6 +185,7 @@ void launch_halo_wide(roms_hip_ctx *c, const HaloSpec *sp, int n);    // ... wit
 int run_set_avg(roms_hip_ctx *c, int part = 0);   // g_avg.cpp
 int run_set_diags(roms_hip_ctx *c);
 // WET_DRY (g_wetdry.cpp)
+int run_obc_tke(roms_hip_ctx *c, int nout);                                // g_obc.cpp
 int run_wetdry(roms_hip_ctx *c, int mode);
 int run_wd_scale3(roms_hip_ctx *c);
 int run_wd_eff(roms_hip_ctx *c);

@@ -2,7 +2,7 @@
 the oracle (oracle/orc.h) and of the reference glue (oracle/ref/ref_glue.F90).  TEST INFRASTRUCTURE."""
 import numpy as np
 
-from roms_amd.cases import SCHEME, benchmark, hip_cfg, upwelling, upwelling_kpp, upwelling_logdrag, upwelling_mask, upwelling_wetdry, wetdry_depth, benchmark_mask, land_mask, kelvin, seamount, grav_adj, overflow, upwelling_prs31, upwelling_bih, upwelling_prs40, upwelling_gls, upwelling_my25, kelvin_gls, gls_cfg, GLS_NAMES, GLS_SETS, lbc_codes, obc_scales  # noqa: F401  (re-exported)
+from roms_amd.cases import LBC_KINDS, SCHEME, benchmark, hip_cfg, upwelling, upwelling_kpp, upwelling_logdrag, upwelling_mask, upwelling_wetdry, wetdry_depth, benchmark_mask, land_mask, kelvin, seamount, grav_adj, overflow, upwelling_prs31, upwelling_bih, upwelling_prs40, upwelling_gls, upwelling_my25, kelvin_gls, gls_cfg, GLS_NAMES, GLS_SETS, lbc_codes, obc_scales  # noqa: F401  (re-exported)
 
 
 def ref_params(cs):
@@ -28,6 +28,8 @@ def ref_params(cs):
         for e in range(4):
             ipar[16 + 4 * v + e] = code[v][e]
     ipar[44] = 1 if cs.get("bry_all") else 0
+    for e, k in enumerate(cs.get("lbc_tke", ())):        # LBC(isMtke): ipar(46:49)
+        ipar[45 + e] = LBC_KINDS[k]
     sc = obc_scales(cs)
     for q, n in enumerate(["FSobc_in", "FSobc_out", "M2obc_in", "M2obc_out", "M3obc_in", "M3obc_out"]):
         for e in range(4):

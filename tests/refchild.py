@@ -19,7 +19,7 @@ def parse(argv):
     kw = {}
     for a in argv:
         k, v = a.split("=")
-        if k in ("hadv", "vadv"):
+        if k in ("hadv", "vadv", "lbc_tke"):
             kw[k] = tuple(v.split(","))
         elif k == "preset":
             kw[k] = v

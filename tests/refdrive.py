@@ -143,7 +143,7 @@ def oracle_diag_line(od):
 def make_case(tag, **kw):
     app, base = CASES[tag]
     k = dict(base)
-    k.update({a: b for a, b in kw.items() if a not in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac")})
+    k.update({a: b for a, b in kw.items() if a not in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac", "lbc_tke")})
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_diag=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag,
                 upwelling_mask=cases.upwelling_mask, upwelling_wetdry=cases.upwelling_wetdry, benchmark_mask=cases.benchmark_mask,
@@ -157,7 +157,7 @@ def make_case(tag, **kw):
         cs["EWperiodic"] = 0                 # all four edges are boundaries
     if lbc is not None:
         cs["lbc"] = lbc
-    for n in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac"):
+    for n in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac", "lbc_tke"):
         if n in kw:
             cs[n] = kw[n]
     return app, cs

@@ -932,10 +932,14 @@ def test_generic_length_scale_closure_matches_oracle(tag):
 
 
 @pytest.mark.gpu
-def test_generic_length_scale_closure_with_open_boundaries_matches_oracle():
+@pytest.mark.parametrize("lbc_tke", [None, ("Gra", "Clo", "Rad", "Clo")])
+def test_generic_length_scale_closure_with_open_boundaries_matches_oracle(lbc_tke):
     """KELVIN's open boundaries with GLS_MIXING on the GPU, 40 steps: the closure is driven hard here (Akv three to four
-    orders above its background), the device `pow` differs from libm's in the last bits: turbulent fields 1e-7, circulation 1e-9."""
+    orders above its background), the device `pow` differs from libm's in the last bits: turbulent fields 1e-7, circulation 1e-9.
+    Also with tkebc_im.F's radiation condition on the eastern edge (LBC(isMtke) = Rad)."""
     cs, g = util.kelvin_gls_case()
+    if lbc_tke:
+        cs["lbc_tke"] = lbc_tke
     O = util.make_oracle(cs, g)
     H = util.make_hip(cs, g)
     O.start()

@@ -578,10 +578,15 @@ def test_generic_length_scale_closure_through_the_fortran_host(emu, tag, monkeyp
         H.finalize()
 
 
-def test_generic_length_scale_closure_with_open_boundaries(emu):
+@pytest.mark.parametrize("lbc_tke", [None, ("Gra", "Clo", "Rad", "Clo"), ("Rad", "Clo", "Gra", "Clo")])
+def test_generic_length_scale_closure_with_open_boundaries(emu, lbc_tke):
     """KELVIN (Chapman / Flather / radiation edges, k_obc.h) with GLS_MIXING: 20 steps, every array the oracle's bits; the
-    bottom stress of the Kelvin wave drives the closure hard (Akv four orders above its background)."""
+    bottom stress of the Kelvin wave drives the closure hard (Akv four orders above its background).  LBC(isMtke): the default
+    (closed where not periodic), and tkebc_im.F's radiation condition on the eastern | western edge with the gradient
+    condition opposite (the oracle pinned to the reference with the same kinds: tests/test_oracle_vs_ref.py)."""
     cs, g = util.kelvin_gls_case()
+    if lbc_tke:
+        cs["lbc_tke"] = lbc_tke
     O = util.make_oracle(cs, g)
     H = util.make_hip(cs, g, emu)
     O.start(); H.start()

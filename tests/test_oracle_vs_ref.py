@@ -275,6 +275,9 @@ MAIN3D_CASES = [
     # the closure driven by the Kelvin wave's bottom stress
     ("kelvin_gls_small", ["nsteps=60"]),
     ("kelvin_gls_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # ... and tkebc_im.F's radiation condition (LBC(isMtke) = Rad) on the eastern | western edge, gradient opposite
+    ("kelvin_gls_small", ["nsteps=40", "lbc_tke=Gra,Clo,Rad,Clo"]),
+    ("kelvin_gls_small", ["nsteps=40", "lbc_tke=Rad,Clo,Gra,Clo", "NtileI=2", "NtileJ=2"]),
     ("upwelling", ["nsteps=100"]),                                               # BASELINE configs[0], full size
     ("benchmark1", ["nsteps=4"]),                                                # BASELINE configs[1], full size
 ]
