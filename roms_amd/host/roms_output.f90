@@ -256,7 +256,7 @@
       CALL io_range (g, i0, i1, j0, j1)
       allocate ( buf(i0:i1,j0:j1,k0:k1) )
       buf=A(i0:i1,j0:j1,k0:k1)
-      IF (land_fill.and.allocated(wfull)) THEN            ! WET_DRY: the wet x land masks rmask_full ... of this record (wrt_his.F: Amask = rmask_full)
+      IF (land_fill.and.wet_dry.and.allocated(wfull)) THEN            ! WET_DRY: the wet x land masks rmask_full ... of this record (wrt_his.F: Amask = rmask_full)
         DO k=k0,k1
           SELECT CASE (g)
             CASE (gR2, gR3, gW3)
@@ -882,7 +882,8 @@
 !  WET_DRY: the wet/dry masks of this record, written without fill values (wrt_his.F:269-310), and the wet x land masks
 !  the other fields of the record are filled with
       IF (wet_dry) THEN
-        IF (.not.allocated(wfull)) allocate ( wfull(LBi:UBi,LBj:UBj,3) )
+        IF (allocated(wfull)) deallocate ( wfull )         ! (a module array: the previous run of this process may have left its own)
+        allocate ( wfull(LBi:UBi,LBj:UBj,3) )
         allocate ( A(LBi:UBi,LBj:UBj,1) )
         land_fill=.FALSE.
         CALL fetch ('rmask_wet', 1, A, ierr); CALL put_field (o%h, o%v_fld(77), rec, gR2, A, 1, 1, 1, ierr)
