@@ -55,8 +55,8 @@ struct S2Fields {
     (dst).duv = (src).duv;                                                                               \
   } while (0)
 struct Step2dArgs {
+  S2Fields F;          // (first: its offsets in the argument block do not move when DGrid grows)
   DGrid G;
-  S2Fields F;
   double w1_m1;        // weight(1,iif-1)
   double w1_0;         // weight(1,iif): the fast-time average of the momentum diagnostics (DIAGNOSTICS_UV, :2707)
   double w2_0, w2_p1;  // weight(2,iif), weight(2,iif+1)

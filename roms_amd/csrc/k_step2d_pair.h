@@ -28,8 +28,8 @@
 #include "k_step2d.h"
 
 struct Step2dPairArgs {
+  S2Fields F;          // (first: DESIGN.md 6)
   DGrid G;             // stepping of the PREDICTOR call: iif >= 2, kstp = 3 - indx1, krhs = indx1, knew = 3
-  S2Fields F;
   double w1_m1;        // weight(1,iif-1)
   double w2_0, w2_p1;  // weight(2,iif), weight(2,iif+1)
   int lev_in;          // physical level holding zeta/ubar/vbar(krhs): G.krhs or a staging level
