@@ -459,8 +459,8 @@ KDEV double blk_psit(double ZoL) {
 }
 
 struct BulkArgs {
-  DGrid G;
   Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
+  DGrid G;
   double ZW, ZT, ZQ;
 };
 

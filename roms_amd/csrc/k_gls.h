@@ -17,8 +17,8 @@
 #include "k_step3d.h"   // ROMS_NPRIV
 
 struct GlsArgs {
-  DGrid G;
   Fields Fv;
+  DGrid G;
   int flags, Lmy25, my25;     // my25: the Mellor-Yamada 2.5 closure (my25_corstep.F) on the same kernels
   double gls_m, gls_n, Kmin, Pmin, cmu0, c1, c2, c3m, c3p, sigk, sigp, Akk_bak, Akp_bak;
   double Zos_min, Zob_min, charnok_alpha, crgban_cw;

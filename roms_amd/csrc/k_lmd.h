@@ -14,8 +14,8 @@
 #include "k_diag3d.h"
 
 struct LmdArgs {
-  DGrid G;
   Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
+  DGrid G;
   double fac1, fac2, fac3;   // lmd_swfrac coefficients for Zscale = -1 and this Jerlov water type
   double lmd_Cg, Vtc;
 };

@@ -16,8 +16,8 @@
 #include "k_diag3d.h"
 
 struct MpArgs {
-  DGrid G;
   Fields Fv;         // the array pointers, by value (a table in device memory would cost every kernel one more dependent round trip)
+  DGrid G;
   int itrc;
 };
 
