@@ -317,26 +317,42 @@ def reference_leg(workload, cs, budget_s=12.0):
     if not os.path.exists(os.path.join(root, "oracle", "_ref", f"libromsref_{app}.so")):
         return None
     code = (
-        "import sys, json, time, resource\n"
+        "import sys, json, time, threading\n"
         f"sys.path.insert(0, {root!r})\n"
-        "resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))\n"
-        "import bench\n"
-        "from tests import refdrive as rd\n"
-        f"cs = bench.params_for({workload!r}, {cs['Lm']}, {cs['Mm']}, {cs['N']}, ntimes=400)\n"
-        "saved = rd.quiet()\n"
-        f"R = rd.reference({app!r}, cs)\n"
-        "t0 = time.perf_counter(); R.main3d(1); t1 = time.perf_counter()\n"
-        f"n = max(2, min(200, int({budget_s} / max(t1 - t0, 1e-4))))\n"
-        "R.main3d(n); t2 = time.perf_counter()\n"
-        "rd.unquiet(saved)\n"
-        "print(json.dumps(dict(n=n, first=t1 - t0, span=t2 - t1)))\n")
+        "def run():\n"
+        "    import bench\n"
+        "    from tests import refdrive as rd\n"
+        f"    cs = bench.params_for({workload!r}, {cs['Lm']}, {cs['Mm']}, {cs['N']}, ntimes=400)\n"
+        "    saved = rd.quiet()\n"
+        f"    R = rd.reference({app!r}, cs)\n"
+        "    t0 = time.perf_counter(); R.main3d(1); t1 = time.perf_counter()\n"
+        f"    n = max(2, min(200, int({budget_s} / max(t1 - t0, 1e-4))))\n"
+        "    R.main3d(n); t2 = time.perf_counter()\n"
+        "    rd.unquiet(saved)\n"
+        "    print(json.dumps(dict(n=n, first=t1 - t0, span=t2 - t1)), flush=True)\n"
+        "# the reference keeps its private (IminS:ImaxS,JminS:JmaxS,N) work arrays on the stack: a thread with a 1 GiB stack of its\n"
+        "# own (an ordinary user cannot raise RLIMIT_STACK beyond the hard limit, and the main thread's stack is fixed at start)\n"
+        "threading.stack_size(1 << 30)\n"
+        "t = threading.Thread(target=run); t.start(); t.join()\n")
     env = dict(os.environ, OMP_NUM_THREADS="1")
+
+    def big_stack():
+        # the reference keeps its private (IminS:ImaxS,JminS:JmaxS,N) work arrays on the stack, and the main thread's stack is
+        # sized when the program starts: raise the limit between fork and the start of the child (to the hard limit where an
+        # ordinary user may not go further)
+        import resource
+        soft, hard = resource.getrlimit(resource.RLIMIT_STACK)
+        try:
+            resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+        except (ValueError, OSError):
+            resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
+
     try:
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, preexec_fn=big_stack)
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
         if p.returncode != 0 or not lines:
             return {"value": None, "kind": "reference", "sample": "the reference library did not run here: " +
-                    (p.stderr.strip().splitlines() or ["?"])[-1][:200]}
+                    (p.stderr.strip().splitlines() or [f"exit code {p.returncode}"])[-1][:200]}
         r = json.loads(lines[-1])
     except (subprocess.TimeoutExpired, ValueError) as e:
         return {"value": None, "kind": "reference", "sample": f"the reference library did not run here: {e}"}
