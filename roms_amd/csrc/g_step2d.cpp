@@ -292,6 +292,41 @@ static void loop_grid(const DGrid &G, DGrid &L) {
 }
 static size_t loop_lds_doubles() { return (size_t)S2L_NLDS * (loop_shape() ? (16 + 2 * S2P_RIM) * (8 + 2 * S2P_RIM) : (32 + 2 * S2P_RIM) * (4 + 2 * S2P_RIM)); }
 #endif
+void step2d_loop_dims(const roms_hip_ctx *c, int &nbx2, int &nby2) {
+#ifdef ROMS_CPU_EMU
+  (void)c; nbx2 = nby2 = 0;
+#else
+  DGrid L;
+  loop_grid(c->G, L);
+  nbx2 = L.nbx2; nby2 = L.nby2;
+#endif
+}
+#ifndef ROMS_CPU_EMU
+// A multi-tile context (round 6): the loop crosses the tile edges through the mailbox slab (k_step2d_loop.h, S2LPeer).  Every
+// rank must take the same decision, so it depends on the partition, the transport and the environment only: equal tiles
+// (the neighbours' sub-tile grids continue mine), the mailbox installed with a loop region on every neighbour, no rank
+// sharing its device with another (the kernels of all ranks must be resident at the same time: ROMS_HIP_LOOP=1 forces it
+// for test set-ups that know their blocks fit side by side), at least one periodic direction (the kernel has no corner
+// averages of a closed basin), the 16x8 shape.
+static bool loop_mt_usable(roms_hip_ctx *c, const DGrid &L, bool forced) {
+  const DGrid &G = c->G;
+  const roms_hip_config &cf = c->cfg;
+  const TileComm &m = c->comm;
+  if (!c->pair_mt || !m.peer_on || !m.loop_rim_off || !m.loop_ring_off) return false;
+  if (m.peer_shared && !forced) return false;
+  if (!(G.ewp || G.nsp) || G.obc || !loop_shape()) return false;
+  if (cf.Lm % cf.NtileI || cf.Mm % cf.NtileJ) return false;
+  if (m.loop_nb2[0] != L.nbx2 || m.loop_nb2[1] != L.nby2) return false;
+  const char *ewh = getenv("ROMS_HIP_LOOP_WHOLE");
+  if (ewh && ewh[0] == '0') return false;                  // (only the whole loop -- first fast step and auxiliary call inside -- crosses tiles)
+  for (int d = 0; d < 8; d++) {
+    if (m.nbr[d] < 0) continue;
+    const TileComm::PeerGeom &g = m.ngeom[d];
+    if (!g.rim_off || !g.ring_off || g.nbx2 != L.nbx2 || g.nby2 != L.nby2) return false;
+  }
+  return true;
+}
+#endif
 bool step2d_loop_usable(roms_hip_ctx *c) {
 #ifdef ROMS_CPU_EMU
   (void)c;
@@ -302,21 +337,27 @@ bool step2d_loop_usable(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const char *e = getenv("ROMS_HIP_LOOP");
   if (e && e[0] == '0') return false;
-  if (!c->pair_on || c->has_exchange || !G.fuse_halo || G.masking) return false;
+  if (!c->pair_on || G.masking) return false;
+  if (!c->has_exchange && !G.fuse_halo) return false;
   if (G.bw2 > 32 || G.bh2 > 4 || getenv("ROMS_HIP_S2D_GENERIC")) return false;
   if (c->cfg.nfast < 3) return false;
   DGrid L;
   loop_grid(G, L);
   if (L.bw2 < 2 || L.bh2 < 2) return false;             // (the neighbour window of the kernel: 3 sub-tiles each way)
+  if (c->has_exchange && !loop_mt_usable(c, L, e && e[0] == '1')) return false;
   // every block must be resident at once: they wait for each other
-  const void *kern = loop_shape() ? (const void *)k_step2d_loop_b : (const void *)k_step2d_loop_a;
+  const void *kern = c->has_exchange ? (const void *)k_step2d_loop_bm : loop_shape() ? (const void *)k_step2d_loop_b : (const void *)k_step2d_loop_a;
   const int nthr = loop_shape() ? 512 : 640;
   if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
   int dev = 0, ncu = 0, per = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, nthr, loop_lds_doubles() * sizeof(double)) != hipSuccess) return false;
   if ((long)L.nbx2 * L.nby2 > (long)ncu * per) return false;
-  if (c->loop_flags) { c->loop_state = 1; return true; }       // (decided again after a configuration call: the buffers exist)
+  if (c->loop_flags) {                                          // (decided again after a configuration call: the buffers exist)
+    c->loop_state = 1;
+    if (c->has_exchange && !getenv("ROMS_HIP_XASYNC")) { halo_fence(c, FG_ALL); c->x_async = false; c->rim_split = false; }
+    return true;
+  }
   void *pf = nullptr, *pw = nullptr;
   if (hipMalloc(&pf, (size_t)L.nbx2 * L.nby2 * S2L_FSTRIDE * sizeof(unsigned)) != hipSuccess) return false;
   c->allocs.push_back(pf);
@@ -339,21 +380,64 @@ bool step2d_loop_usable(roms_hip_ctx *c) {
   c->loop_flags = (unsigned *)pf;
   c->loop_wts = (double *)pw;
   c->loop_state = 1;
+  if (c->has_exchange && !getenv("ROMS_HIP_XASYNC")) {
+    // the step is arranged around the loop on four streams (roms_hip.cpp:main3d_around_loop): every exchange stays in the
+    // stream of its producer, on that stream's mailbox channel -- the other lanes are what it overlaps with
+    halo_fence(c, FG_ALL);
+    c->x_async = false;
+    c->rim_split = false;
+  }
   return true;
 #endif
 }
+
+#ifndef ROMS_CPU_EMU
+// The launch.  Its blocks wait for each other, so all of them must be resident at once.  hipLaunchCooperativeKernel would make
+// the runtime guarantee that (or refuse the launch) -- but the runtime routes cooperative launches through a queue of their
+// own and orders it against the stream with barrier packets on both sides: measured on the MI355X (round 6,
+// tools/gpu_debug/ab_env.sh ROMS_HIP_LOOP_COOP "1 0"), a BENCHMARK1 step takes 1.53-1.58 ms with it against 0.82 ms with the
+// ordinary launch (one-step trace: 70 us of idle queue in front of the kernel, 30 us behind it, and the four streams of the
+// schedule serialised against the cooperative queue).  So the ordinary launch stays the default, guarded by the occupancy
+// query at set-up (every block resident on an otherwise idle device) and by bounded waits: a launch that meets a busy
+// device ends with exit_flag 2 and a message that names ROMS_HIP_LOOP=0 (ctx_check; the step's state is lost, as with any
+// other device error).  Ranks
+// that share a device (test set-ups) do not take the loop at all; ROMS_HIP_LOOP=0 is the switch for any other shared use.
+// ROMS_HIP_LOOP_COOP=1 selects the cooperative launch.
+template <class K>
+static int loop_launch(roms_hip_ctx *c, K kern, const char *label, const Step2dLoopArgs &a, int nthr, size_t lds_doubles) {
+  static const char *ec = getenv("ROMS_HIP_LOOP_COOP");
+  const bool coop = ec && ec[0] == '1' && !g_kp_start && !g_kprof_mode;
+  const dim3 grid((unsigned)a.G.nbx2, (unsigned)a.G.nby2, 1), block((unsigned)nthr);
+  if (coop) {
+    void *args[1] = {(void *)&a};
+    const hipError_t e = hipLaunchCooperativeKernel((const void *)kern, grid, block, args, lds_doubles * sizeof(double), c->stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error(std::string("step2d_loop: the cooperative launch was refused (") + hipGetErrorString(e) +
+                "): the device cannot hold every block of the persistent barotropic loop at once -- ROMS_HIP_LOOP=0 runs the pair launches");
+      return 2;
+    }
+    return 0;
+  }
+  (void)label;
+  KPROF_WRAP(k_step2d_loop, c->stream, ROMS_LAUNCH(kern, grid, block, lds_doubles * sizeof(double), c->stream, a));
+  return 0;
+}
+#endif
 
 // whole = 1: the launch starts with the first fast step and ends with the auxiliary call (c->G = the stepping of the predictor
 // call of iif = 1); 0: fast steps 2 .. nfast only (c->G = that of iif = 2), the per-call kernel in front and behind
 int run_step2d_loop_n(roms_hip_ctx *c, int whole) {
 #ifdef ROMS_CPU_EMU
-  (void)c;
+  (void)c; (void)whole;
   set_error("step2d_loop: not part of the emulated build");
   return 8;
 #else
   const DGrid &G = c->G;
   if (!step2d_loop_usable(c)) { set_error("step2d_loop: this context does not run the persistent barotropic loop"); return 8; }
   if (!G.predictor || G.iif != (whole ? 1 : 2) || G.knew != 3 || G.krhs == 3 || c->b2_stage) { set_error("step2d_loop: needs the stepping of the predictor call of iif = 2 (of iif = 1 for the whole loop)"); return 8; }
+  const bool mt = c->has_exchange;
+  if (mt && !whole) { set_error("step2d_loop: a multi-tile context runs the whole loop only (the stepping of the predictor call of iif = 1)"); return 8; }
   if (c->m2d_dirty) pack_metrics(c);
   Step2dLoopArgs a;
   loop_grid(G, a.G);
@@ -378,9 +462,43 @@ int run_step2d_loop_n(roms_hip_ctx *c, int whole) {
   a.wrapy = G.nsp && G.yloc;
   static const int prio = getenv("ROMS_HIP_LOOP_PRIO") ? atoi(getenv("ROMS_HIP_LOOP_PRIO")) : 3;
   a.prio = prio;
+  memset(&a.P, 0, sizeof(a.P));
+  if (mt) {
+    // the neighbours' rim planes and rings; my point (i,j) in neighbour d's planes is (i + sx, j + sy) of ITS arrays, sx / sy
+    // the shift across the periodic seam where my tile lies on that domain edge
+    const TileComm &m = c->comm;
+    const roms_hip_config &cf = c->cfg;
+    static const int ddx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, ddy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+    a.P.on = 1;
+    a.P.rim = (double *)((char *)m.peer_slab + m.loop_rim_off);
+    a.P.ring = (unsigned *)((char *)m.peer_slab + m.loop_ring_off);
+    for (int d = 0; d < 8; d++) {
+      if (m.nbr[d] < 0) continue;
+      const TileComm::PeerGeom &g = m.ngeom[d];
+      a.P.nbmask |= 1 << d;
+      a.P.nrim[d] = (double *)((char *)m.peer_map[d] + g.rim_off);
+      a.P.nring[d] = (unsigned *)((char *)m.peer_map[d] + g.ring_off);
+      const int sx = ddx[d] < 0 && cf.west_edge ? G.Lm : (ddx[d] > 0 && cf.east_edge ? -G.Lm : 0);
+      const int sy = ddy[d] < 0 && cf.south_edge ? G.Mm : (ddy[d] > 0 && cf.north_edge ? -G.Mm : 0);
+      a.P.nni[d] = g.ni; a.P.nnij[d] = g.ni * g.nj;
+      a.P.noff[d] = (sx - g.LBi) + (sy - g.LBj) * g.ni;
+    }
+    // what the first fast step reads beyond the tile (k_step2d_loop.h, prologue): the krhs = kstp level 5 | 4 lines wide; the
+    // 3-D forcing and its AB3 history on the enlarged sub-tiles (two lines)
+    const size_t o_r0s = (size_t)(G.nstp - 1) * G.nij * (size_t)(G.N + 1), o_r0n = (size_t)(G.nnew - 1) * G.nij * (size_t)(G.N + 1);
+    HaloSpec s1[6] = {{c->F.rufrc, 1, BC_NONE, 'u'}, {c->F.rvfrc, 1, BC_NONE, 'v'},
+                      {c->F.ru + o_r0n, 1, BC_NONE, 'u'}, {c->F.rv + o_r0n, 1, BC_NONE, 'v'},
+                      {c->F.ru + o_r0s, 1, BC_NONE, 'u'}, {c->F.rv + o_r0s, 1, BC_NONE, 'v'}};
+    HaloSpec s2[3] = {{lev2d(c, c->F.zeta, G.kstp), 1, BC_NONE, 'r'}, {lev2d(c, c->F.ubar, G.kstp), 1, BC_NONE, 'u'}, {lev2d(c, c->F.vbar, G.kstp), 1, BC_NONE, 'v'}};
+    launch_halo_multi(c, s1, a.startup == 0 ? 2 : (a.startup == 1 ? 4 : 6));
+    launch_halo_wide(c, s2, 3);
+    if (c->comm_failed) return 2;
+  }
   // the arrival words count on from launch to launch (a reset would be one more operation in the stream, 5 us + a boundary);
-  // zero again long before they wrap
+  // zero again long before they wrap (a multi-tile context: its ring is written by the neighbours -- 2^32 pairs are 70 million
+  // baroclinic steps of BENCHMARK1: the run ends with exit_flag 8 instead)
   if (c->loop_epoch > 0xF0000000u) {
+    if (mt) { set_error("step2d_loop: the arrival counters of a multi-tile context are exhausted"); return 8; }
     const size_t nflag = (size_t)a.G.nbx2 * a.G.nby2 * S2L_FSTRIDE * sizeof(unsigned);
     if (hipMemsetAsync(c->loop_flags, 0, nflag, c->stream) != hipSuccess) { set_error("step2d_loop: hipMemsetAsync"); return 2; }
     c->loop_epoch = 0;
@@ -388,9 +506,21 @@ int run_step2d_loop_n(roms_hip_ctx *c, int whole) {
   a.epoch = c->loop_epoch;
   c->loop_epoch += (unsigned)a.npairs;
   const size_t lds = loop_lds_doubles();
-  if (loop_shape()) LAUNCH_COOP_AS(k_step2d_loop, k_step2d_loop_b, a.G.nbx2, a.G.nby2, 1, 512, lds, c->stream, a);
-  else LAUNCH_COOP_AS(k_step2d_loop, k_step2d_loop_a, a.G.nbx2, a.G.nby2, 1, 640, lds, c->stream, a);
+  int r;
+  if (mt) r = loop_launch(c, k_step2d_loop_bm, "k_step2d_loop", a, 512, lds);
+  else if (loop_shape()) r = loop_launch(c, k_step2d_loop_b, "k_step2d_loop", a, 512, lds);
+  else r = loop_launch(c, k_step2d_loop_a, "k_step2d_loop", a, 640, lds);
+  if (r) return r;
   c->b2_stage = whole ? 0 : (((a.npairs - 1) & 1) ? 5 : 4);     // the last pair's result: committed by the kernel | staged for the auxiliary call
+  if (mt) {
+    // what the pair launches exchange between the pairs, once: the three levels of the state (the logical levels 1, 2 and the
+    // last predictor's level 3), rzeta of both levels, the fast-time averages -- 5 | 4 lines wide, with the boundary fills of
+    // zetabc / u2dbc / v2dbc and the exchanges of step2d_LF_AM3.h:842-883,1030,1068,3041
+    HaloSpec sp[7] = {{c->F.zeta, 3, bc_rstate(c), 'r'}, {c->F.ubar, 3, BC_U, 'u'}, {c->F.vbar, 3, BC_V, 'v'}, {c->F.rzeta, 2, BC_NONE, 'r'},
+                      {c->F.Zt_avg1, 1, BC_NONE, 'r'}, {c->F.DU_avg1, 1, BC_NONE, 'u'}, {c->F.DV_avg1, 1, BC_NONE, 'v'}};
+    launch_halo_wide(c, sp, 7);
+    if (c->comm_failed) return 2;
+  }
   return 0;
 #endif
 }

@@ -34,7 +34,22 @@
 // averages, the last result staged for the auxiliary call iif = nfast+1 (k_step2d_ac commits it).
 //
 // Single tile, fused boundary fills (at least one periodic direction), sub-tiles up to 32x4, no land mask: the
-// configuration of BASELINE's 1-GPU headline.  Everything else keeps the pair / per-call launches.
+// configuration of BASELINE's 1-GPU headline.
+//
+// Multi-tile contexts (round 6, template parameter MT; mp_exchange2d of step2d_LF_AM3.h:714,842,1068,3041 inside the launch):
+// the rim of an edge block reaches into the NEIGHBOURING RANK's tile.  Every rank keeps, in its mailbox slab (uncached
+// memory the neighbours map over hipIpc / xGMI, roms_hip.cpp), two parities x {zeta, ubar, vbar} RIM PLANES laid out like its
+// own arrays, and a RING of arrival words for the neighbours' blocks around its own nbx2 x nby2 grid.  A producer stores
+// the own points that lie in a neighbour's ghost zone (4 lines towards the low side, 5 towards the high side, corners
+// included; the boundary values a closed domain edge derives from them as well) a second time, into that neighbour's rim
+// planes at the index the point has THERE (system-scope write-through stores), drains, and after the barrier lane d stores
+// the pair number into its slot of neighbour d's ring.  A consumer polls ring slots for the candidates beyond its tile and
+// loads the ghost points of its rectangle from its own rim planes (uncached: loads go to HBM).  Two parities suffice for
+// the same reason two staging levels do: the reading relation is symmetric across the tile edge too.  Between two launches
+// the 3-D exchanges of the baroclinic step order the ranks (a rank cannot start the next launch before every neighbour has
+// left this one).  Tiles of equal size on every rank (the sub-tile grids must coincide), at least one periodic direction.
+// What the pair launches exchange between the pairs is exchanged ONCE behind the launch (g_step2d.cpp).
+// Everything else keeps the pair / per-call launches.
 #pragma once
 #include "k_step2d_pair.h"
 
@@ -42,6 +57,17 @@
 #define S2L_NLDS 32
 #define INR(i, j, i0, i1, j0, j1) ((i) >= (i0) && (i) <= (i1) && (j) >= (j0) && (j) <= (j1))
 #define S2L_FSTRIDE 16          // arrival words are 64 bytes apart
+#define S2L_RING 3              // sub-tiles of a neighbouring rank a rectangle can reach (sub-tiles are at least two points wide)
+// multi-tile contexts: the neighbours' rim planes and rings as mapped here, mine
+struct S2LPeer {
+  int on;                       // 0: single tile (the kernels without MT never read this struct)
+  int nbmask;                   // bit d: neighbour d (W, E, S, N, SW, SE, NW, NE) exists
+  double *rim;                  // my rim planes [parity][zeta | ubar | vbar][nij]: the neighbours' edge blocks write my ghost points
+  unsigned *ring;               // arrival words of the neighbours' blocks: (nbx2 + 2 S2L_RING) x (nby2 + 2 S2L_RING) slots, mine unused
+  double *nrim[8];              // neighbour d's rim planes ...
+  unsigned *nring[8];           // ... and ring, as mapped in this process
+  int noff[8], nni[8], nnij[8]; // my point (i,j) in neighbour d's planes: i + j * nni + noff (array origin + the shift across a periodic seam)
+};
 struct Step2dLoopArgs {
   S2Fields F;                   // (first: DESIGN.md 6)
   DGrid G;                      // stepping of the FIRST pair's predictor call: iif = 2, kstp = 3 - indx1, krhs = indx1, knew = 3
@@ -63,6 +89,7 @@ struct Step2dLoopArgs {
   double km1, km2, km3;         // 0.5*dtfast*5/12, 0.5*dtfast*8/12, 0.5*dtfast*1/12 (corrector, momentum)
   int wrapx, wrapy;             // rim indices beyond the tile wrap onto the tile's own points
   int prio;                     // s_setprio of the block's waves (ROMS_HIP_LOOP_PRIO, default 3: as the pair kernel)
+  S2LPeer P;                    // (last: the members above keep their places in the argument block)
 };
 
 KDEV double s2l_ld(const double *p) {
@@ -79,11 +106,65 @@ KDEV void s2l_range(const DGrid &G, int bx, int by, int &i0, int &i1, int &j0, i
   j0 = KMAX(j0, 1) + G.T.Jstr - 1; j1 = KMIN(j1, MmT) + G.T.Jstr - 1;
 }
 
+// ---- multi-tile: a value of field f (0 zeta, 1 ubar, 2 vbar) of parity `par` at (i,j) -- an own point or a boundary point
+// derived from one -- goes to the local staging level and, where (i,j) lies in a neighbour's ghost zone, into that
+// neighbour's rim planes
+KDEV void s2l_sys_st(double *p, double v) {
+  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <bool MT>
+KDEV void s2l_put(const Step2dLoopArgs &a, double *A, int pf, int i, int j, double v) {
+  const DGrid &G = a.G;
+  HB_ST(true, A, (int)X2(i, j), v);
+  if (MT) {
+    const TB &T = G.T;
+    const bool w = i < T.Istr + B2D_GH, e = i > T.Iend - B2D_GL, s = j < T.Jstr + B2D_GH, n = j > T.Jend - B2D_GL;
+    if (!(w || e || s || n)) return;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      const bool hit = d == 0 ? w : d == 1 ? e : d == 2 ? s : d == 3 ? n : d == 4 ? (w && s) : d == 5 ? (e && s) : d == 6 ? (w && n) : (e && n);
+      if (hit && a.P.nrim[d]) s2l_sys_st(a.P.nrim[d] + (size_t)pf * (size_t)a.P.nnij[d] + (i + j * a.P.nni[d] + a.P.noff[d]), v);
+    }
+  }
+}
+// hb_emit2<true> without the periodic images (a multi-tile context has none inside the launch: rim indices beyond the tile
+// are the neighbours' points): the point and the boundary values a closed DOMAIN edge derives from it (k_haloblock.h)
+template <bool MT>
+KDEV void s2l_emit(const Step2dLoopArgs &a, const TB &B, double *A, int pf, int bc, int i, int j, double v) {
+  const DGrid &G = a.G;
+  s2l_put<MT>(a, A, pf, i, j, v);
+  if (i > 2 && i < G.Lm && j > 2 && j < G.Mm) return;
+  if (!G.nsp) {
+    if (bc == BC_R) {
+      if (B.south && j == B.Jstr) s2l_put<MT>(a, A, pf, i, j - 1, v);
+      if (B.north && j == B.Jend) s2l_put<MT>(a, A, pf, i, j + 1, v);
+    } else if (bc == BC_U) {
+      if (B.south && j == B.Jstr) s2l_put<MT>(a, A, pf, i, j - 1, G.gamma2 * v);
+      if (B.north && j == B.Jend) s2l_put<MT>(a, A, pf, i, j + 1, G.gamma2 * v);
+    } else if (bc == BC_V) {
+      if (B.south && j == B.JstrV) s2l_put<MT>(a, A, pf, i, B.Jstr, 0.0);
+      if (B.north && j == B.Jend) s2l_put<MT>(a, A, pf, i, j + 1, 0.0);
+    }
+  }
+  if (!G.ewp) {
+    if (bc == BC_R) {
+      if (B.west && i == B.Istr) s2l_put<MT>(a, A, pf, i - 1, j, v);
+      if (B.east && i == B.Iend) s2l_put<MT>(a, A, pf, i + 1, j, v);
+    } else if (bc == BC_U) {
+      if (B.west && i == B.IstrU) s2l_put<MT>(a, A, pf, B.Istr, j, 0.0);
+      if (B.east && i == B.Iend) s2l_put<MT>(a, A, pf, i + 1, j, 0.0);
+    } else if (bc == BC_V) {
+      if (B.west && i == B.Istr) s2l_put<MT>(a, A, pf, i - 1, j, G.gamma2 * v);
+      if (B.east && i == B.Iend) s2l_put<MT>(a, A, pf, i + 1, j, G.gamma2 * v);
+    }
+  }
+}
+
 // an SGPR zero the compiler cannot see through: indices derived from it are not hoisted out of the stage / the pair loop
 #define S2L_OPQ(name) int name = 0; asm volatile("" : "+s"(name))
 #define S2L_TICK(n) do { if (G.dbg_stop == 98 && p == 3 && t == 0) F.xr[me * 16 + (n)] = (double)wall_clock64(); } while (0)
 
-template <int BWC, int BHC, int NTC>
+template <int BWC, int BHC, int NTC, bool MT = false>
 static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &a, int bx, int by, double *lds) {
   if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
   else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -138,6 +219,10 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
   const bool ownR = rp && INR(i_, j_, KMIN(B.IstrR, B.Istr), B.IendR, KMIN(B.JstrR, B.Jstr), B.JendR);
   const bool inEz = rp && INR(i_, j_, E.IstrU - 1, E.Iend, E.JstrV - 1, E.Jend);       // the predictor's free-surface points
   const bool inBz = rp && INR(i_, j_, B.IstrU - 1, B.Iend, B.JstrV - 1, B.Jend);       // the corrector's
+  // (multi-tile) a rectangle point outside the tile and the boundary points of its closed domain edges: a ghost point, its
+  // value comes from a neighbouring rank's block through my rim planes
+  const bool rem = MT && rp && !INR(iw, jw, G.T.IstrR, G.T.IendR, G.T.JstrR, G.T.JendR);
+  const bool IMG = !MT;                                                                 // periodic images: a single tile stores its own
   // ---- ... and momentum point: cell c of the enlarged sub-tile, its u-point (threads 0..VOFF-1) or v-point (VOFF..)
   const int isvt = t >= VOFF ? 1 : 0, c = t - isvt * VOFF;
   const int mjj = c / EWD, mj_ = B.Jstr - 2 + mjj, mi_ = B.Istr - 2 + c - mjj * EWD;
@@ -184,20 +269,49 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
   // the blocks whose own points this block's rectangle touches (their results are its rim): lane q of wave 0 takes
   // the candidate at offset (q % 7 - 3, q / 7 - 3) -- sub-tiles are at least two points wide and high (g_step2d.cpp)
   int nbf = -1;
+  bool nbrem = false;                    // (multi-tile) the candidate is a block of a neighbouring rank: its word is in my ring
   if (t < 49) {
     const int dx = t % 7 - 3, dy = t / 7 - 3;
-    int nx = bx + dx, ny = by + dy, sx = 0, sy = 0;
+    int nx = bx + dx, ny = by + dy, sx = 0, sy = 0, rx = 0, ry = 0;
     bool ok = true;
+    const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
     if (wrapx) { while (nx < 0) { nx += G.nbx2; sx -= G.Lm; } while (nx >= G.nbx2) { nx -= G.nbx2; sx += G.Lm; } }
+    else if (MT && nx < 0 && nx >= -G.nbx2 && (a.P.nbmask & 1)) { rx = -1; nx += G.nbx2; sx = -LmT; }
+    else if (MT && nx >= G.nbx2 && nx < 2 * G.nbx2 && (a.P.nbmask & 2)) { rx = 1; nx -= G.nbx2; sx = LmT; }
     else if (nx < 0 || nx >= G.nbx2) ok = false;
     if (wrapy) { while (ny < 0) { ny += G.nby2; sy -= G.Mm; } while (ny >= G.nby2) { ny -= G.nby2; sy += G.Mm; } }
+    else if (MT && ny < 0 && ny >= -G.nby2 && (a.P.nbmask & 4)) { ry = -1; ny += G.nby2; sy = -MmT; }
+    else if (MT && ny >= G.nby2 && ny < 2 * G.nby2 && (a.P.nbmask & 8)) { ry = 1; ny -= G.nby2; sy = MmT; }
     else if (ny < 0 || ny >= G.nby2) ok = false;
-    if (ok && !(nx == bx && ny == by)) {
+    if (MT && (rx || ry)) {              // the rank that owns the candidate: W, E, S, N or a corner
+      const int d = ry == 0 ? (rx < 0 ? 0 : 1) : rx == 0 ? (ry < 0 ? 2 : 3) : (ry < 0 ? (rx < 0 ? 4 : 5) : (rx < 0 ? 6 : 7));
+      if (!(a.P.nbmask & (1 << d))) ok = false;
+    }
+    if (ok && (rx || ry || !(nx == bx && ny == by))) {
       int p0, p1, q0, q1;
       s2l_range(G, nx, ny, p0, p1, q0, q1);
-      if (p0 + sx <= B.Iend + S2P_RIM && p1 + sx >= B.Istr - S2P_RIM && q0 + sy <= B.Jend + S2P_RIM && q1 + sy >= B.Jstr - S2P_RIM)
-        nbf = (nx + G.nbx2 * ny) * S2L_FSTRIDE;
+      // (the rectangle as far as the arrays reach: the ghost zone towards a neighbouring rank is 5 | 4 lines)
+      const int ri0 = MT ? KMAX(B.Istr - S2P_RIM, G.LBi) : B.Istr - S2P_RIM, ri1 = MT ? KMIN(B.Iend + S2P_RIM, UBi) : B.Iend + S2P_RIM;
+      const int rj0 = MT ? KMAX(B.Jstr - S2P_RIM, G.LBj) : B.Jstr - S2P_RIM, rj1 = MT ? KMIN(B.Jend + S2P_RIM, UBj) : B.Jend + S2P_RIM;
+      if (p0 + sx <= ri1 && p1 + sx >= ri0 && q0 + sy <= rj1 && q1 + sy >= rj0) {
+        if (MT && (rx || ry)) {
+          nbrem = true;
+          nbf = ((nx + rx * G.nbx2 + S2L_RING) + (G.nbx2 + 2 * S2L_RING) * (ny + ry * G.nby2 + S2L_RING)) * S2L_FSTRIDE;
+        } else nbf = (nx + G.nbx2 * ny) * S2L_FSTRIDE;
+      }
     }
+  }
+  // (multi-tile) the neighbouring ranks this block's own points reach: lane d publishes the block's arrival in neighbour d's ring
+  bool pubd = false;
+  int pubx = 0;
+  if (MT && t < 8) {
+    const TB &T = G.T;
+    const bool w = B.Istr < T.Istr + B2D_GH, e = B.Iend > T.Iend - B2D_GL, s_ = B.Jstr < T.Jstr + B2D_GH, n = B.Jend > T.Jend - B2D_GL;
+    const int ddx = (t == 0 || t == 4 || t == 6) ? -1 : ((t == 1 || t == 5 || t == 7) ? 1 : 0);
+    const int ddy = (t == 2 || t == 4 || t == 5) ? -1 : ((t == 3 || t == 6 || t == 7) ? 1 : 0);
+    pubd = (a.P.nbmask & (1 << t)) && (ddx == 0 || (ddx < 0 ? w : e)) && (ddy == 0 || (ddy < 0 ? s_ : n));
+    // my block as the neighbour numbers it: its own grid continued across the tile edge
+    pubx = ((bx - ddx * G.nbx2 + S2L_RING) + (G.nbx2 + 2 * S2L_RING) * (by - ddy * G.nby2 + S2L_RING)) * S2L_FSTRIDE;
   }
   bool dead = false;
   KSYNC();
@@ -215,7 +329,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
     OPD(wm.pmr0); OPD(wm.pmr1); OPD(wm.pnr0); OPD(wm.pnr1); OPD(wm.or0); OPD(wm.or1); OPD(wm.v2p0); OPD(wm.v2p1); OPD(wm.pmp0); OPD(wm.pmp1);
     OPD(wm.pnp0); OPD(wm.pnp1); OPD(wm.op0); OPD(wm.op1); OPD(w_frc);
 #undef OPD
-    const bool img0 = tail == 0, img1 = tail <= 1, store3 = tail == 0;
+    const bool img0 = tail == 0 && IMG, img1 = tail <= 1 && IMG, lst1 = tail <= 1, store3 = tail == 0;
     const int krhs = (p & 1) ? 3 - G.krhs : G.krhs;   // logical level of the predictor's krhs = the corrector's kstp
     const int lev_out = (p & 1) ? 5 : 4;
     double *zn3 = F.zeta + 2 * G.nij, *un3 = F.ubar + 2 * G.nij, *vn3 = F.vbar + 2 * G.nij;
@@ -229,7 +343,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
     S2L_TICK(0);
     // the previous pair's result is this pair's krhs level: what the last two pair launches commit to the logical
     // levels (k_step2d_pair.h stage 1, `commit`)
-    if (p >= 1 && tail <= 1 && own) {
+    if (p >= 1 && lst1 && own) {
       const int s0 = s0_;
       double *zlog = F.zeta + (size_t)(krhs - 1) * G.nij, *ulog = F.ubar + (size_t)(krhs - 1) * G.nij,
              *vlog = F.vbar + (size_t)(krhs - 1) * G.nij;
@@ -311,8 +425,8 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         gzeta2[s0] = gz * zw;
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (own) {
-          if (store3) hb_emit2(G, B, zn3, BC_R, i, j, zeta_new, nullptr, true);
-          if (img1) hb_emit2(G, B, rz_k, BC_NONE, i, j, rhs_zeta, nullptr, img1);
+          if (store3) hb_emit2(G, B, zn3, BC_R, i, j, zeta_new, nullptr, IMG);
+          if (lst1) hb_emit2(G, B, rz_k, BC_NONE, i, j, rhs_zeta, nullptr, img1);
         }
       }
     }
@@ -354,11 +468,11 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           w_rP = r;
           if (mO) {
             if (!isv) {
-              if (store3) hb_emit2(G, B, un3, BC_U, mi, mj, b, nullptr, true);
-              if (img1) rub_k[x] = r;
+              if (store3) hb_emit2(G, B, un3, BC_U, mi, mj, b, nullptr, IMG);
+              if (lst1) rub_k[x] = r;
             } else {
-              if (store3) hb_emit2(G, B, vn3, BC_V, mi, mj, b, nullptr, true);
-              if (img1) rvb_k[x] = r;
+              if (store3) hb_emit2(G, B, vn3, BC_V, mi, mj, b, nullptr, IMG);
+              if (lst1) rvb_k[x] = r;
             }
           }
         }
@@ -453,7 +567,8 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         gzeta2[s0] = gz * zw;
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (own) {
-          hb_emit2<true>(G, B, zout, BC_R, i, j, zeta_new, nullptr, img0);
+          if (MT) s2l_emit<MT>(a, B, zout, 3 * (p & 1), BC_R, i, j, zeta_new);
+          else hb_emit2<true>(G, B, zout, BC_R, i, j, zeta_new, nullptr, img0);
           ZQ[s0] = zeta_new;
         }
       }
@@ -482,7 +597,10 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           const double rp_ = w_rp;
           const double b = f1 ? (sv * (Dstp0 + Dstp1) + cff * (0.5 * dtfast) * r) * fac
                               : (sv * (Dstp0 + Dstp1) + cff * (k1 * r + k2 * rs - k3 * rp_)) * fac;
-          if (!isv) { hb_emit2<true>(G, B, uout, BC_U, mi, mj, b, nullptr, img0); UQ[s] = b; }
+          if (MT) {
+            if (!isv) { s2l_emit<MT>(a, B, uout, 3 * (p & 1) + 1, BC_U, mi, mj, b); UQ[s] = b; }
+            else { s2l_emit<MT>(a, B, vout, 3 * (p & 1) + 2, BC_V, mi, mj, b); VQ[s] = b; }
+          } else if (!isv) { hb_emit2<true>(G, B, uout, BC_U, mi, mj, b, nullptr, img0); UQ[s] = b; }
           else { hb_emit2<true>(G, B, vout, BC_V, mi, mj, b, nullptr, img0); VQ[s] = b; }
         }
       }
@@ -493,10 +611,16 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its write-through stores have left
     KSYNC();
     if (t == 0) __hip_atomic_store(a.flags + me * S2L_FSTRIDE, a.epoch + (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (MT && pubd) {
+#pragma unroll
+      for (int d = 0; d < 8; d++)          // (static indices into the argument block)
+        if (t == d) __hip_atomic_store(a.P.nring[d] + pubx, a.epoch + (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (t < 64) {
       if (nbf >= 0 && !dead) {
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(a.flags + nbf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.epoch + (unsigned)(p + 1)) {
+        while ((MT && nbrem ? __hip_atomic_load(a.P.ring + nbf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                            : __hip_atomic_load(a.flags + nbf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < a.epoch + (unsigned)(p + 1)) {
           __builtin_amdgcn_s_sleep(1);
           if (wall_clock64() - t0 > a.timeout) {
             dead = true;
@@ -513,7 +637,15 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
       // own points keep what the block computed (stored to ZQ, DQ, UQ, VQ by their threads); every
       // other point of the rectangle -- the rim, and the boundary values behind a closed edge -- is some block's result
       const bool oz = own, ou = own && i >= B.IstrU, ov = own && j >= B.JstrV;
-      if (ina) {
+      if (MT && rem) {
+        if (ina) {                         // a ghost point of the tile: from my rim planes (uncached memory: the loads go to HBM)
+          const double *rq = a.P.rim + (size_t)(3 * (p & 1)) * (size_t)G.nij + x0;
+          const double z = __builtin_nontemporal_load(rq);
+          DQ[s0] = z + sH[s0]; ZQ[s0] = z;
+          UQ[s0] = __builtin_nontemporal_load(rq + G.nij);
+          VQ[s0] = __builtin_nontemporal_load(rq + 2 * G.nij);
+        }
+      } else if (ina) {
         if (!oz) { const double z = s2l_ld(zout + x0); DQ[s0] = z + sH[s0]; ZQ[s0] = z; }
         if (!ou) UQ[s0] = s2l_ld(uout + x0);
         if (!ov) VQ[s0] = s2l_ld(vout + x0);
@@ -534,9 +666,9 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         const int s0 = s0_;
         if (own) {
           double *zlog = F.zeta + (size_t)(kx - 1) * G.nij, *ulog = F.ubar + (size_t)(kx - 1) * G.nij, *vlog = F.vbar + (size_t)(kx - 1) * G.nij;
-          hb_emit2(G, B, zlog, BC_R, i, j, ZP[s0], nullptr, true);
-          if (i >= B.IstrU) hb_emit2(G, B, ulog, BC_U, i, j, UP[s0], nullptr, true);
-          if (j >= B.JstrV) hb_emit2(G, B, vlog, BC_V, i, j, VP[s0], nullptr, true);
+          hb_emit2(G, B, zlog, BC_R, i, j, ZP[s0], nullptr, IMG);
+          if (i >= B.IstrU) hb_emit2(G, B, ulog, BC_U, i, j, UP[s0], nullptr, IMG);
+          if (j >= B.JstrV) hb_emit2(G, B, vlog, BC_V, i, j, VP[s0], nullptr, IMG);
         }
         if (ownR && ina) {
           const bool pz = i >= B.IstrR && j >= B.JstrR, pu = i >= B.Istr && j >= B.JstrR, pv = i >= B.IstrR && j >= B.Jstr;
@@ -551,13 +683,13 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
             const double cff1 = cff * (DP[s0] + DP[(s0 - TW)]);
             dv = VP[s0] * cff1;
           }
-          if (pz) hb_emit2(G, B, F.Zt_avg1, BC_NONE, i, j, aZt[s0] + cA1 * ZP[s0], nullptr, true);
+          if (pz) hb_emit2(G, B, F.Zt_avg1, BC_NONE, i, j, aZt[s0] + cA1 * ZP[s0], nullptr, IMG);
           if (pu) {
-            hb_emit2(G, B, F.DU_avg1, BC_NONE, i, j, aDU1[s0] + cA1 * du, nullptr, true);
+            hb_emit2(G, B, F.DU_avg1, BC_NONE, i, j, aDU1[s0] + cA1 * du, nullptr, IMG);
             F.DU_avg2[x0] = aDU2[s0] + cA2 * du;
           }
           if (pv) {
-            hb_emit2(G, B, F.DV_avg1, BC_NONE, i, j, aDV1[s0] + cA1 * dv, nullptr, true);
+            hb_emit2(G, B, F.DV_avg1, BC_NONE, i, j, aDV1[s0] + cA1 * dv, nullptr, IMG);
             F.DV_avg2[x0] = aDV2[s0] + cA2 * dv;
           }
         }
@@ -588,5 +720,10 @@ static __global__ void __launch_bounds__(640) k_step2d_loop_a(const Step2dLoopAr
 static __global__ void __launch_bounds__(512) k_step2d_loop_b(const Step2dLoopArgs a) {
   extern __shared__ double lds_dyn_[];
   k_step2d_loop_body<16, 8, 512>(a, (int)blockIdx.x, (int)blockIdx.y, lds_dyn_);
+}
+// the same in a multi-tile context: edge blocks hand their rim to the neighbouring ranks and take theirs (S2LPeer)
+static __global__ void __launch_bounds__(512) k_step2d_loop_bm(const Step2dLoopArgs a) {
+  extern __shared__ double lds_dyn_[];
+  k_step2d_loop_body<16, 8, 512, true>(a, (int)blockIdx.x, (int)blockIdx.y, lds_dyn_);
 }
 #endif

@@ -459,6 +459,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   int prio_lo = 0, prio_hi = 0;
   if (getenv("ROMS_HIP_PRIO")) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // (least, greatest)
   if (hipfail(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate")) { delete c; return 2; }
+  c->stream0 = c->stream;
   if (hipfail(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi), "hipStreamCreate")) { delete c; return 2; }
   (void)hipEventCreate(&c->ev0);
   (void)hipEventCreate(&c->ev1);
@@ -1102,7 +1103,13 @@ struct PeerBlob {              // 128 bytes, what roms_hip_peer_export hands out
   unsigned long long raw;      // the slab's address in the exporting process (neighbour contexts of the same process)
   unsigned long long bytes;
   int device, planes;
-  unsigned magic, pad[7];
+  unsigned magic;
+  // round 6: what the persistent barotropic loop of a neighbour needs to address my rim planes and ring (k_step2d_loop.h),
+  // and the physical identity of my device (two ranks on one GPU are recognised by it, not by the ordinal)
+  short LBi, LBj, ni, nj, nbx2, nby2;
+  unsigned rim_off256, ring_off256;    // offsets in the slab in units of 256 bytes (0: none)
+  unsigned busid;
+  unsigned pad;
 };
 static_assert(sizeof(PeerBlob) == 128, "PeerBlob size");
 const unsigned PEER_MAGIC = 0x524d5042u;
@@ -1116,8 +1123,8 @@ extern "C" int roms_hip_peer_export(roms_hip_ctx *c, void *blob128) {
     const DGrid &G = c->G;
     const char *ep = getenv("ROMS_HIP_PEER_PLANES");
     m.peer_planes = ep ? atoi(ep) : 8 * (G.N + 1);
-    size_t off = (PEER_WORDS + (size_t)16 * m.peer_planes * sizeof(unsigned long long) + 4095) & ~(size_t)4095;
-    for (int ch = 0; ch < 2; ch++)
+    size_t off = (PEER_WORDS + (size_t)(8 * PEER_NCH) * m.peer_planes * sizeof(unsigned long long) + 4095) & ~(size_t)4095;
+    for (int ch = 0; ch < PEER_NCH; ch++)
       for (int par = 0; par < 2; par++)
         for (int d = 0; d < 8; d++) {
           m.peer_off[ch][par][d] = off;
@@ -1126,7 +1133,22 @@ extern "C" int roms_hip_peer_export(roms_hip_ctx *c, void *blob128) {
           const size_t w = d < 2 ? gw * G.nj : (d < 4 ? gw * G.ni : gw * gw);
           off += ((size_t)m.peer_planes * w * sizeof(double) + 255) & ~(size_t)255;
         }
+    m.loop_rim_off = m.loop_ring_off = 0;
+    if (c->pair_mt) {                                             // rim planes [2][3][nij] and the ring of the persistent barotropic loop
+      step2d_loop_dims(c, m.loop_nb2[0], m.loop_nb2[1]);
+      m.loop_rim_off = off;
+      off += ((size_t)6 * (size_t)G.nij * sizeof(double) + 255) & ~(size_t)255;
+      m.loop_ring_off = off;
+      off += ((size_t)(m.loop_nb2[0] + 6) * (size_t)(m.loop_nb2[1] + 6) * 16 * sizeof(unsigned) + 255) & ~(size_t)255;
+    }
     m.peer_bytes = off;
+    {
+      char bus[64] = {0};
+      unsigned dom = 0, b = 0, dv = 0, fn = 0;
+      m.busid = 0xFFFFFFFFu;
+      if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), c->cfg.device) == hipSuccess && sscanf(bus, "%x:%x:%x.%x", &dom, &b, &dv, &fn) >= 3)
+        m.busid = (dom << 16) | (b << 8) | (dv << 3) | fn;
+    }
     if (hipfail(hipExtMallocWithFlags(&m.peer_slab, m.peer_bytes, hipDeviceMallocUncached), "hipExtMallocWithFlags (mailbox slab)")) return 2;
     if (hipfail(hipMemset(m.peer_slab, 0, m.peer_bytes), "hipMemset")) return 2;
     if (hipfail(hipMemcpy((char *)m.peer_slab + PEER_TABLE, m.peer_off, sizeof(m.peer_off), hipMemcpyHostToDevice), "hipMemcpy")) return 2;
@@ -1141,6 +1163,10 @@ extern "C" int roms_hip_peer_export(roms_hip_ctx *c, void *blob128) {
   b.raw = (unsigned long long)(uintptr_t)m.peer_slab;
   b.bytes = m.peer_bytes;
   b.device = c->cfg.device; b.planes = m.peer_planes; b.magic = PEER_MAGIC;
+  b.LBi = (short)c->G.LBi; b.LBj = (short)c->G.LBj; b.ni = (short)c->G.ni; b.nj = (short)c->G.nj;
+  b.nbx2 = (short)m.loop_nb2[0]; b.nby2 = (short)m.loop_nb2[1];
+  b.rim_off256 = (unsigned)(m.loop_rim_off >> 8); b.ring_off256 = (unsigned)(m.loop_ring_off >> 8);
+  b.busid = m.busid;
   memcpy(blob128, &b, sizeof(b));
   return 0;
 }
@@ -1159,7 +1185,9 @@ extern "C" int roms_hip_comm_peer(roms_hip_ctx *c, const void *blobs128, int nra
     if (r < 0) continue;
     if (r >= nranks || B[r].magic != PEER_MAGIC) { set_error("roms_hip_comm_peer: bad blob for a neighbour rank"); return 8; }
     if (B[r].planes != m.peer_planes) { set_error("roms_hip_comm_peer: ranks differ in slot capacity"); return 5; }
-    if (B[r].device == c->cfg.device && B[r].pid != (long long)getpid()) m.peer_shared = true;
+    // a neighbour on the SAME physical device (ranks sharing one GPU: test set-ups), whatever ordinal each process knows it by
+    if (B[r].pid != (long long)getpid() && (m.busid != 0xFFFFFFFFu && B[r].busid != 0xFFFFFFFFu ? B[r].busid == m.busid : B[r].device == c->cfg.device)) m.peer_shared = true;
+    m.ngeom[d] = {B[r].LBi, B[r].LBj, B[r].ni, B[r].nj, B[r].nbx2, B[r].nby2, (size_t)B[r].rim_off256 << 8, (size_t)B[r].ring_off256 << 8, B[r].busid};
     for (int e = 0; e < d; e++)
       if (m.nbr[e] == r) { m.peer_map[d] = m.peer_map[e]; break; }
     if (!m.peer_map[d]) {
@@ -1169,13 +1197,14 @@ extern "C" int roms_hip_comm_peer(roms_hip_ctx *c, const void *blobs128, int nra
         m.peer_opened[d] = true;
       }
     }
-    size_t table[2][2][8];
+    size_t table[PEER_NCH][2][8];
     if (hipfail(hipMemcpy(table, (char *)m.peer_map[d] + PEER_TABLE, sizeof(table), hipMemcpyDeviceToHost), "hipMemcpy (neighbour's slot table)")) return 2;
-    for (int ch = 0; ch < 2; ch++)
+    for (int ch = 0; ch < PEER_NCH; ch++)
       for (int par = 0; par < 2; par++) m.peer_noff[d][ch][par] = table[ch][par][g_opp[d]];
   }
-  m.peer_seq[0] = m.peer_seq[1] = 0;
+  for (int ch = 0; ch < PEER_NCH; ch++) m.peer_seq[ch] = 0;
   m.peer_on = true;
+  c->loop_state = 0;                    // (the persistent barotropic loop of a multi-tile context needs the mailbox: decided again)
   // (ranks sharing one device: smaller blocks, so that the waiting unpack blocks of ALL of them fit the device beside the
   // pack blocks they wait for -- 8 ranks x 200 planes x 1024 threads exceed an MI355X's 512 K resident threads)
   { const char *et = getenv("ROMS_HIP_PEER_THREADS"); c->peer_threads = et ? atoi(et) : (m.peer_shared ? 256 : 1024); }
@@ -1343,7 +1372,8 @@ static int exchange_all(roms_hip_ctx *c, const HaloArgs &h, int planes) {
   if (m.peer_on) {
     // two launches: the pack kernel stores into the neighbours' slots and releases their arrival words, the
     // unpack kernel waits for mine (k_halo.h:xchg_peer_pack/unpack)
-    const int ch = async ? 1 : 0;
+    // (the channel of the issuing stream: a lane of the schedule around the barotropic loop has its own)
+    const int ch = async ? 1 : (xs == c->stream2 ? 2 : (xs == c->stream3 ? 3 : (xs == c->stream4 ? 4 : 0)));
     const unsigned long long seq = ++m.peer_seq[ch];
     const int par = (int)(seq & 1);
     static long long timeout = 0;
@@ -1593,6 +1623,7 @@ extern "C" int roms_hip_comm_reset(roms_hip_ctx *c) {
   c->comm.peer_on = false;
   c->comm.fn = nullptr;
   c->comm_failed = false;
+  c->loop_state = 0;
   return 0;
 }
 
@@ -2028,7 +2059,10 @@ static bool late_schedule_ok(roms_hip_ctx *c) {
   // (a masked run keeps the reference order: its boundary fills are separate launches on the compute stream)
   static const char *elm = getenv("ROMS_HIP_LATE_MASK");
   // (prsgrd31: the late schedule relies on k_prs_grad keeping the previous ru/rv bracket for the deferred predictor)
-  return !c->has_exchange && !uvcol && !c->G.dia_ts && !c->G.dia_uv && !c->G.uv_vis4 && !c->G.ts_dif4 && !c->G.mix_geo_uv && (!c->G.masking || (elm && elm[0] == '1')) &&
+  // (a multi-tile context, round 6: the schedule around the persistent loop only, with the mailbox -- every lane has its own
+  // channel -- and every exchange in the stream of its producer: the lanes are what overlaps an exchange with compute)
+  const bool tiles_ok = !c->has_exchange || (c->comm.peer_on && step2d_loop_usable(c) && !c->x_async);
+  return tiles_ok && !uvcol && !c->G.dia_ts && !c->G.dia_uv && !c->G.uv_vis4 && !c->G.ts_dif4 && !c->G.mix_geo_uv && (!c->G.masking || (elm && elm[0] == '1')) &&
          !(elate && elate[0] == '0') && !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_GLS_MIXING | ROMS_MY25_MIXING));
 }
 // ... and the one around the persistent barotropic loop: 0 = no, else its form (ROMS_HIP_LOOP_SCHED: 0 = the loop inside the
@@ -2068,7 +2102,7 @@ static int main3d_one(roms_hip_ctx *c) {
     if (late_schedule_ok(c)) {
       const int form = around_loop_form(c);
       if (form > 0) return main3d_around_loop(c, do_diag, form, data_late);
-      return main3d_late(c, do_diag);
+      if (!c->has_exchange) return main3d_late(c, do_diag);
     }   // (GLS: its two routines keep the reference's places)
   }
   DO(roms_hip_rho_eos(c));                                  // :350

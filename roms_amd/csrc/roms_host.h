@@ -21,6 +21,10 @@ enum { FK_2D = 0, FK_R, FK_W, FK_2Dx3, FK_2Dx2, FK_Rx2, FK_T, FK_Wx2, FK_2DxNT, 
 
 struct Region { double seconds; long calls; };
 
+// channels of the mailbox transport: exchanges of one channel are ordered by the stream they are issued on, and every
+// rank issues the same sequence per channel -- 0 the main compute stream, 1 the exchange stream (asynchronous 3-D
+// exchanges), 2..4 the side streams of the schedule around the barotropic loop (round 6: stream2, stream3, stream4)
+#define PEER_NCH 5
 // inter-tile communication state (multi-GPU runs: one tile per process/GPU)
 struct TileComm {
   int nbr[8];                   // ranks of the W, E, S, N, SW, SE, NW, NE neighbours (-1: none)
@@ -33,15 +37,21 @@ struct TileComm {
   void *peer_slab;              // uncached device memory: slot table, arrival words [channel][direction][plane], then the receive buffers [channel][parity][direction]
   size_t peer_bytes;
   int peer_planes;              // capacity of a slot in planes
-  size_t peer_off[2][2][8];     // byte offsets of MY slots (same table in the slab's header for the neighbours)
+  size_t peer_off[PEER_NCH][2][8];   // byte offsets of MY slots [channel][parity][direction] (same table in the slab's header for the neighbours)
   void *peer_map[8];            // neighbour d's slab in this process's address space (null: none)
-  size_t peer_noff[8][2][2];    // offset in neighbour d's slab of the slot my message to it goes into (its direction opp[d])
+  size_t peer_noff[8][PEER_NCH][2];  // offset in neighbour d's slab of the slot my message to it goes into (its direction opp[d])
   bool peer_opened[8];          // mapped with hipIpcOpenMemHandle (closed at destroy)
-  unsigned long long peer_seq[2];   // exchanges issued per channel (0: compute stream, 1: exchange stream)
+  unsigned long long peer_seq[PEER_NCH];   // exchanges issued per channel
   unsigned long long *peer_err; // pinned host word: set by an unpack kernel whose message did not arrive in time
   bool peer_on;
   bool peer_shared;             // a neighbour rank runs on the SAME device (several ranks sharing one GPU: test set-ups)
   long nexchanges;
+  // the persistent barotropic loop across tiles (k_step2d_loop.h, S2LPeer): my rim planes and ring inside the slab, and the
+  // neighbours' as their blobs describe them
+  size_t loop_rim_off, loop_ring_off;   // byte offsets in MY slab (0: the slab has no such region)
+  int loop_nb2[2];                      // the loop's sub-tile grid the region was sized for
+  struct PeerGeom { int LBi, LBj, ni, nj, nbx2, nby2; size_t rim_off, ring_off; unsigned busid; } ngeom[8];
+  unsigned busid;                       // PCI bus id of my device (domain << 16 | bus << 8 | device << 3 | function)
 };
 
 struct roms_hip_ctx {
@@ -94,6 +104,7 @@ struct roms_hip_ctx {
   Fields *d_F;                  // the same table in device memory: kernels take it by pointer, which
                                 // keeps the by-value kernel arguments small
   kstream_t stream;
+  kstream_t stream0;   // the main compute stream (`stream` is switched between the lanes of a schedule; this one is not)
   std::vector<void *> allocs;
   roms_hip_stepping s;
   bool profile;
@@ -242,6 +253,7 @@ int run_step2d(roms_hip_ctx *c);
 int run_step2d_pair(roms_hip_ctx *c);     // predictor (c->G = its stepping) + corrector of one fast step
 bool step2d_pair_usable(const roms_hip_ctx *c);
 bool step2d_loop_usable(roms_hip_ctx *c);   // fast steps 2 .. nfast as one persistent launch (k_step2d_loop.h)
+void step2d_loop_dims(const roms_hip_ctx *c, int &nbx2, int &nby2);   // its sub-tile grid (the mailbox slab holds a ring of arrival words around it)
 int run_step2d_loop(roms_hip_ctx *c);       // c->G = the stepping of the predictor call of iif = 2, or of iif = 1: then the first fast
                                             // step and the auxiliary call iif = nfast+1 run inside the launch too
 int run_step3d_uv(roms_hip_ctx *c);
