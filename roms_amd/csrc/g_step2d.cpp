@@ -312,7 +312,7 @@ static bool loop_mt_usable(roms_hip_ctx *c, const DGrid &L, bool forced) {
   const DGrid &G = c->G;
   const roms_hip_config &cf = c->cfg;
   const TileComm &m = c->comm;
-  if (!c->pair_mt || !m.peer_on || !m.loop_rim_off || !m.loop_ring_off) return false;
+  if (!c->pair_mt || !m.peer_on || !m.loop_rim_off) return false;
   if (m.peer_shared && !forced) return false;
   if (!(G.ewp || G.nsp) || G.obc || !loop_shape()) return false;
   if (cf.Lm % cf.NtileI || cf.Mm % cf.NtileJ) return false;
@@ -322,7 +322,7 @@ static bool loop_mt_usable(roms_hip_ctx *c, const DGrid &L, bool forced) {
   for (int d = 0; d < 8; d++) {
     if (m.nbr[d] < 0) continue;
     const TileComm::PeerGeom &g = m.ngeom[d];
-    if (!g.rim_off || !g.ring_off || g.nbx2 != L.nbx2 || g.nby2 != L.nby2) return false;
+    if (!g.rim_off || g.nbx2 != L.nbx2 || g.nby2 != L.nby2) return false;
   }
   return true;
 }
@@ -425,6 +425,29 @@ static int loop_launch(roms_hip_ctx *c, K kern, const char *label, const Step2dL
 }
 #endif
 
+// What the first fast step of a multi-tile loop reads beyond the tile (k_step2d_loop.h, prologue), exchanged on the current
+// stream -- the schedule around the loop issues both early, off the critical path; run_step2d_loop_n does what is left:
+//   1  the 3-D forcing rufrc, rvfrc and its AB3 history ru, rv(:,:,0,nnew | nstp) on the enlarged sub-tiles (two lines)
+//   2  the kstp (= krhs) level of zeta, ubar, vbar, 5 | 4 lines wide
+int step2d_loop_pre(roms_hip_ctx *c, int what) {
+  const DGrid &G = c->G;
+  if (what == 1) {
+    const int startup = (G.iic == G.ntfirst) ? 0 : ((G.iic == G.ntfirst + 1) ? 1 : 2);
+    const size_t o_r0s = (size_t)(G.nstp - 1) * G.nij * (size_t)(G.N + 1), o_r0n = (size_t)(G.nnew - 1) * G.nij * (size_t)(G.N + 1);
+    HaloSpec s1[6] = {{c->F.rufrc, 1, BC_NONE, 'u'}, {c->F.rvfrc, 1, BC_NONE, 'v'},
+                      {c->F.ru + o_r0n, 1, BC_NONE, 'u'}, {c->F.rv + o_r0n, 1, BC_NONE, 'v'},
+                      {c->F.ru + o_r0s, 1, BC_NONE, 'u'}, {c->F.rv + o_r0s, 1, BC_NONE, 'v'}};
+    launch_halo_multi(c, s1, startup == 0 ? 2 : (startup == 1 ? 4 : 6));
+    c->loop_pre_frc = true;
+  } else {
+    const int k = c->s.indx1;            // kstp = krhs of the first fast step (main3d.F:824-830)
+    HaloSpec s2[3] = {{lev2d(c, c->F.zeta, k), 1, BC_NONE, 'r'}, {lev2d(c, c->F.ubar, k), 1, BC_NONE, 'u'}, {lev2d(c, c->F.vbar, k), 1, BC_NONE, 'v'}};
+    launch_halo_wide(c, s2, 3);
+    c->loop_pre_state = true;
+  }
+  return c->comm_failed ? 2 : 0;
+}
+
 // whole = 1: the launch starts with the first fast step and ends with the auxiliary call (c->G = the stepping of the predictor
 // call of iif = 1); 0: fast steps 2 .. nfast only (c->G = that of iif = 2), the per-call kernel in front and behind
 int run_step2d_loop_n(roms_hip_ctx *c, int whole) {
@@ -464,35 +487,26 @@ int run_step2d_loop_n(roms_hip_ctx *c, int whole) {
   a.prio = prio;
   memset(&a.P, 0, sizeof(a.P));
   if (mt) {
-    // the neighbours' rim planes and rings; my point (i,j) in neighbour d's planes is (i + sx, j + sy) of ITS arrays, sx / sy
+    // the neighbours' rim planes; my point (i,j) in neighbour d's planes is (i + sx, j + sy) of ITS arrays, sx / sy
     // the shift across the periodic seam where my tile lies on that domain edge
     const TileComm &m = c->comm;
     const roms_hip_config &cf = c->cfg;
     static const int ddx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, ddy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
     a.P.on = 1;
-    a.P.rim = (double *)((char *)m.peer_slab + m.loop_rim_off);
-    a.P.ring = (unsigned *)((char *)m.peer_slab + m.loop_ring_off);
+    a.P.rim = (unsigned long long *)((char *)m.peer_slab + m.loop_rim_off);
     for (int d = 0; d < 8; d++) {
       if (m.nbr[d] < 0) continue;
       const TileComm::PeerGeom &g = m.ngeom[d];
       a.P.nbmask |= 1 << d;
-      a.P.nrim[d] = (double *)((char *)m.peer_map[d] + g.rim_off);
-      a.P.nring[d] = (unsigned *)((char *)m.peer_map[d] + g.ring_off);
+      a.P.nrim[d] = (unsigned long long *)((char *)m.peer_map[d] + g.rim_off);
       const int sx = ddx[d] < 0 && cf.west_edge ? G.Lm : (ddx[d] > 0 && cf.east_edge ? -G.Lm : 0);
       const int sy = ddy[d] < 0 && cf.south_edge ? G.Mm : (ddy[d] > 0 && cf.north_edge ? -G.Mm : 0);
       a.P.nni[d] = g.ni; a.P.nnij[d] = g.ni * g.nj;
       a.P.noff[d] = (sx - g.LBi) + (sy - g.LBj) * g.ni;
     }
-    // what the first fast step reads beyond the tile (k_step2d_loop.h, prologue): the krhs = kstp level 5 | 4 lines wide; the
-    // 3-D forcing and its AB3 history on the enlarged sub-tiles (two lines)
-    const size_t o_r0s = (size_t)(G.nstp - 1) * G.nij * (size_t)(G.N + 1), o_r0n = (size_t)(G.nnew - 1) * G.nij * (size_t)(G.N + 1);
-    HaloSpec s1[6] = {{c->F.rufrc, 1, BC_NONE, 'u'}, {c->F.rvfrc, 1, BC_NONE, 'v'},
-                      {c->F.ru + o_r0n, 1, BC_NONE, 'u'}, {c->F.rv + o_r0n, 1, BC_NONE, 'v'},
-                      {c->F.ru + o_r0s, 1, BC_NONE, 'u'}, {c->F.rv + o_r0s, 1, BC_NONE, 'v'}};
-    HaloSpec s2[3] = {{lev2d(c, c->F.zeta, G.kstp), 1, BC_NONE, 'r'}, {lev2d(c, c->F.ubar, G.kstp), 1, BC_NONE, 'u'}, {lev2d(c, c->F.vbar, G.kstp), 1, BC_NONE, 'v'}};
-    launch_halo_multi(c, s1, a.startup == 0 ? 2 : (a.startup == 1 ? 4 : 6));
-    launch_halo_wide(c, s2, 3);
-    if (c->comm_failed) return 2;
+    if (!c->loop_pre_frc && step2d_loop_pre(c, 1)) return 2;
+    if (!c->loop_pre_state && step2d_loop_pre(c, 2)) return 2;
+    c->loop_pre_frc = c->loop_pre_state = false;
   }
   // the arrival words count on from launch to launch (a reset would be one more operation in the stream, 5 us + a boundary);
   // zero again long before they wrap (a multi-tile context: its ring is written by the neighbours -- 2^32 pairs are 70 million

@@ -38,17 +38,23 @@
 //
 // Multi-tile contexts (round 6, template parameter MT; mp_exchange2d of step2d_LF_AM3.h:714,842,1068,3041 inside the launch):
 // the rim of an edge block reaches into the NEIGHBOURING RANK's tile.  Every rank keeps, in its mailbox slab (uncached
-// memory the neighbours map over hipIpc / xGMI, roms_hip.cpp), two parities x {zeta, ubar, vbar} RIM PLANES laid out like its
-// own arrays, and a RING of arrival words for the neighbours' blocks around its own nbx2 x nby2 grid.  A producer stores
-// the own points that lie in a neighbour's ghost zone (4 lines towards the low side, 5 towards the high side, corners
-// included; the boundary values a closed domain edge derives from them as well) a second time, into that neighbour's rim
-// planes at the index the point has THERE (system-scope write-through stores), drains, and after the barrier lane d stores
-// the pair number into its slot of neighbour d's ring.  A consumer polls ring slots for the candidates beyond its tile and
-// loads the ghost points of its rectangle from its own rim planes (uncached: loads go to HBM).  Two parities suffice for
-// the same reason two staging levels do: the reading relation is symmetric across the tile edge too.  Between two launches
-// the 3-D exchanges of the baroclinic step order the ranks (a rank cannot start the next launch before every neighbour has
-// left this one).  Tiles of equal size on every rank (the sub-tile grids must coincide), at least one periodic direction.
-// What the pair launches exchange between the pairs is exchanged ONCE behind the launch (g_step2d.cpp).
+// memory the neighbours map over hipIpc / xGMI, roms_hip.cpp), two parities x {zeta, ubar, vbar} RIM PLANES indexed like its
+// own arrays, 16 bytes per point: two 8-byte words {low half of the value | pair number}, {high half | pair number}.  An
+// 8-byte store is atomic on every path (HBM, xGMI), so a value can be polled for directly -- no arrival word, no drain
+// between data and flag (the protocol RCCL calls LL).  Per pair
+//   producer   behind its local publication (sc1 stores, drain, arrival word: the blocks of its own tile go on at once) an
+//              edge block stores the own points that lie in a neighbour's ghost zone -- 4 lines towards the low side, 5
+//              towards the high side, corners included; the boundary values a closed domain edge derives from them as
+//              well -- into that neighbour's rim planes at the index the point has THERE (system-scope stores)
+//   consumer   every thread whose rectangle point is a ghost point of the tile polls ITS point in the rim planes until both
+//              words of all three fields carry this pair's number (bounded like the other waits), beside the wave that
+//              polls the arrival words of the tile's own blocks
+// Two parities suffice for the same reason two staging levels do: the reading relation is symmetric across the tile edge
+// too.  Between two launches the 3-D exchanges of the baroclinic step order the ranks (a rank cannot start the next launch
+// before every neighbour has left this one).  Tiles of equal size on every rank, at least one periodic direction.  What
+// the pair launches exchange between the pairs is exchanged ONCE behind the launch (g_step2d.cpp).  Measured (one MI355X,
+// the tile its own W/E neighbour through the mailbox): an arrival-word form -- stores, drain, word in the neighbour's
+// ring, poll, loads: four uncached round trips -- cost 2.7 us per pair (442 us per launch against 363 single-tile).
 // Everything else keeps the pair / per-call launches.
 #pragma once
 #include "k_step2d_pair.h"
@@ -57,15 +63,12 @@
 #define S2L_NLDS 32
 #define INR(i, j, i0, i1, j0, j1) ((i) >= (i0) && (i) <= (i1) && (j) >= (j0) && (j) <= (j1))
 #define S2L_FSTRIDE 16          // arrival words are 64 bytes apart
-#define S2L_RING 3              // sub-tiles of a neighbouring rank a rectangle can reach (sub-tiles are at least two points wide)
-// multi-tile contexts: the neighbours' rim planes and rings as mapped here, mine
+// multi-tile contexts: my rim planes and the neighbours' as mapped here
 struct S2LPeer {
   int on;                       // 0: single tile (the kernels without MT never read this struct)
   int nbmask;                   // bit d: neighbour d (W, E, S, N, SW, SE, NW, NE) exists
-  double *rim;                  // my rim planes [parity][zeta | ubar | vbar][nij]: the neighbours' edge blocks write my ghost points
-  unsigned *ring;               // arrival words of the neighbours' blocks: (nbx2 + 2 S2L_RING) x (nby2 + 2 S2L_RING) slots, mine unused
-  double *nrim[8];              // neighbour d's rim planes ...
-  unsigned *nring[8];           // ... and ring, as mapped in this process
+  unsigned long long *rim;      // my rim planes [parity][zeta | ubar | vbar][nij][2 words]: the neighbours' edge blocks write my ghost points
+  unsigned long long *nrim[8];  // neighbour d's rim planes, as mapped in this process
   int noff[8], nni[8], nnij[8]; // my point (i,j) in neighbour d's planes: i + j * nni + noff (array origin + the shift across a periodic seam)
 };
 struct Step2dLoopArgs {
@@ -106,56 +109,50 @@ KDEV void s2l_range(const DGrid &G, int bx, int by, int &i0, int &i1, int &j0, i
   j0 = KMAX(j0, 1) + G.T.Jstr - 1; j1 = KMIN(j1, MmT) + G.T.Jstr - 1;
 }
 
-// ---- multi-tile: a value of field f (0 zeta, 1 ubar, 2 vbar) of parity `par` at (i,j) -- an own point or a boundary point
-// derived from one -- goes to the local staging level and, where (i,j) lies in a neighbour's ghost zone, into that
-// neighbour's rim planes
-KDEV void s2l_sys_st(double *p, double v) {
-  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// ---- multi-tile: the value of field pf % 3 (0 zeta, 1 ubar, 2 vbar; pf = 3 * parity + field) at (i,j) -- an own point or a
+// boundary point derived from one -- goes into the rim planes of every neighbour in whose ghost zone (i,j) lies, tagged
+KDEV void s2l_ll_st(unsigned long long *q, double v, unsigned tag) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v), tg = (unsigned long long)tag << 32;
+  __hip_atomic_store(q, (b & 0xffffffffull) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(q + 1, (b >> 32) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-template <bool MT>
-KDEV void s2l_put(const Step2dLoopArgs &a, double *A, int pf, int i, int j, double v) {
-  const DGrid &G = a.G;
-  HB_ST(true, A, (int)X2(i, j), v);
-  if (MT) {
-    const TB &T = G.T;
-    const bool w = i < T.Istr + B2D_GH, e = i > T.Iend - B2D_GL, s = j < T.Jstr + B2D_GH, n = j > T.Jend - B2D_GL;
-    if (!(w || e || s || n)) return;
+KDEV void s2l_rput(const Step2dLoopArgs &a, int pf, int i, int j, double v, unsigned tag) {
+  const TB &T = a.G.T;
+  const bool w = i < T.Istr + B2D_GH, e = i > T.Iend - B2D_GL, s = j < T.Jstr + B2D_GH, n = j > T.Jend - B2D_GL;
+  if (!(w || e || s || n)) return;
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
-      const bool hit = d == 0 ? w : d == 1 ? e : d == 2 ? s : d == 3 ? n : d == 4 ? (w && s) : d == 5 ? (e && s) : d == 6 ? (w && n) : (e && n);
-      if (hit && a.P.nrim[d]) s2l_sys_st(a.P.nrim[d] + (size_t)pf * (size_t)a.P.nnij[d] + (i + j * a.P.nni[d] + a.P.noff[d]), v);
-    }
+  for (int d = 0; d < 8; d++) {       // (static indices into the argument block)
+    const bool hit = d == 0 ? w : d == 1 ? e : d == 2 ? s : d == 3 ? n : d == 4 ? (w && s) : d == 5 ? (e && s) : d == 6 ? (w && n) : (e && n);
+    if (hit && a.P.nrim[d]) s2l_ll_st(a.P.nrim[d] + 2 * ((size_t)pf * (size_t)a.P.nnij[d] + (size_t)(i + j * a.P.nni[d] + a.P.noff[d])), v, tag);
   }
 }
-// hb_emit2<true> without the periodic images (a multi-tile context has none inside the launch: rim indices beyond the tile
-// are the neighbours' points): the point and the boundary values a closed DOMAIN edge derives from it (k_haloblock.h)
-template <bool MT>
-KDEV void s2l_emit(const Step2dLoopArgs &a, const TB &B, double *A, int pf, int bc, int i, int j, double v) {
+// the point and the boundary values a closed DOMAIN edge derives from it: the rules of hb_emit2 (k_haloblock.h)
+KDEV void s2l_remit(const Step2dLoopArgs &a, const TB &B, int pf, int bc, int i, int j, double v, unsigned tag) {
   const DGrid &G = a.G;
-  s2l_put<MT>(a, A, pf, i, j, v);
+  s2l_rput(a, pf, i, j, v, tag);
   if (i > 2 && i < G.Lm && j > 2 && j < G.Mm) return;
   if (!G.nsp) {
     if (bc == BC_R) {
-      if (B.south && j == B.Jstr) s2l_put<MT>(a, A, pf, i, j - 1, v);
-      if (B.north && j == B.Jend) s2l_put<MT>(a, A, pf, i, j + 1, v);
+      if (B.south && j == B.Jstr) s2l_rput(a, pf, i, j - 1, v, tag);
+      if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, v, tag);
     } else if (bc == BC_U) {
-      if (B.south && j == B.Jstr) s2l_put<MT>(a, A, pf, i, j - 1, G.gamma2 * v);
-      if (B.north && j == B.Jend) s2l_put<MT>(a, A, pf, i, j + 1, G.gamma2 * v);
+      if (B.south && j == B.Jstr) s2l_rput(a, pf, i, j - 1, G.gamma2 * v, tag);
+      if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, G.gamma2 * v, tag);
     } else if (bc == BC_V) {
-      if (B.south && j == B.JstrV) s2l_put<MT>(a, A, pf, i, B.Jstr, 0.0);
-      if (B.north && j == B.Jend) s2l_put<MT>(a, A, pf, i, j + 1, 0.0);
+      if (B.south && j == B.JstrV) s2l_rput(a, pf, i, B.Jstr, 0.0, tag);
+      if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, 0.0, tag);
     }
   }
   if (!G.ewp) {
     if (bc == BC_R) {
-      if (B.west && i == B.Istr) s2l_put<MT>(a, A, pf, i - 1, j, v);
-      if (B.east && i == B.Iend) s2l_put<MT>(a, A, pf, i + 1, j, v);
+      if (B.west && i == B.Istr) s2l_rput(a, pf, i - 1, j, v, tag);
+      if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, v, tag);
     } else if (bc == BC_U) {
-      if (B.west && i == B.IstrU) s2l_put<MT>(a, A, pf, B.Istr, j, 0.0);
-      if (B.east && i == B.Iend) s2l_put<MT>(a, A, pf, i + 1, j, 0.0);
+      if (B.west && i == B.IstrU) s2l_rput(a, pf, B.Istr, j, 0.0, tag);
+      if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, 0.0, tag);
     } else if (bc == BC_V) {
-      if (B.west && i == B.Istr) s2l_put<MT>(a, A, pf, i - 1, j, G.gamma2 * v);
-      if (B.east && i == B.Iend) s2l_put<MT>(a, A, pf, i + 1, j, G.gamma2 * v);
+      if (B.west && i == B.Istr) s2l_rput(a, pf, i - 1, j, G.gamma2 * v, tag);
+      if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, G.gamma2 * v, tag);
     }
   }
 }
@@ -222,6 +219,10 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
   // (multi-tile) a rectangle point outside the tile and the boundary points of its closed domain edges: a ghost point, its
   // value comes from a neighbouring rank's block through my rim planes
   const bool rem = MT && rp && !INR(iw, jw, G.T.IstrR, G.T.IendR, G.T.JstrR, G.T.JendR);
+  // ... and one the neighbours do write: inside the arrays, and inside the strips they publish (5 lines on my low side, 4 on my
+  // high side, towards a side that has a neighbour)
+  const bool remv = rem && ina && INR(iw, jw, (a.P.nbmask & 1) ? G.T.Istr - B2D_GL : G.T.IstrR, (a.P.nbmask & 2) ? G.T.Iend + B2D_GH : G.T.IendR,
+                                      (a.P.nbmask & 4) ? G.T.Jstr - B2D_GL : G.T.JstrR, (a.P.nbmask & 8) ? G.T.Jend + B2D_GH : G.T.JendR);
   const bool IMG = !MT;                                                                 // periodic images: a single tile stores its own
   // ---- ... and momentum point: cell c of the enlarged sub-tile, its u-point (threads 0..VOFF-1) or v-point (VOFF..)
   const int isvt = t >= VOFF ? 1 : 0, c = t - isvt * VOFF;
@@ -269,50 +270,24 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
   // the blocks whose own points this block's rectangle touches (their results are its rim): lane q of wave 0 takes
   // the candidate at offset (q % 7 - 3, q / 7 - 3) -- sub-tiles are at least two points wide and high (g_step2d.cpp)
   int nbf = -1;
-  bool nbrem = false;                    // (multi-tile) the candidate is a block of a neighbouring rank: its word is in my ring
   if (t < 49) {
     const int dx = t % 7 - 3, dy = t / 7 - 3;
-    int nx = bx + dx, ny = by + dy, sx = 0, sy = 0, rx = 0, ry = 0;
+    int nx = bx + dx, ny = by + dy, sx = 0, sy = 0;
     bool ok = true;
-    const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
     if (wrapx) { while (nx < 0) { nx += G.nbx2; sx -= G.Lm; } while (nx >= G.nbx2) { nx -= G.nbx2; sx += G.Lm; } }
-    else if (MT && nx < 0 && nx >= -G.nbx2 && (a.P.nbmask & 1)) { rx = -1; nx += G.nbx2; sx = -LmT; }
-    else if (MT && nx >= G.nbx2 && nx < 2 * G.nbx2 && (a.P.nbmask & 2)) { rx = 1; nx -= G.nbx2; sx = LmT; }
-    else if (nx < 0 || nx >= G.nbx2) ok = false;
+    else if (nx < 0 || nx >= G.nbx2) ok = false;       // (multi-tile: beyond the tile the points arrive tagged, without a word)
     if (wrapy) { while (ny < 0) { ny += G.nby2; sy -= G.Mm; } while (ny >= G.nby2) { ny -= G.nby2; sy += G.Mm; } }
-    else if (MT && ny < 0 && ny >= -G.nby2 && (a.P.nbmask & 4)) { ry = -1; ny += G.nby2; sy = -MmT; }
-    else if (MT && ny >= G.nby2 && ny < 2 * G.nby2 && (a.P.nbmask & 8)) { ry = 1; ny -= G.nby2; sy = MmT; }
     else if (ny < 0 || ny >= G.nby2) ok = false;
-    if (MT && (rx || ry)) {              // the rank that owns the candidate: W, E, S, N or a corner
-      const int d = ry == 0 ? (rx < 0 ? 0 : 1) : rx == 0 ? (ry < 0 ? 2 : 3) : (ry < 0 ? (rx < 0 ? 4 : 5) : (rx < 0 ? 6 : 7));
-      if (!(a.P.nbmask & (1 << d))) ok = false;
-    }
-    if (ok && (rx || ry || !(nx == bx && ny == by))) {
+    if (ok && !(nx == bx && ny == by)) {
       int p0, p1, q0, q1;
       s2l_range(G, nx, ny, p0, p1, q0, q1);
-      // (the rectangle as far as the arrays reach: the ghost zone towards a neighbouring rank is 5 | 4 lines)
-      const int ri0 = MT ? KMAX(B.Istr - S2P_RIM, G.LBi) : B.Istr - S2P_RIM, ri1 = MT ? KMIN(B.Iend + S2P_RIM, UBi) : B.Iend + S2P_RIM;
-      const int rj0 = MT ? KMAX(B.Jstr - S2P_RIM, G.LBj) : B.Jstr - S2P_RIM, rj1 = MT ? KMIN(B.Jend + S2P_RIM, UBj) : B.Jend + S2P_RIM;
-      if (p0 + sx <= ri1 && p1 + sx >= ri0 && q0 + sy <= rj1 && q1 + sy >= rj0) {
-        if (MT && (rx || ry)) {
-          nbrem = true;
-          nbf = ((nx + rx * G.nbx2 + S2L_RING) + (G.nbx2 + 2 * S2L_RING) * (ny + ry * G.nby2 + S2L_RING)) * S2L_FSTRIDE;
-        } else nbf = (nx + G.nbx2 * ny) * S2L_FSTRIDE;
-      }
+      if (p0 + sx <= B.Iend + S2P_RIM && p1 + sx >= B.Istr - S2P_RIM && q0 + sy <= B.Jend + S2P_RIM && q1 + sy >= B.Jstr - S2P_RIM)
+        nbf = (nx + G.nbx2 * ny) * S2L_FSTRIDE;
     }
   }
-  // (multi-tile) the neighbouring ranks this block's own points reach: lane d publishes the block's arrival in neighbour d's ring
-  bool pubd = false;
-  int pubx = 0;
-  if (MT && t < 8) {
-    const TB &T = G.T;
-    const bool w = B.Istr < T.Istr + B2D_GH, e = B.Iend > T.Iend - B2D_GL, s_ = B.Jstr < T.Jstr + B2D_GH, n = B.Jend > T.Jend - B2D_GL;
-    const int ddx = (t == 0 || t == 4 || t == 6) ? -1 : ((t == 1 || t == 5 || t == 7) ? 1 : 0);
-    const int ddy = (t == 2 || t == 4 || t == 5) ? -1 : ((t == 3 || t == 6 || t == 7) ? 1 : 0);
-    pubd = (a.P.nbmask & (1 << t)) && (ddx == 0 || (ddx < 0 ? w : e)) && (ddy == 0 || (ddy < 0 ? s_ : n));
-    // my block as the neighbour numbers it: its own grid continued across the tile edge
-    pubx = ((bx - ddx * G.nbx2 + S2L_RING) + (G.nbx2 + 2 * S2L_RING) * (by - ddy * G.nby2 + S2L_RING)) * S2L_FSTRIDE;
-  }
+  // (multi-tile) does any own point of this block lie in a neighbour's ghost zone?
+  const bool edgeblk = MT && ((B.Istr < G.T.Istr + B2D_GH && (a.P.nbmask & 1)) || (B.Iend > G.T.Iend - B2D_GL && (a.P.nbmask & 2)) ||
+                              (B.Jstr < G.T.Jstr + B2D_GH && (a.P.nbmask & 4)) || (B.Jend > G.T.Jend - B2D_GL && (a.P.nbmask & 8)));
   bool dead = false;
   KSYNC();
 
@@ -567,8 +542,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         gzeta2[s0] = gz * zw;
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (own) {
-          if (MT) s2l_emit<MT>(a, B, zout, 3 * (p & 1), BC_R, i, j, zeta_new);
-          else hb_emit2<true>(G, B, zout, BC_R, i, j, zeta_new, nullptr, img0);
+          hb_emit2<true>(G, B, zout, BC_R, i, j, zeta_new, nullptr, img0);
           ZQ[s0] = zeta_new;
         }
       }
@@ -597,10 +571,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           const double rp_ = w_rp;
           const double b = f1 ? (sv * (Dstp0 + Dstp1) + cff * (0.5 * dtfast) * r) * fac
                               : (sv * (Dstp0 + Dstp1) + cff * (k1 * r + k2 * rs - k3 * rp_)) * fac;
-          if (MT) {
-            if (!isv) { s2l_emit<MT>(a, B, uout, 3 * (p & 1) + 1, BC_U, mi, mj, b); UQ[s] = b; }
-            else { s2l_emit<MT>(a, B, vout, 3 * (p & 1) + 2, BC_V, mi, mj, b); VQ[s] = b; }
-          } else if (!isv) { hb_emit2<true>(G, B, uout, BC_U, mi, mj, b, nullptr, img0); UQ[s] = b; }
+          if (!isv) { hb_emit2<true>(G, B, uout, BC_U, mi, mj, b, nullptr, img0); UQ[s] = b; }
           else { hb_emit2<true>(G, B, vout, BC_V, mi, mj, b, nullptr, img0); VQ[s] = b; }
         }
       }
@@ -611,16 +582,49 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its write-through stores have left
     KSYNC();
     if (t == 0) __hip_atomic_store(a.flags + me * S2L_FSTRIDE, a.epoch + (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (MT && pubd) {
+    if (MT && edgeblk) {
+      // the neighbouring ranks' ghost points, tagged with the pair (the values are in the Q tiles: the own points' threads stored them)
+      const unsigned tag = a.epoch + (unsigned)(p + 1);
+      if (own) s2l_remit(a, B, 3 * (p & 1), BC_R, i, j, ZQ[s0_], tag);
+      if (mO) s2l_remit(a, B, 3 * (p & 1) + 1 + isvt, isvt ? BC_V : BC_U, mi, mj, (isvt ? VQ : UQ)[ms_], tag);
+    }
+    if (MT && remv && !dead) {
+      // my ghost point: until all six words carry this pair's number (two 16-byte loads per field would do as well: each
+      // 8-byte word is checked by itself)
+      const unsigned tag = a.epoch + (unsigned)(p + 1);
+      const unsigned long long *rq = a.P.rim + 2 * ((size_t)(3 * (p & 1)) * (size_t)G.nij + (size_t)x0);
+      const long long t0 = wall_clock64();
+      for (;;) {
+        unsigned long long w[6];
 #pragma unroll
-      for (int d = 0; d < 8; d++)          // (static indices into the argument block)
-        if (t == d) __hip_atomic_store(a.P.nring[d] + pubx, a.epoch + (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int f = 0; f < 3; f++) {
+          w[2 * f] = __hip_atomic_load(rq + 2 * (size_t)f * (size_t)G.nij, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          w[2 * f + 1] = __hip_atomic_load(rq + 2 * (size_t)f * (size_t)G.nij + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        // (no u-points west of a closed western edge's wall, no v-points south of a closed southern one: nobody writes them)
+        const bool nu = G.ewp || iw >= 1, nv = G.nsp || jw >= 1;
+        const bool all = (unsigned)(w[0] >> 32) == tag && (unsigned)(w[1] >> 32) == tag &&
+                         (!nu || ((unsigned)(w[2] >> 32) == tag && (unsigned)(w[3] >> 32) == tag)) &&
+                         (!nv || ((unsigned)(w[4] >> 32) == tag && (unsigned)(w[5] >> 32) == tag));
+        if (all) {
+          const double z = __longlong_as_double((long long)((w[0] & 0xffffffffull) | (w[1] << 32)));
+          DQ[s0_] = z + sH[s0_]; ZQ[s0_] = z;
+          UQ[s0_] = __longlong_as_double((long long)((w[2] & 0xffffffffull) | (w[3] << 32)));
+          VQ[s0_] = __longlong_as_double((long long)((w[4] & 0xffffffffull) | (w[5] << 32)));
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > a.timeout) {
+          dead = true;
+          *(volatile unsigned long long *)a.err = ((unsigned long long)(p + 1) << 32) | (unsigned long long)(me + 1);
+          break;
+        }
+      }
     }
     if (t < 64) {
       if (nbf >= 0 && !dead) {
         const long long t0 = wall_clock64();
-        while ((MT && nbrem ? __hip_atomic_load(a.P.ring + nbf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                            : __hip_atomic_load(a.flags + nbf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < a.epoch + (unsigned)(p + 1)) {
+        while (__hip_atomic_load(a.flags + nbf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.epoch + (unsigned)(p + 1)) {
           __builtin_amdgcn_s_sleep(1);
           if (wall_clock64() - t0 > a.timeout) {
             dead = true;
@@ -638,13 +642,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
       // other point of the rectangle -- the rim, and the boundary values behind a closed edge -- is some block's result
       const bool oz = own, ou = own && i >= B.IstrU, ov = own && j >= B.JstrV;
       if (MT && rem) {
-        if (ina) {                         // a ghost point of the tile: from my rim planes (uncached memory: the loads go to HBM)
-          const double *rq = a.P.rim + (size_t)(3 * (p & 1)) * (size_t)G.nij + x0;
-          const double z = __builtin_nontemporal_load(rq);
-          DQ[s0] = z + sH[s0]; ZQ[s0] = z;
-          UQ[s0] = __builtin_nontemporal_load(rq + G.nij);
-          VQ[s0] = __builtin_nontemporal_load(rq + 2 * G.nij);
-        }
+        // (a ghost point of the tile: it arrived above, or nobody writes it -- behind a closed domain edge without a neighbour)
       } else if (ina) {
         if (!oz) { const double z = s2l_ld(zout + x0); DQ[s0] = z + sH[s0]; ZQ[s0] = z; }
         if (!ou) UQ[s0] = s2l_ld(uout + x0);

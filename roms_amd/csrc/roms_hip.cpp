@@ -1134,12 +1134,10 @@ extern "C" int roms_hip_peer_export(roms_hip_ctx *c, void *blob128) {
           off += ((size_t)m.peer_planes * w * sizeof(double) + 255) & ~(size_t)255;
         }
     m.loop_rim_off = m.loop_ring_off = 0;
-    if (c->pair_mt) {                                             // rim planes [2][3][nij] and the ring of the persistent barotropic loop
+    if (c->pair_mt) {                                             // rim planes of the persistent barotropic loop: [2][3][nij] x 16 bytes (k_step2d_loop.h)
       step2d_loop_dims(c, m.loop_nb2[0], m.loop_nb2[1]);
       m.loop_rim_off = off;
-      off += ((size_t)6 * (size_t)G.nij * sizeof(double) + 255) & ~(size_t)255;
-      m.loop_ring_off = off;
-      off += ((size_t)(m.loop_nb2[0] + 6) * (size_t)(m.loop_nb2[1] + 6) * 16 * sizeof(unsigned) + 255) & ~(size_t)255;
+      off += ((size_t)6 * (size_t)G.nij * 16 + 255) & ~(size_t)255;
     }
     m.peer_bytes = off;
     {
@@ -1165,7 +1163,7 @@ extern "C" int roms_hip_peer_export(roms_hip_ctx *c, void *blob128) {
   b.device = c->cfg.device; b.planes = m.peer_planes; b.magic = PEER_MAGIC;
   b.LBi = (short)c->G.LBi; b.LBj = (short)c->G.LBj; b.ni = (short)c->G.ni; b.nj = (short)c->G.nj;
   b.nbx2 = (short)m.loop_nb2[0]; b.nby2 = (short)m.loop_nb2[1];
-  b.rim_off256 = (unsigned)(m.loop_rim_off >> 8); b.ring_off256 = (unsigned)(m.loop_ring_off >> 8);
+  b.rim_off256 = (unsigned)(m.loop_rim_off >> 8); b.ring_off256 = 0;
   b.busid = m.busid;
   memcpy(blob128, &b, sizeof(b));
   return 0;
@@ -1984,6 +1982,8 @@ static int main3d_around_loop(roms_hip_ctx *c, bool do_diag, int form, bool with
   lane_record(c, E_W);
   DO(roms_hip_set_zeta(c));                                 // :556
   lane_record(c, E_Z);
+  // (multi-tile: the level the loop's first fast step starts from, 5 | 4 lines wide -- here, 300 us ahead of the launch)
+  if (c->has_exchange) DO(step2d_loop_pre(c, 2));
   lane_wait(c, E_EOS);
   DO(roms_hip_prsgrd(c));                                   // rhs3d.F: prsgrd, rhs3d_tile
   DO(run_rhs3d_pt(c));
@@ -2038,6 +2038,7 @@ static int main3d_around_loop(roms_hip_ctx *c, bool do_diag, int form, bool with
   lane_wait(c, E_UV);
   lane_wait(c, E_D);
   DO(run_rufrc_sums(c));                                    // (the predictor on this stream, the loop behind it in-stream: 0.849 against 0.828 ms)
+  if (c->has_exchange) DO(step2d_loop_pre(c, 1));           // (multi-tile: the forcing on the enlarged sub-tiles, while the other lanes finish)
   if (!diag_main) lane_wait(c, E_X);
   lane_wait(c, E_T3);                                       // (nothing beside the loop)
   lane_wait(c, E_AK);
@@ -2085,6 +2086,7 @@ static int main3d_one(roms_hip_ctx *c) {
   s.nrhs = s.nstp;
   ctx_sync_stepping(c);
   DO(poison_work(c));                                       // (ROMS_HIP_POISON=1 only)
+  c->loop_pre_frc = c->loop_pre_state = false;
   if (c->diag_join_pending && !(late_schedule_ok(c) && around_loop_form(c) > 0)) { lane_wait(c, 11); c->diag_join_pending = false; }
   // set_data (:258) feeds bulk_flux / set_vbc only: the schedule around the persistent loop places it on a side stream
   // beside rho_eos (main3d_around_loop); post_initial reads none of its fields

@@ -46,7 +46,7 @@ struct TileComm {
   bool peer_on;
   bool peer_shared;             // a neighbour rank runs on the SAME device (several ranks sharing one GPU: test set-ups)
   long nexchanges;
-  // the persistent barotropic loop across tiles (k_step2d_loop.h, S2LPeer): my rim planes and ring inside the slab, and the
+  // the persistent barotropic loop across tiles (k_step2d_loop.h, S2LPeer): my rim planes inside the slab, and the
   // neighbours' as their blobs describe them
   size_t loop_rim_off, loop_ring_off;   // byte offsets in MY slab (0: the slab has no such region)
   int loop_nb2[2];                      // the loop's sub-tile grid the region was sized for
@@ -97,6 +97,8 @@ struct roms_hip_ctx {
   unsigned loop_epoch;          // ... hold at most this value (the pairs of all launches so far)
   double *loop_wts;             // weights per pair (device)
   unsigned long long *loop_err; // pinned host word: a wait for a neighbouring block gave up (ctx_check reports it)
+  bool loop_pre_frc = false;    // (multi-tile) this step's schedule has already exchanged what the loop's first fast step reads beyond the tile:
+  bool loop_pre_state = false;  // the 3-D forcing and its history | the kstp level of zeta, ubar, vbar (step2d_loop_pre)
   bool diag_ran;                // a diag report was enqueued since the last blow-up test (roms_hip_main3d)
   int diag_step = -1;           // step count (iic-1) of the report in d_diag, -1: none yet
   DGrid G;
@@ -253,6 +255,7 @@ int run_step2d(roms_hip_ctx *c);
 int run_step2d_pair(roms_hip_ctx *c);     // predictor (c->G = its stepping) + corrector of one fast step
 bool step2d_pair_usable(const roms_hip_ctx *c);
 bool step2d_loop_usable(roms_hip_ctx *c);   // fast steps 2 .. nfast as one persistent launch (k_step2d_loop.h)
+int step2d_loop_pre(roms_hip_ctx *c, int what);   // (multi-tile) 1: exchange rufrc, rvfrc and the AB3 history; 2: the kstp level of the barotropic state, wide
 void step2d_loop_dims(const roms_hip_ctx *c, int &nbx2, int &nby2);   // its sub-tile grid (the mailbox slab holds a ring of arrival words around it)
 int run_step2d_loop(roms_hip_ctx *c);       // c->G = the stepping of the predictor call of iif = 2, or of iif = 1: then the first fast
                                             // step and the auxiliary call iif = nfast+1 run inside the launch too
