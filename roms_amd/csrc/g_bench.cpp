@@ -22,9 +22,13 @@ static const double k_mu2[9] = {23.0, 20.0, 17.0, 14.0, 7.9, 5.13, 3.54, 2.34, 1
 static const double k_r1[9] = {0.58, 0.62, 0.67, 0.77, 0.78, 0.57, 0.57, 0.57, 0.55};
 
 int run_eos_nonlinear(roms_hip_ctx *c) {
-  const TB &B = c->G.T;
   const int N = c->G.N;
   KArgs a = mk(c);
+  // (a multi-tile context: the ghost columns with the tile -- t, z_r, z_w, Hz are valid there, every output is a function of its
+  // own column -- and no exchange behind it: roms_host.h:ghost_tb)
+  const bool gc = ghost_compute(c, 4);
+  if (gc) a.G.T = ghost_tb(c, 3, c->G.Nghost);
+  const TB B = a.G.T;
   const int nxe = B.IendT - B.IstrT + 1, nye = B.JendT - B.JstrT + 1;
   static const char *ept = getenv("ROMS_HIP_EOSPT");
   if (ept ? ept[0] != '0' : (long)nxe * nye <= 64L * 1024L) {       // few columns: chunks of five levels per thread + the column sums
@@ -33,7 +37,7 @@ int run_eos_nonlinear(roms_hip_ctx *c) {
     LAUNCH_THREAD(k_eos_nl_pt, nxe, nye, (N + a.p0 - 1) / a.p0, c->stream, a);
     LAUNCH_THREAD(k_eos_sum, nxe, nye, 1, c->stream, a);
   } else LAUNCH_THREAD(k_eos_nl, nxe, nye, 1, c->stream, a);
-  if (c->G.fuse3d) return 0;   // the kernel stored the periodic images itself (pt_emit)
+  if (c->G.fuse3d || gc) return 0;   // the kernel stored the periodic images itself (pt_emit) | computed the ghost columns
   HaloSpec sp[7] = {{c->F.rho, N, BC_NONE, 'r'},  {c->F.pden, N, BC_NONE, 'r'}, {c->F.alpha, 1, BC_NONE, 'r'},
                     {c->F.beta, 1, BC_NONE, 'r'}, {c->F.rhoA, 1, BC_NONE, 'r'}, {c->F.rhoS, 1, BC_NONE, 'r'},
                     {c->F.bvf, N + 1, BC_NONE, 'r'}};
@@ -201,6 +205,12 @@ int run_set_data_benchmark(roms_hip_ctx *c) {
   double Dangle = 23.44 * cos((172.0 - yday) * 2.0 * pi / 365.2425);   // ana_srflux.h:215-220
   a.Dangle = Dangle * deg2rad;
   a.Hangle = (12.0 - hour) * pi / 12.0;
+  if (ghost_compute(c, 2)) {     // analytic fields of the position: the ghost points with the tile, no exchange (ana_*.h: exchange_r2d_tile)
+    const TB X = ghost_tb(c, 3, G.Nghost);
+    a.G.T = X;
+    LAUNCH_THREAD(k_set_data_bm, X.IendT - X.IstrT + 1, X.JendT - X.JstrT + 1, 1, c->stream, a);
+    return 0;
+  }
   LAUNCH_THREAD(k_set_data_bm, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
   if (G.fuse3d) return 0;   // the kernel stored the periodic images itself (emit_store)
   HaloSpec s1[8] = {{c->F.cloud, 1, BC_NONE, 'r'}, {c->F.Tair, 1, BC_NONE, 'r'},  {c->F.Hair, 1, BC_NONE, 'r'},

@@ -21,6 +21,19 @@ int run_set_depth(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   const int N = c->G.N;
   KArgs a = mk(c);
+  if (ghost_compute(c, 1)) {
+    // Zt_avg1 and h carry valid ghost lines (the exchange behind the fast steps; ini_zeta): depths and thicknesses there are
+    // functions of the column's own Zt_avg1 and h -- computed with the tile, no exchange (set_depth.F:417-440)
+    if (!c->h_ghost_done) {      // (the reference exchanges the time-invariant h with every call: once is enough)
+      const HaloSpec hh = {c->F.h, 1, BC_NONE, 'r'};
+      launch_halo_multi(c, &hh, 1);
+      c->h_ghost_done = true;
+    }
+    const TB X = ghost_tb(c, 3, c->G.Nghost);
+    a.G.T = X;
+    LAUNCH_THREAD(k_set_depth, X.IendT - X.IstrT + 1, X.JendT - X.JstrT + 1, N, c->stream, a);
+    return 0;
+  }
   LAUNCH_THREAD(k_set_depth, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, N, c->stream, a);
   if (c->G.fuse3d) return 0;   // the kernel stored the periodic images itself (emit_store); h is time-invariant
   const HaloSpec hs1[] = {
@@ -37,6 +50,15 @@ int run_set_massflux(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   const int N = c->G.N;
   KArgs a = mk(c);
+  if (ghost_compute(c, 8) && c->G.Nghost == 2) {
+    // Huon(i) = f(Hz(i-1), Hz(i), u(i)): with Hz and u valid on 3 | 2 ghost lines the fluxes on the two ghost lines the
+    // reference's exchange fills (NghostPoints = 2) are computed with the tile (set_massflux.F:139-160)
+    const TB X = ghost_tb(c, 2, 2);
+    a.G.T = X;
+    const int x0 = KMIN(X.IstrP, X.IstrT), y0 = KMIN(X.JstrT, X.JstrP);
+    LAUNCH_THREAD(k_set_massflux, X.IendT - x0 + 1, X.JendT - y0 + 1, N, c->stream, a);
+    return 0;
+  }
   const int i0 = KMIN(B.IstrP, B.IstrT), j0 = KMIN(B.JstrT, B.JstrP);
   LAUNCH_THREAD(k_set_massflux, B.IendT - i0 + 1, B.JendT - j0 + 1, N, c->stream, a);
   if (c->G.fuse3d) return 0;   // the kernel stored the periodic images itself (pt_emit)
@@ -53,6 +75,12 @@ int run_rho_eos(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   const int N = c->G.N;
   KArgs a = mk(c);
+  if (ghost_compute(c, 4)) {      // (the ghost columns with the tile, no exchange: run_eos_nonlinear)
+    const TB X = ghost_tb(c, 3, c->G.Nghost);
+    a.G.T = X;
+    LAUNCH_THREAD(k_rho_eos_lin, X.IendT - X.IstrT + 1, X.JendT - X.JstrT + 1, 1, c->stream, a);
+    return 0;
+  }
   LAUNCH_THREAD(k_rho_eos_lin, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, 1, c->stream, a);
   if (c->G.fuse3d) return 0;   // the kernel stored the periodic images itself (pt_emit)
   const HaloSpec hs3[] = {

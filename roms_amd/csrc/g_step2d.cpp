@@ -493,6 +493,7 @@ int run_step2d_loop_n(roms_hip_ctx *c, int whole) {
     const roms_hip_config &cf = c->cfg;
     static const int ddx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, ddy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
     a.P.on = 1;
+    { static const char *ee = getenv("ROMS_HIP_LOOP_EARLY"); a.P.early = ee && ee[0] == '1' ? 1 : 0; }
     a.P.rim = (unsigned long long *)((char *)m.peer_slab + m.loop_rim_off);
     for (int d = 0; d < 8; d++) {
       if (m.nbr[d] < 0) continue;

@@ -66,6 +66,7 @@
 // multi-tile contexts: my rim planes and the neighbours' as mapped here
 struct S2LPeer {
   int on;                       // 0: single tile (the kernels without MT never read this struct)
+  int early;                    // 1: a value goes to the neighbours where it is computed, in front of the local drain (ROMS_HIP_LOOP_EARLY)
   int nbmask;                   // bit d: neighbour d (W, E, S, N, SW, SE, NW, NE) exists
   unsigned long long *rim;      // my rim planes [parity][zeta | ubar | vbar][nij][2 words]: the neighbours' edge blocks write my ghost points
   unsigned long long *nrim[8];  // neighbour d's rim planes, as mapped in this process
@@ -543,6 +544,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (own) {
           hb_emit2<true>(G, B, zout, BC_R, i, j, zeta_new, nullptr, img0);
+          if (MT && edgeblk && a.P.early) s2l_remit(a, B, 3 * (p & 1), BC_R, i, j, zeta_new, a.epoch + (unsigned)(p + 1));
           ZQ[s0] = zeta_new;
         }
       }
@@ -573,6 +575,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
                               : (sv * (Dstp0 + Dstp1) + cff * (k1 * r + k2 * rs - k3 * rp_)) * fac;
           if (!isv) { hb_emit2<true>(G, B, uout, BC_U, mi, mj, b, nullptr, img0); UQ[s] = b; }
           else { hb_emit2<true>(G, B, vout, BC_V, mi, mj, b, nullptr, img0); VQ[s] = b; }
+          if (MT && edgeblk && a.P.early) s2l_remit(a, B, 3 * (p & 1) + 1 + isv, isv ? BC_V : BC_U, mi, mj, b, a.epoch + (unsigned)(p + 1));
         }
       }
     }
@@ -582,12 +585,40 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its write-through stores have left
     KSYNC();
     if (t == 0) __hip_atomic_store(a.flags + me * S2L_FSTRIDE, a.epoch + (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (MT && edgeblk) {
+    if (MT && edgeblk && !a.P.early) {
       // the neighbouring ranks' ghost points, tagged with the pair (the values are in the Q tiles: the own points' threads stored them)
       const unsigned tag = a.epoch + (unsigned)(p + 1);
       if (own) s2l_remit(a, B, 3 * (p & 1), BC_R, i, j, ZQ[s0_], tag);
       if (mO) s2l_remit(a, B, 3 * (p & 1) + 1 + isvt, isvt ? BC_V : BC_U, mi, mj, (isvt ? VQ : UQ)[ms_], tag);
     }
+    if (t < 64) {
+      if (nbf >= 0 && !dead) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(a.flags + nbf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.epoch + (unsigned)(p + 1)) {
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t0 > a.timeout) {
+            dead = true;
+            *(volatile unsigned long long *)a.err = ((unsigned long long)(p + 1) << 32) | (unsigned long long)(me + 1);
+            break;
+          }
+        }
+      }
+    }
+    KSYNC();
+    S2L_TICK(6);
+    if (rp) {
+      const int s0 = s0_;
+      // own points keep what the block computed (stored to ZQ, DQ, UQ, VQ by their threads); every
+      // other point of the rectangle -- the rim, and the boundary values behind a closed edge -- is some block's result
+      const bool oz = own, ou = own && i >= B.IstrU, ov = own && j >= B.JstrV;
+      if (!(MT && rem) && ina) {
+        if (!oz) { const double z = s2l_ld(zout + x0); DQ[s0] = z + sH[s0]; ZQ[s0] = z; }
+        if (!ou) UQ[s0] = s2l_ld(uout + x0);
+        if (!ov) VQ[s0] = s2l_ld(vout + x0);
+      }
+    }
+    // (multi-tile) the ghost points of the tile, behind the loads from the tile's own blocks: what the neighbouring ranks stored
+    // has been on its way while this block waited for the arrival words and loaded its local rim
     if (MT && remv && !dead) {
       // my ghost point: until all six words carry this pair's number (two 16-byte loads per field would do as well: each
       // 8-byte word is checked by itself)
@@ -619,34 +650,6 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           *(volatile unsigned long long *)a.err = ((unsigned long long)(p + 1) << 32) | (unsigned long long)(me + 1);
           break;
         }
-      }
-    }
-    if (t < 64) {
-      if (nbf >= 0 && !dead) {
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(a.flags + nbf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.epoch + (unsigned)(p + 1)) {
-          __builtin_amdgcn_s_sleep(1);
-          if (wall_clock64() - t0 > a.timeout) {
-            dead = true;
-            *(volatile unsigned long long *)a.err = ((unsigned long long)(p + 1) << 32) | (unsigned long long)(me + 1);
-            break;
-          }
-        }
-      }
-    }
-    KSYNC();
-    S2L_TICK(6);
-    if (rp) {
-      const int s0 = s0_;
-      // own points keep what the block computed (stored to ZQ, DQ, UQ, VQ by their threads); every
-      // other point of the rectangle -- the rim, and the boundary values behind a closed edge -- is some block's result
-      const bool oz = own, ou = own && i >= B.IstrU, ov = own && j >= B.JstrV;
-      if (MT && rem) {
-        // (a ghost point of the tile: it arrived above, or nobody writes it -- behind a closed domain edge without a neighbour)
-      } else if (ina) {
-        if (!oz) { const double z = s2l_ld(zout + x0); DQ[s0] = z + sH[s0]; ZQ[s0] = z; }
-        if (!ou) UQ[s0] = s2l_ld(uout + x0);
-        if (!ov) VQ[s0] = s2l_ld(vout + x0);
       }
     }
     w_rp = w_rP;

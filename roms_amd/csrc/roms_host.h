@@ -1,6 +1,7 @@
 // roms_host.h -- host-side context of libroms_hip.so (shared by the translation units).
 #pragma once
 #include "roms_ctx.h"
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -97,6 +98,7 @@ struct roms_hip_ctx {
   unsigned loop_epoch;          // ... hold at most this value (the pairs of all launches so far)
   double *loop_wts;             // weights per pair (device)
   unsigned long long *loop_err; // pinned host word: a wait for a neighbouring block gave up (ctx_check reports it)
+  bool h_ghost_done = false;    // (multi-tile) the ghost lines of h have been exchanged once (run_set_depth computes the ghost columns itself)
   bool loop_pre_frc = false;    // (multi-tile) this step's schedule has already exchanged what the loop's first fast step reads beyond the tile:
   bool loop_pre_state = false;  // the 3-D forcing and its history | the kstp level of zeta, ubar, vbar (step2d_loop_pre)
   bool diag_ran;                // a diag report was enqueued since the last blow-up test (roms_hip_main3d)
@@ -267,6 +269,25 @@ int run_gls_prestep(roms_hip_ctx *c);
 int run_gls_corstep(roms_hip_ctx *c);
 int run_diag(roms_hip_ctx *c, double *out);
 int run_copy_probe(roms_hip_ctx *c, int reps);
+
+// A multi-tile context: the tile's bounds extended by gl | gh ghost lines towards every side that is not a physical edge.
+// A POINT-WISE producer whose inputs are valid on those lines computes them itself -- the same expression on the same
+// operands the neighbour evaluates at its own points, so the same bits -- and the strip exchange the reference issues behind
+// it (exchange_r3d_tile + mp_exchange3d at the tail of set_depth, ana_* ...) is not needed.  ROMS_HIP_GHOSTCOMP=0: exchange.
+// (a mask: 1 set_depth, 2 set_data, 4 rho_eos, 8 set_massflux; default all)
+inline bool ghost_compute(const roms_hip_ctx *c, int which) {
+  static const char *e = getenv("ROMS_HIP_GHOSTCOMP");
+  static const int mask = e ? atoi(e) : 15;
+  return c->has_exchange && (mask & which);
+}
+inline TB ghost_tb(const roms_hip_ctx *c, int gl, int gh) {
+  const roms_hip_config &cf = c->cfg;
+  // every side that is not a physical edge of the domain: a neighbouring rank, or the tile's own periodic image
+  const bool xw = !(cf.west_edge && !cf.EWperiodic), xe = !(cf.east_edge && !cf.EWperiodic);
+  const bool xs = !(cf.south_edge && !cf.NSperiodic), xn = !(cf.north_edge && !cf.NSperiodic);
+  return make_bounds(cf.Lm, cf.Mm, cf.EWperiodic, cf.NSperiodic, cf.Istr - (xw ? gl : 0), cf.Iend + (xe ? gh : 0),
+                     cf.Jstr - (xs ? gl : 0), cf.Jend + (xn ? gh : 0), cf.west_edge, cf.east_edge, cf.south_edge, cf.north_edge);
+}
 
 // pointer helpers for time levels
 static inline double *t_lev(roms_hip_ctx *c, int n, int itrc) {
