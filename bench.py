@@ -183,9 +183,13 @@ def pmc_traffic(workload, kernel, world):
         # (the profiler lists the instantiation that ran -- k_step2d_loop_b -- the library's timers the family name)
         for name in [kernel] + sorted(k for k in ks if k.startswith(kernel + "_")):
             if name in ks:
+                pmc_traffic.source = os.path.relpath(f, ROOT)
                 return ks[name].get("hbm_bytes_per_launch")
         return None
     return None
+
+
+pmc_traffic.source = None
 
 
 def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
@@ -493,6 +497,37 @@ def whole_step_pass(hiplib, tiling, device, workload, steps=8, warmup=6):
     return rep
 
 
+def tiled_form_pass(tiling, device, steps=20, warmup=6):
+    """The MULTI-TILE form of the headline step on one GPU: BENCHMARK1 512x64x30 with the tile as its own western and eastern
+    neighbour (ROMS_HIP_SELF_EXCHANGE: every periodic ghost line travels through the halo transport instead of a local copy),
+    once through the mailbox -- the persistent barotropic loop handing its rim across the tile edge inside the launch, the
+    schedule around it -- and once through RCCL send/recv groups (the per-pair launches: a collective library cannot be
+    called from inside a kernel).  Every exchange is device-local here: the figures are the cost of the tiled code path, not
+    of xGMI.  ms per step (host-timed, synchronised on both sides) and exchange points per step."""
+    out = {}
+    for tr in ("peer", "rccl"):
+        cs = params_for("benchmark1", ntimes=steps + warmup + 2)
+        cs["ninfo"] = 1
+        try:
+            run = tiling.TiledRun(cs, device=device, self_exchange=True, transport=tr)
+            run.step(warmup)
+            run.sync()
+            x0 = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
+            t0 = time.perf_counter()
+            run.step(steps)
+            run.sync()
+            dt = time.perf_counter() - t0
+            x1 = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
+            out["mailbox" if tr == "peer" else "rccl"] = {"ms_per_step": 1e3 * dt / steps, "exchanges_per_step": (x1 - x0) / steps,
+                                                          "rccl_ranks": run.rccl_ranks()}
+            run.check()
+            run.close()
+        except Exception as e:       # (a reported aid, never a reason to lose the headline line)
+            out["mailbox" if tr == "peer" else "rccl"] = {"error": str(e)[:200]}
+    out["workload"] = "BENCHMARK1 512x64x30, one tile that is its own W/E neighbour through the halo transport (one GPU)"
+    return out
+
+
 def self_launch(ngpus):
     """`python bench.py --gpus N` without torch.distributed.run: start the N ranks as CHILD processes (one per GPU,
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), relay their
@@ -730,10 +765,23 @@ def main():
                 roofline["isolated_launch_us"] = iso * 1e6
                 roofline["frac_isolated"] = fb / iso / 1e9 / HBM_PEAK_GBS
 
+    # the spread of the step time: a pass of its own behind the timed region, a HIP event at
+    # every step boundary on the main stream (the timed region above carries no such markers)
+    spread = None
+    try:
+        ts = sorted(run.step_times(min(40, max(10, args.steps))))
+        if ts:
+            spread = {"n": len(ts), "min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1],
+                      "method": "HIP events at the step boundaries of a separate pass (roms_hip_step_timing)"}
+    except Exception as e:
+        spread = {"error": str(e)[:200]}
+    barrier_sync()
     copy_gbs = run.ctx.copy_probe() if (args.copy_probe or rank == 0) else None
     if roofline is not None:
         roofline["measured_copy_GBs"] = copy_gbs
         roofline["traffic"] = pmc_traffic(args.workload, dominant, world)
+        roofline["traffic_source"] = (f"{pmc_traffic.source}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed "
+                                      "with the round's profiles; read from that file, not collected in this run") if roofline["traffic"] is not None else None
     run.check()                              # blow-up test of the last diagnostics (exit_flag)
     out = None
     if rank == 0:
@@ -762,9 +810,55 @@ def main():
                        "exchanges_per_step": xps},
             "roofline": roofline,
             "north_star_pair": pair,
+            "step_time_ms": spread,
         }
         out["cpu_baseline"] = cpu
     run.close()
+    if world > 1 and not args.share_gpu and not os.environ.get("ROMS_BENCH_NO_AB"):
+        # The same steps through the OTHER device-to-device transport of the library: the headline
+        # above used `run.transport` (auto: the mailbox where its probe passes on every rank, else RCCL); here a fresh set of
+        # contexts with the other one, a short timed region with the same barriers.  rccl_ranks is read from the live RCCL
+        # communicator of whichever of the two runs used it (ncclCommCount).  Guarded: an exception on any rank, or a
+        # rendezvous that does not complete within two minutes, ends the comparison -- never the benchmark line.
+        import signal
+        head_tr = getattr(run, "transport", None)
+        other = "rccl" if head_tr == "peer" else "peer"
+        ab = {"headline": "mailbox" if head_tr == "peer" else head_tr, ("mailbox" if head_tr == "peer" else str(head_tr)): {"ms_per_step": 1e3 * elapsed / args.steps, "exchanges_per_step": xps}}
+
+        def give_up(signum, frame):
+            if rank == 0 and out is not None:
+                ab["error"] = "the comparison run did not finish within 120 s"
+                out["config"]["transport_ab"] = ab
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        signal.signal(signal.SIGALRM, give_up)
+        signal.alarm(120)
+        try:
+            n_ab = max(5, min(args.steps, 20))
+            cs2 = params_for(wl, args.Lm, args.Mm, args.N, ntimes=n_ab + 12)
+            cs2["ninfo"] = 1
+            run2 = tiling.TiledRun(cs2, rank=rank, world=world, device=local_rank, dist=dist, tiles=tiles, weak=weak, transport=other)
+            run2.step(6)
+            run2.sync(); torch.cuda.synchronize(); dist.barrier()
+            run2.exchanges_per_step(0)
+            ta = time.perf_counter()
+            run2.step(n_ab)
+            run2.sync(); torch.cuda.synchronize(); dist.barrier()
+            tb = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            ab["mailbox" if other == "peer" else other] = {"ms_per_step": 1e3 * float(tb.item()) / n_ab, "exchanges_per_step": run2.exchanges_per_step(n_ab),
+                                                           "steps": n_ab}
+            if other == "rccl":
+                ab["rccl_ranks_live"] = run2.rccl_ranks()
+            run2.check()
+            run2.close()
+        except Exception as e:
+            ab["error"] = str(e)[:300]
+        signal.alarm(0)
+        if out is not None:
+            out["config"]["transport_ab"] = ab
+            if ab.get("rccl_ranks_live") is not None:
+                out["config"]["rccl_ranks"] = ab["rccl_ranks_live"]
     if rank == 0 and world == 1 and args.workload == "benchmark1" and not explicit_dims and not args.no_breakdown \
             and not args.no_north_star:
         # BASELINE.json north_star: "step3d_t + rhs3d at 512x512x50" -- a short pass of that grid (UPWELLING
@@ -773,6 +867,8 @@ def main():
         out["north_star_pair_512x512x50_stock"] = north_star_pass(hiplib, tiling, local_rank, steps=4, warmup=8, workload="ns512")
         # the other BASELINE configurations that fit one GPU, driver-timed: whole steps
         out["whole_step"] = {wl: whole_step_pass(hiplib, tiling, local_rank, wl) for wl in ("benchmark2", "benchmark3", "config5", "ns512")}
+        # the multi-tile form of the headline step, on this one GPU
+        out["tiled_form_selfx"] = tiled_form_pass(tiling, local_rank)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

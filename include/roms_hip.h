@@ -375,6 +375,13 @@ long roms_hip_exchange_count(roms_hip_ctx *ctx);
 /* ranks of the built-in RCCL communicator of this context (ncclCommCount); 0: roms_hip_comm_rccl was not called */
 long roms_hip_rccl_ranks(roms_hip_ctx *ctx);
 
+/* measurement aid (round 6): the duration of every baroclinic step of the following roms_hip_main3d calls, from HIP events
+   recorded on the main stream at the step boundaries (main3d.F:216-1148, one pass each): roms_hip_step_timing(ctx, nmax)
+   arms it for up to nmax steps (0: off), roms_hip_step_times synchronises and copies the milliseconds of the steps
+   recorded so far (returns their number, at most cap).  bench.py reports min / median / max from a pass of its own. */
+int roms_hip_step_timing(roms_hip_ctx *ctx, int nmax);
+int roms_hip_step_times(roms_hip_ctx *ctx, double *ms, int cap);
+
 /* measurement aid: `reps` launches of a plain streaming copy (kernel k_copy_probe) between two 3-D
    work arrays; *bytes_per_launch = bytes read + written by one launch.  Timed by the caller with
    roms_hip_kprof: the measured HBM ceiling quoted next to the roofline fractions. */

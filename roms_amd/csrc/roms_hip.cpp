@@ -675,6 +675,8 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   for (void *p : c->allocs) dfree(p);
 #ifndef ROMS_CPU_EMU
   if (c->loop_err) (void)hipHostFree(c->loop_err);
+  for (hipEvent_t e : c->step_ev) (void)hipEventDestroy(e);
+  c->step_ev.clear();
 #endif
   if (c->stage_buf) dfree(c->stage_buf);
   for (int k = 0; k < 8; k++) { if (c->comm.sbuf[k]) dfree(c->comm.sbuf[k]); if (c->comm.rbuf[k]) dfree(c->comm.rbuf[k]); }
@@ -2443,13 +2445,50 @@ extern "C" int roms_hip_get_bounds(roms_hip_ctx *c, int *out) {
   return 0;
 }
 
+extern "C" int roms_hip_step_timing(roms_hip_ctx *c, int nmax) {
+  if (!c || nmax < 0) return 8;
+#ifndef ROMS_CPU_EMU
+  for (hipEvent_t e : c->step_ev) (void)hipEventDestroy(e);
+  c->step_ev.clear();
+  c->step_ev_n = 0;
+  for (int k = 0; k < (nmax > 0 ? nmax + 1 : 0); k++) {
+    hipEvent_t e;
+    if (hipfail(hipEventCreate(&e), "hipEventCreate")) return 2;
+    c->step_ev.push_back(e);
+  }
+#endif
+  return 0;
+}
+extern "C" int roms_hip_step_times(roms_hip_ctx *c, double *ms, int cap) {
+  if (!c || !ms) return 0;
+  int n = 0;
+#ifndef ROMS_CPU_EMU
+  if (c->step_ev_n < 2) return 0;
+  if (hipEventSynchronize(c->step_ev[c->step_ev_n - 1]) != hipSuccess) return 0;
+  for (int k = 1; k < c->step_ev_n && n < cap; k++) {
+    float t = 0.0f;
+    if (hipEventElapsedTime(&t, c->step_ev[k - 1], c->step_ev[k]) != hipSuccess) break;
+    ms[n++] = (double)t;
+  }
+#else
+  (void)cap;
+#endif
+  return n;
+}
+
 extern "C" int roms_hip_main3d(roms_hip_ctx *c, int nsteps) {
   if (!c) return 8;
   static const bool host_trace = getenv("ROMS_HIP_TRACE_HOST") != nullptr;   // measurement aid: host time to enqueue the steps
   const auto t0 = std::chrono::steady_clock::now();
   for (int n = 0; n < nsteps; n++) {
+#ifndef ROMS_CPU_EMU
+    if (!c->step_ev.empty() && c->step_ev_n == 0) { (void)hipEventRecord(c->step_ev[0], c->stream0); c->step_ev_n = 1; }
+#endif
     int r = main3d_one(c);
     if (r) return r;
+#ifndef ROMS_CPU_EMU
+    if (c->step_ev_n > 0 && c->step_ev_n < (int)c->step_ev.size()) (void)hipEventRecord(c->step_ev[c->step_ev_n++], c->stream0);
+#endif
   }
   if (c->diag_join_pending) { lane_wait(c, 11); c->diag_join_pending = false; }   // (main3d_around_loop: diag's reductions on the side stream)
   if (host_trace && nsteps > 0) {

@@ -98,6 +98,8 @@ struct roms_hip_ctx {
   unsigned loop_epoch;          // ... hold at most this value (the pairs of all launches so far)
   double *loop_wts;             // weights per pair (device)
   unsigned long long *loop_err; // pinned host word: a wait for a neighbouring block gave up (ctx_check reports it)
+  std::vector<kevent_t> step_ev;   // roms_hip_step_timing: events at the step boundaries (main stream)
+  int step_ev_n = 0;
   bool h_ghost_done = false;    // (multi-tile) the ghost lines of h have been exchanged once (run_set_depth computes the ghost columns itself)
   bool loop_pre_frc = false;    // (multi-tile) this step's schedule has already exchanged what the loop's first fast step reads beyond the tile:
   bool loop_pre_state = false;  // the 3-D forcing and its history | the kstp level of zeta, ubar, vbar (step2d_loop_pre)

@@ -238,6 +238,16 @@ class TiledRun:
     def sync(self):
         self.ctx.sync()
 
+    def step_times(self, n):
+        """n more main3d passes with a HIP event at every step boundary (roms_hip_step_timing): their durations in ms."""
+        L = self.ctx.L
+        self.ctx._ck(L.roms_hip_step_timing(self.ctx.h, int(n)))
+        self.host.run(n)
+        buf = (C.c_double * n)()
+        k = L.roms_hip_step_times(self.ctx.h, buf, n)
+        L.roms_hip_step_timing(self.ctx.h, 0)
+        return [float(buf[i]) for i in range(k)]
+
     def diag(self):
         """Global diagnostics of diag.F (energies, volume, maximum speed / Courant number)."""
         d = np.array(self.ctx.diag(raw=True))

@@ -11,3 +11,12 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs the reference build oracle/_ref (only in the build container)")
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Which bar the GPU comparisons applied on this machine: printed with the result line."""
+    try:
+        from tests import util
+        terminalreporter.write_line("parity bar on this host: " + util.TOLERANCE_BRANCH)
+    except Exception:
+        pass

@@ -382,10 +382,30 @@ def host_libm_is_the_recorded_one():
             flags = next((l for l in fh if l.startswith("flags")), "").split()
     except OSError:
         return False
-    return "fma" in flags and "avx2" in flags
+    if not ("fma" in flags and "avx2" in flags):
+        return False
+    # ... and the library itself: the file tools/gen_klibm.py read its tables from (by hash), or at least its release
+    import ctypes
+    import hashlib
+    try:
+        with open(LIBM_PATH, "rb") as fh:
+            if hashlib.sha256(fh.read()).hexdigest() == LIBM_SHA256:
+                return True
+    except OSError:
+        pass
+    try:
+        f = ctypes.CDLL(None).gnu_get_libc_version
+        f.restype = ctypes.c_char_p
+        return f().decode() == "2.35"
+    except (OSError, AttributeError):
+        return False
 
 
+LIBM_PATH = "/lib/x86_64-linux-gnu/libm.so.6"
+LIBM_SHA256 = "e5141752c850ea45691513faadc577133fedf77bcbf19473f97e7247561254b2"      # tools/gen_klibm.py: glibc 2.35-0ubuntu3.x
 HOST_FMA = host_libm_is_the_recorded_one()
+TOLERANCE_BRANCH = ("bit-identity (==): the host's libm is the recorded one (glibc 2.35, x86-64 FMA builds)" if HOST_FMA else
+                    "1e-10 relative RMS (north_star): the host's libm is not the recorded one")
 
 
 def agree(a, b, tol):
