@@ -456,7 +456,7 @@ def north_star_pass(hiplib, tiling, device, steps=6, warmup=24, workload="ns512u
     return rep
 
 
-def whole_step_pass(hiplib, tiling, device, workload, steps=8, warmup=6):
+def whole_step_pass(hiplib, tiling, device, workload, steps=8, warmup=6, vary_salt=False):
     """One of the other BASELINE configurations that fit one GPU, on one tile: `steps` steps timed from the host
     (synchronised on both sides) -> ms per step, cell-updates/s and the whole-step fraction of the HBM peak on SURVEY
     8(d)'s bytes per cell-update; then two steps with every launch timed (the dispatch's own begin / end) -> the
@@ -464,6 +464,14 @@ def whole_step_pass(hiplib, tiling, device, workload, steps=8, warmup=6):
     cs = params_for(workload, ntimes=steps + warmup + 2)
     cs["ninfo"] = 1
     run = tiling.TiledRun(cs, device=device)
+    if vary_salt:
+        # UPWELLING's analytic salinity is the constant 35: mpdata_adiff's anti-diffusive velocities of a constant tracer are
+        # zero and its kernels take their early exits.  The honest MPDATA cost needs a second tracer that varies:
+        # S = 35 + 0.05 (T - 14) before the first step (tools/gpu_debug/mp_salt_cost.py)
+        t = run.ctx.download("t")
+        tt = t.reshape(2, 3, -1)
+        tt[1, :, :] = 35.0 + 0.05 * (tt[0, :, :] - 14.0)
+        run.ctx.upload("t", tt.reshape(t.shape))
     run.step(warmup)
     run.sync()
     t0 = time.perf_counter()
@@ -472,7 +480,8 @@ def whole_step_pass(hiplib, tiling, device, workload, steps=8, warmup=6):
     elapsed = time.perf_counter() - t0
     cells = cs["Lm"] * cs["Mm"] * cs["N"]
     wsb = whole_step_bytes_per_cell(cs, run.nfast)
-    rep = {"workload": f"{cs['app'].upper()} {cs['Lm']}x{cs['Mm']}x{cs['N']} on one tile (bench.py --workload {workload})",
+    rep = {"workload": f"{cs['app'].upper()} {cs['Lm']}x{cs['Mm']}x{cs['N']} on one tile (bench.py --workload {workload})" +
+                       (", salinity = 35 + 0.05 (T - 14) at the start instead of the constant 35" if vary_salt else ""),
            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "value": cells * steps / elapsed,
            "unit": "grid-cell-updates/sec", "whole_step_bytes_per_cell": wsb,
            "whole_step_frac": wsb * cells * steps / elapsed / 1e9 / HBM_PEAK_GBS}
@@ -663,12 +672,39 @@ def main():
     cs = params_for(wl, args.Lm, args.Mm, args.N, ntimes=args.steps + args.warmup)
     cs["ninfo"] = 1                          # NINFO of roms_benchmark1.in: diagnostics every step
     transport = args.transport or ("dist_staged" if (args.share_gpu and world > 1) else None)
-    try:
-        run = tiling.TiledRun(cs, rank=rank, world=world, device=local_rank, dist=dist, tiles=tiles, weak=weak,
-                              transport=transport)
-    except hiplib.RomsHipError as e:         # no usable halo transport (both probes failed): say why, stop all ranks
-        print(f"bench.py rank {rank}: {e}", file=sys.stderr, flush=True)
-        raise SystemExit(3)
+    def make_run():
+        try:
+            return tiling.TiledRun(cs, rank=rank, world=world, device=local_rank, dist=dist, tiles=tiles, weak=weak,
+                                   transport=transport)
+        except hiplib.RomsHipError as e:     # no usable halo transport (both probes failed): say why, stop all ranks
+            print(f"bench.py rank {rank}: {e}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
+    run = make_run()
+    loop_fallback = None
+    if world > 1 and os.environ.get("ROMS_HIP_LOOP") is None:
+        # The persistent barotropic loop crosses the tile edges inside one launch (round 6): its blocks wait -- bounded -- for
+        # the neighbouring GPUs' blocks.  No multi-GPU node was available to develop it on, so the first steps are a trial:
+        # if any rank reports a wait that gave up (exit_flag 2), EVERY rank goes back to the pair launches (ROMS_HIP_LOOP=0:
+        # one exchange per predictor+corrector pair, the form of rounds 3-5) with fresh contexts, and the line says so.
+        ok = 1
+        try:
+            run.step(2)
+            run.sync()
+        except hiplib.RomsHipError as e:
+            ok = 0
+            print(f"bench.py rank {rank}: trial steps with the persistent loop across tiles failed: {e}", file=sys.stderr, flush=True)
+        tok = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tok, op=dist.ReduceOp.MIN)
+        if int(tok.item()) == 0:
+            loop_fallback = "the trial steps with the persistent barotropic loop across tiles failed on some rank: pair launches (ROMS_HIP_LOOP=0)"
+            try:
+                run.close()
+            except Exception:
+                pass
+            os.environ["ROMS_HIP_LOOP"] = "0"
+            cs = params_for(wl, args.Lm, args.Mm, args.N, ntimes=args.steps + args.warmup)
+            cs["ninfo"] = 1
+            run = make_run()
     if args.averages > 0:
         run.ctx.avg_config(args.averages)
     if not weak:                             # cs names the global grid: the tile is its NtileI x NtileJ-th part
@@ -807,7 +843,7 @@ def main():
                        "halo_transport": getattr(run, "transport", None) if world > 1 else "none (single tile)",
                        "rccl_ranks": run.rccl_ranks() if world > 1 else None,
                        "transport_probes": getattr(run, "probe_log", None) if world > 1 else None,
-                       "exchanges_per_step": xps},
+                       "exchanges_per_step": xps, "barotropic_loop_fallback": loop_fallback},
             "roofline": roofline,
             "north_star_pair": pair,
             "step_time_ms": spread,
@@ -867,6 +903,7 @@ def main():
         out["north_star_pair_512x512x50_stock"] = north_star_pass(hiplib, tiling, local_rank, steps=4, warmup=8, workload="ns512")
         # the other BASELINE configurations that fit one GPU, driver-timed: whole steps
         out["whole_step"] = {wl: whole_step_pass(hiplib, tiling, local_rank, wl) for wl in ("benchmark2", "benchmark3", "config5", "ns512")}
+        out["whole_step"]["config5_varS"] = whole_step_pass(hiplib, tiling, local_rank, "config5", vary_salt=True)
         # the multi-tile form of the headline step, on this one GPU
         out["tiled_form_selfx"] = tiled_form_pass(tiling, local_rank)
     if dist is not None:

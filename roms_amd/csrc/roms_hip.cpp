@@ -1971,10 +1971,35 @@ static int main3d_around_loop(roms_hip_ctx *c, bool do_diag, int form, bool with
   }
   DO(roms_hip_rho_eos(c));                                  // :350
   lane_record(c, E_EOS);
-  if (with_set_data) lane_wait(c, E_SD);
-  if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));   // :439
-  DO(roms_hip_set_vbc(c));                                  // :445
-  lane_record(c, E_VBC);
+  // Round 6: the chain that decides when the loop can start is set_data -> bulk_flux -> set_vbc -> vertical mixing -> k_pre_new
+  // (one-step traces: 265 of the 304 us in front of the loop); bulk_flux and set_vbc read nothing rho_eos writes, so the chain
+  // starts on stream Y beside rho_eos instead of behind it on this stream, and what ran on Y in the first 100 us -- t3dmix2 and
+  // uv3dmix2_s as terms, which read only the state the step starts from -- runs here behind rho_eos
+  // -- measured, BENCHMARK1, interleaved on one box (tools/gpu_debug/ab_env.sh ROMS_HIP_BULK_LANE "1 0"): 0.830 against 0.820 ms per
+  // step with the order of round 5: the ~530 us of kernels in front of the loop saturate the chip whichever stream they come from
+  // (DESIGN.md 4), a shorter dependency chain does not shorten them.  Kept as a switch (ROMS_HIP_BULK_LANE=1), not the default.
+  static const char *ebl = getenv("ROMS_HIP_BULK_LANE");
+  const bool bulk_y = on && ebl && ebl[0] == '1';
+  auto surface = [&]() -> int {
+    if (with_set_data) lane_wait(c, E_SD);
+    if (cf.options & ROMS_BULK_FLUXES) DO(roms_hip_bulk_flux(c));   // :439
+    DO(roms_hip_set_vbc(c));                                  // :445
+    lane_record(c, E_VBC);
+    return 0;
+  };
+  auto mixing_terms = [&]() -> int {
+    if (c->tmix_terms) { DO(run_t3dmix2(c)); c->tmix_ready = true; }   // t3dmix2 as terms (k_pre_new adds them)
+    DO(run_uv3dmix2_s(c));                                    // the terms of uv3dmix2 (c->late_pre)
+    lane_record(c, E_UV);
+    return 0;
+  };
+  if (bulk_y) {
+    DO(mixing_terms());
+    to(Y);
+    lane_wait(c, E_FORK);
+    DO(surface());
+    to(M);
+  } else DO(surface());
   // (the main stream idles from here to the sums of rufrc: the place to join the reductions of the previous step's diag)
   if (c->diag_join_pending) { lane_wait(c, E_MIX); c->diag_join_pending = false; }
   to(S);
@@ -1990,11 +2015,11 @@ static int main3d_around_loop(roms_hip_ctx *c, bool do_diag, int form, bool with
   DO(roms_hip_prsgrd(c));                                   // rhs3d.F: prsgrd, rhs3d_tile
   DO(run_rhs3d_pt(c));
   lane_record(c, E_D);
-  to(Y);                                                    // what reads only the state the step starts from: in the first
-  lane_wait(c, E_FORK);                                     // 100 us, while the chains above are short kernels waiting on each other
-  if (c->tmix_terms) { DO(run_t3dmix2(c)); c->tmix_ready = true; }   // t3dmix2 as terms (k_pre_new adds them)
-  DO(run_uv3dmix2_s(c));                                    // the terms of uv3dmix2 (c->late_pre)
-  lane_record(c, E_UV);
+  if (!bulk_y) {
+    to(Y);                                                  // what reads only the state the step starts from: in the first
+    lane_wait(c, E_FORK);                                   // 100 us, while the chains above are short kernels waiting on each other
+    DO(mixing_terms());
+  }
   to(X);
   lane_wait(c, E_W);                                        // (neither reads a surface flux: k_pre_new does, behind the closure's wait)
   if (cf.options & ROMS_SOLAR_SOURCE) { DO(run_swdk(c)); c->swdk_ready = true; }
@@ -2031,6 +2056,7 @@ static int main3d_around_loop(roms_hip_ctx *c, bool do_diag, int form, bool with
   else if (kpp) DO(roms_hip_lmd_vmix(c));                          // :527
   if (form == 1) {
     lane_wait(c, E_T3);
+    lane_wait(c, E_UV);                                     // (the mixing terms k_pre_new adds: from the main stream since round 6)
     lane_wait(c, E_D);                                      // (the old ru/rv bracket k_prs_grad kept)
     DO(roms_hip_pre_step3d(c));                             // k_pre_new (+ the uv3dmix2 and t3dmix2 terms)
     DO(roms_hip_t3dmix2(c));                                // (a launch of its own only where it did not run ahead)
@@ -2089,6 +2115,7 @@ static int main3d_one(roms_hip_ctx *c) {
   ctx_sync_stepping(c);
   DO(poison_work(c));                                       // (ROMS_HIP_POISON=1 only)
   c->loop_pre_frc = c->loop_pre_state = false;
+  c->ghost_ok = s.iic != cf.ntstart;                        // (the first step: behind post_initial, below)
   if (c->diag_join_pending && !(late_schedule_ok(c) && around_loop_form(c) > 0)) { lane_wait(c, 11); c->diag_join_pending = false; }
   // set_data (:258) feeds bulk_flux / set_vbc only: the schedule around the persistent loop places it on a side stream
   // beside rho_eos (main3d_around_loop); post_initial reads none of its fields
@@ -2099,6 +2126,7 @@ static int main3d_one(roms_hip_ctx *c) {
     DO(roms_hip_set_depth(c));
     DO(roms_hip_ini_fields(c));
   }
+  c->ghost_ok = true;                                       // (from here on every field the point-wise producers read has been exchanged)
   // diag (:355): device-side reduction every ninfo steps; the blow-up test is made on the host
   // when roms_hip_main3d returns (no per-step host synchronisation)
   const bool do_diag = cf.ninfo > 0 && (s.iic - 1) % cf.ninfo == 0;
@@ -2491,6 +2519,7 @@ extern "C" int roms_hip_main3d(roms_hip_ctx *c, int nsteps) {
 #endif
   }
   if (c->diag_join_pending) { lane_wait(c, 11); c->diag_join_pending = false; }   // (main3d_around_loop: diag's reductions on the side stream)
+  c->ghost_ok = false;
   if (host_trace && nsteps > 0) {
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "roms_hip_main3d: %d steps enqueued in %.1f us of host time (%.1f us per step)\n", nsteps, us, us / nsteps);

@@ -100,6 +100,7 @@ struct roms_hip_ctx {
   unsigned long long *loop_err; // pinned host word: a wait for a neighbouring block gave up (ctx_check reports it)
   std::vector<kevent_t> step_ev;   // roms_hip_step_timing: events at the step boundaries (main stream)
   int step_ev_n = 0;
+  bool ghost_ok = false;        // inside roms_hip_main3d, behind post_initial: every input of the point-wise producers carries valid ghost lines (ghost_compute)
   bool h_ghost_done = false;    // (multi-tile) the ghost lines of h have been exchanged once (run_set_depth computes the ghost columns itself)
   bool loop_pre_frc = false;    // (multi-tile) this step's schedule has already exchanged what the loop's first fast step reads beyond the tile:
   bool loop_pre_state = false;  // the 3-D forcing and its history | the kstp level of zeta, ubar, vbar (step2d_loop_pre)
@@ -275,12 +276,14 @@ int run_copy_probe(roms_hip_ctx *c, int reps);
 // A multi-tile context: the tile's bounds extended by gl | gh ghost lines towards every side that is not a physical edge.
 // A POINT-WISE producer whose inputs are valid on those lines computes them itself -- the same expression on the same
 // operands the neighbour evaluates at its own points, so the same bits -- and the strip exchange the reference issues behind
-// it (exchange_r3d_tile + mp_exchange3d at the tail of set_depth, ana_* ...) is not needed.  ROMS_HIP_GHOSTCOMP=0: exchange.
+// it (exchange_r3d_tile + mp_exchange3d at the tail of set_depth, ana_* ...) is not needed.  Only inside roms_hip_main3d, behind
+// the first step's post_initial (roms_hip_ctx::ghost_ok): roms_hip_start and the per-routine entries work on whatever the caller
+// uploaded, whose ghost lines the reference does not promise either.  ROMS_HIP_GHOSTCOMP=0: exchange.
 // (a mask: 1 set_depth, 2 set_data, 4 rho_eos, 8 set_massflux; default all)
 inline bool ghost_compute(const roms_hip_ctx *c, int which) {
   static const char *e = getenv("ROMS_HIP_GHOSTCOMP");
   static const int mask = e ? atoi(e) : 15;
-  return c->has_exchange && (mask & which);
+  return c->has_exchange && c->ghost_ok && (mask & which);
 }
 inline TB ghost_tb(const roms_hip_ctx *c, int gl, int gh) {
   const roms_hip_config &cf = c->cfg;
