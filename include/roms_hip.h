@@ -264,8 +264,9 @@ int roms_hip_avg_time(roms_hip_ctx *ctx, double *avgtime);
    ntstart of a restart); from then on the kernels of pre_step3d, t3dmix2 and step3d_t store their terms
    (pre_step3d.F:925, t3dmix2_s.h:293, t3dmix2_geo.h:409, t3dmix2_iso.h:428, step3d_t.F:908, :1357, :1716, :1892),
    roms_hip_main3d / roms_hip_output_point call set_diags where main3d.F does, and "DiaTwrk", "DiaTrc", "dia_zeta" can be
-   downloaded.  exit_flag 5: MPDATA tracers, applications without SPLINES_VDIFF, WET_DRY contexts (the refusals of
-   roms_hip_wetdry_config hold whichever call comes first).  The momentum terms (DIAGNOSTICS_UV): roms_hip_diauv_config. */
+   downloaded.  exit_flag 5: MPDATA tracers, applications without SPLINES_VDIFF, WET_DRY contexts (ROMS_WET_DRY in
+   roms_hip_config.options; the refusal holds whichever comes first).  The momentum terms (DIAGNOSTICS_UV): the option bit
+   ROMS_DIAGNOSTICS_UV of roms_hip_config.options (ABI version 4). */
 int roms_hip_dia_config(roms_hip_ctx *ctx, int nDIA, int ntsDIA, int nrrec, int ntstart);
 int roms_hip_set_diags(roms_hip_ctx *ctx);
 /* Biharmonic horizontal mixing along s-surfaces (UV_VIS4 + MIX_S_UV: uv3dmix4_s.h:119-627 and step2d_LF_AM3.h:1653-1920;

@@ -117,12 +117,13 @@ int run_lmd_vmix(roms_hip_ctx *c) {
   if (form == 3 && G.region == 0 && blk_lds <= 160 * 1024) {        // the block form (k_lmd.h: k_lmd_blk): 64 columns per block of 512 threads
     const size_t ldsd = (size_t)(4 * (N + 1) + LMD_BLK_NS) * 64;
 #ifndef ROMS_CPU_EMU
-    static bool big_lds = false;
-    if (ldsd * sizeof(double) > 64 * 1024 && !big_lds) {
+    static bool big_lds[64] = {};          // (the attribute is per device: a process may drive contexts on several)
+    const int dev = c->cfg.device & 63;
+    if (ldsd * sizeof(double) > 64 * 1024 && !big_lds[dev]) {
       if (hipFuncSetAttribute((const void *)k_lmd_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         set_error("k_lmd_blk: cannot raise the dynamic LDS limit"); return 2;
       }
-      big_lds = true;
+      big_lds[dev] = true;
     }
 #endif
     static const char *ebt = getenv("ROMS_HIP_LMDBT");

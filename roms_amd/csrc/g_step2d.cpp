@@ -289,8 +289,10 @@ static void loop_grid(const DGrid &G, DGrid &L) {
   L.nbx2 = KMAX(1, (LmT + bw - 1) / bw); L.nby2 = KMAX(1, (MmT + bh - 1) / bh);
   L.bw2 = (LmT + L.nbx2 - 1) / L.nbx2; L.bh2 = (MmT + L.nby2 - 1) / L.nby2;
   { const char *ex = getenv("ROMS_HIP_S2D_XCD"); L.xmap2 = ((L.nbx2 * L.nby2) % 8 == 0 && L.nbx2 * L.nby2 >= 16 && !(ex && ex[0] == '0')) ? 1 : 0; }
+  { static const char *ep = getenv("ROMS_HIP_LOOP_XCD");
+    if (L.xmap2 && ep && !strcmp(ep, "patch") && L.nbx2 % 4 == 0 && L.nby2 % 2 == 0 && (L.nbx2 / 4) * (L.nby2 / 2) * 8 == L.nbx2 * L.nby2) L.xmap2 = 2; }
 }
-static size_t loop_lds_doubles() { return (size_t)S2L_NLDS * (loop_shape() ? (16 + 2 * S2P_RIM) * (8 + 2 * S2P_RIM) : (32 + 2 * S2P_RIM) * (4 + 2 * S2P_RIM)); }
+static size_t loop_lds_doubles(bool masked = false) { return (size_t)(masked ? S2L_NLDS_MK : S2L_NLDS) * (loop_shape() ? (16 + 2 * S2P_RIM) * (8 + 2 * S2P_RIM) : (32 + 2 * S2P_RIM) * (4 + 2 * S2P_RIM)); }
 #endif
 void step2d_loop_dims(const roms_hip_ctx *c, int &nbx2, int &nby2) {
 #ifdef ROMS_CPU_EMU
@@ -337,7 +339,9 @@ bool step2d_loop_usable(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const char *e = getenv("ROMS_HIP_LOOP");
   if (e && e[0] == '0') return false;
-  if (!c->pair_on || G.masking) return false;
+  if (!c->pair_on) return false;
+  // MASKING (round 6): the 16x8 form carries the masked statements (three more LDS tiles); not with WET_DRY (new masks every call)
+  if (G.masking && (!loop_shape() || G.wet_dry)) return false;
   if (!c->has_exchange && !G.fuse_halo) return false;
   if (G.bw2 > 32 || G.bh2 > 4 || getenv("ROMS_HIP_S2D_GENERIC")) return false;
   if (c->cfg.nfast < 3) return false;
@@ -345,13 +349,22 @@ bool step2d_loop_usable(roms_hip_ctx *c) {
   loop_grid(G, L);
   if (L.bw2 < 2 || L.bh2 < 2) return false;             // (the neighbour window of the kernel: 3 sub-tiles each way)
   if (c->has_exchange && !loop_mt_usable(c, L, e && e[0] == '1')) return false;
+  {
+    // the rim hand-off relies on what gfx942 / gfx950 do with write-through (sc1) stores, a drained vmcnt and sc1 loads (the
+    // MI355X guide's form, outside the HIP memory model): no other architecture takes this kernel
+    hipDeviceProp_t prop;
+    int d0 = 0;
+    if (hipGetDevice(&d0) != hipSuccess || hipGetDeviceProperties(&prop, d0) != hipSuccess) return false;
+    if (strncmp(prop.gcnArchName, "gfx942", 6) && strncmp(prop.gcnArchName, "gfx950", 6)) return false;
+  }
   // every block must be resident at once: they wait for each other
-  const void *kern = c->has_exchange ? (const void *)k_step2d_loop_bm : loop_shape() ? (const void *)k_step2d_loop_b : (const void *)k_step2d_loop_a;
+  const void *kern = c->has_exchange ? (G.masking ? (const void *)k_step2d_loop_bmk : (const void *)k_step2d_loop_bm)
+                                     : G.masking ? (const void *)k_step2d_loop_bk : loop_shape() ? (const void *)k_step2d_loop_b : (const void *)k_step2d_loop_a;
   const int nthr = loop_shape() ? 512 : 640;
   if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
   int dev = 0, ncu = 0, per = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, nthr, loop_lds_doubles() * sizeof(double)) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, nthr, loop_lds_doubles(G.masking != 0) * sizeof(double)) != hipSuccess) return false;
   if ((long)L.nbx2 * L.nby2 > (long)ncu * per) return false;
   if (c->loop_flags) {                                          // (decided again after a configuration call: the buffers exist)
     c->loop_state = 1;
@@ -520,9 +533,11 @@ int run_step2d_loop_n(roms_hip_ctx *c, int whole) {
   }
   a.epoch = c->loop_epoch;
   c->loop_epoch += (unsigned)a.npairs;
-  const size_t lds = loop_lds_doubles();
+  const size_t lds = loop_lds_doubles(G.masking != 0);
   int r;
-  if (mt) r = loop_launch(c, k_step2d_loop_bm, "k_step2d_loop", a, 512, lds);
+  if (mt && G.masking) r = loop_launch(c, k_step2d_loop_bmk, "k_step2d_loop", a, 512, lds);
+  else if (mt) r = loop_launch(c, k_step2d_loop_bm, "k_step2d_loop", a, 512, lds);
+  else if (G.masking) r = loop_launch(c, k_step2d_loop_bk, "k_step2d_loop", a, 512, lds);
   else if (loop_shape()) r = loop_launch(c, k_step2d_loop_b, "k_step2d_loop", a, 512, lds);
   else r = loop_launch(c, k_step2d_loop_a, "k_step2d_loop", a, 640, lds);
   if (r) return r;

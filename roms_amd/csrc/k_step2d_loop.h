@@ -61,6 +61,7 @@
 
 #ifndef ROMS_CPU_EMU
 #define S2L_NLDS 32
+#define S2L_NLDS_MK 35           // + rmask, umask, vmask on the rectangle (MASKING)
 #define INR(i, j, i0, i1, j0, j1) ((i) >= (i0) && (i) <= (i1) && (j) >= (j0) && (j) <= (j1))
 #define S2L_FSTRIDE 16          // arrival words are 64 bytes apart
 // multi-tile contexts: my rim planes and the neighbours' as mapped here
@@ -128,17 +129,17 @@ KDEV void s2l_rput(const Step2dLoopArgs &a, int pf, int i, int j, double v, unsi
   }
 }
 // the point and the boundary values a closed DOMAIN edge derives from it: the rules of hb_emit2 (k_haloblock.h)
-KDEV void s2l_remit(const Step2dLoopArgs &a, const TB &B, int pf, int bc, int i, int j, double v, unsigned tag) {
+KDEV void s2l_remit(const Step2dLoopArgs &a, const TB &B, int pf, int bc, int i, int j, double v, unsigned tag, const double *M = nullptr) {
   const DGrid &G = a.G;
   s2l_rput(a, pf, i, j, v, tag);
   if (i > 2 && i < G.Lm && j > 2 && j < G.Mm) return;
   if (!G.nsp) {
     if (bc == BC_R) {
-      if (B.south && j == B.Jstr) s2l_rput(a, pf, i, j - 1, v, tag);
-      if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, v, tag);
+      if (B.south && j == B.Jstr) s2l_rput(a, pf, i, j - 1, M ? v * M[X2(i, j - 1)] : v, tag);
+      if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, M ? v * M[X2(i, j + 1)] : v, tag);
     } else if (bc == BC_U) {
-      if (B.south && j == B.Jstr) s2l_rput(a, pf, i, j - 1, G.gamma2 * v, tag);
-      if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, G.gamma2 * v, tag);
+      if (B.south && j == B.Jstr) s2l_rput(a, pf, i, j - 1, M ? G.gamma2 * v * M[X2(i, j - 1)] : G.gamma2 * v, tag);
+      if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, M ? G.gamma2 * v * M[X2(i, j + 1)] : G.gamma2 * v, tag);
     } else if (bc == BC_V) {
       if (B.south && j == B.JstrV) s2l_rput(a, pf, i, B.Jstr, 0.0, tag);
       if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, 0.0, tag);
@@ -146,14 +147,14 @@ KDEV void s2l_remit(const Step2dLoopArgs &a, const TB &B, int pf, int bc, int i,
   }
   if (!G.ewp) {
     if (bc == BC_R) {
-      if (B.west && i == B.Istr) s2l_rput(a, pf, i - 1, j, v, tag);
-      if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, v, tag);
+      if (B.west && i == B.Istr) s2l_rput(a, pf, i - 1, j, M ? v * M[X2(i - 1, j)] : v, tag);
+      if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, M ? v * M[X2(i + 1, j)] : v, tag);
     } else if (bc == BC_U) {
       if (B.west && i == B.IstrU) s2l_rput(a, pf, B.Istr, j, 0.0, tag);
       if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, 0.0, tag);
     } else if (bc == BC_V) {
-      if (B.west && i == B.Istr) s2l_rput(a, pf, i - 1, j, G.gamma2 * v, tag);
-      if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, G.gamma2 * v, tag);
+      if (B.west && i == B.Istr) s2l_rput(a, pf, i - 1, j, M ? G.gamma2 * v * M[X2(i - 1, j)] : G.gamma2 * v, tag);
+      if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, M ? G.gamma2 * v * M[X2(i + 1, j)] : G.gamma2 * v, tag);
     }
   }
 }
@@ -162,7 +163,7 @@ KDEV void s2l_remit(const Step2dLoopArgs &a, const TB &B, int pf, int bc, int i,
 #define S2L_OPQ(name) int name = 0; asm volatile("" : "+s"(name))
 #define S2L_TICK(n) do { if (G.dbg_stop == 98 && p == 3 && t == 0) F.xr[me * 16 + (n)] = (double)wall_clock64(); } while (0)
 
-template <int BWC, int BHC, int NTC, bool MT = false>
+template <int BWC, int BHC, int NTC, bool MT = false, bool MK = false>
 static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &a, int bx, int by, double *lds) {
   if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
   else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -196,6 +197,11 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
   // this pair's predictor | of the previous one (= rzeta(ptsk)), and the five fast-time averages
   double *RZ1 = lds + 25 * sz, *RZP = lds + 26 * sz;
   double *aZt = lds + 27 * sz, *aDU1 = lds + 28 * sz, *aDU2 = lds + 29 * sz, *aDV1 = lds + 30 * sz, *aDV2 = lds + 31 * sz;
+  // MASKING (template parameter MK; the masked statements of k_step2d_pair.h): the land/sea masks of the rectangle, the no-slip
+  // factors pmask of the momentum point's two psi points in registers
+  double *sRm = lds + (MK ? 32 : 0) * sz, *sUm = lds + (MK ? 33 : 0) * sz, *sVm = lds + (MK ? 34 : 0) * sz;
+  const double *Mr = MK ? G.rmask : nullptr, *Mu = MK ? G.umask : nullptr, *Mv = MK ? G.vmask : nullptr;
+  double pk0 = 1.0, pk1 = 1.0;
   const double dtfast = G.dtfast, g = G.g;
   const int ni = G.ni, nij = (int)G.nij;
   const int UBi = G.LBi + G.ni - 1, UBj = G.LBj + G.nj - 1;
@@ -250,6 +256,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         UQ[s0_] = F.ubar[x0_ + o_kstp]; VQ[s0_] = F.vbar[x0_ + o_kstp];
         sRhoA[s0_] = F.rhoA[x0_]; sRhoS[s0_] = F.rhoS[x0_];
         sOnu[s0_] = F.on_u[x0_]; sOmv[s0_] = F.om_v[x0_];
+        if (MK) { sRm[s0_] = G.rmask[x0_]; sUm[s0_] = G.umask[x0_]; sVm[s0_] = G.vmask[x0_]; }
         if (ownR) {
           aZt[s0_] = F.Zt_avg1[x0_]; aDU1[s0_] = F.DU_avg1[x0_]; aDU2[s0_] = F.DU_avg2[x0_];
           aDV1[s0_] = F.DV_avg1[x0_]; aDV2[s0_] = F.DV_avg2[x0_];
@@ -258,12 +265,14 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
       } else {
         DP[s0_] = 0.0; UP[s0_] = 0.0; VP[s0_] = 0.0; ZP[s0_] = 0.0; sH[s0_] = 0.0; sPm[s0_] = 0.0; sPn[s0_] = 0.0; sRhoA[s0_] = 0.0;
         DQ[s0_] = 0.0; UQ[s0_] = 0.0; VQ[s0_] = 0.0; ZQ[s0_] = 0.0; sRhoS[s0_] = 0.0; sOnu[s0_] = 0.0; sOmv[s0_] = 0.0;
+        if (MK) { sRm[s0_] = 0.0; sUm[s0_] = 0.0; sVm[s0_] = 0.0; }
       }
     }
     if (mE) {
       const int x1 = isvt ? GIDX(mi_, mj_ - 1) : GIDX(mi_ - 1, mj_);
       const int q1 = isvt ? GIDX(mi_ + 1, mj_) : GIDX(mi_, mj_ + 1);
       wm = isvt ? s2_metrics<1>(mr, mp, mx_, x1, q1) : s2_metrics<0>(mr, mp, mx_, x1, q1);
+      if (MK) { pk0 = G.pmask[mx_]; pk1 = G.pmask[q1]; }
       w_frc = (isvt ? F.rvfrc : F.rufrc)[mx_];
       if (mO) w_rp = (isvt ? F.rvbar : F.rubar)[mx_ + o_ptc];
     }
@@ -323,9 +332,9 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
       const int s0 = s0_;
       double *zlog = F.zeta + (size_t)(krhs - 1) * G.nij, *ulog = F.ubar + (size_t)(krhs - 1) * G.nij,
              *vlog = F.vbar + (size_t)(krhs - 1) * G.nij;
-      hb_emit2(G, B, zlog, BC_R, i, j, ZP[s0], nullptr, img0);
-      if (i >= B.IstrU) hb_emit2(G, B, ulog, BC_U, i, j, UP[s0], nullptr, img0);
-      if (j >= B.JstrV) hb_emit2(G, B, vlog, BC_V, i, j, VP[s0], nullptr, img0);
+      hb_emit2(G, B, zlog, BC_R, i, j, ZP[s0], Mr, img0);
+      if (i >= B.IstrU) hb_emit2(G, B, ulog, BC_U, i, j, UP[s0], Mu, img0);
+      if (j >= B.JstrV) hb_emit2(G, B, vlog, BC_V, i, j, VP[s0], Mv, img0);
     }
     // the converted forcing of the first fast step and its history level: the blocks around this one read rufrc, rvfrc and
     // ru, rv(:,:,0,nstp) of ITS points for the rim of their first predictor -- behind the first exchange they are through
@@ -389,7 +398,8 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         }
         const double rhs_zeta = (du - du1) + (dv - dv1);
         const double zsv = ZQ[s0], zkv = ZP[s0];
-        const double zeta_new = zsv + sPm[s0] * sPn[s0] * cff1z * rhs_zeta;
+        double zeta_new = zsv + sPm[s0] * sPn[s0] * cff1z * rhs_zeta;
+        if (MK) zeta_new = zeta_new * sRm[s0];
         const double zw = f1 ? 0.5 * (zsv + zeta_new) : cff5 * zkv + cff4 * (zsv + zeta_new);
         const double rhoSv = sRhoS[s0];
         D1[s0] = zeta_new + sH[s0];
@@ -401,7 +411,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         gzeta2[s0] = gz * zw;
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (own) {
-          if (store3) hb_emit2(G, B, zn3, BC_R, i, j, zeta_new, nullptr, IMG);
+          if (store3) hb_emit2(G, B, zn3, BC_R, i, j, zeta_new, Mr, IMG);
           if (lst1) hb_emit2(G, B, rz_k, BC_NONE, i, j, rhs_zeta, nullptr, img1);
         }
       }
@@ -419,8 +429,8 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           S2L_OPQ(lo);
           const int s = ms_ + lo, x = mx;
           const int d1 = isv ? TW : 1;
-          const double rhs = isv ? s2_rhs<1>(Tl, wm, Eg, s, mi, mj, g, ADV, COR, CURV, VIS, false, 1.0, 1.0)
-                                 : s2_rhs<0>(Tl, wm, Eg, s, mi, mj, g, ADV, COR, CURV, VIS, false, 1.0, 1.0);
+          const double rhs = isv ? s2_rhs<1>(Tl, wm, Eg, s, mi, mj, g, ADV, COR, CURV, VIS, MK, pk0, pk1)
+                                 : s2_rhs<0>(Tl, wm, Eg, s, mi, mj, g, ADV, COR, CURV, VIS, MK, pk0, pk1);
           double r = rhs;
           if (f1) {
             // coupling with the 3-D forcing :2225-2460: rufrc becomes the fast-time-constant forcing, its history kept in
@@ -439,15 +449,16 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           const double fac = 1.0 / (D1[s] + D1[s - d1]);
           const double Dstp0 = DQ[s], Dstp1 = DQ[s - d1];
           const double sv = (isv ? VQ : UQ)[s];
-          const double b = (sv * (Dstp0 + Dstp1) + cff * c1 * r) * fac;
+          double b = (sv * (Dstp0 + Dstp1) + cff * c1 * r) * fac;
+          if (MK) b = b * (isv ? sVm : sUm)[s];
           (isv ? V1 : U1)[s] = b;
           w_rP = r;
           if (mO) {
             if (!isv) {
-              if (store3) hb_emit2(G, B, un3, BC_U, mi, mj, b, nullptr, IMG);
+              if (store3) hb_emit2(G, B, un3, BC_U, mi, mj, b, Mu, IMG);
               if (lst1) rub_k[x] = r;
             } else {
-              if (store3) hb_emit2(G, B, vn3, BC_V, mi, mj, b, nullptr, IMG);
+              if (store3) hb_emit2(G, B, vn3, BC_V, mi, mj, b, Mv, IMG);
               if (lst1) rvb_k[x] = r;
             }
           }
@@ -466,10 +477,11 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         const int Lm = G.Lm, Mm = G.Mm;
         const double gamma2 = G.gamma2;
         const int zj0 = E.JstrV - 1, zj1 = E.Jend, zi0 = E.IstrU - 1, zi1 = E.Iend;
-        if (cw) KLOOP1(jb, zj0, zj1) { const double v = LA(Z1, 1, jb); LA(Z1, 0, jb) = v; LA(D1, 0, jb) = v + LA(sH, 0, jb); }
-        if (ce) KLOOP1(jb, zj0, zj1) { const double v = LA(Z1, Lm, jb); LA(Z1, Lm + 1, jb) = v; LA(D1, Lm + 1, jb) = v + LA(sH, Lm + 1, jb); }
-        if (cs) KLOOP1(ib, zi0, zi1) { const double v = LA(Z1, ib, 1); LA(Z1, ib, 0) = v; LA(D1, ib, 0) = v + LA(sH, ib, 0); }
-        if (cn) KLOOP1(ib, zi0, zi1) { const double v = LA(Z1, ib, Mm); LA(Z1, ib, Mm + 1) = v; LA(D1, ib, Mm + 1) = v + LA(sH, ib, Mm + 1); }
+#define MK_(T_, i_, j_) (MK ? LA(T_, i_, j_) : 1.0)
+        if (cw) KLOOP1(jb, zj0, zj1) { const double v = LA(Z1, 1, jb) * MK_(sRm, 0, jb); LA(Z1, 0, jb) = v; LA(D1, 0, jb) = v + LA(sH, 0, jb); }
+        if (ce) KLOOP1(jb, zj0, zj1) { const double v = LA(Z1, Lm, jb) * MK_(sRm, Lm + 1, jb); LA(Z1, Lm + 1, jb) = v; LA(D1, Lm + 1, jb) = v + LA(sH, Lm + 1, jb); }
+        if (cs) KLOOP1(ib, zi0, zi1) { const double v = LA(Z1, ib, 1) * MK_(sRm, ib, 0); LA(Z1, ib, 0) = v; LA(D1, ib, 0) = v + LA(sH, ib, 0); }
+        if (cn) KLOOP1(ib, zi0, zi1) { const double v = LA(Z1, ib, Mm) * MK_(sRm, ib, Mm + 1); LA(Z1, ib, Mm + 1) = v; LA(D1, ib, Mm + 1) = v + LA(sH, ib, Mm + 1); }
         if (cw) KLOOP1(jb, j0E, j1E) LA(U1, 1, jb) = 0.0;
         if (ce) KLOOP1(jb, j0E, j1E) LA(U1, Lm + 1, jb) = 0.0;
         if (cs) KLOOP1(ib, i0E, i1E) LA(V1, ib, 1) = 0.0;
@@ -477,13 +489,14 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         KSYNC();
         {
           const int ui0 = cw ? 1 : E.IstrU, ui1 = ce ? Lm + 1 : i1E;
-          if (cs) KLOOP1(ib, ui0, ui1) LA(U1, ib, 0) = gamma2 * LA(U1, ib, 1);
-          if (cn) KLOOP1(ib, ui0, ui1) LA(U1, ib, Mm + 1) = gamma2 * LA(U1, ib, Mm);
+          if (cs) KLOOP1(ib, ui0, ui1) LA(U1, ib, 0) = gamma2 * LA(U1, ib, 1) * MK_(sUm, ib, 0);
+          if (cn) KLOOP1(ib, ui0, ui1) LA(U1, ib, Mm + 1) = gamma2 * LA(U1, ib, Mm) * MK_(sUm, ib, Mm + 1);
           const int vj0 = cs ? 1 : E.JstrV, vj1 = cn ? Mm + 1 : j1E;
-          if (cw) KLOOP1(jb, vj0, vj1) LA(V1, 0, jb) = gamma2 * LA(V1, 1, jb);
-          if (ce) KLOOP1(jb, vj0, vj1) LA(V1, Lm + 1, jb) = gamma2 * LA(V1, Lm, jb);
+          if (cw) KLOOP1(jb, vj0, vj1) LA(V1, 0, jb) = gamma2 * LA(V1, 1, jb) * MK_(sVm, 0, jb);
+          if (ce) KLOOP1(jb, vj0, vj1) LA(V1, Lm + 1, jb) = gamma2 * LA(V1, Lm, jb) * MK_(sVm, Lm + 1, jb);
         }
         KSYNC();
+#undef MK_
 #undef LA
       }
     }
@@ -532,8 +545,9 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         const double zsv = ZP[s0], zkv = Z1[s0];
         const double cff = cff1 * rhs_zeta;
         // (the corrector of the first fast step is a forward-Euler step too: k_step2d.h mode 0)
-        const double zeta_new = f1 ? zsv + sPm[s0] * sPn[s0] * dtfast * rhs_zeta
-                                   : zsv + sPm[s0] * sPn[s0] * (cff + cff2 * RZ1[s0] - cff3 * RZP[s0]);
+        double zeta_new = f1 ? zsv + sPm[s0] * sPn[s0] * dtfast * rhs_zeta
+                             : zsv + sPm[s0] * sPn[s0] * (cff + cff2 * RZ1[s0] - cff3 * RZP[s0]);
+        if (MK) zeta_new = zeta_new * sRm[s0];
         const double zw = f1 ? 0.5 * (zsv + zeta_new) : cff5 * zeta_new + cff4 * zkv;
         const double rhoSv = sRhoS[s0];
         DQ[s0] = zeta_new + sH[s0];
@@ -543,8 +557,8 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         gzeta2[s0] = gz * zw;
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (own) {
-          hb_emit2<true>(G, B, zout, BC_R, i, j, zeta_new, nullptr, img0);
-          if (MT && edgeblk && a.P.early) s2l_remit(a, B, 3 * (p & 1), BC_R, i, j, zeta_new, a.epoch + (unsigned)(p + 1));
+          hb_emit2<true>(G, B, zout, BC_R, i, j, zeta_new, Mr, img0);
+          if (MT && edgeblk && a.P.early) s2l_remit(a, B, 3 * (p & 1), BC_R, i, j, zeta_new, a.epoch + (unsigned)(p + 1), Mr);
           ZQ[s0] = zeta_new;
         }
       }
@@ -562,8 +576,8 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           S2L_OPQ(lo);
           const int s = ms_ + lo;
           const int d1 = isv ? TW : 1;
-          const double rhs = isv ? s2_rhs<1>(Tl, wm, Eg, s, mi, mj, g, ADV, COR, CURV, VIS, false, 1.0, 1.0)
-                                 : s2_rhs<0>(Tl, wm, Eg, s, mi, mj, g, ADV, COR, CURV, VIS, false, 1.0, 1.0);
+          const double rhs = isv ? s2_rhs<1>(Tl, wm, Eg, s, mi, mj, g, ADV, COR, CURV, VIS, MK, pk0, pk1)
+                                 : s2_rhs<0>(Tl, wm, Eg, s, mi, mj, g, ADV, COR, CURV, VIS, MK, pk0, pk1);
           const double r = rhs + w_frc;
           const double cff = (sPm[s] + sPm[s - d1]) * (sPn[s] + sPn[s - d1]);
           const double fac = 1.0 / (DQ[s] + DQ[s - d1]);
@@ -571,11 +585,12 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           const double sv = (isv ? VP : UP)[s];
           const double rs = w_rP;
           const double rp_ = w_rp;
-          const double b = f1 ? (sv * (Dstp0 + Dstp1) + cff * (0.5 * dtfast) * r) * fac
-                              : (sv * (Dstp0 + Dstp1) + cff * (k1 * r + k2 * rs - k3 * rp_)) * fac;
-          if (!isv) { hb_emit2<true>(G, B, uout, BC_U, mi, mj, b, nullptr, img0); UQ[s] = b; }
-          else { hb_emit2<true>(G, B, vout, BC_V, mi, mj, b, nullptr, img0); VQ[s] = b; }
-          if (MT && edgeblk && a.P.early) s2l_remit(a, B, 3 * (p & 1) + 1 + isv, isv ? BC_V : BC_U, mi, mj, b, a.epoch + (unsigned)(p + 1));
+          double b = f1 ? (sv * (Dstp0 + Dstp1) + cff * (0.5 * dtfast) * r) * fac
+                        : (sv * (Dstp0 + Dstp1) + cff * (k1 * r + k2 * rs - k3 * rp_)) * fac;
+          if (MK) b = b * (isv ? sVm : sUm)[s];
+          if (!isv) { hb_emit2<true>(G, B, uout, BC_U, mi, mj, b, Mu, img0); UQ[s] = b; }
+          else { hb_emit2<true>(G, B, vout, BC_V, mi, mj, b, Mv, img0); VQ[s] = b; }
+          if (MT && edgeblk && a.P.early) s2l_remit(a, B, 3 * (p & 1) + 1 + isv, isv ? BC_V : BC_U, mi, mj, b, a.epoch + (unsigned)(p + 1), isv ? Mv : Mu);
         }
       }
     }
@@ -588,8 +603,8 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
     if (MT && edgeblk && !a.P.early) {
       // the neighbouring ranks' ghost points, tagged with the pair (the values are in the Q tiles: the own points' threads stored them)
       const unsigned tag = a.epoch + (unsigned)(p + 1);
-      if (own) s2l_remit(a, B, 3 * (p & 1), BC_R, i, j, ZQ[s0_], tag);
-      if (mO) s2l_remit(a, B, 3 * (p & 1) + 1 + isvt, isvt ? BC_V : BC_U, mi, mj, (isvt ? VQ : UQ)[ms_], tag);
+      if (own) s2l_remit(a, B, 3 * (p & 1), BC_R, i, j, ZQ[s0_], tag, Mr);
+      if (mO) s2l_remit(a, B, 3 * (p & 1) + 1 + isvt, isvt ? BC_V : BC_U, mi, mj, (isvt ? VQ : UQ)[ms_], tag, isvt ? Mv : Mu);
     }
     if (t < 64) {
       if (nbf >= 0 && !dead) {
@@ -667,9 +682,9 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         const int s0 = s0_;
         if (own) {
           double *zlog = F.zeta + (size_t)(kx - 1) * G.nij, *ulog = F.ubar + (size_t)(kx - 1) * G.nij, *vlog = F.vbar + (size_t)(kx - 1) * G.nij;
-          hb_emit2(G, B, zlog, BC_R, i, j, ZP[s0], nullptr, IMG);
-          if (i >= B.IstrU) hb_emit2(G, B, ulog, BC_U, i, j, UP[s0], nullptr, IMG);
-          if (j >= B.JstrV) hb_emit2(G, B, vlog, BC_V, i, j, VP[s0], nullptr, IMG);
+          hb_emit2(G, B, zlog, BC_R, i, j, ZP[s0], Mr, IMG);
+          if (i >= B.IstrU) hb_emit2(G, B, ulog, BC_U, i, j, UP[s0], Mu, IMG);
+          if (j >= B.JstrV) hb_emit2(G, B, vlog, BC_V, i, j, VP[s0], Mv, IMG);
         }
         if (ownR && ina) {
           const bool pz = i >= B.IstrR && j >= B.JstrR, pu = i >= B.Istr && j >= B.JstrR, pv = i >= B.IstrR && j >= B.Jstr;
@@ -721,6 +736,15 @@ static __global__ void __launch_bounds__(640) k_step2d_loop_a(const Step2dLoopAr
 static __global__ void __launch_bounds__(512) k_step2d_loop_b(const Step2dLoopArgs a) {
   extern __shared__ double lds_dyn_[];
   k_step2d_loop_body<16, 8, 512>(a, (int)blockIdx.x, (int)blockIdx.y, lds_dyn_);
+}
+// ... with land/sea masks (MASKING, round 6)
+static __global__ void __launch_bounds__(512) k_step2d_loop_bk(const Step2dLoopArgs a) {
+  extern __shared__ double lds_dyn_[];
+  k_step2d_loop_body<16, 8, 512, false, true>(a, (int)blockIdx.x, (int)blockIdx.y, lds_dyn_);
+}
+static __global__ void __launch_bounds__(512) k_step2d_loop_bmk(const Step2dLoopArgs a) {
+  extern __shared__ double lds_dyn_[];
+  k_step2d_loop_body<16, 8, 512, true, true>(a, (int)blockIdx.x, (int)blockIdx.y, lds_dyn_);
 }
 // the same in a multi-tile context: edge blocks hand their rim to the neighbouring ranks and take theirs (S2LPeer)
 static __global__ void __launch_bounds__(512) k_step2d_loop_bm(const Step2dLoopArgs a) {

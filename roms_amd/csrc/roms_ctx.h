@@ -179,6 +179,14 @@ KHD TB block_bounds2(const DGrid &G, int bx, int by) { return block_bounds_n(G, 
 // to sub-tiles changes (same bits).  xmap2 is set when the number of sub-tiles is a multiple of 8.
 KHD void xcd_remap2(const DGrid &G, int &bx, int &by) {
   if (!G.xmap2) return;
+  if (G.xmap2 == 2) {
+    // (round 6, the persistent loop: ROMS_HIP_LOOP_XCD=patch) the sub-tiles of an XCD form a (nbx2/4) x (nby2/2) PATCH instead of
+    // whole rows: blocks that hand their rims to each other pair after pair then share an L2 on all four sides but the patch edge
+    const int lin = bx + G.nbx2 * by, xcd = lin & 7, r = lin >> 3, pw = G.nbx2 >> 2, ph = G.nby2 >> 1;
+    bx = (xcd & 3) * pw + r % pw;
+    by = (xcd >> 2) * ph + r / pw;
+    return;
+  }
   const int lin = bx + G.nbx2 * by, seg = (G.nbx2 * G.nby2) >> 3;
   const int t = (lin & 7) * seg + (lin >> 3);
   by = t / G.nbx2;

@@ -622,6 +622,10 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   if (cfg->options & (ROMS_NUDGE_M3CLM | ROMS_NUDGE_TCLM_ALL)) {       // climatology nudging: rhs3d.F:654-680, step3d_t.F:1866-1878
     if (c->G.obc) { set_error("climatology nudging with open boundaries: the nudging coefficients of the radiation conditions (t3dbc_im.F:120, u3dbc_im.F:113) are not built"); roms_hip_destroy(c); return 5; }
     if (cfg->options & ROMS_DIAGNOSTICS_UV) { set_error("climatology nudging with DIAGNOSTICS_UV: not built"); roms_hip_destroy(c); return 5; }
+    // (the rule of this library: an option set without a reference-written fixture or a pinned oracle run is refused)
+    if (cfg->options & (ROMS_WET_DRY | ROMS_TS_DIF4 | ROMS_UV_VIS4 | ROMS_MIX_GEO_UV)) {
+      set_error("climatology nudging together with WET_DRY, TS_DIF4 / UV_VIS4 or MIX_GEO_UV: not pinned against the reference"); roms_hip_destroy(c); return 5;
+    }
     c->G.clima = ((cfg->options & ROMS_NUDGE_M3CLM) ? 1 : 0);
     for (int it = 1; it <= c->G.NT; it++) if (cfg->options & ROMS_NUDGE_TCLM(it)) c->G.clima |= 1 << it;
     if (c->G.clima & ~1) c->G.fuse3d = 0;                    // (the nudging sits between t3dbc and the exchange: separate launches)
@@ -630,6 +634,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     if (!(cfg->options & ROMS_UV_VIS2) || c->G.uv_vis4) { set_error("MIX_GEO_UV: the harmonic viscosity only (UV_VIS2; uv3dmix4_geo.h is not built)"); roms_hip_destroy(c); return 5; }
     if (c->G.obc) { set_error("MIX_GEO_UV with open boundaries: not pinned"); roms_hip_destroy(c); return 5; }
     if (cfg->options & ROMS_DIAGNOSTICS_UV) { set_error("MIX_GEO_UV: the DIAGNOSTICS_UV statements of uv3dmix2_geo.h are not built"); roms_hip_destroy(c); return 5; }
+    if (cfg->options & ROMS_WET_DRY) { set_error("MIX_GEO_UV with WET_DRY: not pinned against the reference"); roms_hip_destroy(c); return 5; }
     void *p = nullptr;
     if (dmalloc(&p, (size_t)20 * (size_t)c->G.nij * (size_t)(c->G.N + 1) * sizeof(double))) { roms_hip_destroy(c); return 2; }
     c->allocs.push_back(p);
@@ -2085,13 +2090,14 @@ static bool late_schedule_ok(roms_hip_ctx *c) {
 #else
   const bool uvcol = (cf.options & ROMS_UV_VIS2) && (euc ? euc[0] != '0' : cols >= 128L * 1024L);   // run_uv3dmix2_col's rule
 #endif
-  // (a masked run keeps the reference order: its boundary fills are separate launches on the compute stream)
+  // (a masked run keeps the reference order -- its boundary fills are separate launches on the compute stream -- unless it
+  // takes the persistent barotropic loop (round 6): the schedule around the loop then, 1.015 -> 0.985 ms on BENCHMARK1 with land)
   static const char *elm = getenv("ROMS_HIP_LATE_MASK");
   // (prsgrd31: the late schedule relies on k_prs_grad keeping the previous ru/rv bracket for the deferred predictor)
   // (a multi-tile context, round 6: the schedule around the persistent loop only, with the mailbox -- every lane has its own
   // channel -- and every exchange in the stream of its producer: the lanes are what overlaps an exchange with compute)
   const bool tiles_ok = !c->has_exchange || (c->comm.peer_on && step2d_loop_usable(c) && !c->x_async);
-  return tiles_ok && !uvcol && !c->G.dia_ts && !c->G.dia_uv && !c->G.uv_vis4 && !c->G.ts_dif4 && !c->G.mix_geo_uv && (!c->G.masking || (elm && elm[0] == '1')) &&
+  return tiles_ok && !uvcol && !c->G.dia_ts && !c->G.dia_uv && !c->G.uv_vis4 && !c->G.ts_dif4 && !c->G.mix_geo_uv && (!c->G.masking || (elm ? elm[0] == '1' : step2d_loop_usable(c))) &&
          !(elate && elate[0] == '0') && !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_GLS_MIXING | ROMS_MY25_MIXING));
 }
 // ... and the one around the persistent barotropic loop: 0 = no, else its form (ROMS_HIP_LOOP_SCHED: 0 = the loop inside the

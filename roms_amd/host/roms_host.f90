@@ -1029,6 +1029,8 @@
      &  CALL unsupported ('WET_DRY is built with ANA_VMIX or LMD_MIXING, analytic or bulk fluxes, harmonic mixing along '//  &
      &                    's-surfaces or geopotentials and DJ_GRADPS (not with GLS_MIXING, MY25_MIXING, MIX_ISO_TS, '//  &
      &                    'UV_VIS4, TS_DIF4, other pressure Jacobians)', ierr)
+      IF (wet_dry.and.is_defined('UV_VIS2').and.is_defined('MIX_GEO_UV'))                                       &
+     &  CALL unsupported ('WET_DRY together with MIX_GEO_UV: not pinned against the reference', ierr)
       IF ((mix4(1).and.is_defined('UV_VIS2')).or.(mix4(2).and.is_defined('TS_DIF2')))                          &
      &  CALL unsupported ('harmonic and biharmonic mixing of the same field together (UV_VIS2 + UV_VIS4, TS_DIF2 + TS_DIF4) '// &
      &                    'are not built', ierr)

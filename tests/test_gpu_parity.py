@@ -399,6 +399,46 @@ def test_step2d_forms_match_oracle_and_each_other(workload, dims, tmp_path):
             assert np.array_equal(got[first][n], got[tag][n]), (tag, n, float(np.abs(got[first][n] - got[tag][n]).max()))
 
 
+@pytest.mark.gpu
+def test_persistent_loop_with_land_mask_matches_the_other_engines(tmp_path):
+    """Round 6: the persistent barotropic loop with MASKING (k_step2d_loop_bk: the masked statements of step2d_LF_AM3.h --
+    zeta * rmask :1002, ubar * umask :2560, the no-slip factors of pmask in the viscous stresses :1600, the masked gradient /
+    slip values at closed edges, zetabc.F:264, u2dbc_im.F:989 -- on three more LDS tiles) against the pair launches and the
+    per-call kernel on BENCHMARK with the host's analytic land, a ragged small grid: every state array bit for bit, in the
+    schedule around the loop (the default of a masked run that takes the loop) and in the reference order; the flow moves."""
+    import subprocess
+    import sys
+    import textwrap
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    names = ["zeta", "ubar", "vbar", "rzeta", "rubar", "rvbar", "Zt_avg1", "DU_avg1", "DU_avg2", "DV_avg1", "DV_avg2", "u", "v", "t", "W", "Hz", "rufrc"]
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        import bench
+        from roms_amd import tiling
+        cs = bench.params_for("benchmark1_mask", 200, 44, 10, ntimes=10)
+        cs["ninfo"] = 1
+        run = tiling.TiledRun(cs)
+        run.step(4)
+        run.sync()
+        np.savez(sys.argv[1], **{n: run.ctx.download(n) for n in %r})
+        run.close()
+        print("FORM-RUN-OK")
+    """) % (ROOT, names)
+    got = {}
+    for tag, env in (("loop", {}), ("loop_ref", {"ROMS_HIP_LATE_MASK": "0"}), ("pair", {"ROMS_HIP_LOOP": "0"}), ("percall", {"ROMS_HIP_PAIR": "0"})):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, env=dict(os.environ, ROMS_HIP_LOOP_TIMEOUT="0.2", **env), timeout=600)
+        assert "FORM-RUN-OK" in r.stdout, (tag, r.stdout[-1500:] + r.stderr[-3000:])
+        got[tag] = dict(np.load(f))
+    assert np.abs(got["loop"]["u"]).max() > 1e-4
+    for tag in ("loop_ref", "pair", "percall"):
+        for n in names:
+            assert np.isfinite(got["loop"][n]).all(), n
+            assert np.array_equal(got["loop"][n], got[tag][n]), (tag, n)
+
+
 def test_persistent_loop_gives_up_instead_of_hanging():
     """The persistent barotropic loop (k_step2d_loop.h) bounds every wait for a neighbouring block: with a limit of zero
     every block gives up at its first wait, the launch still ends, and the next entry reports exit_flag 2 with the
@@ -1159,6 +1199,10 @@ def test_persistent_loop_across_tile_edges_matches_single_tile(env):
     assert "LOOP-MT-OK" in r.stdout, (env, r.stdout[-1500:] + r.stderr[-3000:])
     if env:
         return
+    # ... with land (k_step2d_loop_bmk: the masked boundary values travel through the rim planes too)
+    code_m = code.replace('bench.params_for("benchmark1", ntimes=30)', 'bench.params_for("benchmark1_mask", ntimes=30)').replace("(per <= 20)", "(per <= 48)")
+    r = subprocess.run([sys.executable, "-c", code_m], capture_output=True, text=True, env=e, timeout=600)
+    assert "LOOP-MT-OK" in r.stdout, ("mask", r.stdout[-1500:] + r.stderr[-3000:])
     # all eight neighbours (doubly periodic): corner points through the rim planes
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mp", "selfx8.py"), "peer"], capture_output=True, text=True, env=e, timeout=300)
     line = [l for l in r.stdout.splitlines() if l.startswith("SELFX8")]
