@@ -1298,6 +1298,51 @@
       IF (theta_b.gt.0.0_dp) C=(EXP(theta_b*C)-1.0_dp)/(1.0_dp-EXP(-theta_b))
       END FUNCTION stretch_curve
 
+!  level index rk (k on w-levels, k - 1/2 on rho-levels) -> s and C(s) of Vstretching 2, 3, 5
+      SUBROUTINE stretch_level (rk, s, C)
+      real(dp), intent(in) :: rk
+      real(dp), intent(out) :: s, C
+      real(dp) :: rN, Csur, Cbot, wgt, Hscale
+      rN=REAL(N,dp)
+      IF (Vstretching.eq.5) THEN
+        s=-(rk*rk-2.0_dp*rk*rN+rk+rN*rN-rN)/(rN*rN-rN)-0.01_dp*(rk*rk-rk*rN)/(1.0_dp-rN)
+      ELSE
+        s=(1.0_dp/rN)*(rk-rN)
+      END IF
+      SELECT CASE (Vstretching)
+        CASE (2)
+          IF (theta_s.gt.0.0_dp) THEN
+            Csur=(1.0_dp-COSH(theta_s*s))/(COSH(theta_s)-1.0_dp)
+            IF (theta_b.gt.0.0_dp) THEN
+              Cbot=SINH(theta_b*(s+1.0_dp))/SINH(theta_b)-1.0_dp
+              wgt=(s+1.0_dp)**1.0_dp*(1.0_dp+(1.0_dp/1.0_dp)*(1.0_dp-(s+1.0_dp)**1.0_dp))
+              C=wgt*Csur+(1.0_dp-wgt)*Cbot
+            ELSE
+              C=Csur
+            END IF
+          ELSE
+            C=s
+          END IF
+        CASE (3)
+          Hscale=3.0_dp
+          Cbot=LOG(COSH(Hscale*(s+1.0_dp)**theta_b))/LOG(COSH(Hscale))-1.0_dp
+          Csur=-LOG(COSH(Hscale*ABS(s)**theta_s))/LOG(COSH(Hscale))
+          wgt=0.5_dp*(1.0_dp-TANH(Hscale*(s+0.5_dp)))
+          C=wgt*Cbot+(1.0_dp-wgt)*Csur
+        CASE DEFAULT
+          IF (theta_s.gt.0.0_dp) THEN
+            Csur=(1.0_dp-COSH(theta_s*s))/(COSH(theta_s)-1.0_dp)
+          ELSE
+            Csur=-s**2
+          END IF
+          IF (theta_b.gt.0.0_dp) THEN
+            C=(EXP(theta_b*Csur)-1.0_dp)/(1.0_dp-EXP(-theta_b))
+          ELSE
+            C=Csur
+          END IF
+      END SELECT
+      END SUBROUTINE stretch_level
+
       SUBROUTINE vertical_coordinate (ierr)
       integer, intent(out) :: ierr
       integer :: k
@@ -1324,8 +1369,21 @@
         END DO
         RETURN
       END IF
+      IF (Vstretching.eq.2.or.Vstretching.eq.3.or.Vstretching.eq.5) THEN
+!  (round 6) the other curves of set_scoord.F: 2 = Shchepetkin (2005), :240-292; 3 = Geyer's bottom-boundary-layer
+!  function, :298-337; 5 = Souza's quadratic Legendre levels under the double curve of 4, :478-526.  The surface and bottom
+!  w-levels are exact by definition; every interior level is one evaluation of stretch_level
+        sc_w(N)=0.0_dp;   Cs_w(N)=0.0_dp
+        sc_w(0)=-1.0_dp;  Cs_w(0)=-1.0_dp
+        DO k=1,N
+          IF (k.lt.N) CALL stretch_level (REAL(k,dp), sc_w(k), Cs_w(k))
+          CALL stretch_level (REAL(k,dp)-0.5_dp, sc_r(k), Cs_r(k))
+        END DO
+        RETURN
+      END IF
       IF (Vstretching.ne.4) THEN          ! the BASELINE applications use 4
-        CALL unsupported ('Vstretching: built are 1 (Song and Haidvogel 1994) and 4 (Shchepetkin 2010)', ierr)
+        CALL unsupported ('Vstretching: built are 1 (Song and Haidvogel 1994), 2 (Shchepetkin 2005), 3 (Geyer), '//            &
+     &                    '4 (Shchepetkin 2010) and 5 (Souza)', ierr)
         RETURN
       END IF
       dsig=1.0_dp/REAL(N,dp)

@@ -78,6 +78,43 @@ def make_case(case):
     print(f"wrote {tag}_init.npz  ({len(names)} fields, nfast={b[58]})")
 
 
+VSTRETCH_SETS = [(2, 2, 5.0, 0.4, 8), (2, 2, 7.0, 2.0, 12), (2, 2, 6.0, 0.0, 8), (3, 2, 1.3, 2.1, 8), (3, 2, 0.65, 0.58, 12), (5, 2, 5.0, 1.5, 8),
+                 (5, 2, 0.0, 0.0, 12), (5, 1, 4.0, 0.0, 8), (2, 1, 5.0, 0.4, 8)]
+
+
+def make_vstretch(one=None):
+    """vstretch_tables.npz: sc_r, Cs_r, sc_w, Cs_w of the reference's set_scoord.F for the stretching functions the BASELINE
+    applications do not use -- Vstretching 2 (Shchepetkin 2005), 3 (Geyer), 5 (Souza) -- with several parameter sets and both
+    Vtransform; z_r, Hz of the state at rest beside them (UPWELLING 14x18, N = 8 / 12).  One process per set: the
+    reference library holds one configuration per process."""
+    if one is None:
+        out = {}
+        for q in range(len(VSTRETCH_SETS)):
+            subprocess.check_call([sys.executable, __file__, "--vstretch-one", str(q)])
+            d = np.load(f"/tmp/vstretch_{q}.npz")
+            out.update({k: d[k] for k in d.files})
+        np.savez_compressed(os.path.join(HERE, "vstretch_tables.npz"), nsets=np.array(len(VSTRETCH_SETS)), **out)
+        print(f"wrote vstretch_tables.npz ({len(VSTRETCH_SETS)} parameter sets)")
+        return
+    from oracle import ref
+    from tests import cases
+    q = int(one)
+    vs, vt, ths, thb, N = VSTRETCH_SETS[q]
+    cs = cases.upwelling(Lm=14, Mm=18, N=N)
+    cs.update(Vstretching=vs, Vtransform=vt, theta_s=ths, theta_b=thb, Tcline=(25.0 if vt == 2 else 10.0))
+    ip, rp = cases.ref_params(cs)
+    saved = quiet()
+    R = ref.Ref("upwelling", ip, rp)
+    R.initial()
+    out = {f"par{q}": np.array([vs, vt, ths, thb, N, cs["Tcline"]])}
+    for k, (tab, n) in enumerate((("sc_r", N), ("Cs_r", N), ("sc_w", N + 1), ("Cs_w", N + 1))):
+        out[f"{tab}{q}"] = R.table(k + 1, n)
+    out[f"z_r{q}"] = R.get("z_r")
+    out[f"Hz{q}"] = R.get("Hz")
+    os.dup2(saved, 1)
+    np.savez_compressed(f"/tmp/vstretch_{q}.npz", **out)
+
+
 def make_bounds():
     from oracle import ref
     from tests import cases
@@ -344,6 +381,10 @@ if __name__ == "__main__":
         make_kernels(sys.argv[2], sys.argv[3], sys.argv[4:])
     elif len(sys.argv) > 3 and sys.argv[1] == "--sample":
         make_sample(sys.argv[2], int(sys.argv[3]))
+    elif len(sys.argv) > 2 and sys.argv[1] == "--vstretch-one":
+        make_vstretch(sys.argv[2])
+    elif len(sys.argv) > 1 and sys.argv[1] == "--vstretch":
+        make_vstretch()
     elif len(sys.argv) > 1 and sys.argv[1] == "--avg":
         make_avg()
     elif len(sys.argv) > 1 and sys.argv[1] == "--dia":

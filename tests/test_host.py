@@ -84,6 +84,28 @@ ad_LBC(isFsur) ==   Clo     Clo     Clo     Clo
         H.finalize()
 
 
+@pytest.mark.parametrize("q", range(9))
+def test_vertical_stretching_functions_match_reference(q):
+    """Round 6: Vstretching 2 (Shchepetkin 2005), 3 (Geyer), 5 (Souza's quadratic levels) of set_scoord.F:240-337,478-526, several
+    parameter sets and both Vtransform: sc_r, Cs_r, sc_w, Cs_w and the depths z_r, Hz of the state at rest equal the arrays the
+    reference's own object code wrote (tests/golden/vstretch_tables.npz, make_golden.py --vstretch) bit for bit."""
+    from tests import cases
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "vstretch_tables.npz"))
+    vs, vt, ths, thb, N, tcl = d[f"par{q}"]
+    cs = cases.upwelling(Lm=14, Mm=18, N=int(N))
+    cs.update(Vstretching=int(vs), Vtransform=int(vt), theta_s=float(ths), theta_b=float(thb), Tcline=float(tcl))
+    H = _host(cs)
+    try:
+        for n in ("sc_r", "Cs_r", "sc_w", "Cs_w"):
+            assert np.array_equal(H.get(n), d[f"{n}{q}"]), (n, H.get(n), d[f"{n}{q}"])
+        for n in ("z_r", "Hz"):
+            a, b = H.get(n), d[f"{n}{q}"]
+            assert a.size == b.size and np.array_equal(a.ravel(), b.ravel()), n
+        assert np.all(np.diff(d[f"Cs_w{q}"]) > 0)
+    finally:
+        H.finalize()
+
+
 def test_host_needs_device_for_run():
     cs = util.case_for("upwelling_small")
     H = _host(cs)
@@ -149,7 +171,7 @@ def test_reader_accepts_the_reference_spellings(tmp_path):
     (dict(h1="WENO5"), "unknown scheme"),
     (dict(h1="MPDATA"), "MPDATA must be chosen for both"),
     (dict(extra="LuvSrc == T"), "LuvSrc == T"),
-    (dict(extra="Vstretching == 2"), "Vstretching"),
+    (dict(extra="Vstretching == 6"), "Vstretching"),
     (dict(extra="Ngrids = 2"), "Ngrids"),
 ])
 def test_reader_stops_on_settings_it_cannot_honour(tmp_path, kw, needle):
