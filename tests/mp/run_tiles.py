@@ -37,6 +37,7 @@ def main():
     if spec.get("probe"):                          # the transport's self-check before anything else moves
         ok, why = run.probe(3)
         assert ok, why
+    nx0 = run.ctx.L.roms_hip_exchange_count(run.ctx.h)        # (behind the probe: what the steps themselves exchange)
     if spec.get("restart_from"):                   # every rank reads the restart file and uploads its window
         run.get_state(spec["restart_from"], 0)
     if spec.get("advance"):                        # steps with the history / restart records of output.F
@@ -49,7 +50,7 @@ def main():
     nx = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
     if rank == 0:
         print("TRANSPORT", getattr(run, "transport", None), flush=True)
-        np.savez(out, nexchanges=nx, diag=np.array([d["avgke"], d["avgpe"], d["volume"], d["maxspeed"]]), **res)
+        np.savez(out, nexchanges=nx, nexchanges_steps=nx - nx0, diag=np.array([d["avgke"], d["avgpe"], d["volume"], d["maxspeed"]]), **res)
     run.close()
     dist.barrier()
     dist.destroy_process_group()
