@@ -1208,6 +1208,19 @@ extern "C" int roms_hip_comm_peer(roms_hip_ctx *c, const void *blobs128, int nra
       for (int par = 0; par < 2; par++) m.peer_noff[d][ch][par] = table[ch][par][g_opp[d]];
   }
   for (int ch = 0; ch < PEER_NCH; ch++) m.peer_seq[ch] = 0;
+  // (the arrival words of my slots and the elements of my rim planes carry the numbers of the exchanges that wrote them: a transport installed again
+  // counts from one again, so whatever an earlier installation left there goes -- the caller's barrier behind this call keeps
+  // the neighbours from writing before everyone is through, roms_amd/tiling.py:_install_peer)
+  {
+    if (m.peer_bytes > PEER_WORDS && hipfail(hipMemset((char *)m.peer_slab + PEER_WORDS, 0, m.peer_bytes - PEER_WORDS), "hipMemset (mailbox slab)")) return 2;
+    if (hipfail(hipDeviceSynchronize(), "hipDeviceSynchronize")) return 2;
+    c->loop_epoch = 0;
+    if (c->loop_flags) {
+      int nb2x = 0, nb2y = 0;
+      step2d_loop_dims(c, nb2x, nb2y);
+      (void)hipMemset(c->loop_flags, 0, (size_t)nb2x * nb2y * 16 * sizeof(unsigned));
+    }
+  }
   m.peer_on = true;
   c->loop_state = 0;                    // (the persistent barotropic loop of a multi-tile context needs the mailbox: decided again)
   // (ranks sharing one device: smaller blocks, so that the waiting unpack blocks of ALL of them fit the device beside the
