@@ -167,6 +167,10 @@ int run_set_data(roms_hip_ctx *c) {
 int run_omega(roms_hip_ctx *c) {
   const TB &B = c->G.T;
   KArgs a = mk(c);
+  // (round 6, tried and dropped: W on the two ghost lines below and the one above the tile computed with the tile from Huon,
+  // Hvom there -- every line rhs3d.F reads -- instead of exchanged.  It leaves the OUTER ghost lines of a periodic domain edge,
+  // W(-2,:) and W(Lm+2,:), unwritten: nobody reads them, but a serial run defines them, and the tiled runs are held to every
+  // point a serial run defines.)
   {
     static const char *e = getenv("ROMS_HIP_COLLDS");
     const bool l = !(e && e[0] == '0') && 2 * (c->G.N + 1) * 64 * sizeof(double) < 64 * 1024;
@@ -189,7 +193,8 @@ int run_wvelocity(roms_hip_ctx *c, int ninp) {
   };
   // (a single tile whose barotropic kernels store the periodic images of what they write -- DGrid::fuse_halo -- has left
   // DU_avg1, DV_avg1 complete: the fast-time averages are closed by the last call with their images)
-  if (!c->G.fuse_halo) launch_halo_multi(c, hs7, 2);
+  // (... and so has a multi-tile context inside roms_hip_main3d: the exchange behind the fast steps carried them)
+  if (!c->G.fuse_halo && !ghost_compute(c, 64)) launch_halo_multi(c, hs7, 2);
   KArgs a = mk(c, ninp);
   static const char *ef = getenv("ROMS_HIP_WVELF");
   if (ef && ef[0] == '0') {

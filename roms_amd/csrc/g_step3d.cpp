@@ -46,7 +46,10 @@ int run_step3d_uv(roms_hip_ctx *c) {
     else {
       const int wet = G.wet_dry ? BC_WET3 : 0;
       HaloSpec sp[2] = {{uv_lev(c, c->F.u, nnew), N, BC_U | wet, 0}, {uv_lev(c, c->F.v, nnew), N, BC_V | wet, 0}};   // u3dbc/v3dbc :1266,1271
-      launch_halo_multi(c, sp, 2);
+      // (multi-tile: the coupling below reads the tile's own columns and these boundary values only, and exchanges u, v(nnew)
+      // itself: the conditions without the strips)
+      if (ghost_compute(c, 32)) launch_fill_only(c, sp, 2, G.T);
+      else launch_halo_multi(c, sp, 2);
     }
   }
   auto couple = [&]() {

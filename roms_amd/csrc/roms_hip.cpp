@@ -1505,6 +1505,21 @@ void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n) {
   }
 }
 
+void launch_fill_only(roms_hip_ctx *c, const HaloSpec *sp, int n, const TB &X) {
+  HaloArgs a;
+  a.G = c->G;
+  a.G.T = X;
+  a.nitems = n;
+  int planes = 0;
+  for (int k = 0; k < HALO_MAXITEMS; k++) { a.it[k].A = nullptr; a.it[k].nk = 0; a.it[k].bc = BC_NONE; a.it[k].gtype = 0; }
+  for (int k = 0; k < n; k++) {
+    a.it[k].A = sp[k].A; a.it[k].nk = sp[k].nk; a.it[k].bc = sp[k].bc; a.it[k].gtype = (int)sp[k].gtype;
+    planes += sp[k].nk;
+  }
+  if (!(X.west || X.east || X.south || X.north)) return;     // (no edge of the domain on this tile: nothing to fill)
+  LAUNCH_COOP(halo_kernel, 1, 1, planes, 256, 0, c->stream, a);
+}
+
 // Self-check of the installed transport: `reps` exchanges of a work plane whose own points carry a code of their
 // global indices and of the repetition; afterwards every ghost point that comes from a neighbour's own points must
 // hold the code of the point it images (tile arrays are indexed globally, so that is its own index, wrapped where the

@@ -213,6 +213,10 @@ void launch_halo(roms_hip_ctx *c, double *A, int nk, int bc, char gtype);
 void launch_halo_tail(roms_hip_ctx *c, const HaloSpec *sp, int n);
 void launch_halo_multi(roms_hip_ctx *c, const HaloSpec *sp, int n);   // n <= 8 fields in one launch
 void launch_halo_wide(roms_hip_ctx *c, const HaloSpec *sp, int n);    // ... with strips B2D_GL | B2D_GH lines wide (pair kernel)
+// the boundary fills of an exchange point WITHOUT the exchange (multi-tile contexts, round 6: the ghost lines of these fields are
+// computed with the tile or nobody reads them before the next exchange of the same field), on the rectangle X -- the tile, or the
+// tile with the ghost lines a ghost-computing producer has just written (ghost_tb)
+void launch_fill_only(roms_hip_ctx *c, const HaloSpec *sp, int n, const TB &X);
 int run_set_avg(roms_hip_ctx *c, int part = 0);   // g_avg.cpp
 int run_set_diags(roms_hip_ctx *c);
 // WET_DRY (g_wetdry.cpp)
@@ -279,10 +283,11 @@ int run_copy_probe(roms_hip_ctx *c, int reps);
 // it (exchange_r3d_tile + mp_exchange3d at the tail of set_depth, ana_* ...) is not needed.  Only inside roms_hip_main3d, behind
 // the first step's post_initial (roms_hip_ctx::ghost_ok): roms_hip_start and the per-routine entries work on whatever the caller
 // uploaded, whose ghost lines the reference does not promise either.  ROMS_HIP_GHOSTCOMP=0: exchange.
-// (a mask: 1 set_depth, 2 set_data, 4 rho_eos, 8 set_massflux; default all)
+// (a mask: 1 set_depth, 2 set_data, 4 rho_eos, 8 set_massflux, 32 the boundary values of u, v(nnew) in step3d_uv without their
+// exchange, 64 wvelocity without a second exchange of DU_avg1, DV_avg1; default all)
 inline bool ghost_compute(const roms_hip_ctx *c, int which) {
   static const char *e = getenv("ROMS_HIP_GHOSTCOMP");
-  static const int mask = e ? atoi(e) : 15;
+  static const int mask = e ? atoi(e) : 127;
   return c->has_exchange && c->ghost_ok && (mask & which);
 }
 inline TB ghost_tb(const roms_hip_ctx *c, int gl, int gh) {
