@@ -850,7 +850,7 @@ def main():
         }
         out["cpu_baseline"] = cpu
     run.close()
-    if world > 1 and not args.share_gpu and not os.environ.get("ROMS_BENCH_NO_AB"):
+    if world > 1 and (not args.share_gpu or os.environ.get("ROMS_BENCH_FORCE_AB")) and not os.environ.get("ROMS_BENCH_NO_AB"):
         # The same steps through the OTHER device-to-device transport of the library: the headline
         # above used `run.transport` (auto: the mailbox where its probe passes on every rank, else RCCL); here a fresh set of
         # contexts with the other one, a short timed region with the same barriers.  rccl_ranks is read from the live RCCL

@@ -69,6 +69,11 @@ int ctx_check(roms_hip_ctx *c, const char *what) {
     const unsigned long long w = *(volatile unsigned long long *)c->loop_err;
     set_error("barotropic loop (k_step2d_loop): sub-tile " + std::to_string((w & 0xffffffffull) - 1) + " gave up waiting for a neighbouring block in pair " +
               std::to_string(w >> 32) + " (not every block of the launch was resident?); ROMS_HIP_LOOP=0 runs the pair launches, ROMS_HIP_LOOP_TIMEOUT sets the limit in seconds");
+    // reported once: the state of this step is lost (exit_flag 2), and the context leaves the persistent loop for good -- a caller
+    // that goes on from a restart record in the same context gets the pair launches
+    (void)hipDeviceSynchronize();
+    *(volatile unsigned long long *)c->loop_err = 0;
+    c->loop_state = -1;
     return 2;
   }
   return hipfail(hipGetLastError(), what);
