@@ -1228,6 +1228,8 @@ extern "C" int roms_hip_comm_peer(roms_hip_ctx *c, const void *blobs128, int nra
   }
   m.peer_on = true;
   c->loop_state = 0;                    // (the persistent barotropic loop of a multi-tile context needs the mailbox: decided again)
+  // the step is arranged on four streams, every exchange in the stream of its producer on that stream's channel (main3d_around_loop)
+  if (c->pair_mt && !getenv("ROMS_HIP_XASYNC") && !(getenv("ROMS_HIP_MT_LANES") && getenv("ROMS_HIP_MT_LANES")[0] == '0')) { halo_fence(c, FG_ALL); c->x_async = false; c->rim_split = false; }
   // (ranks sharing one device: smaller blocks, so that the waiting unpack blocks of ALL of them fit the device beside the
   // pack blocks they wait for -- 8 ranks x 200 planes x 1024 threads exceed an MI355X's 512 K resident threads)
   { const char *et = getenv("ROMS_HIP_PEER_THREADS"); c->peer_threads = et ? atoi(et) : (m.peer_shared ? 256 : 1024); }
@@ -2048,7 +2050,7 @@ static int main3d_around_loop(roms_hip_ctx *c, bool do_diag, int form, bool with
   DO(roms_hip_set_zeta(c));                                 // :556
   lane_record(c, E_Z);
   // (multi-tile: the level the loop's first fast step starts from, 5 | 4 lines wide -- here, 300 us ahead of the launch)
-  if (c->has_exchange) DO(step2d_loop_pre(c, 2));
+  if (c->has_exchange && step2d_loop_usable(c)) DO(step2d_loop_pre(c, 2));
   lane_wait(c, E_EOS);
   DO(roms_hip_prsgrd(c));                                   // rhs3d.F: prsgrd, rhs3d_tile
   DO(run_rhs3d_pt(c));
@@ -2104,7 +2106,7 @@ static int main3d_around_loop(roms_hip_ctx *c, bool do_diag, int form, bool with
   lane_wait(c, E_UV);
   lane_wait(c, E_D);
   DO(run_rufrc_sums(c));                                    // (the predictor on this stream, the loop behind it in-stream: 0.849 against 0.828 ms)
-  if (c->has_exchange) DO(step2d_loop_pre(c, 1));           // (multi-tile: the forcing on the enlarged sub-tiles, while the other lanes finish)
+  if (c->has_exchange && step2d_loop_usable(c)) DO(step2d_loop_pre(c, 1));   // (multi-tile: the forcing on the enlarged sub-tiles, while the other lanes finish)
   if (!diag_main) lane_wait(c, E_X);
   lane_wait(c, E_T3);                                       // (nothing beside the loop)
   lane_wait(c, E_AK);
@@ -2129,7 +2131,10 @@ static bool late_schedule_ok(roms_hip_ctx *c) {
   // (prsgrd31: the late schedule relies on k_prs_grad keeping the previous ru/rv bracket for the deferred predictor)
   // (a multi-tile context, round 6: the schedule around the persistent loop only, with the mailbox -- every lane has its own
   // channel -- and every exchange in the stream of its producer: the lanes are what overlaps an exchange with compute)
-  const bool tiles_ok = !c->has_exchange || (c->comm.peer_on && step2d_loop_usable(c) && !c->x_async);
+  // ... or, where the loop does not fit (tiles above 32 K columns: BASELINE's 8-GPU partition), with the pair launches in its
+  // place: ROMS_HIP_MT_LANES=0 keeps those contexts in the reference order
+  static const char *eml = getenv("ROMS_HIP_MT_LANES");
+  const bool tiles_ok = !c->has_exchange || (c->comm.peer_on && !c->x_async && (step2d_loop_usable(c) || (c->pair_mt && c->pair_on && !(eml && eml[0] == '0'))));
   return tiles_ok && !uvcol && !c->G.dia_ts && !c->G.dia_uv && !c->G.uv_vis4 && !c->G.ts_dif4 && !c->G.mix_geo_uv && (!c->G.masking || (elm ? elm[0] == '1' : step2d_loop_usable(c))) &&
          !(elate && elate[0] == '0') && !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_GLS_MIXING | ROMS_MY25_MIXING));
 }
@@ -2139,7 +2144,7 @@ static bool late_schedule_ok(roms_hip_ctx *c) {
 static int around_loop_form(roms_hip_ctx *c) {
   static const char *esch = getenv("ROMS_HIP_LOOP_SCHED");
   const int form = esch ? atoi(esch) : 1;
-  return (form > 0 && late_schedule_ok(c) && step2d_loop_usable(c)) ? form : 0;
+  return (form > 0 && late_schedule_ok(c) && (step2d_loop_usable(c) || c->has_exchange)) ? form : 0;
 }
 
 // one pass of STEP_LOOP, main3d.F:216-1148
