@@ -293,17 +293,6 @@ static void loop_grid(const DGrid &G, DGrid &L) {
     if (L.xmap2 && ep && !strcmp(ep, "patch") && L.nbx2 % 4 == 0 && L.nby2 % 2 == 0 && (L.nbx2 / 4) * (L.nby2 / 2) * 8 == L.nbx2 * L.nby2) L.xmap2 = 2; }
 }
 static size_t loop_lds_doubles(bool masked = false) { return (size_t)(masked ? S2L_NLDS_MK : S2L_NLDS) * (loop_shape() ? (16 + 2 * S2P_RIM) * (8 + 2 * S2P_RIM) : (32 + 2 * S2P_RIM) * (4 + 2 * S2P_RIM)); }
-#endif
-void step2d_loop_dims(const roms_hip_ctx *c, int &nbx2, int &nby2) {
-#ifdef ROMS_CPU_EMU
-  (void)c; nbx2 = nby2 = 0;
-#else
-  DGrid L;
-  loop_grid(c->G, L);
-  nbx2 = L.nbx2; nby2 = L.nby2;
-#endif
-}
-#ifndef ROMS_CPU_EMU
 // A multi-tile context (round 6): the loop crosses the tile edges through the mailbox slab (k_step2d_loop.h, S2LPeer).  Every
 // rank must take the same decision, so it depends on the partition, the transport and the environment only: equal tiles
 // (the neighbours' sub-tile grids continue mine), the mailbox installed with a loop region on every neighbour, no rank
@@ -328,7 +317,47 @@ static bool loop_mt_usable(roms_hip_ctx *c, const DGrid &L, bool forced) {
   }
   return true;
 }
+// The launch.  Its blocks wait for each other, so all of them must be resident at once.  hipLaunchCooperativeKernel would make
+// the runtime guarantee that (or refuse the launch) -- but the runtime routes cooperative launches through a queue of their
+// own and orders it against the stream with barrier packets on both sides: measured on the MI355X (round 6,
+// tools/gpu_debug/ab_env.sh ROMS_HIP_LOOP_COOP "1 0"), a BENCHMARK1 step takes 1.53-1.58 ms with it against 0.82 ms with the
+// ordinary launch (one-step trace: 70 us of idle queue in front of the kernel, 30 us behind it, and the four streams of the
+// schedule serialised against the cooperative queue).  So the ordinary launch stays the default, guarded by the occupancy
+// query at set-up (every block resident on an otherwise idle device) and by bounded waits: a launch that meets a busy
+// device ends with exit_flag 2 and a message that names ROMS_HIP_LOOP=0 (ctx_check; the step's state is lost, as with any
+// other device error).  Ranks
+// that share a device (test set-ups) do not take the loop at all; ROMS_HIP_LOOP=0 is the switch for any other shared use.
+// ROMS_HIP_LOOP_COOP=1 selects the cooperative launch.
+template <class K>
+static int loop_launch(roms_hip_ctx *c, K kern, const char *label, const Step2dLoopArgs &a, int nthr, size_t lds_doubles) {
+  static const char *ec = getenv("ROMS_HIP_LOOP_COOP");
+  const bool coop = ec && ec[0] == '1' && !g_kp_start && !g_kprof_mode;
+  const dim3 grid((unsigned)a.G.nbx2, (unsigned)a.G.nby2, 1), block((unsigned)nthr);
+  if (coop) {
+    void *args[1] = {(void *)&a};
+    const hipError_t e = hipLaunchCooperativeKernel((const void *)kern, grid, block, args, lds_doubles * sizeof(double), c->stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error(std::string("step2d_loop: the cooperative launch was refused (") + hipGetErrorString(e) +
+                "): the device cannot hold every block of the persistent barotropic loop at once -- ROMS_HIP_LOOP=0 runs the pair launches");
+      return 2;
+    }
+    return 0;
+  }
+  (void)label;
+  KPROF_WRAP(k_step2d_loop, c->stream, ROMS_LAUNCH(kern, grid, block, lds_doubles * sizeof(double), c->stream, a));
+  return 0;
+}
 #endif
+void step2d_loop_dims(const roms_hip_ctx *c, int &nbx2, int &nby2) {
+#ifdef ROMS_CPU_EMU
+  (void)c; nbx2 = nby2 = 0;
+#else
+  DGrid L;
+  loop_grid(c->G, L);
+  nbx2 = L.nbx2; nby2 = L.nby2;
+#endif
+}
 bool step2d_loop_usable(roms_hip_ctx *c) {
 #ifdef ROMS_CPU_EMU
   (void)c;
@@ -403,40 +432,6 @@ bool step2d_loop_usable(roms_hip_ctx *c) {
   return true;
 #endif
 }
-
-#ifndef ROMS_CPU_EMU
-// The launch.  Its blocks wait for each other, so all of them must be resident at once.  hipLaunchCooperativeKernel would make
-// the runtime guarantee that (or refuse the launch) -- but the runtime routes cooperative launches through a queue of their
-// own and orders it against the stream with barrier packets on both sides: measured on the MI355X (round 6,
-// tools/gpu_debug/ab_env.sh ROMS_HIP_LOOP_COOP "1 0"), a BENCHMARK1 step takes 1.53-1.58 ms with it against 0.82 ms with the
-// ordinary launch (one-step trace: 70 us of idle queue in front of the kernel, 30 us behind it, and the four streams of the
-// schedule serialised against the cooperative queue).  So the ordinary launch stays the default, guarded by the occupancy
-// query at set-up (every block resident on an otherwise idle device) and by bounded waits: a launch that meets a busy
-// device ends with exit_flag 2 and a message that names ROMS_HIP_LOOP=0 (ctx_check; the step's state is lost, as with any
-// other device error).  Ranks
-// that share a device (test set-ups) do not take the loop at all; ROMS_HIP_LOOP=0 is the switch for any other shared use.
-// ROMS_HIP_LOOP_COOP=1 selects the cooperative launch.
-template <class K>
-static int loop_launch(roms_hip_ctx *c, K kern, const char *label, const Step2dLoopArgs &a, int nthr, size_t lds_doubles) {
-  static const char *ec = getenv("ROMS_HIP_LOOP_COOP");
-  const bool coop = ec && ec[0] == '1' && !g_kp_start && !g_kprof_mode;
-  const dim3 grid((unsigned)a.G.nbx2, (unsigned)a.G.nby2, 1), block((unsigned)nthr);
-  if (coop) {
-    void *args[1] = {(void *)&a};
-    const hipError_t e = hipLaunchCooperativeKernel((const void *)kern, grid, block, args, lds_doubles * sizeof(double), c->stream);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      set_error(std::string("step2d_loop: the cooperative launch was refused (") + hipGetErrorString(e) +
-                "): the device cannot hold every block of the persistent barotropic loop at once -- ROMS_HIP_LOOP=0 runs the pair launches");
-      return 2;
-    }
-    return 0;
-  }
-  (void)label;
-  KPROF_WRAP(k_step2d_loop, c->stream, ROMS_LAUNCH(kern, grid, block, lds_doubles * sizeof(double), c->stream, a));
-  return 0;
-}
-#endif
 
 // What the first fast step of a multi-tile loop reads beyond the tile (k_step2d_loop.h, prologue), exchanged on the current
 // stream -- the schedule around the loop issues both early, off the critical path; run_step2d_loop_n does what is left:

@@ -30,6 +30,13 @@
 #define KSYNC() ((void)0)
 #define KSCHED_FENCE() ((void)0)
 typedef void *kstream_t;
+// (step-boundary events of roms_hip_step_timing: the serial emulation has no device clock)
+typedef void *ktimer_t;
+static inline bool ktimer_create(ktimer_t *e) { *e = nullptr; return false; }
+static inline void ktimer_destroy(ktimer_t) {}
+static inline void ktimer_record(ktimer_t, kstream_t) {}
+static inline bool ktimer_sync(ktimer_t) { return false; }
+static inline bool ktimer_elapsed_ms(ktimer_t, ktimer_t, double *) { return false; }
 struct kdim3 { int x, y, z; };
 
 #define COOP_KERNEL(name, ArgT) static inline void name##_body(const ArgT &a, int bx, int by, int bz, double *lds)
@@ -91,6 +98,12 @@ extern int g_emu_reverse;
 // from being hoisted above the earlier chunks (register pressure)
 #define KSCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 typedef hipStream_t kstream_t;
+typedef hipEvent_t ktimer_t;
+static inline bool ktimer_create(ktimer_t *e) { return hipEventCreate(e) == hipSuccess; }
+static inline void ktimer_destroy(ktimer_t e) { (void)hipEventDestroy(e); }
+static inline void ktimer_record(ktimer_t e, kstream_t s) { (void)hipEventRecord(e, s); }
+static inline bool ktimer_sync(ktimer_t e) { return hipEventSynchronize(e) == hipSuccess; }
+static inline bool ktimer_elapsed_ms(ktimer_t a, ktimer_t b, double *ms) { float t = 0.0f; if (hipEventElapsedTime(&t, a, b) != hipSuccess) return false; *ms = (double)t; return true; }
 
 #define COOP_KERNEL(name, ArgT) static __device__ __forceinline__ void name##_body(const ArgT &a, int bx, int by, int bz, double *lds)
 // the __global__ entry: dynamic LDS, block index -> sub-tile (with the XCD-aware remap done

@@ -458,6 +458,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   for (int e = 0; e < 12; e++) c->ev_lane[e] = nullptr;
 #ifdef ROMS_CPU_EMU
   c->stream = nullptr;
+  c->stream0 = nullptr;
   c->stream2 = nullptr;
   c->overlap = false;
 #else
@@ -683,10 +684,10 @@ extern "C" int roms_hip_destroy(roms_hip_ctx *c) {
   }
 #endif
   for (void *p : c->allocs) dfree(p);
+  for (ktimer_t e : c->step_ev) ktimer_destroy(e);
+  c->step_ev.clear();
 #ifndef ROMS_CPU_EMU
   if (c->loop_err) (void)hipHostFree(c->loop_err);
-  for (hipEvent_t e : c->step_ev) (void)hipEventDestroy(e);
-  c->step_ev.clear();
 #endif
   if (c->stage_buf) dfree(c->stage_buf);
   for (int k = 0; k < 8; k++) { if (c->comm.sbuf[k]) dfree(c->comm.sbuf[k]); if (c->comm.rbuf[k]) dfree(c->comm.rbuf[k]); }
@@ -2519,32 +2520,21 @@ extern "C" int roms_hip_get_bounds(roms_hip_ctx *c, int *out) {
 
 extern "C" int roms_hip_step_timing(roms_hip_ctx *c, int nmax) {
   if (!c || nmax < 0) return 8;
-#ifndef ROMS_CPU_EMU
-  for (hipEvent_t e : c->step_ev) (void)hipEventDestroy(e);
+  for (ktimer_t e : c->step_ev) ktimer_destroy(e);
   c->step_ev.clear();
   c->step_ev_n = 0;
   for (int k = 0; k < (nmax > 0 ? nmax + 1 : 0); k++) {
-    hipEvent_t e;
-    if (hipfail(hipEventCreate(&e), "hipEventCreate")) return 2;
+    ktimer_t e;
+    if (!ktimer_create(&e)) { set_error("roms_hip_step_timing: no event timers (hipEventCreate)"); return 2; }
     c->step_ev.push_back(e);
   }
-#endif
   return 0;
 }
 extern "C" int roms_hip_step_times(roms_hip_ctx *c, double *ms, int cap) {
-  if (!c || !ms) return 0;
+  if (!c || !ms || c->step_ev_n < 2 || !ktimer_sync(c->step_ev[c->step_ev_n - 1])) return 0;
   int n = 0;
-#ifndef ROMS_CPU_EMU
-  if (c->step_ev_n < 2) return 0;
-  if (hipEventSynchronize(c->step_ev[c->step_ev_n - 1]) != hipSuccess) return 0;
-  for (int k = 1; k < c->step_ev_n && n < cap; k++) {
-    float t = 0.0f;
-    if (hipEventElapsedTime(&t, c->step_ev[k - 1], c->step_ev[k]) != hipSuccess) break;
-    ms[n++] = (double)t;
-  }
-#else
-  (void)cap;
-#endif
+  for (int k = 1; k < c->step_ev_n && n < cap; k++)
+    if (!ktimer_elapsed_ms(c->step_ev[k - 1], c->step_ev[k], &ms[n++])) return n - 1;
   return n;
 }
 
@@ -2553,14 +2543,10 @@ extern "C" int roms_hip_main3d(roms_hip_ctx *c, int nsteps) {
   static const bool host_trace = getenv("ROMS_HIP_TRACE_HOST") != nullptr;   // measurement aid: host time to enqueue the steps
   const auto t0 = std::chrono::steady_clock::now();
   for (int n = 0; n < nsteps; n++) {
-#ifndef ROMS_CPU_EMU
-    if (!c->step_ev.empty() && c->step_ev_n == 0) { (void)hipEventRecord(c->step_ev[0], c->stream0); c->step_ev_n = 1; }
-#endif
+    if (!c->step_ev.empty() && c->step_ev_n == 0) { ktimer_record(c->step_ev[0], c->stream0); c->step_ev_n = 1; }
     int r = main3d_one(c);
     if (r) return r;
-#ifndef ROMS_CPU_EMU
-    if (c->step_ev_n > 0 && c->step_ev_n < (int)c->step_ev.size()) (void)hipEventRecord(c->step_ev[c->step_ev_n++], c->stream0);
-#endif
+    if (c->step_ev_n > 0 && c->step_ev_n < (int)c->step_ev.size()) ktimer_record(c->step_ev[c->step_ev_n++], c->stream0);
   }
   if (c->diag_join_pending) { lane_wait(c, 11); c->diag_join_pending = false; }   // (main3d_around_loop: diag's reductions on the side stream)
   c->ghost_ok = false;

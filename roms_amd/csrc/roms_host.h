@@ -98,7 +98,7 @@ struct roms_hip_ctx {
   unsigned loop_epoch;          // ... hold at most this value (the pairs of all launches so far)
   double *loop_wts;             // weights per pair (device)
   unsigned long long *loop_err; // pinned host word: a wait for a neighbouring block gave up (ctx_check reports it)
-  std::vector<kevent_t> step_ev;   // roms_hip_step_timing: events at the step boundaries (main stream)
+  std::vector<ktimer_t> step_ev;   // roms_hip_step_timing: events at the step boundaries (main stream)
   int step_ev_n = 0;
   bool ghost_ok = false;        // inside roms_hip_main3d, behind post_initial: every input of the point-wise producers carries valid ghost lines (ghost_compute)
   bool h_ghost_done = false;    // (multi-tile) the ghost lines of h have been exchanged once (run_set_depth computes the ghost columns itself)
