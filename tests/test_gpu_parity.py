@@ -1210,6 +1210,22 @@ def test_persistent_loop_across_tile_edges_matches_single_tile(env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workload,steps", [("benchmark1", 200), ("benchmark1_mask", 100)])
+def test_tiled_form_over_many_steps_matches_single_tile(workload, steps):
+    """The tiled form of BENCHMARK1 (its own W/E neighbour through the mailbox, the loop across the tile edge: 29 pairs per step,
+    two rim parities, arrival counters that count on from launch to launch) over 200 / 100 steps: every field of the
+    single-tile run bit for bit (tools/gpu_debug/selfx_long.py)."""
+    import subprocess
+    import sys
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ROMS_HIP_LOOP_TIMEOUT="0.5")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_debug", "selfx_long.py"), str(steps), workload], capture_output=True, text=True, env=e, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("SELFXLONG")]
+    assert line and "mismatching []" in line[-1], r.stdout[-1500:] + r.stderr[-3000:]
+    assert int(line[-1].split("exchanges")[1].split()[0]) <= 14 * steps + 40
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tiles,port", [((2, 1), 29761), ((1, 2), 29762), ((2, 2), 29763)])
 def test_persistent_loop_between_processes_matches_single_tile(tmp_path, tiles, port):
     """Round 6: the loop across REAL tile edges -- BENCHMARK1 512x64x30 split over 2 or 4 PROCESSES that share cuda:0, each
