@@ -534,6 +534,24 @@ def tiled_form_pass(tiling, device, steps=20, warmup=6):
         except Exception as e:       # (a reported aid, never a reason to lose the headline line)
             out["mailbox" if tr == "peer" else "rccl"] = {"error": str(e)[:200]}
     out["workload"] = "BENCHMARK1 512x64x30, one tile that is its own W/E neighbour through the halo transport (one GPU)"
+    # ... and the tile of BASELINE's 8-GPU configuration (BENCHMARK3 2048x256x30 in 2x4: 1024x64x30 per GPU): too many sub-tiles
+    # for the persistent loop, so the pair launches hand their rim across the tile edge themselves (k_step2d_pair.h)
+    try:
+        cs = params_for("benchmark1", 1024, 64, 30, ntimes=steps + warmup + 2)
+        cs["ninfo"] = 1
+        one = tiling.TiledRun(cs, device=device)
+        one.step(warmup); one.sync()
+        t0 = time.perf_counter(); one.step(steps); one.sync(); t_one = time.perf_counter() - t0
+        one.close()
+        run = tiling.TiledRun(cs, device=device, self_exchange=True, transport="peer")
+        run.step(warmup); run.sync()
+        x0 = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
+        t0 = time.perf_counter(); run.step(steps); run.sync(); dt = time.perf_counter() - t0
+        x1 = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
+        run.check(); run.close()
+        out["mailbox_1024x64x30"] = {"ms_per_step": 1e3 * dt / steps, "exchanges_per_step": (x1 - x0) / steps, "single_tile_ms_per_step": 1e3 * t_one / steps}
+    except Exception as e:
+        out["mailbox_1024x64x30"] = {"error": str(e)[:200]}
     return out
 
 

@@ -204,6 +204,61 @@ bool step2d_pair_usable(const roms_hip_ctx *c) {
   return G.bw2 <= 32 && G.bh2 <= 4;
 }
 
+#ifndef ROMS_CPU_EMU
+// my rim planes and the neighbours' as mapped here; my point (i,j) in neighbour d's planes is (i + sx, j + sy) of ITS arrays, sx / sy
+// the shift across the periodic seam where my tile lies on that domain edge (k_step2d_pair.h: S2LPeer)
+static void fill_peer(roms_hip_ctx *c, S2LPeer &P) {
+  const TileComm &m = c->comm;
+  const roms_hip_config &cf = c->cfg;
+  const DGrid &G = c->G;
+  static const int ddx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, ddy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+  memset(&P, 0, sizeof(P));
+  P.on = 1;
+  P.rim = (kword_t *)((char *)m.peer_slab + m.loop_rim_off);
+  for (int d = 0; d < 8; d++) {
+    if (m.nbr[d] < 0) continue;
+    const TileComm::PeerGeom &g = m.ngeom[d];
+    P.nbmask |= 1 << d;
+    P.nrim[d] = (kword_t *)((char *)m.peer_map[d] + g.rim_off);
+    const int sx = ddx[d] < 0 && cf.west_edge ? G.Lm : (ddx[d] > 0 && cf.east_edge ? -G.Lm : 0);
+    const int sy = ddy[d] < 0 && cf.south_edge ? G.Mm : (ddy[d] > 0 && cf.north_edge ? -G.Mm : 0);
+    P.nni[d] = g.ni; P.nnij[d] = g.ni * g.nj;
+    P.noff[d] = (sx - g.LBi) + (sy - g.LBj) * g.ni;
+  }
+}
+// Multi-tile contexts whose tiles are too large for the persistent loop (more sub-tiles than compute units: the 1024x64 tiles of
+// BASELINE's 8-GPU partition): the pair launches hand the corrector's result across the tile edges themselves -- published into
+// the neighbours' rim planes at the end of a launch, polled for at the start of the next (k_step2d_pair.h: rim_in / rim_out) --
+// instead of one exchange launch behind every pair.  A launch waits only for the neighbours' PREVIOUS launch, so nothing has to be
+// resident at the same time; ranks that share a device still keep the exchanges (a device full of waiting blocks would keep the
+// neighbour's launch from starting).  Same conditions on the partition as the loop: every rank decides alike.
+// ROMS_HIP_PAIR_RIM=0/1 forces.
+static bool pair_rim_usable(roms_hip_ctx *c) {
+  if (c->pair_rim_state) return c->pair_rim_state > 0;
+  c->pair_rim_state = -1;
+  const TileComm &m = c->comm;
+  const roms_hip_config &cf = c->cfg;
+  const char *e = getenv("ROMS_HIP_PAIR_RIM");        // (decided once per context)
+  if (e && e[0] == '0') return false;
+  if (!c->has_exchange || !c->pair_mt || !c->pair_on || !m.peer_on || !m.loop_rim_off || c->G.obc) return false;
+  if (m.peer_shared && !(e && e[0] == '1')) return false;
+  if (cf.Lm % cf.NtileI || cf.Mm % cf.NtileJ) return false;
+  for (int d = 0; d < 8; d++)
+    if (m.nbr[d] >= 0 && !m.ngeom[d].rim_off) return false;
+  if (step2d_loop_usable(c)) return false;
+  hipDeviceProp_t prop;
+  int d0 = 0;
+  if (hipGetDevice(&d0) != hipSuccess || hipGetDeviceProperties(&prop, d0) != hipSuccess) return false;
+  if (strncmp(prop.gcnArchName, "gfx942", 6) && strncmp(prop.gcnArchName, "gfx950", 6)) return false;
+  if (!c->loop_err) {
+    if (hipHostMalloc((void **)&c->loop_err, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { c->loop_err = nullptr; return false; }
+    *c->loop_err = 0;
+  }
+  c->pair_rim_state = 1;
+  return true;
+}
+#endif
+
 int run_step2d_pair(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const roms_hip_config &cf = c->cfg;
@@ -222,6 +277,19 @@ int run_step2d_pair(roms_hip_ctx *c) {
   a.wrapx = G.ewp && G.xloc;
   a.wrapy = G.nsp && G.yloc;
   a.tail = G.nfast - iif;
+  a.rim_in = a.rim_out = 0; a.tag_in = a.tag_out = 0; a.err = nullptr; a.timeout = 0;
+  memset(&a.P, 0, sizeof(a.P));
+#ifndef ROMS_CPU_EMU
+  if (pair_rim_usable(c)) {
+    // (the last two pairs keep their exchanges: they carry what the loop leaves behind -- level 3, rzeta of both levels)
+    static const double tmo = getenv("ROMS_HIP_LOOP_TIMEOUT") ? atof(getenv("ROMS_HIP_LOOP_TIMEOUT")) : 2.0;
+    fill_peer(c, a.P);
+    a.err = c->loop_err; a.timeout = (long long)(tmo * 1e8);
+    a.rim_in = (a.commit && c->b2_rim) ? 1 : 0; a.tag_in = c->pair_epoch;
+    a.rim_out = a.tail > 1 ? 1 : 0;
+    if (a.rim_out) a.tag_out = ++c->pair_epoch;
+  }
+#endif
   if (c->m2d_dirty) pack_metrics(c);
   const bool fixed = G.bw2 <= 32 && G.bh2 <= 4 && !G.masking && !getenv("ROMS_HIP_S2D_GENERIC");
 #ifdef ROMS_CPU_EMU
@@ -252,7 +320,9 @@ int run_step2d_pair(roms_hip_ctx *c) {
   }
 #endif
   c->b2_stage = a.lev_out;
+  c->b2_rim = a.rim_out != 0;
   if (G.fuse_halo) return 0;        // the kernel stored the boundary values and periodic images itself
+  if (a.rim_out) return 0;          // ... or handed its rim to the neighbouring ranks itself (pair_rim_usable)
   // closed basin: zetabc / u2dbc / v2dbc of the corrector's result (staged); the predictor's level 3 and rzeta(krhs) as
   // the per-call sequence leaves them
   const size_t nij = (size_t)G.nij;
@@ -495,24 +565,8 @@ int run_step2d_loop_n(roms_hip_ctx *c, int whole) {
   a.prio = prio;
   memset(&a.P, 0, sizeof(a.P));
   if (mt) {
-    // the neighbours' rim planes; my point (i,j) in neighbour d's planes is (i + sx, j + sy) of ITS arrays, sx / sy
-    // the shift across the periodic seam where my tile lies on that domain edge
-    const TileComm &m = c->comm;
-    const roms_hip_config &cf = c->cfg;
-    static const int ddx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, ddy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
-    a.P.on = 1;
+    fill_peer(c, a.P);
     { static const char *ee = getenv("ROMS_HIP_LOOP_EARLY"); a.P.early = ee && ee[0] == '1' ? 1 : 0; }
-    a.P.rim = (unsigned long long *)((char *)m.peer_slab + m.loop_rim_off);
-    for (int d = 0; d < 8; d++) {
-      if (m.nbr[d] < 0) continue;
-      const TileComm::PeerGeom &g = m.ngeom[d];
-      a.P.nbmask |= 1 << d;
-      a.P.nrim[d] = (unsigned long long *)((char *)m.peer_map[d] + g.rim_off);
-      const int sx = ddx[d] < 0 && cf.west_edge ? G.Lm : (ddx[d] > 0 && cf.east_edge ? -G.Lm : 0);
-      const int sy = ddy[d] < 0 && cf.south_edge ? G.Mm : (ddy[d] > 0 && cf.north_edge ? -G.Mm : 0);
-      a.P.nni[d] = g.ni; a.P.nnij[d] = g.ni * g.nj;
-      a.P.noff[d] = (sx - g.LBi) + (sy - g.LBj) * g.ni;
-    }
     if (!c->loop_pre_frc && step2d_loop_pre(c, 1)) return 2;
     if (!c->loop_pre_state && step2d_loop_pre(c, 2)) return 2;
     c->loop_pre_frc = c->loop_pre_state = false;

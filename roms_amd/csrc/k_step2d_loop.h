@@ -64,15 +64,6 @@
 #define S2L_NLDS_MK 35           // + rmask, umask, vmask on the rectangle (MASKING)
 #define INR(i, j, i0, i1, j0, j1) ((i) >= (i0) && (i) <= (i1) && (j) >= (j0) && (j) <= (j1))
 #define S2L_FSTRIDE 16          // arrival words are 64 bytes apart
-// multi-tile contexts: my rim planes and the neighbours' as mapped here
-struct S2LPeer {
-  int on;                       // 0: single tile (the kernels without MT never read this struct)
-  int early;                    // 1: a value goes to the neighbours where it is computed, in front of the local drain (ROMS_HIP_LOOP_EARLY)
-  int nbmask;                   // bit d: neighbour d (W, E, S, N, SW, SE, NW, NE) exists
-  unsigned long long *rim;      // my rim planes [parity][zeta | ubar | vbar][nij][2 words]: the neighbours' edge blocks write my ghost points
-  unsigned long long *nrim[8];  // neighbour d's rim planes, as mapped in this process
-  int noff[8], nni[8], nnij[8]; // my point (i,j) in neighbour d's planes: i + j * nni + noff (array origin + the shift across a periodic seam)
-};
 struct Step2dLoopArgs {
   S2Fields F;                   // (first: DESIGN.md 6)
   DGrid G;                      // stepping of the FIRST pair's predictor call: iif = 2, kstp = 3 - indx1, krhs = indx1, knew = 3
@@ -109,54 +100,6 @@ KDEV void s2l_range(const DGrid &G, int bx, int by, int &i0, int &i1, int &j0, i
   j0 = 1 + by * cJ - mJ; j1 = j0 + cJ - 1;
   i0 = KMAX(i0, 1) + G.T.Istr - 1; i1 = KMIN(i1, LmT) + G.T.Istr - 1;
   j0 = KMAX(j0, 1) + G.T.Jstr - 1; j1 = KMIN(j1, MmT) + G.T.Jstr - 1;
-}
-
-// ---- multi-tile: the value of field pf % 3 (0 zeta, 1 ubar, 2 vbar; pf = 3 * parity + field) at (i,j) -- an own point or a
-// boundary point derived from one -- goes into the rim planes of every neighbour in whose ghost zone (i,j) lies, tagged
-KDEV void s2l_ll_st(unsigned long long *q, double v, unsigned tag) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v), tg = (unsigned long long)tag << 32;
-  __hip_atomic_store(q, (b & 0xffffffffull) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(q + 1, (b >> 32) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-KDEV void s2l_rput(const Step2dLoopArgs &a, int pf, int i, int j, double v, unsigned tag) {
-  const TB &T = a.G.T;
-  const bool w = i < T.Istr + B2D_GH, e = i > T.Iend - B2D_GL, s = j < T.Jstr + B2D_GH, n = j > T.Jend - B2D_GL;
-  if (!(w || e || s || n)) return;
-#pragma unroll
-  for (int d = 0; d < 8; d++) {       // (static indices into the argument block)
-    const bool hit = d == 0 ? w : d == 1 ? e : d == 2 ? s : d == 3 ? n : d == 4 ? (w && s) : d == 5 ? (e && s) : d == 6 ? (w && n) : (e && n);
-    if (hit && a.P.nrim[d]) s2l_ll_st(a.P.nrim[d] + 2 * ((size_t)pf * (size_t)a.P.nnij[d] + (size_t)(i + j * a.P.nni[d] + a.P.noff[d])), v, tag);
-  }
-}
-// the point and the boundary values a closed DOMAIN edge derives from it: the rules of hb_emit2 (k_haloblock.h)
-KDEV void s2l_remit(const Step2dLoopArgs &a, const TB &B, int pf, int bc, int i, int j, double v, unsigned tag, const double *M = nullptr) {
-  const DGrid &G = a.G;
-  s2l_rput(a, pf, i, j, v, tag);
-  if (i > 2 && i < G.Lm && j > 2 && j < G.Mm) return;
-  if (!G.nsp) {
-    if (bc == BC_R) {
-      if (B.south && j == B.Jstr) s2l_rput(a, pf, i, j - 1, M ? v * M[X2(i, j - 1)] : v, tag);
-      if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, M ? v * M[X2(i, j + 1)] : v, tag);
-    } else if (bc == BC_U) {
-      if (B.south && j == B.Jstr) s2l_rput(a, pf, i, j - 1, M ? G.gamma2 * v * M[X2(i, j - 1)] : G.gamma2 * v, tag);
-      if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, M ? G.gamma2 * v * M[X2(i, j + 1)] : G.gamma2 * v, tag);
-    } else if (bc == BC_V) {
-      if (B.south && j == B.JstrV) s2l_rput(a, pf, i, B.Jstr, 0.0, tag);
-      if (B.north && j == B.Jend) s2l_rput(a, pf, i, j + 1, 0.0, tag);
-    }
-  }
-  if (!G.ewp) {
-    if (bc == BC_R) {
-      if (B.west && i == B.Istr) s2l_rput(a, pf, i - 1, j, M ? v * M[X2(i - 1, j)] : v, tag);
-      if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, M ? v * M[X2(i + 1, j)] : v, tag);
-    } else if (bc == BC_U) {
-      if (B.west && i == B.IstrU) s2l_rput(a, pf, B.Istr, j, 0.0, tag);
-      if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, 0.0, tag);
-    } else if (bc == BC_V) {
-      if (B.west && i == B.Istr) s2l_rput(a, pf, i - 1, j, M ? G.gamma2 * v * M[X2(i - 1, j)] : G.gamma2 * v, tag);
-      if (B.east && i == B.Iend) s2l_rput(a, pf, i + 1, j, M ? G.gamma2 * v * M[X2(i + 1, j)] : G.gamma2 * v, tag);
-    }
-  }
 }
 
 // an SGPR zero the compiler cannot see through: indices derived from it are not hoisted out of the stage / the pair loop
@@ -558,7 +501,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (own) {
           hb_emit2<true>(G, B, zout, BC_R, i, j, zeta_new, Mr, img0);
-          if (MT && edgeblk && a.P.early) s2l_remit(a, B, 3 * (p & 1), BC_R, i, j, zeta_new, a.epoch + (unsigned)(p + 1), Mr);
+          if (MT && edgeblk && a.P.early) s2l_remit(G, a.P, B, 3 * (p & 1), BC_R, i, j, zeta_new, a.epoch + (unsigned)(p + 1), Mr);
           ZQ[s0] = zeta_new;
         }
       }
@@ -590,7 +533,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           if (MK) b = b * (isv ? sVm : sUm)[s];
           if (!isv) { hb_emit2<true>(G, B, uout, BC_U, mi, mj, b, Mu, img0); UQ[s] = b; }
           else { hb_emit2<true>(G, B, vout, BC_V, mi, mj, b, Mv, img0); VQ[s] = b; }
-          if (MT && edgeblk && a.P.early) s2l_remit(a, B, 3 * (p & 1) + 1 + isv, isv ? BC_V : BC_U, mi, mj, b, a.epoch + (unsigned)(p + 1), isv ? Mv : Mu);
+          if (MT && edgeblk && a.P.early) s2l_remit(G, a.P, B, 3 * (p & 1) + 1 + isv, isv ? BC_V : BC_U, mi, mj, b, a.epoch + (unsigned)(p + 1), isv ? Mv : Mu);
         }
       }
     }
@@ -603,8 +546,8 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
     if (MT && edgeblk && !a.P.early) {
       // the neighbouring ranks' ghost points, tagged with the pair (the values are in the Q tiles: the own points' threads stored them)
       const unsigned tag = a.epoch + (unsigned)(p + 1);
-      if (own) s2l_remit(a, B, 3 * (p & 1), BC_R, i, j, ZQ[s0_], tag, Mr);
-      if (mO) s2l_remit(a, B, 3 * (p & 1) + 1 + isvt, isvt ? BC_V : BC_U, mi, mj, (isvt ? VQ : UQ)[ms_], tag, isvt ? Mv : Mu);
+      if (own) s2l_remit(G, a.P, B, 3 * (p & 1), BC_R, i, j, ZQ[s0_], tag, Mr);
+      if (mO) s2l_remit(G, a.P, B, 3 * (p & 1) + 1 + isvt, isvt ? BC_V : BC_U, mi, mj, (isvt ? VQ : UQ)[ms_], tag, isvt ? Mv : Mu);
     }
     if (t < 64) {
       if (nbf >= 0 && !dead) {

@@ -27,6 +27,77 @@
 #pragma once
 #include "k_step2d.h"
 
+// ---- the rim across TILE edges inside a launch (round 6): k_step2d_loop.h (the persistent loop) and, for tiles the loop does not
+// fit, the pair kernel below.  A rank's rim planes live in its mailbox slab (uncached memory the neighbours map over hipIpc /
+// xGMI): two parities x {zeta, ubar, vbar}, indexed like its arrays, 16 bytes per point -- {low half of the value | number of
+// the pair}, {high half | number} -- an 8-byte store is atomic on every path, so a point is polled for directly.
+// multi-tile contexts: my rim planes and the neighbours' as mapped here
+struct S2LPeer {
+  int on;                       // 0: single tile (the kernels without MT never read this struct)
+  int early;                    // 1: a value goes to the neighbours where it is computed, in front of the local drain (ROMS_HIP_LOOP_EARLY)
+  int nbmask;                   // bit d: neighbour d (W, E, S, N, SW, SE, NW, NE) exists
+  kword_t *rim;      // my rim planes [parity][zeta | ubar | vbar][nij][2 words]: the neighbours' edge blocks write my ghost points
+  kword_t *nrim[8];  // neighbour d's rim planes, as mapped in this process
+  int noff[8], nni[8], nnij[8]; // my point (i,j) in neighbour d's planes: i + j * nni + noff (array origin + the shift across a periodic seam)
+};
+
+// ---- multi-tile: the value of field pf % 3 (0 zeta, 1 ubar, 2 vbar; pf = 3 * parity + field) at (i,j) -- an own point or a
+// boundary point derived from one -- goes into the rim planes of every neighbour in whose ghost zone (i,j) lies, tagged
+KDEV void s2l_ll_st(kword_t *q, double v, unsigned tag) {
+  kword_t b;
+  __builtin_memcpy(&b, &v, sizeof(b));
+  const kword_t tg = (kword_t)tag << 32;
+  ksys_st(q, (b & 0xffffffffull) | tg);
+  ksys_st(q + 1, (b >> 32) | tg);
+}
+KDEV double s2l_ll_val(kword_t w0, kword_t w1) {
+  const kword_t b = (w0 & 0xffffffffull) | (w1 << 32);
+  double v;
+  __builtin_memcpy(&v, &b, sizeof(v));
+  return v;
+}
+KDEV void s2l_rput(const DGrid &G, const S2LPeer &P, int pf, int i, int j, double v, unsigned tag) {
+  const TB &T = G.T;
+  const bool w = i < T.Istr + B2D_GH, e = i > T.Iend - B2D_GL, s = j < T.Jstr + B2D_GH, n = j > T.Jend - B2D_GL;
+  if (!(w || e || s || n)) return;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {       // (static indices into the argument block)
+    const bool hit = d == 0 ? w : d == 1 ? e : d == 2 ? s : d == 3 ? n : d == 4 ? (w && s) : d == 5 ? (e && s) : d == 6 ? (w && n) : (e && n);
+    if (hit && P.nrim[d]) s2l_ll_st(P.nrim[d] + 2 * ((size_t)pf * (size_t)P.nnij[d] + (size_t)(i + j * P.nni[d] + P.noff[d])), v, tag);
+  }
+}
+// the point and the boundary values a closed DOMAIN edge derives from it: the rules of hb_emit2 (k_haloblock.h)
+KDEV void s2l_remit(const DGrid &G, const S2LPeer &P, const TB &B, int pf, int bc, int i, int j, double v, unsigned tag, const double *M = nullptr) {
+  s2l_rput(G, P, pf, i, j, v, tag);
+  if (i > 2 && i < G.Lm && j > 2 && j < G.Mm) return;
+  if (!G.nsp) {
+    if (bc == BC_R) {
+      if (B.south && j == B.Jstr) s2l_rput(G, P, pf, i, j - 1, M ? v * M[X2(i, j - 1)] : v, tag);
+      if (B.north && j == B.Jend) s2l_rput(G, P, pf, i, j + 1, M ? v * M[X2(i, j + 1)] : v, tag);
+    } else if (bc == BC_U) {
+      if (B.south && j == B.Jstr) s2l_rput(G, P, pf, i, j - 1, M ? G.gamma2 * v * M[X2(i, j - 1)] : G.gamma2 * v, tag);
+      if (B.north && j == B.Jend) s2l_rput(G, P, pf, i, j + 1, M ? G.gamma2 * v * M[X2(i, j + 1)] : G.gamma2 * v, tag);
+    } else if (bc == BC_V) {
+      if (B.south && j == B.JstrV) s2l_rput(G, P, pf, i, B.Jstr, 0.0, tag);
+      if (B.north && j == B.Jend) s2l_rput(G, P, pf, i, j + 1, 0.0, tag);
+    }
+  }
+  if (!G.ewp) {
+    if (bc == BC_R) {
+      if (B.west && i == B.Istr) s2l_rput(G, P, pf, i - 1, j, M ? v * M[X2(i - 1, j)] : v, tag);
+      if (B.east && i == B.Iend) s2l_rput(G, P, pf, i + 1, j, M ? v * M[X2(i + 1, j)] : v, tag);
+    } else if (bc == BC_U) {
+      if (B.west && i == B.IstrU) s2l_rput(G, P, pf, B.Istr, j, 0.0, tag);
+      if (B.east && i == B.Iend) s2l_rput(G, P, pf, i + 1, j, 0.0, tag);
+    } else if (bc == BC_V) {
+      if (B.west && i == B.Istr) s2l_rput(G, P, pf, i - 1, j, M ? G.gamma2 * v * M[X2(i - 1, j)] : G.gamma2 * v, tag);
+      if (B.east && i == B.Iend) s2l_rput(G, P, pf, i + 1, j, M ? G.gamma2 * v * M[X2(i + 1, j)] : G.gamma2 * v, tag);
+    }
+  }
+}
+
+
+
 struct Step2dPairArgs {
   S2Fields F;          // (first: DESIGN.md 6)
   DGrid G;             // stepping of the PREDICTOR call: iif >= 2, kstp = 3 - indx1, krhs = indx1, knew = 3
@@ -39,6 +110,17 @@ struct Step2dPairArgs {
   int tail;            // pairs still to follow this one: 0 = the last (iif = nfast).  What nobody reads before the loop ends is
                        // stored by the last launches only: level 3 (the predictor's result) by the last one; periodic images of
                        // the committed level and of the staged result by the last one, of rzeta(krhs) by the last two
+  // ---- multi-tile contexts whose tiles are too large for the persistent loop (round 6, g_step2d.cpp:pair_rim_usable): the
+  // corrector's result crosses the tile edges INSIDE the launches instead of through an exchange behind every pair
+  int rim_in;          // the krhs level on the ghost points of the tile: from my rim planes (parity lev_in - 4), polled until the
+                       // points carry tag_in -- the neighbours' previous pair launch published them
+  int rim_out;         // publish the corrector's result -- the own points in the neighbours' ghost zones and the boundary values a
+                       // closed domain edge derives from them -- into their rim planes (parity lev_out - 4), tagged tag_out; the
+                       // boundary values go to the staging level as well (no fill launch follows)
+  unsigned tag_in, tag_out;
+  unsigned long long *err;      // pinned host word: a wait that gave up (bounded like every wait of the library)
+  long long timeout;
+  S2LPeer P;
 };
 
 #define S2P_NLDS 19
@@ -324,8 +406,30 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
   // ---- stage 1: every global read of the kernel ------------------------------------------------
   RLOOP(i, j) {
     if (ina) {
-      const double zkv = F.zeta[x0 + o_in], hv = F.h[x0];
-      const double ukv = F.ubar[x0 + o_in], vkv = F.vbar[x0 + o_in];
+      double zkv, ukv, vkv;
+      const double hv = F.h[x0];
+      // (multi-tile, rim_in) a ghost point of the tile the neighbours publish: 5 lines on my low side, 4 on my high side
+      const bool remv = a.rim_in && !INR(iw_, jw_, T.IstrR, T.IendR, T.JstrR, T.JendR) &&
+                        INR(iw_, jw_, (a.P.nbmask & 1) ? T.Istr - B2D_GL : T.IstrR, (a.P.nbmask & 2) ? T.Iend + B2D_GH : T.IendR,
+                                      (a.P.nbmask & 4) ? T.Jstr - B2D_GL : T.JstrR, (a.P.nbmask & 8) ? T.Jend + B2D_GH : T.JendR);
+      if (remv) {
+        const kword_t *rq = a.P.rim + 2 * ((size_t)(3 * (a.lev_in - 4)) * (size_t)G.nij + (size_t)x0);
+        const bool nu = G.ewp || iw_ >= 1, nv = G.nsp || jw_ >= 1;     // (no u-points west of a western wall, no v-points south of a southern one)
+        const long long t0 = kclock();
+        zkv = 0.0; ukv = 0.0; vkv = 0.0;
+        for (;;) {
+          kword_t w[6];
+          for (int f = 0; f < 3; f++) { w[2 * f] = ksys_ld(rq + 2 * (size_t)f * (size_t)G.nij); w[2 * f + 1] = ksys_ld(rq + 2 * (size_t)f * (size_t)G.nij + 1); }
+          const bool all = (unsigned)(w[0] >> 32) == a.tag_in && (unsigned)(w[1] >> 32) == a.tag_in &&
+                           (!nu || ((unsigned)(w[2] >> 32) == a.tag_in && (unsigned)(w[3] >> 32) == a.tag_in)) &&
+                           (!nv || ((unsigned)(w[4] >> 32) == a.tag_in && (unsigned)(w[5] >> 32) == a.tag_in));
+          if (all) { zkv = s2l_ll_val(w[0], w[1]); if (nu) ukv = s2l_ll_val(w[2], w[3]); if (nv) vkv = s2l_ll_val(w[4], w[5]); break; }
+          knap();
+          if (kclock() - t0 > a.timeout) { *(volatile unsigned long long *)a.err = ((unsigned long long)a.tag_in << 32) | (unsigned long long)(bx + G.nbx2 * by + 1); break; }
+        }
+      } else {
+        zkv = F.zeta[x0 + o_in]; ukv = F.ubar[x0 + o_in]; vkv = F.vbar[x0 + o_in];
+      }
       D0[s0] = zkv + hv;
       U0[s0] = ukv; V0[s0] = vkv; sH[s0] = hv;
       sPm[s0] = F.pm[x0]; sPn[s0] = F.pn[x0];
@@ -638,7 +742,10 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (i >= B.Istr && j >= B.Jstr) {
           if (fuse) hb_emit2(G, B, zout, BC_R, i, j, zeta_new, MSK ? G.rmask : nullptr, img0);
-          else zout[x0] = zeta_new;
+          else if (a.rim_out) {
+            hb_emit2(G, B, zout, BC_R, i, j, zeta_new, MSK ? G.rmask : nullptr, false);
+            s2l_remit(G, a.P, B, 3 * (a.lev_out - 4), BC_R, i, j, zeta_new, a.tag_out, MSK ? G.rmask : nullptr);
+          } else zout[x0] = zeta_new;
         }
       }
     }
@@ -685,10 +792,16 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
         if (MSK) b = b * (isv ? G.vmask : G.umask)[x];
         if (!isv) {
           if (fuse) hb_emit2(G, B, uout, BC_U, i, j, b, MSK ? G.umask : nullptr, img0);
-          else uout[x] = b;
+          else if (a.rim_out) {
+            hb_emit2(G, B, uout, BC_U, i, j, b, MSK ? G.umask : nullptr, false);
+            s2l_remit(G, a.P, B, 3 * (a.lev_out - 4) + 1, BC_U, i, j, b, a.tag_out, MSK ? G.umask : nullptr);
+          } else uout[x] = b;
         } else {
           if (fuse) hb_emit2(G, B, vout, BC_V, i, j, b, MSK ? G.vmask : nullptr, img0);
-          else vout[x] = b;
+          else if (a.rim_out) {
+            hb_emit2(G, B, vout, BC_V, i, j, b, MSK ? G.vmask : nullptr, false);
+            s2l_remit(G, a.P, B, 3 * (a.lev_out - 4) + 2, BC_V, i, j, b, a.tag_out, MSK ? G.vmask : nullptr);
+          } else vout[x] = b;
         }
       }
     }

@@ -30,6 +30,12 @@
 #define KSYNC() ((void)0)
 #define KSCHED_FENCE() ((void)0)
 typedef void *kstream_t;
+// (tagged 8-byte words another rank's kernel polls: the serial emulation has one rank per call, plain accesses)
+typedef unsigned long long kword_t;
+static inline void ksys_st(kword_t *p, kword_t v) { *p = v; }
+static inline kword_t ksys_ld(const kword_t *p) { return *p; }
+static inline long long kclock() { return 0; }
+static inline void knap() {}
 // (step-boundary events of roms_hip_step_timing: the serial emulation has no device clock)
 typedef void *ktimer_t;
 static inline bool ktimer_create(ktimer_t *e) { *e = nullptr; return false; }
@@ -98,6 +104,12 @@ extern int g_emu_reverse;
 // from being hoisted above the earlier chunks (register pressure)
 #define KSCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 typedef hipStream_t kstream_t;
+// tagged 8-byte words another rank's kernel polls: system-scope relaxed accesses (write-through stores, loads past the caches)
+typedef unsigned long long kword_t;
+static __device__ __forceinline__ void ksys_st(kword_t *p, kword_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+static __device__ __forceinline__ kword_t ksys_ld(const kword_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+static __device__ __forceinline__ long long kclock() { return (long long)wall_clock64(); }
+static __device__ __forceinline__ void knap() { __builtin_amdgcn_s_sleep(1); }
 typedef hipEvent_t ktimer_t;
 static inline bool ktimer_create(ktimer_t *e) { return hipEventCreate(e) == hipSuccess; }
 static inline void ktimer_destroy(ktimer_t e) { (void)hipEventDestroy(e); }

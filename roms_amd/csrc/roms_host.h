@@ -102,6 +102,10 @@ struct roms_hip_ctx {
   int step_ev_n = 0;
   bool ghost_ok = false;        // inside roms_hip_main3d, behind post_initial: every input of the point-wise producers carries valid ghost lines (ghost_compute)
   bool h_ghost_done = false;    // (multi-tile) the ghost lines of h have been exchanged once (run_set_depth computes the ghost columns itself)
+  // the pair launches handing their rim across tile edges themselves (tiles too large for the loop; g_step2d.cpp:pair_rim_usable)
+  int pair_rim_state = 0;       // 0: not decided, 1: on, -1: off
+  bool b2_rim = false;          // the staged result of the last pair launch was published into the neighbours' rim planes (not exchanged)
+  unsigned pair_epoch = 0;      // number of the last published pair (the tag its points carry)
   bool loop_pre_frc = false;    // (multi-tile) this step's schedule has already exchanged what the loop's first fast step reads beyond the tile:
   bool loop_pre_state = false;  // the 3-D forcing and its history | the kstp level of zeta, ubar, vbar (step2d_loop_pre)
   bool diag_ran;                // a diag report was enqueued since the last blow-up test (roms_hip_main3d)

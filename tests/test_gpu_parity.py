@@ -1210,6 +1210,51 @@ def test_persistent_loop_across_tile_edges_matches_single_tile(env):
 
 
 @pytest.mark.gpu
+def test_pair_launches_hand_their_rim_across_tile_edges(tmp_path):
+    """Round 6, tiles too large for the persistent loop (more sub-tiles than compute units: the 1024x64 tiles of BASELINE's 8-GPU
+    partition): the predictor+corrector pair launches publish the corrector's result into the neighbours' rim planes at the
+    end of a launch and poll their own ghost points there at the start of the next (k_step2d_pair.h: rim_out / rim_in),
+    instead of one exchange launch behind every pair.  (i) a 1024x64x30 tile as its own W/E neighbour: fields equal the
+    single-tile run bit for bit with and without, 14 against 40 exchange points per step; (ii) all eight neighbours
+    (doubly periodic, the loop switched off); (iii) 2x2 PROCESSES sharing the GPU, each the other's neighbour (a launch
+    waits only for the neighbours' previous launch: nothing has to be resident at the same time)."""
+    import json
+    import subprocess
+    import sys
+    import bench
+    from roms_amd import tiling
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ROMS_HIP_LOOP_TIMEOUT="1.0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_debug", "selfx_pair_rim.py"), "1024", "64", "30", "8"], capture_output=True, text=True, env=e, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("PAIRRIM")]
+    assert len(lines) == 2 and all("mismatching []" in l for l in lines), r.stdout[-1500:] + r.stderr[-3000:]
+    per = [int(l.split("ms/step,")[1].split()[0]) for l in lines]
+    assert per[0] <= 16 and per[1] >= 30, per
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mp", "selfx8.py"), "peer"], capture_output=True, text=True, env=dict(e, ROMS_HIP_LOOP="0"), timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("SELFX8")]
+    assert line and "finite True mismatching []" in line[-1], r.stdout[-1500:] + r.stderr[-3000:]
+    fields = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "Huon", "rho", "Akv", "DU_avg1", "Zt_avg1", "rubar"]
+    steps = 4
+    cs = bench.params_for("benchmark1", ntimes=steps)
+    cs["ninfo"] = 0
+    run = tiling.TiledRun(cs, weak=False)
+    run.step(steps)
+    ref = {n: run.gather(n) for n in fields}
+    run.close()
+    out = str(tmp_path / "tiles_rim.npz")
+    spec = dict(workload="benchmark1", steps=steps, tiles=[2, 2], fields=fields, gpu=True, probe=True, transport="peer")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "29771",
+           os.path.join(ROOT, "tests", "mp", "run_tiles.py"), out, json.dumps(spec)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env=dict(e, OMP_NUM_THREADS="1", ROMS_HIP_PEER_TIMEOUT="10", ROMS_HIP_LOOP="0", ROMS_HIP_PAIR_RIM="1"))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    got = dict(np.load(out))
+    assert int(got["nexchanges_steps"]) <= 20 * steps, int(got["nexchanges_steps"])
+    for n in fields:
+        assert np.array_equal(got[n], ref[n]), n
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("workload,steps", [("benchmark1", 200), ("benchmark1_mask", 100)])
 def test_tiled_form_over_many_steps_matches_single_tile(workload, steps):
     """The tiled form of BENCHMARK1 (its own W/E neighbour through the mailbox, the loop across the tile edge: 29 pairs per step,
