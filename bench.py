@@ -699,7 +699,7 @@ def main():
             raise SystemExit(3)
     run = make_run()
     loop_fallback = None
-    if world > 1 and os.environ.get("ROMS_HIP_LOOP") is None:
+    if world > 1 and os.environ.get("ROMS_HIP_LOOP") is None and os.environ.get("ROMS_HIP_PAIR_RIM") is None:
         # The persistent barotropic loop crosses the tile edges inside one launch (round 6): its blocks wait -- bounded -- for
         # the neighbouring GPUs' blocks.  No multi-GPU node was available to develop it on, so the first steps are a trial:
         # if any rank reports a wait that gave up (exit_flag 2), EVERY rank goes back to the pair launches (ROMS_HIP_LOOP=0:
@@ -714,12 +714,13 @@ def main():
         tok = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tok, op=dist.ReduceOp.MIN)
         if int(tok.item()) == 0:
-            loop_fallback = "the trial steps with the persistent barotropic loop across tiles failed on some rank: pair launches (ROMS_HIP_LOOP=0)"
+            loop_fallback = "the trial steps with the rim handed across tiles inside the barotropic launches failed on some rank: pair launches with an exchange behind each (ROMS_HIP_LOOP=0 ROMS_HIP_PAIR_RIM=0)"
             try:
                 run.close()
             except Exception:
                 pass
             os.environ["ROMS_HIP_LOOP"] = "0"
+            os.environ["ROMS_HIP_PAIR_RIM"] = "0"       # (the rim hand-off of the pair launches waits for the neighbours too)
             cs = params_for(wl, args.Lm, args.Mm, args.N, ntimes=args.steps + args.warmup)
             cs["ninfo"] = 1
             run = make_run()
