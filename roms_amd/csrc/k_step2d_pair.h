@@ -427,6 +427,9 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
           knap();
           if (kclock() - t0 > a.timeout) { *(volatile unsigned long long *)a.err = ((unsigned long long)a.tag_in << 32) | (unsigned long long)(bx + G.nbx2 * by + 1); break; }
         }
+        // (the run-time form keeps no point in registers: its later stages read the level again -- from the staging level, where
+        // this thread now leaves what arrived; every block whose rectangle holds the point stores the same bits)
+        if (!FIXED) { F.zeta[x0 + o_in] = zkv; if (nu) F.ubar[x0 + o_in] = ukv; if (nv) F.vbar[x0 + o_in] = vkv; }
       } else {
         zkv = F.zeta[x0 + o_in]; ukv = F.ubar[x0 + o_in]; vkv = F.vbar[x0 + o_in];
       }

@@ -1179,8 +1179,9 @@ def test_persistent_loop_across_tile_edges_matches_single_tile(env):
         ref.step(6); ref.sync()
         want = {n: ref.gather(n).copy() for n in names}
         ref.close()
-        for loop in ("1", "0"):
+        for loop, rim in (("1", "1"), ("0", "0"), ("0", "1")):      # the loop | the pair launches with an exchange each | with their own rim hand-off
             os.environ["ROMS_HIP_LOOP"] = loop
+            os.environ["ROMS_HIP_PAIR_RIM"] = rim
             run = tiling.TiledRun(cs, self_exchange=True, transport="peer")
             run.step(2); run.sync()
             x0 = run.ctx.L.roms_hip_exchange_count(run.ctx.h)
@@ -1188,9 +1189,9 @@ def test_persistent_loop_across_tile_edges_matches_single_tile(env):
             per = (run.ctx.L.roms_hip_exchange_count(run.ctx.h) - x0) / 4
             bad = [n for n in names if not np.array_equal(run.gather(n), want[n])]
             run.close()
-            assert not bad, (loop, bad)
-            assert (per <= 20) if loop == "1" else (per >= 30), (loop, per)
-            print("LOOP-MT", loop, per)
+            assert not bad, (loop, rim, bad)
+            assert (per <= 22) if (loop == "1" or rim == "1") else (per >= 30), (loop, rim, per)
+            print("LOOP-MT", loop, rim, per)
         print("LOOP-MT-OK")
     """) % (ROOT, ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "z_r", "rho", "Akv", "Akt", "Huon", "Hvom", "DU_avg1", "DU_avg2", "DV_avg1", "Zt_avg1",
                    "rzeta", "rubar", "rvbar", "wvel", "hsbl"])
@@ -1200,7 +1201,7 @@ def test_persistent_loop_across_tile_edges_matches_single_tile(env):
     if env:
         return
     # ... with land (k_step2d_loop_bmk: the masked boundary values travel through the rim planes too)
-    code_m = code.replace('bench.params_for("benchmark1", ntimes=30)', 'bench.params_for("benchmark1_mask", ntimes=30)').replace("(per <= 20)", "(per <= 48)")
+    code_m = code.replace('bench.params_for("benchmark1", ntimes=30)', 'bench.params_for("benchmark1_mask", ntimes=30)').replace("(per <= 22)", "(per <= 48)")
     r = subprocess.run([sys.executable, "-c", code_m], capture_output=True, text=True, env=e, timeout=600)
     assert "LOOP-MT-OK" in r.stdout, ("mask", r.stdout[-1500:] + r.stderr[-3000:])
     # all eight neighbours (doubly periodic): corner points through the rim planes
