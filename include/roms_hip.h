@@ -82,6 +82,8 @@ enum {
                                              forcing: upload them before roms_hip_start and whenever set_data.F would refresh them.
                                              Refused (exit_flag 5) with open boundaries and DIAGNOSTICS_UV */
 #define ROMS_NUDGE_TCLM_ALL (15ull << 38)
+#define ROMS_NUDGE_M2CLM (1ull << 42)     /* LnudgeM2CLM of roms.in (round 6): nudging of ubar, vbar towards "ubarclm", "vbarclm" with "M2nudgcof"
+                                             in every step2d call (step2d_LF_AM3.h:2179-2203); the per-call kernel carries it (no pair / loop launches) */
 #define ROMS_DIAGNOSTICS_UV (1ull << 35)  /* roms_hip_dia_config allocates and switches on the momentum terms too (mod_diags.F:174-222) */
 
 /* GLS_MIXING: the cpp options that select a form of gls_prestep.F / gls_corstep.F (cppdefs.h names).  Stability

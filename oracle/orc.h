@@ -165,6 +165,8 @@ typedef struct orc_s {
   /* climatology nudging (mod_clima.F): tclm, Tnudgcof (i,j,k,itrc) -- per tracer, not the reference's compact index --, uclm, vclm,
      M3nudgcof (i,j,k); clima_flags: bit 0 LnudgeM3CLM, bit itrc LtracerCLM & LnudgeTCLM of tracer itrc (orc_set_clima) */
   double *tclm, *Tnudgcof, *uclm, *vclm, *M3nudgcof;
+  /* ... bit 5 of clima_flags: LnudgeM2CLM (step2d_LF_AM3.h:2179-2203), towards ubarclm, vbarclm with M2nudgcof (i,j) */
+  double *ubarclm, *vbarclm, *M2nudgcof;
   int clima_flags;
   int uv_vis4, ts_dif4;                  /* biharmonic mixing along s-surfaces switched on (orc_set_mix4; orc_mix4.c) */
   int mix_geo_uv;                        /* UV_VIS2 along geopotential surfaces (MIX_GEO_UV; orc_set_geouv, orc_uvmix_geo.c) */

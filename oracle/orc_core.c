@@ -139,6 +139,7 @@ static const fdesc fields[] = {
   FD(cloud, K2), FD(lhflx, K2), FD(shflx, K2), FD(lrflx, K2), FD(evap, K2),
   FD(Akv, KW), FD(Akt, KWxNAT), FD(visc2_r, K2), FD(visc2_p, K2), FD(diff2, K2xNT), FD(visc4_r, K2), FD(visc4_p, K2), FD(diff4, K2xNT),
   FD(tclm, KRxNT), FD(Tnudgcof, KRxNT), FD(uclm, KR), FD(vclm, KR), FD(M3nudgcof, KR),
+  FD(ubarclm, K2), FD(vbarclm, K2), FD(M2nudgcof, K2),
   FD(bvf, KW), FD(alpha, K2), FD(beta, K2), FD(hsbl, K2), FD(ghats, KWxNAT),
   FD(tke, KWx3), FD(gls, KWx3), FD(Lscale, KW), FD(Akk, KW), FD(Akp, KW),
   FD(sc_r, KTAB_R), FD(Cs_r, KTAB_R), FD(sc_w, KTAB_W), FD(Cs_w, KTAB_W),

@@ -416,6 +416,20 @@ void orc_step2d(orc_t *o, int tile) {
 
   if (o->uv_vis4) orc_step2d_vis4(o, b, krhs, Drhs, rhs_ubar, rhs_vbar, U2rhs, V2rhs);   /* UV_VIS4 :1653-1920 (orc_mix4.c) */
 
+  /* nudging of the 2-D momentum towards its climatology, LnudgeM2CLM :2179-2203 */
+  if (o->clima_flags & 32) {
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = IstrU; i <= Iend; i++) {
+        cff = 0.25 * (o->M2nudgcof[X2(i - 1, j)] + o->M2nudgcof[X2(i, j)]) * o->om_u[X2(i, j)] * o->on_u[X2(i, j)];
+        rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] + cff * (Drhs[X2(i - 1, j)] + Drhs[X2(i, j)]) * (o->ubarclm[X2(i, j)] - ubar[X2T(i, j, krhs)]);
+      }
+    for (int j = JstrV; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        cff = 0.25 * (o->M2nudgcof[X2(i, j - 1)] + o->M2nudgcof[X2(i, j)]) * o->om_v[X2(i, j)] * o->on_v[X2(i, j)];
+        rhs_vbar[X2(i, j)] = rhs_vbar[X2(i, j)] + cff * (Drhs[X2(i, j - 1)] + Drhs[X2(i, j)]) * (o->vbarclm[X2(i, j)] - vbar[X2T(i, j, krhs)]);
+      }
+  }
+
   if (o->wet_dry) {                                                      /* :2205-2222 */
     for (int j = Jstr; j <= Jend; j++)
       for (int i = IstrU; i <= Iend; i++) rhs_ubar[X2(i, j)] = rhs_ubar[X2(i, j)] * orc_wd_fac(o->umask_wet[X2(i, j)], rhs_ubar[X2(i, j)]);

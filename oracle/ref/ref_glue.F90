@@ -328,6 +328,10 @@
           Lm3CLM(ng)=.TRUE.
           LnudgeM3CLM(ng)=.TRUE.
         END IF
+        IF (IAND(clima_flags,32).ne.0) THEN
+          Lm2CLM(ng)=.TRUE.
+          LnudgeM2CLM(ng)=.TRUE.
+        END IF
         DO itrc=1,NT(ng)
           IF (IAND(clima_flags,ISHFT(1,itrc)).ne.0) THEN
             LtracerCLM(itrc,ng)=.TRUE.
@@ -1284,6 +1288,9 @@
         F2('Akt',MIXING(ng)%Akt)
         CASE ('tclm'); IF (clima_flags.gt.1) THEN; nel=SIZE(CLIMA(ng)%tclm); CALL cp2(CLIMA(ng)%tclm,SIZE(CLIMA(ng)%tclm),dir,buf); END IF
         CASE ('Tnudgcof'); IF (clima_flags.gt.1) THEN; nel=SIZE(CLIMA(ng)%Tnudgcof); CALL cp2(CLIMA(ng)%Tnudgcof,SIZE(CLIMA(ng)%Tnudgcof),dir,buf); END IF
+        CASE ('ubarclm'); IF (IAND(clima_flags,32).ne.0) THEN; nel=SIZE(CLIMA(ng)%ubarclm); CALL cp2(CLIMA(ng)%ubarclm,SIZE(CLIMA(ng)%ubarclm),dir,buf); END IF
+        CASE ('vbarclm'); IF (IAND(clima_flags,32).ne.0) THEN; nel=SIZE(CLIMA(ng)%vbarclm); CALL cp2(CLIMA(ng)%vbarclm,SIZE(CLIMA(ng)%vbarclm),dir,buf); END IF
+        CASE ('M2nudgcof'); IF (IAND(clima_flags,32).ne.0) THEN; nel=SIZE(CLIMA(ng)%M2nudgcof); CALL cp2(CLIMA(ng)%M2nudgcof,SIZE(CLIMA(ng)%M2nudgcof),dir,buf); END IF
         CASE ('uclm'); IF (IAND(clima_flags,1).ne.0) THEN; nel=SIZE(CLIMA(ng)%uclm); CALL cp2(CLIMA(ng)%uclm,SIZE(CLIMA(ng)%uclm),dir,buf); END IF
         CASE ('vclm'); IF (IAND(clima_flags,1).ne.0) THEN; nel=SIZE(CLIMA(ng)%vclm); CALL cp2(CLIMA(ng)%vclm,SIZE(CLIMA(ng)%vclm),dir,buf); END IF
         CASE ('M3nudgcof'); IF (IAND(clima_flags,1).ne.0) THEN; nel=SIZE(CLIMA(ng)%M3nudgcof); CALL cp2(CLIMA(ng)%M3nudgcof,SIZE(CLIMA(ng)%M3nudgcof),dir,buf); END IF

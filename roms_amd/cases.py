@@ -279,6 +279,9 @@ def clima_arrays(cs, nij, seed=11):
         Tnudgcof=(1.0 / (20.0 * day)) + (1.0 / (2.0 * day) - 1.0 / (20.0 * day)) * rng.random(nij * N * NT),
         uclm=0.1 * rng.standard_normal(nij * N), vclm=0.1 * rng.standard_normal(nij * N),
         M3nudgcof=(1.0 / (20.0 * day)) + (1.0 / (2.0 * day) - 1.0 / (20.0 * day)) * rng.random(nij * N))
+    # (bit 5: the 2-D momentum, LnudgeM2CLM -- drawn behind the others, so that their doubles stay what the fixtures hold)
+    out.update(ubarclm=0.05 * rng.standard_normal(nij), vbarclm=0.05 * rng.standard_normal(nij),
+               M2nudgcof=(1.0 / (10.0 * day)) + (1.0 / (1.0 * day) - 1.0 / (10.0 * day)) * rng.random(nij))
     return out
 
 
@@ -439,6 +442,7 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
         opt |= hiplib.OPTIONS["MIX_GEO_UV"]
     if cs.get("clima"):     # climatology nudging: bit 0 the 3-D momentum, bit itrc tracer itrc
         opt |= hiplib.OPTIONS["NUDGE_M3CLM"] if cs["clima"] & 1 else 0
+        opt |= hiplib.OPTIONS["NUDGE_M2CLM"] if cs["clima"] & 32 else 0
         for it in range(1, 5):
             opt |= hiplib.OPTIONS["NUDGE_TCLM%d" % it] if cs["clima"] & (1 << it) else 0
     if cs.get("wet_dry"):   # WET_DRY with DCRIT; the momentum diagnostics beside the tracer ones (ABI version 4: option bits)

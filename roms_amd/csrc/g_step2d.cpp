@@ -45,6 +45,7 @@ int run_step2d(roms_hip_ctx *c) {
   // behind a pair launch the krhs level is still staged: read it there and commit it (k_step2d_pair.h)
   a.lev_in = c->b2_stage ? c->b2_stage : G.krhs;
   a.commit = c->b2_stage ? 1 : 0;
+  a.om_u = c->F.om_u; a.on_v = c->F.on_v; a.ubarclm = c->F.ubarclm; a.vbarclm = c->F.vbarclm; a.M2nudgcof = c->F.M2nudgcof;
   if (c->b2_stage && !(G.predictor && G.krhs != 3)) { set_error("step2d: a staged pair result can only be followed by a predictor call"); return 8; }
   c->b2_stage = 0;
   if (c->m2d_dirty) pack_metrics(c);
@@ -56,7 +57,7 @@ int run_step2d(roms_hip_ctx *c) {
     variant = 2;                                                  // step: after the averages, below); the generic form carries the branches (k_step2d_wd)
     if (iif <= G.nfast) { int r = run_wetdry(c, 0); if (r) return r; }
   }
-  if (G.dia_uv || G.uv_vis4) variant = 2;                         // (UV_VIS4: the generic form carries the biharmonic block, k_step2d_vis4)                                      // DIAGNOSTICS_UV: the generic form carries the term stores (k_step2d_duv)
+  if (G.dia_uv || G.uv_vis4 || (G.clima & 32)) variant = 2;                         // (UV_VIS4: the generic form carries the biharmonic block, k_step2d_vis4)                                      // DIAGNOSTICS_UV: the generic form carries the term stores (k_step2d_duv)
   // 64x8 sub-tiles: 1024 threads (one rectangle point and one momentum point per thread) measure 3 %
   // faster than 512 threads with two each; ROMS_HIP_S2D_1024=0 selects the latter
   const char *e1024 = getenv("ROMS_HIP_S2D_1024");
@@ -137,6 +138,9 @@ int run_step2d(roms_hip_ctx *c) {
       }
 #endif
       LAUNCH_COOP_AS(k_step2d, k_step2d_duv, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
+    } else if (G.clima & 32) {
+      if (lds * sizeof(double) > 64 * 1024) { set_error("k_step2d_ndg: the sub-tile needs more than 64 KB of LDS (ROMS_HIP_TILE2D)"); return 5; }
+      LAUNCH_COOP_AS(k_step2d, k_step2d_ndg, G.nbx2, G.nby2, 1, nthreads, lds, c->stream, a);
     } else if (G.wet_dry) {
 #ifndef ROMS_CPU_EMU
       static bool big_lds_w = false;
@@ -196,6 +200,7 @@ bool step2d_pair_usable(const roms_hip_ctx *c) {
   if (G.dia_uv) return false;                                            // DIAGNOSTICS_UV: the per-call kernel carries the term stores
   if (G.uv_vis4) return false;                                           // UV_VIS4: the per-call generic kernel carries the biharmonic block
   if (G.wet_dry) return false;                                           // WET_DRY: new masks in front of every call
+  if (G.clima & 32) return false;                                        // LnudgeM2CLM: the per-call kernel carries the nudging term
   const int LmT = G.T.Iend - G.T.Istr + 1, MmT = G.T.Jend - G.T.Jstr + 1;
   if (LmT < 8 || MmT < 8) return false;                                  // the rim (5 | 4 lines) comes from the neighbour's / the tile's own points
   if (pair_lds_doubles(G.bw2, G.bh2) * sizeof(double) > 160 * 1024) return false;

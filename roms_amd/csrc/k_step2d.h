@@ -62,6 +62,9 @@ struct Step2dArgs {
   double w2_0, w2_p1;  // weight(2,iif), weight(2,iif+1)
   int lev_in;          // physical level of zeta/ubar/vbar(krhs): G.krhs, or the staging level the pair kernel left its result in
   int commit;          // (the auxiliary last call behind a pair) copy that level to the logical level G.krhs: k_step2d_pair.h
+  // LnudgeM2CLM (round 6; the NDG instantiation only, behind everything the other kernels read): nudging of the 2-D momentum
+  // towards its climatology, step2d_LF_AM3.h:2179-2203
+  const double *om_u, *on_v, *ubarclm, *vbarclm, *M2nudgcof;
 };
 
 #define STEP2D_NLDS 15
@@ -132,7 +135,7 @@ THREAD_GLOBAL(k_pack_m2d, PackArgs)
 // operator LapU, LapV of ubar, vbar(krhs) on the sub-tile + 1 with its closed / gradient conditions and corner values; the
 // momentum stage then forms the same stress tensor of (LapU, LapV) times the total depth.  The packed metric records carry
 // visc4 in the place of visc2 (g_step2d.cpp:pack_metrics).
-template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0), bool CM = (BWC == 0), int PWR = PTS, bool DUV = false, bool VIS4 = false, bool WD = false>
+template <int BWC, int BHC, int NTC, int PTS, bool MK = (BWC == 0), bool CM = (BWC == 0), int PWR = PTS, bool DUV = false, bool VIS4 = false, bool WD = false, bool NDG = false>
 COOP_KERNEL(k_step2d_t, Step2dArgs) {
   (void)bz;
 #ifndef ROMS_CPU_EMU
@@ -694,6 +697,14 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
       double *r3 = isv ? F.rv : F.ru;
       const double *rb = isv ? F.rvbar : F.rubar;
       double r = rhs;
+      if (NDG) {
+        // nudging towards the 2-D momentum climatology :2179-2203 (Drhs at the point's two rho points, ubar / vbar(krhs))
+        const int dn = isv ? TW : 1;
+        const int xm = isv ? x - ni : x - 1;
+        const double c0 = 0.25 * (a.M2nudgcof[xm] + a.M2nudgcof[x]);
+        const double cffn = isv ? c0 * F.om_v[x] * a.on_v[x] : c0 * a.om_u[x] * F.on_u[x];
+        r = r + cffn * (Drhs[s - dn] + Drhs[s]) * ((isv ? a.vbarclm : a.ubarclm)[x] - (isv ? sVk : sUk)[s]);
+      }
       const double mwet = WD ? (isv ? G.vmask_wet : G.umask_wet)[x] : 1.0;
       if (WD) r = r * wd_fac(mwet, r);                                    // :2205-2222
       double fr = 0.0;
@@ -825,5 +836,7 @@ COOP_KERNEL(k_step2d_vis4, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0, true, true,
 COOP_GLOBAL_LB(k_step2d_vis4, Step2dArgs, 512)
 COOP_KERNEL(k_step2d_wd, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0, true, true, 0, false, false, true>(a, bx, by, bz, lds); }   // ... with wetting and drying (WET_DRY)
 COOP_GLOBAL_LB(k_step2d_wd, Step2dArgs, 512)
+COOP_KERNEL(k_step2d_ndg, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0, true, true, 0, false, false, false, true>(a, bx, by, bz, lds); }   // ... with LnudgeM2CLM
+COOP_GLOBAL_LB(k_step2d_ndg, Step2dArgs, 512)
 COOP_KERNEL(k_step2d_duv, Step2dArgs) { k_step2d_t_body<0, 0, 0, 0, true, true, 0, true>(a, bx, by, bz, lds); }   // ... with the momentum diagnostics (DIAGNOSTICS_UV)
 COOP_GLOBAL_LB(k_step2d_duv, Step2dArgs, 512)

@@ -283,6 +283,7 @@ struct Fields {
   GPtr rmask_wet, umask_wet, vmask_wet, pmask_wet, rmask_full, umask_full, vmask_full, pmask_full, rmask_wet_avg;
   GPtr wd_eff;                         // umask*umask_wet | vmask*vmask_wet as step3d_uv finds them (2 planes; k_wd_eff)
   GPtr tclm, Tnudgcof, uclm, vclm, M3nudgcof;   // climatology and nudging coefficients (mod_clima.F): input like the forcing; tclm, Tnudgcof per tracer
+  GPtr ubarclm, vbarclm, M2nudgcof;             // ... of the 2-D momentum (LnudgeM2CLM, round 6)
   GPtr gwrk;                           // the twenty 3-D work arrays of k_uvmix_geo.h (N+1 planes each; allocated with ROMS_MIX_GEO_UV)
   GPtr tmix;                           // harmonic tracer mixing as terms (N planes per tracer): t3dmix2 run ahead of pre_step3d stores
                                        // what it adds to t(nnew), k_pre_new adds it to the value it sets (allocated with TS_DIF2)

@@ -140,6 +140,7 @@ static const FieldDesc g_fields[] = {
     FD(vmask_full, FK_2D), FD(pmask_full, FK_2D), FD(rmask_wet_avg, FK_2D),      // WET_DRY (wetdry.F)
     // climatology nudging (mod_clima.F; option bits ROMS_NUDGE_M3CLM, ROMS_NUDGE_TCLM): tclm, Tnudgcof hold N planes per tracer
     FD(tclm, FK_RxNT), FD(Tnudgcof, FK_RxNT), FD(uclm, FK_R), FD(vclm, FK_R), FD(M3nudgcof, FK_R),
+    FD(ubarclm, FK_2D), FD(vbarclm, FK_2D), FD(M2nudgcof, FK_2D),
 };
 static const int g_nfields = (int)(sizeof(g_fields) / sizeof(g_fields[0]));
 
@@ -625,16 +626,17 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     const int r = wetdry_config(c, cfg->Dcrit);
     if (r) { roms_hip_destroy(c); return r; }
   }
-  if (cfg->options & (ROMS_NUDGE_M3CLM | ROMS_NUDGE_TCLM_ALL)) {       // climatology nudging: rhs3d.F:654-680, step3d_t.F:1866-1878
+  if (cfg->options & (ROMS_NUDGE_M3CLM | ROMS_NUDGE_TCLM_ALL | ROMS_NUDGE_M2CLM)) {       // climatology nudging: rhs3d.F:654-680, step3d_t.F:1866-1878, step2d_LF_AM3.h:2179
     if (c->G.obc) { set_error("climatology nudging with open boundaries: the nudging coefficients of the radiation conditions (t3dbc_im.F:120, u3dbc_im.F:113) are not built"); roms_hip_destroy(c); return 5; }
     if (cfg->options & ROMS_DIAGNOSTICS_UV) { set_error("climatology nudging with DIAGNOSTICS_UV: not built"); roms_hip_destroy(c); return 5; }
     // (the rule of this library: an option set without a reference-written fixture or a pinned oracle run is refused)
     if (cfg->options & (ROMS_WET_DRY | ROMS_TS_DIF4 | ROMS_UV_VIS4 | ROMS_MIX_GEO_UV)) {
       set_error("climatology nudging together with WET_DRY, TS_DIF4 / UV_VIS4 or MIX_GEO_UV: not pinned against the reference"); roms_hip_destroy(c); return 5;
     }
-    c->G.clima = ((cfg->options & ROMS_NUDGE_M3CLM) ? 1 : 0);
+    c->G.clima = ((cfg->options & ROMS_NUDGE_M3CLM) ? 1 : 0) | ((cfg->options & ROMS_NUDGE_M2CLM) ? 32 : 0);
     for (int it = 1; it <= c->G.NT; it++) if (cfg->options & ROMS_NUDGE_TCLM(it)) c->G.clima |= 1 << it;
-    if (c->G.clima & ~1) c->G.fuse3d = 0;                    // (the nudging sits between t3dbc and the exchange: separate launches)
+    if (c->G.clima & 30) c->G.fuse3d = 0;
+    if (c->G.clima & 32) { c->pair_on = step2d_pair_usable(c); c->loop_state = 0; }     // (LnudgeM2CLM: the per-call barotropic kernel)                    // (the nudging sits between t3dbc and the exchange: separate launches)
   }
   if (cfg->options & ROMS_MIX_GEO_UV) {                     // uv3dmix2_geo.h (k_uvmix_geo.h): twenty 3-D work arrays
     if (!(cfg->options & ROMS_UV_VIS2) || c->G.uv_vis4) { set_error("MIX_GEO_UV: the harmonic viscosity only (UV_VIS2; uv3dmix4_geo.h is not built)"); roms_hip_destroy(c); return 5; }

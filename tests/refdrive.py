@@ -205,6 +205,9 @@ def reference(app, cs):
         if cs["clima"] & 1:
             for n in ("uclm", "vclm", "M3nudgcof"):
                 R.put(n, ca[n])
+        if cs["clima"] & 32:
+            for n in ("ubarclm", "vbarclm", "M2nudgcof"):
+                R.put(n, ca[n])
     return R
 
 

@@ -37,6 +37,7 @@ def _run(tag, hadv, vadv, nsteps):
 
 
 @pytest.mark.parametrize("tag,clima,geouv", [("upwelling_small", 7, False), ("benchmark_small", 7, False), ("upwelling_mask_small", 5, False),
+                                             ("upwelling_small", 32, False), ("upwelling_mask_small", 39, False),      # LnudgeM2CLM (round 6)
                                              ("upwelling_geouv_small", 0, True), ("upwelling_bihgeo_small", 0, False), ("upwelling_bihiso_small", 0, False)])
 def test_round5_options_match_oracle(tag, clima, geouv):
     """The options built in round 5 on the device's default kernel forms (LDS-tiled rhs3d_tile carries the momentum nudging):

@@ -561,6 +561,7 @@ def test_standard_density_jacobian_bitwise(emu, tag):
 
 
 @pytest.mark.parametrize("tag,clima,adv", [("upwelling_small", 7, ("U3", "HSIMT")), ("upwelling_small", 4, ("MPDATA", "MPDATA")),
+                                           ("upwelling_small", 32, ("U3", "HSIMT")), ("upwelling_mask_small", 39, ("U3", "U3")),       # bit 5: LnudgeM2CLM, step2d_LF_AM3.h:2179
                                            ("upwelling_mask_small", 3, ("U3", "U3")), ("benchmark_small", 7, None)])
 def test_climatology_nudging_bitwise(emu, tag, clima, adv):
     """Nudging towards climatology (LnudgeM3CLM: rhs3d.F:654-680 in k_rhs3d_pt; LtracerCLM + LnudgeTCLM: step3d_t.F:1866-1878,

@@ -206,6 +206,9 @@ MAIN3D_CASES = [
     ("upwelling_small", ["nsteps=40", "hadv=U3,HSIMT", "vadv=C4,HSIMT", "clima=7"]),
     ("upwelling_small", ["nsteps=20", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA", "clima=4", "NtileI=2", "NtileJ=2"]),
     ("upwelling_small", ["nsteps=20", "hadv=U3,U3", "vadv=C4,C4", "clima=1"]),
+    # ... bit 5: the 2-D momentum (LnudgeM2CLM, step2d_LF_AM3.h:2179-2203; round 6), alone and with the others, tiled
+    ("upwelling_small", ["nsteps=40", "hadv=U3,HSIMT", "vadv=C4,HSIMT", "clima=32"]),
+    ("upwelling_small", ["nsteps=20", "hadv=U3,U3", "vadv=C4,C4", "clima=39", "NtileI=2", "NtileJ=2"]),
     ("benchmark_small", ["nsteps=100"]),                                         # KPP, bulk fluxes, nonlinear EOS
     ("benchmark_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("upwelling_kpp_small", ["nsteps=100"]),                                     # BASELINE config 5 physics
@@ -214,6 +217,7 @@ MAIN3D_CASES = [
     ("upwelling_noadv_small", ["nsteps=40", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     ("upwelling_noadv_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
     ("upwelling_mask_small", ["nsteps=60", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),   # MASKING: island + headland
+    ("upwelling_mask_small", ["nsteps=30", "hadv=U3,U3", "vadv=C4,C4", "clima=39"]),   # ... with nudging of the 2-D and 3-D momentum and both tracers
     ("upwelling_mask_small", ["nsteps=30", "hadv=A4,C4", "vadv=SPLINES,C4"]),
     ("upwelling_mask_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     ("upwelling_mask_small", ["nsteps=40", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),   # mpdata_adiff.F's 13 masked blocks

@@ -244,7 +244,7 @@ def make_hip(cs, g, lib_path=None, device=0, ninfo=0):
         H.upload("visc2_r", np.zeros(nij)); H.upload("visc2_p", np.zeros(nij)); H.upload("diff2", np.zeros(2 * nij))
     if cs.get("clima"):    # climatology nudging: the climatology and coefficient arrays are input data (cases.clima_arrays)
         for n, a in cases.clima_arrays(cs, np.asarray(g["h"]).size).items():
-            if (cs["clima"] & 1) if n in ("uclm", "vclm", "M3nudgcof") else (cs["clima"] & ~1):      # (only the arrays of the switches that are on exist)
+            if ((cs["clima"] & 32) if n in ("ubarclm", "vbarclm", "M2nudgcof") else (cs["clima"] & 1) if n in ("uclm", "vclm", "M3nudgcof") else (cs["clima"] & 30)):      # (only the arrays of the switches that are on exist)
                 H.upload(n, a)
     return H
 
