@@ -373,6 +373,13 @@ int roms_hip_exchange_probe(roms_hip_ctx *ctx, int reps);
    PREVIOUS repetition's strips -- a slot read too early, a stale line -- is counted.  0, or exit_flag 2. */
 int roms_hip_exchange_soak(roms_hip_ctx *ctx, int reps);
 int roms_hip_comm_reset(roms_hip_ctx *ctx);
+/* round 6: self-check of the RIM PLANES -- the part of the mailbox slab through which the barotropic launches of a multi-tile run
+   hand their rim to the neighbouring ranks themselves (k_step2d_loop.h, k_step2d_pair.h) instead of through exchange launches:
+   index-coded values of every rank's own points into its neighbours' planes, all eight directions, verified on the device.
+   Call it on every rank behind roms_hip_exchange_probe; if it fails on ANY rank, call roms_hip_rim_disable on every rank
+   (the exchanges of rounds 3-5 stay in place of the rim hand-off).  Returns 0 where there is nothing to check. */
+int roms_hip_rim_probe(roms_hip_ctx *ctx, int reps);
+int roms_hip_rim_disable(roms_hip_ctx *ctx);
 /* number of halo exchanges performed so far (0 for a single-tile context) */
 long roms_hip_exchange_count(roms_hip_ctx *ctx);
 /* ranks of the built-in RCCL communicator of this context (ncclCommCount); 0: roms_hip_comm_rccl was not called */

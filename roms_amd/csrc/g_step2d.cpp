@@ -239,6 +239,7 @@ static void fill_peer(roms_hip_ctx *c, S2LPeer &P) {
 // neighbour's launch from starting).  Same conditions on the partition as the loop: every rank decides alike.
 // ROMS_HIP_PAIR_RIM=0/1 forces.
 static bool pair_rim_usable(roms_hip_ctx *c) {
+  if (c->rim_refused) return false;                   // (roms_hip_rim_disable: the self-check of the rim planes failed on some rank)
   if (c->pair_rim_state) return c->pair_rim_state > 0;
   c->pair_rim_state = -1;
   const TileComm &m = c->comm;
@@ -378,7 +379,7 @@ static bool loop_mt_usable(roms_hip_ctx *c, const DGrid &L, bool forced) {
   const DGrid &G = c->G;
   const roms_hip_config &cf = c->cfg;
   const TileComm &m = c->comm;
-  if (!c->pair_mt || !m.peer_on || !m.loop_rim_off) return false;
+  if (!c->pair_mt || !m.peer_on || !m.loop_rim_off || c->rim_refused) return false;
   if (m.peer_shared && !forced) return false;
   if (!(G.ewp || G.nsp) || G.obc || !loop_shape()) return false;
   if (cf.Lm % cf.NtileI || cf.Mm % cf.NtileJ) return false;
@@ -609,3 +610,121 @@ int run_step2d_loop_n(roms_hip_ctx *c, int whole) {
 #endif
 }
 int run_step2d_loop(roms_hip_ctx *c) { return run_step2d_loop_n(c, c->G.iif == 1 ? 1 : 0); }    // (the stepping of the call says which)
+
+
+// ---- self-check of the rim planes (round 6): before a multi-tile run trusts the rim hand-off inside its barotropic launches
+// (k_step2d_loop.h, k_step2d_pair.h: rim_in / rim_out), every rank publishes index-coded values of its own points into the
+// neighbours' rim planes -- every direction, corners included, all six planes, `reps` repetitions with the parities alternating
+// -- and verifies on the device that every ghost point of its own tile receives the code of the point it images: the address of
+// a point in a neighbour's planes (array origin, the shift across a periodic seam), the mapping of the slabs and the visibility
+// of tagged 8-byte words across devices, in the geometry of THIS run.  The tags live above 0xC0000000: the pairs of a run
+// count up from one and never meet them.  0, or exit_flag 2 with the first wrong point; a context without the mailbox or
+// without rim planes returns 0 (nothing to check).
+#ifndef ROMS_CPU_EMU
+struct RimProbeArgs {
+  DGrid G;
+  S2LPeer P;
+  unsigned long long *bad;     // [0] wrong or missing points, [1] packed (i,j) of the first, [2] its plane, [3] 1 = never arrived
+  int rep;
+  int skip;                    // test aid (ROMS_HIP_RIM_PROBE_BREAK): this plane is not published -- the check has to fail
+  long long timeout;
+};
+static __device__ __forceinline__ double rim_code(const DGrid &G, int i, int j, int pf, int rep) {
+  if (i < 1) i += G.Lm; else if (i > G.Lm) i -= G.Lm;
+  if (j < 1) j += G.Mm; else if (j > G.Mm) j -= G.Mm;
+  return ((double)(rep & 0xFFFF) * 8.0 + (double)pf) * 67108864.0 + (double)j * 8192.0 + (double)i;
+}
+static __global__ void k_rim_publish(const RimProbeArgs a, int nx, int ny) {
+  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x), gy = (int)blockIdx.y;
+  if (gx >= nx || gy >= ny) return;
+  const DGrid &G = a.G;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy;
+  for (int f = 0; f < 3; f++) {
+    const int pf = 3 * (a.rep & 1) + f;
+    if (pf == a.skip) continue;
+    s2l_rput(G, a.P, pf, i, j, rim_code(G, i, j, pf, a.rep), 0xC0000000u + (unsigned)a.rep);
+  }
+}
+static __global__ void k_rim_verify(const RimProbeArgs a, int nx, int ny) {
+  const int gx = (int)(blockIdx.x * blockDim.x + threadIdx.x), gy = (int)blockIdx.y;
+  if (gx >= nx || gy >= ny) return;
+  const DGrid &G = a.G;
+  const TB &T = G.T;
+  const int i = G.LBi + gx, j = G.LBj + gy;
+  // a ghost point of the tile that images an OWN point of a neighbouring rank (the strips they publish: 5 | 4 lines)
+  const int dx = i < T.Istr ? -1 : (i > T.Iend ? 1 : 0), dy = j < T.Jstr ? -1 : (j > T.Jend ? 1 : 0);
+  if (dx == 0 && dy == 0) return;
+  if ((dx < 0 && i < T.Istr - B2D_GL) || (dx > 0 && i > T.Iend + B2D_GH) || (dy < 0 && j < T.Jstr - B2D_GL) || (dy > 0 && j > T.Jend + B2D_GH)) return;
+  const int d = dy == 0 ? (dx < 0 ? 0 : 1) : (dx == 0 ? (dy < 0 ? 2 : 3) : (dy < 0 ? (dx < 0 ? 4 : 5) : (dx < 0 ? 6 : 7)));
+  if (!(a.P.nbmask & (1 << d))) return;
+  const unsigned tag = 0xC0000000u + (unsigned)a.rep;
+  const size_t x = X2(i, j);
+  if (ksys_ld((const kword_t *)a.bad)) return;           // (already failed: no more waiting)
+  for (int f = 0; f < 3; f++) {
+    const int pf = 3 * (a.rep & 1) + f;
+    const kword_t *q = a.P.rim + 2 * ((size_t)pf * (size_t)G.nij + x);
+    const long long t0 = kclock();
+    kword_t w0 = 0, w1 = 0;
+    bool here = false;
+    for (;;) {
+      w0 = ksys_ld(q); w1 = ksys_ld(q + 1);
+      if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) { here = true; break; }
+      knap();
+      if (kclock() - t0 > a.timeout) break;
+    }
+    if (!here || s2l_ll_val(w0, w1) != rim_code(G, i, j, pf, a.rep)) {
+      if (atomicAdd(a.bad, 1ull) == 0) {
+        a.bad[1] = ((unsigned long long)(unsigned)(i + 4096) << 32) | (unsigned)(j + 4096);
+        a.bad[2] = (unsigned long long)pf;
+        a.bad[3] = here ? 0ull : 1ull;
+      }
+    }
+  }
+}
+#endif
+int run_rim_probe(roms_hip_ctx *c, int reps) {
+#ifdef ROMS_CPU_EMU
+  (void)c; (void)reps;
+  return 0;
+#else
+  const TileComm &m = c->comm;
+  if (!c->has_exchange || !m.peer_on || !m.loop_rim_off || !c->pair_mt) return 0;
+  for (int d = 0; d < 8; d++)
+    if (m.nbr[d] >= 0 && !m.ngeom[d].rim_off) return 0;
+  const DGrid &G = c->G;
+  RimProbeArgs a;
+  a.G = G;
+  fill_peer(c, a.P);
+  void *pb = nullptr;
+  if (hipMalloc(&pb, 4 * sizeof(unsigned long long)) != hipSuccess) { set_error("rim probe: hipMalloc"); return 2; }
+  (void)hipMemsetAsync(pb, 0, 4 * sizeof(unsigned long long), c->stream);
+  a.bad = (unsigned long long *)pb;
+  const char *brk = getenv("ROMS_HIP_RIM_PROBE_BREAK");
+  a.skip = brk && *brk ? atoi(brk) : -1;
+  a.timeout = a.skip >= 0 ? (long long)(2.0e7) : (long long)(5.0e8);   // 5 s of the 100 MHz clock: the neighbour may still be setting up
+  const int ox = G.T.Iend - G.T.Istr + 1, oy = G.T.Jend - G.T.Jstr + 1;
+  for (int rep = 1; rep <= reps; rep++) {
+    a.rep = rep;
+    hipLaunchKernelGGL(k_rim_publish, dim3((unsigned)((ox + 255) / 256), (unsigned)oy, 1), dim3(256), 0, c->stream, a, ox, oy);
+    hipLaunchKernelGGL(k_rim_verify, dim3((unsigned)((G.ni + 255) / 256), (unsigned)G.nj, 1), dim3(256), 0, c->stream, a, G.ni, G.nj);
+  }
+  unsigned long long bad[4] = {0, 0, 0, 0};
+  const bool ok = hipMemcpyAsync(bad, pb, sizeof(bad), hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+  (void)hipFree(pb);
+  if (!ok) { set_error("rim probe: the device reported an error"); return 2; }
+  if (bad[0]) {
+    char msg[320];
+    snprintf(msg, sizeof(msg), "rim probe: tile %d: %llu ghost points of the rim planes wrong or missing in %d repetitions; first: point (%d,%d), plane %llu, %s",
+             c->cfg.tile, bad[0], reps, (int)(bad[1] >> 32) - 4096, (int)(bad[1] & 0xFFFFFFFFu) - 4096, bad[2], bad[3] ? "never arrived" : "wrong value");
+    set_error(msg);
+    return 2;
+  }
+  return 0;
+#endif
+}
+// the caller's decision after the probe (every rank the same one): no rim hand-off inside the barotropic launches
+void rim_disable(roms_hip_ctx *c) {
+  c->rim_refused = true;                 // (sticky: the states below are decided again by later calls, this is not)
+  if (c->has_exchange) c->loop_state = 0;
+  c->pair_rim_state = 0;
+}

@@ -5,8 +5,10 @@
 // ghost points (exchange_2d.F).  When at least one direction is periodic there are no corner
 // averages, and every boundary or ghost value is a function of ONE interior value.  The thread
 // that computes that value therefore stores all of its images itself: no extra kernel, no barrier,
-// no re-read.  (Closed basins need the corner averages of two different edge values and keep the
-// separate halo launch, as do multi-GPU runs whose strips travel between tiles.)
+// no re-read.  A closed basin (neither direction periodic; round 6) adds the corner averages of two boundary values
+// (zetabc.F:753-782, u2dbc_im.F:1159-1188, v2dbc_im.F:1208-1237) -- both of them derived from the ONE interior point next to
+// the corner, or the zero of the wall: hb_corner, by the thread of that point.  (Multi-GPU runs, whose strips travel
+// between tiles, and open boundaries keep the separate halo launch.)
 //
 //   hb_emit(G, B, A, bc, i, j, v)   A(i,j) = v was computed at an interior point of sub-tile B;
 //                                   stores A(i,j), the boundary values derived from it and the
@@ -32,6 +34,28 @@ KDEV void hb_mirror(const DGrid &G, double *A, int i, int j, double v) {
     for (int a = 0; a < 3; a++)
       if (a < nx && b < ny) A[X2(xs[a], ys[b])] = v;
 }
+
+// Closed basin: the corner value of A behind the interior point (i,j) that lies next to a corner of the domain.  As the
+// reference writes it, 0.5*(boundary value along xi + boundary value along eta): for a rho-type field both are this point's
+// value (times the mask of the boundary point); for ubar one is the slip value behind the southern/northern edge and the other
+// the zero of the western/eastern wall (for vbar the other way round).  ST(x, y, value) stores.
+#define HB_CORNERS(ST)                                                                                                       \
+  if (bc == BC_R) {                                                                                                          \
+    const bool w = B.west && i == B.Istr, e = B.east && i == B.Iend, s_ = B.south && j == B.Jstr, n = B.north && j == B.Jend; \
+    if ((w || e) && (s_ || n)) {                                                                                             \
+      const int ic = w ? i - 1 : i + 1, jc = s_ ? j - 1 : j + 1;                                                             \
+      const double vx = M ? v * M[X2(ic, j)] : v, vy = M ? v * M[X2(i, jc)] : v;                                             \
+      ST(ic, jc, 0.5 * (vy + vx));                                                                                           \
+    }                                                                                                                        \
+  } else if (bc == BC_U) {                                                                                                   \
+    const bool w = B.west && i == B.IstrU, e = B.east && i == B.Iend, s_ = B.south && j == B.Jstr, n = B.north && j == B.Jend; \
+    if (w && (s_ || n)) { const int jc = s_ ? j - 1 : j + 1; ST(B.Istr, jc, 0.5 * ((M ? G.gamma2 * v * M[X2(i, jc)] : G.gamma2 * v) + 0.0)); } \
+    if (e && (s_ || n)) { const int jc = s_ ? j - 1 : j + 1; ST(i + 1, jc, 0.5 * ((M ? G.gamma2 * v * M[X2(i, jc)] : G.gamma2 * v) + 0.0)); } \
+  } else if (bc == BC_V) {                                                                                                   \
+    const bool w = B.west && i == B.Istr, e = B.east && i == B.Iend, s_ = B.south && j == B.JstrV, n = B.north && j == B.Jend; \
+    if (s_ && (w || e)) { const int ic = w ? i - 1 : i + 1; ST(ic, B.Jstr, 0.5 * (0.0 + (M ? G.gamma2 * v * M[X2(ic, j)] : G.gamma2 * v))); } \
+    if (n && (w || e)) { const int ic = w ? i - 1 : i + 1; ST(ic, j + 1, 0.5 * (0.0 + (M ? G.gamma2 * v * M[X2(ic, j)] : G.gamma2 * v))); } \
+  }
 
 // M (MASKING): the mask array of A's grid type, or null -- the gradient / slip value stored at a boundary point is
 // multiplied by the mask of THAT point (zetabc.F:264, u2dbc_im.F:989, v2dbc_im.F:1048); zero values stay zero
@@ -64,6 +88,11 @@ KDEV void hb_emit(const DGrid &G, const TB &B, double *A, int bc, int i, int j, 
       if (B.west && i == B.Istr) hb_mirror(G, A, i - 1, j, M ? G.gamma2 * v * M[X2(i - 1, j)] : G.gamma2 * v);
       if (B.east && i == B.Iend) hb_mirror(G, A, i + 1, j, M ? G.gamma2 * v * M[X2(i + 1, j)] : G.gamma2 * v);
     }
+  }
+  if (!G.ewp && !G.nsp) {
+#define HB_ST1_(x_, y_, v_) A[X2(x_, y_)] = (v_)
+    HB_CORNERS(HB_ST1_)
+#undef HB_ST1_
   }
 }
 
@@ -118,6 +147,11 @@ KDEV void hb_emit2(const DGrid &G, const TB &B, double *A, int bc, int i, int j,
       if (B.west && i == B.Istr) hb_put<WT>(G, A, i - 1, j, M ? G.gamma2 * v * M[X2(i - 1, j)] : G.gamma2 * v, images);
       if (B.east && i == B.Iend) hb_put<WT>(G, A, i + 1, j, M ? G.gamma2 * v * M[X2(i + 1, j)] : G.gamma2 * v, images);
     }
+  }
+  if (!G.ewp && !G.nsp) {
+#define HB_ST2_(x_, y_, v_) HB_ST(WT, A, (int)X2(x_, y_), (v_))
+    HB_CORNERS(HB_ST2_)
+#undef HB_ST2_
   }
 }
 

@@ -423,12 +423,16 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
      // three source lines of a periodic copy
     const int LmT = cfg->Iend - cfg->Istr + 1, MmT = cfg->Jend - cfg->Jstr + 1;
     const char *e = getenv("ROMS_HIP_FUSE_HALO");
-    G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && !c->has_exchange && (cfg->EWperiodic || cfg->NSperiodic) && LmT >= 6 && MmT >= 6 &&
+    // (round 6: a closed basin too -- the corner averages by the thread of the point next to the corner, k_haloblock.h:
+    // HB_CORNERS; ROMS_HIP_FUSE_CLOSED=0 keeps its separate halo launches)
+    const char *ecb = getenv("ROMS_HIP_FUSE_CLOSED");
+    const bool closed_ok = !(ecb && ecb[0] == '0');
+    G.fuse_halo = cfg->NtileI * cfg->NtileJ == 1 && !c->has_exchange && (cfg->EWperiodic || cfg->NSperiodic || closed_ok) && LmT >= 6 && MmT >= 6 &&
                   !(e && e[0] == '0') && !G.obc;
     const char *e3 = getenv("ROMS_HIP_FUSE3D");
     // (a masked run: the barotropic kernel's boundary stores carry the mask of the boundary point, hb_emit; the 3-D
     // producers take the separate halo launches -- their emit_plan knows no mask)
-    G.fuse3d = G.fuse_halo && !(e3 && e3[0] == '0') && !(cfg->options & ROMS_MASKING);
+    G.fuse3d = G.fuse_halo && (cfg->EWperiodic || cfg->NSperiodic) && !(e3 && e3[0] == '0') && !(cfg->options & ROMS_MASKING);
   }
   G.ntfirst = cfg->ntfirst; G.nfast = cfg->nfast;
   G.dt = cfg->dt; G.dtfast = cfg->dtfast; G.rho0 = cfg->rho0; G.g = cfg->g; G.lambda = cfg->lambda;
@@ -1230,6 +1234,7 @@ extern "C" int roms_hip_comm_peer(roms_hip_ctx *c, const void *blobs128, int nra
     }
   }
   m.peer_on = true;
+  c->rim_refused = false;
   c->loop_state = 0;                    // (the persistent barotropic loop of a multi-tile context needs the mailbox: decided again)
   // the step is arranged on four streams, every exchange in the stream of its producer on that stream's channel (main3d_around_loop)
   if (c->pair_mt && !getenv("ROMS_HIP_XASYNC") && !(getenv("ROMS_HIP_MT_LANES") && getenv("ROMS_HIP_MT_LANES")[0] == '0')) { halo_fence(c, FG_ALL); c->x_async = false; c->rim_split = false; }
@@ -1652,6 +1657,19 @@ extern "C" int roms_hip_exchange_soak(roms_hip_ctx *c, int reps) {
     set_error(msg);
     return 2;
   }
+  return 0;
+}
+
+// Self-check of the rim planes the barotropic launches hand their rim through in a multi-tile run (g_step2d.cpp:run_rim_probe);
+// roms_hip_rim_disable: the caller's verdict when the check failed on ANY rank -- every rank then keeps the exchanges.
+extern "C" int roms_hip_rim_probe(roms_hip_ctx *c, int reps) {
+  if (!c || reps < 1) return 8;
+  int r = run_rim_probe(c, reps);
+  return r ? r : ctx_check(c, "rim probe");
+}
+extern "C" int roms_hip_rim_disable(roms_hip_ctx *c) {
+  if (!c) return 8;
+  rim_disable(c);
   return 0;
 }
 

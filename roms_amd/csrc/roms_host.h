@@ -104,6 +104,7 @@ struct roms_hip_ctx {
   bool h_ghost_done = false;    // (multi-tile) the ghost lines of h have been exchanged once (run_set_depth computes the ghost columns itself)
   // the pair launches handing their rim across tile edges themselves (tiles too large for the loop; g_step2d.cpp:pair_rim_usable)
   int pair_rim_state = 0;       // 0: not decided, 1: on, -1: off
+  bool rim_refused = false;     // roms_hip_rim_disable: no rim hand-off inside the barotropic launches (until another transport is installed)
   bool b2_rim = false;          // the staged result of the last pair launch was published into the neighbours' rim planes (not exchanged)
   unsigned pair_epoch = 0;      // number of the last published pair (the tag its points carry)
   bool loop_pre_frc = false;    // (multi-tile) this step's schedule has already exchanged what the loop's first fast step reads beyond the tile:
@@ -268,6 +269,8 @@ int run_step2d(roms_hip_ctx *c);
 int run_step2d_pair(roms_hip_ctx *c);     // predictor (c->G = its stepping) + corrector of one fast step
 bool step2d_pair_usable(const roms_hip_ctx *c);
 bool step2d_loop_usable(roms_hip_ctx *c);   // fast steps 2 .. nfast as one persistent launch (k_step2d_loop.h)
+int run_rim_probe(roms_hip_ctx *c, int reps);      // self-check of the rim planes (g_step2d.cpp)
+void rim_disable(roms_hip_ctx *c);
 int step2d_loop_pre(roms_hip_ctx *c, int what);   // (multi-tile) 1: exchange rufrc, rvfrc and the AB3 history; 2: the kstp level of the barotropic state, wide
 void step2d_loop_dims(const roms_hip_ctx *c, int &nbx2, int &nby2);   // its sub-tile grid (the mailbox slab holds a ring of arrival words around it)
 int run_step2d_loop(roms_hip_ctx *c);       // c->G = the stepping of the predictor call of iif = 2, or of iif = 1: then the first fast

@@ -78,7 +78,7 @@ EXPORTS = ["roms_hip_create", "roms_hip_destroy", "roms_hip_last_error", "roms_h
            "roms_hip_set_stepping", "roms_hip_get_stepping", "roms_hip_wvelocity", "roms_hip_diag", "roms_hip_last_diag", "roms_hip_get_bounds", "roms_hip_output_point", "roms_hip_avg_config", "roms_hip_set_avg", "roms_hip_avg_time",
            "roms_hip_start", "roms_hip_main3d", "roms_hip_profile", "roms_hip_region_seconds",
            "roms_hip_kprof", "roms_hip_kprof_get", "roms_hip_kprof_stride", "roms_hip_kprof_window", "roms_hip_exchange_soak", "roms_hip_dia_config", "roms_hip_wetdry_ini", "roms_hip_set_diags", "roms_hip_dia_time", "roms_hip_kprof_batch", "roms_hip_set_exchange", "roms_hip_rccl_unique_id",
-           "roms_hip_comm_rccl", "roms_hip_peer_export", "roms_hip_comm_peer", "roms_hip_exchange_probe", "roms_hip_comm_reset", "roms_hip_exchange_count", "roms_hip_rccl_ranks", "roms_hip_copy_probe", "roms_hip_step_timing", "roms_hip_step_times"] + \
+           "roms_hip_comm_rccl", "roms_hip_peer_export", "roms_hip_comm_peer", "roms_hip_exchange_probe", "roms_hip_comm_reset", "roms_hip_exchange_count", "roms_hip_rccl_ranks", "roms_hip_copy_probe", "roms_hip_step_timing", "roms_hip_step_times", "roms_hip_rim_probe", "roms_hip_rim_disable"] + \
           ["roms_hip_" + k for k in KERNELS]
 
 

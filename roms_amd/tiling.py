@@ -88,6 +88,8 @@ class TiledRun:
             else:
                 raise ValueError(transport)
         self.transport = transport
+        if transport == "peer" and (world > 1 or self_exchange):
+            self.rim_check()
         self.host.start()
 
     # ------------------------------------------------------------------ transports
@@ -108,6 +110,24 @@ class TiledRun:
         if rc == 0 and soak:
             rc = L.roms_hip_exchange_soak(self.ctx.h, int(soak))
         return rc == 0, (L.roms_hip_last_error() or b"").decode() if rc else ""
+
+    def rim_check(self, reps=4):
+        """roms_hip_rim_probe on every rank (round 6): the rim planes through which the barotropic launches hand their rim to the
+        neighbouring ranks themselves, index-coded and verified on the device.  If ANY rank fails, EVERY rank keeps the exchange
+        launches instead (roms_hip_rim_disable) -- the decision is collective, the run goes on either way."""
+        L = self.ctx.L
+        if self.world > 1:
+            self.dist.barrier()              # (every rank's slab is mapped and zeroed before anyone publishes)
+        rc = L.roms_hip_rim_probe(self.ctx.h, reps)
+        why = (L.roms_hip_last_error() or b"").decode() if rc else ""
+        ok = self._all_ok(rc == 0) if self.world > 1 else rc == 0
+        self.probe_log.append({"rim_planes": "ok" if ok else "failed: exchanges kept", **({"why": why} if why else {})})
+        if not ok:
+            L.roms_hip_rim_disable(self.ctx.h)
+            if why:
+                import sys
+                print(f"[roms_amd] rank {self.rank}: {why}; the barotropic launches keep their exchanges", file=sys.stderr, flush=True)
+        return ok
 
     def _install_auto(self):
         """The mailbox transport where it works -- every rank could map its neighbours' slabs and the index-coded probe

@@ -1257,6 +1257,46 @@ def test_pair_launches_hand_their_rim_across_tile_edges(tmp_path):
 
 
 @pytest.mark.gpu
+def test_rim_planes_are_checked_before_a_run_trusts_them(monkeypatch):
+    """Round 6, include/roms_hip.h:roms_hip_rim_probe -- before a multi-tile run lets its barotropic launches hand their rim to the
+    neighbours through the rim planes, every rank publishes index-coded values of its own points into its neighbours' planes and
+    verifies its own ghost points on the device; the decision is collective (tiling.TiledRun.rim_check).  (i) the check passes in
+    the tiled form of BENCHMARK1 and the run uses the loop across the tile edge (12 exchange points per step); (ii) with one
+    plane left unpublished (ROMS_HIP_RIM_PROBE_BREAK, test aid) the check fails, names the plane, the run falls back to the
+    exchange launches of rounds 3-5 (40 per step) -- and both give the fields of the single-tile run bit for bit."""
+    import bench
+    from roms_amd import tiling
+    monkeypatch.setenv("ROMS_HIP_LOOP_TIMEOUT", "0.5")
+    fields = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "DU_avg1", "Zt_avg1", "rubar"]
+    steps = 3
+    cs = bench.params_for("benchmark1", ntimes=steps)
+    cs["ninfo"] = 0
+    run = tiling.TiledRun(cs, weak=False)
+    run.step(steps)
+    ref = {n: run.gather(n) for n in fields}
+    assert run.probe_log == []                     # (a single tile without a transport: nothing to check)
+    run.close()
+    for brk, lo, hi in ((None, 1, 16), ("5", 30, 99)):
+        if brk:
+            monkeypatch.setenv("ROMS_HIP_RIM_PROBE_BREAK", brk)
+        run = tiling.TiledRun(cs, weak=False, self_exchange=True, transport="peer")
+        log = [p for p in run.probe_log if "rim_planes" in p]
+        assert len(log) == 1
+        if brk:
+            assert log[0]["rim_planes"].startswith("failed") and "plane 5" in log[0]["why"] and "never arrived" in log[0]["why"], log
+        else:
+            assert log[0]["rim_planes"] == "ok", log
+        run.exchanges_per_step(0)
+        run.step(steps)
+        run.sync()
+        per = run.exchanges_per_step(steps)
+        assert lo <= per <= hi, (brk, per)
+        for n in fields:
+            assert np.array_equal(run.gather(n), ref[n]), (brk, n)
+        run.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("workload,steps", [("benchmark1", 200), ("benchmark1_mask", 100)])
 def test_tiled_form_over_many_steps_matches_single_tile(workload, steps):
     """The tiled form of BENCHMARK1 (its own W/E neighbour through the mailbox, the loop across the tile edge: 29 pairs per step,
