@@ -40,6 +40,8 @@ WORKLOADS = {
     "benchmark2": ("benchmark", 1024, 128, 30),
     "benchmark3": ("benchmark", 2048, 256, 30),
     "benchmark1_mask": ("benchmark_mask", 512, 64, 30),   # BENCHMARK1 with the host's analytic land: cost of a MASKING run
+    "benchmark1_closed": ("benchmark_closed", 512, 64, 30),            # ... as a closed basin (walls west and east instead of the periodic channel)
+    "benchmark1_mask_closed": ("benchmark_mask_closed", 512, 64, 30),
     "ns512": ("upwelling", 512, 512, 50),       # north_star roofline size (512x512x50); UPWELLING keeps
                                                 # 1 km cells at any size (BENCHMARK's shelf steepens with Mm)
     "ns512u3": ("upwelling_u3c4", 512, 512, 50),  # the same with U3/C4 advection for both tracers: the schemes
@@ -196,7 +198,10 @@ def params_for(workload, Lm=None, Mm=None, N=None, ntimes=10):
     from roms_amd import cases
     app, lm, mm, n = WORKLOADS[workload]
     Lm, Mm, N = Lm or lm, Mm or mm, N or n
-    if app == "benchmark":
+    if app.endswith("_closed"):
+        cs = params_for({"benchmark_closed": "benchmark1", "benchmark_mask_closed": "benchmark1_mask"}[app], Lm, Mm, N, ntimes)
+        cs["EWperiodic"] = 0
+    elif app == "benchmark":
         cs = cases.benchmark(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)
     elif app == "benchmark_mask":       # BENCHMARK with the host's analytic land (MASKING)
         cs = cases.benchmark_mask(Lm=Lm, Mm=Mm, N=N, ntimes=ntimes)

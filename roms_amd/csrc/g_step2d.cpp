@@ -373,15 +373,14 @@ static size_t loop_lds_doubles(bool masked = false) { return (size_t)(masked ? S
 // rank must take the same decision, so it depends on the partition, the transport and the environment only: equal tiles
 // (the neighbours' sub-tile grids continue mine), the mailbox installed with a loop region on every neighbour, no rank
 // sharing its device with another (the kernels of all ranks must be resident at the same time: ROMS_HIP_LOOP=1 forces it
-// for test set-ups that know their blocks fit side by side), at least one periodic direction (the kernel has no corner
-// averages of a closed basin), the 16x8 shape.
+// for test set-ups that know their blocks fit side by side), no open boundaries, the 16x8 shape.
 static bool loop_mt_usable(roms_hip_ctx *c, const DGrid &L, bool forced) {
   const DGrid &G = c->G;
   const roms_hip_config &cf = c->cfg;
   const TileComm &m = c->comm;
   if (!c->pair_mt || !m.peer_on || !m.loop_rim_off || c->rim_refused) return false;
   if (m.peer_shared && !forced) return false;
-  if (!(G.ewp || G.nsp) || G.obc || !loop_shape()) return false;
+  if (G.obc || !loop_shape()) return false;
   if (cf.Lm % cf.NtileI || cf.Mm % cf.NtileJ) return false;
   if (m.loop_nb2[0] != L.nbx2 || m.loop_nb2[1] != L.nby2) return false;
   const char *ewh = getenv("ROMS_HIP_LOOP_WHOLE");

@@ -439,6 +439,32 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           if (ce) KLOOP1(jb, vj0, vj1) LA(V1, Lm + 1, jb) = gamma2 * LA(V1, Lm, jb) * MK_(sVm, Lm + 1, jb);
         }
         KSYNC();
+        // corners of a closed basin (zetabc.F:753-782, u2dbc_im.F:1159-1188, v2dbc_im.F:1208-1237; as k_step2d_pair.h)
+        if (!(G.ewp || G.nsp)) {
+          if (t == 0) {
+            if (cw && cs) {
+              { const double v = 0.5 * (LA(Z1, 1, 0) + LA(Z1, 0, 1)); LA(Z1, 0, 0) = v; LA(D1, 0, 0) = v + LA(sH, 0, 0); }
+              LA(U1, 1, 0) = 0.5 * (LA(U1, 2, 0) + LA(U1, 1, 1));
+              LA(V1, 0, 1) = 0.5 * (LA(V1, 1, 1) + LA(V1, 0, 2));
+            }
+            if (ce && cs) {
+              { const double v = 0.5 * (LA(Z1, Lm, 0) + LA(Z1, Lm + 1, 1)); LA(Z1, Lm + 1, 0) = v; LA(D1, Lm + 1, 0) = v + LA(sH, Lm + 1, 0); }
+              LA(U1, Lm + 1, 0) = 0.5 * (LA(U1, Lm, 0) + LA(U1, Lm + 1, 1));
+              LA(V1, Lm + 1, 1) = 0.5 * (LA(V1, Lm, 1) + LA(V1, Lm + 1, 2));
+            }
+            if (cw && cn) {
+              { const double v = 0.5 * (LA(Z1, 0, Mm) + LA(Z1, 1, Mm + 1)); LA(Z1, 0, Mm + 1) = v; LA(D1, 0, Mm + 1) = v + LA(sH, 0, Mm + 1); }
+              LA(U1, 1, Mm + 1) = 0.5 * (LA(U1, 1, Mm) + LA(U1, 2, Mm + 1));
+              LA(V1, 0, Mm + 1) = 0.5 * (LA(V1, 0, Mm) + LA(V1, 1, Mm + 1));
+            }
+            if (ce && cn) {
+              { const double v = 0.5 * (LA(Z1, Lm + 1, Mm) + LA(Z1, Lm, Mm + 1)); LA(Z1, Lm + 1, Mm + 1) = v; LA(D1, Lm + 1, Mm + 1) = v + LA(sH, Lm + 1, Mm + 1); }
+              LA(U1, Lm + 1, Mm + 1) = 0.5 * (LA(U1, Lm + 1, Mm) + LA(U1, Lm, Mm + 1));
+              LA(V1, Lm + 1, Mm + 1) = 0.5 * (LA(V1, Lm + 1, Mm) + LA(V1, Lm, Mm + 1));
+            }
+          }
+          KSYNC();
+        }
 #undef MK_
 #undef LA
       }

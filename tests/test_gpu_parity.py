@@ -336,11 +336,12 @@ STEP2D_FORMS = [
     ("d_64x8", {"ROMS_HIP_TILE2D": "64x8"}),                           # k_step2d_d: 1024 threads (64 K .. 256 K points)
     ("b_64x8", {"ROMS_HIP_TILE2D": "64x8", "ROMS_HIP_S2D_1024": "0"}),  # k_step2d_b: 512 threads, two points each
     ("generic", {"ROMS_HIP_S2D_GENERIC": "1", "ROMS_HIP_PAIR": "0"}),  # run-time sub-tile shape
+    ("a_32x4_halo_launches", {"ROMS_HIP_PAIR": "0", "ROMS_HIP_FUSE_HALO": "0"}),   # boundary fills and periodic copies as launches of their own (k_halo.h)
     ("generic_48x6", {"ROMS_HIP_S2D_GENERIC": "1", "ROMS_HIP_TILE2D": "48x6"}),
 ]
 
 
-@pytest.mark.parametrize("workload,dims", [("benchmark1", (200, 44, 10)), ("ns512", (130, 70, 8))])
+@pytest.mark.parametrize("workload,dims", [("benchmark1", (200, 44, 10)), ("ns512", (130, 70, 8)), ("benchmark1_closed", (200, 44, 10))])
 def test_step2d_forms_match_oracle_and_each_other(workload, dims, tmp_path):
     """Every instantiation of the barotropic kernel (g_step2d.cpp picks one by grid size; the environment
     forces each here, in its own process: the switches are read once) on a grid with several sub-tiles in
@@ -401,8 +402,12 @@ def test_step2d_forms_match_oracle_and_each_other(workload, dims, tmp_path):
 
 
 @pytest.mark.gpu
-def test_persistent_loop_with_land_mask_matches_the_other_engines(tmp_path):
-    """Round 6: the persistent barotropic loop with MASKING (k_step2d_loop_bk: the masked statements of step2d_LF_AM3.h --
+@pytest.mark.parametrize("workload", ["benchmark1_mask", "benchmark1_mask_closed"])
+def test_persistent_loop_with_land_mask_matches_the_other_engines(workload, tmp_path):
+    """(benchmark1_mask_closed: the same as a closed basin -- walls west and east, the corner averages of zetabc.F:753,
+    u2dbc_im.F:1159, v2dbc_im.F:1208 with the masks of the boundary points -- where "halo_launches" is round 5's path: the
+    per-call kernel with the boundary fills as launches of their own.)
+    Round 6: the persistent barotropic loop with MASKING (k_step2d_loop_bk: the masked statements of step2d_LF_AM3.h --
     zeta * rmask :1002, ubar * umask :2560, the no-slip factors of pmask in the viscous stresses :1600, the masked gradient /
     slip values at closed edges, zetabc.F:264, u2dbc_im.F:989 -- on three more LDS tiles) against the pair launches and the
     per-call kernel on BENCHMARK with the host's analytic land, a ragged small grid: every state array bit for bit, in the
@@ -418,7 +423,7 @@ def test_persistent_loop_with_land_mask_matches_the_other_engines(tmp_path):
         import numpy as np
         import bench
         from roms_amd import tiling
-        cs = bench.params_for("benchmark1_mask", 200, 44, 10, ntimes=10)
+        cs = bench.params_for(%r, 200, 44, 10, ntimes=10)
         cs["ninfo"] = 1
         run = tiling.TiledRun(cs)
         run.step(4)
@@ -426,15 +431,16 @@ def test_persistent_loop_with_land_mask_matches_the_other_engines(tmp_path):
         np.savez(sys.argv[1], **{n: run.ctx.download(n) for n in %r})
         run.close()
         print("FORM-RUN-OK")
-    """) % (ROOT, names)
+    """) % (ROOT, workload, names)
     got = {}
-    for tag, env in (("loop", {}), ("loop_ref", {"ROMS_HIP_LATE_MASK": "0"}), ("pair", {"ROMS_HIP_LOOP": "0"}), ("percall", {"ROMS_HIP_PAIR": "0"})):
+    for tag, env in (("loop", {}), ("loop_ref", {"ROMS_HIP_LATE_MASK": "0"}), ("pair", {"ROMS_HIP_LOOP": "0"}), ("percall", {"ROMS_HIP_PAIR": "0"}),
+                     ("halo_launches", {"ROMS_HIP_PAIR": "0", "ROMS_HIP_FUSE_HALO": "0"})):
         f = str(tmp_path / (tag + ".npz"))
         r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, env=dict(os.environ, ROMS_HIP_LOOP_TIMEOUT="0.2", **env), timeout=600)
         assert "FORM-RUN-OK" in r.stdout, (tag, r.stdout[-1500:] + r.stderr[-3000:])
         got[tag] = dict(np.load(f))
     assert np.abs(got["loop"]["u"]).max() > 1e-4
-    for tag in ("loop_ref", "pair", "percall"):
+    for tag in ("loop_ref", "pair", "percall", "halo_launches"):
         for n in names:
             assert np.isfinite(got["loop"][n]).all(), n
             assert np.array_equal(got["loop"][n], got[tag][n]), (tag, n)
@@ -1313,8 +1319,11 @@ def test_tiled_form_over_many_steps_matches_single_tile(workload, steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tiles,port", [((2, 1), 29761), ((1, 2), 29762), ((2, 2), 29763)])
-def test_persistent_loop_between_processes_matches_single_tile(tmp_path, tiles, port):
+@pytest.mark.parametrize("tiles,port,workload,engine", [((2, 1), 29761, "benchmark1", "loop"), ((1, 2), 29762, "benchmark1", "loop"), ((2, 2), 29763, "benchmark1", "loop"),
+                                                        # a closed basin: every tile of the 2x2 partition holds a corner of the domain
+                                                        ((2, 2), 29764, "benchmark1_closed", "loop"), ((2, 2), 29765, "benchmark1_closed", "pair_rim"),
+                                                        ((2, 2), 29766, "benchmark1_mask_closed", "loop")])
+def test_persistent_loop_between_processes_matches_single_tile(tmp_path, tiles, port, workload, engine):
     """Round 6: the loop across REAL tile edges -- BENCHMARK1 512x64x30 split over 2 or 4 PROCESSES that share cuda:0, each
     mapping its neighbours' slabs over hipIpc: the neighbour is another rank's context with its own array origin, the
     periodic seam on one side of a tile and an interior tile boundary on the other (2x1), neighbours along eta (1x2), corner
@@ -1322,7 +1331,7 @@ def test_persistent_loop_between_processes_matches_single_tile(tmp_path, tiles, 
     launches: the kernels of all ranks must be resident at once -- here the 256 sub-tiles of all ranks together fill the
     256 CUs exactly, which the device grants when it is otherwise idle; a miss ends in a bounded wait, is retried once and
     then skipped, never hangs).  Gathered fields equal the single-tile run bit for bit, and the steps exchanged <= 20 times
-    each (the pair launches: 42)."""
+    each (the pair launches: 42).  engine "pair_rim": the pair launches handing their rim across instead of the loop."""
     import json
     import subprocess
     import sys
@@ -1331,17 +1340,19 @@ def test_persistent_loop_between_processes_matches_single_tile(tmp_path, tiles, 
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     fields = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "Hz", "Huon", "rho", "Akv", "DU_avg1", "Zt_avg1", "rubar"]
     steps = 4
-    cs = bench.params_for("benchmark1", ntimes=steps)
+    cs = bench.params_for(workload, ntimes=steps)
     cs["ninfo"] = 0
     run = tiling.TiledRun(cs, weak=False)
     run.step(steps)
     ref = {n: run.gather(n) for n in fields}
     run.close()
     out = str(tmp_path / "tiles_loop.npz")
-    spec = dict(workload="benchmark1", steps=steps, tiles=list(tiles), fields=fields, gpu=True, probe=True, transport="peer")
+    spec = dict(workload=workload, steps=steps, tiles=list(tiles), fields=fields, gpu=True, probe=True, transport="peer")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={tiles[0] * tiles[1]}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "mp", "run_tiles.py"), out, json.dumps(spec)]
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", ROMS_HIP_PEER_TIMEOUT="10", ROMS_HIP_LOOP="1", ROMS_HIP_LOOP_TIMEOUT="1.0")
+    if engine == "pair_rim":
+        env.update(ROMS_HIP_LOOP="0", ROMS_HIP_PAIR_RIM="1")
     for attempt in (0, 1):
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
         if p.returncode == 0:

@@ -17,9 +17,9 @@ code = textwrap.dedent("""
     cs["EWperiodic"] = 0
     cs["ninfo"] = 1
     run = tiling.TiledRun(cs)
-    run.step(4); run.sync()
+    run.step(int(sys.argv[4])); run.sync()
     names = ["zeta", "ubar", "vbar", "rzeta", "rubar", "rvbar", "Zt_avg1", "DU_avg1", "DU_avg2", "DV_avg1", "DV_avg2", "u", "v", "t", "W", "Hz", "rufrc"]
-    np.savez(sys.argv[1], **{n: run.ctx.download(n) for n in names})
+    np.savez(sys.argv[1], **{n: run.gather(n) for n in names})
     t0 = time.perf_counter(); run.step(40); run.sync(); t1 = time.perf_counter()
     print("MS", 1e3 * (t1 - t0) / 40)
     run.close()
@@ -31,13 +31,20 @@ for wl in ("benchmark1", "benchmark1_mask"):
         for tag, env in (("loop", {}), ("separate", {"ROMS_HIP_FUSE_CLOSED": "0"}), ("pair", {"ROMS_HIP_LOOP": "0"}), ("percall", {"ROMS_HIP_PAIR": "0"}),
                          ("percall_separate", {"ROMS_HIP_PAIR": "0", "ROMS_HIP_FUSE_CLOSED": "0"})):
             f = "/tmp/cl_%s.npz" % tag
-            r = subprocess.run([sys.executable, "-c", code, f, dims, wl], capture_output=True, text=True, env=dict(os.environ, ROMS_HIP_LOOP_TIMEOUT="0.2", **env), timeout=600)
+            r = subprocess.run([sys.executable, "-c", code, f, dims, wl, os.environ.get("CL_STEPS", "4")], capture_output=True, text=True, env=dict(os.environ, ROMS_HIP_LOOP_TIMEOUT="0.2", **env), timeout=600)
             ms = [l for l in r.stdout.splitlines() if l.startswith("MS")]
             if not ms:
                 print(tag, "FAILED", r.stdout[-500:], r.stderr[-1500:]); continue
             got[tag] = dict(np.load(f))
             print("CLOSEDLOOP", wl, dims or "full", tag, ms[-1], flush=True)
-        for tag in ("separate", "pair", "percall", "percall_separate"):
-            if tag in got and "loop" in got:
-                bad = [n for n in got["loop"] if not np.array_equal(got["loop"][n], got[tag][n])]
-                print("CLOSEDLOOP", wl, dims or "full", "loop vs", tag, "mismatching", bad, "finite", all(np.isfinite(got["loop"][n]).all() for n in got["loop"]), "moving", float(np.abs(got["loop"]["u"]).max()))
+        ref = got.get("percall_separate")
+        for tag in ("loop", "separate", "pair", "percall"):
+            if tag in got and ref is not None:
+                bad = [n for n in ref if not np.array_equal(ref[n], got[tag][n])]
+                where = ""
+                if bad:
+                    d = np.abs(got[tag]["zeta"] - ref["zeta"])
+                    d = d.reshape((-1,) + d.shape[-2:])
+                    jj, ii = np.nonzero(d.max(axis=0))
+                    where = "zeta differs at i(array) %s..%s j %s..%s, max %.3e" % (ii.min() if ii.size else None, ii.max() if ii.size else None, jj.min() if jj.size else None, jj.max() if jj.size else None, d.max())
+                print("CLOSEDLOOP", wl, dims or "full", tag, "vs percall_separate: mismatching", bad, where, "finite", all(np.isfinite(got[tag][n]).all() for n in ref), "moving", float(np.abs(ref["u"]).max()))
