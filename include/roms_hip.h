@@ -84,6 +84,10 @@ enum {
 #define ROMS_NUDGE_TCLM_ALL (15ull << 38)
 #define ROMS_NUDGE_M2CLM (1ull << 42)     /* LnudgeM2CLM of roms.in (round 6): nudging of ubar, vbar towards "ubarclm", "vbarclm" with "M2nudgcof"
                                              in every step2d call (step2d_LF_AM3.h:2179-2203); the per-call kernel carries it (no pair / loop launches) */
+#define ROMS_PRSGRD42 (1ull << 43)        /* PJ_GRADPQ2 (round 6): the finite-volume pressure Jacobian with parabolic WENO reconstruction of density,
+                                             prsgrd42.h:227-482.  A single tile only (its second pass reads rv(Iend+1,j), which no tile computes:
+                                             what a partition gives depends on the partition, in the reference too) */
+#define ROMS_PRSGRD44 (1ull << 44)        /* PJ_GRADPQ4 (round 6): ... with quartic reconstruction and power-law reconciliation, prsgrd44.h:224-508 */
 #define ROMS_DIAGNOSTICS_UV (1ull << 35)  /* roms_hip_dia_config allocates and switches on the momentum terms too (mod_diags.F:174-222) */
 
 /* GLS_MIXING: the cpp options that select a form of gls_prestep.F / gls_corstep.F (cppdefs.h names).  Stability

@@ -168,6 +168,7 @@ typedef struct orc_s {
   /* ... bit 5 of clima_flags: LnudgeM2CLM (step2d_LF_AM3.h:2179-2203), towards ubarclm, vbarclm with M2nudgcof (i,j) */
   double *ubarclm, *vbarclm, *M2nudgcof;
   int clima_flags;
+  int prs_scheme;                        /* 42: PJ_GRADPQ2 (prsgrd42.h), 44: PJ_GRADPQ4 (prsgrd44.h); 0: by the ORC_PRSGRD* bits (orc_set_prsgrd) */
   int uv_vis4, ts_dif4;                  /* biharmonic mixing along s-surfaces switched on (orc_set_mix4; orc_mix4.c) */
   int mix_geo_uv;                        /* UV_VIS2 along geopotential surfaces (MIX_GEO_UV; orc_set_geouv, orc_uvmix_geo.c) */
   double *tke, *gls, *Lscale, *Akk, *Akp;   /* GLS_MIXING: tke, gls(i,j,0:N,3); Lscale, Akk, Akp(i,j,0:N) */
@@ -310,6 +311,9 @@ typedef struct orc_diauv {
 } orc_diauv;
 /* biharmonic horizontal mixing along s-surfaces (UV_VIS4 + MIX_S_UV, TS_DIF4 + MIX_S_TS): orc_mix4.c */
 void orc_set_mix4(orc_t *o, int uv_vis4, int ts_dif4);
+void orc_prsgrd42(orc_t *o, int tile);                        /* orc_prs4x.c */
+void orc_prsgrd44(orc_t *o, int tile);
+void orc_set_prsgrd(orc_t *o, int scheme);                    /* prsgrd.F:16-19: PJ_GRADPQ4 -> prsgrd44.h, PJ_GRADPQ2 -> prsgrd42.h */
 void orc_set_clima(orc_t *o, int flags);                       /* climatology nudging: step3d_t.F:1866-1878, rhs3d.F:654-680 */
 void orc_set_geouv(orc_t *o, int on);                          /* MIX_GEO_UV: uv3dmix2_geo.h in place of uv3dmix2_s.h */
 void orc_uv3dmix2_geo(orc_t *o, int tile);

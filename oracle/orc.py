@@ -168,6 +168,11 @@ class Oracle:
         roots of the coefficients"""
         self.L.orc_set_mix4(C.c_void_p(self.h), int(uv_vis4), int(ts_dif4))
 
+    def set_prsgrd(self, scheme):
+        """the pressure-gradient scheme of prsgrd.F:16-26 beyond the option bits: 42 = PJ_GRADPQ2 (prsgrd42.h), 44 = PJ_GRADPQ4
+        (prsgrd44.h); 0 = what the ORC_PRSGRD* bits say"""
+        self.L.orc_set_prsgrd(C.c_void_p(self.h), int(scheme))
+
     def set_clima(self, flags):
         """climatology nudging on: bit 0 = 3-D momentum (fields "uclm", "vclm", "M3nudgcof"), bit itrc = tracer itrc (fields
         "tclm", "Tnudgcof": N planes per tracer, tracer-major)"""

@@ -110,6 +110,7 @@ static void alloc_bounds(orc_cfg *c) {
 /* ------------------------------------------------------------------- state */
 
 void orc_set_clima(orc_t *o, int flags) { o->clima_flags = flags; }
+void orc_set_prsgrd(orc_t *o, int scheme) { o->prs_scheme = scheme; }
 
 static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
 

@@ -569,7 +569,9 @@ static void orc_prsgrd40(orc_t *o, int tile) {
 
 static void orc_prsgrd32(orc_t *o, int tile);
 void orc_prsgrd(orc_t *o, int tile) {
-  if (o->c.options & ORC_PRSGRD40) orc_prsgrd40(o, tile);
+  if (o->prs_scheme == 44) orc_prsgrd44(o, tile);              /* prsgrd.F:16-19: PJ_GRADPQ4, then PJ_GRADPQ2, come first */
+  else if (o->prs_scheme == 42) orc_prsgrd42(o, tile);
+  else if (o->c.options & ORC_PRSGRD40) orc_prsgrd40(o, tile);
   else if (o->c.options & ORC_PRSGRD31) orc_prsgrd31(o, tile);
   else orc_prsgrd32(o, tile);
   if (o->duv) {        /* DIAGNOSTICS_UV: DiaRU(i,j,k,nrhs,M3pgrd) = ru(i,j,k,nrhs) where every scheme assigns it (prsgrd32.h:364, :428) */

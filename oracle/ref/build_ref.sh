@@ -80,8 +80,9 @@ if [ "$APP" = upwelling_avg_mask ]; then
   UP=UPWELLING; HDR=upwelling_avg_mask; HDRPATH="$HERE/upwelling_avg_mask.h"
   EXTRA="-I$HERE/functionals"
 fi
-if [ "$APP" = upwelling_prs31 ] || [ "$APP" = upwelling_wjgradp ] || [ "$APP" = upwelling_prs40 ]; then
-  # UPWELLING with the standard density Jacobian prsgrd31.h (no DJ_GRADPS; _wjgradp: WJ_GRADP, its weighted form); _prs40: PJ_GRADP, prsgrd40.h
+if [ "$APP" = upwelling_prs31 ] || [ "$APP" = upwelling_wjgradp ] || [ "$APP" = upwelling_prs40 ] || [ "$APP" = upwelling_prs42 ] || [ "$APP" = upwelling_prs44 ]; then
+  # UPWELLING with the standard density Jacobian prsgrd31.h (no DJ_GRADPS; _wjgradp: WJ_GRADP, its weighted form); _prs40: PJ_GRADP, prsgrd40.h;
+  # _prs42: PJ_GRADPQ2, prsgrd42.h; _prs44: PJ_GRADPQ4, prsgrd44.h
   UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
   EXTRA=""
 fi

@@ -162,6 +162,15 @@ def upwelling_prs40(**kw):
     return cs
 
 
+def upwelling_prs4x(scheme=44, **kw):
+    """UPWELLING with the finite-volume pressure Jacobians of Shchepetkin & McWilliams (2003): prsgrd42.h (PJ_GRADPQ2, scheme 42)
+    or prsgrd44.h (PJ_GRADPQ4, scheme 44); the custom application headers oracle/ref/upwelling_prs42.h, upwelling_prs44.h"""
+    cs = upwelling(**kw)
+    cs["app"] = "upwelling_prs%d" % scheme
+    cs["prsgrd"] = int(scheme)
+    return cs
+
+
 def upwelling_bih(visc4=4.0e8, tnu4=(2.0e7, 1.0e7), **kw):
     """UPWELLING with biharmonic mixing of momentum and tracers along s-surfaces (UV_VIS4, TS_DIF4: the custom application
     header oracle/ref/upwelling_bih.h) in place of the harmonic operators; VISC4, TNU4 [m4/s] as roms.in gives them"""
@@ -440,6 +449,8 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
         opt |= (hiplib.OPTIONS["UV_VIS4"] if cs["mix4"][0] else 0) | (hiplib.OPTIONS["TS_DIF4"] if cs["mix4"][1] else 0)
     if cs.get("mix_geo_uv"):
         opt |= hiplib.OPTIONS["MIX_GEO_UV"]
+    if cs.get("prsgrd"):    # PJ_GRADPQ2 / PJ_GRADPQ4
+        opt |= hiplib.OPTIONS["PRSGRD%d" % cs["prsgrd"]]
     if cs.get("clima"):     # climatology nudging: bit 0 the 3-D momentum, bit itrc tracer itrc
         opt |= hiplib.OPTIONS["NUDGE_M3CLM"] if cs["clima"] & 1 else 0
         opt |= hiplib.OPTIONS["NUDGE_M2CLM"] if cs["clima"] & 32 else 0

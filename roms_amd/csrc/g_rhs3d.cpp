@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include "k_rhs3d.h"
 #include "k_mix4.h"
+#include "k_prs4x.h"
 #ifndef ROMS_CPU_EMU
 #include "k_rhs3d_lds.h"
 #include "k_tadv_lds.h"
@@ -154,6 +155,19 @@ int run_prsgrd(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   KArgs a = mk(c);
+  if (G.prs4x) {     // PJ_GRADPQ4, PJ_GRADPQ2 (prsgrd.F:16-19: in front of every other scheme)
+    const bool q4 = G.prs4x == 44;
+    a.p1 = q4 ? 44 : 42;
+    const int e = q4 ? 0 : 1;          // prsgrd42 reconstructs one more column each way (:238: JstrV-2:Jend+1, IstrU-2:Iend+1)
+    LAUNCH_THREAD(k_prs4x_col, (B.Iend + e) - (B.IstrU - 1 - e) + 1, (B.Jend + e) - (B.JstrV - 1 - e) + 1, 1, c->stream, a);
+    if (q4) {
+      LAUNCH_THREAD(k_prs44_grad, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+    } else {
+      LAUNCH_THREAD(k_prs42_grad1, (B.Iend + 1) - (B.IstrU - 1) + 1, (B.Jend + 1) - (B.JstrV - 1) + 1, 2, c->stream, a);
+      LAUNCH_THREAD(k_prs42_grad2, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+    }
+    return run_duv_pgrd(c);
+  }
   if (G.options & ROMS_PRSGRD40) {     // PJ_GRADP: prsgrd40.h
     LAUNCH_THREAD(k_prs40, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
     return run_duv_pgrd(c);

@@ -78,6 +78,7 @@ struct DGrid {
   // step2d_LF_AM3.h:1653-1920), TS_DIF4 + MIX_S_TS (t3dmix4_s.h); coefficient arrays visc4_r, visc4_p, diff4
   int uv_vis4, ts_dif4;
   int clima;           // climatology nudging: bit 0 LnudgeM3CLM (rhs3d.F:654), bit itrc LtracerCLM & LnudgeTCLM of tracer itrc (step3d_t.F:1866)
+  int prs4x;           // 44: PJ_GRADPQ4 (prsgrd44.h), 42: PJ_GRADPQ2 (prsgrd42.h); 0: the scheme the lower option bits name (k_prs4x.h)
   int mix_geo_uv;      // UV_VIS2 along geopotential surfaces (option bit ROMS_MIX_GEO_UV; k_uvmix_geo.h, work arrays Fields::gwrk)
   signed char m2[12], m3[12];
   short ndm2, ndm3, ndrhs;

@@ -642,6 +642,16 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     if (c->G.clima & 30) c->G.fuse3d = 0;
     if (c->G.clima & 32) { c->pair_on = step2d_pair_usable(c); c->loop_state = 0; }     // (LnudgeM2CLM: the per-call barotropic kernel)                    // (the nudging sits between t3dbc and the exchange: separate launches)
   }
+  c->G.prs4x = (cfg->options & ROMS_PRSGRD44) ? 44 : ((cfg->options & ROMS_PRSGRD42) ? 42 : 0);     // prsgrd.F:16-19
+  if (c->G.prs4x) {
+    if (c->G.prs4x == 42 && cfg->NtileI * cfg->NtileJ != 1) {
+      set_error("PJ_GRADPQ2 (prsgrd42.h) on more than one tile: its second pass reads rv(Iend+1,j,k) (prsgrd42.h:449), a column no tile computes -- "
+                "the reference's own result depends on the partition; a single tile, or PJ_GRADPQ4");
+      roms_hip_destroy(c); return 5;
+    }
+    if (cfg->options & ROMS_WET_DRY) { set_error("WET_DRY: the density Jacobian prsgrd32.h only (DJ_GRADPS)"); roms_hip_destroy(c); return 5; }
+    if (c->G.N < 3) { set_error("PJ_GRADPQ2 / PJ_GRADPQ4: the reconstruction needs three levels"); roms_hip_destroy(c); return 5; }
+  }
   if (cfg->options & ROMS_MIX_GEO_UV) {                     // uv3dmix2_geo.h (k_uvmix_geo.h): twenty 3-D work arrays
     if (!(cfg->options & ROMS_UV_VIS2) || c->G.uv_vis4) { set_error("MIX_GEO_UV: the harmonic viscosity only (UV_VIS2; uv3dmix4_geo.h is not built)"); roms_hip_destroy(c); return 5; }
     if (c->G.obc) { set_error("MIX_GEO_UV with open boundaries: not pinned"); roms_hip_destroy(c); return 5; }
@@ -2157,7 +2167,7 @@ static bool late_schedule_ok(roms_hip_ctx *c) {
   static const char *eml = getenv("ROMS_HIP_MT_LANES");
   const bool tiles_ok = !c->has_exchange || (c->comm.peer_on && !c->x_async && (step2d_loop_usable(c) || (c->pair_mt && c->pair_on && !(eml && eml[0] == '0'))));
   return tiles_ok && !uvcol && !c->G.dia_ts && !c->G.dia_uv && !c->G.uv_vis4 && !c->G.ts_dif4 && !c->G.mix_geo_uv && (!c->G.masking || (elm ? elm[0] == '1' : step2d_loop_usable(c))) &&
-         !(elate && elate[0] == '0') && !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_GLS_MIXING | ROMS_MY25_MIXING));
+         !(elate && elate[0] == '0') && !(cf.options & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_PRSGRD42 | ROMS_PRSGRD44 | ROMS_GLS_MIXING | ROMS_MY25_MIXING));
 }
 // ... and the one around the persistent barotropic loop: 0 = no, else its form (ROMS_HIP_LOOP_SCHED: 0 = the loop inside the
 // late-predictor schedule, 1 = pre_step3d / t3dmix2 in front of the loop: the default since their mixing terms are folded
@@ -2419,7 +2429,7 @@ static int wetdry_config(roms_hip_ctx *c, double Dcrit) {
     return 5;
   }
   if ((opt & ROMS_MIX_ISO_TS) || G.uv_vis4 || G.ts_dif4) { set_error("WET_DRY: harmonic mixing along s-surfaces or geopotentials only (t3dmix2_s.h, t3dmix2_geo.h, uv3dmix2_s.h)"); return 5; }
-  if (opt & (ROMS_PRSGRD31 | ROMS_PRSGRD40)) { set_error("WET_DRY: the density Jacobian prsgrd32.h only (DJ_GRADPS)"); return 5; }
+  if (opt & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_PRSGRD42 | ROMS_PRSGRD44)) { set_error("WET_DRY: the density Jacobian prsgrd32.h only (DJ_GRADPS)"); return 5; }
   if (opt & (ROMS_PLAIN_VVISC)) { set_error("WET_DRY: SPLINES_VVISC only"); return 5; }
   if (G.dia_ts || G.dia_uv || c->avg_nAVG > 0) { set_error("WET_DRY: the wet/dry masks of set_avg.F / set_diags.F are not built"); return 5; }
   if (!c->F.wd_eff) {

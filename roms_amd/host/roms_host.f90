@@ -32,6 +32,7 @@
       logical :: mix4(2) = .FALSE.
       real(dp) :: Dcrit = 0.10_dp              ! DCRIT of roms.in (WET_DRY; read_phypar.F:1021)
       logical :: wet_dry = .FALSE.
+      integer :: prs4x = 0                      ! 44: PJ_GRADPQ4 (prsgrd44.h), 42: PJ_GRADPQ2 (prsgrd42.h), 0: the scheme in `options`
       logical :: mix_geo_uv = .FALSE.           ! UV_VIS2 along geopotential surfaces (MIX_GEO_UV: uv3dmix2_geo.h)
       real(dp) :: visc2 = 5.0_dp, tnu2(ROMS_MAXT) = 0.0_dp, Akt_bak(ROMS_MAXT) = 1.0E-6_dp, Akv_bak = 1.0E-5_dp
       real(dp) :: rdrg = 3.0E-4_dp, rdrg2 = 3.0E-3_dp, Zob = 0.02_dp, Zos = 0.02_dp, gamma2 = 1.0_dp
@@ -818,8 +819,13 @@
 !  oracle/ref/upwelling_geouv.h: MASKING and the harmonic viscosity along geopotentials, MIX_GEO_UV)
         IF (MyAppCPP(1:13).eq.'UPWELLING_BIH'.and.(TRIM(common(k)).eq.'UV_VIS2'.or.TRIM(common(k)).eq.'TS_DIF2')) CYCLE
         IF (TRIM(MyAppCPP).eq.'UPWELLING_GEOUV'.and.TRIM(common(k)).eq.'MIX_S_UV') CYCLE
+!  (UPWELLING_PRS40 / _PRS42 / _PRS44 = oracle/ref/upwelling_prs40.h ...: PJ_GRADP / PJ_GRADPQ2 / PJ_GRADPQ4 in DJ_GRADPS' place)
+        IF (MyAppCPP(1:14).eq.'UPWELLING_PRS4'.and.TRIM(common(k)).eq.'DJ_GRADPS') CYCLE
         CALL define (TRIM(common(k)))
       END DO
+      IF (TRIM(MyAppCPP).eq.'UPWELLING_PRS40') CALL define ('PJ_GRADP')
+      IF (TRIM(MyAppCPP).eq.'UPWELLING_PRS42') CALL define ('PJ_GRADPQ2')
+      IF (TRIM(MyAppCPP).eq.'UPWELLING_PRS44') CALL define ('PJ_GRADPQ4')
       IF (MyAppCPP(1:13).eq.'UPWELLING_BIH') THEN
         CALL define ('UV_VIS4'); CALL define ('TS_DIF4')
       END IF
@@ -864,8 +870,8 @@
       CALL define ('ANA_INITIAL'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
       SELECT CASE (TRIM(MyAppCPP))
         CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK', 'UPWELLING_BIH', 'UPWELLING_WETDRY',  &  ! (oracle/ref/upwelling_logdrag.h, _mask.h, _bih.h, _wetdry.h)
-     &        'UPWELLING_BIHGEO', 'UPWELLING_BIHISO', 'UPWELLING_GEOUV',                                              &
-     &        'UPWELLING_GLS', 'UPWELLING_GLS_CA', 'UPWELLING_GLS_CB', 'UPWELLING_GLS_GAL', 'UPWELLING_MY25',         &
+     &        'UPWELLING_BIHGEO', 'UPWELLING_BIHISO', 'UPWELLING_GEOUV', 'UPWELLING_PRS40', 'UPWELLING_PRS42',          &
+     &        'UPWELLING_PRS44', 'UPWELLING_GLS', 'UPWELLING_GLS_CA', 'UPWELLING_GLS_CB', 'UPWELLING_GLS_GAL', 'UPWELLING_MY25',         &
      &        'UPWELLING_MY25_GAL')
 !  UPWELLING_GLS = upwelling.h built with -DGLS_MIXING; _CA, _CB, _GAL = oracle/ref/upwelling_gls_ca.h, _cb.h, _gal.h: the
 !  other compile-time forms of the closure the library is pinned in
@@ -935,7 +941,8 @@
      &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
      &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D, ROMS_GLS_MIXING, ROMS_MY25_MIXING, ROMS_MIX_ISO_TS ]
 !  options whose code is the only form built (accepted, nothing to select) or that only affect output
-      character(len=16), parameter :: inherent(35) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', 'PJ_GRADP', &
+      character(len=16), parameter :: inherent(37) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', 'PJ_GRADP', &
+     &    'PJ_GRADPQ2', 'PJ_GRADPQ4', &
      &    'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
      &    'DJ_GRADPS', 'MIX_S_UV', 'MIX_S_TS', 'SPLINES_VDIFF', 'SPLINES_VVISC', 'UV_LDRAG', 'ANA_SMFLUX',        &
      &    'ANA_STFLUX', 'ANA_SSFLUX', 'ANA_BTFLUX', 'ANA_BSFLUX', 'ANA_SRFLUX', 'LMD_RIMIX', 'LMD_CONVEC',        &
@@ -953,7 +960,7 @@
       upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
      &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING').or.    &
      &    MyAppCPP(1:13).eq.'UPWELLING_BIH'.or.TRIM(MyAppCPP).eq.'UPWELLING_WETDRY'.or.                             &
-     &    TRIM(MyAppCPP).eq.'UPWELLING_GEOUV'.or.                                                                     &
+     &    TRIM(MyAppCPP).eq.'UPWELLING_GEOUV'.or.MyAppCPP(1:14).eq.'UPWELLING_PRS4'.or.                                &
      &    MyAppCPP(1:13).eq.'UPWELLING_GLS'.or.MyAppCPP(1:14).eq.'UPWELLING_MY25'
       bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.TRIM(MyAppCPP).eq.'BENCHMARK_MASK'.or.is_defined('BENCHMARK')
       kelv=TRIM(MyAppCPP).eq.'KELVIN'.or.TRIM(MyAppCPP).eq.'KELVIN_SPLINES'.or.is_defined('KELVIN')
@@ -1005,9 +1012,14 @@
 !  the pressure-gradient scheme (prsgrd.F:16-26): DJ_GRADPS -> prsgrd32.h; none of the four options -> prsgrd31.h, WJ_GRADP its
 !  weighted form
 !  (prsgrd.F tests PJ_GRADPQ4, PJ_GRADPQ2, PJ_GRADP, DJ_GRADPS in this order)
-      IF (is_defined('PJ_GRADPQ2').or.is_defined('PJ_GRADPQ4'))                                                &
-     &  CALL unsupported ('PJ_GRADPQ2 / PJ_GRADPQ4 (prsgrd42/44.h) are not built', ierr)
-      IF (is_defined('PJ_GRADP')) THEN
+      prs4x=0
+      IF (is_defined('PJ_GRADPQ4')) THEN
+        prs4x=44                                  ! (upper word of cfg%options: ROMS_PRSGRD44, below)
+      ELSE IF (is_defined('PJ_GRADPQ2')) THEN
+        prs4x=42
+        IF (NtileI*NtileJ.ne.1) CALL unsupported ('PJ_GRADPQ2 (prsgrd42.h) on more than one tile: its second pass reads '//  &
+     &    'rv(Iend+1,j,k), which no tile computes (prsgrd42.h:449) -- a single tile, or PJ_GRADPQ4', ierr)
+      ELSE IF (is_defined('PJ_GRADP')) THEN
         options=IOR(options, ROMS_PRSGRD40)
       ELSE IF (.not.is_defined('DJ_GRADPS')) THEN
         options=IOR(options, ROMS_PRSGRD31)
@@ -1025,7 +1037,7 @@
 !  solar source of pre_step3d, t3dmix2_geo, mpdata_adiff.  The combinations whose WET_DRY statements the library does not
 !  carry stop here
       IF (wet_dry.and.(IAND(options, IOR(ROMS_GLS_MIXING, IOR(ROMS_MY25_MIXING, IOR(ROMS_MIX_ISO_TS,                      &
-     &    IOR(ROMS_PRSGRD31, ROMS_PRSGRD40))))).ne.0.or.ANY(mix4)))                                                      &
+     &    IOR(ROMS_PRSGRD31, ROMS_PRSGRD40))))).ne.0.or.ANY(mix4).or.prs4x.ne.0))                                        &
      &  CALL unsupported ('WET_DRY is built with ANA_VMIX or LMD_MIXING, analytic or bulk fluxes, harmonic mixing along '//  &
      &                    's-surfaces or geopotentials and DJ_GRADPS (not with GLS_MIXING, MY25_MIXING, MIX_ISO_TS, '//  &
      &                    'UV_VIS4, TS_DIF4, other pressure Jacobians)', ierr)
@@ -2035,6 +2047,8 @@
       IF (mix4(2)) cfg%options=IOR(cfg%options, ROMS_TS_DIF4)
       IF (wet_dry) cfg%options=IOR(cfg%options, ROMS_WET_DRY)
       IF (mix_geo_uv) cfg%options=IOR(cfg%options, ROMS_MIX_GEO_UV)
+      IF (prs4x.eq.44) cfg%options=IOR(cfg%options, ROMS_PRSGRD44)
+      IF (prs4x.eq.42) cfg%options=IOR(cfg%options, ROMS_PRSGRD42)
       cfg%Dcrit=Dcrit
       IF (nDIA.gt.0.and.diag_uv.and.(ANY(DoutM2).or.ANY(DoutM3)).and.IAND(options,ROMS_PLAIN_VVISC).eq.0) THEN
         cfg%options=IOR(cfg%options, ROMS_DIAGNOSTICS_UV)

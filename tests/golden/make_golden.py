@@ -288,6 +288,8 @@ STEP_CASES = [
     # the generic length-scale closure: upwelling.h -DGLS_MIXING (Kantha-Clayson, k-epsilon), Canuto A masked ("gen"),
     # Canuto B with CHARNOK / CRAIG_BANNER / K_C2ADVECTION (k-kl)
     ("upwelling_small_prs40", "upwelling_prs40_small", ["nsteps=60"]),       # PJ_GRADP, prsgrd40.h
+    ("upwelling_small_prs42", "upwelling_prs42_small", ["nsteps=60"]),       # PJ_GRADPQ2, prsgrd42.h (one tile: its second pass, oracle/orc_prs4x.c)
+    ("upwelling_small_prs44", "upwelling_prs44_small", ["nsteps=60"]),       # PJ_GRADPQ4, prsgrd44.h
     ("upwelling_small_bih", "upwelling_bih_small", ["nsteps=60"]),           # UV_VIS4 + TS_DIF4 along s-surfaces (upwelling_bih.h)
     ("upwelling_small_geouv", "upwelling_geouv_small", ["nsteps=60"]),       # UV_VIS2 along geopotentials under MASKING (uv3dmix2_geo.h; upwelling_geouv.h)
     ("upwelling_small_bihiso", "upwelling_bihiso_small", ["nsteps=60"]),     # ... along isopycnals (t3dmix4_iso.h; upwelling_bihiso.h)

@@ -43,6 +43,8 @@ CASES = {
     "upwelling_prs31_small": ("upwelling_prs31", dict(Lm=14, Mm=18, N=8)),
     "upwelling_wjgradp_small": ("upwelling_wjgradp", dict(Lm=14, Mm=18, N=8, wj=True)),
     "upwelling_prs40_small": ("upwelling_prs40", dict(Lm=14, Mm=18, N=8)),          # PJ_GRADP, prsgrd40.h
+    "upwelling_prs42_small": ("upwelling_prs42", dict(Lm=14, Mm=18, N=8, scheme=42)),   # PJ_GRADPQ2, prsgrd42.h
+    "upwelling_prs44_small": ("upwelling_prs44", dict(Lm=14, Mm=18, N=8, scheme=44)),   # PJ_GRADPQ4, prsgrd44.h
     # biharmonic mixing along s-surfaces (oracle/ref/upwelling_bih.h: UV_VIS4, TS_DIF4)
     # harmonic viscosity along geopotential surfaces under MASKING (oracle/ref/upwelling_geouv.h: MIX_GEO_UV, uv3dmix2_geo.h)
     "upwelling_geouv_small": ("upwelling_geouv", dict(Lm=14, Mm=18, N=8)),
@@ -156,7 +158,7 @@ def make_case(tag, **kw):
                 upwelling_avg=cases.upwelling, upwelling_diag=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag, upwelling_noadv=cases.upwelling_noadv,
                 upwelling_mask=cases.upwelling_mask, upwelling_wetdry=cases.upwelling_wetdry, benchmark_mask=cases.benchmark_mask, benchmark_wetdry=cases.benchmark_wetdry,
                 upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
-                upwelling_wjgradp=cases.upwelling_prs31, upwelling_prs40=cases.upwelling_prs40, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
+                upwelling_wjgradp=cases.upwelling_prs31, upwelling_prs40=cases.upwelling_prs40, upwelling_prs42=cases.upwelling_prs4x, upwelling_prs44=cases.upwelling_prs4x, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
                 upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]
     lbc = k.pop("lbc", None)
@@ -224,6 +226,8 @@ def oracle_from(R, cs):
         O.set_wetdry(cs["Dcrit"])
     if cs.get("mix_geo_uv"):
         O.set_geouv()
+    if cs.get("prsgrd"):
+        O.set_prsgrd(cs["prsgrd"])
     if cs.get("clima"):
         O.set_clima(cs["clima"])
         for n, a in cases.clima_arrays(cs, O.ni * O.nj).items():

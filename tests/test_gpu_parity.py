@@ -821,6 +821,7 @@ DETERMINISM_SMALL = [
     ("upwelling_mask_small", {}), ("seamount_small", {}), ("grav_adj_small", {}), ("overflow_small", {}),
     ("kelvin_small", {}), ("kelvin_plain_small", {}), ("upwelling_gls_small", {}), ("upwelling_my25_small", {}),
     ("upwelling_prs31_small", {}), ("upwelling_prs40_small", {}), ("upwelling_logdrag_small", {}), ("upwelling_bih_small", {}),
+    ("upwelling_prs42_small", {}), ("upwelling_prs44_small", {}),
     ("upwelling_wetdry_small", {}),
 ]
 
@@ -991,7 +992,7 @@ XI_PARTNER = dict(u="v", ubar="vbar", Huon="Hvom", ru="rv", DU_avg1="DV_avg1", D
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["seamount_small", "grav_adj_small", "overflow_small", "upwelling_prs31_small", "upwelling_wjgradp_small", "upwelling_prs40_small",
-                                 "upwelling_bih_small"])
+                                 "upwelling_prs42_small", "upwelling_prs44_small", "upwelling_bih_small"])
 def test_more_reference_applications_match_oracle(tag):
     """SEAMOUNT, GRAV_ADJ and OVERFLOW (the reference's own test applications, oracle pinned bit for bit; OVERFLOW with
     MIX_ISO_TS and spline vertical advection of both tracers): 40 steps on the GPU at the north-star tolerance."""

@@ -249,7 +249,9 @@ def test_masking_option_and_analytic_masks(tmp_path):
 
 
 def test_pressure_gradient_scheme_follows_the_header(tmp_path):
-    """prsgrd.F:16-26: DJ_GRADPS -> prsgrd32.h; none of the options -> prsgrd31.h (WJ_GRADP: weighted); PJ_GRADP -> prsgrd40.h; the quadratic PJ schemes stop"""
+    """prsgrd.F:16-26: DJ_GRADPS -> prsgrd32.h; none of the options -> prsgrd31.h (WJ_GRADP: weighted); PJ_GRADP -> prsgrd40.h;
+    PJ_GRADPQ2 / PJ_GRADPQ4 -> prsgrd42.h / prsgrd44.h (round 6: bits of the upper option word; they win over every other
+    scheme, as prsgrd.F tests them first)"""
     from roms_amd import hiplib, hostlib
     ref = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "oracle", "ref"))
     for hdr, p31, wj in (("upwelling_prs31.h", True, False), ("upwelling_wjgradp.h", True, True), ("upwelling_logdrag.h", False, False)):
@@ -263,11 +265,19 @@ def test_pressure_gradient_scheme_follows_the_header(tmp_path):
         assert H.dims["options"] & hiplib.OPTIONS["PRSGRD40"] and not H.dims["options"] & hiplib.OPTIONS["PRSGRD31"]
     finally:
         H.finalize()
-    bad = tmp_path / "pj.h"
-    bad.write_text(open(os.path.join(ref, "upwelling_prs31.h")).read() + "\n#define PJ_GRADPQ4\n")
-    with pytest.raises(hostlib.HostError) as e:
-        _setup(tmp_path, header=str(bad)).finalize()
-    assert e.value.exit_flag == 5 and "PJ_GRADPQ4" in str(e.value)
+    for hdr in ("upwelling_prs42.h", "upwelling_prs44.h"):
+        H = _setup(tmp_path, header=os.path.join(ref, hdr))
+        try:
+            assert not H.dims["options"] & (hiplib.OPTIONS["PRSGRD40"] | hiplib.OPTIONS["PRSGRD31"])
+        finally:
+            H.finalize()
+    both = tmp_path / "pj.h"                                      # (PJ_GRADPQ4 in front of PJ_GRADP: prsgrd.F:16)
+    both.write_text(open(os.path.join(ref, "upwelling_prs40.h")).read() + "\n#define PJ_GRADPQ4\n")
+    H = _setup(tmp_path, header=str(both))
+    try:
+        assert not H.dims["options"] & hiplib.OPTIONS["PRSGRD40"]
+    finally:
+        H.finalize()
 
 
 def test_logdrag_header_selects_the_option(tmp_path):
@@ -359,7 +369,7 @@ def test_application_header_is_read_like_cpp_would(tmp_path):
 
 
 @pytest.mark.parametrize("line,needle", [("#define TS_DIF4", "TS_DIF4"), ("#define GLS_MIXING", "GLS_MIXING"),
-                                         ("#define WET_DRY\n#undef DJ_GRADPS", "WET_DRY"), ("#define PJ_GRADPQ2", "PJ_GRADPQ2"),
+                                         ("#define WET_DRY\n#undef DJ_GRADPS", "WET_DRY"), ("#define LMD_DDMIX", "LMD_DDMIX"),
                                          ("#define UV_QDRAG", "exactly one of UV_LDRAG, UV_QDRAG, UV_LOGDRAG")])
 def test_application_header_with_unbuilt_options_stops(tmp_path, line, needle):
     """An option whose code is not in the library (biharmonic mixing, GLS, wetting and drying with the standard density

@@ -541,9 +541,11 @@ def test_more_reference_applications_bitwise(emu, tag):
     H.close()
 
 
-@pytest.mark.parametrize("tag", ["upwelling_prs31_small", "upwelling_wjgradp_small", "upwelling_prs40_small"])
+@pytest.mark.parametrize("tag", ["upwelling_prs31_small", "upwelling_wjgradp_small", "upwelling_prs40_small", "upwelling_prs42_small", "upwelling_prs44_small"])
 def test_standard_density_jacobian_bitwise(emu, tag):
-    """prsgrd31.h (an application without DJ_GRADPS; WJ_GRADP: the weighted form), k_prs31: 8 steps against the oracle
+    """(upwelling_prs42 / _prs44, round 6: PJ_GRADPQ2 / PJ_GRADPQ4, the finite-volume Jacobians with a reconstructed density
+    profile, prsgrd42.h / prsgrd44.h -- k_prs4x.h; pinned the same way, oracle/orc_prs4x.c.)
+    prsgrd31.h (an application without DJ_GRADPS; WJ_GRADP: the weighted form), k_prs31: 8 steps against the oracle
     (pinned to the reference built from oracle/ref/upwelling_prs31.h / upwelling_wjgradp.h), bit for bit; the result differs
     from the prsgrd32.h run.  upwelling_prs40: PJ_GRADP, the finite-volume scheme prsgrd40.h (k_prs40), pinned the same way."""
     cs = util.case_for(tag)

@@ -251,6 +251,14 @@ MAIN3D_CASES = [
     # the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h (PJ_GRADP)
     ("upwelling_prs40_small", ["nsteps=60"]),
     ("upwelling_prs40_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # the finite-volume Jacobians of Shchepetkin & McWilliams (2003) with a reconstructed density profile (round 6): prsgrd44.h
+    # (PJ_GRADPQ4: quartic, power-law reconciliation; any partition) and prsgrd42.h (PJ_GRADPQ2: parabolic WENO and a second pass
+    # that reads rv(Iend+1,j) -- a column no tile computes: one tile only, oracle/orc_prs4x.c)
+    ("upwelling_prs44_small", ["nsteps=60"]),
+    ("upwelling_prs44_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_prs44_small", ["nsteps=20", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("upwelling_prs42_small", ["nsteps=60"]),
+    ("upwelling_prs42_small", ["nsteps=20", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     # biharmonic mixing along s-surfaces (oracle/ref/upwelling_bih.h: UV_VIS4, TS_DIF4): uv3dmix4_s.h, t3dmix4_s.h and the
     # UV_VIS4 block of step2d_LF_AM3.h; three ghost points (inp_par.F:214)
     ("upwelling_bih_small", ["nsteps=60"]),

@@ -97,6 +97,8 @@ def _interior(cs_dims, a):
     ("upwelling_geouv_mid", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 2), 29635),
     ("upwelling_bihgeo_mid", dict(), (2, 2), 29636),
     ("upwelling_bihiso_mid", dict(), (2, 2), 29646),
+    # round 6: PJ_GRADPQ4 (prsgrd44.h: the reconstruction runs on the tile widened by one column; no partition dependence)
+    ("upwelling_prs44_small", dict(), (2, 2), 29647),
 ])
 def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
     _emu_libs()
@@ -112,6 +114,25 @@ def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
         assert np.array_equal(a, b), (n, float(np.abs(a - b).max()), np.argwhere(a != b)[:5])
     assert got["diag"][2] == pytest.approx(dref["volume"], rel=1e-14)
     assert got["diag"][0] == pytest.approx(dref["avgke"], rel=1e-12)
+
+
+def test_quadratic_pressure_jacobian_with_second_pass_stays_on_one_tile():
+    """PJ_GRADPQ2 (prsgrd42.h) on two tiles: its second pass reads rv(Iend+1,j,k), which no tile computes (prsgrd42.h:449) -- the
+    reference's result depends on the partition there, so host and library stop with exit_flag 5 and say why."""
+    from roms_amd import hiplib, hostlib
+    _emu_libs()
+    cs = util.case_for("upwelling_prs42_small")
+    cs["NtileI"] = 2
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.Host(params=cs, lib_path=os.path.join(EMU, "libroms_host_emu.so"), hip_lib_path=util.EMU_LIB)
+    assert e.value.exit_flag == 5 and "prsgrd42.h:449" in str(e.value)
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    from tests import cases
+    cfg = cases.hip_cfg(cs, float(g["scalars"][0]), int(g["bounds"][58]), g["weight"], g["sc_r"], g["Cs_r"], g["sc_w"], g["Cs_w"])
+    cfg.NtileI = 2                                       # (what a caller with two tiles along xi would pass)
+    with pytest.raises(hiplib.RomsHipError) as e2:
+        hiplib.Context(cfg, util.EMU_LIB)
+    assert "exit_flag=5" in str(e2.value) and "PJ_GRADPQ2" in str(e2.value)
 
 
 def test_partition_rule():

@@ -83,6 +83,8 @@ def case_for(tag, **kw):
         return cases.upwelling_prs31(Lm=14, Mm=18, N=8, **kw)
     if tag == "upwelling_prs40_small":
         return cases.upwelling_prs40(Lm=14, Mm=18, N=8, **kw)
+    if tag in ("upwelling_prs42_small", "upwelling_prs44_small"):
+        return cases.upwelling_prs4x(Lm=14, Mm=18, N=8, scheme=int(tag[13:15]), **kw)
     if tag == "upwelling_bih_small":
         return cases.upwelling_bih(Lm=14, Mm=18, N=8, **kw)
     if tag == "upwelling_geouv_small":
@@ -167,6 +169,8 @@ def make_oracle(cs, g):
         O.set_wetdry(cs["Dcrit"])
     if cs.get("mix_geo_uv"):
         O.set_geouv()
+    if cs.get("prsgrd"):
+        O.set_prsgrd(cs["prsgrd"])
     if cs.get("clima"):
         O.set_clima(cs["clima"])
         for n, a in cases.clima_arrays(cs, np.asarray(g["h"]).size).items():
