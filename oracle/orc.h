@@ -158,6 +158,8 @@ typedef struct orc_s {
   double *Uwind, *Vwind, *Tair, *Pair, *Hair, *rain, *cloud, *lhflx, *shflx, *lrflx, *evap;
   /* mod_mixing */
   double *Akv, *Akt, *visc2_r, *visc2_p, *diff2, *bvf, *alpha, *beta, *hsbl, *ghats;
+  double *alfaobeta;                     /* LMD_DDMIX: ratio of the thermal expansion and saline contraction coefficients (i,j,0:N), rho_eos.F:454, :794 */
+  int ddmix;                             /* LMD_DDMIX on (orc_set_ddmix): lmd_vmix.F:360-428 */
   /* WET_DRY (wetdry.F): time-dependent masks; rmask_wet_avg: sum of the rho mask over the fast steps; *_full: wet mask x land mask */
   double *rmask_wet, *umask_wet, *vmask_wet, *pmask_wet, *rmask_full, *umask_full, *vmask_full, *pmask_full, *rmask_wet_avg;
   int wet_dry; double Dcrit;             /* switched on by orc_set_wetdry (DCRIT of roms.in, read_phypar.F:1021) */
@@ -313,6 +315,7 @@ typedef struct orc_diauv {
 void orc_set_mix4(orc_t *o, int uv_vis4, int ts_dif4);
 void orc_prsgrd42(orc_t *o, int tile);                        /* orc_prs4x.c */
 void orc_prsgrd44(orc_t *o, int tile);
+void orc_set_ddmix(orc_t *o, int on);                         /* LMD_DDMIX: double-diffusive mixing in lmd_vmix's interior scheme */
 void orc_set_prsgrd(orc_t *o, int scheme);                    /* prsgrd.F:16-19: PJ_GRADPQ4 -> prsgrd44.h, PJ_GRADPQ2 -> prsgrd42.h */
 void orc_set_clima(orc_t *o, int flags);                       /* climatology nudging: step3d_t.F:1866-1878, rhs3d.F:654-680 */
 void orc_set_geouv(orc_t *o, int on);                          /* MIX_GEO_UV: uv3dmix2_geo.h in place of uv3dmix2_s.h */

@@ -168,6 +168,11 @@ class Oracle:
         roots of the coefficients"""
         self.L.orc_set_mix4(C.c_void_p(self.h), int(uv_vis4), int(ts_dif4))
 
+    def set_ddmix(self, on=True):
+        """LMD_DDMIX: double-diffusive mixing (salt fingering, diffusive convection) added to Akt in lmd_vmix's interior scheme,
+        lmd_vmix.F:360-428, with alfaobeta of rho_eos.F:454 | :794"""
+        self.L.orc_set_ddmix(C.c_void_p(self.h), int(bool(on)))
+
     def set_prsgrd(self, scheme):
         """the pressure-gradient scheme of prsgrd.F:16-26 beyond the option bits: 42 = PJ_GRADPQ2 (prsgrd42.h), 44 = PJ_GRADPQ4
         (prsgrd44.h); 0 = what the ORC_PRSGRD* bits say"""

@@ -111,6 +111,7 @@ static void alloc_bounds(orc_cfg *c) {
 
 void orc_set_clima(orc_t *o, int flags) { o->clima_flags = flags; }
 void orc_set_prsgrd(orc_t *o, int scheme) { o->prs_scheme = scheme; }
+void orc_set_ddmix(orc_t *o, int on) { o->ddmix = on != 0; }
 
 static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
 
@@ -141,7 +142,7 @@ static const fdesc fields[] = {
   FD(Akv, KW), FD(Akt, KWxNAT), FD(visc2_r, K2), FD(visc2_p, K2), FD(diff2, K2xNT), FD(visc4_r, K2), FD(visc4_p, K2), FD(diff4, K2xNT),
   FD(tclm, KRxNT), FD(Tnudgcof, KRxNT), FD(uclm, KR), FD(vclm, KR), FD(M3nudgcof, KR),
   FD(ubarclm, K2), FD(vbarclm, K2), FD(M2nudgcof, K2),
-  FD(bvf, KW), FD(alpha, K2), FD(beta, K2), FD(hsbl, K2), FD(ghats, KWxNAT),
+  FD(bvf, KW), FD(alpha, K2), FD(beta, K2), FD(hsbl, K2), FD(ghats, KWxNAT), FD(alfaobeta, KW),
   FD(tke, KWx3), FD(gls, KWx3), FD(Lscale, KW), FD(Akk, KW), FD(Akp, KW),
   FD(sc_r, KTAB_R), FD(Cs_r, KTAB_R), FD(sc_w, KTAB_W), FD(Cs_w, KTAB_W),
   FD(zeta_west, KBJ), FD(zeta_east, KBJ), FD(zeta_south, KBI), FD(zeta_north, KBI),

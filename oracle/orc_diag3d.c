@@ -151,6 +151,11 @@ void orc_rho_eos(orc_t *o, int tile) {
         o->alpha[X2(i, j)] = fabs(Tcoef);
         o->beta[X2(i, j)] = (o->c.options & ORC_SALINITY) ? fabs(Scoef) : 0.0;
       }
+      if (o->ddmix) {                     /* LMD_DDMIX :782-796 */
+        const double cff = Scoef == 0.0 ? 1.0 : 1.0 / Scoef;
+        for (int k = 1; k <= N; k++)
+          for (int i = b->IstrT; i <= b->IendT; i++) o->alfaobeta[XW(i, j, k)] = cff * Tcoef;
+      }
     }
   }
   orc_exchange3d(o, b, 'r', rho, N);
@@ -162,6 +167,7 @@ void orc_rho_eos(orc_t *o, int tile) {
   orc_exchange2d(o, b, 'r', rhoA);
   orc_exchange2d(o, b, 'r', rhoS);
   if (o->c.options & (ORC_LMD_MIXING | ORC_GLS_MIXING | ORC_MY25_MIXING)) orc_exchange3d(o, b, 'w', o->bvf, N + 1);
+  if (o->ddmix && (o->c.options & ORC_LMD_MIXING)) orc_exchange3d(o, b, 'w', o->alfaobeta, N + 1);     /* :815-818 */
 }
 
 /* --------------------------------------------------------------- set_vbc */

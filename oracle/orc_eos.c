@@ -110,9 +110,9 @@ void orc_eos_nonlinear(orc_t *o, int tile) {
         bvf[XW(i, j, k)] = -g * (den_up - den_dn) / (0.5 * (den_up + den_dn) * (z_r[X3(i, j, k + 1)] - z_r[X3(i, j, k)]));
       }
     for (int i = b->IstrT; i <= b->IendT; i++) { bvf[XW(i, j, 0)] = 0.0; bvf[XW(i, j, N)] = 0.0; }
-    /* thermal expansion / saline contraction at the surface */
+    /* thermal expansion / saline contraction at the surface; LMD_DDMIX: at every level :435-455, their ratio kept */
+    for (int k = o->ddmix ? 1 : N; k <= N; k++)
     for (int i = b->IstrT; i <= b->IendT; i++) {
-      const int k = N;
       const double Tpr10 = 0.1 * z_r[X3(i, j, k)];
       cff = CX(bulk, i, k) + Tpr10;
       cff1 = Tpr10 * CX(den1, i, k);
@@ -120,6 +120,7 @@ void orc_eos_nonlinear(orc_t *o, int tile) {
       CX(wrk, i, k) = (CX(den, i, k) + 1000.0) * cff * cff;
       CX(Tcof, i, k) = -(CX(DbulkDT, i, k) * cff1 + CX(Dden1DT, i, k) * cff2);
       CX(Scof, i, k) = (CX(DbulkDS, i, k) * cff1 + CX(Dden1DS, i, k) * cff2);
+      if (o->ddmix) o->alfaobeta[XW(i, j, k)] = CX(Tcof, i, k) / CX(Scof, i, k);
     }
     for (int i = b->IstrT; i <= b->IendT; i++) {
       cff = 1.0 / CX(wrk, i, N);
@@ -141,4 +142,5 @@ void orc_eos_nonlinear(orc_t *o, int tile) {
   orc_exchange2d(o, b, 'r', rhoA);
   orc_exchange2d(o, b, 'r', rhoS);
   orc_exchange3d(o, b, 'w', bvf, N + 1);
+  if (o->ddmix) orc_exchange3d(o, b, 'w', o->alfaobeta, N + 1);                            /* :499-502 */
 }

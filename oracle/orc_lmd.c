@@ -109,6 +109,33 @@ static void lmd_interior(orc_t *o, const orc_bounds *b) {
         Akv[XW(i, j, k)] = lmd_iwm + lmd_nu0m * nu_sx;
         Akt[XW4(i, j, k, 1)] = lmd_iws + lmd_nu0s * nu_sx;
         Akt[XW4(i, j, k, 2)] = Akt[XW4(i, j, k, 1)];
+        if (o->ddmix) {
+          /* LMD_DDMIX, lmd_vmix.F:360-428: double-diffusive mixing where the density gradient is stable and that of
+             salinity (salt fingering) or temperature (diffusive convection) is not */
+          const double lmd_Rrho0 = 1.9, lmd_nuf = 10.0E-4, lmd_fdd = 0.7, lmd_nu = 1.5E-6, lmd_tdd1 = 0.909, lmd_tdd2 = 4.6,
+                       lmd_tdd3 = 0.54, lmd_sdd1 = 0.15, lmd_sdd2 = 1.85, lmd_sdd3 = 0.85;
+          const double ddDT = o->t[XT(i, j, k + 1, nstp, 1)] - o->t[XT(i, j, k, nstp, 1)];
+          double ddDS = o->t[XT(i, j, k + 1, nstp, 2)] - o->t[XT(i, j, k, nstp, 2)];
+          ddDS = copysign(1.0, ddDS) * MAX(fabs(ddDS), 1.0E-14);
+          double Rrho = o->alfaobeta[XW(i, j, k)] * ddDT / ddDS;
+          double nu_dds, nu_ddt;
+          if ((Rrho > 1.0) && (ddDS > 0.0)) {                                  /* salt fingering */
+            Rrho = MIN(Rrho, lmd_Rrho0);
+            const double q = (Rrho - 1.0) / (lmd_Rrho0 - 1.0);
+            nu_dds = 1.0 - q * q;
+            nu_dds = lmd_nuf * nu_dds * nu_dds * nu_dds;
+            nu_ddt = lmd_fdd * nu_dds;
+          } else if ((0.0 < Rrho) && (Rrho < 1.0) && (ddDS < 0.0)) {          /* diffusive convection */
+            nu_ddt = lmd_nu * lmd_tdd1 * exp(lmd_tdd2 * exp(-lmd_tdd3 * ((1.0 / Rrho) - 1.0)));
+            if (Rrho < 0.5) nu_dds = nu_ddt * lmd_sdd1 * Rrho;
+            else nu_dds = nu_ddt * (lmd_sdd2 * Rrho - lmd_sdd3);
+          } else {
+            nu_ddt = 0.0;
+            nu_dds = 0.0;
+          }
+          Akt[XW4(i, j, k, 1)] = Akt[XW4(i, j, k, 1)] + nu_ddt;
+          Akt[XW4(i, j, k, 2)] = Akt[XW4(i, j, k, 2)] + nu_dds;
+        }
       }
   free(FC);
   free(Rig);

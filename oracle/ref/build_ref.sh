@@ -45,6 +45,16 @@ if [ "$APP" = upwelling_kpp ]; then
   UP=UPWELLING; HDR=upwelling_kpp; HDRPATH="$HERE/upwelling_kpp.h"
   EXTRA=""
 fi
+if [ "$APP" = upwelling_kpp_ddmix ]; then
+  # ... with double-diffusive mixing in the interior scheme (oracle/ref/upwelling_kpp_ddmix.h: LMD_DDMIX, lmd_vmix.F:360-428; linear EOS)
+  UP=UPWELLING; HDR=upwelling_kpp_ddmix; HDRPATH="$HERE/upwelling_kpp_ddmix.h"
+  EXTRA=""
+fi
+if [ "$APP" = benchmark_ddmix ]; then
+  # the shipped benchmark.h with LMD_DDMIX switched on as a user does (nonlinear EOS: alfaobeta of rho_eos.F:435-455)
+  UP=BENCHMARK; HDR=benchmark; HDRPATH="benchmark.h"
+  EXTRA="-DLMD_DDMIX"
+fi
 if [ "$APP" = upwelling_logdrag ]; then
   # the UPWELLING case with UV_LOGDRAG (oracle/ref/upwelling_logdrag.h): pins the logarithmic bottom stress
   UP=UPWELLING; HDR=upwelling_logdrag; HDRPATH="$HERE/upwelling_logdrag.h"

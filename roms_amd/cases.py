@@ -135,6 +135,51 @@ def upwelling_kpp(**kw):
     return cs
 
 
+def with_ddmix(cs):
+    """... with double-diffusive mixing in the interior scheme of the LMD closure (LMD_DDMIX, lmd_vmix.F:360-428): the reference
+    builds oracle/ref/upwelling_kpp_ddmix.h (linear EOS) and benchmark.h -DLMD_DDMIX (nonlinear EOS: alfaobeta of rho_eos.F:454)"""
+    cs["app"] = cs["app"] + "_ddmix"
+    cs["ddmix"] = 1
+    return cs
+
+
+def upwelling_kpp_ddmix(**kw):
+    return with_ddmix(upwelling_kpp(**kw))
+
+
+def benchmark_ddmix(**kw):
+    return with_ddmix(benchmark(**kw))
+
+
+def ddmix_state(cs, t, LBi, UBi, LBj, UBj):
+    """A temperature / salinity state that reaches every branch of LMD_DDMIX (the analytic initial salinity is uniform: no double
+    diffusion at all).  West half of the domain: S = 35 + s (T - 14), warm and salty above cold and fresh with 1 < Rrho < 1.9
+    (salt fingering).  East half: the temperature profile turned upside down, T' = Tmin + Tmax - T, and S = 35 + c (T' - 14) --
+    cold and fresh above warm and salty, stable by its salinity, 0 < Rrho < 1 (diffusive convection), c chosen per half in eta
+    so that Rrho lies on both sides of 0.5.  `t`: the flat tracer array (i, j, k, 3, NT) of the fixtures; returns the new one."""
+    import numpy as np
+    ni, nj = UBi - LBi + 1, UBj - LBj + 1
+    N, Lm, Mm = cs["N"], cs["Lm"], cs["Mm"]
+    a = np.array(t, dtype=np.float64).reshape(-1, 3, N, nj, ni).copy()
+    T = a[0]
+    ii = np.arange(LBi, UBi + 1)
+    jj = np.arange(LBj, UBj + 1)
+    if cs["EWperiodic"]:
+        ii = (ii - 1) % Lm + 1
+    if cs["NSperiodic"]:
+        jj = (jj - 1) % Mm + 1
+    west = (ii <= Lm // 2)[None, None, None, :]
+    south = (jj <= Mm // 2)[None, None, :, None]
+    nonlin = "NONLIN_EOS" in cs["options"]
+    s, cA, cB = (0.1, 0.6, 0.3) if nonlin else (0.15, 0.5, 0.3)
+    Tf = (T.min() + T.max()) - T
+    Tn = np.where(west, T, Tf)
+    S = np.where(west, 35.0 + s * (T - 14.0), 35.0 + np.where(south, cA, cB) * (Tf - 14.0))
+    a[0] = Tn
+    a[1] = S
+    return a.reshape(np.asarray(t).shape)
+
+
 def upwelling_logdrag(**kw):
     """UPWELLING with the logarithmic bottom drag (UV_LOGDRAG, Zob = 0.02 m) instead of UV_LDRAG: the custom
     application header oracle/ref/upwelling_logdrag.h"""
@@ -449,6 +494,8 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
         opt |= (hiplib.OPTIONS["UV_VIS4"] if cs["mix4"][0] else 0) | (hiplib.OPTIONS["TS_DIF4"] if cs["mix4"][1] else 0)
     if cs.get("mix_geo_uv"):
         opt |= hiplib.OPTIONS["MIX_GEO_UV"]
+    if cs.get("ddmix"):     # LMD_DDMIX
+        opt |= hiplib.OPTIONS["LMD_DDMIX"]
     if cs.get("prsgrd"):    # PJ_GRADPQ2 / PJ_GRADPQ4
         opt |= hiplib.OPTIONS["PRSGRD%d" % cs["prsgrd"]]
     if cs.get("clima"):     # climatology nudging: bit 0 the 3-D momentum, bit itrc tracer itrc

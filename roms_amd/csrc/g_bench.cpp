@@ -45,6 +45,16 @@ int run_eos_nonlinear(roms_hip_ctx *c) {
   return 0;
 }
 
+// LMD_DDMIX: alfaobeta behind either equation of state (k_bench.h:k_eos_alfaobeta), on the columns the density kernel took
+int run_eos_alfaobeta(roms_hip_ctx *c) {
+  KArgs a = mk(c);
+  if (ghost_compute(c, 4)) a.G.T = ghost_tb(c, 3, c->G.Nghost);
+  const TB B = a.G.T;
+  a.p1 = (c->G.options & ROMS_NONLIN_EOS) ? 1 : 0;
+  LAUNCH_THREAD(k_eos_alfaobeta, B.IendT - B.IstrT + 1, B.JendT - B.JstrT + 1, c->G.N, c->stream, a);
+  return 0;
+}
+
 int run_t3dmix2_geo(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   KArgs a = mk(c);

@@ -70,7 +70,13 @@ int run_set_massflux(roms_hip_ctx *c) {
   return 0;
 }
 
+int run_eos_alfaobeta(roms_hip_ctx *c);   // g_bench.cpp
+static int run_rho_eos_only(roms_hip_ctx *c);
 int run_rho_eos(roms_hip_ctx *c) {
+  const int r = run_rho_eos_only(c);
+  return (r || !c->G.ddmix) ? r : run_eos_alfaobeta(c);       // LMD_DDMIX: alfaobeta (rho_eos.F:454, :794)
+}
+static int run_rho_eos_only(roms_hip_ctx *c) {
   if (c->G.options & ROMS_NONLIN_EOS) return run_eos_nonlinear(c);
   const TB &B = c->G.T;
   const int N = c->G.N;

@@ -191,6 +191,32 @@ THREAD_KERNEL(k_eos_nl_pt, KArgs) {
 }
 THREAD_GLOBAL(k_eos_nl_pt, KArgs)
 
+// LMD_DDMIX: alfaobeta(i,j,k) = Tcof/Scof at every level (rho_eos.F:435-455; the surface level's pair is what alpha, beta are made
+// of above) | the constant Tcoef/Scoef of the linear equation of state (:782-796) -- p1 = 1 | 0.  A launch of its own behind the
+// density kernels (they stay as they are: not a BASELINE option); index space (IstrT:IendT, JstrT:JendT, N).
+THREAD_KERNEL(k_eos_alfaobeta, KArgs) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  const int i = G.T.IstrT + gx, j = G.T.JstrT + gy, k = gz + 1, nrhs = G.nrhs;
+  double v;
+  if (a.p1) {
+    const double zr_k = F.z_r[X3(i, j, k)];
+    const EosLevel L = eos_level(F.t[XT(i, j, k, nrhs, 1)], F.t[XT(i, j, k, nrhs, 2)], zr_k);
+    const double Tpr10 = 0.1 * zr_k;
+    const double cff = L.bulk + Tpr10;
+    const double c1 = Tpr10 * L.den1;
+    const double c2 = L.bulk * cff;
+    const double Tcof = -(L.DbulkDT * c1 + L.Dden1DT * c2);
+    const double Scof = (L.DbulkDS * c1 + L.Dden1DS * c2);
+    v = Tcof / Scof;
+  } else {
+    const double cff = G.Scoef == 0.0 ? 1.0 : 1.0 / G.Scoef;
+    v = cff * G.Tcoef;
+  }
+  G.alfaobeta[XW(i, j, k)] = v;
+}
+THREAD_GLOBAL(k_eos_alfaobeta, KArgs)
+
 // rhoA, rhoS (rho_eos.F:382-420) from the rho that k_eos_nl_pt stored: the recurrence from the surface down
 THREAD_KERNEL(k_eos_sum, KArgs) {
   (void)gz;

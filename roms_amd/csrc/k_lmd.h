@@ -30,6 +30,37 @@ struct LmdArgs {
   (void)lmd_am; (void)lmd_as; (void)lmd_cekman; (void)lmd_cmonob; (void)lmd_cm; (void)lmd_cs;                  \
   (void)lmd_epsilon; (void)lmd_zetam; (void)lmd_zetas; (void)vonKar
 
+// LMD_DDMIX, lmd_vmix.F:360-428: the double-diffusive contributions to the temperature | salinity coefficient at W-level k of
+// the column at x = X2(i,j) -- salt fingering where 1 < Rrho and salinity increases upward, diffusive convection where
+// 0 < Rrho < 1 and it decreases (Marmorino & Caldwell 1976) -- from alfaobeta of rho_eos (G.alfaobeta; k_eos_alfaobeta below)
+KDEV void lmd_ddmix(const DGrid &G, const Fields &F, size_t x, int k, size_t ow, double &aktT, double &aktS) {
+  const double lmd_Rrho0 = 1.9, lmd_nuf = 10.0E-4, lmd_fdd = 0.7, lmd_nu = 1.5E-6, lmd_tdd1 = 0.909, lmd_tdd2 = 4.6, lmd_tdd3 = 0.54,
+               lmd_sdd1 = 0.15, lmd_sdd2 = 1.85, lmd_sdd3 = 0.85;
+  const size_t nijN = (size_t)G.nij * (size_t)G.N;
+  const size_t oT = x + (size_t)(k - 1) * (size_t)G.nij + (size_t)(G.nstp - 1) * nijN, oS = oT + 3 * nijN;      // t(i,j,k,nstp,itemp | isalt)
+  const double ddDT = F.t[oT + (size_t)G.nij] - F.t[oT];
+  double ddDS = F.t[oS + (size_t)G.nij] - F.t[oS];
+  ddDS = copysign(1.0, ddDS) * KMAX(fabs(ddDS), 1.0E-14);
+  double Rrho = G.alfaobeta[ow] * ddDT / ddDS;
+  double nu_dds, nu_ddt;
+  if ((Rrho > 1.0) && (ddDS > 0.0)) {
+    Rrho = KMIN(Rrho, lmd_Rrho0);
+    const double q = (Rrho - 1.0) / (lmd_Rrho0 - 1.0);
+    nu_dds = 1.0 - q * q;
+    nu_dds = lmd_nuf * nu_dds * nu_dds * nu_dds;
+    nu_ddt = lmd_fdd * nu_dds;
+  } else if ((0.0 < Rrho) && (Rrho < 1.0) && (ddDS < 0.0)) {
+    nu_ddt = lmd_nu * lmd_tdd1 * kexp(lmd_tdd2 * kexp(-lmd_tdd3 * ((1.0 / Rrho) - 1.0)));
+    if (Rrho < 0.5) nu_dds = nu_ddt * lmd_sdd1 * Rrho;
+    else nu_dds = nu_ddt * (lmd_sdd2 * Rrho - lmd_sdd3);
+  } else {
+    nu_ddt = 0.0;
+    nu_dds = 0.0;
+  }
+  aktT = aktT + nu_ddt;
+  aktS = aktS + nu_dds;
+}
+
 // vertical parabolic-spline derivatives of R, U, V at W-points for column (i,j) :190-260.  Both
 // sweeps take six levels at a time: the inputs of a chunk are loaded first (the loads overlap), then
 // the recurrences run on registers.  with_uv = false computes dR only (FC is rebuilt; dU, dV of the
@@ -161,8 +192,10 @@ KDEV void lmd_interior_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
       const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
       F.Akv[ow] = lmd_iwm + lmd_nu0m * nu_sx;
       const double akt = lmd_iws + lmd_nu0s * nu_sx;
-      F.Akt[ow] = akt;
-      F.Akt[ow + oA] = akt;
+      double aT = akt, aS = akt;
+      if (G.ddmix) lmd_ddmix(G, F, x, k, ow, aT, aS);
+      F.Akt[ow] = aT;
+      F.Akt[ow + oA] = aS;
     }
   }
 }
@@ -495,8 +528,10 @@ KDEV void lmd_col_fused(const LmdArgs &a, int i, int j, double *W0, double *W1, 
         const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
         F.Akv[ow] = lmd_iwm + lmd_nu0m * nu_sx;
         const double akt = lmd_iws + lmd_nu0s * nu_sx;
-        F.Akt[ow] = akt;
-        F.Akt[ow + oA] = akt;
+        double aT = akt, aS = akt;
+        if (G.ddmix) lmd_ddmix(G, F, x, k, ow, aT, aS);
+        F.Akt[ow] = aT;
+        F.Akt[ow + oA] = aS;
       }
     }
   }
@@ -939,8 +974,10 @@ COOP_KERNEL(k_lmd_blk, LmdArgs) {
       const double lmd_iwm = 1.0E-6 * cff, lmd_iws = 1.0E-7 * cff;
       F.Akv[ow] = lmd_iwm + lmd_nu0m * nu_sx;
       const double akt = lmd_iws + lmd_nu0s * nu_sx;
-      F.Akt[ow] = akt;
-      F.Akt[ow + oA] = akt;
+      double aT = akt, aS = akt;
+      if (G.ddmix) lmd_ddmix(G, F, x, k, ow, aT, aS);
+      F.Akt[ow] = aT;
+      F.Akt[ow + oA] = aS;
     }
     const double hz = F.Hz[o];
     const double uk = 0.5 * (uS[o] + uS[o + 1]), vk = 0.5 * (vS[o] + vS[(long)o + ni]);

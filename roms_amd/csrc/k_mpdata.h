@@ -90,14 +90,18 @@ THREAD_KERNEL(k_mp_ta, MpArgs) {
 THREAD_GLOBAL(k_mp_ta, MpArgs)
 
 // ---- Ua (dir 0; index space IstrU-1:Iendp2, JstrV-1:Jendp1) and Va (dir 1; IstrU-1:Iendp1,
-//      JstrVm1:Jendp2), mpdata_adiff.F:307-640, with the closed-wall values :642-720 ------------
+//      min(JstrV-1,JstrVm1):Jendp2), mpdata_adiff.F:307-640, with the closed-wall values :642-720 ------------
 THREAD_KERNEL(k_mp_uva, MpArgs) {
   const DGrid &G = a.G;
   const Fields &F = a.Fv;
   const TB &B = G.T;
   const int N = G.N, itrc = a.itrc;
   const int dir = gz / N, k = gz % N + 1;
-  const int i = B.IstrU - 1 + gx, j = (dir == 0 ? B.JstrV - 1 : B.JstrVm1) + gy;
+  // (Va: the reference's loop starts at JstrVm1 -- behind a closed southern wall that is Jstr+1 -- and its boundary statement then
+  // sets Va(Istrm1:Iendp1,Jstr,:) = 0 (:726-733), which k_mp_beta reads at once: the wall row is part of this index space, its
+  // value the wall rule at the end.  Round 6: until then that row kept the zeros of its allocation and of k_mp_limit's later
+  // store -- right, but a read of scratch nobody had written in this step, which ROMS_HIP_POISON=1 turned into NaN)
+  const int i = B.IstrU - 1 + gx, j = (dir == 0 ? B.JstrV - 1 : KMIN(B.JstrV - 1, B.JstrVm1)) + gy;
   if (i > (dir == 0 ? B.Iendp2 : B.Iendp1) || j > (dir == 0 ? B.Jendp1 : B.Jendp2)) return;
   const double eps = 1.0E-18, eps2 = 1.0E-10, fac = 1.0, dt = G.dt;
   const double *Ta = F.mp3[0] + (size_t)(itrc - 1) * G.nij * N;
@@ -291,7 +295,7 @@ THREAD_KERNEL(k_mp_uvwa, MpArgs) {
   const int N = a.G.N;
   if (gz >= 1) {
     k_mp_uva_body(a, gx, gy, gz - 1);                            // Ua at level gz
-    const int gy1 = gy - (B.JstrVm1 - (B.JstrV - 1));           // (Va's rows start at JstrVm1)
+    const int gy1 = gy - (KMIN(B.JstrV - 1, B.JstrVm1) - (B.JstrV - 1));      // (Va's rows: the wall row of a closed southern edge included)
     if (gy1 >= 0) k_mp_uva_body(a, gx, gy1, N + gz - 1);         // Va
   }
   k_mp_wa_body(a, gx, gy, gz);

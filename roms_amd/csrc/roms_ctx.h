@@ -78,7 +78,6 @@ struct DGrid {
   // step2d_LF_AM3.h:1653-1920), TS_DIF4 + MIX_S_TS (t3dmix4_s.h); coefficient arrays visc4_r, visc4_p, diff4
   int uv_vis4, ts_dif4;
   int clima;           // climatology nudging: bit 0 LnudgeM3CLM (rhs3d.F:654), bit itrc LtracerCLM & LnudgeTCLM of tracer itrc (step3d_t.F:1866)
-  int prs4x;           // 44: PJ_GRADPQ4 (prsgrd44.h), 42: PJ_GRADPQ2 (prsgrd42.h); 0: the scheme the lower option bits name (k_prs4x.h)
   int mix_geo_uv;      // UV_VIS2 along geopotential surfaces (option bit ROMS_MIX_GEO_UV; k_uvmix_geo.h, work arrays Fields::gwrk)
   signed char m2[12], m3[12];
   short ndm2, ndm3, ndrhs;
@@ -87,6 +86,10 @@ struct DGrid {
   int wet_dry;
   double Dcrit;
   const double *rmask_wet, *umask_wet, *vmask_wet, *pmask_wet, *hbath;
+  // round 6, behind everything else (no member above moves)
+  int prs4x;           // 44: PJ_GRADPQ4 (prsgrd44.h), 42: PJ_GRADPQ2 (prsgrd42.h); 0: the scheme the lower option bits name (k_prs4x.h)
+  int ddmix;           // LMD_DDMIX (option bit ROMS_LMD_DDMIX): double-diffusive mixing in lmd_vmix's interior scheme (k_lmd.h), from ...
+  double *alfaobeta;   // ... the ratio of the thermal expansion and saline contraction coefficients (i,j,0:N) rho_eos leaves (rho_eos.F:454, :794)
 };
 
 #ifdef ROMS_CPU_EMU

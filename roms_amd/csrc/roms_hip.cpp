@@ -97,7 +97,13 @@ static int poison_work(roms_hip_ctx *c) {
 #ifndef ROMS_CPU_EMU
   if (hipfail(hipDeviceSynchronize(), "hipDeviceSynchronize")) return 2;    // (side streams of the previous step may still read scratch)
 #endif
-  for (const WorkSpan &x : w) { int r = dpoison(x.p, x.bytes, c->stream); if (r) return r; }
+  static const char *only = getenv("ROMS_HIP_POISON_ONLY");      // (debugging aid: the one span of work_spans' list with this index)
+  int q = 0;
+  for (const WorkSpan &x : w) {
+    if (only && atoi(only) != q++) continue;
+    int r = dpoison(x.p, x.bytes, c->stream);
+    if (r) return r;
+  }
   return dsync(c->stream);
 }
 
@@ -641,6 +647,18 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     for (int it = 1; it <= c->G.NT; it++) if (cfg->options & ROMS_NUDGE_TCLM(it)) c->G.clima |= 1 << it;
     if (c->G.clima & 30) c->G.fuse3d = 0;
     if (c->G.clima & 32) { c->pair_on = step2d_pair_usable(c); c->loop_state = 0; }     // (LnudgeM2CLM: the per-call barotropic kernel)                    // (the nudging sits between t3dbc and the exchange: separate launches)
+  }
+  c->G.ddmix = 0; c->G.alfaobeta = nullptr;
+  if (cfg->options & ROMS_LMD_DDMIX) {                      // lmd_vmix.F:360-428
+    if (!(cfg->options & ROMS_LMD_MIXING)) { set_error("LMD_DDMIX without LMD_MIXING"); roms_hip_destroy(c); return 5; }
+    if (c->G.NT < 2 || !(cfg->options & ROMS_SALINITY)) { set_error("LMD_DDMIX needs salinity (the double-diffusive density ratio)"); roms_hip_destroy(c); return 5; }
+    if (cfg->options & ROMS_WET_DRY) { set_error("LMD_DDMIX with WET_DRY: not pinned against the reference"); roms_hip_destroy(c); return 5; }
+    void *p = nullptr;
+    const size_t nb = (size_t)c->G.nij * (size_t)(c->G.N + 1) * sizeof(double);
+    if (dmalloc(&p, nb)) { roms_hip_destroy(c); return 2; }
+    c->allocs.push_back(p);
+    c->G.alfaobeta = (double *)p;
+    c->G.ddmix = 1;
   }
   c->G.prs4x = (cfg->options & ROMS_PRSGRD44) ? 44 : ((cfg->options & ROMS_PRSGRD42) ? 42 : 0);     // prsgrd.F:16-19
   if (c->G.prs4x) {

@@ -32,6 +32,7 @@
       logical :: mix4(2) = .FALSE.
       real(dp) :: Dcrit = 0.10_dp              ! DCRIT of roms.in (WET_DRY; read_phypar.F:1021)
       logical :: wet_dry = .FALSE.
+      logical :: ddmix = .FALSE.                ! LMD_DDMIX: double-diffusive mixing in lmd_vmix's interior scheme
       integer :: prs4x = 0                      ! 44: PJ_GRADPQ4 (prsgrd44.h), 42: PJ_GRADPQ2 (prsgrd42.h), 0: the scheme in `options`
       logical :: mix_geo_uv = .FALSE.           ! UV_VIS2 along geopotential surfaces (MIX_GEO_UV: uv3dmix2_geo.h)
       real(dp) :: visc2 = 5.0_dp, tnu2(ROMS_MAXT) = 0.0_dp, Akt_bak(ROMS_MAXT) = 1.0E-6_dp, Akv_bak = 1.0E-5_dp
@@ -804,7 +805,8 @@
 !
       SUBROUTINE builtin_defines (ierr)
       integer, intent(inout) :: ierr
-      integer :: k
+      integer :: k, nl
+      logical :: with_ddmix
       character(len=16), parameter :: common(9) = [ character(len=16) :: 'SOLVE3D', 'SALINITY', 'UV_ADV',        &
      &    'UV_COR', 'UV_VIS2', 'MIX_S_UV', 'TS_DIF2', 'DJ_GRADPS', 'ANA_GRID' ]
       character(len=16), parameter :: kpp(7) = [ character(len=16) :: 'LMD_MIXING', 'LMD_RIMIX', 'LMD_CONVEC',    &
@@ -813,6 +815,15 @@
      &    'ANA_BTFLUX', 'ANA_BSFLUX' ]
       character(len=16), parameter :: bulk(9) = [ character(len=16) :: 'BULK_FLUXES', 'LONGWAVE', 'ANA_WINDS',    &
      &    'ANA_TAIR', 'ANA_PAIR', 'ANA_HUMIDITY', 'ANA_RAIN', 'ANA_CLOUD', 'ALBEDO' ]
+!  (<application>_DDMIX = the same application with LMD_DDMIX: oracle/ref/upwelling_kpp_ddmix.h, benchmark.h -DLMD_DDMIX)
+      nl=LEN_TRIM(MyAppCPP)
+      with_ddmix=.FALSE.
+      IF (nl.gt.6) THEN
+        IF (MyAppCPP(nl-5:nl).eq.'_DDMIX') THEN
+          with_ddmix=.TRUE.
+          MyAppCPP=MyAppCPP(1:nl-6)
+        END IF
+      END IF
       DO k=1,SIZE(common)
 !  (UPWELLING_BIH = oracle/ref/upwelling_bih.h: biharmonic mixing along s-surfaces in place of the harmonic operators)
 !  (UPWELLING_BIHGEO = oracle/ref/upwelling_bihgeo.h: ... the tracers along geopotentials; _BIHISO: along isopycnals; UPWELLING_GEOUV =
@@ -925,6 +936,7 @@
           CALL unsupported ('MyAppCPP = '//TRIM(MyAppCPP)//': no built-in option list; give the '//             &
      &                      'application header (ROMS_APP_HEADER / second argument of romsM)', ierr)
       END SELECT
+      IF (with_ddmix) CALL define ('LMD_DDMIX')
       END SUBROUTINE builtin_defines
 !
 !  defined options -> option mask, or exit_flag 5 with the reason.
@@ -941,8 +953,8 @@
      &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
      &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D, ROMS_GLS_MIXING, ROMS_MY25_MIXING, ROMS_MIX_ISO_TS ]
 !  options whose code is the only form built (accepted, nothing to select) or that only affect output
-      character(len=16), parameter :: inherent(37) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', 'PJ_GRADP', &
-     &    'PJ_GRADPQ2', 'PJ_GRADPQ4', &
+      character(len=16), parameter :: inherent(38) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', 'PJ_GRADP', &
+     &    'PJ_GRADPQ2', 'PJ_GRADPQ4', 'LMD_DDMIX', &
      &    'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
      &    'DJ_GRADPS', 'MIX_S_UV', 'MIX_S_TS', 'SPLINES_VDIFF', 'SPLINES_VVISC', 'UV_LDRAG', 'ANA_SMFLUX',        &
      &    'ANA_STFLUX', 'ANA_SSFLUX', 'ANA_BTFLUX', 'ANA_BSFLUX', 'ANA_SRFLUX', 'LMD_RIMIX', 'LMD_CONVEC',        &
@@ -1012,6 +1024,9 @@
 !  the pressure-gradient scheme (prsgrd.F:16-26): DJ_GRADPS -> prsgrd32.h; none of the four options -> prsgrd31.h, WJ_GRADP its
 !  weighted form
 !  (prsgrd.F tests PJ_GRADPQ4, PJ_GRADPQ2, PJ_GRADP, DJ_GRADPS in this order)
+      ddmix=is_defined('LMD_DDMIX')               ! (upper word of cfg%options: ROMS_LMD_DDMIX, below)
+      IF (ddmix.and..not.is_defined('LMD_MIXING')) CALL unsupported ('LMD_DDMIX without LMD_MIXING', ierr)
+      IF (ddmix.and..not.is_defined('SALINITY')) CALL unsupported ('LMD_DDMIX needs SALINITY', ierr)
       prs4x=0
       IF (is_defined('PJ_GRADPQ4')) THEN
         prs4x=44                                  ! (upper word of cfg%options: ROMS_PRSGRD44, below)
@@ -1037,7 +1052,7 @@
 !  solar source of pre_step3d, t3dmix2_geo, mpdata_adiff.  The combinations whose WET_DRY statements the library does not
 !  carry stop here
       IF (wet_dry.and.(IAND(options, IOR(ROMS_GLS_MIXING, IOR(ROMS_MY25_MIXING, IOR(ROMS_MIX_ISO_TS,                      &
-     &    IOR(ROMS_PRSGRD31, ROMS_PRSGRD40))))).ne.0.or.ANY(mix4).or.prs4x.ne.0))                                        &
+     &    IOR(ROMS_PRSGRD31, ROMS_PRSGRD40))))).ne.0.or.ANY(mix4).or.prs4x.ne.0.or.ddmix))                                     &
      &  CALL unsupported ('WET_DRY is built with ANA_VMIX or LMD_MIXING, analytic or bulk fluxes, harmonic mixing along '//  &
      &                    's-surfaces or geopotentials and DJ_GRADPS (not with GLS_MIXING, MY25_MIXING, MIX_ISO_TS, '//  &
      &                    'UV_VIS4, TS_DIF4, other pressure Jacobians)', ierr)
@@ -2047,6 +2062,7 @@
       IF (mix4(2)) cfg%options=IOR(cfg%options, ROMS_TS_DIF4)
       IF (wet_dry) cfg%options=IOR(cfg%options, ROMS_WET_DRY)
       IF (mix_geo_uv) cfg%options=IOR(cfg%options, ROMS_MIX_GEO_UV)
+      IF (ddmix) cfg%options=IOR(cfg%options, ROMS_LMD_DDMIX)
       IF (prs4x.eq.44) cfg%options=IOR(cfg%options, ROMS_PRSGRD44)
       IF (prs4x.eq.42) cfg%options=IOR(cfg%options, ROMS_PRSGRD42)
       cfg%Dcrit=Dcrit

@@ -288,6 +288,8 @@ STEP_CASES = [
     # the generic length-scale closure: upwelling.h -DGLS_MIXING (Kantha-Clayson, k-epsilon), Canuto A masked ("gen"),
     # Canuto B with CHARNOK / CRAIG_BANNER / K_C2ADVECTION (k-kl)
     ("upwelling_small_prs40", "upwelling_prs40_small", ["nsteps=60"]),       # PJ_GRADP, prsgrd40.h
+    ("benchmark_small_ddmix", "benchmark_ddmix_small", ["nsteps=60"]),       # LMD_DDMIX, nonlinear EOS (benchmark.h -DLMD_DDMIX; the state of cases.ddmix_state)
+    ("upwelling_kpp_small_ddmix", "upwelling_kpp_ddmix_small", ["nsteps=40"]),   # ... linear EOS (upwelling_kpp_ddmix.h)
     ("upwelling_small_prs42", "upwelling_prs42_small", ["nsteps=60"]),       # PJ_GRADPQ2, prsgrd42.h (one tile: its second pass, oracle/orc_prs4x.c)
     ("upwelling_small_prs44", "upwelling_prs44_small", ["nsteps=60"]),       # PJ_GRADPQ4, prsgrd44.h
     ("upwelling_small_bih", "upwelling_bih_small", ["nsteps=60"]),           # UV_VIS4 + TS_DIF4 along s-surfaces (upwelling_bih.h)

@@ -20,6 +20,9 @@ CASES = {
     "benchmark_small": ("benchmark", dict(Lm=24, Mm=16, N=10)),
     "benchmark1": ("benchmark", dict()),
     "upwelling_kpp_small": ("upwelling_kpp", dict(Lm=14, Mm=18, N=8)),
+    # LMD_DDMIX (round 6): oracle/ref/upwelling_kpp_ddmix.h (linear EOS), benchmark.h -DLMD_DDMIX (nonlinear EOS); the state of cases.ddmix_state
+    "upwelling_kpp_ddmix_small": ("upwelling_kpp_ddmix", dict(Lm=14, Mm=18, N=8)),
+    "benchmark_ddmix_small": ("benchmark_ddmix", dict(Lm=24, Mm=16, N=10)),
     # the UPWELLING case built WITH its time-averaged output (oracle/ref/upwelling_avg.h): pins set_avg.F
     "upwelling_avg_small": ("upwelling_avg", dict(Lm=14, Mm=18, N=8)),
     # ROMS/Include/upwelling.h AS SHIPPED (AVERAGES, DIAGNOSTICS_TS, DIAGNOSTICS_UV): pins the per-term tracer tendencies
@@ -158,7 +161,7 @@ def make_case(tag, **kw):
                 upwelling_avg=cases.upwelling, upwelling_diag=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag, upwelling_noadv=cases.upwelling_noadv,
                 upwelling_mask=cases.upwelling_mask, upwelling_wetdry=cases.upwelling_wetdry, benchmark_mask=cases.benchmark_mask, benchmark_wetdry=cases.benchmark_wetdry,
                 upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
-                upwelling_wjgradp=cases.upwelling_prs31, upwelling_prs40=cases.upwelling_prs40, upwelling_prs42=cases.upwelling_prs4x, upwelling_prs44=cases.upwelling_prs4x, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
+                upwelling_wjgradp=cases.upwelling_prs31, upwelling_kpp_ddmix=cases.upwelling_kpp_ddmix, benchmark_ddmix=cases.benchmark_ddmix, upwelling_prs40=cases.upwelling_prs40, upwelling_prs42=cases.upwelling_prs4x, upwelling_prs44=cases.upwelling_prs4x, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
                 upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]
     lbc = k.pop("lbc", None)
@@ -196,6 +199,8 @@ def reference(app, cs):
             else:
                 R.put(n, a)
         R.call("wetdry")
+    if cs.get("ddmix"):                 # a state with double diffusion in it (the analytic salinity is uniform): data, cases.ddmix_state
+        R.put("t", cases.ddmix_state(cs, R.get("t"), R.LBi, R.UBi, R.LBj, R.UBj))
     if cs.get("clima"):                 # the climatology and coefficient arrays: data (cases.clima_arrays), the reference's compact
         nij = (R.UBi - R.LBi + 1) * (R.UBj - R.LBj + 1)                              # tracer index = the nudged tracers in order
         ca = cases.clima_arrays(cs, nij)
@@ -228,6 +233,8 @@ def oracle_from(R, cs):
         O.set_geouv()
     if cs.get("prsgrd"):
         O.set_prsgrd(cs["prsgrd"])
+    if cs.get("ddmix"):
+        O.set_ddmix()
     if cs.get("clima"):
         O.set_clima(cs["clima"])
         for n, a in cases.clima_arrays(cs, O.ni * O.nj).items():

@@ -821,14 +821,14 @@ DETERMINISM_SMALL = [
     ("upwelling_mask_small", {}), ("seamount_small", {}), ("grav_adj_small", {}), ("overflow_small", {}),
     ("kelvin_small", {}), ("kelvin_plain_small", {}), ("upwelling_gls_small", {}), ("upwelling_my25_small", {}),
     ("upwelling_prs31_small", {}), ("upwelling_prs40_small", {}), ("upwelling_logdrag_small", {}), ("upwelling_bih_small", {}),
-    ("upwelling_prs42_small", {}), ("upwelling_prs44_small", {}),
+    ("upwelling_prs42_small", {}), ("upwelling_prs44_small", {}), ("benchmark_ddmix_small", {}), ("upwelling_kpp_ddmix_small", {}),
     ("upwelling_wetdry_small", {}),
 ]
 
 
 def _case_state(tag, kw):
     cs = util.case_for(tag, **kw)
-    itag = "upwelling_small" if tag.startswith("upwelling") else tag.replace("_plain", "")
+    itag = "upwelling_small" if tag.startswith("upwelling") else tag.replace("_plain", "").replace("_ddmix", "")
     g = util.load_init(itag, util.nghost_for(cs))
     if cs.get("wet_dry"):
         g = util.with_wetdry(cs, g)
@@ -836,6 +836,8 @@ def _case_state(tag, kw):
         g = util.with_masks(cs, g)
     if "gls_flags" in cs:
         g = util.with_gls(cs, g)
+    if cs.get("ddmix"):
+        g = util.with_ddmix_state(cs, g)
     return cs, g
 
 

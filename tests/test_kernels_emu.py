@@ -834,3 +834,38 @@ def test_kpp_block_form_bitwise(emu, tag):
     """) % (os.path.join(os.path.dirname(__file__), ".."), tag, emu)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ROMS_HIP_LMDCOL="3"), timeout=600)
     assert "BLK-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("tag", ["benchmark_ddmix_small", "upwelling_kpp_ddmix_small"])
+@pytest.mark.parametrize("form", ["0", "1", "2", "3"])
+def test_double_diffusive_mixing_bitwise(emu, tag, form):
+    """LMD_DDMIX (round 6): lmd_vmix.F:360-428 in every form of the KPP kernels (ROMS_HIP_LMDCOL = 0: two kernels, 1: the column
+    kernel, 2: one thread kernel, 3: the block kernel) with alfaobeta of both equations of state (k_eos_alfaobeta) on the state of
+    cases.ddmix_state -- salt fingering capped and not, diffusive convection with Rrho on both sides of 0.5 -- against the oracle
+    (pinned bit for bit to the reference built with the option: tests/test_oracle_vs_ref.py) over 6 steps, every bit; the
+    mixing coefficients differ from the run without the option.  In a child process: the library reads the switch once."""
+    import textwrap
+    code = textwrap.dedent("""
+        import sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        from tests import util
+        tag = %r
+        cs = util.case_for(tag)
+        g = util.with_ddmix_state(cs, util.load_init(util.init_tag(cs), util.nghost_for(cs)))
+        O = util.make_oracle(cs, g)
+        cs0 = dict(cs); cs0.pop("ddmix")
+        O0 = util.make_oracle(cs0, g)
+        H = util.make_hip(cs, g, %r)
+        O.start(); H.start(); O0.start()
+        for _ in range(6):
+            O.main3d_step(); H.main3d(1); O0.main3d_step()
+            for n in util.PROGNOSTIC + ["Akv", "Akt", "hsbl", "ghats"]:
+                a, b = H.download(n), O.field(n)
+                assert np.array_equal(a, b), (n, int((a != b).sum()), float(np.abs(a - b).max()))
+        assert (O.field("Akt") != O0.field("Akt")).sum() > 100
+        H.close()
+        print("DDMIX-OK")
+    """) % (os.path.join(os.path.dirname(__file__), ".."), tag, emu)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ROMS_HIP_LMDCOL=form), timeout=600)
+    assert "DDMIX-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -251,6 +251,12 @@ MAIN3D_CASES = [
     # the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h (PJ_GRADP)
     ("upwelling_prs40_small", ["nsteps=60"]),
     ("upwelling_prs40_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # LMD_DDMIX (round 6): double-diffusive mixing in lmd_vmix's interior scheme, alfaobeta from both equations of state; the
+    # state of cases.ddmix_state has salt fingering in one half and diffusive convection (Rrho on both sides of 0.5) in the other
+    ("upwelling_kpp_ddmix_small", ["nsteps=40"]),
+    ("upwelling_kpp_ddmix_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("benchmark_ddmix_small", ["nsteps=40"]),
+    ("benchmark_ddmix_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     # the finite-volume Jacobians of Shchepetkin & McWilliams (2003) with a reconstructed density profile (round 6): prsgrd44.h
     # (PJ_GRADPQ4: quartic, power-law reconciliation; any partition) and prsgrd42.h (PJ_GRADPQ2: parabolic WENO and a second pass
     # that reads rv(Iend+1,j) -- a column no tile computes: one tile only, oracle/orc_prs4x.c)

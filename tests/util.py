@@ -62,6 +62,10 @@ def case_for(tag, **kw):
         return cases.upwelling_kpp(Lm=14, Mm=18, N=8, **kw)
     if tag == "benchmark_small":
         return cases.benchmark(Lm=24, Mm=16, N=10, **kw)
+    if tag == "upwelling_kpp_ddmix_small":
+        return cases.upwelling_kpp_ddmix(Lm=14, Mm=18, N=8, **kw)
+    if tag == "benchmark_ddmix_small":
+        return cases.benchmark_ddmix(Lm=24, Mm=16, N=10, **kw)
     if tag == "benchmark_mask_small":
         return cases.benchmark_mask(Lm=24, Mm=16, N=10, **kw)
     if tag == "benchmark_wetdry_small":
@@ -171,6 +175,8 @@ def make_oracle(cs, g):
         O.set_geouv()
     if cs.get("prsgrd"):
         O.set_prsgrd(cs["prsgrd"])
+    if cs.get("ddmix"):
+        O.set_ddmix()
     if cs.get("clima"):
         O.set_clima(cs["clima"])
         for n, a in cases.clima_arrays(cs, np.asarray(g["h"]).size).items():
@@ -197,6 +203,14 @@ def with_masks(cs, g):
     assert g["h"].size == (UBi - LBi + 1) * (UBj - LBj + 1)
     for n, a in cases.land_mask(cs, LBi, UBi, LBj, UBj).items():
         g[n] = np.ascontiguousarray(a).ravel()
+    return g
+
+
+def with_ddmix_state(cs, g):
+    """the initial state `g` with the temperature / salinity of cases.ddmix_state: every branch of LMD_DDMIX is reached"""
+    g = dict(g)
+    LBi, UBi, LBj, UBj = [int(x) for x in g["bounds"][:4]]
+    g["t"] = cases.ddmix_state(cs, g["t"], LBi, UBi, LBj, UBj)
     return g
 
 
@@ -330,6 +344,8 @@ class OracleSide:
             self.g = with_wetdry(cs, self.g) if cs.get("wet_dry") else with_masks(cs, self.g)
         if "gls_flags" in cs:                    # initialize_mixing's values of the closure's arrays
             self.g = with_gls(cs, self.g)
+        if cs.get("ddmix"):                      # the temperature / salinity state with double diffusion in it (cases.ddmix_state)
+            self.g = with_ddmix_state(cs, self.g)
         self.O = make_oracle(cs, self.g)
         self.O.start()
 
@@ -431,6 +447,8 @@ class HipSide:
             self.g = with_wetdry(cs, self.g) if cs.get("wet_dry") else with_masks(cs, self.g)
         if "gls_flags" in cs:
             self.g = with_gls(cs, self.g)
+        if cs.get("ddmix"):
+            self.g = with_ddmix_state(cs, self.g)
         self.H = make_hip(cs, self.g, ninfo=ninfo)
         self.H.start()
 
