@@ -13,9 +13,9 @@
  * density slopes; default slope treatment), pinned by oracle/ref/upwelling_bihiso.h in the periodic channel.
  * PARITY: pinned (t3dmix.F builds in oracle/_ref: BENCHMARK for the geopotential form, OVERFLOW for the isopycnic one,
  * oracle/ref/upwelling_bihgeo.h for the biharmonic geopotential form in the periodic channel: main3d 60 steps, 2x2 tiles,
- * rhs3d on a random state.  NOT pinned: the conditions on LapT at closed western / eastern walls and the corner averages
- * (:475-600 for iwest, ieast and the corners) -- the reference's biharmonic libraries give NaN in a closed basin from their
- * own set-up on; the device refuses TS_DIF4 + MIX_GEO_TS there).
+ * rhs3d on a random state; the conditions on LapT at closed western / eastern walls and the corner averages (:475-600 for
+ * iwest, ieast and the corners; t3dmix4_iso.h:504-618) between four walls since round 6: tests/test_oracle_vs_ref.py,
+ * *_closed_small -- whole steps and rhs3d on a perturbed state, 2x2 tiles).
  */
 #include "orc.h"
 #include <stdlib.h>

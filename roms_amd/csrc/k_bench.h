@@ -15,6 +15,22 @@
 // ------------------------------------------------------------------------------- nonlinear EOS
 // one thread per column of (IstrT:IendT, JstrT:JendT); den1, bulk0/1/2 of level k+1 are carried
 // in registers for the Brunt-Vaisala frequency, rhoA/rhoS are accumulated top-down.
+// t3dmix4_geo.h / t3dmix4_iso.h, the first operator at closed western / eastern walls: the column outside is zero, the corner
+// value the average of the two boundary values next to it -- both zero (LBC closed; open boundaries are refused with TS_DIF4)
+#define T3D4_WE_WALLS(L_, ok_)                                                                                   \
+  if (!G.ewp) {                                                                                                   \
+    if (B.west && i == B.Istr) {                                                                                  \
+      L_[(long)(ok_) - 1] = 0.0;                                                                                  \
+      if (!G.nsp && B.south && j == B.Jstr) L_[(long)(ok_) - 1 - ni] = 0.5 * (0.0 + 0.0);                          \
+      if (!G.nsp && B.north && j == B.Jend) L_[(long)(ok_) - 1 + ni] = 0.5 * (0.0 + 0.0);                          \
+    }                                                                                                             \
+    if (B.east && i == B.Iend) {                                                                                  \
+      L_[(long)(ok_) + 1] = 0.0;                                                                                  \
+      if (!G.nsp && B.south && j == B.Jstr) L_[(long)(ok_) + 1 - ni] = 0.5 * (0.0 + 0.0);                          \
+      if (!G.nsp && B.north && j == B.Jend) L_[(long)(ok_) + 1 + ni] = 0.5 * (0.0 + 0.0);                          \
+    }                                                                                                             \
+  }
+
 struct EosLevel { double den, den1, bulk, bulk0, bulk1, bulk2, DbulkDS, DbulkDT, Dden1DS, Dden1DT; };
 
 KDEV EosLevel eos_level(double Tt_in, double Ts_in, double Tp) {
@@ -369,6 +385,8 @@ THREAD_KERNEL(k_t3dmix2_geo, KArgs) {
       // closed southern / northern wall :521-556 (LBC closed: the row outside is zero; gradient: the row inside)
       if (!G.nsp && B.south && j == B.Jstr) LapT[(long)ok - ni] = 0.0;
       if (!G.nsp && B.north && j == B.Jend) LapT[(long)ok + ni] = 0.0;
+      // closed western / eastern wall :475-520 and the corner averages :558-600 (of two zeros) -- round 6, pinned in a closed basin
+      T3D4_WE_WALLS(LapT, ok)
       Lk = Lp; Dm = Dk; Dk = Dp; Tm = Tk; FSm = FSk;
       continue;
     }
@@ -496,6 +514,8 @@ THREAD_KERNEL(k_t3dmix2_iso, KArgs) {
       // closed southern / northern wall :540-574 (LBC closed: the row outside is zero)
       if (!G.nsp && B.south && j == B.Jstr) LapT[(long)ok - ni] = 0.0;
       if (!G.nsp && B.north && j == B.Jend) LapT[(long)ok + ni] = 0.0;
+      // closed western / eastern wall :504-539 and the corner averages :576-618 (of two zeros) -- round 6
+      T3D4_WE_WALLS(LapT, ok)
       Lk = Lp; Dm = Dk; Dk = Dp; Tm = Tk; FSm = FSk;
       continue;
     }

@@ -2407,7 +2407,8 @@ static int mix4_config(roms_hip_ctx *c, int uv_vis4, int ts_dif4) {
   if (!c) return 8;
   DGrid &G = c->G;
   if (!uv_vis4 && !ts_dif4) { G.uv_vis4 = G.ts_dif4 = 0; return 0; }
-  if (ts_dif4 && (G.options & (ROMS_MIX_GEO_TS | ROMS_MIX_ISO_TS)) && !G.ewp) { set_error("TS_DIF4 + MIX_GEO_TS / MIX_ISO_TS in a domain with western / eastern walls: the conditions of t3dmix4_geo.h:475-600 (t3dmix4_iso.h:504-618) there and at the corners are not pinned (periodic channel only)"); return 5; }
+  // (round 6: TS_DIF4 + MIX_GEO_TS / MIX_ISO_TS between western / eastern walls -- the conditions of t3dmix4_geo.h:475-600, t3dmix4_iso.h:504-618
+  // on the first operator there and at the corners -- is pinned in a closed basin and no longer refused)
   if (G.obc) { set_error("UV_VIS4 / TS_DIF4 with open boundaries: the gradient conditions of the first harmonic operator are not built on the device"); return 5; }
   if (G.dia_ts || G.dia_uv) { set_error("UV_VIS4 / TS_DIF4: the per-term diagnostics of the biharmonic operators are not built"); return 5; }
   if (G.wet_dry) { set_error("UV_VIS4 / TS_DIF4 with WET_DRY: harmonic mixing along s-surfaces only (the barotropic kernel of a WET_DRY run carries no biharmonic block)"); return 5; }

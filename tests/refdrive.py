@@ -76,6 +76,12 @@ CASES = {
     "kelvin_plain": ("kelvin", dict(plain=True)),
     # ... and closed-basin variants of the other libraries for the routine-level tests (no RADIATION_2D; MASKING)
     "upwelling_obc_small": ("upwelling", dict(Lm=14, Mm=18, N=8)),
+    # closed basins (round 6): whole steps between four walls -- the corner values of every boundary routine -- and the biharmonic
+    # operators' conditions on the first operator at western / eastern walls (t3dmix4_geo.h:475-600, t3dmix4_iso.h:504-618, t3dmix4_s.h)
+    "upwelling_closed_small": ("upwelling", dict(Lm=14, Mm=18, N=8)),
+    "upwelling_bih_closed_small": ("upwelling_bih", dict(Lm=14, Mm=18, N=8)),
+    "upwelling_bihgeo_closed_small": ("upwelling_bihgeo", dict(Lm=14, Mm=18, N=8)),
+    "upwelling_bihiso_closed_small": ("upwelling_bihiso", dict(Lm=14, Mm=18, N=8)),
     "upwelling_mask_obc_small": ("upwelling_mask", dict(Lm=14, Mm=18, N=8)),
 }
 
@@ -166,8 +172,12 @@ def make_case(tag, **kw):
                 upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]
     lbc = k.pop("lbc", None)
     cs = ctor(**k)
-    if tag.endswith("_obc_small"):
+    if tag.endswith("_obc_small") or tag.endswith("_closed_small"):
         cs["EWperiodic"] = 0                 # all four edges are boundaries
+    if tag.endswith("_closed_small"):
+        cs["closed_state"] = 1               # ... with the set-up arrays of the periodic channel as input data (reference())
+        if "mix4" in cs:                     # (VISC4 = 4e8, TNU4 = 2e7 of the channel cases blow up between four walls within 13 steps --
+            cs["visc4"], cs["tnu4"] = 4.0e7, (2.0e6, 1.0e6)      # in the reference and, bit for bit, in the oracle; a tenth is stable)
     if lbc is not None:
         cs["lbc"] = lbc
     for n in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac", "lbc_tke", "clima"):
@@ -199,6 +209,13 @@ def reference(app, cs):
             else:
                 R.put(n, a)
         R.call("wetdry")
+    if cs.get("closed_state"):          # UPWELLING as a closed basin: ana_grid.h gives its bathymetry for a periodic channel only (h = 0
+        # otherwise: NaN from the first rho_eos on) -- the set-up arrays of the periodic fixture, cut to the closed basin's arrays, are
+        # the input data of the case on both sides (util.closed_basin_state)
+        g = util.closed_basin_state(cs, util.load_init(util.init_tag(cs), util.nghost_for(dict(cs, EWperiodic=1))))
+        for n in util.INIT_FIELDS:
+            if n in g and R.has(n) and R.get(n).size == np.asarray(g[n]).size:
+                R.put(n, g[n])
     if cs.get("ddmix"):                 # a state with double diffusion in it (the analytic salinity is uniform): data, cases.ddmix_state
         R.put("t", cases.ddmix_state(cs, R.get("t"), R.LBi, R.UBi, R.LBj, R.UBj))
     if cs.get("clima"):                 # the climatology and coefficient arrays: data (cases.clima_arrays), the reference's compact

@@ -822,12 +822,20 @@ DETERMINISM_SMALL = [
     ("kelvin_small", {}), ("kelvin_plain_small", {}), ("upwelling_gls_small", {}), ("upwelling_my25_small", {}),
     ("upwelling_prs31_small", {}), ("upwelling_prs40_small", {}), ("upwelling_logdrag_small", {}), ("upwelling_bih_small", {}),
     ("upwelling_prs42_small", {}), ("upwelling_prs44_small", {}), ("benchmark_ddmix_small", {}), ("upwelling_kpp_ddmix_small", {}),
+    # four walls (util.closed_basin_state): the fused corner stores of the barotropic engines, the first biharmonic operator's wall columns
+    ("upwelling_small", {"closed": True}), ("upwelling_bihgeo_small", {"closed": True}), ("upwelling_bihiso_small", {"closed": True}),
     ("upwelling_wetdry_small", {}),
 ]
 
 
 def _case_state(tag, kw):
+    kw = dict(kw)
+    closed = kw.pop("closed", False)
     cs = util.case_for(tag, **kw)
+    if closed:
+        cs["EWperiodic"] = 0
+        if "mix4" in cs:
+            cs["visc4"], cs["tnu4"] = 4.0e7, (2.0e6, 1.0e6)
     itag = "upwelling_small" if tag.startswith("upwelling") else tag.replace("_plain", "").replace("_ddmix", "")
     g = util.load_init(itag, util.nghost_for(cs))
     if cs.get("wet_dry"):
@@ -838,6 +846,8 @@ def _case_state(tag, kw):
         g = util.with_gls(cs, g)
     if cs.get("ddmix"):
         g = util.with_ddmix_state(cs, g)
+    if closed:
+        g = util.closed_basin_state(cs, g)
     return cs, g
 
 
@@ -1021,6 +1031,38 @@ def test_more_reference_applications_match_oracle(tag):
         tol = 1e-9 if (tag == "upwelling_bih_small" and n in ("ru", "rv", "rubar", "rvbar", "rufrc", "rvfrc", "rzeta")) else 1e-10
         assert util.relrms(a, b) <= tol, (n, util.relrms(a, b))
     assert max(np.abs(O.field("u")).max(), np.abs(O.field("v")).max()) > 1e-4
+    H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["upwelling_small", "upwelling_bih_small", "upwelling_bihgeo_small", "upwelling_bihiso_small"])
+def test_closed_basin_matches_oracle(tag):
+    """Round 6, four walls (the state of util.closed_basin_state, on which the oracle equals the reference bit for bit:
+    tests/test_oracle_vs_ref.py *_closed_small): 30 steps on the GPU with the fused barotropic engines -- the corner averages
+    stored by the producing thread, k_haloblock.h -- and the first biharmonic operator's wall columns and corner values
+    (k_bench.h:T3D4_WE_WALLS), perturbed at step 3 so that the walls and corners see gradients.  Bit for bit where the host's
+    libm is the recorded one, 1e-10 otherwise."""
+    cs = util.case_for(tag)
+    cs["EWperiodic"] = 0
+    if "mix4" in cs:
+        cs["visc4"], cs["tnu4"] = 4.0e7, (2.0e6, 1.0e6)
+    g = util.closed_basin_state(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g)
+    O.start(); H.start()
+    rng = np.random.default_rng(5)
+    for step in range(30):
+        if step == 2:
+            for n, amp in (("t", 0.05), ("u", 1e-3), ("v", 1e-3)):
+                a = O.field(n).copy()
+                a += amp * rng.standard_normal(a.size) * (a != 0.0 if n != "t" else 1.0)
+                O.field(n)[:] = a
+                H.upload(n, a)
+        O.main3d_step(); H.main3d(1)
+    for n in util.PROGNOSTIC:
+        a, b = H.download(n), O.field(n)
+        assert np.isfinite(a).all(), n
+        assert util.agree(a, b, 1e-10), (n, util.relrms(a, b))
     H.close()
 
 

@@ -869,3 +869,36 @@ def test_double_diffusive_mixing_bitwise(emu, tag, form):
     """) % (os.path.join(os.path.dirname(__file__), ".."), tag, emu)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ROMS_HIP_LMDCOL=form), timeout=600)
     assert "DDMIX-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("tag", ["upwelling_small", "upwelling_bih_small", "upwelling_bihgeo_small", "upwelling_bihiso_small"])
+def test_closed_basin_with_biharmonic_mixing_bitwise(emu, tag):
+    """Round 6: four walls.  The set-up arrays of the periodic channel cut to the closed basin's arrays (util.closed_basin_state:
+    the reference's ana_grid.h gives UPWELLING no bathymetry without a periodic direction) -- whole steps against the oracle, which
+    is pinned bit for bit to the reference on exactly this state (tests/test_oracle_vs_ref.py: *_closed_small, whole steps and
+    kernel by kernel on perturbed states): the corner values of every boundary routine, the barotropic engines with the corner
+    averages fused into their stores (k_haloblock.h: HB_CORNERS), and the conditions on the first biharmonic operator at the
+    western / eastern walls and the corners -- t3dmix4_s.h, t3dmix4_geo.h:475-600, t3dmix4_iso.h:504-618 (k_bench.h:
+    T3D4_WE_WALLS; refused until round 6) -- with a tenth of the channel cases' VISC4 / TNU4 (those blow up between four
+    walls, in the reference too)."""
+    cs = util.case_for(tag)
+    cs["EWperiodic"] = 0
+    if "mix4" in cs:
+        cs["visc4"], cs["tnu4"] = 4.0e7, (2.0e6, 1.0e6)
+    g = util.closed_basin_state(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start(); H.start()
+    rng = np.random.default_rng(5)
+    for step in range(8):
+        if step == 2:        # a perturbation that reaches the walls and the corners (the state at rest is uniform along xi)
+            for n, amp in (("t", 0.05), ("u", 1e-3), ("v", 1e-3)):
+                a = O.field(n).copy()
+                a += amp * rng.standard_normal(a.size) * (a != 0.0 if n != "t" else 1.0)
+                O.field(n)[:] = a
+                H.upload(n, a)
+        O.main3d_step(); H.main3d(1)
+        for n in util.PROGNOSTIC:
+            assert np.array_equal(H.download(n), O.field(n)), (step, n)
+    assert np.isfinite(O.diag()[0])
+    H.close()

@@ -251,6 +251,14 @@ MAIN3D_CASES = [
     # the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h (PJ_GRADP)
     ("upwelling_prs40_small", ["nsteps=60"]),
     ("upwelling_prs40_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # closed basins (round 6): the periodic channel's set-up arrays between four walls (ana_grid.h has no bathymetry for that) --
+    # every corner value, and the first biharmonic operator's conditions at western / eastern walls (a tenth of VISC4 / TNU4)
+    ("upwelling_closed_small", ["nsteps=30"]),
+    ("upwelling_closed_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
+    ("upwelling_bih_closed_small", ["nsteps=30"]),
+    ("upwelling_bihgeo_closed_small", ["nsteps=30"]),
+    ("upwelling_bihgeo_closed_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_bihiso_closed_small", ["nsteps=30"]),
     # LMD_DDMIX (round 6): double-diffusive mixing in lmd_vmix's interior scheme, alfaobeta from both equations of state; the
     # state of cases.ddmix_state has salt fingering in one half and diffusive convection (Rrho on both sides of 0.5) in the other
     ("upwelling_kpp_ddmix_small", ["nsteps=40"]),
@@ -347,9 +355,17 @@ def test_main3d_steps_bitwise(tag, args):
     ("upwelling_wetdry_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     ("upwelling_wetdry_obc_small", ["hadv=A4,C4", "vadv=SPLINES,C4"]),
     # t3dmix4_geo.h (called by rhs3d) in the periodic channel: the conditions on the first operator at the southern and
-    # northern walls.  (A closed-basin run of the biharmonic libraries is NaN from the reference's own set-up on, so the
-    # western / eastern walls and the corner averages of t3dmix4_geo.h:475-600 are restated in the oracle but NOT pinned; the
-    # device refuses that combination.)
+    # northern walls; *_closed_small (round 6): between four walls -- the western / eastern conditions and the corner averages
+    # of t3dmix4_geo.h:475-600, t3dmix4_iso.h:504-618, t3dmix4_s.h on a perturbed state.  (Until round 6 "the reference is NaN in
+    # a closed basin": its ana_grid.h gives UPWELLING no bathymetry without a periodic direction -- the set-up arrays of the
+    # channel are the case's input now, refdrive.reference -- and the channel cases' VISC4 / TNU4 blow up between four walls.)
+    ("upwelling_closed_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("upwelling_closed_small", ["hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_bih_closed_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("upwelling_bihgeo_closed_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("upwelling_bihgeo_closed_small", ["hadv=U3,U3", "vadv=C4,C4", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_bihiso_closed_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    ("upwelling_bihiso_closed_small", ["hadv=U3,U3", "vadv=C4,C4", "NtileI=2", "NtileJ=2"]),
     ("upwelling_bihgeo_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     ("upwelling_bihgeo_small", ["hadv=U3,U3", "vadv=C4,C4", "NtileI=2", "NtileJ=2"]),
     ("upwelling_bihiso_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
