@@ -322,6 +322,9 @@ void orc_set_geouv(orc_t *o, int on);                          /* MIX_GEO_UV: uv
 void orc_uv3dmix2_geo(orc_t *o, int tile);
 void orc_t3dmix4(orc_t *o, int tile);
 void orc_uv3dmix4(orc_t *o, int tile);
+void orc_uv3dmix4_geo(orc_t *o, int tile);                    /* orc_uvmix_geo.c: UV_VIS4 + MIX_GEO_UV */
+void orc_lap_bc(const orc_t *o, const orc_bounds *b, double *LapU, double *LapV, int isu, int isv, int iu0, int iu1, int ju0,
+                int ju1, int iv0, int iv1, int jv0, int jv1);   /* conditions on the first harmonic operator of momentum (orc_mix4.c) */
 void orc_step2d_vis4(orc_t *o, const orc_bounds *b, int krhs, const double *Drhs, double *rhs_ubar, double *rhs_vbar, double *U2rhs, double *V2rhs);
 int orc_set_diauv(orc_t *o);                 /* allocate (the window is the one of orc_set_dia_window) */
 void orc_diauv_free(orc_t *o);

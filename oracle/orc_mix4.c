@@ -96,8 +96,8 @@ void orc_t3dmix4(orc_t *o, int tile) {
 
 /* the conditions of the first harmonic operator of the momentum equations: uv3dmix4_s.h:335-470 (3-D: LBC of isUvel, isVvel)
    and step2d_LF_AM3.h:1722-1850 (2-D: isUbar, isVbar), on (iu0:iu1, ju0:ju1) for LapU and (iv0:iv1, jv0:jv1) for LapV */
-static void lap_bc(const orc_t *o, const orc_bounds *b, double *LapU, double *LapV, int isu, int isv, int iu0, int iu1, int ju0,
-                   int ju1, int iv0, int iv1, int jv0, int jv1) {
+void orc_lap_bc(const orc_t *o, const orc_bounds *b, double *LapU, double *LapV, int isu, int isv, int iu0, int iu1, int ju0,
+                int ju1, int iv0, int iv1, int jv0, int jv1) {
   ORC_LOCALS(o);
   const orc_cfg *c = &o->c;
   const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
@@ -144,6 +144,7 @@ static void lap_bc(const orc_t *o, const orc_bounds *b, double *LapU, double *La
 
 void orc_uv3dmix4(orc_t *o, int tile) {
   if (!o->uv_vis4) return;
+  if (o->mix_geo_uv) { orc_uv3dmix4_geo(o, tile); return; }          /* uv3dmix.F: MIX_GEO_UV -> uv3dmix4_geo.h */
   ORC_LOCALS(o);
   const orc_bounds *b = &o->b[tile];
   const orc_cfg *c = &o->c;
@@ -199,7 +200,7 @@ void orc_uv3dmix4(orc_t *o, int tile) {
         LapV[X2(i, j)] = 0.125 * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) *
                          ((pn[X2(i, j - 1)] + pn[X2(i, j)]) * (VFx[X2(i + 1, j)] - VFx[X2(i, j)]) -
                           (pm[X2(i, j - 1)] + pm[X2(i, j)]) * (VFe[X2(i, j)] - VFe[X2(i, j - 1)]));
-    lap_bc(o, b, LapU, LapV, ORC_ISUVEL, ORC_ISVVEL, IminU, ImaxU, JminU, JmaxU, IminV, ImaxV, JminV, JmaxV);
+    orc_lap_bc(o, b, LapU, LapV, ORC_ISUVEL, ORC_ISVVEL, IminU, ImaxU, JminU, JmaxU, IminV, ImaxV, JminV, JmaxV);
     for (int j = JstrV - 1; j <= Jend; j++)                      /* second operator :526-575 */
       for (int i = IstrU - 1; i <= Iend; i++) {
         cff = Hz[X3(i, j, k)] * 0.5 *
@@ -298,7 +299,7 @@ void orc_step2d_vis4(orc_t *o, const orc_bounds *b, int krhs, const double *Drhs
       LapV[X2(i, j)] = 0.125 * (pm[X2(i, j)] + pm[X2(i, j - 1)]) * (pn[X2(i, j)] + pn[X2(i, j - 1)]) *
                        ((pn[X2(i, j - 1)] + pn[X2(i, j)]) * (VFx[X2(i + 1, j)] - VFx[X2(i, j)]) -
                         (pm[X2(i, j - 1)] + pm[X2(i, j)]) * (VFe[X2(i, j)] - VFe[X2(i, j - 1)]));
-  lap_bc(o, b, LapU, LapV, ORC_ISUBAR, ORC_ISVBAR, b->IstrUm1, b->Iendp1, b->Jstrm1, b->Jendp1, b->Istrm1, b->Iendp1, b->JstrVm1, b->Jendp1);   /* :1728-1853 */
+  orc_lap_bc(o, b, LapU, LapV, ORC_ISUBAR, ORC_ISVBAR, b->IstrUm1, b->Iendp1, b->Jstrm1, b->Jendp1, b->Istrm1, b->Iendp1, b->JstrVm1, b->Jendp1);   /* :1728-1853 */
   for (int j = Jstr; j <= Jend + 1; j++)                         /* :1856-1893 */
     for (int i = Istr; i <= Iend + 1; i++)
       Drhs_p[X2(i, j)] = 0.25 * (Drhs[X2(i, j)] + Drhs[X2(i - 1, j)] + Drhs[X2(i, j - 1)] + Drhs[X2(i - 1, j - 1)]);

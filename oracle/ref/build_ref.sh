@@ -70,6 +70,11 @@ if [ "$APP" = upwelling_mask ]; then
   UP=UPWELLING; HDR=upwelling_mask; HDRPATH="$HERE/upwelling_mask.h"
   EXTRA="-I$HERE/functionals"     # the user analytical file ana_mask.h of this application
 fi
+if [ "$APP" = upwelling_bihgeouv ]; then
+  # ... with the BIHARMONIC viscosity along geopotential surfaces (oracle/ref/upwelling_bihgeouv.h: UV_VIS4 + MIX_GEO_UV, uv3dmix4_geo.h)
+  UP=UPWELLING; HDR=upwelling_bihgeouv; HDRPATH="$HERE/upwelling_bihgeouv.h"
+  EXTRA="-I$HERE/functionals"
+fi
 if [ "$APP" = upwelling_geouv ]; then
   # UPWELLING + MASKING with the viscosity along geopotential surfaces (oracle/ref/upwelling_geouv.h: MIX_GEO_UV, uv3dmix2_geo.h)
   UP=UPWELLING; HDR=upwelling_geouv; HDRPATH="$HERE/upwelling_geouv.h"

@@ -348,6 +348,18 @@ def upwelling_geouv(**kw):
     return cs
 
 
+def upwelling_bihgeouv(visc4=4.0e7, **kw):
+    """... with the BIHARMONIC viscosity along geopotential surfaces (UV_VIS4 + MIX_GEO_UV, uv3dmix4_geo.h: the rotated stress tensor
+    twice) under MASKING, the tracers with their harmonic operator along s-surfaces; the custom application header
+    oracle/ref/upwelling_bihgeouv.h.  (VISC4 = 4e7: with the 4e8 of the s-surface cases the masked channel blows up within ten
+    steps, in the reference and bit for bit in the oracle.)"""
+    cs = upwelling_geouv(**kw)
+    cs["app"] = "upwelling_bihgeouv"
+    cs["options"] = tuple(o for o in cs["options"] if o != "UV_VIS2")
+    cs["mix4"], cs["visc4"], cs["tnu4"] = (1, 0), visc4, (0.0, 0.0)
+    return cs
+
+
 def upwelling_wetdry(Dcrit=0.1, **kw):
     """UPWELLING with land/sea masking and wetting and drying (MASKING + WET_DRY): the custom application header
     oracle/ref/upwelling_wetdry.h.  The land is `land_mask`; the bathymetry and the initial free surface are

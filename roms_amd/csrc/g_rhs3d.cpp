@@ -228,25 +228,41 @@ int run_t3dmix2(roms_hip_ctx *c) {
   return 0;
 }
 
-// uv3dmix2_geo.h: every loop nest of the routine as a point-wise kernel over all levels (k_uvmix_geo.h)
-static int run_uv3dmix2_geo(roms_hip_ctx *c) {
+// uv3dmix2_geo.h: every loop nest of the routine as a point-wise kernel over all levels (k_uvmix_geo.h); mode 0 harmonic,
+// 1 | 2 the first | second operator of uv3dmix4_geo.h (the first on the ranges widened by one point: ug_ranges)
+static int run_uvmix_geo_op(roms_hip_ctx *c, int mode) {
+  const DGrid &G = c->G;
+  KArgs a = mk(c);
+  a.p0 = mode;
+  const int N = G.N;
+  const UgR R = ug_ranges(G.T, mode);
+  LAUNCH_THREAD(k_uvg_slopes, R.iE1 - KMIN(R.iU1, R.iS1) + 1, R.jE1 - KMIN(R.jS1, R.jV1) + 1, N + 1, c->stream, a);
+  LAUNCH_THREAD(k_uvg_grads, R.iE1 - KMIN(R.iU1, R.iS0) + 1, R.jE1 - KMIN(R.jV1, R.jS0) + 1, N, c->stream, a);
+  LAUNCH_THREAD(k_uvg_flux, R.iE1 - KMIN(R.iU1, R.iS0) + 1, R.jE1 - KMIN(R.jV1, R.jS0) + 1, N, c->stream, a);
+  LAUNCH_THREAD(k_uvg_vflux, R.iE0 - R.iS0 + 1, R.jE0 - R.jS0 + 1, N + 1, c->stream, a);
+  LAUNCH_THREAD(k_uvg_step, R.iE0 - R.iS0 + 1, R.jE0 - R.jS0 + 1, 1, c->stream, a);
+  return 0;
+}
+static int run_uv3dmix2_geo(roms_hip_ctx *c) { return run_uvmix_geo_op(c, 0); }
+// uv3dmix4_geo.h (UV_VIS4 + MIX_GEO_UV, round 6): the operator twice, the conditions on LapU, LapV between
+static int run_uv3dmix4_geo(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
+  int r = run_uvmix_geo_op(c, 1);
+  if (r) return r;
   KArgs a = mk(c);
-  const int N = G.N;
-  LAUNCH_THREAD(k_uvg_slopes, B.Iend + 1 - (KMIN(B.IstrU, B.Istr) - 1) + 1, B.Jend + 1 - (KMIN(B.Jstr, B.JstrV) - 1) + 1, N + 1, c->stream, a);
-  LAUNCH_THREAD(k_uvg_grads, B.Iend + 1 - KMIN(B.IstrU - 1, B.Istr) + 1, B.Jend + 1 - KMIN(B.JstrV - 1, B.Jstr) + 1, N, c->stream, a);
-  LAUNCH_THREAD(k_uvg_flux, B.Iend + 1 - KMIN(B.IstrU - 1, B.Istr) + 1, B.Jend + 1 - KMIN(B.JstrV - 1, B.Jstr) + 1, N, c->stream, a);
-  LAUNCH_THREAD(k_uvg_vflux, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, N + 1, c->stream, a);
-  LAUNCH_THREAD(k_uvg_step, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 1, c->stream, a);
-  return 0;
+  const int nx = (B.Iendp1 + 1) - (B.Istrm1 - 1) + 1, ny = (B.Jendp1 + 1) - (B.Jstrm1 - 1) + 1;
+  a.p1 = 0;
+  LAUNCH_THREAD(k_uvg_lapbc, nx, ny, G.N, c->stream, a);
+  if (!(G.ewp || G.nsp)) { a.p1 = 1; LAUNCH_THREAD(k_uvg_lapbc, nx, ny, G.N, c->stream, a); }
+  return run_uvmix_geo_op(c, 2);
 }
 
 int run_uv3dmix2(roms_hip_ctx *c) {
   const DGrid &G = c->G;
   const TB &B = G.T;
   if (!(G.options & ROMS_UV_VIS2)) return 0;
-  if (G.mix_geo_uv) return run_uv3dmix2_geo(c);
+  if (G.mix_geo_uv) return G.uv_vis4 ? run_uv3dmix4_geo(c) : run_uv3dmix2_geo(c);      // (uv3dmix.F: one of the two)
   KArgs a = mk(c);
   if (G.uv_vis4) launch_uv3dmix4(c, c->late_pre ? 1 : 0);
   else

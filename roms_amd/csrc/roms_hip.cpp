@@ -670,13 +670,13 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     if (cfg->options & ROMS_WET_DRY) { set_error("WET_DRY: the density Jacobian prsgrd32.h only (DJ_GRADPS)"); roms_hip_destroy(c); return 5; }
     if (c->G.N < 3) { set_error("PJ_GRADPQ2 / PJ_GRADPQ4: the reconstruction needs three levels"); roms_hip_destroy(c); return 5; }
   }
-  if (cfg->options & ROMS_MIX_GEO_UV) {                     // uv3dmix2_geo.h (k_uvmix_geo.h): twenty 3-D work arrays
-    if (!(cfg->options & ROMS_UV_VIS2) || c->G.uv_vis4) { set_error("MIX_GEO_UV: the harmonic viscosity only (UV_VIS2; uv3dmix4_geo.h is not built)"); roms_hip_destroy(c); return 5; }
+  if (cfg->options & ROMS_MIX_GEO_UV) {                     // uv3dmix2_geo.h | uv3dmix4_geo.h (k_uvmix_geo.h): twenty-two 3-D work arrays
+    if (!(cfg->options & ROMS_UV_VIS2) && !c->G.uv_vis4) { set_error("MIX_GEO_UV without UV_VIS2 or UV_VIS4"); roms_hip_destroy(c); return 5; }
     if (c->G.obc) { set_error("MIX_GEO_UV with open boundaries: not pinned"); roms_hip_destroy(c); return 5; }
     if (cfg->options & ROMS_DIAGNOSTICS_UV) { set_error("MIX_GEO_UV: the DIAGNOSTICS_UV statements of uv3dmix2_geo.h are not built"); roms_hip_destroy(c); return 5; }
     if (cfg->options & ROMS_WET_DRY) { set_error("MIX_GEO_UV with WET_DRY: not pinned against the reference"); roms_hip_destroy(c); return 5; }
     void *p = nullptr;
-    if (dmalloc(&p, (size_t)20 * (size_t)c->G.nij * (size_t)(c->G.N + 1) * sizeof(double))) { roms_hip_destroy(c); return 2; }
+    if (dmalloc(&p, (size_t)22 * (size_t)c->G.nij * (size_t)(c->G.N + 1) * sizeof(double))) { roms_hip_destroy(c); return 2; }    // (UG_NARR)
     c->allocs.push_back(p);
     c->F.gwrk = (double *)p;
     c->G.mix_geo_uv = 1;

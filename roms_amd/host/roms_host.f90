@@ -828,7 +828,13 @@
 !  (UPWELLING_BIH = oracle/ref/upwelling_bih.h: biharmonic mixing along s-surfaces in place of the harmonic operators)
 !  (UPWELLING_BIHGEO = oracle/ref/upwelling_bihgeo.h: ... the tracers along geopotentials; _BIHISO: along isopycnals; UPWELLING_GEOUV =
 !  oracle/ref/upwelling_geouv.h: MASKING and the harmonic viscosity along geopotentials, MIX_GEO_UV)
-        IF (MyAppCPP(1:13).eq.'UPWELLING_BIH'.and.(TRIM(common(k)).eq.'UV_VIS2'.or.TRIM(common(k)).eq.'TS_DIF2')) CYCLE
+!  (UPWELLING_BIHGEOUV = oracle/ref/upwelling_bihgeouv.h: the BIHARMONIC viscosity along geopotentials, uv3dmix4_geo.h, under MASKING;
+!  the tracers keep their harmonic operator)
+        IF (TRIM(MyAppCPP).eq.'UPWELLING_BIHGEOUV') THEN
+          IF (TRIM(common(k)).eq.'UV_VIS2'.or.TRIM(common(k)).eq.'MIX_S_UV') CYCLE
+        ELSE IF (MyAppCPP(1:13).eq.'UPWELLING_BIH'.and.(TRIM(common(k)).eq.'UV_VIS2'.or.TRIM(common(k)).eq.'TS_DIF2')) THEN
+          CYCLE
+        END IF
         IF (TRIM(MyAppCPP).eq.'UPWELLING_GEOUV'.and.TRIM(common(k)).eq.'MIX_S_UV') CYCLE
 !  (UPWELLING_PRS40 / _PRS42 / _PRS44 = oracle/ref/upwelling_prs40.h ...: PJ_GRADP / PJ_GRADPQ2 / PJ_GRADPQ4 in DJ_GRADPS' place)
         IF (MyAppCPP(1:14).eq.'UPWELLING_PRS4'.and.TRIM(common(k)).eq.'DJ_GRADPS') CYCLE
@@ -837,7 +843,9 @@
       IF (TRIM(MyAppCPP).eq.'UPWELLING_PRS40') CALL define ('PJ_GRADP')
       IF (TRIM(MyAppCPP).eq.'UPWELLING_PRS42') CALL define ('PJ_GRADPQ2')
       IF (TRIM(MyAppCPP).eq.'UPWELLING_PRS44') CALL define ('PJ_GRADPQ4')
-      IF (MyAppCPP(1:13).eq.'UPWELLING_BIH') THEN
+      IF (TRIM(MyAppCPP).eq.'UPWELLING_BIHGEOUV') THEN
+        CALL define ('UV_VIS4'); CALL define ('MIX_GEO_UV')
+      ELSE IF (MyAppCPP(1:13).eq.'UPWELLING_BIH') THEN
         CALL define ('UV_VIS4'); CALL define ('TS_DIF4')
       END IF
       IF (TRIM(MyAppCPP).eq.'UPWELLING_GEOUV') CALL define ('MIX_GEO_UV')
@@ -881,7 +889,7 @@
       CALL define ('ANA_INITIAL'); CALL define ('SPLINES_VDIFF'); CALL define ('SPLINES_VVISC')
       SELECT CASE (TRIM(MyAppCPP))
         CASE ('UPWELLING', 'UPWELLING_KPP', 'UPWELLING_LOGDRAG', 'UPWELLING_MASK', 'UPWELLING_BIH', 'UPWELLING_WETDRY',  &  ! (oracle/ref/upwelling_logdrag.h, _mask.h, _bih.h, _wetdry.h)
-     &        'UPWELLING_BIHGEO', 'UPWELLING_BIHISO', 'UPWELLING_GEOUV', 'UPWELLING_PRS40', 'UPWELLING_PRS42',          &
+     &        'UPWELLING_BIHGEO', 'UPWELLING_BIHISO', 'UPWELLING_GEOUV', 'UPWELLING_BIHGEOUV', 'UPWELLING_PRS40', 'UPWELLING_PRS42',          &
      &        'UPWELLING_PRS44', 'UPWELLING_GLS', 'UPWELLING_GLS_CA', 'UPWELLING_GLS_CB', 'UPWELLING_GLS_GAL', 'UPWELLING_MY25',         &
      &        'UPWELLING_MY25_GAL')
 !  UPWELLING_GLS = upwelling.h built with -DGLS_MIXING; _CA, _CB, _GAL = oracle/ref/upwelling_gls_ca.h, _cb.h, _gal.h: the
@@ -896,7 +904,8 @@
           ELSE IF (TRIM(MyAppCPP).eq.'UPWELLING_GLS_GAL') THEN
             CALL define ('K_C4ADVECTION'); CALL define ('RI_SPLINES')
           END IF
-          IF (TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.TRIM(MyAppCPP).eq.'UPWELLING_GEOUV') CALL define ('MASKING')
+          IF (TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.TRIM(MyAppCPP).eq.'UPWELLING_GEOUV'.or.                               &
+     &        TRIM(MyAppCPP).eq.'UPWELLING_BIHGEOUV') CALL define ('MASKING')
           IF (TRIM(MyAppCPP).eq.'UPWELLING_WETDRY') THEN
             CALL define ('MASKING'); CALL define ('WET_DRY')
           END IF
@@ -1061,14 +1070,15 @@
       IF ((mix4(1).and.is_defined('UV_VIS2')).or.(mix4(2).and.is_defined('TS_DIF2')))                          &
      &  CALL unsupported ('harmonic and biharmonic mixing of the same field together (UV_VIS2 + UV_VIS4, TS_DIF2 + TS_DIF4) '// &
      &                    'are not built', ierr)
-      IF (mix4(1).and..not.is_defined('MIX_S_UV')) CALL unsupported ('UV_VIS4 is built along s-surfaces only (MIX_S_UV)', ierr)
+      IF (mix4(1).and.COUNT((/ is_defined('MIX_S_UV'), is_defined('MIX_GEO_UV') /)).ne.1)                               &
+     &  CALL unsupported ('UV_VIS4 needs exactly one of MIX_S_UV, MIX_GEO_UV', ierr)
       IF (mix4(1)) options=IOR(options, ROMS_UV_VIS2)
       IF (mix4(2)) options=IOR(options, ROMS_TS_DIF2)
 !  (an application without UV_ADV, UV_VIS2 or TS_DIF2 -- the reference's WINDBASIN option set -- runs since round 5: the
 !  library is pinned to a reference build without them, oracle/ref/upwelling_noadv.h)
       IF (is_defined('UV_VIS2').and.COUNT((/ is_defined('MIX_S_UV'), is_defined('MIX_GEO_UV') /)).ne.1)                &
      &  CALL unsupported ('UV_VIS2 needs exactly one of MIX_S_UV, MIX_GEO_UV', ierr)
-      mix_geo_uv=is_defined('UV_VIS2').and.is_defined('MIX_GEO_UV')
+      mix_geo_uv=(is_defined('UV_VIS2').or.mix4(1)).and.is_defined('MIX_GEO_UV')         ! (uv3dmix2_geo.h | uv3dmix4_geo.h, round 6)
       IF ((is_defined('TS_DIF2').or.mix4(2)).and.COUNT((/ is_defined('MIX_S_TS'), is_defined('MIX_GEO_TS'), is_defined('MIX_ISO_TS') /)).ne.1) &
      &  CALL unsupported ('TS_DIF2 needs exactly one of MIX_S_TS, MIX_GEO_TS, MIX_ISO_TS', ierr)
       IF (is_defined('MIX_ISO_TS').and.(is_defined('TS_MIX_MAX_SLOPE').or.is_defined('TS_MIX_MIN_STRAT').or.          &

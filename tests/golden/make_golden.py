@@ -294,6 +294,7 @@ STEP_CASES = [
     ("upwelling_small_prs44", "upwelling_prs44_small", ["nsteps=60"]),       # PJ_GRADPQ4, prsgrd44.h
     ("upwelling_small_bih", "upwelling_bih_small", ["nsteps=60"]),           # UV_VIS4 + TS_DIF4 along s-surfaces (upwelling_bih.h)
     ("upwelling_small_geouv", "upwelling_geouv_small", ["nsteps=60"]),       # UV_VIS2 along geopotentials under MASKING (uv3dmix2_geo.h; upwelling_geouv.h)
+    ("upwelling_small_bihgeouv", "upwelling_bihgeouv_small", ["nsteps=60"]), # UV_VIS4 along geopotentials under MASKING (uv3dmix4_geo.h; upwelling_bihgeouv.h), round 6
     ("upwelling_small_bihiso", "upwelling_bihiso_small", ["nsteps=60"]),     # ... along isopycnals (t3dmix4_iso.h; upwelling_bihiso.h)
     ("upwelling_small_bihgeo", "upwelling_bihgeo_small", ["nsteps=60"]),     # ... the tracers along geopotentials (t3dmix4_geo.h; upwelling_bihgeo.h)
     ("upwelling_small_wetdry", "upwelling_wetdry_small", ["nsteps=60"]),     # MASKING + WET_DRY (upwelling_wetdry.h; cases.wetdry_depth)

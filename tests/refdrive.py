@@ -51,6 +51,8 @@ CASES = {
     # biharmonic mixing along s-surfaces (oracle/ref/upwelling_bih.h: UV_VIS4, TS_DIF4)
     # harmonic viscosity along geopotential surfaces under MASKING (oracle/ref/upwelling_geouv.h: MIX_GEO_UV, uv3dmix2_geo.h)
     "upwelling_geouv_small": ("upwelling_geouv", dict(Lm=14, Mm=18, N=8)),
+    "upwelling_bihgeouv_small": ("upwelling_bihgeouv", dict(Lm=14, Mm=18, N=8)),     # UV_VIS4 + MIX_GEO_UV under MASKING (uv3dmix4_geo.h; round 6)
+    "upwelling_bihgeouv_closed_small": ("upwelling_bihgeouv", dict(Lm=14, Mm=18, N=8)),
     "upwelling_bih_small": ("upwelling_bih", dict(Lm=14, Mm=18, N=8)),
     "upwelling_bihgeo_small": ("upwelling_bihgeo", dict(Lm=14, Mm=18, N=8)),         # ... tracers along geopotentials (t3dmix4_geo.h)
     "upwelling_bihiso_small": ("upwelling_bihiso", dict(Lm=14, Mm=18, N=8)),         # ... along isopycnals (t3dmix4_iso.h)
@@ -166,7 +168,7 @@ def make_case(tag, **kw):
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_diag=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag, upwelling_noadv=cases.upwelling_noadv,
                 upwelling_mask=cases.upwelling_mask, upwelling_wetdry=cases.upwelling_wetdry, benchmark_mask=cases.benchmark_mask, benchmark_wetdry=cases.benchmark_wetdry,
-                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
+                upwelling_avg_mask=cases.upwelling_mask, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeouv=cases.upwelling_bihgeouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
                 upwelling_wjgradp=cases.upwelling_prs31, upwelling_kpp_ddmix=cases.upwelling_kpp_ddmix, benchmark_ddmix=cases.benchmark_ddmix, upwelling_prs40=cases.upwelling_prs40, upwelling_prs42=cases.upwelling_prs4x, upwelling_prs44=cases.upwelling_prs4x, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
                 upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]

@@ -824,6 +824,7 @@ DETERMINISM_SMALL = [
     ("upwelling_prs42_small", {}), ("upwelling_prs44_small", {}), ("benchmark_ddmix_small", {}), ("upwelling_kpp_ddmix_small", {}),
     # four walls (util.closed_basin_state): the fused corner stores of the barotropic engines, the first biharmonic operator's wall columns
     ("upwelling_small", {"closed": True}), ("upwelling_bihgeo_small", {"closed": True}), ("upwelling_bihiso_small", {"closed": True}),
+    ("upwelling_bihgeouv_small", {}), ("upwelling_bihgeouv_small", {"closed": True}),          # uv3dmix4_geo.h: the conditions on LapU, LapV, their corner averages
     ("upwelling_wetdry_small", {}),
 ]
 
@@ -1035,7 +1036,7 @@ def test_more_reference_applications_match_oracle(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["upwelling_small", "upwelling_bih_small", "upwelling_bihgeo_small", "upwelling_bihiso_small"])
+@pytest.mark.parametrize("tag", ["upwelling_small", "upwelling_bih_small", "upwelling_bihgeo_small", "upwelling_bihiso_small", "upwelling_bihgeouv_small"])
 def test_closed_basin_matches_oracle(tag):
     """Round 6, four walls (the state of util.closed_basin_state, on which the oracle equals the reference bit for bit:
     tests/test_oracle_vs_ref.py *_closed_small): 30 steps on the GPU with the fused barotropic engines -- the corner averages
@@ -1046,7 +1047,10 @@ def test_closed_basin_matches_oracle(tag):
     cs["EWperiodic"] = 0
     if "mix4" in cs:
         cs["visc4"], cs["tnu4"] = 4.0e7, (2.0e6, 1.0e6)
-    g = util.closed_basin_state(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    if "MASKING" in cs["options"]:
+        g = util.with_masks(cs, g)
+    g = util.closed_basin_state(cs, g)
     O = util.make_oracle(cs, g)
     H = util.make_hip(cs, g)
     O.start(); H.start()

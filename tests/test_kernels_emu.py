@@ -608,6 +608,38 @@ def test_viscosity_along_geopotentials_bitwise(emu):
     H.close()
 
 
+@pytest.mark.parametrize("closed", [False, True])
+def test_biharmonic_viscosity_along_geopotentials_bitwise(emu, closed):
+    """Round 6: UV_VIS4 + MIX_GEO_UV under MASKING (uv3dmix4_geo.h:296-1478: the kernels of k_uvmix_geo.h in their modes 1 and 2 and
+    k_uvg_lapbc between them) -- 10 steps against the oracle (pinned bit for bit to the reference built from
+    oracle/ref/upwelling_bihgeouv.h: channel, four walls, 2x2 tiles, kernel by kernel on perturbed states), bit for bit, in
+    the periodic channel and between four walls (the corner averages of LapU, LapV); the result differs from the harmonic run."""
+    cs = util.case_for("upwelling_bihgeouv_small")
+    g = util.with_masks(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    csh = util.case_for("upwelling_geouv_small", hadv=cs["hadv"], vadv=cs["vadv"])
+    gh = util.with_masks(csh, util.load_init("upwelling_small", util.nghost_for(cs)))
+    if closed:
+        cs["EWperiodic"] = 0
+        g = util.closed_basin_state(cs, g)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start(); H.start()
+    rng = np.random.default_rng(7)
+    for step in range(10):
+        if step == 2:
+            for n, amp in (("u", 2e-3), ("v", 2e-3)):
+                a = O.field(n).copy()
+                a += amp * rng.standard_normal(a.size) * (a != 0.0)
+                O.field(n)[:] = a
+                H.upload(n, a)
+        O.main3d_step(); H.main3d(1)
+        for n in util.PROGNOSTIC + ["rufrc", "rvfrc"]:
+            a, b = H.download(n), O.field(n)
+            assert np.array_equal(a, b), (step, n, int((a != b).sum()), float(np.abs(a - b).max()))
+    assert np.isfinite(O.field("u")).all() and np.abs(O.field("u")).max() > 1e-4
+    H.close()
+
+
 @pytest.mark.parametrize("tag", ["upwelling_bih_small", "upwelling_bihgeo_small", "upwelling_bihiso_small"])
 def test_biharmonic_mixing_bitwise(emu, tag):
     """UV_VIS4 + TS_DIF4 along s-surfaces (uv3dmix4_s.h, t3dmix4_s.h, the UV_VIS4 block of step2d_LF_AM3.h): k_uv4_lap +

@@ -251,6 +251,11 @@ MAIN3D_CASES = [
     # the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h (PJ_GRADP)
     ("upwelling_prs40_small", ["nsteps=60"]),
     ("upwelling_prs40_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # UV_VIS4 + MIX_GEO_UV (round 6): uv3dmix4_geo.h, the rotated stress tensor twice, under MASKING; in the channel and between four walls
+    ("upwelling_bihgeouv_small", ["nsteps=60"]),
+    ("upwelling_bihgeouv_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=U3,U3", "vadv=C4,C4"]),
+    ("upwelling_bihgeouv_closed_small", ["nsteps=30"]),
+    ("upwelling_bihgeouv_closed_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     # closed basins (round 6): the periodic channel's set-up arrays between four walls (ana_grid.h has no bathymetry for that) --
     # every corner value, and the first biharmonic operator's conditions at western / eastern walls (a tenth of VISC4 / TNU4)
     ("upwelling_closed_small", ["nsteps=30"]),
@@ -359,6 +364,9 @@ def test_main3d_steps_bitwise(tag, args):
     # of t3dmix4_geo.h:475-600, t3dmix4_iso.h:504-618, t3dmix4_s.h on a perturbed state.  (Until round 6 "the reference is NaN in
     # a closed basin": its ana_grid.h gives UPWELLING no bathymetry without a periodic direction -- the set-up arrays of the
     # channel are the case's input now, refdrive.reference -- and the channel cases' VISC4 / TNU4 blow up between four walls.)
+    ("upwelling_bihgeouv_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),                  # uv3dmix4_geo.h (round 6)
+    ("upwelling_bihgeouv_small", ["hadv=U3,U3", "vadv=C4,C4", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_bihgeouv_closed_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     ("upwelling_closed_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     ("upwelling_closed_small", ["hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA", "NtileI=2", "NtileJ=2"]),
     ("upwelling_bih_closed_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),

@@ -97,6 +97,9 @@ def _interior(cs_dims, a):
     ("upwelling_geouv_mid", dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), (2, 2), 29635),
     ("upwelling_bihgeo_mid", dict(), (2, 2), 29636),
     ("upwelling_bihiso_mid", dict(), (2, 2), 29646),
+    # round 6: the BIHARMONIC viscosity along geopotentials (uv3dmix4_geo.h): the first operator on the tile widened by one point
+    # -- three ghost lines of u, v, z_r, Hz --, its conditions on the edge tiles only; MASKING
+    ("upwelling_bihgeouv_mid", dict(hadv=("U3", "U3"), vadv=("C4", "C4")), (2, 2), 29648),
     # round 6: PJ_GRADPQ4 (prsgrd44.h: the reconstruction runs on the tile widened by one column; no partition dependence)
     ("upwelling_prs44_small", dict(), (2, 2), 29647),
 ])

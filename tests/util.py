@@ -85,6 +85,8 @@ def case_for(tag, **kw):
         return cases.upwelling_mask(Lm=34, Mm=40, N=6, **kw)
     if tag == "upwelling_prs31_small":
         return cases.upwelling_prs31(Lm=14, Mm=18, N=8, **kw)
+    if tag == "upwelling_bihgeouv_small":
+        return cases.upwelling_bihgeouv(Lm=14, Mm=18, N=8, **kw)
     if tag == "upwelling_prs40_small":
         return cases.upwelling_prs40(Lm=14, Mm=18, N=8, **kw)
     if tag in ("upwelling_prs42_small", "upwelling_prs44_small"):
@@ -101,6 +103,8 @@ def case_for(tag, **kw):
         return cases.upwelling_bihiso(Lm=34, Mm=40, N=6, **kw)
     if tag == "upwelling_geouv_mid":
         return cases.upwelling_geouv(Lm=34, Mm=40, N=6, **kw)
+    if tag == "upwelling_bihgeouv_mid":
+        return cases.upwelling_bihgeouv(Lm=34, Mm=40, N=6, **kw)
     if tag == "upwelling_bihgeo_mid":
         return cases.upwelling_bihgeo(Lm=34, Mm=40, N=6, **kw)
     if tag == "upwelling_bih_mid":
