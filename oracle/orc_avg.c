@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include "orc.h"
+#define MAX(a, b) ((a) > (b) ? (a) : (b))
+#define MIN(a, b) ((a) < (b) ? (a) : (b))
 
 enum { A_ZETA, A_UBAR, A_VBAR, A_U, A_V, A_OMEGA, A_W, A_RHO, A_T, A_ZZ, A_U2, A_V2, A_UU, A_VV, A_UV, A_HUON,
        A_HVOM, A_TT, A_UT, A_VT, A_HUT, A_HVT, A_NFIELDS };
@@ -32,7 +34,9 @@ static const adesc AD[A_NFIELDS] = {
   {"avg_HuonT", 'u', 1, 1, 4}, {"avg_HvomT", 'v', 1, 1, 5},
 };
 
-typedef struct { int nAVG, ntsAVG, nrrec, ntstart; double *a[A_NFIELDS]; double avgtime; } avg_state;
+/* cnt: WET_DRY -- the wet-point counters GRID%rmask_avg, umask_avg, vmask_avg of set_avg.F:257-288, :1608-1645 (pmask_avg serves
+   the vorticity fields only, which are not among the 22) */
+typedef struct { int nAVG, ntsAVG, nrrec, ntstart; double *a[A_NFIELDS]; double avgtime; double *cnt[3]; } avg_state;
 
 static size_t planes(const orc_t *o, int f) {
   const size_t N = (size_t)o->c.N;
@@ -46,6 +50,7 @@ void orc_set_avg_window(orc_t *o, int nAVG, int ntsAVG, int nrrec, int ntstart) 
   if (!s) {
     s = (avg_state *)calloc(1, sizeof(avg_state));
     for (int f = 0; f < A_NFIELDS; f++) s->a[f] = (double *)calloc(planes(o, f) * o->nij, sizeof(double));
+    for (int m = 0; m < 3; m++) s->cnt[m] = (double *)calloc(o->nij, sizeof(double));
     o->avg = s;
   }
   s->nAVG = nAVG; s->ntsAVG = ntsAVG; s->nrrec = nrrec; s->ntstart = ntstart;
@@ -54,6 +59,7 @@ void orc_avg_free(orc_t *o) {
   avg_state *s = (avg_state *)o->avg;
   if (!s) return;
   for (int f = 0; f < A_NFIELDS; f++) free(s->a[f]);
+  for (int m = 0; m < 3; m++) free(s->cnt[m]);
   free(s);
   o->avg = NULL;
 }
@@ -117,6 +123,20 @@ void orc_set_avg(orc_t *o, int tile) {
   const int accum = !init && iic > ntsAVG;                         /* :1606 */
   const int convert = ((iic > ntsAVG) && ((iic - 1) % nAVG == 0) && (iic != s->ntstart || s->nrrec == 0)) ||
                       ((iic >= ntsAVG) && nAVG == 1);              /* :2962-2965 */
+  /* WET_DRY: every field times the full mask (land x wet) of its grid type where it is set :302, :403 ... and added :1652 ...; the
+     sums are divided by the number of steps the point was wet, :2980-2988 */
+  const int wet = o->wet_dry;
+  const double *mfull[3] = { o->rmask_full, o->umask_full, o->vmask_full };
+  if (wet && (init || accum))
+    for (int m = 0; m < 3; m++) {                                  /* :257-288 | :1608-1645 */
+      int i0, i1, j0, j1;
+      range(b, m, &i0, &i1, &j0, &j1);                             /* rng 0 (rho), 1 (u: Istr:IendR), 2 (v: Jstr:JendR) */
+      for (int j = j0; j <= j1; j++)
+        for (int i = i0; i <= i1; i++) {
+          const double c1 = MAX(0.0, MIN(mfull[m][X2(i, j)], 1.0));
+          s->cnt[m][X2(i, j)] = init ? c1 : s->cnt[m][X2(i, j)] + c1;
+        }
+    }
   if (init || accum)
     for (int f = 0; f < A_NFIELDS; f++) {
       int i0, i1, j0, j1;
@@ -128,7 +148,8 @@ void orc_set_avg(orc_t *o, int tile) {
           for (int j = j0; j <= j1; j++)
             for (int i = i0; i <= i1; i++) {
               double *d = &s->a[f][X2(i, j) + (size_t)(k - ka) * nij + (size_t)(it - 1) * np * nij];
-              const double v = value(o, f, i, j, k, it);
+              double v = value(o, f, i, j, k, it);
+              if (wet) v = v * mfull[AD[f].grid == 'u' ? 1 : AD[f].grid == 'v' ? 2 : 0][X2(i, j)];
               *d = init ? v : *d + v;
             }
     }
@@ -142,7 +163,10 @@ void orc_set_avg(orc_t *o, int tile) {
       const size_t ntr = AD[f].perT ? (size_t)o->c.NT : 1;
       for (size_t p = 0; p < np * ntr; p++)
         for (int j = j0; j <= j1; j++)
-          for (int i = i0; i <= i1; i++) s->a[f][X2(i, j) + p * nij] = fac * s->a[f][X2(i, j) + p * nij];
+          for (int i = i0; i <= i1; i++) {
+            const double fc = wet ? 1.0 / MAX(1.0, s->cnt[AD[f].grid == 'u' ? 1 : AD[f].grid == 'v' ? 2 : 0][X2(i, j)]) : fac;
+            s->a[f][X2(i, j) + p * nij] = fc * s->a[f][X2(i, j) + p * nij];
+          }
       if (o->c.EWperiodic || o->c.NSperiodic)
         for (size_t p = 0; p < np * ntr; p++) orc_exchange2d(o, b, AD[f].grid, s->a[f] + p * nij);
     }

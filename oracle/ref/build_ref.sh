@@ -90,6 +90,11 @@ if [ "$APP" = benchmark_wetdry ]; then
   UP=BENCHMARK; HDR=benchmark_wetdry; HDRPATH="$HERE/benchmark_wetdry.h"
   EXTRA="-I$HERE/functionals"
 fi
+if [ "$APP" = upwelling_wetdry_avg ]; then
+  # MASKING + WET_DRY + AVERAGES (oracle/ref/upwelling_wetdry_avg.h): the wet masks and wet-point counters of set_avg.F
+  UP=UPWELLING; HDR=upwelling_wetdry_avg; HDRPATH="$HERE/upwelling_wetdry_avg.h"
+  EXTRA="-I$HERE/functionals"
+fi
 if [ "$APP" = upwelling_avg_mask ]; then
   # AVERAGES + MASKING (oracle/ref/upwelling_avg_mask.h)
   UP=UPWELLING; HDR=upwelling_avg_mask; HDRPATH="$HERE/upwelling_avg_mask.h"
@@ -198,7 +203,7 @@ FILES="mod_kinds mod_param mod_scalars mod_stepping mod_strings mod_iounits mod_
   set_depth set_massflux rho_eos prsgrd t3dmix uv3dmix set_vbc set_zeta wvelocity diag ini_fields
   mod_sources uv_var_change wetdry step2d omega pre_step3d rhs3d step3d_uv step3d_t
   mpdata_adiff lmd_swfrac lmd_skpp lmd_bkpp lmd_vmix gls_prestep gls_corstep my25_prestep my25_corstep tkebc_im bulk_flux analytical
-  mod_average uv_rotate vorticity set_avg mod_diags set_diags"
+  mod_average uv_rotate vorticity set_masks set_avg mod_diags set_diags"
 TODO=""
 for m in $FILES; do
   src=""

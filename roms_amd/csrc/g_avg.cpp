@@ -33,6 +33,7 @@ static int launch_acc(roms_hip_ctx *c, int init, int part) {
   a.mask = c->avg_mask;
   a.init = init;
   a.fac = 0.0;
+  for (int m = 0; m < 3; m++) a.cnt[m] = c->avg_cnt[m];
   const int nch = (G.N + KCH - 1) / KCH;
   a.gz0 = part == 2 ? 1 : 0;
   const int nz = part == 1 ? 1 : part == 2 ? nch - 1 : nch;
@@ -51,6 +52,7 @@ static int launch_scale(roms_hip_ctx *c) {
   a.init = 0;
   a.gz0 = 0;
   a.fac = 1.0 / (double)c->avg_nAVG;
+  for (int m = 0; m < 3; m++) a.cnt[m] = c->avg_cnt[m];
   int nchunks = 0;
   for (int f = 0; f < AV_NFIELDS; f++) nchunks += (avg_planes(f, G.N, G.NT) + KCH - 1) / KCH;
   LAUNCH_THREAD(k_avg_scale, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, nchunks, c->stream, a);

@@ -27,15 +27,21 @@ struct AvgArgs {
   int init;          // 1: set, 0: add
   int gz0;           // k_avg_acc: first chunk of this launch
   double fac;        // k_avg_scale: 1/nAVG
+  double *cnt[3];    // WET_DRY (round 6): the wet-point counters rmask_avg, umask_avg, vmask_avg of set_avg.F:257-288, :1608-1645
 };
 
 #define AV_ON(f) ((a.mask >> (f)) & 1u)
-#define AV_PUT(f, off, val)                                   \
+// WET_DRY: the value times the full mask (land x wet) of the field's grid type, set_avg.F:302 ... :1652 ... (mr, mu, mv below; 1 otherwise)
+#define AV_PUTM(f, off, val, m_)                              \
   do {                                                        \
     double *d_ = a.A.a[f] + (off);                            \
-    const double v_ = (val);                                  \
+    double v_ = (val);                                        \
+    if (wet) v_ = v_ * (m_);                                  \
     *d_ = a.init ? v_ : *d_ + v_;                             \
   } while (0)
+#define AV_PUT(f, off, val) AV_PUTM(f, off, val, mr)
+#define AV_PUTU(f, off, val) AV_PUTM(f, off, val, mu)
+#define AV_PUTV(f, off, val) AV_PUTM(f, off, val, mv)
 
 THREAD_KERNEL(k_avg_acc, AvgArgs) {
   gz += a.gz0;
@@ -49,19 +55,27 @@ THREAD_KERNEL(k_avg_acc, AvgArgs) {
   const bool uu = i >= B.Istr, vv = j >= B.Jstr;                       // u-type / v-type ranges
   const bool ii = i >= B.Istr && i <= B.Iend, jj = j >= B.Jstr && j <= B.Jend;
   const double *u = F.u + (size_t)(Nout - 1) * nij * (size_t)N + x, *v = F.v + (size_t)(Nout - 1) * nij * (size_t)N + x;
+  const bool wet = G.wet_dry != 0;
+  const double mr = wet ? F.rmask_full[x] : 1.0, mu = wet ? F.umask_full[x] : 1.0, mv = wet ? F.vmask_full[x] : 1.0;
+  if (gz == 0 && wet) {                                                // the wet-point counters :257-288 | :1608-1645
+    const double cr = KMAX(0.0, KMIN(mr, 1.0)), cu = KMAX(0.0, KMIN(mu, 1.0)), cv = KMAX(0.0, KMIN(mv, 1.0));
+    a.cnt[0][x] = a.init ? cr : a.cnt[0][x] + cr;
+    if (uu) a.cnt[1][x] = a.init ? cu : a.cnt[1][x] + cu;
+    if (vv) a.cnt[2][x] = a.init ? cv : a.cnt[2][x] + cv;
+  }
   if (gz == 0) {
     const double z = F.zeta[X2T(i, j, Kout)];
     if (AV_ON(AV_ZETA)) AV_PUT(AV_ZETA, x, z);
     if (AV_ON(AV_ZZ)) AV_PUT(AV_ZZ, x, z * z);
     if (uu) {
       const double ub = F.ubar[X2T(i, j, Kout)];
-      if (AV_ON(AV_UBAR)) AV_PUT(AV_UBAR, x, ub);
-      if (AV_ON(AV_U2)) AV_PUT(AV_U2, x, ub * ub);
+      if (AV_ON(AV_UBAR)) AV_PUTU(AV_UBAR, x, ub);
+      if (AV_ON(AV_U2)) AV_PUTU(AV_U2, x, ub * ub);
     }
     if (vv) {
       const double vb = F.vbar[X2T(i, j, Kout)];
-      if (AV_ON(AV_VBAR)) AV_PUT(AV_VBAR, x, vb);
-      if (AV_ON(AV_V2)) AV_PUT(AV_V2, x, vb * vb);
+      if (AV_ON(AV_VBAR)) AV_PUTV(AV_VBAR, x, vb);
+      if (AV_ON(AV_V2)) AV_PUTV(AV_V2, x, vb * vb);
     }
     if (AV_ON(AV_OMEGA)) AV_PUT(AV_OMEGA, x, F.W[x] * F.pm[x] * F.pn[x]);         // interface 0
     if (AV_ON(AV_W)) AV_PUT(AV_W, x, F.wvel[x]);
@@ -77,14 +91,14 @@ THREAD_KERNEL(k_avg_acc, AvgArgs) {
     if (AV_ON(AV_RHO)) AV_PUT(AV_RHO, o3 + x, F.rho[o3 + x]);
     const double uk = uu ? u[o3] : 0.0, vk = vv ? v[o3] : 0.0;
     if (uu) {
-      if (AV_ON(AV_U)) AV_PUT(AV_U, o3 + x, uk);
-      if (AV_ON(AV_UU)) AV_PUT(AV_UU, o3 + x, uk * uk);
-      if (AV_ON(AV_HUON)) AV_PUT(AV_HUON, o3 + x, F.Huon[o3 + x]);
+      if (AV_ON(AV_U)) AV_PUTU(AV_U, o3 + x, uk);
+      if (AV_ON(AV_UU)) AV_PUTU(AV_UU, o3 + x, uk * uk);
+      if (AV_ON(AV_HUON)) AV_PUTU(AV_HUON, o3 + x, F.Huon[o3 + x]);
     }
     if (vv) {
-      if (AV_ON(AV_V)) AV_PUT(AV_V, o3 + x, vk);
-      if (AV_ON(AV_VV)) AV_PUT(AV_VV, o3 + x, vk * vk);
-      if (AV_ON(AV_HVOM)) AV_PUT(AV_HVOM, o3 + x, F.Hvom[o3 + x]);
+      if (AV_ON(AV_V)) AV_PUTV(AV_V, o3 + x, vk);
+      if (AV_ON(AV_VV)) AV_PUTV(AV_VV, o3 + x, vk * vk);
+      if (AV_ON(AV_HVOM)) AV_PUTV(AV_HVOM, o3 + x, F.Hvom[o3 + x]);
     }
     if (ii && jj && AV_ON(AV_UV)) AV_PUT(AV_UV, o3 + x, 0.25 * (uk + u[o3 + 1]) * (vk + v[o3 + ni]));
     for (int it = 1; it <= NT; it++) {
@@ -95,13 +109,13 @@ THREAD_KERNEL(k_avg_acc, AvgArgs) {
       if (AV_ON(AV_TT)) AV_PUT(AV_TT, ot, tk * tk);
       if (ii) {
         const double ts = t[-1] + tk;
-        if (AV_ON(AV_UT)) AV_PUT(AV_UT, ot, 0.5 * uk * ts);
-        if (AV_ON(AV_HUT)) AV_PUT(AV_HUT, ot, 0.5 * F.Huon[o3 + x] * ts);
+        if (AV_ON(AV_UT)) AV_PUTU(AV_UT, ot, 0.5 * uk * ts);
+        if (AV_ON(AV_HUT)) AV_PUTU(AV_HUT, ot, 0.5 * F.Huon[o3 + x] * ts);
       }
       if (jj) {
         const double ts = t[-ni] + tk;
-        if (AV_ON(AV_VT)) AV_PUT(AV_VT, ot, 0.5 * vk * ts);
-        if (AV_ON(AV_HVT)) AV_PUT(AV_HVT, ot, 0.5 * F.Hvom[o3 + x] * ts);
+        if (AV_ON(AV_VT)) AV_PUTV(AV_VT, ot, 0.5 * vk * ts);
+        if (AV_ON(AV_HVT)) AV_PUTV(AV_HVT, ot, 0.5 * F.Hvom[o3 + x] * ts);
       }
     }
   }
@@ -150,11 +164,13 @@ THREAD_KERNEL(k_avg_scale, AvgArgs) {
   if (i < i0 || i > i1 || j < j0 || j > j1) return;
   const int np = avg_planes(f, N, NT);
   double *d = a.A.a[f] + X2(i, j);
+  // WET_DRY: the sums divided by the number of steps the point was wet, :2980-2988 (else 1/nAVG)
+  const double fac = G.wet_dry ? 1.0 / KMAX(1.0, a.cnt[(r == 1 || r == 4) ? 1 : (r == 2 || r == 5) ? 2 : 0][X2(i, j)]) : a.fac;
 #pragma unroll
   for (int q = 0; q < KCH; q++) {
     const int p = c0 * KCH + q;
     if (p >= np) break;
-    d[(size_t)p * (size_t)G.nij] = a.fac * d[(size_t)p * (size_t)G.nij];
+    d[(size_t)p * (size_t)G.nij] = fac * d[(size_t)p * (size_t)G.nij];
   }
 }
 THREAD_GLOBAL(k_avg_scale, AvgArgs)

@@ -1969,7 +1969,7 @@ static int main3d_late(roms_hip_ctx *c, bool do_diag) {
   DO(roms_hip_wvelocity(c, s.nstp));                        // :535
   if (avg) {                                                // set_avg :562: what the loop overwrites, before it
     lane_wait(c, E_Z);
-    DO(run_set_avg(c, 1));
+    DO(run_set_avg(c, c->G.wet_dry ? 0 : 1));                // (WET_DRY: the whole routine here -- the barotropic steps change the wet masks it multiplies with)
   }
   lane_record(c, E_X);
   to(M);
@@ -1986,7 +1986,7 @@ static int main3d_late(roms_hip_ctx *c, bool do_diag) {
 #endif
   lane_wait(c, E_VBC);
   lane_wait(c, E_D);                                        // (the two-kernel KPP form reuses prsgrd's work array)
-  if (avg) DO(run_set_avg(c, 2));                           // the rest of set_avg: rho, u, v, t, W, wvel, Huon, Hvom stay put
+  if (avg && !c->G.wet_dry) DO(run_set_avg(c, 2));          // the rest of set_avg: rho, u, v, t, W, wvel, Huon, Hvom stay put
   if (cf.options & ROMS_ANA_VMIX) DO(roms_hip_ana_vmix(c));        // :525
   else if (cf.options & ROMS_LMD_MIXING) DO(roms_hip_lmd_vmix(c)); // :527
   if (cf.options & ROMS_SOLAR_SOURCE) { DO(run_swdk(c)); c->swdk_ready = true; }
@@ -2132,9 +2132,9 @@ static int main3d_around_loop(roms_hip_ctx *c, bool do_diag, int form, bool with
   DO(roms_hip_wvelocity(c, s.nstp));
   if (avg) {                                                // set_avg :562: what the loop overwrites, before it
     lane_wait(c, E_Z);
-    DO(run_set_avg(c, 1));
+    DO(run_set_avg(c, c->G.wet_dry ? 0 : 1));                // (WET_DRY: the whole routine here -- the barotropic steps change the wet masks it multiplies with)
   }
-  if (avg) DO(run_set_avg(c, 2));                           // the rest of set_avg: rho, u, v, t, W, wvel, Huon, Hvom stay put
+  if (avg && !c->G.wet_dry) DO(run_set_avg(c, 2));          // the rest of set_avg: rho, u, v, t, W, wvel, Huon, Hvom stay put
   if (!diag_main) lane_record(c, E_X);
   if (diag_split) { DO(enqueue_diag(c, 2)); lane_record(c, E_MIX); c->diag_join_pending = true; }   // (joined in the next step, or when the call ends)
   to(Y);
@@ -2333,7 +2333,15 @@ extern "C" int roms_hip_last_diag(roms_hip_ctx *c, double *out) {
 extern "C" int roms_hip_avg_config(roms_hip_ctx *c, int nAVG, int ntsAVG, int nrrec, int ntstart, unsigned mask) {
   if (!c || nAVG < 0) return 8;
   // (WET_DRY is an option of the context: refused here as the reverse is in roms_hip_create)
-  if (nAVG > 0 && c->G.wet_dry) { set_error("AVERAGES with WET_DRY: the wet/dry masks of set_avg.F are not built"); return 5; }
+  // (WET_DRY, round 6: every field times the full mask of its grid type, the sums divided by the wet-point counters -- k_avg.h)
+  if (nAVG > 0 && c->G.wet_dry)
+    for (int m = 0; m < 3; m++)
+      if (!c->avg_cnt[m]) {
+        void *p = nullptr;
+        if (dmalloc(&p, (size_t)c->G.nij * sizeof(double))) return 2;
+        c->allocs.push_back(p);
+        c->avg_cnt[m] = (double *)p;
+      }
   // (MASKING: the 22 fields built carry no mask arithmetic of their own -- set_avg.F masks the rotated and vorticity
   // fields only -- and accumulate the masked state; pinned with oracle/ref/upwelling_avg_mask.h)
   if (nAVG > 0)
@@ -2450,7 +2458,7 @@ static int wetdry_config(roms_hip_ctx *c, double Dcrit) {
   if ((opt & ROMS_MIX_ISO_TS) || G.uv_vis4 || G.ts_dif4) { set_error("WET_DRY: harmonic mixing along s-surfaces or geopotentials only (t3dmix2_s.h, t3dmix2_geo.h, uv3dmix2_s.h)"); return 5; }
   if (opt & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_PRSGRD42 | ROMS_PRSGRD44)) { set_error("WET_DRY: the density Jacobian prsgrd32.h only (DJ_GRADPS)"); return 5; }
   if (opt & (ROMS_PLAIN_VVISC)) { set_error("WET_DRY: SPLINES_VVISC only"); return 5; }
-  if (G.dia_ts || G.dia_uv || c->avg_nAVG > 0) { set_error("WET_DRY: the wet/dry masks of set_avg.F / set_diags.F are not built"); return 5; }
+  if (G.dia_ts || G.dia_uv) { set_error("WET_DRY: the wet/dry masks of set_diags.F are not built"); return 5; }
   if (!c->F.wd_eff) {
     void *p = nullptr;
     if (dmalloc(&p, (size_t)2 * G.nij * sizeof(double))) return 2;

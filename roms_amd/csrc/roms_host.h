@@ -103,6 +103,7 @@ struct roms_hip_ctx {
   bool ghost_ok = false;        // inside roms_hip_main3d, behind post_initial: every input of the point-wise producers carries valid ghost lines (ghost_compute)
   bool h_ghost_done = false;    // (multi-tile) the ghost lines of h have been exchanged once (run_set_depth computes the ghost columns itself)
   // the pair launches handing their rim across tile edges themselves (tiles too large for the loop; g_step2d.cpp:pair_rim_usable)
+  double *avg_cnt[3] = {nullptr, nullptr, nullptr};   // AVERAGES with WET_DRY: the wet-point counters of set_avg.F (rho, u, v)
   int pair_rim_state = 0;       // 0: not decided, 1: on, -1: off
   bool rim_refused = false;     // roms_hip_rim_disable: no rim hand-off inside the barotropic launches (until another transport is installed)
   bool b2_rim = false;          // the staged result of the last pair launch was published into the neighbours' rim planes (not exchanged)

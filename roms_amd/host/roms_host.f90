@@ -1189,12 +1189,12 @@
       CALL options_from_defines (ierr)
 !  (tracers advected with MPDATA: their Dhadv / Dvadv work arrays are not built -- no diagnostics file for such a run)
       IF (ANY(hadv(1:NT).eq.ROMS_MPDATA)) nDIA=0
-!  WET_DRY: the wet/dry statements of set_avg.F / set_diags.F are not built -- a run that would write averages or
-!  diagnostics files stops here (the library refuses the same: roms_hip_avg_config / _dia_config), instead of
-!  accumulating them without the masks
-      IF (ierr.eq.0.and.wet_dry.and.((nAVG.gt.0.and.ANY(Aout)).or.nDIA.gt.0))                                           &
-     &  CALL unsupported ('WET_DRY together with AVERAGES / DIAGNOSTICS_TS / DIAGNOSTICS_UV output (NAVG, NDIA > 0): '//  &
-     &                    'the wet/dry masks of set_avg.F and set_diags.F are not built; set NAVG = NDIA = 0', ierr)
+!  WET_DRY: the wet/dry statements of set_diags.F are not built -- a run that would write diagnostics files stops here (the
+!  library refuses the same: roms_hip_dia_config), instead of accumulating them without the masks.  (AVERAGES with WET_DRY:
+!  built in round 6 -- the full masks and wet-point counters of set_avg.F, k_avg.h.)
+      IF (ierr.eq.0.and.wet_dry.and.nDIA.gt.0)                                                                            &
+     &  CALL unsupported ('WET_DRY together with DIAGNOSTICS_TS / DIAGNOSTICS_UV output (NDIA > 0): '//                    &
+     &                    'the wet/dry masks of set_diags.F are not built; set NDIA = 0', ierr)
       END SUBROUTINE set_cppdefs
 !
 !=======================================================================

@@ -743,7 +743,8 @@ def test_rccl_self_exchange_eight_neighbours():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,nAVG,ntsAVG,env", [("upwelling_small", 3, 1, {}), ("benchmark_small", 2, 2, {}),
-                                                 ("benchmark_small", 3, 1, {"ROMS_HIP_LATE_PRE": "0"})])
+                                                 ("benchmark_small", 3, 1, {"ROMS_HIP_LATE_PRE": "0"}),
+                                                 ("upwelling_wetdry_small", 3, 1, {})])      # WET_DRY: full masks, wet-point counters (round 6)
 def test_time_averages_match_oracle(tag, nAVG, ntsAVG, env):
     """set_avg (set_avg.F:51, AVERAGES) on the GPU inside roms_hip_main3d -- late-predictor schedule (split around the
     barotropic loop) and reference order -- against the oracle pinned to the reference's set_avg.F: the 22 averaged
@@ -759,7 +760,9 @@ def test_time_averages_match_oracle(tag, nAVG, ntsAVG, env):
         from tests import util
         from roms_amd import hiplib
         cs = util.case_for(%r)
-        g = util.load_init(%r, util.nghost_for(cs))
+        g = util.load_init(util.init_tag(cs) if %r else "", util.nghost_for(cs))
+        if cs.get("wet_dry"):
+            g = util.with_wetdry(cs, g)
         O = util.make_oracle(cs, g)
         H = util.make_hip(cs, g)
         O.set_avg_window(%d, %d)

@@ -274,13 +274,14 @@ def test_applications_without_advection_or_mixing_bitwise(emu, drop, hadv, vadv)
 
 def test_wet_dry_refusals_hold_in_either_call_order(emu):
     """The combinations WET_DRY is not built with are refused with exit_flag 5 wherever they are asked for: the biharmonic
-    operators (option bits of the same roms_hip_config since ABI version 4) by roms_hip_create, AVERAGES and DIAGNOSTICS_TS
-    by their configuration calls (the refusal used to sit in the WET_DRY call only, and the host made that
-    one first), and the host's own reader stops a WET_DRY run that asks for averages."""
+    operators (option bits of the same roms_hip_config since ABI version 4) by roms_hip_create, DIAGNOSTICS_TS
+    by its configuration call (the refusal used to sit in the WET_DRY call only, and the host made that
+    one first), and the host's own reader stops a WET_DRY run that asks for diagnostics.  (AVERAGES with WET_DRY is built
+    since round 6: test_time_averages_bitwise.)"""
     from roms_amd import hiplib, hostlib
     cs = util.case_for("upwelling_wetdry_small", hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT"))
     g = util.with_wetdry(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
-    for call in (lambda H: H.avg_config(4), lambda H: H.dia_config(4)):
+    for call in (lambda H: H.dia_config(4),):
         H = util.make_hip(cs, g, emu)
         with pytest.raises(hiplib.RomsHipError, match="WET_DRY"):
             call(H)
@@ -289,8 +290,8 @@ def test_wet_dry_refusals_hold_in_either_call_order(emu):
         util.make_hip(dict(cs, mix4=(0, 1), visc4=0.0, tnu4=(1.0, 1.0)), g, emu)
     with pytest.raises(hiplib.RomsHipError, match="WET_DRY"):
         util.make_hip(dict(cs, dia_uv=True), g, emu).dia_config(4, uv=True)
-    with pytest.raises(hostlib.HostError, match="WET_DRY together with AVERAGES"):
-        hostlib.Host(params=dict(cs, ninfo=0, NAVG=4, Aout={"idFsur": True}), lib_path=os.path.join(os.path.dirname(emu), "libroms_host_emu.so"),
+    with pytest.raises(hostlib.HostError, match="WET_DRY together with DIAGNOSTICS"):
+        hostlib.Host(params=dict(cs, ninfo=0, NDIA=4, Dout={"idDtrc(iThadv)": (True, True)}), lib_path=os.path.join(os.path.dirname(emu), "libroms_host_emu.so"),
                      hip_lib_path=emu)
 
 
@@ -413,13 +414,19 @@ def test_product_partition_matches_reference_get_bounds(emu):
     assert util.check_tile_bounds(host_lib=host, hip_lib=emu) >= 30
 
 
-@pytest.mark.parametrize("tag,nAVG,ntsAVG", [("upwelling_small", 3, 1), ("benchmark_small", 2, 2), ("upwelling_small", 1, 1)])
+@pytest.mark.parametrize("tag,nAVG,ntsAVG", [("upwelling_small", 3, 1), ("benchmark_small", 2, 2), ("upwelling_small", 1, 1),
+                                             ("upwelling_wetdry_small", 3, 1), ("upwelling_wetdry_small", 1, 1)])
 def test_time_averages_bitwise(emu, tag, nAVG, ntsAVG):
     """set_avg (k_avg.h) inside roms_hip_main3d against the oracle's (pinned to set_avg.F): all 22 averaged arrays
-    after every step -- set, add and convert phases of several windows; averaging does not change the run."""
+    after every step -- set, add and convert phases of several windows; averaging does not change the run.
+    upwelling_wetdry (round 6): WET_DRY -- every field times the full mask (land x wet) of its grid type, the sums divided by the
+    number of steps the point was wet (set_avg.F:257-288, :302 ..., :2980-2988); the oracle equals the reference built from
+    oracle/ref/upwelling_wetdry_avg.h bit for bit (tests/test_oracle_vs_ref.py)."""
     from roms_amd import hiplib
     cs = util.case_for(tag)
-    g = util.load_init(tag, util.nghost_for(cs))
+    g = util.load_init(util.init_tag(cs), util.nghost_for(cs))
+    if cs.get("wet_dry"):
+        g = util.with_wetdry(cs, g)
     O = util.make_oracle(cs, g)
     H = util.make_hip(cs, g, emu)
     O.set_avg_window(nAVG, ntsAVG)

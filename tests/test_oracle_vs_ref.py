@@ -459,6 +459,16 @@ def test_set_avg_on_a_masked_run_bitwise():
     assert "AVG-OK bitwise" in out, out
 
 
+@pytest.mark.parametrize("args", [["nsteps=9", "nAVG=3", "ntsAVG=1"], ["nsteps=6", "nAVG=1", "ntsAVG=1"], ["nsteps=9", "nAVG=4", "ntsAVG=2", "NtileI=2", "NtileJ=2"]])
+def test_set_avg_with_wetting_and_drying_bitwise(args):
+    """AVERAGES together with WET_DRY (round 6; reference built from oracle/ref/upwelling_wetdry_avg.h): every averaged field
+    times the full mask (land x wet) of its grid type where it is set and where it is added (set_avg.F:302 ..., :1652 ...), the
+    wet-point counters rmask_avg / umask_avg / vmask_avg (:257-288, :1608-1645), the sums divided by them (:2980-2988) -- all
+    22 arrays after every call, on the beach-and-ridge state whose shore line moves."""
+    out = _child("avg", "upwelling_wetdry_avg_small", *args)
+    assert "AVG-OK bitwise" in out, out
+
+
 # ----------------------------------------------------------------------------------------------------
 # main3d.F itself cannot be compiled here (it USEs the NetCDF readers and writers); the fixtures and the main3d
 # tests above are driven by oracle/ref/ref_glue.F90:ref_main3d, which calls the reference's kernels in main3d's
