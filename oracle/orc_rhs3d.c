@@ -574,6 +574,19 @@ void orc_prsgrd(orc_t *o, int tile) {
   else if (o->c.options & ORC_PRSGRD40) orc_prsgrd40(o, tile);
   else if (o->c.options & ORC_PRSGRD31) orc_prsgrd31(o, tile);
   else orc_prsgrd32(o, tile);
+  if (o->wet_dry && (o->prs_scheme == 44 || (o->c.options & (ORC_PRSGRD40 | ORC_PRSGRD31)))) {
+    /* WET_DRY: ru, rv times the wet masks where these schemes assign them (prsgrd31.h:239,285,323,369; prsgrd40.h:251,281;
+       prsgrd44.h:466,500) -- prsgrd32 does it inside (:362, :426); prsgrd42 masks its FIRST pass (not carried: refused) */
+    ORC_LOCALS(o);
+    const orc_bounds *b = &o->b[tile];
+    const int nrhs = o->s.nrhs;
+    for (int k = 1; k <= N; k++) {
+      for (int j = b->Jstr; j <= b->Jend; j++)
+        for (int i = b->IstrU; i <= b->Iend; i++) o->ru[XW4(i, j, k, nrhs)] = o->ru[XW4(i, j, k, nrhs)] * o->umask_wet[X2(i, j)];
+      for (int j = b->JstrV; j <= b->Jend; j++)
+        for (int i = b->Istr; i <= b->Iend; i++) o->rv[XW4(i, j, k, nrhs)] = o->rv[XW4(i, j, k, nrhs)] * o->vmask_wet[X2(i, j)];
+    }
+  }
   if (o->duv) {        /* DIAGNOSTICS_UV: DiaRU(i,j,k,nrhs,M3pgrd) = ru(i,j,k,nrhs) where every scheme assigns it (prsgrd32.h:364, :428) */
     ORC_LOCALS(o);
     const orc_bounds *b = &o->b[tile];

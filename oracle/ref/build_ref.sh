@@ -90,6 +90,12 @@ if [ "$APP" = benchmark_wetdry ]; then
   UP=BENCHMARK; HDR=benchmark_wetdry; HDRPATH="$HERE/benchmark_wetdry.h"
   EXTRA="-I$HERE/functionals"
 fi
+if [ "$APP" = upwelling_wetdry_gls ] || [ "$APP" = upwelling_wetdry_my25 ] || [ "$APP" = upwelling_wetdry_geouv ] || [ "$APP" = upwelling_wetdry_prs31 ] || [ "$APP" = upwelling_wetdry_prs44 ]; then
+  # WET_DRY with the closures, the viscosity along geopotentials and the other pressure Jacobians (round 6: oracle/ref/upwelling_wetdry_*.h;
+  # PJ_GRADP does not compile with WET_DRY in the reference itself: prsgrd40.h:98 passes umask_wet, vmask_wet without declaring them)
+  UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"
+  EXTRA="-I$HERE/functionals"
+fi
 if [ "$APP" = upwelling_wetdry_avg ]; then
   # MASKING + WET_DRY + AVERAGES (oracle/ref/upwelling_wetdry_avg.h): the wet masks and wet-point counters of set_avg.F
   UP=UPWELLING; HDR=upwelling_wetdry_avg; HDRPATH="$HERE/upwelling_wetdry_avg.h"

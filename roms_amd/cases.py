@@ -373,6 +373,29 @@ def upwelling_wetdry(Dcrit=0.1, **kw):
     return cs
 
 
+def upwelling_wetdry_x(variant, **kw):
+    """WET_DRY together with what round 6 pinned it with (the custom application headers oracle/ref/upwelling_wetdry_<variant>.h):
+    gls | my25 (the closures: gls_*.F, my25_*.F carry no WET_DRY statement of their own), geouv (uv3dmix2_geo.h's wet masks),
+    prs31 | prs44 (ru, rv times the wet masks, prsgrd31.h:239,285,323,369, prsgrd44.h:466,500; PJ_GRADP + WET_DRY does not compile
+    in the reference: prsgrd40.h:98 uses umask_wet, vmask_wet undeclared)"""
+    cs = upwelling_wetdry(**kw)
+    cs["app"] = "upwelling_wetdry_" + variant
+    if variant in ("gls", "my25"):
+        src = upwelling_gls() if variant == "gls" else upwelling_my25()
+        cs["options"] = tuple(o for o in cs["options"] if o != "ANA_VMIX") + (("GLS_MIXING",) if variant == "gls" else ("MY25_MIXING",))
+        for k in ("gls_flags",) + tuple(GLS_NAMES) + ("Akk_bak", "Akp_bak", "charnok_alpha", "zos_hsig_alpha", "sz_alpha", "crgban_cw"):
+            cs[k] = src[k]
+    elif variant == "geouv":
+        cs["mix_geo_uv"] = 1
+    elif variant == "prs31":
+        cs["options"] = tuple(cs["options"]) + ("PRSGRD31",)
+    elif variant == "prs44":
+        cs["prsgrd"] = 44
+    else:
+        raise ValueError(variant)
+    return cs
+
+
 def wetdry_depth(cs, LBi, UBi, LBj, UBj):
     """h and the initial zeta of the wetting/drying test case on arrays (LBi:UBi, LBj:UBj), [j, i] here: depth 10 m south
     of row Mm/3, from there a plane beach to -0.3 m (30 cm above the still water level) at the northern wall, roughened

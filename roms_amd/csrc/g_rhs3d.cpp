@@ -162,6 +162,7 @@ int run_prsgrd(roms_hip_ctx *c) {
     LAUNCH_THREAD(k_prs4x_col, (B.Iend + e) - (B.IstrU - 1 - e) + 1, (B.Jend + e) - (B.JstrV - 1 - e) + 1, 1, c->stream, a);
     if (q4) {
       LAUNCH_THREAD(k_prs44_grad, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+      if (G.wet_dry) { int r = run_wd_scale3(c); if (r) return r; }     // WET_DRY: ru, rv times the wet masks (prsgrd44.h:466,500)
     } else {
       LAUNCH_THREAD(k_prs42_grad1, (B.Iend + 1) - (B.IstrU - 1) + 1, (B.Jend + 1) - (B.JstrV - 1) + 1, 2, c->stream, a);
       LAUNCH_THREAD(k_prs42_grad2, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
@@ -170,10 +171,12 @@ int run_prsgrd(roms_hip_ctx *c) {
   }
   if (G.options & ROMS_PRSGRD40) {     // PJ_GRADP: prsgrd40.h
     LAUNCH_THREAD(k_prs40, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+    if (G.wet_dry) { int r = run_wd_scale3(c); if (r) return r; }       // WET_DRY: ru, rv times the wet masks (prsgrd40.h:251,281)
     return run_duv_pgrd(c);
   }
   if (G.options & ROMS_PRSGRD31) {     // no DJ_GRADPS: prsgrd31.h (the reference order of main3d: roms_hip.cpp keeps the late-predictor schedule off)
     LAUNCH_THREAD(k_prs31, B.Iend - B.Istr + 1, B.Jend - B.Jstr + 1, 2, c->stream, a);
+    if (G.wet_dry) { int r = run_wd_scale3(c); if (r) return r; }       // WET_DRY: ... (prsgrd31.h:239,285,323,369)
     return run_duv_pgrd(c);
   }
   a.p1 = c->late_pre ? 1 : 0;

@@ -667,14 +667,14 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
                 "the reference's own result depends on the partition; a single tile, or PJ_GRADPQ4");
       roms_hip_destroy(c); return 5;
     }
-    if (cfg->options & ROMS_WET_DRY) { set_error("WET_DRY: the density Jacobian prsgrd32.h only (DJ_GRADPS)"); roms_hip_destroy(c); return 5; }
+    if ((cfg->options & ROMS_WET_DRY) && c->G.prs4x == 42) { set_error("WET_DRY with PJ_GRADPQ2: prsgrd42.h masks its FIRST pass (:355-361), which is not built"); roms_hip_destroy(c); return 5; }
     if (c->G.N < 3) { set_error("PJ_GRADPQ2 / PJ_GRADPQ4: the reconstruction needs three levels"); roms_hip_destroy(c); return 5; }
   }
   if (cfg->options & ROMS_MIX_GEO_UV) {                     // uv3dmix2_geo.h | uv3dmix4_geo.h (k_uvmix_geo.h): twenty-two 3-D work arrays
     if (!(cfg->options & ROMS_UV_VIS2) && !c->G.uv_vis4) { set_error("MIX_GEO_UV without UV_VIS2 or UV_VIS4"); roms_hip_destroy(c); return 5; }
     if (c->G.obc) { set_error("MIX_GEO_UV with open boundaries: not pinned"); roms_hip_destroy(c); return 5; }
     if (cfg->options & ROMS_DIAGNOSTICS_UV) { set_error("MIX_GEO_UV: the DIAGNOSTICS_UV statements of uv3dmix2_geo.h are not built"); roms_hip_destroy(c); return 5; }
-    if (cfg->options & ROMS_WET_DRY) { set_error("MIX_GEO_UV with WET_DRY: not pinned against the reference"); roms_hip_destroy(c); return 5; }
+    if ((cfg->options & ROMS_WET_DRY) && c->G.uv_vis4) { set_error("UV_VIS4 with WET_DRY: harmonic mixing only"); roms_hip_destroy(c); return 5; }
     void *p = nullptr;
     if (dmalloc(&p, (size_t)22 * (size_t)c->G.nij * (size_t)(c->G.N + 1) * sizeof(double))) { roms_hip_destroy(c); return 2; }    // (UG_NARR)
     c->allocs.push_back(p);
@@ -2451,12 +2451,11 @@ static int wetdry_config(roms_hip_ctx *c, double Dcrit) {
   DGrid &G = c->G;
   const int opt = G.options;
   if (!G.masking) { set_error("WET_DRY: needs MASKING (globaldefs.h:152-154 defines it with WET_DRY)"); return 5; }
-  if (opt & (ROMS_GLS_MIXING | ROMS_MY25_MIXING)) {
-    set_error("WET_DRY: not built together with GLS_MIXING / MY25_MIXING (the closures are not pinned under WET_DRY)");
-    return 5;
-  }
+  // (round 6: GLS_MIXING / MY25_MIXING -- their routines carry no WET_DRY statement --, MIX_GEO_UV and the Jacobians prsgrd31 / 40 / 44
+  // are pinned under WET_DRY: oracle/ref/upwelling_wetdry_*.h)
   if ((opt & ROMS_MIX_ISO_TS) || G.uv_vis4 || G.ts_dif4) { set_error("WET_DRY: harmonic mixing along s-surfaces or geopotentials only (t3dmix2_s.h, t3dmix2_geo.h, uv3dmix2_s.h)"); return 5; }
-  if (opt & (ROMS_PRSGRD31 | ROMS_PRSGRD40 | ROMS_PRSGRD42 | ROMS_PRSGRD44)) { set_error("WET_DRY: the density Jacobian prsgrd32.h only (DJ_GRADPS)"); return 5; }
+  if (G.prs4x == 42) { set_error("WET_DRY with PJ_GRADPQ2: prsgrd42.h masks its FIRST pass (:355-361), which is not built"); return 5; }
+  if (opt & ROMS_PRSGRD40) { set_error("WET_DRY with PJ_GRADP: the reference does not compile with the two together (prsgrd40.h:98 passes umask_wet, vmask_wet undeclared) -- nothing to pin against"); return 5; }
   if (opt & (ROMS_PLAIN_VVISC)) { set_error("WET_DRY: SPLINES_VVISC only"); return 5; }
   if (G.dia_ts || G.dia_uv) { set_error("WET_DRY: the wet/dry masks of set_diags.F are not built"); return 5; }
   if (!c->F.wd_eff) {

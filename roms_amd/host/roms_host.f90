@@ -980,7 +980,7 @@
       IF (ierr.ne.0) RETURN
       upw=TRIM(MyAppCPP).eq.'UPWELLING'.or.TRIM(MyAppCPP).eq.'UPWELLING_KPP'.or.                                &
      &    TRIM(MyAppCPP).eq.'UPWELLING_LOGDRAG'.or.TRIM(MyAppCPP).eq.'UPWELLING_MASK'.or.is_defined('UPWELLING').or.    &
-     &    MyAppCPP(1:13).eq.'UPWELLING_BIH'.or.TRIM(MyAppCPP).eq.'UPWELLING_WETDRY'.or.                             &
+     &    MyAppCPP(1:13).eq.'UPWELLING_BIH'.or.MyAppCPP(1:16).eq.'UPWELLING_WETDRY'.or.                             &
      &    TRIM(MyAppCPP).eq.'UPWELLING_GEOUV'.or.MyAppCPP(1:14).eq.'UPWELLING_PRS4'.or.                                &
      &    MyAppCPP(1:13).eq.'UPWELLING_GLS'.or.MyAppCPP(1:14).eq.'UPWELLING_MY25'
       bench=TRIM(MyAppCPP).eq.'BENCHMARK'.or.TRIM(MyAppCPP).eq.'BENCHMARK_MASK'.or.is_defined('BENCHMARK')
@@ -1060,13 +1060,11 @@
 !  step3d_uv, set_vbc with LIMIT_BSTRESS, the closed-boundary routines (option bit ROMS_WET_DRY); round 5: bulk_flux, the
 !  solar source of pre_step3d, t3dmix2_geo, mpdata_adiff.  The combinations whose WET_DRY statements the library does not
 !  carry stop here
-      IF (wet_dry.and.(IAND(options, IOR(ROMS_GLS_MIXING, IOR(ROMS_MY25_MIXING, IOR(ROMS_MIX_ISO_TS,                      &
-     &    IOR(ROMS_PRSGRD31, ROMS_PRSGRD40))))).ne.0.or.ANY(mix4).or.prs4x.ne.0.or.ddmix))                                     &
-     &  CALL unsupported ('WET_DRY is built with ANA_VMIX or LMD_MIXING, analytic or bulk fluxes, harmonic mixing along '//  &
-     &                    's-surfaces or geopotentials and DJ_GRADPS (not with GLS_MIXING, MY25_MIXING, MIX_ISO_TS, '//  &
-     &                    'UV_VIS4, TS_DIF4, other pressure Jacobians)', ierr)
-      IF (wet_dry.and.is_defined('UV_VIS2').and.is_defined('MIX_GEO_UV'))                                       &
-     &  CALL unsupported ('WET_DRY together with MIX_GEO_UV: not pinned against the reference', ierr)
+!  (round 6: the closures GLS_MIXING / MY25_MIXING, MIX_GEO_UV and the Jacobians prsgrd31 / 40 / 44 are pinned under WET_DRY:
+!  oracle/ref/upwelling_wetdry_*.h)
+      IF (wet_dry.and.(IAND(options, IOR(ROMS_MIX_ISO_TS, ROMS_PRSGRD40)).ne.0.or.ANY(mix4).or.prs4x.eq.42.or.ddmix))    &
+     &  CALL unsupported ('WET_DRY is not built with MIX_ISO_TS, UV_VIS4, TS_DIF4, PJ_GRADP (which the reference does not '//   &
+     &                    'compile with WET_DRY either), PJ_GRADPQ2 or LMD_DDMIX', ierr)
       IF ((mix4(1).and.is_defined('UV_VIS2')).or.(mix4(2).and.is_defined('TS_DIF2')))                          &
      &  CALL unsupported ('harmonic and biharmonic mixing of the same field together (UV_VIS2 + UV_VIS4, TS_DIF2 + TS_DIF4) '// &
      &                    'are not built', ierr)
@@ -1908,7 +1906,7 @@
       CALL ini_mixing ()
       CALL level_depths (Zt_avg1)               ! Zt_avg1 = 0: depths of the resting ocean
       CALL initial_state ()
-      IF (TRIM(MyAppCPP).eq.'UPWELLING_WETDRY') CALL wetdry_depths ()
+      IF (MyAppCPP(1:16).eq.'UPWELLING_WETDRY') CALL wetdry_depths ()     ! (UPWELLING_WETDRY_GLS ...: the same case under another header)
       END SUBROUTINE host_setup
 !
 !  The wetting/drying test application UPWELLING_WETDRY (oracle/ref/upwelling_wetdry.h; roms_amd/cases.py:wetdry_depth holds the

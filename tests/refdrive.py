@@ -41,6 +41,12 @@ CASES = {
     "upwelling_wetdry_obc_small": ("upwelling_wetdry", dict(Lm=14, Mm=18, N=8)),      # closed basin: all four walls
     "upwelling_avg_mask_small": ("upwelling_avg_mask", dict(Lm=14, Mm=18, N=8)),      # AVERAGES + MASKING
     "upwelling_wetdry_avg_small": ("upwelling_wetdry_avg", dict(Lm=14, Mm=18, N=8)),  # AVERAGES + WET_DRY (round 6)
+    # WET_DRY with the closures, the viscosity along geopotentials, the other pressure Jacobians (round 6: upwelling_wetdry_*.h)
+    "upwelling_wetdry_gls_small": ("upwelling_wetdry_gls", dict(Lm=14, Mm=18, N=8, variant="gls")),
+    "upwelling_wetdry_my25_small": ("upwelling_wetdry_my25", dict(Lm=14, Mm=18, N=8, variant="my25")),
+    "upwelling_wetdry_geouv_small": ("upwelling_wetdry_geouv", dict(Lm=14, Mm=18, N=8, variant="geouv")),
+    "upwelling_wetdry_prs31_small": ("upwelling_wetdry_prs31", dict(Lm=14, Mm=18, N=8, variant="prs31")),
+    "upwelling_wetdry_prs44_small": ("upwelling_wetdry_prs44", dict(Lm=14, Mm=18, N=8, variant="prs44")),
     # open boundaries: the reference's own KELVIN application (ROMS/Include/kelvin.h, RADIATION_2D) ...
     # more of the reference's own test applications (ROMS/Include/seamount.h, grav_adj.h as shipped)
     # the standard density Jacobian (prsgrd31.h), plain and weighted (WJ_GRADP)
@@ -169,7 +175,8 @@ def make_case(tag, **kw):
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_diag=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag, upwelling_noadv=cases.upwelling_noadv,
                 upwelling_mask=cases.upwelling_mask, upwelling_wetdry=cases.upwelling_wetdry, benchmark_mask=cases.benchmark_mask, benchmark_wetdry=cases.benchmark_wetdry,
-                upwelling_avg_mask=cases.upwelling_mask, upwelling_wetdry_avg=cases.upwelling_wetdry, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeouv=cases.upwelling_bihgeouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
+                upwelling_avg_mask=cases.upwelling_mask, upwelling_wetdry_avg=cases.upwelling_wetdry, upwelling_wetdry_gls=cases.upwelling_wetdry_x, upwelling_wetdry_my25=cases.upwelling_wetdry_x,
+                upwelling_wetdry_geouv=cases.upwelling_wetdry_x, upwelling_wetdry_prs31=cases.upwelling_wetdry_x, upwelling_wetdry_prs44=cases.upwelling_wetdry_x, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeouv=cases.upwelling_bihgeouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
                 upwelling_wjgradp=cases.upwelling_prs31, upwelling_kpp_ddmix=cases.upwelling_kpp_ddmix, benchmark_ddmix=cases.benchmark_ddmix, upwelling_prs40=cases.upwelling_prs40, upwelling_prs42=cases.upwelling_prs4x, upwelling_prs44=cases.upwelling_prs4x, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
                 upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]

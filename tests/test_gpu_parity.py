@@ -827,6 +827,7 @@ DETERMINISM_SMALL = [
     ("upwelling_prs42_small", {}), ("upwelling_prs44_small", {}), ("benchmark_ddmix_small", {}), ("upwelling_kpp_ddmix_small", {}),
     # four walls (util.closed_basin_state): the fused corner stores of the barotropic engines, the first biharmonic operator's wall columns
     ("upwelling_small", {"closed": True}), ("upwelling_bihgeo_small", {"closed": True}), ("upwelling_bihiso_small", {"closed": True}),
+    ("upwelling_wetdry_gls_small", {}), ("upwelling_wetdry_geouv_small", {}), ("upwelling_wetdry_prs44_small", {}),     # WET_DRY x closures / MIX_GEO_UV / PJ_GRADPQ4 (round 6)
     ("upwelling_bihgeouv_small", {}), ("upwelling_bihgeouv_small", {"closed": True}),          # uv3dmix4_geo.h: the conditions on LapU, LapV, their corner averages
     ("upwelling_wetdry_small", {}),
 ]
@@ -1035,6 +1036,29 @@ def test_more_reference_applications_match_oracle(tag):
         tol = 1e-9 if (tag == "upwelling_bih_small" and n in ("ru", "rv", "rubar", "rvbar", "rufrc", "rvfrc", "rzeta")) else 1e-10
         assert util.relrms(a, b) <= tol, (n, util.relrms(a, b))
     assert max(np.abs(O.field("u")).max(), np.abs(O.field("v")).max()) > 1e-4
+    H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["gls", "my25", "geouv", "prs31", "prs44"])
+def test_wet_dry_variants_match_oracle(variant):
+    """Round 6: WET_DRY with GLS_MIXING / MY25_MIXING, MIX_GEO_UV, prsgrd31.h / prsgrd44.h on the GPU -- 40 steps against the oracle
+    (equal to the reference built from oracle/ref/upwelling_wetdry_<variant>.h): bit for bit where the host's libm is the recorded
+    one, 1e-10 otherwise (the closures' arrays 1e-7, as in the closure tests); the wet masks exactly."""
+    cs = util.case_for("upwelling_wetdry_%s_small" % variant)
+    g = util.with_wetdry(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    if "gls_flags" in cs:
+        g = util.with_gls(cs, g)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g)
+    O.start(); H.start()
+    O.main3d_step(40); H.main3d(40)
+    for n in ("rmask_wet", "umask_wet", "vmask_wet"):
+        assert np.array_equal(H.download(n), O.field(n)), n
+    for n in util.PROGNOSTIC:
+        a, b = H.download(n), O.field(n)
+        assert np.isfinite(a).all(), n
+        assert util.agree(a, b, 1e-7 if "gls_flags" in cs else 1e-10), (n, util.relrms(a, b))
     H.close()
 
 

@@ -941,3 +941,28 @@ def test_closed_basin_with_biharmonic_mixing_bitwise(emu, tag):
             assert np.array_equal(H.download(n), O.field(n)), (step, n)
     assert np.isfinite(O.diag()[0])
     H.close()
+
+
+@pytest.mark.parametrize("variant", ["gls", "my25", "geouv", "prs31", "prs44"])
+def test_wet_dry_with_closures_geopotential_viscosity_and_other_jacobians_bitwise(emu, variant):
+    """Round 6: WET_DRY together with GLS_MIXING / MY25_MIXING (their routines carry no WET_DRY statement; the closure sees the
+    masked, limited state), MIX_GEO_UV (uv3dmix2_geo.h's wet masks) and the Jacobians prsgrd31.h / prsgrd44.h (ru, rv times the wet
+    masks) -- refused until now as unpinned; the oracle equals the reference built from oracle/ref/upwelling_wetdry_<variant>.h over
+    40 steps.  20 steps against the oracle, every bit; the shore line moves."""
+    cs = util.case_for("upwelling_wetdry_%s_small" % variant)
+    g = util.with_wetdry(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    if "gls_flags" in cs:
+        g = util.with_gls(cs, g)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start(); H.start()
+    wet0 = O.field("rmask_wet").copy()
+    moved = False
+    for step in range(20):
+        O.main3d_step(); H.main3d(1)
+        for n in util.PROGNOSTIC + ["rmask_wet", "umask_wet", "vmask_wet"] + (["tke", "gls", "Akv"] if "gls_flags" in cs else []):
+            a, b = H.download(n), O.field(n)
+            assert np.array_equal(a, b), (step, n, int((a != b).sum()), float(np.abs(a - b).max()))
+        moved = moved or not np.array_equal(wet0, O.field("rmask_wet"))
+    assert moved
+    H.close()

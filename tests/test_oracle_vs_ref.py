@@ -251,6 +251,16 @@ MAIN3D_CASES = [
     # the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h (PJ_GRADP)
     ("upwelling_prs40_small", ["nsteps=60"]),
     ("upwelling_prs40_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # WET_DRY with the closures (no WET_DRY statement of their own), the viscosity along geopotentials and the Jacobians prsgrd31 / 44
+    # (round 6: oracle/ref/upwelling_wetdry_*.h; PJ_GRADP does not compile with WET_DRY in the reference: prsgrd40.h:98)
+    ("upwelling_wetdry_gls_small", ["nsteps=40"]),
+    ("upwelling_wetdry_gls_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=MPDATA,MPDATA", "vadv=MPDATA,MPDATA"]),
+    ("upwelling_wetdry_my25_small", ["nsteps=40"]),
+    ("upwelling_wetdry_geouv_small", ["nsteps=40"]),
+    ("upwelling_wetdry_geouv_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_wetdry_prs31_small", ["nsteps=40"]),
+    ("upwelling_wetdry_prs44_small", ["nsteps=40"]),
+    ("upwelling_wetdry_prs44_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     # UV_VIS4 + MIX_GEO_UV (round 6): uv3dmix4_geo.h, the rotated stress tensor twice, under MASKING; in the channel and between four walls
     ("upwelling_bihgeouv_small", ["nsteps=60"]),
     ("upwelling_bihgeouv_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=U3,U3", "vadv=C4,C4"]),

@@ -23,7 +23,7 @@ def _emu_libs():
 
 
 def _fields(tag):
-    return FIELDS + (GLS_FIELDS if tag.startswith(("upwelling_gls", "upwelling_my25")) else [])
+    return FIELDS + (GLS_FIELDS if tag.startswith(("upwelling_gls", "upwelling_my25", "upwelling_wetdry_gls", "upwelling_wetdry_my25")) else [])
 
 
 def _single(tag, kw, steps):
@@ -117,6 +117,20 @@ def test_tiled_run_bit_identical_to_single_tile(tmp_path, tag, kw, tiles, port):
         assert np.array_equal(a, b), (n, float(np.abs(a - b).max()), np.argwhere(a != b)[:5])
     assert got["diag"][2] == pytest.approx(dref["volume"], rel=1e-14)
     assert got["diag"][0] == pytest.approx(dref["avgke"], rel=1e-12)
+
+
+@pytest.mark.parametrize("variant,port", [("gls", 29651), ("geouv", 29652), ("prs44", 29653)])
+def test_wet_dry_variants_tiled_bit_identical_to_single_tile(tmp_path, monkeypatch, variant, port):
+    """Round 6: WET_DRY with the generic length-scale closure / the viscosity along geopotentials / PJ_GRADPQ4 on 2x2 tiles -- the host
+    takes the options from the header the reference was built with for the pin (ROMS_APP_HEADER = oracle/ref/upwelling_wetdry_<v>.h);
+    the shore line crosses the tile boundaries; every field of the single-tile run bit for bit."""
+    _emu_libs()
+    monkeypatch.setenv("ROMS_APP_HEADER", os.path.join(ROOT, "oracle", "ref", "upwelling_wetdry_%s.h" % variant))
+    tag, kw, steps = "upwelling_wetdry_%s_mid" % variant, dict(hadv=("U3", "HSIMT"), vadv=("C4", "HSIMT")), 4
+    ref, dref = _single(tag, kw, steps)
+    got = _tiled(tmp_path, tag, kw, steps, (2, 2), port)
+    for n in _fields(tag):
+        assert np.array_equal(got[n], ref[n]), (n, float(np.abs(got[n] - ref[n]).max()))
 
 
 def test_quadratic_pressure_jacobian_with_second_pass_stays_on_one_tile():
