@@ -193,6 +193,10 @@ def make_case(tag, **kw):
     for n in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac", "lbc_tke", "clima"):
         if n in kw:
             cs[n] = kw[n]
+    if cs.get("clima") and "mix4" in cs and cs.get("visc4", 0.0) > 4.0e7:
+        # (nudging towards the climatology of cases.clima_arrays sets the channel in motion: with VISC4 = 4e8, TNU4 = 2e7 the run blows up
+        # within ten steps -- in the reference and, bit for bit, in the oracle; a tenth is stable)
+        cs["visc4"], cs["tnu4"] = 4.0e7, (2.0e6, 1.0e6)
     return app, cs
 
 

@@ -966,3 +966,30 @@ def test_wet_dry_with_closures_geopotential_viscosity_and_other_jacobians_bitwis
         moved = moved or not np.array_equal(wet0, O.field("rmask_wet"))
     assert moved
     H.close()
+
+
+@pytest.mark.parametrize("tag,clima", [("upwelling_wetdry_small", 7), ("upwelling_bih_small", 7), ("upwelling_bihgeo_small", 7),
+                                       ("upwelling_geouv_small", 39), ("upwelling_bihgeouv_small", 7)])
+def test_climatology_nudging_with_wetting_biharmonic_and_geopotential_options_bitwise(emu, tag, clima):
+    """Round 6: nudging of the 3-D momentum and the tracers towards climatology (rhs3d.F:654-680, step3d_t.F:1866-1878) together with
+    WET_DRY, UV_VIS4 / TS_DIF4 and MIX_GEO_UV (with the harmonic form also LnudgeM2CLM: clima 39) -- refused until now as unpinned;
+    the oracle equals the reference with the switches on over 30 steps (tests/test_oracle_vs_ref.py).  15 steps, every bit."""
+    cs = util.case_for(tag)
+    cs["clima"] = clima
+    if "mix4" in cs:
+        cs["visc4"], cs["tnu4"] = min(cs["visc4"], 4.0e7), tuple(min(x, y) for x, y in zip(cs["tnu4"], (2.0e6, 1.0e6)))
+    g = util.load_init("upwelling_small", util.nghost_for(cs))
+    if cs.get("wet_dry"):
+        g = util.with_wetdry(cs, g)
+    elif "MASKING" in cs["options"]:
+        g = util.with_masks(cs, g)
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start(); H.start()
+    for step in range(15):
+        O.main3d_step(); H.main3d(1)
+        for n in util.PROGNOSTIC:
+            a, b = H.download(n), O.field(n)
+            assert np.array_equal(a, b), (step, n, int((a != b).sum()), float(np.abs(a - b).max()))
+    assert np.abs(O.field("u")).max() > 1e-3
+    H.close()

@@ -251,6 +251,13 @@ MAIN3D_CASES = [
     # the finite-volume pressure Jacobian of Lin (1997), prsgrd40.h (PJ_GRADP)
     ("upwelling_prs40_small", ["nsteps=60"]),
     ("upwelling_prs40_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    # climatology nudging (clima 39 = LnudgeM3CLM + both tracers + LnudgeM2CLM) together with WET_DRY, biharmonic mixing and the viscosity
+    # along geopotentials (round 6; a tenth of VISC4 / TNU4 for the biharmonic cases: refdrive.make_case)
+    ("upwelling_wetdry_small", ["nsteps=30", "clima=39"]),
+    ("upwelling_bih_small", ["nsteps=30", "clima=39"]),
+    ("upwelling_bihgeo_small", ["nsteps=30", "clima=39"]),
+    ("upwelling_geouv_small", ["nsteps=30", "clima=39"]),
+    ("upwelling_bihgeouv_small", ["nsteps=30", "clima=39"]),
     # WET_DRY with the closures (no WET_DRY statement of their own), the viscosity along geopotentials and the Jacobians prsgrd31 / 44
     # (round 6: oracle/ref/upwelling_wetdry_*.h; PJ_GRADP does not compile with WET_DRY in the reference: prsgrd40.h:98)
     ("upwelling_wetdry_gls_small", ["nsteps=40"]),
