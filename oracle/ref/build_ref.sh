@@ -50,6 +50,11 @@ if [ "$APP" = upwelling_kpp_ddmix ]; then
   UP=UPWELLING; HDR=upwelling_kpp_ddmix; HDRPATH="$HERE/upwelling_kpp_ddmix.h"
   EXTRA=""
 fi
+if [ "$APP" = benchmark_wetdry_ddmix ]; then
+  # oracle/ref/benchmark_wetdry.h (MASKING + WET_DRY, bulk fluxes, KPP) with LMD_DDMIX on top
+  UP=BENCHMARK; HDR=benchmark_wetdry; HDRPATH="$HERE/benchmark_wetdry.h"
+  EXTRA="-I$HERE/functionals -DLMD_DDMIX"
+fi
 if [ "$APP" = benchmark_ddmix ]; then
   # the shipped benchmark.h with LMD_DDMIX switched on as a user does (nonlinear EOS: alfaobeta of rho_eos.F:435-455)
   UP=BENCHMARK; HDR=benchmark; HDRPATH="benchmark.h"
@@ -90,7 +95,7 @@ if [ "$APP" = benchmark_wetdry ]; then
   UP=BENCHMARK; HDR=benchmark_wetdry; HDRPATH="$HERE/benchmark_wetdry.h"
   EXTRA="-I$HERE/functionals"
 fi
-if [ "$APP" = upwelling_wetdry_gls ] || [ "$APP" = upwelling_wetdry_my25 ] || [ "$APP" = upwelling_wetdry_geouv ] || [ "$APP" = upwelling_wetdry_prs31 ] || [ "$APP" = upwelling_wetdry_prs44 ]; then
+if [ "$APP" = upwelling_wetdry_gls ] || [ "$APP" = upwelling_wetdry_my25 ] || [ "$APP" = upwelling_wetdry_geouv ] || [ "$APP" = upwelling_wetdry_prs31 ] || [ "$APP" = upwelling_wetdry_prs44 ] || [ "$APP" = upwelling_wetdry_iso ]; then
   # WET_DRY with the closures, the viscosity along geopotentials and the other pressure Jacobians (round 6: oracle/ref/upwelling_wetdry_*.h;
   # PJ_GRADP does not compile with WET_DRY in the reference itself: prsgrd40.h:98 passes umask_wet, vmask_wet without declaring them)
   UP=UPWELLING; HDR=$APP; HDRPATH="$HERE/$APP.h"

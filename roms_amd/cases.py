@@ -151,6 +151,10 @@ def benchmark_ddmix(**kw):
     return with_ddmix(benchmark(**kw))
 
 
+def benchmark_wetdry_ddmix(**kw):
+    return with_ddmix(benchmark_wetdry(**kw))
+
+
 def ddmix_state(cs, t, LBi, UBi, LBj, UBj):
     """A temperature / salinity state that reaches every branch of LMD_DDMIX (the analytic initial salinity is uniform: no double
     diffusion at all).  West half of the domain: S = 35 + s (T - 14), warm and salty above cold and fresh with 1 < Rrho < 1.9
@@ -391,6 +395,9 @@ def upwelling_wetdry_x(variant, **kw):
         cs["options"] = tuple(cs["options"]) + ("PRSGRD31",)
     elif variant == "prs44":
         cs["prsgrd"] = 44
+    elif variant == "iso":
+        cs["options"] = tuple(cs["options"]) + ("MIX_ISO_TS",)
+        cs["tnu2"] = (20.0, 10.0)                    # (UPWELLING's TNU2 is zero: the operator would add zeros)
     else:
         raise ValueError(variant)
     return cs

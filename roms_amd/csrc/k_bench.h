@@ -468,6 +468,9 @@ THREAD_KERNEL(k_t3dmix2_iso, KArgs) {
   if (G.masking) {
     cxi = cxi * F.umask[x]; cxp = cxp * F.umask[x + 1]; cej = cej * F.vmask[x]; cep = cep * F.vmask[x + ni];
   }
+  if (G.wet_dry) {                                           // t3dmix2_iso.h:234-236, :266-268 (round 6)
+    cxi = cxi * F.umask_wet[x]; cxp = cxp * F.umask_wet[x + 1]; cej = cej * F.vmask_wet[x]; cep = cep * F.vmask_wet[x + ni];
+  }
   const double fxi = 0.25 * (d2[0] + d2[-1]) * F.on_u[x], fxp = 0.25 * (d2[1] + d2[0]) * F.on_u[x + 1];
   const double fej = 0.25 * (d2[0] + d2[-ni]) * F.om_v[x], fep = 0.25 * (d2[ni] + d2[0]) * F.om_v[x + ni];
   const double c = G.dt * pm[0] * pn[0], eps = 0.5;

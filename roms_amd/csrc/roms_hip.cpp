@@ -260,8 +260,8 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     return 5;
   }
   if ((cfg->options & ROMS_MIX_GEO_TS) && (cfg->options & ROMS_MIX_ISO_TS)) { set_error("MIX_GEO_TS and MIX_ISO_TS exclude each other"); return 5; }
-  if ((cfg->options & ROMS_MIX_ISO_TS) && (cfg->options & (ROMS_MASKING | ROMS_NONLIN_EOS))) {   // (only the pinned combination is offered)
-    set_error("MIX_ISO_TS is pinned to the reference with the linear equation of state and without MASKING only (OVERFLOW)");
+  if ((cfg->options & ROMS_MIX_ISO_TS) && (cfg->options & ROMS_NONLIN_EOS)) {   // (only the pinned combinations are offered: OVERFLOW; round 6: MASKING + WET_DRY)
+    set_error("MIX_ISO_TS is pinned to the reference with the linear equation of state only (OVERFLOW, oracle/ref/upwelling_wetdry_iso.h)");
     return 5;
   }
   if ((cfg->options & ROMS_GLS_MIXING) && (cfg->options & ROMS_MY25_MIXING)) { set_error("GLS_MIXING and MY25_MIXING exclude each other"); return 5; }
@@ -655,7 +655,6 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   if (cfg->options & ROMS_LMD_DDMIX) {                      // lmd_vmix.F:360-428
     if (!(cfg->options & ROMS_LMD_MIXING)) { set_error("LMD_DDMIX without LMD_MIXING"); roms_hip_destroy(c); return 5; }
     if (c->G.NT < 2 || !(cfg->options & ROMS_SALINITY)) { set_error("LMD_DDMIX needs salinity (the double-diffusive density ratio)"); roms_hip_destroy(c); return 5; }
-    if (cfg->options & ROMS_WET_DRY) { set_error("LMD_DDMIX with WET_DRY: not pinned against the reference"); roms_hip_destroy(c); return 5; }
     void *p = nullptr;
     const size_t nb = (size_t)c->G.nij * (size_t)(c->G.N + 1) * sizeof(double);
     if (dmalloc(&p, nb)) { roms_hip_destroy(c); return 2; }
@@ -2456,7 +2455,7 @@ static int wetdry_config(roms_hip_ctx *c, double Dcrit) {
   if (!G.masking) { set_error("WET_DRY: needs MASKING (globaldefs.h:152-154 defines it with WET_DRY)"); return 5; }
   // (round 6: GLS_MIXING / MY25_MIXING -- their routines carry no WET_DRY statement --, MIX_GEO_UV and the Jacobians prsgrd31 / 40 / 44
   // are pinned under WET_DRY: oracle/ref/upwelling_wetdry_*.h)
-  if ((opt & ROMS_MIX_ISO_TS) || G.uv_vis4 || G.ts_dif4) { set_error("WET_DRY: harmonic mixing along s-surfaces or geopotentials only (t3dmix2_s.h, t3dmix2_geo.h, uv3dmix2_s.h)"); return 5; }
+  if (G.uv_vis4 || G.ts_dif4) { set_error("WET_DRY: harmonic mixing only (t3dmix2_s.h, t3dmix2_geo.h, t3dmix2_iso.h, uv3dmix2_s.h, uv3dmix2_geo.h)"); return 5; }
   if (G.prs4x == 42) { set_error("WET_DRY with PJ_GRADPQ2: prsgrd42.h masks its FIRST pass (:355-361), which is not built"); return 5; }
   if (opt & ROMS_PRSGRD40) { set_error("WET_DRY with PJ_GRADP: the reference does not compile with the two together (prsgrd40.h:98 passes umask_wet, vmask_wet undeclared) -- nothing to pin against"); return 5; }
   if (opt & (ROMS_PLAIN_VVISC)) { set_error("WET_DRY: SPLINES_VVISC only"); return 5; }

@@ -1062,9 +1062,9 @@
 !  carry stop here
 !  (round 6: the closures GLS_MIXING / MY25_MIXING, MIX_GEO_UV and the Jacobians prsgrd31 / 40 / 44 are pinned under WET_DRY:
 !  oracle/ref/upwelling_wetdry_*.h)
-      IF (wet_dry.and.(IAND(options, IOR(ROMS_MIX_ISO_TS, ROMS_PRSGRD40)).ne.0.or.ANY(mix4).or.prs4x.eq.42.or.ddmix))    &
-     &  CALL unsupported ('WET_DRY is not built with MIX_ISO_TS, UV_VIS4, TS_DIF4, PJ_GRADP (which the reference does not '//   &
-     &                    'compile with WET_DRY either), PJ_GRADPQ2 or LMD_DDMIX', ierr)
+      IF (wet_dry.and.(IAND(options, ROMS_PRSGRD40).ne.0.or.ANY(mix4).or.prs4x.eq.42))                                  &
+     &  CALL unsupported ('WET_DRY is not built with UV_VIS4, TS_DIF4, PJ_GRADP (which the reference does not '//          &
+     &                    'compile with WET_DRY either) or PJ_GRADPQ2', ierr)
       IF ((mix4(1).and.is_defined('UV_VIS2')).or.(mix4(2).and.is_defined('TS_DIF2')))                          &
      &  CALL unsupported ('harmonic and biharmonic mixing of the same field together (UV_VIS2 + UV_VIS4, TS_DIF2 + TS_DIF4) '// &
      &                    'are not built', ierr)

@@ -23,6 +23,7 @@ CASES = {
     # LMD_DDMIX (round 6): oracle/ref/upwelling_kpp_ddmix.h (linear EOS), benchmark.h -DLMD_DDMIX (nonlinear EOS); the state of cases.ddmix_state
     "upwelling_kpp_ddmix_small": ("upwelling_kpp_ddmix", dict(Lm=14, Mm=18, N=8)),
     "benchmark_ddmix_small": ("benchmark_ddmix", dict(Lm=24, Mm=16, N=10)),
+    "benchmark_wetdry_ddmix_small": ("benchmark_wetdry_ddmix", dict(Lm=24, Mm=16, N=10)),      # ... under WET_DRY
     # the UPWELLING case built WITH its time-averaged output (oracle/ref/upwelling_avg.h): pins set_avg.F
     "upwelling_avg_small": ("upwelling_avg", dict(Lm=14, Mm=18, N=8)),
     # ROMS/Include/upwelling.h AS SHIPPED (AVERAGES, DIAGNOSTICS_TS, DIAGNOSTICS_UV): pins the per-term tracer tendencies
@@ -47,6 +48,7 @@ CASES = {
     "upwelling_wetdry_geouv_small": ("upwelling_wetdry_geouv", dict(Lm=14, Mm=18, N=8, variant="geouv")),
     "upwelling_wetdry_prs31_small": ("upwelling_wetdry_prs31", dict(Lm=14, Mm=18, N=8, variant="prs31")),
     "upwelling_wetdry_prs44_small": ("upwelling_wetdry_prs44", dict(Lm=14, Mm=18, N=8, variant="prs44")),
+    "upwelling_wetdry_iso_small": ("upwelling_wetdry_iso", dict(Lm=14, Mm=18, N=8, variant="iso")),
     # open boundaries: the reference's own KELVIN application (ROMS/Include/kelvin.h, RADIATION_2D) ...
     # more of the reference's own test applications (ROMS/Include/seamount.h, grav_adj.h as shipped)
     # the standard density Jacobian (prsgrd31.h), plain and weighted (WJ_GRADP)
@@ -176,8 +178,8 @@ def make_case(tag, **kw):
                 upwelling_avg=cases.upwelling, upwelling_diag=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag, upwelling_noadv=cases.upwelling_noadv,
                 upwelling_mask=cases.upwelling_mask, upwelling_wetdry=cases.upwelling_wetdry, benchmark_mask=cases.benchmark_mask, benchmark_wetdry=cases.benchmark_wetdry,
                 upwelling_avg_mask=cases.upwelling_mask, upwelling_wetdry_avg=cases.upwelling_wetdry, upwelling_wetdry_gls=cases.upwelling_wetdry_x, upwelling_wetdry_my25=cases.upwelling_wetdry_x,
-                upwelling_wetdry_geouv=cases.upwelling_wetdry_x, upwelling_wetdry_prs31=cases.upwelling_wetdry_x, upwelling_wetdry_prs44=cases.upwelling_wetdry_x, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeouv=cases.upwelling_bihgeouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
-                upwelling_wjgradp=cases.upwelling_prs31, upwelling_kpp_ddmix=cases.upwelling_kpp_ddmix, benchmark_ddmix=cases.benchmark_ddmix, upwelling_prs40=cases.upwelling_prs40, upwelling_prs42=cases.upwelling_prs4x, upwelling_prs44=cases.upwelling_prs4x, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
+                upwelling_wetdry_geouv=cases.upwelling_wetdry_x, upwelling_wetdry_prs31=cases.upwelling_wetdry_x, upwelling_wetdry_prs44=cases.upwelling_wetdry_x, upwelling_wetdry_iso=cases.upwelling_wetdry_x, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeouv=cases.upwelling_bihgeouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
+                upwelling_wjgradp=cases.upwelling_prs31, upwelling_kpp_ddmix=cases.upwelling_kpp_ddmix, benchmark_ddmix=cases.benchmark_ddmix, benchmark_wetdry_ddmix=cases.benchmark_wetdry_ddmix, upwelling_prs40=cases.upwelling_prs40, upwelling_prs42=cases.upwelling_prs4x, upwelling_prs44=cases.upwelling_prs4x, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
                 upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]
     lbc = k.pop("lbc", None)

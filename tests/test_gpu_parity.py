@@ -1040,7 +1040,7 @@ def test_more_reference_applications_match_oracle(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["gls", "my25", "geouv", "prs31", "prs44"])
+@pytest.mark.parametrize("variant", ["gls", "my25", "geouv", "prs31", "prs44", "iso"])
 def test_wet_dry_variants_match_oracle(variant):
     """Round 6: WET_DRY with GLS_MIXING / MY25_MIXING, MIX_GEO_UV, prsgrd31.h / prsgrd44.h on the GPU -- 40 steps against the oracle
     (equal to the reference built from oracle/ref/upwelling_wetdry_<variant>.h): bit for bit where the host's libm is the recorded

@@ -512,11 +512,12 @@ def test_open_boundary_kinds_the_library_does_not_have_stop():
 
 
 def test_isopycnic_mixing_only_in_its_pinned_combination():
-    """MIX_ISO_TS (t3dmix2_iso.h) is pinned to the reference through OVERFLOW -- linear equation of state, no land: with
-    NONLIN_EOS, MASKING or MIX_GEO_TS beside it roms_hip_create stops with exit_flag 5 and the reason."""
+    """MIX_ISO_TS (t3dmix2_iso.h) is pinned to the reference through OVERFLOW and, since round 6, with MASKING + WET_DRY
+    (oracle/ref/upwelling_wetdry_iso.h) -- linear equation of state: with NONLIN_EOS or MIX_GEO_TS beside it roms_hip_create
+    stops with exit_flag 5 and the reason."""
     from roms_amd import hiplib
     g = util.load_init("overflow_small", 2)
-    for extra, needle in (("NONLIN_EOS", "pinned"), ("MASKING", "pinned"), ("MIX_GEO_TS", "exclude")):
+    for extra, needle in (("NONLIN_EOS", "pinned"), ("MIX_GEO_TS", "exclude")):
         cs = util.case_for("overflow_small")
         cs["options"] = tuple(cs["options"]) + (extra,)
         gg = util.with_masks(cs, g) if extra == "MASKING" else g
@@ -943,7 +944,7 @@ def test_closed_basin_with_biharmonic_mixing_bitwise(emu, tag):
     H.close()
 
 
-@pytest.mark.parametrize("variant", ["gls", "my25", "geouv", "prs31", "prs44"])
+@pytest.mark.parametrize("variant", ["gls", "my25", "geouv", "prs31", "prs44", "iso"])
 def test_wet_dry_with_closures_geopotential_viscosity_and_other_jacobians_bitwise(emu, variant):
     """Round 6: WET_DRY together with GLS_MIXING / MY25_MIXING (their routines carry no WET_DRY statement; the closure sees the
     masked, limited state), MIX_GEO_UV (uv3dmix2_geo.h's wet masks) and the Jacobians prsgrd31.h / prsgrd44.h (ru, rv times the wet
@@ -992,4 +993,21 @@ def test_climatology_nudging_with_wetting_biharmonic_and_geopotential_options_bi
             a, b = H.download(n), O.field(n)
             assert np.array_equal(a, b), (step, n, int((a != b).sum()), float(np.abs(a - b).max()))
     assert np.abs(O.field("u")).max() > 1e-3
+    H.close()
+
+
+def test_double_diffusive_mixing_with_wet_dry_bitwise(emu):
+    """LMD_DDMIX under WET_DRY (BENCHMARK with MASKING + WET_DRY, bulk fluxes, KPP: oracle/ref/benchmark_wetdry.h -DLMD_DDMIX pins the
+    oracle over 40 steps): 10 steps against the oracle on the state of cases.ddmix_state, every bit."""
+    cs = util.case_for("benchmark_wetdry_small")
+    cs["ddmix"] = 1
+    g = util.with_ddmix_state(cs, util.with_wetdry(cs, util.load_init(util.init_tag(cs), util.nghost_for(cs))))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start(); H.start()
+    for step in range(10):
+        O.main3d_step(); H.main3d(1)
+        for n in util.PROGNOSTIC + ["Akt", "Akv", "rmask_wet"]:
+            a, b = H.download(n), O.field(n)
+            assert np.array_equal(a, b), (step, n, int((a != b).sum()), float(np.abs(a - b).max()))
     H.close()

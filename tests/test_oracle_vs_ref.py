@@ -268,6 +268,9 @@ MAIN3D_CASES = [
     ("upwelling_wetdry_prs31_small", ["nsteps=40"]),
     ("upwelling_wetdry_prs44_small", ["nsteps=40"]),
     ("upwelling_wetdry_prs44_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_wetdry_iso_small", ["nsteps=40"]),                              # MIX_ISO_TS: t3dmix2_iso.h's masked and wet gradients
+    ("upwelling_wetdry_iso_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("benchmark_wetdry_ddmix_small", ["nsteps=40"]),                            # LMD_DDMIX under WET_DRY (benchmark_wetdry.h -DLMD_DDMIX)
     # UV_VIS4 + MIX_GEO_UV (round 6): uv3dmix4_geo.h, the rotated stress tensor twice, under MASKING; in the channel and between four walls
     ("upwelling_bihgeouv_small", ["nsteps=60"]),
     ("upwelling_bihgeouv_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=U3,U3", "vadv=C4,C4"]),

@@ -87,9 +87,9 @@ def case_for(tag, **kw):
         return cases.upwelling_prs31(Lm=14, Mm=18, N=8, **kw)
     if tag == "upwelling_bihgeouv_small":
         return cases.upwelling_bihgeouv(Lm=14, Mm=18, N=8, **kw)
-    if tag.startswith("upwelling_wetdry_") and tag.endswith("_small") and tag[17:-6] in ("gls", "my25", "geouv", "prs31", "prs44"):
+    if tag.startswith("upwelling_wetdry_") and tag.endswith("_small") and tag[17:-6] in ("gls", "my25", "geouv", "prs31", "prs44", "iso"):
         return cases.upwelling_wetdry_x(tag[17:-6], Lm=14, Mm=18, N=8, **kw)
-    if tag.startswith("upwelling_wetdry_") and tag.endswith("_mid") and tag[17:-4] in ("gls", "my25", "geouv", "prs31", "prs44"):
+    if tag.startswith("upwelling_wetdry_") and tag.endswith("_mid") and tag[17:-4] in ("gls", "my25", "geouv", "prs31", "prs44", "iso"):
         return cases.upwelling_wetdry_x(tag[17:-4], Lm=34, Mm=40, N=6, **kw)
     if tag == "upwelling_prs40_small":
         return cases.upwelling_prs40(Lm=14, Mm=18, N=8, **kw)
