@@ -76,7 +76,7 @@ enum {
 #define ROMS_WET_DRY (1ull << 34)         /* wetting and drying, wetdry.F and its branches (below); roms_hip_config.Dcrit = DCRIT of roms.in */
 #define ROMS_MIX_GEO_UV (1ull << 36)      /* UV_VIS2 along geopotential surfaces: uv3dmix2_geo.h:130-757 (the rotated stress tensor) in place of
                                              uv3dmix2_s.h; with ROMS_UV_VIS4 (round 6): uv3dmix4_geo.h:296-1478, the operator twice, in place of
-                                             uv3dmix4_s.h.  Refused (exit_flag 5) with DIAGNOSTICS_UV, WET_DRY and open boundaries */
+                                             uv3dmix4_s.h.  Refused (exit_flag 5) with DIAGNOSTICS_UV (and, in its biharmonic form, with WET_DRY) */
 #define ROMS_NUDGE_M3CLM (1ull << 37)     /* LnudgeM3CLM of roms.in: nudging of u, v towards "uclm", "vclm" with "M3nudgcof" (rhs3d.F:654-680) */
 #define ROMS_NUDGE_TCLM(itrc) (1ull << (37 + (itrc)))   /* LtracerCLM & LnudgeTCLM of tracer itrc = 1..4: towards "tclm" with "Tnudgcof"
                                              (step3d_t.F:1866-1878; N planes per tracer, tracer-major).  The arrays are inputs like the

@@ -164,6 +164,16 @@ if [ "$APP" = grav_adj ]; then
   UP=GRAV_ADJ; HDR=grav_adj_nodiag; HDRPATH="$HERE/grav_adj_nodiag.h"
   EXTRA=""
 fi
+if [ "$APP" = kelvin_geouv ]; then
+  # KELVIN (open boundaries) with the viscosity along geopotentials (oracle/ref/kelvin_geouv.h: MIX_GEO_UV; round 6)
+  UP=KELVIN; HDR=kelvin_geouv; HDRPATH="$HERE/kelvin_geouv.h"
+  EXTRA=""
+fi
+if [ "$APP" = benchmark_iso ]; then
+  # BENCHMARK with tracer mixing along isopycnals and the nonlinear EOS (oracle/ref/benchmark_iso.h: MIX_ISO_TS; round 6)
+  UP=BENCHMARK; HDR=benchmark_iso; HDRPATH="$HERE/benchmark_iso.h"
+  EXTRA=""
+fi
 if [ "$APP" = kelvin_gls ]; then
   # KELVIN (open boundaries, spline solvers) with GLS_MIXING (oracle/ref/kelvin_gls.h): tkebc next to radiating edges
   UP=KELVIN; HDR=kelvin_gls; HDRPATH="$HERE/kelvin_gls.h"

@@ -289,6 +289,24 @@ def upwelling_gls(form="upwelling_gls", closure="k-epsilon", **kw):
     return cs
 
 
+def kelvin_geouv(**kw):
+    """KELVIN (open boundaries) with the harmonic viscosity along geopotential surfaces (MIX_GEO_UV): oracle/ref/kelvin_geouv.h"""
+    cs = kelvin(**kw)
+    cs["app"] = "kelvin_geouv"
+    cs["mix_geo_uv"] = 1
+    cs["visc2"] = 50.0                   # (roms_kelvin.in has VISC2 = 0: the operator would add zeros)
+    return cs
+
+
+def benchmark_iso(**kw):
+    """BENCHMARK with its tracer mixing along isopycnic instead of geopotential surfaces (MIX_ISO_TS with the nonlinear equation of
+    state): oracle/ref/benchmark_iso.h"""
+    cs = benchmark(**kw)
+    cs["app"] = "benchmark_iso"
+    cs["options"] = tuple("MIX_ISO_TS" if o == "MIX_GEO_TS" else o for o in cs["options"])
+    return cs
+
+
 def kelvin_gls(**kw):
     """KELVIN (open boundaries) with the generic length-scale closure (Canuto A, smoothing, spline shear; k-epsilon):
     the custom application header oracle/ref/kelvin_gls.h"""

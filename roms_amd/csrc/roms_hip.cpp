@@ -260,10 +260,8 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     return 5;
   }
   if ((cfg->options & ROMS_MIX_GEO_TS) && (cfg->options & ROMS_MIX_ISO_TS)) { set_error("MIX_GEO_TS and MIX_ISO_TS exclude each other"); return 5; }
-  if ((cfg->options & ROMS_MIX_ISO_TS) && (cfg->options & ROMS_NONLIN_EOS)) {   // (only the pinned combinations are offered: OVERFLOW; round 6: MASKING + WET_DRY)
-    set_error("MIX_ISO_TS is pinned to the reference with the linear equation of state only (OVERFLOW, oracle/ref/upwelling_wetdry_iso.h)");
-    return 5;
-  }
+  // (MIX_ISO_TS: pinned through OVERFLOW; round 6: with MASKING + WET_DRY, oracle/ref/upwelling_wetdry_iso.h, and with the nonlinear
+  // equation of state, oracle/ref/benchmark_iso.h -- no combination of it is refused any more)
   if ((cfg->options & ROMS_GLS_MIXING) && (cfg->options & ROMS_MY25_MIXING)) { set_error("GLS_MIXING and MY25_MIXING exclude each other"); return 5; }
   if (cfg->options & (ROMS_GLS_MIXING | ROMS_MY25_MIXING)) {     // gls_prestep.F, gls_corstep.F (my25_*.F): one closure, one form of it, sane parameters
     const int st = cfg->gls_flags & (ROMS_GLS_CANUTO_A | ROMS_GLS_CANUTO_B | ROMS_GLS_KANTHA_CLAYSON);
@@ -674,7 +672,7 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
   }
   if (cfg->options & ROMS_MIX_GEO_UV) {                     // uv3dmix2_geo.h | uv3dmix4_geo.h (k_uvmix_geo.h): twenty-two 3-D work arrays
     if (!(cfg->options & ROMS_UV_VIS2) && !c->G.uv_vis4) { set_error("MIX_GEO_UV without UV_VIS2 or UV_VIS4"); roms_hip_destroy(c); return 5; }
-    if (c->G.obc) { set_error("MIX_GEO_UV with open boundaries: not pinned"); roms_hip_destroy(c); return 5; }
+    // (open boundaries: pinned with oracle/ref/kelvin_geouv.h since round 6)
     if (cfg->options & ROMS_DIAGNOSTICS_UV) { set_error("MIX_GEO_UV: the DIAGNOSTICS_UV statements of uv3dmix2_geo.h are not built"); roms_hip_destroy(c); return 5; }
     if ((cfg->options & ROMS_WET_DRY) && c->G.uv_vis4) { set_error("UV_VIS4 with WET_DRY: harmonic mixing only"); roms_hip_destroy(c); return 5; }
     void *p = nullptr;

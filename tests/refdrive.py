@@ -82,6 +82,8 @@ CASES = {
     "grav_adj_small": ("grav_adj", dict(Lm=32, Mm=4, N=10)),
     "kelvin": ("kelvin_splines", dict()),
     "kelvin_small": ("kelvin_splines", dict(Lm=16, Mm=12, N=6)),
+    "kelvin_geouv_small": ("kelvin_geouv", dict(Lm=16, Mm=12, N=6)),   # open boundaries + MIX_GEO_UV (oracle/ref/kelvin_geouv.h; round 6)
+    "benchmark_iso_small": ("benchmark_iso", dict(Lm=24, Mm=16, N=10)),   # MIX_ISO_TS with the nonlinear EOS (oracle/ref/benchmark_iso.h; round 6)
     "kelvin_gls_small": ("kelvin_gls", dict(Lm=16, Mm=12, N=6)),       # open boundaries + GLS_MIXING (oracle/ref/kelvin_gls.h)
     "kelvin_plain_small": ("kelvin", dict(Lm=16, Mm=12, N=6, plain=True)),   # kelvin.h as shipped: the plain vertical solvers
     "kelvin_plain": ("kelvin", dict(plain=True)),
@@ -178,7 +180,7 @@ def make_case(tag, **kw):
                 upwelling_avg=cases.upwelling, upwelling_diag=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag, upwelling_noadv=cases.upwelling_noadv,
                 upwelling_mask=cases.upwelling_mask, upwelling_wetdry=cases.upwelling_wetdry, benchmark_mask=cases.benchmark_mask, benchmark_wetdry=cases.benchmark_wetdry,
                 upwelling_avg_mask=cases.upwelling_mask, upwelling_wetdry_avg=cases.upwelling_wetdry, upwelling_wetdry_gls=cases.upwelling_wetdry_x, upwelling_wetdry_my25=cases.upwelling_wetdry_x,
-                upwelling_wetdry_geouv=cases.upwelling_wetdry_x, upwelling_wetdry_prs31=cases.upwelling_wetdry_x, upwelling_wetdry_prs44=cases.upwelling_wetdry_x, upwelling_wetdry_iso=cases.upwelling_wetdry_x, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeouv=cases.upwelling_bihgeouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
+                upwelling_wetdry_geouv=cases.upwelling_wetdry_x, upwelling_wetdry_prs31=cases.upwelling_wetdry_x, upwelling_wetdry_prs44=cases.upwelling_wetdry_x, upwelling_wetdry_iso=cases.upwelling_wetdry_x, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, kelvin_geouv=cases.kelvin_geouv, benchmark_iso=cases.benchmark_iso, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeouv=cases.upwelling_bihgeouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
                 upwelling_wjgradp=cases.upwelling_prs31, upwelling_kpp_ddmix=cases.upwelling_kpp_ddmix, benchmark_ddmix=cases.benchmark_ddmix, benchmark_wetdry_ddmix=cases.benchmark_wetdry_ddmix, upwelling_prs40=cases.upwelling_prs40, upwelling_prs42=cases.upwelling_prs4x, upwelling_prs44=cases.upwelling_prs4x, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
                 upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]

@@ -513,11 +513,11 @@ def test_open_boundary_kinds_the_library_does_not_have_stop():
 
 def test_isopycnic_mixing_only_in_its_pinned_combination():
     """MIX_ISO_TS (t3dmix2_iso.h) is pinned to the reference through OVERFLOW and, since round 6, with MASKING + WET_DRY
-    (oracle/ref/upwelling_wetdry_iso.h) -- linear equation of state: with NONLIN_EOS or MIX_GEO_TS beside it roms_hip_create
-    stops with exit_flag 5 and the reason."""
+    (oracle/ref/upwelling_wetdry_iso.h) and with the nonlinear equation of state (oracle/ref/benchmark_iso.h): only MIX_GEO_TS
+    beside it stops roms_hip_create, exit_flag 5 and the reason."""
     from roms_amd import hiplib
     g = util.load_init("overflow_small", 2)
-    for extra, needle in (("NONLIN_EOS", "pinned"), ("MIX_GEO_TS", "exclude")):
+    for extra, needle in (("MIX_GEO_TS", "exclude"),):
         cs = util.case_for("overflow_small")
         cs["options"] = tuple(cs["options"]) + (extra,)
         gg = util.with_masks(cs, g) if extra == "MASKING" else g
@@ -1008,6 +1008,24 @@ def test_double_diffusive_mixing_with_wet_dry_bitwise(emu):
     for step in range(10):
         O.main3d_step(); H.main3d(1)
         for n in util.PROGNOSTIC + ["Akt", "Akv", "rmask_wet"]:
+            a, b = H.download(n), O.field(n)
+            assert np.array_equal(a, b), (step, n, int((a != b).sum()), float(np.abs(a - b).max()))
+    H.close()
+
+
+@pytest.mark.parametrize("tag", ["kelvin_geouv_small", "benchmark_iso_small"])
+def test_more_pinned_combinations_bitwise(emu, tag):
+    """Round 6: MIX_GEO_UV beside open boundaries (KELVIN with the viscosity along geopotentials, VISC2 = 50: oracle/ref/kelvin_geouv.h)
+    and MIX_ISO_TS with the nonlinear equation of state (BENCHMARK with its tracer mixing along isopycnals: oracle/ref/benchmark_iso.h)
+    -- refused until now as unpinned; the oracle equals the reference over 40 steps.  20 steps against the oracle, every bit."""
+    cs = util.case_for(tag)
+    g = util.load_init(util.init_tag(cs), util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g, emu)
+    O.start(); H.start()
+    for step in range(20):
+        O.main3d_step(); H.main3d(1)
+        for n in util.PROGNOSTIC:
             a, b = H.download(n), O.field(n)
             assert np.array_equal(a, b), (step, n, int((a != b).sum()), float(np.abs(a - b).max()))
     H.close()

@@ -258,6 +258,10 @@ MAIN3D_CASES = [
     ("upwelling_bihgeo_small", ["nsteps=30", "clima=39"]),
     ("upwelling_geouv_small", ["nsteps=30", "clima=39"]),
     ("upwelling_bihgeouv_small", ["nsteps=30", "clima=39"]),
+    ("kelvin_geouv_small", ["nsteps=40"]),                                       # MIX_GEO_UV beside open boundaries (kelvin_geouv.h)
+    ("kelvin_geouv_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
+    ("benchmark_iso_small", ["nsteps=40"]),                                      # MIX_ISO_TS with the nonlinear EOS (benchmark_iso.h)
+    ("benchmark_iso_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     # WET_DRY with the closures (no WET_DRY statement of their own), the viscosity along geopotentials and the Jacobians prsgrd31 / 44
     # (round 6: oracle/ref/upwelling_wetdry_*.h; PJ_GRADP does not compile with WET_DRY in the reference: prsgrd40.h:98)
     ("upwelling_wetdry_gls_small", ["nsteps=40"]),

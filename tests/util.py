@@ -91,6 +91,10 @@ def case_for(tag, **kw):
         return cases.upwelling_wetdry_x(tag[17:-6], Lm=14, Mm=18, N=8, **kw)
     if tag.startswith("upwelling_wetdry_") and tag.endswith("_mid") and tag[17:-4] in ("gls", "my25", "geouv", "prs31", "prs44", "iso"):
         return cases.upwelling_wetdry_x(tag[17:-4], Lm=34, Mm=40, N=6, **kw)
+    if tag == "kelvin_geouv_small":
+        return cases.kelvin_geouv(Lm=16, Mm=12, N=6, **kw)
+    if tag == "benchmark_iso_small":
+        return cases.benchmark_iso(Lm=24, Mm=16, N=10, **kw)
     if tag == "upwelling_prs40_small":
         return cases.upwelling_prs40(Lm=14, Mm=18, N=8, **kw)
     if tag in ("upwelling_prs42_small", "upwelling_prs44_small"):
