@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define ROMS_HIP_ABI_VERSION 4    /* 2: lateral boundary conditions (lbc ... Tobc_out) appended to roms_hip_config;
+#define ROMS_HIP_ABI_VERSION 5    /* 5 (round 6): obcfac appended -- with climatology nudging the radiation conditions take their time scales
+                                        from the nudging coefficient arrays, obc_in = obcfac * obc_out (u3dbc_im.F:113-118);
+                                     2: lateral boundary conditions (lbc ... Tobc_out) appended to roms_hip_config;
                                      3: the generic length-scale closure (gls_flags ... lbc_tke) appended;
                                      4: options is a 64-bit mask -- UV_VIS4, TS_DIF4, WET_DRY (+ Dcrit, appended),
                                         DIAGNOSTICS_UV are option bits like the others, not configuration calls */
@@ -160,6 +162,9 @@ typedef struct roms_hip_config {
   int lbc_tke[4];
   /* WET_DRY (ABI version 4): DCRIT of roms.in (read_phypar.F:1021), the total depth below which a cell is dry */
   double Dcrit;
+  /* ABI version 5: OBCFAC of roms.in (mod_scalars.F: obcfac) -- the ratio inflow / outflow nudging time scale of the radiation +
+     nudging boundary conditions, used where ROMS_NUDGE_M3CLM / _TCLM / _M2CLM make them read "M3nudgcof" / "Tnudgcof" / "M2nudgcof" */
+  double obcfac;
 } roms_hip_config;
 
 /* time indices of mod_stepping.F / mod_scalars.F that the kernel wrappers read */

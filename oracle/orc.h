@@ -120,6 +120,7 @@ typedef struct {
   int gls_flags;
   double gls_p, gls_m, gls_n, gls_Kmin, gls_Pmin, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp;
   double Akk_bak, Akp_bak, Zos, charnok_alpha, crgban_cw;
+  double obcfac;                        /* OBCFAC: with climatology nudging the radiation conditions read the coefficient arrays, obc_in = obcfac * obc_out */
   int lbc_tke[4];                       /* LBC(isMtke) [iwest, isouth, ieast, inorth]: 0 = closed / periodic as the direction is; ORC_LBC_GRA, ORC_LBC_RAD (tkebc_im.F) */
 } orc_cfg;
 

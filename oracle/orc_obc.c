@@ -302,7 +302,12 @@ static void uv2dbc(const orc_t *o, const orc_bounds *b, int kout, char grid) {
       const double bv = bry[s - lb];
       double val;
       if (kind == ORC_LBC_RAD || kind == ORC_LBC_RADNUD) {
-        val = rad_point(o, &E, Qn, Qo, i, j, NULL, kind == ORC_LBC_RADNUD, o->c.M2obc_in[E.e], o->c.M2obc_out[E.e], dt2d, bv, 0);
+        double oin = o->c.M2obc_in[E.e], oout = o->c.M2obc_out[E.e];
+        if (kind == ORC_LBC_RADNUD && (o->clima_flags & 32)) {     /* LnudgeM2CLM: u2dbc_im.F:158-162 ..., v2dbc_im.F (as u3dbc / v3dbc) */
+          oout = 0.5 * (o->M2nudgcof[X2(i - (isU ? 1 : 0), j - (isU ? 0 : 1))] + o->M2nudgcof[X2(i, j)]);
+          oin = o->c.obcfac * oout;
+        }
+        val = rad_point(o, &E, Qn, Qo, i, j, NULL, kind == ORC_LBC_RADNUD, oin, oout, dt2d, bv, 0);
       } else if (kind == ORC_LBC_CLA) {
         val = bv;
       } else if (kind == ORC_LBC_GRA) {
@@ -446,8 +451,24 @@ static void bc3d(const orc_t *o, const orc_bounds *b, int nout, char grid, int i
       for (int s = E.s0; s <= E.s1; s++) {
         const int i = EI(&E, s), j = EJ(&E, s);
         double val;
-        if (kind == ORC_LBC_RAD || kind == ORC_LBC_RADNUD)
-          val = rad_point(o, &E, Qn, Qo, i, j, fm, kind == ORC_LBC_RADNUD, obc_in, obc_out, dt, bry[s - lb], 0);
+        if (kind == ORC_LBC_RAD || kind == ORC_LBC_RADNUD) {
+          double oin = obc_in, oout = obc_out;
+          if (kind == ORC_LBC_RADNUD) {
+            /* climatology nudging: the time scales of the condition from the nudging coefficient arrays (round 6) --
+               u3dbc_im.F:113-118, :255-260, :397-402, :555-560 (the mean of the two rho points either side of the u point: across
+               the edge at the western / eastern boundary, along it on the boundary row at the southern / northern one),
+               v3dbc_im.F likewise, t3dbc_im.F:120-122 ... (the boundary point itself); obc_in = obcfac * obc_out */
+            if (grid != 'r' && (o->clima_flags & 1)) {
+              const double *cf = o->M3nudgcof + (size_t)(k - 1) * nij;
+              oout = 0.5 * (cf[X2(i - (grid == 'u'), j - (grid == 'v'))] + cf[X2(i, j)]);
+              oin = o->c.obcfac * oout;
+            } else if (grid == 'r' && (o->clima_flags & (1 << itrc))) {
+              oout = o->Tnudgcof[X2(i, j) + ((size_t)(itrc - 1) * N + (size_t)(k - 1)) * nij];
+              oin = o->c.obcfac * oout;
+            }
+          }
+          val = rad_point(o, &E, Qn, Qo, i, j, fm, kind == ORC_LBC_RADNUD, oin, oout, dt, bry[s - lb], 0);
+        }
         else if (kind == ORC_LBC_CLA) val = bry[s - lb];
         else val = Qo[X2(i + E.di, j + E.dj)];                  /* gradient; tracers: closed too (t3dbc_im.F:205-218) */
         if (msk) val = val * qmask[X2(i, j)];

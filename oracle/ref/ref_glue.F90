@@ -211,6 +211,7 @@
         M2obc_out(ng,ibry)=rpar(38+(ibry-1))
         M3obc_in (ng,ibry)=rpar(42+(ibry-1))
         M3obc_out(ng,ibry)=rpar(46+(ibry-1))
+        obcfac(ng)=rpar(85)           ! OBCFAC itself: the conditions read it where climatology nudging gives them their time scales (u3dbc_im.F:117)
         DO itrc=1,NT(ng)
           Tobc_in (itrc,ng,ibry)=rpar(50+8*(MIN(itrc,2)-1)+(ibry-1))
           Tobc_out(itrc,ng,ibry)=rpar(54+8*(MIN(itrc,2)-1)+(ibry-1))
@@ -1019,7 +1020,7 @@
       USE u3dbc_mod, ONLY : u3dbc_tile
       USE v3dbc_mod, ONLY : v3dbc_tile
       integer(c_int), value :: nout
-      integer :: tile, LBi, UBi, LBj, UBj, itrc
+      integer :: tile, LBi, UBi, LBj, UBj, itrc, ic
       integer :: IminS, ImaxS, JminS, JmaxS
       DO tile=first_tile(ng),last_tile(ng)
         LBi=BOUNDS(ng)%LBi(tile)
@@ -1030,8 +1031,10 @@
         ImaxS=BOUNDS(ng)%Iend(tile)+3
         JminS=BOUNDS(ng)%Jstr(tile)-3
         JmaxS=BOUNDS(ng)%Jend(tile)+3
+        ic=0                          ! (the compact index of the nudged tracers, as step3d_t.F:1845-1854 counts it)
         DO itrc=1,NT(ng)
-          CALL t3dbc_tile (ng, tile, itrc, 0, LBi, UBi, LBj, UBj,       &
+          IF (LtracerCLM(itrc,ng).and.LnudgeTCLM(itrc,ng)) ic=ic+1
+          CALL t3dbc_tile (ng, tile, itrc, ic, LBi, UBi, LBj, UBj,      &
      &                     N(ng), NT(ng), IminS, ImaxS, JminS, JmaxS,   &
      &                     nstp(ng), nout, OCEAN(ng)%t)
         END DO

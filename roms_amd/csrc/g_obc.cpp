@@ -8,6 +8,7 @@ static void obc_item(roms_hip_ctx *c, ObcItem &it, double *Qo, const double *Qn,
                      const double *in, const double *out, long level0) {
   const roms_hip_config &cf = c->cfg;
   it.Qo = Qo; it.Qn = Qn; it.nk = nk; it.grid = grid; it.is2d = is2d;
+  it.cof = nullptr; it.obcfac = cf.obcfac;
   // Fields::bry order: west, east, south, north; edges here: ROMS_IWEST, ROMS_ISOUTH, ROMS_IEAST, ROMS_INORTH
   static const int slot[4] = {0, 2, 1, 3};
   for (int e = 0; e < 4; e++) {
@@ -21,7 +22,7 @@ static void obc_item(roms_hip_ctx *c, ObcItem &it, double *Qo, const double *Qn,
 
 static void obc_common(roms_hip_ctx *c, ObcArgs &a) {
   a.G = c->G;
-  for (int q = 0; q < OBC_MAXITEMS; q++) { a.it[q].Qo = nullptr; a.it[q].Qn = nullptr; a.it[q].nk = 0; a.it[q].grid = 'r'; }
+  for (int q = 0; q < OBC_MAXITEMS; q++) { a.it[q].Qo = nullptr; a.it[q].Qn = nullptr; a.it[q].nk = 0; a.it[q].grid = 'r'; a.it[q].cof = nullptr; a.it[q].obcfac = 0.0; }
   a.h = c->F.h; a.pm = c->F.pm; a.pn = c->F.pn;
   static const int slot[4] = {0, 2, 1, 3};
   for (int e = 0; e < 4; e++) a.zbry[e] = c->F.bry[slot[e]];
@@ -44,8 +45,10 @@ int run_obc2d(roms_hip_ctx *c, int kout, unsigned vars) {
   a.zeta_o = lev2d(c, c->F.zeta, kout);
   int n = 0;
   if (vars & 1) obc_item(c, a.it[n++], lev2d(c, c->F.zeta, kout), lev2d(c, c->F.zeta, know), 1, 'r', 1, ROMS_ISFSUR, 0, cf.FSobc_in, cf.FSobc_out, 0);
-  if (vars & 2) obc_item(c, a.it[n++], lev2d(c, c->F.ubar, kout), lev2d(c, c->F.ubar, know), 1, 'u', 1, ROMS_ISUBAR, 1, cf.M2obc_in, cf.M2obc_out, 0);
-  if (vars & 4) obc_item(c, a.it[n++], lev2d(c, c->F.vbar, kout), lev2d(c, c->F.vbar, know), 1, 'v', 1, ROMS_ISVBAR, 2, cf.M2obc_in, cf.M2obc_out, 0);
+  if (vars & 2) { obc_item(c, a.it[n], lev2d(c, c->F.ubar, kout), lev2d(c, c->F.ubar, know), 1, 'u', 1, ROMS_ISUBAR, 1, cf.M2obc_in, cf.M2obc_out, 0);
+                  if (G.clima & 32) a.it[n].cof = c->F.M2nudgcof; n++; }       // LnudgeM2CLM: u2dbc_im.F:158
+  if (vars & 4) { obc_item(c, a.it[n], lev2d(c, c->F.vbar, kout), lev2d(c, c->F.vbar, know), 1, 'v', 1, ROMS_ISVBAR, 2, cf.M2obc_in, cf.M2obc_out, 0);
+                  if (G.clima & 32) a.it[n].cof = c->F.M2nudgcof; n++; }
   a.nitems = n;
   LAUNCH_COOP(k_obc, 1, 1, n, 256, 0, c->stream, a);
   return 0;
@@ -60,6 +63,7 @@ int run_obc3d_uv(roms_hip_ctx *c, int nout) {
   a.dtn = G.dt;
   obc_item(c, a.it[0], uv_lev(c, c->F.u, nout), uv_lev(c, c->F.u, G.nstp), G.N, 'u', 0, ROMS_ISUVEL, 3, cf.M3obc_in, cf.M3obc_out, 0);
   obc_item(c, a.it[1], uv_lev(c, c->F.v, nout), uv_lev(c, c->F.v, G.nstp), G.N, 'v', 0, ROMS_ISVVEL, 4, cf.M3obc_in, cf.M3obc_out, 0);
+  if (G.clima & 1) a.it[0].cof = a.it[1].cof = c->F.M3nudgcof;                 // LnudgeM3CLM: u3dbc_im.F:113, v3dbc_im.F:113
   a.nitems = 2;
   LAUNCH_COOP(k_obc, 1, 1, 2 * G.N, 256, 0, c->stream, a);
   return 0;
@@ -74,6 +78,7 @@ int run_obc3d_t(roms_hip_ctx *c, int nout, int itrc) {
   a.dtn = G.dt;
   obc_item(c, a.it[0], t_lev(c, nout, itrc), t_lev(c, G.nstp, itrc), G.N, 'r', 0, ROMS_ISTVAR + itrc - 1, 5, cf.Tobc_in[itrc - 1], cf.Tobc_out[itrc - 1],
            (long)(itrc - 1) * G.N);
+  if (G.clima & (1 << itrc)) a.it[0].cof = (const double *)c->F.Tnudgcof + (size_t)(itrc - 1) * (size_t)G.N * (size_t)G.nij;      // LnudgeTCLM: t3dbc_im.F:120
   a.nitems = 1;
   LAUNCH_COOP(k_obc, 1, 1, G.N, 256, 0, c->stream, a);
   return 0;

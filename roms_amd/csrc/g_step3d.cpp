@@ -183,10 +183,12 @@ int run_step3d_t(roms_hip_ctx *c) {
   if (G.obc) for (int it = 1; it <= G.NT; it++) { int r = run_obc3d_t(c, nnew, it); if (r) return r; }
   if (G.clima & ~1) {
     // nudging towards the tracer climatology :1866-1878 sits between t3dbc and the land/sea mask + exchange: the boundary
-    // values first (closed walls; no open boundaries with this option), the nudging on the whole (IstrR:IendR, JstrR:JendR)
-    // range, then the mask of the whole plane and the exchange
-    for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, bc_rstate(c, false), 'r'};
-    launch_halo_multi(c, sp, G.NT);
+    // values first (closed walls here; open edges: run_obc3d_t above has set them), the nudging on the whole (IstrR:IendR,
+    // JstrR:JendR) range, then the mask of the whole plane and the exchange
+    if (!G.obc) {
+      for (int it = 1; it <= G.NT; it++) sp[it - 1] = {t_lev(c, nnew, it), N, bc_rstate(c, false), 'r'};
+      launch_halo_multi(c, sp, G.NT);
+    }
     KArgs an;
     an.G = G; an.Fv = c->F; an.p0 = an.p1 = an.p2 = 0;
     LAUNCH_THREAD(k_tnudge, B.IendR - B.IstrR + 1, B.JendR - B.JstrR + 1, N * G.NT, c->stream, an);

@@ -35,6 +35,12 @@ struct ObcItem {
   double obc_in[4], obc_out[4];
   const double *bry[4];  // boundary data of plane 0 per edge
   long bstride[4];       // doubles from one plane's line to the next
+  // climatology nudging (round 6): the radiation + nudging conditions take their time scales from the nudging coefficient array of the
+  // variable -- plane 0 of "M2nudgcof" | "M3nudgcof" | "Tnudgcof"(itrc), rho points -- instead of obc_in / obc_out: the boundary point's
+  // own value for a tracer (t3dbc_im.F:120-122), the mean of the two rho points either side of a velocity point (u3dbc_im.F:113-118,
+  // u2dbc_im.F:158-162 ...), inflow = obcfac x that.  Null: the scales above
+  const double *cof;
+  double obcfac;
 };
 #define OBC_MAXITEMS 3
 struct ObcArgs {
@@ -144,7 +150,13 @@ KDEV void obc_edge_fill(const ObcArgs &a, const ObcItem &it, const ObcEdge &E, d
     const double bv = bry ? bry[s - lb] : 0.0;
     double val;
     if (rad) {
-      val = obc_radiate(G, E, Qn, Qo, i, j, fm, kind == ROMS_LBC_RADNUD, it.obc_in[E.e], it.obc_out[E.e], dtn, bv,
+      double oin = it.obc_in[E.e], oout = it.obc_out[E.e];
+      if (kind == ROMS_LBC_RADNUD && it.cof) {
+        const double *cf = it.cof + (size_t)plane * (size_t)G.nij;
+        oout = grid == 'r' ? cf[X2(i, j)] : 0.5 * (cf[X2(i - (grid == 'u' ? 1 : 0), j - (grid == 'v' ? 1 : 0))] + cf[X2(i, j)]);
+        oin = it.obcfac * oout;
+      }
+      val = obc_radiate(G, E, Qn, Qo, i, j, fm, kind == ROMS_LBC_RADNUD, oin, oout, dtn, bv,
                         it.is2d && grid == 'r' && E.e == ROMS_ISOUTH);
     } else if (kind == ROMS_LBC_CLA) {
       val = bv;

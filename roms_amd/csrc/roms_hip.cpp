@@ -635,7 +635,8 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     if (r) { roms_hip_destroy(c); return r; }
   }
   if (cfg->options & (ROMS_NUDGE_M3CLM | ROMS_NUDGE_TCLM_ALL | ROMS_NUDGE_M2CLM)) {       // climatology nudging: rhs3d.F:654-680, step3d_t.F:1866-1878, step2d_LF_AM3.h:2179
-    if (c->G.obc) { set_error("climatology nudging with open boundaries: the nudging coefficients of the radiation conditions (t3dbc_im.F:120, u3dbc_im.F:113) are not built"); roms_hip_destroy(c); return 5; }
+    // (open boundaries, round 6: the radiation + nudging conditions read the coefficient arrays, k_obc.h: ObcItem::cof; OBCFAC in the
+    // configuration since ABI version 5)
     if (cfg->options & ROMS_DIAGNOSTICS_UV) { set_error("climatology nudging with DIAGNOSTICS_UV: not built"); roms_hip_destroy(c); return 5; }
     // (the rule of this library: an option set without a reference-written fixture or a pinned oracle run is refused)
     // (round 6: nudging of the 3-D momentum and the tracers together with WET_DRY, TS_DIF4 / UV_VIS4 and MIX_GEO_UV is pinned --

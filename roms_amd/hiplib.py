@@ -16,7 +16,7 @@ OPTIONS.update(RADIATION_2D=1 << 16, PLAIN_VDIFF=1 << 17, PLAIN_VVISC=1 << 18, P
                # the upper word (ABI version 4)
                UV_VIS4=1 << 32, TS_DIF4=1 << 33, WET_DRY=1 << 34, DIAGNOSTICS_UV=1 << 35, MIX_GEO_UV=1 << 36, NUDGE_M3CLM=1 << 37, NUDGE_M2CLM=1 << 42, PRSGRD42=1 << 43, PRSGRD44=1 << 44, LMD_DDMIX=1 << 45,
                NUDGE_TCLM1=1 << 38, NUDGE_TCLM2=1 << 39, NUDGE_TCLM3=1 << 40, NUDGE_TCLM4=1 << 41)
-ABI_VERSION = 4
+ABI_VERSION = 5
 # the compile-time forms of GLS_MIXING (roms_hip_config.gls_flags)
 GLS_FLAGS = dict(CANUTO_A=1, CANUTO_B=2, KANTHA_CLAYSON=4, N2S2_HORAVG=8, RI_SPLINES=16, K_C2ADVECTION=32, K_C4ADVECTION=64,
                  CHARNOK=128, CRAIG_BANNER=256)
@@ -58,7 +58,7 @@ class Config(C.Structure):
         ("gls_c3m", C.c_double), ("gls_c3p", C.c_double), ("gls_sigk", C.c_double), ("gls_sigp", C.c_double),
         ("Akk_bak", C.c_double), ("Akp_bak", C.c_double), ("Zos", C.c_double), ("charnok_alpha", C.c_double),
         ("crgban_cw", C.c_double), ("lbc_tke", C.c_int * 4),
-        ("Dcrit", C.c_double),
+        ("Dcrit", C.c_double), ("obcfac", C.c_double),
     ]
 
 

@@ -72,6 +72,7 @@
         integer(c_int) :: lbc_tke(4)
 !  WET_DRY (ABI version 4): DCRIT of roms.in
         real(c_double) :: Dcrit
+        real(c_double) :: obcfac
       END TYPE roms_hip_config
 
       TYPE, bind(C) :: roms_hip_stepping

@@ -2057,7 +2057,8 @@
       tUBi=MERGE(UBi, tIend+Nghost, te)
       tLBj=MERGE(LBj, tJstr-1-Nghost, ts)
       tUBj=MERGE(UBj, tJend+Nghost, tn)
-      cfg%abi_version=4
+      cfg%abi_version=5
+      cfg%obcfac=obcfac
       cfg%device=device
       cfg%Lm=Lm; cfg%Mm=Mm; cfg%N=N; cfg%NT=NT; cfg%NAT=NAT; cfg%Nghost=Nghost
       cfg%LBi=tLBi; cfg%UBi=tUBi; cfg%LBj=tLBj; cfg%UBj=tUBj

@@ -39,6 +39,7 @@ def ref_params(cs):
             rpar[49 + 8 * it + e] = sc["Tobc_in"][it][e]
             rpar[53 + 8 * it + e] = sc["Tobc_out"][it][e]
     rpar[83] = cs.get("Dcrit", 0.0)     # ref_glue.F90: rpar(84), DCRIT (WET_DRY builds)
+    rpar[84] = cs.get("obcfac", 0.0)    # ref_glue.F90: rpar(85), OBCFAC (round 6: the radiation conditions under climatology nudging)
     if "gls_flags" in cs:               # ref_glue.F90: rpar(66..83)
         for k, n in enumerate(GLS_NAMES + ("Akk_bak", "Akp_bak", "charnok_alpha", "zos_hsig_alpha", "sz_alpha", "crgban_cw")):
             rpar[65 + k] = cs[n]
@@ -70,6 +71,7 @@ def oracle_cfg(cs, hc, nfast, weight):
     for k in range(w.shape[1]):
         c.weight[0][k + 1] = w[0, k]
         c.weight[1][k + 1] = w[1, k]
+    c.obcfac = cs.get("obcfac", 0.0)
     c.rho0, c.g, c.lambda_, c.gamma2, c.Cp = cs["rho0"], 9.81, 1.0, cs["gamma2"], 3985.0
     c.R0, c.T0, c.S0, c.Tcoef, c.Scoef = cs["R0"], cs["T0"], cs["S0"], cs["Tcoef"], cs["Scoef"]
     c.hc, c.Vtransform = hc, cs["Vtransform"]

@@ -42,6 +42,8 @@ def mode_main3d(tag, kw):
     """ref_main3d (reference kernels in main3d.F order) against orc_main3d_step."""
     nsteps = kw.pop("nsteps", 10)
     tol = kw.pop("tol", 0.0)
+    if "preset" in kw:                       # the kinds of an obc-mode preset on the edges of a whole run
+        kw["lbc"] = OBC_PRESETS[kw.pop("preset")]
     app, cs = rd.make_case(tag, **kw)
     saved = rd.quiet()
     R = rd.reference(app, cs)

@@ -22,7 +22,7 @@ def test_header_symbols_exported():
     assert len(syms) >= 35
     for s in syms:
         assert hasattr(L, s), s
-    assert L.roms_hip_abi_version() == 4
+    assert L.roms_hip_abi_version() == 5
     assert sorted(hiplib.EXPORTS) == syms
 
 

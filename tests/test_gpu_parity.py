@@ -1153,18 +1153,23 @@ def test_generic_length_scale_closure_with_open_boundaries_matches_oracle(lbc_tk
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["kelvin", "plain", "mixed", "four"])
+@pytest.mark.parametrize("variant", ["kelvin", "plain", "mixed", "mixed_clima", "four"])
 def test_open_boundaries_match_oracle(variant):
     """Open boundaries on the GPU (k_obc.h): the reference's KELVIN application -- Chapman / Flather west, radiation east,
     RADIATION_2D, analytic boundary data computed on the device -- and the other kinds (Chapman explicit, Shchepetkin,
     radiation with nudging, clamped, gradient; all four edges open) with uploaded boundary data, 40 steps against the
     oracle (pinned bit for bit to zetabc.F ... t3dbc_im.F and to whole KELVIN runs of the reference) at the north-star
-    tolerance; the wave has entered the domain."""
+    tolerance; the wave has entered the domain.  mixed_clima: the same edges with the nudging towards climatology on (the
+    radiation + nudging conditions read their time scales from the coefficient arrays, obc_in = obcfac x obc_out)."""
     from roms_amd import hiplib
     from tests.test_kernels_emu import OBC_VARIANTS
-    kw = {} if OBC_VARIANTS[variant] is None else dict(lbc=OBC_VARIANTS[variant])
+    lbc = OBC_VARIANTS[variant]
+    lbc = OBC_VARIANTS[lbc] if isinstance(lbc, str) else lbc
+    kw = {} if lbc is None else dict(lbc=lbc)
     cs = util.case_for("kelvin_plain_small" if variant == "plain" else "kelvin_small", **kw)
-    if variant == "mixed":
+    if variant == "mixed_clima":
+        cs["clima"] = 39
+    if variant.startswith("mixed"):
         cs.update(Znudg=0.5, M2nudg=0.25, M3nudg=2.0, Tnudg=(1.0, 3.0), obcfac=4.0)
     g = util.load_init("kelvin_small", util.nghost_for(cs))
     O = util.make_oracle(cs, g)

@@ -453,6 +453,9 @@ OBC_VARIANTS = {
     "mixed": dict(zeta=("Che", "Clo", "RadNud", "Clo"), ubar=("Shc", "Clo", "RadNud", "Clo"), vbar=("Shc", "Clo", "Gra", "Clo"),
                   u=("RadNud", "Clo", "Gra", "Clo"), v=("Gra", "Clo", "RadNud", "Clo"), temp=("RadNud", "Clo", "Cla", "Clo"),
                   salt=("Cla", "Clo", "Gra", "Clo")),
+    # ... and with nudging towards climatology on: the radiation + nudging edges take their time scales from the coefficient arrays
+    # (u3dbc_im.F:160-171, t3dbc_im.F:157-167, u2dbc_im.F:171-183: obc_out the coefficient at the point, obc_in = obcfac * obc_out)
+    "mixed_clima": "mixed",
     # all four edges open
     "four": dict(zeta=("Cha", "Rad", "Rad", "Che"), ubar=("Fla", "Rad", "Rad", "Shc"), vbar=("Fla", "Rad", "Rad", "Shc"),
                  u=("Rad", "Rad", "Rad", "Gra"), v=("Rad", "Rad", "Rad", "Gra"), temp=("Rad", "Gra", "Rad", "Rad"),
@@ -466,9 +469,13 @@ def test_open_boundaries_bitwise(emu, variant):
     clamped, gradient conditions; the oracle is pinned to the reference routines and to whole runs of the reference's
     KELVIN application): the Kelvin wave entering through the western boundary, 12 steps against the oracle, bit for bit;
     the boundary really is open (the wave arrives: |u| grows from rest)."""
-    kw = {} if OBC_VARIANTS[variant] is None else dict(lbc=OBC_VARIANTS[variant])
+    lbc = OBC_VARIANTS[variant]
+    lbc = OBC_VARIANTS[lbc] if isinstance(lbc, str) else lbc
+    kw = {} if lbc is None else dict(lbc=lbc)
     cs = util.case_for("kelvin_plain_small" if variant == "plain" else "kelvin_small", **kw)
-    if variant == "mixed":
+    if variant == "mixed_clima":
+        cs["clima"] = 39
+    if variant.startswith("mixed"):
         cs.update(Znudg=0.5, M2nudg=0.25, M3nudg=2.0, Tnudg=(1.0, 3.0), obcfac=4.0)
     g = util.load_init("kelvin_small", util.nghost_for(cs))
     O = util.make_oracle(cs, g)

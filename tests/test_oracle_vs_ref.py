@@ -232,6 +232,10 @@ MAIN3D_CASES = [
     ("kelvin_plain_small", ["nsteps=60"]),
     ("kelvin_plain_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     ("kelvin_plain", ["nsteps=96"]),
+    # climatology nudging beside open boundaries (round 6): radiation + nudging edges (tests/refchild.py OBC_PRESETS) with
+    # LnudgeM2CLM + LnudgeM3CLM + LnudgeTCLM on -- the conditions' time scales come from the coefficient arrays and obcfac
+    ("kelvin_plain_small", ["nsteps=20", "preset=F", "clima=39"]),
+    ("kelvin_plain_small", ["nsteps=20", "preset=C", "clima=39", "NtileI=2", "NtileJ=2"]),
     # two more of the reference's test applications: SEAMOUNT (no-slip walls, Akima advection, geopotential mixing without
     # KPP, quadratic drag, no closure) and GRAV_ADJ (lock exchange: MPDATA in a closed channel periodic across, no rotation)
     ("seamount_small", ["nsteps=60"]),
@@ -414,10 +418,12 @@ def test_core_kernels_bitwise(tag, args):
 
 OBC_CASES = [(t, p, a) for t in ("kelvin_plain_small", "upwelling_obc_small", "upwelling_mask_obc_small") for p in "ABCDEFG" for a in ([],)] + \
             [("kelvin_plain_small", p, ["NtileI=2", "NtileJ=2"]) for p in "FG"] + \
-            [("upwelling_wetdry_obc_small", p, a) for p in "ABEFG" for a in ([],)] + [("upwelling_wetdry_obc_small", "F", ["NtileI=2", "NtileJ=2"])]
+            [("upwelling_wetdry_obc_small", p, a) for p in "ABEFG" for a in ([],)] + [("upwelling_wetdry_obc_small", "F", ["NtileI=2", "NtileJ=2"])] + \
+            [(t, p, ["clima=39"]) for t in ("kelvin_plain_small", "upwelling_obc_small", "upwelling_mask_obc_small") for p in "CDFG"] + \
+            [("kelvin_plain_small", "F", ["clima=39", "NtileI=2", "NtileJ=2"])]     # the radiation + nudging presets with the nudging switches on: per-point time scales
 
 
-@pytest.mark.parametrize("tag,preset,args", OBC_CASES, ids=[f"{t}:{p}" + ("+tiles" if a else "") for t, p, a in OBC_CASES])
+@pytest.mark.parametrize("tag,preset,args", OBC_CASES, ids=[f"{t}:{p}" + ("+clima" if "clima=39" in a else "") + ("+tiles" if "NtileI=2" in a else "") for t, p, a in OBC_CASES])
 def test_open_boundary_routines_bitwise(tag, preset, args):
     """zetabc_tile, u2dbc_tile, v2dbc_tile, u3dbc_tile, v3dbc_tile, t3dbc_tile of the reference against the oracle's
     (oracle/orc_obc.c) on a random state with random boundary data: radiation with and without nudging, Chapman explicit
@@ -425,7 +431,8 @@ def test_open_boundary_routines_bitwise(tag, preset, args):
     OBC_PRESETS), for the four stepping variants that select `know` and `dt2d` and the three 3-D time-level pairs; with
     RADIATION_2D (the reference's kelvin.h), without it (UPWELLING's library on a closed-basin grid), under MASKING, and
     on 2x2 tiles.  Includes the reference's southern free-surface radiation branch, which differences towards the boundary
-    row (zetabc.F:455,486-487)."""
+    row (zetabc.F:455,486-487).  With LnudgeM2CLM / LnudgeM3CLM / LnudgeTCLM on (clima=39) the radiation + nudging edges take
+    their time scales from the nudging coefficient arrays and obcfac (u2dbc_im.F:158-183, u3dbc_im.F:113-171, t3dbc_im.F:120-167)."""
     out = _child("obc", tag, "preset=" + preset, *args)
     assert "OBC-OK bitwise" in out, out[-1500:]
 
