@@ -613,7 +613,7 @@ int run_step2d_loop(roms_hip_ctx *c) { return run_step2d_loop_n(c, c->G.iif == 1
 
 // ---- self-check of the rim planes (round 6): before a multi-tile run trusts the rim hand-off inside its barotropic launches
 // (k_step2d_loop.h, k_step2d_pair.h: rim_in / rim_out), every rank publishes index-coded values of its own points into the
-// neighbours' rim planes -- every direction, corners included, all six planes, `reps` repetitions with the parities alternating
+// neighbours' rim planes -- every direction, corners included, all twelve planes over four repetitions, the sets taking turns
 // -- and verifies on the device that every ghost point of its own tile receives the code of the point it images: the address of
 // a point in a neighbour's planes (array origin, the shift across a periodic seam), the mapping of the slabs and the visibility
 // of tagged 8-byte words across devices, in the geometry of THIS run.  The tags live above 0xC0000000: the pairs of a run
@@ -639,7 +639,7 @@ static __global__ void k_rim_publish(const RimProbeArgs a, int nx, int ny) {
   const DGrid &G = a.G;
   const int i = G.T.Istr + gx, j = G.T.Jstr + gy;
   for (int f = 0; f < 3; f++) {
-    const int pf = 3 * (a.rep & 1) + f;
+    const int pf = 3 * (a.rep & 3) + f;
     if (pf == a.skip) continue;
     s2l_rput(G, a.P, pf, i, j, rim_code(G, i, j, pf, a.rep), 0xC0000000u + (unsigned)a.rep);
   }
@@ -660,7 +660,7 @@ static __global__ void k_rim_verify(const RimProbeArgs a, int nx, int ny) {
   const size_t x = X2(i, j);
   if (ksys_ld((const kword_t *)a.bad)) return;           // (already failed: no more waiting)
   for (int f = 0; f < 3; f++) {
-    const int pf = 3 * (a.rep & 1) + f;
+    const int pf = 3 * (a.rep & 3) + f;
     const kword_t *q = a.P.rim + 2 * ((size_t)pf * (size_t)G.nij + x);
     const long long t0 = kclock();
     kword_t w0 = 0, w1 = 0;

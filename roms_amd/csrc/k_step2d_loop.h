@@ -38,7 +38,7 @@
 //
 // Multi-tile contexts (round 6, template parameter MT; mp_exchange2d of step2d_LF_AM3.h:714,842,1068,3041 inside the launch):
 // the rim of an edge block reaches into the NEIGHBOURING RANK's tile.  Every rank keeps, in its mailbox slab (uncached
-// memory the neighbours map over hipIpc / xGMI, roms_hip.cpp), two parities x {zeta, ubar, vbar} RIM PLANES indexed like its
+// memory the neighbours map over hipIpc / xGMI, roms_hip.cpp), four sets x {zeta, ubar, vbar} of RIM PLANES indexed like its
 // own arrays, 16 bytes per point: two 8-byte words {low half of the value | pair number}, {high half | pair number}.  An
 // 8-byte store is atomic on every path (HBM, xGMI), so a value can be polled for directly -- no arrival word, no drain
 // between data and flag (the protocol RCCL calls LL).  Per pair
@@ -49,8 +49,11 @@
 //   consumer   every thread whose rectangle point is a ghost point of the tile polls ITS point in the rim planes until both
 //              words of all three fields carry this pair's number (bounded like the other waits), beside the wave that
 //              polls the arrival words of the tile's own blocks
-// Two parities suffice for the same reason two staging levels do: the reading relation is symmetric across the tile edge
-// too.  Between two launches the 3-D exchanges of the baroclinic step order the ranks (a rank cannot start the next launch
+// FOUR sets of rim planes take turns (pair & 3).  Inside a tile two staging levels suffice because the reading relation between
+// blocks is symmetric; across a tile edge it is not quite (a block two sub-tile rows from the edge reads the neighbour's last
+// line, and the neighbour's edge block waits for nothing of its), so the set a block overwrites is the one of four pairs ago: the
+// publisher of pair n+4 has consumed n+3 of the neighbour's edge blocks, those n+2 of every block beside them -- which therefore
+// is through with pair n+1, the one that read n (k_step2d_pair.h: Step2dPairArgs has the same argument for launches).  Between two launches the 3-D exchanges of the baroclinic step order the ranks (a rank cannot start the next launch
 // before every neighbour has left this one).  Tiles of equal size on every rank, at least one periodic direction.  What
 // the pair launches exchange between the pairs is exchanged ONCE behind the launch (g_step2d.cpp).  Measured (one MI355X,
 // the tile its own W/E neighbour through the mailbox): an arrival-word form -- stores, drain, word in the neighbour's
@@ -527,7 +530,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
         gzetaSA[s0] = zw * (rhoSv - sRhoA[s0]);
         if (own) {
           hb_emit2<true>(G, B, zout, BC_R, i, j, zeta_new, Mr, img0);
-          if (MT && edgeblk && a.P.early) s2l_remit(G, a.P, B, 3 * (p & 1), BC_R, i, j, zeta_new, a.epoch + (unsigned)(p + 1), Mr);
+          if (MT && edgeblk && a.P.early) s2l_remit(G, a.P, B, 3 * (p & 3), BC_R, i, j, zeta_new, a.epoch + (unsigned)(p + 1), Mr);
           ZQ[s0] = zeta_new;
         }
       }
@@ -559,7 +562,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
           if (MK) b = b * (isv ? sVm : sUm)[s];
           if (!isv) { hb_emit2<true>(G, B, uout, BC_U, mi, mj, b, Mu, img0); UQ[s] = b; }
           else { hb_emit2<true>(G, B, vout, BC_V, mi, mj, b, Mv, img0); VQ[s] = b; }
-          if (MT && edgeblk && a.P.early) s2l_remit(G, a.P, B, 3 * (p & 1) + 1 + isv, isv ? BC_V : BC_U, mi, mj, b, a.epoch + (unsigned)(p + 1), isv ? Mv : Mu);
+          if (MT && edgeblk && a.P.early) s2l_remit(G, a.P, B, 3 * (p & 3) + 1 + isv, isv ? BC_V : BC_U, mi, mj, b, a.epoch + (unsigned)(p + 1), isv ? Mv : Mu);
         }
       }
     }
@@ -572,8 +575,8 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
     if (MT && edgeblk && !a.P.early) {
       // the neighbouring ranks' ghost points, tagged with the pair (the values are in the Q tiles: the own points' threads stored them)
       const unsigned tag = a.epoch + (unsigned)(p + 1);
-      if (own) s2l_remit(G, a.P, B, 3 * (p & 1), BC_R, i, j, ZQ[s0_], tag, Mr);
-      if (mO) s2l_remit(G, a.P, B, 3 * (p & 1) + 1 + isvt, isvt ? BC_V : BC_U, mi, mj, (isvt ? VQ : UQ)[ms_], tag, isvt ? Mv : Mu);
+      if (own) s2l_remit(G, a.P, B, 3 * (p & 3), BC_R, i, j, ZQ[s0_], tag, Mr);
+      if (mO) s2l_remit(G, a.P, B, 3 * (p & 3) + 1 + isvt, isvt ? BC_V : BC_U, mi, mj, (isvt ? VQ : UQ)[ms_], tag, isvt ? Mv : Mu);
     }
     if (t < 64) {
       if (nbf >= 0 && !dead) {
@@ -607,7 +610,7 @@ static __device__ __forceinline__ void k_step2d_loop_body(const Step2dLoopArgs &
       // my ghost point: until all six words carry this pair's number (two 16-byte loads per field would do as well: each
       // 8-byte word is checked by itself)
       const unsigned tag = a.epoch + (unsigned)(p + 1);
-      const unsigned long long *rq = a.P.rim + 2 * ((size_t)(3 * (p & 1)) * (size_t)G.nij + (size_t)x0);
+      const unsigned long long *rq = a.P.rim + 2 * ((size_t)(3 * (p & 3)) * (size_t)G.nij + (size_t)x0);
       const long long t0 = wall_clock64();
       for (;;) {
         unsigned long long w[6];

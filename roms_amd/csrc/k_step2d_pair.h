@@ -29,14 +29,14 @@
 
 // ---- the rim across TILE edges inside a launch (round 6): k_step2d_loop.h (the persistent loop) and, for tiles the loop does not
 // fit, the pair kernel below.  A rank's rim planes live in its mailbox slab (uncached memory the neighbours map over hipIpc /
-// xGMI): two parities x {zeta, ubar, vbar}, indexed like its arrays, 16 bytes per point -- {low half of the value | number of
+// xGMI): four sets x {zeta, ubar, vbar}, indexed like its arrays, 16 bytes per point -- {low half of the value | number of
 // the pair}, {high half | number} -- an 8-byte store is atomic on every path, so a point is polled for directly.
 // multi-tile contexts: my rim planes and the neighbours' as mapped here
 struct S2LPeer {
   int on;                       // 0: single tile (the kernels without MT never read this struct)
   int early;                    // 1: a value goes to the neighbours where it is computed, in front of the local drain (ROMS_HIP_LOOP_EARLY)
   int nbmask;                   // bit d: neighbour d (W, E, S, N, SW, SE, NW, NE) exists
-  kword_t *rim;      // my rim planes [parity][zeta | ubar | vbar][nij][2 words]: the neighbours' edge blocks write my ghost points
+  kword_t *rim;      // my rim planes [set][zeta | ubar | vbar][nij][2 words]: the neighbours' edge blocks write my ghost points
   kword_t *nrim[8];  // neighbour d's rim planes, as mapped in this process
   int noff[8], nni[8], nnij[8]; // my point (i,j) in neighbour d's planes: i + j * nni + noff (array origin + the shift across a periodic seam)
 };
@@ -112,11 +112,18 @@ struct Step2dPairArgs {
                        // the committed level and of the staged result by the last one, of rzeta(krhs) by the last two
   // ---- multi-tile contexts whose tiles are too large for the persistent loop (round 6, g_step2d.cpp:pair_rim_usable): the
   // corrector's result crosses the tile edges INSIDE the launches instead of through an exchange behind every pair
-  int rim_in;          // the krhs level on the ghost points of the tile: from my rim planes (parity lev_in - 4), polled until the
+  int rim_in;          // the krhs level on the ghost points of the tile: from my rim planes (set tag_in & 3), polled until the
                        // points carry tag_in -- the neighbours' previous pair launch published them
   int rim_out;         // publish the corrector's result -- the own points in the neighbours' ghost zones and the boundary values a
-                       // closed domain edge derives from them -- into their rim planes (parity lev_out - 4), tagged tag_out; the
+                       // closed domain edge derives from them -- into their rim planes (set tag_out & 3), tagged tag_out; the
                        // boundary values go to the staging level as well (no fill launch follows)
+  // FOUR sets of planes, not two.  The reading relation between blocks is not symmetric across a tile edge (a block two sub-tile
+  // rows from the edge reads the neighbour's last line without publishing anything the neighbour's edge block waits for), and the
+  // blocks of a launch are not all resident: with two sets a late block of launch n+1 could find its point already carrying tag
+  // n+2 and wait for ever (seen with four processes on one device, one run in three).  What the launches DO guarantee: a rank
+  // completes launch m only when every neighbour has published m-1, i.e. has STARTED m-1, i.e. has completed m-2 (stream order).
+  // A block that publishes tag n+4 runs in launch n+4, so its rank has completed n+3 and every neighbour has completed n+1 --
+  // the launch that reads tag n.  Launches without rim_in / rim_out (the ends of a fast loop) are ordered by their exchanges.
   unsigned tag_in, tag_out;
   unsigned long long *err;      // pinned host word: a wait that gave up (bounded like every wait of the library)
   long long timeout;
@@ -413,7 +420,7 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
                         INR(iw_, jw_, (a.P.nbmask & 1) ? T.Istr - B2D_GL : T.IstrR, (a.P.nbmask & 2) ? T.Iend + B2D_GH : T.IendR,
                                       (a.P.nbmask & 4) ? T.Jstr - B2D_GL : T.JstrR, (a.P.nbmask & 8) ? T.Jend + B2D_GH : T.JendR);
       if (remv) {
-        const kword_t *rq = a.P.rim + 2 * ((size_t)(3 * (a.lev_in - 4)) * (size_t)G.nij + (size_t)x0);
+        const kword_t *rq = a.P.rim + 2 * ((size_t)(3 * (int)(a.tag_in & 3u)) * (size_t)G.nij + (size_t)x0);
         const bool nu = G.ewp || iw_ >= 1, nv = G.nsp || jw_ >= 1;     // (no u-points west of a western wall, no v-points south of a southern one)
         const long long t0 = kclock();
         zkv = 0.0; ukv = 0.0; vkv = 0.0;
@@ -747,7 +754,7 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
           if (fuse) hb_emit2(G, B, zout, BC_R, i, j, zeta_new, MSK ? G.rmask : nullptr, img0);
           else if (a.rim_out) {
             hb_emit2(G, B, zout, BC_R, i, j, zeta_new, MSK ? G.rmask : nullptr, false);
-            s2l_remit(G, a.P, B, 3 * (a.lev_out - 4), BC_R, i, j, zeta_new, a.tag_out, MSK ? G.rmask : nullptr);
+            s2l_remit(G, a.P, B, 3 * (int)(a.tag_out & 3u), BC_R, i, j, zeta_new, a.tag_out, MSK ? G.rmask : nullptr);
           } else zout[x0] = zeta_new;
         }
       }
@@ -797,13 +804,13 @@ COOP_KERNEL(k_step2d_pair_t, Step2dPairArgs) {
           if (fuse) hb_emit2(G, B, uout, BC_U, i, j, b, MSK ? G.umask : nullptr, img0);
           else if (a.rim_out) {
             hb_emit2(G, B, uout, BC_U, i, j, b, MSK ? G.umask : nullptr, false);
-            s2l_remit(G, a.P, B, 3 * (a.lev_out - 4) + 1, BC_U, i, j, b, a.tag_out, MSK ? G.umask : nullptr);
+            s2l_remit(G, a.P, B, 3 * (int)(a.tag_out & 3u) + 1, BC_U, i, j, b, a.tag_out, MSK ? G.umask : nullptr);
           } else uout[x] = b;
         } else {
           if (fuse) hb_emit2(G, B, vout, BC_V, i, j, b, MSK ? G.vmask : nullptr, img0);
           else if (a.rim_out) {
             hb_emit2(G, B, vout, BC_V, i, j, b, MSK ? G.vmask : nullptr, false);
-            s2l_remit(G, a.P, B, 3 * (a.lev_out - 4) + 2, BC_V, i, j, b, a.tag_out, MSK ? G.vmask : nullptr);
+            s2l_remit(G, a.P, B, 3 * (int)(a.tag_out & 3u) + 2, BC_V, i, j, b, a.tag_out, MSK ? G.vmask : nullptr);
           } else vout[x] = b;
         }
       }

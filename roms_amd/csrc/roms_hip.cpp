@@ -1182,10 +1182,10 @@ extern "C" int roms_hip_peer_export(roms_hip_ctx *c, void *blob128) {
           off += ((size_t)m.peer_planes * w * sizeof(double) + 255) & ~(size_t)255;
         }
     m.loop_rim_off = m.loop_ring_off = 0;
-    if (c->pair_mt) {                                             // rim planes of the persistent barotropic loop: [2][3][nij] x 16 bytes (k_step2d_loop.h)
+    if (c->pair_mt) {                                             // rim planes [4][3][nij] x 16 bytes: the persistent barotropic loop uses two sets (k_step2d_loop.h), the pair launches four (k_step2d_pair.h: Step2dPairArgs)
       step2d_loop_dims(c, m.loop_nb2[0], m.loop_nb2[1]);
       m.loop_rim_off = off;
-      off += ((size_t)6 * (size_t)G.nij * 16 + 255) & ~(size_t)255;
+      off += ((size_t)12 * (size_t)G.nij * 16 + 255) & ~(size_t)255;
     }
     m.peer_bytes = off;
     {
