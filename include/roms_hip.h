@@ -165,6 +165,10 @@ typedef struct roms_hip_config {
   /* ABI version 5: OBCFAC of roms.in (mod_scalars.F: obcfac) -- the ratio inflow / outflow nudging time scale of the radiation +
      nudging boundary conditions, used where ROMS_NUDGE_M3CLM / _TCLM / _M2CLM make them read "M3nudgcof" / "Tnudgcof" / "M2nudgcof" */
   double obcfac;
+  /* ... and VolCons(west|south|east|north) of roms.in (mod_scalars.F: VolCons): bit ROMS_IWEST .. ROMS_INORTH set = the volume is
+     conserved across that open edge -- obc_volcons.F:60 obc_flux_tile behind every barotropic call, :236 set_DUV_bc_tile in front
+     of the next (step2d_LF_AM3.h:724, :2885).  One tile only: the sum over the tiles (mp_reduce) is not built */
+  int volcons;
 } roms_hip_config;
 
 /* time indices of mod_stepping.F / mod_scalars.F that the kernel wrappers read */

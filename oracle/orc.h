@@ -122,6 +122,7 @@ typedef struct {
   double Akk_bak, Akp_bak, Zos, charnok_alpha, crgban_cw;
   double obcfac;                        /* OBCFAC: with climatology nudging the radiation conditions read the coefficient arrays, obc_in = obcfac * obc_out */
   int lbc_tke[4];                       /* LBC(isMtke) [iwest, isouth, ieast, inorth]: 0 = closed / periodic as the direction is; ORC_LBC_GRA, ORC_LBC_RAD (tkebc_im.F) */
+  int volcons;                          /* VolCons(iwest..inorth) of roms.in: bit e = edge e (obc_volcons.F) */
 } orc_cfg;
 
 /* time-level state of main3d / mod_stepping */
@@ -163,6 +164,9 @@ typedef struct orc_s {
   int ddmix;                             /* LMD_DDMIX on (orc_set_ddmix): lmd_vmix.F:360-428 */
   /* WET_DRY (wetdry.F): time-dependent masks; rmask_wet_avg: sum of the rho mask over the fast steps; *_full: wet mask x land mask */
   double *rmask_wet, *umask_wet, *vmask_wet, *pmask_wet, *rmask_full, *umask_full, *vmask_full, *pmask_full, *rmask_wet_avg;
+  /* obc_volcons.F / mod_scalars.F:1460-1462: cross-section and flux of the open edges summed over the tiles in calling order,
+     the correction velocity; vc_count = tile_count of mod_parallel.F:89 */
+  double bc_area, bc_flux, ubar_xs; int vc_count;
   int wet_dry; double Dcrit;             /* switched on by orc_set_wetdry (DCRIT of roms.in, read_phypar.F:1021) */
   double *visc4_r, *visc4_p, *diff4;     /* UV_VIS4 / TS_DIF4: square roots of the biharmonic coefficients (inp_par.F:634) */
   /* climatology nudging (mod_clima.F): tclm, Tnudgcof (i,j,k,itrc) -- per tracer, not the reference's compact index --, uclm, vclm,

@@ -57,7 +57,7 @@ class Cfg(C.Structure):
         ("gls_Pmin", C.c_double), ("gls_cmu0", C.c_double), ("gls_c1", C.c_double), ("gls_c2", C.c_double),
         ("gls_c3m", C.c_double), ("gls_c3p", C.c_double), ("gls_sigk", C.c_double), ("gls_sigp", C.c_double),
         ("Akk_bak", C.c_double), ("Akp_bak", C.c_double), ("Zos", C.c_double), ("charnok_alpha", C.c_double),
-        ("crgban_cw", C.c_double), ("obcfac", C.c_double), ("lbc_tke", C.c_int * 4),
+        ("crgban_cw", C.c_double), ("obcfac", C.c_double), ("lbc_tke", C.c_int * 4), ("volcons", C.c_int),
     ]
 
 

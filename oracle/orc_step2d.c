@@ -69,6 +69,35 @@ void orc_step2d(orc_t *o, int tile) {
       DVom[X2(i, j)] = VB(i, j, krhs) * cff1;
     }
 
+  /* VolCons: the mass fluxes along the open edges with the correction velocity of the previous call's obc_flux_tile taken off the
+     inflow -- set_DUV_bc_tile, obc_volcons.F:236-370, called at step2d_LF_AM3.h:724; the ranges are obc_volcons.F:300-306's own
+     (the shared-memory form of I_RANGE / J_RANGE: those of Drhs above except in a periodic direction, where they stop short) */
+  if (c->volcons) {
+    const double xs = o->ubar_xs;
+    const int jlo = (JstrV - 1 > 2 ? JstrV - 1 : 2) - 2, jhi = (Jend + 1 < c->Mm ? Jend + 1 : c->Mm) + 1;
+    const int ilo = (IstrU - 1 > 2 ? IstrU - 1 : 2) - 2, ihi = (Iend + 1 < c->Lm ? Iend + 1 : c->Lm) + 1;
+    if ((c->volcons & (1 << ORC_IWEST)) && b->west)
+      for (int j = jlo; j <= jhi; j++) {
+        DUon[X2(Istr, j)] = 0.5 * (Drhs[X2(Istr, j)] + Drhs[X2(Istr - 1, j)]) * (UB(Istr, j, krhs) - xs) * on_u[X2(Istr, j)];
+        if (msk) DUon[X2(Istr, j)] = DUon[X2(Istr, j)] * o->umask[X2(Istr, j)];
+      }
+    if ((c->volcons & (1 << ORC_IEAST)) && b->east)
+      for (int j = jlo; j <= jhi; j++) {
+        DUon[X2(Iend + 1, j)] = 0.5 * (Drhs[X2(Iend + 1, j)] + Drhs[X2(Iend, j)]) * (UB(Iend + 1, j, krhs) + xs) * on_u[X2(Iend + 1, j)];
+        if (msk) DUon[X2(Iend + 1, j)] = DUon[X2(Iend + 1, j)] * o->umask[X2(Iend + 1, j)];
+      }
+    if ((c->volcons & (1 << ORC_ISOUTH)) && b->south)
+      for (int i = ilo; i <= ihi; i++) {
+        DVom[X2(i, Jstr)] = 0.5 * (Drhs[X2(i, Jstr)] + Drhs[X2(i, Jstr - 1)]) * (VB(i, Jstr, krhs) - xs) * om_v[X2(i, Jstr)];
+        if (msk) DVom[X2(i, Jstr)] = DVom[X2(i, Jstr)] * o->vmask[X2(i, Jstr)];
+      }
+    if ((c->volcons & (1 << ORC_INORTH)) && b->north)
+      for (int i = ilo; i <= ihi; i++) {
+        DVom[X2(i, Jend + 1)] = 0.5 * (Drhs[X2(i, Jend + 1)] + Drhs[X2(i, Jend)]) * (VB(i, Jend + 1, krhs) + xs) * om_v[X2(i, Jend + 1)];
+        if (msk) DVom[X2(i, Jend + 1)] = DVom[X2(i, Jend + 1)] * o->vmask[X2(i, Jend + 1)];
+      }
+  }
+
   /* fast-time averaging :739-880 */
   if (PRED) {
     if (iif == 1) {
@@ -699,6 +728,48 @@ void orc_step2d(orc_t *o, int tile) {
   }
   orc_u2dbc(o, b, knew);                                               /* :2871 */
   orc_v2dbc(o, b, knew);                                               /* :2876 */
+  /* VolCons: cross-section and flux of the open edges, obc_flux_tile -- obc_volcons.F:60-233, called at step2d_LF_AM3.h:2885 with
+     knew: this tile's sums in the reference's order (west, east, south, north; ascending index), added to the running sums in
+     calling order; behind the last tile the correction velocity (the shared-memory form :192-227, NSUB tiles) */
+  if (c->volcons) {
+    double my_area = 0.0, my_flux = 0.0;
+    if ((c->volcons & (1 << ORC_IWEST)) && b->west)
+      for (int j = Jstr; j <= Jend; j++) {
+        cff = 0.5 * (Z(Istr - 1, j, knew) + h[X2(Istr - 1, j)] + Z(Istr, j, knew) + h[X2(Istr, j)]) * on_u[X2(Istr, j)];
+        if (msk) cff = cff * o->umask[X2(Istr, j)];
+        my_area = my_area + cff;
+        my_flux = my_flux + cff * UB(Istr, j, knew);
+      }
+    if ((c->volcons & (1 << ORC_IEAST)) && b->east)
+      for (int j = Jstr; j <= Jend; j++) {
+        cff = 0.5 * (Z(Iend, j, knew) + h[X2(Iend, j)] + Z(Iend + 1, j, knew) + h[X2(Iend + 1, j)]) * on_u[X2(Iend + 1, j)];
+        if (msk) cff = cff * o->umask[X2(Iend + 1, j)];
+        my_area = my_area + cff;
+        my_flux = my_flux - cff * UB(Iend + 1, j, knew);
+      }
+    if ((c->volcons & (1 << ORC_ISOUTH)) && b->south)
+      for (int i = Istr; i <= Iend; i++) {
+        cff = 0.5 * (Z(i, Jstr - 1, knew) + h[X2(i, Jstr - 1)] + Z(i, Jstr, knew) + h[X2(i, Jstr)]) * om_v[X2(i, Jstr)];
+        if (msk) cff = cff * o->vmask[X2(i, Jstr)];
+        my_area = my_area + cff;
+        my_flux = my_flux + cff * VB(i, JstrV - 1, knew);
+      }
+    if ((c->volcons & (1 << ORC_INORTH)) && b->north)
+      for (int i = Istr; i <= Iend; i++) {
+        cff = 0.5 * (Z(i, Jend, knew) + h[X2(i, Jend)] + Z(i, Jend + 1, knew) + h[X2(i, Jend + 1)]) * om_v[X2(i, Jend + 1)];
+        if (msk) cff = cff * o->vmask[X2(i, Jend + 1)];
+        my_area = my_area + cff;
+        my_flux = my_flux - cff * VB(i, Jend + 1, knew);
+      }
+    if (o->vc_count == 0) { o->bc_flux = 0.0; o->bc_area = 0.0; }
+    o->bc_area = o->bc_area + my_area;
+    o->bc_flux = o->bc_flux + my_flux;
+    o->vc_count = o->vc_count + 1;
+    if (o->vc_count == c->NtileI * c->NtileJ) {
+      o->vc_count = 0;
+      o->ubar_xs = o->bc_flux / o->bc_area;
+    }
+  }
   orc_exchange2d(o, b, 'u', ubar + (size_t)(knew - 1) * nij);         /* :3043 */
   orc_exchange2d(o, b, 'v', vbar + (size_t)(knew - 1) * nij);
   free(S);

@@ -141,6 +141,14 @@
         END DO
       END DO
 !
+!  VolCons(iwest:inorth): bits 0..3 of ipar(50) (round 6: obc_volcons.F); the running values start from their declarations
+      DO ibry=1,4
+        VolCons(ibry,ng)=BTEST(ipar(50),ibry-1)
+      END DO
+      bc_area=0.0_dp
+      bc_flux=0.0_dp
+      ubar_xs=0.0_dp
+!
 #if defined GLS_MIXING || defined MY25_MIXING
 !  LBC(isMtke): ipar(46:49) at iwest, isouth, ieast, inorth (0 = the default above, 1 Clo, 3 Gra, 5 Rad: tkebc_im.F)
       DO ibry=1,4

@@ -590,6 +590,7 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
     c.blk_ZQ, c.blk_ZT, c.blk_ZW, c.lmd_Jwt = cs["blk_ZQ"], cs["blk_ZT"], cs["blk_ZW"], cs["lmd_Jwt"]
     code, sc = lbc_codes(cs), obc_scales(cs)
     c.obcfac = cs.get("obcfac", 0.0)
+    c.volcons = cs.get("volcons", 0)           # VolCons(west|south|east|north) of roms.in as bits 0..3 (obc_volcons.F)
     for e in range(4):
         for v in range(7):
             c.lbc[e][v] = code[v][e]

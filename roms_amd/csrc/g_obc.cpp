@@ -54,6 +54,17 @@ int run_obc2d(roms_hip_ctx *c, int kout, unsigned vars) {
   return 0;
 }
 
+// obc_flux_tile of level kinp (VolCons)
+int run_obc_flux(roms_hip_ctx *c, int kinp) {
+  const DGrid &G = c->G;
+  ObcFluxArgs a;
+  a.G = G;
+  a.zeta = lev2d(c, c->F.zeta, kinp); a.ubar = lev2d(c, c->F.ubar, kinp); a.vbar = lev2d(c, c->F.vbar, kinp);
+  a.h = c->F.h; a.on_u = c->F.on_u; a.om_v = c->F.om_v;
+  LAUNCH_COOP(k_obc_flux, 1, 1, 1, 256, 2 * OBCF_CHUNK, c->stream, a);
+  return 0;
+}
+
 // u3dbc_tile, v3dbc_tile: levels nstp ("now") and nout
 int run_obc3d_uv(roms_hip_ctx *c, int nout) {
   const DGrid &G = c->G;

@@ -57,7 +57,7 @@ int run_step2d(roms_hip_ctx *c) {
     variant = 2;                                                  // step: after the averages, below); the generic form carries the branches (k_step2d_wd)
     if (iif <= G.nfast) { int r = run_wetdry(c, 0); if (r) return r; }
   }
-  if (G.dia_uv || G.uv_vis4 || (G.clima & 32)) variant = 2;                         // (UV_VIS4: the generic form carries the biharmonic block, k_step2d_vis4)                                      // DIAGNOSTICS_UV: the generic form carries the term stores (k_step2d_duv)
+  if (G.dia_uv || G.uv_vis4 || (G.clima & 32) || G.volcons) variant = 2;                         // (UV_VIS4: the generic form carries the biharmonic block, k_step2d_vis4)                                      // DIAGNOSTICS_UV: the generic form carries the term stores (k_step2d_duv)
   // 64x8 sub-tiles: 1024 threads (one rectangle point and one momentum point per thread) measure 3 %
   // faster than 512 threads with two each; ROMS_HIP_S2D_1024=0 selects the latter
   const char *e1024 = getenv("ROMS_HIP_S2D_1024");
@@ -165,6 +165,7 @@ int run_step2d(roms_hip_ctx *c) {
   }
   if (iif > G.nfast) return 0;
   if (G.obc) { int r = run_obc2d(c, G.knew); if (r) return r; }                  // zetabc, u2dbc, v2dbc with open edges (k_obc.h)
+  if (G.volcons) { int r = run_obc_flux(c, G.knew); if (r) return r; }          // VolCons: obc_flux_tile :2885
   HaloSpec sp[8];
   int n = 0;
   const int wet = G.wet_dry ? BC_WET2 : 0;                                             // (+ the wetting/drying conditions at the end of zetabc / u2dbc / v2dbc)

@@ -268,3 +268,68 @@ COOP_KERNEL(k_obc, ObcArgs) {
   }
 }
 COOP_GLOBAL(k_obc, ObcArgs)
+
+// ---- VolCons: obc_flux_tile (obc_volcons.F:60-233; step2d_LF_AM3.h:2885, behind v2dbc of every barotropic call) -----------------
+// Cross-section and mass flux of the open edges that conserve volume, summed in the reference's order -- west, east, south,
+// north, each along ascending index, one running sum each -- and the correction velocity ubar_xs = bc_flux / bc_area that the
+// next call's mass fluxes take off the inflow (k_step2d.h: set_DUV_bc_tile).  One block: the threads form the terms of a chunk
+// in LDS, one thread adds them up in order (the order is the result: a tree would round differently).  One tile (the sum over
+// tiles is a reduction across ranks the library has not got: roms_hip_create refuses).
+struct ObcFluxArgs {
+  DGrid G;
+  const double *zeta, *ubar, *vbar;   // level knew
+  const double *h, *on_u, *om_v;
+};
+#define OBCF_CHUNK 1024
+COOP_KERNEL(k_obc_flux, ObcFluxArgs) {
+  (void)bx; (void)by; (void)bz;
+  const DGrid &G = a.G;
+  const TB &B = G.T;
+  const int nw = ((G.volcons & (1 << ROMS_IWEST)) && B.west) ? B.Jend - B.Jstr + 1 : 0;
+  const int ne = ((G.volcons & (1 << ROMS_IEAST)) && B.east) ? B.Jend - B.Jstr + 1 : 0;
+  const int ns = ((G.volcons & (1 << ROMS_ISOUTH)) && B.south) ? B.Iend - B.Istr + 1 : 0;
+  const int nn = ((G.volcons & (1 << ROMS_INORTH)) && B.north) ? B.Iend - B.Istr + 1 : 0;
+  const int ntot = nw + ne + ns + nn;
+  double *sA = lds, *sF = lds + OBCF_CHUNK;
+  double my_area = 0.0, my_flux = 0.0;
+  for (int c0 = 0; c0 < ntot; c0 += OBCF_CHUNK) {
+    const int c1 = KMIN(ntot, c0 + OBCF_CHUNK) - 1;
+    KLOOP1(s, c0, c1) {
+      double cff, p;
+      if (s < nw) {
+        const int i = B.Istr, j = B.Jstr + s;
+        cff = 0.5 * (a.zeta[X2(i - 1, j)] + a.h[X2(i - 1, j)] + a.zeta[X2(i, j)] + a.h[X2(i, j)]) * a.on_u[X2(i, j)];
+        if (G.masking) cff = cff * G.umask[X2(i, j)];
+        p = cff * a.ubar[X2(i, j)];
+      } else if (s < nw + ne) {
+        const int i = B.Iend, j = B.Jstr + (s - nw);
+        cff = 0.5 * (a.zeta[X2(i, j)] + a.h[X2(i, j)] + a.zeta[X2(i + 1, j)] + a.h[X2(i + 1, j)]) * a.on_u[X2(i + 1, j)];
+        if (G.masking) cff = cff * G.umask[X2(i + 1, j)];
+        p = -(cff * a.ubar[X2(i + 1, j)]);              // (my_flux - x == my_flux + (-x), bit for bit)
+      } else if (s < nw + ne + ns) {
+        const int i = B.Istr + (s - nw - ne), j = B.Jstr;
+        cff = 0.5 * (a.zeta[X2(i, j - 1)] + a.h[X2(i, j - 1)] + a.zeta[X2(i, j)] + a.h[X2(i, j)]) * a.om_v[X2(i, j)];
+        if (G.masking) cff = cff * G.vmask[X2(i, j)];
+        p = cff * a.vbar[X2(i, B.JstrV - 1)];           // (obc_volcons.F:168 reads vbar(i,JstrV-1))
+      } else {
+        const int i = B.Istr + (s - nw - ne - ns), j = B.Jend;
+        cff = 0.5 * (a.zeta[X2(i, j)] + a.h[X2(i, j)] + a.zeta[X2(i, j + 1)] + a.h[X2(i, j + 1)]) * a.om_v[X2(i, j + 1)];
+        if (G.masking) cff = cff * G.vmask[X2(i, j + 1)];
+        p = -(cff * a.vbar[X2(i, j + 1)]);
+      }
+      sA[s - c0] = cff;
+      sF[s - c0] = p;
+    }
+    KSYNC();
+    if (KTID == 0)
+      for (int s = 0; s <= c1 - c0; s++) { my_area = my_area + sA[s]; my_flux = my_flux + sF[s]; }
+    KSYNC();
+  }
+  if (KTID == 0) {
+    const double bc_area = 0.0 + my_area, bc_flux = 0.0 + my_flux;      // (:203-208 with tile_count = 0 and one tile)
+    G.vcons[0] = bc_area;
+    G.vcons[1] = bc_flux;
+    G.vcons[2] = bc_flux / bc_area;
+  }
+}
+COOP_GLOBAL(k_obc_flux, ObcFluxArgs)

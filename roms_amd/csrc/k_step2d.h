@@ -299,12 +299,28 @@ COOP_KERNEL(k_step2d_t, Step2dArgs) {
           const double cff = 0.5 * PW(r_on_u, F.on_u[x0]);
           const double cff1 = cff * (Drhs[s0] + Drhs[(s0 - 1)]);
           du = sUk[s0] * cff1;
+          if (BWC == 0 && G.volcons) {     // VolCons (the generic form only): set_DUV_bc_tile, obc_volcons.F:310-335, over its own line range
+            const bool w = (G.volcons & (1 << ROMS_IWEST)) && B.west && i == B.Istr, e = (G.volcons & (1 << ROMS_IEAST)) && B.east && i == B.Iend + 1;
+            if ((w || e) && j >= KMAX(2, B.JstrV - 1) - 2 && j <= KMIN(B.Jend + 1, G.Mm) + 1) {
+              const double xs = G.vcons[2];
+              du = 0.5 * (Drhs[s0] + Drhs[(s0 - 1)]) * (w ? sUk[s0] - xs : sUk[s0] + xs) * PW(r_on_u, F.on_u[x0]);
+              if (MSK) du = du * G.umask[x0];
+            }
+          }
           DUon[s0] = du;
         }
         if (j >= B.JstrVm2) {
           const double cff = 0.5 * PW(r_om_v, F.om_v[x0]);
           const double cff1 = cff * (Drhs[s0] + Drhs[(s0 - TW)]);
           dv = sVk[s0] * cff1;
+          if (BWC == 0 && G.volcons) {     // obc_volcons.F:337-362
+            const bool sb = (G.volcons & (1 << ROMS_ISOUTH)) && B.south && j == B.Jstr, nb = (G.volcons & (1 << ROMS_INORTH)) && B.north && j == B.Jend + 1;
+            if ((sb || nb) && i >= KMAX(2, B.IstrU - 1) - 2 && i <= KMIN(B.Iend + 1, G.Lm) + 1) {
+              const double xs = G.vcons[2];
+              dv = 0.5 * (Drhs[s0] + Drhs[(s0 - TW)]) * (sb ? sVk[s0] - xs : sVk[s0] + xs) * PW(r_om_v, F.om_v[x0]);
+              if (MSK) dv = dv * G.vmask[x0];
+            }
+          }
           DVom[s0] = dv;
         }
       }

@@ -90,6 +90,8 @@ struct DGrid {
   int prs4x;           // 44: PJ_GRADPQ4 (prsgrd44.h), 42: PJ_GRADPQ2 (prsgrd42.h); 0: the scheme the lower option bits name (k_prs4x.h)
   int ddmix;           // LMD_DDMIX (option bit ROMS_LMD_DDMIX): double-diffusive mixing in lmd_vmix's interior scheme (k_lmd.h), from ...
   double *alfaobeta;   // ... the ratio of the thermal expansion and saline contraction coefficients (i,j,0:N) rho_eos leaves (rho_eos.F:454, :794)
+  double *vcons;       // VolCons: {bc_area, bc_flux, ubar_xs} of mod_scalars.F:1460-1462 on the device (k_obc.h: k_obc_flux; k_step2d.h reads ubar_xs)
+  int volcons;         // ... bits by edge (obc_volcons.F)
 };
 
 #ifdef ROMS_CPU_EMU

@@ -650,6 +650,27 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     if (c->G.clima & 30) c->G.fuse3d = 0;
     if (c->G.clima & 32) { c->pair_on = step2d_pair_usable(c); c->loop_state = 0; }     // (LnudgeM2CLM: the per-call barotropic kernel)                    // (the nudging sits between t3dbc and the exchange: separate launches)
   }
+  c->G.volcons = 0; c->G.vcons = nullptr;
+  if (cfg->volcons & 15) {                                   // VolCons: obc_volcons.F (round 6)
+    const int vc = cfg->volcons & 15;
+    if (!c->G.obc) { set_error("VolCons without an open boundary"); roms_hip_destroy(c); return 5; }
+    for (int e = 0; e < 4; e++)
+      if ((vc & (1 << e)) && ((e == ROMS_IWEST || e == ROMS_IEAST) ? cfg->EWperiodic : cfg->NSperiodic)) { set_error("VolCons on a periodic edge"); roms_hip_destroy(c); return 5; }
+    if (cfg->NtileI * cfg->NtileJ > 1) {
+      set_error("VolCons on more than one tile: obc_flux_tile sums over the tiles (mp_reduce), a reduction across ranks this library has not got");
+      roms_hip_destroy(c); return 5;
+    }
+    // (pinned: the KELVIN cases with and without masks, all four edges; not with the options whose barotropic kernels are forms of their own)
+    if (cfg->options & (ROMS_WET_DRY | ROMS_UV_VIS4 | ROMS_DIAGNOSTICS_UV | ROMS_NUDGE_M2CLM)) {
+      set_error("VolCons together with WET_DRY, UV_VIS4, DIAGNOSTICS_UV or LnudgeM2CLM: not pinned against the reference, not built"); roms_hip_destroy(c); return 5;
+    }
+    void *p = nullptr;
+    if (dmalloc(&p, 4 * sizeof(double))) { roms_hip_destroy(c); return 2; }
+    c->allocs.push_back(p);
+    // (zeroed by dmalloc: mod_scalars.F:1460-1462, bc_area = bc_flux = ubar_xs = 0)
+    c->G.vcons = (double *)p;
+    c->G.volcons = vc;
+  }
   c->G.ddmix = 0; c->G.alfaobeta = nullptr;
   if (cfg->options & ROMS_LMD_DDMIX) {                      // lmd_vmix.F:360-428
     if (!(cfg->options & ROMS_LMD_MIXING)) { set_error("LMD_DDMIX without LMD_MIXING"); roms_hip_destroy(c); return 5; }

@@ -179,6 +179,7 @@ inline int lbc_kind(const roms_hip_config &cf, int edge, int var) {
   if ((edge == ROMS_IWEST || edge == ROMS_IEAST) ? cf.EWperiodic : cf.NSperiodic) return ROMS_LBC_PER;
   return cf.lbc[edge][var] == ROMS_LBC_DEFAULT ? ROMS_LBC_CLO : cf.lbc[edge][var];
 }
+int run_obc_flux(roms_hip_ctx *c, int kinp);     // obc_flux_tile (VolCons)
 int run_obc2d(roms_hip_ctx *c, int kout, unsigned vars = 7);     // zetabc (1), u2dbc (2), v2dbc (4) of level kout (g_obc.cpp)
 int run_obc3d_uv(roms_hip_ctx *c, int nout);                     // u3dbc, v3dbc
 int run_obc3d_t(roms_hip_ctx *c, int nout, int itrc);            // t3dbc of tracer itrc (1-based)

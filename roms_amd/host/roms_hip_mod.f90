@@ -73,6 +73,7 @@
 !  WET_DRY (ABI version 4): DCRIT of roms.in
         real(c_double) :: Dcrit
         real(c_double) :: obcfac
+        integer(c_int) :: volcons
       END TYPE roms_hip_config
 
       TYPE, bind(C) :: roms_hip_stepping

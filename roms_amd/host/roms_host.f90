@@ -83,6 +83,7 @@
 !  time scales of roms.in in days (ZNUDG M2NUDG M3NUDG TNUDG) and OBCFAC
       integer :: lbc(ROMS_NLBC,4) = 0
       real(dp) :: Znudg = 0.0_dp, M2nudg = 0.0_dp, M3nudg = 0.0_dp, Tnudg(ROMS_MAXT) = 0.0_dp, obcfac = 0.0_dp
+      integer :: volcons = 0
       character(len=32) :: defs(256)              ! cpp options defined by the application header
       integer :: ndefs = 0
       character(len=64) :: xtok(64)               ! tokens of the #if condition being evaluated
@@ -276,13 +277,18 @@
           CASE ('Hout(idHsbl)'); Hout(idHsbl)=istrue(tok(1))
           CASE ('Hout(idMtke)'); HoutMtke=istrue(tok(1))
           CASE ('Hout(idMtls)'); HoutMtls=istrue(tok(1))
+!  VolCons(west|south|east|north) (read_phypar.F: volume conservation across an open edge, obc_volcons.F): bits 0..3 in the order of
+!  iwest, isouth, ieast, inorth
+          CASE ('VolCons(west)');  IF (istrue(tok(1))) volcons=IOR(volcons, 1)
+          CASE ('VolCons(south)'); IF (istrue(tok(1))) volcons=IOR(volcons, 2)
+          CASE ('VolCons(east)');  IF (istrue(tok(1))) volcons=IOR(volcons, 4)
+          CASE ('VolCons(north)'); IF (istrue(tok(1))) volcons=IOR(volcons, 8)
           CASE ('LuvSrc', 'LwSrc', 'LtracerSrc', 'LuvSponge', 'LtracerSponge', 'LsshCLM', 'Lm2CLM', 'Lm3CLM',     &
-     &          'LtracerCLM', 'LnudgeM2CLM', 'LnudgeM3CLM', 'LnudgeTCLM', 'VolCons(west)', 'VolCons(east)',      &
-     &          'VolCons(south)', 'VolCons(north)')
+     &          'LtracerCLM', 'LnudgeM2CLM', 'LnudgeM3CLM', 'LnudgeTCLM')
             DO itr=1,nv
               IF (tok(itr)(1:1).eq.'T'.or.tok(itr)(1:1).eq.'t') THEN
-                CALL unsupported (TRIM(key)//' == T: point sources, sponges, climatology nudging and '//       &
-     &                            'volume conservation are not built', ierr)
+                CALL unsupported (TRIM(key)//' == T: point sources, sponges and climatology input '//           &
+     &                            'are not built', ierr)
               END IF
             END DO
             IF (ierr.ne.0) EXIT
@@ -442,7 +448,7 @@
       ntimes=100; ndtfast=30; ninfo=1; Vtransform=2; Vstretching=4; lmd_Jwt=1
       hadv=ROMS_U3; vadv=ROMS_C4
       EWperiodic=.TRUE.; NSperiodic=.FALSE.
-      lbc=0; Znudg=0.0_dp; M2nudg=0.0_dp; M3nudg=0.0_dp; Tnudg=0.0_dp; obcfac=0.0_dp
+      lbc=0; Znudg=0.0_dp; M2nudg=0.0_dp; M3nudg=0.0_dp; Tnudg=0.0_dp; obcfac=0.0_dp; volcons=0
       dt=300.0_dp; theta_s=3.0_dp; theta_b=0.0_dp; Tcline=25.0_dp; rho0=1025.0_dp
       R0=1027.0_dp; T0=14.0_dp; S0=35.0_dp; Tcoef=1.7E-4_dp; Scoef=0.0_dp
       visc2=5.0_dp; tnu2=0.0_dp; Akt_bak=1.0E-6_dp; Akv_bak=1.0E-5_dp
@@ -1037,6 +1043,8 @@
       IF (ddmix.and..not.is_defined('LMD_MIXING')) CALL unsupported ('LMD_DDMIX without LMD_MIXING', ierr)
       IF (ddmix.and..not.is_defined('SALINITY')) CALL unsupported ('LMD_DDMIX needs SALINITY', ierr)
       prs4x=0
+      IF (volcons.ne.0.and.NtileI*NtileJ.ne.1) CALL unsupported ('VolCons on more than one tile: obc_flux_tile sums over the '//      &
+     &    'tiles (mp_reduce), a reduction across ranks that is not built', ierr)
       IF (is_defined('PJ_GRADPQ4')) THEN
         prs4x=44                                  ! (upper word of cfg%options: ROMS_PRSGRD44, below)
       ELSE IF (is_defined('PJ_GRADPQ2')) THEN
@@ -2059,6 +2067,7 @@
       tUBj=MERGE(UBj, tJend+Nghost, tn)
       cfg%abi_version=5
       cfg%obcfac=obcfac
+      cfg%volcons=volcons
       cfg%device=device
       cfg%Lm=Lm; cfg%Mm=Mm; cfg%N=N; cfg%NT=NT; cfg%NAT=NAT; cfg%Nghost=Nghost
       cfg%LBi=tLBi; cfg%UBi=tUBi; cfg%LBj=tLBj; cfg%UBj=tUBj

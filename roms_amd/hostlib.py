@@ -81,6 +81,9 @@ def write_roms_in(path, p):
             lines.append(f"{name:>12} == {d(p[key])}")
     if "Tnudg" in p:
         lines.append(f"       TNUDG == {tr(d(x) for x in p['Tnudg'])}")
+    for bit, edge in enumerate(("west", "south", "east", "north")):       # VolCons(...) of roms.in from the case's bit mask
+        if p.get("volcons", 0) & (1 << bit):
+            lines.append(f" VolCons({edge}) == T")
     lines += [
         f"      NTIMES == {p.get('ntimes', 10)}", f"          DT == {d(p['dt'])}",
         f"     NDTFAST == {p['ndtfast']}", f"       NINFO == {p.get('ninfo', 1)}",

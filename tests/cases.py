@@ -38,6 +38,7 @@ def ref_params(cs):
         for e in range(4):
             rpar[49 + 8 * it + e] = sc["Tobc_in"][it][e]
             rpar[53 + 8 * it + e] = sc["Tobc_out"][it][e]
+    ipar[49] = cs.get("volcons", 0)     # ref_glue.F90: ipar(50), VolCons(iwest..inorth) as bits 0..3 (round 6: obc_volcons.F)
     rpar[83] = cs.get("Dcrit", 0.0)     # ref_glue.F90: rpar(84), DCRIT (WET_DRY builds)
     rpar[84] = cs.get("obcfac", 0.0)    # ref_glue.F90: rpar(85), OBCFAC (round 6: the radiation conditions under climatology nudging)
     if "gls_flags" in cs:               # ref_glue.F90: rpar(66..83)
@@ -72,6 +73,7 @@ def oracle_cfg(cs, hc, nfast, weight):
         c.weight[0][k + 1] = w[0, k]
         c.weight[1][k + 1] = w[1, k]
     c.obcfac = cs.get("obcfac", 0.0)
+    c.volcons = cs.get("volcons", 0)
     c.rho0, c.g, c.lambda_, c.gamma2, c.Cp = cs["rho0"], 9.81, 1.0, cs["gamma2"], 3985.0
     c.R0, c.T0, c.S0, c.Tcoef, c.Scoef = cs["R0"], cs["T0"], cs["S0"], cs["Tcoef"], cs["Scoef"]
     c.hc, c.Vtransform = hc, cs["Vtransform"]

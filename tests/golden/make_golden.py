@@ -282,6 +282,7 @@ STEP_CASES = [
     # open boundaries: the reference's KELVIN application (oracle/ref/kelvin_splines.h)
     ("kelvin_small", "kelvin_small", ["nsteps=96"]),
     ("kelvin_plain_small", "kelvin_plain_small", ["nsteps=96"]),     # ROMS/Include/kelvin.h as shipped: plain vertical solvers
+    ("kelvin_plain_small_volcons", "kelvin_plain_small", ["nsteps=60", "volcons=5"]),    # ... with VolCons(west) = VolCons(east) = T (obc_volcons.F), round 6
     # two more of the reference's test applications: SEAMOUNT (pressure-gradient test) and GRAV_ADJ (lock exchange, MPDATA)
     ("seamount_small", "seamount_small", ["nsteps=100"]),
     ("grav_adj_small", "grav_adj_small", ["nsteps=100"]),

@@ -92,6 +92,7 @@ CASES = {
     # closed basins (round 6): whole steps between four walls -- the corner values of every boundary routine -- and the biharmonic
     # operators' conditions on the first operator at western / eastern walls (t3dmix4_geo.h:475-600, t3dmix4_iso.h:504-618, t3dmix4_s.h)
     "upwelling_closed_small": ("upwelling", dict(Lm=14, Mm=18, N=8)),
+    "upwelling_mask_closed_small": ("upwelling_mask", dict(Lm=14, Mm=18, N=8)),      # (with open kinds on the edges: the masked open-boundary whole runs, VolCons)
     "upwelling_bih_closed_small": ("upwelling_bih", dict(Lm=14, Mm=18, N=8)),
     "upwelling_bihgeo_closed_small": ("upwelling_bihgeo", dict(Lm=14, Mm=18, N=8)),
     "upwelling_bihiso_closed_small": ("upwelling_bihiso", dict(Lm=14, Mm=18, N=8)),
@@ -175,7 +176,7 @@ def oracle_diag_line(od):
 def make_case(tag, **kw):
     app, base = CASES[tag]
     k = dict(base)
-    k.update({a: b for a, b in kw.items() if a not in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac", "lbc_tke", "clima")})
+    k.update({a: b for a, b in kw.items() if a not in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac", "lbc_tke", "clima", "volcons")})
     ctor = dict(upwelling=cases.upwelling, benchmark=cases.benchmark, upwelling_kpp=cases.upwelling_kpp,
                 upwelling_avg=cases.upwelling, upwelling_diag=cases.upwelling, upwelling_logdrag=cases.upwelling_logdrag, upwelling_noadv=cases.upwelling_noadv,
                 upwelling_mask=cases.upwelling_mask, upwelling_wetdry=cases.upwelling_wetdry, benchmark_mask=cases.benchmark_mask, benchmark_wetdry=cases.benchmark_wetdry,
@@ -194,7 +195,7 @@ def make_case(tag, **kw):
             cs["visc4"], cs["tnu4"] = 4.0e7, (2.0e6, 1.0e6)      # in the reference and, bit for bit, in the oracle; a tenth is stable)
     if lbc is not None:
         cs["lbc"] = lbc
-    for n in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac", "lbc_tke", "clima"):
+    for n in ("bry_all", "Znudg", "M2nudg", "M3nudg", "Tnudg", "obcfac", "lbc_tke", "clima", "volcons"):
         if n in kw:
             cs[n] = kw[n]
     if cs.get("clima") and "mix4" in cs and cs.get("visc4", 0.0) > 4.0e7:

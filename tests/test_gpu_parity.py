@@ -1196,6 +1196,53 @@ def test_open_boundaries_match_oracle(variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant,vc", [("kelvin", 5), ("four", 15), ("masked", 15)])
+def test_volume_conservation_across_open_edges_matches_oracle(variant, vc):
+    """Round 6, VolCons (obc_volcons.F) on the GPU: k_obc_flux behind the boundary conditions of every barotropic call (the sums in
+    the reference's order), the correction velocity taken off the inflow in the next call's mass fluxes (k_step2d.h).  40 steps
+    against the oracle (equal to the reference with VolCons on: tests/test_oracle_vs_ref.py; a reference-written fixture runs in
+    test_gpu_vs_reference.py) at the north-star tolerance: the KELVIN application west + east, all four edges open, a masked
+    basin with open kinds on four edges."""
+    from roms_amd import hiplib
+    from tests.test_kernels_emu import OBC_VARIANTS
+    if variant == "masked":
+        from tests.refchild import OBC_PRESETS
+        cs = util.case_for("upwelling_mask_small")
+        cs["lbc"] = OBC_PRESETS["F"]
+        cs["EWperiodic"] = 0
+        g = util.closed_basin_state(cs, util.with_masks(cs, util.load_init("upwelling_small", util.nghost_for(cs))))
+    else:
+        kw = {} if OBC_VARIANTS[variant] is None else dict(lbc=OBC_VARIANTS[variant])
+        cs = util.case_for("kelvin_small", **kw)
+        g = util.load_init("kelvin_small", util.nghost_for(cs))
+    cs["volcons"] = vc
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g)
+    if variant == "four":
+        rng = np.random.default_rng(3)
+        for n in hiplib.BRY_FIELDS:
+            if n.startswith(("u_", "v_", "t_")) or n.endswith(("south", "north")):
+                a = O.field(n)
+                a[:] = (10.0 if n[0] == "t" else 0.0) + 0.01 * rng.standard_normal(a.size)
+                H.upload(n, a)
+    O.start(); H.start()
+    if variant == "masked":
+        O.main3d_step(2); H.main3d(2)
+        rng = np.random.default_rng(11)
+        for n, amp in (("t", 0.05), ("u", 1e-3), ("v", 1e-3)):
+            a = O.field(n).copy()
+            a += amp * rng.standard_normal(a.size) * (a != 0.0 if n != "t" else 1.0)
+            O.field(n)[:] = a
+            H.upload(n, a)
+    O.main3d_step(40); H.main3d(40)
+    for n in util.PROGNOSTIC:
+        a, b = H.download(n), O.field(n)
+        assert np.isfinite(a).all(), n
+        assert util.agree(a, b, 1e-10), (n, util.relrms(a, b))
+    H.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env", [{}, {"ROMS_HIP_XASYNC": "1"}, {"ROMS_HIP_PEER_THREADS": "64"}])
 def test_mailbox_self_exchange_matches_local_periodic_copy(env):
     """The mailbox transport (include/roms_hip.h:roms_hip_comm_peer) on one GPU with the tile as its own neighbours:

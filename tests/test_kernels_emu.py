@@ -399,6 +399,8 @@ def test_romsM_run_report_is_the_reference_text(emu, tmp_path):
     # the reference's KELVIN application (open boundaries), as shipped and with the spline vertical solvers
     util.check_romsM_report(exe, tmp_path, exact=True, fixture="kelvin_plain_small_steps.npz")
     util.check_romsM_report(exe, tmp_path, exact=True, fixture="kelvin_small_steps.npz")
+    # ... with VolCons(west) == VolCons(east) == T in roms.in (obc_volcons.F; round 6)
+    util.check_romsM_report(exe, tmp_path, exact=True, fixture="kelvin_plain_small_volcons_steps.npz")
     # SEAMOUNT and GRAV_ADJ
     util.check_romsM_report(exe, tmp_path, exact=True, fixture="seamount_small_steps.npz")
     util.check_romsM_report(exe, tmp_path, exact=True, fixture="grav_adj_small_steps.npz")
@@ -499,6 +501,76 @@ def test_open_boundaries_bitwise(emu, variant):
             assert np.array_equal(a, b), (n, float(np.abs(a - b).max()))
     assert np.abs(O.field("u")).max() > 0.05
     H.close()
+
+
+@pytest.mark.parametrize("variant,vc", [("kelvin", 5), ("plain", 5), ("four", 15), ("four", 10), ("masked", 15)])
+def test_volume_conservation_across_open_edges_bitwise(emu, variant, vc):
+    """Round 6, VolCons (obc_volcons.F): behind the boundary conditions of every barotropic call the cross-section and the mass flux
+    of the conserving edges are summed in the reference's order and give the correction velocity ubar_xs (k_obc.h: k_obc_flux, one
+    block, terms in LDS, one thread adds them up in order); the next call takes it off the inflow in its mass fluxes along those
+    edges (k_step2d.h: set_DUV_bc_tile, obc_volcons.F:236-370).  The oracle equals the reference with VolCons on -- KELVIN west +
+    east, all four edges, 2x2 tiles, under MASKING, kernel by kernel (tests/test_oracle_vs_ref.py).  12 steps against the oracle,
+    every bit: the KELVIN application, all four edges open, and a masked basin with open kinds on its four edges; the run differs
+    from the one without."""
+    from roms_amd import hiplib
+    if variant == "masked":
+        from tests.refchild import OBC_PRESETS
+        cs = util.case_for("upwelling_mask_small")
+        cs["lbc"] = OBC_PRESETS["F"]
+        cs["EWperiodic"] = 0
+        g = util.closed_basin_state(cs, util.with_masks(cs, util.load_init("upwelling_small", util.nghost_for(cs))))
+    else:
+        kw = {} if OBC_VARIANTS[variant] is None else dict(lbc=OBC_VARIANTS[variant])
+        cs = util.case_for("kelvin_plain_small" if variant == "plain" else "kelvin_small", **kw)
+        g = util.load_init("kelvin_small", util.nghost_for(cs))
+    cs0 = dict(cs)
+    cs["volcons"] = vc
+    O = util.make_oracle(cs, g)
+    O0 = util.make_oracle(cs0, g)
+    H = util.make_hip(cs, g, emu)
+    if variant == "four":
+        rng = np.random.default_rng(3)
+        for n in hiplib.BRY_FIELDS:
+            if n.startswith(("u_", "v_", "t_")) or n.endswith(("south", "north")):
+                a = O.field(n)
+                a[:] = (10.0 if n[0] == "t" else 0.0) + 0.01 * rng.standard_normal(a.size)
+                O0.field(n)[:] = a
+                H.upload(n, a)
+    O.start(); O0.start(); H.start()
+    rng = np.random.default_rng(11)
+    for step in range(12):
+        if variant == "masked" and step == 2:     # (the basin at rest: set it in motion)
+            for n, amp in (("t", 0.05), ("u", 1e-3), ("v", 1e-3)):
+                a = O.field(n).copy()
+                a += amp * rng.standard_normal(a.size) * (a != 0.0 if n != "t" else 1.0)
+                O.field(n)[:] = a
+                O0.field(n)[:] = a
+                H.upload(n, a)
+        O.main3d_step(); O0.main3d_step(); H.main3d(1)
+        for n in util.PROGNOSTIC:
+            a, b = H.download(n), O.field(n)
+            assert np.isfinite(b).all(), n
+            assert np.array_equal(a, b), (step, n, float(np.abs(a - b).max()))
+    assert not np.array_equal(O.field("ubar"), O0.field("ubar"))
+    H.close()
+
+
+def test_volume_conservation_on_more_than_one_tile_stops(emu):
+    """VolCons on a partition: host and library stop with exit_flag 5 and the reason (the sum over the tiles is a reduction across ranks)"""
+    from roms_amd import hiplib, hostlib
+    cs = util.case_for("kelvin_small")
+    cs["volcons"] = 5
+    cs["NtileI"] = 2
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.Host(params=cs, lib_path=os.path.join(os.path.dirname(emu), "libroms_host_emu.so"), hip_lib_path=emu)
+    assert e.value.exit_flag == 5 and "VolCons on more than one tile" in str(e.value)
+    g = util.load_init("kelvin_small", util.nghost_for(cs))
+    from tests import cases
+    cfg = cases.hip_cfg(cs, float(g["scalars"][0]), int(g["bounds"][58]), g["weight"], g["sc_r"], g["Cs_r"], g["sc_w"], g["Cs_w"])
+    cfg.NtileI = 2
+    with pytest.raises(hiplib.RomsHipError) as e2:
+        hiplib.Context(cfg, emu)
+    assert "exit_flag=5" in str(e2.value) and "VolCons on more than one tile" in str(e2.value)
 
 
 def test_open_boundary_kinds_the_library_does_not_have_stop():

@@ -234,6 +234,15 @@ MAIN3D_CASES = [
     ("kelvin_plain", ["nsteps=96"]),
     # climatology nudging beside open boundaries (round 6): radiation + nudging edges (tests/refchild.py OBC_PRESETS) with
     # LnudgeM2CLM + LnudgeM3CLM + LnudgeTCLM on -- the conditions' time scales come from the coefficient arrays and obcfac
+    # VolCons (round 6; obc_volcons.F: obc_flux_tile behind every barotropic call, set_DUV_bc_tile in front of the next): KELVIN's
+    # western + eastern edge, all four edges of an all-open basin, 2x2 tiles (the running sums in calling order), under MASKING
+    ("kelvin_plain_small", ["nsteps=20", "volcons=5"]),
+    ("kelvin_small", ["nsteps=20", "volcons=5"]),
+    ("kelvin_plain_small", ["nsteps=20", "volcons=5", "NtileI=2", "NtileJ=2"]),
+    ("kelvin_plain_small", ["nsteps=20", "preset=F", "volcons=15"]),
+    ("kelvin_plain_small", ["nsteps=20", "preset=G", "volcons=10", "NtileI=2", "NtileJ=2"]),
+    ("upwelling_mask_closed_small", ["nsteps=12", "preset=F", "volcons=15"]),
+    ("upwelling_mask_closed_small", ["nsteps=12", "preset=B", "volcons=10", "NtileI=2", "NtileJ=2"]),
     ("kelvin_plain_small", ["nsteps=20", "preset=F", "clima=39"]),
     ("kelvin_plain_small", ["nsteps=20", "preset=C", "clima=39", "NtileI=2", "NtileJ=2"]),
     # two more of the reference's test applications: SEAMOUNT (no-slip walls, Akima advection, geopotential mixing without
@@ -407,6 +416,7 @@ def test_main3d_steps_bitwise(tag, args):
     ("upwelling_bihiso_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
     ("upwelling_bihiso_small", ["hadv=U3,U3", "vadv=C4,C4", "NtileI=2", "NtileJ=2"]),
     ("upwelling_geouv_small", ["hadv=U3,HSIMT", "vadv=C4,HSIMT"]),                     # uv3dmix2_geo.h (called by rhs3d)
+    ("kelvin_plain_small", ["volcons=15"]),                                              # obc_volcons.F inside step2d_tile
 ])
 def test_core_kernels_bitwise(tag, args):
     """step2d_tile (step2d_LF_AM3.h:163; first predictor, correctors, last predictor), omega_tile (omega.F:96),
