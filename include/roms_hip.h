@@ -93,6 +93,8 @@ enum {
 #define ROMS_PRSGRD44 (1ull << 44)        /* PJ_GRADPQ4 (round 6): ... with quartic reconstruction and power-law reconciliation, prsgrd44.h:224-508 */
 #define ROMS_LMD_DDMIX (1ull << 45)       /* LMD_DDMIX (round 6, with ROMS_LMD_MIXING): double-diffusive mixing -- salt fingering, diffusive convection -- added to
                                              Akt in the interior scheme, lmd_vmix.F:360-428, from alfaobeta of rho_eos.F:435-455 | :782-796 */
+#define ROMS_LMD_BKPP (1ull << 46)        /* LMD_BKPP (round 6, with ROMS_LMD_MIXING): the bottom boundary layer of the K-profile scheme behind lmd_skpp,
+                                             lmd_bkpp.F:95-806 (RI_SPLINES, the file's own SASHA); MIXING(ng)%hbbl is the field "hbbl" */
 #define ROMS_DIAGNOSTICS_UV (1ull << 35)  /* roms_hip_dia_config allocates and switches on the momentum terms too (mod_diags.F:174-222) */
 
 /* GLS_MIXING: the cpp options that select a form of gls_prestep.F / gls_corstep.F (cppdefs.h names).  Stability

@@ -162,6 +162,7 @@ typedef struct orc_s {
   double *Akv, *Akt, *visc2_r, *visc2_p, *diff2, *bvf, *alpha, *beta, *hsbl, *ghats;
   double *alfaobeta;                     /* LMD_DDMIX: ratio of the thermal expansion and saline contraction coefficients (i,j,0:N), rho_eos.F:454, :794 */
   int ddmix;                             /* LMD_DDMIX on (orc_set_ddmix): lmd_vmix.F:360-428 */
+  double *hbbl; int *kbbl; int bkpp;     /* LMD_BKPP on (orc_set_bkpp): depth and level index of the bottom boundary layer, lmd_bkpp.F */
   /* WET_DRY (wetdry.F): time-dependent masks; rmask_wet_avg: sum of the rho mask over the fast steps; *_full: wet mask x land mask */
   double *rmask_wet, *umask_wet, *vmask_wet, *pmask_wet, *rmask_full, *umask_full, *vmask_full, *pmask_full, *rmask_wet_avg;
   /* obc_volcons.F / mod_scalars.F:1460-1462: cross-section and flux of the open edges summed over the tiles in calling order,
@@ -320,6 +321,7 @@ typedef struct orc_diauv {
 void orc_set_mix4(orc_t *o, int uv_vis4, int ts_dif4);
 void orc_prsgrd42(orc_t *o, int tile);                        /* orc_prs4x.c */
 void orc_prsgrd44(orc_t *o, int tile);
+void orc_set_bkpp(orc_t *o, int on);                          /* LMD_BKPP: the bottom boundary layer behind lmd_skpp (lmd_bkpp.F) */
 void orc_set_ddmix(orc_t *o, int on);                         /* LMD_DDMIX: double-diffusive mixing in lmd_vmix's interior scheme */
 void orc_set_prsgrd(orc_t *o, int scheme);                    /* prsgrd.F:16-19: PJ_GRADPQ4 -> prsgrd44.h, PJ_GRADPQ2 -> prsgrd42.h */
 void orc_set_clima(orc_t *o, int flags);                       /* climatology nudging: step3d_t.F:1866-1878, rhs3d.F:654-680 */

@@ -168,6 +168,10 @@ class Oracle:
         roots of the coefficients"""
         self.L.orc_set_mix4(C.c_void_p(self.h), int(uv_vis4), int(ts_dif4))
 
+    def set_bkpp(self, on=True):
+        """LMD_BKPP: the bottom boundary layer of the K-profile scheme (lmd_bkpp.F)"""
+        self.L.orc_set_bkpp(C.c_void_p(self.h), int(bool(on)))
+
     def set_ddmix(self, on=True):
         """LMD_DDMIX: double-diffusive mixing (salt fingering, diffusive convection) added to Akt in lmd_vmix's interior scheme,
         lmd_vmix.F:360-428, with alfaobeta of rho_eos.F:454 | :794"""

@@ -112,6 +112,7 @@ static void alloc_bounds(orc_cfg *c) {
 void orc_set_clima(orc_t *o, int flags) { o->clima_flags = flags; }
 void orc_set_prsgrd(orc_t *o, int scheme) { o->prs_scheme = scheme; }
 void orc_set_ddmix(orc_t *o, int on) { o->ddmix = on != 0; }
+void orc_set_bkpp(orc_t *o, int on) { o->bkpp = on != 0; }
 
 static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
 
@@ -142,7 +143,7 @@ static const fdesc fields[] = {
   FD(Akv, KW), FD(Akt, KWxNAT), FD(visc2_r, K2), FD(visc2_p, K2), FD(diff2, K2xNT), FD(visc4_r, K2), FD(visc4_p, K2), FD(diff4, K2xNT),
   FD(tclm, KRxNT), FD(Tnudgcof, KRxNT), FD(uclm, KR), FD(vclm, KR), FD(M3nudgcof, KR),
   FD(ubarclm, K2), FD(vbarclm, K2), FD(M2nudgcof, K2),
-  FD(bvf, KW), FD(alpha, K2), FD(beta, K2), FD(hsbl, K2), FD(ghats, KWxNAT), FD(alfaobeta, KW),
+  FD(bvf, KW), FD(alpha, K2), FD(beta, K2), FD(hsbl, K2), FD(hbbl, K2), FD(ghats, KWxNAT), FD(alfaobeta, KW),
   FD(tke, KWx3), FD(gls, KWx3), FD(Lscale, KW), FD(Akk, KW), FD(Akp, KW),
   FD(sc_r, KTAB_R), FD(Cs_r, KTAB_R), FD(sc_w, KTAB_W), FD(Cs_w, KTAB_W),
   FD(zeta_west, KBJ), FD(zeta_east, KBJ), FD(zeta_south, KBI), FD(zeta_north, KBI),
@@ -196,6 +197,7 @@ orc_t *orc_create(const orc_cfg *cfg) {
   for (size_t k = 0; k < o->nij; k++) o->rmask[k] = o->umask[k] = o->vmask[k] = o->pmask[k] = 1.0;   /* all water */
   for (size_t k = 0; k < o->nij; k++) o->rmask_wet[k] = o->umask_wet[k] = o->vmask_wet[k] = o->pmask_wet[k] = 0.0;   /* IniVal, mod_grid.F:1428-1431 */
   o->ksbl = (int *)calloc(o->nij, sizeof(int));
+  o->kbbl = (int *)calloc(o->nij, sizeof(int));
   /* the stepping indices of a state nobody has stepped yet: all 1 (what roms_hip_create sets); every routine checks
      them on entry (ORC_LOCALS -> orc_check_step), so a caller that forgot one reads a defined time level */
   o->s.iif = 1; o->s.indx1 = 1; o->s.kstp = o->s.krhs = o->s.knew = 1; o->s.nstp = o->s.nrhs = o->s.nnew = 1;
@@ -208,6 +210,7 @@ void orc_destroy(orc_t *o) {
   orc_avg_free(o);
   orc_dia_free(o);
   free(o->ksbl);
+  free(o->kbbl);
   free(o->b);
   free(o);
 }

@@ -373,6 +373,198 @@ static void lmd_skpp(orc_t *o, const orc_bounds *b) {
   free(Rref);
 }
 
+/* lmd_bkpp_tile (lmd_bkpp.F:95-806; LMD_BKPP, round 6): the bottom boundary layer of the K-profile scheme, behind lmd_skpp
+   (lmd_vmix.F:86-88).  RI_SPLINES, SASHA (the file defines it for itself, lmd_bkpp.F:3), no LMD_SHAPIRO -- the sub-options of the applications the
+   oracle is pinned to.
+   hbbl of the previous step gives the first guess of the layer's Monin-Obukhov fraction (:244); the scratch planes wm, ws are
+   overwritten level by level as in the reference. */
+static void lmd_bkpp(orc_t *o, const orc_bounds *b) {
+  ORC_LOCALS(o);
+  const int msk = (o->c.options & ORC_MASKING) != 0;
+  const int nstp = o->s.nstp;
+  const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
+  const double eps = 1.0E-10, g = o->c.g, gorho0 = o->c.g / o->c.rho0;
+  double *z_w = o->z_w, *Hz = o->Hz, *u = o->u, *v = o->v, *pden = o->pden, *bvf = o->bvf;
+  double *Akv = o->Akv, *Akt = o->Akt, *hbbl = o->hbbl;
+  double *btflx = o->btflx, *srflx = o->srflx, *bustr = o->bustr, *bvstr = o->bvstr;
+  int *kbbl = o->kbbl, *ksbl = o->ksbl;
+  const size_t cs = ni * (size_t)(N + 1);
+  double *FC = (double *)calloc(4 * cs, sizeof(double)), *dR = FC + cs, *dU = FC + 2 * cs, *dV = FC + 3 * cs;
+  double *Bflux = (double *)calloc(nij * (size_t)(N + 1), sizeof(double));
+  double *S = (double *)calloc(17 * nij, sizeof(double));
+  double *Bo = S, *Bosol = S + nij, *Bfbot = S + 2 * nij, *Gm1 = S + 3 * nij, *Gt1 = S + 4 * nij, *Gs1 = S + 5 * nij,
+         *Ustar = S + 6 * nij, *dGm1dS = S + 7 * nij, *dGt1dS = S + 8 * nij, *dGs1dS = S + 9 * nij, *f1 = S + 10 * nij,
+         *bl_dpth = S + 11 * nij, *swdk = S + 12 * nij, *wm = S + 13 * nij, *ws = S + 14 * nij, *zgrid = S + 15 * nij;
+  double *Rref = (double *)calloc(3 * ni, sizeof(double)), *Uref = Rref + ni, *Vref = Rref + 2 * ni;
+  const double Vtc = lmd_Cv * sqrt(-lmd_betaT) / (sqrt(lmd_cs * lmd_epsilon) * lmd_Ric * vonKar * vonKar);   /* :234 */
+  double cff, cff1, cff2;
+
+  for (int j = Jstr; j <= Jend; j++)
+    for (int i = Istr; i <= Iend; i++) bl_dpth[X2(i, j)] = lmd_epsilon * (hbbl[X2(i, j)] - z_w[XW(i, j, 0)]);     /* :244 */
+  for (int j = Jstr; j <= Jend; j++)
+    for (int i = Istr; i <= Iend; i++) {                                                                        /* :256 */
+      const double a = 0.5 * (bustr[X2(i, j)] + bustr[X2(i + 1, j)]), c = 0.5 * (bvstr[X2(i, j)] + bvstr[X2(i, j + 1)]);
+      Ustar[X2(i, j)] = sqrt(sqrt(a * a + c * c));
+      if (msk) Ustar[X2(i, j)] = Ustar[X2(i, j)] * o->rmask[X2(i, j)];
+    }
+  for (int j = Jstr; j <= Jend; j++)
+    for (int i = Istr; i <= Iend; i++) {                                                                        /* :273 (SALINITY) */
+      Bo[X2(i, j)] = g * (o->alpha[X2(i, j)] * btflx[X2T(i, j, 1)] - o->beta[X2(i, j)] * btflx[X2T(i, j, 2)]);
+      Bosol[X2(i, j)] = g * o->alpha[X2(i, j)] * srflx[X2(i, j)];
+    }
+  for (int k = 0; k <= N; k++) {                                                                                /* :285-303 */
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) zgrid[X2(i, j)] = z_w[XW(i, j, N)] - z_w[XW(i, j, k)];
+    orc_lmd_swfrac(o, b, -1.0, zgrid, swdk);
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++) {
+        Bflux[XW(i, j, k)] = (Bo[X2(i, j)] + Bosol[X2(i, j)] * (1.0 - swdk[X2(i, j)]));
+        if (msk) Bflux[XW(i, j, k)] = Bflux[XW(i, j, k)] * o->rmask[X2(i, j)];
+      }
+  }
+  /* bulk Richardson number and the depth of the layer :308-502 */
+  for (int j = Jstr; j <= Jend; j++) {
+    col_splines(o, j, Istr, Iend, pden, nstp, FC, dR, dU, dV);
+    cff1 = 1.0 / 3.0;
+    cff2 = 1.0 / 6.0;
+    for (int i = Istr; i <= Iend; i++) {                                                                        /* :410-417 */
+      Rref[i - LBi] = pden[X3(i, j, 1)] - Hz[X3(i, j, 1)] * (cff1 * CX(dR, i, 0) + cff2 * CX(dR, i, 1));
+      Uref[i - LBi] = 0.5 * (u[X4(i, j, 1, nstp)] + u[X4(i + 1, j, 1, nstp)]) -
+                      Hz[X3(i, j, 1)] * (cff1 * CX(dU, i, 0) + cff2 * CX(dU, i, 1));
+      Vref[i - LBi] = 0.5 * (v[X4(i, j, 1, nstp)] + v[X4(i, j + 1, 1, nstp)]) -
+                      Hz[X3(i, j, 1)] * (cff1 * CX(dV, i, 0) + cff2 * CX(dV, i, 1));
+    }
+    for (int i = Istr; i <= Iend; i++) {
+      CX(FC, i, 0) = 0.0;
+      for (int k = 1; k <= N; k++) {                                                                            /* :424-466 */
+        const double depth = z_w[XW(i, j, k)] - z_w[XW(i, j, 0)];
+        double sigma;
+        if (Bflux[XW(i, j, k)] < 0.0) sigma = MIN(bl_dpth[X2(i, j)], depth);
+        else sigma = depth;
+        const double Us = Ustar[X2(i, j)];
+        const double Ustar3 = Us * Us * Us;
+        const double zetahat = vonKar * sigma * Bflux[XW(i, j, k)];
+        wscale(Us, zetahat, Ustar3, &wm[X2(i, j)], &ws[X2(i, j)]);
+        const double Rk = pden[X3(i, j, k)] + Hz[X3(i, j, k)] * (cff1 * CX(dR, i, k) + cff2 * CX(dR, i, k - 1));
+        const double Uk = 0.5 * (u[X4(i, j, k, nstp)] + u[X4(i + 1, j, k, nstp)]) +
+                          Hz[X3(i, j, k)] * (cff1 * CX(dU, i, k) + cff2 * CX(dU, i, k - 1));
+        const double Vk = 0.5 * (v[X4(i, j, k, nstp)] + v[X4(i, j + 1, k, nstp)]) +
+                          Hz[X3(i, j, k)] * (cff1 * CX(dV, i, k) + cff2 * CX(dV, i, k - 1));
+        const double Ritop = -gorho0 * (Rk - Rref[i - LBi]) * depth;
+        const double Ribot = (Uk - Uref[i - LBi]) * (Uk - Uref[i - LBi]) + (Vk - Vref[i - LBi]) * (Vk - Vref[i - LBi]) +
+                             Vtc * depth * ws[X2(i, j)] * sqrt(fabs(bvf[XW(i, j, k)]));
+        CX(FC, i, k) = Ritop - lmd_Ric * Ribot;                                                                 /* SASHA (defined at lmd_bkpp.F:3) :460 */
+      }
+    }
+    for (int i = Istr; i <= Iend; i++) {
+      kbbl[X2(i, j)] = N;
+      hbbl[X2(i, j)] = z_w[XW(i, j, N)];
+    }
+    for (int k = 1; k <= N - 1; k++)                                                                            /* SASHA :474-482 */
+      for (int i = Istr; i <= Iend; i++)
+        if (kbbl[X2(i, j)] == N && CX(FC, i, k) > 0.0) {
+          hbbl[X2(i, j)] = (z_w[XW(i, j, k)] * CX(FC, i, k - 1) - z_w[XW(i, j, k - 1)] * CX(FC, i, k)) / (CX(FC, i, k - 1) - CX(FC, i, k));
+          kbbl[X2(i, j)] = k;
+        }
+  }
+  /* (Bfbot at this depth, :501-523, is computed and not used before it is computed again at :600-622) */
+  for (int j = Jstr; j <= Jend; j++)
+    for (int i = Istr; i <= Iend; i++) {                                                                        /* :525-538 */
+      if (Ustar[X2(i, j)] >= 0.0) {
+        const double hekman = lmd_cekman * Ustar[X2(i, j)] / MAX(fabs(o->f[X2(i, j)]), eps) - o->h[X2(i, j)];
+        hbbl[X2(i, j)] = MIN(hekman, hbbl[X2(i, j)]);
+      }
+      hbbl[X2(i, j)] = MIN(hbbl[X2(i, j)], z_w[XW(i, j, N)]);
+      hbbl[X2(i, j)] = MAX(hbbl[X2(i, j)], z_w[XW(i, j, 0)]);
+      if (msk) hbbl[X2(i, j)] = hbbl[X2(i, j)] * o->rmask[X2(i, j)];
+    }
+  orc_bc_r2d(o, b, hbbl);                                                                                       /* :577 */
+  for (int j = Jstr; j <= Jend; j++)
+    for (int i = Istr; i <= Iend; i++) {                                                                        /* :589-598 */
+      kbbl[X2(i, j)] = N;
+      for (int k = 1; k <= N; k++)
+        if (kbbl[X2(i, j)] == N && z_w[XW(i, j, k)] > hbbl[X2(i, j)]) kbbl[X2(i, j)] = k;
+    }
+  for (int j = Jstr; j <= Jend; j++)
+    for (int i = Istr; i <= Iend; i++) {                                                                        /* :604-610 */
+      zgrid[X2(i, j)] = z_w[XW(i, j, N)] - hbbl[X2(i, j)];
+      if (msk) zgrid[X2(i, j)] = zgrid[X2(i, j)] * o->rmask[X2(i, j)];
+    }
+  orc_lmd_swfrac(o, b, -1.0, zgrid, swdk);
+  for (int j = Jstr; j <= Jend; j++)
+    for (int i = Istr; i <= Iend; i++) {
+      Bfbot[X2(i, j)] = (Bo[X2(i, j)] + Bosol[X2(i, j)] * (1.0 - swdk[X2(i, j)]));
+      if (msk) Bfbot[X2(i, j)] = Bfbot[X2(i, j)] * o->rmask[X2(i, j)];
+    }
+  for (int j = Jstr; j <= Jend; j++)
+    for (int i = Istr; i <= Iend; i++) {                                                                        /* :632-662 */
+      bl_dpth[X2(i, j)] = lmd_epsilon * (hbbl[X2(i, j)] - z_w[XW(i, j, 0)]);
+      cff = Bfbot[X2(i, j)] > 0.0 ? 1.0 : lmd_epsilon;
+      const double sigma = cff * (hbbl[X2(i, j)] - z_w[XW(i, j, 0)]);
+      const double Us = Ustar[X2(i, j)];
+      const double Ustar3 = Us * Us * Us;
+      const double zetahat = vonKar * sigma * Bfbot[X2(i, j)];
+      wscale(Us, zetahat, Ustar3, &wm[X2(i, j)], &ws[X2(i, j)]);
+    }
+  for (int j = Jstr; j <= Jend; j++)
+    for (int i = Istr; i <= Iend; i++) {                                                                        /* :672-677 */
+      const double Us = Ustar[X2(i, j)];
+      f1[X2(i, j)] = 5.0 * MAX(0.0, Bfbot[X2(i, j)]) * vonKar / (Us * Us * Us * Us + eps);
+    }
+  for (int j = Jstr; j <= Jend; j++)
+    for (int i = Istr; i <= Iend; i++) {                                                                        /* :679-722 */
+      const double zbl = hbbl[X2(i, j)] - z_w[XW(i, j, 0)];
+      const int k = kbbl[X2(i, j)];
+      cff = 1.0 / (z_w[XW(i, j, k)] - z_w[XW(i, j, k - 1)]);
+      const double cff_dn = cff * (hbbl[X2(i, j)] - z_w[XW(i, j, k - 1)]);
+      const double cff_up = cff * (z_w[XW(i, j, k)] - hbbl[X2(i, j)]);
+      double K_bl = cff_dn * Akv[XW(i, j, k)] + cff_up * Akv[XW(i, j, k - 1)];
+      double dK_bl = -cff * (Akv[XW(i, j, k)] - Akv[XW(i, j, k - 1)]);
+      Gm1[X2(i, j)] = K_bl / (zbl * wm[X2(i, j)] + eps);
+      if (msk) Gm1[X2(i, j)] = Gm1[X2(i, j)] * o->rmask[X2(i, j)];
+      dGm1dS[X2(i, j)] = MIN(0.0, K_bl * f1[X2(i, j)] - dK_bl / (wm[X2(i, j)] + eps));
+      K_bl = cff_dn * Akt[XW4(i, j, k, 1)] + cff_up * Akt[XW4(i, j, k - 1, 1)];
+      dK_bl = -cff * (Akt[XW4(i, j, k, 1)] - Akt[XW4(i, j, k - 1, 1)]);
+      Gt1[X2(i, j)] = K_bl / (zbl * ws[X2(i, j)] + eps);
+      if (msk) Gt1[X2(i, j)] = Gt1[X2(i, j)] * o->rmask[X2(i, j)];
+      dGt1dS[X2(i, j)] = MIN(0.0, K_bl * f1[X2(i, j)] - dK_bl / (ws[X2(i, j)] + eps));
+      K_bl = cff_dn * Akt[XW4(i, j, k, 2)] + cff_up * Akt[XW4(i, j, k - 1, 2)];
+      dK_bl = -cff * (Akt[XW4(i, j, k, 2)] - Akt[XW4(i, j, k - 1, 2)]);
+      Gs1[X2(i, j)] = K_bl / (zbl * ws[X2(i, j)] + eps);
+      if (msk) Gs1[X2(i, j)] = Gs1[X2(i, j)] * o->rmask[X2(i, j)];
+      dGs1dS[X2(i, j)] = MIN(0.0, K_bl * f1[X2(i, j)] - dK_bl / (ws[X2(i, j)] + eps));
+    }
+  for (int k = 1; k <= N - 1; k++)                                                                              /* :728-800 */
+    for (int j = Jstr; j <= Jend; j++)
+      for (int i = Istr; i <= Iend; i++)
+        if (z_w[XW(i, j, k)] < hbbl[X2(i, j)]) {
+          const double depth = z_w[XW(i, j, k)] - z_w[XW(i, j, 0)];
+          double sigma;
+          if (Bflux[XW(i, j, k)] < 0.0) sigma = MIN(bl_dpth[X2(i, j)], depth);
+          else sigma = depth;
+          const double Us = Ustar[X2(i, j)];
+          const double Ustar3 = Us * Us * Us;
+          const double zetahat = vonKar * sigma * Bflux[XW(i, j, k)];
+          wscale(Us, zetahat, Ustar3, &wm[X2(i, j)], &ws[X2(i, j)]);
+          sigma = depth / (hbbl[X2(i, j)] - z_w[XW(i, j, 0)] + eps);
+          if (msk) sigma = sigma * o->rmask[X2(i, j)];
+          const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
+          const double Gm = a1 + a2 * Gm1[X2(i, j)] + a3 * dGm1dS[X2(i, j)];
+          const double Gt = a1 + a2 * Gt1[X2(i, j)] + a3 * dGt1dS[X2(i, j)];
+          const double Gs = a1 + a2 * Gs1[X2(i, j)] + a3 * dGs1dS[X2(i, j)];
+          if (k > ksbl[X2(i, j)]) {
+            Akv[XW(i, j, k)] = MAX(Akv[XW(i, j, k)], depth * wm[X2(i, j)] * (1.0 + sigma * Gm));
+            Akt[XW4(i, j, k, 1)] = MAX(Akt[XW4(i, j, k, 1)], depth * ws[X2(i, j)] * (1.0 + sigma * Gt));
+            Akt[XW4(i, j, k, 2)] = MAX(Akt[XW4(i, j, k, 2)], depth * ws[X2(i, j)] * (1.0 + sigma * Gs));
+          } else {
+            Akv[XW(i, j, k)] = depth * wm[X2(i, j)] * (1.0 + sigma * Gm);
+            Akt[XW4(i, j, k, 1)] = depth * ws[X2(i, j)] * (1.0 + sigma * Gt);
+            Akt[XW4(i, j, k, 2)] = depth * ws[X2(i, j)] * (1.0 + sigma * Gs);
+          }
+        }
+  free(FC); free(Bflux); free(S); free(Rref);
+}
+
 static void lmd_finish(orc_t *o, const orc_bounds *b) {
   ORC_LOCALS(o);
   const int Istr = b->Istr, Iend = b->Iend, Jstr = b->Jstr, Jend = b->Jend;
@@ -409,5 +601,6 @@ void orc_lmd_vmix(orc_t *o, int tile) {
   const orc_bounds *b = &o->b[tile];
   lmd_interior(o, b);
   lmd_skpp(o, b);
+  if (o->bkpp) lmd_bkpp(o, b);                      /* LMD_BKPP: lmd_vmix.F:86-88 */
   lmd_finish(o, b);
 }

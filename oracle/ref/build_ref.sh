@@ -55,6 +55,16 @@ if [ "$APP" = benchmark_wetdry_ddmix ]; then
   UP=BENCHMARK; HDR=benchmark_wetdry; HDRPATH="$HERE/benchmark_wetdry.h"
   EXTRA="-I$HERE/functionals -DLMD_DDMIX"
 fi
+if [ "$APP" = benchmark_bkpp ]; then
+  # the shipped benchmark.h with the bottom boundary layer of the K-profile scheme on top (LMD_BKPP: lmd_bkpp.F), round 6
+  UP=BENCHMARK; HDR=benchmark; HDRPATH="benchmark.h"
+  EXTRA="-DLMD_BKPP"
+fi
+if [ "$APP" = upwelling_kpp_bkpp ]; then
+  # ... and on UPWELLING with KPP (oracle/ref/upwelling_kpp.h: linear EOS, no surface heat flux)
+  UP=UPWELLING; HDR=upwelling_kpp; HDRPATH="$HERE/upwelling_kpp.h"
+  EXTRA="-DLMD_BKPP"
+fi
 if [ "$APP" = benchmark_ddmix ]; then
   # the shipped benchmark.h with LMD_DDMIX switched on as a user does (nonlinear EOS: alfaobeta of rho_eos.F:435-455)
   UP=BENCHMARK; HDR=benchmark; HDRPATH="benchmark.h"
@@ -196,7 +206,7 @@ if [ "$APP" = upwelling_avg ]; then
   EXTRA=""
 fi
 WORK=$(mktemp -d /tmp/romsref_${APP}_XXXX)
-trap 'rm -rf "$WORK"' EXIT
+[ -n "$KEEP_WORK" ] && echo "build_ref: keeping $WORK" || trap 'rm -rf "$WORK"' EXIT
 mkdir -p "$OUT"
 cd "$WORK"   # cpp must run from a writable cwd with absolute input paths
 

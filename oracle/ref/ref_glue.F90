@@ -1339,6 +1339,9 @@
 #ifdef GLS_MIXING
         F2('Akp',MIXING(ng)%Akp)
 #endif
+#ifdef LMD_BKPP
+        F2('hbbl',MIXING(ng)%hbbl)
+#endif
 #ifdef LMD_SKPP
         F2('hsbl',MIXING(ng)%hsbl)
         F2('ghats',MIXING(ng)%ghats)

@@ -143,6 +143,22 @@ def with_ddmix(cs):
     return cs
 
 
+def with_bkpp(cs):
+    """LMD_BKPP: the bottom boundary layer of the K-profile scheme behind lmd_skpp (lmd_bkpp.F) -- the reference builds
+    benchmark.h -DLMD_BKPP (nonlinear EOS, bulk fluxes, shortwave) and oracle/ref/upwelling_kpp.h -DLMD_BKPP (linear EOS)"""
+    cs["app"] = cs["app"] + "_bkpp"
+    cs["bkpp"] = 1
+    return cs
+
+
+def benchmark_bkpp(**kw):
+    return with_bkpp(benchmark(**kw))
+
+
+def upwelling_kpp_bkpp(**kw):
+    return with_bkpp(upwelling_kpp(**kw))
+
+
 def upwelling_kpp_ddmix(**kw):
     return with_ddmix(upwelling_kpp(**kw))
 
@@ -556,6 +572,8 @@ def hip_cfg(cs, hc, nfast, weight, sc_r, Cs_r, sc_w, Cs_w, device=0):
         opt |= hiplib.OPTIONS["MIX_GEO_UV"]
     if cs.get("ddmix"):     # LMD_DDMIX
         opt |= hiplib.OPTIONS["LMD_DDMIX"]
+    if cs.get("bkpp"):      # LMD_BKPP
+        opt |= hiplib.OPTIONS["LMD_BKPP"]
     if cs.get("prsgrd"):    # PJ_GRADPQ2 / PJ_GRADPQ4
         opt |= hiplib.OPTIONS["PRSGRD%d" % cs["prsgrd"]]
     if cs.get("clima"):     # climatology nudging: bit 0 the 3-D momentum, bit itrc tracer itrc

@@ -123,7 +123,8 @@ int run_lmd_vmix(roms_hip_ctx *c) {
   const size_t blk_lds = (size_t)(4 * (N + 1) + LMD_BLK_NS) * 64 * sizeof(double);
   static const char *eblk = getenv("ROMS_HIP_LMDBLK");             // (0: the forms of round 4)
   const bool blk_ok = !(eblk && eblk[0] == '0') && (!c->late_pre || c->kpp_col_ok) && G.region == 0 && blk_lds <= 160 * 1024;
-  const int form = elc ? atoi(elc) : (blk_ok ? 3 : (((!c->late_pre || c->kpp_col_ok) && fits) ? 1 : 0));
+  int form = elc ? atoi(elc) : (blk_ok ? 3 : (((!c->late_pre || c->kpp_col_ok) && fits) ? 1 : 0));
+  if (G.bkpp) form = 0;      // LMD_BKPP: the two THREAD kernels leave Akv, Akt without lmd_finish and the spline columns in the work arrays for k_lmd_bkpp
   if (form == 3 && G.region == 0 && blk_lds <= 160 * 1024) {        // the block form (k_lmd.h: k_lmd_blk): 64 columns per block of 512 threads
     const size_t ldsd = (size_t)(4 * (N + 1) + LMD_BLK_NS) * 64;
 #ifndef ROMS_CPU_EMU
@@ -147,8 +148,15 @@ int run_lmd_vmix(roms_hip_ctx *c) {
     LAUNCH_THREAD(k_lmd_interior, nx, ny, 1, c->stream, a);
     LAUNCH_THREAD(k_lmd_skpp, nx, ny, 1, c->stream, a);
   }
+  if (G.bkpp) LAUNCH_THREAD(k_lmd_bkpp, nx, ny, 1, c->stream, a);    // lmd_bkpp_tile + lmd_finish (lmd_vmix.F:86-90)
   // (lmd_finish: fused into k_lmd_skpp's last sweep)
   if (G.fuse3d) return 0;   // k_lmd_skpp stored the boundary values and images (emit_store)
+  if (G.bkpp) {
+    HaloSpec sb[4] = {{c->F.hsbl, 1, BC_R, 'r'}, {c->F.hbbl, 1, BC_R, 'r'},        // bc_r2d_tile lmd_skpp.F:608, lmd_bkpp.F:577
+                      {c->F.Akv, N + 1, BC_R, 'r'}, {c->F.Akt, (N + 1) * G.NAT, BC_R, 'r'}};
+    launch_halo_tail(c, sb, 4);
+    return 0;
+  }
   HaloSpec sp[3] = {{c->F.hsbl, 1, BC_R, 'r'},                       // bc_r2d_tile lmd_skpp.F:608
                     {c->F.Akv, N + 1, BC_R, 'r'},                    // bc_w3d_tile lmd_vmix.F:740-760
                     {c->F.Akt, (N + 1) * G.NAT, BC_R, 'r'}};

@@ -427,6 +427,10 @@ KDEV void lmd_skpp_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
         F.ghats[ow + x_] = 0.0;
         F.ghats[ow + x_ + oA_] = 0.0;
       }
+      if (G.bkpp) {     // LMD_BKPP: lmd_bkpp works on these values; k_lmd_bkpp applies lmd_finish behind it
+        F.Akv[ow + x_] = akv; F.Akt[ow + x_] = akt1; F.Akt[ow + x_ + oA_] = akt2;
+        continue;
+      }
       // lmd_finish :500-540
       double cff = KMAX(bv[q], lmd_bvfcon);
       cff = KMIN(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
@@ -437,7 +441,159 @@ KDEV void lmd_skpp_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
       emit_store(G, PA, F.Akt + ow + oA_, akt2 + lmd_nu0c * nu_sxc);
     }
   }
+  if (G.bkpp) F.ksbl[x_] = (double)ksbl;        // MIXING(ng)%ksbl for lmd_bkpp.F:779
 }
+
+// ---- LMD_BKPP (round 6): the bottom boundary layer, lmd_bkpp_tile (lmd_bkpp.F:95-806), one thread per column, behind
+// k_lmd_interior + k_lmd_skpp (lmd_vmix.F:86-88) and in front of lmd_finish, which this kernel applies as its last operation on
+// every level (as k_lmd_skpp does without LMD_BKPP).  RI_SPLINES, SASHA (lmd_bkpp.F:3 defines it for the file), no LMD_SHAPIRO.
+// The spline derivatives dR, dU, dV of the column are those k_lmd_interior / k_lmd_skpp left in the work arrays (the same
+// recurrences on the same density and velocities, lmd_bkpp.F:311-348); FC is rebuilt as the critical function; the buoyancy
+// flux profile (its own Bo: the bottom tracer fluxes, :273) is a function of z_w and is evaluated where the reference reads it.
+KDEV void lmd_bkpp_col(const LmdArgs &a, int i, int j, const LmdWk &w) {
+  const DGrid &G = a.G;
+  const Fields &F = a.Fv;
+  LMD_CONSTS;
+  const int N = G.N;
+  const double eps = 1.0E-10, g = G.g, gorho0 = G.g / G.rho0;
+  const double *z_w = F.z_w, *Hz = F.Hz, *pden = F.pden, *bvf = F.bvf;
+  const double *u = F.u + (size_t)(G.nstp - 1) * G.nij * N, *v = F.v + (size_t)(G.nstp - 1) * G.nij * N;
+  double *FC = w.FC, *dR = w.dR, *dU = w.dU, *dV = w.dV;
+  const size_t nij_ = (size_t)G.nij, x_ = X2(i, j), oA_ = nij_ * (size_t)(N + 1);
+  const double zwN = z_w[XW(i, j, N)], zw0 = z_w[XW(i, j, 0)];
+  double hbbl = F.hbbl[x_];
+  double bl_dpth = lmd_epsilon * (hbbl - zw0);                                     // :244
+  const bool msk = G.masking != 0;
+  const double rm = msk ? F.rmask[x_] : 1.0;
+  double Ustar;
+  {
+    const double ba = 0.5 * (F.bustr[X2(i, j)] + F.bustr[X2(i + 1, j)]), bc = 0.5 * (F.bvstr[X2(i, j)] + F.bvstr[X2(i, j + 1)]);
+    Ustar = sqrt(sqrt(ba * ba + bc * bc));                                         // :256
+    if (msk) Ustar = Ustar * rm;
+  }
+  const double Bo = g * (F.alpha[x_] * F.btflx[X2T(i, j, 1)] - F.beta[x_] * F.btflx[X2T(i, j, 2)]);    // :273
+  const double Bosol = g * F.alpha[x_] * F.srflx[x_];
+#define BKPP_BFLUX(k_, out_) { double bf_ = (Bo + Bosol * (1.0 - SWFRAC(zwN - z_w[XW(i, j, k_)]))); if (msk) bf_ = bf_ * rm; out_ = bf_; }   /* :285-303 */
+  const double c13 = 1.0 / 3.0, c16 = 1.0 / 6.0;
+  const double Rref = pden[X3(i, j, 1)] - Hz[X3(i, j, 1)] * (c13 * dR[WKI(0)] + c16 * dR[WKI(1)]);      // :410-417
+  const double Uref = 0.5 * (u[X3(i, j, 1)] + u[X3(i + 1, j, 1)]) - Hz[X3(i, j, 1)] * (c13 * dU[WKI(0)] + c16 * dU[WKI(1)]);
+  const double Vref = 0.5 * (v[X3(i, j, 1)] + v[X3(i, j + 1, 1)]) - Hz[X3(i, j, 1)] * (c13 * dV[WKI(0)] + c16 * dV[WKI(1)]);
+  const double Ustar3 = Ustar * Ustar * Ustar;
+  double wm = 0.0, ws = 0.0;
+  FC[WKI(0)] = 0.0;
+  for (int k = 1; k <= N; k++) {                                                   // :424-466
+    const double depth = z_w[XW(i, j, k)] - zw0;
+    double bf;
+    BKPP_BFLUX(k, bf);
+    const double sigma = (bf < 0.0) ? KMIN(bl_dpth, depth) : depth;
+    const double zetahat = vonKar * sigma * bf;
+    lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+    const double hz = Hz[X3(i, j, k)];
+    const double Rk = pden[X3(i, j, k)] + hz * (c13 * dR[WKI(k)] + c16 * dR[WKI(k - 1)]);
+    const double Uk = 0.5 * (u[X3(i, j, k)] + u[X3(i + 1, j, k)]) + hz * (c13 * dU[WKI(k)] + c16 * dU[WKI(k - 1)]);
+    const double Vk = 0.5 * (v[X3(i, j, k)] + v[X3(i, j + 1, k)]) + hz * (c13 * dV[WKI(k)] + c16 * dV[WKI(k - 1)]);
+    const double Ritop = -gorho0 * (Rk - Rref) * depth;
+    const double du_ = Uk - Uref, dv_ = Vk - Vref;
+    const double Ribot = du_ * du_ + dv_ * dv_ + a.Vtc * depth * ws * sqrt(fabs(bvf[XW(i, j, k)]));
+    FC[WKI(k)] = Ritop - lmd_Ric * Ribot;                                          // SASHA :460
+  }
+  int kbbl = N;
+  hbbl = zwN;
+  for (int k = 1; k <= N - 1; k++) {                                               // SASHA :474-482
+    const double fk = FC[WKI(k)];
+    if (kbbl == N && fk > 0.0) {
+      const double fkm = FC[WKI(k - 1)];
+      hbbl = (z_w[XW(i, j, k)] * fkm - z_w[XW(i, j, k - 1)] * fk) / (fkm - fk);
+      kbbl = k;
+    }
+  }
+  if (Ustar >= 0.0) {                                                              // :525-538
+    const double hekman = lmd_cekman * Ustar / KMAX(fabs(F.f[x_]), eps) - F.h[x_];
+    hbbl = KMIN(hekman, hbbl);
+  }
+  hbbl = KMIN(hbbl, zwN);
+  hbbl = KMAX(hbbl, zw0);
+  if (msk) hbbl = hbbl * rm;
+  F.hbbl[x_] = hbbl;                                                               // (bc_r2d_tile :577: the halo launch behind)
+  kbbl = N;
+  for (int k = 1; k <= N; k++)                                                     // :589-598
+    if (kbbl == N && z_w[XW(i, j, k)] > hbbl) kbbl = k;
+  double Bfbot = (Bo + Bosol * (1.0 - SWFRAC(msk ? (zwN - hbbl) * rm : zwN - hbbl)));   // :604-622
+  if (msk) Bfbot = Bfbot * rm;
+  bl_dpth = lmd_epsilon * (hbbl - zw0);                                            // :632-662
+  {
+    const double cff = (Bfbot > 0.0) ? 1.0 : lmd_epsilon;
+    const double sigma = cff * (hbbl - zw0);
+    const double zetahat = vonKar * sigma * Bfbot;
+    lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+  }
+  const double f1 = 5.0 * KMAX(0.0, Bfbot) * vonKar / (Ustar * Ustar * Ustar * Ustar + eps);   // :672-677
+  const double zbl = hbbl - zw0;
+  double Gm1, Gt1, Gs1, dGm1dS, dGt1dS, dGs1dS;
+  {                                                                                // :679-722
+    const int k = kbbl;
+    const double cff = 1.0 / (z_w[XW(i, j, k)] - z_w[XW(i, j, k - 1)]);
+    const double cff_dn = cff * (hbbl - z_w[XW(i, j, k - 1)]);
+    const double cff_up = cff * (z_w[XW(i, j, k)] - hbbl);
+    double K_bl = cff_dn * F.Akv[XW(i, j, k)] + cff_up * F.Akv[XW(i, j, k - 1)];
+    double dK_bl = -cff * (F.Akv[XW(i, j, k)] - F.Akv[XW(i, j, k - 1)]);
+    Gm1 = K_bl / (zbl * wm + eps);
+    if (msk) Gm1 = Gm1 * rm;
+    dGm1dS = KMIN(0.0, K_bl * f1 - dK_bl / (wm + eps));
+    K_bl = cff_dn * F.Akt[XW4(i, j, k, 1)] + cff_up * F.Akt[XW4(i, j, k - 1, 1)];
+    dK_bl = -cff * (F.Akt[XW4(i, j, k, 1)] - F.Akt[XW4(i, j, k - 1, 1)]);
+    Gt1 = K_bl / (zbl * ws + eps);
+    if (msk) Gt1 = Gt1 * rm;
+    dGt1dS = KMIN(0.0, K_bl * f1 - dK_bl / (ws + eps));
+    K_bl = cff_dn * F.Akt[XW4(i, j, k, 2)] + cff_up * F.Akt[XW4(i, j, k - 1, 2)];
+    dK_bl = -cff * (F.Akt[XW4(i, j, k, 2)] - F.Akt[XW4(i, j, k - 1, 2)]);
+    Gs1 = K_bl / (zbl * ws + eps);
+    if (msk) Gs1 = Gs1 * rm;
+    dGs1dS = KMIN(0.0, K_bl * f1 - dK_bl / (ws + eps));
+  }
+  const int ksbl = (int)F.ksbl[x_];
+  const EmitPlan PA = emit_plan(G, BC_R, i, j);
+  for (int k = 1; k <= N - 1; k++) {                                               // :728-800, then lmd_finish
+    const size_t ow = (size_t)k * nij_;
+    const double zwk = z_w[ow + x_];
+    double akv = F.Akv[ow + x_], akt1 = F.Akt[ow + x_], akt2 = F.Akt[ow + x_ + oA_];
+    if (zwk < hbbl) {
+      const double depth = zwk - zw0;
+      double bf;
+      BKPP_BFLUX(k, bf);
+      double sigma = (bf < 0.0) ? KMIN(bl_dpth, depth) : depth;
+      const double zetahat = vonKar * sigma * bf;
+      lmd_wscale(Ustar, zetahat, Ustar3, wm, ws);
+      sigma = depth / (hbbl - zw0 + eps);
+      if (msk) sigma = sigma * rm;
+      const double a1 = sigma - 2.0, a2 = 3.0 - 2.0 * sigma, a3 = sigma - 1.0;
+      const double Gm = a1 + a2 * Gm1 + a3 * dGm1dS;
+      const double Gt = a1 + a2 * Gt1 + a3 * dGt1dS;
+      const double Gs = a1 + a2 * Gs1 + a3 * dGs1dS;
+      const double kv = depth * wm * (1.0 + sigma * Gm), kt = depth * ws * (1.0 + sigma * Gt), ks_ = depth * ws * (1.0 + sigma * Gs);
+      if (k > ksbl) { akv = KMAX(akv, kv); akt1 = KMAX(akt1, kt); akt2 = KMAX(akt2, ks_); }
+      else { akv = kv; akt1 = kt; akt2 = ks_; }
+    }
+    // lmd_finish (lmd_vmix.F:500-540)
+    double cff = KMAX(bvf[ow + x_], lmd_bvfcon);
+    cff = KMIN(1.0, (lmd_bvfcon - cff) / lmd_bvfcon);
+    double nu_sxc = 1.0 - cff * cff;
+    nu_sxc = nu_sxc * nu_sxc * nu_sxc;
+    emit_store(G, PA, F.Akv + ow, akv + lmd_nu0c * nu_sxc);
+    emit_store(G, PA, F.Akt + ow, akt1 + lmd_nu0c * nu_sxc);
+    emit_store(G, PA, F.Akt + ow + oA_, akt2 + lmd_nu0c * nu_sxc);
+  }
+#undef BKPP_BFLUX
+}
+THREAD_KERNEL(k_lmd_bkpp, LmdArgs) {
+  (void)gz;
+  const DGrid &G = a.G;
+  const int i = G.T.Istr + gx, j = G.T.Jstr + gy;
+  const LmdWk w = {a.Fv.wrk3[1], a.Fv.wrk3[2], a.Fv.wrk3[3], a.Fv.wrk3[4], (size_t)G.nij, X2(i, j)};
+  lmd_bkpp_col(a, i, j, w);
+}
+THREAD_GLOBAL(k_lmd_bkpp, LmdArgs)
+
 THREAD_KERNEL(k_lmd_skpp, LmdArgs) {
   (void)gz;
   const DGrid &G = a.G;

@@ -92,6 +92,7 @@ struct DGrid {
   double *alfaobeta;   // ... the ratio of the thermal expansion and saline contraction coefficients (i,j,0:N) rho_eos leaves (rho_eos.F:454, :794)
   double *vcons;       // VolCons: {bc_area, bc_flux, ubar_xs} of mod_scalars.F:1460-1462 on the device (k_obc.h: k_obc_flux; k_step2d.h reads ubar_xs)
   int volcons;         // ... bits by edge (obc_volcons.F)
+  int bkpp;            // LMD_BKPP (option bit ROMS_LMD_BKPP): the bottom boundary layer behind lmd_skpp (k_lmd.h: k_lmd_bkpp, lmd_bkpp.F; Fields::hbbl, ksbl)
 };
 
 #ifdef ROMS_CPU_EMU
@@ -290,6 +291,7 @@ struct Fields {
   GPtr wd_eff;                         // umask*umask_wet | vmask*vmask_wet as step3d_uv finds them (2 planes; k_wd_eff)
   GPtr tclm, Tnudgcof, uclm, vclm, M3nudgcof;   // climatology and nudging coefficients (mod_clima.F): input like the forcing; tclm, Tnudgcof per tracer
   GPtr ubarclm, vbarclm, M2nudgcof;             // ... of the 2-D momentum (LnudgeM2CLM, round 6)
+  GPtr hbbl, ksbl;                              // LMD_BKPP: MIXING(ng)%hbbl; ksbl of lmd_skpp (as doubles) for lmd_bkpp.F:779
   GPtr gwrk;                           // the twenty 3-D work arrays of k_uvmix_geo.h (N+1 planes each; allocated with ROMS_MIX_GEO_UV)
   GPtr tmix;                           // harmonic tracer mixing as terms (N planes per tracer): t3dmix2 run ahead of pre_step3d stores
                                        // what it adds to t(nnew), k_pre_new adds it to the value it sets (allocated with TS_DIF2)

@@ -147,6 +147,7 @@ static const FieldDesc g_fields[] = {
     // climatology nudging (mod_clima.F; option bits ROMS_NUDGE_M3CLM, ROMS_NUDGE_TCLM): tclm, Tnudgcof hold N planes per tracer
     FD(tclm, FK_RxNT), FD(Tnudgcof, FK_RxNT), FD(uclm, FK_R), FD(vclm, FK_R), FD(M3nudgcof, FK_R),
     FD(ubarclm, FK_2D), FD(vbarclm, FK_2D), FD(M2nudgcof, FK_2D),
+    FD(hbbl, FK_2D), FD(ksbl, FK_2D),                                                   // LMD_BKPP (lmd_bkpp.F)
 };
 static const int g_nfields = (int)(sizeof(g_fields) / sizeof(g_fields[0]));
 
@@ -649,6 +650,15 @@ extern "C" int roms_hip_create(const roms_hip_config *cfg, roms_hip_ctx **out) {
     for (int it = 1; it <= c->G.NT; it++) if (cfg->options & ROMS_NUDGE_TCLM(it)) c->G.clima |= 1 << it;
     if (c->G.clima & 30) c->G.fuse3d = 0;
     if (c->G.clima & 32) { c->pair_on = step2d_pair_usable(c); c->loop_state = 0; }     // (LnudgeM2CLM: the per-call barotropic kernel)                    // (the nudging sits between t3dbc and the exchange: separate launches)
+  }
+  c->G.bkpp = 0;
+  if (cfg->options & ROMS_LMD_BKPP) {                       // lmd_bkpp.F (round 6)
+    if (!(cfg->options & ROMS_LMD_MIXING)) { set_error("LMD_BKPP without LMD_MIXING"); roms_hip_destroy(c); return 5; }
+    if (c->G.NT < 2 || !(cfg->options & ROMS_SALINITY)) { set_error("LMD_BKPP: built with salinity (the reference builds the oracle is pinned to)"); roms_hip_destroy(c); return 5; }
+    // (pinned: benchmark.h and upwelling_kpp.h with -DLMD_BKPP, one tile and 2x2; not with the options below)
+    if (cfg->options & (ROMS_MASKING | ROMS_WET_DRY | ROMS_LMD_DDMIX)) { set_error("LMD_BKPP together with MASKING, WET_DRY or LMD_DDMIX: not pinned against the reference, not built"); roms_hip_destroy(c); return 5; }
+    c->G.bkpp = 1;
+    c->G.fuse3d = 0;                                        // (hbbl's boundary values and the order skpp -> bkpp -> finish: separate launches)
   }
   c->G.volcons = 0; c->G.vcons = nullptr;
   if (cfg->volcons & 15) {                                   // VolCons: obc_volcons.F (round 6)

@@ -14,7 +14,7 @@ OPTIONS = {name: 1 << k for k, name in enumerate(
      "LMD_MIXING", "BULK_FLUXES", "SOLAR_SOURCE", "ANA_VMIX", "SALINITY", "SPHERICAL", "UV_LOGDRAG", "MASKING"])}
 OPTIONS.update(RADIATION_2D=1 << 16, PLAIN_VDIFF=1 << 17, PLAIN_VVISC=1 << 18, PRSGRD31=1 << 19, WJ_GRADP=1 << 27, APP_UPWELLING=1 << 20, APP_BENCHMARK=1 << 21, APP_KELVIN=1 << 22, APP_SEAMOUNT=1 << 23, APP_GRAV_ADJ=1 << 24, GLS_MIXING=1 << 25, PRSGRD40=1 << 26, MY25_MIXING=1 << 28, MIX_ISO_TS=1 << 29, APP_OVERFLOW=1 << 30,
                # the upper word (ABI version 4)
-               UV_VIS4=1 << 32, TS_DIF4=1 << 33, WET_DRY=1 << 34, DIAGNOSTICS_UV=1 << 35, MIX_GEO_UV=1 << 36, NUDGE_M3CLM=1 << 37, NUDGE_M2CLM=1 << 42, PRSGRD42=1 << 43, PRSGRD44=1 << 44, LMD_DDMIX=1 << 45,
+               UV_VIS4=1 << 32, TS_DIF4=1 << 33, WET_DRY=1 << 34, DIAGNOSTICS_UV=1 << 35, MIX_GEO_UV=1 << 36, NUDGE_M3CLM=1 << 37, NUDGE_M2CLM=1 << 42, PRSGRD42=1 << 43, PRSGRD44=1 << 44, LMD_DDMIX=1 << 45, LMD_BKPP=1 << 46,
                NUDGE_TCLM1=1 << 38, NUDGE_TCLM2=1 << 39, NUDGE_TCLM3=1 << 40, NUDGE_TCLM4=1 << 41)
 ABI_VERSION = 5
 # the compile-time forms of GLS_MIXING (roms_hip_config.gls_flags)

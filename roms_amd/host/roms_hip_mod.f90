@@ -27,6 +27,7 @@
      &   ROMS_MIX_GEO_UV = 68719476736_c_int64_t,                                                                        &
      &   ROMS_PRSGRD42 = 8796093022208_c_int64_t, ROMS_PRSGRD44 = 17592186044416_c_int64_t,                               &
      &   ROMS_LMD_DDMIX = 35184372088832_c_int64_t,                                                                      &
+     &   ROMS_LMD_BKPP = 70368744177664_c_int64_t,                                                                      &
      &   ROMS_NUDGE_M3CLM = 137438953472_c_int64_t, ROMS_NUDGE_TCLM1 = 274877906944_c_int64_t       ! (tracer itrc: ISHFT(ROMS_NUDGE_TCLM1, itrc-1))
       integer(c_int), parameter :: ROMS_GLS_CANUTO_A = 1, ROMS_GLS_CANUTO_B = 2, ROMS_GLS_KANTHA_CLAYSON = 4,              &
      &   ROMS_GLS_N2S2_HORAVG = 8, ROMS_GLS_RI_SPLINES = 16, ROMS_GLS_K_C2ADVECTION = 32, ROMS_GLS_K_C4ADVECTION = 64,     &

@@ -33,6 +33,7 @@
       real(dp) :: Dcrit = 0.10_dp              ! DCRIT of roms.in (WET_DRY; read_phypar.F:1021)
       logical :: wet_dry = .FALSE.
       logical :: ddmix = .FALSE.                ! LMD_DDMIX: double-diffusive mixing in lmd_vmix's interior scheme
+      logical :: bkpp = .FALSE.                 ! LMD_BKPP: the bottom boundary layer behind lmd_skpp (lmd_bkpp.F)
       integer :: prs4x = 0                      ! 44: PJ_GRADPQ4 (prsgrd44.h), 42: PJ_GRADPQ2 (prsgrd42.h), 0: the scheme in `options`
       logical :: mix_geo_uv = .FALSE.           ! UV_VIS2 along geopotential surfaces (MIX_GEO_UV: uv3dmix2_geo.h)
       real(dp) :: visc2 = 5.0_dp, tnu2(ROMS_MAXT) = 0.0_dp, Akt_bak(ROMS_MAXT) = 1.0E-6_dp, Akv_bak = 1.0E-5_dp
@@ -812,7 +813,7 @@
       SUBROUTINE builtin_defines (ierr)
       integer, intent(inout) :: ierr
       integer :: k, nl
-      logical :: with_ddmix
+      logical :: with_ddmix, with_bkpp
       character(len=16), parameter :: common(9) = [ character(len=16) :: 'SOLVE3D', 'SALINITY', 'UV_ADV',        &
      &    'UV_COR', 'UV_VIS2', 'MIX_S_UV', 'TS_DIF2', 'DJ_GRADPS', 'ANA_GRID' ]
       character(len=16), parameter :: kpp(7) = [ character(len=16) :: 'LMD_MIXING', 'LMD_RIMIX', 'LMD_CONVEC',    &
@@ -822,6 +823,15 @@
       character(len=16), parameter :: bulk(9) = [ character(len=16) :: 'BULK_FLUXES', 'LONGWAVE', 'ANA_WINDS',    &
      &    'ANA_TAIR', 'ANA_PAIR', 'ANA_HUMIDITY', 'ANA_RAIN', 'ANA_CLOUD', 'ALBEDO' ]
 !  (<application>_DDMIX = the same application with LMD_DDMIX: oracle/ref/upwelling_kpp_ddmix.h, benchmark.h -DLMD_DDMIX)
+!  (<application>_BKPP = the same application with LMD_BKPP: benchmark.h / oracle/ref/upwelling_kpp.h -DLMD_BKPP)
+      nl=LEN_TRIM(MyAppCPP)
+      with_bkpp=.FALSE.
+      IF (nl.gt.5) THEN
+        IF (MyAppCPP(nl-4:nl).eq.'_BKPP') THEN
+          with_bkpp=.TRUE.
+          MyAppCPP=MyAppCPP(1:nl-5)
+        END IF
+      END IF
       nl=LEN_TRIM(MyAppCPP)
       with_ddmix=.FALSE.
       IF (nl.gt.6) THEN
@@ -952,6 +962,7 @@
      &                      'application header (ROMS_APP_HEADER / second argument of romsM)', ierr)
       END SELECT
       IF (with_ddmix) CALL define ('LMD_DDMIX')
+      IF (with_bkpp) CALL define ('LMD_BKPP')
       END SUBROUTINE builtin_defines
 !
 !  defined options -> option mask, or exit_flag 5 with the reason.
@@ -968,7 +979,7 @@
      &    ROMS_CURVGRID, ROMS_NONLIN_EOS, ROMS_UV_QDRAG, ROMS_LMD_MIXING, ROMS_BULK_FLUXES, ROMS_SOLAR_SOURCE,    &
      &    ROMS_ANA_VMIX, ROMS_SALINITY, ROMS_SPHERICAL, ROMS_UV_LOGDRAG, ROMS_MASKING, ROMS_RADIATION_2D, ROMS_GLS_MIXING, ROMS_MY25_MIXING, ROMS_MIX_ISO_TS ]
 !  options whose code is the only form built (accepted, nothing to select) or that only affect output
-      character(len=16), parameter :: inherent(38) = [ character(len=16) :: 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', 'PJ_GRADP', &
+      character(len=16), parameter :: inherent(39) = [ character(len=16) :: 'LMD_BKPP', 'ANA_FSOBC', 'ANA_M2OBC', 'WJ_GRADP', 'PJ_GRADP', &
      &    'PJ_GRADPQ2', 'PJ_GRADPQ4', 'LMD_DDMIX', &
      &    'SOLVE3D', 'ANA_GRID', 'ANA_INITIAL', &
      &    'DJ_GRADPS', 'MIX_S_UV', 'MIX_S_TS', 'SPLINES_VDIFF', 'SPLINES_VVISC', 'UV_LDRAG', 'ANA_SMFLUX',        &
@@ -1040,6 +1051,10 @@
 !  weighted form
 !  (prsgrd.F tests PJ_GRADPQ4, PJ_GRADPQ2, PJ_GRADP, DJ_GRADPS in this order)
       ddmix=is_defined('LMD_DDMIX')               ! (upper word of cfg%options: ROMS_LMD_DDMIX, below)
+      bkpp=is_defined('LMD_BKPP')
+      IF (bkpp.and..not.(is_defined('LMD_MIXING').and.is_defined('SALINITY'))) CALL unsupported ('LMD_BKPP needs LMD_MIXING and SALINITY', ierr)
+      IF (bkpp.and.(is_defined('MASKING').or.is_defined('WET_DRY').or.ddmix)) CALL unsupported ('LMD_BKPP together with MASKING, '//  &
+     &    'WET_DRY or LMD_DDMIX: not pinned against the reference, not built', ierr)
       IF (ddmix.and..not.is_defined('LMD_MIXING')) CALL unsupported ('LMD_DDMIX without LMD_MIXING', ierr)
       IF (ddmix.and..not.is_defined('SALINITY')) CALL unsupported ('LMD_DDMIX needs SALINITY', ierr)
       prs4x=0
@@ -2081,6 +2096,7 @@
       IF (wet_dry) cfg%options=IOR(cfg%options, ROMS_WET_DRY)
       IF (mix_geo_uv) cfg%options=IOR(cfg%options, ROMS_MIX_GEO_UV)
       IF (ddmix) cfg%options=IOR(cfg%options, ROMS_LMD_DDMIX)
+      IF (bkpp) cfg%options=IOR(cfg%options, ROMS_LMD_BKPP)
       IF (prs4x.eq.44) cfg%options=IOR(cfg%options, ROMS_PRSGRD44)
       IF (prs4x.eq.42) cfg%options=IOR(cfg%options, ROMS_PRSGRD42)
       cfg%Dcrit=Dcrit

@@ -2,7 +2,7 @@
 the oracle (oracle/orc.h) and of the reference glue (oracle/ref/ref_glue.F90).  TEST INFRASTRUCTURE."""
 import numpy as np
 
-from roms_amd.cases import LBC_KINDS, SCHEME, benchmark, hip_cfg, upwelling, upwelling_kpp, upwelling_logdrag, upwelling_noadv, upwelling_mask, upwelling_geouv, upwelling_bihgeouv, upwelling_bihiso, clima_arrays, upwelling_wetdry, upwelling_wetdry_x, wetdry_depth, benchmark_mask, benchmark_wetdry, land_mask, kelvin, seamount, grav_adj, overflow, upwelling_prs31, upwelling_bih, upwelling_bihgeo, upwelling_prs40, upwelling_prs4x, upwelling_kpp_ddmix, benchmark_ddmix, benchmark_wetdry_ddmix, ddmix_state, upwelling_gls, upwelling_my25, kelvin_gls, kelvin_geouv, benchmark_iso, gls_cfg, GLS_NAMES, GLS_SETS, lbc_codes, obc_scales  # noqa: F401  (re-exported)
+from roms_amd.cases import LBC_KINDS, SCHEME, benchmark, hip_cfg, upwelling, upwelling_kpp, upwelling_logdrag, upwelling_noadv, upwelling_mask, upwelling_geouv, upwelling_bihgeouv, upwelling_bihiso, clima_arrays, upwelling_wetdry, upwelling_wetdry_x, wetdry_depth, benchmark_mask, benchmark_wetdry, land_mask, kelvin, seamount, grav_adj, overflow, upwelling_prs31, upwelling_bih, upwelling_bihgeo, upwelling_prs40, upwelling_prs4x, upwelling_kpp_ddmix, benchmark_ddmix, benchmark_bkpp, upwelling_kpp_bkpp, with_bkpp, benchmark_wetdry_ddmix, ddmix_state, upwelling_gls, upwelling_my25, kelvin_gls, kelvin_geouv, benchmark_iso, gls_cfg, GLS_NAMES, GLS_SETS, lbc_codes, obc_scales  # noqa: F401  (re-exported)
 
 
 def ref_params(cs):

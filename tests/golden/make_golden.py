@@ -136,7 +136,7 @@ def make_bounds():
 
 KEEP = ["zeta", "ubar", "vbar", "u", "v", "t", "W", "wvel", "Hz", "z_r", "z_w", "Huon", "Hvom", "rho", "ru", "rv",
         "Zt_avg1", "DU_avg1", "DV_avg1", "DU_avg2", "DV_avg2", "rufrc", "rvfrc", "rzeta", "rubar", "rvbar",
-        "Akv", "Akt", "hsbl", "ghats", "stflx", "sustr", "svstr", "bustr", "bvstr", "srflx", "bvf",
+        "Akv", "Akt", "hsbl", "hbbl", "ghats", "stflx", "sustr", "svstr", "bustr", "bvstr", "srflx", "bvf",
         "tke", "gls", "Lscale", "Akk", "Akp",
         "rmask_wet", "umask_wet", "vmask_wet", "pmask_wet", "rmask_full", "umask_full", "vmask_full", "pmask_full", "rmask_wet_avg"]
 
@@ -152,12 +152,22 @@ def make_steps(name, tag, args):
     from tests import refdrive as rd
     kw = _kw(args)
     nsteps = kw.pop("nsteps", 100)
+    kick_ = kw.pop("kick", 0)
     app, cs = rd.make_case(tag, **kw)
+    cs["kick"] = kick_
     saved = rd.quiet()
     R = rd.reference(app, cs)
     names = [n for n in KEEP if R.has(n)]
     out = {}
+    kick = cs.pop("kick", 0)
     for s in range(1, nsteps + 1):
+        if kick and s == 3:                  # random velocities (per cent of 1 m/s) in front of step 3; the arrays travel with the fixture
+            rng = np.random.default_rng(9)
+            for n in ("u", "v"):
+                a = np.array(R.get(n), dtype=float)
+                a = a + 0.01 * kick * rng.standard_normal(a.shape)
+                R.put(n, a)
+                out[f"kick_{n}"] = np.array(R.get(n))
         R.main3d(1)
         if s in (1, 2, 3, nsteps):
             for n in names:
@@ -291,6 +301,10 @@ STEP_CASES = [
     ("upwelling_small_prs40", "upwelling_prs40_small", ["nsteps=60"]),       # PJ_GRADP, prsgrd40.h
     ("benchmark_small_ddmix", "benchmark_ddmix_small", ["nsteps=60"]),       # LMD_DDMIX, nonlinear EOS (benchmark.h -DLMD_DDMIX; the state of cases.ddmix_state)
     ("upwelling_kpp_small_ddmix", "upwelling_kpp_ddmix_small", ["nsteps=40"]),   # ... linear EOS (upwelling_kpp_ddmix.h)
+    # LMD_BKPP (benchmark.h / upwelling_kpp.h -DLMD_BKPP), round 6; kick=30: random velocities of 0.3 m/s in front of step 3 (from rest
+    # the layer stays empty), stored with the fixture
+    ("benchmark_small_bkpp", "benchmark_bkpp_small", ["nsteps=20", "kick=30"]),
+    ("upwelling_kpp_small_bkpp", "upwelling_kpp_bkpp_small", ["nsteps=20", "kick=30"]),
     ("upwelling_small_prs42", "upwelling_prs42_small", ["nsteps=60"]),       # PJ_GRADPQ2, prsgrd42.h (one tile: its second pass, oracle/orc_prs4x.c)
     ("upwelling_small_prs44", "upwelling_prs44_small", ["nsteps=60"]),       # PJ_GRADPQ4, prsgrd44.h
     ("upwelling_small_bih", "upwelling_bih_small", ["nsteps=60"]),           # UV_VIS4 + TS_DIF4 along s-surfaces (upwelling_bih.h)

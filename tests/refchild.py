@@ -44,6 +44,7 @@ def mode_main3d(tag, kw):
     tol = kw.pop("tol", 0.0)
     if "preset" in kw:                       # the kinds of an obc-mode preset on the edges of a whole run
         kw["lbc"] = OBC_PRESETS[kw.pop("preset")]
+    kick = kw.pop("kick", 0)                 # per cent of 1 m/s: random velocities added in front of step 3 (a bottom boundary layer to speak of)
     app, cs = rd.make_case(tag, **kw)
     saved = rd.quiet()
     R = rd.reference(app, cs)
@@ -54,6 +55,8 @@ def mode_main3d(tag, kw):
     dlines = []
     worst = 0.0
     for s in range(1, nsteps + 1):
+        if kick and s == 3:
+            perturb(R, O, np.random.default_rng(9), [("u", 0.01 * kick), ("v", 0.01 * kick)])
         dg = R.main3d(1)
         O.main3d_step(1)
         bad = rd.mismatches(R, O, names)
@@ -67,6 +70,8 @@ def mode_main3d(tag, kw):
     printed = rd.diag_lines()
     ndiag = sum(1 for a, b in zip(printed, dlines) if a == b)
     moved = float(max(np.abs(O.field("u")).max(), np.abs(O.field("v")).max()))      # (OVERFLOW flows along eta only)
+    if cs.get("bkpp"):
+        print("bottom boundary layer: max(hbbl + h)", float((O.field("hbbl") + O.field("h")).max()))
     print("fields", len(names), "steps", nsteps, "max|u|", moved, "worst relrms", worst, "stepping", ok_step,
           "diag lines equal", ndiag, "of", len(printed))
     if tol == 0.0 and (ndiag != nsteps or len(printed) != nsteps):

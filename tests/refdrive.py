@@ -23,6 +23,9 @@ CASES = {
     # LMD_DDMIX (round 6): oracle/ref/upwelling_kpp_ddmix.h (linear EOS), benchmark.h -DLMD_DDMIX (nonlinear EOS); the state of cases.ddmix_state
     "upwelling_kpp_ddmix_small": ("upwelling_kpp_ddmix", dict(Lm=14, Mm=18, N=8)),
     "benchmark_ddmix_small": ("benchmark_ddmix", dict(Lm=24, Mm=16, N=10)),
+    # LMD_BKPP (round 6): benchmark.h -DLMD_BKPP, oracle/ref/upwelling_kpp.h -DLMD_BKPP
+    "benchmark_bkpp_small": ("benchmark_bkpp", dict(Lm=24, Mm=16, N=10)),
+    "upwelling_kpp_bkpp_small": ("upwelling_kpp_bkpp", dict(Lm=14, Mm=18, N=8)),
     "benchmark_wetdry_ddmix_small": ("benchmark_wetdry_ddmix", dict(Lm=24, Mm=16, N=10)),      # ... under WET_DRY
     # the UPWELLING case built WITH its time-averaged output (oracle/ref/upwelling_avg.h): pins set_avg.F
     "upwelling_avg_small": ("upwelling_avg", dict(Lm=14, Mm=18, N=8)),
@@ -182,7 +185,7 @@ def make_case(tag, **kw):
                 upwelling_mask=cases.upwelling_mask, upwelling_wetdry=cases.upwelling_wetdry, benchmark_mask=cases.benchmark_mask, benchmark_wetdry=cases.benchmark_wetdry,
                 upwelling_avg_mask=cases.upwelling_mask, upwelling_wetdry_avg=cases.upwelling_wetdry, upwelling_wetdry_gls=cases.upwelling_wetdry_x, upwelling_wetdry_my25=cases.upwelling_wetdry_x,
                 upwelling_wetdry_geouv=cases.upwelling_wetdry_x, upwelling_wetdry_prs31=cases.upwelling_wetdry_x, upwelling_wetdry_prs44=cases.upwelling_wetdry_x, upwelling_wetdry_iso=cases.upwelling_wetdry_x, kelvin=cases.kelvin, kelvin_splines=cases.kelvin, kelvin_gls=cases.kelvin_gls, kelvin_geouv=cases.kelvin_geouv, benchmark_iso=cases.benchmark_iso, seamount=cases.seamount, grav_adj=cases.grav_adj, overflow=cases.overflow, upwelling_prs31=cases.upwelling_prs31, upwelling_bih=cases.upwelling_bih, upwelling_geouv=cases.upwelling_geouv, upwelling_bihgeouv=cases.upwelling_bihgeouv, upwelling_bihgeo=cases.upwelling_bihgeo, upwelling_bihiso=cases.upwelling_bihiso,
-                upwelling_wjgradp=cases.upwelling_prs31, upwelling_kpp_ddmix=cases.upwelling_kpp_ddmix, benchmark_ddmix=cases.benchmark_ddmix, benchmark_wetdry_ddmix=cases.benchmark_wetdry_ddmix, upwelling_prs40=cases.upwelling_prs40, upwelling_prs42=cases.upwelling_prs4x, upwelling_prs44=cases.upwelling_prs4x, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
+                upwelling_wjgradp=cases.upwelling_prs31, upwelling_kpp_ddmix=cases.upwelling_kpp_ddmix, benchmark_ddmix=cases.benchmark_ddmix, benchmark_bkpp=cases.benchmark_bkpp, upwelling_kpp_bkpp=cases.upwelling_kpp_bkpp, benchmark_wetdry_ddmix=cases.benchmark_wetdry_ddmix, upwelling_prs40=cases.upwelling_prs40, upwelling_prs42=cases.upwelling_prs4x, upwelling_prs44=cases.upwelling_prs4x, upwelling_gls=cases.upwelling_gls, upwelling_gls_ca=cases.upwelling_gls,
                 upwelling_gls_cb=cases.upwelling_gls, upwelling_gls_gal=cases.upwelling_gls,
                 upwelling_my25=cases.upwelling_my25, upwelling_my25_gal=cases.upwelling_my25)[app]
     lbc = k.pop("lbc", None)
@@ -271,6 +274,8 @@ def oracle_from(R, cs):
         O.set_prsgrd(cs["prsgrd"])
     if cs.get("ddmix"):
         O.set_ddmix()
+    if cs.get("bkpp"):
+        O.set_bkpp()
     if cs.get("clima"):
         O.set_clima(cs["clima"])
         for n, a in cases.clima_arrays(cs, O.ni * O.nj).items():
@@ -285,7 +290,7 @@ def oracle_from(R, cs):
 
 def shared_fields(R, O):
     out = []
-    for n in FIELDS + util.WET_FIELDS:
+    for n in FIELDS + util.WET_FIELDS + util.BKPP_FIELDS:
         if not R.has(n):
             continue
         try:

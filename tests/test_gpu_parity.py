@@ -824,7 +824,7 @@ DETERMINISM_SMALL = [
     ("upwelling_mask_small", {}), ("seamount_small", {}), ("grav_adj_small", {}), ("overflow_small", {}),
     ("kelvin_small", {}), ("kelvin_plain_small", {}), ("upwelling_gls_small", {}), ("upwelling_my25_small", {}),
     ("upwelling_prs31_small", {}), ("upwelling_prs40_small", {}), ("upwelling_logdrag_small", {}), ("upwelling_bih_small", {}),
-    ("upwelling_prs42_small", {}), ("upwelling_prs44_small", {}), ("benchmark_ddmix_small", {}), ("upwelling_kpp_ddmix_small", {}),
+    ("upwelling_prs42_small", {}), ("upwelling_prs44_small", {}), ("benchmark_ddmix_small", {}), ("upwelling_kpp_ddmix_small", {}), ("benchmark_bkpp_small", {}), ("upwelling_kpp_bkpp_small", {}),
     # four walls (util.closed_basin_state): the fused corner stores of the barotropic engines, the first biharmonic operator's wall columns
     ("upwelling_small", {"closed": True}), ("upwelling_bihgeo_small", {"closed": True}), ("upwelling_bihiso_small", {"closed": True}),
     ("upwelling_wetdry_gls_small", {}), ("upwelling_wetdry_geouv_small", {}), ("upwelling_wetdry_prs44_small", {}),     # WET_DRY x closures / MIX_GEO_UV / PJ_GRADPQ4 (round 6)
@@ -841,7 +841,7 @@ def _case_state(tag, kw):
         cs["EWperiodic"] = 0
         if "mix4" in cs:
             cs["visc4"], cs["tnu4"] = 4.0e7, (2.0e6, 1.0e6)
-    itag = "upwelling_small" if tag.startswith("upwelling") else tag.replace("_plain", "").replace("_ddmix", "")
+    itag = "upwelling_small" if tag.startswith("upwelling") else tag.replace("_plain", "").replace("_ddmix", "").replace("_bkpp", "")
     g = util.load_init(itag, util.nghost_for(cs))
     if cs.get("wet_dry"):
         g = util.with_wetdry(cs, g)
@@ -1192,6 +1192,33 @@ def test_open_boundaries_match_oracle(variant):
         worst = max(worst, util.relrms(a, b))
         assert util.agree(a, b, 1e-10), (n, util.relrms(a, b))
     assert np.abs(O.field("u")).max() > 0.05
+    H.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["benchmark_bkpp_small", "upwelling_kpp_bkpp_small"])
+def test_bottom_boundary_layer_of_the_k_profile_scheme_matches_oracle(tag):
+    """Round 6, LMD_BKPP on the GPU (k_lmd.h: k_lmd_bkpp; lmd_bkpp.F): 30 steps against the oracle (equal to the reference built
+    with -DLMD_BKPP, from rest and with a layer tens of metres thick) at the north-star tolerance, random velocities of 0.3 m/s
+    added after two steps so that the layer reaches several levels; hbbl itself compared."""
+    cs = util.case_for(tag)
+    g = util.load_init(util.init_tag(cs), util.nghost_for(cs))
+    O = util.make_oracle(cs, g)
+    H = util.make_hip(cs, g)
+    O.start(); H.start()
+    O.main3d_step(2); H.main3d(2)
+    rng = np.random.default_rng(9)
+    for n in ("u", "v"):
+        a = O.field(n).copy()
+        a += 0.3 * rng.standard_normal(a.size)
+        O.field(n)[:] = a
+        H.upload(n, a)
+    O.main3d_step(28); H.main3d(28)
+    for n in util.PROGNOSTIC + ["hbbl"]:
+        a, b = H.download(n), O.field(n)
+        assert np.isfinite(a).all(), n
+        assert util.agree(a, b, 1e-10 if n not in ("Akv", "Akt", "ghats", "hsbl", "hbbl", "bvf") else 1e-7), (n, util.relrms(a, b))
+    assert float((O.field("hbbl") + np.asarray(g["h"]).ravel()).max()) > 30.0
     H.close()
 
 

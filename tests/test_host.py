@@ -369,7 +369,7 @@ def test_application_header_is_read_like_cpp_would(tmp_path):
 
 
 @pytest.mark.parametrize("line,needle", [("#define TS_DIF4", "TS_DIF4"), ("#define GLS_MIXING", "GLS_MIXING"),
-                                         ("#define WET_DRY\n#undef DJ_GRADPS\n#define PJ_GRADP", "WET_DRY"), ("#define LMD_BKPP", "LMD_BKPP"),
+                                         ("#define WET_DRY\n#undef DJ_GRADPS\n#define PJ_GRADP", "WET_DRY"), ("#define LMD_BKPP\n#define LMD_DDMIX", "LMD_BKPP together with"),
                                          ("#define UV_QDRAG", "exactly one of UV_LDRAG, UV_QDRAG, UV_LOGDRAG")])
 def test_application_header_with_unbuilt_options_stops(tmp_path, line, needle):
     """An option whose code is not in the library (biharmonic mixing, GLS, wetting and drying with the standard density

@@ -955,6 +955,49 @@ def test_kpp_block_form_bitwise(emu, tag):
     assert "BLK-OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("tag", ["benchmark_bkpp_small", "upwelling_kpp_bkpp_small"])
+def test_bottom_boundary_layer_of_the_k_profile_scheme_bitwise(emu, tag):
+    """Round 6, LMD_BKPP (lmd_bkpp.F:95-806 with RI_SPLINES and the file's own SASHA; k_lmd.h: k_lmd_bkpp behind k_lmd_interior +
+    k_lmd_skpp, lmd_finish as its last operation): the oracle equals the reference built with -DLMD_BKPP (benchmark.h: nonlinear EOS,
+    bulk fluxes, shortwave; upwelling_kpp.h: linear EOS) from rest and with random velocities added -- a layer 40 to 190 m thick --
+    on one tile and 2x2.  12 steps against the oracle, every bit, hbbl included; from step 3 on (random velocities of 0.3 m/s) the
+    layer reaches several levels and the mixing coefficients differ from the run without the option."""
+    cs = util.case_for(tag)
+    g = util.load_init(util.init_tag(cs), util.nghost_for(cs))
+    cs0 = dict(cs); cs0.pop("bkpp")
+    O = util.make_oracle(cs, g); O0 = util.make_oracle(cs0, g)
+    H = util.make_hip(cs, g, emu)
+    O.start(); O0.start(); H.start()
+    rng = np.random.default_rng(9)
+    for step in range(12):
+        if step == 2:
+            for n in ("u", "v"):
+                a = O.field(n).copy()
+                a += 0.3 * rng.standard_normal(a.size)
+                O.field(n)[:] = a; O0.field(n)[:] = a
+                H.upload(n, a)
+        O.main3d_step(); O0.main3d_step(); H.main3d(1)
+        for n in util.PROGNOSTIC + ["hbbl"]:
+            a, b = H.download(n), O.field(n)
+            assert np.isfinite(b).all(), (step, n)
+            assert np.array_equal(a, b), (step, n, float(np.abs(a - b).max()))
+    assert float((O.field("hbbl") + np.asarray(g["h"]).ravel()).max()) > 30.0
+    assert not np.array_equal(O.field("Akv"), O0.field("Akv"))
+    H.close()
+
+
+def test_bottom_boundary_layer_only_in_its_pinned_combinations():
+    """roms_hip_create: LMD_BKPP with MASKING (or WET_DRY, LMD_DDMIX) is refused with the reason -- no reference build pins it"""
+    from roms_amd import hiplib
+    cs = util.case_for("upwelling_mask_small")
+    cs["options"] = tuple(cs["options"]) + ("LMD_MIXING",) if "LMD_MIXING" not in cs["options"] else cs["options"]
+    cs["bkpp"] = 1
+    g = util.with_masks(cs, util.load_init("upwelling_small", util.nghost_for(cs)))
+    with pytest.raises(hiplib.RomsHipError) as e:
+        util.make_hip(cs, g, util.EMU_LIB)
+    assert "exit_flag=5" in str(e.value) and "LMD_BKPP" in str(e.value), str(e.value)
+
+
 @pytest.mark.parametrize("tag", ["benchmark_ddmix_small", "upwelling_kpp_ddmix_small"])
 @pytest.mark.parametrize("form", ["0", "1", "2", "3"])
 def test_double_diffusive_mixing_bitwise(emu, tag, form):

@@ -305,6 +305,15 @@ MAIN3D_CASES = [
     # state of cases.ddmix_state has salt fingering in one half and diffusive convection (Rrho on both sides of 0.5) in the other
     ("upwelling_kpp_ddmix_small", ["nsteps=40"]),
     ("upwelling_kpp_ddmix_small", ["nsteps=20", "NtileI=2", "NtileJ=2", "hadv=U3,HSIMT", "vadv=C4,HSIMT"]),
+    # LMD_BKPP (round 6; lmd_bkpp.F with RI_SPLINES and the file's own SASHA): benchmark.h and oracle/ref/upwelling_kpp.h with
+    # -DLMD_BKPP.  The runs from rest keep the layer empty (hbbl = -h); kick=30 adds random velocities of 0.3 m/s in front of step 3:
+    # a layer 40 - 190 m thick that reaches several levels (the shape functions, the overlap rule with the surface layer)
+    ("benchmark_bkpp_small", ["nsteps=40"]),
+    ("upwelling_kpp_bkpp_small", ["nsteps=60"]),
+    ("benchmark_bkpp_small", ["nsteps=20", "kick=30"]),
+    ("upwelling_kpp_bkpp_small", ["nsteps=20", "kick=30"]),
+    ("upwelling_kpp_bkpp_small", ["nsteps=20", "kick=30", "NtileI=2", "NtileJ=2"]),
+    ("benchmark_bkpp_small", ["nsteps=20", "kick=30", "NtileI=2", "NtileJ=2"]),
     ("benchmark_ddmix_small", ["nsteps=40"]),
     ("benchmark_ddmix_small", ["nsteps=20", "NtileI=2", "NtileJ=2"]),
     # the finite-volume Jacobians of Shchepetkin & McWilliams (2003) with a reconstructed density profile (round 6): prsgrd44.h

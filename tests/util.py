@@ -17,6 +17,8 @@ INIT_FIELDS = ["h", "f", "fomn", "pm", "pn", "om_r", "on_r", "om_u", "on_u", "om
 # WET_DRY cases only (wetdry.F): the time-dependent masks
 WET_FIELDS = ["rmask_wet", "umask_wet", "vmask_wet", "pmask_wet", "rmask_full", "umask_full", "vmask_full", "pmask_full",
               "rmask_wet_avg"]
+# LMD_BKPP cases only (lmd_bkpp.F): the depth of the bottom boundary layer
+BKPP_FIELDS = ["hbbl"]
 STATE_FIELDS = INIT_FIELDS + ["rzeta", "rubar", "rvbar", "W", "wvel", "ru", "rv", "rufrc", "rvfrc", "DU_avg1",
                               "DU_avg2", "DV_avg1", "DV_avg2", "sustr", "svstr", "bustr", "bvstr", "stflx", "btflx",
                               "stflux", "btflux", "srflx", "ghats", "Uwind", "Vwind", "Tair", "Pair", "Hair", "rain",
@@ -66,6 +68,10 @@ def case_for(tag, **kw):
         return cases.upwelling_kpp_ddmix(Lm=14, Mm=18, N=8, **kw)
     if tag == "benchmark_ddmix_small":
         return cases.benchmark_ddmix(Lm=24, Mm=16, N=10, **kw)
+    if tag == "benchmark_bkpp_small":
+        return cases.benchmark_bkpp(Lm=24, Mm=16, N=10, **kw)
+    if tag == "upwelling_kpp_bkpp_small":
+        return cases.upwelling_kpp_bkpp(Lm=14, Mm=18, N=8, **kw)
     if tag == "benchmark_mask_small":
         return cases.benchmark_mask(Lm=24, Mm=16, N=10, **kw)
     if tag == "benchmark_wetdry_small":
@@ -189,6 +195,8 @@ def make_oracle(cs, g):
         O.set_prsgrd(cs["prsgrd"])
     if cs.get("ddmix"):
         O.set_ddmix()
+    if cs.get("bkpp"):
+        O.set_bkpp()
     if cs.get("clima"):
         O.set_clima(cs["clima"])
         for n, a in cases.clima_arrays(cs, np.asarray(g["h"]).size).items():
@@ -530,6 +538,9 @@ def check_steps_fixture(side, f, meta, tol, tol_loose=None, loose=()):
     done = 0
     ni, nj = side.dims()
     for s in (1, 2, 3, meta["nsteps"]):
+        if s == 3 and "kick_u" in f:          # (a fixture whose generator replaced the velocities in front of step 3: make_golden.py, kick=)
+            side.put("u", f["kick_u"])
+            side.put("v", f["kick_v"])
         side.main3d(s - done)
         done = s
         for n in meta["fields"]:
