@@ -2074,7 +2074,8 @@ static int main3d_around_loop(roms_hip_ctx *c, bool do_diag, int form, bool with
   // (round 5: the block form k_lmd_blk keeps its columns in LDS up to 71 levels)
   const char *eblk = getenv("ROMS_HIP_LMDBLK");
   const bool blk = !(eblk && eblk[0] == '0') && c->G.region == 0 && (size_t)(4 * (c->G.N + 1) + 24) * 64 * sizeof(double) <= 160 * 1024;
-  const bool kpp_col = kpp && (blk || (size_t)3 * (size_t)(c->G.N + 1) * 64 * sizeof(double) < 64 * 1024) && !getenv("ROMS_HIP_LMDCOL");
+  // (LMD_BKPP: k_lmd_bkpp works on the spline columns the two-kernel form leaves in wrk3[1..4])
+  const bool kpp_col = kpp && !c->G.bkpp && (blk || (size_t)3 * (size_t)(c->G.N + 1) * 64 * sizeof(double) < 64 * 1024) && !getenv("ROMS_HIP_LMDCOL");
   c->kpp_col_ok = kpp_col;
   // (ROMS_HIP_FOLD=0: k_uv3dmix2_apply and t3dmix2 as launches of their own behind k_pre_new -- the form the bit-identity
   // of the folded one is tested against)
