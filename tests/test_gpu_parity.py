@@ -1605,7 +1605,9 @@ def test_baseline_configs_in_their_tiled_form_match_single_tile(tmp_path, worklo
            os.path.join(root, "tests", "mp", "run_tiles.py"), out, json.dumps(spec)]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500,
                        env=dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", ROMS_HIP_PEER_TIMEOUT="30"))
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    # (the ranks' own messages first: the launcher's report of eight children pushes them out of a plain tail)
+    said = [l for l in (p.stdout + p.stderr).splitlines() if any(w in l for w in ("exit_flag", "Error", "error:", "assert", "roms_amd"))]
+    assert p.returncode == 0, "\n".join(said[:20]) + "\n" + p.stdout[-1500:] + p.stderr[-1500:]
     assert "TRANSPORT peer" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
     got = dict(np.load(out))
     assert int(got["nexchanges"]) > 30 * steps
